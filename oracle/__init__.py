@@ -1,0 +1,161 @@
+"""CPU checkers for the integration path -- TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this package (see ``oracle/oracle_abi.h``).  Two interchangeable back-ends export the same C ABI:
+
+* ``kind="port"``       ``oracle/libufo_oracle.so`` -- our CPU restatement (``ufo_oracle.cpp``)
+* ``kind="reference"``  ``oracle/_ref/libufo_ref.so`` -- the unmodified reference compiled from
+  ``/root/reference`` by ``oracle/Makefile`` (prebuilt file is used where the reference tree is
+  absent, e.g. on the GPU box)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PATHS = {
+    "port": os.path.join(_HERE, "libufo_oracle.so"),
+    "reference": os.path.join(_HERE, "_ref", "libufo_ref.so"),
+}
+_LIBS: dict = {}
+
+
+def build(kind: str = "port", quiet: bool = True) -> bool:
+    """(Re)build a checker with oracle/Makefile. Returns True if the library exists afterwards."""
+    target = "port" if kind == "port" else "ref"
+    if kind == "reference" and not os.path.isdir("/root/reference/ufomap/include"):
+        return os.path.exists(_PATHS[kind])
+    r = subprocess.run(["make", "-C", _HERE, target], capture_output=quiet, text=True)
+    if r.returncode != 0 and not quiet:
+        print(r.stdout, r.stderr)
+    return os.path.exists(_PATHS[kind])
+
+
+def available(kind: str) -> bool:
+    return os.path.exists(_PATHS[kind])
+
+
+def _load(kind: str):
+    if kind in _LIBS:
+        return _LIBS[kind]
+    path = _PATHS[kind]
+    if not os.path.exists(path):
+        build(kind)
+    lib = C.CDLL(path)
+    vp, u64p, u8p, f32p, f64p = C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint8), C.POINTER(C.c_float), C.POINTER(C.c_double)
+    lib.ufo_oracle_create.restype = vp
+    lib.ufo_oracle_create.argtypes = [C.c_double, C.c_uint, C.c_int] + [C.c_double] * 6 + [C.c_int]
+    lib.ufo_oracle_destroy.argtypes = [vp]
+    lib.ufo_oracle_insert.restype = C.c_int
+    lib.ufo_oracle_insert.argtypes = [vp, f64p, f64p, u8p, C.c_size_t, C.c_double, C.c_uint, C.c_int, C.c_int, C.c_uint]
+    lib.ufo_oracle_export_leaves.restype = C.c_size_t
+    lib.ufo_oracle_export_leaves.argtypes = [vp, C.c_int, u64p, u8p, f32p, u8p, C.c_size_t]
+    lib.ufo_oracle_export_inner.restype = C.c_size_t
+    lib.ufo_oracle_export_inner.argtypes = [vp, u64p, u8p, f32p, u8p, u8p, C.c_size_t]
+    lib.ufo_oracle_minmax_change.restype = C.c_int
+    lib.ufo_oracle_minmax_change.argtypes = [vp, f64p, f64p]
+    lib.ufo_oracle_last_hits.restype = C.c_size_t
+    lib.ufo_oracle_last_hits.argtypes = [vp, u64p, C.c_size_t]
+    lib.ufo_oracle_last_rays.restype = C.c_size_t
+    lib.ufo_oracle_last_rays.argtypes = [vp, f64p, C.c_size_t]
+    lib.ufo_oracle_last_misses.restype = C.c_size_t
+    lib.ufo_oracle_last_misses.argtypes = [vp, u64p, C.c_size_t]
+    lib.ufo_oracle_last_steps.restype = C.c_uint64
+    lib.ufo_oracle_last_steps.argtypes = [vp]
+    lib.ufo_oracle_kind.restype = C.c_char_p
+    _LIBS[kind] = lib
+    return lib
+
+
+def _ptr(a, ty):
+    return None if a is None else a.ctypes.data_as(C.POINTER(ty))
+
+
+class OracleMap:
+    """ctypes view of one CPU checker map (argument meaning = OccupancyMapBase ctor, OMB:859-862)."""
+
+    def __init__(self, resolution, depth_levels=16, automatic_pruning=True, occupied_thres=0.5,
+                 free_thres=0.5, prob_hit=0.7, prob_miss=0.4, clamping_thres_min=0.1192,
+                 clamping_thres_max=0.971, color=False, kind="port"):
+        self.lib = _load(kind)
+        self.kind = kind
+        self.color = bool(color)
+        self.h = self.lib.ufo_oracle_create(resolution, depth_levels, int(automatic_pruning),
+                                            occupied_thres, free_thres, prob_hit, prob_miss,
+                                            clamping_thres_min, clamping_thres_max, int(color))
+        if not self.h:
+            raise ValueError("oracle: invalid constructor arguments")
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.ufo_oracle_destroy(self.h)
+            self.h = None
+
+    def insert(self, origin, xyz, rgb=None, max_range=-1.0, depth=0, discrete=False,
+               simple_ray_casting=False, early_stopping=0):
+        origin = np.ascontiguousarray(origin, dtype=np.float64)
+        xyz = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
+        if rgb is not None:
+            rgb = np.ascontiguousarray(rgb, dtype=np.uint8).reshape(-1, 3)
+            assert rgb.shape[0] == xyz.shape[0]
+        rc = self.lib.ufo_oracle_insert(self.h, _ptr(origin, C.c_double), _ptr(xyz, C.c_double),
+                                        _ptr(rgb, C.c_uint8), xyz.shape[0], float(max_range),
+                                        int(depth), int(discrete), int(simple_ray_casting),
+                                        int(early_stopping))
+        if rc != 0:
+            raise RuntimeError(f"oracle insert failed rc={rc}")
+
+    def leaves(self, include_unknown=False):
+        n = self.lib.ufo_oracle_export_leaves(self.h, int(include_unknown), None, None, None, None, 0)
+        codes = np.empty(n, np.uint64)
+        depths = np.empty(n, np.uint8)
+        occ = np.empty(n, np.float32)
+        rgb = np.zeros((n, 3), np.uint8)
+        self.lib.ufo_oracle_export_leaves(self.h, int(include_unknown), _ptr(codes, C.c_uint64),
+                                          _ptr(depths, C.c_uint8), _ptr(occ, C.c_float),
+                                          _ptr(rgb, C.c_uint8), n)
+        return codes, depths, occ, rgb
+
+    def inner(self):
+        n = self.lib.ufo_oracle_export_inner(self.h, None, None, None, None, None, 0)
+        codes = np.empty(n, np.uint64)
+        depths = np.empty(n, np.uint8)
+        occ = np.empty(n, np.float32)
+        flags = np.empty(n, np.uint8)
+        rgb = np.zeros((n, 3), np.uint8)
+        self.lib.ufo_oracle_export_inner(self.h, _ptr(codes, C.c_uint64), _ptr(depths, C.c_uint8),
+                                         _ptr(occ, C.c_float), _ptr(flags, C.c_uint8),
+                                         _ptr(rgb, C.c_uint8), n)
+        return codes, depths, occ, flags, rgb
+
+    def minmax_change(self):
+        mn = np.empty(3, np.float64)
+        mx = np.empty(3, np.float64)
+        self.lib.ufo_oracle_minmax_change(self.h, _ptr(mn, C.c_double), _ptr(mx, C.c_double))
+        return mn, mx
+
+    # -- stage-level outputs of the last insert (port only) ---------------------------------
+    def _stage(self, fn, dtype, width=1):
+        n = fn(self.h, None, 0)
+        if n == C.c_size_t(-1).value:
+            raise NotImplementedError("stage outputs are only provided by the port")
+        out = np.empty((n, width) if width > 1 else n, dtype)
+        ct = C.c_uint64 if dtype == np.uint64 else C.c_double
+        fn(self.h, _ptr(out, ct), n)
+        return out
+
+    def last_hits(self):
+        return self._stage(self.lib.ufo_oracle_last_hits, np.uint64)
+
+    def last_misses(self):
+        return self._stage(self.lib.ufo_oracle_last_misses, np.uint64)
+
+    def last_rays(self):
+        return self._stage(self.lib.ufo_oracle_last_rays, np.float64, 3)
+
+    def last_steps(self):
+        return int(self.lib.ufo_oracle_last_steps(self.h))

@@ -1,0 +1,71 @@
+/*
+ * oracle_abi.h -- C ABI shared by the two CPU checkers of this repo.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load these libraries, and only as
+ * the checker / the reported CPU baseline -- never as the thing measured or shipped.
+ *
+ * Two libraries export exactly this interface:
+ *   oracle/_ref/libufo_ref.so   the UNMODIFIED reference (UnknownFreeOccupied/ufomap v1) compiled
+ *                               from /root/reference by oracle/Makefile (ref_harness.cpp is the
+ *                               only file of ours in that build; no reference source is copied);
+ *   oracle/libufo_oracle.so     our own CPU restatement of the integration path (ufo_oracle.cpp),
+ *                               validated against libufo_ref.so and the golden vectors.
+ *
+ * Canonical dump format: a node is identified by (code >> 3*depth, depth); leaves
+ * are returned sorted by (depth, shifted code).
+ */
+#ifndef UFO_ORACLE_ABI_H
+#define UFO_ORACLE_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ufo_oracle_map ufo_oracle_map;
+
+/* Constructor arguments mirror OccupancyMapBase (occupancy_map_base.h:859-862). */
+ufo_oracle_map* ufo_oracle_create(double resolution, unsigned depth_levels, int automatic_pruning,
+                                  double occupied_thres, double free_thres, double prob_hit,
+                                  double prob_miss, double clamp_min, double clamp_max, int color);
+void ufo_oracle_destroy(ufo_oracle_map* m);
+
+/* insertPointCloud (discrete=0, occupancy_map_base.h:270) / insertPointCloudDiscrete (discrete=1,
+ * occupancy_map_base.h:340; colour overload occupancy_map_color.h:177). rgb may be NULL.
+ * Returns 0 on success, <0 when the combination is not supported by this checker. */
+int ufo_oracle_insert(ufo_oracle_map* m, const double origin[3], const double* xyz,
+                      const uint8_t* rgb, size_t n, double max_range, unsigned depth, int discrete,
+                      int simple_ray_casting, unsigned early_stopping);
+
+/* Leaves in canonical order. include_unknown=0 skips leaves whose state is "unknown".
+ * Returns the number of leaves (may exceed cap; only cap entries are written). Any output
+ * pointer may be NULL. rgb is 3 bytes per leaf (zeros for a non-colour map). */
+size_t ufo_oracle_export_leaves(const ufo_oracle_map* m, int include_unknown, uint64_t* codes,
+                                uint8_t* depths, float* logodds, uint8_t* rgb, size_t cap);
+
+/* Inner nodes that have children (depth >= 1), canonical order. flags bit0 = contains_free,
+ * bit1 = contains_unknown. */
+size_t ufo_oracle_export_inner(const ufo_oracle_map* m, uint64_t* codes, uint8_t* depths,
+                               float* logodds, uint8_t* flags, uint8_t* rgb, size_t cap);
+
+/* Min/max change AABB (occupancy_map_base.h:305-308, 388-398, 1367-1372). Returns 0 if enabled. */
+int ufo_oracle_minmax_change(const ufo_oracle_map* m, double mn[3], double mx[3]);
+
+/* Stage-level outputs of the LAST insert (restatement only; the reference build returns
+ * (size_t)-1 for these): unique hit codes (depth 0), ray end points, unique miss codes
+ * (shifted by 3*depth), total DDA steps. */
+size_t ufo_oracle_last_hits(const ufo_oracle_map* m, uint64_t* codes, size_t cap);
+size_t ufo_oracle_last_rays(const ufo_oracle_map* m, double* ends_xyz, size_t cap);
+size_t ufo_oracle_last_misses(const ufo_oracle_map* m, uint64_t* codes, size_t cap);
+uint64_t ufo_oracle_last_steps(const ufo_oracle_map* m);
+
+/* "reference" or "port". */
+const char* ufo_oracle_kind(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

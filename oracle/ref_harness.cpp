@@ -1,0 +1,230 @@
+/*
+ * ref_harness.cpp -- C-ABI shim around the UNMODIFIED reference implementation.
+ *
+ * TEST INFRASTRUCTURE ONLY (see oracle_abi.h).  This file is the only source of ours that goes
+ * into oracle/_ref/libufo_ref.so; everything else is compiled where it lies under
+ * /root/reference/ufomap (oracle/Makefile, target `ref`).  No reference source is copied here:
+ * the harness only *calls* the reference's public API
+ *   ufo::map::OccupancyMap / OccupancyMapColor            (occupancy_map.h:55, occupancy_map_color.h:56)
+ *   insertPointCloud / insertPointCloudDiscrete           (occupancy_map_base.h:270, 340;
+ *                                                          occupancy_map_color.h:93, 177)
+ * and walks the resulting tree through the protected accessors a subclass may use
+ *   getRoot / isLeaf / getChild                           (octree.h:948-952, 1089-1127)
+ * so that the dump sees exactly what the reference's own leaf iterator sees (is_leaf flag).
+ *
+ * Do NOT read point queries (getOccupancy(code) ...) from the reference: they are off by one level
+ * (SURVEY.md section 4).
+ */
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <tuple>
+#include <vector>
+
+#include <ufo/map/occupancy_map.h>
+#include <ufo/map/occupancy_map_color.h>
+
+#include "oracle_abi.h"
+
+namespace
+{
+struct Rec {
+	uint64_t code;  // shifted: code >> 3*depth
+	uint8_t depth;
+	float occ;
+	uint8_t flags;
+	uint8_t rgb[3];
+};
+
+inline bool recLess(Rec const& a, Rec const& b)
+{
+	return a.depth != b.depth ? a.depth < b.depth : a.code < b.code;
+}
+
+template <class MAP, bool COLOR>
+struct Probe : MAP {
+	using MAP::MAP;
+	using Inner = typename MAP::INNER_NODE;
+	using Leaf = typename MAP::LEAF_NODE;
+
+	void walk(Leaf const& node, unsigned depth, uint64_t prefix, bool include_unknown,
+	          std::vector<Rec>* leaves, std::vector<Rec>* inner) const
+	{
+		bool leaf = (0 == depth) || MAP::isLeaf(static_cast<Inner const&>(node));
+		Rec r;
+		r.code = prefix;
+		r.depth = static_cast<uint8_t>(depth);
+		r.occ = node.value.occupancy;
+		r.flags = 0;
+		r.rgb[0] = r.rgb[1] = r.rgb[2] = 0;
+		if constexpr (COLOR) {
+			r.rgb[0] = node.value.color.r;
+			r.rgb[1] = node.value.color.g;
+			r.rgb[2] = node.value.color.b;
+		}
+		if (leaf) {
+			if (leaves) {
+				// unknown <=> free_thres <= v <= occupied_thres (occupancy_map_base.h:932-936)
+				bool unknown = MAP::isUnknown(node);
+				if (include_unknown || !unknown) {
+					leaves->push_back(r);
+				}
+			}
+			return;
+		}
+		Inner const& in = static_cast<Inner const&>(node);
+		if (inner) {
+			r.flags = (in.contains_free ? 1 : 0) | (in.contains_unknown ? 2 : 0);
+			inner->push_back(r);
+		}
+		for (unsigned i = 0; i < 8; ++i) {
+			walk(MAP::getChild(in, depth - 1, i), depth - 1, (prefix << 3) | i, include_unknown,
+			     leaves, inner);
+		}
+	}
+
+	void dump(bool include_unknown, std::vector<Rec>* leaves, std::vector<Rec>* inner) const
+	{
+		walk(MAP::getRoot(), MAP::getTreeDepthLevels(), 0, include_unknown, leaves, inner);
+		if (leaves) std::sort(leaves->begin(), leaves->end(), recLess);
+		if (inner) std::sort(inner->begin(), inner->end(), recLess);
+	}
+};
+
+using ProbeOcc = Probe<ufo::map::OccupancyMap, false>;
+using ProbeCol = Probe<ufo::map::OccupancyMapColor, true>;
+}  // namespace
+
+struct ufo_oracle_map {
+	std::unique_ptr<ProbeOcc> occ;
+	std::unique_ptr<ProbeCol> col;
+};
+
+extern "C" {
+
+ufo_oracle_map* ufo_oracle_create(double resolution, unsigned depth_levels, int automatic_pruning,
+                                  double occupied_thres, double free_thres, double prob_hit,
+                                  double prob_miss, double clamp_min, double clamp_max, int color)
+{
+	try {
+		auto* m = new ufo_oracle_map;
+		if (color) {
+			m->col.reset(new ProbeCol(resolution, depth_levels, 0 != automatic_pruning,
+			                          occupied_thres, free_thres, prob_hit, prob_miss, clamp_min,
+			                          clamp_max));
+			m->col->enableMinMaxChangeDetection(true);
+		} else {
+			m->occ.reset(new ProbeOcc(resolution, depth_levels, 0 != automatic_pruning,
+			                          occupied_thres, free_thres, prob_hit, prob_miss, clamp_min,
+			                          clamp_max));
+			m->occ->enableMinMaxChangeDetection(true);
+		}
+		return m;
+	} catch (...) {
+		return nullptr;
+	}
+}
+
+void ufo_oracle_destroy(ufo_oracle_map* m) { delete m; }
+
+int ufo_oracle_insert(ufo_oracle_map* m, const double origin[3], const double* xyz,
+                      const uint8_t* rgb, size_t n, double max_range, unsigned depth, int discrete,
+                      int simple_ray_casting, unsigned early_stopping)
+{
+	ufo::map::Point3 o(origin[0], origin[1], origin[2]);
+	if (rgb) {
+		if (!m->col) return -1;
+		if (!discrete) return -2;  // OccupancyMapColor::insertPointCloud<PointCloudColor> does not compile
+		ufo::map::PointCloudColor cloud;
+		cloud.reserve(n);
+		for (size_t i = 0; i < n; ++i) {
+			cloud.push_back(ufo::map::Point3Color(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2],
+			                                      rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]));
+		}
+		m->col->insertPointCloudDiscrete(o, cloud, max_range, depth, 0 != simple_ray_casting,
+		                                 early_stopping, false);
+		return 0;
+	}
+	ufo::map::PointCloud cloud;
+	cloud.reserve(n);
+	for (size_t i = 0; i < n; ++i) {
+		cloud.push_back(ufo::map::Point3(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]));
+	}
+	if (m->col) {
+		if (discrete) {
+			m->col->insertPointCloudDiscrete(o, cloud, max_range, depth, 0 != simple_ray_casting,
+			                                 early_stopping, false);
+		} else {
+			m->col->insertPointCloud(o, cloud, max_range, depth, 0 != simple_ray_casting,
+			                         early_stopping, false);
+		}
+	} else {
+		if (discrete) {
+			m->occ->insertPointCloudDiscrete(o, cloud, max_range, depth, 0 != simple_ray_casting,
+			                                 early_stopping, false);
+		} else {
+			m->occ->insertPointCloud(o, cloud, max_range, depth, 0 != simple_ray_casting,
+			                         early_stopping, false);
+		}
+	}
+	return 0;
+}
+
+static size_t copyOut(std::vector<Rec> const& v, uint64_t* codes, uint8_t* depths, float* logodds,
+                      uint8_t* flags, uint8_t* rgb, size_t cap)
+{
+	size_t n = std::min(v.size(), cap);
+	for (size_t i = 0; i < n; ++i) {
+		if (codes) codes[i] = v[i].code;
+		if (depths) depths[i] = v[i].depth;
+		if (logodds) logodds[i] = v[i].occ;
+		if (flags) flags[i] = v[i].flags;
+		if (rgb) std::memcpy(rgb + 3 * i, v[i].rgb, 3);
+	}
+	return v.size();
+}
+
+size_t ufo_oracle_export_leaves(const ufo_oracle_map* m, int include_unknown, uint64_t* codes,
+                                uint8_t* depths, float* logodds, uint8_t* rgb, size_t cap)
+{
+	std::vector<Rec> leaves;
+	if (m->col) {
+		m->col->dump(0 != include_unknown, &leaves, nullptr);
+	} else {
+		m->occ->dump(0 != include_unknown, &leaves, nullptr);
+	}
+	return copyOut(leaves, codes, depths, logodds, nullptr, rgb, cap);
+}
+
+size_t ufo_oracle_export_inner(const ufo_oracle_map* m, uint64_t* codes, uint8_t* depths,
+                               float* logodds, uint8_t* flags, uint8_t* rgb, size_t cap)
+{
+	std::vector<Rec> inner;
+	if (m->col) {
+		m->col->dump(true, nullptr, &inner);
+	} else {
+		m->occ->dump(true, nullptr, &inner);
+	}
+	return copyOut(inner, codes, depths, logodds, flags, rgb, cap);
+}
+
+int ufo_oracle_minmax_change(const ufo_oracle_map* m, double mn[3], double mx[3])
+{
+	ufo::map::Point3 a = m->col ? m->col->minChange() : m->occ->minChange();
+	ufo::map::Point3 b = m->col ? m->col->maxChange() : m->occ->maxChange();
+	for (int i = 0; i < 3; ++i) {
+		mn[i] = a[i];
+		mx[i] = b[i];
+	}
+	return 0;
+}
+
+size_t ufo_oracle_last_hits(const ufo_oracle_map*, uint64_t*, size_t) { return (size_t)-1; }
+size_t ufo_oracle_last_rays(const ufo_oracle_map*, double*, size_t) { return (size_t)-1; }
+size_t ufo_oracle_last_misses(const ufo_oracle_map*, uint64_t*, size_t) { return (size_t)-1; }
+uint64_t ufo_oracle_last_steps(const ufo_oracle_map*) { return (uint64_t)-1; }
+
+const char* ufo_oracle_kind(void) { return "reference"; }
+
+}  // extern "C"
