@@ -24,6 +24,11 @@ _PATHS = {
 _LIBS: dict = {}
 
 
+class RunawayRay(RuntimeError):
+    """A ray left the map cube after clipping (end point a few ulp outside): the reference walks
+    ~2^31 cells on such input; the port refuses (rc=-4) before touching the map."""
+
+
 def build(kind: str = "port", quiet: bool = True) -> bool:
     """(Re)build a checker with oracle/Makefile. Returns True if the library exists afterwards."""
     target = "port" if kind == "port" else "ref"
@@ -106,6 +111,8 @@ class OracleMap:
                                         _ptr(rgb, C.c_uint8), xyz.shape[0], float(max_range),
                                         int(depth), int(discrete), int(simple_ray_casting),
                                         int(early_stopping))
+        if rc == -4:
+            raise RunawayRay("input outside the parity contract (runaway ray), map unchanged")
         if rc != 0:
             raise RuntimeError(f"oracle insert failed rc={rc}")
 

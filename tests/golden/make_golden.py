@@ -1,0 +1,103 @@
+"""Generate the golden fixtures under tests/golden/ from the UNMODIFIED reference.
+
+Run in the build container (where /root/reference exists):  python tests/golden/make_golden.py
+Each case stores its inputs (params, per-scan origin/xyz/rgb) and the reference's canonical dumps:
+the known (non-unknown) leaves in full, SHA-256 digests of the complete leaf dump (incl. unknown
+leaves) and of the inner-node dump (value, contains_free/contains_unknown flags, colour), and the
+min/max change AABB.  The fixtures are self-contained: neither /root/reference nor oracle/_ref is
+needed to check against them.
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import OracleMap, build  # noqa: E402
+from ufomap_amd import scans  # noqa: E402
+
+
+def digest(*arrays):
+    h = hashlib.sha256()
+    for a in arrays:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+def cases():
+    o = np.array([0.05, 0.05, 0.05])
+    kat = np.array([[1.0, 0.05, 0.05]])
+    yield "kat_single_ray", dict(resolution=0.16), [dict(origin=o, xyz=kat, max_range=20.0)] * 1
+    yield "kat_saturation_x10", dict(resolution=0.16), [dict(origin=o, xyz=kat, max_range=20.0)] * 10
+    d1 = np.array([[1.0, .05, .05], [1.02, .06, .05], [.05, 30, .05]])
+    yield "kat_discrete_depth1", dict(resolution=0.16), [dict(origin=o, xyz=d1, max_range=20.0, depth=1, discrete=True)]
+    yield "kat_color", dict(resolution=0.08, color=True), [
+        dict(origin=o, xyz=np.array([[1.0, .05, .05], [1.0, .05, .05]]), rgb=np.array([[200, 100, 50], [10, 10, 10]], np.uint8), max_range=20.0, discrete=True),
+        dict(origin=o, xyz=kat, rgb=np.array([[20, 220, 120]], np.uint8), max_range=20.0, discrete=True)]
+    lo, lx, lc = scans.lidar64(beams=8, azimuths=128, colored=True)
+    yield "lidar_small_continuous", dict(resolution=0.16), [dict(origin=lo, xyz=lx, max_range=20.0)]
+    yield "lidar_small_discrete", dict(resolution=0.16), [dict(origin=lo, xyz=lx, max_range=20.0, discrete=True)]
+    yield "lidar_small_discrete_x6", dict(resolution=0.16), [dict(origin=lo, xyz=lx, max_range=20.0, discrete=True)] * 6
+    yield "lidar_small_range8_depth2", dict(resolution=0.16), [dict(origin=lo, xyz=lx, max_range=8.0, depth=2, discrete=True)] * 2
+    yield "lidar_small_simple", dict(resolution=0.16), [dict(origin=lo, xyz=lx, max_range=12.0, simple_ray_casting=True)]
+    yield "lidar_small_nopruning", dict(resolution=0.16, automatic_pruning=False), [dict(origin=lo, xyz=lx, max_range=20.0, discrete=True)] * 3
+    yield "lidar_small_color_8cm", dict(resolution=0.08, color=True), [dict(origin=lo, xyz=lx, rgb=lc, max_range=10.0, discrete=True)] * 2
+    seq = []
+    for s in range(4):
+        so, sx, _ = scans.lidar64(origin=scans.lidar_pose(s), seed=100 + s, beams=8, azimuths=128)
+        seq.append(dict(origin=so, xyz=sx, max_range=20.0, discrete=True))
+    yield "lidar_small_4poses", dict(resolution=0.16), seq
+    ro, rx, _ = scans.random_cloud(300, seed=7, extent=30.0)
+    yield "clip_small_map_continuous", dict(resolution=0.5, depth_levels=6), [dict(origin=ro, xyz=rx, max_range=-1.0)]
+    yield "clip_small_map_discrete", dict(resolution=0.5, depth_levels=6), [dict(origin=ro, xyz=rx, max_range=25.0, discrete=True, depth=1)]
+    yield "clip_origin_outside", dict(resolution=0.5, depth_levels=6), [dict(origin=np.array([40.0, 3.0, -2.0]), xyz=rx, max_range=-1.0)]
+    go, gx, gc = scans.rgbd(width=40, height=30, colored=True)
+    yield "rgbd_small_2mm_depth4", dict(resolution=0.002), [dict(origin=go, xyz=gx, max_range=5.0, depth=4, discrete=True)]
+    yield "rgbd_small_2cm_color", dict(resolution=0.02, color=True), [dict(origin=go, xyz=gx, rgb=gc, max_range=5.0, discrete=True)] * 2
+    yield "sensor_model_custom", dict(resolution=0.1, depth_levels=14, occupied_thres=0.6, free_thres=0.35, prob_hit=0.8, prob_miss=0.3,
+                                      clamping_thres_min=0.05, clamping_thres_max=0.99), [dict(origin=lo, xyz=lx, max_range=15.0, discrete=True)] * 4
+
+
+def main():
+    assert build("reference"), "needs /root/reference to build oracle/_ref"
+    index = {}
+    for name, params, scan_list in cases():
+        m = OracleMap(kind="reference", **params)
+        arrays = {}
+        meta = dict(params=params, scans=[])
+        for i, sc in enumerate(scan_list):
+            sc = dict(sc)
+            origin, xyz, rgb = sc.pop("origin"), sc.pop("xyz"), sc.pop("rgb", None)
+            m.insert(origin, xyz, rgb, **sc)
+            key = None
+            for j in range(i):  # de-duplicate repeated identical scans
+                if scan_list[j] is scan_list[i]:
+                    key = meta["scans"][j]["data"]
+            if key is None:
+                key = f"s{i}"
+                arrays[key + "_origin"] = np.asarray(origin, np.float64)
+                arrays[key + "_xyz"] = np.asarray(xyz, np.float64)
+                if rgb is not None:
+                    arrays[key + "_rgb"] = np.asarray(rgb, np.uint8)
+            meta["scans"].append(dict(data=key, has_rgb=rgb is not None, kwargs=sc))
+        lc, ld, lv, lrgb = m.leaves(True)
+        ic, idp, iv, ifl, irgb = m.inner()
+        mn, mx = m.minmax_change()
+        kc, kd, kv, krgb = m.leaves(False)
+        arrays.update(leaf_codes=kc, leaf_depths=kd, leaf_occ=kv, leaf_rgb=krgb, min_change=mn, max_change=mx)
+        meta.update(n_leaves_all=int(len(lc)), n_inner=int(len(ic)),
+                    sha_leaves_all=digest(lc, ld, lv, lrgb), sha_inner=digest(ic, idp, iv, ifl, irgb))
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), meta=json.dumps(meta), **arrays)
+        index[name] = dict(leaves=int(len(lc)), known=int(len(kc)), inner=int(len(ic)))
+        print(f"{name:32s} leaves={len(lc):7d} known={len(kc):7d} inner={len(ic):6d}")
+    with open(os.path.join(HERE, "INDEX.json"), "w") as f:
+        json.dump(index, f, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()

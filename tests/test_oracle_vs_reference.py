@@ -1,0 +1,76 @@
+"""Pin the CPU restatement against the unmodified reference (oracle/_ref/libufo_ref.so) on inputs
+beyond the golden fixtures.  Skipped where neither /root/reference nor a prebuilt _ref exists."""
+import numpy as np
+import pytest
+
+from conftest import same_dump
+from oracle import OracleMap, RunawayRay
+from ufomap_amd import scans
+
+
+def _pair(**params):
+    return OracleMap(kind="reference", **params), OracleMap(kind="port", **params)
+
+
+def _assert_same(a, b):
+    assert same_dump(a.leaves(True), b.leaves(True)), "leaf dump differs"
+    assert same_dump(a.inner(), b.inner()), "inner dump differs"
+    assert same_dump(a.minmax_change(), b.minmax_change()), "change AABB differs"
+
+
+@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("mode", ["continuous", "discrete", "discrete_d2", "simple"])
+def test_random_clouds_small_map(seed, mode, ref_available, port_available):
+    """Small map cube (+-16 m) and +-30 m points: exercises moveLineInside clipping on both ends."""
+    if not ref_available:
+        pytest.skip("reference build not available")
+    a, b = _pair(resolution=0.5, depth_levels=6)
+    kw = dict(continuous=dict(), discrete=dict(discrete=True), discrete_d2=dict(discrete=True, depth=2),
+              simple=dict(simple_ray_casting=True))[mode]
+    done = 0
+    for it in range(3):
+        o, xyz, _ = scans.random_cloud(400, seed=seed * 10 + it, extent=30.0, origin=(0.3 + 9 * it, -0.2, 0.4))
+        mr = [-1.0, 12.0, 40.0][it]
+        try:
+            b.insert(o, xyz, max_range=mr, **kw)  # the port goes first: it refuses runaway rays
+        except RunawayRay:
+            continue  # the reference would walk ~2^31 cells on this input (see ufo_oracle.cpp)
+        a.insert(o, xyz, max_range=mr, **kw)
+        done += 1
+    assert done >= 2
+    _assert_same(a, b)
+
+
+@pytest.mark.parametrize("discrete", [False, True])
+def test_full_lidar_scan(discrete, ref_available, port_available):
+    """BASELINE configs C1 (continuous) / C2 (discrete): 131 072 points, 16 cm, 20 m."""
+    if not ref_available:
+        pytest.skip("reference build not available")
+    a, b = _pair(resolution=0.16)
+    o, xyz, _ = scans.lidar64()
+    a.insert(o, xyz, max_range=20.0, discrete=discrete)
+    b.insert(o, xyz, max_range=20.0, discrete=discrete)
+    _assert_same(a, b)
+
+
+def test_colour_sequence(ref_available, port_available):
+    if not ref_available:
+        pytest.skip("reference build not available")
+    a, b = _pair(resolution=0.08, color=True)
+    for s in range(3):
+        o, xyz, rgb = scans.lidar64(origin=scans.lidar_pose(s + 2), seed=100 + s, beams=16, azimuths=256, colored=True)
+        a.insert(o, xyz, rgb, max_range=12.0, discrete=True)
+        b.insert(o, xyz, rgb, max_range=12.0, discrete=True)
+    _assert_same(a, b)
+
+
+def test_pruning_collapse_sequence(ref_available, port_available):
+    """Ten identical scans: free space saturates at clamp_min and collapses (history-dependent pruning)."""
+    if not ref_available:
+        pytest.skip("reference build not available")
+    a, b = _pair(resolution=0.16)
+    o, xyz, _ = scans.lidar64(beams=32, azimuths=512)
+    for _ in range(10):
+        a.insert(o, xyz, max_range=20.0, discrete=True)
+        b.insert(o, xyz, max_range=20.0, discrete=True)
+    _assert_same(a, b)
