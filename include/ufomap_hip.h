@@ -1,0 +1,144 @@
+/*
+ * ufomap_hip.h -- C ABI of the MI355X-native scan-integration path for UFOMap.
+ *
+ * The reference (UnknownFreeOccupied/ufomap v1) has no plugin/FFI interface: its boundary is the
+ * C++ member-template surface of ufo::map::OccupancyMapBase<DATA_TYPE>.  This header is the thin
+ * C-ABI layer the host-side mirrors (include/ufomap_amd/occupancy_map.hpp for C++,
+ * ufomap_amd/occupancy_map.py for Python) forward to; each entry point cites the reference
+ * interface it replaces (paths relative to ufomap/include/ufo/map/ in the reference tree).
+ *
+ * Conventions: plain pointers and sizes only; every function that can fail returns int
+ * (0 = UFOMAP_OK, <0 = error) and leaves a message for ufomap_last_error(); nothing throws.
+ * The reference's hot path has no error reporting at all, so UFOMAP_OK is the only
+ * outcome a reference-valid call can produce.  One HIP stream per map handle; at most one
+ * integration in flight per map, like the reference's `integrate_` future
+ * (occupancy_map_base.h:315, 405, 1553).  Not thread-safe per handle (neither is the reference).
+ *
+ * There is NO CPU fallback behind this ABI: without a HIP device every call fails loudly.
+ */
+#ifndef UFOMAP_HIP_H
+#define UFOMAP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UFOMAP_OK 0
+#define UFOMAP_ERR_INVALID -1     /* bad argument (e.g. depth_levels outside [2,21]: octree.h:931-935) */
+#define UFOMAP_ERR_DEVICE -2      /* HIP runtime error / no device */
+#define UFOMAP_ERR_UNSUPPORTED -3 /* early_stopping > 0 (order-dependent, SURVEY.md 7 hard part 6) */
+#define UFOMAP_ERR_RUNAWAY -4     /* a clipped ray left the map cube (reference walks ~2^31 cells); map unchanged */
+#define UFOMAP_ERR_CAPACITY -5    /* scan grid or node table exceeded the configured memory limit */
+
+typedef struct ufomap_map ufomap_map;
+
+/* ---- library ---------------------------------------------------------------------------- */
+const char* ufomap_last_error(void);
+int ufomap_device_count(void);
+const char* ufomap_version(void);
+
+/* ---- map lifetime: OccupancyMap / OccupancyMapColor constructors
+ *      (occupancy_map.h:60-63, occupancy_map_color.h:60-64; defaults occupancy_map_base.h:859-862).
+ *      has_color selects OccupancyMapColor.  device = HIP device ordinal. Returns NULL on error. */
+ufomap_map* ufomap_map_create(double resolution, unsigned depth_levels, int automatic_pruning,
+                              double occupied_thres, double free_thres, double prob_hit,
+                              double prob_miss, double clamping_thres_min,
+                              double clamping_thres_max, int has_color, int device);
+void ufomap_map_destroy(ufomap_map* m);
+/* Octree::clear() (octree.h:541): back to a single unknown root leaf. */
+int ufomap_map_clear(ufomap_map* m);
+/* Pre-size the node table for n 8-child node blocks (optional; the table grows on demand). */
+int ufomap_map_reserve(ufomap_map* m, size_t n_blocks);
+/* Upper bound in bytes for the per-scan dedup grids (default 16 GiB). */
+int ufomap_map_set_scratch_limit(ufomap_map* m, size_t bytes);
+
+/* ---- sensor model setters (occupancy_map_base.h:746-773), probabilities, not log-odds ------- */
+int ufomap_map_set_sensor_model(ufomap_map* m, double occupied_thres, double free_thres,
+                                double prob_hit, double prob_miss, double clamping_thres_min,
+                                double clamping_thres_max);
+
+/* ---- THE HOT PATH ---------------------------------------------------------------------------
+ * insertPointCloud          (discrete=0: occupancy_map_base.h:270-327)
+ * insertPointCloudDiscrete  (discrete=1: occupancy_map_base.h:340-417;
+ *                            with rgb != NULL the colour overload occupancy_map_color.h:177-267)
+ * xyz: n x 3 float64 (AoS, like std::vector<Point3>), rgb: n x 3 uint8 or NULL.
+ * max_range < 0 = unlimited; depth = DepthType at which free space is cleared;
+ * async != 0 returns after enqueueing (the reference's std::async, occupancy_map_base.h:318);
+ * inputs are copied/consumed before the call returns either way (SURVEY.md 8b ownership).
+ * The call first joins any previous integration (occupancy_map_base.h:315).
+ * ufomap_map_insert takes HOST pointers (H2D copy included); ufomap_map_insert_device takes
+ * DEVICE pointers already resident in HBM (must stay valid until ufomap_map_wait). */
+int ufomap_map_insert(ufomap_map* m, const double sensor_origin[3], const double* xyz,
+                      const uint8_t* rgb, size_t n, double max_range, unsigned depth, int discrete,
+                      int simple_ray_casting, unsigned early_stopping, int async);
+int ufomap_map_insert_device(ufomap_map* m, const double sensor_origin[3], const double* d_xyz,
+                             const uint8_t* d_rgb, size_t n, double max_range, unsigned depth,
+                             int discrete, int simple_ray_casting, unsigned early_stopping,
+                             int async);
+/* insertPointCloudWait / insertPointCloudDone (occupancy_map_base.h:430-443).
+ * wait returns the status of the joined integration; done returns 1/0 (or <0 on error). */
+int ufomap_map_wait(ufomap_map* m);
+int ufomap_map_done(ufomap_map* m);
+
+/* ---- read-back (what the reference exposes through beginLeaves()/beginTree(),
+ *      occupancy_map_base.h:93-137; iterator/octree.h:133-158) -------------------------------
+ * Canonical dump: node = (code >> 3*depth, depth); output sorted by (depth, code).
+ * Return the total count (may exceed cap; only cap entries are written); (size_t)-1 on error.
+ * Any output pointer may be NULL.  rgb: 3 bytes per node (zeros for a non-colour map).
+ * flags: bit0 contains_free, bit1 contains_unknown (occupancy_map_node.h:171-176). */
+size_t ufomap_map_export_leaves(ufomap_map* m, int include_unknown, uint64_t* codes,
+                                uint8_t* depths, float* logodds, uint8_t* rgb, size_t cap);
+size_t ufomap_map_export_inner(ufomap_map* m, uint64_t* codes, uint8_t* depths, float* logodds,
+                               uint8_t* flags, uint8_t* rgb, size_t cap);
+
+/* min/max change AABB: minChange()/maxChange()/resetMinMaxChangeDetection
+ * (occupancy_map_base.h:793-822). Always tracked. */
+int ufomap_map_minmax_change(ufomap_map* m, double mn[3], double mx[3]);
+int ufomap_map_reset_minmax_change(ufomap_map* m);
+
+/* getNumInnerNodes / getNumLeafNodes / memoryUsage analogues (octree.h:411-443): live node blocks,
+ * leaves reachable from them, bytes of HBM held by the map. */
+int ufomap_map_stats(ufomap_map* m, uint64_t* n_inner, uint64_t* n_leaf, uint64_t* bytes);
+
+/* ---- stage-level outputs of the last integration (parity tests; SURVEY.md section 4 iii) ----
+ * hits: unique hit voxel codes at depth 0 (`occupied_hits`, occupancy_map_base.h:296);
+ * misses: unique free cells as code >> 3*depth (`free_hits`, occupancy_map_base.h:1356-1365);
+ * both sorted ascending. counts: [0]=points in, [1]=rays cast, [2]=DDA steps, [3]=unique hits,
+ * [4]=unique miss cells, [5]=node blocks touched, [6]=node blocks created. */
+size_t ufomap_map_last_hits(ufomap_map* m, uint64_t* codes, size_t cap);
+size_t ufomap_map_last_misses(ufomap_map* m, uint64_t* codes, size_t cap);
+int ufomap_map_last_counts(ufomap_map* m, uint64_t counts[8]);
+
+/* ---- measurement: per-kernel HIP-event timing on the map's own stream ------------------------
+ * With profiling on, every kernel launch of the hot path is bracketed by hipEvents on the
+ * stream it is launched on. kernel_times returns, for up to cap kernels, the name, number of
+ * launches and total milliseconds since the last reset. Returns the number of kernels. */
+int ufomap_map_set_profiling(ufomap_map* m, int on);
+int ufomap_map_kernel_times(ufomap_map* m, const char** names, uint64_t* launches, double* total_ms,
+                            int cap);
+int ufomap_map_reset_kernel_times(ufomap_map* m);
+
+/* ---- multi-GPU batched scans: stage split ------------------------------------
+ * ufomap_map_scan_keys runs the ray-casting / dedup half of the path for one scan WITHOUT
+ * touching the map and leaves its update list on the device:
+ *   entries: *n_entries records of 16 bytes {u64 location key of an 8-child node block,
+ *            u8 hit mask, u8 miss mask, u8 level, 5 pad/colour index}, see DESIGN.md;
+ * ufomap_map_apply_keys applies one such list (e.g. received from a peer GPU over RCCL) to this
+ * map with the reference's ordering (hits, clamp, misses, clamp). Applying the lists of scans
+ * 0..B-1 in order on every replica reproduces sequential integration bit-exactly. */
+int ufomap_map_scan_keys(ufomap_map* m, const double sensor_origin[3], const double* d_xyz,
+                         const uint8_t* d_rgb, size_t n, double max_range, unsigned depth,
+                         int discrete, int simple_ray_casting, void** d_entries,
+                         size_t* n_entries);
+int ufomap_map_apply_keys(ufomap_map* m, const void* d_entries, size_t n_entries, unsigned depth);
+
+/* Raw HIP stream of the map (hipStream_t), for callers that need to order their own work. */
+void* ufomap_map_stream(ufomap_map* m);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UFOMAP_HIP_H */

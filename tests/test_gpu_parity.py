@@ -1,0 +1,167 @@
+"""HIP path vs oracle -- the parity tests proper (run with -m gpu on an MI355X).
+
+Everything goes through the C ABI (ufomap_amd.occupancy_map -> csrc/libufomap_hip.so).  Bar:
+bit-exact Morton codes / depths / colours and bit-exact float32 log-odds (north_star allows 1e-5;
+we hold 0), including the leaf structure (pruning), inner-node summaries and the change AABB.
+"""
+import numpy as np
+import pytest
+
+import golden_util
+from conftest import same_dump
+
+pytestmark = pytest.mark.gpu
+
+
+def _maps(color=False, **params):
+    from oracle import OracleMap
+    from ufomap_amd import OccupancyMap, OccupancyMapColor
+    g = (OccupancyMapColor if color else OccupancyMap)(**params)
+    o = OracleMap(kind="port", color=color, **params)
+    return g, o
+
+
+def _gpu_insert(g, origin, xyz, rgb=None, max_range=-1.0, depth=0, discrete=False, simple_ray_casting=False, async_=False):
+    from ufomap_amd import PointCloud, PointCloudColor
+    cloud = PointCloudColor(xyz, rgb) if rgb is not None else PointCloud(xyz)
+    fn = g.insertPointCloudDiscrete if discrete else g.insertPointCloud
+    fn(origin, cloud, max_range, depth, simple_ray_casting, 0, async_)
+
+
+def _assert_same_map(g, o, what=""):
+    gl, ol = g.leaves(True), o.leaves(True)
+    assert len(gl[0]) == len(ol[0]), f"{what}: leaf count {len(gl[0])} vs oracle {len(ol[0])}"
+    assert np.array_equal(gl[0], ol[0]) and np.array_equal(gl[1], ol[1]), f"{what}: leaf codes/depths differ"
+    assert np.array_equal(gl[2], ol[2]), f"{what}: log-odds differ, max |d| = {np.abs(gl[2] - ol[2]).max()}"
+    assert np.array_equal(gl[3], ol[3]), f"{what}: colours differ"
+    assert same_dump(g.inner(), o.inner()), f"{what}: inner-node dump differs"
+    assert same_dump(g.minmax_change(), o.minmax_change()), f"{what}: change AABB differs"
+
+
+@pytest.mark.parametrize("name", golden_util.names())
+def test_gpu_matches_golden(name):
+    """Golden vectors generated from the unmodified reference (tests/golden/make_golden.py)."""
+    from ufomap_amd import OccupancyMap, OccupancyMapColor
+    g = golden_util.Golden(name)
+    params = dict(g.params)
+    color = params.pop("color", False)
+    m = (OccupancyMapColor if color else OccupancyMap)(**params)
+    for origin, xyz, rgb, kw in g.scans():
+        _gpu_insert(m, origin, xyz, rgb, **kw)
+    g.check(m)
+
+
+@pytest.mark.parametrize("discrete", [False, True])
+def test_stage_level_hits_and_misses(discrete):
+    """Unique hit codes and unique miss codes of one scan, bit-exact (SURVEY 4 iii)."""
+    from ufomap_amd import scans
+    g, o = _maps(resolution=0.16)
+    origin, xyz, _ = scans.lidar64(beams=32, azimuths=1024)
+    _gpu_insert(g, origin, xyz, max_range=20.0, discrete=discrete)
+    o.insert(origin, xyz, max_range=20.0, discrete=discrete)
+    assert np.array_equal(g.last_hits(), o.last_hits())
+    assert np.array_equal(g.last_misses(), o.last_misses())
+    c = g.last_counts()
+    assert c["rays"] == len(o.last_rays())
+    assert c["steps"] == o.last_steps()
+    _assert_same_map(g, o, "stage")
+
+
+@pytest.mark.parametrize("discrete", [False, True])
+def test_full_lidar_scan_c1_c2(discrete):
+    """BASELINE configs C1 (continuous) and C2 (discrete): 131 072 points, 16 cm, 20 m."""
+    from ufomap_amd import scans
+    g, o = _maps(resolution=0.16)
+    origin, xyz, _ = scans.lidar64()
+    _gpu_insert(g, origin, xyz, max_range=20.0, discrete=discrete)
+    o.insert(origin, xyz, max_range=20.0, discrete=discrete)
+    _assert_same_map(g, o, "C1/C2")
+
+
+def test_batch_of_8_poses_c4_sequential():
+    """BASELINE config C4 integrated sequentially into one map (8 poses)."""
+    from ufomap_amd import scans
+    g, o = _maps(resolution=0.16)
+    for s in range(8):
+        origin, xyz, _ = scans.lidar64(origin=scans.lidar_pose(s), seed=100 + s)
+        _gpu_insert(g, origin, xyz, max_range=20.0, discrete=True)
+        o.insert(origin, xyz, max_range=20.0, discrete=True)
+    _assert_same_map(g, o, "C4")
+
+
+def test_repeated_scan_saturation_and_pruning():
+    """Ten identical scans: clamping at both ends and history-dependent collapse of free space."""
+    from ufomap_amd import scans
+    g, o = _maps(resolution=0.16)
+    origin, xyz, _ = scans.lidar64(beams=32, azimuths=512)
+    for i in range(10):
+        _gpu_insert(g, origin, xyz, max_range=20.0, discrete=True)
+        o.insert(origin, xyz, max_range=20.0, discrete=True)
+        _assert_same_map(g, o, f"scan {i}")
+
+
+def test_colour_c5_8cm():
+    """BASELINE config C5: coloured scan, 8 cm leaf, occupancy + RGB fused update."""
+    from ufomap_amd import scans
+    g, o = _maps(color=True, resolution=0.08)
+    for s in range(2):
+        origin, xyz, rgb = scans.lidar64(origin=scans.lidar_pose(s + 3), seed=100 + s, colored=True)
+        _gpu_insert(g, origin, xyz, rgb, max_range=20.0, discrete=True)
+        o.insert(origin, xyz, rgb, max_range=20.0, discrete=True)
+    _assert_same_map(g, o, "C5")
+
+
+@pytest.mark.parametrize("depth", [3, 6])
+def test_rgbd_c3_insert_depth(depth):
+    """BASELINE config C3 (2 mm, 5 m, 307 200 points) with free space cleared at depth 3 / 6."""
+    from ufomap_amd import scans
+    g, o = _maps(resolution=0.002)
+    origin, xyz, _ = scans.rgbd()
+    for _ in range(2):
+        _gpu_insert(g, origin, xyz, max_range=5.0, depth=depth, discrete=True)
+        o.insert(origin, xyz, max_range=5.0, depth=depth, discrete=True)
+    _assert_same_map(g, o, f"C3 depth {depth}")
+
+
+def test_async_and_wait():
+    from ufomap_amd import scans
+    g, o = _maps(resolution=0.16)
+    origin, xyz, _ = scans.lidar64(beams=16, azimuths=512)
+    _gpu_insert(g, origin, xyz, max_range=20.0, discrete=True, async_=True)
+    g.insertPointCloudWait()
+    assert g.insertPointCloudDone()
+    _gpu_insert(g, origin, xyz, max_range=20.0, discrete=True, async_=True)  # joins nothing pending, then enqueues
+    o.insert(origin, xyz, max_range=20.0, discrete=True)
+    o.insert(origin, xyz, max_range=20.0, discrete=True)
+    _assert_same_map(g, o, "async")
+
+
+def test_edge_cases_empty_and_errors():
+    from ufomap_amd import OccupancyMap, capi
+    with pytest.raises(ValueError):
+        OccupancyMap(0.1, depth_levels=1)
+    with pytest.raises(ValueError):
+        OccupancyMap(0.1, depth_levels=22)
+    m = OccupancyMap(0.16)
+    _gpu_insert(m, [0, 0, 0], np.zeros((0, 3)), max_range=20.0, discrete=True)
+    assert len(m.leaves()[0]) == 0
+    codes, depths, occ, _ = m.leaves(True)
+    assert codes.tolist() == [0] and depths.tolist() == [16] and occ.tolist() == [0.0]
+    with pytest.raises(capi.UfomapError) as e:
+        m.insertPointCloud([0, 0, 0], np.ones((4, 3)), 20.0, 0, False, 3)  # early_stopping unsupported
+    assert e.value.code == capi.ERR_UNSUPPORTED
+
+
+def test_runaway_ray_is_refused_and_map_unchanged():
+    """The input on which the reference walks ~2^31 cells: refused, like the oracle port does."""
+    from oracle import RunawayRay
+    from ufomap_amd import capi
+    g, o = _maps(resolution=0.5, depth_levels=6)
+    origin = np.array([float.fromhex("0x1.24ccccccccccdp+4"), float.fromhex("-0x1.999999999999ap-3"), float.fromhex("0x1.999999999999ap-2")])
+    pt = np.array([[float.fromhex("0x1.cbec1074f2bf0p+2"), float.fromhex("-0x1.d4ce8bc744bffp+4"), float.fromhex("-0x1.7e4cd8d9a9637p+3")]])
+    with pytest.raises(RunawayRay):
+        o.insert(origin, pt, max_range=40.0, discrete=True)
+    with pytest.raises(capi.UfomapError) as e:
+        _gpu_insert(g, origin, pt, max_range=40.0, discrete=True)
+    assert e.value.code in (capi.ERR_RUNAWAY, capi.ERR_CAPACITY)
+    assert len(g.leaves()[0]) == 0

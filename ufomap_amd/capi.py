@@ -1,0 +1,91 @@
+"""ctypes binding of include/ufomap_hip.h (the C-ABI of the HIP library).
+
+The library is built in-tree by ufomap_amd/build.py (csrc/libufomap_hip.so) and loaded from
+there -- never from site-packages -- so that the driver sees which native code ran.  Loading
+fails loudly when the .so is missing; there is no Python or CPU fallback for the hot path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libufomap_hip.so")
+
+UFOMAP_OK = 0
+ERR_INVALID, ERR_DEVICE, ERR_UNSUPPORTED, ERR_RUNAWAY, ERR_CAPACITY = -1, -2, -3, -4, -5
+
+# every symbol include/ufomap_hip.h declares (tests/test_capi_symbols.py checks the .so against this
+# list AND the list against the header)
+SYMBOLS = [
+    "ufomap_last_error", "ufomap_device_count", "ufomap_version", "ufomap_map_create",
+    "ufomap_map_destroy", "ufomap_map_clear", "ufomap_map_reserve", "ufomap_map_set_scratch_limit",
+    "ufomap_map_set_sensor_model", "ufomap_map_insert", "ufomap_map_insert_device",
+    "ufomap_map_wait", "ufomap_map_done", "ufomap_map_export_leaves", "ufomap_map_export_inner",
+    "ufomap_map_minmax_change", "ufomap_map_reset_minmax_change", "ufomap_map_stats",
+    "ufomap_map_last_hits", "ufomap_map_last_misses", "ufomap_map_last_counts",
+    "ufomap_map_set_profiling", "ufomap_map_kernel_times", "ufomap_map_reset_kernel_times",
+    "ufomap_map_scan_keys", "ufomap_map_apply_keys", "ufomap_map_stream",
+]
+
+_lib = None
+
+
+class UfomapError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"ufomap_hip error {code}: {msg}")
+        self.code = code
+
+
+def load():
+    """Load csrc/libufomap_hip.so (raises if it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} not built: run `python -m ufomap_amd.build` (no CPU fallback exists)")
+    lib = C.CDLL(LIB_PATH)
+    vp, sz, dbl, u64p, u8p, f32p, f64p = C.c_void_p, C.c_size_t, C.c_double, C.POINTER(C.c_uint64), C.POINTER(C.c_uint8), C.POINTER(C.c_float), C.POINTER(C.c_double)
+    lib.ufomap_last_error.restype = C.c_char_p
+    lib.ufomap_version.restype = C.c_char_p
+    lib.ufomap_device_count.restype = C.c_int
+    lib.ufomap_map_create.restype = vp
+    lib.ufomap_map_create.argtypes = [dbl, C.c_uint, C.c_int] + [dbl] * 6 + [C.c_int, C.c_int]
+    lib.ufomap_map_destroy.argtypes = [vp]
+    lib.ufomap_map_destroy.restype = None
+    lib.ufomap_map_clear.argtypes = [vp]
+    lib.ufomap_map_reserve.argtypes = [vp, sz]
+    lib.ufomap_map_set_scratch_limit.argtypes = [vp, sz]
+    lib.ufomap_map_set_sensor_model.argtypes = [vp] + [dbl] * 6
+    ins = [vp, f64p, vp, vp, sz, dbl, C.c_uint, C.c_int, C.c_int, C.c_uint, C.c_int]
+    lib.ufomap_map_insert.argtypes = ins
+    lib.ufomap_map_insert_device.argtypes = ins
+    lib.ufomap_map_wait.argtypes = [vp]
+    lib.ufomap_map_done.argtypes = [vp]
+    lib.ufomap_map_export_leaves.restype = sz
+    lib.ufomap_map_export_leaves.argtypes = [vp, C.c_int, u64p, u8p, f32p, u8p, sz]
+    lib.ufomap_map_export_inner.restype = sz
+    lib.ufomap_map_export_inner.argtypes = [vp, u64p, u8p, f32p, u8p, u8p, sz]
+    lib.ufomap_map_minmax_change.argtypes = [vp, f64p, f64p]
+    lib.ufomap_map_reset_minmax_change.argtypes = [vp]
+    lib.ufomap_map_stats.argtypes = [vp, u64p, u64p, u64p]
+    lib.ufomap_map_last_hits.restype = sz
+    lib.ufomap_map_last_hits.argtypes = [vp, u64p, sz]
+    lib.ufomap_map_last_misses.restype = sz
+    lib.ufomap_map_last_misses.argtypes = [vp, u64p, sz]
+    lib.ufomap_map_last_counts.argtypes = [vp, u64p]
+    lib.ufomap_map_set_profiling.argtypes = [vp, C.c_int]
+    lib.ufomap_map_kernel_times.argtypes = [vp, C.POINTER(C.c_char_p), u64p, f64p, C.c_int]
+    lib.ufomap_map_reset_kernel_times.argtypes = [vp]
+    lib.ufomap_map_scan_keys.argtypes = [vp, f64p, vp, vp, sz, dbl, C.c_uint, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(sz)]
+    lib.ufomap_map_apply_keys.argtypes = [vp, vp, sz, C.c_uint]
+    lib.ufomap_map_stream.restype = vp
+    lib.ufomap_map_stream.argtypes = [vp]
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc < 0:
+        raise UfomapError(rc, load().ufomap_last_error().decode())
+    return rc

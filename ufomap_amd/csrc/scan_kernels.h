@@ -1,0 +1,532 @@
+// scan_kernels.h -- per-scan kernels that do NOT touch the map: classify points, de-duplicate
+// hits, cast rays (3D-DDA) into the scan's dedup grid, extract the update list.
+//
+// Replaces (reference, ufomap/include/ufo/map/): the head loops of insertPointCloud /
+// insertPointCloudDiscrete (occupancy_map_base.h:281-309, 354-399; colour: occupancy_map_color.h:
+// 195-247), CodeSet `indices_` (code.h:378-566), freeSpace / freeSpaceNormal / freeSpaceSimple
+// (occupancy_map_base.h:1229-1339), computeRayInit / computeRayTakeStep (octree.h:1192-1233) and
+// CodeMap `free_hits` (code.h:568-785).
+//
+// The per-scan dedup containers become a *dense bit grid over the scan's bounding box*: one byte per
+// 2x2x2 cell block (= one 8-child node block of the octree), bit i = child i. Hits go to grid H
+// (depth 0), misses to grid M (depth = insert depth); when depth == 0 both share one grid geometry.
+// Marking is a fire-and-forget atomicOr; "unique" falls out of the bit set; the update list is read
+// off the non-zero bytes, already grouped per node block.
+#pragma once
+#include "table.h"
+
+namespace ufo
+{
+enum : u32 {
+	ERR_RUNAWAY = 1u,     // a ray exceeded 3*2^L+8 steps (clipped end outside the cube)
+	ERR_GRID_OOB = 2u,    // a DDA cell fell outside the scan grid (should not happen)
+	ERR_TABLE_FULL = 4u,  // node table full
+	ERR_HASH_FULL = 8u,   // hit hash full (should not happen: sized 4x points)
+};
+
+// Geometry of one dedup grid: cells at depth `depth`, blocks of 2x2x2 cells.
+struct Grid {
+	i32 base[3];  // cell coordinate (key >> depth, as signed) of block (0,0,0); even
+	i32 nb[3];    // blocks per axis
+	u32 depth;
+	u32 pad;
+	u64 bytes;  // nb[0]*nb[1]*nb[2] rounded up to 8
+};
+
+struct ScanCtl {
+	u32 n_rays;
+	u32 n_hits;
+	u32 n_entries;
+	u32 n_new;
+	u32 err;
+	u32 wl_count[2];
+	u32 n_codes;
+	i32 mb_min[3], mb_max[3];  // miss-grid cell bbox (cells at insert depth)
+	i32 hb_min[3], hb_max[3];  // hit-grid cell bbox (depth 0)
+	u64 aabb_min[3], aabb_max[3];  // order-encoded doubles: change AABB of this scan
+	unsigned long long n_steps;
+};
+
+struct Entry {
+	u64 lk;    // location key of the node block
+	u8 hit;    // children that received a hit (level-1 blocks only)
+	u8 miss;   // children that received a miss
+	u8 level;  // level of the block = depth of its children + 1
+	u8 pad[5];
+};
+
+// order-preserving double <-> u64 (for atomicMin/Max on doubles)
+__host__ __device__ inline u64 encD(double d)
+{
+	u64 b;
+	memcpy(&b, &d, 8);
+	return (b & 0x8000000000000000ULL) ? ~b : (b | 0x8000000000000000ULL);
+}
+__host__ __device__ inline double decD(u64 e)
+{
+	u64 b = (e & 0x8000000000000000ULL) ? (e & 0x7FFFFFFFFFFFFFFFULL) : ~e;
+	double d;
+	memcpy(&d, &b, 8);
+	return d;
+}
+
+__device__ inline i32 waveMinI(i32 v)
+{
+	for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+	return v;
+}
+__device__ inline i32 waveMaxI(i32 v)
+{
+	for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+	return v;
+}
+__device__ inline double waveMinD(double v)
+{
+	for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o));
+	return v;
+}
+__device__ inline double waveMaxD(double v)
+{
+	for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+	return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K0 classify: one thread per input point. Head loop of insertPointCloud (OMB:281-303) or
+// insertPointCloudDiscrete (OMB:354-386 / OMC.h:195-233) up to, but not including, the
+// first-point-wins de-duplication. Emits per point: ray end, flags, candidate hit code; inserts the
+// candidate into the hit hash with atomicMin(point index) -> "first point in the voxel wins".
+// ------------------------------------------------------------------------------------------------
+enum : u8 { PF_HITCAND = 1, PF_CAST = 2 };
+
+struct HitHash {
+	u64* keys;  // ~0 = empty
+	u32* minidx;
+	u32 mask;
+};
+
+__device__ inline u32 hitHashInsert(const HitHash& h, u64 code, u32 idx, u32* err)
+{
+	u32 s = hash64(code) & h.mask;
+	for (u32 probe = 0; probe <= h.mask; ++probe) {
+		u64 k = __hip_atomic_load(&h.keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (k == ~0ULL) {
+			u64 prev = atomicCAS((unsigned long long*)&h.keys[s], ~0ULL, (unsigned long long)code);
+			k = (prev == ~0ULL) ? code : prev;
+		}
+		if (k == code) {
+			atomicMin(&h.minidx[s], idx);
+			return s;
+		}
+		s = (s + 1) & h.mask;
+	}
+	atomicOr(err, ERR_HASH_FULL);
+	return NONE;
+}
+__device__ inline u32 hitHashFind(const HitHash& h, u64 code)
+{
+	u32 s = hash64(code) & h.mask;
+	for (u32 probe = 0; probe <= h.mask; ++probe) {
+		u64 k = h.keys[s];
+		if (k == code) return s;
+		if (k == ~0ULL) return NONE;
+		s = (s + 1) & h.mask;
+	}
+	return NONE;
+}
+
+template <bool DISCRETE>
+__global__ __launch_bounds__(256) void k_classify(MapGeom g, D3 sensor, const double* __restrict__ xyz, u32 n,
+                                                  double max_range, u32 depth, u32 color_variant, HitHash hh,
+                                                  D3* __restrict__ pt_end, u8* __restrict__ pt_flag,
+                                                  u32* __restrict__ pt_slot, ScanCtl* ctl)
+{
+	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (!DISCRETE) {
+		// OMB:281-303; the change AABB (OMB:305-308) is reduced per wave, so no early return here
+		double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+		if (i < n) {
+			D3 end{xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2]};
+			u8 flag = 0;
+			u32 slot = NONE;
+			D3 origin = sensor;
+			D3 dir = end - origin;
+			double dist = norm(dir);
+			if (moveLineInside(g, origin, end)) {
+				if (0 > max_range || dist <= max_range) {
+					u64 code = morton3(toKey1(g, end.x, 0), toKey1(g, end.y, 0), toKey1(g, end.z, 0));
+					slot = hitHashInsert(hh, code, i, &ctl->err);
+					flag |= PF_HITCAND;
+				} else {
+					dir = dir / dist;
+					end = origin + (dir * max_range);
+				}
+				flag |= PF_CAST;
+				for (int a = 0; a < 3; ++a) {
+					mn[a] = fmin(end[a], origin[a]);
+					mx[a] = fmax(end[a], origin[a]);
+				}
+				pt_end[i] = end;
+			}
+			pt_flag[i] = flag;
+			pt_slot[i] = slot;
+		}
+		for (int a = 0; a < 3; ++a) {
+			double l = waveMinD(mn[a]);
+			double h = waveMaxD(mx[a]);
+			if ((threadIdx.x & 63) == 0 && l < 1e299) {
+				atomicMin((unsigned long long*)&ctl->aabb_min[a], (unsigned long long)encD(l));
+				atomicMax((unsigned long long*)&ctl->aabb_max[a], (unsigned long long)encD(h));
+			}
+		}
+		return;
+	}
+	if (i >= n) return;
+	D3 end{xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2]};
+	u8 flag = 0;
+	u32 slot = NONE;
+	// discrete: OMB:354-371 (colour variant OMC.h:195-219)
+	double sq_max = max_range * max_range;
+	double dsq = sqnorm(end - sensor);
+	if (0 > max_range || dsq < sq_max) {
+		if (inBBX(end, g.hs[g.L])) {
+			u64 code = morton3(toKey1(g, end.x, 0), toKey1(g, end.y, 0), toKey1(g, end.z, 0));
+			slot = hitHashInsert(hh, code, i, &ctl->err);
+			flag |= PF_HITCAND;
+		}
+	} else {
+		D3 c{toCoord1(g, toKey1(g, end.x, depth), depth), toCoord1(g, toKey1(g, end.y, depth), depth),
+		     toCoord1(g, toKey1(g, end.z, depth), depth)};
+		D3 dir = c - sensor;
+		if (color_variant) {
+			dsq = sqnorm(dir);
+			if (0 <= max_range && dsq > sq_max) {
+				dir = dir / sqrt(dsq);
+				end = sensor + (dir * max_range);
+			}
+		} else {
+			double dist = norm(dir);
+			dir = dir / dist;
+			if (0 <= max_range && dist > max_range) end = sensor + (dir * max_range);
+		}
+	}
+	flag |= PF_CAST;
+	pt_end[i] = end;
+	pt_flag[i] = flag;
+	pt_slot[i] = slot;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1 select: first-point-wins (CodeSet semantics, OMB:295 / 358-360), compaction of the surviving
+// rays and of the unique hits, bounding boxes of both dedup grids, change AABB (discrete mode).
+// ------------------------------------------------------------------------------------------------
+template <bool DISCRETE>
+__global__ __launch_bounds__(256) void k_select(MapGeom g, D3 sensor, u32 n, u32 depth, HitHash hh,
+                                                const D3* __restrict__ pt_end, const u8* __restrict__ pt_flag,
+                                                const u32* __restrict__ pt_slot, D3* __restrict__ ray_end,
+                                                u64* __restrict__ hit_code, u32* __restrict__ hit_pt, ScanCtl* ctl)
+{
+	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	u8 flag = (i < n) ? pt_flag[i] : 0;
+	bool cast = (flag & PF_CAST) != 0;
+	bool winner = false;
+	D3 end{0, 0, 0};
+	if (i < n && flag) end = pt_end[i];
+	if (flag & PF_HITCAND) {
+		u32 s = pt_slot[i];
+		winner = (s != NONE) && (hh.minidx[s] == i);
+		if (DISCRETE && !winner) cast = false;  // OMB:358-360: dropped entirely, no ray
+	}
+	i32 hk[3] = {INT32_MAX, INT32_MAX, INT32_MAX};
+	if (winner) {
+		u32 pos = atomicAdd(&ctl->n_hits, 1u);
+		u32 kx = toKey1(g, end.x, 0), ky = toKey1(g, end.y, 0), kz = toKey1(g, end.z, 0);
+		hit_code[pos] = morton3(kx, ky, kz);
+		hit_pt[pos] = i;
+		hk[0] = (i32)kx;
+		hk[1] = (i32)ky;
+		hk[2] = (i32)kz;
+	}
+	// hit-grid bbox
+	for (int a = 0; a < 3; ++a) {
+		i32 lo = waveMinI(hk[a]);
+		i32 hi = waveMaxI(winner ? hk[a] : INT32_MIN);
+		if ((threadIdx.x & 63) == 0 && lo != INT32_MAX) {
+			atomicMin(&ctl->hb_min[a], lo);
+			atomicMax(&ctl->hb_max[a], hi);
+		}
+	}
+	i32 ck[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, ek[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+	double amn[3] = {1e300, 1e300, 1e300}, amx[3] = {-1e300, -1e300, -1e300};
+	bool has_aabb = false;
+	if (cast) {
+		D3 cur = sensor;
+		D3 e2 = end;
+		if (DISCRETE) {
+			// OMB:371-398: clip, snap the ray end to the centre of its depth-`depth` cell
+			if (moveLineInside(g, cur, e2)) {
+				u32 k0 = toKey1(g, e2.x, depth), k1 = toKey1(g, e2.y, depth), k2 = toKey1(g, e2.z, depth);
+				D3 ec{toCoord1(g, k0, depth), toCoord1(g, k1, depth), toCoord1(g, k2, depth)};
+				D3 cc{toCoord1(g, toKey1(g, cur.x, depth), depth), toCoord1(g, toKey1(g, cur.y, depth), depth),
+				      toCoord1(g, toKey1(g, cur.z, depth), depth)};
+				double t = g.hs[depth];
+				for (int a = 0; a < 3; ++a) {
+					amn[a] = fmin(ec[a] - t, cc[a] - t);
+					amx[a] = fmax(ec[a] + t, cc[a] + t);
+				}
+				has_aabb = true;
+				end = ec;
+			} else {
+				cast = false;
+			}
+		}
+		if (cast) {
+			// freeSpace's own clip (OMB:1248) decides whether the ray is walked at all
+			D3 c2 = sensor, e3 = end;
+			if (moveLineInside(g, c2, e3)) {
+				u32 pos = atomicAdd(&ctl->n_rays, 1u);
+				ray_end[pos] = end;
+				for (int a = 0; a < 3; ++a) {
+					i32 ka = (i32)(toKey1(g, e3[a], depth) >> depth);
+					i32 kb = (i32)(toKey1(g, c2[a], depth) >> depth);
+					ck[a] = min(ka, kb);
+					ek[a] = max(ka, kb);
+				}
+			} else {
+				cast = false;
+			}
+		}
+	}
+	for (int a = 0; a < 3; ++a) {
+		i32 lo = waveMinI(ck[a]);
+		i32 hi = waveMaxI(ek[a]);
+		if ((threadIdx.x & 63) == 0 && lo != INT32_MAX) {
+			atomicMin(&ctl->mb_min[a], lo);
+			atomicMax(&ctl->mb_max[a], hi);
+		}
+		if (DISCRETE) {
+			double l = waveMinD(amn[a]);
+			double h = waveMaxD(amx[a]);
+			if ((threadIdx.x & 63) == 0 && l < 1e299) {
+				atomicMin((unsigned long long*)&ctl->aabb_min[a], (unsigned long long)encD(l));
+				atomicMax((unsigned long long*)&ctl->aabb_max[a], (unsigned long long)encD(h));
+			}
+		}
+	}
+	(void)has_aabb;
+}
+
+// ------------------------------------------------------------------------------------------------
+// grid marking helpers
+// ------------------------------------------------------------------------------------------------
+__device__ inline bool gridMark(const Grid& gr, u32* __restrict__ grid, i32 cx, i32 cy, i32 cz)
+{
+	i32 lx = cx - gr.base[0], ly = cy - gr.base[1], lz = cz - gr.base[2];
+	i32 bx = lx >> 1, by = ly >> 1, bz = lz >> 1;
+	if ((u32)bx >= (u32)gr.nb[0] || (u32)by >= (u32)gr.nb[1] || (u32)bz >= (u32)gr.nb[2]) return false;
+	u64 idx = ((u64)bz * (u64)gr.nb[1] + (u64)by) * (u64)gr.nb[0] + (u64)bx;
+	u32 bit = (u32)((lx & 1) | ((ly & 1) << 1) | ((lz & 1) << 2)) + 8u * (u32)(idx & 3);
+	atomicOr(&grid[idx >> 2], 1u << bit);
+	return true;
+}
+
+// K_hitmark: unique hits -> grid H (depth 0)
+__global__ __launch_bounds__(256) void k_hitmark(Grid gr, u32* __restrict__ grid, const u64* __restrict__ hit_code,
+                                                 const ScanCtl* ctl_in, ScanCtl* ctl)
+{
+	u32 n = ctl_in->n_hits;
+	for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		u64 c = hit_code[i];
+		// de-interleave (map/code.h:351-364)
+		u32 k[3];
+		for (int a = 0; a < 3; ++a) {
+			u64 v = (c >> a) & 0x1249249249249249ULL;
+			v = (v ^ (v >> 2)) & 0x10c30c30c30c30c3ULL;
+			v = (v ^ (v >> 4)) & 0x100f00f00f00f00fULL;
+			v = (v ^ (v >> 8)) & 0x1f0000ff0000ffULL;
+			v = (v ^ (v >> 16)) & 0x1f00000000ffffULL;
+			v = (v ^ (v >> 32)) & 0x1fffffULL;
+			k[a] = (u32)v;
+		}
+		if (!gridMark(gr, grid, (i32)k[0], (i32)k[1], (i32)k[2])) atomicOr(&ctl->err, ERR_GRID_OOB);
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2 dda: one lane per ray, sequential FP64 recurrence in the reference's op order
+// (freeSpaceNormal OMB:1261-1301, computeRayInit OCT:1192-1225, computeRayTakeStep OCT:1227-1233,
+// minElementIndex VEC3:244-251). Walks BACKWARDS from the ray end to the sensor. Each visited cell
+// is one atomicOr into grid M.
+// ------------------------------------------------------------------------------------------------
+template <bool SIMPLE>
+__global__ __launch_bounds__(256) void k_dda(MapGeom g, D3 sensor, u32 depth, Grid gr, u32* __restrict__ grid,
+                                             const D3* __restrict__ ray_end, const ScanCtl* ctl_in, ScanCtl* ctl)
+{
+	u32 n = ctl_in->n_rays;
+	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	unsigned long long steps = 0;
+	u32 err = 0;
+	if (i < n) {
+		D3 from = sensor, to = ray_end[i];
+		if (moveLineInside(g, from, to)) {
+			// "Do it backwards" OMB:1266-1272
+			D3 cur = to, end = from;
+			D3 dir = end - cur;
+			double dist = norm(dir);
+			dir = dir / dist;
+			const u64 budget = 3ull * (1ull << g.L) + 8;
+			if (SIMPLE) {
+				// freeSpaceSimple OMB:1303-1339
+				double ns = nodeSize(g, depth);
+				int num_steps = (int)(dist / ns);
+				if (num_steps < 0 || (u64)num_steps > budget) {
+					err |= ERR_RUNAWAY;
+				} else {
+					D3 stepv = dir * ns;
+					for (int s = 0; s <= num_steps; ++s) {
+						i32 cx = (i32)(toKey1(g, cur.x, depth) >> depth), cy = (i32)(toKey1(g, cur.y, depth) >> depth),
+						    cz = (i32)(toKey1(g, cur.z, depth) >> depth);
+						if (!gridMark(gr, grid, cx, cy, cz)) err |= ERR_GRID_OOB;
+						++steps;
+						cur = cur + stepv;
+					}
+				}
+			} else {
+				u32 kx = toKey1(g, cur.x, depth), ky = toKey1(g, cur.y, depth), kz = toKey1(g, cur.z, depth);
+				u32 ex = toKey1(g, end.x, depth), ey = toKey1(g, end.y, depth), ez = toKey1(g, end.z, depth);
+				if (kx == ex && ky == ey && kz == ez) {
+					// OMB:1281-1284
+					if (!gridMark(gr, grid, (i32)(kx >> depth), (i32)(ky >> depth), (i32)(kz >> depth))) err |= ERR_GRID_OOB;
+					steps = 1;
+				} else {
+					// computeRayInit OCT:1204-1224
+					double node_size = nodeSize(g, depth), half = g.hs[depth];
+					double bx = toCoord1(g, kx, depth) - cur.x, by = toCoord1(g, ky, depth) - cur.y,
+					       bz = toCoord1(g, kz, depth) - cur.z;
+					i32 sx, sy, sz;
+					double tdx, tdy, tdz, tmx, tmy, tmz;
+#define UFO_AXIS_INIT(d, b, s, td, tm)                 \
+	if (0 < d) {                                        \
+		s = 1;                                          \
+		b += half;                                      \
+		td = node_size / fabs(d);                       \
+		tm = b / d;                                     \
+	} else if (0 > d) {                                 \
+		s = -1;                                         \
+		b -= half;                                      \
+		td = node_size / fabs(d);                       \
+		tm = b / d;                                     \
+	} else {                                            \
+		s = 0;                                          \
+		td = 1.7976931348623157e308;                    \
+		tm = 1.7976931348623157e308;                    \
+	}
+					UFO_AXIS_INIT(dir.x, bx, sx, tdx, tmx)
+					UFO_AXIS_INIT(dir.y, by, sy, tdy, tmy)
+					UFO_AXIS_INIT(dir.z, bz, sz, tdz, tmz)
+#undef UFO_AXIS_INIT
+					// cells: key >> depth (step is +-2^depth in key units = +-1 cell)
+					i32 cx = (i32)(kx >> depth), cy = (i32)(ky >> depth), cz = (i32)(kz >> depth);
+					const i32 gx = (i32)(ex >> depth), gy = (i32)(ey >> depth), gz = (i32)(ez >> depth);
+					bool go;
+					do {
+						if (++steps > budget) {
+							err |= ERR_RUNAWAY;
+							break;
+						}
+						if (!gridMark(gr, grid, cx, cy, cz)) err |= ERR_GRID_OOB;
+						// minElementIndex VEC3:244-251: x<=y ? (x<=z ? x : z) : (y<=z ? y : z)
+						if (tmx <= tmy) {
+							if (tmx <= tmz) {
+								cx += sx;
+								tmx += tdx;
+							} else {
+								cz += sz;
+								tmz += tdz;
+							}
+						} else {
+							if (tmy <= tmz) {
+								cy += sy;
+								tmy += tdy;
+							} else {
+								cz += sz;
+								tmz += tdz;
+							}
+						}
+						go = (cx != gx || cy != gy || cz != gz) && (fmin(fmin(tmx, tmy), tmz) <= dist);
+					} while (go);
+				}
+			}
+		}
+	}
+	// total step count (diagnostic; drives the algorithmic-bytes figure of bench.py)
+	for (int o = 32; o > 0; o >>= 1) steps += __shfl_xor((unsigned long long)steps, o);
+	if ((threadIdx.x & 63) == 0 && steps) atomicAdd(&ctl->n_steps, steps);
+	if (err) atomicOr(&ctl->err, err);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3 extract: non-zero bytes of the grids -> update list, one entry per touched node block.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_extract(MapGeom g, Grid gr, const u32* __restrict__ gridH,
+                                                 const u32* __restrict__ gridM, Entry* __restrict__ entries,
+                                                 u32 cap, ScanCtl* ctl)
+{
+	u64 nwords = gr.bytes >> 2;
+	for (u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x; w < nwords; w += (u64)gridDim.x * blockDim.x) {
+		u32 h = gridH ? gridH[w] : 0u;
+		u32 m = gridM ? gridM[w] : 0u;
+		if ((h | m) == 0) continue;
+		for (u32 b = 0; b < 4; ++b) {
+			u32 hb = (h >> (8 * b)) & 0xFF, mb = (m >> (8 * b)) & 0xFF;
+			if ((hb | mb) == 0) continue;
+			u64 idx = w * 4 + b;
+			u64 bx = idx % (u64)gr.nb[0];
+			u64 r = idx / (u64)gr.nb[0];
+			u64 by = r % (u64)gr.nb[1];
+			u64 bz = r / (u64)gr.nb[1];
+			// absolute block coordinate = (cell >> 1); cells are key >> depth (key includes the +M offset)
+			u32 ax = (u32)((gr.base[0] >> 1) + (i32)bx), ay = (u32)((gr.base[1] >> 1) + (i32)by),
+			    az = (u32)((gr.base[2] >> 1) + (i32)bz);
+			u32 level = gr.depth + 1;
+			u64 p = morton3(ax, ay, az) & ((1ULL << (3 * (g.L - level))) - 1ULL);
+			u32 pos = atomicAdd(&ctl->n_entries, 1u);
+			if (pos < cap) {
+				Entry e;
+				e.lk = (1ULL << (3 * (g.L - level))) | p;
+				e.hit = (u8)hb;
+				e.miss = (u8)mb;
+				e.level = (u8)level;
+				for (int k = 0; k < 5; ++k) e.pad[k] = 0;
+				entries[pos] = e;
+			}
+		}
+	}
+}
+
+// grid bits -> codes (shifted by 3*depth) for the stage-level parity exports
+__global__ __launch_bounds__(256) void k_grid_codes(MapGeom g, Grid gr, const u32* __restrict__ grid,
+                                                    u64* __restrict__ codes, u32 cap, ScanCtl* ctl)
+{
+	u64 nwords = gr.bytes >> 2;
+	for (u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x; w < nwords; w += (u64)gridDim.x * blockDim.x) {
+		u32 m = grid[w];
+		while (m) {
+			u32 bit = __ffs(m) - 1;
+			m &= m - 1;
+			u64 idx = w * 4 + (bit >> 3);
+			u32 c = bit & 7;
+			u64 bx = idx % (u64)gr.nb[0];
+			u64 r = idx / (u64)gr.nb[0];
+			u64 by = r % (u64)gr.nb[1];
+			u64 bz = r / (u64)gr.nb[1];
+			u32 x = (u32)(gr.base[0] + 2 * (i32)bx + (i32)(c & 1)), y = (u32)(gr.base[1] + 2 * (i32)by + (i32)((c >> 1) & 1)),
+			    z = (u32)(gr.base[2] + 2 * (i32)bz + (i32)((c >> 2) & 1));
+			// cell coordinate = key >> depth; Code(key) >> 3*depth == morton(cell) for keys < 2^21
+			u64 code = morton3(x, y, z);
+			u32 pos = atomicAdd(&ctl->n_codes, 1u);
+			if (pos < cap) codes[pos] = code;
+		}
+	}
+}
+}  // namespace ufo

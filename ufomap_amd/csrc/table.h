@@ -1,0 +1,113 @@
+// table.h -- the GPU-resident linear-hashed octree ("node table") and its device accessors.
+//
+// Replaces the reference's pointer octree (map/octree.h:957-1162: getNodePath/createNode/
+// createChildren/deleteChildren with new/delete of 8-child arrays). One table slot = one 8-child
+// node block, i.e. the `children` array of one inner node:
+//
+//   keys[s]    u64   location key of the inner node:  (1 << 3*(L-d)) | (code >> 3*d), d = node depth
+//                    (sentinel bit encodes the depth; root = 1; 0 = empty slot)
+//   occ[8*s+i] f32   log-odds of child i (child index = x | y<<1 | z<<2, map/code.h:245-248)
+//   rgb[8*s+i] u32   r | g<<8 | b<<16 of child i (colour maps only)
+//   flags[s]   u32   bits 0-7  contains_free of child i      (map/occupancy_map_node.h:171-176)
+//                    bits 8-15 contains_unknown of child i
+//                    bits 16-23 child i is an inner node with a live block of its own
+//                    bit 24 DIRTY (queued for propagation), 25 DEAD (collapsed: the node is a leaf
+//                    again, octree.h:1060-1066), 26 TRANSIENT (a child changed and changed back)
+//   parent[s]  u32   slot of the block that holds this node's own value (NONE for the root)
+//   stamp[s]   u32   id of the scan that created / revived the block ("new this scan")
+//
+// A node's own value lives in its parent's block; the root's value lives in MapRoot.
+// Open addressing, linear probing, power-of-two capacity; blocks are never removed (a collapsed
+// block is marked DEAD and revived by inheritance when a later update descends through it, which
+// is exactly what the reference does with pruning disabled, octree.h:1064).
+#pragma once
+#include "geom.h"
+
+namespace ufo
+{
+enum : u32 {
+	F_CFREE = 0x000000FFu,
+	F_CUNK = 0x0000FF00u,
+	F_INNER = 0x00FF0000u,
+	F_DIRTY = 1u << 24,
+	F_DEAD = 1u << 25,
+	F_TRANS = 1u << 26,
+	NONE = 0xFFFFFFFFu,
+};
+
+struct MapRoot {
+	float occ;
+	u32 flags;  // bit0 contains_free, bit1 contains_unknown
+	u32 rgb;
+	u32 used;  // number of occupied table slots
+};
+
+struct Table {
+	u64* keys;
+	float* occ;
+	u32* rgb;  // nullptr for non-colour maps
+	u32* flags;
+	u32* parent;
+	u32* stamp;
+	MapRoot* root;
+	u32 mask;  // capacity - 1
+};
+
+__device__ inline u32 hash64(u64 k)
+{
+	k ^= k >> 33;
+	k *= 0xff51afd7ed558ccdULL;
+	k ^= k >> 33;
+	k *= 0xc4ceb9fe1a85ec53ULL;
+	k ^= k >> 33;
+	return (u32)k;
+}
+
+// Lookup only. Returns NONE when absent (DEAD blocks are returned: callers check flags).
+__device__ inline u32 tableFind(const Table& t, u64 lk)
+{
+	u32 s = hash64(lk) & t.mask;
+	for (u32 probe = 0; probe <= t.mask; ++probe) {
+		u64 k = __hip_atomic_load(&t.keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (k == lk) return s;
+		if (k == 0) return NONE;
+		s = (s + 1) & t.mask;
+	}
+	return NONE;
+}
+
+// Find or insert/revive. *created = 1 when this thread created the block or revived a DEAD one.
+// Returns NONE when the table is full (caller raises the capacity error).
+__device__ inline u32 tableEnsure(const Table& t, u64 lk, u32 scan_id, u32 max_probe, bool* created)
+{
+	u32 s = hash64(lk) & t.mask;
+	*created = false;
+	for (u32 probe = 0; probe < max_probe; ++probe) {
+		u64 k = __hip_atomic_load(&t.keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (k == 0) {
+			u64 prev = atomicCAS((unsigned long long*)&t.keys[s], 0ULL, (unsigned long long)lk);
+			if (prev == 0) {
+				// empty slots have flags == 0 (table is zero-filled and never shrinks)
+				t.stamp[s] = scan_id;
+				atomicAdd(&t.root->used, 1u);
+				*created = true;
+				return s;
+			}
+			k = prev;
+		}
+		if (k == lk) {
+			u32 f = __hip_atomic_load(&t.flags[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (f & F_DEAD) {
+				u32 old = atomicAnd(&t.flags[s], ~F_DEAD);
+				if (old & F_DEAD) {
+					t.stamp[s] = scan_id;
+					*created = true;
+				}
+			}
+			return s;
+		}
+		s = (s + 1) & t.mask;
+	}
+	return NONE;
+}
+}  // namespace ufo

@@ -1,0 +1,1046 @@
+// ufomap_hip.hip -- C-ABI implementation (include/ufomap_hip.h) over the HIP kernels of
+// scan_kernels.h / map_kernels.h. gfx950 only; build: see ufomap_amd/build.py
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared
+//
+// Launch sequence of one integration (all on the map's own stream):
+//   k_classify -> k_select -> [host reads 1 control block: counts, bounding boxes]
+//   memset grids -> k_hitmark -> k_dda -> k_extract(count) -> [host reads counts, sizes the table]
+//   k_extract(fill) -> k_ensure -> k_init_new -> k_apply_leaf | k_apply_coarse -> k_propagate x (L - level)
+// There is no CPU fallback: every entry point fails with UFOMAP_ERR_DEVICE when HIP is unusable.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ufomap_hip.h"
+#include "map_kernels.h"
+
+using namespace ufo;
+
+namespace
+{
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg)
+{
+	g_err = msg;
+	return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+	do {                                                                                           \
+		hipError_t e__ = (expr);                                                                   \
+		if (e__ != hipSuccess) {                                                                   \
+			return fail(UFOMAP_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e__));    \
+		}                                                                                          \
+	} while (0)
+
+// grow-only device buffer
+struct DevBuf {
+	void* p = nullptr;
+	size_t cap = 0;
+	hipError_t reserve(size_t bytes)
+	{
+		if (bytes <= cap) return hipSuccess;
+		if (p) {
+			hipError_t e = hipFree(p);
+			if (e != hipSuccess) return e;
+			p = nullptr;
+			cap = 0;
+		}
+		size_t want = std::max(bytes, cap + cap / 2);
+		want = (want + 255) & ~(size_t)255;
+		hipError_t e = hipMalloc(&p, want);
+		if (e != hipSuccess) {
+			p = nullptr;
+			return e;
+		}
+		cap = want;
+		return hipSuccess;
+	}
+	void release()
+	{
+		if (p) (void)hipFree(p);
+		p = nullptr;
+		cap = 0;
+	}
+	template <class T>
+	T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct KernelStat {
+	const char* name;
+	uint64_t launches = 0;
+	double total_ms = 0;
+};
+
+struct PendingEvent {
+	hipEvent_t a, b;
+	int stat;
+};
+
+inline u32 nextPow2(u64 v)
+{
+	u64 p = 1;
+	while (p < v) p <<= 1;
+	return (u32)std::min<u64>(p, 1ull << 31);
+}
+}  // namespace
+
+struct ufomap_map {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	hipEvent_t done_ev = nullptr;
+	MapGeom g{};
+	// node table
+	Table t{};
+	DevBuf b_keys, b_occ, b_rgb, b_flags, b_parent, b_stamp, b_root;
+	u32 scan_id = 0;
+	u64 used_est = 0;  // host-side view of MapRoot::used (refreshed at every control-block read)
+	// per-scan buffers
+	DevBuf b_ctl, b_pt_end, b_pt_flag, b_pt_slot, b_ray_end, b_hit_code, b_hit_pt, b_hh_keys, b_hh_idx;
+	DevBuf b_gridH, b_gridM, b_entries, b_ent_slot, b_newlist, b_wl0, b_wl1, b_in_xyz, b_in_rgb, b_codes, b_dump;
+	ScanCtl* h_ctl = nullptr;  // pinned
+	MapRoot* h_root = nullptr;  // pinned
+	size_t scratch_limit = 16ull << 30;
+	// state of the last integration
+	bool pending = false;
+	int pending_status = UFOMAP_OK;
+	Grid gridH{}, gridM{};
+	bool haveH = false, haveM = false;
+	u32 last_depth = 0;
+	u32 hh_mask = 0;  // hit-hash mask of the current scan
+	uint64_t counts[8] = {0};
+	double min_change[3], max_change[3];
+	// profiling
+	bool profiling = false;
+	std::vector<KernelStat> stats;
+	std::vector<PendingEvent> pend_ev;
+	std::vector<hipEvent_t> ev_pool;
+};
+
+namespace
+{
+int statIndex(ufomap_map* m, const char* name)
+{
+	for (size_t i = 0; i < m->stats.size(); ++i)
+		if (m->stats[i].name == name || 0 == strcmp(m->stats[i].name, name)) return (int)i;
+	KernelStat s;
+	s.name = name;
+	m->stats.push_back(s);
+	return (int)m->stats.size() - 1;
+}
+
+hipEvent_t getEvent(ufomap_map* m)
+{
+	if (!m->ev_pool.empty()) {
+		hipEvent_t e = m->ev_pool.back();
+		m->ev_pool.pop_back();
+		return e;
+	}
+	hipEvent_t e = nullptr;
+	(void)hipEventCreate(&e);
+	return e;
+}
+
+struct ProfScope {
+	ufomap_map* m;
+	PendingEvent pe;
+	bool on;
+	ProfScope(ufomap_map* mm, const char* name) : m(mm), on(mm->profiling)
+	{
+		if (on) {
+			pe.a = getEvent(m);
+			pe.b = getEvent(m);
+			pe.stat = statIndex(m, name);
+			(void)hipEventRecord(pe.a, m->stream);
+		}
+	}
+	~ProfScope()
+	{
+		if (on) {
+			(void)hipEventRecord(pe.b, m->stream);
+			m->pend_ev.push_back(pe);
+		}
+	}
+};
+
+void drainEvents(ufomap_map* m)
+{
+	for (PendingEvent& pe : m->pend_ev) {
+		float ms = 0;
+		if (hipEventElapsedTime(&ms, pe.a, pe.b) == hipSuccess) {
+			m->stats[pe.stat].launches += 1;
+			m->stats[pe.stat].total_ms += ms;
+		}
+		m->ev_pool.push_back(pe.a);
+		m->ev_pool.push_back(pe.b);
+	}
+	m->pend_ev.clear();
+}
+
+inline dim3 gridFor(u64 n, u32 block = 256, u32 maxBlocks = 4096)
+{
+	u64 b = (n + block - 1) / block;
+	if (b < 1) b = 1;
+	if (b > maxBlocks) b = maxBlocks;
+	return dim3((u32)b);
+}
+
+int allocTable(ufomap_map* m, u32 cap, Table* out, DevBuf* keys, DevBuf* occ, DevBuf* rgb, DevBuf* flags, DevBuf* parent,
+               DevBuf* stamp)
+{
+	HIP_TRY(keys->reserve((size_t)cap * 8));
+	HIP_TRY(occ->reserve((size_t)cap * 32));
+	if (m->g.color) HIP_TRY(rgb->reserve((size_t)cap * 32));
+	HIP_TRY(flags->reserve((size_t)cap * 4));
+	HIP_TRY(parent->reserve((size_t)cap * 4));
+	HIP_TRY(stamp->reserve((size_t)cap * 4));
+	HIP_TRY(hipMemsetAsync(keys->p, 0, (size_t)cap * 8, m->stream));
+	HIP_TRY(hipMemsetAsync(flags->p, 0, (size_t)cap * 4, m->stream));
+	HIP_TRY(hipMemsetAsync(stamp->p, 0, (size_t)cap * 4, m->stream));
+	HIP_TRY(hipMemsetAsync(parent->p, 0xFF, (size_t)cap * 4, m->stream));
+	out->keys = keys->as<u64>();
+	out->occ = occ->as<float>();
+	out->rgb = m->g.color ? rgb->as<u32>() : nullptr;
+	out->flags = flags->as<u32>();
+	out->parent = parent->as<u32>();
+	out->stamp = stamp->as<u32>();
+	out->root = m->b_root.as<MapRoot>();
+	out->mask = cap - 1;
+	return UFOMAP_OK;
+}
+
+int growTable(ufomap_map* m, u32 new_cap)
+{
+	Table nt{};
+	DevBuf k, o, r, f, p, s;
+	int rc = allocTable(m, new_cap, &nt, &k, &o, &r, &f, &p, &s);
+	if (rc) return rc;
+	u32* d_fail = m->b_ctl.as<u32>() + (sizeof(ScanCtl) + 3) / 4;  // spare word after the control block
+	HIP_TRY(hipMemsetAsync(d_fail, 0, 4, m->stream));
+	{
+		ProfScope ps(m, "k_rehash_copy");
+		hipLaunchKernelGGL(k_rehash_copy, gridFor((u64)m->t.mask + 1), dim3(256), 0, m->stream, m->t, nt, d_fail);
+	}
+	{
+		ProfScope ps(m, "k_rehash_parents");
+		hipLaunchKernelGGL(k_rehash_parents, gridFor((u64)new_cap), dim3(256), 0, m->stream, nt);
+	}
+	HIP_TRY(hipStreamSynchronize(m->stream));
+	m->b_keys.release();
+	m->b_occ.release();
+	m->b_rgb.release();
+	m->b_flags.release();
+	m->b_parent.release();
+	m->b_stamp.release();
+	m->b_keys = k;
+	m->b_occ = o;
+	m->b_rgb = r;
+	m->b_flags = f;
+	m->b_parent = p;
+	m->b_stamp = s;
+	m->t = nt;
+	return UFOMAP_OK;
+}
+
+int resetRoot(ufomap_map* m)
+{
+	// a fresh map's root is one unknown leaf (occupancy_map_base.h:871)
+	m->h_root->occ = 0.0f;
+	m->h_root->flags = (isFreeV(m->g, 0.0f) ? 1u : 0u) | (isUnknownV(m->g, 0.0f) ? 2u : 0u);
+	m->h_root->rgb = 0;
+	m->h_root->used = 0;
+	HIP_TRY(hipMemcpyAsync(m->b_root.p, m->h_root, sizeof(MapRoot), hipMemcpyHostToDevice, m->stream));
+	HIP_TRY(hipStreamSynchronize(m->stream));
+	m->used_est = 0;
+	return UFOMAP_OK;
+}
+
+void setSensorModel(MapGeom& g, double occupied_thres, double free_thres, double prob_hit, double prob_miss, double cmin,
+                    double cmax)
+{
+	auto logit = [](double p) { return std::log(p / (1.0 - p)); };  // occupancy_map_base.h:909
+	g.occ_thr = logit(occupied_thres);
+	g.free_thr = logit(free_thres);
+	g.hit = (float)logit(prob_hit);
+	g.miss_log = logit(prob_miss);
+	g.cmin = (float)logit(cmin);
+	g.cmax = (float)logit(cmax);
+	// toProb(update) with LogitType=float: std::exp(float) (occupancy_map_base.h:911)
+	g.prob_hit_f = 1.0 / (1.0 + std::exp(-g.hit));
+}
+
+// upper bound on the node blocks a list of n entries at `level` inside a grid of nb[] blocks can
+// need: per level, no more distinct ancestors than entries, nor than fit in the bounding box.
+u64 blockBound(const ufomap_map* m, u64 n, const i32 nb[3], u32 level)
+{
+	u64 total = 0;
+	for (u32 l = level; l <= m->g.L; ++l) {
+		u32 sh = l - level;
+		long double vol = 1;
+		for (int a = 0; a < 3; ++a) vol *= (long double)(((u64)nb[a] >> std::min(sh, 62u)) + 2);
+		u64 lim = vol > 1e18L ? (u64)1e18 : (u64)vol;
+		total += std::min<u64>(n, lim);
+	}
+	return total + 8;
+}
+
+int readCtl(ufomap_map* m)
+{
+	HIP_TRY(hipMemcpyAsync(m->h_ctl, m->b_ctl.p, sizeof(ScanCtl), hipMemcpyDeviceToHost, m->stream));
+	HIP_TRY(hipMemcpyAsync(m->h_root, m->b_root.p, sizeof(MapRoot), hipMemcpyDeviceToHost, m->stream));
+	HIP_TRY(hipStreamSynchronize(m->stream));
+	m->used_est = m->h_root->used;
+	return UFOMAP_OK;
+}
+
+int ctlError(ufomap_map* m)
+{
+	u32 e = m->h_ctl->err;
+	if (!e) return UFOMAP_OK;
+	if (e & ERR_RUNAWAY)
+		return fail(UFOMAP_ERR_RUNAWAY,
+		            "a clipped ray left the map cube (end point outside after moveLineInside); the reference walks ~2^31 "
+		            "cells on this input. Map unchanged.");
+	if (e & ERR_TABLE_FULL) return fail(UFOMAP_ERR_CAPACITY, "node table full (internal bound violated)");
+	if (e & ERR_GRID_OOB) return fail(UFOMAP_ERR_CAPACITY, "a ray cell fell outside the scan grid (internal bound violated)");
+	return fail(UFOMAP_ERR_CAPACITY, "hit hash full (internal bound violated)");
+}
+
+int makeGrid(const i32 mn[3], const i32 mx[3], u32 depth, Grid* gr)
+{
+	u64 bytes = 1;
+	for (int a = 0; a < 3; ++a) {
+		long long lo = ((long long)mn[a] - 2) & ~1LL;  // pad by one block, keep the base even
+		long long hi = (long long)mx[a] + 2;
+		long long nb = (hi - lo) / 2 + 1;
+		if (nb <= 0 || nb > (1LL << 30)) return UFOMAP_ERR_CAPACITY;
+		gr->base[a] = (i32)lo;
+		gr->nb[a] = (i32)nb;
+		if (bytes > (1ull << 62) / (u64)nb) return UFOMAP_ERR_CAPACITY;
+		bytes *= (u64)nb;
+	}
+	gr->depth = depth;
+	gr->pad = 0;
+	gr->bytes = (bytes + 7) & ~7ull;
+	return UFOMAP_OK;
+}
+
+// One phase of the map update: entries of one level -> ensure, init, apply, propagate.
+int applyEntries(ufomap_map* m, const Entry* d_entries, u32 n_entries, u32 level, const i32 nb[3], float miss,
+                 const uint8_t* d_rgb)
+{
+	if (0 == n_entries) return UFOMAP_OK;
+	// size the table for the worst case of this phase (true upper bound, see blockBound)
+	u64 need = m->used_est + blockBound(m, n_entries, nb, level);
+	u64 cap = (u64)m->t.mask + 1;
+	if (need * 5 > cap * 3) {  // keep the load factor <= 0.6
+		u64 want = need * 2;
+		if (want > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
+		int rc = growTable(m, nextPow2(want));
+		if (rc) return rc;
+	}
+	u64 newcap = blockBound(m, n_entries, nb, level);
+	HIP_TRY(m->b_ent_slot.reserve((size_t)n_entries * 4));
+	HIP_TRY(m->b_newlist.reserve((size_t)newcap * 4));
+	HIP_TRY(m->b_wl0.reserve(((size_t)n_entries + 8) * 4));
+	HIP_TRY(m->b_wl1.reserve(((size_t)n_entries + 8) * 4));
+	ScanCtl* ctl = m->b_ctl.as<ScanCtl>();
+	const u32* d_n = &ctl->n_entries;
+	HIP_TRY(hipMemsetAsync(&ctl->n_new, 0, 4, m->stream));
+	HIP_TRY(hipMemsetAsync(&ctl->wl_count[0], 0, 8, m->stream));
+	HitHash hh{m->b_hh_keys.as<u64>(), m->b_hh_idx.as<u32>(), m->hh_mask};
+	dim3 ge = gridFor(n_entries);
+	{
+		ProfScope ps(m, "k_ensure");
+		hipLaunchKernelGGL(k_ensure, ge, dim3(256), 0, m->stream, m->t, m->g, d_entries, d_n, m->scan_id, m->b_ent_slot.as<u32>(),
+		                   m->b_newlist.as<u32>(), (u32)std::min<u64>(newcap, 0xFFFFFFFFull), ctl);
+	}
+	{
+		ProfScope ps(m, "k_init_new");
+		hipLaunchKernelGGL(k_init_new, ge, dim3(256), 0, m->stream, m->t, m->g, m->b_newlist.as<u32>(),
+		                   (u32)std::min<u64>(newcap, 0xFFFFFFFFull), m->scan_id, ctl);
+	}
+	if (1 == level) {
+		ProfScope ps(m, "k_apply_leaf");
+		hipLaunchKernelGGL(k_apply_leaf, ge, dim3(256), 0, m->stream, m->t, m->g, d_entries, d_n, m->b_ent_slot.as<u32>(), miss, hh,
+		                   d_rgb, m->b_wl0.as<u32>(), ctl);
+	} else {
+		ProfScope ps(m, "k_apply_coarse");
+		hipLaunchKernelGGL(k_apply_coarse, ge, dim3(256), 0, m->stream, m->t, m->g, d_entries, d_n, m->b_ent_slot.as<u32>(), miss,
+		                   m->b_wl0.as<u32>(), ctl);
+	}
+	// updateParents, one launch per level (OMB:1126-1133)
+	u32 idx = 0;
+	for (u32 l = level + 1; l <= m->g.L; ++l) {
+		ProfScope ps(m, "k_propagate");
+		u32* in = idx ? m->b_wl1.as<u32>() : m->b_wl0.as<u32>();
+		u32* out = idx ? m->b_wl0.as<u32>() : m->b_wl1.as<u32>();
+		hipLaunchKernelGGL(k_reset_wl, dim3(1), dim3(1), 0, m->stream, ctl, idx ^ 1);
+		u64 est = std::max<u64>(1, (u64)n_entries >> (3 * std::min<u32>(l - level - 1, 10)));
+		hipLaunchKernelGGL(k_propagate, gridFor(std::max<u64>(est, 256), 256, 1024), dim3(256), 0, m->stream, m->t, m->g, in, out,
+		                   idx, ctl);
+		idx ^= 1;
+	}
+	HIP_TRY(hipGetLastError());
+	return UFOMAP_OK;
+}
+
+int finishPending(ufomap_map* m)
+{
+	if (!m->pending) return UFOMAP_OK;
+	m->pending = false;
+	int rc = readCtl(m);
+	if (rc) return rc;
+	drainEvents(m);
+	rc = ctlError(m);
+	if (rc) return rc;
+	m->counts[2] = m->h_ctl->n_steps;
+	m->counts[6] = m->h_ctl->n_new;
+	for (int a = 0; a < 3; ++a) {
+		double lo = decD(m->h_ctl->aabb_min[a]), hi = decD(m->h_ctl->aabb_max[a]);
+		if (m->h_ctl->aabb_min[a] != ~0ull) {
+			m->min_change[a] = std::min(m->min_change[a], lo);
+			m->max_change[a] = std::max(m->max_change[a], hi);
+		}
+	}
+	return UFOMAP_OK;
+}
+
+int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const uint8_t* d_rgb, size_t n, double max_range,
+             unsigned depth, int discrete, int simple, unsigned early_stopping, int async)
+{
+	if (!m) return fail(UFOMAP_ERR_INVALID, "null map");
+	HIP_TRY(hipSetDevice(m->device));
+	// join the previous integration first (occupancy_map_base.h:315)
+	int prc = UFOMAP_OK;
+	if (m->pending) {
+		HIP_TRY(hipStreamSynchronize(m->stream));
+		prc = finishPending(m);
+	}
+	(void)prc;
+	if (early_stopping != 0)
+		return fail(UFOMAP_ERR_UNSUPPORTED, "early_stopping > 0 depends on ray order (occupancy_map_base.h:1289-1298); not supported");
+	if (depth >= m->g.L) return fail(UFOMAP_ERR_INVALID, "depth must be < depth_levels");
+	if (d_rgb && !m->g.color) return fail(UFOMAP_ERR_INVALID, "coloured cloud into a non-colour map");
+	if (d_rgb && !discrete)
+		return fail(UFOMAP_ERR_UNSUPPORTED,
+		            "OccupancyMapColor::insertPointCloud<PointCloudColor> does not compile in the reference (SURVEY.md 4)");
+	if (n > 0x7FFFFFFFull) return fail(UFOMAP_ERR_INVALID, "more than 2^31 points");
+	for (int k = 0; k < 8; ++k) m->counts[k] = 0;
+	m->haveH = m->haveM = false;
+	m->last_depth = depth;
+	m->counts[0] = n;
+	if (0 == n) return UFOMAP_OK;
+	m->scan_id += 1;
+	const u32 N = (u32)n;
+	const D3 sensor{origin[0], origin[1], origin[2]};
+
+	// ---- scan phase ----------------------------------------------------------------------------
+	HIP_TRY(m->b_pt_end.reserve(n * sizeof(D3)));
+	HIP_TRY(m->b_pt_flag.reserve(n));
+	HIP_TRY(m->b_pt_slot.reserve(n * 4));
+	HIP_TRY(m->b_ray_end.reserve(n * sizeof(D3)));
+	HIP_TRY(m->b_hit_code.reserve(n * 8));
+	HIP_TRY(m->b_hit_pt.reserve(n * 4));
+	u32 hcap = nextPow2(std::max<u64>(1024, (u64)n * 4));
+	HIP_TRY(m->b_hh_keys.reserve((size_t)hcap * 8));
+	HIP_TRY(m->b_hh_idx.reserve((size_t)hcap * 4));
+	HIP_TRY(hipMemsetAsync(m->b_hh_keys.p, 0xFF, (size_t)hcap * 8, m->stream));
+	HIP_TRY(hipMemsetAsync(m->b_hh_idx.p, 0xFF, (size_t)hcap * 4, m->stream));
+	HitHash hh{m->b_hh_keys.as<u64>(), m->b_hh_idx.as<u32>(), hcap - 1};
+	m->hh_mask = hcap - 1;
+	// control block
+	ScanCtl init;
+	memset(&init, 0, sizeof(init));
+	for (int a = 0; a < 3; ++a) {
+		init.mb_min[a] = init.hb_min[a] = INT32_MAX;
+		init.mb_max[a] = init.hb_max[a] = INT32_MIN;
+		init.aabb_min[a] = ~0ull;
+		init.aabb_max[a] = 0ull;
+	}
+	*m->h_ctl = init;
+	ScanCtl* ctl = m->b_ctl.as<ScanCtl>();
+	HIP_TRY(hipMemcpyAsync(ctl, m->h_ctl, sizeof(ScanCtl), hipMemcpyHostToDevice, m->stream));
+	dim3 gp((N + 255) / 256);
+	{
+		ProfScope ps(m, "k_classify");
+		if (discrete)
+			hipLaunchKernelGGL(k_classify<true>, gp, dim3(256), 0, m->stream, m->g, sensor, d_xyz, N, max_range, (u32)depth,
+			                   (u32)(d_rgb ? 1 : 0), hh, m->b_pt_end.as<D3>(), m->b_pt_flag.as<u8>(), m->b_pt_slot.as<u32>(), ctl);
+		else
+			hipLaunchKernelGGL(k_classify<false>, gp, dim3(256), 0, m->stream, m->g, sensor, d_xyz, N, max_range, (u32)depth, 0u, hh,
+			                   m->b_pt_end.as<D3>(), m->b_pt_flag.as<u8>(), m->b_pt_slot.as<u32>(), ctl);
+	}
+	{
+		ProfScope ps(m, "k_select");
+		if (discrete)
+			hipLaunchKernelGGL(k_select<true>, gp, dim3(256), 0, m->stream, m->g, sensor, N, (u32)depth, hh, m->b_pt_end.as<D3>(),
+			                   m->b_pt_flag.as<u8>(), m->b_pt_slot.as<u32>(), m->b_ray_end.as<D3>(), m->b_hit_code.as<u64>(),
+			                   m->b_hit_pt.as<u32>(), ctl);
+		else
+			hipLaunchKernelGGL(k_select<false>, gp, dim3(256), 0, m->stream, m->g, sensor, N, (u32)depth, hh, m->b_pt_end.as<D3>(),
+			                   m->b_pt_flag.as<u8>(), m->b_pt_slot.as<u32>(), m->b_ray_end.as<D3>(), m->b_hit_code.as<u64>(),
+			                   m->b_hit_pt.as<u32>(), ctl);
+	}
+	HIP_TRY(hipGetLastError());
+	int rc = readCtl(m);
+	if (rc) return rc;
+	rc = ctlError(m);
+	if (rc) return rc;
+	const u32 n_rays = m->h_ctl->n_rays, n_hits = m->h_ctl->n_hits;
+	m->counts[1] = n_rays;
+	m->counts[3] = n_hits;
+	// the scan's change AABB is final after k_select: keep a copy (finishPending merges it)
+	ScanCtl after_select = *m->h_ctl;
+
+	// ---- dedup grids -----------------------------------------------------------------------------
+	i32 hmn[3], hmx[3], mmn[3], mmx[3];
+	for (int a = 0; a < 3; ++a) {
+		hmn[a] = m->h_ctl->hb_min[a];
+		hmx[a] = m->h_ctl->hb_max[a];
+		mmn[a] = m->h_ctl->mb_min[a];
+		mmx[a] = m->h_ctl->mb_max[a];
+	}
+	m->haveH = n_hits > 0;
+	m->haveM = n_rays > 0;
+	if (0 == depth && m->haveH && m->haveM) {
+		for (int a = 0; a < 3; ++a) {
+			hmn[a] = mmn[a] = std::min(hmn[a], mmn[a]);
+			hmx[a] = mmx[a] = std::max(hmx[a], mmx[a]);
+		}
+	}
+	if (m->haveH && makeGrid(hmn, hmx, 0, &m->gridH))
+		return fail(UFOMAP_ERR_CAPACITY, "hit bounding box too large for the scan grid");
+	if (m->haveM && makeGrid(mmn, mmx, (u32)depth, &m->gridM))
+		return fail(UFOMAP_ERR_CAPACITY, "ray bounding box too large for the scan grid (runaway ray?)");
+	u64 gbytes = (m->haveH ? m->gridH.bytes : 0) + (m->haveM ? m->gridM.bytes : 0);
+	if (gbytes > m->scratch_limit)
+		return fail(UFOMAP_ERR_CAPACITY, "scan dedup grids need " + std::to_string(gbytes) + " bytes > scratch limit " +
+		                                     std::to_string(m->scratch_limit) + " (ufomap_map_set_scratch_limit)");
+	if (m->haveH) {
+		HIP_TRY(m->b_gridH.reserve(m->gridH.bytes));
+		HIP_TRY(hipMemsetAsync(m->b_gridH.p, 0, m->gridH.bytes, m->stream));
+		ProfScope ps(m, "k_hitmark");
+		hipLaunchKernelGGL(k_hitmark, gridFor(n_hits), dim3(256), 0, m->stream, m->gridH, m->b_gridH.as<u32>(), m->b_hit_code.as<u64>(),
+		                   ctl, ctl);
+	}
+	if (m->haveM) {
+		HIP_TRY(m->b_gridM.reserve(m->gridM.bytes));
+		HIP_TRY(hipMemsetAsync(m->b_gridM.p, 0, m->gridM.bytes, m->stream));
+		ProfScope ps(m, "k_dda");
+		dim3 gr((n_rays + 255) / 256);
+		if (simple)
+			hipLaunchKernelGGL(k_dda<true>, gr, dim3(256), 0, m->stream, m->g, sensor, (u32)depth, m->gridM, m->b_gridM.as<u32>(),
+			                   m->b_ray_end.as<D3>(), ctl, ctl);
+		else
+			hipLaunchKernelGGL(k_dda<false>, gr, dim3(256), 0, m->stream, m->g, sensor, (u32)depth, m->gridM, m->b_gridM.as<u32>(),
+			                   m->b_ray_end.as<D3>(), ctl, ctl);
+	}
+
+	// ---- map phase(s) ----------------------------------------------------------------------------
+	const float miss = (float)(m->g.miss_log / double((2.0 * depth) + 1));  // OMB:311
+	struct Phase {
+		const u32* H;
+		const u32* M;
+		Grid gr;
+		u32 level;
+	};
+	std::vector<Phase> phases;
+	if (0 == depth) {
+		if (m->haveH || m->haveM)
+			phases.push_back(Phase{m->haveH ? m->b_gridH.as<u32>() : nullptr, m->haveM ? m->b_gridM.as<u32>() : nullptr,
+			                       m->haveM ? m->gridM : m->gridH, 1});
+	} else {
+		if (m->haveH) phases.push_back(Phase{m->b_gridH.as<u32>(), nullptr, m->gridH, 1});
+		if (m->haveM) phases.push_back(Phase{nullptr, m->b_gridM.as<u32>(), m->gridM, (u32)depth + 1});
+	}
+	bool first = true;
+	for (Phase& ph : phases) {
+		// pass 1: count the touched node blocks; pass 2: emit them
+		HIP_TRY(hipMemsetAsync(&ctl->n_entries, 0, 4, m->stream));
+		{
+			ProfScope ps(m, "k_extract_count");
+			hipLaunchKernelGGL(k_extract, gridFor(ph.gr.bytes >> 2, 256, 8192), dim3(256), 0, m->stream, m->g, ph.gr, ph.H, ph.M,
+			                   (Entry*)nullptr, 0u, ctl);
+		}
+		rc = readCtl(m);
+		if (rc) return rc;
+		if (first) {
+			// all rays have been walked: a runaway ray aborts BEFORE the map is touched
+			rc = ctlError(m);
+			if (rc) return rc;
+			first = false;
+		}
+		u32 n_entries = m->h_ctl->n_entries;
+		if (ph.M) m->counts[4] = 0;  // filled by last_misses on demand
+		m->counts[5] += n_entries;
+		if (0 == n_entries) continue;
+		HIP_TRY(m->b_entries.reserve((size_t)n_entries * sizeof(Entry)));
+		HIP_TRY(hipMemsetAsync(&ctl->n_entries, 0, 4, m->stream));
+		{
+			ProfScope ps(m, "k_extract");
+			hipLaunchKernelGGL(k_extract, gridFor(ph.gr.bytes >> 2, 256, 8192), dim3(256), 0, m->stream, m->g, ph.gr, ph.H, ph.M,
+			                   m->b_entries.as<Entry>(), n_entries, ctl);
+		}
+		rc = applyEntries(m, m->b_entries.as<Entry>(), n_entries, ph.level, ph.gr.nb, miss, d_rgb);
+		if (rc) return rc;
+	}
+	(void)after_select;
+	HIP_TRY(hipGetLastError());
+	m->pending = true;
+	if (!async) {
+		HIP_TRY(hipStreamSynchronize(m->stream));
+		return finishPending(m);
+	}
+	HIP_TRY(hipEventRecord(m->done_ev, m->stream));
+	return UFOMAP_OK;
+}
+}  // namespace
+
+extern "C" {
+
+const char* ufomap_last_error(void) { return g_err.c_str(); }
+
+int ufomap_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n;
+}
+
+const char* ufomap_version(void) { return "ufomap_amd 0.1 (gfx950)"; }
+
+ufomap_map* ufomap_map_create(double resolution, unsigned depth_levels, int automatic_pruning, double occupied_thres,
+                              double free_thres, double prob_hit, double prob_miss, double clamping_thres_min,
+                              double clamping_thres_max, int has_color, int device)
+{
+	if (depth_levels < 2 || depth_levels > 21) {  // octree.h:931-935
+		fail(UFOMAP_ERR_INVALID, "depth_levels has to be [2, 21]");
+		return nullptr;
+	}
+	if (!(resolution > 0)) {
+		fail(UFOMAP_ERR_INVALID, "resolution must be positive");
+		return nullptr;
+	}
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+		fail(UFOMAP_ERR_DEVICE, "no HIP device available (this library has no CPU fallback)");
+		return nullptr;
+	}
+	if (device < 0 || device >= ndev) {
+		fail(UFOMAP_ERR_INVALID, "device ordinal out of range");
+		return nullptr;
+	}
+	if (hipSetDevice(device) != hipSuccess) {
+		fail(UFOMAP_ERR_DEVICE, "hipSetDevice failed");
+		return nullptr;
+	}
+	ufomap_map* m = new ufomap_map;
+	m->device = device;
+	MapGeom& g = m->g;
+	g.res = resolution;
+	g.rf = 1.0 / resolution;
+	g.L = depth_levels;
+	g.M = (u32)std::pow(2, depth_levels - 1);
+	g.hs[0] = resolution / 2.0;
+	g.hs[1] = resolution;
+	for (unsigned i = 2; i < 23; ++i) g.hs[i] = g.hs[i - 1] * 2.0;
+	g.color = has_color ? 1 : 0;
+	g.pruning = automatic_pruning ? 1 : 0;
+	setSensorModel(g, occupied_thres, free_thres, prob_hit, prob_miss, clamping_thres_min, clamping_thres_max);
+	bool ok = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) == hipSuccess &&
+	          hipEventCreateWithFlags(&m->done_ev, hipEventDisableTiming) == hipSuccess &&
+	          hipHostMalloc((void**)&m->h_ctl, sizeof(ScanCtl) + 64) == hipSuccess &&
+	          hipHostMalloc((void**)&m->h_root, sizeof(MapRoot)) == hipSuccess &&
+	          m->b_ctl.reserve(sizeof(ScanCtl) + 64) == hipSuccess && m->b_root.reserve(sizeof(MapRoot)) == hipSuccess;
+	if (!ok) {
+		fail(UFOMAP_ERR_DEVICE, "HIP resource creation failed");
+		ufomap_map_destroy(m);
+		return nullptr;
+	}
+	if (allocTable(m, 1u << 16, &m->t, &m->b_keys, &m->b_occ, &m->b_rgb, &m->b_flags, &m->b_parent, &m->b_stamp) ||
+	    resetRoot(m)) {
+		ufomap_map_destroy(m);
+		return nullptr;
+	}
+	for (int a = 0; a < 3; ++a) {
+		m->min_change[a] = g.hs[g.L];  // resetMinMaxChangeDetection (occupancy_map_base.h:806-810)
+		m->max_change[a] = -g.hs[g.L];
+	}
+	return m;
+}
+
+void ufomap_map_destroy(ufomap_map* m)
+{
+	if (!m) return;
+	(void)hipSetDevice(m->device);
+	if (m->stream) (void)hipStreamSynchronize(m->stream);
+	DevBuf* bufs[] = {&m->b_keys,    &m->b_occ,     &m->b_rgb,      &m->b_flags,   &m->b_parent,  &m->b_stamp,   &m->b_root,
+	                  &m->b_ctl,     &m->b_pt_end,  &m->b_pt_flag,  &m->b_pt_slot, &m->b_ray_end, &m->b_hit_code, &m->b_hit_pt,
+	                  &m->b_hh_keys, &m->b_hh_idx,  &m->b_gridH,    &m->b_gridM,   &m->b_entries, &m->b_ent_slot, &m->b_newlist,
+	                  &m->b_wl0,     &m->b_wl1,     &m->b_in_xyz,   &m->b_in_rgb,  &m->b_codes,   &m->b_dump};
+	for (DevBuf* b : bufs) b->release();
+	for (PendingEvent& pe : m->pend_ev) {
+		(void)hipEventDestroy(pe.a);
+		(void)hipEventDestroy(pe.b);
+	}
+	for (hipEvent_t e : m->ev_pool) (void)hipEventDestroy(e);
+	if (m->h_ctl) (void)hipHostFree(m->h_ctl);
+	if (m->h_root) (void)hipHostFree(m->h_root);
+	if (m->done_ev) (void)hipEventDestroy(m->done_ev);
+	if (m->stream) (void)hipStreamDestroy(m->stream);
+	delete m;
+}
+
+int ufomap_map_clear(ufomap_map* m)
+{
+	if (!m) return fail(UFOMAP_ERR_INVALID, "null map");
+	HIP_TRY(hipSetDevice(m->device));
+	HIP_TRY(hipStreamSynchronize(m->stream));
+	(void)finishPending(m);
+	u32 cap = m->t.mask + 1;
+	HIP_TRY(hipMemsetAsync(m->t.keys, 0, (size_t)cap * 8, m->stream));
+	HIP_TRY(hipMemsetAsync(m->t.flags, 0, (size_t)cap * 4, m->stream));
+	HIP_TRY(hipMemsetAsync(m->t.stamp, 0, (size_t)cap * 4, m->stream));
+	return resetRoot(m);
+}
+
+int ufomap_map_reserve(ufomap_map* m, size_t n_blocks)
+{
+	if (!m) return fail(UFOMAP_ERR_INVALID, "null map");
+	HIP_TRY(hipSetDevice(m->device));
+	HIP_TRY(hipStreamSynchronize(m->stream));
+	(void)finishPending(m);
+	u64 want = (u64)n_blocks * 2;
+	if (want > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
+	if (want <= (u64)m->t.mask + 1) return UFOMAP_OK;
+	return growTable(m, nextPow2(want));
+}
+
+int ufomap_map_set_scratch_limit(ufomap_map* m, size_t bytes)
+{
+	if (!m) return fail(UFOMAP_ERR_INVALID, "null map");
+	m->scratch_limit = bytes;
+	return UFOMAP_OK;
+}
+
+int ufomap_map_set_sensor_model(ufomap_map* m, double occupied_thres, double free_thres, double prob_hit, double prob_miss,
+                                double clamping_thres_min, double clamping_thres_max)
+{
+	if (!m) return fail(UFOMAP_ERR_INVALID, "null map");
+	int rc = ufomap_map_wait(m);
+	setSensorModel(m->g, occupied_thres, free_thres, prob_hit, prob_miss, clamping_thres_min, clamping_thres_max);
+	return rc;
+}
+
+int ufomap_map_insert_device(ufomap_map* m, const double sensor_origin[3], const double* d_xyz, const uint8_t* d_rgb, size_t n,
+                             double max_range, unsigned depth, int discrete, int simple_ray_casting, unsigned early_stopping,
+                             int async)
+{
+	return doInsert(m, sensor_origin, d_xyz, d_rgb, n, max_range, depth, discrete, simple_ray_casting, early_stopping, async);
+}
+
+int ufomap_map_insert(ufomap_map* m, const double sensor_origin[3], const double* xyz, const uint8_t* rgb, size_t n,
+                      double max_range, unsigned depth, int discrete, int simple_ray_casting, unsigned early_stopping, int async)
+{
+	if (!m) return fail(UFOMAP_ERR_INVALID, "null map");
+	HIP_TRY(hipSetDevice(m->device));
+	if (m->pending) {
+		HIP_TRY(hipStreamSynchronize(m->stream));
+		(void)finishPending(m);
+	}
+	const double* d_xyz = nullptr;
+	const uint8_t* d_rgb = nullptr;
+	if (n) {
+		// the caller's cloud is never referenced after this call returns (SURVEY.md 8b ownership)
+		HIP_TRY(m->b_in_xyz.reserve(n * 24));
+		HIP_TRY(hipMemcpyAsync(m->b_in_xyz.p, xyz, n * 24, hipMemcpyHostToDevice, m->stream));
+		d_xyz = m->b_in_xyz.as<double>();
+		if (rgb) {
+			HIP_TRY(m->b_in_rgb.reserve(n * 3));
+			HIP_TRY(hipMemcpyAsync(m->b_in_rgb.p, rgb, n * 3, hipMemcpyHostToDevice, m->stream));
+			d_rgb = m->b_in_rgb.as<uint8_t>();
+		}
+		HIP_TRY(hipStreamSynchronize(m->stream));  // pageable source: make the copy complete before returning
+	}
+	return doInsert(m, sensor_origin, d_xyz, d_rgb, n, max_range, depth, discrete, simple_ray_casting, early_stopping, async);
+}
+
+int ufomap_map_wait(ufomap_map* m)
+{
+	if (!m) return fail(UFOMAP_ERR_INVALID, "null map");
+	HIP_TRY(hipSetDevice(m->device));
+	HIP_TRY(hipStreamSynchronize(m->stream));
+	return finishPending(m);
+}
+
+int ufomap_map_done(ufomap_map* m)
+{
+	if (!m) return fail(UFOMAP_ERR_INVALID, "null map");
+	if (!m->pending) return 1;
+	hipError_t e = hipEventQuery(m->done_ev);
+	if (e == hipSuccess) return 1;
+	if (e == hipErrorNotReady) return 0;
+	return fail(UFOMAP_ERR_DEVICE, hipGetErrorString(e));
+}
+
+static bool recLess(const uint64_t* codes, const uint8_t* depths, size_t a, size_t b)
+{
+	return depths[a] != depths[b] ? depths[a] < depths[b] : codes[a] < codes[b];
+}
+
+static size_t exportCommon(ufomap_map* m, bool inner, int include_unknown, uint64_t* codes, uint8_t* depths, float* logodds,
+                           uint8_t* flags, uint8_t* rgb, size_t cap)
+{
+	if (!m) {
+		fail(UFOMAP_ERR_INVALID, "null map");
+		return (size_t)-1;
+	}
+	if (ufomap_map_wait(m) < 0) return (size_t)-1;
+	auto bad = [&](hipError_t e) {
+		if (e != hipSuccess) {
+			fail(UFOMAP_ERR_DEVICE, hipGetErrorString(e));
+			return true;
+		}
+		return false;
+	};
+	// pass 1: count; pass 2: dump everything; host sorts into canonical order
+	DevBuf dcbuf;
+	if (bad(dcbuf.reserve(sizeof(DumpCtl)))) return (size_t)-1;
+	DumpCtl* d_dc = dcbuf.as<DumpCtl>();
+	DumpCtl h{};
+	unsigned long long n_live = 0;
+	size_t total = 0;
+	std::vector<uint64_t> hc;
+	std::vector<uint8_t> hd, hf;
+	std::vector<float> ho;
+	std::vector<u32> hr;
+	for (int pass = 0; pass < 2; ++pass) {
+		unsigned long long dcap = pass ? total : 0;
+		if (pass && 0 == total) break;
+		DevBuf bc, bd, bo, bf, br;
+		if (pass) {
+			if (bad(bc.reserve(dcap * 8)) || bad(bd.reserve(dcap)) || bad(bo.reserve(dcap * 4)) || bad(bf.reserve(dcap)) ||
+			    bad(br.reserve(dcap * 4)))
+				return (size_t)-1;
+		}
+		if (bad(hipMemsetAsync(d_dc, 0, sizeof(DumpCtl), m->stream))) return (size_t)-1;
+		if (inner)
+			hipLaunchKernelGGL(k_export_inner, gridFor((u64)m->t.mask + 1), dim3(256), 0, m->stream, m->t, m->g, bc.as<u64>(),
+			                   bd.as<uint8_t>(), bo.as<float>(), bf.as<uint8_t>(), br.as<u32>(), dcap, d_dc);
+		else
+			hipLaunchKernelGGL(k_export_leaves, gridFor((u64)m->t.mask + 1), dim3(256), 0, m->stream, m->t, m->g, include_unknown,
+			                   bc.as<u64>(), bd.as<uint8_t>(), bo.as<float>(), br.as<u32>(), dcap, d_dc);
+		if (bad(hipMemcpyAsync(&h, d_dc, sizeof(DumpCtl), hipMemcpyDeviceToHost, m->stream))) return (size_t)-1;
+		if (bad(hipStreamSynchronize(m->stream))) return (size_t)-1;
+		if (!pass) {
+			total = h.n_out;
+			n_live = h.n_live;
+		} else {
+			hc.resize(total);
+			hd.resize(total);
+			ho.resize(total);
+			hr.resize(total);
+			if (bad(hipMemcpy(hc.data(), bc.p, total * 8, hipMemcpyDeviceToHost)) ||
+			    bad(hipMemcpy(hd.data(), bd.p, total, hipMemcpyDeviceToHost)) ||
+			    bad(hipMemcpy(ho.data(), bo.p, total * 4, hipMemcpyDeviceToHost)) ||
+			    bad(hipMemcpy(hr.data(), br.p, total * 4, hipMemcpyDeviceToHost)))
+				return (size_t)-1;
+			if (inner) {
+				hf.resize(total);
+				if (bad(hipMemcpy(hf.data(), bf.p, total, hipMemcpyDeviceToHost))) return (size_t)-1;
+			}
+		}
+		bc.release();
+		bd.release();
+		bo.release();
+		bf.release();
+		br.release();
+	}
+	dcbuf.release();
+	// the root alone: a map whose root block is absent or collapsed is a single leaf
+	MapRoot root;
+	if (bad(hipMemcpy(&root, m->b_root.p, sizeof(MapRoot), hipMemcpyDeviceToHost))) return (size_t)-1;
+	if (!inner && 0 == n_live) {  // n_live is counted by the leaf kernel: no live block <=> the root is a leaf
+		bool unknown = isUnknownV(m->g, root.occ);
+		if (include_unknown || !unknown) {
+			hc.push_back(0);
+			hd.push_back((uint8_t)m->g.L);
+			ho.push_back(root.occ);
+			hr.push_back(root.rgb);
+			total += 1;
+		}
+	}
+	std::vector<size_t> order(total);
+	for (size_t i = 0; i < total; ++i) order[i] = i;
+	std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return recLess(hc.data(), hd.data(), a, b); });
+	size_t nout = std::min(total, cap);
+	for (size_t i = 0; i < nout; ++i) {
+		size_t j = order[i];
+		if (codes) codes[i] = hc[j];
+		if (depths) depths[i] = hd[j];
+		if (logodds) logodds[i] = ho[j];
+		if (flags && inner) flags[i] = hf[j];
+		if (rgb) {
+			rgb[3 * i] = (uint8_t)(hr[j] & 0xFF);
+			rgb[3 * i + 1] = (uint8_t)((hr[j] >> 8) & 0xFF);
+			rgb[3 * i + 2] = (uint8_t)((hr[j] >> 16) & 0xFF);
+		}
+	}
+	return total;
+}
+
+size_t ufomap_map_export_leaves(ufomap_map* m, int include_unknown, uint64_t* codes, uint8_t* depths, float* logodds,
+                                uint8_t* rgb, size_t cap)
+{
+	return exportCommon(m, false, include_unknown, codes, depths, logodds, nullptr, rgb, cap);
+}
+
+size_t ufomap_map_export_inner(ufomap_map* m, uint64_t* codes, uint8_t* depths, float* logodds, uint8_t* flags, uint8_t* rgb,
+                               size_t cap)
+{
+	return exportCommon(m, true, 1, codes, depths, logodds, flags, rgb, cap);
+}
+
+int ufomap_map_minmax_change(ufomap_map* m, double mn[3], double mx[3])
+{
+	if (!m) return fail(UFOMAP_ERR_INVALID, "null map");
+	int rc = ufomap_map_wait(m);
+	for (int a = 0; a < 3; ++a) {
+		mn[a] = m->min_change[a];
+		mx[a] = m->max_change[a];
+	}
+	return rc;
+}
+
+int ufomap_map_reset_minmax_change(ufomap_map* m)
+{
+	if (!m) return fail(UFOMAP_ERR_INVALID, "null map");
+	int rc = ufomap_map_wait(m);
+	for (int a = 0; a < 3; ++a) {
+		m->min_change[a] = m->g.hs[m->g.L];
+		m->max_change[a] = -m->g.hs[m->g.L];
+	}
+	return rc;
+}
+
+int ufomap_map_stats(ufomap_map* m, uint64_t* n_inner, uint64_t* n_leaf, uint64_t* bytes)
+{
+	if (!m) return fail(UFOMAP_ERR_INVALID, "null map");
+	int rc = ufomap_map_wait(m);
+	if (rc) return rc;
+	DevBuf dcbuf;
+	HIP_TRY(dcbuf.reserve(sizeof(DumpCtl)));
+	HIP_TRY(hipMemsetAsync(dcbuf.p, 0, sizeof(DumpCtl), m->stream));
+	hipLaunchKernelGGL(k_export_leaves, gridFor((u64)m->t.mask + 1), dim3(256), 0, m->stream, m->t, m->g, 1, (u64*)nullptr,
+	                   (uint8_t*)nullptr, (float*)nullptr, (u32*)nullptr, 0ull, dcbuf.as<DumpCtl>());
+	DumpCtl h{};
+	HIP_TRY(hipMemcpyAsync(&h, dcbuf.p, sizeof(DumpCtl), hipMemcpyDeviceToHost, m->stream));
+	HIP_TRY(hipStreamSynchronize(m->stream));
+	dcbuf.release();
+	if (n_inner) *n_inner = h.n_live;
+	if (n_leaf) *n_leaf = h.n_live ? h.n_leaf : 1;
+	if (bytes) {
+		u64 cap = (u64)m->t.mask + 1;
+		*bytes = cap * (8 + 32 + 12 + (m->g.color ? 32 : 0));
+	}
+	return UFOMAP_OK;
+}
+
+size_t ufomap_map_last_hits(ufomap_map* m, uint64_t* codes, size_t cap)
+{
+	if (!m || ufomap_map_wait(m) < 0) return (size_t)-1;
+	size_t n = (size_t)m->counts[3];
+	std::vector<uint64_t> h(n);
+	if (n && hipMemcpy(h.data(), m->b_hit_code.p, n * 8, hipMemcpyDeviceToHost) != hipSuccess) return (size_t)-1;
+	std::sort(h.begin(), h.end());
+	if (codes) memcpy(codes, h.data(), std::min(n, cap) * 8);
+	return n;
+}
+
+size_t ufomap_map_last_misses(ufomap_map* m, uint64_t* codes, size_t cap)
+{
+	if (!m || ufomap_map_wait(m) < 0) return (size_t)-1;
+	if (!m->haveM) return 0;
+	ScanCtl* ctl = m->b_ctl.as<ScanCtl>();
+	std::vector<uint64_t> h;
+	u32 total = 0;
+	for (int pass = 0; pass < 2; ++pass) {
+		if (hipMemsetAsync(&ctl->n_codes, 0, 4, m->stream) != hipSuccess) return (size_t)-1;
+		if (pass && m->b_codes.reserve((size_t)total * 8) != hipSuccess) return (size_t)-1;
+		hipLaunchKernelGGL(k_grid_codes, gridFor(m->gridM.bytes >> 2, 256, 8192), dim3(256), 0, m->stream, m->g, m->gridM,
+		                   m->b_gridM.as<u32>(), pass ? m->b_codes.as<u64>() : (u64*)nullptr, pass ? total : 0u, ctl);
+		if (hipMemcpyAsync(&total, &ctl->n_codes, 4, hipMemcpyDeviceToHost, m->stream) != hipSuccess) return (size_t)-1;
+		if (hipStreamSynchronize(m->stream) != hipSuccess) return (size_t)-1;
+		if (0 == total) break;
+	}
+	h.resize(total);
+	if (total && hipMemcpy(h.data(), m->b_codes.p, (size_t)total * 8, hipMemcpyDeviceToHost) != hipSuccess) return (size_t)-1;
+	std::sort(h.begin(), h.end());
+	m->counts[4] = total;
+	if (codes) memcpy(codes, h.data(), std::min<size_t>(total, cap) * 8);
+	return total;
+}
+
+int ufomap_map_last_counts(ufomap_map* m, uint64_t counts[8])
+{
+	if (!m) return fail(UFOMAP_ERR_INVALID, "null map");
+	int rc = ufomap_map_wait(m);
+	for (int k = 0; k < 8; ++k) counts[k] = m->counts[k];
+	counts[7] = m->used_est;
+	return rc;
+}
+
+int ufomap_map_set_profiling(ufomap_map* m, int on)
+{
+	if (!m) return fail(UFOMAP_ERR_INVALID, "null map");
+	m->profiling = on != 0;
+	return UFOMAP_OK;
+}
+
+int ufomap_map_kernel_times(ufomap_map* m, const char** names, uint64_t* launches, double* total_ms, int cap)
+{
+	if (!m) return fail(UFOMAP_ERR_INVALID, "null map");
+	(void)ufomap_map_wait(m);
+	drainEvents(m);
+	int n = (int)m->stats.size();
+	for (int i = 0; i < n && i < cap; ++i) {
+		if (names) names[i] = m->stats[i].name;
+		if (launches) launches[i] = m->stats[i].launches;
+		if (total_ms) total_ms[i] = m->stats[i].total_ms;
+	}
+	return n;
+}
+
+int ufomap_map_reset_kernel_times(ufomap_map* m)
+{
+	if (!m) return fail(UFOMAP_ERR_INVALID, "null map");
+	(void)ufomap_map_wait(m);
+	drainEvents(m);
+	for (KernelStat& s : m->stats) {
+		s.launches = 0;
+		s.total_ms = 0;
+	}
+	return UFOMAP_OK;
+}
+
+int ufomap_map_scan_keys(ufomap_map*, const double*, const double*, const uint8_t*, size_t, double, unsigned, int, int, void**,
+                         size_t*)
+{
+	return fail(UFOMAP_ERR_UNSUPPORTED, "ufomap_map_scan_keys: not implemented yet");
+}
+
+int ufomap_map_apply_keys(ufomap_map*, const void*, size_t, unsigned)
+{
+	return fail(UFOMAP_ERR_UNSUPPORTED, "ufomap_map_apply_keys: not implemented yet");
+}
+
+void* ufomap_map_stream(ufomap_map* m) { return m ? (void*)m->stream : nullptr; }
+
+}  // extern "C"

@@ -1,0 +1,200 @@
+"""Host-side mirror of the reference's map API for the integration path (Python flavour).
+
+Mirrors ``ufo::map::OccupancyMap`` / ``ufo::map::OccupancyMapColor`` of the reference
+(ufomap/include/ufo/map/occupancy_map.h:55-85, occupancy_map_color.h:56-98): same method names,
+argument order, defaults and error behaviour for the hot path
+
+    insertPointCloud(sensor_origin, cloud, max_range=-1, depth=0, simple_ray_casting=False,
+                     early_stopping=0, async_=False)                    (occupancy_map_base.h:270-273)
+    insertPointCloudDiscrete(...same tail...)                           (occupancy_map_base.h:340-344)
+    insertPointCloudDone() / insertPointCloudWait()                     (occupancy_map_base.h:430-443)
+
+Everything forwards to the C ABI of ``include/ufomap_hip.h``; the map lives in HBM.  The C++ twin
+is ``include/ufomap_amd/occupancy_map.hpp``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+
+class PointCloud:
+    """``ufo::map::PointCloud`` (point_cloud.h:277): N x 3 float64 points."""
+
+    def __init__(self, xyz=None):
+        self.xyz = np.zeros((0, 3), np.float64) if xyz is None else np.ascontiguousarray(xyz, np.float64).reshape(-1, 3)
+        self.rgb = None
+
+    def size(self):
+        return self.xyz.shape[0]
+
+    __len__ = size
+
+
+class PointCloudColor(PointCloud):
+    """``ufo::map::PointCloudColor`` (point_cloud.h:278): points + 3 x uint8 colour."""
+
+    def __init__(self, xyz=None, rgb=None):
+        super().__init__(xyz)
+        self.rgb = np.zeros((self.size(), 3), np.uint8) if rgb is None else np.ascontiguousarray(rgb, np.uint8).reshape(-1, 3)
+        if self.rgb.shape[0] != self.size():
+            raise ValueError("xyz and rgb differ in length")
+
+
+def _p(a, ty):
+    return None if a is None else a.ctypes.data_as(C.POINTER(ty))
+
+
+class OccupancyMapBase:
+    _color = False
+
+    def __init__(self, resolution, depth_levels=16, automatic_pruning=True, occupied_thres=0.5, free_thres=0.5,
+                 prob_hit=0.7, prob_miss=0.4, clamping_thres_min=0.1192, clamping_thres_max=0.971, device=0):
+        self._lib = capi.load()
+        self._h = self._lib.ufomap_map_create(resolution, depth_levels, int(automatic_pruning), occupied_thres, free_thres,
+                                              prob_hit, prob_miss, clamping_thres_min, clamping_thres_max, int(self._color), device)
+        if not self._h:
+            msg = self._lib.ufomap_last_error().decode()
+            # the reference throws std::invalid_argument for bad depth_levels (octree.h:931-935)
+            raise ValueError(msg) if "depth_levels" in msg or "resolution" in msg else capi.UfomapError(capi.ERR_DEVICE, msg)
+        self.resolution = resolution
+        self.depth_levels = depth_levels
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.ufomap_map_destroy(h)
+
+    # ---- tree type strings (occupancy_map.h:84, occupancy_map_color.h:84-87) -------------------
+    def getTreeType(self):
+        return "occupancy_map_color" if self._color else "occupancy_map"
+
+    # ---- integration -----------------------------------------------------------------------------
+    def _insert(self, sensor_origin, cloud, max_range, depth, discrete, simple_ray_casting, early_stopping, async_):
+        if isinstance(cloud, PointCloud):
+            xyz, rgb = cloud.xyz, cloud.rgb
+        else:
+            xyz, rgb = np.ascontiguousarray(cloud, np.float64).reshape(-1, 3), None
+        o = np.ascontiguousarray(sensor_origin, np.float64)
+        capi.check(self._lib.ufomap_map_insert(self._h, _p(o, C.c_double), xyz.ctypes.data if xyz.size else None,
+                                               rgb.ctypes.data if rgb is not None and rgb.size else None, xyz.shape[0],
+                                               float(max_range), int(depth), int(discrete), int(simple_ray_casting),
+                                               int(early_stopping), int(async_)))
+
+    def insertPointCloud(self, sensor_origin, cloud, max_range=-1.0, depth=0, simple_ray_casting=False, early_stopping=0,
+                         async_=False):
+        self._insert(sensor_origin, cloud, max_range, depth, False, simple_ray_casting, early_stopping, async_)
+
+    def insertPointCloudDiscrete(self, sensor_origin, cloud, max_range=-1.0, depth=0, simple_ray_casting=False,
+                                 early_stopping=0, async_=False):
+        self._insert(sensor_origin, cloud, max_range, depth, True, simple_ray_casting, early_stopping, async_)
+
+    def insert_device(self, sensor_origin, d_xyz_ptr, d_rgb_ptr, n, max_range=-1.0, depth=0, discrete=True,
+                      simple_ray_casting=False, early_stopping=0, async_=False):
+        """Same as the two calls above for a cloud already resident in HBM (raw device pointers)."""
+        o = np.ascontiguousarray(sensor_origin, np.float64)
+        capi.check(self._lib.ufomap_map_insert_device(self._h, _p(o, C.c_double), d_xyz_ptr, d_rgb_ptr, n, float(max_range),
+                                                      int(depth), int(discrete), int(simple_ray_casting), int(early_stopping),
+                                                      int(async_)))
+
+    def insertPointCloudDone(self):
+        return bool(capi.check(self._lib.ufomap_map_done(self._h)))
+
+    def insertPointCloudWait(self):
+        capi.check(self._lib.ufomap_map_wait(self._h))
+
+    # ---- sensor model setters (occupancy_map_base.h:746-773) -------------------------------------
+    def setSensorModel(self, occupied_thres=0.5, free_thres=0.5, prob_hit=0.7, prob_miss=0.4, clamping_thres_min=0.1192,
+                       clamping_thres_max=0.971):
+        capi.check(self._lib.ufomap_map_set_sensor_model(self._h, occupied_thres, free_thres, prob_hit, prob_miss,
+                                                         clamping_thres_min, clamping_thres_max))
+
+    def clear(self):
+        capi.check(self._lib.ufomap_map_clear(self._h))
+
+    def reserve(self, n_blocks):
+        capi.check(self._lib.ufomap_map_reserve(self._h, n_blocks))
+
+    # ---- read-back in the canonical dump format (same tuple layout as oracle.OracleMap) ----------
+    def leaves(self, include_unknown=False):
+        n = self._lib.ufomap_map_export_leaves(self._h, int(include_unknown), None, None, None, None, 0)
+        if n == C.c_size_t(-1).value:
+            capi.check(-2)
+        codes, depths, occ, rgb = np.empty(n, np.uint64), np.empty(n, np.uint8), np.empty(n, np.float32), np.zeros((n, 3), np.uint8)
+        self._lib.ufomap_map_export_leaves(self._h, int(include_unknown), _p(codes, C.c_uint64), _p(depths, C.c_uint8),
+                                           _p(occ, C.c_float), _p(rgb, C.c_uint8), n)
+        return codes, depths, occ, rgb
+
+    def inner(self):
+        n = self._lib.ufomap_map_export_inner(self._h, None, None, None, None, None, 0)
+        if n == C.c_size_t(-1).value:
+            capi.check(-2)
+        codes, depths, occ = np.empty(n, np.uint64), np.empty(n, np.uint8), np.empty(n, np.float32)
+        flags, rgb = np.empty(n, np.uint8), np.zeros((n, 3), np.uint8)
+        self._lib.ufomap_map_export_inner(self._h, _p(codes, C.c_uint64), _p(depths, C.c_uint8), _p(occ, C.c_float),
+                                          _p(flags, C.c_uint8), _p(rgb, C.c_uint8), n)
+        return codes, depths, occ, flags, rgb
+
+    def minmax_change(self):
+        mn, mx = np.empty(3), np.empty(3)
+        capi.check(self._lib.ufomap_map_minmax_change(self._h, _p(mn, C.c_double), _p(mx, C.c_double)))
+        return mn, mx
+
+    minChange = property(lambda self: self.minmax_change()[0])
+    maxChange = property(lambda self: self.minmax_change()[1])
+
+    def resetMinMaxChangeDetection(self):
+        capi.check(self._lib.ufomap_map_reset_minmax_change(self._h))
+
+    def stats(self):
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        capi.check(self._lib.ufomap_map_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(inner_nodes=a.value, leaf_nodes=b.value, bytes=c.value)
+
+    # ---- stage-level outputs / measurement ---------------------------------------------------------
+    def _codes(self, fn):
+        n = fn(self._h, None, 0)
+        if n == C.c_size_t(-1).value:
+            capi.check(-2)
+        out = np.empty(n, np.uint64)
+        fn(self._h, _p(out, C.c_uint64), n)
+        return out
+
+    def last_hits(self):
+        return self._codes(self._lib.ufomap_map_last_hits)
+
+    def last_misses(self):
+        return self._codes(self._lib.ufomap_map_last_misses)
+
+    def last_counts(self):
+        c = np.zeros(8, np.uint64)
+        capi.check(self._lib.ufomap_map_last_counts(self._h, _p(c, C.c_uint64)))
+        keys = ["points", "rays", "steps", "hits", "miss_cells", "blocks_touched", "blocks_created", "blocks_used"]
+        return dict(zip(keys, (int(v) for v in c)))
+
+    def set_profiling(self, on=True):
+        capi.check(self._lib.ufomap_map_set_profiling(self._h, int(on)))
+
+    def reset_kernel_times(self):
+        capi.check(self._lib.ufomap_map_reset_kernel_times(self._h))
+
+    def kernel_times(self):
+        cap = 64
+        names = (C.c_char_p * cap)()
+        launches = np.zeros(cap, np.uint64)
+        ms = np.zeros(cap, np.float64)
+        n = capi.check(self._lib.ufomap_map_kernel_times(self._h, names, _p(launches, C.c_uint64), _p(ms, C.c_double), cap))
+        return {names[i].decode(): dict(launches=int(launches[i]), total_ms=float(ms[i])) for i in range(min(n, cap))}
+
+
+class OccupancyMap(OccupancyMapBase):
+    """``ufo::map::OccupancyMap`` (occupancy_map.h:55)."""
+    _color = False
+
+
+class OccupancyMapColor(OccupancyMapBase):
+    """``ufo::map::OccupancyMapColor`` (occupancy_map_color.h:56)."""
+    _color = True
