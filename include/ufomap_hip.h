@@ -107,7 +107,9 @@ int ufomap_map_stats(ufomap_map* m, uint64_t* n_inner, uint64_t* n_leaf, uint64_
  * hits: unique hit voxel codes at depth 0 (`occupied_hits`, occupancy_map_base.h:296);
  * misses: unique free cells as code >> 3*depth (`free_hits`, occupancy_map_base.h:1356-1365);
  * both sorted ascending. counts: [0]=points in, [1]=rays cast, [2]=DDA steps, [3]=unique hits,
- * [4]=unique miss cells, [5]=node blocks touched, [6]=node blocks created. */
+ * [4]=unique miss cells (filled by last_misses), [5]=node blocks touched, [6]=node blocks created,
+ * [7]=cells dropped because their key fell outside [0,2^L) (clipped rays only; the reference aliases
+ * such keys to the opposite face of the map). */
 size_t ufomap_map_last_hits(ufomap_map* m, uint64_t* codes, size_t cap);
 size_t ufomap_map_last_misses(ufomap_map* m, uint64_t* codes, size_t cap);
 int ufomap_map_last_counts(ufomap_map* m, uint64_t counts[8]);

@@ -71,6 +71,8 @@ def _load(kind: str):
     lib.ufo_oracle_last_misses.argtypes = [vp, u64p, C.c_size_t]
     lib.ufo_oracle_last_steps.restype = C.c_uint64
     lib.ufo_oracle_last_steps.argtypes = [vp]
+    lib.ufo_oracle_last_oob.restype = C.c_uint64
+    lib.ufo_oracle_last_oob.argtypes = [vp]
     lib.ufo_oracle_kind.restype = C.c_char_p
     _LIBS[kind] = lib
     return lib
@@ -166,3 +168,7 @@ class OracleMap:
 
     def last_steps(self):
         return int(self.lib.ufo_oracle_last_steps(self.h))
+
+    def last_oob(self):
+        """Keys of the last insert outside [0, 2^L) (port only; such input is outside the parity contract)."""
+        return int(self.lib.ufo_oracle_last_oob(self.h))

@@ -61,6 +61,11 @@ size_t ufo_oracle_last_hits(const ufo_oracle_map* m, uint64_t* codes, size_t cap
 size_t ufo_oracle_last_rays(const ufo_oracle_map* m, double* ends_xyz, size_t cap);
 size_t ufo_oracle_last_misses(const ufo_oracle_map* m, uint64_t* codes, size_t cap);
 uint64_t ufo_oracle_last_steps(const ufo_oracle_map* m);
+/* Number of hit/miss keys of the last insert with a coordinate outside [0, 2^L): the reference
+ * aliases such keys into the tree (bits above 3L are ignored by getChildIdx, code.h:245-248) and can
+ * apply one voxel twice; the HIP path drops them. Inputs with a non-zero count are outside the
+ * parity contract (only reachable when a segment is clipped at the map cube). */
+uint64_t ufo_oracle_last_oob(const ufo_oracle_map* m);
 
 /* "reference" or "port". */
 const char* ufo_oracle_kind(void);

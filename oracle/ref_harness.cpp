@@ -224,6 +224,7 @@ size_t ufo_oracle_last_hits(const ufo_oracle_map*, uint64_t*, size_t) { return (
 size_t ufo_oracle_last_rays(const ufo_oracle_map*, double*, size_t) { return (size_t)-1; }
 size_t ufo_oracle_last_misses(const ufo_oracle_map*, uint64_t*, size_t) { return (size_t)-1; }
 uint64_t ufo_oracle_last_steps(const ufo_oracle_map*) { return (uint64_t)-1; }
+uint64_t ufo_oracle_last_oob(const ufo_oracle_map*) { return (uint64_t)-1; }
 
 const char* ufo_oracle_kind(void) { return "reference"; }
 

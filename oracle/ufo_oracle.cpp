@@ -97,7 +97,7 @@ struct ufo_oracle_map {
 	/* stage outputs of the last insert */
 	std::vector<u64> last_hits, last_misses;
 	std::vector<V3> last_rays;
-	u64 last_steps;
+	u64 last_steps, last_oob;
 	bool runaway;  // a ray exceeded the step budget (see freeSpaceNormal)
 
 	double size(unsigned d) const { return hs[d + 1]; }
@@ -412,6 +412,7 @@ struct ufo_oracle_map {
 	void emitMiss(std::unordered_set<u64>& set, const u32 k[3], unsigned depth)
 	{
 		++last_steps;
+		if ((k[0] >> L) || (k[1] >> L) || (k[2] >> L)) ++last_oob;
 		set.insert(morton(k) >> (3 * depth));
 	}
 	void freeSpaceNormal(V3 const& from, V3 const& to, std::unordered_set<u64>& set, unsigned depth)
@@ -497,6 +498,7 @@ struct ufo_oracle_map {
 		std::unordered_set<u64> seen0, seend;
 		V3 mnc = bbxMax(), mxc = bbxMin();
 		double sq_max = max_range * max_range;
+		u64 oob_hits = 0;
 		for (size_t p = 0; p < n; ++p) {
 			V3 end = V3{{xyz[3 * p], xyz[3 * p + 1], xyz[3 * p + 2]}};
 			if (!discrete) {
@@ -508,6 +510,7 @@ struct ufo_oracle_map {
 					u32 k[3];
 					toKey(end, 0, k);
 					u64 c = morton(k);
+					if ((k[0] >> L) || (k[1] >> L) || (k[2] >> L)) ++oob_hits;
 					if (seen0.insert(c).second) hits.push_back(Hit{c, {0, 0, 0}});
 				} else {
 					dir = divs(dir, dist);
@@ -573,6 +576,7 @@ struct ufo_oracle_map {
 		/* free space: OMB:1229-1259.  freeSpace() is const and never reads the tree (OMB:1230-1232), so
 		 * computing it before the hits are applied is equivalent to the reference's helper-thread overlap. */
 		last_steps = 0;
+		last_oob = oob_hits;
 		runaway = false;
 		std::unordered_set<u64> free_hits;
 		for (V3 const& pt : rays) {
@@ -675,6 +679,7 @@ ufo_oracle_map* ufo_oracle_create(double resolution, unsigned depth_levels, int 
 	m->min_change = m->bbxMax();
 	m->max_change = m->bbxMin();
 	m->last_steps = 0;
+	m->last_oob = 0;
 	m->runaway = false;
 	return m;
 }
@@ -736,6 +741,7 @@ size_t ufo_oracle_last_misses(const ufo_oracle_map* m, uint64_t* codes, size_t c
 	return m->last_misses.size();
 }
 uint64_t ufo_oracle_last_steps(const ufo_oracle_map* m) { return m->last_steps; }
+uint64_t ufo_oracle_last_oob(const ufo_oracle_map* m) { return m->last_oob; }
 
 const char* ufo_oracle_kind(void) { return "port"; }
 

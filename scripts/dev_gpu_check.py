@@ -64,6 +64,14 @@ if __name__ == "__main__":
     ok &= run("small_disc", dict(resolution=0.16), [(lo, lx, None, dict(max_range=20.0, discrete=True))] * 7)
     ok &= run("small_d2", dict(resolution=0.16), [(lo, lx, None, dict(max_range=8.0, depth=2, discrete=True))] * 3)
     ok &= run("small_color", dict(resolution=0.08), [(lo, lx, lc, dict(max_range=10.0, discrete=True))] * 2, color=True)
+    go, gx, gc = scans.rgbd(width=160, height=120, colored=True)
+    ok &= run("rgbd_d4", dict(resolution=0.002), [(go, gx, None, dict(max_range=5.0, depth=4, discrete=True))] * 3)
+    ok &= run("rgbd_d0_1cm_color", dict(resolution=0.01), [(go, gx, gc, dict(max_range=5.0, discrete=True))] * 2, color=True)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    import golden_util
+    for nm in ["clip_small_map_continuous", "clip_small_map_discrete", "clip_origin_outside"]:
+        gd = golden_util.Golden(nm)
+        ok &= run(nm, gd.params, [(o_, x_, r_, kw_) for o_, x_, r_, kw_ in gd.scans()])
     fo, fx, _ = scans.lidar64()
     ok &= run("C1", dict(resolution=0.16), [(fo, fx, None, dict(max_range=20.0))])
     ok &= run("C2", dict(resolution=0.16), [(fo, fx, None, dict(max_range=20.0, discrete=True))] * 3)

@@ -30,13 +30,22 @@ __device__ inline u32 levelOf(const MapGeom& g, u64 lk) { return g.L - (u32)((63
 // float exp as the reference's toProb sees it: std::exp(float) (OMB:911 with LogitType=float)
 __device__ inline double toProbF(float logit) { return 1.0 / (1.0 + (double)((float)exp((double)(-logit)))); }
 
-// updateNode for a non-leaf node (OMB:1191-1224) + colour average (OMC.cpp:177-222), read-only part
-__device__ inline Summ blockSummary(const Table& t, const MapGeom& g, u32 s, u32 level, u32 f)
+// updateNode for a non-leaf node (OMB:1191-1224) + colour average (OMC.cpp:177-222), read-only part.
+// oc >= 0 substitutes (o_occ, o_fl, o_rgb) for child oc: the summary the node had before that child's
+// last update.
+__device__ inline Summ blockSummary(const Table& t, const MapGeom& g, u32 s, u32 level, u32 f, int oc = -1,
+                                    float o_occ = 0.f, u32 o_fl = 0, u32 o_rgb = 0)
 {
 	Summ r;
 	const float4* pv = reinterpret_cast<const float4*>(t.occ + 8 * (size_t)s);
 	float4 a = pv[0], b = pv[1];
 	float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+	if (oc >= 0) {
+#pragma unroll
+		for (int i = 0; i < 8; ++i)
+			if (i == oc) v[i] = o_occ;
+		f = (f & ~((1u << oc) | (1u << (8 + oc)))) | ((o_fl & 1u) << oc) | (((o_fl >> 1) & 1u) << (8 + oc));
+	}
 	float m = v[0];
 	bool eq = true;
 #pragma unroll
@@ -59,9 +68,10 @@ __device__ inline Summ blockSummary(const Table& t, const MapGeom& g, u32 s, u32
 		double rr = 0, gg = 0, bb = 0;
 		int cnt = 0;
 		u32 c0 = pc[0];
+		if (0 == oc) c0 = o_rgb;
 #pragma unroll
 		for (int i = 0; i < 8; ++i) {
-			u32 c = pc[i];
+			u32 c = (i == oc) ? o_rgb : pc[i];
 			eq = eq && (c == c0);
 			if (c) {
 				double cr = (double)(c & 0xFF), cg = (double)((c >> 8) & 0xFF), cb = (double)((c >> 16) & 0xFF);
@@ -114,6 +124,26 @@ __device__ inline bool writeToParent(const Table& t, const MapGeom& g, u32 s, u6
 	return ch;
 }
 
+// What the parent's slot currently holds for this node (= the node's stored value and flags).
+__device__ inline Summ readStored(const Table& t, const MapGeom& g, u32 s, u64 lk)
+{
+	Summ r;
+	r.collapsible = false;
+	if (1 == lk) {
+		r.occ = t.root->occ;
+		r.fl = t.root->flags & 3u;
+		r.rgb = t.root->rgb;
+		return r;
+	}
+	u32 p = t.parent[s];
+	u32 ci = (u32)(lk & 7);
+	u32 fp = __hip_atomic_load(&t.flags[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	r.occ = t.occ[8 * (size_t)p + ci];
+	r.fl = ((fp >> ci) & 1u) | (((fp >> (8 + ci)) & 1u) << 1);
+	r.rgb = g.color ? t.rgb[8 * (size_t)p + ci] : 0u;
+	return r;
+}
+
 // The node became a leaf again (deleteChildren, octree.h:1060-1066): mark the block DEAD and clear
 // the parent's "child is inner" bit.
 __device__ inline void collapseBlock(const Table& t, u32 s, u64 lk)
@@ -122,9 +152,59 @@ __device__ inline void collapseBlock(const Table& t, u32 s, u64 lk)
 	if (1 != lk) atomicAnd(&t.flags[t.parent[s]], ~(1u << (16 + (u32)(lk & 7))));
 }
 
-__device__ inline void markDirty(const Table& t, u32 p, u32 extra, u32* __restrict__ wl, u32* wl_count)
+__device__ inline bool sameSumm(const MapGeom& g, const Summ& a, const Summ& b)
 {
-	u32 old = atomicOr(&t.flags[p], F_DIRTY | extra);
+	return a.occ == b.occ && a.fl == b.fl && (!g.color || a.rgb == b.rgb);
+}
+
+// ---- last-update chain ----------------------------------------------------------------------------
+// The reference applies updates one at a time; each one first re-expands its whole path (createNode,
+// octree.h:997-1016) and only its own upward pass (updateParents, OMB:1126-1133: stops at the first
+// unchanged node) can collapse a node again. Hence after a phase a node N is collapsed iff the LAST
+// update beneath N reached N (every node below N on its path changed by that single update) and found
+// it collapsible. "Last" is the reference's application order: cloud order for hits (OMB:1351-1354),
+// ascending code order for misses (CodeMap iteration within a subtree; the oracle port applies them
+// sorted). Each node therefore publishes, per phase: whether its last update reached it and changed its
+// summary, and the summary it had just before that update; tmax tells the parent which child carries
+// the last update.
+#define UFO_TAG(phase) ((u64)((phase)&0xFFFFFFu))
+__device__ inline void publishLast(const Table& t, const MapGeom& g, u32 s, u32 phase, bool reachchg, const Summ& pre)
+{
+	t.lu_occ[s] = pre.occ;
+	t.lu_fl[s] = (pre.fl & 3u) | (reachchg ? 0x100u : 0u);
+	if (g.color) t.lu_rgb[s] = pre.rgb;
+	t.lu_phase[s] = phase;
+}
+// carry the time of the last update beneath block s up the tree (max-reduction with early exit)
+__device__ inline void carryTime(const Table& t, u32 s, u64 lk, u32 phase, u64 time)
+{
+	u32 b = s;
+	while (1 != lk) {
+		u32 p = t.parent[b];
+		u64 val = (UFO_TAG(phase) << 40) | (time << 3) | (lk & 7);
+		u64 old = atomicMax((unsigned long long*)&t.tmax[p], (unsigned long long)val);
+		if (old >= val) break;
+		b = p;
+		lk >>= 3;
+	}
+}
+// For block s (location key lk): did the last update beneath it reach it? If so *pre = summary before it.
+__device__ inline bool lastReached(const Table& t, const MapGeom& g, u32 s, u64 lk, u32 level, u32 f, u32 phase, Summ* pre)
+{
+	u64 tv = t.tmax[s];
+	if ((tv >> 40) != UFO_TAG(phase)) return false;
+	int c = (int)(tv & 7);
+	u32 cs = tableFind(t, (lk << 3) | (u64)c);
+	if (cs == NONE || t.lu_phase[cs] != phase) return false;
+	u32 lf = t.lu_fl[cs];
+	if (!(lf & 0x100u)) return false;
+	*pre = blockSummary(t, g, s, level, f, c, t.lu_occ[cs], lf & 3u, g.color ? t.lu_rgb[cs] : 0u);
+	return true;
+}
+
+__device__ inline void markDirty(const Table& t, u32 p, u32* __restrict__ wl, u32* wl_count)
+{
+	u32 old = atomicOr(&t.flags[p], F_DIRTY);
 	if (!(old & F_DIRTY)) wl[atomicAdd(wl_count, 1u)] = p;
 }
 
@@ -237,14 +317,17 @@ __device__ inline u32 blendColor(const MapGeom& g, u32 cur, u32 upd, float occ_o
 }
 
 // ------------------------------------------------------------------------------------------------
-// S3 apply (level-1 blocks): hits with clamp, then misses with clamp (OMB:1351-1365, 1139-1145),
-// followed by this block's own updateNode (OMB:1195-1224) and the hand-off to its parent.
-// One thread per node block: the 8 children are one 32-byte record.
+// S3 apply (level-1 blocks): one phase of insertPointCloudHelper (OMB:1351-1365) -- either all hits
+// of the scan or all misses -- with updateOccupancy's clamp (OMB:1139-1145), followed by this
+// block's own updateNode (OMB:1195-1224) and the hand-off to its parent. One thread per node
+// block: the 8 children are one 32-byte record. Hits and misses are separate phases, each followed
+// by its own propagation, because the reference joins the hit thread before the first miss lands
+// (OMB:1361) and pruning depends on which ancestors were re-evaluated in which phase.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_apply_leaf(Table t, MapGeom g, const Entry* __restrict__ entries,
-                                                    const u32* n_entries_p, const u32* __restrict__ ent_slot, float miss,
-                                                    HitHash hh, const uint8_t* __restrict__ rgb_in, u32* __restrict__ wl,
-                                                    ScanCtl* ctl)
+                                                    const u32* n_entries_p, const u32* __restrict__ ent_slot, float upd,
+                                                    u32 is_hit, u32 phase, HitHash hh, const uint8_t* __restrict__ rgb_in,
+                                                    u32* __restrict__ wl, ScanCtl* ctl)
 {
 	u32 n = *n_entries_p;
 	if (ctl->err) return;
@@ -254,56 +337,52 @@ __global__ __launch_bounds__(256) void k_apply_leaf(Table t, MapGeom g, const En
 		float4* po = reinterpret_cast<float4*>(t.occ + 8 * (size_t)s);
 		float4 a = po[0], b = po[1];
 		float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-		const u64 pcode = (e.lk ^ (1ULL << (3 * (g.L - 1)))) << 3;  // depth-0 code of child 0
-		float mid_max = 0;
-		u32 mid_fl = 0;
-		bool have_mid = false;
-		if (e.hit) {
+		const u32 mask = is_hit ? e.hit : e.miss;
+		// the child updated last: highest code for misses, latest first-point for hits (cloud order)
+		int c_last = 31 - __clz((int)mask);
+		u64 t_last = 0;
+		u32 oldc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+		if (is_hit) {
+			const u64 pcode = (e.lk ^ (1ULL << (3 * (g.L - 1)))) << 3;  // depth-0 code of child 0
 #pragma unroll
 			for (int c = 0; c < 8; ++c) {
-				if ((e.hit >> c) & 1) {
-					if (g.color && rgb_in) {
-						u32 hs = hitHashFind(hh, pcode | (u64)c);
-						if (hs != NONE) {
-							u32 pt = hh.minidx[hs];
-							u32 upd = (u32)rgb_in[3 * (size_t)pt] | ((u32)rgb_in[3 * (size_t)pt + 1] << 8) |
-							          ((u32)rgb_in[3 * (size_t)pt + 2] << 16);
-							u32* pc = t.rgb + 8 * (size_t)s + c;
-							*pc = blendColor(g, *pc, upd, v[c]);
-						}
-					}
-					v[c] = clampAdd(v[c], g.hit, g.cmin, g.cmax);
+				if (!((mask >> c) & 1)) continue;
+				u32 hs = hitHashFind(hh, pcode | (u64)c);
+				if (hs == NONE) continue;
+				u32 pt = hh.minidx[hs];
+				if ((u64)pt >= t_last) {
+					t_last = pt;
+					c_last = c;
 				}
-			}
-			if (e.miss) {
-				have_mid = true;
-				mid_max = v[0];
-#pragma unroll
-				for (int c = 0; c < 8; ++c) {
-					mid_max = fmaxf(mid_max, v[c]);
-					mid_fl |= (isFreeV(g, v[c]) ? 1u : 0u) | (isUnknownV(g, v[c]) ? 2u : 0u);
+				if (g.color && rgb_in) {
+					// updateValue(code, update, color): colour first, with the OLD occupancy (OMC.h:275-277)
+					u32 u = (u32)rgb_in[3 * (size_t)pt] | ((u32)rgb_in[3 * (size_t)pt + 1] << 8) | ((u32)rgb_in[3 * (size_t)pt + 2] << 16);
+					u32* pc = t.rgb + 8 * (size_t)s + c;
+					oldc[c] = *pc;
+					*pc = blendColor(g, oldc[c], u, v[c]);
 				}
 			}
 		}
-		if (e.miss) {
+		u32 old_rgb_last = 0;
 #pragma unroll
-			for (int c = 0; c < 8; ++c)
-				if ((e.miss >> c) & 1) v[c] = clampAdd(v[c], miss, g.cmin, g.cmax);
+		for (int c = 0; c < 8; ++c)
+			if (c == c_last) old_rgb_last = oldc[c];
+		if (g.color && !(is_hit && rgb_in)) old_rgb_last = t.rgb[8 * (size_t)s + c_last];  // colour untouched in this phase
+		float v_old_last = 0.f;
+#pragma unroll
+		for (int c = 0; c < 8; ++c) {
+			if (c == c_last) v_old_last = v[c];
+			if ((mask >> c) & 1) v[c] = clampAdd(v[c], upd, g.cmin, g.cmax);
 		}
 		po[0] = make_float4(v[0], v[1], v[2], v[3]);
 		po[1] = make_float4(v[4], v[5], v[6], v[7]);
 		Summ sm = blockSummary(t, g, s, 1, 0);
-		// what the parent's slot held before this scan touched the block
-		u32 p = t.parent[s];
-		u32 ci = (u32)(e.lk & 7);
-		float old_occ = t.occ[8 * (size_t)p + ci];
-		u32 fp = __hip_atomic_load(&t.flags[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		u32 old_fl = ((fp >> ci) & 1u) | (((fp >> (8 + ci)) & 1u) << 1);
-		bool transient = have_mid && ((mid_max != old_occ || mid_fl != old_fl) || (mid_max != sm.occ || mid_fl != sm.fl));
+		// summary just before the last update of this block (level 1 is always reached: OMB:1128 starts at 1)
+		Summ pre = blockSummary(t, g, s, 1, 0, c_last, v_old_last, 0, old_rgb_last);
+		publishLast(t, g, s, phase, !sameSumm(g, pre, sm), pre);
+		carryTime(t, s, e.lk, phase, t_last);
 		if (sm.collapsible) collapseBlock(t, s, e.lk);
-		bool changed = writeToParent(t, g, s, e.lk, sm);
-		if (changed) markDirty(t, p, 0, wl, &ctl->wl_count[0]);
-		else if (transient) markDirty(t, p, F_TRANS, wl, &ctl->wl_count[0]);
+		if (writeToParent(t, g, s, e.lk, sm)) markDirty(t, t.parent[s], wl, &ctl->wl_count[0]);
 	}
 }
 
@@ -378,7 +457,7 @@ __device__ inline bool subtreeApply(const Table& t, const MapGeom& g, u32 s0, u6
 // summary changed.
 __global__ __launch_bounds__(256) void k_apply_coarse(Table t, MapGeom g, const Entry* __restrict__ entries,
                                                       const u32* n_entries_p, const u32* __restrict__ ent_slot, float miss,
-                                                      u32* __restrict__ wl, ScanCtl* ctl)
+                                                      u32 phase, u32* __restrict__ wl, ScanCtl* ctl)
 {
 	u32 n = *n_entries_p;
 	if (ctl->err) return;
@@ -386,14 +465,18 @@ __global__ __launch_bounds__(256) void k_apply_coarse(Table t, MapGeom g, const 
 		Entry e = entries[i];
 		u32 s = ent_slot[i];
 		u32 level = e.level;
-		bool evaluate = false;
-		for (u32 c = 0; c < 8; ++c) {
+		const int c_last = 31 - __clz((int)e.miss);
+		bool last_reached = false;
+		Summ pre = readStored(t, g, s, e.lk), fin = pre;
+		// children in ascending code order, each one a separate updateValue of the reference
+		for (int c = 0; c < 8; ++c) {
 			if (!((e.miss >> c) & 1)) continue;
 			u32 f = t.flags[s];
+			bool trigger = false;
 			if ((f >> (16 + c)) & 1u) {
 				u64 clk = (e.lk << 3) | (u64)c;
 				u32 cs = tableFind(t, clk);
-				if (cs != NONE && subtreeApply(t, g, cs, clk, level - 1, miss)) evaluate = true;
+				if (cs != NONE) trigger = subtreeApply(t, g, cs, clk, level - 1, miss);
 			} else {
 				float* pv = t.occ + 8 * (size_t)s + c;
 				float v = *pv;
@@ -402,16 +485,24 @@ __global__ __launch_bounds__(256) void k_apply_coarse(Table t, MapGeom g, const 
 				u32 nbits = (isFreeV(g, nv) ? (1u << c) : 0u) | (isUnknownV(g, nv) ? (1u << (8 + c)) : 0u);
 				u32 obits = f & ((1u << c) | (1u << (8 + c)));
 				if (nbits != obits) {
-					evaluate = true;
+					// updateParents starts at the leaf itself: only a FLAG change walks up (OMB:1126-1133, 1181-1189)
+					trigger = true;
 					t.flags[s] = (f & ~((1u << c) | (1u << (8 + c)))) | nbits;
 				}
 			}
+			if (!trigger) continue;
+			// updateNode on this block, as the reference runs it right after this child's update
+			Summ sm = blockSummary(t, g, s, level, t.flags[s]);
+			if (c == c_last) {
+				last_reached = true;
+				pre = readStored(t, g, s, e.lk);
+				if (sm.collapsible) collapseBlock(t, s, e.lk);
+			}
+			fin = sm;
+			if (writeToParent(t, g, s, e.lk, sm) && 1 != e.lk) markDirty(t, t.parent[s], wl, &ctl->wl_count[0]);
 		}
-		if (!evaluate) continue;
-		Summ sm = blockSummary(t, g, s, level, t.flags[s]);
-		if (sm.collapsible) collapseBlock(t, s, e.lk);
-		bool changed = writeToParent(t, g, s, e.lk, sm);
-		if (changed && 1 != e.lk) markDirty(t, t.parent[s], 0, wl, &ctl->wl_count[0]);
+		publishLast(t, g, s, phase, last_reached && !sameSumm(g, pre, fin), pre);
+		carryTime(t, s, e.lk, phase, 0);
 	}
 }
 
@@ -420,21 +511,23 @@ __global__ __launch_bounds__(256) void k_apply_coarse(Table t, MapGeom g, const 
 // changed; a block whose own summary changes queues its parent for the next launch.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_propagate(Table t, MapGeom g, const u32* __restrict__ wl_in, u32* __restrict__ wl_out,
-                                                   u32 in_idx, ScanCtl* ctl)
+                                                   u32 in_idx, u32 phase, ScanCtl* ctl)
 {
 	u32 n = ctl->wl_count[in_idx];
 	if (ctl->err) return;
 	for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
 		u32 s = wl_in[i];
-		u32 old = atomicAnd(&t.flags[s], ~(F_DIRTY | F_TRANS));
+		u32 old = atomicAnd(&t.flags[s], ~F_DIRTY);
 		u64 lk = t.keys[s];
 		u32 level = levelOf(g, lk);
 		Summ sm = blockSummary(t, g, s, level, old);
-		if (sm.collapsible) collapseBlock(t, s, lk);
+		// collapse only if the LAST update beneath this node walked all the way up to it (see above)
+		Summ pre = sm;
+		bool reached = lastReached(t, g, s, lk, level, old, phase, &pre);
+		if (reached && sm.collapsible) collapseBlock(t, s, lk);
 		bool changed = writeToParent(t, g, s, lk, sm);
-		if (1 == lk) continue;
-		if (changed) markDirty(t, t.parent[s], 0, wl_out, &ctl->wl_count[in_idx ^ 1]);
-		else if (old & F_TRANS) markDirty(t, t.parent[s], F_TRANS, wl_out, &ctl->wl_count[in_idx ^ 1]);
+		publishLast(t, g, s, phase, reached && !sameSumm(g, pre, sm), pre);
+		if (changed && 1 != lk) markDirty(t, t.parent[s], wl_out, &ctl->wl_count[in_idx ^ 1]);
 	}
 }
 

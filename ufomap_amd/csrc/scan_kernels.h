@@ -36,7 +36,7 @@ struct Grid {
 struct ScanCtl {
 	u32 n_rays;
 	u32 n_hits;
-	u32 n_entries;
+	u32 n_entries[2];  // [0] hit entries (level 1), [1] miss entries (level depth+1)
 	u32 n_new;
 	u32 err;
 	u32 wl_count[2];
@@ -45,6 +45,8 @@ struct ScanCtl {
 	i32 hb_min[3], hb_max[3];  // hit-grid cell bbox (depth 0)
 	u64 aabb_min[3], aabb_max[3];  // order-encoded doubles: change AABB of this scan
 	unsigned long long n_steps;
+	u32 n_oob;  // cells dropped because their key lies outside [0, 2^L) (the reference aliases them)
+	u32 pad2;
 };
 
 struct Entry {
@@ -122,6 +124,23 @@ __device__ inline u32 hitHashInsert(const HitHash& h, u64 code, u32 idx, u32* er
 	}
 	atomicOr(err, ERR_HASH_FULL);
 	return NONE;
+}
+// Insert `code` if absent; true only for the one thread whose CAS created the entry.
+__device__ inline bool hitHashInsertUnique(const HitHash& h, u64 code, u32* err)
+{
+	u32 s = hash64(code) & h.mask;
+	for (u32 probe = 0; probe <= h.mask; ++probe) {
+		u64 k = __hip_atomic_load(&h.keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (k == ~0ULL) {
+			u64 prev = atomicCAS((unsigned long long*)&h.keys[s], ~0ULL, (unsigned long long)code);
+			if (prev == ~0ULL) return true;
+			k = prev;
+		}
+		if (k == code) return false;
+		s = (s + 1) & h.mask;
+	}
+	atomicOr(err, ERR_HASH_FULL);
+	return false;
 }
 __device__ inline u32 hitHashFind(const HitHash& h, u64 code)
 {
@@ -239,6 +258,13 @@ __global__ __launch_bounds__(256) void k_select(MapGeom g, D3 sensor, u32 n, u32
 	}
 	i32 hk[3] = {INT32_MAX, INT32_MAX, INT32_MAX};
 	if (winner) {
+		u32 kx = toKey1(g, end.x, 0), ky = toKey1(g, end.y, 0), kz = toKey1(g, end.z, 0);
+		if ((kx >> g.L) || (ky >> g.L) || (kz >> g.L)) {
+			winner = false;  // key outside [0, 2^L): dropped (see gridMark)
+			atomicAdd(&ctl->n_oob, 1u);
+		}
+	}
+	if (winner) {
 		u32 pos = atomicAdd(&ctl->n_hits, 1u);
 		u32 kx = toKey1(g, end.x, 0), ky = toKey1(g, end.y, 0), kz = toKey1(g, end.z, 0);
 		hit_code[pos] = morton3(kx, ky, kz);
@@ -264,7 +290,16 @@ __global__ __launch_bounds__(256) void k_select(MapGeom g, D3 sensor, u32 n, u32
 		D3 e2 = end;
 		if (DISCRETE) {
 			// OMB:371-398: clip, snap the ray end to the centre of its depth-`depth` cell
-			if (moveLineInside(g, cur, e2)) {
+			if (!moveLineInside(g, cur, e2)) {
+				cast = false;
+			} else if (0 < depth) {
+				u32 k0 = toKey1(g, e2.x, depth), k1 = toKey1(g, e2.y, depth), k2 = toKey1(g, e2.z, depth);
+				// OMB:380-382: for depth > 0 one ray per depth-`depth` cell. All rays into one cell are
+				// identical (same sensor, end = cell centre), so whichever thread creates the entry casts it.
+				// Bit 63 keeps cell codes apart from the depth-0 hit codes sharing the table.
+				if (!hitHashInsertUnique(hh, morton3(k0, k1, k2) | (1ULL << 63), &ctl->err)) cast = false;
+			}
+			if (cast) {
 				u32 k0 = toKey1(g, e2.x, depth), k1 = toKey1(g, e2.y, depth), k2 = toKey1(g, e2.z, depth);
 				D3 ec{toCoord1(g, k0, depth), toCoord1(g, k1, depth), toCoord1(g, k2, depth)};
 				D3 cc{toCoord1(g, toKey1(g, cur.x, depth), depth), toCoord1(g, toKey1(g, cur.y, depth), depth),
@@ -276,8 +311,6 @@ __global__ __launch_bounds__(256) void k_select(MapGeom g, D3 sensor, u32 n, u32
 				}
 				has_aabb = true;
 				end = ec;
-			} else {
-				cast = false;
 			}
 		}
 		if (cast) {
@@ -286,9 +319,11 @@ __global__ __launch_bounds__(256) void k_select(MapGeom g, D3 sensor, u32 n, u32
 			if (moveLineInside(g, c2, e3)) {
 				u32 pos = atomicAdd(&ctl->n_rays, 1u);
 				ray_end[pos] = end;
+				const i32 lim = (i32)((1u << (g.L - depth)) - 1u);
 				for (int a = 0; a < 3; ++a) {
-					i32 ka = (i32)(toKey1(g, e3[a], depth) >> depth);
-					i32 kb = (i32)(toKey1(g, c2[a], depth) >> depth);
+					// cells outside [0, 2^(L-depth)) are dropped by gridMark: keep them out of the bbox
+					i32 ka = min(max((i32)(toKey1(g, e3[a], depth) >> depth), 0), lim);
+					i32 kb = min(max((i32)(toKey1(g, c2[a], depth) >> depth), 0), lim);
 					ck[a] = min(ka, kb);
 					ek[a] = max(ka, kb);
 				}
@@ -319,8 +354,15 @@ __global__ __launch_bounds__(256) void k_select(MapGeom g, D3 sensor, u32 n, u32
 // ------------------------------------------------------------------------------------------------
 // grid marking helpers
 // ------------------------------------------------------------------------------------------------
-__device__ inline bool gridMark(const Grid& gr, u32* __restrict__ grid, i32 cx, i32 cy, i32 cz)
+// Cells whose key lies outside the map's key range [0, 2^L) are DROPPED (counted in n_oob): they only
+// arise when a segment is clipped at the map cube and its end rounds onto/over a face; the reference
+// aliases such keys to the opposite side of the map (code.h:245-248 ignores the bits above 3L).
+__device__ inline bool gridMark(const Grid& gr, u32* __restrict__ grid, i32 cx, i32 cy, i32 cz, u32 lim, u32* n_oob)
 {
+	if ((u32)cx >= lim || (u32)cy >= lim || (u32)cz >= lim) {
+		atomicAdd(n_oob, 1u);
+		return true;
+	}
 	i32 lx = cx - gr.base[0], ly = cy - gr.base[1], lz = cz - gr.base[2];
 	i32 bx = lx >> 1, by = ly >> 1, bz = lz >> 1;
 	if ((u32)bx >= (u32)gr.nb[0] || (u32)by >= (u32)gr.nb[1] || (u32)bz >= (u32)gr.nb[2]) return false;
@@ -331,7 +373,7 @@ __device__ inline bool gridMark(const Grid& gr, u32* __restrict__ grid, i32 cx, 
 }
 
 // K_hitmark: unique hits -> grid H (depth 0)
-__global__ __launch_bounds__(256) void k_hitmark(Grid gr, u32* __restrict__ grid, const u64* __restrict__ hit_code,
+__global__ __launch_bounds__(256) void k_hitmark(MapGeom g, Grid gr, u32* __restrict__ grid, const u64* __restrict__ hit_code,
                                                  const ScanCtl* ctl_in, ScanCtl* ctl)
 {
 	u32 n = ctl_in->n_hits;
@@ -348,7 +390,7 @@ __global__ __launch_bounds__(256) void k_hitmark(Grid gr, u32* __restrict__ grid
 			v = (v ^ (v >> 32)) & 0x1fffffULL;
 			k[a] = (u32)v;
 		}
-		if (!gridMark(gr, grid, (i32)k[0], (i32)k[1], (i32)k[2])) atomicOr(&ctl->err, ERR_GRID_OOB);
+		if (!gridMark(gr, grid, (i32)k[0], (i32)k[1], (i32)k[2], 1u << g.L, &ctl->n_oob)) atomicOr(&ctl->err, ERR_GRID_OOB);
 	}
 }
 
@@ -366,6 +408,7 @@ __global__ __launch_bounds__(256) void k_dda(MapGeom g, D3 sensor, u32 depth, Gr
 	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
 	unsigned long long steps = 0;
 	u32 err = 0;
+	const u32 lim = 1u << (g.L - depth);
 	if (i < n) {
 		D3 from = sensor, to = ray_end[i];
 		if (moveLineInside(g, from, to)) {
@@ -386,7 +429,7 @@ __global__ __launch_bounds__(256) void k_dda(MapGeom g, D3 sensor, u32 depth, Gr
 					for (int s = 0; s <= num_steps; ++s) {
 						i32 cx = (i32)(toKey1(g, cur.x, depth) >> depth), cy = (i32)(toKey1(g, cur.y, depth) >> depth),
 						    cz = (i32)(toKey1(g, cur.z, depth) >> depth);
-						if (!gridMark(gr, grid, cx, cy, cz)) err |= ERR_GRID_OOB;
+						if (!gridMark(gr, grid, cx, cy, cz, lim, &ctl->n_oob)) err |= ERR_GRID_OOB;
 						++steps;
 						cur = cur + stepv;
 					}
@@ -396,7 +439,7 @@ __global__ __launch_bounds__(256) void k_dda(MapGeom g, D3 sensor, u32 depth, Gr
 				u32 ex = toKey1(g, end.x, depth), ey = toKey1(g, end.y, depth), ez = toKey1(g, end.z, depth);
 				if (kx == ex && ky == ey && kz == ez) {
 					// OMB:1281-1284
-					if (!gridMark(gr, grid, (i32)(kx >> depth), (i32)(ky >> depth), (i32)(kz >> depth))) err |= ERR_GRID_OOB;
+					if (!gridMark(gr, grid, (i32)(kx >> depth), (i32)(ky >> depth), (i32)(kz >> depth), lim, &ctl->n_oob)) err |= ERR_GRID_OOB;
 					steps = 1;
 				} else {
 					// computeRayInit OCT:1204-1224
@@ -434,7 +477,7 @@ __global__ __launch_bounds__(256) void k_dda(MapGeom g, D3 sensor, u32 depth, Gr
 							err |= ERR_RUNAWAY;
 							break;
 						}
-						if (!gridMark(gr, grid, cx, cy, cz)) err |= ERR_GRID_OOB;
+						if (!gridMark(gr, grid, cx, cy, cz, lim, &ctl->n_oob)) err |= ERR_GRID_OOB;
 						// minElementIndex VEC3:244-251: x<=y ? (x<=z ? x : z) : (y<=z ? y : z)
 						if (tmx <= tmy) {
 							if (tmx <= tmz) {
@@ -468,18 +511,19 @@ __global__ __launch_bounds__(256) void k_dda(MapGeom g, D3 sensor, u32 depth, Gr
 // ------------------------------------------------------------------------------------------------
 // K3 extract: non-zero bytes of the grids -> update list, one entry per touched node block.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_extract(MapGeom g, Grid gr, const u32* __restrict__ gridH,
-                                                 const u32* __restrict__ gridM, Entry* __restrict__ entries,
-                                                 u32 cap, ScanCtl* ctl)
+__global__ __launch_bounds__(256) void k_extract(MapGeom g, Grid gr, const u32* __restrict__ grid, u32 which,
+                                                 Entry* __restrict__ entries, u32 cap, ScanCtl* ctl)
 {
 	u64 nwords = gr.bytes >> 2;
+	const u32 level = gr.depth + 1;
 	for (u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x; w < nwords; w += (u64)gridDim.x * blockDim.x) {
-		u32 h = gridH ? gridH[w] : 0u;
-		u32 m = gridM ? gridM[w] : 0u;
-		if ((h | m) == 0) continue;
+		u32 m = grid[w];
+		if (m == 0) continue;
 		for (u32 b = 0; b < 4; ++b) {
-			u32 hb = (h >> (8 * b)) & 0xFF, mb = (m >> (8 * b)) & 0xFF;
-			if ((hb | mb) == 0) continue;
+			u32 mb = (m >> (8 * b)) & 0xFF;
+			if (mb == 0) continue;
+			u32 pos = atomicAdd(&ctl->n_entries[which], 1u);
+			if (pos >= cap) continue;
 			u64 idx = w * 4 + b;
 			u64 bx = idx % (u64)gr.nb[0];
 			u64 r = idx / (u64)gr.nb[0];
@@ -488,18 +532,14 @@ __global__ __launch_bounds__(256) void k_extract(MapGeom g, Grid gr, const u32* 
 			// absolute block coordinate = (cell >> 1); cells are key >> depth (key includes the +M offset)
 			u32 ax = (u32)((gr.base[0] >> 1) + (i32)bx), ay = (u32)((gr.base[1] >> 1) + (i32)by),
 			    az = (u32)((gr.base[2] >> 1) + (i32)bz);
-			u32 level = gr.depth + 1;
 			u64 p = morton3(ax, ay, az) & ((1ULL << (3 * (g.L - level))) - 1ULL);
-			u32 pos = atomicAdd(&ctl->n_entries, 1u);
-			if (pos < cap) {
-				Entry e;
-				e.lk = (1ULL << (3 * (g.L - level))) | p;
-				e.hit = (u8)hb;
-				e.miss = (u8)mb;
-				e.level = (u8)level;
-				for (int k = 0; k < 5; ++k) e.pad[k] = 0;
-				entries[pos] = e;
-			}
+			Entry e;
+			e.lk = (1ULL << (3 * (g.L - level))) | p;
+			e.hit = which ? 0 : (u8)mb;
+			e.miss = which ? (u8)mb : 0;
+			e.level = (u8)level;
+			for (int k = 0; k < 5; ++k) e.pad[k] = 0;
+			entries[pos] = e;
 		}
 	}
 }

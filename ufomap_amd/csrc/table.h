@@ -12,9 +12,14 @@
 //                    bits 8-15 contains_unknown of child i
 //                    bits 16-23 child i is an inner node with a live block of its own
 //                    bit 24 DIRTY (queued for propagation), 25 DEAD (collapsed: the node is a leaf
-//                    again, octree.h:1060-1066), 26 TRANSIENT (a child changed and changed back)
+//                    again, octree.h:1060-1066)
 //   parent[s]  u32   slot of the block that holds this node's own value (NONE for the root)
-//   stamp[s]   u32   id of the scan that created / revived the block ("new this scan")
+//   stamp[s]   u32   id of the phase that created / revived the block ("new this phase")
+//   tmax[s]    u64   (phase tag << 40) | (time of the last update beneath this node << 3) | child index
+//                    that update lies under ("time": point index for hits = cloud order, 0 for misses =
+//                    ascending code order; see map_kernels.h "last-update chain")
+//   lu_*[s]          last-update record of the node for the current phase: did its last update reach it
+//                    and change its summary, and the summary it had just before that update
 //
 // A node's own value lives in its parent's block; the root's value lives in MapRoot.
 // Open addressing, linear probing, power-of-two capacity; blocks are never removed (a collapsed
@@ -31,7 +36,6 @@ enum : u32 {
 	F_INNER = 0x00FF0000u,
 	F_DIRTY = 1u << 24,
 	F_DEAD = 1u << 25,
-	F_TRANS = 1u << 26,
 	NONE = 0xFFFFFFFFu,
 };
 
@@ -49,6 +53,11 @@ struct Table {
 	u32* flags;
 	u32* parent;
 	u32* stamp;
+	u64* tmax;
+	u32* lu_phase;
+	float* lu_occ;
+	u32* lu_fl;   // bit0/1 = contains_free/unknown of the pre-last summary, bit 8 = "reached and changed"
+	u32* lu_rgb;  // colour maps only
 	MapRoot* root;
 	u32 mask;  // capacity - 1
 };

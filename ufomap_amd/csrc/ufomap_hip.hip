@@ -83,6 +83,15 @@ struct PendingEvent {
 	int stat;
 };
 
+struct TableBufs {
+	DevBuf keys, occ, rgb, flags, parent, stamp, tmax, luph, luocc, lufl, lurgb;
+	void release()
+	{
+		DevBuf* all[] = {&keys, &occ, &rgb, &flags, &parent, &stamp, &tmax, &luph, &luocc, &lufl, &lurgb};
+		for (DevBuf* b : all) b->release();
+	}
+};
+
 inline u32 nextPow2(u64 v)
 {
 	u64 p = 1;
@@ -98,7 +107,8 @@ struct ufomap_map {
 	MapGeom g{};
 	// node table
 	Table t{};
-	DevBuf b_keys, b_occ, b_rgb, b_flags, b_parent, b_stamp, b_root;
+	TableBufs tb;
+	DevBuf b_root;
 	u32 scan_id = 0;
 	u64 used_est = 0;  // host-side view of MapRoot::used (refreshed at every control-block read)
 	// per-scan buffers
@@ -191,9 +201,21 @@ inline dim3 gridFor(u64 n, u32 block = 256, u32 maxBlocks = 4096)
 	return dim3((u32)b);
 }
 
-int allocTable(ufomap_map* m, u32 cap, Table* out, DevBuf* keys, DevBuf* occ, DevBuf* rgb, DevBuf* flags, DevBuf* parent,
-               DevBuf* stamp)
+int allocTable(ufomap_map* m, u32 cap, Table* out, TableBufs* tb)
 {
+	DevBuf *keys = &tb->keys, *occ = &tb->occ, *rgb = &tb->rgb, *flags = &tb->flags, *parent = &tb->parent, *stamp = &tb->stamp;
+	HIP_TRY(tb->tmax.reserve((size_t)cap * 8));
+	HIP_TRY(tb->luph.reserve((size_t)cap * 4));
+	HIP_TRY(tb->luocc.reserve((size_t)cap * 4));
+	HIP_TRY(tb->lufl.reserve((size_t)cap * 4));
+	if (m->g.color) HIP_TRY(tb->lurgb.reserve((size_t)cap * 4));
+	HIP_TRY(hipMemsetAsync(tb->tmax.p, 0, (size_t)cap * 8, m->stream));
+	HIP_TRY(hipMemsetAsync(tb->luph.p, 0, (size_t)cap * 4, m->stream));
+	out->tmax = tb->tmax.as<u64>();
+	out->lu_phase = tb->luph.as<u32>();
+	out->lu_occ = tb->luocc.as<float>();
+	out->lu_fl = tb->lufl.as<u32>();
+	out->lu_rgb = m->g.color ? tb->lurgb.as<u32>() : nullptr;
 	HIP_TRY(keys->reserve((size_t)cap * 8));
 	HIP_TRY(occ->reserve((size_t)cap * 32));
 	if (m->g.color) HIP_TRY(rgb->reserve((size_t)cap * 32));
@@ -218,8 +240,8 @@ int allocTable(ufomap_map* m, u32 cap, Table* out, DevBuf* keys, DevBuf* occ, De
 int growTable(ufomap_map* m, u32 new_cap)
 {
 	Table nt{};
-	DevBuf k, o, r, f, p, s;
-	int rc = allocTable(m, new_cap, &nt, &k, &o, &r, &f, &p, &s);
+	TableBufs nb;
+	int rc = allocTable(m, new_cap, &nt, &nb);
 	if (rc) return rc;
 	u32* d_fail = m->b_ctl.as<u32>() + (sizeof(ScanCtl) + 3) / 4;  // spare word after the control block
 	HIP_TRY(hipMemsetAsync(d_fail, 0, 4, m->stream));
@@ -232,18 +254,8 @@ int growTable(ufomap_map* m, u32 new_cap)
 		hipLaunchKernelGGL(k_rehash_parents, gridFor((u64)new_cap), dim3(256), 0, m->stream, nt);
 	}
 	HIP_TRY(hipStreamSynchronize(m->stream));
-	m->b_keys.release();
-	m->b_occ.release();
-	m->b_rgb.release();
-	m->b_flags.release();
-	m->b_parent.release();
-	m->b_stamp.release();
-	m->b_keys = k;
-	m->b_occ = o;
-	m->b_rgb = r;
-	m->b_flags = f;
-	m->b_parent = p;
-	m->b_stamp = s;
+	m->tb.release();
+	m->tb = nb;
 	m->t = nt;
 	return UFOMAP_OK;
 }
@@ -332,26 +344,18 @@ int makeGrid(const i32 mn[3], const i32 mx[3], u32 depth, Grid* gr)
 }
 
 // One phase of the map update: entries of one level -> ensure, init, apply, propagate.
-int applyEntries(ufomap_map* m, const Entry* d_entries, u32 n_entries, u32 level, const i32 nb[3], float miss,
+int applyEntries(ufomap_map* m, const Entry* d_entries, u32 n_entries, u32 which, u32 level, const i32 nb[3], float upd,
                  const uint8_t* d_rgb)
 {
 	if (0 == n_entries) return UFOMAP_OK;
-	// size the table for the worst case of this phase (true upper bound, see blockBound)
-	u64 need = m->used_est + blockBound(m, n_entries, nb, level);
-	u64 cap = (u64)m->t.mask + 1;
-	if (need * 5 > cap * 3) {  // keep the load factor <= 0.6
-		u64 want = need * 2;
-		if (want > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
-		int rc = growTable(m, nextPow2(want));
-		if (rc) return rc;
-	}
+	m->scan_id += 1;  // "new this phase" stamp: blocks made by an earlier phase of the same scan are old
 	u64 newcap = blockBound(m, n_entries, nb, level);
 	HIP_TRY(m->b_ent_slot.reserve((size_t)n_entries * 4));
 	HIP_TRY(m->b_newlist.reserve((size_t)newcap * 4));
 	HIP_TRY(m->b_wl0.reserve(((size_t)n_entries + 8) * 4));
 	HIP_TRY(m->b_wl1.reserve(((size_t)n_entries + 8) * 4));
 	ScanCtl* ctl = m->b_ctl.as<ScanCtl>();
-	const u32* d_n = &ctl->n_entries;
+	const u32* d_n = &ctl->n_entries[which];
 	HIP_TRY(hipMemsetAsync(&ctl->n_new, 0, 4, m->stream));
 	HIP_TRY(hipMemsetAsync(&ctl->wl_count[0], 0, 8, m->stream));
 	HitHash hh{m->b_hh_keys.as<u64>(), m->b_hh_idx.as<u32>(), m->hh_mask};
@@ -368,12 +372,12 @@ int applyEntries(ufomap_map* m, const Entry* d_entries, u32 n_entries, u32 level
 	}
 	if (1 == level) {
 		ProfScope ps(m, "k_apply_leaf");
-		hipLaunchKernelGGL(k_apply_leaf, ge, dim3(256), 0, m->stream, m->t, m->g, d_entries, d_n, m->b_ent_slot.as<u32>(), miss, hh,
-		                   d_rgb, m->b_wl0.as<u32>(), ctl);
+		hipLaunchKernelGGL(k_apply_leaf, ge, dim3(256), 0, m->stream, m->t, m->g, d_entries, d_n, m->b_ent_slot.as<u32>(), upd,
+		                   (u32)(which == 0 ? 1 : 0), m->scan_id, hh, d_rgb, m->b_wl0.as<u32>(), ctl);
 	} else {
 		ProfScope ps(m, "k_apply_coarse");
-		hipLaunchKernelGGL(k_apply_coarse, ge, dim3(256), 0, m->stream, m->t, m->g, d_entries, d_n, m->b_ent_slot.as<u32>(), miss,
-		                   m->b_wl0.as<u32>(), ctl);
+		hipLaunchKernelGGL(k_apply_coarse, ge, dim3(256), 0, m->stream, m->t, m->g, d_entries, d_n, m->b_ent_slot.as<u32>(), upd,
+		                   m->scan_id, m->b_wl0.as<u32>(), ctl);
 	}
 	// updateParents, one launch per level (OMB:1126-1133)
 	u32 idx = 0;
@@ -384,7 +388,7 @@ int applyEntries(ufomap_map* m, const Entry* d_entries, u32 n_entries, u32 level
 		hipLaunchKernelGGL(k_reset_wl, dim3(1), dim3(1), 0, m->stream, ctl, idx ^ 1);
 		u64 est = std::max<u64>(1, (u64)n_entries >> (3 * std::min<u32>(l - level - 1, 10)));
 		hipLaunchKernelGGL(k_propagate, gridFor(std::max<u64>(est, 256), 256, 1024), dim3(256), 0, m->stream, m->t, m->g, in, out,
-		                   idx, ctl);
+		                   idx, m->scan_id, ctl);
 		idx ^= 1;
 	}
 	HIP_TRY(hipGetLastError());
@@ -402,6 +406,7 @@ int finishPending(ufomap_map* m)
 	if (rc) return rc;
 	m->counts[2] = m->h_ctl->n_steps;
 	m->counts[6] = m->h_ctl->n_new;
+	m->counts[7] = m->h_ctl->n_oob;
 	for (int a = 0; a < 3; ++a) {
 		double lo = decD(m->h_ctl->aabb_min[a]), hi = decD(m->h_ctl->aabb_max[a]);
 		if (m->h_ctl->aabb_min[a] != ~0ull) {
@@ -509,12 +514,6 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 	}
 	m->haveH = n_hits > 0;
 	m->haveM = n_rays > 0;
-	if (0 == depth && m->haveH && m->haveM) {
-		for (int a = 0; a < 3; ++a) {
-			hmn[a] = mmn[a] = std::min(hmn[a], mmn[a]);
-			hmx[a] = mmx[a] = std::max(hmx[a], mmx[a]);
-		}
-	}
 	if (m->haveH && makeGrid(hmn, hmx, 0, &m->gridH))
 		return fail(UFOMAP_ERR_CAPACITY, "hit bounding box too large for the scan grid");
 	if (m->haveM && makeGrid(mmn, mmx, (u32)depth, &m->gridM))
@@ -527,7 +526,7 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 		HIP_TRY(m->b_gridH.reserve(m->gridH.bytes));
 		HIP_TRY(hipMemsetAsync(m->b_gridH.p, 0, m->gridH.bytes, m->stream));
 		ProfScope ps(m, "k_hitmark");
-		hipLaunchKernelGGL(k_hitmark, gridFor(n_hits), dim3(256), 0, m->stream, m->gridH, m->b_gridH.as<u32>(), m->b_hit_code.as<u64>(),
+		hipLaunchKernelGGL(k_hitmark, gridFor(n_hits), dim3(256), 0, m->stream, m->g, m->gridH, m->b_gridH.as<u32>(), m->b_hit_code.as<u64>(),
 		                   ctl, ctl);
 	}
 	if (m->haveM) {
@@ -543,54 +542,57 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 			                   m->b_ray_end.as<D3>(), ctl, ctl);
 	}
 
-	// ---- map phase(s) ----------------------------------------------------------------------------
+	// ---- map phases: all hits, then all misses (OMB:1351-1365) ------------------------------------------
 	const float miss = (float)(m->g.miss_log / double((2.0 * depth) + 1));  // OMB:311
-	struct Phase {
-		const u32* H;
-		const u32* M;
-		Grid gr;
-		u32 level;
-	};
-	std::vector<Phase> phases;
-	if (0 == depth) {
-		if (m->haveH || m->haveM)
-			phases.push_back(Phase{m->haveH ? m->b_gridH.as<u32>() : nullptr, m->haveM ? m->b_gridM.as<u32>() : nullptr,
-			                       m->haveM ? m->gridM : m->gridH, 1});
-	} else {
-		if (m->haveH) phases.push_back(Phase{m->b_gridH.as<u32>(), nullptr, m->gridH, 1});
-		if (m->haveM) phases.push_back(Phase{nullptr, m->b_gridM.as<u32>(), m->gridM, (u32)depth + 1});
+	HIP_TRY(hipMemsetAsync(&ctl->n_entries[0], 0, 8, m->stream));
+	if (m->haveH) {
+		ProfScope ps(m, "k_extract_count");
+		hipLaunchKernelGGL(k_extract, gridFor(m->gridH.bytes >> 2, 256, 8192), dim3(256), 0, m->stream, m->g, m->gridH,
+		                   m->b_gridH.as<u32>(), 0u, (Entry*)nullptr, 0u, ctl);
 	}
-	bool first = true;
-	for (Phase& ph : phases) {
-		// pass 1: count the touched node blocks; pass 2: emit them
-		HIP_TRY(hipMemsetAsync(&ctl->n_entries, 0, 4, m->stream));
-		{
-			ProfScope ps(m, "k_extract_count");
-			hipLaunchKernelGGL(k_extract, gridFor(ph.gr.bytes >> 2, 256, 8192), dim3(256), 0, m->stream, m->g, ph.gr, ph.H, ph.M,
-			                   (Entry*)nullptr, 0u, ctl);
-		}
-		rc = readCtl(m);
-		if (rc) return rc;
-		if (first) {
-			// all rays have been walked: a runaway ray aborts BEFORE the map is touched
-			rc = ctlError(m);
+	if (m->haveM) {
+		ProfScope ps(m, "k_extract_count");
+		hipLaunchKernelGGL(k_extract, gridFor(m->gridM.bytes >> 2, 256, 8192), dim3(256), 0, m->stream, m->g, m->gridM,
+		                   m->b_gridM.as<u32>(), 1u, (Entry*)nullptr, 0u, ctl);
+	}
+	rc = readCtl(m);
+	if (rc) return rc;
+	// all rays have been walked: a runaway ray aborts BEFORE the map is touched
+	rc = ctlError(m);
+	if (rc) return rc;
+	const u32 ne_h = m->h_ctl->n_entries[0], ne_m = m->h_ctl->n_entries[1];
+	m->counts[5] = (u64)ne_h + ne_m;
+	{
+		// size the table for the worst case of both phases (true upper bound, see blockBound)
+		u64 need = m->used_est;
+		if (ne_h) need += blockBound(m, ne_h, m->gridH.nb, 1);
+		if (ne_m) need += blockBound(m, ne_m, m->gridM.nb, (u32)depth + 1);
+		u64 cap = (u64)m->t.mask + 1;
+		if (need * 5 > cap * 3) {  // keep the load factor <= 0.6
+			u64 want = need * 2;
+			if (want > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
+			rc = growTable(m, nextPow2(want));
 			if (rc) return rc;
-			first = false;
 		}
-		u32 n_entries = m->h_ctl->n_entries;
-		if (ph.M) m->counts[4] = 0;  // filled by last_misses on demand
-		m->counts[5] += n_entries;
-		if (0 == n_entries) continue;
-		HIP_TRY(m->b_entries.reserve((size_t)n_entries * sizeof(Entry)));
-		HIP_TRY(hipMemsetAsync(&ctl->n_entries, 0, 4, m->stream));
-		{
-			ProfScope ps(m, "k_extract");
-			hipLaunchKernelGGL(k_extract, gridFor(ph.gr.bytes >> 2, 256, 8192), dim3(256), 0, m->stream, m->g, ph.gr, ph.H, ph.M,
-			                   m->b_entries.as<Entry>(), n_entries, ctl);
-		}
-		rc = applyEntries(m, m->b_entries.as<Entry>(), n_entries, ph.level, ph.gr.nb, miss, d_rgb);
-		if (rc) return rc;
 	}
+	HIP_TRY(m->b_entries.reserve(((size_t)ne_h + ne_m + 1) * sizeof(Entry)));
+	Entry* ent_h = m->b_entries.as<Entry>();
+	Entry* ent_m = ent_h + ne_h;
+	HIP_TRY(hipMemsetAsync(&ctl->n_entries[0], 0, 8, m->stream));
+	if (ne_h) {
+		ProfScope ps(m, "k_extract");
+		hipLaunchKernelGGL(k_extract, gridFor(m->gridH.bytes >> 2, 256, 8192), dim3(256), 0, m->stream, m->g, m->gridH,
+		                   m->b_gridH.as<u32>(), 0u, ent_h, ne_h, ctl);
+	}
+	if (ne_m) {
+		ProfScope ps(m, "k_extract");
+		hipLaunchKernelGGL(k_extract, gridFor(m->gridM.bytes >> 2, 256, 8192), dim3(256), 0, m->stream, m->g, m->gridM,
+		                   m->b_gridM.as<u32>(), 1u, ent_m, ne_m, ctl);
+	}
+	rc = applyEntries(m, ent_h, ne_h, 0, 1, m->gridH.nb, m->g.hit, d_rgb);
+	if (rc) return rc;
+	rc = applyEntries(m, ent_m, ne_m, 1, (u32)depth + 1, m->gridM.nb, miss, nullptr);
+	if (rc) return rc;
 	(void)after_select;
 	HIP_TRY(hipGetLastError());
 	m->pending = true;
@@ -664,7 +666,7 @@ ufomap_map* ufomap_map_create(double resolution, unsigned depth_levels, int auto
 		ufomap_map_destroy(m);
 		return nullptr;
 	}
-	if (allocTable(m, 1u << 16, &m->t, &m->b_keys, &m->b_occ, &m->b_rgb, &m->b_flags, &m->b_parent, &m->b_stamp) ||
+	if (allocTable(m, 1u << 16, &m->t, &m->tb) ||
 	    resetRoot(m)) {
 		ufomap_map_destroy(m);
 		return nullptr;
@@ -681,7 +683,8 @@ void ufomap_map_destroy(ufomap_map* m)
 	if (!m) return;
 	(void)hipSetDevice(m->device);
 	if (m->stream) (void)hipStreamSynchronize(m->stream);
-	DevBuf* bufs[] = {&m->b_keys,    &m->b_occ,     &m->b_rgb,      &m->b_flags,   &m->b_parent,  &m->b_stamp,   &m->b_root,
+	m->tb.release();
+	DevBuf* bufs[] = {&m->b_root,
 	                  &m->b_ctl,     &m->b_pt_end,  &m->b_pt_flag,  &m->b_pt_slot, &m->b_ray_end, &m->b_hit_code, &m->b_hit_pt,
 	                  &m->b_hh_keys, &m->b_hh_idx,  &m->b_gridH,    &m->b_gridM,   &m->b_entries, &m->b_ent_slot, &m->b_newlist,
 	                  &m->b_wl0,     &m->b_wl1,     &m->b_in_xyz,   &m->b_in_rgb,  &m->b_codes,   &m->b_dump};
@@ -993,7 +996,6 @@ int ufomap_map_last_counts(ufomap_map* m, uint64_t counts[8])
 	if (!m) return fail(UFOMAP_ERR_INVALID, "null map");
 	int rc = ufomap_map_wait(m);
 	for (int k = 0; k < 8; ++k) counts[k] = m->counts[k];
-	counts[7] = m->used_est;
 	return rc;
 }
 

@@ -172,7 +172,7 @@ class OccupancyMapBase:
     def last_counts(self):
         c = np.zeros(8, np.uint64)
         capi.check(self._lib.ufomap_map_last_counts(self._h, _p(c, C.c_uint64)))
-        keys = ["points", "rays", "steps", "hits", "miss_cells", "blocks_touched", "blocks_created", "blocks_used"]
+        keys = ["points", "rays", "steps", "hits", "miss_cells", "blocks_touched", "blocks_created", "oob_dropped"]
         return dict(zip(keys, (int(v) for v in c)))
 
     def set_profiling(self, on=True):
