@@ -1,0 +1,199 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the scan-integration hot path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W          (N = 1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W          (N > 1, one rank per GPU)
+
+One *step* = one pass of the hot path over one scan: BASELINE.json configs[1] -- a single synthetic
+64-beam LiDAR scan (131 072 points), 16 cm leaf, 20 m max range, insertPointCloudDiscrete (discrete
+integrator + free-space ray cast) into a GPU-resident linear-hashed octree.  Inputs are resident in
+HBM before the timed region starts.  At N > 1 every rank integrates its own scan (the 8 sensor
+poses of configs[3]) and the ranks exchange their per-scan update lists over RCCL so that every
+replica of the map applies all N scans in rank order ("scaling": "weak").
+
+Prints ONE JSON line on rank 0:  metric/value/unit = integrated rays/s (input points per second,
+whole job), ms_per_step, plus
+  roofline     -- dominant kernel (k_dda): algorithmic bytes per launch / HIP-event duration vs 8 TB/s
+  cpu_baseline -- the reference (oracle/_ref) or the oracle port timed on this box's host cores
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+RES, MAX_RANGE, DEPTH = 0.16, 20.0, 0
+P_BYTES = 24  # bytes per input point (3 x f64), SURVEY 8(d)
+
+
+def algorithmic_bytes(n_points, hit_codes, miss_codes, steps, levels=16):
+    """B_scan = P*N + 16*S + 16*(U_h+U_f) + 40*sum_d U_d, counted for the exact input."""
+    touched = np.union1d(hit_codes, miss_codes)
+    sum_ud = 0
+    k = touched
+    for _ in range(1, levels + 1):
+        k = np.unique(k >> np.uint64(3))
+        sum_ud += len(k)
+    terms = dict(points=P_BYTES * n_points, keys=16 * steps, cells=16 * (len(hit_codes) + len(miss_codes)), parents=40 * sum_ud)
+    return sum(terms.values()), terms, sum_ud
+
+
+def cpu_baseline(origin, xyz, budget_s=12.0):
+    """Reference (or port) on the host cores: same scan, same call; fresh map + warm repeats."""
+    from oracle import OracleMap, available, build
+    build("port")
+    kind = "reference" if available("reference") else "port"
+    m = OracleMap(RES, kind=kind)
+    times = []
+    t_start = time.perf_counter()
+    while time.perf_counter() - t_start < budget_s or len(times) < 3:
+        t0 = time.perf_counter()
+        m.insert(origin, xyz, max_range=MAX_RANGE, depth=DEPTH, discrete=True)
+        times.append(time.perf_counter() - t0)
+    warm = float(np.median(times[1:]))
+    return dict(value=xyz.shape[0] / warm, unit="rays/s", cores=2 if kind == "reference" else 1, kind=kind,
+                sample=f"{len(times)} integrations of the same 131072-pt scan into one map on the host "
+                       f"(first/fresh {times[0] * 1e3:.1f} ms, warm median {warm * 1e3:.1f} ms)",
+                ms_per_scan_fresh=times[0] * 1e3, ms_per_scan_warm=warm * 1e3)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-kernels", type=int, default=1, help="bracket every kernel with HIP events in the timed region")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from ufomap_amd import OccupancyMap, scans
+
+    # this rank's scan: pose/seed of BASELINE configs[1] at N=1, the batch poses of configs[3] at N>1
+    if world == 1:
+        origin, xyz, _ = scans.lidar64()
+    else:
+        origin, xyz, _ = scans.lidar64(origin=scans.lidar_pose(rank % 8), seed=100 + rank % 8)
+    n_pts = xyz.shape[0]
+    d_xyz = torch.from_numpy(xyz).to(torch.device("cuda", local_rank))  # resident in HBM before timing
+    m = OccupancyMap(RES, device=local_rank)
+
+    if world > 1:
+        from ufomap_amd import dist as udist
+        batch = udist.BatchIntegrator(m, dist.group.WORLD, torch.device("cuda", local_rank))
+
+        def step():
+            batch.integrate(origin, d_xyz.data_ptr(), n_pts, MAX_RANGE, DEPTH, discrete=True)
+    else:
+        def step():
+            m.insert_device(origin, d_xyz.data_ptr(), None, n_pts, MAX_RANGE, DEPTH, discrete=True, async_=True)
+
+    def sync():
+        m.insertPointCloudWait()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    m.reset_kernel_times()
+    m.set_profiling(bool(args.profile_kernels))
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    m.set_profiling(False)
+    ktimes = m.kernel_times()
+
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=torch.device("cuda", local_rank))
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        # counts of the exact input (from the last integration) for the algorithmic-byte formula
+        if world == 1:
+            counts = m.last_counts()
+            hits, misses = m.last_hits(), m.last_misses()
+        else:
+            m2 = OccupancyMap(RES, device=local_rank)
+            m2.insert_device(origin, d_xyz.data_ptr(), None, n_pts, MAX_RANGE, DEPTH, discrete=True)
+            counts = m2.last_counts()
+            hits, misses = m2.last_hits(), m2.last_misses()
+        b_scan, terms, sum_ud = algorithmic_bytes(n_pts, hits, misses, counts["steps"])
+        ms_per_step = dt / args.steps * 1e3
+        value = n_pts * world * args.steps / dt
+        # dominant kernel = largest total time among the hot-path kernels
+        roof = None
+        kern_ms = {k: (v["total_ms"] / max(v["launches"], 1)) for k, v in ktimes.items() if v["launches"]}
+        per_step_ms = {k: v["total_ms"] / args.steps for k, v in ktimes.items() if v["launches"]}
+        if kern_ms:
+            dom = max(per_step_ms, key=per_step_ms.get)
+            # k_dda fuses key emission and de-duplication: its share of B_scan is the ray list plus the
+            # 16*S key term; any other kernel is priced with its own term
+            share = dict(k_dda=P_BYTES * counts["rays"] + 16 * counts["steps"]).get(dom, b_scan)
+            dur_s = kern_ms[dom] * 1e-3
+            achieved = share / dur_s / 1e9
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+            if os.path.exists(pmc):
+                try:
+                    traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            roof = dict(bound="hbm", kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
+                        traffic=traffic, algorithmic_bytes_per_launch=share, avg_launch_us=kern_ms[dom] * 1e3,
+                        whole_scan=dict(algorithmic_bytes=b_scan, terms=terms, achieved_GBs=b_scan / (ms_per_step * 1e-3) / 1e9,
+                                        frac=b_scan / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS),
+                        kernels_us_per_step={k: round(v * 1e3, 2) for k, v in sorted(per_step_ms.items(), key=lambda kv: -kv[1])})
+        out = {
+            "metric": "integrated rays/sec (input points per second, insertPointCloudDiscrete, 16 cm leaf, 20 m max-range)",
+            "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64 ray casting / u64 Morton keys / f32 log-odds", "data": "synthetic",
+            "config": {"workload": "configs[1]: single synthetic 64-beam LiDAR scan, 131072 pts, 16 cm leaf, 20 m max-range, discrete integrator + free-space raycast, warm map"
+                       if world == 1 else "configs[3]: batch of N concurrent 131072-pt LiDAR scans, 16 cm leaf, one scan per GPU, RCCL exchange of update lists, every replica applies all N in order",
+                       "points_per_scan": n_pts, "rays_cast": counts["rays"], "dda_steps": counts["steps"], "unique_hits": int(len(hits)),
+                       "unique_miss_cells": int(len(misses)), "sum_U_d": sum_ud, "leaf_m": RES, "max_range_m": MAX_RANGE,
+                       "depth_levels": 16, "parallelism": f"scan-per-gpu x{world}"},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(origin, xyz)
+            out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -168,12 +168,15 @@ __device__ inline bool sameSumm(const MapGeom& g, const Summ& a, const Summ& b)
 // summary, and the summary it had just before that update; tmax tells the parent which child carries
 // the last update.
 #define UFO_TAG(phase) ((u64)((phase)&0xFFFFFFu))
-__device__ inline void publishLast(const Table& t, const MapGeom& g, u32 s, u32 phase, bool reachchg, const Summ& pre)
+// The record lives in the PARENT's arrays at [8*parent + child index], so the parent reads it without a
+// hash lookup. lu_fl: bits 0-1 flags of the pre-last summary, bit 8 "reached and changed", bits 9.. phase tag.
+__device__ inline void publishLast(const Table& t, const MapGeom& g, u32 s, u64 lk, u32 phase, bool reachchg, const Summ& pre)
 {
-	t.lu_occ[s] = pre.occ;
-	t.lu_fl[s] = (pre.fl & 3u) | (reachchg ? 0x100u : 0u);
-	if (g.color) t.lu_rgb[s] = pre.rgb;
-	t.lu_phase[s] = phase;
+	if (1 == lk) return;
+	size_t at = 8 * (size_t)t.parent[s] + (size_t)(lk & 7);
+	t.lu_occ[at] = pre.occ;
+	if (g.color) t.lu_rgb[at] = pre.rgb;
+	t.lu_fl[at] = (pre.fl & 3u) | (reachchg ? 0x100u : 0u) | ((phase & 0x3FFFFFu) << 9);
 }
 // carry the time of the last update beneath block s up the tree (max-reduction with early exit)
 __device__ inline void carryTime(const Table& t, u32 s, u64 lk, u32 phase, u64 time)
@@ -194,18 +197,21 @@ __device__ inline bool lastReached(const Table& t, const MapGeom& g, u32 s, u64 
 	u64 tv = t.tmax[s];
 	if ((tv >> 40) != UFO_TAG(phase)) return false;
 	int c = (int)(tv & 7);
-	u32 cs = tableFind(t, (lk << 3) | (u64)c);
-	if (cs == NONE || t.lu_phase[cs] != phase) return false;
-	u32 lf = t.lu_fl[cs];
-	if (!(lf & 0x100u)) return false;
-	*pre = blockSummary(t, g, s, level, f, c, t.lu_occ[cs], lf & 3u, g.color ? t.lu_rgb[cs] : 0u);
+	size_t at = 8 * (size_t)s + (size_t)c;
+	u32 lf = t.lu_fl[at];
+	if ((lf >> 9) != (phase & 0x3FFFFFu) || !(lf & 0x100u)) return false;
+	*pre = blockSummary(t, g, s, level, f, c, t.lu_occ[at], lf & 3u, g.color ? t.lu_rgb[at] : 0u);
 	return true;
 }
 
-__device__ inline void markDirty(const Table& t, u32 p, u32* __restrict__ wl, u32* wl_count)
+// Queue block p for the next propagation level. `want` may differ per lane; the append is one atomic
+// per wave, so every active lane of the wave must make this call.
+__device__ inline void markDirty(const Table& t, bool want, u32 p, u32* __restrict__ wl, u32* wl_count)
 {
-	u32 old = atomicOr(&t.flags[p], F_DIRTY);
-	if (!(old & F_DIRTY)) wl[atomicAdd(wl_count, 1u)] = p;
+	bool first = false;
+	if (want) first = !(atomicOr(&t.flags[p], F_DIRTY) & F_DIRTY);
+	u32 pos = waveAppend(wl_count, first);
+	if (first) wl[pos] = p;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -214,42 +220,58 @@ __device__ inline void markDirty(const Table& t, u32 p, u32* __restrict__ wl, u3
 // already existed (its ancestors exist by induction).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_ensure(Table t, MapGeom g, const Entry* __restrict__ entries,
-                                                const u32* n_entries_p, u32 scan_id, u32* __restrict__ ent_slot,
+                                                const u32* n_entries_p, u32 ent_cap, u32 scan_id, u32* __restrict__ ent_slot,
                                                 u32* __restrict__ newlist, u32 newcap, ScanCtl* ctl)
 {
 	u32 n = *n_entries_p;
 	const u32 max_probe = (t.mask >> 1) + 1;
-	for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-		u64 lk = entries[i].lk;
-		bool cr;
-		u32 s = tableEnsure(t, lk, scan_id, max_probe, &cr);
-		ent_slot[i] = s;
-		if (s == NONE) {
-			atomicOr(&ctl->err, ERR_TABLE_FULL);
-			continue;
-		}
-		while (cr) {
-			u32 pos = atomicAdd(&ctl->n_new, 1u);
-			if (pos < newcap) newlist[pos] = s;
-			else atomicOr(&ctl->err, ERR_TABLE_FULL);
-			if (1 == lk) {
-				t.parent[s] = NONE;
-				break;
-			}
-			u64 plk = lk >> 3;
-			bool pcr;
-			u32 ps = tableEnsure(t, plk, scan_id, max_probe, &pcr);
-			if (ps == NONE) {
+	u32 n_created = 0;
+	if (n > ent_cap) {
+		// the update list did not fit the buffer: nothing may be applied (the host retries)
+		if (0 == blockIdx.x && 0 == threadIdx.x) atomicOr(&ctl->err, ERR_ENTRIES);
+		return;
+	}
+	if (0 == ctl->err) {  // e.g. a runaway ray: leave the map untouched
+		for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+			u64 lk = entries[i].lk;
+			bool cr;
+			u32 s = tableEnsure(t, lk, scan_id, max_probe, &cr, &n_created);
+			ent_slot[i] = s;
+			if (s == NONE) {
 				atomicOr(&ctl->err, ERR_TABLE_FULL);
-				break;
+				continue;
 			}
-			t.parent[s] = ps;
-			atomicOr(&t.flags[ps], 1u << (16 + (u32)(lk & 7)));
-			s = ps;
-			lk = plk;
-			cr = pcr;
+			while (cr) {
+				// divergent loop: aggregate the append over the lanes that are in this iteration
+				const u64 act = __ballot(1);
+				const int leader = __ffsll((unsigned long long)act) - 1;
+				u32 base = 0;
+				if ((int)__lane_id() == leader) base = atomicAdd(&ctl->n_new, (u32)__popcll(act));
+				base = __shfl(base, leader);
+				u32 pos = base + (u32)__popcll(act & ((1ULL << __lane_id()) - 1ULL));
+				if (pos < newcap) newlist[pos] = s;
+				else atomicOr(&ctl->err, ERR_TABLE_FULL);
+				if (1 == lk) {
+					t.parent[s] = NONE;
+					break;
+				}
+				u64 plk = lk >> 3;
+				bool pcr;
+				u32 ps = tableEnsure(t, plk, scan_id, max_probe, &pcr, &n_created);
+				if (ps == NONE) {
+					atomicOr(&ctl->err, ERR_TABLE_FULL);
+					break;
+				}
+				t.parent[s] = ps;
+				atomicOr(&t.flags[ps], 1u << (16 + (u32)(lk & 7)));
+				s = ps;
+				lk = plk;
+				cr = pcr;
+			}
 		}
 	}
+	for (int o = 32; o > 0; o >>= 1) n_created += __shfl_xor(n_created, o);
+	if (__lane_id() == 0 && n_created) atomicAdd(&t.root->used, n_created);
 }
 
 // S2 init: children of a new block inherit the whole value of the node (createChildren,
@@ -379,10 +401,10 @@ __global__ __launch_bounds__(256) void k_apply_leaf(Table t, MapGeom g, const En
 		Summ sm = blockSummary(t, g, s, 1, 0);
 		// summary just before the last update of this block (level 1 is always reached: OMB:1128 starts at 1)
 		Summ pre = blockSummary(t, g, s, 1, 0, c_last, v_old_last, 0, old_rgb_last);
-		publishLast(t, g, s, phase, !sameSumm(g, pre, sm), pre);
+		publishLast(t, g, s, e.lk, phase, !sameSumm(g, pre, sm), pre);
 		carryTime(t, s, e.lk, phase, t_last);
 		if (sm.collapsible) collapseBlock(t, s, e.lk);
-		if (writeToParent(t, g, s, e.lk, sm)) markDirty(t, t.parent[s], wl, &ctl->wl_count[0]);
+		markDirty(t, writeToParent(t, g, s, e.lk, sm), t.parent[s], wl, &ctl->wl_cnt[2]);
 	}
 }
 
@@ -499,9 +521,13 @@ __global__ __launch_bounds__(256) void k_apply_coarse(Table t, MapGeom g, const 
 				if (sm.collapsible) collapseBlock(t, s, e.lk);
 			}
 			fin = sm;
-			if (writeToParent(t, g, s, e.lk, sm) && 1 != e.lk) markDirty(t, t.parent[s], wl, &ctl->wl_count[0]);
+			if (writeToParent(t, g, s, e.lk, sm) && 1 != e.lk) {
+				// divergent context (few coarse entries): plain append
+				u32 pp = t.parent[s];
+				if (!(atomicOr(&t.flags[pp], F_DIRTY) & F_DIRTY)) wl[atomicAdd(&ctl->wl_cnt[level + 1], 1u)] = pp;
+			}
 		}
-		publishLast(t, g, s, phase, last_reached && !sameSumm(g, pre, fin), pre);
+		publishLast(t, g, s, e.lk, phase, last_reached && !sameSumm(g, pre, fin), pre);
 		carryTime(t, s, e.lk, phase, 0);
 	}
 }
@@ -510,13 +536,13 @@ __global__ __launch_bounds__(256) void k_apply_coarse(Table t, MapGeom g, const 
 // P propagate: one level of updateParents (OMB:1126-1133). wl_in holds blocks whose children
 // changed; a block whose own summary changes queues its parent for the next launch.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_propagate(Table t, MapGeom g, const u32* __restrict__ wl_in, u32* __restrict__ wl_out,
-                                                   u32 in_idx, u32 phase, ScanCtl* ctl)
+// one block's updateNode + hand-off; `valid` false lanes only take part in the wave-aggregated append
+__device__ inline void propagateOne(const Table& t, const MapGeom& g, bool valid, u32 s, u32 phase, u32* __restrict__ wl_out,
+                                    u32* cnt_out)
 {
-	u32 n = ctl->wl_count[in_idx];
-	if (ctl->err) return;
-	for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-		u32 s = wl_in[i];
+	bool want = false;
+	u32 par = NONE;
+	if (valid) {
 		u32 old = atomicAnd(&t.flags[s], ~F_DIRTY);
 		u64 lk = t.keys[s];
 		u32 level = levelOf(g, lk);
@@ -526,12 +552,48 @@ __global__ __launch_bounds__(256) void k_propagate(Table t, MapGeom g, const u32
 		bool reached = lastReached(t, g, s, lk, level, old, phase, &pre);
 		if (reached && sm.collapsible) collapseBlock(t, s, lk);
 		bool changed = writeToParent(t, g, s, lk, sm);
-		publishLast(t, g, s, phase, reached && !sameSumm(g, pre, sm), pre);
-		if (changed && 1 != lk) markDirty(t, t.parent[s], wl_out, &ctl->wl_count[in_idx ^ 1]);
+		publishLast(t, g, s, lk, phase, reached && !sameSumm(g, pre, sm), pre);
+		want = changed && 1 != lk;
+		if (want) par = t.parent[s];
 	}
+	markDirty(t, want, par, wl_out, cnt_out);
 }
 
-__global__ void k_reset_wl(ScanCtl* ctl, u32 idx) { ctl->wl_count[idx] = 0; }
+__global__ __launch_bounds__(256) void k_propagate(Table t, MapGeom g, const u32* __restrict__ wl_in, u32* __restrict__ wl_out,
+                                                   u32 level, u32 phase, ScanCtl* ctl)
+{
+	if (ctl->err) return;
+	const u32 n = ctl->wl_cnt[level];
+	const u32 stride = gridDim.x * blockDim.x;
+	const u32 iters = (n + stride - 1) / stride;
+	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	for (u32 it = 0; it < iters; ++it, i += stride) propagateOne(t, g, i < n, i < n ? wl_in[i] : 0u, phase, wl_out, &ctl->wl_cnt[level + 1]);
+}
+
+// All remaining levels in ONE single-workgroup launch: above the first two or three levels the
+// worklists hold a few thousand blocks at most, and 14 dependent launches would cost more than the
+// work (MI355X_MICROARCH.md "boundary": ~1.5-2 us each). Words that other threads modify with
+// atomics in this launch (flags, counters) are read with agent-scope atomic loads (L1 bypass).
+__global__ __launch_bounds__(1024) void k_propagate_tail(Table t, MapGeom g, u32* __restrict__ wl_a, u32* __restrict__ wl_b,
+                                                         u32 first_level, u32 phase, ScanCtl* ctl)
+{
+	if (ctl->err) return;
+	for (u32 level = first_level; level <= g.L; ++level) {
+		u32* in = (level & 1) ? wl_b : wl_a;
+		u32* out = (level & 1) ? wl_a : wl_b;
+		const u32 n = __hip_atomic_load(&ctl->wl_cnt[level], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (0 == n) break;  // uniform
+		const u32 iters = (n + blockDim.x - 1) / blockDim.x;
+		u32 i = threadIdx.x;
+		for (u32 it = 0; it < iters; ++it, i += blockDim.x) {
+			u32 s = 0;
+			if (i < n) s = __hip_atomic_load(&in[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			propagateOne(t, g, i < n, s, phase, out, &ctl->wl_cnt[level + 1]);
+		}
+		__threadfence();
+		__syncthreads();
+	}
+}
 
 // ------------------------------------------------------------------------------------------------
 // read-back

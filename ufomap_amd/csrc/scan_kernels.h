@@ -22,6 +22,7 @@ enum : u32 {
 	ERR_GRID_OOB = 2u,    // a DDA cell fell outside the scan grid (should not happen)
 	ERR_TABLE_FULL = 4u,  // node table full
 	ERR_HASH_FULL = 8u,   // hit hash full (should not happen: sized 4x points)
+	ERR_ENTRIES = 16u,    // update list larger than the buffer the host guessed: host retries with the exact size
 };
 
 // Geometry of one dedup grid: cells at depth `depth`, blocks of 2x2x2 cells.
@@ -37,16 +38,24 @@ struct ScanCtl {
 	u32 n_rays;
 	u32 n_hits;
 	u32 n_entries[2];  // [0] hit entries (level 1), [1] miss entries (level depth+1)
-	u32 n_new;
 	u32 err;
-	u32 wl_count[2];
 	u32 n_codes;
+	u32 n_new;       // --- zeroed per phase, together with wl_cnt (contiguous) ---
+	u32 wl_cnt[24];  // wl_cnt[l] = number of level-l blocks queued for propagation
 	i32 mb_min[3], mb_max[3];  // miss-grid cell bbox (cells at insert depth)
 	i32 hb_min[3], hb_max[3];  // hit-grid cell bbox (depth 0)
 	u64 aabb_min[3], aabb_max[3];  // order-encoded doubles: change AABB of this scan
 	unsigned long long n_steps;
 	u32 n_oob;  // cells dropped because their key lies outside [0, 2^L) (the reference aliases them)
 	u32 pad2;
+};
+
+// Per-workgroup partial results of k_classify / k_select (no atomics on shared words: thousands of
+// waves updating 18 words of one cache line serialise at ~12 ns each); k_reduce_boxes folds them.
+struct BoxPartial {
+	i32 mb_min[3], mb_max[3];
+	i32 hb_min[3], hb_max[3];
+	double aabb_min[3], aabb_max[3];
 };
 
 struct Entry {
@@ -91,6 +100,81 @@ __device__ inline double waveMaxD(double v)
 {
 	for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
 	return v;
+}
+
+// Bounding-box updates: only issue the atomic when it would change the value (nearly never after the
+// first few waves), otherwise thousands of waves serialise on six words.
+__device__ inline void relaxMinI(i32* a, i32 v)
+{
+	if (v < __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(a, v);
+}
+__device__ inline void relaxMaxI(i32* a, i32 v)
+{
+	if (v > __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a, v);
+}
+__device__ inline void relaxMinU64(u64* a, u64 v)
+{
+	if (v < __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin((unsigned long long*)a, (unsigned long long)v);
+}
+__device__ inline void relaxMaxU64(u64* a, u64 v)
+{
+	if (v > __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax((unsigned long long*)a, (unsigned long long)v);
+}
+
+// Wave-aggregated append: one atomicAdd per wave instead of one per lane. A single hot counter costs
+// ~12 ns per atomic (MI355X_MICROARCH.md "fanin"): 36 k appends to one word would be ~0.4 ms.
+// Must be called by all active lanes of the wave at the same program point.
+__device__ inline u32 waveAppend(u32* counter, bool pred)
+{
+	const u64 mask = __ballot(pred);
+	if (0 == mask) return 0;
+	const u32 lane = __lane_id();
+	const int leader = __ffsll((unsigned long long)mask) - 1;
+	u32 base = 0;
+	if ((int)lane == leader) base = atomicAdd(counter, (u32)__popcll(mask));
+	base = __shfl(base, leader);
+	return base + (u32)__popcll(mask & ((1ULL << lane) - 1ULL));
+}
+// Workgroup-aggregated append (one atomic per workgroup); all threads of the block must call it.
+__device__ inline u32 blockAppend(u32* counter, bool pred)
+{
+	__shared__ u32 wcnt[16];
+	__shared__ u32 wbase;
+	const u64 mask = __ballot(pred);
+	const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = (blockDim.x + 63) >> 6;
+	if (0 == lane) wcnt[wave] = (u32)__popcll(mask);
+	__syncthreads();
+	if (0 == threadIdx.x) {
+		u32 total = 0;
+		for (u32 w = 0; w < nw; ++w) total += wcnt[w];
+		wbase = total ? atomicAdd(counter, total) : 0u;
+	}
+	__syncthreads();
+	u32 off = wbase;
+	for (u32 w = 0; w < wave; ++w) off += wcnt[w];
+	off += (u32)__popcll(mask & ((1ULL << lane) - 1ULL));
+	__syncthreads();  // wcnt / wbase may be reused by the next call
+	return off;
+}
+// Same for a per-lane count (0..n): returns the lane's first slot.
+__device__ inline u32 waveAppendN(u32* counter, u32 cnt)
+{
+	u32 incl = cnt;
+	const u32 lane = __lane_id();
+	for (int o = 1; o < 64; o <<= 1) {
+		u32 v = __shfl_up(incl, o);
+		if ((int)lane >= o) incl += v;
+	}
+	u32 total = __shfl(incl, 63);
+	u32 base = 0;
+	if (lane == 63 && total) base = atomicAdd(counter, total);
+	base = __shfl(base, 63);
+	return base + incl - cnt;
+}
+__device__ inline void waveAddU64(unsigned long long* counter, unsigned long long v)
+{
+	for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+	if (__lane_id() == 0 && v) atomicAdd(counter, v);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -154,11 +238,114 @@ __device__ inline u32 hitHashFind(const HitHash& h, u64 code)
 	return NONE;
 }
 
+// Workgroup reduction of up to three (min, max) double pairs and six (min,max) int pairs into part[blockIdx.x].
+// which: bit0 = aabb valid in this kernel, bit1 = hb, bit2 = mb. Called by all 256 threads.
+__device__ inline void blockBoxReduce(BoxPartial* __restrict__ part, u32 which, const double amn[3], const double amx[3],
+                                      const i32 hmn[3], const i32 hmx[3], const i32 mmn[3], const i32 mmx[3])
+{
+	__shared__ double sd[4][6];
+	__shared__ i32 si[4][12];
+	const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	for (int a = 0; a < 3; ++a) {
+		if (which & 1) {
+			double l = waveMinD(amn[a]), h = waveMaxD(amx[a]);
+			if (0 == lane) {
+				sd[wave][a] = l;
+				sd[wave][3 + a] = h;
+			}
+		}
+		if (which & 2) {
+			i32 l = waveMinI(hmn[a]), h = waveMaxI(hmx[a]);
+			if (0 == lane) {
+				si[wave][a] = l;
+				si[wave][3 + a] = h;
+			}
+		}
+		if (which & 4) {
+			i32 l = waveMinI(mmn[a]), h = waveMaxI(mmx[a]);
+			if (0 == lane) {
+				si[wave][6 + a] = l;
+				si[wave][9 + a] = h;
+			}
+		}
+	}
+	__syncthreads();
+	if (0 == threadIdx.x) {
+		BoxPartial& p = part[blockIdx.x];
+		const u32 nw = (blockDim.x + 63) >> 6;
+		for (int a = 0; a < 3; ++a) {
+			if (which & 1) {
+				double l = sd[0][a], h = sd[0][3 + a];
+				for (u32 w = 1; w < nw; ++w) {
+					l = fmin(l, sd[w][a]);
+					h = fmax(h, sd[w][3 + a]);
+				}
+				p.aabb_min[a] = l;
+				p.aabb_max[a] = h;
+			}
+			if (which & 2) {
+				i32 l = si[0][a], h = si[0][3 + a];
+				for (u32 w = 1; w < nw; ++w) {
+					l = min(l, si[w][a]);
+					h = max(h, si[w][3 + a]);
+				}
+				p.hb_min[a] = l;
+				p.hb_max[a] = h;
+			}
+			if (which & 4) {
+				i32 l = si[0][6 + a], h = si[0][9 + a];
+				for (u32 w = 1; w < nw; ++w) {
+					l = min(l, si[w][6 + a]);
+					h = max(h, si[w][9 + a]);
+				}
+				p.mb_min[a] = l;
+				p.mb_max[a] = h;
+			}
+		}
+	}
+}
+
+// Fold the per-workgroup partials into the control block (one workgroup).
+__global__ __launch_bounds__(256) void k_reduce_boxes(const BoxPartial* __restrict__ part, u32 nparts, u32 aabb_from_classify,
+                                                      const BoxPartial* __restrict__ part_classify, ScanCtl* ctl)
+{
+	double amn[3] = {1e300, 1e300, 1e300}, amx[3] = {-1e300, -1e300, -1e300};
+	i32 hmn[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, hmx[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+	i32 mmn[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, mmx[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+	for (u32 i = threadIdx.x; i < nparts; i += blockDim.x) {
+		const BoxPartial& p = part[i];
+		const BoxPartial& q = aabb_from_classify ? part_classify[i] : part[i];
+		for (int a = 0; a < 3; ++a) {
+			amn[a] = fmin(amn[a], q.aabb_min[a]);
+			amx[a] = fmax(amx[a], q.aabb_max[a]);
+			hmn[a] = min(hmn[a], p.hb_min[a]);
+			hmx[a] = max(hmx[a], p.hb_max[a]);
+			mmn[a] = min(mmn[a], p.mb_min[a]);
+			mmx[a] = max(mmx[a], p.mb_max[a]);
+		}
+	}
+	__shared__ BoxPartial out;
+	blockBoxReduce(&out - blockIdx.x, 7, amn, amx, hmn, hmx, mmn, mmx);
+	__syncthreads();
+	if (0 == threadIdx.x) {
+		for (int a = 0; a < 3; ++a) {
+			ctl->hb_min[a] = out.hb_min[a];
+			ctl->hb_max[a] = out.hb_max[a];
+			ctl->mb_min[a] = out.mb_min[a];
+			ctl->mb_max[a] = out.mb_max[a];
+			if (out.aabb_min[a] < 1e299) {
+				ctl->aabb_min[a] = encD(out.aabb_min[a]);
+				ctl->aabb_max[a] = encD(out.aabb_max[a]);
+			}
+		}
+	}
+}
+
 template <bool DISCRETE>
 __global__ __launch_bounds__(256) void k_classify(MapGeom g, D3 sensor, const double* __restrict__ xyz, u32 n,
                                                   double max_range, u32 depth, u32 color_variant, HitHash hh,
                                                   D3* __restrict__ pt_end, u8* __restrict__ pt_flag,
-                                                  u32* __restrict__ pt_slot, ScanCtl* ctl)
+                                                  u32* __restrict__ pt_slot, BoxPartial* __restrict__ part, ScanCtl* ctl)
 {
 	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (!DISCRETE) {
@@ -190,14 +377,7 @@ __global__ __launch_bounds__(256) void k_classify(MapGeom g, D3 sensor, const do
 			pt_flag[i] = flag;
 			pt_slot[i] = slot;
 		}
-		for (int a = 0; a < 3; ++a) {
-			double l = waveMinD(mn[a]);
-			double h = waveMaxD(mx[a]);
-			if ((threadIdx.x & 63) == 0 && l < 1e299) {
-				atomicMin((unsigned long long*)&ctl->aabb_min[a], (unsigned long long)encD(l));
-				atomicMax((unsigned long long*)&ctl->aabb_max[a], (unsigned long long)encD(h));
-			}
-		}
+		blockBoxReduce(part, 1, mn, mx, nullptr, nullptr, nullptr, nullptr);
 		return;
 	}
 	if (i >= n) return;
@@ -243,7 +423,8 @@ template <bool DISCRETE>
 __global__ __launch_bounds__(256) void k_select(MapGeom g, D3 sensor, u32 n, u32 depth, HitHash hh,
                                                 const D3* __restrict__ pt_end, const u8* __restrict__ pt_flag,
                                                 const u32* __restrict__ pt_slot, D3* __restrict__ ray_end,
-                                                u64* __restrict__ hit_code, u32* __restrict__ hit_pt, ScanCtl* ctl)
+                                                u64* __restrict__ hit_code, u32* __restrict__ hit_pt,
+                                                BoxPartial* __restrict__ part, ScanCtl* ctl)
 {
 	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
 	u8 flag = (i < n) ? pt_flag[i] : 0;
@@ -260,12 +441,13 @@ __global__ __launch_bounds__(256) void k_select(MapGeom g, D3 sensor, u32 n, u32
 	if (winner) {
 		u32 kx = toKey1(g, end.x, 0), ky = toKey1(g, end.y, 0), kz = toKey1(g, end.z, 0);
 		if ((kx >> g.L) || (ky >> g.L) || (kz >> g.L)) {
-			winner = false;  // key outside [0, 2^L): dropped (see gridMark)
+			winner = false;  // key outside [0, 2^L): dropped (see gridMark); rare, clipped rays only
 			atomicAdd(&ctl->n_oob, 1u);
 		}
 	}
+	const u32 hpos = blockAppend(&ctl->n_hits, winner);
 	if (winner) {
-		u32 pos = atomicAdd(&ctl->n_hits, 1u);
+		u32 pos = hpos;
 		u32 kx = toKey1(g, end.x, 0), ky = toKey1(g, end.y, 0), kz = toKey1(g, end.z, 0);
 		hit_code[pos] = morton3(kx, ky, kz);
 		hit_pt[pos] = i;
@@ -273,15 +455,7 @@ __global__ __launch_bounds__(256) void k_select(MapGeom g, D3 sensor, u32 n, u32
 		hk[1] = (i32)ky;
 		hk[2] = (i32)kz;
 	}
-	// hit-grid bbox
-	for (int a = 0; a < 3; ++a) {
-		i32 lo = waveMinI(hk[a]);
-		i32 hi = waveMaxI(winner ? hk[a] : INT32_MIN);
-		if ((threadIdx.x & 63) == 0 && lo != INT32_MAX) {
-			atomicMin(&ctl->hb_min[a], lo);
-			atomicMax(&ctl->hb_max[a], hi);
-		}
-	}
+	i32 hkx[3] = {winner ? hk[0] : INT32_MIN, winner ? hk[1] : INT32_MIN, winner ? hk[2] : INT32_MIN};
 	i32 ck[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, ek[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
 	double amn[3] = {1e300, 1e300, 1e300}, amx[3] = {-1e300, -1e300, -1e300};
 	bool has_aabb = false;
@@ -313,41 +487,23 @@ __global__ __launch_bounds__(256) void k_select(MapGeom g, D3 sensor, u32 n, u32
 				end = ec;
 			}
 		}
-		if (cast) {
-			// freeSpace's own clip (OMB:1248) decides whether the ray is walked at all
-			D3 c2 = sensor, e3 = end;
-			if (moveLineInside(g, c2, e3)) {
-				u32 pos = atomicAdd(&ctl->n_rays, 1u);
-				ray_end[pos] = end;
-				const i32 lim = (i32)((1u << (g.L - depth)) - 1u);
-				for (int a = 0; a < 3; ++a) {
-					// cells outside [0, 2^(L-depth)) are dropped by gridMark: keep them out of the bbox
-					i32 ka = min(max((i32)(toKey1(g, e3[a], depth) >> depth), 0), lim);
-					i32 kb = min(max((i32)(toKey1(g, c2[a], depth) >> depth), 0), lim);
-					ck[a] = min(ka, kb);
-					ek[a] = max(ka, kb);
-				}
-			} else {
-				cast = false;
-			}
+	}
+	// freeSpace's own clip (OMB:1248) decides whether the ray is walked at all
+	D3 c2 = sensor, e3 = end;
+	if (cast && !moveLineInside(g, c2, e3)) cast = false;
+	const u32 rpos = blockAppend(&ctl->n_rays, cast);
+	if (cast) {
+		ray_end[rpos] = end;
+		const i32 lim = (i32)((1u << (g.L - depth)) - 1u);
+		for (int a = 0; a < 3; ++a) {
+			// cells outside [0, 2^(L-depth)) are dropped by gridMark: keep them out of the bbox
+			i32 ka = min(max((i32)(toKey1(g, e3[a], depth) >> depth), 0), lim);
+			i32 kb = min(max((i32)(toKey1(g, c2[a], depth) >> depth), 0), lim);
+			ck[a] = min(ka, kb);
+			ek[a] = max(ka, kb);
 		}
 	}
-	for (int a = 0; a < 3; ++a) {
-		i32 lo = waveMinI(ck[a]);
-		i32 hi = waveMaxI(ek[a]);
-		if ((threadIdx.x & 63) == 0 && lo != INT32_MAX) {
-			atomicMin(&ctl->mb_min[a], lo);
-			atomicMax(&ctl->mb_max[a], hi);
-		}
-		if (DISCRETE) {
-			double l = waveMinD(amn[a]);
-			double h = waveMaxD(amx[a]);
-			if ((threadIdx.x & 63) == 0 && l < 1e299) {
-				atomicMin((unsigned long long*)&ctl->aabb_min[a], (unsigned long long)encD(l));
-				atomicMax((unsigned long long*)&ctl->aabb_max[a], (unsigned long long)encD(h));
-			}
-		}
-	}
+	blockBoxReduce(part, DISCRETE ? 7u : 6u, amn, amx, hk, hkx, ck, ek);
 	(void)has_aabb;
 }
 
@@ -400,14 +556,66 @@ __global__ __launch_bounds__(256) void k_hitmark(MapGeom g, Grid gr, u32* __rest
 // minElementIndex VEC3:244-251). Walks BACKWARDS from the ray end to the sensor. Each visited cell
 // is one atomicOr into grid M.
 // ------------------------------------------------------------------------------------------------
-template <bool SIMPLE>
-__global__ __launch_bounds__(256) void k_dda(MapGeom g, D3 sensor, u32 depth, Grid gr, u32* __restrict__ grid,
-                                             const D3* __restrict__ ray_end, const ScanCtl* ctl_in, ScanCtl* ctl)
+#define UFO_DDA_BLOCK 1024
+#define UFO_DDA_FILT 32768            // filter entries (u32 tags): 128 KiB of LDS per workgroup
+#define UFO_DDA_LDSGRID_MAX (144u << 10)  // largest grid kept entirely in LDS (160 KiB per CU)
+
+// How the cells a workgroup's rays visit reach grid M. All rays of a scan converge on the sensor, so
+// the same cells are produced tens of thousands of times (S/U_f = 9..28): an atomic per step
+// on the global grid serialises on a few words (~1 ms for config C2). Three modes, chosen by the host:
+//   DDA_LDSGRID  the whole grid fits in LDS (e.g. 16 cm / 20 m: 74 KB): every workgroup marks a private
+//                LDS copy with ds_or (no global traffic in the ray loop) and ORs its non-zero words
+//                into the global grid once, at the end;
+//   DDA_FILTER   larger grids: a direct-mapped LDS filter with exact 32-bit tags removes the duplicates
+//                produced by the 1024 rays of the workgroup, a plain (possibly stale) look at the grid
+//                word removes most of the rest, then a fire-and-forget atomicOr;
+//   DDA_DIRECT   grids of 2^32 cells or more: no filter tags wide enough, straight atomicOr.
+enum { DDA_LDSGRID = 0, DDA_FILTER = 1, DDA_DIRECT = 2 };
+
+template <int MODE>
+__device__ inline u32 ddaMark(const Grid& gr, u32* __restrict__ grid, u32* __restrict__ lds, i32 cx, i32 cy, i32 cz, u32 lim,
+                              u32* oob)
 {
+	if ((u32)cx >= lim || (u32)cy >= lim || (u32)cz >= lim) {
+		++*oob;
+		return 0;
+	}
+	i32 lx = cx - gr.base[0], ly = cy - gr.base[1], lz = cz - gr.base[2];
+	i32 bx = lx >> 1, by = ly >> 1, bz = lz >> 1;
+	if ((u32)bx >= (u32)gr.nb[0] || (u32)by >= (u32)gr.nb[1] || (u32)bz >= (u32)gr.nb[2]) return ERR_GRID_OOB;
+	u32 child = (u32)((lx & 1) | ((ly & 1) << 1) | ((lz & 1) << 2));
+	if (MODE == DDA_LDSGRID) {
+		u32 idx = ((u32)bz * (u32)gr.nb[1] + (u32)by) * (u32)gr.nb[0] + (u32)bx;
+		atomicOr(&lds[idx >> 2], 1u << (child + 8u * (idx & 3)));
+		return 0;
+	}
+	u64 idx = ((u64)bz * (u64)gr.nb[1] + (u64)by) * (u64)gr.nb[0] + (u64)bx;
+	u32 bit = 1u << (child + 8u * (u32)(idx & 3));
+	u32* w = &grid[idx >> 2];
+	if (MODE == DDA_FILTER) {
+		u32 tag = (u32)(idx << 3) | child;
+		u32 h = (tag * 0x9E3779B1u) >> 17;  // 15 bits
+		if (lds[h] == tag) return 0;
+		lds[h] = tag;
+		if (*w & bit) return 0;
+	}
+	atomicOr(w, bit);
+	return 0;
+}
+
+template <bool SIMPLE, int MODE>
+__global__ __launch_bounds__(UFO_DDA_BLOCK) void k_dda(MapGeom g, D3 sensor, u32 depth, Grid gr, u32* __restrict__ grid,
+                                                       const D3* __restrict__ ray_end, const ScanCtl* ctl_in, ScanCtl* ctl)
+{
+	extern __shared__ __attribute__((aligned(16))) u32 lds[];
+	const u32 lds_words = (MODE == DDA_LDSGRID) ? (u32)(gr.bytes >> 2) : (MODE == DDA_FILTER ? (u32)UFO_DDA_FILT : 0u);
+	const u32 lds_init = (MODE == DDA_LDSGRID) ? 0u : 0xFFFFFFFFu;  // no cell has tag 2^32-1 (host guarantees)
+	for (u32 j = threadIdx.x; j < lds_words; j += UFO_DDA_BLOCK) lds[j] = lds_init;
+	__syncthreads();
 	u32 n = ctl_in->n_rays;
 	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
 	unsigned long long steps = 0;
-	u32 err = 0;
+	u32 err = 0, oob = 0;
 	const u32 lim = 1u << (g.L - depth);
 	if (i < n) {
 		D3 from = sensor, to = ray_end[i];
@@ -429,7 +637,7 @@ __global__ __launch_bounds__(256) void k_dda(MapGeom g, D3 sensor, u32 depth, Gr
 					for (int s = 0; s <= num_steps; ++s) {
 						i32 cx = (i32)(toKey1(g, cur.x, depth) >> depth), cy = (i32)(toKey1(g, cur.y, depth) >> depth),
 						    cz = (i32)(toKey1(g, cur.z, depth) >> depth);
-						if (!gridMark(gr, grid, cx, cy, cz, lim, &ctl->n_oob)) err |= ERR_GRID_OOB;
+						err |= ddaMark<MODE>(gr, grid, lds, cx, cy, cz, lim, &oob);
 						++steps;
 						cur = cur + stepv;
 					}
@@ -439,7 +647,7 @@ __global__ __launch_bounds__(256) void k_dda(MapGeom g, D3 sensor, u32 depth, Gr
 				u32 ex = toKey1(g, end.x, depth), ey = toKey1(g, end.y, depth), ez = toKey1(g, end.z, depth);
 				if (kx == ex && ky == ey && kz == ez) {
 					// OMB:1281-1284
-					if (!gridMark(gr, grid, (i32)(kx >> depth), (i32)(ky >> depth), (i32)(kz >> depth), lim, &ctl->n_oob)) err |= ERR_GRID_OOB;
+					err |= ddaMark<MODE>(gr, grid, lds, (i32)(kx >> depth), (i32)(ky >> depth), (i32)(kz >> depth), lim, &oob);
 					steps = 1;
 				} else {
 					// computeRayInit OCT:1204-1224
@@ -477,7 +685,7 @@ __global__ __launch_bounds__(256) void k_dda(MapGeom g, D3 sensor, u32 depth, Gr
 							err |= ERR_RUNAWAY;
 							break;
 						}
-						if (!gridMark(gr, grid, cx, cy, cz, lim, &ctl->n_oob)) err |= ERR_GRID_OOB;
+						err |= ddaMark<MODE>(gr, grid, lds, cx, cy, cz, lim, &oob);
 						// minElementIndex VEC3:244-251: x<=y ? (x<=z ? x : z) : (y<=z ? y : z)
 						if (tmx <= tmy) {
 							if (tmx <= tmz) {
@@ -502,9 +710,17 @@ __global__ __launch_bounds__(256) void k_dda(MapGeom g, D3 sensor, u32 depth, Gr
 			}
 		}
 	}
+	if (MODE == DDA_LDSGRID) {
+		// one pass over the private copy: OR the non-zero words into the global grid
+		__syncthreads();
+		for (u32 j = threadIdx.x; j < lds_words; j += UFO_DDA_BLOCK) {
+			u32 v = lds[j];
+			if (v && (grid[j] & v) != v) atomicOr(&grid[j], v);
+		}
+	}
 	// total step count (diagnostic; drives the algorithmic-bytes figure of bench.py)
-	for (int o = 32; o > 0; o >>= 1) steps += __shfl_xor((unsigned long long)steps, o);
-	if ((threadIdx.x & 63) == 0 && steps) atomicAdd(&ctl->n_steps, steps);
+	waveAddU64(&ctl->n_steps, steps);
+	if (oob) atomicAdd(&ctl->n_oob, oob);
 	if (err) atomicOr(&ctl->err, err);
 }
 
@@ -514,16 +730,23 @@ __global__ __launch_bounds__(256) void k_dda(MapGeom g, D3 sensor, u32 depth, Gr
 __global__ __launch_bounds__(256) void k_extract(MapGeom g, Grid gr, const u32* __restrict__ grid, u32 which,
                                                  Entry* __restrict__ entries, u32 cap, ScanCtl* ctl)
 {
-	u64 nwords = gr.bytes >> 2;
+	const u64 nwords = gr.bytes >> 2;
 	const u32 level = gr.depth + 1;
-	for (u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x; w < nwords; w += (u64)gridDim.x * blockDim.x) {
-		u32 m = grid[w];
-		if (m == 0) continue;
+	const u64 stride = (u64)gridDim.x * blockDim.x;
+	// uniform trip count so that every lane reaches the wave-aggregated append
+	const u64 iters = (nwords + stride - 1) / stride;
+	u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	for (u64 it = 0; it < iters; ++it, w += stride) {
+		u32 m = (w < nwords) ? grid[w] : 0u;
+		u32 cnt = ((m & 0xFFu) ? 1u : 0u) + ((m & 0xFF00u) ? 1u : 0u) + ((m & 0xFF0000u) ? 1u : 0u) + ((m & 0xFF000000u) ? 1u : 0u);
+		if (0 == __ballot(cnt != 0)) continue;
+		u32 pos = waveAppendN(&ctl->n_entries[which], cnt);
+		if (0 == cnt) continue;
 		for (u32 b = 0; b < 4; ++b) {
 			u32 mb = (m >> (8 * b)) & 0xFF;
 			if (mb == 0) continue;
-			u32 pos = atomicAdd(&ctl->n_entries[which], 1u);
-			if (pos >= cap) continue;
+			u32 my = pos++;
+			if (my >= cap) continue;
 			u64 idx = w * 4 + b;
 			u64 bx = idx % (u64)gr.nb[0];
 			u64 r = idx / (u64)gr.nb[0];
@@ -539,7 +762,7 @@ __global__ __launch_bounds__(256) void k_extract(MapGeom g, Grid gr, const u32* 
 			e.miss = which ? (u8)mb : 0;
 			e.level = (u8)level;
 			for (int k = 0; k < 5; ++k) e.pad[k] = 0;
-			entries[pos] = e;
+			entries[my] = e;
 		}
 	}
 }

@@ -54,10 +54,9 @@ struct Table {
 	u32* parent;
 	u32* stamp;
 	u64* tmax;
-	u32* lu_phase;
-	float* lu_occ;
-	u32* lu_fl;   // bit0/1 = contains_free/unknown of the pre-last summary, bit 8 = "reached and changed"
-	u32* lu_rgb;  // colour maps only
+	float* lu_occ;  // [8*slot + child]: last-update record published by child `child` of this block
+	u32* lu_fl;     // bit0/1 = contains_free/unknown of the pre-last summary, bit 8 = "reached and changed", 9.. = phase tag
+	u32* lu_rgb;    // colour maps only
 	MapRoot* root;
 	u32 mask;  // capacity - 1
 };
@@ -87,7 +86,7 @@ __device__ inline u32 tableFind(const Table& t, u64 lk)
 
 // Find or insert/revive. *created = 1 when this thread created the block or revived a DEAD one.
 // Returns NONE when the table is full (caller raises the capacity error).
-__device__ inline u32 tableEnsure(const Table& t, u64 lk, u32 scan_id, u32 max_probe, bool* created)
+__device__ inline u32 tableEnsure(const Table& t, u64 lk, u32 scan_id, u32 max_probe, bool* created, u32* n_created)
 {
 	u32 s = hash64(lk) & t.mask;
 	*created = false;
@@ -98,7 +97,7 @@ __device__ inline u32 tableEnsure(const Table& t, u64 lk, u32 scan_id, u32 max_p
 			if (prev == 0) {
 				// empty slots have flags == 0 (table is zero-filled and never shrinks)
 				t.stamp[s] = scan_id;
-				atomicAdd(&t.root->used, 1u);
+				++*n_created;  // the caller adds these to MapRoot::used once per wave
 				*created = true;
 				return s;
 			}

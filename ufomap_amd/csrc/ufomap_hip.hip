@@ -113,6 +113,7 @@ struct ufomap_map {
 	u64 used_est = 0;  // host-side view of MapRoot::used (refreshed at every control-block read)
 	// per-scan buffers
 	DevBuf b_ctl, b_pt_end, b_pt_flag, b_pt_slot, b_ray_end, b_hit_code, b_hit_pt, b_hh_keys, b_hh_idx;
+	DevBuf b_part0, b_part1;
 	DevBuf b_gridH, b_gridM, b_entries, b_ent_slot, b_newlist, b_wl0, b_wl1, b_in_xyz, b_in_rgb, b_codes, b_dump;
 	ScanCtl* h_ctl = nullptr;  // pinned
 	MapRoot* h_root = nullptr;  // pinned
@@ -124,6 +125,7 @@ struct ufomap_map {
 	bool haveH = false, haveM = false;
 	u32 last_depth = 0;
 	u32 hh_mask = 0;  // hit-hash mask of the current scan
+	const uint8_t* last_rgb = nullptr;
 	uint64_t counts[8] = {0};
 	double min_change[3], max_change[3];
 	// profiling
@@ -205,14 +207,12 @@ int allocTable(ufomap_map* m, u32 cap, Table* out, TableBufs* tb)
 {
 	DevBuf *keys = &tb->keys, *occ = &tb->occ, *rgb = &tb->rgb, *flags = &tb->flags, *parent = &tb->parent, *stamp = &tb->stamp;
 	HIP_TRY(tb->tmax.reserve((size_t)cap * 8));
-	HIP_TRY(tb->luph.reserve((size_t)cap * 4));
-	HIP_TRY(tb->luocc.reserve((size_t)cap * 4));
-	HIP_TRY(tb->lufl.reserve((size_t)cap * 4));
-	if (m->g.color) HIP_TRY(tb->lurgb.reserve((size_t)cap * 4));
+	HIP_TRY(tb->luocc.reserve((size_t)cap * 32));
+	HIP_TRY(tb->lufl.reserve((size_t)cap * 32));
+	if (m->g.color) HIP_TRY(tb->lurgb.reserve((size_t)cap * 32));
 	HIP_TRY(hipMemsetAsync(tb->tmax.p, 0, (size_t)cap * 8, m->stream));
-	HIP_TRY(hipMemsetAsync(tb->luph.p, 0, (size_t)cap * 4, m->stream));
+	HIP_TRY(hipMemsetAsync(tb->lufl.p, 0, (size_t)cap * 32, m->stream));
 	out->tmax = tb->tmax.as<u64>();
-	out->lu_phase = tb->luph.as<u32>();
 	out->lu_occ = tb->luocc.as<float>();
 	out->lu_fl = tb->lufl.as<u32>();
 	out->lu_rgb = m->g.color ? tb->lurgb.as<u32>() : nullptr;
@@ -343,56 +343,109 @@ int makeGrid(const i32 mn[3], const i32 mx[3], u32 depth, Grid* gr)
 	return UFOMAP_OK;
 }
 
+// upper bound on the blocks of `level` that can lie on the paths of entries inside a grid of nb[] blocks
+u64 levelBound(const i32 nb[3], u32 shift)
+{
+	long double vol = 1;
+	for (int a = 0; a < 3; ++a) vol *= (long double)(((u64)nb[a] >> std::min(shift, 62u)) + 2);
+	return vol > 1e18L ? (u64)1e18 : (u64)vol;
+}
+
 // One phase of the map update: entries of one level -> ensure, init, apply, propagate.
-int applyEntries(ufomap_map* m, const Entry* d_entries, u32 n_entries, u32 which, u32 level, const i32 nb[3], float upd,
+// `cap` is the capacity of the entry buffer (the device-side count may be smaller; if it is larger
+// k_ensure raises ERR_ENTRIES and nothing is applied).
+int applyEntries(ufomap_map* m, const Entry* d_entries, u32 cap, u32 which, u32 level, const i32 nb[3], float upd,
                  const uint8_t* d_rgb)
 {
-	if (0 == n_entries) return UFOMAP_OK;
+	if (0 == cap) return UFOMAP_OK;
 	m->scan_id += 1;  // "new this phase" stamp: blocks made by an earlier phase of the same scan are old
-	u64 newcap = blockBound(m, n_entries, nb, level);
-	HIP_TRY(m->b_ent_slot.reserve((size_t)n_entries * 4));
+	u64 newcap = blockBound(m, cap, nb, level);
+	HIP_TRY(m->b_ent_slot.reserve((size_t)cap * 4));
 	HIP_TRY(m->b_newlist.reserve((size_t)newcap * 4));
-	HIP_TRY(m->b_wl0.reserve(((size_t)n_entries + 8) * 4));
-	HIP_TRY(m->b_wl1.reserve(((size_t)n_entries + 8) * 4));
+	size_t wlcap = (size_t)std::min<u64>(cap, levelBound(nb, 1)) + 8;
+	HIP_TRY(m->b_wl0.reserve(wlcap * 4));
+	HIP_TRY(m->b_wl1.reserve(wlcap * 4));
 	ScanCtl* ctl = m->b_ctl.as<ScanCtl>();
 	const u32* d_n = &ctl->n_entries[which];
-	HIP_TRY(hipMemsetAsync(&ctl->n_new, 0, 4, m->stream));
-	HIP_TRY(hipMemsetAsync(&ctl->wl_count[0], 0, 8, m->stream));
+	HIP_TRY(hipMemsetAsync(&ctl->n_new, 0, 4 * 25, m->stream));  // n_new + wl_cnt[24]
 	HitHash hh{m->b_hh_keys.as<u64>(), m->b_hh_idx.as<u32>(), m->hh_mask};
-	dim3 ge = gridFor(n_entries);
+	u32* wl[2] = {m->b_wl0.as<u32>(), m->b_wl1.as<u32>()};
+	dim3 ge = gridFor(cap);
 	{
 		ProfScope ps(m, "k_ensure");
-		hipLaunchKernelGGL(k_ensure, ge, dim3(256), 0, m->stream, m->t, m->g, d_entries, d_n, m->scan_id, m->b_ent_slot.as<u32>(),
+		hipLaunchKernelGGL(k_ensure, ge, dim3(256), 0, m->stream, m->t, m->g, d_entries, d_n, cap, m->scan_id, m->b_ent_slot.as<u32>(),
 		                   m->b_newlist.as<u32>(), (u32)std::min<u64>(newcap, 0xFFFFFFFFull), ctl);
 	}
 	{
 		ProfScope ps(m, "k_init_new");
-		hipLaunchKernelGGL(k_init_new, ge, dim3(256), 0, m->stream, m->t, m->g, m->b_newlist.as<u32>(),
+		hipLaunchKernelGGL(k_init_new, gridFor(std::min<u64>(newcap, cap)), dim3(256), 0, m->stream, m->t, m->g, m->b_newlist.as<u32>(),
 		                   (u32)std::min<u64>(newcap, 0xFFFFFFFFull), m->scan_id, ctl);
 	}
 	if (1 == level) {
 		ProfScope ps(m, "k_apply_leaf");
 		hipLaunchKernelGGL(k_apply_leaf, ge, dim3(256), 0, m->stream, m->t, m->g, d_entries, d_n, m->b_ent_slot.as<u32>(), upd,
-		                   (u32)(which == 0 ? 1 : 0), m->scan_id, hh, d_rgb, m->b_wl0.as<u32>(), ctl);
+		                   (u32)(which == 0 ? 1 : 0), m->scan_id, hh, d_rgb, wl[0], ctl);
 	} else {
 		ProfScope ps(m, "k_apply_coarse");
 		hipLaunchKernelGGL(k_apply_coarse, ge, dim3(256), 0, m->stream, m->t, m->g, d_entries, d_n, m->b_ent_slot.as<u32>(), upd,
-		                   m->scan_id, m->b_wl0.as<u32>(), ctl);
+		                   m->scan_id, wl[(level + 1) & 1], ctl);
 	}
-	// updateParents, one launch per level (OMB:1126-1133)
-	u32 idx = 0;
-	for (u32 l = level + 1; l <= m->g.L; ++l) {
+	// updateParents (OMB:1126-1133): wide levels one launch each, the narrow rest in one launch
+	u32 l = level + 1;
+	for (; l <= m->g.L; ++l) {
+		u64 bound = std::min<u64>(cap, levelBound(nb, l - level));
+		if (bound <= 8192) break;
 		ProfScope ps(m, "k_propagate");
-		u32* in = idx ? m->b_wl1.as<u32>() : m->b_wl0.as<u32>();
-		u32* out = idx ? m->b_wl0.as<u32>() : m->b_wl1.as<u32>();
-		hipLaunchKernelGGL(k_reset_wl, dim3(1), dim3(1), 0, m->stream, ctl, idx ^ 1);
-		u64 est = std::max<u64>(1, (u64)n_entries >> (3 * std::min<u32>(l - level - 1, 10)));
-		hipLaunchKernelGGL(k_propagate, gridFor(std::max<u64>(est, 256), 256, 1024), dim3(256), 0, m->stream, m->t, m->g, in, out,
-		                   idx, m->scan_id, ctl);
-		idx ^= 1;
+		hipLaunchKernelGGL(k_propagate, gridFor(bound, 256, 1024), dim3(256), 0, m->stream, m->t, m->g, wl[l & 1], wl[(l + 1) & 1], l,
+		                   m->scan_id, ctl);
+	}
+	if (l <= m->g.L) {
+		ProfScope ps(m, "k_propagate_tail");
+		hipLaunchKernelGGL(k_propagate_tail, dim3(1), dim3(1024), 0, m->stream, m->t, m->g, wl[0], wl[1], l, m->scan_id, ctl);
 	}
 	HIP_TRY(hipGetLastError());
 	return UFOMAP_OK;
+}
+
+// The map half of an integration: update lists from the two grids, then hits phase, then misses phase.
+// capH/capM: entry-buffer capacities (upper bounds or guesses; see ERR_ENTRIES).
+int mapPhase(ufomap_map* m, unsigned depth, const uint8_t* d_rgb, u64 capH, u64 capM)
+{
+	ScanCtl* ctl = m->b_ctl.as<ScanCtl>();
+	const float miss = (float)(m->g.miss_log / double((2.0 * depth) + 1));  // OMB:311
+	if (!m->haveH) capH = 0;
+	if (!m->haveM) capM = 0;
+	if (capH > 0x7FFFFFFFull || capM > 0x7FFFFFFFull) return fail(UFOMAP_ERR_CAPACITY, "update list exceeds 2^31 entries");
+	{
+		// size the table for the worst case of both phases (true upper bound, see blockBound)
+		u64 need = m->used_est;
+		if (capH) need += blockBound(m, capH, m->gridH.nb, 1);
+		if (capM) need += blockBound(m, capM, m->gridM.nb, (u32)depth + 1);
+		u64 cap = (u64)m->t.mask + 1;
+		if (need * 5 > cap * 3) {  // keep the load factor <= 0.6
+			u64 want = need * 2;
+			if (want > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
+			int rc = growTable(m, nextPow2(want));
+			if (rc) return rc;
+		}
+	}
+	HIP_TRY(m->b_entries.reserve(((size_t)capH + capM + 1) * sizeof(Entry)));
+	Entry* ent_h = m->b_entries.as<Entry>();
+	Entry* ent_m = ent_h + capH;
+	HIP_TRY(hipMemsetAsync(&ctl->n_entries[0], 0, 8, m->stream));
+	if (capH) {
+		ProfScope ps(m, "k_extract");
+		hipLaunchKernelGGL(k_extract, gridFor(m->gridH.bytes >> 2, 256, 2048), dim3(256), 0, m->stream, m->g, m->gridH,
+		                   m->b_gridH.as<u32>(), 0u, ent_h, (u32)capH, ctl);
+	}
+	if (capM) {
+		ProfScope ps(m, "k_extract");
+		hipLaunchKernelGGL(k_extract, gridFor(m->gridM.bytes >> 2, 256, 2048), dim3(256), 0, m->stream, m->g, m->gridM,
+		                   m->b_gridM.as<u32>(), 1u, ent_m, (u32)capM, ctl);
+	}
+	int rc = applyEntries(m, ent_h, (u32)capH, 0, 1, m->gridH.nb, m->g.hit, d_rgb);
+	if (rc) return rc;
+	return applyEntries(m, ent_m, (u32)capM, 1, (u32)depth + 1, m->gridM.nb, miss, nullptr);
 }
 
 int finishPending(ufomap_map* m)
@@ -401,9 +454,19 @@ int finishPending(ufomap_map* m)
 	m->pending = false;
 	int rc = readCtl(m);
 	if (rc) return rc;
+	if (m->h_ctl->err == ERR_ENTRIES) {
+		// the guessed update-list capacity was too small; nothing was applied. Redo with the exact sizes.
+		u64 capH = m->h_ctl->n_entries[0], capM = m->h_ctl->n_entries[1];
+		HIP_TRY(hipMemsetAsync(&m->b_ctl.as<ScanCtl>()->err, 0, 4, m->stream));
+		rc = mapPhase(m, m->last_depth, m->last_rgb, capH, capM);
+		if (rc) return rc;
+		rc = readCtl(m);
+		if (rc) return rc;
+	}
 	drainEvents(m);
 	rc = ctlError(m);
 	if (rc) return rc;
+	m->counts[5] = (u64)m->h_ctl->n_entries[0] + m->h_ctl->n_entries[1];
 	m->counts[2] = m->h_ctl->n_steps;
 	m->counts[6] = m->h_ctl->n_new;
 	m->counts[7] = m->h_ctl->n_oob;
@@ -473,25 +536,33 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 	ScanCtl* ctl = m->b_ctl.as<ScanCtl>();
 	HIP_TRY(hipMemcpyAsync(ctl, m->h_ctl, sizeof(ScanCtl), hipMemcpyHostToDevice, m->stream));
 	dim3 gp((N + 255) / 256);
+	HIP_TRY(m->b_part0.reserve((size_t)gp.x * sizeof(BoxPartial)));
+	HIP_TRY(m->b_part1.reserve((size_t)gp.x * sizeof(BoxPartial)));
 	{
 		ProfScope ps(m, "k_classify");
 		if (discrete)
 			hipLaunchKernelGGL(k_classify<true>, gp, dim3(256), 0, m->stream, m->g, sensor, d_xyz, N, max_range, (u32)depth,
-			                   (u32)(d_rgb ? 1 : 0), hh, m->b_pt_end.as<D3>(), m->b_pt_flag.as<u8>(), m->b_pt_slot.as<u32>(), ctl);
+			                   (u32)(d_rgb ? 1 : 0), hh, m->b_pt_end.as<D3>(), m->b_pt_flag.as<u8>(), m->b_pt_slot.as<u32>(),
+			                   m->b_part0.as<BoxPartial>(), ctl);
 		else
 			hipLaunchKernelGGL(k_classify<false>, gp, dim3(256), 0, m->stream, m->g, sensor, d_xyz, N, max_range, (u32)depth, 0u, hh,
-			                   m->b_pt_end.as<D3>(), m->b_pt_flag.as<u8>(), m->b_pt_slot.as<u32>(), ctl);
+			                   m->b_pt_end.as<D3>(), m->b_pt_flag.as<u8>(), m->b_pt_slot.as<u32>(), m->b_part0.as<BoxPartial>(), ctl);
 	}
 	{
 		ProfScope ps(m, "k_select");
 		if (discrete)
 			hipLaunchKernelGGL(k_select<true>, gp, dim3(256), 0, m->stream, m->g, sensor, N, (u32)depth, hh, m->b_pt_end.as<D3>(),
 			                   m->b_pt_flag.as<u8>(), m->b_pt_slot.as<u32>(), m->b_ray_end.as<D3>(), m->b_hit_code.as<u64>(),
-			                   m->b_hit_pt.as<u32>(), ctl);
+			                   m->b_hit_pt.as<u32>(), m->b_part1.as<BoxPartial>(), ctl);
 		else
 			hipLaunchKernelGGL(k_select<false>, gp, dim3(256), 0, m->stream, m->g, sensor, N, (u32)depth, hh, m->b_pt_end.as<D3>(),
 			                   m->b_pt_flag.as<u8>(), m->b_pt_slot.as<u32>(), m->b_ray_end.as<D3>(), m->b_hit_code.as<u64>(),
-			                   m->b_hit_pt.as<u32>(), ctl);
+			                   m->b_hit_pt.as<u32>(), m->b_part1.as<BoxPartial>(), ctl);
+	}
+	{
+		ProfScope ps(m, "k_reduce_boxes");
+		hipLaunchKernelGGL(k_reduce_boxes, dim3(1), dim3(256), 0, m->stream, m->b_part1.as<BoxPartial>(), gp.x, (u32)(discrete ? 0 : 1),
+		                   m->b_part0.as<BoxPartial>(), ctl);
 	}
 	HIP_TRY(hipGetLastError());
 	int rc = readCtl(m);
@@ -533,65 +604,32 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 		HIP_TRY(m->b_gridM.reserve(m->gridM.bytes));
 		HIP_TRY(hipMemsetAsync(m->b_gridM.p, 0, m->gridM.bytes, m->stream));
 		ProfScope ps(m, "k_dda");
-		dim3 gr((n_rays + 255) / 256);
-		if (simple)
-			hipLaunchKernelGGL(k_dda<true>, gr, dim3(256), 0, m->stream, m->g, sensor, (u32)depth, m->gridM, m->b_gridM.as<u32>(),
-			                   m->b_ray_end.as<D3>(), ctl, ctl);
-		else
-			hipLaunchKernelGGL(k_dda<false>, gr, dim3(256), 0, m->stream, m->g, sensor, (u32)depth, m->gridM, m->b_gridM.as<u32>(),
-			                   m->b_ray_end.as<D3>(), ctl, ctl);
+		dim3 gr((n_rays + UFO_DDA_BLOCK - 1) / UFO_DDA_BLOCK);
+		const int mode = m->gridM.bytes <= UFO_DDA_LDSGRID_MAX ? DDA_LDSGRID : (m->gridM.bytes < (1ull << 29) ? DDA_FILTER : DDA_DIRECT);
+		const size_t lds = mode == DDA_LDSGRID ? (size_t)m->gridM.bytes : (mode == DDA_FILTER ? (size_t)UFO_DDA_FILT * 4 : 0);
+#define UFO_LAUNCH_DDA(SIMPLE, MODE)                                                                                         \
+	hipLaunchKernelGGL((k_dda<SIMPLE, MODE>), gr, dim3(UFO_DDA_BLOCK), lds, m->stream, m->g, sensor, (u32)depth, m->gridM, \
+	                   m->b_gridM.as<u32>(), m->b_ray_end.as<D3>(), ctl, ctl)
+		if (simple) {
+			if (mode == DDA_LDSGRID) UFO_LAUNCH_DDA(true, DDA_LDSGRID);
+			else if (mode == DDA_FILTER) UFO_LAUNCH_DDA(true, DDA_FILTER);
+			else UFO_LAUNCH_DDA(true, DDA_DIRECT);
+		} else {
+			if (mode == DDA_LDSGRID) UFO_LAUNCH_DDA(false, DDA_LDSGRID);
+			else if (mode == DDA_FILTER) UFO_LAUNCH_DDA(false, DDA_FILTER);
+			else UFO_LAUNCH_DDA(false, DDA_DIRECT);
+		}
+#undef UFO_LAUNCH_DDA
 	}
 
-	// ---- map phases: all hits, then all misses (OMB:1351-1365) ------------------------------------------
-	const float miss = (float)(m->g.miss_log / double((2.0 * depth) + 1));  // OMB:311
-	HIP_TRY(hipMemsetAsync(&ctl->n_entries[0], 0, 8, m->stream));
-	if (m->haveH) {
-		ProfScope ps(m, "k_extract_count");
-		hipLaunchKernelGGL(k_extract, gridFor(m->gridH.bytes >> 2, 256, 8192), dim3(256), 0, m->stream, m->g, m->gridH,
-		                   m->b_gridH.as<u32>(), 0u, (Entry*)nullptr, 0u, ctl);
-	}
-	if (m->haveM) {
-		ProfScope ps(m, "k_extract_count");
-		hipLaunchKernelGGL(k_extract, gridFor(m->gridM.bytes >> 2, 256, 8192), dim3(256), 0, m->stream, m->g, m->gridM,
-		                   m->b_gridM.as<u32>(), 1u, (Entry*)nullptr, 0u, ctl);
-	}
-	rc = readCtl(m);
-	if (rc) return rc;
-	// all rays have been walked: a runaway ray aborts BEFORE the map is touched
-	rc = ctlError(m);
-	if (rc) return rc;
-	const u32 ne_h = m->h_ctl->n_entries[0], ne_m = m->h_ctl->n_entries[1];
-	m->counts[5] = (u64)ne_h + ne_m;
-	{
-		// size the table for the worst case of both phases (true upper bound, see blockBound)
-		u64 need = m->used_est;
-		if (ne_h) need += blockBound(m, ne_h, m->gridH.nb, 1);
-		if (ne_m) need += blockBound(m, ne_m, m->gridM.nb, (u32)depth + 1);
-		u64 cap = (u64)m->t.mask + 1;
-		if (need * 5 > cap * 3) {  // keep the load factor <= 0.6
-			u64 want = need * 2;
-			if (want > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
-			rc = growTable(m, nextPow2(want));
-			if (rc) return rc;
-		}
-	}
-	HIP_TRY(m->b_entries.reserve(((size_t)ne_h + ne_m + 1) * sizeof(Entry)));
-	Entry* ent_h = m->b_entries.as<Entry>();
-	Entry* ent_m = ent_h + ne_h;
-	HIP_TRY(hipMemsetAsync(&ctl->n_entries[0], 0, 8, m->stream));
-	if (ne_h) {
-		ProfScope ps(m, "k_extract");
-		hipLaunchKernelGGL(k_extract, gridFor(m->gridH.bytes >> 2, 256, 8192), dim3(256), 0, m->stream, m->g, m->gridH,
-		                   m->b_gridH.as<u32>(), 0u, ent_h, ne_h, ctl);
-	}
-	if (ne_m) {
-		ProfScope ps(m, "k_extract");
-		hipLaunchKernelGGL(k_extract, gridFor(m->gridM.bytes >> 2, 256, 8192), dim3(256), 0, m->stream, m->g, m->gridM,
-		                   m->b_gridM.as<u32>(), 1u, ent_m, ne_m, ctl);
-	}
-	rc = applyEntries(m, ent_h, ne_h, 0, 1, m->gridH.nb, m->g.hit, d_rgb);
-	if (rc) return rc;
-	rc = applyEntries(m, ent_m, ne_m, 1, (u32)depth + 1, m->gridM.nb, miss, nullptr);
+	// ---- map phases: all hits, then all misses (OMB:1351-1365). No host round trip here: the update-list
+	// buffers are sized from upper bounds (hit blocks <= unique hits; miss blocks <= blocks of the grid, capped
+	// by a guess for huge grids -- ERR_ENTRIES makes the host retry with the exact size). A runaway ray sets
+	// ctl->err in k_dda, and every map kernel returns early on it: the map stays untouched.
+	m->last_rgb = d_rgb;
+	u64 capH = m->haveH ? std::min<u64>(n_hits, m->gridH.bytes) : 0;
+	u64 capM = m->haveM ? std::min<u64>(m->gridM.bytes, std::max<u64>(1u << 20, (u64)n_rays * 64)) : 0;
+	rc = mapPhase(m, depth, d_rgb, capH, capM);
 	if (rc) return rc;
 	(void)after_select;
 	HIP_TRY(hipGetLastError());
@@ -671,6 +709,14 @@ ufomap_map* ufomap_map_create(double resolution, unsigned depth_levels, int auto
 		ufomap_map_destroy(m);
 		return nullptr;
 	}
+	{
+		// the DDA kernels use up to 144 KiB of dynamic LDS (whole-grid mode) / 128 KiB (filter mode)
+		const int maxlds = (int)UFO_DDA_LDSGRID_MAX;
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dda<false, DDA_LDSGRID>), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dda<true, DDA_LDSGRID>), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dda<false, DDA_FILTER>), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dda<true, DDA_FILTER>), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds);
+	}
 	for (int a = 0; a < 3; ++a) {
 		m->min_change[a] = g.hs[g.L];  // resetMinMaxChangeDetection (occupancy_map_base.h:806-810)
 		m->max_change[a] = -g.hs[g.L];
@@ -686,7 +732,7 @@ void ufomap_map_destroy(ufomap_map* m)
 	m->tb.release();
 	DevBuf* bufs[] = {&m->b_root,
 	                  &m->b_ctl,     &m->b_pt_end,  &m->b_pt_flag,  &m->b_pt_slot, &m->b_ray_end, &m->b_hit_code, &m->b_hit_pt,
-	                  &m->b_hh_keys, &m->b_hh_idx,  &m->b_gridH,    &m->b_gridM,   &m->b_entries, &m->b_ent_slot, &m->b_newlist,
+	                  &m->b_hh_keys, &m->b_hh_idx,  &m->b_gridH,    &m->b_gridM,   &m->b_part0,   &m->b_part1,   &m->b_entries, &m->b_ent_slot, &m->b_newlist,
 	                  &m->b_wl0,     &m->b_wl1,     &m->b_in_xyz,   &m->b_in_rgb,  &m->b_codes,   &m->b_dump};
 	for (DevBuf* b : bufs) b->release();
 	for (PendingEvent& pe : m->pend_ev) {
@@ -951,7 +997,7 @@ int ufomap_map_stats(ufomap_map* m, uint64_t* n_inner, uint64_t* n_leaf, uint64_
 	if (n_leaf) *n_leaf = h.n_live ? h.n_leaf : 1;
 	if (bytes) {
 		u64 cap = (u64)m->t.mask + 1;
-		*bytes = cap * (8 + 32 + 12 + (m->g.color ? 32 : 0));
+		*bytes = cap * (8 + 32 + 12 + 8 + 64 + (m->g.color ? 64 : 0));
 	}
 	return UFOMAP_OK;
 }
