@@ -93,6 +93,7 @@ __device__ inline Summ blockSummary(const Table& t, const MapGeom& g, u32 s, u32
 
 // Write a block's summary into the slot that holds the node's own value. Returns "changed"
 // (the bool updateNode returns, OMB:1215-1223 / OMC.cpp:118-121).
+template <bool WG = false>
 __device__ inline bool writeToParent(const Table& t, const MapGeom& g, u32 s, u64 lk, const Summ& sm)
 {
 	if (1 == lk) {
@@ -106,7 +107,7 @@ __device__ inline bool writeToParent(const Table& t, const MapGeom& g, u32 s, u6
 	u32 p = t.parent[s];
 	u32 ci = (u32)(lk & 7);
 	float* po = t.occ + 8 * (size_t)p + ci;
-	u32 fp = __hip_atomic_load(&t.flags[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	u32 fp = aLoad<WG>(&t.flags[p]);
 	u32 old_fl = ((fp >> ci) & 1u) | (((fp >> (8 + ci)) & 1u) << 1);
 	bool ch = (*po != sm.occ) || (old_fl != sm.fl);
 	if (g.color) {
@@ -118,8 +119,8 @@ __device__ inline bool writeToParent(const Table& t, const MapGeom& g, u32 s, u6
 	if (old_fl != sm.fl) {
 		u32 setm = ((sm.fl & 1u) << ci) | (((sm.fl >> 1) & 1u) << (8 + ci));
 		u32 clrm = ((1u << ci) | (1u << (8 + ci))) & ~setm;
-		if (setm) atomicOr(&t.flags[p], setm);
-		if (clrm) atomicAnd(&t.flags[p], ~clrm);
+		if (setm) aOr<WG>(&t.flags[p], setm);
+		if (clrm) aAnd<WG>(&t.flags[p], ~clrm);
 	}
 	return ch;
 }
@@ -146,10 +147,11 @@ __device__ inline Summ readStored(const Table& t, const MapGeom& g, u32 s, u64 l
 
 // The node became a leaf again (deleteChildren, octree.h:1060-1066): mark the block DEAD and clear
 // the parent's "child is inner" bit.
+template <bool WG = false>
 __device__ inline void collapseBlock(const Table& t, u32 s, u64 lk)
 {
-	atomicOr(&t.flags[s], F_DEAD);
-	if (1 != lk) atomicAnd(&t.flags[t.parent[s]], ~(1u << (16 + (u32)(lk & 7))));
+	aOr<WG>(&t.flags[s], F_DEAD);
+	if (1 != lk) aAnd<WG>(&t.flags[t.parent[s]], ~(1u << (16 + (u32)(lk & 7))));
 }
 
 __device__ inline bool sameSumm(const MapGeom& g, const Summ& a, const Summ& b)
@@ -206,11 +208,12 @@ __device__ inline bool lastReached(const Table& t, const MapGeom& g, u32 s, u64 
 
 // Queue block p for the next propagation level. `want` may differ per lane; the append is one atomic
 // per wave, so every active lane of the wave must make this call.
+template <bool WG = false>
 __device__ inline void markDirty(const Table& t, bool want, u32 p, u32* __restrict__ wl, u32* wl_count)
 {
 	bool first = false;
-	if (want) first = !(atomicOr(&t.flags[p], F_DIRTY) & F_DIRTY);
-	u32 pos = waveAppend(wl_count, first);
+	if (want) first = !(aOr<WG>(&t.flags[p], F_DIRTY) & F_DIRTY);
+	u32 pos = waveAppend<WG>(wl_count, first);
 	if (first) wl[pos] = p;
 }
 
@@ -537,26 +540,27 @@ __global__ __launch_bounds__(256) void k_apply_coarse(Table t, MapGeom g, const 
 // changed; a block whose own summary changes queues its parent for the next launch.
 // ------------------------------------------------------------------------------------------------
 // one block's updateNode + hand-off; `valid` false lanes only take part in the wave-aggregated append
+template <bool WG>
 __device__ inline void propagateOne(const Table& t, const MapGeom& g, bool valid, u32 s, u32 phase, u32* __restrict__ wl_out,
                                     u32* cnt_out)
 {
 	bool want = false;
 	u32 par = NONE;
 	if (valid) {
-		u32 old = atomicAnd(&t.flags[s], ~F_DIRTY);
+		u32 old = aAnd<WG>(&t.flags[s], ~F_DIRTY);
 		u64 lk = t.keys[s];
 		u32 level = levelOf(g, lk);
 		Summ sm = blockSummary(t, g, s, level, old);
 		// collapse only if the LAST update beneath this node walked all the way up to it (see above)
 		Summ pre = sm;
 		bool reached = lastReached(t, g, s, lk, level, old, phase, &pre);
-		if (reached && sm.collapsible) collapseBlock(t, s, lk);
-		bool changed = writeToParent(t, g, s, lk, sm);
+		if (reached && sm.collapsible) collapseBlock<WG>(t, s, lk);
+		bool changed = writeToParent<WG>(t, g, s, lk, sm);
 		publishLast(t, g, s, lk, phase, reached && !sameSumm(g, pre, sm), pre);
 		want = changed && 1 != lk;
 		if (want) par = t.parent[s];
 	}
-	markDirty(t, want, par, wl_out, cnt_out);
+	markDirty<WG>(t, want, par, wl_out, cnt_out);
 }
 
 __global__ __launch_bounds__(256) void k_propagate(Table t, MapGeom g, const u32* __restrict__ wl_in, u32* __restrict__ wl_out,
@@ -567,13 +571,14 @@ __global__ __launch_bounds__(256) void k_propagate(Table t, MapGeom g, const u32
 	const u32 stride = gridDim.x * blockDim.x;
 	const u32 iters = (n + stride - 1) / stride;
 	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-	for (u32 it = 0; it < iters; ++it, i += stride) propagateOne(t, g, i < n, i < n ? wl_in[i] : 0u, phase, wl_out, &ctl->wl_cnt[level + 1]);
+	for (u32 it = 0; it < iters; ++it, i += stride) propagateOne<false>(t, g, i < n, i < n ? wl_in[i] : 0u, phase, wl_out, &ctl->wl_cnt[level + 1]);
 }
 
 // All remaining levels in ONE single-workgroup launch: above the first two or three levels the
 // worklists hold a few thousand blocks at most, and 14 dependent launches would cost more than the
-// work (MI355X_MICROARCH.md "boundary": ~1.5-2 us each). Words that other threads modify with
-// atomics in this launch (flags, counters) are read with agent-scope atomic loads (L1 bypass).
+// work (MI355X_MICROARCH.md "boundary": ~1.5-2 us each). Only this workgroup touches the queued
+// blocks, their parents and the counters during the launch, so all atomics are workgroup-scope (done in
+// the XCD's L2 instead of an sc1 round trip to the memory side per hop).
 __global__ __launch_bounds__(1024) void k_propagate_tail(Table t, MapGeom g, u32* __restrict__ wl_a, u32* __restrict__ wl_b,
                                                          u32 first_level, u32 phase, ScanCtl* ctl)
 {
@@ -581,17 +586,17 @@ __global__ __launch_bounds__(1024) void k_propagate_tail(Table t, MapGeom g, u32
 	for (u32 level = first_level; level <= g.L; ++level) {
 		u32* in = (level & 1) ? wl_b : wl_a;
 		u32* out = (level & 1) ? wl_a : wl_b;
-		const u32 n = __hip_atomic_load(&ctl->wl_cnt[level], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		// level `first_level` was filled by an earlier launch; the later ones by this workgroup
+		const u32 n = aLoad<true>(&ctl->wl_cnt[level]);
 		if (0 == n) break;  // uniform
 		const u32 iters = (n + blockDim.x - 1) / blockDim.x;
 		u32 i = threadIdx.x;
 		for (u32 it = 0; it < iters; ++it, i += blockDim.x) {
 			u32 s = 0;
-			if (i < n) s = __hip_atomic_load(&in[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			propagateOne(t, g, i < n, s, phase, out, &ctl->wl_cnt[level + 1]);
+			if (i < n) s = in[i];
+			propagateOne<true>(t, g, i < n, s, phase, out, &ctl->wl_cnt[level + 1]);
 		}
-		__threadfence();
-		__syncthreads();
+		__syncthreads();  // workgroup-scope release/acquire: the next level reads what this one wrote
 	}
 }
 

@@ -121,9 +121,33 @@ __device__ inline void relaxMaxU64(u64* a, u64 v)
 	if (v > __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax((unsigned long long*)a, (unsigned long long)v);
 }
 
+// Atomics at a chosen scope. WG = true: workgroup scope (executed in the XCD's L2, no sc1 round trip to
+// the memory side) -- only legal when a single workgroup touches the word during the launch.
+template <bool WG>
+__device__ inline u32 aOr(u32* p, u32 v)
+{
+	return WG ? __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : atomicOr(p, v);
+}
+template <bool WG>
+__device__ inline u32 aAnd(u32* p, u32 v)
+{
+	return WG ? __hip_atomic_fetch_and(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : atomicAnd(p, v);
+}
+template <bool WG>
+__device__ inline u32 aAdd(u32* p, u32 v)
+{
+	return WG ? __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : atomicAdd(p, v);
+}
+template <bool WG>
+__device__ inline u32 aLoad(const u32* p)
+{
+	return WG ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // Wave-aggregated append: one atomicAdd per wave instead of one per lane. A single hot counter costs
 // ~12 ns per atomic (MI355X_MICROARCH.md "fanin"): 36 k appends to one word would be ~0.4 ms.
 // Must be called by all active lanes of the wave at the same program point.
+template <bool WG = false>
 __device__ inline u32 waveAppend(u32* counter, bool pred)
 {
 	const u64 mask = __ballot(pred);
@@ -131,7 +155,7 @@ __device__ inline u32 waveAppend(u32* counter, bool pred)
 	const u32 lane = __lane_id();
 	const int leader = __ffsll((unsigned long long)mask) - 1;
 	u32 base = 0;
-	if ((int)lane == leader) base = atomicAdd(counter, (u32)__popcll(mask));
+	if ((int)lane == leader) base = aAdd<WG>(counter, (u32)__popcll(mask));
 	base = __shfl(base, leader);
 	return base + (u32)__popcll(mask & ((1ULL << lane) - 1ULL));
 }
