@@ -137,6 +137,11 @@ int ufomap_map_scan_keys(ufomap_map* m, const double sensor_origin[3], const dou
                          size_t* n_entries);
 int ufomap_map_apply_keys(ufomap_map* m, const void* d_entries, size_t n_entries, unsigned depth);
 
+/* Diagnostics: up to 64 raw 64-bit words written by the last integration's kernels (per-level
+ * wall_clock64 stamps of the propagation tails: [level] hits phase, [32+level] misses phase, [31]/[63]
+ * end stamps; 100 MHz clock). Not part of the reference's surface. */
+int ufomap_map_debug(ufomap_map* m, uint64_t* out, int n);
+
 /* Raw HIP stream of the map (hipStream_t), for callers that need to order their own work. */
 void* ufomap_map_stream(ufomap_map* m);
 

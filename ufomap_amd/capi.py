@@ -25,7 +25,7 @@ SYMBOLS = [
     "ufomap_map_minmax_change", "ufomap_map_reset_minmax_change", "ufomap_map_stats",
     "ufomap_map_last_hits", "ufomap_map_last_misses", "ufomap_map_last_counts",
     "ufomap_map_set_profiling", "ufomap_map_kernel_times", "ufomap_map_reset_kernel_times",
-    "ufomap_map_scan_keys", "ufomap_map_apply_keys", "ufomap_map_stream",
+    "ufomap_map_scan_keys", "ufomap_map_apply_keys", "ufomap_map_stream", "ufomap_map_debug",
 ]
 
 _lib = None
@@ -79,6 +79,7 @@ def load():
     lib.ufomap_map_reset_kernel_times.argtypes = [vp]
     lib.ufomap_map_scan_keys.argtypes = [vp, f64p, vp, vp, sz, dbl, C.c_uint, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(sz)]
     lib.ufomap_map_apply_keys.argtypes = [vp, vp, sz, C.c_uint]
+    lib.ufomap_map_debug.argtypes = [vp, u64p, C.c_int]
     lib.ufomap_map_stream.restype = vp
     lib.ufomap_map_stream.argtypes = [vp]
     _lib = lib

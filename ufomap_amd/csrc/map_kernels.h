@@ -224,7 +224,7 @@ __device__ inline void markDirty(const Table& t, bool want, u32 p, u32* __restri
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_ensure(Table t, MapGeom g, const Entry* __restrict__ entries,
                                                 const u32* n_entries_p, u32 ent_cap, u32 scan_id, u32* __restrict__ ent_slot,
-                                                u32* __restrict__ newlist, u32 newcap, ScanCtl* ctl)
+                                                u32* __restrict__ newlist, u32 newcap, ScanCtl::PhaseCtr* pc, ScanCtl* ctl)
 {
 	u32 n = *n_entries_p;
 	const u32 max_probe = (t.mask >> 1) + 1;
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) void k_ensure(Table t, MapGeom g, const Entry*
 				const u64 act = __ballot(1);
 				const int leader = __ffsll((unsigned long long)act) - 1;
 				u32 base = 0;
-				if ((int)__lane_id() == leader) base = atomicAdd(&ctl->n_new, (u32)__popcll(act));
+				if ((int)__lane_id() == leader) base = atomicAdd(&pc->n_new, (u32)__popcll(act));
 				base = __shfl(base, leader);
 				u32 pos = base + (u32)__popcll(act & ((1ULL << __lane_id()) - 1ULL));
 				if (pos < newcap) newlist[pos] = s;
@@ -280,9 +280,9 @@ __global__ __launch_bounds__(256) void k_ensure(Table t, MapGeom g, const Entry*
 // S2 init: children of a new block inherit the whole value of the node (createChildren,
 // octree.h:1044-1054). The node's value is found in the first ancestor block that is not new.
 __global__ __launch_bounds__(256) void k_init_new(Table t, MapGeom g, const u32* __restrict__ newlist, u32 newcap,
-                                                  u32 scan_id, const ScanCtl* ctl)
+                                                  u32 scan_id, const ScanCtl::PhaseCtr* pc, const ScanCtl* ctl)
 {
-	u32 n = min(ctl->n_new, newcap);
+	u32 n = min(pc->n_new, newcap);
 	if (ctl->err) return;
 	for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
 		u32 s = newlist[i];
@@ -352,7 +352,7 @@ __device__ inline u32 blendColor(const MapGeom& g, u32 cur, u32 upd, float occ_o
 __global__ __launch_bounds__(256) void k_apply_leaf(Table t, MapGeom g, const Entry* __restrict__ entries,
                                                     const u32* n_entries_p, const u32* __restrict__ ent_slot, float upd,
                                                     u32 is_hit, u32 phase, HitHash hh, const uint8_t* __restrict__ rgb_in,
-                                                    u32* __restrict__ wl, ScanCtl* ctl)
+                                                    u32* __restrict__ wl, ScanCtl::PhaseCtr* pc, ScanCtl* ctl)
 {
 	u32 n = *n_entries_p;
 	if (ctl->err) return;
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(256) void k_apply_leaf(Table t, MapGeom g, const En
 		publishLast(t, g, s, e.lk, phase, !sameSumm(g, pre, sm), pre);
 		carryTime(t, s, e.lk, phase, t_last);
 		if (sm.collapsible) collapseBlock(t, s, e.lk);
-		markDirty(t, writeToParent(t, g, s, e.lk, sm), t.parent[s], wl, &ctl->wl_cnt[2]);
+		markDirty(t, writeToParent(t, g, s, e.lk, sm), t.parent[s], wl, &pc->wl_cnt[2]);
 	}
 }
 
@@ -482,7 +482,7 @@ __device__ inline bool subtreeApply(const Table& t, const MapGeom& g, u32 s0, u6
 // summary changed.
 __global__ __launch_bounds__(256) void k_apply_coarse(Table t, MapGeom g, const Entry* __restrict__ entries,
                                                       const u32* n_entries_p, const u32* __restrict__ ent_slot, float miss,
-                                                      u32 phase, u32* __restrict__ wl, ScanCtl* ctl)
+                                                      u32 phase, u32* __restrict__ wl, ScanCtl::PhaseCtr* pc, ScanCtl* ctl)
 {
 	u32 n = *n_entries_p;
 	if (ctl->err) return;
@@ -527,7 +527,7 @@ __global__ __launch_bounds__(256) void k_apply_coarse(Table t, MapGeom g, const 
 			if (writeToParent(t, g, s, e.lk, sm) && 1 != e.lk) {
 				// divergent context (few coarse entries): plain append
 				u32 pp = t.parent[s];
-				if (!(atomicOr(&t.flags[pp], F_DIRTY) & F_DIRTY)) wl[atomicAdd(&ctl->wl_cnt[level + 1], 1u)] = pp;
+				if (!(atomicOr(&t.flags[pp], F_DIRTY) & F_DIRTY)) wl[atomicAdd(&pc->wl_cnt[level + 1], 1u)] = pp;
 			}
 		}
 		publishLast(t, g, s, e.lk, phase, last_reached && !sameSumm(g, pre, fin), pre);
@@ -547,8 +547,13 @@ __device__ inline void propagateOne(const Table& t, const MapGeom& g, bool valid
 	bool want = false;
 	u32 par = NONE;
 	if (valid) {
-		u32 old = aAnd<WG>(&t.flags[s], ~F_DIRTY);
+		// independent loads first (one memory round trip instead of a chain), then the flag RMW
 		u64 lk = t.keys[s];
+		u32 pslot = t.parent[s];
+		u64 tv_prefetch = t.tmax[s];
+		float4 occ_pf = *reinterpret_cast<const float4*>(t.occ + 8 * (size_t)s);
+		u32 old = aAnd<WG>(&t.flags[s], ~F_DIRTY);
+		asm volatile("" ::"v"(pslot), "v"(tv_prefetch), "v"(occ_pf.x));  // keep the early loads where they are
 		u32 level = levelOf(g, lk);
 		Summ sm = blockSummary(t, g, s, level, old);
 		// collapse only if the LAST update beneath this node walked all the way up to it (see above)
@@ -564,14 +569,14 @@ __device__ inline void propagateOne(const Table& t, const MapGeom& g, bool valid
 }
 
 __global__ __launch_bounds__(256) void k_propagate(Table t, MapGeom g, const u32* __restrict__ wl_in, u32* __restrict__ wl_out,
-                                                   u32 level, u32 phase, ScanCtl* ctl)
+                                                   u32 level, u32 phase, ScanCtl::PhaseCtr* pc, const ScanCtl* ctl)
 {
 	if (ctl->err) return;
-	const u32 n = ctl->wl_cnt[level];
+	const u32 n = pc->wl_cnt[level];
 	const u32 stride = gridDim.x * blockDim.x;
 	const u32 iters = (n + stride - 1) / stride;
 	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-	for (u32 it = 0; it < iters; ++it, i += stride) propagateOne<false>(t, g, i < n, i < n ? wl_in[i] : 0u, phase, wl_out, &ctl->wl_cnt[level + 1]);
+	for (u32 it = 0; it < iters; ++it, i += stride) propagateOne<false>(t, g, i < n, i < n ? wl_in[i] : 0u, phase, wl_out, &pc->wl_cnt[level + 1]);
 }
 
 // All remaining levels in ONE single-workgroup launch: above the first two or three levels the
@@ -580,24 +585,26 @@ __global__ __launch_bounds__(256) void k_propagate(Table t, MapGeom g, const u32
 // blocks, their parents and the counters during the launch, so all atomics are workgroup-scope (done in
 // the XCD's L2 instead of an sc1 round trip to the memory side per hop).
 __global__ __launch_bounds__(1024) void k_propagate_tail(Table t, MapGeom g, u32* __restrict__ wl_a, u32* __restrict__ wl_b,
-                                                         u32 first_level, u32 phase, ScanCtl* ctl)
+                                                         u32 first_level, u32 phase, ScanCtl::PhaseCtr* pc, ScanCtl* ctl, u32 dbg_at)
 {
 	if (ctl->err) return;
 	for (u32 level = first_level; level <= g.L; ++level) {
+		if (0 == threadIdx.x) ctl->dbg[dbg_at + level] = wall_clock64();
 		u32* in = (level & 1) ? wl_b : wl_a;
 		u32* out = (level & 1) ? wl_a : wl_b;
 		// level `first_level` was filled by an earlier launch; the later ones by this workgroup
-		const u32 n = aLoad<true>(&ctl->wl_cnt[level]);
+		const u32 n = aLoad<true>(&pc->wl_cnt[level]);
 		if (0 == n) break;  // uniform
 		const u32 iters = (n + blockDim.x - 1) / blockDim.x;
 		u32 i = threadIdx.x;
 		for (u32 it = 0; it < iters; ++it, i += blockDim.x) {
 			u32 s = 0;
 			if (i < n) s = in[i];
-			propagateOne<true>(t, g, i < n, s, phase, out, &ctl->wl_cnt[level + 1]);
+			propagateOne<true>(t, g, i < n, s, phase, out, &pc->wl_cnt[level + 1]);
 		}
 		__syncthreads();  // workgroup-scope release/acquire: the next level reads what this one wrote
 	}
+	if (0 == threadIdx.x) ctl->dbg[dbg_at + 31] = wall_clock64();
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -40,14 +40,17 @@ struct ScanCtl {
 	u32 n_entries[2];  // [0] hit entries (level 1), [1] miss entries (level depth+1)
 	u32 err;
 	u32 n_codes;
-	u32 n_new;       // --- zeroed per phase, together with wl_cnt (contiguous) ---
-	u32 wl_cnt[24];  // wl_cnt[l] = number of level-l blocks queued for propagation
+	struct PhaseCtr {
+		u32 n_new;       // blocks created / revived by this phase
+		u32 wl_cnt[24];  // wl_cnt[l] = number of level-l blocks queued for propagation
+	} ph[2];             // [0] hits phase, [1] misses phase (zeroed with the control block upload)
 	i32 mb_min[3], mb_max[3];  // miss-grid cell bbox (cells at insert depth)
 	i32 hb_min[3], hb_max[3];  // hit-grid cell bbox (depth 0)
 	u64 aabb_min[3], aabb_max[3];  // order-encoded doubles: change AABB of this scan
 	unsigned long long n_steps;
 	u32 n_oob;  // cells dropped because their key lies outside [0, 2^L) (the reference aliases them)
 	u32 pad2;
+	unsigned long long dbg[64];  // diagnostics (ufomap_map_debug): per-level clocks of the propagation tails
 };
 
 // Per-workgroup partial results of k_classify / k_select (no atomics on shared words: thousands of
@@ -634,7 +637,12 @@ __global__ __launch_bounds__(UFO_DDA_BLOCK) void k_dda(MapGeom g, D3 sensor, u32
 	extern __shared__ __attribute__((aligned(16))) u32 lds[];
 	const u32 lds_words = (MODE == DDA_LDSGRID) ? (u32)(gr.bytes >> 2) : (MODE == DDA_FILTER ? (u32)UFO_DDA_FILT : 0u);
 	const u32 lds_init = (MODE == DDA_LDSGRID) ? 0u : 0xFFFFFFFFu;  // no cell has tag 2^32-1 (host guarantees)
-	for (u32 j = threadIdx.x; j < lds_words; j += UFO_DDA_BLOCK) lds[j] = lds_init;
+	if (MODE == DDA_LDSGRID) {
+		uint4* l4 = reinterpret_cast<uint4*>(lds);
+		for (u32 j = threadIdx.x; j < (lds_words >> 2); j += blockDim.x) l4[j] = make_uint4(0, 0, 0, 0);
+	} else {
+		for (u32 j = threadIdx.x; j < lds_words; j += blockDim.x) lds[j] = lds_init;
+	}
 	__syncthreads();
 	u32 n = ctl_in->n_rays;
 	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -703,49 +711,137 @@ __global__ __launch_bounds__(UFO_DDA_BLOCK) void k_dda(MapGeom g, D3 sensor, u32
 					// cells: key >> depth (step is +-2^depth in key units = +-1 cell)
 					i32 cx = (i32)(kx >> depth), cy = (i32)(ky >> depth), cz = (i32)(kz >> depth);
 					const i32 gx = (i32)(ex >> depth), gy = (i32)(ey >> depth), gz = (i32)(ez >> depth);
-					bool go;
-					do {
-						if (++steps > budget) {
-							err |= ERR_RUNAWAY;
-							break;
-						}
-						err |= ddaMark<MODE>(gr, grid, lds, cx, cy, cz, lim, &oob);
-						// minElementIndex VEC3:244-251: x<=y ? (x<=z ? x : z) : (y<=z ? y : z)
-						if (tmx <= tmy) {
-							if (tmx <= tmz) {
-								cx += sx;
-								tmx += tdx;
-							} else {
-								cz += sz;
-								tmz += tdz;
+					// One dependent instruction chain per ray: a single wave retires ~1 instruction per 8 cycles,
+					// so the step body is kept short and straight-line. The walk is monotone per axis between the
+					// start and the goal cell, so range checks are done once per ray: if both ends lie inside the
+					// key range and (with the one-block padding) inside the grid, no step needs a check.
+					const i32 l0x = cx - gr.base[0], l0y = cy - gr.base[1], l0z = cz - gr.base[2];
+					const i32 l1x = gx - gr.base[0], l1y = gy - gr.base[1], l1z = gz - gr.base[2];
+					const i32 mxx = 2 * gr.nb[0] - 2, mxy = 2 * gr.nb[1] - 2, mxz = 2 * gr.nb[2] - 2;
+					const bool safe = (u32)cx < lim && (u32)cy < lim && (u32)cz < lim && (u32)gx < lim && (u32)gy < lim && (u32)gz < lim &&
+					                  l0x >= 1 && l0y >= 1 && l0z >= 1 && l1x >= 1 && l1y >= 1 && l1z >= 1 && l0x <= mxx && l0y <= mxy &&
+					                  l0z <= mxz && l1x <= mxx && l1y <= mxy && l1z <= mxz && budget < 0xFFFFFFFFull;
+					if (safe) {
+						// local cell coordinates; the goal test and the grid index work on them directly
+						u32 lx = (u32)l0x, ly = (u32)l0y, lz = (u32)l0z;
+						const u32 tx = (u32)l1x, ty = (u32)l1y, tz = (u32)l1z;
+						const u32 nbx = (u32)gr.nb[0], nby = (u32)gr.nb[1];
+						const u32 budget32 = (u32)budget;
+						u32 cnt = 0;
+						bool go;
+						do {
+							if (++cnt > budget32) {
+								err |= ERR_RUNAWAY;
+								break;
 							}
-						} else {
-							if (tmy <= tmz) {
-								cy += sy;
-								tmy += tdy;
+							const u32 idx = ((lz >> 1) * nby + (ly >> 1)) * nbx + (lx >> 1);
+							const u32 bit = (lx & 1u) | ((ly & 1u) << 1) | ((lz & 1u) << 2) | ((idx & 3u) << 3);
+							if (MODE == DDA_LDSGRID) {
+								atomicOr(&lds[idx >> 2], 1u << bit);
 							} else {
-								cz += sz;
-								tmz += tdz;
+								u32* w = &grid[idx >> 2];
+								bool skip = false;
+								if (MODE == DDA_FILTER) {
+									const u32 tag = (idx << 3) | (bit & 7u);
+									const u32 h = (tag * 0x9E3779B1u) >> 17;
+									skip = lds[h] == tag;
+									if (!skip) {
+										lds[h] = tag;
+										skip = (*w >> bit) & 1u;
+									}
+								}
+								if (!skip) atomicOr(w, 1u << bit);
 							}
-						}
-						go = (cx != gx || cy != gy || cz != gz) && (fmin(fmin(tmx, tmy), tmz) <= dist);
-					} while (go);
+							// minElementIndex VEC3:244-251: x<=y ? (x<=z ? x : z) : (y<=z ? y : z), branch-free.
+							// Only the selected axis' t_max is touched (OCT:1227-1233), so the other two keep their bits.
+							const bool xy = tmx <= tmy, xz = tmx <= tmz, yz = tmy <= tmz;
+							const bool selx = xy && xz;
+							const bool sely = !xy && yz;
+							const bool selz = !(selx || sely);
+							lx += selx ? (u32)sx : 0u;
+							ly += sely ? (u32)sy : 0u;
+							lz += selz ? (u32)sz : 0u;
+							const double nx = tmx + tdx, ny = tmy + tdy, nz = tmz + tdz;
+							tmx = selx ? nx : tmx;
+							tmy = sely ? ny : tmy;
+							tmz = selz ? nz : tmz;
+							const double m1 = (tmy < tmx) ? tmy : tmx;  // std::min (VEC3:241)
+							const double m2 = (tmz < m1) ? tmz : m1;
+							go = (((lx ^ tx) | (ly ^ ty) | (lz ^ tz)) != 0u) && (m2 <= dist);
+						} while (go);
+						steps = cnt > budget32 ? budget32 : cnt;
+					} else {
+						// clipped or padded-out rays (rare): every step checked
+						bool go;
+						do {
+							if (++steps > budget) {
+								err |= ERR_RUNAWAY;
+								break;
+							}
+							err |= ddaMark<MODE>(gr, grid, lds, cx, cy, cz, lim, &oob);
+							if (tmx <= tmy) {
+								if (tmx <= tmz) {
+									cx += sx;
+									tmx += tdx;
+								} else {
+									cz += sz;
+									tmz += tdz;
+								}
+							} else {
+								if (tmy <= tmz) {
+									cy += sy;
+									tmy += tdy;
+								} else {
+									cz += sz;
+									tmz += tdz;
+								}
+							}
+							go = (cx != gx || cy != gy || cz != gz) && (fmin(fmin(tmx, tmy), tmz) <= dist);
+						} while (go);
+					}
 				}
 			}
 		}
 	}
 	if (MODE == DDA_LDSGRID) {
-		// one pass over the private copy: OR the non-zero words into the global grid
+		// Hand the private copy over as this workgroup's SLAB: plain coalesced 16-byte stores, no atomics
+		// (hundreds of workgroups OR-ing into the same few thousand words cost ~0.1 us per atomic in
+		// aggregate). k_merge_slabs ORs the slabs into grid M.
 		__syncthreads();
-		for (u32 j = threadIdx.x; j < lds_words; j += UFO_DDA_BLOCK) {
-			u32 v = lds[j];
-			if (v && (grid[j] & v) != v) atomicOr(&grid[j], v);
-		}
+		const uint4* l4 = reinterpret_cast<const uint4*>(lds);
+		uint4* out4 = reinterpret_cast<uint4*>(grid) + (size_t)blockIdx.x * (lds_words >> 2);
+		const u32 n4 = lds_words >> 2;  // the host rounds grid.bytes to 16
+		for (u32 j = threadIdx.x; j < n4; j += blockDim.x) out4[j] = l4[j];
 	}
 	// total step count (diagnostic; drives the algorithmic-bytes figure of bench.py)
 	waveAddU64(&ctl->n_steps, steps);
 	if (oob) atomicAdd(&ctl->n_oob, oob);
 	if (err) atomicOr(&ctl->err, err);
+}
+
+// OR the per-workgroup slabs of k_dda (LDS-grid mode) into grid M. One thread per 16-byte column.
+__global__ __launch_bounds__(256) void k_merge_slabs(const uint4* __restrict__ slabs, u32 n_slabs, u32 n4, uint4* __restrict__ grid)
+{
+	for (u32 j = blockIdx.x * blockDim.x + threadIdx.x; j < n4; j += gridDim.x * blockDim.x) {
+		uint4 acc = make_uint4(0, 0, 0, 0);
+		const uint4* p = slabs + j;
+		u32 s = 0;
+		for (; s + 4 <= n_slabs; s += 4) {
+			uint4 a = p[(size_t)s * n4], b = p[(size_t)(s + 1) * n4], c = p[(size_t)(s + 2) * n4], d = p[(size_t)(s + 3) * n4];
+			acc.x |= a.x | b.x | c.x | d.x;
+			acc.y |= a.y | b.y | c.y | d.y;
+			acc.z |= a.z | b.z | c.z | d.z;
+			acc.w |= a.w | b.w | c.w | d.w;
+		}
+		for (; s < n_slabs; ++s) {
+			uint4 a = p[(size_t)s * n4];
+			acc.x |= a.x;
+			acc.y |= a.y;
+			acc.z |= a.z;
+			acc.w |= a.w;
+		}
+		grid[j] = acc;
+	}
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -113,7 +113,7 @@ struct ufomap_map {
 	u64 used_est = 0;  // host-side view of MapRoot::used (refreshed at every control-block read)
 	// per-scan buffers
 	DevBuf b_ctl, b_pt_end, b_pt_flag, b_pt_slot, b_ray_end, b_hit_code, b_hit_pt, b_hh_keys, b_hh_idx;
-	DevBuf b_part0, b_part1;
+	DevBuf b_part0, b_part1, b_slabs;
 	DevBuf b_gridH, b_gridM, b_entries, b_ent_slot, b_newlist, b_wl0, b_wl1, b_in_xyz, b_in_rgb, b_codes, b_dump;
 	ScanCtl* h_ctl = nullptr;  // pinned
 	MapRoot* h_root = nullptr;  // pinned
@@ -339,7 +339,7 @@ int makeGrid(const i32 mn[3], const i32 mx[3], u32 depth, Grid* gr)
 	}
 	gr->depth = depth;
 	gr->pad = 0;
-	gr->bytes = (bytes + 7) & ~7ull;
+	gr->bytes = (bytes + 15) & ~15ull;  // whole uint4 words (k_dda's LDS copy is read 16 B at a time)
 	return UFOMAP_OK;
 }
 
@@ -355,7 +355,7 @@ u64 levelBound(const i32 nb[3], u32 shift)
 // `cap` is the capacity of the entry buffer (the device-side count may be smaller; if it is larger
 // k_ensure raises ERR_ENTRIES and nothing is applied).
 int applyEntries(ufomap_map* m, const Entry* d_entries, u32 cap, u32 which, u32 level, const i32 nb[3], float upd,
-                 const uint8_t* d_rgb)
+                 const uint8_t* d_rgb, bool zero_ctr)
 {
 	if (0 == cap) return UFOMAP_OK;
 	m->scan_id += 1;  // "new this phase" stamp: blocks made by an earlier phase of the same scan are old
@@ -367,41 +367,42 @@ int applyEntries(ufomap_map* m, const Entry* d_entries, u32 cap, u32 which, u32 
 	HIP_TRY(m->b_wl1.reserve(wlcap * 4));
 	ScanCtl* ctl = m->b_ctl.as<ScanCtl>();
 	const u32* d_n = &ctl->n_entries[which];
-	HIP_TRY(hipMemsetAsync(&ctl->n_new, 0, 4 * 25, m->stream));  // n_new + wl_cnt[24]
+	ScanCtl::PhaseCtr* pc = &ctl->ph[which];
+	if (zero_ctr) HIP_TRY(hipMemsetAsync(pc, 0, sizeof(ScanCtl::PhaseCtr), m->stream));
 	HitHash hh{m->b_hh_keys.as<u64>(), m->b_hh_idx.as<u32>(), m->hh_mask};
 	u32* wl[2] = {m->b_wl0.as<u32>(), m->b_wl1.as<u32>()};
 	dim3 ge = gridFor(cap);
 	{
 		ProfScope ps(m, "k_ensure");
 		hipLaunchKernelGGL(k_ensure, ge, dim3(256), 0, m->stream, m->t, m->g, d_entries, d_n, cap, m->scan_id, m->b_ent_slot.as<u32>(),
-		                   m->b_newlist.as<u32>(), (u32)std::min<u64>(newcap, 0xFFFFFFFFull), ctl);
+		                   m->b_newlist.as<u32>(), (u32)std::min<u64>(newcap, 0xFFFFFFFFull), pc, ctl);
 	}
 	{
 		ProfScope ps(m, "k_init_new");
 		hipLaunchKernelGGL(k_init_new, gridFor(std::min<u64>(newcap, cap)), dim3(256), 0, m->stream, m->t, m->g, m->b_newlist.as<u32>(),
-		                   (u32)std::min<u64>(newcap, 0xFFFFFFFFull), m->scan_id, ctl);
+		                   (u32)std::min<u64>(newcap, 0xFFFFFFFFull), m->scan_id, pc, ctl);
 	}
 	if (1 == level) {
 		ProfScope ps(m, "k_apply_leaf");
 		hipLaunchKernelGGL(k_apply_leaf, ge, dim3(256), 0, m->stream, m->t, m->g, d_entries, d_n, m->b_ent_slot.as<u32>(), upd,
-		                   (u32)(which == 0 ? 1 : 0), m->scan_id, hh, d_rgb, wl[0], ctl);
+		                   (u32)(which == 0 ? 1 : 0), m->scan_id, hh, d_rgb, wl[0], pc, ctl);
 	} else {
 		ProfScope ps(m, "k_apply_coarse");
 		hipLaunchKernelGGL(k_apply_coarse, ge, dim3(256), 0, m->stream, m->t, m->g, d_entries, d_n, m->b_ent_slot.as<u32>(), upd,
-		                   m->scan_id, wl[(level + 1) & 1], ctl);
+		                   m->scan_id, wl[(level + 1) & 1], pc, ctl);
 	}
 	// updateParents (OMB:1126-1133): wide levels one launch each, the narrow rest in one launch
 	u32 l = level + 1;
 	for (; l <= m->g.L; ++l) {
 		u64 bound = std::min<u64>(cap, levelBound(nb, l - level));
-		if (bound <= 8192) break;
+		if (bound <= 2048) break;
 		ProfScope ps(m, "k_propagate");
 		hipLaunchKernelGGL(k_propagate, gridFor(bound, 256, 1024), dim3(256), 0, m->stream, m->t, m->g, wl[l & 1], wl[(l + 1) & 1], l,
-		                   m->scan_id, ctl);
+		                   m->scan_id, pc, ctl);
 	}
 	if (l <= m->g.L) {
 		ProfScope ps(m, "k_propagate_tail");
-		hipLaunchKernelGGL(k_propagate_tail, dim3(1), dim3(1024), 0, m->stream, m->t, m->g, wl[0], wl[1], l, m->scan_id, ctl);
+		hipLaunchKernelGGL(k_propagate_tail, dim3(1), dim3(1024), 0, m->stream, m->t, m->g, wl[0], wl[1], l, m->scan_id, pc, ctl, which * 32u);
 	}
 	HIP_TRY(hipGetLastError());
 	return UFOMAP_OK;
@@ -409,7 +410,7 @@ int applyEntries(ufomap_map* m, const Entry* d_entries, u32 cap, u32 which, u32 
 
 // The map half of an integration: update lists from the two grids, then hits phase, then misses phase.
 // capH/capM: entry-buffer capacities (upper bounds or guesses; see ERR_ENTRIES).
-int mapPhase(ufomap_map* m, unsigned depth, const uint8_t* d_rgb, u64 capH, u64 capM)
+int mapPhase(ufomap_map* m, unsigned depth, const uint8_t* d_rgb, u64 capH, u64 capM, bool retry)
 {
 	ScanCtl* ctl = m->b_ctl.as<ScanCtl>();
 	const float miss = (float)(m->g.miss_log / double((2.0 * depth) + 1));  // OMB:311
@@ -432,7 +433,7 @@ int mapPhase(ufomap_map* m, unsigned depth, const uint8_t* d_rgb, u64 capH, u64 
 	HIP_TRY(m->b_entries.reserve(((size_t)capH + capM + 1) * sizeof(Entry)));
 	Entry* ent_h = m->b_entries.as<Entry>();
 	Entry* ent_m = ent_h + capH;
-	HIP_TRY(hipMemsetAsync(&ctl->n_entries[0], 0, 8, m->stream));
+	if (retry) HIP_TRY(hipMemsetAsync(&ctl->n_entries[0], 0, 8, m->stream));  // otherwise zero from the control-block upload
 	if (capH) {
 		ProfScope ps(m, "k_extract");
 		hipLaunchKernelGGL(k_extract, gridFor(m->gridH.bytes >> 2, 256, 2048), dim3(256), 0, m->stream, m->g, m->gridH,
@@ -443,9 +444,9 @@ int mapPhase(ufomap_map* m, unsigned depth, const uint8_t* d_rgb, u64 capH, u64 
 		hipLaunchKernelGGL(k_extract, gridFor(m->gridM.bytes >> 2, 256, 2048), dim3(256), 0, m->stream, m->g, m->gridM,
 		                   m->b_gridM.as<u32>(), 1u, ent_m, (u32)capM, ctl);
 	}
-	int rc = applyEntries(m, ent_h, (u32)capH, 0, 1, m->gridH.nb, m->g.hit, d_rgb);
+	int rc = applyEntries(m, ent_h, (u32)capH, 0, 1, m->gridH.nb, m->g.hit, d_rgb, retry);
 	if (rc) return rc;
-	return applyEntries(m, ent_m, (u32)capM, 1, (u32)depth + 1, m->gridM.nb, miss, nullptr);
+	return applyEntries(m, ent_m, (u32)capM, 1, (u32)depth + 1, m->gridM.nb, miss, nullptr, retry);
 }
 
 int finishPending(ufomap_map* m)
@@ -458,7 +459,7 @@ int finishPending(ufomap_map* m)
 		// the guessed update-list capacity was too small; nothing was applied. Redo with the exact sizes.
 		u64 capH = m->h_ctl->n_entries[0], capM = m->h_ctl->n_entries[1];
 		HIP_TRY(hipMemsetAsync(&m->b_ctl.as<ScanCtl>()->err, 0, 4, m->stream));
-		rc = mapPhase(m, m->last_depth, m->last_rgb, capH, capM);
+		rc = mapPhase(m, m->last_depth, m->last_rgb, capH, capM, true);
 		if (rc) return rc;
 		rc = readCtl(m);
 		if (rc) return rc;
@@ -468,7 +469,7 @@ int finishPending(ufomap_map* m)
 	if (rc) return rc;
 	m->counts[5] = (u64)m->h_ctl->n_entries[0] + m->h_ctl->n_entries[1];
 	m->counts[2] = m->h_ctl->n_steps;
-	m->counts[6] = m->h_ctl->n_new;
+	m->counts[6] = (u64)m->h_ctl->ph[0].n_new + m->h_ctl->ph[1].n_new;
 	m->counts[7] = m->h_ctl->n_oob;
 	for (int a = 0; a < 3; ++a) {
 		double lo = decD(m->h_ctl->aabb_min[a]), hi = decD(m->h_ctl->aabb_max[a]);
@@ -516,7 +517,7 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 	HIP_TRY(m->b_ray_end.reserve(n * sizeof(D3)));
 	HIP_TRY(m->b_hit_code.reserve(n * 8));
 	HIP_TRY(m->b_hit_pt.reserve(n * 4));
-	u32 hcap = nextPow2(std::max<u64>(1024, (u64)n * 4));
+	u32 hcap = nextPow2(std::max<u64>(1024, (u64)n * 2 + (depth ? (u64)n * 2 : 0)));  // load <= 0.5 (hits, + ray cells when depth > 0)
 	HIP_TRY(m->b_hh_keys.reserve((size_t)hcap * 8));
 	HIP_TRY(m->b_hh_idx.reserve((size_t)hcap * 4));
 	HIP_TRY(hipMemsetAsync(m->b_hh_keys.p, 0xFF, (size_t)hcap * 8, m->stream));
@@ -565,9 +566,9 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 		                   m->b_part0.as<BoxPartial>(), ctl);
 	}
 	HIP_TRY(hipGetLastError());
-	int rc = readCtl(m);
-	if (rc) return rc;
-	rc = ctlError(m);
+	HIP_TRY(hipMemcpyAsync(m->h_ctl, m->b_ctl.p, sizeof(ScanCtl), hipMemcpyDeviceToHost, m->stream));
+	HIP_TRY(hipStreamSynchronize(m->stream));
+	int rc = ctlError(m);
 	if (rc) return rc;
 	const u32 n_rays = m->h_ctl->n_rays, n_hits = m->h_ctl->n_hits;
 	m->counts[1] = n_rays;
@@ -602,14 +603,27 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 	}
 	if (m->haveM) {
 		HIP_TRY(m->b_gridM.reserve(m->gridM.bytes));
-		HIP_TRY(hipMemsetAsync(m->b_gridM.p, 0, m->gridM.bytes, m->stream));
-		ProfScope ps(m, "k_dda");
-		dim3 gr((n_rays + UFO_DDA_BLOCK - 1) / UFO_DDA_BLOCK);
 		const int mode = m->gridM.bytes <= UFO_DDA_LDSGRID_MAX ? DDA_LDSGRID : (m->gridM.bytes < (1ull << 29) ? DDA_FILTER : DDA_DIRECT);
 		const size_t lds = mode == DDA_LDSGRID ? (size_t)m->gridM.bytes : (mode == DDA_FILTER ? (size_t)UFO_DDA_FILT * 4 : 0);
+		// Workgroup size: each ray is one dependent instruction chain (~180 steps), so the kernel's time is
+		// the longest ray's latency whatever the occupancy (measured: 128- and 1024-thread workgroups run
+		// the same). Large workgroups mean fewer LDS-grid slabs to merge and a wider dedup scope for the
+		// filter, so use the maximum unless the scan is tiny.
+		u32 blk = UFO_DDA_BLOCK;
+		while (blk > 128 && (n_rays + blk - 1) / blk < 32) blk >>= 1;
+		dim3 gr((n_rays + blk - 1) / blk);
+		u32* dda_out = m->b_gridM.as<u32>();
+		if (mode == DDA_LDSGRID) {
+			HIP_TRY(m->b_slabs.reserve((size_t)gr.x * m->gridM.bytes));  // <= 512 x 144 KiB
+			dda_out = m->b_slabs.as<u32>();
+		} else {
+			HIP_TRY(hipMemsetAsync(m->b_gridM.p, 0, m->gridM.bytes, m->stream));
+		}
+		{
+		ProfScope ps(m, "k_dda");
 #define UFO_LAUNCH_DDA(SIMPLE, MODE)                                                                                         \
-	hipLaunchKernelGGL((k_dda<SIMPLE, MODE>), gr, dim3(UFO_DDA_BLOCK), lds, m->stream, m->g, sensor, (u32)depth, m->gridM, \
-	                   m->b_gridM.as<u32>(), m->b_ray_end.as<D3>(), ctl, ctl)
+	hipLaunchKernelGGL((k_dda<SIMPLE, MODE>), gr, dim3(blk), lds, m->stream, m->g, sensor, (u32)depth, m->gridM, \
+	                   dda_out, m->b_ray_end.as<D3>(), ctl, ctl)
 		if (simple) {
 			if (mode == DDA_LDSGRID) UFO_LAUNCH_DDA(true, DDA_LDSGRID);
 			else if (mode == DDA_FILTER) UFO_LAUNCH_DDA(true, DDA_FILTER);
@@ -620,6 +634,13 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 			else UFO_LAUNCH_DDA(false, DDA_DIRECT);
 		}
 #undef UFO_LAUNCH_DDA
+		}
+		if (mode == DDA_LDSGRID) {
+			ProfScope ps(m, "k_merge_slabs");
+			const u32 n4 = (u32)(m->gridM.bytes >> 4);
+			hipLaunchKernelGGL(k_merge_slabs, gridFor(n4, 256, 2048), dim3(256), 0, m->stream, m->b_slabs.as<uint4>(), gr.x, n4,
+			                   m->b_gridM.as<uint4>());
+		}
 	}
 
 	// ---- map phases: all hits, then all misses (OMB:1351-1365). No host round trip here: the update-list
@@ -629,7 +650,7 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 	m->last_rgb = d_rgb;
 	u64 capH = m->haveH ? std::min<u64>(n_hits, m->gridH.bytes) : 0;
 	u64 capM = m->haveM ? std::min<u64>(m->gridM.bytes, std::max<u64>(1u << 20, (u64)n_rays * 64)) : 0;
-	rc = mapPhase(m, depth, d_rgb, capH, capM);
+	rc = mapPhase(m, depth, d_rgb, capH, capM, false);
 	if (rc) return rc;
 	(void)after_select;
 	HIP_TRY(hipGetLastError());
@@ -732,7 +753,7 @@ void ufomap_map_destroy(ufomap_map* m)
 	m->tb.release();
 	DevBuf* bufs[] = {&m->b_root,
 	                  &m->b_ctl,     &m->b_pt_end,  &m->b_pt_flag,  &m->b_pt_slot, &m->b_ray_end, &m->b_hit_code, &m->b_hit_pt,
-	                  &m->b_hh_keys, &m->b_hh_idx,  &m->b_gridH,    &m->b_gridM,   &m->b_part0,   &m->b_part1,   &m->b_entries, &m->b_ent_slot, &m->b_newlist,
+	                  &m->b_hh_keys, &m->b_hh_idx,  &m->b_gridH,    &m->b_gridM,   &m->b_part0,   &m->b_part1,   &m->b_slabs,   &m->b_entries, &m->b_ent_slot, &m->b_newlist,
 	                  &m->b_wl0,     &m->b_wl1,     &m->b_in_xyz,   &m->b_in_rgb,  &m->b_codes,   &m->b_dump};
 	for (DevBuf* b : bufs) b->release();
 	for (PendingEvent& pe : m->pend_ev) {
@@ -1087,6 +1108,14 @@ int ufomap_map_scan_keys(ufomap_map*, const double*, const double*, const uint8_
 int ufomap_map_apply_keys(ufomap_map*, const void*, size_t, unsigned)
 {
 	return fail(UFOMAP_ERR_UNSUPPORTED, "ufomap_map_apply_keys: not implemented yet");
+}
+
+int ufomap_map_debug(ufomap_map* m, uint64_t* out, int n)
+{
+	if (!m) return fail(UFOMAP_ERR_INVALID, "null map");
+	int rc = ufomap_map_wait(m);
+	for (int i = 0; i < n && i < 64; ++i) out[i] = m->h_ctl->dbg[i];
+	return rc;
 }
 
 void* ufomap_map_stream(ufomap_map* m) { return m ? (void*)m->stream : nullptr; }
