@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-batch", action="store_true", help="run the N>1 code path (scan/exchange/apply) even with one rank")
     ap.add_argument("--profile-kernels", type=int, default=1, help="bracket every kernel with HIP events in the timed region")
     args = ap.parse_args()
 
@@ -86,8 +87,15 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    batch_mode = world > 1 or args.force_batch
+    # RCCL prints a version banner on stdout: keep stdout clean for the ONE JSON line (banner -> stderr)
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+    if batch_mode:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     from ufomap_amd import OccupancyMap, scans
@@ -101,7 +109,7 @@ def main():
     d_xyz = torch.from_numpy(xyz).to(torch.device("cuda", local_rank))  # resident in HBM before timing
     m = OccupancyMap(RES, device=local_rank)
 
-    if world > 1:
+    if batch_mode:
         from ufomap_amd import dist as udist
         batch = udist.BatchIntegrator(m, dist.group.WORLD, torch.device("cuda", local_rank))
 
@@ -114,7 +122,7 @@ def main():
     def sync():
         m.insertPointCloudWait()
         torch.cuda.synchronize()
-        if world > 1:
+        if batch_mode:
             dist.barrier()
 
     for _ in range(args.warmup):
@@ -142,14 +150,14 @@ def main():
         m.set_profiling(False)
         ktimes = m.kernel_times()
 
-    if world > 1:
+    if batch_mode:
         tt = torch.tensor([dt], dtype=torch.float64, device=torch.device("cuda", local_rank))
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
     if rank == 0:
         # counts of the exact input (from the last integration) for the algorithmic-byte formula
-        if world == 1:
+        if not batch_mode:
             counts = m.last_counts()
             hits, misses = m.last_hits(), m.last_misses()
         else:
@@ -190,19 +198,26 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64 ray casting / u64 Morton keys / f32 log-odds", "data": "synthetic",
             "config": {"workload": "configs[1]: single synthetic 64-beam LiDAR scan, 131072 pts, 16 cm leaf, 20 m max-range, discrete integrator + free-space raycast, warm map"
-                       if world == 1 else "configs[3]: batch of N concurrent 131072-pt LiDAR scans, 16 cm leaf, one scan per GPU, RCCL exchange of update lists, every replica applies all N in order",
+                       if not batch_mode else "configs[3]: batch of N concurrent 131072-pt LiDAR scans, 16 cm leaf, one scan per GPU, RCCL exchange of update lists, every replica applies all N in order",
                        "points_per_scan": n_pts, "rays_cast": counts["rays"], "dda_steps": counts["steps"], "unique_hits": int(len(hits)),
                        "unique_miss_cells": int(len(misses)), "sum_U_d": sum_ud, "leaf_m": RES, "max_range_m": MAX_RANGE,
                        "depth_levels": 16, "parallelism": f"scan-per-gpu x{world}"},
             "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if not batch_mode and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(origin, xyz)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
         else:
             out["cpu_baseline"] = None
+        sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)  # RCCL's banner sits in the C stdio buffer
+        except Exception:
+            pass
+        os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if batch_mode:
         dist.barrier()
         dist.destroy_process_group()
 

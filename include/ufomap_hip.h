@@ -123,19 +123,31 @@ int ufomap_map_kernel_times(ufomap_map* m, const char** names, uint64_t* launche
                             int cap);
 int ufomap_map_reset_kernel_times(ufomap_map* m);
 
-/* ---- multi-GPU batched scans: stage split ------------------------------------
- * ufomap_map_scan_keys runs the ray-casting / dedup half of the path for one scan WITHOUT
- * touching the map and leaves its update list on the device:
- *   entries: *n_entries records of 16 bytes {u64 location key of an 8-child node block,
- *            u8 hit mask, u8 miss mask, u8 level, 5 pad/colour index}, see DESIGN.md;
- * ufomap_map_apply_keys applies one such list (e.g. received from a peer GPU over RCCL) to this
- * map with the reference's ordering (hits, clamp, misses, clamp). Applying the lists of scans
- * 0..B-1 in order on every replica reproduces sequential integration bit-exactly. */
-int ufomap_map_scan_keys(ufomap_map* m, const double sensor_origin[3], const double* d_xyz,
-                         const uint8_t* d_rgb, size_t n, double max_range, unsigned depth,
-                         int discrete, int simple_ray_casting, void** d_entries,
-                         size_t* n_entries);
-int ufomap_map_apply_keys(ufomap_map* m, const void* d_entries, size_t n_entries, unsigned depth);
+/* ---- multi-GPU batched scans: the path split at its only exchange point -----------
+ * The reference integrates scans one after the other into one tree. For a batch of scans taken by
+ * different sensors (BASELINE config C4) every GPU ray-casts ITS scan (scan_keys: the ~80 % of the work
+ * that never reads the map) and produces the scan's update list; the lists are exchanged (RCCL
+ * all-gather, done by the caller) and every replica applies all lists in scan order (apply_keys), which
+ * reproduces sequential integration bit-exactly -- clamping makes summed log-odds deltas inexact.
+ *
+ * An update list is n_hit + n_miss records of 16 bytes, hit records first:
+ *   u64 location key of an 8-child node block | u8 hit mask | u8 miss mask | u8 level |
+ *   u8 child updated last | u32 point index of that update (hits: cloud order)
+ * scan_keys leaves the list in the map's scratch memory (valid until the next call on this map);
+ * get_keys copies it (device to device) into caller memory, e.g. a torch tensor used as RCCL buffer.
+ * apply_keys: non-colour maps only. d_xyz / d_dst / d_entries are DEVICE pointers. */
+typedef struct ufomap_keys_info {
+	uint32_t n_hit, n_miss; /* records */
+	int32_t nb_hit[3];      /* extent of the scan's hit grid in node blocks (sizes the node table) */
+	int32_t nb_miss[3];
+	uint32_t depth;         /* insert depth of the scan: miss records are level depth+1 */
+	uint32_t reserved;
+} ufomap_keys_info;
+int ufomap_map_scan_keys(ufomap_map* m, const double sensor_origin[3], const double* d_xyz, size_t n,
+                         double max_range, unsigned depth, int discrete, int simple_ray_casting,
+                         ufomap_keys_info* info);
+int ufomap_map_get_keys(ufomap_map* m, void* d_dst, size_t cap_entries, const ufomap_keys_info* info);
+int ufomap_map_apply_keys(ufomap_map* m, const void* d_entries, const ufomap_keys_info* info);
 
 /* Diagnostics: up to 64 raw 64-bit words written by the last integration's kernels (per-level
  * wall_clock64 stamps of the propagation tails: [level] hits phase, [32+level] misses phase, [31]/[63]

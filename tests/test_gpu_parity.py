@@ -165,3 +165,55 @@ def test_runaway_ray_is_refused_and_map_unchanged():
         _gpu_insert(g, origin, pt, max_range=40.0, discrete=True)
     assert e.value.code in (capi.ERR_RUNAWAY, capi.ERR_CAPACITY)
     assert len(g.leaves()[0]) == 0
+
+
+def test_split_path_equals_sequential_c4():
+    """scan_keys + apply_keys (the multi-GPU split of the path) applied in scan order on one GPU equals
+    sequential insertPointCloudDiscrete of the same 8 scans (BASELINE config C4), bit for bit."""
+    import torch
+    from ufomap_amd import OccupancyMap, scans
+    from ufomap_amd.dist import ENTRY_BYTES
+    seq, o = _maps(resolution=0.16)
+    split = OccupancyMap(0.16)
+    scanner = OccupancyMap(0.16)  # plays "another GPU": only ever scans, its own map stays empty
+    lists = []
+    for s in range(8):
+        origin, xyz, _ = scans.lidar64(origin=scans.lidar_pose(s), seed=100 + s, beams=32, azimuths=1024)
+        _gpu_insert(seq, origin, xyz, max_range=20.0, discrete=True)
+        o.insert(origin, xyz, max_range=20.0, discrete=True)
+        d = torch.from_numpy(xyz).cuda()
+        info = scanner.scan_keys(origin, d.data_ptr(), xyz.shape[0], 20.0, 0, True)
+        buf = torch.empty((info.n_hit + info.n_miss) * ENTRY_BYTES, dtype=torch.uint8, device="cuda")
+        scanner.get_keys(buf.data_ptr(), info.n_hit + info.n_miss, info)
+        lists.append((info, buf))
+    assert len(scanner.leaves()[0]) == 0  # scanning never touches the map
+    for info, buf in lists:
+        split.apply_keys(buf.data_ptr(), info)
+    _assert_same_map(seq, o, "sequential")
+    assert same_dump(split.leaves(True), o.leaves(True)), "split path: leaves differ"
+    assert same_dump(split.inner(), o.inner()), "split path: inner nodes differ"
+
+
+def test_batch_integrator_rccl_world1():
+    """BatchIntegrator on HBM tensors through the nccl (RCCL) backend with a single rank: the same code
+    path the 8-GPU run takes, minus the peers."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from ufomap_amd import OccupancyMap, scans
+    from ufomap_amd.dist import BatchIntegrator
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        g, o = _maps(resolution=0.16)
+        bi = BatchIntegrator(g, dist.group.WORLD, torch.device("cuda", 0))
+        for s in range(3):
+            origin, xyz, _ = scans.lidar64(origin=scans.lidar_pose(s), seed=100 + s, beams=32, azimuths=1024)
+            d = torch.from_numpy(xyz).cuda()
+            bi.integrate(origin, d.data_ptr(), xyz.shape[0], 20.0, 0, True)
+            o.insert(origin, xyz, max_range=20.0, discrete=True)
+        assert same_dump(g.leaves(True), o.leaves(True))
+        assert same_dump(g.inner(), o.inner())
+    finally:
+        dist.destroy_process_group()

@@ -25,10 +25,31 @@ SYMBOLS = [
     "ufomap_map_minmax_change", "ufomap_map_reset_minmax_change", "ufomap_map_stats",
     "ufomap_map_last_hits", "ufomap_map_last_misses", "ufomap_map_last_counts",
     "ufomap_map_set_profiling", "ufomap_map_kernel_times", "ufomap_map_reset_kernel_times",
-    "ufomap_map_scan_keys", "ufomap_map_apply_keys", "ufomap_map_stream", "ufomap_map_debug",
+    "ufomap_map_scan_keys", "ufomap_map_get_keys", "ufomap_map_apply_keys", "ufomap_map_stream", "ufomap_map_debug",
 ]
 
 _lib = None
+
+
+class KeysInfo(C.Structure):
+    """``ufomap_keys_info`` of include/ufomap_hip.h (header of one scan's update list)."""
+    _fields_ = [("n_hit", C.c_uint32), ("n_miss", C.c_uint32), ("nb_hit", C.c_int32 * 3), ("nb_miss", C.c_int32 * 3),
+                ("depth", C.c_uint32), ("reserved", C.c_uint32)]
+
+    WORDS = 10  # as a flat int32 vector for exchange between ranks
+
+    def to_list(self):
+        return [self.n_hit, self.n_miss, *self.nb_hit, *self.nb_miss, self.depth, self.reserved]
+
+    @classmethod
+    def from_list(cls, v):
+        k = cls()
+        k.n_hit, k.n_miss = int(v[0]), int(v[1])
+        for a in range(3):
+            k.nb_hit[a] = int(v[2 + a])
+            k.nb_miss[a] = int(v[5 + a])
+        k.depth, k.reserved = int(v[8]), int(v[9])
+        return k
 
 
 class UfomapError(RuntimeError):
@@ -77,8 +98,9 @@ def load():
     lib.ufomap_map_set_profiling.argtypes = [vp, C.c_int]
     lib.ufomap_map_kernel_times.argtypes = [vp, C.POINTER(C.c_char_p), u64p, f64p, C.c_int]
     lib.ufomap_map_reset_kernel_times.argtypes = [vp]
-    lib.ufomap_map_scan_keys.argtypes = [vp, f64p, vp, vp, sz, dbl, C.c_uint, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(sz)]
-    lib.ufomap_map_apply_keys.argtypes = [vp, vp, sz, C.c_uint]
+    lib.ufomap_map_scan_keys.argtypes = [vp, f64p, vp, sz, dbl, C.c_uint, C.c_int, C.c_int, C.POINTER(KeysInfo)]
+    lib.ufomap_map_get_keys.argtypes = [vp, vp, sz, C.POINTER(KeysInfo)]
+    lib.ufomap_map_apply_keys.argtypes = [vp, vp, C.POINTER(KeysInfo)]
     lib.ufomap_map_debug.argtypes = [vp, u64p, C.c_int]
     lib.ufomap_map_stream.restype = vp
     lib.ufomap_map_stream.argtypes = [vp]

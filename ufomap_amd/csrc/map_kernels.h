@@ -363,11 +363,11 @@ __global__ __launch_bounds__(256) void k_apply_leaf(Table t, MapGeom g, const En
 		float4 a = po[0], b = po[1];
 		float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 		const u32 mask = is_hit ? e.hit : e.miss;
-		// the child updated last: highest code for misses, latest first-point for hits (cloud order)
-		int c_last = 31 - __clz((int)mask);
-		u64 t_last = 0;
+		// the child updated last (k_extract): highest code for misses, latest first-point for hits
+		const int c_last = (int)e.c_last;
+		const u64 t_last = e.t_last;
 		u32 oldc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-		if (is_hit) {
+		if (is_hit && g.color && rgb_in) {
 			const u64 pcode = (e.lk ^ (1ULL << (3 * (g.L - 1)))) << 3;  // depth-0 code of child 0
 #pragma unroll
 			for (int c = 0; c < 8; ++c) {
@@ -375,17 +375,11 @@ __global__ __launch_bounds__(256) void k_apply_leaf(Table t, MapGeom g, const En
 				u32 hs = hitHashFind(hh, pcode | (u64)c);
 				if (hs == NONE) continue;
 				u32 pt = hh.minidx[hs];
-				if ((u64)pt >= t_last) {
-					t_last = pt;
-					c_last = c;
-				}
-				if (g.color && rgb_in) {
-					// updateValue(code, update, color): colour first, with the OLD occupancy (OMC.h:275-277)
-					u32 u = (u32)rgb_in[3 * (size_t)pt] | ((u32)rgb_in[3 * (size_t)pt + 1] << 8) | ((u32)rgb_in[3 * (size_t)pt + 2] << 16);
-					u32* pc = t.rgb + 8 * (size_t)s + c;
-					oldc[c] = *pc;
-					*pc = blendColor(g, oldc[c], u, v[c]);
-				}
+				// updateValue(code, update, color): colour first, with the OLD occupancy (OMC.h:275-277)
+				u32 u = (u32)rgb_in[3 * (size_t)pt] | ((u32)rgb_in[3 * (size_t)pt + 1] << 8) | ((u32)rgb_in[3 * (size_t)pt + 2] << 16);
+				u32* pc = t.rgb + 8 * (size_t)s + c;
+				oldc[c] = *pc;
+				*pc = blendColor(g, oldc[c], u, v[c]);
 			}
 		}
 		u32 old_rgb_last = 0;

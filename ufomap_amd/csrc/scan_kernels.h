@@ -66,7 +66,8 @@ struct Entry {
 	u8 hit;    // children that received a hit (level-1 blocks only)
 	u8 miss;   // children that received a miss
 	u8 level;  // level of the block = depth of its children + 1
-	u8 pad[5];
+	u8 c_last;  // hits phase: child that the reference updates last (latest first-point, cloud order)
+	u32 t_last; // hits phase: point index of that child's first point ("time" of the block's last update)
 };
 
 // order-preserving double <-> u64 (for atomicMin/Max on doubles)
@@ -556,7 +557,8 @@ __device__ inline bool gridMark(const Grid& gr, u32* __restrict__ grid, i32 cx, 
 }
 
 // K_hitmark: unique hits -> grid H (depth 0)
-__global__ __launch_bounds__(256) void k_hitmark(MapGeom g, Grid gr, u32* __restrict__ grid, const u64* __restrict__ hit_code,
+__global__ __launch_bounds__(256) void k_hitmark(MapGeom g, Grid gr, u32* __restrict__ grid, u32* __restrict__ blk_time,
+                                                 const u64* __restrict__ hit_code, const u32* __restrict__ hit_pt,
                                                  const ScanCtl* ctl_in, ScanCtl* ctl)
 {
 	u32 n = ctl_in->n_hits;
@@ -574,6 +576,14 @@ __global__ __launch_bounds__(256) void k_hitmark(MapGeom g, Grid gr, u32* __rest
 			k[a] = (u32)v;
 		}
 		if (!gridMark(gr, grid, (i32)k[0], (i32)k[1], (i32)k[2], 1u << g.L, &ctl->n_oob)) atomicOr(&ctl->err, ERR_GRID_OOB);
+		// "time" of the block's last hit: hits are applied in cloud order (OMB:1351-1354), so the child whose
+		// first point comes latest is updated last. One atomicMax per hit on (point index << 3 | child).
+		i32 lx = (i32)k[0] - gr.base[0], ly = (i32)k[1] - gr.base[1], lz = (i32)k[2] - gr.base[2];
+		if (lx >= 0 && ly >= 0 && lz >= 0 && (lx >> 1) < gr.nb[0] && (ly >> 1) < gr.nb[1] && (lz >> 1) < gr.nb[2]) {
+			u64 idx = ((u64)(lz >> 1) * (u64)gr.nb[1] + (u64)(ly >> 1)) * (u64)gr.nb[0] + (u64)(lx >> 1);
+			u32 child = (u32)((lx & 1) | ((ly & 1) << 1) | ((lz & 1) << 2));
+			atomicMax(&blk_time[idx], (hit_pt[i] << 3) | child);
+		}
 	}
 }
 
@@ -848,7 +858,7 @@ __global__ __launch_bounds__(256) void k_merge_slabs(const uint4* __restrict__ s
 // K3 extract: non-zero bytes of the grids -> update list, one entry per touched node block.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_extract(MapGeom g, Grid gr, const u32* __restrict__ grid, u32 which,
-                                                 Entry* __restrict__ entries, u32 cap, ScanCtl* ctl)
+                                                 const u32* __restrict__ blk_time, Entry* __restrict__ entries, u32 cap, ScanCtl* ctl)
 {
 	const u64 nwords = gr.bytes >> 2;
 	const u32 level = gr.depth + 1;
@@ -881,7 +891,13 @@ __global__ __launch_bounds__(256) void k_extract(MapGeom g, Grid gr, const u32* 
 			e.hit = which ? 0 : (u8)mb;
 			e.miss = which ? (u8)mb : 0;
 			e.level = (u8)level;
-			for (int k = 0; k < 5; ++k) e.pad[k] = 0;
+			e.c_last = (u8)(31 - __clz((int)mb));  // misses: ascending code order -> highest child
+			e.t_last = 0;
+			if (0 == which) {
+				u32 tv = blk_time[idx];  // k_hitmark: latest first-point among the block's hit voxels
+				e.t_last = tv >> 3;
+				e.c_last = (u8)(tv & 7u);
+			}
 			entries[my] = e;
 		}
 	}

@@ -113,7 +113,7 @@ struct ufomap_map {
 	u64 used_est = 0;  // host-side view of MapRoot::used (refreshed at every control-block read)
 	// per-scan buffers
 	DevBuf b_ctl, b_pt_end, b_pt_flag, b_pt_slot, b_ray_end, b_hit_code, b_hit_pt, b_hh_keys, b_hh_idx;
-	DevBuf b_part0, b_part1, b_slabs;
+	DevBuf b_part0, b_part1, b_slabs, b_blktime;
 	DevBuf b_gridH, b_gridM, b_entries, b_ent_slot, b_newlist, b_wl0, b_wl1, b_in_xyz, b_in_rgb, b_codes, b_dump;
 	ScanCtl* h_ctl = nullptr;  // pinned
 	MapRoot* h_root = nullptr;  // pinned
@@ -408,43 +408,57 @@ int applyEntries(ufomap_map* m, const Entry* d_entries, u32 cap, u32 which, u32 
 	return UFOMAP_OK;
 }
 
-// The map half of an integration: update lists from the two grids, then hits phase, then misses phase.
-// capH/capM: entry-buffer capacities (upper bounds or guesses; see ERR_ENTRIES).
-int mapPhase(ufomap_map* m, unsigned depth, const uint8_t* d_rgb, u64 capH, u64 capM, bool retry)
+// Make sure the node table can take the worst case of both phases (true upper bound, see blockBound).
+int sizeTable(ufomap_map* m, u64 capH, const i32 nbH[3], u64 capM, const i32 nbM[3], unsigned depth)
+{
+	u64 need = m->used_est;
+	if (capH) need += blockBound(m, capH, nbH, 1);
+	if (capM) need += blockBound(m, capM, nbM, (u32)depth + 1);
+	u64 cap = (u64)m->t.mask + 1;
+	if (need * 5 > cap * 3) {  // keep the load factor <= 0.6
+		u64 want = need * 2;
+		if (want > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
+		return growTable(m, nextPow2(want));
+	}
+	return UFOMAP_OK;
+}
+
+// Update lists from the two grids of the current scan into b_entries: hit entries first, then miss entries.
+// capH/capM: capacities (upper bounds or guesses; the device-side counts land in ctl->n_entries[]).
+int extractLists(ufomap_map* m, u64 capH, u64 capM, bool zero_counts)
 {
 	ScanCtl* ctl = m->b_ctl.as<ScanCtl>();
-	const float miss = (float)(m->g.miss_log / double((2.0 * depth) + 1));  // OMB:311
-	if (!m->haveH) capH = 0;
-	if (!m->haveM) capM = 0;
 	if (capH > 0x7FFFFFFFull || capM > 0x7FFFFFFFull) return fail(UFOMAP_ERR_CAPACITY, "update list exceeds 2^31 entries");
-	{
-		// size the table for the worst case of both phases (true upper bound, see blockBound)
-		u64 need = m->used_est;
-		if (capH) need += blockBound(m, capH, m->gridH.nb, 1);
-		if (capM) need += blockBound(m, capM, m->gridM.nb, (u32)depth + 1);
-		u64 cap = (u64)m->t.mask + 1;
-		if (need * 5 > cap * 3) {  // keep the load factor <= 0.6
-			u64 want = need * 2;
-			if (want > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
-			int rc = growTable(m, nextPow2(want));
-			if (rc) return rc;
-		}
-	}
 	HIP_TRY(m->b_entries.reserve(((size_t)capH + capM + 1) * sizeof(Entry)));
 	Entry* ent_h = m->b_entries.as<Entry>();
 	Entry* ent_m = ent_h + capH;
-	if (retry) HIP_TRY(hipMemsetAsync(&ctl->n_entries[0], 0, 8, m->stream));  // otherwise zero from the control-block upload
+	if (zero_counts) HIP_TRY(hipMemsetAsync(&ctl->n_entries[0], 0, 8, m->stream));  // otherwise zero from the control-block upload
 	if (capH) {
 		ProfScope ps(m, "k_extract");
 		hipLaunchKernelGGL(k_extract, gridFor(m->gridH.bytes >> 2, 256, 2048), dim3(256), 0, m->stream, m->g, m->gridH,
-		                   m->b_gridH.as<u32>(), 0u, ent_h, (u32)capH, ctl);
+		                   m->b_gridH.as<u32>(), 0u, m->b_blktime.as<u32>(), ent_h, (u32)capH, ctl);
 	}
 	if (capM) {
 		ProfScope ps(m, "k_extract");
 		hipLaunchKernelGGL(k_extract, gridFor(m->gridM.bytes >> 2, 256, 2048), dim3(256), 0, m->stream, m->g, m->gridM,
-		                   m->b_gridM.as<u32>(), 1u, ent_m, (u32)capM, ctl);
+		                   m->b_gridM.as<u32>(), 1u, (const u32*)nullptr, ent_m, (u32)capM, ctl);
 	}
-	int rc = applyEntries(m, ent_h, (u32)capH, 0, 1, m->gridH.nb, m->g.hit, d_rgb, retry);
+	return UFOMAP_OK;
+}
+
+// The map half of an integration: update lists from the two grids, then hits phase, then misses phase.
+int mapPhase(ufomap_map* m, unsigned depth, const uint8_t* d_rgb, u64 capH, u64 capM, bool retry)
+{
+	const float miss = (float)(m->g.miss_log / double((2.0 * depth) + 1));  // OMB:311
+	if (!m->haveH) capH = 0;
+	if (!m->haveM) capM = 0;
+	int rc = sizeTable(m, capH, m->gridH.nb, capM, m->gridM.nb, depth);
+	if (rc) return rc;
+	rc = extractLists(m, capH, capM, retry);
+	if (rc) return rc;
+	Entry* ent_h = m->b_entries.as<Entry>();
+	Entry* ent_m = ent_h + capH;
+	rc = applyEntries(m, ent_h, (u32)capH, 0, 1, m->gridH.nb, m->g.hit, d_rgb, retry);
 	if (rc) return rc;
 	return applyEntries(m, ent_m, (u32)capM, 1, (u32)depth + 1, m->gridM.nb, miss, nullptr, retry);
 }
@@ -481,8 +495,10 @@ int finishPending(ufomap_map* m)
 	return UFOMAP_OK;
 }
 
-int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const uint8_t* d_rgb, size_t n, double max_range,
-             unsigned depth, int discrete, int simple, unsigned early_stopping, int async)
+// The scan half of an integration (never touches the map): classify, de-duplicate, cast the rays into
+// the dedup grids. On return *n_hits_out / *n_rays_out hold the unique hits / rays cast.
+int scanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, const uint8_t* d_rgb, size_t n, double max_range,
+              unsigned depth, int discrete, int simple, unsigned early_stopping, u32* n_hits_out, u32* n_rays_out)
 {
 	if (!m) return fail(UFOMAP_ERR_INVALID, "null map");
 	HIP_TRY(hipSetDevice(m->device));
@@ -597,9 +613,12 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 	if (m->haveH) {
 		HIP_TRY(m->b_gridH.reserve(m->gridH.bytes));
 		HIP_TRY(hipMemsetAsync(m->b_gridH.p, 0, m->gridH.bytes, m->stream));
+		if (n > (1u << 29)) return fail(UFOMAP_ERR_INVALID, "more than 2^29 points in one scan");
+		HIP_TRY(m->b_blktime.reserve(m->gridH.bytes * 4));
+		HIP_TRY(hipMemsetAsync(m->b_blktime.p, 0, m->gridH.bytes * 4, m->stream));
 		ProfScope ps(m, "k_hitmark");
-		hipLaunchKernelGGL(k_hitmark, gridFor(n_hits), dim3(256), 0, m->stream, m->g, m->gridH, m->b_gridH.as<u32>(), m->b_hit_code.as<u64>(),
-		                   ctl, ctl);
+		hipLaunchKernelGGL(k_hitmark, gridFor(n_hits), dim3(256), 0, m->stream, m->g, m->gridH, m->b_gridH.as<u32>(), m->b_blktime.as<u32>(),
+		                   m->b_hit_code.as<u64>(), m->b_hit_pt.as<u32>(), ctl, ctl);
 	}
 	if (m->haveM) {
 		HIP_TRY(m->b_gridM.reserve(m->gridM.bytes));
@@ -643,6 +662,19 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 		}
 	}
 
+	*n_hits_out = n_hits;
+	*n_rays_out = n_rays;
+	(void)after_select;
+	HIP_TRY(hipGetLastError());
+	return UFOMAP_OK;
+}
+
+int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const uint8_t* d_rgb, size_t n, double max_range,
+             unsigned depth, int discrete, int simple, unsigned early_stopping, int async)
+{
+	u32 n_hits = 0, n_rays = 0;
+	int rc = scanPhase(m, origin, d_xyz, d_rgb, n, max_range, depth, discrete, simple, early_stopping, &n_hits, &n_rays);
+	if (rc || 0 == n) return rc;
 	// ---- map phases: all hits, then all misses (OMB:1351-1365). No host round trip here: the update-list
 	// buffers are sized from upper bounds (hit blocks <= unique hits; miss blocks <= blocks of the grid, capped
 	// by a guess for huge grids -- ERR_ENTRIES makes the host retry with the exact size). A runaway ray sets
@@ -652,7 +684,6 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 	u64 capM = m->haveM ? std::min<u64>(m->gridM.bytes, std::max<u64>(1u << 20, (u64)n_rays * 64)) : 0;
 	rc = mapPhase(m, depth, d_rgb, capH, capM, false);
 	if (rc) return rc;
-	(void)after_select;
 	HIP_TRY(hipGetLastError());
 	m->pending = true;
 	if (!async) {
@@ -753,7 +784,7 @@ void ufomap_map_destroy(ufomap_map* m)
 	m->tb.release();
 	DevBuf* bufs[] = {&m->b_root,
 	                  &m->b_ctl,     &m->b_pt_end,  &m->b_pt_flag,  &m->b_pt_slot, &m->b_ray_end, &m->b_hit_code, &m->b_hit_pt,
-	                  &m->b_hh_keys, &m->b_hh_idx,  &m->b_gridH,    &m->b_gridM,   &m->b_part0,   &m->b_part1,   &m->b_slabs,   &m->b_entries, &m->b_ent_slot, &m->b_newlist,
+	                  &m->b_hh_keys, &m->b_hh_idx,  &m->b_gridH,    &m->b_gridM,   &m->b_part0,   &m->b_part1,   &m->b_slabs,   &m->b_blktime,   &m->b_entries, &m->b_ent_slot, &m->b_newlist,
 	                  &m->b_wl0,     &m->b_wl1,     &m->b_in_xyz,   &m->b_in_rgb,  &m->b_codes,   &m->b_dump};
 	for (DevBuf* b : bufs) b->release();
 	for (PendingEvent& pe : m->pend_ev) {
@@ -1099,15 +1130,94 @@ int ufomap_map_reset_kernel_times(ufomap_map* m)
 	return UFOMAP_OK;
 }
 
-int ufomap_map_scan_keys(ufomap_map*, const double*, const double*, const uint8_t*, size_t, double, unsigned, int, int, void**,
-                         size_t*)
+int ufomap_map_scan_keys(ufomap_map* m, const double sensor_origin[3], const double* d_xyz, size_t n, double max_range,
+                         unsigned depth, int discrete, int simple_ray_casting, ufomap_keys_info* info)
 {
-	return fail(UFOMAP_ERR_UNSUPPORTED, "ufomap_map_scan_keys: not implemented yet");
+	if (!m || !info) return fail(UFOMAP_ERR_INVALID, "null argument");
+	memset(info, 0, sizeof(*info));
+	info->depth = depth;
+	u32 n_hits = 0, n_rays = 0;
+	int rc = scanPhase(m, sensor_origin, d_xyz, nullptr, n, max_range, depth, discrete, simple_ray_casting, 0, &n_hits, &n_rays);
+	if (rc || 0 == n) return rc;
+	u64 capH = m->haveH ? std::min<u64>(n_hits, m->gridH.bytes) : 0;
+	u64 capM = m->haveM ? std::min<u64>(m->gridM.bytes, std::max<u64>(1u << 20, (u64)n_rays * 64)) : 0;
+	for (int attempt = 0; attempt < 2; ++attempt) {
+		rc = extractLists(m, capH, capM, attempt > 0);
+		if (rc) return rc;
+		rc = readCtl(m);
+		if (rc) return rc;
+		rc = ctlError(m);  // e.g. a runaway ray
+		if (rc) return rc;
+		if (m->h_ctl->n_entries[0] <= capH && m->h_ctl->n_entries[1] <= capM) break;
+		capH = m->h_ctl->n_entries[0];
+		capM = m->h_ctl->n_entries[1];
+	}
+	// compact: miss entries directly behind the hit entries
+	const u32 nh = m->h_ctl->n_entries[0], nm = m->h_ctl->n_entries[1];
+	if (nh != capH && nm) {
+		HIP_TRY(m->b_codes.reserve((size_t)nm * sizeof(Entry)));
+		HIP_TRY(hipMemcpyAsync(m->b_codes.p, m->b_entries.as<Entry>() + capH, (size_t)nm * sizeof(Entry), hipMemcpyDeviceToDevice, m->stream));
+		HIP_TRY(hipMemcpyAsync(m->b_entries.as<Entry>() + nh, m->b_codes.p, (size_t)nm * sizeof(Entry), hipMemcpyDeviceToDevice, m->stream));
+		HIP_TRY(hipStreamSynchronize(m->stream));
+	}
+	info->n_hit = nh;
+	info->n_miss = nm;
+	for (int a = 0; a < 3; ++a) {
+		info->nb_hit[a] = m->haveH ? m->gridH.nb[a] : 0;
+		info->nb_miss[a] = m->haveM ? m->gridM.nb[a] : 0;
+	}
+	m->counts[2] = m->h_ctl->n_steps;
+	m->counts[5] = (u64)nh + nm;
+	drainEvents(m);
+	return UFOMAP_OK;
 }
 
-int ufomap_map_apply_keys(ufomap_map*, const void*, size_t, unsigned)
+int ufomap_map_get_keys(ufomap_map* m, void* d_dst, size_t cap_entries, const ufomap_keys_info* info)
 {
-	return fail(UFOMAP_ERR_UNSUPPORTED, "ufomap_map_apply_keys: not implemented yet");
+	if (!m || !info) return fail(UFOMAP_ERR_INVALID, "null argument");
+	size_t tot = (size_t)info->n_hit + info->n_miss;
+	if (tot > cap_entries) return fail(UFOMAP_ERR_CAPACITY, "destination too small for the update list");
+	HIP_TRY(hipSetDevice(m->device));
+	if (tot) HIP_TRY(hipMemcpyAsync(d_dst, m->b_entries.p, tot * sizeof(Entry), hipMemcpyDeviceToDevice, m->stream));
+	HIP_TRY(hipStreamSynchronize(m->stream));
+	return UFOMAP_OK;
+}
+
+int ufomap_map_apply_keys(ufomap_map* m, const void* d_entries, const ufomap_keys_info* info)
+{
+	if (!m || !info) return fail(UFOMAP_ERR_INVALID, "null argument");
+	if (m->g.color) return fail(UFOMAP_ERR_UNSUPPORTED, "update lists carry no colour: apply_keys works on OccupancyMap only");
+	if (info->depth >= m->g.L) return fail(UFOMAP_ERR_INVALID, "depth must be < depth_levels");
+	HIP_TRY(hipSetDevice(m->device));
+	if (m->pending) {
+		HIP_TRY(hipStreamSynchronize(m->stream));
+		int prc = finishPending(m);
+		if (prc) return prc;
+	}
+	const u32 nh = info->n_hit, nm = info->n_miss;
+	if (0 == nh + nm) return UFOMAP_OK;
+	// fresh control block: the entry counts are known exactly here
+	ScanCtl init;
+	memset(&init, 0, sizeof(init));
+	init.n_entries[0] = nh;
+	init.n_entries[1] = nm;
+	for (int a = 0; a < 3; ++a) {
+		init.aabb_min[a] = ~0ull;
+		init.aabb_max[a] = 0ull;
+	}
+	*m->h_ctl = init;
+	HIP_TRY(hipMemcpyAsync(m->b_ctl.p, m->h_ctl, sizeof(ScanCtl), hipMemcpyHostToDevice, m->stream));
+	int rc = sizeTable(m, nh, info->nb_hit, nm, info->nb_miss, info->depth);
+	if (rc) return rc;
+	const Entry* ent = static_cast<const Entry*>(d_entries);
+	const float miss = (float)(m->g.miss_log / double((2.0 * info->depth) + 1));
+	rc = applyEntries(m, ent, nh, 0, 1, info->nb_hit, m->g.hit, nullptr, false);
+	if (rc) return rc;
+	rc = applyEntries(m, ent + nh, nm, 1, info->depth + 1, info->nb_miss, miss, nullptr, false);
+	if (rc) return rc;
+	m->pending = true;
+	HIP_TRY(hipStreamSynchronize(m->stream));
+	return finishPending(m);
 }
 
 int ufomap_map_debug(ufomap_map* m, uint64_t* out, int n)

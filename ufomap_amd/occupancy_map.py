@@ -100,6 +100,23 @@ class OccupancyMapBase:
                                                       int(depth), int(discrete), int(simple_ray_casting), int(early_stopping),
                                                       int(async_)))
 
+    # ---- multi-GPU batched scans: the path split at its exchange point (include/ufomap_hip.h) ------
+    ENTRY_BYTES = 16
+
+    def scan_keys(self, sensor_origin, d_xyz_ptr, n, max_range=-1.0, depth=0, discrete=True, simple_ray_casting=False):
+        """Ray-cast one scan WITHOUT touching the map; returns the header of its update list."""
+        o = np.ascontiguousarray(sensor_origin, np.float64)
+        info = capi.KeysInfo()
+        capi.check(self._lib.ufomap_map_scan_keys(self._h, _p(o, C.c_double), d_xyz_ptr, n, float(max_range), int(depth),
+                                                  int(discrete), int(simple_ray_casting), C.byref(info)))
+        return info
+
+    def get_keys(self, d_dst_ptr, cap_entries, info):
+        capi.check(self._lib.ufomap_map_get_keys(self._h, d_dst_ptr, cap_entries, C.byref(info)))
+
+    def apply_keys(self, d_entries_ptr, info):
+        capi.check(self._lib.ufomap_map_apply_keys(self._h, d_entries_ptr, C.byref(info)))
+
     def insertPointCloudDone(self):
         return bool(capi.check(self._lib.ufomap_map_done(self._h)))
 
