@@ -149,6 +149,11 @@ int ufomap_map_scan_keys(ufomap_map* m, const double sensor_origin[3], const dou
 int ufomap_map_get_keys(ufomap_map* m, void* d_dst, size_t cap_entries, const ufomap_keys_info* info);
 int ufomap_map_apply_keys(ufomap_map* m, const void* d_entries, const ufomap_keys_info* info);
 
+/* Diagnostic overrides for tests: "dda_mode" (-1 auto; 1 / 2 force the LDS-filter / direct variants of
+ * the ray kernel on grids that would fit in LDS), "entry_guess" (cap of the guessed update-list size, to
+ * exercise the exact-size retry). Results never depend on these. */
+int ufomap_map_set_option(ufomap_map* m, const char* key, long long value);
+
 /* Diagnostics: up to 64 raw 64-bit words written by the last integration's kernels (per-level
  * wall_clock64 stamps of the propagation tails: [level] hits phase, [32+level] misses phase, [31]/[63]
  * end stamps; 100 MHz clock). Not part of the reference's surface. */

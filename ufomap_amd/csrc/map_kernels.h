@@ -223,14 +223,16 @@ __device__ inline void markDirty(const Table& t, bool want, u32 p, u32* __restri
 // already existed (its ancestors exist by induction).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_ensure(Table t, MapGeom g, const Entry* __restrict__ entries,
-                                                const u32* n_entries_p, u32 ent_cap, u32 scan_id, u32* __restrict__ ent_slot,
-                                                u32* __restrict__ newlist, u32 newcap, ScanCtl::PhaseCtr* pc, ScanCtl* ctl)
+                                                const u32* n_entries_p, u32 cap_h, u32 cap_m, u32 scan_id,
+                                                u32* __restrict__ ent_slot, u32* __restrict__ newlist, u32 newcap,
+                                                ScanCtl::PhaseCtr* pc, ScanCtl* ctl)
 {
 	u32 n = *n_entries_p;
 	const u32 max_probe = (t.mask >> 1) + 1;
 	u32 n_created = 0;
-	if (n > ent_cap) {
-		// the update list did not fit the buffer: nothing may be applied (the host retries)
+	if (ctl->n_entries[0] > cap_h || ctl->n_entries[1] > cap_m) {
+		// one of the two update lists did not fit its buffer: NOTHING may be applied, in either phase
+		// (both lists are extracted before the first phase starts); the host retries with the exact sizes
 		if (0 == blockIdx.x && 0 == threadIdx.x) atomicOr(&ctl->err, ERR_ENTRIES);
 		return;
 	}
@@ -405,121 +407,203 @@ __global__ __launch_bounds__(256) void k_apply_leaf(Table t, MapGeom g, const En
 	}
 }
 
-// updateAllChildren (OMB:1085-1120) on the subtree below block `s0` (level `lvl0`), iterative.
-// Returns the bool the reference returns: something changed AND the node's summary changed.
-__device__ inline bool subtreeApply(const Table& t, const MapGeom& g, u32 s0, u64 lk0, u32 lvl0, float u)
+// ------------------------------------------------------------------------------------------------
+// S3c coarse misses (insert depth d > 0): the update list holds level d+1 blocks ("holders") whose
+// masked children are depth-d nodes. A child that is a leaf is updated in place (OMB:1067-1072); a child
+// that has been expanded gets the update on every leaf below it (updateAllChildren, OMB:1085-1120).
+// The reference recurses per node; here the subtrees of ALL entries are walked level-synchronously:
+//   k_coarse_begin  per entry: leaf children updated, expanded children pushed onto the visit list
+//   k_coarse_down   per level, top-down: leaves of every visited block updated, inner children pushed
+//   k_coarse_up     per level, bottom-up: blocks with a changed child re-evaluated (updateNode) and their
+//                   summary handed to the parent -- `changed && updateNode(node)` of OMB:1119
+//   k_coarse_end    per entry: the holder's own updateNode, reproducing the reference's child-by-child
+//                   order (each child is a separate updateValue; the walk up from a LEAF child starts only
+//                   on a flag change, OMB:1126-1133 + 1181-1189, so the stored max can be stale -- kept)
+// (A per-thread depth-first walk of each subtree took 800 ms on config C3 at depth 6.)
+// ------------------------------------------------------------------------------------------------
+struct CoarseRec {
+	float old_occ[8];  // children values before the phase
+	u32 old_flags;     // holder's flags word before the phase
+	u32 leaf_trig;     // leaf children whose flags changed (bit per child)
+	u32 inner_mask;    // miss children that were expanded
+	u32 pad;
+};
+
+__device__ inline void visitPush(u32 slot, u32* __restrict__ dlist, u32 dcap, ScanCtl* ctl)
 {
-	u32 st_s[22];
-	u64 st_lk[22];
-	u32 st_i[22];
-	bool st_ch[22];
-	int sp = 0;
-	st_s[0] = s0;
-	st_lk[0] = lk0;
-	st_i[0] = 0;
-	st_ch[0] = false;
-	u32 lvl = lvl0;
-	bool ret = false;
-	while (sp >= 0) {
-		u32 s = st_s[sp];
-		if (st_i[sp] < 8) {
-			u32 i = st_i[sp]++;
-			u32 f = t.flags[s];
-			if (lvl > 1 && ((f >> (16 + i)) & 1u)) {
-				u64 clk = (st_lk[sp] << 3) | (u64)i;
-				u32 cs = tableFind(t, clk);
-				if (cs == NONE) continue;  // cannot happen: inner bit implies a live block
-				++sp;
-				--lvl;
-				st_s[sp] = cs;
-				st_lk[sp] = clk;
-				st_i[sp] = 0;
-				st_ch[sp] = false;
-			} else {
-				float* pv = t.occ + 8 * (size_t)s + i;
-				float v = *pv;
-				float nv = clampAdd(v, u, g.cmin, g.cmax);
-				if (nv != v) {
-					*pv = nv;
-					st_ch[sp] = true;
-					if (lvl > 1) {
-						// updateNode on a leaf inner node: flags from its own value (OMB:1181-1189)
-						u32 nf = f & ~((1u << i) | (1u << (8 + i)));
-						nf |= (isFreeV(g, nv) ? (1u << i) : 0u) | (isUnknownV(g, nv) ? (1u << (8 + i)) : 0u);
-						if (nf != f) {
-							// the top block's flags word is private to this thread too (its parent's is not)
-							atomicAnd(&t.flags[s], nf | ~(F_CFREE | F_CUNK));
-							atomicOr(&t.flags[s], nf & (F_CFREE | F_CUNK));
-						}
-					}
-				}
-			}
-		} else {
-			ret = false;
-			if (st_ch[sp]) {
-				Summ sm = blockSummary(t, g, s, lvl, t.flags[s]);
-				if (sm.collapsible) collapseBlock(t, s, st_lk[sp]);
-				ret = writeToParent(t, g, s, st_lk[sp], sm);
-			}
-			--sp;
-			++lvl;
-			if (sp >= 0 && ret) st_ch[sp] = true;
-		}
-	}
-	return ret;
+	u32 pos = atomicAdd(&ctl->dl_total, 1u);
+	if (pos < dcap) dlist[pos] = slot;
+	else atomicOr(&ctl->err, ERR_TABLE_FULL);
 }
 
-// S3c apply (blocks above level 1): misses at depth >= 1 (insert_depth > 0). A child that is a leaf
-// is updated in place (OMB:1067-1072); a child that has been expanded gets the update on every leaf
-// below it (OMB:1073-1079). The block itself is re-evaluated only when the reference would walk up
-// to it: a leaf child's *flags* changed (OMB:1126-1133 starts at the leaf itself) or a subtree's
-// summary changed.
-__global__ __launch_bounds__(256) void k_apply_coarse(Table t, MapGeom g, const Entry* __restrict__ entries,
-                                                      const u32* n_entries_p, const u32* __restrict__ ent_slot, float miss,
-                                                      u32 phase, u32* __restrict__ wl, ScanCtl::PhaseCtr* pc, ScanCtl* ctl)
+__global__ __launch_bounds__(256) void k_coarse_begin(Table t, MapGeom g, const Entry* __restrict__ entries, const u32* n_entries_p,
+                                                      const u32* __restrict__ ent_slot, float miss, CoarseRec* __restrict__ rec,
+                                                      u32* __restrict__ dlist, u32 dcap, ScanCtl* ctl)
 {
 	u32 n = *n_entries_p;
 	if (ctl->err) return;
 	for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
 		Entry e = entries[i];
 		u32 s = ent_slot[i];
-		u32 level = e.level;
-		const int c_last = 31 - __clz((int)e.miss);
-		bool last_reached = false;
-		Summ pre = readStored(t, g, s, e.lk), fin = pre;
-		// children in ascending code order, each one a separate updateValue of the reference
+		CoarseRec r;
+		u32 f = t.flags[s];
+		r.old_flags = f;
+		r.leaf_trig = 0;
+		r.inner_mask = 0;
+		r.pad = 0;
+		u32 nf = f;
 		for (int c = 0; c < 8; ++c) {
+			float* pv = t.occ + 8 * (size_t)s + c;
+			float v = *pv;
+			r.old_occ[c] = v;
 			if (!((e.miss >> c) & 1)) continue;
-			u32 f = t.flags[s];
-			bool trigger = false;
 			if ((f >> (16 + c)) & 1u) {
-				u64 clk = (e.lk << 3) | (u64)c;
-				u32 cs = tableFind(t, clk);
-				if (cs != NONE) trigger = subtreeApply(t, g, cs, clk, level - 1, miss);
+				u32 cs = tableFind(t, (e.lk << 3) | (u64)c);
+				if (cs != NONE) {
+					r.inner_mask |= 1u << c;
+					visitPush(cs, dlist, dcap, ctl);
+				}
 			} else {
-				float* pv = t.occ + 8 * (size_t)s + c;
-				float v = *pv;
 				float nv = clampAdd(v, miss, g.cmin, g.cmax);
 				*pv = nv;
 				u32 nbits = (isFreeV(g, nv) ? (1u << c) : 0u) | (isUnknownV(g, nv) ? (1u << (8 + c)) : 0u);
 				u32 obits = f & ((1u << c) | (1u << (8 + c)));
 				if (nbits != obits) {
-					// updateParents starts at the leaf itself: only a FLAG change walks up (OMB:1126-1133, 1181-1189)
-					trigger = true;
-					t.flags[s] = (f & ~((1u << c) | (1u << (8 + c)))) | nbits;
+					r.leaf_trig |= 1u << c;
+					nf = (nf & ~((1u << c) | (1u << (8 + c)))) | nbits;
 				}
 			}
-			if (!trigger) continue;
-			// updateNode on this block, as the reference runs it right after this child's update
-			Summ sm = blockSummary(t, g, s, level, t.flags[s]);
-			if (c == c_last) {
+		}
+		if (nf != f) {
+			// only CFREE/CUNK bits of this block change here; nobody else touches this word in this kernel
+			t.flags[s] = nf;
+		}
+		rec[i] = r;
+	}
+}
+
+// records where the next level's part of the visit list starts (single thread, between levels)
+__global__ void k_coarse_mark(ScanCtl* ctl, u32 level) { ctl->dl_start[level] = ctl->dl_total; }
+
+__global__ __launch_bounds__(256) void k_coarse_down(Table t, MapGeom g, u32 level, float miss, u32* __restrict__ dlist, u32 dcap,
+                                                     ScanCtl* ctl)
+{
+	if (ctl->err) return;
+	const u32 lo = ctl->dl_start[level + 1], hi = min(ctl->dl_start[level], dcap);
+	for (u32 i = lo + blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += gridDim.x * blockDim.x) {
+		const u32 s = dlist[i];
+		const u64 lk = t.keys[s];
+		const u32 f = t.flags[s];
+		float4* po = reinterpret_cast<float4*>(t.occ + 8 * (size_t)s);
+		float4 a = po[0], b = po[1];
+		float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+		u32 nf = f;
+		bool changed = false;
+#pragma unroll
+		for (int c = 0; c < 8; ++c) {
+			if (level > 1 && ((f >> (16 + c)) & 1u)) {
+				u32 cs = tableFind(t, (lk << 3) | (u64)c);
+				if (cs != NONE) visitPush(cs, dlist, dcap, ctl);
+				continue;
+			}
+			float nv = clampAdd(v[c], miss, g.cmin, g.cmax);
+			if (nv != v[c]) {
+				v[c] = nv;
+				changed = true;
+				if (level > 1) {
+					// updateNode on a leaf inner node: flags from its own value (OMB:1181-1189)
+					nf &= ~((1u << c) | (1u << (8 + c)));
+					nf |= (isFreeV(g, nv) ? (1u << c) : 0u) | (isUnknownV(g, nv) ? (1u << (8 + c)) : 0u);
+				}
+			}
+		}
+		if (changed) {
+			po[0] = make_float4(v[0], v[1], v[2], v[3]);
+			po[1] = make_float4(v[4], v[5], v[6], v[7]);
+			t.flags[s] = nf | F_SUB;  // this block's word is private to this thread until the up pass
+		}
+	}
+}
+
+__global__ __launch_bounds__(256) void k_coarse_up(Table t, MapGeom g, u32 level, const u32* __restrict__ dlist, u32 dcap,
+                                                   ScanCtl* ctl)
+{
+	if (ctl->err) return;
+	const u32 lo = ctl->dl_start[level + 1], hi = min(ctl->dl_start[level], dcap);
+	for (u32 i = lo + blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += gridDim.x * blockDim.x) {
+		const u32 s = dlist[i];
+		u32 f = atomicAnd(&t.flags[s], ~F_SUB);
+		if (!(f & F_SUB)) continue;  // nothing changed beneath: the reference does not call updateNode either
+		const u64 lk = t.keys[s];
+		Summ sm = blockSummary(t, g, s, level, f);
+		if (sm.collapsible) collapseBlock(t, s, lk);
+		if (writeToParent(t, g, s, lk, sm)) atomicOr(&t.flags[t.parent[s]], F_SUB);
+	}
+}
+
+__global__ __launch_bounds__(256) void k_coarse_end(Table t, MapGeom g, const Entry* __restrict__ entries, const u32* n_entries_p,
+                                                    const u32* __restrict__ ent_slot, const CoarseRec* __restrict__ rec, u32 phase,
+                                                    u32* __restrict__ wl, ScanCtl::PhaseCtr* pc, ScanCtl* ctl)
+{
+	u32 n = *n_entries_p;
+	if (ctl->err) return;
+	for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		const Entry e = entries[i];
+		const u32 s = ent_slot[i];
+		const u32 level = e.level;
+		const CoarseRec r = rec[i];
+		u32 f = atomicAnd(&t.flags[s], ~F_SUB);  // SUB may have been set by expanded children; not needed here
+		f &= ~F_SUB;
+		const int c_last = (int)e.c_last;  // highest miss child = the reference's last updateValue on this block
+		// which children "triggered" a walk up to this block (see header): leaf -> flags changed;
+		// expanded -> its summary (the slot in this block) changed
+		u32 trig = r.leaf_trig;
+		float cur[8];
+		for (int c = 0; c < 8; ++c) {
+			cur[c] = t.occ[8 * (size_t)s + c];
+			if ((r.inner_mask >> c) & 1u) {
+				u32 ob = r.old_flags & ((1u << c) | (1u << (8 + c))), nb = f & ((1u << c) | (1u << (8 + c)));
+				if (cur[c] != r.old_occ[c] || ob != nb) trig |= 1u << c;
+			}
+		}
+		Summ pre = readStored(t, g, s, e.lk), fin = pre;
+		bool last_reached = false;
+		if (trig) {
+			const int c_t = 31 - __clz((int)trig);
+			// the last updateNode of this block ran right after child c_t: later children still had their old state
+			float m = 0.f;
+			u32 ff = 0, fu = 0;
+			for (int c = 0; c < 8; ++c) {
+				const bool later = c > c_t && ((e.miss >> c) & 1);
+				const float v = later ? r.old_occ[c] : cur[c];
+				const u32 wf = later ? r.old_flags : f;
+				m = (0 == c) ? v : fmaxf(m, v);
+				ff |= (wf >> c) & 1u;
+				fu |= (wf >> (8 + c)) & 1u;
+			}
+			Summ sm = blockSummary(t, g, s, level, f);  // colour average and collapsibility on the current state
+			sm.occ = m;
+			sm.fl = ff | (fu << 1);
+			if (c_t == c_last) {
+				// last child triggered: the walk reached this block on its final state
 				last_reached = true;
-				pre = readStored(t, g, s, e.lk);
 				if (sm.collapsible) collapseBlock(t, s, e.lk);
+				// summary just before: child c_last with its old state
+				float pm = 0.f;
+				u32 pf = 0, pu = 0;
+				for (int c = 0; c < 8; ++c) {
+					const float v = (c == c_last) ? r.old_occ[c] : cur[c];
+					const u32 wf = (c == c_last) ? r.old_flags : f;
+					pm = (0 == c) ? v : fmaxf(pm, v);
+					pf |= (wf >> c) & 1u;
+					pu |= (wf >> (8 + c)) & 1u;
+				}
+				pre = sm;
+				pre.occ = pm;
+				pre.fl = pf | (pu << 1);
 			}
 			fin = sm;
 			if (writeToParent(t, g, s, e.lk, sm) && 1 != e.lk) {
-				// divergent context (few coarse entries): plain append
 				u32 pp = t.parent[s];
 				if (!(atomicOr(&t.flags[pp], F_DIRTY) & F_DIRTY)) wl[atomicAdd(&pc->wl_cnt[level + 1], 1u)] = pp;
 			}
@@ -529,10 +613,6 @@ __global__ __launch_bounds__(256) void k_apply_coarse(Table t, MapGeom g, const 
 	}
 }
 
-// ------------------------------------------------------------------------------------------------
-// P propagate: one level of updateParents (OMB:1126-1133). wl_in holds blocks whose children
-// changed; a block whose own summary changes queues its parent for the next launch.
-// ------------------------------------------------------------------------------------------------
 // one block's updateNode + hand-off; `valid` false lanes only take part in the wave-aggregated append
 template <bool WG>
 __device__ inline void propagateOne(const Table& t, const MapGeom& g, bool valid, u32 s, u32 phase, u32* __restrict__ wl_out,

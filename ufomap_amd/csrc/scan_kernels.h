@@ -50,6 +50,8 @@ struct ScanCtl {
 	unsigned long long n_steps;
 	u32 n_oob;  // cells dropped because their key lies outside [0, 2^L) (the reference aliases them)
 	u32 pad2;
+	u32 dl_total;      // coarse-miss phase: blocks visited so far (all levels, appended level by level)
+	u32 dl_start[25];  // dl_start[l] .. dl_start[l-1] = range of the level-l blocks in the visit list
 	unsigned long long dbg[64];  // diagnostics (ufomap_map_debug): per-level clocks of the propagation tails
 };
 
@@ -556,34 +558,62 @@ __device__ inline bool gridMark(const Grid& gr, u32* __restrict__ grid, i32 cx, 
 	return true;
 }
 
-// K_hitmark: unique hits -> grid H (depth 0)
-__global__ __launch_bounds__(256) void k_hitmark(MapGeom g, Grid gr, u32* __restrict__ grid, u32* __restrict__ blk_time,
-                                                 const u64* __restrict__ hit_code, const u32* __restrict__ hit_pt,
+// Hits are few (<= N) and, at fine resolutions, scattered over a huge bounding box (C3: 3e5 hits in 1e9
+// cells), so they are grouped per node block through a small open-addressing hash instead of a dense grid:
+// key = code >> 3 (the level-1 node), value = mask of hit children + the cloud-order "time" of the block's
+// last hit (first-point index << 3 | child; the reference applies hits in cloud order, OMB:1351-1354).
+struct HitBlocks {
+	u64* keys;  // ~0 = empty
+	u32* mask;
+	u32* time;
+	u32 cap_mask;
+};
+
+__global__ __launch_bounds__(256) void k_hitmark(HitBlocks hb, const u64* __restrict__ hit_code, const u32* __restrict__ hit_pt,
                                                  const ScanCtl* ctl_in, ScanCtl* ctl)
 {
 	u32 n = ctl_in->n_hits;
 	for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-		u64 c = hit_code[i];
-		// de-interleave (map/code.h:351-364)
-		u32 k[3];
-		for (int a = 0; a < 3; ++a) {
-			u64 v = (c >> a) & 0x1249249249249249ULL;
-			v = (v ^ (v >> 2)) & 0x10c30c30c30c30c3ULL;
-			v = (v ^ (v >> 4)) & 0x100f00f00f00f00fULL;
-			v = (v ^ (v >> 8)) & 0x1f0000ff0000ffULL;
-			v = (v ^ (v >> 16)) & 0x1f00000000ffffULL;
-			v = (v ^ (v >> 32)) & 0x1fffffULL;
-			k[a] = (u32)v;
+		const u64 c = hit_code[i];
+		const u64 key = c >> 3;
+		const u32 child = (u32)(c & 7);
+		u32 s = hash64(key) & hb.cap_mask;
+		for (u32 probe = 0; probe <= hb.cap_mask; ++probe) {
+			u64 k = __hip_atomic_load(&hb.keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (k == ~0ULL) {
+				u64 prev = atomicCAS((unsigned long long*)&hb.keys[s], ~0ULL, (unsigned long long)key);
+				k = (prev == ~0ULL) ? key : prev;
+			}
+			if (k == key) {
+				atomicOr(&hb.mask[s], 1u << child);
+				atomicMax(&hb.time[s], (hit_pt[i] << 3) | child);
+				break;
+			}
+			s = (s + 1) & hb.cap_mask;
 		}
-		if (!gridMark(gr, grid, (i32)k[0], (i32)k[1], (i32)k[2], 1u << g.L, &ctl->n_oob)) atomicOr(&ctl->err, ERR_GRID_OOB);
-		// "time" of the block's last hit: hits are applied in cloud order (OMB:1351-1354), so the child whose
-		// first point comes latest is updated last. One atomicMax per hit on (point index << 3 | child).
-		i32 lx = (i32)k[0] - gr.base[0], ly = (i32)k[1] - gr.base[1], lz = (i32)k[2] - gr.base[2];
-		if (lx >= 0 && ly >= 0 && lz >= 0 && (lx >> 1) < gr.nb[0] && (ly >> 1) < gr.nb[1] && (lz >> 1) < gr.nb[2]) {
-			u64 idx = ((u64)(lz >> 1) * (u64)gr.nb[1] + (u64)(ly >> 1)) * (u64)gr.nb[0] + (u64)(lx >> 1);
-			u32 child = (u32)((lx & 1) | ((ly & 1) << 1) | ((lz & 1) << 2));
-			atomicMax(&blk_time[idx], (hit_pt[i] << 3) | child);
-		}
+	}
+}
+
+// hit blocks -> update list (hit entries, level 1)
+__global__ __launch_bounds__(256) void k_extract_hits(MapGeom g, HitBlocks hb, Entry* __restrict__ entries, u32 cap, ScanCtl* ctl)
+{
+	const u32 nslots = hb.cap_mask + 1;
+	const u32 stride = gridDim.x * blockDim.x;
+	const u32 iters = (nslots + stride - 1) / stride;
+	u32 s = blockIdx.x * blockDim.x + threadIdx.x;
+	for (u32 it = 0; it < iters; ++it, s += stride) {
+		const bool have = s < nslots && hb.keys[s] != ~0ULL;
+		const u32 pos = waveAppend(&ctl->n_entries[0], have);
+		if (!have || pos >= cap) continue;
+		Entry e;
+		e.lk = (1ULL << (3 * (g.L - 1))) | hb.keys[s];
+		e.hit = (u8)hb.mask[s];
+		e.miss = 0;
+		e.level = 1;
+		const u32 tv = hb.time[s];
+		e.c_last = (u8)(tv & 7u);
+		e.t_last = tv >> 3;
+		entries[pos] = e;
 	}
 }
 
@@ -731,7 +761,61 @@ __global__ __launch_bounds__(UFO_DDA_BLOCK) void k_dda(MapGeom g, D3 sensor, u32
 					const bool safe = (u32)cx < lim && (u32)cy < lim && (u32)cz < lim && (u32)gx < lim && (u32)gy < lim && (u32)gz < lim &&
 					                  l0x >= 1 && l0y >= 1 && l0z >= 1 && l1x >= 1 && l1y >= 1 && l1z >= 1 && l0x <= mxx && l0y <= mxy &&
 					                  l0z <= mxz && l1x <= mxx && l1y <= mxy && l1z <= mxz && budget < 0xFFFFFFFFull;
-					if (safe) {
+					if (safe && mxx < 1023 && mxy < 1023 && mxz < 1023) {
+						// Packed local cell coordinates x | y<<10 | z<<20 (each < 1024: always true for LDS-sized grids):
+						// one add moves the cell, one compare tests the goal, bit-field extracts feed the grid index.
+						u32 pk = (u32)l0x | ((u32)l0y << 10) | ((u32)l0z << 20);
+						const u32 gpk = (u32)l1x | ((u32)l1y << 10) | ((u32)l1z << 20);
+						const u32 dxs = (u32)sx, dys = (u32)sy << 10, dzs = (u32)sz << 20;  // two's complement: -1 << k works field-wise
+						const u32 nbx = (u32)gr.nb[0], nby = (u32)gr.nb[1];
+						const u32 budget32 = (u32)budget;
+						u32 cnt = 0;
+						// the minimum of the three t_max serves twice: it selects the axis (lowest index among the
+						// minima == VEC3:244-251) and, one step later, it is the `t_max.min() <= distance` test (OMB:1300)
+						double m = (tmy < tmx) ? tmy : tmx;
+						m = (tmz < m) ? tmz : m;
+						bool go;
+						do {
+							if (++cnt > budget32) {
+								err |= ERR_RUNAWAY;
+								break;
+							}
+							const u32 bxx = (pk >> 1) & 511u, byy = (pk >> 11) & 511u, bzz = pk >> 21;
+							const u32 idx = __umul24(__umul24(bzz, nby) + byy, nbx) + bxx;
+							const u32 bit = (pk & 1u) | ((pk >> 9) & 2u) | ((pk >> 18) & 4u) | ((idx & 3u) << 3);
+							u32 seen = 0;
+							if (MODE == DDA_LDSGRID) seen = lds[idx >> 2];  // issued early, consumed after the arithmetic below
+							if (MODE != DDA_LDSGRID) {
+								u32* w = &grid[idx >> 2];
+								bool skip = false;
+								if (MODE == DDA_FILTER) {
+									const u32 tag = (idx << 3) | (bit & 7u);
+									const u32 h = (tag * 0x9E3779B1u) >> 17;
+									skip = lds[h] == tag;
+									if (!skip) {
+										lds[h] = tag;
+										skip = (*w >> bit) & 1u;
+									}
+								}
+								if (!skip) atomicOr(w, 1u << bit);
+							}
+							const bool selx = tmx == m;
+							const bool sely = !selx && (tmy == m);
+							pk += selx ? dxs : (sely ? dys : dzs);
+							const double nx = tmx + tdx, ny = tmy + tdy, nz = tmz + tdz;
+							tmx = selx ? nx : tmx;
+							tmy = sely ? ny : tmy;
+							tmz = (selx || sely) ? tmz : nz;
+							m = (tmy < tmx) ? tmy : tmx;  // std::min (VEC3:241)
+							m = (tmz < m) ? tmz : m;
+							// Test before set: near the sensor every lane of every wave wants the same few LDS words; a
+							// 64-way same-address ds_or serialises (64+ cycles per wave-instruction), a same-address read
+							// is a broadcast. Once a cell is marked nobody pays for it again.
+							if (MODE == DDA_LDSGRID && !((seen >> bit) & 1u)) atomicOr(&lds[idx >> 2], 1u << bit);
+							go = (pk != gpk) && (m <= dist);
+						} while (go);
+						steps = cnt > budget32 ? budget32 : cnt;
+					} else if (safe) {
 						// local cell coordinates; the goal test and the grid index work on them directly
 						u32 lx = (u32)l0x, ly = (u32)l0y, lz = (u32)l0z;
 						const u32 tx = (u32)l1x, ty = (u32)l1y, tz = (u32)l1z;
@@ -858,7 +942,7 @@ __global__ __launch_bounds__(256) void k_merge_slabs(const uint4* __restrict__ s
 // K3 extract: non-zero bytes of the grids -> update list, one entry per touched node block.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_extract(MapGeom g, Grid gr, const u32* __restrict__ grid, u32 which,
-                                                 const u32* __restrict__ blk_time, Entry* __restrict__ entries, u32 cap, ScanCtl* ctl)
+                                                 Entry* __restrict__ entries, u32 cap, ScanCtl* ctl)
 {
 	const u64 nwords = gr.bytes >> 2;
 	const u32 level = gr.depth + 1;
@@ -893,11 +977,6 @@ __global__ __launch_bounds__(256) void k_extract(MapGeom g, Grid gr, const u32* 
 			e.level = (u8)level;
 			e.c_last = (u8)(31 - __clz((int)mb));  // misses: ascending code order -> highest child
 			e.t_last = 0;
-			if (0 == which) {
-				u32 tv = blk_time[idx];  // k_hitmark: latest first-point among the block's hit voxels
-				e.t_last = tv >> 3;
-				e.c_last = (u8)(tv & 7u);
-			}
 			entries[my] = e;
 		}
 	}

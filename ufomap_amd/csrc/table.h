@@ -12,7 +12,7 @@
 //                    bits 8-15 contains_unknown of child i
 //                    bits 16-23 child i is an inner node with a live block of its own
 //                    bit 24 DIRTY (queued for propagation), 25 DEAD (collapsed: the node is a leaf
-//                    again, octree.h:1060-1066)
+//                    again, octree.h:1060-1066), 26 SUB (changed during a coarse-miss subtree update)
 //   parent[s]  u32   slot of the block that holds this node's own value (NONE for the root)
 //   stamp[s]   u32   id of the phase that created / revived the block ("new this phase")
 //   tmax[s]    u64   (phase tag << 40) | (time of the last update beneath this node << 3) | child index
@@ -36,6 +36,7 @@ enum : u32 {
 	F_INNER = 0x00FF0000u,
 	F_DIRTY = 1u << 24,
 	F_DEAD = 1u << 25,
+	F_SUB = 1u << 26,  // coarse-miss phase: a leaf child or a child's summary changed, re-evaluate bottom-up
 	NONE = 0xFFFFFFFFu,
 };
 

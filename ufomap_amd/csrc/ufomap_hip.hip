@@ -113,8 +113,10 @@ struct ufomap_map {
 	u64 used_est = 0;  // host-side view of MapRoot::used (refreshed at every control-block read)
 	// per-scan buffers
 	DevBuf b_ctl, b_pt_end, b_pt_flag, b_pt_slot, b_ray_end, b_hit_code, b_hit_pt, b_hh_keys, b_hh_idx;
-	DevBuf b_part0, b_part1, b_slabs, b_blktime;
-	DevBuf b_gridH, b_gridM, b_entries, b_ent_slot, b_newlist, b_wl0, b_wl1, b_in_xyz, b_in_rgb, b_codes, b_dump;
+	DevBuf b_part0, b_part1, b_slabs, b_hb_keys, b_hb_mask, b_hb_time;
+	u32 hb_cap_mask = 0;
+	DevBuf b_crec, b_dlist;
+	DevBuf b_gridM, b_entries, b_ent_slot, b_newlist, b_wl0, b_wl1, b_in_xyz, b_in_rgb, b_codes, b_dump;
 	ScanCtl* h_ctl = nullptr;  // pinned
 	MapRoot* h_root = nullptr;  // pinned
 	size_t scratch_limit = 16ull << 30;
@@ -126,6 +128,10 @@ struct ufomap_map {
 	u32 last_depth = 0;
 	u32 hh_mask = 0;  // hit-hash mask of the current scan
 	const uint8_t* last_rgb = nullptr;
+	// diagnostic overrides (ufomap_map_set_option); -1 / 0 = automatic
+	u64 scan_new_bound = 0;  // upper bound of the blocks both phases of the current scan can create
+	int opt_dda_mode = -1;
+	u64 opt_entry_guess = 0;
 	uint64_t counts[8] = {0};
 	double min_change[3], max_change[3];
 	// profiling
@@ -355,7 +361,7 @@ u64 levelBound(const i32 nb[3], u32 shift)
 // `cap` is the capacity of the entry buffer (the device-side count may be smaller; if it is larger
 // k_ensure raises ERR_ENTRIES and nothing is applied).
 int applyEntries(ufomap_map* m, const Entry* d_entries, u32 cap, u32 which, u32 level, const i32 nb[3], float upd,
-                 const uint8_t* d_rgb, bool zero_ctr)
+                 const uint8_t* d_rgb, bool zero_ctr, u32 cap_h, u32 cap_m)
 {
 	if (0 == cap) return UFOMAP_OK;
 	m->scan_id += 1;  // "new this phase" stamp: blocks made by an earlier phase of the same scan are old
@@ -374,7 +380,7 @@ int applyEntries(ufomap_map* m, const Entry* d_entries, u32 cap, u32 which, u32 
 	dim3 ge = gridFor(cap);
 	{
 		ProfScope ps(m, "k_ensure");
-		hipLaunchKernelGGL(k_ensure, ge, dim3(256), 0, m->stream, m->t, m->g, d_entries, d_n, cap, m->scan_id, m->b_ent_slot.as<u32>(),
+		hipLaunchKernelGGL(k_ensure, ge, dim3(256), 0, m->stream, m->t, m->g, d_entries, d_n, cap_h, cap_m, m->scan_id, m->b_ent_slot.as<u32>(),
 		                   m->b_newlist.as<u32>(), (u32)std::min<u64>(newcap, 0xFFFFFFFFull), pc, ctl);
 	}
 	{
@@ -387,9 +393,36 @@ int applyEntries(ufomap_map* m, const Entry* d_entries, u32 cap, u32 which, u32 
 		hipLaunchKernelGGL(k_apply_leaf, ge, dim3(256), 0, m->stream, m->t, m->g, d_entries, d_n, m->b_ent_slot.as<u32>(), upd,
 		                   (u32)(which == 0 ? 1 : 0), m->scan_id, hh, d_rgb, wl[0], pc, ctl);
 	} else {
-		ProfScope ps(m, "k_apply_coarse");
-		hipLaunchKernelGGL(k_apply_coarse, ge, dim3(256), 0, m->stream, m->t, m->g, d_entries, d_n, m->b_ent_slot.as<u32>(), upd,
-		                   m->scan_id, wl[(level + 1) & 1], pc, ctl);
+		// coarse misses: level-synchronous walk of the subtrees below the masked children (map_kernels.h S3c)
+		// every live block can be visited: blocks known at the last control-block read + everything this scan may add
+		const u64 dcap64 = std::min<u64>((u64)m->t.mask + 1, m->used_est + m->scan_new_bound + 8);
+		const u32 dcap = (u32)std::min<u64>(dcap64, 0xFFFFFFF0ull);
+		HIP_TRY(m->b_crec.reserve((size_t)cap * sizeof(CoarseRec)));
+		HIP_TRY(m->b_dlist.reserve((size_t)dcap * 4));
+		if (zero_ctr) HIP_TRY(hipMemsetAsync(&ctl->dl_total, 0, 4 * 26, m->stream));  // dl_total + dl_start[25]
+		CoarseRec* rec = m->b_crec.as<CoarseRec>();
+		u32* dl = m->b_dlist.as<u32>();
+		dim3 gd = gridFor(std::max<u64>(dcap, 256), 256, 4096);
+		{
+			ProfScope ps(m, "k_coarse_begin");
+			hipLaunchKernelGGL(k_coarse_begin, ge, dim3(256), 0, m->stream, m->t, m->g, d_entries, d_n, m->b_ent_slot.as<u32>(), upd, rec,
+			                   dl, dcap, ctl);
+			hipLaunchKernelGGL(k_coarse_mark, dim3(1), dim3(1), 0, m->stream, ctl, level - 1);
+		}
+		for (u32 l = level - 1; l >= 1; --l) {
+			ProfScope ps(m, "k_coarse_down");
+			hipLaunchKernelGGL(k_coarse_down, gd, dim3(256), 0, m->stream, m->t, m->g, l, upd, dl, dcap, ctl);
+			if (l > 1) hipLaunchKernelGGL(k_coarse_mark, dim3(1), dim3(1), 0, m->stream, ctl, l - 1);
+		}
+		for (u32 l = 1; l + 1 <= level; ++l) {
+			ProfScope ps(m, "k_coarse_up");
+			hipLaunchKernelGGL(k_coarse_up, gd, dim3(256), 0, m->stream, m->t, m->g, l, dl, dcap, ctl);
+		}
+		{
+			ProfScope ps(m, "k_coarse_end");
+			hipLaunchKernelGGL(k_coarse_end, ge, dim3(256), 0, m->stream, m->t, m->g, d_entries, d_n, m->b_ent_slot.as<u32>(), rec,
+			                   m->scan_id, wl[(level + 1) & 1], pc, ctl);
+		}
 	}
 	// updateParents (OMB:1126-1133): wide levels one launch each, the narrow rest in one launch
 	u32 l = level + 1;
@@ -412,8 +445,10 @@ int applyEntries(ufomap_map* m, const Entry* d_entries, u32 cap, u32 which, u32 
 int sizeTable(ufomap_map* m, u64 capH, const i32 nbH[3], u64 capM, const i32 nbM[3], unsigned depth)
 {
 	u64 need = m->used_est;
-	if (capH) need += blockBound(m, capH, nbH, 1);
-	if (capM) need += blockBound(m, capM, nbM, (u32)depth + 1);
+	m->scan_new_bound = 0;
+	if (capH) m->scan_new_bound += blockBound(m, capH, nbH, 1);
+	if (capM) m->scan_new_bound += blockBound(m, capM, nbM, (u32)depth + 1);
+	need += m->scan_new_bound;
 	u64 cap = (u64)m->t.mask + 1;
 	if (need * 5 > cap * 3) {  // keep the load factor <= 0.6
 		u64 want = need * 2;
@@ -435,13 +470,14 @@ int extractLists(ufomap_map* m, u64 capH, u64 capM, bool zero_counts)
 	if (zero_counts) HIP_TRY(hipMemsetAsync(&ctl->n_entries[0], 0, 8, m->stream));  // otherwise zero from the control-block upload
 	if (capH) {
 		ProfScope ps(m, "k_extract");
-		hipLaunchKernelGGL(k_extract, gridFor(m->gridH.bytes >> 2, 256, 2048), dim3(256), 0, m->stream, m->g, m->gridH,
-		                   m->b_gridH.as<u32>(), 0u, m->b_blktime.as<u32>(), ent_h, (u32)capH, ctl);
+		HitBlocks hb{m->b_hb_keys.as<u64>(), m->b_hb_mask.as<u32>(), m->b_hb_time.as<u32>(), m->hb_cap_mask};
+		hipLaunchKernelGGL(k_extract_hits, gridFor((u64)m->hb_cap_mask + 1, 256, 2048), dim3(256), 0, m->stream, m->g, hb, ent_h,
+		                   (u32)capH, ctl);
 	}
 	if (capM) {
 		ProfScope ps(m, "k_extract");
 		hipLaunchKernelGGL(k_extract, gridFor(m->gridM.bytes >> 2, 256, 2048), dim3(256), 0, m->stream, m->g, m->gridM,
-		                   m->b_gridM.as<u32>(), 1u, (const u32*)nullptr, ent_m, (u32)capM, ctl);
+		                   m->b_gridM.as<u32>(), 1u, ent_m, (u32)capM, ctl);
 	}
 	return UFOMAP_OK;
 }
@@ -458,9 +494,9 @@ int mapPhase(ufomap_map* m, unsigned depth, const uint8_t* d_rgb, u64 capH, u64 
 	if (rc) return rc;
 	Entry* ent_h = m->b_entries.as<Entry>();
 	Entry* ent_m = ent_h + capH;
-	rc = applyEntries(m, ent_h, (u32)capH, 0, 1, m->gridH.nb, m->g.hit, d_rgb, retry);
+	rc = applyEntries(m, ent_h, (u32)capH, 0, 1, m->gridH.nb, m->g.hit, d_rgb, retry, (u32)capH, (u32)capM);
 	if (rc) return rc;
-	return applyEntries(m, ent_m, (u32)capM, 1, (u32)depth + 1, m->gridM.nb, miss, nullptr, retry);
+	return applyEntries(m, ent_m, (u32)capM, 1, (u32)depth + 1, m->gridM.nb, miss, nullptr, retry, (u32)capH, (u32)capM);
 }
 
 int finishPending(ufomap_map* m)
@@ -606,23 +642,28 @@ int scanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, const 
 		return fail(UFOMAP_ERR_CAPACITY, "hit bounding box too large for the scan grid");
 	if (m->haveM && makeGrid(mmn, mmx, (u32)depth, &m->gridM))
 		return fail(UFOMAP_ERR_CAPACITY, "ray bounding box too large for the scan grid (runaway ray?)");
-	u64 gbytes = (m->haveH ? m->gridH.bytes : 0) + (m->haveM ? m->gridM.bytes : 0);
+	u64 gbytes = m->haveM ? m->gridM.bytes : 0;  // hits are grouped through a hash, only grid M is dense
 	if (gbytes > m->scratch_limit)
 		return fail(UFOMAP_ERR_CAPACITY, "scan dedup grids need " + std::to_string(gbytes) + " bytes > scratch limit " +
 		                                     std::to_string(m->scratch_limit) + " (ufomap_map_set_scratch_limit)");
 	if (m->haveH) {
-		HIP_TRY(m->b_gridH.reserve(m->gridH.bytes));
-		HIP_TRY(hipMemsetAsync(m->b_gridH.p, 0, m->gridH.bytes, m->stream));
 		if (n > (1u << 29)) return fail(UFOMAP_ERR_INVALID, "more than 2^29 points in one scan");
-		HIP_TRY(m->b_blktime.reserve(m->gridH.bytes * 4));
-		HIP_TRY(hipMemsetAsync(m->b_blktime.p, 0, m->gridH.bytes * 4, m->stream));
+		const u32 hbcap = nextPow2(std::max<u64>(256, (u64)n_hits * 2));
+		m->hb_cap_mask = hbcap - 1;
+		HIP_TRY(m->b_hb_keys.reserve((size_t)hbcap * 8));
+		HIP_TRY(m->b_hb_mask.reserve((size_t)hbcap * 4));
+		HIP_TRY(m->b_hb_time.reserve((size_t)hbcap * 4));
+		HIP_TRY(hipMemsetAsync(m->b_hb_keys.p, 0xFF, (size_t)hbcap * 8, m->stream));
+		HIP_TRY(hipMemsetAsync(m->b_hb_mask.p, 0, (size_t)hbcap * 4, m->stream));
+		HIP_TRY(hipMemsetAsync(m->b_hb_time.p, 0, (size_t)hbcap * 4, m->stream));
 		ProfScope ps(m, "k_hitmark");
-		hipLaunchKernelGGL(k_hitmark, gridFor(n_hits), dim3(256), 0, m->stream, m->g, m->gridH, m->b_gridH.as<u32>(), m->b_blktime.as<u32>(),
-		                   m->b_hit_code.as<u64>(), m->b_hit_pt.as<u32>(), ctl, ctl);
+		HitBlocks hb{m->b_hb_keys.as<u64>(), m->b_hb_mask.as<u32>(), m->b_hb_time.as<u32>(), m->hb_cap_mask};
+		hipLaunchKernelGGL(k_hitmark, gridFor(n_hits), dim3(256), 0, m->stream, hb, m->b_hit_code.as<u64>(), m->b_hit_pt.as<u32>(), ctl, ctl);
 	}
 	if (m->haveM) {
 		HIP_TRY(m->b_gridM.reserve(m->gridM.bytes));
-		const int mode = m->gridM.bytes <= UFO_DDA_LDSGRID_MAX ? DDA_LDSGRID : (m->gridM.bytes < (1ull << 29) ? DDA_FILTER : DDA_DIRECT);
+		int mode = m->gridM.bytes <= UFO_DDA_LDSGRID_MAX ? DDA_LDSGRID : (m->gridM.bytes < (1ull << 29) ? DDA_FILTER : DDA_DIRECT);
+		if (m->opt_dda_mode >= 0 && m->opt_dda_mode >= mode) mode = m->opt_dda_mode;  // tests may force a more general mode
 		const size_t lds = mode == DDA_LDSGRID ? (size_t)m->gridM.bytes : (mode == DDA_FILTER ? (size_t)UFO_DDA_FILT * 4 : 0);
 		// Workgroup size: each ray is one dependent instruction chain (~180 steps), so the kernel's time is
 		// the longest ray's latency whatever the occupancy (measured: 128- and 1024-thread workgroups run
@@ -680,8 +721,9 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 	// by a guess for huge grids -- ERR_ENTRIES makes the host retry with the exact size). A runaway ray sets
 	// ctl->err in k_dda, and every map kernel returns early on it: the map stays untouched.
 	m->last_rgb = d_rgb;
-	u64 capH = m->haveH ? std::min<u64>(n_hits, m->gridH.bytes) : 0;
+	u64 capH = m->haveH ? (u64)n_hits : 0;
 	u64 capM = m->haveM ? std::min<u64>(m->gridM.bytes, std::max<u64>(1u << 20, (u64)n_rays * 64)) : 0;
+	if (m->opt_entry_guess && capM > m->opt_entry_guess) capM = m->opt_entry_guess;  // tests: force the ERR_ENTRIES retry
 	rc = mapPhase(m, depth, d_rgb, capH, capM, false);
 	if (rc) return rc;
 	HIP_TRY(hipGetLastError());
@@ -784,7 +826,7 @@ void ufomap_map_destroy(ufomap_map* m)
 	m->tb.release();
 	DevBuf* bufs[] = {&m->b_root,
 	                  &m->b_ctl,     &m->b_pt_end,  &m->b_pt_flag,  &m->b_pt_slot, &m->b_ray_end, &m->b_hit_code, &m->b_hit_pt,
-	                  &m->b_hh_keys, &m->b_hh_idx,  &m->b_gridH,    &m->b_gridM,   &m->b_part0,   &m->b_part1,   &m->b_slabs,   &m->b_blktime,   &m->b_entries, &m->b_ent_slot, &m->b_newlist,
+	                  &m->b_hh_keys, &m->b_hh_idx,  &m->b_gridM,   &m->b_crec,    &m->b_dlist,   &m->b_part0,   &m->b_part1,   &m->b_slabs,   &m->b_hb_keys, &m->b_hb_mask, &m->b_hb_time,   &m->b_entries, &m->b_ent_slot, &m->b_newlist,
 	                  &m->b_wl0,     &m->b_wl1,     &m->b_in_xyz,   &m->b_in_rgb,  &m->b_codes,   &m->b_dump};
 	for (DevBuf* b : bufs) b->release();
 	for (PendingEvent& pe : m->pend_ev) {
@@ -1139,7 +1181,7 @@ int ufomap_map_scan_keys(ufomap_map* m, const double sensor_origin[3], const dou
 	u32 n_hits = 0, n_rays = 0;
 	int rc = scanPhase(m, sensor_origin, d_xyz, nullptr, n, max_range, depth, discrete, simple_ray_casting, 0, &n_hits, &n_rays);
 	if (rc || 0 == n) return rc;
-	u64 capH = m->haveH ? std::min<u64>(n_hits, m->gridH.bytes) : 0;
+	u64 capH = m->haveH ? (u64)n_hits : 0;
 	u64 capM = m->haveM ? std::min<u64>(m->gridM.bytes, std::max<u64>(1u << 20, (u64)n_rays * 64)) : 0;
 	for (int attempt = 0; attempt < 2; ++attempt) {
 		rc = extractLists(m, capH, capM, attempt > 0);
@@ -1211,13 +1253,27 @@ int ufomap_map_apply_keys(ufomap_map* m, const void* d_entries, const ufomap_key
 	if (rc) return rc;
 	const Entry* ent = static_cast<const Entry*>(d_entries);
 	const float miss = (float)(m->g.miss_log / double((2.0 * info->depth) + 1));
-	rc = applyEntries(m, ent, nh, 0, 1, info->nb_hit, m->g.hit, nullptr, false);
+	rc = applyEntries(m, ent, nh, 0, 1, info->nb_hit, m->g.hit, nullptr, false, nh, nm);
 	if (rc) return rc;
-	rc = applyEntries(m, ent + nh, nm, 1, info->depth + 1, info->nb_miss, miss, nullptr, false);
+	rc = applyEntries(m, ent + nh, nm, 1, info->depth + 1, info->nb_miss, miss, nullptr, false, nh, nm);
 	if (rc) return rc;
 	m->pending = true;
 	HIP_TRY(hipStreamSynchronize(m->stream));
 	return finishPending(m);
+}
+
+int ufomap_map_set_option(ufomap_map* m, const char* key, long long value)
+{
+	if (!m || !key) return fail(UFOMAP_ERR_INVALID, "null argument");
+	if (0 == strcmp(key, "dda_mode")) {
+		if (value < -1 || value > 2) return fail(UFOMAP_ERR_INVALID, "dda_mode: -1 auto, 0 LDS grid, 1 LDS filter, 2 direct");
+		m->opt_dda_mode = (int)value;
+	} else if (0 == strcmp(key, "entry_guess")) {
+		m->opt_entry_guess = value > 0 ? (u64)value : 0;
+	} else {
+		return fail(UFOMAP_ERR_INVALID, std::string("unknown option ") + key);
+	}
+	return UFOMAP_OK;
 }
 
 int ufomap_map_debug(ufomap_map* m, uint64_t* out, int n)

@@ -192,6 +192,9 @@ class OccupancyMapBase:
         keys = ["points", "rays", "steps", "hits", "miss_cells", "blocks_touched", "blocks_created", "oob_dropped"]
         return dict(zip(keys, (int(v) for v in c)))
 
+    def set_option(self, key, value):
+        capi.check(self._lib.ufomap_map_set_option(self._h, key.encode(), int(value)))
+
     def set_profiling(self, on=True):
         capi.check(self._lib.ufomap_map_set_profiling(self._h, int(on)))
 
