@@ -279,6 +279,21 @@ __global__ __launch_bounds__(256) void k_ensure(Table t, MapGeom g, const Entry*
 	if (__lane_id() == 0 && n_created) atomicAdd(&t.root->used, n_created);
 }
 
+// How many entries would have to create (or revive) their block: exact count used by the host before it
+// decides to grow the table (the a-priori bound assumes every entry is new, which is far off on a warm map).
+__global__ __launch_bounds__(256) void k_count_missing(Table t, const Entry* __restrict__ entries, const u32* n_entries_p, u32 cap,
+                                                       u32* __restrict__ out)
+{
+	const u32 n = min(*n_entries_p, cap);
+	u32 miss = 0;
+	for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		u32 s = tableFind(t, entries[i].lk);
+		if (s == NONE || (t.flags[s] & F_DEAD)) ++miss;
+	}
+	for (int o = 32; o > 0; o >>= 1) miss += __shfl_xor(miss, o);
+	if (__lane_id() == 0 && miss) atomicAdd(out, miss);
+}
+
 // S2 init: children of a new block inherit the whole value of the node (createChildren,
 // octree.h:1044-1054). The node's value is found in the first ancestor block that is not new.
 __global__ __launch_bounds__(256) void k_init_new(Table t, MapGeom g, const u32* __restrict__ newlist, u32 newcap,

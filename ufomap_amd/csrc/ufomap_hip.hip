@@ -441,21 +441,39 @@ int applyEntries(ufomap_map* m, const Entry* d_entries, u32 cap, u32 which, u32 
 	return UFOMAP_OK;
 }
 
-// Make sure the node table can take the worst case of both phases (true upper bound, see blockBound).
-int sizeTable(ufomap_map* m, u64 capH, const i32 nbH[3], u64 capM, const i32 nbM[3], unsigned depth)
+// Make sure the node table can take what both phases may create. The a-priori bound (blockBound with every
+// entry new) is a true upper bound but far too pessimistic on a warm map; when it asks for growth, count
+// the entries whose block is really missing (one extra kernel + host read on this rare path) and bound again.
+int sizeTable(ufomap_map* m, const Entry* ent_h, u64 capH, const i32 nbH[3], const Entry* ent_m, u64 capM, const i32 nbM[3],
+              unsigned depth)
 {
-	u64 need = m->used_est;
-	m->scan_new_bound = 0;
-	if (capH) m->scan_new_bound += blockBound(m, capH, nbH, 1);
-	if (capM) m->scan_new_bound += blockBound(m, capM, nbM, (u32)depth + 1);
-	need += m->scan_new_bound;
+	auto bound = [&](u64 nh, u64 nm) {
+		u64 b = 0;
+		if (nh) b += blockBound(m, nh, nbH, 1);
+		if (nm) b += blockBound(m, nm, nbM, (u32)depth + 1);
+		return b;
+	};
+	m->scan_new_bound = bound(capH, capM);
 	u64 cap = (u64)m->t.mask + 1;
-	if (need * 5 > cap * 3) {  // keep the load factor <= 0.6
-		u64 want = need * 2;
-		if (want > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
-		return growTable(m, nextPow2(want));
+	if ((m->used_est + m->scan_new_bound) * 5 <= cap * 3) return UFOMAP_OK;  // load factor stays <= 0.6
+	if (ent_h || ent_m) {
+		ScanCtl* ctl = m->b_ctl.as<ScanCtl>();
+		u32* d_cnt = reinterpret_cast<u32*>(&ctl->dbg[60]);  // two spare words of the control block
+		HIP_TRY(hipMemsetAsync(d_cnt, 0, 8, m->stream));
+		if (capH)
+			hipLaunchKernelGGL(k_count_missing, gridFor(capH), dim3(256), 0, m->stream, m->t, ent_h, &ctl->n_entries[0], (u32)capH, d_cnt);
+		if (capM)
+			hipLaunchKernelGGL(k_count_missing, gridFor(capM), dim3(256), 0, m->stream, m->t, ent_m, &ctl->n_entries[1], (u32)capM, d_cnt + 1);
+		int rc = readCtl(m);
+		if (rc) return rc;
+		u32 cnt[2];
+		memcpy(cnt, &m->h_ctl->dbg[60], 8);
+		if (m->h_ctl->n_entries[0] <= capH && m->h_ctl->n_entries[1] <= capM) m->scan_new_bound = bound(cnt[0], cnt[1]);
+		if ((m->used_est + m->scan_new_bound) * 5 <= cap * 3) return UFOMAP_OK;
 	}
-	return UFOMAP_OK;
+	u64 want = (m->used_est + m->scan_new_bound) * 2;
+	if (want > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
+	return growTable(m, nextPow2(want));
 }
 
 // Update lists from the two grids of the current scan into b_entries: hit entries first, then miss entries.
@@ -488,12 +506,12 @@ int mapPhase(ufomap_map* m, unsigned depth, const uint8_t* d_rgb, u64 capH, u64 
 	const float miss = (float)(m->g.miss_log / double((2.0 * depth) + 1));  // OMB:311
 	if (!m->haveH) capH = 0;
 	if (!m->haveM) capM = 0;
-	int rc = sizeTable(m, capH, m->gridH.nb, capM, m->gridM.nb, depth);
-	if (rc) return rc;
-	rc = extractLists(m, capH, capM, retry);
+	int rc = extractLists(m, capH, capM, retry);
 	if (rc) return rc;
 	Entry* ent_h = m->b_entries.as<Entry>();
 	Entry* ent_m = ent_h + capH;
+	rc = sizeTable(m, ent_h, capH, m->gridH.nb, ent_m, capM, m->gridM.nb, depth);
+	if (rc) return rc;
 	rc = applyEntries(m, ent_h, (u32)capH, 0, 1, m->gridH.nb, m->g.hit, d_rgb, retry, (u32)capH, (u32)capM);
 	if (rc) return rc;
 	return applyEntries(m, ent_m, (u32)capM, 1, (u32)depth + 1, m->gridM.nb, miss, nullptr, retry, (u32)capH, (u32)capM);
@@ -1249,9 +1267,9 @@ int ufomap_map_apply_keys(ufomap_map* m, const void* d_entries, const ufomap_key
 	}
 	*m->h_ctl = init;
 	HIP_TRY(hipMemcpyAsync(m->b_ctl.p, m->h_ctl, sizeof(ScanCtl), hipMemcpyHostToDevice, m->stream));
-	int rc = sizeTable(m, nh, info->nb_hit, nm, info->nb_miss, info->depth);
-	if (rc) return rc;
 	const Entry* ent = static_cast<const Entry*>(d_entries);
+	int rc = sizeTable(m, ent, nh, info->nb_hit, ent + nh, nm, info->nb_miss, info->depth);
+	if (rc) return rc;
 	const float miss = (float)(m->g.miss_log / double((2.0 * info->depth) + 1));
 	rc = applyEntries(m, ent, nh, 0, 1, info->nb_hit, m->g.hit, nullptr, false, nh, nm);
 	if (rc) return rc;
