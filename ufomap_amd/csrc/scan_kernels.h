@@ -594,17 +594,21 @@ __global__ __launch_bounds__(256) void k_hitmark(HitBlocks hb, const u64* __rest
 	}
 }
 
-// hit blocks -> update list (hit entries, level 1)
+// hit blocks -> update list (hit entries, level 1). Each lane takes 8 slots so that a wave reserves its
+// output with ONE atomic (an atomic per wave-iteration on a single counter costs ~12 ns each).
 __global__ __launch_bounds__(256) void k_extract_hits(MapGeom g, HitBlocks hb, Entry* __restrict__ entries, u32 cap, ScanCtl* ctl)
 {
 	const u32 nslots = hb.cap_mask + 1;
-	const u32 stride = gridDim.x * blockDim.x;
-	const u32 iters = (nslots + stride - 1) / stride;
-	u32 s = blockIdx.x * blockDim.x + threadIdx.x;
-	for (u32 it = 0; it < iters; ++it, s += stride) {
-		const bool have = s < nslots && hb.keys[s] != ~0ULL;
-		const u32 pos = waveAppend(&ctl->n_entries[0], have);
-		if (!have || pos >= cap) continue;
+	const u32 base = (blockIdx.x * blockDim.x + threadIdx.x) * 8u;
+	u32 have = 0;
+	for (u32 k = 0; k < 8u; ++k)
+		if (base + k < nslots && hb.keys[base + k] != ~0ULL) have |= 1u << k;
+	u32 pos = waveAppendN(&ctl->n_entries[0], (u32)__popc(have));
+	for (u32 k = 0; k < 8u; ++k) {
+		if (!((have >> k) & 1u)) continue;
+		const u32 s = base + k;
+		const u32 my = pos++;
+		if (my >= cap) continue;
 		Entry e;
 		e.lk = (1ULL << (3 * (g.L - 1))) | hb.keys[s];
 		e.hit = (u8)hb.mask[s];
@@ -613,7 +617,7 @@ __global__ __launch_bounds__(256) void k_extract_hits(MapGeom g, HitBlocks hb, E
 		const u32 tv = hb.time[s];
 		e.c_last = (u8)(tv & 7u);
 		e.t_last = tv >> 3;
-		entries[pos] = e;
+		entries[my] = e;
 	}
 }
 
@@ -913,28 +917,326 @@ __global__ __launch_bounds__(UFO_DDA_BLOCK) void k_dda(MapGeom g, D3 sensor, u32
 	if (err) atomicOr(&ctl->err, err);
 }
 
-// OR the per-workgroup slabs of k_dda (LDS-grid mode) into grid M. One thread per 16-byte column.
-__global__ __launch_bounds__(256) void k_merge_slabs(const uint4* __restrict__ slabs, u32 n_slabs, u32 n4, uint4* __restrict__ grid)
+// ------------------------------------------------------------------------------------------------
+// K2' dda, segmented: several lanes per ray.
+//
+// The lane-per-ray kernel above is bound by the latency of ONE ray's dependent chain (~180 steps x ~350
+// cycles); occupancy does not help. But the traversal is a 3-way merge of three independent sequences
+// T_a[k] = t_max_a + k * t_delta_a (each built by REPEATED rounding additions, OCT:1232), popped smallest
+// first with ties to the lower axis (VEC3:244-251). Element B[m] of axis b is popped before element A[k]
+// of axis a iff B[m] < A[k], or B[m] == A[k] and b < a -- independent of the third axis. So the state
+// right after the k0-th pop of the ray's dominant axis a* can be rebuilt exactly without walking there:
+// k0 additions give A[k0-1] and A[k0]; for each other axis a short add/compare loop counts the elements
+// that precede A[k0-1] and leaves that axis' t_max. Each of the 2 or 4 lanes of a ray rebuilds the start
+// of its segment (boundaries at equal counts of a*-pops), checks the loop condition there (OMB:1300; t_max
+// minima are monotone, and the goal cell cannot be reached before the last segment) and walks only its
+// share with the same branch-free step. Bit-identical cells, 2-4 x shorter dependent chain. (More lanes
+// per ray stop paying: measured 8 lanes/ray is throughput-bound and slower than 4.)
+// Rays that are not "safe" (clipped at the map cube) are walked by the group's first lane alone.
+// ------------------------------------------------------------------------------------------------
+#define UFO_SEG_MAX 4  // lanes per ray: 1, 2 or 4, chosen by the host so that the launch is ~4k waves
+
+// Initial state of one ray's walk, written by k_ray_setup (one lane per ray, dense) and read by the
+// lanes that walk it.
+struct RayState {
+	double tm[3], td[3], dist;
+	u32 pk0, gpk;   // packed local start / goal cell (x | y<<10 | z<<20)
+	i32 start[3];   // unpacked cells for the checked sequential walk
+	i32 goal[3];
+	int8_t s[3];    // step per axis (-1, 0, +1)
+	uint8_t status; // 0 nothing to do, 1 single cell, 2 safe: segmented walk, 3 clipped: checked sequential walk
+};
+
+// clip (OMB:1248), keys, computeRayInit (OCT:1192-1225): everything of a ray that is not the walk itself
+__global__ __launch_bounds__(256) void k_ray_setup(MapGeom g, D3 sensor, u32 depth, Grid gr, const D3* __restrict__ ray_end,
+                                                   RayState* __restrict__ rs, const ScanCtl* ctl_in)
 {
-	for (u32 j = blockIdx.x * blockDim.x + threadIdx.x; j < n4; j += gridDim.x * blockDim.x) {
+	const u32 n = ctl_in->n_rays;
+	const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	RayState r;
+	r.status = 0;
+	const u32 lim = 1u << (g.L - depth);
+	D3 from = sensor, to = ray_end[i];
+	if (moveLineInside(g, from, to)) {
+		D3 cur = to, end = from;  // "do it backwards" OMB:1266-1272
+		D3 dir = end - cur;
+		const double dist = norm(dir);
+		dir = dir / dist;
+		r.dist = dist;
+		const u32 kx = toKey1(g, cur.x, depth), ky = toKey1(g, cur.y, depth), kz = toKey1(g, cur.z, depth);
+		const u32 ex = toKey1(g, end.x, depth), ey = toKey1(g, end.y, depth), ez = toKey1(g, end.z, depth);
+		const i32 cx = (i32)(kx >> depth), cy = (i32)(ky >> depth), cz = (i32)(kz >> depth);
+		const i32 gx = (i32)(ex >> depth), gy = (i32)(ey >> depth), gz = (i32)(ez >> depth);
+		r.start[0] = cx;
+		r.start[1] = cy;
+		r.start[2] = cz;
+		r.goal[0] = gx;
+		r.goal[1] = gy;
+		r.goal[2] = gz;
+		if (kx == ex && ky == ey && kz == ez) {
+			r.status = 1;  // OMB:1281-1284
+		} else {
+			const double node_size = nodeSize(g, depth), half = g.hs[depth];
+			double bx = toCoord1(g, kx, depth) - cur.x, by = toCoord1(g, ky, depth) - cur.y, bz = toCoord1(g, kz, depth) - cur.z;
+			i32 sx, sy, sz;
+			double tdx, tdy, tdz, tmx, tmy, tmz;
+#define UFO_AXIS_INIT(d, b, s, td, tm)                 \
+	if (0 < d) {                                        \
+		s = 1;                                          \
+		b += half;                                      \
+		td = node_size / fabs(d);                       \
+		tm = b / d;                                     \
+	} else if (0 > d) {                                 \
+		s = -1;                                         \
+		b -= half;                                      \
+		td = node_size / fabs(d);                       \
+		tm = b / d;                                     \
+	} else {                                            \
+		s = 0;                                          \
+		td = 1.7976931348623157e308;                    \
+		tm = 1.7976931348623157e308;                    \
+	}
+			UFO_AXIS_INIT(dir.x, bx, sx, tdx, tmx)
+			UFO_AXIS_INIT(dir.y, by, sy, tdy, tmy)
+			UFO_AXIS_INIT(dir.z, bz, sz, tdz, tmz)
+#undef UFO_AXIS_INIT
+			r.s[0] = (int8_t)sx;
+			r.s[1] = (int8_t)sy;
+			r.s[2] = (int8_t)sz;
+			r.td[0] = tdx;
+			r.td[1] = tdy;
+			r.td[2] = tdz;
+			r.tm[0] = tmx;
+			r.tm[1] = tmy;
+			r.tm[2] = tmz;
+			const i32 l0x = cx - gr.base[0], l0y = cy - gr.base[1], l0z = cz - gr.base[2];
+			const i32 l1x = gx - gr.base[0], l1y = gy - gr.base[1], l1z = gz - gr.base[2];
+			const i32 mxx = 2 * gr.nb[0] - 2, mxy = 2 * gr.nb[1] - 2, mxz = 2 * gr.nb[2] - 2;
+			const bool safe = (u32)cx < lim && (u32)cy < lim && (u32)cz < lim && (u32)gx < lim && (u32)gy < lim && (u32)gz < lim &&
+			                  l0x >= 1 && l0y >= 1 && l0z >= 1 && l1x >= 1 && l1y >= 1 && l1z >= 1 && l0x <= mxx && l0y <= mxy &&
+			                  l0z <= mxz && l1x <= mxx && l1y <= mxy && l1z <= mxz;
+			if (safe) {
+				r.pk0 = (u32)l0x | ((u32)l0y << 10) | ((u32)l0z << 20);
+				r.gpk = (u32)l1x | ((u32)l1y << 10) | ((u32)l1z << 20);
+				r.status = 2;
+			} else {
+				r.status = 3;
+			}
+		}
+	}
+	rs[i] = r;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(UFO_DDA_BLOCK) void k_dda_seg(MapGeom g, u32 depth, Grid gr, u32* __restrict__ grid,
+                                                           const RayState* __restrict__ rs, u32 seg_shift, const ScanCtl* ctl_in,
+                                                           ScanCtl* ctl)
+{
+	extern __shared__ __attribute__((aligned(16))) u32 lds[];
+	const u32 lds_words = (MODE == DDA_LDSGRID) ? (u32)(gr.bytes >> 2) : (MODE == DDA_FILTER ? (u32)UFO_DDA_FILT : 0u);
+	if (MODE == DDA_LDSGRID) {
+		uint4* l4 = reinterpret_cast<uint4*>(lds);
+		for (u32 j = threadIdx.x; j < (lds_words >> 2); j += blockDim.x) l4[j] = make_uint4(0, 0, 0, 0);
+	} else {
+		for (u32 j = threadIdx.x; j < lds_words; j += blockDim.x) lds[j] = 0xFFFFFFFFu;
+	}
+	__syncthreads();
+	const u32 n = ctl_in->n_rays;
+	const u32 tid = blockIdx.x * blockDim.x + threadIdx.x;
+	const u32 nseg = 1u << seg_shift;
+	const u32 ray = tid >> seg_shift;
+	const u32 sg = tid & (nseg - 1u);
+	unsigned long long steps = 0;
+	u32 err = 0, oob = 0;
+	const u32 lim = 1u << (g.L - depth);
+	if (ray < n) {
+		const RayState* r = rs + ray;
+		const u32 status = r->status;
+		if (0 == sg && 1 == status) {
+			err |= ddaMark<MODE>(gr, grid, lds, r->start[0], r->start[1], r->start[2], lim, &oob);
+			steps = 1;
+		} else if (0 == sg && 3 == status) {
+			// clipped ray (rare): sequential walk with every step checked, by this lane alone
+			i32 cx = r->start[0], cy = r->start[1], cz = r->start[2];
+			const i32 gx = r->goal[0], gy = r->goal[1], gz = r->goal[2];
+			const i32 sx = r->s[0], sy = r->s[1], sz = r->s[2];
+			double tmx = r->tm[0], tmy = r->tm[1], tmz = r->tm[2];
+			const double tdx = r->td[0], tdy = r->td[1], tdz = r->td[2], dist = r->dist;
+			const u64 budget = 3ull * (1ull << g.L) + 8;
+			bool go;
+			do {
+				if (++steps > budget) {
+					err |= ERR_RUNAWAY;
+					break;
+				}
+				err |= ddaMark<MODE>(gr, grid, lds, cx, cy, cz, lim, &oob);
+				if (tmx <= tmy) {
+					if (tmx <= tmz) {
+						cx += sx;
+						tmx += tdx;
+					} else {
+						cz += sz;
+						tmz += tdz;
+					}
+				} else {
+					if (tmy <= tmz) {
+						cy += sy;
+						tmy += tdy;
+					} else {
+						cz += sz;
+						tmz += tdz;
+					}
+				}
+				go = (cx != gx || cy != gy || cz != gz) && (fmin(fmin(tmx, tmy), tmz) <= dist);
+			} while (go);
+		} else if (2 == status) {
+			const u32 pk0 = r->pk0, gpk = r->gpk;
+			const i32 sx = r->s[0], sy = r->s[1], sz = r->s[2];
+			double tmx = r->tm[0], tmy = r->tm[1], tmz = r->tm[2];
+			const double tdx = r->td[0], tdy = r->td[1], tdz = r->td[2], dist = r->dist;
+			// dominant axis a* and this lane's segment [k0, k1) in pops of a*
+			const u32 dxn = (u32)abs((i32)(gpk & 1023u) - (i32)(pk0 & 1023u));
+			const u32 dyn = (u32)abs((i32)((gpk >> 10) & 1023u) - (i32)((pk0 >> 10) & 1023u));
+			const u32 dzn = (u32)abs((i32)(gpk >> 20) - (i32)(pk0 >> 20));
+			const u32 ax = (dxn >= dyn && dxn >= dzn) ? 0u : (dyn >= dzn ? 1u : 2u);
+			const u32 dmax = ax == 0 ? dxn : (ax == 1 ? dyn : dzn);
+			const u32 w = (dmax + nseg - 1) >> seg_shift;  // >= 1 (the cells differ)
+			const u32 k0 = sg * w;
+			const bool active = (0 == sg) || (k0 < dmax);
+			const u32 k1 = (k0 + w < dmax) ? (k0 + w) : 0xFFFFFFFFu;  // the last active segment runs to the end
+			if (active) {
+				const u32 dxs = (u32)sx, dys = (u32)sy << 10, dzs = (u32)sz << 20;
+				u32 pk = pk0;
+				if (sg > 0) {
+					// state right after the k0-th pop of axis a*: element A[k0-1] was popped, t_max_a* = A[k0]
+					double ta = ax == 0 ? tmx : (ax == 1 ? tmy : tmz);
+					const double tda = ax == 0 ? tdx : (ax == 1 ? tdy : tdz);
+					double v = ta;
+					for (u32 i = 0; i < k0; ++i) {
+						v = ta;
+						ta = ta + tda;
+					}
+					// other axes: elements popped before A[k0-1] (strictly smaller, or equal when the axis has priority)
+					u32 cb0 = 0, cb1 = 0;
+					const u32 b0 = ax == 0 ? 1u : 0u, b1 = ax == 2 ? 1u : 2u;  // the two other axes, ascending
+					double t0 = b0 == 0 ? tmx : tmy, d0 = b0 == 0 ? tdx : tdy;
+					double t1 = b1 == 1 ? tmy : tmz, d1 = b1 == 1 ? tdy : tdz;
+					const bool p0 = b0 < ax, p1 = b1 < ax;  // lower axis index wins ties (VEC3:244-251)
+					while (cb0 < 2048u && (p0 ? (t0 <= v) : (t0 < v))) {
+						t0 = t0 + d0;
+						++cb0;
+					}
+					while (cb1 < 2048u && (p1 ? (t1 <= v) : (t1 < v))) {
+						t1 = t1 + d1;
+						++cb1;
+					}
+					const u32 da = ax == 0 ? dxs : (ax == 1 ? dys : dzs);
+					const u32 db0 = b0 == 0 ? dxs : dys, db1 = b1 == 1 ? dys : dzs;
+					pk = pk0 + k0 * da + cb0 * db0 + cb1 * db1;
+					if (ax == 0) {
+						tmx = ta;
+						tmy = t0;
+						tmz = t1;
+					} else if (ax == 1) {
+						tmy = ta;
+						tmx = t0;
+						tmz = t1;
+					} else {
+						tmz = ta;
+						tmx = t0;
+						tmy = t1;
+					}
+				}
+				double m = (tmy < tmx) ? tmy : tmx;
+				m = (tmz < m) ? tmz : m;
+				// loop condition at the segment start (OMB:1300); segment 0 starts the do-while unconditionally
+				bool go = (0 == sg) || ((pk != gpk) && (m <= dist));
+				const u32 nbx = (u32)gr.nb[0], nby = (u32)gr.nb[1];
+				u32 ka = k0, cnt = 0;
+				while (go) {
+					++cnt;
+					const u32 bxx = (pk >> 1) & 511u, byy = (pk >> 11) & 511u, bzz = pk >> 21;
+					const u32 idx = __umul24(__umul24(bzz, nby) + byy, nbx) + bxx;
+					const u32 bit = (pk & 1u) | ((pk >> 9) & 2u) | ((pk >> 18) & 4u) | ((idx & 3u) << 3);
+					if (MODE == DDA_LDSGRID) {
+						atomicOr(&lds[idx >> 2], 1u << bit);
+					} else {
+						u32* wd = &grid[idx >> 2];
+						bool skip = false;
+						if (MODE == DDA_FILTER) {
+							const u32 tag = (idx << 3) | (bit & 7u);
+							const u32 h = (tag * 0x9E3779B1u) >> 17;
+							skip = lds[h] == tag;
+							if (!skip) {
+								lds[h] = tag;
+								skip = (*wd >> bit) & 1u;
+							}
+						}
+						if (!skip) atomicOr(wd, 1u << bit);
+					}
+					const bool selx = tmx == m;
+					const bool sely = !selx && (tmy == m);
+					const bool selz = !(selx || sely);
+					pk += selx ? dxs : (sely ? dys : dzs);
+					const double nx = tmx + tdx, ny = tmy + tdy, nz = tmz + tdz;
+					tmx = selx ? nx : tmx;
+					tmy = sely ? ny : tmy;
+					tmz = selz ? nz : tmz;
+					m = (tmy < tmx) ? tmy : tmx;
+					m = (tmz < m) ? tmz : m;
+					const bool sela = ax == 0 ? selx : (ax == 1 ? sely : selz);
+					ka += sela ? 1u : 0u;
+					go = (pk != gpk) && (m <= dist) && (ka != k1) && (cnt < 4096u);
+				}
+				steps += cnt;
+			}
+		}
+	}
+	if (MODE == DDA_LDSGRID) {
+		__syncthreads();
+		const uint4* l4 = reinterpret_cast<const uint4*>(lds);
+		uint4* out4 = reinterpret_cast<uint4*>(grid) + (size_t)blockIdx.x * (lds_words >> 2);
+		const u32 n4 = lds_words >> 2;
+		for (u32 j = threadIdx.x; j < n4; j += blockDim.x) out4[j] = l4[j];
+	}
+	waveAddU64(&ctl->n_steps, steps);
+	if (oob) atomicAdd(&ctl->n_oob, oob);
+	if (err) atomicOr(&ctl->err, err);
+}
+
+// OR the per-workgroup slabs of the ray kernels (LDS-grid mode) into grid M. Workgroup = 64 columns of
+// 16 bytes x 16 slab lanes: every thread ORs the slabs s = lane, lane+16, ... of its column (independent
+// loads, 1 KiB contiguous per slab per wave), the 16 partial results are combined through LDS.
+__global__ __launch_bounds__(1024) void k_merge_slabs(const uint4* __restrict__ slabs, u32 n_slabs, u32 n4, uint4* __restrict__ grid)
+{
+	__shared__ uint4 part[16][64];
+	const u32 col = threadIdx.x & 63u, sl = threadIdx.x >> 6;
+	for (u32 j0 = blockIdx.x * 64u; j0 < n4; j0 += gridDim.x * 64u) {
+		const u32 j = j0 + col;
 		uint4 acc = make_uint4(0, 0, 0, 0);
-		const uint4* p = slabs + j;
-		u32 s = 0;
-		for (; s + 4 <= n_slabs; s += 4) {
-			uint4 a = p[(size_t)s * n4], b = p[(size_t)(s + 1) * n4], c = p[(size_t)(s + 2) * n4], d = p[(size_t)(s + 3) * n4];
-			acc.x |= a.x | b.x | c.x | d.x;
-			acc.y |= a.y | b.y | c.y | d.y;
-			acc.z |= a.z | b.z | c.z | d.z;
-			acc.w |= a.w | b.w | c.w | d.w;
+		if (j < n4) {
+			for (u32 s = sl; s < n_slabs; s += 16u) {
+				const uint4 a = slabs[(size_t)s * n4 + j];
+				acc.x |= a.x;
+				acc.y |= a.y;
+				acc.z |= a.z;
+				acc.w |= a.w;
+			}
 		}
-		for (; s < n_slabs; ++s) {
-			uint4 a = p[(size_t)s * n4];
-			acc.x |= a.x;
-			acc.y |= a.y;
-			acc.z |= a.z;
-			acc.w |= a.w;
+		part[sl][col] = acc;
+		__syncthreads();
+		if (0 == sl && j < n4) {
+			for (u32 k = 1; k < 16u; ++k) {
+				const uint4 a = part[k][col];
+				acc.x |= a.x;
+				acc.y |= a.y;
+				acc.z |= a.z;
+				acc.w |= a.w;
+			}
+			grid[j] = acc;
 		}
-		grid[j] = acc;
+		__syncthreads();
 	}
 }
 

@@ -115,7 +115,7 @@ struct ufomap_map {
 	DevBuf b_ctl, b_pt_end, b_pt_flag, b_pt_slot, b_ray_end, b_hit_code, b_hit_pt, b_hh_keys, b_hh_idx;
 	DevBuf b_part0, b_part1, b_slabs, b_hb_keys, b_hb_mask, b_hb_time;
 	u32 hb_cap_mask = 0;
-	DevBuf b_crec, b_dlist;
+	DevBuf b_crec, b_dlist, b_rays;
 	DevBuf b_gridM, b_entries, b_ent_slot, b_newlist, b_wl0, b_wl1, b_in_xyz, b_in_rgb, b_codes, b_dump;
 	ScanCtl* h_ctl = nullptr;  // pinned
 	MapRoot* h_root = nullptr;  // pinned
@@ -131,6 +131,7 @@ struct ufomap_map {
 	// diagnostic overrides (ufomap_map_set_option); -1 / 0 = automatic
 	u64 scan_new_bound = 0;  // upper bound of the blocks both phases of the current scan can create
 	int opt_dda_mode = -1;
+	int opt_dda_seg = 1;  // 0 = force the lane-per-ray kernel
 	u64 opt_entry_guess = 0;
 	uint64_t counts[8] = {0};
 	double min_change[3], max_change[3];
@@ -487,9 +488,9 @@ int extractLists(ufomap_map* m, u64 capH, u64 capM, bool zero_counts)
 	Entry* ent_m = ent_h + capH;
 	if (zero_counts) HIP_TRY(hipMemsetAsync(&ctl->n_entries[0], 0, 8, m->stream));  // otherwise zero from the control-block upload
 	if (capH) {
-		ProfScope ps(m, "k_extract");
+		ProfScope ps(m, "k_extract_hits");
 		HitBlocks hb{m->b_hb_keys.as<u64>(), m->b_hb_mask.as<u32>(), m->b_hb_time.as<u32>(), m->hb_cap_mask};
-		hipLaunchKernelGGL(k_extract_hits, gridFor((u64)m->hb_cap_mask + 1, 256, 2048), dim3(256), 0, m->stream, m->g, hb, ent_h,
+		hipLaunchKernelGGL(k_extract_hits, dim3((u32)(((u64)m->hb_cap_mask + 1 + 2047) / 2048)), dim3(256), 0, m->stream, m->g, hb, ent_h,
 		                   (u32)capH, ctl);
 	}
 	if (capM) {
@@ -687,22 +688,42 @@ int scanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, const 
 		// the longest ray's latency whatever the occupancy (measured: 128- and 1024-thread workgroups run
 		// the same). Large workgroups mean fewer LDS-grid slabs to merge and a wider dedup scope for the
 		// filter, so use the maximum unless the scan is tiny.
+		// The segmented kernel (8 lanes per ray) needs 10-bit local cell coordinates; the sequential kernel is the
+		// general fallback (fixed-step "simple" casting, huge grids).
+		const bool packed = 2 * m->gridM.nb[0] < 1023 && 2 * m->gridM.nb[1] < 1023 && 2 * m->gridM.nb[2] < 1023;
+		const bool seg = !simple && mode != DDA_DIRECT && packed && m->opt_dda_seg != 0;
+		// lanes per ray: as many as keep the launch around 4k waves (all resident at once, not issue-bound)
+		u32 seg_shift = 0;
+		while (seg && (1u << (seg_shift + 1)) <= UFO_SEG_MAX && ((u64)n_rays << (seg_shift + 1)) <= 4096ull * 64) ++seg_shift;
+		const u64 lanes = (u64)n_rays << seg_shift;
 		u32 blk = UFO_DDA_BLOCK;
-		while (blk > 128 && (n_rays + blk - 1) / blk < 32) blk >>= 1;
-		dim3 gr((n_rays + blk - 1) / blk);
+		while (blk > 128 && (lanes + blk - 1) / blk < 32) blk >>= 1;
+		dim3 gr((u32)((lanes + blk - 1) / blk));
 		u32* dda_out = m->b_gridM.as<u32>();
 		if (mode == DDA_LDSGRID) {
-			HIP_TRY(m->b_slabs.reserve((size_t)gr.x * m->gridM.bytes));  // <= 512 x 144 KiB
+			HIP_TRY(m->b_slabs.reserve((size_t)gr.x * m->gridM.bytes));
 			dda_out = m->b_slabs.as<u32>();
 		} else {
 			HIP_TRY(hipMemsetAsync(m->b_gridM.p, 0, m->gridM.bytes, m->stream));
+		}
+		if (seg) {
+			HIP_TRY(m->b_rays.reserve((size_t)n_rays * sizeof(RayState)));
+			ProfScope ps(m, "k_ray_setup");
+			hipLaunchKernelGGL(k_ray_setup, dim3((n_rays + 255) / 256), dim3(256), 0, m->stream, m->g, sensor, (u32)depth, m->gridM,
+			                   m->b_ray_end.as<D3>(), m->b_rays.as<RayState>(), ctl);
 		}
 		{
 		ProfScope ps(m, "k_dda");
 #define UFO_LAUNCH_DDA(SIMPLE, MODE)                                                                                         \
 	hipLaunchKernelGGL((k_dda<SIMPLE, MODE>), gr, dim3(blk), lds, m->stream, m->g, sensor, (u32)depth, m->gridM, \
 	                   dda_out, m->b_ray_end.as<D3>(), ctl, ctl)
-		if (simple) {
+#define UFO_LAUNCH_SEG(MODE)                                                                                    \
+	hipLaunchKernelGGL((k_dda_seg<MODE>), gr, dim3(blk), lds, m->stream, m->g, (u32)depth, m->gridM, dda_out, \
+	                   m->b_rays.as<RayState>(), seg_shift, ctl, ctl)
+		if (seg) {
+			if (mode == DDA_LDSGRID) UFO_LAUNCH_SEG(DDA_LDSGRID);
+			else UFO_LAUNCH_SEG(DDA_FILTER);
+		} else if (simple) {
 			if (mode == DDA_LDSGRID) UFO_LAUNCH_DDA(true, DDA_LDSGRID);
 			else if (mode == DDA_FILTER) UFO_LAUNCH_DDA(true, DDA_FILTER);
 			else UFO_LAUNCH_DDA(true, DDA_DIRECT);
@@ -712,12 +733,13 @@ int scanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, const 
 			else UFO_LAUNCH_DDA(false, DDA_DIRECT);
 		}
 #undef UFO_LAUNCH_DDA
+#undef UFO_LAUNCH_SEG
 		}
 		if (mode == DDA_LDSGRID) {
 			ProfScope ps(m, "k_merge_slabs");
 			const u32 n4 = (u32)(m->gridM.bytes >> 4);
-			hipLaunchKernelGGL(k_merge_slabs, gridFor(n4, 256, 2048), dim3(256), 0, m->stream, m->b_slabs.as<uint4>(), gr.x, n4,
-			                   m->b_gridM.as<uint4>());
+			hipLaunchKernelGGL(k_merge_slabs, dim3(std::min<u32>((n4 + 63) / 64, 1024)), dim3(1024), 0, m->stream, m->b_slabs.as<uint4>(), gr.x,
+			                   n4, m->b_gridM.as<uint4>());
 		}
 	}
 
@@ -828,6 +850,8 @@ ufomap_map* ufomap_map_create(double resolution, unsigned depth_levels, int auto
 		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dda<true, DDA_LDSGRID>), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds);
 		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dda<false, DDA_FILTER>), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds);
 		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dda<true, DDA_FILTER>), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dda_seg<DDA_LDSGRID>), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dda_seg<DDA_FILTER>), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds);
 	}
 	for (int a = 0; a < 3; ++a) {
 		m->min_change[a] = g.hs[g.L];  // resetMinMaxChangeDetection (occupancy_map_base.h:806-810)
@@ -844,7 +868,7 @@ void ufomap_map_destroy(ufomap_map* m)
 	m->tb.release();
 	DevBuf* bufs[] = {&m->b_root,
 	                  &m->b_ctl,     &m->b_pt_end,  &m->b_pt_flag,  &m->b_pt_slot, &m->b_ray_end, &m->b_hit_code, &m->b_hit_pt,
-	                  &m->b_hh_keys, &m->b_hh_idx,  &m->b_gridM,   &m->b_crec,    &m->b_dlist,   &m->b_part0,   &m->b_part1,   &m->b_slabs,   &m->b_hb_keys, &m->b_hb_mask, &m->b_hb_time,   &m->b_entries, &m->b_ent_slot, &m->b_newlist,
+	                  &m->b_hh_keys, &m->b_hh_idx,  &m->b_gridM,   &m->b_crec,    &m->b_dlist,   &m->b_rays,   &m->b_part0,   &m->b_part1,   &m->b_slabs,   &m->b_hb_keys, &m->b_hb_mask, &m->b_hb_time,   &m->b_entries, &m->b_ent_slot, &m->b_newlist,
 	                  &m->b_wl0,     &m->b_wl1,     &m->b_in_xyz,   &m->b_in_rgb,  &m->b_codes,   &m->b_dump};
 	for (DevBuf* b : bufs) b->release();
 	for (PendingEvent& pe : m->pend_ev) {
@@ -1286,6 +1310,8 @@ int ufomap_map_set_option(ufomap_map* m, const char* key, long long value)
 	if (0 == strcmp(key, "dda_mode")) {
 		if (value < -1 || value > 2) return fail(UFOMAP_ERR_INVALID, "dda_mode: -1 auto, 0 LDS grid, 1 LDS filter, 2 direct");
 		m->opt_dda_mode = (int)value;
+	} else if (0 == strcmp(key, "dda_seg")) {
+		m->opt_dda_seg = value ? 1 : 0;
 	} else if (0 == strcmp(key, "entry_guess")) {
 		m->opt_entry_guess = value > 0 ? (u64)value : 0;
 	} else {
