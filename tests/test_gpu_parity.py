@@ -234,9 +234,9 @@ def test_all_ray_kernel_modes_agree(mode):
     _assert_same_map(g, o, f"dda_mode {mode}")
 
 
-def test_update_list_retry_and_table_growth():
-    """A too-small guess for the update list makes the device refuse to apply anything and the host retry
-    with the exact size; the node table grows by re-hash several times on the way. Result unchanged."""
+def test_update_list_count_pass_and_table_growth():
+    """A grid larger than the list-size guess takes the counting pass (exact update-list size); the node
+    table grows by re-hash several times on the way. Result unchanged."""
     from ufomap_amd import scans
     g, o = _maps(resolution=0.08)
     g.set_option("entry_guess", 1000)
@@ -287,3 +287,21 @@ def test_full_size_c3_depth0_counts():
     (the reference needs 85-168 s and 20 GB for this scan)."""
     c = _c3_depth0_properties(640, 480, False)
     assert c["steps"] > 3e8
+
+
+def test_pipelined_async_inserts_equal_sequential():
+    """async=True: the scan half of scan i+1 overlaps the map half of scan i on a second stream (the
+    reference overlaps its head loop with the previous integration, OMB:315). Same map as sequential."""
+    from ufomap_amd import scans
+    g, o = _maps(resolution=0.16)
+    clouds = []
+    for s in range(8):
+        origin, xyz, _ = scans.lidar64(origin=scans.lidar_pose(s), seed=100 + s, beams=32, azimuths=1024)
+        clouds.append((origin, xyz))
+        o.insert(origin, xyz, max_range=20.0, discrete=True)
+    for origin, xyz in clouds:
+        _gpu_insert(g, origin, xyz, max_range=20.0, discrete=True, async_=True)  # host buffers: copied before return
+    g.insertPointCloudWait()
+    assert g.insertPointCloudDone()
+    _assert_same_map(g, o, "pipelined")
+    assert g.last_counts()["points"] == clouds[-1][1].shape[0]

@@ -628,7 +628,25 @@ __global__ __launch_bounds__(256) void k_coarse_end(Table t, MapGeom g, const En
 	}
 }
 
-// one block's updateNode + hand-off; `valid` false lanes only take part in the wave-aggregated append
+// one block's updateNode (collapse only when the last-update chain reaches it) + hand-off of its summary.
+// Returns true when the summary changed, i.e. the parent (*par) has to be re-evaluated.
+template <bool WG>
+__device__ inline bool propagateCore(const Table& t, const MapGeom& g, u32 s, u32 old, u32 phase, u32* par)
+{
+	const u64 lk = t.keys[s];
+	const u32 level = levelOf(g, lk);
+	Summ sm = blockSummary(t, g, s, level, old);
+	Summ pre = sm;
+	const bool reached = lastReached(t, g, s, lk, level, old, phase, &pre);
+	if (reached && sm.collapsible) collapseBlock<WG>(t, s, lk);
+	const bool changed = writeToParent<WG>(t, g, s, lk, sm);
+	publishLast(t, g, s, lk, phase, reached && !sameSumm(g, pre, sm), pre);
+	const bool want = changed && 1 != lk;
+	if (want) *par = t.parent[s];
+	return want;
+}
+
+// worklist flavour; `valid` false lanes only take part in the wave-aggregated append
 template <bool WG>
 __device__ inline void propagateOne(const Table& t, const MapGeom& g, bool valid, u32 s, u32 phase, u32* __restrict__ wl_out,
                                     u32* cnt_out)
@@ -636,23 +654,8 @@ __device__ inline void propagateOne(const Table& t, const MapGeom& g, bool valid
 	bool want = false;
 	u32 par = NONE;
 	if (valid) {
-		// independent loads first (one memory round trip instead of a chain), then the flag RMW
-		u64 lk = t.keys[s];
-		u32 pslot = t.parent[s];
-		u64 tv_prefetch = t.tmax[s];
-		float4 occ_pf = *reinterpret_cast<const float4*>(t.occ + 8 * (size_t)s);
-		u32 old = aAnd<WG>(&t.flags[s], ~F_DIRTY);
-		asm volatile("" ::"v"(pslot), "v"(tv_prefetch), "v"(occ_pf.x));  // keep the early loads where they are
-		u32 level = levelOf(g, lk);
-		Summ sm = blockSummary(t, g, s, level, old);
-		// collapse only if the LAST update beneath this node walked all the way up to it (see above)
-		Summ pre = sm;
-		bool reached = lastReached(t, g, s, lk, level, old, phase, &pre);
-		if (reached && sm.collapsible) collapseBlock<WG>(t, s, lk);
-		bool changed = writeToParent<WG>(t, g, s, lk, sm);
-		publishLast(t, g, s, lk, phase, reached && !sameSumm(g, pre, sm), pre);
-		want = changed && 1 != lk;
-		if (want) par = t.parent[s];
+		const u32 old = aAnd<WG>(&t.flags[s], ~F_DIRTY);
+		want = propagateCore<WG>(t, g, s, old, phase, &par);
 	}
 	markDirty<WG>(t, want, par, wl_out, cnt_out);
 }
@@ -684,6 +687,42 @@ __global__ __launch_bounds__(1024) void k_propagate_tail(Table t, MapGeom g, u32
 		// level `first_level` was filled by an earlier launch; the later ones by this workgroup
 		const u32 n = aLoad<true>(&pc->wl_cnt[level]);
 		if (0 == n) break;  // uniform
+		if (n <= 64u) {
+			// Narrow from here to the root (each level has at most as many dirty blocks as the one below): one
+			// wave carries the items in registers -- no worklist, no DIRTY bits, no counters, no block barrier.
+			// Parents are de-duplicated with ballots; a workgroup-scope fence orders a level's stores before
+			// the next level's loads (same wave, same CU).
+			if (threadIdx.x >= 64u) return;
+			const u32 lane = threadIdx.x;
+			u32 s = lane < n ? in[lane] : NONE;
+			bool first = true;
+			for (u32 guard = 0; guard < 32u; ++guard) {
+				const bool valid = s != NONE;
+				if (0 == __ballot(valid)) break;
+				bool want = false;
+				u32 par = NONE;
+				if (valid) {
+					// items of the first round came off the worklist (DIRTY set); later rounds were never queued
+					const u32 old = first ? aAnd<true>(&t.flags[s], ~F_DIRTY) : aLoad<true>(&t.flags[s]);
+					want = propagateCore<true>(t, g, s, old, phase, &par);
+				}
+				first = false;
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+				u32 next = NONE;
+				u64 todo = __ballot(want);
+				while (todo) {
+					const int ld = __ffsll((unsigned long long)todo) - 1;
+					const u32 pl = __shfl(par, ld);
+					const u64 same = __ballot(want && par == pl);
+					if ((int)lane == ld) next = pl;
+					todo &= ~same;
+				}
+				s = next;
+			}
+			if (0 == lane) ctl->dbg[dbg_at + 31] = wall_clock64();
+			return;
+		}
 		const u32 iters = (n + blockDim.x - 1) / blockDim.x;
 		u32 i = threadIdx.x;
 		for (u32 it = 0; it < iters; ++it, i += blockDim.x) {

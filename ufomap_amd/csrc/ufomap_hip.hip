@@ -100,10 +100,23 @@ inline u32 nextPow2(u64 v)
 }
 }  // namespace
 
+// What the map half of scan i needs while the scan half of scan i+1 already runs on the other stream:
+// double-buffered and swapped at the start of every scan (see doInsert).
+struct HandOver {
+	DevBuf b_ctl, b_entries, b_hh_keys, b_hh_idx, b_in_xyz, b_in_rgb;
+	ScanCtl* h_ctl = nullptr;  // pinned
+	u32 hh_mask = 0;
+	uint64_t counts[8] = {0};
+};
+
 struct ufomap_map {
 	int device = 0;
-	hipStream_t stream = nullptr;
-	hipEvent_t done_ev = nullptr;
+	hipStream_t stream = nullptr;   // map stream: everything that touches the node table
+	hipStream_t sstream = nullptr;  // scan stream: classify .. extract of the NEXT scan overlaps the previous map phase
+	hipStream_t cs = nullptr;       // stream the helpers currently launch on
+	hipEvent_t done_ev = nullptr, scan_ev = nullptr;
+	HandOver alt;                   // the other set of hand-over buffers
+	int async_status = UFOMAP_OK;   // first error of an integration that was joined by a later call
 	MapGeom g{};
 	// node table
 	Table t{};
@@ -176,13 +189,13 @@ struct ProfScope {
 			pe.a = getEvent(m);
 			pe.b = getEvent(m);
 			pe.stat = statIndex(m, name);
-			(void)hipEventRecord(pe.a, m->stream);
+			(void)hipEventRecord(pe.a, m->cs);
 		}
 	}
 	~ProfScope()
 	{
 		if (on) {
-			(void)hipEventRecord(pe.b, m->stream);
+			(void)hipEventRecord(pe.b, m->cs);
 			m->pend_ev.push_back(pe);
 		}
 	}
@@ -190,7 +203,12 @@ struct ProfScope {
 
 void drainEvents(ufomap_map* m)
 {
+	std::vector<PendingEvent> later;
 	for (PendingEvent& pe : m->pend_ev) {
+		if (hipEventQuery(pe.b) != hipSuccess) {
+			later.push_back(pe);  // e.g. the next scan's kernels on the scan stream: not finished yet
+			continue;
+		}
 		float ms = 0;
 		if (hipEventElapsedTime(&ms, pe.a, pe.b) == hipSuccess) {
 			m->stats[pe.stat].launches += 1;
@@ -199,7 +217,7 @@ void drainEvents(ufomap_map* m)
 		m->ev_pool.push_back(pe.a);
 		m->ev_pool.push_back(pe.b);
 	}
-	m->pend_ev.clear();
+	m->pend_ev.swap(later);
 }
 
 inline dim3 gridFor(u64 n, u32 block = 256, u32 maxBlocks = 4096)
@@ -251,16 +269,16 @@ int growTable(ufomap_map* m, u32 new_cap)
 	int rc = allocTable(m, new_cap, &nt, &nb);
 	if (rc) return rc;
 	u32* d_fail = m->b_ctl.as<u32>() + (sizeof(ScanCtl) + 3) / 4;  // spare word after the control block
-	HIP_TRY(hipMemsetAsync(d_fail, 0, 4, m->stream));
+	HIP_TRY(hipMemsetAsync(d_fail, 0, 4, m->cs));
 	{
 		ProfScope ps(m, "k_rehash_copy");
-		hipLaunchKernelGGL(k_rehash_copy, gridFor((u64)m->t.mask + 1), dim3(256), 0, m->stream, m->t, nt, d_fail);
+		hipLaunchKernelGGL(k_rehash_copy, gridFor((u64)m->t.mask + 1), dim3(256), 0, m->cs, m->t, nt, d_fail);
 	}
 	{
 		ProfScope ps(m, "k_rehash_parents");
-		hipLaunchKernelGGL(k_rehash_parents, gridFor((u64)new_cap), dim3(256), 0, m->stream, nt);
+		hipLaunchKernelGGL(k_rehash_parents, gridFor((u64)new_cap), dim3(256), 0, m->cs, nt);
 	}
-	HIP_TRY(hipStreamSynchronize(m->stream));
+	HIP_TRY(hipStreamSynchronize(m->cs));
 	m->tb.release();
 	m->tb = nb;
 	m->t = nt;
@@ -309,11 +327,24 @@ u64 blockBound(const ufomap_map* m, u64 n, const i32 nb[3], u32 level)
 	return total + 8;
 }
 
+void swapSets(ufomap_map* m)
+{
+	std::swap(m->b_ctl, m->alt.b_ctl);
+	std::swap(m->b_entries, m->alt.b_entries);
+	std::swap(m->b_hh_keys, m->alt.b_hh_keys);
+	std::swap(m->b_hh_idx, m->alt.b_hh_idx);
+	std::swap(m->b_in_xyz, m->alt.b_in_xyz);
+	std::swap(m->b_in_rgb, m->alt.b_in_rgb);
+	std::swap(m->h_ctl, m->alt.h_ctl);
+	std::swap(m->hh_mask, m->alt.hh_mask);
+	for (int k = 0; k < 8; ++k) std::swap(m->counts[k], m->alt.counts[k]);
+}
+
 int readCtl(ufomap_map* m)
 {
-	HIP_TRY(hipMemcpyAsync(m->h_ctl, m->b_ctl.p, sizeof(ScanCtl), hipMemcpyDeviceToHost, m->stream));
-	HIP_TRY(hipMemcpyAsync(m->h_root, m->b_root.p, sizeof(MapRoot), hipMemcpyDeviceToHost, m->stream));
-	HIP_TRY(hipStreamSynchronize(m->stream));
+	HIP_TRY(hipMemcpyAsync(m->h_ctl, m->b_ctl.p, sizeof(ScanCtl), hipMemcpyDeviceToHost, m->cs));
+	HIP_TRY(hipMemcpyAsync(m->h_root, m->b_root.p, sizeof(MapRoot), hipMemcpyDeviceToHost, m->cs));
+	HIP_TRY(hipStreamSynchronize(m->cs));
 	m->used_est = m->h_root->used;
 	return UFOMAP_OK;
 }
@@ -327,6 +358,7 @@ int ctlError(ufomap_map* m)
 		            "a clipped ray left the map cube (end point outside after moveLineInside); the reference walks ~2^31 "
 		            "cells on this input. Map unchanged.");
 	if (e & ERR_TABLE_FULL) return fail(UFOMAP_ERR_CAPACITY, "node table full (internal bound violated)");
+	if (e & ERR_ENTRIES) return fail(UFOMAP_ERR_CAPACITY, "update list larger than its buffer (internal bound violated); map unchanged");
 	if (e & ERR_GRID_OOB) return fail(UFOMAP_ERR_CAPACITY, "a ray cell fell outside the scan grid (internal bound violated)");
 	return fail(UFOMAP_ERR_CAPACITY, "hit hash full (internal bound violated)");
 }
@@ -375,23 +407,23 @@ int applyEntries(ufomap_map* m, const Entry* d_entries, u32 cap, u32 which, u32 
 	ScanCtl* ctl = m->b_ctl.as<ScanCtl>();
 	const u32* d_n = &ctl->n_entries[which];
 	ScanCtl::PhaseCtr* pc = &ctl->ph[which];
-	if (zero_ctr) HIP_TRY(hipMemsetAsync(pc, 0, sizeof(ScanCtl::PhaseCtr), m->stream));
+	if (zero_ctr) HIP_TRY(hipMemsetAsync(pc, 0, sizeof(ScanCtl::PhaseCtr), m->cs));
 	HitHash hh{m->b_hh_keys.as<u64>(), m->b_hh_idx.as<u32>(), m->hh_mask};
 	u32* wl[2] = {m->b_wl0.as<u32>(), m->b_wl1.as<u32>()};
 	dim3 ge = gridFor(cap);
 	{
 		ProfScope ps(m, "k_ensure");
-		hipLaunchKernelGGL(k_ensure, ge, dim3(256), 0, m->stream, m->t, m->g, d_entries, d_n, cap_h, cap_m, m->scan_id, m->b_ent_slot.as<u32>(),
+		hipLaunchKernelGGL(k_ensure, ge, dim3(256), 0, m->cs, m->t, m->g, d_entries, d_n, cap_h, cap_m, m->scan_id, m->b_ent_slot.as<u32>(),
 		                   m->b_newlist.as<u32>(), (u32)std::min<u64>(newcap, 0xFFFFFFFFull), pc, ctl);
 	}
 	{
 		ProfScope ps(m, "k_init_new");
-		hipLaunchKernelGGL(k_init_new, gridFor(std::min<u64>(newcap, cap)), dim3(256), 0, m->stream, m->t, m->g, m->b_newlist.as<u32>(),
+		hipLaunchKernelGGL(k_init_new, gridFor(std::min<u64>(newcap, cap)), dim3(256), 0, m->cs, m->t, m->g, m->b_newlist.as<u32>(),
 		                   (u32)std::min<u64>(newcap, 0xFFFFFFFFull), m->scan_id, pc, ctl);
 	}
 	if (1 == level) {
 		ProfScope ps(m, "k_apply_leaf");
-		hipLaunchKernelGGL(k_apply_leaf, ge, dim3(256), 0, m->stream, m->t, m->g, d_entries, d_n, m->b_ent_slot.as<u32>(), upd,
+		hipLaunchKernelGGL(k_apply_leaf, ge, dim3(256), 0, m->cs, m->t, m->g, d_entries, d_n, m->b_ent_slot.as<u32>(), upd,
 		                   (u32)(which == 0 ? 1 : 0), m->scan_id, hh, d_rgb, wl[0], pc, ctl);
 	} else {
 		// coarse misses: level-synchronous walk of the subtrees below the masked children (map_kernels.h S3c)
@@ -400,28 +432,28 @@ int applyEntries(ufomap_map* m, const Entry* d_entries, u32 cap, u32 which, u32 
 		const u32 dcap = (u32)std::min<u64>(dcap64, 0xFFFFFFF0ull);
 		HIP_TRY(m->b_crec.reserve((size_t)cap * sizeof(CoarseRec)));
 		HIP_TRY(m->b_dlist.reserve((size_t)dcap * 4));
-		if (zero_ctr) HIP_TRY(hipMemsetAsync(&ctl->dl_total, 0, 4 * 26, m->stream));  // dl_total + dl_start[25]
+		if (zero_ctr) HIP_TRY(hipMemsetAsync(&ctl->dl_total, 0, 4 * 26, m->cs));  // dl_total + dl_start[25]
 		CoarseRec* rec = m->b_crec.as<CoarseRec>();
 		u32* dl = m->b_dlist.as<u32>();
 		dim3 gd = gridFor(std::max<u64>(dcap, 256), 256, 4096);
 		{
 			ProfScope ps(m, "k_coarse_begin");
-			hipLaunchKernelGGL(k_coarse_begin, ge, dim3(256), 0, m->stream, m->t, m->g, d_entries, d_n, m->b_ent_slot.as<u32>(), upd, rec,
+			hipLaunchKernelGGL(k_coarse_begin, ge, dim3(256), 0, m->cs, m->t, m->g, d_entries, d_n, m->b_ent_slot.as<u32>(), upd, rec,
 			                   dl, dcap, ctl);
-			hipLaunchKernelGGL(k_coarse_mark, dim3(1), dim3(1), 0, m->stream, ctl, level - 1);
+			hipLaunchKernelGGL(k_coarse_mark, dim3(1), dim3(1), 0, m->cs, ctl, level - 1);
 		}
 		for (u32 l = level - 1; l >= 1; --l) {
 			ProfScope ps(m, "k_coarse_down");
-			hipLaunchKernelGGL(k_coarse_down, gd, dim3(256), 0, m->stream, m->t, m->g, l, upd, dl, dcap, ctl);
-			if (l > 1) hipLaunchKernelGGL(k_coarse_mark, dim3(1), dim3(1), 0, m->stream, ctl, l - 1);
+			hipLaunchKernelGGL(k_coarse_down, gd, dim3(256), 0, m->cs, m->t, m->g, l, upd, dl, dcap, ctl);
+			if (l > 1) hipLaunchKernelGGL(k_coarse_mark, dim3(1), dim3(1), 0, m->cs, ctl, l - 1);
 		}
 		for (u32 l = 1; l + 1 <= level; ++l) {
 			ProfScope ps(m, "k_coarse_up");
-			hipLaunchKernelGGL(k_coarse_up, gd, dim3(256), 0, m->stream, m->t, m->g, l, dl, dcap, ctl);
+			hipLaunchKernelGGL(k_coarse_up, gd, dim3(256), 0, m->cs, m->t, m->g, l, dl, dcap, ctl);
 		}
 		{
 			ProfScope ps(m, "k_coarse_end");
-			hipLaunchKernelGGL(k_coarse_end, ge, dim3(256), 0, m->stream, m->t, m->g, d_entries, d_n, m->b_ent_slot.as<u32>(), rec,
+			hipLaunchKernelGGL(k_coarse_end, ge, dim3(256), 0, m->cs, m->t, m->g, d_entries, d_n, m->b_ent_slot.as<u32>(), rec,
 			                   m->scan_id, wl[(level + 1) & 1], pc, ctl);
 		}
 	}
@@ -431,12 +463,12 @@ int applyEntries(ufomap_map* m, const Entry* d_entries, u32 cap, u32 which, u32 
 		u64 bound = std::min<u64>(cap, levelBound(nb, l - level));
 		if (bound <= 2048) break;
 		ProfScope ps(m, "k_propagate");
-		hipLaunchKernelGGL(k_propagate, gridFor(bound, 256, 1024), dim3(256), 0, m->stream, m->t, m->g, wl[l & 1], wl[(l + 1) & 1], l,
+		hipLaunchKernelGGL(k_propagate, gridFor(bound, 256, 1024), dim3(256), 0, m->cs, m->t, m->g, wl[l & 1], wl[(l + 1) & 1], l,
 		                   m->scan_id, pc, ctl);
 	}
 	if (l <= m->g.L) {
 		ProfScope ps(m, "k_propagate_tail");
-		hipLaunchKernelGGL(k_propagate_tail, dim3(1), dim3(1024), 0, m->stream, m->t, m->g, wl[0], wl[1], l, m->scan_id, pc, ctl, which * 32u);
+		hipLaunchKernelGGL(k_propagate_tail, dim3(1), dim3(1024), 0, m->cs, m->t, m->g, wl[0], wl[1], l, m->scan_id, pc, ctl, which * 32u);
 	}
 	HIP_TRY(hipGetLastError());
 	return UFOMAP_OK;
@@ -460,11 +492,11 @@ int sizeTable(ufomap_map* m, const Entry* ent_h, u64 capH, const i32 nbH[3], con
 	if (ent_h || ent_m) {
 		ScanCtl* ctl = m->b_ctl.as<ScanCtl>();
 		u32* d_cnt = reinterpret_cast<u32*>(&ctl->dbg[60]);  // two spare words of the control block
-		HIP_TRY(hipMemsetAsync(d_cnt, 0, 8, m->stream));
+		HIP_TRY(hipMemsetAsync(d_cnt, 0, 8, m->cs));
 		if (capH)
-			hipLaunchKernelGGL(k_count_missing, gridFor(capH), dim3(256), 0, m->stream, m->t, ent_h, &ctl->n_entries[0], (u32)capH, d_cnt);
+			hipLaunchKernelGGL(k_count_missing, gridFor(capH), dim3(256), 0, m->cs, m->t, ent_h, &ctl->n_entries[0], (u32)capH, d_cnt);
 		if (capM)
-			hipLaunchKernelGGL(k_count_missing, gridFor(capM), dim3(256), 0, m->stream, m->t, ent_m, &ctl->n_entries[1], (u32)capM, d_cnt + 1);
+			hipLaunchKernelGGL(k_count_missing, gridFor(capM), dim3(256), 0, m->cs, m->t, ent_m, &ctl->n_entries[1], (u32)capM, d_cnt + 1);
 		int rc = readCtl(m);
 		if (rc) return rc;
 		u32 cnt[2];
@@ -486,53 +518,43 @@ int extractLists(ufomap_map* m, u64 capH, u64 capM, bool zero_counts)
 	HIP_TRY(m->b_entries.reserve(((size_t)capH + capM + 1) * sizeof(Entry)));
 	Entry* ent_h = m->b_entries.as<Entry>();
 	Entry* ent_m = ent_h + capH;
-	if (zero_counts) HIP_TRY(hipMemsetAsync(&ctl->n_entries[0], 0, 8, m->stream));  // otherwise zero from the control-block upload
+	if (zero_counts) HIP_TRY(hipMemsetAsync(&ctl->n_entries[0], 0, 8, m->cs));  // otherwise zero from the control-block upload
 	if (capH) {
 		ProfScope ps(m, "k_extract_hits");
 		HitBlocks hb{m->b_hb_keys.as<u64>(), m->b_hb_mask.as<u32>(), m->b_hb_time.as<u32>(), m->hb_cap_mask};
-		hipLaunchKernelGGL(k_extract_hits, dim3((u32)(((u64)m->hb_cap_mask + 1 + 2047) / 2048)), dim3(256), 0, m->stream, m->g, hb, ent_h,
+		hipLaunchKernelGGL(k_extract_hits, dim3((u32)(((u64)m->hb_cap_mask + 1 + 2047) / 2048)), dim3(256), 0, m->cs, m->g, hb, ent_h,
 		                   (u32)capH, ctl);
 	}
 	if (capM) {
 		ProfScope ps(m, "k_extract");
-		hipLaunchKernelGGL(k_extract, gridFor(m->gridM.bytes >> 2, 256, 2048), dim3(256), 0, m->stream, m->g, m->gridM,
+		hipLaunchKernelGGL(k_extract, gridFor(m->gridM.bytes >> 2, 256, 2048), dim3(256), 0, m->cs, m->g, m->gridM,
 		                   m->b_gridM.as<u32>(), 1u, ent_m, (u32)capM, ctl);
 	}
 	return UFOMAP_OK;
 }
 
-// The map half of an integration: update lists from the two grids, then hits phase, then misses phase.
-int mapPhase(ufomap_map* m, unsigned depth, const uint8_t* d_rgb, u64 capH, u64 capM, bool retry)
+// The map half of an integration (map stream): size the table, hits phase, then misses phase (OMB:1351-1365).
+// The two update lists are already in b_entries (hit entries first); capH/capM are their capacities
+// (true upper bounds or exact counts, so the device-side counts always fit).
+int mapPhase(ufomap_map* m, unsigned depth, const uint8_t* d_rgb, u64 capH, u64 capM)
 {
 	const float miss = (float)(m->g.miss_log / double((2.0 * depth) + 1));  // OMB:311
-	if (!m->haveH) capH = 0;
-	if (!m->haveM) capM = 0;
-	int rc = extractLists(m, capH, capM, retry);
-	if (rc) return rc;
 	Entry* ent_h = m->b_entries.as<Entry>();
 	Entry* ent_m = ent_h + capH;
-	rc = sizeTable(m, ent_h, capH, m->gridH.nb, ent_m, capM, m->gridM.nb, depth);
+	int rc = sizeTable(m, ent_h, capH, m->gridH.nb, ent_m, capM, m->gridM.nb, depth);
 	if (rc) return rc;
-	rc = applyEntries(m, ent_h, (u32)capH, 0, 1, m->gridH.nb, m->g.hit, d_rgb, retry, (u32)capH, (u32)capM);
+	rc = applyEntries(m, ent_h, (u32)capH, 0, 1, m->gridH.nb, m->g.hit, d_rgb, false, (u32)capH, (u32)capM);
 	if (rc) return rc;
-	return applyEntries(m, ent_m, (u32)capM, 1, (u32)depth + 1, m->gridM.nb, miss, nullptr, retry, (u32)capH, (u32)capM);
+	return applyEntries(m, ent_m, (u32)capM, 1, (u32)depth + 1, m->gridM.nb, miss, nullptr, false, (u32)capH, (u32)capM);
 }
 
 int finishPending(ufomap_map* m)
 {
 	if (!m->pending) return UFOMAP_OK;
 	m->pending = false;
+	m->cs = m->stream;
 	int rc = readCtl(m);
 	if (rc) return rc;
-	if (m->h_ctl->err == ERR_ENTRIES) {
-		// the guessed update-list capacity was too small; nothing was applied. Redo with the exact sizes.
-		u64 capH = m->h_ctl->n_entries[0], capM = m->h_ctl->n_entries[1];
-		HIP_TRY(hipMemsetAsync(&m->b_ctl.as<ScanCtl>()->err, 0, 4, m->stream));
-		rc = mapPhase(m, m->last_depth, m->last_rgb, capH, capM, true);
-		if (rc) return rc;
-		rc = readCtl(m);
-		if (rc) return rc;
-	}
 	drainEvents(m);
 	rc = ctlError(m);
 	if (rc) return rc;
@@ -557,13 +579,6 @@ int scanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, const 
 {
 	if (!m) return fail(UFOMAP_ERR_INVALID, "null map");
 	HIP_TRY(hipSetDevice(m->device));
-	// join the previous integration first (occupancy_map_base.h:315)
-	int prc = UFOMAP_OK;
-	if (m->pending) {
-		HIP_TRY(hipStreamSynchronize(m->stream));
-		prc = finishPending(m);
-	}
-	(void)prc;
 	if (early_stopping != 0)
 		return fail(UFOMAP_ERR_UNSUPPORTED, "early_stopping > 0 depends on ray order (occupancy_map_base.h:1289-1298); not supported");
 	if (depth >= m->g.L) return fail(UFOMAP_ERR_INVALID, "depth must be < depth_levels");
@@ -591,8 +606,8 @@ int scanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, const 
 	u32 hcap = nextPow2(std::max<u64>(1024, (u64)n * 2 + (depth ? (u64)n * 2 : 0)));  // load <= 0.5 (hits, + ray cells when depth > 0)
 	HIP_TRY(m->b_hh_keys.reserve((size_t)hcap * 8));
 	HIP_TRY(m->b_hh_idx.reserve((size_t)hcap * 4));
-	HIP_TRY(hipMemsetAsync(m->b_hh_keys.p, 0xFF, (size_t)hcap * 8, m->stream));
-	HIP_TRY(hipMemsetAsync(m->b_hh_idx.p, 0xFF, (size_t)hcap * 4, m->stream));
+	HIP_TRY(hipMemsetAsync(m->b_hh_keys.p, 0xFF, (size_t)hcap * 8, m->cs));
+	HIP_TRY(hipMemsetAsync(m->b_hh_idx.p, 0xFF, (size_t)hcap * 4, m->cs));
 	HitHash hh{m->b_hh_keys.as<u64>(), m->b_hh_idx.as<u32>(), hcap - 1};
 	m->hh_mask = hcap - 1;
 	// control block
@@ -606,39 +621,39 @@ int scanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, const 
 	}
 	*m->h_ctl = init;
 	ScanCtl* ctl = m->b_ctl.as<ScanCtl>();
-	HIP_TRY(hipMemcpyAsync(ctl, m->h_ctl, sizeof(ScanCtl), hipMemcpyHostToDevice, m->stream));
+	HIP_TRY(hipMemcpyAsync(ctl, m->h_ctl, sizeof(ScanCtl), hipMemcpyHostToDevice, m->cs));
 	dim3 gp((N + 255) / 256);
 	HIP_TRY(m->b_part0.reserve((size_t)gp.x * sizeof(BoxPartial)));
 	HIP_TRY(m->b_part1.reserve((size_t)gp.x * sizeof(BoxPartial)));
 	{
 		ProfScope ps(m, "k_classify");
 		if (discrete)
-			hipLaunchKernelGGL(k_classify<true>, gp, dim3(256), 0, m->stream, m->g, sensor, d_xyz, N, max_range, (u32)depth,
+			hipLaunchKernelGGL(k_classify<true>, gp, dim3(256), 0, m->cs, m->g, sensor, d_xyz, N, max_range, (u32)depth,
 			                   (u32)(d_rgb ? 1 : 0), hh, m->b_pt_end.as<D3>(), m->b_pt_flag.as<u8>(), m->b_pt_slot.as<u32>(),
 			                   m->b_part0.as<BoxPartial>(), ctl);
 		else
-			hipLaunchKernelGGL(k_classify<false>, gp, dim3(256), 0, m->stream, m->g, sensor, d_xyz, N, max_range, (u32)depth, 0u, hh,
+			hipLaunchKernelGGL(k_classify<false>, gp, dim3(256), 0, m->cs, m->g, sensor, d_xyz, N, max_range, (u32)depth, 0u, hh,
 			                   m->b_pt_end.as<D3>(), m->b_pt_flag.as<u8>(), m->b_pt_slot.as<u32>(), m->b_part0.as<BoxPartial>(), ctl);
 	}
 	{
 		ProfScope ps(m, "k_select");
 		if (discrete)
-			hipLaunchKernelGGL(k_select<true>, gp, dim3(256), 0, m->stream, m->g, sensor, N, (u32)depth, hh, m->b_pt_end.as<D3>(),
+			hipLaunchKernelGGL(k_select<true>, gp, dim3(256), 0, m->cs, m->g, sensor, N, (u32)depth, hh, m->b_pt_end.as<D3>(),
 			                   m->b_pt_flag.as<u8>(), m->b_pt_slot.as<u32>(), m->b_ray_end.as<D3>(), m->b_hit_code.as<u64>(),
 			                   m->b_hit_pt.as<u32>(), m->b_part1.as<BoxPartial>(), ctl);
 		else
-			hipLaunchKernelGGL(k_select<false>, gp, dim3(256), 0, m->stream, m->g, sensor, N, (u32)depth, hh, m->b_pt_end.as<D3>(),
+			hipLaunchKernelGGL(k_select<false>, gp, dim3(256), 0, m->cs, m->g, sensor, N, (u32)depth, hh, m->b_pt_end.as<D3>(),
 			                   m->b_pt_flag.as<u8>(), m->b_pt_slot.as<u32>(), m->b_ray_end.as<D3>(), m->b_hit_code.as<u64>(),
 			                   m->b_hit_pt.as<u32>(), m->b_part1.as<BoxPartial>(), ctl);
 	}
 	{
 		ProfScope ps(m, "k_reduce_boxes");
-		hipLaunchKernelGGL(k_reduce_boxes, dim3(1), dim3(256), 0, m->stream, m->b_part1.as<BoxPartial>(), gp.x, (u32)(discrete ? 0 : 1),
+		hipLaunchKernelGGL(k_reduce_boxes, dim3(1), dim3(256), 0, m->cs, m->b_part1.as<BoxPartial>(), gp.x, (u32)(discrete ? 0 : 1),
 		                   m->b_part0.as<BoxPartial>(), ctl);
 	}
 	HIP_TRY(hipGetLastError());
-	HIP_TRY(hipMemcpyAsync(m->h_ctl, m->b_ctl.p, sizeof(ScanCtl), hipMemcpyDeviceToHost, m->stream));
-	HIP_TRY(hipStreamSynchronize(m->stream));
+	HIP_TRY(hipMemcpyAsync(m->h_ctl, m->b_ctl.p, sizeof(ScanCtl), hipMemcpyDeviceToHost, m->cs));
+	HIP_TRY(hipStreamSynchronize(m->cs));
 	int rc = ctlError(m);
 	if (rc) return rc;
 	const u32 n_rays = m->h_ctl->n_rays, n_hits = m->h_ctl->n_hits;
@@ -672,12 +687,12 @@ int scanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, const 
 		HIP_TRY(m->b_hb_keys.reserve((size_t)hbcap * 8));
 		HIP_TRY(m->b_hb_mask.reserve((size_t)hbcap * 4));
 		HIP_TRY(m->b_hb_time.reserve((size_t)hbcap * 4));
-		HIP_TRY(hipMemsetAsync(m->b_hb_keys.p, 0xFF, (size_t)hbcap * 8, m->stream));
-		HIP_TRY(hipMemsetAsync(m->b_hb_mask.p, 0, (size_t)hbcap * 4, m->stream));
-		HIP_TRY(hipMemsetAsync(m->b_hb_time.p, 0, (size_t)hbcap * 4, m->stream));
+		HIP_TRY(hipMemsetAsync(m->b_hb_keys.p, 0xFF, (size_t)hbcap * 8, m->cs));
+		HIP_TRY(hipMemsetAsync(m->b_hb_mask.p, 0, (size_t)hbcap * 4, m->cs));
+		HIP_TRY(hipMemsetAsync(m->b_hb_time.p, 0, (size_t)hbcap * 4, m->cs));
 		ProfScope ps(m, "k_hitmark");
 		HitBlocks hb{m->b_hb_keys.as<u64>(), m->b_hb_mask.as<u32>(), m->b_hb_time.as<u32>(), m->hb_cap_mask};
-		hipLaunchKernelGGL(k_hitmark, gridFor(n_hits), dim3(256), 0, m->stream, hb, m->b_hit_code.as<u64>(), m->b_hit_pt.as<u32>(), ctl, ctl);
+		hipLaunchKernelGGL(k_hitmark, gridFor(n_hits), dim3(256), 0, m->cs, hb, m->b_hit_code.as<u64>(), m->b_hit_pt.as<u32>(), ctl, ctl);
 	}
 	if (m->haveM) {
 		HIP_TRY(m->b_gridM.reserve(m->gridM.bytes));
@@ -704,21 +719,21 @@ int scanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, const 
 			HIP_TRY(m->b_slabs.reserve((size_t)gr.x * m->gridM.bytes));
 			dda_out = m->b_slabs.as<u32>();
 		} else {
-			HIP_TRY(hipMemsetAsync(m->b_gridM.p, 0, m->gridM.bytes, m->stream));
+			HIP_TRY(hipMemsetAsync(m->b_gridM.p, 0, m->gridM.bytes, m->cs));
 		}
 		if (seg) {
 			HIP_TRY(m->b_rays.reserve((size_t)n_rays * sizeof(RayState)));
 			ProfScope ps(m, "k_ray_setup");
-			hipLaunchKernelGGL(k_ray_setup, dim3((n_rays + 255) / 256), dim3(256), 0, m->stream, m->g, sensor, (u32)depth, m->gridM,
+			hipLaunchKernelGGL(k_ray_setup, dim3((n_rays + 255) / 256), dim3(256), 0, m->cs, m->g, sensor, (u32)depth, m->gridM,
 			                   m->b_ray_end.as<D3>(), m->b_rays.as<RayState>(), ctl);
 		}
 		{
 		ProfScope ps(m, "k_dda");
 #define UFO_LAUNCH_DDA(SIMPLE, MODE)                                                                                         \
-	hipLaunchKernelGGL((k_dda<SIMPLE, MODE>), gr, dim3(blk), lds, m->stream, m->g, sensor, (u32)depth, m->gridM, \
+	hipLaunchKernelGGL((k_dda<SIMPLE, MODE>), gr, dim3(blk), lds, m->cs, m->g, sensor, (u32)depth, m->gridM, \
 	                   dda_out, m->b_ray_end.as<D3>(), ctl, ctl)
 #define UFO_LAUNCH_SEG(MODE)                                                                                    \
-	hipLaunchKernelGGL((k_dda_seg<MODE>), gr, dim3(blk), lds, m->stream, m->g, (u32)depth, m->gridM, dda_out, \
+	hipLaunchKernelGGL((k_dda_seg<MODE>), gr, dim3(blk), lds, m->cs, m->g, (u32)depth, m->gridM, dda_out, \
 	                   m->b_rays.as<RayState>(), seg_shift, ctl, ctl)
 		if (seg) {
 			if (mode == DDA_LDSGRID) UFO_LAUNCH_SEG(DDA_LDSGRID);
@@ -738,7 +753,7 @@ int scanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, const 
 		if (mode == DDA_LDSGRID) {
 			ProfScope ps(m, "k_merge_slabs");
 			const u32 n4 = (u32)(m->gridM.bytes >> 4);
-			hipLaunchKernelGGL(k_merge_slabs, dim3(std::min<u32>((n4 + 63) / 64, 1024)), dim3(1024), 0, m->stream, m->b_slabs.as<uint4>(), gr.x,
+			hipLaunchKernelGGL(k_merge_slabs, dim3(std::min<u32>((n4 + 63) / 64, 1024)), dim3(1024), 0, m->cs, m->b_slabs.as<uint4>(), gr.x,
 			                   n4, m->b_gridM.as<uint4>());
 		}
 	}
@@ -750,30 +765,81 @@ int scanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, const 
 	return UFOMAP_OK;
 }
 
-int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const uint8_t* d_rgb, size_t n, double max_range,
-             unsigned depth, int discrete, int simple, unsigned early_stopping, int async)
+// Size the update-list buffers and extract both lists on the scan stream. The capacities are true upper
+// bounds (hit blocks <= unique hits; miss blocks <= blocks of grid M) or, for huge sparse grids, the exact
+// count from a counting pass -- the device-side counts always fit.
+int extractPhase(ufomap_map* m, u32 n_hits, u32 n_rays, u64* capH_out, u64* capM_out)
 {
+	ScanCtl* ctl = m->b_ctl.as<ScanCtl>();
+	u64 capH = m->haveH ? (u64)n_hits : 0;
+	u64 capM = m->haveM ? m->gridM.bytes : 0;
+	const u64 guess = m->opt_entry_guess ? m->opt_entry_guess : std::max<u64>(1u << 20, (u64)n_rays * 64);
+	if (capM > guess) {
+		// counting pass (cap = 0 writes nothing), then the exact size
+		ProfScope ps(m, "k_extract_count");
+		hipLaunchKernelGGL(k_extract, gridFor(m->gridM.bytes >> 2, 256, 2048), dim3(256), 0, m->cs, m->g, m->gridM, m->b_gridM.as<u32>(), 1u,
+		                   (Entry*)nullptr, 0u, ctl);
+		HIP_TRY(hipMemcpyAsync(m->h_ctl, m->b_ctl.p, sizeof(ScanCtl), hipMemcpyDeviceToHost, m->cs));
+		HIP_TRY(hipStreamSynchronize(m->cs));
+		capM = m->h_ctl->n_entries[1];
+		HIP_TRY(hipMemsetAsync(&ctl->n_entries[1], 0, 4, m->cs));
+	}
+	int rc = extractLists(m, capH, capM, false);
+	if (rc) return rc;
+	*capH_out = capH;
+	*capM_out = capM;
+	return UFOMAP_OK;
+}
+
+// join the integration whose map phase was enqueued by the previous call (its hand-over set is `alt` now)
+int joinPrevious(ufomap_map* m)
+{
+	if (!m->pending) return UFOMAP_OK;
+	HIP_TRY(hipStreamSynchronize(m->stream));
+	swapSets(m);
+	int rc = finishPending(m);
+	swapSets(m);
+	if (rc && UFOMAP_OK == m->async_status) m->async_status = rc;
+	return rc;
+}
+
+int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const uint8_t* d_rgb, size_t n, double max_range,
+             unsigned depth, int discrete, int simple, unsigned early_stopping, int async, bool swapped)
+{
+	if (!m) return fail(UFOMAP_ERR_INVALID, "null map");
+	HIP_TRY(hipSetDevice(m->device));
+	// The scan half never reads the map (freeSpace is const, OMB:1230-1232): it runs on the scan stream
+	// while the map half of the previous integration may still be updating the tree on the map stream --
+	// the reference overlaps its head loop with the previous integration the same way (the join sits
+	// after the head loop, OMB:315). Hand-over buffers are double-buffered and swapped here.
+	if (!swapped) swapSets(m);
+	m->cs = m->sstream;
 	u32 n_hits = 0, n_rays = 0;
 	int rc = scanPhase(m, origin, d_xyz, d_rgb, n, max_range, depth, discrete, simple, early_stopping, &n_hits, &n_rays);
-	if (rc || 0 == n) return rc;
-	// ---- map phases: all hits, then all misses (OMB:1351-1365). No host round trip here: the update-list
-	// buffers are sized from upper bounds (hit blocks <= unique hits; miss blocks <= blocks of the grid, capped
-	// by a guess for huge grids -- ERR_ENTRIES makes the host retry with the exact size). A runaway ray sets
-	// ctl->err in k_dda, and every map kernel returns early on it: the map stays untouched.
+	u64 capH = 0, capM = 0;
+	if (!rc && n) rc = extractPhase(m, n_hits, n_rays, &capH, &capM);
+	if (!rc && n) rc = (hipEventRecord(m->scan_ev, m->sstream) == hipSuccess) ? UFOMAP_OK : fail(UFOMAP_ERR_DEVICE, "hipEventRecord");
+	// join the previous integration (occupancy_map_base.h:315): its status is reported by wait()/this call
+	int prc = joinPrevious(m);
+	if (rc || 0 == n) {
+		if (rc) (void)hipStreamSynchronize(m->sstream);
+		return rc ? rc : prc;
+	}
+	// ---- map half on the map stream, after the scan half of THIS scan ----
+	m->cs = m->stream;
+	HIP_TRY(hipStreamWaitEvent(m->stream, m->scan_ev, 0));
 	m->last_rgb = d_rgb;
-	u64 capH = m->haveH ? (u64)n_hits : 0;
-	u64 capM = m->haveM ? std::min<u64>(m->gridM.bytes, std::max<u64>(1u << 20, (u64)n_rays * 64)) : 0;
-	if (m->opt_entry_guess && capM > m->opt_entry_guess) capM = m->opt_entry_guess;  // tests: force the ERR_ENTRIES retry
-	rc = mapPhase(m, depth, d_rgb, capH, capM, false);
+	rc = mapPhase(m, depth, d_rgb, capH, capM);
 	if (rc) return rc;
 	HIP_TRY(hipGetLastError());
 	m->pending = true;
 	if (!async) {
 		HIP_TRY(hipStreamSynchronize(m->stream));
-		return finishPending(m);
+		rc = finishPending(m);
+		return rc ? rc : prc;
 	}
 	HIP_TRY(hipEventRecord(m->done_ev, m->stream));
-	return UFOMAP_OK;
+	return prc;
 }
 }  // namespace
 
@@ -829,8 +895,12 @@ ufomap_map* ufomap_map_create(double resolution, unsigned depth_levels, int auto
 	g.pruning = automatic_pruning ? 1 : 0;
 	setSensorModel(g, occupied_thres, free_thres, prob_hit, prob_miss, clamping_thres_min, clamping_thres_max);
 	bool ok = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) == hipSuccess &&
+	          hipStreamCreateWithFlags(&m->sstream, hipStreamNonBlocking) == hipSuccess &&
 	          hipEventCreateWithFlags(&m->done_ev, hipEventDisableTiming) == hipSuccess &&
+	          hipEventCreateWithFlags(&m->scan_ev, hipEventDisableTiming) == hipSuccess &&
 	          hipHostMalloc((void**)&m->h_ctl, sizeof(ScanCtl) + 64) == hipSuccess &&
+	          hipHostMalloc((void**)&m->alt.h_ctl, sizeof(ScanCtl) + 64) == hipSuccess &&
+	          m->alt.b_ctl.reserve(sizeof(ScanCtl) + 64) == hipSuccess &&
 	          hipHostMalloc((void**)&m->h_root, sizeof(MapRoot)) == hipSuccess &&
 	          m->b_ctl.reserve(sizeof(ScanCtl) + 64) == hipSuccess && m->b_root.reserve(sizeof(MapRoot)) == hipSuccess;
 	if (!ok) {
@@ -838,6 +908,9 @@ ufomap_map* ufomap_map_create(double resolution, unsigned depth_levels, int auto
 		ufomap_map_destroy(m);
 		return nullptr;
 	}
+	m->cs = m->stream;
+	memset(m->h_ctl, 0, sizeof(ScanCtl));
+	memset(m->alt.h_ctl, 0, sizeof(ScanCtl));
 	if (allocTable(m, 1u << 16, &m->t, &m->tb) ||
 	    resetRoot(m)) {
 		ufomap_map_destroy(m);
@@ -864,8 +937,14 @@ void ufomap_map_destroy(ufomap_map* m)
 {
 	if (!m) return;
 	(void)hipSetDevice(m->device);
+	if (m->sstream) (void)hipStreamSynchronize(m->sstream);
 	if (m->stream) (void)hipStreamSynchronize(m->stream);
 	m->tb.release();
+	DevBuf* abufs[] = {&m->alt.b_ctl, &m->alt.b_entries, &m->alt.b_hh_keys, &m->alt.b_hh_idx, &m->alt.b_in_xyz, &m->alt.b_in_rgb};
+	for (DevBuf* b : abufs) b->release();
+	if (m->alt.h_ctl) (void)hipHostFree(m->alt.h_ctl);
+	if (m->scan_ev) (void)hipEventDestroy(m->scan_ev);
+	if (m->sstream) (void)hipStreamDestroy(m->sstream);
 	DevBuf* bufs[] = {&m->b_root,
 	                  &m->b_ctl,     &m->b_pt_end,  &m->b_pt_flag,  &m->b_pt_slot, &m->b_ray_end, &m->b_hit_code, &m->b_hit_pt,
 	                  &m->b_hh_keys, &m->b_hh_idx,  &m->b_gridM,   &m->b_crec,    &m->b_dlist,   &m->b_rays,   &m->b_part0,   &m->b_part1,   &m->b_slabs,   &m->b_hb_keys, &m->b_hb_mask, &m->b_hb_time,   &m->b_entries, &m->b_ent_slot, &m->b_newlist,
@@ -887,8 +966,8 @@ int ufomap_map_clear(ufomap_map* m)
 {
 	if (!m) return fail(UFOMAP_ERR_INVALID, "null map");
 	HIP_TRY(hipSetDevice(m->device));
-	HIP_TRY(hipStreamSynchronize(m->stream));
-	(void)finishPending(m);
+	(void)ufomap_map_wait(m);
+	m->cs = m->stream;
 	u32 cap = m->t.mask + 1;
 	HIP_TRY(hipMemsetAsync(m->t.keys, 0, (size_t)cap * 8, m->stream));
 	HIP_TRY(hipMemsetAsync(m->t.flags, 0, (size_t)cap * 4, m->stream));
@@ -900,8 +979,8 @@ int ufomap_map_reserve(ufomap_map* m, size_t n_blocks)
 {
 	if (!m) return fail(UFOMAP_ERR_INVALID, "null map");
 	HIP_TRY(hipSetDevice(m->device));
-	HIP_TRY(hipStreamSynchronize(m->stream));
-	(void)finishPending(m);
+	(void)ufomap_map_wait(m);
+	m->cs = m->stream;
 	u64 want = (u64)n_blocks * 2;
 	if (want > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
 	if (want <= (u64)m->t.mask + 1) return UFOMAP_OK;
@@ -928,7 +1007,7 @@ int ufomap_map_insert_device(ufomap_map* m, const double sensor_origin[3], const
                              double max_range, unsigned depth, int discrete, int simple_ray_casting, unsigned early_stopping,
                              int async)
 {
-	return doInsert(m, sensor_origin, d_xyz, d_rgb, n, max_range, depth, discrete, simple_ray_casting, early_stopping, async);
+	return doInsert(m, sensor_origin, d_xyz, d_rgb, n, max_range, depth, discrete, simple_ray_casting, early_stopping, async, false);
 }
 
 int ufomap_map_insert(ufomap_map* m, const double sensor_origin[3], const double* xyz, const uint8_t* rgb, size_t n,
@@ -936,33 +1015,41 @@ int ufomap_map_insert(ufomap_map* m, const double sensor_origin[3], const double
 {
 	if (!m) return fail(UFOMAP_ERR_INVALID, "null map");
 	HIP_TRY(hipSetDevice(m->device));
-	if (m->pending) {
-		HIP_TRY(hipStreamSynchronize(m->stream));
-		(void)finishPending(m);
-	}
+	swapSets(m);  // the staging buffers belong to the hand-over set of THIS scan
 	const double* d_xyz = nullptr;
 	const uint8_t* d_rgb = nullptr;
 	if (n) {
 		// the caller's cloud is never referenced after this call returns (SURVEY.md 8b ownership)
-		HIP_TRY(m->b_in_xyz.reserve(n * 24));
-		HIP_TRY(hipMemcpyAsync(m->b_in_xyz.p, xyz, n * 24, hipMemcpyHostToDevice, m->stream));
+		hipError_t e = m->b_in_xyz.reserve(n * 24);
+		if (e == hipSuccess) e = hipMemcpyAsync(m->b_in_xyz.p, xyz, n * 24, hipMemcpyHostToDevice, m->sstream);
 		d_xyz = m->b_in_xyz.as<double>();
-		if (rgb) {
-			HIP_TRY(m->b_in_rgb.reserve(n * 3));
-			HIP_TRY(hipMemcpyAsync(m->b_in_rgb.p, rgb, n * 3, hipMemcpyHostToDevice, m->stream));
+		if (e == hipSuccess && rgb) {
+			e = m->b_in_rgb.reserve(n * 3);
+			if (e == hipSuccess) e = hipMemcpyAsync(m->b_in_rgb.p, rgb, n * 3, hipMemcpyHostToDevice, m->sstream);
 			d_rgb = m->b_in_rgb.as<uint8_t>();
 		}
-		HIP_TRY(hipStreamSynchronize(m->stream));  // pageable source: make the copy complete before returning
+		if (e == hipSuccess) e = hipStreamSynchronize(m->sstream);  // pageable source: copy complete before returning
+		if (e != hipSuccess) {
+			swapSets(m);
+			return fail(UFOMAP_ERR_DEVICE, hipGetErrorString(e));
+		}
 	}
-	return doInsert(m, sensor_origin, d_xyz, d_rgb, n, max_range, depth, discrete, simple_ray_casting, early_stopping, async);
+	return doInsert(m, sensor_origin, d_xyz, d_rgb, n, max_range, depth, discrete, simple_ray_casting, early_stopping, async, true);
 }
 
 int ufomap_map_wait(ufomap_map* m)
 {
 	if (!m) return fail(UFOMAP_ERR_INVALID, "null map");
 	HIP_TRY(hipSetDevice(m->device));
+	HIP_TRY(hipStreamSynchronize(m->sstream));
 	HIP_TRY(hipStreamSynchronize(m->stream));
-	return finishPending(m);
+	int rc = finishPending(m);
+	if (UFOMAP_OK == rc && UFOMAP_OK != m->async_status) {
+		rc = m->async_status;
+		g_err = "an earlier asynchronous integration failed";
+	}
+	m->async_status = UFOMAP_OK;
+	return rc;
 }
 
 int ufomap_map_done(ufomap_map* m)
@@ -1220,29 +1307,27 @@ int ufomap_map_scan_keys(ufomap_map* m, const double sensor_origin[3], const dou
 	if (!m || !info) return fail(UFOMAP_ERR_INVALID, "null argument");
 	memset(info, 0, sizeof(*info));
 	info->depth = depth;
+	HIP_TRY(hipSetDevice(m->device));
+	int rc = ufomap_map_wait(m);  // this entry point does not pipeline
+	if (rc) return rc;
+	m->cs = m->sstream;
 	u32 n_hits = 0, n_rays = 0;
-	int rc = scanPhase(m, sensor_origin, d_xyz, nullptr, n, max_range, depth, discrete, simple_ray_casting, 0, &n_hits, &n_rays);
+	rc = scanPhase(m, sensor_origin, d_xyz, nullptr, n, max_range, depth, discrete, simple_ray_casting, 0, &n_hits, &n_rays);
 	if (rc || 0 == n) return rc;
-	u64 capH = m->haveH ? (u64)n_hits : 0;
-	u64 capM = m->haveM ? std::min<u64>(m->gridM.bytes, std::max<u64>(1u << 20, (u64)n_rays * 64)) : 0;
-	for (int attempt = 0; attempt < 2; ++attempt) {
-		rc = extractLists(m, capH, capM, attempt > 0);
-		if (rc) return rc;
-		rc = readCtl(m);
-		if (rc) return rc;
-		rc = ctlError(m);  // e.g. a runaway ray
-		if (rc) return rc;
-		if (m->h_ctl->n_entries[0] <= capH && m->h_ctl->n_entries[1] <= capM) break;
-		capH = m->h_ctl->n_entries[0];
-		capM = m->h_ctl->n_entries[1];
-	}
+	u64 capH = 0, capM = 0;
+	rc = extractPhase(m, n_hits, n_rays, &capH, &capM);
+	if (rc) return rc;
+	rc = readCtl(m);  // on the scan stream: waits for the extraction
+	if (rc) return rc;
+	rc = ctlError(m);  // e.g. a runaway ray
+	if (rc) return rc;
 	// compact: miss entries directly behind the hit entries
 	const u32 nh = m->h_ctl->n_entries[0], nm = m->h_ctl->n_entries[1];
 	if (nh != capH && nm) {
 		HIP_TRY(m->b_codes.reserve((size_t)nm * sizeof(Entry)));
-		HIP_TRY(hipMemcpyAsync(m->b_codes.p, m->b_entries.as<Entry>() + capH, (size_t)nm * sizeof(Entry), hipMemcpyDeviceToDevice, m->stream));
-		HIP_TRY(hipMemcpyAsync(m->b_entries.as<Entry>() + nh, m->b_codes.p, (size_t)nm * sizeof(Entry), hipMemcpyDeviceToDevice, m->stream));
-		HIP_TRY(hipStreamSynchronize(m->stream));
+		HIP_TRY(hipMemcpyAsync(m->b_codes.p, m->b_entries.as<Entry>() + capH, (size_t)nm * sizeof(Entry), hipMemcpyDeviceToDevice, m->cs));
+		HIP_TRY(hipMemcpyAsync(m->b_entries.as<Entry>() + nh, m->b_codes.p, (size_t)nm * sizeof(Entry), hipMemcpyDeviceToDevice, m->cs));
+		HIP_TRY(hipStreamSynchronize(m->cs));
 	}
 	info->n_hit = nh;
 	info->n_miss = nm;
@@ -1253,6 +1338,7 @@ int ufomap_map_scan_keys(ufomap_map* m, const double sensor_origin[3], const dou
 	m->counts[2] = m->h_ctl->n_steps;
 	m->counts[5] = (u64)nh + nm;
 	drainEvents(m);
+	m->cs = m->stream;
 	return UFOMAP_OK;
 }
 
@@ -1273,13 +1359,13 @@ int ufomap_map_apply_keys(ufomap_map* m, const void* d_entries, const ufomap_key
 	if (m->g.color) return fail(UFOMAP_ERR_UNSUPPORTED, "update lists carry no colour: apply_keys works on OccupancyMap only");
 	if (info->depth >= m->g.L) return fail(UFOMAP_ERR_INVALID, "depth must be < depth_levels");
 	HIP_TRY(hipSetDevice(m->device));
-	if (m->pending) {
-		HIP_TRY(hipStreamSynchronize(m->stream));
-		int prc = finishPending(m);
+	{
+		int prc = ufomap_map_wait(m);
 		if (prc) return prc;
 	}
 	const u32 nh = info->n_hit, nm = info->n_miss;
 	if (0 == nh + nm) return UFOMAP_OK;
+	m->cs = m->stream;
 	// fresh control block: the entry counts are known exactly here
 	ScanCtl init;
 	memset(&init, 0, sizeof(init));
