@@ -94,6 +94,14 @@ size_t ufomap_map_export_leaves(ufomap_map* m, int include_unknown, uint64_t* co
 size_t ufomap_map_export_inner(ufomap_map* m, uint64_t* codes, uint8_t* depths, float* logodds,
                                uint8_t* flags, uint8_t* rgb, size_t cap);
 
+/* Octree::write(std::ostream&) (octree.h:833-868) with compress=false, min_depth=0 and no bounding volume:
+ * the text header followed by the pre-order node stream of OccupancyMapBase::writeNodes
+ * (occupancy_map_base.h:1457-1533). Byte-identical to what the reference writes for the same map, so the
+ * result can be loaded by the reference (`Octree::read`), wrapped into a ufomap_msgs/UFOMap message
+ * (ufomap_msgs conversions.h:162-186 sends exactly this node stream) or saved as a .ufo file.
+ * Returns the total size in bytes (header + data), writing only if cap is large enough; (size_t)-1 on error. */
+size_t ufomap_map_write(ufomap_map* m, uint8_t* buf, size_t cap);
+
 /* min/max change AABB: minChange()/maxChange()/resetMinMaxChangeDetection
  * (occupancy_map_base.h:793-822). Always tracked. */
 int ufomap_map_minmax_change(ufomap_map* m, double mn[3], double mx[3]);

@@ -61,6 +61,8 @@ def _load(kind: str):
     lib.ufo_oracle_export_leaves.argtypes = [vp, C.c_int, u64p, u8p, f32p, u8p, C.c_size_t]
     lib.ufo_oracle_export_inner.restype = C.c_size_t
     lib.ufo_oracle_export_inner.argtypes = [vp, u64p, u8p, f32p, u8p, u8p, C.c_size_t]
+    lib.ufo_oracle_write.restype = C.c_size_t
+    lib.ufo_oracle_write.argtypes = [vp, u8p, C.c_size_t]
     lib.ufo_oracle_minmax_change.restype = C.c_int
     lib.ufo_oracle_minmax_change.argtypes = [vp, f64p, f64p]
     lib.ufo_oracle_last_hits.restype = C.c_size_t
@@ -140,6 +142,13 @@ class OracleMap:
                                          _ptr(occ, C.c_float), _ptr(flags, C.c_uint8),
                                          _ptr(rgb, C.c_uint8), n)
         return codes, depths, occ, flags, rgb
+
+    def write(self):
+        """The map as the reference's .ufo byte stream (Octree::write, uncompressed)."""
+        n = self.lib.ufo_oracle_write(self.h, None, 0)
+        buf = np.empty(n, np.uint8)
+        self.lib.ufo_oracle_write(self.h, _ptr(buf, C.c_uint8), n)
+        return buf.tobytes()
 
     def minmax_change(self):
         mn = np.empty(3, np.float64)

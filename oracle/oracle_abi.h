@@ -51,6 +51,11 @@ size_t ufo_oracle_export_leaves(const ufo_oracle_map* m, int include_unknown, ui
 size_t ufo_oracle_export_inner(const ufo_oracle_map* m, uint64_t* codes, uint8_t* depths,
                                float* logodds, uint8_t* flags, uint8_t* rgb, size_t cap);
 
+/* The map as the reference's byte stream: Octree::write(std::ostream&, compress=false) (octree.h:833-868):
+ * text header + pre-order node stream (occupancy_map_base.h:1457-1533). Returns the size; writes only if
+ * cap is large enough. */
+size_t ufo_oracle_write(const ufo_oracle_map* m, uint8_t* buf, size_t cap);
+
 /* Min/max change AABB (occupancy_map_base.h:305-308, 388-398, 1367-1372). Returns 0 if enabled. */
 int ufo_oracle_minmax_change(const ufo_oracle_map* m, double mn[3], double mx[3]);
 

@@ -19,6 +19,7 @@
 #include <cstdint>
 #include <cstring>
 #include <memory>
+#include <sstream>
 #include <tuple>
 #include <vector>
 
@@ -207,6 +208,16 @@ size_t ufo_oracle_export_inner(const ufo_oracle_map* m, uint64_t* codes, uint8_t
 		m->occ->dump(true, nullptr, &inner);
 	}
 	return copyOut(inner, codes, depths, logodds, flags, rgb, cap);
+}
+
+size_t ufo_oracle_write(const ufo_oracle_map* m, uint8_t* buf, size_t cap)
+{
+	std::stringstream ss(std::ios_base::in | std::ios_base::out | std::ios_base::binary);
+	bool ok = m->col ? m->col->write(ss, false) : m->occ->write(ss, false);
+	if (!ok) return (size_t)-1;
+	std::string const bytes = ss.str();
+	if (buf && cap >= bytes.size()) std::memcpy(buf, bytes.data(), bytes.size());
+	return bytes.size();
 }
 
 int ufo_oracle_minmax_change(const ufo_oracle_map* m, double mn[3], double mx[3])

@@ -21,6 +21,8 @@
 #include <cstdint>
 #include <cstring>
 #include <limits>
+#include <sstream>
+#include <string>
 #include <unordered_set>
 #include <vector>
 
@@ -608,6 +610,57 @@ struct ufo_oracle_map {
 		return 0;
 	}
 
+	/* node payload: OccupancyNode::writeData / ColorOccupancyNode::writeData (occupancy_map_node.h:67-71, 150-153) */
+	void putData(std::string& out, Node const& nd) const
+	{
+		out.append(reinterpret_cast<const char*>(&nd.occ), 4);
+		if (color) out.append(reinterpret_cast<const char*>(nd.rgb), 3);
+	}
+	/* writeNodesRecurs (occupancy_map_base.h:1484-1533), no bounding volume, min_depth 0 */
+	void writeRecurs(std::string& out, int n, unsigned depth) const
+	{
+		int b = pool[n].child;
+		uint8_t children = 0;
+		for (int i = 0; i < 8; ++i)
+			if (depth - 1 > 0 && !pool[b + i].leaf) children |= (uint8_t)(1u << i);
+		out.push_back((char)children);
+		for (int i = 0; i < 8; ++i) {
+			if ((children >> i) & 1) {
+				if (1 == depth - 1) {
+					int gb = pool[b + i].child;
+					for (int j = 0; j < 8; ++j) putData(out, pool[gb + j]);
+				} else {
+					writeRecurs(out, b + i, depth - 1);
+				}
+			} else {
+				putData(out, pool[b + i]);
+			}
+		}
+	}
+	/* Octree::write (octree.h:833-868) + writeNodes (occupancy_map_base.h:1457-1482) */
+	std::string writeStream() const
+	{
+		std::string data;
+		if (!pool[0].leaf) {
+			data.push_back((char)0xFF);
+			writeRecurs(data, 0, L);
+		} else {
+			data.push_back((char)0);
+			putData(data, pool[0]);
+		}
+		std::ostringstream hd;
+		hd << "# UFOMap file";
+		hd << "\n# (feel free to add / change comments, but leave the first line as it is!)\n#\n";
+		hd << "version " << "1.0.0" << std::endl;
+		hd << "id " << (color ? "occupancy_map_color" : "occupancy_map") << std::endl;
+		hd << "resolution " << res << std::endl;
+		hd << "depth_levels " << L << std::endl;
+		hd << "compressed " << false << std::endl;
+		hd << "uncompressed_data_size " << (int)data.size() << std::endl;
+		hd << "data" << std::endl;
+		return hd.str() + data;
+	}
+
 	void walk(int n, unsigned depth, u64 prefix, bool inc_unknown, std::vector<Rec>* leaves, std::vector<Rec>* inner) const
 	{
 		Node const& nd = pool[n];
@@ -711,6 +764,13 @@ size_t ufo_oracle_export_inner(const ufo_oracle_map* m, uint64_t* codes, uint8_t
 	m->walk(0, m->L, 0, true, nullptr, &inner);
 	std::sort(inner.begin(), inner.end(), recLess);
 	return copyOut(inner, codes, depths, logodds, flags, rgb, cap);
+}
+
+size_t ufo_oracle_write(const ufo_oracle_map* m, uint8_t* buf, size_t cap)
+{
+	std::string const bytes = m->writeStream();
+	if (buf && cap >= bytes.size()) std::memcpy(buf, bytes.data(), bytes.size());
+	return bytes.size();
 }
 
 int ufo_oracle_minmax_change(const ufo_oracle_map* m, double mn[3], double mx[3])

@@ -4,7 +4,8 @@ Run in the build container (where /root/reference exists):  python tests/golden/
 Each case stores its inputs (params, per-scan origin/xyz/rgb) and the reference's canonical dumps:
 the known (non-unknown) leaves in full, SHA-256 digests of the complete leaf dump (incl. unknown
 leaves) and of the inner-node dump (value, contains_free/contains_unknown flags, colour), and the
-min/max change AABB.  The fixtures are self-contained: neither /root/reference nor oracle/_ref is
+min/max change AABB, and the SHA-256 of the map's byte stream as the reference's own write() produces
+it (octree.h:833-868).  The fixtures are self-contained: neither /root/reference nor oracle/_ref is
 needed to check against them.
 """
 import hashlib
@@ -112,6 +113,8 @@ def main():
         mn, mx = m.minmax_change()
         kc, kd, kv, krgb = m.leaves(False)
         arrays.update(leaf_codes=kc, leaf_depths=kd, leaf_occ=kv, leaf_rgb=krgb, min_change=mn, max_change=mx)
+        wb = m.write()
+        meta.update(write_size=len(wb), sha_write=hashlib.sha256(wb).hexdigest())
         meta.update(n_leaves_all=int(len(lc)), n_inner=int(len(ic)),
                     sha_leaves_all=digest(lc, ld, lv, lrgb), sha_inner=digest(ic, idp, iv, ifl, irgb))
         np.savez_compressed(os.path.join(HERE, name + ".npz"), meta=json.dumps(meta), **arrays)

@@ -48,5 +48,9 @@ class Golden:
         ic, idp, iv, ifl, irgb = m.inner()
         assert len(ic) == self.meta["n_inner"], f"{self.name}: inner-node count differs"
         assert digest(ic, idp, iv, ifl, irgb) == self.meta["sha_inner"], f"{self.name}: inner dump digest differs"
+        if "sha_write" in self.meta and hasattr(m, "write"):
+            wb = m.write()
+            assert len(wb) == self.meta["write_size"], f"{self.name}: byte-stream size differs from the reference's write()"
+            assert hashlib.sha256(wb).hexdigest() == self.meta["sha_write"], f"{self.name}: byte stream differs from the reference's write()"
         mn, mx = m.minmax_change()
         assert np.array_equal(mn, self.z["min_change"]) and np.array_equal(mx, self.z["max_change"]), f"{self.name}: change AABB differs"

@@ -36,6 +36,7 @@ def _assert_same_map(g, o, what=""):
     assert np.array_equal(gl[3], ol[3]), f"{what}: colours differ"
     assert same_dump(g.inner(), o.inner()), f"{what}: inner-node dump differs"
     assert same_dump(g.minmax_change(), o.minmax_change()), f"{what}: change AABB differs"
+    assert g.write() == o.write(), f"{what}: map byte stream differs from the reference format writer"
 
 
 @pytest.mark.parametrize("name", golden_util.names())
@@ -305,3 +306,14 @@ def test_pipelined_async_inserts_equal_sequential():
     assert g.insertPointCloudDone()
     _assert_same_map(g, o, "pipelined")
     assert g.last_counts()["points"] == clouds[-1][1].shape[0]
+
+
+def test_write_empty_map_and_file(tmp_path):
+    """Octree::write on a fresh map (root = one unknown leaf) and through a file."""
+    g, o = _maps(resolution=0.16)
+    assert g.write() == o.write()
+    gc, oc = _maps(color=True, resolution=0.08)
+    assert gc.write() == oc.write()
+    p = tmp_path / "map.ufo"
+    g.write(str(p))
+    assert p.read_bytes() == o.write() and p.read_bytes().startswith(b"# UFOMap file")

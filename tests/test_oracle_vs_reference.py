@@ -16,6 +16,7 @@ def _assert_same(a, b):
     assert same_dump(a.leaves(True), b.leaves(True)), "leaf dump differs"
     assert same_dump(a.inner(), b.inner()), "inner dump differs"
     assert same_dump(a.minmax_change(), b.minmax_change()), "change AABB differs"
+    assert a.write() == b.write(), "byte stream (Octree::write) differs"
 
 
 @pytest.mark.parametrize("seed", range(6))

@@ -804,6 +804,94 @@ __global__ __launch_bounds__(256) void k_export_inner(Table t, MapGeom g, u64* _
 }
 
 // ------------------------------------------------------------------------------------------------
+// Map byte stream: the node part of Octree::write / OccupancyMapBase::writeNodes
+// (octree.h:833-917, occupancy_map_base.h:1457-1533): pre-order; per inner node of depth >= 2 one byte
+// "child i has children", then per child either its subtree or its leaf payload (float log-odds [+ 3 bytes
+// r,g,b]); the eight leaves of a depth-1 node follow each other without a mask byte. Pre-order offsets come
+// from subtree sizes: sizes bottom-up (one launch per level), offsets and bytes top-down.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ser_count(Table t, MapGeom g, u32* __restrict__ level_cnt)
+{
+	u32 ncap = t.mask + 1;
+	for (u32 s = blockIdx.x * blockDim.x + threadIdx.x; s < ncap; s += gridDim.x * blockDim.x) {
+		u64 lk = t.keys[s];
+		if (0 == lk || (t.flags[s] & F_DEAD)) continue;
+		atomicAdd(&level_cnt[levelOf(g, lk)], 1u);
+	}
+}
+__global__ __launch_bounds__(256) void k_ser_collect(Table t, MapGeom g, const u32* __restrict__ level_off, u32* __restrict__ level_fill,
+                                                     u32* __restrict__ list)
+{
+	u32 ncap = t.mask + 1;
+	for (u32 s = blockIdx.x * blockDim.x + threadIdx.x; s < ncap; s += gridDim.x * blockDim.x) {
+		u64 lk = t.keys[s];
+		if (0 == lk || (t.flags[s] & F_DEAD)) continue;
+		u32 l = levelOf(g, lk);
+		list[level_off[l] + atomicAdd(&level_fill[l], 1u)] = s;
+	}
+}
+__global__ __launch_bounds__(256) void k_ser_sizes(Table t, MapGeom g, const u32* __restrict__ list, u32 n, u32 level, u32 D,
+                                                   u64* __restrict__ size)
+{
+	for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		const u32 s = list[i];
+		if (1 == level) {
+			size[s] = 8ull * D;
+			continue;
+		}
+		const u64 lk = t.keys[s];
+		const u32 f = t.flags[s];
+		u64 sz = 1;
+		for (u32 c = 0; c < 8; ++c) {
+			if ((f >> (16 + c)) & 1u) {
+				u32 cs = tableFind(t, (lk << 3) | (u64)c);
+				sz += (cs != NONE) ? size[cs] : D;
+			} else {
+				sz += D;
+			}
+		}
+		size[s] = sz;
+	}
+}
+__device__ inline void serPutLeaf(uint8_t* __restrict__ out, u64 at, float v, u32 rgb, u32 D)
+{
+	u32 b;
+	memcpy(&b, &v, 4);
+	out[at] = (uint8_t)b;
+	out[at + 1] = (uint8_t)(b >> 8);
+	out[at + 2] = (uint8_t)(b >> 16);
+	out[at + 3] = (uint8_t)(b >> 24);
+	if (D > 4) {
+		out[at + 4] = (uint8_t)rgb;
+		out[at + 5] = (uint8_t)(rgb >> 8);
+		out[at + 6] = (uint8_t)(rgb >> 16);
+	}
+}
+__global__ __launch_bounds__(256) void k_ser_write(Table t, MapGeom g, const u32* __restrict__ list, u32 n, u32 level, u32 D,
+                                                   const u64* __restrict__ size, u64* __restrict__ off, uint8_t* __restrict__ out)
+{
+	for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		const u32 s = list[i];
+		const u64 lk = t.keys[s];
+		u64 at = (1 == lk) ? 1ull : off[s];  // the root's subtree starts behind the 0xFF byte of writeNodes
+		const u32 f = t.flags[s];
+		if (level >= 2) out[at++] = (uint8_t)((f >> 16) & 0xFFu);
+		for (u32 c = 0; c < 8; ++c) {
+			if (level >= 2 && ((f >> (16 + c)) & 1u)) {
+				u32 cs = tableFind(t, (lk << 3) | (u64)c);
+				if (cs != NONE) {
+					off[cs] = at;
+					at += size[cs];
+					continue;
+				}
+			}
+			serPutLeaf(out, at, t.occ[8 * (size_t)s + c], t.rgb ? t.rgb[8 * (size_t)s + c] : 0u, D);
+			at += D;
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
 // table growth: re-insert every block into a table of twice/four times the capacity
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_rehash_copy(Table src, Table dst, u32* fail)

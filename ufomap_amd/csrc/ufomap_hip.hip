@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <sstream>
 #include <string>
 #include <vector>
 
@@ -1388,6 +1389,100 @@ int ufomap_map_apply_keys(ufomap_map* m, const void* d_entries, const ufomap_key
 	m->pending = true;
 	HIP_TRY(hipStreamSynchronize(m->stream));
 	return finishPending(m);
+}
+
+size_t ufomap_map_write(ufomap_map* m, uint8_t* buf, size_t cap)
+{
+	if (!m) {
+		fail(UFOMAP_ERR_INVALID, "null map");
+		return (size_t)-1;
+	}
+	if (ufomap_map_wait(m) < 0) return (size_t)-1;
+	auto bad = [&](hipError_t e) {
+		if (e != hipSuccess) {
+			fail(UFOMAP_ERR_DEVICE, hipGetErrorString(e));
+			return true;
+		}
+		return false;
+	};
+	m->cs = m->stream;
+	const u32 D = m->g.color ? 7u : 4u;
+	const u32 L = m->g.L;
+	// live blocks per level
+	DevBuf b_cnt, b_list, b_size, b_off, b_out;
+	u32 h_cnt[32] = {0}, h_off[32] = {0};
+	if (bad(b_cnt.reserve(3 * 32 * 4)) || bad(hipMemsetAsync(b_cnt.p, 0, 3 * 32 * 4, m->stream))) return (size_t)-1;
+	u32* d_cnt = b_cnt.as<u32>();
+	hipLaunchKernelGGL(k_ser_count, gridFor((u64)m->t.mask + 1), dim3(256), 0, m->stream, m->t, m->g, d_cnt);
+	if (bad(hipMemcpyAsync(h_cnt, d_cnt, 32 * 4, hipMemcpyDeviceToHost, m->stream)) || bad(hipStreamSynchronize(m->stream))) return (size_t)-1;
+	u64 n_live = 0;
+	for (u32 l = 0; l < 32; ++l) {
+		h_off[l] = (u32)n_live;
+		n_live += h_cnt[l];
+	}
+	MapRoot root;
+	if (bad(hipMemcpy(&root, m->b_root.p, sizeof(MapRoot), hipMemcpyDeviceToHost))) return (size_t)-1;
+	std::vector<uint8_t> data;
+	if (0 == h_cnt[L]) {
+		// the root is a leaf: children byte 0, then the root's payload (occupancy_map_base.h:1472-1478)
+		data.resize(1 + D);
+		data[0] = 0;
+		memcpy(&data[1], &root.occ, 4);
+		if (D > 4) {
+			data[5] = (uint8_t)root.rgb;
+			data[6] = (uint8_t)(root.rgb >> 8);
+			data[7] = (uint8_t)(root.rgb >> 16);
+		}
+	} else {
+		const size_t ncap = (size_t)m->t.mask + 1;
+		if (bad(b_list.reserve(std::max<u64>(n_live, 1) * 4)) || bad(b_size.reserve(ncap * 8)) || bad(b_off.reserve(ncap * 8)) ||
+		    bad(hipMemcpyAsync(d_cnt + 32, h_off, 32 * 4, hipMemcpyHostToDevice, m->stream)))
+			return (size_t)-1;
+		hipLaunchKernelGGL(k_ser_collect, gridFor((u64)m->t.mask + 1), dim3(256), 0, m->stream, m->t, m->g, d_cnt + 32, d_cnt + 64, b_list.as<u32>());
+		for (u32 l = 1; l <= L; ++l)
+			if (h_cnt[l])
+				hipLaunchKernelGGL(k_ser_sizes, gridFor(h_cnt[l]), dim3(256), 0, m->stream, m->t, m->g, b_list.as<u32>() + h_off[l], h_cnt[l], l, D,
+				                   b_size.as<u64>());
+		// total = 0xFF byte + subtree of the root block
+		u32 root_slot = 0;
+		if (bad(hipMemcpyAsync(&root_slot, b_list.as<u32>() + h_off[L], 4, hipMemcpyDeviceToHost, m->stream)) || bad(hipStreamSynchronize(m->stream)))
+			return (size_t)-1;
+		u64 root_size = 0;
+		if (bad(hipMemcpy(&root_size, b_size.as<u64>() + root_slot, 8, hipMemcpyDeviceToHost))) return (size_t)-1;
+		const u64 total = 1 + root_size;
+		if (bad(b_out.reserve(total))) return (size_t)-1;
+		const uint8_t ff = 0xFF;
+		if (bad(hipMemcpyAsync(b_out.p, &ff, 1, hipMemcpyHostToDevice, m->stream))) return (size_t)-1;
+		for (u32 l = L; l >= 1; --l)
+			if (h_cnt[l])
+				hipLaunchKernelGGL(k_ser_write, gridFor(h_cnt[l]), dim3(256), 0, m->stream, m->t, m->g, b_list.as<u32>() + h_off[l], h_cnt[l], l, D,
+				                   b_size.as<u64>(), b_off.as<u64>(), b_out.as<uint8_t>());
+		data.resize(total);
+		if (bad(hipMemcpyAsync(data.data(), b_out.p, total, hipMemcpyDeviceToHost, m->stream)) || bad(hipStreamSynchronize(m->stream))) return (size_t)-1;
+	}
+	b_cnt.release();
+	b_list.release();
+	b_size.release();
+	b_off.release();
+	b_out.release();
+	// text header exactly as Octree::write prints it (octree.h:850-861)
+	std::ostringstream hd;
+	hd << "# UFOMap file";
+	hd << "\n# (feel free to add / change comments, but leave the first line as it is!)\n#\n";
+	hd << "version " << "1.0.0" << std::endl;
+	hd << "id " << (m->g.color ? "occupancy_map_color" : "occupancy_map") << std::endl;
+	hd << "resolution " << m->g.res << std::endl;
+	hd << "depth_levels " << m->g.L << std::endl;
+	hd << "compressed " << false << std::endl;
+	hd << "uncompressed_data_size " << (int)data.size() << std::endl;
+	hd << "data" << std::endl;
+	const std::string h = hd.str();
+	const size_t total = h.size() + data.size();
+	if (buf && cap >= total) {
+		memcpy(buf, h.data(), h.size());
+		memcpy(buf + h.size(), data.data(), data.size());
+	}
+	return total;
 }
 
 int ufomap_map_set_option(ufomap_map* m, const char* key, long long value)

@@ -155,6 +155,20 @@ class OccupancyMapBase:
                                           _p(flags, C.c_uint8), _p(rgb, C.c_uint8), n)
         return codes, depths, occ, flags, rgb
 
+    def write(self, filename=None):
+        """``Octree::write`` (octree.h:779-868): the reference's .ufo byte stream (uncompressed). Returns the
+        bytes; also writes them to ``filename`` when given."""
+        n = self._lib.ufomap_map_write(self._h, None, 0)
+        if n == C.c_size_t(-1).value:
+            capi.check(-2)
+        buf = np.empty(n, np.uint8)
+        self._lib.ufomap_map_write(self._h, _p(buf, C.c_uint8), n)
+        data = buf.tobytes()
+        if filename:
+            with open(filename, "wb") as f:
+                f.write(data)
+        return data
+
     def minmax_change(self):
         mn, mx = np.empty(3), np.empty(3)
         capi.check(self._lib.ufomap_map_minmax_change(self._h, _p(mn, C.c_double), _p(mx, C.c_double)))
