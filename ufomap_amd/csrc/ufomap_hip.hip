@@ -490,7 +490,10 @@ int sizeTable(ufomap_map* m, const Entry* ent_h, u64 capH, const i32 nbH[3], con
 	m->scan_new_bound = bound(capH, capM);
 	u64 cap = (u64)m->t.mask + 1;
 	if ((m->used_est + m->scan_new_bound) * 5 <= cap * 3) return UFOMAP_OK;  // load factor stays <= 0.6
-	if (ent_h || ent_m) {
+	// small tables simply grow to the pessimistic size once (cheap, and the fast check passes from then on);
+	// the exact count is worth a kernel and a host round trip only when growing would cost gigabytes
+	const bool cheap = (m->used_est + m->scan_new_bound) * 2 <= (1ull << 22);
+	if (!cheap && (ent_h || ent_m)) {
 		ScanCtl* ctl = m->b_ctl.as<ScanCtl>();
 		u32* d_cnt = reinterpret_cast<u32*>(&ctl->dbg[60]);  // two spare words of the control block
 		HIP_TRY(hipMemsetAsync(d_cnt, 0, 8, m->cs));
