@@ -159,7 +159,9 @@ int ufomap_map_apply_keys(ufomap_map* m, const void* d_entries, const ufomap_key
 
 /* Diagnostic overrides for tests: "dda_mode" (-1 auto; 1 / 2 force the LDS-filter / direct variants of
  * the ray kernel on grids that would fit in LDS), "entry_guess" (cap of the guessed update-list size, to
- * exercise the exact-size retry). Results never depend on these. */
+ * exercise the exact-size retry), "dda_seg" (0: one lane per ray), "merge_phases" (0: hits and misses of a
+ * depth-0 scan as two passes over the tree instead of one; the environment variable UFOMAP_MERGE_PHASES
+ * sets the default for new maps). Results never depend on these. */
 int ufomap_map_set_option(ufomap_map* m, const char* key, long long value);
 
 /* Diagnostics: up to 64 raw 64-bit words written by the last integration's kernels (per-level

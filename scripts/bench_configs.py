@@ -17,12 +17,20 @@ def run(name, cls, res, origin, xyz, rgb, max_range, depth, discrete, reps):
         t0 = time.perf_counter()
         m.insert_device(origin, d.data_ptr(), drgb.data_ptr() if drgb is not None else None, xyz.shape[0], max_range, depth, discrete)
         ts.append(time.perf_counter() - t0)
+    top = None
+    if "--kernels" in sys.argv:
+        m.reset_kernel_times(); m.set_profiling(True)
+        for _ in range(5):
+            m.insert_device(origin, d.data_ptr(), drgb.data_ptr() if drgb is not None else None, xyz.shape[0], max_range, depth, discrete)
+        m.set_profiling(False)
+        kt = m.kernel_times()
+        top = {k: round(v["total_ms"] / 5 * 1e3, 1) for k, v in sorted(kt.items(), key=lambda kv: -kv[1]["total_ms"])[:7]}
     c = m.last_counts()
     st = m.stats()
     out = dict(config=name, points=xyz.shape[0], rays=c["rays"], steps=c["steps"], hits=c["hits"], ms_fresh=ts[0] * 1e3,
                ms_warm_median=float(np.median(ts[1:])) * 1e3 if reps > 1 else None,
                rays_per_s_warm=xyz.shape[0] / float(np.median(ts[1:])) if reps > 1 else None, live_blocks=st["inner_nodes"], leaves=st["leaf_nodes"],
-               table_bytes=st["bytes"])
+               table_bytes=st["bytes"], kernels_us=top)
     print(json.dumps(out), flush=True)
 
 

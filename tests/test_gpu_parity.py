@@ -90,6 +90,23 @@ def test_batch_of_8_poses_c4_sequential():
     _assert_same_map(g, o, "C4")
 
 
+@pytest.mark.parametrize("merge", [0, 1])
+def test_one_pass_and_two_pass_map_update_agree(merge):
+    """Depth-0 scans update the tree in one pass (hits + misses merged) by default; the two-pass form
+    (also used for insert depth > 0 and for update lists from other GPUs) must give the same map:
+    moving sensor, colour, overlapping hit/miss voxels, saturation and collapse."""
+    from ufomap_amd import scans
+    for color in (True, False):
+        g, o = _maps(color=color, resolution=0.16)
+        g.set_option("merge_phases", merge)
+        for s in range(6):
+            origin, xyz, rgb = scans.lidar64(beams=32, azimuths=512, origin=scans.lidar_pose(s % 3), seed=7 + (s % 3), colored=color)
+            discrete = True if color else bool(s & 1)  # the colour overload exists for the discrete integrator only
+            _gpu_insert(g, origin, xyz, rgb, max_range=12.0, discrete=discrete)
+            o.insert(origin, xyz, rgb, max_range=12.0, discrete=discrete)
+            _assert_same_map(g, o, f"merge={merge} color={color} scan {s}")
+
+
 def test_repeated_scan_saturation_and_pruning():
     """Ten identical scans: clamping at both ends and history-dependent collapse of free space."""
     from ufomap_amd import scans

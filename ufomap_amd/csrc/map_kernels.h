@@ -366,10 +366,18 @@ __device__ inline u32 blendColor(const MapGeom& g, u32 cur, u32 upd, float occ_o
 // by its own propagation, because the reference joins the hit thread before the first miss lands
 // (OMB:1361) and pruning depends on which ancestors were re-evaluated in which phase.
 // ------------------------------------------------------------------------------------------------
+// `mode`: 0 = the misses of the scan, 1 = its hits (two separate phases, each with its own propagation: used
+// for insert depth > 0 and for update lists that arrive from other GPUs), 2 = MERGED: hits, then misses, in
+// one pass over a list that holds every touched block once. One pass is enough because after the scan a
+// node's value depends on the final values beneath it only, and its collapse state on the LAST update
+// beneath it only (last-update chain above) -- and "last" is well defined across the two phases: every miss
+// comes after every hit (the reference joins the hit thread before the first miss lands, OMB:1361).
+#define UFO_MISS_TIME (1ull << 33)  // later than any hit (hit time = point index < 2^32)
 __global__ __launch_bounds__(256) void k_apply_leaf(Table t, MapGeom g, const Entry* __restrict__ entries,
-                                                    const u32* n_entries_p, const u32* __restrict__ ent_slot, float upd,
-                                                    u32 is_hit, u32 phase, HitHash hh, const uint8_t* __restrict__ rgb_in,
-                                                    u32* __restrict__ wl, ScanCtl::PhaseCtr* pc, ScanCtl* ctl)
+                                                    const u32* n_entries_p, const u32* __restrict__ ent_slot, float upd_hit,
+                                                    float upd_miss, u32 mode, u32 phase, HitHash hh,
+                                                    const uint8_t* __restrict__ rgb_in, u32* __restrict__ wl,
+                                                    ScanCtl::PhaseCtr* pc, ScanCtl* ctl)
 {
 	u32 n = *n_entries_p;
 	if (ctl->err) return;
@@ -379,16 +387,20 @@ __global__ __launch_bounds__(256) void k_apply_leaf(Table t, MapGeom g, const En
 		float4* po = reinterpret_cast<float4*>(t.occ + 8 * (size_t)s);
 		float4 a = po[0], b = po[1];
 		float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-		const u32 mask = is_hit ? e.hit : e.miss;
-		// the child updated last (k_extract): highest code for misses, latest first-point for hits
-		const int c_last = (int)e.c_last;
-		const u64 t_last = e.t_last;
+		const u32 hmask = (0 != mode) ? e.hit : 0u;
+		const u32 mmask = (1 != mode) ? e.miss : 0u;
+		// the child updated last: for misses the highest code (ascending code order), for hits the latest
+		// first-point (cloud order; k_hitmark); a miss is later than any hit
+		const bool last_is_miss = 0 != mmask;
+		const int c_last = (2 == mode) ? (last_is_miss ? (31 - __clz((int)mmask)) : (int)e.c_last) : (int)e.c_last;
+		const u64 t_last = (2 == mode) ? (last_is_miss ? UFO_MISS_TIME : (u64)e.t_last) : (u64)e.t_last;
+		const bool blend = hmask && g.color && rgb_in;
 		u32 oldc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-		if (is_hit && g.color && rgb_in) {
+		if (blend) {
 			const u64 pcode = (e.lk ^ (1ULL << (3 * (g.L - 1)))) << 3;  // depth-0 code of child 0
 #pragma unroll
 			for (int c = 0; c < 8; ++c) {
-				if (!((mask >> c) & 1)) continue;
+				if (!((hmask >> c) & 1)) continue;
 				u32 hs = hitHashFind(hh, pcode | (u64)c);
 				if (hs == NONE) continue;
 				u32 pt = hh.minidx[hs];
@@ -403,22 +415,35 @@ __global__ __launch_bounds__(256) void k_apply_leaf(Table t, MapGeom g, const En
 #pragma unroll
 		for (int c = 0; c < 8; ++c)
 			if (c == c_last) old_rgb_last = oldc[c];
-		if (g.color && !(is_hit && rgb_in)) old_rgb_last = t.rgb[8 * (size_t)s + c_last];  // colour untouched in this phase
+		// colour of the last-updated child just before that update: misses leave the colour alone
+		if (g.color && (last_is_miss || !blend)) old_rgb_last = t.rgb[8 * (size_t)s + c_last];
 		float v_old_last = 0.f;
 #pragma unroll
 		for (int c = 0; c < 8; ++c) {
-			if (c == c_last) v_old_last = v[c];
-			if ((mask >> c) & 1) v[c] = clampAdd(v[c], upd, g.cmin, g.cmax);
+			float x = v[c];
+			if ((hmask >> c) & 1) {
+				if (c == c_last && !last_is_miss) v_old_last = x;
+				x = clampAdd(x, upd_hit, g.cmin, g.cmax);
+			}
+			if ((mmask >> c) & 1) {
+				if (c == c_last) v_old_last = x;  // last_is_miss
+				x = clampAdd(x, upd_miss, g.cmin, g.cmax);
+			}
+			v[c] = x;
 		}
 		po[0] = make_float4(v[0], v[1], v[2], v[3]);
 		po[1] = make_float4(v[4], v[5], v[6], v[7]);
 		Summ sm = blockSummary(t, g, s, 1, 0);
 		// summary just before the last update of this block (level 1 is always reached: OMB:1128 starts at 1)
 		Summ pre = blockSummary(t, g, s, 1, 0, c_last, v_old_last, 0, old_rgb_last);
-		publishLast(t, g, s, e.lk, phase, !sameSumm(g, pre, sm), pre);
+		const bool reachchg = !sameSumm(g, pre, sm);
+		publishLast(t, g, s, e.lk, phase, reachchg, pre);
 		carryTime(t, s, e.lk, phase, t_last);
 		if (sm.collapsible) collapseBlock(t, s, e.lk);
-		markDirty(t, writeToParent(t, g, s, e.lk, sm), t.parent[s], wl, &pc->wl_cnt[2]);
+		// the parent is re-evaluated when the stored summary changed over the whole pass, or when the last
+		// update alone changed it (its upward walk reached the parent even if the net change is nil)
+		const bool changed = writeToParent(t, g, s, e.lk, sm);
+		markDirty(t, changed || reachchg, t.parent[s], wl, &pc->wl_cnt[2]);
 	}
 }
 
@@ -640,8 +665,9 @@ __device__ inline bool propagateCore(const Table& t, const MapGeom& g, u32 s, u3
 	const bool reached = lastReached(t, g, s, lk, level, old, phase, &pre);
 	if (reached && sm.collapsible) collapseBlock<WG>(t, s, lk);
 	const bool changed = writeToParent<WG>(t, g, s, lk, sm);
-	publishLast(t, g, s, lk, phase, reached && !sameSumm(g, pre, sm), pre);
-	const bool want = changed && 1 != lk;
+	const bool reachchg = reached && !sameSumm(g, pre, sm);
+	publishLast(t, g, s, lk, phase, reachchg, pre);
+	const bool want = (changed || reachchg) && 1 != lk;
 	if (want) *par = t.parent[s];
 	return want;
 }

@@ -594,15 +594,31 @@ __global__ __launch_bounds__(256) void k_hitmark(HitBlocks hb, const u64* __rest
 	}
 }
 
+// slot of a node block in the hit-block hash, NONE when the block received no hit
+__device__ inline u32 hitBlocksFind(const HitBlocks& hb, u64 key)
+{
+	if (!hb.keys) return 0xFFFFFFFFu;
+	u32 s = hash64(key) & hb.cap_mask;
+	for (u32 probe = 0; probe <= hb.cap_mask; ++probe) {
+		const u64 k = hb.keys[s];
+		if (k == key) return s;
+		if (k == ~0ULL) return 0xFFFFFFFFu;
+		s = (s + 1) & hb.cap_mask;
+	}
+	return 0xFFFFFFFFu;
+}
+#define UFO_HB_TAKEN 0x100u  // HitBlocks::mask: the block's hits already travel with its miss entry (merged list)
+
 // hit blocks -> update list (hit entries, level 1). Each lane takes 8 slots so that a wave reserves its
 // output with ONE atomic (an atomic per wave-iteration on a single counter costs ~12 ns each).
+// Blocks flagged UFO_HB_TAKEN by k_extract<true> are skipped (their hits are part of a merged entry).
 __global__ __launch_bounds__(256) void k_extract_hits(MapGeom g, HitBlocks hb, Entry* __restrict__ entries, u32 cap, ScanCtl* ctl)
 {
 	const u32 nslots = hb.cap_mask + 1;
 	const u32 base = (blockIdx.x * blockDim.x + threadIdx.x) * 8u;
 	u32 have = 0;
 	for (u32 k = 0; k < 8u; ++k)
-		if (base + k < nslots && hb.keys[base + k] != ~0ULL) have |= 1u << k;
+		if (base + k < nslots && hb.keys[base + k] != ~0ULL && !(hb.mask[base + k] & UFO_HB_TAKEN)) have |= 1u << k;
 	u32 pos = waveAppendN(&ctl->n_entries[0], (u32)__popc(have));
 	for (u32 k = 0; k < 8u; ++k) {
 		if (!((have >> k) & 1u)) continue;
@@ -1243,8 +1259,11 @@ __global__ __launch_bounds__(1024) void k_merge_slabs(const uint4* __restrict__ 
 // ------------------------------------------------------------------------------------------------
 // K3 extract: non-zero bytes of the grids -> update list, one entry per touched node block.
 // ------------------------------------------------------------------------------------------------
+// MERGED (insert depth 0 only): one list for the whole scan -- a block with misses also carries the mask of
+// its hit children (looked up in the hit-block hash, which is flagged so that k_extract_hits skips it).
+template <bool MERGED>
 __global__ __launch_bounds__(256) void k_extract(MapGeom g, Grid gr, const u32* __restrict__ grid, u32 which,
-                                                 Entry* __restrict__ entries, u32 cap, ScanCtl* ctl)
+                                                 Entry* __restrict__ entries, u32 cap, ScanCtl* ctl, HitBlocks hb)
 {
 	const u64 nwords = gr.bytes >> 2;
 	const u32 level = gr.depth + 1;
@@ -1279,6 +1298,17 @@ __global__ __launch_bounds__(256) void k_extract(MapGeom g, Grid gr, const u32* 
 			e.level = (u8)level;
 			e.c_last = (u8)(31 - __clz((int)mb));  // misses: ascending code order -> highest child
 			e.t_last = 0;
+			if (MERGED) {
+				e.miss = (u8)mb;
+				const u32 hs = hitBlocksFind(hb, p);
+				if (hs != 0xFFFFFFFFu) {
+					const u32 hm = hb.mask[hs];
+					e.hit = (u8)hm;
+					hb.mask[hs] = hm | UFO_HB_TAKEN;  // this thread is the only one that looks this block up
+				} else {
+					e.hit = 0;
+				}
+			}
 			entries[my] = e;
 		}
 	}

@@ -146,6 +146,8 @@ struct ufomap_map {
 	u64 scan_new_bound = 0;  // upper bound of the blocks both phases of the current scan can create
 	int opt_dda_mode = -1;
 	int opt_dda_seg = 1;  // 0 = force the lane-per-ray kernel
+	int opt_dda_block = 0, opt_dda_lanes = 0;  // 0 = automatic
+	int opt_merge = 1;    // 0 = hits and misses as two separate passes over the tree also at insert depth 0
 	u64 opt_entry_guess = 0;
 	uint64_t counts[8] = {0};
 	double min_change[3], max_change[3];
@@ -394,15 +396,26 @@ u64 levelBound(const i32 nb[3], u32 shift)
 // One phase of the map update: entries of one level -> ensure, init, apply, propagate.
 // `cap` is the capacity of the entry buffer (the device-side count may be smaller; if it is larger
 // k_ensure raises ERR_ENTRIES and nothing is applied).
+// Merged mode (nbB != nullptr, level 1): the list holds every touched block of the scan once -- up to cap - capB
+// blocks inside grid nb[] (hits) and capB blocks inside grid nbB[] (misses); `which` is 0.
 int applyEntries(ufomap_map* m, const Entry* d_entries, u32 cap, u32 which, u32 level, const i32 nb[3], float upd,
-                 const uint8_t* d_rgb, bool zero_ctr, u32 cap_h, u32 cap_m)
+                 const uint8_t* d_rgb, bool zero_ctr, u32 cap_h, u32 cap_m, u32 capB = 0, const i32* nbB = nullptr,
+                 float upd_miss = 0.f)
 {
 	if (0 == cap) return UFOMAP_OK;
+	const bool merged = nullptr != nbB;
+	const u32 capA = merged ? cap - capB : cap;
+	// blocks of level `level + sh` that the entries' paths can touch
+	auto lvlBound = [&](u32 sh) {
+		u64 b = capA ? std::min<u64>(capA, levelBound(nb, sh)) : 0;
+		if (merged && capB) b += std::min<u64>(capB, levelBound(nbB, sh));
+		return b;
+	};
 	m->scan_id += 1;  // "new this phase" stamp: blocks made by an earlier phase of the same scan are old
-	u64 newcap = blockBound(m, cap, nb, level);
+	u64 newcap = (capA ? blockBound(m, capA, nb, level) : 0) + ((merged && capB) ? blockBound(m, capB, nbB, level) : 0);
 	HIP_TRY(m->b_ent_slot.reserve((size_t)cap * 4));
 	HIP_TRY(m->b_newlist.reserve((size_t)newcap * 4));
-	size_t wlcap = (size_t)std::min<u64>(cap, levelBound(nb, 1)) + 8;
+	size_t wlcap = (size_t)lvlBound(1) + 8;
 	HIP_TRY(m->b_wl0.reserve(wlcap * 4));
 	HIP_TRY(m->b_wl1.reserve(wlcap * 4));
 	ScanCtl* ctl = m->b_ctl.as<ScanCtl>();
@@ -424,8 +437,10 @@ int applyEntries(ufomap_map* m, const Entry* d_entries, u32 cap, u32 which, u32 
 	}
 	if (1 == level) {
 		ProfScope ps(m, "k_apply_leaf");
-		hipLaunchKernelGGL(k_apply_leaf, ge, dim3(256), 0, m->cs, m->t, m->g, d_entries, d_n, m->b_ent_slot.as<u32>(), upd,
-		                   (u32)(which == 0 ? 1 : 0), m->scan_id, hh, d_rgb, wl[0], pc, ctl);
+		const u32 mode = merged ? 2u : (which == 0 ? 1u : 0u);
+		hipLaunchKernelGGL(k_apply_leaf, ge, dim3(256), 0, m->cs, m->t, m->g, d_entries, d_n, m->b_ent_slot.as<u32>(),
+		                   merged ? upd : (which == 0 ? upd : 0.f), merged ? upd_miss : (which == 0 ? 0.f : upd), mode, m->scan_id, hh,
+		                   d_rgb, wl[0], pc, ctl);
 	} else {
 		// coarse misses: level-synchronous walk of the subtrees below the masked children (map_kernels.h S3c)
 		// every live block can be visited: blocks known at the last control-block read + everything this scan may add
@@ -461,7 +476,7 @@ int applyEntries(ufomap_map* m, const Entry* d_entries, u32 cap, u32 which, u32 
 	// updateParents (OMB:1126-1133): wide levels one launch each, the narrow rest in one launch
 	u32 l = level + 1;
 	for (; l <= m->g.L; ++l) {
-		u64 bound = std::min<u64>(cap, levelBound(nb, l - level));
+		u64 bound = lvlBound(l - level);
 		if (bound <= 2048) break;
 		ProfScope ps(m, "k_propagate");
 		hipLaunchKernelGGL(k_propagate, gridFor(bound, 256, 1024), dim3(256), 0, m->cs, m->t, m->g, wl[l & 1], wl[(l + 1) & 1], l,
@@ -479,7 +494,7 @@ int applyEntries(ufomap_map* m, const Entry* d_entries, u32 cap, u32 which, u32 
 // entry new) is a true upper bound but far too pessimistic on a warm map; when it asks for growth, count
 // the entries whose block is really missing (one extra kernel + host read on this rare path) and bound again.
 int sizeTable(ufomap_map* m, const Entry* ent_h, u64 capH, const i32 nbH[3], const Entry* ent_m, u64 capM, const i32 nbM[3],
-              unsigned depth)
+              unsigned depth, bool merged = false)
 {
 	auto bound = [&](u64 nh, u64 nm) {
 		u64 b = 0;
@@ -497,15 +512,23 @@ int sizeTable(ufomap_map* m, const Entry* ent_h, u64 capH, const i32 nbH[3], con
 		ScanCtl* ctl = m->b_ctl.as<ScanCtl>();
 		u32* d_cnt = reinterpret_cast<u32*>(&ctl->dbg[60]);  // two spare words of the control block
 		HIP_TRY(hipMemsetAsync(d_cnt, 0, 8, m->cs));
-		if (capH)
-			hipLaunchKernelGGL(k_count_missing, gridFor(capH), dim3(256), 0, m->cs, m->t, ent_h, &ctl->n_entries[0], (u32)capH, d_cnt);
-		if (capM)
-			hipLaunchKernelGGL(k_count_missing, gridFor(capM), dim3(256), 0, m->cs, m->t, ent_m, &ctl->n_entries[1], (u32)capM, d_cnt + 1);
+		if (merged) {
+			// one list (ent_h, capacity capH + capM): a missing block lies in the hit grid or in the miss grid
+			hipLaunchKernelGGL(k_count_missing, gridFor(capH + capM), dim3(256), 0, m->cs, m->t, ent_h, &ctl->n_entries[0],
+			                   (u32)(capH + capM), d_cnt);
+		} else {
+			if (capH)
+				hipLaunchKernelGGL(k_count_missing, gridFor(capH), dim3(256), 0, m->cs, m->t, ent_h, &ctl->n_entries[0], (u32)capH, d_cnt);
+			if (capM)
+				hipLaunchKernelGGL(k_count_missing, gridFor(capM), dim3(256), 0, m->cs, m->t, ent_m, &ctl->n_entries[1], (u32)capM, d_cnt + 1);
+		}
 		int rc = readCtl(m);
 		if (rc) return rc;
 		u32 cnt[2];
 		memcpy(cnt, &m->h_ctl->dbg[60], 8);
-		if (m->h_ctl->n_entries[0] <= capH && m->h_ctl->n_entries[1] <= capM) m->scan_new_bound = bound(cnt[0], cnt[1]);
+		if (merged) {
+			if (m->h_ctl->n_entries[0] <= capH + capM) m->scan_new_bound = bound(capH ? cnt[0] : 0, capM ? cnt[0] : 0);
+		} else if (m->h_ctl->n_entries[0] <= capH && m->h_ctl->n_entries[1] <= capM) m->scan_new_bound = bound(cnt[0], cnt[1]);
 		if ((m->used_est + m->scan_new_bound) * 5 <= cap * 3) return UFOMAP_OK;
 	}
 	u64 want = (m->used_est + m->scan_new_bound) * 2;
@@ -515,14 +538,31 @@ int sizeTable(ufomap_map* m, const Entry* ent_h, u64 capH, const i32 nbH[3], con
 
 // Update lists from the two grids of the current scan into b_entries: hit entries first, then miss entries.
 // capH/capM: capacities (upper bounds or guesses; the device-side counts land in ctl->n_entries[]).
-int extractLists(ufomap_map* m, u64 capH, u64 capM, bool zero_counts)
+// merged (insert depth 0): ONE list in which a block with hits and misses appears once (misses first, then
+// the blocks that only received hits); its count is n_entries[0], its capacity capH + capM.
+int extractLists(ufomap_map* m, u64 capH, u64 capM, bool zero_counts, bool merged = false)
 {
 	ScanCtl* ctl = m->b_ctl.as<ScanCtl>();
-	if (capH > 0x7FFFFFFFull || capM > 0x7FFFFFFFull) return fail(UFOMAP_ERR_CAPACITY, "update list exceeds 2^31 entries");
+	if (capH > 0x7FFFFFFFull || capM > 0x7FFFFFFFull || capH + capM > 0x7FFFFFFFull)
+		return fail(UFOMAP_ERR_CAPACITY, "update list exceeds 2^31 entries");
 	HIP_TRY(m->b_entries.reserve(((size_t)capH + capM + 1) * sizeof(Entry)));
 	Entry* ent_h = m->b_entries.as<Entry>();
 	Entry* ent_m = ent_h + capH;
 	if (zero_counts) HIP_TRY(hipMemsetAsync(&ctl->n_entries[0], 0, 8, m->cs));  // otherwise zero from the control-block upload
+	if (merged) {
+		HitBlocks hb{capH ? m->b_hb_keys.as<u64>() : nullptr, m->b_hb_mask.as<u32>(), m->b_hb_time.as<u32>(), m->hb_cap_mask};
+		if (capM) {
+			ProfScope ps(m, "k_extract");
+			hipLaunchKernelGGL(k_extract<true>, gridFor(m->gridM.bytes >> 2, 256, 2048), dim3(256), 0, m->cs, m->g, m->gridM,
+			                   m->b_gridM.as<u32>(), 0u, ent_h, (u32)(capH + capM), ctl, hb);
+		}
+		if (capH) {
+			ProfScope ps(m, "k_extract_hits");
+			hipLaunchKernelGGL(k_extract_hits, dim3((u32)(((u64)m->hb_cap_mask + 1 + 2047) / 2048)), dim3(256), 0, m->cs, m->g, hb, ent_h,
+			                   (u32)(capH + capM), ctl);
+		}
+		return UFOMAP_OK;
+	}
 	if (capH) {
 		ProfScope ps(m, "k_extract_hits");
 		HitBlocks hb{m->b_hb_keys.as<u64>(), m->b_hb_mask.as<u32>(), m->b_hb_time.as<u32>(), m->hb_cap_mask};
@@ -531,8 +571,8 @@ int extractLists(ufomap_map* m, u64 capH, u64 capM, bool zero_counts)
 	}
 	if (capM) {
 		ProfScope ps(m, "k_extract");
-		hipLaunchKernelGGL(k_extract, gridFor(m->gridM.bytes >> 2, 256, 2048), dim3(256), 0, m->cs, m->g, m->gridM,
-		                   m->b_gridM.as<u32>(), 1u, ent_m, (u32)capM, ctl);
+		hipLaunchKernelGGL(k_extract<false>, gridFor(m->gridM.bytes >> 2, 256, 2048), dim3(256), 0, m->cs, m->g, m->gridM,
+		                   m->b_gridM.as<u32>(), 1u, ent_m, (u32)capM, ctl, HitBlocks{nullptr, nullptr, nullptr, 0});
 	}
 	return UFOMAP_OK;
 }
@@ -540,13 +580,16 @@ int extractLists(ufomap_map* m, u64 capH, u64 capM, bool zero_counts)
 // The map half of an integration (map stream): size the table, hits phase, then misses phase (OMB:1351-1365).
 // The two update lists are already in b_entries (hit entries first); capH/capM are their capacities
 // (true upper bounds or exact counts, so the device-side counts always fit).
-int mapPhase(ufomap_map* m, unsigned depth, const uint8_t* d_rgb, u64 capH, u64 capM)
+int mapPhase(ufomap_map* m, unsigned depth, const uint8_t* d_rgb, u64 capH, u64 capM, bool merged)
 {
 	const float miss = (float)(m->g.miss_log / double((2.0 * depth) + 1));  // OMB:311
 	Entry* ent_h = m->b_entries.as<Entry>();
 	Entry* ent_m = ent_h + capH;
-	int rc = sizeTable(m, ent_h, capH, m->gridH.nb, ent_m, capM, m->gridM.nb, depth);
+	int rc = sizeTable(m, ent_h, capH, m->gridH.nb, ent_m, capM, m->gridM.nb, depth, merged);
 	if (rc) return rc;
+	if (merged)
+		return applyEntries(m, ent_h, (u32)(capH + capM), 0, 1, m->gridH.nb, m->g.hit, d_rgb, false, (u32)(capH + capM), 0u, (u32)capM,
+		                    m->gridM.nb, miss);
 	rc = applyEntries(m, ent_h, (u32)capH, 0, 1, m->gridH.nb, m->g.hit, d_rgb, false, (u32)capH, (u32)capM);
 	if (rc) return rc;
 	return applyEntries(m, ent_m, (u32)capM, 1, (u32)depth + 1, m->gridM.nb, miss, nullptr, false, (u32)capH, (u32)capM);
@@ -703,20 +746,21 @@ int scanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, const 
 		int mode = m->gridM.bytes <= UFO_DDA_LDSGRID_MAX ? DDA_LDSGRID : (m->gridM.bytes < (1ull << 29) ? DDA_FILTER : DDA_DIRECT);
 		if (m->opt_dda_mode >= 0 && m->opt_dda_mode >= mode) mode = m->opt_dda_mode;  // tests may force a more general mode
 		const size_t lds = mode == DDA_LDSGRID ? (size_t)m->gridM.bytes : (mode == DDA_FILTER ? (size_t)UFO_DDA_FILT * 4 : 0);
-		// Workgroup size: each ray is one dependent instruction chain (~180 steps), so the kernel's time is
-		// the longest ray's latency whatever the occupancy (measured: 128- and 1024-thread workgroups run
-		// the same). Large workgroups mean fewer LDS-grid slabs to merge and a wider dedup scope for the
-		// filter, so use the maximum unless the scan is tiny.
-		// The segmented kernel (8 lanes per ray) needs 10-bit local cell coordinates; the sequential kernel is the
-		// general fallback (fixed-step "simple" casting, huge grids).
+		// Launch shape (measured on C2, 36.6 k rays, LDS-grid mode; lanes per ray x threads per workgroup ->
+		// walk kernel): 1x256 33 us, 2x512 34, 2x256 39, 1x512 42, 2x1024 43, 4x1024 47, 4x512 51, 1x128 52,
+		// 1x1024 63. A ray (segment) is one dependent instruction chain, so few waves per SIMD hide little;
+		// beyond one workgroup per CU the per-workgroup cost of the LDS-grid copy (zero, store, merge) takes
+		// over; and a segment lane replays its start state (k0 additions), which makes 4 lanes per ray a loss
+		// unless the scan is tiny. Hence: about one workgroup per CU, of 256..1024 threads, 1-2 lanes per ray.
 		const bool packed = 2 * m->gridM.nb[0] < 1023 && 2 * m->gridM.nb[1] < 1023 && 2 * m->gridM.nb[2] < 1023;
 		const bool seg = !simple && mode != DDA_DIRECT && packed && m->opt_dda_seg != 0;
-		// lanes per ray: as many as keep the launch around 4k waves (all resident at once, not issue-bound)
 		u32 seg_shift = 0;
-		while (seg && (1u << (seg_shift + 1)) <= UFO_SEG_MAX && ((u64)n_rays << (seg_shift + 1)) <= 4096ull * 64) ++seg_shift;
+		if (seg) seg_shift = n_rays <= 8192u ? 2u : (n_rays <= 65536u ? 1u : 0u);
+		if (seg && m->opt_dda_lanes > 0) seg_shift = m->opt_dda_lanes == 1 ? 0 : (m->opt_dda_lanes == 2 ? 1 : 2);
 		const u64 lanes = (u64)n_rays << seg_shift;
-		u32 blk = UFO_DDA_BLOCK;
-		while (blk > 128 && (lanes + blk - 1) / blk < 32) blk >>= 1;
+		u32 blk = (u32)std::min<u64>(UFO_DDA_BLOCK, std::max<u64>(256, (((lanes + 255) / 256) + 63) & ~63ull));
+		if (lanes < 256u * 32u) blk = 128;  // tiny scans: spread over more CUs
+		if (m->opt_dda_block >= 64 && m->opt_dda_block <= UFO_DDA_BLOCK) blk = (u32)m->opt_dda_block;
 		dim3 gr((u32)((lanes + blk - 1) / blk));
 		u32* dda_out = m->b_gridM.as<u32>();
 		if (mode == DDA_LDSGRID) {
@@ -772,7 +816,7 @@ int scanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, const 
 // Size the update-list buffers and extract both lists on the scan stream. The capacities are true upper
 // bounds (hit blocks <= unique hits; miss blocks <= blocks of grid M) or, for huge sparse grids, the exact
 // count from a counting pass -- the device-side counts always fit.
-int extractPhase(ufomap_map* m, u32 n_hits, u32 n_rays, u64* capH_out, u64* capM_out)
+int extractPhase(ufomap_map* m, u32 n_hits, u32 n_rays, u64* capH_out, u64* capM_out, bool merged)
 {
 	ScanCtl* ctl = m->b_ctl.as<ScanCtl>();
 	u64 capH = m->haveH ? (u64)n_hits : 0;
@@ -781,14 +825,14 @@ int extractPhase(ufomap_map* m, u32 n_hits, u32 n_rays, u64* capH_out, u64* capM
 	if (capM > guess) {
 		// counting pass (cap = 0 writes nothing), then the exact size
 		ProfScope ps(m, "k_extract_count");
-		hipLaunchKernelGGL(k_extract, gridFor(m->gridM.bytes >> 2, 256, 2048), dim3(256), 0, m->cs, m->g, m->gridM, m->b_gridM.as<u32>(), 1u,
-		                   (Entry*)nullptr, 0u, ctl);
+		hipLaunchKernelGGL(k_extract<false>, gridFor(m->gridM.bytes >> 2, 256, 2048), dim3(256), 0, m->cs, m->g, m->gridM,
+		                   m->b_gridM.as<u32>(), 1u, (Entry*)nullptr, 0u, ctl, HitBlocks{nullptr, nullptr, nullptr, 0});
 		HIP_TRY(hipMemcpyAsync(m->h_ctl, m->b_ctl.p, sizeof(ScanCtl), hipMemcpyDeviceToHost, m->cs));
 		HIP_TRY(hipStreamSynchronize(m->cs));
 		capM = m->h_ctl->n_entries[1];
 		HIP_TRY(hipMemsetAsync(&ctl->n_entries[1], 0, 4, m->cs));
 	}
-	int rc = extractLists(m, capH, capM, false);
+	int rc = extractLists(m, capH, capM, false, merged);
 	if (rc) return rc;
 	*capH_out = capH;
 	*capM_out = capM;
@@ -821,7 +865,9 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 	u32 n_hits = 0, n_rays = 0;
 	int rc = scanPhase(m, origin, d_xyz, d_rgb, n, max_range, depth, discrete, simple, early_stopping, &n_hits, &n_rays);
 	u64 capH = 0, capM = 0;
-	if (!rc && n) rc = extractPhase(m, n_hits, n_rays, &capH, &capM);
+	// insert depth 0: hits and misses of the scan as ONE pass over the tree (map_kernels.h, k_apply_leaf mode 2)
+	const bool merged = 0 == depth && 0 != m->opt_merge;
+	if (!rc && n) rc = extractPhase(m, n_hits, n_rays, &capH, &capM, merged);
 	if (!rc && n) rc = (hipEventRecord(m->scan_ev, m->sstream) == hipSuccess) ? UFOMAP_OK : fail(UFOMAP_ERR_DEVICE, "hipEventRecord");
 	// join the previous integration (occupancy_map_base.h:315): its status is reported by wait()/this call
 	int prc = joinPrevious(m);
@@ -833,7 +879,7 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 	m->cs = m->stream;
 	HIP_TRY(hipStreamWaitEvent(m->stream, m->scan_ev, 0));
 	m->last_rgb = d_rgb;
-	rc = mapPhase(m, depth, d_rgb, capH, capM);
+	rc = mapPhase(m, depth, d_rgb, capH, capM, merged);
 	if (rc) return rc;
 	HIP_TRY(hipGetLastError());
 	m->pending = true;
@@ -886,6 +932,7 @@ ufomap_map* ufomap_map_create(double resolution, unsigned depth_levels, int auto
 		return nullptr;
 	}
 	ufomap_map* m = new ufomap_map;
+	if (const char* e = getenv("UFOMAP_MERGE_PHASES")) m->opt_merge = atoi(e) != 0;  // test override, see ufomap_map_set_option
 	m->device = device;
 	MapGeom& g = m->g;
 	g.res = resolution;
@@ -1319,7 +1366,7 @@ int ufomap_map_scan_keys(ufomap_map* m, const double sensor_origin[3], const dou
 	rc = scanPhase(m, sensor_origin, d_xyz, nullptr, n, max_range, depth, discrete, simple_ray_casting, 0, &n_hits, &n_rays);
 	if (rc || 0 == n) return rc;
 	u64 capH = 0, capM = 0;
-	rc = extractPhase(m, n_hits, n_rays, &capH, &capM);
+	rc = extractPhase(m, n_hits, n_rays, &capH, &capM, false);
 	if (rc) return rc;
 	rc = readCtl(m);  // on the scan stream: waits for the extraction
 	if (rc) return rc;
@@ -1496,6 +1543,12 @@ int ufomap_map_set_option(ufomap_map* m, const char* key, long long value)
 		m->opt_dda_mode = (int)value;
 	} else if (0 == strcmp(key, "dda_seg")) {
 		m->opt_dda_seg = value ? 1 : 0;
+	} else if (0 == strcmp(key, "dda_block")) {
+		m->opt_dda_block = (int)value;
+	} else if (0 == strcmp(key, "dda_lanes")) {
+		m->opt_dda_lanes = (int)value;
+	} else if (0 == strcmp(key, "merge_phases")) {
+		m->opt_merge = value ? 1 : 0;
 	} else if (0 == strcmp(key, "entry_guess")) {
 		m->opt_entry_guess = value > 0 ? (u64)value : 0;
 	} else {
