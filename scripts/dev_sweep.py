@@ -29,6 +29,7 @@ def run(opts, steps=300, prof=False, async_=True):
         out["us"] = {k: round(v["total_ms"] / steps * 1e3, 1) for k, v in sorted(kt.items(), key=lambda kv: -kv[1]["total_ms"]) if v["launches"]}
     print(json.dumps(out), flush=True)
 
-for blk in (128, 256, 512, 1024):
-    for lanes in (1, 2):
-        run({"dda_block": blk, "dda_lanes": lanes}, steps=100, prof=True)
+run({"cast": 0}, steps=100, prof=True)
+run({}, steps=100, prof=True)
+run({}, steps=300)
+run({}, steps=300, async_=False)

@@ -11,7 +11,7 @@ import csv, glob, collections
 for f in sorted(glob.glob("gpurun_out/pmc_dda/*/*counter_collection.csv")):
     acc = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(f)):
-        if "k_dda" in r["Kernel_Name"] or "k_propagate_tail" in r["Kernel_Name"]:
+        if "k_dda" in r["Kernel_Name"] or "k_walk" in r["Kernel_Name"]:
             k = (r["Kernel_Name"].split("(")[0][-40:], r["Counter_Name"])
             acc[k][0] += 1; acc[k][1] += float(r["Counter_Value"])
     for k, (n, t) in sorted(acc.items()):

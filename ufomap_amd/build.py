@@ -15,7 +15,7 @@ LIB = os.path.join(CSRC, "libufomap_hip.so")
 SOURCES = ["ufomap_hip.hip"]
 HEADERS = ["geom.h", "table.h", "scan_kernels.h", "map_kernels.h", os.path.join("..", "..", "include", "ufomap_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-         "-fgpu-rdc" if False else "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+         "-fgpu-rdc" if False else "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-bitwise-instead-of-logical"]
 
 
 def needs_build() -> bool:

@@ -30,9 +30,11 @@ struct Grid {
 	i32 base[3];  // cell coordinate (key >> depth, as signed) of block (0,0,0); even
 	i32 nb[3];    // blocks per axis
 	u32 depth;
-	u32 pad;
-	u64 bytes;  // nb[0]*nb[1]*nb[2] rounded up to 8
+	u32 layout;  // 0: one byte per block (bit = child index); 1: one bit per cell, x fastest, rows padded to 32 cells
+	u64 bytes;   // layout 0: nb[0]*nb[1]*nb[2]; layout 1: rowBits/8 * 2nb[1] * 2nb[2] (= blocks incl. padding); rounded up to 16
 };
+// layout 1: bits per row of cells
+__host__ __device__ inline u32 gridRowBits(const Grid& gr) { return (((u32)gr.nb[0] * 2u) + 31u) & ~31u; }
 
 struct ScanCtl {
 	u32 n_rays;
@@ -964,16 +966,11 @@ struct RayState {
 };
 
 // clip (OMB:1248), keys, computeRayInit (OCT:1192-1225): everything of a ray that is not the walk itself
-__global__ __launch_bounds__(256) void k_ray_setup(MapGeom g, D3 sensor, u32 depth, Grid gr, const D3* __restrict__ ray_end,
-                                                   RayState* __restrict__ rs, const ScanCtl* ctl_in)
+__device__ inline void raySetup(const MapGeom& g, const D3& sensor, u32 depth, const Grid& gr, D3 to, RayState& r)
 {
-	const u32 n = ctl_in->n_rays;
-	const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n) return;
-	RayState r;
 	r.status = 0;
 	const u32 lim = 1u << (g.L - depth);
-	D3 from = sensor, to = ray_end[i];
+	D3 from = sensor;
 	if (moveLineInside(g, from, to)) {
 		D3 cur = to, end = from;  // "do it backwards" OMB:1266-1272
 		D3 dir = end - cur;
@@ -1041,6 +1038,16 @@ __global__ __launch_bounds__(256) void k_ray_setup(MapGeom g, D3 sensor, u32 dep
 			}
 		}
 	}
+}
+
+__global__ __launch_bounds__(256) void k_ray_setup(MapGeom g, D3 sensor, u32 depth, Grid gr, const D3* __restrict__ ray_end,
+                                                   RayState* __restrict__ rs, const ScanCtl* ctl_in)
+{
+	const u32 n = ctl_in->n_rays;
+	const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	RayState r;
+	raySetup(g, sensor, depth, gr, ray_end[i], r);
 	rs[i] = r;
 }
 
@@ -1221,13 +1228,544 @@ __global__ __launch_bounds__(UFO_DDA_BLOCK) void k_dda_seg(MapGeom g, u32 depth,
 	if (err) atomicOr(&ctl->err, err);
 }
 
+// Sum `steps` over the workgroup and store it as this workgroup's partial (k_merge_slabs adds them up).
+__device__ inline void blockStoreSteps(unsigned long long steps, unsigned long long* __restrict__ steps_part)
+{
+	__shared__ unsigned long long acc;
+	if (0 == threadIdx.x) acc = 0;
+	__syncthreads();
+	for (int o = 32; o > 0; o >>= 1) steps += __shfl_xor(steps, o);
+	if (0 == (threadIdx.x & 63u) && steps) atomicAdd(&acc, steps);
+	__syncthreads();
+	if (0 == threadIdx.x) steps_part[blockIdx.x] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2w: the ray walk for scans whose cell grid fits in LDS as ONE BIT PER CELL (Grid::layout 1) -- the fast
+// path of every LiDAR-sized scan. Same rays, same cells, same order as k_dda_seg (see there for the segment
+// construction); what changes is the cost of a step. A lone wave per SIMD issues one VALU instruction every
+// ~4-8 cycles whatever it waits for, so a ray's time is (steps) x (instructions per step), and the step is
+// cut from ~65 to ~30 instructions:
+//   * the cell is ONE linear bit index lin (x + rowBits*(y + ny*z)); a step adds one of three strides, the
+//     mark is ds_or(lds[lin>>5], 1<<(lin&31)) -- no unpacking, no block/child arithmetic;
+//   * the axis choice is three independent compares (x if tx<=ty && tx<=tz, else y if ty<=tz, else z:
+//     VEC3:244-251) instead of a min3 followed by equality tests, and the loop test min(t) <= dist
+//     (OMB:1300) is "any t <= dist": no dependent min chain;
+//   * a segment ends where the next lane's segment starts (a DDA path never revisits a cell), so counting
+//     the pops of the dominant axis disappears from the loop: one integer compare serves goal and hand-over.
+// ------------------------------------------------------------------------------------------------
+__device__ inline u32 pkToLin(u32 pk, u32 rowBits, u32 planeBits)
+{
+	return (pk & 1023u) + ((pk >> 10) & 1023u) * rowBits + (pk >> 20) * planeBits;
+}
+// checked mark of one cell (single-cell rays, clipped rays)
+__device__ inline u32 markBitChecked(const Grid& gr, u32* __restrict__ lds, u32 rowBits, u32 planeBits, i32 cx, i32 cy, i32 cz, u32 lim,
+                                     u32* oob)
+{
+	if ((u32)cx >= lim || (u32)cy >= lim || (u32)cz >= lim) {
+		++*oob;
+		return 0;
+	}
+	const i32 lx = cx - gr.base[0], ly = cy - gr.base[1], lz = cz - gr.base[2];
+	if ((u32)lx >= 2u * (u32)gr.nb[0] || (u32)ly >= 2u * (u32)gr.nb[1] || (u32)lz >= 2u * (u32)gr.nb[2]) return ERR_GRID_OOB;
+	const u32 lin = (u32)lx + (u32)ly * rowBits + (u32)lz * planeBits;
+	atomicOr(&lds[lin >> 5], 1u << (lin & 31u));
+	return 0;
+}
+
+__global__ __launch_bounds__(UFO_DDA_BLOCK) void k_walk(MapGeom g, u32 depth, Grid gr, u32* __restrict__ slabs,
+                                                        const RayState* __restrict__ rs, u32 seg_shift, const ScanCtl* ctl_in,
+                                                        ScanCtl* ctl, u32 dbg, unsigned long long* __restrict__ steps_part)
+{
+	extern __shared__ __attribute__((aligned(16))) u32 lds[];
+	const u32 lds_words = (u32)(gr.bytes >> 2);
+	{
+		uint4* l4 = reinterpret_cast<uint4*>(lds);
+		for (u32 j = threadIdx.x; j < (lds_words >> 2); j += blockDim.x) l4[j] = make_uint4(0, 0, 0, 0);
+	}
+	__syncthreads();
+	const u32 rowBits = gridRowBits(gr), planeBits = rowBits * 2u * (u32)gr.nb[1];
+	const u32 n = ctl_in->n_rays;
+	const u32 tid = blockIdx.x * blockDim.x + threadIdx.x;
+	const u32 nseg = 1u << seg_shift;
+	const u32 ray = tid >> seg_shift;
+	const u32 sg = tid & (nseg - 1u);
+	unsigned long long steps = 0;
+	u32 err = 0, oob = 0;
+	const u32 lim = 1u << (g.L - depth);
+	// ---- per-lane preparation (divergent) ----
+	bool go = false;
+	u32 lin = 0, glin = 0xFFFFFFFFu;
+	i32 dlx = 0, dly = 0, dlz = 0;
+	double tmx = 0, tmy = 0, tmz = 0, tdx = 0, tdy = 0, tdz = 0, dist = 0;
+	if (ray < n) {
+		const RayState* r = rs + ray;
+		const u32 status = r->status;
+		if (0 == sg && 1 == status) {
+			err |= markBitChecked(gr, lds, rowBits, planeBits, r->start[0], r->start[1], r->start[2], lim, &oob);
+			steps = 1;
+		} else if (0 == sg && 3 == status) {
+			// clipped ray (rare): sequential walk with every step checked, by this lane alone
+			i32 cx = r->start[0], cy = r->start[1], cz = r->start[2];
+			const i32 gx = r->goal[0], gy = r->goal[1], gz = r->goal[2];
+			const i32 sx = r->s[0], sy = r->s[1], sz = r->s[2];
+			double ax_ = r->tm[0], ay_ = r->tm[1], az_ = r->tm[2];
+			const double bx_ = r->td[0], by_ = r->td[1], bz_ = r->td[2], dd = r->dist;
+			const u64 budget = 3ull * (1ull << g.L) + 8;
+			bool more;
+			do {
+				if (++steps > budget) {
+					err |= ERR_RUNAWAY;
+					break;
+				}
+				err |= markBitChecked(gr, lds, rowBits, planeBits, cx, cy, cz, lim, &oob);
+				if (ax_ <= ay_) {
+					if (ax_ <= az_) {
+						cx += sx;
+						ax_ += bx_;
+					} else {
+						cz += sz;
+						az_ += bz_;
+					}
+				} else {
+					if (ay_ <= az_) {
+						cy += sy;
+						ay_ += by_;
+					} else {
+						cz += sz;
+						az_ += bz_;
+					}
+				}
+				more = (cx != gx || cy != gy || cz != gz) && (fmin(fmin(ax_, ay_), az_) <= dd);
+			} while (more);
+		} else if (2 == status) {
+			const u32 pk0 = r->pk0, gpk = r->gpk;
+			const i32 sx = r->s[0], sy = r->s[1], sz = r->s[2];
+			tmx = r->tm[0];
+			tmy = r->tm[1];
+			tmz = r->tm[2];
+			tdx = r->td[0];
+			tdy = r->td[1];
+			tdz = r->td[2];
+			dist = r->dist;
+			dlx = sx;
+			dly = sy * (i32)rowBits;
+			dlz = sz * (i32)planeBits;
+			glin = pkToLin(gpk, rowBits, planeBits);
+			// dominant axis a* and this lane's segment start k0 in pops of a* (k_dda_seg)
+			const u32 dxn = (u32)abs((i32)(gpk & 1023u) - (i32)(pk0 & 1023u));
+			const u32 dyn = (u32)abs((i32)((gpk >> 10) & 1023u) - (i32)((pk0 >> 10) & 1023u));
+			const u32 dzn = (u32)abs((i32)(gpk >> 20) - (i32)(pk0 >> 20));
+			const u32 ax = (dxn >= dyn && dxn >= dzn) ? 0u : (dyn >= dzn ? 1u : 2u);
+			const u32 dmax = ax == 0 ? dxn : (ax == 1 ? dyn : dzn);
+			const u32 w = (dmax + nseg - 1) >> seg_shift;  // >= 1 (the cells differ)
+			const u32 k0 = sg * w;
+			const bool active = (0 == sg) || (k0 < dmax);
+			if (active) {
+				lin = pkToLin(pk0, rowBits, planeBits);
+				if (sg > 0) {
+					// state right after the k0-th pop of axis a*: element A[k0-1] was popped, t_max_a* = A[k0]
+					double ta = ax == 0 ? tmx : (ax == 1 ? tmy : tmz);
+					const double tda = ax == 0 ? tdx : (ax == 1 ? tdy : tdz);
+					double v = ta;
+					for (u32 i = 0; i < k0; ++i) {
+						v = ta;
+						ta = ta + tda;
+					}
+					// other axes: elements popped before A[k0-1] (strictly smaller, or equal when the axis has priority)
+					u32 cb0 = 0, cb1 = 0;
+					const u32 b0 = ax == 0 ? 1u : 0u, b1 = ax == 2 ? 1u : 2u;  // the two other axes, ascending
+					double t0 = b0 == 0 ? tmx : tmy, d0 = b0 == 0 ? tdx : tdy;
+					double t1 = b1 == 1 ? tmy : tmz, d1 = b1 == 1 ? tdy : tdz;
+					const bool p0 = b0 < ax, p1 = b1 < ax;  // lower axis index wins ties (VEC3:244-251)
+					while (cb0 < 2048u && (p0 ? (t0 <= v) : (t0 < v))) {
+						t0 = t0 + d0;
+						++cb0;
+					}
+					while (cb1 < 2048u && (p1 ? (t1 <= v) : (t1 < v))) {
+						t1 = t1 + d1;
+						++cb1;
+					}
+					const i32 da = ax == 0 ? dlx : (ax == 1 ? dly : dlz);
+					const i32 db0 = b0 == 0 ? dlx : dly, db1 = b1 == 1 ? dly : dlz;
+					lin = lin + (u32)((i32)k0 * da + (i32)cb0 * db0 + (i32)cb1 * db1);
+					if (ax == 0) {
+						tmx = ta;
+						tmy = t0;
+						tmz = t1;
+					} else if (ax == 1) {
+						tmy = ta;
+						tmx = t0;
+						tmz = t1;
+					} else {
+						tmz = ta;
+						tmx = t0;
+						tmy = t1;
+					}
+				}
+				// loop condition at the segment start (OMB:1300); segment 0 starts the do-while unconditionally
+				go = (0 == sg) || ((lin != glin) && (tmx <= dist || tmy <= dist || tmz <= dist));
+			}
+		}
+	}
+	// ---- a segment ends where the next one starts (uniform: every lane of the wave takes part) ----
+	const u32 my_start = go ? lin : glin;  // a segment that does not start leaves the rest to its predecessor's own test
+	const u32 nxt = __shfl_down(my_start, 1);
+	const u32 end = (sg + 1u < nseg) ? nxt : glin;  // lanes of one ray are adjacent and never straddle a wave (nseg | 64)
+	// ---- the walk ----
+	const long long idist = __double_as_longlong(dist);
+	const u32 lin_first = lin;
+	u32 cnt = 0;  // uniform guard only; the lane's step count is the L1 distance it covered (below)
+	if (dbg & 2u) go = false;  // timing experiments only (ufomap_map_set_option "walk_dbg")
+	while (go) {
+		++cnt;
+		if (!(dbg & 1u)) atomicOr(&lds[lin >> 5], 1u << (lin & 31u));
+		const bool cxy = tmx <= tmy, cxz = tmx <= tmz, cyz = tmy <= tmz;
+		const bool selx = cxy & cxz;
+		const bool sely = !cxy & cyz;
+		const bool selz = !(selx | sely);
+		lin += (u32)(selx ? dlx : (sely ? dly : dlz));
+		const double nx = tmx + tdx, ny = tmy + tdy, nz = tmz + tdz;
+		tmx = selx ? nx : tmx;
+		tmy = sely ? ny : tmy;
+		tmz = selz ? nz : tmz;
+		// t_max values and dist are non-negative doubles: their order is the order of their bit patterns
+		const bool more = (__double_as_longlong(tmx) <= idist) | (__double_as_longlong(tmy) <= idist) | (__double_as_longlong(tmz) <= idist);
+		go = (lin != end) & more & (cnt < 4096u);
+	}
+	{
+		// every step moves one cell along one axis and never turns back: steps = L1 distance covered
+		const u32 ny = 2u * (u32)gr.nb[1];
+		const u32 r0 = lin_first / rowBits, r1 = lin / rowBits;
+		const i32 ddx = (i32)(lin % rowBits) - (i32)(lin_first % rowBits), ddy = (i32)(r1 % ny) - (i32)(r0 % ny),
+		          ddz = (i32)(r1 / ny) - (i32)(r0 / ny);
+		steps += (u32)(abs(ddx) + abs(ddy) + abs(ddz));
+	}
+	__syncthreads();
+	{
+		const uint4* l4 = reinterpret_cast<const uint4*>(lds);
+		uint4* out4 = reinterpret_cast<uint4*>(slabs) + (size_t)blockIdx.x * (lds_words >> 2);
+		const u32 n4 = lds_words >> 2;
+		for (u32 j = threadIdx.x; j < n4; j += blockDim.x) out4[j] = l4[j];
+	}
+	blockStoreSteps(steps, steps_part);
+	if (oob) atomicAdd(&ctl->n_oob, oob);
+	if (err) atomicOr(&ctl->err, err);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2c: ray set-up, segmentation and walk in ONE launch (bit-per-cell LDS grid; the default for LiDAR-sized
+// scans). k_walk's time is its longest ray: a lone wave issues a ~40-instruction step every ~190 cycles and
+// a 250-step ray takes 20 us, while the chip as a whole would need 4 us for all the steps. So the unit of
+// work becomes a SEGMENT of about K steps, whatever the ray:
+//   1. one lane per ray: clip, keys, computeRayInit (raySetup);
+//   2. the same lane cuts its ray at every w-th pop of the dominant axis (w chosen so that a segment has
+//      ~K steps) and builds each cut's exact state with the three independent addition chains of k_dda_seg --
+//      incrementally from cut to cut, so the whole ray costs one addition per step, not one step per step;
+//   3. segments go through an LDS queue to whichever lane is free: every lane walks ~K steps, waves are
+//      homogeneous, and a workgroup takes every nWG-th ray, so all workgroups see the same mix of rays.
+// Marks go to the workgroup's private LDS bit grid, handed over as a slab (k_merge_slabs), as in k_walk.
+// ------------------------------------------------------------------------------------------------
+#define UFO_CAST_BATCH 256u   // rays set up per round of a workgroup
+#define UFO_CAST_QCAP 1024u   // segment queue entries
+struct SegRec {
+	double tm[3];
+	u32 lin, end;
+	u32 ray;  // index into the round's ray constants | first << 31 (segment 0 of its ray: the do-while body runs unconditionally, OMB:1286)
+	u32 pad;
+};
+struct RayConst {
+	double td[3], dist;
+	i32 dl[3];
+	u32 glin;
+};
+struct RayHdr {
+	double tm[3];
+	u32 lin0, ax, w, nseg;  // nseg == 0: nothing to cut (not a "safe" ray)
+	u32 off, pad;
+};
+#define UFO_CAST_LDS_EXTRA (UFO_CAST_BATCH * (sizeof(RayConst) + sizeof(RayHdr)) + UFO_CAST_QCAP * sizeof(SegRec) + 128u)
+
+__global__ __launch_bounds__(512) void k_cast(MapGeom g, D3 sensor, u32 depth, Grid gr, u32* __restrict__ slabs,
+                                              const D3* __restrict__ ray_end, u32 k_min, const ScanCtl* ctl_in, ScanCtl* ctl,
+                                              unsigned long long* __restrict__ steps_part)
+{
+	extern __shared__ __attribute__((aligned(16))) u32 lds[];
+	const u32 lds_words = (u32)(gr.bytes >> 2);
+	RayConst* rc = reinterpret_cast<RayConst*>(lds + lds_words);
+	RayHdr* hd = reinterpret_cast<RayHdr*>(rc + UFO_CAST_BATCH);
+	SegRec* q = reinterpret_cast<SegRec*>(hd + UFO_CAST_BATCH);
+	u32* sh = reinterpret_cast<u32*>(q + UFO_CAST_QCAP);  // [0..7], [16..23]: per-wave partial sums
+	{
+		uint4* l4 = reinterpret_cast<uint4*>(lds);
+		for (u32 j = threadIdx.x; j < (lds_words >> 2); j += blockDim.x) l4[j] = make_uint4(0, 0, 0, 0);
+	}
+	const u32 rowBits = gridRowBits(gr), planeBits = rowBits * 2u * (u32)gr.nb[1];
+	const u32 n = ctl_in->n_rays;
+	const u32 lim = 1u << (g.L - depth);
+	const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+	const u32 nwaves = min(8u, (blockDim.x + 63u) >> 6);
+	unsigned long long steps = 0;
+	u32 err = 0, oob = 0;
+	// rays of this workgroup: blockIdx.x, blockIdx.x + gridDim.x, ... in rounds of UFO_CAST_BATCH
+	const u32 mine = (n > blockIdx.x) ? (n - blockIdx.x + gridDim.x - 1) / gridDim.x : 0u;
+	for (u32 base = 0; base < mine; base += UFO_CAST_BATCH) {
+		__syncthreads();  // previous round's queue and constants are no longer read (also orders the LDS zeroing)
+		const u32 t = threadIdx.x;
+		const bool have = t < UFO_CAST_BATCH && base + t < mine;
+		// ---- 1. one lane per ray: clip, keys, computeRayInit ----
+		u32 l1 = 0, dmax = 0, ax = 0, status = 0, lin0 = 0;
+		if (have) {
+			RayState r;
+			raySetup(g, sensor, depth, gr, ray_end[blockIdx.x + (size_t)(base + t) * gridDim.x], r);
+			status = r.status;
+			if (1 == r.status) {
+				err |= markBitChecked(gr, lds, rowBits, planeBits, r.start[0], r.start[1], r.start[2], lim, &oob);
+				steps += 1;
+			} else if (3 == r.status) {
+				// clipped ray (rare): sequential walk with every step checked, by this lane alone
+				i32 cx = r.start[0], cy = r.start[1], cz = r.start[2];
+				double ax_ = r.tm[0], ay_ = r.tm[1], az_ = r.tm[2];
+				const u64 budget = 3ull * (1ull << g.L) + 8;
+				u64 st = 0;
+				bool more;
+				do {
+					if (++st > budget) {
+						err |= ERR_RUNAWAY;
+						break;
+					}
+					err |= markBitChecked(gr, lds, rowBits, planeBits, cx, cy, cz, lim, &oob);
+					if (ax_ <= ay_) {
+						if (ax_ <= az_) {
+							cx += r.s[0];
+							ax_ += r.td[0];
+						} else {
+							cz += r.s[2];
+							az_ += r.td[2];
+						}
+					} else {
+						if (ay_ <= az_) {
+							cy += r.s[1];
+							ay_ += r.td[1];
+						} else {
+							cz += r.s[2];
+							az_ += r.td[2];
+						}
+					}
+					more = (cx != r.goal[0] || cy != r.goal[1] || cz != r.goal[2]) && (fmin(fmin(ax_, ay_), az_) <= r.dist);
+				} while (more);
+				steps += st > budget ? budget : st;
+			} else if (2 == r.status) {
+				const u32 dxn = (u32)abs((i32)(r.gpk & 1023u) - (i32)(r.pk0 & 1023u));
+				const u32 dyn = (u32)abs((i32)((r.gpk >> 10) & 1023u) - (i32)((r.pk0 >> 10) & 1023u));
+				const u32 dzn = (u32)abs((i32)(r.gpk >> 20) - (i32)(r.pk0 >> 20));
+				ax = (dxn >= dyn && dxn >= dzn) ? 0u : (dyn >= dzn ? 1u : 2u);
+				dmax = ax == 0 ? dxn : (ax == 1 ? dyn : dzn);
+				l1 = dxn + dyn + dzn;
+				lin0 = pkToLin(r.pk0, rowBits, planeBits);
+				RayConst c;
+				c.td[0] = r.td[0];
+				c.td[1] = r.td[1];
+				c.td[2] = r.td[2];
+				c.dist = r.dist;
+				c.dl[0] = r.s[0];
+				c.dl[1] = (i32)r.s[1] * (i32)rowBits;
+				c.dl[2] = (i32)r.s[2] * (i32)planeBits;
+				c.glin = pkToLin(r.gpk, rowBits, planeBits);
+				rc[t] = c;
+				hd[t].tm[0] = r.tm[0];
+				hd[t].tm[1] = r.tm[1];
+				hd[t].tm[2] = r.tm[2];
+			}
+		}
+		// ---- 2. segment length for this round: about K steps, and the queue must hold every segment ----
+		u32 tot = l1, cntr = (2 == status) ? 1u : 0u;
+		for (int o = 32; o > 0; o >>= 1) {
+			tot += __shfl_xor(tot, o);
+			cntr += __shfl_xor(cntr, o);
+		}
+		if (0 == lane && wave < 8u) {
+			sh[wave] = tot;
+			sh[16 + wave] = cntr;
+		}
+		__syncthreads();
+		u32 total = 0, nray2 = 0;
+		for (u32 wv = 0; wv < nwaves; ++wv) {
+			total += sh[wv];
+			nray2 += sh[16 + wv];
+		}
+		// a ray of l1 steps cut every w = max(1, floor(dmax*K/l1)) pops has at most 2*l1/K + 1 segments
+		u32 K = k_min;
+		{
+			const u32 room = UFO_CAST_QCAP - nray2;  // >= QCAP - BATCH > 0
+			const u32 need = (2u * total + room - 1u) / room;
+			K = max(K, need);
+		}
+		u32 w = 1, nseg = 0;
+		if (2 == status) {
+			w = (u32)(((u64)dmax * K) / l1);
+			if (w < 1u) w = 1u;
+			nseg = (dmax + w - 1u) / w;  // >= 1 (start and goal differ)
+		}
+		__syncthreads();  // sh[] is reused below
+		u32 incl = nseg;
+		for (int o = 1; o < 64; o <<= 1) {
+			const u32 v = __shfl_up(incl, o);
+			if ((int)lane >= o) incl += v;
+		}
+		if (63u == lane && wave < 8u) sh[wave] = incl;
+		__syncthreads();
+		u32 off = incl - nseg, nsegs = 0;
+		for (u32 wv = 0; wv < nwaves; ++wv) {
+			const u32 v = sh[wv];
+			if (wv < wave) off += v;
+			nsegs += v;
+		}
+		if (t < UFO_CAST_BATCH) {
+			hd[t].lin0 = lin0;
+			hd[t].ax = ax;
+			hd[t].w = w;
+			hd[t].nseg = nseg;
+			hd[t].off = off;
+		}
+		for (u32 si = threadIdx.x; si < nsegs; si += blockDim.x) q[si].lin = 0;  // cut cells are summed up from two lanes
+		__syncthreads();
+		// ---- 3. cut states from the three independent addition chains (k_dda_seg), two lanes per ray: each
+		//         owns one of the non-dominant axes and runs the dominant chain a* alongside ----
+		// after k0 = j*w pops of a*: element A[k0-1] (= v) was popped and t_max_a* = A[k0]; of the other axis the
+		// elements before v were popped (strictly smaller, or equal when the axis has priority: the lower axis
+		// index wins ties, VEC3:244-251) -- their count moves the cut's cell.
+		for (u32 idx = threadIdx.x; idx < 2u * UFO_CAST_BATCH; idx += blockDim.x) {
+			const u32 ry = idx & (UFO_CAST_BATCH - 1u), role = idx / UFO_CAST_BATCH;
+			const RayHdr h = hd[ry];
+			if (0 == h.nseg) continue;
+			const RayConst c = rc[ry];
+			if (0 == role) {
+				SegRec rec;
+				rec.tm[0] = h.tm[0];
+				rec.tm[1] = h.tm[1];
+				rec.tm[2] = h.tm[2];
+				rec.lin = h.lin0;
+				rec.end = c.glin;
+				rec.ray = ry | 0x80000000u;
+				rec.pad = 0;
+				q[h.off] = rec;
+			}
+			const u32 axd = h.ax;
+			const u32 b = (0 == role) ? (axd == 0 ? 1u : 0u) : (axd == 2 ? 1u : 2u);
+			const bool pri = b < axd;
+			double ta = axd == 0 ? h.tm[0] : (axd == 1 ? h.tm[1] : h.tm[2]), v = ta;
+			const double tda = axd == 0 ? c.td[0] : (axd == 1 ? c.td[1] : c.td[2]);
+			const i32 da = axd == 0 ? c.dl[0] : (axd == 1 ? c.dl[1] : c.dl[2]);
+			double tb = b == 0 ? h.tm[0] : (b == 1 ? h.tm[1] : h.tm[2]);
+			const double dbt = b == 0 ? c.td[0] : (b == 1 ? c.td[1] : c.td[2]);
+			const i32 dbl = b == 0 ? c.dl[0] : (b == 1 ? c.dl[1] : c.dl[2]);
+			u32 ka = 0, cb = 0;
+			for (u32 j = 1; j < h.nseg; ++j) {
+				const u32 k0 = j * h.w;  // < dmax
+				for (; ka < k0; ++ka) {
+					v = ta;
+					ta = ta + tda;
+				}
+				// pop while the condition holds, four candidates at a time (same sequence of additions)
+				while (cb < 2048u) {
+					const double s1 = tb + dbt, s2 = s1 + dbt, s3 = s2 + dbt;
+					const bool c0 = pri ? (tb <= v) : (tb < v);
+					if (!c0) break;
+					const bool c1 = pri ? (s1 <= v) : (s1 < v), c2 = pri ? (s2 <= v) : (s2 < v), c3 = pri ? (s3 <= v) : (s3 < v);
+					if (c1 & c2 & c3) {
+						tb = s3 + dbt;
+						cb += 4u;
+					} else {
+						tb = c1 ? (c2 ? s3 : s2) : s1;
+						cb += 1u + (c1 ? (c2 ? 2u : 1u) : 0u);
+						break;
+					}
+				}
+				SegRec* o = &q[h.off + j];
+				if (0 == role) {
+					o->tm[axd] = ta;
+					o->end = c.glin;
+					o->ray = ry;
+				}
+				o->tm[b] = tb;
+				atomicAdd(&o->lin, (0 == role ? h.lin0 + (u32)((i32)k0 * da) : 0u) + (u32)((i32)cb * dbl));
+			}
+		}
+		__syncthreads();
+		// 3c. a segment stops where the next one of its ray starts
+		for (u32 si = threadIdx.x; si + 1u < nsegs; si += blockDim.x)
+			if (!(q[si + 1u].ray & 0x80000000u)) q[si].end = q[si + 1u].lin;
+		__syncthreads();
+		// ---- 4. every lane walks segments ----
+		for (u32 si = threadIdx.x; si < nsegs; si += blockDim.x) {
+			const SegRec rec = q[si];
+			const RayConst c = rc[rec.ray & 0x7FFFFFFFu];
+			double tmx = rec.tm[0], tmy = rec.tm[1], tmz = rec.tm[2];
+			const double tdx = c.td[0], tdy = c.td[1], tdz = c.td[2];
+			const long long idist = __double_as_longlong(c.dist);
+			const i32 dlx = c.dl[0], dly = c.dl[1], dlz = c.dl[2];
+			const u32 end = rec.end;
+			u32 lin = rec.lin;
+			// loop condition at the segment start (OMB:1300); segment 0 starts the do-while unconditionally.
+			// t_max values and dist are non-negative doubles: their order is the order of their bit patterns
+			bool go = (0 != (rec.ray & 0x80000000u)) ||
+			          ((lin != c.glin) && ((__double_as_longlong(tmx) <= idist) | (__double_as_longlong(tmy) <= idist) |
+			                               (__double_as_longlong(tmz) <= idist)));
+			const u32 lin_first = lin;
+			u32 cnt = 0;  // uniform guard only
+			while (go) {
+				++cnt;
+				atomicOr(&lds[lin >> 5], 1u << (lin & 31u));
+				const bool cxy = tmx <= tmy, cxz = tmx <= tmz, cyz = tmy <= tmz;
+				const bool selx = cxy & cxz;
+				const bool sely = !cxy & cyz;
+				const bool selz = !(selx | sely);
+				lin += (u32)(selx ? dlx : (sely ? dly : dlz));
+				const double nx = tmx + tdx, ny = tmy + tdy, nz = tmz + tdz;
+				tmx = selx ? nx : tmx;
+				tmy = sely ? ny : tmy;
+				tmz = selz ? nz : tmz;
+				const bool more =
+				    (__double_as_longlong(tmx) <= idist) | (__double_as_longlong(tmy) <= idist) | (__double_as_longlong(tmz) <= idist);
+				go = (lin != end) & more & (cnt < 4096u);
+			}
+			// every step moves one cell along one axis and never turns back: steps = L1 distance covered
+			const u32 ny2 = 2u * (u32)gr.nb[1];
+			const u32 r0 = lin_first / rowBits, r1 = lin / rowBits;
+			const i32 ddx = (i32)(lin % rowBits) - (i32)(lin_first % rowBits), ddy = (i32)(r1 % ny2) - (i32)(r0 % ny2),
+			          ddz = (i32)(r1 / ny2) - (i32)(r0 / ny2);
+			steps += (u32)(abs(ddx) + abs(ddy) + abs(ddz));
+		}
+	}
+	__syncthreads();
+	{
+		const uint4* l4 = reinterpret_cast<const uint4*>(lds);
+		uint4* out4 = reinterpret_cast<uint4*>(slabs) + (size_t)blockIdx.x * (lds_words >> 2);
+		const u32 n4 = lds_words >> 2;
+		for (u32 j = threadIdx.x; j < n4; j += blockDim.x) out4[j] = l4[j];
+	}
+	blockStoreSteps(steps, steps_part);
+	if (oob) atomicAdd(&ctl->n_oob, oob);
+	if (err) atomicOr(&ctl->err, err);
+}
+
 // OR the per-workgroup slabs of the ray kernels (LDS-grid mode) into grid M. Workgroup = 64 columns of
 // 16 bytes x 16 slab lanes: every thread ORs the slabs s = lane, lane+16, ... of its column (independent
 // loads, 1 KiB contiguous per slab per wave), the 16 partial results are combined through LDS.
-__global__ __launch_bounds__(1024) void k_merge_slabs(const uint4* __restrict__ slabs, u32 n_slabs, u32 n4, uint4* __restrict__ grid)
+// steps_part (optional): per-workgroup step counts of k_walk / k_cast, folded into ScanCtl::n_steps here --
+// one atomic per wave on that single word would cost the ray kernel ~12 ns each, serialised.
+__global__ __launch_bounds__(1024) void k_merge_slabs(const uint4* __restrict__ slabs, u32 n_slabs, u32 n4, uint4* __restrict__ grid,
+                                                      const unsigned long long* __restrict__ steps_part, ScanCtl* ctl)
 {
 	__shared__ uint4 part[16][64];
 	const u32 col = threadIdx.x & 63u, sl = threadIdx.x >> 6;
+	if (steps_part && 0 == blockIdx.x && threadIdx.x < 64u) {
+		unsigned long long v = 0;
+		for (u32 s = threadIdx.x; s < n_slabs; s += 64u) v += steps_part[s];
+		for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+		if (0 == threadIdx.x && v) atomicAdd(&ctl->n_steps, v);
+	}
 	for (u32 j0 = blockIdx.x * 64u; j0 < n4; j0 += gridDim.x * 64u) {
 		const u32 j = j0 + col;
 		uint4 acc = make_uint4(0, 0, 0, 0);
@@ -1335,6 +1873,85 @@ __global__ __launch_bounds__(256) void k_grid_codes(MapGeom g, Grid gr, const u3
 			// cell coordinate = key >> depth; Code(key) >> 3*depth == morton(cell) for keys < 2^21
 			u64 code = morton3(x, y, z);
 			u32 pos = atomicAdd(&ctl->n_codes, 1u);
+			if (pos < cap) codes[pos] = code;
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3 / stage export for Grid::layout 1 (one bit per cell): a thread takes one 32-cell word of an even row
+// (y, z even) together with the same word of rows (y+1, z), (y, z+1), (y+1, z+1) = 16 node blocks.
+// ------------------------------------------------------------------------------------------------
+template <bool MERGED>
+__global__ __launch_bounds__(256) void k_extract_bits(MapGeom g, Grid gr, const u32* __restrict__ grid, u32 which,
+                                                      Entry* __restrict__ entries, u32 cap, ScanCtl* ctl, HitBlocks hb)
+{
+	const u32 rowW = gridRowBits(gr) >> 5;
+	const u32 nby = (u32)gr.nb[1], nbz = (u32)gr.nb[2];
+	const u64 nitems = (u64)rowW * nby * nbz * 16u;  // one thread per node block; 16 consecutive threads share four words
+	const u32 level = gr.depth + 1;
+	const u64 stride = (u64)gridDim.x * blockDim.x;
+	const u64 iters = (nitems + stride - 1) / stride;  // uniform trip count: every lane reaches the wave-aggregated append
+	u64 it_ = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	for (u64 it = 0; it < iters; ++it, it_ += stride) {
+		u32 mb = 0, bx = 0, by = 0, bz = 0;
+		if (it_ < nitems) {
+			const u32 j2 = ((u32)it_ & 15u) * 2u;
+			const u64 wi = it_ >> 4;
+			const u32 wx = (u32)(wi % rowW);
+			const u64 r = wi / rowW;
+			by = (u32)(r % nby);
+			bz = (u32)(r / nby);
+			bx = wx * 16u + (j2 >> 1);
+			const u64 row00 = ((u64)(2 * bz) * (2 * nby) + 2 * by) * rowW + wx;
+			const u32 w00 = grid[row00], w10 = grid[row00 + rowW], w01 = grid[row00 + (u64)2 * nby * rowW],
+			          w11 = grid[row00 + (u64)2 * nby * rowW + rowW];
+			mb = ((w00 >> j2) & 3u) | (((w10 >> j2) & 3u) << 2) | (((w01 >> j2) & 3u) << 4) | (((w11 >> j2) & 3u) << 6);
+		}
+		const bool have = 0 != mb;
+		const u32 my = blockAppend(&ctl->n_entries[which], have);  // one atomic per workgroup (uniform trip count)
+		if (!have || my >= cap) continue;
+		u32 ax = (u32)((gr.base[0] >> 1) + (i32)bx), ay = (u32)((gr.base[1] >> 1) + (i32)by), az = (u32)((gr.base[2] >> 1) + (i32)bz);
+		u64 p = morton3(ax, ay, az) & ((1ULL << (3 * (g.L - level))) - 1ULL);
+		Entry e;
+		e.lk = (1ULL << (3 * (g.L - level))) | p;
+		e.hit = which ? 0 : (u8)mb;
+		e.miss = which ? (u8)mb : 0;
+		e.level = (u8)level;
+		e.c_last = (u8)(31 - __clz((int)mb));  // misses: ascending code order -> highest child
+		e.t_last = 0;
+		if (MERGED) {
+			e.miss = (u8)mb;
+			const u32 hs = hitBlocksFind(hb, p);
+			if (hs != 0xFFFFFFFFu) {
+				const u32 hm = hb.mask[hs];
+				e.hit = (u8)hm;
+				hb.mask[hs] = hm | UFO_HB_TAKEN;
+			} else {
+				e.hit = 0;
+			}
+		}
+		entries[my] = e;
+	}
+}
+
+__global__ __launch_bounds__(256) void k_grid_codes_bits(MapGeom g, Grid gr, const u32* __restrict__ grid, u64* __restrict__ codes,
+                                                         u32 cap, ScanCtl* ctl)
+{
+	const u32 rowW = gridRowBits(gr) >> 5;
+	const u32 ny = 2u * (u32)gr.nb[1];
+	const u64 nwords = (u64)rowW * ny * 2u * (u32)gr.nb[2];
+	for (u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x; w < nwords; w += (u64)gridDim.x * blockDim.x) {
+		u32 m = grid[w];
+		const u32 wx = (u32)(w % rowW);
+		const u64 r = w / rowW;
+		const u32 ly = (u32)(r % ny), lz = (u32)(r / ny);
+		while (m) {
+			const u32 bit = __ffs(m) - 1;
+			m &= m - 1;
+			const u32 x = (u32)(gr.base[0] + (i32)(wx * 32u + bit)), y = (u32)(gr.base[1] + (i32)ly), z = (u32)(gr.base[2] + (i32)lz);
+			const u64 code = morton3(x, y, z);
+			const u32 pos = atomicAdd(&ctl->n_codes, 1u);
 			if (pos < cap) codes[pos] = code;
 		}
 	}

@@ -147,6 +147,9 @@ struct ufomap_map {
 	int opt_dda_mode = -1;
 	int opt_dda_seg = 1;  // 0 = force the lane-per-ray kernel
 	int opt_dda_block = 0, opt_dda_lanes = 0;  // 0 = automatic
+	int opt_cast = 1, opt_cast_wgs = 0, opt_cast_k = 32;  // fused ray kernel: on/off, workgroups (0 = 256), steps per segment
+	int opt_walk_dbg = 0; // timing experiments: 1 = no marks, 2 = no walk (results wrong)
+	int opt_bits = 1;     // 0 = never use the bit-per-cell grid / k_walk
 	int opt_merge = 1;    // 0 = hits and misses as two separate passes over the tree also at insert depth 0
 	u64 opt_entry_guess = 0;
 	uint64_t counts[8] = {0};
@@ -380,7 +383,7 @@ int makeGrid(const i32 mn[3], const i32 mx[3], u32 depth, Grid* gr)
 		bytes *= (u64)nb;
 	}
 	gr->depth = depth;
-	gr->pad = 0;
+	gr->layout = 0;
 	gr->bytes = (bytes + 15) & ~15ull;  // whole uint4 words (k_dda's LDS copy is read 16 B at a time)
 	return UFOMAP_OK;
 }
@@ -553,8 +556,12 @@ int extractLists(ufomap_map* m, u64 capH, u64 capM, bool zero_counts, bool merge
 		HitBlocks hb{capH ? m->b_hb_keys.as<u64>() : nullptr, m->b_hb_mask.as<u32>(), m->b_hb_time.as<u32>(), m->hb_cap_mask};
 		if (capM) {
 			ProfScope ps(m, "k_extract");
-			hipLaunchKernelGGL(k_extract<true>, gridFor(m->gridM.bytes >> 2, 256, 2048), dim3(256), 0, m->cs, m->g, m->gridM,
-			                   m->b_gridM.as<u32>(), 0u, ent_h, (u32)(capH + capM), ctl, hb);
+			if (1 == m->gridM.layout)
+				hipLaunchKernelGGL(k_extract_bits<true>, gridFor(m->gridM.bytes, 256, 2048), dim3(256), 0, m->cs, m->g, m->gridM,
+				                   m->b_gridM.as<u32>(), 0u, ent_h, (u32)(capH + capM), ctl, hb);
+			else
+				hipLaunchKernelGGL(k_extract<true>, gridFor(m->gridM.bytes >> 2, 256, 2048), dim3(256), 0, m->cs, m->g, m->gridM,
+				                   m->b_gridM.as<u32>(), 0u, ent_h, (u32)(capH + capM), ctl, hb);
 		}
 		if (capH) {
 			ProfScope ps(m, "k_extract_hits");
@@ -571,8 +578,12 @@ int extractLists(ufomap_map* m, u64 capH, u64 capM, bool zero_counts, bool merge
 	}
 	if (capM) {
 		ProfScope ps(m, "k_extract");
-		hipLaunchKernelGGL(k_extract<false>, gridFor(m->gridM.bytes >> 2, 256, 2048), dim3(256), 0, m->cs, m->g, m->gridM,
-		                   m->b_gridM.as<u32>(), 1u, ent_m, (u32)capM, ctl, HitBlocks{nullptr, nullptr, nullptr, 0});
+		if (1 == m->gridM.layout)
+			hipLaunchKernelGGL(k_extract_bits<false>, gridFor(m->gridM.bytes, 256, 2048), dim3(256), 0, m->cs, m->g, m->gridM,
+			                   m->b_gridM.as<u32>(), 1u, ent_m, (u32)capM, ctl, HitBlocks{nullptr, nullptr, nullptr, 0});
+		else
+			hipLaunchKernelGGL(k_extract<false>, gridFor(m->gridM.bytes >> 2, 256, 2048), dim3(256), 0, m->cs, m->g, m->gridM,
+			                   m->b_gridM.as<u32>(), 1u, ent_m, (u32)capM, ctl, HitBlocks{nullptr, nullptr, nullptr, 0});
 	}
 	return UFOMAP_OK;
 }
@@ -723,6 +734,16 @@ int scanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, const 
 		return fail(UFOMAP_ERR_CAPACITY, "hit bounding box too large for the scan grid");
 	if (m->haveM && makeGrid(mmn, mmx, (u32)depth, &m->gridM))
 		return fail(UFOMAP_ERR_CAPACITY, "ray bounding box too large for the scan grid (runaway ray?)");
+	if (m->haveM && !simple && m->opt_dda_seg != 0 && m->opt_bits != 0 && m->opt_dda_mode <= 0) {
+		// one bit per cell (rows padded to 32 cells) when that fits in LDS: the fast walk kernel (k_walk)
+		Grid& gr = m->gridM;
+		const bool packed = 2 * gr.nb[0] < 1023 && 2 * gr.nb[1] < 1023 && 2 * gr.nb[2] < 1023;
+		const u64 bytes1 = (u64)(gridRowBits(gr) >> 3) * (2ull * (u64)gr.nb[1]) * (2ull * (u64)gr.nb[2]);
+		if (packed && bytes1 <= UFO_DDA_LDSGRID_MAX) {
+			gr.layout = 1;
+			gr.bytes = (bytes1 + 15) & ~15ull;
+		}
+	}
 	u64 gbytes = m->haveM ? m->gridM.bytes : 0;  // hits are grouped through a hash, only grid M is dense
 	if (gbytes > m->scratch_limit)
 		return fail(UFOMAP_ERR_CAPACITY, "scan dedup grids need " + std::to_string(gbytes) + " bytes > scratch limit " +
@@ -764,11 +785,29 @@ int scanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, const 
 		dim3 gr((u32)((lanes + blk - 1) / blk));
 		u32* dda_out = m->b_gridM.as<u32>();
 		if (mode == DDA_LDSGRID) {
-			HIP_TRY(m->b_slabs.reserve((size_t)gr.x * m->gridM.bytes));
+			HIP_TRY(m->b_slabs.reserve((size_t)gr.x * m->gridM.bytes + (size_t)gr.x * 8));
 			dda_out = m->b_slabs.as<u32>();
 		} else {
 			HIP_TRY(hipMemsetAsync(m->b_gridM.p, 0, m->gridM.bytes, m->cs));
 		}
+		// fused set-up + segment queue + walk (k_cast) when the bit grid and its queue fit in LDS
+		const bool cast = 1 == m->gridM.layout && m->opt_cast != 0 && m->gridM.bytes + UFO_CAST_LDS_EXTRA <= (160u << 10) - 512u;
+		if (cast) {
+			const u32 cblk = (m->opt_dda_block >= 256 && m->opt_dda_block <= 512) ? (u32)m->opt_dda_block : 512u;
+			u32 nwg = m->opt_cast_wgs > 0 ? (u32)m->opt_cast_wgs : 256u;
+			nwg = std::max<u32>(1u, std::min<u32>(nwg, (n_rays + 63u) / 64u));
+			HIP_TRY(m->b_slabs.reserve((size_t)nwg * m->gridM.bytes + (size_t)nwg * 8));
+			unsigned long long* sp = reinterpret_cast<unsigned long long*>(m->b_slabs.as<char>() + (size_t)nwg * m->gridM.bytes);
+			{
+				ProfScope ps(m, "k_dda");
+				hipLaunchKernelGGL(k_cast, dim3(nwg), dim3(cblk), (size_t)m->gridM.bytes + UFO_CAST_LDS_EXTRA, m->cs, m->g, sensor, (u32)depth,
+				                   m->gridM, m->b_slabs.as<u32>(), m->b_ray_end.as<D3>(), (u32)std::max(8, m->opt_cast_k), ctl, ctl, sp);
+			}
+			ProfScope ps(m, "k_merge_slabs");
+			const u32 n4 = (u32)(m->gridM.bytes >> 4);
+			hipLaunchKernelGGL(k_merge_slabs, dim3(std::min<u32>((n4 + 63) / 64, 1024)), dim3(1024), 0, m->cs, m->b_slabs.as<uint4>(), nwg, n4,
+			                   m->b_gridM.as<uint4>(), sp, ctl);
+		} else {
 		if (seg) {
 			HIP_TRY(m->b_rays.reserve((size_t)n_rays * sizeof(RayState)));
 			ProfScope ps(m, "k_ray_setup");
@@ -783,7 +822,12 @@ int scanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, const 
 #define UFO_LAUNCH_SEG(MODE)                                                                                    \
 	hipLaunchKernelGGL((k_dda_seg<MODE>), gr, dim3(blk), lds, m->cs, m->g, (u32)depth, m->gridM, dda_out, \
 	                   m->b_rays.as<RayState>(), seg_shift, ctl, ctl)
-		if (seg) {
+		if (1 == m->gridM.layout) {
+			// (layout 1 is only chosen when seg is possible and the bit grid fits in LDS)
+			hipLaunchKernelGGL(k_walk, gr, dim3(blk), lds, m->cs, m->g, (u32)depth, m->gridM, dda_out, m->b_rays.as<RayState>(), seg_shift,
+			                   ctl, ctl, (u32)m->opt_walk_dbg,
+			                   reinterpret_cast<unsigned long long*>(m->b_slabs.as<char>() + (size_t)gr.x * m->gridM.bytes));
+		} else if (seg) {
 			if (mode == DDA_LDSGRID) UFO_LAUNCH_SEG(DDA_LDSGRID);
 			else UFO_LAUNCH_SEG(DDA_FILTER);
 		} else if (simple) {
@@ -802,8 +846,12 @@ int scanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, const 
 			ProfScope ps(m, "k_merge_slabs");
 			const u32 n4 = (u32)(m->gridM.bytes >> 4);
 			hipLaunchKernelGGL(k_merge_slabs, dim3(std::min<u32>((n4 + 63) / 64, 1024)), dim3(1024), 0, m->cs, m->b_slabs.as<uint4>(), gr.x,
-			                   n4, m->b_gridM.as<uint4>());
+			                   n4, m->b_gridM.as<uint4>(),
+			                   1 == m->gridM.layout ? reinterpret_cast<const unsigned long long*>(m->b_slabs.as<char>() + (size_t)gr.x * m->gridM.bytes)
+			                                        : (const unsigned long long*)nullptr,
+			                   ctl);
 		}
+		}  // !cast
 	}
 
 	*n_hits_out = n_hits;
@@ -825,8 +873,12 @@ int extractPhase(ufomap_map* m, u32 n_hits, u32 n_rays, u64* capH_out, u64* capM
 	if (capM > guess) {
 		// counting pass (cap = 0 writes nothing), then the exact size
 		ProfScope ps(m, "k_extract_count");
-		hipLaunchKernelGGL(k_extract<false>, gridFor(m->gridM.bytes >> 2, 256, 2048), dim3(256), 0, m->cs, m->g, m->gridM,
-		                   m->b_gridM.as<u32>(), 1u, (Entry*)nullptr, 0u, ctl, HitBlocks{nullptr, nullptr, nullptr, 0});
+		if (1 == m->gridM.layout)
+			hipLaunchKernelGGL(k_extract_bits<false>, gridFor(m->gridM.bytes, 256, 2048), dim3(256), 0, m->cs, m->g, m->gridM,
+			                   m->b_gridM.as<u32>(), 1u, (Entry*)nullptr, 0u, ctl, HitBlocks{nullptr, nullptr, nullptr, 0});
+		else
+			hipLaunchKernelGGL(k_extract<false>, gridFor(m->gridM.bytes >> 2, 256, 2048), dim3(256), 0, m->cs, m->g, m->gridM,
+			                   m->b_gridM.as<u32>(), 1u, (Entry*)nullptr, 0u, ctl, HitBlocks{nullptr, nullptr, nullptr, 0});
 		HIP_TRY(hipMemcpyAsync(m->h_ctl, m->b_ctl.p, sizeof(ScanCtl), hipMemcpyDeviceToHost, m->cs));
 		HIP_TRY(hipStreamSynchronize(m->cs));
 		capM = m->h_ctl->n_entries[1];
@@ -976,6 +1028,8 @@ ufomap_map* ufomap_map_create(double resolution, unsigned depth_levels, int auto
 		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dda<true, DDA_FILTER>), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds);
 		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dda_seg<DDA_LDSGRID>), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds);
 		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dda_seg<DDA_FILTER>), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_walk), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cast), hipFuncAttributeMaxDynamicSharedMemorySize, (160 << 10) - 512);
 	}
 	for (int a = 0; a < 3; ++a) {
 		m->min_change[a] = g.hs[g.L];  // resetMinMaxChangeDetection (occupancy_map_base.h:806-810)
@@ -1297,8 +1351,12 @@ size_t ufomap_map_last_misses(ufomap_map* m, uint64_t* codes, size_t cap)
 	for (int pass = 0; pass < 2; ++pass) {
 		if (hipMemsetAsync(&ctl->n_codes, 0, 4, m->stream) != hipSuccess) return (size_t)-1;
 		if (pass && m->b_codes.reserve((size_t)total * 8) != hipSuccess) return (size_t)-1;
-		hipLaunchKernelGGL(k_grid_codes, gridFor(m->gridM.bytes >> 2, 256, 8192), dim3(256), 0, m->stream, m->g, m->gridM,
-		                   m->b_gridM.as<u32>(), pass ? m->b_codes.as<u64>() : (u64*)nullptr, pass ? total : 0u, ctl);
+		if (1 == m->gridM.layout)
+			hipLaunchKernelGGL(k_grid_codes_bits, gridFor(m->gridM.bytes >> 2, 256, 8192), dim3(256), 0, m->stream, m->g, m->gridM,
+			                   m->b_gridM.as<u32>(), pass ? m->b_codes.as<u64>() : (u64*)nullptr, pass ? total : 0u, ctl);
+		else
+			hipLaunchKernelGGL(k_grid_codes, gridFor(m->gridM.bytes >> 2, 256, 8192), dim3(256), 0, m->stream, m->g, m->gridM,
+			                   m->b_gridM.as<u32>(), pass ? m->b_codes.as<u64>() : (u64*)nullptr, pass ? total : 0u, ctl);
 		if (hipMemcpyAsync(&total, &ctl->n_codes, 4, hipMemcpyDeviceToHost, m->stream) != hipSuccess) return (size_t)-1;
 		if (hipStreamSynchronize(m->stream) != hipSuccess) return (size_t)-1;
 		if (0 == total) break;
@@ -1543,6 +1601,16 @@ int ufomap_map_set_option(ufomap_map* m, const char* key, long long value)
 		m->opt_dda_mode = (int)value;
 	} else if (0 == strcmp(key, "dda_seg")) {
 		m->opt_dda_seg = value ? 1 : 0;
+	} else if (0 == strcmp(key, "cast")) {
+		m->opt_cast = value ? 1 : 0;
+	} else if (0 == strcmp(key, "cast_wgs")) {
+		m->opt_cast_wgs = (int)value;
+	} else if (0 == strcmp(key, "cast_k")) {
+		m->opt_cast_k = (int)value;
+	} else if (0 == strcmp(key, "walk_dbg")) {
+		m->opt_walk_dbg = (int)value;
+	} else if (0 == strcmp(key, "dda_bits")) {
+		m->opt_bits = value ? 1 : 0;
 	} else if (0 == strcmp(key, "dda_block")) {
 		m->opt_dda_block = (int)value;
 	} else if (0 == strcmp(key, "dda_lanes")) {
