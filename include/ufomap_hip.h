@@ -156,6 +156,11 @@ int ufomap_map_scan_keys(ufomap_map* m, const double sensor_origin[3], const dou
                          ufomap_keys_info* info);
 int ufomap_map_get_keys(ufomap_map* m, void* d_dst, size_t cap_entries, const ufomap_keys_info* info);
 int ufomap_map_apply_keys(ufomap_map* m, const void* d_entries, const ufomap_keys_info* info);
+/* The update lists of n_lists scans (insert depth 0; list j = what get_keys returned for scan j) applied in
+ * order 0..n_lists-1 with ONE walk of the tree for the whole batch. Same map as n_lists calls of
+ * ufomap_map_apply_keys, i.e. as the reference integrating the scans one after the other
+ * (occupancy_map_base.h:340-417 called n_lists times). */
+int ufomap_map_apply_keys_batch(ufomap_map* m, const void* const* d_lists, const ufomap_keys_info* infos, int n_lists);
 
 /* Diagnostic overrides for tests: "dda_mode" (-1 auto; 1 / 2 force the LDS-filter / direct variants of
  * the ray kernel on grids that would fit in LDS), "entry_guess" (cap of the guessed update-list size, to

@@ -212,6 +212,34 @@ def test_split_path_equals_sequential_c4():
     assert same_dump(split.inner(), o.inner()), "split path: inner nodes differ"
 
 
+@pytest.mark.parametrize("chunk", [8, 3])
+def test_batch_apply_equals_sequential_c4(chunk):
+    """BASELINE config C4: the update lists of a batch of scans applied with ONE walk of the tree
+    (ufomap_map_apply_keys_batch) give the map the reference builds by integrating the scans one after
+    the other -- values, inner nodes and the history-dependent leaf structure; two rounds over the same
+    poses so that clamping and collapse are exercised across batches."""
+    import torch
+    from ufomap_amd import scans, OccupancyMap
+    g, o = _maps(resolution=0.16)
+    scanner = OccupancyMap(0.16)  # never integrates: only casts rays
+    bufs, infos = [], []
+    for rnd in range(2):
+        for s0 in range(0, 8, chunk):
+            bufs.clear(); infos.clear()
+            for s in range(s0, min(8, s0 + chunk)):
+                origin, xyz, _ = scans.lidar64(beams=32, azimuths=1024, origin=scans.lidar_pose(s), seed=100 + s)
+                d = torch.from_numpy(xyz).cuda()
+                info = scanner.scan_keys(origin, d.data_ptr(), xyz.shape[0], 20.0, 0, True)
+                buf = torch.empty((info.n_hit + info.n_miss) * 16, dtype=torch.uint8, device="cuda")
+                scanner.get_keys(buf.data_ptr(), buf.numel() // 16, info)
+                bufs.append(buf); infos.append(info)
+                o.insert(origin, xyz, max_range=20.0, discrete=True)
+            g.apply_keys_batch([b.data_ptr() for b in bufs], infos)
+            what = f"batch round {rnd} chunk from {s0}"  # (the change AABB belongs to the scanning side)
+            assert same_dump(g.leaves(True), o.leaves(True)), what + ": leaves differ"
+            assert same_dump(g.inner(), o.inner()), what + ": inner nodes differ"
+
+
 def test_batch_integrator_rccl_world1():
     """BatchIntegrator on HBM tensors through the nccl (RCCL) backend with a single rank: the same code
     path the 8-GPU run takes, minus the peers."""

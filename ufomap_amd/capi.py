@@ -25,7 +25,7 @@ SYMBOLS = [
     "ufomap_map_write", "ufomap_map_minmax_change", "ufomap_map_reset_minmax_change", "ufomap_map_stats",
     "ufomap_map_last_hits", "ufomap_map_last_misses", "ufomap_map_last_counts",
     "ufomap_map_set_profiling", "ufomap_map_kernel_times", "ufomap_map_reset_kernel_times",
-    "ufomap_map_scan_keys", "ufomap_map_get_keys", "ufomap_map_apply_keys", "ufomap_map_stream", "ufomap_map_debug", "ufomap_map_set_option",
+    "ufomap_map_scan_keys", "ufomap_map_get_keys", "ufomap_map_apply_keys", "ufomap_map_apply_keys_batch", "ufomap_map_stream", "ufomap_map_debug", "ufomap_map_set_option",
 ]
 
 _lib = None
@@ -103,6 +103,7 @@ def load():
     lib.ufomap_map_scan_keys.argtypes = [vp, f64p, vp, sz, dbl, C.c_uint, C.c_int, C.c_int, C.POINTER(KeysInfo)]
     lib.ufomap_map_get_keys.argtypes = [vp, vp, sz, C.POINTER(KeysInfo)]
     lib.ufomap_map_apply_keys.argtypes = [vp, vp, C.POINTER(KeysInfo)]
+    lib.ufomap_map_apply_keys_batch.argtypes = [vp, C.POINTER(C.c_void_p), C.POINTER(KeysInfo), C.c_int]
     lib.ufomap_map_debug.argtypes = [vp, u64p, C.c_int]
     lib.ufomap_map_set_option.argtypes = [vp, C.c_char_p, C.c_longlong]
     lib.ufomap_map_stream.restype = vp

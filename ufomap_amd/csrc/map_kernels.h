@@ -372,7 +372,7 @@ __device__ inline u32 blendColor(const MapGeom& g, u32 cur, u32 upd, float occ_o
 // node's value depends on the final values beneath it only, and its collapse state on the LAST update
 // beneath it only (last-update chain above) -- and "last" is well defined across the two phases: every miss
 // comes after every hit (the reference joins the hit thread before the first miss lands, OMB:1361).
-#define UFO_MISS_TIME (1ull << 33)  // later than any hit (hit time = point index < 2^32)
+#define UFO_MISS_TIME (1ull << 29)  // later than any hit of the scan (hit time = point index < 2^29)
 __global__ __launch_bounds__(256) void k_apply_leaf(Table t, MapGeom g, const Entry* __restrict__ entries,
                                                     const u32* n_entries_p, const u32* __restrict__ ent_slot, float upd_hit,
                                                     float upd_miss, u32 mode, u32 phase, HitHash hh,
@@ -444,6 +444,85 @@ __global__ __launch_bounds__(256) void k_apply_leaf(Table t, MapGeom g, const En
 		// update alone changed it (its upward walk reached the parent even if the net change is nil)
 		const bool changed = writeToParent(t, g, s, e.lk, sm);
 		markDirty(t, changed || reachchg, t.parent[s], wl, &pc->wl_cnt[2]);
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// S3b batch of scans (update lists of several scans, insert depth 0; ufomap_map_apply_keys_batch): the tree is
+// walked ONCE for the whole batch. The lists are applied to the voxels in the reference's order -- scan by
+// scan, hits before misses -- by one light launch each (k_apply_values: values only). A block remembers its
+// last update (child, the child's value just before, time) in the record arrays of ITS OWN slot, which are
+// otherwise unused at level 1 (the children of a level-1 block are voxels and publish nothing); the touched
+// blocks are queued once, and k_finish_leaf then does for each what k_apply_leaf does at its end. Time orders
+// the whole batch: (scan << 30) | (miss << 29) | point index, so the last-update chain above works unchanged.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_apply_values(Table t, MapGeom g, const Entry* __restrict__ entries, const u32* n_entries_p,
+                                                      const u32* __restrict__ ent_slot, float upd, u32 is_hit, u32 phase, u64 time_hi,
+                                                      u32* __restrict__ wl, ScanCtl::PhaseCtr* pc, const ScanCtl* ctl)
+{
+	const u32 n = *n_entries_p;
+	if (ctl->err) return;
+	const u32 stride = gridDim.x * blockDim.x;
+	const u32 iters = (n + stride - 1) / stride;  // uniform trip count for the wave-aggregated append
+	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	for (u32 it = 0; it < iters; ++it, i += stride) {
+		bool first = false;
+		u32 s = 0;
+		if (i < n) {
+			const Entry e = entries[i];
+			s = ent_slot[i];
+			float4* po = reinterpret_cast<float4*>(t.occ + 8 * (size_t)s);
+			float4 a = po[0], b = po[1];
+			float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+			const u32 mask = is_hit ? e.hit : e.miss;
+			const int c_last = (int)e.c_last;  // hits: latest first-point (cloud order); misses: highest code
+			float v_old_last = 0.f;
+#pragma unroll
+			for (int c = 0; c < 8; ++c) {
+				if (c == c_last) v_old_last = v[c];
+				if ((mask >> c) & 1) v[c] = clampAdd(v[c], upd, g.cmin, g.cmax);
+			}
+			po[0] = make_float4(v[0], v[1], v[2], v[3]);
+			po[1] = make_float4(v[4], v[5], v[6], v[7]);
+			t.lu_occ[8 * (size_t)s + c_last] = v_old_last;
+			t.tmax[s] = (UFO_TAG(phase) << 40) | ((time_hi | (is_hit ? (u64)e.t_last : 0ull)) << 3) | (u64)c_last;
+			first = !(atomicOr(&t.flags[s], F_DIRTY) & F_DIRTY);
+		}
+		const u32 pos = waveAppend(&pc->wl_cnt[1], first);
+		if (first) wl[pos] = s;
+	}
+}
+
+__global__ __launch_bounds__(256) void k_finish_leaf(Table t, MapGeom g, const u32* __restrict__ wl_in, u32* __restrict__ wl_out, u32 phase,
+                                                     ScanCtl::PhaseCtr* pc, const ScanCtl* ctl)
+{
+	if (ctl->err) return;
+	const u32 n = pc->wl_cnt[1];
+	const u32 stride = gridDim.x * blockDim.x;
+	const u32 iters = (n + stride - 1) / stride;
+	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	for (u32 it = 0; it < iters; ++it, i += stride) {
+		bool want = false;
+		u32 par = NONE;
+		if (i < n) {
+			const u32 s = wl_in[i];
+			atomicAnd(&t.flags[s], ~F_DIRTY);
+			const u64 lk = t.keys[s];
+			const u64 tv = t.tmax[s];
+			const int c_last = (int)(tv & 7);
+			const u64 time = (tv >> 3) & ((1ull << 37) - 1ull);
+			const Summ sm = blockSummary(t, g, s, 1, 0);
+			// summary just before the block's last update (level 1 is always reached: OMB:1128 starts at 1)
+			const Summ pre = blockSummary(t, g, s, 1, 0, c_last, t.lu_occ[8 * (size_t)s + c_last], 0, g.color ? t.rgb[8 * (size_t)s + c_last] : 0u);
+			const bool reachchg = !sameSumm(g, pre, sm);
+			publishLast(t, g, s, lk, phase, reachchg, pre);
+			carryTime(t, s, lk, phase, time);
+			if (sm.collapsible) collapseBlock(t, s, lk);
+			const bool changed = writeToParent(t, g, s, lk, sm);
+			want = changed || reachchg;
+			par = t.parent[s];
+		}
+		markDirty(t, want, par, wl_out, &pc->wl_cnt[2]);
 	}
 }
 

@@ -396,6 +396,27 @@ u64 levelBound(const i32 nb[3], u32 shift)
 	return vol > 1e18L ? (u64)1e18 : (u64)vol;
 }
 
+// updateParents (OMB:1126-1133) from level `first` upward: wide levels one launch each, the narrow rest in one
+// launch. bound(l) = upper bound of the queued blocks of level l; the level-l worklist is b_wl[l & 1].
+template <typename F>
+void propagateLevels(ufomap_map* m, u32 first, F bound, ScanCtl::PhaseCtr* pc, u32 which)
+{
+	ScanCtl* ctl = m->b_ctl.as<ScanCtl>();
+	u32* wl[2] = {m->b_wl0.as<u32>(), m->b_wl1.as<u32>()};
+	u32 l = first;
+	for (; l <= m->g.L; ++l) {
+		const u64 b = bound(l);
+		if (b <= 2048) break;
+		ProfScope ps(m, "k_propagate");
+		hipLaunchKernelGGL(k_propagate, gridFor(b, 256, 1024), dim3(256), 0, m->cs, m->t, m->g, wl[l & 1], wl[(l + 1) & 1], l, m->scan_id, pc,
+		                   ctl);
+	}
+	if (l <= m->g.L) {
+		ProfScope ps(m, "k_propagate_tail");
+		hipLaunchKernelGGL(k_propagate_tail, dim3(1), dim3(1024), 0, m->cs, m->t, m->g, wl[0], wl[1], l, m->scan_id, pc, ctl, which * 32u);
+	}
+}
+
 // One phase of the map update: entries of one level -> ensure, init, apply, propagate.
 // `cap` is the capacity of the entry buffer (the device-side count may be smaller; if it is larger
 // k_ensure raises ERR_ENTRIES and nothing is applied).
@@ -476,19 +497,7 @@ int applyEntries(ufomap_map* m, const Entry* d_entries, u32 cap, u32 which, u32 
 			                   m->scan_id, wl[(level + 1) & 1], pc, ctl);
 		}
 	}
-	// updateParents (OMB:1126-1133): wide levels one launch each, the narrow rest in one launch
-	u32 l = level + 1;
-	for (; l <= m->g.L; ++l) {
-		u64 bound = lvlBound(l - level);
-		if (bound <= 2048) break;
-		ProfScope ps(m, "k_propagate");
-		hipLaunchKernelGGL(k_propagate, gridFor(bound, 256, 1024), dim3(256), 0, m->cs, m->t, m->g, wl[l & 1], wl[(l + 1) & 1], l,
-		                   m->scan_id, pc, ctl);
-	}
-	if (l <= m->g.L) {
-		ProfScope ps(m, "k_propagate_tail");
-		hipLaunchKernelGGL(k_propagate_tail, dim3(1), dim3(1024), 0, m->cs, m->t, m->g, wl[0], wl[1], l, m->scan_id, pc, ctl, which * 32u);
-	}
+	propagateLevels(m, level + 1, [&](u32 l) { return lvlBound(l - level); }, pc, which);
 	HIP_TRY(hipGetLastError());
 	return UFOMAP_OK;
 }
@@ -1494,6 +1503,129 @@ int ufomap_map_apply_keys(ufomap_map* m, const void* d_entries, const ufomap_key
 	if (rc) return rc;
 	rc = applyEntries(m, ent + nh, nm, 1, info->depth + 1, info->nb_miss, miss, nullptr, false, nh, nm);
 	if (rc) return rc;
+	m->pending = true;
+	HIP_TRY(hipStreamSynchronize(m->stream));
+	return finishPending(m);
+}
+
+int ufomap_map_apply_keys_batch(ufomap_map* m, const void* const* d_lists, const ufomap_keys_info* infos, int n_lists)
+{
+	if (!m || !d_lists || !infos || n_lists < 0) return fail(UFOMAP_ERR_INVALID, "null argument");
+	if (m->g.color) return fail(UFOMAP_ERR_UNSUPPORTED, "update lists carry no colour: apply_keys works on OccupancyMap only");
+	if (n_lists > 128) return fail(UFOMAP_ERR_INVALID, "at most 128 update lists per batch");
+	for (int j = 0; j < n_lists; ++j)
+		if (0 != infos[j].depth) return fail(UFOMAP_ERR_UNSUPPORTED, "apply_keys_batch: insert depth 0 only (apply deeper scans one by one)");
+	HIP_TRY(hipSetDevice(m->device));
+	{
+		int prc = ufomap_map_wait(m);
+		if (prc) return prc;
+	}
+	u64 total = 0;
+	for (int j = 0; j < n_lists; ++j) total += (u64)infos[j].n_hit + infos[j].n_miss;
+	if (0 == total) return UFOMAP_OK;
+	if (total > 0x7FFFFFFFull) return fail(UFOMAP_ERR_CAPACITY, "update lists exceed 2^31 entries");
+	m->cs = m->stream;
+	ScanCtl init;
+	memset(&init, 0, sizeof(init));
+	for (int a = 0; a < 3; ++a) {
+		init.aabb_min[a] = ~0ull;
+		init.aabb_max[a] = 0ull;
+	}
+	*m->h_ctl = init;
+	HIP_TRY(hipMemcpyAsync(m->b_ctl.p, m->h_ctl, sizeof(ScanCtl), hipMemcpyHostToDevice, m->stream));
+	ScanCtl* ctl = m->b_ctl.as<ScanCtl>();
+	ScanCtl::PhaseCtr* pc = &ctl->ph[0];
+	// sub-lists in application order: scan 0 hits, scan 0 misses, scan 1 hits, ...; their counts live on the device
+	struct Sub {
+		const Entry* ent;
+		u32 n, off, is_hit, scan;
+		const i32* nb;
+	};
+	std::vector<Sub> subs;
+	std::vector<u32> h_cnt;
+	u32 off = 0;
+	u64 new_bound = 0;
+	for (int j = 0; j < n_lists; ++j) {
+		const Entry* e = static_cast<const Entry*>(d_lists[j]);
+		const u32 nh = infos[j].n_hit, nm = infos[j].n_miss;
+		if (nh) {
+			subs.push_back(Sub{e, nh, off, 1u, (u32)j, infos[j].nb_hit});
+			new_bound += blockBound(m, nh, infos[j].nb_hit, 1);
+			off += nh;
+		}
+		if (nm) {
+			subs.push_back(Sub{e + nh, nm, off, 0u, (u32)j, infos[j].nb_miss});
+			new_bound += blockBound(m, nm, infos[j].nb_miss, 1);
+			off += nm;
+		}
+	}
+	for (const Sub& sb : subs) h_cnt.push_back(sb.n);
+	HIP_TRY(m->b_crec.reserve(h_cnt.size() * 4 + 16));
+	HIP_TRY(hipMemcpyAsync(m->b_crec.p, h_cnt.data(), h_cnt.size() * 4, hipMemcpyHostToDevice, m->stream));
+	const u32* d_cnt = m->b_crec.as<u32>();
+	// node table: every entry new is a true upper bound; on a warm map count the missing blocks before growing
+	m->scan_new_bound = new_bound;
+	{
+		const u64 cap = (u64)m->t.mask + 1;
+		if ((m->used_est + new_bound) * 5 > cap * 3) {
+			const bool cheap = (m->used_est + new_bound) * 2 <= (1ull << 22);
+			if (!cheap) {
+				u32* d_miss = reinterpret_cast<u32*>(&ctl->dbg[60]);
+				HIP_TRY(hipMemsetAsync(d_miss, 0, 8, m->cs));
+				for (size_t k = 0; k < subs.size(); ++k)
+					hipLaunchKernelGGL(k_count_missing, gridFor(subs[k].n), dim3(256), 0, m->cs, m->t, subs[k].ent, d_cnt + k, subs[k].n, d_miss);
+				int rc = readCtl(m);
+				if (rc) return rc;
+				u32 cnt = 0;
+				memcpy(&cnt, &m->h_ctl->dbg[60], 4);
+				u64 b = 0;
+				for (const Sub& sb : subs) b += blockBound(m, std::min<u64>(cnt, sb.n), sb.nb, 1);
+				m->scan_new_bound = new_bound = std::min(new_bound, b);
+			}
+			if ((m->used_est + new_bound) * 5 > cap * 3) {
+				const u64 want = (m->used_est + new_bound) * 2;
+				if (want > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
+				int rc = growTable(m, nextPow2(want));
+				if (rc) return rc;
+			}
+		}
+	}
+	m->scan_id += 1;  // ONE phase for the whole batch
+	const u32 newcap = (u32)std::min<u64>(new_bound, 0xFFFFFFFFull);
+	HIP_TRY(m->b_ent_slot.reserve((size_t)total * 4));
+	HIP_TRY(m->b_newlist.reserve((size_t)newcap * 4));
+	HIP_TRY(m->b_wl0.reserve((size_t)total * 4 + 32));
+	HIP_TRY(m->b_wl1.reserve((size_t)total * 4 + 32));
+	u32* wl[2] = {m->b_wl0.as<u32>(), m->b_wl1.as<u32>()};
+	for (size_t k = 0; k < subs.size(); ++k) {
+		ProfScope ps(m, "k_ensure");
+		hipLaunchKernelGGL(k_ensure, gridFor(subs[k].n), dim3(256), 0, m->cs, m->t, m->g, subs[k].ent, d_cnt + k, 0xFFFFFFFFu, 0xFFFFFFFFu, m->scan_id,
+		                   m->b_ent_slot.as<u32>() + subs[k].off, m->b_newlist.as<u32>(), newcap, pc, ctl);
+	}
+	{
+		ProfScope ps(m, "k_init_new");
+		hipLaunchKernelGGL(k_init_new, gridFor(std::min<u64>(newcap, total)), dim3(256), 0, m->cs, m->t, m->g, m->b_newlist.as<u32>(), newcap,
+		                   m->scan_id, pc, ctl);
+	}
+	const float miss = (float)m->g.miss_log;  // insert depth 0 (OMB:311)
+	for (size_t k = 0; k < subs.size(); ++k) {
+		ProfScope ps(m, "k_apply_values");
+		const u64 time_hi = ((u64)subs[k].scan << 30) | (subs[k].is_hit ? 0ull : (1ull << 29));
+		hipLaunchKernelGGL(k_apply_values, gridFor(subs[k].n), dim3(256), 0, m->cs, m->t, m->g, subs[k].ent, d_cnt + k,
+		                   m->b_ent_slot.as<u32>() + subs[k].off, subs[k].is_hit ? m->g.hit : miss, subs[k].is_hit, m->scan_id, time_hi, wl[1], pc,
+		                   ctl);
+	}
+	{
+		ProfScope ps(m, "k_finish_leaf");
+		hipLaunchKernelGGL(k_finish_leaf, gridFor(total, 256, 1024), dim3(256), 0, m->cs, m->t, m->g, wl[1], wl[0], m->scan_id, pc, ctl);
+	}
+	auto bound = [&](u32 l) {
+		u64 b = 0;
+		for (const Sub& sb : subs) b += std::min<u64>(sb.n, levelBound(sb.nb, l - 1));
+		return b;
+	};
+	propagateLevels(m, 2, bound, pc, 0);
+	HIP_TRY(hipGetLastError());
 	m->pending = true;
 	HIP_TRY(hipStreamSynchronize(m->stream));
 	return finishPending(m);

@@ -4,7 +4,8 @@ One process per GPU (``torch.distributed``, backend ``nccl`` = RCCL over xGMI; `
 tests).  Per batch every rank ray-casts ITS scan -- the part of the path that never reads the map --
 into an *update list* (16-byte records, ``include/ufomap_hip.h``), the lists are exchanged with ONE
 padded all-gather (plus a tiny all-gather of their headers), and every rank applies the lists of
-ranks 0..N-1 in rank order to its replica of the map.  Applying in order reproduces the reference's
+ranks 0..N-1 in rank order to its replica of the map -- with ONE walk of the tree for the whole batch
+(``ufomap_map_apply_keys_batch``).  Applying in order reproduces the reference's
 sequential integration bit-exactly on every replica; a float all-reduce of log-odds deltas would not
 (clamping after every hit phase and every miss phase is not associative).
 
@@ -67,6 +68,16 @@ class MapBackend:
         if info.n_hit + info.n_miss:
             self.m.apply_keys(payload.data_ptr(), info)
 
+    def apply_all(self, headers, lists):
+        """All ranks' lists in rank order. Depth-0 scans go through ONE walk of the tree
+        (``ufomap_map_apply_keys_batch``); a batch with deeper scans is applied list by list."""
+        infos = [KeysInfo.from_list(headers[r].tolist()) for r in range(len(lists))]
+        if all(k.depth == 0 for k in infos) and len(infos) <= 128:
+            self.m.apply_keys_batch([lists[r].data_ptr() if lists[r].numel() else 0 for r in range(len(lists))], infos)
+        else:
+            for r in range(len(lists)):
+                self.apply(r, headers[r], lists[r])
+
 
 class BatchIntegrator:
     """``integrate`` = one batch step: scan locally, exchange, apply every rank's list in rank order."""
@@ -80,6 +91,9 @@ class BatchIntegrator:
         headers, lists = exchange_lists(payload, header, self.group)
         if payload.is_cuda:
             torch.cuda.current_stream(payload.device).synchronize()  # RCCL ran on torch's stream, apply runs on the map's
-        for r in range(len(lists)):
-            self.backend.apply(r, headers[r], lists[r])
+        if hasattr(self.backend, "apply_all"):
+            self.backend.apply_all(headers, lists)
+        else:
+            for r in range(len(lists)):
+                self.backend.apply(r, headers[r], lists[r])
         return headers

@@ -117,6 +117,15 @@ class OccupancyMapBase:
     def apply_keys(self, d_entries_ptr, info):
         capi.check(self._lib.ufomap_map_apply_keys(self._h, d_entries_ptr, C.byref(info)))
 
+    def apply_keys_batch(self, d_entries_ptrs, infos):
+        """Update lists of several depth-0 scans, applied in list order with one walk of the tree."""
+        n = len(infos)
+        ptrs = (C.c_void_p * max(n, 1))(*[C.c_void_p(int(p)) for p in d_entries_ptrs])
+        arr = (capi.KeysInfo * max(n, 1))()
+        for i, k in enumerate(infos):
+            arr[i] = k
+        capi.check(self._lib.ufomap_map_apply_keys_batch(self._h, ptrs, arr, n))
+
     def insertPointCloudDone(self):
         return bool(capi.check(self._lib.ufomap_map_done(self._h)))
 
