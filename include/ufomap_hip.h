@@ -149,7 +149,8 @@ typedef struct ufomap_keys_info {
 	int32_t nb_hit[3];      /* extent of the scan's hit grid in node blocks (sizes the node table) */
 	int32_t nb_miss[3];
 	uint32_t depth;         /* insert depth of the scan: miss records are level depth+1 */
-	uint32_t reserved;
+	uint32_t reserved;      /* bit 0: merged list (depth 0): n_hit records that carry the hit AND the miss mask of
+	                           their block, n_miss = 0 -- what scan_keys produces for depth-0 scans */
 } ufomap_keys_info;
 int ufomap_map_scan_keys(ufomap_map* m, const double sensor_origin[3], const double* d_xyz, size_t n,
                          double max_range, unsigned depth, int discrete, int simple_ray_casting,
@@ -159,7 +160,10 @@ int ufomap_map_apply_keys(ufomap_map* m, const void* d_entries, const ufomap_key
 /* The update lists of n_lists scans (insert depth 0; list j = what get_keys returned for scan j) applied in
  * order 0..n_lists-1 with ONE walk of the tree for the whole batch. Same map as n_lists calls of
  * ufomap_map_apply_keys, i.e. as the reference integrating the scans one after the other
- * (occupancy_map_base.h:340-417 called n_lists times). */
+ * (occupancy_map_base.h:340-417 called n_lists times). With ufomap_map_set_option(m, "async_apply", 1) the call
+ * returns after enqueueing (the lists must stay valid until the next call on this map that joins the update:
+ * apply_keys*, insert*, wait, any reader); ufomap_map_scan_keys of the NEXT batch does not join it -- ray casting
+ * never reads the map -- so it overlaps with the update. */
 int ufomap_map_apply_keys_batch(ufomap_map* m, const void* const* d_lists, const ufomap_keys_info* infos, int n_lists);
 
 /* Diagnostic overrides for tests: "dda_mode" (-1 auto; 1 / 2 force the LDS-filter / direct variants of

@@ -1,7 +1,7 @@
 """The N>1 path on CPU: world_size-2 gloo processes run BatchIntegrator with a stub backend.
 
-What is checked is everything that is NOT a kernel: the header/payload all-gather with ragged list
-lengths (padding, trimming), and that every rank applies the lists of ranks 0..N-1 in rank order with
+What is checked is everything that is NOT a kernel: the single all-gather of header + list slots with ragged list
+lengths (padding, trimming, agreed capacity growth), and that every rank applies the lists of ranks 0..N-1 in rank order with
 the exact bytes the producing rank emitted -- the property that makes the replicas identical to
 sequential integration."""
 import hashlib
@@ -47,7 +47,7 @@ def _worker(rank, world, port, sizes, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     be = StubBackend(rank, sizes)
-    bi = BatchIntegrator(backend=be, group=dist.group.WORLD)
+    bi = BatchIntegrator(backend=be, group=dist.group.WORLD, initial_cap=1024)  # small: the growth path runs too
     for _ in range(len(sizes)):
         bi.integrate(np.zeros(3), 0, 0, 20.0, 0, True)
     q.put((rank, be.applied))

@@ -185,15 +185,18 @@ def test_runaway_ray_is_refused_and_map_unchanged():
     assert len(g.leaves()[0]) == 0
 
 
-def test_split_path_equals_sequential_c4():
+@pytest.mark.parametrize("merged_lists", [1, 0])
+def test_split_path_equals_sequential_c4(merged_lists):
     """scan_keys + apply_keys (the multi-GPU split of the path) applied in scan order on one GPU equals
-    sequential insertPointCloudDiscrete of the same 8 scans (BASELINE config C4), bit for bit."""
+    sequential insertPointCloudDiscrete of the same 8 scans (BASELINE config C4), bit for bit -- with the
+    merged per-scan list (one record per block) and with separate hit and miss lists."""
     import torch
     from ufomap_amd import OccupancyMap, scans
     from ufomap_amd.dist import ENTRY_BYTES
     seq, o = _maps(resolution=0.16)
     split = OccupancyMap(0.16)
     scanner = OccupancyMap(0.16)  # plays "another GPU": only ever scans, its own map stays empty
+    scanner.set_option("merge_phases", merged_lists)
     lists = []
     for s in range(8):
         origin, xyz, _ = scans.lidar64(origin=scans.lidar_pose(s), seed=100 + s, beams=32, azimuths=1024)

@@ -454,11 +454,12 @@ __global__ __launch_bounds__(256) void k_apply_leaf(Table t, MapGeom g, const En
 // last update (child, the child's value just before, time) in the record arrays of ITS OWN slot, which are
 // otherwise unused at level 1 (the children of a level-1 block are voxels and publish nothing); the touched
 // blocks are queued once, and k_finish_leaf then does for each what k_apply_leaf does at its end. Time orders
-// the whole batch: (scan << 30) | (miss << 29) | point index, so the last-update chain above works unchanged.
+// the whole batch: (scan << 30) | (miss << 29) | point index, so the last-update chain above works unchanged. A list is a scan's
+// hits, its misses, or both merged (one record per block with both masks, as k_apply_leaf mode 2).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_apply_values(Table t, MapGeom g, const Entry* __restrict__ entries, const u32* n_entries_p,
-                                                      const u32* __restrict__ ent_slot, float upd, u32 is_hit, u32 phase, u64 time_hi,
-                                                      u32* __restrict__ wl, ScanCtl::PhaseCtr* pc, const ScanCtl* ctl)
+                                                      const u32* __restrict__ ent_slot, float upd_hit, float upd_miss, u32 mode, u32 phase,
+                                                      u64 time_hi, u32* __restrict__ wl, ScanCtl::PhaseCtr* pc, const ScanCtl* ctl)
 {
 	const u32 n = *n_entries_p;
 	if (ctl->err) return;
@@ -474,18 +475,30 @@ __global__ __launch_bounds__(256) void k_apply_values(Table t, MapGeom g, const 
 			float4* po = reinterpret_cast<float4*>(t.occ + 8 * (size_t)s);
 			float4 a = po[0], b = po[1];
 			float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-			const u32 mask = is_hit ? e.hit : e.miss;
-			const int c_last = (int)e.c_last;  // hits: latest first-point (cloud order); misses: highest code
+			// mode as in k_apply_leaf: 0 = a list of misses, 1 = a list of hits, 2 = one scan's merged list
+			const u32 hmask = (0 != mode) ? e.hit : 0u;
+			const u32 mmask = (1 != mode) ? e.miss : 0u;
+			const bool last_is_miss = 0 != mmask;
+			const int c_last = (2 == mode && last_is_miss) ? (31 - __clz((int)mmask)) : (int)e.c_last;
+			const u64 t_last = last_is_miss ? UFO_MISS_TIME : (u64)e.t_last;
 			float v_old_last = 0.f;
 #pragma unroll
 			for (int c = 0; c < 8; ++c) {
-				if (c == c_last) v_old_last = v[c];
-				if ((mask >> c) & 1) v[c] = clampAdd(v[c], upd, g.cmin, g.cmax);
+				float x = v[c];
+				if ((hmask >> c) & 1) {
+					if (c == c_last && !last_is_miss) v_old_last = x;
+					x = clampAdd(x, upd_hit, g.cmin, g.cmax);
+				}
+				if ((mmask >> c) & 1) {
+					if (c == c_last) v_old_last = x;  // last_is_miss
+					x = clampAdd(x, upd_miss, g.cmin, g.cmax);
+				}
+				v[c] = x;
 			}
 			po[0] = make_float4(v[0], v[1], v[2], v[3]);
 			po[1] = make_float4(v[4], v[5], v[6], v[7]);
 			t.lu_occ[8 * (size_t)s + c_last] = v_old_last;
-			t.tmax[s] = (UFO_TAG(phase) << 40) | ((time_hi | (is_hit ? (u64)e.t_last : 0ull)) << 3) | (u64)c_last;
+			t.tmax[s] = (UFO_TAG(phase) << 40) | ((time_hi | t_last) << 3) | (u64)c_last;
 			first = !(atomicOr(&t.flags[s], F_DIRTY) & F_DIRTY);
 		}
 		const u32 pos = waveAppend(&pc->wl_cnt[1], first);

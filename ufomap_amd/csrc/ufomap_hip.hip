@@ -137,6 +137,8 @@ struct ufomap_map {
 	// state of the last integration
 	bool pending = false;
 	int pending_status = UFOMAP_OK;
+	int cur_set = 0, pending_set = 0;  // which hand-over set is current / holds the control block of the pending integration
+	int opt_async_apply = 0;           // ufomap_map_apply_keys_batch returns after enqueueing (join at the next call / wait)
 	Grid gridH{}, gridM{};
 	bool haveH = false, haveM = false;
 	u32 last_depth = 0;
@@ -344,6 +346,7 @@ void swapSets(ufomap_map* m)
 	std::swap(m->h_ctl, m->alt.h_ctl);
 	std::swap(m->hh_mask, m->alt.hh_mask);
 	for (int k = 0; k < 8; ++k) std::swap(m->counts[k], m->alt.counts[k]);
+	m->cur_set ^= 1;
 }
 
 int readCtl(ufomap_map* m)
@@ -901,13 +904,21 @@ int extractPhase(ufomap_map* m, u32 n_hits, u32 n_rays, u64* capH_out, u64* capM
 }
 
 // join the integration whose map phase was enqueued by the previous call (its hand-over set is `alt` now)
+int finishPendingAnySet(ufomap_map* m)
+{
+	if (!m->pending) return UFOMAP_OK;
+	if (m->pending_set == m->cur_set) return finishPending(m);
+	swapSets(m);
+	int rc = finishPending(m);
+	swapSets(m);
+	return rc;
+}
+
 int joinPrevious(ufomap_map* m)
 {
 	if (!m->pending) return UFOMAP_OK;
 	HIP_TRY(hipStreamSynchronize(m->stream));
-	swapSets(m);
-	int rc = finishPending(m);
-	swapSets(m);
+	int rc = finishPendingAnySet(m);
 	if (rc && UFOMAP_OK == m->async_status) m->async_status = rc;
 	return rc;
 }
@@ -944,6 +955,7 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 	if (rc) return rc;
 	HIP_TRY(hipGetLastError());
 	m->pending = true;
+	m->pending_set = m->cur_set;
 	if (!async) {
 		HIP_TRY(hipStreamSynchronize(m->stream));
 		rc = finishPending(m);
@@ -1157,7 +1169,7 @@ int ufomap_map_wait(ufomap_map* m)
 	HIP_TRY(hipSetDevice(m->device));
 	HIP_TRY(hipStreamSynchronize(m->sstream));
 	HIP_TRY(hipStreamSynchronize(m->stream));
-	int rc = finishPending(m);
+	int rc = finishPendingAnySet(m);
 	if (UFOMAP_OK == rc && UFOMAP_OK != m->async_status) {
 		rc = m->async_status;
 		g_err = "an earlier asynchronous integration failed";
@@ -1426,14 +1438,18 @@ int ufomap_map_scan_keys(ufomap_map* m, const double sensor_origin[3], const dou
 	memset(info, 0, sizeof(*info));
 	info->depth = depth;
 	HIP_TRY(hipSetDevice(m->device));
-	int rc = ufomap_map_wait(m);  // this entry point does not pipeline
-	if (rc) return rc;
+	// Ray casting never reads the map: it runs on the scan stream with its own hand-over set while an update
+	// enqueued earlier (asynchronous insert / apply_keys_batch) may still be walking the tree on the map stream.
+	HIP_TRY(hipStreamSynchronize(m->sstream));
+	swapSets(m);
 	m->cs = m->sstream;
 	u32 n_hits = 0, n_rays = 0;
-	rc = scanPhase(m, sensor_origin, d_xyz, nullptr, n, max_range, depth, discrete, simple_ray_casting, 0, &n_hits, &n_rays);
+	int rc = scanPhase(m, sensor_origin, d_xyz, nullptr, n, max_range, depth, discrete, simple_ray_casting, 0, &n_hits, &n_rays);
 	if (rc || 0 == n) return rc;
 	u64 capH = 0, capM = 0;
-	rc = extractPhase(m, n_hits, n_rays, &capH, &capM, false);
+	// insert depth 0: ONE list, a block with hits and misses appears once with both masks (flagged in `reserved`)
+	const bool merged = 0 == depth && 0 != m->opt_merge;
+	rc = extractPhase(m, n_hits, n_rays, &capH, &capM, merged);
 	if (rc) return rc;
 	rc = readCtl(m);  // on the scan stream: waits for the extraction
 	if (rc) return rc;
@@ -1441,7 +1457,8 @@ int ufomap_map_scan_keys(ufomap_map* m, const double sensor_origin[3], const dou
 	if (rc) return rc;
 	// compact: miss entries directly behind the hit entries
 	const u32 nh = m->h_ctl->n_entries[0], nm = m->h_ctl->n_entries[1];
-	if (nh != capH && nm) {
+	info->reserved = merged ? 1u : 0u;
+	if (!merged && nh != capH && nm) {
 		HIP_TRY(m->b_codes.reserve((size_t)nm * sizeof(Entry)));
 		HIP_TRY(hipMemcpyAsync(m->b_codes.p, m->b_entries.as<Entry>() + capH, (size_t)nm * sizeof(Entry), hipMemcpyDeviceToDevice, m->cs));
 		HIP_TRY(hipMemcpyAsync(m->b_entries.as<Entry>() + nh, m->b_codes.p, (size_t)nm * sizeof(Entry), hipMemcpyDeviceToDevice, m->cs));
@@ -1466,8 +1483,8 @@ int ufomap_map_get_keys(ufomap_map* m, void* d_dst, size_t cap_entries, const uf
 	size_t tot = (size_t)info->n_hit + info->n_miss;
 	if (tot > cap_entries) return fail(UFOMAP_ERR_CAPACITY, "destination too small for the update list");
 	HIP_TRY(hipSetDevice(m->device));
-	if (tot) HIP_TRY(hipMemcpyAsync(d_dst, m->b_entries.p, tot * sizeof(Entry), hipMemcpyDeviceToDevice, m->stream));
-	HIP_TRY(hipStreamSynchronize(m->stream));
+	if (tot) HIP_TRY(hipMemcpyAsync(d_dst, m->b_entries.p, tot * sizeof(Entry), hipMemcpyDeviceToDevice, m->sstream));
+	HIP_TRY(hipStreamSynchronize(m->sstream));
 	return UFOMAP_OK;
 }
 
@@ -1481,6 +1498,7 @@ int ufomap_map_apply_keys(ufomap_map* m, const void* d_entries, const ufomap_key
 		int prc = ufomap_map_wait(m);
 		if (prc) return prc;
 	}
+	if (info->reserved & 1u) return ufomap_map_apply_keys_batch(m, &d_entries, info, 1);  // merged list
 	const u32 nh = info->n_hit, nm = info->n_miss;
 	if (0 == nh + nm) return UFOMAP_OK;
 	m->cs = m->stream;
@@ -1504,6 +1522,7 @@ int ufomap_map_apply_keys(ufomap_map* m, const void* d_entries, const ufomap_key
 	rc = applyEntries(m, ent + nh, nm, 1, info->depth + 1, info->nb_miss, miss, nullptr, false, nh, nm);
 	if (rc) return rc;
 	m->pending = true;
+	m->pending_set = m->cur_set;
 	HIP_TRY(hipStreamSynchronize(m->stream));
 	return finishPending(m);
 }
@@ -1517,7 +1536,13 @@ int ufomap_map_apply_keys_batch(ufomap_map* m, const void* const* d_lists, const
 		if (0 != infos[j].depth) return fail(UFOMAP_ERR_UNSUPPORTED, "apply_keys_batch: insert depth 0 only (apply deeper scans one by one)");
 	HIP_TRY(hipSetDevice(m->device));
 	{
-		int prc = ufomap_map_wait(m);
+		// join what is in flight on the map stream (not the scan stream: ray casting of the next batch may overlap)
+		int prc = joinPrevious(m);
+		if (UFOMAP_OK == prc && UFOMAP_OK != m->async_status) {
+			prc = m->async_status;
+			g_err = "an earlier asynchronous integration failed";
+		}
+		m->async_status = UFOMAP_OK;
 		if (prc) return prc;
 	}
 	u64 total = 0;
@@ -1538,8 +1563,14 @@ int ufomap_map_apply_keys_batch(ufomap_map* m, const void* const* d_lists, const
 	// sub-lists in application order: scan 0 hits, scan 0 misses, scan 1 hits, ...; their counts live on the device
 	struct Sub {
 		const Entry* ent;
-		u32 n, off, is_hit, scan;
-		const i32* nb;
+		u32 n, off, mode, scan;  // mode: 0 misses, 1 hits, 2 merged (k_apply_values)
+		const i32* nbA;          // grid the entries lie in ...
+		const i32* nbB;          // ... or, merged lists, this one (nullptr otherwise)
+	};
+	auto subNew = [&](const Sub& sb, u64 cnt) {
+		u64 b = blockBound(m, std::min<u64>(cnt, sb.n), sb.nbA, 1);
+		if (sb.nbB) b += blockBound(m, std::min<u64>(cnt, sb.n), sb.nbB, 1);
+		return b;
 	};
 	std::vector<Sub> subs;
 	std::vector<u32> h_cnt;
@@ -1548,17 +1579,25 @@ int ufomap_map_apply_keys_batch(ufomap_map* m, const void* const* d_lists, const
 	for (int j = 0; j < n_lists; ++j) {
 		const Entry* e = static_cast<const Entry*>(d_lists[j]);
 		const u32 nh = infos[j].n_hit, nm = infos[j].n_miss;
+		if (infos[j].reserved & 1u) {
+			// merged list: n_hit records, each with the hit and the miss mask of its block
+			if (nm) return fail(UFOMAP_ERR_INVALID, "merged update list with a separate miss list");
+			if (nh) {
+				subs.push_back(Sub{e, nh, off, 2u, (u32)j, infos[j].nb_hit, infos[j].nb_miss});
+				off += nh;
+			}
+			continue;
+		}
 		if (nh) {
-			subs.push_back(Sub{e, nh, off, 1u, (u32)j, infos[j].nb_hit});
-			new_bound += blockBound(m, nh, infos[j].nb_hit, 1);
+			subs.push_back(Sub{e, nh, off, 1u, (u32)j, infos[j].nb_hit, nullptr});
 			off += nh;
 		}
 		if (nm) {
-			subs.push_back(Sub{e + nh, nm, off, 0u, (u32)j, infos[j].nb_miss});
-			new_bound += blockBound(m, nm, infos[j].nb_miss, 1);
+			subs.push_back(Sub{e + nh, nm, off, 0u, (u32)j, infos[j].nb_miss, nullptr});
 			off += nm;
 		}
 	}
+	for (const Sub& sb : subs) new_bound += subNew(sb, sb.n);
 	for (const Sub& sb : subs) h_cnt.push_back(sb.n);
 	HIP_TRY(m->b_crec.reserve(h_cnt.size() * 4 + 16));
 	HIP_TRY(hipMemcpyAsync(m->b_crec.p, h_cnt.data(), h_cnt.size() * 4, hipMemcpyHostToDevice, m->stream));
@@ -1579,7 +1618,7 @@ int ufomap_map_apply_keys_batch(ufomap_map* m, const void* const* d_lists, const
 				u32 cnt = 0;
 				memcpy(&cnt, &m->h_ctl->dbg[60], 4);
 				u64 b = 0;
-				for (const Sub& sb : subs) b += blockBound(m, std::min<u64>(cnt, sb.n), sb.nb, 1);
+				for (const Sub& sb : subs) b += subNew(sb, cnt);
 				m->scan_new_bound = new_bound = std::min(new_bound, b);
 			}
 			if ((m->used_est + new_bound) * 5 > cap * 3) {
@@ -1610,10 +1649,9 @@ int ufomap_map_apply_keys_batch(ufomap_map* m, const void* const* d_lists, const
 	const float miss = (float)m->g.miss_log;  // insert depth 0 (OMB:311)
 	for (size_t k = 0; k < subs.size(); ++k) {
 		ProfScope ps(m, "k_apply_values");
-		const u64 time_hi = ((u64)subs[k].scan << 30) | (subs[k].is_hit ? 0ull : (1ull << 29));
+		const u64 time_hi = (u64)subs[k].scan << 30;
 		hipLaunchKernelGGL(k_apply_values, gridFor(subs[k].n), dim3(256), 0, m->cs, m->t, m->g, subs[k].ent, d_cnt + k,
-		                   m->b_ent_slot.as<u32>() + subs[k].off, subs[k].is_hit ? m->g.hit : miss, subs[k].is_hit, m->scan_id, time_hi, wl[1], pc,
-		                   ctl);
+		                   m->b_ent_slot.as<u32>() + subs[k].off, m->g.hit, miss, subs[k].mode, m->scan_id, time_hi, wl[1], pc, ctl);
 	}
 	{
 		ProfScope ps(m, "k_finish_leaf");
@@ -1621,12 +1659,22 @@ int ufomap_map_apply_keys_batch(ufomap_map* m, const void* const* d_lists, const
 	}
 	auto bound = [&](u32 l) {
 		u64 b = 0;
-		for (const Sub& sb : subs) b += std::min<u64>(sb.n, levelBound(sb.nb, l - 1));
+		for (const Sub& sb : subs) {
+			u64 x = levelBound(sb.nbA, l - 1);
+			if (sb.nbB) x += levelBound(sb.nbB, l - 1);
+			b += std::min<u64>(sb.n, x);
+		}
 		return b;
 	};
 	propagateLevels(m, 2, bound, pc, 0);
 	HIP_TRY(hipGetLastError());
 	m->pending = true;
+	m->pending_set = m->cur_set;
+	if (m->opt_async_apply) {
+		// the caller keeps the lists alive until the next call on this map has joined the update
+		HIP_TRY(hipEventRecord(m->done_ev, m->stream));
+		return UFOMAP_OK;
+	}
 	HIP_TRY(hipStreamSynchronize(m->stream));
 	return finishPending(m);
 }
@@ -1733,6 +1781,8 @@ int ufomap_map_set_option(ufomap_map* m, const char* key, long long value)
 		m->opt_dda_mode = (int)value;
 	} else if (0 == strcmp(key, "dda_seg")) {
 		m->opt_dda_seg = value ? 1 : 0;
+	} else if (0 == strcmp(key, "async_apply")) {
+		m->opt_async_apply = value ? 1 : 0;
 	} else if (0 == strcmp(key, "cast")) {
 		m->opt_cast = value ? 1 : 0;
 	} else if (0 == strcmp(key, "cast_wgs")) {
