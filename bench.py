@@ -16,7 +16,7 @@ replica of the map applies all N scans in rank order ("scaling": "weak").
 
 Prints ONE JSON line on rank 0:  metric/value/unit = integrated rays/s (input points per second,
 whole job), ms_per_step, plus
-  roofline     -- dominant kernel (k_dda): algorithmic bytes per launch / HIP-event duration vs 8 TB/s
+  roofline     -- dominant kernel (the ray walk, k_cast + slab merge): algorithmic bytes per launch / HIP-event duration vs 8 TB/s
   cpu_baseline -- the reference (oracle/_ref) or the oracle port timed on this box's host cores
 """
 from __future__ import annotations
@@ -185,10 +185,12 @@ def main():
         kern_ms = {k: (v["total_ms"] / max(v["launches"], 1)) for k, v in ktimes.items() if v["launches"]}
         per_step_ms = {k: v["total_ms"] / args.steps for k, v in ktimes.items() if v["launches"]}
         if kern_ms:
-            # The dominant kernel is the ray walk: it carries 16*S of B_scan (82 %). Since round 1 it is
-            # split in three launches per scan (per-ray set-up, segmented walk, slab merge); their durations add.
-            group = [k for k in ("k_ray_setup", "k_dda", "k_merge_slabs") if k in kern_ms]
-            dom = "k_dda"
+            # The dominant kernel is the ray walk: it carries 16*S of B_scan (82 %). It is one launch (k_cast:
+            # set-up + segment queue + walk) plus the slab merge for LiDAR-sized scans, or set-up + walk + merge
+            # for the other grid sizes; the durations of whatever ran add up.
+            walkers = ("k_cast", "k_walk", "k_dda_seg", "k_dda")  # whichever variant the grid size selects
+            group = [k for k in ("k_ray_setup",) + walkers + ("k_merge_slabs",) if k in kern_ms]
+            dom = next(k for k in walkers if k in kern_ms)
             # k_dda fuses key emission and de-duplication: its share of B_scan is the ray list plus the
             # 16*S key term
             share = P_BYTES * counts["rays"] + 16 * counts["steps"]
@@ -199,7 +201,9 @@ def main():
             if os.path.exists(pmc):
                 try:
                     pj = json.load(open(pmc))
-                    vals = [pj.get(k, {}).get("hbm_bytes_per_launch") for k in group]
+                    # keys are rocprofv3 kernel names (template arguments included): match by prefix
+                    vals = [next((v.get("hbm_bytes_per_launch") for kk, v in pj.items() if kk == k or kk.startswith(k + "<")), None)
+                            for k in group]
                     traffic = sum(v for v in vals if v) if any(vals) else None
                 except Exception:
                     traffic = None

@@ -811,7 +811,7 @@ int scanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, const 
 			HIP_TRY(m->b_slabs.reserve((size_t)nwg * m->gridM.bytes + (size_t)nwg * 8));
 			unsigned long long* sp = reinterpret_cast<unsigned long long*>(m->b_slabs.as<char>() + (size_t)nwg * m->gridM.bytes);
 			{
-				ProfScope ps(m, "k_dda");
+				ProfScope ps(m, "k_cast");
 				hipLaunchKernelGGL(k_cast, dim3(nwg), dim3(cblk), (size_t)m->gridM.bytes + UFO_CAST_LDS_EXTRA, m->cs, m->g, sensor, (u32)depth,
 				                   m->gridM, m->b_slabs.as<u32>(), m->b_ray_end.as<D3>(), (u32)std::max(8, m->opt_cast_k), ctl, ctl, sp);
 			}
@@ -827,7 +827,7 @@ int scanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, const 
 			                   m->b_ray_end.as<D3>(), m->b_rays.as<RayState>(), ctl);
 		}
 		{
-		ProfScope ps(m, "k_dda");
+		ProfScope ps(m, 1 == m->gridM.layout ? "k_walk" : (seg ? "k_dda_seg" : "k_dda"));
 #define UFO_LAUNCH_DDA(SIMPLE, MODE)                                                                                         \
 	hipLaunchKernelGGL((k_dda<SIMPLE, MODE>), gr, dim3(blk), lds, m->cs, m->g, sensor, (u32)depth, m->gridM, \
 	                   dda_out, m->b_ray_end.as<D3>(), ctl, ctl)
