@@ -268,12 +268,27 @@ def test_batch_integrator_rccl_world1():
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2])
-def test_all_ray_kernel_modes_agree(mode):
-    """LDS-grid, LDS-filter and direct-atomic variants of k_dda produce the same map (and the oracle's)."""
+RAY_KERNELS = {
+    "cast": {},                                        # k_cast: set-up + uniform segments + walk (default)
+    "cast_k8_64wgs": {"cast_k": 8, "cast_wgs": 64},    # many short segments, several rounds per workgroup
+    "walk_1lane": {"cast": 0, "dda_lanes": 1},         # k_ray_setup + k_walk (bit grid in LDS)
+    "walk_4lanes": {"cast": 0, "dda_lanes": 4},
+    "seg_bytes_lds": {"dda_bits": 0},                  # k_dda_seg<DDA_LDSGRID> (byte-per-block grid in LDS)
+    "seq_bytes_lds": {"dda_bits": 0, "dda_seg": 0},    # k_dda<false, DDA_LDSGRID>, one lane per ray
+    "filter": {"dda_mode": 1},                         # k_dda_seg<DDA_FILTER>
+    "direct": {"dda_mode": 2},                         # k_dda<false, DDA_DIRECT>
+}
+
+
+@pytest.mark.parametrize("variant", sorted(RAY_KERNELS))
+def test_all_ray_kernel_modes_agree(variant):
+    """Every variant of the ray kernel (fused / segmented / sequential; LDS bit grid, LDS byte grid, LDS
+    filter, direct atomics) marks the same cells in the same number of steps: the oracle's."""
     from ufomap_amd import scans
     g, o = _maps(resolution=0.16)
-    g.set_option("dda_mode", mode)
+    for k, v in RAY_KERNELS[variant].items():
+        g.set_option(k, v)
+    mode = variant
     origin, xyz, _ = scans.lidar64(beams=32, azimuths=1024)
     for _ in range(2):
         _gpu_insert(g, origin, xyz, max_range=20.0, discrete=False)
