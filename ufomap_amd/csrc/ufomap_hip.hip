@@ -511,7 +511,13 @@ int applyEntries(ufomap_map* m, const Entry* d_entries, u32 cap, u32 which, u32 
 int sizeTable(ufomap_map* m, const Entry* ent_h, u64 capH, const i32 nbH[3], const Entry* ent_m, u64 capM, const i32 nbM[3],
               unsigned depth, bool merged = false)
 {
+	// merged list (depth 0) whose hit box lies inside the ray box: all entries are blocks of the miss grid
+	bool h_in_m = merged && capH && capM && m->haveH && m->haveM && nbH == m->gridH.nb && nbM == m->gridM.nb;
+	for (int a = 0; a < 3 && h_in_m; ++a)
+		h_in_m = m->gridH.base[a] >= m->gridM.base[a] &&
+		         (long long)m->gridH.base[a] + 2ll * m->gridH.nb[a] <= (long long)m->gridM.base[a] + 2ll * m->gridM.nb[a];
 	auto bound = [&](u64 nh, u64 nm) {
+		if (h_in_m) return blockBound(m, nh + nm, nbM, 1);
 		u64 b = 0;
 		if (nh) b += blockBound(m, nh, nbH, 1);
 		if (nm) b += blockBound(m, nm, nbM, (u32)depth + 1);
@@ -542,7 +548,8 @@ int sizeTable(ufomap_map* m, const Entry* ent_h, u64 capH, const i32 nbH[3], con
 		u32 cnt[2];
 		memcpy(cnt, &m->h_ctl->dbg[60], 8);
 		if (merged) {
-			if (m->h_ctl->n_entries[0] <= capH + capM) m->scan_new_bound = bound(capH ? cnt[0] : 0, capM ? cnt[0] : 0);
+			if (m->h_ctl->n_entries[0] <= capH + capM)
+				m->scan_new_bound = h_in_m ? blockBound(m, cnt[0], nbM, 1) : bound(capH ? cnt[0] : 0, capM ? cnt[0] : 0);
 		} else if (m->h_ctl->n_entries[0] <= capH && m->h_ctl->n_entries[1] <= capM) m->scan_new_bound = bound(cnt[0], cnt[1]);
 		if ((m->used_est + m->scan_new_bound) * 5 <= cap * 3) return UFOMAP_OK;
 	}
