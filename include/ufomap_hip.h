@@ -80,6 +80,20 @@ int ufomap_map_insert_device(ufomap_map* m, const double sensor_origin[3], const
                              int async);
 /* insertPointCloudWait / insertPointCloudDone (occupancy_map_base.h:430-443).
  * wait returns the status of the joined integration; done returns 1/0 (or <0 on error). */
+/* The three lines in front of the hot path in the reference's server (ufomap_mapping/src/server.cpp:114-120):
+ *   rosToUfo(msg, cloud)            ufomap_ros/src/conversions.cpp:98-138   float32 fields -> Point3Color, NaN dropped
+ *   cloud.transform(transform)      map/point_cloud.h:157-166, math/pose6.h:114-125, math/quaternion.h:253-286
+ *   map.insertPointCloudDiscrete(transform.translation(), cloud, ...)
+ * on the raw records of a sensor_msgs/PointCloud2: `data` = n_points records of point_step bytes (host memory, or
+ * device memory if data_on_device), float32 x / y / z at off_x / off_y / off_z, bytes r / g / b at off_r / off_g /
+ * off_b (all three -1: no colour; the sub-bytes of a packed "rgb" field at offset o are b = o, g = o+1, r = o+2).
+ * Conversion, NaN filter and transform run inside the first kernel of the scan, in the reference's operation
+ * order (same keys, bit for bit); the float64 cloud is never materialised. discrete = 0 gives insertPointCloud. */
+int ufomap_map_insert_pointcloud2(ufomap_map* m, const double translation[3], const double rotation_wxyz[4], const void* data,
+                                  int data_on_device, size_t n_points, uint32_t point_step, int off_x, int off_y, int off_z,
+                                  int off_r, int off_g, int off_b, double max_range, unsigned depth, int discrete,
+                                  int simple_ray_casting, unsigned early_stopping, int async);
+
 int ufomap_map_wait(ufomap_map* m);
 int ufomap_map_done(ufomap_map* m);
 

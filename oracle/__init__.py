@@ -75,6 +75,8 @@ def _load(kind: str):
     lib.ufo_oracle_last_steps.argtypes = [vp]
     lib.ufo_oracle_last_oob.restype = C.c_uint64
     lib.ufo_oracle_last_oob.argtypes = [vp]
+    lib.ufo_oracle_ingest.restype = C.c_size_t
+    lib.ufo_oracle_ingest.argtypes = [u8p, C.c_size_t, C.c_uint32] + [C.c_int] * 6 + [C.POINTER(C.c_double)] * 3 + [u8p]
     lib.ufo_oracle_kind.restype = C.c_char_p
     _LIBS[kind] = lib
     return lib
@@ -82,6 +84,23 @@ def _load(kind: str):
 
 def _ptr(a, ty):
     return None if a is None else a.ctypes.data_as(C.POINTER(ty))
+
+
+def ingest(data, step, off_xyz, off_rgb, rot_wxyz, trans, kind="port"):
+    """rosToUfo + PointCloud::transform of the reference on a raw PointCloud2-style byte buffer.
+    data: uint8 array of n*step bytes; off_xyz = (x, y, z) byte offsets of float32 fields; off_rgb = (r, g, b)
+    byte offsets or None. Returns (xyz float64 [k, 3], rgb uint8 [k, 3]) of the k points without NaN."""
+    lib = _load(kind)
+    data = np.ascontiguousarray(data, dtype=np.uint8).reshape(-1)
+    n = data.size // step
+    xyz = np.empty((max(n, 1), 3), np.float64)
+    rgb = np.empty((max(n, 1), 3), np.uint8)
+    q = np.ascontiguousarray(rot_wxyz, dtype=np.float64)
+    t = np.ascontiguousarray(trans, dtype=np.float64)
+    orgb = off_rgb if off_rgb is not None else (-1, -1, -1)
+    k = lib.ufo_oracle_ingest(_ptr(data, C.c_uint8), n, step, *[int(o) for o in off_xyz], *[int(o) for o in orgb],
+                              _ptr(q, C.c_double), _ptr(t, C.c_double), _ptr(xyz, C.c_double), _ptr(rgb, C.c_uint8))
+    return xyz[:k].copy(), rgb[:k].copy()
 
 
 class OracleMap:

@@ -73,6 +73,14 @@ uint64_t ufo_oracle_last_steps(const ufo_oracle_map* m);
 uint64_t ufo_oracle_last_oob(const ufo_oracle_map* m);
 
 /* "reference" or "port". */
+/* Ingest in front of the hot path: rosToUfo (ufomap_ros/ufomap_ros/src/conversions.cpp:
+ * 98-138: float32 x, y, z [+ r, g, b bytes] at byte offsets inside records of `step` bytes; points with a NaN
+ * coordinate are dropped) followed by PointCloud::transform (map/point_cloud.h:157-166 -> math/pose6.h:114-125
+ * -> math/quaternion.h:253-286: q v q^-1, then + translation, all in double). Returns the number of points
+ * kept; xyz_out[3k..], rgb_out[3k..] (rgb_out may be NULL; off_r < 0: colour 0,0,0 as Point3Color(x,y,z)). */
+size_t ufo_oracle_ingest(const uint8_t* data, size_t n, uint32_t step, int off_x, int off_y, int off_z, int off_r, int off_g,
+                         int off_b, const double rot_wxyz[4], const double trans[3], double* xyz_out, uint8_t* rgb_out);
+
 const char* ufo_oracle_kind(void);
 
 #ifdef __cplusplus

@@ -16,6 +16,7 @@
  * (SURVEY.md section 4).
  */
 #include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <memory>
@@ -236,6 +237,42 @@ size_t ufo_oracle_last_rays(const ufo_oracle_map*, double*, size_t) { return (si
 size_t ufo_oracle_last_misses(const ufo_oracle_map*, uint64_t*, size_t) { return (size_t)-1; }
 uint64_t ufo_oracle_last_steps(const ufo_oracle_map*) { return (uint64_t)-1; }
 uint64_t ufo_oracle_last_oob(const ufo_oracle_map*) { return (uint64_t)-1; }
+
+// The conversion loop of ufomap_ros (conversions.cpp:98-138) needs ROS message types and is restated here; the
+// transform is the reference's own Pose6::transform on its own Point3Color.
+size_t ufo_oracle_ingest(const uint8_t* data, size_t n, uint32_t step, int off_x, int off_y, int off_z, int off_r, int off_g,
+                         int off_b, const double q[4], const double t[3], double* xyz_out, uint8_t* rgb_out)
+{
+	const ufo::math::Pose6 pose(ufo::math::Vector3(t[0], t[1], t[2]), ufo::math::Quaternion(q[0], q[1], q[2], q[3]));
+	ufo::map::PointCloudColor cloud;
+	for (size_t i = 0; i < n; ++i) {
+		const uint8_t* rec = data + i * (size_t)step;
+		float fx, fy, fz;
+		memcpy(&fx, rec + off_x, 4);
+		memcpy(&fy, rec + off_y, 4);
+		memcpy(&fz, rec + off_z, 4);
+		if (!std::isnan(fx) && !std::isnan(fy) && !std::isnan(fz)) {
+			if (off_r >= 0)
+				cloud.push_back(ufo::map::Point3Color(fx, fy, fz, rec[off_r], rec[off_g], rec[off_b]));
+			else
+				cloud.push_back(ufo::map::Point3Color(fx, fy, fz));
+		}
+	}
+	cloud.transform(pose, false);
+	size_t k = 0;
+	for (auto const& p : cloud) {
+		xyz_out[3 * k] = p.x();
+		xyz_out[3 * k + 1] = p.y();
+		xyz_out[3 * k + 2] = p.z();
+		if (rgb_out) {
+			rgb_out[3 * k] = p.getColor().r;
+			rgb_out[3 * k + 1] = p.getColor().g;
+			rgb_out[3 * k + 2] = p.getColor().b;
+		}
+		++k;
+	}
+	return k;
+}
 
 const char* ufo_oracle_kind(void) { return "reference"; }
 

@@ -803,6 +803,45 @@ size_t ufo_oracle_last_misses(const ufo_oracle_map* m, uint64_t* codes, size_t c
 uint64_t ufo_oracle_last_steps(const ufo_oracle_map* m) { return m->last_steps; }
 uint64_t ufo_oracle_last_oob(const ufo_oracle_map* m) { return m->last_oob; }
 
+// Quaternion::operator* (math/quaternion.h:253-259), operands (w, x, y, z)
+static void quatMul(const double a[4], const double b[4], double r[4])
+{
+	r[0] = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+	r[1] = a[2] * b[3] - b[2] * a[3] + a[0] * b[1] + b[0] * a[1];
+	r[2] = a[3] * b[1] - b[3] * a[1] + a[0] * b[2] + b[0] * a[2];
+	r[3] = a[1] * b[2] - b[1] * a[2] + a[0] * b[3] + b[0] * a[3];
+}
+
+size_t ufo_oracle_ingest(const uint8_t* data, size_t n, uint32_t step, int off_x, int off_y, int off_z, int off_r, int off_g,
+                         int off_b, const double q[4], const double t[3], double* xyz_out, uint8_t* rgb_out)
+{
+	size_t k = 0;
+	const double qi[4] = {q[0], -q[1], -q[2], -q[3]};  // Quaternion::inversed (quaternion.h:266)
+	for (size_t i = 0; i < n; ++i) {
+		const uint8_t* rec = data + i * (size_t)step;
+		float fx, fy, fz;
+		memcpy(&fx, rec + off_x, 4);
+		memcpy(&fy, rec + off_y, 4);
+		memcpy(&fz, rec + off_z, 4);
+		if (std::isnan(fx) || std::isnan(fy) || std::isnan(fz)) continue;  // conversions.cpp:92 / 124-125
+		// Pose6::transform (pose6.h:114-125): rotation_.rotate(v) (quaternion.h:277-286: *this * v * inversed()), += translation_
+		const double v[4] = {0.0, (double)fx, (double)fy, (double)fz};  // Quaternion(0, v(0), v(1), v(2)) (quaternion.h:263)
+		double a[4], r[4];
+		quatMul(q, v, a);
+		quatMul(a, qi, r);
+		xyz_out[3 * k] = r[1] + t[0];
+		xyz_out[3 * k + 1] = r[2] + t[1];
+		xyz_out[3 * k + 2] = r[3] + t[2];
+		if (rgb_out) {
+			rgb_out[3 * k] = off_r >= 0 ? rec[off_r] : 0;
+			rgb_out[3 * k + 1] = off_g >= 0 ? rec[off_g] : 0;
+			rgb_out[3 * k + 2] = off_b >= 0 ? rec[off_b] : 0;
+		}
+		++k;
+	}
+	return k;
+}
+
 const char* ufo_oracle_kind(void) { return "port"; }
 
 }  // extern "C"

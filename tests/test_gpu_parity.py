@@ -243,6 +243,41 @@ def test_batch_apply_equals_sequential_c4(chunk):
             assert same_dump(g.inner(), o.inner()), what + ": inner nodes differ"
 
 
+@pytest.mark.parametrize("color", [False, True])
+def test_pointcloud2_ingest_fused_equals_reference_chain(color):
+    """raw PointCloud2 records -> NaN filter -> Pose6 transform -> insertPointCloudDiscrete,
+    fused into the scan's first kernel, against the oracle's restatement of the reference chain
+    (rosToUfo, PointCloud::transform, insertPointCloudDiscrete): same map bit for bit, host and device data."""
+    import torch
+    import oracle
+    from ufomap_amd import scans
+    g, o = _maps(color=color, resolution=0.16)
+    rng = np.random.default_rng(3)
+    for s in range(3):
+        # a LiDAR scan in the sensor frame, as float32 records with NaN returns and a moving pose
+        _, xyz, rgb = scans.lidar64(beams=32, azimuths=512, origin=(0.0, 0.0, 0.0), seed=20 + s, colored=True)
+        n = xyz.shape[0]
+        step = 32
+        buf = rng.integers(0, 256, (n, step), dtype=np.uint8)
+        f = xyz.astype(np.float32)
+        f[::29, s % 3] = np.nan
+        buf[:, 0:12] = f.view(np.uint8).reshape(n, 12)
+        buf[:, 16], buf[:, 17], buf[:, 18] = rgb[:, 2], rgb[:, 1], rgb[:, 0]  # packed "rgb": b, g, r
+        q = np.array([np.cos(0.1 * (s + 1)), 0.02 * s, -0.03, np.sin(0.1 * (s + 1))])
+        q /= np.linalg.norm(q)
+        t = np.array([0.4 * s, -0.2 * s, 0.9])
+        oxyz, orgb = (0, 4, 8), (18, 17, 16)
+        if s == 1:
+            d = torch.from_numpy(buf.reshape(-1)).cuda()
+            g.insertPointCloud2(t, q, d.data_ptr(), step, oxyz, orgb if color else None, max_range=15.0, n_points=n)
+        else:
+            g.insertPointCloud2(t, q, buf, step, oxyz, orgb if color else None, max_range=15.0)
+        cxyz, crgb = oracle.ingest(buf, step, oxyz, orgb if color else None, q, t, "port")
+        assert cxyz.shape[0] < n
+        o.insert(t, cxyz, crgb if color else None, max_range=15.0, discrete=True)
+        _assert_same_map(g, o, f"pointcloud2 scan {s}")
+
+
 def test_batch_integrator_rccl_world1():
     """BatchIntegrator on HBM tensors through the nccl (RCCL) backend with a single rank: the same code
     path the 8-GPU run takes, minus the peers."""

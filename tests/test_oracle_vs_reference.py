@@ -75,3 +75,35 @@ def test_pruning_collapse_sequence(ref_available, port_available):
         a.insert(o, xyz, max_range=20.0, discrete=True)
         b.insert(o, xyz, max_range=20.0, discrete=True)
     _assert_same(a, b)
+
+
+def _pc2_records(n=4000, step=32, seed=5, nan_every=13):
+    """A PointCloud2-style record stream: float32 x, y, z at 0/4/8, packed rgb (b, g, r, a) at 16, padding."""
+    rng = np.random.default_rng(seed)
+    buf = rng.integers(0, 256, (n, step), dtype=np.uint8)  # padding bytes are arbitrary
+    xyz = rng.uniform(-9.0, 9.0, (n, 3)).astype(np.float32)
+    xyz[::nan_every, rng.integers(0, 3)] = np.nan
+    buf[:, 0:12] = xyz.view(np.uint8).reshape(n, 12)
+    return buf, (0, 4, 8), (18, 17, 16)
+
+
+def test_ingest_port_equals_reference_pose6_transform():
+    """rosToUfo + PointCloud::transform: the restatement's quaternion arithmetic equals the reference's own
+    Pose6::transform bit for bit (SURVEY.md 8f rank 2), NaN points dropped, colour bytes taken along."""
+    import oracle
+    buf, oxyz, orgb = _pc2_records()
+    rng = np.random.default_rng(9)
+    for k in range(5):
+        q = rng.normal(size=4)
+        q /= np.linalg.norm(q)
+        t = rng.uniform(-3, 3, 3)
+        a = oracle.ingest(buf, buf.shape[1], oxyz, orgb, q, t, "port")
+        b = oracle.ingest(buf, buf.shape[1], oxyz, orgb, q, t, "reference")
+        assert a[0].shape[0] == buf.shape[0] - len(range(0, buf.shape[0], 13))
+        assert np.array_equal(a[0].view(np.uint64), b[0].view(np.uint64))
+        assert np.array_equal(a[1], b[1])
+    # identity pose: float32 -> float64 conversion only (plus the +-0 arithmetic of the quaternion product)
+    a = oracle.ingest(buf, buf.shape[1], oxyz, None, [1.0, 0, 0, 0], [0.0, 0, 0], "port")
+    keep = ~np.isnan(buf[:, 0:12].copy().view(np.float32).reshape(-1, 3)).any(axis=1)
+    assert np.array_equal(a[0], buf[:, 0:12].copy().view(np.float32).reshape(-1, 3)[keep].astype(np.float64))
+    assert not a[1].any()

@@ -20,7 +20,7 @@ ERR_INVALID, ERR_DEVICE, ERR_UNSUPPORTED, ERR_RUNAWAY, ERR_CAPACITY = -1, -2, -3
 SYMBOLS = [
     "ufomap_last_error", "ufomap_device_count", "ufomap_version", "ufomap_map_create",
     "ufomap_map_destroy", "ufomap_map_clear", "ufomap_map_reserve", "ufomap_map_set_scratch_limit",
-    "ufomap_map_set_sensor_model", "ufomap_map_insert", "ufomap_map_insert_device",
+    "ufomap_map_set_sensor_model", "ufomap_map_insert", "ufomap_map_insert_device", "ufomap_map_insert_pointcloud2",
     "ufomap_map_wait", "ufomap_map_done", "ufomap_map_export_leaves", "ufomap_map_export_inner",
     "ufomap_map_write", "ufomap_map_minmax_change", "ufomap_map_reset_minmax_change", "ufomap_map_stats",
     "ufomap_map_last_hits", "ufomap_map_last_misses", "ufomap_map_last_counts",
@@ -102,6 +102,8 @@ def load():
     lib.ufomap_map_reset_kernel_times.argtypes = [vp]
     lib.ufomap_map_scan_keys.argtypes = [vp, f64p, vp, sz, dbl, C.c_uint, C.c_int, C.c_int, C.POINTER(KeysInfo)]
     lib.ufomap_map_get_keys.argtypes = [vp, vp, sz, C.POINTER(KeysInfo)]
+    lib.ufomap_map_insert_pointcloud2.argtypes = [vp, f64p, f64p, vp, C.c_int, sz, C.c_uint32] + [C.c_int] * 6 + [
+        dbl, C.c_uint, C.c_int, C.c_int, C.c_uint, C.c_int]
     lib.ufomap_map_apply_keys.argtypes = [vp, vp, C.POINTER(KeysInfo)]
     lib.ufomap_map_apply_keys_batch.argtypes = [vp, C.POINTER(C.c_void_p), C.POINTER(KeysInfo), C.c_int]
     lib.ufomap_map_debug.argtypes = [vp, u64p, C.c_int]

@@ -217,6 +217,59 @@ __device__ inline void waveAddU64(unsigned long long* counter, unsigned long lon
 // ------------------------------------------------------------------------------------------------
 enum : u8 { PF_HITCAND = 1, PF_CAST = 2 };
 
+// Ingest fused into the head loop (ufomap_map_insert_pointcloud2): the cloud arrives as the
+// raw records of a sensor_msgs/PointCloud2 -- float32 x, y, z (+ r, g, b bytes) at byte offsets inside records of
+// `step` bytes -- and each point is converted, NaN-filtered (rosToUfo, ufomap_ros/src/conversions.cpp:98-138) and
+// moved to the map frame (PointCloud::transform, point_cloud.h:157-166 -> Pose6::transform, pose6.h:114-125 ->
+// Quaternion::rotate, quaternion.h:277-286) right where it is read; the float64 cloud never exists in memory.
+struct Ingest {
+	const uint8_t* data;  // nullptr: the cloud is an array of doubles x, y, z
+	u32 step, ox, oy, oz;
+	i32 orr, og, ob;      // -1: no colour fields
+	double q[4];          // rotation w, x, y, z
+	double t[3];
+	uint8_t* rgb_out;     // compact r, g, b per point for the colour blend of the map half (nullptr: none)
+};
+// Quaternion::operator* (quaternion.h:253-259), operands (w, x, y, z), the reference's operation order
+__device__ inline void quatMul(const double a[4], const double b[4], double r[4])
+{
+	r[0] = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+	r[1] = a[2] * b[3] - b[2] * a[3] + a[0] * b[1] + b[0] * a[1];
+	r[2] = a[3] * b[1] - b[3] * a[1] + a[0] * b[2] + b[0] * a[2];
+	r[3] = a[1] * b[2] - b[1] * a[2] + a[0] * b[3] + b[0] * a[3];
+}
+// Point i of the cloud in the map frame; false for a point with a NaN coordinate (dropped by rosToUfo; on the
+// plain double path the reference would feed NaN into toKey -- undefined -- so such points are skipped as well).
+__device__ inline bool loadPoint(const double* __restrict__ xyz, const Ingest& ing, u32 i, D3* out)
+{
+	if (!ing.data) {
+		const D3 p{xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2]};
+		*out = p;
+		return !(p.x != p.x || p.y != p.y || p.z != p.z);
+	}
+	*out = D3{0.0, 0.0, 0.0};
+	const uint8_t* rec = ing.data + (size_t)i * ing.step;
+	float fx, fy, fz;
+	memcpy(&fx, rec + ing.ox, 4);
+	memcpy(&fy, rec + ing.oy, 4);
+	memcpy(&fz, rec + ing.oz, 4);
+	if (ing.rgb_out) {
+		ing.rgb_out[3 * (size_t)i] = ing.orr >= 0 ? rec[ing.orr] : (uint8_t)0;
+		ing.rgb_out[3 * (size_t)i + 1] = ing.og >= 0 ? rec[ing.og] : (uint8_t)0;
+		ing.rgb_out[3 * (size_t)i + 2] = ing.ob >= 0 ? rec[ing.ob] : (uint8_t)0;
+	}
+	if (fx != fx || fy != fy || fz != fz) return false;
+	const double v[4] = {0.0, (double)fx, (double)fy, (double)fz};  // Quaternion(0, v) (quaternion.h:263)
+	const double qi[4] = {ing.q[0], -ing.q[1], -ing.q[2], -ing.q[3]};  // inversed() (quaternion.h:266)
+	double a[4], r[4];
+	quatMul(ing.q, v, a);
+	quatMul(a, qi, r);
+	out->x = r[1] + ing.t[0];
+	out->y = r[2] + ing.t[1];
+	out->z = r[3] + ing.t[2];
+	return true;
+}
+
 struct HitHash {
 	u64* keys;  // ~0 = empty
 	u32* minidx;
@@ -338,8 +391,9 @@ __device__ inline void blockBoxReduce(BoxPartial* __restrict__ part, u32 which, 
 }
 
 // Fold the per-workgroup partials into the control block (one workgroup).
-__global__ __launch_bounds__(256) void k_reduce_boxes(const BoxPartial* __restrict__ part, u32 nparts, u32 aabb_from_classify,
-                                                      const BoxPartial* __restrict__ part_classify, ScanCtl* ctl)
+// Fold the per-workgroup partials into the control block. Called by all 256 threads of ONE workgroup.
+__device__ inline void reduceBoxes(const BoxPartial* __restrict__ part, u32 nparts, u32 aabb_from_classify,
+                                   const BoxPartial* __restrict__ part_classify, ScanCtl* ctl)
 {
 	double amn[3] = {1e300, 1e300, 1e300}, amx[3] = {-1e300, -1e300, -1e300};
 	i32 hmn[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, hmx[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
@@ -373,24 +427,33 @@ __global__ __launch_bounds__(256) void k_reduce_boxes(const BoxPartial* __restri
 	}
 }
 
+__global__ __launch_bounds__(256) void k_reduce_boxes(const BoxPartial* __restrict__ part, u32 nparts, u32 aabb_from_classify,
+                                                      const BoxPartial* __restrict__ part_classify, ScanCtl* ctl)
+{
+	reduceBoxes(part, nparts, aabb_from_classify, part_classify, ctl);
+}
+
+
 template <bool DISCRETE>
 __global__ __launch_bounds__(256) void k_classify(MapGeom g, D3 sensor, const double* __restrict__ xyz, u32 n,
                                                   double max_range, u32 depth, u32 color_variant, HitHash hh,
                                                   D3* __restrict__ pt_end, u8* __restrict__ pt_flag,
-                                                  u32* __restrict__ pt_slot, BoxPartial* __restrict__ part, ScanCtl* ctl)
+                                                  u32* __restrict__ pt_slot, BoxPartial* __restrict__ part, ScanCtl* ctl,
+                                                  Ingest ing)
 {
 	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (!DISCRETE) {
 		// OMB:281-303; the change AABB (OMB:305-308) is reduced per wave, so no early return here
 		double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
 		if (i < n) {
-			D3 end{xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2]};
+			D3 end;
+			const bool valid = loadPoint(xyz, ing, i, &end);
 			u8 flag = 0;
 			u32 slot = NONE;
 			D3 origin = sensor;
 			D3 dir = end - origin;
 			double dist = norm(dir);
-			if (moveLineInside(g, origin, end)) {
+			if (valid && moveLineInside(g, origin, end)) {
 				if (0 > max_range || dist <= max_range) {
 					u64 code = morton3(toKey1(g, end.x, 0), toKey1(g, end.y, 0), toKey1(g, end.z, 0));
 					slot = hitHashInsert(hh, code, i, &ctl->err);
@@ -413,7 +476,12 @@ __global__ __launch_bounds__(256) void k_classify(MapGeom g, D3 sensor, const do
 		return;
 	}
 	if (i >= n) return;
-	D3 end{xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2]};
+	D3 end;
+	if (!loadPoint(xyz, ing, i, &end)) {
+		pt_flag[i] = 0;
+		pt_slot[i] = NONE;
+		return;
+	}
 	u8 flag = 0;
 	u32 slot = NONE;
 	// discrete: OMB:354-371 (colour variant OMC.h:195-219)
@@ -537,6 +605,9 @@ __global__ __launch_bounds__(256) void k_select(MapGeom g, D3 sensor, u32 n, u32
 	}
 	blockBoxReduce(part, DISCRETE ? 7u : 6u, amn, amx, hk, hkx, ck, ek);
 	(void)has_aabb;
+	// (Folding the partials here by the last workgroup to finish -- release fence, ticket, acquire fence -- was
+	// measured: 512 agent-scope fences write back / invalidate the L2 so often that k_select went from 24 to 64 us
+	// and the map kernels running on the other stream slowed down too. The reduction stays a launch of its own.)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -636,6 +707,15 @@ __global__ __launch_bounds__(256) void k_extract_hits(MapGeom g, HitBlocks hb, E
 		e.c_last = (u8)(tv & 7u);
 		e.t_last = tv >> 3;
 		entries[my] = e;
+	}
+	// this kernel is the last reader of the hash: leave it empty for the next scan (saves three memsets per scan)
+	for (u32 k = 0; k < 8u; ++k) {
+		const u32 s = base + k;
+		if (s < nslots && hb.keys[s] != ~0ULL) {
+			hb.keys[s] = ~0ULL;
+			hb.mask[s] = 0u;
+			hb.time[s] = 0u;
+		}
 	}
 }
 

@@ -129,6 +129,8 @@ struct ufomap_map {
 	DevBuf b_ctl, b_pt_end, b_pt_flag, b_pt_slot, b_ray_end, b_hit_code, b_hit_pt, b_hh_keys, b_hh_idx;
 	DevBuf b_part0, b_part1, b_slabs, b_hb_keys, b_hb_mask, b_hb_time;
 	u32 hb_cap_mask = 0;
+	Ingest ing{};      // ufomap_map_insert_pointcloud2: raw PointCloud2 records, converted inside k_classify
+	u32 hb_clean = 0;  // slots [0, hb_clean) of the hit-block hash are known to be empty
 	DevBuf b_crec, b_dlist, b_rays;
 	DevBuf b_gridM, b_entries, b_ent_slot, b_newlist, b_wl0, b_wl1, b_in_xyz, b_in_rgb, b_codes, b_dump;
 	ScanCtl* h_ctl = nullptr;  // pinned
@@ -586,6 +588,7 @@ int extractLists(ufomap_map* m, u64 capH, u64 capM, bool zero_counts, bool merge
 			ProfScope ps(m, "k_extract_hits");
 			hipLaunchKernelGGL(k_extract_hits, dim3((u32)(((u64)m->hb_cap_mask + 1 + 2047) / 2048)), dim3(256), 0, m->cs, m->g, hb, ent_h,
 			                   (u32)(capH + capM), ctl);
+			m->hb_clean = m->hb_cap_mask + 1;
 		}
 		return UFOMAP_OK;
 	}
@@ -594,6 +597,7 @@ int extractLists(ufomap_map* m, u64 capH, u64 capM, bool zero_counts, bool merge
 		HitBlocks hb{m->b_hb_keys.as<u64>(), m->b_hb_mask.as<u32>(), m->b_hb_time.as<u32>(), m->hb_cap_mask};
 		hipLaunchKernelGGL(k_extract_hits, dim3((u32)(((u64)m->hb_cap_mask + 1 + 2047) / 2048)), dim3(256), 0, m->cs, m->g, hb, ent_h,
 		                   (u32)capH, ctl);
+		m->hb_clean = m->hb_cap_mask + 1;
 	}
 	if (capM) {
 		ProfScope ps(m, "k_extract");
@@ -707,10 +711,11 @@ int scanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, const 
 		if (discrete)
 			hipLaunchKernelGGL(k_classify<true>, gp, dim3(256), 0, m->cs, m->g, sensor, d_xyz, N, max_range, (u32)depth,
 			                   (u32)(d_rgb ? 1 : 0), hh, m->b_pt_end.as<D3>(), m->b_pt_flag.as<u8>(), m->b_pt_slot.as<u32>(),
-			                   m->b_part0.as<BoxPartial>(), ctl);
+			                   m->b_part0.as<BoxPartial>(), ctl, m->ing);
 		else
 			hipLaunchKernelGGL(k_classify<false>, gp, dim3(256), 0, m->cs, m->g, sensor, d_xyz, N, max_range, (u32)depth, 0u, hh,
-			                   m->b_pt_end.as<D3>(), m->b_pt_flag.as<u8>(), m->b_pt_slot.as<u32>(), m->b_part0.as<BoxPartial>(), ctl);
+			                   m->b_pt_end.as<D3>(), m->b_pt_flag.as<u8>(), m->b_pt_slot.as<u32>(), m->b_part0.as<BoxPartial>(), ctl,
+			                   m->ing);
 	}
 	{
 		ProfScope ps(m, "k_select");
@@ -771,12 +776,19 @@ int scanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, const 
 		if (n > (1u << 29)) return fail(UFOMAP_ERR_INVALID, "more than 2^29 points in one scan");
 		const u32 hbcap = nextPow2(std::max<u64>(256, (u64)n_hits * 2));
 		m->hb_cap_mask = hbcap - 1;
+		const void *p0 = m->b_hb_keys.p, *p1 = m->b_hb_mask.p, *p2 = m->b_hb_time.p;
 		HIP_TRY(m->b_hb_keys.reserve((size_t)hbcap * 8));
 		HIP_TRY(m->b_hb_mask.reserve((size_t)hbcap * 4));
 		HIP_TRY(m->b_hb_time.reserve((size_t)hbcap * 4));
-		HIP_TRY(hipMemsetAsync(m->b_hb_keys.p, 0xFF, (size_t)hbcap * 8, m->cs));
-		HIP_TRY(hipMemsetAsync(m->b_hb_mask.p, 0, (size_t)hbcap * 4, m->cs));
-		HIP_TRY(hipMemsetAsync(m->b_hb_time.p, 0, (size_t)hbcap * 4, m->cs));
+		if (p0 != m->b_hb_keys.p || p1 != m->b_hb_mask.p || p2 != m->b_hb_time.p) m->hb_clean = 0;
+		// k_extract_hits leaves the slots it read empty: only slots never used before need the memsets
+		if (hbcap > m->hb_clean) {
+			const size_t from = m->hb_clean, cnt = hbcap - m->hb_clean;
+			HIP_TRY(hipMemsetAsync(m->b_hb_keys.as<u64>() + from, 0xFF, cnt * 8, m->cs));
+			HIP_TRY(hipMemsetAsync(m->b_hb_mask.as<u32>() + from, 0, cnt * 4, m->cs));
+			HIP_TRY(hipMemsetAsync(m->b_hb_time.as<u32>() + from, 0, cnt * 4, m->cs));
+		}
+		m->hb_clean = 0;  // dirty until this scan's k_extract_hits has been enqueued (extractLists)
 		ProfScope ps(m, "k_hitmark");
 		HitBlocks hb{m->b_hb_keys.as<u64>(), m->b_hb_mask.as<u32>(), m->b_hb_time.as<u32>(), m->hb_cap_mask};
 		hipLaunchKernelGGL(k_hitmark, gridFor(n_hits), dim3(256), 0, m->cs, hb, m->b_hit_code.as<u64>(), m->b_hit_pt.as<u32>(), ctl, ctl);
@@ -1168,6 +1180,59 @@ int ufomap_map_insert(ufomap_map* m, const double sensor_origin[3], const double
 		}
 	}
 	return doInsert(m, sensor_origin, d_xyz, d_rgb, n, max_range, depth, discrete, simple_ray_casting, early_stopping, async, true);
+}
+
+int ufomap_map_insert_pointcloud2(ufomap_map* m, const double translation[3], const double rotation_wxyz[4], const void* data,
+                                  int data_on_device, size_t n_points, uint32_t point_step, int off_x, int off_y, int off_z, int off_r,
+                                  int off_g, int off_b, double max_range, unsigned depth, int discrete, int simple_ray_casting,
+                                  unsigned early_stopping, int async)
+{
+	if (!m || !translation || !rotation_wxyz || (n_points && !data)) return fail(UFOMAP_ERR_INVALID, "null argument");
+	const bool has_rgb = off_r >= 0 && off_g >= 0 && off_b >= 0;
+	if (off_x < 0 || off_y < 0 || off_z < 0 || (u64)std::max(std::max(off_x, off_y), off_z) + 4 > point_step ||
+	    (has_rgb && (u32)std::max(std::max(off_r, off_g), off_b) >= point_step))
+		return fail(UFOMAP_ERR_INVALID, "field offsets outside the point record");
+	if (m->g.color && !discrete)
+		return fail(UFOMAP_ERR_UNSUPPORTED, "OccupancyMapColor::insertPointCloud<PointCloudColor> does not compile in the reference (SURVEY.md 4)");
+	HIP_TRY(hipSetDevice(m->device));
+	swapSets(m);  // the staging buffers belong to the hand-over set of THIS scan
+	const uint8_t* d_data = static_cast<const uint8_t*>(data);
+	hipError_t e = hipSuccess;
+	if (n_points && !data_on_device) {
+		// the caller's message is never referenced after this call returns; what crosses PCIe is the raw record
+		// stream (point_step bytes per point), not 24 bytes of float64 per point
+		e = m->b_in_xyz.reserve(n_points * (size_t)point_step);
+		if (e == hipSuccess) e = hipMemcpyAsync(m->b_in_xyz.p, data, n_points * (size_t)point_step, hipMemcpyHostToDevice, m->sstream);
+		if (e == hipSuccess) e = hipStreamSynchronize(m->sstream);
+		d_data = m->b_in_xyz.as<uint8_t>();
+	}
+	uint8_t* d_rgb = nullptr;
+	if (e == hipSuccess && n_points && m->g.color) {
+		e = m->b_in_rgb.reserve(n_points * 3);
+		d_rgb = m->b_in_rgb.as<uint8_t>();
+	}
+	if (e != hipSuccess) {
+		swapSets(m);
+		return fail(UFOMAP_ERR_DEVICE, hipGetErrorString(e));
+	}
+	Ingest ing{};
+	ing.data = d_data;
+	ing.step = point_step;
+	ing.ox = (u32)off_x;
+	ing.oy = (u32)off_y;
+	ing.oz = (u32)off_z;
+	ing.orr = has_rgb ? off_r : -1;
+	ing.og = has_rgb ? off_g : -1;
+	ing.ob = has_rgb ? off_b : -1;
+	for (int k = 0; k < 4; ++k) ing.q[k] = rotation_wxyz[k];
+	for (int k = 0; k < 3; ++k) ing.t[k] = translation[k];
+	ing.rgb_out = d_rgb;
+	m->ing = ing;
+	// insertPointCloudDiscrete(transform.translation(), cloud, ...) (ufomap_mapping/src/server.cpp:118-120)
+	const int rc = doInsert(m, translation, reinterpret_cast<const double*>(d_data), d_rgb, n_points, max_range, depth, discrete,
+	                        simple_ray_casting, early_stopping, async, true);
+	m->ing = Ingest{};
+	return rc;
 }
 
 int ufomap_map_wait(ufomap_map* m)

@@ -100,6 +100,25 @@ class OccupancyMapBase:
                                                       int(depth), int(discrete), int(simple_ray_casting), int(early_stopping),
                                                       int(async_)))
 
+    def insertPointCloud2(self, translation, rotation_wxyz, data, point_step, off_xyz, off_rgb=None, max_range=-1.0, depth=0,
+                          discrete=True, simple_ray_casting=False, early_stopping=0, async_=False, n_points=None):
+        """rosToUfo + cloud.transform(pose) + insertPointCloudDiscrete(pose.translation(), cloud, ...) of the
+        reference's server (ufomap_mapping/src/server.cpp:114-120) on the raw records of a PointCloud2:
+        ``data`` = uint8 numpy array (host) or an int device pointer (then pass ``n_points``); float32 x, y, z
+        at byte offsets ``off_xyz``; bytes r, g, b at ``off_rgb`` (None: no colour)."""
+        t = np.ascontiguousarray(translation, np.float64)
+        q = np.ascontiguousarray(rotation_wxyz, np.float64)
+        orgb = tuple(int(o) for o in off_rgb) if off_rgb is not None else (-1, -1, -1)
+        if isinstance(data, (int, np.integer)):
+            ptr, on_dev, n = int(data), 1, int(n_points)
+        else:
+            data = np.ascontiguousarray(data, np.uint8).reshape(-1)
+            ptr, on_dev, n = data.ctypes.data if data.size else None, 0, data.size // int(point_step)
+        capi.check(self._lib.ufomap_map_insert_pointcloud2(self._h, _p(t, C.c_double), _p(q, C.c_double), ptr, on_dev, n, int(point_step),
+                                                           int(off_xyz[0]), int(off_xyz[1]), int(off_xyz[2]), *orgb, float(max_range),
+                                                           int(depth), int(discrete), int(simple_ray_casting), int(early_stopping),
+                                                           int(async_)))
+
     # ---- multi-GPU batched scans: the path split at its exchange point (include/ufomap_hip.h) ------
     ENTRY_BYTES = 16
 
