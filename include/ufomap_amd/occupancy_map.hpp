@@ -102,6 +102,18 @@ class OccupancyMapBase
 	{
 		insert(sensor_origin, cloud, max_range, depth, true, simple_ray_casting, early_stopping, async);
 	}
+	// The server's rosToUfo + cloud.transform(pose) + insertPointCloudDiscrete(pose.translation(), cloud, ...)
+	// (ufomap_mapping/src/server.cpp:114-120) on the raw records of a sensor_msgs/PointCloud2 (msg.data,
+	// msg.point_step, field offsets; r/g/b offsets -1 without colour): conversion, NaN filter and transform run
+	// inside the first kernel of the scan. No counterpart of this name in the reference.
+	void insertPointCloud2(double const translation[3], double const rotation_wxyz[4], void const* data, std::size_t n_points,
+	                       unsigned point_step, int off_x, int off_y, int off_z, int off_r = -1, int off_g = -1, int off_b = -1,
+	                       double max_range = -1, DepthType depth = 0, bool simple_ray_casting = false, unsigned int early_stopping = 0,
+	                       bool async = false, bool data_on_device = false)
+	{
+		check(ufomap_map_insert_pointcloud2(map_, translation, rotation_wxyz, data, data_on_device, n_points, point_step, off_x, off_y, off_z,
+		                                    off_r, off_g, off_b, max_range, depth, 1, simple_ray_casting, early_stopping, async));
+	}
 	bool insertPointCloudDone() const { return check(ufomap_map_done(map_)) != 0; }
 	void insertPointCloudWait() const { check(ufomap_map_wait(map_)); }
 
