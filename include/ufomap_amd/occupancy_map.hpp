@@ -117,6 +117,27 @@ class OccupancyMapBase
 	bool insertPointCloudDone() const { return check(ufomap_map_done(map_)) != 0; }
 	void insertPointCloudWait() const { check(ufomap_map_wait(map_)); }
 
+	// ---- robot clearing (occupancy_map_base.h:492-518; ufomap_mapping/src/server.cpp:152-155) --------
+	// setValueVolume(ufo::geometry::AABB(min, max), occupancy_value, min_depth): the AABB is passed as the two
+	// corners the server constructs it from.
+	void setValueVolume(Point3 const& aabb_min, Point3 const& aabb_max, double occupancy_value, DepthType min_depth = 0)
+	{
+		double const mn[3] = {aabb_min.x(), aabb_min.y(), aabb_min.z()}, mx[3] = {aabb_max.x(), aabb_max.y(), aabb_max.z()};
+		check(ufomap_map_set_value_volume(map_, mn, mx, occupancy_value, min_depth));
+	}
+	double getClampingThresMin() const
+	{
+		double a = 0, b = 0;
+		check(ufomap_map_clamping_thres(map_, &a, &b));
+		return a;
+	}
+	double getClampingThresMax() const
+	{
+		double a = 0, b = 0;
+		check(ufomap_map_clamping_thres(map_, &a, &b));
+		return b;
+	}
+
 	// ---- sensor model (occupancy_map_base.h:746-773) -------------------------------------------------
 	void setSensorModel(double occupied_thres, double free_thres, double prob_hit, double prob_miss, double clamping_thres_min,
 	                    double clamping_thres_max)

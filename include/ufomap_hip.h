@@ -94,6 +94,16 @@ int ufomap_map_insert_pointcloud2(ufomap_map* m, const double translation[3], co
                                   int off_r, int off_g, int off_b, double max_range, unsigned depth, int discrete,
                                   int simple_ray_casting, unsigned early_stopping, int async);
 
+/* OccupancyMapBase::setValueVolume(ufo::geometry::AABB(aabb_min, aabb_max), occupancy_value, min_depth)
+ * (occupancy_map_base.h:492-518, 986-1031): every node of depth min_depth (voxel for 0) whose box intersects the
+ * volume gets clamp(toLogit(occupancy_value)), expanded nodes among them lose their subtrees, ancestors are
+ * re-evaluated and pruned exactly as the reference's recursion does. The server calls it after every scan to
+ * clear the robot's own volume (ufomap_mapping/src/server.cpp:137-168). AABB volumes only. */
+int ufomap_map_set_value_volume(ufomap_map* m, const double aabb_min[3], const double aabb_max[3], double occupancy_value,
+                                unsigned min_depth);
+/* getClampingThresMin() / getClampingThresMax() (occupancy_map_base.h:742-744), the value the server passes */
+int ufomap_map_clamping_thres(ufomap_map* m, double* thres_min, double* thres_max);
+
 int ufomap_map_wait(ufomap_map* m);
 int ufomap_map_done(ufomap_map* m);
 

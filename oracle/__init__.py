@@ -75,6 +75,9 @@ def _load(kind: str):
     lib.ufo_oracle_last_steps.argtypes = [vp]
     lib.ufo_oracle_last_oob.restype = C.c_uint64
     lib.ufo_oracle_last_oob.argtypes = [vp]
+    lib.ufo_oracle_set_value_volume.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.c_uint]
+    lib.ufo_oracle_clamping_thres.restype = None
+    lib.ufo_oracle_clamping_thres.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.ufo_oracle_ingest.restype = C.c_size_t
     lib.ufo_oracle_ingest.argtypes = [u8p, C.c_size_t, C.c_uint32] + [C.c_int] * 6 + [C.POINTER(C.c_double)] * 3 + [u8p]
     lib.ufo_oracle_kind.restype = C.c_char_p
@@ -168,6 +171,17 @@ class OracleMap:
         buf = np.empty(n, np.uint8)
         self.lib.ufo_oracle_write(self.h, _ptr(buf, C.c_uint8), n)
         return buf.tobytes()
+
+    def setValueVolume(self, aabb_min, aabb_max, occupancy_value, min_depth=0):
+        """OccupancyMapBase::setValueVolume(AABB(min, max), occupancy_value, min_depth) (robot clearing)."""
+        mn = np.ascontiguousarray(aabb_min, np.float64)
+        mx = np.ascontiguousarray(aabb_max, np.float64)
+        self.lib.ufo_oracle_set_value_volume(self.h, _ptr(mn, C.c_double), _ptr(mx, C.c_double), float(occupancy_value), int(min_depth))
+
+    def clamping_thres(self):
+        a, b = C.c_double(), C.c_double()
+        self.lib.ufo_oracle_clamping_thres(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
 
     def minmax_change(self):
         mn = np.empty(3, np.float64)

@@ -73,6 +73,14 @@ uint64_t ufo_oracle_last_steps(const ufo_oracle_map* m);
 uint64_t ufo_oracle_last_oob(const ufo_oracle_map* m);
 
 /* "reference" or "port". */
+/* Robot clearing: OccupancyMapBase::setValueVolume(AABB(mn, mx), occupancy_value, min_depth)
+ * (map/occupancy_map_base.h:492-518, 986-1031; geometry/aabb.h:62-65; collision_checks.cpp:256-264) as the server
+ * calls it after every scan (ufomap_mapping/src/server.cpp:152-155). occupancy_value is a probability. */
+int ufo_oracle_set_value_volume(ufo_oracle_map* m, const double mn[3], const double mx[3], double occupancy_value,
+                                unsigned min_depth);
+/* getClampingThresMin() / getClampingThresMax() (occupancy_map_base.h:742-744): toProb of the stored logits */
+void ufo_oracle_clamping_thres(const ufo_oracle_map* m, double* thres_min, double* thres_max);
+
 /* Ingest in front of the hot path: rosToUfo (ufomap_ros/ufomap_ros/src/conversions.cpp:
  * 98-138: float32 x, y, z [+ r, g, b bytes] at byte offsets inside records of `step` bytes; points with a NaN
  * coordinate are dropped) followed by PointCloud::transform (map/point_cloud.h:157-166 -> math/pose6.h:114-125

@@ -238,6 +238,22 @@ size_t ufo_oracle_last_misses(const ufo_oracle_map*, uint64_t*, size_t) { return
 uint64_t ufo_oracle_last_steps(const ufo_oracle_map*) { return (uint64_t)-1; }
 uint64_t ufo_oracle_last_oob(const ufo_oracle_map*) { return (uint64_t)-1; }
 
+int ufo_oracle_set_value_volume(ufo_oracle_map* m, const double mn[3], const double mx[3], double occupancy_value, unsigned min_depth)
+{
+	// exactly what the server does (ufomap_mapping/src/server.cpp:152-155): AABB(min, max), then setValueVolume
+	ufo::geometry::AABB aabb(ufo::geometry::Point(mn[0], mn[1], mn[2]), ufo::geometry::Point(mx[0], mx[1], mx[2]));
+	if (m->col)
+		m->col->setValueVolume(aabb, occupancy_value, min_depth);
+	else
+		m->occ->setValueVolume(aabb, occupancy_value, min_depth);
+	return 0;
+}
+void ufo_oracle_clamping_thres(const ufo_oracle_map* m, double* thres_min, double* thres_max)
+{
+	*thres_min = m->col ? m->col->getClampingThresMin() : m->occ->getClampingThresMin();
+	*thres_max = m->col ? m->col->getClampingThresMax() : m->occ->getClampingThresMax();
+}
+
 // The conversion loop of ufomap_ros (conversions.cpp:98-138) needs ROS message types and is restated here; the
 // transform is the reference's own Pose6::transform on its own Point3Color.
 size_t ufo_oracle_ingest(const uint8_t* data, size_t n, uint32_t step, int off_x, int off_y, int off_z, int off_r, int off_g,

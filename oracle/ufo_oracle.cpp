@@ -611,6 +611,73 @@ struct ufo_oracle_map {
 	}
 
 	/* node payload: OccupancyNode::writeData / ColorOccupancyNode::writeData (occupancy_map_node.h:67-71, 150-153) */
+	/* occupancy_map_base.h:1151-1157 (LogitType = float: the double logit is converted, then clamped) */
+	bool setOccupancy(float& cur, double new_value) const
+	{
+		float old = cur;
+		float nv = (float)new_value, lo = (float)cmin_log, hi = (float)cmax_log;
+		cur = (nv < lo) ? lo : ((hi < nv) ? hi : nv);
+		return old != cur;
+	}
+	/* geometry/collision_checks.cpp:256-264 with AABB::getMin/getMax (aabb.h:67-69): volume = (centre, half size) */
+	static bool intersects(V3 const& c1, V3 const& h1, V3 const& c2, V3 const& h2)
+	{
+		for (int a = 0; a < 3; ++a) {
+			double min1 = c1.v[a] - h1.v[a], max1 = c1.v[a] + h1.v[a], min2 = c2.v[a] - h2.v[a], max2 = c2.v[a] + h2.v[a];
+			if (!(min1 <= max2) || !(min2 <= max1)) return false;
+		}
+		return true;
+	}
+	/* occupancy_map_base.h:986-1031 */
+	bool setValueVolumeRecurs(V3 const& vc, V3 const& vh, double value, int n, V3 const& center, unsigned depth, unsigned min_depth)
+	{
+		unsigned const cd = depth - 1;
+		double const chs = hs[cd];
+		createChildren(n, depth);
+		V3 const h{{chs, chs, chs}};
+		bool changed = false;
+		for (int i = 0; i < 8; ++i) {
+			V3 c = center;  // octree.h:625-633
+			c.v[0] += ((i & 1) ? chs : -chs);
+			c.v[1] += ((i & 2) ? chs : -chs);
+			c.v[2] += ((i & 4) ? chs : -chs);
+			if (!intersects(vc, vh, c, h)) continue;
+			int ch = pool[n].child + i;
+			if (0 == cd) {
+				if (setOccupancy(pool[ch].occ, value)) changed = true;
+			} else if (min_depth < cd) {
+				if (setValueVolumeRecurs(vc, vh, value, ch, c, cd, min_depth)) changed = true;
+			} else {
+				deleteChildren(ch, cd, false);
+				if (setOccupancy(pool[ch].occ, value)) changed = true;
+				if (updateNode(ch, cd)) changed = true;
+			}
+		}
+		return !changed || updateNode(n, depth);
+	}
+	/* occupancy_map_base.h:492-518 */
+	void setValueVolume(const double mn[3], const double mx[3], double occupancy_value, unsigned min_depth)
+	{
+		if (L < min_depth) return;
+		// AABB(min, max) (aabb.h:62-65): half_size = (max - min) / 2, center = min + half_size
+		V3 vh, vc;
+		for (int a = 0; a < 3; ++a) {
+			vh.v[a] = (mx[a] - mn[a]) / 2.0;
+			vc.v[a] = mn[a] + vh.v[a];
+		}
+		V3 const center{{0, 0, 0}};
+		double const half = hs[L];
+		if (!intersects(vc, vh, center, V3{{half, half, half}})) return;
+		double const logit = std::log(occupancy_value / (1.0 - occupancy_value));  // toLogit, OMB:909
+		if (L == min_depth) {
+			deleteChildren(0, L, false);
+			setOccupancy(pool[0].occ, logit);
+			updateNode(0, L);
+			return;
+		}
+		if (setValueVolumeRecurs(vc, vh, logit, 0, center, L, min_depth)) updateNode(0, L);
+	}
+
 	void putData(std::string& out, Node const& nd) const
 	{
 		out.append(reinterpret_cast<const char*>(&nd.occ), 4);
@@ -802,6 +869,18 @@ size_t ufo_oracle_last_misses(const ufo_oracle_map* m, uint64_t* codes, size_t c
 }
 uint64_t ufo_oracle_last_steps(const ufo_oracle_map* m) { return m->last_steps; }
 uint64_t ufo_oracle_last_oob(const ufo_oracle_map* m) { return m->last_oob; }
+
+int ufo_oracle_set_value_volume(ufo_oracle_map* m, const double mn[3], const double mx[3], double occupancy_value, unsigned min_depth)
+{
+	m->setValueVolume(mn, mx, occupancy_value, min_depth);
+	return 0;
+}
+void ufo_oracle_clamping_thres(const ufo_oracle_map* m, double* thres_min, double* thres_max)
+{
+	// toProb(LogitType) with LogitType = float: std::exp(float) (OMB:911, 742-744)
+	*thres_min = ufo_oracle_map::toProb((float)m->cmin_log);
+	*thres_max = ufo_oracle_map::toProb((float)m->cmax_log);
+}
 
 // Quaternion::operator* (math/quaternion.h:253-259), operands (w, x, y, z)
 static void quatMul(const double a[4], const double b[4], double r[4])

@@ -278,6 +278,43 @@ def test_pointcloud2_ingest_fused_equals_reference_chain(color):
         _assert_same_map(g, o, f"pointcloud2 scan {s}")
 
 
+@pytest.mark.parametrize("color", [False, True])
+def test_set_value_volume_robot_clearing(color):
+    """the server's per-scan robot clearing -- setValueVolume(AABB around the sensor,
+    getClampingThresMin(), clearing depth) after every insert -- level-synchronous on the GPU against the
+    reference's recursion: values, inner nodes, pruned structure, byte stream; min_depth 0, 1, 2."""
+    from ufomap_amd import scans
+    g, o = _maps(color=color, resolution=0.16)
+    assert g.getClampingThresMin() == o.clamping_thres()[0] and g.getClampingThresMax() == o.clamping_thres()[1]
+    for s in range(3):
+        origin, xyz, rgb = scans.lidar64(beams=32, azimuths=512, origin=scans.lidar_pose(s), seed=3 + s, colored=color)
+        _gpu_insert(g, origin, xyz, rgb if color else None, max_range=12.0, discrete=True)
+        o.insert(origin, xyz, rgb if color else None, max_range=12.0, discrete=True)
+        c = np.array(origin)
+        for md in (0, 1, 2, 0):
+            ext = np.array([0.45, 0.45, 0.6]) * (1 + md)
+            g.setValueVolume(c - ext, c + ext, g.getClampingThresMin(), md)
+            o.setValueVolume(c - ext, c + ext, o.clamping_thres()[0], md)
+            what = f"scan {s} min_depth {md}"
+            assert same_dump(g.leaves(True), o.leaves(True)), what + ": leaves differ"
+            assert same_dump(g.inner(), o.inner()), what + ": inner nodes differ"
+        assert g.write() == o.write()
+    # fresh map: the volume expands unknown space from the root down
+    g2, o2 = _maps(color=color, resolution=0.16)
+    g2.setValueVolume([-0.5, -0.3, -0.2], [0.7, 0.4, 0.9], 0.3, 0)
+    o2.setValueVolume([-0.5, -0.3, -0.2], [0.7, 0.4, 0.9], 0.3, 0)
+    assert same_dump(g2.leaves(True), o2.leaves(True)) and same_dump(g2.inner(), o2.inner())
+    # no-ops: outside the map, min_depth beyond the tree
+    before = g2.write()
+    g2.setValueVolume([1e7, 1e7, 1e7], [2e7, 2e7, 2e7], 0.2, 0)
+    g2.setValueVolume([-1, -1, -1], [1, 1, 1], 0.2, 40)
+    assert g2.write() == before
+    # min_depth == depth_levels: the root itself
+    g2.setValueVolume([-1, -1, -1], [1, 1, 1], 0.2, 16)
+    o2.setValueVolume([-1, -1, -1], [1, 1, 1], 0.2, 16)
+    assert same_dump(g2.leaves(True), o2.leaves(True)) and same_dump(g2.inner(), o2.inner())
+
+
 def test_batch_integrator_rccl_world1():
     """BatchIntegrator on HBM tensors through the nccl (RCCL) backend with a single rank: the same code
     path the 8-GPU run takes, minus the peers."""

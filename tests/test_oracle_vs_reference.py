@@ -107,3 +107,32 @@ def test_ingest_port_equals_reference_pose6_transform():
     keep = ~np.isnan(buf[:, 0:12].copy().view(np.float32).reshape(-1, 3)).any(axis=1)
     assert np.array_equal(a[0], buf[:, 0:12].copy().view(np.float32).reshape(-1, 3)[keep].astype(np.float64))
     assert not a[1].any()
+
+
+@pytest.mark.parametrize("color", [False, True])
+def test_set_value_volume_port_equals_reference(color):
+    """Robot clearing: setValueVolume(AABB, getClampingThresMin(), min_depth) after every
+    scan, as the server does; min_depth 0, 1, 2 (subtrees deleted), pruning on and off."""
+    from ufomap_amd import scans
+    from oracle import OracleMap
+    for pruning in (True, False):
+        p = OracleMap(0.16, color=color, automatic_pruning=pruning, kind="port")
+        r = OracleMap(0.16, color=color, automatic_pruning=pruning, kind="reference")
+        assert p.clamping_thres() == r.clamping_thres()
+        for s in range(3):
+            origin, xyz, rgb = scans.lidar64(beams=16, azimuths=256, origin=scans.lidar_pose(s), seed=3 + s, colored=color)
+            for m in (p, r):
+                m.insert(origin, xyz, rgb if color else None, max_range=10.0, discrete=True)
+            c = np.array(origin)
+            for md in (0, 1, 2, 0):
+                ext = np.array([0.45, 0.45, 0.6]) * (1 + md)
+                for m in (p, r):
+                    m.setValueVolume(c - ext, c + ext, m.clamping_thres()[0], md)
+                assert same_dump(p.leaves(True), r.leaves(True)), (pruning, s, md)
+                assert same_dump(p.inner(), r.inner()), (pruning, s, md)
+                assert p.write() == r.write()
+    # a volume outside the map, and min_depth beyond the tree: no-ops
+    before = p.write()
+    p.setValueVolume([1e7, 1e7, 1e7], [2e7, 2e7, 2e7], 0.2, 0)
+    p.setValueVolume([-1, -1, -1], [1, 1, 1], 0.2, 40)
+    assert p.write() == before

@@ -854,6 +854,221 @@ __global__ __launch_bounds__(1024) void k_propagate_tail(Table t, MapGeom g, u32
 }
 
 // ------------------------------------------------------------------------------------------------
+// Robot clearing: OccupancyMapBase::setValueVolume(AABB, value, min_depth)
+// (occupancy_map_base.h:492-518) with setValueVolumeRecurs (986-1031) as the server calls it after every scan
+// (ufomap_mapping/src/server.cpp:152-155). The reference recurses from the root through every node whose box
+// intersects the volume (createChildren on each: a leaf on the way is expanded by inheritance), sets the
+// intersecting children at min_depth (or the voxels), and on the way back calls updateNode on a node only if
+// something beneath it changed -- returning "true" also when NOTHING changed (`return !changed || updateNode`),
+// which the caller counts as a change. Here the recursion is level-synchronous: one launch per level down
+// (k_vol_down: a record per visited node, its centre carried along because the reference adds +-half sizes
+// level by level, octree.h:625-633), a breadth-first kill of the subtrees that deleteChildren removes
+// (k_vol_kill), one launch per level up (k_vol_up).
+// ------------------------------------------------------------------------------------------------
+struct VolRec {
+	u64 lk;       // key of the visited node's children block
+	double c[3];  // centre of the node
+	u32 parent;   // record of the parent node (NONE for the root)
+	u32 slot;     // table slot of the children block
+	u32 changed;  // "changed" of the reference's loop: own children, plus what the recursion into them returned
+	u32 pad;
+};
+struct VolArgs {
+	double vc[3], vh[3];  // the volume: AABB(min, max) = centre, half size (geometry/aabb.h:62-65)
+	float val;            // clamp(float(toLogit(occupancy_value))) (occupancy_map_base.h:1151-1157)
+	u32 min_depth;
+};
+// geometry::intersects(AABB, AABB) (collision_checks.cpp:256-264) on getMin/getMax (aabb.h:67-69)
+__device__ inline bool volIntersects(const VolArgs& a, const double c[3], double h)
+{
+#pragma unroll
+	for (int k = 0; k < 3; ++k) {
+		const double min1 = a.vc[k] - a.vh[k], max1 = a.vc[k] + a.vh[k], min2 = c[k] - h, max2 = c[k] + h;
+		if (!(min1 <= max2) || !(min2 <= max1)) return false;
+	}
+	return true;
+}
+
+__global__ void k_vol_begin(VolRec* __restrict__ rec, ScanCtl* ctl, u32 L)
+{
+	VolRec r;
+	r.lk = 1;
+	r.c[0] = r.c[1] = r.c[2] = 0.0;
+	r.parent = NONE;
+	r.slot = NONE;
+	r.changed = 0;
+	r.pad = 0;
+	rec[0] = r;
+	ctl->dl_start[L] = 0;
+	ctl->dl_total = 1;
+	ctl->dl_start[L - 1] = 1;
+}
+
+// One level of the descent: the records of depth `cd` nodes are [dl_start[cd], dl_start[cd-1]).
+// kill: blocks whose subtree deleteChildren removes (children at min_depth that had been expanded).
+__global__ __launch_bounds__(256) void k_vol_down(Table t, MapGeom g, VolArgs a, u32 cd, VolRec* __restrict__ rec, u32 rcap,
+                                                  u32* __restrict__ kill, u32 kcap, u32 scan_id, ScanCtl* ctl)
+{
+	const u32 lo = ctl->dl_start[cd], hi = min(ctl->dl_start[cd - 1], rcap);
+	const u32 max_probe = (t.mask >> 1) + 1;
+	const u32 child_depth = cd - 1;
+	const double chs = g.hs[child_depth];
+	u32 n_created = 0;
+	for (u32 r = lo + blockIdx.x * blockDim.x + threadIdx.x; r < hi; r += gridDim.x * blockDim.x) {
+		VolRec me = rec[r];
+		// createChildren (octree.h:1022-1058): a leaf node gets its 8 children, each a copy of the node
+		bool created;
+		const u32 s = tableEnsure(t, me.lk, scan_id, max_probe, &created, &n_created);
+		if (s == NONE) {
+			atomicOr(&ctl->err, ERR_TABLE_FULL);
+			continue;
+		}
+		rec[r].slot = s;
+		if (created) {
+			float v;
+			u32 col = 0;
+			if (1 == me.lk) {
+				t.parent[s] = NONE;
+				v = t.root->occ;
+				col = t.root->rgb;
+			} else {
+				const u32 p = rec[me.parent].slot, ci = (u32)(me.lk & 7);
+				t.parent[s] = p;
+				atomicOr(&t.flags[p], 1u << (16 + ci));
+				v = t.occ[8 * (size_t)p + ci];
+				if (g.color) col = t.rgb[8 * (size_t)p + ci];
+			}
+			float4 vv = make_float4(v, v, v, v);
+			float4* po = reinterpret_cast<float4*>(t.occ + 8 * (size_t)s);
+			po[0] = vv;
+			po[1] = vv;
+			if (g.color) {
+				uint4 cc = make_uint4(col, col, col, col);
+				uint4* pc = reinterpret_cast<uint4*>(t.rgb + 8 * (size_t)s);
+				pc[0] = cc;
+				pc[1] = cc;
+			}
+			// leaf children carry the flags of a leaf with this value (as k_init_new; OMB:1181-1189)
+			t.flags[s] = (isFreeV(g, v) ? F_CFREE : 0u) | (isUnknownV(g, v) ? F_CUNK : 0u);
+		}
+		u32 changed = 0;
+		for (u32 i = 0; i < 8; ++i) {
+			double cc[3] = {me.c[0], me.c[1], me.c[2]};  // getChildCenter (octree.h:625-633)
+			cc[0] += ((i & 1) ? chs : -chs);
+			cc[1] += ((i & 2) ? chs : -chs);
+			cc[2] += ((i & 4) ? chs : -chs);
+			if (!volIntersects(a, cc, chs)) continue;
+			float* pv = t.occ + 8 * (size_t)s + i;
+			if (0 == child_depth) {
+				if (*pv != a.val) changed = 1;  // setOccupancy (OMB:1151-1157)
+				*pv = a.val;
+			} else if (a.min_depth < child_depth) {
+				const u32 pos = atomicAdd(&ctl->dl_total, 1u);
+				if (pos < rcap) {
+					VolRec ch;
+					ch.lk = (me.lk << 3) | (u64)i;
+					ch.c[0] = cc[0];
+					ch.c[1] = cc[1];
+					ch.c[2] = cc[2];
+					ch.parent = r;
+					ch.slot = NONE;
+					ch.changed = 0;
+					ch.pad = 0;
+					rec[pos] = ch;
+				} else {
+					atomicOr(&ctl->err, ERR_ENTRIES);
+				}
+			} else {
+				// deleteChildren(child) + setOccupancy(child) + updateNode(child), the child now a leaf (OMB:1019-1026)
+				const u32 f = __hip_atomic_load(&t.flags[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if (f & (1u << (16 + i))) {
+					const u32 cs = tableFind(t, (me.lk << 3) | (u64)i);
+					if (cs != NONE) {
+						const u32 kp = atomicAdd(&ctl->n_codes, 1u);
+						if (kp < kcap) kill[kp] = cs;
+						else atomicOr(&ctl->err, ERR_ENTRIES);
+					}
+					atomicAnd(&t.flags[s], ~(1u << (16 + i)));
+				}
+				if (*pv != a.val) changed = 1;
+				*pv = a.val;
+				const u32 nf = isFreeV(g, a.val) ? 1u : 0u, nu = isUnknownV(g, a.val) ? 1u : 0u;
+				if (((f >> i) & 1u) != nf || ((f >> (8 + i)) & 1u) != nu) changed = 1;  // updateNode, leaf branch (OMB:1181-1189)
+				atomicAnd(&t.flags[s], ~((1u << i) | (1u << (8 + i))));
+				if (nf | nu) atomicOr(&t.flags[s], (nf << i) | (nu << (8 + i)));
+			}
+		}
+		rec[r].changed = changed;
+	}
+	for (int o = 32; o > 0; o >>= 1) n_created += __shfl_xor(n_created, o);
+	if (__lane_id() == 0 && n_created) atomicAdd(&t.root->used, n_created);
+}
+
+// Breadth-first removal of subtrees: blocks kill[lo, hi) die, their live child blocks are appended.
+// The range bounds live in ctl->dbg[56] (lo) / ctl->n_codes (end of the list); k_vol_kill_mark advances lo.
+__global__ void k_vol_kill_mark(ScanCtl* ctl, u32 which)
+{
+	if (0 == which) {
+		ctl->dbg[56] = 0;
+		ctl->dbg[57] = ctl->n_codes;
+	} else {
+		ctl->dbg[56] = ctl->dbg[57];
+		ctl->dbg[57] = ctl->n_codes;
+	}
+}
+__global__ __launch_bounds__(256) void k_vol_kill(Table t, u32* __restrict__ kill, u32 kcap, ScanCtl* ctl)
+{
+	const u32 lo = (u32)ctl->dbg[56], hi = min((u32)ctl->dbg[57], kcap);
+	for (u32 k = lo + blockIdx.x * blockDim.x + threadIdx.x; k < hi; k += gridDim.x * blockDim.x) {
+		const u32 s = kill[k];
+		const u32 f = t.flags[s];
+		const u64 lk = t.keys[s];
+		for (u32 i = 0; i < 8; ++i) {
+			if (!(f & (1u << (16 + i)))) continue;
+			const u32 cs = tableFind(t, (lk << 3) | (u64)i);
+			if (cs == NONE) continue;
+			const u32 kp = atomicAdd(&ctl->n_codes, 1u);
+			if (kp < kcap) kill[kp] = cs;
+			else atomicOr(&ctl->err, ERR_ENTRIES);
+		}
+		t.flags[s] = (f & ~(F_INNER | F_DIRTY | F_SUB)) | F_DEAD;  // a revived block starts without inner children
+	}
+}
+
+// One level of the way back: `return !changed || updateNode(node, depth)` (OMB:1030) for the depth-`cd` records.
+__global__ __launch_bounds__(256) void k_vol_up(Table t, MapGeom g, u32 cd, VolRec* __restrict__ rec, u32 rcap, const ScanCtl* ctl)
+{
+	if (ctl->err) return;
+	const u32 lo = ctl->dl_start[cd], hi = min(ctl->dl_start[cd - 1], rcap);
+	for (u32 r = lo + blockIdx.x * blockDim.x + threadIdx.x; r < hi; r += gridDim.x * blockDim.x) {
+		const VolRec me = rec[r];
+		bool ret = true;
+		if (me.changed) {
+			// updateNode of a node with children (OMB:1191-1224): summary, collapse, compare
+			const u32 f = t.flags[me.slot];
+			const Summ sm = blockSummary(t, g, me.slot, cd, f);
+			if (sm.collapsible) collapseBlock(t, me.slot, me.lk);
+			ret = writeToParent(t, g, me.slot, me.lk, sm);
+		}
+		if (ret && me.parent != NONE) atomicOr(&rec[me.parent].changed, 1u);
+	}
+}
+
+// min_depth == depth_levels: the root itself is set (OMB:505-511) -- every block dies
+__global__ __launch_bounds__(256) void k_vol_root(Table t, MapGeom g, float val)
+{
+	const u32 ncap = t.mask + 1;
+	for (u32 s = blockIdx.x * blockDim.x + threadIdx.x; s < ncap; s += gridDim.x * blockDim.x) {
+		if (0 == t.keys[s]) continue;
+		t.flags[s] = (t.flags[s] & ~(F_INNER | F_DIRTY | F_SUB)) | F_DEAD;
+	}
+	if (0 == blockIdx.x && 0 == threadIdx.x) {
+		t.root->occ = val;
+		t.root->flags = (isFreeV(g, val) ? 1u : 0u) | (isUnknownV(g, val) ? 2u : 0u);
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
 // read-back
 // ------------------------------------------------------------------------------------------------
 struct DumpCtl {

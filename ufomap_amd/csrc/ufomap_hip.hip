@@ -1235,6 +1235,106 @@ int ufomap_map_insert_pointcloud2(ufomap_map* m, const double translation[3], co
 	return rc;
 }
 
+int ufomap_map_clamping_thres(ufomap_map* m, double* thres_min, double* thres_max)
+{
+	if (!m) return fail(UFOMAP_ERR_INVALID, "null map");
+	// getClampingThresMin/Max (occupancy_map_base.h:742-744): toProb(LogitType) with LogitType = float, std::exp(float)
+	if (thres_min) *thres_min = 1.0 / (1.0 + std::exp(-m->g.cmin));
+	if (thres_max) *thres_max = 1.0 / (1.0 + std::exp(-m->g.cmax));
+	return UFOMAP_OK;
+}
+
+int ufomap_map_set_value_volume(ufomap_map* m, const double aabb_min[3], const double aabb_max[3], double occupancy_value,
+                                unsigned min_depth)
+{
+	if (!m || !aabb_min || !aabb_max) return fail(UFOMAP_ERR_INVALID, "null argument");
+	HIP_TRY(hipSetDevice(m->device));
+	int rc = ufomap_map_wait(m);
+	if (rc) return rc;
+	const u32 L = m->g.L;
+	if (L < min_depth) return UFOMAP_OK;  // OMB:495-497
+	VolArgs a;
+	for (int k = 0; k < 3; ++k) {
+		a.vh[k] = (aabb_max[k] - aabb_min[k]) / 2.0;  // AABB(min, max), geometry/aabb.h:62-65
+		a.vc[k] = aabb_min[k] + a.vh[k];
+	}
+	a.min_depth = min_depth;
+	{
+		// the root's box (OMB:499-505)
+		const double half = m->g.hs[L];
+		for (int k = 0; k < 3; ++k) {
+			const double min1 = a.vc[k] - a.vh[k], max1 = a.vc[k] + a.vh[k], min2 = 0.0 - half, max2 = 0.0 + half;
+			if (!(min1 <= max2) || !(min2 <= max1)) return UFOMAP_OK;  // no node intersects
+		}
+	}
+	{
+		const float nv = (float)std::log(occupancy_value / (1.0 - occupancy_value));  // toLogit (OMB:909) -> LogitType
+		a.val = (nv < m->g.cmin) ? m->g.cmin : ((m->g.cmax < nv) ? m->g.cmax : nv);   // std::clamp (OMB:1154)
+	}
+	m->cs = m->stream;
+	ScanCtl init;
+	memset(&init, 0, sizeof(init));
+	for (int k = 0; k < 3; ++k) {
+		init.aabb_min[k] = ~0ull;
+		init.aabb_max[k] = 0ull;
+	}
+	*m->h_ctl = init;
+	HIP_TRY(hipMemcpyAsync(m->b_ctl.p, m->h_ctl, sizeof(ScanCtl), hipMemcpyHostToDevice, m->stream));
+	ScanCtl* ctl = m->b_ctl.as<ScanCtl>();
+	m->scan_id += 1;
+	if (L == min_depth) {
+		hipLaunchKernelGGL(k_vol_root, gridFor((u64)m->t.mask + 1), dim3(256), 0, m->cs, m->t, m->g, a.val);
+	} else {
+		// records per level: nodes of that depth whose box can intersect the volume
+		u64 level_cap[24] = {0}, total = 0;
+		for (u32 cd = L; cd > min_depth; --cd) {
+			long double c = 1;
+			for (int k = 0; k < 3; ++k) c *= std::floor((long double)(2.0 * a.vh[k]) / (long double)nodeSize(m->g, cd)) + 2.0L;
+			level_cap[cd] = c > 4e9L ? (u64)4e9 : (u64)c;
+			if (cd == L) level_cap[cd] = 1;
+			total += level_cap[cd];
+		}
+		if (total > 0x7FFFFFFFull || total * sizeof(VolRec) > m->scratch_limit)
+			return fail(UFOMAP_ERR_CAPACITY, "setValueVolume: the volume covers too many nodes for the scratch limit");
+		const u32 rcap = (u32)total;
+		// every visited node may get a new children block
+		{
+			const u64 cap = (u64)m->t.mask + 1;
+			if ((m->used_est + total) * 5 > cap * 3) {
+				const u64 want = (m->used_est + total) * 2;
+				if (want > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
+				rc = growTable(m, nextPow2(want));
+				if (rc) return rc;
+			}
+		}
+		const u32 kcap = (u32)std::min<u64>(m->used_est + 8, 0x7FFFFFFFull);
+		HIP_TRY(m->b_crec.reserve((size_t)rcap * sizeof(VolRec)));
+		HIP_TRY(m->b_dlist.reserve((size_t)kcap * 4));
+		VolRec* rec = m->b_crec.as<VolRec>();
+		u32* kill = m->b_dlist.as<u32>();
+		hipLaunchKernelGGL(k_vol_begin, dim3(1), dim3(1), 0, m->cs, rec, ctl, L);
+		for (u32 cd = L; cd > min_depth; --cd) {
+			hipLaunchKernelGGL(k_vol_down, gridFor(level_cap[cd], 256, 4096), dim3(256), 0, m->cs, m->t, m->g, a, cd, rec, rcap, kill, kcap,
+			                   m->scan_id, ctl);
+			if (cd - 1 > min_depth && cd >= 2) hipLaunchKernelGGL(k_coarse_mark, dim3(1), dim3(1), 0, m->cs, ctl, cd - 2);
+		}
+		if (min_depth >= 1) {
+			hipLaunchKernelGGL(k_vol_kill_mark, dim3(1), dim3(1), 0, m->cs, ctl, 0u);
+			for (u32 l = 0; l < min_depth; ++l) {
+				hipLaunchKernelGGL(k_vol_kill, gridFor(std::max<u64>(kcap, 256), 256, 4096), dim3(256), 0, m->cs, m->t, kill, kcap, ctl);
+				hipLaunchKernelGGL(k_vol_kill_mark, dim3(1), dim3(1), 0, m->cs, ctl, 1u);
+			}
+		}
+		for (u32 cd = min_depth + 1; cd <= L; ++cd)
+			hipLaunchKernelGGL(k_vol_up, gridFor(level_cap[cd], 256, 4096), dim3(256), 0, m->cs, m->t, m->g, cd, rec, rcap, ctl);
+	}
+	HIP_TRY(hipGetLastError());
+	m->pending = true;
+	m->pending_set = m->cur_set;
+	HIP_TRY(hipStreamSynchronize(m->stream));
+	return finishPending(m);
+}
+
 int ufomap_map_wait(ufomap_map* m)
 {
 	if (!m) return fail(UFOMAP_ERR_INVALID, "null map");

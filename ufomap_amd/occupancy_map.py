@@ -119,6 +119,24 @@ class OccupancyMapBase:
                                                            int(depth), int(discrete), int(simple_ray_casting), int(early_stopping),
                                                            int(async_)))
 
+    def setValueVolume(self, aabb_min, aabb_max, occupancy_value, min_depth=0):
+        """OccupancyMapBase::setValueVolume(ufo::geometry::AABB(min, max), occupancy_value, min_depth)
+        (occupancy_map_base.h:492-518): the server's robot clearing (ufomap_mapping/src/server.cpp:152-155)."""
+        mn = np.ascontiguousarray(aabb_min, np.float64)
+        mx = np.ascontiguousarray(aabb_max, np.float64)
+        capi.check(self._lib.ufomap_map_set_value_volume(self._h, _p(mn, C.c_double), _p(mx, C.c_double), float(occupancy_value),
+                                                         int(min_depth)))
+
+    def getClampingThresMin(self):
+        a = np.zeros(2, np.float64)
+        capi.check(self._lib.ufomap_map_clamping_thres(self._h, _p(a[0:1], C.c_double), _p(a[1:2], C.c_double)))
+        return float(a[0])
+
+    def getClampingThresMax(self):
+        a = np.zeros(2, np.float64)
+        capi.check(self._lib.ufomap_map_clamping_thres(self._h, _p(a[0:1], C.c_double), _p(a[1:2], C.c_double)))
+        return float(a[1])
+
     # ---- multi-GPU batched scans: the path split at its exchange point (include/ufomap_hip.h) ------
     ENTRY_BYTES = 16
 
