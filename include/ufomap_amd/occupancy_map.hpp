@@ -122,7 +122,7 @@ class OccupancyMapBase
 	// corners the server constructs it from.
 	void setValueVolume(Point3 const& aabb_min, Point3 const& aabb_max, double occupancy_value, DepthType min_depth = 0)
 	{
-		double const mn[3] = {aabb_min.x(), aabb_min.y(), aabb_min.z()}, mx[3] = {aabb_max.x(), aabb_max.y(), aabb_max.z()};
+		double const mn[3] = {aabb_min.x, aabb_min.y, aabb_min.z}, mx[3] = {aabb_max.x, aabb_max.y, aabb_max.z};
 		check(ufomap_map_set_value_volume(map_, mn, mx, occupancy_value, min_depth));
 	}
 	double getClampingThresMin() const
