@@ -19,7 +19,9 @@
 #pragma once
 
 #include <array>
+#include <cmath>
 #include <cstdint>
+#include <utility>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -116,6 +118,30 @@ class OccupancyMapBase
 	}
 	bool insertPointCloudDone() const { return check(ufomap_map_done(map_)) != 0; }
 	void insertPointCloudWait() const { check(ufomap_map_wait(map_)); }
+
+	// ---- point queries (occupancy_map_base.h:599-728), answered by ufomap_map_query -------------------
+	std::pair<float, uint8_t> query(Point3 const& coord, DepthType depth) const
+	{
+		double const p[3] = {coord.x, coord.y, coord.z};
+		float lo = 0;
+		uint8_t st = 0;
+		check(ufomap_map_query(map_, p, 0, 1, depth, &lo, &st));
+		return {lo, st};
+	}
+	enum class OccupancyState { unknown, free, occupied };  // map/types.h
+	OccupancyState getState(Point3 const& coord, DepthType depth = 0) const
+	{
+		uint8_t st = query(coord, depth).second;
+		return (st & 1) ? OccupancyState::occupied : ((st & 2) ? OccupancyState::free : OccupancyState::unknown);
+	}
+	bool isOccupied(Point3 const& coord, DepthType depth = 0) const { return 0 != (query(coord, depth).second & 1); }
+	bool isFree(Point3 const& coord, DepthType depth = 0) const { return 0 != (query(coord, depth).second & 2); }
+	bool isUnknown(Point3 const& coord, DepthType depth = 0) const { return 0 != (query(coord, depth).second & 4); }
+	bool containsOccupied(Point3 const& coord, DepthType depth = 0) const { return isOccupied(coord, depth); }
+	bool containsFree(Point3 const& coord, DepthType depth = 0) const { return 0 != (query(coord, depth).second & 8); }
+	bool containsUnknown(Point3 const& coord, DepthType depth = 0) const { return 0 != (query(coord, depth).second & 16); }
+	// getOccupancy = toProb(LogitType) with LogitType = float (occupancy_map_base.h:599-602, 911)
+	double getOccupancy(Point3 const& coord, DepthType depth = 0) const { return 1.0 / (1.0 + std::exp(-query(coord, depth).first)); }
 
 	// ---- robot clearing (occupancy_map_base.h:492-518; ufomap_mapping/src/server.cpp:152-155) --------
 	// setValueVolume(ufo::geometry::AABB(min, max), occupancy_value, min_depth): the AABB is passed as the two

@@ -101,6 +101,14 @@ int ufomap_map_insert_pointcloud2(ufomap_map* m, const double translation[3], co
  * clear the robot's own volume (ufomap_mapping/src/server.cpp:137-168). AABB volumes only. */
 int ufomap_map_set_value_volume(ufomap_map* m, const double aabb_min[3], const double aabb_max[3], double occupancy_value,
                                 unsigned min_depth);
+/* Batch of point queries: per coordinate (n x 3 doubles, host memory or device memory if xyz_on_device) at `depth`
+ *   logodds[i]  occupancy log-odds of the node Octree::getNode(toCode(coord, depth)) returns (map/octree.h:974-985);
+ *               getOccupancy(coord, depth) is toProb of it (occupancy_map_base.h:599-613)
+ *   state[i]    bit 0 occupied | bit 1 free | bit 2 unknown = getState (619-634, hence isOccupied/isFree/isUnknown,
+ *               637-680; containsOccupied = isOccupied, 686-691), bit 3 containsFree, bit 4 containsUnknown (693-728)
+ * getNode's loop stops one level early (the node of depth + 1 answers for a fully expanded path); this is
+ * reproduced, so every answer equals the reference's. Outputs are host arrays. */
+int ufomap_map_query(ufomap_map* m, const double* xyz, int xyz_on_device, size_t n, unsigned depth, float* logodds, uint8_t* state);
 /* getClampingThresMin() / getClampingThresMax() (occupancy_map_base.h:742-744), the value the server passes */
 int ufomap_map_clamping_thres(ufomap_map* m, double* thres_min, double* thres_max);
 

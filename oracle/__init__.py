@@ -75,6 +75,8 @@ def _load(kind: str):
     lib.ufo_oracle_last_steps.argtypes = [vp]
     lib.ufo_oracle_last_oob.restype = C.c_uint64
     lib.ufo_oracle_last_oob.argtypes = [vp]
+    lib.ufo_oracle_query.restype = None
+    lib.ufo_oracle_query.argtypes = [vp, C.POINTER(C.c_double), C.c_size_t, C.c_uint, C.POINTER(C.c_float), u8p]
     lib.ufo_oracle_set_value_volume.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.c_uint]
     lib.ufo_oracle_clamping_thres.restype = None
     lib.ufo_oracle_clamping_thres.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
@@ -171,6 +173,15 @@ class OracleMap:
         buf = np.empty(n, np.uint8)
         self.lib.ufo_oracle_write(self.h, _ptr(buf, C.c_uint8), n)
         return buf.tobytes()
+
+    def query(self, xyz, depth=0):
+        """Per coordinate: (log-odds of the node Octree::getNode returns, state bits: 1 occupied, 2 free,
+        4 unknown, 8 containsFree, 16 containsUnknown)."""
+        xyz = np.ascontiguousarray(xyz, np.float64).reshape(-1, 3)
+        lo = np.empty(xyz.shape[0], np.float32)
+        st = np.empty(xyz.shape[0], np.uint8)
+        self.lib.ufo_oracle_query(self.h, _ptr(xyz, C.c_double), xyz.shape[0], int(depth), _ptr(lo, C.c_float), _ptr(st, C.c_uint8))
+        return lo, st
 
     def setValueVolume(self, aabb_min, aabb_max, occupancy_value, min_depth=0):
         """OccupancyMapBase::setValueVolume(AABB(min, max), occupancy_value, min_depth) (robot clearing)."""

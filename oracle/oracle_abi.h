@@ -81,6 +81,15 @@ int ufo_oracle_set_value_volume(ufo_oracle_map* m, const double mn[3], const dou
 /* getClampingThresMin() / getClampingThresMax() (occupancy_map_base.h:742-744): toProb of the stored logits */
 void ufo_oracle_clamping_thres(const ufo_oracle_map* m, double* thres_min, double* thres_max);
 
+/* Point queries: for each coordinate, code = toCode(coord, depth) and
+ * (node, d) = Octree::getNode(code) (map/octree.h:974-985). NOTE the reference's loop stops one level early:
+ * on a fully expanded path the node returned is the one at depth code.depth + 1 (reported as code.depth); where
+ * the path ends in a leaf earlier, that leaf with its true depth. Everything below is evaluated on THAT node:
+ *   logodds[i]  node->value.occupancy (getOccupancy(code) is toProb of it, OMB:599-613)
+ *   state[i]    bit 0 occupied / bit 1 free / bit 2 unknown  = getState(code) (OMB:619-634)
+ *               bit 3 containsFree(code), bit 4 containsUnknown(code) (OMB:693-728, 953-968) */
+void ufo_oracle_query(const ufo_oracle_map* m, const double* xyz, size_t n, unsigned depth, float* logodds, uint8_t* state);
+
 /* Ingest in front of the hot path: rosToUfo (ufomap_ros/ufomap_ros/src/conversions.cpp:
  * 98-138: float32 x, y, z [+ r, g, b bytes] at byte offsets inside records of `step` bytes; points with a NaN
  * coordinate are dropped) followed by PointCloud::transform (map/point_cloud.h:157-166 -> math/pose6.h:114-125

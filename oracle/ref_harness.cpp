@@ -86,6 +86,24 @@ struct Probe : MAP {
 		}
 	}
 
+	// the reference's own query functions on one coordinate (occupancy_map_base.h:599-728) + the raw logit of the
+	// node Octree::getNode returns
+	void query(double x, double y, double z, unsigned depth, float* logodds, uint8_t* state) const
+	{
+		ufo::map::Point3 p(x, y, z);
+		auto code = MAP::toCode(p, depth);
+		*logodds = MAP::getNode(code).first->value.occupancy;
+		uint8_t st = 0;
+		switch (MAP::getState(p, depth)) {
+			case ufo::map::OccupancyState::occupied: st = 1; break;
+			case ufo::map::OccupancyState::free: st = 2; break;
+			default: st = 4; break;
+		}
+		if (MAP::containsFree(p, depth)) st |= 8;
+		if (MAP::containsUnknown(p, depth)) st |= 16;
+		*state = st;
+	}
+
 	void dump(bool include_unknown, std::vector<Rec>* leaves, std::vector<Rec>* inner) const
 	{
 		walk(MAP::getRoot(), MAP::getTreeDepthLevels(), 0, include_unknown, leaves, inner);
@@ -237,6 +255,16 @@ size_t ufo_oracle_last_rays(const ufo_oracle_map*, double*, size_t) { return (si
 size_t ufo_oracle_last_misses(const ufo_oracle_map*, uint64_t*, size_t) { return (size_t)-1; }
 uint64_t ufo_oracle_last_steps(const ufo_oracle_map*) { return (uint64_t)-1; }
 uint64_t ufo_oracle_last_oob(const ufo_oracle_map*) { return (uint64_t)-1; }
+
+void ufo_oracle_query(const ufo_oracle_map* m, const double* xyz, size_t n, unsigned depth, float* logodds, uint8_t* state)
+{
+	for (size_t q = 0; q < n; ++q) {
+		if (m->col)
+			m->col->query(xyz[3 * q], xyz[3 * q + 1], xyz[3 * q + 2], depth, logodds + q, state + q);
+		else
+			m->occ->query(xyz[3 * q], xyz[3 * q + 1], xyz[3 * q + 2], depth, logodds + q, state + q);
+	}
+}
 
 int ufo_oracle_set_value_volume(ufo_oracle_map* m, const double mn[3], const double mx[3], double occupancy_value, unsigned min_depth)
 {

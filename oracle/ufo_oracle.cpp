@@ -870,6 +870,36 @@ size_t ufo_oracle_last_misses(const ufo_oracle_map* m, uint64_t* codes, size_t c
 uint64_t ufo_oracle_last_steps(const ufo_oracle_map* m) { return m->last_steps; }
 uint64_t ufo_oracle_last_oob(const ufo_oracle_map* m) { return m->last_oob; }
 
+void ufo_oracle_query(const ufo_oracle_map* m, const double* xyz, size_t n, unsigned depth, float* logodds, uint8_t* state)
+{
+	for (size_t q = 0; q < n; ++q) {
+		V3 p{{xyz[3 * q], xyz[3 * q + 1], xyz[3 * q + 2]}};
+		u32 k[3];
+		m->toKey(p, depth, k);
+		const u64 code = morton(k);  // Code(toCode(key), depth) (code.h:183-192)
+		// Octree::getNode (octree.h:974-985)
+		int node = 0;
+		unsigned rd = depth;
+		bool early = false;
+		for (unsigned d = m->L - 1; d > depth; --d) {
+			if (m->pool[node].leaf) {  // !hasChildren (octree.h:1134)
+				rd = d + 1;
+				early = true;
+				break;
+			}
+			node = m->pool[node].child + (int)((code >> (3 * d)) & 7);  // getChildIdx (code.h:245-248)
+		}
+		(void)early;
+		const Node& nd = m->pool[node];
+		logodds[q] = nd.occ;
+		uint8_t st = m->isOccupied(nd.occ) ? 1 : (m->isFree(nd.occ) ? 2 : 4);  // OMB:619-634
+		const bool cfree = (0 == rd) ? m->isFree(nd.occ) : nd.cfree;        // OMB:962-968
+		const bool cunk = (0 == rd) ? m->isUnknown(nd.occ) : nd.cunk;       // OMB:953-959
+		st |= (cfree ? 8 : 0) | (cunk ? 16 : 0);
+		state[q] = st;
+	}
+}
+
 int ufo_oracle_set_value_volume(ufo_oracle_map* m, const double mn[3], const double mx[3], double occupancy_value, unsigned min_depth)
 {
 	m->setValueVolume(mn, mx, occupancy_value, min_depth);

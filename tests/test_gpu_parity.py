@@ -315,6 +315,33 @@ def test_set_value_volume_robot_clearing(color):
     assert same_dump(g2.leaves(True), o2.leaves(True)) and same_dump(g2.inner(), o2.inner())
 
 
+@pytest.mark.parametrize("color", [False, True])
+def test_point_queries(color):
+    """batched getState / contains* / log-odds queries against the oracle (which is pinned on the
+    reference's own query functions), after scans and a robot clearing; near surfaces, free, unknown, far away."""
+    from ufomap_amd import scans
+    g, o = _maps(color=color, resolution=0.16)
+    for s in range(3):
+        origin, xyz, rgb = scans.lidar64(beams=32, azimuths=512, origin=scans.lidar_pose(s), seed=3 + s, colored=color)
+        _gpu_insert(g, origin, xyz, rgb if color else None, max_range=12.0, discrete=True)
+        o.insert(origin, xyz, rgb if color else None, max_range=12.0, discrete=True)
+    c = np.array(origin)
+    g.setValueVolume(c - 0.5, c + 0.5, g.getClampingThresMin(), 1)
+    o.setValueVolume(c - 0.5, c + 0.5, o.clamping_thres()[0], 1)
+    rng = np.random.default_rng(0)
+    q = np.concatenate([xyz[::5] + rng.normal(0, 0.05, xyz[::5].shape), rng.uniform(-15, 15, (20000, 3)), rng.uniform(-4000, 4000, (2000, 3))])
+    for depth in (0, 1, 2, 5, 14, 15):
+        a, b = g.query(q, depth), o.query(q, depth)
+        assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)), f"depth {depth}: log-odds differ"
+        assert np.array_equal(a[1], b[1]), f"depth {depth}: states differ"
+    assert len(set(g.query(q, 0)[1] & 7)) == 3
+    assert g.isOccupied(xyz[0]) == bool(o.query(xyz[0])[1][0] & 1)
+    # fresh map: everything is the unknown root
+    g2, _ = _maps(color=color, resolution=0.16)
+    lo, st = g2.query(q[:100], 0)
+    assert not lo.any() and set(st) == {4 | 16}
+
+
 def test_batch_integrator_rccl_world1():
     """BatchIntegrator on HBM tensors through the nccl (RCCL) backend with a single rank: the same code
     path the 8-GPU run takes, minus the peers."""

@@ -136,3 +136,23 @@ def test_set_value_volume_port_equals_reference(color):
     p.setValueVolume([1e7, 1e7, 1e7], [2e7, 2e7, 2e7], 0.2, 0)
     p.setValueVolume([-1, -1, -1], [1, 1, 1], 0.2, 40)
     assert p.write() == before
+
+
+@pytest.mark.parametrize("color", [False, True])
+def test_point_queries_port_equals_reference(color):
+    """getState / contains* / the node's log-odds through the reference's own getNode (with
+    its depth convention) for points near surfaces, in free and unknown space and kilometres away."""
+    from ufomap_amd import scans
+    from oracle import OracleMap
+    p = OracleMap(0.16, color=color, kind="port")
+    r = OracleMap(0.16, color=color, kind="reference")
+    for s in range(3):
+        origin, xyz, rgb = scans.lidar64(beams=16, azimuths=256, origin=scans.lidar_pose(s), seed=3 + s, colored=color)
+        for m in (p, r):
+            m.insert(origin, xyz, rgb if color else None, max_range=10.0, discrete=True)
+    rng = np.random.default_rng(0)
+    q = np.concatenate([xyz[::7] + rng.normal(0, 0.05, xyz[::7].shape), rng.uniform(-15, 15, (3000, 3)), rng.uniform(-4000, 4000, (500, 3))])
+    for depth in (0, 1, 2, 5, 14, 15):
+        a, b = p.query(q, depth), r.query(q, depth)
+        assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)) and np.array_equal(a[1], b[1]), depth
+    assert len(set(p.query(q, 0)[1] & 7)) == 3  # occupied, free and unknown all occur

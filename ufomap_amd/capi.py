@@ -20,7 +20,7 @@ ERR_INVALID, ERR_DEVICE, ERR_UNSUPPORTED, ERR_RUNAWAY, ERR_CAPACITY = -1, -2, -3
 SYMBOLS = [
     "ufomap_last_error", "ufomap_device_count", "ufomap_version", "ufomap_map_create",
     "ufomap_map_destroy", "ufomap_map_clear", "ufomap_map_reserve", "ufomap_map_set_scratch_limit",
-    "ufomap_map_set_sensor_model", "ufomap_map_insert", "ufomap_map_insert_device", "ufomap_map_insert_pointcloud2", "ufomap_map_set_value_volume", "ufomap_map_clamping_thres",
+    "ufomap_map_set_sensor_model", "ufomap_map_insert", "ufomap_map_insert_device", "ufomap_map_insert_pointcloud2", "ufomap_map_set_value_volume", "ufomap_map_query", "ufomap_map_clamping_thres",
     "ufomap_map_wait", "ufomap_map_done", "ufomap_map_export_leaves", "ufomap_map_export_inner",
     "ufomap_map_write", "ufomap_map_minmax_change", "ufomap_map_reset_minmax_change", "ufomap_map_stats",
     "ufomap_map_last_hits", "ufomap_map_last_misses", "ufomap_map_last_counts",
@@ -82,6 +82,7 @@ def load():
     lib.ufomap_map_insert.argtypes = ins
     lib.ufomap_map_insert_device.argtypes = ins
     lib.ufomap_map_set_value_volume.argtypes = [vp, f64p, f64p, dbl, C.c_uint]
+    lib.ufomap_map_query.argtypes = [vp, vp, C.c_int, sz, C.c_uint, f32p, u8p]
     lib.ufomap_map_clamping_thres.argtypes = [vp, f64p, f64p]
     lib.ufomap_map_wait.argtypes = [vp]
     lib.ufomap_map_done.argtypes = [vp]

@@ -1069,6 +1069,49 @@ __global__ __launch_bounds__(256) void k_vol_root(Table t, MapGeom g, float val)
 }
 
 // ------------------------------------------------------------------------------------------------
+// Point queries: getState / isOccupied / isFree / isUnknown / containsFree / containsUnknown /
+// getOccupancy of a coordinate at a depth (occupancy_map_base.h:599-728), all evaluated on the node that
+// Octree::getNode(toCode(coord, depth)) returns (octree.h:974-985) -- whose loop stops one level early: on a fully
+// expanded path that is the node at depth + 1 (reported as depth), else the leaf that ends the path (true depth).
+// Reproduced as is: the callers of the reference see exactly this. One thread per query, one hash lookup per level.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_query(Table t, MapGeom g, const double* __restrict__ xyz, u32 n, u32 depth,
+                                               float* __restrict__ logodds, uint8_t* __restrict__ state)
+{
+	for (u32 q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) {
+		const u64 code = morton3(toKey1(g, xyz[3 * (size_t)q], depth), toKey1(g, xyz[3 * (size_t)q + 1], depth),
+		                         toKey1(g, xyz[3 * (size_t)q + 2], depth));
+		float occ = t.root->occ;
+		u32 fl = t.root->flags & 3u;
+		u32 rd = depth;
+		u64 bkey = 1;  // key of the current node's children block
+		u32 bs = tableFind(t, bkey);
+		bool leaf = bs == NONE || (t.flags[bs] & F_DEAD);
+		for (u32 d = g.L - 1; d > depth; --d) {
+			if (leaf) {  // !hasChildren (octree.h:979-981)
+				rd = d + 1;
+				break;
+			}
+			const u32 ci = (u32)((code >> (3 * d)) & 7);  // getChildIdx (code.h:245-248)
+			const u32 f = t.flags[bs];
+			occ = t.occ[8 * (size_t)bs + ci];
+			fl = ((f >> ci) & 1u) | (((f >> (8 + ci)) & 1u) << 1);
+			bkey = (bkey << 3) | (u64)ci;
+			leaf = true;
+			if (f & (1u << (16 + ci))) {
+				bs = tableFind(t, bkey);
+				leaf = bs == NONE || (t.flags[bs] & F_DEAD);
+			}
+		}
+		logodds[q] = occ;
+		uint8_t st = (g.occ_thr < (double)occ) ? 1 : (isFreeV(g, occ) ? 2 : 4);
+		const bool cfree = (0 == rd) ? isFreeV(g, occ) : (0 != (fl & 1u));
+		const bool cunk = (0 == rd) ? isUnknownV(g, occ) : (0 != (fl & 2u));
+		state[q] = st | (cfree ? 8 : 0) | (cunk ? 16 : 0);
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
 // read-back
 // ------------------------------------------------------------------------------------------------
 struct DumpCtl {

@@ -1235,6 +1235,38 @@ int ufomap_map_insert_pointcloud2(ufomap_map* m, const double translation[3], co
 	return rc;
 }
 
+int ufomap_map_query(ufomap_map* m, const double* xyz, int xyz_on_device, size_t n, unsigned depth, float* logodds, uint8_t* state)
+{
+	if (!m || (n && (!xyz || !logodds || !state))) return fail(UFOMAP_ERR_INVALID, "null argument");
+	if (depth >= m->g.L) return fail(UFOMAP_ERR_INVALID, "depth must be < depth_levels");
+	if (n > 0x7FFFFFFFull) return fail(UFOMAP_ERR_INVALID, "more than 2^31 queries");
+	HIP_TRY(hipSetDevice(m->device));
+	int rc = ufomap_map_wait(m);
+	if (rc || 0 == n) return rc;
+	DevBuf b_in, b_lo, b_st;
+	const double* d_xyz = xyz;
+	hipError_t e = hipSuccess;
+	if (!xyz_on_device) {
+		e = b_in.reserve(n * 24);
+		if (e == hipSuccess) e = hipMemcpyAsync(b_in.p, xyz, n * 24, hipMemcpyHostToDevice, m->stream);
+		d_xyz = b_in.as<double>();
+	}
+	if (e == hipSuccess) e = b_lo.reserve(n * 4);
+	if (e == hipSuccess) e = b_st.reserve(n);
+	if (e == hipSuccess) {
+		hipLaunchKernelGGL(k_query, gridFor(n), dim3(256), 0, m->stream, m->t, m->g, d_xyz, (u32)n, (u32)depth, b_lo.as<float>(),
+		                   b_st.as<uint8_t>());
+		e = hipMemcpyAsync(logodds, b_lo.p, n * 4, hipMemcpyDeviceToHost, m->stream);
+	}
+	if (e == hipSuccess) e = hipMemcpyAsync(state, b_st.p, n, hipMemcpyDeviceToHost, m->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
+	b_in.release();
+	b_lo.release();
+	b_st.release();
+	if (e != hipSuccess) return fail(UFOMAP_ERR_DEVICE, hipGetErrorString(e));
+	return UFOMAP_OK;
+}
+
 int ufomap_map_clamping_thres(ufomap_map* m, double* thres_min, double* thres_max)
 {
 	if (!m) return fail(UFOMAP_ERR_INVALID, "null map");

@@ -119,6 +119,38 @@ class OccupancyMapBase:
                                                            int(depth), int(discrete), int(simple_ray_casting), int(early_stopping),
                                                            int(async_)))
 
+    # ---- point queries (occupancy_map_base.h:599-728), batched ---------------------------------------
+    OCCUPIED, FREE, UNKNOWN, CONTAINS_FREE, CONTAINS_UNKNOWN = 1, 2, 4, 8, 16
+
+    def query(self, xyz, depth=0):
+        """Per coordinate: (log-odds, state bits) of the node the reference's getNode returns; see
+        ``ufomap_map_query`` in include/ufomap_hip.h. ``xyz``: [n, 3] float64 (host)."""
+        xyz = np.ascontiguousarray(xyz, np.float64).reshape(-1, 3)
+        n = xyz.shape[0]
+        lo = np.empty(n, np.float32)
+        st = np.empty(n, np.uint8)
+        capi.check(self._lib.ufomap_map_query(self._h, xyz.ctypes.data if n else None, 0, n, int(depth), _p(lo, C.c_float),
+                                              _p(st, C.c_uint8)))
+        return lo, st
+
+    def getState(self, coord, depth=0):
+        return int(self.query(coord, depth)[1][0]) & 7
+
+    def isOccupied(self, coord, depth=0):
+        return self.getState(coord, depth) == self.OCCUPIED
+
+    def isFree(self, coord, depth=0):
+        return self.getState(coord, depth) == self.FREE
+
+    def isUnknown(self, coord, depth=0):
+        return self.getState(coord, depth) == self.UNKNOWN
+
+    def containsFree(self, coord, depth=0):
+        return bool(self.query(coord, depth)[1][0] & self.CONTAINS_FREE)
+
+    def containsUnknown(self, coord, depth=0):
+        return bool(self.query(coord, depth)[1][0] & self.CONTAINS_UNKNOWN)
+
     def setValueVolume(self, aabb_min, aabb_max, occupancy_value, min_depth=0):
         """OccupancyMapBase::setValueVolume(ufo::geometry::AABB(min, max), occupancy_value, min_depth)
         (occupancy_map_base.h:492-518): the server's robot clearing (ufomap_mapping/src/server.cpp:152-155)."""
