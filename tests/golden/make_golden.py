@@ -86,9 +86,64 @@ def cases():
                                       clamping_thres_min=0.05, clamping_thres_max=0.99), [dict(origin=lo, xyz=lx, max_range=15.0, discrete=True)] * 4
 
 
+def server_loop_cases():
+    """The server's per-message sequence (ufomap_mapping/src/server.cpp:113-168): rosToUfo + transform (raw
+    PointCloud2 records + pose), insertPointCloudDiscrete, robot clearing -- then point queries."""
+    for name, color, res, clear_depth in (("srv_loop_16cm", False, 0.16, 0), ("srv_loop_color_8cm_clear1", True, 0.08, 1)):
+        rng = np.random.default_rng(11)
+        steps = []
+        for s in range(3):
+            _, xyz, rgb = scans.lidar64(beams=16, azimuths=256, origin=(0.0, 0.0, 0.0), seed=40 + s, colored=True)
+            n, step = xyz.shape[0], 32
+            buf = rng.integers(0, 256, (n, step), dtype=np.uint8)
+            f = xyz.astype(np.float32)
+            f[::23, s % 3] = np.nan
+            buf[:, 0:12] = f.view(np.uint8).reshape(n, 12)
+            buf[:, 16], buf[:, 17], buf[:, 18] = rgb[:, 2], rgb[:, 1], rgb[:, 0]
+            q = np.array([np.cos(0.15 * (s + 1)), 0.01 * s, -0.02, np.sin(0.15 * (s + 1))])
+            q /= np.linalg.norm(q)
+            t = np.array([0.5 * s, -0.25 * s, 0.8])
+            steps.append(dict(data=buf, step=step, off_xyz=(0, 4, 8), off_rgb=(18, 17, 16), q=q, t=t, max_range=8.0,
+                              clear_min=t - np.array([0.4, 0.4, 0.5]), clear_max=t + np.array([0.4, 0.4, 0.5]), clear_depth=clear_depth))
+        qs = np.concatenate([rng.uniform(-9, 9, (3000, 3)), rng.uniform(-3000, 3000, (200, 3))])
+        yield name, dict(resolution=res, color=color), steps, qs
+
+
+def make_server_loops(index):
+    import oracle
+    for name, params, steps, qs in server_loop_cases():
+        m = OracleMap(kind="reference", **params)
+        arrays, meta = {"queries": qs}, dict(params=params, steps=[])
+        for i, st in enumerate(steps):
+            orgb = st["off_rgb"] if params["color"] else None
+            xyz, rgb = oracle.ingest(st["data"], st["step"], st["off_xyz"], orgb, st["q"], st["t"], "reference")
+            m.insert(st["t"], xyz, rgb if params["color"] else None, max_range=st["max_range"], discrete=True)
+            thr = m.clamping_thres()[0]
+            m.setValueVolume(st["clear_min"], st["clear_max"], thr, st["clear_depth"])
+            arrays[f"d{i}_data"] = st["data"]
+            arrays[f"d{i}_q"], arrays[f"d{i}_t"] = st["q"], st["t"]
+            arrays[f"d{i}_clear_min"], arrays[f"d{i}_clear_max"] = st["clear_min"], st["clear_max"]
+            meta["steps"].append(dict(step=st["step"], off_xyz=st["off_xyz"], off_rgb=st["off_rgb"], max_range=st["max_range"],
+                                      clear_depth=st["clear_depth"], clear_value=thr, n_kept=int(xyz.shape[0]),
+                                      sha_cloud=digest(xyz, rgb)))
+        lc, ld, lv, lrgb = m.leaves(True)
+        ic, idp, iv, ifl, irgb = m.inner()
+        wb = m.write()
+        meta.update(n_leaves_all=int(len(lc)), n_inner=int(len(ic)), sha_leaves_all=digest(lc, ld, lv, lrgb),
+                    sha_inner=digest(ic, idp, iv, ifl, irgb), write_size=len(wb), sha_write=hashlib.sha256(wb).hexdigest(),
+                    query_depths=[0, 1, 3])
+        for d in meta["query_depths"]:
+            lo, stt = m.query(qs, d)
+            arrays[f"q{d}_logodds"], arrays[f"q{d}_state"] = lo, stt
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), meta=json.dumps(meta), **arrays)
+        index[name] = dict(leaves=int(len(lc)), inner=int(len(ic)))
+        print(f"{name:32s} leaves={len(lc):7d} inner={len(ic):6d}")
+
+
 def main():
     assert build("reference"), "needs /root/reference to build oracle/_ref"
     index = {}
+    make_server_loops(index)
     for name, params, scan_list in cases():
         m = OracleMap(kind="reference", **params)
         arrays = {}

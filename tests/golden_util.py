@@ -10,7 +10,13 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def names():
-    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+    """Insert-sequence fixtures (the srv_* files hold the server-loop sequences: see ServerLoop)."""
+    return sorted(n for n in (os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+                  if not n.startswith("srv_"))
+
+
+def server_loop_names():
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "srv_*.npz")))
 
 
 def digest(*arrays):
@@ -54,3 +60,35 @@ class Golden:
             assert hashlib.sha256(wb).hexdigest() == self.meta["sha_write"], f"{self.name}: byte stream differs from the reference's write()"
         mn, mx = m.minmax_change()
         assert np.array_equal(mn, self.z["min_change"]) and np.array_equal(mx, self.z["max_change"]), f"{self.name}: change AABB differs"
+
+
+class ServerLoop:
+    """A recorded run of the reference through the server's per-message sequence (raw PointCloud2 records + pose
+    -> rosToUfo + transform -> insertPointCloudDiscrete -> setValueVolume around the sensor), then point queries.
+    `replay(ingest_insert, clear, query, dump)` drives any implementation through it and checks every output."""
+
+    def __init__(self, name):
+        z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+        self.name, self.z = name, z
+        self.meta = json.loads(str(z["meta"]))
+        self.params = self.meta["params"]
+
+    def steps(self):
+        for i, st in enumerate(self.meta["steps"]):
+            yield dict(st, data=self.z[f"d{i}_data"], q=self.z[f"d{i}_q"], t=self.z[f"d{i}_t"], clear_min=self.z[f"d{i}_clear_min"],
+                       clear_max=self.z[f"d{i}_clear_max"])
+
+    def check_map(self, m):
+        lc, ld, lv, lrgb = m.leaves(True)
+        assert len(lc) == self.meta["n_leaves_all"], f"{self.name}: leaf count differs"
+        assert digest(lc, ld, lv, lrgb) == self.meta["sha_leaves_all"], f"{self.name}: leaf dump digest differs"
+        ic, idp, iv, ifl, irgb = m.inner()
+        assert digest(ic, idp, iv, ifl, irgb) == self.meta["sha_inner"], f"{self.name}: inner dump digest differs"
+        wb = m.write()
+        assert hashlib.sha256(wb).hexdigest() == self.meta["sha_write"], f"{self.name}: byte stream differs from the reference's write()"
+
+    def check_queries(self, query):
+        for d in self.meta["query_depths"]:
+            lo, st = query(self.z["queries"], d)
+            assert np.array_equal(np.asarray(lo).view(np.uint32), self.z[f"q{d}_logodds"].view(np.uint32)), f"{self.name}: query log-odds differ at depth {d}"
+            assert np.array_equal(st, self.z[f"q{d}_state"]), f"{self.name}: query states differ at depth {d}"

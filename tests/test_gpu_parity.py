@@ -342,6 +342,24 @@ def test_point_queries(color):
     assert not lo.any() and set(st) == {4 | 16}
 
 
+@pytest.mark.parametrize("name", golden_util.server_loop_names())
+def test_gpu_matches_server_loop_golden(name):
+    """The server's per-message sequence on the GPU -- fused PointCloud2 ingest + discrete integration, robot
+    clearing, point queries -- against a recorded run of the unmodified reference (needs no oracle at run time)."""
+    from ufomap_amd import OccupancyMap, OccupancyMapColor
+    g = golden_util.ServerLoop(name)
+    params = dict(g.params)
+    color = params.pop("color", False)
+    m = (OccupancyMapColor if color else OccupancyMap)(**params)
+    for st in g.steps():
+        m.insertPointCloud2(st["t"], st["q"], st["data"], st["step"], st["off_xyz"], st["off_rgb"] if color else None,
+                            max_range=st["max_range"])
+        assert m.getClampingThresMin() == st["clear_value"]
+        m.setValueVolume(st["clear_min"], st["clear_max"], st["clear_value"], st["clear_depth"])
+    g.check_map(m)
+    g.check_queries(m.query)
+
+
 def test_batch_integrator_rccl_world1():
     """BatchIntegrator on HBM tensors through the nccl (RCCL) backend with a single rank: the same code
     path the 8-GPU run takes, minus the peers."""

@@ -86,3 +86,22 @@ def test_empty_cloud_is_a_noop(port_available):
     m.insert([0, 0, 0], np.zeros((0, 3)), max_range=20, discrete=True)
     assert len(m.leaves()[0]) == 0
     assert len(m.leaves(True)[0]) == 1  # the root: one unknown leaf (OMB:871)
+
+
+@pytest.mark.parametrize("name", golden_util.server_loop_names())
+def test_port_matches_server_loop_golden(name, port_available):
+    """Ingest (rosToUfo + Pose6 transform), insertPointCloudDiscrete, robot clearing and point queries of the
+    restatement against a recorded run of the unmodified reference (tests/golden/make_golden.py)."""
+    import oracle
+    from oracle import OracleMap
+    g = golden_util.ServerLoop(name)
+    m = OracleMap(kind="port", **g.params)
+    color = g.params.get("color", False)
+    for st in g.steps():
+        xyz, rgb = oracle.ingest(st["data"], st["step"], st["off_xyz"], st["off_rgb"] if color else None, st["q"], st["t"], "port")
+        assert xyz.shape[0] == st["n_kept"] and golden_util.digest(xyz, rgb) == st["sha_cloud"], "transformed cloud differs"
+        m.insert(st["t"], xyz, rgb if color else None, max_range=st["max_range"], discrete=True)
+        assert m.clamping_thres()[0] == st["clear_value"]
+        m.setValueVolume(st["clear_min"], st["clear_max"], st["clear_value"], st["clear_depth"])
+    g.check_map(m)
+    g.check_queries(m.query)
