@@ -202,12 +202,15 @@ int ufomap_map_apply_keys_batch(ufomap_map* m, const void* const* d_lists, const
  * the ray kernel on grids that would fit in LDS), "entry_guess" (cap of the guessed update-list size, to
  * exercise the exact-size retry), "dda_seg" (0: one lane per ray), "merge_phases" (0: hits and misses of a
  * depth-0 scan as two passes over the tree instead of one; the environment variable UFOMAP_MERGE_PHASES
- * sets the default for new maps). Results never depend on these. */
+ * sets the default for new maps), "spec" (0: always read a scan's bounding boxes back before sizing its ray
+ * grid; default 1: a depth-0 scan is enqueued on the grid predicted from the previous scan and repeated if it
+ * does not fit). Results never depend on these. */
 int ufomap_map_set_option(ufomap_map* m, const char* key, long long value);
 
 /* Diagnostics: up to 64 raw 64-bit words written by the last integration's kernels (per-level
  * wall_clock64 stamps of the propagation tails: [level] hits phase, [32+level] misses phase, [31]/[63]
- * end stamps; 100 MHz clock). Not part of the reference's surface. */
+ * end stamps; 100 MHz clock); [62] scans enqueued on a predicted ray grid, [63] of which had to be repeated.
+ * Not part of the reference's surface. */
 int ufomap_map_debug(ufomap_map* m, uint64_t* out, int n);
 
 /* Raw HIP stream of the map (hipStream_t), for callers that need to order their own work. */

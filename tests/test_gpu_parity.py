@@ -360,6 +360,37 @@ def test_gpu_matches_server_loop_golden(name):
     g.check_queries(m.query)
 
 
+@pytest.mark.parametrize("async_", [False, True])
+def test_predicted_grid_scans_and_their_repeats(async_):
+    """Depth-0 scans are enqueued on the ray grid predicted from the previous scan (no read-back of the boxes in
+    the middle of the scan); a scan that does not fit flags itself, leaves the map alone and is repeated when it is
+    joined. A sensor that stands still, drifts within the margin and jumps by metres: same map as the oracle after
+    every scan, with predictions used and repeats happening."""
+    from ufomap_amd import scans
+    g, o = _maps(resolution=0.16)
+    base = np.array(scans.lidar_pose(0), dtype=np.float64)
+    offsets = [(0, 0, 0), (0, 0, 0), (0.1, 0.05, 0), (0.3, -0.2, 0.05), (3.0, 2.0, 0.3), (3.0, 2.0, 0.3), (-2.5, 1.0, 0.0), (-2.4, 1.1, 0.0)]
+    for i, off in enumerate(offsets):
+        origin, xyz, _ = scans.lidar64(beams=32, azimuths=512, origin=tuple(base + np.array(off)), seed=50 + i)
+        _gpu_insert(g, origin, xyz, max_range=10.0 + (i % 3), discrete=bool(i & 1), async_=async_)
+        o.insert(origin, xyz, max_range=10.0 + (i % 3), discrete=bool(i & 1))
+        if not async_:
+            _assert_same_map(g, o, f"scan {i}")
+    g.insertPointCloudWait()
+    _assert_same_map(g, o, "final")
+    d = g.debug()
+    assert d[62] >= 4, "predictions were not used"
+    assert 1 <= d[63] < d[62], "the jumps should have forced repeats (and only some scans)"
+    # with predictions switched off: the same map
+    g2, _ = _maps(resolution=0.16)
+    g2.set_option("spec", 0)
+    for i, off in enumerate(offsets):
+        origin, xyz, _ = scans.lidar64(beams=32, azimuths=512, origin=tuple(base + np.array(off)), seed=50 + i)
+        _gpu_insert(g2, origin, xyz, max_range=10.0 + (i % 3), discrete=bool(i & 1))
+    assert same_dump(g2.leaves(True), g.leaves(True)) and same_dump(g2.inner(), g.inner())
+    assert g2.debug()[62] == 0
+
+
 def test_batch_integrator_rccl_world1():
     """BatchIntegrator on HBM tensors through the nccl (RCCL) backend with a single rank: the same code
     path the 8-GPU run takes, minus the peers."""

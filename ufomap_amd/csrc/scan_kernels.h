@@ -23,6 +23,7 @@ enum : u32 {
 	ERR_TABLE_FULL = 4u,  // node table full
 	ERR_HASH_FULL = 8u,   // hit hash full (should not happen: sized 4x points)
 	ERR_ENTRIES = 16u,    // update list larger than the buffer the host guessed: host retries with the exact size
+	ERR_SPEC = 32u,       // the scan was launched on a grid predicted from the previous scan and does not fit it: the host repeats it
 };
 
 // Geometry of one dedup grid: cells at depth `depth`, blocks of 2x2x2 cells.
@@ -393,7 +394,7 @@ __device__ inline void blockBoxReduce(BoxPartial* __restrict__ part, u32 which, 
 // Fold the per-workgroup partials into the control block (one workgroup).
 // Fold the per-workgroup partials into the control block. Called by all 256 threads of ONE workgroup.
 __device__ inline void reduceBoxes(const BoxPartial* __restrict__ part, u32 nparts, u32 aabb_from_classify,
-                                   const BoxPartial* __restrict__ part_classify, ScanCtl* ctl)
+                                   const BoxPartial* __restrict__ part_classify, ScanCtl* ctl, Grid spec, u32 use_spec)
 {
 	double amn[3] = {1e300, 1e300, 1e300}, amx[3] = {-1e300, -1e300, -1e300};
 	i32 hmn[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, hmx[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
@@ -423,14 +424,22 @@ __device__ inline void reduceBoxes(const BoxPartial* __restrict__ part, u32 npar
 				ctl->aabb_min[a] = encD(out.aabb_min[a]);
 				ctl->aabb_max[a] = encD(out.aabb_max[a]);
 			}
+			// the rest of the scan was enqueued on a grid predicted from the previous scan (no host round trip for the
+			// boxes): it is valid iff the grid the host would have made (makeGrid: one block of padding, even base)
+			// lies inside the predicted one
+			if (use_spec && ctl->n_rays) {
+				const long long lo = ((long long)out.mb_min[a] - 2) & ~1LL, hi = (long long)out.mb_max[a] + 2;
+				const long long nb = (hi - lo) / 2 + 1;
+				if (lo < (long long)spec.base[a] || lo + 2 * nb > (long long)spec.base[a] + 2ll * spec.nb[a]) atomicOr(&ctl->err, ERR_SPEC);
+			}
 		}
 	}
 }
 
 __global__ __launch_bounds__(256) void k_reduce_boxes(const BoxPartial* __restrict__ part, u32 nparts, u32 aabb_from_classify,
-                                                      const BoxPartial* __restrict__ part_classify, ScanCtl* ctl)
+                                                      const BoxPartial* __restrict__ part_classify, ScanCtl* ctl, Grid spec, u32 use_spec)
 {
-	reduceBoxes(part, nparts, aabb_from_classify, part_classify, ctl);
+	reduceBoxes(part, nparts, aabb_from_classify, part_classify, ctl, spec, use_spec);
 }
 
 
@@ -1571,6 +1580,7 @@ __global__ __launch_bounds__(512) void k_cast(MapGeom g, D3 sensor, u32 depth, G
                                               unsigned long long* __restrict__ steps_part)
 {
 	extern __shared__ __attribute__((aligned(16))) u32 lds[];
+	if (ctl_in->err & ERR_SPEC) return;  // the scan does not fit the predicted grid: it will be repeated (uniform exit)
 	const u32 lds_words = (u32)(gr.bytes >> 2);
 	RayConst* rc = reinterpret_cast<RayConst*>(lds + lds_words);
 	RayHdr* hd = reinterpret_cast<RayHdr*>(rc + UFO_CAST_BATCH);

@@ -103,11 +103,26 @@ inline u32 nextPow2(u64 v)
 
 // What the map half of scan i needs while the scan half of scan i+1 already runs on the other stream:
 // double-buffered and swapped at the start of every scan (see doInsert).
+// The arguments of an integration, kept with its hand-over set: a scan that was enqueued speculatively (on a grid
+// predicted from the previous scan) and turns out not to fit is repeated from them when it is joined.
+struct ScanArgs {
+	bool spec = false;
+	double origin[3] = {0, 0, 0};
+	const double* d_xyz = nullptr;
+	const uint8_t* d_rgb = nullptr;
+	size_t n = 0;
+	double max_range = -1;
+	unsigned depth = 0;
+	int discrete = 0, simple = 0;
+	Ingest ing{};
+};
+
 struct HandOver {
 	DevBuf b_ctl, b_entries, b_hh_keys, b_hh_idx, b_in_xyz, b_in_rgb;
 	ScanCtl* h_ctl = nullptr;  // pinned
 	u32 hh_mask = 0;
 	uint64_t counts[8] = {0};
+	ScanArgs args;
 };
 
 struct ufomap_map {
@@ -140,6 +155,11 @@ struct ufomap_map {
 	bool pending = false;
 	int pending_status = UFOMAP_OK;
 	int cur_set = 0, pending_set = 0;  // which hand-over set is current / holds the control block of the pending integration
+	ScanArgs args;                     // of the integration that uses the current hand-over set
+	Grid spec_grid{};                  // ray grid predicted for the next depth-0 scan (from the last one's box + margin)
+	bool spec_valid = false;
+	int opt_spec = 1;                  // 0 = always read the boxes back before sizing the grid
+	uint64_t n_spec = 0, n_spec_redo = 0;
 	int opt_async_apply = 0;           // ufomap_map_apply_keys_batch returns after enqueueing (join at the next call / wait)
 	Grid gridH{}, gridM{};
 	bool haveH = false, haveM = false;
@@ -348,6 +368,7 @@ void swapSets(ufomap_map* m)
 	std::swap(m->h_ctl, m->alt.h_ctl);
 	std::swap(m->hh_mask, m->alt.hh_mask);
 	for (int k = 0; k < 8; ++k) std::swap(m->counts[k], m->alt.counts[k]);
+	std::swap(m->args, m->alt.args);
 	m->cur_set ^= 1;
 }
 
@@ -629,6 +650,34 @@ int mapPhase(ufomap_map* m, unsigned depth, const uint8_t* d_rgb, u64 capH, u64 
 	return applyEntries(m, ent_m, (u32)capM, 1, (u32)depth + 1, m->gridM.nb, miss, nullptr, false, (u32)capH, (u32)capM);
 }
 
+int redoScan(ufomap_map* m);
+
+// Predict the ray grid of the next depth-0 scan from the box of the one just finished: the same box plus a margin
+// of up to two node blocks for sensor motion, as long as k_cast still fits its bit grid and segment queue in LDS.
+void predictGrid(ufomap_map* m)
+{
+	m->spec_valid = false;
+	const ScanArgs& a = m->args;
+	if (!m->opt_spec || !m->opt_merge || !m->opt_cast || !m->opt_bits || !m->opt_dda_seg || m->opt_dda_mode > 0) return;
+	if (0 != a.depth || a.simple || 0 == a.n || 0 == m->h_ctl->n_rays) return;
+	for (int margin = 2; margin >= 0 && !m->spec_valid; --margin) {
+		i32 mn[3], mx[3];
+		for (int k = 0; k < 3; ++k) {
+			mn[k] = m->h_ctl->mb_min[k] - 2 * margin;
+			mx[k] = m->h_ctl->mb_max[k] + 2 * margin;
+		}
+		Grid gr;
+		if (makeGrid(mn, mx, 0, &gr)) continue;
+		const bool packed = 2 * gr.nb[0] < 1023 && 2 * gr.nb[1] < 1023 && 2 * gr.nb[2] < 1023;
+		const u64 bytes1 = (u64)(gridRowBits(gr) >> 3) * (2ull * (u64)gr.nb[1]) * (2ull * (u64)gr.nb[2]);
+		if (!packed || ((bytes1 + 15) & ~15ull) + UFO_CAST_LDS_EXTRA > (160u << 10) - 512u) continue;
+		gr.layout = 1;
+		gr.bytes = (bytes1 + 15) & ~15ull;
+		m->spec_grid = gr;
+		m->spec_valid = true;
+	}
+}
+
 int finishPending(ufomap_map* m)
 {
 	if (!m->pending) return UFOMAP_OK;
@@ -637,8 +686,12 @@ int finishPending(ufomap_map* m)
 	int rc = readCtl(m);
 	if (rc) return rc;
 	drainEvents(m);
+	if (m->args.spec && m->h_ctl->err) return redoScan(m);  // did not fit the predicted grid (or any other flag): map untouched
 	rc = ctlError(m);
 	if (rc) return rc;
+	m->counts[1] = m->h_ctl->n_rays;
+	m->counts[3] = m->h_ctl->n_hits;
+	if (m->args.n) predictGrid(m);  // (non-scan updates leave the prediction as it is)
 	m->counts[5] = (u64)m->h_ctl->n_entries[0] + m->h_ctl->n_entries[1];
 	m->counts[2] = m->h_ctl->n_steps;
 	m->counts[6] = (u64)m->h_ctl->ph[0].n_new + m->h_ctl->ph[1].n_new;
@@ -656,7 +709,7 @@ int finishPending(ufomap_map* m)
 // The scan half of an integration (never touches the map): classify, de-duplicate, cast the rays into
 // the dedup grids. On return *n_hits_out / *n_rays_out hold the unique hits / rays cast.
 int scanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, const uint8_t* d_rgb, size_t n, double max_range,
-              unsigned depth, int discrete, int simple, unsigned early_stopping, u32* n_hits_out, u32* n_rays_out)
+              unsigned depth, int discrete, int simple, unsigned early_stopping, u32* n_hits_out, u32* n_rays_out, bool spec = false)
 {
 	if (!m) return fail(UFOMAP_ERR_INVALID, "null map");
 	HIP_TRY(hipSetDevice(m->device));
@@ -731,18 +784,27 @@ int scanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, const 
 	{
 		ProfScope ps(m, "k_reduce_boxes");
 		hipLaunchKernelGGL(k_reduce_boxes, dim3(1), dim3(256), 0, m->cs, m->b_part1.as<BoxPartial>(), gp.x, (u32)(discrete ? 0 : 1),
-		                   m->b_part0.as<BoxPartial>(), ctl);
+		                   m->b_part0.as<BoxPartial>(), ctl, m->spec_grid, (u32)(spec ? 1 : 0));
 	}
 	HIP_TRY(hipGetLastError());
+	u32 n_rays, n_hits;
+	if (spec) {
+		// No read-back: the rest of the scan is enqueued on the grid predicted from the previous scan, with the
+		// point count as the bound of rays and hits; k_reduce_boxes has flagged the scan (ERR_SPEC) if its box
+		// does not fit, every later kernel of a flagged scan leaves the map alone, and the join repeats it.
+		n_rays = n_hits = N;
+		m->haveH = m->haveM = true;
+		m->gridM = m->spec_grid;
+		m->gridH = m->spec_grid;  // the hits are ray ends: same box (only used for bounds)
+	} else {
 	HIP_TRY(hipMemcpyAsync(m->h_ctl, m->b_ctl.p, sizeof(ScanCtl), hipMemcpyDeviceToHost, m->cs));
 	HIP_TRY(hipStreamSynchronize(m->cs));
 	int rc = ctlError(m);
 	if (rc) return rc;
-	const u32 n_rays = m->h_ctl->n_rays, n_hits = m->h_ctl->n_hits;
+	n_rays = m->h_ctl->n_rays;
+	n_hits = m->h_ctl->n_hits;
 	m->counts[1] = n_rays;
 	m->counts[3] = n_hits;
-	// the scan's change AABB is final after k_select: keep a copy (finishPending merges it)
-	ScanCtl after_select = *m->h_ctl;
 
 	// ---- dedup grids -----------------------------------------------------------------------------
 	i32 hmn[3], hmx[3], mmn[3], mmx[3];
@@ -758,7 +820,8 @@ int scanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, const 
 		return fail(UFOMAP_ERR_CAPACITY, "hit bounding box too large for the scan grid");
 	if (m->haveM && makeGrid(mmn, mmx, (u32)depth, &m->gridM))
 		return fail(UFOMAP_ERR_CAPACITY, "ray bounding box too large for the scan grid (runaway ray?)");
-	if (m->haveM && !simple && m->opt_dda_seg != 0 && m->opt_bits != 0 && m->opt_dda_mode <= 0) {
+	}
+	if (!spec && m->haveM && !simple && m->opt_dda_seg != 0 && m->opt_bits != 0 && m->opt_dda_mode <= 0) {
 		// one bit per cell (rows padded to 32 cells) when that fits in LDS: the fast walk kernel (k_walk)
 		Grid& gr = m->gridM;
 		const bool packed = 2 * gr.nb[0] < 1023 && 2 * gr.nb[1] < 1023 && 2 * gr.nb[2] < 1023;
@@ -887,7 +950,6 @@ int scanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, const 
 
 	*n_hits_out = n_hits;
 	*n_rays_out = n_rays;
-	(void)after_select;
 	HIP_TRY(hipGetLastError());
 	return UFOMAP_OK;
 }
@@ -943,7 +1005,7 @@ int joinPrevious(ufomap_map* m)
 }
 
 int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const uint8_t* d_rgb, size_t n, double max_range,
-             unsigned depth, int discrete, int simple, unsigned early_stopping, int async, bool swapped)
+             unsigned depth, int discrete, int simple, unsigned early_stopping, int async, bool swapped, int spec_mode = 0)
 {
 	if (!m) return fail(UFOMAP_ERR_INVALID, "null map");
 	HIP_TRY(hipSetDevice(m->device));
@@ -953,11 +1015,29 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 	// after the head loop, OMB:315). Hand-over buffers are double-buffered and swapped here.
 	if (!swapped) swapSets(m);
 	m->cs = m->sstream;
-	u32 n_hits = 0, n_rays = 0;
-	int rc = scanPhase(m, origin, d_xyz, d_rgb, n, max_range, depth, discrete, simple, early_stopping, &n_hits, &n_rays);
-	u64 capH = 0, capM = 0;
 	// insert depth 0: hits and misses of the scan as ONE pass over the tree (map_kernels.h, k_apply_leaf mode 2)
 	const bool merged = 0 == depth && 0 != m->opt_merge;
+	// Speculation: enqueue the whole scan on the grid predicted from the previous one instead of reading the
+	// bounding boxes back in the middle of the scan half (a host round trip of ~25 us on a 120 us chain).
+	const bool spec = (0 == spec_mode ? (m->opt_spec && m->spec_valid) : false) && merged && !simple && 0 == early_stopping && n > 0 &&
+	                  n <= (1u << 29) && !(d_rgb && !m->g.color);
+	{
+		ScanArgs& a = m->args;
+		a.spec = spec;
+		for (int k = 0; k < 3; ++k) a.origin[k] = origin[k];
+		a.d_xyz = d_xyz;
+		a.d_rgb = d_rgb;
+		a.n = n;
+		a.max_range = max_range;
+		a.depth = depth;
+		a.discrete = discrete;
+		a.simple = simple;
+		a.ing = m->ing;
+	}
+	if (spec) ++m->n_spec;
+	u32 n_hits = 0, n_rays = 0;
+	int rc = scanPhase(m, origin, d_xyz, d_rgb, n, max_range, depth, discrete, simple, early_stopping, &n_hits, &n_rays, spec);
+	u64 capH = 0, capM = 0;
 	if (!rc && n) rc = extractPhase(m, n_hits, n_rays, &capH, &capM, merged);
 	if (!rc && n) rc = (hipEventRecord(m->scan_ev, m->sstream) == hipSuccess) ? UFOMAP_OK : fail(UFOMAP_ERR_DEVICE, "hipEventRecord");
 	// join the previous integration (occupancy_map_base.h:315): its status is reported by wait()/this call
@@ -982,6 +1062,50 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 	}
 	HIP_TRY(hipEventRecord(m->done_ev, m->stream));
 	return prc;
+}
+// Repeat, synchronously and with the boxes read back, the integration whose hand-over set is current: it had been
+// enqueued on a predicted grid and flagged itself (ERR_SPEC, or a bound derived from the prediction was exceeded),
+// so nothing of it has reached the map. Called from finishPending, i.e. before any later update of the map.
+int redoScan(ufomap_map* m)
+{
+	const ScanArgs a = m->args;
+	m->args.spec = false;
+	m->spec_valid = false;
+	++m->n_spec_redo;
+	// the scan half of the NEXT integration may already have run: what it left in the map object is restored
+	const Grid sgM = m->gridM, sgH = m->gridH;
+	const bool shH = m->haveH, shM = m->haveM;
+	const u32 shb = m->hb_cap_mask, sld = m->last_depth;
+	const uint8_t* slr = m->last_rgb;
+	const Ingest sing = m->ing;
+	m->ing = a.ing;
+	m->cs = m->sstream;
+	u32 n_hits = 0, n_rays = 0;
+	int rc = scanPhase(m, a.origin, a.d_xyz, a.d_rgb, a.n, a.max_range, a.depth, a.discrete, a.simple, 0, &n_hits, &n_rays, false);
+	u64 capH = 0, capM = 0;
+	const bool merged = 0 == a.depth && 0 != m->opt_merge;
+	if (!rc) rc = extractPhase(m, n_hits, n_rays, &capH, &capM, merged);
+	if (!rc) rc = (hipStreamSynchronize(m->sstream) == hipSuccess) ? UFOMAP_OK : fail(UFOMAP_ERR_DEVICE, "hipStreamSynchronize");
+	if (!rc) {
+		m->cs = m->stream;
+		m->last_rgb = a.d_rgb;
+		rc = mapPhase(m, a.depth, a.d_rgb, capH, capM, merged);
+	}
+	if (!rc) rc = (hipStreamSynchronize(m->stream) == hipSuccess) ? UFOMAP_OK : fail(UFOMAP_ERR_DEVICE, "hipStreamSynchronize");
+	if (!rc) {
+		m->pending = true;
+		m->pending_set = m->cur_set;
+		rc = finishPending(m);
+	}
+	m->gridM = sgM;
+	m->gridH = sgH;
+	m->haveH = shH;
+	m->haveM = shM;
+	m->hb_cap_mask = shb;
+	m->last_depth = sld;
+	m->last_rgb = slr;
+	m->ing = sing;
+	return rc;
 }
 }  // namespace
 
@@ -1304,6 +1428,7 @@ int ufomap_map_set_value_volume(ufomap_map* m, const double aabb_min[3], const d
 		a.val = (nv < m->g.cmin) ? m->g.cmin : ((m->g.cmax < nv) ? m->g.cmax : nv);   // std::clamp (OMB:1154)
 	}
 	m->cs = m->stream;
+	m->args = ScanArgs{};
 	ScanCtl init;
 	memset(&init, 0, sizeof(init));
 	for (int k = 0; k < 3; ++k) {
@@ -1646,6 +1771,7 @@ int ufomap_map_scan_keys(ufomap_map* m, const double sensor_origin[3], const dou
 	// enqueued earlier (asynchronous insert / apply_keys_batch) may still be walking the tree on the map stream.
 	HIP_TRY(hipStreamSynchronize(m->sstream));
 	swapSets(m);
+	m->args = ScanArgs{};
 	m->cs = m->sstream;
 	u32 n_hits = 0, n_rays = 0;
 	int rc = scanPhase(m, sensor_origin, d_xyz, nullptr, n, max_range, depth, discrete, simple_ray_casting, 0, &n_hits, &n_rays);
@@ -1706,6 +1832,7 @@ int ufomap_map_apply_keys(ufomap_map* m, const void* d_entries, const ufomap_key
 	const u32 nh = info->n_hit, nm = info->n_miss;
 	if (0 == nh + nm) return UFOMAP_OK;
 	m->cs = m->stream;
+	m->args = ScanArgs{};
 	// fresh control block: the entry counts are known exactly here
 	ScanCtl init;
 	memset(&init, 0, sizeof(init));
@@ -1754,6 +1881,7 @@ int ufomap_map_apply_keys_batch(ufomap_map* m, const void* const* d_lists, const
 	if (0 == total) return UFOMAP_OK;
 	if (total > 0x7FFFFFFFull) return fail(UFOMAP_ERR_CAPACITY, "update lists exceed 2^31 entries");
 	m->cs = m->stream;
+	m->args = ScanArgs{};
 	ScanCtl init;
 	memset(&init, 0, sizeof(init));
 	for (int a = 0; a < 3; ++a) {
@@ -1985,6 +2113,9 @@ int ufomap_map_set_option(ufomap_map* m, const char* key, long long value)
 		m->opt_dda_mode = (int)value;
 	} else if (0 == strcmp(key, "dda_seg")) {
 		m->opt_dda_seg = value ? 1 : 0;
+	} else if (0 == strcmp(key, "spec")) {
+		m->opt_spec = value ? 1 : 0;
+		if (!m->opt_spec) m->spec_valid = false;
 	} else if (0 == strcmp(key, "async_apply")) {
 		m->opt_async_apply = value ? 1 : 0;
 	} else if (0 == strcmp(key, "cast")) {
@@ -2016,6 +2147,8 @@ int ufomap_map_debug(ufomap_map* m, uint64_t* out, int n)
 	if (!m) return fail(UFOMAP_ERR_INVALID, "null map");
 	int rc = ufomap_map_wait(m);
 	for (int i = 0; i < n && i < 64; ++i) out[i] = m->h_ctl->dbg[i];
+	if (n > 62) out[62] = m->n_spec;       // scans enqueued on a predicted grid
+	if (n > 63) out[63] = m->n_spec_redo;  // ... of which had to be repeated
 	return rc;
 }
 

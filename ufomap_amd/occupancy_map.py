@@ -284,6 +284,11 @@ class OccupancyMapBase:
         keys = ["points", "rays", "steps", "hits", "miss_cells", "blocks_touched", "blocks_created", "oob_dropped"]
         return dict(zip(keys, (int(v) for v in c)))
 
+    def debug(self):
+        out = (C.c_uint64 * 64)()
+        capi.check(self._lib.ufomap_map_debug(self._h, out, 64))
+        return [int(v) for v in out]
+
     def set_option(self, key, value):
         capi.check(self._lib.ufomap_map_set_option(self._h, key.encode(), int(value)))
 
