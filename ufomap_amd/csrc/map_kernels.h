@@ -217,6 +217,10 @@ __device__ inline void markDirty(const Table& t, bool want, u32 p, u32* __restri
 	if (first) wl[pos] = p;
 }
 
+// clear flag bits of a control block (the host re-runs an update that had stood back: ERR_PREV only -- a flag the
+// scan raised itself must survive)
+__global__ void k_ctl_clear(ScanCtl* ctl, u32 bits) { atomicAnd(&ctl->err, ~bits); }
+
 // ------------------------------------------------------------------------------------------------
 // S1 ensure: createNode (octree.h:997-1016) for every entry, batched: the thread that creates or
 // revives a block also links it to its parent and continues upward; stops at the first block that
@@ -225,11 +229,18 @@ __device__ inline void markDirty(const Table& t, bool want, u32 p, u32* __restri
 __global__ __launch_bounds__(256) void k_ensure(Table t, MapGeom g, const Entry* __restrict__ entries,
                                                 const u32* n_entries_p, u32 cap_h, u32 cap_m, u32 scan_id,
                                                 u32* __restrict__ ent_slot, u32* __restrict__ newlist, u32 newcap,
-                                                ScanCtl::PhaseCtr* pc, ScanCtl* ctl)
+                                                ScanCtl::PhaseCtr* pc, ScanCtl* ctl, const ScanCtl* prev)
 {
 	u32 n = *n_entries_p;
 	const u32 max_probe = (t.mask >> 1) + 1;
 	u32 n_created = 0;
+	if (prev && prev->err) {
+		// This update was enqueued before its predecessor had been checked by the host (so that the two run back to
+		// back). The predecessor flagged itself -- it has left the map alone and will be repeated -- hence this one
+		// must not reach the map before it: stand back, the host re-runs both in order.
+		if (0 == blockIdx.x && 0 == threadIdx.x) atomicOr(&ctl->err, ERR_PREV);
+		return;
+	}
 	if (ctl->n_entries[0] > cap_h || ctl->n_entries[1] > cap_m) {
 		// one of the two update lists did not fit its buffer: NOTHING may be applied, in either phase
 		// (both lists are extracted before the first phase starts); the host retries with the exact sizes
@@ -797,6 +808,7 @@ __global__ __launch_bounds__(256) void k_propagate(Table t, MapGeom g, const u32
 __global__ __launch_bounds__(1024) void k_propagate_tail(Table t, MapGeom g, u32* __restrict__ wl_a, u32* __restrict__ wl_b,
                                                          u32 first_level, u32 phase, ScanCtl::PhaseCtr* pc, ScanCtl* ctl, u32 dbg_at)
 {
+	if (0 == threadIdx.x) ctl->used_now = t.root->used;  // blocks are only created by k_ensure, long done
 	if (ctl->err) return;
 	for (u32 level = first_level; level <= g.L; ++level) {
 		if (0 == threadIdx.x) ctl->dbg[dbg_at + level] = wall_clock64();

@@ -23,6 +23,7 @@ enum : u32 {
 	ERR_TABLE_FULL = 4u,  // node table full
 	ERR_HASH_FULL = 8u,   // hit hash full (should not happen: sized 4x points)
 	ERR_ENTRIES = 16u,    // update list larger than the buffer the host guessed: host retries with the exact size
+	ERR_PREV = 64u,       // the integration enqueued just before this one flagged an error: this one stands back, the host re-runs both in order
 	ERR_SPEC = 32u,       // the scan was launched on a grid predicted from the previous scan and does not fit it: the host repeats it
 };
 
@@ -52,7 +53,7 @@ struct ScanCtl {
 	u64 aabb_min[3], aabb_max[3];  // order-encoded doubles: change AABB of this scan
 	unsigned long long n_steps;
 	u32 n_oob;  // cells dropped because their key lies outside [0, 2^L) (the reference aliases them)
-	u32 pad2;
+	u32 used_now;  // MapRoot::used, mirrored here by k_propagate_tail so that the host reads ONE block per update
 	u32 dl_total;      // coarse-miss phase: blocks visited so far (all levels, appended level by level)
 	u32 dl_start[25];  // dl_start[l] .. dl_start[l-1] = range of the level-l blocks in the visit list
 	unsigned long long dbg[64];  // diagnostics (ufomap_map_debug): per-level clocks of the propagation tails

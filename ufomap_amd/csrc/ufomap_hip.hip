@@ -123,6 +123,7 @@ struct HandOver {
 	u32 hh_mask = 0;
 	uint64_t counts[8] = {0};
 	ScanArgs args;
+	hipEvent_t done_ev = nullptr;  // end of the integration that uses this set
 };
 
 struct ufomap_map {
@@ -131,6 +132,10 @@ struct ufomap_map {
 	hipStream_t sstream = nullptr;  // scan stream: classify .. extract of the NEXT scan overlaps the previous map phase
 	hipStream_t cs = nullptr;       // stream the helpers currently launch on
 	hipEvent_t done_ev = nullptr, scan_ev = nullptr;
+	hipStream_t xstream = nullptr;  // read-back of control blocks whose producers are known to be complete
+	bool prev_flagged = false;      // the integration joined last had flagged an error (finishPending)
+	u64 pending_bound = 0;          // upper bound of the blocks the pending integration may add to the table
+	int opt_early = 1;              // enqueue the map half before the previous integration has been joined (doInsert)
 	HandOver alt;                   // the other set of hand-over buffers
 	int async_status = UFOMAP_OK;   // first error of an integration that was joined by a later call
 	MapGeom g{};
@@ -369,6 +374,7 @@ void swapSets(ufomap_map* m)
 	std::swap(m->hh_mask, m->alt.hh_mask);
 	for (int k = 0; k < 8; ++k) std::swap(m->counts[k], m->alt.counts[k]);
 	std::swap(m->args, m->alt.args);
+	std::swap(m->done_ev, m->alt.done_ev);
 	m->cur_set ^= 1;
 }
 
@@ -378,6 +384,23 @@ int readCtl(ufomap_map* m)
 	HIP_TRY(hipMemcpyAsync(m->h_root, m->b_root.p, sizeof(MapRoot), hipMemcpyDeviceToHost, m->cs));
 	HIP_TRY(hipStreamSynchronize(m->cs));
 	m->used_est = m->h_root->used;
+	return UFOMAP_OK;
+}
+
+// the same for an integration that is known to be complete (stream or event synchronised by the caller): on the
+// read-back stream, so that it does not queue behind a later update already enqueued on the map stream
+int readCtlDone(ufomap_map* m)
+{
+	HIP_TRY(hipMemcpyAsync(m->h_ctl, m->b_ctl.p, sizeof(ScanCtl), hipMemcpyDeviceToHost, m->xstream));
+	HIP_TRY(hipStreamSynchronize(m->xstream));
+	if (m->h_ctl->used_now) {
+		m->used_est = m->h_ctl->used_now;  // MapRoot::used as the propagation tail saw it (after all creations of the update)
+	} else {
+		// an update without a propagation tail (nothing to apply, or it stood back): read the root
+		HIP_TRY(hipMemcpyAsync(m->h_root, m->b_root.p, sizeof(MapRoot), hipMemcpyDeviceToHost, m->xstream));
+		HIP_TRY(hipStreamSynchronize(m->xstream));
+		m->used_est = m->h_root->used;
+	}
 	return UFOMAP_OK;
 }
 
@@ -450,7 +473,7 @@ void propagateLevels(ufomap_map* m, u32 first, F bound, ScanCtl::PhaseCtr* pc, u
 // blocks inside grid nb[] (hits) and capB blocks inside grid nbB[] (misses); `which` is 0.
 int applyEntries(ufomap_map* m, const Entry* d_entries, u32 cap, u32 which, u32 level, const i32 nb[3], float upd,
                  const uint8_t* d_rgb, bool zero_ctr, u32 cap_h, u32 cap_m, u32 capB = 0, const i32* nbB = nullptr,
-                 float upd_miss = 0.f)
+                 float upd_miss = 0.f, const ScanCtl* prev = nullptr)
 {
 	if (0 == cap) return UFOMAP_OK;
 	const bool merged = nullptr != nbB;
@@ -472,13 +495,13 @@ int applyEntries(ufomap_map* m, const Entry* d_entries, u32 cap, u32 which, u32 
 	const u32* d_n = &ctl->n_entries[which];
 	ScanCtl::PhaseCtr* pc = &ctl->ph[which];
 	if (zero_ctr) HIP_TRY(hipMemsetAsync(pc, 0, sizeof(ScanCtl::PhaseCtr), m->cs));
-	HitHash hh{m->b_hh_keys.as<u64>(), m->b_hh_idx.as<u32>(), m->hh_mask};
+	HitHash hh{m->b_hh_keys.as<u64>(), reinterpret_cast<u32*>(m->b_hh_keys.as<u64>() + ((size_t)m->hh_mask + 1)), m->hh_mask};
 	u32* wl[2] = {m->b_wl0.as<u32>(), m->b_wl1.as<u32>()};
 	dim3 ge = gridFor(cap);
 	{
 		ProfScope ps(m, "k_ensure");
 		hipLaunchKernelGGL(k_ensure, ge, dim3(256), 0, m->cs, m->t, m->g, d_entries, d_n, cap_h, cap_m, m->scan_id, m->b_ent_slot.as<u32>(),
-		                   m->b_newlist.as<u32>(), (u32)std::min<u64>(newcap, 0xFFFFFFFFull), pc, ctl);
+		                   m->b_newlist.as<u32>(), (u32)std::min<u64>(newcap, 0xFFFFFFFFull), pc, ctl, prev);
 	}
 	{
 		ProfScope ps(m, "k_init_new");
@@ -531,8 +554,10 @@ int applyEntries(ufomap_map* m, const Entry* d_entries, u32 cap, u32 which, u32 
 // Make sure the node table can take what both phases may create. The a-priori bound (blockBound with every
 // entry new) is a true upper bound but far too pessimistic on a warm map; when it asks for growth, count
 // the entries whose block is really missing (one extra kernel + host read on this rare path) and bound again.
+// extra_used / no_grow: the caller has an update in flight that may add up to extra_used blocks and cannot wait for
+// it here; if the table might not take both, 1 is returned (nothing done) and the caller joins first.
 int sizeTable(ufomap_map* m, const Entry* ent_h, u64 capH, const i32 nbH[3], const Entry* ent_m, u64 capM, const i32 nbM[3],
-              unsigned depth, bool merged = false)
+              unsigned depth, bool merged = false, u64 extra_used = 0, bool no_grow = false)
 {
 	// merged list (depth 0) whose hit box lies inside the ray box: all entries are blocks of the miss grid
 	bool h_in_m = merged && capH && capM && m->haveH && m->haveM && nbH == m->gridH.nb && nbM == m->gridM.nb;
@@ -548,7 +573,8 @@ int sizeTable(ufomap_map* m, const Entry* ent_h, u64 capH, const i32 nbH[3], con
 	};
 	m->scan_new_bound = bound(capH, capM);
 	u64 cap = (u64)m->t.mask + 1;
-	if ((m->used_est + m->scan_new_bound) * 5 <= cap * 3) return UFOMAP_OK;  // load factor stays <= 0.6
+	if ((m->used_est + extra_used + m->scan_new_bound) * 5 <= cap * 3) return UFOMAP_OK;  // load factor stays <= 0.6
+	if (no_grow) return 1;
 	// small tables simply grow to the pessimistic size once (cheap, and the fast check passes from then on);
 	// the exact count is worth a kernel and a host round trip only when growing would cost gigabytes
 	const bool cheap = (m->used_est + m->scan_new_bound) * 2 <= (1ull << 22);
@@ -635,16 +661,19 @@ int extractLists(ufomap_map* m, u64 capH, u64 capM, bool zero_counts, bool merge
 // The map half of an integration (map stream): size the table, hits phase, then misses phase (OMB:1351-1365).
 // The two update lists are already in b_entries (hit entries first); capH/capM are their capacities
 // (true upper bounds or exact counts, so the device-side counts always fit).
-int mapPhase(ufomap_map* m, unsigned depth, const uint8_t* d_rgb, u64 capH, u64 capM, bool merged)
+// prev != nullptr: control block of the integration enqueued just before, not yet checked by the host (doInsert);
+// returns 1 (nothing enqueued) if the table might have to grow while that one is in flight.
+int mapPhase(ufomap_map* m, unsigned depth, const uint8_t* d_rgb, u64 capH, u64 capM, bool merged, const ScanCtl* prev = nullptr,
+             u64 extra_used = 0)
 {
 	const float miss = (float)(m->g.miss_log / double((2.0 * depth) + 1));  // OMB:311
 	Entry* ent_h = m->b_entries.as<Entry>();
 	Entry* ent_m = ent_h + capH;
-	int rc = sizeTable(m, ent_h, capH, m->gridH.nb, ent_m, capM, m->gridM.nb, depth, merged);
+	int rc = sizeTable(m, ent_h, capH, m->gridH.nb, ent_m, capM, m->gridM.nb, depth, merged, extra_used, nullptr != prev);
 	if (rc) return rc;
 	if (merged)
 		return applyEntries(m, ent_h, (u32)(capH + capM), 0, 1, m->gridH.nb, m->g.hit, d_rgb, false, (u32)(capH + capM), 0u, (u32)capM,
-		                    m->gridM.nb, miss);
+		                    m->gridM.nb, miss, prev);
 	rc = applyEntries(m, ent_h, (u32)capH, 0, 1, m->gridH.nb, m->g.hit, d_rgb, false, (u32)capH, (u32)capM);
 	if (rc) return rc;
 	return applyEntries(m, ent_m, (u32)capM, 1, (u32)depth + 1, m->gridM.nb, miss, nullptr, false, (u32)capH, (u32)capM);
@@ -683,10 +712,14 @@ int finishPending(ufomap_map* m)
 	if (!m->pending) return UFOMAP_OK;
 	m->pending = false;
 	m->cs = m->stream;
-	int rc = readCtl(m);
+	int rc = readCtlDone(m);
 	if (rc) return rc;
 	drainEvents(m);
-	if (m->args.spec && m->h_ctl->err) return redoScan(m);  // did not fit the predicted grid (or any other flag): map untouched
+	if (m->h_ctl->err) m->prev_flagged = true;  // (sticky: doInsert resets it before a join)
+	// Flagged and repeatable: a speculative scan that did not fit its predicted grid (or exceeded a bound derived from
+	// it), or an update that stood back because the control block it looked at for its predecessor was flagged
+	// (ERR_PREV). Nothing of it has reached the map; repeat it now, i.e. before any later update.
+	if (m->h_ctl->err && m->args.n && (m->args.spec || (m->h_ctl->err & ERR_PREV))) return redoScan(m);
 	rc = ctlError(m);
 	if (rc) return rc;
 	m->counts[1] = m->h_ctl->n_rays;
@@ -738,11 +771,10 @@ int scanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, const 
 	HIP_TRY(m->b_hit_code.reserve(n * 8));
 	HIP_TRY(m->b_hit_pt.reserve(n * 4));
 	u32 hcap = nextPow2(std::max<u64>(1024, (u64)n * 2 + (depth ? (u64)n * 2 : 0)));  // load <= 0.5 (hits, + ray cells when depth > 0)
-	HIP_TRY(m->b_hh_keys.reserve((size_t)hcap * 8));
-	HIP_TRY(m->b_hh_idx.reserve((size_t)hcap * 4));
-	HIP_TRY(hipMemsetAsync(m->b_hh_keys.p, 0xFF, (size_t)hcap * 8, m->cs));
-	HIP_TRY(hipMemsetAsync(m->b_hh_idx.p, 0xFF, (size_t)hcap * 4, m->cs));
-	HitHash hh{m->b_hh_keys.as<u64>(), m->b_hh_idx.as<u32>(), hcap - 1};
+	// keys and point indices in ONE buffer (keys first): one memset per scan instead of two
+	HIP_TRY(m->b_hh_keys.reserve((size_t)hcap * 12));
+	HIP_TRY(hipMemsetAsync(m->b_hh_keys.p, 0xFF, (size_t)hcap * 12, m->cs));
+	HitHash hh{m->b_hh_keys.as<u64>(), reinterpret_cast<u32*>(m->b_hh_keys.as<u64>() + hcap), hcap - 1};
 	m->hh_mask = hcap - 1;
 	// control block
 	ScanCtl init;
@@ -1040,8 +1072,42 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 	u64 capH = 0, capM = 0;
 	if (!rc && n) rc = extractPhase(m, n_hits, n_rays, &capH, &capM, merged);
 	if (!rc && n) rc = (hipEventRecord(m->scan_ev, m->sstream) == hipSuccess) ? UFOMAP_OK : fail(UFOMAP_ERR_DEVICE, "hipEventRecord");
+	// ---- early map half: enqueue THIS scan's tree update behind the previous one BEFORE that one has been joined,
+	// so that the two run back to back on the map stream (otherwise the GPU idles while the host reads the previous
+	// control block and enqueues six launches). The first kernel looks at the predecessor's error flags: if it
+	// flagged itself, this update stands back too (ERR_PREV) and both are re-run in order below.
+	bool early = false;
+	if (!rc && n && async && merged && m->opt_early && m->pending && m->pending_set != m->cur_set && !m->profiling) {
+		m->cs = m->stream;
+		HIP_TRY(hipStreamWaitEvent(m->stream, m->scan_ev, 0));
+		m->last_rgb = d_rgb;
+		const int erc = mapPhase(m, depth, d_rgb, capH, capM, merged, m->alt.b_ctl.as<ScanCtl>(), m->pending_bound);
+		if (erc < 0) return erc;
+		early = 0 == erc;  // 1: the table might have to grow: join first (below)
+		if (early) HIP_TRY(hipEventRecord(m->done_ev, m->stream));
+	}
 	// join the previous integration (occupancy_map_base.h:315): its status is reported by wait()/this call
-	int prc = joinPrevious(m);
+	int prc;
+	if (early) {
+		HIP_TRY(hipEventSynchronize(m->alt.done_ev));  // the predecessor alone: this scan's update keeps running
+		m->prev_flagged = false;
+		prc = finishPendingAnySet(m);
+		if (prc && UFOMAP_OK == m->async_status) m->async_status = prc;
+		if (m->prev_flagged) {
+			// the predecessor had flagged itself (and has been repeated, or has failed): this update stood back
+			HIP_TRY(hipStreamSynchronize(m->stream));
+			hipLaunchKernelGGL(k_ctl_clear, dim3(1), dim3(1), 0, m->stream, m->b_ctl.as<ScanCtl>(), (u32)ERR_PREV);
+			m->cs = m->stream;
+			rc = mapPhase(m, depth, d_rgb, capH, capM, merged);
+			if (rc) return rc;
+			HIP_TRY(hipEventRecord(m->done_ev, m->stream));
+		}
+		m->pending = true;
+		m->pending_set = m->cur_set;
+		m->pending_bound = m->scan_new_bound;
+		return prc;
+	}
+	prc = joinPrevious(m);
 	if (rc || 0 == n) {
 		if (rc) (void)hipStreamSynchronize(m->sstream);
 		return rc ? rc : prc;
@@ -1055,6 +1121,7 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 	HIP_TRY(hipGetLastError());
 	m->pending = true;
 	m->pending_set = m->cur_set;
+	m->pending_bound = m->scan_new_bound;
 	if (!async) {
 		HIP_TRY(hipStreamSynchronize(m->stream));
 		rc = finishPending(m);
@@ -1072,6 +1139,9 @@ int redoScan(ufomap_map* m)
 	m->args.spec = false;
 	m->spec_valid = false;
 	++m->n_spec_redo;
+	// an update enqueued behind this one looks at this control block when it starts: let it do so (and stand back)
+	// before the block is rewritten
+	HIP_TRY(hipStreamSynchronize(m->stream));
 	// the scan half of the NEXT integration may already have run: what it left in the map object is restored
 	const Grid sgM = m->gridM, sgH = m->gridH;
 	const bool shH = m->haveH, shM = m->haveM;
@@ -1163,7 +1233,9 @@ ufomap_map* ufomap_map_create(double resolution, unsigned depth_levels, int auto
 	setSensorModel(g, occupied_thres, free_thres, prob_hit, prob_miss, clamping_thres_min, clamping_thres_max);
 	bool ok = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) == hipSuccess &&
 	          hipStreamCreateWithFlags(&m->sstream, hipStreamNonBlocking) == hipSuccess &&
+	          hipStreamCreateWithFlags(&m->xstream, hipStreamNonBlocking) == hipSuccess &&
 	          hipEventCreateWithFlags(&m->done_ev, hipEventDisableTiming) == hipSuccess &&
+	          hipEventCreateWithFlags(&m->alt.done_ev, hipEventDisableTiming) == hipSuccess &&
 	          hipEventCreateWithFlags(&m->scan_ev, hipEventDisableTiming) == hipSuccess &&
 	          hipHostMalloc((void**)&m->h_ctl, sizeof(ScanCtl) + 64) == hipSuccess &&
 	          hipHostMalloc((void**)&m->alt.h_ctl, sizeof(ScanCtl) + 64) == hipSuccess &&
@@ -1227,6 +1299,8 @@ void ufomap_map_destroy(ufomap_map* m)
 	if (m->h_ctl) (void)hipHostFree(m->h_ctl);
 	if (m->h_root) (void)hipHostFree(m->h_root);
 	if (m->done_ev) (void)hipEventDestroy(m->done_ev);
+	if (m->alt.done_ev) (void)hipEventDestroy(m->alt.done_ev);
+	if (m->xstream) (void)hipStreamDestroy(m->xstream);
 	if (m->stream) (void)hipStreamDestroy(m->stream);
 	delete m;
 }
@@ -1511,7 +1585,7 @@ int ufomap_map_done(ufomap_map* m)
 {
 	if (!m) return fail(UFOMAP_ERR_INVALID, "null map");
 	if (!m->pending) return 1;
-	hipError_t e = hipEventQuery(m->done_ev);
+	hipError_t e = hipEventQuery(m->pending_set == m->cur_set ? m->done_ev : m->alt.done_ev);
 	if (e == hipSuccess) return 1;
 	if (e == hipErrorNotReady) return 0;
 	return fail(UFOMAP_ERR_DEVICE, hipGetErrorString(e));
@@ -1971,7 +2045,7 @@ int ufomap_map_apply_keys_batch(ufomap_map* m, const void* const* d_lists, const
 	for (size_t k = 0; k < subs.size(); ++k) {
 		ProfScope ps(m, "k_ensure");
 		hipLaunchKernelGGL(k_ensure, gridFor(subs[k].n), dim3(256), 0, m->cs, m->t, m->g, subs[k].ent, d_cnt + k, 0xFFFFFFFFu, 0xFFFFFFFFu, m->scan_id,
-		                   m->b_ent_slot.as<u32>() + subs[k].off, m->b_newlist.as<u32>(), newcap, pc, ctl);
+		                   m->b_ent_slot.as<u32>() + subs[k].off, m->b_newlist.as<u32>(), newcap, pc, ctl, (const ScanCtl*)nullptr);
 	}
 	{
 		ProfScope ps(m, "k_init_new");
@@ -2002,6 +2076,7 @@ int ufomap_map_apply_keys_batch(ufomap_map* m, const void* const* d_lists, const
 	HIP_TRY(hipGetLastError());
 	m->pending = true;
 	m->pending_set = m->cur_set;
+	m->pending_bound = m->scan_new_bound;
 	if (m->opt_async_apply) {
 		// the caller keeps the lists alive until the next call on this map has joined the update
 		HIP_TRY(hipEventRecord(m->done_ev, m->stream));
@@ -2113,6 +2188,8 @@ int ufomap_map_set_option(ufomap_map* m, const char* key, long long value)
 		m->opt_dda_mode = (int)value;
 	} else if (0 == strcmp(key, "dda_seg")) {
 		m->opt_dda_seg = value ? 1 : 0;
+	} else if (0 == strcmp(key, "early_map")) {
+		m->opt_early = value ? 1 : 0;
 	} else if (0 == strcmp(key, "spec")) {
 		m->opt_spec = value ? 1 : 0;
 		if (!m->opt_spec) m->spec_valid = false;
