@@ -1365,7 +1365,7 @@ __device__ inline u32 markBitChecked(const Grid& gr, u32* __restrict__ lds, u32 
 
 __global__ __launch_bounds__(UFO_DDA_BLOCK) void k_walk(MapGeom g, u32 depth, Grid gr, u32* __restrict__ slabs,
                                                         const RayState* __restrict__ rs, u32 seg_shift, const ScanCtl* ctl_in,
-                                                        ScanCtl* ctl, u32 dbg, unsigned long long* __restrict__ steps_part)
+                                                        ScanCtl* ctl, unsigned long long* __restrict__ steps_part)
 {
 	extern __shared__ __attribute__((aligned(16))) u32 lds[];
 	const u32 lds_words = (u32)(gr.bytes >> 2);
@@ -1506,10 +1506,9 @@ __global__ __launch_bounds__(UFO_DDA_BLOCK) void k_walk(MapGeom g, u32 depth, Gr
 	const long long idist = __double_as_longlong(dist);
 	const u32 lin_first = lin;
 	u32 cnt = 0;  // uniform guard only; the lane's step count is the L1 distance it covered (below)
-	if (dbg & 2u) go = false;  // timing experiments only (ufomap_map_set_option "walk_dbg")
 	while (go) {
 		++cnt;
-		if (!(dbg & 1u)) atomicOr(&lds[lin >> 5], 1u << (lin & 31u));
+		atomicOr(&lds[lin >> 5], 1u << (lin & 31u));
 		const bool cxy = tmx <= tmy, cxz = tmx <= tmz, cyz = tmy <= tmz;
 		const bool selx = cxy & cxz;
 		const bool sely = !cxy & cyz;

@@ -2,10 +2,14 @@
 // scan_kernels.h / map_kernels.h. gfx950 only; build: see ufomap_amd/build.py
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared
 //
-// Launch sequence of one integration (all on the map's own stream):
-//   k_classify -> k_select -> [host reads 1 control block: counts, bounding boxes]
-//   memset grids -> k_hitmark -> k_dda -> k_extract(count) -> [host reads counts, sizes the table]
-//   k_extract(fill) -> k_ensure -> k_init_new -> k_apply_leaf | k_apply_coarse -> k_propagate x (L - level)
+// Launch sequence of one depth-0 integration in the steady state (doInsert):
+//   scan stream: memset hit hash -> control block H2D -> k_classify -> k_select -> k_reduce_boxes (checks the
+//                predicted ray grid) -> k_hitmark -> k_cast -> k_merge_slabs -> k_extract_bits -> k_extract_hits
+//   map stream:  [waits for the scan] k_ensure (gates on the predecessor's flags) -> k_init_new -> k_apply_leaf ->
+//                k_propagate x wide levels -> k_propagate_tail
+//   join (of the PREVIOUS integration): event wait -> one control-block D2H on the read-back stream
+// Other grid sizes / insert depths: the boxes are read back after k_select (scanPhase), larger grids use
+// k_ray_setup + k_walk / k_dda_seg / k_dda, insert depth > 0 adds the k_coarse_* phase and walks the tree twice.
 // There is no CPU fallback: every entry point fails with UFOMAP_ERR_DEVICE when HIP is unusable.
 #include <hip/hip_runtime.h>
 
@@ -118,7 +122,7 @@ struct ScanArgs {
 };
 
 struct HandOver {
-	DevBuf b_ctl, b_entries, b_hh_keys, b_hh_idx, b_in_xyz, b_in_rgb;
+	DevBuf b_ctl, b_entries, b_hh_keys, b_in_xyz, b_in_rgb;  // b_hh_keys: hit hash, keys followed by point indices
 	ScanCtl* h_ctl = nullptr;  // pinned
 	u32 hh_mask = 0;
 	uint64_t counts[8] = {0};
@@ -146,7 +150,7 @@ struct ufomap_map {
 	u32 scan_id = 0;
 	u64 used_est = 0;  // host-side view of MapRoot::used (refreshed at every control-block read)
 	// per-scan buffers
-	DevBuf b_ctl, b_pt_end, b_pt_flag, b_pt_slot, b_ray_end, b_hit_code, b_hit_pt, b_hh_keys, b_hh_idx;
+	DevBuf b_ctl, b_pt_end, b_pt_flag, b_pt_slot, b_ray_end, b_hit_code, b_hit_pt, b_hh_keys;
 	DevBuf b_part0, b_part1, b_slabs, b_hb_keys, b_hb_mask, b_hb_time;
 	u32 hb_cap_mask = 0;
 	Ingest ing{};      // ufomap_map_insert_pointcloud2: raw PointCloud2 records, converted inside k_classify
@@ -177,7 +181,6 @@ struct ufomap_map {
 	int opt_dda_seg = 1;  // 0 = force the lane-per-ray kernel
 	int opt_dda_block = 0, opt_dda_lanes = 0;  // 0 = automatic
 	int opt_cast = 1, opt_cast_wgs = 0, opt_cast_k = 32;  // fused ray kernel: on/off, workgroups (0 = 256), steps per segment
-	int opt_walk_dbg = 0; // timing experiments: 1 = no marks, 2 = no walk (results wrong)
 	int opt_bits = 1;     // 0 = never use the bit-per-cell grid / k_walk
 	int opt_merge = 1;    // 0 = hits and misses as two separate passes over the tree also at insert depth 0
 	u64 opt_entry_guess = 0;
@@ -367,7 +370,6 @@ void swapSets(ufomap_map* m)
 	std::swap(m->b_ctl, m->alt.b_ctl);
 	std::swap(m->b_entries, m->alt.b_entries);
 	std::swap(m->b_hh_keys, m->alt.b_hh_keys);
-	std::swap(m->b_hh_idx, m->alt.b_hh_idx);
 	std::swap(m->b_in_xyz, m->alt.b_in_xyz);
 	std::swap(m->b_in_rgb, m->alt.b_in_rgb);
 	std::swap(m->h_ctl, m->alt.h_ctl);
@@ -951,7 +953,7 @@ int scanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, const 
 		if (1 == m->gridM.layout) {
 			// (layout 1 is only chosen when seg is possible and the bit grid fits in LDS)
 			hipLaunchKernelGGL(k_walk, gr, dim3(blk), lds, m->cs, m->g, (u32)depth, m->gridM, dda_out, m->b_rays.as<RayState>(), seg_shift,
-			                   ctl, ctl, (u32)m->opt_walk_dbg,
+			                   ctl, ctl,
 			                   reinterpret_cast<unsigned long long*>(m->b_slabs.as<char>() + (size_t)gr.x * m->gridM.bytes));
 		} else if (seg) {
 			if (mode == DDA_LDSGRID) UFO_LAUNCH_SEG(DDA_LDSGRID);
@@ -1281,14 +1283,14 @@ void ufomap_map_destroy(ufomap_map* m)
 	if (m->sstream) (void)hipStreamSynchronize(m->sstream);
 	if (m->stream) (void)hipStreamSynchronize(m->stream);
 	m->tb.release();
-	DevBuf* abufs[] = {&m->alt.b_ctl, &m->alt.b_entries, &m->alt.b_hh_keys, &m->alt.b_hh_idx, &m->alt.b_in_xyz, &m->alt.b_in_rgb};
+	DevBuf* abufs[] = {&m->alt.b_ctl, &m->alt.b_entries, &m->alt.b_hh_keys, &m->alt.b_in_xyz, &m->alt.b_in_rgb};
 	for (DevBuf* b : abufs) b->release();
 	if (m->alt.h_ctl) (void)hipHostFree(m->alt.h_ctl);
 	if (m->scan_ev) (void)hipEventDestroy(m->scan_ev);
 	if (m->sstream) (void)hipStreamDestroy(m->sstream);
 	DevBuf* bufs[] = {&m->b_root,
 	                  &m->b_ctl,     &m->b_pt_end,  &m->b_pt_flag,  &m->b_pt_slot, &m->b_ray_end, &m->b_hit_code, &m->b_hit_pt,
-	                  &m->b_hh_keys, &m->b_hh_idx,  &m->b_gridM,   &m->b_crec,    &m->b_dlist,   &m->b_rays,   &m->b_part0,   &m->b_part1,   &m->b_slabs,   &m->b_hb_keys, &m->b_hb_mask, &m->b_hb_time,   &m->b_entries, &m->b_ent_slot, &m->b_newlist,
+	                  &m->b_hh_keys, &m->b_gridM,   &m->b_crec,    &m->b_dlist,   &m->b_rays,   &m->b_part0,   &m->b_part1,   &m->b_slabs,   &m->b_hb_keys, &m->b_hb_mask, &m->b_hb_time,   &m->b_entries, &m->b_ent_slot, &m->b_newlist,
 	                  &m->b_wl0,     &m->b_wl1,     &m->b_in_xyz,   &m->b_in_rgb,  &m->b_codes,   &m->b_dump};
 	for (DevBuf* b : bufs) b->release();
 	for (PendingEvent& pe : m->pend_ev) {
@@ -2201,8 +2203,6 @@ int ufomap_map_set_option(ufomap_map* m, const char* key, long long value)
 		m->opt_cast_wgs = (int)value;
 	} else if (0 == strcmp(key, "cast_k")) {
 		m->opt_cast_k = (int)value;
-	} else if (0 == strcmp(key, "walk_dbg")) {
-		m->opt_walk_dbg = (int)value;
 	} else if (0 == strcmp(key, "dda_bits")) {
 		m->opt_bits = value ? 1 : 0;
 	} else if (0 == strcmp(key, "dda_block")) {
