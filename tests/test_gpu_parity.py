@@ -391,6 +391,79 @@ def test_predicted_grid_scans_and_their_repeats(async_):
     assert g2.debug()[62] == 0
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_operation_sequence(seed):
+    """Everything interleaved as a caller might: sync and pipelined inserts (continuous / discrete, insert depth
+    0-2, plain and fused-ingest), robot clearing at depth 0-2, batches of update lists from a second map, point
+    queries -- with a sensor that drifts and sometimes jumps (predicted grids fit, then do not). The oracle runs
+    the reference's sequence of calls; compared at checkpoints and at the end, byte stream included."""
+    import torch
+    import oracle
+    from ufomap_amd import scans, OccupancyMap
+    rng = np.random.default_rng(seed)
+    g, o = _maps(resolution=0.16)
+    scanner = OccupancyMap(0.16)
+    pos = np.array(scans.lidar_pose(0), dtype=np.float64)
+    keep = []  # device buffers of pipelined inserts stay alive until joined
+    for step in range(28):
+        pos = pos + (rng.uniform(-3, 3, 3) * [1, 1, 0.1] if rng.random() < 0.15 else rng.uniform(-0.08, 0.08, 3) * [1, 1, 0.2])
+        origin, xyz, _ = scans.lidar64(beams=16, azimuths=256, origin=tuple(pos), seed=1000 * seed + step)
+        mr = float(rng.choice([6.0, 9.0, 12.0]))
+        op = rng.choice(["insert", "insert", "insert", "async", "async", "pc2", "clear", "batch", "depth"])
+        if op in ("insert", "async"):
+            disc = bool(rng.integers(0, 2))
+            if op == "async":
+                d = torch.from_numpy(xyz).cuda()
+                keep.append(d)
+                g.insert_device(origin, d.data_ptr(), None, xyz.shape[0], mr, 0, discrete=disc, async_=True)
+            else:
+                _gpu_insert(g, origin, xyz, max_range=mr, discrete=disc)
+            o.insert(origin, xyz, max_range=mr, discrete=disc)
+        elif op == "depth":
+            dep = int(rng.integers(1, 3))
+            _gpu_insert(g, origin, xyz, max_range=mr, depth=dep, discrete=True)
+            o.insert(origin, xyz, max_range=mr, depth=dep, discrete=True)
+        elif op == "pc2":
+            f = (xyz - origin).astype(np.float32)
+            f[::31, int(rng.integers(0, 3))] = np.nan
+            buf = np.zeros((f.shape[0], 16), np.uint8)
+            buf[:, 0:12] = f.view(np.uint8).reshape(-1, 12)
+            q = np.array([1.0, 0.0, 0.0, 0.0])
+            g.insertPointCloud2(origin, q, buf, 16, (0, 4, 8), None, max_range=mr)
+            cx, _ = oracle.ingest(buf, 16, (0, 4, 8), None, q, origin, "port")
+            o.insert(origin, cx, max_range=mr, discrete=True)
+        elif op == "clear":
+            md = int(rng.integers(0, 3))
+            ext = rng.uniform(0.3, 0.9, 3)
+            g.setValueVolume(pos - ext, pos + ext, g.getClampingThresMin(), md)
+            o.setValueVolume(pos - ext, pos + ext, o.clamping_thres()[0], md)
+        elif op == "batch":
+            bufs, infos = [], []
+            for k in range(2):
+                o2, x2, _ = scans.lidar64(beams=16, azimuths=256, origin=tuple(pos + [0.05 * k, 0, 0]), seed=77 * seed + 10 * step + k)
+                d = torch.from_numpy(x2).cuda()
+                info = scanner.scan_keys(o2, d.data_ptr(), x2.shape[0], mr, 0, True)
+                b = torch.empty((info.n_hit + info.n_miss) * 16, dtype=torch.uint8, device="cuda")
+                scanner.get_keys(b.data_ptr(), b.numel() // 16, info)
+                bufs.append(b)
+                infos.append(info)
+                o.insert(o2, x2, max_range=mr, discrete=True)
+            g.apply_keys_batch([b.data_ptr() for b in bufs], infos)
+        if step % 9 == 8:
+            g.insertPointCloudWait()
+            keep.clear()
+            assert same_dump(g.leaves(True), o.leaves(True)), f"seed {seed} step {step} ({op}): leaves differ"
+            assert same_dump(g.inner(), o.inner()), f"seed {seed} step {step} ({op}): inner nodes differ"
+            qs = np.concatenate([xyz[::11], rng.uniform(-12, 12, (500, 3)) + pos])
+            a, b = g.query(qs, int(rng.integers(0, 4))), None
+            d = int(rng.integers(0, 4))
+            a, b = g.query(qs, d), o.query(qs, d)
+            assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)) and np.array_equal(a[1], b[1]), f"seed {seed} step {step}: queries differ"
+    g.insertPointCloudWait()
+    assert same_dump(g.leaves(True), o.leaves(True)) and same_dump(g.inner(), o.inner()), f"seed {seed}: final map differs"
+    assert g.write() == o.write()
+
+
 def test_batch_integrator_rccl_world1():
     """BatchIntegrator on HBM tensors through the nccl (RCCL) backend with a single rank: the same code
     path the 8-GPU run takes, minus the peers."""
