@@ -71,9 +71,9 @@ int ufomap_map_set_sensor_model(ufomap_map* m, double occupied_thres, double fre
  * The call first joins any previous integration (occupancy_map_base.h:315).
  * ufomap_map_insert takes HOST pointers (H2D copy included); ufomap_map_insert_device takes
  * DEVICE pointers already resident in HBM. With async != 0 a device cloud must stay valid and unchanged
- * until the integration has been joined -- by ufomap_map_wait, by any reader, or by the NEXT insert call
- * returning (every insert joins its predecessor before it returns): kernels read it after the call has
- * returned, and a scan that was enqueued on a ray grid predicted from the previous scan and turns out not to
+ * until the integration has been joined -- by ufomap_map_wait, by any reader, or by the SECOND-NEXT insert call
+ * returning (insert i joins insert i-2 before it returns; two updates may be in flight): kernels read it after
+ * the call has returned, and a scan that was enqueued on a ray grid predicted from the previous scan and turns out not to
  * fit it is repeated from the same buffer at that join ("spec", ufomap_map_set_option). */
 int ufomap_map_insert(ufomap_map* m, const double sensor_origin[3], const double* xyz,
                       const uint8_t* rgb, size_t n, double max_range, unsigned depth, int discrete,

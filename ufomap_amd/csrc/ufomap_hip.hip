@@ -128,6 +128,8 @@ struct HandOver {
 	uint64_t counts[8] = {0};
 	ScanArgs args;
 	hipEvent_t done_ev = nullptr;  // end of the integration that uses this set
+	bool pending = false;          // that integration has been enqueued and not yet been joined
+	u64 bound = 0;                 // upper bound of the blocks it may add to the node table
 };
 
 struct ufomap_map {
@@ -138,9 +140,10 @@ struct ufomap_map {
 	hipEvent_t done_ev = nullptr, scan_ev = nullptr;
 	hipStream_t xstream = nullptr;  // read-back of control blocks whose producers are known to be complete
 	bool prev_flagged = false;      // the integration joined last had flagged an error (finishPending)
-	u64 pending_bound = 0;          // upper bound of the blocks the pending integration may add to the table
 	int opt_early = 1;              // enqueue the map half before the previous integration has been joined (doInsert)
-	HandOver alt;                   // the other set of hand-over buffers
+	HandOver alt[2];                // the other hand-over sets: alt[1] = the previous integration's, alt[0] = the one before
+	u64 bound = 0;                  // (of the current set, see HandOver::bound)
+	                  // the other set of hand-over buffers
 	int async_status = UFOMAP_OK;   // first error of an integration that was joined by a later call
 	MapGeom g{};
 	// node table
@@ -163,7 +166,6 @@ struct ufomap_map {
 	// state of the last integration
 	bool pending = false;
 	int pending_status = UFOMAP_OK;
-	int cur_set = 0, pending_set = 0;  // which hand-over set is current / holds the control block of the pending integration
 	ScanArgs args;                     // of the integration that uses the current hand-over set
 	Grid spec_grid{};                  // ray grid predicted for the next depth-0 scan (from the last one's box + margin)
 	bool spec_valid = false;
@@ -365,19 +367,38 @@ u64 blockBound(const ufomap_map* m, u64 n, const i32 nb[3], u32 level)
 	return total + 8;
 }
 
-void swapSets(ufomap_map* m)
+// exchange the current hand-over set (members of the map object) with another one
+void swapWith(ufomap_map* m, HandOver& o)
 {
-	std::swap(m->b_ctl, m->alt.b_ctl);
-	std::swap(m->b_entries, m->alt.b_entries);
-	std::swap(m->b_hh_keys, m->alt.b_hh_keys);
-	std::swap(m->b_in_xyz, m->alt.b_in_xyz);
-	std::swap(m->b_in_rgb, m->alt.b_in_rgb);
-	std::swap(m->h_ctl, m->alt.h_ctl);
-	std::swap(m->hh_mask, m->alt.hh_mask);
-	for (int k = 0; k < 8; ++k) std::swap(m->counts[k], m->alt.counts[k]);
-	std::swap(m->args, m->alt.args);
-	std::swap(m->done_ev, m->alt.done_ev);
-	m->cur_set ^= 1;
+	std::swap(m->b_ctl, o.b_ctl);
+	std::swap(m->b_entries, o.b_entries);
+	std::swap(m->b_hh_keys, o.b_hh_keys);
+	std::swap(m->b_in_xyz, o.b_in_xyz);
+	std::swap(m->b_in_rgb, o.b_in_rgb);
+	std::swap(m->h_ctl, o.h_ctl);
+	std::swap(m->hh_mask, o.hh_mask);
+	for (int k = 0; k < 8; ++k) std::swap(m->counts[k], o.counts[k]);
+	std::swap(m->args, o.args);
+	std::swap(m->done_ev, o.done_ev);
+	std::swap(m->pending, o.pending);
+	std::swap(m->bound, o.bound);
+}
+
+int finishSet(ufomap_map* m, int k);
+
+// A new integration begins: the oldest hand-over set becomes the current one (its integration is joined first if it
+// is still pending), the set that was current becomes alt[1] (the predecessor), the old alt[1] becomes alt[0].
+int rotateSets(ufomap_map* m)
+{
+	int rc = UFOMAP_OK;
+	if (m->alt[0].pending) {
+		(void)hipEventSynchronize(m->alt[0].done_ev);
+		rc = finishSet(m, 0);
+		if (rc && UFOMAP_OK == m->async_status) m->async_status = rc;
+	}
+	swapWith(m, m->alt[0]);
+	std::swap(m->alt[0], m->alt[1]);
+	return rc;
 }
 
 int readCtl(ufomap_map* m)
@@ -559,7 +580,7 @@ int applyEntries(ufomap_map* m, const Entry* d_entries, u32 cap, u32 which, u32 
 // extra_used / no_grow: the caller has an update in flight that may add up to extra_used blocks and cannot wait for
 // it here; if the table might not take both, 1 is returned (nothing done) and the caller joins first.
 int sizeTable(ufomap_map* m, const Entry* ent_h, u64 capH, const i32 nbH[3], const Entry* ent_m, u64 capM, const i32 nbM[3],
-              unsigned depth, bool merged = false, u64 extra_used = 0, bool no_grow = false)
+              unsigned depth, bool merged = false, u64 extra_used = 0, bool no_grow = false, u32 headroom_scans = 0)
 {
 	// merged list (depth 0) whose hit box lies inside the ray box: all entries are blocks of the miss grid
 	bool h_in_m = merged && capH && capM && m->haveH && m->haveM && nbH == m->gridH.nb && nbM == m->gridM.nb;
@@ -575,6 +596,9 @@ int sizeTable(ufomap_map* m, const Entry* ent_h, u64 capH, const i32 nbH[3], con
 	};
 	m->scan_new_bound = bound(capH, capM);
 	u64 cap = (u64)m->t.mask + 1;
+	// headroom_scans: a stream of pipelined scans keeps up to two more updates of this size in flight; size the
+	// table for that now, so that the following updates can be enqueued without joining their predecessors
+	extra_used += (u64)headroom_scans * m->scan_new_bound;
 	if ((m->used_est + extra_used + m->scan_new_bound) * 5 <= cap * 3) return UFOMAP_OK;  // load factor stays <= 0.6
 	if (no_grow) return 1;
 	// small tables simply grow to the pessimistic size once (cheap, and the fast check passes from then on);
@@ -602,9 +626,9 @@ int sizeTable(ufomap_map* m, const Entry* ent_h, u64 capH, const i32 nbH[3], con
 			if (m->h_ctl->n_entries[0] <= capH + capM)
 				m->scan_new_bound = h_in_m ? blockBound(m, cnt[0], nbM, 1) : bound(capH ? cnt[0] : 0, capM ? cnt[0] : 0);
 		} else if (m->h_ctl->n_entries[0] <= capH && m->h_ctl->n_entries[1] <= capM) m->scan_new_bound = bound(cnt[0], cnt[1]);
-		if ((m->used_est + m->scan_new_bound) * 5 <= cap * 3) return UFOMAP_OK;
+		if ((m->used_est + extra_used + m->scan_new_bound) * 5 <= cap * 3) return UFOMAP_OK;
 	}
-	u64 want = (m->used_est + m->scan_new_bound) * 2;
+	u64 want = (m->used_est + extra_used + m->scan_new_bound) * 2;
 	if (want > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
 	return growTable(m, nextPow2(want));
 }
@@ -666,12 +690,12 @@ int extractLists(ufomap_map* m, u64 capH, u64 capM, bool zero_counts, bool merge
 // prev != nullptr: control block of the integration enqueued just before, not yet checked by the host (doInsert);
 // returns 1 (nothing enqueued) if the table might have to grow while that one is in flight.
 int mapPhase(ufomap_map* m, unsigned depth, const uint8_t* d_rgb, u64 capH, u64 capM, bool merged, const ScanCtl* prev = nullptr,
-             u64 extra_used = 0)
+             u64 extra_used = 0, u32 headroom_scans = 0)
 {
 	const float miss = (float)(m->g.miss_log / double((2.0 * depth) + 1));  // OMB:311
 	Entry* ent_h = m->b_entries.as<Entry>();
 	Entry* ent_m = ent_h + capH;
-	int rc = sizeTable(m, ent_h, capH, m->gridH.nb, ent_m, capM, m->gridM.nb, depth, merged, extra_used, nullptr != prev);
+	int rc = sizeTable(m, ent_h, capH, m->gridH.nb, ent_m, capM, m->gridM.nb, depth, merged, extra_used, nullptr != prev, headroom_scans);
 	if (rc) return rc;
 	if (merged)
 		return applyEntries(m, ent_h, (u32)(capH + capM), 0, 1, m->gridH.nb, m->g.hit, d_rgb, false, (u32)(capH + capM), 0u, (u32)capM,
@@ -1018,22 +1042,24 @@ int extractPhase(ufomap_map* m, u32 n_hits, u32 n_rays, u64* capH_out, u64* capM
 	return UFOMAP_OK;
 }
 
-// join the integration whose map phase was enqueued by the previous call (its hand-over set is `alt` now)
-int finishPendingAnySet(ufomap_map* m)
+// finish (read back, check, repeat if flagged) the integration of hand-over set alt[k]; its kernels must be complete
+int finishSet(ufomap_map* m, int k)
 {
-	if (!m->pending) return UFOMAP_OK;
-	if (m->pending_set == m->cur_set) return finishPending(m);
-	swapSets(m);
+	if (!m->alt[k].pending) return UFOMAP_OK;
+	swapWith(m, m->alt[k]);
 	int rc = finishPending(m);
-	swapSets(m);
+	swapWith(m, m->alt[k]);
 	return rc;
 }
 
-int joinPrevious(ufomap_map* m)
+// join the integrations enqueued by earlier calls, oldest first (the current set's own is not touched)
+int joinOlder(ufomap_map* m)
 {
-	if (!m->pending) return UFOMAP_OK;
+	if (!m->alt[0].pending && !m->alt[1].pending) return UFOMAP_OK;
 	HIP_TRY(hipStreamSynchronize(m->stream));
-	int rc = finishPendingAnySet(m);
+	int rc = finishSet(m, 0);
+	int rc1 = finishSet(m, 1);
+	if (!rc) rc = rc1;
 	if (rc && UFOMAP_OK == m->async_status) m->async_status = rc;
 	return rc;
 }
@@ -1047,7 +1073,7 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 	// while the map half of the previous integration may still be updating the tree on the map stream --
 	// the reference overlaps its head loop with the previous integration the same way (the join sits
 	// after the head loop, OMB:315). Hand-over buffers are double-buffered and swapped here.
-	if (!swapped) swapSets(m);
+	if (!swapped) (void)rotateSets(m);
 	m->cs = m->sstream;
 	// insert depth 0: hits and misses of the scan as ONE pass over the tree (map_kernels.h, k_apply_leaf mode 2)
 	const bool merged = 0 == depth && 0 != m->opt_merge;
@@ -1075,28 +1101,37 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 	if (!rc && n) rc = extractPhase(m, n_hits, n_rays, &capH, &capM, merged);
 	if (!rc && n) rc = (hipEventRecord(m->scan_ev, m->sstream) == hipSuccess) ? UFOMAP_OK : fail(UFOMAP_ERR_DEVICE, "hipEventRecord");
 	// ---- early map half: enqueue THIS scan's tree update behind the previous one BEFORE that one has been joined,
-	// so that the two run back to back on the map stream (otherwise the GPU idles while the host reads the previous
-	// control block and enqueues six launches). The first kernel looks at the predecessor's error flags: if it
-	// flagged itself, this update stands back too (ERR_PREV) and both are re-run in order below.
+	// so that the updates run back to back on the map stream and the next call can start its scan half while two
+	// updates are still in flight (three hand-over sets). The first kernel looks at the predecessor's error flags:
+	// if it flagged itself, this update stands back too (ERR_PREV, which cascades) and everything flagged is re-run
+	// in order when it is joined.
 	bool early = false;
-	if (!rc && n && async && merged && m->opt_early && m->pending && m->pending_set != m->cur_set && !m->profiling) {
+	if (!rc && n && async && merged && m->opt_early && m->alt[1].pending && !m->profiling) {
 		m->cs = m->stream;
 		HIP_TRY(hipStreamWaitEvent(m->stream, m->scan_ev, 0));
 		m->last_rgb = d_rgb;
-		const int erc = mapPhase(m, depth, d_rgb, capH, capM, merged, m->alt.b_ctl.as<ScanCtl>(), m->pending_bound);
+		const u64 in_flight = m->alt[1].bound + (m->alt[0].pending ? m->alt[0].bound : 0);
+		const int erc = mapPhase(m, depth, d_rgb, capH, capM, merged, m->alt[1].b_ctl.as<ScanCtl>(), in_flight);
 		if (erc < 0) return erc;
 		early = 0 == erc;  // 1: the table might have to grow: join first (below)
 		if (early) HIP_TRY(hipEventRecord(m->done_ev, m->stream));
 	}
-	// join the previous integration (occupancy_map_base.h:315): its status is reported by wait()/this call
-	int prc;
+	int prc = UFOMAP_OK;
 	if (early) {
-		HIP_TRY(hipEventSynchronize(m->alt.done_ev));  // the predecessor alone: this scan's update keeps running
+		// join the integration before the previous one (long finished as a rule): the previous one and this one keep running
 		m->prev_flagged = false;
-		prc = finishPendingAnySet(m);
-		if (prc && UFOMAP_OK == m->async_status) m->async_status = prc;
+		if (m->alt[0].pending) {
+			HIP_TRY(hipEventSynchronize(m->alt[0].done_ev));
+			prc = finishSet(m, 0);
+			if (prc && UFOMAP_OK == m->async_status) m->async_status = prc;
+		}
 		if (m->prev_flagged) {
-			// the predecessor had flagged itself (and has been repeated, or has failed): this update stood back
+			// it had flagged itself (and has been repeated, or has failed): the previous update and this one stood back.
+			// Drain in order: the previous one is repeated by its own join, then this one's tree update is enqueued again.
+			HIP_TRY(hipStreamSynchronize(m->stream));
+			const int prc1 = finishSet(m, 1);
+			if (!prc) prc = prc1;
+			if (prc1 && UFOMAP_OK == m->async_status) m->async_status = prc1;
 			HIP_TRY(hipStreamSynchronize(m->stream));
 			hipLaunchKernelGGL(k_ctl_clear, dim3(1), dim3(1), 0, m->stream, m->b_ctl.as<ScanCtl>(), (u32)ERR_PREV);
 			m->cs = m->stream;
@@ -1105,11 +1140,11 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 			HIP_TRY(hipEventRecord(m->done_ev, m->stream));
 		}
 		m->pending = true;
-		m->pending_set = m->cur_set;
-		m->pending_bound = m->scan_new_bound;
+		m->bound = m->scan_new_bound;
 		return prc;
 	}
-	prc = joinPrevious(m);
+	// join the previous integrations (occupancy_map_base.h:315): their status is reported by wait()/this call
+	prc = joinOlder(m);
 	if (rc || 0 == n) {
 		if (rc) (void)hipStreamSynchronize(m->sstream);
 		return rc ? rc : prc;
@@ -1118,12 +1153,11 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 	m->cs = m->stream;
 	HIP_TRY(hipStreamWaitEvent(m->stream, m->scan_ev, 0));
 	m->last_rgb = d_rgb;
-	rc = mapPhase(m, depth, d_rgb, capH, capM, merged);
+	rc = mapPhase(m, depth, d_rgb, capH, capM, merged, nullptr, 0, (async && merged && m->opt_early) ? 2u : 0u);
 	if (rc) return rc;
 	HIP_TRY(hipGetLastError());
 	m->pending = true;
-	m->pending_set = m->cur_set;
-	m->pending_bound = m->scan_new_bound;
+	m->bound = m->scan_new_bound;
 	if (!async) {
 		HIP_TRY(hipStreamSynchronize(m->stream));
 		rc = finishPending(m);
@@ -1166,7 +1200,6 @@ int redoScan(ufomap_map* m)
 	if (!rc) rc = (hipStreamSynchronize(m->stream) == hipSuccess) ? UFOMAP_OK : fail(UFOMAP_ERR_DEVICE, "hipStreamSynchronize");
 	if (!rc) {
 		m->pending = true;
-		m->pending_set = m->cur_set;
 		rc = finishPending(m);
 	}
 	m->gridM = sgM;
@@ -1237,11 +1270,13 @@ ufomap_map* ufomap_map_create(double resolution, unsigned depth_levels, int auto
 	          hipStreamCreateWithFlags(&m->sstream, hipStreamNonBlocking) == hipSuccess &&
 	          hipStreamCreateWithFlags(&m->xstream, hipStreamNonBlocking) == hipSuccess &&
 	          hipEventCreateWithFlags(&m->done_ev, hipEventDisableTiming) == hipSuccess &&
-	          hipEventCreateWithFlags(&m->alt.done_ev, hipEventDisableTiming) == hipSuccess &&
+	          hipEventCreateWithFlags(&m->alt[0].done_ev, hipEventDisableTiming) == hipSuccess &&
+	          hipEventCreateWithFlags(&m->alt[1].done_ev, hipEventDisableTiming) == hipSuccess &&
 	          hipEventCreateWithFlags(&m->scan_ev, hipEventDisableTiming) == hipSuccess &&
 	          hipHostMalloc((void**)&m->h_ctl, sizeof(ScanCtl) + 64) == hipSuccess &&
-	          hipHostMalloc((void**)&m->alt.h_ctl, sizeof(ScanCtl) + 64) == hipSuccess &&
-	          m->alt.b_ctl.reserve(sizeof(ScanCtl) + 64) == hipSuccess &&
+	          hipHostMalloc((void**)&m->alt[0].h_ctl, sizeof(ScanCtl) + 64) == hipSuccess &&
+	          hipHostMalloc((void**)&m->alt[1].h_ctl, sizeof(ScanCtl) + 64) == hipSuccess &&
+	          m->alt[0].b_ctl.reserve(sizeof(ScanCtl) + 64) == hipSuccess && m->alt[1].b_ctl.reserve(sizeof(ScanCtl) + 64) == hipSuccess &&
 	          hipHostMalloc((void**)&m->h_root, sizeof(MapRoot)) == hipSuccess &&
 	          m->b_ctl.reserve(sizeof(ScanCtl) + 64) == hipSuccess && m->b_root.reserve(sizeof(MapRoot)) == hipSuccess;
 	if (!ok) {
@@ -1251,7 +1286,8 @@ ufomap_map* ufomap_map_create(double resolution, unsigned depth_levels, int auto
 	}
 	m->cs = m->stream;
 	memset(m->h_ctl, 0, sizeof(ScanCtl));
-	memset(m->alt.h_ctl, 0, sizeof(ScanCtl));
+	memset(m->alt[0].h_ctl, 0, sizeof(ScanCtl));
+	memset(m->alt[1].h_ctl, 0, sizeof(ScanCtl));
 	if (allocTable(m, 1u << 16, &m->t, &m->tb) ||
 	    resetRoot(m)) {
 		ufomap_map_destroy(m);
@@ -1283,9 +1319,12 @@ void ufomap_map_destroy(ufomap_map* m)
 	if (m->sstream) (void)hipStreamSynchronize(m->sstream);
 	if (m->stream) (void)hipStreamSynchronize(m->stream);
 	m->tb.release();
-	DevBuf* abufs[] = {&m->alt.b_ctl, &m->alt.b_entries, &m->alt.b_hh_keys, &m->alt.b_in_xyz, &m->alt.b_in_rgb};
-	for (DevBuf* b : abufs) b->release();
-	if (m->alt.h_ctl) (void)hipHostFree(m->alt.h_ctl);
+	for (HandOver& a : m->alt) {
+		DevBuf* abufs[] = {&a.b_ctl, &a.b_entries, &a.b_hh_keys, &a.b_in_xyz, &a.b_in_rgb};
+		for (DevBuf* b : abufs) b->release();
+		if (a.h_ctl) (void)hipHostFree(a.h_ctl);
+		if (a.done_ev) (void)hipEventDestroy(a.done_ev);
+	}
 	if (m->scan_ev) (void)hipEventDestroy(m->scan_ev);
 	if (m->sstream) (void)hipStreamDestroy(m->sstream);
 	DevBuf* bufs[] = {&m->b_root,
@@ -1301,7 +1340,6 @@ void ufomap_map_destroy(ufomap_map* m)
 	if (m->h_ctl) (void)hipHostFree(m->h_ctl);
 	if (m->h_root) (void)hipHostFree(m->h_root);
 	if (m->done_ev) (void)hipEventDestroy(m->done_ev);
-	if (m->alt.done_ev) (void)hipEventDestroy(m->alt.done_ev);
 	if (m->xstream) (void)hipStreamDestroy(m->xstream);
 	if (m->stream) (void)hipStreamDestroy(m->stream);
 	delete m;
@@ -1360,7 +1398,7 @@ int ufomap_map_insert(ufomap_map* m, const double sensor_origin[3], const double
 {
 	if (!m) return fail(UFOMAP_ERR_INVALID, "null map");
 	HIP_TRY(hipSetDevice(m->device));
-	swapSets(m);  // the staging buffers belong to the hand-over set of THIS scan
+	(void)rotateSets(m);  // the staging buffers belong to the hand-over set of THIS scan
 	const double* d_xyz = nullptr;
 	const uint8_t* d_rgb = nullptr;
 	if (n) {
@@ -1374,10 +1412,7 @@ int ufomap_map_insert(ufomap_map* m, const double sensor_origin[3], const double
 			d_rgb = m->b_in_rgb.as<uint8_t>();
 		}
 		if (e == hipSuccess) e = hipStreamSynchronize(m->sstream);  // pageable source: copy complete before returning
-		if (e != hipSuccess) {
-			swapSets(m);
-			return fail(UFOMAP_ERR_DEVICE, hipGetErrorString(e));
-		}
+		if (e != hipSuccess) return fail(UFOMAP_ERR_DEVICE, hipGetErrorString(e));
 	}
 	return doInsert(m, sensor_origin, d_xyz, d_rgb, n, max_range, depth, discrete, simple_ray_casting, early_stopping, async, true);
 }
@@ -1395,7 +1430,7 @@ int ufomap_map_insert_pointcloud2(ufomap_map* m, const double translation[3], co
 	if (m->g.color && !discrete)
 		return fail(UFOMAP_ERR_UNSUPPORTED, "OccupancyMapColor::insertPointCloud<PointCloudColor> does not compile in the reference (SURVEY.md 4)");
 	HIP_TRY(hipSetDevice(m->device));
-	swapSets(m);  // the staging buffers belong to the hand-over set of THIS scan
+	(void)rotateSets(m);  // the staging buffers belong to the hand-over set of THIS scan
 	const uint8_t* d_data = static_cast<const uint8_t*>(data);
 	hipError_t e = hipSuccess;
 	if (n_points && !data_on_device) {
@@ -1411,10 +1446,7 @@ int ufomap_map_insert_pointcloud2(ufomap_map* m, const double translation[3], co
 		e = m->b_in_rgb.reserve(n_points * 3);
 		d_rgb = m->b_in_rgb.as<uint8_t>();
 	}
-	if (e != hipSuccess) {
-		swapSets(m);
-		return fail(UFOMAP_ERR_DEVICE, hipGetErrorString(e));
-	}
+	if (e != hipSuccess) return fail(UFOMAP_ERR_DEVICE, hipGetErrorString(e));
 	Ingest ing{};
 	ing.data = d_data;
 	ing.step = point_step;
@@ -1563,7 +1595,6 @@ int ufomap_map_set_value_volume(ufomap_map* m, const double aabb_min[3], const d
 	}
 	HIP_TRY(hipGetLastError());
 	m->pending = true;
-	m->pending_set = m->cur_set;
 	HIP_TRY(hipStreamSynchronize(m->stream));
 	return finishPending(m);
 }
@@ -1574,7 +1605,13 @@ int ufomap_map_wait(ufomap_map* m)
 	HIP_TRY(hipSetDevice(m->device));
 	HIP_TRY(hipStreamSynchronize(m->sstream));
 	HIP_TRY(hipStreamSynchronize(m->stream));
-	int rc = finishPendingAnySet(m);
+	int rc = finishSet(m, 0);  // oldest first
+	{
+		const int rc1 = finishSet(m, 1);
+		if (!rc) rc = rc1;
+		const int rc2 = finishPending(m);
+		if (!rc) rc = rc2;
+	}
 	if (UFOMAP_OK == rc && UFOMAP_OK != m->async_status) {
 		rc = m->async_status;
 		g_err = "an earlier asynchronous integration failed";
@@ -1586,8 +1623,10 @@ int ufomap_map_wait(ufomap_map* m)
 int ufomap_map_done(ufomap_map* m)
 {
 	if (!m) return fail(UFOMAP_ERR_INVALID, "null map");
-	if (!m->pending) return 1;
-	hipError_t e = hipEventQuery(m->pending_set == m->cur_set ? m->done_ev : m->alt.done_ev);
+	// the map stream runs the integrations in order: the most recent pending one is the last to finish
+	hipEvent_t ev = m->pending ? m->done_ev : (m->alt[1].pending ? m->alt[1].done_ev : (m->alt[0].pending ? m->alt[0].done_ev : nullptr));
+	if (!ev) return 1;
+	hipError_t e = hipEventQuery(ev);
 	if (e == hipSuccess) return 1;
 	if (e == hipErrorNotReady) return 0;
 	return fail(UFOMAP_ERR_DEVICE, hipGetErrorString(e));
@@ -1846,7 +1885,7 @@ int ufomap_map_scan_keys(ufomap_map* m, const double sensor_origin[3], const dou
 	// Ray casting never reads the map: it runs on the scan stream with its own hand-over set while an update
 	// enqueued earlier (asynchronous insert / apply_keys_batch) may still be walking the tree on the map stream.
 	HIP_TRY(hipStreamSynchronize(m->sstream));
-	swapSets(m);
+	(void)rotateSets(m);
 	m->args = ScanArgs{};
 	m->cs = m->sstream;
 	u32 n_hits = 0, n_rays = 0;
@@ -1929,7 +1968,6 @@ int ufomap_map_apply_keys(ufomap_map* m, const void* d_entries, const ufomap_key
 	rc = applyEntries(m, ent + nh, nm, 1, info->depth + 1, info->nb_miss, miss, nullptr, false, nh, nm);
 	if (rc) return rc;
 	m->pending = true;
-	m->pending_set = m->cur_set;
 	HIP_TRY(hipStreamSynchronize(m->stream));
 	return finishPending(m);
 }
@@ -1944,7 +1982,11 @@ int ufomap_map_apply_keys_batch(ufomap_map* m, const void* const* d_lists, const
 	HIP_TRY(hipSetDevice(m->device));
 	{
 		// join what is in flight on the map stream (not the scan stream: ray casting of the next batch may overlap)
-		int prc = joinPrevious(m);
+		int prc = joinOlder(m);
+		if (!prc && m->pending) {  // (an update enqueued on this very set: scan_keys was not called in between)
+			HIP_TRY(hipStreamSynchronize(m->stream));
+			prc = finishPending(m);
+		}
 		if (UFOMAP_OK == prc && UFOMAP_OK != m->async_status) {
 			prc = m->async_status;
 			g_err = "an earlier asynchronous integration failed";
@@ -2077,8 +2119,7 @@ int ufomap_map_apply_keys_batch(ufomap_map* m, const void* const* d_lists, const
 	propagateLevels(m, 2, bound, pc, 0);
 	HIP_TRY(hipGetLastError());
 	m->pending = true;
-	m->pending_set = m->cur_set;
-	m->pending_bound = m->scan_new_bound;
+	m->bound = m->scan_new_bound;
 	if (m->opt_async_apply) {
 		// the caller keeps the lists alive until the next call on this map has joined the update
 		HIP_TRY(hipEventRecord(m->done_ev, m->stream));
