@@ -93,8 +93,9 @@ __device__ inline Summ blockSummary(const Table& t, const MapGeom& g, u32 s, u32
 
 // Write a block's summary into the slot that holds the node's own value. Returns "changed"
 // (the bool updateNode returns, OMB:1215-1223 / OMC.cpp:118-121).
+// p_known: the caller already holds t.parent[s] (the wave-resident chain of k_propagate_tail prefetches it)
 template <bool WG = false>
-__device__ inline bool writeToParent(const Table& t, const MapGeom& g, u32 s, u64 lk, const Summ& sm)
+__device__ inline bool writeToParent(const Table& t, const MapGeom& g, u32 s, u64 lk, const Summ& sm, u32 p_known = NONE)
 {
 	if (1 == lk) {
 		MapRoot* r = t.root;
@@ -104,7 +105,7 @@ __device__ inline bool writeToParent(const Table& t, const MapGeom& g, u32 s, u6
 		r->rgb = sm.rgb;
 		return ch;
 	}
-	u32 p = t.parent[s];
+	u32 p = (p_known != NONE) ? p_known : t.parent[s];
 	u32 ci = (u32)(lk & 7);
 	float* po = t.occ + 8 * (size_t)p + ci;
 	u32 fp = aLoad<WG>(&t.flags[p]);
@@ -148,10 +149,10 @@ __device__ inline Summ readStored(const Table& t, const MapGeom& g, u32 s, u64 l
 // The node became a leaf again (deleteChildren, octree.h:1060-1066): mark the block DEAD and clear
 // the parent's "child is inner" bit.
 template <bool WG = false>
-__device__ inline void collapseBlock(const Table& t, u32 s, u64 lk)
+__device__ inline void collapseBlock(const Table& t, u32 s, u64 lk, u32 p_known = NONE)
 {
 	aOr<WG>(&t.flags[s], F_DEAD);
-	if (1 != lk) aAnd<WG>(&t.flags[t.parent[s]], ~(1u << (16 + (u32)(lk & 7))));
+	if (1 != lk) aAnd<WG>(&t.flags[(p_known != NONE) ? p_known : t.parent[s]], ~(1u << (16 + (u32)(lk & 7))));
 }
 
 __device__ inline bool sameSumm(const MapGeom& g, const Summ& a, const Summ& b)
@@ -172,10 +173,11 @@ __device__ inline bool sameSumm(const MapGeom& g, const Summ& a, const Summ& b)
 #define UFO_TAG(phase) ((u64)((phase)&0xFFFFFFu))
 // The record lives in the PARENT's arrays at [8*parent + child index], so the parent reads it without a
 // hash lookup. lu_fl: bits 0-1 flags of the pre-last summary, bit 8 "reached and changed", bits 9.. phase tag.
-__device__ inline void publishLast(const Table& t, const MapGeom& g, u32 s, u64 lk, u32 phase, bool reachchg, const Summ& pre)
+__device__ inline void publishLast(const Table& t, const MapGeom& g, u32 s, u64 lk, u32 phase, bool reachchg, const Summ& pre,
+                                   u32 p_known = NONE)
 {
 	if (1 == lk) return;
-	size_t at = 8 * (size_t)t.parent[s] + (size_t)(lk & 7);
+	size_t at = 8 * (size_t)((p_known != NONE) ? p_known : t.parent[s]) + (size_t)(lk & 7);
 	t.lu_occ[at] = pre.occ;
 	if (g.color) t.lu_rgb[at] = pre.rgb;
 	t.lu_fl[at] = (pre.fl & 3u) | (reachchg ? 0x100u : 0u) | ((phase & 0x3FFFFFu) << 9);
@@ -194,9 +196,10 @@ __device__ inline void carryTime(const Table& t, u32 s, u64 lk, u32 phase, u64 t
 	}
 }
 // For block s (location key lk): did the last update beneath it reach it? If so *pre = summary before it.
-__device__ inline bool lastReached(const Table& t, const MapGeom& g, u32 s, u64 lk, u32 level, u32 f, u32 phase, Summ* pre)
+__device__ inline bool lastReached(const Table& t, const MapGeom& g, u32 s, u64 lk, u32 level, u32 f, u32 phase, Summ* pre,
+                                   const u64* tv_known = nullptr)
 {
-	u64 tv = t.tmax[s];
+	u64 tv = tv_known ? *tv_known : t.tmax[s];
 	if ((tv >> 40) != UFO_TAG(phase)) return false;
 	int c = (int)(tv & 7);
 	size_t at = 8 * (size_t)s + (size_t)c;
@@ -776,6 +779,22 @@ __device__ inline bool propagateCore(const Table& t, const MapGeom& g, u32 s, u3
 }
 
 // worklist flavour; `valid` false lanes only take part in the wave-aggregated append
+// the same with the block's key, its tmax word and its parent slot already in registers: every remaining load
+// depends on s alone, so one level of the wave-resident chain is ONE round of loads instead of three
+template <bool WG>
+__device__ inline bool propagateCoreKnown(const Table& t, const MapGeom& g, u32 s, u32 old, u32 phase, u64 lk, u64 tv, u32 ps)
+{
+	const u32 level = levelOf(g, lk);
+	Summ sm = blockSummary(t, g, s, level, old);
+	Summ pre = sm;
+	const bool reached = lastReached(t, g, s, lk, level, old, phase, &pre, &tv);
+	if (reached && sm.collapsible) collapseBlock<WG>(t, s, lk, ps);
+	const bool changed = writeToParent<WG>(t, g, s, lk, sm, ps);
+	const bool reachchg = reached && !sameSumm(g, pre, sm);
+	publishLast(t, g, s, lk, phase, reachchg, pre, ps);
+	return (changed || reachchg) && 1 != lk;
+}
+
 template <bool WG>
 __device__ inline void propagateOne(const Table& t, const MapGeom& g, bool valid, u32 s, u32 phase, u32* __restrict__ wl_out,
                                     u32* cnt_out)
@@ -825,16 +844,31 @@ __global__ __launch_bounds__(1024) void k_propagate_tail(Table t, MapGeom g, u32
 			if (threadIdx.x >= 64u) return;
 			const u32 lane = threadIdx.x;
 			u32 s = lane < n ? in[lane] : NONE;
+			// key, tmax word and parent slot of the lane's block travel with it; those of the NEXT block (the parent)
+			// are loaded while this one is evaluated -- they do not change during propagation (tmax is final after the
+			// apply kernels, the key of a parent is the child's key >> 3) -- so a level costs one round of loads
+			u64 lk = 1, tv = 0;
+			u32 ps = NONE;
+			if (s != NONE) {
+				lk = t.keys[s];
+				tv = t.tmax[s];
+				ps = (1 != lk) ? t.parent[s] : NONE;
+			}
 			bool first = true;
 			for (u32 guard = 0; guard < 32u; ++guard) {
 				const bool valid = s != NONE;
 				if (0 == __ballot(valid)) break;
 				bool want = false;
-				u32 par = NONE;
+				u64 tv_n = 0;
+				u32 pp_n = NONE;
 				if (valid) {
+					if (1 != lk) {
+						tv_n = t.tmax[ps];
+						pp_n = (1 != (lk >> 3)) ? t.parent[ps] : NONE;
+					}
 					// items of the first round came off the worklist (DIRTY set); later rounds were never queued
 					const u32 old = first ? aAnd<true>(&t.flags[s], ~F_DIRTY) : aLoad<true>(&t.flags[s]);
-					want = propagateCore<true>(t, g, s, old, phase, &par);
+					want = propagateCoreKnown<true>(t, g, s, old, phase, lk, tv, ps);
 				}
 				first = false;
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -843,12 +877,16 @@ __global__ __launch_bounds__(1024) void k_propagate_tail(Table t, MapGeom g, u32
 				u64 todo = __ballot(want);
 				while (todo) {
 					const int ld = __ffsll((unsigned long long)todo) - 1;
-					const u32 pl = __shfl(par, ld);
-					const u64 same = __ballot(want && par == pl);
+					const u32 pl = __shfl(ps, ld);
+					const u64 same = __ballot(want && ps == pl);
 					if ((int)lane == ld) next = pl;
 					todo &= ~same;
 				}
+				// the leader of a parent continues with what it prefetched for it (every child holds the same values)
 				s = next;
+				lk >>= 3;
+				tv = tv_n;
+				ps = pp_n;
 			}
 			if (0 == lane) ctl->dbg[dbg_at + 31] = wall_clock64();
 			return;
