@@ -5,19 +5,34 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W          (N > 1, one rank per GPU)
 
-One *step* = one pass of the hot path over one scan: BASELINE.json configs[1] -- a single synthetic
-64-beam LiDAR scan (131 072 points), 16 cm leaf, 20 m max range, insertPointCloudDiscrete (discrete
-integrator + free-space ray cast) into a GPU-resident linear-hashed octree.  Inputs are resident in
-HBM before the timed region starts.  Steps are issued with async=true, the reference server's default
-(Server.cfg: async True): like the reference, the library overlaps the part of scan i+1 that does not
-read the map with the tree update of scan i; `ms_per_scan_sync_latency` is the non-overlapped time.  At N > 1 every rank integrates its own scan (the 8 sensor
-poses of configs[3]) and the ranks exchange their per-scan update lists over RCCL so that every
-replica of the map applies all N scans in rank order ("scaling": "weak").
+One *step* = one pass of the hot path over one scan: BASELINE.json configs[1] -- a synthetic 64-beam LiDAR scan
+(131 072 points), 16 cm leaf, 20 m max range, insertPointCloudDiscrete (discrete integrator + free-space ray cast)
+into a GPU-resident linear-hashed octree.  The sensor MOVES: step i integrates the scan taken at pose i mod 8 of
+BASELINE configs[3] (3 m apart, seeds 100 + pose), starting from a FRESH map, so that node blocks are created,
+values change, summaries propagate and the predicted ray grid sometimes misses -- what a mapping server sees, not a
+static sensor re-integrating one scan into a saturated map (kept as the extra key `resident_static`).
 
-Prints ONE JSON line on rank 0:  metric/value/unit = integrated rays/s (input points per second,
-whole job), ms_per_step, plus
-  roofline     -- dominant kernel (the ray walk, k_cast + slab merge): algorithmic bytes per launch / HIP-event duration vs 8 TB/s
-  cpu_baseline -- the reference (oracle/_ref) or the oracle port timed on this box's host cores
+Timed region = W warm-up steps into a cleared map, barrier + synchronise, EXACTLY K steps, synchronise + barrier.
+With the driver's K = 20 that is only a few milliseconds, so the region is REPEATED (map cleared, same W + K
+steps) until at least 0.5 s of timed steps have accumulated; `value` is total points / total timed seconds over
+all repetitions (`repeats`, `timed_region_s`; `ms_per_step_median_rep` for the spread).
+
+Legs (all on the same scan sequence; every leg's final map must equal the CPU checker's, see `self_check`):
+  value / ms_per_step    clouds resident in HBM (ufomap_map_insert_device), async=true  -- the headline, as the
+                         task's measurement rule wants it: inputs in HBM when the timed region starts
+  host_pointer           the call the reference's server makes: ufomap_map_insert with a PAGEABLE host cloud
+                         (24 B/point over PCIe inside the timed region; pinned staging, copy overlapped), async=true
+  host_pinned            the same with the cloud in caller-owned pinned memory (DMA straight from it)
+  sync_latency           async=false: one scan at a time, nothing overlapped
+  resident_static        round 1's figure: one scan re-integrated into a saturated map from a static pose
+At N > 1 every rank integrates its own moving sensor (pose (rank + i) mod 8) and the ranks exchange their per-scan
+update lists over RCCL so that every replica of the map applies all N scans in rank order ("scaling": "weak").
+
+Prints ONE JSON line on rank 0: metric/value/unit = integrated rays/s (input points per second, whole job), plus
+  roofline     -- dominant kernel (the ray walk): algorithmic bytes per launch / HIP-event duration vs 8 TB/s,
+                  `dominant_by_time` = the kernel with the largest total time, `traffic` = PMC bytes (profiles/)
+  cpu_baseline -- the reference (oracle/_ref) or the oracle port on this box's host cores, same scan sequence
+Exit code 3 when a leg's map differs from the CPU checker's.
 """
 from __future__ import annotations
 
@@ -35,6 +50,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 RES, MAX_RANGE, DEPTH = 0.16, 20.0, 0
 P_BYTES = 24  # bytes per input point (3 x f64), SURVEY 8(d)
+N_POSES = 8
+MIN_TIMED_S = 0.5
 
 
 def algorithmic_bytes(n_points, hit_codes, miss_codes, steps, levels=16):
@@ -49,33 +66,45 @@ def algorithmic_bytes(n_points, hit_codes, miss_codes, steps, levels=16):
     return sum(terms.values()), terms, sum_ud
 
 
-def cpu_baseline(origin, xyz, budget_s=12.0):
-    """Reference (or port) on the host cores: same scan, same call; fresh map + warm repeats."""
+def make_clouds():
+    from ufomap_amd import scans
+    return [scans.lidar64(origin=scans.lidar_pose(s), seed=100 + s) for s in range(N_POSES)]
+
+
+def cpu_baseline(clouds, seq, budget_s=12.0):
+    """Reference (or port) on the host cores: the same scan sequence into a fresh map, repeated while the budget lasts."""
     from oracle import OracleMap, available, build
     build("port")
     kind = "reference" if available("reference") else "port"
-    m = OracleMap(RES, kind=kind)
-    times = []
+    per_scan, reps = [], 0
     t_start = time.perf_counter()
-    while time.perf_counter() - t_start < budget_s or len(times) < 3:
-        t0 = time.perf_counter()
-        m.insert(origin, xyz, max_range=MAX_RANGE, depth=DEPTH, discrete=True)
-        times.append(time.perf_counter() - t0)
-    warm = float(np.median(times[1:]))
-    return dict(value=xyz.shape[0] / warm, unit="rays/s", cores=2 if kind == "reference" else 1, kind=kind,
-                sample=f"{len(times)} integrations of the same 131072-pt scan into one map on the host "
-                       f"(first/fresh {times[0] * 1e3:.1f} ms, warm median {warm * 1e3:.1f} ms)",
-                ms_per_scan_fresh=times[0] * 1e3, ms_per_scan_warm=warm * 1e3)
+    while reps < 1 or time.perf_counter() - t_start < budget_s:
+        m = OracleMap(RES, kind=kind)
+        for p in seq:
+            origin, xyz, _ = clouds[p]
+            t0 = time.perf_counter()
+            m.insert(origin, xyz, max_range=MAX_RANGE, depth=DEPTH, discrete=True)
+            per_scan.append(time.perf_counter() - t0)
+        reps += 1
+    mean = float(np.mean(per_scan))
+    n = clouds[0][1].shape[0]
+    return dict(value=n / mean, unit="rays/s", cores=2 if kind == "reference" else 1, kind=kind,
+                sample=f"{reps} x the bench's {len(seq)}-scan moving-sensor sequence (131072-pt scans) into a fresh map on the host "
+                       f"(mean {mean * 1e3:.1f} ms/scan, median {float(np.median(per_scan)) * 1e3:.1f}, first {per_scan[0] * 1e3:.1f})",
+                ms_per_scan_mean=mean * 1e3, ms_per_scan_median=float(np.median(per_scan)) * 1e3)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-self-check", action="store_true")
     ap.add_argument("--force-batch", action="store_true", help="run the N>1 code path (scan/exchange/apply) even with one rank")
-    ap.add_argument("--profile-kernels", type=int, default=1, help="bracket every kernel with HIP events in the timed region")
+    ap.add_argument("--profile-kernels", type=int, default=1, help="extra leg with every kernel bracketed by HIP events (roofline)")
+    ap.add_argument("--min-timed-s", type=float, default=MIN_TIMED_S)
+    ap.add_argument("--only-headline", action="store_true", help="skip the extra legs (profiling runs)")
     args = ap.parse_args()
 
     import torch
@@ -89,6 +118,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
     batch_mode = world > 1 or args.force_batch
     # RCCL prints a version banner on stdout: keep stdout clean for the ONE JSON line (banner -> stderr)
     saved_stdout = os.dup(1)
@@ -98,137 +128,228 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group(backend="nccl", device_id=dev)
 
-    from ufomap_amd import OccupancyMap, scans
+    from ufomap_amd import OccupancyMap, PointCloud
 
-    # this rank's scan: pose/seed of BASELINE configs[1] at N=1, the batch poses of configs[3] at N>1
-    if world == 1:
-        origin, xyz, _ = scans.lidar64()
-    else:
-        origin, xyz, _ = scans.lidar64(origin=scans.lidar_pose(rank % 8), seed=100 + rank % 8)
-    n_pts = xyz.shape[0]
-    d_xyz = torch.from_numpy(xyz).to(torch.device("cuda", local_rank))  # resident in HBM before timing
-    m = OccupancyMap(RES, device=local_rank)
+    K, W = args.steps, args.warmup
+    clouds = make_clouds()
+    n_pts = clouds[0][1].shape[0]
+    d_clouds = [torch.from_numpy(c[1]).to(dev) for c in clouds]  # resident in HBM before any timed region
+    pose_of = lambda i, r=rank: (r + i) % N_POSES  # noqa: E731  (step i of rank r)
+    seq = [pose_of(i) for i in range(W + K)]
 
-    if batch_mode:
-        from ufomap_amd import dist as udist
-        batch = udist.BatchIntegrator(m, dist.group.WORLD, torch.device("cuda", local_rank))
-
-        def step():
-            batch.integrate(origin, d_xyz.data_ptr(), n_pts, MAX_RANGE, DEPTH, discrete=True)
-    else:
-        def step():
-            m.insert_device(origin, d_xyz.data_ptr(), None, n_pts, MAX_RANGE, DEPTH, discrete=True, async_=True)
-
-    def sync():
-        m.insertPointCloudWait()
+    def barrier():
         torch.cuda.synchronize()
         if batch_mode:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        step()
-    sync()
-    # timed region: EXACTLY K steps, barrier + synchronize on both sides
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync()
-    dt = time.perf_counter() - t0
-    # the same K steps again with every kernel launch bracketed by HIP events on the map's own stream
-    # (roofline leg). The events cost ~1/3 of the step time on this launch-dense path, so they are kept
-    # out of `value`; `ms_per_step_with_events` reports the perturbed figure.
-    ktimes, dt_ev = {}, None
-    if args.profile_kernels:
+    def run_leg(m, step_fn, min_timed_s, prepare=None, max_reps=4000):
+        """W warm-up + exactly K timed steps from a cleared map, repeated until min_timed_s of timed steps."""
+        dts = []
+        while True:
+            m.insertPointCloudWait()
+            m.clear()
+            if prepare:
+                prepare()
+            for i in range(W):
+                step_fn(i)
+            m.insertPointCloudWait()
+            barrier()
+            t0 = time.perf_counter()
+            for i in range(W, W + K):
+                step_fn(i)
+            m.insertPointCloudWait()
+            barrier()
+            dt = time.perf_counter() - t0
+            if batch_mode:
+                tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dt = float(tt.item())
+            dts.append(dt)
+            done = sum(dts) >= min_timed_s or len(dts) >= max_reps
+            if batch_mode:  # every rank takes the same decision
+                flag = torch.tensor([1 if done else 0], dtype=torch.int32, device=dev)
+                dist.broadcast(flag, 0)
+                done = bool(flag.item())
+            if done:
+                return dts
+
+    def leg_summary(dts, scans_per_step=1):
+        tot = float(sum(dts))
+        return dict(rays_per_s=n_pts * scans_per_step * K * len(dts) / tot, ms_per_step=tot / (K * len(dts)) * 1e3,
+                    ms_per_step_median_rep=float(np.median(dts)) / K * 1e3, repeats=len(dts), timed_region_s=tot)
+
+    m = OccupancyMap(RES, device=local_rank)
+    if batch_mode:
+        from ufomap_amd import dist as udist
+        batch = udist.BatchIntegrator(m, dist.group.WORLD, dev)
+
+        def step_resident(i):
+            p = pose_of(i)
+            batch.integrate(clouds[p][0], d_clouds[p].data_ptr(), n_pts, MAX_RANGE, DEPTH, discrete=True)
+    else:
+        def step_resident(i):
+            p = pose_of(i)
+            m.insert_device(clouds[p][0], d_clouds[p].data_ptr(), None, n_pts, MAX_RANGE, DEPTH, discrete=True, async_=True)
+
+    # ---- headline leg -----------------------------------------------------------------------------------------
+    dts = run_leg(m, step_resident, args.min_timed_s)
+    head = leg_summary(dts, world)
+    digests = {"resident": m.digest()}
+    final_dump = (m.leaves(True), m.inner()) if rank == 0 else None
+
+    extra = {}
+    ktimes = {}
+    if not batch_mode and not args.only_headline:
+        # ---- the call the reference's server makes: host pointer in, H2D inside the timed region ----------------
+        host_clouds = [PointCloud(c[1].copy()) for c in clouds]  # pageable
+
+        def step_host(i):
+            p = pose_of(i)
+            m.insertPointCloudDiscrete(clouds[p][0], host_clouds[p], MAX_RANGE, DEPTH, False, 0, True)
+        extra["host_pointer"] = dict(leg_summary(run_leg(m, step_host, args.min_timed_s)),
+                                     note="ufomap_map_insert, pageable 24 B/point cloud: host memcpy into pinned staging + async H2D inside the timed region; async=true")
+        digests["host_pointer"] = m.digest()
+        pinned = [torch.from_numpy(c[1].copy()).pin_memory() for c in clouds]
+        pinned_clouds = [PointCloud(t.numpy()) for t in pinned]
+
+        def step_pinned(i):
+            p = pose_of(i)
+            m.insertPointCloudDiscrete(clouds[p][0], pinned_clouds[p], MAX_RANGE, DEPTH, False, 0, True)
+        extra["host_pinned"] = dict(leg_summary(run_leg(m, step_pinned, args.min_timed_s)),
+                                    note="ufomap_map_insert, cloud in caller-owned pinned memory: DMA straight from it, the call returns when the copy is done")
+        digests["host_pinned"] = m.digest()
+
+        def step_sync(i):
+            p = pose_of(i)
+            m.insert_device(clouds[p][0], d_clouds[p].data_ptr(), None, n_pts, MAX_RANGE, DEPTH, discrete=True, async_=False)
+        extra["sync_latency"] = dict(leg_summary(run_leg(m, step_sync, min(args.min_timed_s, 0.25))), note="async=false, HBM-resident clouds")
+        digests["sync"] = m.digest()
+
+        # ---- round 1's figure: one scan re-integrated from a static pose into a saturated map -------------------
+        ms = OccupancyMap(RES, device=local_rank)
+        d0, o0 = d_clouds[0], clouds[0][0]
+        for _ in range(max(W, 12)):
+            ms.insert_device(o0, d0.data_ptr(), None, n_pts, MAX_RANGE, DEPTH, discrete=True, async_=True)
+        ms.insertPointCloudWait()
+        torch.cuda.synchronize()
+        reps_s = max(K, int(0.25 / 1.5e-4))
+        t0 = time.perf_counter()
+        for _ in range(reps_s):
+            ms.insert_device(o0, d0.data_ptr(), None, n_pts, MAX_RANGE, DEPTH, discrete=True, async_=True)
+        ms.insertPointCloudWait()
+        torch.cuda.synchronize()
+        dt_s = time.perf_counter() - t0
+        extra["resident_static"] = dict(rays_per_s=n_pts * reps_s / dt_s, ms_per_step=dt_s / reps_s * 1e3, steps=reps_s,
+                                        note="steady-state best case: same scan, static pose, saturated map (round 1's headline conditions)")
+        del ms
+
+    # ---- per-kernel HIP events (roofline leg): sync calls so that a kernel's events do not straddle overlapped work --
+    dt_ev = None
+    if args.profile_kernels and not batch_mode:
         m.reset_kernel_times()
         m.set_profiling(True)
-        sync()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        sync()
-        dt_ev = time.perf_counter() - t1
+        dt_ev = run_leg(m, step_resident, 0.0, max_reps=3)
         m.set_profiling(False)
         ktimes = m.kernel_times()
+        n_prof_steps = (W + K) * len(dt_ev)
+        digests["events"] = m.digest()
 
-    # single-scan latency (sync call: no overlap with a following scan), N = 1 only
-    lat_ms = None
-    if not batch_mode:
-        sync()
-        t2 = time.perf_counter()
-        for _ in range(min(args.steps, 50)):
-            m.insert_device(origin, d_xyz.data_ptr(), None, n_pts, MAX_RANGE, DEPTH, discrete=True, async_=False)
-        torch.cuda.synchronize()
-        lat_ms = (time.perf_counter() - t2) / min(args.steps, 50) * 1e3
+    # ---- counts of the exact inputs (per pose, fresh map): algorithmic bytes, rays cast, DDA steps -------------------
+    counts, alg = [], []
+    if rank == 0:
+        mc = OccupancyMap(RES, device=local_rank)
+        for p in sorted(set(seq[W:])):
+            mc.clear()
+            mc.insert_device(clouds[p][0], d_clouds[p].data_ptr(), None, n_pts, MAX_RANGE, DEPTH, discrete=True)
+            c = mc.last_counts()
+            hits, misses = mc.last_hits(), mc.last_misses()
+            b, terms, sum_ud = algorithmic_bytes(n_pts, hits, misses, c["steps"])
+            counts.append(dict(pose=p, rays=c["rays"], steps=c["steps"], hits=len(hits), miss_cells=len(misses), sum_U_d=sum_ud))
+            alg.append((b, terms))
+        del mc
 
-    if batch_mode:
-        tt = torch.tensor([dt], dtype=torch.float64, device=torch.device("cuda", local_rank))
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    # ---- self-check: every leg ends on the map the CPU checker builds from the same W + K scans ----------------------
+    self_check = None
+    if rank == 0 and not args.no_self_check:
+        from oracle import OracleMap, available, build
+        build("port")
+        kind = "reference" if available("reference") else "port"
+        t0 = time.perf_counter()
+        o = OracleMap(RES, kind=kind)
+        n_scans = 0
+        for i in range(W + K):
+            for r in range(world):
+                origin, xyz, _ = clouds[pose_of(i, r)]
+                o.insert(origin, xyz, max_range=MAX_RANGE, depth=DEPTH, discrete=True)
+                n_scans += 1
+        ol, oi = o.leaves(True), o.inner()
+        same = all(np.array_equal(a, b) for a, b in zip(final_dump[0], ol)) and all(np.array_equal(a, b) for a, b in zip(final_dump[1], oi))
+        legs_equal = len(set(digests.values())) == 1
+        self_check = dict(checker=kind, scans=n_scans, leaves=int(len(ol[0])), inner=int(len(oi[0])), map_equals_checker=bool(same),
+                          legs_agree=bool(legs_equal), legs=sorted(digests), seconds=round(time.perf_counter() - t0, 1))
 
     if rank == 0:
-        # counts of the exact input (from the last integration) for the algorithmic-byte formula
-        if not batch_mode:
-            counts = m.last_counts()
-            hits, misses = m.last_hits(), m.last_misses()
-        else:
-            m2 = OccupancyMap(RES, device=local_rank)
-            m2.insert_device(origin, d_xyz.data_ptr(), None, n_pts, MAX_RANGE, DEPTH, discrete=True)
-            counts = m2.last_counts()
-            hits, misses = m2.last_hits(), m2.last_misses()
-        b_scan, terms, sum_ud = algorithmic_bytes(n_pts, hits, misses, counts["steps"])
-        ms_per_step = dt / args.steps * 1e3
-        value = n_pts * world * args.steps / dt
-        # dominant kernel = largest total time among the hot-path kernels
+        value = head["rays_per_s"]
+        mean_rays = float(np.mean([c["rays"] for c in counts]))
+        mean_steps = float(np.mean([c["steps"] for c in counts]))
+        b_scan = float(np.mean([a[0] for a in alg]))
+        terms = {k: float(np.mean([a[1][k] for a in alg])) for k in alg[0][1]}
         roof = None
         kern_ms = {k: (v["total_ms"] / max(v["launches"], 1)) for k, v in ktimes.items() if v["launches"]}
-        per_step_ms = {k: v["total_ms"] / args.steps for k, v in ktimes.items() if v["launches"]}
+        per_step_ms = {k: v["total_ms"] / n_prof_steps for k, v in ktimes.items() if v["launches"]} if ktimes else {}
         if kern_ms:
-            # The dominant kernel is the ray walk: it carries 16*S of B_scan (82 %). It is one launch (k_cast:
-            # set-up + segment queue + walk) plus the slab merge for LiDAR-sized scans, or set-up + walk + merge
-            # for the other grid sizes; the durations of whatever ran add up.
-            walkers = ("k_cast", "k_walk", "k_dda_seg", "k_dda")  # whichever variant the grid size selects
+            # The dominant kernel by algorithmic bytes is the ray walk: it carries the 16*S term of B_scan (82 %). It is
+            # one launch (k_cast: set-up + segment queue + walk) plus the slab merge for LiDAR-sized scans, or
+            # set-up + walk + merge for the other grid sizes; the durations of whatever ran add up.
+            walkers = ("k_cast", "k_walk", "k_dda_seg", "k_dda")
             group = [k for k in ("k_ray_setup",) + walkers + ("k_merge_slabs",) if k in kern_ms]
             dom = next(k for k in walkers if k in kern_ms)
-            # k_dda fuses key emission and de-duplication: its share of B_scan is the ray list plus the
-            # 16*S key term
-            share = P_BYTES * counts["rays"] + 16 * counts["steps"]
+            share = P_BYTES * mean_rays + 16 * mean_steps
             dur_s = sum(per_step_ms[k] for k in group) * 1e-3
             achieved = share / dur_s / 1e9
-            traffic = None
+            traffic, traffic_src = None, None
             pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
             if os.path.exists(pmc):
                 try:
                     pj = json.load(open(pmc))
-                    # keys are rocprofv3 kernel names (template arguments included): match by prefix
-                    vals = [next((v.get("hbm_bytes_per_launch") for kk, v in pj.items() if kk == k or kk.startswith(k + "<")), None)
-                            for k in group]
+                    vals = [next((v.get("hbm_bytes_per_launch") for kk, v in pj.items() if kk == k or kk.startswith(k + "<")), None) for k in group]
                     traffic = sum(v for v in vals if v) if any(vals) else None
+                    traffic_src = "profiles/pmc_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this round, scripts/profile_gpu.sh)"
                 except Exception:
                     traffic = None
+            by_time = max(per_step_ms, key=per_step_ms.get)
             roof = dict(bound="hbm", kernel="+".join(group), achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
-                        traffic=traffic, algorithmic_bytes_per_launch=share, avg_launch_us=dur_s * 1e6,
+                        traffic=traffic, traffic_source=traffic_src, algorithmic_bytes_per_launch=share, avg_launch_us=dur_s * 1e6,
                         walk_kernel_only=dict(avg_launch_us=kern_ms[dom] * 1e3, achieved_GBs=share / (kern_ms[dom] * 1e-3) / 1e9,
                                               frac=share / (kern_ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS),
-                        whole_scan=dict(algorithmic_bytes=b_scan, terms=terms, achieved_GBs=b_scan / (ms_per_step * 1e-3) / 1e9,
-                                        frac=b_scan / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS),
-                        kernels_us_per_step={k: round(v * 1e3, 2) for k, v in sorted(per_step_ms.items(), key=lambda kv: -kv[1])})
+                        dominant_by_time=dict(kernel=by_time, us_per_step=per_step_ms[by_time] * 1e3, avg_launch_us=kern_ms[by_time] * 1e3),
+                        whole_scan=dict(algorithmic_bytes=b_scan, terms=terms, achieved_GBs=b_scan / (head["ms_per_step"] * 1e-3) / 1e9,
+                                        frac=b_scan / (head["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS),
+                        kernels_us_per_step={k: round(v * 1e3, 2) for k, v in sorted(per_step_ms.items(), key=lambda kv: -kv[1])},
+                        launches_per_step=round(sum(v["launches"] for v in ktimes.values()) / n_prof_steps, 2))
         out = {
             "metric": "integrated rays/sec (input points per second, insertPointCloudDiscrete, 16 cm leaf, 20 m max-range)",
-            "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "ms_per_scan_sync_latency": lat_ms, "ms_per_step_with_events": (dt_ev / args.steps * 1e3) if dt_ev else None,
+            "value": value, "unit": "rays/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": head["ms_per_step"], "ms_per_step_median_rep": head["ms_per_step_median_rep"],
+            "repeats": head["repeats"], "timed_region_s": head["timed_region_s"],
+            "rays_cast_per_s": value / n_pts * mean_rays, "dda_steps_per_s": value / n_pts * mean_steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64 ray casting / u64 Morton keys / f32 log-odds", "data": "synthetic",
-            "config": {"workload": "configs[1]: single synthetic 64-beam LiDAR scan, 131072 pts, 16 cm leaf, 20 m max-range, discrete integrator + free-space raycast, warm map"
-                       if not batch_mode else "configs[3]: batch of N concurrent 131072-pt LiDAR scans, 16 cm leaf, one scan per GPU, RCCL exchange of update lists, every replica applies all N in order",
-                       "points_per_scan": n_pts, "rays_cast": counts["rays"], "dda_steps": counts["steps"], "unique_hits": int(len(hits)),
-                       "unique_miss_cells": int(len(misses)), "sum_U_d": sum_ud, "leaf_m": RES, "max_range_m": MAX_RANGE,
-                       "depth_levels": 16, "parallelism": f"scan-per-gpu x{world}"},
-            "roofline": roof,
+            "config": {"workload": ("configs[1]: synthetic 64-beam LiDAR scans, 131072 pts each, 16 cm leaf, 20 m max-range, discrete integrator + "
+                                    "free-space raycast; moving sensor (pose i mod 8 of configs[3], 3 m apart), fresh map per repetition, clouds resident in HBM, async=true")
+                       if not batch_mode else
+                       "configs[3]: batch of N concurrent 131072-pt LiDAR scans per step (moving sensors), 16 cm leaf, one scan per GPU, RCCL exchange of update lists, every replica applies all N in order",
+                       "points_per_scan": n_pts, "rays_cast_mean": mean_rays, "dda_steps_mean": mean_steps, "per_pose": counts,
+                       "leaf_m": RES, "max_range_m": MAX_RANGE, "depth_levels": 16, "parallelism": f"scan-per-gpu x{world}"},
+            "roofline": roof, "self_check": self_check,
         }
+        out.update(extra)
+        if dt_ev:
+            out["ms_per_step_with_events"] = float(sum(dt_ev)) / (K * len(dt_ev)) * 1e3
         if not batch_mode and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(origin, xyz)
+            out["cpu_baseline"] = cpu_baseline(clouds, seq)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
         else:
             out["cpu_baseline"] = None
@@ -240,9 +361,13 @@ def main():
             pass
         os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)
+    bad = bool(self_check) and not (self_check["map_equals_checker"] and self_check["legs_agree"])
     if batch_mode:
         dist.barrier()
         dist.destroy_process_group()
+    if bad:
+        sys.stderr.write("bench.py: SELF-CHECK FAILED -- a leg's final map differs from the CPU checker's\n")
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

@@ -1,77 +1,342 @@
-// occupancy_map.hpp -- C++ host-side mirror of the reference's map API for the integration path.
+// occupancy_map.hpp -- C++ host-side mirror of the reference's map API for the integration path and its callers.
 //
-// Same namespace, class names, member signatures, defaults and error behaviour as the reference
-// (UnknownFreeOccupied/ufomap v1, paths relative to ufomap/include/ufo/):
-//   ufo::map::OccupancyMap / OccupancyMapColor            map/occupancy_map.h:55-85, map/occupancy_map_color.h:56-98
-//   insertPointCloud(origin, cloud, max_range=-1, depth=0, simple_ray_casting=false,
-//                    early_stopping=0, async=false)        map/occupancy_map_base.h:270-273
-//   insertPointCloudDiscrete(...same tail...)              map/occupancy_map_base.h:340-344, map/occupancy_map_color.h:177-181
-//   insertPointCloudDone() / insertPointCloudWait()        map/occupancy_map_base.h:430-443
-//   sensor-model setters                                   map/occupancy_map_base.h:746-773
-//   minChange()/maxChange()/resetMinMaxChangeDetection()   map/occupancy_map_base.h:793-822
-//   std::invalid_argument for depth_levels outside [2,21]  map/octree.h:931-935
-// Everything forwards to the C ABI of include/ufomap_hip.h; the tree lives in HBM (linear-hashed octree),
-// there is no CPU fallback. Header-only; link with ufomap_amd/csrc/libufomap_hip.so.
+// Same namespaces, class names, member signatures, defaults and error behaviour as the reference
+// (UnknownFreeOccupied/ufomap v1, paths relative to ufomap/include/ufo/), so that the translation unit of the
+// reference's caller -- ufomap_ros/ufomap_mapping/src/server.cpp -- compiles against this header with the map calls
+// unchanged (tests/cpp/server_calls.cpp reproduces those calls line by line and is compiled by the test-suite):
+//   ufo::math::Vector3 / Quaternion / Pose6                math/vector3.h:52-328, math/quaternion.h, math/pose6.h:55-140
+//   ufo::geometry::AABB / BoundingVar / BoundingVolume     geometry/aabb.h:50-72, geometry/bounding_volume.h:50-120
+//   ufo::map::Point3 = math::Vector3, Point3Color, Color   map/types.h:56-102, map/color.h:56-86
+//   ufo::map::PointCloud / PointCloudColor (+ transform)   map/point_cloud.h:62-281
+//   ufo::map::OccupancyMap / OccupancyMapColor             map/occupancy_map.h:55-85, map/occupancy_map_color.h:56-98
+//     insertPointCloud / insertPointCloudDiscrete (+ the Pose6 overloads)   map/occupancy_map_base.h:270-428
+//     insertPointCloudDone / insertPointCloudWait                          map/occupancy_map_base.h:430-443
+//     setValueVolume, point queries, sensor-model getters and setters      map/occupancy_map_base.h:492-518, 599-773
+//     change detection: code set and min/max AABB                          map/occupancy_map_base.h:779-822
+//     beginLeaves / beginTree (AABB + state filter)                        map/occupancy_map_base.h:93-165, iterator/*.h
+//     read / readData / write / writeData, clear, getters                  map/octree.h:541-917
+//   std::invalid_argument for depth_levels outside [2,21]                  map/octree.h:931-935
+// Everything forwards to the C ABI of include/ufomap_hip.h; the tree lives in HBM (linear-hashed octree), there is
+// no CPU fallback. Header-only; link with ufomap_amd/csrc/libufomap_hip.so.
 //
-// What is NOT mirrored (out of the hot path's scope): iterators, point queries, castRay,
-// setValueVolume, read/write, Pose6 overloads (transform the cloud on the host first, as
-// occupancy_map_base.h:329-338 does).
+// Differences a caller can see: bounding volumes other than AABB (frustum, OBB, sphere, ...) are not accepted by the
+// device path (std::variant<AABB> only); iterators walk a snapshot taken by begin*() (the reference's iterators
+// alias the live tree); nearest-neighbour iterators and castRay (which does not compile in the reference) are absent.
 #pragma once
 
+#include <algorithm>
 #include <array>
 #include <cmath>
 #include <cstdint>
-#include <utility>
+#include <cstring>
+#include <fstream>
+#include <istream>
+#include <iterator>
+#include <memory>
+#include <ostream>
+#include <sstream>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
+#include <utility>
+#include <variant>
 #include <vector>
 
 #include "../ufomap_hip.h"
 
+namespace ufo::math
+{
+// math/vector3.h:52-328 -- three doubles with the reference's accessors and (component-wise) arithmetic
+class Vector3
+{
+ public:
+	Vector3() : data_{0.0, 0.0, 0.0} {}
+	Vector3(double x, double y, double z) : data_{x, y, z} {}
+	double& operator()(size_t i) { return data_[i]; }
+	double const& operator()(size_t i) const { return data_[i]; }
+	double& operator[](size_t i) { return data_[i]; }
+	double const& operator[](size_t i) const { return data_[i]; }
+	double& x() { return data_[0]; }
+	double const& x() const { return data_[0]; }
+	double& y() { return data_[1]; }
+	double const& y() const { return data_[1]; }
+	double& z() { return data_[2]; }
+	double const& z() const { return data_[2]; }
+	double& roll() { return data_[0]; }
+	double const& roll() const { return data_[0]; }
+	double& pitch() { return data_[1]; }
+	double const& pitch() const { return data_[1]; }
+	double& yaw() { return data_[2]; }
+	double const& yaw() const { return data_[2]; }
+	Vector3 operator-() const { return Vector3(-data_[0], -data_[1], -data_[2]); }
+	Vector3 operator-(Vector3 const& o) const { return Vector3(data_[0] - o[0], data_[1] - o[1], data_[2] - o[2]); }
+	Vector3 operator+(Vector3 const& o) const { return Vector3(data_[0] + o[0], data_[1] + o[1], data_[2] + o[2]); }
+	Vector3 operator*(Vector3 const& o) const { return Vector3(data_[0] * o[0], data_[1] * o[1], data_[2] * o[2]); }
+	Vector3 operator/(Vector3 const& o) const { return Vector3(data_[0] / o[0], data_[1] / o[1], data_[2] / o[2]); }
+	Vector3 operator-(double v) const { return Vector3(data_[0] - v, data_[1] - v, data_[2] - v); }
+	Vector3 operator+(double v) const { return Vector3(data_[0] + v, data_[1] + v, data_[2] + v); }
+	Vector3 operator*(double v) const { return Vector3(data_[0] * v, data_[1] * v, data_[2] * v); }
+	Vector3 operator/(double v) const { return Vector3(data_[0] / v, data_[1] / v, data_[2] / v); }
+	void operator-=(Vector3 const& o) { *this = *this - o; }
+	void operator+=(Vector3 const& o) { *this = *this + o; }
+	void operator*=(Vector3 const& o) { *this = *this * o; }
+	void operator/=(Vector3 const& o) { *this = *this / o; }
+	void operator-=(double v) { *this = *this - v; }
+	void operator+=(double v) { *this = *this + v; }
+	void operator*=(double v) { *this = *this * v; }
+	void operator/=(double v) { *this = *this / v; }
+	bool operator==(Vector3 const& o) const { return data_[0] == o[0] && data_[1] == o[1] && data_[2] == o[2]; }
+	bool operator!=(Vector3 const& o) const { return !(*this == o); }
+	double dot(Vector3 const& o) const { return (data_[0] * o[0]) + (data_[1] * o[1]) + (data_[2] * o[2]); }
+	Vector3 cross(Vector3 const& o) const
+	{
+		return Vector3((data_[1] * o[2]) - (data_[2] * o[1]), (data_[2] * o[0]) - (data_[0] * o[2]), (data_[0] * o[1]) - (data_[1] * o[0]));
+	}
+	double squaredNorm() const { return (data_[0] * data_[0]) + (data_[1] * data_[1]) + (data_[2] * data_[2]); }
+	double norm() const { return std::sqrt(squaredNorm()); }
+	Vector3& normalize()
+	{
+		*this /= norm();
+		return *this;
+	}
+	Vector3 normalized() const
+	{
+		Vector3 t(*this);
+		return t.normalize();
+	}
+	double distance(Vector3 const& o) const { return (*this - o).norm(); }
+	size_t size() const { return 3; }
+	double min() const { return std::min(std::min(data_[0], data_[1]), data_[2]); }
+	double max() const { return std::max(std::max(data_[0], data_[1]), data_[2]); }
+	size_t minElementIndex() const { return data_[0] <= data_[1] ? (data_[0] <= data_[2] ? 0 : 2) : (data_[1] <= data_[2] ? 1 : 2); }
+	size_t maxElementIndex() const { return data_[0] >= data_[1] ? (data_[0] >= data_[2] ? 0 : 2) : (data_[1] >= data_[2] ? 1 : 2); }
+	double const* data() const { return data_.data(); }
+
+ private:
+	std::array<double, 3> data_;
+};
+
+// math/quaternion.h: w, x, y, z; operator* and rotate keep the reference's operation order (253-286)
+class Quaternion
+{
+ public:
+	Quaternion() : data_{1, 0, 0, 0} {}
+	Quaternion(double w, double x, double y, double z) : data_{w, x, y, z} {}
+	Quaternion(double roll, double pitch, double yaw)
+	{
+		// quaternion.h:69-93: Euler angles -> rotation matrix -> quaternion
+		double const sr = std::sin(roll), sp = std::sin(pitch), sy = std::sin(yaw), cr = std::cos(roll), cp = std::cos(pitch), cy = std::cos(yaw);
+		double const m00 = cy * cp, m11 = sy * sp * sr + cy * cr, m22 = cp * cr;
+		double const m01 = cy * sp * sr - sy * cr, m02 = cy * sp * cr + sy * sr, m10 = sy * cp, m12 = sy * sp * cr - cy * sr, m20 = -sp, m21 = cp * sr;
+		double const w_ = std::sqrt(std::max(0.0, 1 + m00 + m11 + m22)) / 2.0, x_ = std::sqrt(std::max(0.0, 1 + m00 - m11 - m22)) / 2.0;
+		double const y_ = std::sqrt(std::max(0.0, 1 - m00 + m11 - m22)) / 2.0, z_ = std::sqrt(std::max(0.0, 1 - m00 - m11 + m22)) / 2.0;
+		data_ = {w_, (m21 - m12) >= 0 ? std::fabs(x_) : -std::fabs(x_), (m02 - m20) >= 0 ? std::fabs(y_) : -std::fabs(y_),
+		         (m10 - m01) >= 0 ? std::fabs(z_) : -std::fabs(z_)};
+	}
+	double const& w() const { return data_[0]; }
+	double& w() { return data_[0]; }
+	double const& x() const { return data_[1]; }
+	double& x() { return data_[1]; }
+	double const& y() const { return data_[2]; }
+	double& y() { return data_[2]; }
+	double const& z() const { return data_[3]; }
+	double& z() { return data_[3]; }
+	Quaternion operator*(Quaternion const& r) const
+	{
+		return Quaternion(w() * r.w() - x() * r.x() - y() * r.y() - z() * r.z(), y() * r.z() - r.y() * z() + w() * r.x() + r.w() * x(),
+		                  z() * r.x() - r.z() * x() + w() * r.y() + r.w() * y(), x() * r.y() - r.x() * y() + w() * r.z() + r.w() * z());
+	}
+	Quaternion operator*(Vector3 const& v) const { return *this * Quaternion(0, v(0), v(1), v(2)); }
+	Quaternion inversed() const { return Quaternion(w(), -x(), -y(), -z()); }
+	double norm() const { return std::sqrt(w() * w() + x() * x() + y() * y() + z() * z()); }
+	Quaternion normalized() const
+	{
+		double const n = norm();
+		return n > 0 ? Quaternion(w() / n, x() / n, y() / n, z() / n) : *this;
+	}
+	template <typename T, typename = std::enable_if_t<std::is_base_of_v<Vector3, T>>>
+	T rotate(T const& v) const
+	{
+		T out = v;
+		Quaternion const q = *this * v * this->inversed();
+		out.x() = q.x();
+		out.y() = q.y();
+		out.z() = q.z();
+		return out;
+	}
+	bool operator==(Quaternion const& o) const { return data_ == o.data_; }
+	bool operator!=(Quaternion const& o) const { return data_ != o.data_; }
+	double const* data() const { return data_.data(); }
+
+ private:
+	std::array<double, 4> data_;
+};
+
+// math/pose6.h:55-140
+class Pose6
+{
+ public:
+	Pose6() {}
+	Pose6(Vector3 const& translation, Quaternion const& rotation) : translation_(translation), rotation_(rotation) {}
+	Pose6(double x, double y, double z, double roll, double pitch, double yaw) : translation_(x, y, z), rotation_(roll, pitch, yaw) {}
+	Pose6(double tx, double ty, double tz, double rw, double rx, double ry, double rz) : translation_(tx, ty, tz), rotation_(rw, rx, ry, rz) {}
+	Vector3& translation() { return translation_; }
+	Vector3 translation() const { return translation_; }
+	Quaternion& rotation() { return rotation_; }
+	Quaternion rotation() const { return rotation_; }
+	double x() const { return translation_[0]; }
+	double y() const { return translation_[1]; }
+	double z() const { return translation_[2]; }
+	template <typename T, typename = std::enable_if_t<std::is_base_of_v<Vector3, T>>>
+	T transform(T const& v) const
+	{
+		T out = v;
+		Vector3 const r = rotation_.rotate(v);  // q v q^-1 ...
+		out.x() = r.x();
+		out.y() = r.y();
+		out.z() = r.z();
+		out += translation_;  // ... then + t (pose6.h:114-125)
+		return out;
+	}
+	Pose6 inversed() const
+	{
+		Pose6 r(*this);
+		r.rotation_ = r.rotation_.inversed().normalized();
+		r.translation_ = r.rotation_.rotate(-translation_);
+		return r;
+	}
+
+ private:
+	Vector3 translation_;
+	Quaternion rotation_;
+};
+}  // namespace ufo::math
+
+namespace ufo::geometry
+{
+using Point = ufo::math::Vector3;
+
+// geometry/aabb.h:50-72
+struct AABB {
+	Point center;
+	Point half_size;
+	AABB() {}
+	AABB(Point const& center_, double half) : center(center_), half_size(half, half, half) {}
+	AABB(Point const& min, Point const& max) : half_size((max - min) / 2.0) { center = min + half_size; }
+	Point getMin() const { return center - half_size; }
+	Point getMax() const { return center + half_size; }
+};
+
+// geometry/bounding_volume.h: the reference's variant also holds Frustum, LineSegment, OBB, Plane, Point, Ray and
+// Sphere; the device path evaluates AABBs (what the server builds: server.cpp:152, 184).
+using BoundingVar = std::variant<AABB>;
+class BoundingVolume
+{
+ public:
+	void add(BoundingVar const& bv) { bounding_volume_.push_back(bv); }
+	size_t size() const { return bounding_volume_.size(); }
+	bool empty() const { return bounding_volume_.empty(); }
+	std::vector<BoundingVar>::iterator begin() { return bounding_volume_.begin(); }
+	std::vector<BoundingVar>::const_iterator begin() const { return bounding_volume_.begin(); }
+	std::vector<BoundingVar>::iterator end() { return bounding_volume_.end(); }
+	std::vector<BoundingVar>::const_iterator end() const { return bounding_volume_.end(); }
+
+ private:
+	std::vector<BoundingVar> bounding_volume_;
+};
+}  // namespace ufo::geometry
+
 namespace ufo::map
 {
+using KeyType = unsigned int;    // map/types.h:55
 using DepthType = unsigned int;  // map/types.h:56
-
-struct Point3 {  // math/vector3.h: three doubles
-	double x = 0, y = 0, z = 0;
-	Point3() = default;
-	Point3(double x_, double y_, double z_) : x(x_), y(y_), z(z_) {}
-};
+using CodeType = uint64_t;       // map/code.h
+using Point3 = ufo::math::Vector3;  // map/types.h:58
 
 struct Color {  // map/color.h:56-86
 	uint8_t r = 0, g = 0, b = 0;
 	Color() = default;
 	Color(uint8_t r_, uint8_t g_, uint8_t b_) : r(r_), g(g_), b(b_) {}
 	bool isSet() const { return 0 != r || 0 != g || 0 != b; }
+	bool operator==(Color const& o) const { return r == o.r && g == o.g && b == o.b; }
+	bool operator!=(Color const& o) const { return !(*this == o); }
 };
 
-struct Point3Color : Point3 {  // map/types.h:60-102
-	Color color;
-	Point3Color() = default;
-	Point3Color(double x_, double y_, double z_, uint8_t r = 0, uint8_t g = 0, uint8_t b = 0) : Point3(x_, y_, z_), color(r, g, b) {}
-	Color const& getColor() const { return color; }
+class Point3Color : public Point3  // map/types.h:60-102
+{
+ public:
+	Point3Color() {}
+	Point3Color(Point3 const& point, Color const& color) : Point3(point), color_(color) {}
+	Point3Color(double x, double y, double z, uint8_t r, uint8_t g, uint8_t b) : Point3(x, y, z), color_(r, g, b) {}
+	Point3Color(Point3 const& point) : Point3(point) {}
+	Point3Color(double x, double y, double z) : Point3(x, y, z) {}
+	Color const& getColor() const { return color_; }
+	Color& getColor() { return color_; }
+	void setColor(Color const& c) { color_ = c; }
+	void setColor(uint8_t r, uint8_t g, uint8_t b) { color_ = Color(r, g, b); }
+
+ protected:
+	Color color_;
 };
 
-// map/point_cloud.h:62-281 -- std::vector wrapper
+// map/point_cloud.h:62-281 -- std::vector wrapper; transform applies Pose6::transform to every point (157-166)
 template <typename T>
 class PointCloudT
 {
  public:
+	using value_type = T;
+	PointCloudT() {}
 	void push_back(T const& p) { cloud_.push_back(p); }
 	void reserve(size_t n) { cloud_.reserve(n); }
+	void resize(size_t n) { cloud_.resize(n); }
 	size_t size() const { return cloud_.size(); }
 	bool empty() const { return cloud_.empty(); }
 	T const& operator[](size_t i) const { return cloud_[i]; }
 	T& operator[](size_t i) { return cloud_[i]; }
-	auto begin() const { return cloud_.begin(); }
-	auto end() const { return cloud_.end(); }
+	typename std::vector<T>::iterator begin() { return cloud_.begin(); }
+	typename std::vector<T>::iterator end() { return cloud_.end(); }
+	typename std::vector<T>::const_iterator begin() const { return cloud_.begin(); }
+	typename std::vector<T>::const_iterator end() const { return cloud_.end(); }
 	void clear() { cloud_.clear(); }
+	void transform(ufo::math::Pose6 const& pose, bool /*parallel*/ = false)
+	{
+		for (T& p : cloud_) p = pose.transform(p);
+	}
 
  private:
 	std::vector<T> cloud_;
 };
 using PointCloud = PointCloudT<Point3>;            // map/point_cloud.h:277
 using PointCloudColor = PointCloudT<Point3Color>;  // map/point_cloud.h:278
+
+// map/code.h:69-371 -- a Morton code with its depth (the part callers of the map see)
+class Code
+{
+ public:
+	Code() : code_(0), depth_(0) {}
+	Code(CodeType code, DepthType depth = 0) : code_(code), depth_(depth) {}
+	CodeType getCode() const { return code_; }
+	DepthType getDepth() const { return depth_; }
+	bool operator==(Code const& o) const { return code_ == o.code_ && depth_ == o.depth_; }
+	bool operator!=(Code const& o) const { return !(*this == o); }
+	bool operator<(Code const& o) const { return code_ < o.code_ || (code_ == o.code_ && depth_ < o.depth_); }
+
+ private:
+	CodeType code_;
+	DepthType depth_;
+};
+
+// map/occupancy_map_node.h:52-111
+template <typename T>
+struct OccupancyNode {
+	T occupancy = 0;
+};
+template <typename T>
+struct ColorOccupancyNode : OccupancyNode<T> {
+	Color color;
+};
+
+enum class OccupancyState { unknown, free, occupied };  // map/types.h
 
 class DeviceError : public std::runtime_error
 {
@@ -83,55 +348,109 @@ class DeviceError : public std::runtime_error
 	int code_;
 };
 
-// map/occupancy_map_base.h:75 -- the part of OccupancyMapBase that is the integration path
-class OccupancyMapBase
+// map/occupancy_map_base.h:75 over map/octree.h:91 -- the part of OccupancyMapBase / Octree that is the integration
+// path and what its callers use around it
+template <bool COLOR>
+class OccupancyMapDevice
 {
  public:
-	OccupancyMapBase(OccupancyMapBase const&) = delete;
-	OccupancyMapBase& operator=(OccupancyMapBase const&) = delete;
-	virtual ~OccupancyMapBase() { ufomap_map_destroy(map_); }
+	using LogitType = float;
+	using NodeType = std::conditional_t<COLOR, ColorOccupancyNode<float>, OccupancyNode<float>>;
 
-	virtual std::string getTreeType() const noexcept = 0;
+	OccupancyMapDevice(OccupancyMapDevice const&) = delete;
+	OccupancyMapDevice& operator=(OccupancyMapDevice const&) = delete;
+	virtual ~OccupancyMapDevice() { ufomap_map_destroy(map_); }
 
-	// ---- integration (occupancy_map_base.h:270-443) ------------------------------------------------
-	void insertPointCloud(Point3 const& sensor_origin, PointCloud const& cloud, double max_range = -1, DepthType depth = 0,
+	// ---- octree.h:117, 580-586, 411-443, 541-575 ------------------------------------------------------------
+	static std::string getFileVersion() noexcept { return "1.0.0"; }
+	std::string getTreeType() const noexcept { return COLOR ? "occupancy_map_color" : "occupancy_map"; }
+	double getResolution() const noexcept { return resolution_; }
+	DepthType getTreeDepthLevels() const noexcept { return depth_levels_; }
+	Code getRootCode() const noexcept { return Code(0, depth_levels_); }
+	double getNodeSize(DepthType depth) const { return std::ldexp(resolution_, (int)depth); }
+	double getNodeHalfSize(DepthType depth) const { return std::ldexp(resolution_, (int)depth - 1); }
+	Point3 getMin() const
+	{
+		double const h = -getNodeHalfSize(depth_levels_);
+		return Point3(h, h, h);
+	}
+	Point3 getMax() const
+	{
+		double const h = getNodeHalfSize(depth_levels_);
+		return Point3(h, h, h);
+	}
+	std::size_t getNumInnerNodes() const { return stats()[0]; }
+	std::size_t getNumLeafNodes() const { return stats()[1]; }
+	std::size_t memoryUsage() const { return stats()[2]; }  // bytes of HBM held by the node table
+	std::size_t size() const
+	{
+		auto const s = stats();
+		return s[0] + s[1];
+	}
+	void clear() { check(ufomap_map_clear(map_)); }
+	void clear(double new_resolution, DepthType new_depth_levels)
+	{
+		if (new_depth_levels < 2 || new_depth_levels > 21) throw std::invalid_argument("depth_levels can be minimum 2 and maximum 21");
+		check(ufomap_map_clear_to(map_, new_resolution, new_depth_levels));
+		resolution_ = new_resolution;
+		depth_levels_ = new_depth_levels;
+	}
+
+	// ---- integration (occupancy_map_base.h:270-443) ------------------------------------------------------------
+	template <typename T>
+	void insertPointCloud(Point3 const& sensor_origin, T const& cloud, double max_range = -1, DepthType depth = 0,
 	                      bool simple_ray_casting = false, unsigned int early_stopping = 0, bool async = false)
 	{
 		insert(sensor_origin, cloud, max_range, depth, false, simple_ray_casting, early_stopping, async);
 	}
-	void insertPointCloudDiscrete(Point3 const& sensor_origin, PointCloud const& cloud, double max_range = -1, DepthType depth = 0,
+	template <typename T>
+	void insertPointCloud(Point3 const& sensor_origin, T cloud, math::Pose6 const& frame_origin, double max_range = -1, DepthType depth = 0,
+	                      bool simple_ray_casting = false, unsigned int early_stopping = 0, bool async = false)
+	{
+		cloud.transform(frame_origin, async);  // occupancy_map_base.h:329-338
+		insertPointCloud(sensor_origin, cloud, max_range, depth, simple_ray_casting, early_stopping, async);
+	}
+	template <typename T>
+	void insertPointCloudDiscrete(Point3 const& sensor_origin, T const& cloud, double max_range = -1, DepthType depth = 0,
 	                              bool simple_ray_casting = false, unsigned int early_stopping = 0, bool async = false)
 	{
 		insert(sensor_origin, cloud, max_range, depth, true, simple_ray_casting, early_stopping, async);
+	}
+	template <typename T>
+	void InsertPointCloudDiscrete(Point3 const& sensor_origin, T cloud, math::Pose6 const& frame_origin, double max_range = -1,
+	                              DepthType depth = 0, bool simple_ray_casting = false, unsigned int early_stopping = 0, bool async = false)
+	{
+		cloud.transform(frame_origin, async);  // occupancy_map_base.h:419-428 (capital I as in the reference)
+		insertPointCloudDiscrete(sensor_origin, cloud, max_range, depth, simple_ray_casting, early_stopping, async);
 	}
 	// The server's rosToUfo + cloud.transform(pose) + insertPointCloudDiscrete(pose.translation(), cloud, ...)
 	// (ufomap_mapping/src/server.cpp:114-120) on the raw records of a sensor_msgs/PointCloud2 (msg.data,
 	// msg.point_step, field offsets; r/g/b offsets -1 without colour): conversion, NaN filter and transform run
 	// inside the first kernel of the scan. No counterpart of this name in the reference.
-	void insertPointCloud2(double const translation[3], double const rotation_wxyz[4], void const* data, std::size_t n_points,
-	                       unsigned point_step, int off_x, int off_y, int off_z, int off_r = -1, int off_g = -1, int off_b = -1,
-	                       double max_range = -1, DepthType depth = 0, bool simple_ray_casting = false, unsigned int early_stopping = 0,
-	                       bool async = false, bool data_on_device = false)
+	void insertPointCloud2(math::Pose6 const& frame_origin, void const* data, std::size_t n_points, unsigned point_step, int off_x, int off_y,
+	                       int off_z, int off_r = -1, int off_g = -1, int off_b = -1, double max_range = -1, DepthType depth = 0,
+	                       bool simple_ray_casting = false, unsigned int early_stopping = 0, bool async = false, bool data_on_device = false)
 	{
-		check(ufomap_map_insert_pointcloud2(map_, translation, rotation_wxyz, data, data_on_device, n_points, point_step, off_x, off_y, off_z,
-		                                    off_r, off_g, off_b, max_range, depth, 1, simple_ray_casting, early_stopping, async));
+		math::Vector3 const t = frame_origin.translation();
+		math::Quaternion const q = frame_origin.rotation();
+		check(ufomap_map_insert_pointcloud2(map_, t.data(), q.data(), data, data_on_device, n_points, point_step, off_x, off_y, off_z, off_r, off_g,
+		                                    off_b, max_range, depth, 1, simple_ray_casting, early_stopping, async));
 	}
 	bool insertPointCloudDone() const { return check(ufomap_map_done(map_)) != 0; }
 	void insertPointCloudWait() const { check(ufomap_map_wait(map_)); }
 
-	// ---- point queries (occupancy_map_base.h:599-728), answered by ufomap_map_query -------------------
-	std::pair<float, uint8_t> query(Point3 const& coord, DepthType depth) const
+	// ---- robot clearing (occupancy_map_base.h:492-518; ufomap_mapping/src/server.cpp:152-155, 354) -------------
+	void setValueVolume(ufo::geometry::BoundingVar const& bounding_volume, double occupancy_value, DepthType min_depth = 0)
 	{
-		double const p[3] = {coord.x, coord.y, coord.z};
-		float lo = 0;
-		uint8_t st = 0;
-		check(ufomap_map_query(map_, p, 0, 1, depth, &lo, &st));
-		return {lo, st};
+		// (centre, half size) travel as they are: the reference intersects with these members, not with min / max
+		ufo::geometry::AABB const& a = std::get<ufo::geometry::AABB>(bounding_volume);
+		check(ufomap_map_set_value_volume_ch(map_, a.center.data(), a.half_size.data(), occupancy_value, min_depth));
 	}
-	enum class OccupancyState { unknown, free, occupied };  // map/types.h
+
+	// ---- point queries (occupancy_map_base.h:599-728), answered by ufomap_map_query ----------------------------
 	OccupancyState getState(Point3 const& coord, DepthType depth = 0) const
 	{
-		uint8_t st = query(coord, depth).second;
+		uint8_t const st = query(coord, depth).second;
 		return (st & 1) ? OccupancyState::occupied : ((st & 2) ? OccupancyState::free : OccupancyState::unknown);
 	}
 	bool isOccupied(Point3 const& coord, DepthType depth = 0) const { return 0 != (query(coord, depth).second & 1); }
@@ -140,38 +459,56 @@ class OccupancyMapBase
 	bool containsOccupied(Point3 const& coord, DepthType depth = 0) const { return isOccupied(coord, depth); }
 	bool containsFree(Point3 const& coord, DepthType depth = 0) const { return 0 != (query(coord, depth).second & 8); }
 	bool containsUnknown(Point3 const& coord, DepthType depth = 0) const { return 0 != (query(coord, depth).second & 16); }
-	// getOccupancy = toProb(LogitType) with LogitType = float (occupancy_map_base.h:599-602, 911)
-	double getOccupancy(Point3 const& coord, DepthType depth = 0) const { return 1.0 / (1.0 + std::exp(-query(coord, depth).first)); }
+	double getOccupancy(Point3 const& coord, DepthType depth = 0) const { return toProb(query(coord, depth).first); }
+	static double toLogit(double prob) { return std::log(prob / (1.0 - prob)); }          // occupancy_map_base.h:909
+	static double toProb(LogitType logit) { return 1.0 / (1.0 + std::exp(-logit)); }      // occupancy_map_base.h:911
 
-	// ---- robot clearing (occupancy_map_base.h:492-518; ufomap_mapping/src/server.cpp:152-155) --------
-	// setValueVolume(ufo::geometry::AABB(min, max), occupancy_value, min_depth): the AABB is passed as the two
-	// corners the server constructs it from.
-	void setValueVolume(Point3 const& aabb_min, Point3 const& aabb_max, double occupancy_value, DepthType min_depth = 0)
+	// ---- sensor model (occupancy_map_base.h:734-773) -----------------------------------------------------------
+	double getOccupiedThres() const { return model()[0]; }
+	double getFreeThres() const { return model()[1]; }
+	double getProbHit() const { return model()[2]; }
+	double getProbMiss() const { return model()[3]; }
+	double getClampingThresMin() const { return model()[4]; }
+	double getClampingThresMax() const { return model()[5]; }
+	void setOccupiedFreeThres(double new_occupied_thres, double new_free_thres)
 	{
-		double const mn[3] = {aabb_min.x, aabb_min.y, aabb_min.z}, mx[3] = {aabb_max.x, aabb_max.y, aabb_max.z};
-		check(ufomap_map_set_value_volume(map_, mn, mx, occupancy_value, min_depth));
+		check(ufomap_map_set_occupied_free_thres(map_, new_occupied_thres, new_free_thres));
 	}
-	double getClampingThresMin() const
-	{
-		double a = 0, b = 0;
-		check(ufomap_map_clamping_thres(map_, &a, &b));
-		return a;
-	}
-	double getClampingThresMax() const
-	{
-		double a = 0, b = 0;
-		check(ufomap_map_clamping_thres(map_, &a, &b));
-		return b;
-	}
+	void setProbHit(double probability) { check(ufomap_map_set_model_value(map_, 2, probability)); }
+	void setProbMiss(double probability) { check(ufomap_map_set_model_value(map_, 3, probability)); }
+	void setClampingThresMin(double probability) { check(ufomap_map_set_model_value(map_, 4, probability)); }
+	void setClampingThresMax(double probability) { check(ufomap_map_set_model_value(map_, 5, probability)); }
 
-	// ---- sensor model (occupancy_map_base.h:746-773) -------------------------------------------------
-	void setSensorModel(double occupied_thres, double free_thres, double prob_hit, double prob_miss, double clamping_thres_min,
-	                    double clamping_thres_max)
+	// ---- change detection (occupancy_map_base.h:779-822) -------------------------------------------------------
+	void enableChangeDetection(bool enable) noexcept
 	{
-		check(ufomap_map_set_sensor_model(map_, occupied_thres, free_thres, prob_hit, prob_miss, clamping_thres_min, clamping_thres_max));
+		change_detection_ = enable;
+		(void)ufomap_map_enable_change_detection(map_, enable);
 	}
-
-	// ---- change detection (occupancy_map_base.h:793-822) ---------------------------------------------
+	bool isChangeDetectionEnabled() const noexcept { return change_detection_; }
+	void resetChangeDetection() noexcept
+	{
+		(void)ufomap_map_reset_change_detection(map_);
+		changes_.clear();
+	}
+	std::size_t numChangedDetected() const
+	{
+		fetchChanges();
+		return changes_.size();
+	}
+	std::vector<Code>::const_iterator changesBegin() const
+	{
+		fetchChanges();
+		return changes_.begin();
+	}
+	std::vector<Code>::const_iterator changesEnd() const { return changes_.end(); }
+	void enableMinMaxChangeDetection(bool enable) noexcept
+	{
+		if (!min_max_change_detection_ && enable) (void)ufomap_map_reset_minmax_change(map_);
+		min_max_change_detection_ = enable;
+		(void)ufomap_map_enable_minmax_change_detection(map_, enable);
+	}
+	bool isMinMaxChangeDetectionEnabled() const noexcept { return min_max_change_detection_; }
 	Point3 minChange() const
 	{
 		double mn[3], mx[3];
@@ -184,41 +521,203 @@ class OccupancyMapBase
 		check(ufomap_map_minmax_change(map_, mn, mx));
 		return Point3(mx[0], mx[1], mx[2]);
 	}
-	void resetMinMaxChangeDetection() { check(ufomap_map_reset_minmax_change(map_)); }
-
-	void clear() { check(ufomap_map_clear(map_)); }  // octree.h:541
-
-	// ---- read-back in the canonical dump format (what beginLeaves() yields, occupancy_map_base.h:130-137) ----
-	struct Leaf {
-		uint64_t code;  // Code >> 3*depth
-		uint8_t depth;
-		float logodds;
-		Color color;
-	};
-	std::vector<Leaf> leaves(bool include_unknown = false) const
+	void resetMinMaxChangeDetection() noexcept { (void)ufomap_map_reset_minmax_change(map_); }
+	bool validMinMaxChange() const
 	{
-		size_t n = ufomap_map_export_leaves(map_, include_unknown, nullptr, nullptr, nullptr, nullptr, 0);
-		if (n == (size_t)-1) check(UFOMAP_ERR_DEVICE);
-		std::vector<uint64_t> c(n);
-		std::vector<uint8_t> d(n), rgb(3 * n);
-		std::vector<float> v(n);
-		ufomap_map_export_leaves(map_, include_unknown, c.data(), d.data(), v.data(), rgb.data(), n);
-		std::vector<Leaf> out(n);
-		for (size_t i = 0; i < n; ++i) out[i] = Leaf{c[i], d[i], v[i], Color(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2])};
-		return out;
+		double mn[3], mx[3];
+		check(ufomap_map_minmax_change(map_, mn, mx));
+		for (int i : {0, 1, 2})
+			if (mn[i] > mx[i]) return false;
+		return true;
+	}
+
+	// ---- iterators (occupancy_map_base.h:93-165; iterator/octree.h, iterator/occupancy_map.h) ------------------
+	// begin*() runs the traversal on the device (ufomap_map_iterate: bounding-volume, state and depth filters of
+	// validNode / validReturnNode) and returns a forward iterator over the result, in the reference's order.
+	class Iterator
+	{
+	 public:
+		using difference_type = std::ptrdiff_t;
+		using value_type = NodeType;
+		using pointer = NodeType const*;
+		using reference = NodeType const&;
+		using iterator_category = std::forward_iterator_tag;
+		Iterator() {}
+		reference operator*() const { return snap_->node[i_]; }
+		pointer operator->() const { return &snap_->node[i_]; }
+		Iterator& operator++()
+		{
+			if (snap_ && ++i_ >= snap_->node.size()) snap_.reset();
+			return *this;
+		}
+		Iterator operator++(int)
+		{
+			Iterator r = *this;
+			++(*this);
+			return r;
+		}
+		// the reference compares the tree pointer only (iterator/octree.h:113-117): "at end" vs "not at end"
+		bool operator==(Iterator const& o) const { return !snap_ == !o.snap_; }
+		bool operator!=(Iterator const& o) const { return !(*this == o); }
+		DepthType getDepth() const { return snap_->depth[i_]; }
+		Code getCode() const { return Code(snap_->code[i_] << (3 * snap_->depth[i_]), snap_->depth[i_]); }
+		double getSize() const { return std::ldexp(snap_->resolution, (int)getDepth()); }
+		double getHalfSize() const { return std::ldexp(snap_->resolution, (int)getDepth() - 1); }
+		Point3 getCenter() const
+		{
+			// the reference accumulates child centres from the root down (octree.h:625-633): same additions, same order
+			Point3 c(0, 0, 0);
+			uint64_t const full = snap_->code[i_] << (3 * snap_->depth[i_]);
+			for (int d = (int)snap_->depth_levels - 1; d >= (int)getDepth(); --d) {
+				unsigned const idx = (unsigned)((full >> (3 * d)) & 7u);
+				double const hs = std::ldexp(snap_->resolution, d - 1);
+				c[0] += (idx & 1) ? hs : -hs;
+				c[1] += (idx & 2) ? hs : -hs;
+				c[2] += (idx & 4) ? hs : -hs;
+			}
+			return c;
+		}
+		double getX() const { return getCenter()[0]; }
+		double getY() const { return getCenter()[1]; }
+		double getZ() const { return getCenter()[2]; }
+		ufo::geometry::AABB getBoundingVolume() const { return ufo::geometry::AABB(getCenter(), getHalfSize()); }
+		bool isPureLeaf() const { return 0 == getDepth(); }
+		bool isLeaf() const { return 0 != (snap_->flags[i_] & 4); }
+		bool hasChildren() const { return !isLeaf(); }
+		bool isOccupied() const { return snap_->occ_thr < (double)snap_->node[i_].occupancy; }
+		bool isFree() const { return snap_->free_thr > (double)snap_->node[i_].occupancy; }
+		bool isUnknown() const { return !isOccupied() && !isFree(); }
+		bool containsOccupied() const { return isOccupied(); }
+		bool containsFree() const { return 0 == getDepth() ? isFree() : 0 != (snap_->flags[i_] & 1); }
+		bool containsUnknown() const { return 0 == getDepth() ? isUnknown() : 0 != (snap_->flags[i_] & 2); }
+		double getOccupancy() const { return toProb(snap_->node[i_].occupancy); }
+
+	 private:
+		friend class OccupancyMapDevice;
+		struct Snapshot {
+			std::vector<NodeType> node;
+			std::vector<uint64_t> code;  // code >> 3*depth
+			std::vector<uint8_t> depth, flags;
+			double resolution = 0, occ_thr = 0, free_thr = 0;
+			DepthType depth_levels = 0;
+		};
+		std::shared_ptr<Snapshot> snap_;
+		size_t i_ = 0;
+	};
+	using LeafIterator = Iterator;
+	using TreeIterator = Iterator;
+
+	Iterator beginLeaves(bool occupied_space = true, bool free_space = true, bool unknown_space = false, bool contains = false,
+	                     DepthType min_depth = 0) const
+	{
+		return iterate(nullptr, true, occupied_space, free_space, unknown_space, contains, min_depth);
+	}
+	Iterator beginLeaves(ufo::geometry::BoundingVar const& bounding_volume, bool occupied_space = true, bool free_space = true,
+	                     bool unknown_space = false, bool contains = false, DepthType min_depth = 0) const
+	{
+		return iterate(&std::get<ufo::geometry::AABB>(bounding_volume), true, occupied_space, free_space, unknown_space, contains, min_depth);
+	}
+	Iterator endLeaves() const noexcept { return Iterator(); }
+	Iterator beginTree(bool occupied_space = true, bool free_space = true, bool unknown_space = false, bool contains = false,
+	                   DepthType min_depth = 0) const
+	{
+		return iterate(nullptr, false, occupied_space, free_space, unknown_space, contains, min_depth);
+	}
+	Iterator beginTree(ufo::geometry::BoundingVar const& bounding_volume, bool occupied_space = true, bool free_space = true,
+	                   bool unknown_space = false, bool contains = false, DepthType min_depth = 0) const
+	{
+		return iterate(&std::get<ufo::geometry::AABB>(bounding_volume), false, occupied_space, free_space, unknown_space, contains, min_depth);
+	}
+	Iterator endTree() const noexcept { return Iterator(); }
+
+	// ---- input / output (octree.h:691-917) ---------------------------------------------------------------------
+	bool write(std::string const& filename, bool compress = false, DepthType min_depth = 0, int compression_acceleration_level = 1,
+	           int compression_level = 0) const
+	{
+		return write(filename, ufo::geometry::BoundingVolume(), compress, min_depth, compression_acceleration_level, compression_level);
+	}
+	bool write(std::string const& filename, ufo::geometry::BoundingVolume const& bounding_volume, bool compress = false,
+	           DepthType min_depth = 0, int compression_acceleration_level = 1, int compression_level = 0) const
+	{
+		std::ofstream file(filename.c_str(), std::ios_base::out | std::ios_base::binary);
+		if (!file.is_open()) return false;
+		bool const ok = write(file, bounding_volume, compress, min_depth, compression_acceleration_level, compression_level);
+		file.close();
+		return ok;
+	}
+	bool write(std::ostream& s, bool compress = false, DepthType min_depth = 0, int compression_acceleration_level = 1,
+	           int compression_level = 0) const
+	{
+		return write(s, ufo::geometry::BoundingVolume(), compress, min_depth, compression_acceleration_level, compression_level);
+	}
+	bool write(std::ostream& s, ufo::geometry::BoundingVolume const& bounding_volume, bool compress = false, DepthType min_depth = 0,
+	           int compression_acceleration_level = 1, int compression_level = 0) const
+	{
+		std::vector<uint8_t> buf;
+		if (0 > serialise(buf, bounding_volume, compress, min_depth, compression_acceleration_level, compression_level, true)) return false;
+		s.write(reinterpret_cast<char const*>(buf.data()), (std::streamsize)buf.size());
+		return s.good();
+	}
+	int writeData(std::ostream& s, bool compress = false, DepthType min_depth = 0, int compression_acceleration_level = 1,
+	              int compression_level = 0) const
+	{
+		return writeData(s, ufo::geometry::BoundingVolume(), compress, min_depth, compression_acceleration_level, compression_level);
+	}
+	int writeData(std::ostream& s, ufo::geometry::BoundingVolume const& bounding_volume, bool compress = false, DepthType min_depth = 0,
+	              int compression_acceleration_level = 1, int compression_level = 0) const
+	{
+		std::vector<uint8_t> buf;
+		int const n = serialise(buf, bounding_volume, compress, min_depth, compression_acceleration_level, compression_level, false);
+		if (0 <= n) s.write(reinterpret_cast<char const*>(buf.data()), (std::streamsize)buf.size());
+		return n;
+	}
+	bool read(std::string const& filename)
+	{
+		std::ifstream file(filename.c_str(), std::ios_base::in | std::ios_base::binary);
+		if (!file.is_open()) return false;
+		return read(file);
+	}
+	bool read(std::istream& s)
+	{
+		std::vector<char> const all((std::istreambuf_iterator<char>(s)), std::istreambuf_iterator<char>());
+		double res = 0;
+		unsigned levels = 0;
+		int const rc = ufomap_map_read(map_, reinterpret_cast<uint8_t const*>(all.data()), all.size(), &res, &levels);
+		if (rc < 0) return false;
+		resolution_ = res;
+		depth_levels_ = levels;
+		return true;
+	}
+	bool readData(std::istream& s, double resolution, DepthType depth_levels, int uncompressed_data_size = 1, bool compressed = false)
+	{
+		return readData(s, ufo::geometry::BoundingVolume(), resolution, depth_levels, uncompressed_data_size, compressed);
+	}
+	bool readData(std::istream& s, ufo::geometry::BoundingVolume const& bounding_volume, double resolution, DepthType depth_levels,
+	              int uncompressed_data_size = 1, bool compressed = false)
+	{
+		std::vector<char> const all((std::istreambuf_iterator<char>(s)), std::istreambuf_iterator<char>());
+		double mn[3], mx[3];
+		bool const has_bv = corners(bounding_volume, mn, mx);
+		int const rc = ufomap_map_read_data(map_, reinterpret_cast<uint8_t const*>(all.data()), all.size(), has_bv ? mn : nullptr,
+		                                    has_bv ? mx : nullptr, resolution, depth_levels, uncompressed_data_size, compressed);
+		if (rc < 0) return false;
+		resolution_ = resolution;
+		depth_levels_ = depth_levels;
+		return true;
 	}
 
 	ufomap_map* handle() const { return map_; }
 
  protected:
-	OccupancyMapBase(double resolution, DepthType depth_levels, bool automatic_pruning, double occupied_thres, double free_thres,
-	                 double prob_hit, double prob_miss, double clamping_thres_min, double clamping_thres_max, bool color, int device)
+	OccupancyMapDevice(double resolution, DepthType depth_levels, bool automatic_pruning, double occupied_thres, double free_thres,
+	                   double prob_hit, double prob_miss, double clamping_thres_min, double clamping_thres_max, int device)
+	    : resolution_(resolution), depth_levels_(depth_levels)
 	{
 		if (depth_levels < 2 || depth_levels > 21) {  // octree.h:931-935
-			throw std::invalid_argument("depth_levels has to be [2, 21]");
+			throw std::invalid_argument("depth_levels can be minimum 2 and maximum 21");
 		}
 		map_ = ufomap_map_create(resolution, depth_levels, automatic_pruning, occupied_thres, free_thres, prob_hit, prob_miss,
-		                         clamping_thres_min, clamping_thres_max, color ? 1 : 0, device);
+		                         clamping_thres_min, clamping_thres_max, COLOR ? 1 : 0, device);
 		if (!map_) throw DeviceError(UFOMAP_ERR_DEVICE, ufomap_last_error());
 	}
 
@@ -227,67 +726,166 @@ class OccupancyMapBase
 		if (rc < 0) throw DeviceError(rc, ufomap_last_error());
 		return rc;
 	}
+	std::array<uint64_t, 3> stats() const
+	{
+		std::array<uint64_t, 3> s{};
+		check(ufomap_map_stats(map_, &s[0], &s[1], &s[2]));
+		return s;
+	}
+	std::array<double, 6> model() const
+	{
+		std::array<double, 6> v{};
+		check(ufomap_map_get_sensor_model(map_, v.data()));
+		return v;
+	}
+	std::pair<float, uint8_t> query(Point3 const& coord, DepthType depth) const
+	{
+		float lo = 0;
+		uint8_t st = 0;
+		check(ufomap_map_query(map_, coord.data(), 0, 1, depth, &lo, &st));
+		return {lo, st};
+	}
+	static bool corners(ufo::geometry::BoundingVolume const& bv, double mn[3], double mx[3])
+	{
+		if (bv.empty()) return false;
+		if (bv.size() > 1) throw std::invalid_argument("the device path takes one AABB per call");
+		ufo::geometry::AABB const& a = std::get<ufo::geometry::AABB>(*bv.begin());
+		for (int k = 0; k < 3; ++k) {
+			mn[k] = a.center[k];     // (centre, half size) travel as they are: the reference intersects with them
+			mx[k] = a.half_size[k];  //  without going back through min / max
+		}
+		return true;
+	}
+	int serialise(std::vector<uint8_t>& buf, ufo::geometry::BoundingVolume const& bv, bool compress, DepthType min_depth, int accel, int level,
+	              bool header) const
+	{
+		double c[3], h[3];
+		bool const has_bv = corners(bv, c, h);
+		long long usize = -1;
+		size_t const n = ufomap_map_write_ex(map_, has_bv ? c : nullptr, has_bv ? h : nullptr, compress, min_depth, accel, level, header, nullptr,
+		                                     0, &usize);
+		if (n == (size_t)-1) return -1;
+		buf.resize(n);
+		if ((size_t)-1 == ufomap_map_write_ex(map_, has_bv ? c : nullptr, has_bv ? h : nullptr, compress, min_depth, accel, level, header,
+		                                      buf.data(), buf.size(), &usize))
+			return -1;
+		return (int)usize;
+	}
+	Iterator iterate(ufo::geometry::AABB const* aabb, bool only_leaves, bool occupied_space, bool free_space, bool unknown_space, bool contains,
+	                 DepthType min_depth) const
+	{
+		double const* c = aabb ? aabb->center.data() : nullptr;
+		double const* h = aabb ? aabb->half_size.data() : nullptr;
+		size_t const n = ufomap_map_iterate(map_, c, h, occupied_space, free_space, unknown_space, contains, min_depth, only_leaves, nullptr,
+		                                    nullptr, nullptr, nullptr, nullptr, 0);
+		if (n == (size_t)-1) check(UFOMAP_ERR_DEVICE);
+		Iterator it;
+		if (0 == n) return it;
+		auto snap = std::make_shared<typename Iterator::Snapshot>();
+		snap->code.resize(n);
+		snap->depth.resize(n);
+		snap->flags.resize(n);
+		snap->node.resize(n);
+		std::vector<float> lo(n);
+		std::vector<uint8_t> rgb(3 * n);
+		size_t const got = ufomap_map_iterate(map_, c, h, occupied_space, free_space, unknown_space, contains, min_depth, only_leaves,
+		                                      snap->code.data(), snap->depth.data(), lo.data(), rgb.data(), snap->flags.data(), n);
+		if (got != n) check(UFOMAP_ERR_DEVICE);
+		for (size_t i = 0; i < n; ++i) {
+			snap->node[i].occupancy = lo[i];
+			if constexpr (COLOR) snap->node[i].color = Color(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]);
+		}
+		auto const mdl = model();
+		snap->occ_thr = toLogit(mdl[0]);
+		snap->free_thr = toLogit(mdl[1]);
+		snap->resolution = resolution_;
+		snap->depth_levels = depth_levels_;
+		it.snap_ = std::move(snap);
+		return it;
+	}
+	void fetchChanges() const
+	{
+		size_t const n = ufomap_map_changes(map_, nullptr, nullptr, 0);
+		if (n == (size_t)-1) check(UFOMAP_ERR_DEVICE);
+		std::vector<uint64_t> c(n);
+		std::vector<uint8_t> d(n);
+		ufomap_map_changes(map_, c.data(), d.data(), n);
+		changes_.resize(n);
+		for (size_t i = 0; i < n; ++i) changes_[i] = Code(c[i] << (3 * d[i]), d[i]);
+	}
 
-	void insert(Point3 const& o, PointCloud const& cloud, double max_range, DepthType depth, bool discrete, bool simple,
+	template <typename T>
+	void insert(Point3 const& o, PointCloudT<T> const& cloud, double max_range, DepthType depth, bool discrete, bool simple,
 	            unsigned int early_stopping, bool async)
 	{
 		static_assert(sizeof(Point3) == 24, "Point3 must be three packed doubles");
-		const double origin[3] = {o.x, o.y, o.z};
-		const double* xyz = cloud.empty() ? nullptr : &cloud[0].x;
-		check(ufomap_map_insert(map_, origin, xyz, nullptr, cloud.size(), max_range, depth, discrete, simple, early_stopping, async));
+		if constexpr (std::is_same_v<T, Point3>) {
+			double const* xyz = cloud.empty() ? nullptr : cloud[0].data();
+			check(ufomap_map_insert(map_, o.data(), xyz, nullptr, cloud.size(), max_range, depth, discrete, simple, early_stopping, async));
+		} else {
+			// Point3Color is not a packed xyz array: split into the two arrays the C ABI takes
+			static_assert(COLOR, "a coloured cloud needs an OccupancyMapColor (occupancy_map_color.h:177-181)");
+			xyz_.resize(3 * cloud.size());
+			rgb_.resize(3 * cloud.size());
+			for (size_t i = 0; i < cloud.size(); ++i) {
+				xyz_[3 * i] = cloud[i].x();
+				xyz_[3 * i + 1] = cloud[i].y();
+				xyz_[3 * i + 2] = cloud[i].z();
+				rgb_[3 * i] = cloud[i].getColor().r;
+				rgb_[3 * i + 1] = cloud[i].getColor().g;
+				rgb_[3 * i + 2] = cloud[i].getColor().b;
+			}
+			check(ufomap_map_insert(map_, o.data(), xyz_.data(), rgb_.data(), cloud.size(), max_range, depth, discrete, simple, early_stopping, async));
+		}
 	}
 
 	ufomap_map* map_ = nullptr;
+	double resolution_;
+	DepthType depth_levels_;
+	bool change_detection_ = false, min_max_change_detection_ = false;
+	mutable std::vector<Code> changes_;
+	std::vector<double> xyz_;  // staging of a coloured cloud (consumed by the call: the C ABI copies before it returns)
+	std::vector<uint8_t> rgb_;
 };
 
 // map/occupancy_map.h:55-85
-class OccupancyMap : public OccupancyMapBase
+class OccupancyMap : public OccupancyMapDevice<false>
 {
  public:
 	OccupancyMap(double resolution, DepthType depth_levels = 16, bool automatic_pruning = true, double occupied_thres = 0.5,
 	             double free_thres = 0.5, double prob_hit = 0.7, double prob_miss = 0.4, double clamping_thres_min = 0.1192,
 	             double clamping_thres_max = 0.971, int device = 0)
-	    : OccupancyMapBase(resolution, depth_levels, automatic_pruning, occupied_thres, free_thres, prob_hit, prob_miss,
-	                       clamping_thres_min, clamping_thres_max, false, device)
+	    : OccupancyMapDevice<false>(resolution, depth_levels, automatic_pruning, occupied_thres, free_thres, prob_hit, prob_miss,
+	                                clamping_thres_min, clamping_thres_max, device)
 	{
 	}
-	std::string getTreeType() const noexcept override { return "occupancy_map"; }
+	// occupancy_map.h:65-70: construct from a file
+	OccupancyMap(std::string const& filename, bool automatic_pruning = true, double occupied_thres = 0.5, double free_thres = 0.5,
+	             double prob_hit = 0.7, double prob_miss = 0.4, double clamping_thres_min = 0.1192, double clamping_thres_max = 0.971, int device = 0)
+	    : OccupancyMap(0.1, 16, automatic_pruning, occupied_thres, free_thres, prob_hit, prob_miss, clamping_thres_min, clamping_thres_max, device)
+	{
+		read(filename);
+	}
 };
 
 // map/occupancy_map_color.h:56-98
-class OccupancyMapColor : public OccupancyMapBase
+class OccupancyMapColor : public OccupancyMapDevice<true>
 {
  public:
 	OccupancyMapColor(double resolution, DepthType depth_levels = 16, bool automatic_pruning = true, double occupied_thres = 0.5,
 	                  double free_thres = 0.5, double prob_hit = 0.7, double prob_miss = 0.4, double clamping_thres_min = 0.1192,
 	                  double clamping_thres_max = 0.971, int device = 0)
-	    : OccupancyMapBase(resolution, depth_levels, automatic_pruning, occupied_thres, free_thres, prob_hit, prob_miss,
-	                       clamping_thres_min, clamping_thres_max, true, device)
+	    : OccupancyMapDevice<true>(resolution, depth_levels, automatic_pruning, occupied_thres, free_thres, prob_hit, prob_miss,
+	                               clamping_thres_min, clamping_thres_max, device)
 	{
 	}
-	std::string getTreeType() const noexcept override { return "occupancy_map_color"; }
-
-	using OccupancyMapBase::insertPointCloud;
-	using OccupancyMapBase::insertPointCloudDiscrete;
-
-	// occupancy_map_color.h:177-267: the colour-carrying overload (the only one the ROS server calls, server.cpp:118-120)
-	void insertPointCloudDiscrete(Point3 const& sensor_origin, PointCloudColor const& cloud, double max_range = -1, DepthType depth = 0,
-	                              bool simple_ray_casting = false, unsigned int early_stopping = 0, bool async = false)
+	OccupancyMapColor(std::string const& filename, bool automatic_pruning = true, double occupied_thres = 0.5, double free_thres = 0.5,
+	                  double prob_hit = 0.7, double prob_miss = 0.4, double clamping_thres_min = 0.1192, double clamping_thres_max = 0.971,
+	                  int device = 0)
+	    : OccupancyMapColor(0.1, 16, automatic_pruning, occupied_thres, free_thres, prob_hit, prob_miss, clamping_thres_min, clamping_thres_max,
+	                        device)
 	{
-		// Point3Color is not a packed xyz array: split into the two arrays the C ABI takes
-		std::vector<double> xyz(3 * cloud.size());
-		std::vector<uint8_t> rgb(3 * cloud.size());
-		for (size_t i = 0; i < cloud.size(); ++i) {
-			xyz[3 * i] = cloud[i].x;
-			xyz[3 * i + 1] = cloud[i].y;
-			xyz[3 * i + 2] = cloud[i].z;
-			rgb[3 * i] = cloud[i].color.r;
-			rgb[3 * i + 1] = cloud[i].color.g;
-			rgb[3 * i + 2] = cloud[i].color.b;
-		}
-		const double origin[3] = {sensor_origin.x, sensor_origin.y, sensor_origin.z};
-		check(ufomap_map_insert(map_, origin, xyz.data(), rgb.data(), cloud.size(), max_range, depth, 1, simple_ray_casting, early_stopping,
-		                        async));
+		read(filename);
 	}
 };
 }  // namespace ufo::map

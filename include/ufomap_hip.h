@@ -10,9 +10,10 @@
  * Conventions: plain pointers and sizes only; every function that can fail returns int
  * (0 = UFOMAP_OK, <0 = error) and leaves a message for ufomap_last_error(); nothing throws.
  * The reference's hot path has no error reporting at all, so UFOMAP_OK is the only
- * outcome a reference-valid call can produce.  One HIP stream per map handle; at most one
- * integration in flight per map, like the reference's `integrate_` future
- * (occupancy_map_base.h:315, 405, 1553).  Not thread-safe per handle (neither is the reference).
+ * outcome a reference-valid call can produce.  A map handle owns three HIP streams (scan half, tree update,
+ * read-back); with async != 0 up to two tree updates may be in flight while the next scan is cast -- the
+ * reference has one `integrate_` future (occupancy_map_base.h:315, 405, 1553) and overlaps only its head loop
+ * with it; results are identical either way.  Not thread-safe per handle (neither is the reference).
  *
  * There is NO CPU fallback behind this ABI: without a HIP device every call fails loudly.
  */
@@ -119,6 +120,64 @@ int ufomap_map_clamping_thres(ufomap_map* m, double* thres_min, double* thres_ma
 int ufomap_map_wait(ufomap_map* m);
 int ufomap_map_done(ufomap_map* m);
 
+/* ---- what the reference's callers use around the hot path (ufomap_mapping/src/server.cpp) ------------------------------
+ * Bounding volumes are AABBs given as (centre[3], half_size[3]) -- the members of ufo::geometry::AABB (geometry/aabb.h:
+ * 50-72), which the reference's intersection tests read directly; NULL pointers = no bounding volume. */
+
+/* Octree::clear(new_resolution, new_depth_levels) (octree.h:544-575): back to a single unknown root at a new geometry. */
+int ufomap_map_clear_to(ufomap_map* m, double resolution, unsigned depth_levels);
+/* getOccupiedThres / getFreeThres / getProbHit / getProbMiss / getClampingThresMin / getClampingThresMax
+ * (occupancy_map_base.h:734-744): toProb(LogitType = float) of the stored logits, in this order. */
+int ufomap_map_get_sensor_model(ufomap_map* m, double out[6]);
+/* setProbHit (which = 2) / setProbMiss (3) / setClampingThresMin (4) / setClampingThresMax (5)
+ * (occupancy_map_base.h:761-773; server.cpp:468-471): stores toLogit(probability); the tree is not touched. */
+int ufomap_map_set_model_value(ufomap_map* m, int which, double probability);
+/* setOccupiedFreeThres (occupancy_map_base.h:746-759): the reference writes the tree to a stream, changes the
+ * thresholds and reads it back, so that every inner node's contains_free / contains_unknown (and its max, and the
+ * pruning) is re-evaluated; done the same way here, on the device (ufomap_map_write_ex + ufomap_map_read_data). */
+int ufomap_map_set_occupied_free_thres(ufomap_map* m, double occupied_thres, double free_thres);
+/* setValueVolume with the AABB as the reference holds it (centre, half size): what a BoundingVar carries. */
+int ufomap_map_set_value_volume_ch(ufomap_map* m, const double aabb_center[3], const double aabb_half[3], double occupancy_value,
+                                   unsigned min_depth);
+
+/* Change detection (occupancy_map_base.h:779-791): while enabled, every leaf update that changes a value records its
+ * code (occupancy_map_base.h:1070-1072, 1094-1108; occupancy_map_color.h:278-280) in a set. changes() returns the set
+ * as (code >> 3*depth, depth) sorted by (depth, code); the total is returned, at most cap entries are written. */
+int ufomap_map_enable_change_detection(ufomap_map* m, int enable);
+int ufomap_map_reset_change_detection(ufomap_map* m);
+size_t ufomap_map_changes(ufomap_map* m, uint64_t* codes, uint8_t* depths, size_t cap);
+/* enableMinMaxChangeDetection (occupancy_map_base.h:791-797): the change AABB only grows while enabled (default here:
+ * enabled, as the server sets it, server.cpp:74). */
+int ufomap_map_enable_minmax_change_detection(ufomap_map* m, int enable);
+
+/* beginLeaves / beginTree (occupancy_map_base.h:93-165) run to the end: the nodes OccupancyMapIterator
+ * (iterator/occupancy_map.h:168-208 over iterator/octree.h:186-300) returns for a bounding volume, the three state
+ * switches, `contains` and min_depth, in the iterator's (pre-order) sequence. Evaluated level by level on the
+ * device; only the matching nodes are copied back. flags: bit 0 contains_free, bit 1 contains_unknown, bit 2 the
+ * node is a leaf. Returns the total (may exceed cap); (size_t)-1 on error. Any output pointer may be NULL. */
+size_t ufomap_map_iterate(ufomap_map* m, const double* aabb_center, const double* aabb_half, int occupied_space, int free_space,
+                          int unknown_space, int contains, unsigned min_depth, int only_leaves, uint64_t* codes, uint8_t* depths,
+                          float* logodds, uint8_t* rgb, uint8_t* flags, size_t cap);
+
+/* Octree::write / writeData with all their arguments (octree.h:779-917; occupancy_map_base.h:1457-1533): bounding
+ * volume, LZ4 compression (LZ4_compress_fast with acceleration_level, or LZ4_compress_HC when compression_level > 0:
+ * octree.h:1430-1458; liblz4 is loaded at run time), min_depth (nodes at min_depth are written as leaves). header != 0:
+ * write() = text header + data; header == 0: writeData() = data only, which is what ufomap_msgs::ufoToMsg puts
+ * into a UFOMap message (ufomap_msgs/conversions.h:162-186; server.cpp:200, 305, 333). *uncompressed_size (may be
+ * NULL) receives writeData's return value. Returns the number of bytes, written only if cap is large enough. */
+size_t ufomap_map_write_ex(ufomap_map* m, const double* aabb_center, const double* aabb_half, int compress, unsigned min_depth,
+                           int compression_acceleration_level, int compression_level, int header, uint8_t* buf, size_t cap,
+                           long long* uncompressed_size);
+/* Octree::read(std::istream&) (octree.h:701-735): header + data as write() produces them; the map takes the file's
+ * resolution and depth_levels (returned through the two pointers, which may be NULL). */
+int ufomap_map_read(ufomap_map* m, const uint8_t* buf, size_t n, double* resolution, unsigned* depth_levels);
+/* Octree::readData (octree.h:737-777) -> readNodes (occupancy_map_base.h:1379-1455): the node stream of a UFOMap
+ * message / file merged into the tree -- nodes inside the bounding volume are replaced by the stream's, their
+ * ancestors re-evaluated (updateNode, pruning). */
+int ufomap_map_read_data(ufomap_map* m, const uint8_t* data, size_t n, const double* aabb_center, const double* aabb_half,
+                         double resolution, unsigned depth_levels, int uncompressed_data_size, int compressed);
+
+
 /* ---- read-back (what the reference exposes through beginLeaves()/beginTree(),
  *      occupancy_map_base.h:93-137; iterator/octree.h:133-158) -------------------------------
  * Canonical dump: node = (code >> 3*depth, depth); output sorted by (depth, code).
@@ -129,6 +188,14 @@ size_t ufomap_map_export_leaves(ufomap_map* m, int include_unknown, uint64_t* co
                                 uint8_t* depths, float* logodds, uint8_t* rgb, size_t cap);
 size_t ufomap_map_export_inner(ufomap_map* m, uint64_t* codes, uint8_t* depths, float* logodds,
                                uint8_t* flags, uint8_t* rgb, size_t cap);
+
+/* Order-independent fingerprint of the two dumps above, computed on the device in one pass (no export, no sort):
+ * per record h = mix64(mix64(code >> 3*depth | depth << 58) ^ (float32 bits | rgb24 << 32 | flags << 56)), mix64 =
+ * the splitmix64 finaliser; out[0..2] = number of leaves, sum and xor of their h (flags = 0); out[3..5] the same
+ * over the inner nodes. Equal dumps <=> equal digests (up to 2^-64); tests/golden_util.py computes the same value
+ * from a reference dump. Used for maps too large to export (config C3 at insert depth 0: 3.4e8 leaves) and by
+ * replicas of one map on several GPUs to check each other. Not part of the reference's surface. */
+int ufomap_map_digest(ufomap_map* m, int include_unknown, uint64_t out[6]);
 
 /* Octree::write(std::ostream&) (octree.h:833-868) with compress=false, min_depth=0 and no bounding volume:
  * the text header followed by the pre-order node stream of OccupancyMapBase::writeNodes

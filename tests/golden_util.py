@@ -92,3 +92,44 @@ class ServerLoop:
             lo, st = query(self.z["queries"], d)
             assert np.array_equal(np.asarray(lo).view(np.uint32), self.z[f"q{d}_logodds"].view(np.uint32)), f"{self.name}: query log-odds differ at depth {d}"
             assert np.array_equal(st, self.z[f"q{d}_state"]), f"{self.name}: query states differ at depth {d}"
+
+
+# ---- order-independent dump fingerprint (the host-side twin of ufomap_map_digest, include/ufomap_hip.h) ----------
+_M1, _M2 = np.uint64(0xBF58476D1CE4E5B9), np.uint64(0x94D049BB133111EB)
+
+
+def _mix64(z):
+    with np.errstate(over="ignore"):
+        z = (z ^ (z >> np.uint64(30))) * _M1
+        z = (z ^ (z >> np.uint64(27))) * _M2
+        return z ^ (z >> np.uint64(31))
+
+
+def _fold(h):
+    if len(h) == 0:
+        return 0, 0, 0
+    with np.errstate(over="ignore"):
+        return len(h), int(np.add.reduce(h, dtype=np.uint64)), int(np.bitwise_xor.reduce(h))
+
+
+def dump_digest(leaves, inner):
+    """(n_leaves, sum, xor, n_inner, sum, xor) of a canonical dump: ``leaves`` = (codes, depths, occ, rgb) and ``inner`` =
+    (codes, depths, occ, flags, rgb) as OracleMap / OccupancyMap return them. Equals ``OccupancyMap.digest()``."""
+    out = []
+    for dump, has_flags in ((leaves, False), (inner, True)):
+        codes, depths, occ = dump[0], dump[1], dump[2]
+        rgb = dump[4] if has_flags else dump[3]
+        key = codes.astype(np.uint64) | (depths.astype(np.uint64) << np.uint64(58))
+        val = occ.astype(np.float32).view(np.uint32).astype(np.uint64)
+        val |= (rgb[:, 0].astype(np.uint64) | (rgb[:, 1].astype(np.uint64) << np.uint64(8)) | (rgb[:, 2].astype(np.uint64) << np.uint64(16))) << np.uint64(32)
+        if has_flags:
+            val |= dump[3].astype(np.uint64) << np.uint64(56)
+        out.extend(_fold(_mix64(_mix64(key) ^ val)))
+    return tuple(out)
+
+
+def digests():
+    """Digest fixtures made from the unmodified reference by tests/golden/make_digests.py (configs too large for a
+    full dump in the repo or for the CPU oracle inside a test)."""
+    with open(os.path.join(GOLDEN_DIR, "digests.json")) as f:
+        return json.load(f)

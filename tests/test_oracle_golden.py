@@ -105,3 +105,37 @@ def test_port_matches_server_loop_golden(name, port_available):
         m.setValueVolume(st["clear_min"], st["clear_max"], st["clear_value"], st["clear_depth"])
     g.check_map(m)
     g.check_queries(m.query)
+
+
+@pytest.mark.parametrize("name", ["c1_full", "c2_full_x3", "c4_8poses_x2", "c5_colour_8cm"])
+def test_port_matches_reference_digests_full_size(name, port_available):
+    """Full-size BASELINE configurations: the port's dumps have the fingerprints the UNMODIFIED reference's dumps had
+    when tests/golden/make_digests.py ran (needs neither /root/reference nor oracle/_ref)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from make_digests import make_scan
+    from oracle import OracleMap
+    fx = golden_util.digests()[name]
+    m = OracleMap(kind="port", **fx["params"])
+    for i, ((gen, gkw, ikw), st) in enumerate(zip(fx["scans"], fx["steps"])):
+        origin, xyz, rgb = make_scan(gen, gkw)
+        m.insert(origin, xyz, rgb, **ikw)
+        assert golden_util.dump_digest(m.leaves(True), m.inner()) == tuple(int(v) for v in st["digest"]), f"{name}: scan {i}"
+
+
+def test_dump_digest_is_order_independent_and_sensitive():
+    rng = np.random.default_rng(0)
+    n = 1000
+    leaves = (rng.integers(0, 1 << 48, n).astype(np.uint64), rng.integers(0, 5, n).astype(np.uint8), rng.normal(size=n).astype(np.float32),
+              rng.integers(0, 256, (n, 3)).astype(np.uint8))
+    inner = (leaves[0][:100], leaves[1][:100], leaves[2][:100], rng.integers(0, 4, 100).astype(np.uint8), leaves[3][:100])
+    d0 = golden_util.dump_digest(leaves, inner)
+    perm = rng.permutation(n)
+    assert golden_util.dump_digest(tuple(a[perm] for a in leaves), inner) == d0
+    l2 = tuple(a.copy() for a in leaves)
+    l2[2][17] = np.nextafter(l2[2][17], np.float32(9))
+    assert golden_util.dump_digest(l2, inner) != d0
+    i2 = tuple(a.copy() for a in inner)
+    i2[3][5] ^= 1
+    assert golden_util.dump_digest(leaves, i2)[3:] != d0[3:] and golden_util.dump_digest(leaves, i2)[:3] == d0[:3]

@@ -22,7 +22,7 @@ SYMBOLS = [
     "ufomap_map_destroy", "ufomap_map_clear", "ufomap_map_reserve", "ufomap_map_set_scratch_limit",
     "ufomap_map_set_sensor_model", "ufomap_map_insert", "ufomap_map_insert_device", "ufomap_map_insert_pointcloud2", "ufomap_map_set_value_volume", "ufomap_map_query", "ufomap_map_clamping_thres",
     "ufomap_map_wait", "ufomap_map_done", "ufomap_map_export_leaves", "ufomap_map_export_inner",
-    "ufomap_map_write", "ufomap_map_minmax_change", "ufomap_map_reset_minmax_change", "ufomap_map_stats",
+    "ufomap_map_write", "ufomap_map_digest", "ufomap_map_minmax_change", "ufomap_map_reset_minmax_change", "ufomap_map_stats",
     "ufomap_map_last_hits", "ufomap_map_last_misses", "ufomap_map_last_counts",
     "ufomap_map_set_profiling", "ufomap_map_kernel_times", "ufomap_map_reset_kernel_times",
     "ufomap_map_scan_keys", "ufomap_map_get_keys", "ufomap_map_apply_keys", "ufomap_map_apply_keys_batch", "ufomap_map_stream", "ufomap_map_debug", "ufomap_map_set_option",
@@ -90,6 +90,7 @@ def load():
     lib.ufomap_map_export_leaves.argtypes = [vp, C.c_int, u64p, u8p, f32p, u8p, sz]
     lib.ufomap_map_export_inner.restype = sz
     lib.ufomap_map_export_inner.argtypes = [vp, u64p, u8p, f32p, u8p, u8p, sz]
+    lib.ufomap_map_digest.argtypes = [vp, C.c_int, u64p]
     lib.ufomap_map_write.restype = sz
     lib.ufomap_map_write.argtypes = [vp, u8p, sz]
     lib.ufomap_map_minmax_change.argtypes = [vp, f64p, f64p]

@@ -37,7 +37,7 @@ __device__ inline Summ blockSummary(const Table& t, const MapGeom& g, u32 s, u32
                                     float o_occ = 0.f, u32 o_fl = 0, u32 o_rgb = 0)
 {
 	Summ r;
-	const float4* pv = reinterpret_cast<const float4*>(t.occ + 8 * (size_t)s);
+	const float4* pv = reinterpret_cast<const float4*>(t.occ(s));
 	float4 a = pv[0], b = pv[1];
 	float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 	if (oc >= 0) {
@@ -93,7 +93,7 @@ __device__ inline Summ blockSummary(const Table& t, const MapGeom& g, u32 s, u32
 
 // Write a block's summary into the slot that holds the node's own value. Returns "changed"
 // (the bool updateNode returns, OMB:1215-1223 / OMC.cpp:118-121).
-// p_known: the caller already holds t.parent[s] (the wave-resident chain of k_propagate_tail prefetches it)
+// p_known: the caller already holds t.parent(s) (the wave-resident chain of k_propagate_tail prefetches it)
 template <bool WG = false>
 __device__ inline bool writeToParent(const Table& t, const MapGeom& g, u32 s, u64 lk, const Summ& sm, u32 p_known = NONE)
 {
@@ -105,10 +105,10 @@ __device__ inline bool writeToParent(const Table& t, const MapGeom& g, u32 s, u6
 		r->rgb = sm.rgb;
 		return ch;
 	}
-	u32 p = (p_known != NONE) ? p_known : t.parent[s];
+	u32 p = (p_known != NONE) ? p_known : t.parent(s);
 	u32 ci = (u32)(lk & 7);
-	float* po = t.occ + 8 * (size_t)p + ci;
-	u32 fp = aLoad<WG>(&t.flags[p]);
+	float* po = t.occ(p) + ci;
+	u32 fp = aLoad<WG>(&t.flags(p));
 	u32 old_fl = ((fp >> ci) & 1u) | (((fp >> (8 + ci)) & 1u) << 1);
 	bool ch = (*po != sm.occ) || (old_fl != sm.fl);
 	if (g.color) {
@@ -120,8 +120,8 @@ __device__ inline bool writeToParent(const Table& t, const MapGeom& g, u32 s, u6
 	if (old_fl != sm.fl) {
 		u32 setm = ((sm.fl & 1u) << ci) | (((sm.fl >> 1) & 1u) << (8 + ci));
 		u32 clrm = ((1u << ci) | (1u << (8 + ci))) & ~setm;
-		if (setm) aOr<WG>(&t.flags[p], setm);
-		if (clrm) aAnd<WG>(&t.flags[p], ~clrm);
+		if (setm) aOr<WG>(&t.flags(p), setm);
+		if (clrm) aAnd<WG>(&t.flags(p), ~clrm);
 	}
 	return ch;
 }
@@ -137,10 +137,10 @@ __device__ inline Summ readStored(const Table& t, const MapGeom& g, u32 s, u64 l
 		r.rgb = t.root->rgb;
 		return r;
 	}
-	u32 p = t.parent[s];
+	u32 p = t.parent(s);
 	u32 ci = (u32)(lk & 7);
-	u32 fp = __hip_atomic_load(&t.flags[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	r.occ = t.occ[8 * (size_t)p + ci];
+	u32 fp = __hip_atomic_load(&t.flags(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	r.occ = t.occ(p)[ci];
 	r.fl = ((fp >> ci) & 1u) | (((fp >> (8 + ci)) & 1u) << 1);
 	r.rgb = g.color ? t.rgb[8 * (size_t)p + ci] : 0u;
 	return r;
@@ -151,8 +151,8 @@ __device__ inline Summ readStored(const Table& t, const MapGeom& g, u32 s, u64 l
 template <bool WG = false>
 __device__ inline void collapseBlock(const Table& t, u32 s, u64 lk, u32 p_known = NONE)
 {
-	aOr<WG>(&t.flags[s], F_DEAD);
-	if (1 != lk) aAnd<WG>(&t.flags[(p_known != NONE) ? p_known : t.parent[s]], ~(1u << (16 + (u32)(lk & 7))));
+	aOr<WG>(&t.flags(s), F_DEAD);
+	if (1 != lk) aAnd<WG>(&t.flags((p_known != NONE) ? p_known : t.parent(s)), ~(1u << (16 + (u32)(lk & 7))));
 }
 
 __device__ inline bool sameSumm(const MapGeom& g, const Summ& a, const Summ& b)
@@ -177,7 +177,7 @@ __device__ inline void publishLast(const Table& t, const MapGeom& g, u32 s, u64 
                                    u32 p_known = NONE)
 {
 	if (1 == lk) return;
-	size_t at = 8 * (size_t)((p_known != NONE) ? p_known : t.parent[s]) + (size_t)(lk & 7);
+	size_t at = 8 * (size_t)((p_known != NONE) ? p_known : t.parent(s)) + (size_t)(lk & 7);
 	t.lu_occ[at] = pre.occ;
 	if (g.color) t.lu_rgb[at] = pre.rgb;
 	t.lu_fl[at] = (pre.fl & 3u) | (reachchg ? 0x100u : 0u) | ((phase & 0x3FFFFFu) << 9);
@@ -187,7 +187,7 @@ __device__ inline void carryTime(const Table& t, u32 s, u64 lk, u32 phase, u64 t
 {
 	u32 b = s;
 	while (1 != lk) {
-		u32 p = t.parent[b];
+		u32 p = t.parent(b);
 		u64 val = (UFO_TAG(phase) << 40) | (time << 3) | (lk & 7);
 		u64 old = atomicMax((unsigned long long*)&t.tmax[p], (unsigned long long)val);
 		if (old >= val) break;
@@ -215,7 +215,7 @@ template <bool WG = false>
 __device__ inline void markDirty(const Table& t, bool want, u32 p, u32* __restrict__ wl, u32* wl_count)
 {
 	bool first = false;
-	if (want) first = !(aOr<WG>(&t.flags[p], F_DIRTY) & F_DIRTY);
+	if (want) first = !(aOr<WG>(&t.flags(p), F_DIRTY) & F_DIRTY);
 	u32 pos = waveAppend<WG>(wl_count, first);
 	if (first) wl[pos] = p;
 }
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void k_ensure(Table t, MapGeom g, const Entry*
 				if (pos < newcap) newlist[pos] = s;
 				else atomicOr(&ctl->err, ERR_TABLE_FULL);
 				if (1 == lk) {
-					t.parent[s] = NONE;
+					t.parent(s) = NONE;
 					break;
 				}
 				u64 plk = lk >> 3;
@@ -281,8 +281,8 @@ __global__ __launch_bounds__(256) void k_ensure(Table t, MapGeom g, const Entry*
 					atomicOr(&ctl->err, ERR_TABLE_FULL);
 					break;
 				}
-				t.parent[s] = ps;
-				atomicOr(&t.flags[ps], 1u << (16 + (u32)(lk & 7)));
+				t.parent(s) = ps;
+				atomicOr(&t.flags(ps), 1u << (16 + (u32)(lk & 7)));
 				s = ps;
 				lk = plk;
 				cr = pcr;
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) void k_count_missing(Table t, const Entry* __r
 	u32 miss = 0;
 	for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
 		u32 s = tableFind(t, entries[i].lk);
-		if (s == NONE || (t.flags[s] & F_DEAD)) ++miss;
+		if (s == NONE || (t.flags(s) & F_DEAD)) ++miss;
 	}
 	for (int o = 32; o > 0; o >>= 1) miss += __shfl_xor(miss, o);
 	if (__lane_id() == 0 && miss) atomicAdd(out, miss);
@@ -321,23 +321,23 @@ __global__ __launch_bounds__(256) void k_init_new(Table t, MapGeom g, const u32*
 		float v;
 		u32 c = 0;
 		for (;;) {
-			u64 lk = t.keys[a];
+			u64 lk = t.key(a);
 			if (1 == lk) {
 				v = t.root->occ;
 				c = t.root->rgb;
 				break;
 			}
-			u32 p = t.parent[a];
-			if (t.stamp[p] != scan_id) {
+			u32 p = t.parent(a);
+			if (t.stamp(p) != scan_id) {
 				u32 ci = (u32)(lk & 7);
-				v = t.occ[8 * (size_t)p + ci];
+				v = t.occ(p)[ci];
 				if (g.color) c = t.rgb[8 * (size_t)p + ci];
 				break;
 			}
 			a = p;
 		}
 		float4 vv = make_float4(v, v, v, v);
-		float4* po = reinterpret_cast<float4*>(t.occ + 8 * (size_t)s);
+		float4* po = reinterpret_cast<float4*>(t.occ(s));
 		po[0] = vv;
 		po[1] = vv;
 		if (g.color) {
@@ -348,8 +348,8 @@ __global__ __launch_bounds__(256) void k_init_new(Table t, MapGeom g, const u32*
 		}
 		// leaf children carry the flags of a leaf with this value (OMB:1181-1189)
 		u32 masks = (isFreeV(g, v) ? F_CFREE : 0u) | (isUnknownV(g, v) ? F_CUNK : 0u);
-		u32 f = t.flags[s];
-		t.flags[s] = (f & F_INNER) | masks;
+		u32 f = t.flags(s);
+		t.flags(s) = (f & F_INNER) | masks;
 	}
 }
 
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(256) void k_apply_leaf(Table t, MapGeom g, const En
 	for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
 		Entry e = entries[i];
 		u32 s = ent_slot[i];
-		float4* po = reinterpret_cast<float4*>(t.occ + 8 * (size_t)s);
+		float4* po = reinterpret_cast<float4*>(t.occ(s));
 		float4 a = po[0], b = po[1];
 		float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 		const u32 hmask = (0 != mode) ? e.hit : 0u;
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(256) void k_apply_leaf(Table t, MapGeom g, const En
 		// the parent is re-evaluated when the stored summary changed over the whole pass, or when the last
 		// update alone changed it (its upward walk reached the parent even if the net change is nil)
 		const bool changed = writeToParent(t, g, s, e.lk, sm);
-		markDirty(t, changed || reachchg, t.parent[s], wl, &pc->wl_cnt[2]);
+		markDirty(t, changed || reachchg, t.parent(s), wl, &pc->wl_cnt[2]);
 	}
 }
 
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(256) void k_apply_values(Table t, MapGeom g, const 
 		if (i < n) {
 			const Entry e = entries[i];
 			s = ent_slot[i];
-			float4* po = reinterpret_cast<float4*>(t.occ + 8 * (size_t)s);
+			float4* po = reinterpret_cast<float4*>(t.occ(s));
 			float4 a = po[0], b = po[1];
 			float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 			// mode as in k_apply_leaf: 0 = a list of misses, 1 = a list of hits, 2 = one scan's merged list
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(256) void k_apply_values(Table t, MapGeom g, const 
 			po[1] = make_float4(v[4], v[5], v[6], v[7]);
 			t.lu_occ[8 * (size_t)s + c_last] = v_old_last;
 			t.tmax[s] = (UFO_TAG(phase) << 40) | ((time_hi | t_last) << 3) | (u64)c_last;
-			first = !(atomicOr(&t.flags[s], F_DIRTY) & F_DIRTY);
+			first = !(atomicOr(&t.flags(s), F_DIRTY) & F_DIRTY);
 		}
 		const u32 pos = waveAppend(&pc->wl_cnt[1], first);
 		if (first) wl[pos] = s;
@@ -533,8 +533,8 @@ __global__ __launch_bounds__(256) void k_finish_leaf(Table t, MapGeom g, const u
 		u32 par = NONE;
 		if (i < n) {
 			const u32 s = wl_in[i];
-			atomicAnd(&t.flags[s], ~F_DIRTY);
-			const u64 lk = t.keys[s];
+			atomicAnd(&t.flags(s), ~F_DIRTY);
+			const u64 lk = t.key(s);
 			const u64 tv = t.tmax[s];
 			const int c_last = (int)(tv & 7);
 			const u64 time = (tv >> 3) & ((1ull << 37) - 1ull);
@@ -547,7 +547,7 @@ __global__ __launch_bounds__(256) void k_finish_leaf(Table t, MapGeom g, const u
 			if (sm.collapsible) collapseBlock(t, s, lk);
 			const bool changed = writeToParent(t, g, s, lk, sm);
 			want = changed || reachchg;
-			par = t.parent[s];
+			par = t.parent(s);
 		}
 		markDirty(t, want, par, wl_out, &pc->wl_cnt[2]);
 	}
@@ -592,14 +592,14 @@ __global__ __launch_bounds__(256) void k_coarse_begin(Table t, MapGeom g, const 
 		Entry e = entries[i];
 		u32 s = ent_slot[i];
 		CoarseRec r;
-		u32 f = t.flags[s];
+		u32 f = t.flags(s);
 		r.old_flags = f;
 		r.leaf_trig = 0;
 		r.inner_mask = 0;
 		r.pad = 0;
 		u32 nf = f;
 		for (int c = 0; c < 8; ++c) {
-			float* pv = t.occ + 8 * (size_t)s + c;
+			float* pv = t.occ(s) + c;
 			float v = *pv;
 			r.old_occ[c] = v;
 			if (!((e.miss >> c) & 1)) continue;
@@ -622,7 +622,7 @@ __global__ __launch_bounds__(256) void k_coarse_begin(Table t, MapGeom g, const 
 		}
 		if (nf != f) {
 			// only CFREE/CUNK bits of this block change here; nobody else touches this word in this kernel
-			t.flags[s] = nf;
+			t.flags(s) = nf;
 		}
 		rec[i] = r;
 	}
@@ -638,9 +638,9 @@ __global__ __launch_bounds__(256) void k_coarse_down(Table t, MapGeom g, u32 lev
 	const u32 lo = ctl->dl_start[level + 1], hi = min(ctl->dl_start[level], dcap);
 	for (u32 i = lo + blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += gridDim.x * blockDim.x) {
 		const u32 s = dlist[i];
-		const u64 lk = t.keys[s];
-		const u32 f = t.flags[s];
-		float4* po = reinterpret_cast<float4*>(t.occ + 8 * (size_t)s);
+		const u64 lk = t.key(s);
+		const u32 f = t.flags(s);
+		float4* po = reinterpret_cast<float4*>(t.occ(s));
 		float4 a = po[0], b = po[1];
 		float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 		u32 nf = f;
@@ -666,7 +666,7 @@ __global__ __launch_bounds__(256) void k_coarse_down(Table t, MapGeom g, u32 lev
 		if (changed) {
 			po[0] = make_float4(v[0], v[1], v[2], v[3]);
 			po[1] = make_float4(v[4], v[5], v[6], v[7]);
-			t.flags[s] = nf | F_SUB;  // this block's word is private to this thread until the up pass
+			t.flags(s) = nf | F_SUB;  // this block's word is private to this thread until the up pass
 		}
 	}
 }
@@ -678,12 +678,12 @@ __global__ __launch_bounds__(256) void k_coarse_up(Table t, MapGeom g, u32 level
 	const u32 lo = ctl->dl_start[level + 1], hi = min(ctl->dl_start[level], dcap);
 	for (u32 i = lo + blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += gridDim.x * blockDim.x) {
 		const u32 s = dlist[i];
-		u32 f = atomicAnd(&t.flags[s], ~F_SUB);
+		u32 f = atomicAnd(&t.flags(s), ~F_SUB);
 		if (!(f & F_SUB)) continue;  // nothing changed beneath: the reference does not call updateNode either
-		const u64 lk = t.keys[s];
+		const u64 lk = t.key(s);
 		Summ sm = blockSummary(t, g, s, level, f);
 		if (sm.collapsible) collapseBlock(t, s, lk);
-		if (writeToParent(t, g, s, lk, sm)) atomicOr(&t.flags[t.parent[s]], F_SUB);
+		if (writeToParent(t, g, s, lk, sm)) atomicOr(&t.flags(t.parent(s)), F_SUB);
 	}
 }
 
@@ -698,7 +698,7 @@ __global__ __launch_bounds__(256) void k_coarse_end(Table t, MapGeom g, const En
 		const u32 s = ent_slot[i];
 		const u32 level = e.level;
 		const CoarseRec r = rec[i];
-		u32 f = atomicAnd(&t.flags[s], ~F_SUB);  // SUB may have been set by expanded children; not needed here
+		u32 f = atomicAnd(&t.flags(s), ~F_SUB);  // SUB may have been set by expanded children; not needed here
 		f &= ~F_SUB;
 		const int c_last = (int)e.c_last;  // highest miss child = the reference's last updateValue on this block
 		// which children "triggered" a walk up to this block (see header): leaf -> flags changed;
@@ -706,7 +706,7 @@ __global__ __launch_bounds__(256) void k_coarse_end(Table t, MapGeom g, const En
 		u32 trig = r.leaf_trig;
 		float cur[8];
 		for (int c = 0; c < 8; ++c) {
-			cur[c] = t.occ[8 * (size_t)s + c];
+			cur[c] = t.occ(s)[c];
 			if ((r.inner_mask >> c) & 1u) {
 				u32 ob = r.old_flags & ((1u << c) | (1u << (8 + c))), nb = f & ((1u << c) | (1u << (8 + c)));
 				if (cur[c] != r.old_occ[c] || ob != nb) trig |= 1u << c;
@@ -750,8 +750,8 @@ __global__ __launch_bounds__(256) void k_coarse_end(Table t, MapGeom g, const En
 			}
 			fin = sm;
 			if (writeToParent(t, g, s, e.lk, sm) && 1 != e.lk) {
-				u32 pp = t.parent[s];
-				if (!(atomicOr(&t.flags[pp], F_DIRTY) & F_DIRTY)) wl[atomicAdd(&pc->wl_cnt[level + 1], 1u)] = pp;
+				u32 pp = t.parent(s);
+				if (!(atomicOr(&t.flags(pp), F_DIRTY) & F_DIRTY)) wl[atomicAdd(&pc->wl_cnt[level + 1], 1u)] = pp;
 			}
 		}
 		publishLast(t, g, s, e.lk, phase, last_reached && !sameSumm(g, pre, fin), pre);
@@ -764,7 +764,7 @@ __global__ __launch_bounds__(256) void k_coarse_end(Table t, MapGeom g, const En
 template <bool WG>
 __device__ inline bool propagateCore(const Table& t, const MapGeom& g, u32 s, u32 old, u32 phase, u32* par)
 {
-	const u64 lk = t.keys[s];
+	const u64 lk = t.key(s);
 	const u32 level = levelOf(g, lk);
 	Summ sm = blockSummary(t, g, s, level, old);
 	Summ pre = sm;
@@ -774,7 +774,7 @@ __device__ inline bool propagateCore(const Table& t, const MapGeom& g, u32 s, u3
 	const bool reachchg = reached && !sameSumm(g, pre, sm);
 	publishLast(t, g, s, lk, phase, reachchg, pre);
 	const bool want = (changed || reachchg) && 1 != lk;
-	if (want) *par = t.parent[s];
+	if (want) *par = t.parent(s);
 	return want;
 }
 
@@ -802,7 +802,7 @@ __device__ inline void propagateOne(const Table& t, const MapGeom& g, bool valid
 	bool want = false;
 	u32 par = NONE;
 	if (valid) {
-		const u32 old = aAnd<WG>(&t.flags[s], ~F_DIRTY);
+		const u32 old = aAnd<WG>(&t.flags(s), ~F_DIRTY);
 		want = propagateCore<WG>(t, g, s, old, phase, &par);
 	}
 	markDirty<WG>(t, want, par, wl_out, cnt_out);
@@ -850,9 +850,9 @@ __global__ __launch_bounds__(1024) void k_propagate_tail(Table t, MapGeom g, u32
 			u64 lk = 1, tv = 0;
 			u32 ps = NONE;
 			if (s != NONE) {
-				lk = t.keys[s];
+				lk = t.key(s);
 				tv = t.tmax[s];
-				ps = (1 != lk) ? t.parent[s] : NONE;
+				ps = (1 != lk) ? t.parent(s) : NONE;
 			}
 			bool first = true;
 			for (u32 guard = 0; guard < 32u; ++guard) {
@@ -864,10 +864,10 @@ __global__ __launch_bounds__(1024) void k_propagate_tail(Table t, MapGeom g, u32
 				if (valid) {
 					if (1 != lk) {
 						tv_n = t.tmax[ps];
-						pp_n = (1 != (lk >> 3)) ? t.parent[ps] : NONE;
+						pp_n = (1 != (lk >> 3)) ? t.parent(ps) : NONE;
 					}
 					// items of the first round came off the worklist (DIRTY set); later rounds were never queued
-					const u32 old = first ? aAnd<true>(&t.flags[s], ~F_DIRTY) : aLoad<true>(&t.flags[s]);
+					const u32 old = first ? aAnd<true>(&t.flags(s), ~F_DIRTY) : aLoad<true>(&t.flags(s));
 					want = propagateCoreKnown<true>(t, g, s, old, phase, lk, tv, ps);
 				}
 				first = false;
@@ -978,18 +978,18 @@ __global__ __launch_bounds__(256) void k_vol_down(Table t, MapGeom g, VolArgs a,
 			float v;
 			u32 col = 0;
 			if (1 == me.lk) {
-				t.parent[s] = NONE;
+				t.parent(s) = NONE;
 				v = t.root->occ;
 				col = t.root->rgb;
 			} else {
 				const u32 p = rec[me.parent].slot, ci = (u32)(me.lk & 7);
-				t.parent[s] = p;
-				atomicOr(&t.flags[p], 1u << (16 + ci));
-				v = t.occ[8 * (size_t)p + ci];
+				t.parent(s) = p;
+				atomicOr(&t.flags(p), 1u << (16 + ci));
+				v = t.occ(p)[ci];
 				if (g.color) col = t.rgb[8 * (size_t)p + ci];
 			}
 			float4 vv = make_float4(v, v, v, v);
-			float4* po = reinterpret_cast<float4*>(t.occ + 8 * (size_t)s);
+			float4* po = reinterpret_cast<float4*>(t.occ(s));
 			po[0] = vv;
 			po[1] = vv;
 			if (g.color) {
@@ -999,7 +999,7 @@ __global__ __launch_bounds__(256) void k_vol_down(Table t, MapGeom g, VolArgs a,
 				pc[1] = cc;
 			}
 			// leaf children carry the flags of a leaf with this value (as k_init_new; OMB:1181-1189)
-			t.flags[s] = (isFreeV(g, v) ? F_CFREE : 0u) | (isUnknownV(g, v) ? F_CUNK : 0u);
+			t.flags(s) = (isFreeV(g, v) ? F_CFREE : 0u) | (isUnknownV(g, v) ? F_CUNK : 0u);
 		}
 		u32 changed = 0;
 		for (u32 i = 0; i < 8; ++i) {
@@ -1008,7 +1008,7 @@ __global__ __launch_bounds__(256) void k_vol_down(Table t, MapGeom g, VolArgs a,
 			cc[1] += ((i & 2) ? chs : -chs);
 			cc[2] += ((i & 4) ? chs : -chs);
 			if (!volIntersects(a, cc, chs)) continue;
-			float* pv = t.occ + 8 * (size_t)s + i;
+			float* pv = t.occ(s) + i;
 			if (0 == child_depth) {
 				if (*pv != a.val) changed = 1;  // setOccupancy (OMB:1151-1157)
 				*pv = a.val;
@@ -1030,7 +1030,7 @@ __global__ __launch_bounds__(256) void k_vol_down(Table t, MapGeom g, VolArgs a,
 				}
 			} else {
 				// deleteChildren(child) + setOccupancy(child) + updateNode(child), the child now a leaf (OMB:1019-1026)
-				const u32 f = __hip_atomic_load(&t.flags[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				const u32 f = __hip_atomic_load(&t.flags(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				if (f & (1u << (16 + i))) {
 					const u32 cs = tableFind(t, (me.lk << 3) | (u64)i);
 					if (cs != NONE) {
@@ -1038,14 +1038,14 @@ __global__ __launch_bounds__(256) void k_vol_down(Table t, MapGeom g, VolArgs a,
 						if (kp < kcap) kill[kp] = cs;
 						else atomicOr(&ctl->err, ERR_ENTRIES);
 					}
-					atomicAnd(&t.flags[s], ~(1u << (16 + i)));
+					atomicAnd(&t.flags(s), ~(1u << (16 + i)));
 				}
 				if (*pv != a.val) changed = 1;
 				*pv = a.val;
 				const u32 nf = isFreeV(g, a.val) ? 1u : 0u, nu = isUnknownV(g, a.val) ? 1u : 0u;
 				if (((f >> i) & 1u) != nf || ((f >> (8 + i)) & 1u) != nu) changed = 1;  // updateNode, leaf branch (OMB:1181-1189)
-				atomicAnd(&t.flags[s], ~((1u << i) | (1u << (8 + i))));
-				if (nf | nu) atomicOr(&t.flags[s], (nf << i) | (nu << (8 + i)));
+				atomicAnd(&t.flags(s), ~((1u << i) | (1u << (8 + i))));
+				if (nf | nu) atomicOr(&t.flags(s), (nf << i) | (nu << (8 + i)));
 			}
 		}
 		rec[r].changed = changed;
@@ -1071,8 +1071,8 @@ __global__ __launch_bounds__(256) void k_vol_kill(Table t, u32* __restrict__ kil
 	const u32 lo = (u32)ctl->dbg[56], hi = min((u32)ctl->dbg[57], kcap);
 	for (u32 k = lo + blockIdx.x * blockDim.x + threadIdx.x; k < hi; k += gridDim.x * blockDim.x) {
 		const u32 s = kill[k];
-		const u32 f = t.flags[s];
-		const u64 lk = t.keys[s];
+		const u32 f = t.flags(s);
+		const u64 lk = t.key(s);
 		for (u32 i = 0; i < 8; ++i) {
 			if (!(f & (1u << (16 + i)))) continue;
 			const u32 cs = tableFind(t, (lk << 3) | (u64)i);
@@ -1081,7 +1081,7 @@ __global__ __launch_bounds__(256) void k_vol_kill(Table t, u32* __restrict__ kil
 			if (kp < kcap) kill[kp] = cs;
 			else atomicOr(&ctl->err, ERR_ENTRIES);
 		}
-		t.flags[s] = (f & ~(F_INNER | F_DIRTY | F_SUB)) | F_DEAD;  // a revived block starts without inner children
+		t.flags(s) = (f & ~(F_INNER | F_DIRTY | F_SUB)) | F_DEAD;  // a revived block starts without inner children
 	}
 }
 
@@ -1095,7 +1095,7 @@ __global__ __launch_bounds__(256) void k_vol_up(Table t, MapGeom g, u32 cd, VolR
 		bool ret = true;
 		if (me.changed) {
 			// updateNode of a node with children (OMB:1191-1224): summary, collapse, compare
-			const u32 f = t.flags[me.slot];
+			const u32 f = t.flags(me.slot);
 			const Summ sm = blockSummary(t, g, me.slot, cd, f);
 			if (sm.collapsible) collapseBlock(t, me.slot, me.lk);
 			ret = writeToParent(t, g, me.slot, me.lk, sm);
@@ -1109,8 +1109,8 @@ __global__ __launch_bounds__(256) void k_vol_root(Table t, MapGeom g, float val)
 {
 	const u32 ncap = t.mask + 1;
 	for (u32 s = blockIdx.x * blockDim.x + threadIdx.x; s < ncap; s += gridDim.x * blockDim.x) {
-		if (0 == t.keys[s]) continue;
-		t.flags[s] = (t.flags[s] & ~(F_INNER | F_DIRTY | F_SUB)) | F_DEAD;
+		if (0 == t.key(s)) continue;
+		t.flags(s) = (t.flags(s) & ~(F_INNER | F_DIRTY | F_SUB)) | F_DEAD;
 	}
 	if (0 == blockIdx.x && 0 == threadIdx.x) {
 		t.root->occ = val;
@@ -1136,21 +1136,21 @@ __global__ __launch_bounds__(256) void k_query(Table t, MapGeom g, const double*
 		u32 rd = depth;
 		u64 bkey = 1;  // key of the current node's children block
 		u32 bs = tableFind(t, bkey);
-		bool leaf = bs == NONE || (t.flags[bs] & F_DEAD);
+		bool leaf = bs == NONE || (t.flags(bs) & F_DEAD);
 		for (u32 d = g.L - 1; d > depth; --d) {
 			if (leaf) {  // !hasChildren (octree.h:979-981)
 				rd = d + 1;
 				break;
 			}
 			const u32 ci = (u32)((code >> (3 * d)) & 7);  // getChildIdx (code.h:245-248)
-			const u32 f = t.flags[bs];
-			occ = t.occ[8 * (size_t)bs + ci];
+			const u32 f = t.flags(bs);
+			occ = t.occ(bs)[ci];
 			fl = ((f >> ci) & 1u) | (((f >> (8 + ci)) & 1u) << 1);
 			bkey = (bkey << 3) | (u64)ci;
 			leaf = true;
 			if (f & (1u << (16 + ci))) {
 				bs = tableFind(t, bkey);
-				leaf = bs == NONE || (t.flags[bs] & F_DEAD);
+				leaf = bs == NONE || (t.flags(bs) & F_DEAD);
 			}
 		}
 		logodds[q] = occ;
@@ -1176,16 +1176,16 @@ __global__ __launch_bounds__(256) void k_export_leaves(Table t, MapGeom g, int i
 {
 	u32 ncap = t.mask + 1;
 	for (u32 s = blockIdx.x * blockDim.x + threadIdx.x; s < ncap; s += gridDim.x * blockDim.x) {
-		u64 lk = t.keys[s];
+		u64 lk = t.key(s);
 		if (0 == lk) continue;
-		u32 f = t.flags[s];
+		u32 f = t.flags(s);
 		if (f & F_DEAD) continue;
 		u32 level = levelOf(g, lk);
 		u64 p = lk ^ (1ULL << (3 * (g.L - level)));
 		atomicAdd(&dc->n_live, 1ULL);
 		for (u32 i = 0; i < 8; ++i) {
 			if (level > 1 && ((f >> (16 + i)) & 1u)) continue;
-			float v = t.occ[8 * (size_t)s + i];
+			float v = t.occ(s)[i];
 			atomicAdd(&dc->n_leaf, 1ULL);
 			if (!include_unknown && isUnknownV(g, v)) continue;
 			unsigned long long pos = atomicAdd(&dc->n_out, 1ULL);
@@ -1205,9 +1205,9 @@ __global__ __launch_bounds__(256) void k_export_inner(Table t, MapGeom g, u64* _
 {
 	u32 ncap = t.mask + 1;
 	for (u32 s = blockIdx.x * blockDim.x + threadIdx.x; s < ncap; s += gridDim.x * blockDim.x) {
-		u64 lk = t.keys[s];
+		u64 lk = t.key(s);
 		if (0 == lk) continue;
-		u32 f = t.flags[s];
+		u32 f = t.flags(s);
 		if (f & F_DEAD) continue;
 		u32 level = levelOf(g, lk);
 		unsigned long long pos = atomicAdd(&dc->n_out, 1ULL);
@@ -1219,12 +1219,84 @@ __global__ __launch_bounds__(256) void k_export_inner(Table t, MapGeom g, u64* _
 			flags[pos] = (uint8_t)(t.root->flags & 3u);
 			rgb[pos] = t.root->rgb;
 		} else {
-			u32 p = t.parent[s];
+			u32 p = t.parent(s);
 			u32 ci = (u32)(lk & 7);
-			u32 fp = t.flags[p];
-			occ[pos] = t.occ[8 * (size_t)p + ci];
+			u32 fp = t.flags(p);
+			occ[pos] = t.occ(p)[ci];
 			flags[pos] = (uint8_t)(((fp >> ci) & 1u) | (((fp >> (8 + ci)) & 1u) << 1));
 			rgb[pos] = t.rgb ? t.rgb[8 * (size_t)p + ci] : 0u;
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// Order-independent fingerprint of the canonical dump (ufomap_map_digest): per record
+//   h = mix64(mix64(code >> 3*depth | depth << 58) ^ (float bits | rgb << 32 | flags << 56))
+// out[0..2] = count, sum, xor over the leaves; out[3..5] the same over the inner nodes. Maps that are too large to
+// export and sort on the host (config C3 at insert depth 0: 3.4e8 leaves) are compared through it, and replicas of
+// one map on several GPUs can check each other with 48 bytes.
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ inline u64 mix64(u64 z)
+{
+	z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+	z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+	return z ^ (z >> 31);
+}
+__host__ __device__ inline u64 digestRecord(u64 code_shifted, u32 depth, float occ, u32 rgb, u32 flags)
+{
+	u32 ob;
+	memcpy(&ob, &occ, 4);
+	return mix64(mix64(code_shifted | ((u64)depth << 58)) ^ ((u64)ob | ((u64)(rgb & 0xFFFFFFu) << 32) | ((u64)(flags & 0xFFu) << 56)));
+}
+__global__ __launch_bounds__(256) void k_digest(Table t, MapGeom g, int include_unknown, unsigned long long* __restrict__ out)
+{
+	u32 ncap = t.mask + 1;
+	u64 acc[6] = {0, 0, 0, 0, 0, 0};
+	for (u32 s = blockIdx.x * blockDim.x + threadIdx.x; s < ncap; s += gridDim.x * blockDim.x) {
+		const u64 lk = t.key(s);
+		if (0 == lk) continue;
+		const u32 f = t.flags(s);
+		if (f & F_DEAD) continue;
+		const u32 level = levelOf(g, lk);
+		const u64 p = lk ^ (1ULL << (3 * (g.L - level)));
+		{
+			float v;
+			u32 fl, c;
+			if (1 == lk) {
+				v = t.root->occ;
+				fl = t.root->flags & 3u;
+				c = t.root->rgb;
+			} else {
+				const u32 pp = t.parent(s), ci = (u32)(lk & 7), fp = t.flags(pp);
+				v = t.occ(pp)[ci];
+				fl = ((fp >> ci) & 1u) | (((fp >> (8 + ci)) & 1u) << 1);
+				c = t.rgb ? t.rgb[8 * (size_t)pp + ci] : 0u;
+			}
+			const u64 h = digestRecord(p, level, v, c, fl);
+			acc[3] += 1;
+			acc[4] += h;
+			acc[5] ^= h;
+		}
+		for (u32 i = 0; i < 8; ++i) {
+			if (level > 1 && ((f >> (16 + i)) & 1u)) continue;
+			const float v = t.occ(s)[i];
+			if (!include_unknown && isUnknownV(g, v)) continue;
+			const u64 h = digestRecord((p << 3) | (u64)i, level - 1, v, t.rgb ? t.rgb[8 * (size_t)s + i] : 0u, 0u);
+			acc[0] += 1;
+			acc[1] += h;
+			acc[2] ^= h;
+		}
+	}
+	for (int k = 0; k < 6; ++k) {
+		u64 v = acc[k];
+		const bool x = (2 == k || 5 == k);
+		for (int o = 32; o > 0; o >>= 1) {
+			const u64 w = __shfl_xor(v, o);
+			v = x ? (v ^ w) : (v + w);
+		}
+		if (0 == __lane_id() && v) {
+			if (x) atomicXor(&out[k], (unsigned long long)v);
+			else atomicAdd(&out[k], (unsigned long long)v);
 		}
 	}
 }
@@ -1240,8 +1312,8 @@ __global__ __launch_bounds__(256) void k_ser_count(Table t, MapGeom g, u32* __re
 {
 	u32 ncap = t.mask + 1;
 	for (u32 s = blockIdx.x * blockDim.x + threadIdx.x; s < ncap; s += gridDim.x * blockDim.x) {
-		u64 lk = t.keys[s];
-		if (0 == lk || (t.flags[s] & F_DEAD)) continue;
+		u64 lk = t.key(s);
+		if (0 == lk || (t.flags(s) & F_DEAD)) continue;
 		atomicAdd(&level_cnt[levelOf(g, lk)], 1u);
 	}
 }
@@ -1250,8 +1322,8 @@ __global__ __launch_bounds__(256) void k_ser_collect(Table t, MapGeom g, const u
 {
 	u32 ncap = t.mask + 1;
 	for (u32 s = blockIdx.x * blockDim.x + threadIdx.x; s < ncap; s += gridDim.x * blockDim.x) {
-		u64 lk = t.keys[s];
-		if (0 == lk || (t.flags[s] & F_DEAD)) continue;
+		u64 lk = t.key(s);
+		if (0 == lk || (t.flags(s) & F_DEAD)) continue;
 		u32 l = levelOf(g, lk);
 		list[level_off[l] + atomicAdd(&level_fill[l], 1u)] = s;
 	}
@@ -1265,8 +1337,8 @@ __global__ __launch_bounds__(256) void k_ser_sizes(Table t, MapGeom g, const u32
 			size[s] = 8ull * D;
 			continue;
 		}
-		const u64 lk = t.keys[s];
-		const u32 f = t.flags[s];
+		const u64 lk = t.key(s);
+		const u32 f = t.flags(s);
 		u64 sz = 1;
 		for (u32 c = 0; c < 8; ++c) {
 			if ((f >> (16 + c)) & 1u) {
@@ -1298,9 +1370,9 @@ __global__ __launch_bounds__(256) void k_ser_write(Table t, MapGeom g, const u32
 {
 	for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
 		const u32 s = list[i];
-		const u64 lk = t.keys[s];
+		const u64 lk = t.key(s);
 		u64 at = (1 == lk) ? 1ull : off[s];  // the root's subtree starts behind the 0xFF byte of writeNodes
-		const u32 f = t.flags[s];
+		const u32 f = t.flags(s);
 		if (level >= 2) out[at++] = (uint8_t)((f >> 16) & 0xFFu);
 		for (u32 c = 0; c < 8; ++c) {
 			if (level >= 2 && ((f >> (16 + c)) & 1u)) {
@@ -1311,7 +1383,7 @@ __global__ __launch_bounds__(256) void k_ser_write(Table t, MapGeom g, const u32
 					continue;
 				}
 			}
-			serPutLeaf(out, at, t.occ[8 * (size_t)s + c], t.rgb ? t.rgb[8 * (size_t)s + c] : 0u, D);
+			serPutLeaf(out, at, t.occ(s)[c], t.rgb ? t.rgb[8 * (size_t)s + c] : 0u, D);
 			at += D;
 		}
 	}
@@ -1324,12 +1396,12 @@ __global__ __launch_bounds__(256) void k_rehash_copy(Table src, Table dst, u32* 
 {
 	u32 ncap = src.mask + 1;
 	for (u32 s = blockIdx.x * blockDim.x + threadIdx.x; s < ncap; s += gridDim.x * blockDim.x) {
-		u64 lk = src.keys[s];
+		u64 lk = src.key(s);
 		if (0 == lk) continue;
 		u32 d = hash64(lk) & dst.mask;
 		bool ok = false;
 		for (u32 probe = 0; probe <= dst.mask; ++probe) {
-			u64 prev = atomicCAS((unsigned long long*)&dst.keys[d], 0ULL, (unsigned long long)lk);
+			u64 prev = atomicCAS((unsigned long long*)&dst.key(d), 0ULL, (unsigned long long)lk);
 			if (prev == 0) {
 				ok = true;
 				break;
@@ -1340,8 +1412,8 @@ __global__ __launch_bounds__(256) void k_rehash_copy(Table src, Table dst, u32* 
 			atomicOr(fail, 1u);
 			continue;
 		}
-		const float4* so = reinterpret_cast<const float4*>(src.occ + 8 * (size_t)s);
-		float4* dofs = reinterpret_cast<float4*>(dst.occ + 8 * (size_t)d);
+		const float4* so = reinterpret_cast<const float4*>(src.occ(s));
+		float4* dofs = reinterpret_cast<float4*>(dst.occ(d));
 		dofs[0] = so[0];
 		dofs[1] = so[1];
 		if (src.rgb) {
@@ -1350,17 +1422,17 @@ __global__ __launch_bounds__(256) void k_rehash_copy(Table src, Table dst, u32* 
 			dcl[0] = sc[0];
 			dcl[1] = sc[1];
 		}
-		dst.flags[d] = src.flags[s];
-		dst.stamp[d] = src.stamp[s];
+		dst.flags(d) = src.flags(s);
+		dst.stamp(d) = src.stamp(s);
 	}
 }
 __global__ __launch_bounds__(256) void k_rehash_parents(Table dst)
 {
 	u32 ncap = dst.mask + 1;
 	for (u32 s = blockIdx.x * blockDim.x + threadIdx.x; s < ncap; s += gridDim.x * blockDim.x) {
-		u64 lk = dst.keys[s];
+		u64 lk = dst.key(s);
 		if (0 == lk) continue;
-		dst.parent[s] = (1 == lk) ? NONE : tableFind(dst, lk >> 3);
+		dst.parent(s) = (1 == lk) ? NONE : tableFind(dst, lk >> 3);
 	}
 }
 }  // namespace ufo

@@ -4,17 +4,18 @@
 // createChildren/deleteChildren with new/delete of 8-child arrays). One table slot = one 8-child
 // node block, i.e. the `children` array of one inner node:
 //
-//   keys[s]    u64   location key of the inner node:  (1 << 3*(L-d)) | (code >> 3*d), d = node depth
+// (struct Block below; rgb and the last-update records are separate arrays)
+//   key        u64   location key of the inner node:  (1 << 3*(L-d)) | (code >> 3*d), d = node depth
 //                    (sentinel bit encodes the depth; root = 1; 0 = empty slot)
-//   occ[8*s+i] f32   log-odds of child i (child index = x | y<<1 | z<<2, map/code.h:245-248)
+//   occ[i]     f32   log-odds of child i (child index = x | y<<1 | z<<2, map/code.h:245-248)
 //   rgb[8*s+i] u32   r | g<<8 | b<<16 of child i (colour maps only)
-//   flags[s]   u32   bits 0-7  contains_free of child i      (map/occupancy_map_node.h:171-176)
+//   flags      u32   bits 0-7  contains_free of child i      (map/occupancy_map_node.h:171-176)
 //                    bits 8-15 contains_unknown of child i
 //                    bits 16-23 child i is an inner node with a live block of its own
 //                    bit 24 DIRTY (queued for propagation), 25 DEAD (collapsed: the node is a leaf
 //                    again, octree.h:1060-1066), 26 SUB (changed during a coarse-miss subtree update)
-//   parent[s]  u32   slot of the block that holds this node's own value (NONE for the root)
-//   stamp[s]   u32   id of the phase that created / revived the block ("new this phase")
+//   parent     u32   slot of the block that holds this node's own value (NONE for the root)
+//   stamp      u32   id of the phase that created / revived the block ("new this phase")
 //   tmax[s]    u64   (phase tag << 40) | (time of the last update beneath this node << 3) | child index
 //                    that update lies under ("time": point index for hits = cloud order, 0 for misses =
 //                    ascending code order; see map_kernels.h "last-update chain")
@@ -47,19 +48,33 @@ struct MapRoot {
 	u32 used;  // number of occupied table slots
 };
 
+// One table slot: the record of one 8-child node block, 64 bytes, 64-byte aligned -- what a lookup finds (the key),
+// what an update reads and writes (the 8 child values) and what the walk up needs (flags, parent) arrive with ONE
+// memory transaction. (Round 1 kept these as separate arrays: one block touch pulled five cache lines.)
+struct alignas(64) Block {
+	float occ[8];  // log-odds of the 8 children; 16-byte aligned for float4 access
+	u64 key;       // location key, 0 = empty slot
+	u32 flags;
+	u32 parent;
+	u32 stamp;
+	u32 pad[3];
+};
+static_assert(sizeof(Block) == 64, "Block must be one 64-byte record");
+
 struct Table {
-	u64* keys;
-	float* occ;
-	u32* rgb;  // nullptr for non-colour maps
-	u32* flags;
-	u32* parent;
-	u32* stamp;
+	Block* blk;
+	u32* rgb;  // [8*slot + child], colour maps only (nullptr otherwise)
 	u64* tmax;
 	float* lu_occ;  // [8*slot + child]: last-update record published by child `child` of this block
 	u32* lu_fl;     // bit0/1 = contains_free/unknown of the pre-last summary, bit 8 = "reached and changed", 9.. = phase tag
 	u32* lu_rgb;    // colour maps only
 	MapRoot* root;
 	u32 mask;  // capacity - 1
+	__device__ __forceinline__ u64& key(u32 s) const { return blk[s].key; }
+	__device__ __forceinline__ float* occ(u32 s) const { return blk[s].occ; }
+	__device__ __forceinline__ u32& flags(u32 s) const { return blk[s].flags; }
+	__device__ __forceinline__ u32& parent(u32 s) const { return blk[s].parent; }
+	__device__ __forceinline__ u32& stamp(u32 s) const { return blk[s].stamp; }
 };
 
 __device__ inline u32 hash64(u64 k)
@@ -77,7 +92,7 @@ __device__ inline u32 tableFind(const Table& t, u64 lk)
 {
 	u32 s = hash64(lk) & t.mask;
 	for (u32 probe = 0; probe <= t.mask; ++probe) {
-		u64 k = __hip_atomic_load(&t.keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		u64 k = __hip_atomic_load(&t.key(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		if (k == lk) return s;
 		if (k == 0) return NONE;
 		s = (s + 1) & t.mask;
@@ -92,12 +107,12 @@ __device__ inline u32 tableEnsure(const Table& t, u64 lk, u32 scan_id, u32 max_p
 	u32 s = hash64(lk) & t.mask;
 	*created = false;
 	for (u32 probe = 0; probe < max_probe; ++probe) {
-		u64 k = __hip_atomic_load(&t.keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		u64 k = __hip_atomic_load(&t.key(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		if (k == 0) {
-			u64 prev = atomicCAS((unsigned long long*)&t.keys[s], 0ULL, (unsigned long long)lk);
+			u64 prev = atomicCAS((unsigned long long*)&t.key(s), 0ULL, (unsigned long long)lk);
 			if (prev == 0) {
 				// empty slots have flags == 0 (table is zero-filled and never shrinks)
-				t.stamp[s] = scan_id;
+				t.stamp(s) = scan_id;
 				++*n_created;  // the caller adds these to MapRoot::used once per wave
 				*created = true;
 				return s;
@@ -105,11 +120,11 @@ __device__ inline u32 tableEnsure(const Table& t, u64 lk, u32 scan_id, u32 max_p
 			k = prev;
 		}
 		if (k == lk) {
-			u32 f = __hip_atomic_load(&t.flags[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			u32 f = __hip_atomic_load(&t.flags(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			if (f & F_DEAD) {
-				u32 old = atomicAnd(&t.flags[s], ~F_DEAD);
+				u32 old = atomicAnd(&t.flags(s), ~F_DEAD);
 				if (old & F_DEAD) {
-					t.stamp[s] = scan_id;
+					t.stamp(s) = scan_id;
 					*created = true;
 				}
 			}

@@ -89,10 +89,10 @@ struct PendingEvent {
 };
 
 struct TableBufs {
-	DevBuf keys, occ, rgb, flags, parent, stamp, tmax, luph, luocc, lufl, lurgb;
+	DevBuf blk, rgb, tmax, luocc, lufl, lurgb;
 	void release()
 	{
-		DevBuf* all[] = {&keys, &occ, &rgb, &flags, &parent, &stamp, &tmax, &luph, &luocc, &lufl, &lurgb};
+		DevBuf* all[] = {&blk, &rgb, &tmax, &luocc, &lufl, &lurgb};
 		for (DevBuf* b : all) b->release();
 	}
 };
@@ -124,6 +124,8 @@ struct ScanArgs {
 struct HandOver {
 	DevBuf b_ctl, b_entries, b_hh_keys, b_in_xyz, b_in_rgb;  // b_hh_keys: hit hash, keys followed by point indices
 	ScanCtl* h_ctl = nullptr;  // pinned
+	void* h_stage = nullptr;   // pinned staging of a pageable host cloud (ufomap_map_insert): filled by the host, drained by
+	size_t h_stage_cap = 0;    // an asynchronous H2D copy on the scan stream; free again once the set's integration is joined
 	u32 hh_mask = 0;
 	uint64_t counts[8] = {0};
 	ScanArgs args;
@@ -161,6 +163,9 @@ struct ufomap_map {
 	DevBuf b_crec, b_dlist, b_rays;
 	DevBuf b_gridM, b_entries, b_ent_slot, b_newlist, b_wl0, b_wl1, b_in_xyz, b_in_rgb, b_codes, b_dump;
 	ScanCtl* h_ctl = nullptr;  // pinned
+	void* h_stage = nullptr;   // pinned staging buffer of the current hand-over set (HandOver::h_stage)
+	size_t h_stage_cap = 0;
+	hipEvent_t copy_ev = nullptr;  // end of the H2D copy of a cloud that lies in caller-owned pinned memory
 	MapRoot* h_root = nullptr;  // pinned
 	size_t scratch_limit = 16ull << 30;
 	// state of the last integration
@@ -270,33 +275,24 @@ inline dim3 gridFor(u64 n, u32 block = 256, u32 maxBlocks = 4096)
 
 int allocTable(ufomap_map* m, u32 cap, Table* out, TableBufs* tb)
 {
-	DevBuf *keys = &tb->keys, *occ = &tb->occ, *rgb = &tb->rgb, *flags = &tb->flags, *parent = &tb->parent, *stamp = &tb->stamp;
+	HIP_TRY(tb->blk.reserve((size_t)cap * sizeof(Block)));
 	HIP_TRY(tb->tmax.reserve((size_t)cap * 8));
 	HIP_TRY(tb->luocc.reserve((size_t)cap * 32));
 	HIP_TRY(tb->lufl.reserve((size_t)cap * 32));
-	if (m->g.color) HIP_TRY(tb->lurgb.reserve((size_t)cap * 32));
+	if (m->g.color) {
+		HIP_TRY(tb->rgb.reserve((size_t)cap * 32));
+		HIP_TRY(tb->lurgb.reserve((size_t)cap * 32));
+	}
+	// an empty slot is all zeros: key 0, flags 0, stamp 0 (values and parent are written when a block is created)
+	HIP_TRY(hipMemsetAsync(tb->blk.p, 0, (size_t)cap * sizeof(Block), m->stream));
 	HIP_TRY(hipMemsetAsync(tb->tmax.p, 0, (size_t)cap * 8, m->stream));
 	HIP_TRY(hipMemsetAsync(tb->lufl.p, 0, (size_t)cap * 32, m->stream));
+	out->blk = tb->blk.as<Block>();
+	out->rgb = m->g.color ? tb->rgb.as<u32>() : nullptr;
 	out->tmax = tb->tmax.as<u64>();
 	out->lu_occ = tb->luocc.as<float>();
 	out->lu_fl = tb->lufl.as<u32>();
 	out->lu_rgb = m->g.color ? tb->lurgb.as<u32>() : nullptr;
-	HIP_TRY(keys->reserve((size_t)cap * 8));
-	HIP_TRY(occ->reserve((size_t)cap * 32));
-	if (m->g.color) HIP_TRY(rgb->reserve((size_t)cap * 32));
-	HIP_TRY(flags->reserve((size_t)cap * 4));
-	HIP_TRY(parent->reserve((size_t)cap * 4));
-	HIP_TRY(stamp->reserve((size_t)cap * 4));
-	HIP_TRY(hipMemsetAsync(keys->p, 0, (size_t)cap * 8, m->stream));
-	HIP_TRY(hipMemsetAsync(flags->p, 0, (size_t)cap * 4, m->stream));
-	HIP_TRY(hipMemsetAsync(stamp->p, 0, (size_t)cap * 4, m->stream));
-	HIP_TRY(hipMemsetAsync(parent->p, 0xFF, (size_t)cap * 4, m->stream));
-	out->keys = keys->as<u64>();
-	out->occ = occ->as<float>();
-	out->rgb = m->g.color ? rgb->as<u32>() : nullptr;
-	out->flags = flags->as<u32>();
-	out->parent = parent->as<u32>();
-	out->stamp = stamp->as<u32>();
 	out->root = m->b_root.as<MapRoot>();
 	out->mask = cap - 1;
 	return UFOMAP_OK;
@@ -376,6 +372,8 @@ void swapWith(ufomap_map* m, HandOver& o)
 	std::swap(m->b_in_xyz, o.b_in_xyz);
 	std::swap(m->b_in_rgb, o.b_in_rgb);
 	std::swap(m->h_ctl, o.h_ctl);
+	std::swap(m->h_stage, o.h_stage);
+	std::swap(m->h_stage_cap, o.h_stage_cap);
 	std::swap(m->hh_mask, o.hh_mask);
 	for (int k = 0; k < 8; ++k) std::swap(m->counts[k], o.counts[k]);
 	std::swap(m->args, o.args);
@@ -1273,6 +1271,7 @@ ufomap_map* ufomap_map_create(double resolution, unsigned depth_levels, int auto
 	          hipEventCreateWithFlags(&m->alt[0].done_ev, hipEventDisableTiming) == hipSuccess &&
 	          hipEventCreateWithFlags(&m->alt[1].done_ev, hipEventDisableTiming) == hipSuccess &&
 	          hipEventCreateWithFlags(&m->scan_ev, hipEventDisableTiming) == hipSuccess &&
+	          hipEventCreateWithFlags(&m->copy_ev, hipEventDisableTiming) == hipSuccess &&
 	          hipHostMalloc((void**)&m->h_ctl, sizeof(ScanCtl) + 64) == hipSuccess &&
 	          hipHostMalloc((void**)&m->alt[0].h_ctl, sizeof(ScanCtl) + 64) == hipSuccess &&
 	          hipHostMalloc((void**)&m->alt[1].h_ctl, sizeof(ScanCtl) + 64) == hipSuccess &&
@@ -1323,6 +1322,7 @@ void ufomap_map_destroy(ufomap_map* m)
 		DevBuf* abufs[] = {&a.b_ctl, &a.b_entries, &a.b_hh_keys, &a.b_in_xyz, &a.b_in_rgb};
 		for (DevBuf* b : abufs) b->release();
 		if (a.h_ctl) (void)hipHostFree(a.h_ctl);
+		if (a.h_stage) (void)hipHostFree(a.h_stage);
 		if (a.done_ev) (void)hipEventDestroy(a.done_ev);
 	}
 	if (m->scan_ev) (void)hipEventDestroy(m->scan_ev);
@@ -1338,6 +1338,8 @@ void ufomap_map_destroy(ufomap_map* m)
 	}
 	for (hipEvent_t e : m->ev_pool) (void)hipEventDestroy(e);
 	if (m->h_ctl) (void)hipHostFree(m->h_ctl);
+	if (m->h_stage) (void)hipHostFree(m->h_stage);
+	if (m->copy_ev) (void)hipEventDestroy(m->copy_ev);
 	if (m->h_root) (void)hipHostFree(m->h_root);
 	if (m->done_ev) (void)hipEventDestroy(m->done_ev);
 	if (m->xstream) (void)hipStreamDestroy(m->xstream);
@@ -1352,9 +1354,9 @@ int ufomap_map_clear(ufomap_map* m)
 	(void)ufomap_map_wait(m);
 	m->cs = m->stream;
 	u32 cap = m->t.mask + 1;
-	HIP_TRY(hipMemsetAsync(m->t.keys, 0, (size_t)cap * 8, m->stream));
-	HIP_TRY(hipMemsetAsync(m->t.flags, 0, (size_t)cap * 4, m->stream));
-	HIP_TRY(hipMemsetAsync(m->t.stamp, 0, (size_t)cap * 4, m->stream));
+	HIP_TRY(hipMemsetAsync(m->t.blk, 0, (size_t)cap * sizeof(Block), m->stream));
+	HIP_TRY(hipMemsetAsync(m->t.tmax, 0, (size_t)cap * 8, m->stream));
+	HIP_TRY(hipMemsetAsync(m->t.lu_fl, 0, (size_t)cap * 32, m->stream));
 	return resetRoot(m);
 }
 
@@ -1393,28 +1395,61 @@ int ufomap_map_insert_device(ufomap_map* m, const double sensor_origin[3], const
 	return doInsert(m, sensor_origin, d_xyz, d_rgb, n, max_range, depth, discrete, simple_ray_casting, early_stopping, async, false);
 }
 
+// Host cloud -> HBM for the hand-over set of THIS scan (already rotated in) without stalling the caller on the GPU.
+// The caller's buffers are never referenced after the insert call returns (SURVEY.md 8b ownership):
+//  * pageable memory (the normal case, e.g. the std::vector of a PointCloud): the host copies it into the set's PINNED
+//    staging buffer and an asynchronous H2D copy drains that on the scan stream -- no synchronisation at all, so with
+//    async=true the copy of scan i+1 overlaps the kernels of scan i; the staging buffer is free again when the set's
+//    integration has been joined (rotateSets), which is before the set is used for another scan;
+//  * caller-owned pinned memory (hipHostMalloc / hipHostRegister): DMA straight from it; only the copy is awaited.
+static int uploadCloud(ufomap_map* m, const void* a, size_t a_bytes, const void* b, size_t b_bytes, const void** d_a, const void** d_b)
+{
+	*d_a = *d_b = nullptr;
+	if (0 == a_bytes) return UFOMAP_OK;
+	HIP_TRY(m->b_in_xyz.reserve(a_bytes));
+	if (b_bytes) HIP_TRY(m->b_in_rgb.reserve(b_bytes));
+	auto isPinned = [](const void* p) {
+		hipPointerAttribute_t at;
+		const bool ok = hipPointerGetAttributes(&at, p) == hipSuccess && at.type == hipMemoryTypeHost;
+		(void)hipGetLastError();  // an unregistered pointer is an "error" on some runtimes: not ours
+		return ok;
+	};
+	if (isPinned(a) && (!b_bytes || isPinned(b))) {
+		HIP_TRY(hipMemcpyAsync(m->b_in_xyz.p, a, a_bytes, hipMemcpyHostToDevice, m->sstream));
+		if (b_bytes) HIP_TRY(hipMemcpyAsync(m->b_in_rgb.p, b, b_bytes, hipMemcpyHostToDevice, m->sstream));
+		HIP_TRY(hipEventRecord(m->copy_ev, m->sstream));
+		HIP_TRY(hipEventSynchronize(m->copy_ev));
+	} else {
+		const size_t off_b = (a_bytes + 255) & ~(size_t)255, need = off_b + b_bytes;
+		if (need > m->h_stage_cap) {
+			if (m->h_stage) HIP_TRY(hipHostFree(m->h_stage));
+			m->h_stage = nullptr;
+			m->h_stage_cap = 0;
+			const size_t want = (need + need / 2 + 4095) & ~(size_t)4095;
+			HIP_TRY(hipHostMalloc(&m->h_stage, want));
+			m->h_stage_cap = want;
+		}
+		memcpy(m->h_stage, a, a_bytes);
+		if (b_bytes) memcpy(static_cast<char*>(m->h_stage) + off_b, b, b_bytes);
+		HIP_TRY(hipMemcpyAsync(m->b_in_xyz.p, m->h_stage, a_bytes, hipMemcpyHostToDevice, m->sstream));
+		if (b_bytes) HIP_TRY(hipMemcpyAsync(m->b_in_rgb.p, static_cast<char*>(m->h_stage) + off_b, b_bytes, hipMemcpyHostToDevice, m->sstream));
+	}
+	*d_a = m->b_in_xyz.p;
+	if (b_bytes) *d_b = m->b_in_rgb.p;
+	return UFOMAP_OK;
+}
+
 int ufomap_map_insert(ufomap_map* m, const double sensor_origin[3], const double* xyz, const uint8_t* rgb, size_t n,
                       double max_range, unsigned depth, int discrete, int simple_ray_casting, unsigned early_stopping, int async)
 {
 	if (!m) return fail(UFOMAP_ERR_INVALID, "null map");
 	HIP_TRY(hipSetDevice(m->device));
 	(void)rotateSets(m);  // the staging buffers belong to the hand-over set of THIS scan
-	const double* d_xyz = nullptr;
-	const uint8_t* d_rgb = nullptr;
-	if (n) {
-		// the caller's cloud is never referenced after this call returns (SURVEY.md 8b ownership)
-		hipError_t e = m->b_in_xyz.reserve(n * 24);
-		if (e == hipSuccess) e = hipMemcpyAsync(m->b_in_xyz.p, xyz, n * 24, hipMemcpyHostToDevice, m->sstream);
-		d_xyz = m->b_in_xyz.as<double>();
-		if (e == hipSuccess && rgb) {
-			e = m->b_in_rgb.reserve(n * 3);
-			if (e == hipSuccess) e = hipMemcpyAsync(m->b_in_rgb.p, rgb, n * 3, hipMemcpyHostToDevice, m->sstream);
-			d_rgb = m->b_in_rgb.as<uint8_t>();
-		}
-		if (e == hipSuccess) e = hipStreamSynchronize(m->sstream);  // pageable source: copy complete before returning
-		if (e != hipSuccess) return fail(UFOMAP_ERR_DEVICE, hipGetErrorString(e));
-	}
-	return doInsert(m, sensor_origin, d_xyz, d_rgb, n, max_range, depth, discrete, simple_ray_casting, early_stopping, async, true);
+	const void *d_xyz = nullptr, *d_rgb = nullptr;
+	const int urc = uploadCloud(m, xyz, n * 24, rgb, rgb ? n * 3 : 0, &d_xyz, &d_rgb);
+	if (urc) return urc;
+	return doInsert(m, sensor_origin, static_cast<const double*>(d_xyz), static_cast<const uint8_t*>(d_rgb), n, max_range, depth, discrete,
+	                simple_ray_casting, early_stopping, async, true);
 }
 
 int ufomap_map_insert_pointcloud2(ufomap_map* m, const double translation[3], const double rotation_wxyz[4], const void* data,
@@ -1436,10 +1471,10 @@ int ufomap_map_insert_pointcloud2(ufomap_map* m, const double translation[3], co
 	if (n_points && !data_on_device) {
 		// the caller's message is never referenced after this call returns; what crosses PCIe is the raw record
 		// stream (point_step bytes per point), not 24 bytes of float64 per point
-		e = m->b_in_xyz.reserve(n_points * (size_t)point_step);
-		if (e == hipSuccess) e = hipMemcpyAsync(m->b_in_xyz.p, data, n_points * (size_t)point_step, hipMemcpyHostToDevice, m->sstream);
-		if (e == hipSuccess) e = hipStreamSynchronize(m->sstream);
-		d_data = m->b_in_xyz.as<uint8_t>();
+		const void *d_a = nullptr, *d_b = nullptr;
+		const int urc = uploadCloud(m, data, n_points * (size_t)point_step, nullptr, 0, &d_a, &d_b);
+		if (urc) return urc;
+		d_data = static_cast<const uint8_t*>(d_a);
 	}
 	uint8_t* d_rgb = nullptr;
 	if (e == hipSuccess && n_points && m->g.color) {
@@ -1790,7 +1825,37 @@ int ufomap_map_stats(ufomap_map* m, uint64_t* n_inner, uint64_t* n_leaf, uint64_
 	if (n_leaf) *n_leaf = h.n_live ? h.n_leaf : 1;
 	if (bytes) {
 		u64 cap = (u64)m->t.mask + 1;
-		*bytes = cap * (8 + 32 + 12 + 8 + 64 + (m->g.color ? 64 : 0));
+		*bytes = cap * (sizeof(Block) + 8 + 64 + (m->g.color ? 96 : 0));
+	}
+	return UFOMAP_OK;
+}
+
+int ufomap_map_digest(ufomap_map* m, int include_unknown, uint64_t out[6])
+{
+	if (!m || !out) return fail(UFOMAP_ERR_INVALID, "null argument");
+	int rc = ufomap_map_wait(m);
+	if (rc) return rc;
+	DevBuf db;
+	HIP_TRY(db.reserve(6 * 8));
+	hipError_t e = hipMemsetAsync(db.p, 0, 6 * 8, m->stream);
+	if (e == hipSuccess) {
+		hipLaunchKernelGGL(k_digest, gridFor((u64)m->t.mask + 1), dim3(256), 0, m->stream, m->t, m->g, include_unknown,
+		                   db.as<unsigned long long>());
+		e = hipMemcpyAsync(out, db.p, 6 * 8, hipMemcpyDeviceToHost, m->stream);
+	}
+	if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
+	db.release();
+	if (e != hipSuccess) return fail(UFOMAP_ERR_DEVICE, hipGetErrorString(e));
+	if (0 == out[3]) {
+		// no live block: the map is its root, one leaf of depth depth_levels (as in the leaf export)
+		MapRoot root;
+		HIP_TRY(hipMemcpy(&root, m->b_root.p, sizeof(MapRoot), hipMemcpyDeviceToHost));
+		if (include_unknown || !isUnknownV(m->g, root.occ)) {
+			const u64 h = digestRecord(0, m->g.L, root.occ, root.rgb, 0u);
+			out[0] = 1;
+			out[1] = h;
+			out[2] = h;
+		}
 	}
 	return UFOMAP_OK;
 }

@@ -247,6 +247,14 @@ class OccupancyMapBase:
                 f.write(data)
         return data
 
+    def digest(self, include_unknown=True):
+        """Order-independent fingerprint of ``leaves(include_unknown)`` and ``inner()`` (``ufomap_map_digest``):
+        (n_leaves, sum, xor, n_inner, sum, xor) as Python ints; ``tests/golden_util.dump_digest`` computes the same
+        from a dump."""
+        out = np.zeros(6, np.uint64)
+        capi.check(self._lib.ufomap_map_digest(self._h, int(include_unknown), _p(out, C.c_uint64)))
+        return tuple(int(v) for v in out)
+
     def minmax_change(self):
         mn, mx = np.empty(3), np.empty(3)
         capi.check(self._lib.ufomap_map_minmax_change(self._h, _p(mn, C.c_double), _p(mx, C.c_double)))
