@@ -11,7 +11,8 @@ int main()
 		ufo::map::PointCloud cloud;
 		cloud.push_back(ufo::map::Point3(1.0, 0.05, 0.05));
 		map.insertPointCloud(ufo::map::Point3(0.05, 0.05, 0.05), cloud, 20.0);
-		for (auto const& leaf : map.leaves()) std::printf("%llu %u %.6f\n", (unsigned long long)leaf.code, leaf.depth, leaf.logodds);
+		for (auto it = map.beginLeaves(), end = map.endLeaves(); it != end; ++it)
+			std::printf("%llu %u %.6f\n", (unsigned long long)it.getCode().getCode(), it.getDepth(), it->occupancy);
 	} catch (ufo::map::DeviceError const& e) {
 		std::printf("device error %d: %s\n", e.code(), e.what());
 		return 2;

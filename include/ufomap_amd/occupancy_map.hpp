@@ -504,8 +504,7 @@ class OccupancyMapDevice
 	std::vector<Code>::const_iterator changesEnd() const { return changes_.end(); }
 	void enableMinMaxChangeDetection(bool enable) noexcept
 	{
-		if (!min_max_change_detection_ && enable) (void)ufomap_map_reset_minmax_change(map_);
-		min_max_change_detection_ = enable;
+		min_max_change_detection_ = enable;  // (the C ABI resets the box when detection goes from off to on, as OMB:793-795)
 		(void)ufomap_map_enable_minmax_change_detection(map_, enable);
 	}
 	bool isMinMaxChangeDetectionEnabled() const noexcept { return min_max_change_detection_; }
@@ -842,7 +841,7 @@ class OccupancyMapDevice
 	ufomap_map* map_ = nullptr;
 	double resolution_;
 	DepthType depth_levels_;
-	bool change_detection_ = false, min_max_change_detection_ = false;
+	bool change_detection_ = false, min_max_change_detection_ = true;  // (the device path tracks the box by default)
 	mutable std::vector<Code> changes_;
 	std::vector<double> xyz_;  // staging of a coloured cloud (consumed by the call: the C ABI copies before it returns)
 	std::vector<uint8_t> rgb_;

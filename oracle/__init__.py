@@ -82,6 +82,22 @@ def _load(kind: str):
     lib.ufo_oracle_clamping_thres.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.ufo_oracle_ingest.restype = C.c_size_t
     lib.ufo_oracle_ingest.argtypes = [u8p, C.c_size_t, C.c_uint32] + [C.c_int] * 6 + [C.POINTER(C.c_double)] * 3 + [u8p]
+    lib.ufo_oracle_iterate.restype = C.c_size_t
+    lib.ufo_oracle_iterate.argtypes = [vp, f64p, f64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_int, u64p, u8p, f32p, u8p, u8p, C.c_size_t]
+    lib.ufo_oracle_enable_change_detection.argtypes = [vp, C.c_int]
+    lib.ufo_oracle_reset_change_detection.argtypes = [vp]
+    lib.ufo_oracle_changes.restype = C.c_size_t
+    lib.ufo_oracle_changes.argtypes = [vp, u64p, u8p, C.c_size_t]
+    lib.ufo_oracle_enable_minmax_change_detection.argtypes = [vp, C.c_int]
+    lib.ufo_oracle_write_ex.restype = C.c_size_t
+    lib.ufo_oracle_write_ex.argtypes = [vp, f64p, f64p, C.c_int, C.c_uint, C.c_int, C.c_int, C.c_int, u8p, C.c_size_t, C.POINTER(C.c_longlong)]
+    lib.ufo_oracle_read.argtypes = [vp, u8p, C.c_size_t]
+    lib.ufo_oracle_read_data.argtypes = [vp, u8p, C.c_size_t, f64p, f64p, C.c_double, C.c_uint, C.c_int, C.c_int]
+    lib.ufo_oracle_get_sensor_model.argtypes = [vp, f64p]
+    lib.ufo_oracle_set_model_value.argtypes = [vp, C.c_int, C.c_double]
+    lib.ufo_oracle_set_occupied_free_thres.argtypes = [vp, C.c_double, C.c_double]
+    lib.ufo_oracle_clear_to.argtypes = [vp, C.c_double, C.c_uint]
+    lib.ufo_oracle_set_value_volume_ch.argtypes = [vp, f64p, f64p, C.c_double, C.c_uint]
     lib.ufo_oracle_kind.restype = C.c_char_p
     _LIBS[kind] = lib
     return lib
@@ -199,6 +215,85 @@ class OracleMap:
         mx = np.empty(3, np.float64)
         self.lib.ufo_oracle_minmax_change(self.h, _ptr(mn, C.c_double), _ptr(mx, C.c_double))
         return mn, mx
+
+
+    # ---- round-2 rows: the reference build only (oracle_abi.h) ------------------------------------------------
+    @staticmethod
+    def _bv(aabb):
+        if aabb is None:
+            return None, None, None
+        c = np.ascontiguousarray(aabb[0], np.float64)
+        h = np.ascontiguousarray(aabb[1], np.float64)
+        return (c, h), _ptr(c, C.c_double), _ptr(h, C.c_double)
+
+    def _need(self, ok):
+        if not ok:
+            raise NotImplementedError("provided by the reference build only (oracle/_ref/libufo_ref.so)")
+
+    def iterate(self, aabb=None, occupied_space=True, free_space=True, unknown_space=False, contains=False, min_depth=0, only_leaves=True):
+        keep, pc, ph = self._bv(aabb)
+        a = (int(occupied_space), int(free_space), int(unknown_space), int(contains), int(min_depth), int(only_leaves))
+        n = self.lib.ufo_oracle_iterate(self.h, pc, ph, *a, None, None, None, None, None, 0)
+        self._need(n != C.c_size_t(-1).value)
+        codes, depths, occ = np.empty(n, np.uint64), np.empty(n, np.uint8), np.empty(n, np.float32)
+        rgb, flags = np.zeros((n, 3), np.uint8), np.empty(n, np.uint8)
+        self.lib.ufo_oracle_iterate(self.h, pc, ph, *a, _ptr(codes, C.c_uint64), _ptr(depths, C.c_uint8), _ptr(occ, C.c_float),
+                                    _ptr(rgb, C.c_uint8), _ptr(flags, C.c_uint8), n)
+        return codes, depths, occ, rgb, flags
+
+    def enableChangeDetection(self, enable=True):
+        self._need(self.lib.ufo_oracle_enable_change_detection(self.h, int(enable)) == 0)
+
+    def resetChangeDetection(self):
+        self._need(self.lib.ufo_oracle_reset_change_detection(self.h) == 0)
+
+    def changes(self):
+        n = self.lib.ufo_oracle_changes(self.h, None, None, 0)
+        self._need(n != C.c_size_t(-1).value)
+        codes, depths = np.empty(n, np.uint64), np.empty(n, np.uint8)
+        self.lib.ufo_oracle_changes(self.h, _ptr(codes, C.c_uint64), _ptr(depths, C.c_uint8), n)
+        return codes, depths
+
+    def enableMinMaxChangeDetection(self, enable=True):
+        self._need(self.lib.ufo_oracle_enable_minmax_change_detection(self.h, int(enable)) == 0)
+
+    def write_ex(self, aabb=None, compress=False, min_depth=0, compression_acceleration_level=1, compression_level=0, header=True):
+        keep, pc, ph = self._bv(aabb)
+        us = C.c_longlong(-1)
+        a = (int(compress), int(min_depth), int(compression_acceleration_level), int(compression_level), int(header))
+        n = self.lib.ufo_oracle_write_ex(self.h, pc, ph, *a, None, 0, C.byref(us))
+        self._need(n != C.c_size_t(-1).value)
+        buf = np.empty(max(n, 1), np.uint8)
+        self.lib.ufo_oracle_write_ex(self.h, pc, ph, *a, _ptr(buf, C.c_uint8), n, C.byref(us))
+        return buf[:n].tobytes(), int(us.value)
+
+    def read(self, data):
+        b = np.frombuffer(data, np.uint8)
+        self._need(self.lib.ufo_oracle_read(self.h, _ptr(b, C.c_uint8), b.size) == 0)
+
+    def readData(self, data, resolution, depth_levels, uncompressed_data_size=1, compressed=False, aabb=None):
+        b = np.frombuffer(data, np.uint8)
+        keep, pc, ph = self._bv(aabb)
+        self._need(self.lib.ufo_oracle_read_data(self.h, _ptr(b, C.c_uint8) if b.size else None, b.size, pc, ph, float(resolution), int(depth_levels),
+                                                 int(uncompressed_data_size), int(compressed)) == 0)
+
+    def sensor_model(self):
+        out = np.zeros(6, np.float64)
+        self._need(self.lib.ufo_oracle_get_sensor_model(self.h, _ptr(out, C.c_double)) == 0)
+        return tuple(float(v) for v in out)
+
+    def set_model_value(self, which, p):
+        self._need(self.lib.ufo_oracle_set_model_value(self.h, int(which), float(p)) == 0)
+
+    def setOccupiedFreeThres(self, occupied_thres, free_thres):
+        self._need(self.lib.ufo_oracle_set_occupied_free_thres(self.h, float(occupied_thres), float(free_thres)) == 0)
+
+    def clear_to(self, resolution, depth_levels):
+        self._need(self.lib.ufo_oracle_clear_to(self.h, float(resolution), int(depth_levels)) == 0)
+
+    def setValueVolumeAABB(self, center, half_size, occupancy_value, min_depth=0):
+        c, h = np.ascontiguousarray(center, np.float64), np.ascontiguousarray(half_size, np.float64)
+        self._need(self.lib.ufo_oracle_set_value_volume_ch(self.h, _ptr(c, C.c_double), _ptr(h, C.c_double), float(occupancy_value), int(min_depth)) == 0)
 
     # -- stage-level outputs of the last insert (port only) ---------------------------------
     def _stage(self, fn, dtype, width=1):

@@ -98,6 +98,36 @@ void ufo_oracle_query(const ufo_oracle_map* m, const double* xyz, size_t n, unsi
 size_t ufo_oracle_ingest(const uint8_t* data, size_t n, uint32_t step, int off_x, int off_y, int off_z, int off_r, int off_g,
                          int off_b, const double rot_wxyz[4], const double trans[3], double* xyz_out, uint8_t* rgb_out);
 
+
+/* ---- round 2: what the reference's callers use around the hot path. Provided by the REFERENCE build only
+ * (the port returns -1 / (size_t)-1): the parity tests for these rows need oracle/_ref/libufo_ref.so, which is built
+ * where /root/reference exists and travels to the GPU box. Bounding volumes: AABB as (centre[3], half_size[3]) or
+ * NULL, NULL. ---- */
+/* beginLeaves (only_leaves) / beginTree run to the end (occupancy_map_base.h:93-165): the nodes in iteration order.
+ * flags: bit 0 contains_free, bit 1 contains_unknown, bit 2 leaf. */
+size_t ufo_oracle_iterate(const ufo_oracle_map* m, const double* aabb_center, const double* aabb_half, int occupied_space, int free_space,
+                          int unknown_space, int contains, unsigned min_depth, int only_leaves, uint64_t* codes, uint8_t* depths,
+                          float* logodds, uint8_t* rgb, uint8_t* flags, size_t cap);
+/* enableChangeDetection / resetChangeDetection / changesBegin..End (occupancy_map_base.h:779-791), sorted by (depth, code) */
+int ufo_oracle_enable_change_detection(ufo_oracle_map* m, int enable);
+int ufo_oracle_reset_change_detection(ufo_oracle_map* m);
+size_t ufo_oracle_changes(const ufo_oracle_map* m, uint64_t* codes, uint8_t* depths, size_t cap);
+int ufo_oracle_enable_minmax_change_detection(ufo_oracle_map* m, int enable);
+/* write (header != 0) / writeData (header == 0) with all arguments (octree.h:779-917) */
+size_t ufo_oracle_write_ex(const ufo_oracle_map* m, const double* aabb_center, const double* aabb_half, int compress, unsigned min_depth,
+                           int accel, int level, int header, uint8_t* buf, size_t cap, long long* uncompressed_size);
+/* read(std::istream&) / readData(...) (octree.h:701-777) */
+int ufo_oracle_read(ufo_oracle_map* m, const uint8_t* buf, size_t n);
+int ufo_oracle_read_data(ufo_oracle_map* m, const uint8_t* data, size_t n, const double* aabb_center, const double* aabb_half,
+                         double resolution, unsigned depth_levels, int uncompressed_data_size, int compressed);
+/* getters in the order occupied, free, hit, miss, clamp min, clamp max (occupancy_map_base.h:734-744); setters 746-773 */
+int ufo_oracle_get_sensor_model(const ufo_oracle_map* m, double out[6]);
+int ufo_oracle_set_model_value(ufo_oracle_map* m, int which, double probability);
+int ufo_oracle_set_occupied_free_thres(ufo_oracle_map* m, double occupied_thres, double free_thres);
+int ufo_oracle_clear_to(ufo_oracle_map* m, double resolution, unsigned depth_levels);
+/* setValueVolume with the AABB given as (centre, half size) */
+int ufo_oracle_set_value_volume_ch(ufo_oracle_map* m, const double c[3], const double h[3], double occupancy_value, unsigned min_depth);
+
 const char* ufo_oracle_kind(void);
 
 #ifdef __cplusplus

@@ -321,3 +321,187 @@ size_t ufo_oracle_ingest(const uint8_t* data, size_t n, uint32_t step, int off_x
 const char* ufo_oracle_kind(void) { return "reference"; }
 
 }  // extern "C"
+
+// ---- round 2: iterators, change detection, write / read with all arguments, sensor-model accessors --------------
+namespace
+{
+template <class IT, class MAP>
+size_t runIterator(MAP const& map, IT it, IT end, bool color, uint64_t* codes, uint8_t* depths, float* logodds, uint8_t* rgb, uint8_t* flags,
+                   size_t cap)
+{
+	size_t n = 0;
+	for (; it != end; ++it, ++n) {
+		if (n >= cap) continue;
+		const unsigned d = it.getDepth();
+		if (codes) codes[n] = it.getCode().getCode() >> (3 * d);
+		if (depths) depths[n] = (uint8_t)d;
+		if (logodds) logodds[n] = it->occupancy;
+		if (flags) flags[n] = (it.containsFree() ? 1 : 0) | (it.containsUnknown() ? 2 : 0) | (it.isLeaf() ? 4 : 0);
+		if (rgb) {
+			rgb[3 * n] = rgb[3 * n + 1] = rgb[3 * n + 2] = 0;
+			if constexpr (std::is_same_v<MAP, ProbeCol>) {
+				rgb[3 * n] = it->color.r;
+				rgb[3 * n + 1] = it->color.g;
+				rgb[3 * n + 2] = it->color.b;
+			}
+		}
+	}
+	(void)map;
+	(void)color;
+	return n;
+}
+template <class MAP>
+size_t iterateMap(MAP const& map, const double* c, const double* h, bool o, bool f, bool u, bool contains, unsigned min_depth, bool only_leaves,
+                  uint64_t* codes, uint8_t* depths, float* logodds, uint8_t* rgb, uint8_t* flags, size_t cap)
+{
+	ufo::geometry::BoundingVolume bv;
+	if (c) {
+		ufo::geometry::AABB a;
+		a.center = ufo::geometry::Point(c[0], c[1], c[2]);
+		a.half_size = ufo::geometry::Point(h[0], h[1], h[2]);
+		bv.add(a);
+	}
+	if (only_leaves) return runIterator(map, map.beginLeaves(bv, o, f, u, contains, min_depth), map.endLeaves(), false, codes, depths, logodds, rgb, flags, cap);
+	return runIterator(map, map.beginTree(bv, o, f, u, contains, min_depth), map.endTree(), false, codes, depths, logodds, rgb, flags, cap);
+}
+ufo::geometry::BoundingVolume makeBv(const double* c, const double* h)
+{
+	ufo::geometry::BoundingVolume bv;
+	if (c) {
+		ufo::geometry::AABB a;
+		a.center = ufo::geometry::Point(c[0], c[1], c[2]);
+		a.half_size = ufo::geometry::Point(h[0], h[1], h[2]);
+		bv.add(a);
+	}
+	return bv;
+}
+}  // namespace
+
+extern "C" {
+size_t ufo_oracle_iterate(const ufo_oracle_map* m, const double* c, const double* h, int o, int f, int u, int contains, unsigned min_depth,
+                          int only_leaves, uint64_t* codes, uint8_t* depths, float* logodds, uint8_t* rgb, uint8_t* flags, size_t cap)
+{
+	if (m->col) return iterateMap(*m->col, c, h, o, f, u, contains, min_depth, only_leaves, codes, depths, logodds, rgb, flags, cap);
+	return iterateMap(*m->occ, c, h, o, f, u, contains, min_depth, only_leaves, codes, depths, logodds, rgb, flags, cap);
+}
+int ufo_oracle_enable_change_detection(ufo_oracle_map* m, int enable)
+{
+	if (m->col) m->col->enableChangeDetection(0 != enable);
+	else m->occ->enableChangeDetection(0 != enable);
+	return 0;
+}
+int ufo_oracle_reset_change_detection(ufo_oracle_map* m)
+{
+	if (m->col) m->col->resetChangeDetection();
+	else m->occ->resetChangeDetection();
+	return 0;
+}
+size_t ufo_oracle_changes(const ufo_oracle_map* m, uint64_t* codes, uint8_t* depths, size_t cap)
+{
+	std::vector<std::pair<uint8_t, uint64_t>> v;
+	auto collect = [&](auto const& map) {
+		for (auto it = map.changesBegin(); it != map.changesEnd(); ++it) {
+			ufo::map::Code const c = *it;
+			v.emplace_back((uint8_t)c.getDepth(), c.getCode() >> (3 * c.getDepth()));
+		}
+	};
+	if (m->col) collect(*m->col);
+	else collect(*m->occ);
+	std::sort(v.begin(), v.end());
+	for (size_t i = 0; i < v.size() && i < cap; ++i) {
+		if (codes) codes[i] = v[i].second;
+		if (depths) depths[i] = v[i].first;
+	}
+	return v.size();
+}
+int ufo_oracle_enable_minmax_change_detection(ufo_oracle_map* m, int enable)
+{
+	if (m->col) m->col->enableMinMaxChangeDetection(0 != enable);
+	else m->occ->enableMinMaxChangeDetection(0 != enable);
+	return 0;
+}
+size_t ufo_oracle_write_ex(const ufo_oracle_map* m, const double* c, const double* h, int compress, unsigned min_depth, int accel, int level,
+                           int header, uint8_t* buf, size_t cap, long long* uncompressed_size)
+{
+	std::stringstream ss(std::ios_base::in | std::ios_base::out | std::ios_base::binary);
+	const ufo::geometry::BoundingVolume bv = makeBv(c, h);
+	long long us = -1;
+	if (header) {
+		const bool ok = m->col ? m->col->write(ss, bv, 0 != compress, min_depth, accel, level) : m->occ->write(ss, bv, 0 != compress, min_depth, accel, level);
+		if (!ok) return (size_t)-1;
+	} else {
+		us = m->col ? m->col->writeData(ss, bv, 0 != compress, min_depth, accel, level) : m->occ->writeData(ss, bv, 0 != compress, min_depth, accel, level);
+		if (us < 0) return (size_t)-1;
+	}
+	if (uncompressed_size) *uncompressed_size = us;
+	std::string const bytes = ss.str();
+	if (buf && cap >= bytes.size()) std::memcpy(buf, bytes.data(), bytes.size());
+	return bytes.size();
+}
+int ufo_oracle_read(ufo_oracle_map* m, const uint8_t* buf, size_t n)
+{
+	std::stringstream ss(std::ios_base::in | std::ios_base::out | std::ios_base::binary);
+	ss.write(reinterpret_cast<const char*>(buf), (std::streamsize)n);
+	const bool ok = m->col ? m->col->read(ss) : m->occ->read(ss);
+	return ok ? 0 : -1;
+}
+int ufo_oracle_read_data(ufo_oracle_map* m, const uint8_t* data, size_t n, const double* c, const double* h, double resolution,
+                         unsigned depth_levels, int uncompressed_data_size, int compressed)
+{
+	std::stringstream ss(std::ios_base::in | std::ios_base::out | std::ios_base::binary);
+	ss.write(reinterpret_cast<const char*>(data), (std::streamsize)n);
+	const ufo::geometry::BoundingVolume bv = makeBv(c, h);
+	const bool ok = m->col ? m->col->readData(ss, bv, resolution, depth_levels, uncompressed_data_size, 0 != compressed)
+	                       : m->occ->readData(ss, bv, resolution, depth_levels, uncompressed_data_size, 0 != compressed);
+	return ok ? 0 : -1;
+}
+int ufo_oracle_get_sensor_model(const ufo_oracle_map* m, double out[6])
+{
+	auto get = [&](auto const& map) {
+		out[0] = map.getOccupiedThres();
+		out[1] = map.getFreeThres();
+		out[2] = map.getProbHit();
+		out[3] = map.getProbMiss();
+		out[4] = map.getClampingThresMin();
+		out[5] = map.getClampingThresMax();
+	};
+	if (m->col) get(*m->col);
+	else get(*m->occ);
+	return 0;
+}
+int ufo_oracle_set_model_value(ufo_oracle_map* m, int which, double p)
+{
+	auto set = [&](auto& map) {
+		switch (which) {
+			case 2: map.setProbHit(p); break;
+			case 3: map.setProbMiss(p); break;
+			case 4: map.setClampingThresMin(p); break;
+			case 5: map.setClampingThresMax(p); break;
+			default: return -1;
+		}
+		return 0;
+	};
+	return m->col ? set(*m->col) : set(*m->occ);
+}
+int ufo_oracle_set_occupied_free_thres(ufo_oracle_map* m, double occupied_thres, double free_thres)
+{
+	if (m->col) m->col->setOccupiedFreeThres(occupied_thres, free_thres);
+	else m->occ->setOccupiedFreeThres(occupied_thres, free_thres);
+	return 0;
+}
+int ufo_oracle_clear_to(ufo_oracle_map* m, double resolution, unsigned depth_levels)
+{
+	if (m->col) m->col->clear(resolution, depth_levels);
+	else m->occ->clear(resolution, depth_levels);
+	return 0;
+}
+int ufo_oracle_set_value_volume_ch(ufo_oracle_map* m, const double c[3], const double h[3], double occupancy_value, unsigned min_depth)
+{
+	ufo::geometry::AABB a;
+	a.center = ufo::geometry::Point(c[0], c[1], c[2]);
+	a.half_size = ufo::geometry::Point(h[0], h[1], h[2]);
+	if (m->col) m->col->setValueVolume(a, occupancy_value, min_depth);
+	else m->occ->setValueVolume(a, occupancy_value, min_depth);
+	return 0;
+}
+}  // extern "C"

@@ -954,3 +954,25 @@ size_t ufo_oracle_ingest(const uint8_t* data, size_t n, uint32_t step, int off_x
 const char* ufo_oracle_kind(void) { return "port"; }
 
 }  // extern "C"
+
+// ---- round 2 rows (iterators, change set, write/read with all arguments, model accessors): the REFERENCE build is the
+// checker for these (oracle_abi.h); the port does not restate them.
+extern "C" {
+size_t ufo_oracle_iterate(const ufo_oracle_map*, const double*, const double*, int, int, int, int, unsigned, int, uint64_t*, uint8_t*, float*,
+                          uint8_t*, uint8_t*, size_t) { return (size_t)-1; }
+int ufo_oracle_enable_change_detection(ufo_oracle_map*, int) { return -1; }
+int ufo_oracle_reset_change_detection(ufo_oracle_map*) { return -1; }
+size_t ufo_oracle_changes(const ufo_oracle_map*, uint64_t*, uint8_t*, size_t) { return (size_t)-1; }
+int ufo_oracle_enable_minmax_change_detection(ufo_oracle_map*, int) { return -1; }
+size_t ufo_oracle_write_ex(const ufo_oracle_map*, const double*, const double*, int, unsigned, int, int, int, uint8_t*, size_t, long long*)
+{
+	return (size_t)-1;
+}
+int ufo_oracle_read(ufo_oracle_map*, const uint8_t*, size_t) { return -1; }
+int ufo_oracle_read_data(ufo_oracle_map*, const uint8_t*, size_t, const double*, const double*, double, unsigned, int, int) { return -1; }
+int ufo_oracle_get_sensor_model(const ufo_oracle_map*, double*) { return -1; }
+int ufo_oracle_set_model_value(ufo_oracle_map*, int, double) { return -1; }
+int ufo_oracle_set_occupied_free_thres(ufo_oracle_map*, double, double) { return -1; }
+int ufo_oracle_clear_to(ufo_oracle_map*, double, unsigned) { return -1; }
+int ufo_oracle_set_value_volume_ch(ufo_oracle_map*, const double*, const double*, double, unsigned) { return -1; }
+}

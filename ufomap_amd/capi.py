@@ -25,6 +25,9 @@ SYMBOLS = [
     "ufomap_map_write", "ufomap_map_digest", "ufomap_map_minmax_change", "ufomap_map_reset_minmax_change", "ufomap_map_stats",
     "ufomap_map_last_hits", "ufomap_map_last_misses", "ufomap_map_last_counts",
     "ufomap_map_set_profiling", "ufomap_map_kernel_times", "ufomap_map_reset_kernel_times",
+    "ufomap_map_clear_to", "ufomap_map_get_sensor_model", "ufomap_map_set_model_value", "ufomap_map_set_occupied_free_thres",
+    "ufomap_map_set_value_volume_ch", "ufomap_map_enable_change_detection", "ufomap_map_reset_change_detection", "ufomap_map_changes",
+    "ufomap_map_enable_minmax_change_detection", "ufomap_map_iterate", "ufomap_map_write_ex", "ufomap_map_read", "ufomap_map_read_data",
     "ufomap_map_scan_keys", "ufomap_map_get_keys", "ufomap_map_apply_keys", "ufomap_map_apply_keys_batch", "ufomap_map_stream", "ufomap_map_debug", "ufomap_map_set_option",
 ]
 
@@ -110,6 +113,22 @@ def load():
         dbl, C.c_uint, C.c_int, C.c_int, C.c_uint, C.c_int]
     lib.ufomap_map_apply_keys.argtypes = [vp, vp, C.POINTER(KeysInfo)]
     lib.ufomap_map_apply_keys_batch.argtypes = [vp, C.POINTER(C.c_void_p), C.POINTER(KeysInfo), C.c_int]
+    lib.ufomap_map_clear_to.argtypes = [vp, dbl, C.c_uint]
+    lib.ufomap_map_get_sensor_model.argtypes = [vp, f64p]
+    lib.ufomap_map_set_model_value.argtypes = [vp, C.c_int, dbl]
+    lib.ufomap_map_set_occupied_free_thres.argtypes = [vp, dbl, dbl]
+    lib.ufomap_map_set_value_volume_ch.argtypes = [vp, f64p, f64p, dbl, C.c_uint]
+    lib.ufomap_map_enable_change_detection.argtypes = [vp, C.c_int]
+    lib.ufomap_map_reset_change_detection.argtypes = [vp]
+    lib.ufomap_map_changes.restype = sz
+    lib.ufomap_map_changes.argtypes = [vp, u64p, u8p, sz]
+    lib.ufomap_map_enable_minmax_change_detection.argtypes = [vp, C.c_int]
+    lib.ufomap_map_iterate.restype = sz
+    lib.ufomap_map_iterate.argtypes = [vp, f64p, f64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_int, u64p, u8p, f32p, u8p, u8p, sz]
+    lib.ufomap_map_write_ex.restype = sz
+    lib.ufomap_map_write_ex.argtypes = [vp, f64p, f64p, C.c_int, C.c_uint, C.c_int, C.c_int, C.c_int, u8p, sz, C.POINTER(C.c_longlong)]
+    lib.ufomap_map_read.argtypes = [vp, u8p, sz, f64p, C.POINTER(C.c_uint)]
+    lib.ufomap_map_read_data.argtypes = [vp, u8p, sz, f64p, f64p, dbl, C.c_uint, C.c_int, C.c_int]
     lib.ufomap_map_debug.argtypes = [vp, u64p, C.c_int]
     lib.ufomap_map_set_option.argtypes = [vp, C.c_char_p, C.c_longlong]
     lib.ufomap_map_stream.restype = vp

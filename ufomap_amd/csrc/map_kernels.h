@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256) void k_apply_leaf(Table t, MapGeom g, const En
                                                     const u32* n_entries_p, const u32* __restrict__ ent_slot, float upd_hit,
                                                     float upd_miss, u32 mode, u32 phase, HitHash hh,
                                                     const uint8_t* __restrict__ rgb_in, u32* __restrict__ wl,
-                                                    ScanCtl::PhaseCtr* pc, ScanCtl* ctl)
+                                                    ScanCtl::PhaseCtr* pc, ScanCtl* ctl, ChangeLog cl)
 {
 	u32 n = *n_entries_p;
 	if (ctl->err) return;
@@ -432,21 +432,27 @@ __global__ __launch_bounds__(256) void k_apply_leaf(Table t, MapGeom g, const En
 		// colour of the last-updated child just before that update: misses leave the colour alone
 		if (g.color && (last_is_miss || !blend)) old_rgb_last = t.rgb[8 * (size_t)s + c_last];
 		float v_old_last = 0.f;
+		u32 chg = 0;  // children whose value a hit or a miss changed: updateOccupancy returned true (OMB:1069-1072)
 #pragma unroll
 		for (int c = 0; c < 8; ++c) {
 			float x = v[c];
 			if ((hmask >> c) & 1) {
 				if (c == c_last && !last_is_miss) v_old_last = x;
-				x = clampAdd(x, upd_hit, g.cmin, g.cmax);
+				const float y = clampAdd(x, upd_hit, g.cmin, g.cmax);
+				chg |= (y != x) ? (1u << c) : 0u;
+				x = y;
 			}
 			if ((mmask >> c) & 1) {
 				if (c == c_last) v_old_last = x;  // last_is_miss
-				x = clampAdd(x, upd_miss, g.cmin, g.cmax);
+				const float y = clampAdd(x, upd_miss, g.cmin, g.cmax);
+				chg |= (y != x) ? (1u << c) : 0u;
+				x = y;
 			}
 			v[c] = x;
 		}
 		po[0] = make_float4(v[0], v[1], v[2], v[3]);
 		po[1] = make_float4(v[4], v[5], v[6], v[7]);
+		logChanges(t, cl, (e.lk ^ (1ULL << (3 * (g.L - 1)))) << 3, 0u, chg);
 		Summ sm = blockSummary(t, g, s, 1, 0);
 		// summary just before the last update of this block (level 1 is always reached: OMB:1128 starts at 1)
 		Summ pre = blockSummary(t, g, s, 1, 0, c_last, v_old_last, 0, old_rgb_last);
@@ -473,7 +479,7 @@ __global__ __launch_bounds__(256) void k_apply_leaf(Table t, MapGeom g, const En
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_apply_values(Table t, MapGeom g, const Entry* __restrict__ entries, const u32* n_entries_p,
                                                       const u32* __restrict__ ent_slot, float upd_hit, float upd_miss, u32 mode, u32 phase,
-                                                      u64 time_hi, u32* __restrict__ wl, ScanCtl::PhaseCtr* pc, const ScanCtl* ctl)
+                                                      u64 time_hi, u32* __restrict__ wl, ScanCtl::PhaseCtr* pc, const ScanCtl* ctl, ChangeLog cl)
 {
 	const u32 n = *n_entries_p;
 	if (ctl->err) return;
@@ -496,21 +502,27 @@ __global__ __launch_bounds__(256) void k_apply_values(Table t, MapGeom g, const 
 			const int c_last = (2 == mode && last_is_miss) ? (31 - __clz((int)mmask)) : (int)e.c_last;
 			const u64 t_last = last_is_miss ? UFO_MISS_TIME : (u64)e.t_last;
 			float v_old_last = 0.f;
+			u32 chg = 0;
 #pragma unroll
 			for (int c = 0; c < 8; ++c) {
 				float x = v[c];
 				if ((hmask >> c) & 1) {
 					if (c == c_last && !last_is_miss) v_old_last = x;
-					x = clampAdd(x, upd_hit, g.cmin, g.cmax);
+					const float y = clampAdd(x, upd_hit, g.cmin, g.cmax);
+					chg |= (y != x) ? (1u << c) : 0u;
+					x = y;
 				}
 				if ((mmask >> c) & 1) {
 					if (c == c_last) v_old_last = x;  // last_is_miss
-					x = clampAdd(x, upd_miss, g.cmin, g.cmax);
+					const float y = clampAdd(x, upd_miss, g.cmin, g.cmax);
+					chg |= (y != x) ? (1u << c) : 0u;
+					x = y;
 				}
 				v[c] = x;
 			}
 			po[0] = make_float4(v[0], v[1], v[2], v[3]);
 			po[1] = make_float4(v[4], v[5], v[6], v[7]);
+			logChanges(t, cl, (e.lk ^ (1ULL << (3 * (g.L - 1)))) << 3, 0u, chg);
 			t.lu_occ[8 * (size_t)s + c_last] = v_old_last;
 			t.tmax[s] = (UFO_TAG(phase) << 40) | ((time_hi | t_last) << 3) | (u64)c_last;
 			first = !(atomicOr(&t.flags(s), F_DIRTY) & F_DIRTY);
@@ -584,13 +596,14 @@ __device__ inline void visitPush(u32 slot, u32* __restrict__ dlist, u32 dcap, Sc
 
 __global__ __launch_bounds__(256) void k_coarse_begin(Table t, MapGeom g, const Entry* __restrict__ entries, const u32* n_entries_p,
                                                       const u32* __restrict__ ent_slot, float miss, CoarseRec* __restrict__ rec,
-                                                      u32* __restrict__ dlist, u32 dcap, ScanCtl* ctl)
+                                                      u32* __restrict__ dlist, u32 dcap, ScanCtl* ctl, ChangeLog cl)
 {
 	u32 n = *n_entries_p;
 	if (ctl->err) return;
 	for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
 		Entry e = entries[i];
 		u32 s = ent_slot[i];
+		u32 chg = 0;
 		CoarseRec r;
 		u32 f = t.flags(s);
 		r.old_flags = f;
@@ -612,6 +625,7 @@ __global__ __launch_bounds__(256) void k_coarse_begin(Table t, MapGeom g, const 
 			} else {
 				float nv = clampAdd(v, miss, g.cmin, g.cmax);
 				*pv = nv;
+				chg |= (nv != v) ? (1u << c) : 0u;  // updateValue on a leaf: the update's own code (OMB:1069-1072)
 				u32 nbits = (isFreeV(g, nv) ? (1u << c) : 0u) | (isUnknownV(g, nv) ? (1u << (8 + c)) : 0u);
 				u32 obits = f & ((1u << c) | (1u << (8 + c)));
 				if (nbits != obits) {
@@ -625,6 +639,7 @@ __global__ __launch_bounds__(256) void k_coarse_begin(Table t, MapGeom g, const 
 			t.flags(s) = nf;
 		}
 		rec[i] = r;
+		logChanges(t, cl, (e.lk ^ (1ULL << (3 * (g.L - (u32)e.level)))) << 3, (u32)e.level - 1u, chg);
 	}
 }
 
@@ -632,7 +647,7 @@ __global__ __launch_bounds__(256) void k_coarse_begin(Table t, MapGeom g, const 
 __global__ void k_coarse_mark(ScanCtl* ctl, u32 level) { ctl->dl_start[level] = ctl->dl_total; }
 
 __global__ __launch_bounds__(256) void k_coarse_down(Table t, MapGeom g, u32 level, float miss, u32* __restrict__ dlist, u32 dcap,
-                                                     ScanCtl* ctl)
+                                                     ScanCtl* ctl, ChangeLog cl, u32 ins_depth)
 {
 	if (ctl->err) return;
 	const u32 lo = ctl->dl_start[level + 1], hi = min(ctl->dl_start[level], dcap);
@@ -667,6 +682,12 @@ __global__ __launch_bounds__(256) void k_coarse_down(Table t, MapGeom g, u32 lev
 			po[0] = make_float4(v[0], v[1], v[2], v[3]);
 			po[1] = make_float4(v[4], v[5], v[6], v[7]);
 			t.flags(s) = nf | F_SUB;  // this block's word is private to this thread until the up pass
+			// updateAllChildren records the code of the node whose leaf child changed (OMB:1094-1095, 1106-1107). Below the
+			// update's own node the reference derives that code with Code::getChild (code.h:257-267), which ADDS the child
+			// index to a code whose centre-offset bits (octree.h:321: all three bits of digit depth-1 set) are still in
+			// place: the sum carries, and what lands in the set is the node's code + 7 in that digit. Reproduced as is.
+			const u64 own = lk ^ (1ULL << (3 * (g.L - level)));
+			logChange(t, cl, level < ins_depth ? own + (7ULL << (3 * (ins_depth - 1 - level))) : own, level);
 		}
 	}
 }
@@ -1162,6 +1183,125 @@ __global__ __launch_bounds__(256) void k_query(Table t, MapGeom g, const double*
 }
 
 // ------------------------------------------------------------------------------------------------
+// Leaf / tree iteration with bounding volume, state filter and min_depth: what
+// beginLeaves / beginTree (occupancy_map_base.h:93-165) yield when run to the end. The reference's iterator walks
+// depth-first (iterator/octree.h:255-300), descending into a node only if validNode holds for it
+// (iterator/occupancy_map.h:168-190: the node's box intersects the bounding volume AND the state filter -- on the
+// contains_* summaries unless the node sits at min_depth and `contains` is off) and returning it if validReturnNode
+// holds (192-207: leaves and min_depth nodes for the leaf iterator). Here the same predicates run level by level:
+// one record per inner node to descend into, its centre carried along because the reference accumulates child
+// centres from the root down (octree.h:625-633); matching nodes are appended unordered and the host sorts them
+// into pre-order.
+// ------------------------------------------------------------------------------------------------
+struct IterArgs {
+	double vc[3], vh[3];  // the bounding volume: AABB centre, half size
+	u32 has_bv, occ, fre, unk, contains, min_depth, only_leaf, pad;
+};
+struct IterRec {
+	u64 lk;  // key of the node's children block
+	double c[3];
+};
+struct IterOut {
+	u64* codes;
+	u8* depths;
+	float* occ;
+	u32* rgb;
+	u8* flags;
+	u32 cap;
+};
+__device__ inline bool iterState(const MapGeom& g, const IterArgs& a, float v, u32 cf, u32 cu, u32 depth, bool use_contains)
+{
+	const bool isocc = g.occ_thr < (double)v, isfree = isFreeV(g, v), isunk = isUnknownV(g, v);
+	if (use_contains) {
+		// containsOccupied = isOccupied; containsFree / containsUnknown: own state at depth 0, stored flags above (OMB:946-980)
+		const bool cfree = (0 == depth) ? isfree : (0 != cf), cunk = (0 == depth) ? isunk : (0 != cu);
+		return (a.occ && isocc) || (a.unk && cunk) || (a.fre && cfree);
+	}
+	return (a.occ && isocc) || (a.unk && isunk) || (a.fre && isfree);
+}
+__device__ inline void iterVisit(const Table& t, const MapGeom& g, const IterArgs& a, u64 node_code, u32 depth, const double c[3], float v,
+                                 u32 cf, u32 cu, u32 rgb, bool has_children, u64 child_lk, IterRec* __restrict__ rec, u32 rcap,
+                                 const IterOut& out, ScanCtl* ctl)
+{
+	if (a.has_bv) {
+		VolArgs va;
+		for (int k = 0; k < 3; ++k) {
+			va.vc[k] = a.vc[k];
+			va.vh[k] = a.vh[k];
+		}
+		if (!volIntersects(va, c, g.hs[depth])) return;  // Base::validNode (iterator/octree.h:214-244)
+	}
+	if (!iterState(g, a, v, cf, cu, depth, a.contains || a.min_depth != depth)) return;  // validNode
+	const bool leaf = !has_children;
+	const bool ret = a.only_leaf ? ((a.min_depth == depth || leaf) && iterState(g, a, v, cf, cu, depth, false))
+	                             : iterState(g, a, v, cf, cu, depth, 0 != a.contains);
+	if (ret) {
+		const u32 pos = atomicAdd(&ctl->n_codes, 1u);
+		if (pos < out.cap) {
+			out.codes[pos] = node_code;
+			out.depths[pos] = (u8)depth;
+			out.occ[pos] = v;
+			out.rgb[pos] = rgb;
+			out.flags[pos] = (u8)((0 == depth ? ((isFreeV(g, v) ? 1u : 0u) | (isUnknownV(g, v) ? 2u : 0u)) : ((cf ? 1u : 0u) | (cu ? 2u : 0u))) |
+			                      (leaf ? 4u : 0u));
+		}
+	}
+	if (!(depth <= a.min_depth || leaf)) {  // singleIncrement: descend (iterator/octree.h:266-274)
+		const u32 rp = atomicAdd(&ctl->dl_total, 1u);
+		if (rp < rcap) {
+			IterRec r;
+			r.lk = child_lk;
+			r.c[0] = c[0];
+			r.c[1] = c[1];
+			r.c[2] = c[2];
+			rec[rp] = r;
+		} else {
+			atomicOr(&ctl->err, ERR_ENTRIES);
+		}
+	}
+}
+__global__ void k_iter_root(Table t, MapGeom g, IterArgs a, IterRec* __restrict__ rec, u32 rcap, IterOut out, ScanCtl* ctl)
+{
+	ctl->dl_start[g.L] = 0;
+	if (g.L >= a.min_depth) {  // init(): `current_depth_ >= min_depth_` (iterator/octree.h:203)
+		const u32 rs = tableFind(t, 1);
+		const bool has_children = rs != NONE && !(t.flags(rs) & F_DEAD);
+		const double c[3] = {0.0, 0.0, 0.0};
+		iterVisit(t, g, a, 0, g.L, c, t.root->occ, t.root->flags & 1u, t.root->flags & 2u, t.root->rgb, has_children, 1, rec, rcap, out, ctl);
+	}
+	ctl->dl_start[g.L - 1] = ctl->dl_total;
+}
+// the records of depth `cd` nodes are [dl_start[cd], dl_start[cd-1]); their children (depth cd-1) are visited
+__global__ __launch_bounds__(256) void k_iter_level(Table t, MapGeom g, IterArgs a, u32 cd, IterRec* __restrict__ rec, u32 rcap, IterOut out,
+                                                    ScanCtl* ctl)
+{
+	const u32 lo = ctl->dl_start[cd], hi = min(ctl->dl_start[cd - 1], rcap);
+	const u32 n = (hi - lo) * 8u;
+	const u32 child_depth = cd - 1;
+	const double chs = g.hs[child_depth];
+	for (u32 w = blockIdx.x * blockDim.x + threadIdx.x; w < n; w += gridDim.x * blockDim.x) {
+		const IterRec me = rec[lo + (w >> 3)];
+		const u32 i = w & 7u;
+		const u32 s = tableFind(t, me.lk);
+		if (s == NONE) continue;
+		const u32 f = t.flags(s);
+		double cc[3] = {me.c[0], me.c[1], me.c[2]};  // getChildCenter (octree.h:625-633)
+		cc[0] += ((i & 1) ? chs : -chs);
+		cc[1] += ((i & 2) ? chs : -chs);
+		cc[2] += ((i & 4) ? chs : -chs);
+		const u64 clk = (me.lk << 3) | (u64)i;
+		bool has_children = false;
+		if (child_depth >= 1 && ((f >> (16 + i)) & 1u)) {
+			const u32 cs = tableFind(t, clk);
+			has_children = cs != NONE && !(t.flags(cs) & F_DEAD);
+		}
+		const u64 code = clk ^ (1ULL << (3 * (g.L - child_depth)));
+		iterVisit(t, g, a, code, child_depth, cc, t.occ(s)[i], (f >> i) & 1u, (f >> (8 + i)) & 1u, t.rgb ? t.rgb[8 * (size_t)s + i] : 0u,
+		          has_children, clk, rec, rcap, out, ctl);
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
 // read-back
 // ------------------------------------------------------------------------------------------------
 struct DumpCtl {
@@ -1328,25 +1468,55 @@ __global__ __launch_bounds__(256) void k_ser_collect(Table t, MapGeom g, const u
 		list[level_off[l] + atomicAdd(&level_fill[l], 1u)] = s;
 	}
 }
-__global__ __launch_bounds__(256) void k_ser_sizes(Table t, MapGeom g, const u32* __restrict__ list, u32 n, u32 level, u32 D,
+// Bounding volume and min_depth of Octree::write / writeData (octree.h:779-917): only children whose box intersects the
+// volume are written (the mask byte is written regardless), and nodes at depth <= min_depth are written as leaves.
+struct SerArgs {
+	double vc[3], vh[3];
+	u32 has_bv, min_depth;
+};
+// centre of the node whose children block has key lk (node depth = level), accumulated from the root down exactly as
+// writeNodesRecurs does through getChildCenter (octree.h:625-633)
+__device__ inline void keyCenter(const MapGeom& g, u64 lk, u32 level, double c[3])
+{
+	c[0] = c[1] = c[2] = 0.0;
+	for (u32 d = g.L; d-- > level;) {
+		const u32 idx = (u32)((lk >> (3 * (d - level))) & 7u);
+		const double hs = g.hs[d];
+		c[0] += ((idx & 1) ? hs : -hs);
+		c[1] += ((idx & 2) ? hs : -hs);
+		c[2] += ((idx & 4) ? hs : -hs);
+	}
+}
+__device__ inline bool serChildIn(const SerArgs& sa, const double c[3], u32 i, double chs)
+{
+	if (!sa.has_bv) return true;
+	const double cc[3] = {c[0] + ((i & 1) ? chs : -chs), c[1] + ((i & 2) ? chs : -chs), c[2] + ((i & 4) ? chs : -chs)};
+	VolArgs va;
+	for (int k = 0; k < 3; ++k) {
+		va.vc[k] = sa.vc[k];
+		va.vh[k] = sa.vh[k];
+	}
+	return volIntersects(va, cc, chs);
+}
+__global__ __launch_bounds__(256) void k_ser_sizes(Table t, MapGeom g, SerArgs sa, const u32* __restrict__ list, u32 n, u32 level, u32 D,
                                                    u64* __restrict__ size)
 {
+	const double chs = g.hs[level - 1];
 	for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
 		const u32 s = list[i];
-		if (1 == level) {
-			size[s] = 8ull * D;
-			continue;
-		}
 		const u64 lk = t.key(s);
+		double c[3];
+		if (sa.has_bv) keyCenter(g, lk, level, c);
 		const u32 f = t.flags(s);
-		u64 sz = 1;
-		for (u32 c = 0; c < 8; ++c) {
-			if ((f >> (16 + c)) & 1u) {
-				u32 cs = tableFind(t, (lk << 3) | (u64)c);
-				sz += (cs != NONE) ? size[cs] : D;
-			} else {
-				sz += D;
+		u64 sz = (1 == level) ? 0 : 1;  // the eight leaves of a depth-1 node follow each other without a mask byte
+		for (u32 ch = 0; ch < 8; ++ch) {
+			if (!serChildIn(sa, c, ch, chs)) continue;
+			u64 add = D;
+			if (level >= 2 && level - 1 > sa.min_depth && ((f >> (16 + ch)) & 1u)) {
+				const u32 cs = tableFind(t, (lk << 3) | (u64)ch);
+				if (cs != NONE && !(t.flags(cs) & F_DEAD)) add = size[cs];
 			}
+			sz += add;
 		}
 		size[s] = sz;
 	}
@@ -1365,27 +1535,141 @@ __device__ inline void serPutLeaf(uint8_t* __restrict__ out, u64 at, float v, u3
 		out[at + 6] = (uint8_t)(rgb >> 16);
 	}
 }
-__global__ __launch_bounds__(256) void k_ser_write(Table t, MapGeom g, const u32* __restrict__ list, u32 n, u32 level, u32 D,
+// off[] is pre-set to ~0: a block whose offset nobody wrote lies outside the bounding volume (or below min_depth)
+__global__ __launch_bounds__(256) void k_ser_write(Table t, MapGeom g, SerArgs sa, const u32* __restrict__ list, u32 n, u32 level, u32 D,
                                                    const u64* __restrict__ size, u64* __restrict__ off, uint8_t* __restrict__ out)
 {
+	const double chs = g.hs[level - 1];
 	for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
 		const u32 s = list[i];
 		const u64 lk = t.key(s);
 		u64 at = (1 == lk) ? 1ull : off[s];  // the root's subtree starts behind the 0xFF byte of writeNodes
+		if (at == ~0ull) continue;
+		double c[3];
+		if (sa.has_bv) keyCenter(g, lk, level, c);
 		const u32 f = t.flags(s);
-		if (level >= 2) out[at++] = (uint8_t)((f >> 16) & 0xFFu);
-		for (u32 c = 0; c < 8; ++c) {
-			if (level >= 2 && ((f >> (16 + c)) & 1u)) {
-				u32 cs = tableFind(t, (lk << 3) | (u64)c);
-				if (cs != NONE) {
-					off[cs] = at;
-					at += size[cs];
-					continue;
+		u32 cslot[8];
+		u32 mask = 0;
+		for (u32 ch = 0; ch < 8; ++ch) {
+			cslot[ch] = NONE;
+			if (level >= 2 && level - 1 > sa.min_depth && ((f >> (16 + ch)) & 1u)) {
+				const u32 cs = tableFind(t, (lk << 3) | (u64)ch);
+				if (cs != NONE && !(t.flags(cs) & F_DEAD)) {
+					cslot[ch] = cs;
+					mask |= 1u << ch;
 				}
 			}
-			serPutLeaf(out, at, t.occ(s)[c], t.rgb ? t.rgb[8 * (size_t)s + c] : 0u, D);
+		}
+		if (level >= 2) out[at++] = (uint8_t)mask;  // written for all eight children, intersecting or not (OMB:1500-1512)
+		for (u32 ch = 0; ch < 8; ++ch) {
+			if (!serChildIn(sa, c, ch, chs)) continue;
+			if (cslot[ch] != NONE) {
+				off[cslot[ch]] = at;
+				at += size[cslot[ch]];
+				continue;
+			}
+			serPutLeaf(out, at, t.occ(s)[ch], t.rgb ? t.rgb[8 * (size_t)s + ch] : 0u, D);
 			at += D;
 		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// Reading a node stream into the map (second half): OccupancyMapBase::readNodes / readNodesRecurs
+// (occupancy_map_base.h:1379-1455). The stream is pre-order with implicit structure, so the host walks it once (sizes
+// of earlier siblings decide where a subtree starts) and emits one ReadRec per node that has children in the stream;
+// the device then does what the recursion does, level by level: createChildren on the node (a leaf is expanded by
+// inheritance), for every child inside the bounding volume either the stream's leaf data (deleteChildren + readData +
+// the leaf's own updateNode) or the recursion, and on the way back updateNode on every node of the stream.
+// ------------------------------------------------------------------------------------------------
+struct ReadRec {
+	u64 lk;          // key of the node's children block
+	u32 parent;      // record of the parent node (NONE for the root)
+	u32 slot;        // table slot, filled by k_read_down
+	u32 set_mask;    // children whose leaf data the stream holds
+	u32 inner_mask;  // children that have children in the stream
+	float val[8];
+	u32 rgb[8];
+	u32 pad[2];
+};
+__global__ __launch_bounds__(256) void k_read_down(Table t, MapGeom g, ReadRec* __restrict__ rec, u32 lo, u32 hi, u32 level, u32* __restrict__ kill,
+                                                   u32 kcap, u32 scan_id, ScanCtl* ctl)
+{
+	const u32 max_probe = (t.mask >> 1) + 1;
+	u32 n_created = 0;
+	for (u32 r = lo + blockIdx.x * blockDim.x + threadIdx.x; r < hi; r += gridDim.x * blockDim.x) {
+		const ReadRec me = rec[r];
+		bool created;
+		const u32 s = tableEnsure(t, me.lk, scan_id, max_probe, &created, &n_created);
+		if (s == NONE) {
+			atomicOr(&ctl->err, ERR_TABLE_FULL);
+			continue;
+		}
+		rec[r].slot = s;
+		if (created) {
+			// createChildren (octree.h:1022-1058): the 8 children are copies of the node
+			float v;
+			u32 col = 0;
+			if (1 == me.lk) {
+				t.parent(s) = NONE;
+				v = t.root->occ;
+				col = t.root->rgb;
+			} else {
+				const u32 p = rec[me.parent].slot, ci = (u32)(me.lk & 7);
+				t.parent(s) = p;
+				atomicOr(&t.flags(p), 1u << (16 + ci));
+				v = t.occ(p)[ci];
+				if (g.color) col = t.rgb[8 * (size_t)p + ci];
+			}
+			const float4 vv = make_float4(v, v, v, v);
+			float4* po = reinterpret_cast<float4*>(t.occ(s));
+			po[0] = vv;
+			po[1] = vv;
+			if (g.color) {
+				const uint4 cc = make_uint4(col, col, col, col);
+				uint4* pc = reinterpret_cast<uint4*>(t.rgb + 8 * (size_t)s);
+				pc[0] = cc;
+				pc[1] = cc;
+			}
+			t.flags(s) = (isFreeV(g, v) ? F_CFREE : 0u) | (isUnknownV(g, v) ? F_CUNK : 0u);
+		}
+		u32 f = t.flags(s);
+		for (u32 i = 0; i < 8; ++i) {
+			if (!((me.set_mask >> i) & 1u)) continue;
+			if (level >= 2 && (f & (1u << (16 + i)))) {
+				// deleteChildren(child) (occupancy_map_base.h:1446): its whole subtree dies
+				const u32 cs = tableFind(t, (me.lk << 3) | (u64)i);
+				if (cs != NONE) {
+					const u32 kp = atomicAdd(&ctl->n_codes, 1u);
+					if (kp < kcap) kill[kp] = cs;
+					else atomicOr(&ctl->err, ERR_ENTRIES);
+				}
+				f &= ~(1u << (16 + i));
+			}
+			const float v = me.val[i];
+			t.occ(s)[i] = v;
+			if (g.color) t.rgb[8 * (size_t)s + i] = me.rgb[i];
+			// the leaf's own updateNode: indicators from its value (OMB:1181-1189)
+			f = (f & ~((1u << i) | (1u << (8 + i)))) | (isFreeV(g, v) ? (1u << i) : 0u) | (isUnknownV(g, v) ? (1u << (8 + i)) : 0u);
+		}
+		// this block's word is private to this thread during the launch: other records' creations set bits in THEIR
+		// parents' words, which are blocks of the previous (upper) level
+		t.flags(s) = f;
+	}
+	for (int o = 32; o > 0; o >>= 1) n_created += __shfl_xor(n_created, o);
+	if (__lane_id() == 0 && n_created) atomicAdd(&t.root->used, n_created);
+}
+// updateNode on the way back (occupancy_map_base.h:1438, 1447, 1452): every node of the stream, unconditionally
+__global__ __launch_bounds__(256) void k_read_up(Table t, MapGeom g, const ReadRec* __restrict__ rec, u32 lo, u32 hi, u32 level, const ScanCtl* ctl)
+{
+	if (ctl->err) return;
+	for (u32 r = lo + blockIdx.x * blockDim.x + threadIdx.x; r < hi; r += gridDim.x * blockDim.x) {
+		const u32 s = rec[r].slot;
+		const u64 lk = rec[r].lk;
+		const u32 f = t.flags(s);
+		const Summ sm = blockSummary(t, g, s, level, f);
+		if (sm.collapsible) collapseBlock(t, s, lk);
+		(void)writeToParent(t, g, s, lk, sm);
 	}
 }
 

@@ -46,6 +46,17 @@ struct MapRoot {
 	u32 flags;  // bit0 contains_free, bit1 contains_unknown
 	u32 rgb;
 	u32 used;  // number of occupied table slots
+	u32 n_changes;     // change detection (occupancy_map_base.h:779-791): records appended to the change log so far
+	u32 chg_overflow;  // a record did not fit the log (the host sizes it for the worst case: must stay 0)
+	u32 pad[2];
+};
+
+// Change log: while change detection is enabled every leaf update that changes a value appends the code the reference
+// inserts into `changes_` (occupancy_map_base.h:1070-1072, 1094-1108) as (code >> 3*depth) | depth << 58; the host
+// sorts and de-duplicates when the set is read (ufomap_map_changes). buf == nullptr: disabled.
+struct ChangeLog {
+	u64* buf;
+	u32 cap;
 };
 
 // One table slot: the record of one 8-child node block, 64 bytes, 64-byte aligned -- what a lookup finds (the key),
@@ -133,5 +144,25 @@ __device__ inline u32 tableEnsure(const Table& t, u64 lk, u32 scan_id, u32 max_p
 		s = (s + 1) & t.mask;
 	}
 	return NONE;
+}
+// children `mask` of the node whose children have codes base | c at `depth`
+__device__ inline void logChanges(const Table& t, const ChangeLog& cl, u64 base, u32 depth, u32 mask)
+{
+	if (!cl.buf || 0 == mask) return;
+	u32 pos = atomicAdd(&t.root->n_changes, (u32)__popc(mask));
+	while (mask) {
+		const u32 c = (u32)__ffs(mask) - 1u;
+		mask &= mask - 1u;
+		if (pos < cl.cap) cl.buf[pos] = (base | (u64)c) | ((u64)depth << 58);
+		else t.root->chg_overflow = 1u;
+		++pos;
+	}
+}
+__device__ inline void logChange(const Table& t, const ChangeLog& cl, u64 code_shifted, u32 depth)
+{
+	if (!cl.buf) return;
+	const u32 pos = atomicAdd(&t.root->n_changes, 1u);
+	if (pos < cl.cap) cl.buf[pos] = code_shifted | ((u64)depth << 58);
+	else t.root->chg_overflow = 1u;
 }
 }  // namespace ufo

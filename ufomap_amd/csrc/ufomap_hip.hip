@@ -12,9 +12,11 @@
 // k_ray_setup + k_walk / k_dda_seg / k_dda, insert depth > 0 adds the k_coarse_* phase and walks the tree twice.
 // There is no CPU fallback: every entry point fails with UFOMAP_ERR_DEVICE when HIP is unusable.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <sstream>
@@ -148,6 +150,11 @@ struct ufomap_map {
 	                  // the other set of hand-over buffers
 	int async_status = UFOMAP_OK;   // first error of an integration that was joined by a later call
 	MapGeom g{};
+	double model_log[6] = {0, 0, 0, 0, 0, 0};  // toLogit of occupied_thres, free_thres, prob_hit, prob_miss, clamp min, clamp max (OMB:1536-1542)
+	bool chg_enabled = false;                 // enableChangeDetection (OMB:783): leaf updates append to the change log
+	DevBuf b_changes;                         // the log: u64 records (table.h: ChangeLog)
+	u32 chg_cap = 0;
+	bool minmax_enabled = true;               // enableMinMaxChangeDetection (OMB:791-797); on by default, as the server sets it
 	// node table
 	Table t{};
 	TableBufs tb;
@@ -328,24 +335,33 @@ int resetRoot(ufomap_map* m)
 	m->h_root->flags = (isFreeV(m->g, 0.0f) ? 1u : 0u) | (isUnknownV(m->g, 0.0f) ? 2u : 0u);
 	m->h_root->rgb = 0;
 	m->h_root->used = 0;
-	HIP_TRY(hipMemcpyAsync(m->b_root.p, m->h_root, sizeof(MapRoot), hipMemcpyHostToDevice, m->stream));
+	// (the change log's counters behind these four words stay: Octree::clear does not touch changes_)
+	HIP_TRY(hipMemcpyAsync(m->b_root.p, m->h_root, offsetof(MapRoot, n_changes), hipMemcpyHostToDevice, m->stream));
 	HIP_TRY(hipStreamSynchronize(m->stream));
 	m->used_est = 0;
 	return UFOMAP_OK;
 }
 
-void setSensorModel(MapGeom& g, double occupied_thres, double free_thres, double prob_hit, double prob_miss, double cmin,
-                    double cmax)
+// sensor model from its six logits (occupancy_map_base.h:864-869, 909): thresholds stay double (OMB:926-940), the
+// update and clamping values are narrowed to LogitType = float where they are used (OMB:296, 311, 1142-1143)
+void applyModel(ufomap_map* m)
 {
-	auto logit = [](double p) { return std::log(p / (1.0 - p)); };  // occupancy_map_base.h:909
-	g.occ_thr = logit(occupied_thres);
-	g.free_thr = logit(free_thres);
-	g.hit = (float)logit(prob_hit);
-	g.miss_log = logit(prob_miss);
-	g.cmin = (float)logit(cmin);
-	g.cmax = (float)logit(cmax);
+	MapGeom& g = m->g;
+	g.occ_thr = m->model_log[0];
+	g.free_thr = m->model_log[1];
+	g.hit = (float)m->model_log[2];
+	g.miss_log = m->model_log[3];
+	g.cmin = (float)m->model_log[4];
+	g.cmax = (float)m->model_log[5];
 	// toProb(update) with LogitType=float: std::exp(float) (occupancy_map_base.h:911)
 	g.prob_hit_f = 1.0 / (1.0 + std::exp(-g.hit));
+}
+void setSensorModel(ufomap_map* m, double occupied_thres, double free_thres, double prob_hit, double prob_miss, double cmin, double cmax)
+{
+	auto logit = [](double p) { return std::log(p / (1.0 - p)); };  // occupancy_map_base.h:909
+	const double v[6] = {occupied_thres, free_thres, prob_hit, prob_miss, cmin, cmax};
+	for (int k = 0; k < 6; ++k) m->model_log[k] = logit(v[k]);
+	applyModel(m);
 }
 
 // upper bound on the node blocks a list of n entries at `level` inside a grid of nb[] blocks can
@@ -466,6 +482,38 @@ u64 levelBound(const i32 nb[3], u32 shift)
 	return vol > 1e18L ? (u64)1e18 : (u64)vol;
 }
 
+
+// ---- change log (change detection) ------------------------------------------------------------------------------
+// the log the update kernels append to; empty (disabled) unless enableChangeDetection is on
+ChangeLog changeLog(const ufomap_map* m) { return m->chg_enabled ? ChangeLog{m->b_changes.as<u64>(), m->chg_cap} : ChangeLog{nullptr, 0u}; }
+
+// room for `extra` more records: the log grows by copy. Synchronises the map stream (change detection runs every
+// update synchronously, see doInsert: it is a diagnostic mode, not the fast path).
+int ensureChangeCap(ufomap_map* m, u64 extra)
+{
+	if (!m->chg_enabled) return UFOMAP_OK;
+	HIP_TRY(hipStreamSynchronize(m->stream));
+	HIP_TRY(hipMemcpy(m->h_root, m->b_root.p, sizeof(MapRoot), hipMemcpyDeviceToHost));
+	const u64 have = m->h_root->n_changes;
+	if (have + extra <= m->chg_cap) return UFOMAP_OK;
+	const u64 want = std::max<u64>(have + extra, (u64)m->chg_cap * 2);
+	if (want > 0xFFFFFFF0ull) return fail(UFOMAP_ERR_CAPACITY, "change log exceeds 2^32 records (read or reset the change set)");
+	void* np = nullptr;
+	HIP_TRY(hipMalloc(&np, (size_t)want * 8));
+	if (have) {
+		hipError_t e = hipMemcpy(np, m->b_changes.p, (size_t)std::min<u64>(have, m->chg_cap) * 8, hipMemcpyDeviceToDevice);
+		if (e != hipSuccess) {
+			(void)hipFree(np);
+			return fail(UFOMAP_ERR_DEVICE, hipGetErrorString(e));
+		}
+	}
+	m->b_changes.release();
+	m->b_changes.p = np;
+	m->b_changes.cap = (size_t)want * 8;
+	m->chg_cap = (u32)want;
+	return UFOMAP_OK;
+}
+
 // updateParents (OMB:1126-1133) from level `first` upward: wide levels one launch each, the narrow rest in one
 // launch. bound(l) = upper bound of the queued blocks of level l; the level-l worklist is b_wl[l & 1].
 template <typename F>
@@ -505,6 +553,11 @@ int applyEntries(ufomap_map* m, const Entry* d_entries, u32 cap, u32 which, u32 
 		if (merged && capB) b += std::min<u64>(capB, levelBound(nbB, sh));
 		return b;
 	};
+	if (m->chg_enabled) {
+		const int crc = ensureChangeCap(m, (u64)cap * 8 + ((1 == level) ? 0 : (u64)m->t.mask + 1));
+		if (crc) return crc;
+	}
+	const ChangeLog cl = changeLog(m);
 	m->scan_id += 1;  // "new this phase" stamp: blocks made by an earlier phase of the same scan are old
 	u64 newcap = (capA ? blockBound(m, capA, nb, level) : 0) + ((merged && capB) ? blockBound(m, capB, nbB, level) : 0);
 	HIP_TRY(m->b_ent_slot.reserve((size_t)cap * 4));
@@ -534,7 +587,7 @@ int applyEntries(ufomap_map* m, const Entry* d_entries, u32 cap, u32 which, u32 
 		const u32 mode = merged ? 2u : (which == 0 ? 1u : 0u);
 		hipLaunchKernelGGL(k_apply_leaf, ge, dim3(256), 0, m->cs, m->t, m->g, d_entries, d_n, m->b_ent_slot.as<u32>(),
 		                   merged ? upd : (which == 0 ? upd : 0.f), merged ? upd_miss : (which == 0 ? 0.f : upd), mode, m->scan_id, hh,
-		                   d_rgb, wl[0], pc, ctl);
+		                   d_rgb, wl[0], pc, ctl, cl);
 	} else {
 		// coarse misses: level-synchronous walk of the subtrees below the masked children (map_kernels.h S3c)
 		// every live block can be visited: blocks known at the last control-block read + everything this scan may add
@@ -549,12 +602,12 @@ int applyEntries(ufomap_map* m, const Entry* d_entries, u32 cap, u32 which, u32 
 		{
 			ProfScope ps(m, "k_coarse_begin");
 			hipLaunchKernelGGL(k_coarse_begin, ge, dim3(256), 0, m->cs, m->t, m->g, d_entries, d_n, m->b_ent_slot.as<u32>(), upd, rec,
-			                   dl, dcap, ctl);
+			                   dl, dcap, ctl, cl);
 			hipLaunchKernelGGL(k_coarse_mark, dim3(1), dim3(1), 0, m->cs, ctl, level - 1);
 		}
 		for (u32 l = level - 1; l >= 1; --l) {
 			ProfScope ps(m, "k_coarse_down");
-			hipLaunchKernelGGL(k_coarse_down, gd, dim3(256), 0, m->cs, m->t, m->g, l, upd, dl, dcap, ctl);
+			hipLaunchKernelGGL(k_coarse_down, gd, dim3(256), 0, m->cs, m->t, m->g, l, upd, dl, dcap, ctl, cl, level - 1);
 			if (l > 1) hipLaunchKernelGGL(k_coarse_mark, dim3(1), dim3(1), 0, m->cs, ctl, l - 1);
 		}
 		for (u32 l = 1; l + 1 <= level; ++l) {
@@ -755,7 +808,7 @@ int finishPending(ufomap_map* m)
 	m->counts[7] = m->h_ctl->n_oob;
 	for (int a = 0; a < 3; ++a) {
 		double lo = decD(m->h_ctl->aabb_min[a]), hi = decD(m->h_ctl->aabb_max[a]);
-		if (m->h_ctl->aabb_min[a] != ~0ull) {
+		if (m->minmax_enabled && m->h_ctl->aabb_min[a] != ~0ull) {  // OMB:1367: only while enabled
 			m->min_change[a] = std::min(m->min_change[a], lo);
 			m->max_change[a] = std::max(m->max_change[a], hi);
 		}
@@ -1072,6 +1125,7 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 	// the reference overlaps its head loop with the previous integration the same way (the join sits
 	// after the head loop, OMB:315). Hand-over buffers are double-buffered and swapped here.
 	if (!swapped) (void)rotateSets(m);
+	if (m->chg_enabled) async = 0;  // the change log is sized between updates: one update at a time
 	m->cs = m->sstream;
 	// insert depth 0: hits and misses of the scan as ONE pass over the tree (map_kernels.h, k_apply_leaf mode 2)
 	const bool merged = 0 == depth && 0 != m->opt_merge;
@@ -1263,7 +1317,7 @@ ufomap_map* ufomap_map_create(double resolution, unsigned depth_levels, int auto
 	for (unsigned i = 2; i < 23; ++i) g.hs[i] = g.hs[i - 1] * 2.0;
 	g.color = has_color ? 1 : 0;
 	g.pruning = automatic_pruning ? 1 : 0;
-	setSensorModel(g, occupied_thres, free_thres, prob_hit, prob_miss, clamping_thres_min, clamping_thres_max);
+	setSensorModel(m, occupied_thres, free_thres, prob_hit, prob_miss, clamping_thres_min, clamping_thres_max);
 	bool ok = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) == hipSuccess &&
 	          hipStreamCreateWithFlags(&m->sstream, hipStreamNonBlocking) == hipSuccess &&
 	          hipStreamCreateWithFlags(&m->xstream, hipStreamNonBlocking) == hipSuccess &&
@@ -1287,8 +1341,7 @@ ufomap_map* ufomap_map_create(double resolution, unsigned depth_levels, int auto
 	memset(m->h_ctl, 0, sizeof(ScanCtl));
 	memset(m->alt[0].h_ctl, 0, sizeof(ScanCtl));
 	memset(m->alt[1].h_ctl, 0, sizeof(ScanCtl));
-	if (allocTable(m, 1u << 16, &m->t, &m->tb) ||
-	    resetRoot(m)) {
+	if (hipMemset(m->b_root.p, 0, sizeof(MapRoot)) != hipSuccess || allocTable(m, 1u << 16, &m->t, &m->tb) || resetRoot(m)) {
 		ufomap_map_destroy(m);
 		return nullptr;
 	}
@@ -1318,6 +1371,7 @@ void ufomap_map_destroy(ufomap_map* m)
 	if (m->sstream) (void)hipStreamSynchronize(m->sstream);
 	if (m->stream) (void)hipStreamSynchronize(m->stream);
 	m->tb.release();
+	m->b_changes.release();
 	for (HandOver& a : m->alt) {
 		DevBuf* abufs[] = {&a.b_ctl, &a.b_entries, &a.b_hh_keys, &a.b_in_xyz, &a.b_in_rgb};
 		for (DevBuf* b : abufs) b->release();
@@ -1384,8 +1438,15 @@ int ufomap_map_set_sensor_model(ufomap_map* m, double occupied_thres, double fre
 {
 	if (!m) return fail(UFOMAP_ERR_INVALID, "null map");
 	int rc = ufomap_map_wait(m);
-	setSensorModel(m->g, occupied_thres, free_thres, prob_hit, prob_miss, clamping_thres_min, clamping_thres_max);
-	return rc;
+	if (rc) return rc;
+	auto logit = [](double p) { return std::log(p / (1.0 - p)); };
+	if (logit(occupied_thres) != m->model_log[0] || logit(free_thres) != m->model_log[1]) {
+		// new thresholds change every stored contains_free / contains_unknown: re-evaluate the tree as the reference does
+		rc = ufomap_map_set_occupied_free_thres(m, occupied_thres, free_thres);
+		if (rc) return rc;
+	}
+	setSensorModel(m, occupied_thres, free_thres, prob_hit, prob_miss, clamping_thres_min, clamping_thres_max);
+	return UFOMAP_OK;
 }
 
 int ufomap_map_insert_device(ufomap_map* m, const double sensor_origin[3], const double* d_xyz, const uint8_t* d_rgb, size_t n,
@@ -1547,6 +1608,18 @@ int ufomap_map_set_value_volume(ufomap_map* m, const double aabb_min[3], const d
                                 unsigned min_depth)
 {
 	if (!m || !aabb_min || !aabb_max) return fail(UFOMAP_ERR_INVALID, "null argument");
+	double vc[3], vh[3];
+	for (int k = 0; k < 3; ++k) {
+		vh[k] = (aabb_max[k] - aabb_min[k]) / 2.0;  // AABB(min, max), geometry/aabb.h:62-65
+		vc[k] = aabb_min[k] + vh[k];
+	}
+	return ufomap_map_set_value_volume_ch(m, vc, vh, occupancy_value, min_depth);
+}
+
+int ufomap_map_set_value_volume_ch(ufomap_map* m, const double aabb_center[3], const double aabb_half[3], double occupancy_value,
+                                   unsigned min_depth)
+{
+	if (!m || !aabb_center || !aabb_half) return fail(UFOMAP_ERR_INVALID, "null argument");
 	HIP_TRY(hipSetDevice(m->device));
 	int rc = ufomap_map_wait(m);
 	if (rc) return rc;
@@ -1554,8 +1627,8 @@ int ufomap_map_set_value_volume(ufomap_map* m, const double aabb_min[3], const d
 	if (L < min_depth) return UFOMAP_OK;  // OMB:495-497
 	VolArgs a;
 	for (int k = 0; k < 3; ++k) {
-		a.vh[k] = (aabb_max[k] - aabb_min[k]) / 2.0;  // AABB(min, max), geometry/aabb.h:62-65
-		a.vc[k] = aabb_min[k] + a.vh[k];
+		a.vh[k] = aabb_half[k];
+		a.vc[k] = aabb_center[k];
 	}
 	a.min_depth = min_depth;
 	{
@@ -1632,6 +1705,217 @@ int ufomap_map_set_value_volume(ufomap_map* m, const double aabb_min[3], const d
 	m->pending = true;
 	HIP_TRY(hipStreamSynchronize(m->stream));
 	return finishPending(m);
+}
+
+int ufomap_map_clear_to(ufomap_map* m, double resolution, unsigned depth_levels)
+{
+	if (!m) return fail(UFOMAP_ERR_INVALID, "null map");
+	if (depth_levels < 2 || depth_levels > 21) return fail(UFOMAP_ERR_INVALID, "depth_levels has to be [2, 21]");
+	if (!(resolution > 0)) return fail(UFOMAP_ERR_INVALID, "resolution must be positive");
+	int rc = ufomap_map_clear(m);
+	if (rc) return rc;
+	MapGeom& g = m->g;
+	g.res = resolution;
+	g.rf = 1.0 / resolution;
+	g.L = depth_levels;
+	g.M = (u32)std::pow(2, depth_levels - 1);
+	g.hs[0] = resolution / 2.0;
+	g.hs[1] = resolution;
+	for (unsigned i = 2; i < 23; ++i) g.hs[i] = g.hs[i - 1] * 2.0;
+	m->spec_valid = false;
+	return UFOMAP_OK;
+}
+
+int ufomap_map_get_sensor_model(ufomap_map* m, double out[6])
+{
+	if (!m || !out) return fail(UFOMAP_ERR_INVALID, "null argument");
+	// toProb(LogitType) with LogitType = float: the stored double is narrowed first, std::exp(float) (OMB:734-744, 911)
+	for (int k = 0; k < 6; ++k) out[k] = 1.0 / (1.0 + std::exp(-(float)m->model_log[k]));
+	return UFOMAP_OK;
+}
+
+int ufomap_map_set_model_value(ufomap_map* m, int which, double probability)
+{
+	if (!m) return fail(UFOMAP_ERR_INVALID, "null map");
+	if (which < 2 || which > 5) return fail(UFOMAP_ERR_INVALID, "which: 2 prob_hit, 3 prob_miss, 4 clamping_thres_min, 5 clamping_thres_max");
+	int rc = ufomap_map_wait(m);
+	m->model_log[which] = std::log(probability / (1.0 - probability));
+	applyModel(m);
+	return rc;
+}
+
+int ufomap_map_enable_minmax_change_detection(ufomap_map* m, int enable)
+{
+	if (!m) return fail(UFOMAP_ERR_INVALID, "null map");
+	int rc = ufomap_map_wait(m);
+	if (!m->minmax_enabled && enable) {  // occupancy_map_base.h:793-795
+		for (int a = 0; a < 3; ++a) {
+			m->min_change[a] = m->g.hs[m->g.L];
+			m->max_change[a] = -m->g.hs[m->g.L];
+		}
+	}
+	m->minmax_enabled = enable != 0;
+	return rc;
+}
+
+int ufomap_map_enable_change_detection(ufomap_map* m, int enable)
+{
+	if (!m) return fail(UFOMAP_ERR_INVALID, "null map");
+	HIP_TRY(hipSetDevice(m->device));
+	int rc = ufomap_map_wait(m);
+	m->chg_enabled = enable != 0;
+	if (m->chg_enabled && 0 == m->chg_cap) {
+		HIP_TRY(m->b_changes.reserve((size_t)(1u << 20) * 8));
+		m->chg_cap = 1u << 20;
+	}
+	return rc;
+}
+
+int ufomap_map_reset_change_detection(ufomap_map* m)
+{
+	if (!m) return fail(UFOMAP_ERR_INVALID, "null map");
+	HIP_TRY(hipSetDevice(m->device));
+	int rc = ufomap_map_wait(m);
+	HIP_TRY(hipMemset(reinterpret_cast<char*>(m->b_root.p) + offsetof(MapRoot, n_changes), 0, 8));
+	return rc;
+}
+
+size_t ufomap_map_changes(ufomap_map* m, uint64_t* codes, uint8_t* depths, size_t cap)
+{
+	if (!m || ufomap_map_wait(m) < 0) return (size_t)-1;
+	MapRoot root;
+	if (hipMemcpy(&root, m->b_root.p, sizeof(MapRoot), hipMemcpyDeviceToHost) != hipSuccess) return (size_t)-1;
+	if (root.chg_overflow) {
+		fail(UFOMAP_ERR_CAPACITY, "change log overflowed (internal bound violated)");
+		return (size_t)-1;
+	}
+	const size_t n = root.n_changes;
+	std::vector<uint64_t> h(n);
+	if (n && hipMemcpy(h.data(), m->b_changes.p, n * 8, hipMemcpyDeviceToHost) != hipSuccess) return (size_t)-1;
+	std::sort(h.begin(), h.end());  // depth sits in the top bits: (depth, code) order
+	h.erase(std::unique(h.begin(), h.end()), h.end());
+	if (h.size() < n) {
+		// keep the log compact: the set, once
+		const u32 nn = (u32)h.size();
+		if ((nn && hipMemcpy(m->b_changes.p, h.data(), h.size() * 8, hipMemcpyHostToDevice) != hipSuccess) ||
+		    hipMemcpy(reinterpret_cast<char*>(m->b_root.p) + offsetof(MapRoot, n_changes), &nn, 4, hipMemcpyHostToDevice) != hipSuccess)
+			return (size_t)-1;
+	}
+	for (size_t i = 0; i < h.size() && i < cap; ++i) {
+		if (codes) codes[i] = h[i] & ((1ULL << 58) - 1ULL);
+		if (depths) depths[i] = (uint8_t)(h[i] >> 58);
+	}
+	return h.size();
+}
+
+size_t ufomap_map_iterate(ufomap_map* m, const double* aabb_center, const double* aabb_half, int occupied_space, int free_space,
+                          int unknown_space, int contains, unsigned min_depth, int only_leaves, uint64_t* codes, uint8_t* depths,
+                          float* logodds, uint8_t* rgb, uint8_t* flags, size_t cap)
+{
+	if (!m || ((nullptr == aabb_center) != (nullptr == aabb_half))) {
+		fail(UFOMAP_ERR_INVALID, "null map / half a bounding volume");
+		return (size_t)-1;
+	}
+	if (ufomap_map_wait(m) < 0) return (size_t)-1;
+	auto bad = [&](hipError_t e) {
+		if (e != hipSuccess) {
+			fail(UFOMAP_ERR_DEVICE, hipGetErrorString(e));
+			return true;
+		}
+		return false;
+	};
+	const u32 L = m->g.L;
+	IterArgs a{};
+	a.has_bv = aabb_center ? 1u : 0u;
+	for (int k = 0; k < 3 && aabb_center; ++k) {
+		a.vc[k] = aabb_center[k];
+		a.vh[k] = aabb_half[k];
+	}
+	a.occ = occupied_space ? 1u : 0u;
+	a.fre = free_space ? 1u : 0u;
+	a.unk = unknown_space ? 1u : 0u;
+	a.contains = contains ? 1u : 0u;
+	a.min_depth = min_depth;
+	a.only_leaf = only_leaves ? 1u : 0u;
+	m->cs = m->stream;
+	// one record per inner node that is descended into: at most the live blocks
+	{
+		MapRoot root;
+		if (bad(hipMemcpy(&root, m->b_root.p, sizeof(MapRoot), hipMemcpyDeviceToHost))) return (size_t)-1;
+		m->used_est = root.used;
+	}
+	const u32 rcap = (u32)std::min<u64>(m->used_est + 8, 0x7FFFFFF0ull);
+	if (bad(m->b_crec.reserve((size_t)rcap * sizeof(IterRec)))) return (size_t)-1;
+	IterRec* rec = m->b_crec.as<IterRec>();
+	ScanCtl* ctl = m->b_ctl.as<ScanCtl>();
+	DevBuf bc, bd, bo, br, bf;
+	std::vector<uint64_t> hc;
+	std::vector<uint8_t> hd, hf;
+	std::vector<float> ho;
+	std::vector<u32> hr;
+	size_t total = 0;
+	for (int pass = 0; pass < 2; ++pass) {
+		const u32 ocap = pass ? (u32)total : 0u;
+		if (pass) {
+			if (0 == total) break;
+			if (bad(bc.reserve((size_t)ocap * 8)) || bad(bd.reserve(ocap)) || bad(bo.reserve((size_t)ocap * 4)) || bad(br.reserve((size_t)ocap * 4)) ||
+			    bad(bf.reserve(ocap)))
+				return (size_t)-1;
+		}
+		if (bad(hipMemsetAsync(ctl, 0, sizeof(ScanCtl), m->stream))) return (size_t)-1;
+		const IterOut out{bc.as<u64>(), bd.as<u8>(), bo.as<float>(), br.as<u32>(), bf.as<u8>(), ocap};
+		hipLaunchKernelGGL(k_iter_root, dim3(1), dim3(1), 0, m->stream, m->t, m->g, a, rec, rcap, out, ctl);
+		for (u32 cd = L; cd >= 1 && cd > min_depth; --cd) {
+			hipLaunchKernelGGL(k_iter_level, gridFor((u64)rcap * 8, 256, 2048), dim3(256), 0, m->stream, m->t, m->g, a, cd, rec, rcap, out, ctl);
+			if (cd >= 2) hipLaunchKernelGGL(k_coarse_mark, dim3(1), dim3(1), 0, m->stream, ctl, cd - 2);
+		}
+		if (bad(hipMemcpyAsync(m->h_ctl, ctl, sizeof(ScanCtl), hipMemcpyDeviceToHost, m->stream)) || bad(hipStreamSynchronize(m->stream)))
+			return (size_t)-1;
+		if (m->h_ctl->err) {
+			fail(UFOMAP_ERR_CAPACITY, "iterate: record list too small (internal bound violated)");
+			return (size_t)-1;
+		}
+		total = m->h_ctl->n_codes;
+		if (pass) {
+			hc.resize(total);
+			hd.resize(total);
+			ho.resize(total);
+			hr.resize(total);
+			hf.resize(total);
+			if (bad(hipMemcpy(hc.data(), bc.p, total * 8, hipMemcpyDeviceToHost)) || bad(hipMemcpy(hd.data(), bd.p, total, hipMemcpyDeviceToHost)) ||
+			    bad(hipMemcpy(ho.data(), bo.p, total * 4, hipMemcpyDeviceToHost)) || bad(hipMemcpy(hr.data(), br.p, total * 4, hipMemcpyDeviceToHost)) ||
+			    bad(hipMemcpy(hf.data(), bf.p, total, hipMemcpyDeviceToHost)))
+				return (size_t)-1;
+		} else if (0 == cap || (!codes && !depths && !logodds && !rgb && !flags)) {
+			break;  // the caller only asked for the count
+		}
+	}
+	bc.release();
+	bd.release();
+	bo.release();
+	br.release();
+	bf.release();
+	if (hc.size() != total) return total;
+	// pre-order: ascending position of the node's first voxel, a node before its descendants
+	std::vector<size_t> order(total);
+	for (size_t i = 0; i < total; ++i) order[i] = i;
+	std::sort(order.begin(), order.end(), [&](size_t x, size_t y) {
+		const uint64_t fx = hc[x] << (3 * hd[x]), fy = hc[y] << (3 * hd[y]);
+		return fx != fy ? fx < fy : hd[x] > hd[y];
+	});
+	for (size_t i = 0; i < total && i < cap; ++i) {
+		const size_t j = order[i];
+		if (codes) codes[i] = hc[j];
+		if (depths) depths[i] = hd[j];
+		if (logodds) logodds[i] = ho[j];
+		if (flags) flags[i] = hf[j];
+		if (rgb) {
+			rgb[3 * i] = (uint8_t)(hr[j] & 0xFF);
+			rgb[3 * i + 1] = (uint8_t)((hr[j] >> 8) & 0xFF);
+			rgb[3 * i + 2] = (uint8_t)((hr[j] >> 16) & 0xFF);
+		}
+	}
+	return total;
 }
 
 int ufomap_map_wait(ufomap_map* m)
@@ -2144,6 +2428,11 @@ int ufomap_map_apply_keys_batch(ufomap_map* m, const void* const* d_lists, const
 			}
 		}
 	}
+	if (m->chg_enabled) {
+		const int crc = ensureChangeCap(m, total * 8);
+		if (crc) return crc;
+	}
+	const ChangeLog cl = changeLog(m);
 	m->scan_id += 1;  // ONE phase for the whole batch
 	const u32 newcap = (u32)std::min<u64>(new_bound, 0xFFFFFFFFull);
 	HIP_TRY(m->b_ent_slot.reserve((size_t)total * 4));
@@ -2166,7 +2455,7 @@ int ufomap_map_apply_keys_batch(ufomap_map* m, const void* const* d_lists, const
 		ProfScope ps(m, "k_apply_values");
 		const u64 time_hi = (u64)subs[k].scan << 30;
 		hipLaunchKernelGGL(k_apply_values, gridFor(subs[k].n), dim3(256), 0, m->cs, m->t, m->g, subs[k].ent, d_cnt + k,
-		                   m->b_ent_slot.as<u32>() + subs[k].off, m->g.hit, miss, subs[k].mode, m->scan_id, time_hi, wl[1], pc, ctl);
+		                   m->b_ent_slot.as<u32>() + subs[k].off, m->g.hit, miss, subs[k].mode, m->scan_id, time_hi, wl[1], pc, ctl, cl);
 	}
 	{
 		ProfScope ps(m, "k_finish_leaf");
@@ -2185,7 +2474,7 @@ int ufomap_map_apply_keys_batch(ufomap_map* m, const void* const* d_lists, const
 	HIP_TRY(hipGetLastError());
 	m->pending = true;
 	m->bound = m->scan_new_bound;
-	if (m->opt_async_apply) {
+	if (m->opt_async_apply && !m->chg_enabled) {
 		// the caller keeps the lists alive until the next call on this map has joined the update
 		HIP_TRY(hipEventRecord(m->done_ev, m->stream));
 		return UFOMAP_OK;
@@ -2194,40 +2483,77 @@ int ufomap_map_apply_keys_batch(ufomap_map* m, const void* const* d_lists, const
 	return finishPending(m);
 }
 
-size_t ufomap_map_write(ufomap_map* m, uint8_t* buf, size_t cap)
+// liblz4, loaded at run time (the reference links it for its I/O only: octree.h:1430-1486)
+extern "C++" {
+namespace
 {
-	if (!m) {
-		fail(UFOMAP_ERR_INVALID, "null map");
-		return (size_t)-1;
-	}
-	if (ufomap_map_wait(m) < 0) return (size_t)-1;
-	auto bad = [&](hipError_t e) {
-		if (e != hipSuccess) {
-			fail(UFOMAP_ERR_DEVICE, hipGetErrorString(e));
-			return true;
+struct Lz4 {
+	int (*bound)(int) = nullptr;
+	int (*fast)(const char*, char*, int, int, int) = nullptr;
+	int (*hc)(const char*, char*, int, int, int) = nullptr;
+	int (*safe)(const char*, char*, int, int) = nullptr;
+	bool ok = false;
+};
+const Lz4& lz4()
+{
+	static Lz4 z = [] {
+		Lz4 r;
+		void* h = nullptr;
+		for (const char* name : {"liblz4.so.1", "liblz4.so", "/usr/lib/x86_64-linux-gnu/liblz4.so.1"}) {
+			h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+			if (h) break;
 		}
-		return false;
-	};
+		if (h) {
+			r.bound = reinterpret_cast<int (*)(int)>(dlsym(h, "LZ4_compressBound"));
+			r.fast = reinterpret_cast<int (*)(const char*, char*, int, int, int)>(dlsym(h, "LZ4_compress_fast"));
+			r.hc = reinterpret_cast<int (*)(const char*, char*, int, int, int)>(dlsym(h, "LZ4_compress_HC"));
+			r.safe = reinterpret_cast<int (*)(const char*, char*, int, int)>(dlsym(h, "LZ4_decompress_safe"));
+			r.ok = r.bound && r.fast && r.hc && r.safe;
+		}
+		return r;
+	}();
+	return z;
+}
+
+// the node stream of writeNodes (occupancy_map_base.h:1457-1533) for the whole map or the part inside a bounding volume
+int serialiseNodes(ufomap_map* m, const SerArgs& sa, std::vector<uint8_t>& data)
+{
+	data.clear();
 	m->cs = m->stream;
 	const u32 D = m->g.color ? 7u : 4u;
 	const u32 L = m->g.L;
-	// live blocks per level
+	if (sa.has_bv) {
+		// the root's box against the volume (OMB:1461-1467): nothing is written, not even the root byte
+		const double h = m->g.hs[L];
+		for (int k = 0; k < 3; ++k) {
+			const double min1 = sa.vc[k] - sa.vh[k], max1 = sa.vc[k] + sa.vh[k], min2 = 0.0 - h, max2 = 0.0 + h;
+			if (!(min1 <= max2) || !(min2 <= max1)) return UFOMAP_OK;
+		}
+	}
 	DevBuf b_cnt, b_list, b_size, b_off, b_out;
+	struct Guard {
+		DevBuf* b[5];
+		~Guard()
+		{
+			for (DevBuf* x : b) x->release();
+		}
+	} guard{{&b_cnt, &b_list, &b_size, &b_off, &b_out}};
 	u32 h_cnt[32] = {0}, h_off[32] = {0};
-	if (bad(b_cnt.reserve(3 * 32 * 4)) || bad(hipMemsetAsync(b_cnt.p, 0, 3 * 32 * 4, m->stream))) return (size_t)-1;
+	HIP_TRY(b_cnt.reserve(3 * 32 * 4));
+	HIP_TRY(hipMemsetAsync(b_cnt.p, 0, 3 * 32 * 4, m->stream));
 	u32* d_cnt = b_cnt.as<u32>();
 	hipLaunchKernelGGL(k_ser_count, gridFor((u64)m->t.mask + 1), dim3(256), 0, m->stream, m->t, m->g, d_cnt);
-	if (bad(hipMemcpyAsync(h_cnt, d_cnt, 32 * 4, hipMemcpyDeviceToHost, m->stream)) || bad(hipStreamSynchronize(m->stream))) return (size_t)-1;
+	HIP_TRY(hipMemcpyAsync(h_cnt, d_cnt, 32 * 4, hipMemcpyDeviceToHost, m->stream));
+	HIP_TRY(hipStreamSynchronize(m->stream));
 	u64 n_live = 0;
 	for (u32 l = 0; l < 32; ++l) {
 		h_off[l] = (u32)n_live;
 		n_live += h_cnt[l];
 	}
 	MapRoot root;
-	if (bad(hipMemcpy(&root, m->b_root.p, sizeof(MapRoot), hipMemcpyDeviceToHost))) return (size_t)-1;
-	std::vector<uint8_t> data;
-	if (0 == h_cnt[L]) {
-		// the root is a leaf: children byte 0, then the root's payload (occupancy_map_base.h:1472-1478)
+	HIP_TRY(hipMemcpy(&root, m->b_root.p, sizeof(MapRoot), hipMemcpyDeviceToHost));
+	if (0 == h_cnt[L] || L <= sa.min_depth) {
+		// the root is (written as) a leaf: children byte 0, then the root's payload (occupancy_map_base.h:1469-1478)
 		data.resize(1 + D);
 		data[0] = 0;
 		memcpy(&data[1], &root.occ, 4);
@@ -2236,56 +2562,389 @@ size_t ufomap_map_write(ufomap_map* m, uint8_t* buf, size_t cap)
 			data[6] = (uint8_t)(root.rgb >> 8);
 			data[7] = (uint8_t)(root.rgb >> 16);
 		}
-	} else {
-		const size_t ncap = (size_t)m->t.mask + 1;
-		if (bad(b_list.reserve(std::max<u64>(n_live, 1) * 4)) || bad(b_size.reserve(ncap * 8)) || bad(b_off.reserve(ncap * 8)) ||
-		    bad(hipMemcpyAsync(d_cnt + 32, h_off, 32 * 4, hipMemcpyHostToDevice, m->stream)))
-			return (size_t)-1;
-		hipLaunchKernelGGL(k_ser_collect, gridFor((u64)m->t.mask + 1), dim3(256), 0, m->stream, m->t, m->g, d_cnt + 32, d_cnt + 64, b_list.as<u32>());
-		for (u32 l = 1; l <= L; ++l)
-			if (h_cnt[l])
-				hipLaunchKernelGGL(k_ser_sizes, gridFor(h_cnt[l]), dim3(256), 0, m->stream, m->t, m->g, b_list.as<u32>() + h_off[l], h_cnt[l], l, D,
-				                   b_size.as<u64>());
-		// total = 0xFF byte + subtree of the root block
-		u32 root_slot = 0;
-		if (bad(hipMemcpyAsync(&root_slot, b_list.as<u32>() + h_off[L], 4, hipMemcpyDeviceToHost, m->stream)) || bad(hipStreamSynchronize(m->stream)))
-			return (size_t)-1;
-		u64 root_size = 0;
-		if (bad(hipMemcpy(&root_size, b_size.as<u64>() + root_slot, 8, hipMemcpyDeviceToHost))) return (size_t)-1;
-		const u64 total = 1 + root_size;
-		if (bad(b_out.reserve(total))) return (size_t)-1;
-		const uint8_t ff = 0xFF;
-		if (bad(hipMemcpyAsync(b_out.p, &ff, 1, hipMemcpyHostToDevice, m->stream))) return (size_t)-1;
-		for (u32 l = L; l >= 1; --l)
-			if (h_cnt[l])
-				hipLaunchKernelGGL(k_ser_write, gridFor(h_cnt[l]), dim3(256), 0, m->stream, m->t, m->g, b_list.as<u32>() + h_off[l], h_cnt[l], l, D,
-				                   b_size.as<u64>(), b_off.as<u64>(), b_out.as<uint8_t>());
-		data.resize(total);
-		if (bad(hipMemcpyAsync(data.data(), b_out.p, total, hipMemcpyDeviceToHost, m->stream)) || bad(hipStreamSynchronize(m->stream))) return (size_t)-1;
+		return UFOMAP_OK;
 	}
-	b_cnt.release();
-	b_list.release();
-	b_size.release();
-	b_off.release();
-	b_out.release();
-	// text header exactly as Octree::write prints it (octree.h:850-861)
-	std::ostringstream hd;
-	hd << "# UFOMap file";
-	hd << "\n# (feel free to add / change comments, but leave the first line as it is!)\n#\n";
-	hd << "version " << "1.0.0" << std::endl;
-	hd << "id " << (m->g.color ? "occupancy_map_color" : "occupancy_map") << std::endl;
-	hd << "resolution " << m->g.res << std::endl;
-	hd << "depth_levels " << m->g.L << std::endl;
-	hd << "compressed " << false << std::endl;
-	hd << "uncompressed_data_size " << (int)data.size() << std::endl;
-	hd << "data" << std::endl;
-	const std::string h = hd.str();
+	const u32 first = std::max<u32>(1u, sa.min_depth + 1);  // blocks of nodes above min_depth
+	const size_t ncap = (size_t)m->t.mask + 1;
+	HIP_TRY(b_list.reserve(std::max<u64>(n_live, 1) * 4));
+	HIP_TRY(b_size.reserve(ncap * 8));
+	HIP_TRY(b_off.reserve(ncap * 8));
+	HIP_TRY(hipMemcpyAsync(d_cnt + 32, h_off, 32 * 4, hipMemcpyHostToDevice, m->stream));
+	HIP_TRY(hipMemsetAsync(b_off.p, 0xFF, ncap * 8, m->stream));
+	hipLaunchKernelGGL(k_ser_collect, gridFor((u64)m->t.mask + 1), dim3(256), 0, m->stream, m->t, m->g, d_cnt + 32, d_cnt + 64, b_list.as<u32>());
+	for (u32 l = first; l <= L; ++l)
+		if (h_cnt[l])
+			hipLaunchKernelGGL(k_ser_sizes, gridFor(h_cnt[l]), dim3(256), 0, m->stream, m->t, m->g, sa, b_list.as<u32>() + h_off[l], h_cnt[l], l, D,
+			                   b_size.as<u64>());
+	// total = 0xFF byte + subtree of the root block
+	u32 root_slot = 0;
+	HIP_TRY(hipMemcpyAsync(&root_slot, b_list.as<u32>() + h_off[L], 4, hipMemcpyDeviceToHost, m->stream));
+	HIP_TRY(hipStreamSynchronize(m->stream));
+	u64 root_size = 0;
+	HIP_TRY(hipMemcpy(&root_size, b_size.as<u64>() + root_slot, 8, hipMemcpyDeviceToHost));
+	const u64 total = 1 + root_size;
+	if (total > 0x7FFFFFFFull) return fail(UFOMAP_ERR_CAPACITY, "map byte stream exceeds 2^31 bytes (the reference's size field is an int)");
+	HIP_TRY(b_out.reserve(total));
+	const uint8_t ff = 0xFF;
+	HIP_TRY(hipMemcpyAsync(b_out.p, &ff, 1, hipMemcpyHostToDevice, m->stream));
+	for (u32 l = L; l >= first; --l)
+		if (h_cnt[l])
+			hipLaunchKernelGGL(k_ser_write, gridFor(h_cnt[l]), dim3(256), 0, m->stream, m->t, m->g, sa, b_list.as<u32>() + h_off[l], h_cnt[l], l, D,
+			                   b_size.as<u64>(), b_off.as<u64>(), b_out.as<uint8_t>());
+	data.resize(total);
+	HIP_TRY(hipMemcpyAsync(data.data(), b_out.p, total, hipMemcpyDeviceToHost, m->stream));
+	HIP_TRY(hipStreamSynchronize(m->stream));
+	return UFOMAP_OK;
+}
+}  // namespace
+}  // extern "C++"
+
+size_t ufomap_map_write_ex(ufomap_map* m, const double* aabb_center, const double* aabb_half, int compress, unsigned min_depth,
+                           int compression_acceleration_level, int compression_level, int header, uint8_t* buf, size_t cap,
+                           long long* uncompressed_size)
+{
+	if (!m || ((nullptr == aabb_center) != (nullptr == aabb_half))) {
+		fail(UFOMAP_ERR_INVALID, "null map / half a bounding volume");
+		return (size_t)-1;
+	}
+	if (ufomap_map_wait(m) < 0) return (size_t)-1;
+	SerArgs sa{};
+	sa.has_bv = aabb_center ? 1u : 0u;
+	for (int k = 0; k < 3 && aabb_center; ++k) {
+		sa.vc[k] = aabb_center[k];
+		sa.vh[k] = aabb_half[k];
+	}
+	sa.min_depth = min_depth;
+	std::vector<uint8_t> data;
+	if (serialiseNodes(m, sa, data)) return (size_t)-1;
+	const long long usize = (long long)data.size();
+	if (uncompressed_size) *uncompressed_size = usize;
+	if (compress) {
+		// compressData (octree.h:1430-1458)
+		const Lz4& z = lz4();
+		if (!z.ok) {
+			fail(UFOMAP_ERR_UNSUPPORTED, "liblz4 could not be loaded: compressed output is not available");
+			return (size_t)-1;
+		}
+		const int bound = z.bound((int)data.size());
+		std::vector<uint8_t> comp((size_t)std::max(bound, 1));
+		const int n = 0 >= compression_level
+		                  ? z.fast(reinterpret_cast<const char*>(data.data()), reinterpret_cast<char*>(comp.data()), (int)data.size(), bound,
+		                           compression_acceleration_level)
+		                  : z.hc(reinterpret_cast<const char*>(data.data()), reinterpret_cast<char*>(comp.data()), (int)data.size(), bound,
+		                         compression_level);
+		if (n < 0) {
+			fail(UFOMAP_ERR_DEVICE, "LZ4 compression failed");
+			return (size_t)-1;
+		}
+		comp.resize((size_t)n);
+		data.swap(comp);
+	}
+	std::string h;
+	if (header) {
+		// text header exactly as Octree::write prints it (octree.h:850-861)
+		std::ostringstream hd;
+		hd << "# UFOMap file";
+		hd << "\n# (feel free to add / change comments, but leave the first line as it is!)\n#\n";
+		hd << "version " << "1.0.0" << std::endl;
+		hd << "id " << (m->g.color ? "occupancy_map_color" : "occupancy_map") << std::endl;
+		hd << "resolution " << m->g.res << std::endl;
+		hd << "depth_levels " << m->g.L << std::endl;
+		hd << "compressed " << (compress ? true : false) << std::endl;
+		hd << "uncompressed_data_size " << (int)usize << std::endl;
+		hd << "data" << std::endl;
+		h = hd.str();
+	}
 	const size_t total = h.size() + data.size();
 	if (buf && cap >= total) {
 		memcpy(buf, h.data(), h.size());
-		memcpy(buf + h.size(), data.data(), data.size());
+		if (!data.empty()) memcpy(buf + h.size(), data.data(), data.size());
 	}
 	return total;
+}
+
+extern "C++" {
+namespace
+{
+// one pass over a node stream (readNodesRecurs, occupancy_map_base.h:1405-1455): a ReadRec per node with children
+struct StreamParser {
+	const uint8_t* p;
+	size_t n, pos = 0;
+	bool bad = false;
+	u32 D;
+	const MapGeom* g;
+	bool has_bv;
+	double vc[3], vh[3];
+	std::vector<ReadRec> recs[24];  // by level (= depth of the node)
+
+	bool inside(const double c[3], double h) const
+	{
+		if (!has_bv) return true;
+		for (int k = 0; k < 3; ++k) {
+			const double min1 = vc[k] - vh[k], max1 = vc[k] + vh[k], min2 = c[k] - h, max2 = c[k] + h;
+			if (!(min1 <= max2) || !(min2 <= max1)) return false;
+		}
+		return true;
+	}
+	void leaf(float* v, u32* rgb)
+	{
+		if (pos + D > n) {
+			bad = true;
+			*v = 0;
+			*rgb = 0;
+			return;
+		}
+		memcpy(v, p + pos, 4);
+		*rgb = D > 4 ? ((u32)p[pos + 4] | ((u32)p[pos + 5] << 8) | ((u32)p[pos + 6] << 16)) : 0u;
+		pos += D;
+	}
+	void node(u64 lk, u32 cd, const double c[3], u32 parent)
+	{
+		if (bad || pos >= n) {
+			bad = true;
+			return;
+		}
+		const uint8_t children = p[pos++];
+		const u32 mine = (u32)recs[cd].size();
+		ReadRec r{};
+		r.lk = lk;
+		r.parent = parent;
+		r.slot = NONE;
+		recs[cd].push_back(r);
+		const double chs = g->hs[cd - 1];
+		u32 set_mask = 0, inner_mask = 0;
+		for (u32 i = 0; i < 8 && !bad; ++i) {
+			const double cc[3] = {c[0] + ((i & 1) ? chs : -chs), c[1] + ((i & 2) ? chs : -chs), c[2] + ((i & 4) ? chs : -chs)};
+			if (!inside(cc, chs)) continue;
+			if ((children >> i) & 1u) {
+				inner_mask |= 1u << i;
+				if (2 == cd) {
+					// a depth-1 child: its 8 voxels follow without a mask byte (OMB:1427-1438)
+					ReadRec cr{};
+					cr.lk = (lk << 3) | (u64)i;
+					cr.parent = mine;
+					cr.slot = NONE;
+					const double ghs = g->hs[0];
+					for (u32 j = 0; j < 8 && !bad; ++j) {
+						const double gc[3] = {cc[0] + ((j & 1) ? ghs : -ghs), cc[1] + ((j & 2) ? ghs : -ghs), cc[2] + ((j & 4) ? ghs : -ghs)};
+						if (!inside(gc, ghs)) continue;
+						cr.set_mask |= 1u << j;
+						leaf(&cr.val[j], &cr.rgb[j]);
+					}
+					recs[1].push_back(cr);
+				} else {
+					node((lk << 3) | (u64)i, cd - 1, cc, mine);
+				}
+			} else {
+				float v;
+				u32 col;
+				leaf(&v, &col);
+				set_mask |= 1u << i;
+				recs[cd][mine].val[i] = v;
+				recs[cd][mine].rgb[i] = col;
+			}
+		}
+		recs[cd][mine].set_mask = set_mask;
+		recs[cd][mine].inner_mask = inner_mask;
+	}
+};
+
+// readNodes (occupancy_map_base.h:1379-1403) on an uncompressed node stream
+int readNodes(ufomap_map* m, const uint8_t* data, size_t n, const double* aabb_center, const double* aabb_half)
+{
+	const u32 L = m->g.L;
+	const u32 D = m->g.color ? 7u : 4u;
+	if (aabb_center) {
+		const double h = m->g.hs[L];
+		for (int k = 0; k < 3; ++k) {
+			const double min1 = aabb_center[k] - aabb_half[k], max1 = aabb_center[k] + aabb_half[k], min2 = 0.0 - h, max2 = 0.0 + h;
+			if (!(min1 <= max2) || !(min2 <= max1)) return UFOMAP_OK;  // no node intersects
+		}
+	}
+	if (n < 1) return fail(UFOMAP_ERR_INVALID, "empty node stream");
+	m->cs = m->stream;
+	m->args = ScanArgs{};
+	ScanCtl init;
+	memset(&init, 0, sizeof(init));
+	for (int k = 0; k < 3; ++k) {
+		init.aabb_min[k] = ~0ull;
+		init.aabb_max[k] = 0ull;
+	}
+	*m->h_ctl = init;
+	HIP_TRY(hipMemcpyAsync(m->b_ctl.p, m->h_ctl, sizeof(ScanCtl), hipMemcpyHostToDevice, m->stream));
+	ScanCtl* ctl = m->b_ctl.as<ScanCtl>();
+	m->scan_id += 1;
+	if (0 == data[0]) {
+		// the stream's root is a leaf: deleteChildren(root), readData, updateNode (occupancy_map_base.h:1394-1399)
+		if (n < 1 + (size_t)D) return fail(UFOMAP_ERR_INVALID, "truncated node stream");
+		float v;
+		memcpy(&v, data + 1, 4);
+		const u32 col = D > 4 ? ((u32)data[5] | ((u32)data[6] << 8) | ((u32)data[7] << 16)) : 0u;
+		hipLaunchKernelGGL(k_vol_root, gridFor((u64)m->t.mask + 1), dim3(256), 0, m->cs, m->t, m->g, v);
+		HIP_TRY(hipMemcpyAsync(reinterpret_cast<char*>(m->b_root.p) + offsetof(MapRoot, rgb), &col, 4, hipMemcpyHostToDevice, m->stream));
+		HIP_TRY(hipStreamSynchronize(m->stream));
+		return UFOMAP_OK;
+	}
+	StreamParser sp;
+	sp.p = data;
+	sp.n = n;
+	sp.pos = 1;  // behind the root's children byte
+	sp.D = D;
+	sp.g = &m->g;
+	sp.has_bv = nullptr != aabb_center;
+	for (int k = 0; k < 3 && aabb_center; ++k) {
+		sp.vc[k] = aabb_center[k];
+		sp.vh[k] = aabb_half[k];
+	}
+	const double c0[3] = {0.0, 0.0, 0.0};
+	sp.node(1, L, c0, NONE);
+	if (sp.bad) return fail(UFOMAP_ERR_INVALID, "truncated node stream");
+	// records level by level, root first; parents are indices into the level above
+	u32 off[24] = {0};
+	u64 total = 0;
+	for (u32 l = L; l >= 1; --l) {
+		off[l] = (u32)total;
+		total += sp.recs[l].size();
+	}
+	if (total > 0x7FFFFFF0ull) return fail(UFOMAP_ERR_CAPACITY, "node stream too large");
+	std::vector<ReadRec> all;
+	all.reserve((size_t)total);
+	for (u32 l = L; l >= 1; --l)
+		for (ReadRec r : sp.recs[l]) {
+			if (r.parent != NONE) r.parent += off[l + 1];
+			all.push_back(r);
+		}
+	// every record may create a block
+	{
+		const u64 cap = (u64)m->t.mask + 1;
+		if ((m->used_est + total) * 5 > cap * 3) {
+			const u64 want = (m->used_est + total) * 2;
+			if (want > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
+			int rc = growTable(m, nextPow2(want));
+			if (rc) return rc;
+		}
+	}
+	const u32 kcap = (u32)std::min<u64>(m->used_est + 8, 0x7FFFFFFFull);
+	HIP_TRY(m->b_crec.reserve((size_t)total * sizeof(ReadRec)));
+	HIP_TRY(m->b_dlist.reserve((size_t)kcap * 4));
+	HIP_TRY(hipMemcpyAsync(m->b_crec.p, all.data(), (size_t)total * sizeof(ReadRec), hipMemcpyHostToDevice, m->stream));
+	ReadRec* rec = m->b_crec.as<ReadRec>();
+	u32* kill = m->b_dlist.as<u32>();
+	for (u32 l = L; l >= 1; --l) {
+		const u32 cnt = (u32)sp.recs[l].size();
+		if (cnt) hipLaunchKernelGGL(k_read_down, gridFor(cnt, 256, 4096), dim3(256), 0, m->cs, m->t, m->g, rec, off[l], off[l] + cnt, l, kill, kcap, m->scan_id, ctl);
+	}
+	hipLaunchKernelGGL(k_vol_kill_mark, dim3(1), dim3(1), 0, m->cs, ctl, 0u);
+	for (u32 l = 0; l + 1 < L; ++l) {
+		hipLaunchKernelGGL(k_vol_kill, gridFor(std::max<u64>(kcap, 256), 256, 4096), dim3(256), 0, m->cs, m->t, kill, kcap, ctl);
+		hipLaunchKernelGGL(k_vol_kill_mark, dim3(1), dim3(1), 0, m->cs, ctl, 1u);
+	}
+	for (u32 l = 1; l <= L; ++l) {
+		const u32 cnt = (u32)sp.recs[l].size();
+		if (cnt) hipLaunchKernelGGL(k_read_up, gridFor(cnt, 256, 4096), dim3(256), 0, m->cs, m->t, m->g, rec, off[l], off[l] + cnt, l, ctl);
+	}
+	HIP_TRY(hipGetLastError());
+	m->pending = true;
+	HIP_TRY(hipStreamSynchronize(m->stream));  // (`all` is pageable: the upload has completed before it goes out of scope)
+	return finishPending(m);
+}
+}  // namespace
+}  // extern "C++"
+
+int ufomap_map_read_data(ufomap_map* m, const uint8_t* data, size_t n, const double* aabb_center, const double* aabb_half,
+                         double resolution, unsigned depth_levels, int uncompressed_data_size, int compressed)
+{
+	if (!m || (n && !data) || ((nullptr == aabb_center) != (nullptr == aabb_half))) return fail(UFOMAP_ERR_INVALID, "null argument");
+	HIP_TRY(hipSetDevice(m->device));
+	int rc = ufomap_map_wait(m);
+	if (rc) return rc;
+	if (m->g.res != resolution || m->g.L != depth_levels) {  // readData (octree.h:760-762)
+		rc = ufomap_map_clear_to(m, resolution, depth_levels);
+		if (rc) return rc;
+	}
+	{
+		// used_est may be stale after a clear
+		MapRoot root;
+		HIP_TRY(hipMemcpy(&root, m->b_root.p, sizeof(MapRoot), hipMemcpyDeviceToHost));
+		m->used_est = root.used;
+	}
+	if (compressed) {
+		// decompressData (octree.h:1460-1486)
+		const Lz4& z = lz4();
+		if (!z.ok) return fail(UFOMAP_ERR_UNSUPPORTED, "liblz4 could not be loaded: compressed input is not available");
+		if (uncompressed_data_size < 0) return fail(UFOMAP_ERR_INVALID, "negative uncompressed_data_size");
+		std::vector<uint8_t> raw((size_t)std::max(uncompressed_data_size, 1));
+		const int got = z.safe(reinterpret_cast<const char*>(data), reinterpret_cast<char*>(raw.data()), (int)n, uncompressed_data_size);
+		if (got < 0) return fail(UFOMAP_ERR_INVALID, "LZ4 decompression failed");
+		return readNodes(m, raw.data(), (size_t)got, aabb_center, aabb_half);
+	}
+	return readNodes(m, data, n, aabb_center, aabb_half);
+}
+
+int ufomap_map_read(ufomap_map* m, const uint8_t* buf, size_t n, double* resolution, unsigned* depth_levels)
+{
+	if (!m || !buf) return fail(UFOMAP_ERR_INVALID, "null argument");
+	// Octree::read / readHeader (octree.h:701-735, 640-688): first line, then "token value" lines up to "data"
+	static const char kHeader[] = "# UFOMap file";
+	if (n < sizeof(kHeader) - 1 || 0 != memcmp(buf, kHeader, sizeof(kHeader) - 1)) return fail(UFOMAP_ERR_INVALID, "not a UFOMap file");
+	size_t pos = 0;
+	auto line = [&](std::string* out) {
+		if (pos >= n) return false;
+		size_t e = pos;
+		while (e < n && buf[e] != '\n') ++e;
+		out->assign(reinterpret_cast<const char*>(buf) + pos, e - pos);
+		pos = std::min(n, e + 1);
+		return true;
+	};
+	std::string ln, id;
+	double res = 0;
+	unsigned levels = 0;
+	int compressed = 0, usize = 0;
+	bool got_data = false;
+	(void)line(&ln);  // the file header line
+	while (line(&ln)) {
+		std::istringstream is(ln);
+		std::string tok;
+		if (!(is >> tok)) continue;
+		if ("data" == tok) {
+			got_data = true;
+			break;
+		}
+		if ('#' == tok[0]) continue;
+		if ("id" == tok) is >> id;
+		else if ("resolution" == tok) is >> res;
+		else if ("depth_levels" == tok) is >> levels;
+		else if ("compressed" == tok) is >> compressed;
+		else if ("uncompressed_data_size" == tok) is >> usize;
+	}
+	if (!got_data || !(res > 0) || levels < 2 || levels > 21) return fail(UFOMAP_ERR_INVALID, "malformed UFOMap header");
+	if (id != (m->g.color ? "occupancy_map_color" : "occupancy_map"))
+		return fail(UFOMAP_ERR_INVALID, "file holds a '" + id + "', the map is a '" + (m->g.color ? "occupancy_map_color" : "occupancy_map") + "'");
+	int rc = ufomap_map_read_data(m, buf + pos, n - pos, nullptr, nullptr, res, levels, usize, compressed);
+	if (rc) return rc;
+	if (resolution) *resolution = res;
+	if (depth_levels) *depth_levels = levels;
+	return UFOMAP_OK;
+}
+
+int ufomap_map_set_occupied_free_thres(ufomap_map* m, double occupied_thres, double free_thres)
+{
+	if (!m) return fail(UFOMAP_ERR_INVALID, "null map");
+	// setOccupiedFreeThres (occupancy_map_base.h:746-759): write, change the thresholds, read back
+	long long usize = 0;
+	const size_t n = ufomap_map_write_ex(m, nullptr, nullptr, 0, 0, 1, 0, 0, nullptr, 0, &usize);
+	if (n == (size_t)-1) return UFOMAP_ERR_DEVICE;
+	std::vector<uint8_t> data(n);
+	if ((size_t)-1 == ufomap_map_write_ex(m, nullptr, nullptr, 0, 0, 1, 0, 0, data.data(), data.size(), &usize)) return UFOMAP_ERR_DEVICE;
+	m->model_log[0] = std::log(occupied_thres / (1.0 - occupied_thres));
+	m->model_log[1] = std::log(free_thres / (1.0 - free_thres));
+	applyModel(m);
+	return ufomap_map_read_data(m, data.data(), data.size(), nullptr, nullptr, m->g.res, m->g.L, (int)usize, 0);
+}
+
+size_t ufomap_map_write(ufomap_map* m, uint8_t* buf, size_t cap)
+{
+	return ufomap_map_write_ex(m, nullptr, nullptr, 0, 0, 1, 0, 1, buf, cap, nullptr);
 }
 
 int ufomap_map_set_option(ufomap_map* m, const char* key, long long value)

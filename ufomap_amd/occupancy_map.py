@@ -169,6 +169,109 @@ class OccupancyMapBase:
         capi.check(self._lib.ufomap_map_clamping_thres(self._h, _p(a[0:1], C.c_double), _p(a[1:2], C.c_double)))
         return float(a[1])
 
+
+    # ---- what the reference's callers use around the hot path (round 2; include/ufomap_hip.h) ---------------------
+    @staticmethod
+    def _bv(aabb):
+        """aabb = None or (centre[3], half_size[3]) -- the members of ufo::geometry::AABB."""
+        if aabb is None:
+            return None, None, None
+        c = np.ascontiguousarray(aabb[0], np.float64)
+        h = np.ascontiguousarray(aabb[1], np.float64)
+        return (c, h), _p(c, C.c_double), _p(h, C.c_double)
+
+    def iterate(self, aabb=None, occupied_space=True, free_space=True, unknown_space=False, contains=False, min_depth=0, only_leaves=True):
+        """``beginLeaves`` (only_leaves) / ``beginTree`` (occupancy_map_base.h:93-165) run to the end, on the device:
+        (codes >> 3*depth, depths, log-odds, rgb, flags) in the iterator's order."""
+        keep, pc, ph = self._bv(aabb)
+        a = (int(occupied_space), int(free_space), int(unknown_space), int(contains), int(min_depth), int(only_leaves))
+        n = self._lib.ufomap_map_iterate(self._h, pc, ph, *a, None, None, None, None, None, 0)
+        if n == C.c_size_t(-1).value:
+            capi.check(-2)
+        codes, depths, occ = np.empty(n, np.uint64), np.empty(n, np.uint8), np.empty(n, np.float32)
+        rgb, flags = np.zeros((n, 3), np.uint8), np.empty(n, np.uint8)
+        if n:
+            got = self._lib.ufomap_map_iterate(self._h, pc, ph, *a, _p(codes, C.c_uint64), _p(depths, C.c_uint8), _p(occ, C.c_float),
+                                               _p(rgb, C.c_uint8), _p(flags, C.c_uint8), n)
+            assert got == n
+        return codes, depths, occ, rgb, flags
+
+    def enableChangeDetection(self, enable=True):
+        capi.check(self._lib.ufomap_map_enable_change_detection(self._h, int(enable)))
+
+    def resetChangeDetection(self):
+        capi.check(self._lib.ufomap_map_reset_change_detection(self._h))
+
+    def changes(self):
+        """The change set (occupancy_map_base.h:779-791) as (codes >> 3*depth, depths), sorted by (depth, code)."""
+        n = self._lib.ufomap_map_changes(self._h, None, None, 0)
+        if n == C.c_size_t(-1).value:
+            capi.check(-2)
+        codes, depths = np.empty(n, np.uint64), np.empty(n, np.uint8)
+        if n:
+            self._lib.ufomap_map_changes(self._h, _p(codes, C.c_uint64), _p(depths, C.c_uint8), n)
+        return codes, depths
+
+    def enableMinMaxChangeDetection(self, enable=True):
+        capi.check(self._lib.ufomap_map_enable_minmax_change_detection(self._h, int(enable)))
+
+    def write_ex(self, aabb=None, compress=False, min_depth=0, compression_acceleration_level=1, compression_level=0, header=True):
+        """``Octree::write`` (header) / ``writeData`` with all arguments (octree.h:779-917). Returns (bytes, uncompressed size)."""
+        keep, pc, ph = self._bv(aabb)
+        us = C.c_longlong(-1)
+        a = (int(compress), int(min_depth), int(compression_acceleration_level), int(compression_level), int(header))
+        n = self._lib.ufomap_map_write_ex(self._h, pc, ph, *a, None, 0, C.byref(us))
+        if n == C.c_size_t(-1).value:
+            capi.check(-2)
+        buf = np.empty(max(n, 1), np.uint8)
+        self._lib.ufomap_map_write_ex(self._h, pc, ph, *a, _p(buf, C.c_uint8), n, C.byref(us))
+        return buf[:n].tobytes(), int(us.value)
+
+    def read(self, data):
+        """``Octree::read(std::istream&)``: header + node stream as ``write`` produces them."""
+        b = np.frombuffer(data, np.uint8)
+        res, lv = C.c_double(), C.c_uint()
+        capi.check(self._lib.ufomap_map_read(self._h, _p(b, C.c_uint8), b.size, C.byref(res), C.byref(lv)))
+        self.resolution, self.depth_levels = res.value, lv.value
+
+    def readData(self, data, resolution, depth_levels, uncompressed_data_size=1, compressed=False, aabb=None):
+        """``Octree::readData`` (octree.h:737-777): a UFOMap message's node stream merged into the map."""
+        b = np.frombuffer(data, np.uint8)
+        keep, pc, ph = self._bv(aabb)
+        capi.check(self._lib.ufomap_map_read_data(self._h, _p(b, C.c_uint8) if b.size else None, b.size, pc, ph, float(resolution), int(depth_levels),
+                                                  int(uncompressed_data_size), int(compressed)))
+        self.resolution, self.depth_levels = resolution, depth_levels
+
+    def sensor_model(self):
+        """(occupied_thres, free_thres, prob_hit, prob_miss, clamping_thres_min, clamping_thres_max) as the reference's getters return them."""
+        out = np.zeros(6, np.float64)
+        capi.check(self._lib.ufomap_map_get_sensor_model(self._h, _p(out, C.c_double)))
+        return tuple(float(v) for v in out)
+
+    def setProbHit(self, p):
+        capi.check(self._lib.ufomap_map_set_model_value(self._h, 2, float(p)))
+
+    def setProbMiss(self, p):
+        capi.check(self._lib.ufomap_map_set_model_value(self._h, 3, float(p)))
+
+    def setClampingThresMin(self, p):
+        capi.check(self._lib.ufomap_map_set_model_value(self._h, 4, float(p)))
+
+    def setClampingThresMax(self, p):
+        capi.check(self._lib.ufomap_map_set_model_value(self._h, 5, float(p)))
+
+    def setOccupiedFreeThres(self, occupied_thres, free_thres):
+        capi.check(self._lib.ufomap_map_set_occupied_free_thres(self._h, float(occupied_thres), float(free_thres)))
+
+    def clear_to(self, resolution, depth_levels):
+        """``Octree::clear(new_resolution, new_depth_levels)`` (octree.h:544-575)."""
+        capi.check(self._lib.ufomap_map_clear_to(self._h, float(resolution), int(depth_levels)))
+        self.resolution, self.depth_levels = resolution, depth_levels
+
+    def setValueVolumeAABB(self, center, half_size, occupancy_value, min_depth=0):
+        c, h = np.ascontiguousarray(center, np.float64), np.ascontiguousarray(half_size, np.float64)
+        capi.check(self._lib.ufomap_map_set_value_volume_ch(self._h, _p(c, C.c_double), _p(h, C.c_double), float(occupancy_value), int(min_depth)))
+
     # ---- multi-GPU batched scans: the path split at its exchange point (include/ufomap_hip.h) ------
     ENTRY_BYTES = 16
 
