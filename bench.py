@@ -303,11 +303,12 @@ def main():
             # The dominant kernel by algorithmic bytes is the ray walk: it carries the 16*S term of B_scan (82 %). It is
             # one launch (k_cast: set-up + segment queue + walk) plus the slab merge for LiDAR-sized scans, or
             # set-up + walk + merge for the other grid sizes; the durations of whatever ran add up.
-            walkers = ("k_cast", "k_walk", "k_dda_seg", "k_dda")
-            group = [k for k in ("k_ray_setup",) + walkers + ("k_merge_slabs",) if k in kern_ms]
+            walkers = ("k_fcast", "k_cast", "k_walk", "k_dda_seg", "k_dda")  # fast path first: it runs all steady-state scans
             dom = next(k for k in walkers if k in kern_ms)
+            group = [dom, "k_fmerge"] if dom == "k_fcast" else [k for k in ("k_ray_setup",) + walkers[1:] + ("k_merge_slabs",) if k in kern_ms]
+            group = [k for k in group if k in kern_ms]
             share = P_BYTES * mean_rays + 16 * mean_steps
-            dur_s = sum(per_step_ms[k] for k in group) * 1e-3
+            dur_s = sum(kern_ms[k] for k in group) * 1e-3  # average launch durations of the kernels that make up one ray walk
             achieved = share / dur_s / 1e9
             traffic, traffic_src = None, None
             pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")

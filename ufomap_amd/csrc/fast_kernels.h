@@ -1,0 +1,1239 @@
+// fast_kernels.h -- the steady-state pipeline of a depth-0 scan whose ray grid fits in LDS (every LiDAR-sized scan):
+//
+//   scan stream   k_fhits   k_fcast   k_merge_slabs                    (never touch the map)
+//   map stream                                       k_tile   k_ftail  (the whole tree update)
+//
+// five launches per scan where the general path (scan_kernels.h / map_kernels.h: classify, select, reduce_boxes, hitmark,
+// cast, merge_slabs, extract x2, ensure, init_new, apply_leaf, propagate x2, propagate_tail) needs fourteen. What makes
+// that possible:
+//   * the scan runs on the ray grid PREDICTED from the previous scans (ufomap_hip.hip: predictGrid), so every array of
+//     the scan has a dense, known geometry: "first point in a voxel wins" (CodeSet `indices_`, occupancy_map_base.h:295,
+//     358-360) is one atomicMin on a dense u32 array over the grid's cells instead of a hash insert, and nothing has to
+//     be compacted into lists between kernels;
+//   * k_fcast re-derives a point's ray from the input cloud (the head loop is ~100 flops per point) instead of reading a
+//     ray list that a separate compaction kernel wrote;
+//   * the tree update is TILED: one wavefront owns one depth-3 node (8x8x8 voxels: 64 level-1 node blocks, 8 level-2
+//     blocks, 1 level-3 block) and does everything the reference's updateValue does beneath it -- createNode with
+//     inheritance, updateOccupancy for hits then misses, updateNode / pruning on the way up (occupancy_map_base.h:
+//     1063-1224, octree.h:997-1162) -- in registers and cross-lane operations, reading the scan's bit grid directly and
+//     writing each 64-byte block record exactly once; the few hundred node blocks above depth 3 are finished by ONE
+//     workgroup that holds them in LDS (k_ftail), where a level costs a barrier instead of a round trip to HBM.
+// Semantics are those of the general path (map_kernels.h: "last-update chain"), which stays in place for everything
+// else -- first scans, insert depth > 0, grids beyond LDS, colour maps, update lists from other GPUs -- and doubles as
+// the on-GPU cross-check of this file (tests run both on the same scans).
+#pragma once
+#include "map_kernels.h"
+
+namespace ufo
+{
+// Geometry shared by the five kernels: the predicted bit grid (Grid::layout 1) and the depth-3 tiles that cover it.
+struct FastGeo {
+	Grid gr;
+	u32 rowBits, planeBits;  // bits per row of cells (x), per plane (x, y): a cell's index is lx + ly*rowBits + lz*planeBits
+	i32 tbase[3];            // absolute tile coordinate (cell >> 3) of tile (0, 0, 0)
+	u32 nt[3];               // tiles per axis
+	u32 ntiles;
+	u32 ncells;              // entries of the first-point array (planeBits * 2*nb[2])
+};
+
+// One input point through the head loop of insertPointCloud (occupancy_map_base.h:281-303) or
+// insertPointCloudDiscrete (354-398; colour variant occupancy_map_color.h:195-233) at insert depth 0, up to but not
+// including "first point in the voxel wins". Same arithmetic, same order as k_classify / k_select (scan_kernels.h).
+struct PointRay {
+	D3 end;       // ray end as freeSpace gets it (discrete: centre of the end's voxel)
+	u32 cell;     // index of the hit voxel in the grid (hit candidates only)
+	bool cast;    // a ray is cast unless the point loses its voxel to an earlier point (discrete mode)
+	bool hitcand; // the point lies in range: its voxel receives a hit if the point is the first one in it
+	bool odd;     // needs the general path: clipped at the map cube, or outside the predicted grid
+};
+template <bool DISCRETE>
+__device__ inline PointRay pointRay(const MapGeom& g, const FastGeo& fg, const D3& sensor, const double* __restrict__ xyz, const Ingest& ing,
+                                    u32 i, double max_range, u32 color_variant, double amn[3], double amx[3])
+{
+	PointRay r;
+	r.cast = r.hitcand = r.odd = false;
+	r.cell = 0;
+	D3 end;
+	if (!loadPoint(xyz, ing, i, &end)) {
+		r.end = end;
+		return r;
+	}
+	const double h = g.hs[g.L];
+	// the fast path handles segments that lie inside the map cube (no clipping, moveLineInside leaves them alone)
+	if (!inBBX(sensor, h) || !inBBX(end, h)) {
+		r.odd = true;
+		r.end = end;
+		return r;
+	}
+	D3 hit_at = end;
+	if (DISCRETE) {
+		const double sq_max = max_range * max_range;
+		double dsq = sqnorm(end - sensor);
+		if (0 > max_range || dsq < sq_max) {
+			r.hitcand = true;
+		} else {
+			D3 c{toCoord1(g, toKey1(g, end.x, 0), 0), toCoord1(g, toKey1(g, end.y, 0), 0), toCoord1(g, toKey1(g, end.z, 0), 0)};
+			D3 dir = c - sensor;
+			if (color_variant) {
+				dsq = sqnorm(dir);
+				if (0 <= max_range && dsq > sq_max) {
+					dir = dir / sqrt(dsq);
+					end = sensor + (dir * max_range);
+				}
+			} else {
+				const double dist = norm(dir);
+				dir = dir / dist;
+				if (0 <= max_range && dist > max_range) end = sensor + (dir * max_range);
+			}
+		}
+		// OMB:371-398: the ray ends at the centre of its end's voxel
+		const u32 k0 = toKey1(g, end.x, 0), k1 = toKey1(g, end.y, 0), k2 = toKey1(g, end.z, 0);
+		const D3 ec{toCoord1(g, k0, 0), toCoord1(g, k1, 0), toCoord1(g, k2, 0)};
+		const D3 cc{toCoord1(g, toKey1(g, sensor.x, 0), 0), toCoord1(g, toKey1(g, sensor.y, 0), 0), toCoord1(g, toKey1(g, sensor.z, 0), 0)};
+		const double t = g.hs[0];
+		for (int a = 0; a < 3; ++a) {
+			amn[a] = fmin(ec[a] - t, cc[a] - t);
+			amx[a] = fmax(ec[a] + t, cc[a] + t);
+		}
+		end = ec;
+	} else {
+		D3 dir = end - sensor;
+		const double dist = norm(dir);
+		if (0 > max_range || dist <= max_range) {
+			r.hitcand = true;
+		} else {
+			dir = dir / dist;
+			end = sensor + (dir * max_range);
+			if (!inBBX(end, h)) r.odd = true;
+		}
+		for (int a = 0; a < 3; ++a) {
+			amn[a] = fmin(end[a], sensor[a]);
+			amx[a] = fmax(end[a], sensor[a]);
+		}
+	}
+	r.cast = true;
+	r.end = end;
+	// both end cells inside the interior of the predicted grid (one block of padding) and inside the key range: every
+	// cell of the walk is, then (a DDA path is monotone per axis)
+	const i32 lim = (i32)((1u << g.L) - 1u);
+	const i32 mx[3] = {2 * fg.gr.nb[0] - 2, 2 * fg.gr.nb[1] - 2, 2 * fg.gr.nb[2] - 2};
+	i32 le[3], ls[3];
+	for (int a = 0; a < 3; ++a) {
+		const i32 ke = (i32)toKey1(g, end[a], 0), ks = (i32)toKey1(g, sensor[a], 0);
+		if (ke < 0 || ke > lim || ks < 0 || ks > lim) r.odd = true;
+		le[a] = ke - fg.gr.base[a];
+		ls[a] = ks - fg.gr.base[a];
+		if (le[a] < 1 || le[a] > mx[a] || ls[a] < 1 || ls[a] > mx[a]) r.odd = true;
+	}
+	if (r.hitcand && !r.odd) {
+		// the hit voxel: the original point's (== the ray end's voxel in both modes; continuous mode: hit_at == end)
+		i32 lh[3];
+		for (int a = 0; a < 3; ++a) {
+			lh[a] = (i32)toKey1(g, hit_at[a], 0) - fg.gr.base[a];
+			if (lh[a] < 1 || lh[a] > mx[a]) r.odd = true;
+		}
+		r.cell = (u32)lh[0] + (u32)lh[1] * fg.rowBits + (u32)lh[2] * fg.planeBits;
+	}
+	return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// F1: first point in the voxel (atomicMin of the point index on the dense cell array), bounding boxes, validity of
+// the predicted grid for this scan (ERR_SPEC: the host repeats the scan on the general path).
+// ------------------------------------------------------------------------------------------------
+template <bool DISCRETE>
+__global__ __launch_bounds__(256) void k_fhits(MapGeom g, FastGeo fg, D3 sensor, const double* __restrict__ xyz, u32 n, double max_range,
+                                               u32 color_variant, u32* __restrict__ first, BoxPartial* __restrict__ part, ScanCtl* ctl,
+                                               Ingest ing)
+{
+	const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	double amn[3] = {1e300, 1e300, 1e300}, amx[3] = {-1e300, -1e300, -1e300};
+	i32 ck[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, ek[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+	bool odd = false;
+	if (i < n) {
+		const PointRay r = pointRay<DISCRETE>(g, fg, sensor, xyz, ing, i, max_range, color_variant, amn, amx);
+		odd = r.odd;
+		if (!r.odd) {
+			if (r.hitcand) atomicMin(&first[r.cell], i);
+			if (r.cast) {
+				for (int a = 0; a < 3; ++a) {
+					const i32 ka = (i32)toKey1(g, r.end[a], 0), kb = (i32)toKey1(g, sensor[a], 0);
+					ck[a] = min(ka, kb);
+					ek[a] = max(ka, kb);
+				}
+			}
+		}
+	}
+	if (__ballot(odd) && 0 == (threadIdx.x & 63u)) atomicOr(&ctl->err, ERR_SPEC);
+	i32 none_lo[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, none_hi[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+	blockBoxReduce(part, 7u, amn, amx, none_lo, none_hi, ck, ek);
+}
+
+// ------------------------------------------------------------------------------------------------
+// F2: the ray kernel of the fast path = k_cast (scan_kernels.h: set-up, segment queue, walk; bit grid in LDS) fed from
+// the input cloud instead of a compacted ray list. A workgroup takes the points blockIdx.x, blockIdx.x + gridDim.x, ...;
+// a prologue runs the head loop on them, drops the points that lose their voxel to an earlier point (discrete mode,
+// OMB:358-360: first[cell] != own index) and compacts the surviving ray ends into the workgroup's own stretch of a
+// scratch array; from there on it is k_cast's round structure.
+// ------------------------------------------------------------------------------------------------
+template <bool DISCRETE>
+__global__ __launch_bounds__(512) void k_fcast(MapGeom g, FastGeo fg, D3 sensor, const double* __restrict__ xyz, u32 n, double max_range,
+                                               u32 color_variant, const u32* __restrict__ first, D3* __restrict__ ray_scratch, u32 cap_wg,
+                                               u32* __restrict__ slabs, u32 k_min, const ScanCtl* ctl_in, ScanCtl* ctl,
+                                               unsigned long long* __restrict__ steps_part, Ingest ing)
+{
+	extern __shared__ __attribute__((aligned(16))) u32 lds[];
+	if (ctl_in->err) return;  // the scan does not fit the predicted grid (k_fhits): it will be repeated (uniform exit)
+	const Grid& gr = fg.gr;
+	const u32 depth = 0;
+	const u32 lds_words = (u32)(gr.bytes >> 2);
+	RayConst* rc = reinterpret_cast<RayConst*>(lds + lds_words);
+	RayHdr* hd = reinterpret_cast<RayHdr*>(rc + UFO_CAST_BATCH);
+	SegRec* q = reinterpret_cast<SegRec*>(hd + UFO_CAST_BATCH);
+	u32* sh = reinterpret_cast<u32*>(q + UFO_CAST_QCAP);  // [0..7], [16..23]: per-wave partial sums; [24] ray count; [25] hit count
+	{
+		uint4* l4 = reinterpret_cast<uint4*>(lds);
+		for (u32 j = threadIdx.x; j < (lds_words >> 2); j += blockDim.x) l4[j] = make_uint4(0, 0, 0, 0);
+	}
+	if (0 == threadIdx.x) {
+		sh[24] = 0;
+		sh[25] = 0;
+	}
+	__syncthreads();
+	const u32 rowBits = fg.rowBits, planeBits = fg.planeBits;
+	const u32 lim = 1u << (g.L - depth);
+	const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+	const u32 nwaves = min(8u, (blockDim.x + 63u) >> 6);
+	unsigned long long steps = 0;
+	u32 err = 0, oob = 0;
+	// ---- 0. head loop on this workgroup's points; surviving ray ends -> ray_scratch[blockIdx.x * cap_wg ...] ----
+	{
+		const u32 pts = (n > blockIdx.x) ? (n - blockIdx.x + gridDim.x - 1) / gridDim.x : 0u;
+		D3* mine_out = ray_scratch + (size_t)blockIdx.x * cap_wg;
+		u32 nhit = 0;
+		for (u32 p0 = 0; p0 < pts; p0 += blockDim.x) {  // uniform trip count
+			const u32 p = p0 + threadIdx.x;
+			bool cast = false;
+			D3 end{0, 0, 0};
+			if (p < pts) {
+				const u32 i = blockIdx.x + p * gridDim.x;
+				double amn[3], amx[3];
+				const PointRay r = pointRay<DISCRETE>(g, fg, sensor, xyz, ing, i, max_range, color_variant, amn, amx);
+				cast = r.cast && !r.odd;
+				if (r.hitcand && !r.odd) {
+					const bool winner = first[r.cell] == i;
+					nhit += winner ? 1u : 0u;
+					if (DISCRETE && !winner) cast = false;  // OMB:358-360: dropped entirely, no ray
+				}
+				end = r.end;
+			}
+			const u64 m = __ballot(cast);
+			u32 base = 0;
+			if (0 == lane && m) base = atomicAdd(&sh[24], (u32)__popcll(m));
+			base = __shfl(base, 0);
+			if (cast) {
+				const u32 pos = base + (u32)__popcll(m & ((1ULL << lane) - 1ULL));
+				if (pos < cap_wg) mine_out[pos] = end;
+			}
+		}
+		for (int o = 32; o > 0; o >>= 1) nhit += __shfl_xor(nhit, o);
+		if (0 == lane && nhit) atomicAdd(&sh[25], nhit);
+	}
+	__syncthreads();
+	const u32 mine = min(sh[24], cap_wg);
+	if (0 == threadIdx.x) {
+		if (mine) atomicAdd(&ctl->n_rays, mine);
+		if (sh[25]) atomicAdd(&ctl->n_hits, sh[25]);
+	}
+	const D3* my_rays = ray_scratch + (size_t)blockIdx.x * cap_wg;
+	for (u32 base = 0; base < mine; base += UFO_CAST_BATCH) {
+		__syncthreads();  // previous round's queue and constants are no longer read
+		const u32 t = threadIdx.x;
+		const bool have = t < UFO_CAST_BATCH && base + t < mine;
+		// ---- 1. one lane per ray: clip, keys, computeRayInit ----
+		u32 l1 = 0, dmax = 0, ax = 0, status = 0, lin0 = 0;
+		if (have) {
+			RayState r;
+			raySetup(g, sensor, depth, gr, my_rays[base + t], r);
+			status = r.status;
+			if (1 == r.status) {
+				err |= markBitChecked(gr, lds, rowBits, planeBits, r.start[0], r.start[1], r.start[2], lim, &oob);
+				steps += 1;
+			} else if (3 == r.status) {
+				err |= ERR_GRID_OOB;  // cannot happen: pointRay admits only rays inside the grid's interior
+			} else if (2 == r.status) {
+				const u32 dxn = (u32)abs((i32)(r.gpk & 1023u) - (i32)(r.pk0 & 1023u));
+				const u32 dyn = (u32)abs((i32)((r.gpk >> 10) & 1023u) - (i32)((r.pk0 >> 10) & 1023u));
+				const u32 dzn = (u32)abs((i32)(r.gpk >> 20) - (i32)(r.pk0 >> 20));
+				ax = (dxn >= dyn && dxn >= dzn) ? 0u : (dyn >= dzn ? 1u : 2u);
+				dmax = ax == 0 ? dxn : (ax == 1 ? dyn : dzn);
+				l1 = dxn + dyn + dzn;
+				lin0 = pkToLin(r.pk0, rowBits, planeBits);
+				RayConst c;
+				c.td[0] = r.td[0];
+				c.td[1] = r.td[1];
+				c.td[2] = r.td[2];
+				c.dist = r.dist;
+				c.dl[0] = r.s[0];
+				c.dl[1] = (i32)r.s[1] * (i32)rowBits;
+				c.dl[2] = (i32)r.s[2] * (i32)planeBits;
+				c.glin = pkToLin(r.gpk, rowBits, planeBits);
+				rc[t] = c;
+				hd[t].tm[0] = r.tm[0];
+				hd[t].tm[1] = r.tm[1];
+				hd[t].tm[2] = r.tm[2];
+			}
+		}
+		// ---- 2. segment length for this round: about K steps, and the queue must hold every segment ----
+		u32 tot = l1, cntr = (2 == status) ? 1u : 0u;
+		for (int o = 32; o > 0; o >>= 1) {
+			tot += __shfl_xor(tot, o);
+			cntr += __shfl_xor(cntr, o);
+		}
+		if (0 == lane && wave < 8u) {
+			sh[wave] = tot;
+			sh[16 + wave] = cntr;
+		}
+		__syncthreads();
+		u32 total = 0, nray2 = 0;
+		for (u32 wv = 0; wv < nwaves; ++wv) {
+			total += sh[wv];
+			nray2 += sh[16 + wv];
+		}
+		u32 K = k_min;
+		{
+			const u32 room = UFO_CAST_QCAP - nray2;  // >= QCAP - BATCH > 0
+			const u32 need = (2u * total + room - 1u) / room;
+			K = max(K, need);
+		}
+		u32 w = 1, nseg = 0;
+		if (2 == status) {
+			w = (u32)(((u64)dmax * K) / l1);
+			if (w < 1u) w = 1u;
+			nseg = (dmax + w - 1u) / w;  // >= 1 (start and goal differ)
+		}
+		__syncthreads();  // sh[] is reused below
+		u32 incl = nseg;
+		for (int o = 1; o < 64; o <<= 1) {
+			const u32 v = __shfl_up(incl, o);
+			if ((int)lane >= o) incl += v;
+		}
+		if (63u == lane && wave < 8u) sh[wave] = incl;
+		__syncthreads();
+		u32 off = incl - nseg, nsegs = 0;
+		for (u32 wv = 0; wv < nwaves; ++wv) {
+			const u32 v = sh[wv];
+			if (wv < wave) off += v;
+			nsegs += v;
+		}
+		if (t < UFO_CAST_BATCH) {
+			hd[t].lin0 = lin0;
+			hd[t].ax = ax;
+			hd[t].w = w;
+			hd[t].nseg = nseg;
+			hd[t].off = off;
+		}
+		for (u32 si = threadIdx.x; si < nsegs; si += blockDim.x) q[si].lin = 0;  // cut cells are summed up from two lanes
+		__syncthreads();
+		// ---- 3. cut states from the three independent addition chains (k_dda_seg), two lanes per ray ----
+		for (u32 idx = threadIdx.x; idx < 2u * UFO_CAST_BATCH; idx += blockDim.x) {
+			const u32 ry = idx & (UFO_CAST_BATCH - 1u), role = idx / UFO_CAST_BATCH;
+			const RayHdr h = hd[ry];
+			if (0 == h.nseg) continue;
+			const RayConst c = rc[ry];
+			if (0 == role) {
+				SegRec rec;
+				rec.tm[0] = h.tm[0];
+				rec.tm[1] = h.tm[1];
+				rec.tm[2] = h.tm[2];
+				rec.lin = h.lin0;
+				rec.end = c.glin;
+				rec.ray = ry | 0x80000000u;
+				rec.pad = 0;
+				q[h.off] = rec;
+			}
+			const u32 axd = h.ax;
+			const u32 b = (0 == role) ? (axd == 0 ? 1u : 0u) : (axd == 2 ? 1u : 2u);
+			const bool pri = b < axd;
+			double ta = axd == 0 ? h.tm[0] : (axd == 1 ? h.tm[1] : h.tm[2]), v = ta;
+			const double tda = axd == 0 ? c.td[0] : (axd == 1 ? c.td[1] : c.td[2]);
+			const i32 da = axd == 0 ? c.dl[0] : (axd == 1 ? c.dl[1] : c.dl[2]);
+			double tb = b == 0 ? h.tm[0] : (b == 1 ? h.tm[1] : h.tm[2]);
+			const double dbt = b == 0 ? c.td[0] : (b == 1 ? c.td[1] : c.td[2]);
+			const i32 dbl = b == 0 ? c.dl[0] : (b == 1 ? c.dl[1] : c.dl[2]);
+			u32 ka = 0, cb = 0;
+			for (u32 j = 1; j < h.nseg; ++j) {
+				const u32 k0 = j * h.w;  // < dmax
+				for (; ka < k0; ++ka) {
+					v = ta;
+					ta = ta + tda;
+				}
+				while (cb < 2048u) {
+					const double s1 = tb + dbt, s2 = s1 + dbt, s3 = s2 + dbt;
+					const bool c0 = pri ? (tb <= v) : (tb < v);
+					if (!c0) break;
+					const bool c1 = pri ? (s1 <= v) : (s1 < v), c2 = pri ? (s2 <= v) : (s2 < v), c3 = pri ? (s3 <= v) : (s3 < v);
+					if (c1 & c2 & c3) {
+						tb = s3 + dbt;
+						cb += 4u;
+					} else {
+						tb = c1 ? (c2 ? s3 : s2) : s1;
+						cb += 1u + (c1 ? (c2 ? 2u : 1u) : 0u);
+						break;
+					}
+				}
+				if (cb >= 2048u) err |= ERR_RUNAWAY;  // (guard of the pop loop: cannot trip inside a grid of < 1024 cells per axis)
+				SegRec* o = &q[h.off + j];
+				if (0 == role) {
+					o->tm[axd] = ta;
+					o->end = c.glin;
+					o->ray = ry;
+				}
+				o->tm[b] = tb;
+				atomicAdd(&o->lin, (0 == role ? h.lin0 + (u32)((i32)k0 * da) : 0u) + (u32)((i32)cb * dbl));
+			}
+		}
+		__syncthreads();
+		for (u32 si = threadIdx.x; si + 1u < nsegs; si += blockDim.x)
+			if (!(q[si + 1u].ray & 0x80000000u)) q[si].end = q[si + 1u].lin;
+		__syncthreads();
+		// ---- 4. every lane walks segments ----
+		for (u32 si = threadIdx.x; si < nsegs; si += blockDim.x) {
+			const SegRec rec = q[si];
+			const RayConst c = rc[rec.ray & 0x7FFFFFFFu];
+			double tmx = rec.tm[0], tmy = rec.tm[1], tmz = rec.tm[2];
+			const double tdx = c.td[0], tdy = c.td[1], tdz = c.td[2];
+			const long long idist = __double_as_longlong(c.dist);
+			const i32 dlx = c.dl[0], dly = c.dl[1], dlz = c.dl[2];
+			const u32 end = rec.end;
+			u32 lin = rec.lin;
+			bool go = (0 != (rec.ray & 0x80000000u)) ||
+			          ((lin != c.glin) && ((__double_as_longlong(tmx) <= idist) | (__double_as_longlong(tmy) <= idist) |
+			                               (__double_as_longlong(tmz) <= idist)));
+			const u32 lin_first = lin;
+			u32 cnt = 0;
+			while (go) {
+				++cnt;
+				atomicOr(&lds[lin >> 5], 1u << (lin & 31u));
+				const bool cxy = tmx <= tmy, cxz = tmx <= tmz, cyz = tmy <= tmz;
+				const bool selx = cxy & cxz;
+				const bool sely = !cxy & cyz;
+				const bool selz = !(selx | sely);
+				lin += (u32)(selx ? dlx : (sely ? dly : dlz));
+				const double nx = tmx + tdx, ny = tmy + tdy, nz = tmz + tdz;
+				tmx = selx ? nx : tmx;
+				tmy = sely ? ny : tmy;
+				tmz = selz ? nz : tmz;
+				const bool more =
+				    (__double_as_longlong(tmx) <= idist) | (__double_as_longlong(tmy) <= idist) | (__double_as_longlong(tmz) <= idist);
+				go = (lin != end) & more & (cnt < 4096u);
+			}
+			if (cnt >= 4096u) err |= ERR_RUNAWAY;  // (a segment is ~K steps by construction)
+			const u32 ny2 = 2u * (u32)gr.nb[1];
+			const u32 r0 = lin_first / rowBits, r1 = lin / rowBits;
+			const i32 ddx = (i32)(lin % rowBits) - (i32)(lin_first % rowBits), ddy = (i32)(r1 % ny2) - (i32)(r0 % ny2),
+			          ddz = (i32)(r1 / ny2) - (i32)(r0 / ny2);
+			steps += (u32)(abs(ddx) + abs(ddy) + abs(ddz));
+		}
+	}
+	__syncthreads();
+	{
+		const uint4* l4 = reinterpret_cast<const uint4*>(lds);
+		uint4* out4 = reinterpret_cast<uint4*>(slabs) + (size_t)blockIdx.x * (lds_words >> 2);
+		const u32 n4 = lds_words >> 2;
+		for (u32 j = threadIdx.x; j < n4; j += blockDim.x) out4[j] = l4[j];
+	}
+	blockStoreSteps(steps, steps_part);
+	if (oob) atomicAdd(&ctl->n_oob, oob);
+	if (err) atomicOr(&ctl->err, err);
+}
+
+// ------------------------------------------------------------------------------------------------
+// F3: k_merge_slabs (scan_kernels.h) + which depth-3 tiles of the grid hold a marked cell (one bit per tile): the
+// tree-update kernels start from that bitmap instead of searching the grid.
+// ------------------------------------------------------------------------------------------------
+#define UFO_FAST_MAX_TILES 8192u
+__global__ __launch_bounds__(1024) void k_fmerge(FastGeo fg, const uint4* __restrict__ slabs, u32 n_slabs, u32 n4, uint4* __restrict__ grid,
+                                                 const unsigned long long* __restrict__ steps_part, u32* __restrict__ tile_bits, ScanCtl* ctl)
+{
+	__shared__ uint4 part[16][64];
+	__shared__ u32 tb[UFO_FAST_MAX_TILES / 32];
+	if (ctl->err) return;
+	const u32 col = threadIdx.x & 63u, sl = threadIdx.x >> 6;
+	for (u32 j = threadIdx.x; j < UFO_FAST_MAX_TILES / 32; j += blockDim.x) tb[j] = 0;
+	if (steps_part && 0 == blockIdx.x && threadIdx.x < 64u) {
+		unsigned long long v = 0;
+		for (u32 s = threadIdx.x; s < n_slabs; s += 64u) v += steps_part[s];
+		for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+		if (0 == threadIdx.x && v) atomicAdd(&ctl->n_steps, v);
+	}
+	__syncthreads();
+	const u32 rowW = fg.rowBits >> 5, ny = 2u * (u32)fg.gr.nb[1];
+	for (u32 j0 = blockIdx.x * 64u; j0 < n4; j0 += gridDim.x * 64u) {
+		const u32 j = j0 + col;
+		uint4 acc = make_uint4(0, 0, 0, 0);
+		if (j < n4) {
+			for (u32 s = sl; s < n_slabs; s += 16u) {
+				const uint4 a = slabs[(size_t)s * n4 + j];
+				acc.x |= a.x;
+				acc.y |= a.y;
+				acc.z |= a.z;
+				acc.w |= a.w;
+			}
+		}
+		part[sl][col] = acc;
+		__syncthreads();
+		if (0 == sl && j < n4) {
+			for (u32 k = 1; k < 16u; ++k) {
+				const uint4 a = part[k][col];
+				acc.x |= a.x;
+				acc.y |= a.y;
+				acc.z |= a.z;
+				acc.w |= a.w;
+			}
+			grid[j] = acc;
+			const u32 wv[4] = {acc.x, acc.y, acc.z, acc.w};
+			for (u32 k = 0; k < 4u; ++k) {
+				u32 m = wv[k];
+				if (0 == m) continue;
+				const u32 widx = 4u * j + k;
+				const u32 row = widx / rowW, wx = widx % rowW;
+				const u32 ly = row % ny, lz = row / ny;
+				if (lz >= 2u * (u32)fg.gr.nb[2]) continue;  // (padding behind the last row)
+				const i32 ty = ((fg.gr.base[1] + (i32)ly) >> 3) - fg.tbase[1], tz = ((fg.gr.base[2] + (i32)lz) >> 3) - fg.tbase[2];
+				while (m) {
+					const u32 bit = (u32)__ffs(m) - 1u;
+					const i32 ax = fg.gr.base[0] + (i32)(32u * wx + bit);
+					const i32 tx = (ax >> 3) - fg.tbase[0];
+					// all cells of this word that fall into the same tile
+					const i32 first_in_tile = ((ax >> 3) << 3) - fg.gr.base[0] - (i32)(32u * wx);  // bit index of the tile's first cell (may be < 0)
+					const u32 lo = (u32)max(first_in_tile, 0), hi = (u32)min(first_in_tile + 8, 32);
+					const u32 span = (hi >= 32u ? 0xFFFFFFFFu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
+					m &= ~span;
+					const u32 tile = (u32)tx + fg.nt[0] * ((u32)ty + fg.nt[1] * (u32)tz);
+					if (tile < fg.ntiles) atomicOr(&tb[tile >> 5], 1u << (tile & 31u));
+				}
+			}
+		}
+		__syncthreads();
+	}
+	for (u32 j = threadIdx.x; j < (fg.ntiles + 31u) / 32u; j += blockDim.x)
+		if (tb[j]) atomicOr(&tile_bits[j], tb[j]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tree update, part 1 (k_fupper): the node blocks ABOVE the tiles. The active tiles' ancestors -- level 4 up to the
+// root block, a few hundred blocks for a LiDAR scan -- are collected in LDS (a hash set per level), created where they
+// do not exist yet (createNode, octree.h:997-1016) and initialised top-down by inheritance (createChildren,
+// octree.h:1044-1054), so that every tile finds its level-4 block in place and initialised. The node list (key, table
+// slot, parent index, level ranges) is left in global memory for k_ftail, which finishes these blocks after the tiles.
+// ------------------------------------------------------------------------------------------------
+#define UFO_UPPER_MAX 1024u   // node blocks above the tiles that one scan may touch (the host checks the grid against it)
+#define UFO_UPPER_HASH 4096u
+struct UpperNode {
+	u64 lk;
+	u32 slot;
+	u32 parent;  // index of the parent node in the list (NONE for the root block)
+};
+struct UpperHdr {
+	u32 count;
+	u32 start[24];  // nodes of level l are [start[l], start[l+1])
+	u32 pad[7];
+};
+__device__ inline u32 upperHash(u64 k) { return hash64(k) & (UFO_UPPER_HASH - 1u); }
+// level-3 block key of a tile; false if the tile lies outside the key range
+__device__ inline bool tileKey(const MapGeom& g, const FastGeo& fg, u32 tile, u64* lk3, u32* tcoord)
+{
+	const u32 ttx = tile % fg.nt[0], r = tile / fg.nt[0];
+	const u32 tty = r % fg.nt[1], ttz = r / fg.nt[1];
+	const i32 T[3] = {fg.tbase[0] + (i32)ttx, fg.tbase[1] + (i32)tty, fg.tbase[2] + (i32)ttz};
+	const i32 lim = (i32)(1u << (g.L - 3u));
+	if (T[0] < 0 || T[1] < 0 || T[2] < 0 || T[0] >= lim || T[1] >= lim || T[2] >= lim) return false;
+	*lk3 = (1ULL << (3 * (g.L - 3))) | morton3((u32)T[0], (u32)T[1], (u32)T[2]);
+	if (tcoord) {
+		tcoord[0] = ttx;
+		tcoord[1] = tty;
+		tcoord[2] = ttz;
+	}
+	return true;
+}
+
+__global__ __launch_bounds__(1024) void k_fupper(Table t, MapGeom g, FastGeo fg, const u32* __restrict__ tile_bits, u32 scan_id,
+                                                 UpperNode* __restrict__ nodes, UpperHdr* __restrict__ hdr, u32* __restrict__ tile_node,
+                                                 ScanCtl* ctl, const ScanCtl* prev)
+{
+	__shared__ u64 hk[UFO_UPPER_HASH];
+	__shared__ u32 hv[UFO_UPPER_HASH];
+	__shared__ u64 nk[UFO_UPPER_MAX];
+	__shared__ u32 nslot[UFO_UPPER_MAX], npar[UFO_UPPER_MAX], nflags[UFO_UPPER_MAX];
+	__shared__ float nocc[UFO_UPPER_MAX][8];
+	__shared__ uint8_t ncreated[UFO_UPPER_MAX];
+	__shared__ u32 count, start[25], overflow, created_total;
+	if (prev && prev->err) {
+		// the update enqueued just before this one flagged itself and left the map alone: this one stands back too
+		if (0 == threadIdx.x) atomicOr(&ctl->err, ERR_PREV);
+		return;
+	}
+	if (ctl->err) return;  // e.g. ERR_SPEC: map untouched, the host repeats the scan
+	for (u32 j = threadIdx.x; j < UFO_UPPER_HASH; j += blockDim.x) hk[j] = 0;
+	if (0 == threadIdx.x) {
+		count = 0;
+		overflow = 0;
+		created_total = 0;
+		for (int l = 0; l < 25; ++l) start[l] = 0;
+	}
+	__syncthreads();
+	const u32 L = g.L;
+	// insert `key` if absent (pass A of a level: winners allocate a node)
+	auto insert = [&](u64 key) {
+		u32 h = upperHash(key);
+		for (u32 probe = 0; probe < UFO_UPPER_HASH; ++probe) {
+			const u64 prevk = atomicCAS((unsigned long long*)&hk[h], 0ULL, (unsigned long long)key);
+			if (0 == prevk) {
+				const u32 idx = atomicAdd(&count, 1u);
+				if (idx < UFO_UPPER_MAX) {
+					nk[idx] = key;
+					hv[h] = idx;
+				} else {
+					overflow = 1u;
+					hv[h] = 0;
+				}
+				return;
+			}
+			if (prevk == key) return;
+			h = (h + 1u) & (UFO_UPPER_HASH - 1u);
+		}
+		overflow = 1u;
+	};
+	auto lookup = [&](u64 key) -> u32 {
+		u32 h = upperHash(key);
+		for (u32 probe = 0; probe < UFO_UPPER_HASH; ++probe) {
+			const u64 k = hk[h];
+			if (k == key) return hv[h];
+			if (0 == k) return NONE;
+			h = (h + 1u) & (UFO_UPPER_HASH - 1u);
+		}
+		return NONE;
+	};
+	// ---- level 4: parents of the active tiles ----
+	for (u32 tile = threadIdx.x; tile < fg.ntiles; tile += blockDim.x) {
+		if (!((tile_bits[tile >> 5] >> (tile & 31u)) & 1u)) continue;
+		u64 lk3;
+		if (!tileKey(g, fg, tile, &lk3, nullptr)) continue;
+		insert(lk3 >> 3);
+	}
+	__syncthreads();
+	if (0 == threadIdx.x) {
+		start[4] = 0;
+		start[5] = min(count, UFO_UPPER_MAX);
+	}
+	__syncthreads();
+	// ---- levels 5 .. L: parents of the level below ----
+	for (u32 l = 4; l < L; ++l) {
+		const u32 lo = start[l], hi = start[l + 1];
+		for (u32 i = lo + threadIdx.x; i < hi; i += blockDim.x) insert(nk[i] >> 3);
+		__syncthreads();
+		if (0 == threadIdx.x) start[l + 2] = min(count, UFO_UPPER_MAX);
+		__syncthreads();
+		for (u32 i = lo + threadIdx.x; i < hi; i += blockDim.x) npar[i] = lookup(nk[i] >> 3);
+	}
+	__syncthreads();
+	if (overflow) {
+		// more blocks above the tiles than this kernel holds: nothing has touched the map yet, the host repeats the scan
+		// on the general path
+		if (0 == threadIdx.x) atomicOr(&ctl->err, ERR_SPEC);
+		return;
+	}
+	const u32 U = count;
+	const u32 max_probe = (t.mask >> 1) + 1;
+	// ---- find or create every block; existing ones are loaded ----
+	u32 n_created = 0;
+	for (u32 i = threadIdx.x; i < U; i += blockDim.x) {
+		bool cr;
+		const u32 s = tableEnsure(t, nk[i], scan_id, max_probe, &cr, &n_created);
+		nslot[i] = s;
+		ncreated[i] = cr ? 1 : 0;
+		if (1 == nk[i]) npar[i] = NONE;
+		if (s == NONE) {
+			atomicOr(&ctl->err, ERR_TABLE_FULL);
+			continue;
+		}
+		if (!cr) {
+			const float4* po = reinterpret_cast<const float4*>(t.occ(s));
+			const float4 a = po[0], b = po[1];
+			nocc[i][0] = a.x; nocc[i][1] = a.y; nocc[i][2] = a.z; nocc[i][3] = a.w;
+			nocc[i][4] = b.x; nocc[i][5] = b.y; nocc[i][6] = b.z; nocc[i][7] = b.w;
+			nflags[i] = t.flags(s);
+		} else {
+			nflags[i] = 0;
+		}
+	}
+	if (n_created) atomicAdd(&created_total, n_created);
+	__syncthreads();
+	// ---- top-down: new blocks inherit the node's value from the parent block (octree.h:1044-1054) ----
+	for (u32 l = L; l >= 4; --l) {
+		for (u32 i = start[l] + threadIdx.x; i < start[l + 1]; i += blockDim.x) {
+			if (!ncreated[i] || nslot[i] == NONE) continue;
+			float v;
+			if (1 == nk[i]) {
+				v = t.root->occ;
+			} else {
+				const u32 p = npar[i], ci = (u32)(nk[i] & 7);
+				v = nocc[p][ci];
+				atomicOr(&nflags[p], 1u << (16 + ci));
+			}
+			for (int c = 0; c < 8; ++c) nocc[i][c] = v;
+			// leaf children carry the flags of a leaf with this value (OMB:1181-1189)
+			atomicOr(&nflags[i], (isFreeV(g, v) ? F_CFREE : 0u) | (isUnknownV(g, v) ? F_CUNK : 0u));
+		}
+		__syncthreads();
+	}
+	// ---- write back: new blocks completely, flags of all (a new child sets its parent's "child is inner" bit) ----
+	for (u32 i = threadIdx.x; i < U; i += blockDim.x) {
+		const u32 s = nslot[i];
+		if (s == NONE) continue;
+		if (ncreated[i]) {
+			float4* po = reinterpret_cast<float4*>(t.occ(s));
+			po[0] = make_float4(nocc[i][0], nocc[i][1], nocc[i][2], nocc[i][3]);
+			po[1] = make_float4(nocc[i][4], nocc[i][5], nocc[i][6], nocc[i][7]);
+			t.parent(s) = (1 == nk[i]) ? NONE : nslot[npar[i]];
+		}
+		t.flags(s) = nflags[i];
+		UpperNode un;
+		un.lk = nk[i];
+		un.slot = s;
+		un.parent = npar[i];
+		nodes[i] = un;
+	}
+	for (u32 tile = threadIdx.x; tile < fg.ntiles; tile += blockDim.x) {
+		u32 v = NONE;
+		u64 lk3;
+		if (((tile_bits[tile >> 5] >> (tile & 31u)) & 1u) && tileKey(g, fg, tile, &lk3, nullptr)) v = lookup(lk3 >> 3);
+		tile_node[tile] = v;
+	}
+	if (0 == threadIdx.x) {
+		hdr->count = U;
+		for (int l = 0; l < 24; ++l) hdr->start[l] = start[l];
+		if (created_total) {
+			atomicAdd(&t.root->used, created_total);
+			atomicAdd(&ctl->ph[0].n_new, created_total);
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tree update, part 2 (k_tile): one wavefront per active depth-3 tile. Lane l owns the level-1 node block whose 6-bit
+// position inside the tile is l (three Morton digits: child index inside the level-2 block = l & 7, level-2 block =
+// l >> 3) AND the slice of every block above that lies on its path: "its" depth-1 node's value in the level-2 block,
+// "its" depth-2 node's value in the level-3 block (replicated over the 8 lanes of a group). A level of updateNode is
+// then a reduction over 8 lanes (xor shuffles 1, 2, 4 for level 2; 8, 16, 32 for level 3) -- every lane ends up with
+// the same summary, nothing is broadcast, nothing goes through memory. Reads: 4 words of the bit grid, up to 8 entries
+// of the first-point array and one 64-byte block record per lane, the parents' slices (coalesced 4-byte loads).
+// Writes: each touched block record once.
+//
+// Semantics per level are exactly k_apply_leaf + propagateCore (map_kernels.h): hits (clamp) then misses (clamp) on
+// the voxels; a block's summary goes to its parent's slot; a parent is re-evaluated only if a child's stored summary
+// changed or the child's last update alone changed it; a node collapses only if the last update beneath it reached it.
+// At insert depth 0 every touched block has a miss (the end cell of every ray is a miss cell, OMB:1286), and misses
+// are applied after all hits in ascending code order: "the last update beneath a node" is always the miss in the
+// highest touched child, at every level.
+// ------------------------------------------------------------------------------------------------
+struct TileRec {
+	float occ, pre_occ;  // summary of the tile's level-3 block after the scan / just before its last update
+	u32 slot;            // table slot of the level-3 block
+	u32 bits;            // 0-1 fl, 2-3 pre fl, 4 evaluated (summary handed to the parent), 5 last update reached and changed it
+};
+__device__ inline u32 flagsOf(const MapGeom& g, float v) { return (isFreeV(g, v) ? 1u : 0u) | (isUnknownV(g, v) ? 2u : 0u); }
+// reductions over the 8 lanes that differ in the three lane-index bits starting at bit `sh` (0: a level-2 group, 3: across groups)
+__device__ inline float grpMax(float v, int sh)
+{
+	for (int o = 1; o < 8; o <<= 1) v = fmaxf(v, __shfl_xor(v, o << sh));
+	return v;
+}
+__device__ inline u32 grpOr(u32 v, int sh)
+{
+	for (int o = 1; o < 8; o <<= 1) v |= __shfl_xor(v, o << sh);
+	return v;
+}
+__device__ inline u32 grpMaxU(u32 v, int sh)
+{
+	for (int o = 1; o < 8; o <<= 1) v = max(v, (u32)__shfl_xor(v, o << sh));
+	return v;
+}
+__device__ inline bool grpAllEq(float v, int sh, u32 lane)
+{
+	// value of the group's first lane, compared by every lane, AND-reduced
+	const float first = __shfl(v, (int)(sh ? (lane & 7u) : (lane & ~7u)));
+	return 0 == grpOr((v == first) ? 0u : 1u, sh);
+}
+
+__global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, const u32* __restrict__ gridM, u32* __restrict__ first,
+                                              const u32* __restrict__ tile_bits, const u32* __restrict__ tile_node,
+                                              const UpperNode* __restrict__ nodes, TileRec* __restrict__ recs, float upd_hit, float upd_miss,
+                                              u32 scan_id, u64* __restrict__ hit_codes, u32 hit_cap, ScanCtl* ctl)
+{
+	const u32 lane = threadIdx.x & 63u;
+	const u32 tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+	if (tile >= fg.ntiles) return;
+	if (ctl->err) return;  // (raised before anything touched the map: k_fhits / k_fcast / k_fupper; uniform)
+	if (!((tile_bits[tile >> 5] >> (tile & 31u)) & 1u)) return;
+	u64 lk3;
+	u32 tt[3];
+	if (!tileKey(g, fg, tile, &lk3, tt)) return;
+	const u32 n4 = tile_node[tile];
+	if (n4 == NONE) return;
+	const u32 s4 = nodes[n4].slot;
+	const u32 ci3 = (u32)(lk3 & 7);
+	const u32 c2 = lane >> 3, c1 = lane & 7u;
+	const u32 bx = (c1 & 1u) | ((c2 & 1u) << 1), by = ((c1 >> 1) & 1u) | (((c2 >> 1) & 1u) << 1), bz = ((c1 >> 2) & 1u) | (((c2 >> 2) & 1u) << 1);
+	// ---- miss mask of the lane's level-1 block from the bit grid, hits from the first-point array ----
+	const i32 ox = (fg.tbase[0] + (i32)tt[0]) * 8 - fg.gr.base[0] + 2 * (i32)bx;
+	const i32 oy = (fg.tbase[1] + (i32)tt[1]) * 8 - fg.gr.base[1] + 2 * (i32)by;
+	const i32 oz = (fg.tbase[2] + (i32)tt[2]) * 8 - fg.gr.base[2] + 2 * (i32)bz;
+	const i32 nx = 2 * fg.gr.nb[0], ny = 2 * fg.gr.nb[1], nz = 2 * fg.gr.nb[2];
+	const u32 rowW = fg.rowBits >> 5;
+	u32 mmask = 0, hmask = 0;
+	u32 hit_pt[8];
+#pragma unroll
+	for (int c = 0; c < 8; ++c) hit_pt[c] = 0xFFFFFFFFu;
+	if (ox >= 0 && ox + 1 < nx) {
+#pragma unroll
+		for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+			for (int dy = 0; dy < 2; ++dy) {
+				const i32 ly = oy + dy, lz = oz + dz;
+				if (ly < 0 || ly >= ny || lz < 0 || lz >= nz) continue;
+				const u32 w = gridM[((u32)lz * (u32)ny + (u32)ly) * rowW + ((u32)ox >> 5)];
+				mmask |= ((w >> ((u32)ox & 31u)) & 3u) << (2 * dy + 4 * dz);
+			}
+	}
+	const bool active = 0 != mmask;
+	u32 nhit = 0;
+	if (active) {
+#pragma unroll
+		for (int c = 0; c < 8; ++c) {
+			if (!((mmask >> c) & 1u)) continue;
+			const u32 cell = (u32)(ox + (c & 1)) + (u32)(oy + ((c >> 1) & 1)) * fg.rowBits + (u32)(oz + ((c >> 2) & 1)) * fg.planeBits;
+			const u32 f = first[cell];
+			if (f != 0xFFFFFFFFu) {
+				hit_pt[c] = f;
+				hmask |= 1u << c;
+				first[cell] = 0xFFFFFFFFu;  // this kernel is the array's last reader: leave it clean for the next scan
+				++nhit;
+			}
+		}
+	}
+	// ---- the blocks: level 3 (lane 0), level 2 (first lane of an active group), level 1 (active lanes) ----
+	const u32 max_probe = (t.mask >> 1) + 1;
+	u32 n_created = 0;
+	const u32 act2 = grpOr(active ? 1u : 0u, 0);  // the lane's level-2 group is touched
+	bool cr3 = false, cr2 = false, cr1 = false;
+	u32 s3 = NONE, s2 = NONE, s1 = NONE;
+	const u64 lk2 = (lk3 << 3) | (u64)c2, lk1 = (lk2 << 3) | (u64)c1;
+	if (0 == lane) s3 = tableEnsure(t, lk3, scan_id, max_probe, &cr3, &n_created);
+	if (0 == c1 && act2) s2 = tableEnsure(t, lk2, scan_id, max_probe, &cr2, &n_created);
+	if (active) s1 = tableEnsure(t, lk1, scan_id, max_probe, &cr1, &n_created);
+	s3 = __shfl(s3, 0);
+	cr3 = 0 != __shfl(cr3 ? 1 : 0, 0);
+	s2 = __shfl(s2, (int)(lane & ~7u));
+	cr2 = 0 != __shfl(cr2 ? 1 : 0, (int)(lane & ~7u));
+	if (__ballot((0 == lane && s3 == NONE) || (act2 && s2 == NONE) || (active && s1 == NONE))) {
+		if (0 == lane) atomicOr(&ctl->err, ERR_TABLE_FULL);  // (the host sizes the table for the worst case before launching)
+		return;
+	}
+	// ---- stored state of the lane's slices; new blocks inherit (octree.h:1044-1054) ----
+	// depth-3 node (the tile): its value lives in the level-4 block
+	const float v3s = t.occ(s4)[ci3];
+	const u32 f4 = t.flags(s4);
+	const u32 f3s = ((f4 >> ci3) & 1u) | (((f4 >> (8 + ci3)) & 1u) << 1);
+	// depth-2 node c2: slot c2 of the level-3 block
+	float v2s;
+	u32 f2s, in2s;  // stored value, flags, "has a live block" of the lane's depth-2 node
+	if (cr3) {
+		v2s = v3s;
+		f2s = flagsOf(g, v3s);
+		in2s = 0;
+	} else {
+		const u32 fl3 = t.flags(s3);
+		v2s = t.occ(s3)[c2];
+		f2s = ((fl3 >> c2) & 1u) | (((fl3 >> (8 + c2)) & 1u) << 1);
+		in2s = (fl3 >> (16 + c2)) & 1u;
+	}
+	// depth-1 node c1 of group c2: slot c1 of the level-2 block (if the group is touched)
+	float v1s = v2s;
+	u32 f1s = flagsOf(g, v2s), in1s = 0;
+	if (act2 && !cr2) {
+		const u32 fl2 = t.flags(s2);
+		v1s = t.occ(s2)[c1];
+		f1s = ((fl2 >> c1) & 1u) | (((fl2 >> (8 + c1)) & 1u) << 1);
+		in1s = (fl2 >> (16 + c1)) & 1u;
+	}
+	// ---- level 1: updateOccupancy on the voxels (hits, then misses), the block's own updateNode ----
+	float cur1 = v1s;   // current value / flags of the lane's depth-1 node
+	u32 curf1 = f1s, in1 = in1s;
+	bool want1 = false, reach1 = false;
+	float pre1 = v1s;
+	u32 pref1 = f1s;
+	if (active) {
+		float v[8];
+		if (cr1) {
+#pragma unroll
+			for (int c = 0; c < 8; ++c) v[c] = v1s;
+		} else {
+			const float4* po = reinterpret_cast<const float4*>(t.occ(s1));
+			const float4 a = po[0], b = po[1];
+			v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+			v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+		}
+		const int c_last = 31 - __clz((int)mmask);  // ascending code order: the highest touched voxel is updated last
+		float v_old_last = 0.f;
+#pragma unroll
+		for (int c = 0; c < 8; ++c) {
+			float x = v[c];
+			if ((hmask >> c) & 1u) x = clampAdd(x, upd_hit, g.cmin, g.cmax);
+			if ((mmask >> c) & 1u) {
+				if (c == c_last) v_old_last = x;
+				x = clampAdd(x, upd_miss, g.cmin, g.cmax);
+			}
+			v[c] = x;
+		}
+		float4* po = reinterpret_cast<float4*>(t.occ(s1));
+		po[0] = make_float4(v[0], v[1], v[2], v[3]);
+		po[1] = make_float4(v[4], v[5], v[6], v[7]);
+		// updateNode of a depth-1 node (OMB:1195-1224): max, flags from the 8 voxels, collapsible if all equal
+		float m = v[0], pm = (0 == c_last) ? v_old_last : v[0];
+		u32 fl = 0, pfl = 0;
+		bool eq = true;
+#pragma unroll
+		for (int c = 0; c < 8; ++c) {
+			const float pv = (c == c_last) ? v_old_last : v[c];
+			m = fmaxf(m, v[c]);
+			pm = fmaxf(pm, pv);
+			fl |= flagsOf(g, v[c]);
+			pfl |= flagsOf(g, pv);
+			eq = eq && (v[c] == v[0]);
+		}
+		reach1 = !(pm == m && pfl == fl);  // level 1 is always reached (OMB:1128 starts at depth 1)
+		pre1 = pm;
+		pref1 = pfl;
+		const bool dead1 = eq;             // collapsed: the node is a leaf again (octree.h:1060-1066)
+		in1 = dead1 ? 0u : 1u;
+		want1 = (m != v1s) || (fl != f1s) || reach1;
+		cur1 = m;
+		curf1 = fl;
+		// the record's tail: flags (low bits as k_init_new leaves them for a new block) + parent, one 8-byte store
+		u32 fw = cr1 ? ((isFreeV(g, v1s) ? F_CFREE : 0u) | (isUnknownV(g, v1s) ? F_CUNK : 0u)) : (t.flags(s1) & ~(F_DEAD | F_DIRTY));
+		if (dead1) fw |= F_DEAD;
+		t.flags(s1) = fw;
+		t.parent(s1) = s2;
+	}
+	// ---- level 2 (reductions over the 8 lanes of a group; every lane of the group computes the same) ----
+	const u32 top1 = grpMaxU(active ? (c1 + 1u) : 0u, 0);     // 1 + the highest touched child of the group (0: none)
+	const bool eval2 = 0 != grpOr(want1 ? 1u : 0u, 0);
+	float cur2 = v2s;
+	u32 curf2 = f2s, in2 = in2s;
+	bool want2 = false, reach2 = false, dead2 = false;
+	float pre2 = v2s;
+	u32 pref2 = f2s;
+	{
+		const float m = grpMax(cur1, 0);
+		const u32 fl = grpOr(curf1, 0);
+		const bool eq = grpAllEq(cur1, 0, lane);
+		const u32 inner_any = grpOr(in1, 0);
+		const bool is_top = active && (c1 + 1u == top1);
+		const bool reached = 0 != grpOr((is_top && reach1) ? 1u : 0u, 0);  // the last update beneath reached the child and changed it
+		const float pm = grpMax(is_top ? pre1 : cur1, 0);
+		const u32 pfl = grpOr(is_top ? pref1 : curf1, 0);
+		if (eval2) {
+			dead2 = reached && eq && 0 == inner_any;
+			reach2 = reached && !(pm == m && pfl == fl);
+			want2 = (m != v2s) || (fl != f2s) || reach2;
+			pre2 = pm;
+			pref2 = pfl;
+			cur2 = m;
+			curf2 = fl;
+		}
+		if (act2) in2 = dead2 ? 0u : 1u;
+	}
+	if (act2) {
+		// the level-2 record: the lane writes its child's slot; the group's first lane the flags + parent
+		if (active || cr2) t.occ(s2)[c1] = cur1;
+		const u32 fbits = grpOr(((curf1 & 1u) << c1) | (((curf1 >> 1) & 1u) << (8 + c1)) | (in1 << (16 + c1)), 0);
+		if (0 == c1) {
+			t.flags(s2) = fbits | (dead2 ? F_DEAD : 0u);
+			t.parent(s2) = s3;
+		}
+	}
+	// ---- level 3 (reductions across the 8 groups; every lane computes the same) ----
+	const u32 top2 = grpMaxU(act2 ? (c2 + 1u) : 0u, 3);
+	const bool eval3 = 0 != grpOr(want2 ? 1u : 0u, 3);
+	bool reach3 = false, dead3 = false;
+	float m3 = v3s, pm3 = v3s;
+	u32 fl3n = f3s, pfl3 = f3s;
+	{
+		const float m = grpMax(cur2, 3);
+		const u32 fl = grpOr(curf2, 3);
+		const bool eq = grpAllEq(cur2, 3, lane);
+		const u32 inner_any = grpOr(in2, 3);
+		const bool is_top = act2 && (c2 + 1u == top2);
+		const bool reached = 0 != grpOr((is_top && reach2) ? 1u : 0u, 3);
+		const float pm = grpMax(is_top ? pre2 : cur2, 3);
+		const u32 pfl = grpOr(is_top ? pref2 : curf2, 3);
+		if (eval3) {
+			dead3 = reached && eq && 0 == inner_any;
+			reach3 = reached && !(pm == m && pfl == fl);
+			m3 = m;
+			fl3n = fl;
+			pm3 = pm;
+			pfl3 = pfl;
+		}
+	}
+	{
+		// the level-3 record: first lane of every group writes its slot (all eight when the block is new), lane 0 the rest
+		if (0 == c1 && (act2 || cr3)) t.occ(s3)[c2] = cur2;
+		const u32 fbits = grpOr((0 == c1) ? (((curf2 & 1u) << c2) | (((curf2 >> 1) & 1u) << (8 + c2)) | (in2 << (16 + c2))) : 0u, 3);
+		if (0 == lane) {
+			t.flags(s3) = fbits | (dead3 ? F_DEAD : 0u);
+			t.parent(s3) = s4;
+			// "child is inner" bit of the tile in its level-4 block (k_ftail reads the word after this kernel)
+			if (dead3) atomicAnd(&t.flags(s4), ~(1u << (16 + ci3)));
+			else if (cr3) atomicOr(&t.flags(s4), 1u << (16 + ci3));
+			TileRec r;
+			r.occ = m3;
+			r.pre_occ = pm3;
+			r.slot = s3;
+			r.bits = (fl3n & 3u) | ((pfl3 & 3u) << 2) | (eval3 ? 16u : 0u) | (reach3 ? 32u : 0u);
+			recs[tile] = r;
+		}
+	}
+	// ---- bookkeeping: blocks created, hit voxels of the scan (stage-level output) ----
+	for (int o = 32; o > 0; o >>= 1) n_created += __shfl_xor(n_created, o);
+	if (0 == lane && n_created) {
+		atomicAdd(&t.root->used, n_created);
+		atomicAdd(&ctl->ph[0].n_new, n_created);
+	}
+	if (hit_codes) {
+		u32 incl = nhit;
+		for (int o = 1; o < 64; o <<= 1) {
+			const u32 x = __shfl_up(incl, o);
+			if ((int)lane >= o) incl += x;
+		}
+		const u32 total = __shfl(incl, 63);
+		u32 base = 0;
+		if (63u == lane && total) base = atomicAdd(&ctl->n_codes, total);
+		base = __shfl(base, 63) + incl - nhit;
+		const u64 code0 = (lk1 ^ (1ULL << (3 * (g.L - 1)))) << 3;
+		for (int c = 0; c < 8; ++c)
+			if ((hmask >> c) & 1u) {
+				if (base < hit_cap) hit_codes[base] = code0 | (u64)c;
+				++base;
+			}
+	}
+	const u32 touched = (u32)__popcll(__ballot(active));
+	if (0 == lane) atomicAdd(&ctl->n_entries[0], touched);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tree update, part 3 (k_ftail): updateParents (occupancy_map_base.h:1126-1133) above the tiles. One workgroup loads the
+// blocks k_fupper listed into LDS, takes the tiles' hand-over records (summary, "last update reached and changed it",
+// summary before that update), and walks level 4 .. root with one barrier pair per level: a block is re-evaluated only
+// if a child asked for it, collapses only if the last update beneath it (the highest touched child, see k_tile)
+// reached it, and hands its own record to its parent. Then every block is written back once, the root summary goes to
+// MapRoot, and the scan's bounding boxes (per-workgroup partials of k_fhits) are folded for the host.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_ftail(Table t, MapGeom g, FastGeo fg, u32* __restrict__ tile_bits,
+                                                const u32* __restrict__ tile_node, const UpperNode* __restrict__ nodes,
+                                                const UpperHdr* __restrict__ hdr, const TileRec* __restrict__ recs,
+                                                const BoxPartial* __restrict__ part, u32 nparts, ScanCtl* ctl)
+{
+	__shared__ u64 nk[UFO_UPPER_MAX];
+	__shared__ u32 nslot[UFO_UPPER_MAX], npar[UFO_UPPER_MAX], nflags[UFO_UPPER_MAX], top[UFO_UPPER_MAX], lu_bits[UFO_UPPER_MAX];
+	__shared__ float nocc[UFO_UPPER_MAX][8], lu_occ[UFO_UPPER_MAX];
+	__shared__ uint8_t dirty[UFO_UPPER_MAX];
+	__shared__ u32 start[25];
+	__shared__ double rd[16][6];
+	__shared__ i32 ri[16][6];
+	if (0 == threadIdx.x) ctl->used_now = t.root->used;  // blocks are only created by k_fupper / k_tile, long done
+	// ---- the scan's boxes: cell box of its rays (predicts the next grid) and the change AABB (OMB:305-308, 388-398) ----
+	{
+		double amn[3] = {1e300, 1e300, 1e300}, amx[3] = {-1e300, -1e300, -1e300};
+		i32 mmn[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, mmx[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+		for (u32 i = threadIdx.x; i < nparts; i += blockDim.x) {
+			const BoxPartial& p = part[i];
+			for (int a = 0; a < 3; ++a) {
+				amn[a] = fmin(amn[a], p.aabb_min[a]);
+				amx[a] = fmax(amx[a], p.aabb_max[a]);
+				mmn[a] = min(mmn[a], p.mb_min[a]);
+				mmx[a] = max(mmx[a], p.mb_max[a]);
+			}
+		}
+		const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+		for (int a = 0; a < 3; ++a) {
+			const double l = waveMinD(amn[a]), h = waveMaxD(amx[a]);
+			const i32 il = waveMinI(mmn[a]), ih = waveMaxI(mmx[a]);
+			if (0 == lane) {
+				rd[wave][a] = l;
+				rd[wave][3 + a] = h;
+				ri[wave][a] = il;
+				ri[wave][3 + a] = ih;
+			}
+		}
+		__syncthreads();
+		if (0 == threadIdx.x) {
+			const u32 nw = (blockDim.x + 63u) >> 6;
+			for (int a = 0; a < 3; ++a) {
+				double l = rd[0][a], h = rd[0][3 + a];
+				i32 il = ri[0][a], ih = ri[0][3 + a];
+				for (u32 w = 1; w < nw; ++w) {
+					l = fmin(l, rd[w][a]);
+					h = fmax(h, rd[w][3 + a]);
+					il = min(il, ri[w][a]);
+					ih = max(ih, ri[w][3 + a]);
+				}
+				ctl->mb_min[a] = il;
+				ctl->mb_max[a] = ih;
+				ctl->hb_min[a] = il;
+				ctl->hb_max[a] = ih;
+				if (l < 1e299) {
+					ctl->aabb_min[a] = encD(l);
+					ctl->aabb_max[a] = encD(h);
+				}
+			}
+		}
+	}
+	if (ctl->err) return;  // the scan stood back (ERR_SPEC / ERR_PREV / a bound): the map is as it was
+	const u32 U = min(hdr->count, UFO_UPPER_MAX);
+	const u32 L = g.L;
+	if (threadIdx.x < 25u) start[threadIdx.x] = threadIdx.x < 24u ? hdr->start[threadIdx.x] : U;
+	for (u32 i = threadIdx.x; i < U; i += blockDim.x) {
+		const UpperNode un = nodes[i];
+		nk[i] = un.lk;
+		nslot[i] = un.slot;
+		npar[i] = un.parent;
+		const float4* po = reinterpret_cast<const float4*>(t.occ(un.slot));
+		const float4 a = po[0], b = po[1];
+		nocc[i][0] = a.x; nocc[i][1] = a.y; nocc[i][2] = a.z; nocc[i][3] = a.w;
+		nocc[i][4] = b.x; nocc[i][5] = b.y; nocc[i][6] = b.z; nocc[i][7] = b.w;
+		nflags[i] = t.flags(un.slot) & ~F_DIRTY;
+		top[i] = 0;
+		lu_bits[i] = 0;
+		lu_occ[i] = 0.f;
+		dirty[i] = 0;
+	}
+	__syncthreads();
+	// ---- the tiles hand their level-3 summaries to their level-4 blocks (writeToParent) ----
+	for (u32 tile = threadIdx.x; tile < fg.ntiles; tile += blockDim.x) {
+		if (!((tile_bits[tile >> 5] >> (tile & 31u)) & 1u)) continue;
+		const u32 n4 = tile_node[tile];
+		u64 lk3;
+		if (n4 == NONE || !tileKey(g, fg, tile, &lk3, nullptr)) continue;
+		const u32 ci = (u32)(lk3 & 7);
+		const TileRec r = recs[tile];
+		atomicMax(&top[n4], ci + 1u);
+		if (r.bits & 16u) {
+			const u32 f = nflags[n4];
+			const u32 old_fl = ((f >> ci) & 1u) | (((f >> (8 + ci)) & 1u) << 1), fl = r.bits & 3u;
+			const bool changed = nocc[n4][ci] != r.occ || old_fl != fl;
+			nocc[n4][ci] = r.occ;
+			if (old_fl != fl) {
+				const u32 setm = ((fl & 1u) << ci) | (((fl >> 1) & 1u) << (8 + ci));
+				const u32 clrm = ((1u << ci) | (1u << (8 + ci))) & ~setm;
+				if (setm) atomicOr(&nflags[n4], setm);
+				if (clrm) atomicAnd(&nflags[n4], ~clrm);
+			}
+			if (changed || (r.bits & 32u)) dirty[n4] = 1;
+		}
+	}
+	__syncthreads();
+	for (u32 tile = threadIdx.x; tile < fg.ntiles; tile += blockDim.x) {
+		if (!((tile_bits[tile >> 5] >> (tile & 31u)) & 1u)) continue;
+		const u32 n4 = tile_node[tile];
+		u64 lk3;
+		if (n4 == NONE || !tileKey(g, fg, tile, &lk3, nullptr)) continue;
+		const u32 ci = (u32)(lk3 & 7);
+		if (ci + 1u != top[n4]) continue;  // the highest touched child carries the last update beneath the block
+		const TileRec r = recs[tile];
+		lu_bits[n4] = ((r.bits & 16u) && (r.bits & 32u) ? 4u : 0u) | ((r.bits >> 2) & 3u);
+		lu_occ[n4] = r.pre_occ;
+	}
+	__syncthreads();
+	// ---- level by level to the root ----
+	for (u32 l = 4; l <= L; ++l) {
+		const u32 lo = start[l], hi = min(start[l + 1], U);
+		bool my_reach = false, evaluated = false;
+		float my_pre = 0.f;
+		u32 my_prefl = 0, p = NONE, ci = 0;
+		const u32 i = lo + threadIdx.x;
+		const bool have = i < hi;  // (a level holds far fewer blocks than the workgroup has threads; checked by the host's bound)
+		if (have) {
+			const u64 lk = nk[i];
+			p = npar[i];
+			ci = (u32)(lk & 7);
+			if (dirty[i]) {
+				evaluated = true;
+				const u32 f = nflags[i];
+				float m = nocc[i][0];
+				bool eq = true;
+				for (int c = 1; c < 8; ++c) {
+					m = fmaxf(m, nocc[i][c]);
+					eq = eq && (nocc[i][c] == nocc[i][0]);
+				}
+				const u32 fl = ((f & F_CFREE) ? 1u : 0u) | ((f & F_CUNK) ? 2u : 0u);
+				const u32 tc = top[i] - 1u;  // (top[i] >= 1: a dirty block has a touched child)
+				const bool reached = 0 != (lu_bits[i] & 4u);
+				float pm = m;
+				u32 pfl = fl;
+				if (reached) {
+					// summary with the top child as it was before its last update
+					pm = (0 == tc) ? lu_occ[i] : nocc[i][0];
+					for (u32 c = 1; c < 8; ++c) pm = fmaxf(pm, c == tc ? lu_occ[i] : nocc[i][c]);
+					const u32 fsub = (f & ~((1u << tc) | (1u << (8 + tc)))) | ((lu_bits[i] & 1u) << tc) | (((lu_bits[i] >> 1) & 1u) << (8 + tc));
+					pfl = ((fsub & F_CFREE) ? 1u : 0u) | ((fsub & F_CUNK) ? 2u : 0u);
+				}
+				const bool dead = reached && eq && 0 == (f & F_INNER);
+				if (dead) {
+					atomicOr(&nflags[i], F_DEAD);
+					if (1 != lk) atomicAnd(&nflags[p], ~(1u << (16 + ci)));
+				}
+				if (1 == lk) {
+					t.root->occ = m;
+					t.root->flags = fl;
+				} else {
+					const u32 fp = nflags[p];
+					const u32 old_fl = ((fp >> ci) & 1u) | (((fp >> (8 + ci)) & 1u) << 1);
+					const bool changed = nocc[p][ci] != m || old_fl != fl;
+					nocc[p][ci] = m;
+					if (old_fl != fl) {
+						const u32 setm = ((fl & 1u) << ci) | (((fl >> 1) & 1u) << (8 + ci));
+						const u32 clrm = ((1u << ci) | (1u << (8 + ci))) & ~setm;
+						if (setm) atomicOr(&nflags[p], setm);
+						if (clrm) atomicAnd(&nflags[p], ~clrm);
+					}
+					my_reach = reached && !(pm == m && pfl == fl);
+					my_pre = pm;
+					my_prefl = pfl;
+					if (changed || my_reach) dirty[p] = 1;
+				}
+			}
+			if (p != NONE) atomicMax(&top[p], ci + 1u);  // the time of the last update travels up whether or not the block was evaluated
+		}
+		__syncthreads();
+		if (have && p != NONE && ci + 1u == top[p]) {
+			lu_bits[p] = (evaluated && my_reach ? 4u : 0u) | (my_prefl & 3u);
+			lu_occ[p] = my_pre;
+		}
+		__syncthreads();
+	}
+	// ---- every block back to the table, once ----
+	for (u32 i = threadIdx.x; i < U; i += blockDim.x) {
+		const u32 s = nslot[i];
+		float4* po = reinterpret_cast<float4*>(t.occ(s));
+		po[0] = make_float4(nocc[i][0], nocc[i][1], nocc[i][2], nocc[i][3]);
+		po[1] = make_float4(nocc[i][4], nocc[i][5], nocc[i][6], nocc[i][7]);
+		t.flags(s) = nflags[i];
+	}
+	// this kernel is the tile bitmap's last reader: leave it empty for the set's next scan
+	__syncthreads();
+	for (u32 j = threadIdx.x; j < (fg.ntiles + 31u) / 32u; j += blockDim.x) tile_bits[j] = 0;
+}
+}  // namespace ufo

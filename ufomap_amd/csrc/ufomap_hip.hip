@@ -24,7 +24,7 @@
 #include <vector>
 
 #include "../../include/ufomap_hip.h"
-#include "map_kernels.h"
+#include "fast_kernels.h"
 
 using namespace ufo;
 
@@ -125,6 +125,12 @@ struct ScanArgs {
 
 struct HandOver {
 	DevBuf b_ctl, b_entries, b_hh_keys, b_in_xyz, b_in_rgb;  // b_hh_keys: hit hash, keys followed by point indices
+	// what the tree update of a fast-path scan (fast_kernels.h) reads after the scan half has moved on to the next scan
+	DevBuf b_gridM, b_part1, b_hit_code, b_first, b_tilebits;
+	uint64_t seq = 0;         // running number of the integration that uses this set
+	bool first_dirty = true;  // b_first / b_tilebits are left clean by k_tile / k_ftail unless the scan stood back
+	bool fast = false;        // the integration that uses this set runs on the fast path
+	FastGeo fgeo{};
 	ScanCtl* h_ctl = nullptr;  // pinned
 	void* h_stage = nullptr;   // pinned staging of a pageable host cloud (ufomap_map_insert): filled by the host, drained by
 	size_t h_stage_cap = 0;    // an asynchronous H2D copy on the scan stream; free again once the set's integration is joined
@@ -164,6 +170,13 @@ struct ufomap_map {
 	// per-scan buffers
 	DevBuf b_ctl, b_pt_end, b_pt_flag, b_pt_slot, b_ray_end, b_hit_code, b_hit_pt, b_hh_keys;
 	DevBuf b_part0, b_part1, b_slabs, b_hb_keys, b_hb_mask, b_hb_time;
+	DevBuf b_first, b_tilebits;                      // fast path, per hand-over set (HandOver)
+	DevBuf b_upper, b_uhdr, b_tilenode, b_tilerec;   // fast path, map stream only
+	bool first_dirty = true, fast = false;
+	uint64_t seq = 0, latest_seq = 0;  // seq: of the integration that uses the current set; latest_seq: of the newest one enqueued
+	FastGeo fgeo{};
+	int opt_fast = 1;  // 0 = never take the fast path (fast_kernels.h)
+	uint64_t n_fast = 0;
 	u32 hb_cap_mask = 0;
 	Ingest ing{};      // ufomap_map_insert_pointcloud2: raw PointCloud2 records, converted inside k_classify
 	u32 hb_clean = 0;  // slots [0, hb_clean) of the hit-block hash are known to be empty
@@ -387,6 +400,15 @@ void swapWith(ufomap_map* m, HandOver& o)
 	std::swap(m->b_hh_keys, o.b_hh_keys);
 	std::swap(m->b_in_xyz, o.b_in_xyz);
 	std::swap(m->b_in_rgb, o.b_in_rgb);
+	std::swap(m->b_gridM, o.b_gridM);
+	std::swap(m->b_part1, o.b_part1);
+	std::swap(m->b_hit_code, o.b_hit_code);
+	std::swap(m->b_first, o.b_first);
+	std::swap(m->b_tilebits, o.b_tilebits);
+	std::swap(m->first_dirty, o.first_dirty);
+	std::swap(m->seq, o.seq);
+	std::swap(m->fast, o.fast);
+	std::swap(m->fgeo, o.fgeo);
 	std::swap(m->h_ctl, o.h_ctl);
 	std::swap(m->h_stage, o.h_stage);
 	std::swap(m->h_stage_cap, o.h_stage_cap);
@@ -758,29 +780,201 @@ int mapPhase(ufomap_map* m, unsigned depth, const uint8_t* d_rgb, u64 capH, u64 
 
 int redoScan(ufomap_map* m);
 
+// ---- the fast path (fast_kernels.h): a depth-0 scan on the predicted ray grid, five + one launches ------------------
+FastGeo makeFastGeo(const Grid& gr)
+{
+	FastGeo fg{};
+	fg.gr = gr;
+	fg.rowBits = gridRowBits(gr);
+	fg.planeBits = fg.rowBits * 2u * (u32)gr.nb[1];
+	fg.ncells = fg.planeBits * 2u * (u32)gr.nb[2];
+	u64 nt = 1;
+	for (int a = 0; a < 3; ++a) {
+		fg.tbase[a] = gr.base[a] >> 3;  // arithmetic shift: floor
+		const i32 last = (gr.base[a] + 2 * gr.nb[a] - 1) >> 3;
+		fg.nt[a] = (u32)(last - fg.tbase[a] + 1);
+		nt *= fg.nt[a];
+	}
+	fg.ntiles = (u32)std::min<u64>(nt, 0xFFFFFFFFull);
+	return fg;
+}
+
+// upper bound of the node blocks one scan inside grid gr can create: every level-1 block of the grid and all ancestors
+u64 fastBound(const ufomap_map* m, const Grid& gr)
+{
+	return blockBound(m, (u64)gr.nb[0] * (u64)gr.nb[1] * (u64)gr.nb[2], gr.nb, 1);
+}
+
+bool fastEligible(const ufomap_map* m, const Grid& gr, unsigned depth, int simple, const uint8_t* d_rgb, size_t n)
+{
+	if (!m->opt_fast || 0 != depth || simple || m->g.color || d_rgb || m->chg_enabled || m->g.L < 5 || 0 == n || n > (1u << 29)) return false;
+	if (1 != gr.layout) return false;
+	const FastGeo fg = makeFastGeo(gr);
+	if (fg.ntiles > UFO_FAST_MAX_TILES) return false;
+	// node blocks above the tiles that the scan can touch: k_fupper / k_ftail hold them in LDS
+	u64 upper = 0;
+	for (u32 l = 4; l <= m->g.L; ++l) upper += std::min<u64>(levelBound(gr.nb, l - 1), 1ull << 20);
+	return upper <= UFO_UPPER_MAX;
+}
+
+// scan half on the scan stream: first-point array, rays, merged bit grid + tile bitmap
+int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, size_t n, double max_range, int discrete)
+{
+	HIP_TRY(hipSetDevice(m->device));
+	for (int k = 0; k < 8; ++k) m->counts[k] = 0;
+	m->counts[0] = n;
+	m->last_depth = 0;
+	m->haveH = m->haveM = true;
+	m->gridM = m->spec_grid;
+	m->gridH = m->spec_grid;
+	m->scan_id += 1;
+	const FastGeo fg = makeFastGeo(m->spec_grid);
+	m->fgeo = fg;
+	m->fast = true;
+	const u32 N = (u32)n;
+	const D3 sensor{origin[0], origin[1], origin[2]};
+	const size_t cf = m->b_first.cap, ct = m->b_tilebits.cap;  // (a re-allocation may well return the old address: compare sizes)
+	HIP_TRY(m->b_first.reserve((size_t)fg.ncells * 4));
+	HIP_TRY(m->b_tilebits.reserve(UFO_FAST_MAX_TILES / 8));
+	if (cf != m->b_first.cap || ct != m->b_tilebits.cap) m->first_dirty = true;
+	if (m->first_dirty || 2 == m->opt_fast) {  // (option fast = 2: never trust the self-cleaning, a debugging aid)
+		HIP_TRY(hipMemsetAsync(m->b_first.p, 0xFF, m->b_first.cap, m->cs));
+		HIP_TRY(hipMemsetAsync(m->b_tilebits.p, 0, m->b_tilebits.cap, m->cs));
+		m->first_dirty = false;
+	}
+	HIP_TRY(m->b_gridM.reserve(fg.gr.bytes));
+	HIP_TRY(m->b_hit_code.reserve(n * 8));
+	ScanCtl init;
+	memset(&init, 0, sizeof(init));
+	for (int a = 0; a < 3; ++a) {
+		init.mb_min[a] = init.hb_min[a] = INT32_MAX;
+		init.mb_max[a] = init.hb_max[a] = INT32_MIN;
+		init.aabb_min[a] = ~0ull;
+		init.aabb_max[a] = 0ull;
+	}
+	*m->h_ctl = init;
+	ScanCtl* ctl = m->b_ctl.as<ScanCtl>();
+	HIP_TRY(hipMemcpyAsync(ctl, m->h_ctl, sizeof(ScanCtl), hipMemcpyHostToDevice, m->cs));
+	const dim3 gp((N + 255) / 256);
+	HIP_TRY(m->b_part1.reserve((size_t)gp.x * sizeof(BoxPartial)));
+	{
+		ProfScope ps(m, "k_fhits");
+		if (discrete)
+			hipLaunchKernelGGL(k_fhits<true>, gp, dim3(256), 0, m->cs, m->g, fg, sensor, d_xyz, N, max_range, 0u, m->b_first.as<u32>(),
+			                   m->b_part1.as<BoxPartial>(), ctl, m->ing);
+		else
+			hipLaunchKernelGGL(k_fhits<false>, gp, dim3(256), 0, m->cs, m->g, fg, sensor, d_xyz, N, max_range, 0u, m->b_first.as<u32>(),
+			                   m->b_part1.as<BoxPartial>(), ctl, m->ing);
+	}
+	u32 nwg = m->opt_cast_wgs > 0 ? (u32)m->opt_cast_wgs : 256u;
+	nwg = std::max<u32>(1u, std::min<u32>(nwg, (N + 63u) / 64u));
+	const u32 cap_wg = (N + nwg - 1) / nwg;
+	HIP_TRY(m->b_ray_end.reserve((size_t)cap_wg * nwg * sizeof(D3)));
+	HIP_TRY(m->b_slabs.reserve((size_t)nwg * fg.gr.bytes + (size_t)nwg * 8));
+	unsigned long long* sp = reinterpret_cast<unsigned long long*>(m->b_slabs.as<char>() + (size_t)nwg * fg.gr.bytes);
+	{
+		ProfScope ps(m, "k_fcast");
+		const size_t lds = (size_t)fg.gr.bytes + UFO_CAST_LDS_EXTRA;
+		if (discrete)
+			hipLaunchKernelGGL(k_fcast<true>, dim3(nwg), dim3(512), lds, m->cs, m->g, fg, sensor, d_xyz, N, max_range, 0u, m->b_first.as<u32>(),
+			                   m->b_ray_end.as<D3>(), cap_wg, m->b_slabs.as<u32>(), (u32)std::max(8, m->opt_cast_k), ctl, ctl, sp, m->ing);
+		else
+			hipLaunchKernelGGL(k_fcast<false>, dim3(nwg), dim3(512), lds, m->cs, m->g, fg, sensor, d_xyz, N, max_range, 0u, m->b_first.as<u32>(),
+			                   m->b_ray_end.as<D3>(), cap_wg, m->b_slabs.as<u32>(), (u32)std::max(8, m->opt_cast_k), ctl, ctl, sp, m->ing);
+	}
+	{
+		ProfScope ps(m, "k_fmerge");
+		const u32 n4 = (u32)(fg.gr.bytes >> 4);
+		hipLaunchKernelGGL(k_fmerge, dim3(std::min<u32>((n4 + 63) / 64, 1024)), dim3(1024), 0, m->cs, fg, m->b_slabs.as<uint4>(), nwg, n4,
+		                   m->b_gridM.as<uint4>(), sp, m->b_tilebits.as<u32>(), ctl);
+	}
+	HIP_TRY(hipGetLastError());
+	++m->n_fast;
+	return UFOMAP_OK;
+}
+
+// map half on the map stream. prev / extra_used as mapPhase: returns 1 (nothing enqueued) if the table might have to
+// grow while another update is in flight.
+int fastMapPhase(ufomap_map* m, const ScanCtl* prev, u64 extra_used, u32 headroom_scans)
+{
+	const FastGeo& fg = m->fgeo;
+	m->scan_new_bound = fastBound(m, fg.gr);
+	{
+		const u64 cap = (u64)m->t.mask + 1;
+		const u64 extra = extra_used + (u64)headroom_scans * m->scan_new_bound;
+		if ((m->used_est + extra + m->scan_new_bound) * 5 > cap * 3) {
+			if (prev) return 1;
+			const u64 want = (m->used_est + extra + m->scan_new_bound) * 2;
+			if (want > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
+			int rc = growTable(m, nextPow2(want));
+			if (rc) return rc;
+		}
+	}
+	m->scan_id += 1;
+	HIP_TRY(m->b_upper.reserve((size_t)UFO_UPPER_MAX * sizeof(UpperNode)));
+	HIP_TRY(m->b_uhdr.reserve(sizeof(UpperHdr)));
+	HIP_TRY(m->b_tilenode.reserve((size_t)UFO_FAST_MAX_TILES * 4));
+	HIP_TRY(m->b_tilerec.reserve((size_t)UFO_FAST_MAX_TILES * sizeof(TileRec)));
+	ScanCtl* ctl = m->b_ctl.as<ScanCtl>();
+	const float miss = (float)m->g.miss_log;  // insert depth 0 (OMB:311)
+	{
+		ProfScope ps(m, "k_fupper");
+		hipLaunchKernelGGL(k_fupper, dim3(1), dim3(1024), 0, m->cs, m->t, m->g, fg, m->b_tilebits.as<u32>(), m->scan_id, m->b_upper.as<UpperNode>(),
+		                   m->b_uhdr.as<UpperHdr>(), m->b_tilenode.as<u32>(), ctl, prev);
+	}
+	{
+		ProfScope ps(m, "k_tile");
+		hipLaunchKernelGGL(k_tile, dim3((fg.ntiles + 3) / 4), dim3(256), 0, m->cs, m->t, m->g, fg, m->b_gridM.as<u32>(), m->b_first.as<u32>(),
+		                   m->b_tilebits.as<u32>(), m->b_tilenode.as<u32>(), m->b_upper.as<UpperNode>(), m->b_tilerec.as<TileRec>(), m->g.hit, miss,
+		                   m->scan_id, m->b_hit_code.as<u64>(), (u32)std::min<u64>(m->b_hit_code.cap / 8, 0xFFFFFFFFull), ctl);
+	}
+	{
+		ProfScope ps(m, "k_ftail");
+		const u32 nparts = (u32)((m->counts[0] + 255) / 256);
+		hipLaunchKernelGGL(k_ftail, dim3(1), dim3(1024), 0, m->cs, m->t, m->g, fg, m->b_tilebits.as<u32>(), m->b_tilenode.as<u32>(),
+		                   m->b_upper.as<UpperNode>(), m->b_uhdr.as<UpperHdr>(), m->b_tilerec.as<TileRec>(), m->b_part1.as<BoxPartial>(), nparts,
+		                   ctl);
+	}
+	HIP_TRY(hipGetLastError());
+	return UFOMAP_OK;
+}
+
+
 // Predict the ray grid of the next depth-0 scan from the box of the one just finished: the same box plus a margin
 // of up to two node blocks for sensor motion, as long as k_cast still fits its bit grid and segment queue in LDS.
 void predictGrid(ufomap_map* m)
 {
+	const bool had = m->spec_valid;
+	const Grid prev = m->spec_grid;
 	m->spec_valid = false;
 	const ScanArgs& a = m->args;
 	if (!m->opt_spec || !m->opt_merge || !m->opt_cast || !m->opt_bits || !m->opt_dda_seg || m->opt_dda_mode > 0) return;
 	if (0 != a.depth || a.simple || 0 == a.n || 0 == m->h_ctl->n_rays) return;
-	for (int margin = 2; margin >= 0 && !m->spec_valid; --margin) {
-		i32 mn[3], mx[3];
-		for (int k = 0; k < 3; ++k) {
-			mn[k] = m->h_ctl->mb_min[k] - 2 * margin;
-			mx[k] = m->h_ctl->mb_max[k] + 2 * margin;
+	// First choice: the union of this scan's box with the grid predicted so far -- a sensor that moves about a room keeps
+	// producing boxes inside one hull, and a prediction that covers the hull never misses again. Second choice: this
+	// scan's box alone, with up to two blocks of margin for sensor motion.
+	for (int pass = (had && 0 == prev.depth) ? 0 : 1; pass < 2 && !m->spec_valid; ++pass) {
+		for (int margin = 2; margin >= 0 && !m->spec_valid; --margin) {
+			i32 mn[3], mx[3];
+			for (int k = 0; k < 3; ++k) {
+				mn[k] = m->h_ctl->mb_min[k] - 2 * margin;
+				mx[k] = m->h_ctl->mb_max[k] + 2 * margin;
+				if (0 == pass) {
+					// interior of the previous grid (makeGrid pads by one block on either side)
+					mn[k] = std::min(mn[k], prev.base[k] + 2);
+					mx[k] = std::max(mx[k], prev.base[k] + 2 * prev.nb[k] - 3);
+				}
+			}
+			Grid gr;
+			if (makeGrid(mn, mx, 0, &gr)) continue;
+			const bool packed = 2 * gr.nb[0] < 1023 && 2 * gr.nb[1] < 1023 && 2 * gr.nb[2] < 1023;
+			const u64 bytes1 = (u64)(gridRowBits(gr) >> 3) * (2ull * (u64)gr.nb[1]) * (2ull * (u64)gr.nb[2]);
+			if (!packed || ((bytes1 + 15) & ~15ull) + UFO_CAST_LDS_EXTRA > (160u << 10) - 512u) continue;
+			gr.layout = 1;
+			gr.bytes = (bytes1 + 15) & ~15ull;
+			m->spec_grid = gr;
+			m->spec_valid = true;
 		}
-		Grid gr;
-		if (makeGrid(mn, mx, 0, &gr)) continue;
-		const bool packed = 2 * gr.nb[0] < 1023 && 2 * gr.nb[1] < 1023 && 2 * gr.nb[2] < 1023;
-		const u64 bytes1 = (u64)(gridRowBits(gr) >> 3) * (2ull * (u64)gr.nb[1]) * (2ull * (u64)gr.nb[2]);
-		if (!packed || ((bytes1 + 15) & ~15ull) + UFO_CAST_LDS_EXTRA > (160u << 10) - 512u) continue;
-		gr.layout = 1;
-		gr.bytes = (bytes1 + 15) & ~15ull;
-		m->spec_grid = gr;
-		m->spec_valid = true;
 	}
 }
 
@@ -793,6 +987,8 @@ int finishPending(ufomap_map* m)
 	if (rc) return rc;
 	drainEvents(m);
 	if (m->h_ctl->err) m->prev_flagged = true;  // (sticky: doInsert resets it before a join)
+	if (m->h_ctl->err && m->fast) m->first_dirty = true;  // the tree update stood back: it did not clean the set's scratch arrays
+	m->fast = false;
 	// Flagged and repeatable: a speculative scan that did not fit its predicted grid (or exceeded a bound derived from
 	// it), or an update that stood back because the control block it looked at for its predecessor was flagged
 	// (ERR_PREV). Nothing of it has reached the map; repeat it now, i.e. before any later update.
@@ -948,11 +1144,11 @@ int scanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, const 
 		if (n > (1u << 29)) return fail(UFOMAP_ERR_INVALID, "more than 2^29 points in one scan");
 		const u32 hbcap = nextPow2(std::max<u64>(256, (u64)n_hits * 2));
 		m->hb_cap_mask = hbcap - 1;
-		const void *p0 = m->b_hb_keys.p, *p1 = m->b_hb_mask.p, *p2 = m->b_hb_time.p;
+		const size_t p0 = m->b_hb_keys.cap, p1 = m->b_hb_mask.cap, p2 = m->b_hb_time.cap;  // (a re-allocation may return the old address: compare sizes)
 		HIP_TRY(m->b_hb_keys.reserve((size_t)hbcap * 8));
 		HIP_TRY(m->b_hb_mask.reserve((size_t)hbcap * 4));
 		HIP_TRY(m->b_hb_time.reserve((size_t)hbcap * 4));
-		if (p0 != m->b_hb_keys.p || p1 != m->b_hb_mask.p || p2 != m->b_hb_time.p) m->hb_clean = 0;
+		if (p0 != m->b_hb_keys.cap || p1 != m->b_hb_mask.cap || p2 != m->b_hb_time.cap) m->hb_clean = 0;
 		// k_extract_hits leaves the slots it read empty: only slots never used before need the memsets
 		if (hbcap > m->hb_clean) {
 			const size_t from = m->hb_clean, cnt = hbcap - m->hb_clean;
@@ -1125,6 +1321,7 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 	// the reference overlaps its head loop with the previous integration the same way (the join sits
 	// after the head loop, OMB:315). Hand-over buffers are double-buffered and swapped here.
 	if (!swapped) (void)rotateSets(m);
+	m->seq = ++m->latest_seq;
 	if (m->chg_enabled) async = 0;  // the change log is sized between updates: one update at a time
 	m->cs = m->sstream;
 	// insert depth 0: hits and misses of the scan as ONE pass over the tree (map_kernels.h, k_apply_leaf mode 2)
@@ -1147,10 +1344,20 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 		a.ing = m->ing;
 	}
 	if (spec) ++m->n_spec;
+	// the fast path (fast_kernels.h): the whole scan on the predicted grid in five launches, the tree update tiled
+	const bool fast = spec && fastEligible(m, m->spec_grid, depth, simple, d_rgb, n) && nullptr == m->ing.rgb_out;
 	u32 n_hits = 0, n_rays = 0;
-	int rc = scanPhase(m, origin, d_xyz, d_rgb, n, max_range, depth, discrete, simple, early_stopping, &n_hits, &n_rays, spec);
 	u64 capH = 0, capM = 0;
-	if (!rc && n) rc = extractPhase(m, n_hits, n_rays, &capH, &capM, merged);
+	int rc;
+	if (fast) {
+		rc = fastScanPhase(m, origin, d_xyz, n, max_range, discrete);
+	} else {
+		rc = scanPhase(m, origin, d_xyz, d_rgb, n, max_range, depth, discrete, simple, early_stopping, &n_hits, &n_rays, spec);
+		if (!rc && n) rc = extractPhase(m, n_hits, n_rays, &capH, &capM, merged);
+	}
+	auto mapHalf = [&](const ScanCtl* prev, u64 extra_used, u32 headroom) {
+		return fast ? fastMapPhase(m, prev, extra_used, headroom) : mapPhase(m, depth, d_rgb, capH, capM, merged, prev, extra_used, headroom);
+	};
 	if (!rc && n) rc = (hipEventRecord(m->scan_ev, m->sstream) == hipSuccess) ? UFOMAP_OK : fail(UFOMAP_ERR_DEVICE, "hipEventRecord");
 	// ---- early map half: enqueue THIS scan's tree update behind the previous one BEFORE that one has been joined,
 	// so that the updates run back to back on the map stream and the next call can start its scan half while two
@@ -1163,7 +1370,7 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 		HIP_TRY(hipStreamWaitEvent(m->stream, m->scan_ev, 0));
 		m->last_rgb = d_rgb;
 		const u64 in_flight = m->alt[1].bound + (m->alt[0].pending ? m->alt[0].bound : 0);
-		const int erc = mapPhase(m, depth, d_rgb, capH, capM, merged, m->alt[1].b_ctl.as<ScanCtl>(), in_flight);
+		const int erc = mapHalf(m->alt[1].b_ctl.as<ScanCtl>(), in_flight, 0u);
 		if (erc < 0) return erc;
 		early = 0 == erc;  // 1: the table might have to grow: join first (below)
 		if (early) HIP_TRY(hipEventRecord(m->done_ev, m->stream));
@@ -1187,7 +1394,7 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 			HIP_TRY(hipStreamSynchronize(m->stream));
 			hipLaunchKernelGGL(k_ctl_clear, dim3(1), dim3(1), 0, m->stream, m->b_ctl.as<ScanCtl>(), (u32)ERR_PREV);
 			m->cs = m->stream;
-			rc = mapPhase(m, depth, d_rgb, capH, capM, merged);
+			rc = mapHalf(nullptr, 0, 0u);
 			if (rc) return rc;
 			HIP_TRY(hipEventRecord(m->done_ev, m->stream));
 		}
@@ -1205,14 +1412,26 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 	m->cs = m->stream;
 	HIP_TRY(hipStreamWaitEvent(m->stream, m->scan_ev, 0));
 	m->last_rgb = d_rgb;
-	rc = mapPhase(m, depth, d_rgb, capH, capM, merged, nullptr, 0, (async && merged && m->opt_early) ? 2u : 0u);
+	rc = mapHalf(nullptr, 0, (async && merged && m->opt_early) ? 2u : 0u);
 	if (rc) return rc;
 	HIP_TRY(hipGetLastError());
 	m->pending = true;
 	m->bound = m->scan_new_bound;
 	if (!async) {
 		HIP_TRY(hipStreamSynchronize(m->stream));
+		const bool was_fast = fast;
 		rc = finishPending(m);
+		if (was_fast && 3 == m->opt_fast) {
+			// debugging aid: the scratch arrays must have been left clean
+			std::vector<u32> h(m->b_first.cap / 4), tb(m->b_tilebits.cap / 4);
+			(void)hipMemcpy(h.data(), m->b_first.p, h.size() * 4, hipMemcpyDeviceToHost);
+			(void)hipMemcpy(tb.data(), m->b_tilebits.p, tb.size() * 4, hipMemcpyDeviceToHost);
+			size_t bad = 0, badt = 0;
+			for (u32 v : h) bad += v != 0xFFFFFFFFu;
+			for (u32 v : tb) badt += v != 0u;
+			fprintf(stderr, "[fast dbg] first[]: %zu of %zu entries not clean, tile bitmap: %zu words not clean, dirty flag %d\n", bad, h.size(), badt,
+			        (int)m->first_dirty);
+		}
 		return rc ? rc : prc;
 	}
 	HIP_TRY(hipEventRecord(m->done_ev, m->stream));
@@ -1254,13 +1473,16 @@ int redoScan(ufomap_map* m)
 		m->pending = true;
 		rc = finishPending(m);
 	}
-	m->gridM = sgM;
-	m->gridH = sgH;
-	m->haveH = shH;
-	m->haveM = shM;
-	m->hb_cap_mask = shb;
-	m->last_depth = sld;
-	m->last_rgb = slr;
+	if (m->seq != m->latest_seq) {
+		// a later integration's scan half has already run: the map object describes ITS grids
+		m->gridM = sgM;
+		m->gridH = sgH;
+		m->haveH = shH;
+		m->haveM = shM;
+		m->hb_cap_mask = shb;
+		m->last_depth = sld;
+		m->last_rgb = slr;
+	}
 	m->ing = sing;
 	return rc;
 }
@@ -1373,7 +1595,7 @@ void ufomap_map_destroy(ufomap_map* m)
 	m->tb.release();
 	m->b_changes.release();
 	for (HandOver& a : m->alt) {
-		DevBuf* abufs[] = {&a.b_ctl, &a.b_entries, &a.b_hh_keys, &a.b_in_xyz, &a.b_in_rgb};
+		DevBuf* abufs[] = {&a.b_ctl, &a.b_entries, &a.b_hh_keys, &a.b_in_xyz, &a.b_in_rgb, &a.b_gridM, &a.b_part1, &a.b_hit_code, &a.b_first, &a.b_tilebits};
 		for (DevBuf* b : abufs) b->release();
 		if (a.h_ctl) (void)hipHostFree(a.h_ctl);
 		if (a.h_stage) (void)hipHostFree(a.h_stage);
@@ -1384,7 +1606,8 @@ void ufomap_map_destroy(ufomap_map* m)
 	DevBuf* bufs[] = {&m->b_root,
 	                  &m->b_ctl,     &m->b_pt_end,  &m->b_pt_flag,  &m->b_pt_slot, &m->b_ray_end, &m->b_hit_code, &m->b_hit_pt,
 	                  &m->b_hh_keys, &m->b_gridM,   &m->b_crec,    &m->b_dlist,   &m->b_rays,   &m->b_part0,   &m->b_part1,   &m->b_slabs,   &m->b_hb_keys, &m->b_hb_mask, &m->b_hb_time,   &m->b_entries, &m->b_ent_slot, &m->b_newlist,
-	                  &m->b_wl0,     &m->b_wl1,     &m->b_in_xyz,   &m->b_in_rgb,  &m->b_codes,   &m->b_dump};
+	                  &m->b_wl0,     &m->b_wl1,     &m->b_in_xyz,   &m->b_in_rgb,  &m->b_codes,   &m->b_dump,
+	                  &m->b_first,   &m->b_tilebits, &m->b_upper,   &m->b_uhdr,    &m->b_tilenode, &m->b_tilerec};
 	for (DevBuf* b : bufs) b->release();
 	for (PendingEvent& pe : m->pend_ev) {
 		(void)hipEventDestroy(pe.a);
@@ -2960,6 +3183,8 @@ int ufomap_map_set_option(ufomap_map* m, const char* key, long long value)
 	} else if (0 == strcmp(key, "spec")) {
 		m->opt_spec = value ? 1 : 0;
 		if (!m->opt_spec) m->spec_valid = false;
+	} else if (0 == strcmp(key, "fast")) {
+		m->opt_fast = (int)value;
 	} else if (0 == strcmp(key, "async_apply")) {
 		m->opt_async_apply = value ? 1 : 0;
 	} else if (0 == strcmp(key, "cast")) {
@@ -2991,6 +3216,7 @@ int ufomap_map_debug(ufomap_map* m, uint64_t* out, int n)
 	for (int i = 0; i < n && i < 64; ++i) out[i] = m->h_ctl->dbg[i];
 	if (n > 62) out[62] = m->n_spec;       // scans enqueued on a predicted grid
 	if (n > 63) out[63] = m->n_spec_redo;  // ... of which had to be repeated
+	if (n > 61) out[61] = m->n_fast;       // scans enqueued on the fast path (fast_kernels.h)
 	return rc;
 }
 
