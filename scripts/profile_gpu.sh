@@ -10,7 +10,7 @@ OUT="$ROOT/gpurun_out/prof_$TAG"
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-CMD="python $ROOT/bench.py --steps 50 --warmup 10 --no-cpu-baseline --profile-kernels 0"
+CMD="python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-self-check --only-headline --profile-kernels 0 --min-timed-s 0.05"
 timeout 600 rocprofv3 -f csv --kernel-trace --stats -d "$OUT/stats" -o stats -- $CMD > "$OUT/stats.log" 2>&1
 timeout 600 rocprofv3 -f csv --pmc FETCH_SIZE --kernel-trace -d "$OUT/pmc_fetch" -o fetch -- $CMD > "$OUT/pmc_fetch.log" 2>&1
 timeout 600 rocprofv3 -f csv --pmc WRITE_SIZE --kernel-trace -d "$OUT/pmc_write" -o write -- $CMD > "$OUT/pmc_write.log" 2>&1

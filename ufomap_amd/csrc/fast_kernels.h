@@ -242,8 +242,9 @@ __global__ __launch_bounds__(512) void k_fcast(MapGeom g, FastGeo fg, D3 sensor,
 	__syncthreads();
 	const u32 mine = min(sh[24], cap_wg);
 	if (0 == threadIdx.x) {
-		if (mine) atomicAdd(&ctl->n_rays, mine);
-		if (sh[25]) atomicAdd(&ctl->n_hits, sh[25]);
+		// per-workgroup partials, folded by k_fmerge (256 workgroups adding to one word serialise at ~12 ns each)
+		steps_part[gridDim.x + blockIdx.x] = mine;
+		steps_part[2u * gridDim.x + blockIdx.x] = sh[25];
 	}
 	const D3* my_rays = ray_scratch + (size_t)blockIdx.x * cap_wg;
 	for (u32 base = 0; base < mine; base += UFO_CAST_BATCH) {
@@ -462,10 +463,22 @@ __global__ __launch_bounds__(1024) void k_fmerge(FastGeo fg, const uint4* __rest
 	const u32 col = threadIdx.x & 63u, sl = threadIdx.x >> 6;
 	for (u32 j = threadIdx.x; j < UFO_FAST_MAX_TILES / 32; j += blockDim.x) tb[j] = 0;
 	if (steps_part && 0 == blockIdx.x && threadIdx.x < 64u) {
-		unsigned long long v = 0;
-		for (u32 s = threadIdx.x; s < n_slabs; s += 64u) v += steps_part[s];
-		for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-		if (0 == threadIdx.x && v) atomicAdd(&ctl->n_steps, v);
+		unsigned long long v = 0, r = 0, h = 0;
+		for (u32 s = threadIdx.x; s < n_slabs; s += 64u) {
+			v += steps_part[s];
+			r += steps_part[n_slabs + s];
+			h += steps_part[2u * n_slabs + s];
+		}
+		for (int o = 32; o > 0; o >>= 1) {
+			v += __shfl_xor(v, o);
+			r += __shfl_xor(r, o);
+			h += __shfl_xor(h, o);
+		}
+		if (0 == threadIdx.x) {
+			if (v) atomicAdd(&ctl->n_steps, v);
+			ctl->n_rays = (u32)r;
+			ctl->n_hits = (u32)h;
+		}
 	}
 	__syncthreads();
 	const u32 rowW = fg.rowBits >> 5, ny = 2u * (u32)fg.gr.nb[1];
@@ -558,9 +571,9 @@ __device__ inline bool tileKey(const MapGeom& g, const FastGeo& fg, u32 tile, u6
 	return true;
 }
 
-__global__ __launch_bounds__(1024) void k_fupper(Table t, MapGeom g, FastGeo fg, const u32* __restrict__ tile_bits, u32 scan_id,
-                                                 UpperNode* __restrict__ nodes, UpperHdr* __restrict__ hdr, u32* __restrict__ tile_node,
-                                                 ScanCtl* ctl, const ScanCtl* prev)
+__global__ __launch_bounds__(512) void k_fupper(Table t, MapGeom g, FastGeo fg, const u32* __restrict__ tile_bits, u32 scan_id,
+                                                UpperNode* __restrict__ nodes, UpperHdr* __restrict__ hdr, u32* __restrict__ tile_node,
+                                                u32* __restrict__ tile_s4, ScanCtl* ctl, const ScanCtl* prev)
 {
 	__shared__ u64 hk[UFO_UPPER_HASH];
 	__shared__ u32 hv[UFO_UPPER_HASH];
@@ -568,24 +581,25 @@ __global__ __launch_bounds__(1024) void k_fupper(Table t, MapGeom g, FastGeo fg,
 	__shared__ u32 nslot[UFO_UPPER_MAX], npar[UFO_UPPER_MAX], nflags[UFO_UPPER_MAX];
 	__shared__ float nocc[UFO_UPPER_MAX][8];
 	__shared__ uint8_t ncreated[UFO_UPPER_MAX];
-	__shared__ u32 count, start[25], overflow, created_total;
+	__shared__ u32 count, overflow, created_total;
 	if (prev && prev->err) {
 		// the update enqueued just before this one flagged itself and left the map alone: this one stands back too
 		if (0 == threadIdx.x) atomicOr(&ctl->err, ERR_PREV);
 		return;
 	}
 	if (ctl->err) return;  // e.g. ERR_SPEC: map untouched, the host repeats the scan
-	for (u32 j = threadIdx.x; j < UFO_UPPER_HASH; j += blockDim.x) hk[j] = 0;
+	for (u32 j = threadIdx.x; j < UFO_UPPER_HASH; j += blockDim.x) {
+		hk[j] = 0;
+		hv[j] = NONE;
+	}
 	if (0 == threadIdx.x) {
 		count = 0;
 		overflow = 0;
 		created_total = 0;
-		for (int l = 0; l < 25; ++l) start[l] = 0;
 	}
 	__syncthreads();
-	const u32 L = g.L;
-	// insert `key` if absent (pass A of a level: winners allocate a node)
-	auto insert = [&](u64 key) {
+	// insert `key` if absent; true for the thread that created the entry
+	auto insert = [&](u64 key) -> bool {
 		u32 h = upperHash(key);
 		for (u32 probe = 0; probe < UFO_UPPER_HASH; ++probe) {
 			const u64 prevk = atomicCAS((unsigned long long*)&hk[h], 0ULL, (unsigned long long)key);
@@ -596,14 +610,14 @@ __global__ __launch_bounds__(1024) void k_fupper(Table t, MapGeom g, FastGeo fg,
 					hv[h] = idx;
 				} else {
 					overflow = 1u;
-					hv[h] = 0;
 				}
-				return;
+				return true;
 			}
-			if (prevk == key) return;
+			if (prevk == key) return false;
 			h = (h + 1u) & (UFO_UPPER_HASH - 1u);
 		}
 		overflow = 1u;
+		return false;
 	};
 	auto lookup = [&](u64 key) -> u32 {
 		u32 h = upperHash(key);
@@ -615,27 +629,14 @@ __global__ __launch_bounds__(1024) void k_fupper(Table t, MapGeom g, FastGeo fg,
 		}
 		return NONE;
 	};
-	// ---- level 4: parents of the active tiles ----
+	// ---- the set of blocks above the tiles: every active tile inserts its ancestors, level 4 upward, and stops at the
+	// first one that is already there (whoever put it there continues) ----
 	for (u32 tile = threadIdx.x; tile < fg.ntiles; tile += blockDim.x) {
 		if (!((tile_bits[tile >> 5] >> (tile & 31u)) & 1u)) continue;
 		u64 lk3;
 		if (!tileKey(g, fg, tile, &lk3, nullptr)) continue;
-		insert(lk3 >> 3);
-	}
-	__syncthreads();
-	if (0 == threadIdx.x) {
-		start[4] = 0;
-		start[5] = min(count, UFO_UPPER_MAX);
-	}
-	__syncthreads();
-	// ---- levels 5 .. L: parents of the level below ----
-	for (u32 l = 4; l < L; ++l) {
-		const u32 lo = start[l], hi = start[l + 1];
-		for (u32 i = lo + threadIdx.x; i < hi; i += blockDim.x) insert(nk[i] >> 3);
-		__syncthreads();
-		if (0 == threadIdx.x) start[l + 2] = min(count, UFO_UPPER_MAX);
-		__syncthreads();
-		for (u32 i = lo + threadIdx.x; i < hi; i += blockDim.x) npar[i] = lookup(nk[i] >> 3);
+		for (u64 key = lk3 >> 3; key >= 1; key >>= 3)
+			if (!insert(key) || 1 == key) break;
 	}
 	__syncthreads();
 	if (overflow) {
@@ -649,11 +650,13 @@ __global__ __launch_bounds__(1024) void k_fupper(Table t, MapGeom g, FastGeo fg,
 	// ---- find or create every block; existing ones are loaded ----
 	u32 n_created = 0;
 	for (u32 i = threadIdx.x; i < U; i += blockDim.x) {
+		const u64 lk = nk[i];
+		npar[i] = (1 == lk) ? NONE : lookup(lk >> 3);
 		bool cr;
-		const u32 s = tableEnsure(t, nk[i], scan_id, max_probe, &cr, &n_created);
+		const u32 s = tableEnsure(t, lk, scan_id, max_probe, &cr, &n_created);
 		nslot[i] = s;
 		ncreated[i] = cr ? 1 : 0;
-		if (1 == nk[i]) npar[i] = NONE;
+		nflags[i] = 0;
 		if (s == NONE) {
 			atomicOr(&ctl->err, ERR_TABLE_FULL);
 			continue;
@@ -664,30 +667,34 @@ __global__ __launch_bounds__(1024) void k_fupper(Table t, MapGeom g, FastGeo fg,
 			nocc[i][0] = a.x; nocc[i][1] = a.y; nocc[i][2] = a.z; nocc[i][3] = a.w;
 			nocc[i][4] = b.x; nocc[i][5] = b.y; nocc[i][6] = b.z; nocc[i][7] = b.w;
 			nflags[i] = t.flags(s);
-		} else {
-			nflags[i] = 0;
 		}
 	}
 	if (n_created) atomicAdd(&created_total, n_created);
 	__syncthreads();
-	// ---- top-down: new blocks inherit the node's value from the parent block (octree.h:1044-1054) ----
-	for (u32 l = L; l >= 4; --l) {
-		for (u32 i = start[l] + threadIdx.x; i < start[l + 1]; i += blockDim.x) {
-			if (!ncreated[i] || nslot[i] == NONE) continue;
-			float v;
-			if (1 == nk[i]) {
-				v = t.root->occ;
-			} else {
-				const u32 p = npar[i], ci = (u32)(nk[i] & 7);
-				v = nocc[p][ci];
-				atomicOr(&nflags[p], 1u << (16 + ci));
+	// ---- new blocks inherit the value of the nearest ancestor node that existed before (octree.h:1044-1054): walk up
+	// the list through the new blocks (a handful of LDS reads, no level-by-level barriers) ----
+	for (u32 i = threadIdx.x; i < U; i += blockDim.x) {
+		if (!ncreated[i] || nslot[i] == NONE) continue;
+		u32 cur = i;
+		float v;
+		for (;;) {
+			const u32 p = npar[cur];
+			if (p == NONE) {
+				v = t.root->occ;  // the root block itself is new: the root's value
+				break;
 			}
-			for (int c = 0; c < 8; ++c) nocc[i][c] = v;
-			// leaf children carry the flags of a leaf with this value (OMB:1181-1189)
-			atomicOr(&nflags[i], (isFreeV(g, v) ? F_CFREE : 0u) | (isUnknownV(g, v) ? F_CUNK : 0u));
+			if (!ncreated[p]) {
+				v = nocc[p][(u32)(nk[cur] & 7)];  // (slots of existing blocks are not written in this kernel)
+				break;
+			}
+			cur = p;
 		}
-		__syncthreads();
+		for (int c = 0; c < 8; ++c) nocc[i][c] = v;
+		// leaf children carry the flags of a leaf with this value (OMB:1181-1189)
+		atomicOr(&nflags[i], (isFreeV(g, v) ? F_CFREE : 0u) | (isUnknownV(g, v) ? F_CUNK : 0u));
+		if (npar[i] != NONE) atomicOr(&nflags[npar[i]], 1u << (16 + (u32)(nk[i] & 7)));
 	}
+	__syncthreads();
 	// ---- write back: new blocks completely, flags of all (a new child sets its parent's "child is inner" bit) ----
 	for (u32 i = threadIdx.x; i < U; i += blockDim.x) {
 		const u32 s = nslot[i];
@@ -710,10 +717,10 @@ __global__ __launch_bounds__(1024) void k_fupper(Table t, MapGeom g, FastGeo fg,
 		u64 lk3;
 		if (((tile_bits[tile >> 5] >> (tile & 31u)) & 1u) && tileKey(g, fg, tile, &lk3, nullptr)) v = lookup(lk3 >> 3);
 		tile_node[tile] = v;
+		tile_s4[tile] = (v != NONE) ? nslot[v] : NONE;
 	}
 	if (0 == threadIdx.x) {
 		hdr->count = U;
-		for (int l = 0; l < 24; ++l) hdr->start[l] = start[l];
 		if (created_total) {
 			atomicAdd(&t.root->used, created_total);
 			atomicAdd(&ctl->ph[0].n_new, created_total);
@@ -742,6 +749,11 @@ struct TileRec {
 	float occ, pre_occ;  // summary of the tile's level-3 block after the scan / just before its last update
 	u32 slot;            // table slot of the level-3 block
 	u32 bits;            // 0-1 fl, 2-3 pre fl, 4 evaluated (summary handed to the parent), 5 last update reached and changed it
+	// bookkeeping that must not become 1 400 atomics on one word (each ~12 ns, serialised): summed up by k_ftail
+	u32 seq;             // scan that wrote the record (the hit masks below are valid for that scan only)
+	u32 touched;         // level-1 blocks updated
+	u32 nhit;            // voxels that received a hit
+	u32 ncreated;        // node blocks created
 };
 __device__ inline u32 flagsOf(const MapGeom& g, float v) { return (isFreeV(g, v) ? 1u : 0u) | (isUnknownV(g, v) ? 2u : 0u); }
 // reductions over the 8 lanes that differ in the three lane-index bits starting at bit `sh` (0: a level-2 group, 3: across groups)
@@ -768,9 +780,8 @@ __device__ inline bool grpAllEq(float v, int sh, u32 lane)
 }
 
 __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, const u32* __restrict__ gridM, u32* __restrict__ first,
-                                              const u32* __restrict__ tile_bits, const u32* __restrict__ tile_node,
-                                              const UpperNode* __restrict__ nodes, TileRec* __restrict__ recs, float upd_hit, float upd_miss,
-                                              u32 scan_id, u64* __restrict__ hit_codes, u32 hit_cap, ScanCtl* ctl)
+                                              const u32* __restrict__ tile_bits, const u32* __restrict__ tile_s4, TileRec* __restrict__ recs,
+                                              float upd_hit, float upd_miss, u32 scan_id, uint8_t* __restrict__ tile_hmask, ScanCtl* ctl)
 {
 	const u32 lane = threadIdx.x & 63u;
 	const u32 tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -780,71 +791,94 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 	u64 lk3;
 	u32 tt[3];
 	if (!tileKey(g, fg, tile, &lk3, tt)) return;
-	const u32 n4 = tile_node[tile];
-	if (n4 == NONE) return;
-	const u32 s4 = nodes[n4].slot;
+	const u32 s4 = tile_s4[tile];
+	if (s4 == NONE) return;
 	const u32 ci3 = (u32)(lk3 & 7);
 	const u32 c2 = lane >> 3, c1 = lane & 7u;
 	const u32 bx = (c1 & 1u) | ((c2 & 1u) << 1), by = ((c1 >> 1) & 1u) | (((c2 >> 1) & 1u) << 1), bz = ((c1 >> 2) & 1u) | (((c2 >> 2) & 1u) << 1);
-	// ---- miss mask of the lane's level-1 block from the bit grid, hits from the first-point array ----
+	const u64 lk2 = (lk3 << 3) | (u64)c2, lk1 = (lk2 << 3) | (u64)c1;
+	// The wave's time is its chain of dependent memory round trips, so everything that can be asked for at once is:
+	// round 1: the bit grid words, the level-4 slice and a SPECULATIVE lookup of every block the tile could touch
+	// (64 level-1 keys by the 64 lanes, the 8 level-2 keys and the level-3 key by lanes 0..8); round 2: the records
+	// and slices behind those slots and the first-point entries of the marked cells; round 3 (rare): creations.
+	// ---- round 1 ----
 	const i32 ox = (fg.tbase[0] + (i32)tt[0]) * 8 - fg.gr.base[0] + 2 * (i32)bx;
 	const i32 oy = (fg.tbase[1] + (i32)tt[1]) * 8 - fg.gr.base[1] + 2 * (i32)by;
 	const i32 oz = (fg.tbase[2] + (i32)tt[2]) * 8 - fg.gr.base[2] + 2 * (i32)bz;
 	const i32 nx = 2 * fg.gr.nb[0], ny = 2 * fg.gr.nb[1], nz = 2 * fg.gr.nb[2];
 	const u32 rowW = fg.rowBits >> 5;
-	u32 mmask = 0, hmask = 0;
-	u32 hit_pt[8];
-#pragma unroll
-	for (int c = 0; c < 8; ++c) hit_pt[c] = 0xFFFFFFFFu;
+	u32 gw[4] = {0, 0, 0, 0};
 	if (ox >= 0 && ox + 1 < nx) {
 #pragma unroll
-		for (int dz = 0; dz < 2; ++dz)
-#pragma unroll
-			for (int dy = 0; dy < 2; ++dy) {
-				const i32 ly = oy + dy, lz = oz + dz;
-				if (ly < 0 || ly >= ny || lz < 0 || lz >= nz) continue;
-				const u32 w = gridM[((u32)lz * (u32)ny + (u32)ly) * rowW + ((u32)ox >> 5)];
-				mmask |= ((w >> ((u32)ox & 31u)) & 3u) << (2 * dy + 4 * dz);
-			}
+		for (int k = 0; k < 4; ++k) {
+			const i32 ly = oy + (k & 1), lz = oz + (k >> 1);
+			if (ly >= 0 && ly < ny && lz >= 0 && lz < nz) gw[k] = gridM[((u32)lz * (u32)ny + (u32)ly) * rowW + ((u32)ox >> 5)];
+		}
 	}
+	const float v3s = t.occ(s4)[ci3];
+	const u32 f4 = t.flags(s4);
+	u32 s1 = tableFind(t, lk1);
+	u32 sx = NONE;  // lanes 0..7: the level-2 block of group `lane`; lane 8: the level-3 block
+	if (lane < 8u) sx = tableFind(t, (lk3 << 3) | (u64)lane);
+	else if (8u == lane) sx = tableFind(t, lk3);
+	u32 s3 = __shfl(sx, 8), s2 = __shfl(sx, (int)c2);
+	u32 mmask = 0;
+#pragma unroll
+	for (int k = 0; k < 4; ++k) mmask |= ((gw[k] >> ((u32)ox & 31u)) & 3u) << (2 * (k & 1) + 4 * (k >> 1));
 	const bool active = 0 != mmask;
-	u32 nhit = 0;
+	const u32 act2 = grpOr(active ? 1u : 0u, 0);  // the lane's level-2 group is touched
+	// ---- round 2 ----
+	u32 fl3 = F_DEAD, fl2 = F_DEAD, fl1 = F_DEAD;
+	float v2l = 0.f, v1l = 0.f;
+	float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
+	if (s3 != NONE) {
+		fl3 = t.flags(s3);
+		v2l = t.occ(s3)[c2];
+	}
+	if (s2 != NONE && act2) {
+		fl2 = t.flags(s2);
+		v1l = t.occ(s2)[c1];
+	}
+	if (s1 != NONE && active) {
+		fl1 = t.flags(s1);
+		const float4* po = reinterpret_cast<const float4*>(t.occ(s1));
+		ra = po[0];
+		rb = po[1];
+	}
+	u32 hmask = 0, nhit = 0;
 	if (active) {
 #pragma unroll
 		for (int c = 0; c < 8; ++c) {
 			if (!((mmask >> c) & 1u)) continue;
 			const u32 cell = (u32)(ox + (c & 1)) + (u32)(oy + ((c >> 1) & 1)) * fg.rowBits + (u32)(oz + ((c >> 2) & 1)) * fg.planeBits;
-			const u32 f = first[cell];
-			if (f != 0xFFFFFFFFu) {
-				hit_pt[c] = f;
+			if (first[cell] != 0xFFFFFFFFu) {
 				hmask |= 1u << c;
 				first[cell] = 0xFFFFFFFFu;  // this kernel is the array's last reader: leave it clean for the next scan
 				++nhit;
 			}
 		}
 	}
-	// ---- the blocks: level 3 (lane 0), level 2 (first lane of an active group), level 1 (active lanes) ----
-	const u32 max_probe = (t.mask >> 1) + 1;
+	// ---- which blocks are there (a block found DEAD was collapsed: the node is a leaf, octree.h:1060-1066) ----
+	bool cr3 = (s3 == NONE) || 0 != (fl3 & F_DEAD);
+	bool cr2 = act2 && (cr3 || s2 == NONE || 0 != (fl2 & F_DEAD));
+	bool cr1 = active && (cr2 || s1 == NONE || 0 != (fl1 & F_DEAD));
+	// ---- round 3: createNode for what is missing (octree.h:997-1016) ----
 	u32 n_created = 0;
-	const u32 act2 = grpOr(active ? 1u : 0u, 0);  // the lane's level-2 group is touched
-	bool cr3 = false, cr2 = false, cr1 = false;
-	u32 s3 = NONE, s2 = NONE, s1 = NONE;
-	const u64 lk2 = (lk3 << 3) | (u64)c2, lk1 = (lk2 << 3) | (u64)c1;
-	if (0 == lane) s3 = tableEnsure(t, lk3, scan_id, max_probe, &cr3, &n_created);
-	if (0 == c1 && act2) s2 = tableEnsure(t, lk2, scan_id, max_probe, &cr2, &n_created);
-	if (active) s1 = tableEnsure(t, lk1, scan_id, max_probe, &cr1, &n_created);
-	s3 = __shfl(s3, 0);
-	cr3 = 0 != __shfl(cr3 ? 1 : 0, 0);
-	s2 = __shfl(s2, (int)(lane & ~7u));
-	cr2 = 0 != __shfl(cr2 ? 1 : 0, (int)(lane & ~7u));
-	if (__ballot((0 == lane && s3 == NONE) || (act2 && s2 == NONE) || (active && s1 == NONE))) {
-		if (0 == lane) atomicOr(&ctl->err, ERR_TABLE_FULL);  // (the host sizes the table for the worst case before launching)
-		return;
+	if (__ballot(cr3 || cr2 || cr1)) {
+		const u32 max_probe = (t.mask >> 1) + 1;
+		bool dummy;
+		if (cr3 && 0 == lane) s3 = tableEnsure(t, lk3, scan_id, max_probe, &dummy, &n_created);
+		if (cr2 && 0 == c1) s2 = tableEnsure(t, lk2, scan_id, max_probe, &dummy, &n_created);
+		if (cr1) s1 = tableEnsure(t, lk1, scan_id, max_probe, &dummy, &n_created);
+		s3 = __shfl(s3, 0);
+		s2 = __shfl(s2, (int)(lane & ~7u));
+		if (__ballot((s3 == NONE) || (act2 && s2 == NONE) || (active && s1 == NONE))) {
+			if (0 == lane) atomicOr(&ctl->err, ERR_TABLE_FULL);  // (the host sizes the table for the worst case before launching)
+			return;
+		}
 	}
 	// ---- stored state of the lane's slices; new blocks inherit (octree.h:1044-1054) ----
 	// depth-3 node (the tile): its value lives in the level-4 block
-	const float v3s = t.occ(s4)[ci3];
-	const u32 f4 = t.flags(s4);
 	const u32 f3s = ((f4 >> ci3) & 1u) | (((f4 >> (8 + ci3)) & 1u) << 1);
 	// depth-2 node c2: slot c2 of the level-3 block
 	float v2s;
@@ -854,8 +888,7 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 		f2s = flagsOf(g, v3s);
 		in2s = 0;
 	} else {
-		const u32 fl3 = t.flags(s3);
-		v2s = t.occ(s3)[c2];
+		v2s = v2l;
 		f2s = ((fl3 >> c2) & 1u) | (((fl3 >> (8 + c2)) & 1u) << 1);
 		in2s = (fl3 >> (16 + c2)) & 1u;
 	}
@@ -863,8 +896,7 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 	float v1s = v2s;
 	u32 f1s = flagsOf(g, v2s), in1s = 0;
 	if (act2 && !cr2) {
-		const u32 fl2 = t.flags(s2);
-		v1s = t.occ(s2)[c1];
+		v1s = v1l;
 		f1s = ((fl2 >> c1) & 1u) | (((fl2 >> (8 + c1)) & 1u) << 1);
 		in1s = (fl2 >> (16 + c1)) & 1u;
 	}
@@ -880,10 +912,8 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 #pragma unroll
 			for (int c = 0; c < 8; ++c) v[c] = v1s;
 		} else {
-			const float4* po = reinterpret_cast<const float4*>(t.occ(s1));
-			const float4 a = po[0], b = po[1];
-			v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
-			v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+			v[0] = ra.x; v[1] = ra.y; v[2] = ra.z; v[3] = ra.w;
+			v[4] = rb.x; v[5] = rb.y; v[6] = rb.z; v[7] = rb.w;
 		}
 		const int c_last = 31 - __clz((int)mmask);  // ascending code order: the highest touched voxel is updated last
 		float v_old_last = 0.f;
@@ -922,7 +952,7 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 		cur1 = m;
 		curf1 = fl;
 		// the record's tail: flags (low bits as k_init_new leaves them for a new block) + parent, one 8-byte store
-		u32 fw = cr1 ? ((isFreeV(g, v1s) ? F_CFREE : 0u) | (isUnknownV(g, v1s) ? F_CUNK : 0u)) : (t.flags(s1) & ~(F_DEAD | F_DIRTY));
+		u32 fw = cr1 ? ((isFreeV(g, v1s) ? F_CFREE : 0u) | (isUnknownV(g, v1s) ? F_CUNK : 0u)) : (fl1 & ~(F_DEAD | F_DIRTY));
 		if (dead1) fw |= F_DEAD;
 		t.flags(s1) = fw;
 		t.parent(s1) = s2;
@@ -1003,34 +1033,25 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 			r.pre_occ = pm3;
 			r.slot = s3;
 			r.bits = (fl3n & 3u) | ((pfl3 & 3u) << 2) | (eval3 ? 16u : 0u) | (reach3 ? 32u : 0u);
+			r.seq = scan_id;
+			r.touched = r.nhit = r.ncreated = 0;  // (filled in below)
 			recs[tile] = r;
 		}
 	}
-	// ---- bookkeeping: blocks created, hit voxels of the scan (stage-level output) ----
-	for (int o = 32; o > 0; o >>= 1) n_created += __shfl_xor(n_created, o);
-	if (0 == lane && n_created) {
-		atomicAdd(&t.root->used, n_created);
-		atomicAdd(&ctl->ph[0].n_new, n_created);
+	// ---- bookkeeping (per tile, no shared counters): blocks created / touched, the hit masks of the 64 level-1 blocks
+	// (stage-level output: ufomap_map_last_hits rebuilds the hit codes from them on demand) ----
+	for (int o = 32; o > 0; o >>= 1) {
+		n_created += __shfl_xor(n_created, o);
+		nhit += __shfl_xor(nhit, o);
 	}
-	if (hit_codes) {
-		u32 incl = nhit;
-		for (int o = 1; o < 64; o <<= 1) {
-			const u32 x = __shfl_up(incl, o);
-			if ((int)lane >= o) incl += x;
-		}
-		const u32 total = __shfl(incl, 63);
-		u32 base = 0;
-		if (63u == lane && total) base = atomicAdd(&ctl->n_codes, total);
-		base = __shfl(base, 63) + incl - nhit;
-		const u64 code0 = (lk1 ^ (1ULL << (3 * (g.L - 1)))) << 3;
-		for (int c = 0; c < 8; ++c)
-			if ((hmask >> c) & 1u) {
-				if (base < hit_cap) hit_codes[base] = code0 | (u64)c;
-				++base;
-			}
-	}
+	tile_hmask[(size_t)tile * 64u + lane] = (uint8_t)hmask;
 	const u32 touched = (u32)__popcll(__ballot(active));
-	if (0 == lane) atomicAdd(&ctl->n_entries[0], touched);
+	if (0 == lane) {
+		recs[tile].seq = scan_id;
+		recs[tile].touched = touched;
+		recs[tile].nhit = nhit;
+		recs[tile].ncreated = n_created;
+	}
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1041,19 +1062,20 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 // reached it, and hands its own record to its parent. Then every block is written back once, the root summary goes to
 // MapRoot, and the scan's bounding boxes (per-workgroup partials of k_fhits) are folded for the host.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_ftail(Table t, MapGeom g, FastGeo fg, u32* __restrict__ tile_bits,
-                                                const u32* __restrict__ tile_node, const UpperNode* __restrict__ nodes,
-                                                const UpperHdr* __restrict__ hdr, const TileRec* __restrict__ recs,
-                                                const BoxPartial* __restrict__ part, u32 nparts, ScanCtl* ctl)
+__global__ __launch_bounds__(512) void k_ftail(Table t, MapGeom g, FastGeo fg, u32* __restrict__ tile_bits,
+                                               const u32* __restrict__ tile_node, const UpperNode* __restrict__ nodes,
+                                               const UpperHdr* __restrict__ hdr, const TileRec* __restrict__ recs,
+                                               const BoxPartial* __restrict__ part, u32 nparts, ScanCtl* ctl)
 {
 	__shared__ u64 nk[UFO_UPPER_MAX];
 	__shared__ u32 nslot[UFO_UPPER_MAX], npar[UFO_UPPER_MAX], nflags[UFO_UPPER_MAX], top[UFO_UPPER_MAX], lu_bits[UFO_UPPER_MAX];
+	__shared__ u32 order[UFO_UPPER_MAX];  // node indices grouped by level
 	__shared__ float nocc[UFO_UPPER_MAX][8], lu_occ[UFO_UPPER_MAX];
 	__shared__ uint8_t dirty[UFO_UPPER_MAX];
-	__shared__ u32 start[25];
-	__shared__ double rd[16][6];
-	__shared__ i32 ri[16][6];
-	if (0 == threadIdx.x) ctl->used_now = t.root->used;  // blocks are only created by k_fupper / k_tile, long done
+	__shared__ u32 lcount[25], lstart[26];
+	__shared__ double rd[8][6];
+	__shared__ i32 ri[8][6];
+	if (threadIdx.x < 25u) lcount[threadIdx.x] = 0;
 	// ---- the scan's boxes: cell box of its rays (predicts the next grid) and the change AABB (OMB:305-308, 388-398) ----
 	{
 		double amn[3] = {1e300, 1e300, 1e300}, amx[3] = {-1e300, -1e300, -1e300};
@@ -1071,7 +1093,7 @@ __global__ __launch_bounds__(1024) void k_ftail(Table t, MapGeom g, FastGeo fg, 
 		for (int a = 0; a < 3; ++a) {
 			const double l = waveMinD(amn[a]), h = waveMaxD(amx[a]);
 			const i32 il = waveMinI(mmn[a]), ih = waveMaxI(mmx[a]);
-			if (0 == lane) {
+			if (0 == lane && wave < 8u) {
 				rd[wave][a] = l;
 				rd[wave][3 + a] = h;
 				ri[wave][a] = il;
@@ -1080,7 +1102,7 @@ __global__ __launch_bounds__(1024) void k_ftail(Table t, MapGeom g, FastGeo fg, 
 		}
 		__syncthreads();
 		if (0 == threadIdx.x) {
-			const u32 nw = (blockDim.x + 63u) >> 6;
+			const u32 nw = min(8u, (blockDim.x + 63u) >> 6);
 			for (int a = 0; a < 3; ++a) {
 				double l = rd[0][a], h = rd[0][3 + a];
 				i32 il = ri[0][a], ih = ri[0][3 + a];
@@ -1104,7 +1126,6 @@ __global__ __launch_bounds__(1024) void k_ftail(Table t, MapGeom g, FastGeo fg, 
 	if (ctl->err) return;  // the scan stood back (ERR_SPEC / ERR_PREV / a bound): the map is as it was
 	const u32 U = min(hdr->count, UFO_UPPER_MAX);
 	const u32 L = g.L;
-	if (threadIdx.x < 25u) start[threadIdx.x] = threadIdx.x < 24u ? hdr->start[threadIdx.x] : U;
 	for (u32 i = threadIdx.x; i < U; i += blockDim.x) {
 		const UpperNode un = nodes[i];
 		nk[i] = un.lk;
@@ -1119,9 +1140,25 @@ __global__ __launch_bounds__(1024) void k_ftail(Table t, MapGeom g, FastGeo fg, 
 		lu_bits[i] = 0;
 		lu_occ[i] = 0.f;
 		dirty[i] = 0;
+		atomicAdd(&lcount[levelOf(g, un.lk)], 1u);
 	}
 	__syncthreads();
+	if (0 == threadIdx.x) {
+		u32 acc = 0;
+		for (u32 l = 0; l < 25u; ++l) {
+			lstart[l] = acc;
+			acc += lcount[l];
+			lcount[l] = 0;
+		}
+		lstart[25] = acc;
+	}
+	__syncthreads();
+	for (u32 i = threadIdx.x; i < U; i += blockDim.x) {
+		const u32 l = levelOf(g, nk[i]);
+		order[lstart[l] + atomicAdd(&lcount[l], 1u)] = i;
+	}
 	// ---- the tiles hand their level-3 summaries to their level-4 blocks (writeToParent) ----
+	u32 my_touched = 0, my_nhit = 0, my_created = 0;
 	for (u32 tile = threadIdx.x; tile < fg.ntiles; tile += blockDim.x) {
 		if (!((tile_bits[tile >> 5] >> (tile & 31u)) & 1u)) continue;
 		const u32 n4 = tile_node[tile];
@@ -1129,6 +1166,9 @@ __global__ __launch_bounds__(1024) void k_ftail(Table t, MapGeom g, FastGeo fg, 
 		if (n4 == NONE || !tileKey(g, fg, tile, &lk3, nullptr)) continue;
 		const u32 ci = (u32)(lk3 & 7);
 		const TileRec r = recs[tile];
+		my_touched += r.touched;
+		my_nhit += r.nhit;
+		my_created += r.ncreated;
 		atomicMax(&top[n4], ci + 1u);
 		if (r.bits & 16u) {
 			const u32 f = nflags[n4];
@@ -1144,6 +1184,21 @@ __global__ __launch_bounds__(1024) void k_ftail(Table t, MapGeom g, FastGeo fg, 
 			if (changed || (r.bits & 32u)) dirty[n4] = 1;
 		}
 	}
+	{
+		// the tiles' bookkeeping: one atomic per wave on words only this workgroup touches
+		for (int o = 32; o > 0; o >>= 1) {
+			my_touched += __shfl_xor(my_touched, o);
+			my_nhit += __shfl_xor(my_nhit, o);
+			my_created += __shfl_xor(my_created, o);
+		}
+		if (0 == (threadIdx.x & 63u)) {
+			if (my_touched) atomicAdd(&ctl->n_entries[0], my_touched);
+			if (my_created) {
+				atomicAdd(&ctl->ph[0].n_new, my_created);
+				atomicAdd(&t.root->used, my_created);
+			}
+		}
+	}
 	__syncthreads();
 	for (u32 tile = threadIdx.x; tile < fg.ntiles; tile += blockDim.x) {
 		if (!((tile_bits[tile >> 5] >> (tile & 31u)) & 1u)) continue;
@@ -1157,73 +1212,108 @@ __global__ __launch_bounds__(1024) void k_ftail(Table t, MapGeom g, FastGeo fg, 
 		lu_occ[n4] = r.pre_occ;
 	}
 	__syncthreads();
-	// ---- level by level to the root ----
-	for (u32 l = 4; l <= L; ++l) {
-		const u32 lo = start[l], hi = min(start[l + 1], U);
-		bool my_reach = false, evaluated = false;
-		float my_pre = 0.f;
-		u32 my_prefl = 0, p = NONE, ci = 0;
-		const u32 i = lo + threadIdx.x;
-		const bool have = i < hi;  // (a level holds far fewer blocks than the workgroup has threads; checked by the host's bound)
-		if (have) {
-			const u64 lk = nk[i];
-			p = npar[i];
-			ci = (u32)(lk & 7);
-			if (dirty[i]) {
-				evaluated = true;
-				const u32 f = nflags[i];
-				float m = nocc[i][0];
-				bool eq = true;
-				for (int c = 1; c < 8; ++c) {
-					m = fmaxf(m, nocc[i][c]);
-					eq = eq && (nocc[i][c] == nocc[i][0]);
-				}
-				const u32 fl = ((f & F_CFREE) ? 1u : 0u) | ((f & F_CUNK) ? 2u : 0u);
-				const u32 tc = top[i] - 1u;  // (top[i] >= 1: a dirty block has a touched child)
-				const bool reached = 0 != (lu_bits[i] & 4u);
-				float pm = m;
-				u32 pfl = fl;
-				if (reached) {
-					// summary with the top child as it was before its last update
-					pm = (0 == tc) ? lu_occ[i] : nocc[i][0];
-					for (u32 c = 1; c < 8; ++c) pm = fmaxf(pm, c == tc ? lu_occ[i] : nocc[i][c]);
-					const u32 fsub = (f & ~((1u << tc) | (1u << (8 + tc)))) | ((lu_bits[i] & 1u) << tc) | (((lu_bits[i] >> 1) & 1u) << (8 + tc));
-					pfl = ((fsub & F_CFREE) ? 1u : 0u) | ((fsub & F_CUNK) ? 2u : 0u);
-				}
-				const bool dead = reached && eq && 0 == (f & F_INNER);
-				if (dead) {
-					atomicOr(&nflags[i], F_DEAD);
-					if (1 != lk) atomicAnd(&nflags[p], ~(1u << (16 + ci)));
-				}
-				if (1 == lk) {
-					t.root->occ = m;
-					t.root->flags = fl;
-				} else {
-					const u32 fp = nflags[p];
-					const u32 old_fl = ((fp >> ci) & 1u) | (((fp >> (8 + ci)) & 1u) << 1);
-					const bool changed = nocc[p][ci] != m || old_fl != fl;
-					nocc[p][ci] = m;
-					if (old_fl != fl) {
-						const u32 setm = ((fl & 1u) << ci) | (((fl >> 1) & 1u) << (8 + ci));
-						const u32 clrm = ((1u << ci) | (1u << (8 + ci))) & ~setm;
-						if (setm) atomicOr(&nflags[p], setm);
-						if (clrm) atomicAnd(&nflags[p], ~clrm);
-					}
-					my_reach = reached && !(pm == m && pfl == fl);
-					my_pre = pm;
-					my_prefl = pfl;
-					if (changed || my_reach) dirty[p] = 1;
-				}
+	// ---- level by level to the root. One step = every block of a level: re-evaluate if a child asked for it, hand the
+	// summary to the parent, pass the "last update" record on. Wide levels: the whole workgroup, a barrier pair per
+	// level; from the first level that fits one wavefront on, wave 0 alone carries on -- LDS operations of one wave
+	// execute in order, so a level costs a wait on the LDS queue instead of a barrier. ----
+	auto step = [&](u32 i, bool have, u32* p_out, u32* ci_out, bool* reach_out, float* pre_out, u32* prefl_out) {
+		*p_out = NONE;
+		*ci_out = 0;
+		*reach_out = false;
+		*pre_out = 0.f;
+		*prefl_out = 0;
+		if (!have) return;
+		const u64 lk = nk[i];
+		const u32 p = npar[i], ci = (u32)(lk & 7);
+		*p_out = p;
+		*ci_out = ci;
+		if (dirty[i]) {
+			const u32 f = nflags[i];
+			float m = nocc[i][0];
+			bool eq = true;
+			for (int c = 1; c < 8; ++c) {
+				m = fmaxf(m, nocc[i][c]);
+				eq = eq && (nocc[i][c] == nocc[i][0]);
 			}
-			if (p != NONE) atomicMax(&top[p], ci + 1u);  // the time of the last update travels up whether or not the block was evaluated
+			const u32 fl = ((f & F_CFREE) ? 1u : 0u) | ((f & F_CUNK) ? 2u : 0u);
+			const u32 tc = top[i] - 1u;  // (top[i] >= 1: a dirty block has a touched child)
+			const bool reached = 0 != (lu_bits[i] & 4u);
+			float pm = m;
+			u32 pfl = fl;
+			if (reached) {
+				// summary with the top child as it was before its last update
+				pm = (0 == tc) ? lu_occ[i] : nocc[i][0];
+				for (u32 c = 1; c < 8; ++c) pm = fmaxf(pm, c == tc ? lu_occ[i] : nocc[i][c]);
+				const u32 fsub = (f & ~((1u << tc) | (1u << (8 + tc)))) | ((lu_bits[i] & 1u) << tc) | (((lu_bits[i] >> 1) & 1u) << (8 + tc));
+				pfl = ((fsub & F_CFREE) ? 1u : 0u) | ((fsub & F_CUNK) ? 2u : 0u);
+			}
+			const bool dead = reached && eq && 0 == (f & F_INNER);
+			if (dead) {
+				atomicOr(&nflags[i], F_DEAD);
+				if (1 != lk) atomicAnd(&nflags[p], ~(1u << (16 + ci)));
+			}
+			if (1 == lk) {
+				t.root->occ = m;
+				t.root->flags = fl;
+			} else {
+				const u32 fp = nflags[p];
+				const u32 old_fl = ((fp >> ci) & 1u) | (((fp >> (8 + ci)) & 1u) << 1);
+				const bool changed = nocc[p][ci] != m || old_fl != fl;
+				nocc[p][ci] = m;
+				if (old_fl != fl) {
+					const u32 setm = ((fl & 1u) << ci) | (((fl >> 1) & 1u) << (8 + ci));
+					const u32 clrm = ((1u << ci) | (1u << (8 + ci))) & ~setm;
+					if (setm) atomicOr(&nflags[p], setm);
+					if (clrm) atomicAnd(&nflags[p], ~clrm);
+				}
+				*reach_out = reached && !(pm == m && pfl == fl);
+				*pre_out = pm;
+				*prefl_out = pfl;
+				if (changed || *reach_out) dirty[p] = 1;
+			}
+		}
+		if (p != NONE) atomicMax(&top[p], ci + 1u);  // the time of the last update travels up whether or not the block was evaluated
+	};
+	auto publish = [&](bool have, u32 p, u32 ci, bool reach, float pre, u32 prefl) {
+		if (have && p != NONE && ci + 1u == top[p]) {
+			lu_bits[p] = (reach ? 4u : 0u) | (prefl & 3u);
+			lu_occ[p] = pre;
+		}
+	};
+	u32 l = 4;
+	for (; l <= L; ++l) {
+		const u32 lo = lstart[l], hi = lstart[l + 1];
+		if (hi - lo <= 64u) break;  // (levels only get narrower towards the root)
+		// (a wide level can hold more blocks than the workgroup has threads: two sweeps with the barrier pair around both)
+		u32 p[2], ci[2], prefl[2];
+		bool reach[2], have[2];
+		float pre[2];
+		for (int k = 0; k < 2; ++k) {
+			const u32 idx = lo + threadIdx.x + (u32)k * blockDim.x;
+			have[k] = idx < hi;
+			step(have[k] ? order[idx] : 0u, have[k], &p[k], &ci[k], &reach[k], &pre[k], &prefl[k]);
 		}
 		__syncthreads();
-		if (have && p != NONE && ci + 1u == top[p]) {
-			lu_bits[p] = (evaluated && my_reach ? 4u : 0u) | (my_prefl & 3u);
-			lu_occ[p] = my_pre;
-		}
+		for (int k = 0; k < 2; ++k) publish(have[k], p[k], ci[k], reach[k], pre[k], prefl[k]);
 		__syncthreads();
 	}
+	if (threadIdx.x < 64u) {
+		for (; l <= L; ++l) {
+			const u32 lo = lstart[l], hi = lstart[l + 1];
+			const u32 idx = lo + threadIdx.x;
+			const bool have = idx < hi;
+			u32 p, ci, prefl;
+			bool reach;
+			float pre;
+			step(have ? order[idx] : 0u, have, &p, &ci, &reach, &pre, &prefl);
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+			publish(have, p, ci, reach, pre, prefl);
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+		}
+	}
+	__syncthreads();
 	// ---- every block back to the table, once ----
 	for (u32 i = threadIdx.x; i < U; i += blockDim.x) {
 		const u32 s = nslot[i];
@@ -1234,6 +1324,27 @@ __global__ __launch_bounds__(1024) void k_ftail(Table t, MapGeom g, FastGeo fg, 
 	}
 	// this kernel is the tile bitmap's last reader: leave it empty for the set's next scan
 	__syncthreads();
+	if (0 == threadIdx.x) ctl->used_now = __hip_atomic_load(&t.root->used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the host's view of the table's fill
 	for (u32 j = threadIdx.x; j < (fg.ntiles + 31u) / 32u; j += blockDim.x) tile_bits[j] = 0;
+}
+
+// Stage-level output of a fast-path scan (ufomap_map_last_hits): the hit voxels' codes from the per-tile hit masks.
+__global__ __launch_bounds__(256) void k_fhitcodes(MapGeom g, FastGeo fg, const TileRec* __restrict__ recs, const uint8_t* __restrict__ tile_hmask,
+                                                   u32 scan_id, u64* __restrict__ codes, u32 cap, u32* __restrict__ count)
+{
+	const u32 lane = threadIdx.x & 63u;
+	const u32 tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+	if (tile >= fg.ntiles || recs[tile].seq != scan_id || 0 == recs[tile].nhit) return;
+	u64 lk3;
+	if (!tileKey(g, fg, tile, &lk3, nullptr)) return;
+	const u32 hm = tile_hmask[(size_t)tile * 64u + lane];
+	const u64 lk1 = (lk3 << 6) | (u64)lane;
+	const u64 code0 = (lk1 ^ (1ULL << (3 * (g.L - 1)))) << 3;
+	u32 pos = waveAppendN(count, (u32)__popc(hm));
+	for (u32 c = 0; c < 8; ++c)
+		if ((hm >> c) & 1u) {
+			if (pos < cap) codes[pos] = code0 | (u64)c;
+			++pos;
+		}
 }
 }  // namespace ufo

@@ -171,7 +171,10 @@ struct ufomap_map {
 	DevBuf b_ctl, b_pt_end, b_pt_flag, b_pt_slot, b_ray_end, b_hit_code, b_hit_pt, b_hh_keys;
 	DevBuf b_part0, b_part1, b_slabs, b_hb_keys, b_hb_mask, b_hb_time;
 	DevBuf b_first, b_tilebits;                      // fast path, per hand-over set (HandOver)
-	DevBuf b_upper, b_uhdr, b_tilenode, b_tilerec;   // fast path, map stream only
+	DevBuf b_upper, b_uhdr, b_tilenode, b_tiles4, b_tilerec, b_tilehm;   // fast path, map stream only
+	u32 fast_hits_scan = 0;  // scan_id of the fast-path update whose hit masks are in b_tilehm
+	bool fast_hits_valid = false;  // the most recent integration that finished ran on the fast path
+	FastGeo fgeo_last{};
 	bool first_dirty = true, fast = false;
 	uint64_t seq = 0, latest_seq = 0;  // seq: of the integration that uses the current set; latest_seq: of the newest one enqueued
 	FastGeo fgeo{};
@@ -766,6 +769,7 @@ int mapPhase(ufomap_map* m, unsigned depth, const uint8_t* d_rgb, u64 capH, u64 
              u64 extra_used = 0, u32 headroom_scans = 0)
 {
 	const float miss = (float)(m->g.miss_log / double((2.0 * depth) + 1));  // OMB:311
+	m->fast_hits_valid = false;
 	Entry* ent_h = m->b_entries.as<Entry>();
 	Entry* ent_m = ent_h + capH;
 	int rc = sizeTable(m, ent_h, capH, m->gridH.nb, ent_m, capM, m->gridM.nb, depth, merged, extra_used, nullptr != prev, headroom_scans);
@@ -870,7 +874,7 @@ int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, si
 	nwg = std::max<u32>(1u, std::min<u32>(nwg, (N + 63u) / 64u));
 	const u32 cap_wg = (N + nwg - 1) / nwg;
 	HIP_TRY(m->b_ray_end.reserve((size_t)cap_wg * nwg * sizeof(D3)));
-	HIP_TRY(m->b_slabs.reserve((size_t)nwg * fg.gr.bytes + (size_t)nwg * 8));
+	HIP_TRY(m->b_slabs.reserve((size_t)nwg * fg.gr.bytes + (size_t)nwg * 8 * 3));  // slabs + per-workgroup steps / rays / hits
 	unsigned long long* sp = reinterpret_cast<unsigned long long*>(m->b_slabs.as<char>() + (size_t)nwg * fg.gr.bytes);
 	{
 		ProfScope ps(m, "k_fcast");
@@ -914,24 +918,29 @@ int fastMapPhase(ufomap_map* m, const ScanCtl* prev, u64 extra_used, u32 headroo
 	HIP_TRY(m->b_upper.reserve((size_t)UFO_UPPER_MAX * sizeof(UpperNode)));
 	HIP_TRY(m->b_uhdr.reserve(sizeof(UpperHdr)));
 	HIP_TRY(m->b_tilenode.reserve((size_t)UFO_FAST_MAX_TILES * 4));
+	HIP_TRY(m->b_tiles4.reserve((size_t)UFO_FAST_MAX_TILES * 4));
+	HIP_TRY(m->b_tilehm.reserve((size_t)UFO_FAST_MAX_TILES * 64));
+	m->fast_hits_scan = m->scan_id;
+	m->fast_hits_valid = true;
+	m->fgeo_last = fg;
 	HIP_TRY(m->b_tilerec.reserve((size_t)UFO_FAST_MAX_TILES * sizeof(TileRec)));
 	ScanCtl* ctl = m->b_ctl.as<ScanCtl>();
 	const float miss = (float)m->g.miss_log;  // insert depth 0 (OMB:311)
 	{
 		ProfScope ps(m, "k_fupper");
-		hipLaunchKernelGGL(k_fupper, dim3(1), dim3(1024), 0, m->cs, m->t, m->g, fg, m->b_tilebits.as<u32>(), m->scan_id, m->b_upper.as<UpperNode>(),
-		                   m->b_uhdr.as<UpperHdr>(), m->b_tilenode.as<u32>(), ctl, prev);
+		hipLaunchKernelGGL(k_fupper, dim3(1), dim3(512), 0, m->cs, m->t, m->g, fg, m->b_tilebits.as<u32>(), m->scan_id, m->b_upper.as<UpperNode>(),
+		                   m->b_uhdr.as<UpperHdr>(), m->b_tilenode.as<u32>(), m->b_tiles4.as<u32>(), ctl, prev);
 	}
 	{
 		ProfScope ps(m, "k_tile");
 		hipLaunchKernelGGL(k_tile, dim3((fg.ntiles + 3) / 4), dim3(256), 0, m->cs, m->t, m->g, fg, m->b_gridM.as<u32>(), m->b_first.as<u32>(),
-		                   m->b_tilebits.as<u32>(), m->b_tilenode.as<u32>(), m->b_upper.as<UpperNode>(), m->b_tilerec.as<TileRec>(), m->g.hit, miss,
-		                   m->scan_id, m->b_hit_code.as<u64>(), (u32)std::min<u64>(m->b_hit_code.cap / 8, 0xFFFFFFFFull), ctl);
+		                   m->b_tilebits.as<u32>(), m->b_tiles4.as<u32>(), m->b_tilerec.as<TileRec>(), m->g.hit, miss,
+		                   m->scan_id, m->b_tilehm.as<uint8_t>(), ctl);
 	}
 	{
 		ProfScope ps(m, "k_ftail");
 		const u32 nparts = (u32)((m->counts[0] + 255) / 256);
-		hipLaunchKernelGGL(k_ftail, dim3(1), dim3(1024), 0, m->cs, m->t, m->g, fg, m->b_tilebits.as<u32>(), m->b_tilenode.as<u32>(),
+		hipLaunchKernelGGL(k_ftail, dim3(1), dim3(512), 0, m->cs, m->t, m->g, fg, m->b_tilebits.as<u32>(), m->b_tilenode.as<u32>(),
 		                   m->b_upper.as<UpperNode>(), m->b_uhdr.as<UpperHdr>(), m->b_tilerec.as<TileRec>(), m->b_part1.as<BoxPartial>(), nparts,
 		                   ctl);
 	}
@@ -1607,7 +1616,7 @@ void ufomap_map_destroy(ufomap_map* m)
 	                  &m->b_ctl,     &m->b_pt_end,  &m->b_pt_flag,  &m->b_pt_slot, &m->b_ray_end, &m->b_hit_code, &m->b_hit_pt,
 	                  &m->b_hh_keys, &m->b_gridM,   &m->b_crec,    &m->b_dlist,   &m->b_rays,   &m->b_part0,   &m->b_part1,   &m->b_slabs,   &m->b_hb_keys, &m->b_hb_mask, &m->b_hb_time,   &m->b_entries, &m->b_ent_slot, &m->b_newlist,
 	                  &m->b_wl0,     &m->b_wl1,     &m->b_in_xyz,   &m->b_in_rgb,  &m->b_codes,   &m->b_dump,
-	                  &m->b_first,   &m->b_tilebits, &m->b_upper,   &m->b_uhdr,    &m->b_tilenode, &m->b_tilerec};
+	                  &m->b_first,   &m->b_tilebits, &m->b_upper,   &m->b_uhdr,    &m->b_tilenode, &m->b_tiles4, &m->b_tilerec, &m->b_tilehm};
 	for (DevBuf* b : bufs) b->release();
 	for (PendingEvent& pe : m->pend_ev) {
 		(void)hipEventDestroy(pe.a);
@@ -2372,6 +2381,14 @@ size_t ufomap_map_last_hits(ufomap_map* m, uint64_t* codes, size_t cap)
 	if (!m || ufomap_map_wait(m) < 0) return (size_t)-1;
 	size_t n = (size_t)m->counts[3];
 	std::vector<uint64_t> h(n);
+	if (n && m->fast_hits_valid) {
+		// the last integration ran on the fast path: rebuild the codes from the tiles' hit masks
+		ScanCtl* ctl = m->b_ctl.as<ScanCtl>();
+		if (m->b_hit_code.reserve(n * 8) != hipSuccess || hipMemsetAsync(&ctl->n_codes, 0, 4, m->stream) != hipSuccess) return (size_t)-1;
+		hipLaunchKernelGGL(k_fhitcodes, dim3((m->fgeo_last.ntiles + 3) / 4), dim3(256), 0, m->stream, m->g, m->fgeo_last, m->b_tilerec.as<TileRec>(),
+		                   m->b_tilehm.as<uint8_t>(), m->fast_hits_scan, m->b_hit_code.as<u64>(), (u32)n, &ctl->n_codes);
+		if (hipStreamSynchronize(m->stream) != hipSuccess) return (size_t)-1;
+	}
 	if (n && hipMemcpy(h.data(), m->b_hit_code.p, n * 8, hipMemcpyDeviceToHost) != hipSuccess) return (size_t)-1;
 	std::sort(h.begin(), h.end());
 	if (codes) memcpy(codes, h.data(), std::min(n, cap) * 8);
