@@ -453,15 +453,86 @@ __global__ __launch_bounds__(512) void k_fcast(MapGeom g, FastGeo fg, D3 sensor,
 // F3: k_merge_slabs (scan_kernels.h) + which depth-3 tiles of the grid hold a marked cell (one bit per tile): the
 // tree-update kernels start from that bitmap instead of searching the grid.
 // ------------------------------------------------------------------------------------------------
+// The node blocks above the tiles, found without searching: the tiles form a regular grid, so do their ancestors --
+// level l is the tile grid coarsened by 2^(l-3). One dense grid of cells per level 4 .. L (a few hundred cells in all);
+// off[l] = first cell of level l in the concatenation, which is therefore in level order. Filled by the host.
+#define UFO_UPPER_MAX 1024u  // cells (hence node blocks) above the tiles that one scan may touch; the host keeps other scans off this path
+struct UpperGeo {
+	i32 lo[24][3];
+	u32 n[24][3];
+	u32 off[25];
+};
+__host__ __device__ inline u32 upperCell(const UpperGeo& ug, u32 l, const i32 c[3])
+{
+	const i32 x = c[0] - ug.lo[l][0], y = c[1] - ug.lo[l][1], z = c[2] - ug.lo[l][2];
+	if (x < 0 || y < 0 || z < 0 || (u32)x >= ug.n[l][0] || (u32)y >= ug.n[l][1] || (u32)z >= ug.n[l][2]) return 0xFFFFFFFFu;
+	return ug.off[l] + (u32)x + ug.n[l][0] * ((u32)y + ug.n[l][1] * (u32)z);
+}
 #define UFO_FAST_MAX_TILES 8192u
+// The LAST workgroup of the launch does not merge: it folds the per-workgroup bounding boxes of k_fhits (cell box of the
+// rays: predicts the next grid; change AABB, OMB:305-308, 388-398) into the control block, beside the others.
 __global__ __launch_bounds__(1024) void k_fmerge(FastGeo fg, const uint4* __restrict__ slabs, u32 n_slabs, u32 n4, uint4* __restrict__ grid,
-                                                 const unsigned long long* __restrict__ steps_part, u32* __restrict__ tile_bits, ScanCtl* ctl)
+                                                 const unsigned long long* __restrict__ steps_part, u32* __restrict__ tile_bits,
+                                                 UpperGeo ug, u32 L, u32* __restrict__ upper_bits, const BoxPartial* __restrict__ boxes, u32 nboxes,
+                                                 ScanCtl* ctl)
 {
 	__shared__ uint4 part[16][64];
 	__shared__ u32 tb[UFO_FAST_MAX_TILES / 32];
+	__shared__ u32 ub[UFO_UPPER_MAX / 32];
+	if (blockIdx.x + 1u == gridDim.x) {
+		__shared__ double rd[16][6];
+		__shared__ i32 ri[16][6];
+		double amn[3] = {1e300, 1e300, 1e300}, amx[3] = {-1e300, -1e300, -1e300};
+		i32 mmn[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, mmx[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+		for (u32 i = threadIdx.x; i < nboxes; i += blockDim.x) {
+			const BoxPartial& p = boxes[i];
+			for (int a = 0; a < 3; ++a) {
+				amn[a] = fmin(amn[a], p.aabb_min[a]);
+				amx[a] = fmax(amx[a], p.aabb_max[a]);
+				mmn[a] = min(mmn[a], p.mb_min[a]);
+				mmx[a] = max(mmx[a], p.mb_max[a]);
+			}
+		}
+		const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+		for (int a = 0; a < 3; ++a) {
+			const double l = waveMinD(amn[a]), h = waveMaxD(amx[a]);
+			const i32 il = waveMinI(mmn[a]), ih = waveMaxI(mmx[a]);
+			if (0 == lane) {
+				rd[wave][a] = l;
+				rd[wave][3 + a] = h;
+				ri[wave][a] = il;
+				ri[wave][3 + a] = ih;
+			}
+		}
+		__syncthreads();
+		if (0 == threadIdx.x) {
+			const u32 nw = (blockDim.x + 63u) >> 6;
+			for (int a = 0; a < 3; ++a) {
+				double l = rd[0][a], h = rd[0][3 + a];
+				i32 il = ri[0][a], ih = ri[0][3 + a];
+				for (u32 w = 1; w < nw; ++w) {
+					l = fmin(l, rd[w][a]);
+					h = fmax(h, rd[w][3 + a]);
+					il = min(il, ri[w][a]);
+					ih = max(ih, ri[w][3 + a]);
+				}
+				ctl->mb_min[a] = il;
+				ctl->mb_max[a] = ih;
+				ctl->hb_min[a] = il;
+				ctl->hb_max[a] = ih;
+				if (l < 1e299) {
+					ctl->aabb_min[a] = encD(l);
+					ctl->aabb_max[a] = encD(h);
+				}
+			}
+		}
+		return;
+	}
+	const u32 nmerge = gridDim.x - 1u;  // workgroups that merge
 	if (ctl->err) return;
 	const u32 col = threadIdx.x & 63u, sl = threadIdx.x >> 6;
 	for (u32 j = threadIdx.x; j < UFO_FAST_MAX_TILES / 32; j += blockDim.x) tb[j] = 0;
+	if (threadIdx.x < UFO_UPPER_MAX / 32) ub[threadIdx.x] = 0;
 	if (steps_part && 0 == blockIdx.x && threadIdx.x < 64u) {
 		unsigned long long v = 0, r = 0, h = 0;
 		for (u32 s = threadIdx.x; s < n_slabs; s += 64u) {
@@ -482,7 +553,7 @@ __global__ __launch_bounds__(1024) void k_fmerge(FastGeo fg, const uint4* __rest
 	}
 	__syncthreads();
 	const u32 rowW = fg.rowBits >> 5, ny = 2u * (u32)fg.gr.nb[1];
-	for (u32 j0 = blockIdx.x * 64u; j0 < n4; j0 += gridDim.x * 64u) {
+	for (u32 j0 = blockIdx.x * 64u; j0 < n4; j0 += nmerge * 64u) {
 		const u32 j = j0 + col;
 		uint4 acc = make_uint4(0, 0, 0, 0);
 		if (j < n4) {
@@ -524,7 +595,17 @@ __global__ __launch_bounds__(1024) void k_fmerge(FastGeo fg, const uint4* __rest
 					const u32 span = (hi >= 32u ? 0xFFFFFFFFu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
 					m &= ~span;
 					const u32 tile = (u32)tx + fg.nt[0] * ((u32)ty + fg.nt[1] * (u32)tz);
-					if (tile < fg.ntiles) atomicOr(&tb[tile >> 5], 1u << (tile & 31u));
+					if (tile < fg.ntiles && !((atomicOr(&tb[tile >> 5], 1u << (tile & 31u)) >> (tile & 31u)) & 1u)) {
+						// first sight of this tile in this workgroup: its ancestors' cells, level 4 .. L
+						i32 c[3] = {ax >> 3, (fg.gr.base[1] + (i32)ly) >> 3, (fg.gr.base[2] + (i32)lz) >> 3};
+						for (u32 l = 4; l <= L; ++l) {
+							c[0] >>= 1;
+							c[1] >>= 1;
+							c[2] >>= 1;
+							const u32 cell = upperCell(ug, l, c);
+							if (cell >= UFO_UPPER_MAX || ((atomicOr(&ub[cell >> 5], 1u << (cell & 31u)) >> (cell & 31u)) & 1u)) break;  // (already there: so are its ancestors)
+						}
+					}
 				}
 			}
 		}
@@ -532,211 +613,20 @@ __global__ __launch_bounds__(1024) void k_fmerge(FastGeo fg, const uint4* __rest
 	}
 	for (u32 j = threadIdx.x; j < (fg.ntiles + 31u) / 32u; j += blockDim.x)
 		if (tb[j]) atomicOr(&tile_bits[j], tb[j]);
+	if (threadIdx.x < UFO_UPPER_MAX / 32 && ub[threadIdx.x]) atomicOr(&upper_bits[threadIdx.x], ub[threadIdx.x]);
 }
 
 // ------------------------------------------------------------------------------------------------
-// Tree update, part 1 (k_fupper): the node blocks ABOVE the tiles. The active tiles' ancestors -- level 4 up to the
-// root block, a few hundred blocks for a LiDAR scan -- are collected in LDS (a hash set per level), created where they
-// do not exist yet (createNode, octree.h:997-1016) and initialised top-down by inheritance (createChildren,
-// octree.h:1044-1054), so that every tile finds its level-4 block in place and initialised. The node list (key, table
-// slot, parent index, level ranges) is left in global memory for k_ftail, which finishes these blocks after the tiles.
-// ------------------------------------------------------------------------------------------------
-#define UFO_UPPER_MAX 1024u   // node blocks above the tiles that one scan may touch (the host checks the grid against it)
-#define UFO_UPPER_HASH 4096u
-struct UpperNode {
-	u64 lk;
-	u32 slot;
-	u32 parent;  // index of the parent node in the list (NONE for the root block)
-};
-struct UpperHdr {
-	u32 count;
-	u32 start[24];  // nodes of level l are [start[l], start[l+1])
-	u32 pad[7];
-};
-__device__ inline u32 upperHash(u64 k) { return hash64(k) & (UFO_UPPER_HASH - 1u); }
-// level-3 block key of a tile; false if the tile lies outside the key range
-__device__ inline bool tileKey(const MapGeom& g, const FastGeo& fg, u32 tile, u64* lk3, u32* tcoord)
-{
-	const u32 ttx = tile % fg.nt[0], r = tile / fg.nt[0];
-	const u32 tty = r % fg.nt[1], ttz = r / fg.nt[1];
-	const i32 T[3] = {fg.tbase[0] + (i32)ttx, fg.tbase[1] + (i32)tty, fg.tbase[2] + (i32)ttz};
-	const i32 lim = (i32)(1u << (g.L - 3u));
-	if (T[0] < 0 || T[1] < 0 || T[2] < 0 || T[0] >= lim || T[1] >= lim || T[2] >= lim) return false;
-	*lk3 = (1ULL << (3 * (g.L - 3))) | morton3((u32)T[0], (u32)T[1], (u32)T[2]);
-	if (tcoord) {
-		tcoord[0] = ttx;
-		tcoord[1] = tty;
-		tcoord[2] = ttz;
-	}
-	return true;
-}
-
-__global__ __launch_bounds__(512) void k_fupper(Table t, MapGeom g, FastGeo fg, const u32* __restrict__ tile_bits, u32 scan_id,
-                                                UpperNode* __restrict__ nodes, UpperHdr* __restrict__ hdr, u32* __restrict__ tile_node,
-                                                u32* __restrict__ tile_s4, ScanCtl* ctl, const ScanCtl* prev)
-{
-	__shared__ u64 hk[UFO_UPPER_HASH];
-	__shared__ u32 hv[UFO_UPPER_HASH];
-	__shared__ u64 nk[UFO_UPPER_MAX];
-	__shared__ u32 nslot[UFO_UPPER_MAX], npar[UFO_UPPER_MAX], nflags[UFO_UPPER_MAX];
-	__shared__ float nocc[UFO_UPPER_MAX][8];
-	__shared__ uint8_t ncreated[UFO_UPPER_MAX];
-	__shared__ u32 count, overflow, created_total;
-	if (prev && prev->err) {
-		// the update enqueued just before this one flagged itself and left the map alone: this one stands back too
-		if (0 == threadIdx.x) atomicOr(&ctl->err, ERR_PREV);
-		return;
-	}
-	if (ctl->err) return;  // e.g. ERR_SPEC: map untouched, the host repeats the scan
-	for (u32 j = threadIdx.x; j < UFO_UPPER_HASH; j += blockDim.x) {
-		hk[j] = 0;
-		hv[j] = NONE;
-	}
-	if (0 == threadIdx.x) {
-		count = 0;
-		overflow = 0;
-		created_total = 0;
-	}
-	__syncthreads();
-	// insert `key` if absent; true for the thread that created the entry
-	auto insert = [&](u64 key) -> bool {
-		u32 h = upperHash(key);
-		for (u32 probe = 0; probe < UFO_UPPER_HASH; ++probe) {
-			const u64 prevk = atomicCAS((unsigned long long*)&hk[h], 0ULL, (unsigned long long)key);
-			if (0 == prevk) {
-				const u32 idx = atomicAdd(&count, 1u);
-				if (idx < UFO_UPPER_MAX) {
-					nk[idx] = key;
-					hv[h] = idx;
-				} else {
-					overflow = 1u;
-				}
-				return true;
-			}
-			if (prevk == key) return false;
-			h = (h + 1u) & (UFO_UPPER_HASH - 1u);
-		}
-		overflow = 1u;
-		return false;
-	};
-	auto lookup = [&](u64 key) -> u32 {
-		u32 h = upperHash(key);
-		for (u32 probe = 0; probe < UFO_UPPER_HASH; ++probe) {
-			const u64 k = hk[h];
-			if (k == key) return hv[h];
-			if (0 == k) return NONE;
-			h = (h + 1u) & (UFO_UPPER_HASH - 1u);
-		}
-		return NONE;
-	};
-	// ---- the set of blocks above the tiles: every active tile inserts its ancestors, level 4 upward, and stops at the
-	// first one that is already there (whoever put it there continues) ----
-	for (u32 tile = threadIdx.x; tile < fg.ntiles; tile += blockDim.x) {
-		if (!((tile_bits[tile >> 5] >> (tile & 31u)) & 1u)) continue;
-		u64 lk3;
-		if (!tileKey(g, fg, tile, &lk3, nullptr)) continue;
-		for (u64 key = lk3 >> 3; key >= 1; key >>= 3)
-			if (!insert(key) || 1 == key) break;
-	}
-	__syncthreads();
-	if (overflow) {
-		// more blocks above the tiles than this kernel holds: nothing has touched the map yet, the host repeats the scan
-		// on the general path
-		if (0 == threadIdx.x) atomicOr(&ctl->err, ERR_SPEC);
-		return;
-	}
-	const u32 U = count;
-	const u32 max_probe = (t.mask >> 1) + 1;
-	// ---- find or create every block; existing ones are loaded ----
-	u32 n_created = 0;
-	for (u32 i = threadIdx.x; i < U; i += blockDim.x) {
-		const u64 lk = nk[i];
-		npar[i] = (1 == lk) ? NONE : lookup(lk >> 3);
-		bool cr;
-		const u32 s = tableEnsure(t, lk, scan_id, max_probe, &cr, &n_created);
-		nslot[i] = s;
-		ncreated[i] = cr ? 1 : 0;
-		nflags[i] = 0;
-		if (s == NONE) {
-			atomicOr(&ctl->err, ERR_TABLE_FULL);
-			continue;
-		}
-		if (!cr) {
-			const float4* po = reinterpret_cast<const float4*>(t.occ(s));
-			const float4 a = po[0], b = po[1];
-			nocc[i][0] = a.x; nocc[i][1] = a.y; nocc[i][2] = a.z; nocc[i][3] = a.w;
-			nocc[i][4] = b.x; nocc[i][5] = b.y; nocc[i][6] = b.z; nocc[i][7] = b.w;
-			nflags[i] = t.flags(s);
-		}
-	}
-	if (n_created) atomicAdd(&created_total, n_created);
-	__syncthreads();
-	// ---- new blocks inherit the value of the nearest ancestor node that existed before (octree.h:1044-1054): walk up
-	// the list through the new blocks (a handful of LDS reads, no level-by-level barriers) ----
-	for (u32 i = threadIdx.x; i < U; i += blockDim.x) {
-		if (!ncreated[i] || nslot[i] == NONE) continue;
-		u32 cur = i;
-		float v;
-		for (;;) {
-			const u32 p = npar[cur];
-			if (p == NONE) {
-				v = t.root->occ;  // the root block itself is new: the root's value
-				break;
-			}
-			if (!ncreated[p]) {
-				v = nocc[p][(u32)(nk[cur] & 7)];  // (slots of existing blocks are not written in this kernel)
-				break;
-			}
-			cur = p;
-		}
-		for (int c = 0; c < 8; ++c) nocc[i][c] = v;
-		// leaf children carry the flags of a leaf with this value (OMB:1181-1189)
-		atomicOr(&nflags[i], (isFreeV(g, v) ? F_CFREE : 0u) | (isUnknownV(g, v) ? F_CUNK : 0u));
-		if (npar[i] != NONE) atomicOr(&nflags[npar[i]], 1u << (16 + (u32)(nk[i] & 7)));
-	}
-	__syncthreads();
-	// ---- write back: new blocks completely, flags of all (a new child sets its parent's "child is inner" bit) ----
-	for (u32 i = threadIdx.x; i < U; i += blockDim.x) {
-		const u32 s = nslot[i];
-		if (s == NONE) continue;
-		if (ncreated[i]) {
-			float4* po = reinterpret_cast<float4*>(t.occ(s));
-			po[0] = make_float4(nocc[i][0], nocc[i][1], nocc[i][2], nocc[i][3]);
-			po[1] = make_float4(nocc[i][4], nocc[i][5], nocc[i][6], nocc[i][7]);
-			t.parent(s) = (1 == nk[i]) ? NONE : nslot[npar[i]];
-		}
-		t.flags(s) = nflags[i];
-		UpperNode un;
-		un.lk = nk[i];
-		un.slot = s;
-		un.parent = npar[i];
-		nodes[i] = un;
-	}
-	for (u32 tile = threadIdx.x; tile < fg.ntiles; tile += blockDim.x) {
-		u32 v = NONE;
-		u64 lk3;
-		if (((tile_bits[tile >> 5] >> (tile & 31u)) & 1u) && tileKey(g, fg, tile, &lk3, nullptr)) v = lookup(lk3 >> 3);
-		tile_node[tile] = v;
-		tile_s4[tile] = (v != NONE) ? nslot[v] : NONE;
-	}
-	if (0 == threadIdx.x) {
-		hdr->count = U;
-		if (created_total) {
-			atomicAdd(&t.root->used, created_total);
-			atomicAdd(&ctl->ph[0].n_new, created_total);
-		}
-	}
-}
-
-// ------------------------------------------------------------------------------------------------
-// Tree update, part 2 (k_tile): one wavefront per active depth-3 tile. Lane l owns the level-1 node block whose 6-bit
+// Tree update, part 1 (k_tile): one wavefront per active depth-3 tile. Lane l owns the level-1 node block whose 6-bit
 // position inside the tile is l (three Morton digits: child index inside the level-2 block = l & 7, level-2 block =
 // l >> 3) AND the slice of every block above that lies on its path: "its" depth-1 node's value in the level-2 block,
 // "its" depth-2 node's value in the level-3 block (replicated over the 8 lanes of a group). A level of updateNode is
 // then a reduction over 8 lanes (xor shuffles 1, 2, 4 for level 2; 8, 16, 32 for level 3) -- every lane ends up with
 // the same summary, nothing is broadcast, nothing goes through memory. Reads: 4 words of the bit grid, up to 8 entries
 // of the first-point array and one 64-byte block record per lane, the parents' slices (coalesced 4-byte loads).
-// Writes: each touched block record once.
+// Writes: each touched block record once. Nothing above level 3 is written here: a tile whose level-3 block is new
+// looks its inherited value up (read-only: nobody changes the blocks above during this launch) and leaves the rest --
+// creating the blocks above, linking, their summaries -- to k_ftail.
 //
 // Semantics per level are exactly k_apply_leaf + propagateCore (map_kernels.h): hits (clamp) then misses (clamp) on
 // the voxels; a block's summary goes to its parent's slot; a parent is re-evaluated only if a child's stored summary
@@ -748,9 +638,10 @@ __global__ __launch_bounds__(512) void k_fupper(Table t, MapGeom g, FastGeo fg, 
 struct TileRec {
 	float occ, pre_occ;  // summary of the tile's level-3 block after the scan / just before its last update
 	u32 slot;            // table slot of the level-3 block
-	u32 bits;            // 0-1 fl, 2-3 pre fl, 4 evaluated (summary handed to the parent), 5 last update reached and changed it
+	u32 bits;            // 0-1 fl, 2-3 pre fl, 4 evaluated (summary handed to the parent), 5 last update reached and changed it,
+	                     // 6 the level-3 block is new (to be linked to its parent), 7 it collapsed
 	// bookkeeping that must not become 1 400 atomics on one word (each ~12 ns, serialised): summed up by k_ftail
-	u32 seq;             // scan that wrote the record (the hit masks below are valid for that scan only)
+	u32 seq;             // scan that wrote the record (the hit masks are valid for that scan only)
 	u32 touched;         // level-1 blocks updated
 	u32 nhit;            // voxels that received a hit
 	u32 ncreated;        // node blocks created
@@ -778,29 +669,48 @@ __device__ inline bool grpAllEq(float v, int sh, u32 lane)
 	const float first = __shfl(v, (int)(sh ? (lane & 7u) : (lane & ~7u)));
 	return 0 == grpOr((v == first) ? 0u : 1u, sh);
 }
+// level-3 block key of a tile; false if the tile lies outside the key range
+__device__ inline bool tileKey(const MapGeom& g, const FastGeo& fg, u32 tile, u64* lk3, u32* tcoord)
+{
+	const u32 ttx = tile % fg.nt[0], r = tile / fg.nt[0];
+	const u32 tty = r % fg.nt[1], ttz = r / fg.nt[1];
+	const i32 T[3] = {fg.tbase[0] + (i32)ttx, fg.tbase[1] + (i32)tty, fg.tbase[2] + (i32)ttz};
+	const i32 lim = (i32)(1u << (g.L - 3u));
+	if (T[0] < 0 || T[1] < 0 || T[2] < 0 || T[0] >= lim || T[1] >= lim || T[2] >= lim) return false;
+	*lk3 = (1ULL << (3 * (g.L - 3))) | morton3((u32)T[0], (u32)T[1], (u32)T[2]);
+	if (tcoord) {
+		tcoord[0] = ttx;
+		tcoord[1] = tty;
+		tcoord[2] = ttz;
+	}
+	return true;
+}
 
 __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, const u32* __restrict__ gridM, u32* __restrict__ first,
-                                              const u32* __restrict__ tile_bits, const u32* __restrict__ tile_s4, TileRec* __restrict__ recs,
-                                              float upd_hit, float upd_miss, u32 scan_id, uint8_t* __restrict__ tile_hmask, ScanCtl* ctl)
+                                              const u32* __restrict__ tile_bits, TileRec* __restrict__ recs, float upd_hit, float upd_miss,
+                                              u32 scan_id, uint8_t* __restrict__ tile_hmask, ScanCtl* ctl, const ScanCtl* prev)
 {
 	const u32 lane = threadIdx.x & 63u;
 	const u32 tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
 	if (tile >= fg.ntiles) return;
-	if (ctl->err) return;  // (raised before anything touched the map: k_fhits / k_fcast / k_fupper; uniform)
-	if (!((tile_bits[tile >> 5] >> (tile & 31u)) & 1u)) return;
+	const u32 tword = tile_bits[tile >> 5];
+	if (prev && prev->err) {
+		// the update enqueued just before this one flagged itself and left the map alone: this one stands back too
+		// (k_ftail raises ERR_PREV for the host); uniform
+		return;
+	}
+	if (ctl->err) return;  // raised by the scan half (k_fhits / k_fcast), i.e. before anything touched the map; uniform
+	if (!((tword >> (tile & 31u)) & 1u)) return;
 	u64 lk3;
 	u32 tt[3];
 	if (!tileKey(g, fg, tile, &lk3, tt)) return;
-	const u32 s4 = tile_s4[tile];
-	if (s4 == NONE) return;
-	const u32 ci3 = (u32)(lk3 & 7);
 	const u32 c2 = lane >> 3, c1 = lane & 7u;
 	const u32 bx = (c1 & 1u) | ((c2 & 1u) << 1), by = ((c1 >> 1) & 1u) | (((c2 >> 1) & 1u) << 1), bz = ((c1 >> 2) & 1u) | (((c2 >> 2) & 1u) << 1);
 	const u64 lk2 = (lk3 << 3) | (u64)c2, lk1 = (lk2 << 3) | (u64)c1;
 	// The wave's time is its chain of dependent memory round trips, so everything that can be asked for at once is:
-	// round 1: the bit grid words, the level-4 slice and a SPECULATIVE lookup of every block the tile could touch
-	// (64 level-1 keys by the 64 lanes, the 8 level-2 keys and the level-3 key by lanes 0..8); round 2: the records
-	// and slices behind those slots and the first-point entries of the marked cells; round 3 (rare): creations.
+	// round 1: the bit grid words and a SPECULATIVE lookup of every block the tile could touch (64 level-1 keys by the
+	// 64 lanes, the 8 level-2 keys and the level-3 key by lanes 0..8); round 2: the records and slices behind those
+	// slots and the first-point entries of the marked cells; round 3 (rare): creations.
 	// ---- round 1 ----
 	const i32 ox = (fg.tbase[0] + (i32)tt[0]) * 8 - fg.gr.base[0] + 2 * (i32)bx;
 	const i32 oy = (fg.tbase[1] + (i32)tt[1]) * 8 - fg.gr.base[1] + 2 * (i32)by;
@@ -815,8 +725,6 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 			if (ly >= 0 && ly < ny && lz >= 0 && lz < nz) gw[k] = gridM[((u32)lz * (u32)ny + (u32)ly) * rowW + ((u32)ox >> 5)];
 		}
 	}
-	const float v3s = t.occ(s4)[ci3];
-	const u32 f4 = t.flags(s4);
 	u32 s1 = tableFind(t, lk1);
 	u32 sx = NONE;  // lanes 0..7: the level-2 block of group `lane`; lane 8: the level-3 block
 	if (lane < 8u) sx = tableFind(t, (lk3 << 3) | (u64)lane);
@@ -859,18 +767,32 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 		}
 	}
 	// ---- which blocks are there (a block found DEAD was collapsed: the node is a leaf, octree.h:1060-1066) ----
-	bool cr3 = (s3 == NONE) || 0 != (fl3 & F_DEAD);
-	bool cr2 = act2 && (cr3 || s2 == NONE || 0 != (fl2 & F_DEAD));
-	bool cr1 = active && (cr2 || s1 == NONE || 0 != (fl1 & F_DEAD));
-	// ---- round 3: createNode for what is missing (octree.h:997-1016) ----
+	const bool cr3 = (s3 == NONE) || 0 != (fl3 & F_DEAD);
+	const bool cr2 = act2 && (cr3 || s2 == NONE || 0 != (fl2 & F_DEAD));
+	const bool cr1 = active && (cr2 || s1 == NONE || 0 != (fl1 & F_DEAD));
+	// ---- round 3: createNode for what is missing (octree.h:997-1016); a new level-3 block inherits the value of the
+	// nearest node above that has one (the blocks above are not written during this launch) ----
 	u32 n_created = 0;
+	float v3s = 0.f;
 	if (__ballot(cr3 || cr2 || cr1)) {
 		const u32 max_probe = (t.mask >> 1) + 1;
 		bool dummy;
-		if (cr3 && 0 == lane) s3 = tableEnsure(t, lk3, scan_id, max_probe, &dummy, &n_created);
+		if (cr3 && 0 == lane) {
+			s3 = tableEnsure(t, lk3, scan_id, max_probe, &dummy, &n_created);
+			v3s = t.root->occ;
+			for (u64 k = lk3 >> 3, below = lk3; k >= 1; below = k, k >>= 3) {
+				const u32 sa = tableFind(t, k);
+				if (sa != NONE && !(t.flags(sa) & F_DEAD)) {
+					v3s = t.occ(sa)[(u32)(below & 7)];
+					break;
+				}
+				if (1 == k) break;
+			}
+		}
 		if (cr2 && 0 == c1) s2 = tableEnsure(t, lk2, scan_id, max_probe, &dummy, &n_created);
 		if (cr1) s1 = tableEnsure(t, lk1, scan_id, max_probe, &dummy, &n_created);
 		s3 = __shfl(s3, 0);
+		v3s = __shfl(v3s, 0);
 		s2 = __shfl(s2, (int)(lane & ~7u));
 		if (__ballot((s3 == NONE) || (act2 && s2 == NONE) || (active && s1 == NONE))) {
 			if (0 == lane) atomicOr(&ctl->err, ERR_TABLE_FULL);  // (the host sizes the table for the worst case before launching)
@@ -878,8 +800,6 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 		}
 	}
 	// ---- stored state of the lane's slices; new blocks inherit (octree.h:1044-1054) ----
-	// depth-3 node (the tile): its value lives in the level-4 block
-	const u32 f3s = ((f4 >> ci3) & 1u) | (((f4 >> (8 + ci3)) & 1u) << 1);
 	// depth-2 node c2: slot c2 of the level-3 block
 	float v2s;
 	u32 f2s, in2s;  // stored value, flags, "has a live block" of the lane's depth-2 node
@@ -900,6 +820,7 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 		f1s = ((fl2 >> c1) & 1u) | (((fl2 >> (8 + c1)) & 1u) << 1);
 		in1s = (fl2 >> (16 + c1)) & 1u;
 	}
+	const u32 f3s = 0;  // (only the defaults of a summary that is not handed over)
 	// ---- level 1: updateOccupancy on the voxels (hits, then misses), the block's own updateNode ----
 	float cur1 = v1s;   // current value / flags of the lane's depth-1 node
 	u32 curf1 = f1s, in1 = in1s;
@@ -1022,166 +943,206 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 		// the level-3 record: first lane of every group writes its slot (all eight when the block is new), lane 0 the rest
 		if (0 == c1 && (act2 || cr3)) t.occ(s3)[c2] = cur2;
 		const u32 fbits = grpOr((0 == c1) ? (((curf2 & 1u) << c2) | (((curf2 >> 1) & 1u) << (8 + c2)) | (in2 << (16 + c2))) : 0u, 3);
+		for (int o = 32; o > 0; o >>= 1) {
+			n_created += __shfl_xor(n_created, o);
+			nhit += __shfl_xor(nhit, o);
+		}
+		const u32 touched = (u32)__popcll(__ballot(active));
 		if (0 == lane) {
-			t.flags(s3) = fbits | (dead3 ? F_DEAD : 0u);
-			t.parent(s3) = s4;
-			// "child is inner" bit of the tile in its level-4 block (k_ftail reads the word after this kernel)
-			if (dead3) atomicAnd(&t.flags(s4), ~(1u << (16 + ci3)));
-			else if (cr3) atomicOr(&t.flags(s4), 1u << (16 + ci3));
+			t.flags(s3) = fbits | (dead3 ? F_DEAD : 0u);  // (the parent link of a new block: k_ftail)
 			TileRec r;
 			r.occ = m3;
 			r.pre_occ = pm3;
 			r.slot = s3;
-			r.bits = (fl3n & 3u) | ((pfl3 & 3u) << 2) | (eval3 ? 16u : 0u) | (reach3 ? 32u : 0u);
+			r.bits = (fl3n & 3u) | ((pfl3 & 3u) << 2) | (eval3 ? 16u : 0u) | (reach3 ? 32u : 0u) | (cr3 ? 64u : 0u) | (dead3 ? 128u : 0u);
 			r.seq = scan_id;
-			r.touched = r.nhit = r.ncreated = 0;  // (filled in below)
+			r.touched = touched;
+			r.nhit = nhit;
+			r.ncreated = n_created;
 			recs[tile] = r;
 		}
 	}
-	// ---- bookkeeping (per tile, no shared counters): blocks created / touched, the hit masks of the 64 level-1 blocks
-	// (stage-level output: ufomap_map_last_hits rebuilds the hit codes from them on demand) ----
-	for (int o = 32; o > 0; o >>= 1) {
-		n_created += __shfl_xor(n_created, o);
-		nhit += __shfl_xor(nhit, o);
-	}
+	// the hit masks of the 64 level-1 blocks (stage-level output: ufomap_map_last_hits rebuilds the hit codes on demand)
 	tile_hmask[(size_t)tile * 64u + lane] = (uint8_t)hmask;
-	const u32 touched = (u32)__popcll(__ballot(active));
-	if (0 == lane) {
-		recs[tile].seq = scan_id;
-		recs[tile].touched = touched;
-		recs[tile].nhit = nhit;
-		recs[tile].ncreated = n_created;
-	}
 }
 
 // ------------------------------------------------------------------------------------------------
-// Tree update, part 3 (k_ftail): updateParents (occupancy_map_base.h:1126-1133) above the tiles. One workgroup loads the
-// blocks k_fupper listed into LDS, takes the tiles' hand-over records (summary, "last update reached and changed it",
-// summary before that update), and walks level 4 .. root with one barrier pair per level: a block is re-evaluated only
-// if a child asked for it, collapses only if the last update beneath it (the highest touched child, see k_tile)
-// reached it, and hands its own record to its parent. Then every block is written back once, the root summary goes to
-// MapRoot, and the scan's bounding boxes (per-workgroup partials of k_fhits) are folded for the host.
+// Tree update, part 2 (k_ftail): everything above the tiles, by ONE workgroup with the blocks in LDS.
+//   1. Which blocks: the tiles form a regular grid, so do their ancestors -- level l is the tile grid coarsened by
+//      2^(l-3). A dense activity map per level (a few hundred cells in all) is filled bottom-up from the tile bitmap;
+//      active cells become the node list, level by level (no hashing, no sorting: a level's nodes are contiguous).
+//   2. createNode (octree.h:997-1016) for every node: find or create its block, load it, and let a new block inherit
+//      the value of the nearest node above that had one (createChildren, octree.h:1044-1054).
+//   3. The tiles' hand-over records: summary into the level-4 slot (writeToParent), the new tiles are linked.
+//   4. updateParents (occupancy_map_base.h:1126-1133) level 4 .. root: a block is re-evaluated only if a child asked for
+//      it, collapses only if the last update beneath it (the highest touched child, see k_tile) reached it, hands its
+//      own record on; a level that re-evaluates nothing ends the walk (nothing above can change). Wide levels take a
+//      barrier pair each; from the first level that fits one wavefront on, wave 0 alone carries on -- LDS operations of
+//      one wave execute in order.
+//   5. Every block back to the table once; the root summary to MapRoot; bookkeeping for the host.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void k_ftail(Table t, MapGeom g, FastGeo fg, u32* __restrict__ tile_bits,
-                                               const u32* __restrict__ tile_node, const UpperNode* __restrict__ nodes,
-                                               const UpperHdr* __restrict__ hdr, const TileRec* __restrict__ recs,
-                                               const BoxPartial* __restrict__ part, u32 nparts, ScanCtl* ctl)
+__global__ __launch_bounds__(512) void k_ftail(Table t, MapGeom g, FastGeo fg, UpperGeo ugp, u32* __restrict__ tile_bits,
+                                               u32* __restrict__ upper_bits, const TileRec* __restrict__ recs, u32 scan_id, ScanCtl* ctl,
+                                               const ScanCtl* prev)
 {
+	__shared__ UpperGeo ug;
+	__shared__ u32 tbits[UFO_FAST_MAX_TILES / 32], ubits[UFO_UPPER_MAX / 32], uprefix[UFO_UPPER_MAX / 32 + 1];
 	__shared__ u64 nk[UFO_UPPER_MAX];
 	__shared__ u32 nslot[UFO_UPPER_MAX], npar[UFO_UPPER_MAX], nflags[UFO_UPPER_MAX], top[UFO_UPPER_MAX], lu_bits[UFO_UPPER_MAX];
-	__shared__ u32 order[UFO_UPPER_MAX];  // node indices grouped by level
 	__shared__ float nocc[UFO_UPPER_MAX][8], lu_occ[UFO_UPPER_MAX];
-	__shared__ uint8_t dirty[UFO_UPPER_MAX];
-	__shared__ u32 lcount[25], lstart[26];
-	__shared__ double rd[8][6];
-	__shared__ i32 ri[8][6];
-	if (threadIdx.x < 25u) lcount[threadIdx.x] = 0;
-	// ---- the scan's boxes: cell box of its rays (predicts the next grid) and the change AABB (OMB:305-308, 388-398) ----
-	{
-		double amn[3] = {1e300, 1e300, 1e300}, amx[3] = {-1e300, -1e300, -1e300};
-		i32 mmn[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, mmx[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
-		for (u32 i = threadIdx.x; i < nparts; i += blockDim.x) {
-			const BoxPartial& p = part[i];
-			for (int a = 0; a < 3; ++a) {
-				amn[a] = fmin(amn[a], p.aabb_min[a]);
-				amx[a] = fmax(amx[a], p.aabb_max[a]);
-				mmn[a] = min(mmn[a], p.mb_min[a]);
-				mmx[a] = max(mmx[a], p.mb_max[a]);
-			}
-		}
-		const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-		for (int a = 0; a < 3; ++a) {
-			const double l = waveMinD(amn[a]), h = waveMaxD(amx[a]);
-			const i32 il = waveMinI(mmn[a]), ih = waveMaxI(mmx[a]);
-			if (0 == lane && wave < 8u) {
-				rd[wave][a] = l;
-				rd[wave][3 + a] = h;
-				ri[wave][a] = il;
-				ri[wave][3 + a] = ih;
-			}
-		}
-		__syncthreads();
-		if (0 == threadIdx.x) {
-			const u32 nw = min(8u, (blockDim.x + 63u) >> 6);
-			for (int a = 0; a < 3; ++a) {
-				double l = rd[0][a], h = rd[0][3 + a];
-				i32 il = ri[0][a], ih = ri[0][3 + a];
-				for (u32 w = 1; w < nw; ++w) {
-					l = fmin(l, rd[w][a]);
-					h = fmax(h, rd[w][3 + a]);
-					il = min(il, ri[w][a]);
-					ih = max(ih, ri[w][3 + a]);
-				}
-				ctl->mb_min[a] = il;
-				ctl->mb_max[a] = ih;
-				ctl->hb_min[a] = il;
-				ctl->hb_max[a] = ih;
-				if (l < 1e299) {
-					ctl->aabb_min[a] = encD(l);
-					ctl->aabb_max[a] = encD(h);
-				}
-			}
-		}
+	__shared__ uint8_t dirty[UFO_UPPER_MAX], ncreated[UFO_UPPER_MAX];
+	__shared__ u32 lstart[26], created_total, any_dirty;
+	if (prev && prev->err) {
+		// the update enqueued just before this one flagged itself and left the map alone: this one stood back too (k_tile)
+		if (0 == threadIdx.x) atomicOr(&ctl->err, ERR_PREV);
+		return;
 	}
-	if (ctl->err) return;  // the scan stood back (ERR_SPEC / ERR_PREV / a bound): the map is as it was
-	const u32 U = min(hdr->count, UFO_UPPER_MAX);
+	if (ctl->err) return;  // the scan stood back (ERR_SPEC / a bound): the map is as it was
 	const u32 L = g.L;
+	const u32 nwords = (fg.ntiles + 31u) / 32u;
+	for (u32 j = threadIdx.x; j < nwords; j += blockDim.x) tbits[j] = tile_bits[j];  // the bitmaps in one round of loads
+	if (threadIdx.x < UFO_UPPER_MAX / 32) ubits[threadIdx.x] = upper_bits[threadIdx.x];
+	if (0 == threadIdx.x) {
+		ug = ugp;
+		created_total = 0;
+	}
+	__syncthreads();
+	// ---- 1. the active cells (bitmap filled by k_fmerge) become the node list, in cell order = level order ----
+	if (0 == threadIdx.x) {
+		u32 acc = 0;
+		for (u32 j = 0; j < UFO_UPPER_MAX / 32; ++j) {
+			uprefix[j] = acc;
+			acc += (u32)__popc(ubits[j]);
+		}
+		uprefix[UFO_UPPER_MAX / 32] = acc;
+	}
+	__syncthreads();
+	auto idOf = [&](u32 cell) -> u32 {  // node of a dense cell (NONE: not active)
+		if (cell >= UFO_UPPER_MAX) return NONE;
+		const u32 w = ubits[cell >> 5], b = cell & 31u;
+		if (!((w >> b) & 1u)) return NONE;
+		return uprefix[cell >> 5] + (u32)__popc(w & ((1u << b) - 1u));
+	};
+	if (threadIdx.x <= L + 1u && threadIdx.x >= 4u) {
+		// nodes of level l are [lstart[l], lstart[l+1]): the cells below off[l] that are active
+		const u32 c0 = min(ug.off[min(threadIdx.x, L + 1u)], UFO_UPPER_MAX);
+		lstart[threadIdx.x] = uprefix[c0 >> 5] + ((c0 & 31u) ? (u32)__popc(ubits[c0 >> 5] & ((1u << (c0 & 31u)) - 1u)) : 0u);
+	}
+	const u32 ncells = min(ug.off[L + 1], UFO_UPPER_MAX);
+	for (u32 cell = threadIdx.x; cell < ncells; cell += blockDim.x) {
+		const u32 id = idOf(cell);
+		if (id == NONE) continue;
+		u32 l = 4;
+		while (l < L && cell >= ug.off[l + 1]) ++l;
+		const u32 c = cell - ug.off[l];
+		const u32 x = c % ug.n[l][0], r = c / ug.n[l][0];
+		const i32 ac[3] = {ug.lo[l][0] + (i32)x, ug.lo[l][1] + (i32)(r % ug.n[l][1]), ug.lo[l][2] + (i32)(r / ug.n[l][1])};
+		nk[id] = (1ULL << (3 * (L - l))) | morton3((u32)ac[0], (u32)ac[1], (u32)ac[2]);
+		u32 par = NONE;
+		if (l < L) {
+			const i32 pc[3] = {ac[0] >> 1, ac[1] >> 1, ac[2] >> 1};
+			par = idOf(upperCell(ug, l + 1, pc));
+		}
+		npar[id] = par;
+	}
+	__syncthreads();
+	const u32 U = lstart[L + 1];
+	const u32 max_probe = (t.mask >> 1) + 1;
+	// ---- 2. find or create every block; existing ones are loaded; parents ----
+	u32 n_created = 0;
 	for (u32 i = threadIdx.x; i < U; i += blockDim.x) {
-		const UpperNode un = nodes[i];
-		nk[i] = un.lk;
-		nslot[i] = un.slot;
-		npar[i] = un.parent;
-		const float4* po = reinterpret_cast<const float4*>(t.occ(un.slot));
-		const float4 a = po[0], b = po[1];
-		nocc[i][0] = a.x; nocc[i][1] = a.y; nocc[i][2] = a.z; nocc[i][3] = a.w;
-		nocc[i][4] = b.x; nocc[i][5] = b.y; nocc[i][6] = b.z; nocc[i][7] = b.w;
-		nflags[i] = t.flags(un.slot) & ~F_DIRTY;
+		const u64 lk = nk[i];
+		bool cr;
+		const u32 s = tableEnsure(t, lk, scan_id, max_probe, &cr, &n_created);
+		nslot[i] = s;
+		ncreated[i] = cr ? 1 : 0;
+		nflags[i] = 0;
 		top[i] = 0;
 		lu_bits[i] = 0;
 		lu_occ[i] = 0.f;
 		dirty[i] = 0;
-		atomicAdd(&lcount[levelOf(g, un.lk)], 1u);
-	}
-	__syncthreads();
-	if (0 == threadIdx.x) {
-		u32 acc = 0;
-		for (u32 l = 0; l < 25u; ++l) {
-			lstart[l] = acc;
-			acc += lcount[l];
-			lcount[l] = 0;
+		if (s == NONE) {
+			atomicOr(&ctl->err, ERR_TABLE_FULL);
+			continue;
 		}
-		lstart[25] = acc;
+		if (!cr) {
+			const float4* po = reinterpret_cast<const float4*>(t.occ(s));
+			const float4 a = po[0], b = po[1];
+			nocc[i][0] = a.x; nocc[i][1] = a.y; nocc[i][2] = a.z; nocc[i][3] = a.w;
+			nocc[i][4] = b.x; nocc[i][5] = b.y; nocc[i][6] = b.z; nocc[i][7] = b.w;
+			nflags[i] = t.flags(s) & ~F_DIRTY;
+		}
+	}
+	if (n_created) atomicAdd(&created_total, n_created);
+	__syncthreads();
+	// new blocks inherit the value of the nearest node above that had a block (walk up the list through the new ones)
+	for (u32 i = threadIdx.x; i < U; i += blockDim.x) {
+		if (!ncreated[i] || nslot[i] == NONE) continue;
+		u32 cur = i;
+		float v;
+		for (;;) {
+			const u32 p = npar[cur];
+			if (p == NONE) {
+				v = t.root->occ;  // the root block itself is new: the root's value
+				break;
+			}
+			if (!ncreated[p]) {
+				v = nocc[p][(u32)(nk[cur] & 7)];  // (slots of existing blocks have not been written yet)
+				break;
+			}
+			cur = p;
+		}
+		for (int c = 0; c < 8; ++c) nocc[i][c] = v;
+		// leaf children carry the flags of a leaf with this value (OMB:1181-1189)
+		atomicOr(&nflags[i], (isFreeV(g, v) ? F_CFREE : 0u) | (isUnknownV(g, v) ? F_CUNK : 0u));
+		if (npar[i] != NONE) atomicOr(&nflags[npar[i]], 1u << (16 + (u32)(nk[i] & 7)));
 	}
 	__syncthreads();
-	for (u32 i = threadIdx.x; i < U; i += blockDim.x) {
-		const u32 l = levelOf(g, nk[i]);
-		order[lstart[l] + atomicAdd(&lcount[l], 1u)] = i;
-	}
-	// ---- the tiles hand their level-3 summaries to their level-4 blocks (writeToParent) ----
+	// ---- 3. the tiles hand their level-3 summaries to their level-4 blocks (writeToParent); new tiles are linked ----
 	u32 my_touched = 0, my_nhit = 0, my_created = 0;
-	for (u32 tile = threadIdx.x; tile < fg.ntiles; tile += blockDim.x) {
-		if (!((tile_bits[tile >> 5] >> (tile & 31u)) & 1u)) continue;
-		const u32 n4 = tile_node[tile];
-		u64 lk3;
-		if (n4 == NONE || !tileKey(g, fg, tile, &lk3, nullptr)) continue;
-		const u32 ci = (u32)(lk3 & 7);
-		const TileRec r = recs[tile];
-		my_touched += r.touched;
-		my_nhit += r.nhit;
-		my_created += r.ncreated;
-		atomicMax(&top[n4], ci + 1u);
-		if (r.bits & 16u) {
-			const u32 f = nflags[n4];
-			const u32 old_fl = ((f >> ci) & 1u) | (((f >> (8 + ci)) & 1u) << 1), fl = r.bits & 3u;
-			const bool changed = nocc[n4][ci] != r.occ || old_fl != fl;
-			nocc[n4][ci] = r.occ;
-			if (old_fl != fl) {
-				const u32 setm = ((fl & 1u) << ci) | (((fl >> 1) & 1u) << (8 + ci));
-				const u32 clrm = ((1u << ci) | (1u << (8 + ci))) & ~setm;
-				if (setm) atomicOr(&nflags[n4], setm);
-				if (clrm) atomicAnd(&nflags[n4], ~clrm);
+	constexpr u32 CH = 4;  // tiles per thread and sweep: their records are requested together
+	for (u32 t0 = 0; t0 < fg.ntiles; t0 += CH * blockDim.x) {
+		TileRec r[CH];
+		bool on[CH];
+#pragma unroll
+		for (u32 k = 0; k < CH; ++k) {
+			const u32 tile = t0 + k * blockDim.x + threadIdx.x;
+			on[k] = tile < fg.ntiles && 0 != ((tbits[tile >> 5] >> (tile & 31u)) & 1u);
+			if (on[k]) r[k] = recs[tile];
+		}
+#pragma unroll
+		for (u32 k = 0; k < CH; ++k) {
+			if (!on[k] || r[k].seq != scan_id) continue;
+			const u32 tile = t0 + k * blockDim.x + threadIdx.x;
+			u64 lk3;
+			if (!tileKey(g, fg, tile, &lk3, nullptr)) continue;
+			const u32 ci = (u32)(lk3 & 7);
+			const u32 ttx = tile % fg.nt[0], rr = tile / fg.nt[0];
+			const i32 pc[3] = {(fg.tbase[0] + (i32)ttx) >> 1, (fg.tbase[1] + (i32)(rr % fg.nt[1])) >> 1, (fg.tbase[2] + (i32)(rr / fg.nt[1])) >> 1};
+			const u32 cell = upperCell(ug, 4, pc);
+			const u32 n4 = idOf(cell);
+			if (n4 == NONE || n4 >= U) continue;
+			my_touched += r[k].touched;
+			my_nhit += r[k].nhit;
+			my_created += r[k].ncreated;
+			const u32 bits = r[k].bits;
+			if (bits & 64u) t.parent(r[k].slot) = nslot[n4];  // a new level-3 block: its parent link
+			if (bits & 128u) atomicAnd(&nflags[n4], ~(1u << (16 + ci)));
+			else if (bits & 64u) atomicOr(&nflags[n4], 1u << (16 + ci));
+			atomicMax(&top[n4], ci + 1u);
+			if (bits & 16u) {
+				const u32 f = nflags[n4];
+				const u32 old_fl = ((f >> ci) & 1u) | (((f >> (8 + ci)) & 1u) << 1), fl = bits & 3u;
+				const bool changed = nocc[n4][ci] != r[k].occ || old_fl != fl;
+				nocc[n4][ci] = r[k].occ;
+				if (old_fl != fl) {
+					const u32 setm = ((fl & 1u) << ci) | (((fl >> 1) & 1u) << (8 + ci));
+					const u32 clrm = ((1u << ci) | (1u << (8 + ci))) & ~setm;
+					if (setm) atomicOr(&nflags[n4], setm);
+					if (clrm) atomicAnd(&nflags[n4], ~clrm);
+				}
+				if (changed || (bits & 32u)) dirty[n4] = 1;
 			}
-			if (changed || (r.bits & 32u)) dirty[n4] = 1;
 		}
 	}
 	{
@@ -1193,41 +1154,45 @@ __global__ __launch_bounds__(512) void k_ftail(Table t, MapGeom g, FastGeo fg, u
 		}
 		if (0 == (threadIdx.x & 63u)) {
 			if (my_touched) atomicAdd(&ctl->n_entries[0], my_touched);
-			if (my_created) {
-				atomicAdd(&ctl->ph[0].n_new, my_created);
-				atomicAdd(&t.root->used, my_created);
-			}
+			if (my_created) atomicAdd(&created_total, my_created);
 		}
 	}
 	__syncthreads();
-	for (u32 tile = threadIdx.x; tile < fg.ntiles; tile += blockDim.x) {
-		if (!((tile_bits[tile >> 5] >> (tile & 31u)) & 1u)) continue;
-		const u32 n4 = tile_node[tile];
-		u64 lk3;
-		if (n4 == NONE || !tileKey(g, fg, tile, &lk3, nullptr)) continue;
-		const u32 ci = (u32)(lk3 & 7);
-		if (ci + 1u != top[n4]) continue;  // the highest touched child carries the last update beneath the block
-		const TileRec r = recs[tile];
-		lu_bits[n4] = ((r.bits & 16u) && (r.bits & 32u) ? 4u : 0u) | ((r.bits >> 2) & 3u);
-		lu_occ[n4] = r.pre_occ;
+	// who carries the last update beneath a level-4 block: its highest touched tile (records are L2-warm now)
+	for (u32 t0 = 0; t0 < fg.ntiles; t0 += CH * blockDim.x) {
+#pragma unroll
+		for (u32 k = 0; k < CH; ++k) {
+			const u32 tile = t0 + k * blockDim.x + threadIdx.x;
+			if (tile >= fg.ntiles || !((tbits[tile >> 5] >> (tile & 31u)) & 1u)) continue;
+			u64 lk3;
+			if (!tileKey(g, fg, tile, &lk3, nullptr)) continue;
+			const u32 ci = (u32)(lk3 & 7);
+			const u32 ttx = tile % fg.nt[0], rr = tile / fg.nt[0];
+			const i32 pc[3] = {(fg.tbase[0] + (i32)ttx) >> 1, (fg.tbase[1] + (i32)(rr % fg.nt[1])) >> 1, (fg.tbase[2] + (i32)(rr / fg.nt[1])) >> 1};
+			const u32 cell = upperCell(ug, 4, pc);
+			const u32 n4 = idOf(cell);
+			if (n4 == NONE || n4 >= U || ci + 1u != top[n4]) continue;
+			const TileRec r = recs[tile];
+			if (r.seq != scan_id) continue;
+			lu_bits[n4] = ((r.bits & 16u) && (r.bits & 32u) ? 4u : 0u) | ((r.bits >> 2) & 3u);
+			lu_occ[n4] = r.pre_occ;
+		}
 	}
 	__syncthreads();
-	// ---- level by level to the root. One step = every block of a level: re-evaluate if a child asked for it, hand the
-	// summary to the parent, pass the "last update" record on. Wide levels: the whole workgroup, a barrier pair per
-	// level; from the first level that fits one wavefront on, wave 0 alone carries on -- LDS operations of one wave
-	// execute in order, so a level costs a wait on the LDS queue instead of a barrier. ----
-	auto step = [&](u32 i, bool have, u32* p_out, u32* ci_out, bool* reach_out, float* pre_out, u32* prefl_out) {
+	// ---- 4. level by level to the root ----
+	auto step = [&](u32 i, bool have, u32* p_out, u32* ci_out, bool* reach_out, float* pre_out, u32* prefl_out) -> bool {
 		*p_out = NONE;
 		*ci_out = 0;
 		*reach_out = false;
 		*pre_out = 0.f;
 		*prefl_out = 0;
-		if (!have) return;
+		if (!have) return false;
 		const u64 lk = nk[i];
 		const u32 p = npar[i], ci = (u32)(lk & 7);
 		*p_out = p;
 		*ci_out = ci;
-		if (dirty[i]) {
+		const bool evaluated = 0 != dirty[i];
+		if (evaluated) {
 			const u32 f = nflags[i];
 			float m = nocc[i][0];
 			bool eq = true;
@@ -1273,6 +1238,7 @@ __global__ __launch_bounds__(512) void k_ftail(Table t, MapGeom g, FastGeo fg, u
 			}
 		}
 		if (p != NONE) atomicMax(&top[p], ci + 1u);  // the time of the last update travels up whether or not the block was evaluated
+		return evaluated;
 	};
 	auto publish = [&](bool have, u32 p, u32 ci, bool reach, float pre, u32 prefl) {
 		if (have && p != NONE && ci + 1u == top[p]) {
@@ -1284,18 +1250,26 @@ __global__ __launch_bounds__(512) void k_ftail(Table t, MapGeom g, FastGeo fg, u
 	for (; l <= L; ++l) {
 		const u32 lo = lstart[l], hi = lstart[l + 1];
 		if (hi - lo <= 64u) break;  // (levels only get narrower towards the root)
+		if (0 == threadIdx.x) any_dirty = 0;
+		__syncthreads();
 		// (a wide level can hold more blocks than the workgroup has threads: two sweeps with the barrier pair around both)
 		u32 p[2], ci[2], prefl[2];
-		bool reach[2], have[2];
+		bool reach[2], have[2], ev = false;
 		float pre[2];
 		for (int k = 0; k < 2; ++k) {
 			const u32 idx = lo + threadIdx.x + (u32)k * blockDim.x;
 			have[k] = idx < hi;
-			step(have[k] ? order[idx] : 0u, have[k], &p[k], &ci[k], &reach[k], &pre[k], &prefl[k]);
+			ev |= step(idx, have[k], &p[k], &ci[k], &reach[k], &pre[k], &prefl[k]);
 		}
+		if (ev) any_dirty = 1;
 		__syncthreads();
 		for (int k = 0; k < 2; ++k) publish(have[k], p[k], ci[k], reach[k], pre[k], prefl[k]);
+		const bool stop = 0 == any_dirty;
 		__syncthreads();
+		if (stop) {
+			l = L + 1;  // nothing was re-evaluated on this level: nothing above can change
+			break;
+		}
 	}
 	if (threadIdx.x < 64u) {
 		for (; l <= L; ++l) {
@@ -1305,7 +1279,8 @@ __global__ __launch_bounds__(512) void k_ftail(Table t, MapGeom g, FastGeo fg, u
 			u32 p, ci, prefl;
 			bool reach;
 			float pre;
-			step(have ? order[idx] : 0u, have, &p, &ci, &reach, &pre, &prefl);
+			const bool ev = step(idx, have, &p, &ci, &reach, &pre, &prefl);
+			if (0 == __ballot(ev)) break;  // nothing was re-evaluated on this level: nothing above can change
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 			publish(have, p, ci, reach, pre, prefl);
@@ -1314,18 +1289,27 @@ __global__ __launch_bounds__(512) void k_ftail(Table t, MapGeom g, FastGeo fg, u
 		}
 	}
 	__syncthreads();
-	// ---- every block back to the table, once ----
+	// ---- 5. every block back to the table, once ----
 	for (u32 i = threadIdx.x; i < U; i += blockDim.x) {
 		const u32 s = nslot[i];
+		if (s == NONE) continue;
 		float4* po = reinterpret_cast<float4*>(t.occ(s));
 		po[0] = make_float4(nocc[i][0], nocc[i][1], nocc[i][2], nocc[i][3]);
 		po[1] = make_float4(nocc[i][4], nocc[i][5], nocc[i][6], nocc[i][7]);
 		t.flags(s) = nflags[i];
+		if (ncreated[i]) t.parent(s) = (npar[i] != NONE) ? nslot[npar[i]] : NONE;
 	}
 	// this kernel is the tile bitmap's last reader: leave it empty for the set's next scan
-	__syncthreads();
-	if (0 == threadIdx.x) ctl->used_now = __hip_atomic_load(&t.root->used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the host's view of the table's fill
-	for (u32 j = threadIdx.x; j < (fg.ntiles + 31u) / 32u; j += blockDim.x) tile_bits[j] = 0;
+	for (u32 j = threadIdx.x; j < nwords; j += blockDim.x) tile_bits[j] = 0;
+	if (threadIdx.x < UFO_UPPER_MAX / 32) upper_bits[threadIdx.x] = 0;
+	if (0 == threadIdx.x) {
+		u32 used = __hip_atomic_load(&t.root->used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (created_total) {
+			used = atomicAdd(&t.root->used, created_total) + created_total;
+			atomicAdd(&ctl->ph[0].n_new, created_total);
+		}
+		ctl->used_now = used;  // the host's view of the table's fill
+	}
 }
 
 // Stage-level output of a fast-path scan (ufomap_map_last_hits): the hit voxels' codes from the per-tile hit masks.

@@ -126,11 +126,12 @@ struct ScanArgs {
 struct HandOver {
 	DevBuf b_ctl, b_entries, b_hh_keys, b_in_xyz, b_in_rgb;  // b_hh_keys: hit hash, keys followed by point indices
 	// what the tree update of a fast-path scan (fast_kernels.h) reads after the scan half has moved on to the next scan
-	DevBuf b_gridM, b_part1, b_hit_code, b_first, b_tilebits;
+	DevBuf b_gridM, b_part1, b_hit_code, b_first, b_tilebits, b_upperbits;
 	uint64_t seq = 0;         // running number of the integration that uses this set
 	bool first_dirty = true;  // b_first / b_tilebits are left clean by k_tile / k_ftail unless the scan stood back
 	bool fast = false;        // the integration that uses this set runs on the fast path
 	FastGeo fgeo{};
+	UpperGeo ugeo{};
 	ScanCtl* h_ctl = nullptr;  // pinned
 	void* h_stage = nullptr;   // pinned staging of a pageable host cloud (ufomap_map_insert): filled by the host, drained by
 	size_t h_stage_cap = 0;    // an asynchronous H2D copy on the scan stream; free again once the set's integration is joined
@@ -170,8 +171,9 @@ struct ufomap_map {
 	// per-scan buffers
 	DevBuf b_ctl, b_pt_end, b_pt_flag, b_pt_slot, b_ray_end, b_hit_code, b_hit_pt, b_hh_keys;
 	DevBuf b_part0, b_part1, b_slabs, b_hb_keys, b_hb_mask, b_hb_time;
-	DevBuf b_first, b_tilebits;                      // fast path, per hand-over set (HandOver)
-	DevBuf b_upper, b_uhdr, b_tilenode, b_tiles4, b_tilerec, b_tilehm;   // fast path, map stream only
+	DevBuf b_first, b_tilebits, b_upperbits;         // fast path, per hand-over set (HandOver)
+	UpperGeo ugeo{};
+	DevBuf b_tilerec, b_tilehm;   // fast path, map stream only
 	u32 fast_hits_scan = 0;  // scan_id of the fast-path update whose hit masks are in b_tilehm
 	bool fast_hits_valid = false;  // the most recent integration that finished ran on the fast path
 	FastGeo fgeo_last{};
@@ -408,6 +410,8 @@ void swapWith(ufomap_map* m, HandOver& o)
 	std::swap(m->b_hit_code, o.b_hit_code);
 	std::swap(m->b_first, o.b_first);
 	std::swap(m->b_tilebits, o.b_tilebits);
+	std::swap(m->b_upperbits, o.b_upperbits);
+	std::swap(m->ugeo, o.ugeo);
 	std::swap(m->first_dirty, o.first_dirty);
 	std::swap(m->seq, o.seq);
 	std::swap(m->fast, o.fast);
@@ -809,16 +813,36 @@ u64 fastBound(const ufomap_map* m, const Grid& gr)
 	return blockBound(m, (u64)gr.nb[0] * (u64)gr.nb[1] * (u64)gr.nb[2], gr.nb, 1);
 }
 
+// dense grids of the cells above the tiles (fast_kernels.h: UpperGeo); returns the total number of cells
+u64 makeUpperGeo(const FastGeo& fg, u32 L, UpperGeo* ug)
+{
+	memset(ug, 0, sizeof(*ug));
+	u64 off = 0;
+	for (u32 l = 4; l <= L; ++l) {
+		const u32 sh = l - 3u;
+		ug->off[l] = (u32)std::min<u64>(off, 0xFFFFFFFFull);
+		u64 sz = 1;
+		for (int a = 0; a < 3; ++a) {
+			ug->lo[l][a] = fg.tbase[a] >> sh;
+			ug->n[l][a] = (u32)(((fg.tbase[a] + (i32)fg.nt[a] - 1) >> sh) - ug->lo[l][a] + 1);
+			sz *= ug->n[l][a];
+		}
+		off += sz;
+	}
+	for (u32 l = L + 1; l < 25; ++l) ug->off[l] = (u32)std::min<u64>(off, 0xFFFFFFFFull);
+	return off;
+}
+
 bool fastEligible(const ufomap_map* m, const Grid& gr, unsigned depth, int simple, const uint8_t* d_rgb, size_t n)
 {
 	if (!m->opt_fast || 0 != depth || simple || m->g.color || d_rgb || m->chg_enabled || m->g.L < 5 || 0 == n || n > (1u << 29)) return false;
 	if (1 != gr.layout) return false;
 	const FastGeo fg = makeFastGeo(gr);
 	if (fg.ntiles > UFO_FAST_MAX_TILES) return false;
-	// node blocks above the tiles that the scan can touch: k_fupper / k_ftail hold them in LDS
-	u64 upper = 0;
-	for (u32 l = 4; l <= m->g.L; ++l) upper += std::min<u64>(levelBound(gr.nb, l - 1), 1ull << 20);
-	return upper <= UFO_UPPER_MAX;
+	// node blocks above the tiles that the scan can touch: k_ftail finds them on dense per-level grids (the tile grid
+	// coarsened level by level) and holds them in LDS -- their number is bounded by the number of cells
+	UpperGeo ug;
+	return makeUpperGeo(fg, m->g.L, &ug) <= UFO_UPPER_MAX;
 }
 
 // scan half on the scan stream: first-point array, rays, merged bit grid + tile bitmap
@@ -837,13 +861,16 @@ int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, si
 	m->fast = true;
 	const u32 N = (u32)n;
 	const D3 sensor{origin[0], origin[1], origin[2]};
-	const size_t cf = m->b_first.cap, ct = m->b_tilebits.cap;  // (a re-allocation may well return the old address: compare sizes)
+	(void)makeUpperGeo(fg, m->g.L, &m->ugeo);
+	const size_t cf = m->b_first.cap, ct = m->b_tilebits.cap, cu = m->b_upperbits.cap;  // (a re-allocation may well return the old address: compare sizes)
 	HIP_TRY(m->b_first.reserve((size_t)fg.ncells * 4));
 	HIP_TRY(m->b_tilebits.reserve(UFO_FAST_MAX_TILES / 8));
-	if (cf != m->b_first.cap || ct != m->b_tilebits.cap) m->first_dirty = true;
+	HIP_TRY(m->b_upperbits.reserve(UFO_UPPER_MAX / 8));
+	if (cf != m->b_first.cap || ct != m->b_tilebits.cap || cu != m->b_upperbits.cap) m->first_dirty = true;
 	if (m->first_dirty || 2 == m->opt_fast) {  // (option fast = 2: never trust the self-cleaning, a debugging aid)
 		HIP_TRY(hipMemsetAsync(m->b_first.p, 0xFF, m->b_first.cap, m->cs));
 		HIP_TRY(hipMemsetAsync(m->b_tilebits.p, 0, m->b_tilebits.cap, m->cs));
+		HIP_TRY(hipMemsetAsync(m->b_upperbits.p, 0, m->b_upperbits.cap, m->cs));
 		m->first_dirty = false;
 	}
 	HIP_TRY(m->b_gridM.reserve(fg.gr.bytes));
@@ -889,8 +916,9 @@ int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, si
 	{
 		ProfScope ps(m, "k_fmerge");
 		const u32 n4 = (u32)(fg.gr.bytes >> 4);
-		hipLaunchKernelGGL(k_fmerge, dim3(std::min<u32>((n4 + 63) / 64, 1024)), dim3(1024), 0, m->cs, fg, m->b_slabs.as<uint4>(), nwg, n4,
-		                   m->b_gridM.as<uint4>(), sp, m->b_tilebits.as<u32>(), ctl);
+		hipLaunchKernelGGL(k_fmerge, dim3(std::min<u32>((n4 + 63) / 64, 1024) + 1u), dim3(1024), 0, m->cs, fg, m->b_slabs.as<uint4>(), nwg, n4,
+		                   m->b_gridM.as<uint4>(), sp, m->b_tilebits.as<u32>(), m->ugeo, m->g.L, m->b_upperbits.as<u32>(), m->b_part1.as<BoxPartial>(),
+		                   gp.x, ctl);
 	}
 	HIP_TRY(hipGetLastError());
 	++m->n_fast;
@@ -915,34 +943,22 @@ int fastMapPhase(ufomap_map* m, const ScanCtl* prev, u64 extra_used, u32 headroo
 		}
 	}
 	m->scan_id += 1;
-	HIP_TRY(m->b_upper.reserve((size_t)UFO_UPPER_MAX * sizeof(UpperNode)));
-	HIP_TRY(m->b_uhdr.reserve(sizeof(UpperHdr)));
-	HIP_TRY(m->b_tilenode.reserve((size_t)UFO_FAST_MAX_TILES * 4));
-	HIP_TRY(m->b_tiles4.reserve((size_t)UFO_FAST_MAX_TILES * 4));
+	HIP_TRY(m->b_tilerec.reserve((size_t)UFO_FAST_MAX_TILES * sizeof(TileRec)));
 	HIP_TRY(m->b_tilehm.reserve((size_t)UFO_FAST_MAX_TILES * 64));
 	m->fast_hits_scan = m->scan_id;
 	m->fast_hits_valid = true;
 	m->fgeo_last = fg;
-	HIP_TRY(m->b_tilerec.reserve((size_t)UFO_FAST_MAX_TILES * sizeof(TileRec)));
 	ScanCtl* ctl = m->b_ctl.as<ScanCtl>();
 	const float miss = (float)m->g.miss_log;  // insert depth 0 (OMB:311)
 	{
-		ProfScope ps(m, "k_fupper");
-		hipLaunchKernelGGL(k_fupper, dim3(1), dim3(512), 0, m->cs, m->t, m->g, fg, m->b_tilebits.as<u32>(), m->scan_id, m->b_upper.as<UpperNode>(),
-		                   m->b_uhdr.as<UpperHdr>(), m->b_tilenode.as<u32>(), m->b_tiles4.as<u32>(), ctl, prev);
-	}
-	{
 		ProfScope ps(m, "k_tile");
 		hipLaunchKernelGGL(k_tile, dim3((fg.ntiles + 3) / 4), dim3(256), 0, m->cs, m->t, m->g, fg, m->b_gridM.as<u32>(), m->b_first.as<u32>(),
-		                   m->b_tilebits.as<u32>(), m->b_tiles4.as<u32>(), m->b_tilerec.as<TileRec>(), m->g.hit, miss,
-		                   m->scan_id, m->b_tilehm.as<uint8_t>(), ctl);
+		                   m->b_tilebits.as<u32>(), m->b_tilerec.as<TileRec>(), m->g.hit, miss, m->scan_id, m->b_tilehm.as<uint8_t>(), ctl, prev);
 	}
 	{
 		ProfScope ps(m, "k_ftail");
-		const u32 nparts = (u32)((m->counts[0] + 255) / 256);
-		hipLaunchKernelGGL(k_ftail, dim3(1), dim3(512), 0, m->cs, m->t, m->g, fg, m->b_tilebits.as<u32>(), m->b_tilenode.as<u32>(),
-		                   m->b_upper.as<UpperNode>(), m->b_uhdr.as<UpperHdr>(), m->b_tilerec.as<TileRec>(), m->b_part1.as<BoxPartial>(), nparts,
-		                   ctl);
+		hipLaunchKernelGGL(k_ftail, dim3(1), dim3(512), 0, m->cs, m->t, m->g, fg, m->ugeo, m->b_tilebits.as<u32>(), m->b_upperbits.as<u32>(),
+		                   m->b_tilerec.as<TileRec>(), m->scan_id, ctl, prev);
 	}
 	HIP_TRY(hipGetLastError());
 	return UFOMAP_OK;
@@ -1604,7 +1620,7 @@ void ufomap_map_destroy(ufomap_map* m)
 	m->tb.release();
 	m->b_changes.release();
 	for (HandOver& a : m->alt) {
-		DevBuf* abufs[] = {&a.b_ctl, &a.b_entries, &a.b_hh_keys, &a.b_in_xyz, &a.b_in_rgb, &a.b_gridM, &a.b_part1, &a.b_hit_code, &a.b_first, &a.b_tilebits};
+		DevBuf* abufs[] = {&a.b_ctl, &a.b_entries, &a.b_hh_keys, &a.b_in_xyz, &a.b_in_rgb, &a.b_gridM, &a.b_part1, &a.b_hit_code, &a.b_first, &a.b_tilebits, &a.b_upperbits};
 		for (DevBuf* b : abufs) b->release();
 		if (a.h_ctl) (void)hipHostFree(a.h_ctl);
 		if (a.h_stage) (void)hipHostFree(a.h_stage);
@@ -1616,7 +1632,7 @@ void ufomap_map_destroy(ufomap_map* m)
 	                  &m->b_ctl,     &m->b_pt_end,  &m->b_pt_flag,  &m->b_pt_slot, &m->b_ray_end, &m->b_hit_code, &m->b_hit_pt,
 	                  &m->b_hh_keys, &m->b_gridM,   &m->b_crec,    &m->b_dlist,   &m->b_rays,   &m->b_part0,   &m->b_part1,   &m->b_slabs,   &m->b_hb_keys, &m->b_hb_mask, &m->b_hb_time,   &m->b_entries, &m->b_ent_slot, &m->b_newlist,
 	                  &m->b_wl0,     &m->b_wl1,     &m->b_in_xyz,   &m->b_in_rgb,  &m->b_codes,   &m->b_dump,
-	                  &m->b_first,   &m->b_tilebits, &m->b_upper,   &m->b_uhdr,    &m->b_tilenode, &m->b_tiles4, &m->b_tilerec, &m->b_tilehm};
+	                  &m->b_first,   &m->b_tilebits, &m->b_upperbits, &m->b_tilerec, &m->b_tilehm};
 	for (DevBuf* b : bufs) b->release();
 	for (PendingEvent& pe : m->pend_ev) {
 		(void)hipEventDestroy(pe.a);
