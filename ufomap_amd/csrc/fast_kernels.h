@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void k_fhits(MapGeom g, FastGeo fg, D3 sensor,
 	}
 	if (__ballot(odd) && 0 == (threadIdx.x & 63u)) atomicOr(&ctl->err, ERR_SPEC);
 	i32 none_lo[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, none_hi[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
-	blockBoxReduce(part, 7u, amn, amx, none_lo, none_hi, ck, ek);
+	blockBoxReduce(part, 7u, amn, amx, none_lo, none_hi, ck, ek);  // (folded by k_fmerge's last workgroup)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -453,33 +453,17 @@ __global__ __launch_bounds__(512) void k_fcast(MapGeom g, FastGeo fg, D3 sensor,
 // F3: k_merge_slabs (scan_kernels.h) + which depth-3 tiles of the grid hold a marked cell (one bit per tile): the
 // tree-update kernels start from that bitmap instead of searching the grid.
 // ------------------------------------------------------------------------------------------------
-// The node blocks above the tiles, found without searching: the tiles form a regular grid, so do their ancestors --
-// level l is the tile grid coarsened by 2^(l-3). One dense grid of cells per level 4 .. L (a few hundred cells in all);
-// off[l] = first cell of level l in the concatenation, which is therefore in level order. Filled by the host.
-#define UFO_UPPER_MAX 1024u  // cells (hence node blocks) above the tiles that one scan may touch; the host keeps other scans off this path
-struct UpperGeo {
-	i32 lo[24][3];
-	u32 n[24][3];
-	u32 off[25];
-};
-__host__ __device__ inline u32 upperCell(const UpperGeo& ug, u32 l, const i32 c[3])
-{
-	const i32 x = c[0] - ug.lo[l][0], y = c[1] - ug.lo[l][1], z = c[2] - ug.lo[l][2];
-	if (x < 0 || y < 0 || z < 0 || (u32)x >= ug.n[l][0] || (u32)y >= ug.n[l][1] || (u32)z >= ug.n[l][2]) return 0xFFFFFFFFu;
-	return ug.off[l] + (u32)x + ug.n[l][0] * ((u32)y + ug.n[l][1] * (u32)z);
-}
 #define UFO_FAST_MAX_TILES 8192u
-// The LAST workgroup of the launch does not merge: it folds the per-workgroup bounding boxes of k_fhits (cell box of the
-// rays: predicts the next grid; change AABB, OMB:305-308, 388-398) into the control block, beside the others.
 __global__ __launch_bounds__(1024) void k_fmerge(FastGeo fg, const uint4* __restrict__ slabs, u32 n_slabs, u32 n4, uint4* __restrict__ grid,
                                                  const unsigned long long* __restrict__ steps_part, u32* __restrict__ tile_bits,
-                                                 UpperGeo ug, u32 L, u32* __restrict__ upper_bits, const BoxPartial* __restrict__ boxes, u32 nboxes,
-                                                 ScanCtl* ctl)
+                                                 const BoxPartial* __restrict__ boxes, u32 nboxes, ScanCtl* ctl)
 {
 	__shared__ uint4 part[16][64];
 	__shared__ u32 tb[UFO_FAST_MAX_TILES / 32];
-	__shared__ u32 ub[UFO_UPPER_MAX / 32];
 	if (blockIdx.x + 1u == gridDim.x) {
+		// The LAST workgroup of the launch does not merge: it folds the per-workgroup bounding boxes of k_fhits (cell box of
+		// the rays: predicts the next grid; change AABB, OMB:305-308, 388-398) into the control block, beside the others.
+		// (Atomics from every workgroup of k_fhits on these 12 words, even guarded by a load, tripled that kernel's time.)
 		__shared__ double rd[16][6];
 		__shared__ i32 ri[16][6];
 		double amn[3] = {1e300, 1e300, 1e300}, amx[3] = {-1e300, -1e300, -1e300};
@@ -505,25 +489,24 @@ __global__ __launch_bounds__(1024) void k_fmerge(FastGeo fg, const uint4* __rest
 			}
 		}
 		__syncthreads();
-		if (0 == threadIdx.x) {
+		if (threadIdx.x < 6u) {
+			const u32 a = threadIdx.x % 3u, k = threadIdx.x;
+			const bool is_max = k >= 3u;
 			const u32 nw = (blockDim.x + 63u) >> 6;
-			for (int a = 0; a < 3; ++a) {
-				double l = rd[0][a], h = rd[0][3 + a];
-				i32 il = ri[0][a], ih = ri[0][3 + a];
-				for (u32 w = 1; w < nw; ++w) {
-					l = fmin(l, rd[w][a]);
-					h = fmax(h, rd[w][3 + a]);
-					il = min(il, ri[w][a]);
-					ih = max(ih, ri[w][3 + a]);
-				}
-				ctl->mb_min[a] = il;
-				ctl->mb_max[a] = ih;
-				ctl->hb_min[a] = il;
-				ctl->hb_max[a] = ih;
-				if (l < 1e299) {
-					ctl->aabb_min[a] = encD(l);
-					ctl->aabb_max[a] = encD(h);
-				}
+			double d = rd[0][k];
+			i32 v = ri[0][k];
+			for (u32 w = 1; w < nw; ++w) {
+				d = is_max ? fmax(d, rd[w][k]) : fmin(d, rd[w][k]);
+				v = is_max ? max(v, ri[w][k]) : min(v, ri[w][k]);
+			}
+			if (is_max) {
+				ctl->mb_max[a] = v;
+				ctl->hb_max[a] = v;
+				if (d > -1e299) ctl->aabb_max[a] = encD(d);
+			} else {
+				ctl->mb_min[a] = v;
+				ctl->hb_min[a] = v;
+				if (d < 1e299) ctl->aabb_min[a] = encD(d);
 			}
 		}
 		return;
@@ -532,7 +515,6 @@ __global__ __launch_bounds__(1024) void k_fmerge(FastGeo fg, const uint4* __rest
 	if (ctl->err) return;
 	const u32 col = threadIdx.x & 63u, sl = threadIdx.x >> 6;
 	for (u32 j = threadIdx.x; j < UFO_FAST_MAX_TILES / 32; j += blockDim.x) tb[j] = 0;
-	if (threadIdx.x < UFO_UPPER_MAX / 32) ub[threadIdx.x] = 0;
 	if (steps_part && 0 == blockIdx.x && threadIdx.x < 64u) {
 		unsigned long long v = 0, r = 0, h = 0;
 		for (u32 s = threadIdx.x; s < n_slabs; s += 64u) {
@@ -595,17 +577,7 @@ __global__ __launch_bounds__(1024) void k_fmerge(FastGeo fg, const uint4* __rest
 					const u32 span = (hi >= 32u ? 0xFFFFFFFFu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
 					m &= ~span;
 					const u32 tile = (u32)tx + fg.nt[0] * ((u32)ty + fg.nt[1] * (u32)tz);
-					if (tile < fg.ntiles && !((atomicOr(&tb[tile >> 5], 1u << (tile & 31u)) >> (tile & 31u)) & 1u)) {
-						// first sight of this tile in this workgroup: its ancestors' cells, level 4 .. L
-						i32 c[3] = {ax >> 3, (fg.gr.base[1] + (i32)ly) >> 3, (fg.gr.base[2] + (i32)lz) >> 3};
-						for (u32 l = 4; l <= L; ++l) {
-							c[0] >>= 1;
-							c[1] >>= 1;
-							c[2] >>= 1;
-							const u32 cell = upperCell(ug, l, c);
-							if (cell >= UFO_UPPER_MAX || ((atomicOr(&ub[cell >> 5], 1u << (cell & 31u)) >> (cell & 31u)) & 1u)) break;  // (already there: so are its ancestors)
-						}
-					}
+					if (tile < fg.ntiles) atomicOr(&tb[tile >> 5], 1u << (tile & 31u));
 				}
 			}
 		}
@@ -613,9 +585,23 @@ __global__ __launch_bounds__(1024) void k_fmerge(FastGeo fg, const uint4* __rest
 	}
 	for (u32 j = threadIdx.x; j < (fg.ntiles + 31u) / 32u; j += blockDim.x)
 		if (tb[j]) atomicOr(&tile_bits[j], tb[j]);
-	if (threadIdx.x < UFO_UPPER_MAX / 32 && ub[threadIdx.x]) atomicOr(&upper_bits[threadIdx.x], ub[threadIdx.x]);
 }
 
+// The node blocks above the tiles, found without searching: the tiles form a regular grid, so do their ancestors --
+// level l is the tile grid coarsened by 2^(l-3). One dense grid of cells per level 4 .. L (a few hundred cells in all);
+// off[l] = first cell of level l in the concatenation, which is therefore in level order. Filled by the host.
+#define UFO_UPPER_MAX 1024u  // cells (hence node blocks) above the tiles that one scan may touch; the host keeps other scans off this path
+struct UpperGeo {
+	i32 lo[24][3];
+	u32 n[24][3];
+	u32 off[25];
+};
+__host__ __device__ inline u32 upperCell(const UpperGeo& ug, u32 l, const i32 c[3])
+{
+	const i32 x = c[0] - ug.lo[l][0], y = c[1] - ug.lo[l][1], z = c[2] - ug.lo[l][2];
+	if (x < 0 || y < 0 || z < 0 || (u32)x >= ug.n[l][0] || (u32)y >= ug.n[l][1] || (u32)z >= ug.n[l][2]) return 0xFFFFFFFFu;
+	return ug.off[l] + (u32)x + ug.n[l][0] * ((u32)y + ug.n[l][1] * (u32)z);
+}
 // ------------------------------------------------------------------------------------------------
 // Tree update, part 1 (k_tile): one wavefront per active depth-3 tile. Lane l owns the level-1 node block whose 6-bit
 // position inside the tile is l (three Morton digits: child index inside the level-2 block = l & 7, level-2 block =
@@ -639,13 +625,14 @@ struct TileRec {
 	float occ, pre_occ;  // summary of the tile's level-3 block after the scan / just before its last update
 	u32 slot;            // table slot of the level-3 block
 	u32 bits;            // 0-1 fl, 2-3 pre fl, 4 evaluated (summary handed to the parent), 5 last update reached and changed it,
-	                     // 6 the level-3 block is new (to be linked to its parent), 7 it collapsed
-	// bookkeeping that must not become 1 400 atomics on one word (each ~12 ns, serialised): summed up by k_ftail
+	                     // 6 the level-3 block is new (to be linked to its parent), 7 it collapsed, 8-10 child index in the parent
 	u32 seq;             // scan that wrote the record (the hit masks are valid for that scan only)
-	u32 touched;         // level-1 blocks updated
-	u32 nhit;            // voxels that received a hit
-	u32 ncreated;        // node blocks created
+	// bookkeeping that must not become 1 400 atomics on one word (each ~12 ns, serialised): summed up by k_ftail.
+	// bits 0-7 level-1 blocks updated (<= 64), 8-17 voxels that received a hit (<= 512), 18-24 node blocks created (<= 73)
+	u32 counts;
+	u32 pad[2];
 };
+__host__ __device__ inline u32 tileRecHits(const TileRec& r) { return (r.counts >> 8) & 1023u; }
 __device__ inline u32 flagsOf(const MapGeom& g, float v) { return (isFreeV(g, v) ? 1u : 0u) | (isUnknownV(g, v) ? 2u : 0u); }
 // reductions over the 8 lanes that differ in the three lane-index bits starting at bit `sh` (0: a level-2 group, 3: across groups)
 __device__ inline float grpMax(float v, int sh)
@@ -955,10 +942,10 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 			r.pre_occ = pm3;
 			r.slot = s3;
 			r.bits = (fl3n & 3u) | ((pfl3 & 3u) << 2) | (eval3 ? 16u : 0u) | (reach3 ? 32u : 0u) | (cr3 ? 64u : 0u) | (dead3 ? 128u : 0u);
+			r.bits |= (u32)(lk3 & 7) << 8;
 			r.seq = scan_id;
-			r.touched = touched;
-			r.nhit = nhit;
-			r.ncreated = n_created;
+			r.counts = touched | (nhit << 8) | (n_created << 18);
+			r.pad[0] = r.pad[1] = 0;
 			recs[tile] = r;
 		}
 	}
@@ -969,29 +956,35 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 // ------------------------------------------------------------------------------------------------
 // Tree update, part 2 (k_ftail): everything above the tiles, by ONE workgroup with the blocks in LDS.
 //   1. Which blocks: the tiles form a regular grid, so do their ancestors -- level l is the tile grid coarsened by
-//      2^(l-3). A dense activity map per level (a few hundred cells in all) is filled bottom-up from the tile bitmap;
-//      active cells become the node list, level by level (no hashing, no sorting: a level's nodes are contiguous).
+//      2^(l-3). Every active tile marks its ancestors in a bitmap over those dense grids (a few hundred cells in all, in
+//      LDS; a tile stops at the first ancestor somebody else marked); a prefix popcount turns the bitmap into the node
+//      list, in cell order = level order (no hashing, no sorting).
 //   2. createNode (octree.h:997-1016) for every node: find or create its block, load it, and let a new block inherit
 //      the value of the nearest node above that had one (createChildren, octree.h:1044-1054).
 //   3. The tiles' hand-over records: summary into the level-4 slot (writeToParent), the new tiles are linked.
-//   4. updateParents (occupancy_map_base.h:1126-1133) level 4 .. root: a block is re-evaluated only if a child asked for
-//      it, collapses only if the last update beneath it (the highest touched child, see k_tile) reached it, hands its
-//      own record on; a level that re-evaluates nothing ends the walk (nothing above can change). Wide levels take a
-//      barrier pair each; from the first level that fits one wavefront on, wave 0 alone carries on -- LDS operations of
-//      one wave execute in order.
+//   4. updateParents (occupancy_map_base.h:1126-1133) level 4 .. root, eight lanes per block (lane = child; the block's
+//      summary is three xor shuffles): a block is re-evaluated only if a child asked for it, collapses only if the last
+//      update beneath it (the highest touched child, see k_tile) reached it, and leaves what its parent needs to know
+//      about that last update in its own out_* entry; a level that re-evaluates nothing ends the walk (nothing above can
+//      change). One barrier per level; once a level has at most 8 blocks, wave 0 alone carries on without barriers -- LDS
+//      operations of one wave execute in order.
 //   5. Every block back to the table once; the root summary to MapRoot; bookkeeping for the host.
+// The kernel's duration is its longest chain of dependent instructions (a lone workgroup hides nothing), so the code
+// below counts instructions, not bytes.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void k_ftail(Table t, MapGeom g, FastGeo fg, UpperGeo ugp, u32* __restrict__ tile_bits,
-                                               u32* __restrict__ upper_bits, const TileRec* __restrict__ recs, u32 scan_id, ScanCtl* ctl,
-                                               const ScanCtl* prev)
+#define UFO_FTAIL_THREADS 1024
+static_assert(UFO_FTAIL_THREADS == UFO_UPPER_MAX, "k_ftail: one thread per cell of the dense grids above the tiles");
+__global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g, FastGeo fg, UpperGeo ugp, u32* __restrict__ tile_bits,
+                                                             const TileRec* __restrict__ recs, u32 scan_id, ScanCtl* ctl, const ScanCtl* prev)
 {
 	__shared__ UpperGeo ug;
 	__shared__ u32 tbits[UFO_FAST_MAX_TILES / 32], ubits[UFO_UPPER_MAX / 32], uprefix[UFO_UPPER_MAX / 32 + 1];
 	__shared__ u64 nk[UFO_UPPER_MAX];
-	__shared__ u32 nslot[UFO_UPPER_MAX], npar[UFO_UPPER_MAX], nflags[UFO_UPPER_MAX], top[UFO_UPPER_MAX], lu_bits[UFO_UPPER_MAX];
-	__shared__ float nocc[UFO_UPPER_MAX][8], lu_occ[UFO_UPPER_MAX];
+	__shared__ unsigned long long top64[UFO_UPPER_MAX];  // (1 + child index of the highest touched child) << 32 | who it is (tile or node)
+	__shared__ u32 nslot[UFO_UPPER_MAX], npar[UFO_UPPER_MAX], nflags[UFO_UPPER_MAX], out_bits[UFO_UPPER_MAX];
+	__shared__ float nocc[UFO_UPPER_MAX][8], out_pre[UFO_UPPER_MAX];
 	__shared__ uint8_t dirty[UFO_UPPER_MAX], ncreated[UFO_UPPER_MAX];
-	__shared__ u32 lstart[26], created_total, any_dirty;
+	__shared__ u32 lstart[26], lvl_dirty[26], created_total;
 	if (prev && prev->err) {
 		// the update enqueued just before this one flagged itself and left the map alone: this one stood back too (k_tile)
 		if (0 == threadIdx.x) atomicOr(&ctl->err, ERR_PREV);
@@ -1000,21 +993,44 @@ __global__ __launch_bounds__(512) void k_ftail(Table t, MapGeom g, FastGeo fg, U
 	if (ctl->err) return;  // the scan stood back (ERR_SPEC / a bound): the map is as it was
 	const u32 L = g.L;
 	const u32 nwords = (fg.ntiles + 31u) / 32u;
-	for (u32 j = threadIdx.x; j < nwords; j += blockDim.x) tbits[j] = tile_bits[j];  // the bitmaps in one round of loads
-	if (threadIdx.x < UFO_UPPER_MAX / 32) ubits[threadIdx.x] = upper_bits[threadIdx.x];
-	if (0 == threadIdx.x) {
-		ug = ugp;
-		created_total = 0;
+	const u32 lane = threadIdx.x & 63u;
+	for (u32 j = threadIdx.x; j < nwords; j += blockDim.x) tbits[j] = tile_bits[j];
+	if (threadIdx.x < UFO_UPPER_MAX / 32) ubits[threadIdx.x] = 0;
+	if (threadIdx.x >= 64u && threadIdx.x < 64u + sizeof(UpperGeo) / 4u) reinterpret_cast<u32*>(&ug)[threadIdx.x - 64u] = reinterpret_cast<const u32*>(&ugp)[threadIdx.x - 64u];
+	if (threadIdx.x < 26u) lvl_dirty[threadIdx.x] = 0;
+	if (0 == threadIdx.x) created_total = 0;
+	__syncthreads();
+	// ---- 1. the active cells become the node list ----
+	constexpr u32 MAXT = UFO_FAST_MAX_TILES / UFO_FTAIL_THREADS;  // tiles per thread: tile = k * blockDim + thread
+	u32 cell4[MAXT];  // the level-4 parent's cell of the thread's tiles (NONE: tile not active)
+#pragma unroll
+	for (u32 k = 0; k < MAXT; ++k) {
+		const u32 tile = k * blockDim.x + threadIdx.x;
+		cell4[k] = NONE;
+		if (tile >= fg.ntiles || !((tbits[tile >> 5] >> (tile & 31u)) & 1u)) continue;
+		const u32 ttx = tile % fg.nt[0], rr = tile / fg.nt[0];
+		i32 c[3] = {fg.tbase[0] + (i32)ttx, fg.tbase[1] + (i32)(rr % fg.nt[1]), fg.tbase[2] + (i32)(rr / fg.nt[1])};
+		const i32 lim = (i32)(1u << (L - 3u));
+		if (c[0] < 0 || c[1] < 0 || c[2] < 0 || c[0] >= lim || c[1] >= lim || c[2] >= lim) continue;  // (outside the key range: k_tile skipped it, too)
+		for (u32 l = 4; l <= L; ++l) {
+			c[0] >>= 1;
+			c[1] >>= 1;
+			c[2] >>= 1;
+			const u32 cell = upperCell(ug, l, c);
+			if (4u == l) cell4[k] = cell;
+			if (cell >= UFO_UPPER_MAX || ((atomicOr(&ubits[cell >> 5], 1u << (cell & 31u)) >> (cell & 31u)) & 1u)) break;  // (already there: so are its ancestors)
+		}
 	}
 	__syncthreads();
-	// ---- 1. the active cells (bitmap filled by k_fmerge) become the node list, in cell order = level order ----
-	if (0 == threadIdx.x) {
-		u32 acc = 0;
-		for (u32 j = 0; j < UFO_UPPER_MAX / 32; ++j) {
-			uprefix[j] = acc;
-			acc += (u32)__popc(ubits[j]);
+	if (threadIdx.x < 64u) {
+		// prefix popcount over the bitmap's 32 words
+		const u32 c = (lane < UFO_UPPER_MAX / 32) ? (u32)__popc(ubits[lane]) : 0u;
+		u32 incl = c;
+		for (int o = 1; o < 64; o <<= 1) {
+			const u32 v = __shfl_up(incl, o);
+			if ((int)lane >= o) incl += v;
 		}
-		uprefix[UFO_UPPER_MAX / 32] = acc;
+		if (lane <= UFO_UPPER_MAX / 32) uprefix[lane] = incl - c;
 	}
 	__syncthreads();
 	auto idOf = [&](u32 cell) -> u32 {  // node of a dense cell (NONE: not active)
@@ -1025,56 +1041,55 @@ __global__ __launch_bounds__(512) void k_ftail(Table t, MapGeom g, FastGeo fg, U
 	};
 	if (threadIdx.x <= L + 1u && threadIdx.x >= 4u) {
 		// nodes of level l are [lstart[l], lstart[l+1]): the cells below off[l] that are active
-		const u32 c0 = min(ug.off[min(threadIdx.x, L + 1u)], UFO_UPPER_MAX);
+		const u32 c0 = min(ug.off[threadIdx.x], UFO_UPPER_MAX);
 		lstart[threadIdx.x] = uprefix[c0 >> 5] + ((c0 & 31u) ? (u32)__popc(ubits[c0 >> 5] & ((1u << (c0 & 31u)) - 1u)) : 0u);
 	}
 	const u32 ncells = min(ug.off[L + 1], UFO_UPPER_MAX);
-	for (u32 cell = threadIdx.x; cell < ncells; cell += blockDim.x) {
-		const u32 id = idOf(cell);
-		if (id == NONE) continue;
-		u32 l = 4;
-		while (l < L && cell >= ug.off[l + 1]) ++l;
-		const u32 c = cell - ug.off[l];
-		const u32 x = c % ug.n[l][0], r = c / ug.n[l][0];
-		const i32 ac[3] = {ug.lo[l][0] + (i32)x, ug.lo[l][1] + (i32)(r % ug.n[l][1]), ug.lo[l][2] + (i32)(r / ug.n[l][1])};
-		nk[id] = (1ULL << (3 * (L - l))) | morton3((u32)ac[0], (u32)ac[1], (u32)ac[2]);
-		u32 par = NONE;
-		if (l < L) {
-			const i32 pc[3] = {ac[0] >> 1, ac[1] >> 1, ac[2] >> 1};
-			par = idOf(upperCell(ug, l + 1, pc));
-		}
-		npar[id] = par;
-	}
-	__syncthreads();
-	const u32 U = lstart[L + 1];
 	const u32 max_probe = (t.mask >> 1) + 1;
-	// ---- 2. find or create every block; existing ones are loaded; parents ----
 	u32 n_created = 0;
-	for (u32 i = threadIdx.x; i < U; i += blockDim.x) {
-		const u64 lk = nk[i];
-		bool cr;
-		const u32 s = tableEnsure(t, lk, scan_id, max_probe, &cr, &n_created);
-		nslot[i] = s;
-		ncreated[i] = cr ? 1 : 0;
-		nflags[i] = 0;
-		top[i] = 0;
-		lu_bits[i] = 0;
-		lu_occ[i] = 0.f;
-		dirty[i] = 0;
-		if (s == NONE) {
-			atomicOr(&ctl->err, ERR_TABLE_FULL);
-			continue;
-		}
-		if (!cr) {
-			const float4* po = reinterpret_cast<const float4*>(t.occ(s));
-			const float4 a = po[0], b = po[1];
-			nocc[i][0] = a.x; nocc[i][1] = a.y; nocc[i][2] = a.z; nocc[i][3] = a.w;
-			nocc[i][4] = b.x; nocc[i][5] = b.y; nocc[i][6] = b.z; nocc[i][7] = b.w;
-			nflags[i] = t.flags(s) & ~F_DIRTY;
+	// ---- 2. one thread per active cell: the node's key, parent, block (found or created, loaded) ----
+	{
+		const u32 cell = threadIdx.x;  // (UFO_UPPER_MAX == blockDim.x)
+		const u32 id = cell < ncells ? idOf(cell) : NONE;
+		if (id != NONE) {
+			u32 l = 4;
+			while (l < L && cell >= ug.off[l + 1]) ++l;
+			const u32 c = cell - ug.off[l];
+			const u32 x = c % ug.n[l][0], r = c / ug.n[l][0];
+			const i32 ac[3] = {ug.lo[l][0] + (i32)x, ug.lo[l][1] + (i32)(r % ug.n[l][1]), ug.lo[l][2] + (i32)(r / ug.n[l][1])};
+			const u64 lk = (1ULL << (3 * (L - l))) | morton3((u32)ac[0], (u32)ac[1], (u32)ac[2]);
+			nk[id] = lk;
+			u32 par = NONE;
+			if (l < L) {
+				const i32 pc[3] = {ac[0] >> 1, ac[1] >> 1, ac[2] >> 1};
+				par = idOf(upperCell(ug, l + 1, pc));
+			}
+			npar[id] = par;
+			bool cr;
+			const u32 s = tableEnsure(t, lk, scan_id, max_probe, &cr, &n_created);
+			nslot[id] = s;
+			ncreated[id] = cr ? 1 : 0;
+			top64[id] = 0;
+			out_bits[id] = 0;
+			out_pre[id] = 0.f;
+			dirty[id] = 0;
+			u32 fl = 0;
+			if (s == NONE) {
+				atomicOr(&ctl->err, ERR_TABLE_FULL);
+			} else if (!cr) {
+				const float4* po = reinterpret_cast<const float4*>(t.occ(s));
+				const float4 a = po[0], b = po[1];
+				float4* lo4 = reinterpret_cast<float4*>(nocc[id]);
+				lo4[0] = a;
+				lo4[1] = b;
+				fl = t.flags(s) & ~F_DIRTY;
+			}
+			nflags[id] = fl;
 		}
 	}
 	if (n_created) atomicAdd(&created_total, n_created);
 	__syncthreads();
+	const u32 U = lstart[L + 1];
 	// new blocks inherit the value of the nearest node above that had a block (walk up the list through the new ones)
 	for (u32 i = threadIdx.x; i < U; i += blockDim.x) {
 		if (!ncreated[i] || nslot[i] == NONE) continue;
@@ -1099,37 +1114,25 @@ __global__ __launch_bounds__(512) void k_ftail(Table t, MapGeom g, FastGeo fg, U
 	}
 	__syncthreads();
 	// ---- 3. the tiles hand their level-3 summaries to their level-4 blocks (writeToParent); new tiles are linked ----
-	u32 my_touched = 0, my_nhit = 0, my_created = 0;
-	constexpr u32 CH = 4;  // tiles per thread and sweep: their records are requested together
-	for (u32 t0 = 0; t0 < fg.ntiles; t0 += CH * blockDim.x) {
-		TileRec r[CH];
-		bool on[CH];
+	u32 my_touched = 0, my_created = 0;
+	{
+		TileRec r[MAXT];
 #pragma unroll
-		for (u32 k = 0; k < CH; ++k) {
-			const u32 tile = t0 + k * blockDim.x + threadIdx.x;
-			on[k] = tile < fg.ntiles && 0 != ((tbits[tile >> 5] >> (tile & 31u)) & 1u);
-			if (on[k]) r[k] = recs[tile];
-		}
+		for (u32 k = 0; k < MAXT; ++k)
+			if (cell4[k] != NONE) r[k] = recs[k * blockDim.x + threadIdx.x];  // (requested together)
 #pragma unroll
-		for (u32 k = 0; k < CH; ++k) {
-			if (!on[k] || r[k].seq != scan_id) continue;
-			const u32 tile = t0 + k * blockDim.x + threadIdx.x;
-			u64 lk3;
-			if (!tileKey(g, fg, tile, &lk3, nullptr)) continue;
-			const u32 ci = (u32)(lk3 & 7);
-			const u32 ttx = tile % fg.nt[0], rr = tile / fg.nt[0];
-			const i32 pc[3] = {(fg.tbase[0] + (i32)ttx) >> 1, (fg.tbase[1] + (i32)(rr % fg.nt[1])) >> 1, (fg.tbase[2] + (i32)(rr / fg.nt[1])) >> 1};
-			const u32 cell = upperCell(ug, 4, pc);
-			const u32 n4 = idOf(cell);
-			if (n4 == NONE || n4 >= U) continue;
-			my_touched += r[k].touched;
-			my_nhit += r[k].nhit;
-			my_created += r[k].ncreated;
-			const u32 bits = r[k].bits;
+		for (u32 k = 0; k < MAXT; ++k) {
+			if (cell4[k] == NONE || r[k].seq != scan_id) continue;
+			const u32 tile = k * blockDim.x + threadIdx.x;
+			const u32 n4 = idOf(cell4[k]);
+			if (n4 == NONE) continue;  // (cannot happen: marked above)
+			my_touched += r[k].counts & 255u;
+			my_created += (r[k].counts >> 18) & 127u;
+			const u32 bits = r[k].bits, ci = (bits >> 8) & 7u;
 			if (bits & 64u) t.parent(r[k].slot) = nslot[n4];  // a new level-3 block: its parent link
 			if (bits & 128u) atomicAnd(&nflags[n4], ~(1u << (16 + ci)));
 			else if (bits & 64u) atomicOr(&nflags[n4], 1u << (16 + ci));
-			atomicMax(&top[n4], ci + 1u);
+			atomicMax(&top64[n4], ((unsigned long long)(ci + 1u) << 32) | tile);
 			if (bits & 16u) {
 				const u32 f = nflags[n4];
 				const u32 old_fl = ((f >> ci) & 1u) | (((f >> (8 + ci)) & 1u) << 1), fl = bits & 3u;
@@ -1149,124 +1152,100 @@ __global__ __launch_bounds__(512) void k_ftail(Table t, MapGeom g, FastGeo fg, U
 		// the tiles' bookkeeping: one atomic per wave on words only this workgroup touches
 		for (int o = 32; o > 0; o >>= 1) {
 			my_touched += __shfl_xor(my_touched, o);
-			my_nhit += __shfl_xor(my_nhit, o);
 			my_created += __shfl_xor(my_created, o);
 		}
-		if (0 == (threadIdx.x & 63u)) {
+		if (0 == lane) {
 			if (my_touched) atomicAdd(&ctl->n_entries[0], my_touched);
 			if (my_created) atomicAdd(&created_total, my_created);
 		}
 	}
 	__syncthreads();
-	// who carries the last update beneath a level-4 block: its highest touched tile (records are L2-warm now)
-	for (u32 t0 = 0; t0 < fg.ntiles; t0 += CH * blockDim.x) {
-#pragma unroll
-		for (u32 k = 0; k < CH; ++k) {
-			const u32 tile = t0 + k * blockDim.x + threadIdx.x;
-			if (tile >= fg.ntiles || !((tbits[tile >> 5] >> (tile & 31u)) & 1u)) continue;
-			u64 lk3;
-			if (!tileKey(g, fg, tile, &lk3, nullptr)) continue;
-			const u32 ci = (u32)(lk3 & 7);
-			const u32 ttx = tile % fg.nt[0], rr = tile / fg.nt[0];
-			const i32 pc[3] = {(fg.tbase[0] + (i32)ttx) >> 1, (fg.tbase[1] + (i32)(rr % fg.nt[1])) >> 1, (fg.tbase[2] + (i32)(rr / fg.nt[1])) >> 1};
-			const u32 cell = upperCell(ug, 4, pc);
-			const u32 n4 = idOf(cell);
-			if (n4 == NONE || n4 >= U || ci + 1u != top[n4]) continue;
-			const TileRec r = recs[tile];
-			if (r.seq != scan_id) continue;
-			lu_bits[n4] = ((r.bits & 16u) && (r.bits & 32u) ? 4u : 0u) | ((r.bits >> 2) & 3u);
-			lu_occ[n4] = r.pre_occ;
-		}
+	// who carries the last update beneath a level-4 block: its highest touched tile (the record is L2-warm)
+	for (u32 i = lstart[4] + threadIdx.x; i < lstart[5]; i += blockDim.x) {
+		const unsigned long long tt = top64[i];
+		if (0 == tt) continue;
+		const TileRec r = recs[(u32)tt];
+		out_bits[i] = ((r.bits & 16u) && (r.bits & 32u) ? 4u : 0u) | ((r.bits >> 2) & 3u);  // (parked in the block's own entry until its step)
+		out_pre[i] = r.pre_occ;
 	}
 	__syncthreads();
-	// ---- 4. level by level to the root ----
-	auto step = [&](u32 i, bool have, u32* p_out, u32* ci_out, bool* reach_out, float* pre_out, u32* prefl_out) -> bool {
-		*p_out = NONE;
-		*ci_out = 0;
-		*reach_out = false;
-		*pre_out = 0.f;
-		*prefl_out = 0;
-		if (!have) return false;
-		const u64 lk = nk[i];
-		const u32 p = npar[i], ci = (u32)(lk & 7);
-		*p_out = p;
-		*ci_out = ci;
-		const bool evaluated = 0 != dirty[i];
+	// ---- 4. level by level to the root: lanes 8k .. 8k+7 of a wave take one block, lane = child ----
+	auto step8 = [&](u32 i, bool have, u32 l) -> bool {
+		const u32 sub = lane & 7u;
+		const float v = have ? nocc[i][sub] : 0.f;
+		const bool evaluated = have && 0 != dirty[i];
+		// (all lanes run the shuffles; only the first lane of an evaluated block acts on the results)
+		const unsigned long long tt = have ? top64[i] : 0ull;
+		const u32 tc = (u32)(tt >> 32) - 1u;  // (>= 0 for an evaluated block: it has a touched child)
+		u32 lub = 0;
+		float luo = 0.f;
 		if (evaluated) {
-			const u32 f = nflags[i];
-			float m = nocc[i][0];
-			bool eq = true;
-			for (int c = 1; c < 8; ++c) {
-				m = fmaxf(m, nocc[i][c]);
-				eq = eq && (nocc[i][c] == nocc[i][0]);
-			}
-			const u32 fl = ((f & F_CFREE) ? 1u : 0u) | ((f & F_CUNK) ? 2u : 0u);
-			const u32 tc = top[i] - 1u;  // (top[i] >= 1: a dirty block has a touched child)
-			const bool reached = 0 != (lu_bits[i] & 4u);
-			float pm = m;
-			u32 pfl = fl;
-			if (reached) {
-				// summary with the top child as it was before its last update
-				pm = (0 == tc) ? lu_occ[i] : nocc[i][0];
-				for (u32 c = 1; c < 8; ++c) pm = fmaxf(pm, c == tc ? lu_occ[i] : nocc[i][c]);
-				const u32 fsub = (f & ~((1u << tc) | (1u << (8 + tc)))) | ((lu_bits[i] & 1u) << tc) | (((lu_bits[i] >> 1) & 1u) << (8 + tc));
-				pfl = ((fsub & F_CFREE) ? 1u : 0u) | ((fsub & F_CUNK) ? 2u : 0u);
-			}
-			const bool dead = reached && eq && 0 == (f & F_INNER);
-			if (dead) {
-				atomicOr(&nflags[i], F_DEAD);
-				if (1 != lk) atomicAnd(&nflags[p], ~(1u << (16 + ci)));
-			}
-			if (1 == lk) {
-				t.root->occ = m;
-				t.root->flags = fl;
-			} else {
-				const u32 fp = nflags[p];
-				const u32 old_fl = ((fp >> ci) & 1u) | (((fp >> (8 + ci)) & 1u) << 1);
-				const bool changed = nocc[p][ci] != m || old_fl != fl;
-				nocc[p][ci] = m;
-				if (old_fl != fl) {
-					const u32 setm = ((fl & 1u) << ci) | (((fl >> 1) & 1u) << (8 + ci));
-					const u32 clrm = ((1u << ci) | (1u << (8 + ci))) & ~setm;
-					if (setm) atomicOr(&nflags[p], setm);
-					if (clrm) atomicAnd(&nflags[p], ~clrm);
+			const u32 who = (4u == l) ? i : (u32)tt;  // level 4: parked in the block's own entry by the tile pass
+			lub = out_bits[who];
+			luo = out_pre[who];
+		}
+		const bool reached = 0 != (lub & 4u);
+		const float m = grpMax(v, 0);
+		const bool eq = grpAllEq(v, 0, lane);
+		const float pm = grpMax((reached && sub == tc) ? luo : v, 0);
+		if (have && 0 == sub) {
+			const u64 lk = nk[i];
+			const u32 p = npar[i], ci = (u32)(lk & 7);
+			u32 ob = 0;
+			float op = 0.f;
+			if (evaluated) {
+				const u32 f = nflags[i];
+				const u32 fl = ((f & F_CFREE) ? 1u : 0u) | ((f & F_CUNK) ? 2u : 0u);
+				u32 pfl = fl;
+				if (reached) {
+					// summary with the top child as it was before its last update
+					const u32 fsub = (f & ~((1u << tc) | (1u << (8 + tc)))) | ((lub & 1u) << tc) | (((lub >> 1) & 1u) << (8 + tc));
+					pfl = ((fsub & F_CFREE) ? 1u : 0u) | ((fsub & F_CUNK) ? 2u : 0u);
 				}
-				*reach_out = reached && !(pm == m && pfl == fl);
-				*pre_out = pm;
-				*prefl_out = pfl;
-				if (changed || *reach_out) dirty[p] = 1;
+				const bool dead = reached && eq && 0 == (f & F_INNER);
+				if (dead) {
+					atomicOr(&nflags[i], F_DEAD);
+					if (1 != lk) atomicAnd(&nflags[p], ~(1u << (16 + ci)));
+				}
+				if (1 == lk) {
+					t.root->occ = m;
+					t.root->flags = fl;
+				} else {
+					const u32 fp = nflags[p];
+					const u32 old_fl = ((fp >> ci) & 1u) | (((fp >> (8 + ci)) & 1u) << 1);
+					const bool changed = nocc[p][ci] != m || old_fl != fl;
+					nocc[p][ci] = m;
+					if (old_fl != fl) {
+						const u32 setm = ((fl & 1u) << ci) | (((fl >> 1) & 1u) << (8 + ci));
+						const u32 clrm = ((1u << ci) | (1u << (8 + ci))) & ~setm;
+						if (setm) atomicOr(&nflags[p], setm);
+						if (clrm) atomicAnd(&nflags[p], ~clrm);
+					}
+					const bool reach_out = reached && !((reached ? pm : m) == m && pfl == fl);
+					ob = (reach_out ? 4u : 0u) | (pfl & 3u);
+					op = reached ? pm : m;
+					if (changed || reach_out) dirty[p] = 1;
+				}
 			}
+			// what the parent needs if this block turns out to be its highest touched child
+			out_bits[i] = ob;
+			out_pre[i] = op;
+			if (p != NONE) atomicMax(&top64[p], ((unsigned long long)(ci + 1u) << 32) | i);  // the time of the last update travels up whether or not the block was evaluated
 		}
-		if (p != NONE) atomicMax(&top[p], ci + 1u);  // the time of the last update travels up whether or not the block was evaluated
 		return evaluated;
-	};
-	auto publish = [&](bool have, u32 p, u32 ci, bool reach, float pre, u32 prefl) {
-		if (have && p != NONE && ci + 1u == top[p]) {
-			lu_bits[p] = (reach ? 4u : 0u) | (prefl & 3u);
-			lu_occ[p] = pre;
-		}
 	};
 	u32 l = 4;
 	for (; l <= L; ++l) {
 		const u32 lo = lstart[l], hi = lstart[l + 1];
-		if (hi - lo <= 64u) break;  // (levels only get narrower towards the root)
-		if (0 == threadIdx.x) any_dirty = 0;
-		__syncthreads();
-		// (a wide level can hold more blocks than the workgroup has threads: two sweeps with the barrier pair around both)
-		u32 p[2], ci[2], prefl[2];
-		bool reach[2], have[2], ev = false;
-		float pre[2];
-		for (int k = 0; k < 2; ++k) {
-			const u32 idx = lo + threadIdx.x + (u32)k * blockDim.x;
-			have[k] = idx < hi;
-			ev |= step(idx, have[k], &p[k], &ci[k], &reach[k], &pre[k], &prefl[k]);
+		if (hi - lo <= 8u) break;  // (levels only get narrower towards the root)
+		bool ev = false;
+		for (u32 i0 = lo; i0 < hi; i0 += blockDim.x >> 3) {
+			const u32 i = i0 + (threadIdx.x >> 3);
+			ev |= step8(i, i < hi, l);
 		}
-		if (ev) any_dirty = 1;
+		if (ev) lvl_dirty[l] = 1;
 		__syncthreads();
-		for (int k = 0; k < 2; ++k) publish(have[k], p[k], ci[k], reach[k], pre[k], prefl[k]);
-		const bool stop = 0 == any_dirty;
-		__syncthreads();
-		if (stop) {
+		if (0 == lvl_dirty[l]) {
 			l = L + 1;  // nothing was re-evaluated on this level: nothing above can change
 			break;
 		}
@@ -1274,16 +1253,9 @@ __global__ __launch_bounds__(512) void k_ftail(Table t, MapGeom g, FastGeo fg, U
 	if (threadIdx.x < 64u) {
 		for (; l <= L; ++l) {
 			const u32 lo = lstart[l], hi = lstart[l + 1];
-			const u32 idx = lo + threadIdx.x;
-			const bool have = idx < hi;
-			u32 p, ci, prefl;
-			bool reach;
-			float pre;
-			const bool ev = step(idx, have, &p, &ci, &reach, &pre, &prefl);
+			const u32 i = lo + (lane >> 3);
+			const bool ev = step8(i, i < hi, l);
 			if (0 == __ballot(ev)) break;  // nothing was re-evaluated on this level: nothing above can change
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-			publish(have, p, ci, reach, pre, prefl);
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 		}
@@ -1294,14 +1266,14 @@ __global__ __launch_bounds__(512) void k_ftail(Table t, MapGeom g, FastGeo fg, U
 		const u32 s = nslot[i];
 		if (s == NONE) continue;
 		float4* po = reinterpret_cast<float4*>(t.occ(s));
-		po[0] = make_float4(nocc[i][0], nocc[i][1], nocc[i][2], nocc[i][3]);
-		po[1] = make_float4(nocc[i][4], nocc[i][5], nocc[i][6], nocc[i][7]);
+		const float4* li = reinterpret_cast<const float4*>(nocc[i]);
+		po[0] = li[0];
+		po[1] = li[1];
 		t.flags(s) = nflags[i];
 		if (ncreated[i]) t.parent(s) = (npar[i] != NONE) ? nslot[npar[i]] : NONE;
 	}
 	// this kernel is the tile bitmap's last reader: leave it empty for the set's next scan
 	for (u32 j = threadIdx.x; j < nwords; j += blockDim.x) tile_bits[j] = 0;
-	if (threadIdx.x < UFO_UPPER_MAX / 32) upper_bits[threadIdx.x] = 0;
 	if (0 == threadIdx.x) {
 		u32 used = __hip_atomic_load(&t.root->used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		if (created_total) {
@@ -1318,7 +1290,7 @@ __global__ __launch_bounds__(256) void k_fhitcodes(MapGeom g, FastGeo fg, const 
 {
 	const u32 lane = threadIdx.x & 63u;
 	const u32 tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-	if (tile >= fg.ntiles || recs[tile].seq != scan_id || 0 == recs[tile].nhit) return;
+	if (tile >= fg.ntiles || recs[tile].seq != scan_id || 0 == tileRecHits(recs[tile])) return;
 	u64 lk3;
 	if (!tileKey(g, fg, tile, &lk3, nullptr)) return;
 	const u32 hm = tile_hmask[(size_t)tile * 64u + lane];

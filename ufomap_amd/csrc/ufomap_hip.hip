@@ -917,8 +917,7 @@ int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, si
 		ProfScope ps(m, "k_fmerge");
 		const u32 n4 = (u32)(fg.gr.bytes >> 4);
 		hipLaunchKernelGGL(k_fmerge, dim3(std::min<u32>((n4 + 63) / 64, 1024) + 1u), dim3(1024), 0, m->cs, fg, m->b_slabs.as<uint4>(), nwg, n4,
-		                   m->b_gridM.as<uint4>(), sp, m->b_tilebits.as<u32>(), m->ugeo, m->g.L, m->b_upperbits.as<u32>(), m->b_part1.as<BoxPartial>(),
-		                   gp.x, ctl);
+		                   m->b_gridM.as<uint4>(), sp, m->b_tilebits.as<u32>(), m->b_part1.as<BoxPartial>(), gp.x, ctl);
 	}
 	HIP_TRY(hipGetLastError());
 	++m->n_fast;
@@ -957,7 +956,7 @@ int fastMapPhase(ufomap_map* m, const ScanCtl* prev, u64 extra_used, u32 headroo
 	}
 	{
 		ProfScope ps(m, "k_ftail");
-		hipLaunchKernelGGL(k_ftail, dim3(1), dim3(512), 0, m->cs, m->t, m->g, fg, m->ugeo, m->b_tilebits.as<u32>(), m->b_upperbits.as<u32>(),
+		hipLaunchKernelGGL(k_ftail, dim3(1), dim3(UFO_FTAIL_THREADS), 0, m->cs, m->t, m->g, fg, m->ugeo, m->b_tilebits.as<u32>(),
 		                   m->b_tilerec.as<TileRec>(), m->scan_id, ctl, prev);
 	}
 	HIP_TRY(hipGetLastError());
