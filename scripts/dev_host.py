@@ -1,28 +1,27 @@
-"""Dev: is the pipelined insert host-bound? Per-call host time vs step time."""
+"""Host time inside the insert call (pipelined, HBM-resident clouds): is the host or the GPU the limiter?"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from ufomap_amd import OccupancyMap, scans
-origin, xyz, _ = scans.lidar64()
-n = xyz.shape[0]
-d = torch.from_numpy(xyz).cuda()
-import sys as _s
-m = OccupancyMap(0.16)
-for kv in _s.argv[1:]:
-    k, v = kv.split("=")
-    m.set_option(k, int(v))
-for _ in range(30):
-    m.insert_device(origin, d.data_ptr(), None, n, 20.0, 0, discrete=True, async_=True)
-m.insertPointCloudWait()
-ts = []
+clouds = []
+for p in range(8):
+    origin, xyz, _ = scans.lidar64(origin=scans.lidar_pose(p), seed=100 + p)
+    clouds.append((origin, torch.from_numpy(xyz).cuda(), xyz.shape[0]))
+g = OccupancyMap(0.16)
+for rep in range(3):
+    for i in range(48):
+        o, d, n = clouds[i % 8]
+        g.insert_device(o, d.data_ptr(), None, n, 20.0, 0, discrete=True, async_=True)
+g.insertPointCloudWait()
+d0 = g.debug()
 t0 = time.perf_counter()
-for _ in range(400):
-    a = time.perf_counter()
-    m.insert_device(origin, d.data_ptr(), None, n, 20.0, 0, discrete=True, async_=True)
-    ts.append(time.perf_counter() - a)
-m.insertPointCloudWait()
-tot = (time.perf_counter() - t0) / 400
-ts = np.array(ts) * 1e6
-print("step us", round(tot * 1e6, 1), "call us: median", round(float(np.median(ts)), 1), "p10", round(float(np.percentile(ts, 10)), 1), "p90", round(float(np.percentile(ts, 90)), 1))
-# how long does the GPU need when everything is queued? enqueue-only cost: time N calls with spec but without waiting... (call includes the join)
-print("replays / spec used / repeats:", m.debug()[61:64])
+N = 480
+for i in range(N):
+    o, d, n = clouds[i % 8]
+    g.insert_device(o, d.data_ptr(), None, n, 20.0, 0, discrete=True, async_=True)
+t1 = time.perf_counter()
+g.insertPointCloudWait()
+t2 = time.perf_counter()
+d1 = g.debug()
+h = [(d1[52 + k] - d0[52 + k]) / N / 1000.0 for k in range(4)]
+print(f"per scan: wall {1e6 * (t2 - t0) / N:.1f} us (call loop {1e6 * (t1 - t0) / N:.1f} us); inside doInsert: scan enqueue {h[0]:.1f}, map enqueue {h[1]:.1f}, join {h[2]:.1f}, total {h[3]:.1f} us")

@@ -183,7 +183,8 @@ __global__ __launch_bounds__(512) void k_fcast(MapGeom g, FastGeo fg, D3 sensor,
                                                unsigned long long* __restrict__ steps_part, Ingest ing)
 {
 	extern __shared__ __attribute__((aligned(16))) u32 lds[];
-	if (ctl_in->err) return;  // the scan does not fit the predicted grid (k_fhits): it will be repeated (uniform exit)
+	const u32 err_in = ctl_in->err;  // (looked at once the LDS grid has been cleared: the load is in flight meanwhile)
+	if (0 == (threadIdx.x | blockIdx.x)) ctl->dbg[30] = wall_clock64();  // (diagnostics)
 	const Grid& gr = fg.gr;
 	const u32 depth = 0;
 	const u32 lds_words = (u32)(gr.bytes >> 2);
@@ -199,6 +200,7 @@ __global__ __launch_bounds__(512) void k_fcast(MapGeom g, FastGeo fg, D3 sensor,
 		sh[24] = 0;
 		sh[25] = 0;
 	}
+	if (err_in) return;  // the scan does not fit the predicted grid (k_fhits): it will be repeated (uniform exit)
 	__syncthreads();
 	const u32 rowBits = fg.rowBits, planeBits = fg.planeBits;
 	const u32 lim = 1u << (g.L - depth);
@@ -206,6 +208,7 @@ __global__ __launch_bounds__(512) void k_fcast(MapGeom g, FastGeo fg, D3 sensor,
 	const u32 nwaves = min(8u, (blockDim.x + 63u) >> 6);
 	unsigned long long steps = 0;
 	u32 err = 0, oob = 0;
+	if (0 == (threadIdx.x | blockIdx.x)) ctl->dbg[31] = wall_clock64();  // (diagnostics)
 	// ---- 0. head loop on this workgroup's points; surviving ray ends -> ray_scratch[blockIdx.x * cap_wg ...] ----
 	{
 		const u32 pts = (n > blockIdx.x) ? (n - blockIdx.x + gridDim.x - 1) / gridDim.x : 0u;
@@ -241,6 +244,7 @@ __global__ __launch_bounds__(512) void k_fcast(MapGeom g, FastGeo fg, D3 sensor,
 	}
 	__syncthreads();
 	const u32 mine = min(sh[24], cap_wg);
+	if (0 == (threadIdx.x | blockIdx.x)) ctl->dbg[32] = wall_clock64();  // (diagnostics)
 	if (0 == threadIdx.x) {
 		// per-workgroup partials, folded by k_fmerge (256 workgroups adding to one word serialise at ~12 ns each)
 		steps_part[gridDim.x + blockIdx.x] = mine;
@@ -285,6 +289,7 @@ __global__ __launch_bounds__(512) void k_fcast(MapGeom g, FastGeo fg, D3 sensor,
 				hd[t].tm[2] = r.tm[2];
 			}
 		}
+		if (0 == (threadIdx.x | blockIdx.x)) ctl->dbg[33] = wall_clock64();  // (diagnostics)
 		// ---- 2. segment length for this round: about K steps, and the queue must hold every segment ----
 		u32 tot = l1, cntr = (2 == status) ? 1u : 0u;
 		for (int o = 32; o > 0; o >>= 1) {
@@ -336,6 +341,7 @@ __global__ __launch_bounds__(512) void k_fcast(MapGeom g, FastGeo fg, D3 sensor,
 		}
 		for (u32 si = threadIdx.x; si < nsegs; si += blockDim.x) q[si].lin = 0;  // cut cells are summed up from two lanes
 		__syncthreads();
+		if (0 == (threadIdx.x | blockIdx.x)) ctl->dbg[34] = wall_clock64();  // (diagnostics)
 		// ---- 3. cut states from the three independent addition chains (k_dda_seg), two lanes per ray ----
 		for (u32 idx = threadIdx.x; idx < 2u * UFO_CAST_BATCH; idx += blockDim.x) {
 			const u32 ry = idx & (UFO_CAST_BATCH - 1u), role = idx / UFO_CAST_BATCH;
@@ -398,6 +404,7 @@ __global__ __launch_bounds__(512) void k_fcast(MapGeom g, FastGeo fg, D3 sensor,
 		for (u32 si = threadIdx.x; si + 1u < nsegs; si += blockDim.x)
 			if (!(q[si + 1u].ray & 0x80000000u)) q[si].end = q[si + 1u].lin;
 		__syncthreads();
+		if (0 == (threadIdx.x | blockIdx.x)) ctl->dbg[35] = wall_clock64();  // (diagnostics)
 		// ---- 4. every lane walks segments ----
 		for (u32 si = threadIdx.x; si < nsegs; si += blockDim.x) {
 			const SegRec rec = q[si];
@@ -438,15 +445,18 @@ __global__ __launch_bounds__(512) void k_fcast(MapGeom g, FastGeo fg, D3 sensor,
 		}
 	}
 	__syncthreads();
+	if (0 == (threadIdx.x | blockIdx.x)) ctl->dbg[36] = wall_clock64();  // (diagnostics)
 	{
 		const uint4* l4 = reinterpret_cast<const uint4*>(lds);
 		uint4* out4 = reinterpret_cast<uint4*>(slabs) + (size_t)blockIdx.x * (lds_words >> 2);
 		const u32 n4 = lds_words >> 2;
 		for (u32 j = threadIdx.x; j < n4; j += blockDim.x) out4[j] = l4[j];
 	}
+	if (0 == (threadIdx.x | blockIdx.x)) ctl->dbg[37] = wall_clock64();  // (diagnostics)
 	blockStoreSteps(steps, steps_part);
 	if (oob) atomicAdd(&ctl->n_oob, oob);
 	if (err) atomicOr(&ctl->err, err);
+	if (0 == (threadIdx.x | blockIdx.x)) ctl->dbg[38] = wall_clock64();  // (diagnostics)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -598,9 +608,12 @@ struct UpperGeo {
 };
 __host__ __device__ inline u32 upperCell(const UpperGeo& ug, u32 l, const i32 c[3])
 {
-	const i32 x = c[0] - ug.lo[l][0], y = c[1] - ug.lo[l][1], z = c[2] - ug.lo[l][2];
-	if (x < 0 || y < 0 || z < 0 || (u32)x >= ug.n[l][0] || (u32)y >= ug.n[l][1] || (u32)z >= ug.n[l][2]) return 0xFFFFFFFFu;
-	return ug.off[l] + (u32)x + ug.n[l][0] * ((u32)y + ug.n[l][1] * (u32)z);
+	// (no short-circuit evaluation: with a uniform level the seven words are scalar loads, and a chain of branches would
+	// wait for them one at a time -- measured: 650 cycles per call in k_ftail's marking loop)
+	const u32 n0 = ug.n[l][0], n1 = ug.n[l][1], n2 = ug.n[l][2], off = ug.off[l];
+	const u32 x = (u32)(c[0] - ug.lo[l][0]), y = (u32)(c[1] - ug.lo[l][1]), z = (u32)(c[2] - ug.lo[l][2]);  // (negative: huge)
+	const bool inside = (x < n0) & (y < n1) & (z < n2);
+	return inside ? off + x + n0 * (y + n1 * z) : 0xFFFFFFFFu;
 }
 // ------------------------------------------------------------------------------------------------
 // Tree update, part 1 (k_tile): one wavefront per active depth-3 tile. Lane l owns the level-1 node block whose 6-bit
@@ -680,13 +693,12 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 	const u32 lane = threadIdx.x & 63u;
 	const u32 tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
 	if (tile >= fg.ntiles) return;
+	// three words can end the wave here; they are asked for together (a wave's time is its chain of dependent round trips)
 	const u32 tword = tile_bits[tile >> 5];
-	if (prev && prev->err) {
-		// the update enqueued just before this one flagged itself and left the map alone: this one stands back too
-		// (k_ftail raises ERR_PREV for the host); uniform
-		return;
-	}
-	if (ctl->err) return;  // raised by the scan half (k_fhits / k_fcast), i.e. before anything touched the map; uniform
+	const u32 perr = (prev ? prev : ctl)->err;  // the update enqueued just before this one flagged itself and left the map alone:
+	                                            // this one stands back too (k_ftail raises ERR_PREV for the host)
+	const u32 cerr = ctl->err;                  // raised by the scan half (k_fhits / k_fcast), i.e. before anything touched the map
+	if (perr | cerr) return;                    // (uniform)
 	if (!((tword >> (tile & 31u)) & 1u)) return;
 	u64 lk3;
 	u32 tt[3];
@@ -975,7 +987,8 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 #define UFO_FTAIL_THREADS 1024
 static_assert(UFO_FTAIL_THREADS == UFO_UPPER_MAX, "k_ftail: one thread per cell of the dense grids above the tiles");
 __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g, FastGeo fg, UpperGeo ugp, u32* __restrict__ tile_bits,
-                                                             const TileRec* __restrict__ recs, u32 scan_id, ScanCtl* ctl, const ScanCtl* prev)
+                                                             const TileRec* __restrict__ recs, u32 scan_id, ScanCtl* ctl, const ScanCtl* prev,
+                                                             ScanCtl* host_result, const ScanCtl* ctl_init)
 {
 	__shared__ UpperGeo ug;
 	__shared__ u32 tbits[UFO_FAST_MAX_TILES / 32], ubits[UFO_UPPER_MAX / 32], uprefix[UFO_UPPER_MAX / 32 + 1];
@@ -985,46 +998,85 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 	__shared__ float nocc[UFO_UPPER_MAX][8], out_pre[UFO_UPPER_MAX];
 	__shared__ uint8_t dirty[UFO_UPPER_MAX], ncreated[UFO_UPPER_MAX];
 	__shared__ u32 lstart[26], lvl_dirty[26], created_total;
-	if (prev && prev->err) {
-		// the update enqueued just before this one flagged itself and left the map alone: this one stood back too (k_tile)
-		if (0 == threadIdx.x) atomicOr(&ctl->err, ERR_PREV);
-		return;
-	}
-	if (ctl->err) return;  // the scan stood back (ERR_SPEC / a bound): the map is as it was
-	const u32 L = g.L;
+	// one copy of the activity bitmap per wavefront while it is being filled: LDS atomics of one instruction that hit the same
+	// word are executed one lane after the other, and here nearly all lanes do (neighbouring cells, common ancestors) --
+	// with a shared copy the 16 waves would queue behind one another on top (measured: 5.5 us for 12 levels)
+	__shared__ u32 wbits[UFO_FTAIL_THREADS / 64][UFO_UPPER_MAX / 32];
 	const u32 nwords = (fg.ntiles + 31u) / 32u;
+	{
+		// (one round of loads: the two error words and the tile bitmap)
+		const u32 perr = prev ? prev->err : 0u, cerr = ctl->err;
+		for (u32 j = threadIdx.x; j < nwords; j += blockDim.x) tbits[j] = tile_bits[j];
+		if (perr) {
+			// the update enqueued just before this one flagged itself and left the map alone: this one stood back too (k_tile)
+			if (0 == threadIdx.x) host_result->err = atomicOr(&ctl->err, ERR_PREV) | ERR_PREV;
+			return;
+		}
+		if (cerr) {  // the scan stood back (ERR_SPEC / a bound): the map is as it was
+			if (0 == threadIdx.x) host_result->err = cerr;
+			return;
+		}
+	}
+	if (0 == threadIdx.x) ctl->dbg[10] = wall_clock64();  // (diagnostics: ufomap_map_debug)
+	const u32 L = g.L;
 	const u32 lane = threadIdx.x & 63u;
-	for (u32 j = threadIdx.x; j < nwords; j += blockDim.x) tbits[j] = tile_bits[j];
-	if (threadIdx.x < UFO_UPPER_MAX / 32) ubits[threadIdx.x] = 0;
+	for (u32 j = threadIdx.x; j < (UFO_FTAIL_THREADS / 64) * (UFO_UPPER_MAX / 32); j += blockDim.x) (&wbits[0][0])[j] = 0;
 	if (threadIdx.x >= 64u && threadIdx.x < 64u + sizeof(UpperGeo) / 4u) reinterpret_cast<u32*>(&ug)[threadIdx.x - 64u] = reinterpret_cast<const u32*>(&ugp)[threadIdx.x - 64u];
 	if (threadIdx.x < 26u) lvl_dirty[threadIdx.x] = 0;
 	if (0 == threadIdx.x) created_total = 0;
 	__syncthreads();
+	if (0 == threadIdx.x) ctl->dbg[11] = wall_clock64();  // (diagnostics: ufomap_map_debug)
 	// ---- 1. the active cells become the node list ----
 	constexpr u32 MAXT = UFO_FAST_MAX_TILES / UFO_FTAIL_THREADS;  // tiles per thread: tile = k * blockDim + thread
 	u32 cell4[MAXT];  // the level-4 parent's cell of the thread's tiles (NONE: tile not active)
+	// (two phases, no atomic whose result anybody waits for: a walk "up until somebody else has been here" is a chain of
+	// dependent LDS round trips per level, and at the start nobody has been anywhere)
 #pragma unroll
 	for (u32 k = 0; k < MAXT; ++k) {
 		const u32 tile = k * blockDim.x + threadIdx.x;
 		cell4[k] = NONE;
 		if (tile >= fg.ntiles || !((tbits[tile >> 5] >> (tile & 31u)) & 1u)) continue;
 		const u32 ttx = tile % fg.nt[0], rr = tile / fg.nt[0];
-		i32 c[3] = {fg.tbase[0] + (i32)ttx, fg.tbase[1] + (i32)(rr % fg.nt[1]), fg.tbase[2] + (i32)(rr / fg.nt[1])};
+		const i32 c[3] = {fg.tbase[0] + (i32)ttx, fg.tbase[1] + (i32)(rr % fg.nt[1]), fg.tbase[2] + (i32)(rr / fg.nt[1])};
 		const i32 lim = (i32)(1u << (L - 3u));
 		if (c[0] < 0 || c[1] < 0 || c[2] < 0 || c[0] >= lim || c[1] >= lim || c[2] >= lim) continue;  // (outside the key range: k_tile skipped it, too)
-		for (u32 l = 4; l <= L; ++l) {
-			c[0] >>= 1;
-			c[1] >>= 1;
-			c[2] >>= 1;
-			const u32 cell = upperCell(ug, l, c);
-			if (4u == l) cell4[k] = cell;
-			if (cell >= UFO_UPPER_MAX || ((atomicOr(&ubits[cell >> 5], 1u << (cell & 31u)) >> (cell & 31u)) & 1u)) break;  // (already there: so are its ancestors)
+		const i32 pc[3] = {c[0] >> 1, c[1] >> 1, c[2] >> 1};
+		const u32 cell = upperCell(ugp, 4, pc);  // (geometry with a uniform index: scalar loads from the kernel arguments)
+		if (cell >= UFO_UPPER_MAX) continue;
+		cell4[k] = cell;
+		__hip_atomic_fetch_or(&wbits[threadIdx.x >> 6][cell >> 5], 1u << (cell & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+	}
+	__syncthreads();
+	if (0 == threadIdx.x) ctl->dbg[21] = wall_clock64();
+	{
+		// every active level-4 cell marks its ancestors, level 5 .. L
+		const u32 cell = threadIdx.x;
+		const u32 n4 = min(ugp.off[5], UFO_UPPER_MAX);
+		u32 seen = 0;
+		if (cell < n4)
+			for (u32 w = 0; w < UFO_FTAIL_THREADS / 64; ++w) seen |= wbits[w][cell >> 5];
+		if ((seen >> (cell & 31u)) & 1u) {
+			const u32 x = cell % ugp.n[4][0], r = cell / ugp.n[4][0];
+			i32 c[3] = {ugp.lo[4][0] + (i32)x, ugp.lo[4][1] + (i32)(r % ugp.n[4][1]), ugp.lo[4][2] + (i32)(r / ugp.n[4][1])};
+			for (u32 l = 5; l <= L; ++l) {
+				c[0] >>= 1;
+				c[1] >>= 1;
+				c[2] >>= 1;
+				const u32 up = upperCell(ugp, l, c);  // (uniform level: scalar loads; measured faster than the LDS copy, 2.8 vs 4.3 us)
+				if (up < UFO_UPPER_MAX) __hip_atomic_fetch_or(&wbits[threadIdx.x >> 6][up >> 5], 1u << (up & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			}
 		}
 	}
 	__syncthreads();
+	if (0 == threadIdx.x) ctl->dbg[22] = wall_clock64();
 	if (threadIdx.x < 64u) {
-		// prefix popcount over the bitmap's 32 words
-		const u32 c = (lane < UFO_UPPER_MAX / 32) ? (u32)__popc(ubits[lane]) : 0u;
+		// the waves' copies become one bitmap; prefix popcount over its 32 words
+		u32 word = 0;
+		if (lane < UFO_UPPER_MAX / 32) {
+			for (u32 w = 0; w < UFO_FTAIL_THREADS / 64; ++w) word |= wbits[w][lane];
+			ubits[lane] = word;
+		}
+		const u32 c = (u32)__popc(word);
 		u32 incl = c;
 		for (int o = 1; o < 64; o <<= 1) {
 			const u32 v = __shfl_up(incl, o);
@@ -1033,6 +1085,7 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 		if (lane <= UFO_UPPER_MAX / 32) uprefix[lane] = incl - c;
 	}
 	__syncthreads();
+	if (0 == threadIdx.x) ctl->dbg[12] = wall_clock64();  // (diagnostics: ufomap_map_debug)
 	auto idOf = [&](u32 cell) -> u32 {  // node of a dense cell (NONE: not active)
 		if (cell >= UFO_UPPER_MAX) return NONE;
 		const u32 w = ubits[cell >> 5], b = cell & 31u;
@@ -1041,10 +1094,10 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 	};
 	if (threadIdx.x <= L + 1u && threadIdx.x >= 4u) {
 		// nodes of level l are [lstart[l], lstart[l+1]): the cells below off[l] that are active
-		const u32 c0 = min(ug.off[threadIdx.x], UFO_UPPER_MAX);
+		const u32 c0 = min(ug.off[threadIdx.x], UFO_UPPER_MAX);  // (divergent index: the LDS copy)
 		lstart[threadIdx.x] = uprefix[c0 >> 5] + ((c0 & 31u) ? (u32)__popc(ubits[c0 >> 5] & ((1u << (c0 & 31u)) - 1u)) : 0u);
 	}
-	const u32 ncells = min(ug.off[L + 1], UFO_UPPER_MAX);
+	const u32 ncells = min(ugp.off[L + 1], UFO_UPPER_MAX);
 	const u32 max_probe = (t.mask >> 1) + 1;
 	u32 n_created = 0;
 	// ---- 2. one thread per active cell: the node's key, parent, block (found or created, loaded) ----
@@ -1053,7 +1106,7 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 		const u32 id = cell < ncells ? idOf(cell) : NONE;
 		if (id != NONE) {
 			u32 l = 4;
-			while (l < L && cell >= ug.off[l + 1]) ++l;
+			for (u32 k = 5; k <= L; ++k) l += (cell >= ug.off[k]) ? 1u : 0u;  // (levels are consecutive ranges of cells)
 			const u32 c = cell - ug.off[l];
 			const u32 x = c % ug.n[l][0], r = c / ug.n[l][0];
 			const i32 ac[3] = {ug.lo[l][0] + (i32)x, ug.lo[l][1] + (i32)(r % ug.n[l][1]), ug.lo[l][2] + (i32)(r / ug.n[l][1])};
@@ -1089,6 +1142,7 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 	}
 	if (n_created) atomicAdd(&created_total, n_created);
 	__syncthreads();
+	if (0 == threadIdx.x) ctl->dbg[13] = wall_clock64();  // (diagnostics: ufomap_map_debug)
 	const u32 U = lstart[L + 1];
 	// new blocks inherit the value of the nearest node above that had a block (walk up the list through the new ones)
 	for (u32 i = threadIdx.x; i < U; i += blockDim.x) {
@@ -1113,6 +1167,7 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 		if (npar[i] != NONE) atomicOr(&nflags[npar[i]], 1u << (16 + (u32)(nk[i] & 7)));
 	}
 	__syncthreads();
+	if (0 == threadIdx.x) ctl->dbg[14] = wall_clock64();  // (diagnostics: ufomap_map_debug)
 	// ---- 3. the tiles hand their level-3 summaries to their level-4 blocks (writeToParent); new tiles are linked ----
 	u32 my_touched = 0, my_created = 0;
 	{
@@ -1160,6 +1215,7 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 		}
 	}
 	__syncthreads();
+	if (0 == threadIdx.x) ctl->dbg[15] = wall_clock64();  // (diagnostics: ufomap_map_debug)
 	// who carries the last update beneath a level-4 block: its highest touched tile (the record is L2-warm)
 	for (u32 i = lstart[4] + threadIdx.x; i < lstart[5]; i += blockDim.x) {
 		const unsigned long long tt = top64[i];
@@ -1169,6 +1225,7 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 		out_pre[i] = r.pre_occ;
 	}
 	__syncthreads();
+	if (0 == threadIdx.x) ctl->dbg[16] = wall_clock64();  // (diagnostics: ufomap_map_debug)
 	// ---- 4. level by level to the root: lanes 8k .. 8k+7 of a wave take one block, lane = child ----
 	auto step8 = [&](u32 i, bool have, u32 l) -> bool {
 		const u32 sub = lane & 7u;
@@ -1250,6 +1307,7 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 			break;
 		}
 	}
+	if (0 == threadIdx.x) ctl->dbg[17] = wall_clock64();  // (diagnostics: ufomap_map_debug)
 	if (threadIdx.x < 64u) {
 		for (; l <= L; ++l) {
 			const u32 lo = lstart[l], hi = lstart[l + 1];
@@ -1261,6 +1319,7 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 		}
 	}
 	__syncthreads();
+	if (0 == threadIdx.x) ctl->dbg[18] = wall_clock64();  // (diagnostics: ufomap_map_debug)
 	// ---- 5. every block back to the table, once ----
 	for (u32 i = threadIdx.x; i < U; i += blockDim.x) {
 		const u32 s = nslot[i];
@@ -1280,7 +1339,23 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 			used = atomicAdd(&t.root->used, created_total) + created_total;
 			atomicAdd(&ctl->ph[0].n_new, created_total);
 		}
+		ctl->dbg[19] = wall_clock64();
+		ctl->dbg[20] = U | ((unsigned long long)l << 32);
 		ctl->used_now = used;  // the host's view of the table's fill
+	}
+	// The finished control block goes to the host's pinned copy from here (no read-back copy, no stream synchronisation on
+	// the host: it waits for this launch's event and reads), and the device copy returns to the start state of a scan
+	// (no upload before the set's next scan). An update that flagged an error has left above: the host falls back to copies.
+	__syncthreads();
+	{
+		u32* dev = reinterpret_cast<u32*>(ctl);
+		u32* host = reinterpret_cast<u32*>(host_result);
+		const u32* init = reinterpret_cast<const u32*>(ctl_init);
+		const u32 e = __hip_atomic_load(&ctl->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		for (u32 w = threadIdx.x; w < sizeof(ScanCtl) / 4u; w += blockDim.x) {
+			host[w] = __hip_atomic_load(&dev[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (0 == e) dev[w] = init[w];  // (an error raised in this very kernel, ERR_TABLE_FULL, stays for the successor to see)
+		}
 	}
 }
 

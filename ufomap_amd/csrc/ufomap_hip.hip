@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstring>
 #include <sstream>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -126,13 +127,15 @@ struct ScanArgs {
 struct HandOver {
 	DevBuf b_ctl, b_entries, b_hh_keys, b_in_xyz, b_in_rgb;  // b_hh_keys: hit hash, keys followed by point indices
 	// what the tree update of a fast-path scan (fast_kernels.h) reads after the scan half has moved on to the next scan
-	DevBuf b_gridM, b_part1, b_hit_code, b_first, b_tilebits, b_upperbits;
+	DevBuf b_gridM, b_part1, b_hit_code, b_first, b_tilebits;
 	uint64_t seq = 0;         // running number of the integration that uses this set
 	bool first_dirty = true;  // b_first / b_tilebits are left clean by k_tile / k_ftail unless the scan stood back
 	bool fast = false;        // the integration that uses this set runs on the fast path
 	FastGeo fgeo{};
 	UpperGeo ugeo{};
 	ScanCtl* h_ctl = nullptr;  // pinned
+	ScanCtl* h_res = nullptr;  // pinned: the finished control block as k_ftail stored it
+	bool ctl_clean = false;    // b_ctl holds the fast path's start state
 	void* h_stage = nullptr;   // pinned staging of a pageable host cloud (ufomap_map_insert): filled by the host, drained by
 	size_t h_stage_cap = 0;    // an asynchronous H2D copy on the scan stream; free again once the set's integration is joined
 	u32 hh_mask = 0;
@@ -147,8 +150,10 @@ struct ufomap_map {
 	int device = 0;
 	hipStream_t stream = nullptr;   // map stream: everything that touches the node table
 	hipStream_t sstream = nullptr;  // scan stream: classify .. extract of the NEXT scan overlaps the previous map phase
+	hipStream_t pstream = nullptr;  // prep stream: H2D copy of a host cloud and the fast path's first kernel (k_fhits) -- neither depends
+	                                // on the scan before, so they overlap its ray kernel instead of queueing behind it
 	hipStream_t cs = nullptr;       // stream the helpers currently launch on
-	hipEvent_t done_ev = nullptr, scan_ev = nullptr;
+	hipEvent_t done_ev = nullptr, scan_ev = nullptr, prep_ev = nullptr;
 	hipStream_t xstream = nullptr;  // read-back of control blocks whose producers are known to be complete
 	bool prev_flagged = false;      // the integration joined last had flagged an error (finishPending)
 	int opt_early = 1;              // enqueue the map half before the previous integration has been joined (doInsert)
@@ -171,7 +176,7 @@ struct ufomap_map {
 	// per-scan buffers
 	DevBuf b_ctl, b_pt_end, b_pt_flag, b_pt_slot, b_ray_end, b_hit_code, b_hit_pt, b_hh_keys;
 	DevBuf b_part0, b_part1, b_slabs, b_hb_keys, b_hb_mask, b_hb_time;
-	DevBuf b_first, b_tilebits, b_upperbits;         // fast path, per hand-over set (HandOver)
+	DevBuf b_first, b_tilebits;         // fast path, per hand-over set (HandOver)
 	UpperGeo ugeo{};
 	DevBuf b_tilerec, b_tilehm;   // fast path, map stream only
 	u32 fast_hits_scan = 0;  // scan_id of the fast-path update whose hit masks are in b_tilehm
@@ -181,6 +186,7 @@ struct ufomap_map {
 	uint64_t seq = 0, latest_seq = 0;  // seq: of the integration that uses the current set; latest_seq: of the newest one enqueued
 	FastGeo fgeo{};
 	int opt_fast = 1;  // 0 = never take the fast path (fast_kernels.h)
+	u64 host_ns[4] = {0, 0, 0, 0};  // diagnostics: host time inside doInsert -- scan half enqueue, map half enqueue, join, total
 	uint64_t n_fast = 0;
 	u32 hb_cap_mask = 0;
 	Ingest ing{};      // ufomap_map_insert_pointcloud2: raw PointCloud2 records, converted inside k_classify
@@ -188,6 +194,10 @@ struct ufomap_map {
 	DevBuf b_crec, b_dlist, b_rays;
 	DevBuf b_gridM, b_entries, b_ent_slot, b_newlist, b_wl0, b_wl1, b_in_xyz, b_in_rgb, b_codes, b_dump;
 	ScanCtl* h_ctl = nullptr;  // pinned
+	ScanCtl* h_res = nullptr;  // pinned: k_ftail stores the finished control block here itself (no read-back copy, no stream sync)
+	bool ctl_clean = false;    // the device control block holds the fast path's start state (k_ftail left it so): no upload
+	DevBuf b_ctl_init;         // that start state, uploaded once
+	bool ctl_init_done = false;
 	void* h_stage = nullptr;   // pinned staging buffer of the current hand-over set (HandOver::h_stage)
 	size_t h_stage_cap = 0;
 	hipEvent_t copy_ev = nullptr;  // end of the H2D copy of a cloud that lies in caller-owned pinned memory
@@ -410,13 +420,14 @@ void swapWith(ufomap_map* m, HandOver& o)
 	std::swap(m->b_hit_code, o.b_hit_code);
 	std::swap(m->b_first, o.b_first);
 	std::swap(m->b_tilebits, o.b_tilebits);
-	std::swap(m->b_upperbits, o.b_upperbits);
 	std::swap(m->ugeo, o.ugeo);
 	std::swap(m->first_dirty, o.first_dirty);
 	std::swap(m->seq, o.seq);
 	std::swap(m->fast, o.fast);
 	std::swap(m->fgeo, o.fgeo);
 	std::swap(m->h_ctl, o.h_ctl);
+	std::swap(m->h_res, o.h_res);
+	std::swap(m->ctl_clean, o.ctl_clean);
 	std::swap(m->h_stage, o.h_stage);
 	std::swap(m->h_stage_cap, o.h_stage_cap);
 	std::swap(m->hh_mask, o.hh_mask);
@@ -862,15 +873,15 @@ int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, si
 	const u32 N = (u32)n;
 	const D3 sensor{origin[0], origin[1], origin[2]};
 	(void)makeUpperGeo(fg, m->g.L, &m->ugeo);
-	const size_t cf = m->b_first.cap, ct = m->b_tilebits.cap, cu = m->b_upperbits.cap;  // (a re-allocation may well return the old address: compare sizes)
+	const size_t cf = m->b_first.cap, ct = m->b_tilebits.cap;  // (a re-allocation may well return the old address: compare sizes)
 	HIP_TRY(m->b_first.reserve((size_t)fg.ncells * 4));
 	HIP_TRY(m->b_tilebits.reserve(UFO_FAST_MAX_TILES / 8));
-	HIP_TRY(m->b_upperbits.reserve(UFO_UPPER_MAX / 8));
-	if (cf != m->b_first.cap || ct != m->b_tilebits.cap || cu != m->b_upperbits.cap) m->first_dirty = true;
+	if (cf != m->b_first.cap || ct != m->b_tilebits.cap) m->first_dirty = true;
+	// k_fhits depends on nothing but the cloud: on the prep stream it overlaps the ray kernel of the scan before
+	m->cs = m->pstream;
 	if (m->first_dirty || 2 == m->opt_fast) {  // (option fast = 2: never trust the self-cleaning, a debugging aid)
 		HIP_TRY(hipMemsetAsync(m->b_first.p, 0xFF, m->b_first.cap, m->cs));
 		HIP_TRY(hipMemsetAsync(m->b_tilebits.p, 0, m->b_tilebits.cap, m->cs));
-		HIP_TRY(hipMemsetAsync(m->b_upperbits.p, 0, m->b_upperbits.cap, m->cs));
 		m->first_dirty = false;
 	}
 	HIP_TRY(m->b_gridM.reserve(fg.gr.bytes));
@@ -883,9 +894,18 @@ int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, si
 		init.aabb_min[a] = ~0ull;
 		init.aabb_max[a] = 0ull;
 	}
-	*m->h_ctl = init;
 	ScanCtl* ctl = m->b_ctl.as<ScanCtl>();
-	HIP_TRY(hipMemcpyAsync(ctl, m->h_ctl, sizeof(ScanCtl), hipMemcpyHostToDevice, m->cs));
+	if (!m->ctl_init_done) {
+		HIP_TRY(hipMemcpy(m->b_ctl_init.p, &init, sizeof(ScanCtl), hipMemcpyHostToDevice));
+		m->ctl_init_done = true;
+	}
+	if (!m->ctl_clean || 2 == m->opt_fast) {
+		// (steady state: the tree update of the set's previous scan has left the block in this very state, k_ftail)
+		*m->h_ctl = init;
+		HIP_TRY(hipMemcpyAsync(ctl, m->h_ctl, sizeof(ScanCtl), hipMemcpyHostToDevice, m->cs));
+	}
+	m->ctl_clean = false;  // (until that scan's tree update has been joined and found clean)
+	m->h_res->err = ERR_NOT_STORED;
 	const dim3 gp((N + 255) / 256);
 	HIP_TRY(m->b_part1.reserve((size_t)gp.x * sizeof(BoxPartial)));
 	{
@@ -897,6 +917,9 @@ int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, si
 			hipLaunchKernelGGL(k_fhits<false>, gp, dim3(256), 0, m->cs, m->g, fg, sensor, d_xyz, N, max_range, 0u, m->b_first.as<u32>(),
 			                   m->b_part1.as<BoxPartial>(), ctl, m->ing);
 	}
+	HIP_TRY(hipEventRecord(m->prep_ev, m->pstream));
+	m->cs = m->sstream;
+	HIP_TRY(hipStreamWaitEvent(m->sstream, m->prep_ev, 0));
 	u32 nwg = m->opt_cast_wgs > 0 ? (u32)m->opt_cast_wgs : 256u;
 	nwg = std::max<u32>(1u, std::min<u32>(nwg, (N + 63u) / 64u));
 	const u32 cap_wg = (N + nwg - 1) / nwg;
@@ -957,7 +980,7 @@ int fastMapPhase(ufomap_map* m, const ScanCtl* prev, u64 extra_used, u32 headroo
 	{
 		ProfScope ps(m, "k_ftail");
 		hipLaunchKernelGGL(k_ftail, dim3(1), dim3(UFO_FTAIL_THREADS), 0, m->cs, m->t, m->g, fg, m->ugeo, m->b_tilebits.as<u32>(),
-		                   m->b_tilerec.as<TileRec>(), m->scan_id, ctl, prev);
+		                   m->b_tilerec.as<TileRec>(), m->scan_id, ctl, prev, m->h_res, m->b_ctl_init.as<ScanCtl>());
 	}
 	HIP_TRY(hipGetLastError());
 	return UFOMAP_OK;
@@ -1007,7 +1030,15 @@ int finishPending(ufomap_map* m)
 	if (!m->pending) return UFOMAP_OK;
 	m->pending = false;
 	m->cs = m->stream;
-	int rc = readCtlDone(m);
+	int rc = UFOMAP_OK;
+	if (m->fast && 0 == m->h_res->err) {
+		// k_ftail stored the finished control block in pinned memory itself and left the device copy in its start state
+		memcpy(m->h_ctl, m->h_res, sizeof(ScanCtl));
+		m->used_est = m->h_ctl->used_now;
+		m->ctl_clean = true;
+	} else {
+		rc = readCtlDone(m);
+	}
 	if (rc) return rc;
 	drainEvents(m);
 	if (m->h_ctl->err) m->prev_flagged = true;  // (sticky: doInsert resets it before a join)
@@ -1085,6 +1116,7 @@ int scanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, const 
 	*m->h_ctl = init;
 	ScanCtl* ctl = m->b_ctl.as<ScanCtl>();
 	HIP_TRY(hipMemcpyAsync(ctl, m->h_ctl, sizeof(ScanCtl), hipMemcpyHostToDevice, m->cs));
+	m->ctl_clean = false;  // (the set's device control block no longer holds the fast path's start state)
 	dim3 gp((N + 255) / 256);
 	HIP_TRY(m->b_part0.reserve((size_t)gp.x * sizeof(BoxPartial)));
 	HIP_TRY(m->b_part1.reserve((size_t)gp.x * sizeof(BoxPartial)));
@@ -1344,6 +1376,15 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 	// while the map half of the previous integration may still be updating the tree on the map stream --
 	// the reference overlaps its head loop with the previous integration the same way (the join sits
 	// after the head loop, OMB:315). Hand-over buffers are double-buffered and swapped here.
+	const auto t_begin = std::chrono::steady_clock::now();
+	struct Total {
+		ufomap_map* m;
+		std::chrono::steady_clock::time_point t0;
+		~Total() { m->host_ns[3] += (u64)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); }
+	} total_timer{m, t_begin};
+	auto lap = [&](int k, std::chrono::steady_clock::time_point since) {
+		m->host_ns[k] += (u64)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - since).count();
+	};
 	if (!swapped) (void)rotateSets(m);
 	m->seq = ++m->latest_seq;
 	if (m->chg_enabled) async = 0;  // the change log is sized between updates: one update at a time
@@ -1376,9 +1417,13 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 	if (fast) {
 		rc = fastScanPhase(m, origin, d_xyz, n, max_range, discrete);
 	} else {
+		// (a host cloud is copied on the prep stream)
+		HIP_TRY(hipEventRecord(m->prep_ev, m->pstream));
+		HIP_TRY(hipStreamWaitEvent(m->sstream, m->prep_ev, 0));
 		rc = scanPhase(m, origin, d_xyz, d_rgb, n, max_range, depth, discrete, simple, early_stopping, &n_hits, &n_rays, spec);
 		if (!rc && n) rc = extractPhase(m, n_hits, n_rays, &capH, &capM, merged);
 	}
+	lap(0, t_begin);
 	auto mapHalf = [&](const ScanCtl* prev, u64 extra_used, u32 headroom) {
 		return fast ? fastMapPhase(m, prev, extra_used, headroom) : mapPhase(m, depth, d_rgb, capH, capM, merged, prev, extra_used, headroom);
 	};
@@ -1394,19 +1439,23 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 		HIP_TRY(hipStreamWaitEvent(m->stream, m->scan_ev, 0));
 		m->last_rgb = d_rgb;
 		const u64 in_flight = m->alt[1].bound + (m->alt[0].pending ? m->alt[0].bound : 0);
+		const auto t_map = std::chrono::steady_clock::now();
 		const int erc = mapHalf(m->alt[1].b_ctl.as<ScanCtl>(), in_flight, 0u);
 		if (erc < 0) return erc;
 		early = 0 == erc;  // 1: the table might have to grow: join first (below)
 		if (early) HIP_TRY(hipEventRecord(m->done_ev, m->stream));
+		lap(1, t_map);
 	}
 	int prc = UFOMAP_OK;
 	if (early) {
 		// join the integration before the previous one (long finished as a rule): the previous one and this one keep running
 		m->prev_flagged = false;
 		if (m->alt[0].pending) {
+			const auto t_join = std::chrono::steady_clock::now();
 			HIP_TRY(hipEventSynchronize(m->alt[0].done_ev));
 			prc = finishSet(m, 0);
 			if (prc && UFOMAP_OK == m->async_status) m->async_status = prc;
+			lap(2, t_join);
 		}
 		if (m->prev_flagged) {
 			// it had flagged itself (and has been repeated, or has failed): the previous update and this one stood back.
@@ -1567,6 +1616,8 @@ ufomap_map* ufomap_map_create(double resolution, unsigned depth_levels, int auto
 	bool ok = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) == hipSuccess &&
 	          hipStreamCreateWithFlags(&m->sstream, hipStreamNonBlocking) == hipSuccess &&
 	          hipStreamCreateWithFlags(&m->xstream, hipStreamNonBlocking) == hipSuccess &&
+	          hipStreamCreateWithFlags(&m->pstream, hipStreamNonBlocking) == hipSuccess &&
+	          hipEventCreateWithFlags(&m->prep_ev, hipEventDisableTiming) == hipSuccess &&
 	          hipEventCreateWithFlags(&m->done_ev, hipEventDisableTiming) == hipSuccess &&
 	          hipEventCreateWithFlags(&m->alt[0].done_ev, hipEventDisableTiming) == hipSuccess &&
 	          hipEventCreateWithFlags(&m->alt[1].done_ev, hipEventDisableTiming) == hipSuccess &&
@@ -1575,6 +1626,10 @@ ufomap_map* ufomap_map_create(double resolution, unsigned depth_levels, int auto
 	          hipHostMalloc((void**)&m->h_ctl, sizeof(ScanCtl) + 64) == hipSuccess &&
 	          hipHostMalloc((void**)&m->alt[0].h_ctl, sizeof(ScanCtl) + 64) == hipSuccess &&
 	          hipHostMalloc((void**)&m->alt[1].h_ctl, sizeof(ScanCtl) + 64) == hipSuccess &&
+	          hipHostMalloc((void**)&m->h_res, sizeof(ScanCtl) + 64) == hipSuccess &&
+	          hipHostMalloc((void**)&m->alt[0].h_res, sizeof(ScanCtl) + 64) == hipSuccess &&
+	          hipHostMalloc((void**)&m->alt[1].h_res, sizeof(ScanCtl) + 64) == hipSuccess &&
+	          m->b_ctl_init.reserve(sizeof(ScanCtl) + 64) == hipSuccess &&
 	          m->alt[0].b_ctl.reserve(sizeof(ScanCtl) + 64) == hipSuccess && m->alt[1].b_ctl.reserve(sizeof(ScanCtl) + 64) == hipSuccess &&
 	          hipHostMalloc((void**)&m->h_root, sizeof(MapRoot)) == hipSuccess &&
 	          m->b_ctl.reserve(sizeof(ScanCtl) + 64) == hipSuccess && m->b_root.reserve(sizeof(MapRoot)) == hipSuccess;
@@ -1614,24 +1669,28 @@ void ufomap_map_destroy(ufomap_map* m)
 {
 	if (!m) return;
 	(void)hipSetDevice(m->device);
+	if (m->pstream) (void)hipStreamSynchronize(m->pstream);
 	if (m->sstream) (void)hipStreamSynchronize(m->sstream);
 	if (m->stream) (void)hipStreamSynchronize(m->stream);
 	m->tb.release();
 	m->b_changes.release();
 	for (HandOver& a : m->alt) {
-		DevBuf* abufs[] = {&a.b_ctl, &a.b_entries, &a.b_hh_keys, &a.b_in_xyz, &a.b_in_rgb, &a.b_gridM, &a.b_part1, &a.b_hit_code, &a.b_first, &a.b_tilebits, &a.b_upperbits};
+		DevBuf* abufs[] = {&a.b_ctl, &a.b_entries, &a.b_hh_keys, &a.b_in_xyz, &a.b_in_rgb, &a.b_gridM, &a.b_part1, &a.b_hit_code, &a.b_first, &a.b_tilebits};
 		for (DevBuf* b : abufs) b->release();
 		if (a.h_ctl) (void)hipHostFree(a.h_ctl);
+		if (a.h_res) (void)hipHostFree(a.h_res);
 		if (a.h_stage) (void)hipHostFree(a.h_stage);
 		if (a.done_ev) (void)hipEventDestroy(a.done_ev);
 	}
 	if (m->scan_ev) (void)hipEventDestroy(m->scan_ev);
 	if (m->sstream) (void)hipStreamDestroy(m->sstream);
+	if (m->pstream) (void)hipStreamDestroy(m->pstream);
+	if (m->prep_ev) (void)hipEventDestroy(m->prep_ev);
 	DevBuf* bufs[] = {&m->b_root,
 	                  &m->b_ctl,     &m->b_pt_end,  &m->b_pt_flag,  &m->b_pt_slot, &m->b_ray_end, &m->b_hit_code, &m->b_hit_pt,
 	                  &m->b_hh_keys, &m->b_gridM,   &m->b_crec,    &m->b_dlist,   &m->b_rays,   &m->b_part0,   &m->b_part1,   &m->b_slabs,   &m->b_hb_keys, &m->b_hb_mask, &m->b_hb_time,   &m->b_entries, &m->b_ent_slot, &m->b_newlist,
 	                  &m->b_wl0,     &m->b_wl1,     &m->b_in_xyz,   &m->b_in_rgb,  &m->b_codes,   &m->b_dump,
-	                  &m->b_first,   &m->b_tilebits, &m->b_upperbits, &m->b_tilerec, &m->b_tilehm};
+	                  &m->b_first,   &m->b_tilebits, &m->b_tilerec, &m->b_tilehm};
 	for (DevBuf* b : bufs) b->release();
 	for (PendingEvent& pe : m->pend_ev) {
 		(void)hipEventDestroy(pe.a);
@@ -1639,6 +1698,7 @@ void ufomap_map_destroy(ufomap_map* m)
 	}
 	for (hipEvent_t e : m->ev_pool) (void)hipEventDestroy(e);
 	if (m->h_ctl) (void)hipHostFree(m->h_ctl);
+	if (m->h_res) (void)hipHostFree(m->h_res);
 	if (m->h_stage) (void)hipHostFree(m->h_stage);
 	if (m->copy_ev) (void)hipEventDestroy(m->copy_ev);
 	if (m->h_root) (void)hipHostFree(m->h_root);
@@ -1723,9 +1783,9 @@ static int uploadCloud(ufomap_map* m, const void* a, size_t a_bytes, const void*
 		return ok;
 	};
 	if (isPinned(a) && (!b_bytes || isPinned(b))) {
-		HIP_TRY(hipMemcpyAsync(m->b_in_xyz.p, a, a_bytes, hipMemcpyHostToDevice, m->sstream));
-		if (b_bytes) HIP_TRY(hipMemcpyAsync(m->b_in_rgb.p, b, b_bytes, hipMemcpyHostToDevice, m->sstream));
-		HIP_TRY(hipEventRecord(m->copy_ev, m->sstream));
+		HIP_TRY(hipMemcpyAsync(m->b_in_xyz.p, a, a_bytes, hipMemcpyHostToDevice, m->pstream));
+		if (b_bytes) HIP_TRY(hipMemcpyAsync(m->b_in_rgb.p, b, b_bytes, hipMemcpyHostToDevice, m->pstream));
+		HIP_TRY(hipEventRecord(m->copy_ev, m->pstream));
 		HIP_TRY(hipEventSynchronize(m->copy_ev));
 	} else {
 		const size_t off_b = (a_bytes + 255) & ~(size_t)255, need = off_b + b_bytes;
@@ -1739,8 +1799,8 @@ static int uploadCloud(ufomap_map* m, const void* a, size_t a_bytes, const void*
 		}
 		memcpy(m->h_stage, a, a_bytes);
 		if (b_bytes) memcpy(static_cast<char*>(m->h_stage) + off_b, b, b_bytes);
-		HIP_TRY(hipMemcpyAsync(m->b_in_xyz.p, m->h_stage, a_bytes, hipMemcpyHostToDevice, m->sstream));
-		if (b_bytes) HIP_TRY(hipMemcpyAsync(m->b_in_rgb.p, static_cast<char*>(m->h_stage) + off_b, b_bytes, hipMemcpyHostToDevice, m->sstream));
+		HIP_TRY(hipMemcpyAsync(m->b_in_xyz.p, m->h_stage, a_bytes, hipMemcpyHostToDevice, m->pstream));
+		if (b_bytes) HIP_TRY(hipMemcpyAsync(m->b_in_rgb.p, static_cast<char*>(m->h_stage) + off_b, b_bytes, hipMemcpyHostToDevice, m->pstream));
 	}
 	*d_a = m->b_in_xyz.p;
 	if (b_bytes) *d_b = m->b_in_rgb.p;
@@ -1900,6 +1960,7 @@ int ufomap_map_set_value_volume_ch(ufomap_map* m, const double aabb_center[3], c
 	}
 	*m->h_ctl = init;
 	HIP_TRY(hipMemcpyAsync(m->b_ctl.p, m->h_ctl, sizeof(ScanCtl), hipMemcpyHostToDevice, m->stream));
+	m->ctl_clean = false;  // (the set's device control block no longer holds the fast path's start state)
 	ScanCtl* ctl = m->b_ctl.as<ScanCtl>();
 	m->scan_id += 1;
 	if (L == min_depth) {
@@ -2110,6 +2171,7 @@ size_t ufomap_map_iterate(ufomap_map* m, const double* aabb_center, const double
 				return (size_t)-1;
 		}
 		if (bad(hipMemsetAsync(ctl, 0, sizeof(ScanCtl), m->stream))) return (size_t)-1;
+		m->ctl_clean = false;  // (the set's device control block no longer holds the fast path's start state)
 		const IterOut out{bc.as<u64>(), bd.as<u8>(), bo.as<float>(), br.as<u32>(), bf.as<u8>(), ocap};
 		hipLaunchKernelGGL(k_iter_root, dim3(1), dim3(1), 0, m->stream, m->t, m->g, a, rec, rcap, out, ctl);
 		for (u32 cd = L; cd >= 1 && cd > min_depth; --cd) {
@@ -2169,6 +2231,7 @@ int ufomap_map_wait(ufomap_map* m)
 {
 	if (!m) return fail(UFOMAP_ERR_INVALID, "null map");
 	HIP_TRY(hipSetDevice(m->device));
+	HIP_TRY(hipStreamSynchronize(m->pstream));
 	HIP_TRY(hipStreamSynchronize(m->sstream));
 	HIP_TRY(hipStreamSynchronize(m->stream));
 	int rc = finishSet(m, 0);  // oldest first
@@ -2563,6 +2626,7 @@ int ufomap_map_apply_keys(ufomap_map* m, const void* d_entries, const ufomap_key
 	}
 	*m->h_ctl = init;
 	HIP_TRY(hipMemcpyAsync(m->b_ctl.p, m->h_ctl, sizeof(ScanCtl), hipMemcpyHostToDevice, m->stream));
+	m->ctl_clean = false;  // (the set's device control block no longer holds the fast path's start state)
 	const Entry* ent = static_cast<const Entry*>(d_entries);
 	int rc = sizeTable(m, ent, nh, info->nb_hit, ent + nh, nm, info->nb_miss, info->depth);
 	if (rc) return rc;
@@ -2612,6 +2676,7 @@ int ufomap_map_apply_keys_batch(ufomap_map* m, const void* const* d_lists, const
 	}
 	*m->h_ctl = init;
 	HIP_TRY(hipMemcpyAsync(m->b_ctl.p, m->h_ctl, sizeof(ScanCtl), hipMemcpyHostToDevice, m->stream));
+	m->ctl_clean = false;  // (the set's device control block no longer holds the fast path's start state)
 	ScanCtl* ctl = m->b_ctl.as<ScanCtl>();
 	ScanCtl::PhaseCtr* pc = &ctl->ph[0];
 	// sub-lists in application order: scan 0 hits, scan 0 misses, scan 1 hits, ...; their counts live on the device
@@ -3027,6 +3092,7 @@ int readNodes(ufomap_map* m, const uint8_t* data, size_t n, const double* aabb_c
 	}
 	*m->h_ctl = init;
 	HIP_TRY(hipMemcpyAsync(m->b_ctl.p, m->h_ctl, sizeof(ScanCtl), hipMemcpyHostToDevice, m->stream));
+	m->ctl_clean = false;  // (the set's device control block no longer holds the fast path's start state)
 	ScanCtl* ctl = m->b_ctl.as<ScanCtl>();
 	m->scan_id += 1;
 	if (0 == data[0]) {
@@ -3249,6 +3315,7 @@ int ufomap_map_debug(ufomap_map* m, uint64_t* out, int n)
 	if (n > 62) out[62] = m->n_spec;       // scans enqueued on a predicted grid
 	if (n > 63) out[63] = m->n_spec_redo;  // ... of which had to be repeated
 	if (n > 61) out[61] = m->n_fast;       // scans enqueued on the fast path (fast_kernels.h)
+	for (int k = 0; k < 4 && 52 + k < n; ++k) out[52 + k] = m->host_ns[k];  // host time inside doInsert (ns): scan enqueue, map enqueue, join, total
 	return rc;
 }
 
