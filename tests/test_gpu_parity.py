@@ -496,6 +496,10 @@ RAY_KERNELS = {
     "walk_4lanes": {"cast": 0, "dda_lanes": 4},
     "seg_bytes_lds": {"dda_bits": 0},                  # k_dda_seg<DDA_LDSGRID> (byte-per-block grid in LDS)
     "seq_bytes_lds": {"dda_bits": 0, "dda_seg": 0},    # k_dda<false, DDA_LDSGRID>, one lane per ray
+    "cast_box": {"cast_global": 2, "spec": 0},         # k_cast<2>: bit grid in HBM, a workgroup's box of it in LDS (grids beyond LDS)
+    "cast_box_k8_64wgs": {"cast_global": 2, "spec": 0, "cast_k": 8, "cast_wgs": 64},
+    "cast_box_fallback": {"cast_global": 4, "spec": 0},  # ... boxes that do not fit: marks one by one through the LDS filter
+    "cast_global": {"cast_global": 3, "spec": 0},      # k_cast<1>: every mark through the LDS filter
     "filter": {"dda_mode": 1},                         # k_dda_seg<DDA_FILTER>
     "direct": {"dda_mode": 2},                         # k_dda<false, DDA_DIRECT>
 }

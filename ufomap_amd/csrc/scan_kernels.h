@@ -535,7 +535,7 @@ __global__ __launch_bounds__(256) void k_select(MapGeom g, D3 sensor, u32 n, u32
                                                 const D3* __restrict__ pt_end, const u8* __restrict__ pt_flag,
                                                 const u32* __restrict__ pt_slot, D3* __restrict__ ray_end,
                                                 u64* __restrict__ hit_code, u32* __restrict__ hit_pt,
-                                                BoxPartial* __restrict__ part, ScanCtl* ctl)
+                                                BoxPartial* __restrict__ part, ScanCtl* ctl, u32* __restrict__ blk_range)
 {
 	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
 	u8 flag = (i < n) ? pt_flag[i] : 0;
@@ -603,6 +603,15 @@ __global__ __launch_bounds__(256) void k_select(MapGeom g, D3 sensor, u32 n, u32
 	D3 c2 = sensor, e3 = end;
 	if (cast && !moveLineInside(g, c2, e3)) cast = false;
 	const u32 rpos = blockAppend(&ctl->n_rays, cast);
+	{
+		// where this workgroup's rays lie in the list (they are contiguous, in point order): k_cast<2> hands whole workgroups'
+		// stretches to its workgroups, because rays of neighbouring points are neighbours in space
+		const u32 rcount = (u32)__syncthreads_count(cast ? 1 : 0);
+		if (0 == threadIdx.x) {
+			blk_range[2u * blockIdx.x] = rpos;  // (thread 0's slot is the stretch's first)
+			blk_range[2u * blockIdx.x + 1u] = rcount;
+		}
+	}
 	if (cast) {
 		ray_end[rpos] = end;
 		const i32 lim = (i32)((1u << (g.L - depth)) - 1u);
@@ -1245,6 +1254,7 @@ __global__ __launch_bounds__(UFO_DDA_BLOCK) void k_dda_seg(MapGeom g, u32 depth,
 						t1 = t1 + d1;
 						++cb1;
 					}
+					if (cb0 >= 2048u || cb1 >= 2048u) err |= ERR_RUNAWAY;  // (cannot trip: < 1024 cells per axis)
 					const u32 da = ax == 0 ? dxs : (ax == 1 ? dys : dzs);
 					const u32 db0 = b0 == 0 ? dxs : dys, db1 = b1 == 1 ? dys : dzs;
 					pk = pk0 + k0 * da + cb0 * db0 + cb1 * db1;
@@ -1303,6 +1313,7 @@ __global__ __launch_bounds__(UFO_DDA_BLOCK) void k_dda_seg(MapGeom g, u32 depth,
 					ka += sela ? 1u : 0u;
 					go = (pk != gpk) && (m <= dist) && (ka != k1) && (cnt < 4096u);
 				}
+				if (cnt >= 4096u) err |= ERR_RUNAWAY;  // (a packed grid has < 1024 cells per axis: a ray has < 3072 steps)
 				steps += cnt;
 			}
 		}
@@ -1477,6 +1488,7 @@ __global__ __launch_bounds__(UFO_DDA_BLOCK) void k_walk(MapGeom g, u32 depth, Gr
 						t1 = t1 + d1;
 						++cb1;
 					}
+					if (cb0 >= 2048u || cb1 >= 2048u) err |= ERR_RUNAWAY;  // (cannot trip: < 1024 cells per axis)
 					const i32 da = ax == 0 ? dlx : (ax == 1 ? dly : dlz);
 					const i32 db0 = b0 == 0 ? dlx : dly, db1 = b1 == 1 ? dly : dlz;
 					lin = lin + (u32)((i32)k0 * da + (i32)cb0 * db0 + (i32)cb1 * db1);
@@ -1523,6 +1535,7 @@ __global__ __launch_bounds__(UFO_DDA_BLOCK) void k_walk(MapGeom g, u32 depth, Gr
 		const bool more = (__double_as_longlong(tmx) <= idist) | (__double_as_longlong(tmy) <= idist) | (__double_as_longlong(tmz) <= idist);
 		go = (lin != end) & more & (cnt < 4096u);
 	}
+	if (cnt >= 4096u) err |= ERR_RUNAWAY;  // (a packed grid has < 1024 cells per axis: a ray has < 3072 steps)
 	{
 		// every step moves one cell along one axis and never turns back: steps = L1 distance covered
 		const u32 ny = 2u * (u32)gr.nb[1];
@@ -1575,43 +1588,212 @@ struct RayHdr {
 	u32 off, pad;
 };
 #define UFO_CAST_LDS_EXTRA (UFO_CAST_BATCH * (sizeof(RayConst) + sizeof(RayHdr)) + UFO_CAST_QCAP * sizeof(SegRec) + 128u)
+#define UFO_CAST2_BATCH 128u
+#define UFO_CAST2_QCAP 512u
+#define UFO_CAST2_LDS_EXTRA (UFO_CAST2_BATCH * (sizeof(RayConst) + sizeof(RayHdr)) + UFO_CAST2_QCAP * sizeof(SegRec) + 128u)
 
-__global__ __launch_bounds__(512) void k_cast(MapGeom g, D3 sensor, u32 depth, Grid gr, u32* __restrict__ slabs,
+// MODE 0: the whole bit grid in LDS, handed over as a slab (above).
+// Grids beyond LDS (e.g. 8 cm / 20 m: 0.8 MB) keep the rounds -- set-up, cuts, balanced segment walk -- and change where a
+// mark goes; `slabs` is the (zeroed) global bit grid then and nothing is merged afterwards:
+// MODE 2 (default): a workgroup takes the rays of CONSECUTIVE points of the cloud (whole stretches of the ray list as
+//         workgroups of k_select wrote them). Points that follow one another in a scan lie next to one another in space,
+//         and all rays start at the sensor: the rays stay inside a small box (sensor cell + their end cells), and that box
+//         of the grid is what the workgroup keeps in LDS -- same marks, same speed as MODE 0
+//         -- and ORs into the global grid at the end, one atomic per non-zero word. A stretch whose box does not fit
+//         (an unordered cloud) falls back to MODE 1's marks for this workgroup.
+// MODE 1: marks go to the global grid one by one: through a direct-mapped LDS filter with exact tags (the cell's linear
+//         index) that removes what this workgroup's own rays repeat, then a fire-and-forget atomicOr. Scattered device-
+//         scope atomics complete at ~17 per ns on this chip: 0.8 ms for the 8 cm scan's 14.5 M steps (measured), which is
+//         why this is only the fallback.
+#define UFO_CAST_FILT_LOG2 14u  // 16 Ki tags = 64 KiB of LDS
+#define UFO_CAST_STRETCHES 16u  // k_cast<2>: a workgroup takes the rays of at most this many workgroups of k_select
+template <bool GLOBAL>
+__device__ inline void castMark(u32* __restrict__ lds, u32* __restrict__ grid, u32 lin)
+{
+	if (!GLOBAL) {
+		atomicOr(&lds[lin >> 5], 1u << (lin & 31u));
+		return;
+	}
+	const u32 h = (lin * 0x9E3779B1u) >> (32u - UFO_CAST_FILT_LOG2);
+	if (lds[h] == lin) return;
+	lds[h] = lin;
+	// fire and forget: looking at the word first (is the bit there already?) would put a global round trip into the
+	// dependent chain of every step (measured: 1.24 ms instead of 0.47 for the 8 cm scan)
+	__hip_atomic_fetch_or(&grid[lin >> 5], 1u << (lin & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool GLOBAL>
+__device__ inline u32 castMarkChecked(const Grid& gr, u32* __restrict__ lds, u32* __restrict__ grid, u32 rowBits, u32 planeBits, i32 cx, i32 cy,
+                                      i32 cz, u32 lim, u32* oob)
+{
+	if (!GLOBAL) return markBitChecked(gr, lds, rowBits, planeBits, cx, cy, cz, lim, oob);
+	if ((u32)cx >= lim || (u32)cy >= lim || (u32)cz >= lim) {
+		++*oob;
+		return 0;
+	}
+	const i32 lx = cx - gr.base[0], ly = cy - gr.base[1], lz = cz - gr.base[2];
+	if ((u32)lx >= 2u * (u32)gr.nb[0] || (u32)ly >= 2u * (u32)gr.nb[1] || (u32)lz >= 2u * (u32)gr.nb[2]) return ERR_GRID_OOB;
+	castMark<true>(lds, grid, (u32)lx + (u32)ly * rowBits + (u32)lz * planeBits);
+	return 0;
+}
+
+// start and goal cell of a ray's walk (the head of raySetup): everything the walk marks lies in the box they span
+__device__ inline bool rayEndCells(const MapGeom& g, const D3& sensor, u32 depth, D3 to, i32 c0[3], i32 c1[3])
+{
+	D3 from = sensor;
+	if (!moveLineInside(g, from, to)) return false;
+	c0[0] = (i32)(toKey1(g, to.x, depth) >> depth);
+	c0[1] = (i32)(toKey1(g, to.y, depth) >> depth);
+	c0[2] = (i32)(toKey1(g, to.z, depth) >> depth);
+	c1[0] = (i32)(toKey1(g, from.x, depth) >> depth);
+	c1[1] = (i32)(toKey1(g, from.y, depth) >> depth);
+	c1[2] = (i32)(toKey1(g, from.z, depth) >> depth);
+	return true;
+}
+
+__device__ inline u32 castMarkCheckedDyn(bool glob, const Grid& gr, u32* __restrict__ lds, u32* __restrict__ grid, u32 rowBits, u32 planeBits,
+                                         i32 cx, i32 cy, i32 cz, u32 lim, u32* oob)
+{
+	return glob ? castMarkChecked<true>(gr, lds, grid, rowBits, planeBits, cx, cy, cz, lim, oob)
+	            : castMarkChecked<false>(gr, lds, grid, rowBits, planeBits, cx, cy, cz, lim, oob);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(512) void k_cast(MapGeom g, D3 sensor, u32 depth, Grid grid_all, u32* __restrict__ slabs,
                                               const D3* __restrict__ ray_end, u32 k_min, const ScanCtl* ctl_in, ScanCtl* ctl,
-                                              unsigned long long* __restrict__ steps_part)
+                                              unsigned long long* __restrict__ steps_part, u32 lds_grid_bytes,
+                                              const u32* __restrict__ blk_range, u32 n_blk, u32 box_limit_bytes)
 {
 	extern __shared__ __attribute__((aligned(16))) u32 lds[];
+	// rays set up per round, segment queue entries (MODE 2: smaller rounds leave more of the LDS to the box)
+	constexpr u32 BATCH = (2 == MODE) ? UFO_CAST2_BATCH : UFO_CAST_BATCH, QCAP = (2 == MODE) ? UFO_CAST2_QCAP : UFO_CAST_QCAP;
 	if (ctl_in->err & ERR_SPEC) return;  // the scan does not fit the predicted grid: it will be repeated (uniform exit)
-	const u32 lds_words = (u32)(gr.bytes >> 2);
-	RayConst* rc = reinterpret_cast<RayConst*>(lds + lds_words);
-	RayHdr* hd = reinterpret_cast<RayHdr*>(rc + UFO_CAST_BATCH);
-	SegRec* q = reinterpret_cast<SegRec*>(hd + UFO_CAST_BATCH);
-	u32* sh = reinterpret_cast<u32*>(q + UFO_CAST_QCAP);  // [0..7], [16..23]: per-wave partial sums
-	{
-		uint4* l4 = reinterpret_cast<uint4*>(lds);
-		for (u32 j = threadIdx.x; j < (lds_words >> 2); j += blockDim.x) l4[j] = make_uint4(0, 0, 0, 0);
-	}
-	const u32 rowBits = gridRowBits(gr), planeBits = rowBits * 2u * (u32)gr.nb[1];
 	const u32 n = ctl_in->n_rays;
+	// rays of this workgroup: blockIdx.x, blockIdx.x + gridDim.x, ...; MODE 2: the stretches of the ray list that
+	// UFO_CAST_STRETCHES-or-fewer consecutive workgroups of k_select wrote (their points are consecutive in the cloud)
+	__shared__ u32 st_first[UFO_CAST_STRETCHES], st_pre[UFO_CAST_STRETCHES + 1];
+	u32 mine = (n > blockIdx.x) ? (n - blockIdx.x + gridDim.x - 1) / gridDim.x : 0u;
+	if (2 == MODE) {
+		const u32 per = (n_blk + gridDim.x - 1u) / gridDim.x;  // <= UFO_CAST_STRETCHES (host)
+		if (0 == threadIdx.x) {
+			u32 acc = 0;
+			for (u32 k = 0; k < UFO_CAST_STRETCHES; ++k) {
+				const u32 b = blockIdx.x * per + k;
+				const bool have = k < per && b < n_blk;
+				st_first[k] = have ? blk_range[2u * b] : 0u;
+				st_pre[k] = acc;
+				acc += have ? blk_range[2u * b + 1u] : 0u;
+			}
+			st_pre[UFO_CAST_STRETCHES] = acc;
+		}
+		__syncthreads();
+		mine = st_pre[UFO_CAST_STRETCHES];
+	}
+	auto rayIndex = [&](u32 i) -> size_t {  // position in the ray list of this workgroup's i-th ray
+		if (2 != MODE) return blockIdx.x + (size_t)i * gridDim.x;
+		u32 k = 0;
+		while (k + 1u < UFO_CAST_STRETCHES && i >= st_pre[k + 1u]) ++k;
+		return (size_t)st_first[k] + (i - st_pre[k]);
+	};
+	// LDS: [grid region: the bit grid / this pass's box of it / the filter][round constants, headers, segment queue]
+	const u32 region_words = (0 == MODE) ? (u32)(grid_all.bytes >> 2) : (1 == MODE ? (1u << UFO_CAST_FILT_LOG2) : (lds_grid_bytes >> 2));
+	RayConst* rc = reinterpret_cast<RayConst*>(lds + region_words);
+	RayHdr* hd = reinterpret_cast<RayHdr*>(rc + BATCH);
+	SegRec* q = reinterpret_cast<SegRec*>(hd + BATCH);
+	u32* sh = reinterpret_cast<u32*>(q + QCAP);  // [0..7], [16..23]: per-wave partial sums
 	const u32 lim = 1u << (g.L - depth);
 	const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
 	const u32 nwaves = min(8u, (blockDim.x + 63u) >> 6);
 	unsigned long long steps = 0;
 	u32 err = 0, oob = 0;
-	// rays of this workgroup: blockIdx.x, blockIdx.x + gridDim.x, ... in rounds of UFO_CAST_BATCH
-	const u32 mine = (n > blockIdx.x) ? (n - blockIdx.x + gridDim.x - 1) / gridDim.x : 0u;
-	for (u32 base = 0; base < mine; base += UFO_CAST_BATCH) {
+	// MODE 2 works through its rays in PASSES: as many consecutive rays as have a box that fits in LDS (the stretch is
+	// halved until it does); a stretch of <= 32 rays whose box still does not fit is marked through the filter
+	u32 ps = 0, pe = mine;
+	for (;;) {
+	Grid gr = grid_all;  // the grid the walk addresses: the scan's, or this pass's box of it
+	bool glob = 1 == MODE;
+	i32 boxo[3] = {0, 0, 0};  // offset of the box inside the scan's grid (cells; x a multiple of 32)
+	pe = mine;
+	if (2 == MODE) {
+		__shared__ i32 bb[6];
+		for (;;) {
+			__syncthreads();
+			if (threadIdx.x < 3u) {
+				bb[threadIdx.x] = INT32_MAX;
+				bb[3 + threadIdx.x] = INT32_MIN;
+			}
+			__syncthreads();
+			i32 lo[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, hi[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+			for (u32 i = ps + threadIdx.x; i < pe; i += blockDim.x) {
+				i32 c0[3], c1[3];
+				if (!rayEndCells(g, sensor, depth, ray_end[rayIndex(i)], c0, c1)) continue;
+				for (int a = 0; a < 3; ++a) {
+					lo[a] = min(lo[a], min(c0[a], c1[a]));
+					hi[a] = max(hi[a], max(c0[a], c1[a]));
+				}
+			}
+			for (int a = 0; a < 3; ++a) {
+				const i32 l = waveMinI(lo[a]), h = waveMaxI(hi[a]);
+				if (0 == (threadIdx.x & 63u)) {
+					if (l != INT32_MAX) atomicMin(&bb[a], l);
+					if (h != INT32_MIN) atomicMax(&bb[3 + a], h);
+				}
+			}
+			__syncthreads();
+			glob = true;
+			if (bb[0] > bb[3]) break;  // (no ray of the stretch is walked at all)
+			// the box as the host makes the scan's grid (makeGrid: one block of padding, even base), x moved down to a
+			// multiple of 32 cells inside the scan's grid so that words map onto words; never beyond the scan's grid
+			Grid sub = grid_all;
+			bool ok = true;
+			u64 rows = 1;
+			for (int a = 0; a < 3; ++a) {
+				i32 l = (bb[a] - 2) & ~1, h = bb[3 + a] + 2;
+				if (0 == a) l = grid_all.base[0] + (((l - grid_all.base[0]) >> 5) << 5);
+				l = max(l, grid_all.base[a]);
+				h = min(h, grid_all.base[a] + 2 * grid_all.nb[a] - 1);
+				if (h < l) ok = false;
+				sub.base[a] = l;
+				sub.nb[a] = (h - l) / 2 + 1;
+				boxo[a] = l - grid_all.base[a];
+				if (a) rows *= 2ull * (u64)sub.nb[a];
+			}
+			const u64 bytes = (((u64)(gridRowBits(sub) >> 3) * rows) + 15ull) & ~15ull;
+			if (ok && bytes <= (u64)box_limit_bytes) {
+				sub.bytes = bytes;
+				gr = sub;
+				glob = false;
+				break;
+			}
+			if (pe - ps <= 32u) break;
+			pe = ps + (pe - ps + 1u) / 2u;
+		}
+		if (glob && pe > ps && 0 == threadIdx.x) {
+			atomicAdd(&ctl->dbg[40], 1ull);  // (diagnostics: passes marked through the filter)
+			ctl->dbg[41] = ((u64)(u32)(bb[3] - bb[0]) << 40) | ((u64)(u32)(bb[4] - bb[1]) << 20) | (u64)(u32)(bb[5] - bb[2]);
+			ctl->dbg[42] = ((u64)ps << 32) | pe;
+			ctl->dbg[43] = mine;
+		}
+	}
+	const u32 lds_words = glob ? (1u << UFO_CAST_FILT_LOG2) : (u32)(gr.bytes >> 2);
+	{
+		uint4* l4 = reinterpret_cast<uint4*>(lds);
+		const u32 fill = glob ? 0xFFFFFFFFu : 0u;  // (filter tags: no cell has this index)
+		for (u32 j = threadIdx.x; j < (lds_words >> 2); j += blockDim.x) l4[j] = make_uint4(fill, fill, fill, fill);
+	}
+	const u32 rowBits = gridRowBits(gr), planeBits = rowBits * 2u * (u32)gr.nb[1];
+	// in rounds of BATCH
+	for (u32 base = ps; base < pe; base += BATCH) {
 		__syncthreads();  // previous round's queue and constants are no longer read (also orders the LDS zeroing)
 		const u32 t = threadIdx.x;
-		const bool have = t < UFO_CAST_BATCH && base + t < mine;
+		const bool have = t < BATCH && base + t < pe;
 		// ---- 1. one lane per ray: clip, keys, computeRayInit ----
 		u32 l1 = 0, dmax = 0, ax = 0, status = 0, lin0 = 0;
 		if (have) {
 			RayState r;
-			raySetup(g, sensor, depth, gr, ray_end[blockIdx.x + (size_t)(base + t) * gridDim.x], r);
+			raySetup(g, sensor, depth, gr, ray_end[rayIndex(base + t)], r);
 			status = r.status;
 			if (1 == r.status) {
-				err |= markBitChecked(gr, lds, rowBits, planeBits, r.start[0], r.start[1], r.start[2], lim, &oob);
+				err |= castMarkCheckedDyn(glob, gr, lds, slabs, rowBits, planeBits, r.start[0], r.start[1], r.start[2], lim, &oob);
 				steps += 1;
 			} else if (3 == r.status) {
 				// clipped ray (rare): sequential walk with every step checked, by this lane alone
@@ -1625,7 +1807,7 @@ __global__ __launch_bounds__(512) void k_cast(MapGeom g, D3 sensor, u32 depth, G
 						err |= ERR_RUNAWAY;
 						break;
 					}
-					err |= markBitChecked(gr, lds, rowBits, planeBits, cx, cy, cz, lim, &oob);
+					err |= castMarkCheckedDyn(glob, gr, lds, slabs, rowBits, planeBits, cx, cy, cz, lim, &oob);
 					if (ax_ <= ay_) {
 						if (ax_ <= az_) {
 							cx += r.s[0];
@@ -1688,7 +1870,7 @@ __global__ __launch_bounds__(512) void k_cast(MapGeom g, D3 sensor, u32 depth, G
 		// a ray of l1 steps cut every w = max(1, floor(dmax*K/l1)) pops has at most 2*l1/K + 1 segments
 		u32 K = k_min;
 		{
-			const u32 room = UFO_CAST_QCAP - nray2;  // >= QCAP - BATCH > 0
+			const u32 room = QCAP - nray2;  // >= QCAP - BATCH > 0
 			const u32 need = (2u * total + room - 1u) / room;
 			K = max(K, need);
 		}
@@ -1712,7 +1894,7 @@ __global__ __launch_bounds__(512) void k_cast(MapGeom g, D3 sensor, u32 depth, G
 			if (wv < wave) off += v;
 			nsegs += v;
 		}
-		if (t < UFO_CAST_BATCH) {
+		if (t < BATCH) {
 			hd[t].lin0 = lin0;
 			hd[t].ax = ax;
 			hd[t].w = w;
@@ -1726,8 +1908,8 @@ __global__ __launch_bounds__(512) void k_cast(MapGeom g, D3 sensor, u32 depth, G
 		// after k0 = j*w pops of a*: element A[k0-1] (= v) was popped and t_max_a* = A[k0]; of the other axis the
 		// elements before v were popped (strictly smaller, or equal when the axis has priority: the lower axis
 		// index wins ties, VEC3:244-251) -- their count moves the cut's cell.
-		for (u32 idx = threadIdx.x; idx < 2u * UFO_CAST_BATCH; idx += blockDim.x) {
-			const u32 ry = idx & (UFO_CAST_BATCH - 1u), role = idx / UFO_CAST_BATCH;
+		for (u32 idx = threadIdx.x; idx < 2u * BATCH; idx += blockDim.x) {
+			const u32 ry = idx & (BATCH - 1u), role = idx / BATCH;
 			const RayHdr h = hd[ry];
 			if (0 == h.nseg) continue;
 			const RayConst c = rc[ry];
@@ -1773,6 +1955,7 @@ __global__ __launch_bounds__(512) void k_cast(MapGeom g, D3 sensor, u32 depth, G
 						break;
 					}
 				}
+				if (cb >= 2048u) err |= ERR_RUNAWAY;  // (guard of the pop loop: cannot trip inside a grid of < 1024 cells per axis)
 				SegRec* o = &q[h.off + j];
 				if (0 == role) {
 					o->tm[axd] = ta;
@@ -1807,7 +1990,8 @@ __global__ __launch_bounds__(512) void k_cast(MapGeom g, D3 sensor, u32 depth, G
 			u32 cnt = 0;  // uniform guard only
 			while (go) {
 				++cnt;
-				atomicOr(&lds[lin >> 5], 1u << (lin & 31u));
+				if (glob) castMark<true>(lds, slabs, lin);
+				else castMark<false>(lds, slabs, lin);
 				const bool cxy = tmx <= tmy, cxz = tmx <= tmz, cyz = tmy <= tmz;
 				const bool selx = cxy & cxz;
 				const bool sely = !cxy & cyz;
@@ -1821,6 +2005,7 @@ __global__ __launch_bounds__(512) void k_cast(MapGeom g, D3 sensor, u32 depth, G
 				    (__double_as_longlong(tmx) <= idist) | (__double_as_longlong(tmy) <= idist) | (__double_as_longlong(tmz) <= idist);
 				go = (lin != end) & more & (cnt < 4096u);
 			}
+			if (cnt >= 4096u) err |= ERR_RUNAWAY;  // (a segment is ~K steps by construction: the guard cannot trip)
 			// every step moves one cell along one axis and never turns back: steps = L1 distance covered
 			const u32 ny2 = 2u * (u32)gr.nb[1];
 			const u32 r0 = lin_first / rowBits, r1 = lin / rowBits;
@@ -1830,13 +2015,30 @@ __global__ __launch_bounds__(512) void k_cast(MapGeom g, D3 sensor, u32 depth, G
 		}
 	}
 	__syncthreads();
-	{
+	if (0 == MODE) {
 		const uint4* l4 = reinterpret_cast<const uint4*>(lds);
 		uint4* out4 = reinterpret_cast<uint4*>(slabs) + (size_t)blockIdx.x * (lds_words >> 2);
 		const u32 n4 = lds_words >> 2;
 		for (u32 j = threadIdx.x; j < n4; j += blockDim.x) out4[j] = l4[j];
+	} else if (!glob) {
+		// the box goes into the scan's grid: a row of the box is a stretch of a row of the grid, word for word
+		const u32 rowW = rowBits >> 5, ny = 2u * (u32)gr.nb[1];
+		const u32 growW = gridRowBits(grid_all) >> 5, gny = 2u * (u32)grid_all.nb[1];
+		for (u32 j = threadIdx.x; j < lds_words; j += blockDim.x) {
+			const u32 wv = lds[j];
+			if (0 == wv) continue;
+			const u32 wx = j % rowW, r = j / rowW;
+			const u32 ly = r % ny, lz = r / ny;
+			if (lz >= 2u * (u32)gr.nb[2]) continue;  // (padding behind the last row)
+			const size_t gi = ((size_t)(lz + (u32)boxo[2]) * gny + (ly + (u32)boxo[1])) * growW + wx + ((u32)boxo[0] >> 5);
+			__hip_atomic_fetch_or(&slabs[gi], wv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
 	}
+	if (2 != MODE || pe >= mine) break;
+	ps = pe;
+	}  // passes
 	blockStoreSteps(steps, steps_part);
+	if (0 != MODE && 0 == threadIdx.x && steps_part[blockIdx.x]) atomicAdd(&ctl->n_steps, steps_part[blockIdx.x]);  // (nobody merges afterwards)
 	if (oob) atomicAdd(&ctl->n_oob, oob);
 	if (err) atomicOr(&ctl->err, err);
 }

@@ -179,6 +179,7 @@ struct ufomap_map {
 	DevBuf b_first, b_tilebits;         // fast path, per hand-over set (HandOver)
 	UpperGeo ugeo{};
 	DevBuf b_tilerec, b_tilehm;   // fast path, map stream only
+	DevBuf b_blk_range;           // k_select: where each of its workgroups' rays lie in the ray list (k_cast<2>)
 	u32 fast_hits_scan = 0;  // scan_id of the fast-path update whose hit masks are in b_tilehm
 	bool fast_hits_valid = false;  // the most recent integration that finished ran on the fast path
 	FastGeo fgeo_last{};
@@ -186,6 +187,7 @@ struct ufomap_map {
 	uint64_t seq = 0, latest_seq = 0;  // seq: of the integration that uses the current set; latest_seq: of the newest one enqueued
 	FastGeo fgeo{};
 	int opt_fast = 1;  // 0 = never take the fast path (fast_kernels.h)
+	int opt_cast_global = 1;  // 0 = grids beyond LDS go through k_dda_seg / k_dda (byte-per-block grid) instead of k_cast<true>
 	u64 host_ns[4] = {0, 0, 0, 0};  // diagnostics: host time inside doInsert -- scan half enqueue, map half enqueue, join, total
 	uint64_t n_fast = 0;
 	u32 hb_cap_mask = 0;
@@ -1131,16 +1133,17 @@ int scanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, const 
 			                   m->b_pt_end.as<D3>(), m->b_pt_flag.as<u8>(), m->b_pt_slot.as<u32>(), m->b_part0.as<BoxPartial>(), ctl,
 			                   m->ing);
 	}
+	HIP_TRY(m->b_blk_range.reserve((size_t)gp.x * 8));
 	{
 		ProfScope ps(m, "k_select");
 		if (discrete)
 			hipLaunchKernelGGL(k_select<true>, gp, dim3(256), 0, m->cs, m->g, sensor, N, (u32)depth, hh, m->b_pt_end.as<D3>(),
 			                   m->b_pt_flag.as<u8>(), m->b_pt_slot.as<u32>(), m->b_ray_end.as<D3>(), m->b_hit_code.as<u64>(),
-			                   m->b_hit_pt.as<u32>(), m->b_part1.as<BoxPartial>(), ctl);
+			                   m->b_hit_pt.as<u32>(), m->b_part1.as<BoxPartial>(), ctl, m->b_blk_range.as<u32>());
 		else
 			hipLaunchKernelGGL(k_select<false>, gp, dim3(256), 0, m->cs, m->g, sensor, N, (u32)depth, hh, m->b_pt_end.as<D3>(),
 			                   m->b_pt_flag.as<u8>(), m->b_pt_slot.as<u32>(), m->b_ray_end.as<D3>(), m->b_hit_code.as<u64>(),
-			                   m->b_hit_pt.as<u32>(), m->b_part1.as<BoxPartial>(), ctl);
+			                   m->b_hit_pt.as<u32>(), m->b_part1.as<BoxPartial>(), ctl, m->b_blk_range.as<u32>());
 	}
 	{
 		ProfScope ps(m, "k_reduce_boxes");
@@ -1187,7 +1190,9 @@ int scanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, const 
 		Grid& gr = m->gridM;
 		const bool packed = 2 * gr.nb[0] < 1023 && 2 * gr.nb[1] < 1023 && 2 * gr.nb[2] < 1023;
 		const u64 bytes1 = (u64)(gridRowBits(gr) >> 3) * (2ull * (u64)gr.nb[1]) * (2ull * (u64)gr.nb[2]);
-		if (packed && bytes1 <= UFO_DDA_LDSGRID_MAX) {
+		// ... and, with the marks going to the global grid through an LDS filter (k_cast<true>), for every grid the packed
+		// coordinates can address (< 1023 cells per axis, e.g. 8 cm / 20 m)
+		if (packed && (bytes1 <= UFO_DDA_LDSGRID_MAX || (m->opt_cast != 0 && m->opt_cast_global != 0 && bytes1 < (1ull << 28)))) {
 			gr.layout = 1;
 			gr.bytes = (bytes1 + 15) & ~15ull;
 		}
@@ -1221,6 +1226,9 @@ int scanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, const 
 		HIP_TRY(m->b_gridM.reserve(m->gridM.bytes));
 		int mode = m->gridM.bytes <= UFO_DDA_LDSGRID_MAX ? DDA_LDSGRID : (m->gridM.bytes < (1ull << 29) ? DDA_FILTER : DDA_DIRECT);
 		if (m->opt_dda_mode >= 0 && m->opt_dda_mode >= mode) mode = m->opt_dda_mode;  // tests may force a more general mode
+		// bit grid beyond LDS (or option cast_global = 2, for tests): k_cast<true> marks the global grid directly
+		const bool castg = 1 == m->gridM.layout && m->opt_cast != 0 && (m->gridM.bytes > UFO_DDA_LDSGRID_MAX || m->opt_cast_global >= 2);
+		if (castg) mode = DDA_FILTER;  // (the grid is cleared below, nothing is merged afterwards)
 		const size_t lds = mode == DDA_LDSGRID ? (size_t)m->gridM.bytes : (mode == DDA_FILTER ? (size_t)UFO_DDA_FILT * 4 : 0);
 		// Launch shape (measured on C2, 36.6 k rays, LDS-grid mode; lanes per ray x threads per workgroup ->
 		// walk kernel): 1x256 33 us, 2x512 34, 2x256 39, 1x512 42, 2x1024 43, 4x1024 47, 4x512 51, 1x128 52,
@@ -1246,8 +1254,26 @@ int scanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, const 
 			HIP_TRY(hipMemsetAsync(m->b_gridM.p, 0, m->gridM.bytes, m->cs));
 		}
 		// fused set-up + segment queue + walk (k_cast) when the bit grid and its queue fit in LDS
-		const bool cast = 1 == m->gridM.layout && m->opt_cast != 0 && m->gridM.bytes + UFO_CAST_LDS_EXTRA <= (160u << 10) - 512u;
-		if (cast) {
+		const bool cast = !castg && 1 == m->gridM.layout && m->opt_cast != 0 && m->gridM.bytes + UFO_CAST_LDS_EXTRA <= (160u << 10) - 512u;
+		if (castg) {
+			const u32 n_blk = (u32)((n + 255) / 256);  // workgroups of k_select
+			u32 nwg = m->opt_cast_wgs > 0 ? (u32)m->opt_cast_wgs : std::min<u32>(n_blk, 1024u);
+			nwg = std::max<u32>(1u, std::min<u32>(nwg, (n_rays + 63u) / 64u));
+			HIP_TRY(m->b_slabs.reserve((size_t)std::max(nwg, n_blk) * 8));
+			ProfScope ps(m, "k_cast_global");
+			// LDS: a workgroup's box of the grid (at least the fallback's filter), beside the rounds' queue and constants
+			const u32 grid_lds = ((160u << 10) - 1024u - (u32)UFO_CAST2_LDS_EXTRA) & ~15u;
+			if (3 == m->opt_cast_global) {  // (tests: marks one by one for every workgroup)
+				hipLaunchKernelGGL(k_cast<1>, dim3(nwg), dim3(512), ((size_t)4u << UFO_CAST_FILT_LOG2) + UFO_CAST_LDS_EXTRA, m->cs, m->g, sensor,
+				                   (u32)depth, m->gridM, m->b_gridM.as<u32>(), m->b_ray_end.as<D3>(), (u32)std::max(8, m->opt_cast_k), ctl, ctl,
+				                   m->b_slabs.as<unsigned long long>(), 0u, (const u32*)nullptr, 0u, 0u);
+			} else {
+				nwg = std::max<u32>(nwg, (n_blk + UFO_CAST_STRETCHES - 1u) / UFO_CAST_STRETCHES);
+				hipLaunchKernelGGL(k_cast<2>, dim3(nwg), dim3(512), (size_t)grid_lds + UFO_CAST2_LDS_EXTRA, m->cs, m->g, sensor, (u32)depth, m->gridM,
+				                   m->b_gridM.as<u32>(), m->b_ray_end.as<D3>(), (u32)std::max(8, m->opt_cast_k), ctl, ctl,
+				                   m->b_slabs.as<unsigned long long>(), grid_lds, m->b_blk_range.as<u32>(), n_blk, 4 == m->opt_cast_global ? 4096u : grid_lds);
+			}
+		} else if (cast) {
 			const u32 cblk = (m->opt_dda_block >= 256 && m->opt_dda_block <= 512) ? (u32)m->opt_dda_block : 512u;
 			u32 nwg = m->opt_cast_wgs > 0 ? (u32)m->opt_cast_wgs : 256u;
 			nwg = std::max<u32>(1u, std::min<u32>(nwg, (n_rays + 63u) / 64u));
@@ -1255,8 +1281,8 @@ int scanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, const 
 			unsigned long long* sp = reinterpret_cast<unsigned long long*>(m->b_slabs.as<char>() + (size_t)nwg * m->gridM.bytes);
 			{
 				ProfScope ps(m, "k_cast");
-				hipLaunchKernelGGL(k_cast, dim3(nwg), dim3(cblk), (size_t)m->gridM.bytes + UFO_CAST_LDS_EXTRA, m->cs, m->g, sensor, (u32)depth,
-				                   m->gridM, m->b_slabs.as<u32>(), m->b_ray_end.as<D3>(), (u32)std::max(8, m->opt_cast_k), ctl, ctl, sp);
+				hipLaunchKernelGGL(k_cast<0>, dim3(nwg), dim3(cblk), (size_t)m->gridM.bytes + UFO_CAST_LDS_EXTRA, m->cs, m->g, sensor, (u32)depth,
+				                   m->gridM, m->b_slabs.as<u32>(), m->b_ray_end.as<D3>(), (u32)std::max(8, m->opt_cast_k), ctl, ctl, sp, 0u, (const u32*)nullptr, 0u, 0u);
 			}
 			ProfScope ps(m, "k_merge_slabs");
 			const u32 n4 = (u32)(m->gridM.bytes >> 4);
@@ -1656,7 +1682,9 @@ ufomap_map* ufomap_map_create(double resolution, unsigned depth_levels, int auto
 		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dda_seg<DDA_LDSGRID>), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds);
 		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dda_seg<DDA_FILTER>), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds);
 		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_walk), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds);
-		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cast), hipFuncAttributeMaxDynamicSharedMemorySize, (160 << 10) - 512);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cast<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (160 << 10) - 512);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cast<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (160 << 10) - 512);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cast<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (160 << 10) - 512);
 	}
 	for (int a = 0; a < 3; ++a) {
 		m->min_change[a] = g.hs[g.L];  // resetMinMaxChangeDetection (occupancy_map_base.h:806-810)
@@ -1690,7 +1718,7 @@ void ufomap_map_destroy(ufomap_map* m)
 	                  &m->b_ctl,     &m->b_pt_end,  &m->b_pt_flag,  &m->b_pt_slot, &m->b_ray_end, &m->b_hit_code, &m->b_hit_pt,
 	                  &m->b_hh_keys, &m->b_gridM,   &m->b_crec,    &m->b_dlist,   &m->b_rays,   &m->b_part0,   &m->b_part1,   &m->b_slabs,   &m->b_hb_keys, &m->b_hb_mask, &m->b_hb_time,   &m->b_entries, &m->b_ent_slot, &m->b_newlist,
 	                  &m->b_wl0,     &m->b_wl1,     &m->b_in_xyz,   &m->b_in_rgb,  &m->b_codes,   &m->b_dump,
-	                  &m->b_first,   &m->b_tilebits, &m->b_tilerec, &m->b_tilehm};
+	                  &m->b_first,   &m->b_tilebits, &m->b_tilerec, &m->b_tilehm, &m->b_blk_range, &m->b_ctl_init};
 	for (DevBuf* b : bufs) b->release();
 	for (PendingEvent& pe : m->pend_ev) {
 		(void)hipEventDestroy(pe.a);
@@ -3285,6 +3313,8 @@ int ufomap_map_set_option(ufomap_map* m, const char* key, long long value)
 		m->opt_fast = (int)value;
 	} else if (0 == strcmp(key, "async_apply")) {
 		m->opt_async_apply = value ? 1 : 0;
+	} else if (0 == strcmp(key, "cast_global")) {
+		m->opt_cast_global = (int)value;
 	} else if (0 == strcmp(key, "cast")) {
 		m->opt_cast = value ? 1 : 0;
 	} else if (0 == strcmp(key, "cast_wgs")) {
