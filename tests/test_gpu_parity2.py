@@ -190,3 +190,32 @@ def test_pinned_and_pageable_host_clouds_pipelined():
         buf[:] = np.nan  # scribble over the caller's buffer right after the call
     g.insertPointCloudWait()
     _assert_same_map(g, o, "host clouds")
+
+
+@pytest.mark.parametrize("mode", ["small_limit", "near_wrap"])
+def test_phase_tags_restart(mode):
+    """The per-phase tags in the table (24 bits in tmax, 22 in lu_fl) are cleared and the numbering restarts before
+    the shortest can wrap (phaseGuard): same maps as the reference across restarts, pruning history included -- with
+    the restart forced every few scans, and with the counter started just below the real limit."""
+    from oracle import OracleMap, available
+    from ufomap_amd import OccupancyMap, PointCloud, scans
+    kind = "reference" if available("reference") else "port"
+    g, o = OccupancyMap(0.16), OracleMap(0.16, kind=kind)
+    if mode == "small_limit":
+        g.set_option("phase_limit", 7)
+    else:
+        g.set_option("scan_id", (1 << 22) - (1 << 12) - 5)
+    for i in range(14):
+        p = [0, 0, 1, 1, 0, 2, 2, 2, 0, 1, 0, 0, 2, 1][i]
+        origin, xyz, _ = scans.lidar64(beams=16, azimuths=512, origin=scans.lidar_pose(p), seed=100 + p)
+        discrete = bool(i % 3)
+        (g.insertPointCloudDiscrete if discrete else g.insertPointCloud)(origin, PointCloud(xyz), 12.0, 0, False, 0, bool(i % 2))
+        o.insert(origin, xyz, max_range=12.0, discrete=discrete)
+        if i % 4 == 3:
+            g.insertPointCloudWait()
+            assert g.digest() == golden_util.dump_digest(o.leaves(True), o.inner()), f"scan {i}"
+    g.insertPointCloudWait()
+    assert g.digest() == golden_util.dump_digest(o.leaves(True), o.inner())
+    assert g.write() == o.write()
+    resets = g.debug()[51]
+    assert resets >= (3 if mode == "small_limit" else 1), resets

@@ -220,6 +220,28 @@ __device__ inline void markDirty(const Table& t, bool want, u32 p, u32* __restri
 	if (first) wl[pos] = p;
 }
 
+// Phase tags start over (ufomap_hip.hip: phaseGuard): no block may look created, reached or timed "in this phase"
+// to a phase that reuses an old number. One thread per slot.
+__global__ __launch_bounds__(256) void k_reset_tags(Table t)
+{
+	const u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (s > (u64)t.mask) return;
+	t.stamp((u32)s) = 0;
+	t.tmax[s] = 0;
+	uint4* f = reinterpret_cast<uint4*>(t.lu_fl + 8 * s);
+	f[0] = make_uint4(0, 0, 0, 0);
+	f[1] = make_uint4(0, 0, 0, 0);
+}
+
+// a few counters from the host, by value (no host buffer whose lifetime anybody has to think about)
+struct SmallCounts {
+	u32 v[256];
+};
+__global__ void k_store_counts(SmallCounts c, u32 n, u32* __restrict__ out)
+{
+	if (threadIdx.x < n) out[threadIdx.x] = c.v[threadIdx.x];
+}
+
 // clear flag bits of a control block (the host re-runs an update that had stood back: ERR_PREV only -- a flag the
 // scan raised itself must survive)
 __global__ void k_ctl_clear(ScanCtl* ctl, u32 bits) { atomicAnd(&ctl->err, ~bits); }

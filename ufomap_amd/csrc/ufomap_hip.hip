@@ -48,9 +48,30 @@ int fail(int code, const std::string& msg)
 	} while (0)
 
 // grow-only device buffer
+// device allocation, move-only owner: released when it goes out of scope (every early return of the functions below)
 struct DevBuf {
 	void* p = nullptr;
 	size_t cap = 0;
+	DevBuf() = default;
+	DevBuf(const DevBuf&) = delete;
+	DevBuf& operator=(const DevBuf&) = delete;
+	DevBuf(DevBuf&& o) noexcept : p(o.p), cap(o.cap)
+	{
+		o.p = nullptr;
+		o.cap = 0;
+	}
+	DevBuf& operator=(DevBuf&& o) noexcept
+	{
+		if (this != &o) {
+			release();
+			p = o.p;
+			cap = o.cap;
+			o.p = nullptr;
+			o.cap = 0;
+		}
+		return *this;
+	}
+	~DevBuf() { release(); }
 	hipError_t reserve(size_t bytes)
 	{
 		if (bytes <= cap) return hipSuccess;
@@ -172,6 +193,9 @@ struct ufomap_map {
 	TableBufs tb;
 	DevBuf b_root;
 	u32 scan_id = 0;
+	bool poisoned = false;  // an update overran the node table half-way (ctlError): only clear / destroy are accepted
+	u32 phase_limit = (1u << 22) - (1u << 12);  // phaseGuard: tags are cleared and the numbering restarts here
+	u64 n_phase_resets = 0;
 	u64 used_est = 0;  // host-side view of MapRoot::used (refreshed at every control-block read)
 	// per-scan buffers
 	DevBuf b_ctl, b_pt_end, b_pt_flag, b_pt_slot, b_ray_end, b_hit_code, b_hit_pt, b_hh_keys;
@@ -352,8 +376,11 @@ int growTable(ufomap_map* m, u32 new_cap)
 		hipLaunchKernelGGL(k_rehash_parents, gridFor((u64)new_cap), dim3(256), 0, m->cs, nt);
 	}
 	HIP_TRY(hipStreamSynchronize(m->cs));
-	m->tb.release();
-	m->tb = nb;
+	u32 failed = 0;
+	HIP_TRY(hipMemcpy(&failed, d_fail, 4, hipMemcpyDeviceToHost));
+	if (failed)  // (cannot happen at load <= 0.5; the old table stays, `nb` is released on return)
+		return fail(UFOMAP_ERR_CAPACITY, "re-hash into the larger node table dropped " + std::to_string(failed) + " blocks; map unchanged");
+	m->tb = std::move(nb);  // (releases the old arrays)
 	m->t = nt;
 	return UFOMAP_OK;
 }
@@ -441,12 +468,32 @@ void swapWith(ufomap_map* m, HandOver& o)
 }
 
 int finishSet(ufomap_map* m, int k);
+extern "C" int ufomap_map_wait(ufomap_map* m);
+
+// Phase numbers (ufomap_map::scan_id) tag "created / reached / timed in this phase" in the table: 24 bits in tmax, 22 in
+// lu_fl, 32 in the stamps and the fast path's tile records. Before the shortest tag can wrap, everything in flight is
+// joined, every tag in the table is cleared and the numbering starts over -- a full pass over the table every ~4 million
+// phases (about 2 million scans). `phase_limit` is an option so that tests can make it happen every few scans.
+int phaseGuard(ufomap_map* m)
+{
+	if (m->scan_id < m->phase_limit) return UFOMAP_OK;
+	const int rc = ufomap_map_wait(m);
+	if (rc) return rc;
+	hipLaunchKernelGGL(k_reset_tags, gridFor((u64)m->t.mask + 1), dim3(256), 0, m->stream, m->t);
+	if (m->b_tilerec.p) HIP_TRY(hipMemsetAsync(m->b_tilerec.p, 0, m->b_tilerec.cap, m->stream));
+	HIP_TRY(hipStreamSynchronize(m->stream));
+	m->scan_id = 0;
+	m->fast_hits_valid = false;
+	++m->n_phase_resets;
+	return UFOMAP_OK;
+}
 
 // A new integration begins: the oldest hand-over set becomes the current one (its integration is joined first if it
 // is still pending), the set that was current becomes alt[1] (the predecessor), the old alt[1] becomes alt[0].
 int rotateSets(ufomap_map* m)
 {
-	int rc = UFOMAP_OK;
+	int rc = phaseGuard(m);
+	if (rc) return rc;
 	if (m->alt[0].pending) {
 		(void)hipEventSynchronize(m->alt[0].done_ev);
 		rc = finishSet(m, 0);
@@ -491,7 +538,12 @@ int ctlError(ufomap_map* m)
 		return fail(UFOMAP_ERR_RUNAWAY,
 		            "a clipped ray left the map cube (end point outside after moveLineInside); the reference walks ~2^31 "
 		            "cells on this input. Map unchanged.");
-	if (e & ERR_TABLE_FULL) return fail(UFOMAP_ERR_CAPACITY, "node table full (internal bound violated)");
+	if (e & ERR_TABLE_FULL) {
+		// blocks created before the table ran full are linked into the tree with unset contents: the handle refuses
+		// further work until ufomap_map_clear
+		m->poisoned = true;
+		return fail(UFOMAP_ERR_CAPACITY, "node table full (internal bound violated): the map is inconsistent, ufomap_map_clear it");
+	}
 	if (e & ERR_ENTRIES) return fail(UFOMAP_ERR_CAPACITY, "update list larger than its buffer (internal bound violated); map unchanged");
 	if (e & ERR_GRID_OOB) return fail(UFOMAP_ERR_CAPACITY, "a ray cell fell outside the scan grid (internal bound violated)");
 	return fail(UFOMAP_ERR_CAPACITY, "hit hash full (internal bound violated)");
@@ -1411,6 +1463,7 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 	auto lap = [&](int k, std::chrono::steady_clock::time_point since) {
 		m->host_ns[k] += (u64)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - since).count();
 	};
+	if (m->poisoned) return fail(UFOMAP_ERR_CAPACITY, "the map is inconsistent after a node table overflow: ufomap_map_clear it");
 	if (!swapped) (void)rotateSets(m);
 	m->seq = ++m->latest_seq;
 	if (m->chg_enabled) async = 0;  // the change log is sized between updates: one update at a time
@@ -1741,6 +1794,7 @@ int ufomap_map_clear(ufomap_map* m)
 	if (!m) return fail(UFOMAP_ERR_INVALID, "null map");
 	HIP_TRY(hipSetDevice(m->device));
 	(void)ufomap_map_wait(m);
+	m->poisoned = false;
 	m->cs = m->stream;
 	u32 cap = m->t.mask + 1;
 	HIP_TRY(hipMemsetAsync(m->t.blk, 0, (size_t)cap * sizeof(Block), m->stream));
@@ -1840,6 +1894,7 @@ int ufomap_map_insert(ufomap_map* m, const double sensor_origin[3], const double
 {
 	if (!m) return fail(UFOMAP_ERR_INVALID, "null map");
 	HIP_TRY(hipSetDevice(m->device));
+	if (m->poisoned) return fail(UFOMAP_ERR_CAPACITY, "the map is inconsistent after a node table overflow: ufomap_map_clear it");
 	(void)rotateSets(m);  // the staging buffers belong to the hand-over set of THIS scan
 	const void *d_xyz = nullptr, *d_rgb = nullptr;
 	const int urc = uploadCloud(m, xyz, n * 24, rgb, rgb ? n * 3 : 0, &d_xyz, &d_rgb);
@@ -1861,6 +1916,7 @@ int ufomap_map_insert_pointcloud2(ufomap_map* m, const double translation[3], co
 	if (m->g.color && !discrete)
 		return fail(UFOMAP_ERR_UNSUPPORTED, "OccupancyMapColor::insertPointCloud<PointCloudColor> does not compile in the reference (SURVEY.md 4)");
 	HIP_TRY(hipSetDevice(m->device));
+	if (m->poisoned) return fail(UFOMAP_ERR_CAPACITY, "the map is inconsistent after a node table overflow: ufomap_map_clear it");
 	(void)rotateSets(m);  // the staging buffers belong to the hand-over set of THIS scan
 	const uint8_t* d_data = static_cast<const uint8_t*>(data);
 	hipError_t e = hipSuccess;
@@ -1958,6 +2014,7 @@ int ufomap_map_set_value_volume_ch(ufomap_map* m, const double aabb_center[3], c
 	HIP_TRY(hipSetDevice(m->device));
 	int rc = ufomap_map_wait(m);
 	if (rc) return rc;
+	if ((rc = phaseGuard(m))) return rc;
 	const u32 L = m->g.L;
 	if (L < min_depth) return UFOMAP_OK;  // OMB:495-497
 	VolArgs a;
@@ -2632,6 +2689,7 @@ int ufomap_map_apply_keys(ufomap_map* m, const void* d_entries, const ufomap_key
 {
 	if (!m || !info) return fail(UFOMAP_ERR_INVALID, "null argument");
 	if (m->g.color) return fail(UFOMAP_ERR_UNSUPPORTED, "update lists carry no colour: apply_keys works on OccupancyMap only");
+	if (const int grc = phaseGuard(m)) return grc;
 	if (info->depth >= m->g.L) return fail(UFOMAP_ERR_INVALID, "depth must be < depth_levels");
 	HIP_TRY(hipSetDevice(m->device));
 	{
@@ -2747,7 +2805,13 @@ int ufomap_map_apply_keys_batch(ufomap_map* m, const void* const* d_lists, const
 	for (const Sub& sb : subs) new_bound += subNew(sb, sb.n);
 	for (const Sub& sb : subs) h_cnt.push_back(sb.n);
 	HIP_TRY(m->b_crec.reserve(h_cnt.size() * 4 + 16));
-	HIP_TRY(hipMemcpyAsync(m->b_crec.p, h_cnt.data(), h_cnt.size() * 4, hipMemcpyHostToDevice, m->stream));
+	{
+		// the counts travel as kernel arguments (captured at launch): an asynchronous copy from this local vector could
+		// still be reading it after an async_apply call has returned
+		SmallCounts sc{};
+		for (size_t k = 0; k < h_cnt.size() && k < 256; ++k) sc.v[k] = h_cnt[k];
+		hipLaunchKernelGGL(k_store_counts, dim3(1), dim3(256), 0, m->stream, sc, (u32)std::min<size_t>(h_cnt.size(), 256), m->b_crec.as<u32>());
+	}
 	const u32* d_cnt = m->b_crec.as<u32>();
 	// node table: every entry new is a true upper bound; on a warm map count the missing blocks before growing
 	m->scan_new_bound = new_bound;
@@ -3313,6 +3377,11 @@ int ufomap_map_set_option(ufomap_map* m, const char* key, long long value)
 		m->opt_fast = (int)value;
 	} else if (0 == strcmp(key, "async_apply")) {
 		m->opt_async_apply = value ? 1 : 0;
+	} else if (0 == strcmp(key, "phase_limit")) {
+		m->phase_limit = (u32)std::max<long long>(4, value);
+	} else if (0 == strcmp(key, "scan_id")) {
+		(void)ufomap_map_wait(m);
+		m->scan_id = (u32)value;  // (tests: start near the limit)
 	} else if (0 == strcmp(key, "cast_global")) {
 		m->opt_cast_global = (int)value;
 	} else if (0 == strcmp(key, "cast")) {
@@ -3345,6 +3414,7 @@ int ufomap_map_debug(ufomap_map* m, uint64_t* out, int n)
 	if (n > 62) out[62] = m->n_spec;       // scans enqueued on a predicted grid
 	if (n > 63) out[63] = m->n_spec_redo;  // ... of which had to be repeated
 	if (n > 61) out[61] = m->n_fast;       // scans enqueued on the fast path (fast_kernels.h)
+	if (n > 51) out[51] = m->n_phase_resets;  // phaseGuard
 	for (int k = 0; k < 4 && 52 + k < n; ++k) out[52 + k] = m->host_ns[k];  // host time inside doInsert (ns): scan enqueue, map enqueue, join, total
 	return rc;
 }
