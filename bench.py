@@ -97,6 +97,7 @@ def cpu_baseline(clouds, seq, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--python-exchange", action="store_true", help="N > 1: exchange the update lists with torch.distributed instead of the C ABI's own RCCL call")
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -183,7 +184,16 @@ def main():
     m = OccupancyMap(RES, device=local_rank)
     if batch_mode:
         from ufomap_amd import dist as udist
-        batch = udist.BatchIntegrator(m, dist.group.WORLD, dev)
+        # the batch step is ONE call of the C ABI (ufomap_map_insert_batch: scan, RCCL all-gather, apply); torch.distributed
+        # only carries the communicator id, the barriers and the max over ranks of this script. --python-exchange selects
+        # the same protocol written with torch collectives (ufomap_amd/dist.py: BatchIntegrator), which is also what the
+        # gloo tests drive on CPU.
+        batch_impl = "c_abi:ufomap_map_insert_batch"
+        if args.python_exchange:
+            batch = udist.BatchIntegrator(m, dist.group.WORLD, dev)
+            batch_impl = "python:torch.distributed all_gather + ufomap_map_apply_keys_batch"
+        else:
+            batch = udist.CBatchIntegrator(m, local_rank, dist.group.WORLD)
 
         def step_resident(i):
             p = pose_of(i)
@@ -343,7 +353,8 @@ def main():
                        if not batch_mode else
                        "configs[3]: batch of N concurrent 131072-pt LiDAR scans per step (moving sensors), 16 cm leaf, one scan per GPU, RCCL exchange of update lists, every replica applies all N in order",
                        "points_per_scan": n_pts, "rays_cast_mean": mean_rays, "dda_steps_mean": mean_steps, "per_pose": counts,
-                       "leaf_m": RES, "max_range_m": MAX_RANGE, "depth_levels": 16, "parallelism": f"scan-per-gpu x{world}"},
+                       "leaf_m": RES, "max_range_m": MAX_RANGE, "depth_levels": 16, "parallelism": f"scan-per-gpu x{world}",
+                       **({"batch_impl": batch_impl} if batch_mode else {})},
             "roofline": roof, "self_check": self_check,
         }
         out.update(extra)

@@ -269,6 +269,28 @@ int ufomap_map_apply_keys(ufomap_map* m, const void* d_entries, const ufomap_key
  * never reads the map -- so it overlaps with the update. */
 int ufomap_map_apply_keys_batch(ufomap_map* m, const void* const* d_lists, const ufomap_keys_info* infos, int n_lists);
 
+/* ---- batched multi-sensor integration across GPUs (BASELINE config C4) ------------------------------
+ * One process per GPU. Every rank calls ufomap_map_insert_batch with ITS scan of the batch: the scan is ray-cast into
+ * an update list (ufomap_map_scan_keys), ONE RCCL all-gather of fixed-size slots (header + list) moves the lists of
+ * all ranks to all ranks, and every rank applies them in rank order with one walk of its replica's tree
+ * (ufomap_map_apply_keys_batch). Every replica then equals the reference's map after
+ * insertPointCloudDiscrete / insertPointCloud (occupancy_map_base.h:270-417) of scan 0, 1, ..., world-1 in that order.
+ * Depth 0, non-colour maps. librccl is loaded at run time (UFOMAP_RCCL_LIB overrides the name; a copy already in the
+ * process is preferred).
+ *   ufomap_comm_unique_id   on ONE rank; the 128 bytes reach the others by the host's own means (file, socket, MPI...)
+ *   ufomap_comm_create      ncclCommInitRank on `device` (collective: all ranks call it)
+ *   ufomap_comm_from_nccl   wrap a communicator the host already has (ncclComm_t); not destroyed by ufomap_comm_destroy
+ *   ufomap_comm_stats       out[0] world, [1] rank, [2] slot capacity in bytes, [3] times the capacity had to grow */
+#define UFOMAP_COMM_ID_BYTES 128
+typedef struct ufomap_comm ufomap_comm;
+int ufomap_comm_unique_id(uint8_t id[UFOMAP_COMM_ID_BYTES]);
+ufomap_comm* ufomap_comm_create(const uint8_t id[UFOMAP_COMM_ID_BYTES], int world, int rank, int device);
+ufomap_comm* ufomap_comm_from_nccl(void* nccl_comm, int world, int rank, int device);
+void ufomap_comm_destroy(ufomap_comm* c);
+int ufomap_comm_stats(const ufomap_comm* c, uint64_t out[4]);
+int ufomap_map_insert_batch(ufomap_map* m, ufomap_comm* c, const double sensor_origin[3], const double* d_xyz, size_t n,
+                            double max_range, unsigned depth, int discrete);
+
 /* Diagnostic overrides for tests: "dda_mode" (-1 auto; 1 / 2 force the LDS-filter / direct variants of
  * the ray kernel on grids that would fit in LDS), "entry_guess" (cap of the guessed update-list size, to
  * exercise the exact-size retry), "dda_seg" (0: one lane per ray), "merge_phases" (0: hits and misses of a

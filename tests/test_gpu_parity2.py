@@ -219,3 +219,31 @@ def test_phase_tags_restart(mode):
     assert g.write() == o.write()
     resets = g.debug()[51]
     assert resets >= (3 if mode == "small_limit" else 1), resets
+
+
+def test_insert_batch_c_abi_world1():
+    """ufomap_map_insert_batch: scan -> RCCL all-gather of update-list slots -> apply, all inside the C library (the
+    communicator comes from ufomap_comm_create; no torch.distributed anywhere). One rank: the code path of the 8-GPU
+    run minus the peers. The slot capacity starts small here so that the all-ranks-grow-alike rule is exercised too."""
+    import torch
+    from oracle import OracleMap, available
+    from ufomap_amd import OccupancyMap, Comm, scans
+    kind = "reference" if available("reference") else "port"
+    g, o = OccupancyMap(0.16), OracleMap(0.16, kind=kind)
+    g.set_option("async_apply", 1)
+    comm = Comm(Comm.unique_id(), 1, 0, 0)
+    try:
+        for s in range(5):
+            origin, xyz, _ = scans.lidar64(origin=scans.lidar_pose(s % 3), seed=100 + s % 3, beams=32, azimuths=1024)
+            d = torch.from_numpy(xyz).cuda()
+            g.insert_batch(comm, origin, d.data_ptr(), xyz.shape[0], 20.0, 0, bool(s % 2))
+            o.insert(origin, xyz, max_range=20.0, discrete=bool(s % 2))
+            torch.cuda.synchronize()
+        g.insertPointCloudWait()
+        assert g.digest() == golden_util.dump_digest(o.leaves(True), o.inner())
+        assert g.write() == o.write()
+        st = comm.stats()
+        assert st["world"] == 1 and st["slot_bytes"] >= 1 << 20
+    finally:
+        g.insertPointCloudWait()
+        comm.close()

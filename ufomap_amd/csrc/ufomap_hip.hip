@@ -2895,6 +2895,217 @@ int ufomap_map_apply_keys_batch(ufomap_map* m, const void* const* d_lists, const
 	return finishPending(m);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Batched multi-sensor integration across GPUs behind the C ABI (BASELINE config C4): one process per
+// GPU, every rank ray-casts ITS scan into an update list, ONE RCCL all-gather of fixed-size slots (header + list)
+// moves all lists to all ranks, every rank applies the N lists in rank order with one walk of its replica's tree
+// (ufomap_map_apply_keys_batch) -- the same map on every rank as the reference integrating the N scans one after the
+// other. RCCL is loaded at run time (an already loaded copy is preferred, e.g. the one torch brought): the library has
+// no link-time dependency on it, and a single-GPU host never touches it.
+// ------------------------------------------------------------------------------------------------------------------
+extern "C++" {
+struct IdBytes {
+	char b[128];  // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES)
+};
+namespace
+{
+struct Rccl {
+	void* lib = nullptr;
+	int (*GetUniqueId)(void*) = nullptr;
+	int (*CommInitRank)(void**, int, /* ncclUniqueId by value */ IdBytes, int) = nullptr;
+	int (*CommDestroy)(void*) = nullptr;
+	int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+	const char* (*GetErrorString)(int) = nullptr;
+};
+Rccl* rccl()
+{
+	static Rccl r;
+	static bool tried = false;
+	if (tried) return r.lib ? &r : nullptr;
+	tried = true;
+	const char* env = getenv("UFOMAP_RCCL_LIB");
+	const char* names[] = {env, "librccl.so.1", "librccl.so"};
+	void* h = nullptr;
+	for (const char* name : names) {  // a copy that is already in the process first
+		if (!name || !*name) continue;
+		h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+		if (h) break;
+	}
+	for (const char* name : names) {
+		if (h) break;
+		if (!name || !*name) continue;
+		h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+	}
+	if (!h) return nullptr;
+	r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+	r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+	r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+	r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(h, "ncclAllGather"));
+	r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+	if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather) return nullptr;
+	r.lib = h;
+	return &r;
+}
+int rcclFail(int code, const char* what)
+{
+	Rccl* r = rccl();
+	return fail(UFOMAP_ERR_DEVICE, std::string(what) + ": " + ((r && r->GetErrorString) ? r->GetErrorString(code) : "RCCL error ") + " (" +
+	                                   std::to_string(code) + ")");
+}
+constexpr size_t kSlotHeader = 64;  // ufomap_keys_info (40 bytes), padded: travels in front of the list
+}  // namespace
+}  // extern "C++"
+
+struct ufomap_comm {
+	void* comm = nullptr;  // ncclComm_t
+	bool own = false;
+	int world = 1, rank = 0, device = 0;
+	size_t cap = 1u << 20;  // bytes per slot; all ranks hold the same value (it only grows, by a rule all ranks apply alike)
+	DevBuf send, recv[2];
+	int flip = 0;
+	uint8_t* h_hdr = nullptr;  // pinned: world headers
+	uint64_t n_regrow = 0;
+};
+
+int ufomap_comm_unique_id(uint8_t id[UFOMAP_COMM_ID_BYTES])
+{
+	if (!id) return fail(UFOMAP_ERR_INVALID, "null argument");
+	Rccl* r = rccl();
+	if (!r) return fail(UFOMAP_ERR_UNSUPPORTED, "librccl not found (set UFOMAP_RCCL_LIB)");
+	static_assert(UFOMAP_COMM_ID_BYTES == sizeof(IdBytes), "ncclUniqueId is 128 bytes");
+	const int e = r->GetUniqueId(id);
+	return e ? rcclFail(e, "ncclGetUniqueId") : UFOMAP_OK;
+}
+
+static ufomap_comm* commAlloc(int world, int rank, int device)
+{
+	if (world < 1 || world > 128 || rank < 0 || rank >= world) {
+		(void)fail(UFOMAP_ERR_INVALID, "comm: need 1 <= world <= 128 and 0 <= rank < world");
+		return nullptr;
+	}
+	if (hipSetDevice(device) != hipSuccess) {
+		(void)fail(UFOMAP_ERR_DEVICE, "hipSetDevice");
+		return nullptr;
+	}
+	ufomap_comm* c = new ufomap_comm;
+	c->world = world;
+	c->rank = rank;
+	c->device = device;
+	if (hipHostMalloc((void**)&c->h_hdr, (size_t)world * kSlotHeader) != hipSuccess) {
+		delete c;
+		(void)fail(UFOMAP_ERR_DEVICE, "hipHostMalloc");
+		return nullptr;
+	}
+	return c;
+}
+
+ufomap_comm* ufomap_comm_create(const uint8_t id[UFOMAP_COMM_ID_BYTES], int world, int rank, int device)
+{
+	Rccl* r = rccl();
+	if (!r || !id) {
+		(void)fail(UFOMAP_ERR_UNSUPPORTED, "librccl not found (set UFOMAP_RCCL_LIB)");
+		return nullptr;
+	}
+	ufomap_comm* c = commAlloc(world, rank, device);
+	if (!c) return nullptr;
+	IdBytes ib;
+	memcpy(ib.b, id, sizeof(ib.b));
+	const int e = r->CommInitRank(&c->comm, world, ib, rank);
+	if (e) {
+		(void)rcclFail(e, "ncclCommInitRank");
+		(void)hipHostFree(c->h_hdr);
+		delete c;
+		return nullptr;
+	}
+	c->own = true;
+	return c;
+}
+
+ufomap_comm* ufomap_comm_from_nccl(void* nccl_comm, int world, int rank, int device)
+{
+	if (!nccl_comm || !rccl()) {
+		(void)fail(UFOMAP_ERR_UNSUPPORTED, "no communicator / librccl not found");
+		return nullptr;
+	}
+	ufomap_comm* c = commAlloc(world, rank, device);
+	if (c) c->comm = nccl_comm;
+	return c;
+}
+
+void ufomap_comm_destroy(ufomap_comm* c)
+{
+	if (!c) return;
+	(void)hipSetDevice(c->device);
+	(void)hipDeviceSynchronize();
+	if (c->own && c->comm) (void)rccl()->CommDestroy(c->comm);
+	if (c->h_hdr) (void)hipHostFree(c->h_hdr);
+	delete c;
+}
+
+int ufomap_comm_stats(const ufomap_comm* c, uint64_t out[4])
+{
+	if (!c || !out) return fail(UFOMAP_ERR_INVALID, "null argument");
+	out[0] = (uint64_t)c->world;
+	out[1] = (uint64_t)c->rank;
+	out[2] = (uint64_t)c->cap;
+	out[3] = c->n_regrow;
+	return UFOMAP_OK;
+}
+
+int ufomap_map_insert_batch(ufomap_map* m, ufomap_comm* c, const double sensor_origin[3], const double* d_xyz, size_t n, double max_range,
+                            unsigned depth, int discrete)
+{
+	if (!m || !c || !sensor_origin) return fail(UFOMAP_ERR_INVALID, "null argument");
+	if (m->g.color) return fail(UFOMAP_ERR_UNSUPPORTED, "update lists carry no colour: insert_batch works on OccupancyMap only");
+	if (0 != depth) return fail(UFOMAP_ERR_UNSUPPORTED, "insert_batch: insert depth 0 only");
+	Rccl* r = rccl();
+	if (!r) return fail(UFOMAP_ERR_UNSUPPORTED, "librccl not found (set UFOMAP_RCCL_LIB)");
+	HIP_TRY(hipSetDevice(m->device));
+	// 1. this rank's scan -> update list (scan stream; never reads the map: overlaps the previous batch's tree update)
+	ufomap_keys_info info;
+	int rc = ufomap_map_scan_keys(m, sensor_origin, d_xyz, n, max_range, depth, discrete, 0, &info);
+	if (rc) return rc;
+	const size_t my_bytes = ((size_t)info.n_hit + info.n_miss) * sizeof(Entry);
+	const int W = c->world;
+	std::vector<ufomap_keys_info> infos((size_t)W);
+	for (;;) {
+		// 2. header + list into this rank's slot, ONE all-gather of fixed-size slots, the W headers back to the host
+		HIP_TRY(c->send.reserve(c->cap));
+		HIP_TRY(c->recv[0].reserve(c->cap * (size_t)W));
+		HIP_TRY(c->recv[1].reserve(c->cap * (size_t)W));
+		uint8_t* send = c->send.as<uint8_t>();
+		uint8_t* recv = c->recv[c->flip].as<uint8_t>();
+		memset(c->h_hdr, 0, kSlotHeader);
+		memcpy(c->h_hdr, &info, sizeof(info));
+		HIP_TRY(hipMemcpyAsync(send, c->h_hdr, kSlotHeader, hipMemcpyHostToDevice, m->sstream));
+		const bool fits = kSlotHeader + my_bytes <= c->cap;  // (if not, the header alone tells everybody how much room is needed)
+		if (fits && my_bytes) HIP_TRY(hipMemcpyAsync(send + kSlotHeader, m->b_entries.p, my_bytes, hipMemcpyDeviceToDevice, m->sstream));
+		const int e = r->AllGather(send, recv, c->cap, /* ncclChar */ 0, c->comm, m->sstream);
+		if (e) return rcclFail(e, "ncclAllGather");
+		HIP_TRY(hipMemcpy2DAsync(c->h_hdr, kSlotHeader, recv, c->cap, kSlotHeader, (size_t)W, hipMemcpyDeviceToHost, m->sstream));
+		HIP_TRY(hipStreamSynchronize(m->sstream));
+		size_t need = 0;
+		for (int k = 0; k < W; ++k) {
+			memcpy(&infos[(size_t)k], c->h_hdr + (size_t)k * kSlotHeader, sizeof(ufomap_keys_info));
+			need = std::max(need, kSlotHeader + ((size_t)infos[(size_t)k].n_hit + infos[(size_t)k].n_miss) * sizeof(Entry));
+		}
+		if (need <= c->cap) break;
+		// some rank's list did not fit: every rank sees that in the headers and grows to the same capacity; an update of
+		// an earlier batch that still reads the old receive buffers finishes first
+		rc = ufomap_map_wait(m);
+		if (rc) return rc;
+		while (c->cap < need) c->cap *= 2;
+		++c->n_regrow;
+	}
+	// 3. the W lists in rank order, one walk of the tree; with option async_apply the call returns after enqueueing and
+	// the next batch's scan overlaps it (two receive buffers, used alternately)
+	std::vector<const void*> lists((size_t)W);
+	uint8_t* recv = c->recv[c->flip].as<uint8_t>();
+	for (int k = 0; k < W; ++k) lists[(size_t)k] = (infos[(size_t)k].n_hit + infos[(size_t)k].n_miss) ? recv + (size_t)k * c->cap + kSlotHeader : nullptr;
+	c->flip ^= 1;
+	return ufomap_map_apply_keys_batch(m, lists.data(), infos.data(), W);
+}
+
 // liblz4, loaded at run time (the reference links it for its I/O only: octree.h:1430-1486)
 extern "C++" {
 namespace

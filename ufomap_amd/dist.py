@@ -123,3 +123,28 @@ class BatchIntegrator:
             for r in range(len(lists)):
                 self.backend.apply(r, headers[r], lists[r])
         return headers
+
+
+class CBatchIntegrator:
+    """The same batch step through the C ABI alone (``ufomap_map_insert_batch``, include/ufomap_hip.h): scan, RCCL
+    all-gather and apply are one library call; torch.distributed is only used here to hand the communicator's
+    128-byte id from rank 0 to the others (any out-of-band channel would do: this is what a C++ host does with
+    its own transport)."""
+
+    def __init__(self, occupancy_map, device_index: int, group=None):
+        from .occupancy_map import Comm
+        self.m = occupancy_map
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        ids = [Comm.unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(ids, src=0, group=group)
+        self.comm = Comm(ids[0], world, rank, device_index)
+        self.m.set_option("async_apply", 1)
+
+    def integrate(self, origin, d_xyz_ptr, n, max_range=-1.0, depth=0, discrete=True):
+        self.m.insert_batch(self.comm, origin, d_xyz_ptr, n, max_range, depth, discrete)
+
+    def close(self):
+        self.m.insertPointCloudWait()
+        self.comm.close()

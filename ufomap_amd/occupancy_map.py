@@ -298,6 +298,13 @@ class OccupancyMapBase:
             arr[i] = k
         capi.check(self._lib.ufomap_map_apply_keys_batch(self._h, ptrs, arr, n))
 
+    def insert_batch(self, comm, origin, d_xyz_ptr, n, max_range=-1.0, depth=0, discrete=True):
+        """This rank's scan of a multi-GPU batch (``ufomap_map_insert_batch``): ray casting here, one RCCL all-gather of the
+        update lists, all ranks' lists applied in rank order."""
+        o = np.ascontiguousarray(origin, dtype=np.float64)
+        capi.check(self._lib.ufomap_map_insert_batch(self._h, comm._h, _p(o, C.c_double), C.c_void_p(int(d_xyz_ptr)), n, float(max_range),
+                                                     int(depth), int(discrete)))
+
     def insertPointCloudDone(self):
         return bool(capi.check(self._lib.ufomap_map_done(self._h)))
 
@@ -416,6 +423,43 @@ class OccupancyMapBase:
         ms = np.zeros(cap, np.float64)
         n = capi.check(self._lib.ufomap_map_kernel_times(self._h, names, _p(launches, C.c_uint64), _p(ms, C.c_double), cap))
         return {names[i].decode(): dict(launches=int(launches[i]), total_ms=float(ms[i])) for i in range(min(n, cap))}
+
+
+class Comm:
+    """``ufomap_comm``: the RCCL communicator of the batched multi-GPU path, behind the C ABI (one process per GPU)."""
+
+    ID_BYTES = 128
+
+    def __init__(self, unique_id: bytes, world: int, rank: int, device: int = 0):
+        self._lib = capi.load()
+        buf = (C.c_uint8 * self.ID_BYTES).from_buffer_copy(bytes(unique_id))
+        self._h = self._lib.ufomap_comm_create(buf, world, rank, device)
+        if not self._h:
+            raise RuntimeError(self._lib.ufomap_last_error().decode())
+        self.world, self.rank = world, rank
+
+    @staticmethod
+    def unique_id() -> bytes:
+        lib = capi.load()
+        buf = (C.c_uint8 * Comm.ID_BYTES)()
+        capi.check(lib.ufomap_comm_unique_id(buf))
+        return bytes(buf)
+
+    def stats(self):
+        out = (C.c_uint64 * 4)()
+        capi.check(self._lib.ufomap_comm_stats(self._h, out))
+        return dict(world=int(out[0]), rank=int(out[1]), slot_bytes=int(out[2]), regrown=int(out[3]))
+
+    def close(self):
+        if self._h:
+            self._lib.ufomap_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class OccupancyMap(OccupancyMapBase):
