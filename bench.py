@@ -207,6 +207,7 @@ def main():
     dts = run_leg(m, step_resident, args.min_timed_s)
     head = leg_summary(dts, world)
     digests = {"resident": m.digest()}
+    mem_stats = m.stats()
     final_dump = (m.leaves(True), m.inner()) if rank == 0 else None
 
     extra = {}
@@ -356,6 +357,9 @@ def main():
                        "leaf_m": RES, "max_range_m": MAX_RANGE, "depth_levels": 16, "parallelism": f"scan-per-gpu x{world}",
                        **({"batch_impl": batch_impl} if batch_mode else {})},
             "roofline": roof, "self_check": self_check,
+            "memory": {"table_bytes": mem_stats["bytes"], "live_blocks": mem_stats["inner_nodes"], "leaves": mem_stats["leaf_nodes"],
+                       "bytes_per_live_block": mem_stats["bytes_per_block"],
+                       "note": "node table as allocated (64 B block record + 72 B per-phase words per slot, load <= 0.6) after the headline leg's last repetition"},
         }
         out.update(extra)
         if dt_ev:

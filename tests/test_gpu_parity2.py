@@ -247,3 +247,47 @@ def test_insert_batch_c_abi_world1():
     finally:
         g.insertPointCloudWait()
         comm.close()
+
+
+@pytest.mark.parametrize("case", ["depth0_16cm", "depth0_8cm_colour", "depth2_4cm", "continuous_16cm"])
+def test_sparse_ray_cell_set_beyond_scratch_limit(case):
+    """A scan whose bounding box needs more scratch than the limit allows goes through the sparse set of ray cells
+    (Grid::layout 2) instead of failing: the reference's CodeMap has no size bound (code.h:568-785). Forced here by an
+    option; the set starts at 64 Ki slots and doubles until the scan fits (the 8 cm case needs several rounds)."""
+    from oracle import OracleMap, available
+    from ufomap_amd import OccupancyMap, OccupancyMapColor, PointCloud, PointCloudColor, scans
+    kind = "reference" if available("reference") else "port"
+    res, depth, color, discrete, full = {"depth0_16cm": (0.16, 0, False, True, False), "depth0_8cm_colour": (0.08, 0, True, True, True),
+                                         "depth2_4cm": (0.04, 2, False, True, False), "continuous_16cm": (0.16, 0, False, False, False)}[case]
+    g = (OccupancyMapColor if color else OccupancyMap)(res)
+    o = OracleMap(res, kind=kind, color=color)
+    g.set_option("sparse_set", 1)
+    g.set_option("spec", 0)
+    kw = {} if full else dict(beams=32, azimuths=1024)
+    for s in range(3):
+        origin, xyz, rgb = scans.lidar64(origin=scans.lidar_pose(s), seed=100 + s, colored=color, **kw)
+        cloud = PointCloudColor(xyz, rgb) if color else PointCloud(xyz)
+        (g.insertPointCloudDiscrete if discrete else g.insertPointCloud)(origin, cloud, 20.0, depth, False, 0, False)
+        o.insert(origin, xyz, rgb, max_range=20.0, depth=depth, discrete=discrete)
+        if kind == "port":
+            assert g.last_counts()["steps"] == o.last_steps()
+    assert g.digest() == golden_util.dump_digest(o.leaves(True), o.inner())
+    assert g.write() == o.write()
+
+
+def test_far_returns_take_the_sparse_set_by_themselves():
+    """Three returns 1.5 - 3 km away in an otherwise small 2 cm scan: the scan's box would need ~10^14 bytes as a dense
+    grid (far beyond the default 16 GB scratch limit), the rays touch ~400 k cells. No option set: the sparse set is what
+    the library falls back to on its own, and the map equals the reference's."""
+    from oracle import OracleMap, available
+    from ufomap_amd import OccupancyMap, PointCloud, scans
+    kind = "reference" if available("reference") else "port"
+    g, o = OccupancyMap(0.02, depth_levels=20), OracleMap(0.02, depth_levels=20, kind=kind)  # (the reference smashes its stack at depth_levels 21)
+    origin, xyz, _ = scans.lidar64(beams=8, azimuths=256)
+    far = np.array([[1500.3, 2.1, 40.7], [-30.2, 2950.9, -12.4], [800.5, -700.25, 300.125]])
+    xyz = np.ascontiguousarray(np.concatenate([xyz * 0.2, far]))
+    for discrete in (True, False):
+        (g.insertPointCloudDiscrete if discrete else g.insertPointCloud)(origin, PointCloud(xyz), -1.0, 0, False, 0, False)
+        o.insert(origin, xyz, max_range=-1.0, discrete=discrete)
+    assert g.last_counts()["steps"] > 300000
+    assert g.digest() == golden_util.dump_digest(o.leaves(True), o.inner())

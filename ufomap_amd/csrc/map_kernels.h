@@ -1698,12 +1698,18 @@ __global__ __launch_bounds__(256) void k_read_up(Table t, MapGeom g, const ReadR
 // ------------------------------------------------------------------------------------------------
 // table growth: re-insert every block into a table of twice/four times the capacity
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_rehash_copy(Table src, Table dst, u32* fail)
+// Collapsed blocks (F_DEAD: the node is a leaf again, octree.h:1060-1066 deleteChildren) are not copied: nothing refers
+// to them (the parent's INNER bit went with the collapse) and createNode makes a fresh block if the node is ever split
+// again -- a re-hash is where their slots are reclaimed. `copied` counts what the new table holds (MapRoot::used).
+__global__ __launch_bounds__(256) void k_rehash_copy(Table src, Table dst, u32* fail, u32* copied)
 {
 	u32 ncap = src.mask + 1;
+	u32 mine = 0;
 	for (u32 s = blockIdx.x * blockDim.x + threadIdx.x; s < ncap; s += gridDim.x * blockDim.x) {
 		u64 lk = src.key(s);
 		if (0 == lk) continue;
+		if (src.flags(s) & F_DEAD) continue;
+		++mine;
 		u32 d = hash64(lk) & dst.mask;
 		bool ok = false;
 		for (u32 probe = 0; probe <= dst.mask; ++probe) {
@@ -1731,6 +1737,8 @@ __global__ __launch_bounds__(256) void k_rehash_copy(Table src, Table dst, u32* 
 		dst.flags(d) = src.flags(s);
 		dst.stamp(d) = src.stamp(s);
 	}
+	for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+	if (0 == (threadIdx.x & 63u) && mine) atomicAdd(copied, mine);
 }
 __global__ __launch_bounds__(256) void k_rehash_parents(Table dst)
 {

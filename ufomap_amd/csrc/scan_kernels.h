@@ -33,7 +33,8 @@ struct Grid {
 	i32 base[3];  // cell coordinate (key >> depth, as signed) of block (0,0,0); even
 	i32 nb[3];    // blocks per axis
 	u32 depth;
-	u32 layout;  // 0: one byte per block (bit = child index); 1: one bit per cell, x fastest, rows padded to 32 cells
+	u32 layout;  // 0: one byte per block (bit = child index); 1: one bit per cell, x fastest, rows padded to 32 cells;
+	             // 2: no dense grid, a hash set of node blocks (MissSet) -- boxes beyond the scratch limit
 	u64 bytes;   // layout 0: nb[0]*nb[1]*nb[2]; layout 1: rowBits/8 * 2nb[1] * 2nb[2] (= blocks incl. padding); rounded up to 16
 };
 // layout 1: bits per row of cells
@@ -2141,6 +2142,154 @@ __global__ __launch_bounds__(256) void k_extract(MapGeom g, Grid gr, const u32* 
 				}
 			}
 			entries[my] = e;
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// Grid::layout 2: NO dense grid. The reference's CodeMap has no size bound (code.h:568-785); a scan whose bounding box
+// would need more scratch than ufomap_map_set_scratch_limit allows (a few far returns in an otherwise small scan: the
+// box is what grows, not the number of cells) keeps the ray cells in a hash set of node blocks instead: key = Morton
+// code of the block at level depth+1, value = mask of its marked children -- the update-list record, deduplicated as
+// it is produced. One lane per ray, every step is one insert-or-OR; the host doubles the set and repeats the walk if it
+// fills up (ERR_ENTRIES). Slower per step than any of the grid kernels (a device-scope CAS/OR per step, ~17 per ns for
+// the whole chip), but bounded by the cells the rays touch, not by the box they span.
+// ------------------------------------------------------------------------------------------------
+struct MissSet {
+	u64* keys;  // ~0 = empty
+	u32* mask;
+	u32 cap_mask;
+	u32* count;  // occupied slots
+};
+__device__ inline u32 missSetMark(const MissSet& ms, i32 cx, i32 cy, i32 cz, u32 lim, u32* oob)
+{
+	if ((u32)cx >= lim || (u32)cy >= lim || (u32)cz >= lim) {
+		++*oob;  // key outside [0, 2^L): dropped, as gridMark does
+		return 0;
+	}
+	const u64 key = morton3((u32)cx >> 1, (u32)cy >> 1, (u32)cz >> 1);
+	const u32 bit = 1u << ((cx & 1) | ((cy & 1) << 1) | ((cz & 1) << 2));
+	u32 s = hash64(key) & ms.cap_mask;
+	const u32 max_probe = (ms.cap_mask >> 1) + 1u;
+	for (u32 probe = 0; probe < max_probe; ++probe) {
+		u64 k = __hip_atomic_load(&ms.keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (k == ~0ULL) {
+			// (a load factor above 1/2 counts as full: the host doubles the set and repeats the walk)
+			if (__hip_atomic_load(ms.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > (ms.cap_mask >> 1)) return ERR_ENTRIES;
+			const u64 prev = atomicCAS((unsigned long long*)&ms.keys[s], ~0ULL, (unsigned long long)key);
+			if (prev == ~0ULL) atomicAdd(ms.count, 1u);
+			k = (prev == ~0ULL) ? key : prev;
+		}
+		if (k == key) {
+			if (!(__hip_atomic_load(&ms.mask[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) atomicOr(&ms.mask[s], bit);
+			return 0;
+		}
+		s = (s + 1) & ms.cap_mask;
+	}
+	return ERR_ENTRIES;
+}
+
+__global__ __launch_bounds__(256) void k_dda_set(MapGeom g, D3 sensor, u32 depth, Grid gr, MissSet ms, const D3* __restrict__ ray_end,
+                                                 const ScanCtl* ctl_in, ScanCtl* ctl)
+{
+	const u32 n = ctl_in->n_rays;
+	const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	const u32 lim = 1u << (g.L - depth);
+	unsigned long long steps = 0;
+	u32 err = 0, oob = 0;
+	if (i < n) {
+		RayState r;
+		raySetup(g, sensor, depth, gr, ray_end[i], r);
+		if (1 == r.status) {
+			err |= missSetMark(ms, r.start[0], r.start[1], r.start[2], lim, &oob);
+			steps = 1;
+		} else if (0 != r.status) {
+			// freeSpaceNormal (OMB:1261-1301) step by step, every cell through the set
+			i32 cx = r.start[0], cy = r.start[1], cz = r.start[2];
+			double tx = r.tm[0], ty = r.tm[1], tz = r.tm[2];
+			const u64 budget = 3ull * (1ull << g.L) + 8;
+			bool more;
+			do {
+				if (++steps > budget) {
+					err |= ERR_RUNAWAY;
+					break;
+				}
+				err |= missSetMark(ms, cx, cy, cz, lim, &oob);
+				if (err & ERR_ENTRIES) break;  // the walk is repeated with a larger set
+				if (tx <= ty) {
+					if (tx <= tz) {
+						cx += r.s[0];
+						tx += r.td[0];
+					} else {
+						cz += r.s[2];
+						tz += r.td[2];
+					}
+				} else {
+					if (ty <= tz) {
+						cy += r.s[1];
+						ty += r.td[1];
+					} else {
+						cz += r.s[2];
+						tz += r.td[2];
+					}
+				}
+				more = (cx != r.goal[0] || cy != r.goal[1] || cz != r.goal[2]) && (fmin(fmin(tx, ty), tz) <= r.dist);
+			} while (more);
+			if (steps > budget) steps = budget;
+		}
+	}
+	waveAddU64(&ctl->n_steps, steps);
+	if (oob) atomicAdd(&ctl->n_oob, oob);
+	if (err) atomicOr(&ctl->err, err);
+}
+
+// the set's records -> update list (k_extract for Grid::layout 2); MERGED as there
+template <bool MERGED>
+__global__ __launch_bounds__(256) void k_extract_set(MapGeom g, Grid gr, MissSet ms, u32 which, Entry* __restrict__ entries, u32 cap, ScanCtl* ctl,
+                                                     HitBlocks hb)
+{
+	const u32 level = gr.depth + 1;
+	const u32 nslots = ms.cap_mask + 1u;
+	const u32 stride = gridDim.x * blockDim.x;
+	const u32 iters = (nslots + stride - 1) / stride;  // uniform trip count: every lane reaches the wave-aggregated append
+	u32 s = blockIdx.x * blockDim.x + threadIdx.x;
+	for (u32 it = 0; it < iters; ++it, s += stride) {
+		const bool have = s < nslots && ms.keys[s] != ~0ULL && 0 != (ms.mask[s] & 0xFFu);
+		const u32 my = waveAppend(&ctl->n_entries[which], have);
+		if (!have || my >= cap) continue;
+		const u64 p = ms.keys[s] & ((1ULL << (3 * (g.L - level))) - 1ULL);
+		const u32 mb = ms.mask[s] & 0xFFu;
+		Entry e;
+		e.lk = (1ULL << (3 * (g.L - level))) | p;
+		e.hit = 0;
+		e.miss = (u8)mb;
+		e.level = (u8)level;
+		e.c_last = (u8)(31 - __clz((int)mb));  // misses: ascending code order -> highest child
+		e.t_last = 0;
+		if (MERGED) {
+			const u32 hs = hitBlocksFind(hb, p);
+			if (hs != 0xFFFFFFFFu) {
+				const u32 hm = hb.mask[hs];
+				e.hit = (u8)hm;
+				hb.mask[hs] = hm | UFO_HB_TAKEN;
+			}
+		}
+		entries[my] = e;
+	}
+}
+// the set's cells as codes (stage-level parity export)
+__global__ __launch_bounds__(256) void k_set_codes(MissSet ms, u64* __restrict__ codes, u32 cap, ScanCtl* ctl)
+{
+	const u32 nslots = ms.cap_mask + 1u;
+	for (u32 s = blockIdx.x * blockDim.x + threadIdx.x; s < nslots; s += gridDim.x * blockDim.x) {
+		const u64 k = ms.keys[s];
+		if (k == ~0ULL) continue;
+		u32 m = ms.mask[s] & 0xFFu;
+		while (m) {
+			const u32 c = (u32)__ffs(m) - 1u;
+			m &= m - 1u;
+			const u32 pos = atomicAdd(&ctl->n_codes, 1u);
+			if (pos < cap) codes[pos] = (k << 3) | (u64)c;
 		}
 	}
 }

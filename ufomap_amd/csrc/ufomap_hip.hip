@@ -193,6 +193,8 @@ struct ufomap_map {
 	TableBufs tb;
 	DevBuf b_root;
 	u32 scan_id = 0;
+	u64 miss_set_slots = 0;  // Grid::layout 2: capacity of the sparse set of ray cells (grows by doubling, remembered)
+	u32 miss_set_count = 0;  // ... node blocks in it after the last walk
 	bool poisoned = false;  // an update overran the node table half-way (ctlError): only clear / destroy are accepted
 	u32 phase_limit = (1u << 22) - (1u << 12);  // phaseGuard: tags are cleared and the numbering restarts here
 	u64 n_phase_resets = 0;
@@ -211,6 +213,7 @@ struct ufomap_map {
 	uint64_t seq = 0, latest_seq = 0;  // seq: of the integration that uses the current set; latest_seq: of the newest one enqueued
 	FastGeo fgeo{};
 	int opt_fast = 1;  // 0 = never take the fast path (fast_kernels.h)
+	int opt_sparse_set = 0;   // 1 = every scan's ray cells through the sparse set (Grid::layout 2), whatever its box needs
 	int opt_cast_global = 1;  // 0 = grids beyond LDS go through k_dda_seg / k_dda (byte-per-block grid) instead of k_cast<true>
 	u64 host_ns[4] = {0, 0, 0, 0};  // diagnostics: host time inside doInsert -- scan half enqueue, map half enqueue, join, total
 	uint64_t n_fast = 0;
@@ -365,21 +368,24 @@ int growTable(ufomap_map* m, u32 new_cap)
 	TableBufs nb;
 	int rc = allocTable(m, new_cap, &nt, &nb);
 	if (rc) return rc;
-	u32* d_fail = m->b_ctl.as<u32>() + (sizeof(ScanCtl) + 3) / 4;  // spare word after the control block
-	HIP_TRY(hipMemsetAsync(d_fail, 0, 4, m->cs));
+	u32* d_fail = m->b_ctl.as<u32>() + (sizeof(ScanCtl) + 3) / 4;  // two spare words after the control block: failures, blocks copied
+	HIP_TRY(hipMemsetAsync(d_fail, 0, 8, m->cs));
 	{
 		ProfScope ps(m, "k_rehash_copy");
-		hipLaunchKernelGGL(k_rehash_copy, gridFor((u64)m->t.mask + 1), dim3(256), 0, m->cs, m->t, nt, d_fail);
+		hipLaunchKernelGGL(k_rehash_copy, gridFor((u64)m->t.mask + 1), dim3(256), 0, m->cs, m->t, nt, d_fail, d_fail + 1);
 	}
 	{
 		ProfScope ps(m, "k_rehash_parents");
 		hipLaunchKernelGGL(k_rehash_parents, gridFor((u64)new_cap), dim3(256), 0, m->cs, nt);
 	}
 	HIP_TRY(hipStreamSynchronize(m->cs));
-	u32 failed = 0;
-	HIP_TRY(hipMemcpy(&failed, d_fail, 4, hipMemcpyDeviceToHost));
-	if (failed)  // (cannot happen at load <= 0.5; the old table stays, `nb` is released on return)
-		return fail(UFOMAP_ERR_CAPACITY, "re-hash into the larger node table dropped " + std::to_string(failed) + " blocks; map unchanged");
+	u32 res[2] = {0, 0};
+	HIP_TRY(hipMemcpy(res, d_fail, 8, hipMemcpyDeviceToHost));
+	if (res[0])  // (cannot happen at load <= 0.5; the old table stays, `nb` is released on return)
+		return fail(UFOMAP_ERR_CAPACITY, "re-hash into the larger node table failed; map unchanged");
+	// collapsed blocks were left behind: the fill count is what was copied
+	HIP_TRY(hipMemcpy(&m->b_root.as<MapRoot>()->used, &res[1], 4, hipMemcpyHostToDevice));
+	m->used_est = res[1];
 	m->tb = std::move(nb);  // (releases the old arrays)
 	m->t = nt;
 	return UFOMAP_OK;
@@ -793,7 +799,13 @@ int extractLists(ufomap_map* m, u64 capH, u64 capM, bool zero_counts, bool merge
 	if (zero_counts) HIP_TRY(hipMemsetAsync(&ctl->n_entries[0], 0, 8, m->cs));  // otherwise zero from the control-block upload
 	if (merged) {
 		HitBlocks hb{capH ? m->b_hb_keys.as<u64>() : nullptr, m->b_hb_mask.as<u32>(), m->b_hb_time.as<u32>(), m->hb_cap_mask};
-		if (capM) {
+		if (capM && 2 == m->gridM.layout) {
+			ProfScope ps(m, "k_extract_set");
+			const u64 slots = m->miss_set_slots;
+			const MissSet ms{m->b_gridM.as<u64>(), reinterpret_cast<u32*>(m->b_gridM.as<u64>() + slots), (u32)(slots - 1), nullptr};
+			hipLaunchKernelGGL(k_extract_set<true>, gridFor(slots, 256, 2048), dim3(256), 0, m->cs, m->g, m->gridM, ms, 0u, ent_h, (u32)(capH + capM),
+			                   ctl, hb);
+		} else if (capM) {
 			ProfScope ps(m, "k_extract");
 			if (1 == m->gridM.layout)
 				hipLaunchKernelGGL(k_extract_bits<true>, gridFor(m->gridM.bytes, 256, 2048), dim3(256), 0, m->cs, m->g, m->gridM,
@@ -817,7 +829,13 @@ int extractLists(ufomap_map* m, u64 capH, u64 capM, bool zero_counts, bool merge
 		                   (u32)capH, ctl);
 		m->hb_clean = m->hb_cap_mask + 1;
 	}
-	if (capM) {
+	if (capM && 2 == m->gridM.layout) {
+		ProfScope ps(m, "k_extract_set");
+		const u64 slots = m->miss_set_slots;
+		const MissSet ms{m->b_gridM.as<u64>(), reinterpret_cast<u32*>(m->b_gridM.as<u64>() + slots), (u32)(slots - 1), nullptr};
+		hipLaunchKernelGGL(k_extract_set<false>, gridFor(slots, 256, 2048), dim3(256), 0, m->cs, m->g, m->gridM, ms, 1u, ent_m, (u32)capM, ctl,
+		                   HitBlocks{nullptr, nullptr, nullptr, 0});
+	} else if (capM) {
 		ProfScope ps(m, "k_extract");
 		if (1 == m->gridM.layout)
 			hipLaunchKernelGGL(k_extract_bits<false>, gridFor(m->gridM.bytes, 256, 2048), dim3(256), 0, m->cs, m->g, m->gridM,
@@ -1250,9 +1268,14 @@ int scanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, const 
 		}
 	}
 	u64 gbytes = m->haveM ? m->gridM.bytes : 0;  // hits are grouped through a hash, only grid M is dense
-	if (gbytes > m->scratch_limit)
-		return fail(UFOMAP_ERR_CAPACITY, "scan dedup grids need " + std::to_string(gbytes) + " bytes > scratch limit " +
-		                                     std::to_string(m->scratch_limit) + " (ufomap_map_set_scratch_limit)");
+	if (gbytes > m->scratch_limit || (m->opt_sparse_set && m->haveM && !simple)) {  // (option sparse_set: tests)
+		// the box is too large for a dense grid: the ray cells go through a hash set of node blocks instead (Grid::layout 2,
+		// scan_kernels.h: MissSet) -- bounded by the cells the rays touch, as the reference's CodeMap is
+		if (simple)
+			return fail(UFOMAP_ERR_CAPACITY, "scan dedup grid needs " + std::to_string(gbytes) + " bytes > scratch limit " +
+			                                     std::to_string(m->scratch_limit) + " (ufomap_map_set_scratch_limit; simple ray casting has no sparse fallback)");
+		m->gridM.layout = 2;
+	}
 	if (m->haveH) {
 		if (n > (1u << 29)) return fail(UFOMAP_ERR_INVALID, "more than 2^29 points in one scan");
 		const u32 hbcap = nextPow2(std::max<u64>(256, (u64)n_hits * 2));
@@ -1274,7 +1297,40 @@ int scanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, const 
 		HitBlocks hb{m->b_hb_keys.as<u64>(), m->b_hb_mask.as<u32>(), m->b_hb_time.as<u32>(), m->hb_cap_mask};
 		hipLaunchKernelGGL(k_hitmark, gridFor(n_hits), dim3(256), 0, m->cs, hb, m->b_hit_code.as<u64>(), m->b_hit_pt.as<u32>(), ctl, ctl);
 	}
-	if (m->haveM) {
+	if (m->haveM && 2 == m->gridM.layout) {
+		// sparse: walk into the set; if it fills up, double it and walk again (the size is remembered for later scans)
+		for (;;) {
+			const u64 slots = std::max<u64>(m->miss_set_slots, 1ull << 16);
+			if (slots * 12 > m->scratch_limit && slots > (1ull << 16))
+				return fail(UFOMAP_ERR_CAPACITY, "the scan's ray cells do not fit the scratch limit even as a sparse set (ufomap_map_set_scratch_limit)");
+			m->miss_set_slots = slots;
+			HIP_TRY(m->b_gridM.reserve(slots * 12 + 16));
+			u64* keys = m->b_gridM.as<u64>();
+			u32* mask = reinterpret_cast<u32*>(keys + slots);
+			u32* count = mask + slots;
+			HIP_TRY(hipMemsetAsync(keys, 0xFF, slots * 8, m->cs));
+			HIP_TRY(hipMemsetAsync(mask, 0, slots * 4 + 16, m->cs));
+			m->gridM.bytes = slots * 12;
+			const MissSet ms{keys, mask, (u32)(slots - 1), count};
+			{
+				ProfScope ps(m, "k_dda_set");
+				hipLaunchKernelGGL(k_dda_set, dim3((n_rays + 255) / 256), dim3(256), 0, m->cs, m->g, sensor, (u32)depth, m->gridM, ms,
+				                   m->b_ray_end.as<D3>(), ctl, ctl);
+			}
+			HIP_TRY(hipMemcpyAsync(m->h_ctl, m->b_ctl.p, sizeof(ScanCtl), hipMemcpyDeviceToHost, m->cs));
+			HIP_TRY(hipMemcpyAsync(&m->miss_set_count, count, 4, hipMemcpyDeviceToHost, m->cs));
+			HIP_TRY(hipStreamSynchronize(m->cs));
+			if (!(m->h_ctl->err & ERR_ENTRIES)) break;
+			if (slots >= (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "sparse ray-cell set would exceed 2^31 node blocks");
+			m->miss_set_slots = slots * 2;
+			// the flag and the step count of the abandoned walk go; what the head kernels left in the control block stays
+			hipLaunchKernelGGL(k_ctl_clear, dim3(1), dim3(1), 0, m->cs, ctl, (u32)ERR_ENTRIES);
+			HIP_TRY(hipMemsetAsync(&ctl->n_steps, 0, 8, m->cs));
+			HIP_TRY(hipMemsetAsync(&ctl->n_oob, 0, 4, m->cs));
+		}
+		const int erc = ctlError(m);
+		if (erc) return erc;
+	} else if (m->haveM) {
 		HIP_TRY(m->b_gridM.reserve(m->gridM.bytes));
 		int mode = m->gridM.bytes <= UFO_DDA_LDSGRID_MAX ? DDA_LDSGRID : (m->gridM.bytes < (1ull << 29) ? DDA_FILTER : DDA_DIRECT);
 		if (m->opt_dda_mode >= 0 && m->opt_dda_mode >= mode) mode = m->opt_dda_mode;  // tests may force a more general mode
@@ -1400,9 +1456,9 @@ int extractPhase(ufomap_map* m, u32 n_hits, u32 n_rays, u64* capH_out, u64* capM
 {
 	ScanCtl* ctl = m->b_ctl.as<ScanCtl>();
 	u64 capH = m->haveH ? (u64)n_hits : 0;
-	u64 capM = m->haveM ? m->gridM.bytes : 0;
+	u64 capM = m->haveM ? (2 == m->gridM.layout ? (u64)m->miss_set_count : m->gridM.bytes) : 0;
 	const u64 guess = m->opt_entry_guess ? m->opt_entry_guess : std::max<u64>(1u << 20, (u64)n_rays * 64);
-	if (capM > guess) {
+	if (capM > guess && 2 != m->gridM.layout) {
 		// counting pass (cap = 0 writes nothing), then the exact size
 		ProfScope ps(m, "k_extract_count");
 		if (1 == m->gridM.layout)
@@ -2568,7 +2624,12 @@ size_t ufomap_map_last_misses(ufomap_map* m, uint64_t* codes, size_t cap)
 	for (int pass = 0; pass < 2; ++pass) {
 		if (hipMemsetAsync(&ctl->n_codes, 0, 4, m->stream) != hipSuccess) return (size_t)-1;
 		if (pass && m->b_codes.reserve((size_t)total * 8) != hipSuccess) return (size_t)-1;
-		if (1 == m->gridM.layout)
+		if (2 == m->gridM.layout) {
+			const u64 slots = m->miss_set_slots;
+			const MissSet ms{m->b_gridM.as<u64>(), reinterpret_cast<u32*>(m->b_gridM.as<u64>() + slots), (u32)(slots - 1), nullptr};
+			hipLaunchKernelGGL(k_set_codes, gridFor(slots, 256, 8192), dim3(256), 0, m->stream, ms, pass ? m->b_codes.as<u64>() : (u64*)nullptr,
+			                   pass ? total : 0u, ctl);
+		} else if (1 == m->gridM.layout)
 			hipLaunchKernelGGL(k_grid_codes_bits, gridFor(m->gridM.bytes >> 2, 256, 8192), dim3(256), 0, m->stream, m->g, m->gridM,
 			                   m->b_gridM.as<u32>(), pass ? m->b_codes.as<u64>() : (u64*)nullptr, pass ? total : 0u, ctl);
 		else
@@ -3588,6 +3649,8 @@ int ufomap_map_set_option(ufomap_map* m, const char* key, long long value)
 		m->opt_fast = (int)value;
 	} else if (0 == strcmp(key, "async_apply")) {
 		m->opt_async_apply = value ? 1 : 0;
+	} else if (0 == strcmp(key, "sparse_set")) {
+		m->opt_sparse_set = value ? 1 : 0;
 	} else if (0 == strcmp(key, "phase_limit")) {
 		m->phase_limit = (u32)std::max<long long>(4, value);
 	} else if (0 == strcmp(key, "scan_id")) {

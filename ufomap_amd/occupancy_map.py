@@ -305,6 +305,10 @@ class OccupancyMapBase:
         capi.check(self._lib.ufomap_map_insert_batch(self._h, comm._h, _p(o, C.c_double), C.c_void_p(int(d_xyz_ptr)), n, float(max_range),
                                                      int(depth), int(discrete)))
 
+    def set_scratch_limit(self, n_bytes):
+        """``ufomap_map_set_scratch_limit``: largest dense per-scan grid; scans beyond it take the sparse set of ray cells."""
+        capi.check(self._lib.ufomap_map_set_scratch_limit(self._h, int(n_bytes)))
+
     def insertPointCloudDone(self):
         return bool(capi.check(self._lib.ufomap_map_done(self._h)))
 
@@ -379,7 +383,8 @@ class OccupancyMapBase:
     def stats(self):
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
         capi.check(self._lib.ufomap_map_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
-        return dict(inner_nodes=a.value, leaf_nodes=b.value, bytes=c.value)
+        # bytes: the node table as allocated (all slots); bytes_per_block: per LIVE node block (= inner node with its 8 children)
+        return dict(inner_nodes=a.value, leaf_nodes=b.value, bytes=c.value, bytes_per_block=(c.value / a.value) if a.value else float("nan"))
 
     # ---- stage-level outputs / measurement ---------------------------------------------------------
     def _codes(self, fn):
