@@ -10,8 +10,8 @@
  * Conventions: plain pointers and sizes only; every function that can fail returns int
  * (0 = UFOMAP_OK, <0 = error) and leaves a message for ufomap_last_error(); nothing throws.
  * The reference's hot path has no error reporting at all, so UFOMAP_OK is the only
- * outcome a reference-valid call can produce.  A map handle owns three HIP streams (scan half, tree update,
- * read-back); with async != 0 up to two tree updates may be in flight while the next scan is cast -- the
+ * outcome a reference-valid call can produce.  A map handle owns four HIP streams (cloud upload + first
+ * kernel of a scan, scan half, tree update, read-back); with async != 0 up to two tree updates may be in flight while the next scan is cast -- the
  * reference has one `integrate_` future (occupancy_map_base.h:315, 405, 1553) and overlaps only its head loop
  * with it; results are identical either way.  Not thread-safe per handle (neither is the reference).
  *
@@ -53,7 +53,9 @@ void ufomap_map_destroy(ufomap_map* m);
 int ufomap_map_clear(ufomap_map* m);
 /* Pre-size the node table for n 8-child node blocks (optional; the table grows on demand). */
 int ufomap_map_reserve(ufomap_map* m, size_t n_blocks);
-/* Upper bound in bytes for the per-scan dedup grids (default 16 GiB). */
+/* Upper bound in bytes for a scan's dense dedup grid (default 16 GiB). A scan whose bounding box needs more keeps its ray
+ * cells in a sparse set of node blocks instead (bounded by the cells the rays touch, as the reference's CodeMap is,
+ * code.h:568-785; slower per step); the set itself must fit the limit too. */
 int ufomap_map_set_scratch_limit(ufomap_map* m, size_t bytes);
 
 /* ---- sensor model setters (occupancy_map_base.h:746-773), probabilities, not log-odds ------- */
@@ -297,7 +299,10 @@ int ufomap_map_insert_batch(ufomap_map* m, ufomap_comm* c, const double sensor_o
  * depth-0 scan as two passes over the tree instead of one; the environment variable UFOMAP_MERGE_PHASES
  * sets the default for new maps), "spec" (0: always read a scan's bounding boxes back before sizing its ray
  * grid; default 1: a depth-0 scan is enqueued on the grid predicted from the previous scan and repeated if it
- * does not fit). Results never depend on these. */
+ * does not fit), "fast" (0: never take the five-launch steady-state path of fast_kernels.h), "cast_global" (0: grids
+ * beyond LDS through k_dda_seg instead of k_cast<2>; 2-4: force the box / filter variants on small grids), "sparse_set"
+ * (1: every scan's ray cells through the sparse set), "phase_limit" / "scan_id" (when the per-phase tags restart),
+ * "async_apply" (apply_keys_batch / insert_batch return after enqueueing). Results never depend on these. */
 int ufomap_map_set_option(ufomap_map* m, const char* key, long long value);
 
 /* Diagnostics: up to 64 raw 64-bit words written by the last integration's kernels (per-level
