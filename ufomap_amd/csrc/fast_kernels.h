@@ -141,10 +141,17 @@ __device__ inline PointRay pointRay(const MapGeom& g, const FastGeo& fg, const D
 // F1: first point in the voxel (atomicMin of the point index on the dense cell array), bounding boxes, validity of
 // the predicted grid for this scan (ERR_SPEC: the host repeats the scan on the general path).
 // ------------------------------------------------------------------------------------------------
+// What k_fhits found out about a point, for k_fcast (which would otherwise run the same ~100 double-precision operations
+// per point again): 32 bytes per point, written once, read once.
+struct PointRec {
+	D3 end;     // ray end as freeSpace gets it
+	u32 cell;   // hit voxel's index in the grid (hit candidates only)
+	u32 flags;  // 1 cast, 2 hit candidate, 4 odd
+};
 template <bool DISCRETE>
 __global__ __launch_bounds__(256) void k_fhits(MapGeom g, FastGeo fg, D3 sensor, const double* __restrict__ xyz, u32 n, double max_range,
                                                u32 color_variant, u32* __restrict__ first, BoxPartial* __restrict__ part, ScanCtl* ctl,
-                                               Ingest ing)
+                                               Ingest ing, PointRec* __restrict__ recs)
 {
 	const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
 	double amn[3] = {1e300, 1e300, 1e300}, amx[3] = {-1e300, -1e300, -1e300};
@@ -153,6 +160,11 @@ __global__ __launch_bounds__(256) void k_fhits(MapGeom g, FastGeo fg, D3 sensor,
 	if (i < n) {
 		const PointRay r = pointRay<DISCRETE>(g, fg, sensor, xyz, ing, i, max_range, color_variant, amn, amx);
 		odd = r.odd;
+		PointRec pr;
+		pr.end = r.end;
+		pr.cell = r.cell;
+		pr.flags = (r.cast ? 1u : 0u) | (r.hitcand ? 2u : 0u) | (r.odd ? 4u : 0u);
+		recs[i] = pr;
 		if (!r.odd) {
 			if (r.hitcand) atomicMin(&first[r.cell], i);
 			if (r.cast) {
@@ -180,7 +192,7 @@ template <bool DISCRETE>
 __global__ __launch_bounds__(512) void k_fcast(MapGeom g, FastGeo fg, D3 sensor, const double* __restrict__ xyz, u32 n, double max_range,
                                                u32 color_variant, const u32* __restrict__ first, D3* __restrict__ ray_scratch, u32 cap_wg,
                                                u32* __restrict__ slabs, u32 k_min, const ScanCtl* ctl_in, ScanCtl* ctl,
-                                               unsigned long long* __restrict__ steps_part, Ingest ing)
+                                               unsigned long long* __restrict__ steps_part, Ingest ing, const PointRec* __restrict__ recs)
 {
 	extern __shared__ __attribute__((aligned(16))) u32 lds[];
 	const u32 err_in = ctl_in->err;  // (looked at once the LDS grid has been cleared: the load is in flight meanwhile)
@@ -220,10 +232,10 @@ __global__ __launch_bounds__(512) void k_fcast(MapGeom g, FastGeo fg, D3 sensor,
 			D3 end{0, 0, 0};
 			if (p < pts) {
 				const u32 i = blockIdx.x + p * gridDim.x;
-				double amn[3], amx[3];
-				const PointRay r = pointRay<DISCRETE>(g, fg, sensor, xyz, ing, i, max_range, color_variant, amn, amx);
-				cast = r.cast && !r.odd;
-				if (r.hitcand && !r.odd) {
+				const PointRec r = recs[i];  // (k_fhits ran the head loop on the point)
+				const bool odd = 0 != (r.flags & 4u);
+				cast = (r.flags & 1u) && !odd;
+				if ((r.flags & 2u) && !odd) {
 					const bool winner = first[r.cell] == i;
 					nhit += winner ? 1u : 0u;
 					if (DISCRETE && !winner) cast = false;  // OMB:358-360: dropped entirely, no ray
@@ -339,16 +351,16 @@ __global__ __launch_bounds__(512) void k_fcast(MapGeom g, FastGeo fg, D3 sensor,
 			hd[t].nseg = nseg;
 			hd[t].off = off;
 		}
-		for (u32 si = threadIdx.x; si < nsegs; si += blockDim.x) q[si].lin = 0;  // cut cells are summed up from two lanes
 		__syncthreads();
 		if (0 == (threadIdx.x | blockIdx.x)) ctl->dbg[34] = wall_clock64();  // (diagnostics)
-		// ---- 3. cut states from the three independent addition chains (k_dda_seg), two lanes per ray ----
-		for (u32 idx = threadIdx.x; idx < 2u * UFO_CAST_BATCH; idx += blockDim.x) {
-			const u32 ry = idx & (UFO_CAST_BATCH - 1u), role = idx / UFO_CAST_BATCH;
+		// ---- 3. cut states from the three independent addition chains (k_dda_seg) ----
+		// 3a. one lane per ray: the dominant chain a*, once. After k0 = j*w pops of a*: element A[k0-1] (= v) was popped
+		// and t_max_a* = A[k0]. v is parked in the cut's two other t_max fields for the lanes of 3b.
+		if (threadIdx.x < UFO_CAST_BATCH) {
+			const u32 ry = threadIdx.x;
 			const RayHdr h = hd[ry];
-			if (0 == h.nseg) continue;
-			const RayConst c = rc[ry];
-			if (0 == role) {
+			if (0 != h.nseg) {
+				const RayConst c = rc[ry];
 				SegRec rec;
 				rec.tm[0] = h.tm[0];
 				rec.tm[1] = h.tm[1];
@@ -358,46 +370,76 @@ __global__ __launch_bounds__(512) void k_fcast(MapGeom g, FastGeo fg, D3 sensor,
 				rec.ray = ry | 0x80000000u;
 				rec.pad = 0;
 				q[h.off] = rec;
-			}
-			const u32 axd = h.ax;
-			const u32 b = (0 == role) ? (axd == 0 ? 1u : 0u) : (axd == 2 ? 1u : 2u);
-			const bool pri = b < axd;
-			double ta = axd == 0 ? h.tm[0] : (axd == 1 ? h.tm[1] : h.tm[2]), v = ta;
-			const double tda = axd == 0 ? c.td[0] : (axd == 1 ? c.td[1] : c.td[2]);
-			const i32 da = axd == 0 ? c.dl[0] : (axd == 1 ? c.dl[1] : c.dl[2]);
-			double tb = b == 0 ? h.tm[0] : (b == 1 ? h.tm[1] : h.tm[2]);
-			const double dbt = b == 0 ? c.td[0] : (b == 1 ? c.td[1] : c.td[2]);
-			const i32 dbl = b == 0 ? c.dl[0] : (b == 1 ? c.dl[1] : c.dl[2]);
-			u32 ka = 0, cb = 0;
-			for (u32 j = 1; j < h.nseg; ++j) {
-				const u32 k0 = j * h.w;  // < dmax
-				for (; ka < k0; ++ka) {
-					v = ta;
-					ta = ta + tda;
-				}
-				while (cb < 2048u) {
-					const double s1 = tb + dbt, s2 = s1 + dbt, s3 = s2 + dbt;
-					const bool c0 = pri ? (tb <= v) : (tb < v);
-					if (!c0) break;
-					const bool c1 = pri ? (s1 <= v) : (s1 < v), c2 = pri ? (s2 <= v) : (s2 < v), c3 = pri ? (s3 <= v) : (s3 < v);
-					if (c1 & c2 & c3) {
-						tb = s3 + dbt;
-						cb += 4u;
-					} else {
-						tb = c1 ? (c2 ? s3 : s2) : s1;
-						cb += 1u + (c1 ? (c2 ? 2u : 1u) : 0u);
-						break;
+				const u32 axd = h.ax;
+				const u32 b0 = axd == 0 ? 1u : 0u, b1 = axd == 2 ? 1u : 2u;
+				double ta = axd == 0 ? h.tm[0] : (axd == 1 ? h.tm[1] : h.tm[2]), v = ta;
+				const double tda = axd == 0 ? c.td[0] : (axd == 1 ? c.td[1] : c.td[2]);
+				const i32 da = axd == 0 ? c.dl[0] : (axd == 1 ? c.dl[1] : c.dl[2]);
+				for (u32 j = 1; j < h.nseg; ++j) {
+					// w pops to the next cut, four at a time (the same sequence of additions; v = the last element popped)
+					u32 n = h.w;
+					for (; n >= 4u; n -= 4u) {
+						const double t1 = ta + tda, t2 = t1 + tda, t3 = t2 + tda;
+						v = t3;
+						ta = t3 + tda;
 					}
-				}
-				if (cb >= 2048u) err |= ERR_RUNAWAY;  // (guard of the pop loop: cannot trip inside a grid of < 1024 cells per axis)
-				SegRec* o = &q[h.off + j];
-				if (0 == role) {
+					for (; n > 0u; --n) {
+						v = ta;
+						ta = ta + tda;
+					}
+					SegRec* o = &q[h.off + j];
 					o->tm[axd] = ta;
+					o->tm[b0] = v;
+					o->tm[b1] = v;
+					o->lin = h.lin0 + (u32)((i32)(j * h.w) * da);
 					o->end = c.glin;
 					o->ray = ry;
 				}
+			}
+		}
+		__syncthreads();
+		if (0 == (threadIdx.x | blockIdx.x)) ctl->dbg[44] = wall_clock64();  // (diagnostics)
+		// 3b. two lanes per ray, one per other axis: of that axis the elements before v were popped (strictly smaller, or
+		// equal when the axis has priority: the lower axis index wins ties, VEC3:244-251) -- their count moves the cut's
+		// cell; four candidates per iteration (same sequence of additions)
+		for (u32 idx = threadIdx.x; idx < 2u * UFO_CAST_BATCH; idx += blockDim.x) {
+			const u32 ry = idx & (UFO_CAST_BATCH - 1u), role = idx / UFO_CAST_BATCH;
+			const RayHdr h = hd[ry];
+			if (h.nseg < 2u) continue;
+			const RayConst c = rc[ry];
+			const u32 axd = h.ax;
+			const u32 b = (0 == role) ? (axd == 0 ? 1u : 0u) : (axd == 2 ? 1u : 2u);
+			const bool pri = b < axd;
+			double tb = b == 0 ? h.tm[0] : (b == 1 ? h.tm[1] : h.tm[2]);
+			const double dbt = b == 0 ? c.td[0] : (b == 1 ? c.td[1] : c.td[2]);
+			const i32 dbl = b == 0 ? c.dl[0] : (b == 1 ? c.dl[1] : c.dl[2]);
+			// ONE loop over the candidates of all cuts (a loop per cut would cost a wave, at every cut, the longest run of any
+			// of its rays): an iteration tests four candidates against the current cut's v and either pops them all, or pops
+			// the ones before v, stores the cut and moves on to the next
+			u32 cb = 0, j = 1;
+			SegRec* o = &q[h.off + 1u];
+			double v = o->tm[b];
+			u32 guard = 0;
+			while (j < h.nseg) {
+				const double s1 = tb + dbt, s2 = s1 + dbt, s3 = s2 + dbt;
+				const bool c0 = pri ? (tb <= v) : (tb < v);
+				const bool c1 = c0 & (pri ? (s1 <= v) : (s1 < v)), c2 = c1 & (pri ? (s2 <= v) : (s2 < v)), c3 = c2 & (pri ? (s3 <= v) : (s3 < v));
+				if (c3) {
+					tb = s3 + dbt;
+					cb += 4u;
+					if (++guard > 1024u) {
+						err |= ERR_RUNAWAY;  // (cannot trip inside a grid of < 1024 cells per axis)
+						break;
+					}
+					continue;
+				}
+				tb = c2 ? s3 : (c1 ? s2 : (c0 ? s1 : tb));
+				cb += (c0 ? 1u : 0u) + (c1 ? 1u : 0u) + (c2 ? 1u : 0u);
 				o->tm[b] = tb;
-				atomicAdd(&o->lin, (0 == role ? h.lin0 + (u32)((i32)k0 * da) : 0u) + (u32)((i32)cb * dbl));
+				if (cb) atomicAdd(&o->lin, (u32)((i32)cb * dbl));
+				++j;
+				++o;
+				if (j < h.nseg) v = o->tm[b];
 			}
 		}
 		__syncthreads();
@@ -693,6 +735,7 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 	const u32 lane = threadIdx.x & 63u;
 	const u32 tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
 	if (tile >= fg.ntiles) return;
+	__builtin_amdgcn_s_setprio(2);  // (the map stream is the pipeline's critical path: ahead of the ray kernel's waves)
 	// three words can end the wave here; they are asked for together (a wave's time is its chain of dependent round trips)
 	const u32 tword = tile_bits[tile >> 5];
 	const u32 perr = (prev ? prev : ctl)->err;  // the update enqueued just before this one flagged itself and left the map alone:
@@ -988,8 +1031,14 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 static_assert(UFO_FTAIL_THREADS == UFO_UPPER_MAX, "k_ftail: one thread per cell of the dense grids above the tiles");
 __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g, FastGeo fg, UpperGeo ugp, u32* __restrict__ tile_bits,
                                                              const TileRec* __restrict__ recs, u32 scan_id, ScanCtl* ctl, const ScanCtl* prev,
-                                                             ScanCtl* host_result, const ScanCtl* ctl_init)
+                                                             ScanCtl* host_result, const ScanCtl* ctl_init, unsigned long long done_value)
 {
+	// the host waits for THIS word (behind the pinned control block), not for an event: an event record is one more packet
+	// the map stream's command processor has to get through between two scans (~5 us, scripts/micro/stream_wait.hip)
+	unsigned long long* host_done = reinterpret_cast<unsigned long long*>(host_result + 1);
+	// This lone workgroup shares its CU with waves of the next scan's ray kernel and of k_tile; its time is its chain of
+	// dependent instructions, so its waves take issue priority over theirs (measured: 35 -> 27 us when overlapped).
+	__builtin_amdgcn_s_setprio(3);
 	__shared__ UpperGeo ug;
 	__shared__ u32 tbits[UFO_FAST_MAX_TILES / 32], ubits[UFO_UPPER_MAX / 32], uprefix[UFO_UPPER_MAX / 32 + 1];
 	__shared__ u64 nk[UFO_UPPER_MAX];
@@ -1009,11 +1058,19 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 		for (u32 j = threadIdx.x; j < nwords; j += blockDim.x) tbits[j] = tile_bits[j];
 		if (perr) {
 			// the update enqueued just before this one flagged itself and left the map alone: this one stood back too (k_tile)
-			if (0 == threadIdx.x) host_result->err = atomicOr(&ctl->err, ERR_PREV) | ERR_PREV;
+			if (0 == threadIdx.x) {
+				host_result->err = atomicOr(&ctl->err, ERR_PREV) | ERR_PREV;
+				__threadfence_system();
+				__hip_atomic_store(host_done, done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+			}
 			return;
 		}
 		if (cerr) {  // the scan stood back (ERR_SPEC / a bound): the map is as it was
-			if (0 == threadIdx.x) host_result->err = cerr;
+			if (0 == threadIdx.x) {
+				host_result->err = cerr;
+				__threadfence_system();
+				__hip_atomic_store(host_done, done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+			}
 			return;
 		}
 	}
@@ -1357,6 +1414,15 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 			if (0 == e) dev[w] = init[w];  // (an error raised in this very kernel, ERR_TABLE_FULL, stays for the successor to see)
 		}
 	}
+	__syncthreads();  // (every thread's stores to the pinned block have been acknowledged: the barrier waits for them)
+	if (0 == threadIdx.x) __hip_atomic_store(host_done, done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);  // (the kernel's last action)
+}
+
+// a stream's "everything before this is done" for another stream (hipStreamWaitValue64 on signal memory: 3-4 us where an
+// event record + wait costs 9-15, scripts/micro/stream_wait*.hip)
+__global__ void k_signal(unsigned long long* flag, unsigned long long value)
+{
+	__hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Stage-level output of a fast-path scan (ufomap_map_last_hits): the hit voxels' codes from the per-tile hit masks.

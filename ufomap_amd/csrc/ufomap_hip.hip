@@ -21,6 +21,7 @@
 #include <cstring>
 #include <sstream>
 #include <chrono>
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -156,6 +157,8 @@ struct HandOver {
 	UpperGeo ugeo{};
 	ScanCtl* h_ctl = nullptr;  // pinned
 	ScanCtl* h_res = nullptr;  // pinned: the finished control block as k_ftail stored it
+	unsigned long long *sig_prep = nullptr, *sig_scan = nullptr;  // signal memory: "first kernel done" / "scan half done" of the set's scan
+	bool done_by_flag = false; // the set's integration announces its end in the word behind h_res, not by done_ev
 	bool ctl_clean = false;    // b_ctl holds the fast path's start state
 	void* h_stage = nullptr;   // pinned staging of a pageable host cloud (ufomap_map_insert): filled by the host, drained by
 	size_t h_stage_cap = 0;    // an asynchronous H2D copy on the scan stream; free again once the set's integration is joined
@@ -224,6 +227,8 @@ struct ufomap_map {
 	DevBuf b_gridM, b_entries, b_ent_slot, b_newlist, b_wl0, b_wl1, b_in_xyz, b_in_rgb, b_codes, b_dump;
 	ScanCtl* h_ctl = nullptr;  // pinned
 	ScanCtl* h_res = nullptr;  // pinned: k_ftail stores the finished control block here itself (no read-back copy, no stream sync)
+	unsigned long long *sig_prep = nullptr, *sig_scan = nullptr;  // (HandOver)
+	bool done_by_flag = false;
 	bool ctl_clean = false;    // the device control block holds the fast path's start state (k_ftail left it so): no upload
 	DevBuf b_ctl_init;         // that start state, uploaded once
 	bool ctl_init_done = false;
@@ -462,6 +467,9 @@ void swapWith(ufomap_map* m, HandOver& o)
 	std::swap(m->fgeo, o.fgeo);
 	std::swap(m->h_ctl, o.h_ctl);
 	std::swap(m->h_res, o.h_res);
+	std::swap(m->sig_prep, o.sig_prep);
+	std::swap(m->sig_scan, o.sig_scan);
+	std::swap(m->done_by_flag, o.done_by_flag);
 	std::swap(m->ctl_clean, o.ctl_clean);
 	std::swap(m->h_stage, o.h_stage);
 	std::swap(m->h_stage_cap, o.h_stage_cap);
@@ -494,6 +502,27 @@ int phaseGuard(ufomap_map* m)
 	return UFOMAP_OK;
 }
 
+// Wait for the integration that uses hand-over set s. General path: the set's event. Fast path: k_ftail's last action is a
+// store of the integration's number into pinned memory behind the result block -- the host reads that word instead of
+// having the stream process an event record after every scan; if the word does not show up within a few milliseconds
+// (a stream error?) the map stream is synchronised, which reports whatever went wrong.
+hipError_t waitSetDone(ufomap_map* m, HandOver& s)
+{
+	if (!s.done_by_flag) return hipEventSynchronize(s.done_ev);
+	volatile unsigned long long* done = reinterpret_cast<volatile unsigned long long*>(s.h_res + 1);
+	const auto t0 = std::chrono::steady_clock::now();
+	for (u32 spins = 0; *done != (unsigned long long)s.seq; ++spins) {
+		if (0 == (spins & 1023u) && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) {
+			const hipError_t e = hipStreamSynchronize(m->stream);
+			if (e != hipSuccess) return e;
+			if (*done != (unsigned long long)s.seq) return hipErrorUnknown;  // (the kernel ran and did not store: cannot happen)
+			break;
+		}
+	}
+	std::atomic_thread_fence(std::memory_order_acquire);
+	return hipSuccess;
+}
+
 // A new integration begins: the oldest hand-over set becomes the current one (its integration is joined first if it
 // is still pending), the set that was current becomes alt[1] (the predecessor), the old alt[1] becomes alt[0].
 int rotateSets(ufomap_map* m)
@@ -501,7 +530,7 @@ int rotateSets(ufomap_map* m)
 	int rc = phaseGuard(m);
 	if (rc) return rc;
 	if (m->alt[0].pending) {
-		(void)hipEventSynchronize(m->alt[0].done_ev);
+		(void)waitSetDone(m, m->alt[0]);
 		rc = finishSet(m, 0);
 		if (rc && UFOMAP_OK == m->async_status) m->async_status = rc;
 	}
@@ -957,7 +986,7 @@ int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, si
 		m->first_dirty = false;
 	}
 	HIP_TRY(m->b_gridM.reserve(fg.gr.bytes));
-	HIP_TRY(m->b_hit_code.reserve(n * 8));
+	HIP_TRY(m->b_hit_code.reserve(n * sizeof(PointRec)));  // (per-point records of the head loop: k_fhits -> k_fcast)
 	ScanCtl init;
 	memset(&init, 0, sizeof(init));
 	for (int a = 0; a < 3; ++a) {
@@ -977,21 +1006,22 @@ int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, si
 		HIP_TRY(hipMemcpyAsync(ctl, m->h_ctl, sizeof(ScanCtl), hipMemcpyHostToDevice, m->cs));
 	}
 	m->ctl_clean = false;  // (until that scan's tree update has been joined and found clean)
-	m->h_res->err = ERR_NOT_STORED;
 	const dim3 gp((N + 255) / 256);
 	HIP_TRY(m->b_part1.reserve((size_t)gp.x * sizeof(BoxPartial)));
 	{
 		ProfScope ps(m, "k_fhits");
 		if (discrete)
 			hipLaunchKernelGGL(k_fhits<true>, gp, dim3(256), 0, m->cs, m->g, fg, sensor, d_xyz, N, max_range, 0u, m->b_first.as<u32>(),
-			                   m->b_part1.as<BoxPartial>(), ctl, m->ing);
+			                   m->b_part1.as<BoxPartial>(), ctl, m->ing, m->b_hit_code.as<PointRec>());
 		else
 			hipLaunchKernelGGL(k_fhits<false>, gp, dim3(256), 0, m->cs, m->g, fg, sensor, d_xyz, N, max_range, 0u, m->b_first.as<u32>(),
-			                   m->b_part1.as<BoxPartial>(), ctl, m->ing);
+			                   m->b_part1.as<BoxPartial>(), ctl, m->ing, m->b_hit_code.as<PointRec>());
 	}
-	HIP_TRY(hipEventRecord(m->prep_ev, m->pstream));
+	// stream-to-stream hand-overs of this path are words in signal memory written by a one-thread kernel and awaited by
+	// hipStreamWaitValue64 (3-4 us per hand-over; an event record + wait is two packets and 9-15 us)
+	hipLaunchKernelGGL(k_signal, dim3(1), dim3(1), 0, m->pstream, m->sig_prep, (unsigned long long)m->seq);
 	m->cs = m->sstream;
-	HIP_TRY(hipStreamWaitEvent(m->sstream, m->prep_ev, 0));
+	HIP_TRY(hipStreamWaitValue64(m->sstream, m->sig_prep, m->seq, hipStreamWaitValueGte, ~0ull));
 	u32 nwg = m->opt_cast_wgs > 0 ? (u32)m->opt_cast_wgs : 256u;
 	nwg = std::max<u32>(1u, std::min<u32>(nwg, (N + 63u) / 64u));
 	const u32 cap_wg = (N + nwg - 1) / nwg;
@@ -1003,10 +1033,10 @@ int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, si
 		const size_t lds = (size_t)fg.gr.bytes + UFO_CAST_LDS_EXTRA;
 		if (discrete)
 			hipLaunchKernelGGL(k_fcast<true>, dim3(nwg), dim3(512), lds, m->cs, m->g, fg, sensor, d_xyz, N, max_range, 0u, m->b_first.as<u32>(),
-			                   m->b_ray_end.as<D3>(), cap_wg, m->b_slabs.as<u32>(), (u32)std::max(8, m->opt_cast_k), ctl, ctl, sp, m->ing);
+			                   m->b_ray_end.as<D3>(), cap_wg, m->b_slabs.as<u32>(), (u32)std::max(8, m->opt_cast_k), ctl, ctl, sp, m->ing, m->b_hit_code.as<PointRec>());
 		else
 			hipLaunchKernelGGL(k_fcast<false>, dim3(nwg), dim3(512), lds, m->cs, m->g, fg, sensor, d_xyz, N, max_range, 0u, m->b_first.as<u32>(),
-			                   m->b_ray_end.as<D3>(), cap_wg, m->b_slabs.as<u32>(), (u32)std::max(8, m->opt_cast_k), ctl, ctl, sp, m->ing);
+			                   m->b_ray_end.as<D3>(), cap_wg, m->b_slabs.as<u32>(), (u32)std::max(8, m->opt_cast_k), ctl, ctl, sp, m->ing, m->b_hit_code.as<PointRec>());
 	}
 	{
 		ProfScope ps(m, "k_fmerge");
@@ -1014,6 +1044,7 @@ int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, si
 		hipLaunchKernelGGL(k_fmerge, dim3(std::min<u32>((n4 + 63) / 64, 1024) + 1u), dim3(1024), 0, m->cs, fg, m->b_slabs.as<uint4>(), nwg, n4,
 		                   m->b_gridM.as<uint4>(), sp, m->b_tilebits.as<u32>(), m->b_part1.as<BoxPartial>(), gp.x, ctl);
 	}
+	hipLaunchKernelGGL(k_signal, dim3(1), dim3(1), 0, m->sstream, m->sig_scan, (unsigned long long)m->seq);
 	HIP_TRY(hipGetLastError());
 	++m->n_fast;
 	return UFOMAP_OK;
@@ -1037,6 +1068,8 @@ int fastMapPhase(ufomap_map* m, const ScanCtl* prev, u64 extra_used, u32 headroo
 		}
 	}
 	m->scan_id += 1;
+	m->h_res->err = ERR_NOT_STORED;
+	*reinterpret_cast<volatile unsigned long long*>(m->h_res + 1) = 0ull;  // k_ftail's "done" word
 	HIP_TRY(m->b_tilerec.reserve((size_t)UFO_FAST_MAX_TILES * sizeof(TileRec)));
 	HIP_TRY(m->b_tilehm.reserve((size_t)UFO_FAST_MAX_TILES * 64));
 	m->fast_hits_scan = m->scan_id;
@@ -1052,7 +1085,7 @@ int fastMapPhase(ufomap_map* m, const ScanCtl* prev, u64 extra_used, u32 headroo
 	{
 		ProfScope ps(m, "k_ftail");
 		hipLaunchKernelGGL(k_ftail, dim3(1), dim3(UFO_FTAIL_THREADS), 0, m->cs, m->t, m->g, fg, m->ugeo, m->b_tilebits.as<u32>(),
-		                   m->b_tilerec.as<TileRec>(), m->scan_id, ctl, prev, m->h_res, m->b_ctl_init.as<ScanCtl>());
+		                   m->b_tilerec.as<TileRec>(), m->scan_id, ctl, prev, m->h_res, m->b_ctl_init.as<ScanCtl>(), (unsigned long long)m->seq);
 	}
 	HIP_TRY(hipGetLastError());
 	return UFOMAP_OK;
@@ -1562,7 +1595,16 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 	auto mapHalf = [&](const ScanCtl* prev, u64 extra_used, u32 headroom) {
 		return fast ? fastMapPhase(m, prev, extra_used, headroom) : mapPhase(m, depth, d_rgb, capH, capM, merged, prev, extra_used, headroom);
 	};
-	if (!rc && n) rc = (hipEventRecord(m->scan_ev, m->sstream) == hipSuccess) ? UFOMAP_OK : fail(UFOMAP_ERR_DEVICE, "hipEventRecord");
+	if (!rc && n && !fast) rc = (hipEventRecord(m->scan_ev, m->sstream) == hipSuccess) ? UFOMAP_OK : fail(UFOMAP_ERR_DEVICE, "hipEventRecord");
+	// the map stream waits for this scan's scan half (fast path: its signal word; general path: the event)
+	auto waitScanHalf = [&]() -> hipError_t {
+		return fast ? hipStreamWaitValue64(m->stream, m->sig_scan, m->seq, hipStreamWaitValueGte, ~0ull) : hipStreamWaitEvent(m->stream, m->scan_ev, 0);
+	};
+	// ... and its end is announced by k_ftail's word in pinned memory (fast path) or by the set's event
+	auto recordDone = [&]() -> hipError_t {
+		m->done_by_flag = fast;
+		return fast ? hipSuccess : hipEventRecord(m->done_ev, m->stream);
+	};
 	// ---- early map half: enqueue THIS scan's tree update behind the previous one BEFORE that one has been joined,
 	// so that the updates run back to back on the map stream and the next call can start its scan half while two
 	// updates are still in flight (three hand-over sets). The first kernel looks at the predecessor's error flags:
@@ -1571,14 +1613,14 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 	bool early = false;
 	if (!rc && n && async && merged && m->opt_early && m->alt[1].pending && !m->profiling) {
 		m->cs = m->stream;
-		HIP_TRY(hipStreamWaitEvent(m->stream, m->scan_ev, 0));
+		HIP_TRY(waitScanHalf());
 		m->last_rgb = d_rgb;
 		const u64 in_flight = m->alt[1].bound + (m->alt[0].pending ? m->alt[0].bound : 0);
 		const auto t_map = std::chrono::steady_clock::now();
 		const int erc = mapHalf(m->alt[1].b_ctl.as<ScanCtl>(), in_flight, 0u);
 		if (erc < 0) return erc;
 		early = 0 == erc;  // 1: the table might have to grow: join first (below)
-		if (early) HIP_TRY(hipEventRecord(m->done_ev, m->stream));
+		if (early) HIP_TRY(recordDone());
 		lap(1, t_map);
 	}
 	int prc = UFOMAP_OK;
@@ -1587,7 +1629,7 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 		m->prev_flagged = false;
 		if (m->alt[0].pending) {
 			const auto t_join = std::chrono::steady_clock::now();
-			HIP_TRY(hipEventSynchronize(m->alt[0].done_ev));
+			HIP_TRY(waitSetDone(m, m->alt[0]));
 			prc = finishSet(m, 0);
 			if (prc && UFOMAP_OK == m->async_status) m->async_status = prc;
 			lap(2, t_join);
@@ -1604,7 +1646,7 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 			m->cs = m->stream;
 			rc = mapHalf(nullptr, 0, 0u);
 			if (rc) return rc;
-			HIP_TRY(hipEventRecord(m->done_ev, m->stream));
+			HIP_TRY(recordDone());
 		}
 		m->pending = true;
 		m->bound = m->scan_new_bound;
@@ -1618,7 +1660,7 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 	}
 	// ---- map half on the map stream, after the scan half of THIS scan ----
 	m->cs = m->stream;
-	HIP_TRY(hipStreamWaitEvent(m->stream, m->scan_ev, 0));
+	HIP_TRY(waitScanHalf());
 	m->last_rgb = d_rgb;
 	rc = mapHalf(nullptr, 0, (async && merged && m->opt_early) ? 2u : 0u);
 	if (rc) return rc;
@@ -1642,7 +1684,7 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 		}
 		return rc ? rc : prc;
 	}
-	HIP_TRY(hipEventRecord(m->done_ev, m->stream));
+	HIP_TRY(recordDone());
 	return prc;
 }
 // Repeat, synchronously and with the boxes read back, the integration whose hand-over set is current: it had been
@@ -1765,9 +1807,19 @@ ufomap_map* ufomap_map_create(double resolution, unsigned depth_levels, int auto
 	          hipHostMalloc((void**)&m->alt[0].h_res, sizeof(ScanCtl) + 64) == hipSuccess &&
 	          hipHostMalloc((void**)&m->alt[1].h_res, sizeof(ScanCtl) + 64) == hipSuccess &&
 	          m->b_ctl_init.reserve(sizeof(ScanCtl) + 64) == hipSuccess &&
+	          hipExtMallocWithFlags((void**)&m->sig_prep, 8, hipMallocSignalMemory) == hipSuccess &&
+	          hipExtMallocWithFlags((void**)&m->sig_scan, 8, hipMallocSignalMemory) == hipSuccess &&
+	          hipExtMallocWithFlags((void**)&m->alt[0].sig_prep, 8, hipMallocSignalMemory) == hipSuccess &&
+	          hipExtMallocWithFlags((void**)&m->alt[0].sig_scan, 8, hipMallocSignalMemory) == hipSuccess &&
+	          hipExtMallocWithFlags((void**)&m->alt[1].sig_prep, 8, hipMallocSignalMemory) == hipSuccess &&
+	          hipExtMallocWithFlags((void**)&m->alt[1].sig_scan, 8, hipMallocSignalMemory) == hipSuccess &&
 	          m->alt[0].b_ctl.reserve(sizeof(ScanCtl) + 64) == hipSuccess && m->alt[1].b_ctl.reserve(sizeof(ScanCtl) + 64) == hipSuccess &&
 	          hipHostMalloc((void**)&m->h_root, sizeof(MapRoot)) == hipSuccess &&
 	          m->b_ctl.reserve(sizeof(ScanCtl) + 64) == hipSuccess && m->b_root.reserve(sizeof(MapRoot)) == hipSuccess;
+	if (ok) {
+		unsigned long long* sigs[] = {m->sig_prep, m->sig_scan, m->alt[0].sig_prep, m->alt[0].sig_scan, m->alt[1].sig_prep, m->alt[1].sig_scan};
+		for (unsigned long long* sg : sigs) ok = ok && hipMemset(sg, 0, 8) == hipSuccess;
+	}
 	if (!ok) {
 		fail(UFOMAP_ERR_DEVICE, "HIP resource creation failed");
 		ufomap_map_destroy(m);
@@ -1816,6 +1868,8 @@ void ufomap_map_destroy(ufomap_map* m)
 		for (DevBuf* b : abufs) b->release();
 		if (a.h_ctl) (void)hipHostFree(a.h_ctl);
 		if (a.h_res) (void)hipHostFree(a.h_res);
+		if (a.sig_prep) (void)hipFree(a.sig_prep);
+		if (a.sig_scan) (void)hipFree(a.sig_scan);
 		if (a.h_stage) (void)hipHostFree(a.h_stage);
 		if (a.done_ev) (void)hipEventDestroy(a.done_ev);
 	}
@@ -1836,6 +1890,8 @@ void ufomap_map_destroy(ufomap_map* m)
 	for (hipEvent_t e : m->ev_pool) (void)hipEventDestroy(e);
 	if (m->h_ctl) (void)hipHostFree(m->h_ctl);
 	if (m->h_res) (void)hipHostFree(m->h_res);
+	if (m->sig_prep) (void)hipFree(m->sig_prep);
+	if (m->sig_scan) (void)hipFree(m->sig_scan);
 	if (m->h_stage) (void)hipHostFree(m->h_stage);
 	if (m->copy_ev) (void)hipEventDestroy(m->copy_ev);
 	if (m->h_root) (void)hipHostFree(m->h_root);
@@ -2394,6 +2450,15 @@ int ufomap_map_done(ufomap_map* m)
 {
 	if (!m) return fail(UFOMAP_ERR_INVALID, "null map");
 	// the map stream runs the integrations in order: the most recent pending one is the last to finish
+	{
+		// (fast path: the integration's end is a word in pinned memory, not an event)
+		const bool by_flag = m->pending ? m->done_by_flag : (m->alt[1].pending ? m->alt[1].done_by_flag : (m->alt[0].pending ? m->alt[0].done_by_flag : false));
+		if (by_flag) {
+			const ScanCtl* hr = m->pending ? m->h_res : (m->alt[1].pending ? m->alt[1].h_res : m->alt[0].h_res);
+			const uint64_t sq = m->pending ? m->seq : (m->alt[1].pending ? m->alt[1].seq : m->alt[0].seq);
+			return *reinterpret_cast<const volatile unsigned long long*>(hr + 1) == (unsigned long long)sq ? 1 : 0;
+		}
+	}
 	hipEvent_t ev = m->pending ? m->done_ev : (m->alt[1].pending ? m->alt[1].done_ev : (m->alt[0].pending ? m->alt[0].done_ev : nullptr));
 	if (!ev) return 1;
 	hipError_t e = hipEventQuery(ev);
@@ -2949,6 +3014,7 @@ int ufomap_map_apply_keys_batch(ufomap_map* m, const void* const* d_lists, const
 	m->bound = m->scan_new_bound;
 	if (m->opt_async_apply && !m->chg_enabled) {
 		// the caller keeps the lists alive until the next call on this map has joined the update
+		m->done_by_flag = false;
 		HIP_TRY(hipEventRecord(m->done_ev, m->stream));
 		return UFOMAP_OK;
 	}
