@@ -1418,11 +1418,18 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 	if (0 == threadIdx.x) __hip_atomic_store(host_done, done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);  // (the kernel's last action)
 }
 
-// a stream's "everything before this is done" for another stream (hipStreamWaitValue64 on signal memory: 3-4 us where an
-// event record + wait costs 9-15, scripts/micro/stream_wait*.hip)
+// Stream-to-stream hand-overs without events: a one-thread kernel at the end of the producing stream's work stores the
+// scan's number into a word of device memory (k_signal), a one-wave kernel in front of the consuming stream's work waits
+// for it (k_gate; a single wave cannot keep anything from being scheduled). Measured per hand-over, stream idle time
+// included (scripts/micro/stream_wait*.hip and rocprofv3 traces of the pipeline): event record + wait 9-15 us,
+// hipStreamWaitValue64 on signal memory 5-7 us (it is a polling kernel too, on host-coherent memory), this 2-3 us.
 __global__ void k_signal(unsigned long long* flag, unsigned long long value)
 {
-	__hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+	__hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void k_gate(const unsigned long long* flag, unsigned long long value)
+{
+	while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < value) __builtin_amdgcn_s_sleep(1);
 }
 
 // Stage-level output of a fast-path scan (ufomap_map_last_hits): the hit voxels' codes from the per-tile hit masks.

@@ -1017,11 +1017,10 @@ int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, si
 			hipLaunchKernelGGL(k_fhits<false>, gp, dim3(256), 0, m->cs, m->g, fg, sensor, d_xyz, N, max_range, 0u, m->b_first.as<u32>(),
 			                   m->b_part1.as<BoxPartial>(), ctl, m->ing, m->b_hit_code.as<PointRec>());
 	}
-	// stream-to-stream hand-overs of this path are words in signal memory written by a one-thread kernel and awaited by
-	// hipStreamWaitValue64 (3-4 us per hand-over; an event record + wait is two packets and 9-15 us)
+	// stream-to-stream hand-overs of this path: k_signal / k_gate (fast_kernels.h), not events
 	hipLaunchKernelGGL(k_signal, dim3(1), dim3(1), 0, m->pstream, m->sig_prep, (unsigned long long)m->seq);
 	m->cs = m->sstream;
-	HIP_TRY(hipStreamWaitValue64(m->sstream, m->sig_prep, m->seq, hipStreamWaitValueGte, ~0ull));
+	hipLaunchKernelGGL(k_gate, dim3(1), dim3(1), 0, m->sstream, m->sig_prep, (unsigned long long)m->seq);
 	u32 nwg = m->opt_cast_wgs > 0 ? (u32)m->opt_cast_wgs : 256u;
 	nwg = std::max<u32>(1u, std::min<u32>(nwg, (N + 63u) / 64u));
 	const u32 cap_wg = (N + nwg - 1) / nwg;
@@ -1598,7 +1597,9 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 	if (!rc && n && !fast) rc = (hipEventRecord(m->scan_ev, m->sstream) == hipSuccess) ? UFOMAP_OK : fail(UFOMAP_ERR_DEVICE, "hipEventRecord");
 	// the map stream waits for this scan's scan half (fast path: its signal word; general path: the event)
 	auto waitScanHalf = [&]() -> hipError_t {
-		return fast ? hipStreamWaitValue64(m->stream, m->sig_scan, m->seq, hipStreamWaitValueGte, ~0ull) : hipStreamWaitEvent(m->stream, m->scan_ev, 0);
+		if (!fast) return hipStreamWaitEvent(m->stream, m->scan_ev, 0);
+		hipLaunchKernelGGL(k_gate, dim3(1), dim3(1), 0, m->stream, m->sig_scan, (unsigned long long)m->seq);
+		return hipSuccess;
 	};
 	// ... and its end is announced by k_ftail's word in pinned memory (fast path) or by the set's event
 	auto recordDone = [&]() -> hipError_t {
@@ -1807,12 +1808,12 @@ ufomap_map* ufomap_map_create(double resolution, unsigned depth_levels, int auto
 	          hipHostMalloc((void**)&m->alt[0].h_res, sizeof(ScanCtl) + 64) == hipSuccess &&
 	          hipHostMalloc((void**)&m->alt[1].h_res, sizeof(ScanCtl) + 64) == hipSuccess &&
 	          m->b_ctl_init.reserve(sizeof(ScanCtl) + 64) == hipSuccess &&
-	          hipExtMallocWithFlags((void**)&m->sig_prep, 8, hipMallocSignalMemory) == hipSuccess &&
-	          hipExtMallocWithFlags((void**)&m->sig_scan, 8, hipMallocSignalMemory) == hipSuccess &&
-	          hipExtMallocWithFlags((void**)&m->alt[0].sig_prep, 8, hipMallocSignalMemory) == hipSuccess &&
-	          hipExtMallocWithFlags((void**)&m->alt[0].sig_scan, 8, hipMallocSignalMemory) == hipSuccess &&
-	          hipExtMallocWithFlags((void**)&m->alt[1].sig_prep, 8, hipMallocSignalMemory) == hipSuccess &&
-	          hipExtMallocWithFlags((void**)&m->alt[1].sig_scan, 8, hipMallocSignalMemory) == hipSuccess &&
+	          hipMalloc((void**)&m->sig_prep, 8) == hipSuccess &&
+	          hipMalloc((void**)&m->sig_scan, 8) == hipSuccess &&
+	          hipMalloc((void**)&m->alt[0].sig_prep, 8) == hipSuccess &&
+	          hipMalloc((void**)&m->alt[0].sig_scan, 8) == hipSuccess &&
+	          hipMalloc((void**)&m->alt[1].sig_prep, 8) == hipSuccess &&
+	          hipMalloc((void**)&m->alt[1].sig_scan, 8) == hipSuccess &&
 	          m->alt[0].b_ctl.reserve(sizeof(ScanCtl) + 64) == hipSuccess && m->alt[1].b_ctl.reserve(sizeof(ScanCtl) + 64) == hipSuccess &&
 	          hipHostMalloc((void**)&m->h_root, sizeof(MapRoot)) == hipSuccess &&
 	          m->b_ctl.reserve(sizeof(ScanCtl) + 64) == hipSuccess && m->b_root.reserve(sizeof(MapRoot)) == hipSuccess;
