@@ -248,18 +248,25 @@ int ufomap_map_reset_kernel_times(ufomap_map* m);
  *   u8 child updated last | u32 point index of that update (hits: cloud order)
  * scan_keys leaves the list in the map's scratch memory (valid until the next call on this map);
  * get_keys copies it (device to device) into caller memory, e.g. a torch tensor used as RCCL buffer.
- * apply_keys: non-colour maps only. d_xyz / d_dst / d_entries are DEVICE pointers. */
+ * d_xyz / d_dst / d_entries are DEVICE pointers. */
 typedef struct ufomap_keys_info {
 	uint32_t n_hit, n_miss; /* records */
 	int32_t nb_hit[3];      /* extent of the scan's hit grid in node blocks (sizes the node table) */
 	int32_t nb_miss[3];
 	uint32_t depth;         /* insert depth of the scan: miss records are level depth+1 */
-	uint32_t reserved;      /* bit 0: merged list (depth 0): n_hit records that carry the hit AND the miss mask of
+	uint32_t reserved;      /* bit 1: a colour section follows the records (ufomap_map_scan_keys_rgb);
+	                           bit 0: merged list (depth 0): n_hit records that carry the hit AND the miss mask of
 	                           their block, n_miss = 0 -- what scan_keys produces for depth-0 scans */
 } ufomap_keys_info;
 int ufomap_map_scan_keys(ufomap_map* m, const double sensor_origin[3], const double* d_xyz, size_t n,
                          double max_range, unsigned depth, int discrete, int simple_ray_casting,
                          ufomap_keys_info* info);
+/* Colour maps (occupancy_map_color.h:177-267, discrete integrator, insert depth 0): the list gets a colour section behind
+ * its records -- 8 x uint32 (r | g<<8 | b<<16) per hit record, the colour of the first point of every hit voxel, which
+ * is what the reference blends in (225-233) -- and bit 1 of `reserved` says so. get_keys copies it too (cap_entries counts
+ * 16-byte units: n_hit + n_miss + 2 * n_hit); apply_keys / apply_keys_batch on a colour map require it. */
+int ufomap_map_scan_keys_rgb(ufomap_map* m, const double sensor_origin[3], const double* d_xyz, const uint8_t* d_rgb, size_t n,
+                             double max_range, unsigned depth, int discrete, int simple_ray_casting, ufomap_keys_info* info);
 int ufomap_map_get_keys(ufomap_map* m, void* d_dst, size_t cap_entries, const ufomap_keys_info* info);
 int ufomap_map_apply_keys(ufomap_map* m, const void* d_entries, const ufomap_keys_info* info);
 /* The update lists of n_lists scans (insert depth 0; list j = what get_keys returned for scan j) applied in
@@ -277,7 +284,7 @@ int ufomap_map_apply_keys_batch(ufomap_map* m, const void* const* d_lists, const
  * all ranks to all ranks, and every rank applies them in rank order with one walk of its replica's tree
  * (ufomap_map_apply_keys_batch). Every replica then equals the reference's map after
  * insertPointCloudDiscrete / insertPointCloud (occupancy_map_base.h:270-417) of scan 0, 1, ..., world-1 in that order.
- * Depth 0, non-colour maps. librccl is loaded at run time (UFOMAP_RCCL_LIB overrides the name; a copy already in the
+ * Depth 0; colour maps exchange a colour section with the records (ufomap_map_scan_keys_rgb). librccl is loaded at run time (UFOMAP_RCCL_LIB overrides the name; a copy already in the
  * process is preferred).
  *   ufomap_comm_unique_id   on ONE rank; the 128 bytes reach the others by the host's own means (file, socket, MPI...)
  *   ufomap_comm_create      ncclCommInitRank on `device` (collective: all ranks call it)
@@ -290,8 +297,9 @@ ufomap_comm* ufomap_comm_create(const uint8_t id[UFOMAP_COMM_ID_BYTES], int worl
 ufomap_comm* ufomap_comm_from_nccl(void* nccl_comm, int world, int rank, int device);
 void ufomap_comm_destroy(ufomap_comm* c);
 int ufomap_comm_stats(const ufomap_comm* c, uint64_t out[4]);
-int ufomap_map_insert_batch(ufomap_map* m, ufomap_comm* c, const double sensor_origin[3], const double* d_xyz, size_t n,
-                            double max_range, unsigned depth, int discrete);
+int ufomap_map_insert_batch(ufomap_map* m, ufomap_comm* c, const double sensor_origin[3], const double* d_xyz,
+                            const uint8_t* d_rgb /* colour maps: 3 bytes per point; else NULL */, size_t n, double max_range,
+                            unsigned depth, int discrete);
 
 /* Diagnostic overrides for tests: "dda_mode" (-1 auto; 1 / 2 force the LDS-filter / direct variants of
  * the ray kernel on grids that would fit in LDS), "entry_guess" (cap of the guessed update-list size, to

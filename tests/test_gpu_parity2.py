@@ -291,3 +291,56 @@ def test_far_returns_take_the_sparse_set_by_themselves():
         o.insert(origin, xyz, max_range=-1.0, discrete=discrete)
     assert g.last_counts()["steps"] > 300000
     assert g.digest() == golden_util.dump_digest(o.leaves(True), o.inner())
+
+
+def test_colour_update_lists_batch_equals_sequential():
+    """Colour maps through the split path: each scan's update list carries a colour section (the colour of the first
+    point of every hit voxel), the lists of a batch are applied with one walk of the tree, and the replica equals
+    the reference's OccupancyMapColor after insertPointCloudDiscrete of the scans one by one (occupancy_map_color.h:
+    177-267) -- values, colours, inner summaries, pruning. Moving sensor, overlapping voxels, three batches of three."""
+    import torch
+    from oracle import OracleMap, available
+    from ufomap_amd import OccupancyMapColor, scans
+    kind = "reference" if available("reference") else "port"
+    g, o = OccupancyMapColor(0.16), OracleMap(0.16, kind=kind, color=True)
+    scratch = OccupancyMapColor(0.16)  # a second handle does the ray casting (as another GPU would)
+    for batch in range(3):
+        bufs, infos = [], []
+        for k in range(3):
+            p = (batch + 2 * k) % 4
+            origin, xyz, rgb = scans.lidar64(beams=32, azimuths=1024, origin=scans.lidar_pose(p), seed=100 + p + 10 * batch, colored=True)
+            d, dc = torch.from_numpy(xyz).cuda(), torch.from_numpy(rgb).cuda()
+            caster = scratch if k % 2 else g
+            info = caster.scan_keys(origin, d.data_ptr(), xyz.shape[0], 15.0, 0, True, d_rgb_ptr=dc.data_ptr())
+            assert info.reserved & 2 and info.list_bytes == (info.n_hit + info.n_miss) * 16 + info.n_hit * 32
+            buf = torch.empty(info.list_bytes, dtype=torch.uint8, device="cuda")
+            caster.get_keys(buf.data_ptr(), buf.numel() // 16, info)
+            bufs.append(buf)
+            infos.append(info)
+            o.insert(origin, xyz, rgb, max_range=15.0, discrete=True)
+        g.apply_keys_batch([b.data_ptr() for b in bufs], infos)
+        g.insertPointCloudWait()
+        assert g.digest() == golden_util.dump_digest(o.leaves(True), o.inner()), f"batch {batch}"
+    assert g.write() == o.write()
+
+
+def test_insert_batch_c_abi_world1_colour():
+    """ufomap_map_insert_batch on an OccupancyMapColor: the colour sections travel through the RCCL all-gather."""
+    import torch
+    from oracle import OracleMap, available
+    from ufomap_amd import OccupancyMapColor, Comm, scans
+    kind = "reference" if available("reference") else "port"
+    g, o = OccupancyMapColor(0.16), OracleMap(0.16, kind=kind, color=True)
+    comm = Comm(Comm.unique_id(), 1, 0, 0)
+    try:
+        for s in range(4):
+            origin, xyz, rgb = scans.lidar64(origin=scans.lidar_pose(s % 3), seed=100 + s % 3, beams=32, azimuths=1024, colored=True)
+            d, dc = torch.from_numpy(xyz).cuda(), torch.from_numpy(rgb).cuda()
+            g.insert_batch(comm, origin, d.data_ptr(), xyz.shape[0], 20.0, 0, True, d_rgb_ptr=dc.data_ptr())
+            o.insert(origin, xyz, rgb, max_range=20.0, discrete=True)
+            torch.cuda.synchronize()
+        g.insertPointCloudWait()
+        assert g.digest() == golden_util.dump_digest(o.leaves(True), o.inner())
+    finally:
+        g.insertPointCloudWait()
+        comm.close()

@@ -28,7 +28,7 @@ SYMBOLS = [
     "ufomap_map_clear_to", "ufomap_map_get_sensor_model", "ufomap_map_set_model_value", "ufomap_map_set_occupied_free_thres",
     "ufomap_map_set_value_volume_ch", "ufomap_map_enable_change_detection", "ufomap_map_reset_change_detection", "ufomap_map_changes",
     "ufomap_map_enable_minmax_change_detection", "ufomap_map_iterate", "ufomap_map_write_ex", "ufomap_map_read", "ufomap_map_read_data",
-    "ufomap_map_scan_keys", "ufomap_map_get_keys", "ufomap_map_apply_keys", "ufomap_map_apply_keys_batch",
+    "ufomap_map_scan_keys", "ufomap_map_scan_keys_rgb", "ufomap_map_get_keys", "ufomap_map_apply_keys", "ufomap_map_apply_keys_batch",
     "ufomap_comm_unique_id", "ufomap_comm_create", "ufomap_comm_from_nccl", "ufomap_comm_destroy", "ufomap_comm_stats", "ufomap_map_insert_batch",
     "ufomap_map_stream", "ufomap_map_debug", "ufomap_map_set_option",
 ]
@@ -42,6 +42,11 @@ class KeysInfo(C.Structure):
                 ("depth", C.c_uint32), ("reserved", C.c_uint32)]
 
     WORDS = 10  # as a flat int32 vector for exchange between ranks
+
+    @property
+    def list_bytes(self):
+        """Size of the list on the wire: 16-byte records + (colour maps) 32 bytes of colours per hit record."""
+        return (self.n_hit + self.n_miss) * 16 + (self.n_hit * 32 if (self.reserved & 2) else 0)
 
     def to_list(self):
         return [self.n_hit, self.n_miss, *self.nb_hit, *self.nb_miss, self.depth, self.reserved]
@@ -110,6 +115,7 @@ def load():
     lib.ufomap_map_kernel_times.argtypes = [vp, C.POINTER(C.c_char_p), u64p, f64p, C.c_int]
     lib.ufomap_map_reset_kernel_times.argtypes = [vp]
     lib.ufomap_map_scan_keys.argtypes = [vp, f64p, vp, sz, dbl, C.c_uint, C.c_int, C.c_int, C.POINTER(KeysInfo)]
+    lib.ufomap_map_scan_keys_rgb.argtypes = [vp, f64p, vp, vp, sz, dbl, C.c_uint, C.c_int, C.c_int, C.POINTER(KeysInfo)]
     lib.ufomap_map_get_keys.argtypes = [vp, vp, sz, C.POINTER(KeysInfo)]
     lib.ufomap_map_insert_pointcloud2.argtypes = [vp, f64p, f64p, vp, C.c_int, sz, C.c_uint32] + [C.c_int] * 6 + [
         dbl, C.c_uint, C.c_int, C.c_int, C.c_uint, C.c_int]
@@ -123,7 +129,7 @@ def load():
     lib.ufomap_comm_destroy.restype = None
     lib.ufomap_comm_destroy.argtypes = [vp]
     lib.ufomap_comm_stats.argtypes = [vp, C.POINTER(C.c_uint64)]
-    lib.ufomap_map_insert_batch.argtypes = [vp, vp, f64p, vp, sz, dbl, C.c_uint, C.c_int]
+    lib.ufomap_map_insert_batch.argtypes = [vp, vp, f64p, vp, vp, sz, dbl, C.c_uint, C.c_int]
     lib.ufomap_map_clear_to.argtypes = [vp, dbl, C.c_uint]
     lib.ufomap_map_get_sensor_model.argtypes = [vp, f64p]
     lib.ufomap_map_set_model_value.argtypes = [vp, C.c_int, dbl]

@@ -242,6 +242,31 @@ __global__ void k_store_counts(SmallCounts c, u32 n, u32* __restrict__ out)
 	if (threadIdx.x < n) out[threadIdx.x] = c.v[threadIdx.x];
 }
 
+// The colour section of an update list (ufomap_keys_info::reserved bit 1): for each of the first n records, the colours
+// of its hit voxels = the colour of the first point in the voxel (what k_apply_leaf finds through the hit hash,
+// occupancy_map_color.h:225-233), 0 for the other children.
+__global__ __launch_bounds__(256) void k_list_colors(MapGeom g, const Entry* __restrict__ entries, u32 n, HitHash hh, const uint8_t* __restrict__ rgb_in,
+                                                     u32* __restrict__ out)
+{
+	const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const Entry e = entries[i];
+	const u64 pcode = (e.lk ^ (1ULL << (3 * (g.L - 1)))) << 3;  // depth-0 code of child 0
+	u32 col[8];
+#pragma unroll
+	for (int c = 0; c < 8; ++c) {
+		col[c] = 0;
+		if (!((e.hit >> c) & 1)) continue;
+		const u32 hs = hitHashFind(hh, pcode | (u64)c);
+		if (hs == NONE) continue;
+		const u32 pt = hh.minidx[hs];
+		col[c] = (u32)rgb_in[3 * (size_t)pt] | ((u32)rgb_in[3 * (size_t)pt + 1] << 8) | ((u32)rgb_in[3 * (size_t)pt + 2] << 16);
+	}
+	uint4* o = reinterpret_cast<uint4*>(out + 8 * (size_t)i);
+	o[0] = make_uint4(col[0], col[1], col[2], col[3]);
+	o[1] = make_uint4(col[4], col[5], col[6], col[7]);
+}
+
 // clear flag bits of a control block (the host re-runs an update that had stood back: ERR_PREV only -- a flag the
 // scan raised itself must survive)
 __global__ void k_ctl_clear(ScanCtl* ctl, u32 bits) { atomicAnd(&ctl->err, ~bits); }
@@ -501,8 +526,11 @@ __global__ __launch_bounds__(256) void k_apply_leaf(Table t, MapGeom g, const En
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_apply_values(Table t, MapGeom g, const Entry* __restrict__ entries, const u32* n_entries_p,
                                                       const u32* __restrict__ ent_slot, float upd_hit, float upd_miss, u32 mode, u32 phase,
-                                                      u64 time_hi, u32* __restrict__ wl, ScanCtl::PhaseCtr* pc, const ScanCtl* ctl, ChangeLog cl)
+                                                      u64 time_hi, u32* __restrict__ wl, ScanCtl::PhaseCtr* pc, const ScanCtl* ctl, ChangeLog cl,
+                                                      const u32* __restrict__ list_rgb)
 {
+	// list_rgb (colour maps): 8 colours per record, the colour of the first point of every hit voxel -- what k_apply_leaf
+	// looks up through the scan's hit hash travels with the list here (the list may come from another GPU)
 	const u32 n = *n_entries_p;
 	if (ctl->err) return;
 	const u32 stride = gridDim.x * blockDim.x;
@@ -525,6 +553,21 @@ __global__ __launch_bounds__(256) void k_apply_values(Table t, MapGeom g, const 
 			const u64 t_last = last_is_miss ? UFO_MISS_TIME : (u64)e.t_last;
 			float v_old_last = 0.f;
 			u32 chg = 0;
+			if (g.color && list_rgb && hmask) {
+				// updateValue(code, update, color): colour first, with the OLD occupancy (OMC.h:275-277)
+				u32 old_rgb_last = 0;
+#pragma unroll
+				for (int c = 0; c < 8; ++c) {
+					if (!((hmask >> c) & 1)) continue;
+					u32* pcol = t.rgb + 8 * (size_t)s + c;
+					const u32 oldc = *pcol;
+					*pcol = blendColor(g, oldc, list_rgb[8 * (size_t)i + c], v[c]);
+					if (c == c_last) old_rgb_last = oldc;
+				}
+				// colour of the last-updated child just before that update (a miss leaves the colour alone: k_finish_leaf then
+				// takes the colour as it is)
+				if (!last_is_miss) t.lu_rgb[8 * (size_t)s + c_last] = old_rgb_last;
+			}
 #pragma unroll
 			for (int c = 0; c < 8; ++c) {
 				float x = v[c];
@@ -574,7 +617,10 @@ __global__ __launch_bounds__(256) void k_finish_leaf(Table t, MapGeom g, const u
 			const u64 time = (tv >> 3) & ((1ull << 37) - 1ull);
 			const Summ sm = blockSummary(t, g, s, 1, 0);
 			// summary just before the block's last update (level 1 is always reached: OMB:1128 starts at 1)
-			const Summ pre = blockSummary(t, g, s, 1, 0, c_last, t.lu_occ[8 * (size_t)s + c_last], 0, g.color ? t.rgb[8 * (size_t)s + c_last] : 0u);
+			// (colour just before the last update: a miss does not touch it; a hit's old colour was parked by k_apply_values)
+			const bool last_was_miss = 0 != (time & UFO_MISS_TIME);
+			const u32 pre_rgb = g.color ? (last_was_miss ? t.rgb[8 * (size_t)s + c_last] : t.lu_rgb[8 * (size_t)s + c_last]) : 0u;
+			const Summ pre = blockSummary(t, g, s, 1, 0, c_last, t.lu_occ[8 * (size_t)s + c_last], 0, pre_rgb);
 			const bool reachchg = !sameSumm(g, pre, sm);
 			publishLast(t, g, s, lk, phase, reachchg, pre);
 			carryTime(t, s, lk, phase, time);

@@ -822,7 +822,8 @@ int extractLists(ufomap_map* m, u64 capH, u64 capM, bool zero_counts, bool merge
 	ScanCtl* ctl = m->b_ctl.as<ScanCtl>();
 	if (capH > 0x7FFFFFFFull || capM > 0x7FFFFFFFull || capH + capM > 0x7FFFFFFFull)
 		return fail(UFOMAP_ERR_CAPACITY, "update list exceeds 2^31 entries");
-	HIP_TRY(m->b_entries.reserve(((size_t)capH + capM + 1) * sizeof(Entry)));
+	// (+ 32 bytes per record for the colour section of a colour map's update list: ufomap_map_scan_keys_rgb)
+	HIP_TRY(m->b_entries.reserve(((size_t)capH + capM + 1) * (sizeof(Entry) + (m->g.color ? 32u : 0u))));
 	Entry* ent_h = m->b_entries.as<Entry>();
 	Entry* ent_m = ent_h + capH;
 	if (zero_counts) HIP_TRY(hipMemsetAsync(&ctl->n_entries[0], 0, 8, m->cs));  // otherwise zero from the control-block upload
@@ -2757,7 +2758,16 @@ int ufomap_map_reset_kernel_times(ufomap_map* m)
 int ufomap_map_scan_keys(ufomap_map* m, const double sensor_origin[3], const double* d_xyz, size_t n, double max_range,
                          unsigned depth, int discrete, int simple_ray_casting, ufomap_keys_info* info)
 {
+	return ufomap_map_scan_keys_rgb(m, sensor_origin, d_xyz, nullptr, n, max_range, depth, discrete, simple_ray_casting, info);
+}
+
+int ufomap_map_scan_keys_rgb(ufomap_map* m, const double sensor_origin[3], const double* d_xyz, const uint8_t* d_rgb, size_t n, double max_range,
+                             unsigned depth, int discrete, int simple_ray_casting, ufomap_keys_info* info)
+{
 	if (!m || !info) return fail(UFOMAP_ERR_INVALID, "null argument");
+	if (d_rgb && !m->g.color) return fail(UFOMAP_ERR_INVALID, "colours for a map without colour");
+	if (d_rgb && !discrete) return fail(UFOMAP_ERR_UNSUPPORTED, "colour integration exists for the discrete integrator only (occupancy_map_color.h:177)");
+	if (d_rgb && 0 != depth) return fail(UFOMAP_ERR_UNSUPPORTED, "update lists with colour: insert depth 0 only");
 	memset(info, 0, sizeof(*info));
 	info->depth = depth;
 	HIP_TRY(hipSetDevice(m->device));
@@ -2768,7 +2778,7 @@ int ufomap_map_scan_keys(ufomap_map* m, const double sensor_origin[3], const dou
 	m->args = ScanArgs{};
 	m->cs = m->sstream;
 	u32 n_hits = 0, n_rays = 0;
-	int rc = scanPhase(m, sensor_origin, d_xyz, nullptr, n, max_range, depth, discrete, simple_ray_casting, 0, &n_hits, &n_rays);
+	int rc = scanPhase(m, sensor_origin, d_xyz, d_rgb, n, max_range, depth, discrete, simple_ray_casting, 0, &n_hits, &n_rays);
 	if (rc || 0 == n) return rc;
 	u64 capH = 0, capM = 0;
 	// insert depth 0: ONE list, a block with hits and misses appears once with both masks (flagged in `reserved`)
@@ -2790,6 +2800,14 @@ int ufomap_map_scan_keys(ufomap_map* m, const double sensor_origin[3], const dou
 	}
 	info->n_hit = nh;
 	info->n_miss = nm;
+	if (d_rgb && nh) {
+		// colour section behind the records: 8 colours per hit record (merged list: every record)
+		const HitHash hh{m->b_hh_keys.as<u64>(), reinterpret_cast<u32*>(m->b_hh_keys.as<u64>() + ((size_t)m->hh_mask + 1)), m->hh_mask};
+		hipLaunchKernelGGL(k_list_colors, gridFor(nh), dim3(256), 0, m->cs, m->g, m->b_entries.as<Entry>(), nh, hh, d_rgb,
+		                   reinterpret_cast<u32*>(m->b_entries.as<Entry>() + ((size_t)nh + nm)));
+		HIP_TRY(hipStreamSynchronize(m->cs));
+		info->reserved |= 2u;
+	}
 	for (int a = 0; a < 3; ++a) {
 		info->nb_hit[a] = m->haveH ? m->gridH.nb[a] : 0;
 		info->nb_miss[a] = m->haveM ? m->gridM.nb[a] : 0;
@@ -2805,6 +2823,7 @@ int ufomap_map_get_keys(ufomap_map* m, void* d_dst, size_t cap_entries, const uf
 {
 	if (!m || !info) return fail(UFOMAP_ERR_INVALID, "null argument");
 	size_t tot = (size_t)info->n_hit + info->n_miss;
+	if (info->reserved & 2u) tot += 2 * (size_t)info->n_hit;  // colour section: 32 bytes per hit record
 	if (tot > cap_entries) return fail(UFOMAP_ERR_CAPACITY, "destination too small for the update list");
 	HIP_TRY(hipSetDevice(m->device));
 	if (tot) HIP_TRY(hipMemcpyAsync(d_dst, m->b_entries.p, tot * sizeof(Entry), hipMemcpyDeviceToDevice, m->sstream));
@@ -2815,7 +2834,7 @@ int ufomap_map_get_keys(ufomap_map* m, void* d_dst, size_t cap_entries, const uf
 int ufomap_map_apply_keys(ufomap_map* m, const void* d_entries, const ufomap_keys_info* info)
 {
 	if (!m || !info) return fail(UFOMAP_ERR_INVALID, "null argument");
-	if (m->g.color) return fail(UFOMAP_ERR_UNSUPPORTED, "update lists carry no colour: apply_keys works on OccupancyMap only");
+	if (m->g.color) return ufomap_map_apply_keys_batch(m, &d_entries, info, 1);  // (checks that the list carries colours)
 	if (const int grc = phaseGuard(m)) return grc;
 	if (info->depth >= m->g.L) return fail(UFOMAP_ERR_INVALID, "depth must be < depth_levels");
 	HIP_TRY(hipSetDevice(m->device));
@@ -2856,7 +2875,11 @@ int ufomap_map_apply_keys(ufomap_map* m, const void* d_entries, const ufomap_key
 int ufomap_map_apply_keys_batch(ufomap_map* m, const void* const* d_lists, const ufomap_keys_info* infos, int n_lists)
 {
 	if (!m || !d_lists || !infos || n_lists < 0) return fail(UFOMAP_ERR_INVALID, "null argument");
-	if (m->g.color) return fail(UFOMAP_ERR_UNSUPPORTED, "update lists carry no colour: apply_keys works on OccupancyMap only");
+	if (m->g.color)
+		for (int j = 0; j < n_lists; ++j)
+			if (infos[j].n_hit && !(infos[j].reserved & 2u))
+				return fail(UFOMAP_ERR_INVALID, "a colour map needs update lists with a colour section (ufomap_map_scan_keys_rgb)");
+	if (const int grc = phaseGuard(m)) return grc;
 	if (n_lists > 128) return fail(UFOMAP_ERR_INVALID, "at most 128 update lists per batch");
 	for (int j = 0; j < n_lists; ++j)
 		if (0 != infos[j].depth) return fail(UFOMAP_ERR_UNSUPPORTED, "apply_keys_batch: insert depth 0 only (apply deeper scans one by one)");
@@ -2895,6 +2918,7 @@ int ufomap_map_apply_keys_batch(ufomap_map* m, const void* const* d_lists, const
 	// sub-lists in application order: scan 0 hits, scan 0 misses, scan 1 hits, ...; their counts live on the device
 	struct Sub {
 		const Entry* ent;
+		const u32* rgb;          // colour section of the list (hit / merged sub-lists of a colour map), else nullptr
 		u32 n, off, mode, scan;  // mode: 0 misses, 1 hits, 2 merged (k_apply_values)
 		const i32* nbA;          // grid the entries lie in ...
 		const i32* nbB;          // ... or, merged lists, this one (nullptr otherwise)
@@ -2911,21 +2935,22 @@ int ufomap_map_apply_keys_batch(ufomap_map* m, const void* const* d_lists, const
 	for (int j = 0; j < n_lists; ++j) {
 		const Entry* e = static_cast<const Entry*>(d_lists[j]);
 		const u32 nh = infos[j].n_hit, nm = infos[j].n_miss;
+		const u32* rgbs = (m->g.color && (infos[j].reserved & 2u)) ? reinterpret_cast<const u32*>(e + ((size_t)nh + nm)) : nullptr;
 		if (infos[j].reserved & 1u) {
 			// merged list: n_hit records, each with the hit and the miss mask of its block
 			if (nm) return fail(UFOMAP_ERR_INVALID, "merged update list with a separate miss list");
 			if (nh) {
-				subs.push_back(Sub{e, nh, off, 2u, (u32)j, infos[j].nb_hit, infos[j].nb_miss});
+				subs.push_back(Sub{e, rgbs, nh, off, 2u, (u32)j, infos[j].nb_hit, infos[j].nb_miss});
 				off += nh;
 			}
 			continue;
 		}
 		if (nh) {
-			subs.push_back(Sub{e, nh, off, 1u, (u32)j, infos[j].nb_hit, nullptr});
+			subs.push_back(Sub{e, rgbs, nh, off, 1u, (u32)j, infos[j].nb_hit, nullptr});
 			off += nh;
 		}
 		if (nm) {
-			subs.push_back(Sub{e + nh, nm, off, 0u, (u32)j, infos[j].nb_miss, nullptr});
+			subs.push_back(Sub{e + nh, nullptr, nm, off, 0u, (u32)j, infos[j].nb_miss, nullptr});
 			off += nm;
 		}
 	}
@@ -2994,7 +3019,7 @@ int ufomap_map_apply_keys_batch(ufomap_map* m, const void* const* d_lists, const
 		ProfScope ps(m, "k_apply_values");
 		const u64 time_hi = (u64)subs[k].scan << 30;
 		hipLaunchKernelGGL(k_apply_values, gridFor(subs[k].n), dim3(256), 0, m->cs, m->t, m->g, subs[k].ent, d_cnt + k,
-		                   m->b_ent_slot.as<u32>() + subs[k].off, m->g.hit, miss, subs[k].mode, m->scan_id, time_hi, wl[1], pc, ctl, cl);
+		                   m->b_ent_slot.as<u32>() + subs[k].off, m->g.hit, miss, subs[k].mode, m->scan_id, time_hi, wl[1], pc, ctl, cl, subs[k].rgb);
 	}
 	{
 		ProfScope ps(m, "k_finish_leaf");
@@ -3180,20 +3205,23 @@ int ufomap_comm_stats(const ufomap_comm* c, uint64_t out[4])
 	return UFOMAP_OK;
 }
 
-int ufomap_map_insert_batch(ufomap_map* m, ufomap_comm* c, const double sensor_origin[3], const double* d_xyz, size_t n, double max_range,
-                            unsigned depth, int discrete)
+int ufomap_map_insert_batch(ufomap_map* m, ufomap_comm* c, const double sensor_origin[3], const double* d_xyz, const uint8_t* d_rgb, size_t n,
+                            double max_range, unsigned depth, int discrete)
 {
 	if (!m || !c || !sensor_origin) return fail(UFOMAP_ERR_INVALID, "null argument");
-	if (m->g.color) return fail(UFOMAP_ERR_UNSUPPORTED, "update lists carry no colour: insert_batch works on OccupancyMap only");
+	if (m->g.color && !d_rgb && n) return fail(UFOMAP_ERR_INVALID, "a colour map needs the points' colours");
 	if (0 != depth) return fail(UFOMAP_ERR_UNSUPPORTED, "insert_batch: insert depth 0 only");
 	Rccl* r = rccl();
 	if (!r) return fail(UFOMAP_ERR_UNSUPPORTED, "librccl not found (set UFOMAP_RCCL_LIB)");
 	HIP_TRY(hipSetDevice(m->device));
 	// 1. this rank's scan -> update list (scan stream; never reads the map: overlaps the previous batch's tree update)
 	ufomap_keys_info info;
-	int rc = ufomap_map_scan_keys(m, sensor_origin, d_xyz, n, max_range, depth, discrete, 0, &info);
+	int rc = ufomap_map_scan_keys_rgb(m, sensor_origin, d_xyz, m->g.color ? d_rgb : nullptr, n, max_range, depth, discrete, 0, &info);
 	if (rc) return rc;
-	const size_t my_bytes = ((size_t)info.n_hit + info.n_miss) * sizeof(Entry);
+	auto listBytes = [](const ufomap_keys_info& k) {  // records + colour section
+		return ((size_t)k.n_hit + k.n_miss) * sizeof(Entry) + ((k.reserved & 2u) ? (size_t)k.n_hit * 32u : 0u);
+	};
+	const size_t my_bytes = listBytes(info);
 	const int W = c->world;
 	std::vector<ufomap_keys_info> infos((size_t)W);
 	for (;;) {
@@ -3215,7 +3243,7 @@ int ufomap_map_insert_batch(ufomap_map* m, ufomap_comm* c, const double sensor_o
 		size_t need = 0;
 		for (int k = 0; k < W; ++k) {
 			memcpy(&infos[(size_t)k], c->h_hdr + (size_t)k * kSlotHeader, sizeof(ufomap_keys_info));
-			need = std::max(need, kSlotHeader + ((size_t)infos[(size_t)k].n_hit + infos[(size_t)k].n_miss) * sizeof(Entry));
+			need = std::max(need, kSlotHeader + listBytes(infos[(size_t)k]));
 		}
 		if (need <= c->cap) break;
 		// some rank's list did not fit: every rank sees that in the headers and grows to the same capacity; an update of

@@ -33,9 +33,9 @@ class MapBackend:
         self.m.set_option("async_apply", 1)
         self._buf = torch.empty(0, dtype=torch.uint8, device=device)
 
-    def scan(self, origin, d_xyz_ptr, n, max_range, depth, discrete):
-        info = self.m.scan_keys(origin, d_xyz_ptr, n, max_range, depth, discrete)
-        nbytes = (info.n_hit + info.n_miss) * ENTRY_BYTES
+    def scan(self, origin, d_xyz_ptr, n, max_range, depth, discrete, d_rgb_ptr=None):
+        info = self.m.scan_keys(origin, d_xyz_ptr, n, max_range, depth, discrete, d_rgb_ptr=d_rgb_ptr)
+        nbytes = info.list_bytes  # records + colour section (colour maps)
         if self._buf.numel() < nbytes:
             self._buf = torch.empty(max(nbytes, 2 * self._buf.numel()), dtype=torch.uint8, device=self.device)
         if nbytes:
@@ -104,6 +104,7 @@ class BatchIntegrator:
             dist.all_gather_into_tensor(recv.view(-1), send, group=self.group)
             headers = recv[:, : 4 * KeysInfo.WORDS].contiguous().view(torch.int32).view(world, KeysInfo.WORDS).cpu()
             nbytes = (headers[:, 0].to(torch.int64) + headers[:, 1].to(torch.int64)) * ENTRY_BYTES
+            nbytes = nbytes + torch.where((headers[:, 9] & 2) != 0, headers[:, 0].to(torch.int64) * 32, torch.zeros_like(nbytes))  # colour sections
             need = HDR_BYTES + int(nbytes.max().item())
             if need <= self._cap:
                 return headers, [recv[r, HDR_BYTES: HDR_BYTES + int(nbytes[r])] for r in range(world)]
@@ -112,8 +113,9 @@ class BatchIntegrator:
             if hasattr(self.backend, "join"):
                 self.backend.join()  # an update still reading the old receive buffers finishes before they go
 
-    def integrate(self, origin, d_xyz_ptr, n, max_range=-1.0, depth=0, discrete=True):
-        payload, header = self.backend.scan(origin, d_xyz_ptr, n, max_range, depth, discrete)
+    def integrate(self, origin, d_xyz_ptr, n, max_range=-1.0, depth=0, discrete=True, d_rgb_ptr=None):
+        payload, header = (self.backend.scan(origin, d_xyz_ptr, n, max_range, depth, discrete, d_rgb_ptr) if d_rgb_ptr
+                           else self.backend.scan(origin, d_xyz_ptr, n, max_range, depth, discrete))
         headers, lists = self.exchange(payload, header)
         if payload.is_cuda:
             torch.cuda.current_stream(payload.device).synchronize()  # RCCL ran on torch's stream, apply runs on the map's
@@ -142,8 +144,8 @@ class CBatchIntegrator:
         self.comm = Comm(ids[0], world, rank, device_index)
         self.m.set_option("async_apply", 1)
 
-    def integrate(self, origin, d_xyz_ptr, n, max_range=-1.0, depth=0, discrete=True):
-        self.m.insert_batch(self.comm, origin, d_xyz_ptr, n, max_range, depth, discrete)
+    def integrate(self, origin, d_xyz_ptr, n, max_range=-1.0, depth=0, discrete=True, d_rgb_ptr=None):
+        self.m.insert_batch(self.comm, origin, d_xyz_ptr, n, max_range, depth, discrete, d_rgb_ptr=d_rgb_ptr)
 
     def close(self):
         self.m.insertPointCloudWait()

@@ -275,12 +275,13 @@ class OccupancyMapBase:
     # ---- multi-GPU batched scans: the path split at its exchange point (include/ufomap_hip.h) ------
     ENTRY_BYTES = 16
 
-    def scan_keys(self, sensor_origin, d_xyz_ptr, n, max_range=-1.0, depth=0, discrete=True, simple_ray_casting=False):
-        """Ray-cast one scan WITHOUT touching the map; returns the header of its update list."""
+    def scan_keys(self, sensor_origin, d_xyz_ptr, n, max_range=-1.0, depth=0, discrete=True, simple_ray_casting=False, d_rgb_ptr=None):
+        """Ray-cast one scan WITHOUT touching the map; returns the header of its update list (colour maps: pass the
+        points' colours, the list then carries a colour section: ``info.list_bytes``)."""
         o = np.ascontiguousarray(sensor_origin, np.float64)
         info = capi.KeysInfo()
-        capi.check(self._lib.ufomap_map_scan_keys(self._h, _p(o, C.c_double), d_xyz_ptr, n, float(max_range), int(depth),
-                                                  int(discrete), int(simple_ray_casting), C.byref(info)))
+        capi.check(self._lib.ufomap_map_scan_keys_rgb(self._h, _p(o, C.c_double), d_xyz_ptr, d_rgb_ptr, n, float(max_range), int(depth),
+                                                      int(discrete), int(simple_ray_casting), C.byref(info)))
         return info
 
     def get_keys(self, d_dst_ptr, cap_entries, info):
@@ -298,12 +299,12 @@ class OccupancyMapBase:
             arr[i] = k
         capi.check(self._lib.ufomap_map_apply_keys_batch(self._h, ptrs, arr, n))
 
-    def insert_batch(self, comm, origin, d_xyz_ptr, n, max_range=-1.0, depth=0, discrete=True):
+    def insert_batch(self, comm, origin, d_xyz_ptr, n, max_range=-1.0, depth=0, discrete=True, d_rgb_ptr=None):
         """This rank's scan of a multi-GPU batch (``ufomap_map_insert_batch``): ray casting here, one RCCL all-gather of the
         update lists, all ranks' lists applied in rank order."""
         o = np.ascontiguousarray(origin, dtype=np.float64)
-        capi.check(self._lib.ufomap_map_insert_batch(self._h, comm._h, _p(o, C.c_double), C.c_void_p(int(d_xyz_ptr)), n, float(max_range),
-                                                     int(depth), int(discrete)))
+        capi.check(self._lib.ufomap_map_insert_batch(self._h, comm._h, _p(o, C.c_double), C.c_void_p(int(d_xyz_ptr)),
+                                                     C.c_void_p(int(d_rgb_ptr)) if d_rgb_ptr else None, n, float(max_range), int(depth), int(discrete)))
 
     def set_scratch_limit(self, n_bytes):
         """``ufomap_map_set_scratch_limit``: largest dense per-scan grid; scans beyond it take the sparse set of ray cells."""
