@@ -171,16 +171,18 @@ __device__ inline bool sameSumm(const MapGeom& g, const Summ& a, const Summ& b)
 // summary, and the summary it had just before that update; tmax tells the parent which child carries
 // the last update.
 #define UFO_TAG(phase) ((u64)((phase)&0xFFFFFFu))
-// The record lives in the PARENT's arrays at [8*parent + child index], so the parent reads it without a
-// hash lookup. lu_fl: bits 0-1 flags of the pre-last summary, bit 8 "reached and changed", bits 9.. phase tag.
+// ONE record per block, in the block's own slot (8 bytes, 12 with colour); the parent pulls the record of the child that
+// carries the last update (tmax names it) with one hash lookup. (Round 1 kept eight records per slot in the parent's
+// arrays -- no lookup, but 64-96 bytes of every table slot for words that only live during a phase.)
+// lu_fl: bits 0-1 flags of the pre-last summary, bit 8 "reached and changed", bits 9.. phase tag.
 __device__ inline void publishLast(const Table& t, const MapGeom& g, u32 s, u64 lk, u32 phase, bool reachchg, const Summ& pre,
                                    u32 p_known = NONE)
 {
 	if (1 == lk) return;
-	size_t at = 8 * (size_t)((p_known != NONE) ? p_known : t.parent(s)) + (size_t)(lk & 7);
-	t.lu_occ[at] = pre.occ;
-	if (g.color) t.lu_rgb[at] = pre.rgb;
-	t.lu_fl[at] = (pre.fl & 3u) | (reachchg ? 0x100u : 0u) | ((phase & 0x3FFFFFu) << 9);
+	(void)p_known;
+	t.lu_occ[s] = pre.occ;
+	if (g.color) t.lu_rgb[s] = pre.rgb;
+	t.lu_fl[s] = (pre.fl & 3u) | (reachchg ? 0x100u : 0u) | ((phase & 0x3FFFFFu) << 9);
 }
 // carry the time of the last update beneath block s up the tree (max-reduction with early exit)
 __device__ inline void carryTime(const Table& t, u32 s, u64 lk, u32 phase, u64 time)
@@ -202,10 +204,11 @@ __device__ inline bool lastReached(const Table& t, const MapGeom& g, u32 s, u64 
 	u64 tv = tv_known ? *tv_known : t.tmax[s];
 	if ((tv >> 40) != UFO_TAG(phase)) return false;
 	int c = (int)(tv & 7);
-	size_t at = 8 * (size_t)s + (size_t)c;
-	u32 lf = t.lu_fl[at];
+	const u32 cs = tableFind(t, (lk << 3) | (u64)c);  // the child's block: updated in this phase, so it is there (maybe just collapsed)
+	if (cs == NONE) return false;
+	u32 lf = t.lu_fl[cs];
 	if ((lf >> 9) != (phase & 0x3FFFFFu) || !(lf & 0x100u)) return false;
-	*pre = blockSummary(t, g, s, level, f, c, t.lu_occ[at], lf & 3u, g.color ? t.lu_rgb[at] : 0u);
+	*pre = blockSummary(t, g, s, level, f, c, t.lu_occ[cs], lf & 3u, g.color ? t.lu_rgb[cs] : 0u);
 	return true;
 }
 
@@ -228,9 +231,7 @@ __global__ __launch_bounds__(256) void k_reset_tags(Table t)
 	if (s > (u64)t.mask) return;
 	t.stamp((u32)s) = 0;
 	t.tmax[s] = 0;
-	uint4* f = reinterpret_cast<uint4*>(t.lu_fl + 8 * s);
-	f[0] = make_uint4(0, 0, 0, 0);
-	f[1] = make_uint4(0, 0, 0, 0);
+	t.lu_fl[s] = 0;
 }
 
 // a few counters from the host, by value (no host buffer whose lifetime anybody has to think about)
@@ -566,7 +567,7 @@ __global__ __launch_bounds__(256) void k_apply_values(Table t, MapGeom g, const 
 				}
 				// colour of the last-updated child just before that update (a miss leaves the colour alone: k_finish_leaf then
 				// takes the colour as it is)
-				if (!last_is_miss) t.lu_rgb[8 * (size_t)s + c_last] = old_rgb_last;
+				if (!last_is_miss) t.lu_rgb[s] = old_rgb_last;
 			}
 #pragma unroll
 			for (int c = 0; c < 8; ++c) {
@@ -588,7 +589,7 @@ __global__ __launch_bounds__(256) void k_apply_values(Table t, MapGeom g, const 
 			po[0] = make_float4(v[0], v[1], v[2], v[3]);
 			po[1] = make_float4(v[4], v[5], v[6], v[7]);
 			logChanges(t, cl, (e.lk ^ (1ULL << (3 * (g.L - 1)))) << 3, 0u, chg);
-			t.lu_occ[8 * (size_t)s + c_last] = v_old_last;
+			t.lu_occ[s] = v_old_last;
 			t.tmax[s] = (UFO_TAG(phase) << 40) | ((time_hi | t_last) << 3) | (u64)c_last;
 			first = !(atomicOr(&t.flags(s), F_DIRTY) & F_DIRTY);
 		}
@@ -619,8 +620,8 @@ __global__ __launch_bounds__(256) void k_finish_leaf(Table t, MapGeom g, const u
 			// summary just before the block's last update (level 1 is always reached: OMB:1128 starts at 1)
 			// (colour just before the last update: a miss does not touch it; a hit's old colour was parked by k_apply_values)
 			const bool last_was_miss = 0 != (time & UFO_MISS_TIME);
-			const u32 pre_rgb = g.color ? (last_was_miss ? t.rgb[8 * (size_t)s + c_last] : t.lu_rgb[8 * (size_t)s + c_last]) : 0u;
-			const Summ pre = blockSummary(t, g, s, 1, 0, c_last, t.lu_occ[8 * (size_t)s + c_last], 0, pre_rgb);
+			const u32 pre_rgb = g.color ? (last_was_miss ? t.rgb[8 * (size_t)s + c_last] : t.lu_rgb[s]) : 0u;
+			const Summ pre = blockSummary(t, g, s, 1, 0, c_last, t.lu_occ[s], 0, pre_rgb);
 			const bool reachchg = !sameSumm(g, pre, sm);
 			publishLast(t, g, s, lk, phase, reachchg, pre);
 			carryTime(t, s, lk, phase, time);

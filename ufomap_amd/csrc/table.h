@@ -76,7 +76,7 @@ struct Table {
 	Block* blk;
 	u32* rgb;  // [8*slot + child], colour maps only (nullptr otherwise)
 	u64* tmax;
-	float* lu_occ;  // [8*slot + child]: last-update record published by child `child` of this block
+	float* lu_occ;  // [slot]: the block's last-update record (map_kernels.h: publishLast); level-1 blocks park the old value of their last-updated voxel here first
 	u32* lu_fl;     // bit0/1 = contains_free/unknown of the pre-last summary, bit 8 = "reached and changed", 9.. = phase tag
 	u32* lu_rgb;    // colour maps only
 	MapRoot* root;

@@ -346,16 +346,16 @@ int allocTable(ufomap_map* m, u32 cap, Table* out, TableBufs* tb)
 {
 	HIP_TRY(tb->blk.reserve((size_t)cap * sizeof(Block)));
 	HIP_TRY(tb->tmax.reserve((size_t)cap * 8));
-	HIP_TRY(tb->luocc.reserve((size_t)cap * 32));
-	HIP_TRY(tb->lufl.reserve((size_t)cap * 32));
+	HIP_TRY(tb->luocc.reserve((size_t)cap * 4));
+	HIP_TRY(tb->lufl.reserve((size_t)cap * 4));
 	if (m->g.color) {
 		HIP_TRY(tb->rgb.reserve((size_t)cap * 32));
-		HIP_TRY(tb->lurgb.reserve((size_t)cap * 32));
+		HIP_TRY(tb->lurgb.reserve((size_t)cap * 4));
 	}
 	// an empty slot is all zeros: key 0, flags 0, stamp 0 (values and parent are written when a block is created)
 	HIP_TRY(hipMemsetAsync(tb->blk.p, 0, (size_t)cap * sizeof(Block), m->stream));
 	HIP_TRY(hipMemsetAsync(tb->tmax.p, 0, (size_t)cap * 8, m->stream));
-	HIP_TRY(hipMemsetAsync(tb->lufl.p, 0, (size_t)cap * 32, m->stream));
+	HIP_TRY(hipMemsetAsync(tb->lufl.p, 0, (size_t)cap * 4, m->stream));
 	out->blk = tb->blk.as<Block>();
 	out->rgb = m->g.color ? tb->rgb.as<u32>() : nullptr;
 	out->tmax = tb->tmax.as<u64>();
@@ -1913,7 +1913,7 @@ int ufomap_map_clear(ufomap_map* m)
 	u32 cap = m->t.mask + 1;
 	HIP_TRY(hipMemsetAsync(m->t.blk, 0, (size_t)cap * sizeof(Block), m->stream));
 	HIP_TRY(hipMemsetAsync(m->t.tmax, 0, (size_t)cap * 8, m->stream));
-	HIP_TRY(hipMemsetAsync(m->t.lu_fl, 0, (size_t)cap * 32, m->stream));
+	HIP_TRY(hipMemsetAsync(m->t.lu_fl, 0, (size_t)cap * 4, m->stream));
 	return resetRoot(m);
 }
 
@@ -2627,7 +2627,7 @@ int ufomap_map_stats(ufomap_map* m, uint64_t* n_inner, uint64_t* n_leaf, uint64_
 	if (n_leaf) *n_leaf = h.n_live ? h.n_leaf : 1;
 	if (bytes) {
 		u64 cap = (u64)m->t.mask + 1;
-		*bytes = cap * (sizeof(Block) + 8 + 64 + (m->g.color ? 96 : 0));
+		*bytes = cap * (sizeof(Block) + 8 + 8 + (m->g.color ? 32 + 4 : 0));  // record + tmax + last-update record (+ colours)
 	}
 	return UFOMAP_OK;
 }
