@@ -359,7 +359,7 @@ def main():
             "roofline": roof, "self_check": self_check,
             "memory": {"table_bytes": mem_stats["bytes"], "live_blocks": mem_stats["inner_nodes"], "leaves": mem_stats["leaf_nodes"],
                        "bytes_per_live_block": mem_stats["bytes_per_block"],
-                       "note": "node table as allocated (64 B block record + 72 B per-phase words per slot, load <= 0.6) after the headline leg's last repetition"},
+                       "note": "node table as allocated (64 B block record + 16 B per-phase words per slot, load <= 0.6, sized for three pipelined scans' worst case) after the headline leg's last repetition"},
         }
         out.update(extra)
         if dt_ev:

@@ -1027,6 +1027,28 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 // The kernel's duration is its longest chain of dependent instructions (a lone workgroup hides nothing), so the code
 // below counts instructions, not bytes.
 // ------------------------------------------------------------------------------------------------
+// one level of the dense grids above the tiles, computed from the tile grid (the same numbers makeUpperGeo tabulates on
+// the host: no table look-ups in the kernel -- scalar loads of the kernel arguments cost ~200 cycles each there)
+struct UpperLevel {
+	i32 lo[3];
+	u32 n[3];
+};
+__device__ inline UpperLevel upperLevel(const FastGeo& fg, u32 l)
+{
+	UpperLevel u;
+	const u32 sh = l - 3u;
+	for (int a = 0; a < 3; ++a) {
+		u.lo[a] = fg.tbase[a] >> sh;
+		u.n[a] = (u32)(((fg.tbase[a] + (i32)fg.nt[a] - 1) >> sh) - u.lo[a] + 1);
+	}
+	return u;
+}
+__device__ inline u32 upperCellAt(const UpperLevel& u, u32 off, const i32 c[3])
+{
+	const u32 x = (u32)(c[0] - u.lo[0]), y = (u32)(c[1] - u.lo[1]), z = (u32)(c[2] - u.lo[2]);  // (negative: huge)
+	const bool inside = (x < u.n[0]) & (y < u.n[1]) & (z < u.n[2]);
+	return inside ? off + x + u.n[0] * (y + u.n[1] * z) : 0xFFFFFFFFu;
+}
 #define UFO_FTAIL_THREADS 1024
 static_assert(UFO_FTAIL_THREADS == UFO_UPPER_MAX, "k_ftail: one thread per cell of the dense grids above the tiles");
 __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g, FastGeo fg, UpperGeo ugp, u32* __restrict__ tile_bits,
@@ -1039,7 +1061,6 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 	// This lone workgroup shares its CU with waves of the next scan's ray kernel and of k_tile; its time is its chain of
 	// dependent instructions, so its waves take issue priority over theirs (measured: 35 -> 27 us when overlapped).
 	__builtin_amdgcn_s_setprio(3);
-	__shared__ UpperGeo ug;
 	__shared__ u32 tbits[UFO_FAST_MAX_TILES / 32], ubits[UFO_UPPER_MAX / 32], uprefix[UFO_UPPER_MAX / 32 + 1];
 	__shared__ u64 nk[UFO_UPPER_MAX];
 	__shared__ unsigned long long top64[UFO_UPPER_MAX];  // (1 + child index of the highest touched child) << 32 | who it is (tile or node)
@@ -1078,12 +1099,14 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 	const u32 L = g.L;
 	const u32 lane = threadIdx.x & 63u;
 	for (u32 j = threadIdx.x; j < (UFO_FTAIL_THREADS / 64) * (UFO_UPPER_MAX / 32); j += blockDim.x) (&wbits[0][0])[j] = 0;
-	if (threadIdx.x >= 64u && threadIdx.x < 64u + sizeof(UpperGeo) / 4u) reinterpret_cast<u32*>(&ug)[threadIdx.x - 64u] = reinterpret_cast<const u32*>(&ugp)[threadIdx.x - 64u];
+	(void)ugp;
 	if (threadIdx.x < 26u) lvl_dirty[threadIdx.x] = 0;
 	if (0 == threadIdx.x) created_total = 0;
 	__syncthreads();
 	if (0 == threadIdx.x) ctl->dbg[11] = wall_clock64();  // (diagnostics: ufomap_map_debug)
 	// ---- 1. the active cells become the node list ----
+	const UpperLevel u4 = upperLevel(fg, 4u);
+	const u32 n4all = u4.n[0] * u4.n[1] * u4.n[2];  // cells of level 4 = first cell of level 5
 	constexpr u32 MAXT = UFO_FAST_MAX_TILES / UFO_FTAIL_THREADS;  // tiles per thread: tile = k * blockDim + thread
 	u32 cell4[MAXT];  // the level-4 parent's cell of the thread's tiles (NONE: tile not active)
 	// (two phases, no atomic whose result anybody waits for: a walk "up until somebody else has been here" is a chain of
@@ -1098,7 +1121,7 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 		const i32 lim = (i32)(1u << (L - 3u));
 		if (c[0] < 0 || c[1] < 0 || c[2] < 0 || c[0] >= lim || c[1] >= lim || c[2] >= lim) continue;  // (outside the key range: k_tile skipped it, too)
 		const i32 pc[3] = {c[0] >> 1, c[1] >> 1, c[2] >> 1};
-		const u32 cell = upperCell(ugp, 4, pc);  // (geometry with a uniform index: scalar loads from the kernel arguments)
+		const u32 cell = upperCellAt(u4, 0u, pc);
 		if (cell >= UFO_UPPER_MAX) continue;
 		cell4[k] = cell;
 		__hip_atomic_fetch_or(&wbits[threadIdx.x >> 6][cell >> 5], 1u << (cell & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1108,19 +1131,22 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 	{
 		// every active level-4 cell marks its ancestors, level 5 .. L
 		const u32 cell = threadIdx.x;
-		const u32 n4 = min(ugp.off[5], UFO_UPPER_MAX);
+		const u32 n4 = min(n4all, UFO_UPPER_MAX);
 		u32 seen = 0;
 		if (cell < n4)
 			for (u32 w = 0; w < UFO_FTAIL_THREADS / 64; ++w) seen |= wbits[w][cell >> 5];
 		if ((seen >> (cell & 31u)) & 1u) {
-			const u32 x = cell % ugp.n[4][0], r = cell / ugp.n[4][0];
-			i32 c[3] = {ugp.lo[4][0] + (i32)x, ugp.lo[4][1] + (i32)(r % ugp.n[4][1]), ugp.lo[4][2] + (i32)(r / ugp.n[4][1])};
-			for (u32 l = 5; l <= L; ++l) {
+			const u32 x = cell % u4.n[0], r = cell / u4.n[0];
+			i32 c[3] = {u4.lo[0] + (i32)x, u4.lo[1] + (i32)(r % u4.n[1]), u4.lo[2] + (i32)(r / u4.n[1])};
+			u32 off = n4all;
+			for (u32 l = 5; l <= L; ++l) {  // (uniform: the level's geometry is scalar arithmetic)
+				const UpperLevel ul = upperLevel(fg, l);
 				c[0] >>= 1;
 				c[1] >>= 1;
 				c[2] >>= 1;
-				const u32 up = upperCell(ugp, l, c);  // (uniform level: scalar loads; measured faster than the LDS copy, 2.8 vs 4.3 us)
+				const u32 up = upperCellAt(ul, off, c);
 				if (up < UFO_UPPER_MAX) __hip_atomic_fetch_or(&wbits[threadIdx.x >> 6][up >> 5], 1u << (up & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				off += ul.n[0] * ul.n[1] * ul.n[2];
 			}
 		}
 	}
@@ -1149,12 +1175,26 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 		if (!((w >> b) & 1u)) return NONE;
 		return uprefix[cell >> 5] + (u32)__popc(w & ((1u << b) - 1u));
 	};
-	if (threadIdx.x <= L + 1u && threadIdx.x >= 4u) {
-		// nodes of level l are [lstart[l], lstart[l+1]): the cells below off[l] that are active
-		const u32 c0 = min(ug.off[threadIdx.x], UFO_UPPER_MAX);  // (divergent index: the LDS copy)
-		lstart[threadIdx.x] = uprefix[c0 >> 5] + ((c0 & 31u) ? (u32)__popc(ubits[c0 >> 5] & ((1u << (c0 & 31u)) - 1u)) : 0u);
+	// first cell of every level (off[l]; off[L+1] = number of cells), by every thread: a uniform loop of scalar arithmetic
+	u32 my_l = 4, my_off = 0, ncells = 0;
+	{
+		u32 off = 0;
+		for (u32 k = 4; k <= L; ++k) {
+			const UpperLevel uk = upperLevel(fg, k);
+			if (threadIdx.x >= off) {  // (the level whose range holds this thread's cell is the last one that starts at or below it)
+				my_l = k;
+				my_off = off;
+			}
+			if (threadIdx.x == k) {
+				// nodes of level l are [lstart[l], lstart[l+1]): the cells below off[l] that are active
+				const u32 c0 = min(off, UFO_UPPER_MAX);
+				lstart[k] = uprefix[c0 >> 5] + ((c0 & 31u) ? (u32)__popc(ubits[c0 >> 5] & ((1u << (c0 & 31u)) - 1u)) : 0u);
+			}
+			off += uk.n[0] * uk.n[1] * uk.n[2];
+		}
+		ncells = min(off, UFO_UPPER_MAX);
+		if (threadIdx.x == L + 1u) lstart[L + 1u] = uprefix[ncells >> 5] + ((ncells & 31u) ? (u32)__popc(ubits[ncells >> 5] & ((1u << (ncells & 31u)) - 1u)) : 0u);
 	}
-	const u32 ncells = min(ugp.off[L + 1], UFO_UPPER_MAX);
 	const u32 max_probe = (t.mask >> 1) + 1;
 	u32 n_created = 0;
 	// ---- 2. one thread per active cell: the node's key, parent, block (found or created, loaded) ----
@@ -1162,17 +1202,17 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 		const u32 cell = threadIdx.x;  // (UFO_UPPER_MAX == blockDim.x)
 		const u32 id = cell < ncells ? idOf(cell) : NONE;
 		if (id != NONE) {
-			u32 l = 4;
-			for (u32 k = 5; k <= L; ++k) l += (cell >= ug.off[k]) ? 1u : 0u;  // (levels are consecutive ranges of cells)
-			const u32 c = cell - ug.off[l];
-			const u32 x = c % ug.n[l][0], r = c / ug.n[l][0];
-			const i32 ac[3] = {ug.lo[l][0] + (i32)x, ug.lo[l][1] + (i32)(r % ug.n[l][1]), ug.lo[l][2] + (i32)(r / ug.n[l][1])};
+			const u32 l = my_l;
+			const UpperLevel ul = upperLevel(fg, l);  // (per-thread level: vector arithmetic)
+			const u32 c = cell - my_off;
+			const u32 x = c % ul.n[0], r = c / ul.n[0];
+			const i32 ac[3] = {ul.lo[0] + (i32)x, ul.lo[1] + (i32)(r % ul.n[1]), ul.lo[2] + (i32)(r / ul.n[1])};
 			const u64 lk = (1ULL << (3 * (L - l))) | morton3((u32)ac[0], (u32)ac[1], (u32)ac[2]);
 			nk[id] = lk;
 			u32 par = NONE;
 			if (l < L) {
 				const i32 pc[3] = {ac[0] >> 1, ac[1] >> 1, ac[2] >> 1};
-				par = idOf(upperCell(ug, l + 1, pc));
+				par = idOf(upperCellAt(upperLevel(fg, l + 1u), my_off + ul.n[0] * ul.n[1] * ul.n[2], pc));
 			}
 			npar[id] = par;
 			bool cr;
