@@ -1467,9 +1467,19 @@ __global__ void k_signal(unsigned long long* flag, unsigned long long value)
 {
 	__hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
-__global__ void k_gate(const unsigned long long* flag, unsigned long long value)
+// (The wait is bounded: a tool that serialises kernels across streams -- rocprofv3 --pmc does -- would keep the producer
+// from ever running while this wave spins. The host does not use gates when it sees such a tool, ufomap_hip.hip:
+// useGates; should one slip through, the gate gives up after ~2 s and flags the scan, which then leaves the map alone.)
+__global__ void k_gate(const unsigned long long* flag, unsigned long long value, ScanCtl* ctl)
 {
-	while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < value) __builtin_amdgcn_s_sleep(1);
+	const unsigned long long t0 = wall_clock64();
+	while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < value) {
+		__builtin_amdgcn_s_sleep(1);
+		if (wall_clock64() - t0 > 200000000ull) {  // 100 MHz clock
+			atomicOr(&ctl->err, ERR_GATE);
+			return;
+		}
+	}
 }
 
 // Stage-level output of a fast-path scan (ufomap_map_last_hits): the hit voxels' codes from the per-tile hit masks.

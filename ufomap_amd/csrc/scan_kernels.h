@@ -23,6 +23,7 @@ enum : u32 {
 	ERR_TABLE_FULL = 4u,  // node table full
 	ERR_HASH_FULL = 8u,   // hit hash full (should not happen: sized 4x points)
 	ERR_ENTRIES = 16u,    // update list larger than the buffer the host guessed: host retries with the exact size
+	ERR_GATE = 128u,      // a stream hand-over (fast_kernels.h: k_gate) timed out: kernels serialised by a tool? the scan left the map alone
 	ERR_NOT_STORED = 0x40000000u,  // (host side only: the pinned result block of a fast-path update has not been written)
 	ERR_PREV = 64u,       // the integration enqueued just before this one flagged an error: this one stands back, the host re-runs both in order
 	ERR_SPEC = 32u,       // the scan was launched on a grid predicted from the previous scan and does not fit it: the host repeats it

@@ -216,6 +216,8 @@ struct ufomap_map {
 	uint64_t seq = 0, latest_seq = 0;  // seq: of the integration that uses the current set; latest_seq: of the newest one enqueued
 	FastGeo fgeo{};
 	int opt_fast = 1;  // 0 = never take the fast path (fast_kernels.h)
+	int opt_gates = 1;        // 0 = events instead of gate kernels between the streams of the steady-state path
+	bool gates = false;       // ... as decided for the scan being enqueued
 	int opt_sparse_set = 0;   // 1 = every scan's ray cells through the sparse set (Grid::layout 2), whatever its box needs
 	int opt_cast_global = 1;  // 0 = grids beyond LDS go through k_dda_seg / k_dda (byte-per-block grid) instead of k_cast<true>
 	u64 host_ns[4] = {0, 0, 0, 0};  // diagnostics: host time inside doInsert -- scan half enqueue, map half enqueue, join, total
@@ -482,6 +484,22 @@ void swapWith(ufomap_map* m, HandOver& o)
 }
 
 int finishSet(ufomap_map* m, int k);
+
+// Stream-to-stream hand-overs of the steady-state path are spinning one-wave kernels (k_gate) unless something is known
+// to serialise kernels across streams -- then a gate would wait for a producer that is not allowed to run: counter
+// collection of rocprofv3 (--pmc), rocprof v1/v2 (HSA_TOOLS_LIB), AMD_SERIALIZE_KERNEL, HIP_LAUNCH_BLOCKING. Events then.
+bool useGates(const ufomap_map* m)
+{
+	static const bool env_ok = [] {
+		auto on = [](const char* k) {
+			const char* v = getenv(k);
+			return v && *v && 0 != strcmp(v, "0");
+		};
+		return !(on("ROCPROF_COUNTER_COLLECTION") || getenv("ROCPROF_COUNTERS") || getenv("HSA_TOOLS_LIB") || on("AMD_SERIALIZE_KERNEL") ||
+		         on("HIP_LAUNCH_BLOCKING") || on("UFOMAP_NO_GATES"));
+	}();
+	return env_ok && 0 != m->opt_gates;
+}
 extern "C" int ufomap_map_wait(ufomap_map* m);
 
 // Phase numbers (ufomap_map::scan_id) tag "created / reached / timed in this phase" in the table: 24 bits in tmax, 22 in
@@ -573,6 +591,8 @@ int ctlError(ufomap_map* m)
 		return fail(UFOMAP_ERR_RUNAWAY,
 		            "a clipped ray left the map cube (end point outside after moveLineInside); the reference walks ~2^31 "
 		            "cells on this input. Map unchanged.");
+	if (e & ERR_GATE)
+		return fail(UFOMAP_ERR_DEVICE, "a stream hand-over timed out (are kernels being serialised across streams by a tool? set UFOMAP_NO_GATES=1); map unchanged");
 	if (e & ERR_TABLE_FULL) {
 		// blocks created before the table ran full are linked into the tree with unset contents: the handle refuses
 		// further work until ufomap_map_clear
@@ -1019,9 +1039,15 @@ int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, si
 			                   m->b_part1.as<BoxPartial>(), ctl, m->ing, m->b_hit_code.as<PointRec>());
 	}
 	// stream-to-stream hand-overs of this path: k_signal / k_gate (fast_kernels.h), not events
-	hipLaunchKernelGGL(k_signal, dim3(1), dim3(1), 0, m->pstream, m->sig_prep, (unsigned long long)m->seq);
+	m->gates = useGates(m);
+	if (m->gates) {
+		hipLaunchKernelGGL(k_signal, dim3(1), dim3(1), 0, m->pstream, m->sig_prep, (unsigned long long)m->seq);
+		hipLaunchKernelGGL(k_gate, dim3(1), dim3(1), 0, m->sstream, m->sig_prep, (unsigned long long)m->seq, ctl);
+	} else {
+		HIP_TRY(hipEventRecord(m->prep_ev, m->pstream));
+		HIP_TRY(hipStreamWaitEvent(m->sstream, m->prep_ev, 0));
+	}
 	m->cs = m->sstream;
-	hipLaunchKernelGGL(k_gate, dim3(1), dim3(1), 0, m->sstream, m->sig_prep, (unsigned long long)m->seq);
 	u32 nwg = m->opt_cast_wgs > 0 ? (u32)m->opt_cast_wgs : 256u;
 	nwg = std::max<u32>(1u, std::min<u32>(nwg, (N + 63u) / 64u));
 	const u32 cap_wg = (N + nwg - 1) / nwg;
@@ -1044,7 +1070,7 @@ int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, si
 		hipLaunchKernelGGL(k_fmerge, dim3(std::min<u32>((n4 + 63) / 64, 1024) + 1u), dim3(1024), 0, m->cs, fg, m->b_slabs.as<uint4>(), nwg, n4,
 		                   m->b_gridM.as<uint4>(), sp, m->b_tilebits.as<u32>(), m->b_part1.as<BoxPartial>(), gp.x, ctl);
 	}
-	hipLaunchKernelGGL(k_signal, dim3(1), dim3(1), 0, m->sstream, m->sig_scan, (unsigned long long)m->seq);
+	if (m->gates) hipLaunchKernelGGL(k_signal, dim3(1), dim3(1), 0, m->sstream, m->sig_scan, (unsigned long long)m->seq);
 	HIP_TRY(hipGetLastError());
 	++m->n_fast;
 	return UFOMAP_OK;
@@ -1595,11 +1621,12 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 	auto mapHalf = [&](const ScanCtl* prev, u64 extra_used, u32 headroom) {
 		return fast ? fastMapPhase(m, prev, extra_used, headroom) : mapPhase(m, depth, d_rgb, capH, capM, merged, prev, extra_used, headroom);
 	};
-	if (!rc && n && !fast) rc = (hipEventRecord(m->scan_ev, m->sstream) == hipSuccess) ? UFOMAP_OK : fail(UFOMAP_ERR_DEVICE, "hipEventRecord");
+	const bool gated = fast && m->gates;  // the hand-over to the map stream is a signal word, not an event
+	if (!rc && n && !gated) rc = (hipEventRecord(m->scan_ev, m->sstream) == hipSuccess) ? UFOMAP_OK : fail(UFOMAP_ERR_DEVICE, "hipEventRecord");
 	// the map stream waits for this scan's scan half (fast path: its signal word; general path: the event)
 	auto waitScanHalf = [&]() -> hipError_t {
-		if (!fast) return hipStreamWaitEvent(m->stream, m->scan_ev, 0);
-		hipLaunchKernelGGL(k_gate, dim3(1), dim3(1), 0, m->stream, m->sig_scan, (unsigned long long)m->seq);
+		if (!gated) return hipStreamWaitEvent(m->stream, m->scan_ev, 0);
+		hipLaunchKernelGGL(k_gate, dim3(1), dim3(1), 0, m->stream, m->sig_scan, (unsigned long long)m->seq, m->b_ctl.as<ScanCtl>());
 		return hipSuccess;
 	};
 	// ... and its end is announced by k_ftail's word in pinned memory (fast path) or by the set's event
@@ -3744,6 +3771,8 @@ int ufomap_map_set_option(ufomap_map* m, const char* key, long long value)
 		m->opt_fast = (int)value;
 	} else if (0 == strcmp(key, "async_apply")) {
 		m->opt_async_apply = value ? 1 : 0;
+	} else if (0 == strcmp(key, "gates")) {
+		m->opt_gates = value ? 1 : 0;
 	} else if (0 == strcmp(key, "sparse_set")) {
 		m->opt_sparse_set = value ? 1 : 0;
 	} else if (0 == strcmp(key, "phase_limit")) {
