@@ -1,17 +1,18 @@
 // fast_kernels.h -- the steady-state pipeline of a depth-0 scan whose ray grid fits in LDS (every LiDAR-sized scan):
 //
-//   scan stream   k_fhits   k_fcast   k_merge_slabs                    (never touch the map)
-//   map stream                                       k_tile   k_ftail  (the whole tree update)
+//   prep stream   k_fhits  (k_signal)                                              (needs only the cloud)
+//   scan stream            (k_gate) k_fcast   k_fmerge  (k_signal)                 (never touch the map)
+//   map stream                                          (k_gate) k_tile   k_ftail  (the whole tree update)
 //
-// five launches per scan where the general path (scan_kernels.h / map_kernels.h: classify, select, reduce_boxes, hitmark,
-// cast, merge_slabs, extract x2, ensure, init_new, apply_leaf, propagate x2, propagate_tail) needs fourteen. What makes
-// that possible:
+// five working launches per scan (plus the one-thread hand-over kernels between the streams) where the general path
+// (scan_kernels.h / map_kernels.h: classify, select, reduce_boxes, hitmark, cast, merge_slabs, extract x2, ensure,
+// init_new, apply_leaf, propagate x2, propagate_tail) needs fourteen. What makes that possible:
 //   * the scan runs on the ray grid PREDICTED from the previous scans (ufomap_hip.hip: predictGrid), so every array of
 //     the scan has a dense, known geometry: "first point in a voxel wins" (CodeSet `indices_`, occupancy_map_base.h:295,
 //     358-360) is one atomicMin on a dense u32 array over the grid's cells instead of a hash insert, and nothing has to
 //     be compacted into lists between kernels;
-//   * k_fcast re-derives a point's ray from the input cloud (the head loop is ~100 flops per point) instead of reading a
-//     ray list that a separate compaction kernel wrote;
+//   * k_fcast takes a point's ray from the 32-byte record k_fhits left for it and drops the points that lost their voxel
+//     itself, instead of reading a ray list that a separate compaction kernel wrote;
 //   * the tree update is TILED: one wavefront owns one depth-3 node (8x8x8 voxels: 64 level-1 node blocks, 8 level-2
 //     blocks, 1 level-3 block) and does everything the reference's updateValue does beneath it -- createNode with
 //     inheritance, updateOccupancy for hits then misses, updateNode / pruning on the way up (occupancy_map_base.h:
@@ -26,7 +27,7 @@
 
 namespace ufo
 {
-// Geometry shared by the five kernels: the predicted bit grid (Grid::layout 1) and the depth-3 tiles that cover it.
+// Geometry shared by these kernels: the predicted bit grid (Grid::layout 1) and the depth-3 tiles that cover it.
 struct FastGeo {
 	Grid gr;
 	u32 rowBits, planeBits;  // bits per row of cells (x), per plane (x, y): a cell's index is lx + ly*rowBits + lz*planeBits

@@ -2,14 +2,20 @@
 // scan_kernels.h / map_kernels.h. gfx950 only; build: see ufomap_amd/build.py
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared
 //
-// Launch sequence of one depth-0 integration in the steady state (doInsert):
+// Launch sequence of one depth-0 integration in the steady state (doInsert; fast_kernels.h):
+//   prep stream: [H2D of a host cloud] -> k_fhits -> k_signal
+//   scan stream: k_gate -> k_fcast -> k_fmerge -> k_signal
+//   map stream:  k_gate -> k_tile (looks at the predecessor's flags) -> k_ftail (stores the finished control block and
+//                the scan's number into pinned host memory)
+//   join (of the integration before the previous one): the host polls that word; no copy, no stream synchronisation
+// First scans, colour maps, insert depth > 0, grids beyond LDS (the general path):
 //   scan stream: memset hit hash -> control block H2D -> k_classify -> k_select -> k_reduce_boxes (checks the
-//                predicted ray grid) -> k_hitmark -> k_cast -> k_merge_slabs -> k_extract_bits -> k_extract_hits
-//   map stream:  [waits for the scan] k_ensure (gates on the predecessor's flags) -> k_init_new -> k_apply_leaf ->
-//                k_propagate x wide levels -> k_propagate_tail
-//   join (of the PREVIOUS integration): event wait -> one control-block D2H on the read-back stream
-// Other grid sizes / insert depths: the boxes are read back after k_select (scanPhase), larger grids use
-// k_ray_setup + k_walk / k_dda_seg / k_dda, insert depth > 0 adds the k_coarse_* phase and walks the tree twice.
+//                predicted ray grid) -> k_hitmark -> k_cast<0|2> -> [k_merge_slabs] -> k_extract_bits -> k_extract_hits
+//   map stream:  [waits for the scan's event] k_ensure -> k_init_new -> k_apply_leaf -> k_propagate x wide levels ->
+//                k_propagate_tail; join: event wait -> one control-block D2H on the read-back stream
+// Without a predicted grid the boxes are read back after k_select (scanPhase); grids of > 1023 cells per axis and
+// simple ray casting use k_dda, boxes beyond the scratch limit k_dda_set; insert depth > 0 adds the k_coarse_* phase
+// and walks the tree twice.
 // There is no CPU fallback: every entry point fails with UFOMAP_ERR_DEVICE when HIP is unusable.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
