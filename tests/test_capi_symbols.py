@@ -78,3 +78,30 @@ def test_product_code_does_not_touch_the_oracle():
             if "ufo_oracle" in open(os.path.join(base, f), errors="ignore").read():
                 offenders.append(os.path.join(base, f))
     assert offenders == []
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/ufomap_hip.h is the drop-in boundary: it must compile as C99 (plain pointers and sizes, no C++), and a C
+    host of the multi-GPU batch entry must compile and link against the library."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "host.c"
+    src.write_text(
+        '#include <stdio.h>\n#include "ufomap_hip.h"\n'
+        "int main(void) {\n"
+        "  uint8_t id[UFOMAP_COMM_ID_BYTES];\n"
+        "  ufomap_keys_info k; k.n_hit = 0;\n"
+        "  if (ufomap_device_count() <= 0) { printf(\"no device: %s\\n\", ufomap_last_error()); return 0; }\n"
+        "  if (ufomap_comm_unique_id(id)) return 2;\n"
+        "  ufomap_comm* c = ufomap_comm_create(id, 1, 0, 0);\n"
+        "  ufomap_map* m = ufomap_map_create(0.16, 16, 1, 0.5, 0.5, 0.7, 0.4, 0.1192, 0.971, 0, 0);\n"
+        "  double o[3] = {0, 0, 0};\n"
+        "  int rc = (c && m) ? ufomap_map_insert_batch(m, c, o, 0, 0, 0, 20.0, 0, 1) : 3;\n"
+        "  ufomap_map_destroy(m); ufomap_comm_destroy(c); (void)k; return rc;\n}\n")
+    exe = tmp_path / "host"
+    lib_dir = os.path.join(root, "ufomap_amd", "csrc")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"), str(src), "-o", str(exe),
+                    "-L", lib_dir, "-l:libufomap_hip.so", "-Wl,-rpath," + lib_dir], check=True)
+    # (without a GPU the program reports that and exits 0; with one it runs a world-1 batch step)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
