@@ -74,6 +74,17 @@ __host__ __device__ inline u64 spread3(u32 a)
 	c = (c | c << 2) & 0x1249249249249249ULL;
 	return c;
 }
+// inverse of spread3: every third bit -> 21 bits
+__host__ __device__ inline u32 compact3(u64 c)
+{
+	c &= 0x1249249249249249ULL;
+	c = (c | c >> 2) & 0x10c30c30c30c30c3ULL;
+	c = (c | c >> 4) & 0x100f00f00f00f00fULL;
+	c = (c | c >> 8) & 0x1f0000ff0000ffULL;
+	c = (c | c >> 16) & 0x1f00000000ffffULL;
+	c = (c | c >> 32) & 0x1fffffULL;
+	return (u32)c;
+}
 // map/code.h:183-192: x -> bits 0,3,6.., y -> 1,4,7.., z -> 2,5,8..
 __host__ __device__ inline u64 morton3(u32 x, u32 y, u32 z) { return spread3(x) | (spread3(y) << 1) | (spread3(z) << 2); }
 

@@ -356,6 +356,50 @@ __global__ __launch_bounds__(256) void k_count_missing(Table t, const Entry* __r
 	if (__lane_id() == 0 && miss) atomicAdd(out, miss);
 }
 
+// How many level-2 and level-3 blocks the missing level-1 entries can make new: the distinct missing parents /
+// grandparents, counted through bitmaps over the scan's box (level-1 block coordinates b0 .. b0 + nb - 1). The a-priori
+// bound takes min(entries, cells of the box) per level, which for a surface scanned at 2 mm is 8x too many at level 2
+// (49 M entries, 6 M distinct parents) and makes the table twice as large as it has to be.
+struct ParentBox {
+	i32 lo2[3], lo3[3];  // first level-2 / level-3 block coordinate of the box
+	u32 n2[3], n3[3];
+};
+__global__ __launch_bounds__(256) void k_mark_parents(Table t, MapGeom g, const Entry* __restrict__ entries, const u32* n_entries_p, u32 cap,
+                                                      ParentBox pb, u32* __restrict__ bits2, u32* __restrict__ bits3)
+{
+	const u32 n = min(*n_entries_p, cap);
+	for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		const u64 lk = entries[i].lk;
+		const u32 s = tableFind(t, lk);
+		if (s != NONE && !(t.flags(s) & F_DEAD)) continue;  // the block is there: so are its ancestors
+		const u64 p = lk ^ (1ULL << (3 * (g.L - 1)));
+		const i32 x = (i32)compact3(p), y = (i32)compact3(p >> 1), z = (i32)compact3(p >> 2);
+		const u32 s2 = tableFind(t, lk >> 3);
+		if (s2 == NONE || (t.flags(s2) & F_DEAD)) {
+			const u32 a = (u32)((x >> 1) - pb.lo2[0]), b = (u32)((y >> 1) - pb.lo2[1]), c = (u32)((z >> 1) - pb.lo2[2]);
+			if (a < pb.n2[0] && b < pb.n2[1] && c < pb.n2[2]) {
+				const u64 idx = ((u64)c * pb.n2[1] + b) * pb.n2[0] + a;
+				atomicOr(&bits2[idx >> 5], 1u << (idx & 31u));
+			}
+			const u32 s3 = tableFind(t, lk >> 6);
+			if (s3 == NONE || (t.flags(s3) & F_DEAD)) {
+				const u32 a3 = (u32)((x >> 2) - pb.lo3[0]), b3 = (u32)((y >> 2) - pb.lo3[1]), c3 = (u32)((z >> 2) - pb.lo3[2]);
+				if (a3 < pb.n3[0] && b3 < pb.n3[1] && c3 < pb.n3[2]) {
+					const u64 idx = ((u64)c3 * pb.n3[1] + b3) * pb.n3[0] + a3;
+					atomicOr(&bits3[idx >> 5], 1u << (idx & 31u));
+				}
+			}
+		}
+	}
+}
+__global__ __launch_bounds__(256) void k_popcount(const u32* __restrict__ bits, u64 nwords, unsigned long long* __restrict__ out)
+{
+	unsigned long long c = 0;
+	for (u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x; w < nwords; w += (u64)gridDim.x * blockDim.x) c += (unsigned long long)__popc(bits[w]);
+	for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+	if (__lane_id() == 0 && c) atomicAdd(out, c);
+}
+
 // S2 init: children of a new block inherit the whole value of the node (createChildren,
 // octree.h:1044-1054). The node's value is found in the first ancestor block that is not new.
 __global__ __launch_bounds__(256) void k_init_new(Table t, MapGeom g, const u32* __restrict__ newlist, u32 newcap,

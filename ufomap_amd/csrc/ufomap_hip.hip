@@ -833,6 +833,42 @@ int sizeTable(ufomap_map* m, const Entry* ent_h, u64 capH, const i32 nbH[3], con
 				m->scan_new_bound = h_in_m ? blockBound(m, cnt[0], nbM, 1) : bound(capH ? cnt[0] : 0, capM ? cnt[0] : 0);
 		} else if (m->h_ctl->n_entries[0] <= capH && m->h_ctl->n_entries[1] <= capM) m->scan_new_bound = bound(cnt[0], cnt[1]);
 		if ((m->used_est + extra_used + m->scan_new_bound) * 5 <= cap * 3) return UFOMAP_OK;
+		// Still growing, and by gigabytes: count the distinct missing parents and grandparents exactly (k_mark_parents)
+		// instead of bounding them by min(entries, cells of the box) -- a merged list inside one box only
+		if (merged && h_in_m && m->h_ctl->n_entries[0] <= capH + capM && cnt[0] > (1u << 20)) {
+			ParentBox pb;
+			u64 bits2 = 1, bits3 = 1;
+			for (int a = 0; a < 3; ++a) {
+				const long long b0 = (long long)(m->gridM.base[a] >> 1), b1 = b0 + m->gridM.nb[a] - 1;  // level-1 block coordinates of the box
+				pb.lo2[a] = (i32)(b0 >> 1);
+				pb.n2[a] = (u32)((b1 >> 1) - (b0 >> 1) + 1);
+				pb.lo3[a] = (i32)(b0 >> 2);
+				pb.n3[a] = (u32)((b1 >> 2) - (b0 >> 2) + 1);
+				bits2 *= pb.n2[a];
+				bits3 *= pb.n3[a];
+			}
+			if (bits2 <= (1ull << 32)) {  // (<= 512 MB of bitmap)
+				const u64 w2 = (bits2 + 31) / 32, w3 = (bits3 + 31) / 32;
+				DevBuf bm;
+				HIP_TRY(bm.reserve((w2 + w3) * 4 + 64));
+				HIP_TRY(hipMemsetAsync(bm.p, 0, (w2 + w3) * 4 + 64, m->cs));
+				u32* d2 = bm.as<u32>();
+				u32* d3 = d2 + w2;
+				unsigned long long* d_out = reinterpret_cast<unsigned long long*>(d3 + w3 + ((w2 + w3) & 1));
+				hipLaunchKernelGGL(k_mark_parents, gridFor(capH + capM), dim3(256), 0, m->cs, m->t, m->g, ent_h, &ctl->n_entries[0], (u32)(capH + capM), pb, d2,
+				                   d3);
+				hipLaunchKernelGGL(k_popcount, gridFor(w2, 256, 4096), dim3(256), 0, m->cs, d2, w2, d_out);
+				hipLaunchKernelGGL(k_popcount, gridFor(w3, 256, 4096), dim3(256), 0, m->cs, d3, w3, d_out + 1);
+				unsigned long long h_out[2] = {0, 0};
+				HIP_TRY(hipMemcpyAsync(h_out, d_out, 16, hipMemcpyDeviceToHost, m->cs));
+				HIP_TRY(hipStreamSynchronize(m->cs));
+				// level 1: the missing entries; level 2, 3: counted; above: no more than level 3 has, nor than fit in the box
+				u64 b = (u64)cnt[0] + h_out[0] + h_out[1] + 8;
+				for (u32 l = 4; l <= m->g.L; ++l) b += std::min<u64>(h_out[1], levelBound(nbM, l - 1));
+				m->scan_new_bound = std::min(m->scan_new_bound, b);
+				if ((m->used_est + extra_used + m->scan_new_bound) * 5 <= cap * 3) return UFOMAP_OK;
+			}
+		}
 	}
 	u64 want = (m->used_est + extra_used + m->scan_new_bound) * 2;
 	if (want > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
