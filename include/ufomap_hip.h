@@ -16,6 +16,11 @@
  * with it; results are identical either way.  Not thread-safe per handle (neither is the reference).
  *
  * There is NO CPU fallback behind this ABI: without a HIP device every call fails loudly.
+ *
+ * Environment: UFOMAP_NO_GATES=1 -- hand-overs between the handle's streams through HIP events instead of one-wave gate
+ * kernels (chosen automatically under tools that serialise kernels across streams: rocprofv3 --pmc, rocprof v1/v2,
+ * AMD_SERIALIZE_KERNEL, HIP_LAUNCH_BLOCKING); UFOMAP_RCCL_LIB -- name of the RCCL library for ufomap_comm_*;
+ * UFOMAP_MERGE_PHASES -- see ufomap_map_set_option. Results never depend on them.
  */
 #ifndef UFOMAP_HIP_H
 #define UFOMAP_HIP_H

@@ -8,8 +8,9 @@ for p in range(8):
     origin, xyz, _ = scans.lidar64(origin=scans.lidar_pose(p), seed=100 + p)
     clouds.append((origin, torch.from_numpy(xyz).cuda(), xyz.shape[0]))
 g = OccupancyMap(0.16)
-if len(sys.argv) > 1:
-    g.set_option("cast_wgs", int(sys.argv[1]))
+for kv in sys.argv[1:]:  # e.g. cast_wgs=248 cast_k=24
+    k, v = kv.split("=") if "=" in kv else ("cast_wgs", kv)
+    g.set_option(k, int(v))
 for rep in range(3):
     for i in range(48):
         o, d, n = clouds[i % 8]
