@@ -222,6 +222,7 @@ struct ufomap_map {
 	uint64_t seq = 0, latest_seq = 0;  // seq: of the integration that uses the current set; latest_seq: of the newest one enqueued
 	FastGeo fgeo{};
 	int opt_fast = 1;  // 0 = never take the fast path (fast_kernels.h)
+	int opt_tile_waves = 4;   // k_tile: tiles per workgroup
 	int opt_gates = 1;        // 0 = events instead of gate kernels between the streams of the steady-state path
 	bool gates = false;       // ... as decided for the scan being enqueued
 	int opt_sparse_set = 0;   // 1 = every scan's ray cells through the sparse set (Grid::layout 2), whatever its box needs
@@ -1147,7 +1148,8 @@ int fastMapPhase(ufomap_map* m, const ScanCtl* prev, u64 extra_used, u32 headroo
 	const float miss = (float)m->g.miss_log;  // insert depth 0 (OMB:311)
 	{
 		ProfScope ps(m, "k_tile");
-		hipLaunchKernelGGL(k_tile, dim3((fg.ntiles + 3) / 4), dim3(256), 0, m->cs, m->t, m->g, fg, m->b_gridM.as<u32>(), m->b_first.as<u32>(),
+		const u32 tw = (m->opt_tile_waves >= 1 && m->opt_tile_waves <= 4) ? (u32)m->opt_tile_waves : 4u;  // wavefronts (= tiles) per workgroup
+		hipLaunchKernelGGL(k_tile, dim3((fg.ntiles + tw - 1) / tw), dim3(64u * tw), 0, m->cs, m->t, m->g, fg, m->b_gridM.as<u32>(), m->b_first.as<u32>(),
 		                   m->b_tilebits.as<u32>(), m->b_tilerec.as<TileRec>(), m->g.hit, miss, m->scan_id, m->b_tilehm.as<uint8_t>(), ctl, prev);
 	}
 	{
@@ -3813,6 +3815,8 @@ int ufomap_map_set_option(ufomap_map* m, const char* key, long long value)
 		m->opt_fast = (int)value;
 	} else if (0 == strcmp(key, "async_apply")) {
 		m->opt_async_apply = value ? 1 : 0;
+	} else if (0 == strcmp(key, "tile_waves")) {
+		m->opt_tile_waves = (int)value;
 	} else if (0 == strcmp(key, "gates")) {
 		m->opt_gates = value ? 1 : 0;
 	} else if (0 == strcmp(key, "sparse_set")) {
