@@ -1,0 +1,150 @@
+"""Round 3 (run with -m gpu on an MI355X): ONE walk of the tree for a batch of scans (fast_kernels.h: k_tile / k_ftail
+over B scans) must leave exactly the map the reference leaves after integrating the scans one after the other
+(occupancy_map_base.h:340-417 called B times) -- values, flags, leaf structure under pruning, byte stream."""
+import numpy as np
+import pytest
+
+from conftest import same_dump
+
+pytestmark = pytest.mark.gpu
+
+
+def _kind():
+    import oracle
+    return "reference" if oracle.available("reference") else "port"
+
+
+def _maps(kind="port", **params):
+    from oracle import OracleMap
+    from ufomap_amd import OccupancyMap
+    return OccupancyMap(**params), OracleMap(kind=kind, **params)
+
+
+def _insert(g, origin, xyz, max_range, discrete, async_):
+    from ufomap_amd import PointCloud
+    (g.insertPointCloudDiscrete if discrete else g.insertPointCloud)(origin, PointCloud(xyz), max_range, 0, False, 0, async_)
+
+
+def _assert_same_map(g, o, what=""):
+    gl, ol = g.leaves(True), o.leaves(True)
+    assert len(gl[0]) == len(ol[0]), f"{what}: leaf count {len(gl[0])} vs oracle {len(ol[0])}"
+    assert np.array_equal(gl[0], ol[0]) and np.array_equal(gl[1], ol[1]), f"{what}: leaf codes/depths differ"
+    assert np.array_equal(gl[2], ol[2]), f"{what}: log-odds differ"
+    assert same_dump(g.inner(), o.inner()), f"{what}: inner-node dump differs"
+    assert g.write() == o.write(), f"{what}: map byte stream differs"
+
+
+def _sequence(n_scans, beams=32, azimuths=512, spread=1.0, seed0=300):
+    """A sensor that wanders about: the same voxels are hit, missed, saturate, collapse and are re-expanded again and again."""
+    from ufomap_amd import scans
+    base = np.array(scans.lidar_pose(0), dtype=np.float64)
+    rng = np.random.default_rng(seed0)
+    out = []
+    for i in range(n_scans):
+        off = rng.uniform(-spread, spread, 3) * [1, 1, 0.1]
+        out.append(scans.lidar64(beams=beams, azimuths=azimuths, origin=tuple(base + off), seed=seed0 + i)[:2])
+    return out
+
+
+@pytest.mark.parametrize("batch_max,discrete", [(2, True), (4, True), (16, True), (3, False), (8, False)])
+def test_batched_walks_equal_sequential(batch_max, discrete):
+    """Pipelined scans whose tree updates are held back until `batch_max` of them share a walk (option defer = 1: whatever the
+    map stream is doing) against the reference integrating them one by one -- compared after every few batches and at the end."""
+    seq = _sequence(26)
+    g, o = _maps(kind=_kind() if batch_max != 4 else "port", resolution=0.16)
+    g.set_option("batch_max", batch_max)
+    g.set_option("defer", 1)
+    for i, (origin, xyz) in enumerate(seq):
+        _insert(g, origin, xyz, 12.0, discrete, True)
+        o.insert(origin, xyz, max_range=12.0, discrete=discrete)
+        if i in (9, 17):
+            g.insertPointCloudWait()
+            _assert_same_map(g, o, f"after scan {i}")
+            if o.kind == "port":  # (stage outputs -- the last scan's hit / miss codes -- are provided by the port only)
+                assert np.array_equal(g.last_hits(), o.last_hits()) and np.array_equal(g.last_misses(), o.last_misses())
+    g.insertPointCloudWait()
+    _assert_same_map(g, o, "final")
+    d = g.debug()
+    assert d[61] >= 20, "the scans did not take the fast path"
+    assert d[59] == d[61], "every fast-path scan belongs to exactly one walk"
+    assert d[60] < d[59], f"no walk took more than one scan ({d[60]} walks, {d[59]} scans)"
+    assert d[60] <= (d[59] + batch_max - 1) // batch_max + 8, f"walks are smaller than asked for ({d[60]} walks, {d[59]} scans, batch_max {batch_max})"
+
+
+def test_batched_walk_saturation_and_pruning():
+    """The same scan over and over from two alternating poses: voxels saturate, whole subtrees collapse, are re-expanded by the
+    next scan and collapse again -- inside ONE walk (the collapse of scan b is undone by scan b + 1 on the register copy)."""
+    from ufomap_amd import scans
+    g, o = _maps(kind=_kind(), resolution=0.16)
+    g.set_option("batch_max", 8)
+    g.set_option("defer", 1)
+    poses = [scans.lidar_pose(0), tuple(np.array(scans.lidar_pose(0)) + [0.35, -0.2, 0.0])]
+    clouds = [scans.lidar64(beams=32, azimuths=512, origin=p, seed=7 + k)[:2] for k, p in enumerate(poses)]
+    for i in range(34):
+        origin, xyz = clouds[i & 1]
+        _insert(g, origin, xyz, 8.0, True, True)
+        o.insert(origin, xyz, max_range=8.0, discrete=True)
+        if i in (1, 18):
+            g.insertPointCloudWait()
+            _assert_same_map(g, o, f"after scan {i}")
+    g.insertPointCloudWait()
+    _assert_same_map(g, o, "final")
+    assert g.debug()[60] < g.debug()[59]
+
+
+def test_batch_with_a_scan_that_does_not_fit_its_predicted_grid():
+    """One scan of a batch jumps by metres: it flags itself, the whole walk stands back, every scan of it is repeated in order."""
+    from ufomap_amd import scans
+    g, o = _maps(kind=_kind(), resolution=0.16)
+    g.set_option("batch_max", 4)
+    g.set_option("defer", 1)
+    base = np.array(scans.lidar_pose(0), dtype=np.float64)
+    offs = [(0, 0, 0)] * 4 + [(0.1, 0, 0), (0.2, 0.1, 0), (6.0, 4.0, 0.2), (0.2, 0.0, 0), (0.1, 0.1, 0), (6.0, 4.1, 0.2), (6.1, 4.0, 0.2), (0, 0, 0)] + [(0.05, 0, 0)] * 5
+    for i, off in enumerate(offs):
+        origin, xyz, _ = scans.lidar64(beams=32, azimuths=512, origin=tuple(base + np.array(off)), seed=900 + i)
+        _insert(g, origin, xyz, 10.0, True, True)
+        o.insert(origin, xyz, max_range=10.0, discrete=True)
+    g.insertPointCloudWait()
+    _assert_same_map(g, o, "final")
+    d = g.debug()
+    assert d[63] >= 1, "the jump should have forced a repeat"
+
+
+def test_fast_path_counter_and_general_path_agree_on_the_bench_sequence():
+    """The bench's 25-scan moving-sensor sequence with the steady-state path on and off: same map, and the counters prove the
+    five-launch path really ran (a regression of fastEligible or a gate time-out would otherwise pass every other test on the
+    general path and only show up as a slow bench)."""
+    import torch
+    from ufomap_amd import scans, OccupancyMap
+    clouds = [scans.lidar64(origin=scans.lidar_pose(s), seed=100 + s) for s in range(8)]
+    d_clouds = [torch.from_numpy(c[1]).cuda() for c in clouds]
+    digests, counters = [], []
+    for fast in (1, 0):
+        g = OccupancyMap(0.16)
+        g.set_option("fast", fast)
+        for i in range(25):
+            p = i % 8
+            g.insert_device(clouds[p][0], d_clouds[p].data_ptr(), None, d_clouds[p].shape[0], max_range=20.0, depth=0, discrete=True, async_=True)
+        g.insertPointCloudWait()
+        digests.append(g.digest())
+        counters.append(g.debug())
+    assert digests[0] == digests[1]
+    on, off = counters
+    assert on[61] >= 20 and on[59] == on[61] and on[60] >= 1, f"fast path did not run: {on[59:64]}"
+    assert on[58] == 0, "a stream hand-over timed out"
+    assert off[61] == 0 and off[60] == 0
+
+
+def test_many_handles_keep_their_maps_apart():
+    """Three maps fed in turn with pipelined scans (3 x 4 streams on the device's hardware queues, gates spinning on all of
+    them): every map equals its own sequential result; hand-over time-outs, if any, only cost time."""
+    from ufomap_amd import scans
+    maps = [_maps(resolution=0.16) for _ in range(3)]
+    for i in range(12):
+        for k, (g, o) in enumerate(maps):
+            origin, xyz, _ = scans.lidar64(beams=16, azimuths=512, origin=scans.lidar_pose((i + k) % 4), seed=40 * k + i)
+            _insert(g, origin, xyz, 10.0, True, True)
+            o.insert(origin, xyz, max_range=10.0, discrete=True)
+    for k, (g, o) in enumerate(maps):
+        g.insertPointCloudWait()
+        _assert_same_map(g, o, f"map {k}")

@@ -152,9 +152,12 @@ struct PointRec {
 template <bool DISCRETE>
 __global__ __launch_bounds__(256) void k_fhits(MapGeom g, FastGeo fg, D3 sensor, const double* __restrict__ xyz, u32 n, double max_range,
                                                u32 color_variant, u32* __restrict__ first, BoxPartial* __restrict__ part, ScanCtl* ctl,
-                                               Ingest ing, PointRec* __restrict__ recs)
+                                               Ingest ing, PointRec* __restrict__ recs, uint4* __restrict__ gridH4, u32 n4)
 {
 	const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	// the scan's hit grid (one bit per cell, the ray grid's layout; marked by k_fcast for the first point of every hit
+	// voxel) starts empty: this is the first kernel of the scan's chain, and the set's previous scan has been joined
+	for (u32 j = i; j < n4; j += gridDim.x * blockDim.x) gridH4[j] = make_uint4(0, 0, 0, 0);
 	double amn[3] = {1e300, 1e300, 1e300}, amx[3] = {-1e300, -1e300, -1e300};
 	i32 ck[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, ek[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
 	bool odd = false;
@@ -191,9 +194,10 @@ __global__ __launch_bounds__(256) void k_fhits(MapGeom g, FastGeo fg, D3 sensor,
 // ------------------------------------------------------------------------------------------------
 template <bool DISCRETE>
 __global__ __launch_bounds__(512) void k_fcast(MapGeom g, FastGeo fg, D3 sensor, const double* __restrict__ xyz, u32 n, double max_range,
-                                               u32 color_variant, const u32* __restrict__ first, D3* __restrict__ ray_scratch, u32 cap_wg,
+                                               u32 color_variant, u32* __restrict__ first, D3* __restrict__ ray_scratch, u32 cap_wg,
                                                u32* __restrict__ slabs, u32 k_min, const ScanCtl* ctl_in, ScanCtl* ctl,
-                                               unsigned long long* __restrict__ steps_part, Ingest ing, const PointRec* __restrict__ recs)
+                                               unsigned long long* __restrict__ steps_part, Ingest ing, const PointRec* __restrict__ recs,
+                                               u32* __restrict__ gridH)
 {
 	extern __shared__ __attribute__((aligned(16))) u32 lds[];
 	const u32 err_in = ctl_in->err;  // (looked at once the LDS grid has been cleared: the load is in flight meanwhile)
@@ -237,8 +241,16 @@ __global__ __launch_bounds__(512) void k_fcast(MapGeom g, FastGeo fg, D3 sensor,
 				const bool odd = 0 != (r.flags & 4u);
 				cast = (r.flags & 1u) && !odd;
 				if ((r.flags & 2u) && !odd) {
-					const bool winner = first[r.cell] == i;
+					const bool winner = __hip_atomic_load(&first[r.cell], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == i;
 					nhit += winner ? 1u : 0u;
+					if (winner) {
+						// the voxel receives a hit (OMB:295, 358-360: its first point's): one bit in the scan's hit grid, which is
+						// what the tree update reads. The winner is the entry's only reader that needs its value (a loser sees
+						// somebody else's index or the empty mark -- not its own either way): it leaves the array clean for the
+						// set's next scan.
+						atomicOr(&gridH[r.cell >> 5], 1u << (r.cell & 31u));
+						__hip_atomic_store(&first[r.cell], 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					}
 					if (DISCRETE && !winner) cast = false;  // OMB:358-360: dropped entirely, no ray
 				}
 				end = r.end;
@@ -659,36 +671,52 @@ __host__ __device__ inline u32 upperCell(const UpperGeo& ug, u32 l, const i32 c[
 	return inside ? off + x + n0 * (y + n1 * z) : 0xFFFFFFFFu;
 }
 // ------------------------------------------------------------------------------------------------
-// Tree update, part 1 (k_tile): one wavefront per active depth-3 tile. Lane l owns the level-1 node block whose 6-bit
-// position inside the tile is l (three Morton digits: child index inside the level-2 block = l & 7, level-2 block =
-// l >> 3) AND the slice of every block above that lies on its path: "its" depth-1 node's value in the level-2 block,
-// "its" depth-2 node's value in the level-3 block (replicated over the 8 lanes of a group). A level of updateNode is
-// then a reduction over 8 lanes (xor shuffles 1, 2, 4 for level 2; 8, 16, 32 for level 3) -- every lane ends up with
-// the same summary, nothing is broadcast, nothing goes through memory. Reads: 4 words of the bit grid, up to 8 entries
-// of the first-point array and one 64-byte block record per lane, the parents' slices (coalesced 4-byte loads).
+// Tree update, part 1 (k_tile): one wavefront per active depth-3 tile, ONE WALK FOR A BATCH OF SCANS. Lane l owns the
+// level-1 node block whose 6-bit position inside the tile is l (three Morton digits: child index inside the level-2
+// block = l & 7, level-2 block = l >> 3) AND the slice of every block above that lies on its path: "its" depth-1 node's
+// value in the level-2 block, "its" depth-2 node's value in the level-3 block (replicated over the 8 lanes of a group).
+// A level of updateNode is then a reduction over 8 lanes (xor shuffles 1, 2, 4 for level 2; 8, 16, 32 for level 3) --
+// every lane ends up with the same summary, nothing is broadcast, nothing goes through memory.
+//
+// The batch: scans 0 .. B-1 (one GPU: the scans that queued up behind the previous walk; several GPUs: the scans of
+// all ranks, in rank order) are applied IN ORDER, exactly as if the reference had integrated them one after the other
+// (occupancy_map_base.h:340-417 called B times) -- but the tile's 73 block records are read once, live in registers
+// while the B scans go over them (createNode with inheritance, updateOccupancy, updateNode, pruning and re-expansion
+// of what an earlier scan of the batch collapsed: all of it on the register copy), and are written once. Per scan the
+// wave reads 8 words per lane: its cells' bits in the scan's miss grid (ray cells) and hit grid.
+// Reads: those words, one 64-byte block record per lane, the parents' slices (coalesced 4-byte loads).
 // Writes: each touched block record once. Nothing above level 3 is written here: a tile whose level-3 block is new
 // looks its inherited value up (read-only: nobody changes the blocks above during this launch) and leaves the rest --
 // creating the blocks above, linking, their summaries -- to k_ftail.
 //
-// Semantics per level are exactly k_apply_leaf + propagateCore (map_kernels.h): hits (clamp) then misses (clamp) on
-// the voxels; a block's summary goes to its parent's slot; a parent is re-evaluated only if a child's stored summary
-// changed or the child's last update alone changed it; a node collapses only if the last update beneath it reached it.
-// At insert depth 0 every touched block has a miss (the end cell of every ray is a miss cell, OMB:1286), and misses
-// are applied after all hits in ascending code order: "the last update beneath a node" is always the miss in the
-// highest touched child, at every level.
+// Semantics per scan and level are exactly k_apply_leaf + propagateCore (map_kernels.h): hits (clamp) then misses
+// (clamp) on the voxels; a block's summary goes to its parent's slot; a parent is re-evaluated only if a child's stored
+// summary changed or the child's last update alone changed it; a node collapses only if the last update beneath it
+// reached it. At insert depth 0 every touched block has a miss (the end cell of every ray is a miss cell, OMB:1286), and
+// misses are applied after all hits in ascending code order: "the last update beneath a node" is always the miss in
+// the highest touched child of the LAST scan that touched it, at every level.
 // ------------------------------------------------------------------------------------------------
+#define UFO_BATCH_MAX 16u  // scans per walk (a larger batch is applied as several walks)
+struct TileBatch {
+	u32 B;
+	u32 pad;
+	const u32* gridM[UFO_BATCH_MAX];  // ray cells of scan b (bit grid, Grid::layout 1)
+	const u32* gridH[UFO_BATCH_MAX];  // hit voxels of scan b (same layout)
+	u32* tile_bits[UFO_BATCH_MAX];    // depth-3 tiles of the grid that hold a ray cell of scan b (cleared by k_ftail)
+	ScanCtl* ctl[UFO_BATCH_MAX];      // control block of scan b (err: the scan half flagged the scan; the walk stands back)
+};
 struct TileRec {
-	float occ, pre_occ;  // summary of the tile's level-3 block after the scan / just before its last update
+	float occ, pre_occ;  // summary of the tile's level-3 block after the batch / just before its last update
 	u32 slot;            // table slot of the level-3 block
 	u32 bits;            // 0-1 fl, 2-3 pre fl, 4 evaluated (summary handed to the parent), 5 last update reached and changed it,
 	                     // 6 the level-3 block is new (to be linked to its parent), 7 it collapsed, 8-10 child index in the parent
-	u32 seq;             // scan that wrote the record (the hit masks are valid for that scan only)
+	u32 seq;             // walk that wrote the record
 	// bookkeeping that must not become 1 400 atomics on one word (each ~12 ns, serialised): summed up by k_ftail.
-	// bits 0-7 level-1 blocks updated (<= 64), 8-17 voxels that received a hit (<= 512), 18-24 node blocks created (<= 73)
+	// bits 0-10 level-1 blocks updated (<= 64 per scan), 11-24 voxels that received a hit (<= 512 per scan), 25-31 node blocks created (<= 73)
 	u32 counts;
-	u32 pad[2];
+	u32 last;            // index (in the batch) of the last scan that touched the tile: the "time" of its last update
+	u32 pad;
 };
-__host__ __device__ inline u32 tileRecHits(const TileRec& r) { return (r.counts >> 8) & 1023u; }
 __device__ inline u32 flagsOf(const MapGeom& g, float v) { return (isFreeV(g, v) ? 1u : 0u) | (isUnknownV(g, v) ? 2u : 0u); }
 // reductions over the 8 lanes that differ in the three lane-index bits starting at bit `sh` (0: a level-2 group, 3: across groups)
 __device__ inline float grpMax(float v, int sh)
@@ -729,21 +757,26 @@ __device__ inline bool tileKey(const MapGeom& g, const FastGeo& fg, u32 tile, u6
 	return true;
 }
 
-__global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, const u32* __restrict__ gridM, u32* __restrict__ first,
-                                              const u32* __restrict__ tile_bits, TileRec* __restrict__ recs, float upd_hit, float upd_miss,
-                                              u32 scan_id, uint8_t* __restrict__ tile_hmask, ScanCtl* ctl, const ScanCtl* prev)
+__global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, TileBatch tb, TileRec* __restrict__ recs, float upd_hit, float upd_miss,
+                                              u32 scan_id, const u32* __restrict__ prev_stat)
 {
 	const u32 lane = threadIdx.x & 63u;
 	const u32 tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
 	if (tile >= fg.ntiles) return;
 	__builtin_amdgcn_s_setprio(2);  // (the map stream is the pipeline's critical path: ahead of the ray kernel's waves)
-	// three words can end the wave here; they are asked for together (a wave's time is its chain of dependent round trips)
-	const u32 tword = tile_bits[tile >> 5];
-	const u32 perr = (prev ? prev : ctl)->err;  // the update enqueued just before this one flagged itself and left the map alone:
-	                                            // this one stands back too (k_ftail raises ERR_PREV for the host)
-	const u32 cerr = ctl->err;                  // raised by the scan half (k_fhits / k_fcast), i.e. before anything touched the map
-	if (perr | cerr) return;                    // (uniform)
-	if (!((tword >> (tile & 31u)) & 1u)) return;
+	const u32 B = tb.B;
+	// words that can end the wave here are asked for together (a wave's time is its chain of dependent round trips):
+	// the walk enqueued just before this one flagged itself and left the map alone (this one stands back too, k_ftail
+	// tells the host); a scan of the batch was flagged by its scan half (k_fhits / k_fcast), i.e. before anything touched
+	// the map; the tile holds no ray cell of any scan
+	u32 errs = prev_stat ? *prev_stat : 0u;
+	u32 tmask = 0;  // bit b: the tile holds a ray cell of scan b
+	for (u32 b = 0; b < B; ++b) {
+		errs |= tb.ctl[b]->err;
+		tmask |= ((tb.tile_bits[b][tile >> 5] >> (tile & 31u)) & 1u) << b;
+	}
+	if (errs) return;  // (uniform)
+	if (!tmask) return;
 	u64 lk3;
 	u32 tt[3];
 	if (!tileKey(g, fg, tile, &lk3, tt)) return;
@@ -751,21 +784,68 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 	const u32 bx = (c1 & 1u) | ((c2 & 1u) << 1), by = ((c1 >> 1) & 1u) | (((c2 >> 1) & 1u) << 1), bz = ((c1 >> 2) & 1u) | (((c2 >> 2) & 1u) << 1);
 	const u64 lk2 = (lk3 << 3) | (u64)c2, lk1 = (lk2 << 3) | (u64)c1;
 	// The wave's time is its chain of dependent memory round trips, so everything that can be asked for at once is:
-	// round 1: the bit grid words and a SPECULATIVE lookup of every block the tile could touch (64 level-1 keys by the
+	// round 1: the grid words and a SPECULATIVE lookup of every block the tile could touch (64 level-1 keys by the
 	// 64 lanes, the 8 level-2 keys and the level-3 key by lanes 0..8); round 2: the records and slices behind those
-	// slots and the first-point entries of the marked cells; round 3 (rare): creations.
+	// slots; round 3 (rare): creations.
 	// ---- round 1 ----
 	const i32 ox = (fg.tbase[0] + (i32)tt[0]) * 8 - fg.gr.base[0] + 2 * (i32)bx;
 	const i32 oy = (fg.tbase[1] + (i32)tt[1]) * 8 - fg.gr.base[1] + 2 * (i32)by;
 	const i32 oz = (fg.tbase[2] + (i32)tt[2]) * 8 - fg.gr.base[2] + 2 * (i32)bz;
 	const i32 nx = 2 * fg.gr.nb[0], ny = 2 * fg.gr.nb[1], nz = 2 * fg.gr.nb[2];
 	const u32 rowW = fg.rowBits >> 5;
-	u32 gw[4] = {0, 0, 0, 0};
-	if (ox >= 0 && ox + 1 < nx) {
+	// the lane's 8 cells in every scan's grids: 8 bits of ray cells + 8 bits of hits per scan, packed (scans 0-7 / 8-15)
+	u64 mmA = 0, mmB = 0, hmA = 0, hmB = 0;
+	{
+		u32 widx[4];
+		bool wok[4];
 #pragma unroll
 		for (int k = 0; k < 4; ++k) {
 			const i32 ly = oy + (k & 1), lz = oz + (k >> 1);
-			if (ly >= 0 && ly < ny && lz >= 0 && lz < nz) gw[k] = gridM[((u32)lz * (u32)ny + (u32)ly) * rowW + ((u32)ox >> 5)];
+			wok[k] = ox >= 0 && ox + 1 < nx && ly >= 0 && ly < ny && lz >= 0 && lz < nz;
+			widx[k] = wok[k] ? ((u32)lz * (u32)ny + (u32)ly) * rowW + ((u32)ox >> 5) : 0u;
+		}
+		const u32 sh = (u32)ox & 31u;
+		// four scans' words at a time (32 loads in flight), scans that do not touch the tile are skipped (uniform)
+		u32 rem = tmask;
+		while (rem) {
+			u32 bs[4], nb = 0;
+#pragma unroll
+			for (int q = 0; q < 4; ++q) {
+				bs[q] = rem ? (u32)__ffs(rem) - 1u : bs[0];
+				nb += rem ? 1u : 0u;
+				rem &= rem - 1u;  // (0 stays 0)
+			}
+			u32 wm[4][4], wh[4][4];
+#pragma unroll
+			for (int q = 0; q < 4; ++q) {
+				const u32* gM = tb.gridM[bs[q]];
+				const u32* gH = tb.gridH[bs[q]];
+#pragma unroll
+				for (int k = 0; k < 4; ++k) {
+					wm[q][k] = wok[k] ? gM[widx[k]] : 0u;
+					wh[q][k] = wok[k] ? gH[widx[k]] : 0u;
+				}
+			}
+#pragma unroll
+			for (int q = 0; q < 4; ++q) {
+				u32 mm = 0, hm = 0;
+#pragma unroll
+				for (int k = 0; k < 4; ++k) {
+					mm |= ((wm[q][k] >> sh) & 3u) << (2 * (k & 1) + 4 * (k >> 1));
+					hm |= ((wh[q][k] >> sh) & 3u) << (2 * (k & 1) + 4 * (k >> 1));
+				}
+				hm &= mm;  // (a hit voxel is a ray cell: the end cell of its point's ray)
+				if ((u32)q < nb) {
+					const u32 s8 = 8u * (bs[q] & 7u);
+					if (bs[q] < 8u) {
+						mmA |= (u64)mm << s8;
+						hmA |= (u64)hm << s8;
+					} else {
+						mmB |= (u64)mm << s8;
+						hmB |= (u64)hm << s8;
+					}
+				}
+			}
 		}
 	}
 	u32 s1 = tableFind(t, lk1);
@@ -773,242 +853,273 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 	if (lane < 8u) sx = tableFind(t, (lk3 << 3) | (u64)lane);
 	else if (8u == lane) sx = tableFind(t, lk3);
 	u32 s3 = __shfl(sx, 8), s2 = __shfl(sx, (int)c2);
-	u32 mmask = 0;
-#pragma unroll
-	for (int k = 0; k < 4; ++k) mmask |= ((gw[k] >> ((u32)ox & 31u)) & 3u) << (2 * (k & 1) + 4 * (k >> 1));
-	const bool active = 0 != mmask;
-	const u32 act2 = grpOr(active ? 1u : 0u, 0);  // the lane's level-2 group is touched
-	// ---- round 2 ----
-	u32 fl3 = F_DEAD, fl2 = F_DEAD, fl1 = F_DEAD;
+	const bool uactive = 0 != (mmA | mmB);                 // the lane's block is touched by some scan of the batch
+	const u32 uact2 = grpOr(uactive ? 1u : 0u, 0);         // ... its level-2 group is
+	// ---- round 2: the records as they are stored (a block found DEAD was collapsed: the node is a leaf, octree.h:1060-1066;
+	// a block that is not there counts as DEAD) ----
+	u32 fl3r = F_DEAD, fl2r = F_DEAD, fl1r = F_DEAD;
 	float v2l = 0.f, v1l = 0.f;
-	float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
+	float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 	if (s3 != NONE) {
-		fl3 = t.flags(s3);
+		fl3r = t.flags(s3);
 		v2l = t.occ(s3)[c2];
 	}
-	if (s2 != NONE && act2) {
-		fl2 = t.flags(s2);
+	if (s2 != NONE && uact2) {
+		fl2r = t.flags(s2);
 		v1l = t.occ(s2)[c1];
 	}
-	if (s1 != NONE && active) {
-		fl1 = t.flags(s1);
+	if (s1 != NONE && uactive) {
+		fl1r = t.flags(s1);
 		const float4* po = reinterpret_cast<const float4*>(t.occ(s1));
-		ra = po[0];
-		rb = po[1];
+		const float4 ra = po[0], rb = po[1];
+		v[0] = ra.x; v[1] = ra.y; v[2] = ra.z; v[3] = ra.w;
+		v[4] = rb.x; v[5] = rb.y; v[6] = rb.z; v[7] = rb.w;
 	}
-	u32 hmask = 0, nhit = 0;
-	if (active) {
-#pragma unroll
-		for (int c = 0; c < 8; ++c) {
-			if (!((mmask >> c) & 1u)) continue;
-			const u32 cell = (u32)(ox + (c & 1)) + (u32)(oy + ((c >> 1) & 1)) * fg.rowBits + (u32)(oz + ((c >> 2) & 1)) * fg.planeBits;
-			if (first[cell] != 0xFFFFFFFFu) {
-				hmask |= 1u << c;
-				first[cell] = 0xFFFFFFFFu;  // this kernel is the array's last reader: leave it clean for the next scan
-				++nhit;
-			}
-		}
-	}
-	// ---- which blocks are there (a block found DEAD was collapsed: the node is a leaf, octree.h:1060-1066) ----
-	const bool cr3 = (s3 == NONE) || 0 != (fl3 & F_DEAD);
-	const bool cr2 = act2 && (cr3 || s2 == NONE || 0 != (fl2 & F_DEAD));
-	const bool cr1 = active && (cr2 || s1 == NONE || 0 != (fl1 & F_DEAD));
-	// ---- round 3: createNode for what is missing (octree.h:997-1016); a new level-3 block inherits the value of the
-	// nearest node above that has one (the blocks above are not written during this launch) ----
+	// ---- round 3: createNode for what is missing from the table (octree.h:997-1016); a level-3 block that is not live
+	// inherits the value of the nearest node above that has one (the blocks above are not written during this launch) ----
 	u32 n_created = 0;
 	float v3s = 0.f;
-	if (__ballot(cr3 || cr2 || cr1)) {
-		const u32 max_probe = (t.mask >> 1) + 1;
-		bool dummy;
-		if (cr3 && 0 == lane) {
-			s3 = tableEnsure(t, lk3, scan_id, max_probe, &dummy, &n_created);
-			v3s = t.root->occ;
-			for (u64 k = lk3 >> 3, below = lk3; k >= 1; below = k, k >>= 3) {
-				const u32 sa = tableFind(t, k);
-				if (sa != NONE && !(t.flags(sa) & F_DEAD)) {
-					v3s = t.occ(sa)[(u32)(below & 7)];
-					break;
+	{
+		const bool need3 = 0 != (fl3r & F_DEAD);
+		const bool mk3 = s3 == NONE, mk2 = uact2 && s2 == NONE && 0 == c1, mk1 = uactive && s1 == NONE;
+		if (__ballot(need3 || mk2 || mk1)) {
+			const u32 max_probe = (t.mask >> 1) + 1;
+			bool dummy;
+			if (need3 && 0 == lane) {
+				if (mk3) s3 = tableEnsure(t, lk3, scan_id, max_probe, &dummy, &n_created);
+				v3s = t.root->occ;
+				for (u64 k = lk3 >> 3, below = lk3; k >= 1; below = k, k >>= 3) {
+					const u32 sa = tableFind(t, k);
+					if (sa != NONE && !(t.flags(sa) & F_DEAD)) {
+						v3s = t.occ(sa)[(u32)(below & 7)];
+						break;
+					}
+					if (1 == k) break;
 				}
-				if (1 == k) break;
+			}
+			if (mk2) s2 = tableEnsure(t, lk2, scan_id, max_probe, &dummy, &n_created);
+			if (mk1) s1 = tableEnsure(t, lk1, scan_id, max_probe, &dummy, &n_created);
+			s3 = __shfl(s3, 0);
+			v3s = __shfl(v3s, 0);
+			s2 = __shfl(s2, (int)(lane & ~7u));
+			if (__ballot((s3 == NONE) || (uact2 && s2 == NONE) || (uactive && s1 == NONE))) {
+				if (0 == lane) atomicOr(&tb.ctl[B - 1u]->err, ERR_TABLE_FULL);  // (the host sizes the table for the worst case before launching)
+				return;
 			}
 		}
-		if (cr2 && 0 == c1) s2 = tableEnsure(t, lk2, scan_id, max_probe, &dummy, &n_created);
-		if (cr1) s1 = tableEnsure(t, lk1, scan_id, max_probe, &dummy, &n_created);
-		s3 = __shfl(s3, 0);
-		v3s = __shfl(v3s, 0);
-		s2 = __shfl(s2, (int)(lane & ~7u));
-		if (__ballot((s3 == NONE) || (act2 && s2 == NONE) || (active && s1 == NONE))) {
-			if (0 == lane) atomicOr(&ctl->err, ERR_TABLE_FULL);  // (the host sizes the table for the worst case before launching)
-			return;
+	}
+	// ---- the scans of the batch, in order, on the register copy of the tile's records ----
+	bool w2 = false, w3 = false;      // the lane's slot of the level-2 / level-3 record has to be written
+	bool any_eval3 = false, created3 = false, reach_last = false;
+	float m3c = 0.f, pm_last = 0.f;   // summary of the level-3 block as last evaluated / before its last update
+	u32 fl3c = 0, pfl_last = 0, last_b = 0;
+	u32 n_touched = 0, nhit = 0;
+	for (u32 b = 0; b < B; ++b) {
+		if (8u == b) {
+			mmA = mmB;
+			hmA = hmB;
 		}
-	}
-	// ---- stored state of the lane's slices; new blocks inherit (octree.h:1044-1054) ----
-	// depth-2 node c2: slot c2 of the level-3 block
-	float v2s;
-	u32 f2s, in2s;  // stored value, flags, "has a live block" of the lane's depth-2 node
-	if (cr3) {
-		v2s = v3s;
-		f2s = flagsOf(g, v3s);
-		in2s = 0;
-	} else {
-		v2s = v2l;
-		f2s = ((fl3 >> c2) & 1u) | (((fl3 >> (8 + c2)) & 1u) << 1);
-		in2s = (fl3 >> (16 + c2)) & 1u;
-	}
-	// depth-1 node c1 of group c2: slot c1 of the level-2 block (if the group is touched)
-	float v1s = v2s;
-	u32 f1s = flagsOf(g, v2s), in1s = 0;
-	if (act2 && !cr2) {
-		v1s = v1l;
-		f1s = ((fl2 >> c1) & 1u) | (((fl2 >> (8 + c1)) & 1u) << 1);
-		in1s = (fl2 >> (16 + c1)) & 1u;
-	}
-	const u32 f3s = 0;  // (only the defaults of a summary that is not handed over)
-	// ---- level 1: updateOccupancy on the voxels (hits, then misses), the block's own updateNode ----
-	float cur1 = v1s;   // current value / flags of the lane's depth-1 node
-	u32 curf1 = f1s, in1 = in1s;
-	bool want1 = false, reach1 = false;
-	float pre1 = v1s;
-	u32 pref1 = f1s;
-	if (active) {
-		float v[8];
-		if (cr1) {
-#pragma unroll
-			for (int c = 0; c < 8; ++c) v[c] = v1s;
+		const u32 mmask = (u32)mmA & 255u, hmask = (u32)hmA & 255u;
+		mmA >>= 8;
+		hmA >>= 8;
+		if (!((tmask >> b) & 1u)) continue;  // (uniform)
+		const bool active = 0 != mmask;
+		const u32 act2 = grpOr(active ? 1u : 0u, 0);  // the lane's level-2 group is touched by this scan
+		// which blocks are there for this scan
+		const bool cr3 = 0 != (fl3r & F_DEAD);
+		const bool cr2 = act2 && (cr3 || 0 != (fl2r & F_DEAD));
+		const bool cr1 = active && (cr2 || 0 != (fl1r & F_DEAD));
+		created3 = created3 || cr3;
+		// ---- stored state of the lane's slices; new blocks inherit (octree.h:1044-1054) ----
+		// depth-2 node c2: slot c2 of the level-3 block
+		float v2s;
+		u32 f2s, in2s;  // stored value, flags, "has a live block" of the lane's depth-2 node
+		if (cr3) {
+			v2s = v3s;
+			f2s = flagsOf(g, v3s);
+			in2s = 0;
 		} else {
-			v[0] = ra.x; v[1] = ra.y; v[2] = ra.z; v[3] = ra.w;
-			v[4] = rb.x; v[5] = rb.y; v[6] = rb.z; v[7] = rb.w;
+			v2s = v2l;
+			f2s = ((fl3r >> c2) & 1u) | (((fl3r >> (8 + c2)) & 1u) << 1);
+			in2s = (fl3r >> (16 + c2)) & 1u;
 		}
-		const int c_last = 31 - __clz((int)mmask);  // ascending code order: the highest touched voxel is updated last
-		float v_old_last = 0.f;
+		// depth-1 node c1 of group c2: slot c1 of the level-2 block (if the group is touched)
+		float v1s = v2s;
+		u32 f1s = flagsOf(g, v2s), in1s = 0;
+		if (act2 && !cr2) {
+			v1s = v1l;
+			f1s = ((fl2r >> c1) & 1u) | (((fl2r >> (8 + c1)) & 1u) << 1);
+			in1s = (fl2r >> (16 + c1)) & 1u;
+		}
+		const u32 f3s = 0;  // (only the defaults of a summary that is not handed over)
+		// ---- level 1: updateOccupancy on the voxels (hits, then misses), the block's own updateNode ----
+		float cur1 = v1s;  // current value / flags of the lane's depth-1 node
+		u32 curf1 = f1s, in1 = in1s;
+		bool want1 = false, reach1 = false;
+		float pre1 = v1s;
+		u32 pref1 = f1s;
+		if (active) {
+			if (cr1) {
 #pragma unroll
-		for (int c = 0; c < 8; ++c) {
-			float x = v[c];
-			if ((hmask >> c) & 1u) x = clampAdd(x, upd_hit, g.cmin, g.cmax);
-			if ((mmask >> c) & 1u) {
-				if (c == c_last) v_old_last = x;
-				x = clampAdd(x, upd_miss, g.cmin, g.cmax);
+				for (int c = 0; c < 8; ++c) v[c] = v1s;
 			}
-			v[c] = x;
+			const int c_last = 31 - __clz((int)mmask);  // ascending code order: the highest touched voxel is updated last
+			float v_old_last = 0.f;
+#pragma unroll
+			for (int c = 0; c < 8; ++c) {
+				float x = v[c];
+				if ((hmask >> c) & 1u) x = clampAdd(x, upd_hit, g.cmin, g.cmax);
+				if ((mmask >> c) & 1u) {
+					if (c == c_last) v_old_last = x;
+					x = clampAdd(x, upd_miss, g.cmin, g.cmax);
+				}
+				v[c] = x;
+			}
+			// updateNode of a depth-1 node (OMB:1195-1224): max, flags from the 8 voxels, collapsible if all equal
+			float m = v[0], pm = (0 == c_last) ? v_old_last : v[0];
+			u32 fl = 0, pfl = 0;
+			bool eq = true;
+#pragma unroll
+			for (int c = 0; c < 8; ++c) {
+				const float pv = (c == c_last) ? v_old_last : v[c];
+				m = fmaxf(m, v[c]);
+				pm = fmaxf(pm, pv);
+				fl |= flagsOf(g, v[c]);
+				pfl |= flagsOf(g, pv);
+				eq = eq && (v[c] == v[0]);
+			}
+			reach1 = !(pm == m && pfl == fl);  // level 1 is always reached (OMB:1128 starts at depth 1)
+			pre1 = pm;
+			pref1 = pfl;
+			const bool dead1 = eq;             // collapsed: the node is a leaf again (octree.h:1060-1066)
+			in1 = dead1 ? 0u : 1u;
+			want1 = (m != v1s) || (fl != f1s) || reach1;
+			cur1 = m;
+			curf1 = fl;
+			// the record's flags (low bits as k_init_new leaves them for a new block)
+			u32 fw = cr1 ? ((isFreeV(g, v1s) ? F_CFREE : 0u) | (isUnknownV(g, v1s) ? F_CUNK : 0u)) : (fl1r & ~(F_DEAD | F_DIRTY));
+			if (dead1) fw |= F_DEAD;
+			fl1r = fw;
+			nhit += (u32)__popc(hmask);
 		}
+		// ---- level 2 (reductions over the 8 lanes of a group; every lane of the group computes the same) ----
+		const u32 top1 = grpMaxU(active ? (c1 + 1u) : 0u, 0);     // 1 + the highest touched child of the group (0: none)
+		const bool eval2 = 0 != grpOr(want1 ? 1u : 0u, 0);
+		float cur2 = v2s;
+		u32 curf2 = f2s, in2 = in2s;
+		bool want2 = false, reach2 = false, dead2 = false;
+		float pre2 = v2s;
+		u32 pref2 = f2s;
+		{
+			const float m = grpMax(cur1, 0);
+			const u32 fl = grpOr(curf1, 0);
+			const bool eq = grpAllEq(cur1, 0, lane);
+			const u32 inner_any = grpOr(in1, 0);
+			const bool is_top = active && (c1 + 1u == top1);
+			const bool reached = 0 != grpOr((is_top && reach1) ? 1u : 0u, 0);  // the last update beneath reached the child and changed it
+			const float pm = grpMax(is_top ? pre1 : cur1, 0);
+			const u32 pfl = grpOr(is_top ? pref1 : curf1, 0);
+			if (eval2) {
+				dead2 = reached && eq && 0 == inner_any;
+				reach2 = reached && !(pm == m && pfl == fl);
+				want2 = (m != v2s) || (fl != f2s) || reach2;
+				pre2 = pm;
+				pref2 = pfl;
+				cur2 = m;
+				curf2 = fl;
+			}
+			if (act2) in2 = dead2 ? 0u : 1u;
+		}
+		if (act2) {
+			// the level-2 record: the lane's child slot; flags of the whole block
+			if (active || cr2) {
+				v1l = cur1;
+				w2 = true;
+			}
+			const u32 fbits = grpOr(((curf1 & 1u) << c1) | (((curf1 >> 1) & 1u) << (8 + c1)) | (in1 << (16 + c1)), 0);
+			fl2r = fbits | (dead2 ? F_DEAD : 0u);
+		}
+		// ---- level 3 (reductions across the 8 groups; every lane computes the same) ----
+		const u32 top2 = grpMaxU(act2 ? (c2 + 1u) : 0u, 3);
+		const bool eval3 = 0 != grpOr(want2 ? 1u : 0u, 3);
+		bool reach3 = false, dead3 = false;
+		float m3 = v3s, pm3 = v3s;
+		u32 fl3n = f3s, pfl3 = f3s;
+		{
+			const float m = grpMax(cur2, 3);
+			const u32 fl = grpOr(curf2, 3);
+			const bool eq = grpAllEq(cur2, 3, lane);
+			const u32 inner_any = grpOr(in2, 3);
+			const bool is_top = act2 && (c2 + 1u == top2);
+			const bool reached = 0 != grpOr((is_top && reach2) ? 1u : 0u, 3);
+			const float pm = grpMax(is_top ? pre2 : cur2, 3);
+			const u32 pfl = grpOr(is_top ? pref2 : curf2, 3);
+			if (eval3) {
+				dead3 = reached && eq && 0 == inner_any;
+				reach3 = reached && !(pm == m && pfl == fl);
+				m3 = m;
+				fl3n = fl;
+				pm3 = pm;
+				pfl3 = pfl;
+			}
+		}
+		{
+			// the level-3 record: the group's slot (all eight when the block is new); flags of the whole block
+			if (act2 || cr3) {
+				v2l = cur2;
+				w3 = true;
+			}
+			const u32 fbits = grpOr((0 == c1) ? (((curf2 & 1u) << c2) | (((curf2 >> 1) & 1u) << (8 + c2)) | (in2 << (16 + c2))) : 0u, 3);
+			fl3r = fbits | (dead3 ? F_DEAD : 0u);
+		}
+		// what k_ftail needs: the summary as last evaluated, and how the tile's LAST update (this scan's, so far) went
+		if (eval3) {
+			any_eval3 = true;
+			m3c = m3;
+			fl3c = fl3n;
+		}
+		reach_last = reach3;
+		pm_last = pm3;
+		pfl_last = pfl3;
+		last_b = b;
+		if (dead3) v3s = m3;  // a later scan of the batch re-expands the node from its own value (all children were equal to it)
+		n_touched += (u32)__popcll(__ballot(active));
+	}
+	// ---- every touched record back to the table, once ----
+	if (uactive) {
 		float4* po = reinterpret_cast<float4*>(t.occ(s1));
 		po[0] = make_float4(v[0], v[1], v[2], v[3]);
 		po[1] = make_float4(v[4], v[5], v[6], v[7]);
-		// updateNode of a depth-1 node (OMB:1195-1224): max, flags from the 8 voxels, collapsible if all equal
-		float m = v[0], pm = (0 == c_last) ? v_old_last : v[0];
-		u32 fl = 0, pfl = 0;
-		bool eq = true;
-#pragma unroll
-		for (int c = 0; c < 8; ++c) {
-			const float pv = (c == c_last) ? v_old_last : v[c];
-			m = fmaxf(m, v[c]);
-			pm = fmaxf(pm, pv);
-			fl |= flagsOf(g, v[c]);
-			pfl |= flagsOf(g, pv);
-			eq = eq && (v[c] == v[0]);
-		}
-		reach1 = !(pm == m && pfl == fl);  // level 1 is always reached (OMB:1128 starts at depth 1)
-		pre1 = pm;
-		pref1 = pfl;
-		const bool dead1 = eq;             // collapsed: the node is a leaf again (octree.h:1060-1066)
-		in1 = dead1 ? 0u : 1u;
-		want1 = (m != v1s) || (fl != f1s) || reach1;
-		cur1 = m;
-		curf1 = fl;
-		// the record's tail: flags (low bits as k_init_new leaves them for a new block) + parent, one 8-byte store
-		u32 fw = cr1 ? ((isFreeV(g, v1s) ? F_CFREE : 0u) | (isUnknownV(g, v1s) ? F_CUNK : 0u)) : (fl1 & ~(F_DEAD | F_DIRTY));
-		if (dead1) fw |= F_DEAD;
-		t.flags(s1) = fw;
+		t.flags(s1) = fl1r;
 		t.parent(s1) = s2;
 	}
-	// ---- level 2 (reductions over the 8 lanes of a group; every lane of the group computes the same) ----
-	const u32 top1 = grpMaxU(active ? (c1 + 1u) : 0u, 0);     // 1 + the highest touched child of the group (0: none)
-	const bool eval2 = 0 != grpOr(want1 ? 1u : 0u, 0);
-	float cur2 = v2s;
-	u32 curf2 = f2s, in2 = in2s;
-	bool want2 = false, reach2 = false, dead2 = false;
-	float pre2 = v2s;
-	u32 pref2 = f2s;
-	{
-		const float m = grpMax(cur1, 0);
-		const u32 fl = grpOr(curf1, 0);
-		const bool eq = grpAllEq(cur1, 0, lane);
-		const u32 inner_any = grpOr(in1, 0);
-		const bool is_top = active && (c1 + 1u == top1);
-		const bool reached = 0 != grpOr((is_top && reach1) ? 1u : 0u, 0);  // the last update beneath reached the child and changed it
-		const float pm = grpMax(is_top ? pre1 : cur1, 0);
-		const u32 pfl = grpOr(is_top ? pref1 : curf1, 0);
-		if (eval2) {
-			dead2 = reached && eq && 0 == inner_any;
-			reach2 = reached && !(pm == m && pfl == fl);
-			want2 = (m != v2s) || (fl != f2s) || reach2;
-			pre2 = pm;
-			pref2 = pfl;
-			cur2 = m;
-			curf2 = fl;
-		}
-		if (act2) in2 = dead2 ? 0u : 1u;
-	}
-	if (act2) {
-		// the level-2 record: the lane writes its child's slot; the group's first lane the flags + parent
-		if (active || cr2) t.occ(s2)[c1] = cur1;
-		const u32 fbits = grpOr(((curf1 & 1u) << c1) | (((curf1 >> 1) & 1u) << (8 + c1)) | (in1 << (16 + c1)), 0);
+	if (uact2) {
+		if (w2) t.occ(s2)[c1] = v1l;
 		if (0 == c1) {
-			t.flags(s2) = fbits | (dead2 ? F_DEAD : 0u);
+			t.flags(s2) = fl2r;
 			t.parent(s2) = s3;
 		}
 	}
-	// ---- level 3 (reductions across the 8 groups; every lane computes the same) ----
-	const u32 top2 = grpMaxU(act2 ? (c2 + 1u) : 0u, 3);
-	const bool eval3 = 0 != grpOr(want2 ? 1u : 0u, 3);
-	bool reach3 = false, dead3 = false;
-	float m3 = v3s, pm3 = v3s;
-	u32 fl3n = f3s, pfl3 = f3s;
-	{
-		const float m = grpMax(cur2, 3);
-		const u32 fl = grpOr(curf2, 3);
-		const bool eq = grpAllEq(cur2, 3, lane);
-		const u32 inner_any = grpOr(in2, 3);
-		const bool is_top = act2 && (c2 + 1u == top2);
-		const bool reached = 0 != grpOr((is_top && reach2) ? 1u : 0u, 3);
-		const float pm = grpMax(is_top ? pre2 : cur2, 3);
-		const u32 pfl = grpOr(is_top ? pref2 : curf2, 3);
-		if (eval3) {
-			dead3 = reached && eq && 0 == inner_any;
-			reach3 = reached && !(pm == m && pfl == fl);
-			m3 = m;
-			fl3n = fl;
-			pm3 = pm;
-			pfl3 = pfl;
-		}
+	if (0 == c1 && w3) t.occ(s3)[c2] = v2l;
+	for (int o = 32; o > 0; o >>= 1) {
+		n_created += __shfl_xor(n_created, o);
+		nhit += __shfl_xor(nhit, o);
 	}
-	{
-		// the level-3 record: first lane of every group writes its slot (all eight when the block is new), lane 0 the rest
-		if (0 == c1 && (act2 || cr3)) t.occ(s3)[c2] = cur2;
-		const u32 fbits = grpOr((0 == c1) ? (((curf2 & 1u) << c2) | (((curf2 >> 1) & 1u) << (8 + c2)) | (in2 << (16 + c2))) : 0u, 3);
-		for (int o = 32; o > 0; o >>= 1) {
-			n_created += __shfl_xor(n_created, o);
-			nhit += __shfl_xor(nhit, o);
-		}
-		const u32 touched = (u32)__popcll(__ballot(active));
-		if (0 == lane) {
-			t.flags(s3) = fbits | (dead3 ? F_DEAD : 0u);  // (the parent link of a new block: k_ftail)
-			TileRec r;
-			r.occ = m3;
-			r.pre_occ = pm3;
-			r.slot = s3;
-			r.bits = (fl3n & 3u) | ((pfl3 & 3u) << 2) | (eval3 ? 16u : 0u) | (reach3 ? 32u : 0u) | (cr3 ? 64u : 0u) | (dead3 ? 128u : 0u);
-			r.bits |= (u32)(lk3 & 7) << 8;
-			r.seq = scan_id;
-			r.counts = touched | (nhit << 8) | (n_created << 18);
-			r.pad[0] = r.pad[1] = 0;
-			recs[tile] = r;
-		}
+	if (0 == lane) {
+		t.flags(s3) = fl3r;  // (the parent link of a new block: k_ftail)
+		TileRec r;
+		r.occ = m3c;
+		r.pre_occ = pm_last;
+		r.slot = s3;
+		r.bits = (fl3c & 3u) | ((pfl_last & 3u) << 2) | (any_eval3 ? 16u : 0u) | (reach_last ? 32u : 0u) | (created3 ? 64u : 0u) | ((fl3r & F_DEAD) ? 128u : 0u);
+		r.bits |= (u32)(lk3 & 7) << 8;
+		r.seq = scan_id;
+		r.counts = n_touched | (nhit << 11) | (n_created << 25);
+		r.last = last_b;
+		r.pad = 0;
+		recs[tile] = r;
 	}
-	// the hit masks of the 64 level-1 blocks (stage-level output: ufomap_map_last_hits rebuilds the hit codes on demand)
-	tile_hmask[(size_t)tile * 64u + lane] = (uint8_t)hmask;
 }
-
 // ------------------------------------------------------------------------------------------------
 // Tree update, part 2 (k_ftail): everything above the tiles, by ONE workgroup with the blocks in LDS.
 //   1. Which blocks: the tiles form a regular grid, so do their ancestors -- level l is the tile grid coarsened by
@@ -1052,19 +1163,26 @@ __device__ inline u32 upperCellAt(const UpperLevel& u, u32 off, const i32 c[3])
 }
 #define UFO_FTAIL_THREADS 1024
 static_assert(UFO_FTAIL_THREADS == UFO_UPPER_MAX, "k_ftail: one thread per cell of the dense grids above the tiles");
-__global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g, FastGeo fg, UpperGeo ugp, u32* __restrict__ tile_bits,
-                                                             const TileRec* __restrict__ recs, u32 scan_id, ScanCtl* ctl, const ScanCtl* prev,
-                                                             ScanCtl* host_result, const ScanCtl* ctl_init, unsigned long long done_value)
+// where the scans of a walk report to: scan b's finished control block goes to host_result[b] (pinned host memory, or
+// device memory when nobody polls), followed by the word the host waits for
+struct TailBatch {
+	ScanCtl* host_result[UFO_BATCH_MAX];
+	unsigned long long done_value[UFO_BATCH_MAX];
+};
+__global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g, FastGeo fg, TileBatch tb, TailBatch hb,
+                                                             const TileRec* __restrict__ recs, u32 scan_id, const u32* __restrict__ prev_stat,
+                                                             u32* __restrict__ own_stat, const ScanCtl* ctl_init)
 {
-	// the host waits for THIS word (behind the pinned control block), not for an event: an event record is one more packet
+	// the host waits for the word behind a scan's pinned result block, not for an event: an event record is one more packet
 	// the map stream's command processor has to get through between two scans (~5 us, scripts/micro/stream_wait.hip)
-	unsigned long long* host_done = reinterpret_cast<unsigned long long*>(host_result + 1);
+	const u32 B = tb.B;
+	ScanCtl* const ctl = tb.ctl[B - 1u];  // what the walk as a whole reports (blocks touched / created, table fill, clocks) goes with its last scan
 	// This lone workgroup shares its CU with waves of the next scan's ray kernel and of k_tile; its time is its chain of
 	// dependent instructions, so its waves take issue priority over theirs (measured: 35 -> 27 us when overlapped).
 	__builtin_amdgcn_s_setprio(3);
 	__shared__ u32 tbits[UFO_FAST_MAX_TILES / 32], ubits[UFO_UPPER_MAX / 32], uprefix[UFO_UPPER_MAX / 32 + 1];
 	__shared__ u64 nk[UFO_UPPER_MAX];
-	__shared__ unsigned long long top64[UFO_UPPER_MAX];  // (1 + child index of the highest touched child) << 32 | who it is (tile or node)
+	__shared__ unsigned long long top64[UFO_UPPER_MAX];  // (1 + last scan of the batch that touched the subtree) << 40 | (1 + child index of the highest child it touched) << 32 | who that is (tile or node)
 	__shared__ u32 nslot[UFO_UPPER_MAX], npar[UFO_UPPER_MAX], nflags[UFO_UPPER_MAX], out_bits[UFO_UPPER_MAX];
 	__shared__ float nocc[UFO_UPPER_MAX][8], out_pre[UFO_UPPER_MAX];
 	__shared__ uint8_t dirty[UFO_UPPER_MAX], ncreated[UFO_UPPER_MAX];
@@ -1075,24 +1193,30 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 	__shared__ u32 wbits[UFO_FTAIL_THREADS / 64][UFO_UPPER_MAX / 32];
 	const u32 nwords = (fg.ntiles + 31u) / 32u;
 	{
-		// (one round of loads: the two error words and the tile bitmap)
-		const u32 perr = prev ? prev->err : 0u, cerr = ctl->err;
-		for (u32 j = threadIdx.x; j < nwords; j += blockDim.x) tbits[j] = tile_bits[j];
-		if (perr) {
-			// the update enqueued just before this one flagged itself and left the map alone: this one stood back too (k_tile)
-			if (0 == threadIdx.x) {
-				host_result->err = atomicOr(&ctl->err, ERR_PREV) | ERR_PREV;
-				__threadfence_system();
-				__hip_atomic_store(host_done, done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-			}
-			return;
+		// (one round of loads: the error words and the scans' tile bitmaps, whose union is the walk's)
+		const u32 perr = prev_stat ? *prev_stat : 0u;
+		u32 cerr = 0;
+		for (u32 b = 0; b < B; ++b) cerr |= tb.ctl[b]->err;
+		for (u32 j = threadIdx.x; j < nwords; j += blockDim.x) {
+			u32 w = 0;
+			for (u32 b = 0; b < B; ++b) w |= tb.tile_bits[b][j];
+			tbits[j] = w;
 		}
-		if (cerr) {  // the scan stood back (ERR_SPEC / a bound): the map is as it was
-			if (0 == threadIdx.x) {
-				host_result->err = cerr;
+		if (perr | cerr) {
+			// the walk enqueued just before this one flagged itself and left the map alone, or the scan half of one of this
+			// walk's scans flagged it (ERR_SPEC / a bound): the whole walk stood back (k_tile), the map is as it was. Every
+			// scan of the walk is reported flagged -- with its own error, the others with ERR_PREV -- and the host repeats
+			// them in order; the walk enqueued behind this one finds own_stat set and stands back as well.
+			if (threadIdx.x < B) {
+				const u32 b = threadIdx.x;
+				const u32 own = tb.ctl[b]->err;
+				// (ERR_TABLE_FULL from this walk's own k_tile: the map IS inconsistent, and every scan of the walk says so)
+				const u32 e = ((perr || 0 == own) ? (atomicOr(&tb.ctl[b]->err, ERR_PREV) | ERR_PREV) : own) | (cerr & ERR_TABLE_FULL);
+				hb.host_result[b]->err = e;
 				__threadfence_system();
-				__hip_atomic_store(host_done, done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+				__hip_atomic_store(reinterpret_cast<unsigned long long*>(hb.host_result[b] + 1), hb.done_value[b], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 			}
+			if (0 == threadIdx.x) *own_stat = 1u;
 			return;
 		}
 	}
@@ -1100,7 +1224,6 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 	const u32 L = g.L;
 	const u32 lane = threadIdx.x & 63u;
 	for (u32 j = threadIdx.x; j < (UFO_FTAIL_THREADS / 64) * (UFO_UPPER_MAX / 32); j += blockDim.x) (&wbits[0][0])[j] = 0;
-	(void)ugp;
 	if (threadIdx.x < 26u) lvl_dirty[threadIdx.x] = 0;
 	if (0 == threadIdx.x) created_total = 0;
 	__syncthreads();
@@ -1279,13 +1402,13 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 			const u32 tile = k * blockDim.x + threadIdx.x;
 			const u32 n4 = idOf(cell4[k]);
 			if (n4 == NONE) continue;  // (cannot happen: marked above)
-			my_touched += r[k].counts & 255u;
-			my_created += (r[k].counts >> 18) & 127u;
+			my_touched += r[k].counts & 2047u;
+			my_created += r[k].counts >> 25;
 			const u32 bits = r[k].bits, ci = (bits >> 8) & 7u;
 			if (bits & 64u) t.parent(r[k].slot) = nslot[n4];  // a new level-3 block: its parent link
 			if (bits & 128u) atomicAnd(&nflags[n4], ~(1u << (16 + ci)));
 			else if (bits & 64u) atomicOr(&nflags[n4], 1u << (16 + ci));
-			atomicMax(&top64[n4], ((unsigned long long)(ci + 1u) << 32) | tile);
+			atomicMax(&top64[n4], ((unsigned long long)(r[k].last + 1u) << 40) | ((unsigned long long)(ci + 1u) << 32) | tile);
 			if (bits & 16u) {
 				const u32 f = nflags[n4];
 				const u32 old_fl = ((f >> ci) & 1u) | (((f >> (8 + ci)) & 1u) << 1), fl = bits & 3u;
@@ -1331,7 +1454,7 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 		const bool evaluated = have && 0 != dirty[i];
 		// (all lanes run the shuffles; only the first lane of an evaluated block acts on the results)
 		const unsigned long long tt = have ? top64[i] : 0ull;
-		const u32 tc = (u32)(tt >> 32) - 1u;  // (>= 0 for an evaluated block: it has a touched child)
+		const u32 tc = ((u32)(tt >> 32) & 255u) - 1u;  // (>= 0 for an evaluated block: it has a touched child)
 		u32 lub = 0;
 		float luo = 0.f;
 		if (evaluated) {
@@ -1385,7 +1508,9 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 			// what the parent needs if this block turns out to be its highest touched child
 			out_bits[i] = ob;
 			out_pre[i] = op;
-			if (p != NONE) atomicMax(&top64[p], ((unsigned long long)(ci + 1u) << 32) | i);  // the time of the last update travels up whether or not the block was evaluated
+			// the time of the last update beneath (last scan of the batch that touched the subtree, then the child it lies
+			// under) travels up whether or not the block was evaluated
+			if (p != NONE) atomicMax(&top64[p], (tt & 0xFFFFFF0000000000ull) | ((unsigned long long)(ci + 1u) << 32) | i);
 		}
 		return evaluated;
 	};
@@ -1429,8 +1554,9 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 		t.flags(s) = nflags[i];
 		if (ncreated[i]) t.parent(s) = (npar[i] != NONE) ? nslot[npar[i]] : NONE;
 	}
-	// this kernel is the tile bitmap's last reader: leave it empty for the set's next scan
-	for (u32 j = threadIdx.x; j < nwords; j += blockDim.x) tile_bits[j] = 0;
+	// this kernel is the tile bitmaps' last reader: leave them empty for their sets' next scans
+	for (u32 b = 0; b < B; ++b)
+		for (u32 j = threadIdx.x; j < nwords; j += blockDim.x) tb.tile_bits[b][j] = 0;
 	if (0 == threadIdx.x) {
 		u32 used = __hip_atomic_load(&t.root->used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		if (created_total) {
@@ -1441,22 +1567,31 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 		ctl->dbg[20] = U | ((unsigned long long)l << 32);
 		ctl->used_now = used;  // the host's view of the table's fill
 	}
-	// The finished control block goes to the host's pinned copy from here (no read-back copy, no stream synchronisation on
-	// the host: it waits for this launch's event and reads), and the device copy returns to the start state of a scan
-	// (no upload before the set's next scan). An update that flagged an error has left above: the host falls back to copies.
+	// The finished control blocks go to the host's pinned copies from here (no read-back copy, no stream synchronisation on
+	// the host: it polls the word behind a block and reads), and the device copies return to the start state of a scan
+	// (no upload before their sets' next scans). A walk that stood back has left above: the host falls back to copies.
 	__syncthreads();
+	const u32 e = __hip_atomic_load(&ctl->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (raised during the walk: ERR_TABLE_FULL)
 	{
-		u32* dev = reinterpret_cast<u32*>(ctl);
-		u32* host = reinterpret_cast<u32*>(host_result);
 		const u32* init = reinterpret_cast<const u32*>(ctl_init);
-		const u32 e = __hip_atomic_load(&ctl->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		for (u32 w = threadIdx.x; w < sizeof(ScanCtl) / 4u; w += blockDim.x) {
-			host[w] = __hip_atomic_load(&dev[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			if (0 == e) dev[w] = init[w];  // (an error raised in this very kernel, ERR_TABLE_FULL, stays for the successor to see)
+		const u32 used = __hip_atomic_load(&ctl->used_now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		constexpr u32 W = sizeof(ScanCtl) / 4u, W_USED = offsetof(ScanCtl, used_now) / 4u, W_ERR = offsetof(ScanCtl, err) / 4u;
+		for (u32 k = threadIdx.x; k < B * W; k += blockDim.x) {
+			const u32 b = k / W, w = k % W;
+			u32* dev = reinterpret_cast<u32*>(tb.ctl[b]);
+			u32* host = reinterpret_cast<u32*>(hb.host_result[b]);
+			u32 x = __hip_atomic_load(&dev[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (W_USED == w) x = used;   // the table's fill after the walk: in every scan's block (the host reads whichever it joins)
+			if (W_ERR == w) x |= e;      // a failed walk has failed for all of its scans
+			host[w] = x;
+			if (0 == e) dev[w] = init[w];  // (an error raised in this very kernel stays for the host to read)
 		}
 	}
-	__syncthreads();  // (every thread's stores to the pinned block have been acknowledged: the barrier waits for them)
-	if (0 == threadIdx.x) __hip_atomic_store(host_done, done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);  // (the kernel's last action)
+	__syncthreads();  // (every thread's stores to the pinned blocks have been acknowledged: the barrier waits for them)
+	if (threadIdx.x < B)
+		__hip_atomic_store(reinterpret_cast<unsigned long long*>(hb.host_result[threadIdx.x] + 1), hb.done_value[threadIdx.x], __ATOMIC_RELEASE,
+		                   __HIP_MEMORY_SCOPE_SYSTEM);
+	if (0 == threadIdx.x) *own_stat = e ? 1u : 0u;  // (the kernel's last actions; the walk enqueued behind this one looks at own_stat)
 }
 
 // Stream-to-stream hand-overs without events: a one-thread kernel at the end of the producing stream's work stores the
@@ -1471,35 +1606,16 @@ __global__ void k_signal(unsigned long long* flag, unsigned long long value)
 // (The wait is bounded: a tool that serialises kernels across streams -- rocprofv3 --pmc does -- would keep the producer
 // from ever running while this wave spins. The host does not use gates when it sees such a tool, ufomap_hip.hip:
 // useGates; should one slip through, the gate gives up after ~2 s and flags the scan, which then leaves the map alone.)
-__global__ void k_gate(const unsigned long long* flag, unsigned long long value, ScanCtl* ctl)
+__global__ void k_gate(const unsigned long long* flag, unsigned long long value, ScanCtl* ctl, unsigned long long max_ticks)
 {
 	const unsigned long long t0 = wall_clock64();
 	while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < value) {
 		__builtin_amdgcn_s_sleep(1);
-		if (wall_clock64() - t0 > 200000000ull) {  // 100 MHz clock
+		if (wall_clock64() - t0 > max_ticks) {  // 100 MHz clock
 			atomicOr(&ctl->err, ERR_GATE);
 			return;
 		}
 	}
 }
 
-// Stage-level output of a fast-path scan (ufomap_map_last_hits): the hit voxels' codes from the per-tile hit masks.
-__global__ __launch_bounds__(256) void k_fhitcodes(MapGeom g, FastGeo fg, const TileRec* __restrict__ recs, const uint8_t* __restrict__ tile_hmask,
-                                                   u32 scan_id, u64* __restrict__ codes, u32 cap, u32* __restrict__ count)
-{
-	const u32 lane = threadIdx.x & 63u;
-	const u32 tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-	if (tile >= fg.ntiles || recs[tile].seq != scan_id || 0 == tileRecHits(recs[tile])) return;
-	u64 lk3;
-	if (!tileKey(g, fg, tile, &lk3, nullptr)) return;
-	const u32 hm = tile_hmask[(size_t)tile * 64u + lane];
-	const u64 lk1 = (lk3 << 6) | (u64)lane;
-	const u64 code0 = (lk1 ^ (1ULL << (3 * (g.L - 1)))) << 3;
-	u32 pos = waveAppendN(count, (u32)__popc(hm));
-	for (u32 c = 0; c < 8; ++c)
-		if ((hm >> c) & 1u) {
-			if (pos < cap) codes[pos] = code0 | (u64)c;
-			++pos;
-		}
-}
 }  // namespace ufo

@@ -152,13 +152,19 @@ struct ScanArgs {
 	Ingest ing{};
 };
 
+constexpr int kAlt = 7;  // hand-over sets besides the current one: up to kAlt + 1 integrations in flight
+
 struct HandOver {
 	DevBuf b_ctl, b_entries, b_hh_keys, b_in_xyz, b_in_rgb;  // b_hh_keys: hit hash, keys followed by point indices
 	// what the tree update of a fast-path scan (fast_kernels.h) reads after the scan half has moved on to the next scan
-	DevBuf b_gridM, b_part1, b_hit_code, b_first, b_tilebits;
+	DevBuf b_gridM, b_gridH, b_part1, b_hit_code, b_first, b_tilebits;
 	uint64_t seq = 0;         // running number of the integration that uses this set
-	bool first_dirty = true;  // b_first / b_tilebits are left clean by k_tile / k_ftail unless the scan stood back
+	bool first_dirty = true;  // b_first / b_tilebits are left clean by k_fcast / k_ftail unless the scan stood back
 	bool fast = false;        // the integration that uses this set runs on the fast path
+	bool deferred = false;    // ... and its tree update has not been enqueued yet: it will share a walk with the scans behind it
+	bool walk_last = false;   // ... and is the last scan of its walk
+	uint64_t walk_id = 0;     // running number of that walk (its status word: b_wstat[walk_id & 63])
+	bool hit_grid = false;    // the hits of the set's scan are in b_gridH (fast path), not in the hit list (ufomap_map_last_hits)
 	FastGeo fgeo{};
 	UpperGeo ugeo{};
 	ScanCtl* h_ctl = nullptr;  // pinned
@@ -187,7 +193,7 @@ struct ufomap_map {
 	hipStream_t xstream = nullptr;  // read-back of control blocks whose producers are known to be complete
 	bool prev_flagged = false;      // the integration joined last had flagged an error (finishPending)
 	int opt_early = 1;              // enqueue the map half before the previous integration has been joined (doInsert)
-	HandOver alt[2];                // the other hand-over sets: alt[1] = the previous integration's, alt[0] = the one before
+	HandOver alt[kAlt];             // the other hand-over sets, in no particular order: integrations are told apart by `seq`
 	u64 bound = 0;                  // (of the current set, see HandOver::bound)
 	                  // the other set of hand-over buffers
 	int async_status = UFOMAP_OK;   // first error of an integration that was joined by a later call
@@ -211,14 +217,17 @@ struct ufomap_map {
 	// per-scan buffers
 	DevBuf b_ctl, b_pt_end, b_pt_flag, b_pt_slot, b_ray_end, b_hit_code, b_hit_pt, b_hh_keys;
 	DevBuf b_part0, b_part1, b_slabs, b_hb_keys, b_hb_mask, b_hb_time;
-	DevBuf b_first, b_tilebits;         // fast path, per hand-over set (HandOver)
+	DevBuf b_first, b_tilebits, b_gridH;  // fast path, per hand-over set (HandOver)
 	UpperGeo ugeo{};
-	DevBuf b_tilerec, b_tilehm;   // fast path, map stream only
+	DevBuf b_tilerec;             // fast path, map stream only
+	DevBuf b_wstat;               // fast path: status words of the last 64 walks (0: applied; else it stood back / failed)
 	DevBuf b_blk_range;           // k_select: where each of its workgroups' rays lie in the ray list (k_cast<2>)
-	u32 fast_hits_scan = 0;  // scan_id of the fast-path update whose hit masks are in b_tilehm
-	bool fast_hits_valid = false;  // the most recent integration that finished ran on the fast path
-	FastGeo fgeo_last{};
-	bool first_dirty = true, fast = false;
+	bool first_dirty = true, fast = false, deferred = false, walk_last = false, hit_grid = false;  // (HandOver)
+	uint64_t walk_id = 0;         // (HandOver)
+	uint64_t n_walks = 0, n_walk_scans = 0, n_gate_timeouts = 0;  // fast-path walks enqueued, scans in them; stream hand-overs that timed out
+	int opt_batch_max = 8;        // scans per walk when scans queue up behind the tree update (1 = one walk per scan)
+	int opt_defer = 0;            // test aid: 1 = a scan's tree update waits for batch_max scans (or a join) whatever the map stream does
+	int opt_gate_us = 20000;      // a stream hand-over gives up after this long (and the handle stops using gates)
 	uint64_t seq = 0, latest_seq = 0;  // seq: of the integration that uses the current set; latest_seq: of the newest one enqueued
 	FastGeo fgeo{};
 	int opt_fast = 1;  // 0 = never take the fast path (fast_kernels.h)
@@ -465,6 +474,11 @@ void swapWith(ufomap_map* m, HandOver& o)
 	std::swap(m->b_in_xyz, o.b_in_xyz);
 	std::swap(m->b_in_rgb, o.b_in_rgb);
 	std::swap(m->b_gridM, o.b_gridM);
+	std::swap(m->b_gridH, o.b_gridH);
+	std::swap(m->deferred, o.deferred);
+	std::swap(m->walk_last, o.walk_last);
+	std::swap(m->walk_id, o.walk_id);
+	std::swap(m->hit_grid, o.hit_grid);
 	std::swap(m->b_part1, o.b_part1);
 	std::swap(m->b_hit_code, o.b_hit_code);
 	std::swap(m->b_first, o.b_first);
@@ -491,6 +505,7 @@ void swapWith(ufomap_map* m, HandOver& o)
 }
 
 int finishSet(ufomap_map* m, int k);
+int finishPending(ufomap_map* m);
 
 // Stream-to-stream hand-overs of the steady-state path are spinning one-wave kernels (k_gate) unless something is known
 // to serialise kernels across streams -- then a gate would wait for a producer that is not allowed to run: counter
@@ -522,7 +537,6 @@ int phaseGuard(ufomap_map* m)
 	if (m->b_tilerec.p) HIP_TRY(hipMemsetAsync(m->b_tilerec.p, 0, m->b_tilerec.cap, m->stream));
 	HIP_TRY(hipStreamSynchronize(m->stream));
 	m->scan_id = 0;
-	m->fast_hits_valid = false;
 	++m->n_phase_resets;
 	return UFOMAP_OK;
 }
@@ -548,19 +562,102 @@ hipError_t waitSetDone(ufomap_map* m, HandOver& s)
 	return hipSuccess;
 }
 
-// A new integration begins: the oldest hand-over set becomes the current one (its integration is joined first if it
-// is still pending), the set that was current becomes alt[1] (the predecessor), the old alt[1] becomes alt[0].
+// ---- the hand-over sets in flight, told apart by their integrations' running numbers (HandOver::seq) ----
+int oldestPendingAlt(const ufomap_map* m)
+{
+	int k = -1;
+	for (int i = 0; i < kAlt; ++i)
+		if (m->alt[i].pending && (k < 0 || m->alt[i].seq < m->alt[k].seq)) k = i;
+	return k;
+}
+int countPendingAlts(const ufomap_map* m)
+{
+	int n = 0;
+	for (int i = 0; i < kAlt; ++i) n += m->alt[i].pending ? 1 : 0;
+	return n;
+}
+// has the integration of set s finished? (never blocks)
+bool setDoneNow(const HandOver& s)
+{
+	bool done;
+	if (s.done_by_flag) done = *reinterpret_cast<const volatile unsigned long long*>(s.h_res + 1) == (unsigned long long)s.seq;
+	else done = hipEventQuery(s.done_ev) == hipSuccess;
+	if (done) std::atomic_thread_fence(std::memory_order_acquire);
+	return done;
+}
+int flushDeferred(ufomap_map* m);
+
+// Join the oldest integration among the other sets; if its tree update has not been enqueued yet (it was waiting for
+// company, doInsert), that happens first.
+int joinOldestAlt(ufomap_map* m)
+{
+	const int k = oldestPendingAlt(m);
+	if (k < 0) return UFOMAP_OK;
+	if (m->alt[k].deferred) {
+		const int frc = flushDeferred(m);
+		if (frc) return frc;
+	}
+	HIP_TRY(waitSetDone(m, m->alt[k]));
+	const int rc = finishSet(m, k);
+	if (rc && UFOMAP_OK == m->async_status) m->async_status = rc;
+	return rc;
+}
+
+// Every integration whose tree update has been enqueued is joined, oldest first; what still waits for company stays.
+// (After a flagged integration has been repeated everything enqueued behind it has stood back and is repeated here.)
+int joinEnqueued(ufomap_map* m)
+{
+	HIP_TRY(hipStreamSynchronize(m->stream));
+	int rc = UFOMAP_OK;
+	for (;;) {
+		const int k = oldestPendingAlt(m);
+		if (k < 0 || m->alt[k].deferred) break;
+		const int r = finishSet(m, k);
+		if (!rc) rc = r;
+	}
+	if (m->pending && !m->deferred) {
+		HIP_TRY(hipStreamSynchronize(m->stream));  // (a repeated scan above has enqueued more)
+		const int r = finishPending(m);
+		if (!rc) rc = r;
+	}
+	if (rc && UFOMAP_OK == m->async_status) m->async_status = rc;
+	return rc;
+}
+
+// Integrations that have completed are taken in (grid prediction, table fill, flagged scans repeated), oldest first,
+// without waiting for anything. Stops at the first one that flagged itself (ufomap_map::prev_flagged: the caller drains).
+int joinCompleted(ufomap_map* m)
+{
+	int rc = UFOMAP_OK;
+	m->prev_flagged = false;
+	for (;;) {
+		const int k = oldestPendingAlt(m);
+		if (k < 0 || m->alt[k].deferred || !setDoneNow(m->alt[k])) break;
+		const int r = finishSet(m, k);
+		if (!rc) rc = r;
+		if (m->prev_flagged) break;
+	}
+	if (rc && UFOMAP_OK == m->async_status) m->async_status = rc;
+	return rc;
+}
+
+// A new integration begins: it gets a hand-over set of its own. The current set is reused if its integration has been
+// joined; else the current set changes places with an idle one, or -- all sets in use -- with the oldest integration's,
+// which is joined first.
 int rotateSets(ufomap_map* m)
 {
 	int rc = phaseGuard(m);
 	if (rc) return rc;
-	if (m->alt[0].pending) {
-		(void)waitSetDone(m, m->alt[0]);
-		rc = finishSet(m, 0);
-		if (rc && UFOMAP_OK == m->async_status) m->async_status = rc;
+	if (!m->pending) return UFOMAP_OK;
+	int k = -1;
+	for (int i = 0; i < kAlt && k < 0; ++i)
+		if (!m->alt[i].pending) k = i;
+	if (k < 0) {
+		k = oldestPendingAlt(m);
+		rc = joinOldestAlt(m);
+		if (m->alt[k].pending) return rc ? rc : fail(UFOMAP_ERR_DEVICE, "no hand-over set could be freed");
 	}
-	swapWith(m, m->alt[0]);
-	std::swap(m->alt[0], m->alt[1]);
+	swapWith(m, m->alt[k]);
 	return rc;
 }
 
@@ -949,7 +1046,7 @@ int mapPhase(ufomap_map* m, unsigned depth, const uint8_t* d_rgb, u64 capH, u64 
              u64 extra_used = 0, u32 headroom_scans = 0)
 {
 	const float miss = (float)(m->g.miss_log / double((2.0 * depth) + 1));  // OMB:311
-	m->fast_hits_valid = false;
+	m->hit_grid = false;
 	Entry* ent_h = m->b_entries.as<Entry>();
 	Entry* ent_m = ent_h + capH;
 	int rc = sizeTable(m, ent_h, capH, m->gridH.nb, ent_m, capM, m->gridM.nb, depth, merged, extra_used, nullptr != prev, headroom_scans);
@@ -1021,6 +1118,8 @@ bool fastEligible(const ufomap_map* m, const Grid& gr, unsigned depth, int simpl
 	return makeUpperGeo(fg, m->g.L, &ug) <= UFO_UPPER_MAX;
 }
 
+unsigned long long gateTicks(const ufomap_map* m) { return (unsigned long long)std::max(100, m->opt_gate_us) * 100ull; }  // wall_clock64: 100 MHz
+
 // scan half on the scan stream: first-point array, rays, merged bit grid + tile bitmap
 int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, size_t n, double max_range, int discrete)
 {
@@ -1050,6 +1149,8 @@ int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, si
 		m->first_dirty = false;
 	}
 	HIP_TRY(m->b_gridM.reserve(fg.gr.bytes));
+	HIP_TRY(m->b_gridH.reserve(fg.gr.bytes));  // hit voxels, the ray grid's layout: zeroed by k_fhits, marked by k_fcast, read by k_tile
+	m->hit_grid = true;
 	HIP_TRY(m->b_hit_code.reserve(n * sizeof(PointRec)));  // (per-point records of the head loop: k_fhits -> k_fcast)
 	ScanCtl init;
 	memset(&init, 0, sizeof(init));
@@ -1076,16 +1177,16 @@ int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, si
 		ProfScope ps(m, "k_fhits");
 		if (discrete)
 			hipLaunchKernelGGL(k_fhits<true>, gp, dim3(256), 0, m->cs, m->g, fg, sensor, d_xyz, N, max_range, 0u, m->b_first.as<u32>(),
-			                   m->b_part1.as<BoxPartial>(), ctl, m->ing, m->b_hit_code.as<PointRec>());
+			                   m->b_part1.as<BoxPartial>(), ctl, m->ing, m->b_hit_code.as<PointRec>(), m->b_gridH.as<uint4>(), (u32)(fg.gr.bytes >> 4));
 		else
 			hipLaunchKernelGGL(k_fhits<false>, gp, dim3(256), 0, m->cs, m->g, fg, sensor, d_xyz, N, max_range, 0u, m->b_first.as<u32>(),
-			                   m->b_part1.as<BoxPartial>(), ctl, m->ing, m->b_hit_code.as<PointRec>());
+			                   m->b_part1.as<BoxPartial>(), ctl, m->ing, m->b_hit_code.as<PointRec>(), m->b_gridH.as<uint4>(), (u32)(fg.gr.bytes >> 4));
 	}
 	// stream-to-stream hand-overs of this path: k_signal / k_gate (fast_kernels.h), not events
 	m->gates = useGates(m);
 	if (m->gates) {
 		hipLaunchKernelGGL(k_signal, dim3(1), dim3(1), 0, m->pstream, m->sig_prep, (unsigned long long)m->seq);
-		hipLaunchKernelGGL(k_gate, dim3(1), dim3(1), 0, m->sstream, m->sig_prep, (unsigned long long)m->seq, ctl);
+		hipLaunchKernelGGL(k_gate, dim3(1), dim3(1), 0, m->sstream, m->sig_prep, (unsigned long long)m->seq, ctl, gateTicks(m));
 	} else {
 		HIP_TRY(hipEventRecord(m->prep_ev, m->pstream));
 		HIP_TRY(hipStreamWaitEvent(m->sstream, m->prep_ev, 0));
@@ -1102,10 +1203,10 @@ int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, si
 		const size_t lds = (size_t)fg.gr.bytes + UFO_CAST_LDS_EXTRA;
 		if (discrete)
 			hipLaunchKernelGGL(k_fcast<true>, dim3(nwg), dim3(512), lds, m->cs, m->g, fg, sensor, d_xyz, N, max_range, 0u, m->b_first.as<u32>(),
-			                   m->b_ray_end.as<D3>(), cap_wg, m->b_slabs.as<u32>(), (u32)std::max(8, m->opt_cast_k), ctl, ctl, sp, m->ing, m->b_hit_code.as<PointRec>());
+			                   m->b_ray_end.as<D3>(), cap_wg, m->b_slabs.as<u32>(), (u32)std::max(8, m->opt_cast_k), ctl, ctl, sp, m->ing, m->b_hit_code.as<PointRec>(), m->b_gridH.as<u32>());
 		else
 			hipLaunchKernelGGL(k_fcast<false>, dim3(nwg), dim3(512), lds, m->cs, m->g, fg, sensor, d_xyz, N, max_range, 0u, m->b_first.as<u32>(),
-			                   m->b_ray_end.as<D3>(), cap_wg, m->b_slabs.as<u32>(), (u32)std::max(8, m->opt_cast_k), ctl, ctl, sp, m->ing, m->b_hit_code.as<PointRec>());
+			                   m->b_ray_end.as<D3>(), cap_wg, m->b_slabs.as<u32>(), (u32)std::max(8, m->opt_cast_k), ctl, ctl, sp, m->ing, m->b_hit_code.as<PointRec>(), m->b_gridH.as<u32>());
 	}
 	{
 		ProfScope ps(m, "k_fmerge");
@@ -1119,48 +1220,149 @@ int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, si
 	return UFOMAP_OK;
 }
 
-// map half on the map stream. prev / extra_used as mapPhase: returns 1 (nothing enqueued) if the table might have to
-// grow while another update is in flight.
-int fastMapPhase(ufomap_map* m, const ScanCtl* prev, u64 extra_used, u32 headroom_scans)
+// What a walk needs from a hand-over set, wherever the set is (k < 0: the current set, whose members live in the map object).
+struct SetPtrs {
+	DevBuf *b_ctl, *b_gridM, *b_gridH, *b_tilebits;
+	ScanCtl** h_res;
+	uint64_t *seq, *walk_id;
+	u64* bound;
+	bool *pending, *deferred, *walk_last, *done_by_flag;
+	FastGeo* fgeo;
+	unsigned long long** sig_scan;
+};
+SetPtrs ptrsOf(ufomap_map* m, int k)
 {
-	const FastGeo& fg = m->fgeo;
-	m->scan_new_bound = fastBound(m, fg.gr);
+	if (k < 0)
+		return SetPtrs{&m->b_ctl, &m->b_gridM, &m->b_gridH, &m->b_tilebits, &m->h_res, &m->seq, &m->walk_id, &m->bound, &m->pending, &m->deferred,
+		               &m->walk_last, &m->done_by_flag, &m->fgeo, &m->sig_scan};
+	HandOver& a = m->alt[k];
+	return SetPtrs{&a.b_ctl, &a.b_gridM, &a.b_gridH, &a.b_tilebits, &a.h_res, &a.seq, &a.walk_id, &a.bound, &a.pending, &a.deferred,
+	               &a.walk_last, &a.done_by_flag, &a.fgeo, &a.sig_scan};
+}
+
+// The tree update of a run of fast-path scans that share a ray grid -- ONE walk (k_tile + k_ftail) on the map stream,
+// the scans applied in order (fast_kernels.h). run[0 .. nrun): the scans' sets, oldest first (index into alt, < 0: the
+// current set); their scan halves have been enqueued on the scan stream.
+int enqueueWalk(ufomap_map* m, const int* run, int nrun)
+{
+	const SetPtrs last = ptrsOf(m, run[nrun - 1]);
+	const FastGeo fg = *last.fgeo;
+	const u64 bound = fastBound(m, fg.gr);  // (every block of the grid new: no more, however many scans walk it)
+	auto inRun = [&](int k) {
+		for (int i = 0; i < nrun; ++i)
+			if (run[i] == k) return true;
+		return false;
+	};
+	// The update enqueued just before this one, if it has not been joined: this walk looks at its status when it starts and
+	// stands back if that one did (everything flagged is then repeated in order when it is joined).
+	const u32* prev_stat = nullptr;
+	u64 in_flight = 0;
+	auto scanQueue = [&]() {
+		prev_stat = nullptr;
+		in_flight = 0;
+		int pk = -1;
+		for (int i = 0; i < kAlt; ++i) {
+			const HandOver& a = m->alt[i];
+			if (!a.pending || a.deferred || inRun(i)) continue;
+			in_flight += a.bound;
+			if (pk < 0 || a.seq > m->alt[pk].seq) pk = i;
+		}
+		if (pk >= 0)
+			prev_stat = m->alt[pk].done_by_flag ? m->b_wstat.as<u32>() + (m->alt[pk].walk_id & 63u) : &m->alt[pk].b_ctl.as<ScanCtl>()->err;
+	};
+	scanQueue();
+	m->cs = m->stream;
 	{
+		// node table: room for what this walk can create on top of what the updates in flight can
 		const u64 cap = (u64)m->t.mask + 1;
-		const u64 extra = extra_used + (u64)headroom_scans * m->scan_new_bound;
-		if ((m->used_est + extra + m->scan_new_bound) * 5 > cap * 3) {
-			if (prev) return 1;
-			const u64 want = (m->used_est + extra + m->scan_new_bound) * 2;
-			if (want > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
-			int rc = growTable(m, nextPow2(want));
-			if (rc) return rc;
+		if ((m->used_est + in_flight + bound) * 5 > cap * 3) {
+			if (in_flight) {
+				const int jrc = joinEnqueued(m);  // (the table cannot be exchanged under an update in flight)
+				if (jrc < 0) return jrc;
+				scanQueue();
+			}
+			if ((m->used_est + bound) * 5 > ((u64)m->t.mask + 1) * 3) {
+				const u64 want = (m->used_est + 3 * bound) * 2;  // (room for the walks that will be enqueued behind this one, too)
+				if (want > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
+				m->cs = m->stream;
+				const int rc = growTable(m, nextPow2(want));
+				if (rc) return rc;
+			}
 		}
 	}
+	m->scan_new_bound = bound;
 	m->scan_id += 1;
-	m->h_res->err = ERR_NOT_STORED;
-	*reinterpret_cast<volatile unsigned long long*>(m->h_res + 1) = 0ull;  // k_ftail's "done" word
+	const uint64_t wid = ++m->n_walks;
+	m->n_walk_scans += (uint64_t)nrun;
 	HIP_TRY(m->b_tilerec.reserve((size_t)UFO_FAST_MAX_TILES * sizeof(TileRec)));
-	HIP_TRY(m->b_tilehm.reserve((size_t)UFO_FAST_MAX_TILES * 64));
-	m->fast_hits_scan = m->scan_id;
-	m->fast_hits_valid = true;
-	m->fgeo_last = fg;
-	ScanCtl* ctl = m->b_ctl.as<ScanCtl>();
+	TileBatch tb{};
+	TailBatch hb{};
+	tb.B = (u32)nrun;
+	for (int i = 0; i < nrun; ++i) {
+		const SetPtrs p = ptrsOf(m, run[i]);
+		tb.gridM[i] = p.b_gridM->as<u32>();
+		tb.gridH[i] = p.b_gridH->as<u32>();
+		tb.tile_bits[i] = p.b_tilebits->as<u32>();
+		tb.ctl[i] = p.b_ctl->as<ScanCtl>();
+		hb.host_result[i] = *p.h_res;
+		hb.done_value[i] = (unsigned long long)*p.seq;
+		(*p.h_res)->err = ERR_NOT_STORED;
+		*reinterpret_cast<volatile unsigned long long*>(*p.h_res + 1) = 0ull;  // k_ftail's "done" word
+		*p.pending = true;
+		*p.deferred = false;
+		*p.done_by_flag = true;
+		*p.walk_last = i + 1 == nrun;
+		*p.walk_id = wid;
+		*p.bound = (i + 1 == nrun) ? bound : 0;
+	}
+	m->cs = m->stream;
+	// the map stream waits for the scan half of the run's newest scan (the scan stream works them off in order): its
+	// signal word, or -- without gates -- the event recorded behind it
+	if (m->gates)
+		hipLaunchKernelGGL(k_gate, dim3(1), dim3(1), 0, m->stream, *last.sig_scan, (unsigned long long)*last.seq, tb.ctl[nrun - 1], gateTicks(m));
+	else
+		HIP_TRY(hipStreamWaitEvent(m->stream, m->scan_ev, 0));
 	const float miss = (float)m->g.miss_log;  // insert depth 0 (OMB:311)
+	u32* own_stat = m->b_wstat.as<u32>() + (wid & 63u);
 	{
 		ProfScope ps(m, "k_tile");
 		const u32 tw = (m->opt_tile_waves >= 1 && m->opt_tile_waves <= 4) ? (u32)m->opt_tile_waves : 4u;  // wavefronts (= tiles) per workgroup
-		hipLaunchKernelGGL(k_tile, dim3((fg.ntiles + tw - 1) / tw), dim3(64u * tw), 0, m->cs, m->t, m->g, fg, m->b_gridM.as<u32>(), m->b_first.as<u32>(),
-		                   m->b_tilebits.as<u32>(), m->b_tilerec.as<TileRec>(), m->g.hit, miss, m->scan_id, m->b_tilehm.as<uint8_t>(), ctl, prev);
+		hipLaunchKernelGGL(k_tile, dim3((fg.ntiles + tw - 1) / tw), dim3(64u * tw), 0, m->cs, m->t, m->g, fg, tb, m->b_tilerec.as<TileRec>(), m->g.hit, miss,
+		                   m->scan_id, prev_stat);
 	}
 	{
 		ProfScope ps(m, "k_ftail");
-		hipLaunchKernelGGL(k_ftail, dim3(1), dim3(UFO_FTAIL_THREADS), 0, m->cs, m->t, m->g, fg, m->ugeo, m->b_tilebits.as<u32>(),
-		                   m->b_tilerec.as<TileRec>(), m->scan_id, ctl, prev, m->h_res, m->b_ctl_init.as<ScanCtl>(), (unsigned long long)m->seq);
+		hipLaunchKernelGGL(k_ftail, dim3(1), dim3(UFO_FTAIL_THREADS), 0, m->cs, m->t, m->g, fg, tb, hb, m->b_tilerec.as<TileRec>(), m->scan_id, prev_stat,
+		                   own_stat, m->b_ctl_init.as<ScanCtl>());
 	}
 	HIP_TRY(hipGetLastError());
 	return UFOMAP_OK;
 }
 
+// Enqueue the tree updates of every scan that is still waiting for company: runs of scans on the same ray grid share a
+// walk. (The current set holds the newest integration; what waits is always the newest scans.)
+int flushDeferred(ufomap_map* m)
+{
+	int idx[kAlt + 1], n = 0;
+	for (int i = 0; i < kAlt; ++i)
+		if (m->alt[i].pending && m->alt[i].deferred) idx[n++] = i;
+	std::sort(idx, idx + n, [&](int a, int b) { return m->alt[a].seq < m->alt[b].seq; });
+	if (m->pending && m->deferred) idx[n++] = -1;
+	const int bmax = std::max(1, std::min<int>(m->opt_batch_max, (int)UFO_BATCH_MAX));
+	for (int a = 0; a < n;) {
+		int b = a + 1;
+		const FastGeo& ga = *ptrsOf(m, idx[a]).fgeo;
+		while (b < n && b - a < bmax) {
+			const FastGeo& gb = *ptrsOf(m, idx[b]).fgeo;
+			if (0 != memcmp(ga.gr.base, gb.gr.base, sizeof(ga.gr.base)) || 0 != memcmp(ga.gr.nb, gb.gr.nb, sizeof(ga.gr.nb))) break;
+			++b;
+		}
+		const int rc = enqueueWalk(m, idx + a, b - a);
+		if (rc) return rc;
+		a = b;
+	}
+	return UFOMAP_OK;
+}
 
 // Predict the ray grid of the next depth-0 scan from the box of the one just finished: the same box plus a margin
 // of up to two node blocks for sensor motion, as long as k_cast still fits its bit grid and segment queue in LDS.
@@ -1222,7 +1424,14 @@ int finishPending(ufomap_map* m)
 	// Flagged and repeatable: a speculative scan that did not fit its predicted grid (or exceeded a bound derived from
 	// it), or an update that stood back because the control block it looked at for its predecessor was flagged
 	// (ERR_PREV). Nothing of it has reached the map; repeat it now, i.e. before any later update.
-	if (m->h_ctl->err && m->args.n && (m->args.spec || (m->h_ctl->err & ERR_PREV))) return redoScan(m);
+	if (m->h_ctl->err & ERR_GATE) {
+		// A stream hand-over of the scan timed out: something keeps kernels of different streams from running side by side
+		// (a profiler serialising them, fewer hardware queues than streams). Nothing of the scan has reached the map; it
+		// is repeated below, and this handle hands over with events from now on.
+		++m->n_gate_timeouts;
+		m->opt_gates = 0;
+	}
+	if (m->h_ctl->err && m->args.n && (m->args.spec || (m->h_ctl->err & (ERR_PREV | ERR_GATE)))) return redoScan(m);
 	rc = ctlError(m);
 	if (rc) return rc;
 	m->counts[1] = m->h_ctl->n_rays;
@@ -1595,11 +1804,14 @@ int finishSet(ufomap_map* m, int k)
 // join the integrations enqueued by earlier calls, oldest first (the current set's own is not touched)
 int joinOlder(ufomap_map* m)
 {
-	if (!m->alt[0].pending && !m->alt[1].pending) return UFOMAP_OK;
+	if (oldestPendingAlt(m) < 0) return UFOMAP_OK;
+	int rc = flushDeferred(m);  // (what waited for company is enqueued now)
+	if (rc) return rc;
 	HIP_TRY(hipStreamSynchronize(m->stream));
-	int rc = finishSet(m, 0);
-	int rc1 = finishSet(m, 1);
-	if (!rc) rc = rc1;
+	for (int k; (k = oldestPendingAlt(m)) >= 0;) {
+		const int r = finishSet(m, k);
+		if (!rc) rc = r;
+	}
 	if (rc && UFOMAP_OK == m->async_status) m->async_status = rc;
 	return rc;
 }
@@ -1654,74 +1866,144 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 	int rc;
 	if (fast) {
 		rc = fastScanPhase(m, origin, d_xyz, n, max_range, discrete);
-	} else {
-		// (a host cloud is copied on the prep stream)
-		HIP_TRY(hipEventRecord(m->prep_ev, m->pstream));
-		HIP_TRY(hipStreamWaitEvent(m->sstream, m->prep_ev, 0));
-		rc = scanPhase(m, origin, d_xyz, d_rgb, n, max_range, depth, discrete, simple, early_stopping, &n_hits, &n_rays, spec);
-		if (!rc && n) rc = extractPhase(m, n_hits, n_rays, &capH, &capM, merged);
+		if (!rc && !m->gates) rc = (hipEventRecord(m->scan_ev, m->sstream) == hipSuccess) ? UFOMAP_OK : fail(UFOMAP_ERR_DEVICE, "hipEventRecord");
+		lap(0, t_begin);
+		if (rc) {
+			(void)hipStreamSynchronize(m->sstream);
+			return rc;
+		}
+		// ---- the tree update: ONE walk for as many scans as have queued up (enqueueWalk). The scan's update is enqueued
+		// right away unless two walks are already waiting on the map stream -- then it waits for company: the walk that is
+		// enqueued once one of those has finished takes every scan that has arrived by then (up to batch_max) in one go,
+		// its cost all but independent of their number. A host that feeds scans no faster than the map stream takes them
+		// never waits; anything that needs the map (wait, done, a query, a general-path update, a set to reuse) enqueues
+		// what is waiting first.
+		m->pending = true;
+		m->deferred = true;
+		m->bound = 0;
+		m->last_rgb = nullptr;
+		const auto t_map = std::chrono::steady_clock::now();
+		bool defer = false;
+		const int bmax = std::max(1, std::min<int>(m->opt_batch_max, (int)UFO_BATCH_MAX));
+		if (async && m->opt_early && !m->profiling && bmax > 1) {
+			int ndef = 1, nwalk = 0, nidle = 0;
+			for (int i = 0; i < kAlt; ++i) {
+				const HandOver& a = m->alt[i];
+				if (!a.pending) ++nidle;
+				else if (a.deferred) ++ndef;
+				else if ((!a.done_by_flag || a.walk_last) && !setDoneNow(a)) ++nwalk;
+			}
+			defer = ndef < bmax && nidle > 0 && (m->opt_defer || nwalk >= 2);
+		}
+		if (!defer) {
+			rc = flushDeferred(m);
+			if (rc) return rc;
+		}
+		lap(1, t_map);
+		int prc = UFOMAP_OK;
+		if (!async) {
+			prc = joinOlder(m);  // (occupancy_map_base.h:315: the previous integrations are joined first)
+			HIP_TRY(hipStreamSynchronize(m->stream));
+			rc = finishPending(m);
+			if (3 == m->opt_fast) {
+				// debugging aid: the scratch arrays must have been left clean
+				std::vector<u32> h(m->b_first.cap / 4), tbw(m->b_tilebits.cap / 4);
+				(void)hipMemcpy(h.data(), m->b_first.p, h.size() * 4, hipMemcpyDeviceToHost);
+				(void)hipMemcpy(tbw.data(), m->b_tilebits.p, tbw.size() * 4, hipMemcpyDeviceToHost);
+				size_t bad = 0, badt = 0;
+				for (u32 v : h) bad += v != 0xFFFFFFFFu;
+				for (u32 v : tbw) badt += v != 0u;
+				fprintf(stderr, "[fast dbg] first[]: %zu of %zu entries not clean, tile bitmap: %zu words not clean, dirty flag %d\n", bad, h.size(), badt,
+				        (int)m->first_dirty);
+			}
+			return rc ? rc : prc;
+		}
+		const auto t_join = std::chrono::steady_clock::now();
+		prc = joinCompleted(m);
+		if (m->prev_flagged) {
+			// an integration that was joined had flagged itself (and has been repeated, or has failed): every walk enqueued
+			// behind it stood back. Drain in order -- each is repeated by its own join -- before anything new is enqueued.
+			const int drc = joinEnqueued(m);
+			if (!prc) prc = drc;
+			m->prev_flagged = false;
+		}
+		lap(2, t_join);
+		return prc;
 	}
+	// ---- the general path ----
+	m->fast = false;
+	m->deferred = false;
+	{
+		// its tree update is enqueued by this call: what waits for company goes first; at most two older integrations stay in flight
+		const int frc = flushDeferred(m);
+		if (frc) return frc;
+		while (countPendingAlts(m) > 2) (void)joinOldestAlt(m);
+	}
+	// (a host cloud is copied on the prep stream)
+	HIP_TRY(hipEventRecord(m->prep_ev, m->pstream));
+	HIP_TRY(hipStreamWaitEvent(m->sstream, m->prep_ev, 0));
+	rc = scanPhase(m, origin, d_xyz, d_rgb, n, max_range, depth, discrete, simple, early_stopping, &n_hits, &n_rays, spec);
+	if (!rc && n) rc = extractPhase(m, n_hits, n_rays, &capH, &capM, merged);
 	lap(0, t_begin);
-	auto mapHalf = [&](const ScanCtl* prev, u64 extra_used, u32 headroom) {
-		return fast ? fastMapPhase(m, prev, extra_used, headroom) : mapPhase(m, depth, d_rgb, capH, capM, merged, prev, extra_used, headroom);
-	};
-	const bool gated = fast && m->gates;  // the hand-over to the map stream is a signal word, not an event
-	if (!rc && n && !gated) rc = (hipEventRecord(m->scan_ev, m->sstream) == hipSuccess) ? UFOMAP_OK : fail(UFOMAP_ERR_DEVICE, "hipEventRecord");
-	// the map stream waits for this scan's scan half (fast path: its signal word; general path: the event)
-	auto waitScanHalf = [&]() -> hipError_t {
-		if (!gated) return hipStreamWaitEvent(m->stream, m->scan_ev, 0);
-		hipLaunchKernelGGL(k_gate, dim3(1), dim3(1), 0, m->stream, m->sig_scan, (unsigned long long)m->seq, m->b_ctl.as<ScanCtl>());
-		return hipSuccess;
-	};
-	// ... and its end is announced by k_ftail's word in pinned memory (fast path) or by the set's event
-	auto recordDone = [&]() -> hipError_t {
-		m->done_by_flag = fast;
-		return fast ? hipSuccess : hipEventRecord(m->done_ev, m->stream);
-	};
+	auto mapHalf = [&](const ScanCtl* prev, u64 extra_used, u32 headroom) { return mapPhase(m, depth, d_rgb, capH, capM, merged, prev, extra_used, headroom); };
+	if (!rc && n) rc = (hipEventRecord(m->scan_ev, m->sstream) == hipSuccess) ? UFOMAP_OK : fail(UFOMAP_ERR_DEVICE, "hipEventRecord");
+	// the update enqueued just before this one, if it has not been joined
+	int pk = -1;
+	u64 in_flight = 0;
+	for (int i = 0; i < kAlt; ++i) {
+		if (!m->alt[i].pending) continue;
+		in_flight += m->alt[i].bound;
+		if (pk < 0 || m->alt[i].seq > m->alt[pk].seq) pk = i;
+	}
 	// ---- early map half: enqueue THIS scan's tree update behind the previous one BEFORE that one has been joined,
 	// so that the updates run back to back on the map stream and the next call can start its scan half while two
-	// updates are still in flight (three hand-over sets). The first kernel looks at the predecessor's error flags:
-	// if it flagged itself, this update stands back too (ERR_PREV, which cascades) and everything flagged is re-run
-	// in order when it is joined.
+	// updates are still in flight. The first kernel looks at the predecessor's error flags: if it flagged itself, this
+	// update stands back too (ERR_PREV, which cascades) and everything flagged is re-run in order when it is joined.
 	bool early = false;
-	if (!rc && n && async && merged && m->opt_early && m->alt[1].pending && !m->profiling) {
+	if (!rc && n && async && merged && m->opt_early && pk >= 0 && !m->profiling) {
 		m->cs = m->stream;
-		HIP_TRY(waitScanHalf());
+		HIP_TRY(hipStreamWaitEvent(m->stream, m->scan_ev, 0));
 		m->last_rgb = d_rgb;
-		const u64 in_flight = m->alt[1].bound + (m->alt[0].pending ? m->alt[0].bound : 0);
 		const auto t_map = std::chrono::steady_clock::now();
-		const int erc = mapHalf(m->alt[1].b_ctl.as<ScanCtl>(), in_flight, 0u);
+		const int erc = mapHalf(m->alt[pk].b_ctl.as<ScanCtl>(), in_flight, 0u);
 		if (erc < 0) return erc;
 		early = 0 == erc;  // 1: the table might have to grow: join first (below)
-		if (early) HIP_TRY(recordDone());
+		if (early) {
+			m->done_by_flag = false;
+			HIP_TRY(hipEventRecord(m->done_ev, m->stream));
+		}
 		lap(1, t_map);
 	}
 	int prc = UFOMAP_OK;
 	if (early) {
-		// join the integration before the previous one (long finished as a rule): the previous one and this one keep running
+		// join all but the previous integration (long finished as a rule): the previous one and this one keep running
 		m->prev_flagged = false;
-		if (m->alt[0].pending) {
-			const auto t_join = std::chrono::steady_clock::now();
-			HIP_TRY(waitSetDone(m, m->alt[0]));
-			prc = finishSet(m, 0);
-			if (prc && UFOMAP_OK == m->async_status) m->async_status = prc;
-			lap(2, t_join);
+		const auto t_join = std::chrono::steady_clock::now();
+		while (countPendingAlts(m) > 1 && !m->prev_flagged) {
+			const int r = joinOldestAlt(m);
+			if (!prc) prc = r;
 		}
+		lap(2, t_join);
 		if (m->prev_flagged) {
 			// it had flagged itself (and has been repeated, or has failed): the previous update and this one stood back.
-			// Drain in order: the previous one is repeated by its own join, then this one's tree update is enqueued again.
+			// Drain in order: the previous ones are repeated by their own joins, then this one's tree update is enqueued again.
 			HIP_TRY(hipStreamSynchronize(m->stream));
-			const int prc1 = finishSet(m, 1);
-			if (!prc) prc = prc1;
-			if (prc1 && UFOMAP_OK == m->async_status) m->async_status = prc1;
+			for (int k; (k = oldestPendingAlt(m)) >= 0;) {
+				const int r = finishSet(m, k);
+				if (!prc) prc = r;
+				if (r && UFOMAP_OK == m->async_status) m->async_status = r;
+			}
 			HIP_TRY(hipStreamSynchronize(m->stream));
 			hipLaunchKernelGGL(k_ctl_clear, dim3(1), dim3(1), 0, m->stream, m->b_ctl.as<ScanCtl>(), (u32)ERR_PREV);
 			m->cs = m->stream;
 			rc = mapHalf(nullptr, 0, 0u);
 			if (rc) return rc;
-			HIP_TRY(recordDone());
+			m->done_by_flag = false;
+			HIP_TRY(hipEventRecord(m->done_ev, m->stream));
+			m->prev_flagged = false;
 		}
 		m->pending = true;
+		m->deferred = false;
 		m->bound = m->scan_new_bound;
 		return prc;
 	}
@@ -1733,31 +2015,21 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 	}
 	// ---- map half on the map stream, after the scan half of THIS scan ----
 	m->cs = m->stream;
-	HIP_TRY(waitScanHalf());
+	HIP_TRY(hipStreamWaitEvent(m->stream, m->scan_ev, 0));
 	m->last_rgb = d_rgb;
 	rc = mapHalf(nullptr, 0, (async && merged && m->opt_early) ? 2u : 0u);
 	if (rc) return rc;
 	HIP_TRY(hipGetLastError());
 	m->pending = true;
+	m->deferred = false;
 	m->bound = m->scan_new_bound;
 	if (!async) {
 		HIP_TRY(hipStreamSynchronize(m->stream));
-		const bool was_fast = fast;
 		rc = finishPending(m);
-		if (was_fast && 3 == m->opt_fast) {
-			// debugging aid: the scratch arrays must have been left clean
-			std::vector<u32> h(m->b_first.cap / 4), tb(m->b_tilebits.cap / 4);
-			(void)hipMemcpy(h.data(), m->b_first.p, h.size() * 4, hipMemcpyDeviceToHost);
-			(void)hipMemcpy(tb.data(), m->b_tilebits.p, tb.size() * 4, hipMemcpyDeviceToHost);
-			size_t bad = 0, badt = 0;
-			for (u32 v : h) bad += v != 0xFFFFFFFFu;
-			for (u32 v : tb) badt += v != 0u;
-			fprintf(stderr, "[fast dbg] first[]: %zu of %zu entries not clean, tile bitmap: %zu words not clean, dirty flag %d\n", bad, h.size(), badt,
-			        (int)m->first_dirty);
-		}
 		return rc ? rc : prc;
 	}
-	HIP_TRY(recordDone());
+	m->done_by_flag = false;
+	HIP_TRY(hipEventRecord(m->done_ev, m->stream));
 	return prc;
 }
 // Repeat, synchronously and with the boxes read back, the integration whose hand-over set is current: it had been
@@ -1869,29 +2141,24 @@ ufomap_map* ufomap_map_create(double resolution, unsigned depth_levels, int auto
 	          hipStreamCreateWithFlags(&m->pstream, hipStreamNonBlocking) == hipSuccess &&
 	          hipEventCreateWithFlags(&m->prep_ev, hipEventDisableTiming) == hipSuccess &&
 	          hipEventCreateWithFlags(&m->done_ev, hipEventDisableTiming) == hipSuccess &&
-	          hipEventCreateWithFlags(&m->alt[0].done_ev, hipEventDisableTiming) == hipSuccess &&
-	          hipEventCreateWithFlags(&m->alt[1].done_ev, hipEventDisableTiming) == hipSuccess &&
 	          hipEventCreateWithFlags(&m->scan_ev, hipEventDisableTiming) == hipSuccess &&
 	          hipEventCreateWithFlags(&m->copy_ev, hipEventDisableTiming) == hipSuccess &&
 	          hipHostMalloc((void**)&m->h_ctl, sizeof(ScanCtl) + 64) == hipSuccess &&
-	          hipHostMalloc((void**)&m->alt[0].h_ctl, sizeof(ScanCtl) + 64) == hipSuccess &&
-	          hipHostMalloc((void**)&m->alt[1].h_ctl, sizeof(ScanCtl) + 64) == hipSuccess &&
 	          hipHostMalloc((void**)&m->h_res, sizeof(ScanCtl) + 64) == hipSuccess &&
-	          hipHostMalloc((void**)&m->alt[0].h_res, sizeof(ScanCtl) + 64) == hipSuccess &&
-	          hipHostMalloc((void**)&m->alt[1].h_res, sizeof(ScanCtl) + 64) == hipSuccess &&
 	          m->b_ctl_init.reserve(sizeof(ScanCtl) + 64) == hipSuccess &&
-	          hipMalloc((void**)&m->sig_prep, 8) == hipSuccess &&
-	          hipMalloc((void**)&m->sig_scan, 8) == hipSuccess &&
-	          hipMalloc((void**)&m->alt[0].sig_prep, 8) == hipSuccess &&
-	          hipMalloc((void**)&m->alt[0].sig_scan, 8) == hipSuccess &&
-	          hipMalloc((void**)&m->alt[1].sig_prep, 8) == hipSuccess &&
-	          hipMalloc((void**)&m->alt[1].sig_scan, 8) == hipSuccess &&
-	          m->alt[0].b_ctl.reserve(sizeof(ScanCtl) + 64) == hipSuccess && m->alt[1].b_ctl.reserve(sizeof(ScanCtl) + 64) == hipSuccess &&
+	          m->b_wstat.reserve(64 * 4) == hipSuccess && hipMemset(m->b_wstat.p, 0, 64 * 4) == hipSuccess &&
+	          hipMalloc((void**)&m->sig_prep, 8) == hipSuccess && hipMemset(m->sig_prep, 0, 8) == hipSuccess &&
+	          hipMalloc((void**)&m->sig_scan, 8) == hipSuccess && hipMemset(m->sig_scan, 0, 8) == hipSuccess &&
 	          hipHostMalloc((void**)&m->h_root, sizeof(MapRoot)) == hipSuccess &&
 	          m->b_ctl.reserve(sizeof(ScanCtl) + 64) == hipSuccess && m->b_root.reserve(sizeof(MapRoot)) == hipSuccess;
-	if (ok) {
-		unsigned long long* sigs[] = {m->sig_prep, m->sig_scan, m->alt[0].sig_prep, m->alt[0].sig_scan, m->alt[1].sig_prep, m->alt[1].sig_scan};
-		for (unsigned long long* sg : sigs) ok = ok && hipMemset(sg, 0, 8) == hipSuccess;
+	for (int i = 0; ok && i < kAlt; ++i) {
+		HandOver& a = m->alt[i];
+		ok = hipEventCreateWithFlags(&a.done_ev, hipEventDisableTiming) == hipSuccess &&
+		     hipHostMalloc((void**)&a.h_ctl, sizeof(ScanCtl) + 64) == hipSuccess && hipHostMalloc((void**)&a.h_res, sizeof(ScanCtl) + 64) == hipSuccess &&
+		     hipMalloc((void**)&a.sig_prep, 8) == hipSuccess && hipMemset(a.sig_prep, 0, 8) == hipSuccess &&
+		     hipMalloc((void**)&a.sig_scan, 8) == hipSuccess && hipMemset(a.sig_scan, 0, 8) == hipSuccess &&
+		     a.b_ctl.reserve(sizeof(ScanCtl) + 64) == hipSuccess;
+		if (ok) memset(a.h_ctl, 0, sizeof(ScanCtl));
 	}
 	if (!ok) {
 		fail(UFOMAP_ERR_DEVICE, "HIP resource creation failed");
@@ -1900,8 +2167,6 @@ ufomap_map* ufomap_map_create(double resolution, unsigned depth_levels, int auto
 	}
 	m->cs = m->stream;
 	memset(m->h_ctl, 0, sizeof(ScanCtl));
-	memset(m->alt[0].h_ctl, 0, sizeof(ScanCtl));
-	memset(m->alt[1].h_ctl, 0, sizeof(ScanCtl));
 	if (hipMemset(m->b_root.p, 0, sizeof(MapRoot)) != hipSuccess || allocTable(m, 1u << 16, &m->t, &m->tb) || resetRoot(m)) {
 		ufomap_map_destroy(m);
 		return nullptr;
@@ -1937,7 +2202,7 @@ void ufomap_map_destroy(ufomap_map* m)
 	m->tb.release();
 	m->b_changes.release();
 	for (HandOver& a : m->alt) {
-		DevBuf* abufs[] = {&a.b_ctl, &a.b_entries, &a.b_hh_keys, &a.b_in_xyz, &a.b_in_rgb, &a.b_gridM, &a.b_part1, &a.b_hit_code, &a.b_first, &a.b_tilebits};
+		DevBuf* abufs[] = {&a.b_ctl, &a.b_entries, &a.b_hh_keys, &a.b_in_xyz, &a.b_in_rgb, &a.b_gridM, &a.b_gridH, &a.b_part1, &a.b_hit_code, &a.b_first, &a.b_tilebits};
 		for (DevBuf* b : abufs) b->release();
 		if (a.h_ctl) (void)hipHostFree(a.h_ctl);
 		if (a.h_res) (void)hipHostFree(a.h_res);
@@ -1954,7 +2219,7 @@ void ufomap_map_destroy(ufomap_map* m)
 	                  &m->b_ctl,     &m->b_pt_end,  &m->b_pt_flag,  &m->b_pt_slot, &m->b_ray_end, &m->b_hit_code, &m->b_hit_pt,
 	                  &m->b_hh_keys, &m->b_gridM,   &m->b_crec,    &m->b_dlist,   &m->b_rays,   &m->b_part0,   &m->b_part1,   &m->b_slabs,   &m->b_hb_keys, &m->b_hb_mask, &m->b_hb_time,   &m->b_entries, &m->b_ent_slot, &m->b_newlist,
 	                  &m->b_wl0,     &m->b_wl1,     &m->b_in_xyz,   &m->b_in_rgb,  &m->b_codes,   &m->b_dump,
-	                  &m->b_first,   &m->b_tilebits, &m->b_tilerec, &m->b_tilehm, &m->b_blk_range, &m->b_ctl_init};
+	                  &m->b_first,   &m->b_tilebits, &m->b_tilerec, &m->b_gridH, &m->b_wstat, &m->b_blk_range, &m->b_ctl_init};
 	for (DevBuf* b : bufs) b->release();
 	for (PendingEvent& pe : m->pend_ev) {
 		(void)hipEventDestroy(pe.a);
@@ -2503,36 +2768,47 @@ int ufomap_map_wait(ufomap_map* m)
 	HIP_TRY(hipSetDevice(m->device));
 	HIP_TRY(hipStreamSynchronize(m->pstream));
 	HIP_TRY(hipStreamSynchronize(m->sstream));
-	HIP_TRY(hipStreamSynchronize(m->stream));
-	int rc = finishSet(m, 0);  // oldest first
+	// what has been enqueued first, oldest first (a flagged integration is repeated before anything newer is applied) ...
+	int rc = joinEnqueued(m);
 	{
-		const int rc1 = finishSet(m, 1);
+		// ... then the scans whose tree update was still waiting for company
+		const int frc = flushDeferred(m);
+		if (!rc) rc = frc;
+		const int rc1 = joinEnqueued(m);
 		if (!rc) rc = rc1;
-		const int rc2 = finishPending(m);
-		if (!rc) rc = rc2;
 	}
 	if (UFOMAP_OK == rc && UFOMAP_OK != m->async_status) {
 		rc = m->async_status;
 		g_err = "an earlier asynchronous integration failed";
 	}
 	m->async_status = UFOMAP_OK;
+	m->prev_flagged = false;
 	return rc;
 }
 
 int ufomap_map_done(ufomap_map* m)
 {
 	if (!m) return fail(UFOMAP_ERR_INVALID, "null map");
-	// the map stream runs the integrations in order: the most recent pending one is the last to finish
+	// nothing finishes that has not been enqueued: the tree updates that were waiting for company go first
 	{
-		// (fast path: the integration's end is a word in pinned memory, not an event)
-		const bool by_flag = m->pending ? m->done_by_flag : (m->alt[1].pending ? m->alt[1].done_by_flag : (m->alt[0].pending ? m->alt[0].done_by_flag : false));
-		if (by_flag) {
-			const ScanCtl* hr = m->pending ? m->h_res : (m->alt[1].pending ? m->alt[1].h_res : m->alt[0].h_res);
-			const uint64_t sq = m->pending ? m->seq : (m->alt[1].pending ? m->alt[1].seq : m->alt[0].seq);
-			return *reinterpret_cast<const volatile unsigned long long*>(hr + 1) == (unsigned long long)sq ? 1 : 0;
-		}
+		const int frc = flushDeferred(m);
+		if (frc) return frc;
 	}
-	hipEvent_t ev = m->pending ? m->done_ev : (m->alt[1].pending ? m->alt[1].done_ev : (m->alt[0].pending ? m->alt[0].done_ev : nullptr));
+	// the map stream runs the integrations in order: the most recent pending one is the last to finish
+	const HandOver* newest = nullptr;
+	if (!m->pending)
+		for (int i = 0; i < kAlt; ++i)
+			if (m->alt[i].pending && (!newest || m->alt[i].seq > newest->seq)) newest = &m->alt[i];
+	const bool any = m->pending || newest;
+	if (!any) return 1;
+	const bool by_flag = m->pending ? m->done_by_flag : newest->done_by_flag;
+	if (by_flag) {
+		// (fast path: the integration's end is a word in pinned memory, not an event)
+		const ScanCtl* hr = m->pending ? m->h_res : newest->h_res;
+		const uint64_t sq = m->pending ? m->seq : newest->seq;
+		return *reinterpret_cast<const volatile unsigned long long*>(hr + 1) == (unsigned long long)sq ? 1 : 0;
+	}
+	hipEvent_t ev = m->pending ? m->done_ev : newest->done_ev;
 	if (!ev) return 1;
 	hipError_t e = hipEventQuery(ev);
 	if (e == hipSuccess) return 1;
@@ -2738,13 +3014,14 @@ size_t ufomap_map_last_hits(ufomap_map* m, uint64_t* codes, size_t cap)
 	if (!m || ufomap_map_wait(m) < 0) return (size_t)-1;
 	size_t n = (size_t)m->counts[3];
 	std::vector<uint64_t> h(n);
-	if (n && m->fast_hits_valid) {
-		// the last integration ran on the fast path: rebuild the codes from the tiles' hit masks
+	if (n && m->hit_grid) {
+		// the last integration ran on the fast path: its hit voxels are the set bits of the scan's hit grid
 		ScanCtl* ctl = m->b_ctl.as<ScanCtl>();
 		if (m->b_hit_code.reserve(n * 8) != hipSuccess || hipMemsetAsync(&ctl->n_codes, 0, 4, m->stream) != hipSuccess) return (size_t)-1;
-		hipLaunchKernelGGL(k_fhitcodes, dim3((m->fgeo_last.ntiles + 3) / 4), dim3(256), 0, m->stream, m->g, m->fgeo_last, m->b_tilerec.as<TileRec>(),
-		                   m->b_tilehm.as<uint8_t>(), m->fast_hits_scan, m->b_hit_code.as<u64>(), (u32)n, &ctl->n_codes);
+		hipLaunchKernelGGL(k_grid_codes_bits, gridFor(m->fgeo.gr.bytes >> 2, 256, 8192), dim3(256), 0, m->stream, m->g, m->fgeo.gr, m->b_gridH.as<u32>(),
+		                   m->b_hit_code.as<u64>(), (u32)n, ctl);
 		if (hipStreamSynchronize(m->stream) != hipSuccess) return (size_t)-1;
+		(void)hipMemsetAsync(&ctl->n_codes, 0, 4, m->stream);  // (the fast path's start state of the block)
 	}
 	if (n && hipMemcpy(h.data(), m->b_hit_code.p, n * 8, hipMemcpyDeviceToHost) != hipSuccess) return (size_t)-1;
 	std::sort(h.begin(), h.end());
@@ -3819,6 +4096,12 @@ int ufomap_map_set_option(ufomap_map* m, const char* key, long long value)
 		m->opt_tile_waves = (int)value;
 	} else if (0 == strcmp(key, "gates")) {
 		m->opt_gates = value ? 1 : 0;
+	} else if (0 == strcmp(key, "batch_max")) {
+		m->opt_batch_max = (int)std::max<long long>(1, std::min<long long>(value, (long long)UFO_BATCH_MAX));
+	} else if (0 == strcmp(key, "defer")) {
+		m->opt_defer = value ? 1 : 0;
+	} else if (0 == strcmp(key, "gate_us")) {
+		m->opt_gate_us = (int)std::max<long long>(100, std::min<long long>(value, 10000000));
 	} else if (0 == strcmp(key, "sparse_set")) {
 		m->opt_sparse_set = value ? 1 : 0;
 	} else if (0 == strcmp(key, "phase_limit")) {
@@ -3858,6 +4141,9 @@ int ufomap_map_debug(ufomap_map* m, uint64_t* out, int n)
 	if (n > 62) out[62] = m->n_spec;       // scans enqueued on a predicted grid
 	if (n > 63) out[63] = m->n_spec_redo;  // ... of which had to be repeated
 	if (n > 61) out[61] = m->n_fast;       // scans enqueued on the fast path (fast_kernels.h)
+	if (n > 60) out[60] = m->n_walks;      // ... walks of the tree that applied them (one walk takes every scan that has queued up)
+	if (n > 59) out[59] = m->n_walk_scans; // ... scans in those walks
+	if (n > 58) out[58] = m->n_gate_timeouts;  // stream hand-overs that timed out (the handle uses events from then on)
 	if (n > 51) out[51] = m->n_phase_resets;  // phaseGuard
 	for (int k = 0; k < 4 && 52 + k < n; ++k) out[52 + k] = m->host_ns[k];  // host time inside doInsert (ns): scan enqueue, map enqueue, join, total
 	return rc;
