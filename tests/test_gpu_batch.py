@@ -148,3 +148,32 @@ def test_many_handles_keep_their_maps_apart():
     for k, (g, o) in enumerate(maps):
         g.insertPointCloudWait()
         _assert_same_map(g, o, f"map {k}")
+
+
+@pytest.mark.parametrize("sect_box,cloud", [(4096, "lidar"), (8192, "random"), (36 << 10, "random"), (36 << 10, "lidar")])
+def test_sector_ray_kernel_budgets_and_unordered_clouds(sect_box, cloud):
+    """The fast path's ray kernel keeps a workgroup's SECTOR of the ray grid in LDS: with a tiny LDS budget the stretches are
+    halved into several passes, and rays that still do not fit (or an unordered cloud) mark the global grid directly -- same
+    cells, same step counts, same map as the oracle and as the whole-grid form (k_fcast + k_fmerge)."""
+    from ufomap_amd import scans
+    g, o = _maps(resolution=0.16)
+    g2, _ = _maps(resolution=0.16)
+    g.set_option("sect_box", sect_box)
+    g.set_option("cast_sector", 2)
+    g2.set_option("cast_sector", 0)
+    for i in range(6):
+        if cloud == "lidar":
+            origin, xyz, _ = scans.lidar64(beams=32, azimuths=1024, origin=scans.lidar_pose(i % 2), seed=60 + i)
+        else:
+            origin, xyz, _ = scans.random_cloud(20000, seed=70 + i, extent=7.0)
+        for m in (g, g2):
+            _insert(m, origin, xyz, 9.0, bool(i & 1), False)
+        o.insert(origin, xyz, max_range=9.0, discrete=bool(i & 1))
+        _assert_same_map(g, o, f"scan {i}")
+        assert g.last_counts()["steps"] == o.last_steps() == g2.last_counts()["steps"]
+        assert np.array_equal(g.last_hits(), o.last_hits()) and np.array_equal(g.last_misses(), o.last_misses())
+        assert g.digest() == g2.digest()
+    d = g.debug()
+    assert d[61] >= 4, "the scans did not take the fast path"
+    if sect_box <= 8192:
+        assert d[57] > 0, "no sector had to mark the global grid directly (is the budget honoured?)"

@@ -228,6 +228,10 @@ struct ufomap_map {
 	int opt_batch_max = 8;        // scans per walk when scans queue up behind the tree update (1 = one walk per scan)
 	int opt_defer = 0;            // test aid: 1 = a scan's tree update waits for batch_max scans (or a join) whatever the map stream does
 	int opt_gate_us = 20000;      // a stream hand-over gives up after this long (and the handle stops using gates)
+	int opt_cast_sector = 1;      // fast path's ray kernel: 1 = sector form (k_fsect), 0 = whole grid per workgroup + slab merge (k_fcast, k_fmerge)
+	int opt_sect_box = 36 << 10;  // ... LDS budget of a sector's box of the ray grid (bytes)
+	DevBuf b_sect;                // k_fsect's per-workgroup partial results + ticket word (scan stream only)
+	uint64_t n_sect_direct = 0;   // k_fsect passes that had to mark the global grid directly (boxes beyond the LDS budget)
 	uint64_t seq = 0, latest_seq = 0;  // seq: of the integration that uses the current set; latest_seq: of the newest one enqueued
 	FastGeo fgeo{};
 	int opt_fast = 1;  // 0 = never take the fast path (fast_kernels.h)
@@ -1177,10 +1181,10 @@ int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, si
 		ProfScope ps(m, "k_fhits");
 		if (discrete)
 			hipLaunchKernelGGL(k_fhits<true>, gp, dim3(256), 0, m->cs, m->g, fg, sensor, d_xyz, N, max_range, 0u, m->b_first.as<u32>(),
-			                   m->b_part1.as<BoxPartial>(), ctl, m->ing, m->b_hit_code.as<PointRec>(), m->b_gridH.as<uint4>(), (u32)(fg.gr.bytes >> 4));
+			                   m->b_part1.as<BoxPartial>(), ctl, m->ing, m->b_hit_code.as<PointRec>(), m->b_gridH.as<uint4>(), m->b_gridM.as<uint4>(), (u32)(fg.gr.bytes >> 4));
 		else
 			hipLaunchKernelGGL(k_fhits<false>, gp, dim3(256), 0, m->cs, m->g, fg, sensor, d_xyz, N, max_range, 0u, m->b_first.as<u32>(),
-			                   m->b_part1.as<BoxPartial>(), ctl, m->ing, m->b_hit_code.as<PointRec>(), m->b_gridH.as<uint4>(), (u32)(fg.gr.bytes >> 4));
+			                   m->b_part1.as<BoxPartial>(), ctl, m->ing, m->b_hit_code.as<PointRec>(), m->b_gridH.as<uint4>(), m->b_gridM.as<uint4>(), (u32)(fg.gr.bytes >> 4));
 	}
 	// stream-to-stream hand-overs of this path: k_signal / k_gate (fast_kernels.h), not events
 	m->gates = useGates(m);
@@ -1192,27 +1196,48 @@ int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, si
 		HIP_TRY(hipStreamWaitEvent(m->sstream, m->prep_ev, 0));
 	}
 	m->cs = m->sstream;
-	u32 nwg = m->opt_cast_wgs > 0 ? (u32)m->opt_cast_wgs : 256u;
-	nwg = std::max<u32>(1u, std::min<u32>(nwg, (N + 63u) / 64u));
-	const u32 cap_wg = (N + nwg - 1) / nwg;
-	HIP_TRY(m->b_ray_end.reserve((size_t)cap_wg * nwg * sizeof(D3)));
-	HIP_TRY(m->b_slabs.reserve((size_t)nwg * fg.gr.bytes + (size_t)nwg * 8 * 3));  // slabs + per-workgroup steps / rays / hits
-	unsigned long long* sp = reinterpret_cast<unsigned long long*>(m->b_slabs.as<char>() + (size_t)nwg * fg.gr.bytes);
-	{
-		ProfScope ps(m, "k_fcast");
-		const size_t lds = (size_t)fg.gr.bytes + UFO_CAST_LDS_EXTRA;
+	if (m->opt_cast_sector) {
+		// sector form: a workgroup per 256 consecutive points, its box of the grid in LDS, ORed into the scan's grid; the
+		// workgroup that finishes last folds counters and boxes (fast_kernels.h: k_fsect) -- one launch
+		const u32 nwg = (N + UFO_SECT_THREADS - 1u) / UFO_SECT_THREADS;
+		const u32 box = (u32)std::min<u64>((u64)std::max(4096, m->opt_sect_box) & ~15ull, (fg.gr.bytes + 15ull) & ~15ull);
+		// per-workgroup steps / rays / hits / direct marks + the ticket word (which starts at 0; the last workgroup leaves it so)
+		const size_t pcap = m->b_sect.cap;
+		HIP_TRY(m->b_sect.reserve((size_t)(4u * nwg + 1u) * 8));
+		if (pcap != m->b_sect.cap) HIP_TRY(hipMemsetAsync(m->b_sect.p, 0, m->b_sect.cap, m->cs));
+		ProfScope ps(m, "k_fsect");
+		const size_t lds = (size_t)box + UFO_SECT_LDS_EXTRA;
 		if (discrete)
-			hipLaunchKernelGGL(k_fcast<true>, dim3(nwg), dim3(512), lds, m->cs, m->g, fg, sensor, d_xyz, N, max_range, 0u, m->b_first.as<u32>(),
-			                   m->b_ray_end.as<D3>(), cap_wg, m->b_slabs.as<u32>(), (u32)std::max(8, m->opt_cast_k), ctl, ctl, sp, m->ing, m->b_hit_code.as<PointRec>(), m->b_gridH.as<u32>());
+			hipLaunchKernelGGL(k_fsect<true>, dim3(nwg), dim3(UFO_SECT_THREADS), lds, m->cs, m->g, fg, sensor, N, m->b_first.as<u32>(), m->b_gridM.as<u32>(),
+			                   m->b_gridH.as<u32>(), m->b_tilebits.as<u32>(), (u32)std::max(8, m->opt_cast_k), box, ctl, m->b_sect.as<unsigned long long>(),
+			                   m->b_hit_code.as<PointRec>(), m->b_part1.as<BoxPartial>(), gp.x);
 		else
-			hipLaunchKernelGGL(k_fcast<false>, dim3(nwg), dim3(512), lds, m->cs, m->g, fg, sensor, d_xyz, N, max_range, 0u, m->b_first.as<u32>(),
-			                   m->b_ray_end.as<D3>(), cap_wg, m->b_slabs.as<u32>(), (u32)std::max(8, m->opt_cast_k), ctl, ctl, sp, m->ing, m->b_hit_code.as<PointRec>(), m->b_gridH.as<u32>());
-	}
-	{
-		ProfScope ps(m, "k_fmerge");
-		const u32 n4 = (u32)(fg.gr.bytes >> 4);
-		hipLaunchKernelGGL(k_fmerge, dim3(std::min<u32>((n4 + 63) / 64, 1024) + 1u), dim3(1024), 0, m->cs, fg, m->b_slabs.as<uint4>(), nwg, n4,
-		                   m->b_gridM.as<uint4>(), sp, m->b_tilebits.as<u32>(), m->b_part1.as<BoxPartial>(), gp.x, ctl);
+			hipLaunchKernelGGL(k_fsect<false>, dim3(nwg), dim3(UFO_SECT_THREADS), lds, m->cs, m->g, fg, sensor, N, m->b_first.as<u32>(), m->b_gridM.as<u32>(),
+			                   m->b_gridH.as<u32>(), m->b_tilebits.as<u32>(), (u32)std::max(8, m->opt_cast_k), box, ctl, m->b_sect.as<unsigned long long>(),
+			                   m->b_hit_code.as<PointRec>(), m->b_part1.as<BoxPartial>(), gp.x);
+	} else {
+		u32 nwg = m->opt_cast_wgs > 0 ? (u32)m->opt_cast_wgs : 256u;
+		nwg = std::max<u32>(1u, std::min<u32>(nwg, (N + 63u) / 64u));
+		const u32 cap_wg = (N + nwg - 1) / nwg;
+		HIP_TRY(m->b_ray_end.reserve((size_t)cap_wg * nwg * sizeof(D3)));
+		HIP_TRY(m->b_slabs.reserve((size_t)nwg * fg.gr.bytes + (size_t)nwg * 8 * 3));  // slabs + per-workgroup steps / rays / hits
+		unsigned long long* sp = reinterpret_cast<unsigned long long*>(m->b_slabs.as<char>() + (size_t)nwg * fg.gr.bytes);
+		{
+			ProfScope ps(m, "k_fcast");
+			const size_t lds = (size_t)fg.gr.bytes + UFO_CAST_LDS_EXTRA;
+			if (discrete)
+				hipLaunchKernelGGL(k_fcast<true>, dim3(nwg), dim3(512), lds, m->cs, m->g, fg, sensor, d_xyz, N, max_range, 0u, m->b_first.as<u32>(),
+				                   m->b_ray_end.as<D3>(), cap_wg, m->b_slabs.as<u32>(), (u32)std::max(8, m->opt_cast_k), ctl, ctl, sp, m->ing, m->b_hit_code.as<PointRec>(), m->b_gridH.as<u32>());
+			else
+				hipLaunchKernelGGL(k_fcast<false>, dim3(nwg), dim3(512), lds, m->cs, m->g, fg, sensor, d_xyz, N, max_range, 0u, m->b_first.as<u32>(),
+				                   m->b_ray_end.as<D3>(), cap_wg, m->b_slabs.as<u32>(), (u32)std::max(8, m->opt_cast_k), ctl, ctl, sp, m->ing, m->b_hit_code.as<PointRec>(), m->b_gridH.as<u32>());
+		}
+		{
+			ProfScope ps(m, "k_fmerge");
+			const u32 n4 = (u32)(fg.gr.bytes >> 4);
+			hipLaunchKernelGGL(k_fmerge, dim3(std::min<u32>((n4 + 63) / 64, 1024) + 1u), dim3(1024), 0, m->cs, fg, m->b_slabs.as<uint4>(), nwg, n4,
+			                   m->b_gridM.as<uint4>(), sp, m->b_tilebits.as<u32>(), m->b_part1.as<BoxPartial>(), gp.x, ctl);
+		}
 	}
 	if (m->gates) hipLaunchKernelGGL(k_signal, dim3(1), dim3(1), 0, m->sstream, m->sig_scan, (unsigned long long)m->seq);
 	HIP_TRY(hipGetLastError());
@@ -1413,6 +1438,12 @@ int finishPending(ufomap_map* m)
 		memcpy(m->h_ctl, m->h_res, sizeof(ScanCtl));
 		m->used_est = m->h_ctl->used_now;
 		m->ctl_clean = true;
+		if (m->opt_cast_sector && m->h_ctl->dbg[40]) {
+			// sectors of this scan did not fit their LDS budget and marked the global grid cell by cell: a cloud whose points
+			// are not ordered in space. If that was a sizeable part of the scan, this handle goes back to whole-grid workgroups.
+			m->n_sect_direct += m->h_ctl->dbg[40];
+			if (m->h_ctl->dbg[41] * 8 > m->h_ctl->n_steps && 1 == m->opt_cast_sector) m->opt_cast_sector = 0;
+		}
 	} else {
 		rc = readCtlDone(m);
 	}
@@ -2184,6 +2215,8 @@ ufomap_map* ufomap_map_create(double resolution, unsigned depth_levels, int auto
 		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cast<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (160 << 10) - 512);
 		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cast<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (160 << 10) - 512);
 		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cast<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (160 << 10) - 512);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fsect<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (160 << 10) - 2048);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fsect<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (160 << 10) - 2048);
 	}
 	for (int a = 0; a < 3; ++a) {
 		m->min_change[a] = g.hs[g.L];  // resetMinMaxChangeDetection (occupancy_map_base.h:806-810)
@@ -2219,7 +2252,7 @@ void ufomap_map_destroy(ufomap_map* m)
 	                  &m->b_ctl,     &m->b_pt_end,  &m->b_pt_flag,  &m->b_pt_slot, &m->b_ray_end, &m->b_hit_code, &m->b_hit_pt,
 	                  &m->b_hh_keys, &m->b_gridM,   &m->b_crec,    &m->b_dlist,   &m->b_rays,   &m->b_part0,   &m->b_part1,   &m->b_slabs,   &m->b_hb_keys, &m->b_hb_mask, &m->b_hb_time,   &m->b_entries, &m->b_ent_slot, &m->b_newlist,
 	                  &m->b_wl0,     &m->b_wl1,     &m->b_in_xyz,   &m->b_in_rgb,  &m->b_codes,   &m->b_dump,
-	                  &m->b_first,   &m->b_tilebits, &m->b_tilerec, &m->b_gridH, &m->b_wstat, &m->b_blk_range, &m->b_ctl_init};
+	                  &m->b_first,   &m->b_tilebits, &m->b_tilerec, &m->b_gridH, &m->b_wstat, &m->b_sect, &m->b_blk_range, &m->b_ctl_init};
 	for (DevBuf* b : bufs) b->release();
 	for (PendingEvent& pe : m->pend_ev) {
 		(void)hipEventDestroy(pe.a);
@@ -4096,6 +4129,10 @@ int ufomap_map_set_option(ufomap_map* m, const char* key, long long value)
 		m->opt_tile_waves = (int)value;
 	} else if (0 == strcmp(key, "gates")) {
 		m->opt_gates = value ? 1 : 0;
+	} else if (0 == strcmp(key, "cast_sector")) {
+		m->opt_cast_sector = (int)value;  // (2: sector form whatever the clouds look like)
+	} else if (0 == strcmp(key, "sect_box")) {
+		m->opt_sect_box = (int)std::max<long long>(4096, std::min<long long>(value, 120 << 10));
 	} else if (0 == strcmp(key, "batch_max")) {
 		m->opt_batch_max = (int)std::max<long long>(1, std::min<long long>(value, (long long)UFO_BATCH_MAX));
 	} else if (0 == strcmp(key, "defer")) {
@@ -4143,6 +4180,7 @@ int ufomap_map_debug(ufomap_map* m, uint64_t* out, int n)
 	if (n > 61) out[61] = m->n_fast;       // scans enqueued on the fast path (fast_kernels.h)
 	if (n > 60) out[60] = m->n_walks;      // ... walks of the tree that applied them (one walk takes every scan that has queued up)
 	if (n > 59) out[59] = m->n_walk_scans; // ... scans in those walks
+	if (n > 57) out[57] = m->n_sect_direct;  // sector passes of the fast path's ray kernel that marked the global grid directly
 	if (n > 58) out[58] = m->n_gate_timeouts;  // stream hand-overs that timed out (the handle uses events from then on)
 	if (n > 51) out[51] = m->n_phase_resets;  // phaseGuard
 	for (int k = 0; k < 4 && 52 + k < n; ++k) out[52 + k] = m->host_ns[k];  // host time inside doInsert (ns): scan enqueue, map enqueue, join, total
