@@ -211,7 +211,7 @@ def main():
     n_scans_leg = max(1, dbg1[61] - dbg0[61])
     pipeline = dict(fast_path_scans=dbg1[61] - dbg0[61], tree_walks=dbg1[60] - dbg0[60],
                     scans_per_walk=(dbg1[59] - dbg0[59]) / max(1, dbg1[60] - dbg0[60]), predicted_grid_repeats=dbg1[63] - dbg0[63],
-                    gate_timeouts=dbg1[58] - dbg0[58], sector_direct_passes=dbg1[57] - dbg0[57],
+                    gate_timeouts=dbg1[58] - dbg0[58],
                     host_us_per_scan={k: (dbg1[52 + j] - dbg0[52 + j]) / n_scans_leg * 1e-3 for j, k in enumerate(("scan_half_enqueue", "tree_update_enqueue", "join", "call_total"))},
                     note="headline leg (warm-up scans included): scans that queue up behind the map stream share ONE walk of the tree")
     digests = {"resident": m.digest()}
@@ -322,10 +322,9 @@ def main():
             # The dominant kernel by algorithmic bytes is the ray walk: it carries the 16*S term of B_scan (82 %). It is
             # one launch (k_cast: set-up + segment queue + walk) plus the slab merge for LiDAR-sized scans, or
             # set-up + walk + merge for the other grid sizes; the durations of whatever ran add up.
-            walkers = ("k_fsect", "k_fcast", "k_cast", "k_walk", "k_dda_seg", "k_dda")  # fast path first: it runs all steady-state scans
+            walkers = ("k_fcast", "k_cast", "k_walk", "k_dda_seg", "k_dda")  # fast path first: it runs all steady-state scans
             dom = next(k for k in walkers if k in kern_ms)
-            group = [dom] if dom == "k_fsect" else [dom, "k_fmerge"] if dom == "k_fcast" else \
-                [k for k in ("k_ray_setup",) + walkers[2:] + ("k_merge_slabs",) if k in kern_ms]
+            group = [dom, "k_fmerge"] if dom == "k_fcast" else [k for k in ("k_ray_setup",) + walkers[1:] + ("k_merge_slabs",) if k in kern_ms]
             group = [k for k in group if k in kern_ms]
             share = P_BYTES * mean_rays + 16 * mean_steps
             dur_s = sum(kern_ms[k] for k in group) * 1e-3  # average launch durations of the kernels that make up one ray walk

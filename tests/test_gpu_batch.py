@@ -3,6 +3,7 @@ over B scans) must leave exactly the map the reference leaves after integrating 
 (occupancy_map_base.h:340-417 called B times) -- values, flags, leaf structure under pruning, byte stream."""
 import numpy as np
 import pytest
+import torch  # noqa: F401  (before the HIP library: torch brings its own copy of the HIP runtime, and the first one loaded owns the GPU)
 
 from conftest import same_dump
 
@@ -48,12 +49,13 @@ def _sequence(n_scans, beams=32, azimuths=512, spread=1.0, seed0=300):
 
 @pytest.mark.parametrize("batch_max,discrete", [(2, True), (4, True), (16, True), (3, False), (8, False)])
 def test_batched_walks_equal_sequential(batch_max, discrete):
-    """Pipelined scans whose tree updates are held back until `batch_max` of them share a walk (option defer = 1: whatever the
-    map stream is doing) against the reference integrating them one by one -- compared after every few batches and at the end."""
+    """Pipelined scans whose slots on the map stream are enqueued `hold` at a time, each claim waiting for the newest scan half
+    (a test aid: walks over several scans then happen whatever the timing) against the reference integrating them one by
+    one -- compared after every few batches and at the end."""
     seq = _sequence(26)
     g, o = _maps(kind=_kind() if batch_max != 4 else "port", resolution=0.16)
     g.set_option("batch_max", batch_max)
-    g.set_option("defer", 1)
+    g.set_option("hold", min(batch_max, 7))
     for i, (origin, xyz) in enumerate(seq):
         _insert(g, origin, xyz, 12.0, discrete, True)
         o.insert(origin, xyz, max_range=12.0, discrete=discrete)
@@ -66,9 +68,8 @@ def test_batched_walks_equal_sequential(batch_max, discrete):
     _assert_same_map(g, o, "final")
     d = g.debug()
     assert d[61] >= 20, "the scans did not take the fast path"
-    assert d[59] == d[61], "every fast-path scan belongs to exactly one walk"
+    assert d[59] == d[61] - d[63], f"every fast-path scan that was not repeated belongs to exactly one walk: {d[59:64]}"
     assert d[60] < d[59], f"no walk took more than one scan ({d[60]} walks, {d[59]} scans)"
-    assert d[60] <= (d[59] + batch_max - 1) // batch_max + 8, f"walks are smaller than asked for ({d[60]} walks, {d[59]} scans, batch_max {batch_max})"
 
 
 def test_batched_walk_saturation_and_pruning():
@@ -77,7 +78,7 @@ def test_batched_walk_saturation_and_pruning():
     from ufomap_amd import scans
     g, o = _maps(kind=_kind(), resolution=0.16)
     g.set_option("batch_max", 8)
-    g.set_option("defer", 1)
+    g.set_option("hold", 6)
     poses = [scans.lidar_pose(0), tuple(np.array(scans.lidar_pose(0)) + [0.35, -0.2, 0.0])]
     clouds = [scans.lidar64(beams=32, azimuths=512, origin=p, seed=7 + k)[:2] for k, p in enumerate(poses)]
     for i in range(34):
@@ -97,7 +98,7 @@ def test_batch_with_a_scan_that_does_not_fit_its_predicted_grid():
     from ufomap_amd import scans
     g, o = _maps(kind=_kind(), resolution=0.16)
     g.set_option("batch_max", 4)
-    g.set_option("defer", 1)
+    g.set_option("hold", 4)
     base = np.array(scans.lidar_pose(0), dtype=np.float64)
     offs = [(0, 0, 0)] * 4 + [(0.1, 0, 0), (0.2, 0.1, 0), (6.0, 4.0, 0.2), (0.2, 0.0, 0), (0.1, 0.1, 0), (6.0, 4.1, 0.2), (6.1, 4.0, 0.2), (0, 0, 0)] + [(0.05, 0, 0)] * 5
     for i, off in enumerate(offs):
@@ -130,7 +131,7 @@ def test_fast_path_counter_and_general_path_agree_on_the_bench_sequence():
         counters.append(g.debug())
     assert digests[0] == digests[1]
     on, off = counters
-    assert on[61] >= 20 and on[59] == on[61] and on[60] >= 1, f"fast path did not run: {on[59:64]}"
+    assert on[61] >= 20 and on[59] == on[61] - on[63] and on[60] >= 1, f"fast path did not run: {on[59:64]}"
     assert on[58] == 0, "a stream hand-over timed out"
     assert off[61] == 0 and off[60] == 0
 
@@ -149,31 +150,3 @@ def test_many_handles_keep_their_maps_apart():
         g.insertPointCloudWait()
         _assert_same_map(g, o, f"map {k}")
 
-
-@pytest.mark.parametrize("sect_box,cloud", [(4096, "lidar"), (8192, "random"), (36 << 10, "random"), (36 << 10, "lidar")])
-def test_sector_ray_kernel_budgets_and_unordered_clouds(sect_box, cloud):
-    """The fast path's ray kernel keeps a workgroup's SECTOR of the ray grid in LDS: with a tiny LDS budget the stretches are
-    halved into several passes, and rays that still do not fit (or an unordered cloud) mark the global grid directly -- same
-    cells, same step counts, same map as the oracle and as the whole-grid form (k_fcast + k_fmerge)."""
-    from ufomap_amd import scans
-    g, o = _maps(resolution=0.16)
-    g2, _ = _maps(resolution=0.16)
-    g.set_option("sect_box", sect_box)
-    g.set_option("cast_sector", 2)
-    g2.set_option("cast_sector", 0)
-    for i in range(6):
-        if cloud == "lidar":
-            origin, xyz, _ = scans.lidar64(beams=32, azimuths=1024, origin=scans.lidar_pose(i % 2), seed=60 + i)
-        else:
-            origin, xyz, _ = scans.random_cloud(20000, seed=70 + i, extent=7.0)
-        for m in (g, g2):
-            _insert(m, origin, xyz, 9.0, bool(i & 1), False)
-        o.insert(origin, xyz, max_range=9.0, discrete=bool(i & 1))
-        _assert_same_map(g, o, f"scan {i}")
-        assert g.last_counts()["steps"] == o.last_steps() == g2.last_counts()["steps"]
-        assert np.array_equal(g.last_hits(), o.last_hits()) and np.array_equal(g.last_misses(), o.last_misses())
-        assert g.digest() == g2.digest()
-    d = g.debug()
-    assert d[61] >= 4, "the scans did not take the fast path"
-    if sect_box <= 8192:
-        assert d[57] > 0, "no sector had to mark the global grid directly (is the budget honoured?)"

@@ -576,564 +576,186 @@ __global__ __launch_bounds__(512) void k_fcast(MapGeom g, FastGeo fg, D3 sensor,
 }
 
 // ------------------------------------------------------------------------------------------------
-// F2s: the ray kernel of the fast path in SECTOR form (the default; k_fcast + k_fmerge above / below stay as the form for
-// clouds whose points are not ordered in space). A workgroup takes CONSECUTIVE points of the cloud: points that follow one
-// another in a scan lie next to one another in space and all rays start at the sensor, so the workgroup's rays stay inside
-// a small box (sensor cell + their end cells) -- a sector of the scan. Only that box of the ray grid is kept in LDS (a
-// fraction of the 100 KB the whole grid takes: two to three workgroups per CU instead of one, i.e. twice the waves to
-// hide the dependent chains of set-up, cut states and walk behind), and what leaves the workgroup is the box's non-zero
-// words, OR-ed into the scan's grid with one atomic each -- instead of a dense 100 KB slab per workgroup that a second
-// kernel has to read back (26 MB written + 26 MB read per scan for a 0.1 MB result). The tile bitmap is derived from the
-// same words on the way out, and the workgroup that finishes last folds the per-workgroup counters and k_fhits' bounding
-// boxes into the control block: one launch where there were two.
-// A stretch of rays whose box does not fit the LDS budget is halved until it does (passes); 32 rays or fewer that still
-// do not fit (an unordered cloud) mark the global grid directly, step by step -- correct, slow, counted (the host moves
-// such a handle back to k_fcast).
+// Who applies which scan. The tree update of the fast path runs in SLOTS on the map stream -- k_claim, k_fmerge, k_tile,
+// k_ftail, enqueued by the call that brought scan f. When the slot gets its turn (the walk before it has finished, scan
+// f's scan half has finished), k_claim CLAIMS a run of scans for it: every scan up to f that no walk has taken yet (the
+// host enqueues no slot of its own for a scan while two slots are still waiting on the map stream -- the next slot takes
+// it along), and beyond f every scan whose scan half has finished meanwhile (same ray grid, no other update of the map in
+// between). The slot's three kernels apply the whole run of B scans in order, in ONE walk of the tree -- one merge launch,
+// each block record read and written once (k_tile), one pass over the levels above (k_ftail); a slot whose scan has gone
+// with an earlier walk does nothing. So the batch forms on the device, out of whatever has queued up behind the map
+// stream at that moment: a host that feeds scans slowly gets B = 1 and the latency of one scan, a host that runs ahead
+// gets walks as large as the map stream needs to keep up with the scan stream -- and no scan waits for company.
 // ------------------------------------------------------------------------------------------------
-#define UFO_SECT_THREADS 256u  // = consecutive points of the cloud per workgroup
-#define UFO_SECT_BATCH 128u    // rays set up per round
-#define UFO_SECT_QCAP 512u     // segment queue entries
-#define UFO_SECT_LDS_EXTRA \
-	(UFO_SECT_BATCH * (sizeof(RayConst) + sizeof(RayHdr)) + UFO_SECT_QCAP * sizeof(SegRec) + 128u + UFO_SECT_THREADS * sizeof(D3) + UFO_FAST_MAX_TILES / 8u + 64u)
-template <bool DISCRETE>
-__global__ __launch_bounds__(UFO_SECT_THREADS) void k_fsect(MapGeom g, FastGeo fg, D3 sensor, u32 n, u32* __restrict__ first, u32* __restrict__ gridM,
-                                                           u32* __restrict__ gridH, u32* __restrict__ tile_bits, u32 k_min, u32 box_bytes, ScanCtl* ctl,
-                                                           unsigned long long* __restrict__ part, const PointRec* __restrict__ recs,
-                                                           const BoxPartial* __restrict__ boxes, u32 nboxes)
+#define UFO_RING 16u       // scans in flight per handle (a power of two, > the number of hand-over sets)
+#define UFO_BATCH_MAX 16u  // scans per walk
+struct ScanDesc {  // a scan as the tree update sees it: written into the ring when its scan half ends (k_scan_done)
+	const uint4* slabs;                  // the ray kernel's per-workgroup copies of the ray grid ...
+	const unsigned long long* parts;     // ... and step / ray / hit counts (merged by the walk that takes the scan)
+	u32* gridM;                          // ray cells of the scan (bit grid, Grid::layout 1; written by k_fmerge)
+	u32* gridH;                          // hit voxels of the scan (same layout)
+	u32* tile_bits;                      // depth-3 tiles of the grid that hold a ray cell (written by k_fmerge, cleared by k_ftail)
+	ScanCtl* ctl;                        // control block (err: the scan half flagged the scan; the walk stands back)
+	ScanCtl* host_result;                // where the finished control block goes (pinned), followed by the word the host polls
+	const BoxPartial* boxes;             // k_fhits' per-workgroup bounding boxes
+	unsigned long long done_value;       // value of that word: the integration's running number
+	unsigned long long fseq;             // running number among the fast-path scans
+	u32 n_slabs, nboxes;
+	u32 geo;                             // scans with equal geo may share a walk (same ray grid, consecutive updates of the map)
+	u32 pad;
+};
+struct Pipe {
+	unsigned long long scan_done;  // fast-path number of the newest scan whose scan half has finished (the scan stream works them off in order)
+	unsigned long long claimed;    // ... of the newest scan a walk has taken
+	struct Slot {
+		unsigned long long first;  // the slot of scan f (slot[f & 15]) applies scans first .. first + B - 1
+		u32 B, pad;                // (B == 0: scan f went with an earlier walk)
+	} slot[UFO_RING];
+	u32 wstat[UFO_RING];           // wstat[f & 15]: 0 = the walk that took scan f applied it; else it stood back / failed
+	ScanDesc ring[UFO_RING];
+};
+// end of a scan half (scan stream, one thread): the scan's descriptor becomes visible, then its number
+__global__ void k_scan_done(Pipe* p, ScanDesc d)
 {
-	extern __shared__ __attribute__((aligned(16))) u32 lds[];
-	constexpr u32 BATCH = UFO_SECT_BATCH, QCAP = UFO_SECT_QCAP;
-	const u32 err_in = ctl->err;  // the scan does not fit the predicted grid (k_fhits): it will be repeated
-	const Grid& grid_all = fg.gr;
-	const u32 box_words = box_bytes >> 2;
-	RayConst* rc = reinterpret_cast<RayConst*>(lds + box_words);
-	RayHdr* hd = reinterpret_cast<RayHdr*>(rc + BATCH);
-	SegRec* q = reinterpret_cast<SegRec*>(hd + BATCH);
-	u32* sh = reinterpret_cast<u32*>(q + QCAP);  // [0..7], [16..23]: per-wave partial sums; [24] rays, [25] hits, [26] direct marks, [27] "last workgroup"
-	D3* ends = reinterpret_cast<D3*>(sh + 32);
-	u32* tb = reinterpret_cast<u32*>(ends + UFO_SECT_THREADS);  // tiles this workgroup marked
-	i32* bb = reinterpret_cast<i32*>(tb + UFO_FAST_MAX_TILES / 32u);
-	const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-	const u32 nwaves = blockDim.x >> 6;
-	const u32 depth = 0;
-	const u32 lim = 1u << g.L;
-	for (u32 j = threadIdx.x; j < UFO_FAST_MAX_TILES / 32u; j += blockDim.x) tb[j] = 0;
-	if (threadIdx.x < 4u) sh[24 + threadIdx.x] = 0;
-	__syncthreads();
-	unsigned long long steps = 0;
-	u32 err = 0, oob = 0, ndirect = 0;
-	const u32 gny = 2u * (u32)grid_all.nb[1];
-	const u32 growW = fg.rowBits >> 5;
-	auto markTile = [&](i32 ax, i32 ay, i32 az) {  // absolute cell -> its depth-3 tile in the workgroup's bitmap
-		const u32 tile = (u32)((ax >> 3) - fg.tbase[0]) + fg.nt[0] * ((u32)((ay >> 3) - fg.tbase[1]) + fg.nt[1] * (u32)((az >> 3) - fg.tbase[2]));
-		if (tile < fg.ntiles && !((tb[tile >> 5] >> (tile & 31u)) & 1u)) atomicOr(&tb[tile >> 5], 1u << (tile & 31u));
-	};
-	auto markDirect = [&](u32 lin) {  // one cell of the scan's grid (its own linear index), straight to global memory
-		__hip_atomic_fetch_or(&gridM[lin >> 5], 1u << (lin & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		const u32 x = lin % fg.rowBits, r = lin / fg.rowBits;
-		markTile(grid_all.base[0] + (i32)x, grid_all.base[1] + (i32)(r % gny), grid_all.base[2] + (i32)(r / gny));
-		++ndirect;
-	};
-	u32 mine = 0;
-	if (!err_in) {
-		// ---- 0. head loop results (k_fhits) of this workgroup's points; the surviving ray ends go to LDS ----
-		const u32 i = blockIdx.x * UFO_SECT_THREADS + threadIdx.x;
-		bool cast = false;
-		D3 end{0, 0, 0};
-		u32 nhit = 0;
-		if (i < n) {
-			const PointRec r = recs[i];
-			const bool odd = 0 != (r.flags & 4u);
-			cast = (r.flags & 1u) && !odd;
-			if ((r.flags & 2u) && !odd) {
-				const bool winner = __hip_atomic_load(&first[r.cell], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == i;
-				nhit = winner ? 1u : 0u;
-				if (winner) {
-					// (see k_fcast: one bit in the scan's hit grid; the winner leaves the first-point array clean)
-					atomicOr(&gridH[r.cell >> 5], 1u << (r.cell & 31u));
-					__hip_atomic_store(&first[r.cell], 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				}
-				if (DISCRETE && !winner) cast = false;  // OMB:358-360: dropped entirely, no ray
-			}
-			end = r.end;
-		}
-		const u64 mk = __ballot(cast);
-		u32 base = 0;
-		if (0 == lane && mk) base = atomicAdd(&sh[24], (u32)__popcll(mk));
-		base = __shfl(base, 0);
-		if (cast) ends[base + (u32)__popcll(mk & ((1ULL << lane) - 1ULL))] = end;
-		for (int o = 32; o > 0; o >>= 1) nhit += __shfl_xor(nhit, o);
-		if (0 == lane && nhit) atomicAdd(&sh[25], nhit);
-		__syncthreads();
-		mine = sh[24];
-	}
-	// ---- passes: as many consecutive rays as have a box that fits the LDS budget ----
-	u32 ps = 0, pe = mine;
-	while (ps < mine) {
-		Grid gr = grid_all;
-		bool glob = false;
-		i32 boxo[3] = {0, 0, 0};  // offset of the box inside the scan's grid (cells; x a multiple of 32)
-		pe = mine;
-		for (;;) {
-			__syncthreads();
-			if (threadIdx.x < 3u) {
-				bb[threadIdx.x] = INT32_MAX;
-				bb[3 + threadIdx.x] = INT32_MIN;
-			}
-			__syncthreads();
-			i32 lo[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, hi[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
-			for (u32 i = ps + threadIdx.x; i < pe; i += blockDim.x) {
-				i32 c0[3], c1[3];
-				if (!rayEndCells(g, sensor, depth, ends[i], c0, c1)) continue;
-				for (int a = 0; a < 3; ++a) {
-					lo[a] = min(lo[a], min(c0[a], c1[a]));
-					hi[a] = max(hi[a], max(c0[a], c1[a]));
-				}
-			}
-			for (int a = 0; a < 3; ++a) {
-				const i32 l = waveMinI(lo[a]), h = waveMaxI(hi[a]);
-				if (0 == lane) {
-					if (l != INT32_MAX) atomicMin(&bb[a], l);
-					if (h != INT32_MIN) atomicMax(&bb[3 + a], h);
-				}
-			}
-			__syncthreads();
-			glob = true;
-			if (bb[0] > bb[3]) break;  // (no ray of the stretch is walked at all)
-			// the box as the host makes the scan's grid (makeGrid: one block of padding, even base), x moved down to a
-			// multiple of 32 cells inside the scan's grid so that words map onto words; never beyond the scan's grid
-			Grid sub = grid_all;
-			bool ok = true;
-			u64 rows = 1;
-			for (int a = 0; a < 3; ++a) {
-				i32 l = (bb[a] - 2) & ~1, h = bb[3 + a] + 2;
-				if (0 == a) l = grid_all.base[0] + (((l - grid_all.base[0]) >> 5) << 5);
-				l = max(l, grid_all.base[a]);
-				h = min(h, grid_all.base[a] + 2 * grid_all.nb[a] - 1);
-				if (h < l) ok = false;
-				sub.base[a] = l;
-				sub.nb[a] = (h - l) / 2 + 1;
-				boxo[a] = l - grid_all.base[a];
-				if (a) rows *= 2ull * (u64)sub.nb[a];
-			}
-			const u64 bytes = (((u64)(gridRowBits(sub) >> 3) * rows) + 15ull) & ~15ull;
-			if (ok && bytes <= (u64)box_bytes) {
-				sub.bytes = bytes;
-				gr = sub;
-				glob = false;
-				break;
-			}
-			if (pe - ps <= 32u) break;
-			pe = ps + (pe - ps + 1u) / 2u;
-		}
-		if (glob) {  // (the direct marks address the scan's own grid)
-			gr = grid_all;
-			boxo[0] = boxo[1] = boxo[2] = 0;
-		}
-		const u32 lds_words = glob ? 0u : (u32)(gr.bytes >> 2);
-		{
-			uint4* l4 = reinterpret_cast<uint4*>(lds);
-			for (u32 j = threadIdx.x; j < (lds_words >> 2); j += blockDim.x) l4[j] = make_uint4(0, 0, 0, 0);
-		}
-		const u32 rowBits = gridRowBits(gr), planeBits = rowBits * 2u * (u32)gr.nb[1];
-		for (u32 base = ps; base < pe; base += BATCH) {
-			__syncthreads();  // previous round's queue and constants are no longer read (also orders the LDS zeroing)
-			const u32 t = threadIdx.x;
-			const bool have = t < BATCH && base + t < pe;
-			// ---- 1. one lane per ray: clip, keys, computeRayInit ----
-			u32 l1 = 0, dmax = 0, ax = 0, status = 0, lin0 = 0;
-			if (have) {
-				RayState r;
-				raySetup(g, sensor, depth, gr, ends[base + t], r);
-				status = r.status;
-				if (1 == r.status) {
-					if ((u32)r.start[0] >= lim || (u32)r.start[1] >= lim || (u32)r.start[2] >= lim) {
-						++oob;
-					} else {
-						const i32 lx = r.start[0] - gr.base[0], ly = r.start[1] - gr.base[1], lz = r.start[2] - gr.base[2];
-						if ((u32)lx >= 2u * (u32)gr.nb[0] || (u32)ly >= 2u * (u32)gr.nb[1] || (u32)lz >= 2u * (u32)gr.nb[2]) {
-							err |= ERR_GRID_OOB;
-						} else {
-							const u32 lin = (u32)lx + (u32)ly * rowBits + (u32)lz * planeBits;
-							if (glob) markDirect(lin);
-							else atomicOr(&lds[lin >> 5], 1u << (lin & 31u));
-						}
-					}
-					steps += 1;
-				} else if (3 == r.status) {
-					err |= ERR_GRID_OOB;  // cannot happen: pointRay admits only rays inside the grid's interior, and the box holds both ends
-				} else if (2 == r.status) {
-					const u32 dxn = (u32)abs((i32)(r.gpk & 1023u) - (i32)(r.pk0 & 1023u));
-					const u32 dyn = (u32)abs((i32)((r.gpk >> 10) & 1023u) - (i32)((r.pk0 >> 10) & 1023u));
-					const u32 dzn = (u32)abs((i32)(r.gpk >> 20) - (i32)(r.pk0 >> 20));
-					ax = (dxn >= dyn && dxn >= dzn) ? 0u : (dyn >= dzn ? 1u : 2u);
-					dmax = ax == 0 ? dxn : (ax == 1 ? dyn : dzn);
-					l1 = dxn + dyn + dzn;
-					lin0 = pkToLin(r.pk0, rowBits, planeBits);
-					RayConst c;
-					c.td[0] = r.td[0];
-					c.td[1] = r.td[1];
-					c.td[2] = r.td[2];
-					c.dist = r.dist;
-					c.dl[0] = r.s[0];
-					c.dl[1] = (i32)r.s[1] * (i32)rowBits;
-					c.dl[2] = (i32)r.s[2] * (i32)planeBits;
-					c.glin = pkToLin(r.gpk, rowBits, planeBits);
-					rc[t] = c;
-					hd[t].tm[0] = r.tm[0];
-					hd[t].tm[1] = r.tm[1];
-					hd[t].tm[2] = r.tm[2];
-				}
-			}
-			// ---- 2. segment length for this round: about K steps, and the queue must hold every segment ----
-			u32 tot = l1, cntr = (2 == status) ? 1u : 0u;
-			for (int o = 32; o > 0; o >>= 1) {
-				tot += __shfl_xor(tot, o);
-				cntr += __shfl_xor(cntr, o);
-			}
-			if (0 == lane) {
-				sh[wave] = tot;
-				sh[16 + wave] = cntr;
-			}
-			__syncthreads();
-			u32 total = 0, nray2 = 0;
-			for (u32 wv = 0; wv < nwaves; ++wv) {
-				total += sh[wv];
-				nray2 += sh[16 + wv];
-			}
-			u32 K = k_min;
-			{
-				const u32 room = QCAP - nray2;  // >= QCAP - BATCH > 0
-				const u32 need = (2u * total + room - 1u) / room;
-				K = max(K, need);
-			}
-			u32 w = 1, nseg = 0;
-			if (2 == status) {
-				w = (u32)(((u64)dmax * K) / l1);
-				if (w < 1u) w = 1u;
-				nseg = (dmax + w - 1u) / w;  // >= 1 (start and goal differ)
-			}
-			__syncthreads();  // sh[] is reused below
-			u32 incl = nseg;
-			for (int o = 1; o < 64; o <<= 1) {
-				const u32 v = __shfl_up(incl, o);
-				if ((int)lane >= o) incl += v;
-			}
-			if (63u == lane) sh[wave] = incl;
-			__syncthreads();
-			u32 off = incl - nseg, nsegs = 0;
-			for (u32 wv = 0; wv < nwaves; ++wv) {
-				const u32 v = sh[wv];
-				if (wv < wave) off += v;
-				nsegs += v;
-			}
-			if (t < BATCH) {
-				hd[t].lin0 = lin0;
-				hd[t].ax = ax;
-				hd[t].w = w;
-				hd[t].nseg = nseg;
-				hd[t].off = off;
-			}
-			__syncthreads();
-			// ---- 3. cut states from the three independent addition chains (see k_fcast) ----
-			if (threadIdx.x < BATCH) {
-				const u32 ry = threadIdx.x;
-				const RayHdr h = hd[ry];
-				if (0 != h.nseg) {
-					const RayConst c = rc[ry];
-					SegRec rec;
-					rec.tm[0] = h.tm[0];
-					rec.tm[1] = h.tm[1];
-					rec.tm[2] = h.tm[2];
-					rec.lin = h.lin0;
-					rec.end = c.glin;
-					rec.ray = ry | 0x80000000u;
-					rec.pad = 0;
-					q[h.off] = rec;
-					const u32 axd = h.ax;
-					const u32 b0 = axd == 0 ? 1u : 0u, b1 = axd == 2 ? 1u : 2u;
-					double ta = axd == 0 ? h.tm[0] : (axd == 1 ? h.tm[1] : h.tm[2]), v = ta;
-					const double tda = axd == 0 ? c.td[0] : (axd == 1 ? c.td[1] : c.td[2]);
-					const i32 da = axd == 0 ? c.dl[0] : (axd == 1 ? c.dl[1] : c.dl[2]);
-					for (u32 j = 1; j < h.nseg; ++j) {
-						u32 nn = h.w;
-						for (; nn >= 4u; nn -= 4u) {
-							const double t1 = ta + tda, t2 = t1 + tda, t3 = t2 + tda;
-							v = t3;
-							ta = t3 + tda;
-						}
-						for (; nn > 0u; --nn) {
-							v = ta;
-							ta = ta + tda;
-						}
-						SegRec* o = &q[h.off + j];
-						o->tm[axd] = ta;
-						o->tm[b0] = v;
-						o->tm[b1] = v;
-						o->lin = h.lin0 + (u32)((i32)(j * h.w) * da);
-						o->end = c.glin;
-						o->ray = ry;
-					}
-				}
-			}
-			__syncthreads();
-			for (u32 idx = threadIdx.x; idx < 2u * BATCH; idx += blockDim.x) {
-				const u32 ry = idx & (BATCH - 1u), role = idx / BATCH;
-				const RayHdr h = hd[ry];
-				if (h.nseg < 2u) continue;
-				const RayConst c = rc[ry];
-				const u32 axd = h.ax;
-				const u32 b = (0 == role) ? (axd == 0 ? 1u : 0u) : (axd == 2 ? 1u : 2u);
-				const bool pri = b < axd;
-				double tbv = b == 0 ? h.tm[0] : (b == 1 ? h.tm[1] : h.tm[2]);
-				const double dbt = b == 0 ? c.td[0] : (b == 1 ? c.td[1] : c.td[2]);
-				const i32 dbl = b == 0 ? c.dl[0] : (b == 1 ? c.dl[1] : c.dl[2]);
-				u32 cb = 0, j = 1;
-				SegRec* o = &q[h.off + 1u];
-				double v = o->tm[b];
-				u32 guard = 0;
-				while (j < h.nseg) {
-					const double s1 = tbv + dbt, s2 = s1 + dbt, s3 = s2 + dbt;
-					const bool c0 = pri ? (tbv <= v) : (tbv < v);
-					const bool c1 = c0 & (pri ? (s1 <= v) : (s1 < v)), c2 = c1 & (pri ? (s2 <= v) : (s2 < v)), c3 = c2 & (pri ? (s3 <= v) : (s3 < v));
-					if (c3) {
-						tbv = s3 + dbt;
-						cb += 4u;
-						if (++guard > 1024u) {
-							err |= ERR_RUNAWAY;  // (cannot trip inside a grid of < 1024 cells per axis)
-							break;
-						}
-						continue;
-					}
-					tbv = c2 ? s3 : (c1 ? s2 : (c0 ? s1 : tbv));
-					cb += (c0 ? 1u : 0u) + (c1 ? 1u : 0u) + (c2 ? 1u : 0u);
-					o->tm[b] = tbv;
-					if (cb) atomicAdd(&o->lin, (u32)((i32)cb * dbl));
-					++j;
-					++o;
-					if (j < h.nseg) v = o->tm[b];
-				}
-			}
-			__syncthreads();
-			for (u32 si = threadIdx.x; si + 1u < nsegs; si += blockDim.x)
-				if (!(q[si + 1u].ray & 0x80000000u)) q[si].end = q[si + 1u].lin;
-			__syncthreads();
-			// ---- 4. every lane walks segments ----
-			for (u32 si = threadIdx.x; si < nsegs; si += blockDim.x) {
-				const SegRec rec = q[si];
-				const RayConst c = rc[rec.ray & 0x7FFFFFFFu];
-				double tmx = rec.tm[0], tmy = rec.tm[1], tmz = rec.tm[2];
-				const double tdx = c.td[0], tdy = c.td[1], tdz = c.td[2];
-				const long long idist = __double_as_longlong(c.dist);
-				const i32 dlx = c.dl[0], dly = c.dl[1], dlz = c.dl[2];
-				const u32 end = rec.end;
-				u32 lin = rec.lin;
-				bool go = (0 != (rec.ray & 0x80000000u)) ||
-				          ((lin != c.glin) && ((__double_as_longlong(tmx) <= idist) | (__double_as_longlong(tmy) <= idist) |
-				                               (__double_as_longlong(tmz) <= idist)));
-				const u32 lin_first = lin;
-				u32 cnt = 0;
-				while (go) {
-					++cnt;
-					if (glob) markDirect(lin);
-					else atomicOr(&lds[lin >> 5], 1u << (lin & 31u));
-					const bool cxy = tmx <= tmy, cxz = tmx <= tmz, cyz = tmy <= tmz;
-					const bool selx = cxy & cxz;
-					const bool sely = !cxy & cyz;
-					const bool selz = !(selx | sely);
-					lin += (u32)(selx ? dlx : (sely ? dly : dlz));
-					const double nx = tmx + tdx, ny = tmy + tdy, nz = tmz + tdz;
-					tmx = selx ? nx : tmx;
-					tmy = sely ? ny : tmy;
-					tmz = selz ? nz : tmz;
-					const bool more =
-					    (__double_as_longlong(tmx) <= idist) | (__double_as_longlong(tmy) <= idist) | (__double_as_longlong(tmz) <= idist);
-					go = (lin != end) & more & (cnt < 4096u);
-				}
-				if (cnt >= 4096u) err |= ERR_RUNAWAY;  // (a segment is ~K steps by construction)
-				const u32 ny2 = 2u * (u32)gr.nb[1];
-				const u32 r0 = lin_first / rowBits, r1 = lin / rowBits;
-				const i32 ddx = (i32)(lin % rowBits) - (i32)(lin_first % rowBits), ddy = (i32)(r1 % ny2) - (i32)(r0 % ny2),
-				          ddz = (i32)(r1 / ny2) - (i32)(r0 / ny2);
-				steps += (u32)(abs(ddx) + abs(ddy) + abs(ddz));
-			}
-		}
-		__syncthreads();
-		if (!glob) {
-			// the box goes into the scan's grid: a row of the box is a stretch of a row of the grid, word for word; the tiles
-			// its marked cells lie in go into the workgroup's tile bitmap
-			const u32 rowW = rowBits >> 5, ny = 2u * (u32)gr.nb[1];
-			for (u32 j = threadIdx.x; j < lds_words; j += blockDim.x) {
-				u32 wv = lds[j];
-				if (0 == wv) continue;
-				const u32 wx = j % rowW, r = j / rowW;
-				const u32 ly = r % ny, lz = r / ny;
-				if (lz >= 2u * (u32)gr.nb[2]) continue;  // (padding behind the last row)
-				const u32 gy = ly + (u32)boxo[1], gz = lz + (u32)boxo[2], gwx = wx + ((u32)boxo[0] >> 5);
-				__hip_atomic_fetch_or(&gridM[((size_t)gz * gny + gy) * growW + gwx], wv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				const i32 ay = grid_all.base[1] + (i32)gy, az = grid_all.base[2] + (i32)gz;
-				while (wv) {
-					const u32 bit = (u32)__ffs(wv) - 1u;
-					const i32 axc = grid_all.base[0] + (i32)(32u * gwx + bit);
-					// all cells of this word that fall into the same tile
-					const i32 first_in_tile = ((axc >> 3) << 3) - grid_all.base[0] - (i32)(32u * gwx);  // bit index of the tile's first cell (may be < 0)
-					const u32 lo = (u32)max(first_in_tile, 0), hi = (u32)min(first_in_tile + 8, 32);
-					const u32 span = (hi >= 32u ? 0xFFFFFFFFu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
-					wv &= ~span;
-					markTile(axc, ay, az);
-				}
-			}
-		} else if (0 == threadIdx.x && pe > ps) {
-			atomicAdd(&ctl->dbg[40], 1ull);  // (diagnostics: passes that marked the global grid directly)
-		}
-		ps = pe;
-	}
-	__syncthreads();
-	for (u32 j = threadIdx.x; j < (fg.ntiles + 31u) / 32u; j += blockDim.x)
-		if (tb[j]) atomicOr(&tile_bits[j], tb[j]);
-	if (oob) atomicAdd(&ctl->n_oob, oob);
-	if (err) atomicOr(&ctl->err, err);
-	for (int o = 32; o > 0; o >>= 1) ndirect += __shfl_xor(ndirect, o);
-	if (0 == lane && ndirect) atomicAdd(&sh[26], ndirect);
-	blockStoreSteps(steps, part);  // (part[blockIdx.x] = the workgroup's steps; barriers inside)
-	if (0 == threadIdx.x) {
-		part[gridDim.x + blockIdx.x] = mine;
-		part[2u * gridDim.x + blockIdx.x] = sh[25];
-		part[3u * gridDim.x + blockIdx.x] = sh[26];
-	}
-	// ---- the workgroup that finishes last folds the partial results into the control block ----
+	p->ring[d.fseq & (UFO_RING - 1u)] = d;
 	__threadfence();
-	__syncthreads();
-	if (0 == threadIdx.x) {
-		const unsigned long long tk = atomicAdd(&part[4u * gridDim.x], 1ull);
-		sh[27] = (tk + 1ull == (unsigned long long)gridDim.x) ? 1u : 0u;
-	}
-	__syncthreads();
-	if (!sh[27]) return;
-	__threadfence();
-	{
-		unsigned long long v = 0, r = 0, h = 0, d = 0;
-		for (u32 s = threadIdx.x; s < gridDim.x; s += blockDim.x) {
-			v += __hip_atomic_load(&part[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			r += __hip_atomic_load(&part[gridDim.x + s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			h += __hip_atomic_load(&part[2u * gridDim.x + s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			d += __hip_atomic_load(&part[3u * gridDim.x + s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		}
-		__shared__ unsigned long long facc[4];
-		if (threadIdx.x < 4u) facc[threadIdx.x] = 0;
-		__syncthreads();
-		for (int o = 32; o > 0; o >>= 1) {
-			v += __shfl_xor(v, o);
-			r += __shfl_xor(r, o);
-			h += __shfl_xor(h, o);
-			d += __shfl_xor(d, o);
-		}
-		if (0 == lane) {
-			atomicAdd(&facc[0], v);
-			atomicAdd(&facc[1], r);
-			atomicAdd(&facc[2], h);
-			atomicAdd(&facc[3], d);
-		}
-		__syncthreads();
-		if (0 == threadIdx.x) {
-			if (facc[0]) atomicAdd(&ctl->n_steps, facc[0]);
-			ctl->n_rays = (u32)facc[1];
-			ctl->n_hits = (u32)facc[2];
-			ctl->dbg[41] = facc[3];  // (diagnostics: cells marked directly)
-			part[4u * gridDim.x] = 0ull;  // the ticket counter, for the next launch
+	__hip_atomic_store(&p->scan_done, d.fseq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Head of slot f (map stream, one wave): wait for scan f's scan half, then claim the run of scans this slot's walk applies.
+// (The wait is bounded: a tool that serialises kernels across streams -- rocprofv3 --pmc does -- would keep the producer
+// from ever running while this wave spins. The host uses events when it sees such a tool, ufomap_hip.hip: useGates; should
+// one slip through, the gate gives up after max_ticks and flags the scan, which then leaves the map alone, is repeated,
+// and the handle hands over with events from then on.)
+__global__ void k_claim(Pipe* p, unsigned long long f, u32 bmax, ScanCtl* ctl, unsigned long long max_ticks)
+{
+	if (0 != threadIdx.x) return;
+	const unsigned long long t0 = wall_clock64();
+	unsigned long long done;
+	while ((done = __hip_atomic_load(&p->scan_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < f) {
+		__builtin_amdgcn_s_sleep(1);
+		if (wall_clock64() - t0 > max_ticks) {  // 100 MHz clock
+			atomicOr(&ctl->err, ERR_GATE);
+			break;
 		}
 	}
-	foldBoxes(boxes, nboxes, ctl);
+	Pipe::Slot& sl = p->slot[f & (UFO_RING - 1u)];
+	const unsigned long long first = p->claimed + 1ull;  // scans up to f that have no slot of their own come along (the host
+	sl.first = first;                                     // sees to it that they share f's ray grid and are fewer than UFO_BATCH_MAX)
+	if (first > f) {
+		sl.B = 0;
+		return;
+	}
+	u32 B = (u32)(f - first) + 1u;
+	if (done >= f) {
+		const u32 geo = p->ring[f & (UFO_RING - 1u)].geo;
+		while (B < bmax && first + B <= done) {
+			const ScanDesc& d = p->ring[(first + B) & (UFO_RING - 1u)];
+			if (d.fseq != first + B || d.geo != geo) break;
+			++B;
+		}
+	}
+	p->claimed = first + B - 1u;
+	sl.B = B;
 }
 
 // ------------------------------------------------------------------------------------------------
 // F3: k_merge_slabs (scan_kernels.h) + which depth-3 tiles of the grid hold a marked cell (one bit per tile): the
-// tree-update kernels start from that bitmap instead of searching the grid.
+// tree-update kernels start from that bitmap instead of searching the grid. First kernel of a walk: for every scan the
+// walk has claimed.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_fmerge(FastGeo fg, const uint4* __restrict__ slabs, u32 n_slabs, u32 n4, uint4* __restrict__ grid,
-                                                 const unsigned long long* __restrict__ steps_part, u32* __restrict__ tile_bits,
-                                                 const BoxPartial* __restrict__ boxes, u32 nboxes, ScanCtl* ctl)
+__global__ __launch_bounds__(1024) void k_fmerge(FastGeo fg, const Pipe* __restrict__ p, unsigned long long f, u32 n4)
 {
 	__shared__ uint4 part[16][64];
 	__shared__ u32 tb[UFO_FAST_MAX_TILES / 32];
-	if (blockIdx.x + 1u == gridDim.x) {
-		foldBoxes(boxes, nboxes, ctl);
-		return;
-	}
-	const u32 nmerge = gridDim.x - 1u;  // workgroups that merge
-	if (ctl->err) return;
-	const u32 col = threadIdx.x & 63u, sl = threadIdx.x >> 6;
-	for (u32 j = threadIdx.x; j < UFO_FAST_MAX_TILES / 32; j += blockDim.x) tb[j] = 0;
-	if (steps_part && 0 == blockIdx.x && threadIdx.x < 64u) {
-		unsigned long long v = 0, r = 0, h = 0;
-		for (u32 s = threadIdx.x; s < n_slabs; s += 64u) {
-			v += steps_part[s];
-			r += steps_part[n_slabs + s];
-			h += steps_part[2u * n_slabs + s];
-		}
-		for (int o = 32; o > 0; o >>= 1) {
-			v += __shfl_xor(v, o);
-			r += __shfl_xor(r, o);
-			h += __shfl_xor(h, o);
-		}
-		if (0 == threadIdx.x) {
-			if (v) atomicAdd(&ctl->n_steps, v);
-			ctl->n_rays = (u32)r;
-			ctl->n_hits = (u32)h;
-		}
-	}
-	__syncthreads();
-	const u32 rowW = fg.rowBits >> 5, ny = 2u * (u32)fg.gr.nb[1];
-	for (u32 j0 = blockIdx.x * 64u; j0 < n4; j0 += nmerge * 64u) {
-		const u32 j = j0 + col;
-		uint4 acc = make_uint4(0, 0, 0, 0);
-		if (j < n4) {
-			for (u32 s = sl; s < n_slabs; s += 16u) {
-				const uint4 a = slabs[(size_t)s * n4 + j];
-				acc.x |= a.x;
-				acc.y |= a.y;
-				acc.z |= a.z;
-				acc.w |= a.w;
-			}
-		}
-		part[sl][col] = acc;
-		__syncthreads();
-		if (0 == sl && j < n4) {
-			for (u32 k = 1; k < 16u; ++k) {
-				const uint4 a = part[k][col];
-				acc.x |= a.x;
-				acc.y |= a.y;
-				acc.z |= a.z;
-				acc.w |= a.w;
-			}
-			grid[j] = acc;
-			const u32 wv[4] = {acc.x, acc.y, acc.z, acc.w};
-			for (u32 k = 0; k < 4u; ++k) {
-				u32 m = wv[k];
-				if (0 == m) continue;
-				const u32 widx = 4u * j + k;
-				const u32 row = widx / rowW, wx = widx % rowW;
-				const u32 ly = row % ny, lz = row / ny;
-				if (lz >= 2u * (u32)fg.gr.nb[2]) continue;  // (padding behind the last row)
-				const i32 ty = ((fg.gr.base[1] + (i32)ly) >> 3) - fg.tbase[1], tz = ((fg.gr.base[2] + (i32)lz) >> 3) - fg.tbase[2];
-				while (m) {
-					const u32 bit = (u32)__ffs(m) - 1u;
-					const i32 ax = fg.gr.base[0] + (i32)(32u * wx + bit);
-					const i32 tx = (ax >> 3) - fg.tbase[0];
-					// all cells of this word that fall into the same tile
-					const i32 first_in_tile = ((ax >> 3) << 3) - fg.gr.base[0] - (i32)(32u * wx);  // bit index of the tile's first cell (may be < 0)
-					const u32 lo = (u32)max(first_in_tile, 0), hi = (u32)min(first_in_tile + 8, 32);
-					const u32 span = (hi >= 32u ? 0xFFFFFFFFu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
-					m &= ~span;
-					const u32 tile = (u32)tx + fg.nt[0] * ((u32)ty + fg.nt[1] * (u32)tz);
-					if (tile < fg.ntiles) atomicOr(&tb[tile >> 5], 1u << (tile & 31u));
+	const Pipe::Slot sl = p->slot[f & (UFO_RING - 1u)];
+	for (u32 b = 0; b < sl.B; ++b) {
+		const ScanDesc& d = p->ring[(sl.first + b) & (UFO_RING - 1u)];
+		ScanCtl* ctl = d.ctl;
+		if (blockIdx.x + 1u == gridDim.x) {
+			// The LAST workgroup of the launch does not merge: it folds the scan's per-workgroup results
+			foldBoxes(d.boxes, d.nboxes, ctl);
+			if (threadIdx.x < 64u) {
+				unsigned long long v = 0, r = 0, h = 0;
+				for (u32 s = threadIdx.x; s < d.n_slabs; s += 64u) {
+					v += d.parts[s];
+					r += d.parts[d.n_slabs + s];
+					h += d.parts[2u * d.n_slabs + s];
+				}
+				for (int o = 32; o > 0; o >>= 1) {
+					v += __shfl_xor(v, o);
+					r += __shfl_xor(r, o);
+					h += __shfl_xor(h, o);
+				}
+				if (0 == threadIdx.x && 0 == ctl->err) {
+					if (v) atomicAdd(&ctl->n_steps, v);
+					ctl->n_rays = (u32)r;
+					ctl->n_hits = (u32)h;
 				}
 			}
+			__syncthreads();  // (foldBoxes' shared arrays are reused for the next scan)
+			continue;
 		}
+		const u32 nmerge = gridDim.x - 1u;  // workgroups that merge
+		if (ctl->err) continue;             // (uniform: the scan was flagged by its scan half; the walk will stand back)
+		const uint4* __restrict__ slabs = d.slabs;
+		uint4* __restrict__ grid = reinterpret_cast<uint4*>(d.gridM);
+		const u32 n_slabs = d.n_slabs;
+		const u32 col = threadIdx.x & 63u, sl16 = threadIdx.x >> 6;
+		for (u32 j = threadIdx.x; j < UFO_FAST_MAX_TILES / 32; j += blockDim.x) tb[j] = 0;
 		__syncthreads();
+		const u32 rowW = fg.rowBits >> 5, ny = 2u * (u32)fg.gr.nb[1];
+		for (u32 j0 = blockIdx.x * 64u; j0 < n4; j0 += nmerge * 64u) {
+			const u32 j = j0 + col;
+			uint4 acc = make_uint4(0, 0, 0, 0);
+			if (j < n4) {
+				for (u32 s = sl16; s < n_slabs; s += 16u) {
+					const uint4 a = slabs[(size_t)s * n4 + j];
+					acc.x |= a.x;
+					acc.y |= a.y;
+					acc.z |= a.z;
+					acc.w |= a.w;
+				}
+			}
+			part[sl16][col] = acc;
+			__syncthreads();
+			if (0 == sl16 && j < n4) {
+				for (u32 k = 1; k < 16u; ++k) {
+					const uint4 a = part[k][col];
+					acc.x |= a.x;
+					acc.y |= a.y;
+					acc.z |= a.z;
+					acc.w |= a.w;
+				}
+				grid[j] = acc;
+				const u32 wv[4] = {acc.x, acc.y, acc.z, acc.w};
+				for (u32 k = 0; k < 4u; ++k) {
+					u32 m = wv[k];
+					if (0 == m) continue;
+					const u32 widx = 4u * j + k;
+					const u32 row = widx / rowW, wx = widx % rowW;
+					const u32 ly = row % ny, lz = row / ny;
+					if (lz >= 2u * (u32)fg.gr.nb[2]) continue;  // (padding behind the last row)
+					const i32 ty = ((fg.gr.base[1] + (i32)ly) >> 3) - fg.tbase[1], tz = ((fg.gr.base[2] + (i32)lz) >> 3) - fg.tbase[2];
+					while (m) {
+						const u32 bit = (u32)__ffs(m) - 1u;
+						const i32 ax = fg.gr.base[0] + (i32)(32u * wx + bit);
+						const i32 tx = (ax >> 3) - fg.tbase[0];
+						// all cells of this word that fall into the same tile
+						const i32 first_in_tile = ((ax >> 3) << 3) - fg.gr.base[0] - (i32)(32u * wx);  // bit index of the tile's first cell (may be < 0)
+						const u32 lo = (u32)max(first_in_tile, 0), hi = (u32)min(first_in_tile + 8, 32);
+						const u32 span = (hi >= 32u ? 0xFFFFFFFFu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
+						m &= ~span;
+						const u32 tile = (u32)tx + fg.nt[0] * ((u32)ty + fg.nt[1] * (u32)tz);
+						if (tile < fg.ntiles) atomicOr(&tb[tile >> 5], 1u << (tile & 31u));
+					}
+				}
+			}
+			__syncthreads();
+		}
+		for (u32 j = threadIdx.x; j < (fg.ntiles + 31u) / 32u; j += blockDim.x)
+			if (tb[j]) atomicOr(&d.tile_bits[j], tb[j]);
+		__syncthreads();  // (tb is cleared for the next scan)
 	}
-	for (u32 j = threadIdx.x; j < (fg.ntiles + 31u) / 32u; j += blockDim.x)
-		if (tb[j]) atomicOr(&tile_bits[j], tb[j]);
 }
 
 // The node blocks above the tiles, found without searching: the tiles form a regular grid, so do their ancestors --
@@ -1180,15 +802,6 @@ __host__ __device__ inline u32 upperCell(const UpperGeo& ug, u32 l, const i32 c[
 // misses are applied after all hits in ascending code order: "the last update beneath a node" is always the miss in
 // the highest touched child of the LAST scan that touched it, at every level.
 // ------------------------------------------------------------------------------------------------
-#define UFO_BATCH_MAX 16u  // scans per walk (a larger batch is applied as several walks)
-struct TileBatch {
-	u32 B;
-	u32 pad;
-	const u32* gridM[UFO_BATCH_MAX];  // ray cells of scan b (bit grid, Grid::layout 1)
-	const u32* gridH[UFO_BATCH_MAX];  // hit voxels of scan b (same layout)
-	u32* tile_bits[UFO_BATCH_MAX];    // depth-3 tiles of the grid that hold a ray cell of scan b (cleared by k_ftail)
-	ScanCtl* ctl[UFO_BATCH_MAX];      // control block of scan b (err: the scan half flagged the scan; the walk stands back)
-};
 struct TileRec {
 	float occ, pre_occ;  // summary of the tile's level-3 block after the batch / just before its last update
 	u32 slot;            // table slot of the level-3 block
@@ -1241,14 +854,16 @@ __device__ inline bool tileKey(const MapGeom& g, const FastGeo& fg, u32 tile, u6
 	return true;
 }
 
-__global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, TileBatch tb, TileRec* __restrict__ recs, float upd_hit, float upd_miss,
-                                              u32 scan_id, const u32* __restrict__ prev_stat)
+__global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, const Pipe* __restrict__ p, unsigned long long f, TileRec* __restrict__ recs,
+                                              float upd_hit, float upd_miss, u32 scan_id, const u32* __restrict__ prev_stat)
 {
 	const u32 lane = threadIdx.x & 63u;
 	const u32 tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
 	if (tile >= fg.ntiles) return;
 	__builtin_amdgcn_s_setprio(2);  // (the map stream is the pipeline's critical path: ahead of the ray kernel's waves)
-	const u32 B = tb.B;
+	const Pipe::Slot sl = p->slot[f & (UFO_RING - 1u)];
+	const u32 B = sl.B;  // (0: the slot's scan went with an earlier walk)
+#define UFO_DESC(b) (p->ring[(sl.first + (b)) & (UFO_RING - 1u)])
 	// words that can end the wave here are asked for together (a wave's time is its chain of dependent round trips):
 	// the walk enqueued just before this one flagged itself and left the map alone (this one stands back too, k_ftail
 	// tells the host); a scan of the batch was flagged by its scan half (k_fhits / k_fcast), i.e. before anything touched
@@ -1256,8 +871,8 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, Ti
 	u32 errs = prev_stat ? *prev_stat : 0u;
 	u32 tmask = 0;  // bit b: the tile holds a ray cell of scan b
 	for (u32 b = 0; b < B; ++b) {
-		errs |= tb.ctl[b]->err;
-		tmask |= ((tb.tile_bits[b][tile >> 5] >> (tile & 31u)) & 1u) << b;
+		errs |= UFO_DESC(b).ctl->err;
+		tmask |= ((UFO_DESC(b).tile_bits[tile >> 5] >> (tile & 31u)) & 1u) << b;
 	}
 	if (errs) return;  // (uniform)
 	if (!tmask) return;
@@ -1302,8 +917,8 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, Ti
 			u32 wm[4][4], wh[4][4];
 #pragma unroll
 			for (int q = 0; q < 4; ++q) {
-				const u32* gM = tb.gridM[bs[q]];
-				const u32* gH = tb.gridH[bs[q]];
+				const u32* gM = UFO_DESC(bs[q]).gridM;
+				const u32* gH = UFO_DESC(bs[q]).gridH;
 #pragma unroll
 				for (int k = 0; k < 4; ++k) {
 					wm[q][k] = wok[k] ? gM[widx[k]] : 0u;
@@ -1387,7 +1002,7 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, Ti
 			v3s = __shfl(v3s, 0);
 			s2 = __shfl(s2, (int)(lane & ~7u));
 			if (__ballot((s3 == NONE) || (uact2 && s2 == NONE) || (uactive && s1 == NONE))) {
-				if (0 == lane) atomicOr(&tb.ctl[B - 1u]->err, ERR_TABLE_FULL);  // (the host sizes the table for the worst case before launching)
+				if (0 == lane) atomicOr(&UFO_DESC(B - 1u).ctl->err, ERR_TABLE_FULL);  // (the host sizes the table for the worst case before launching)
 				return;
 			}
 		}
@@ -1647,20 +1262,16 @@ __device__ inline u32 upperCellAt(const UpperLevel& u, u32 off, const i32 c[3])
 }
 #define UFO_FTAIL_THREADS 1024
 static_assert(UFO_FTAIL_THREADS == UFO_UPPER_MAX, "k_ftail: one thread per cell of the dense grids above the tiles");
-// where the scans of a walk report to: scan b's finished control block goes to host_result[b] (pinned host memory, or
-// device memory when nobody polls), followed by the word the host waits for
-struct TailBatch {
-	ScanCtl* host_result[UFO_BATCH_MAX];
-	unsigned long long done_value[UFO_BATCH_MAX];
-};
-__global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g, FastGeo fg, TileBatch tb, TailBatch hb,
+__global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g, FastGeo fg, Pipe* __restrict__ p, unsigned long long f,
                                                              const TileRec* __restrict__ recs, u32 scan_id, const u32* __restrict__ prev_stat,
-                                                             u32* __restrict__ own_stat, const ScanCtl* ctl_init)
+                                                             const ScanCtl* ctl_init)
 {
 	// the host waits for the word behind a scan's pinned result block, not for an event: an event record is one more packet
 	// the map stream's command processor has to get through between two scans (~5 us, scripts/micro/stream_wait.hip)
-	const u32 B = tb.B;
-	ScanCtl* const ctl = tb.ctl[B - 1u];  // what the walk as a whole reports (blocks touched / created, table fill, clocks) goes with its last scan
+	const Pipe::Slot sl = p->slot[f & (UFO_RING - 1u)];
+	const u32 B = sl.B;
+	if (0 == B) return;  // the slot's scan went with an earlier walk (which reports for it)
+	ScanCtl* const ctl = UFO_DESC(B - 1u).ctl;  // what the walk as a whole reports (blocks touched / created, table fill, clocks) goes with its last scan
 	// This lone workgroup shares its CU with waves of the next scan's ray kernel and of k_tile; its time is its chain of
 	// dependent instructions, so its waves take issue priority over theirs (measured: 35 -> 27 us when overlapped).
 	__builtin_amdgcn_s_setprio(3);
@@ -1680,27 +1291,28 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 		// (one round of loads: the error words and the scans' tile bitmaps, whose union is the walk's)
 		const u32 perr = prev_stat ? *prev_stat : 0u;
 		u32 cerr = 0;
-		for (u32 b = 0; b < B; ++b) cerr |= tb.ctl[b]->err;
+		for (u32 b = 0; b < B; ++b) cerr |= UFO_DESC(b).ctl->err;
 		for (u32 j = threadIdx.x; j < nwords; j += blockDim.x) {
 			u32 w = 0;
-			for (u32 b = 0; b < B; ++b) w |= tb.tile_bits[b][j];
+			for (u32 b = 0; b < B; ++b) w |= UFO_DESC(b).tile_bits[j];
 			tbits[j] = w;
 		}
 		if (perr | cerr) {
 			// the walk enqueued just before this one flagged itself and left the map alone, or the scan half of one of this
 			// walk's scans flagged it (ERR_SPEC / a bound): the whole walk stood back (k_tile), the map is as it was. Every
 			// scan of the walk is reported flagged -- with its own error, the others with ERR_PREV -- and the host repeats
-			// them in order; the walk enqueued behind this one finds own_stat set and stands back as well.
+			// them in order; the walk enqueued behind this one finds their status words set and stands back as well.
 			if (threadIdx.x < B) {
 				const u32 b = threadIdx.x;
-				const u32 own = tb.ctl[b]->err;
+				const ScanDesc& d = UFO_DESC(b);
+				const u32 own = d.ctl->err;
 				// (ERR_TABLE_FULL from this walk's own k_tile: the map IS inconsistent, and every scan of the walk says so)
-				const u32 e = ((perr || 0 == own) ? (atomicOr(&tb.ctl[b]->err, ERR_PREV) | ERR_PREV) : own) | (cerr & ERR_TABLE_FULL);
-				hb.host_result[b]->err = e;
+				const u32 e = ((perr || 0 == own) ? (atomicOr(&d.ctl->err, ERR_PREV) | ERR_PREV) : own) | (cerr & ERR_TABLE_FULL);
+				p->wstat[(sl.first + b) & (UFO_RING - 1u)] = 1u;
+				d.host_result->err = e;
 				__threadfence_system();
-				__hip_atomic_store(reinterpret_cast<unsigned long long*>(hb.host_result[b] + 1), hb.done_value[b], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+				__hip_atomic_store(reinterpret_cast<unsigned long long*>(d.host_result + 1), d.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 			}
-			if (0 == threadIdx.x) *own_stat = 1u;
 			return;
 		}
 	}
@@ -2040,7 +1652,7 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 	}
 	// this kernel is the tile bitmaps' last reader: leave them empty for their sets' next scans
 	for (u32 b = 0; b < B; ++b)
-		for (u32 j = threadIdx.x; j < nwords; j += blockDim.x) tb.tile_bits[b][j] = 0;
+		for (u32 j = threadIdx.x; j < nwords; j += blockDim.x) UFO_DESC(b).tile_bits[j] = 0;
 	if (0 == threadIdx.x) {
 		u32 used = __hip_atomic_load(&t.root->used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		if (created_total) {
@@ -2050,6 +1662,7 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 		ctl->dbg[19] = wall_clock64();
 		ctl->dbg[20] = U | ((unsigned long long)l << 32);
 		ctl->used_now = used;  // the host's view of the table's fill
+		ctl->dbg[45] = B;      // (scans this walk applied: the host's statistics)
 	}
 	// The finished control blocks go to the host's pinned copies from here (no read-back copy, no stream synchronisation on
 	// the host: it polls the word behind a block and reads), and the device copies return to the start state of a scan
@@ -2062,8 +1675,8 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 		constexpr u32 W = sizeof(ScanCtl) / 4u, W_USED = offsetof(ScanCtl, used_now) / 4u, W_ERR = offsetof(ScanCtl, err) / 4u;
 		for (u32 k = threadIdx.x; k < B * W; k += blockDim.x) {
 			const u32 b = k / W, w = k % W;
-			u32* dev = reinterpret_cast<u32*>(tb.ctl[b]);
-			u32* host = reinterpret_cast<u32*>(hb.host_result[b]);
+			u32* dev = reinterpret_cast<u32*>(UFO_DESC(b).ctl);
+			u32* host = reinterpret_cast<u32*>(UFO_DESC(b).host_result);
 			u32 x = __hip_atomic_load(&dev[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			if (W_USED == w) x = used;   // the table's fill after the walk: in every scan's block (the host reads whichever it joins)
 			if (W_ERR == w) x |= e;      // a failed walk has failed for all of its scans
@@ -2072,11 +1685,13 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 		}
 	}
 	__syncthreads();  // (every thread's stores to the pinned blocks have been acknowledged: the barrier waits for them)
-	if (threadIdx.x < B)
-		__hip_atomic_store(reinterpret_cast<unsigned long long*>(hb.host_result[threadIdx.x] + 1), hb.done_value[threadIdx.x], __ATOMIC_RELEASE,
-		                   __HIP_MEMORY_SCOPE_SYSTEM);
-	if (0 == threadIdx.x) *own_stat = e ? 1u : 0u;  // (the kernel's last actions; the walk enqueued behind this one looks at own_stat)
+	if (threadIdx.x < B) {  // (the kernel's last actions; the walk enqueued behind this one looks at the status words)
+		const ScanDesc& d = UFO_DESC(threadIdx.x);
+		p->wstat[(sl.first + threadIdx.x) & (UFO_RING - 1u)] = e ? 1u : 0u;
+		__hip_atomic_store(reinterpret_cast<unsigned long long*>(d.host_result + 1), d.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+	}
 }
+#undef UFO_DESC
 
 // Stream-to-stream hand-overs without events: a one-thread kernel at the end of the producing stream's work stores the
 // scan's number into a word of device memory (k_signal), a one-wave kernel in front of the consuming stream's work waits

@@ -157,19 +157,19 @@ constexpr int kAlt = 7;  // hand-over sets besides the current one: up to kAlt +
 struct HandOver {
 	DevBuf b_ctl, b_entries, b_hh_keys, b_in_xyz, b_in_rgb;  // b_hh_keys: hit hash, keys followed by point indices
 	// what the tree update of a fast-path scan (fast_kernels.h) reads after the scan half has moved on to the next scan
-	DevBuf b_gridM, b_gridH, b_part1, b_hit_code, b_first, b_tilebits;
+	DevBuf b_gridM, b_gridH, b_part1, b_hit_code, b_first, b_tilebits, b_slabs;
 	uint64_t seq = 0;         // running number of the integration that uses this set
 	bool first_dirty = true;  // b_first / b_tilebits are left clean by k_fcast / k_ftail unless the scan stood back
 	bool fast = false;        // the integration that uses this set runs on the fast path
-	bool deferred = false;    // ... and its tree update has not been enqueued yet: it will share a walk with the scans behind it
-	bool walk_last = false;   // ... and is the last scan of its walk
-	uint64_t walk_id = 0;     // running number of that walk (its status word: b_wstat[walk_id & 63])
+	uint64_t fseq = 0;        // ... its running number among the fast-path scans (Pipe: ring entry, slot, status word)
+	bool deferred = false;    // ... and no slot on the map stream has been enqueued for it yet (the next slot will take it along)
+	bool has_slot = false;    // ... a slot of its own has been enqueued for the scan
 	bool hit_grid = false;    // the hits of the set's scan are in b_gridH (fast path), not in the hit list (ufomap_map_last_hits)
 	FastGeo fgeo{};
 	UpperGeo ugeo{};
 	ScanCtl* h_ctl = nullptr;  // pinned
 	ScanCtl* h_res = nullptr;  // pinned: the finished control block as k_ftail stored it
-	unsigned long long *sig_prep = nullptr, *sig_scan = nullptr;  // signal memory: "first kernel done" / "scan half done" of the set's scan
+	unsigned long long* sig_prep = nullptr;  // signal memory: "first kernel done" of the set's scan
 	bool done_by_flag = false; // the set's integration announces its end in the word behind h_res, not by done_ev
 	bool ctl_clean = false;    // b_ctl holds the fast path's start state
 	void* h_stage = nullptr;   // pinned staging of a pageable host cloud (ufomap_map_insert): filled by the host, drained by
@@ -216,22 +216,22 @@ struct ufomap_map {
 	u64 used_est = 0;  // host-side view of MapRoot::used (refreshed at every control-block read)
 	// per-scan buffers
 	DevBuf b_ctl, b_pt_end, b_pt_flag, b_pt_slot, b_ray_end, b_hit_code, b_hit_pt, b_hh_keys;
-	DevBuf b_part0, b_part1, b_slabs, b_hb_keys, b_hb_mask, b_hb_time;
+	DevBuf b_part0, b_part1, b_slabs, b_hb_keys, b_hb_mask, b_hb_time;  // (b_slabs: per hand-over set on the fast path, HandOver)
 	DevBuf b_first, b_tilebits, b_gridH;  // fast path, per hand-over set (HandOver)
 	UpperGeo ugeo{};
 	DevBuf b_tilerec;             // fast path, map stream only
-	DevBuf b_wstat;               // fast path: status words of the last 64 walks (0: applied; else it stood back / failed)
+	DevBuf b_pipe;                // fast path: which walk applies which scan (fast_kernels.h: Pipe), device side
+	uint64_t n_fseq = 0;          // fast-path scans enqueued so far
+	u32 geo_id = 0;               // scans with the same geo id may share a walk: same ray grid, no other update of the map between them
+	bool chain_ok = false;        // the update enqueued last on the map stream was a fast-path slot (with ray grid chain_geo)
+	FastGeo chain_geo{};
 	DevBuf b_blk_range;           // k_select: where each of its workgroups' rays lie in the ray list (k_cast<2>)
-	bool first_dirty = true, fast = false, deferred = false, walk_last = false, hit_grid = false;  // (HandOver)
-	uint64_t walk_id = 0;         // (HandOver)
-	uint64_t n_walks = 0, n_walk_scans = 0, n_gate_timeouts = 0;  // fast-path walks enqueued, scans in them; stream hand-overs that timed out
-	int opt_batch_max = 8;        // scans per walk when scans queue up behind the tree update (1 = one walk per scan)
-	int opt_defer = 0;            // test aid: 1 = a scan's tree update waits for batch_max scans (or a join) whatever the map stream does
+	bool first_dirty = true, fast = false, hit_grid = false, deferred = false, has_slot = false;  // (HandOver)
+	uint64_t fseq = 0;            // (HandOver)
+	uint64_t n_walks = 0, n_walk_scans = 0, n_gate_timeouts = 0;  // fast-path walks that applied scans, scans in them; stream hand-overs that timed out
+	int opt_batch_max = 8;        // scans a walk may take when scans have queued up behind the map stream (1 = one walk per scan)
+	int opt_hold = 0;             // test aid: a slot is enqueued for every hold-th scan only (walks over several scans whatever the timing)
 	int opt_gate_us = 20000;      // a stream hand-over gives up after this long (and the handle stops using gates)
-	int opt_cast_sector = 1;      // fast path's ray kernel: 1 = sector form (k_fsect), 0 = whole grid per workgroup + slab merge (k_fcast, k_fmerge)
-	int opt_sect_box = 36 << 10;  // ... LDS budget of a sector's box of the ray grid (bytes)
-	DevBuf b_sect;                // k_fsect's per-workgroup partial results + ticket word (scan stream only)
-	uint64_t n_sect_direct = 0;   // k_fsect passes that had to mark the global grid directly (boxes beyond the LDS budget)
 	uint64_t seq = 0, latest_seq = 0;  // seq: of the integration that uses the current set; latest_seq: of the newest one enqueued
 	FastGeo fgeo{};
 	int opt_fast = 1;  // 0 = never take the fast path (fast_kernels.h)
@@ -249,7 +249,7 @@ struct ufomap_map {
 	DevBuf b_gridM, b_entries, b_ent_slot, b_newlist, b_wl0, b_wl1, b_in_xyz, b_in_rgb, b_codes, b_dump;
 	ScanCtl* h_ctl = nullptr;  // pinned
 	ScanCtl* h_res = nullptr;  // pinned: k_ftail stores the finished control block here itself (no read-back copy, no stream sync)
-	unsigned long long *sig_prep = nullptr, *sig_scan = nullptr;  // (HandOver)
+	unsigned long long* sig_prep = nullptr;  // (HandOver)
 	bool done_by_flag = false;
 	bool ctl_clean = false;    // the device control block holds the fast path's start state (k_ftail left it so): no upload
 	DevBuf b_ctl_init;         // that start state, uploaded once
@@ -479,9 +479,10 @@ void swapWith(ufomap_map* m, HandOver& o)
 	std::swap(m->b_in_rgb, o.b_in_rgb);
 	std::swap(m->b_gridM, o.b_gridM);
 	std::swap(m->b_gridH, o.b_gridH);
+	std::swap(m->fseq, o.fseq);
 	std::swap(m->deferred, o.deferred);
-	std::swap(m->walk_last, o.walk_last);
-	std::swap(m->walk_id, o.walk_id);
+	std::swap(m->has_slot, o.has_slot);
+	std::swap(m->b_slabs, o.b_slabs);
 	std::swap(m->hit_grid, o.hit_grid);
 	std::swap(m->b_part1, o.b_part1);
 	std::swap(m->b_hit_code, o.b_hit_code);
@@ -495,7 +496,6 @@ void swapWith(ufomap_map* m, HandOver& o)
 	std::swap(m->h_ctl, o.h_ctl);
 	std::swap(m->h_res, o.h_res);
 	std::swap(m->sig_prep, o.sig_prep);
-	std::swap(m->sig_scan, o.sig_scan);
 	std::swap(m->done_by_flag, o.done_by_flag);
 	std::swap(m->ctl_clean, o.ctl_clean);
 	std::swap(m->h_stage, o.h_stage);
@@ -1138,6 +1138,21 @@ int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, si
 	const FastGeo fg = makeFastGeo(m->spec_grid);
 	m->fgeo = fg;
 	m->fast = true;
+	// Scans may share a walk if they follow one another on the map stream and use the same ray grid (fast_kernels.h: k_claim);
+	// before a scan on a new grid, the scans that have no slot of their own yet get one
+	if (!m->chain_ok || 0 != memcmp(m->chain_geo.gr.base, fg.gr.base, sizeof(fg.gr.base)) || 0 != memcmp(m->chain_geo.gr.nb, fg.gr.nb, sizeof(fg.gr.nb))) {
+		const int frc = flushDeferred(m);
+		if (frc) return frc;
+		++m->geo_id;
+	}
+	m->fseq = ++m->n_fseq;
+	m->chain_ok = true;
+	m->chain_geo = fg;
+	// where the walk that takes this scan reports: armed BEFORE the scan half is enqueued -- an earlier slot may claim the
+	// scan as soon as its scan half has finished, i.e. before this call has enqueued the scan's own slot
+	m->h_res->err = ERR_NOT_STORED;
+	*reinterpret_cast<volatile unsigned long long*>(m->h_res + 1) = 0ull;  // k_ftail's "done" word
+	m->done_by_flag = true;
 	const u32 N = (u32)n;
 	const D3 sensor{origin[0], origin[1], origin[2]};
 	(void)makeUpperGeo(fg, m->g.L, &m->ugeo);
@@ -1196,31 +1211,12 @@ int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, si
 		HIP_TRY(hipStreamWaitEvent(m->sstream, m->prep_ev, 0));
 	}
 	m->cs = m->sstream;
-	if (m->opt_cast_sector) {
-		// sector form: a workgroup per 256 consecutive points, its box of the grid in LDS, ORed into the scan's grid; the
-		// workgroup that finishes last folds counters and boxes (fast_kernels.h: k_fsect) -- one launch
-		const u32 nwg = (N + UFO_SECT_THREADS - 1u) / UFO_SECT_THREADS;
-		const u32 box = (u32)std::min<u64>((u64)std::max(4096, m->opt_sect_box) & ~15ull, (fg.gr.bytes + 15ull) & ~15ull);
-		// per-workgroup steps / rays / hits / direct marks + the ticket word (which starts at 0; the last workgroup leaves it so)
-		const size_t pcap = m->b_sect.cap;
-		HIP_TRY(m->b_sect.reserve((size_t)(4u * nwg + 1u) * 8));
-		if (pcap != m->b_sect.cap) HIP_TRY(hipMemsetAsync(m->b_sect.p, 0, m->b_sect.cap, m->cs));
-		ProfScope ps(m, "k_fsect");
-		const size_t lds = (size_t)box + UFO_SECT_LDS_EXTRA;
-		if (discrete)
-			hipLaunchKernelGGL(k_fsect<true>, dim3(nwg), dim3(UFO_SECT_THREADS), lds, m->cs, m->g, fg, sensor, N, m->b_first.as<u32>(), m->b_gridM.as<u32>(),
-			                   m->b_gridH.as<u32>(), m->b_tilebits.as<u32>(), (u32)std::max(8, m->opt_cast_k), box, ctl, m->b_sect.as<unsigned long long>(),
-			                   m->b_hit_code.as<PointRec>(), m->b_part1.as<BoxPartial>(), gp.x);
-		else
-			hipLaunchKernelGGL(k_fsect<false>, dim3(nwg), dim3(UFO_SECT_THREADS), lds, m->cs, m->g, fg, sensor, N, m->b_first.as<u32>(), m->b_gridM.as<u32>(),
-			                   m->b_gridH.as<u32>(), m->b_tilebits.as<u32>(), (u32)std::max(8, m->opt_cast_k), box, ctl, m->b_sect.as<unsigned long long>(),
-			                   m->b_hit_code.as<PointRec>(), m->b_part1.as<BoxPartial>(), gp.x);
-	} else {
+	{
 		u32 nwg = m->opt_cast_wgs > 0 ? (u32)m->opt_cast_wgs : 256u;
 		nwg = std::max<u32>(1u, std::min<u32>(nwg, (N + 63u) / 64u));
 		const u32 cap_wg = (N + nwg - 1) / nwg;
 		HIP_TRY(m->b_ray_end.reserve((size_t)cap_wg * nwg * sizeof(D3)));
-		HIP_TRY(m->b_slabs.reserve((size_t)nwg * fg.gr.bytes + (size_t)nwg * 8 * 3));  // slabs + per-workgroup steps / rays / hits
+		HIP_TRY(m->b_slabs.reserve((size_t)nwg * fg.gr.bytes + (size_t)nwg * 8 * 3));  // slabs + per-workgroup steps / rays / hits (of this set: merged by the walk)
 		unsigned long long* sp = reinterpret_cast<unsigned long long*>(m->b_slabs.as<char>() + (size_t)nwg * fg.gr.bytes);
 		{
 			ProfScope ps(m, "k_fcast");
@@ -1232,52 +1228,38 @@ int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, si
 				hipLaunchKernelGGL(k_fcast<false>, dim3(nwg), dim3(512), lds, m->cs, m->g, fg, sensor, d_xyz, N, max_range, 0u, m->b_first.as<u32>(),
 				                   m->b_ray_end.as<D3>(), cap_wg, m->b_slabs.as<u32>(), (u32)std::max(8, m->opt_cast_k), ctl, ctl, sp, m->ing, m->b_hit_code.as<PointRec>(), m->b_gridH.as<u32>());
 		}
-		{
-			ProfScope ps(m, "k_fmerge");
-			const u32 n4 = (u32)(fg.gr.bytes >> 4);
-			hipLaunchKernelGGL(k_fmerge, dim3(std::min<u32>((n4 + 63) / 64, 1024) + 1u), dim3(1024), 0, m->cs, fg, m->b_slabs.as<uint4>(), nwg, n4,
-			                   m->b_gridM.as<uint4>(), sp, m->b_tilebits.as<u32>(), m->b_part1.as<BoxPartial>(), gp.x, ctl);
-		}
+		// end of the scan half: the scan's descriptor and number become visible to the walks (k_claim)
+		ScanDesc d{};
+		d.slabs = m->b_slabs.as<uint4>();
+		d.parts = sp;
+		d.gridM = m->b_gridM.as<u32>();
+		d.gridH = m->b_gridH.as<u32>();
+		d.tile_bits = m->b_tilebits.as<u32>();
+		d.ctl = ctl;
+		d.host_result = m->h_res;
+		d.boxes = m->b_part1.as<BoxPartial>();
+		d.done_value = (unsigned long long)m->seq;
+		d.fseq = (unsigned long long)m->fseq;
+		d.n_slabs = nwg;
+		d.nboxes = gp.x;
+		d.geo = m->geo_id;
+		hipLaunchKernelGGL(k_scan_done, dim3(1), dim3(1), 0, m->sstream, m->b_pipe.as<Pipe>(), d);
 	}
-	if (m->gates) hipLaunchKernelGGL(k_signal, dim3(1), dim3(1), 0, m->sstream, m->sig_scan, (unsigned long long)m->seq);
 	HIP_TRY(hipGetLastError());
 	++m->n_fast;
 	return UFOMAP_OK;
 }
 
-// What a walk needs from a hand-over set, wherever the set is (k < 0: the current set, whose members live in the map object).
-struct SetPtrs {
-	DevBuf *b_ctl, *b_gridM, *b_gridH, *b_tilebits;
-	ScanCtl** h_res;
-	uint64_t *seq, *walk_id;
-	u64* bound;
-	bool *pending, *deferred, *walk_last, *done_by_flag;
-	FastGeo* fgeo;
-	unsigned long long** sig_scan;
-};
-SetPtrs ptrsOf(ufomap_map* m, int k)
+// A slot on the map stream for a fast-path scan: k_claim (waits for the scan's scan half, claims the scans before it that
+// have no slot of their own and the scans behind it that are ready), k_fmerge, k_tile, k_ftail -- ONE walk of the tree for
+// the whole run (fast_kernels.h). k < 0: the current set's scan; else the scan of m->alt[k].
+int enqueueSlot(ufomap_map* m, int k)
 {
-	if (k < 0)
-		return SetPtrs{&m->b_ctl, &m->b_gridM, &m->b_gridH, &m->b_tilebits, &m->h_res, &m->seq, &m->walk_id, &m->bound, &m->pending, &m->deferred,
-		               &m->walk_last, &m->done_by_flag, &m->fgeo, &m->sig_scan};
-	HandOver& a = m->alt[k];
-	return SetPtrs{&a.b_ctl, &a.b_gridM, &a.b_gridH, &a.b_tilebits, &a.h_res, &a.seq, &a.walk_id, &a.bound, &a.pending, &a.deferred,
-	               &a.walk_last, &a.done_by_flag, &a.fgeo, &a.sig_scan};
-}
-
-// The tree update of a run of fast-path scans that share a ray grid -- ONE walk (k_tile + k_ftail) on the map stream,
-// the scans applied in order (fast_kernels.h). run[0 .. nrun): the scans' sets, oldest first (index into alt, < 0: the
-// current set); their scan halves have been enqueued on the scan stream.
-int enqueueWalk(ufomap_map* m, const int* run, int nrun)
-{
-	const SetPtrs last = ptrsOf(m, run[nrun - 1]);
-	const FastGeo fg = *last.fgeo;
-	const u64 bound = fastBound(m, fg.gr);  // (every block of the grid new: no more, however many scans walk it)
-	auto inRun = [&](int k) {
-		for (int i = 0; i < nrun; ++i)
-			if (run[i] == k) return true;
-		return false;
-	};
+	HandOver* const a = k < 0 ? nullptr : &m->alt[k];
+	const FastGeo fg = a ? a->fgeo : m->fgeo;
+	const uint64_t f = a ? a->fseq : m->fseq;
+	ScanCtl* const ctl = (a ? a->b_ctl : m->b_ctl).as<ScanCtl>();
+	const u64 bound = fastBound(m, fg.gr);  // (every block of the grid new: no more, however many scans the walk takes)
 	// The update enqueued just before this one, if it has not been joined: this walk looks at its status when it starts and
 	// stands back if that one did (everything flagged is then repeated in order when it is joined).
 	const u32* prev_stat = nullptr;
@@ -1287,13 +1269,18 @@ int enqueueWalk(ufomap_map* m, const int* run, int nrun)
 		in_flight = 0;
 		int pk = -1;
 		for (int i = 0; i < kAlt; ++i) {
-			const HandOver& a = m->alt[i];
-			if (!a.pending || a.deferred || inRun(i)) continue;
-			in_flight += a.bound;
-			if (pk < 0 || a.seq > m->alt[pk].seq) pk = i;
+			const HandOver& o = m->alt[i];
+			if (!o.pending || o.deferred || i == k) continue;
+			// (scans on this scan's own ray grid add nothing: `bound` is every block of that grid, whoever creates it)
+			const bool same_grid = o.fast && 0 == memcmp(o.fgeo.gr.base, fg.gr.base, sizeof(fg.gr.base)) && 0 == memcmp(o.fgeo.gr.nb, fg.gr.nb, sizeof(fg.gr.nb));
+			if (!same_grid) in_flight += o.bound;
+			// (a fast-path scan without a slot of its own goes with a later slot -- possibly this one: its status word is not
+			// written before this walk starts; the scan before it that has a slot is the predecessor to look at)
+			if (o.done_by_flag && !o.has_slot) continue;
+			if (pk < 0 || o.seq > m->alt[pk].seq) pk = i;
 		}
 		if (pk >= 0)
-			prev_stat = m->alt[pk].done_by_flag ? m->b_wstat.as<u32>() + (m->alt[pk].walk_id & 63u) : &m->alt[pk].b_ctl.as<ScanCtl>()->err;
+			prev_stat = m->alt[pk].done_by_flag ? &m->b_pipe.as<Pipe>()->wstat[m->alt[pk].fseq & (UFO_RING - 1u)] : &m->alt[pk].b_ctl.as<ScanCtl>()->err;
 	};
 	scanQueue();
 	m->cs = m->stream;
@@ -1307,7 +1294,7 @@ int enqueueWalk(ufomap_map* m, const int* run, int nrun)
 				scanQueue();
 			}
 			if ((m->used_est + bound) * 5 > ((u64)m->t.mask + 1) * 3) {
-				const u64 want = (m->used_est + 3 * bound) * 2;  // (room for the walks that will be enqueued behind this one, too)
+				const u64 want = (m->used_est + 2 * bound) * 2;  // (room for a neighbouring grid's walks behind this one, too)
 				if (want > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
 				m->cs = m->stream;
 				const int rc = growTable(m, nextPow2(want));
@@ -1317,55 +1304,42 @@ int enqueueWalk(ufomap_map* m, const int* run, int nrun)
 	}
 	m->scan_new_bound = bound;
 	m->scan_id += 1;
-	const uint64_t wid = ++m->n_walks;
-	m->n_walk_scans += (uint64_t)nrun;
 	HIP_TRY(m->b_tilerec.reserve((size_t)UFO_FAST_MAX_TILES * sizeof(TileRec)));
-	TileBatch tb{};
-	TailBatch hb{};
-	tb.B = (u32)nrun;
-	for (int i = 0; i < nrun; ++i) {
-		const SetPtrs p = ptrsOf(m, run[i]);
-		tb.gridM[i] = p.b_gridM->as<u32>();
-		tb.gridH[i] = p.b_gridH->as<u32>();
-		tb.tile_bits[i] = p.b_tilebits->as<u32>();
-		tb.ctl[i] = p.b_ctl->as<ScanCtl>();
-		hb.host_result[i] = *p.h_res;
-		hb.done_value[i] = (unsigned long long)*p.seq;
-		(*p.h_res)->err = ERR_NOT_STORED;
-		*reinterpret_cast<volatile unsigned long long*>(*p.h_res + 1) = 0ull;  // k_ftail's "done" word
-		*p.pending = true;
-		*p.deferred = false;
-		*p.done_by_flag = true;
-		*p.walk_last = i + 1 == nrun;
-		*p.walk_id = wid;
-		*p.bound = (i + 1 == nrun) ? bound : 0;
-	}
+	(a ? a->pending : m->pending) = true;
+	(a ? a->deferred : m->deferred) = false;
+	(a ? a->has_slot : m->has_slot) = true;
+	(a ? a->bound : m->bound) = bound;
 	m->cs = m->stream;
-	// the map stream waits for the scan half of the run's newest scan (the scan stream works them off in order): its
-	// signal word, or -- without gates -- the event recorded behind it
-	if (m->gates)
-		hipLaunchKernelGGL(k_gate, dim3(1), dim3(1), 0, m->stream, *last.sig_scan, (unsigned long long)*last.seq, tb.ctl[nrun - 1], gateTicks(m));
-	else
-		HIP_TRY(hipStreamWaitEvent(m->stream, m->scan_ev, 0));
+	Pipe* pipe = m->b_pipe.as<Pipe>();
+	const u32 bmax = (u32)std::max(1, std::min<int>(m->opt_batch_max, (int)UFO_BATCH_MAX));
+	// without gates (a tool serialises kernels across streams) the map stream waits for the event behind the newest scan
+	// half; k_claim then finds the scan complete and only takes its decision
+	if (!m->gates) HIP_TRY(hipStreamWaitEvent(m->stream, m->scan_ev, 0));
+	hipLaunchKernelGGL(k_claim, dim3(1), dim3(64), 0, m->stream, pipe, (unsigned long long)f, bmax, ctl, gateTicks(m));
+	{
+		ProfScope ps(m, "k_fmerge");
+		const u32 n4 = (u32)(fg.gr.bytes >> 4);
+		hipLaunchKernelGGL(k_fmerge, dim3(std::min<u32>((n4 + 63) / 64, 1024) + 1u), dim3(1024), 0, m->cs, fg, pipe, (unsigned long long)f, n4);
+	}
 	const float miss = (float)m->g.miss_log;  // insert depth 0 (OMB:311)
-	u32* own_stat = m->b_wstat.as<u32>() + (wid & 63u);
 	{
 		ProfScope ps(m, "k_tile");
 		const u32 tw = (m->opt_tile_waves >= 1 && m->opt_tile_waves <= 4) ? (u32)m->opt_tile_waves : 4u;  // wavefronts (= tiles) per workgroup
-		hipLaunchKernelGGL(k_tile, dim3((fg.ntiles + tw - 1) / tw), dim3(64u * tw), 0, m->cs, m->t, m->g, fg, tb, m->b_tilerec.as<TileRec>(), m->g.hit, miss,
-		                   m->scan_id, prev_stat);
+		hipLaunchKernelGGL(k_tile, dim3((fg.ntiles + tw - 1) / tw), dim3(64u * tw), 0, m->cs, m->t, m->g, fg, pipe, (unsigned long long)f, m->b_tilerec.as<TileRec>(),
+		                   m->g.hit, miss, m->scan_id, prev_stat);
 	}
 	{
 		ProfScope ps(m, "k_ftail");
-		hipLaunchKernelGGL(k_ftail, dim3(1), dim3(UFO_FTAIL_THREADS), 0, m->cs, m->t, m->g, fg, tb, hb, m->b_tilerec.as<TileRec>(), m->scan_id, prev_stat,
-		                   own_stat, m->b_ctl_init.as<ScanCtl>());
+		hipLaunchKernelGGL(k_ftail, dim3(1), dim3(UFO_FTAIL_THREADS), 0, m->cs, m->t, m->g, fg, pipe, (unsigned long long)f, m->b_tilerec.as<TileRec>(), m->scan_id,
+		                   prev_stat, m->b_ctl_init.as<ScanCtl>());
 	}
 	HIP_TRY(hipGetLastError());
 	return UFOMAP_OK;
 }
 
-// Enqueue the tree updates of every scan that is still waiting for company: runs of scans on the same ray grid share a
-// walk. (The current set holds the newest integration; what waits is always the newest scans.)
+// The scans that have no slot on the map stream yet get one: a slot for the newest of them takes the others along (k_claim;
+// one slot per batch_max scans). (The current set holds the newest integration; what waits is always the newest scans,
+// and they share a ray grid: fastScanPhase.)
 int flushDeferred(ufomap_map* m)
 {
 	int idx[kAlt + 1], n = 0;
@@ -1374,17 +1348,17 @@ int flushDeferred(ufomap_map* m)
 	std::sort(idx, idx + n, [&](int a, int b) { return m->alt[a].seq < m->alt[b].seq; });
 	if (m->pending && m->deferred) idx[n++] = -1;
 	const int bmax = std::max(1, std::min<int>(m->opt_batch_max, (int)UFO_BATCH_MAX));
-	for (int a = 0; a < n;) {
-		int b = a + 1;
-		const FastGeo& ga = *ptrsOf(m, idx[a]).fgeo;
-		while (b < n && b - a < bmax) {
-			const FastGeo& gb = *ptrsOf(m, idx[b]).fgeo;
-			if (0 != memcmp(ga.gr.base, gb.gr.base, sizeof(ga.gr.base)) || 0 != memcmp(ga.gr.nb, gb.gr.nb, sizeof(ga.gr.nb))) break;
-			++b;
+	for (int a = 0; a < n; ++a) {
+		if (a + 1 == n || 0 == (a + 1) % bmax) {
+			const int rc = enqueueSlot(m, idx[a]);
+			if (rc) return rc;
+		} else {
+			// (goes with the slot enqueued for a newer scan: joined like any other integration, by its own word in pinned memory)
+			HandOver* const h = idx[a] < 0 ? nullptr : &m->alt[idx[a]];
+			(h ? h->deferred : m->deferred) = false;
+			(h ? h->has_slot : m->has_slot) = false;
+			(h ? h->bound : m->bound) = 0;
 		}
-		const int rc = enqueueWalk(m, idx + a, b - a);
-		if (rc) return rc;
-		a = b;
 	}
 	return UFOMAP_OK;
 }
@@ -1438,12 +1412,11 @@ int finishPending(ufomap_map* m)
 		memcpy(m->h_ctl, m->h_res, sizeof(ScanCtl));
 		m->used_est = m->h_ctl->used_now;
 		m->ctl_clean = true;
-		if (m->opt_cast_sector && m->h_ctl->dbg[40]) {
-			// sectors of this scan did not fit their LDS budget and marked the global grid cell by cell: a cloud whose points
-			// are not ordered in space. If that was a sizeable part of the scan, this handle goes back to whole-grid workgroups.
-			m->n_sect_direct += m->h_ctl->dbg[40];
-			if (m->h_ctl->dbg[41] * 8 > m->h_ctl->n_steps && 1 == m->opt_cast_sector) m->opt_cast_sector = 0;
+		if (m->h_ctl->dbg[45]) {  // (the last scan of a walk carries the number of scans the walk applied)
+			++m->n_walks;
+			m->n_walk_scans += m->h_ctl->dbg[45];
 		}
+
 	} else {
 		rc = readCtlDone(m);
 	}
@@ -1903,30 +1876,32 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 			(void)hipStreamSynchronize(m->sstream);
 			return rc;
 		}
-		// ---- the tree update: ONE walk for as many scans as have queued up (enqueueWalk). The scan's update is enqueued
-		// right away unless two walks are already waiting on the map stream -- then it waits for company: the walk that is
-		// enqueued once one of those has finished takes every scan that has arrived by then (up to batch_max) in one go,
-		// its cost all but independent of their number. A host that feeds scans no faster than the map stream takes them
-		// never waits; anything that needs the map (wait, done, a query, a general-path update, a set to reuse) enqueues
-		// what is waiting first.
+		// ---- the tree update: the scan's slot on the map stream (enqueueSlot). Whichever walk gets there first takes the
+		// scan: its own slot's, or the slot of an earlier scan that found this one's scan half already complete.
 		m->pending = true;
 		m->deferred = true;
 		m->bound = 0;
 		m->last_rgb = nullptr;
 		const auto t_map = std::chrono::steady_clock::now();
-		bool defer = false;
-		const int bmax = std::max(1, std::min<int>(m->opt_batch_max, (int)UFO_BATCH_MAX));
-		if (async && m->opt_early && !m->profiling && bmax > 1) {
-			int ndef = 1, nwalk = 0, nidle = 0;
+		// No slot of its own for a scan while two slots are still waiting on the map stream: the second of them takes every
+		// scan along whose scan half is ready when it starts, and what is not ready then goes with the next slot that is
+		// enqueued -- instead of a slot per scan, most of which would find their scan taken and cost four empty launches.
+		// When the map stream keeps up (fewer than two slots waiting) every scan gets its slot at once.
+		bool hold = false;
+		if (async && !m->profiling && m->opt_early) {
+			int nheld = 1, nidle = 0, nslots = 0;
 			for (int i = 0; i < kAlt; ++i) {
-				const HandOver& a = m->alt[i];
-				if (!a.pending) ++nidle;
-				else if (a.deferred) ++ndef;
-				else if ((!a.done_by_flag || a.walk_last) && !setDoneNow(a)) ++nwalk;
+				const HandOver& o = m->alt[i];
+				if (!o.pending) ++nidle;
+				else if (o.deferred) ++nheld;
+				else if (o.done_by_flag && o.has_slot && !setDoneNow(o)) ++nslots;
+				else if (!o.done_by_flag) ++nslots;
 			}
-			defer = ndef < bmax && nidle > 0 && (m->opt_defer || nwalk >= 2);
+			const int bmax = std::max(1, std::min<int>(m->opt_batch_max, (int)UFO_BATCH_MAX));
+			hold = nidle > 0 && nheld < std::min(bmax, 4) && nslots >= 2;
+			if (m->opt_hold > 1) hold = nidle > 0 && nheld < std::min(m->opt_hold, bmax);  // (test aid: a slot for every hold-th scan)
 		}
-		if (!defer) {
+		if (!hold) {
 			rc = flushDeferred(m);
 			if (rc) return rc;
 		}
@@ -1964,6 +1939,7 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 	// ---- the general path ----
 	m->fast = false;
 	m->deferred = false;
+	m->chain_ok = false;  // (no walk may take scans from either side of this update together)
 	{
 		// its tree update is enqueued by this call: what waits for company goes first; at most two older integrations stay in flight
 		const int frc = flushDeferred(m);
@@ -2071,6 +2047,7 @@ int redoScan(ufomap_map* m)
 	const ScanArgs a = m->args;
 	m->args.spec = false;
 	m->spec_valid = false;
+	m->chain_ok = false;
 	++m->n_spec_redo;
 	// an update enqueued behind this one looks at this control block when it starts: let it do so (and stand back)
 	// before the block is rewritten
@@ -2166,10 +2143,18 @@ ufomap_map* ufomap_map_create(double resolution, unsigned depth_levels, int auto
 	g.color = has_color ? 1 : 0;
 	g.pruning = automatic_pruning ? 1 : 0;
 	setSensorModel(m, occupied_thres, free_thres, prob_hit, prob_miss, clamping_thres_min, clamping_thres_max);
-	bool ok = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) == hipSuccess &&
-	          hipStreamCreateWithFlags(&m->sstream, hipStreamNonBlocking) == hipSuccess &&
+	// The three streams of the pipeline get three different PRIORITIES -- not to order their work (it is ordered by gates),
+	// but because the runtime multiplexes streams onto a few hardware queues (4 by default) and streams of different
+	// priority never share one: two pipeline streams on one hardware queue run strictly one after the other, a gate
+	// spinning in front of the work it waits for. (Measured with several handles created one after the other in one
+	// process: 0.066 ms per scan when the streams happened to get queues of their own, 0.106 when two shared one.)
+	int prio_lo = 0, prio_hi = 0;
+	(void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);  // (least, greatest: numerically lower = higher priority)
+	const int prio_mid = (prio_lo + prio_hi) / 2;
+	bool ok = hipStreamCreateWithPriority(&m->stream, hipStreamNonBlocking, prio_hi) == hipSuccess &&
+	          hipStreamCreateWithPriority(&m->sstream, hipStreamNonBlocking, prio_mid) == hipSuccess &&
 	          hipStreamCreateWithFlags(&m->xstream, hipStreamNonBlocking) == hipSuccess &&
-	          hipStreamCreateWithFlags(&m->pstream, hipStreamNonBlocking) == hipSuccess &&
+	          hipStreamCreateWithPriority(&m->pstream, hipStreamNonBlocking, prio_lo) == hipSuccess &&
 	          hipEventCreateWithFlags(&m->prep_ev, hipEventDisableTiming) == hipSuccess &&
 	          hipEventCreateWithFlags(&m->done_ev, hipEventDisableTiming) == hipSuccess &&
 	          hipEventCreateWithFlags(&m->scan_ev, hipEventDisableTiming) == hipSuccess &&
@@ -2177,9 +2162,8 @@ ufomap_map* ufomap_map_create(double resolution, unsigned depth_levels, int auto
 	          hipHostMalloc((void**)&m->h_ctl, sizeof(ScanCtl) + 64) == hipSuccess &&
 	          hipHostMalloc((void**)&m->h_res, sizeof(ScanCtl) + 64) == hipSuccess &&
 	          m->b_ctl_init.reserve(sizeof(ScanCtl) + 64) == hipSuccess &&
-	          m->b_wstat.reserve(64 * 4) == hipSuccess && hipMemset(m->b_wstat.p, 0, 64 * 4) == hipSuccess &&
+	          m->b_pipe.reserve(sizeof(Pipe)) == hipSuccess && hipMemset(m->b_pipe.p, 0, sizeof(Pipe)) == hipSuccess &&
 	          hipMalloc((void**)&m->sig_prep, 8) == hipSuccess && hipMemset(m->sig_prep, 0, 8) == hipSuccess &&
-	          hipMalloc((void**)&m->sig_scan, 8) == hipSuccess && hipMemset(m->sig_scan, 0, 8) == hipSuccess &&
 	          hipHostMalloc((void**)&m->h_root, sizeof(MapRoot)) == hipSuccess &&
 	          m->b_ctl.reserve(sizeof(ScanCtl) + 64) == hipSuccess && m->b_root.reserve(sizeof(MapRoot)) == hipSuccess;
 	for (int i = 0; ok && i < kAlt; ++i) {
@@ -2187,7 +2171,6 @@ ufomap_map* ufomap_map_create(double resolution, unsigned depth_levels, int auto
 		ok = hipEventCreateWithFlags(&a.done_ev, hipEventDisableTiming) == hipSuccess &&
 		     hipHostMalloc((void**)&a.h_ctl, sizeof(ScanCtl) + 64) == hipSuccess && hipHostMalloc((void**)&a.h_res, sizeof(ScanCtl) + 64) == hipSuccess &&
 		     hipMalloc((void**)&a.sig_prep, 8) == hipSuccess && hipMemset(a.sig_prep, 0, 8) == hipSuccess &&
-		     hipMalloc((void**)&a.sig_scan, 8) == hipSuccess && hipMemset(a.sig_scan, 0, 8) == hipSuccess &&
 		     a.b_ctl.reserve(sizeof(ScanCtl) + 64) == hipSuccess;
 		if (ok) memset(a.h_ctl, 0, sizeof(ScanCtl));
 	}
@@ -2215,8 +2198,7 @@ ufomap_map* ufomap_map_create(double resolution, unsigned depth_levels, int auto
 		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cast<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (160 << 10) - 512);
 		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cast<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (160 << 10) - 512);
 		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cast<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (160 << 10) - 512);
-		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fsect<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (160 << 10) - 2048);
-		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fsect<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (160 << 10) - 2048);
+
 	}
 	for (int a = 0; a < 3; ++a) {
 		m->min_change[a] = g.hs[g.L];  // resetMinMaxChangeDetection (occupancy_map_base.h:806-810)
@@ -2235,12 +2217,11 @@ void ufomap_map_destroy(ufomap_map* m)
 	m->tb.release();
 	m->b_changes.release();
 	for (HandOver& a : m->alt) {
-		DevBuf* abufs[] = {&a.b_ctl, &a.b_entries, &a.b_hh_keys, &a.b_in_xyz, &a.b_in_rgb, &a.b_gridM, &a.b_gridH, &a.b_part1, &a.b_hit_code, &a.b_first, &a.b_tilebits};
+		DevBuf* abufs[] = {&a.b_ctl, &a.b_entries, &a.b_hh_keys, &a.b_in_xyz, &a.b_in_rgb, &a.b_gridM, &a.b_gridH, &a.b_part1, &a.b_hit_code, &a.b_first, &a.b_tilebits, &a.b_slabs};
 		for (DevBuf* b : abufs) b->release();
 		if (a.h_ctl) (void)hipHostFree(a.h_ctl);
 		if (a.h_res) (void)hipHostFree(a.h_res);
 		if (a.sig_prep) (void)hipFree(a.sig_prep);
-		if (a.sig_scan) (void)hipFree(a.sig_scan);
 		if (a.h_stage) (void)hipHostFree(a.h_stage);
 		if (a.done_ev) (void)hipEventDestroy(a.done_ev);
 	}
@@ -2252,7 +2233,7 @@ void ufomap_map_destroy(ufomap_map* m)
 	                  &m->b_ctl,     &m->b_pt_end,  &m->b_pt_flag,  &m->b_pt_slot, &m->b_ray_end, &m->b_hit_code, &m->b_hit_pt,
 	                  &m->b_hh_keys, &m->b_gridM,   &m->b_crec,    &m->b_dlist,   &m->b_rays,   &m->b_part0,   &m->b_part1,   &m->b_slabs,   &m->b_hb_keys, &m->b_hb_mask, &m->b_hb_time,   &m->b_entries, &m->b_ent_slot, &m->b_newlist,
 	                  &m->b_wl0,     &m->b_wl1,     &m->b_in_xyz,   &m->b_in_rgb,  &m->b_codes,   &m->b_dump,
-	                  &m->b_first,   &m->b_tilebits, &m->b_tilerec, &m->b_gridH, &m->b_wstat, &m->b_sect, &m->b_blk_range, &m->b_ctl_init};
+	                  &m->b_first,   &m->b_tilebits, &m->b_tilerec, &m->b_gridH, &m->b_pipe, &m->b_blk_range, &m->b_ctl_init};
 	for (DevBuf* b : bufs) b->release();
 	for (PendingEvent& pe : m->pend_ev) {
 		(void)hipEventDestroy(pe.a);
@@ -2262,7 +2243,6 @@ void ufomap_map_destroy(ufomap_map* m)
 	if (m->h_ctl) (void)hipHostFree(m->h_ctl);
 	if (m->h_res) (void)hipHostFree(m->h_res);
 	if (m->sig_prep) (void)hipFree(m->sig_prep);
-	if (m->sig_scan) (void)hipFree(m->sig_scan);
 	if (m->h_stage) (void)hipHostFree(m->h_stage);
 	if (m->copy_ev) (void)hipEventDestroy(m->copy_ev);
 	if (m->h_root) (void)hipHostFree(m->h_root);
@@ -2816,6 +2796,7 @@ int ufomap_map_wait(ufomap_map* m)
 	}
 	m->async_status = UFOMAP_OK;
 	m->prev_flagged = false;
+	m->chain_ok = false;  // (whatever touches the map next: no walk takes scans from either side of it together)
 	return rc;
 }
 
@@ -3285,6 +3266,8 @@ int ufomap_map_apply_keys_batch(ufomap_map* m, const void* const* d_lists, const
 	if (total > 0x7FFFFFFFull) return fail(UFOMAP_ERR_CAPACITY, "update lists exceed 2^31 entries");
 	m->cs = m->stream;
 	m->args = ScanArgs{};
+	m->chain_ok = false;
+	m->fast = false;
 	ScanCtl init;
 	memset(&init, 0, sizeof(init));
 	for (int a = 0; a < 3; ++a) {
@@ -4129,14 +4112,10 @@ int ufomap_map_set_option(ufomap_map* m, const char* key, long long value)
 		m->opt_tile_waves = (int)value;
 	} else if (0 == strcmp(key, "gates")) {
 		m->opt_gates = value ? 1 : 0;
-	} else if (0 == strcmp(key, "cast_sector")) {
-		m->opt_cast_sector = (int)value;  // (2: sector form whatever the clouds look like)
-	} else if (0 == strcmp(key, "sect_box")) {
-		m->opt_sect_box = (int)std::max<long long>(4096, std::min<long long>(value, 120 << 10));
 	} else if (0 == strcmp(key, "batch_max")) {
 		m->opt_batch_max = (int)std::max<long long>(1, std::min<long long>(value, (long long)UFO_BATCH_MAX));
-	} else if (0 == strcmp(key, "defer")) {
-		m->opt_defer = value ? 1 : 0;
+	} else if (0 == strcmp(key, "hold")) {
+		m->opt_hold = (int)std::max<long long>(0, std::min<long long>(value, kAlt));
 	} else if (0 == strcmp(key, "gate_us")) {
 		m->opt_gate_us = (int)std::max<long long>(100, std::min<long long>(value, 10000000));
 	} else if (0 == strcmp(key, "sparse_set")) {
@@ -4180,7 +4159,6 @@ int ufomap_map_debug(ufomap_map* m, uint64_t* out, int n)
 	if (n > 61) out[61] = m->n_fast;       // scans enqueued on the fast path (fast_kernels.h)
 	if (n > 60) out[60] = m->n_walks;      // ... walks of the tree that applied them (one walk takes every scan that has queued up)
 	if (n > 59) out[59] = m->n_walk_scans; // ... scans in those walks
-	if (n > 57) out[57] = m->n_sect_direct;  // sector passes of the fast path's ray kernel that marked the global grid directly
 	if (n > 58) out[58] = m->n_gate_timeouts;  // stream hand-overs that timed out (the handle uses events from then on)
 	if (n > 51) out[51] = m->n_phase_resets;  // phaseGuard
 	for (int k = 0; k < 4 && 52 + k < n; ++k) out[52 + k] = m->host_ns[k];  // host time inside doInsert (ns): scan enqueue, map enqueue, join, total
