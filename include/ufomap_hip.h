@@ -78,11 +78,10 @@ int ufomap_map_set_sensor_model(ufomap_map* m, double occupied_thres, double fre
  * inputs are copied/consumed before the call returns either way (SURVEY.md 8b ownership).
  * The call first joins any previous integration (occupancy_map_base.h:315).
  * ufomap_map_insert takes HOST pointers (H2D copy included); ufomap_map_insert_device takes
- * DEVICE pointers already resident in HBM. With async != 0 a device cloud must stay valid and unchanged
- * until the integration has been joined -- by ufomap_map_wait, by any reader, or by the SECOND-NEXT insert call
- * returning (insert i joins insert i-2 before it returns; two updates may be in flight): kernels read it after
- * the call has returned, and a scan that was enqueued on a ray grid predicted from the previous scan and turns out not to
- * fit it is repeated from the same buffer at that join ("spec", ufomap_map_set_option). */
+ * DEVICE pointers already resident in HBM. Either way the caller's buffers are not referenced after the call has
+ * returned, asynchronous or not: the steady-state path reads a device cloud with its first kernel only, keeps the
+ * points it needs for a possible repeat of the scan, and the call returns when that kernel has run (normally before
+ * the rest of the scan has been enqueued); the general path works on a device-to-device copy. */
 int ufomap_map_insert(ufomap_map* m, const double sensor_origin[3], const double* xyz,
                       const uint8_t* rgb, size_t n, double max_range, unsigned depth, int discrete,
                       int simple_ray_casting, unsigned early_stopping, int async);
@@ -302,6 +301,10 @@ ufomap_comm* ufomap_comm_create(const uint8_t id[UFOMAP_COMM_ID_BYTES], int worl
 ufomap_comm* ufomap_comm_from_nccl(void* nccl_comm, int world, int rank, int device);
 void ufomap_comm_destroy(ufomap_comm* c);
 int ufomap_comm_stats(const ufomap_comm* c, uint64_t out[4]);
+/* out[0] steps of ufomap_map_insert_batch that exchanged bit grids and applied all ranks' scans with one walk (the steady
+ * state), [1] steps that were repeated in update-list form (a rank's scan did not fit the ranks' common ray grid),
+ * [2] 1 if the ranks currently share a ray grid, [3] reserved */
+int ufomap_comm_counters(const ufomap_comm* c, uint64_t out[4]);
 int ufomap_map_insert_batch(ufomap_map* m, ufomap_comm* c, const double sensor_origin[3], const double* d_xyz,
                             const uint8_t* d_rgb /* colour maps: 3 bytes per point; else NULL */, size_t n, double max_range,
                             unsigned depth, int discrete);

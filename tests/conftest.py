@@ -9,6 +9,11 @@ import sys
 import numpy as np
 import pytest
 
+try:  # torch first: it brings its own copy of the HIP runtime, and whichever copy is loaded first owns the GPU -- a test
+    import torch  # noqa: F401  that loads libufomap_hip.so (linked against /opt/rocm) before torch would leave torch without devices
+except Exception:  # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -150,3 +150,147 @@ def test_many_handles_keep_their_maps_apart():
         g.insertPointCloudWait()
         _assert_same_map(g, o, f"map {k}")
 
+
+
+@pytest.mark.parametrize("color", [False, True])
+def test_device_cloud_may_be_reused_as_soon_as_the_call_returns(color):
+    """ufomap_map_insert_device(async=1): the caller's device buffers are overwritten with garbage the moment each call has
+    returned -- while the scan is still in flight, and before the scans that have to be REPEATED (the sensor jumps: the
+    predicted ray grid does not fit) are repeated. The map must equal the reference's all the same (include/ufomap_hip.h:
+    inputs are consumed before the call returns)."""
+    from oracle import OracleMap
+    from ufomap_amd import OccupancyMap, OccupancyMapColor, scans
+    g = (OccupancyMapColor if color else OccupancyMap)(0.16)
+    o = OracleMap(0.16, kind="port", color=color)
+    base = np.array(scans.lidar_pose(0), dtype=np.float64)
+    offs = [(0, 0, 0), (0.05, 0, 0), (0.1, 0.05, 0), (5.0, 3.0, 0.2), (5.1, 3.0, 0.2), (0.1, 0, 0), (0.15, 0, 0), (-4.0, 2.0, 0), (0, 0, 0), (0.02, 0, 0)]
+    n = 16 * 512
+    d = torch.empty((n, 3), dtype=torch.float64, device="cuda")
+    drgb = torch.empty((n, 3), dtype=torch.uint8, device="cuda")
+    for i, off in enumerate(offs):
+        origin, xyz, rgb = scans.lidar64(beams=16, azimuths=512, origin=tuple(base + np.array(off)), seed=300 + i, colored=color)
+        d.copy_(torch.from_numpy(xyz))
+        if color:
+            drgb.copy_(torch.from_numpy(rgb))
+        torch.cuda.synchronize()
+        g.insert_device(origin, d.data_ptr(), drgb.data_ptr() if color else None, n, 10.0, 0, True, False, 0, True)
+        d.fill_(float(1000 + i))  # the buffers are the caller's again
+        drgb.fill_(7)
+        torch.cuda.synchronize()
+        o.insert(origin, xyz, rgb if color else None, max_range=10.0, discrete=True)
+    g.insertPointCloudWait()
+    gl, ol = g.leaves(True), o.leaves(True)
+    assert all(np.array_equal(a, b) for a, b in zip(gl, ol)) and same_dump(g.inner(), o.inner())
+    if not color:
+        assert g.debug()[63] >= 1, "the jumps should have forced repeats"
+
+
+# ---- ufomap_map_insert_batch with MORE THAN ONE RANK, through the C ABI, on one GPU -----------------------------------------
+# tests/cpp/rccl_shim.cpp stands in for librccl (UFOMAP_RCCL_LIB): two processes on device 0, the all-gather staged through
+# POSIX shared memory. What is tested is everything around the collective: the slot/capacity-growth loop of the update-list
+# form, the fast-path form (bit grids, one walk for both ranks' scans), the ranks' common ray grid, the collective repeat
+# of a step that a rank's scan does not fit, an empty cloud on one rank -- every replica must equal the reference's map
+# after the same scans one by one in (step, rank) order.
+
+def _build_shim():
+    import os
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    src, out = os.path.join(here, "cpp", "rccl_shim.cpp"), os.path.join(here, "cpp", "librccl_shim.so")
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        subprocess.run(["/opt/rocm/bin/hipcc", "-O2", "-shared", "-fPIC", src, "-o", out, "-lrt"], check=True, capture_output=True)
+    return out
+
+
+def _batch_plan(world, steps):
+    """(step, rank) -> (origin, cloud parameters): sensors that drift, one that jumps by metres (the common grid does not fit),
+    one empty cloud."""
+    from ufomap_amd import scans
+    plan = {}
+    for i in range(steps):
+        for r in range(world):
+            base = np.array(scans.lidar_pose(r % 4), dtype=np.float64)
+            off = np.array([0.05 * i, -0.03 * i * (r + 1), 0.0])
+            if i == 5 and r == world - 1:
+                off = off + np.array([7.0, 5.0, 0.2])  # jump: this rank's scan leaves the ranks' common grid
+            empty = (i == 3 and r == 0)
+            plan[(i, r)] = (tuple(base + off), 700 + 10 * i + r, empty)
+    return plan
+
+
+def _batch_cloud(entry):
+    from ufomap_amd import scans
+    origin, seed, empty = entry
+    o, xyz, _ = scans.lidar64(beams=16, azimuths=512, origin=origin, seed=seed)
+    return o, (xyz[:0] if empty else xyz)
+
+
+def _batch_rank(rank, world, steps, shim, id_q, out_q, comm_slot):
+    import os
+    os.environ["UFOMAP_RCCL_LIB"] = shim
+    os.environ["UFOMAP_COMM_SLOT"] = str(comm_slot)
+    import torch as th
+    from ufomap_amd import OccupancyMap
+    from ufomap_amd.occupancy_map import Comm
+    try:
+        if rank == 0:
+            uid = Comm.unique_id()
+            for _ in range(world - 1):
+                id_q.put(uid)
+        else:
+            uid = id_q.get(timeout=120)
+        g = OccupancyMap(0.16)
+        g.set_option("async_apply", 1)
+        comm = Comm(uid, world, rank, 0)
+        plan = _batch_plan(world, steps)
+        keep = []
+        for i in range(steps):
+            origin, xyz = _batch_cloud(plan[(i, rank)])
+            d = th.from_numpy(np.ascontiguousarray(xyz)).cuda() if len(xyz) else th.empty(0, dtype=th.float64, device="cuda")
+            keep.append(d)
+            g.insert_batch(comm, origin, d.data_ptr() if len(xyz) else 0, len(xyz), 10.0, 0, True)
+        g.insertPointCloudWait()
+        out_q.put((rank, g.digest(), comm.counters(), comm.stats(), g.debug()[58:64]))
+        comm.close()
+    except Exception as e:  # noqa: BLE001
+        out_q.put((rank, "error: " + repr(e), None, None, None))
+
+
+def test_insert_batch_two_ranks_on_one_gpu():
+    import torch.multiprocessing as mp
+    from oracle import OracleMap
+    from ufomap_amd import OccupancyMap
+    shim = _build_shim()
+    world, steps = 2, 9
+    ctx = mp.get_context("spawn")
+    id_q, out_q = ctx.Queue(), ctx.Queue()
+    procs = [ctx.Process(target=_batch_rank, args=(r, world, steps, shim, id_q, out_q, 4096)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = {}
+    for _ in range(world):
+        r = out_q.get(timeout=300)
+        results[r[0]] = r
+    for p in procs:
+        p.join(timeout=60)
+    for r in range(world):
+        assert not isinstance(results[r][1], str), results[r][1]
+    # the reference's map after the same scans, one by one, in (step, rank) order
+    o = OracleMap(0.16, kind=_kind())
+    g1 = OccupancyMap(0.16)  # ... and its digest through the single-GPU path (the digest is computed on the device)
+    plan = _batch_plan(world, steps)
+    from ufomap_amd import PointCloud
+    for i in range(steps):
+        for r in range(world):
+            origin, xyz = _batch_cloud(plan[(i, r)])
+            o.insert(origin, xyz, max_range=10.0, discrete=True)
+            g1.insertPointCloudDiscrete(origin, PointCloud(xyz), 10.0)
+    _assert_same_map(g1, o, "single-GPU path vs reference")
+    want = g1.digest()
+    for r in range(world):
+        assert results[r][1] == want, f"replica of rank {r} differs from the sequential map"
+    c0 = results[0][2]
+    assert c0 == results[1][2], "the ranks disagree about which steps took which form"
+    assert c0["fast_steps"] >= 4, f"the fast-path form of the step did not run: {c0}"
+    assert c0["repeated_steps"] >= 1, f"the jump should have forced a collective repeat: {c0}"
+    assert results[0][3]["regrown"] >= 1, "the update-list slot should have had to grow (4 KiB to start with)"

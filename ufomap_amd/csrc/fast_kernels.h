@@ -154,7 +154,8 @@ struct PointRec {
 template <bool DISCRETE>
 __global__ __launch_bounds__(256) void k_fhits(MapGeom g, FastGeo fg, D3 sensor, const double* __restrict__ xyz, u32 n, double max_range,
                                                u32 color_variant, u32* __restrict__ first, BoxPartial* __restrict__ part, ScanCtl* ctl,
-                                               Ingest ing, PointRec* __restrict__ recs, uint4* __restrict__ gridH4, uint4* __restrict__ gridM4, u32 n4)
+                                               Ingest ing, PointRec* __restrict__ recs, uint4* __restrict__ gridH4, uint4* __restrict__ gridM4, u32 n4,
+                                               double* __restrict__ keep)
 {
 	const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
 	// the scan's hit grid (one bit per cell, the ray grid's layout; marked by the ray kernel for the first point of every
@@ -168,6 +169,16 @@ __global__ __launch_bounds__(256) void k_fhits(MapGeom g, FastGeo fg, D3 sensor,
 	i32 ck[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, ek[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
 	bool odd = false;
 	if (i < n) {
+		if (keep) {
+			// The caller's cloud is read by THIS kernel only: the point as it enters the head loop (map frame, float64; NaN for a
+			// point the ingest drops) is kept in the hand-over set, so that a scan that has to be repeated -- it did not fit
+			// its predicted grid -- never goes back to a buffer the caller may have reused since the call returned.
+			D3 pt;
+			if (!loadPoint(xyz, ing, i, &pt)) pt = D3{__builtin_nan(""), __builtin_nan(""), __builtin_nan("")};
+			keep[3 * (size_t)i] = pt.x;
+			keep[3 * (size_t)i + 1] = pt.y;
+			keep[3 * (size_t)i + 2] = pt.z;
+		}
 		const PointRay r = pointRay<DISCRETE>(g, fg, sensor, xyz, ing, i, max_range, color_variant, amn, amx);
 		odd = r.odd;
 		PointRec pr;
@@ -618,8 +629,44 @@ struct Pipe {
 __global__ void k_scan_done(Pipe* p, ScanDesc d)
 {
 	p->ring[d.fseq & (UFO_RING - 1u)] = d;
-	__threadfence();
 	__hip_atomic_store(&p->scan_done, d.fseq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+// A walk whose scans the HOST names (several GPUs: the scans of all ranks, gathered; ufomap_map_insert_batch): slot 0 of a
+// Pipe of its own applies scans 0 .. B-1, the descriptors arrive as kernel arguments.
+struct DescPack {
+	ScanDesc d[UFO_BATCH_MAX];
+};
+__global__ void k_batch_descs(Pipe* p, DescPack pack, u32 B)
+{
+	if (threadIdx.x < B) p->ring[threadIdx.x] = pack.d[threadIdx.x];
+	if (0 == threadIdx.x) {
+		p->slot[0].first = 0;
+		p->slot[0].B = B;
+	}
+}
+// What a rank contributes to the exchange of a batch step, in one piece: [control block (1 KiB) | tile bitmap (1 KiB) |
+// ray cells | hit voxels] -- 2 KiB + two bit grids, ~200 KB for a 16 cm / 20 m scan (the update list of the same scan: 0.8 MB).
+#define UFO_XSLOT_CTL 1024u
+#define UFO_XSLOT_HDR 2048u
+static_assert(sizeof(ScanCtl) <= UFO_XSLOT_CTL && UFO_FAST_MAX_TILES / 8u <= UFO_XSLOT_HDR - UFO_XSLOT_CTL, "exchange slot layout");
+__global__ __launch_bounds__(256) void k_pack_slot(uint4* __restrict__ dst, const uint4* __restrict__ ctl, const uint4* __restrict__ tile_bits,
+                                                   const uint4* __restrict__ gridM, const uint4* __restrict__ gridH, u32 n4)
+{
+	const u32 nctl = (u32)((sizeof(ScanCtl) + 15u) / 16u), ntb = UFO_FAST_MAX_TILES / 8u / 16u;
+	const u32 total = UFO_XSLOT_HDR / 16u + 2u * n4;
+	for (u32 j = blockIdx.x * blockDim.x + threadIdx.x; j < total; j += gridDim.x * blockDim.x) {
+		uint4 v = make_uint4(0, 0, 0, 0);
+		if (j < UFO_XSLOT_CTL / 16u) {
+			if (j < nctl) v = ctl[j];
+		} else if (j < UFO_XSLOT_HDR / 16u) {
+			if (j - UFO_XSLOT_CTL / 16u < ntb) v = tile_bits[j - UFO_XSLOT_CTL / 16u];
+		} else if (j < UFO_XSLOT_HDR / 16u + n4) {
+			v = gridM[j - UFO_XSLOT_HDR / 16u];
+		} else {
+			v = gridH[j - UFO_XSLOT_HDR / 16u - n4];
+		}
+		dst[j] = v;
+	}
 }
 // Head of slot f (map stream, one wave): wait for scan f's scan half, then claim the run of scans this slot's walk applies.
 // (The wait is bounded: a tool that serialises kernels across streams -- rocprofv3 --pmc does -- would keep the producer
@@ -1698,9 +1745,11 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 // for it (k_gate; a single wave cannot keep anything from being scheduled). Measured per hand-over, stream idle time
 // included (scripts/micro/stream_wait*.hip and rocprofv3 traces of the pipeline): event record + wait 9-15 us,
 // hipStreamWaitValue64 on signal memory 5-7 us (it is a polling kernel too, on host-coherent memory), this 2-3 us.
-__global__ void k_signal(unsigned long long* flag, unsigned long long value)
+__global__ void k_signal(unsigned long long* flag, unsigned long long value, unsigned long long* host_flag)
 {
 	__hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+	// (pinned host memory: the call that enqueued the scan returns once k_fhits has consumed the caller's cloud)
+	if (host_flag) __hip_atomic_store(host_flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // (The wait is bounded: a tool that serialises kernels across streams -- rocprofv3 --pmc does -- would keep the producer
 // from ever running while this wave spins. The host does not use gates when it sees such a tool, ufomap_hip.hip:

@@ -164,6 +164,14 @@ struct HandOver {
 	uint64_t fseq = 0;        // ... its running number among the fast-path scans (Pipe: ring entry, slot, status word)
 	bool deferred = false;    // ... and no slot on the map stream has been enqueued for it yet (the next slot will take it along)
 	bool has_slot = false;    // ... a slot of its own has been enqueued for the scan
+	DevBuf b_keep;            // the scan's points as its head loop saw them (written by k_fhits): what a repeat of the scan reads
+	// a step of ufomap_map_insert_batch on the fast path: this rank's scan, exchanged as bit grids, one walk for all ranks' scans
+	int batch_world = 0;           // 0: not such a step; else the number of ranks
+	struct ufomap_comm* comm = nullptr;
+	DevBuf b_xsend, b_xrecv, b_bpipe;  // exchange slot of this rank, the gathered slots, the walk's own Pipe (fast_kernels.h)
+	uint8_t* h_res_all = nullptr;  // pinned: the finished control blocks of the other ranks' scans (errors, boxes)
+	int h_res_all_world = 0;
+	hipEvent_t xchg_ev = nullptr;  // end of the all-gather on the scan stream
 	bool hit_grid = false;    // the hits of the set's scan are in b_gridH (fast path), not in the hit list (ufomap_map_last_hits)
 	FastGeo fgeo{};
 	UpperGeo ugeo{};
@@ -227,7 +235,15 @@ struct ufomap_map {
 	FastGeo chain_geo{};
 	DevBuf b_blk_range;           // k_select: where each of its workgroups' rays lie in the ray list (k_cast<2>)
 	bool first_dirty = true, fast = false, hit_grid = false, deferred = false, has_slot = false;  // (HandOver)
+	int batch_world = 0;          // (HandOver)
+	struct ufomap_comm* comm = nullptr;
+	DevBuf b_xsend, b_xrecv, b_bpipe;
+	uint8_t* h_res_all = nullptr;
+	int h_res_all_world = 0;
+	hipEvent_t xchg_ev = nullptr;
 	uint64_t fseq = 0;            // (HandOver)
+	DevBuf b_keep;                // (HandOver)
+	unsigned long long* h_prep = nullptr;  // pinned: integration number of the newest scan whose k_fhits has finished (k_signal)
 	uint64_t n_walks = 0, n_walk_scans = 0, n_gate_timeouts = 0;  // fast-path walks that applied scans, scans in them; stream hand-overs that timed out
 	int opt_batch_max = 8;        // scans a walk may take when scans have queued up behind the map stream (1 = one walk per scan)
 	int opt_hold = 0;             // test aid: a slot is enqueued for every hold-th scan only (walks over several scans whatever the timing)
@@ -480,8 +496,17 @@ void swapWith(ufomap_map* m, HandOver& o)
 	std::swap(m->b_gridM, o.b_gridM);
 	std::swap(m->b_gridH, o.b_gridH);
 	std::swap(m->fseq, o.fseq);
+	std::swap(m->b_keep, o.b_keep);
 	std::swap(m->deferred, o.deferred);
 	std::swap(m->has_slot, o.has_slot);
+	std::swap(m->batch_world, o.batch_world);
+	std::swap(m->comm, o.comm);
+	std::swap(m->b_xsend, o.b_xsend);
+	std::swap(m->b_xrecv, o.b_xrecv);
+	std::swap(m->b_bpipe, o.b_bpipe);
+	std::swap(m->h_res_all, o.h_res_all);
+	std::swap(m->h_res_all_world, o.h_res_all_world);
+	std::swap(m->xchg_ev, o.xchg_ev);
 	std::swap(m->b_slabs, o.b_slabs);
 	std::swap(m->hit_grid, o.hit_grid);
 	std::swap(m->b_part1, o.b_part1);
@@ -1125,7 +1150,7 @@ bool fastEligible(const ufomap_map* m, const Grid& gr, unsigned depth, int simpl
 unsigned long long gateTicks(const ufomap_map* m) { return (unsigned long long)std::max(100, m->opt_gate_us) * 100ull; }  // wall_clock64: 100 MHz
 
 // scan half on the scan stream: first-point array, rays, merged bit grid + tile bitmap
-int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, size_t n, double max_range, int discrete)
+int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, size_t n, double max_range, int discrete, bool batch_step = false)
 {
 	HIP_TRY(hipSetDevice(m->device));
 	for (int k = 0; k < 8; ++k) m->counts[k] = 0;
@@ -1140,14 +1165,22 @@ int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, si
 	m->fast = true;
 	// Scans may share a walk if they follow one another on the map stream and use the same ray grid (fast_kernels.h: k_claim);
 	// before a scan on a new grid, the scans that have no slot of their own yet get one
-	if (!m->chain_ok || 0 != memcmp(m->chain_geo.gr.base, fg.gr.base, sizeof(fg.gr.base)) || 0 != memcmp(m->chain_geo.gr.nb, fg.gr.nb, sizeof(fg.gr.nb))) {
+	if (batch_step) {
+		// (a step of ufomap_map_insert_batch: its walk is enqueued by the host for the scans of all ranks; no claims)
 		const int frc = flushDeferred(m);
 		if (frc) return frc;
-		++m->geo_id;
+		m->chain_ok = false;
+		m->fseq = 0;
+	} else {
+		if (!m->chain_ok || 0 != memcmp(m->chain_geo.gr.base, fg.gr.base, sizeof(fg.gr.base)) || 0 != memcmp(m->chain_geo.gr.nb, fg.gr.nb, sizeof(fg.gr.nb))) {
+			const int frc = flushDeferred(m);
+			if (frc) return frc;
+			++m->geo_id;
+		}
+		m->fseq = ++m->n_fseq;
+		m->chain_ok = true;
+		m->chain_geo = fg;
 	}
-	m->fseq = ++m->n_fseq;
-	m->chain_ok = true;
-	m->chain_geo = fg;
 	// where the walk that takes this scan reports: armed BEFORE the scan half is enqueued -- an earlier slot may claim the
 	// scan as soon as its scan half has finished, i.e. before this call has enqueued the scan's own slot
 	m->h_res->err = ERR_NOT_STORED;
@@ -1171,6 +1204,15 @@ int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, si
 	HIP_TRY(m->b_gridH.reserve(fg.gr.bytes));  // hit voxels, the ray grid's layout: zeroed by k_fhits, marked by k_fcast, read by k_tile
 	m->hit_grid = true;
 	HIP_TRY(m->b_hit_code.reserve(n * sizeof(PointRec)));  // (per-point records of the head loop: k_fhits -> k_fcast)
+	// a cloud in the caller's device memory (or raw records) is kept as float64 points for a possible repeat of the scan; a
+	// host cloud already lies in the set's own staging buffer
+	double* keep = nullptr;
+	if (m->ing.data || d_xyz != m->b_in_xyz.as<double>()) {
+		HIP_TRY(m->b_keep.reserve(n * 24));
+		keep = m->b_keep.as<double>();
+		m->args.d_xyz = keep;
+		m->args.ing = Ingest{};
+	}
 	ScanCtl init;
 	memset(&init, 0, sizeof(init));
 	for (int a = 0; a < 3; ++a) {
@@ -1196,15 +1238,15 @@ int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, si
 		ProfScope ps(m, "k_fhits");
 		if (discrete)
 			hipLaunchKernelGGL(k_fhits<true>, gp, dim3(256), 0, m->cs, m->g, fg, sensor, d_xyz, N, max_range, 0u, m->b_first.as<u32>(),
-			                   m->b_part1.as<BoxPartial>(), ctl, m->ing, m->b_hit_code.as<PointRec>(), m->b_gridH.as<uint4>(), m->b_gridM.as<uint4>(), (u32)(fg.gr.bytes >> 4));
+			                   m->b_part1.as<BoxPartial>(), ctl, m->ing, m->b_hit_code.as<PointRec>(), m->b_gridH.as<uint4>(), m->b_gridM.as<uint4>(), (u32)(fg.gr.bytes >> 4), keep);
 		else
 			hipLaunchKernelGGL(k_fhits<false>, gp, dim3(256), 0, m->cs, m->g, fg, sensor, d_xyz, N, max_range, 0u, m->b_first.as<u32>(),
-			                   m->b_part1.as<BoxPartial>(), ctl, m->ing, m->b_hit_code.as<PointRec>(), m->b_gridH.as<uint4>(), m->b_gridM.as<uint4>(), (u32)(fg.gr.bytes >> 4));
+			                   m->b_part1.as<BoxPartial>(), ctl, m->ing, m->b_hit_code.as<PointRec>(), m->b_gridH.as<uint4>(), m->b_gridM.as<uint4>(), (u32)(fg.gr.bytes >> 4), keep);
 	}
 	// stream-to-stream hand-overs of this path: k_signal / k_gate (fast_kernels.h), not events
 	m->gates = useGates(m);
 	if (m->gates) {
-		hipLaunchKernelGGL(k_signal, dim3(1), dim3(1), 0, m->pstream, m->sig_prep, (unsigned long long)m->seq);
+		hipLaunchKernelGGL(k_signal, dim3(1), dim3(1), 0, m->pstream, m->sig_prep, (unsigned long long)m->seq, m->h_prep);
 		hipLaunchKernelGGL(k_gate, dim3(1), dim3(1), 0, m->sstream, m->sig_prep, (unsigned long long)m->seq, ctl, gateTicks(m));
 	} else {
 		HIP_TRY(hipEventRecord(m->prep_ev, m->pstream));
@@ -1243,10 +1285,42 @@ int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, si
 		d.n_slabs = nwg;
 		d.nboxes = gp.x;
 		d.geo = m->geo_id;
-		hipLaunchKernelGGL(k_scan_done, dim3(1), dim3(1), 0, m->sstream, m->b_pipe.as<Pipe>(), d);
+		if (!batch_step) {
+			hipLaunchKernelGGL(k_scan_done, dim3(1), dim3(1), 0, m->sstream, m->b_pipe.as<Pipe>(), d);
+		} else {
+			// the other ranks get this scan as two bit grids, not as 256 slabs: merged here, on the scan stream
+			DescPack pk{};
+			pk.d[0] = d;
+			pk.d[0].fseq = 0;
+			Pipe* bp = m->b_bpipe.as<Pipe>();
+			hipLaunchKernelGGL(k_batch_descs, dim3(1), dim3(64), 0, m->sstream, bp, pk, 1u);
+			ProfScope ps(m, "k_fmerge");
+			const u32 n4 = (u32)(fg.gr.bytes >> 4);
+			hipLaunchKernelGGL(k_fmerge, dim3(std::min<u32>((n4 + 63) / 64, 1024) + 1u), dim3(1024), 0, m->sstream, fg, bp, 0ull, n4);
+		}
 	}
 	HIP_TRY(hipGetLastError());
 	++m->n_fast;
+	return UFOMAP_OK;
+}
+
+// The call returns once the caller's device cloud has been consumed: k_fhits has run (fast path: the word k_signal stores
+// in pinned memory, normally there long before the rest of the call has been enqueued), or the prep stream's event.
+int awaitCloudConsumed(ufomap_map* m)
+{
+	if (m->gates) {
+		volatile unsigned long long* hp = m->h_prep;
+		const auto t0 = std::chrono::steady_clock::now();
+		for (u32 spins = 0; *hp < (unsigned long long)m->seq; ++spins) {
+			if (0 == (spins & 1023u) && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) {
+				HIP_TRY(hipStreamSynchronize(m->pstream));
+				break;
+			}
+		}
+		std::atomic_thread_fence(std::memory_order_acquire);
+		return UFOMAP_OK;
+	}
+	HIP_TRY(hipEventSynchronize(m->prep_ev));
 	return UFOMAP_OK;
 }
 
@@ -1363,25 +1437,18 @@ int flushDeferred(ufomap_map* m)
 	return UFOMAP_OK;
 }
 
-// Predict the ray grid of the next depth-0 scan from the box of the one just finished: the same box plus a margin
-// of up to two node blocks for sensor motion, as long as k_cast still fits its bit grid and segment queue in LDS.
-void predictGrid(ufomap_map* m)
+// The ray grid for the next depth-0 scans from a box of ray cells [mn, mx]: first choice the union of the box with the
+// grid predicted so far (a sensor that moves about a room keeps producing boxes inside one hull, and a prediction that
+// covers the hull never misses again), second choice the box alone, each with up to two node blocks of margin for sensor
+// motion -- as long as the ray kernel still fits its bit grid and segment queue in LDS.
+bool gridFromBox(bool had, const Grid& prev, const i32 bmn[3], const i32 bmx[3], Grid* out)
 {
-	const bool had = m->spec_valid;
-	const Grid prev = m->spec_grid;
-	m->spec_valid = false;
-	const ScanArgs& a = m->args;
-	if (!m->opt_spec || !m->opt_merge || !m->opt_cast || !m->opt_bits || !m->opt_dda_seg || m->opt_dda_mode > 0) return;
-	if (0 != a.depth || a.simple || 0 == a.n || 0 == m->h_ctl->n_rays) return;
-	// First choice: the union of this scan's box with the grid predicted so far -- a sensor that moves about a room keeps
-	// producing boxes inside one hull, and a prediction that covers the hull never misses again. Second choice: this
-	// scan's box alone, with up to two blocks of margin for sensor motion.
-	for (int pass = (had && 0 == prev.depth) ? 0 : 1; pass < 2 && !m->spec_valid; ++pass) {
-		for (int margin = 2; margin >= 0 && !m->spec_valid; --margin) {
+	for (int pass = (had && 0 == prev.depth) ? 0 : 1; pass < 2; ++pass) {
+		for (int margin = 2; margin >= 0; --margin) {
 			i32 mn[3], mx[3];
 			for (int k = 0; k < 3; ++k) {
-				mn[k] = m->h_ctl->mb_min[k] - 2 * margin;
-				mx[k] = m->h_ctl->mb_max[k] + 2 * margin;
+				mn[k] = bmn[k] - 2 * margin;
+				mx[k] = bmx[k] + 2 * margin;
 				if (0 == pass) {
 					// interior of the previous grid (makeGrid pads by one block on either side)
 					mn[k] = std::min(mn[k], prev.base[k] + 2);
@@ -1395,11 +1462,27 @@ void predictGrid(ufomap_map* m)
 			if (!packed || ((bytes1 + 15) & ~15ull) + UFO_CAST_LDS_EXTRA > (160u << 10) - 512u) continue;
 			gr.layout = 1;
 			gr.bytes = (bytes1 + 15) & ~15ull;
-			m->spec_grid = gr;
-			m->spec_valid = true;
+			*out = gr;
+			return true;
 		}
 	}
+	return false;
 }
+
+// Predict the ray grid of the next depth-0 scan from the box of the one just finished.
+void predictGrid(ufomap_map* m)
+{
+	const bool had = m->spec_valid;
+	const Grid prev = m->spec_grid;
+	m->spec_valid = false;
+	const ScanArgs& a = m->args;
+	if (!m->opt_spec || !m->opt_merge || !m->opt_cast || !m->opt_bits || !m->opt_dda_seg || m->opt_dda_mode > 0) return;
+	if (0 != a.depth || a.simple || 0 == a.n || 0 == m->h_ctl->n_rays) return;
+	m->spec_valid = gridFromBox(had, prev, m->h_ctl->mb_min, m->h_ctl->mb_max, &m->spec_grid);
+}
+
+int redoBatchStep(ufomap_map* m);
+void predictCommonGrid(ufomap_map* m);
 
 int finishPending(ufomap_map* m)
 {
@@ -1435,12 +1518,18 @@ int finishPending(ufomap_map* m)
 		++m->n_gate_timeouts;
 		m->opt_gates = 0;
 	}
+	if (m->batch_world) {
+		// a step of ufomap_map_insert_batch: a flagged scan of ANY rank made the walk stand back on every rank (all see the
+		// same gathered control blocks), and every rank repeats the step here, at the same point of its sequence of calls
+		if (m->h_ctl->err & (ERR_SPEC | ERR_PREV | ERR_GATE | ERR_RUNAWAY)) return redoBatchStep(m);
+		if (0 == m->h_ctl->err) predictCommonGrid(m);
+	}
 	if (m->h_ctl->err && m->args.n && (m->args.spec || (m->h_ctl->err & (ERR_PREV | ERR_GATE)))) return redoScan(m);
 	rc = ctlError(m);
 	if (rc) return rc;
 	m->counts[1] = m->h_ctl->n_rays;
 	m->counts[3] = m->h_ctl->n_hits;
-	if (m->args.n) predictGrid(m);  // (non-scan updates leave the prediction as it is)
+	if (m->args.n && !m->batch_world) predictGrid(m);  // (non-scan updates leave the prediction as it is)
 	m->counts[5] = (u64)m->h_ctl->n_entries[0] + m->h_ctl->n_entries[1];
 	m->counts[2] = m->h_ctl->n_steps;
 	m->counts[6] = (u64)m->h_ctl->ph[0].n_new + m->h_ctl->ph[1].n_new;
@@ -1821,8 +1910,11 @@ int joinOlder(ufomap_map* m)
 }
 
 int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const uint8_t* d_rgb, size_t n, double max_range,
-             unsigned depth, int discrete, int simple, unsigned early_stopping, int async, bool swapped, int spec_mode = 0)
+             unsigned depth, int discrete, int simple, unsigned early_stopping, int async, bool swapped, int spec_mode = 0, int caller_dev = -1)
 {
+	// caller_dev: the cloud lies in device memory that belongs to the caller (default: whenever the set was not rotated in by
+	// an upload, i.e. ufomap_map_insert_device). Such a cloud is consumed before this call returns, asynchronous or not.
+	const bool caller_owned = caller_dev < 0 ? !swapped : 0 != caller_dev;
 	if (!m) return fail(UFOMAP_ERR_INVALID, "null map");
 	HIP_TRY(hipSetDevice(m->device));
 	// The scan half never reads the map (freeSpace is const, OMB:1230-1232): it runs on the scan stream
@@ -1906,6 +1998,10 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 			if (rc) return rc;
 		}
 		lap(1, t_map);
+		if (async && caller_owned) {
+			const int wrc = awaitCloudConsumed(m);
+			if (wrc) return wrc;
+		}
 		int prc = UFOMAP_OK;
 		if (!async) {
 			prc = joinOlder(m);  // (occupancy_map_base.h:315: the previous integrations are joined first)
@@ -1946,10 +2042,36 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 		if (frc) return frc;
 		while (countPendingAlts(m) > 2) (void)joinOldestAlt(m);
 	}
+	bool staged = false;
+	if (async && caller_owned && n) {
+		// The kernels of this path read the cloud (and, colour maps, the colours: in the map half) after the call has
+		// returned: they read the set's own copy, made on the prep stream -- a device-to-device copy, awaited below.
+		const size_t xyz_bytes = m->ing.data ? n * (size_t)m->ing.step : n * 24;
+		HIP_TRY(m->b_in_xyz.reserve(xyz_bytes));
+		HIP_TRY(hipMemcpyAsync(m->b_in_xyz.p, m->ing.data ? static_cast<const void*>(m->ing.data) : static_cast<const void*>(d_xyz), xyz_bytes,
+		                       hipMemcpyDeviceToDevice, m->pstream));
+		if (m->ing.data) {
+			m->ing.data = m->b_in_xyz.as<uint8_t>();
+			d_xyz = reinterpret_cast<const double*>(m->ing.data);
+		} else {
+			d_xyz = m->b_in_xyz.as<double>();
+		}
+		if (d_rgb && d_rgb != m->b_in_rgb.as<uint8_t>()) {
+			HIP_TRY(m->b_in_rgb.reserve(n * 3));
+			HIP_TRY(hipMemcpyAsync(m->b_in_rgb.p, d_rgb, n * 3, hipMemcpyDeviceToDevice, m->pstream));
+			d_rgb = m->b_in_rgb.as<uint8_t>();
+		}
+		HIP_TRY(hipEventRecord(m->copy_ev, m->pstream));
+		m->args.d_xyz = d_xyz;
+		m->args.d_rgb = d_rgb;
+		m->args.ing = m->ing;
+		staged = true;
+	}
 	// (a host cloud is copied on the prep stream)
 	HIP_TRY(hipEventRecord(m->prep_ev, m->pstream));
 	HIP_TRY(hipStreamWaitEvent(m->sstream, m->prep_ev, 0));
 	rc = scanPhase(m, origin, d_xyz, d_rgb, n, max_range, depth, discrete, simple, early_stopping, &n_hits, &n_rays, spec);
+	if (staged) HIP_TRY(hipEventSynchronize(m->copy_ev));
 	if (!rc && n) rc = extractPhase(m, n_hits, n_rays, &capH, &capM, merged);
 	lap(0, t_begin);
 	auto mapHalf = [&](const ScanCtl* prev, u64 extra_used, u32 headroom) { return mapPhase(m, depth, d_rgb, capH, capM, merged, prev, extra_used, headroom); };
@@ -2165,6 +2287,7 @@ ufomap_map* ufomap_map_create(double resolution, unsigned depth_levels, int auto
 	          m->b_pipe.reserve(sizeof(Pipe)) == hipSuccess && hipMemset(m->b_pipe.p, 0, sizeof(Pipe)) == hipSuccess &&
 	          hipMalloc((void**)&m->sig_prep, 8) == hipSuccess && hipMemset(m->sig_prep, 0, 8) == hipSuccess &&
 	          hipHostMalloc((void**)&m->h_root, sizeof(MapRoot)) == hipSuccess &&
+	          hipHostMalloc((void**)&m->h_prep, 64) == hipSuccess &&
 	          m->b_ctl.reserve(sizeof(ScanCtl) + 64) == hipSuccess && m->b_root.reserve(sizeof(MapRoot)) == hipSuccess;
 	for (int i = 0; ok && i < kAlt; ++i) {
 		HandOver& a = m->alt[i];
@@ -2181,6 +2304,7 @@ ufomap_map* ufomap_map_create(double resolution, unsigned depth_levels, int auto
 	}
 	m->cs = m->stream;
 	memset(m->h_ctl, 0, sizeof(ScanCtl));
+	*m->h_prep = 0ull;
 	if (hipMemset(m->b_root.p, 0, sizeof(MapRoot)) != hipSuccess || allocTable(m, 1u << 16, &m->t, &m->tb) || resetRoot(m)) {
 		ufomap_map_destroy(m);
 		return nullptr;
@@ -2217,12 +2341,15 @@ void ufomap_map_destroy(ufomap_map* m)
 	m->tb.release();
 	m->b_changes.release();
 	for (HandOver& a : m->alt) {
-		DevBuf* abufs[] = {&a.b_ctl, &a.b_entries, &a.b_hh_keys, &a.b_in_xyz, &a.b_in_rgb, &a.b_gridM, &a.b_gridH, &a.b_part1, &a.b_hit_code, &a.b_first, &a.b_tilebits, &a.b_slabs};
+		DevBuf* abufs[] = {&a.b_ctl, &a.b_entries, &a.b_hh_keys, &a.b_in_xyz, &a.b_in_rgb, &a.b_gridM, &a.b_gridH, &a.b_part1, &a.b_hit_code, &a.b_first, &a.b_tilebits, &a.b_slabs, &a.b_keep};
 		for (DevBuf* b : abufs) b->release();
 		if (a.h_ctl) (void)hipHostFree(a.h_ctl);
 		if (a.h_res) (void)hipHostFree(a.h_res);
 		if (a.sig_prep) (void)hipFree(a.sig_prep);
 		if (a.h_stage) (void)hipHostFree(a.h_stage);
+		if (a.h_res_all) (void)hipHostFree(a.h_res_all);
+		if (a.xchg_ev) (void)hipEventDestroy(a.xchg_ev);
+		for (DevBuf* b : {&a.b_xsend, &a.b_xrecv, &a.b_bpipe}) b->release();
 		if (a.done_ev) (void)hipEventDestroy(a.done_ev);
 	}
 	if (m->scan_ev) (void)hipEventDestroy(m->scan_ev);
@@ -2233,7 +2360,7 @@ void ufomap_map_destroy(ufomap_map* m)
 	                  &m->b_ctl,     &m->b_pt_end,  &m->b_pt_flag,  &m->b_pt_slot, &m->b_ray_end, &m->b_hit_code, &m->b_hit_pt,
 	                  &m->b_hh_keys, &m->b_gridM,   &m->b_crec,    &m->b_dlist,   &m->b_rays,   &m->b_part0,   &m->b_part1,   &m->b_slabs,   &m->b_hb_keys, &m->b_hb_mask, &m->b_hb_time,   &m->b_entries, &m->b_ent_slot, &m->b_newlist,
 	                  &m->b_wl0,     &m->b_wl1,     &m->b_in_xyz,   &m->b_in_rgb,  &m->b_codes,   &m->b_dump,
-	                  &m->b_first,   &m->b_tilebits, &m->b_tilerec, &m->b_gridH, &m->b_pipe, &m->b_blk_range, &m->b_ctl_init};
+	                  &m->b_first,   &m->b_tilebits, &m->b_tilerec, &m->b_gridH, &m->b_pipe, &m->b_keep, &m->b_blk_range, &m->b_ctl_init};
 	for (DevBuf* b : bufs) b->release();
 	for (PendingEvent& pe : m->pend_ev) {
 		(void)hipEventDestroy(pe.a);
@@ -2244,8 +2371,12 @@ void ufomap_map_destroy(ufomap_map* m)
 	if (m->h_res) (void)hipHostFree(m->h_res);
 	if (m->sig_prep) (void)hipFree(m->sig_prep);
 	if (m->h_stage) (void)hipHostFree(m->h_stage);
+	if (m->h_res_all) (void)hipHostFree(m->h_res_all);
+	if (m->xchg_ev) (void)hipEventDestroy(m->xchg_ev);
+	for (DevBuf* b : {&m->b_xsend, &m->b_xrecv, &m->b_bpipe}) b->release();
 	if (m->copy_ev) (void)hipEventDestroy(m->copy_ev);
 	if (m->h_root) (void)hipHostFree(m->h_root);
+	if (m->h_prep) (void)hipHostFree(m->h_prep);
 	if (m->done_ev) (void)hipEventDestroy(m->done_ev);
 	if (m->xstream) (void)hipStreamDestroy(m->xstream);
 	if (m->stream) (void)hipStreamDestroy(m->stream);
@@ -2412,7 +2543,7 @@ int ufomap_map_insert_pointcloud2(ufomap_map* m, const double translation[3], co
 	m->ing = ing;
 	// insertPointCloudDiscrete(transform.translation(), cloud, ...) (ufomap_mapping/src/server.cpp:118-120)
 	const int rc = doInsert(m, translation, reinterpret_cast<const double*>(d_data), d_rgb, n_points, max_range, depth, discrete,
-	                        simple_ray_casting, early_stopping, async, true);
+	                        simple_ray_casting, early_stopping, async, true, 0, data_on_device ? 1 : 0);
 	m->ing = Ingest{};
 	return rc;
 }
@@ -3123,6 +3254,10 @@ int ufomap_map_scan_keys(ufomap_map* m, const double sensor_origin[3], const dou
 	return ufomap_map_scan_keys_rgb(m, sensor_origin, d_xyz, nullptr, n, max_range, depth, discrete, simple_ray_casting, info);
 }
 
+int scanKeysCore(ufomap_map* m, const double sensor_origin[3], const double* d_xyz, const uint8_t* d_rgb, size_t n, double max_range, unsigned depth,
+                 int discrete, int simple_ray_casting, ufomap_keys_info* info);
+int applyKeysBatchCore(ufomap_map* m, const void* const* d_lists, const ufomap_keys_info* infos, int n_lists, bool sync);
+
 int ufomap_map_scan_keys_rgb(ufomap_map* m, const double sensor_origin[3], const double* d_xyz, const uint8_t* d_rgb, size_t n, double max_range,
                              unsigned depth, int discrete, int simple_ray_casting, ufomap_keys_info* info)
 {
@@ -3130,14 +3265,24 @@ int ufomap_map_scan_keys_rgb(ufomap_map* m, const double sensor_origin[3], const
 	if (d_rgb && !m->g.color) return fail(UFOMAP_ERR_INVALID, "colours for a map without colour");
 	if (d_rgb && !discrete) return fail(UFOMAP_ERR_UNSUPPORTED, "colour integration exists for the discrete integrator only (occupancy_map_color.h:177)");
 	if (d_rgb && 0 != depth) return fail(UFOMAP_ERR_UNSUPPORTED, "update lists with colour: insert depth 0 only");
-	memset(info, 0, sizeof(*info));
-	info->depth = depth;
 	HIP_TRY(hipSetDevice(m->device));
 	// Ray casting never reads the map: it runs on the scan stream with its own hand-over set while an update
 	// enqueued earlier (asynchronous insert / apply_keys_batch) may still be walking the tree on the map stream.
 	HIP_TRY(hipStreamSynchronize(m->sstream));
 	(void)rotateSets(m);
 	m->args = ScanArgs{};
+	return scanKeysCore(m, sensor_origin, d_xyz, d_rgb, n, max_range, depth, discrete, simple_ray_casting, info);
+}
+
+// (the scan itself, on the current hand-over set)
+int scanKeysCore(ufomap_map* m, const double sensor_origin[3], const double* d_xyz, const uint8_t* d_rgb, size_t n, double max_range, unsigned depth,
+                 int discrete, int simple_ray_casting, ufomap_keys_info* info)
+{
+	memset(info, 0, sizeof(*info));
+	info->depth = depth;
+	m->fast = false;
+	m->deferred = false;
+	m->batch_world = 0;
 	m->cs = m->sstream;
 	u32 n_hits = 0, n_rays = 0;
 	int rc = scanPhase(m, sensor_origin, d_xyz, d_rgb, n, max_range, depth, discrete, simple_ray_casting, 0, &n_hits, &n_rays);
@@ -3260,6 +3405,12 @@ int ufomap_map_apply_keys_batch(ufomap_map* m, const void* const* d_lists, const
 		m->async_status = UFOMAP_OK;
 		if (prc) return prc;
 	}
+	return applyKeysBatchCore(m, d_lists, infos, n_lists, false);
+}
+
+// (the update itself, on the current hand-over set; nothing is joined here. sync: wait for it whatever option async_apply says)
+int applyKeysBatchCore(ufomap_map* m, const void* const* d_lists, const ufomap_keys_info* infos, int n_lists, bool sync)
+{
 	u64 total = 0;
 	for (int j = 0; j < n_lists; ++j) total += (u64)infos[j].n_hit + infos[j].n_miss;
 	if (0 == total) return UFOMAP_OK;
@@ -3402,7 +3553,7 @@ int ufomap_map_apply_keys_batch(ufomap_map* m, const void* const* d_lists, const
 	HIP_TRY(hipGetLastError());
 	m->pending = true;
 	m->bound = m->scan_new_bound;
-	if (m->opt_async_apply && !m->chg_enabled) {
+	if (m->opt_async_apply && !m->chg_enabled && !sync) {
 		// the caller keeps the lists alive until the next call on this map has joined the update
 		m->done_by_flag = false;
 		HIP_TRY(hipEventRecord(m->done_ev, m->stream));
@@ -3436,32 +3587,35 @@ struct Rccl {
 };
 Rccl* rccl()
 {
-	static Rccl r;
-	static bool tried = false;
-	if (tried) return r.lib ? &r : nullptr;
-	tried = true;
-	const char* env = getenv("UFOMAP_RCCL_LIB");
-	const char* names[] = {env, "librccl.so.1", "librccl.so"};
-	void* h = nullptr;
-	for (const char* name : names) {  // a copy that is already in the process first
-		if (!name || !*name) continue;
-		h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
-		if (h) break;
-	}
-	for (const char* name : names) {
-		if (h) break;
-		if (!name || !*name) continue;
-		h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-	}
-	if (!h) return nullptr;
-	r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
-	r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
-	r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
-	r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(h, "ncclAllGather"));
-	r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
-	if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather) return nullptr;
-	r.lib = h;
-	return &r;
+	// (initialised once, thread-safely: a function-local static)
+	static Rccl r = [] {
+		Rccl x;
+		const char* env = getenv("UFOMAP_RCCL_LIB");
+		void* h = nullptr;
+		if (env && *env) {
+			// the host names the library (tests: a stand-in that runs the collective through shared memory): that one and no other
+			h = dlopen(env, RTLD_NOW | RTLD_LOCAL);
+		} else {
+			const char* names[] = {"librccl.so.1", "librccl.so"};
+			for (const char* name : names) {  // a copy that is already in the process first
+				h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+				if (h) break;
+			}
+			for (const char* name : names) {
+				if (h) break;
+				h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+			}
+		}
+		if (!h) return x;
+		x.GetUniqueId = reinterpret_cast<decltype(x.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+		x.CommInitRank = reinterpret_cast<decltype(x.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+		x.CommDestroy = reinterpret_cast<decltype(x.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+		x.AllGather = reinterpret_cast<decltype(x.AllGather)>(dlsym(h, "ncclAllGather"));
+		x.GetErrorString = reinterpret_cast<decltype(x.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+		if (x.GetUniqueId && x.CommInitRank && x.CommDestroy && x.AllGather) x.lib = h;
+		return x;
+	}();
+	return r.lib ? &r : nullptr;
 }
 int rcclFail(int code, const char* what)
 {
@@ -3469,7 +3623,7 @@ int rcclFail(int code, const char* what)
 	return fail(UFOMAP_ERR_DEVICE, std::string(what) + ": " + ((r && r->GetErrorString) ? r->GetErrorString(code) : "RCCL error ") + " (" +
 	                                   std::to_string(code) + ")");
 }
-constexpr size_t kSlotHeader = 64;  // ufomap_keys_info (40 bytes), padded: travels in front of the list
+constexpr size_t kSlotHeader = 128;  // ufomap_keys_info (40 bytes) + status and ray-cell box of the rank's scan (HdrTail), padded: travels in front of the list
 }  // namespace
 }  // extern "C++"
 
@@ -3482,6 +3636,10 @@ struct ufomap_comm {
 	int flip = 0;
 	uint8_t* h_hdr = nullptr;  // pinned: world headers
 	uint64_t n_regrow = 0;
+	// the ranks' common ray grid for the fast-path form of a step: derived from gathered data only, hence equal on all ranks
+	Grid spec_grid{};
+	bool spec_valid = false;
+	uint64_t n_fast_steps = 0, n_redo_steps = 0;
 };
 
 int ufomap_comm_unique_id(uint8_t id[UFOMAP_COMM_ID_BYTES])
@@ -3508,6 +3666,7 @@ static ufomap_comm* commAlloc(int world, int rank, int device)
 	c->world = world;
 	c->rank = rank;
 	c->device = device;
+	if (const char* e = getenv("UFOMAP_COMM_SLOT")) c->cap = std::max<size_t>(256, (size_t)atoll(e));  // (tests: a slot so small that it has to grow)
 	if (hipHostMalloc((void**)&c->h_hdr, (size_t)world * kSlotHeader) != hipSuccess) {
 		delete c;
 		(void)fail(UFOMAP_ERR_DEVICE, "hipHostMalloc");
@@ -3569,61 +3728,404 @@ int ufomap_comm_stats(const ufomap_comm* c, uint64_t out[4])
 	return UFOMAP_OK;
 }
 
+extern "C++" {
+namespace
+{
+constexpr size_t kResStride = (sizeof(ScanCtl) + 64 + 63) & ~(size_t)63;  // one pinned result block + the word behind it
+
+// the W - 1 result blocks of the other ranks' scans of a batch step (the own scan reports to the set's h_res)
+ScanCtl* otherResult(uint8_t* all, int w) { return reinterpret_cast<ScanCtl*>(all + (size_t)w * kResStride); }
+
+// Update-list form of a batch step (colour maps, first steps, grids beyond LDS, and the collective repeat of a fast step
+// that a rank's scan did not fit): this rank's scan -> update list (scan stream; never reads the map), ONE all-gather of
+// fixed-size slots [64-byte header | list | padding], all ranks' lists in rank order through one walk of the tree
+// (ufomap_map_apply_keys_batch). A rank whose scan FAILED still takes part in the collective -- with a status word in
+// its header and an empty list -- and every rank returns that error: nobody is left waiting in the all-gather.
+int listBatchStep(ufomap_map* m, ufomap_comm* c, const double origin[3], const double* d_xyz, const uint8_t* d_rgb, size_t n, double max_range,
+                  int discrete, bool in_join)
+{
+	Rccl* r = rccl();
+	const int W = c->world;
+	ufomap_keys_info info;
+	// (in_join: called while a step is being joined -- the current hand-over set is that step's, nothing else is joined or rotated)
+	int scan_rc = in_join ? scanKeysCore(m, origin, d_xyz, m->g.color ? d_rgb : nullptr, n, max_range, 0, discrete, 0, &info)
+	                      : ufomap_map_scan_keys_rgb(m, origin, d_xyz, m->g.color ? d_rgb : nullptr, n, max_range, 0, discrete, 0, &info);
+	std::string scan_msg = scan_rc ? g_err : std::string();
+	if (scan_rc) memset(&info, 0, sizeof(info));
+	auto listBytes = [](const ufomap_keys_info& k) {  // records + colour section
+		return ((size_t)k.n_hit + k.n_miss) * sizeof(Entry) + ((k.reserved & 2u) ? (size_t)k.n_hit * 32u : 0u);
+	};
+	const size_t my_bytes = listBytes(info);
+	struct HdrTail {  // behind the 40 bytes of ufomap_keys_info in the header
+		i32 status;    // 0, or the error code of this rank's scan (its list is empty then)
+		i32 have_box;  // the scan cast rays: box = their cells' bounding box (cells at depth 0)
+		i32 box[6];
+	};
+	static_assert(sizeof(ufomap_keys_info) + sizeof(HdrTail) <= kSlotHeader, "exchange header");
+	std::vector<ufomap_keys_info> infos((size_t)W);
+	std::vector<i32> boxes((size_t)W * 6, 0);
+	std::vector<char> have_box((size_t)W, 0);
+	int first_status = 0, first_rank = -1;
+	for (;;) {
+		// header + list into this rank's slot, ONE all-gather of fixed-size slots, the W headers back to the host
+		hipError_t he = c->send.reserve(c->cap);
+		if (he == hipSuccess) he = c->recv[0].reserve(c->cap * (size_t)W);
+		if (he == hipSuccess) he = c->recv[1].reserve(c->cap * (size_t)W);
+		if (he != hipSuccess) return fail(UFOMAP_ERR_DEVICE, "exchange buffers: out of device memory");  // (before any rank's first collective on these buffers)
+		uint8_t* send = c->send.as<uint8_t>();
+		uint8_t* recv = c->recv[c->flip].as<uint8_t>();
+		memset(c->h_hdr, 0, kSlotHeader);
+		memcpy(c->h_hdr, &info, sizeof(info));
+		{
+			HdrTail t{};
+			t.status = scan_rc;
+			t.have_box = (!scan_rc && n && m->h_ctl->n_rays && m->h_ctl->mb_min[0] <= m->h_ctl->mb_max[0]) ? 1 : 0;
+			for (int a = 0; a < 3 && t.have_box; ++a) {
+				t.box[a] = m->h_ctl->mb_min[a];
+				t.box[3 + a] = m->h_ctl->mb_max[a];
+			}
+			memcpy(c->h_hdr + sizeof(info), &t, sizeof(t));
+		}
+		bool ok = hipMemcpyAsync(send, c->h_hdr, kSlotHeader, hipMemcpyHostToDevice, m->sstream) == hipSuccess;
+		const bool fits = kSlotHeader + my_bytes <= c->cap;  // (if not, the header alone tells everybody how much room is needed)
+		if (ok && fits && my_bytes) ok = hipMemcpyAsync(send + kSlotHeader, m->b_entries.p, my_bytes, hipMemcpyDeviceToDevice, m->sstream) == hipSuccess;
+		const int e = r->AllGather(send, recv, c->cap, /* ncclChar */ 0, c->comm, m->sstream);
+		if (e) return rcclFail(e, "ncclAllGather");
+		HIP_TRY(hipMemcpy2DAsync(c->h_hdr, kSlotHeader, recv, c->cap, kSlotHeader, (size_t)W, hipMemcpyDeviceToHost, m->sstream));
+		HIP_TRY(hipStreamSynchronize(m->sstream));
+		if (!ok) return fail(UFOMAP_ERR_DEVICE, "copy into the exchange slot failed");
+		size_t need = 0;
+		first_status = 0;
+		first_rank = -1;
+		for (int k = 0; k < W; ++k) {
+			const uint8_t* h = c->h_hdr + (size_t)k * kSlotHeader;
+			memcpy(&infos[(size_t)k], h, sizeof(ufomap_keys_info));
+			HdrTail t;
+			memcpy(&t, h + sizeof(ufomap_keys_info), sizeof(t));
+			if (t.status && 0 == first_status) {
+				first_status = t.status;
+				first_rank = k;
+			}
+			have_box[(size_t)k] = t.have_box ? 1 : 0;
+			for (int a = 0; a < 6; ++a) boxes[(size_t)k * 6 + a] = t.box[a];
+			need = std::max(need, kSlotHeader + listBytes(infos[(size_t)k]));
+		}
+		if (need <= c->cap) break;
+		// some rank's list did not fit: every rank sees that in the headers and grows to the same capacity; an update of
+		// an earlier batch that still reads the old receive buffers finishes first
+		if (in_join) HIP_TRY(hipStreamSynchronize(m->stream));
+		else {
+			const int wrc = ufomap_map_wait(m);
+			if (wrc) return wrc;
+		}
+		while (c->cap < need) c->cap *= 2;
+		++c->n_regrow;
+	}
+	if (first_status) {
+		// (every rank takes this exit: the maps stay equal -- none has applied anything of the step)
+		if (scan_rc) return fail(scan_rc, scan_msg);
+		return fail(first_status, "ufomap_map_insert_batch: the scan of rank " + std::to_string(first_rank) + " failed; nothing of this step was applied");
+	}
+	// the ranks' common ray grid for the steps to come (every rank computes it from the same gathered boxes)
+	{
+		i32 mn[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, mx[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+		bool any = false;
+		for (int k = 0; k < W; ++k) {
+			if (!have_box[(size_t)k]) continue;
+			any = true;
+			for (int a = 0; a < 3; ++a) {
+				mn[a] = std::min(mn[a], boxes[(size_t)k * 6 + a]);
+				mx[a] = std::max(mx[a], boxes[(size_t)k * 6 + 3 + a]);
+			}
+		}
+		const bool had = c->spec_valid;
+		const Grid prev = c->spec_grid;
+		c->spec_valid = any && gridFromBox(had, prev, mn, mx, &c->spec_grid);
+	}
+	// the W lists in rank order, one walk of the tree; with option async_apply the call returns after enqueueing and
+	// the next batch's scan overlaps it (two receive buffers, used alternately)
+	std::vector<const void*> lists((size_t)W);
+	uint8_t* recv = c->recv[c->flip].as<uint8_t>();
+	for (int k = 0; k < W; ++k) lists[(size_t)k] = (infos[(size_t)k].n_hit + infos[(size_t)k].n_miss) ? recv + (size_t)k * c->cap + kSlotHeader : nullptr;
+	c->flip ^= 1;
+	if (in_join) return applyKeysBatchCore(m, lists.data(), infos.data(), W, true);
+	return ufomap_map_apply_keys_batch(m, lists.data(), infos.data(), W);
+}
+
+// The ranks' common ray grid after a fast-path step has been joined: from the boxes of all ranks' scans (the finished
+// control blocks of the walk: every rank holds the same ones).
+void predictCommonGrid(ufomap_map* m)
+{
+	ufomap_comm* c = m->comm;
+	if (!c) return;
+	i32 mn[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, mx[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+	bool any = false;
+	for (int w = 0; w < m->batch_world; ++w) {
+		const ScanCtl* rc = (w == c->rank) ? m->h_ctl : otherResult(m->h_res_all, w);
+		if (0 == rc->n_rays || rc->mb_min[0] > rc->mb_max[0]) continue;
+		any = true;
+		for (int a = 0; a < 3; ++a) {
+			mn[a] = std::min(mn[a], rc->mb_min[a]);
+			mx[a] = std::max(mx[a], rc->mb_max[a]);
+		}
+	}
+	if (!any) return;  // (a step of empty clouds: the grid stays)
+	const bool had = c->spec_valid;
+	const Grid prev = c->spec_grid;
+	c->spec_valid = gridFromBox(had, prev, mn, mx, &c->spec_grid);
+}
+
+// One step of ufomap_map_insert_batch on the fast path: this rank's scan on the ranks' common ray grid, merged to two bit
+// grids on the scan stream, ONE all-gather of [control block | tile bitmap | ray cells | hit voxels] (~0.2 MB per rank), ONE
+// walk of the tree for the scans of all ranks in rank order (k_tile / k_ftail over W scans) -- enqueued, not awaited: no
+// host round trip inside the step; what the host needs to know (errors, boxes) it reads when the step is joined.
+int fastBatchStep(ufomap_map* m, ufomap_comm* c, const double origin[3], const double* d_xyz, size_t n, double max_range, int discrete)
+{
+	Rccl* r = rccl();
+	const int W = c->world;
+	m->spec_grid = c->spec_grid;
+	m->spec_valid = true;
+	const FastGeo fg = makeFastGeo(c->spec_grid);
+	const size_t G = (size_t)fg.gr.bytes, slot = (UFO_XSLOT_HDR + 2 * G + 255) & ~(size_t)255;
+	m->batch_world = W;
+	m->comm = c;
+	HIP_TRY(m->b_xsend.reserve(slot));
+	HIP_TRY(m->b_xrecv.reserve(slot * (size_t)W));
+	{
+		const size_t pc = m->b_bpipe.cap;
+		HIP_TRY(m->b_bpipe.reserve(sizeof(Pipe)));
+		if (pc != m->b_bpipe.cap) HIP_TRY(hipMemsetAsync(m->b_bpipe.p, 0, sizeof(Pipe), m->sstream));
+	}
+	if (m->h_res_all_world < W) {
+		if (m->h_res_all) HIP_TRY(hipHostFree(m->h_res_all));
+		m->h_res_all = nullptr;
+		HIP_TRY(hipHostMalloc((void**)&m->h_res_all, kResStride * (size_t)W));
+		m->h_res_all_world = W;
+	}
+	if (!m->xchg_ev) HIP_TRY(hipEventCreateWithFlags(&m->xchg_ev, hipEventDisableTiming));
+	for (int w = 0; w < W; ++w) {  // (armed before anything of the step is enqueued)
+		otherResult(m->h_res_all, w)->err = ERR_NOT_STORED;
+		*reinterpret_cast<volatile unsigned long long*>(otherResult(m->h_res_all, w) + 1) = 0ull;
+	}
+	ScanCtl* ctl = m->b_ctl.as<ScanCtl>();
+	int rc = UFOMAP_OK;
+	if (n) {
+		rc = fastScanPhase(m, origin, d_xyz, n, max_range, discrete, true);
+	} else {
+		// an empty cloud on this rank: an empty contribution (the collective is entered all the same)
+		for (int k = 0; k < 8; ++k) m->counts[k] = 0;
+		m->fgeo = fg;
+		m->fast = true;
+		m->fseq = 0;
+		m->chain_ok = false;
+		m->gridM = m->gridH = c->spec_grid;
+		m->haveH = m->haveM = true;
+		m->hit_grid = true;
+		m->last_depth = 0;
+		m->h_res->err = ERR_NOT_STORED;
+		*reinterpret_cast<volatile unsigned long long*>(m->h_res + 1) = 0ull;
+		m->done_by_flag = true;
+		rc = flushDeferred(m);
+		if (!m->ctl_init_done) {
+			ScanCtl init;
+			memset(&init, 0, sizeof(init));
+			for (int a = 0; a < 3; ++a) {
+				init.mb_min[a] = init.hb_min[a] = INT32_MAX;
+				init.mb_max[a] = init.hb_max[a] = INT32_MIN;
+				init.aabb_min[a] = ~0ull;
+				init.aabb_max[a] = 0ull;
+			}
+			HIP_TRY(hipMemcpy(m->b_ctl_init.p, &init, sizeof(ScanCtl), hipMemcpyHostToDevice));
+			m->ctl_init_done = true;
+		}
+		HIP_TRY(m->b_gridM.reserve(G));
+		HIP_TRY(m->b_gridH.reserve(G));
+		HIP_TRY(m->b_tilebits.reserve(UFO_FAST_MAX_TILES / 8));
+		HIP_TRY(hipMemcpyAsync(ctl, m->b_ctl_init.p, sizeof(ScanCtl), hipMemcpyDeviceToDevice, m->sstream));
+		HIP_TRY(hipMemsetAsync(m->b_gridM.p, 0, G, m->sstream));
+		HIP_TRY(hipMemsetAsync(m->b_gridH.p, 0, G, m->sstream));
+		HIP_TRY(hipMemsetAsync(m->b_tilebits.p, 0, UFO_FAST_MAX_TILES / 8, m->sstream));
+		m->ctl_clean = false;
+	}
+	if (rc) return rc;  // (device / allocation failures only: a scan that does not fit flags itself on the device)
+	const u32 n4 = (u32)(G >> 4);
+	uint8_t* send = m->b_xsend.as<uint8_t>();
+	uint8_t* recv = m->b_xrecv.as<uint8_t>();
+	hipLaunchKernelGGL(k_pack_slot, dim3(64), dim3(256), 0, m->sstream, reinterpret_cast<uint4*>(send), reinterpret_cast<const uint4*>(ctl),
+	                   m->b_tilebits.as<uint4>(), m->b_gridM.as<uint4>(), m->b_gridH.as<uint4>(), n4);
+	{
+		const int e = r->AllGather(send, recv, slot, /* ncclChar */ 0, c->comm, m->sstream);
+		if (e) return rcclFail(e, "ncclAllGather");
+	}
+	HIP_TRY(hipEventRecord(m->xchg_ev, m->sstream));
+	// ---- the walk: the scans of ranks 0 .. W-1 in this order (UFO_BATCH_MAX at a time) ----
+	m->cs = m->stream;
+	const u64 bound = fastBound(m, fg.gr);
+	{
+		u64 in_flight = 0;
+		for (int i = 0; i < kAlt; ++i)
+			if (m->alt[i].pending && !(m->alt[i].fast && 0 == memcmp(m->alt[i].fgeo.gr.base, fg.gr.base, sizeof(fg.gr.base)) &&
+			                           0 == memcmp(m->alt[i].fgeo.gr.nb, fg.gr.nb, sizeof(fg.gr.nb))))
+				in_flight += m->alt[i].bound;
+		if ((m->used_est + in_flight + bound) * 5 > ((u64)m->t.mask + 1) * 3) {
+			const int jrc = joinEnqueued(m);  // (deterministic: every rank's replica holds the same number of blocks)
+			if (jrc < 0) return jrc;
+			if ((m->used_est + bound) * 5 > ((u64)m->t.mask + 1) * 3) {
+				const u64 want = (m->used_est + 2 * bound) * 2;
+				if (want > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
+				m->cs = m->stream;
+				const int grc = growTable(m, nextPow2(want));
+				if (grc) return grc;
+			}
+		}
+	}
+	const u32* prev_stat = nullptr;
+	{
+		int pk = -1;
+		for (int i = 0; i < kAlt; ++i) {
+			const HandOver& o = m->alt[i];
+			if (!o.pending || o.deferred || (o.done_by_flag && !o.has_slot)) continue;
+			if (pk < 0 || o.seq > m->alt[pk].seq) pk = i;
+		}
+		if (pk >= 0) {
+			const HandOver& o = m->alt[pk];
+			prev_stat = !o.done_by_flag ? &o.b_ctl.as<ScanCtl>()->err
+			            : o.batch_world ? &o.b_bpipe.as<Pipe>()->wstat[0] : &m->b_pipe.as<Pipe>()->wstat[o.fseq & (UFO_RING - 1u)];
+		}
+	}
+	m->scan_new_bound = bound;
+	HIP_TRY(m->b_tilerec.reserve((size_t)UFO_FAST_MAX_TILES * sizeof(TileRec)));
+	HIP_TRY(hipStreamWaitEvent(m->stream, m->xchg_ev, 0));
+	Pipe* bp = m->b_bpipe.as<Pipe>();
+	const float miss = (float)m->g.miss_log;
+	for (int w0 = 0; w0 < W; w0 += (int)UFO_BATCH_MAX) {
+		const int B = std::min<int>((int)UFO_BATCH_MAX, W - w0);
+		DescPack pk{};
+		for (int b = 0; b < B; ++b) {
+			const int w = w0 + b;
+			uint8_t* base = recv + (size_t)w * slot;
+			ScanDesc& d = pk.d[b];
+			const bool own = w == c->rank;
+			// (the own scan's control block and tile bitmap are the set's: the walk leaves them in their start state)
+			d.ctl = own ? ctl : reinterpret_cast<ScanCtl*>(base);
+			d.tile_bits = own ? m->b_tilebits.as<u32>() : reinterpret_cast<u32*>(base + UFO_XSLOT_CTL);
+			d.gridM = reinterpret_cast<u32*>(base + UFO_XSLOT_HDR);
+			d.gridH = reinterpret_cast<u32*>(base + UFO_XSLOT_HDR + G);
+			d.host_result = own ? m->h_res : otherResult(m->h_res_all, w);
+			d.done_value = (unsigned long long)m->seq;
+			d.fseq = (unsigned long long)b;
+		}
+		m->scan_id += 1;
+		hipLaunchKernelGGL(k_batch_descs, dim3(1), dim3(64), 0, m->stream, bp, pk, (u32)B);
+		{
+			ProfScope ps(m, "k_tile");
+			const u32 tw = (m->opt_tile_waves >= 1 && m->opt_tile_waves <= 4) ? (u32)m->opt_tile_waves : 4u;
+			hipLaunchKernelGGL(k_tile, dim3((fg.ntiles + tw - 1) / tw), dim3(64u * tw), 0, m->stream, m->t, m->g, fg, bp, 0ull, m->b_tilerec.as<TileRec>(), m->g.hit,
+			                   miss, m->scan_id, prev_stat);
+		}
+		{
+			ProfScope ps(m, "k_ftail");
+			hipLaunchKernelGGL(k_ftail, dim3(1), dim3(UFO_FTAIL_THREADS), 0, m->stream, m->t, m->g, fg, bp, 0ull, m->b_tilerec.as<TileRec>(), m->scan_id, prev_stat,
+			                   m->b_ctl_init.as<ScanCtl>());
+		}
+		prev_stat = &bp->wstat[0];  // (a second walk of the same step looks at the first)
+	}
+	HIP_TRY(hipGetLastError());
+	m->pending = true;
+	m->deferred = false;
+	m->has_slot = true;
+	m->bound = bound;
+	m->last_rgb = nullptr;
+	++c->n_fast_steps;
+	return UFOMAP_OK;
+}
+
+// A step of ufomap_map_insert_batch whose walk stood back (the scan of some rank did not fit the common ray grid) is
+// repeated in update-list form by ALL ranks, here -- i.e. while the step is being joined, which every rank does at the same
+// point of its sequence of calls. Nothing of the step has reached the map; the steps enqueued behind it have stood back
+// too and are repeated by their own joins, in order.
+int redoBatchStep(ufomap_map* m)
+{
+	const ScanArgs a = m->args;
+	ufomap_comm* c = m->comm;
+	m->batch_world = 0;
+	m->args.spec = false;
+	m->chain_ok = false;
+	m->first_dirty = true;
+	++m->n_spec_redo;
+	if (!c) return fail(UFOMAP_ERR_INVALID, "batch step without a communicator");
+	++c->n_redo_steps;  // (the list form extends the ranks' common grid by the boxes it gathers)
+	HIP_TRY(hipStreamSynchronize(m->stream));
+	return listBatchStep(m, c, a.origin, a.d_xyz, nullptr, a.n, a.max_range, a.discrete, true);
+}
+}  // namespace
+}  // extern "C++"
+
+int ufomap_comm_counters(const ufomap_comm* c, uint64_t out[4])
+{
+	if (!c || !out) return fail(UFOMAP_ERR_INVALID, "null argument");
+	out[0] = c->n_fast_steps;
+	out[1] = c->n_redo_steps;
+	out[2] = c->spec_valid ? 1u : 0u;
+	out[3] = 0;
+	return UFOMAP_OK;
+}
+
 int ufomap_map_insert_batch(ufomap_map* m, ufomap_comm* c, const double sensor_origin[3], const double* d_xyz, const uint8_t* d_rgb, size_t n,
                             double max_range, unsigned depth, int discrete)
 {
 	if (!m || !c || !sensor_origin) return fail(UFOMAP_ERR_INVALID, "null argument");
 	if (m->g.color && !d_rgb && n) return fail(UFOMAP_ERR_INVALID, "a colour map needs the points' colours");
 	if (0 != depth) return fail(UFOMAP_ERR_UNSUPPORTED, "insert_batch: insert depth 0 only");
-	Rccl* r = rccl();
-	if (!r) return fail(UFOMAP_ERR_UNSUPPORTED, "librccl not found (set UFOMAP_RCCL_LIB)");
+	if (c->device != m->device) return fail(UFOMAP_ERR_INVALID, "the communicator was created on another device than the map");
+	if (!rccl()) return fail(UFOMAP_ERR_UNSUPPORTED, "librccl not found (set UFOMAP_RCCL_LIB)");
 	HIP_TRY(hipSetDevice(m->device));
-	// 1. this rank's scan -> update list (scan stream; never reads the map: overlaps the previous batch's tree update)
-	ufomap_keys_info info;
-	int rc = ufomap_map_scan_keys_rgb(m, sensor_origin, d_xyz, m->g.color ? d_rgb : nullptr, n, max_range, depth, discrete, 0, &info);
-	if (rc) return rc;
-	auto listBytes = [](const ufomap_keys_info& k) {  // records + colour section
-		return ((size_t)k.n_hit + k.n_miss) * sizeof(Entry) + ((k.reserved & 2u) ? (size_t)k.n_hit * 32u : 0u);
-	};
-	const size_t my_bytes = listBytes(info);
-	const int W = c->world;
-	std::vector<ufomap_keys_info> infos((size_t)W);
-	for (;;) {
-		// 2. header + list into this rank's slot, ONE all-gather of fixed-size slots, the W headers back to the host
-		HIP_TRY(c->send.reserve(c->cap));
-		HIP_TRY(c->recv[0].reserve(c->cap * (size_t)W));
-		HIP_TRY(c->recv[1].reserve(c->cap * (size_t)W));
-		uint8_t* send = c->send.as<uint8_t>();
-		uint8_t* recv = c->recv[c->flip].as<uint8_t>();
-		memset(c->h_hdr, 0, kSlotHeader);
-		memcpy(c->h_hdr, &info, sizeof(info));
-		HIP_TRY(hipMemcpyAsync(send, c->h_hdr, kSlotHeader, hipMemcpyHostToDevice, m->sstream));
-		const bool fits = kSlotHeader + my_bytes <= c->cap;  // (if not, the header alone tells everybody how much room is needed)
-		if (fits && my_bytes) HIP_TRY(hipMemcpyAsync(send + kSlotHeader, m->b_entries.p, my_bytes, hipMemcpyDeviceToDevice, m->sstream));
-		const int e = r->AllGather(send, recv, c->cap, /* ncclChar */ 0, c->comm, m->sstream);
-		if (e) return rcclFail(e, "ncclAllGather");
-		HIP_TRY(hipMemcpy2DAsync(c->h_hdr, kSlotHeader, recv, c->cap, kSlotHeader, (size_t)W, hipMemcpyDeviceToHost, m->sstream));
-		HIP_TRY(hipStreamSynchronize(m->sstream));
-		size_t need = 0;
-		for (int k = 0; k < W; ++k) {
-			memcpy(&infos[(size_t)k], c->h_hdr + (size_t)k * kSlotHeader, sizeof(ufomap_keys_info));
-			need = std::max(need, kSlotHeader + listBytes(infos[(size_t)k]));
-		}
-		if (need <= c->cap) break;
-		// some rank's list did not fit: every rank sees that in the headers and grows to the same capacity; an update of
-		// an earlier batch that still reads the old receive buffers finishes first
-		rc = ufomap_map_wait(m);
-		if (rc) return rc;
-		while (c->cap < need) c->cap *= 2;
-		++c->n_regrow;
+	if (m->poisoned) return fail(UFOMAP_ERR_CAPACITY, "the map is inconsistent after a node table overflow: ufomap_map_clear it");
+	// Which form the step takes is decided from what ALL ranks know alike: the common ray grid (derived from gathered boxes
+	// only), the map's configuration (the same on every rank by contract), never from this rank's cloud.
+	const bool fast = c->spec_valid && m->opt_fast && m->opt_spec && !m->g.color && !m->chg_enabled && m->g.L >= 5 && nullptr == m->ing.data &&
+	                  fastEligible(m, c->spec_grid, 0, 0, nullptr, 1);
+	if (!fast) {
+		// (joins what is in flight where it has to: scan_keys / apply_keys_batch)
+		m->batch_world = 0;
+		return listBatchStep(m, c, sensor_origin, d_xyz, d_rgb, n, max_range, discrete, false);
 	}
-	// 3. the W lists in rank order, one walk of the tree; with option async_apply the call returns after enqueueing and
-	// the next batch's scan overlaps it (two receive buffers, used alternately)
-	std::vector<const void*> lists((size_t)W);
-	uint8_t* recv = c->recv[c->flip].as<uint8_t>();
-	for (int k = 0; k < W; ++k) lists[(size_t)k] = (infos[(size_t)k].n_hit + infos[(size_t)k].n_miss) ? recv + (size_t)k * c->cap + kSlotHeader : nullptr;
-	c->flip ^= 1;
-	return ufomap_map_apply_keys_batch(m, lists.data(), infos.data(), W);
+	// Joins happen at fixed points of the sequence of calls -- the step two before this one is joined here -- never "when it
+	// happens to be complete": a step that has to be repeated is repeated by all ranks together (a collective).
+	int prc = rotateSets(m);
+	while (countPendingAlts(m) > 1) {
+		const int jrc = joinOldestAlt(m);
+		if (!prc) prc = jrc;
+	}
+	if (prc) return prc;
+	if (!c->spec_valid) {  // (the join repeated a step through the list form and found no common grid after it)
+		m->batch_world = 0;
+		return listBatchStep(m, c, sensor_origin, d_xyz, d_rgb, n, max_range, discrete, false);
+	}
+	m->seq = ++m->latest_seq;
+	{
+		ScanArgs& a = m->args;
+		a = ScanArgs{};
+		a.spec = true;
+		for (int k = 0; k < 3; ++k) a.origin[k] = sensor_origin[k];
+		a.d_xyz = d_xyz;
+		a.n = n;
+		a.max_range = max_range;
+		a.discrete = discrete;
+	}
+	m->gates = useGates(m);
+	const int rc = fastBatchStep(m, c, sensor_origin, d_xyz, n, max_range, discrete);
+	if (rc) return rc;
+	if (n) {  // (the caller's cloud has been consumed when the call returns: k_fhits kept what a repeat of the step needs)
+		const int wrc = awaitCloudConsumed(m);
+		if (wrc) return wrc;
+	}
+	if (m->opt_async_apply && !m->profiling) return UFOMAP_OK;
+	// not asynchronous: the step is joined here (by every rank)
+	const int jrc = joinOlder(m);
+	HIP_TRY(hipStreamSynchronize(m->stream));
+	const int frc = finishPending(m);
+	return frc ? frc : jrc;
 }
 
 // liblz4, loaded at run time (the reference links it for its I/O only: octree.h:1430-1486)

@@ -456,6 +456,11 @@ class Comm:
         capi.check(self._lib.ufomap_comm_stats(self._h, out))
         return dict(world=int(out[0]), rank=int(out[1]), slot_bytes=int(out[2]), regrown=int(out[3]))
 
+    def counters(self):
+        out = (C.c_uint64 * 4)()
+        capi.check(self._lib.ufomap_comm_counters(self._h, out))
+        return dict(fast_steps=int(out[0]), repeated_steps=int(out[1]), common_grid=bool(out[2]))
+
     def close(self):
         if self._h:
             self._lib.ufomap_comm_destroy(self._h)
