@@ -8,30 +8,46 @@
 One *step* = one pass of the hot path over one scan: BASELINE.json configs[1] -- a synthetic 64-beam LiDAR scan
 (131 072 points), 16 cm leaf, 20 m max range, insertPointCloudDiscrete (discrete integrator + free-space ray cast)
 into a GPU-resident linear-hashed octree.  The sensor MOVES: step i integrates the scan taken at pose i mod 8 of
-BASELINE configs[3] (3 m apart, seeds 100 + pose), starting from a FRESH map, so that node blocks are created,
-values change, summaries propagate and the predicted ray grid sometimes misses -- what a mapping server sees, not a
-static sensor re-integrating one scan into a saturated map (kept as the extra key `resident_static`).
+BASELINE configs[3] (3 m apart, seeds 100 + pose), starting from a FRESH map in every repetition, so that node blocks
+are created, values change and summaries propagate -- what a mapping server sees, not a static sensor re-integrating
+one scan into a saturated map (kept as the extra key `resident_static`).  The ray grid the scans are enqueued on is
+predicted from the scans before; after the first pass over the 8 poses it is their common hull and survives the
+map's clear(), so in the timed region no scan is repeated for a misprediction (`pipeline.predicted_grid_repeats`).
 
 Timed region = W warm-up steps into a cleared map, barrier + synchronise, EXACTLY K steps, synchronise + barrier.
 With the driver's K = 20 that is only a few milliseconds, so the region is REPEATED (map cleared, same W + K
 steps) until at least 0.5 s of timed steps have accumulated; `value` is total points / total timed seconds over
 all repetitions (`repeats`, `timed_region_s`; `ms_per_step_median_rep` for the spread).
 
+Which number is which.  `value` is measured with the clouds ALREADY RESIDENT IN HBM when the timed region starts
+(ufomap_map_insert_device, async=true), as the task's measurement rules prescribe.  SURVEY.md 8(d) defines the metric
+for the call the reference's server makes -- host cloud in, H2D inside the timed call: that figure is
+`value_incl_h2d` (= the `host_pointer` leg); `pointcloud2` is the same with the raw float32 records of a
+sensor_msgs/PointCloud2 (16 B per point over PCIe, conversion and transform fused into the first kernel), and
+`server_loop` the server's whole per-message sequence (ingest + integrate, robot clearing, serialising the changed
+part of the map; server.cpp:114-225).
+
 Legs (all on the same scan sequence; every leg's final map must equal the CPU checker's, see `self_check`):
-  value / ms_per_step    clouds resident in HBM (ufomap_map_insert_device), async=true  -- the headline, as the
-                         task's measurement rule wants it: inputs in HBM when the timed region starts
-  host_pointer           the call the reference's server makes: ufomap_map_insert with a PAGEABLE host cloud
-                         (24 B/point over PCIe inside the timed region; pinned staging, copy overlapped), async=true
+  value / ms_per_step    clouds resident in HBM (ufomap_map_insert_device), async=true  -- the headline
+  host_pointer           ufomap_map_insert with a PAGEABLE host cloud (24 B/point over PCIe inside the timed region;
+                         pinned staging, copy overlapped), async=true                  -- = value_incl_h2d
   host_pinned            the same with the cloud in caller-owned pinned memory (DMA straight from it)
+  pointcloud2            ufomap_map_insert_pointcloud2: float32 x, y, z records (16 B/point) + pose, async=true
+  server_loop            per scan: pointcloud2 ingest + integrate, setValueVolume(robot box), writeData(changed AABB)
   sync_latency           async=false: one scan at a time, nothing overlapped
   resident_static        round 1's figure: one scan re-integrated into a saturated map from a static pose
-At N > 1 every rank integrates its own moving sensor (pose (rank + i) mod 8) and the ranks exchange their per-scan
-update lists over RCCL so that every replica of the map applies all N scans in rank order ("scaling": "weak").
+  other_configs          BASELINE configs C1, C5, C3 (insert depth 6 / 3 / 0): ms per scan, each map checked against the
+                         reference's digest (tests/golden/digests.json) or the reference itself
+At N > 1 every rank integrates its own moving sensor (pose (rank + i) mod 8): one call of ufomap_map_insert_batch per
+step -- the ranks exchange their scans as bit grids over RCCL (one all-gather) and every replica of the map applies
+all N scans in rank order with ONE walk of the tree ("scaling": "weak").
 
 Prints ONE JSON line on rank 0: metric/value/unit = integrated rays/s (input points per second, whole job), plus
-  roofline     -- dominant kernel (the ray walk): algorithmic bytes per launch / HIP-event duration vs 8 TB/s,
-                  `dominant_by_time` = the kernel with the largest total time, `traffic` = PMC bytes (profiles/)
+  roofline     -- dominant kernel (the ray walk k_fcast: one launch = one scan): algorithmic bytes per launch / HIP-event
+                  duration vs 8 TB/s; `frac_rocprof` = the same with rocprofv3's average duration (profiles/);
+                  `dominant_by_time` = the kernel with the largest total time; `traffic` = PMC bytes (profiles/)
   cpu_baseline -- the reference (oracle/_ref) or the oracle port on this box's host cores, same scan sequence
+  pipeline     -- how many scans shared a walk of the tree, host time per scan
 Exit code 3 when a leg's map differs from the CPU checker's.
 """
 from __future__ import annotations
@@ -94,6 +110,87 @@ def cpu_baseline(clouds, seq, budget_s=12.0):
                 ms_per_scan_mean=mean * 1e3, ms_per_scan_median=float(np.median(per_scan)) * 1e3)
 
 
+def other_configs(device, big):
+    """BASELINE configs C1, C5 and C3 (insert depth 6 / 3 / 0) on this GPU: sync calls, cloud resident in HBM, the fixture's scan
+    sequence into a fresh map. The map after every scan is compared with the UNMODIFIED reference: its digest recorded in
+    tests/golden/digests.json (C1, C5, C3 at depth 0: 85-170 s per scan on the CPU), or the reference run here (C3 at depth 6 / 3)."""
+    import torch
+    from ufomap_amd import OccupancyMap, OccupancyMapColor, scans
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import golden_util
+    fixtures = json.load(open(os.path.join(ROOT, "tests", "golden", "digests.json")))
+    out = {}
+
+    def gen(g, kw):
+        kw = dict(kw)
+        if "pose" in kw:
+            kw["origin"] = scans.lidar_pose(kw.pop("pose"))
+        return getattr(scans, g)(**kw)
+
+    def run(label, params, seq, want, warm_reps):
+        params = dict(params)
+        color = params.pop("color", False)
+        m = (OccupancyMapColor if color else OccupancyMap)(device=device, **params)
+        ms, ok = [], True
+        last = None
+        for k, (g, gkw, ikw) in enumerate(seq):
+            origin, xyz, rgb = gen(g, gkw)
+            d = torch.from_numpy(xyz).to(f"cuda:{device}")
+            drgb = torch.from_numpy(rgb).to(f"cuda:{device}") if (rgb is not None and color) else None
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            m.insert_device(origin, d.data_ptr(), drgb.data_ptr() if drgb is not None else None, xyz.shape[0], ikw.get("max_range", -1.0),
+                            ikw.get("depth", 0), ikw.get("discrete", False))
+            ms.append((time.perf_counter() - t0) * 1e3)
+            if want is not None:
+                ok = ok and [str(v) for v in m.digest()] == want[k]
+            last = (origin, d, drgb, xyz.shape[0], ikw)
+        c = m.last_counts()
+        st = m.stats()
+        dig = tuple(m.digest())  # (of the fixture's scans: before the warm repetitions below)
+        warm = []
+        for _ in range(warm_reps):  # the last scan again into the now warm map (values saturate; what a static sensor costs)
+            origin, d, drgb, n, ikw = last
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            m.insert_device(origin, d.data_ptr(), drgb.data_ptr() if drgb is not None else None, n, ikw.get("max_range", -1.0), ikw.get("depth", 0),
+                            ikw.get("discrete", False))
+            warm.append((time.perf_counter() - t0) * 1e3)
+        out[label] = dict(points=c["points"], rays=c["rays"], dda_steps=c["steps"], ms_per_scan_fixture=[round(v, 4) for v in ms],
+                          ms_warm_median=(float(np.median(warm)) if warm else None), digest_ok=bool(ok), checked_against=("tests/golden/digests.json (unmodified reference)" if want is not None else None),
+                          live_blocks=st["inner_nodes"], leaves=st["leaf_nodes"], table_bytes=st["bytes"])
+        return dig
+
+    for label, name, reps in (("C1_lidar16cm_continuous", "c1_full", 10), ("C5_lidar8cm_colour", "c5_colour_8cm", 10)) + ((("C3_rgbd2mm_depth0", "c3_depth0_full", 1),) if big else ()):
+        fx = fixtures[name]
+        run(label, fx["params"], fx["scans"], [s["digest"] for s in fx["steps"]], reps)
+        if label == "C3_rgbd2mm_depth0":
+            # the one bandwidth-bound configuration: SURVEY 8d's B_scan = 24 N + 16 S + 16 (touched voxels) + 40 (touched node blocks),
+            # with the fresh map's leaves / inner nodes as the touched voxels / blocks of its single scan
+            c = out[label]
+            b = 24 * c["points"] + 16 * c["dda_steps"] + 16 * c["leaves"] + 40 * c["live_blocks"]
+            c["algorithmic_bytes"] = b
+            c["hbm_roofline_frac_fresh_map"] = b / (c["ms_per_scan_fixture"][0] * 1e-3) / 1e9 / HBM_PEAK_GBS
+            c["hbm_roofline_frac_warm_map"] = b / (c["ms_warm_median"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+        torch.cuda.empty_cache()
+    # C3 at insert depth 6 / 3: the reference itself is the checker (80-400 ms per scan on the CPU)
+    from oracle import OracleMap, available, build
+    build("port")
+    kind = "reference" if available("reference") else "port"
+    go, gx, _ = scans.rgbd()
+    for depth in (6, 3):
+        label = f"C3_rgbd2mm_depth{depth}"
+        seq = [("rgbd", {}, dict(max_range=5.0, depth=depth, discrete=True))] * 2
+        dig = run(label, dict(resolution=0.002), seq, None, 6)
+        o = OracleMap(0.002, kind=kind)
+        for _ in range(2):
+            o.insert(go, gx, max_range=5.0, depth=depth, discrete=True)
+        out[label]["digest_ok"] = bool(dig == tuple(golden_util.dump_digest(o.leaves(True), o.inner())))
+        out[label]["checked_against"] = f"the {kind} build run here on the same two scans"
+        del o
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -106,6 +203,8 @@ def main():
     ap.add_argument("--profile-kernels", type=int, default=1, help="extra leg with every kernel bracketed by HIP events (roofline)")
     ap.add_argument("--min-timed-s", type=float, default=MIN_TIMED_S)
     ap.add_argument("--only-headline", action="store_true", help="skip the extra legs (profiling runs)")
+    ap.add_argument("--big", type=int, default=1, help="other_configs: include C3 at insert depth 0 (2 mm, 3.4e8 leaves, ~11 GB of node table)")
+    ap.add_argument("--no-other-configs", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -246,6 +345,42 @@ def main():
         extra["sync_latency"] = dict(leg_summary(run_leg(m, step_sync, min(args.min_timed_s, 0.25))), note="async=false, HBM-resident clouds")
         digests["sync"] = m.digest()
 
+        # ---- the raw records of a PointCloud2 (float32 x, y, z, pad: 16 B/point) + the sensor's pose, host memory --------
+        rec = []
+        ident = np.array([1.0, 0.0, 0.0, 0.0])
+        for origin, xyz, _ in clouds:
+            b = np.zeros((n_pts, 4), np.float32)
+            b[:, :3] = (xyz - origin[None, :]).astype(np.float32)  # sensor frame
+            rec.append(np.ascontiguousarray(b).view(np.uint8).reshape(-1))
+
+        def step_pc2(i):
+            p = pose_of(i)
+            m.insertPointCloud2(clouds[p][0], ident, rec[p], 16, (0, 4, 8), None, MAX_RANGE, DEPTH, True, False, 0, True)
+        extra["pointcloud2"] = dict(leg_summary(run_leg(m, step_pc2, args.min_timed_s)),
+                                    note="ufomap_map_insert_pointcloud2: float32 records (16 B/point over PCIe) + pose; rosToUfo + transform fused into the first kernel; async=true")
+        digests_pc2 = {"pointcloud2": m.digest()}
+
+        # ---- the server's per-message sequence (server.cpp:114-225): ingest + integrate, clear the robot's volume, serialise
+        # the part of the map that changed (writeData of the change AABB, what ufoToMsg publishes) ---------------------------
+        robot = np.array([0.5, 0.5, 0.75])
+        pub = dict(bytes=0, msgs=0)
+
+        def step_server(i):
+            p = pose_of(i)
+            m.insertPointCloud2(clouds[p][0], ident, rec[p], 16, (0, 4, 8), None, MAX_RANGE, DEPTH, True, False, 0, True)
+            m.setValueVolume(clouds[p][0] - robot, clouds[p][0] + robot, m.getClampingThresMin(), 0)
+            mn, mx = m.minmax_change()
+            m.resetMinMaxChangeDetection()
+            data, _ = m.write_ex(aabb=(mn, mx), compress=False, min_depth=0, header=False)
+            pub["bytes"] += len(data)
+            pub["msgs"] += 1
+        dts_srv = run_leg(m, step_server, min(args.min_timed_s, 0.25), prepare=m.resetMinMaxChangeDetection)
+        extra["server_loop"] = dict(leg_summary(dts_srv), bytes_per_publish=pub["bytes"] / max(1, pub["msgs"]),
+                                    note="per scan: pointcloud2 ingest + integrate, setValueVolume(robot box, clamping_thres_min), writeData(change AABB) "
+                                         "+ resetMinMaxChangeDetection (server.cpp:114-225)")
+        digests_pc2["server_loop"] = m.digest()
+        m.resetMinMaxChangeDetection()
+
         # ---- round 1's figure: one scan re-integrated from a static pose into a saturated map -------------------
         ms = OccupancyMap(RES, device=local_rank)
         d0, o0 = d_clouds[0], clouds[0][0]
@@ -263,6 +398,11 @@ def main():
         extra["resident_static"] = dict(rays_per_s=n_pts * reps_s / dt_s, ms_per_step=dt_s / reps_s * 1e3, steps=reps_s,
                                         note="steady-state best case: same scan, static pose, saturated map (round 1's headline conditions)")
         del ms
+
+    # ---- the other BASELINE configurations: ms per scan, every map checked ----------------------------------------------
+    other = None
+    if not batch_mode and not args.only_headline and not args.no_other_configs and rank == 0:
+        other = other_configs(local_rank, bool(args.big))
 
     # ---- per-kernel HIP events (roofline leg): sync calls so that a kernel's events do not straddle overlapped work --
     dt_ev = None
@@ -308,6 +448,26 @@ def main():
         legs_equal = len(set(digests.values())) == 1
         self_check = dict(checker=kind, scans=n_scans, leaves=int(len(ol[0])), inner=int(len(oi[0])), map_equals_checker=bool(same),
                           legs_agree=bool(legs_equal), legs=sorted(digests), seconds=round(time.perf_counter() - t0, 1))
+        if not batch_mode and not args.only_headline:
+            # the PointCloud2 legs: the reference fed through ITS ingest (rosToUfo + transform of the same records), then -- for the
+            # server loop -- its setValueVolume and resetMinMaxChangeDetection per scan
+            import oracle as _or
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import golden_util
+            o2, o3 = OracleMap(RES, kind=kind), OracleMap(RES, kind=kind)
+            for i in range(W + K):
+                p = pose_of(i)
+                xyz32, _ = _or.ingest(rec[p], 16, (0, 4, 8), None, ident, clouds[p][0], kind)
+                for om in (o2, o3):
+                    om.insert(clouds[p][0], xyz32, max_range=MAX_RANGE, depth=DEPTH, discrete=True)
+                o3.setValueVolume(clouds[p][0] - robot, clouds[p][0] + robot, o3.clamping_thres()[0], 0)
+            ok2 = tuple(digests_pc2["pointcloud2"]) == tuple(golden_util.dump_digest(o2.leaves(True), o2.inner()))
+            ok3 = tuple(digests_pc2["server_loop"]) == tuple(golden_util.dump_digest(o3.leaves(True), o3.inner()))
+            self_check.update(pointcloud2_equals_checker=bool(ok2), server_loop_equals_checker=bool(ok3))
+            same = same and ok2 and ok3
+            self_check["map_equals_checker"] = bool(same)
+        if other:
+            self_check["other_configs_ok"] = all(v["digest_ok"] for v in other.values())
 
     if rank == 0:
         value = head["rays_per_s"]
@@ -324,7 +484,9 @@ def main():
             # set-up + walk + merge for the other grid sizes; the durations of whatever ran add up.
             walkers = ("k_fcast", "k_cast", "k_walk", "k_dda_seg", "k_dda")  # fast path first: it runs all steady-state scans
             dom = next(k for k in walkers if k in kern_ms)
-            group = [dom, "k_fmerge"] if dom == "k_fcast" else [k for k in ("k_ray_setup",) + walkers[1:] + ("k_merge_slabs",) if k in kern_ms]
+            # (k_fcast: one launch = one scan. The slab merge k_fmerge is part of the tree walk now -- one launch for all the scans
+            # the walk takes -- and is not counted into the ray walk's duration any more.)
+            group = [dom] if dom == "k_fcast" else [k for k in ("k_ray_setup",) + walkers[1:] + ("k_merge_slabs",) if k in kern_ms]
             group = [k for k in group if k in kern_ms]
             share = P_BYTES * mean_rays + 16 * mean_steps
             dur_s = sum(kern_ms[k] for k in group) * 1e-3  # average launch durations of the kernels that make up one ray walk
@@ -336,12 +498,25 @@ def main():
                     pj = json.load(open(pmc))
                     vals = [next((v.get("hbm_bytes_per_launch") for kk, v in pj.items() if kk == k or kk.startswith(k + "<")), None) for k in group]
                     traffic = sum(v for v in vals if v) if any(vals) else None
-                    traffic_src = "profiles/pmc_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this round, scripts/profile_gpu.sh)"
+                    import hashlib
+                    traffic_src = ("profiles/pmc_latest.json (sha256 " + hashlib.sha256(open(pmc, "rb").read()).hexdigest()[:16] +
+                                   "): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, scripts/profile_gpu.sh -- a builder-run file, not measured in this run")
                 except Exception:
                     traffic = None
             by_time = max(per_step_ms, key=per_step_ms.get)
+            frac_rocprof, rocprof_src = None, None
+            for tag in ("r03", "r02"):
+                f = os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv")
+                if os.path.exists(f):
+                    import csv
+                    import hashlib
+                    rows = {r["kernel"].split("<")[0]: float(r["avg_ns"]) for r in csv.DictReader(open(f)) if r.get("avg_ns")}
+                    if all(k in rows for k in group):
+                        frac_rocprof = share / (sum(rows[k] for k in group) * 1e-9) / 1e9 / HBM_PEAK_GBS
+                        rocprof_src = f"profiles/{tag}_kernel_stats.csv (sha256 {hashlib.sha256(open(f, 'rb').read()).hexdigest()[:16]}): rocprofv3 --kernel-trace --stats of this command"
+                    break
             roof = dict(bound="hbm", kernel="+".join(group), achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
-                        traffic=traffic, traffic_source=traffic_src, algorithmic_bytes_per_launch=share, avg_launch_us=dur_s * 1e6,
+                        frac_rocprof=frac_rocprof, frac_rocprof_source=rocprof_src, traffic=traffic, traffic_source=traffic_src, algorithmic_bytes_per_launch=share, avg_launch_us=dur_s * 1e6,
                         walk_kernel_only=dict(avg_launch_us=kern_ms[dom] * 1e3, achieved_GBs=share / (kern_ms[dom] * 1e-3) / 1e9,
                                               frac=share / (kern_ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS),
                         dominant_by_time=dict(kernel=by_time, us_per_step=per_step_ms[by_time] * 1e3, avg_launch_us=kern_ms[by_time] * 1e3),
@@ -360,7 +535,7 @@ def main():
             "config": {"workload": ("configs[1]: synthetic 64-beam LiDAR scans, 131072 pts each, 16 cm leaf, 20 m max-range, discrete integrator + "
                                     "free-space raycast; moving sensor (pose i mod 8 of configs[3], 3 m apart), fresh map per repetition, clouds resident in HBM, async=true")
                        if not batch_mode else
-                       "configs[3]: batch of N concurrent 131072-pt LiDAR scans per step (moving sensors), 16 cm leaf, one scan per GPU, RCCL exchange of update lists, every replica applies all N in order",
+                       "configs[3]: batch of N concurrent 131072-pt LiDAR scans per step (moving sensors), 16 cm leaf, one scan per GPU, ONE RCCL all-gather of the scans as bit grids, every replica applies all N in rank order with one walk of the tree",
                        "points_per_scan": n_pts, "rays_cast_mean": mean_rays, "dda_steps_mean": mean_steps, "per_pose": counts,
                        "leaf_m": RES, "max_range_m": MAX_RANGE, "depth_levels": 16, "parallelism": f"scan-per-gpu x{world}",
                        **({"batch_impl": batch_impl} if batch_mode else {})},
@@ -370,6 +545,12 @@ def main():
                        "note": "node table as allocated (64 B block record + 16 B per-phase words per slot, load <= 0.6, sized for three pipelined scans' worst case) after the headline leg's last repetition"},
         }
         out.update(extra)
+        if "host_pointer" in extra:
+            out["value_incl_h2d"] = extra["host_pointer"]["rays_per_s"]
+            out["value_definitions"] = ("value: clouds resident in HBM when the timed region starts (the task's measurement rule); value_incl_h2d: the call the "
+                                        "reference's server makes, pageable host cloud in, 24 B/point over PCIe inside the timed region (SURVEY.md 8d's definition)")
+        if other:
+            out["other_configs"] = other
         if dt_ev:
             out["ms_per_step_with_events"] = float(sum(dt_ev)) / (K * len(dt_ev)) * 1e3
         if not batch_mode and not args.no_cpu_baseline:
@@ -385,7 +566,8 @@ def main():
             pass
         os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)
-    bad = bool(self_check) and not (self_check["map_equals_checker"] and self_check["legs_agree"])
+    bad = bool(self_check) and not (self_check["map_equals_checker"] and self_check["legs_agree"] and self_check.get("other_configs_ok", True))
+    bad = bad or (rank == 0 and not batch_mode and pipeline["gate_timeouts"] > 0)  # a stream hand-over timed out inside a timed region
     if batch_mode:
         dist.barrier()
         dist.destroy_process_group()

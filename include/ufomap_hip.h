@@ -320,6 +320,9 @@ int ufomap_map_insert_batch(ufomap_map* m, ufomap_comm* c, const double sensor_o
  * (1: every scan's ray cells through the sparse set), "phase_limit" / "scan_id" (when the per-phase tags restart),
  * "async_apply" (apply_keys_batch / insert_batch return after enqueueing). Results never depend on these. */
 int ufomap_map_set_option(ufomap_map* m, const char* key, long long value);
+/* Diagnostics: std::exp(float) as the device evaluates it inside toProb (occupancy_map_base.h:911 with LogitType = float;
+ * ufomap_amd/csrc/expf_ref.h), on n host values. tests/: equal to the host's libm expf, which is what the reference calls. */
+int ufomap_dev_expf(const float* x, float* out, size_t n, int device);
 
 /* Diagnostics: up to 64 raw 64-bit words written by the last integration's kernels (per-level
  * wall_clock64 stamps of the propagation tails: [level] hits phase, [32+level] misses phase, [31]/[63]

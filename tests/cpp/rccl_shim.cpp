@@ -9,7 +9,9 @@
 #include <atomic>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -22,6 +24,8 @@ struct Header {
 	std::atomic<uint32_t> arrived, generation, attached;
 };
 struct Comm {
+	bool replicate;  // UFOMAP_SHIM_REPLICATE=1 (scripts/bench_batch_model.py): ONE process plays all ranks -- every slot of an
+	                 // all-gather is a copy of the caller's (device-to-device on the stream): the walk for N ranks' scans, measured on one GPU
 	int world, rank, fd;
 	char name[64];
 	uint8_t* base;
@@ -57,6 +61,15 @@ int ncclCommInitRank(void** comm, int world, ShimId id, int rank)
 	Comm* c = new Comm;
 	c->world = world;
 	c->rank = rank;
+	const char* rep = getenv("UFOMAP_SHIM_REPLICATE");
+	c->replicate = rep && *rep && '0' != *rep;
+	if (c->replicate) {
+		c->fd = -1;
+		c->base = nullptr;
+		c->bytes = 0;
+		*comm = c;
+		return 0;
+	}
 	snprintf(c->name, sizeof(c->name), "%s", id.b);
 	c->bytes = 4096 + (size_t)world * kSlotMax;
 	c->fd = shm_open(c->name, O_CREAT | O_RDWR, 0600);
@@ -72,6 +85,10 @@ int ncclCommInitRank(void** comm, int world, ShimId id, int rank)
 int ncclCommDestroy(void* comm)
 {
 	Comm* c = static_cast<Comm*>(comm);
+	if (c->replicate) {
+		delete c;
+		return 0;
+	}
 	munmap(c->base, c->bytes);
 	close(c->fd);
 	shm_unlink(c->name);
@@ -81,6 +98,11 @@ int ncclCommDestroy(void* comm)
 int ncclAllGather(const void* send, void* recv, size_t count, int /*datatype: bytes*/, void* comm, hipStream_t stream)
 {
 	Comm* c = static_cast<Comm*>(comm);
+	if (c->replicate) {
+		for (int r = 0; r < c->world; ++r)
+			if (hipMemcpyAsync(static_cast<uint8_t*>(recv) + (size_t)r * count, send, count, hipMemcpyDeviceToDevice, stream) != hipSuccess) return 1;
+		return 0;
+	}
 	if (count > kSlotMax) return 3;
 	if (hipStreamSynchronize(stream) != hipSuccess) return 1;
 	if (hipMemcpy(c->slot(c->rank), send, count, hipMemcpyDeviceToHost) != hipSuccess) return 1;

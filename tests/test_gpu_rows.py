@@ -70,6 +70,36 @@ def test_leaf_and_tree_iteration_with_bounding_volume_and_state_filter(color):
         _same(g2.iterate(*args), o2.iterate(*args), f"fresh map {args}")
 
 
+def test_change_detection_code_set_deep_trees():
+    """depth_levels = 20 / 21: a depth-0 code is 60 / 63 bits wide -- the change log's records (table.h: ChangeLog) must hold it
+    together with the depth (a depth field in the top bits, as the records used to be packed, collides from 20 levels on).
+    20 levels: against the reference. 21 levels: the reference smashes its stack there (insertPointCloud*), so the same
+    scans must give change sets of the same sizes and depths as at 20 levels (same resolution: the same voxels)."""
+    from ufomap_amd import OccupancyMap, scans
+    g, o = _maps(resolution=0.16, depth_levels=20)
+    g21 = OccupancyMap(0.16, depth_levels=21)
+    for m in (g, o, g21):
+        m.enableChangeDetection(True)
+    for s in range(4):
+        # positive AND negative coordinates: the high Morton bits of a code are set for non-negative coordinates
+        origin, xyz, _ = scans.lidar64(beams=8, azimuths=128, origin=(0.1 + 40.0 * (s & 1), -0.2, 1.7), seed=21 + s)
+        depth = 1 if s == 2 else 0
+        kw = dict(max_range=8.0, depth=depth, discrete=bool(s & 1) or depth > 0)
+        _insert(g, o, origin, xyz, None, **kw)
+        _insert(g21, _Null(), origin, xyz, None, **kw)
+        _same(g.changes(), o.changes(), f"20 levels, scan {s}")
+        c20, c21 = g.changes(), g21.changes()
+        assert len(c20[0]) == len(c21[0]) and np.array_equal(np.sort(c20[1]), np.sort(c21[1])), f"21 levels, scan {s}"
+    assert len(g.changes()[0]) > 500 and int(g.changes()[0].max()) >> 58 != 0, "no code reached the bits the old packing used for the depth"
+    assert int(g21.changes()[0].max()) >> 61 != 0
+    assert same_dump(g.leaves(True), o.leaves(True))
+
+
+class _Null:
+    def insert(self, *a, **k):
+        pass
+
+
 @pytest.mark.parametrize("color", [False, True])
 def test_change_detection_code_set(color):
     """enableChangeDetection: every leaf update that changes a value records its code (occupancy_map_base.h:1070-1072,
@@ -204,3 +234,21 @@ def test_minmax_change_detection_switch_and_clear_to():
     _insert(g, o, origin, xyz, max_range=3.0, discrete=True)
     assert same_dump(g.leaves(True), o.leaves(True)) and same_dump(g.inner(), o.inner())
     assert g.write() == o.write_ex()[0]
+
+
+def test_device_expf_equals_the_hosts_libm():
+    """toProb's std::exp(float) on the device (expf_ref.h) against this box's libm -- the function the reference calls -- on
+    16 M random arguments in [-16, 16] and the special values (the host-side sweep of EVERY float in that range runs in the
+    CPU suite: tests/test_toprob_sweep.py; here the device is shown to run the same function)."""
+    import ctypes as C
+    from test_toprob_sweep import _build
+    from ufomap_amd import capi
+    lib, host = capi.load(), C.CDLL(_build(shared=True))
+    rng = np.random.default_rng(3)
+    x = np.concatenate([rng.uniform(-16, 16, 1 << 24).astype(np.float32), (rng.standard_normal(1 << 20) * 1e-3).astype(np.float32),
+                        np.array([0.0, -0.0, 88.7, 88.73, 100.0, -103.9, -104.0, -200.0, np.inf, -np.inf, 1e-45, -1e-45], np.float32)])
+    dev, ref = np.empty_like(x), np.empty_like(x)
+    capi.check(lib.ufomap_dev_expf(C.c_void_p(x.ctypes.data), C.c_void_p(dev.ctypes.data), C.c_size_t(x.size), 0))
+    host.expf_libm(C.c_void_p(x.ctypes.data), C.c_void_p(ref.ctypes.data), C.c_size_t(x.size))
+    bad = np.nonzero(dev.view(np.uint32) != ref.view(np.uint32))[0]
+    assert bad.size == 0, f"{bad.size} values differ, e.g. exp({x[bad[0]]!r}) = {dev[bad[0]]!r} on the device, {ref[bad[0]]!r} on the host"

@@ -14,6 +14,7 @@
 //   apply   : all hits (clamp), then all misses (clamp), one thread per 8-child node block
 //   propagate: level by level, only where a child's summary changed (OMB:1126-1133 early exit)
 #pragma once
+#include "expf_ref.h"
 #include "scan_kernels.h"
 
 namespace ufo
@@ -27,8 +28,14 @@ struct Summ {
 
 __device__ inline u32 levelOf(const MapGeom& g, u64 lk) { return g.L - (u32)((63 - __clzll((long long)lk)) / 3); }
 
-// float exp as the reference's toProb sees it: std::exp(float) (OMB:911 with LogitType=float)
-__device__ inline double toProbF(float logit) { return 1.0 / (1.0 + (double)((float)exp((double)(-logit)))); }
+// float exp as the reference's toProb sees it: std::exp(float) (OMB:911 with LogitType=float) -- glibc's expf, bit for bit
+// (expf_ref.h; swept against the host's libm over every float32 a clamped log-odds can take: tests/test_toprob_sweep.py)
+__device__ inline double toProbF(float logit) { return 1.0 / (1.0 + (double)ufoExpfRef(-logit)); }
+// (diagnostics, ufomap_dev_expf: the device's std::exp(float) on an array, in place)
+__global__ void k_dev_expf(float* __restrict__ x, u32 n)
+{
+	for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) x[i] = ufoExpfRef(x[i]);
+}
 
 // updateNode for a non-leaf node (OMB:1191-1224) + colour average (OMC.cpp:177-222), read-only part.
 // oc >= 0 substitutes (o_occ, o_fl, o_rgb) for child oc: the summary the node had before that child's
@@ -1561,24 +1568,44 @@ __global__ __launch_bounds__(256) void k_digest(Table t, MapGeom g, int include_
 // r,g,b]); the eight leaves of a depth-1 node follow each other without a mask byte. Pre-order offsets come
 // from subtree sizes: sizes bottom-up (one launch per level), offsets and bytes top-down.
 // ------------------------------------------------------------------------------------------------
+// (The per-level counters are hot words: tens of thousands of live blocks on 16 of them. A workgroup counts in LDS and adds
+// its totals with one atomic per level -- straight atomics serialise at ~12 ns each: 0.4 ms for a 30 k-block map.)
 __global__ __launch_bounds__(256) void k_ser_count(Table t, MapGeom g, u32* __restrict__ level_cnt)
 {
+	__shared__ u32 cnt[32];
+	if (threadIdx.x < 32u) cnt[threadIdx.x] = 0;
+	__syncthreads();
 	u32 ncap = t.mask + 1;
 	for (u32 s = blockIdx.x * blockDim.x + threadIdx.x; s < ncap; s += gridDim.x * blockDim.x) {
 		u64 lk = t.key(s);
 		if (0 == lk || (t.flags(s) & F_DEAD)) continue;
-		atomicAdd(&level_cnt[levelOf(g, lk)], 1u);
+		atomicAdd(&cnt[levelOf(g, lk)], 1u);
 	}
+	__syncthreads();
+	if (threadIdx.x < 32u && cnt[threadIdx.x]) atomicAdd(&level_cnt[threadIdx.x], cnt[threadIdx.x]);
 }
 __global__ __launch_bounds__(256) void k_ser_collect(Table t, MapGeom g, const u32* __restrict__ level_off, u32* __restrict__ level_fill,
                                                      u32* __restrict__ list)
 {
+	__shared__ u32 cnt[32], base[32];
 	u32 ncap = t.mask + 1;
-	for (u32 s = blockIdx.x * blockDim.x + threadIdx.x; s < ncap; s += gridDim.x * blockDim.x) {
-		u64 lk = t.key(s);
-		if (0 == lk || (t.flags(s) & F_DEAD)) continue;
-		u32 l = levelOf(g, lk);
-		list[level_off[l] + atomicAdd(&level_fill[l], 1u)] = s;
+	for (u32 s0 = blockIdx.x * blockDim.x; s0 < ncap; s0 += gridDim.x * blockDim.x) {  // (uniform trip count: barriers inside)
+		if (threadIdx.x < 32u) cnt[threadIdx.x] = 0;
+		__syncthreads();
+		const u32 s = s0 + threadIdx.x;
+		u32 l = 0xFFFFFFFFu, rank = 0;
+		if (s < ncap) {
+			u64 lk = t.key(s);
+			if (0 != lk && !(t.flags(s) & F_DEAD)) {
+				l = levelOf(g, lk);
+				rank = atomicAdd(&cnt[l], 1u);
+			}
+		}
+		__syncthreads();
+		if (threadIdx.x < 32u && cnt[threadIdx.x]) base[threadIdx.x] = atomicAdd(&level_fill[threadIdx.x], cnt[threadIdx.x]);
+		__syncthreads();
+		if (l != 0xFFFFFFFFu) list[level_off[l] + base[l] + rank] = s;
+		__syncthreads();
 	}
 }
 // Bounding volume and min_depth of Octree::write / writeData (octree.h:779-917): only children whose box intersects the
@@ -1611,8 +1638,8 @@ __device__ inline bool serChildIn(const SerArgs& sa, const double c[3], u32 i, d
 	}
 	return volIntersects(va, cc, chs);
 }
-__global__ __launch_bounds__(256) void k_ser_sizes(Table t, MapGeom g, SerArgs sa, const u32* __restrict__ list, u32 n, u32 level, u32 D,
-                                                   u64* __restrict__ size)
+__device__ inline void serSizesLevel(const Table& t, const MapGeom& g, const SerArgs& sa, const u32* __restrict__ list, u32 n, u32 level, u32 D,
+                                     u64* __restrict__ size)
 {
 	const double chs = g.hs[level - 1];
 	for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -1634,6 +1661,27 @@ __global__ __launch_bounds__(256) void k_ser_sizes(Table t, MapGeom g, SerArgs s
 		size[s] = sz;
 	}
 }
+__global__ __launch_bounds__(256) void k_ser_sizes(Table t, MapGeom g, SerArgs sa, const u32* __restrict__ list, u32 n, u32 level, u32 D,
+                                                   u64* __restrict__ size)
+{
+	serSizesLevel(t, g, sa, list, n, level, D, size);
+}
+// the levels l_from .. l_to (towards the root: few blocks each) by ONE workgroup, a barrier per level instead of a launch
+struct SerLevels {
+	u32 off[32], cnt[32];
+};
+__global__ __launch_bounds__(1024) void k_ser_sizes_tail(Table t, MapGeom g, SerArgs sa, const u32* __restrict__ list, SerLevels lv, u32 l_from, u32 l_to,
+                                                         u32 D, u64* __restrict__ size, unsigned long long* __restrict__ total_out)
+{
+	for (u32 l = l_from; l <= l_to; ++l) {
+		if (lv.cnt[l]) serSizesLevel(t, g, sa, list + lv.off[l], lv.cnt[l], l, D, size);
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+		__syncthreads();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+	}
+	// the stream's length: the 0xFF byte + the subtree of the root block (the last level's only block)
+	if (0 == threadIdx.x && total_out) *total_out = 1ull + size[list[lv.off[l_to]]];
+}
 __device__ inline void serPutLeaf(uint8_t* __restrict__ out, u64 at, float v, u32 rgb, u32 D)
 {
 	u32 b;
@@ -1649,8 +1697,8 @@ __device__ inline void serPutLeaf(uint8_t* __restrict__ out, u64 at, float v, u3
 	}
 }
 // off[] is pre-set to ~0: a block whose offset nobody wrote lies outside the bounding volume (or below min_depth)
-__global__ __launch_bounds__(256) void k_ser_write(Table t, MapGeom g, SerArgs sa, const u32* __restrict__ list, u32 n, u32 level, u32 D,
-                                                   const u64* __restrict__ size, u64* __restrict__ off, uint8_t* __restrict__ out)
+__device__ inline void serWriteLevel(const Table& t, const MapGeom& g, const SerArgs& sa, const u32* __restrict__ list, u32 n, u32 level, u32 D,
+                                     const u64* __restrict__ size, u64* __restrict__ off, uint8_t* __restrict__ out)
 {
 	const double chs = g.hs[level - 1];
 	for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -1684,6 +1732,26 @@ __global__ __launch_bounds__(256) void k_ser_write(Table t, MapGeom g, SerArgs s
 			serPutLeaf(out, at, t.occ(s)[ch], t.rgb ? t.rgb[8 * (size_t)s + ch] : 0u, D);
 			at += D;
 		}
+	}
+}
+
+__global__ __launch_bounds__(256) void k_ser_write(Table t, MapGeom g, SerArgs sa, const u32* __restrict__ list, u32 n, u32 level, u32 D,
+                                                   const u64* __restrict__ size, u64* __restrict__ off, uint8_t* __restrict__ out)
+{
+	serWriteLevel(t, g, sa, list, n, level, D, size, off, out);
+}
+// the levels l_from down to l_to (from the root: few blocks each) by ONE workgroup; the first byte of the stream (0xFF,
+// writeNodes) comes from here, too
+__global__ __launch_bounds__(1024) void k_ser_write_tail(Table t, MapGeom g, SerArgs sa, const u32* __restrict__ list, SerLevels lv, u32 l_from, u32 l_to,
+                                                         u32 D, const u64* __restrict__ size, u64* __restrict__ off, uint8_t* __restrict__ out)
+{
+	if (0 == threadIdx.x) out[0] = 0xFF;
+	for (u32 l = l_from; l + 1 > l_to; --l) {
+		if (lv.cnt[l]) serWriteLevel(t, g, sa, list + lv.off[l], lv.cnt[l], l, D, size, off, out);
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+		__syncthreads();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+		if (0 == l) break;
 	}
 }
 

@@ -52,11 +52,15 @@ struct MapRoot {
 };
 
 // Change log: while change detection is enabled every leaf update that changes a value appends the code the reference
-// inserts into `changes_` (occupancy_map_base.h:1070-1072, 1094-1108) as (code >> 3*depth) | depth << 58; the host
-// sorts and de-duplicates when the set is read (ufomap_map_changes). buf == nullptr: disabled.
+// inserts into `changes_` (occupancy_map_base.h:1070-1072, 1094-1108) as (1 << 3*(L-depth)) | (code >> 3*depth) -- the code's
+// 3*(L-depth) significant bits behind a sentinel bit whose position tells the depth (the form of the table's location
+// keys): 64 bits hold it for every depth_levels the map accepts (21: 63 bits + sentinel), where a depth field in the top
+// bits would collide with the code from depth_levels = 20 on. The host decodes, sorts and de-duplicates when the set is
+// read (ufomap_map_changes). buf == nullptr: disabled.
 struct ChangeLog {
 	u64* buf;
 	u32 cap;
+	u32 L;
 };
 
 // One table slot: the record of one 8-child node block, 64 bytes, 64-byte aligned -- what a lookup finds (the key),
@@ -153,7 +157,7 @@ __device__ inline void logChanges(const Table& t, const ChangeLog& cl, u64 base,
 	while (mask) {
 		const u32 c = (u32)__ffs(mask) - 1u;
 		mask &= mask - 1u;
-		if (pos < cl.cap) cl.buf[pos] = (base | (u64)c) | ((u64)depth << 58);
+		if (pos < cl.cap) cl.buf[pos] = (base | (u64)c) | (1ULL << (3u * (cl.L - depth)));
 		else t.root->chg_overflow = 1u;
 		++pos;
 	}
@@ -162,7 +166,7 @@ __device__ inline void logChange(const Table& t, const ChangeLog& cl, u64 code_s
 {
 	if (!cl.buf) return;
 	const u32 pos = atomicAdd(&t.root->n_changes, 1u);
-	if (pos < cl.cap) cl.buf[pos] = code_shifted | ((u64)depth << 58);
+	if (pos < cl.cap) cl.buf[pos] = code_shifted | (1ULL << (3u * (cl.L - depth)));
 	else t.root->chg_overflow = 1u;
 }
 }  // namespace ufo

@@ -228,6 +228,8 @@ struct ufomap_map {
 	DevBuf b_first, b_tilebits, b_gridH;  // fast path, per hand-over set (HandOver)
 	UpperGeo ugeo{};
 	DevBuf b_tilerec;             // fast path, map stream only
+	DevBuf b_ser[5];              // scratch of the map byte stream (serialiseNodes), kept between calls
+	uint8_t* h_ser = nullptr;     // ... pinned: per-level counts, the root, the stream's length
 	DevBuf b_pipe;                // fast path: which walk applies which scan (fast_kernels.h: Pipe), device side
 	uint64_t n_fseq = 0;          // fast-path scans enqueued so far
 	u32 geo_id = 0;               // scans with the same geo id may share a walk: same ray grid, no other update of the map between them
@@ -767,7 +769,7 @@ u64 levelBound(const i32 nb[3], u32 shift)
 
 // ---- change log (change detection) ------------------------------------------------------------------------------
 // the log the update kernels append to; empty (disabled) unless enableChangeDetection is on
-ChangeLog changeLog(const ufomap_map* m) { return m->chg_enabled ? ChangeLog{m->b_changes.as<u64>(), m->chg_cap} : ChangeLog{nullptr, 0u}; }
+ChangeLog changeLog(const ufomap_map* m) { return m->chg_enabled ? ChangeLog{m->b_changes.as<u64>(), m->chg_cap, m->g.L} : ChangeLog{nullptr, 0u, m->g.L}; }
 
 // room for `extra` more records: the log grows by copy. Synchronises the map stream (change detection runs every
 // update synchronously, see doInsert: it is a diagnostic mode, not the fast path).
@@ -2377,6 +2379,8 @@ void ufomap_map_destroy(ufomap_map* m)
 	if (m->copy_ev) (void)hipEventDestroy(m->copy_ev);
 	if (m->h_root) (void)hipHostFree(m->h_root);
 	if (m->h_prep) (void)hipHostFree(m->h_prep);
+	if (m->h_ser) (void)hipHostFree(m->h_ser);
+	for (DevBuf& b : m->b_ser) b.release();
 	if (m->done_ev) (void)hipEventDestroy(m->done_ev);
 	if (m->xstream) (void)hipStreamDestroy(m->xstream);
 	if (m->stream) (void)hipStreamDestroy(m->stream);
@@ -2725,10 +2729,12 @@ int ufomap_map_set_model_value(ufomap_map* m, int which, double probability)
 {
 	if (!m) return fail(UFOMAP_ERR_INVALID, "null map");
 	if (which < 2 || which > 5) return fail(UFOMAP_ERR_INVALID, "which: 2 prob_hit, 3 prob_miss, 4 clamping_thres_min, 5 clamping_thres_max");
-	int rc = ufomap_map_wait(m);
+	if (!(probability > 0.0 && probability < 1.0)) return fail(UFOMAP_ERR_INVALID, "a probability strictly between 0 and 1 is needed (its logit is stored)");
+	const int rc = ufomap_map_wait(m);
+	if (rc) return rc;  // (the model is not changed under an integration that failed)
 	m->model_log[which] = std::log(probability / (1.0 - probability));
 	applyModel(m);
-	return rc;
+	return UFOMAP_OK;
 }
 
 int ufomap_map_enable_minmax_change_detection(ufomap_map* m, int enable)
@@ -2779,7 +2785,7 @@ size_t ufomap_map_changes(ufomap_map* m, uint64_t* codes, uint8_t* depths, size_
 	const size_t n = root.n_changes;
 	std::vector<uint64_t> h(n);
 	if (n && hipMemcpy(h.data(), m->b_changes.p, n * 8, hipMemcpyDeviceToHost) != hipSuccess) return (size_t)-1;
-	std::sort(h.begin(), h.end());  // depth sits in the top bits: (depth, code) order
+	std::sort(h.begin(), h.end());
 	h.erase(std::unique(h.begin(), h.end()), h.end());
 	if (h.size() < n) {
 		// keep the log compact: the set, once
@@ -2788,9 +2794,17 @@ size_t ufomap_map_changes(ufomap_map* m, uint64_t* codes, uint8_t* depths, size_
 		    hipMemcpy(reinterpret_cast<char*>(m->b_root.p) + offsetof(MapRoot, n_changes), &nn, 4, hipMemcpyHostToDevice) != hipSuccess)
 			return (size_t)-1;
 	}
-	for (size_t i = 0; i < h.size() && i < cap; ++i) {
-		if (codes) codes[i] = h[i] & ((1ULL << 58) - 1ULL);
-		if (depths) depths[i] = (uint8_t)(h[i] >> 58);
+	// a record is (1 << 3*(L-depth)) | (code >> 3*depth) (table.h: ChangeLog): the sentinel's position gives the depth. Out in
+	// (depth, code) order.
+	std::vector<std::pair<uint8_t, uint64_t>> recs(h.size());
+	for (size_t i = 0; i < h.size(); ++i) {
+		const int p = 63 - __builtin_clzll(h[i] | 1ULL);
+		recs[i] = {(uint8_t)(m->g.L - (u32)p / 3u), h[i] ^ (1ULL << p)};
+	}
+	std::sort(recs.begin(), recs.end());
+	for (size_t i = 0; i < recs.size() && i < cap; ++i) {
+		if (codes) codes[i] = recs[i].second;
+		if (depths) depths[i] = recs[i].first;
 	}
 	return h.size();
 }
@@ -3283,6 +3297,14 @@ int scanKeysCore(ufomap_map* m, const double sensor_origin[3], const double* d_x
 	m->fast = false;
 	m->deferred = false;
 	m->batch_world = 0;
+	struct RestoreStream {  // (every exit: the helpers launch on the map stream again, finished events are taken in)
+		ufomap_map* m;
+		~RestoreStream()
+		{
+			drainEvents(m);
+			m->cs = m->stream;
+		}
+	} restore{m};
 	m->cs = m->sstream;
 	u32 n_hits = 0, n_rays = 0;
 	int rc = scanPhase(m, sensor_origin, d_xyz, d_rgb, n, max_range, depth, discrete, simple_ray_casting, 0, &n_hits, &n_rays);
@@ -4175,28 +4197,27 @@ int serialiseNodes(ufomap_map* m, const SerArgs& sa, std::vector<uint8_t>& data)
 			if (!(min1 <= max2) || !(min2 <= max1)) return UFOMAP_OK;
 		}
 	}
-	DevBuf b_cnt, b_list, b_size, b_off, b_out;
-	struct Guard {
-		DevBuf* b[5];
-		~Guard()
-		{
-			for (DevBuf* x : b) x->release();
-		}
-	} guard{{&b_cnt, &b_list, &b_size, &b_off, &b_out}};
-	u32 h_cnt[32] = {0}, h_off[32] = {0};
-	HIP_TRY(b_cnt.reserve(3 * 32 * 4));
-	HIP_TRY(hipMemsetAsync(b_cnt.p, 0, 3 * 32 * 4, m->stream));
+	// (scratch kept with the map: a publish per scan must not pay five allocations)
+	DevBuf &b_cnt = m->b_ser[0], &b_list = m->b_ser[1], &b_size = m->b_ser[2], &b_off = m->b_ser[3], &b_out = m->b_ser[4];
+	if (!m->h_ser) HIP_TRY(hipHostMalloc((void**)&m->h_ser, 512));
+	u32* h_cnt = reinterpret_cast<u32*>(m->h_ser);                                    // [32] live blocks per level
+	MapRoot* h_root = reinterpret_cast<MapRoot*>(m->h_ser + 128);
+	unsigned long long* h_total = reinterpret_cast<unsigned long long*>(m->h_ser + 256);
+	u32 h_off[32] = {0};
+	HIP_TRY(b_cnt.reserve(3 * 32 * 4 + 16));
+	HIP_TRY(hipMemsetAsync(b_cnt.p, 0, 3 * 32 * 4 + 16, m->stream));
 	u32* d_cnt = b_cnt.as<u32>();
+	unsigned long long* d_total = reinterpret_cast<unsigned long long*>(d_cnt + 96);
 	hipLaunchKernelGGL(k_ser_count, gridFor((u64)m->t.mask + 1), dim3(256), 0, m->stream, m->t, m->g, d_cnt);
 	HIP_TRY(hipMemcpyAsync(h_cnt, d_cnt, 32 * 4, hipMemcpyDeviceToHost, m->stream));
+	HIP_TRY(hipMemcpyAsync(h_root, m->b_root.p, sizeof(MapRoot), hipMemcpyDeviceToHost, m->stream));
 	HIP_TRY(hipStreamSynchronize(m->stream));
 	u64 n_live = 0;
 	for (u32 l = 0; l < 32; ++l) {
 		h_off[l] = (u32)n_live;
 		n_live += h_cnt[l];
 	}
-	MapRoot root;
-	HIP_TRY(hipMemcpy(&root, m->b_root.p, sizeof(MapRoot), hipMemcpyDeviceToHost));
+	const MapRoot root = *h_root;
 	if (0 == h_cnt[L] || L <= sa.min_depth) {
 		// the root is (written as) a leaf: children byte 0, then the root's payload (occupancy_map_base.h:1469-1478)
 		data.resize(1 + D);
@@ -4214,25 +4235,30 @@ int serialiseNodes(ufomap_map* m, const SerArgs& sa, std::vector<uint8_t>& data)
 	HIP_TRY(b_list.reserve(std::max<u64>(n_live, 1) * 4));
 	HIP_TRY(b_size.reserve(ncap * 8));
 	HIP_TRY(b_off.reserve(ncap * 8));
-	HIP_TRY(hipMemcpyAsync(d_cnt + 32, h_off, 32 * 4, hipMemcpyHostToDevice, m->stream));
+	SerLevels lv{};
+	for (u32 l = 0; l < 32; ++l) {
+		lv.off[l] = h_off[l];
+		lv.cnt[l] = h_cnt[l];
+	}
+	HIP_TRY(hipMemcpyAsync(d_cnt + 32, h_off, 32 * 4, hipMemcpyHostToDevice, m->stream));  // (h_off: read by the copy before this function returns -- it synchronises below)
 	HIP_TRY(hipMemsetAsync(b_off.p, 0xFF, ncap * 8, m->stream));
 	hipLaunchKernelGGL(k_ser_collect, gridFor((u64)m->t.mask + 1), dim3(256), 0, m->stream, m->t, m->g, d_cnt + 32, d_cnt + 64, b_list.as<u32>());
-	for (u32 l = first; l <= L; ++l)
+	// wide levels: a launch each; from the first level of at most 2048 blocks up to the root: ONE workgroup, a barrier per level
+	u32 l_tail = L;
+	while (l_tail > first && h_cnt[l_tail - 1] <= 2048u) --l_tail;
+	for (u32 l = first; l < l_tail; ++l)
 		if (h_cnt[l])
 			hipLaunchKernelGGL(k_ser_sizes, gridFor(h_cnt[l]), dim3(256), 0, m->stream, m->t, m->g, sa, b_list.as<u32>() + h_off[l], h_cnt[l], l, D,
 			                   b_size.as<u64>());
-	// total = 0xFF byte + subtree of the root block
-	u32 root_slot = 0;
-	HIP_TRY(hipMemcpyAsync(&root_slot, b_list.as<u32>() + h_off[L], 4, hipMemcpyDeviceToHost, m->stream));
+	hipLaunchKernelGGL(k_ser_sizes_tail, dim3(1), dim3(1024), 0, m->stream, m->t, m->g, sa, b_list.as<u32>(), lv, l_tail, L, D, b_size.as<u64>(), d_total);
+	HIP_TRY(hipMemcpyAsync(h_total, d_total, 8, hipMemcpyDeviceToHost, m->stream));
 	HIP_TRY(hipStreamSynchronize(m->stream));
-	u64 root_size = 0;
-	HIP_TRY(hipMemcpy(&root_size, b_size.as<u64>() + root_slot, 8, hipMemcpyDeviceToHost));
-	const u64 total = 1 + root_size;
+	const u64 total = *h_total;  // 0xFF byte + subtree of the root block
 	if (total > 0x7FFFFFFFull) return fail(UFOMAP_ERR_CAPACITY, "map byte stream exceeds 2^31 bytes (the reference's size field is an int)");
 	HIP_TRY(b_out.reserve(total));
-	const uint8_t ff = 0xFF;
-	HIP_TRY(hipMemcpyAsync(b_out.p, &ff, 1, hipMemcpyHostToDevice, m->stream));
-	for (u32 l = L; l >= first; --l)
+	hipLaunchKernelGGL(k_ser_write_tail, dim3(1), dim3(1024), 0, m->stream, m->t, m->g, sa, b_list.as<u32>(), lv, L, l_tail, D, b_size.as<u64>(), b_off.as<u64>(),
+	                   b_out.as<uint8_t>());
+	for (u32 l = l_tail; l-- > first;)
 		if (h_cnt[l])
 			hipLaunchKernelGGL(k_ser_write, gridFor(h_cnt[l]), dim3(256), 0, m->stream, m->t, m->g, sa, b_list.as<u32>() + h_off[l], h_cnt[l], l, D,
 			                   b_size.as<u64>(), b_off.as<u64>(), b_out.as<uint8_t>());
@@ -4321,6 +4347,8 @@ struct StreamParser {
 	bool has_bv;
 	double vc[3], vh[3];
 	std::vector<ReadRec> recs[24];  // by level (= depth of the node)
+	size_t n_recs = 0;              // a record (~100 bytes) per node with children: bounded while parsing, not afterwards
+	static constexpr size_t kMaxRecs = 1u << 26;
 
 	bool inside(const double c[3], double h) const
 	{
@@ -4350,6 +4378,10 @@ struct StreamParser {
 			return;
 		}
 		const uint8_t children = p[pos++];
+		if (++n_recs > kMaxRecs) {
+			bad = true;  // (more inner nodes than a map this library can hold: not a stream it wrote)
+			return;
+		}
 		const u32 mine = (u32)recs[cd].size();
 		ReadRec r{};
 		r.lk = lk;
@@ -4376,6 +4408,7 @@ struct StreamParser {
 						cr.set_mask |= 1u << j;
 						leaf(&cr.val[j], &cr.rgb[j]);
 					}
+					if (++n_recs > kMaxRecs) bad = true;
 					recs[1].push_back(cr);
 				} else {
 					node((lk << 3) | (u64)i, cd - 1, cc, mine);
@@ -4519,6 +4552,10 @@ int ufomap_map_read_data(ufomap_map* m, const uint8_t* data, size_t n, const dou
 		const Lz4& z = lz4();
 		if (!z.ok) return fail(UFOMAP_ERR_UNSUPPORTED, "liblz4 could not be loaded: compressed input is not available");
 		if (uncompressed_data_size < 0) return fail(UFOMAP_ERR_INVALID, "negative uncompressed_data_size");
+		if (n > 0x7FFFFFFFull) return fail(UFOMAP_ERR_INVALID, "compressed stream longer than 2^31 bytes (LZ4's size arguments are ints)");
+		// (LZ4 cannot expand a block by more than a factor of 255: a header that claims more is not believed -- it would
+		// only size an allocation)
+		if ((u64)uncompressed_data_size > 255ull * (u64)n + 64ull) return fail(UFOMAP_ERR_INVALID, "uncompressed_data_size is impossible for a compressed stream of this length");
 		std::vector<uint8_t> raw((size_t)std::max(uncompressed_data_size, 1));
 		const int got = z.safe(reinterpret_cast<const char*>(data), reinterpret_cast<char*>(raw.data()), (int)n, uncompressed_data_size);
 		if (got < 0) return fail(UFOMAP_ERR_INVALID, "LZ4 decompression failed");
@@ -4668,5 +4705,18 @@ int ufomap_map_debug(ufomap_map* m, uint64_t* out, int n)
 }
 
 void* ufomap_map_stream(ufomap_map* m) { return m ? (void*)m->stream : nullptr; }
+
+int ufomap_dev_expf(const float* x, float* out, size_t n, int device)
+{
+	if ((n && (!x || !out)) || n > (1ull << 31)) return fail(UFOMAP_ERR_INVALID, "null argument / more than 2^31 values");
+	HIP_TRY(hipSetDevice(device));
+	DevBuf b;
+	HIP_TRY(b.reserve(std::max<size_t>(n, 1) * 4));
+	HIP_TRY(hipMemcpy(b.p, x, n * 4, hipMemcpyHostToDevice));
+	hipLaunchKernelGGL(k_dev_expf, gridFor(n), dim3(256), 0, nullptr, b.as<float>(), (u32)n);
+	HIP_TRY(hipDeviceSynchronize());
+	HIP_TRY(hipMemcpy(out, b.p, n * 4, hipMemcpyDeviceToHost));
+	return UFOMAP_OK;
+}
 
 }  // extern "C"

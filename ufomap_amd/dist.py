@@ -140,7 +140,9 @@ class CBatchIntegrator:
         rank = dist.get_rank(group) if dist.is_initialized() else 0
         ids = [Comm.unique_id() if rank == 0 else None]
         if world > 1:
-            dist.broadcast_object_list(ids, src=0, group=group)
+            # (src is a GLOBAL rank: the first rank of the group, which need not be global rank 0)
+            src = dist.get_global_rank(group, 0) if group is not None and hasattr(dist, "get_global_rank") else 0
+            dist.broadcast_object_list(ids, src=src, group=group)
         self.comm = Comm(ids[0], world, rank, device_index)
         self.m.set_option("async_apply", 1)
 

@@ -220,11 +220,16 @@ class OccupancyMapBase:
         keep, pc, ph = self._bv(aabb)
         us = C.c_longlong(-1)
         a = (int(compress), int(min_depth), int(compression_acceleration_level), int(compression_level), int(header))
-        n = self._lib.ufomap_map_write_ex(self._h, pc, ph, *a, None, 0, C.byref(us))
+        # one serialisation when the stream fits the buffer kept from the last call (the C call returns the size it needs)
+        buf = getattr(self, "_wbuf", None)
+        if buf is None:
+            buf = self._wbuf = np.empty(1 << 16, np.uint8)
+        n = self._lib.ufomap_map_write_ex(self._h, pc, ph, *a, _p(buf, C.c_uint8), buf.size, C.byref(us))
         if n == C.c_size_t(-1).value:
             capi.check(-2)
-        buf = np.empty(max(n, 1), np.uint8)
-        self._lib.ufomap_map_write_ex(self._h, pc, ph, *a, _p(buf, C.c_uint8), n, C.byref(us))
+        if n > buf.size:
+            buf = self._wbuf = np.empty(n + n // 2, np.uint8)
+            self._lib.ufomap_map_write_ex(self._h, pc, ph, *a, _p(buf, C.c_uint8), buf.size, C.byref(us))
         return buf[:n].tobytes(), int(us.value)
 
     def read(self, data):
