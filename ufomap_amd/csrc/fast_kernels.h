@@ -154,17 +154,9 @@ struct PointRec {
 template <bool DISCRETE>
 __global__ __launch_bounds__(256) void k_fhits(MapGeom g, FastGeo fg, D3 sensor, const double* __restrict__ xyz, u32 n, double max_range,
                                                u32 color_variant, u32* __restrict__ first, BoxPartial* __restrict__ part, ScanCtl* ctl,
-                                               Ingest ing, PointRec* __restrict__ recs, uint4* __restrict__ gridH4, uint4* __restrict__ gridM4, u32 n4,
-                                               double* __restrict__ keep)
+                                               Ingest ing, PointRec* __restrict__ recs, double* __restrict__ keep)
 {
 	const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-	// the scan's hit grid (one bit per cell, the ray grid's layout; marked by the ray kernel for the first point of every
-	// hit voxel) and its ray grid (the sector form ORs into it) start empty: this is the first kernel of the scan's chain,
-	// and the set's previous scan has been joined
-	for (u32 j = i; j < n4; j += gridDim.x * blockDim.x) {
-		gridH4[j] = make_uint4(0, 0, 0, 0);
-		gridM4[j] = make_uint4(0, 0, 0, 0);
-	}
 	double amn[3] = {1e300, 1e300, 1e300}, amx[3] = {-1e300, -1e300, -1e300};
 	i32 ck[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, ek[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
 	bool odd = false;
@@ -266,10 +258,9 @@ __device__ inline void foldBoxes(const BoxPartial* __restrict__ boxes, u32 nboxe
 // ------------------------------------------------------------------------------------------------
 template <bool DISCRETE>
 __global__ __launch_bounds__(512) void k_fcast(MapGeom g, FastGeo fg, D3 sensor, const double* __restrict__ xyz, u32 n, double max_range,
-                                               u32 color_variant, u32* __restrict__ first, D3* __restrict__ ray_scratch, u32 cap_wg,
+                                               u32 color_variant, const u32* __restrict__ first, D3* __restrict__ ray_scratch, u32 cap_wg,
                                                u32* __restrict__ slabs, u32 k_min, const ScanCtl* ctl_in, ScanCtl* ctl,
-                                               unsigned long long* __restrict__ steps_part, Ingest ing, const PointRec* __restrict__ recs,
-                                               u32* __restrict__ gridH)
+                                               unsigned long long* __restrict__ steps_part, Ingest ing, const PointRec* __restrict__ recs)
 {
 	extern __shared__ __attribute__((aligned(16))) u32 lds[];
 	const u32 err_in = ctl_in->err;  // (looked at once the LDS grid has been cleared: the load is in flight meanwhile)
@@ -313,16 +304,11 @@ __global__ __launch_bounds__(512) void k_fcast(MapGeom g, FastGeo fg, D3 sensor,
 				const bool odd = 0 != (r.flags & 4u);
 				cast = (r.flags & 1u) && !odd;
 				if ((r.flags & 2u) && !odd) {
-					const bool winner = __hip_atomic_load(&first[r.cell], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == i;
+					// (the voxel receives a hit, OMB:295, 358-360: its first point's. The scan's hit grid -- what the tree update
+					// reads -- is derived from this array by k_fmerge, which also leaves it clean for the set's next scan: 35 k
+					// scattered atomics less in this kernel, which sets the pipeline's period.)
+					const bool winner = first[r.cell] == i;
 					nhit += winner ? 1u : 0u;
-					if (winner) {
-						// the voxel receives a hit (OMB:295, 358-360: its first point's): one bit in the scan's hit grid, which is
-						// what the tree update reads. The winner is the entry's only reader that needs its value (a loser sees
-						// somebody else's index or the empty mark -- not its own either way): it leaves the array clean for the
-						// set's next scan.
-						atomicOr(&gridH[r.cell >> 5], 1u << (r.cell & 31u));
-						__hip_atomic_store(&first[r.cell], 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-					}
 					if (DISCRETE && !winner) cast = false;  // OMB:358-360: dropped entirely, no ray
 				}
 				end = r.end;
@@ -604,7 +590,8 @@ struct ScanDesc {  // a scan as the tree update sees it: written into the ring w
 	const uint4* slabs;                  // the ray kernel's per-workgroup copies of the ray grid ...
 	const unsigned long long* parts;     // ... and step / ray / hit counts (merged by the walk that takes the scan)
 	u32* gridM;                          // ray cells of the scan (bit grid, Grid::layout 1; written by k_fmerge)
-	u32* gridH;                          // hit voxels of the scan (same layout)
+	u32* gridH;                          // hit voxels of the scan (same layout; written by k_fmerge from `first`)
+	u32* first;                          // first point of every cell (k_fhits' atomicMin; 0xFFFFFFFF: none), left clean by k_fmerge
 	u32* tile_bits;                      // depth-3 tiles of the grid that hold a ray cell (written by k_fmerge, cleared by k_ftail)
 	ScanCtl* ctl;                        // control block (err: the scan half flagged the scan; the walk stands back)
 	ScanCtl* host_result;                // where the finished control block goes (pinned), followed by the word the host polls
@@ -713,6 +700,7 @@ __global__ void k_claim(Pipe* p, unsigned long long f, u32 bmax, ScanCtl* ctl, u
 __global__ __launch_bounds__(1024) void k_fmerge(FastGeo fg, const Pipe* __restrict__ p, unsigned long long f, u32 n4)
 {
 	__shared__ uint4 part[16][64];
+	__shared__ uint8_t hb[16][64];
 	__shared__ u32 tb[UFO_FAST_MAX_TILES / 32];
 	const Pipe::Slot sl = p->slot[f & (UFO_RING - 1u)];
 	for (u32 b = 0; b < sl.B; ++b) {
@@ -763,9 +751,31 @@ __global__ __launch_bounds__(1024) void k_fmerge(FastGeo fg, const Pipe* __restr
 					acc.w |= a.w;
 				}
 			}
+			// the scan's hit grid: one bit per cell that holds a first point (the voxel receives a hit, OMB:295, 358-360), from the
+			// dense first-point array -- 128 entries per column, eight per slab lane -- which is left clean for the set's next scan
+			u32 hbits = 0;
+			if (j < n4 && d.first) {
+				uint4* f4 = reinterpret_cast<uint4*>(d.first + (size_t)128u * j + 8u * sl16);
+				const uint4 fa = f4[0], fb = f4[1];
+				hbits = (fa.x != 0xFFFFFFFFu ? 1u : 0u) | (fa.y != 0xFFFFFFFFu ? 2u : 0u) | (fa.z != 0xFFFFFFFFu ? 4u : 0u) | (fa.w != 0xFFFFFFFFu ? 8u : 0u) |
+				        (fb.x != 0xFFFFFFFFu ? 16u : 0u) | (fb.y != 0xFFFFFFFFu ? 32u : 0u) | (fb.z != 0xFFFFFFFFu ? 64u : 0u) | (fb.w != 0xFFFFFFFFu ? 128u : 0u);
+				if (hbits) {
+					f4[0] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+					f4[1] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+				}
+			}
+			hb[sl16][col] = (uint8_t)hbits;
 			part[sl16][col] = acc;
 			__syncthreads();
 			if (0 == sl16 && j < n4) {
+				if (d.first) {
+					uint4 hv;
+					hv.x = (u32)hb[0][col] | ((u32)hb[1][col] << 8) | ((u32)hb[2][col] << 16) | ((u32)hb[3][col] << 24);
+					hv.y = (u32)hb[4][col] | ((u32)hb[5][col] << 8) | ((u32)hb[6][col] << 16) | ((u32)hb[7][col] << 24);
+					hv.z = (u32)hb[8][col] | ((u32)hb[9][col] << 8) | ((u32)hb[10][col] << 16) | ((u32)hb[11][col] << 24);
+					hv.w = (u32)hb[12][col] | ((u32)hb[13][col] << 8) | ((u32)hb[14][col] << 16) | ((u32)hb[15][col] << 24);
+					reinterpret_cast<uint4*>(d.gridH)[j] = hv;
+				}
 				for (u32 k = 1; k < 16u; ++k) {
 					const uint4 a = part[k][col];
 					acc.x |= a.x;

@@ -1869,7 +1869,7 @@ __global__ __launch_bounds__(256) void k_rehash_copy(Table src, Table dst, u32* 
 		if (0 == lk) continue;
 		if (src.flags(s) & F_DEAD) continue;
 		++mine;
-		u32 d = hash64(lk) & dst.mask;
+		u32 d = tableHome(dst, lk);
 		bool ok = false;
 		for (u32 probe = 0; probe <= dst.mask; ++probe) {
 			u64 prev = atomicCAS((unsigned long long*)&dst.key(d), 0ULL, (unsigned long long)lk);
@@ -1877,7 +1877,7 @@ __global__ __launch_bounds__(256) void k_rehash_copy(Table src, Table dst, u32* 
 				ok = true;
 				break;
 			}
-			d = (d + 1) & dst.mask;
+			d = tableNext(dst, d);
 		}
 		if (!ok) {
 			atomicOr(fail, 1u);

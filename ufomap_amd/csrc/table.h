@@ -23,7 +23,8 @@
 //                    and change its summary, and the summary it had just before that update
 //
 // A node's own value lives in its parent's block; the root's value lives in MapRoot.
-// Open addressing, linear probing, power-of-two capacity; blocks are never removed (a collapsed
+// Open addressing, linear probing, ANY capacity (the home slot is hash * capacity >> 32: no power of two needed, so a table
+// is as large as its blocks need and not up to twice that); blocks are never removed (a collapsed
 // block is marked DEAD and revived by inheritance when a later update descends through it, which
 // is exactly what the reference does with pruning disabled, octree.h:1064).
 #pragma once
@@ -84,7 +85,7 @@ struct Table {
 	u32* lu_fl;     // bit0/1 = contains_free/unknown of the pre-last summary, bit 8 = "reached and changed", 9.. = phase tag
 	u32* lu_rgb;    // colour maps only
 	MapRoot* root;
-	u32 mask;  // capacity - 1
+	u32 mask;  // capacity - 1 (the capacity need not be a power of two: tableHome / tableNext)
 	__device__ __forceinline__ u64& key(u32 s) const { return blk[s].key; }
 	__device__ __forceinline__ float* occ(u32 s) const { return blk[s].occ; }
 	__device__ __forceinline__ u32& flags(u32 s) const { return blk[s].flags; }
@@ -102,15 +103,19 @@ __device__ inline u32 hash64(u64 k)
 	return (u32)k;
 }
 
+// home slot of a key and the probe sequence's next slot, for any capacity
+__device__ __forceinline__ u32 tableHome(const Table& t, u64 lk) { return (u32)(((u64)hash64(lk) * ((u64)t.mask + 1ull)) >> 32); }
+__device__ __forceinline__ u32 tableNext(const Table& t, u32 s) { return s == t.mask ? 0u : s + 1u; }
+
 // Lookup only. Returns NONE when absent (DEAD blocks are returned: callers check flags).
 __device__ inline u32 tableFind(const Table& t, u64 lk)
 {
-	u32 s = hash64(lk) & t.mask;
+	u32 s = tableHome(t, lk);
 	for (u32 probe = 0; probe <= t.mask; ++probe) {
 		u64 k = __hip_atomic_load(&t.key(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		if (k == lk) return s;
 		if (k == 0) return NONE;
-		s = (s + 1) & t.mask;
+		s = tableNext(t, s);
 	}
 	return NONE;
 }
@@ -119,7 +124,7 @@ __device__ inline u32 tableFind(const Table& t, u64 lk)
 // Returns NONE when the table is full (caller raises the capacity error).
 __device__ inline u32 tableEnsure(const Table& t, u64 lk, u32 scan_id, u32 max_probe, bool* created, u32* n_created)
 {
-	u32 s = hash64(lk) & t.mask;
+	u32 s = tableHome(t, lk);
 	*created = false;
 	for (u32 probe = 0; probe < max_probe; ++probe) {
 		u64 k = __hip_atomic_load(&t.key(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -145,7 +150,7 @@ __device__ inline u32 tableEnsure(const Table& t, u64 lk, u32 scan_id, u32 max_p
 			}
 			return s;
 		}
-		s = (s + 1) & t.mask;
+		s = tableNext(t, s);
 	}
 	return NONE;
 }

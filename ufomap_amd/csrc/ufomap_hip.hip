@@ -134,6 +134,16 @@ inline u32 nextPow2(u64 v)
 	while (p < v) p <<= 1;
 	return (u32)std::min<u64>(p, 1ull << 31);
 }
+// Capacity of the node table for `need` blocks (those that are there + those the next update can create): load 0.59 when
+// they all exist -- just under the 0.6 at which a table is exchanged for a larger one -- and at least 1.5 x the present
+// capacity, so that a map that keeps growing is re-hashed a logarithmic number of times. Any number (a multiple of 4096),
+// not a power of two: that alone cost up to 2 x (C3 at insert depth 0: 10.7 GB where 6.7 GB do).
+inline u32 tableCapFor(u64 need, u64 cap_now)
+{
+	u64 c = std::max<u64>((need * 27 + 15) / 16, cap_now + cap_now / 2);
+	c = (std::max<u64>(c, 1u << 16) + 4095) & ~4095ull;
+	return (u32)std::min<u64>(c, 1ull << 31);
+}
 }  // namespace
 
 // What the map half of scan i needs while the scan half of scan i+1 already runs on the other stream:
@@ -999,9 +1009,9 @@ int sizeTable(ufomap_map* m, const Entry* ent_h, u64 capH, const i32 nbH[3], con
 			}
 		}
 	}
-	u64 want = (m->used_est + extra_used + m->scan_new_bound) * 2;
-	if (want > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
-	return growTable(m, nextPow2(want));
+	const u64 want = tableCapFor(m->used_est + extra_used + m->scan_new_bound, (u64)m->t.mask + 1);
+	if ((m->used_est + extra_used + m->scan_new_bound) * 27 / 16 > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
+	return growTable(m, (u32)want);
 }
 
 // Update lists from the two grids of the current scan into b_entries: hit entries first, then miss entries.
@@ -1192,7 +1202,7 @@ int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, si
 	const D3 sensor{origin[0], origin[1], origin[2]};
 	(void)makeUpperGeo(fg, m->g.L, &m->ugeo);
 	const size_t cf = m->b_first.cap, ct = m->b_tilebits.cap;  // (a re-allocation may well return the old address: compare sizes)
-	HIP_TRY(m->b_first.reserve((size_t)fg.ncells * 4));
+	HIP_TRY(m->b_first.reserve(((size_t)fg.gr.bytes * 8 + 127) / 128 * 128 * 4));  // (one entry per bit of the grid, whole 128-entry columns: k_fmerge)
 	HIP_TRY(m->b_tilebits.reserve(UFO_FAST_MAX_TILES / 8));
 	if (cf != m->b_first.cap || ct != m->b_tilebits.cap) m->first_dirty = true;
 	// k_fhits depends on nothing but the cloud: on the prep stream it overlaps the ray kernel of the scan before
@@ -1240,10 +1250,10 @@ int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, si
 		ProfScope ps(m, "k_fhits");
 		if (discrete)
 			hipLaunchKernelGGL(k_fhits<true>, gp, dim3(256), 0, m->cs, m->g, fg, sensor, d_xyz, N, max_range, 0u, m->b_first.as<u32>(),
-			                   m->b_part1.as<BoxPartial>(), ctl, m->ing, m->b_hit_code.as<PointRec>(), m->b_gridH.as<uint4>(), m->b_gridM.as<uint4>(), (u32)(fg.gr.bytes >> 4), keep);
+			                   m->b_part1.as<BoxPartial>(), ctl, m->ing, m->b_hit_code.as<PointRec>(), keep);
 		else
 			hipLaunchKernelGGL(k_fhits<false>, gp, dim3(256), 0, m->cs, m->g, fg, sensor, d_xyz, N, max_range, 0u, m->b_first.as<u32>(),
-			                   m->b_part1.as<BoxPartial>(), ctl, m->ing, m->b_hit_code.as<PointRec>(), m->b_gridH.as<uint4>(), m->b_gridM.as<uint4>(), (u32)(fg.gr.bytes >> 4), keep);
+			                   m->b_part1.as<BoxPartial>(), ctl, m->ing, m->b_hit_code.as<PointRec>(), keep);
 	}
 	// stream-to-stream hand-overs of this path: k_signal / k_gate (fast_kernels.h), not events
 	m->gates = useGates(m);
@@ -1267,10 +1277,10 @@ int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, si
 			const size_t lds = (size_t)fg.gr.bytes + UFO_CAST_LDS_EXTRA;
 			if (discrete)
 				hipLaunchKernelGGL(k_fcast<true>, dim3(nwg), dim3(512), lds, m->cs, m->g, fg, sensor, d_xyz, N, max_range, 0u, m->b_first.as<u32>(),
-				                   m->b_ray_end.as<D3>(), cap_wg, m->b_slabs.as<u32>(), (u32)std::max(8, m->opt_cast_k), ctl, ctl, sp, m->ing, m->b_hit_code.as<PointRec>(), m->b_gridH.as<u32>());
+				                   m->b_ray_end.as<D3>(), cap_wg, m->b_slabs.as<u32>(), (u32)std::max(8, m->opt_cast_k), ctl, ctl, sp, m->ing, m->b_hit_code.as<PointRec>());
 			else
 				hipLaunchKernelGGL(k_fcast<false>, dim3(nwg), dim3(512), lds, m->cs, m->g, fg, sensor, d_xyz, N, max_range, 0u, m->b_first.as<u32>(),
-				                   m->b_ray_end.as<D3>(), cap_wg, m->b_slabs.as<u32>(), (u32)std::max(8, m->opt_cast_k), ctl, ctl, sp, m->ing, m->b_hit_code.as<PointRec>(), m->b_gridH.as<u32>());
+				                   m->b_ray_end.as<D3>(), cap_wg, m->b_slabs.as<u32>(), (u32)std::max(8, m->opt_cast_k), ctl, ctl, sp, m->ing, m->b_hit_code.as<PointRec>());
 		}
 		// end of the scan half: the scan's descriptor and number become visible to the walks (k_claim)
 		ScanDesc d{};
@@ -1278,6 +1288,7 @@ int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, si
 		d.parts = sp;
 		d.gridM = m->b_gridM.as<u32>();
 		d.gridH = m->b_gridH.as<u32>();
+		d.first = m->b_first.as<u32>();
 		d.tile_bits = m->b_tilebits.as<u32>();
 		d.ctl = ctl;
 		d.host_result = m->h_res;
@@ -1370,10 +1381,10 @@ int enqueueSlot(ufomap_map* m, int k)
 				scanQueue();
 			}
 			if ((m->used_est + bound) * 5 > ((u64)m->t.mask + 1) * 3) {
-				const u64 want = (m->used_est + 2 * bound) * 2;  // (room for a neighbouring grid's walks behind this one, too)
-				if (want > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
+				const u64 want = tableCapFor(m->used_est + bound, (u64)m->t.mask + 1);
+				if ((m->used_est + bound) * 27 / 16 > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
 				m->cs = m->stream;
-				const int rc = growTable(m, nextPow2(want));
+				const int rc = growTable(m, (u32)want);
 				if (rc) return rc;
 			}
 		}
@@ -2407,10 +2418,10 @@ int ufomap_map_reserve(ufomap_map* m, size_t n_blocks)
 	HIP_TRY(hipSetDevice(m->device));
 	(void)ufomap_map_wait(m);
 	m->cs = m->stream;
-	u64 want = (u64)n_blocks * 2;
-	if (want > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
-	if (want <= (u64)m->t.mask + 1) return UFOMAP_OK;
-	return growTable(m, nextPow2(want));
+	if ((u64)n_blocks * 27 / 16 > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
+	if ((u64)n_blocks * 5 <= ((u64)m->t.mask + 1) * 3) return UFOMAP_OK;  // (they fit at load 0.6)
+	const u64 want = tableCapFor((u64)n_blocks, 0);
+	return growTable(m, (u32)want);
 }
 
 int ufomap_map_set_scratch_limit(ufomap_map* m, size_t bytes)
@@ -2665,9 +2676,9 @@ int ufomap_map_set_value_volume_ch(ufomap_map* m, const double aabb_center[3], c
 		{
 			const u64 cap = (u64)m->t.mask + 1;
 			if ((m->used_est + total) * 5 > cap * 3) {
-				const u64 want = (m->used_est + total) * 2;
-				if (want > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
-				rc = growTable(m, nextPow2(want));
+				const u64 want = tableCapFor(m->used_est + total, (u64)m->t.mask + 1);
+				if ((m->used_est + total) * 27 / 16 > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
+				rc = growTable(m, (u32)want);
 				if (rc) return rc;
 			}
 		}
@@ -3522,9 +3533,9 @@ int applyKeysBatchCore(ufomap_map* m, const void* const* d_lists, const ufomap_k
 				m->scan_new_bound = new_bound = std::min(new_bound, b);
 			}
 			if ((m->used_est + new_bound) * 5 > cap * 3) {
-				const u64 want = (m->used_est + new_bound) * 2;
-				if (want > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
-				int rc = growTable(m, nextPow2(want));
+				const u64 want = tableCapFor(m->used_est + new_bound, (u64)m->t.mask + 1);
+				if ((m->used_est + new_bound) * 27 / 16 > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
+				int rc = growTable(m, (u32)want);
 				if (rc) return rc;
 			}
 		}
@@ -3993,10 +4004,10 @@ int fastBatchStep(ufomap_map* m, ufomap_comm* c, const double origin[3], const d
 			const int jrc = joinEnqueued(m);  // (deterministic: every rank's replica holds the same number of blocks)
 			if (jrc < 0) return jrc;
 			if ((m->used_est + bound) * 5 > ((u64)m->t.mask + 1) * 3) {
-				const u64 want = (m->used_est + 2 * bound) * 2;
-				if (want > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
+				const u64 want = tableCapFor(m->used_est + bound, (u64)m->t.mask + 1);
+				if ((m->used_est + bound) * 27 / 16 > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
 				m->cs = m->stream;
-				const int grc = growTable(m, nextPow2(want));
+				const int grc = growTable(m, (u32)want);
 				if (grc) return grc;
 			}
 		}
@@ -4497,9 +4508,9 @@ int readNodes(ufomap_map* m, const uint8_t* data, size_t n, const double* aabb_c
 	{
 		const u64 cap = (u64)m->t.mask + 1;
 		if ((m->used_est + total) * 5 > cap * 3) {
-			const u64 want = (m->used_est + total) * 2;
-			if (want > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
-			int rc = growTable(m, nextPow2(want));
+			const u64 want = tableCapFor(m->used_est + total, (u64)m->t.mask + 1);
+			if ((m->used_est + total) * 27 / 16 > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
+			int rc = growTable(m, (u32)want);
 			if (rc) return rc;
 		}
 	}
