@@ -1,27 +1,32 @@
 // fast_kernels.h -- the steady-state pipeline of a depth-0 scan whose ray grid fits in LDS (every LiDAR-sized scan):
 //
-//   prep stream   k_fhits  (k_signal)                                              (needs only the cloud)
-//   scan stream            (k_gate) k_fcast   k_fmerge  (k_signal)                 (never touch the map)
-//   map stream                                          (k_gate) k_tile   k_ftail  (the whole tree update)
+//   prep stream   k_fhits  (k_signal)                                   (needs only the cloud; keeps the points for a repeat)
+//   scan stream            (k_gate) k_fcast  (k_scan_done)              (never touches the map)
+//   map stream                               (k_claim) k_fmerge  k_tile  k_ftail     ONE walk of the tree for every scan
+//                                                                                     that has queued up by then
 //
-// five working launches per scan (plus the one-thread hand-over kernels between the streams) where the general path
-// (scan_kernels.h / map_kernels.h: classify, select, reduce_boxes, hitmark, cast, merge_slabs, extract x2, ensure,
-// init_new, apply_leaf, propagate x2, propagate_tail) needs fourteen. What makes that possible:
+// four working launches per scan on the streams that matter, and the three of the map stream are shared by all the scans
+// a walk takes -- where the general path (scan_kernels.h / map_kernels.h: classify, select, reduce_boxes, hitmark, cast,
+// merge_slabs, extract x2, ensure, init_new, apply_leaf, propagate x2, propagate_tail) needs fourteen per scan. What makes
+// that possible:
 //   * the scan runs on the ray grid PREDICTED from the previous scans (ufomap_hip.hip: predictGrid), so every array of
 //     the scan has a dense, known geometry: "first point in a voxel wins" (CodeSet `indices_`, occupancy_map_base.h:295,
 //     358-360) is one atomicMin on a dense u32 array over the grid's cells instead of a hash insert, and nothing has to
 //     be compacted into lists between kernels;
 //   * k_fcast takes a point's ray from the 32-byte record k_fhits left for it and drops the points that lost their voxel
 //     itself, instead of reading a ray list that a separate compaction kernel wrote;
-//   * the tree update is TILED: one wavefront owns one depth-3 node (8x8x8 voxels: 64 level-1 node blocks, 8 level-2
-//     blocks, 1 level-3 block) and does everything the reference's updateValue does beneath it -- createNode with
+//   * what a scan hands to the tree update is two bit grids (ray cells, hit voxels) and a bitmap of the depth-3 tiles they
+//     touch -- 0.2 MB, the same whether the update runs on this GPU or on seven others (ufomap_map_insert_batch);
+//   * the tree update is TILED and BATCHED: one wavefront owns one depth-3 node (8x8x8 voxels: 64 level-1 node blocks, 8
+//     level-2 blocks, 1 level-3 block) and does everything the reference's updateValue does beneath it -- createNode with
 //     inheritance, updateOccupancy for hits then misses, updateNode / pruning on the way up (occupancy_map_base.h:
-//     1063-1224, octree.h:997-1162) -- in registers and cross-lane operations, reading the scan's bit grid directly and
-//     writing each 64-byte block record exactly once; the few hundred node blocks above depth 3 are finished by ONE
-//     workgroup that holds them in LDS (k_ftail), where a level costs a barrier instead of a round trip to HBM.
+//     1063-1224, octree.h:997-1162) -- in registers and cross-lane operations, for B scans in order, reading each 64-byte
+//     block record once and writing it once; the few hundred node blocks above depth 3 are finished by ONE workgroup that
+//     holds them in LDS (k_ftail), where a level costs a barrier instead of a round trip to HBM;
+//   * which scans a walk takes is decided on the device when the walk starts (k_claim): whatever has queued up.
 // Semantics are those of the general path (map_kernels.h: "last-update chain"), which stays in place for everything
-// else -- first scans, insert depth > 0, grids beyond LDS, colour maps, update lists from other GPUs -- and doubles as
-// the on-GPU cross-check of this file (tests run both on the same scans).
+// else -- first scans, insert depth > 0, grids beyond LDS, colour maps -- and doubles as the on-GPU cross-check of this
+// file (tests run both on the same scans).
 #pragma once
 #include "map_kernels.h"
 
@@ -660,19 +665,28 @@ __global__ __launch_bounds__(256) void k_pack_slot(uint4* __restrict__ dst, cons
 // from ever running while this wave spins. The host uses events when it sees such a tool, ufomap_hip.hip: useGates; should
 // one slip through, the gate gives up after max_ticks and flags the scan, which then leaves the map alone, is repeated,
 // and the handle hands over with events from then on.)
-__global__ void k_claim(Pipe* p, unsigned long long f, u32 bmax, ScanCtl* ctl, unsigned long long max_ticks)
+__global__ void k_claim(Pipe* p, unsigned long long f, u32 bmax, ScanCtl* ctl, unsigned long long max_ticks, ScanCtl* host_result,
+                        unsigned long long done_value)
 {
 	if (0 != threadIdx.x) return;
 	const unsigned long long t0 = wall_clock64();
 	unsigned long long done;
+	Pipe::Slot& sl = p->slot[f & (UFO_RING - 1u)];
 	while ((done = __hip_atomic_load(&p->scan_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < f) {
 		__builtin_amdgcn_s_sleep(1);
 		if (wall_clock64() - t0 > max_ticks) {  // 100 MHz clock
+			// The scan half never finished (its descriptor is not in the ring): the slot applies nothing, its scan is reported
+			// as flagged -- the host repeats it -- and the walks behind this one stand back.
 			atomicOr(&ctl->err, ERR_GATE);
-			break;
+			sl.first = p->claimed + 1ull;
+			sl.B = 0;
+			p->wstat[f & (UFO_RING - 1u)] = 1u;
+			host_result->err = ERR_GATE;
+			__threadfence_system();
+			__hip_atomic_store(reinterpret_cast<unsigned long long*>(host_result + 1), done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+			return;
 		}
 	}
-	Pipe::Slot& sl = p->slot[f & (UFO_RING - 1u)];
 	const unsigned long long first = p->claimed + 1ull;  // scans up to f that have no slot of their own come along (the host
 	sl.first = first;                                     // sees to it that they share f's ray grid and are fewer than UFO_BATCH_MAX)
 	if (first > f) {

@@ -1402,7 +1402,8 @@ int enqueueSlot(ufomap_map* m, int k)
 	// without gates (a tool serialises kernels across streams) the map stream waits for the event behind the newest scan
 	// half; k_claim then finds the scan complete and only takes its decision
 	if (!m->gates) HIP_TRY(hipStreamWaitEvent(m->stream, m->scan_ev, 0));
-	hipLaunchKernelGGL(k_claim, dim3(1), dim3(64), 0, m->stream, pipe, (unsigned long long)f, bmax, ctl, gateTicks(m));
+	hipLaunchKernelGGL(k_claim, dim3(1), dim3(64), 0, m->stream, pipe, (unsigned long long)f, bmax, ctl, gateTicks(m), a ? a->h_res : m->h_res,
+	                   (unsigned long long)(a ? a->seq : m->seq));
 	{
 		ProfScope ps(m, "k_fmerge");
 		const u32 n4 = (u32)(fg.gr.bytes >> 4);
