@@ -4,10 +4,11 @@
 //
 // Launch sequence of one depth-0 integration in the steady state (doInsert; fast_kernels.h):
 //   prep stream: [H2D of a host cloud] -> k_fhits -> k_signal
-//   scan stream: k_gate -> k_fcast -> k_fmerge -> k_signal
-//   map stream:  k_gate -> k_tile (looks at the predecessor's flags) -> k_ftail (stores the finished control block and
-//                the scan's number into pinned host memory)
-//   join (of the integration before the previous one): the host polls that word; no copy, no stream synchronisation
+//   scan stream: k_gate -> k_fcast -> k_scan_done (the scan's descriptor and number become visible to the walks)
+//   map stream:  k_claim (waits for the scan half; takes every scan that is ready along) -> k_fmerge -> k_tile (looks at
+//                the predecessor's status) -> k_ftail (stores the finished control blocks and the scans' numbers into
+//                pinned host memory) -- ONE slot for all the scans it takes; no slot of its own for a scan while two are waiting
+//   join (of integrations that have completed): the host polls those words; no copy, no stream synchronisation
 // First scans, colour maps, insert depth > 0, grids beyond LDS (the general path):
 //   scan stream: memset hit hash -> control block H2D -> k_classify -> k_select -> k_reduce_boxes (checks the
 //                predicted ray grid) -> k_hitmark -> k_cast<0|2> -> [k_merge_slabs] -> k_extract_bits -> k_extract_hits
