@@ -185,6 +185,48 @@ def test_device_cloud_may_be_reused_as_soon_as_the_call_returns(color):
         assert g.debug()[63] >= 1, "the jumps should have forced repeats"
 
 
+_FEW_QUEUES = r"""
+import sys, time
+import numpy as np
+import torch
+from ufomap_amd import OccupancyMap, PointCloud, scans
+maps = [OccupancyMap(0.16) for _ in range(3)]
+refs = [OccupancyMap(0.16) for _ in range(3)]
+for r in refs:
+    r.set_option("fast", 0)   # general path, synchronous: the checker inside this process
+t0 = time.time()
+for i in range(16):
+    for k in range(3):
+        origin, xyz, _ = scans.lidar64(beams=16, azimuths=512, origin=scans.lidar_pose((i + k) % 4), seed=40 * k + i)
+        maps[k].insertPointCloudDiscrete(origin, PointCloud(xyz), 10.0, 0, False, 0, True)
+        refs[k].insertPointCloudDiscrete(origin, PointCloud(xyz), 10.0, 0, False, 0, False)
+for m in maps:
+    m.insertPointCloudWait()
+dt = time.time() - t0
+ok = all(m.digest() == r.digest() for m, r in zip(maps, refs))
+print("RESULT", int(ok), sum(m.debug()[58] for m in maps), sum(m.debug()[61] for m in maps), round(dt, 2))
+"""
+
+
+@pytest.mark.parametrize("queues", ["2", "1"])
+def test_gates_with_fewer_hardware_queues_than_streams(queues):
+    """GPU_MAX_HW_QUEUES = 2 / 1 and three maps fed in turn: their twelve streams share one or two hardware queues, so a gate
+    can sit in front of the very work it waits for. That must only cost time, and a bounded amount of it: a hand-over that
+    times out (20 ms) flags its scan, which is repeated, and the handle hands over with events from then on -- every map
+    still equals its sequential result."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, GPU_MAX_HW_QUEUES=queues, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = subprocess.run([sys.executable, "-c", _FEW_QUEUES], env=env, capture_output=True, text=True, timeout=280)
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("RESULT")]
+    assert line, out.stdout[-2000:] + out.stderr[-2000:]
+    ok, timeouts, fast, secs = line[0].split()[1:]
+    assert ok == "1", "a map differs from its sequential result"
+    assert int(fast) > 0, "the steady-state path never ran"
+    assert float(secs) < 60.0, f"{secs} s for 48 small scans: hand-over time-outs are not bounded ({timeouts} of them)"
+
+
 # ---- ufomap_map_insert_batch with MORE THAN ONE RANK, through the C ABI, on one GPU -----------------------------------------
 # tests/cpp/rccl_shim.cpp stands in for librccl (UFOMAP_RCCL_LIB): two processes on device 0, the all-gather staged through
 # POSIX shared memory. What is tested is everything around the collective: the slot/capacity-growth loop of the update-list

@@ -494,7 +494,16 @@ __global__ __launch_bounds__(256) void k_apply_leaf(Table t, MapGeom g, const En
 {
 	u32 n = *n_entries_p;
 	if (ctl->err) return;
-	for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+	// Parents to queue for the next level are STAGED in LDS and appended to the worklist eight iterations' worth at a time:
+	// the worklist counter is one word, an atomic on it costs ~12 ns whoever issues it, and one per wave and iteration was
+	// 0.77 M of them = 9 of this kernel's 11 ms on a 49 M-entry list (C3 at insert depth 0).
+	__shared__ u32 stage[256][8];
+	u32 nstage = 0;
+	const u32 stride = gridDim.x * blockDim.x;
+	const u32 iters = (n + stride - 1) / stride;  // (uniform trip count: the flush is a wave-wide operation)
+	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	for (u32 it = 0; it < iters; ++it, i += stride) {
+	if (i < n) {
 		Entry e = entries[i];
 		u32 s = ent_slot[i];
 		float4* po = reinterpret_cast<float4*>(t.occ(s));
@@ -562,7 +571,16 @@ __global__ __launch_bounds__(256) void k_apply_leaf(Table t, MapGeom g, const En
 		// the parent is re-evaluated when the stored summary changed over the whole pass, or when the last
 		// update alone changed it (its upward walk reached the parent even if the net change is nil)
 		const bool changed = writeToParent(t, g, s, e.lk, sm);
-		markDirty(t, changed || reachchg, t.parent(s), wl, &pc->wl_cnt[2]);
+		if (changed || reachchg) {
+			const u32 par = t.parent(s);
+			if (!(atomicOr(&t.flags(par), F_DIRTY) & F_DIRTY)) stage[threadIdx.x][nstage++] = par;
+		}
+	}
+		if (7u == (it & 7u) || it + 1u == iters) {
+			const u32 pos = waveAppendN(&pc->wl_cnt[2], nstage);
+			for (u32 k = 0; k < nstage; ++k) wl[pos + k] = stage[threadIdx.x][k];
+			nstage = 0;
+		}
 	}
 }
 

@@ -135,13 +135,14 @@ inline u32 nextPow2(u64 v)
 	while (p < v) p <<= 1;
 	return (u32)std::min<u64>(p, 1ull << 31);
 }
-// Capacity of the node table for `need` blocks (those that are there + those the next update can create): load 0.59 when
-// they all exist -- just under the 0.6 at which a table is exchanged for a larger one -- and at least 1.5 x the present
-// capacity, so that a map that keeps growing is re-hashed a logarithmic number of times. Any number (a multiple of 4096),
-// not a power of two: that alone cost up to 2 x (C3 at insert depth 0: 10.7 GB where 6.7 GB do).
+// Capacity of the node table for `need` blocks (those that are there + those the next update can create): load 0.57 when
+// they all exist -- a little under the 0.6 at which a table is exchanged for a larger one, so that a scan that adds a few
+// per cent does not re-hash gigabytes -- and at least 1.5 x the present capacity, so that a map that keeps growing is
+// re-hashed a logarithmic number of times. Any number (a multiple of 4096), not a power of two: that alone cost up to
+// 2 x (C3 at insert depth 0: 10.7 GB where 6.9 GB do).
 inline u32 tableCapFor(u64 need, u64 cap_now)
 {
-	u64 c = std::max<u64>((need * 27 + 15) / 16, cap_now + cap_now / 2);
+	u64 c = std::max<u64>((need * 7 + 3) / 4, cap_now + cap_now / 2);
 	c = (std::max<u64>(c, 1u << 16) + 4095) & ~4095ull;
 	return (u32)std::min<u64>(c, 1ull << 31);
 }
@@ -1011,7 +1012,7 @@ int sizeTable(ufomap_map* m, const Entry* ent_h, u64 capH, const i32 nbH[3], con
 		}
 	}
 	const u64 want = tableCapFor(m->used_est + extra_used + m->scan_new_bound, (u64)m->t.mask + 1);
-	if ((m->used_est + extra_used + m->scan_new_bound) * 27 / 16 > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
+	if ((m->used_est + extra_used + m->scan_new_bound) * 7 / 4 > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
 	return growTable(m, (u32)want);
 }
 
@@ -1383,7 +1384,7 @@ int enqueueSlot(ufomap_map* m, int k)
 			}
 			if ((m->used_est + bound) * 5 > ((u64)m->t.mask + 1) * 3) {
 				const u64 want = tableCapFor(m->used_est + bound, (u64)m->t.mask + 1);
-				if ((m->used_est + bound) * 27 / 16 > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
+				if ((m->used_est + bound) * 7 / 4 > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
 				m->cs = m->stream;
 				const int rc = growTable(m, (u32)want);
 				if (rc) return rc;
@@ -2420,7 +2421,7 @@ int ufomap_map_reserve(ufomap_map* m, size_t n_blocks)
 	HIP_TRY(hipSetDevice(m->device));
 	(void)ufomap_map_wait(m);
 	m->cs = m->stream;
-	if ((u64)n_blocks * 27 / 16 > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
+	if ((u64)n_blocks * 7 / 4 > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
 	if ((u64)n_blocks * 5 <= ((u64)m->t.mask + 1) * 3) return UFOMAP_OK;  // (they fit at load 0.6)
 	const u64 want = tableCapFor((u64)n_blocks, 0);
 	return growTable(m, (u32)want);
@@ -2679,7 +2680,7 @@ int ufomap_map_set_value_volume_ch(ufomap_map* m, const double aabb_center[3], c
 			const u64 cap = (u64)m->t.mask + 1;
 			if ((m->used_est + total) * 5 > cap * 3) {
 				const u64 want = tableCapFor(m->used_est + total, (u64)m->t.mask + 1);
-				if ((m->used_est + total) * 27 / 16 > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
+				if ((m->used_est + total) * 7 / 4 > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
 				rc = growTable(m, (u32)want);
 				if (rc) return rc;
 			}
@@ -3536,7 +3537,7 @@ int applyKeysBatchCore(ufomap_map* m, const void* const* d_lists, const ufomap_k
 			}
 			if ((m->used_est + new_bound) * 5 > cap * 3) {
 				const u64 want = tableCapFor(m->used_est + new_bound, (u64)m->t.mask + 1);
-				if ((m->used_est + new_bound) * 27 / 16 > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
+				if ((m->used_est + new_bound) * 7 / 4 > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
 				int rc = growTable(m, (u32)want);
 				if (rc) return rc;
 			}
@@ -4007,7 +4008,7 @@ int fastBatchStep(ufomap_map* m, ufomap_comm* c, const double origin[3], const d
 			if (jrc < 0) return jrc;
 			if ((m->used_est + bound) * 5 > ((u64)m->t.mask + 1) * 3) {
 				const u64 want = tableCapFor(m->used_est + bound, (u64)m->t.mask + 1);
-				if ((m->used_est + bound) * 27 / 16 > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
+				if ((m->used_est + bound) * 7 / 4 > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
 				m->cs = m->stream;
 				const int grc = growTable(m, (u32)want);
 				if (grc) return grc;
@@ -4511,7 +4512,7 @@ int readNodes(ufomap_map* m, const uint8_t* data, size_t n, const double* aabb_c
 		const u64 cap = (u64)m->t.mask + 1;
 		if ((m->used_est + total) * 5 > cap * 3) {
 			const u64 want = tableCapFor(m->used_est + total, (u64)m->t.mask + 1);
-			if ((m->used_est + total) * 27 / 16 > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
+			if ((m->used_est + total) * 7 / 4 > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
 			int rc = growTable(m, (u32)want);
 			if (rc) return rc;
 		}
