@@ -283,13 +283,19 @@ int ufomap_map_apply_keys(ufomap_map* m, const void* d_entries, const ufomap_key
 int ufomap_map_apply_keys_batch(ufomap_map* m, const void* const* d_lists, const ufomap_keys_info* infos, int n_lists);
 
 /* ---- batched multi-sensor integration across GPUs (BASELINE config C4) ------------------------------
- * One process per GPU. Every rank calls ufomap_map_insert_batch with ITS scan of the batch: the scan is ray-cast into
- * an update list (ufomap_map_scan_keys), ONE RCCL all-gather of fixed-size slots (header + list) moves the lists of
- * all ranks to all ranks, and every rank applies them in rank order with one walk of its replica's tree
- * (ufomap_map_apply_keys_batch). Every replica then equals the reference's map after
- * insertPointCloudDiscrete / insertPointCloud (occupancy_map_base.h:270-417) of scan 0, 1, ..., world-1 in that order.
- * Depth 0; colour maps exchange a colour section with the records (ufomap_map_scan_keys_rgb). librccl is loaded at run time (UFOMAP_RCCL_LIB overrides the name; a copy already in the
- * process is preferred).
+ * One process per GPU. Every rank calls ufomap_map_insert_batch with ITS scan of the batch; every replica then equals
+ * the reference's map after insertPointCloudDiscrete / insertPointCloud (occupancy_map_base.h:270-417) of scan 0, 1, ...,
+ * world-1 in that order. Steady state (plain map, the ranks share a ray grid): the scan is ray-cast on that grid and
+ * travels as two bit grids + a tile bitmap + its control block (~0.2 MB) in ONE RCCL all-gather; ONE walk of the tree
+ * applies all ranks' scans in rank order, enqueued behind the previous step's (option "async_apply": the call returns
+ * after enqueueing). First steps, colour maps (ufomap_map_scan_keys_rgb: a colour section travels with the records) and
+ * grids beyond LDS exchange update lists (ufomap_map_scan_keys / ufomap_map_apply_keys_batch) in fixed-size slots that
+ * grow alike on all ranks; a step whose common grid a rank's scan does not fit is repeated in that form by ALL ranks when
+ * it is joined. Contract: every rank makes the same sequence of calls on its map with the same map parameters and
+ * options (joins happen at fixed points of that sequence); cloud, size (0 allowed), pose and max_range are the rank's
+ * own. A rank whose scan fails still takes part in the collective and every rank returns the error. Insert depth 0.
+ * d_xyz / d_rgb are consumed when the call returns. librccl is loaded at run time (a copy already in the process is
+ * preferred; UFOMAP_RCCL_LIB names the library to use instead -- then that one only).
  *   ufomap_comm_unique_id   on ONE rank; the 128 bytes reach the others by the host's own means (file, socket, MPI...)
  *   ufomap_comm_create      ncclCommInitRank on `device` (collective: all ranks call it)
  *   ufomap_comm_from_nccl   wrap a communicator the host already has (ncclComm_t); not destroyed by ufomap_comm_destroy
@@ -315,7 +321,10 @@ int ufomap_map_insert_batch(ufomap_map* m, ufomap_comm* c, const double sensor_o
  * depth-0 scan as two passes over the tree instead of one; the environment variable UFOMAP_MERGE_PHASES
  * sets the default for new maps), "spec" (0: always read a scan's bounding boxes back before sizing its ray
  * grid; default 1: a depth-0 scan is enqueued on the grid predicted from the previous scan and repeated if it
- * does not fit), "fast" (0: never take the five-launch steady-state path of fast_kernels.h), "cast_global" (0: grids
+ * does not fit), "fast" (0: never take the steady-state path of fast_kernels.h), "batch_max" (scans one walk of the tree may take when scans
+ * have queued up behind the map stream: 1 .. 16, default 8), "hold" (test aid: a slot on the map stream for every hold-th
+ * scan only, so that walks over several scans happen whatever the timing), "gate_us" (a stream hand-over gives up after
+ * this long and the handle uses events from then on; default 20000), "cast_global" (0: grids
  * beyond LDS through k_dda_seg instead of k_cast<2>; 2-4: force the box / filter variants on small grids), "sparse_set"
  * (1: every scan's ray cells through the sparse set), "phase_limit" / "scan_id" (when the per-phase tags restart),
  * "async_apply" (apply_keys_batch / insert_batch return after enqueueing). Results never depend on these. */
