@@ -44,7 +44,7 @@ for spec in sys.argv[1:] or [""]:
             m.set_option(k, int(v))
     run(m, 3)
     d0 = m.debug()
-    dts = run(m, 60)
+    dts = run(m, int(os.environ.get("REPS", "60")))
     d1 = m.debug()
     dig = m.digest()
     if ref_digest is None:

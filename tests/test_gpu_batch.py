@@ -136,6 +136,33 @@ def test_fast_path_counter_and_general_path_agree_on_the_bench_sequence():
     assert off[61] == 0 and off[60] == 0
 
 
+@pytest.mark.parametrize("opts", [{"solo": 0}, {"solo": 1}, {"lazy_done": 0}, {"lazy_done": 1, "cast_wgs": 64}, {"cast_wgs": 256, "cast_batch": 96, "cast_qcap": 256},
+                                  {"cast_threads": 1024, "cast_wgs": 100, "cast_batch": 320}, {"cast_prio": 3, "tstamps": 1}])
+def test_scheduling_options_never_change_the_map(opts):
+    """How the five kernels are enqueued -- a synchronous call alone on the map stream (solo), the end of a scan half
+    published by the next scan's gate kernel (lazy_done), the ray kernel's workgroups / rays per round / segment queue --
+    is scheduling only: synchronous, asynchronous and mixed sequences of calls, continuous and discrete, leave the
+    reference's map, and the counters say the fast path ran."""
+    g, o = _maps(_kind(), resolution=0.16)
+    for k, v in opts.items():
+        g.set_option(k, v)
+    seq = _sequence(14, beams=32, azimuths=512, spread=0.5, seed0=900)
+    pattern = [False, False, True, True, True, False, True, True, False, False, True, True, True, True]  # async?
+    for i, ((origin, xyz), async_) in enumerate(zip(seq, pattern)):
+        discrete = i % 3 != 2
+        _insert(g, origin, xyz, 15.0, discrete, async_)
+        o.insert(origin, xyz, max_range=15.0, discrete=discrete)
+        if not async_ and i in (1, 5, 9):
+            assert g.digest() == g.digest(), "digest is stable"
+    g.insertPointCloudWait()
+    _assert_same_map(g, o, f"options {opts}")
+    d = g.debug()
+    assert d[61] >= 8 and d[58] == 0, f"fast path did not run / a hand-over timed out: {d[58:64]}"
+    if opts.get("tstamps"):
+        ts, newest = g.timeline()
+        assert newest >= 1 and ts[newest % 4096, 6] > ts[newest % 4096, 2] > 0, "pipeline time stamps of the newest scan"
+
+
 def test_many_handles_keep_their_maps_apart():
     """Three maps fed in turn with pipelined scans (3 x 4 streams on the device's hardware queues, gates spinning on all of
     them): every map equals its own sequential result; hand-over time-outs, if any, only cost time."""

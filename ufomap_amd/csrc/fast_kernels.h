@@ -254,6 +254,43 @@ __device__ inline void foldBoxes(const BoxPartial* __restrict__ boxes, u32 nboxe
 	}
 }
 
+// ---- scans as the tree update sees them (who applies which scan: see k_claim below) ----
+#define UFO_RING 16u       // scans in flight per handle (a power of two, > the number of hand-over sets)
+#define UFO_BATCH_MAX 16u  // scans per walk
+struct ScanDesc {  // a scan as the tree update sees it: written into the ring when its scan half ends (k_scan_done)
+	const uint4* slabs;                  // the ray kernel's per-workgroup copies of the ray grid ...
+	const unsigned long long* parts;     // ... and step / ray / hit counts (merged by the walk that takes the scan)
+	u32* gridM;                          // ray cells of the scan (bit grid, Grid::layout 1; written by k_fmerge)
+	u32* gridH;                          // hit voxels of the scan (same layout; written by k_fmerge from `first`)
+	u32* first;                          // first point of every cell (k_fhits' atomicMin; 0xFFFFFFFF: none), left clean by k_fmerge
+	u32* tile_bits;                      // depth-3 tiles of the grid that hold a ray cell (written by k_fmerge, cleared by k_ftail)
+	ScanCtl* ctl;                        // control block (err: the scan half flagged the scan; the walk stands back)
+	ScanCtl* host_result;                // where the finished control block goes (pinned), followed by the word the host polls
+	const BoxPartial* boxes;             // k_fhits' per-workgroup bounding boxes
+	unsigned long long done_value;       // value of that word: the integration's running number
+	unsigned long long fseq;             // running number among the fast-path scans
+	u32 n_slabs, nboxes;
+	u32 geo;                             // scans with equal geo may share a walk (same ray grid, consecutive updates of the map)
+	u32 pad;
+};
+struct Pipe {
+	unsigned long long scan_done;  // fast-path number of the newest scan whose scan half has finished (the scan stream works them off in order)
+	unsigned long long claimed;    // ... of the newest scan a walk has taken
+	struct Slot {
+		unsigned long long first;  // the slot of scan f (slot[f & 15]) applies scans first .. first + B - 1
+		u32 B, pad;                // (B == 0: scan f went with an earlier walk)
+	} slot[UFO_RING];
+	u32 wstat[UFO_RING];           // wstat[f & 15]: 0 = the walk that took scan f applied it; else it stood back / failed
+	ScanDesc ring[UFO_RING];
+	unsigned long long* ts;        // developer aid (option "tstamps"): device clock at the pipeline's hand-overs, 8 words per scan
+};
+// [0] k_signal (first-point pass done)  [1] gate entered  [2] gate open  [3] scan half published  [4] k_claim entered
+// [5] k_claim done  [6] k_ftail done  [7] scans the walk took; 100 MHz clock
+#define UFO_TS_SCANS 4096u
+__device__ __forceinline__ void tsMark(unsigned long long* ts, unsigned long long f, u32 k, unsigned long long v)
+{
+	if (ts) ts[(f & (UFO_TS_SCANS - 1u)) * 8u + k] = v;
+}
 // ------------------------------------------------------------------------------------------------
 // F2: the ray kernel of the fast path = k_cast (scan_kernels.h: set-up, segment queue, walk; bit grid in LDS) fed from
 // the input cloud instead of a compacted ray list. A workgroup takes the points blockIdx.x, blockIdx.x + gridDim.x, ...;
@@ -262,11 +299,25 @@ __device__ inline void foldBoxes(const BoxPartial* __restrict__ boxes, u32 nboxe
 // scratch array; from there on it is k_cast's round structure.
 // ------------------------------------------------------------------------------------------------
 template <bool DISCRETE>
-__global__ __launch_bounds__(512) void k_fcast(MapGeom g, FastGeo fg, D3 sensor, const double* __restrict__ xyz, u32 n, double max_range,
+__global__ __launch_bounds__(1024) void k_fcast(MapGeom g, FastGeo fg, D3 sensor, const double* __restrict__ xyz, u32 n, double max_range,
                                                u32 color_variant, const u32* __restrict__ first, D3* __restrict__ ray_scratch, u32 cap_wg,
                                                u32* __restrict__ slabs, u32 k_min, const ScanCtl* ctl_in, ScanCtl* ctl,
-                                               unsigned long long* __restrict__ steps_part, Ingest ing, const PointRec* __restrict__ recs)
+                                               unsigned long long* __restrict__ steps_part, Ingest ing, const PointRec* __restrict__ recs, u32 batch, u32 qcap,
+                                               u32 prio, Pipe* solo, ScanDesc solo_desc)
 {
+	// (solo: a synchronous call with nothing else in flight runs its five kernels on ONE stream -- no hand-over kernels,
+	// no claim; the walk's descriptor is written here, into a Pipe of the scan's own: slot 0 = this scan alone)
+	if (solo && 0 == (threadIdx.x | blockIdx.x)) {
+		solo->ring[0] = solo_desc;
+		solo->slot[0].first = 0;
+		solo->slot[0].B = 1;
+	}
+	// (batch, qcap: rays set up per round and segment queue entries -- they size the workgroup's LDS beside the bit grid,
+	// ufomap_hip.hip: castLds; prio: wave priority, the kernel that sets the pipeline's period shares its SIMDs with the
+	// kernels of the two other streams)
+	if (prio >= 3u) __builtin_amdgcn_s_setprio(3);
+	else if (2u == prio) __builtin_amdgcn_s_setprio(2);
+	else if (1u == prio) __builtin_amdgcn_s_setprio(1);
 	extern __shared__ __attribute__((aligned(16))) u32 lds[];
 	const u32 err_in = ctl_in->err;  // (looked at once the LDS grid has been cleared: the load is in flight meanwhile)
 	if (0 == (threadIdx.x | blockIdx.x)) ctl->dbg[30] = wall_clock64();  // (diagnostics)
@@ -274,23 +325,23 @@ __global__ __launch_bounds__(512) void k_fcast(MapGeom g, FastGeo fg, D3 sensor,
 	const u32 depth = 0;
 	const u32 lds_words = (u32)(gr.bytes >> 2);
 	RayConst* rc = reinterpret_cast<RayConst*>(lds + lds_words);
-	RayHdr* hd = reinterpret_cast<RayHdr*>(rc + UFO_CAST_BATCH);
-	SegRec* q = reinterpret_cast<SegRec*>(hd + UFO_CAST_BATCH);
-	u32* sh = reinterpret_cast<u32*>(q + UFO_CAST_QCAP);  // [0..7], [16..23]: per-wave partial sums; [24] ray count; [25] hit count
+	RayHdr* hd = reinterpret_cast<RayHdr*>(rc + batch);
+	SegRec* q = reinterpret_cast<SegRec*>(hd + batch);
+	u32* sh = reinterpret_cast<u32*>(q + qcap);  // [0..15], [16..31]: per-wave partial sums; [32] ray count; [33] hit count
 	{
 		uint4* l4 = reinterpret_cast<uint4*>(lds);
 		for (u32 j = threadIdx.x; j < (lds_words >> 2); j += blockDim.x) l4[j] = make_uint4(0, 0, 0, 0);
 	}
 	if (0 == threadIdx.x) {
-		sh[24] = 0;
-		sh[25] = 0;
+		sh[32] = 0;
+		sh[33] = 0;
 	}
 	if (err_in) return;  // the scan does not fit the predicted grid (k_fhits): it will be repeated (uniform exit)
 	__syncthreads();
 	const u32 rowBits = fg.rowBits, planeBits = fg.planeBits;
 	const u32 lim = 1u << (g.L - depth);
 	const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-	const u32 nwaves = min(8u, (blockDim.x + 63u) >> 6);
+	const u32 nwaves = min(16u, (blockDim.x + 63u) >> 6);
 	unsigned long long steps = 0;
 	u32 err = 0, oob = 0;
 	if (0 == (threadIdx.x | blockIdx.x)) ctl->dbg[31] = wall_clock64();  // (diagnostics)
@@ -320,7 +371,7 @@ __global__ __launch_bounds__(512) void k_fcast(MapGeom g, FastGeo fg, D3 sensor,
 			}
 			const u64 m = __ballot(cast);
 			u32 base = 0;
-			if (0 == lane && m) base = atomicAdd(&sh[24], (u32)__popcll(m));
+			if (0 == lane && m) base = atomicAdd(&sh[32], (u32)__popcll(m));
 			base = __shfl(base, 0);
 			if (cast) {
 				const u32 pos = base + (u32)__popcll(m & ((1ULL << lane) - 1ULL));
@@ -328,21 +379,21 @@ __global__ __launch_bounds__(512) void k_fcast(MapGeom g, FastGeo fg, D3 sensor,
 			}
 		}
 		for (int o = 32; o > 0; o >>= 1) nhit += __shfl_xor(nhit, o);
-		if (0 == lane && nhit) atomicAdd(&sh[25], nhit);
+		if (0 == lane && nhit) atomicAdd(&sh[33], nhit);
 	}
 	__syncthreads();
-	const u32 mine = min(sh[24], cap_wg);
+	const u32 mine = min(sh[32], cap_wg);
 	if (0 == (threadIdx.x | blockIdx.x)) ctl->dbg[32] = wall_clock64();  // (diagnostics)
 	if (0 == threadIdx.x) {
 		// per-workgroup partials, folded by k_fmerge (256 workgroups adding to one word serialise at ~12 ns each)
 		steps_part[gridDim.x + blockIdx.x] = mine;
-		steps_part[2u * gridDim.x + blockIdx.x] = sh[25];
+		steps_part[2u * gridDim.x + blockIdx.x] = sh[33];
 	}
 	const D3* my_rays = ray_scratch + (size_t)blockIdx.x * cap_wg;
-	for (u32 base = 0; base < mine; base += UFO_CAST_BATCH) {
+	for (u32 base = 0; base < mine; base += batch) {
 		__syncthreads();  // previous round's queue and constants are no longer read
 		const u32 t = threadIdx.x;
-		const bool have = t < UFO_CAST_BATCH && base + t < mine;
+		const bool have = t < batch && base + t < mine;
 		// ---- 1. one lane per ray: clip, keys, computeRayInit ----
 		u32 l1 = 0, dmax = 0, ax = 0, status = 0, lin0 = 0;
 		if (have) {
@@ -384,7 +435,7 @@ __global__ __launch_bounds__(512) void k_fcast(MapGeom g, FastGeo fg, D3 sensor,
 			tot += __shfl_xor(tot, o);
 			cntr += __shfl_xor(cntr, o);
 		}
-		if (0 == lane && wave < 8u) {
+		if (0 == lane && wave < 16u) {
 			sh[wave] = tot;
 			sh[16 + wave] = cntr;
 		}
@@ -394,33 +445,39 @@ __global__ __launch_bounds__(512) void k_fcast(MapGeom g, FastGeo fg, D3 sensor,
 			total += sh[wv];
 			nray2 += sh[16 + wv];
 		}
+		// K = k_min unless the queue cannot hold the segments that gives: then the K that is certain to fit (w is rounded
+		// down: at most 2 * total / K + one segment per ray)
 		u32 K = k_min;
-		{
-			const u32 room = UFO_CAST_QCAP - nray2;  // >= QCAP - BATCH > 0
-			const u32 need = (2u * total + room - 1u) / room;
-			K = max(K, need);
+		const u32 room = qcap - nray2;  // >= qcap - batch > 0
+		const u32 need = (2u * total + room - 1u) / room;
+		u32 w = 1, nseg = 0, off = 0, nsegs = 0;
+		for (u32 attempt = 0;; ++attempt) {
+			w = 1;
+			nseg = 0;
+			if (2 == status) {
+				w = (u32)(((u64)dmax * K) / l1);
+				if (w < 1u) w = 1u;
+				nseg = (dmax + w - 1u) / w;  // >= 1 (start and goal differ)
+			}
+			__syncthreads();  // sh[] is reused below
+			u32 incl = nseg;
+			for (int o = 1; o < 64; o <<= 1) {
+				const u32 v = __shfl_up(incl, o);
+				if ((int)lane >= o) incl += v;
+			}
+			if (63u == lane && wave < 16u) sh[wave] = incl;
+			__syncthreads();
+			off = incl - nseg;
+			nsegs = 0;
+			for (u32 wv = 0; wv < nwaves; ++wv) {
+				const u32 v = sh[wv];
+				if (wv < wave) off += v;
+				nsegs += v;
+			}
+			if (nsegs <= qcap || attempt || need <= K) break;  // (uniform)
+			K = need;
 		}
-		u32 w = 1, nseg = 0;
-		if (2 == status) {
-			w = (u32)(((u64)dmax * K) / l1);
-			if (w < 1u) w = 1u;
-			nseg = (dmax + w - 1u) / w;  // >= 1 (start and goal differ)
-		}
-		__syncthreads();  // sh[] is reused below
-		u32 incl = nseg;
-		for (int o = 1; o < 64; o <<= 1) {
-			const u32 v = __shfl_up(incl, o);
-			if ((int)lane >= o) incl += v;
-		}
-		if (63u == lane && wave < 8u) sh[wave] = incl;
-		__syncthreads();
-		u32 off = incl - nseg, nsegs = 0;
-		for (u32 wv = 0; wv < nwaves; ++wv) {
-			const u32 v = sh[wv];
-			if (wv < wave) off += v;
-			nsegs += v;
-		}
-		if (t < UFO_CAST_BATCH) {
+		if (t < batch) {
 			hd[t].lin0 = lin0;
 			hd[t].ax = ax;
 			hd[t].w = w;
@@ -432,7 +489,7 @@ __global__ __launch_bounds__(512) void k_fcast(MapGeom g, FastGeo fg, D3 sensor,
 		// ---- 3. cut states from the three independent addition chains (k_dda_seg) ----
 		// 3a. one lane per ray: the dominant chain a*, once. After k0 = j*w pops of a*: element A[k0-1] (= v) was popped
 		// and t_max_a* = A[k0]. v is parked in the cut's two other t_max fields for the lanes of 3b.
-		if (threadIdx.x < UFO_CAST_BATCH) {
+		if (threadIdx.x < batch) {
 			const u32 ry = threadIdx.x;
 			const RayHdr h = hd[ry];
 			if (0 != h.nseg) {
@@ -478,8 +535,8 @@ __global__ __launch_bounds__(512) void k_fcast(MapGeom g, FastGeo fg, D3 sensor,
 		// 3b. two lanes per ray, one per other axis: of that axis the elements before v were popped (strictly smaller, or
 		// equal when the axis has priority: the lower axis index wins ties, VEC3:244-251) -- their count moves the cut's
 		// cell; four candidates per iteration (same sequence of additions)
-		for (u32 idx = threadIdx.x; idx < 2u * UFO_CAST_BATCH; idx += blockDim.x) {
-			const u32 ry = idx & (UFO_CAST_BATCH - 1u), role = idx / UFO_CAST_BATCH;
+		for (u32 idx = threadIdx.x; idx < 2u * batch; idx += blockDim.x) {
+			const u32 role = idx >= batch ? 1u : 0u, ry = idx - role * batch;
 			const RayHdr h = hd[ry];
 			if (h.nseg < 2u) continue;
 			const RayConst c = rc[ry];
@@ -589,37 +646,10 @@ __global__ __launch_bounds__(512) void k_fcast(MapGeom g, FastGeo fg, D3 sensor,
 // stream at that moment: a host that feeds scans slowly gets B = 1 and the latency of one scan, a host that runs ahead
 // gets walks as large as the map stream needs to keep up with the scan stream -- and no scan waits for company.
 // ------------------------------------------------------------------------------------------------
-#define UFO_RING 16u       // scans in flight per handle (a power of two, > the number of hand-over sets)
-#define UFO_BATCH_MAX 16u  // scans per walk
-struct ScanDesc {  // a scan as the tree update sees it: written into the ring when its scan half ends (k_scan_done)
-	const uint4* slabs;                  // the ray kernel's per-workgroup copies of the ray grid ...
-	const unsigned long long* parts;     // ... and step / ray / hit counts (merged by the walk that takes the scan)
-	u32* gridM;                          // ray cells of the scan (bit grid, Grid::layout 1; written by k_fmerge)
-	u32* gridH;                          // hit voxels of the scan (same layout; written by k_fmerge from `first`)
-	u32* first;                          // first point of every cell (k_fhits' atomicMin; 0xFFFFFFFF: none), left clean by k_fmerge
-	u32* tile_bits;                      // depth-3 tiles of the grid that hold a ray cell (written by k_fmerge, cleared by k_ftail)
-	ScanCtl* ctl;                        // control block (err: the scan half flagged the scan; the walk stands back)
-	ScanCtl* host_result;                // where the finished control block goes (pinned), followed by the word the host polls
-	const BoxPartial* boxes;             // k_fhits' per-workgroup bounding boxes
-	unsigned long long done_value;       // value of that word: the integration's running number
-	unsigned long long fseq;             // running number among the fast-path scans
-	u32 n_slabs, nboxes;
-	u32 geo;                             // scans with equal geo may share a walk (same ray grid, consecutive updates of the map)
-	u32 pad;
-};
-struct Pipe {
-	unsigned long long scan_done;  // fast-path number of the newest scan whose scan half has finished (the scan stream works them off in order)
-	unsigned long long claimed;    // ... of the newest scan a walk has taken
-	struct Slot {
-		unsigned long long first;  // the slot of scan f (slot[f & 15]) applies scans first .. first + B - 1
-		u32 B, pad;                // (B == 0: scan f went with an earlier walk)
-	} slot[UFO_RING];
-	u32 wstat[UFO_RING];           // wstat[f & 15]: 0 = the walk that took scan f applied it; else it stood back / failed
-	ScanDesc ring[UFO_RING];
-};
 // end of a scan half (scan stream, one thread): the scan's descriptor becomes visible, then its number
 __global__ void k_scan_done(Pipe* p, ScanDesc d)
 {
+	tsMark(p->ts, d.fseq, 3, wall_clock64());
 	p->ring[d.fseq & (UFO_RING - 1u)] = d;
 	__hip_atomic_store(&p->scan_done, d.fseq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -670,6 +700,7 @@ __global__ void k_claim(Pipe* p, unsigned long long f, u32 bmax, ScanCtl* ctl, u
 {
 	if (0 != threadIdx.x) return;
 	const unsigned long long t0 = wall_clock64();
+	tsMark(p->ts, f, 4, t0);
 	unsigned long long done;
 	Pipe::Slot& sl = p->slot[f & (UFO_RING - 1u)];
 	while ((done = __hip_atomic_load(&p->scan_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < f) {
@@ -691,6 +722,7 @@ __global__ void k_claim(Pipe* p, unsigned long long f, u32 bmax, ScanCtl* ctl, u
 	sl.first = first;                                     // sees to it that they share f's ray grid and are fewer than UFO_BATCH_MAX)
 	if (first > f) {
 		sl.B = 0;
+		tsMark(p->ts, f, 5, wall_clock64());
 		return;
 	}
 	u32 B = (u32)(f - first) + 1u;
@@ -704,6 +736,8 @@ __global__ void k_claim(Pipe* p, unsigned long long f, u32 bmax, ScanCtl* ctl, u
 	}
 	p->claimed = first + B - 1u;
 	sl.B = B;
+	tsMark(p->ts, f, 5, wall_clock64());
+	tsMark(p->ts, f, 7, B);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1734,6 +1768,7 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 		ctl->dbg[20] = U | ((unsigned long long)l << 32);
 		ctl->used_now = used;  // the host's view of the table's fill
 		ctl->dbg[45] = B;      // (scans this walk applied: the host's statistics)
+		tsMark(p->ts, f, 6, wall_clock64());
 	}
 	// The finished control blocks go to the host's pinned copies from here (no read-back copy, no stream synchronisation on
 	// the host: it polls the word behind a block and reads), and the device copies return to the start state of a scan
@@ -1769,8 +1804,9 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 // for it (k_gate; a single wave cannot keep anything from being scheduled). Measured per hand-over, stream idle time
 // included (scripts/micro/stream_wait*.hip and rocprofv3 traces of the pipeline): event record + wait 9-15 us,
 // hipStreamWaitValue64 on signal memory 5-7 us (it is a polling kernel too, on host-coherent memory), this 2-3 us.
-__global__ void k_signal(unsigned long long* flag, unsigned long long value, unsigned long long* host_flag)
+__global__ void k_signal(unsigned long long* flag, unsigned long long value, unsigned long long* host_flag, unsigned long long* ts, unsigned long long f)
 {
+	tsMark(ts, f, 0, wall_clock64());
 	__hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 	// (pinned host memory: the call that enqueued the scan returns once k_fhits has consumed the caller's cloud)
 	if (host_flag) __hip_atomic_store(host_flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1778,9 +1814,11 @@ __global__ void k_signal(unsigned long long* flag, unsigned long long value, uns
 // (The wait is bounded: a tool that serialises kernels across streams -- rocprofv3 --pmc does -- would keep the producer
 // from ever running while this wave spins. The host does not use gates when it sees such a tool, ufomap_hip.hip:
 // useGates; should one slip through, the gate gives up after ~2 s and flags the scan, which then leaves the map alone.)
-__global__ void k_gate(const unsigned long long* flag, unsigned long long value, ScanCtl* ctl, unsigned long long max_ticks)
+__device__ __forceinline__ void gateWait(const unsigned long long* flag, unsigned long long value, ScanCtl* ctl, unsigned long long max_ticks,
+                                         unsigned long long* ts, unsigned long long f)
 {
 	const unsigned long long t0 = wall_clock64();
+	tsMark(ts, f, 1, t0);
 	while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < value) {
 		__builtin_amdgcn_s_sleep(1);
 		if (wall_clock64() - t0 > max_ticks) {  // 100 MHz clock
@@ -1788,6 +1826,24 @@ __global__ void k_gate(const unsigned long long* flag, unsigned long long value,
 			return;
 		}
 	}
+	tsMark(ts, f, 2, wall_clock64());
+}
+__global__ void k_gate(const unsigned long long* flag, unsigned long long value, ScanCtl* ctl, unsigned long long max_ticks, unsigned long long* ts,
+                       unsigned long long f)
+{
+	gateWait(flag, value, ctl, max_ticks, ts, f);
+}
+// The end of one scan half and the gate of the next in ONE launch (asynchronous calls in a row: the host keeps the
+// descriptor of scan i back and hands it over with the gate of scan i+1 -- one one-wave kernel per scan on the scan stream
+// instead of two; whatever needs scan i before another scan arrives publishes it with k_scan_done, ufomap_hip.hip:
+// publishScanDone).
+__global__ void k_done_gate(Pipe* p, ScanDesc d, const unsigned long long* flag, unsigned long long value, ScanCtl* ctl, unsigned long long max_ticks,
+                            unsigned long long f)
+{
+	tsMark(p->ts, d.fseq, 3, wall_clock64());
+	p->ring[d.fseq & (UFO_RING - 1u)] = d;
+	__hip_atomic_store(&p->scan_done, d.fseq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+	gateWait(flag, value, ctl, max_ticks, p->ts, f);
 }
 
 }  // namespace ufo

@@ -242,6 +242,7 @@ struct ufomap_map {
 	DevBuf b_tilerec;             // fast path, map stream only
 	DevBuf b_ser[5];              // scratch of the map byte stream (serialiseNodes), kept between calls
 	uint8_t* h_ser = nullptr;     // ... pinned: per-level counts, the root, the stream's length
+	DevBuf b_ts;                  // developer aid (option "tstamps"): device clock at the pipeline's hand-overs (fast_kernels.h: Pipe::ts)
 	DevBuf b_pipe;                // fast path: which walk applies which scan (fast_kernels.h: Pipe), device side
 	uint64_t n_fseq = 0;          // fast-path scans enqueued so far
 	u32 geo_id = 0;               // scans with the same geo id may share a walk: same ray grid, no other update of the map between them
@@ -260,6 +261,13 @@ struct ufomap_map {
 	unsigned long long* h_prep = nullptr;  // pinned: integration number of the newest scan whose k_fhits has finished (k_signal)
 	uint64_t n_walks = 0, n_walk_scans = 0, n_gate_timeouts = 0;  // fast-path walks that applied scans, scans in them; stream hand-overs that timed out
 	int opt_batch_max = 8;        // scans a walk may take when scans have queued up behind the map stream (1 = one walk per scan)
+	int opt_solo = 1;             // synchronous calls with nothing in flight run on the map stream alone
+	bool solo = false;            // ... the current integration does
+	int opt_cast_threads = 512;
+	int opt_cast_batch = 256, opt_cast_qcap = 1024, opt_cast_prio = 0;  // k_fcast: rays per round, segment queue entries (LDS), wave priority
+	int opt_lazy_done = 1;        // asynchronous fast-path calls: the end of scan half i is published by the gate kernel of scan i+1 (k_done_gate)
+	ScanDesc sd_saved{};          // ... the descriptor kept back,
+	bool sd_pending = false;      // ... if any
 	int opt_hold = 0;             // test aid: a slot is enqueued for every hold-th scan only (walks over several scans whatever the timing)
 	int opt_gate_us = 20000;      // a stream hand-over gives up after this long (and the handle stops using gates)
 	uint64_t seq = 0, latest_seq = 0;  // seq: of the integration that uses the current set; latest_seq: of the newest one enqueued
@@ -628,7 +636,7 @@ bool setDoneNow(const HandOver& s)
 	if (done) std::atomic_thread_fence(std::memory_order_acquire);
 	return done;
 }
-int flushDeferred(ufomap_map* m);
+int flushDeferred(ufomap_map* m, bool publish = true);
 
 // Join the oldest integration among the other sets; if its tree update has not been enqueued yet (it was waiting for
 // company, doInsert), that happens first.
@@ -1164,7 +1172,18 @@ bool fastEligible(const ufomap_map* m, const Grid& gr, unsigned depth, int simpl
 unsigned long long gateTicks(const ufomap_map* m) { return (unsigned long long)std::max(100, m->opt_gate_us) * 100ull; }  // wall_clock64: 100 MHz
 
 // scan half on the scan stream: first-point array, rays, merged bit grid + tile bitmap
-int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, size_t n, double max_range, int discrete, bool batch_step = false)
+// The descriptor of the newest scan half, if the host has kept it back (fastScanPhase, lazy_done), is published now.
+int publishScanDone(ufomap_map* m)
+{
+	if (!m->sd_pending) return UFOMAP_OK;
+	hipLaunchKernelGGL(k_scan_done, dim3(1), dim3(1), 0, m->sstream, m->b_pipe.as<Pipe>(), m->sd_saved);
+	m->sd_pending = false;
+	HIP_TRY(hipGetLastError());
+	return UFOMAP_OK;
+}
+
+int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, size_t n, double max_range, int discrete, bool batch_step = false,
+                  bool lazy_done = false, bool solo = false, bool uploaded = false)
 {
 	HIP_TRY(hipSetDevice(m->device));
 	for (int k = 0; k < 8; ++k) m->counts[k] = 0;
@@ -1179,12 +1198,23 @@ int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, si
 	m->fast = true;
 	// Scans may share a walk if they follow one another on the map stream and use the same ray grid (fast_kernels.h: k_claim);
 	// before a scan on a new grid, the scans that have no slot of their own yet get one
-	if (batch_step) {
-		// (a step of ufomap_map_insert_batch: its walk is enqueued by the host for the scans of all ranks; no claims)
+	m->solo = solo;
+	if (batch_step || solo) {
+		// (a step of ufomap_map_insert_batch: its walk is enqueued by the host for the scans of all ranks; no claims. Solo:
+		// a synchronous call with nothing in flight -- the scan and its walk on the map stream, a Pipe of their own)
 		const int frc = flushDeferred(m);
 		if (frc) return frc;
 		m->chain_ok = false;
 		m->fseq = 0;
+		if (solo) {
+			if (uploaded) {  // (a host cloud is copied on the prep stream)
+				HIP_TRY(hipEventRecord(m->prep_ev, m->pstream));
+				HIP_TRY(hipStreamWaitEvent(m->stream, m->prep_ev, 0));
+			}
+			const size_t pc = m->b_bpipe.cap;
+			HIP_TRY(m->b_bpipe.reserve(sizeof(Pipe)));
+			if (pc != m->b_bpipe.cap) HIP_TRY(hipMemsetAsync(m->b_bpipe.p, 0, sizeof(Pipe), m->stream));
+		}
 	} else {
 		if (!m->chain_ok || 0 != memcmp(m->chain_geo.gr.base, fg.gr.base, sizeof(fg.gr.base)) || 0 != memcmp(m->chain_geo.gr.nb, fg.gr.nb, sizeof(fg.gr.nb))) {
 			const int frc = flushDeferred(m);
@@ -1208,7 +1238,7 @@ int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, si
 	HIP_TRY(m->b_tilebits.reserve(UFO_FAST_MAX_TILES / 8));
 	if (cf != m->b_first.cap || ct != m->b_tilebits.cap) m->first_dirty = true;
 	// k_fhits depends on nothing but the cloud: on the prep stream it overlaps the ray kernel of the scan before
-	m->cs = m->pstream;
+	m->cs = solo ? m->stream : m->pstream;
 	if (m->first_dirty || 2 == m->opt_fast) {  // (option fast = 2: never trust the self-cleaning, a debugging aid)
 		HIP_TRY(hipMemsetAsync(m->b_first.p, 0xFF, m->b_first.cap, m->cs));
 		HIP_TRY(hipMemsetAsync(m->b_tilebits.p, 0, m->b_tilebits.cap, m->cs));
@@ -1259,31 +1289,38 @@ int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, si
 	}
 	// stream-to-stream hand-overs of this path: k_signal / k_gate (fast_kernels.h), not events
 	m->gates = useGates(m);
-	if (m->gates) {
-		hipLaunchKernelGGL(k_signal, dim3(1), dim3(1), 0, m->pstream, m->sig_prep, (unsigned long long)m->seq, m->h_prep);
-		hipLaunchKernelGGL(k_gate, dim3(1), dim3(1), 0, m->sstream, m->sig_prep, (unsigned long long)m->seq, ctl, gateTicks(m));
+	if (solo) {
+		// (one stream: nothing to hand over)
+	} else if (m->gates) {
+		hipLaunchKernelGGL(k_signal, dim3(1), dim3(1), 0, m->pstream, m->sig_prep, (unsigned long long)m->seq, m->h_prep, batch_step ? nullptr : m->b_ts.as<unsigned long long>(),
+		                   (unsigned long long)m->fseq);
+		if (m->sd_pending) {
+			// (the scan half before this one ends and this one's gate opens in one launch)
+			hipLaunchKernelGGL(k_done_gate, dim3(1), dim3(1), 0, m->sstream, m->b_pipe.as<Pipe>(), m->sd_saved, m->sig_prep, (unsigned long long)m->seq, ctl,
+			                   gateTicks(m), (unsigned long long)m->fseq);
+			m->sd_pending = false;
+		} else {
+			hipLaunchKernelGGL(k_gate, dim3(1), dim3(1), 0, m->sstream, m->sig_prep, (unsigned long long)m->seq, ctl, gateTicks(m),
+			                   batch_step ? nullptr : m->b_ts.as<unsigned long long>(), (unsigned long long)m->fseq);
+		}
 	} else {
+		const int prc = publishScanDone(m);
+		if (prc) return prc;
 		HIP_TRY(hipEventRecord(m->prep_ev, m->pstream));
 		HIP_TRY(hipStreamWaitEvent(m->sstream, m->prep_ev, 0));
 	}
-	m->cs = m->sstream;
+	m->cs = solo ? m->stream : m->sstream;
 	{
-		u32 nwg = m->opt_cast_wgs > 0 ? (u32)m->opt_cast_wgs : 256u;
+		// One workgroup per CU is what the ray kernel's LDS allows, and alone it is fastest with one on every CU. In a row
+		// of asynchronous scans it shares the chip with the first-point pass of the next scan and the tree update of the
+		// scan before: with a workgroup on three CUs in four it does not wait for the last CUs those kernels hold, and they
+		// have CUs where nothing else competes (measured, scripts/dev_ab.py cast_wgs=...: 256 -> 0.052, 192 -> 0.046 ms/scan).
+		u32 nwg = m->opt_cast_wgs > 0 ? (u32)m->opt_cast_wgs : (lazy_done ? 192u : 256u);
 		nwg = std::max<u32>(1u, std::min<u32>(nwg, (N + 63u) / 64u));
 		const u32 cap_wg = (N + nwg - 1) / nwg;
 		HIP_TRY(m->b_ray_end.reserve((size_t)cap_wg * nwg * sizeof(D3)));
 		HIP_TRY(m->b_slabs.reserve((size_t)nwg * fg.gr.bytes + (size_t)nwg * 8 * 3));  // slabs + per-workgroup steps / rays / hits (of this set: merged by the walk)
 		unsigned long long* sp = reinterpret_cast<unsigned long long*>(m->b_slabs.as<char>() + (size_t)nwg * fg.gr.bytes);
-		{
-			ProfScope ps(m, "k_fcast");
-			const size_t lds = (size_t)fg.gr.bytes + UFO_CAST_LDS_EXTRA;
-			if (discrete)
-				hipLaunchKernelGGL(k_fcast<true>, dim3(nwg), dim3(512), lds, m->cs, m->g, fg, sensor, d_xyz, N, max_range, 0u, m->b_first.as<u32>(),
-				                   m->b_ray_end.as<D3>(), cap_wg, m->b_slabs.as<u32>(), (u32)std::max(8, m->opt_cast_k), ctl, ctl, sp, m->ing, m->b_hit_code.as<PointRec>());
-			else
-				hipLaunchKernelGGL(k_fcast<false>, dim3(nwg), dim3(512), lds, m->cs, m->g, fg, sensor, d_xyz, N, max_range, 0u, m->b_first.as<u32>(),
-				                   m->b_ray_end.as<D3>(), cap_wg, m->b_slabs.as<u32>(), (u32)std::max(8, m->opt_cast_k), ctl, ctl, sp, m->ing, m->b_hit_code.as<PointRec>());
-		}
 		// end of the scan half: the scan's descriptor and number become visible to the walks (k_claim)
 		ScanDesc d{};
 		d.slabs = m->b_slabs.as<uint4>();
@@ -1300,8 +1337,46 @@ int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, si
 		d.n_slabs = nwg;
 		d.nboxes = gp.x;
 		d.geo = m->geo_id;
-		if (!batch_step) {
-			hipLaunchKernelGGL(k_scan_done, dim3(1), dim3(1), 0, m->sstream, m->b_pipe.as<Pipe>(), d);
+		Pipe* const solo_pipe = solo ? m->b_bpipe.as<Pipe>() : nullptr;
+		{
+			ProfScope ps(m, "k_fcast");
+			// LDS beside the bit grid: ray constants + segment queue. Sized for the rays a workgroup gets (a round of `batch`
+			// rays; more rays = more rounds), not for the worst case: what the ray kernel leaves free on a CU is what the
+			// kernels of the other two streams can run in beside it.
+			u32 batch = (u32)std::min<long long>(512, std::max<long long>(64, m->opt_cast_batch));
+			u32 qcap = (u32)std::min<long long>(2048, std::max<long long>(2 * batch, m->opt_cast_qcap));
+			const u32 prio = (u32)m->opt_cast_prio;
+			const u32 cthreads = m->opt_cast_threads >= 1024 ? 1024u : (m->opt_cast_threads >= 768 ? 768u : 512u);
+			auto ldsFor = [&](u32 b, u32 q) { return (size_t)fg.gr.bytes + (size_t)b * (sizeof(RayConst) + sizeof(RayHdr)) + (size_t)q * sizeof(SegRec) + 256u; };
+			if (ldsFor(batch, qcap) > (160u << 10) - 256u) {
+				batch = UFO_CAST_BATCH;
+				qcap = UFO_CAST_QCAP;
+			}
+			const size_t lds = ldsFor(batch, qcap);
+			{
+				static const bool trace = nullptr != getenv("UFOMAP_TRACE_GRID");
+				if (trace)
+					fprintf(stderr, "[ufomap] fast grid: %d x %d x %d blocks, %llu bytes; k_fcast: %u workgroups, %zu bytes of LDS each\n", fg.gr.nb[0], fg.gr.nb[1],
+					        fg.gr.nb[2], (unsigned long long)fg.gr.bytes, nwg, lds);
+			}
+			if (discrete)
+				hipLaunchKernelGGL(k_fcast<true>, dim3(nwg), dim3(cthreads), lds, m->cs, m->g, fg, sensor, d_xyz, N, max_range, 0u, m->b_first.as<u32>(),
+				                   m->b_ray_end.as<D3>(), cap_wg, m->b_slabs.as<u32>(), (u32)std::max(8, m->opt_cast_k), ctl, ctl, sp, m->ing, m->b_hit_code.as<PointRec>(), batch, qcap, prio, solo_pipe, d);
+			else
+				hipLaunchKernelGGL(k_fcast<false>, dim3(nwg), dim3(cthreads), lds, m->cs, m->g, fg, sensor, d_xyz, N, max_range, 0u, m->b_first.as<u32>(),
+				                   m->b_ray_end.as<D3>(), cap_wg, m->b_slabs.as<u32>(), (u32)std::max(8, m->opt_cast_k), ctl, ctl, sp, m->ing, m->b_hit_code.as<PointRec>(), batch, qcap, prio, solo_pipe, d);
+		}
+		if (solo) {
+			// (k_fcast has written the descriptor itself)
+		} else if (!batch_step) {
+			// Asynchronous calls in a row: the descriptor is kept back and published by the next scan's gate kernel (k_done_gate)
+			// -- or by whatever needs this scan's tree update first (flushDeferred) -- one launch less per scan on this stream.
+			if (lazy_done && m->gates) {
+				m->sd_saved = d;
+				m->sd_pending = true;
+			} else {
+				hipLaunchKernelGGL(k_scan_done, dim3(1), dim3(1), 0, m->sstream, m->b_pipe.as<Pipe>(), d);
+			}
 		} else {
 			// the other ranks get this scan as two bit grids, not as 256 slabs: merged here, on the scan stream
 			DescPack pk{};
@@ -1399,13 +1474,16 @@ int enqueueSlot(ufomap_map* m, int k)
 	(a ? a->has_slot : m->has_slot) = true;
 	(a ? a->bound : m->bound) = bound;
 	m->cs = m->stream;
-	Pipe* pipe = m->b_pipe.as<Pipe>();
+	const bool solo = !a && m->solo;
+	Pipe* pipe = solo ? m->b_bpipe.as<Pipe>() : m->b_pipe.as<Pipe>();
 	const u32 bmax = (u32)std::max(1, std::min<int>(m->opt_batch_max, (int)UFO_BATCH_MAX));
 	// without gates (a tool serialises kernels across streams) the map stream waits for the event behind the newest scan
 	// half; k_claim then finds the scan complete and only takes its decision
-	if (!m->gates) HIP_TRY(hipStreamWaitEvent(m->stream, m->scan_ev, 0));
-	hipLaunchKernelGGL(k_claim, dim3(1), dim3(64), 0, m->stream, pipe, (unsigned long long)f, bmax, ctl, gateTicks(m), a ? a->h_res : m->h_res,
-	                   (unsigned long long)(a ? a->seq : m->seq));
+	if (!solo) {
+		if (!m->gates) HIP_TRY(hipStreamWaitEvent(m->stream, m->scan_ev, 0));
+		hipLaunchKernelGGL(k_claim, dim3(1), dim3(64), 0, m->stream, pipe, (unsigned long long)f, bmax, ctl, gateTicks(m), a ? a->h_res : m->h_res,
+		                   (unsigned long long)(a ? a->seq : m->seq));
+	}
 	{
 		ProfScope ps(m, "k_fmerge");
 		const u32 n4 = (u32)(fg.gr.bytes >> 4);
@@ -1430,13 +1508,19 @@ int enqueueSlot(ufomap_map* m, int k)
 // The scans that have no slot on the map stream yet get one: a slot for the newest of them takes the others along (k_claim;
 // one slot per batch_max scans). (The current set holds the newest integration; what waits is always the newest scans,
 // and they share a ray grid: fastScanPhase.)
-int flushDeferred(ufomap_map* m)
+int flushDeferred(ufomap_map* m, bool publish)
 {
+	// (publish = false: a scan whose descriptor the host still keeps back stays as it is -- no slot may wait for it --
+	// and what is older gets its slots)
+	if (publish) {
+		const int prc = publishScanDone(m);
+		if (prc) return prc;
+	}
 	int idx[kAlt + 1], n = 0;
 	for (int i = 0; i < kAlt; ++i)
 		if (m->alt[i].pending && m->alt[i].deferred) idx[n++] = i;
 	std::sort(idx, idx + n, [&](int a, int b) { return m->alt[a].seq < m->alt[b].seq; });
-	if (m->pending && m->deferred) idx[n++] = -1;
+	if (m->pending && m->deferred && !m->sd_pending) idx[n++] = -1;
 	const int bmax = std::max(1, std::min<int>(m->opt_batch_max, (int)UFO_BATCH_MAX));
 	for (int a = 0; a < n; ++a) {
 		if (a + 1 == n || 0 == (a + 1) % bmax) {
@@ -1977,8 +2061,10 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 	u64 capH = 0, capM = 0;
 	int rc;
 	if (fast) {
-		rc = fastScanPhase(m, origin, d_xyz, n, max_range, discrete);
-		if (!rc && !m->gates) rc = (hipEventRecord(m->scan_ev, m->sstream) == hipSuccess) ? UFOMAP_OK : fail(UFOMAP_ERR_DEVICE, "hipEventRecord");
+		// a synchronous call with nothing in flight: the whole integration on the map stream (no hand-overs between streams)
+		const bool solo = !async && m->opt_solo && oldestPendingAlt(m) < 0 && !m->sd_pending;
+		rc = fastScanPhase(m, origin, d_xyz, n, max_range, discrete, false, async && !m->profiling && m->opt_early && m->opt_lazy_done, solo, swapped);
+		if (!rc && !m->gates && !solo) rc = (hipEventRecord(m->scan_ev, m->sstream) == hipSuccess) ? UFOMAP_OK : fail(UFOMAP_ERR_DEVICE, "hipEventRecord");
 		lap(0, t_begin);
 		if (rc) {
 			(void)hipStreamSynchronize(m->sstream);
@@ -1997,7 +2083,7 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 		// When the map stream keeps up (fewer than two slots waiting) every scan gets its slot at once.
 		bool hold = false;
 		if (async && !m->profiling && m->opt_early) {
-			int nheld = 1, nidle = 0, nslots = 0;
+			int nheld = m->sd_pending ? 0 : 1, nidle = 0, nslots = 0;  // (a scan whose descriptor is kept back cannot get a slot yet)
 			for (int i = 0; i < kAlt; ++i) {
 				const HandOver& o = m->alt[i];
 				if (!o.pending) ++nidle;
@@ -2010,7 +2096,7 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 			if (m->opt_hold > 1) hold = nidle > 0 && nheld < std::min(m->opt_hold, bmax);  // (test aid: a slot for every hold-th scan)
 		}
 		if (!hold) {
-			rc = flushDeferred(m);
+			rc = flushDeferred(m, false);
 			if (rc) return rc;
 		}
 		lap(1, t_map);
@@ -4667,6 +4753,30 @@ int ufomap_map_set_option(ufomap_map* m, const char* key, long long value)
 		m->opt_gates = value ? 1 : 0;
 	} else if (0 == strcmp(key, "batch_max")) {
 		m->opt_batch_max = (int)std::max<long long>(1, std::min<long long>(value, (long long)UFO_BATCH_MAX));
+	} else if (0 == strcmp(key, "tstamps")) {
+		const int wrc = ufomap_map_wait(m);
+		if (wrc) return wrc;
+		unsigned long long* ts = nullptr;
+		if (value) {
+			HIP_TRY(m->b_ts.reserve((size_t)UFO_TS_SCANS * 64));
+			HIP_TRY(hipMemset(m->b_ts.p, 0, (size_t)UFO_TS_SCANS * 64));
+			ts = m->b_ts.as<unsigned long long>();
+		} else {
+			m->b_ts.release();
+		}
+		HIP_TRY(hipMemcpy(reinterpret_cast<char*>(m->b_pipe.p) + offsetof(Pipe, ts), &ts, sizeof(ts), hipMemcpyHostToDevice));
+	} else if (0 == strcmp(key, "solo")) {
+		m->opt_solo = value ? 1 : 0;
+	} else if (0 == strcmp(key, "cast_threads")) {
+		m->opt_cast_threads = (int)value;
+	} else if (0 == strcmp(key, "cast_batch")) {
+		m->opt_cast_batch = (int)value;
+	} else if (0 == strcmp(key, "cast_qcap")) {
+		m->opt_cast_qcap = (int)value;
+	} else if (0 == strcmp(key, "cast_prio")) {
+		m->opt_cast_prio = (int)std::max<long long>(0, std::min<long long>(3, value));
+	} else if (0 == strcmp(key, "lazy_done")) {
+		m->opt_lazy_done = value ? 1 : 0;
 	} else if (0 == strcmp(key, "hold")) {
 		m->opt_hold = (int)std::max<long long>(0, std::min<long long>(value, kAlt));
 	} else if (0 == strcmp(key, "gate_us")) {
@@ -4719,6 +4829,17 @@ int ufomap_map_debug(ufomap_map* m, uint64_t* out, int n)
 }
 
 void* ufomap_map_stream(ufomap_map* m) { return m ? (void*)m->stream : nullptr; }
+
+int ufomap_map_timeline(ufomap_map* m, unsigned long long* out, size_t n_words, unsigned long long* newest)
+{
+	if (!m || !out) return fail(UFOMAP_ERR_INVALID, "null argument");
+	const int wrc = ufomap_map_wait(m);
+	if (wrc) return wrc;
+	if (!m->b_ts.p) return fail(UFOMAP_ERR_INVALID, "option tstamps is off");
+	HIP_TRY(hipMemcpy(out, m->b_ts.p, std::min<size_t>(n_words, (size_t)UFO_TS_SCANS * 8) * 8, hipMemcpyDeviceToHost));
+	if (newest) *newest = m->n_fseq;
+	return UFOMAP_OK;
+}
 
 int ufomap_dev_expf(const float* x, float* out, size_t n, int device)
 {

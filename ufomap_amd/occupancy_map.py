@@ -418,6 +418,13 @@ class OccupancyMapBase:
         capi.check(self._lib.ufomap_map_debug(self._h, out, 64))
         return [int(v) for v in out]
 
+    def timeline(self):
+        """(records[4096, 8] uint64, newest scan number): ``ufomap_map_timeline`` (option "tstamps" = 1)."""
+        out = np.zeros((4096, 8), np.uint64)
+        newest = C.c_uint64(0)
+        capi.check(self._lib.ufomap_map_timeline(self._h, C.c_void_p(out.ctypes.data), C.c_size_t(out.size), C.byref(newest)))
+        return out, int(newest.value)
+
     def set_option(self, key, value):
         capi.check(self._lib.ufomap_map_set_option(self._h, key.encode(), int(value)))
 
