@@ -122,6 +122,8 @@ def test_change_detection_code_set(color):
             assert len(g.changes()[0]) == 0
     assert sizes[0] > 1000 and sizes[5] < sizes[4]
     assert same_dump(g.leaves(True), o.leaves(True))
+    if not color:  # (the tiled tree update logs the changed voxels itself: k_tile)
+        assert g.debug()[61] >= 3, f"change detection kept the scans off the fast path: {g.debug()[58:64]}"
     g.enableChangeDetection(False)
     o.enableChangeDetection(False)
     before = len(g.changes()[0])

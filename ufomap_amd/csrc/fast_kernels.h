@@ -960,7 +960,7 @@ __device__ inline bool tileKey(const MapGeom& g, const FastGeo& fg, u32 tile, u6
 }
 
 __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, const Pipe* __restrict__ p, unsigned long long f, TileRec* __restrict__ recs,
-                                              float upd_hit, float upd_miss, u32 scan_id, const u32* __restrict__ prev_stat)
+                                              float upd_hit, float upd_miss, u32 scan_id, const u32* __restrict__ prev_stat, ChangeLog cl)
 {
 	const u32 lane = threadIdx.x & 63u;
 	const u32 tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -1169,16 +1169,25 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 			}
 			const int c_last = 31 - __clz((int)mmask);  // ascending code order: the highest touched voxel is updated last
 			float v_old_last = 0.f;
+			u32 chg = 0;  // voxels whose value a hit or a miss changed: updateOccupancy returned true (OMB:1069-1072)
 #pragma unroll
 			for (int c = 0; c < 8; ++c) {
 				float x = v[c];
-				if ((hmask >> c) & 1u) x = clampAdd(x, upd_hit, g.cmin, g.cmax);
+				if ((hmask >> c) & 1u) {
+					const float y = clampAdd(x, upd_hit, g.cmin, g.cmax);
+					chg |= (y != x) ? (1u << c) : 0u;
+					x = y;
+				}
 				if ((mmask >> c) & 1u) {
 					if (c == c_last) v_old_last = x;
-					x = clampAdd(x, upd_miss, g.cmin, g.cmax);
+					const float y = clampAdd(x, upd_miss, g.cmin, g.cmax);
+					chg |= (y != x) ? (1u << c) : 0u;
+					x = y;
 				}
 				v[c] = x;
 			}
+			// change detection (OMB:783, 1069-1072): the voxels' codes go to the log, as k_apply_leaf's do
+			if (cl.buf) logChanges(t, cl, (lk1 ^ (1ULL << (3 * (g.L - 1)))) << 3, 0u, chg);
 			// updateNode of a depth-1 node (OMB:1195-1224): max, flags from the 8 voxels, collapsible if all equal
 			float m = v[0], pm = (0 == c_last) ? v_old_last : v[0];
 			u32 fl = 0, pfl = 0;

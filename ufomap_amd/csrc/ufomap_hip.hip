@@ -1159,7 +1159,7 @@ u64 makeUpperGeo(const FastGeo& fg, u32 L, UpperGeo* ug)
 
 bool fastEligible(const ufomap_map* m, const Grid& gr, unsigned depth, int simple, const uint8_t* d_rgb, size_t n)
 {
-	if (!m->opt_fast || 0 != depth || simple || m->g.color || d_rgb || m->chg_enabled || m->g.L < 5 || 0 == n || n > (1u << 29)) return false;
+	if (!m->opt_fast || 0 != depth || simple || m->g.color || d_rgb || m->g.L < 5 || 0 == n || n > (1u << 29)) return false;
 	if (1 != gr.layout) return false;
 	const FastGeo fg = makeFastGeo(gr);
 	if (fg.ntiles > UFO_FAST_MAX_TILES) return false;
@@ -1466,6 +1466,11 @@ int enqueueSlot(ufomap_map* m, int k)
 			}
 		}
 	}
+	if (m->chg_enabled) {
+		// change detection: every voxel of the ray grid may change (updates run one at a time in this mode, doInsert)
+		const int crc = ensureChangeCap(m, (u64)fg.gr.bytes * 8u);
+		if (crc) return crc;
+	}
 	m->scan_new_bound = bound;
 	m->scan_id += 1;
 	HIP_TRY(m->b_tilerec.reserve((size_t)UFO_FAST_MAX_TILES * sizeof(TileRec)));
@@ -1494,7 +1499,7 @@ int enqueueSlot(ufomap_map* m, int k)
 		ProfScope ps(m, "k_tile");
 		const u32 tw = (m->opt_tile_waves >= 1 && m->opt_tile_waves <= 4) ? (u32)m->opt_tile_waves : 4u;  // wavefronts (= tiles) per workgroup
 		hipLaunchKernelGGL(k_tile, dim3((fg.ntiles + tw - 1) / tw), dim3(64u * tw), 0, m->cs, m->t, m->g, fg, pipe, (unsigned long long)f, m->b_tilerec.as<TileRec>(),
-		                   m->g.hit, miss, m->scan_id, prev_stat);
+		                   m->g.hit, miss, m->scan_id, prev_stat, changeLog(m));
 	}
 	{
 		ProfScope ps(m, "k_ftail");
@@ -2107,7 +2112,19 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 		int prc = UFOMAP_OK;
 		if (!async) {
 			prc = joinOlder(m);  // (occupancy_map_base.h:315: the previous integrations are joined first)
-			HIP_TRY(hipStreamSynchronize(m->stream));
+			{
+				// the word k_ftail stores behind the result block in pinned memory (as the joins of asynchronous scans do): the
+				// host sees it a few microseconds before a stream synchronisation would return
+				volatile unsigned long long* done = reinterpret_cast<volatile unsigned long long*>(m->h_res + 1);
+				const auto t0 = std::chrono::steady_clock::now();
+				for (u32 spins = 0; *done != (unsigned long long)m->seq; ++spins) {
+					if (0 == (spins & 1023u) && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) {
+						HIP_TRY(hipStreamSynchronize(m->stream));
+						break;
+					}
+				}
+				std::atomic_thread_fence(std::memory_order_acquire);
+			}
 			rc = finishPending(m);
 			if (3 == m->opt_fast) {
 				// debugging aid: the scratch arrays must have been left clean
@@ -4143,7 +4160,7 @@ int fastBatchStep(ufomap_map* m, ufomap_comm* c, const double origin[3], const d
 			ProfScope ps(m, "k_tile");
 			const u32 tw = (m->opt_tile_waves >= 1 && m->opt_tile_waves <= 4) ? (u32)m->opt_tile_waves : 4u;
 			hipLaunchKernelGGL(k_tile, dim3((fg.ntiles + tw - 1) / tw), dim3(64u * tw), 0, m->stream, m->t, m->g, fg, bp, 0ull, m->b_tilerec.as<TileRec>(), m->g.hit,
-			                   miss, m->scan_id, prev_stat);
+			                   miss, m->scan_id, prev_stat, changeLog(m));
 		}
 		{
 			ProfScope ps(m, "k_ftail");
