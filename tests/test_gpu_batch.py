@@ -163,6 +163,64 @@ def test_scheduling_options_never_change_the_map(opts):
         assert newest >= 1 and ts[newest % 4096, 6] > ts[newest % 4096, 2] > 0, "pipeline time stamps of the newest scan"
 
 
+def _assert_same_colour_map(g, o, what=""):
+    gl, ol = g.leaves(True), o.leaves(True)
+    assert len(gl[0]) == len(ol[0]), f"{what}: leaf count {len(gl[0])} vs oracle {len(ol[0])}"
+    for k in range(len(gl)):
+        assert np.array_equal(gl[k], ol[k]), f"{what}: leaf output {k} differs"
+    assert same_dump(g.inner(), o.inner()), f"{what}: inner-node dump differs"
+    assert g.write() == o.write(), f"{what}: map byte stream differs"
+
+
+@pytest.mark.parametrize("mode", ["sync", "async", "batched", "mixed_clouds"])
+def test_colour_maps_on_the_fast_path(mode):
+    """OccupancyMapColor through the tiled tree update (k_tile<true> / k_ftail<true>): the voxel takes the colour of its
+    first point blended with what it has (OMC.h:195-287, OMC.cpp:142-171), every node above carries the root mean square
+    of its children's colours, pruning needs equal colours (OMC.cpp:115-140) -- against the reference scan by scan:
+    leaves with colours, inner nodes, byte stream; synchronous, pipelined, several scans per walk, and colour maps fed
+    with plain clouds in between (continuous mode included). The counters prove the fast path ran."""
+    from ufomap_amd import scans, OccupancyMapColor, PointCloud, PointCloudColor
+    from oracle import OracleMap
+    kind = _kind()
+    g, o = OccupancyMapColor(resolution=0.16), OracleMap(kind=kind, color=True, resolution=0.16)
+    if mode == "batched":
+        g.set_option("hold", 4)
+    base = np.array(scans.lidar_pose(0), dtype=np.float64)
+    rng = np.random.default_rng(77)
+    n_scans = 18
+    for i in range(n_scans):
+        off = rng.uniform(-0.6, 0.6, 3) * [1, 1, 0.1]
+        origin, xyz, rgb = scans.lidar64(beams=32, azimuths=512, origin=tuple(base + off), seed=500 + i, colored=True)
+        if i % 5 == 4:
+            rgb = np.full_like(rgb, 90 + i)  # (a scan of one colour: whole subtrees become equal and collapse)
+        plain = mode == "mixed_clouds" and i % 3 == 1
+        discrete = True if not plain else (i % 2 == 0)
+        cloud = PointCloud(xyz) if plain else PointCloudColor(xyz, rgb)
+        async_ = mode in ("async", "batched") or (mode == "mixed_clouds" and i % 4 == 3)
+        (g.insertPointCloudDiscrete if discrete else g.insertPointCloud)(origin, cloud, 12.0, 0, False, 0, async_)
+        o.insert(origin, xyz, None if plain else rgb, max_range=12.0, discrete=discrete)
+        if i in (2, 9):
+            g.insertPointCloudWait()
+            _assert_same_colour_map(g, o, f"{mode}: after scan {i}")
+    g.insertPointCloudWait()
+    _assert_same_colour_map(g, o, f"{mode}: final")
+    d = g.debug()
+    assert d[61] >= n_scans - 4 and d[58] == 0, f"colour scans did not take the fast path: {d[58:64]}"
+    if mode == "batched":
+        assert d[60] < d[59], f"no walk took more than one scan ({d[60]} walks, {d[59]} scans)"
+    # the same sequence with the fast path off for colour maps: the general path gives the same map
+    g2 = OccupancyMapColor(resolution=0.16)
+    g2.set_option("fast_color", 0)
+    rng = np.random.default_rng(77)
+    for i in range(6):
+        off = rng.uniform(-0.6, 0.6, 3) * [1, 1, 0.1]
+        origin, xyz, rgb = scans.lidar64(beams=32, azimuths=512, origin=tuple(base + off), seed=500 + i, colored=True)
+        if i % 5 == 4:
+            rgb = np.full_like(rgb, 90 + i)
+        g2.insertPointCloudDiscrete(origin, PointCloudColor(xyz, rgb), 12.0)
+    assert g2.debug()[61] == 0
+
+
 def test_many_handles_keep_their_maps_apart():
     """Three maps fed in turn with pipelined scans (3 x 4 streams on the device's hardware queues, gates spinning on all of
     them): every map equals its own sequential result; hand-over time-outs, if any, only cost time."""

@@ -159,7 +159,8 @@ struct PointRec {
 template <bool DISCRETE>
 __global__ __launch_bounds__(256) void k_fhits(MapGeom g, FastGeo fg, D3 sensor, const double* __restrict__ xyz, u32 n, double max_range,
                                                u32 color_variant, u32* __restrict__ first, BoxPartial* __restrict__ part, ScanCtl* ctl,
-                                               Ingest ing, PointRec* __restrict__ recs, double* __restrict__ keep)
+                                               Ingest ing, PointRec* __restrict__ recs, double* __restrict__ keep, const uint8_t* __restrict__ rgb_in,
+                                               uint8_t* __restrict__ rgb_keep)
 {
 	const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
 	double amn[3] = {1e300, 1e300, 1e300}, amx[3] = {-1e300, -1e300, -1e300};
@@ -175,6 +176,11 @@ __global__ __launch_bounds__(256) void k_fhits(MapGeom g, FastGeo fg, D3 sensor,
 			keep[3 * (size_t)i] = pt.x;
 			keep[3 * (size_t)i + 1] = pt.y;
 			keep[3 * (size_t)i + 2] = pt.z;
+		}
+		if (rgb_keep) {  // (the colours likewise: read by the tree update, long after the call has returned)
+			rgb_keep[3 * (size_t)i] = rgb_in[3 * (size_t)i];
+			rgb_keep[3 * (size_t)i + 1] = rgb_in[3 * (size_t)i + 1];
+			rgb_keep[3 * (size_t)i + 2] = rgb_in[3 * (size_t)i + 2];
 		}
 		const PointRay r = pointRay<DISCRETE>(g, fg, sensor, xyz, ing, i, max_range, color_variant, amn, amx);
 		odd = r.odd;
@@ -272,6 +278,8 @@ struct ScanDesc {  // a scan as the tree update sees it: written into the ring w
 	u32 n_slabs, nboxes;
 	u32 geo;                             // scans with equal geo may share a walk (same ray grid, consecutive updates of the map)
 	u32 pad;
+	const uint8_t* rgb;                  // colour maps: the points' colours (3 bytes each; nullptr: a cloud without colours). The walk
+	                                     // then reads `first` itself (the colour of a voxel's first point, OMC.h:195-233) and cleans it
 };
 struct Pipe {
 	unsigned long long scan_done;  // fast-path number of the newest scan whose scan half has finished (the scan stream works them off in order)
@@ -807,7 +815,7 @@ __global__ __launch_bounds__(1024) void k_fmerge(FastGeo fg, const Pipe* __restr
 				const uint4 fa = f4[0], fb = f4[1];
 				hbits = (fa.x != 0xFFFFFFFFu ? 1u : 0u) | (fa.y != 0xFFFFFFFFu ? 2u : 0u) | (fa.z != 0xFFFFFFFFu ? 4u : 0u) | (fa.w != 0xFFFFFFFFu ? 8u : 0u) |
 				        (fb.x != 0xFFFFFFFFu ? 16u : 0u) | (fb.y != 0xFFFFFFFFu ? 32u : 0u) | (fb.z != 0xFFFFFFFFu ? 64u : 0u) | (fb.w != 0xFFFFFFFFu ? 128u : 0u);
-				if (hbits) {
+				if (hbits && !d.rgb) {  // (a coloured scan: k_tile reads the first points -- whose colour the voxel gets -- and cleans up)
 					f4[0] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
 					f4[1] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
 				}
@@ -917,7 +925,7 @@ struct TileRec {
 	// bits 0-10 level-1 blocks updated (<= 64 per scan), 11-24 voxels that received a hit (<= 512 per scan), 25-31 node blocks created (<= 73)
 	u32 counts;
 	u32 last;            // index (in the batch) of the last scan that touched the tile: the "time" of its last update
-	u32 pad;
+	u32 rgb;             // colour maps: colour summary of the level-3 block as last evaluated (updateNode, OMC.cpp:115-140)
 };
 __device__ inline u32 flagsOf(const MapGeom& g, float v) { return (isFreeV(g, v) ? 1u : 0u) | (isUnknownV(g, v) ? 2u : 0u); }
 // reductions over the 8 lanes that differ in the three lane-index bits starting at bit `sh` (0: a level-2 group, 3: across groups)
@@ -942,6 +950,44 @@ __device__ inline bool grpAllEq(float v, int sh, u32 lane)
 	const float first = __shfl(v, (int)(sh ? (lane & 7u) : (lane & ~7u)));
 	return 0 == grpOr((v == first) ? 0u : 1u, sh);
 }
+__device__ inline bool grpAllEqU(u32 v, int sh, u32 lane)
+{
+	const u32 first = (u32)__shfl((int)v, (int)(sh ? (lane & 7u) : (lane & ~7u)));
+	return 0 == grpOr((v == first) ? 0u : 1u, sh);
+}
+// Colour summary of a node (updateNode of a colour map, OMC.cpp:115-140 = blockSummary, map_kernels.h): per channel the
+// root mean square of the children that have a colour. Sums of at most eight squares of bytes: exact in any order.
+__device__ inline void rgbSq(u32 c, double& rr, double& gg, double& bb, u32& cnt)
+{
+	if (c) {
+		const double cr = (double)(c & 0xFFu), cg = (double)((c >> 8) & 0xFFu), cb = (double)((c >> 16) & 0xFFu);
+		rr += cr * cr;
+		gg += cg * cg;
+		bb += cb * cb;
+		++cnt;
+	}
+}
+__device__ inline u32 rgbRms(double rr, double gg, double bb, u32 cnt)
+{
+	if (0 == cnt) return 0u;
+	const double num = (double)cnt;
+	const u32 R = (u32)(uint8_t)sqrt(rr / num), G = (u32)(uint8_t)sqrt(gg / num), B = (u32)(uint8_t)sqrt(bb / num);
+	return R | (G << 8) | (B << 16);
+}
+// ... over the 8 lanes of a group (lane = child): every lane gets the summary
+__device__ inline u32 grpRgb(u32 c, int sh)
+{
+	double rr = 0, gg = 0, bb = 0;
+	u32 cnt = 0;
+	rgbSq(c, rr, gg, bb, cnt);
+	for (int o = 1; o < 8; o <<= 1) {
+		rr += __shfl_xor(rr, o << sh);
+		gg += __shfl_xor(gg, o << sh);
+		bb += __shfl_xor(bb, o << sh);
+		cnt += (u32)__shfl_xor((int)cnt, o << sh);
+	}
+	return rgbRms(rr, gg, bb, cnt);
+}
 // level-3 block key of a tile; false if the tile lies outside the key range
 __device__ inline bool tileKey(const MapGeom& g, const FastGeo& fg, u32 tile, u64* lk3, u32* tcoord)
 {
@@ -959,6 +1005,12 @@ __device__ inline bool tileKey(const MapGeom& g, const FastGeo& fg, u32 tile, u6
 	return true;
 }
 
+// COLOR (OccupancyMapColor): every node carries a colour beside its value. A voxel that receives a hit takes the colour
+// of its first point, blended with the colour it has (updateNodeColor, OMC.cpp:142-171: with the occupancy BEFORE the
+// hit); misses leave colours alone -- so the last update beneath a node (a miss) never changes a colour and the "reached"
+// chain is the one of plain maps; what colours add: a summary per node (root mean square per channel), "all children
+// equal" includes their colours, and a changed colour summary re-evaluates the parent like a changed value does.
+template <bool COLOR>
 __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, const Pipe* __restrict__ p, unsigned long long f, TileRec* __restrict__ recs,
                                               float upd_hit, float upd_miss, u32 scan_id, const u32* __restrict__ prev_stat, ChangeLog cl)
 {
@@ -1064,13 +1116,17 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 	u32 fl3r = F_DEAD, fl2r = F_DEAD, fl1r = F_DEAD;
 	float v2l = 0.f, v1l = 0.f;
 	float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+	u32 r2l = 0, r1l = 0;  // COLOR: the colours beside v2l, v1l, v[]
+	u32 col[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 	if (s3 != NONE) {
 		fl3r = t.flags(s3);
 		v2l = t.occ(s3)[c2];
+		if (COLOR) r2l = t.rgb[8 * (size_t)s3 + c2];
 	}
 	if (s2 != NONE && uact2) {
 		fl2r = t.flags(s2);
 		v1l = t.occ(s2)[c1];
+		if (COLOR) r1l = t.rgb[8 * (size_t)s2 + c1];
 	}
 	if (s1 != NONE && uactive) {
 		fl1r = t.flags(s1);
@@ -1078,11 +1134,18 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 		const float4 ra = po[0], rb = po[1];
 		v[0] = ra.x; v[1] = ra.y; v[2] = ra.z; v[3] = ra.w;
 		v[4] = rb.x; v[5] = rb.y; v[6] = rb.z; v[7] = rb.w;
+		if (COLOR) {
+			const uint4* pc = reinterpret_cast<const uint4*>(t.rgb + 8 * (size_t)s1);
+			const uint4 ca = pc[0], cb = pc[1];
+			col[0] = ca.x; col[1] = ca.y; col[2] = ca.z; col[3] = ca.w;
+			col[4] = cb.x; col[5] = cb.y; col[6] = cb.z; col[7] = cb.w;
+		}
 	}
 	// ---- round 3: createNode for what is missing from the table (octree.h:997-1016); a level-3 block that is not live
 	// inherits the value of the nearest node above that has one (the blocks above are not written during this launch) ----
 	u32 n_created = 0;
 	float v3s = 0.f;
+	u32 r3s = 0;  // COLOR: the colour that goes with v3s
 	{
 		const bool need3 = 0 != (fl3r & F_DEAD);
 		const bool mk3 = s3 == NONE, mk2 = uact2 && s2 == NONE && 0 == c1, mk1 = uactive && s1 == NONE;
@@ -1092,10 +1155,12 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 			if (need3 && 0 == lane) {
 				if (mk3) s3 = tableEnsure(t, lk3, scan_id, max_probe, &dummy, &n_created);
 				v3s = t.root->occ;
+				if (COLOR) r3s = t.root->rgb;
 				for (u64 k = lk3 >> 3, below = lk3; k >= 1; below = k, k >>= 3) {
 					const u32 sa = tableFind(t, k);
 					if (sa != NONE && !(t.flags(sa) & F_DEAD)) {
 						v3s = t.occ(sa)[(u32)(below & 7)];
+						if (COLOR) r3s = t.rgb[8 * (size_t)sa + (u32)(below & 7)];
 						break;
 					}
 					if (1 == k) break;
@@ -1105,6 +1170,7 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 			if (mk1) s1 = tableEnsure(t, lk1, scan_id, max_probe, &dummy, &n_created);
 			s3 = __shfl(s3, 0);
 			v3s = __shfl(v3s, 0);
+			if (COLOR) r3s = (u32)__shfl((int)r3s, 0);
 			s2 = __shfl(s2, (int)(lane & ~7u));
 			if (__ballot((s3 == NONE) || (uact2 && s2 == NONE) || (uactive && s1 == NONE))) {
 				if (0 == lane) atomicOr(&UFO_DESC(B - 1u).ctl->err, ERR_TABLE_FULL);  // (the host sizes the table for the worst case before launching)
@@ -1116,7 +1182,7 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 	bool w2 = false, w3 = false;      // the lane's slot of the level-2 / level-3 record has to be written
 	bool any_eval3 = false, created3 = false, reach_last = false;
 	float m3c = 0.f, pm_last = 0.f;   // summary of the level-3 block as last evaluated / before its last update
-	u32 fl3c = 0, pfl_last = 0, last_b = 0;
+	u32 fl3c = 0, pfl_last = 0, last_b = 0, rgb3c = 0;
 	u32 n_touched = 0, nhit = 0;
 	for (u32 b = 0; b < B; ++b) {
 		if (8u == b) {
@@ -1138,11 +1204,14 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 		// depth-2 node c2: slot c2 of the level-3 block
 		float v2s;
 		u32 f2s, in2s;  // stored value, flags, "has a live block" of the lane's depth-2 node
+		u32 r2s = 0, r1s = 0;  // COLOR: stored colours of the lane's depth-2 / depth-1 node
 		if (cr3) {
 			v2s = v3s;
 			f2s = flagsOf(g, v3s);
 			in2s = 0;
+			r2s = r3s;
 		} else {
+			r2s = r2l;
 			v2s = v2l;
 			f2s = ((fl3r >> c2) & 1u) | (((fl3r >> (8 + c2)) & 1u) << 1);
 			in2s = (fl3r >> (16 + c2)) & 1u;
@@ -1150,7 +1219,9 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 		// depth-1 node c1 of group c2: slot c1 of the level-2 block (if the group is touched)
 		float v1s = v2s;
 		u32 f1s = flagsOf(g, v2s), in1s = 0;
+		r1s = r2s;
 		if (act2 && !cr2) {
+			r1s = r1l;
 			v1s = v1l;
 			f1s = ((fl2r >> c1) & 1u) | (((fl2r >> (8 + c1)) & 1u) << 1);
 			in1s = (fl2r >> (16 + c1)) & 1u;
@@ -1162,10 +1233,33 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 		bool want1 = false, reach1 = false;
 		float pre1 = v1s;
 		u32 pref1 = f1s;
+		u32 curc1 = r1s;  // COLOR: current colour of the lane's depth-1 node
 		if (active) {
 			if (cr1) {
 #pragma unroll
-				for (int c = 0; c < 8; ++c) v[c] = v1s;
+				for (int c = 0; c < 8; ++c) {
+					v[c] = v1s;
+					if (COLOR) col[c] = r1s;
+				}
+			}
+			if (COLOR) {
+				// updateValue(code, update, color) (OMC.h:275-277): the colour first, with the occupancy the voxel has before the
+				// hit; the colour is the one of the voxel's FIRST point (OMC.h:195-233), whose index the dense first-point array
+				// holds -- read here (k_fmerge left the array alone for a coloured scan) and cleaned for the set's next scan
+				const uint8_t* rgbp = UFO_DESC(b).rgb;
+				if (rgbp && hmask) {
+					u32* fp = UFO_DESC(b).first;
+#pragma unroll
+					for (int c = 0; c < 8; ++c) {
+						if (!((hmask >> c) & 1u)) continue;
+						const u32 cell = (u32)(ox + (c & 1)) + (u32)(oy + ((c >> 1) & 1)) * fg.rowBits + (u32)(oz + (c >> 2)) * fg.planeBits;
+						const u32 pt = fp[cell];
+						fp[cell] = 0xFFFFFFFFu;
+						if (0xFFFFFFFFu == pt) continue;  // (cannot happen: the hit grid was derived from this array)
+						const u32 u = (u32)rgbp[3 * (size_t)pt] | ((u32)rgbp[3 * (size_t)pt + 1] << 8) | ((u32)rgbp[3 * (size_t)pt + 2] << 16);
+						col[c] = blendColor(g, col[c], u, v[c]);
+					}
+				}
 			}
 			const int c_last = 31 - __clz((int)mmask);  // ascending code order: the highest touched voxel is updated last
 			float v_old_last = 0.f;
@@ -1201,12 +1295,22 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 				pfl |= flagsOf(g, pv);
 				eq = eq && (v[c] == v[0]);
 			}
+			if (COLOR) {
+				double rr = 0, gg = 0, bb = 0;
+				u32 cnt = 0;
+#pragma unroll
+				for (int c = 0; c < 8; ++c) {
+					rgbSq(col[c], rr, gg, bb, cnt);
+					eq = eq && (col[c] == col[0]);
+				}
+				curc1 = rgbRms(rr, gg, bb, cnt);
+			}
 			reach1 = !(pm == m && pfl == fl);  // level 1 is always reached (OMB:1128 starts at depth 1)
 			pre1 = pm;
 			pref1 = pfl;
 			const bool dead1 = eq;             // collapsed: the node is a leaf again (octree.h:1060-1066)
 			in1 = dead1 ? 0u : 1u;
-			want1 = (m != v1s) || (fl != f1s) || reach1;
+			want1 = (m != v1s) || (fl != f1s) || reach1 || (COLOR && curc1 != r1s);
 			cur1 = m;
 			curf1 = fl;
 			// the record's flags (low bits as k_init_new leaves them for a new block)
@@ -1223,10 +1327,12 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 		bool want2 = false, reach2 = false, dead2 = false;
 		float pre2 = v2s;
 		u32 pref2 = f2s;
+		u32 curc2 = r2s;
 		{
 			const float m = grpMax(cur1, 0);
 			const u32 fl = grpOr(curf1, 0);
-			const bool eq = grpAllEq(cur1, 0, lane);
+			const bool eq = grpAllEq(cur1, 0, lane) && (!COLOR || grpAllEqU(curc1, 0, lane));
+			const u32 rgb2 = COLOR ? grpRgb(curc1, 0) : 0u;
 			const u32 inner_any = grpOr(in1, 0);
 			const bool is_top = active && (c1 + 1u == top1);
 			const bool reached = 0 != grpOr((is_top && reach1) ? 1u : 0u, 0);  // the last update beneath reached the child and changed it
@@ -1235,11 +1341,12 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 			if (eval2) {
 				dead2 = reached && eq && 0 == inner_any;
 				reach2 = reached && !(pm == m && pfl == fl);
-				want2 = (m != v2s) || (fl != f2s) || reach2;
+				want2 = (m != v2s) || (fl != f2s) || reach2 || (COLOR && rgb2 != r2s);
 				pre2 = pm;
 				pref2 = pfl;
 				cur2 = m;
 				curf2 = fl;
+				curc2 = rgb2;
 			}
 			if (act2) in2 = dead2 ? 0u : 1u;
 		}
@@ -1247,6 +1354,7 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 			// the level-2 record: the lane's child slot; flags of the whole block
 			if (active || cr2) {
 				v1l = cur1;
+				r1l = curc1;
 				w2 = true;
 			}
 			const u32 fbits = grpOr(((curf1 & 1u) << c1) | (((curf1 >> 1) & 1u) << (8 + c1)) | (in1 << (16 + c1)), 0);
@@ -1257,11 +1365,12 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 		const bool eval3 = 0 != grpOr(want2 ? 1u : 0u, 3);
 		bool reach3 = false, dead3 = false;
 		float m3 = v3s, pm3 = v3s;
-		u32 fl3n = f3s, pfl3 = f3s;
+		u32 fl3n = f3s, pfl3 = f3s, rgb3n = r3s;
 		{
 			const float m = grpMax(cur2, 3);
 			const u32 fl = grpOr(curf2, 3);
-			const bool eq = grpAllEq(cur2, 3, lane);
+			const bool eq = grpAllEq(cur2, 3, lane) && (!COLOR || grpAllEqU(curc2, 3, lane));
+			const u32 rgb3 = COLOR ? grpRgb(curc2, 3) : 0u;
 			const u32 inner_any = grpOr(in2, 3);
 			const bool is_top = act2 && (c2 + 1u == top2);
 			const bool reached = 0 != grpOr((is_top && reach2) ? 1u : 0u, 3);
@@ -1274,12 +1383,14 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 				fl3n = fl;
 				pm3 = pm;
 				pfl3 = pfl;
+				rgb3n = rgb3;
 			}
 		}
 		{
 			// the level-3 record: the group's slot (all eight when the block is new); flags of the whole block
 			if (act2 || cr3) {
 				v2l = cur2;
+				r2l = curc2;
 				w3 = true;
 			}
 			const u32 fbits = grpOr((0 == c1) ? (((curf2 & 1u) << c2) | (((curf2 >> 1) & 1u) << (8 + c2)) | (in2 << (16 + c2))) : 0u, 3);
@@ -1290,12 +1401,16 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 			any_eval3 = true;
 			m3c = m3;
 			fl3c = fl3n;
+			rgb3c = rgb3n;
 		}
 		reach_last = reach3;
 		pm_last = pm3;
 		pfl_last = pfl3;
 		last_b = b;
-		if (dead3) v3s = m3;  // a later scan of the batch re-expands the node from its own value (all children were equal to it)
+		if (dead3) {  // a later scan of the batch re-expands the node from its own value (all children were equal to it)
+			v3s = m3;
+			r3s = rgb3n;
+		}
 		n_touched += (u32)__popcll(__ballot(active));
 	}
 	// ---- every touched record back to the table, once ----
@@ -1305,15 +1420,26 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 		po[1] = make_float4(v[4], v[5], v[6], v[7]);
 		t.flags(s1) = fl1r;
 		t.parent(s1) = s2;
+		if (COLOR) {
+			uint4* pc = reinterpret_cast<uint4*>(t.rgb + 8 * (size_t)s1);
+			pc[0] = make_uint4(col[0], col[1], col[2], col[3]);
+			pc[1] = make_uint4(col[4], col[5], col[6], col[7]);
+		}
 	}
 	if (uact2) {
-		if (w2) t.occ(s2)[c1] = v1l;
+		if (w2) {
+			t.occ(s2)[c1] = v1l;
+			if (COLOR) t.rgb[8 * (size_t)s2 + c1] = r1l;
+		}
 		if (0 == c1) {
 			t.flags(s2) = fl2r;
 			t.parent(s2) = s3;
 		}
 	}
-	if (0 == c1 && w3) t.occ(s3)[c2] = v2l;
+	if (0 == c1 && w3) {
+		t.occ(s3)[c2] = v2l;
+		if (COLOR) t.rgb[8 * (size_t)s3 + c2] = r2l;
+	}
 	for (int o = 32; o > 0; o >>= 1) {
 		n_created += __shfl_xor(n_created, o);
 		nhit += __shfl_xor(nhit, o);
@@ -1329,7 +1455,7 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 		r.seq = scan_id;
 		r.counts = n_touched | (nhit << 11) | (n_created << 25);
 		r.last = last_b;
-		r.pad = 0;
+		r.rgb = rgb3c;
 		recs[tile] = r;
 	}
 }
@@ -1376,6 +1502,7 @@ __device__ inline u32 upperCellAt(const UpperLevel& u, u32 off, const i32 c[3])
 }
 #define UFO_FTAIL_THREADS 1024
 static_assert(UFO_FTAIL_THREADS == UFO_UPPER_MAX, "k_ftail: one thread per cell of the dense grids above the tiles");
+template <bool COLOR>
 __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g, FastGeo fg, Pipe* __restrict__ p, unsigned long long f,
                                                              const TileRec* __restrict__ recs, u32 scan_id, const u32* __restrict__ prev_stat,
                                                              const ScanCtl* ctl_init)
@@ -1394,6 +1521,7 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 	__shared__ unsigned long long top64[UFO_UPPER_MAX];  // (1 + last scan of the batch that touched the subtree) << 40 | (1 + child index of the highest child it touched) << 32 | who that is (tile or node)
 	__shared__ u32 nslot[UFO_UPPER_MAX], npar[UFO_UPPER_MAX], nflags[UFO_UPPER_MAX], out_bits[UFO_UPPER_MAX];
 	__shared__ float nocc[UFO_UPPER_MAX][8], out_pre[UFO_UPPER_MAX];
+	__shared__ u32 nrgb[COLOR ? UFO_UPPER_MAX : 1u][8];  // colour maps: the children's colours beside nocc (see k_tile)
 	__shared__ uint8_t dirty[UFO_UPPER_MAX], ncreated[UFO_UPPER_MAX];
 	__shared__ u32 lstart[26], lvl_dirty[26], created_total;
 	// one copy of the activity bitmap per wavefront while it is being filled: LDS atomics of one instruction that hit the same
@@ -1566,6 +1694,13 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 				float4* lo4 = reinterpret_cast<float4*>(nocc[id]);
 				lo4[0] = a;
 				lo4[1] = b;
+				if (COLOR) {
+					const uint4* pc = reinterpret_cast<const uint4*>(t.rgb + 8 * (size_t)s);
+					const uint4 ca = pc[0], cb = pc[1];
+					uint4* lc4 = reinterpret_cast<uint4*>(nrgb[id]);
+					lc4[0] = ca;
+					lc4[1] = cb;
+				}
 				fl = t.flags(s) & ~F_DIRTY;
 			}
 			nflags[id] = fl;
@@ -1580,19 +1715,24 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 		if (!ncreated[i] || nslot[i] == NONE) continue;
 		u32 cur = i;
 		float v;
+		u32 vc = 0;
 		for (;;) {
 			const u32 p = npar[cur];
 			if (p == NONE) {
 				v = t.root->occ;  // the root block itself is new: the root's value
+				if (COLOR) vc = t.root->rgb;
 				break;
 			}
 			if (!ncreated[p]) {
 				v = nocc[p][(u32)(nk[cur] & 7)];  // (slots of existing blocks have not been written yet)
+				if (COLOR) vc = nrgb[p][(u32)(nk[cur] & 7)];
 				break;
 			}
 			cur = p;
 		}
 		for (int c = 0; c < 8; ++c) nocc[i][c] = v;
+		if (COLOR)
+			for (int c = 0; c < 8; ++c) nrgb[i][c] = vc;
 		// leaf children carry the flags of a leaf with this value (OMB:1181-1189)
 		atomicOr(&nflags[i], (isFreeV(g, v) ? F_CFREE : 0u) | (isUnknownV(g, v) ? F_CUNK : 0u));
 		if (npar[i] != NONE) atomicOr(&nflags[npar[i]], 1u << (16 + (u32)(nk[i] & 7)));
@@ -1622,8 +1762,9 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 			if (bits & 16u) {
 				const u32 f = nflags[n4];
 				const u32 old_fl = ((f >> ci) & 1u) | (((f >> (8 + ci)) & 1u) << 1), fl = bits & 3u;
-				const bool changed = nocc[n4][ci] != r[k].occ || old_fl != fl;
+				const bool changed = nocc[n4][ci] != r[k].occ || old_fl != fl || (COLOR && nrgb[n4][ci] != r[k].rgb);
 				nocc[n4][ci] = r[k].occ;
+				if (COLOR) nrgb[n4][ci] = r[k].rgb;
 				if (old_fl != fl) {
 					const u32 setm = ((fl & 1u) << ci) | (((fl >> 1) & 1u) << (8 + ci));
 					const u32 clrm = ((1u << ci) | (1u << (8 + ci))) & ~setm;
@@ -1674,7 +1815,9 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 		}
 		const bool reached = 0 != (lub & 4u);
 		const float m = grpMax(v, 0);
-		const bool eq = grpAllEq(v, 0, lane);
+		const u32 cv = (COLOR && have) ? nrgb[i][sub] : 0u;
+		const bool eq = grpAllEq(v, 0, lane) && (!COLOR || grpAllEqU(cv, 0, lane));
+		const u32 rgb = COLOR ? grpRgb(cv, 0) : 0u;
 		const float pm = grpMax((reached && sub == tc) ? luo : v, 0);
 		if (have && 0 == sub) {
 			const u64 lk = nk[i];
@@ -1698,11 +1841,13 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 				if (1 == lk) {
 					t.root->occ = m;
 					t.root->flags = fl;
+					if (COLOR) t.root->rgb = rgb;
 				} else {
 					const u32 fp = nflags[p];
 					const u32 old_fl = ((fp >> ci) & 1u) | (((fp >> (8 + ci)) & 1u) << 1);
-					const bool changed = nocc[p][ci] != m || old_fl != fl;
+					const bool changed = nocc[p][ci] != m || old_fl != fl || (COLOR && nrgb[p][ci] != rgb);
 					nocc[p][ci] = m;
+					if (COLOR) nrgb[p][ci] = rgb;
 					if (old_fl != fl) {
 						const u32 setm = ((fl & 1u) << ci) | (((fl >> 1) & 1u) << (8 + ci));
 						const u32 clrm = ((1u << ci) | (1u << (8 + ci))) & ~setm;
@@ -1761,6 +1906,12 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 		const float4* li = reinterpret_cast<const float4*>(nocc[i]);
 		po[0] = li[0];
 		po[1] = li[1];
+		if (COLOR) {
+			uint4* pc = reinterpret_cast<uint4*>(t.rgb + 8 * (size_t)s);
+			const uint4* lc = reinterpret_cast<const uint4*>(nrgb[i]);
+			pc[0] = lc[0];
+			pc[1] = lc[1];
+		}
 		t.flags(s) = nflags[i];
 		if (ncreated[i]) t.parent(s) = (npar[i] != NONE) ? nslot[npar[i]] : NONE;
 	}

@@ -177,6 +177,7 @@ struct HandOver {
 	bool deferred = false;    // ... and no slot on the map stream has been enqueued for it yet (the next slot will take it along)
 	bool has_slot = false;    // ... a slot of its own has been enqueued for the scan
 	DevBuf b_keep;            // the scan's points as its head loop saw them (written by k_fhits): what a repeat of the scan reads
+	DevBuf b_keep_rgb;        // ... and their colours (colour maps: read by the tree update, fast_kernels.h: k_tile)
 	// a step of ufomap_map_insert_batch on the fast path: this rank's scan, exchanged as bit grids, one walk for all ranks' scans
 	int batch_world = 0;           // 0: not such a step; else the number of ranks
 	struct ufomap_comm* comm = nullptr;
@@ -257,10 +258,11 @@ struct ufomap_map {
 	int h_res_all_world = 0;
 	hipEvent_t xchg_ev = nullptr;
 	uint64_t fseq = 0;            // (HandOver)
-	DevBuf b_keep;                // (HandOver)
+	DevBuf b_keep, b_keep_rgb;    // (HandOver)
 	unsigned long long* h_prep = nullptr;  // pinned: integration number of the newest scan whose k_fhits has finished (k_signal)
 	uint64_t n_walks = 0, n_walk_scans = 0, n_gate_timeouts = 0;  // fast-path walks that applied scans, scans in them; stream hand-overs that timed out
 	int opt_batch_max = 8;        // scans a walk may take when scans have queued up behind the map stream (1 = one walk per scan)
+	int opt_fast_color = 1;       // colour maps on the fast path (0: the general path, as before round 3)
 	int opt_solo = 1;             // synchronous calls with nothing in flight run on the map stream alone
 	bool solo = false;            // ... the current integration does
 	int opt_cast_threads = 512;
@@ -519,6 +521,7 @@ void swapWith(ufomap_map* m, HandOver& o)
 	std::swap(m->b_gridH, o.b_gridH);
 	std::swap(m->fseq, o.fseq);
 	std::swap(m->b_keep, o.b_keep);
+	std::swap(m->b_keep_rgb, o.b_keep_rgb);
 	std::swap(m->deferred, o.deferred);
 	std::swap(m->has_slot, o.has_slot);
 	std::swap(m->batch_world, o.batch_world);
@@ -1157,9 +1160,12 @@ u64 makeUpperGeo(const FastGeo& fg, u32 L, UpperGeo* ug)
 	return off;
 }
 
-bool fastEligible(const ufomap_map* m, const Grid& gr, unsigned depth, int simple, const uint8_t* d_rgb, size_t n)
+bool fastEligible(const ufomap_map* m, const Grid& gr, unsigned depth, int simple, const uint8_t* d_rgb, size_t n, int discrete = 1)
 {
-	if (!m->opt_fast || 0 != depth || simple || m->g.color || d_rgb || m->g.L < 5 || 0 == n || n > (1u << 29)) return false;
+	if (!m->opt_fast || 0 != depth || simple || m->g.L < 5 || 0 == n || n > (1u << 29)) return false;
+	// (a coloured cloud into a plain map, a coloured cloud in continuous mode: the general path reports them)
+	if (d_rgb && (!m->g.color || !discrete)) return false;
+	if (m->g.color && 0 == m->opt_fast_color) return false;
 	if (1 != gr.layout) return false;
 	const FastGeo fg = makeFastGeo(gr);
 	if (fg.ntiles > UFO_FAST_MAX_TILES) return false;
@@ -1183,7 +1189,7 @@ int publishScanDone(ufomap_map* m)
 }
 
 int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, size_t n, double max_range, int discrete, bool batch_step = false,
-                  bool lazy_done = false, bool solo = false, bool uploaded = false)
+                  bool lazy_done = false, bool solo = false, bool uploaded = false, const uint8_t* d_rgb = nullptr)
 {
 	HIP_TRY(hipSetDevice(m->device));
 	for (int k = 0; k < 8; ++k) m->counts[k] = 0;
@@ -1257,6 +1263,16 @@ int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, si
 		m->args.d_xyz = keep;
 		m->args.ing = Ingest{};
 	}
+	// (colours: read by the tree update -- and by a repeat of the scan -- after the call has returned)
+	uint8_t* keep_rgb = nullptr;
+	const uint8_t* scan_rgb = d_rgb;
+	if (d_rgb && d_rgb != m->b_in_rgb.as<uint8_t>()) {
+		HIP_TRY(m->b_keep_rgb.reserve(n * 3));
+		keep_rgb = m->b_keep_rgb.as<uint8_t>();
+		m->args.d_rgb = keep_rgb;
+		scan_rgb = keep_rgb;
+	}
+	const u32 color_variant = d_rgb ? 1u : 0u;  // (the head loop of OccupancyMapColor::insertPointCloudDiscrete, OMC.h:195-233)
 	ScanCtl init;
 	memset(&init, 0, sizeof(init));
 	for (int a = 0; a < 3; ++a) {
@@ -1281,11 +1297,11 @@ int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, si
 	{
 		ProfScope ps(m, "k_fhits");
 		if (discrete)
-			hipLaunchKernelGGL(k_fhits<true>, gp, dim3(256), 0, m->cs, m->g, fg, sensor, d_xyz, N, max_range, 0u, m->b_first.as<u32>(),
-			                   m->b_part1.as<BoxPartial>(), ctl, m->ing, m->b_hit_code.as<PointRec>(), keep);
+			hipLaunchKernelGGL(k_fhits<true>, gp, dim3(256), 0, m->cs, m->g, fg, sensor, d_xyz, N, max_range, color_variant, m->b_first.as<u32>(),
+			                   m->b_part1.as<BoxPartial>(), ctl, m->ing, m->b_hit_code.as<PointRec>(), keep, d_rgb, keep_rgb);
 		else
 			hipLaunchKernelGGL(k_fhits<false>, gp, dim3(256), 0, m->cs, m->g, fg, sensor, d_xyz, N, max_range, 0u, m->b_first.as<u32>(),
-			                   m->b_part1.as<BoxPartial>(), ctl, m->ing, m->b_hit_code.as<PointRec>(), keep);
+			                   m->b_part1.as<BoxPartial>(), ctl, m->ing, m->b_hit_code.as<PointRec>(), keep, nullptr, nullptr);
 	}
 	// stream-to-stream hand-overs of this path: k_signal / k_gate (fast_kernels.h), not events
 	m->gates = useGates(m);
@@ -1337,6 +1353,7 @@ int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, si
 		d.n_slabs = nwg;
 		d.nboxes = gp.x;
 		d.geo = m->geo_id;
+		d.rgb = scan_rgb;
 		Pipe* const solo_pipe = solo ? m->b_bpipe.as<Pipe>() : nullptr;
 		{
 			ProfScope ps(m, "k_fcast");
@@ -1498,13 +1515,21 @@ int enqueueSlot(ufomap_map* m, int k)
 	{
 		ProfScope ps(m, "k_tile");
 		const u32 tw = (m->opt_tile_waves >= 1 && m->opt_tile_waves <= 4) ? (u32)m->opt_tile_waves : 4u;  // wavefronts (= tiles) per workgroup
-		hipLaunchKernelGGL(k_tile, dim3((fg.ntiles + tw - 1) / tw), dim3(64u * tw), 0, m->cs, m->t, m->g, fg, pipe, (unsigned long long)f, m->b_tilerec.as<TileRec>(),
-		                   m->g.hit, miss, m->scan_id, prev_stat, changeLog(m));
+		if (m->g.color)
+			hipLaunchKernelGGL(k_tile<true>, dim3((fg.ntiles + tw - 1) / tw), dim3(64u * tw), 0, m->cs, m->t, m->g, fg, pipe, (unsigned long long)f,
+			                   m->b_tilerec.as<TileRec>(), m->g.hit, miss, m->scan_id, prev_stat, changeLog(m));
+		else
+			hipLaunchKernelGGL(k_tile<false>, dim3((fg.ntiles + tw - 1) / tw), dim3(64u * tw), 0, m->cs, m->t, m->g, fg, pipe, (unsigned long long)f,
+			                   m->b_tilerec.as<TileRec>(), m->g.hit, miss, m->scan_id, prev_stat, changeLog(m));
 	}
 	{
 		ProfScope ps(m, "k_ftail");
-		hipLaunchKernelGGL(k_ftail, dim3(1), dim3(UFO_FTAIL_THREADS), 0, m->cs, m->t, m->g, fg, pipe, (unsigned long long)f, m->b_tilerec.as<TileRec>(), m->scan_id,
-		                   prev_stat, m->b_ctl_init.as<ScanCtl>());
+		if (m->g.color)
+			hipLaunchKernelGGL(k_ftail<true>, dim3(1), dim3(UFO_FTAIL_THREADS), 0, m->cs, m->t, m->g, fg, pipe, (unsigned long long)f, m->b_tilerec.as<TileRec>(),
+			                   m->scan_id, prev_stat, m->b_ctl_init.as<ScanCtl>());
+		else
+			hipLaunchKernelGGL(k_ftail<false>, dim3(1), dim3(UFO_FTAIL_THREADS), 0, m->cs, m->t, m->g, fg, pipe, (unsigned long long)f, m->b_tilerec.as<TileRec>(),
+			                   m->scan_id, prev_stat, m->b_ctl_init.as<ScanCtl>());
 	}
 	HIP_TRY(hipGetLastError());
 	return UFOMAP_OK;
@@ -2061,14 +2086,14 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 	}
 	if (spec) ++m->n_spec;
 	// the fast path (fast_kernels.h): the whole scan on the predicted grid in five launches, the tree update tiled
-	const bool fast = spec && fastEligible(m, m->spec_grid, depth, simple, d_rgb, n) && nullptr == m->ing.rgb_out;
+	const bool fast = spec && fastEligible(m, m->spec_grid, depth, simple, d_rgb, n, discrete) && nullptr == m->ing.rgb_out;
 	u32 n_hits = 0, n_rays = 0;
 	u64 capH = 0, capM = 0;
 	int rc;
 	if (fast) {
 		// a synchronous call with nothing in flight: the whole integration on the map stream (no hand-overs between streams)
 		const bool solo = !async && m->opt_solo && oldestPendingAlt(m) < 0 && !m->sd_pending;
-		rc = fastScanPhase(m, origin, d_xyz, n, max_range, discrete, false, async && !m->profiling && m->opt_early && m->opt_lazy_done, solo, swapped);
+		rc = fastScanPhase(m, origin, d_xyz, n, max_range, discrete, false, async && !m->profiling && m->opt_early && m->opt_lazy_done, solo, swapped, d_rgb);
 		if (!rc && !m->gates && !solo) rc = (hipEventRecord(m->scan_ev, m->sstream) == hipSuccess) ? UFOMAP_OK : fail(UFOMAP_ERR_DEVICE, "hipEventRecord");
 		lap(0, t_begin);
 		if (rc) {
@@ -2460,7 +2485,7 @@ void ufomap_map_destroy(ufomap_map* m)
 	m->tb.release();
 	m->b_changes.release();
 	for (HandOver& a : m->alt) {
-		DevBuf* abufs[] = {&a.b_ctl, &a.b_entries, &a.b_hh_keys, &a.b_in_xyz, &a.b_in_rgb, &a.b_gridM, &a.b_gridH, &a.b_part1, &a.b_hit_code, &a.b_first, &a.b_tilebits, &a.b_slabs, &a.b_keep};
+		DevBuf* abufs[] = {&a.b_ctl, &a.b_entries, &a.b_hh_keys, &a.b_in_xyz, &a.b_in_rgb, &a.b_gridM, &a.b_gridH, &a.b_part1, &a.b_hit_code, &a.b_first, &a.b_tilebits, &a.b_slabs, &a.b_keep, &a.b_keep_rgb};
 		for (DevBuf* b : abufs) b->release();
 		if (a.h_ctl) (void)hipHostFree(a.h_ctl);
 		if (a.h_res) (void)hipHostFree(a.h_res);
@@ -2479,7 +2504,7 @@ void ufomap_map_destroy(ufomap_map* m)
 	                  &m->b_ctl,     &m->b_pt_end,  &m->b_pt_flag,  &m->b_pt_slot, &m->b_ray_end, &m->b_hit_code, &m->b_hit_pt,
 	                  &m->b_hh_keys, &m->b_gridM,   &m->b_crec,    &m->b_dlist,   &m->b_rays,   &m->b_part0,   &m->b_part1,   &m->b_slabs,   &m->b_hb_keys, &m->b_hb_mask, &m->b_hb_time,   &m->b_entries, &m->b_ent_slot, &m->b_newlist,
 	                  &m->b_wl0,     &m->b_wl1,     &m->b_in_xyz,   &m->b_in_rgb,  &m->b_codes,   &m->b_dump,
-	                  &m->b_first,   &m->b_tilebits, &m->b_tilerec, &m->b_gridH, &m->b_pipe, &m->b_keep, &m->b_blk_range, &m->b_ctl_init};
+	                  &m->b_first,   &m->b_tilebits, &m->b_tilerec, &m->b_gridH, &m->b_pipe, &m->b_keep, &m->b_keep_rgb, &m->b_blk_range, &m->b_ctl_init};
 	for (DevBuf* b : bufs) b->release();
 	for (PendingEvent& pe : m->pend_ev) {
 		(void)hipEventDestroy(pe.a);
@@ -4159,12 +4184,12 @@ int fastBatchStep(ufomap_map* m, ufomap_comm* c, const double origin[3], const d
 		{
 			ProfScope ps(m, "k_tile");
 			const u32 tw = (m->opt_tile_waves >= 1 && m->opt_tile_waves <= 4) ? (u32)m->opt_tile_waves : 4u;
-			hipLaunchKernelGGL(k_tile, dim3((fg.ntiles + tw - 1) / tw), dim3(64u * tw), 0, m->stream, m->t, m->g, fg, bp, 0ull, m->b_tilerec.as<TileRec>(), m->g.hit,
+			hipLaunchKernelGGL(k_tile<false>, dim3((fg.ntiles + tw - 1) / tw), dim3(64u * tw), 0, m->stream, m->t, m->g, fg, bp, 0ull, m->b_tilerec.as<TileRec>(), m->g.hit,
 			                   miss, m->scan_id, prev_stat, changeLog(m));
 		}
 		{
 			ProfScope ps(m, "k_ftail");
-			hipLaunchKernelGGL(k_ftail, dim3(1), dim3(UFO_FTAIL_THREADS), 0, m->stream, m->t, m->g, fg, bp, 0ull, m->b_tilerec.as<TileRec>(), m->scan_id, prev_stat,
+			hipLaunchKernelGGL(k_ftail<false>, dim3(1), dim3(UFO_FTAIL_THREADS), 0, m->stream, m->t, m->g, fg, bp, 0ull, m->b_tilerec.as<TileRec>(), m->scan_id, prev_stat,
 			                   m->b_ctl_init.as<ScanCtl>());
 		}
 		prev_stat = &bp->wstat[0];  // (a second walk of the same step looks at the first)
@@ -4782,6 +4807,8 @@ int ufomap_map_set_option(ufomap_map* m, const char* key, long long value)
 			m->b_ts.release();
 		}
 		HIP_TRY(hipMemcpy(reinterpret_cast<char*>(m->b_pipe.p) + offsetof(Pipe, ts), &ts, sizeof(ts), hipMemcpyHostToDevice));
+	} else if (0 == strcmp(key, "fast_color")) {
+		m->opt_fast_color = value ? 1 : 0;
 	} else if (0 == strcmp(key, "solo")) {
 		m->opt_solo = value ? 1 : 0;
 	} else if (0 == strcmp(key, "cast_threads")) {
