@@ -12,8 +12,14 @@ from ufomap_amd import OccupancyMap, OccupancyMapColor, scans  # noqa: E402
 lo, lx, lc = scans.lidar64(colored=True)
 d = torch.from_numpy(lx).cuda()
 drgb = torch.from_numpy(lc).cuda()
-for name, cls, res, rgb in (("colour 8 cm", OccupancyMapColor, 0.08, True), ("plain 8 cm", OccupancyMap, 0.08, False), ("plain 16 cm", OccupancyMap, 0.16, False)):
+CASES = (("colour 8 cm", OccupancyMapColor, 0.08, True, {}), ("plain 8 cm", OccupancyMap, 0.08, False, {}), ("plain 16 cm", OccupancyMap, 0.16, False, {}),
+         ("colour 16 cm", OccupancyMapColor, 0.16, True, {}), ("colour 16 cm, general path", OccupancyMapColor, 0.16, True, {"fast_color": 0}))
+for name, cls, res, rgb, opts in CASES:
+    if os.environ.get("ONLY") and os.environ["ONLY"] not in name:
+        continue
     m = cls(res)
+    for k, v in opts.items():
+        m.set_option(k, v)
     for o in sys.argv[1:]:
         k, v = o.split("=")
         m.set_option(k, int(v))

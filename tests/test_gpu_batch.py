@@ -221,6 +221,46 @@ def test_colour_maps_on_the_fast_path(mode):
     assert g2.debug()[61] == 0
 
 
+@pytest.mark.parametrize("color,mode", [(False, "sync"), (False, "async"), (False, "batched"), (True, "sync"), (True, "batched")])
+def test_ray_grids_beyond_lds_on_the_fast_path(color, mode):
+    """A scan whose ray grid does not fit the ray kernel's LDS (5 cm voxels, 12 m range: ~2 MB of bits, ~25 000 tiles) still
+    takes the tiled tree update: rays through k_fselect / k_cast<2> into a grid in HBM, level 4 of the tree in parallel
+    (k_up), k_ftail from level 5 -- against the reference scan by scan, plain and colour maps, continuous scans in between,
+    one walk for several scans; and with option big = 0 (the general path) the same map."""
+    from ufomap_amd import scans, OccupancyMap, OccupancyMapColor, PointCloud, PointCloudColor
+    from oracle import OracleMap
+    cls = OccupancyMapColor if color else OccupancyMap
+    g, o = cls(resolution=0.05), OracleMap(kind=_kind(), color=color, resolution=0.05)
+    g2 = cls(resolution=0.05)
+    g2.set_option("big", 0)
+    if mode == "batched":
+        g.set_option("hold", 3)
+    base = np.array(scans.lidar_pose(0), dtype=np.float64)
+    rng = np.random.default_rng(5)
+    n_scans = 9
+    for i in range(n_scans):
+        off = rng.uniform(-0.4, 0.4, 3) * [1, 1, 0.1]
+        origin, xyz, rgb = scans.lidar64(beams=32, azimuths=384, origin=tuple(base + off), seed=700 + i, colored=True)
+        discrete = color or i % 3 != 2
+        cloud = PointCloudColor(xyz, rgb) if color else PointCloud(xyz)
+        async_ = mode != "sync"
+        for m in (g, g2):
+            (m.insertPointCloudDiscrete if discrete else m.insertPointCloud)(origin, cloud, 12.0, 0, False, 0, async_)
+        o.insert(origin, xyz, rgb if color else None, max_range=12.0, discrete=discrete)
+        if i == 4:
+            g.insertPointCloudWait()
+            (_assert_same_colour_map if color else _assert_same_map)(g, o, f"after scan {i}")
+    g.insertPointCloudWait()
+    g2.insertPointCloudWait()
+    (_assert_same_colour_map if color else _assert_same_map)(g, o, "final")
+    assert g.digest() == g2.digest(), "fast path and general path disagree"
+    d, d2 = g.debug(), g2.debug()
+    assert d[61] >= n_scans - 3 and d[58] == 0, f"the scans did not take the fast path: {d[58:64]}"
+    assert d2[61] == 0
+    if mode == "batched":
+        assert d[60] < d[59], f"no walk took more than one scan ({d[60]} walks, {d[59]} scans)"
+
+
 def test_many_handles_keep_their_maps_apart():
     """Three maps fed in turn with pipelined scans (3 x 4 streams on the device's hardware queues, gates spinning on all of
     them): every map equals its own sequential result; hand-over time-outs, if any, only cost time."""

@@ -30,6 +30,7 @@
 #pragma once
 #include "map_kernels.h"
 
+#define UFO_BIG_MAX_TILES 65536u  // depth-3 tiles of a ray grid beyond LDS (k_fselect / k_cast<2> / k_up); its level-4 cells: <= UFO_FAST_MAX_TILES
 #define UFO_FAST_MAX_TILES 8192u  // depth-3 tiles of a ray grid that takes the fast path (the host keeps larger grids off it)
 
 namespace ufo
@@ -42,6 +43,7 @@ struct FastGeo {
 	u32 nt[3];               // tiles per axis
 	u32 ntiles;
 	u32 ncells;              // entries of the first-point array (planeBits * 2*nb[2])
+	u32 tl;                  // level of the "tiles" tbase / nt / ntiles describe: 3 (k_tile's); k_ftail after k_up: 4 (FastGeo of the level-4 cells)
 };
 
 // One input point through the head loop of insertPointCloud (occupancy_map_base.h:281-303) or
@@ -203,6 +205,46 @@ __global__ __launch_bounds__(256) void k_fhits(MapGeom g, FastGeo fg, D3 sensor,
 	if (__ballot(odd) && 0 == (threadIdx.x & 63u)) atomicOr(&ctl->err, ERR_SPEC);
 	i32 none_lo[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, none_hi[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
 	blockBoxReduce(part, 7u, amn, amx, none_lo, none_hi, ck, ek);  // (folded by k_fmerge's last workgroup)
+}
+
+// ------------------------------------------------------------------------------------------------
+// F2b (ray grids beyond LDS): "first point in the voxel wins" and the compaction of the surviving ray ends -- what
+// k_fcast's prologue does per workgroup -- as a launch of its own, in the form the ray kernel of such grids reads
+// (k_cast<2>, scan_kernels.h: the ray list in cloud order + where every 256-point stretch of the cloud starts in it).
+// ------------------------------------------------------------------------------------------------
+template <bool DISCRETE>
+__global__ __launch_bounds__(256) void k_fselect(u32 n, const u32* __restrict__ first, const PointRec* __restrict__ recs, D3* __restrict__ ray_end,
+                                                 u32* __restrict__ blk_range, ScanCtl* ctl)
+{
+	if (ctl->err) {  // (k_fhits: the scan does not fit the predicted grid; uniform exit, the scan will be repeated)
+		if (0 == threadIdx.x) {
+			blk_range[2u * blockIdx.x] = 0;
+			blk_range[2u * blockIdx.x + 1u] = 0;
+		}
+		return;
+	}
+	const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	bool cast = false, winner = false;
+	D3 end{0, 0, 0};
+	if (i < n) {
+		const PointRec r = recs[i];
+		const bool odd = 0 != (r.flags & 4u);
+		cast = (r.flags & 1u) && !odd;
+		if ((r.flags & 2u) && !odd) {
+			winner = first[r.cell] == i;
+			if (DISCRETE && !winner) cast = false;  // OMB:358-360: dropped entirely, no ray
+		}
+		end = r.end;
+	}
+	const u32 rpos = blockAppend(&ctl->n_rays, cast);
+	const u32 rcount = (u32)__syncthreads_count(cast ? 1 : 0);
+	const u32 hcount = (u32)__syncthreads_count(winner ? 1 : 0);
+	if (0 == threadIdx.x) {
+		blk_range[2u * blockIdx.x] = rpos;  // (thread 0's slot is the stretch's first)
+		blk_range[2u * blockIdx.x + 1u] = rcount;
+		if (hcount) atomicAdd(&ctl->n_hits, hcount);
+	}
+	if (cast) ray_end[rpos] = end;
 }
 
 // Fold the per-workgroup bounding boxes of k_fhits (cell box of the rays: predicts the next grid; change AABB, OMB:305-308,
@@ -757,11 +799,15 @@ __global__ __launch_bounds__(1024) void k_fmerge(FastGeo fg, const Pipe* __restr
 {
 	__shared__ uint4 part[16][64];
 	__shared__ uint8_t hb[16][64];
-	__shared__ u32 tb[UFO_FAST_MAX_TILES / 32];
+	__shared__ u32 tb[UFO_BIG_MAX_TILES / 32];
 	const Pipe::Slot sl = p->slot[f & (UFO_RING - 1u)];
+	const u32 tb_words = (fg.ntiles + 31u) / 32u;
 	for (u32 b = 0; b < sl.B; ++b) {
 		const ScanDesc& d = p->ring[(sl.first + b) & (UFO_RING - 1u)];
 		ScanCtl* ctl = d.ctl;
+		// (n_slabs == 0: a ray grid beyond LDS -- the ray kernel has marked the scan's grid in HBM itself, k_cast<2>; what is left
+		// to do here is the hit grid and the tile bitmap)
+		const bool noslab = 0 == d.n_slabs;
 		if (blockIdx.x + 1u == gridDim.x) {
 			// The LAST workgroup of the launch does not merge: it folds the scan's per-workgroup results
 			foldBoxes(d.boxes, d.nboxes, ctl);
@@ -777,7 +823,7 @@ __global__ __launch_bounds__(1024) void k_fmerge(FastGeo fg, const Pipe* __restr
 					r += __shfl_xor(r, o);
 					h += __shfl_xor(h, o);
 				}
-				if (0 == threadIdx.x && 0 == ctl->err) {
+				if (0 == threadIdx.x && 0 == ctl->err && !noslab) {
 					if (v) atomicAdd(&ctl->n_steps, v);
 					ctl->n_rays = (u32)r;
 					ctl->n_hits = (u32)h;
@@ -792,13 +838,15 @@ __global__ __launch_bounds__(1024) void k_fmerge(FastGeo fg, const Pipe* __restr
 		uint4* __restrict__ grid = reinterpret_cast<uint4*>(d.gridM);
 		const u32 n_slabs = d.n_slabs;
 		const u32 col = threadIdx.x & 63u, sl16 = threadIdx.x >> 6;
-		for (u32 j = threadIdx.x; j < UFO_FAST_MAX_TILES / 32; j += blockDim.x) tb[j] = 0;
+		for (u32 j = threadIdx.x; j < tb_words; j += blockDim.x) tb[j] = 0;
 		__syncthreads();
 		const u32 rowW = fg.rowBits >> 5, ny = 2u * (u32)fg.gr.nb[1];
 		for (u32 j0 = blockIdx.x * 64u; j0 < n4; j0 += nmerge * 64u) {
 			const u32 j = j0 + col;
 			uint4 acc = make_uint4(0, 0, 0, 0);
-			if (j < n4) {
+			if (j < n4 && noslab) {
+				if (0 == sl16) acc = grid[j];
+			} else if (j < n4) {
 				for (u32 s = sl16; s < n_slabs; s += 16u) {
 					const uint4 a = slabs[(size_t)s * n4 + j];
 					acc.x |= a.x;
@@ -832,14 +880,16 @@ __global__ __launch_bounds__(1024) void k_fmerge(FastGeo fg, const Pipe* __restr
 					hv.w = (u32)hb[12][col] | ((u32)hb[13][col] << 8) | ((u32)hb[14][col] << 16) | ((u32)hb[15][col] << 24);
 					reinterpret_cast<uint4*>(d.gridH)[j] = hv;
 				}
-				for (u32 k = 1; k < 16u; ++k) {
-					const uint4 a = part[k][col];
-					acc.x |= a.x;
-					acc.y |= a.y;
-					acc.z |= a.z;
-					acc.w |= a.w;
+				if (!noslab) {
+					for (u32 k = 1; k < 16u; ++k) {
+						const uint4 a = part[k][col];
+						acc.x |= a.x;
+						acc.y |= a.y;
+						acc.z |= a.z;
+						acc.w |= a.w;
+					}
+					grid[j] = acc;
 				}
-				grid[j] = acc;
 				const u32 wv[4] = {acc.x, acc.y, acc.z, acc.w};
 				for (u32 k = 0; k < 4u; ++k) {
 					u32 m = wv[k];
@@ -865,7 +915,7 @@ __global__ __launch_bounds__(1024) void k_fmerge(FastGeo fg, const Pipe* __restr
 			}
 			__syncthreads();
 		}
-		for (u32 j = threadIdx.x; j < (fg.ntiles + 31u) / 32u; j += blockDim.x)
+		for (u32 j = threadIdx.x; j < tb_words; j += blockDim.x)
 			if (tb[j]) atomicOr(&d.tile_bits[j], tb[j]);
 		__syncthreads();  // (tb is cleared for the next scan)
 	}
@@ -1487,7 +1537,7 @@ struct UpperLevel {
 __device__ inline UpperLevel upperLevel(const FastGeo& fg, u32 l)
 {
 	UpperLevel u;
-	const u32 sh = l - 3u;
+	const u32 sh = l - fg.tl;
 	for (int a = 0; a < 3; ++a) {
 		u.lo[a] = fg.tbase[a] >> sh;
 		u.n[a] = (u32)(((fg.tbase[a] + (i32)fg.nt[a] - 1) >> sh) - u.lo[a] + 1);
@@ -1500,13 +1550,184 @@ __device__ inline u32 upperCellAt(const UpperLevel& u, u32 off, const i32 c[3])
 	const bool inside = (x < u.n[0]) & (y < u.n[1]) & (z < u.n[2]);
 	return inside ? off + x + u.n[0] * (y + u.n[1] * z) : 0xFFFFFFFFu;
 }
+// ------------------------------------------------------------------------------------------------
+// Tree update, part 1b (k_up; ray grids beyond LDS only): LEVEL 4 IN PARALLEL. k_ftail holds every block above the tiles
+// in the LDS of one workgroup, at most UFO_UPPER_MAX of them -- a grid of tens of thousands of tiles has more level-4
+// blocks than that. Here eight lanes take one level-4 block (lane = child = one tile's hand-over record): createNode
+// with inheritance, the children's summaries into its slots, updateNode -- one step of k_ftail's level loop, the same
+// rules -- and the block leaves a hand-over record of its own, in the tiles' format: k_ftail then starts one level
+// higher, with the level-4 blocks as its "tiles" (FastGeo::tl = 4).
+// ------------------------------------------------------------------------------------------------
+template <bool COLOR>
+__global__ __launch_bounds__(256) void k_up(Table t, MapGeom g, FastGeo fg, const Pipe* __restrict__ p, unsigned long long f, const TileRec* __restrict__ recs,
+                                            TileRec* __restrict__ recs_up, u32* __restrict__ up_bits, u32 scan_id, const u32* __restrict__ prev_stat)
+{
+	const Pipe::Slot sl = p->slot[f & (UFO_RING - 1u)];
+	const u32 B = sl.B;
+	if (0 == B) return;
+	u32 errs = prev_stat ? *prev_stat : 0u;
+	for (u32 b = 0; b < B; ++b) errs |= UFO_DESC(b).ctl->err;  // (UFO_DESC: k_tile's)
+	if (errs) return;  // (uniform: the walk stands back, k_tile has left the map alone)
+	ScanCtl* const ctl = UFO_DESC(B - 1u).ctl;
+	const u32 L = g.L;
+	const u32 lane = threadIdx.x & 63u, sub = lane & 7u;
+	const UpperLevel u4 = upperLevel(fg, 4u);
+	const u32 n4 = u4.n[0] * u4.n[1] * u4.n[2];
+	const u32 cell = (blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+	// the lane's child: tile (2 * cell + d) of the tile grid
+	i32 ac[3] = {0, 0, 0};
+	TileRec r;
+	r.bits = 0;
+	bool have = false;
+	if (cell < n4) {
+		const u32 x = cell % u4.n[0], rr = cell / u4.n[0];
+		ac[0] = u4.lo[0] + (i32)x;
+		ac[1] = u4.lo[1] + (i32)(rr % u4.n[1]);
+		ac[2] = u4.lo[2] + (i32)(rr / u4.n[1]);
+		const i32 tx = 2 * ac[0] + (i32)(sub & 1u) - fg.tbase[0], ty = 2 * ac[1] + (i32)((sub >> 1) & 1u) - fg.tbase[1],
+		          tz = 2 * ac[2] + (i32)(sub >> 2) - fg.tbase[2];
+		if (tx >= 0 && ty >= 0 && tz >= 0 && (u32)tx < fg.nt[0] && (u32)ty < fg.nt[1] && (u32)tz < fg.nt[2]) {
+			r = recs[(u32)tx + fg.nt[0] * ((u32)ty + fg.nt[1] * (u32)tz)];
+			have = r.seq == scan_id;  // (written by this walk's k_tile: the tile holds a ray cell of one of its scans)
+		}
+	}
+	const bool act = 0 != grpOr(have ? 1u : 0u, 0);  // (whole groups of 8 lanes)
+	// ---- createNode (octree.h:997-1016): lane 0 of the group finds or creates the block; a new (or revived) block inherits
+	// the value of the nearest node above that has a live block (nothing above level 4 is written during this launch) ----
+	const u64 lk = (1ULL << (3 * (L - 4u))) | morton3((u32)ac[0], (u32)ac[1], (u32)ac[2]);
+	u32 s = NONE, n_created = 0, fw = 0;
+	bool cr = false;
+	float vin = 0.f;
+	u32 cin = 0;
+	if (act && 0 == sub) {
+		s = tableEnsure(t, lk, scan_id, (t.mask >> 1) + 1, &cr, &n_created);
+		if (s == NONE) {
+			atomicOr(&ctl->err, ERR_TABLE_FULL);
+		} else if (cr) {
+			vin = t.root->occ;
+			if (COLOR) cin = t.root->rgb;
+			for (u64 k = lk >> 3, below = lk; k >= 1; below = k, k >>= 3) {
+				const u32 sa = tableFind(t, k);
+				if (sa != NONE && !(t.flags(sa) & F_DEAD)) {
+					vin = t.occ(sa)[(u32)(below & 7)];
+					if (COLOR) cin = t.rgb[8 * (size_t)sa + (u32)(below & 7)];
+					break;
+				}
+				if (1 == k) break;
+			}
+			// leaf children carry the flags of a leaf with this value (OMB:1181-1189)
+			fw = (isFreeV(g, vin) ? F_CFREE : 0u) | (isUnknownV(g, vin) ? F_CUNK : 0u);
+		} else {
+			fw = t.flags(s) & ~F_DIRTY;
+		}
+	}
+	const int l0 = (int)(lane & ~7u);
+	s = (u32)__shfl((int)s, l0);
+	cr = 0 != __shfl(cr ? 1 : 0, l0);
+	fw = (u32)__shfl((int)fw, l0);
+	vin = __shfl(vin, l0);
+	cin = (u32)__shfl((int)cin, l0);
+	const bool ok = act && s != NONE;
+	float v = vin;
+	u32 c = cin;
+	if (ok && !cr) {
+		v = t.occ(s)[sub];
+		if (COLOR) c = t.rgb[8 * (size_t)s + sub];
+	}
+	// ---- the tiles' hand-over records (what k_ftail does for level 4 when it starts at the tiles): summary into the
+	// child's slot, link, "is inner" bit, who carries the last update ----
+	u32 setb = 0, clrb = 0, key = 0, lub = 0;
+	float luo = 0.f;
+	bool dirty = false;
+	u32 touched = 0, created = n_created;
+	if (ok && have) {
+		const u32 bits = r.bits;
+		touched = r.counts & 2047u;
+		created += r.counts >> 25;
+		if (bits & 64u) t.parent(r.slot) = s;  // a new level-3 block: its parent link
+		if (bits & 128u) clrb |= 1u << (16 + sub);
+		else if (bits & 64u) setb |= 1u << (16 + sub);
+		key = ((r.last + 1u) << 4) | (sub + 1u);
+		if (bits & 16u) {
+			const u32 old_fl = ((fw >> sub) & 1u) | (((fw >> (8 + sub)) & 1u) << 1), fl = bits & 3u;
+			const bool changed = v != r.occ || old_fl != fl || (COLOR && c != r.rgb);
+			v = r.occ;
+			if (COLOR) c = r.rgb;
+			const u32 sm = ((fl & 1u) << sub) | (((fl >> 1) & 1u) << (8 + sub));
+			setb |= sm;
+			clrb |= ((1u << sub) | (1u << (8 + sub))) & ~sm;
+			dirty = changed || 0 != (bits & 32u);
+		}
+		lub = (((bits & 16u) && (bits & 32u)) ? 4u : 0u) | ((bits >> 2) & 3u);
+		luo = r.pre_occ;
+	}
+	fw = (fw & ~grpOr(clrb, 0)) | grpOr(setb, 0);
+	const u32 topkey = grpMaxU(key, 0);
+	const u32 tc = (topkey & 15u) - 1u;  // the child that carries the last update beneath the block
+	const bool evaluated = 0 != grpOr(dirty ? 1u : 0u, 0);
+	const u32 lubt = (u32)__shfl((int)lub, l0 + (int)(tc & 7u));
+	const float luot = __shfl(luo, l0 + (int)(tc & 7u));
+	const bool reached = evaluated && 0 != (lubt & 4u);
+	// ---- updateNode (OMB:1195-1224), as k_ftail's step: the summary, the summary just before the last update beneath ----
+	const float m = grpMax(v, 0);
+	const bool eq = grpAllEq(v, 0, lane) && (!COLOR || grpAllEqU(c, 0, lane));
+	const u32 rgb = COLOR ? grpRgb(c, 0) : 0u;
+	const float pm = grpMax((reached && sub == tc) ? luot : v, 0);
+	u32 fl = 0, pfl = 0;
+	bool dead = false, reach_out = false;
+	if (evaluated) {
+		fl = ((fw & F_CFREE) ? 1u : 0u) | ((fw & F_CUNK) ? 2u : 0u);
+		pfl = fl;
+		if (reached) {
+			const u32 fsub = (fw & ~((1u << tc) | (1u << (8 + tc)))) | ((lubt & 1u) << tc) | (((lubt >> 1) & 1u) << (8 + tc));
+			pfl = ((fsub & F_CFREE) ? 1u : 0u) | ((fsub & F_CUNK) ? 2u : 0u);
+		}
+		dead = reached && eq && 0 == (fw & F_INNER);
+		reach_out = reached && !(pm == m && pfl == fl);
+	}
+	// ---- the block back to the table, its own hand-over record ----
+	if (ok) {
+		t.occ(s)[sub] = v;
+		if (COLOR) t.rgb[8 * (size_t)s + sub] = c;
+		if (0 == sub) {
+			t.flags(s) = fw | (dead ? F_DEAD : 0u);
+			TileRec o;
+			o.occ = m;
+			o.pre_occ = reached ? pm : m;
+			o.slot = s;
+			o.bits = (fl & 3u) | ((pfl & 3u) << 2) | (evaluated ? 16u : 0u) | (reach_out ? 32u : 0u) | (cr ? 64u : 0u) | (dead ? 128u : 0u) | ((u32)(lk & 7) << 8);
+			o.seq = scan_id;
+			o.counts = 0;  // (the bookkeeping goes straight to the control block, below)
+			o.last = (topkey >> 4) - 1u;
+			o.rgb = rgb;
+			recs_up[cell] = o;
+			atomicOr(&up_bits[cell >> 5], 1u << (cell & 31u));
+		}
+	}
+	for (int o = 32; o > 0; o >>= 1) {
+		touched += __shfl_xor(touched, o);
+		created += __shfl_xor(created, o);
+	}
+	if (0 == lane) {
+		if (touched) atomicAdd(&ctl->n_entries[0], touched);
+		if (created) {
+			atomicAdd(&t.root->used, created);
+			atomicAdd(&ctl->ph[0].n_new, created);
+		}
+	}
+}
+
 #define UFO_FTAIL_THREADS 1024
 static_assert(UFO_FTAIL_THREADS == UFO_UPPER_MAX, "k_ftail: one thread per cell of the dense grids above the tiles");
 template <bool COLOR>
 __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g, FastGeo fg, Pipe* __restrict__ p, unsigned long long f,
                                                              const TileRec* __restrict__ recs, u32 scan_id, const u32* __restrict__ prev_stat,
-                                                             const ScanCtl* ctl_init)
+                                                             const ScanCtl* ctl_init, u32* __restrict__ up_bits, u32 nwords3)
 {
+	// (fg.tl = 3: the tiles are k_tile's, their activity bitmap the union of the scans' tile bitmaps. fg.tl = 4, ray grids
+	// beyond LDS: the "tiles" are the level-4 blocks k_up has evaluated, fg describes THEIR grid, up_bits is their activity
+	// bitmap; nwords3 = words of a scan's tile bitmap, which this kernel leaves clean either way)
+	const u32 tl = fg.tl;
 	// the host waits for the word behind a scan's pinned result block, not for an event: an event record is one more packet
 	// the map stream's command processor has to get through between two scans (~5 us, scripts/micro/stream_wait.hip)
 	const Pipe::Slot sl = p->slot[f & (UFO_RING - 1u)];
@@ -1536,7 +1757,9 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 		for (u32 b = 0; b < B; ++b) cerr |= UFO_DESC(b).ctl->err;
 		for (u32 j = threadIdx.x; j < nwords; j += blockDim.x) {
 			u32 w = 0;
-			for (u32 b = 0; b < B; ++b) w |= UFO_DESC(b).tile_bits[j];
+			if (up_bits) w = up_bits[j];
+			else
+				for (u32 b = 0; b < B; ++b) w |= UFO_DESC(b).tile_bits[j];
 			tbits[j] = w;
 		}
 		if (perr | cerr) {
@@ -1567,7 +1790,7 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 	__syncthreads();
 	if (0 == threadIdx.x) ctl->dbg[11] = wall_clock64();  // (diagnostics: ufomap_map_debug)
 	// ---- 1. the active cells become the node list ----
-	const UpperLevel u4 = upperLevel(fg, 4u);
+	const UpperLevel u4 = upperLevel(fg, tl + 1u);
 	const u32 n4all = u4.n[0] * u4.n[1] * u4.n[2];  // cells of level 4 = first cell of level 5
 	constexpr u32 MAXT = UFO_FAST_MAX_TILES / UFO_FTAIL_THREADS;  // tiles per thread: tile = k * blockDim + thread
 	u32 cell4[MAXT];  // the level-4 parent's cell of the thread's tiles (NONE: tile not active)
@@ -1580,7 +1803,7 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 		if (tile >= fg.ntiles || !((tbits[tile >> 5] >> (tile & 31u)) & 1u)) continue;
 		const u32 ttx = tile % fg.nt[0], rr = tile / fg.nt[0];
 		const i32 c[3] = {fg.tbase[0] + (i32)ttx, fg.tbase[1] + (i32)(rr % fg.nt[1]), fg.tbase[2] + (i32)(rr / fg.nt[1])};
-		const i32 lim = (i32)(1u << (L - 3u));
+		const i32 lim = (i32)(1u << (L - tl));
 		if (c[0] < 0 || c[1] < 0 || c[2] < 0 || c[0] >= lim || c[1] >= lim || c[2] >= lim) continue;  // (outside the key range: k_tile skipped it, too)
 		const i32 pc[3] = {c[0] >> 1, c[1] >> 1, c[2] >> 1};
 		const u32 cell = upperCellAt(u4, 0u, pc);
@@ -1601,7 +1824,7 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 			const u32 x = cell % u4.n[0], r = cell / u4.n[0];
 			i32 c[3] = {u4.lo[0] + (i32)x, u4.lo[1] + (i32)(r % u4.n[1]), u4.lo[2] + (i32)(r / u4.n[1])};
 			u32 off = n4all;
-			for (u32 l = 5; l <= L; ++l) {  // (uniform: the level's geometry is scalar arithmetic)
+			for (u32 l = tl + 2u; l <= L; ++l) {  // (uniform: the level's geometry is scalar arithmetic)
 				const UpperLevel ul = upperLevel(fg, l);
 				c[0] >>= 1;
 				c[1] >>= 1;
@@ -1638,10 +1861,10 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 		return uprefix[cell >> 5] + (u32)__popc(w & ((1u << b) - 1u));
 	};
 	// first cell of every level (off[l]; off[L+1] = number of cells), by every thread: a uniform loop of scalar arithmetic
-	u32 my_l = 4, my_off = 0, ncells = 0;
+	u32 my_l = tl + 1u, my_off = 0, ncells = 0;
 	{
 		u32 off = 0;
-		for (u32 k = 4; k <= L; ++k) {
+		for (u32 k = tl + 1u; k <= L; ++k) {
 			const UpperLevel uk = upperLevel(fg, k);
 			if (threadIdx.x >= off) {  // (the level whose range holds this thread's cell is the last one that starts at or below it)
 				my_l = k;
@@ -1789,7 +2012,7 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 	__syncthreads();
 	if (0 == threadIdx.x) ctl->dbg[15] = wall_clock64();  // (diagnostics: ufomap_map_debug)
 	// who carries the last update beneath a level-4 block: its highest touched tile (the record is L2-warm)
-	for (u32 i = lstart[4] + threadIdx.x; i < lstart[5]; i += blockDim.x) {
+	for (u32 i = lstart[tl + 1u] + threadIdx.x; i < lstart[tl + 2u]; i += blockDim.x) {
 		const unsigned long long tt = top64[i];
 		if (0 == tt) continue;
 		const TileRec r = recs[(u32)tt];
@@ -1809,7 +2032,7 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 		u32 lub = 0;
 		float luo = 0.f;
 		if (evaluated) {
-			const u32 who = (4u == l) ? i : (u32)tt;  // level 4: parked in the block's own entry by the tile pass
+			const u32 who = (tl + 1u == l) ? i : (u32)tt;  // level 4: parked in the block's own entry by the tile pass
 			lub = out_bits[who];
 			luo = out_pre[who];
 		}
@@ -1869,7 +2092,7 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 		}
 		return evaluated;
 	};
-	u32 l = 4;
+	u32 l = tl + 1u;
 	for (; l <= L; ++l) {
 		const u32 lo = lstart[l], hi = lstart[l + 1];
 		if (hi - lo <= 8u) break;  // (levels only get narrower towards the root)
@@ -1917,7 +2140,9 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 	}
 	// this kernel is the tile bitmaps' last reader: leave them empty for their sets' next scans
 	for (u32 b = 0; b < B; ++b)
-		for (u32 j = threadIdx.x; j < nwords; j += blockDim.x) UFO_DESC(b).tile_bits[j] = 0;
+		for (u32 j = threadIdx.x; j < nwords3; j += blockDim.x) UFO_DESC(b).tile_bits[j] = 0;
+	if (up_bits)
+		for (u32 j = threadIdx.x; j < nwords; j += blockDim.x) up_bits[j] = 0;
 	if (0 == threadIdx.x) {
 		u32 used = __hip_atomic_load(&t.root->used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		if (created_total) {

@@ -243,6 +243,7 @@ struct ufomap_map {
 	DevBuf b_tilerec;             // fast path, map stream only
 	DevBuf b_ser[5];              // scratch of the map byte stream (serialiseNodes), kept between calls
 	uint8_t* h_ser = nullptr;     // ... pinned: per-level counts, the root, the stream's length
+	DevBuf b_upbits;              // grids beyond LDS: which level-4 blocks the walk's k_up has evaluated (bitmap; left clean by k_ftail)
 	DevBuf b_ts;                  // developer aid (option "tstamps"): device clock at the pipeline's hand-overs (fast_kernels.h: Pipe::ts)
 	DevBuf b_pipe;                // fast path: which walk applies which scan (fast_kernels.h: Pipe), device side
 	uint64_t n_fseq = 0;          // fast-path scans enqueued so far
@@ -262,6 +263,7 @@ struct ufomap_map {
 	unsigned long long* h_prep = nullptr;  // pinned: integration number of the newest scan whose k_fhits has finished (k_signal)
 	uint64_t n_walks = 0, n_walk_scans = 0, n_gate_timeouts = 0;  // fast-path walks that applied scans, scans in them; stream hand-overs that timed out
 	int opt_batch_max = 8;        // scans a walk may take when scans have queued up behind the map stream (1 = one walk per scan)
+	int opt_big = 1;              // ray grids beyond LDS on the fast path (k_fselect / k_cast<2> / k_up); 0: the general path
 	int opt_fast_color = 1;       // colour maps on the fast path (0: the general path, as before round 3)
 	int opt_solo = 1;             // synchronous calls with nothing in flight run on the map stream alone
 	bool solo = false;            // ... the current integration does
@@ -1131,7 +1133,27 @@ FastGeo makeFastGeo(const Grid& gr)
 		nt *= fg.nt[a];
 	}
 	fg.ntiles = (u32)std::min<u64>(nt, 0xFFFFFFFFull);
+	fg.tl = 3;
 	return fg;
+}
+
+// does the ray kernel of the steady-state path hold this grid in LDS (k_fcast)? Else the grid is a "big" one: its rays go
+// through k_fselect / k_cast<2> (marks in HBM), its tree update through k_tile / k_up / k_ftail
+bool gridFitsLds(const Grid& gr) { return 1 == gr.layout && gr.bytes + UFO_CAST_LDS_EXTRA <= (160u << 10) - 512u; }
+
+// the level-4 cells of a tile grid as a tile grid of their own (what k_ftail works on after k_up)
+FastGeo makeUpGeo(const FastGeo& fg)
+{
+	FastGeo u = fg;
+	u64 nt = 1;
+	for (int a = 0; a < 3; ++a) {
+		u.tbase[a] = fg.tbase[a] >> 1;
+		u.nt[a] = (u32)(((fg.tbase[a] + (i32)fg.nt[a] - 1) >> 1) - u.tbase[a] + 1);
+		nt *= u.nt[a];
+	}
+	u.ntiles = (u32)std::min<u64>(nt, 0xFFFFFFFFull);
+	u.tl = 4;
+	return u;
 }
 
 // upper bound of the node blocks one scan inside grid gr can create: every level-1 block of the grid and all ancestors
@@ -1145,8 +1167,8 @@ u64 makeUpperGeo(const FastGeo& fg, u32 L, UpperGeo* ug)
 {
 	memset(ug, 0, sizeof(*ug));
 	u64 off = 0;
-	for (u32 l = 4; l <= L; ++l) {
-		const u32 sh = l - 3u;
+	for (u32 l = fg.tl + 1u; l <= L; ++l) {
+		const u32 sh = l - fg.tl;
 		ug->off[l] = (u32)std::min<u64>(off, 0xFFFFFFFFull);
 		u64 sz = 1;
 		for (int a = 0; a < 3; ++a) {
@@ -1168,11 +1190,17 @@ bool fastEligible(const ufomap_map* m, const Grid& gr, unsigned depth, int simpl
 	if (m->g.color && 0 == m->opt_fast_color) return false;
 	if (1 != gr.layout) return false;
 	const FastGeo fg = makeFastGeo(gr);
-	if (fg.ntiles > UFO_FAST_MAX_TILES) return false;
-	// node blocks above the tiles that the scan can touch: k_ftail finds them on dense per-level grids (the tile grid
-	// coarsened level by level) and holds them in LDS -- their number is bounded by the number of cells
 	UpperGeo ug;
-	return makeUpperGeo(fg, m->g.L, &ug) <= UFO_UPPER_MAX;
+	if (gridFitsLds(gr)) {
+		if (fg.ntiles > UFO_FAST_MAX_TILES) return false;
+		// node blocks above the tiles that the scan can touch: k_ftail finds them on dense per-level grids (the tile grid
+		// coarsened level by level) and holds them in LDS -- their number is bounded by the number of cells
+		return makeUpperGeo(fg, m->g.L, &ug) <= UFO_UPPER_MAX;
+	}
+	// a ray grid beyond LDS: level 4 goes through k_up, k_ftail starts above it
+	if (!m->opt_big || m->g.L < 6 || fg.ntiles > UFO_BIG_MAX_TILES || (u64)fg.ncells * 4u > (1ull << 30)) return false;
+	const FastGeo fu = makeUpGeo(fg);
+	return fu.ntiles <= UFO_FAST_MAX_TILES && makeUpperGeo(fu, m->g.L, &ug) <= UFO_UPPER_MAX;
 }
 
 unsigned long long gateTicks(const ufomap_map* m) { return (unsigned long long)std::max(100, m->opt_gate_us) * 100ull; }  // wall_clock64: 100 MHz
@@ -1241,7 +1269,8 @@ int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, si
 	(void)makeUpperGeo(fg, m->g.L, &m->ugeo);
 	const size_t cf = m->b_first.cap, ct = m->b_tilebits.cap;  // (a re-allocation may well return the old address: compare sizes)
 	HIP_TRY(m->b_first.reserve(((size_t)fg.gr.bytes * 8 + 127) / 128 * 128 * 4));  // (one entry per bit of the grid, whole 128-entry columns: k_fmerge)
-	HIP_TRY(m->b_tilebits.reserve(UFO_FAST_MAX_TILES / 8));
+	const bool big = !gridFitsLds(m->spec_grid);  // the ray grid lives in HBM: k_fselect + k_cast<2> instead of k_fcast
+	HIP_TRY(m->b_tilebits.reserve((big ? UFO_BIG_MAX_TILES : UFO_FAST_MAX_TILES) / 8));
 	if (cf != m->b_first.cap || ct != m->b_tilebits.cap) m->first_dirty = true;
 	// k_fhits depends on nothing but the cloud: on the prep stream it overlaps the ray kernel of the scan before
 	m->cs = solo ? m->stream : m->pstream;
@@ -1326,7 +1355,60 @@ int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, si
 		HIP_TRY(hipStreamWaitEvent(m->sstream, m->prep_ev, 0));
 	}
 	m->cs = solo ? m->stream : m->sstream;
-	{
+	if (big) {
+		// ---- a ray grid beyond LDS: the surviving rays are compacted (k_fselect) and walked by the ray kernel of the general
+		// path (k_cast<2>: a workgroup takes consecutive stretches of the cloud and marks an LDS box of the grid, ORed into
+		// the grid in HBM) -- no slabs; the walk derives the hit grid and the tile bitmap from the grid (k_fmerge) ----
+		const u32 n_blk = gp.x;  // workgroups of k_fselect = 256-point stretches of the cloud
+		HIP_TRY(m->b_ray_end.reserve((size_t)N * sizeof(D3)));
+		HIP_TRY(m->b_blk_range.reserve((size_t)n_blk * 8));
+		u32 nwg = m->opt_cast_wgs > 0 ? (u32)m->opt_cast_wgs : std::min<u32>(n_blk, 1024u);
+		nwg = std::max<u32>(std::max<u32>(1u, nwg), (n_blk + UFO_CAST_STRETCHES - 1u) / UFO_CAST_STRETCHES);
+		HIP_TRY(m->b_slabs.reserve((size_t)std::max(nwg, n_blk) * 8));
+		HIP_TRY(hipMemsetAsync(m->b_gridM.p, 0, fg.gr.bytes, m->cs));
+		{
+			ProfScope ps(m, "k_fselect");
+			if (discrete)
+				hipLaunchKernelGGL(k_fselect<true>, gp, dim3(256), 0, m->cs, N, m->b_first.as<u32>(), m->b_hit_code.as<PointRec>(), m->b_ray_end.as<D3>(),
+				                   m->b_blk_range.as<u32>(), ctl);
+			else
+				hipLaunchKernelGGL(k_fselect<false>, gp, dim3(256), 0, m->cs, N, m->b_first.as<u32>(), m->b_hit_code.as<PointRec>(), m->b_ray_end.as<D3>(),
+				                   m->b_blk_range.as<u32>(), ctl);
+		}
+		{
+			ProfScope ps(m, "k_cast_global");
+			const u32 grid_lds = ((160u << 10) - 1024u - (u32)UFO_CAST2_LDS_EXTRA) & ~15u;
+			hipLaunchKernelGGL(k_cast<2>, dim3(nwg), dim3(512), (size_t)grid_lds + UFO_CAST2_LDS_EXTRA, m->cs, m->g, sensor, 0u, fg.gr, m->b_gridM.as<u32>(),
+			                   m->b_ray_end.as<D3>(), (u32)std::max(8, m->opt_cast_k), ctl, ctl, m->b_slabs.as<unsigned long long>(), grid_lds,
+			                   m->b_blk_range.as<u32>(), n_blk, grid_lds);
+		}
+		ScanDesc d{};
+		d.slabs = nullptr;
+		d.parts = nullptr;
+		d.gridM = m->b_gridM.as<u32>();
+		d.gridH = m->b_gridH.as<u32>();
+		d.first = m->b_first.as<u32>();
+		d.tile_bits = m->b_tilebits.as<u32>();
+		d.ctl = ctl;
+		d.host_result = m->h_res;
+		d.boxes = m->b_part1.as<BoxPartial>();
+		d.done_value = (unsigned long long)m->seq;
+		d.fseq = (unsigned long long)m->fseq;
+		d.n_slabs = 0;
+		d.nboxes = gp.x;
+		d.geo = m->geo_id;
+		d.rgb = scan_rgb;
+		if (solo) {
+			DescPack pk{};
+			pk.d[0] = d;
+			hipLaunchKernelGGL(k_batch_descs, dim3(1), dim3(64), 0, m->cs, m->b_bpipe.as<Pipe>(), pk, 1u);
+		} else if (lazy_done && m->gates) {
+			m->sd_saved = d;
+			m->sd_pending = true;
+		} else {
+			hipLaunchKernelGGL(k_scan_done, dim3(1), dim3(1), 0, m->sstream, m->b_pipe.as<Pipe>(), d);
+		}
+	} else {
 		// One workgroup per CU is what the ray kernel's LDS allows, and alone it is fastest with one on every CU. In a row
 		// of asynchronous scans it shares the chip with the first-point pass of the next scan and the tree update of the
 		// scan before: with a workgroup on three CUs in four it does not wait for the last CUs those kernels hold, and they
@@ -1490,7 +1572,21 @@ int enqueueSlot(ufomap_map* m, int k)
 	}
 	m->scan_new_bound = bound;
 	m->scan_id += 1;
-	HIP_TRY(m->b_tilerec.reserve((size_t)UFO_FAST_MAX_TILES * sizeof(TileRec)));
+	const bool big_grid = !gridFitsLds(fg.gr);
+	{
+		// hand-over records: the tiles' (k_tile), behind them the level-4 blocks' of a grid beyond LDS (k_up); new memory is
+		// zeroed -- a record counts if it carries the walk's number
+		const size_t want = (big_grid ? (size_t)UFO_BIG_MAX_TILES + UFO_FAST_MAX_TILES : (size_t)UFO_FAST_MAX_TILES) * sizeof(TileRec);
+		if (m->b_tilerec.cap < want) {
+			HIP_TRY(hipStreamSynchronize(m->stream));  // (a walk in flight reads the old array)
+			HIP_TRY(m->b_tilerec.reserve(want));
+			HIP_TRY(hipMemsetAsync(m->b_tilerec.p, 0, m->b_tilerec.cap, m->stream));
+		}
+		if (big_grid && !m->b_upbits.p) {
+			HIP_TRY(m->b_upbits.reserve(UFO_FAST_MAX_TILES / 8));
+			HIP_TRY(hipMemsetAsync(m->b_upbits.p, 0, m->b_upbits.cap, m->stream));
+		}
+	}
 	(a ? a->pending : m->pending) = true;
 	(a ? a->deferred : m->deferred) = false;
 	(a ? a->has_slot : m->has_slot) = true;
@@ -1522,14 +1618,37 @@ int enqueueSlot(ufomap_map* m, int k)
 			hipLaunchKernelGGL(k_tile<false>, dim3((fg.ntiles + tw - 1) / tw), dim3(64u * tw), 0, m->cs, m->t, m->g, fg, pipe, (unsigned long long)f,
 			                   m->b_tilerec.as<TileRec>(), m->g.hit, miss, m->scan_id, prev_stat, changeLog(m));
 	}
-	{
+	const u32 nwords3 = (fg.ntiles + 31u) / 32u;
+	if (big_grid) {
+		// a ray grid beyond LDS: level 4 in parallel (k_up), k_ftail starts above it -- the level-4 blocks are its "tiles"
+		const FastGeo fu = makeUpGeo(fg);
+		TileRec* recs_up = m->b_tilerec.as<TileRec>() + UFO_BIG_MAX_TILES;
+		u32* up_bits = m->b_upbits.as<u32>();
+		{
+			ProfScope ps(m, "k_up");
+			const dim3 gu((fu.ntiles * 8u + 255u) / 256u);
+			if (m->g.color)
+				hipLaunchKernelGGL(k_up<true>, gu, dim3(256), 0, m->cs, m->t, m->g, fg, pipe, (unsigned long long)f, m->b_tilerec.as<TileRec>(), recs_up, up_bits,
+				                   m->scan_id, prev_stat);
+			else
+				hipLaunchKernelGGL(k_up<false>, gu, dim3(256), 0, m->cs, m->t, m->g, fg, pipe, (unsigned long long)f, m->b_tilerec.as<TileRec>(), recs_up, up_bits,
+				                   m->scan_id, prev_stat);
+		}
+		ProfScope ps(m, "k_ftail");
+		if (m->g.color)
+			hipLaunchKernelGGL(k_ftail<true>, dim3(1), dim3(UFO_FTAIL_THREADS), 0, m->cs, m->t, m->g, fu, pipe, (unsigned long long)f, recs_up, m->scan_id, prev_stat,
+			                   m->b_ctl_init.as<ScanCtl>(), up_bits, nwords3);
+		else
+			hipLaunchKernelGGL(k_ftail<false>, dim3(1), dim3(UFO_FTAIL_THREADS), 0, m->cs, m->t, m->g, fu, pipe, (unsigned long long)f, recs_up, m->scan_id, prev_stat,
+			                   m->b_ctl_init.as<ScanCtl>(), up_bits, nwords3);
+	} else {
 		ProfScope ps(m, "k_ftail");
 		if (m->g.color)
 			hipLaunchKernelGGL(k_ftail<true>, dim3(1), dim3(UFO_FTAIL_THREADS), 0, m->cs, m->t, m->g, fg, pipe, (unsigned long long)f, m->b_tilerec.as<TileRec>(),
-			                   m->scan_id, prev_stat, m->b_ctl_init.as<ScanCtl>());
+			                   m->scan_id, prev_stat, m->b_ctl_init.as<ScanCtl>(), (u32*)nullptr, nwords3);
 		else
 			hipLaunchKernelGGL(k_ftail<false>, dim3(1), dim3(UFO_FTAIL_THREADS), 0, m->cs, m->t, m->g, fg, pipe, (unsigned long long)f, m->b_tilerec.as<TileRec>(),
-			                   m->scan_id, prev_stat, m->b_ctl_init.as<ScanCtl>());
+			                   m->scan_id, prev_stat, m->b_ctl_init.as<ScanCtl>(), (u32*)nullptr, nwords3);
 	}
 	HIP_TRY(hipGetLastError());
 	return UFOMAP_OK;
@@ -1571,8 +1690,10 @@ int flushDeferred(ufomap_map* m, bool publish)
 // grid predicted so far (a sensor that moves about a room keeps producing boxes inside one hull, and a prediction that
 // covers the hull never misses again), second choice the box alone, each with up to two node blocks of margin for sensor
 // motion -- as long as the ray kernel still fits its bit grid and segment queue in LDS.
-bool gridFromBox(bool had, const Grid& prev, const i32 bmn[3], const i32 bmx[3], Grid* out)
+bool gridFromBox(bool had, const Grid& prev, const i32 bmn[3], const i32 bmx[3], Grid* out, bool allow_big = false)
 {
+	// (big: no grid that the ray kernel can hold in LDS -- then a grid in HBM, k_fselect / k_cast<2> / k_up, up to 8 MiB of bits)
+	for (int big = 0; big <= (allow_big ? 1 : 0); ++big)
 	for (int pass = (had && 0 == prev.depth) ? 0 : 1; pass < 2; ++pass) {
 		for (int margin = 2; margin >= 0; --margin) {
 			i32 mn[3], mx[3];
@@ -1589,7 +1710,8 @@ bool gridFromBox(bool had, const Grid& prev, const i32 bmn[3], const i32 bmx[3],
 			if (makeGrid(mn, mx, 0, &gr)) continue;
 			const bool packed = 2 * gr.nb[0] < 1023 && 2 * gr.nb[1] < 1023 && 2 * gr.nb[2] < 1023;
 			const u64 bytes1 = (u64)(gridRowBits(gr) >> 3) * (2ull * (u64)gr.nb[1]) * (2ull * (u64)gr.nb[2]);
-			if (!packed || ((bytes1 + 15) & ~15ull) + UFO_CAST_LDS_EXTRA > (160u << 10) - 512u) continue;
+			if (!packed) continue;
+			if (big ? bytes1 > (8ull << 20) : ((bytes1 + 15) & ~15ull) + UFO_CAST_LDS_EXTRA > (160u << 10) - 512u) continue;
 			gr.layout = 1;
 			gr.bytes = (bytes1 + 15) & ~15ull;
 			*out = gr;
@@ -1608,7 +1730,7 @@ void predictGrid(ufomap_map* m)
 	const ScanArgs& a = m->args;
 	if (!m->opt_spec || !m->opt_merge || !m->opt_cast || !m->opt_bits || !m->opt_dda_seg || m->opt_dda_mode > 0) return;
 	if (0 != a.depth || a.simple || 0 == a.n || 0 == m->h_ctl->n_rays) return;
-	m->spec_valid = gridFromBox(had, prev, m->h_ctl->mb_min, m->h_ctl->mb_max, &m->spec_grid);
+	m->spec_valid = gridFromBox(had, prev, m->h_ctl->mb_min, m->h_ctl->mb_max, &m->spec_grid, 0 != m->opt_big && 0 != m->opt_fast && m->g.L >= 6);
 }
 
 int redoBatchStep(ufomap_map* m);
@@ -2069,8 +2191,11 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 	const bool merged = 0 == depth && 0 != m->opt_merge;
 	// Speculation: enqueue the whole scan on the grid predicted from the previous one instead of reading the
 	// bounding boxes back in the middle of the scan half (a host round trip of ~25 us on a 120 us chain).
-	const bool spec = (0 == spec_mode ? (m->opt_spec && m->spec_valid) : false) && merged && !simple && 0 == early_stopping && n > 0 &&
-	                  n <= (1u << 29) && !(d_rgb && !m->g.color);
+	bool spec = (0 == spec_mode ? (m->opt_spec && m->spec_valid) : false) && merged && !simple && 0 == early_stopping && n > 0 &&
+	            n <= (1u << 29) && !(d_rgb && !m->g.color);
+	// the fast path (fast_kernels.h): the whole scan on the predicted grid in five launches, the tree update tiled
+	const bool fast = spec && fastEligible(m, m->spec_grid, depth, simple, d_rgb, n, discrete) && nullptr == m->ing.rgb_out;
+	if (spec && !fast && !gridFitsLds(m->spec_grid)) spec = false;  // (grids beyond LDS are predicted for the fast path only)
 	{
 		ScanArgs& a = m->args;
 		a.spec = spec;
@@ -2085,8 +2210,6 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 		a.ing = m->ing;
 	}
 	if (spec) ++m->n_spec;
-	// the fast path (fast_kernels.h): the whole scan on the predicted grid in five launches, the tree update tiled
-	const bool fast = spec && fastEligible(m, m->spec_grid, depth, simple, d_rgb, n, discrete) && nullptr == m->ing.rgb_out;
 	u32 n_hits = 0, n_rays = 0;
 	u64 capH = 0, capM = 0;
 	int rc;
@@ -4190,7 +4313,7 @@ int fastBatchStep(ufomap_map* m, ufomap_comm* c, const double origin[3], const d
 		{
 			ProfScope ps(m, "k_ftail");
 			hipLaunchKernelGGL(k_ftail<false>, dim3(1), dim3(UFO_FTAIL_THREADS), 0, m->stream, m->t, m->g, fg, bp, 0ull, m->b_tilerec.as<TileRec>(), m->scan_id, prev_stat,
-			                   m->b_ctl_init.as<ScanCtl>());
+			                   m->b_ctl_init.as<ScanCtl>(), (u32*)nullptr, (fg.ntiles + 31u) / 32u);
 		}
 		prev_stat = &bp->wstat[0];  // (a second walk of the same step looks at the first)
 	}
@@ -4807,6 +4930,8 @@ int ufomap_map_set_option(ufomap_map* m, const char* key, long long value)
 			m->b_ts.release();
 		}
 		HIP_TRY(hipMemcpy(reinterpret_cast<char*>(m->b_pipe.p) + offsetof(Pipe, ts), &ts, sizeof(ts), hipMemcpyHostToDevice));
+	} else if (0 == strcmp(key, "big")) {
+		m->opt_big = value ? 1 : 0;
 	} else if (0 == strcmp(key, "fast_color")) {
 		m->opt_fast_color = value ? 1 : 0;
 	} else if (0 == strcmp(key, "solo")) {
