@@ -213,16 +213,21 @@ __global__ __launch_bounds__(256) void k_fhits(MapGeom g, FastGeo fg, D3 sensor,
 // (k_cast<2>, scan_kernels.h: the ray list in cloud order + where every 256-point stretch of the cloud starts in it).
 // ------------------------------------------------------------------------------------------------
 template <bool DISCRETE>
-__global__ __launch_bounds__(256) void k_fselect(u32 n, const u32* __restrict__ first, const PointRec* __restrict__ recs, D3* __restrict__ ray_end,
-                                                 u32* __restrict__ blk_range, ScanCtl* ctl)
+__global__ __launch_bounds__(256) void k_fselect(u32 n, u32* __restrict__ first, const PointRec* __restrict__ recs, D3* __restrict__ ray_end,
+                                                 u32* __restrict__ blk_range, unsigned long long* __restrict__ parts, u32* __restrict__ gridH, u32 clean_first,
+                                                 const ScanCtl* ctl)
 {
+	// No word that every workgroup would have to add to (each such atomic is ~12 ns, one after the other): a stretch's rays
+	// go to the stretch's own 256 slots of the ray list, the counts to per-stretch partials (folded by k_fmerge).
 	if (ctl->err) {  // (k_fhits: the scan does not fit the predicted grid; uniform exit, the scan will be repeated)
 		if (0 == threadIdx.x) {
 			blk_range[2u * blockIdx.x] = 0;
 			blk_range[2u * blockIdx.x + 1u] = 0;
+			parts[blockIdx.x] = 0;
 		}
 		return;
 	}
+	__shared__ u32 wcnt[4];
 	const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
 	bool cast = false, winner = false;
 	D3 end{0, 0, 0};
@@ -233,18 +238,32 @@ __global__ __launch_bounds__(256) void k_fselect(u32 n, const u32* __restrict__ 
 		if ((r.flags & 2u) && !odd) {
 			winner = first[r.cell] == i;
 			if (DISCRETE && !winner) cast = false;  // OMB:358-360: dropped entirely, no ray
+			if (winner) {
+				// the voxel receives a hit (OMB:295, 358-360): its bit in the scan's hit grid; and the first-point array is left
+				// clean for the set's next scan (a point of the same voxel that looks later finds "none", which is not its index
+				// either) -- unless the tree update needs the first points for their colours and cleans up itself (k_tile)
+				atomicOr(&gridH[r.cell >> 5], 1u << (r.cell & 31u));
+				if (clean_first) first[r.cell] = 0xFFFFFFFFu;
+			}
 		}
 		end = r.end;
 	}
-	const u32 rpos = blockAppend(&ctl->n_rays, cast);
-	const u32 rcount = (u32)__syncthreads_count(cast ? 1 : 0);
-	const u32 hcount = (u32)__syncthreads_count(winner ? 1 : 0);
-	if (0 == threadIdx.x) {
-		blk_range[2u * blockIdx.x] = rpos;  // (thread 0's slot is the stretch's first)
-		blk_range[2u * blockIdx.x + 1u] = rcount;
-		if (hcount) atomicAdd(&ctl->n_hits, hcount);
+	const u64 mask = __ballot(cast);
+	const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+	if (0 == lane) wcnt[wave] = (u32)__popcll(mask);
+	const u32 hcount = (u32)__syncthreads_count(winner ? 1 : 0);  // (a barrier: wcnt is complete)
+	u32 off = 0, rcount = 0;
+	for (u32 w = 0; w < 4u; ++w) {
+		if (w < wave) off += wcnt[w];
+		rcount += wcnt[w];
 	}
-	if (cast) ray_end[rpos] = end;
+	const u32 base = blockIdx.x * blockDim.x;
+	if (cast) ray_end[base + off + (u32)__popcll(mask & ((1ULL << lane) - 1ULL))] = end;
+	if (0 == threadIdx.x) {
+		blk_range[2u * blockIdx.x] = base;
+		blk_range[2u * blockIdx.x + 1u] = rcount;
+		parts[blockIdx.x] = (unsigned long long)rcount | ((unsigned long long)hcount << 32);
+	}
 }
 
 // Fold the per-workgroup bounding boxes of k_fhits (cell box of the rays: predicts the next grid; change AABB, OMB:305-308,
@@ -823,7 +842,21 @@ __global__ __launch_bounds__(1024) void k_fmerge(FastGeo fg, const Pipe* __restr
 					r += __shfl_xor(r, o);
 					h += __shfl_xor(h, o);
 				}
-				if (0 == threadIdx.x && 0 == ctl->err && !noslab) {
+				if (noslab) {
+					// (a grid beyond LDS: rays cast / voxels hit per 256-point stretch of the cloud, k_fselect)
+					r = h = 0;
+					for (u32 s = threadIdx.x; s < d.nboxes; s += 64u) {
+						const unsigned long long q = d.parts[s];
+						r += q & 0xFFFFFFFFull;
+						h += q >> 32;
+					}
+					for (int o = 32; o > 0; o >>= 1) {
+						r += __shfl_xor(r, o);
+						h += __shfl_xor(h, o);
+					}
+					v = 0;  // (k_cast<2> has added its steps itself)
+				}
+				if (0 == threadIdx.x && 0 == ctl->err) {
 					if (v) atomicAdd(&ctl->n_steps, v);
 					ctl->n_rays = (u32)r;
 					ctl->n_hits = (u32)h;
@@ -858,7 +891,7 @@ __global__ __launch_bounds__(1024) void k_fmerge(FastGeo fg, const Pipe* __restr
 			// the scan's hit grid: one bit per cell that holds a first point (the voxel receives a hit, OMB:295, 358-360), from the
 			// dense first-point array -- 128 entries per column, eight per slab lane -- which is left clean for the set's next scan
 			u32 hbits = 0;
-			if (j < n4 && d.first) {
+			if (j < n4 && d.first && !noslab) {  // (noslab: k_fselect has built the hit grid)
 				uint4* f4 = reinterpret_cast<uint4*>(d.first + (size_t)128u * j + 8u * sl16);
 				const uint4 fa = f4[0], fb = f4[1];
 				hbits = (fa.x != 0xFFFFFFFFu ? 1u : 0u) | (fa.y != 0xFFFFFFFFu ? 2u : 0u) | (fa.z != 0xFFFFFFFFu ? 4u : 0u) | (fa.w != 0xFFFFFFFFu ? 8u : 0u) |
@@ -872,7 +905,7 @@ __global__ __launch_bounds__(1024) void k_fmerge(FastGeo fg, const Pipe* __restr
 			part[sl16][col] = acc;
 			__syncthreads();
 			if (0 == sl16 && j < n4) {
-				if (d.first) {
+				if (d.first && !noslab) {
 					uint4 hv;
 					hv.x = (u32)hb[0][col] | ((u32)hb[1][col] << 8) | ((u32)hb[2][col] << 16) | ((u32)hb[3][col] << 24);
 					hv.y = (u32)hb[4][col] | ((u32)hb[5][col] << 8) | ((u32)hb[6][col] << 16) | ((u32)hb[7][col] << 24);

@@ -1360,20 +1360,22 @@ int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, si
 		// path (k_cast<2>: a workgroup takes consecutive stretches of the cloud and marks an LDS box of the grid, ORed into
 		// the grid in HBM) -- no slabs; the walk derives the hit grid and the tile bitmap from the grid (k_fmerge) ----
 		const u32 n_blk = gp.x;  // workgroups of k_fselect = 256-point stretches of the cloud
-		HIP_TRY(m->b_ray_end.reserve((size_t)N * sizeof(D3)));
+		HIP_TRY(m->b_ray_end.reserve((size_t)n_blk * 256u * sizeof(D3)));
 		HIP_TRY(m->b_blk_range.reserve((size_t)n_blk * 8));
 		u32 nwg = m->opt_cast_wgs > 0 ? (u32)m->opt_cast_wgs : std::min<u32>(n_blk, 1024u);
 		nwg = std::max<u32>(std::max<u32>(1u, nwg), (n_blk + UFO_CAST_STRETCHES - 1u) / UFO_CAST_STRETCHES);
-		HIP_TRY(m->b_slabs.reserve((size_t)std::max(nwg, n_blk) * 8));
+		HIP_TRY(m->b_slabs.reserve((size_t)std::max(nwg, n_blk) * 8 + (size_t)n_blk * 8));  // k_cast<2>'s step counts | k_fselect's per-stretch counts
+		unsigned long long* parts = m->b_slabs.as<unsigned long long>() + std::max(nwg, n_blk);
 		HIP_TRY(hipMemsetAsync(m->b_gridM.p, 0, fg.gr.bytes, m->cs));
+		HIP_TRY(hipMemsetAsync(m->b_gridH.p, 0, fg.gr.bytes, m->cs));
 		{
 			ProfScope ps(m, "k_fselect");
 			if (discrete)
 				hipLaunchKernelGGL(k_fselect<true>, gp, dim3(256), 0, m->cs, N, m->b_first.as<u32>(), m->b_hit_code.as<PointRec>(), m->b_ray_end.as<D3>(),
-				                   m->b_blk_range.as<u32>(), ctl);
+				                   m->b_blk_range.as<u32>(), parts, m->b_gridH.as<u32>(), scan_rgb ? 0u : 1u, ctl);
 			else
 				hipLaunchKernelGGL(k_fselect<false>, gp, dim3(256), 0, m->cs, N, m->b_first.as<u32>(), m->b_hit_code.as<PointRec>(), m->b_ray_end.as<D3>(),
-				                   m->b_blk_range.as<u32>(), ctl);
+				                   m->b_blk_range.as<u32>(), parts, m->b_gridH.as<u32>(), scan_rgb ? 0u : 1u, ctl);
 		}
 		{
 			ProfScope ps(m, "k_cast_global");
@@ -1384,7 +1386,7 @@ int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, si
 		}
 		ScanDesc d{};
 		d.slabs = nullptr;
-		d.parts = nullptr;
+		d.parts = parts;
 		d.gridM = m->b_gridM.as<u32>();
 		d.gridH = m->b_gridH.as<u32>();
 		d.first = m->b_first.as<u32>();
