@@ -158,7 +158,8 @@ def other_configs(device, big):
             warm.append((time.perf_counter() - t0) * 1e3)
         out[label] = dict(points=c["points"], rays=c["rays"], dda_steps=c["steps"], ms_per_scan_fixture=[round(v, 4) for v in ms],
                           ms_warm_median=(float(np.median(warm)) if warm else None), digest_ok=bool(ok), checked_against=("tests/golden/digests.json (unmodified reference)" if want is not None else None),
-                          live_blocks=st["inner_nodes"], leaves=st["leaf_nodes"], table_bytes=st["bytes"])
+                          live_blocks=st["inner_nodes"], leaves=st["leaf_nodes"], table_bytes=st["bytes"],
+                          fast_path_scans=int(m.debug()[61]), scans=len(seq) + warm_reps)
         return dig
 
     for label, name, reps in (("C1_lidar16cm_continuous", "c1_full", 10), ("C5_lidar8cm_colour", "c5_colour_8cm", 10)) + ((("C3_rgbd2mm_depth0", "c3_depth0_full", 1),) if big else ()):

@@ -223,24 +223,24 @@ def test_colour_maps_on_the_fast_path(mode):
 
 @pytest.mark.parametrize("color,mode", [(False, "sync"), (False, "async"), (False, "batched"), (True, "sync"), (True, "batched")])
 def test_ray_grids_beyond_lds_on_the_fast_path(color, mode):
-    """A scan whose ray grid does not fit the ray kernel's LDS (5 cm voxels, 12 m range: ~2 MB of bits, ~25 000 tiles) still
+    """A scan whose ray grid does not fit the ray kernel's LDS (6 cm voxels, 12 m range: ~1 MB of bits, ~15 000 tiles) still
     takes the tiled tree update: rays through k_fselect / k_cast<2> into a grid in HBM, level 4 of the tree in parallel
     (k_up), k_ftail from level 5 -- against the reference scan by scan, plain and colour maps, continuous scans in between,
     one walk for several scans; and with option big = 0 (the general path) the same map."""
     from ufomap_amd import scans, OccupancyMap, OccupancyMapColor, PointCloud, PointCloudColor
     from oracle import OracleMap
     cls = OccupancyMapColor if color else OccupancyMap
-    g, o = cls(resolution=0.05), OracleMap(kind=_kind(), color=color, resolution=0.05)
-    g2 = cls(resolution=0.05)
+    g, o = cls(resolution=0.06), OracleMap(kind=_kind(), color=color, resolution=0.06)
+    g2 = cls(resolution=0.06)
     g2.set_option("big", 0)
     if mode == "batched":
         g.set_option("hold", 3)
     base = np.array(scans.lidar_pose(0), dtype=np.float64)
     rng = np.random.default_rng(5)
-    n_scans = 9
+    n_scans = 8
     for i in range(n_scans):
         off = rng.uniform(-0.4, 0.4, 3) * [1, 1, 0.1]
-        origin, xyz, rgb = scans.lidar64(beams=32, azimuths=384, origin=tuple(base + off), seed=700 + i, colored=True)
+        origin, xyz, rgb = scans.lidar64(beams=24, azimuths=384, origin=tuple(base + off), seed=700 + i, colored=True)
         discrete = color or i % 3 != 2
         cloud = PointCloudColor(xyz, rgb) if color else PointCloud(xyz)
         async_ = mode != "sync"
