@@ -17,7 +17,9 @@ map's clear(), so in the timed region no scan is repeated for a misprediction (`
 Timed region = W warm-up steps into a cleared map, barrier + synchronise, EXACTLY K steps, synchronise + barrier.
 With the driver's K = 20 that is only a few milliseconds, so the region is REPEATED (map cleared, same W + K
 steps) until at least 0.5 s of timed steps have accumulated; `value` is total points / total timed seconds over
-all repetitions (`repeats`, `timed_region_s`; `ms_per_step_median_rep` for the spread).
+all repetitions (`repeats`, `timed_region_s`; `ms_per_step_median_rep` for the spread). Python's cyclic garbage
+collector is off while the legs run (as in `timeit`): with torch imported one full collection is a 35 ms pause of the
+calling thread, which a C++ caller of the library does not have.
 
 Which number is which.  `value` is measured with the clouds ALREADY RESIDENT IN HBM when the timed region starts
 (ufomap_map_insert_device, async=true), as the task's measurement rules prescribe.  SURVEY.md 8(d) defines the metric
@@ -211,6 +213,13 @@ def main():
     import torch
     import torch.distributed as dist
 
+    # The timed loops are Python: no cyclic garbage collection inside them (as `timeit` does it). With torch imported a full
+    # collection stops this thread for ~35 ms -- 800 scans' worth -- once in a few thousand calls; the library's own caller,
+    # a C++ node, has no such pauses (scripts/dev_ab.py shows the per-repetition spread with and without).
+    import gc
+    gc.collect()
+    gc.freeze()
+    gc.disable()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

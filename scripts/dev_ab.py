@@ -12,6 +12,11 @@ import torch  # noqa: E402
 from ufomap_amd import OccupancyMap, scans  # noqa: E402
 
 K, W = 40, 8
+if os.environ.get("NOGC"):
+    import gc
+    gc.collect()
+    gc.freeze()
+    gc.disable()
 clouds = [scans.lidar64(origin=scans.lidar_pose(s), seed=100 + s) for s in range(8)]
 d_clouds = [torch.from_numpy(c[1]).cuda() for c in clouds]
 n_pts = clouds[0][1].shape[0]
@@ -50,6 +55,9 @@ for spec in sys.argv[1:] or [""]:
     if ref_digest is None:
         ref_digest = dig
     ns = max(1, d1[61] - d0[61])
+    srt = np.sort(dts) / K * 1e3
+    print("   rep ms/scan: min %.4f p25 %.4f p50 %.4f p75 %.4f p90 %.4f max %.4f; reps slower than 1.3 x median: %d of %d" % (
+        srt[0], srt[len(srt) // 4], srt[len(srt) // 2], srt[3 * len(srt) // 4], srt[9 * len(srt) // 10], srt[-1], int((srt > 1.3 * srt[len(srt) // 2]).sum()), len(srt)))
     line = f"{spec:45s} ms/scan {np.sum(dts) / (K * len(dts)) * 1e3:.4f} (median rep {np.median(dts) / K * 1e3:.4f})  scans/walk {(d1[59] - d0[59]) / max(1, d1[60] - d0[60]):.2f}" \
            f"  host us/scan {(d1[55] - d0[55]) / ns * 1e-3:.1f} (scan-half enq {(d1[52] - d0[52]) / ns * 1e-3:.1f}, slot enq {(d1[53] - d0[53]) / ns * 1e-3:.1f}, join {(d1[54] - d0[54]) / ns * 1e-3:.1f})  redo {d1[63] - d0[63]} gate_to {d1[58]} same_map {dig == ref_digest}"
     m.reset_kernel_times()

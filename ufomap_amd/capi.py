@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libufomap_hip.so")
+LIB_PATH = os.environ.get("UFOMAP_HIP_LIB") or os.path.join(HERE, "csrc", "libufomap_hip.so")  # (the variable: developer A/B of two builds)
 
 UFOMAP_OK = 0
 ERR_INVALID, ERR_DEVICE, ERR_UNSUPPORTED, ERR_RUNAWAY, ERR_CAPACITY = -1, -2, -3, -4, -5
