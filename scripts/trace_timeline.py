@@ -9,8 +9,14 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 skip = float(sys.argv[2]) if len(sys.argv) > 2 else 0.3
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 t0, t1 = int(rows[0]["Start_Timestamp"]), int(rows[-1]["End_Timestamp"])
-lo = t0 + (t1 - t0) * skip
-rows = [r for r in rows if int(r["Start_Timestamp"]) >= lo]
+# the steady-state part: between the launches of the ray kernel at `skip` and at 95 % of its launches (a bench run ends with
+# self-check exports and starts with warm-up, neither of which is the pipeline)
+fc = [int(r["Start_Timestamp"]) for r in rows if "k_fcast" in r["Kernel_Name"]]
+if len(fc) > 20:
+    lo, hi = fc[int(len(fc) * skip)], fc[int(len(fc) * 0.95)]
+else:
+    lo, hi = t0 + (t1 - t0) * skip, t1
+rows = [r for r in rows if lo <= int(r["Start_Timestamp"]) <= hi]
 span = (int(rows[-1]["End_Timestamp"]) - int(rows[0]["Start_Timestamp"])) * 1e-3
 per_q = defaultdict(list)
 dur = defaultdict(list)
