@@ -321,7 +321,14 @@ int ufomap_map_insert_batch(ufomap_map* m, ufomap_comm* c, const double sensor_o
  * depth-0 scan as two passes over the tree instead of one; the environment variable UFOMAP_MERGE_PHASES
  * sets the default for new maps), "spec" (0: always read a scan's bounding boxes back before sizing its ray
  * grid; default 1: a depth-0 scan is enqueued on the grid predicted from the previous scan and repeated if it
- * does not fit), "fast" (0: never take the steady-state path of fast_kernels.h), "batch_max" (scans one walk of the tree may take when scans
+ * does not fit), "fast" (0: never take the steady-state path of fast_kernels.h), "fast_color" (0: colour maps keep to the
+ * general path), "big" (0: so do scans whose ray grid does not fit in LDS), "solo" (0: a synchronous call with nothing in
+ * flight uses the three pipeline streams like an asynchronous one instead of the map stream alone), "lazy_done" (0: the end
+ * of a scan half is published by a kernel of its own instead of the next scan's gate kernel), "cast_wgs" (workgroups of the
+ * steady-state ray kernel; default: one per CU for a synchronous call, on three CUs in four for asynchronous calls in a
+ * row), "cast_threads" / "cast_batch" / "cast_qcap" / "cast_prio" (its workgroup size, rays per round, segment queue
+ * entries, wave priority), "tstamps" (1: the hand-over kernels record the device clock, ufomap_map_timeline),
+ * "batch_max" (scans one walk of the tree may take when scans
  * have queued up behind the map stream: 1 .. 16, default 8), "hold" (test aid: a slot on the map stream for every hold-th
  * scan only, so that walks over several scans happen whatever the timing), "gate_us" (a stream hand-over gives up after
  * this long and the handle uses events from then on; default 20000), "cast_global" (0: grids
