@@ -1115,8 +1115,8 @@ __global__ void k_vol_begin(VolRec* __restrict__ rec, ScanCtl* ctl, u32 L)
 
 // One level of the descent: the records of depth `cd` nodes are [dl_start[cd], dl_start[cd-1]).
 // kill: blocks whose subtree deleteChildren removes (children at min_depth that had been expanded).
-__global__ __launch_bounds__(256) void k_vol_down(Table t, MapGeom g, VolArgs a, u32 cd, VolRec* __restrict__ rec, u32 rcap,
-                                                  u32* __restrict__ kill, u32 kcap, u32 scan_id, ScanCtl* ctl)
+__device__ inline void volDownLevel(const Table& t, const MapGeom& g, const VolArgs& a, u32 cd, VolRec* __restrict__ rec, u32 rcap, u32* __restrict__ kill,
+                                    u32 kcap, u32 scan_id, ScanCtl* ctl)
 {
 	const u32 lo = ctl->dl_start[cd], hi = min(ctl->dl_start[cd - 1], rcap);
 	const u32 max_probe = (t.mask >> 1) + 1;
@@ -1213,6 +1213,12 @@ __global__ __launch_bounds__(256) void k_vol_down(Table t, MapGeom g, VolArgs a,
 	if (__lane_id() == 0 && n_created) atomicAdd(&t.root->used, n_created);
 }
 
+__global__ __launch_bounds__(256) void k_vol_down(Table t, MapGeom g, VolArgs a, u32 cd, VolRec* __restrict__ rec, u32 rcap,
+                                                  u32* __restrict__ kill, u32 kcap, u32 scan_id, ScanCtl* ctl)
+{
+	volDownLevel(t, g, a, cd, rec, rcap, kill, kcap, scan_id, ctl);
+}
+
 // Breadth-first removal of subtrees: blocks kill[lo, hi) die, their live child blocks are appended.
 // The range bounds live in ctl->dbg[56] (lo) / ctl->n_codes (end of the list); k_vol_kill_mark advances lo.
 __global__ void k_vol_kill_mark(ScanCtl* ctl, u32 which)
@@ -1245,7 +1251,7 @@ __global__ __launch_bounds__(256) void k_vol_kill(Table t, u32* __restrict__ kil
 }
 
 // One level of the way back: `return !changed || updateNode(node, depth)` (OMB:1030) for the depth-`cd` records.
-__global__ __launch_bounds__(256) void k_vol_up(Table t, MapGeom g, u32 cd, VolRec* __restrict__ rec, u32 rcap, const ScanCtl* ctl)
+__device__ inline void volUpLevel(const Table& t, const MapGeom& g, u32 cd, VolRec* __restrict__ rec, u32 rcap, const ScanCtl* ctl)
 {
 	if (ctl->err) return;
 	const u32 lo = ctl->dl_start[cd], hi = min(ctl->dl_start[cd - 1], rcap);
@@ -1260,6 +1266,49 @@ __global__ __launch_bounds__(256) void k_vol_up(Table t, MapGeom g, u32 cd, VolR
 			ret = writeToParent(t, g, me.slot, me.lk, sm);
 		}
 		if (ret && me.parent != NONE) atomicOr(&rec[me.parent].changed, 1u);
+	}
+}
+
+__global__ __launch_bounds__(256) void k_vol_up(Table t, MapGeom g, u32 cd, VolRec* __restrict__ rec, u32 rcap, const ScanCtl* ctl)
+{
+	volUpLevel(t, g, cd, rec, rcap, ctl);
+}
+// A volume of a few thousand nodes at most (the robot's own box, cleared after every scan: server.cpp:122-160) at
+// min_depth 0: the whole descent and the way back by ONE workgroup, a barrier per level -- instead of three launches per
+// level (48 for 16 levels, ~4 us each and nothing to do in most of them).
+__global__ __launch_bounds__(1024) void k_vol_all(Table t, MapGeom g, VolArgs a, u32 L, VolRec* __restrict__ rec, u32 rcap, u32* __restrict__ kill, u32 kcap,
+                                                  u32 scan_id, ScanCtl* ctl)
+{
+	auto levelSync = [] {
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+		__syncthreads();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+	};
+	if (0 == threadIdx.x) {
+		VolRec r;
+		r.lk = 1;
+		r.c[0] = r.c[1] = r.c[2] = 0.0;
+		r.parent = NONE;
+		r.slot = NONE;
+		r.changed = 0;
+		r.pad = 0;
+		rec[0] = r;
+		ctl->dl_start[L] = 0;
+		ctl->dl_total = 1;
+		ctl->dl_start[L - 1] = 1;
+	}
+	levelSync();
+	for (u32 cd = L; cd > a.min_depth; --cd) {
+		volDownLevel(t, g, a, cd, rec, rcap, kill, kcap, scan_id, ctl);
+		levelSync();
+		if (cd - 1 > a.min_depth && cd >= 2) {
+			if (0 == threadIdx.x) ctl->dl_start[cd - 2] = ctl->dl_total;  // (k_coarse_mark)
+			levelSync();
+		}
+	}
+	for (u32 cd = a.min_depth + 1; cd <= L; ++cd) {
+		volUpLevel(t, g, cd, rec, rcap, ctl);
+		levelSync();
 	}
 }
 
@@ -1656,27 +1705,30 @@ __device__ inline bool serChildIn(const SerArgs& sa, const double c[3], u32 i, d
 	}
 	return volIntersects(va, cc, chs);
 }
+// EIGHT LANES PER BLOCK (lane = child): the children's lookups -- a hash probe each, a dependent chain of global loads --
+// run side by side instead of one after the other (the narrow levels are walked by one workgroup, a barrier per level:
+// their time is this chain times the number of levels), the sum is three xor shuffles.
 __device__ inline void serSizesLevel(const Table& t, const MapGeom& g, const SerArgs& sa, const u32* __restrict__ list, u32 n, u32 level, u32 D,
                                      u64* __restrict__ size)
 {
 	const double chs = g.hs[level - 1];
-	for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+	const u32 ch = threadIdx.x & 7u;
+	for (u32 i = (blockIdx.x * blockDim.x + threadIdx.x) >> 3; i < n; i += (gridDim.x * blockDim.x) >> 3) {  // (uniform per group of 8 lanes)
 		const u32 s = list[i];
 		const u64 lk = t.key(s);
-		double c[3];
+		double c[3] = {0, 0, 0};
 		if (sa.has_bv) keyCenter(g, lk, level, c);
 		const u32 f = t.flags(s);
-		u64 sz = (1 == level) ? 0 : 1;  // the eight leaves of a depth-1 node follow each other without a mask byte
-		for (u32 ch = 0; ch < 8; ++ch) {
-			if (!serChildIn(sa, c, ch, chs)) continue;
-			u64 add = D;
+		unsigned long long add = 0;
+		if (serChildIn(sa, c, ch, chs)) {
+			add = D;
 			if (level >= 2 && level - 1 > sa.min_depth && ((f >> (16 + ch)) & 1u)) {
 				const u32 cs = tableFind(t, (lk << 3) | (u64)ch);
 				if (cs != NONE && !(t.flags(cs) & F_DEAD)) add = size[cs];
 			}
-			sz += add;
 		}
-		size[s] = sz;
+		for (int o = 1; o < 8; o <<= 1) add += __shfl_xor(add, o);
+		if (0 == ch) size[s] = add + ((1 == level) ? 0ull : 1ull);  // the eight leaves of a depth-1 node follow each other without a mask byte
 	}
 }
 __global__ __launch_bounds__(256) void k_ser_sizes(Table t, MapGeom g, SerArgs sa, const u32* __restrict__ list, u32 n, u32 level, u32 D,
@@ -1702,53 +1754,47 @@ __global__ __launch_bounds__(1024) void k_ser_sizes_tail(Table t, MapGeom g, Ser
 }
 __device__ inline void serPutLeaf(uint8_t* __restrict__ out, u64 at, float v, u32 rgb, u32 D)
 {
-	u32 b;
-	memcpy(&b, &v, 4);
-	out[at] = (uint8_t)b;
-	out[at + 1] = (uint8_t)(b >> 8);
-	out[at + 2] = (uint8_t)(b >> 16);
-	out[at + 3] = (uint8_t)(b >> 24);
+	memcpy(out + at, &v, 4);  // (one unaligned 32-bit store: global memory takes them, and the stream has no alignment)
 	if (D > 4) {
 		out[at + 4] = (uint8_t)rgb;
 		out[at + 5] = (uint8_t)(rgb >> 8);
 		out[at + 6] = (uint8_t)(rgb >> 16);
 	}
 }
-// off[] is pre-set to ~0: a block whose offset nobody wrote lies outside the bounding volume (or below min_depth)
+// off[] is pre-set to ~0: a block whose offset nobody wrote lies outside the bounding volume (or below min_depth).
+// Eight lanes per block as in serSizesLevel; a child's position is a prefix sum over the children before it.
 __device__ inline void serWriteLevel(const Table& t, const MapGeom& g, const SerArgs& sa, const u32* __restrict__ list, u32 n, u32 level, u32 D,
                                      const u64* __restrict__ size, u64* __restrict__ off, uint8_t* __restrict__ out)
 {
 	const double chs = g.hs[level - 1];
-	for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+	const u32 ch = threadIdx.x & 7u;
+	for (u32 i = (blockIdx.x * blockDim.x + threadIdx.x) >> 3; i < n; i += (gridDim.x * blockDim.x) >> 3) {  // (uniform per group of 8 lanes)
 		const u32 s = list[i];
 		const u64 lk = t.key(s);
-		u64 at = (1 == lk) ? 1ull : off[s];  // the root's subtree starts behind the 0xFF byte of writeNodes
-		if (at == ~0ull) continue;
-		double c[3];
+		const u64 at0 = (1 == lk) ? 1ull : off[s];  // the root's subtree starts behind the 0xFF byte of writeNodes
+		if (at0 == ~0ull) continue;
+		double c[3] = {0, 0, 0};
 		if (sa.has_bv) keyCenter(g, lk, level, c);
 		const u32 f = t.flags(s);
-		u32 cslot[8];
-		u32 mask = 0;
-		for (u32 ch = 0; ch < 8; ++ch) {
-			cslot[ch] = NONE;
-			if (level >= 2 && level - 1 > sa.min_depth && ((f >> (16 + ch)) & 1u)) {
-				const u32 cs = tableFind(t, (lk << 3) | (u64)ch);
-				if (cs != NONE && !(t.flags(cs) & F_DEAD)) {
-					cslot[ch] = cs;
-					mask |= 1u << ch;
-				}
-			}
+		u32 cslot = NONE;
+		if (level >= 2 && level - 1 > sa.min_depth && ((f >> (16 + ch)) & 1u)) {
+			const u32 cs = tableFind(t, (lk << 3) | (u64)ch);
+			if (cs != NONE && !(t.flags(cs) & F_DEAD)) cslot = cs;
 		}
-		if (level >= 2) out[at++] = (uint8_t)mask;  // written for all eight children, intersecting or not (OMB:1500-1512)
-		for (u32 ch = 0; ch < 8; ++ch) {
-			if (!serChildIn(sa, c, ch, chs)) continue;
-			if (cslot[ch] != NONE) {
-				off[cslot[ch]] = at;
-				at += size[cslot[ch]];
-				continue;
-			}
-			serPutLeaf(out, at, t.occ(s)[ch], t.rgb ? t.rgb[8 * (size_t)s + ch] : 0u, D);
-			at += D;
+		u32 mask = (cslot != NONE) ? (1u << ch) : 0u;
+		for (int o = 1; o < 8; o <<= 1) mask |= (u32)__shfl_xor((int)mask, o);
+		const bool in = serChildIn(sa, c, ch, chs);
+		const unsigned long long w = in ? ((cslot != NONE) ? (unsigned long long)size[cslot] : (unsigned long long)D) : 0ull;
+		unsigned long long incl = w;
+		for (int o = 1; o < 8; o <<= 1) {
+			const unsigned long long v = __shfl_up(incl, o);
+			if ((int)ch >= o) incl += v;
+		}
+		const u64 at = at0 + ((level >= 2) ? 1ull : 0ull) + (incl - w);
+		if (0 == ch && level >= 2) out[at0] = (uint8_t)mask;  // written for all eight children, intersecting or not (OMB:1500-1512)
+		if (in) {
+			if (cslot != NONE) off[cslot] = at;
+			else serPutLeaf(out, at, t.occ(s)[ch], t.rgb ? t.rgb[8 * (size_t)s + ch] : 0u, D);
 		}
 	}
 }
@@ -1771,6 +1817,71 @@ __global__ __launch_bounds__(1024) void k_ser_write_tail(Table t, MapGeom g, Ser
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 		if (0 == l) break;
 	}
+}
+
+// ---- the same without the host in the middle (maps of up to a few hundred thousand blocks: what a server publishes after
+// every scan). The level counts stay on the device (k_ser_prefix turns them into the SerLevels the kernels read), the
+// output buffer is sized by the table's fill, the two widest levels get a launch each with a fixed grid, the rest is the
+// one-workgroup tail, and the last kernel copies the stream -- whose length only the device knows -- into pinned host
+// memory with 16-byte stores: ONE stream synchronisation per serialisation instead of three.
+__global__ void k_ser_prefix(u32* __restrict__ cnt /* [0..31] live blocks per level; out: [32..63] first list entry per level */, SerLevels* lv)
+{
+	if (0 != threadIdx.x) return;
+	u32 off = 0;
+	for (u32 l = 0; l < 32; ++l) {
+		lv->off[l] = off;
+		lv->cnt[l] = cnt[l];
+		cnt[32 + l] = off;
+		off += cnt[l];
+	}
+}
+__global__ __launch_bounds__(256) void k_ser_sizes_dev(Table t, MapGeom g, SerArgs sa, const u32* __restrict__ list, const SerLevels* lv, u32 level, u32 D,
+                                                       u64* __restrict__ size)
+{
+	if (lv->cnt[level]) serSizesLevel(t, g, sa, list + lv->off[level], lv->cnt[level], level, D, size);
+}
+__global__ __launch_bounds__(1024) void k_ser_sizes_tail_dev(Table t, MapGeom g, SerArgs sa, const u32* __restrict__ list, const SerLevels* lvp, u32 l_from,
+                                                             u32 l_to, u32 D, u64* __restrict__ size, unsigned long long* __restrict__ total_out)
+{
+	for (u32 l = l_from; l <= l_to; ++l) {
+		if (lvp->cnt[l]) serSizesLevel(t, g, sa, list + lvp->off[l], lvp->cnt[l], l, D, size);
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+		__syncthreads();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+	}
+	// (no live root block: the root is a leaf -- the host writes that stream itself; 0 tells it)
+	if (0 == threadIdx.x) *total_out = lvp->cnt[l_to] ? 1ull + size[list[lvp->off[l_to]]] : 0ull;
+}
+__global__ __launch_bounds__(256) void k_ser_write_dev(Table t, MapGeom g, SerArgs sa, const u32* __restrict__ list, const SerLevels* lv, u32 level, u32 D,
+                                                       const u64* __restrict__ size, u64* __restrict__ off, uint8_t* __restrict__ out, const unsigned long long* total,
+                                                       unsigned long long cap)
+{
+	if (0 == *total || *total > cap) return;  // (uniform)
+	if (lv->cnt[level]) serWriteLevel(t, g, sa, list + lv->off[level], lv->cnt[level], level, D, size, off, out);
+}
+__global__ __launch_bounds__(1024) void k_ser_write_tail_dev(Table t, MapGeom g, SerArgs sa, const u32* __restrict__ list, const SerLevels* lvp, u32 l_from,
+                                                             u32 l_to, u32 D, const u64* __restrict__ size, u64* __restrict__ off, uint8_t* __restrict__ out,
+                                                             const unsigned long long* total, unsigned long long cap)
+{
+	if (0 == *total || *total > cap) return;  // (uniform: nothing to write / the host's bound was too small -- it repeats the long way)
+	if (0 == threadIdx.x) out[0] = 0xFF;
+	for (u32 l = l_from; l + 1 > l_to; --l) {
+		if (lvp->cnt[l]) serWriteLevel(t, g, sa, list + lvp->off[l], lvp->cnt[l], l, D, size, off, out);
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+		__syncthreads();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+		if (0 == l) break;
+	}
+}
+__global__ __launch_bounds__(256) void k_ser_copy_out(const uint4* __restrict__ out, const unsigned long long* __restrict__ total, unsigned long long cap,
+                                                      uint4* __restrict__ h_out, unsigned long long* __restrict__ h_total)
+{
+	const unsigned long long n = *total;
+	if (n && n <= cap) {
+		const unsigned long long n4 = (n + 15ull) >> 4;
+		for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (unsigned long long)gridDim.x * blockDim.x) h_out[i] = out[i];
+	}
+	if (0 == (blockIdx.x | threadIdx.x)) *h_total = n;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -263,6 +263,10 @@ struct ufomap_map {
 	unsigned long long* h_prep = nullptr;  // pinned: integration number of the newest scan whose k_fhits has finished (k_signal)
 	uint64_t n_walks = 0, n_walk_scans = 0, n_gate_timeouts = 0;  // fast-path walks that applied scans, scans in them; stream hand-overs that timed out
 	int opt_batch_max = 8;        // scans a walk may take when scans have queued up behind the map stream (1 = one walk per scan)
+	int opt_vol_fused = 1;        // setValueVolume of a small volume at min_depth 0: one launch for all levels
+	int opt_ser_short = 1;        // serialisation without host round trips in the middle (maps up to 32 MiB of stream)
+	uint8_t* h_out = nullptr;     // ... its pinned output buffer
+	size_t h_out_cap = 0;
 	int opt_big = 1;              // ray grids beyond LDS on the fast path (k_fselect / k_cast<2> / k_up); 0: the general path
 	int opt_fast_color = 1;       // colour maps on the fast path (0: the general path, as before round 3)
 	int opt_solo = 1;             // synchronous calls with nothing in flight run on the map stream alone
@@ -2647,6 +2651,7 @@ void ufomap_map_destroy(ufomap_map* m)
 	if (m->h_root) (void)hipHostFree(m->h_root);
 	if (m->h_prep) (void)hipHostFree(m->h_prep);
 	if (m->h_ser) (void)hipHostFree(m->h_ser);
+	if (m->h_out) (void)hipHostFree(m->h_out);
 	for (DevBuf& b : m->b_ser) b.release();
 	if (m->done_ev) (void)hipEventDestroy(m->done_ev);
 	if (m->xstream) (void)hipStreamDestroy(m->xstream);
@@ -2943,6 +2948,10 @@ int ufomap_map_set_value_volume_ch(ufomap_map* m, const double aabb_center[3], c
 		HIP_TRY(m->b_dlist.reserve((size_t)kcap * 4));
 		VolRec* rec = m->b_crec.as<VolRec>();
 		u32* kill = m->b_dlist.as<u32>();
+		if (0 == min_depth && total <= 8192 && m->opt_vol_fused) {
+			// (a small volume: one workgroup walks all levels, map_kernels.h: k_vol_all)
+			hipLaunchKernelGGL(k_vol_all, dim3(1), dim3(1024), 0, m->cs, m->t, m->g, a, L, rec, rcap, kill, kcap, m->scan_id, ctl);
+		} else {
 		hipLaunchKernelGGL(k_vol_begin, dim3(1), dim3(1), 0, m->cs, rec, ctl, L);
 		for (u32 cd = L; cd > min_depth; --cd) {
 			hipLaunchKernelGGL(k_vol_down, gridFor(level_cap[cd], 256, 4096), dim3(256), 0, m->cs, m->t, m->g, a, cd, rec, rcap, kill, kcap,
@@ -2958,6 +2967,7 @@ int ufomap_map_set_value_volume_ch(ufomap_map* m, const double aabb_center[3], c
 		}
 		for (u32 cd = min_depth + 1; cd <= L; ++cd)
 			hipLaunchKernelGGL(k_vol_up, gridFor(level_cap[cd], 256, 4096), dim3(256), 0, m->cs, m->t, m->g, cd, rec, rcap, ctl);
+		}
 	}
 	HIP_TRY(hipGetLastError());
 	m->pending = true;
@@ -4449,6 +4459,72 @@ const Lz4& lz4()
 	return z;
 }
 
+// The node stream without the host in the middle (map_kernels.h: k_ser_prefix ... k_ser_copy_out): one synchronisation.
+// Returns 1 when the long way has to be taken (a map too large for the bound, no live root block).
+int serialiseNodesShort(ufomap_map* m, const SerArgs& sa, std::vector<uint8_t>& data)
+{
+	const u32 D = m->g.color ? 7u : 4u;
+	const u32 L = m->g.L;
+	if (!m->opt_ser_short || 0 == m->used_est || L <= sa.min_depth) return 1;
+	const u64 bound = 1ull + (u64)m->used_est * (1ull + 8ull * D) + 64ull;  // every block: a mask byte and eight leaf payloads at most
+	if (bound > (32ull << 20)) return 1;
+	DevBuf &b_cnt = m->b_ser[0], &b_list = m->b_ser[1], &b_size = m->b_ser[2], &b_off = m->b_ser[3], &b_out = m->b_ser[4];
+	const size_t ncap = (size_t)m->t.mask + 1;
+	HIP_TRY(b_cnt.reserve(3 * 32 * 4 + 16 + sizeof(SerLevels)));
+	HIP_TRY(b_list.reserve(((size_t)m->used_est + 8) * 4));
+	HIP_TRY(b_size.reserve(ncap * 8));
+	HIP_TRY(b_off.reserve(ncap * 8));
+	HIP_TRY(b_out.reserve((bound + 15) & ~15ull));
+	if (m->h_out_cap < bound) {
+		if (m->h_out) (void)hipHostFree(m->h_out);
+		m->h_out = nullptr;
+		m->h_out_cap = 0;
+		const size_t want = (size_t)((bound + bound / 2 + 4095) & ~4095ull);
+		HIP_TRY(hipHostMalloc((void**)&m->h_out, want));
+		m->h_out_cap = want;
+	}
+	if (!m->h_ser) HIP_TRY(hipHostMalloc((void**)&m->h_ser, 512));
+	volatile unsigned long long* h_total = reinterpret_cast<volatile unsigned long long*>(m->h_ser + 256);
+	u32* d_cnt = b_cnt.as<u32>();
+	unsigned long long* d_total = reinterpret_cast<unsigned long long*>(d_cnt + 96);
+	SerLevels* d_lv = reinterpret_cast<SerLevels*>(d_cnt + 100);
+	hipStream_t st = m->stream;
+	static const bool trace = nullptr != getenv("UFOMAP_TRACE_SER");
+	const auto t0 = std::chrono::steady_clock::now();
+	HIP_TRY(hipMemsetAsync(b_cnt.p, 0, 3 * 32 * 4 + 16, st));
+	hipLaunchKernelGGL(k_ser_count, gridFor((u64)m->t.mask + 1), dim3(256), 0, st, m->t, m->g, d_cnt);
+	hipLaunchKernelGGL(k_ser_prefix, dim3(1), dim3(64), 0, st, d_cnt, d_lv);
+	HIP_TRY(hipMemsetAsync(b_off.p, 0xFF, ncap * 8, st));
+	hipLaunchKernelGGL(k_ser_collect, gridFor((u64)m->t.mask + 1), dim3(256), 0, st, m->t, m->g, d_cnt + 32, d_cnt + 64, b_list.as<u32>());
+	const u32 first = std::max<u32>(1u, sa.min_depth + 1);  // blocks of nodes above min_depth
+	const u32 l_tail = std::min<u32>(first + 2u, L);        // the two widest levels: a launch each; the rest: one workgroup
+	for (u32 l = first; l < l_tail; ++l)
+		hipLaunchKernelGGL(k_ser_sizes_dev, dim3(1024), dim3(256), 0, st, m->t, m->g, sa, b_list.as<u32>(), d_lv, l, D, b_size.as<u64>());
+	hipLaunchKernelGGL(k_ser_sizes_tail_dev, dim3(1), dim3(1024), 0, st, m->t, m->g, sa, b_list.as<u32>(), d_lv, l_tail, L, D, b_size.as<u64>(), d_total);
+	const unsigned long long cap = bound;
+	hipLaunchKernelGGL(k_ser_write_tail_dev, dim3(1), dim3(1024), 0, st, m->t, m->g, sa, b_list.as<u32>(), d_lv, L, l_tail, D, b_size.as<u64>(), b_off.as<u64>(),
+	                   b_out.as<uint8_t>(), d_total, cap);
+	for (u32 l = l_tail; l-- > first;)
+		hipLaunchKernelGGL(k_ser_write_dev, dim3(1024), dim3(256), 0, st, m->t, m->g, sa, b_list.as<u32>(), d_lv, l, D, b_size.as<u64>(), b_off.as<u64>(),
+		                   b_out.as<uint8_t>(), d_total, cap);
+	hipLaunchKernelGGL(k_ser_copy_out, dim3(128), dim3(256), 0, st, b_out.as<uint4>(), d_total, cap, reinterpret_cast<uint4*>(m->h_out),
+	                   const_cast<unsigned long long*>(h_total));
+	HIP_TRY(hipGetLastError());
+	const auto t1 = std::chrono::steady_clock::now();
+	HIP_TRY(hipStreamSynchronize(st));
+	const auto t2 = std::chrono::steady_clock::now();
+	const u64 total = *h_total;
+	if (trace) {
+		auto us = [](auto a, auto b) { return (double)std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count() * 1e-3; };
+		fprintf(stderr, "[ufomap] serialise: enqueue %.1f us, wait %.1f us, %llu bytes, table %llu slots, %llu used\n", us(t0, t1), us(t1, t2),
+		        (unsigned long long)total, (unsigned long long)m->t.mask + 1, (unsigned long long)m->used_est);
+	}
+	if (0 == total || total > cap) return 1;  // the root is a leaf / more than the bound (cannot happen): the long way
+	if (total > 0x7FFFFFFFull) return fail(UFOMAP_ERR_CAPACITY, "map byte stream exceeds 2^31 bytes (the reference's size field is an int)");
+	data.assign(m->h_out, m->h_out + total);
+	return UFOMAP_OK;
+}
+
 // the node stream of writeNodes (occupancy_map_base.h:1457-1533) for the whole map or the part inside a bounding volume
 int serialiseNodes(ufomap_map* m, const SerArgs& sa, std::vector<uint8_t>& data)
 {
@@ -4464,6 +4540,11 @@ int serialiseNodes(ufomap_map* m, const SerArgs& sa, std::vector<uint8_t>& data)
 			if (!(min1 <= max2) || !(min2 <= max1)) return UFOMAP_OK;
 		}
 	}
+	{
+		const int src = serialiseNodesShort(m, sa, data);
+		if (src <= 0) return src;
+		data.clear();
+	}
 	// (scratch kept with the map: a publish per scan must not pay five allocations)
 	DevBuf &b_cnt = m->b_ser[0], &b_list = m->b_ser[1], &b_size = m->b_ser[2], &b_off = m->b_ser[3], &b_out = m->b_ser[4];
 	if (!m->h_ser) HIP_TRY(hipHostMalloc((void**)&m->h_ser, 512));
@@ -4471,7 +4552,7 @@ int serialiseNodes(ufomap_map* m, const SerArgs& sa, std::vector<uint8_t>& data)
 	MapRoot* h_root = reinterpret_cast<MapRoot*>(m->h_ser + 128);
 	unsigned long long* h_total = reinterpret_cast<unsigned long long*>(m->h_ser + 256);
 	u32 h_off[32] = {0};
-	HIP_TRY(b_cnt.reserve(3 * 32 * 4 + 16));
+	HIP_TRY(b_cnt.reserve(3 * 32 * 4 + 16 + sizeof(SerLevels)));
 	HIP_TRY(hipMemsetAsync(b_cnt.p, 0, 3 * 32 * 4 + 16, m->stream));
 	u32* d_cnt = b_cnt.as<u32>();
 	unsigned long long* d_total = reinterpret_cast<unsigned long long*>(d_cnt + 96);
@@ -4515,7 +4596,7 @@ int serialiseNodes(ufomap_map* m, const SerArgs& sa, std::vector<uint8_t>& data)
 	while (l_tail > first && h_cnt[l_tail - 1] <= 2048u) --l_tail;
 	for (u32 l = first; l < l_tail; ++l)
 		if (h_cnt[l])
-			hipLaunchKernelGGL(k_ser_sizes, gridFor(h_cnt[l]), dim3(256), 0, m->stream, m->t, m->g, sa, b_list.as<u32>() + h_off[l], h_cnt[l], l, D,
+			hipLaunchKernelGGL(k_ser_sizes, gridFor((u64)h_cnt[l] * 8u), dim3(256), 0, m->stream, m->t, m->g, sa, b_list.as<u32>() + h_off[l], h_cnt[l], l, D,
 			                   b_size.as<u64>());
 	hipLaunchKernelGGL(k_ser_sizes_tail, dim3(1), dim3(1024), 0, m->stream, m->t, m->g, sa, b_list.as<u32>(), lv, l_tail, L, D, b_size.as<u64>(), d_total);
 	HIP_TRY(hipMemcpyAsync(h_total, d_total, 8, hipMemcpyDeviceToHost, m->stream));
@@ -4527,7 +4608,7 @@ int serialiseNodes(ufomap_map* m, const SerArgs& sa, std::vector<uint8_t>& data)
 	                   b_out.as<uint8_t>());
 	for (u32 l = l_tail; l-- > first;)
 		if (h_cnt[l])
-			hipLaunchKernelGGL(k_ser_write, gridFor(h_cnt[l]), dim3(256), 0, m->stream, m->t, m->g, sa, b_list.as<u32>() + h_off[l], h_cnt[l], l, D,
+			hipLaunchKernelGGL(k_ser_write, gridFor((u64)h_cnt[l] * 8u), dim3(256), 0, m->stream, m->t, m->g, sa, b_list.as<u32>() + h_off[l], h_cnt[l], l, D,
 			                   b_size.as<u64>(), b_off.as<u64>(), b_out.as<uint8_t>());
 	data.resize(total);
 	HIP_TRY(hipMemcpyAsync(data.data(), b_out.p, total, hipMemcpyDeviceToHost, m->stream));
@@ -4932,6 +5013,10 @@ int ufomap_map_set_option(ufomap_map* m, const char* key, long long value)
 			m->b_ts.release();
 		}
 		HIP_TRY(hipMemcpy(reinterpret_cast<char*>(m->b_pipe.p) + offsetof(Pipe, ts), &ts, sizeof(ts), hipMemcpyHostToDevice));
+	} else if (0 == strcmp(key, "vol_fused")) {
+		m->opt_vol_fused = value ? 1 : 0;
+	} else if (0 == strcmp(key, "ser_short")) {
+		m->opt_ser_short = value ? 1 : 0;
 	} else if (0 == strcmp(key, "big")) {
 		m->opt_big = value ? 1 : 0;
 	} else if (0 == strcmp(key, "fast_color")) {
