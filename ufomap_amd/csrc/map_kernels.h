@@ -1873,10 +1873,92 @@ __global__ __launch_bounds__(1024) void k_ser_write_tail_dev(Table t, MapGeom g,
 		if (0 == l) break;
 	}
 }
+// Both passes over the narrow levels by ONE workgroup in one launch: sizes bottom-up, then offsets and bytes top-down,
+// with what the first pass found out about every child (its block's slot, its share of the stream) kept in LDS -- the
+// second pass costs no hash probe and no flag word, i.e. one dependent global load per level (the block's own offset)
+// instead of five. Up to UFO_SER_TAIL_MAX blocks in these levels (else the two separate kernels).
+#define UFO_SER_TAIL_MAX 2048u
+__global__ __launch_bounds__(1024) void k_ser_tail_dev(Table t, MapGeom g, SerArgs sa, const u32* __restrict__ list, const SerLevels* lvp, u32 l_tail, u32 L,
+                                                       u32 D, u64* __restrict__ size, u64* __restrict__ off, uint8_t* __restrict__ out,
+                                                       unsigned long long* __restrict__ total_out, unsigned long long cap)
+{
+	__shared__ u32 cw[UFO_SER_TAIL_MAX][8], cs_[UFO_SER_TAIL_MAX][8];  // per child: bytes it contributes (0: outside the volume), slot of its block (NONE: a leaf)
+	__shared__ u32 lo[32], ln[32];
+	if (threadIdx.x < 32u) {
+		lo[threadIdx.x] = lvp->off[threadIdx.x];
+		ln[threadIdx.x] = lvp->cnt[threadIdx.x];
+	}
+	__syncthreads();
+	const u32 base = lo[l_tail];
+	if (lo[L] + ln[L] - base > UFO_SER_TAIL_MAX) {  // (uniform) more blocks than the LDS arrays hold: the host takes the long way
+		if (0 == threadIdx.x) *total_out = ~0ull;
+		return;
+	}
+	const u32 ch = threadIdx.x & 7u;
+	auto levelSync = [] {
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+		__syncthreads();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+	};
+	// ---- sizes, bottom-up (serSizesLevel, eight lanes per block) ----
+	for (u32 l = l_tail; l <= L; ++l) {
+		const double chs = g.hs[l - 1];
+		for (u32 i = threadIdx.x >> 3; i < ln[l]; i += blockDim.x >> 3) {
+			const u32 j = lo[l] - base + i;
+			const u32 s = list[lo[l] + i];
+			const u64 lk = t.key(s);
+			double c[3] = {0, 0, 0};
+			if (sa.has_bv) keyCenter(g, lk, l, c);
+			const u32 f = t.flags(s);
+			unsigned long long add = 0;
+			u32 cslot = NONE;
+			if (l >= 2 && l - 1 > sa.min_depth && ((f >> (16 + ch)) & 1u)) {
+				const u32 cs = tableFind(t, (lk << 3) | (u64)ch);
+				if (cs != NONE && !(t.flags(cs) & F_DEAD)) cslot = cs;
+			}
+			if (serChildIn(sa, c, ch, chs)) add = (cslot != NONE) ? size[cslot] : (unsigned long long)D;
+			cw[j][ch] = (u32)add;
+			cs_[j][ch] = cslot;
+			for (int o = 1; o < 8; o <<= 1) add += __shfl_xor(add, o);
+			if (0 == ch) size[s] = add + ((1 == l) ? 0ull : 1ull);
+		}
+		levelSync();
+	}
+	const unsigned long long total = ln[L] ? 1ull + size[list[lo[L]]] : 0ull;  // (no live root block: the root is a leaf, the host writes that stream itself)
+	if (0 == threadIdx.x) *total_out = total;
+	if (0 == total || total > cap) return;  // (uniform; too large for the host's bound cannot happen)
+	// ---- offsets and bytes, top-down (serWriteLevel) ----
+	if (0 == threadIdx.x) out[0] = 0xFF;
+	for (u32 l = L; l + 1 > l_tail; --l) {
+		for (u32 i = threadIdx.x >> 3; i < ln[l]; i += blockDim.x >> 3) {
+			const u32 j = lo[l] - base + i;
+			const u32 s = list[lo[l] + i];
+			const u64 at0 = (l == L) ? 1ull : off[s];  // the root's subtree starts behind the 0xFF byte of writeNodes
+			if (at0 == ~0ull) continue;
+			const u32 w = cw[j][ch], cslot = cs_[j][ch];
+			u32 mask = (cslot != NONE) ? (1u << ch) : 0u;
+			for (int o = 1; o < 8; o <<= 1) mask |= (u32)__shfl_xor((int)mask, o);
+			u32 incl = w;
+			for (int o = 1; o < 8; o <<= 1) {
+				const u32 v = (u32)__shfl_up((int)incl, o);
+				if ((int)ch >= o) incl += v;
+			}
+			const u64 at = at0 + ((l >= 2) ? 1ull : 0ull) + (u64)(incl - w);
+			if (0 == ch && l >= 2) out[at0] = (uint8_t)mask;
+			if (w) {
+				if (cslot != NONE) off[cslot] = at;
+				else serPutLeaf(out, at, t.occ(s)[ch], t.rgb ? t.rgb[8 * (size_t)s + ch] : 0u, D);
+			}
+		}
+		levelSync();
+		if (0 == l) break;
+	}
+}
 __global__ __launch_bounds__(256) void k_ser_copy_out(const uint4* __restrict__ out, const unsigned long long* __restrict__ total, unsigned long long cap,
-                                                      uint4* __restrict__ h_out, unsigned long long* __restrict__ h_total)
+                                                      uint4* __restrict__ h_out, unsigned long long* __restrict__ h_total, const SerLevels* lv, u32 l_tail, u32 L)
 {
 	const unsigned long long n = *total;
+	if (0 == (blockIdx.x | threadIdx.x)) h_total[1] = lv->off[L] + lv->cnt[L] - lv->off[l_tail];  // blocks in the narrow levels: the host's choice next time
 	if (n && n <= cap) {
 		const unsigned long long n4 = (n + 15ull) >> 4;
 		for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (unsigned long long)gridDim.x * blockDim.x) h_out[i] = out[i];

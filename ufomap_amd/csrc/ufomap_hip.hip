@@ -263,6 +263,7 @@ struct ufomap_map {
 	unsigned long long* h_prep = nullptr;  // pinned: integration number of the newest scan whose k_fhits has finished (k_signal)
 	uint64_t n_walks = 0, n_walk_scans = 0, n_gate_timeouts = 0;  // fast-path walks that applied scans, scans in them; stream hand-overs that timed out
 	int opt_batch_max = 8;        // scans a walk may take when scans have queued up behind the map stream (1 = one walk per scan)
+	u32 ser_tail_blocks = 0xFFFFFFFFu, ser_tail_first = 0;  // blocks in the serialiser's narrow levels as the last serialisation found them
 	int opt_vol_fused = 1;        // setValueVolume of a small volume at min_depth 0: one launch for all levels
 	int opt_ser_short = 1;        // serialisation without host round trips in the middle (maps up to 32 MiB of stream)
 	uint8_t* h_out = nullptr;     // ... its pinned output buffer
@@ -4500,26 +4501,35 @@ int serialiseNodesShort(ufomap_map* m, const SerArgs& sa, std::vector<uint8_t>& 
 	const u32 l_tail = std::min<u32>(first + 2u, L);        // the two widest levels: a launch each; the rest: one workgroup
 	for (u32 l = first; l < l_tail; ++l)
 		hipLaunchKernelGGL(k_ser_sizes_dev, dim3(1024), dim3(256), 0, st, m->t, m->g, sa, b_list.as<u32>(), d_lv, l, D, b_size.as<u64>());
-	hipLaunchKernelGGL(k_ser_sizes_tail_dev, dim3(1), dim3(1024), 0, st, m->t, m->g, sa, b_list.as<u32>(), d_lv, l_tail, L, D, b_size.as<u64>(), d_total);
 	const unsigned long long cap = bound;
-	hipLaunchKernelGGL(k_ser_write_tail_dev, dim3(1), dim3(1024), 0, st, m->t, m->g, sa, b_list.as<u32>(), d_lv, L, l_tail, D, b_size.as<u64>(), b_off.as<u64>(),
-	                   b_out.as<uint8_t>(), d_total, cap);
+	// (the narrow levels: both passes in one launch when they hold few enough blocks for its LDS -- as the previous
+	// serialisation of this map found; should the map have outgrown that since, the kernel says so and the long way is taken)
+	if (m->ser_tail_blocks <= UFO_SER_TAIL_MAX - 64u && m->ser_tail_first == l_tail) {
+		hipLaunchKernelGGL(k_ser_tail_dev, dim3(1), dim3(1024), 0, st, m->t, m->g, sa, b_list.as<u32>(), d_lv, l_tail, L, D, b_size.as<u64>(), b_off.as<u64>(),
+		                   b_out.as<uint8_t>(), d_total, cap);
+	} else {
+		hipLaunchKernelGGL(k_ser_sizes_tail_dev, dim3(1), dim3(1024), 0, st, m->t, m->g, sa, b_list.as<u32>(), d_lv, l_tail, L, D, b_size.as<u64>(), d_total);
+		hipLaunchKernelGGL(k_ser_write_tail_dev, dim3(1), dim3(1024), 0, st, m->t, m->g, sa, b_list.as<u32>(), d_lv, L, l_tail, D, b_size.as<u64>(), b_off.as<u64>(),
+		                   b_out.as<uint8_t>(), d_total, cap);
+	}
 	for (u32 l = l_tail; l-- > first;)
 		hipLaunchKernelGGL(k_ser_write_dev, dim3(1024), dim3(256), 0, st, m->t, m->g, sa, b_list.as<u32>(), d_lv, l, D, b_size.as<u64>(), b_off.as<u64>(),
 		                   b_out.as<uint8_t>(), d_total, cap);
 	hipLaunchKernelGGL(k_ser_copy_out, dim3(128), dim3(256), 0, st, b_out.as<uint4>(), d_total, cap, reinterpret_cast<uint4*>(m->h_out),
-	                   const_cast<unsigned long long*>(h_total));
+	                   const_cast<unsigned long long*>(h_total), d_lv, l_tail, L);
 	HIP_TRY(hipGetLastError());
 	const auto t1 = std::chrono::steady_clock::now();
 	HIP_TRY(hipStreamSynchronize(st));
 	const auto t2 = std::chrono::steady_clock::now();
 	const u64 total = *h_total;
+	m->ser_tail_blocks = (u32)std::min<unsigned long long>((unsigned long long)h_total[1], 0xFFFFFFFFull);
+	m->ser_tail_first = l_tail;
 	if (trace) {
 		auto us = [](auto a, auto b) { return (double)std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count() * 1e-3; };
-		fprintf(stderr, "[ufomap] serialise: enqueue %.1f us, wait %.1f us, %llu bytes, table %llu slots, %llu used\n", us(t0, t1), us(t1, t2),
-		        (unsigned long long)total, (unsigned long long)m->t.mask + 1, (unsigned long long)m->used_est);
+		fprintf(stderr, "[ufomap] serialise: enqueue %.1f us, wait %.1f us, %llu bytes, table %llu slots, %llu used, %u blocks in the narrow levels (from level %u)\n", us(t0, t1), us(t1, t2),
+		        (unsigned long long)total, (unsigned long long)m->t.mask + 1, (unsigned long long)m->used_est, m->ser_tail_blocks, m->ser_tail_first);
 	}
-	if (0 == total || total > cap) return 1;  // the root is a leaf / more than the bound (cannot happen): the long way
+	if (0 == total || total > cap) return 1;  // the root is a leaf / the narrow levels outgrew the one-launch form / more than the bound: the long way
 	if (total > 0x7FFFFFFFull) return fail(UFOMAP_ERR_CAPACITY, "map byte stream exceeds 2^31 bytes (the reference's size field is an int)");
 	data.assign(m->h_out, m->h_out + total);
 	return UFOMAP_OK;
