@@ -264,6 +264,7 @@ struct ufomap_map {
 	uint64_t n_walks = 0, n_walk_scans = 0, n_gate_timeouts = 0;  // fast-path walks that applied scans, scans in them; stream hand-overs that timed out
 	int opt_batch_max = 8;        // scans a walk may take when scans have queued up behind the map stream (1 = one walk per scan)
 	u32 ser_tail_blocks = 0xFFFFFFFFu, ser_tail_first = 0;  // blocks in the serialiser's narrow levels as the last serialisation found them
+	int n_cus = 256;              // compute units of the device (the ray kernel's LDS allows one workgroup on each)
 	int opt_vol_fused = 1;        // setValueVolume of a small volume at min_depth 0: one launch for all levels
 	int opt_ser_short = 1;        // serialisation without host round trips in the middle (maps up to 32 MiB of stream)
 	uint8_t* h_out = nullptr;     // ... its pinned output buffer
@@ -1420,7 +1421,7 @@ int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, si
 		// of asynchronous scans it shares the chip with the first-point pass of the next scan and the tree update of the
 		// scan before: with a workgroup on three CUs in four it does not wait for the last CUs those kernels hold, and they
 		// have CUs where nothing else competes (measured, scripts/dev_ab.py cast_wgs=...: 256 -> 0.052, 192 -> 0.046 ms/scan).
-		u32 nwg = m->opt_cast_wgs > 0 ? (u32)m->opt_cast_wgs : (lazy_done ? 192u : 256u);
+		u32 nwg = m->opt_cast_wgs > 0 ? (u32)m->opt_cast_wgs : (lazy_done ? (u32)(3 * m->n_cus / 4) : (u32)m->n_cus);
 		nwg = std::max<u32>(1u, std::min<u32>(nwg, (N + 63u) / 64u));
 		const u32 cap_wg = (N + nwg - 1) / nwg;
 		HIP_TRY(m->b_ray_end.reserve((size_t)cap_wg * nwg * sizeof(D3)));
@@ -2544,6 +2545,10 @@ ufomap_map* ufomap_map_create(double resolution, unsigned depth_levels, int auto
 	// priority never share one: two pipeline streams on one hardware queue run strictly one after the other, a gate
 	// spinning in front of the work it waits for. (Measured with several handles created one after the other in one
 	// process: 0.066 ms per scan when the streams happened to get queues of their own, 0.106 when two shared one.)
+	{
+		int cus = 0;
+		if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) m->n_cus = cus;
+	}
 	int prio_lo = 0, prio_hi = 0;
 	(void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);  // (least, greatest: numerically lower = higher priority)
 	const int prio_mid = (prio_lo + prio_hi) / 2;
