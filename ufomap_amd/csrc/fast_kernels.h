@@ -1,9 +1,13 @@
-// fast_kernels.h -- the steady-state pipeline of a depth-0 scan whose ray grid fits in LDS (every LiDAR-sized scan):
+// fast_kernels.h -- the steady-state pipeline of a depth-0 scan on a predicted ray grid (plain and colour maps):
 //
 //   prep stream   k_fhits  (k_signal)                                   (needs only the cloud; keeps the points for a repeat)
-//   scan stream            (k_gate) k_fcast  (k_scan_done)              (never touches the map)
+//   scan stream            (k_done_gate) k_fcast                        (never touches the map; k_done_gate = the end of the
+//                                                                        previous scan half + this one's gate, one launch)
 //   map stream                               (k_claim) k_fmerge  k_tile  k_ftail     ONE walk of the tree for every scan
 //                                                                                     that has queued up by then
+//   a ray grid beyond LDS (up to 65 536 tiles): k_fselect + k_cast<2> (scan_kernels.h) instead of k_fcast, and k_up --
+//   level 4 of the tree in parallel -- between k_tile and k_ftail; a synchronous call with nothing in flight: the five
+//   kernels on the map stream alone, no hand-over kernels
 //
 // four working launches per scan on the streams that matter, and the three of the map stream are shared by all the scans
 // a walk takes -- where the general path (scan_kernels.h / map_kernels.h: classify, select, reduce_boxes, hitmark, cast,
@@ -25,8 +29,8 @@
 //     holds them in LDS (k_ftail), where a level costs a barrier instead of a round trip to HBM;
 //   * which scans a walk takes is decided on the device when the walk starts (k_claim): whatever has queued up.
 // Semantics are those of the general path (map_kernels.h: "last-update chain"), which stays in place for everything
-// else -- first scans, insert depth > 0, grids beyond LDS, colour maps -- and doubles as the on-GPU cross-check of this
-// file (tests run both on the same scans).
+// else -- first scans, insert depth > 0, simple ray casting, more than 1022 cells per axis -- and doubles as the on-GPU
+// cross-check of this file (tests run both on the same scans).
 #pragma once
 #include "map_kernels.h"
 

@@ -4,12 +4,15 @@
 //
 // Launch sequence of one depth-0 integration in the steady state (doInsert; fast_kernels.h):
 //   prep stream: [H2D of a host cloud] -> k_fhits -> k_signal
-//   scan stream: k_gate -> k_fcast -> k_scan_done (the scan's descriptor and number become visible to the walks)
+//   scan stream: k_done_gate (the descriptor and number of the scan half BEFORE become visible to the walks; then the gate
+//                of this one: waits for k_signal) -> k_fcast [a grid beyond LDS: memsets -> k_fselect -> k_cast<2>]
 //   map stream:  k_claim (waits for the scan half; takes every scan that is ready along) -> k_fmerge -> k_tile (looks at
 //                the predecessor's status) -> k_ftail (stores the finished control blocks and the scans' numbers into
-//                pinned host memory) -- ONE slot for all the scans it takes; no slot of its own for a scan while two are waiting
+//                pinned host memory) [a grid beyond LDS: k_up between k_tile and k_ftail] -- ONE slot for all the scans it
+//                takes; no slot of its own for a scan while two are waiting. A synchronous call with nothing in flight:
+//                k_fhits -> k_fcast -> k_fmerge -> k_tile -> k_ftail on the map stream alone.
 //   join (of integrations that have completed): the host polls those words; no copy, no stream synchronisation
-// First scans, colour maps, insert depth > 0, grids beyond LDS (the general path):
+// First scans, insert depth > 0, simple ray casting, > 1022 cells per axis (the general path):
 //   scan stream: memset hit hash -> control block H2D -> k_classify -> k_select -> k_reduce_boxes (checks the
 //                predicted ray grid) -> k_hitmark -> k_cast<0|2> -> [k_merge_slabs] -> k_extract_bits -> k_extract_hits
 //   map stream:  [waits for the scan's event] k_ensure -> k_init_new -> k_apply_leaf -> k_propagate x wide levels ->
@@ -1613,7 +1616,8 @@ int enqueueSlot(ufomap_map* m, int k)
 	{
 		ProfScope ps(m, "k_fmerge");
 		const u32 n4 = (u32)(fg.gr.bytes >> 4);
-		hipLaunchKernelGGL(k_fmerge, dim3(std::min<u32>((n4 + 63) / 64, 1024) + 1u), dim3(1024), 0, m->cs, fg, pipe, (unsigned long long)f, n4);
+		// (a grid beyond LDS has no slabs to merge: sixteen of the kernel's seventeen waves per workgroup would only meet at its barriers)
+		hipLaunchKernelGGL(k_fmerge, dim3(std::min<u32>((n4 + 63) / 64, 1024) + 1u), dim3(big_grid ? 64 : 1024), 0, m->cs, fg, pipe, (unsigned long long)f, n4);
 	}
 	const float miss = (float)m->g.miss_log;  // insert depth 0 (OMB:311)
 	{
