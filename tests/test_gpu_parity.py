@@ -276,6 +276,14 @@ def test_pointcloud2_ingest_fused_equals_reference_chain(color):
         assert cxyz.shape[0] < n
         o.insert(t, cxyz, crgb if color else None, max_range=15.0, discrete=True)
         _assert_same_map(g, o, f"pointcloud2 scan {s}")
+    # the same records again from the last pose: on the ray grid predicted from the scans before, i.e. through the tiled tree
+    # update -- colours included (they reach it in the set's own array, written by the first kernel that loads the points)
+    before = g.debug()[61]
+    for _ in range(2):
+        g.insertPointCloud2(t, q, buf, step, oxyz, orgb if color else None, max_range=15.0)
+        o.insert(t, cxyz, crgb if color else None, max_range=15.0, discrete=True)
+    _assert_same_map(g, o, "pointcloud2, repeated scans")
+    assert g.debug()[61] > before, "PointCloud2 records did not take the fast path"
 
 
 @pytest.mark.parametrize("color", [False, True])

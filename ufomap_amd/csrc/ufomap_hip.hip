@@ -2206,7 +2206,9 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 	bool spec = (0 == spec_mode ? (m->opt_spec && m->spec_valid) : false) && merged && !simple && 0 == early_stopping && n > 0 &&
 	            n <= (1u << 29) && !(d_rgb && !m->g.color);
 	// the fast path (fast_kernels.h): the whole scan on the predicted grid in five launches, the tree update tiled
-	const bool fast = spec && fastEligible(m, m->spec_grid, depth, simple, d_rgb, n, discrete) && nullptr == m->ing.rgb_out;
+	// (PointCloud2 records with colours: the first kernel that loads the points -- k_fhits here -- leaves the colours in the
+	// set's own array, Ingest::rgb_out, which is what the tree update reads)
+	const bool fast = spec && fastEligible(m, m->spec_grid, depth, simple, d_rgb, n, discrete);
 	if (spec && !fast && !gridFitsLds(m->spec_grid)) spec = false;  // (grids beyond LDS are predicted for the fast path only)
 	{
 		ScanArgs& a = m->args;
