@@ -9,7 +9,10 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
-from ufomap_amd import OccupancyMap, scans  # noqa: E402
+from ufomap_amd import OccupancyMap, OccupancyMapColor, scans  # noqa: E402
+
+RES = float(os.environ.get("RES", "0.16"))       # leaf size (0.08: the ray grid lives in HBM)
+COLOR = bool(int(os.environ.get("COLOR", "0")))  # colour map + coloured clouds
 
 K, W = 40, 8
 if os.environ.get("NOGC"):
@@ -17,8 +20,9 @@ if os.environ.get("NOGC"):
     gc.collect()
     gc.freeze()
     gc.disable()
-clouds = [scans.lidar64(origin=scans.lidar_pose(s), seed=100 + s) for s in range(8)]
+clouds = [scans.lidar64(origin=scans.lidar_pose(s), seed=100 + s, colored=COLOR) for s in range(8)]
 d_clouds = [torch.from_numpy(c[1]).cuda() for c in clouds]
+d_rgb = [torch.from_numpy(c[2]).cuda() if COLOR else None for c in clouds]
 n_pts = clouds[0][1].shape[0]
 
 
@@ -28,12 +32,12 @@ def run(m, reps):
         m.insertPointCloudWait()
         m.clear()
         for i in range(W):
-            m.insert_device(clouds[i % 8][0], d_clouds[i % 8].data_ptr(), None, n_pts, 20.0, 0, discrete=True, async_=True)
+            m.insert_device(clouds[i % 8][0], d_clouds[i % 8].data_ptr(), d_rgb[i % 8].data_ptr() if COLOR else None, n_pts, 20.0, 0, discrete=True, async_=True)
         m.insertPointCloudWait()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(W, W + K):
-            m.insert_device(clouds[i % 8][0], d_clouds[i % 8].data_ptr(), None, n_pts, 20.0, 0, discrete=True, async_=True)
+            m.insert_device(clouds[i % 8][0], d_clouds[i % 8].data_ptr(), d_rgb[i % 8].data_ptr() if COLOR else None, n_pts, 20.0, 0, discrete=True, async_=True)
         m.insertPointCloudWait()
         torch.cuda.synchronize()
         dts.append(time.perf_counter() - t0)
@@ -42,7 +46,7 @@ def run(m, reps):
 
 ref_digest = None
 for spec in sys.argv[1:] or [""]:
-    m = OccupancyMap(0.16)
+    m = (OccupancyMapColor if COLOR else OccupancyMap)(RES)
     for kv in spec.split(","):
         if kv:
             k, v = kv.split("=")
