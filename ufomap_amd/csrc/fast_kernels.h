@@ -518,11 +518,10 @@ __global__ __launch_bounds__(1024) void k_fcast(MapGeom g, FastGeo fg, D3 sensor
 			total += sh[wv];
 			nray2 += sh[16 + wv];
 		}
-		// K = k_min unless the queue cannot hold the segments that gives: then the K that is certain to fit (w is rounded
-		// down: at most 2 * total / K + one segment per ray)
+		// K = k_min unless the queue cannot hold the segments that gives: then the K that is certain to fit
 		u32 K = k_min;
 		const u32 room = qcap - nray2;  // >= qcap - batch > 0
-		const u32 need = (2u * total + room - 1u) / room;
+		const u32 need = (total + room - 1u) / room + 3u;  // (scan_kernels.h, k_cast: at most l1/(K-3) + 1 segments per ray)
 		u32 w = 1, nseg = 0, off = 0, nsegs = 0;
 		for (u32 attempt = 0;; ++attempt) {
 			w = 1;

@@ -1869,11 +1869,14 @@ __global__ __launch_bounds__(512) void k_cast(MapGeom g, D3 sensor, u32 depth, G
 			total += sh[wv];
 			nray2 += sh[16 + wv];
 		}
-		// a ray of l1 steps cut every w = max(1, floor(dmax*K/l1)) pops has at most 2*l1/K + 1 segments
+		// A ray of l1 steps is cut every w = floor(dmax*K/l1) pops of its dominant axis. With x = dmax*K/l1 >= K/3 (l1 <= 3 dmax)
+		// w >= x - 1, so the ray has at most dmax/(x-1) + 1 = l1/(K - l1/dmax) + 1 <= l1/(K-3) + 1 segments: the queue holds
+		// them all if K >= total/room + 3. (The bound used to be 2*l1/K + 1, i.e. K >= 2*total/room: segments twice as long
+		// as the queue needs when it is the queue that decides -- long rays, k_cast<2>'s small queue.)
 		u32 K = k_min;
 		{
 			const u32 room = QCAP - nray2;  // >= QCAP - BATCH > 0
-			const u32 need = (2u * total + room - 1u) / room;
+			const u32 need = (total + room - 1u) / room + 3u;
 			K = max(K, need);
 		}
 		u32 w = 1, nseg = 0;
@@ -1911,7 +1914,7 @@ __global__ __launch_bounds__(512) void k_cast(MapGeom g, D3 sensor, u32 depth, G
 		// elements before v were popped (strictly smaller, or equal when the axis has priority: the lower axis
 		// index wins ties, VEC3:244-251) -- their count moves the cut's cell.
 		for (u32 idx = threadIdx.x; idx < 2u * BATCH; idx += blockDim.x) {
-			const u32 ry = idx & (BATCH - 1u), role = idx / BATCH;
+			const u32 role = idx >= BATCH ? 1u : 0u, ry = idx - role * BATCH;
 			const RayHdr h = hd[ry];
 			if (0 == h.nseg) continue;
 			const RayConst c = rc[ry];
