@@ -1652,7 +1652,7 @@ __global__ __launch_bounds__(256) void k_ser_count(Table t, MapGeom g, u32* __re
 	if (threadIdx.x < 32u && cnt[threadIdx.x]) atomicAdd(&level_cnt[threadIdx.x], cnt[threadIdx.x]);
 }
 __global__ __launch_bounds__(256) void k_ser_collect(Table t, MapGeom g, const u32* __restrict__ level_off, u32* __restrict__ level_fill,
-                                                     u32* __restrict__ list)
+                                                     u32* __restrict__ list, u32 list_cap)
 {
 	__shared__ u32 cnt[32], base[32];
 	u32 ncap = t.mask + 1;
@@ -1671,7 +1671,10 @@ __global__ __launch_bounds__(256) void k_ser_collect(Table t, MapGeom g, const u
 		__syncthreads();
 		if (threadIdx.x < 32u && cnt[threadIdx.x]) base[threadIdx.x] = atomicAdd(&level_fill[threadIdx.x], cnt[threadIdx.x]);
 		__syncthreads();
-		if (l != 0xFFFFFFFFu) list[level_off[l] + base[l] + rank] = s;
+		if (l != 0xFFFFFFFFu) {
+			const u32 at = level_off[l] + base[l] + rank;
+			if (at < list_cap) list[at] = s;
+		}
 		__syncthreads();
 	}
 }
@@ -1824,15 +1827,23 @@ __global__ __launch_bounds__(1024) void k_ser_write_tail(Table t, MapGeom g, Ser
 // output buffer is sized by the table's fill, the two widest levels get a launch each with a fixed grid, the rest is the
 // one-workgroup tail, and the last kernel copies the stream -- whose length only the device knows -- into pinned host
 // memory with 16-byte stores: ONE stream synchronisation per serialisation instead of three.
-__global__ void k_ser_prefix(u32* __restrict__ cnt /* [0..31] live blocks per level; out: [32..63] first list entry per level */, SerLevels* lv)
+__global__ void k_ser_prefix(u32* __restrict__ cnt /* [0..31] live blocks per level; out: [32..63] first list entry per level */, SerLevels* lv,
+                             u32 list_cap)
 {
 	if (0 != threadIdx.x) return;
 	u32 off = 0;
+	for (u32 l = 0; l < 32; ++l) off += cnt[l];
+	// (the host sized the block list from its view of the table's fill; should the map hold more live blocks than that --
+	// it cannot after a join, but nothing here depends on it -- the levels are reported empty: the stream's length comes
+	// out as 0 and the host takes the long way, which counts first)
+	const bool fits = off <= list_cap;
+	off = 0;
 	for (u32 l = 0; l < 32; ++l) {
+		const u32 c = fits ? cnt[l] : 0u;
 		lv->off[l] = off;
-		lv->cnt[l] = cnt[l];
+		lv->cnt[l] = c;
 		cnt[32 + l] = off;
-		off += cnt[l];
+		off += c;
 	}
 }
 __global__ __launch_bounds__(256) void k_ser_sizes_dev(Table t, MapGeom g, SerArgs sa, const u32* __restrict__ list, const SerLevels* lv, u32 level, u32 D,

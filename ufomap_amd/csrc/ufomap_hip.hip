@@ -4505,9 +4505,10 @@ int serialiseNodesShort(ufomap_map* m, const SerArgs& sa, std::vector<uint8_t>& 
 	const auto t0 = std::chrono::steady_clock::now();
 	HIP_TRY(hipMemsetAsync(b_cnt.p, 0, 3 * 32 * 4 + 16, st));
 	hipLaunchKernelGGL(k_ser_count, gridFor((u64)m->t.mask + 1), dim3(256), 0, st, m->t, m->g, d_cnt);
-	hipLaunchKernelGGL(k_ser_prefix, dim3(1), dim3(64), 0, st, d_cnt, d_lv);
+	const u32 list_cap = (u32)std::min<u64>(m->used_est + 8, 0xFFFFFFFFull);
+	hipLaunchKernelGGL(k_ser_prefix, dim3(1), dim3(64), 0, st, d_cnt, d_lv, list_cap);
 	HIP_TRY(hipMemsetAsync(b_off.p, 0xFF, ncap * 8, st));
-	hipLaunchKernelGGL(k_ser_collect, gridFor((u64)m->t.mask + 1), dim3(256), 0, st, m->t, m->g, d_cnt + 32, d_cnt + 64, b_list.as<u32>());
+	hipLaunchKernelGGL(k_ser_collect, gridFor((u64)m->t.mask + 1), dim3(256), 0, st, m->t, m->g, d_cnt + 32, d_cnt + 64, b_list.as<u32>(), list_cap);
 	const u32 first = std::max<u32>(1u, sa.min_depth + 1);  // blocks of nodes above min_depth
 	const u32 l_tail = std::min<u32>(first + 2u, L);        // the two widest levels: a launch each; the rest: one workgroup
 	for (u32 l = first; l < l_tail; ++l)
@@ -4611,7 +4612,8 @@ int serialiseNodes(ufomap_map* m, const SerArgs& sa, std::vector<uint8_t>& data)
 	}
 	HIP_TRY(hipMemcpyAsync(d_cnt + 32, h_off, 32 * 4, hipMemcpyHostToDevice, m->stream));  // (h_off: read by the copy before this function returns -- it synchronises below)
 	HIP_TRY(hipMemsetAsync(b_off.p, 0xFF, ncap * 8, m->stream));
-	hipLaunchKernelGGL(k_ser_collect, gridFor((u64)m->t.mask + 1), dim3(256), 0, m->stream, m->t, m->g, d_cnt + 32, d_cnt + 64, b_list.as<u32>());
+	hipLaunchKernelGGL(k_ser_collect, gridFor((u64)m->t.mask + 1), dim3(256), 0, m->stream, m->t, m->g, d_cnt + 32, d_cnt + 64, b_list.as<u32>(),
+	                   (u32)std::min<u64>(std::max<u64>(n_live, 1), 0xFFFFFFFFull));
 	// wide levels: a launch each; from the first level of at most 2048 blocks up to the root: ONE workgroup, a barrier per level
 	u32 l_tail = L;
 	while (l_tail > first && h_cnt[l_tail - 1] <= 2048u) --l_tail;
