@@ -13,7 +13,7 @@
 // a walk takes -- where the general path (scan_kernels.h / map_kernels.h: classify, select, reduce_boxes, hitmark, cast,
 // merge_slabs, extract x2, ensure, init_new, apply_leaf, propagate x2, propagate_tail) needs fourteen per scan. What makes
 // that possible:
-//   * the scan runs on the ray grid PREDICTED from the previous scans (ufomap_hip.hip: predictGrid), so every array of
+//   * the scan runs on the ray grid PREDICTED from the previous scans (host_fast_path.inl: predictGrid), so every array of
 //     the scan has a dense, known geometry: "first point in a voxel wins" (CodeSet `indices_`, occupancy_map_base.h:295,
 //     358-360) is one atomicMin on a dense u32 array over the grid's cells instead of a hash insert, and nothing has to
 //     be compacted into lists between kernels;
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(1024) void k_fcast(MapGeom g, FastGeo fg, D3 sensor
 		solo->slot[0].B = 1;
 	}
 	// (batch, qcap: rays set up per round and segment queue entries -- they size the workgroup's LDS beside the bit grid,
-	// ufomap_hip.hip: castLds; prio: wave priority, the kernel that sets the pipeline's period shares its SIMDs with the
+	// host_fast_path.inl: fastScanPhase; prio: wave priority, the kernel that sets the pipeline's period shares its SIMDs with the
 	// kernels of the two other streams)
 	if (prio >= 3u) __builtin_amdgcn_s_setprio(3);
 	else if (2u == prio) __builtin_amdgcn_s_setprio(2);

@@ -1,5 +1,7 @@
 // ufomap_hip.hip -- C-ABI implementation (include/ufomap_hip.h) over the HIP kernels of
-// scan_kernels.h / map_kernels.h. gfx950 only; build: see ufomap_amd/build.py
+// scan_kernels.h / map_kernels.h / fast_kernels.h. gfx950 only; build: see ufomap_amd/build.py. ONE translation unit; three
+// parts of it live in files of their own, included where they used to stand: host_fast_path.inl (the steady-state path's
+// host side), host_multi_gpu.inl (ufomap_comm_*, ufomap_map_insert_batch), host_serialise.inl (write / read of the byte stream)
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared
 //
 // Launch sequence of one depth-0 integration in the steady state (doInsert; fast_kernels.h):
@@ -1126,628 +1128,7 @@ int mapPhase(ufomap_map* m, unsigned depth, const uint8_t* d_rgb, u64 capH, u64 
 
 int redoScan(ufomap_map* m);
 
-// ---- the fast path (fast_kernels.h): a depth-0 scan on the predicted ray grid, five + one launches ------------------
-FastGeo makeFastGeo(const Grid& gr)
-{
-	FastGeo fg{};
-	fg.gr = gr;
-	fg.rowBits = gridRowBits(gr);
-	fg.planeBits = fg.rowBits * 2u * (u32)gr.nb[1];
-	fg.ncells = fg.planeBits * 2u * (u32)gr.nb[2];
-	u64 nt = 1;
-	for (int a = 0; a < 3; ++a) {
-		fg.tbase[a] = gr.base[a] >> 3;  // arithmetic shift: floor
-		const i32 last = (gr.base[a] + 2 * gr.nb[a] - 1) >> 3;
-		fg.nt[a] = (u32)(last - fg.tbase[a] + 1);
-		nt *= fg.nt[a];
-	}
-	fg.ntiles = (u32)std::min<u64>(nt, 0xFFFFFFFFull);
-	fg.tl = 3;
-	return fg;
-}
-
-// does the ray kernel of the steady-state path hold this grid in LDS (k_fcast)? Else the grid is a "big" one: its rays go
-// through k_fselect / k_cast<2> (marks in HBM), its tree update through k_tile / k_up / k_ftail
-bool gridFitsLds(const Grid& gr) { return 1 == gr.layout && gr.bytes + UFO_CAST_LDS_EXTRA <= (160u << 10) - 512u; }
-
-// the level-4 cells of a tile grid as a tile grid of their own (what k_ftail works on after k_up)
-FastGeo makeUpGeo(const FastGeo& fg)
-{
-	FastGeo u = fg;
-	u64 nt = 1;
-	for (int a = 0; a < 3; ++a) {
-		u.tbase[a] = fg.tbase[a] >> 1;
-		u.nt[a] = (u32)(((fg.tbase[a] + (i32)fg.nt[a] - 1) >> 1) - u.tbase[a] + 1);
-		nt *= u.nt[a];
-	}
-	u.ntiles = (u32)std::min<u64>(nt, 0xFFFFFFFFull);
-	u.tl = 4;
-	return u;
-}
-
-// upper bound of the node blocks one scan inside grid gr can create: every level-1 block of the grid and all ancestors
-u64 fastBound(const ufomap_map* m, const Grid& gr)
-{
-	return blockBound(m, (u64)gr.nb[0] * (u64)gr.nb[1] * (u64)gr.nb[2], gr.nb, 1);
-}
-
-// dense grids of the cells above the tiles (fast_kernels.h: UpperGeo); returns the total number of cells
-u64 makeUpperGeo(const FastGeo& fg, u32 L, UpperGeo* ug)
-{
-	memset(ug, 0, sizeof(*ug));
-	u64 off = 0;
-	for (u32 l = fg.tl + 1u; l <= L; ++l) {
-		const u32 sh = l - fg.tl;
-		ug->off[l] = (u32)std::min<u64>(off, 0xFFFFFFFFull);
-		u64 sz = 1;
-		for (int a = 0; a < 3; ++a) {
-			ug->lo[l][a] = fg.tbase[a] >> sh;
-			ug->n[l][a] = (u32)(((fg.tbase[a] + (i32)fg.nt[a] - 1) >> sh) - ug->lo[l][a] + 1);
-			sz *= ug->n[l][a];
-		}
-		off += sz;
-	}
-	for (u32 l = L + 1; l < 25; ++l) ug->off[l] = (u32)std::min<u64>(off, 0xFFFFFFFFull);
-	return off;
-}
-
-bool fastEligible(const ufomap_map* m, const Grid& gr, unsigned depth, int simple, const uint8_t* d_rgb, size_t n, int discrete = 1)
-{
-	if (!m->opt_fast || 0 != depth || simple || m->g.L < 5 || 0 == n || n > (1u << 29)) return false;
-	// (a coloured cloud into a plain map, a coloured cloud in continuous mode: the general path reports them)
-	if (d_rgb && (!m->g.color || !discrete)) return false;
-	if (m->g.color && 0 == m->opt_fast_color) return false;
-	if (1 != gr.layout) return false;
-	const FastGeo fg = makeFastGeo(gr);
-	UpperGeo ug;
-	if (gridFitsLds(gr)) {
-		if (fg.ntiles > UFO_FAST_MAX_TILES) return false;
-		// node blocks above the tiles that the scan can touch: k_ftail finds them on dense per-level grids (the tile grid
-		// coarsened level by level) and holds them in LDS -- their number is bounded by the number of cells
-		return makeUpperGeo(fg, m->g.L, &ug) <= UFO_UPPER_MAX;
-	}
-	// a ray grid beyond LDS: level 4 goes through k_up, k_ftail starts above it
-	if (!m->opt_big || m->g.L < 6 || fg.ntiles > UFO_BIG_MAX_TILES || (u64)fg.ncells * 4u > (1ull << 30)) return false;
-	const FastGeo fu = makeUpGeo(fg);
-	return fu.ntiles <= UFO_FAST_MAX_TILES && makeUpperGeo(fu, m->g.L, &ug) <= UFO_UPPER_MAX;
-}
-
-unsigned long long gateTicks(const ufomap_map* m) { return (unsigned long long)std::max(100, m->opt_gate_us) * 100ull; }  // wall_clock64: 100 MHz
-
-// scan half on the scan stream: first-point array, rays, merged bit grid + tile bitmap
-// The descriptor of the newest scan half, if the host has kept it back (fastScanPhase, lazy_done), is published now.
-int publishScanDone(ufomap_map* m)
-{
-	if (!m->sd_pending) return UFOMAP_OK;
-	hipLaunchKernelGGL(k_scan_done, dim3(1), dim3(1), 0, m->sstream, m->b_pipe.as<Pipe>(), m->sd_saved);
-	m->sd_pending = false;
-	HIP_TRY(hipGetLastError());
-	return UFOMAP_OK;
-}
-
-int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, size_t n, double max_range, int discrete, bool batch_step = false,
-                  bool lazy_done = false, bool solo = false, bool uploaded = false, const uint8_t* d_rgb = nullptr)
-{
-	HIP_TRY(hipSetDevice(m->device));
-	for (int k = 0; k < 8; ++k) m->counts[k] = 0;
-	m->counts[0] = n;
-	m->last_depth = 0;
-	m->haveH = m->haveM = true;
-	m->gridM = m->spec_grid;
-	m->gridH = m->spec_grid;
-	m->scan_id += 1;
-	const FastGeo fg = makeFastGeo(m->spec_grid);
-	m->fgeo = fg;
-	m->fast = true;
-	// Scans may share a walk if they follow one another on the map stream and use the same ray grid (fast_kernels.h: k_claim);
-	// before a scan on a new grid, the scans that have no slot of their own yet get one
-	m->solo = solo;
-	if (batch_step || solo) {
-		// (a step of ufomap_map_insert_batch: its walk is enqueued by the host for the scans of all ranks; no claims. Solo:
-		// a synchronous call with nothing in flight -- the scan and its walk on the map stream, a Pipe of their own)
-		const int frc = flushDeferred(m);
-		if (frc) return frc;
-		m->chain_ok = false;
-		m->fseq = 0;
-		if (solo) {
-			if (uploaded) {  // (a host cloud is copied on the prep stream)
-				HIP_TRY(hipEventRecord(m->prep_ev, m->pstream));
-				HIP_TRY(hipStreamWaitEvent(m->stream, m->prep_ev, 0));
-			}
-			const size_t pc = m->b_bpipe.cap;
-			HIP_TRY(m->b_bpipe.reserve(sizeof(Pipe)));
-			if (pc != m->b_bpipe.cap) HIP_TRY(hipMemsetAsync(m->b_bpipe.p, 0, sizeof(Pipe), m->stream));
-		}
-	} else {
-		if (!m->chain_ok || 0 != memcmp(m->chain_geo.gr.base, fg.gr.base, sizeof(fg.gr.base)) || 0 != memcmp(m->chain_geo.gr.nb, fg.gr.nb, sizeof(fg.gr.nb))) {
-			const int frc = flushDeferred(m);
-			if (frc) return frc;
-			++m->geo_id;
-		}
-		m->fseq = ++m->n_fseq;
-		m->chain_ok = true;
-		m->chain_geo = fg;
-	}
-	// where the walk that takes this scan reports: armed BEFORE the scan half is enqueued -- an earlier slot may claim the
-	// scan as soon as its scan half has finished, i.e. before this call has enqueued the scan's own slot
-	m->h_res->err = ERR_NOT_STORED;
-	*reinterpret_cast<volatile unsigned long long*>(m->h_res + 1) = 0ull;  // k_ftail's "done" word
-	m->done_by_flag = true;
-	const u32 N = (u32)n;
-	const D3 sensor{origin[0], origin[1], origin[2]};
-	(void)makeUpperGeo(fg, m->g.L, &m->ugeo);
-	const size_t cf = m->b_first.cap, ct = m->b_tilebits.cap;  // (a re-allocation may well return the old address: compare sizes)
-	HIP_TRY(m->b_first.reserve(((size_t)fg.gr.bytes * 8 + 127) / 128 * 128 * 4));  // (one entry per bit of the grid, whole 128-entry columns: k_fmerge)
-	const bool big = !gridFitsLds(m->spec_grid);  // the ray grid lives in HBM: k_fselect + k_cast<2> instead of k_fcast
-	HIP_TRY(m->b_tilebits.reserve((big ? UFO_BIG_MAX_TILES : UFO_FAST_MAX_TILES) / 8));
-	if (cf != m->b_first.cap || ct != m->b_tilebits.cap) m->first_dirty = true;
-	// k_fhits depends on nothing but the cloud: on the prep stream it overlaps the ray kernel of the scan before
-	m->cs = solo ? m->stream : m->pstream;
-	if (m->first_dirty || 2 == m->opt_fast) {  // (option fast = 2: never trust the self-cleaning, a debugging aid)
-		HIP_TRY(hipMemsetAsync(m->b_first.p, 0xFF, m->b_first.cap, m->cs));
-		HIP_TRY(hipMemsetAsync(m->b_tilebits.p, 0, m->b_tilebits.cap, m->cs));
-		m->first_dirty = false;
-	}
-	HIP_TRY(m->b_gridM.reserve(fg.gr.bytes));
-	HIP_TRY(m->b_gridH.reserve(fg.gr.bytes));  // hit voxels, the ray grid's layout: zeroed by k_fhits, marked by k_fcast, read by k_tile
-	m->hit_grid = true;
-	HIP_TRY(m->b_hit_code.reserve(n * sizeof(PointRec)));  // (per-point records of the head loop: k_fhits -> k_fcast)
-	// a cloud in the caller's device memory (or raw records) is kept as float64 points for a possible repeat of the scan; a
-	// host cloud already lies in the set's own staging buffer
-	double* keep = nullptr;
-	if (m->ing.data || d_xyz != m->b_in_xyz.as<double>()) {
-		HIP_TRY(m->b_keep.reserve(n * 24));
-		keep = m->b_keep.as<double>();
-		m->args.d_xyz = keep;
-		m->args.ing = Ingest{};
-	}
-	// (colours: read by the tree update -- and by a repeat of the scan -- after the call has returned)
-	uint8_t* keep_rgb = nullptr;
-	const uint8_t* scan_rgb = d_rgb;
-	if (d_rgb && d_rgb != m->b_in_rgb.as<uint8_t>()) {
-		HIP_TRY(m->b_keep_rgb.reserve(n * 3));
-		keep_rgb = m->b_keep_rgb.as<uint8_t>();
-		m->args.d_rgb = keep_rgb;
-		scan_rgb = keep_rgb;
-	}
-	const u32 color_variant = d_rgb ? 1u : 0u;  // (the head loop of OccupancyMapColor::insertPointCloudDiscrete, OMC.h:195-233)
-	ScanCtl init;
-	memset(&init, 0, sizeof(init));
-	for (int a = 0; a < 3; ++a) {
-		init.mb_min[a] = init.hb_min[a] = INT32_MAX;
-		init.mb_max[a] = init.hb_max[a] = INT32_MIN;
-		init.aabb_min[a] = ~0ull;
-		init.aabb_max[a] = 0ull;
-	}
-	ScanCtl* ctl = m->b_ctl.as<ScanCtl>();
-	if (!m->ctl_init_done) {
-		HIP_TRY(hipMemcpy(m->b_ctl_init.p, &init, sizeof(ScanCtl), hipMemcpyHostToDevice));
-		m->ctl_init_done = true;
-	}
-	if (!m->ctl_clean || 2 == m->opt_fast) {
-		// (steady state: the tree update of the set's previous scan has left the block in this very state, k_ftail)
-		*m->h_ctl = init;
-		HIP_TRY(hipMemcpyAsync(ctl, m->h_ctl, sizeof(ScanCtl), hipMemcpyHostToDevice, m->cs));
-	}
-	m->ctl_clean = false;  // (until that scan's tree update has been joined and found clean)
-	const dim3 gp((N + 255) / 256);
-	HIP_TRY(m->b_part1.reserve((size_t)gp.x * sizeof(BoxPartial)));
-	{
-		ProfScope ps(m, "k_fhits");
-		if (discrete)
-			hipLaunchKernelGGL(k_fhits<true>, gp, dim3(256), 0, m->cs, m->g, fg, sensor, d_xyz, N, max_range, color_variant, m->b_first.as<u32>(),
-			                   m->b_part1.as<BoxPartial>(), ctl, m->ing, m->b_hit_code.as<PointRec>(), keep, d_rgb, keep_rgb);
-		else
-			hipLaunchKernelGGL(k_fhits<false>, gp, dim3(256), 0, m->cs, m->g, fg, sensor, d_xyz, N, max_range, 0u, m->b_first.as<u32>(),
-			                   m->b_part1.as<BoxPartial>(), ctl, m->ing, m->b_hit_code.as<PointRec>(), keep, nullptr, nullptr);
-	}
-	// stream-to-stream hand-overs of this path: k_signal / k_gate (fast_kernels.h), not events
-	m->gates = useGates(m);
-	if (solo) {
-		// (one stream: nothing to hand over)
-	} else if (m->gates) {
-		hipLaunchKernelGGL(k_signal, dim3(1), dim3(1), 0, m->pstream, m->sig_prep, (unsigned long long)m->seq, m->h_prep, batch_step ? nullptr : m->b_ts.as<unsigned long long>(),
-		                   (unsigned long long)m->fseq);
-		if (m->sd_pending) {
-			// (the scan half before this one ends and this one's gate opens in one launch)
-			hipLaunchKernelGGL(k_done_gate, dim3(1), dim3(1), 0, m->sstream, m->b_pipe.as<Pipe>(), m->sd_saved, m->sig_prep, (unsigned long long)m->seq, ctl,
-			                   gateTicks(m), (unsigned long long)m->fseq);
-			m->sd_pending = false;
-		} else {
-			hipLaunchKernelGGL(k_gate, dim3(1), dim3(1), 0, m->sstream, m->sig_prep, (unsigned long long)m->seq, ctl, gateTicks(m),
-			                   batch_step ? nullptr : m->b_ts.as<unsigned long long>(), (unsigned long long)m->fseq);
-		}
-	} else {
-		const int prc = publishScanDone(m);
-		if (prc) return prc;
-		HIP_TRY(hipEventRecord(m->prep_ev, m->pstream));
-		HIP_TRY(hipStreamWaitEvent(m->sstream, m->prep_ev, 0));
-	}
-	m->cs = solo ? m->stream : m->sstream;
-	if (big) {
-		// ---- a ray grid beyond LDS: the surviving rays are compacted (k_fselect) and walked by the ray kernel of the general
-		// path (k_cast<2>: a workgroup takes consecutive stretches of the cloud and marks an LDS box of the grid, ORed into
-		// the grid in HBM) -- no slabs; the walk derives the hit grid and the tile bitmap from the grid (k_fmerge) ----
-		const u32 n_blk = gp.x;  // workgroups of k_fselect = 256-point stretches of the cloud
-		HIP_TRY(m->b_ray_end.reserve((size_t)n_blk * 256u * sizeof(D3)));
-		HIP_TRY(m->b_blk_range.reserve((size_t)n_blk * 8));
-		u32 nwg = m->opt_cast_wgs > 0 ? (u32)m->opt_cast_wgs : std::min<u32>(n_blk, 1024u);
-		nwg = std::max<u32>(std::max<u32>(1u, nwg), (n_blk + UFO_CAST_STRETCHES - 1u) / UFO_CAST_STRETCHES);
-		HIP_TRY(m->b_slabs.reserve((size_t)std::max(nwg, n_blk) * 8 + (size_t)n_blk * 8));  // k_cast<2>'s step counts | k_fselect's per-stretch counts
-		unsigned long long* parts = m->b_slabs.as<unsigned long long>() + std::max(nwg, n_blk);
-		HIP_TRY(hipMemsetAsync(m->b_gridM.p, 0, fg.gr.bytes, m->cs));
-		HIP_TRY(hipMemsetAsync(m->b_gridH.p, 0, fg.gr.bytes, m->cs));
-		{
-			ProfScope ps(m, "k_fselect");
-			if (discrete)
-				hipLaunchKernelGGL(k_fselect<true>, gp, dim3(256), 0, m->cs, N, m->b_first.as<u32>(), m->b_hit_code.as<PointRec>(), m->b_ray_end.as<D3>(),
-				                   m->b_blk_range.as<u32>(), parts, m->b_gridH.as<u32>(), scan_rgb ? 0u : 1u, ctl);
-			else
-				hipLaunchKernelGGL(k_fselect<false>, gp, dim3(256), 0, m->cs, N, m->b_first.as<u32>(), m->b_hit_code.as<PointRec>(), m->b_ray_end.as<D3>(),
-				                   m->b_blk_range.as<u32>(), parts, m->b_gridH.as<u32>(), scan_rgb ? 0u : 1u, ctl);
-		}
-		{
-			ProfScope ps(m, "k_cast_global");
-			const u32 grid_lds = ((160u << 10) - 1024u - (u32)UFO_CAST2_LDS_EXTRA) & ~15u;
-			hipLaunchKernelGGL(k_cast<2>, dim3(nwg), dim3(512), (size_t)grid_lds + UFO_CAST2_LDS_EXTRA, m->cs, m->g, sensor, 0u, fg.gr, m->b_gridM.as<u32>(),
-			                   m->b_ray_end.as<D3>(), (u32)std::max(8, m->opt_cast_k), ctl, ctl, m->b_slabs.as<unsigned long long>(), grid_lds,
-			                   m->b_blk_range.as<u32>(), n_blk, grid_lds);
-		}
-		ScanDesc d{};
-		d.slabs = nullptr;
-		d.parts = parts;
-		d.gridM = m->b_gridM.as<u32>();
-		d.gridH = m->b_gridH.as<u32>();
-		d.first = m->b_first.as<u32>();
-		d.tile_bits = m->b_tilebits.as<u32>();
-		d.ctl = ctl;
-		d.host_result = m->h_res;
-		d.boxes = m->b_part1.as<BoxPartial>();
-		d.done_value = (unsigned long long)m->seq;
-		d.fseq = (unsigned long long)m->fseq;
-		d.n_slabs = 0;
-		d.nboxes = gp.x;
-		d.geo = m->geo_id;
-		d.rgb = scan_rgb;
-		if (solo) {
-			DescPack pk{};
-			pk.d[0] = d;
-			hipLaunchKernelGGL(k_batch_descs, dim3(1), dim3(64), 0, m->cs, m->b_bpipe.as<Pipe>(), pk, 1u);
-		} else if (lazy_done && m->gates) {
-			m->sd_saved = d;
-			m->sd_pending = true;
-		} else {
-			hipLaunchKernelGGL(k_scan_done, dim3(1), dim3(1), 0, m->sstream, m->b_pipe.as<Pipe>(), d);
-		}
-	} else {
-		// One workgroup per CU is what the ray kernel's LDS allows, and alone it is fastest with one on every CU. In a row
-		// of asynchronous scans it shares the chip with the first-point pass of the next scan and the tree update of the
-		// scan before: with a workgroup on three CUs in four it does not wait for the last CUs those kernels hold, and they
-		// have CUs where nothing else competes (measured, scripts/dev_ab.py cast_wgs=...: 256 -> 0.052, 192 -> 0.046 ms/scan).
-		u32 nwg = m->opt_cast_wgs > 0 ? (u32)m->opt_cast_wgs : (lazy_done ? (u32)(3 * m->n_cus / 4) : (u32)m->n_cus);
-		nwg = std::max<u32>(1u, std::min<u32>(nwg, (N + 63u) / 64u));
-		const u32 cap_wg = (N + nwg - 1) / nwg;
-		HIP_TRY(m->b_ray_end.reserve((size_t)cap_wg * nwg * sizeof(D3)));
-		HIP_TRY(m->b_slabs.reserve((size_t)nwg * fg.gr.bytes + (size_t)nwg * 8 * 3));  // slabs + per-workgroup steps / rays / hits (of this set: merged by the walk)
-		unsigned long long* sp = reinterpret_cast<unsigned long long*>(m->b_slabs.as<char>() + (size_t)nwg * fg.gr.bytes);
-		// end of the scan half: the scan's descriptor and number become visible to the walks (k_claim)
-		ScanDesc d{};
-		d.slabs = m->b_slabs.as<uint4>();
-		d.parts = sp;
-		d.gridM = m->b_gridM.as<u32>();
-		d.gridH = m->b_gridH.as<u32>();
-		d.first = m->b_first.as<u32>();
-		d.tile_bits = m->b_tilebits.as<u32>();
-		d.ctl = ctl;
-		d.host_result = m->h_res;
-		d.boxes = m->b_part1.as<BoxPartial>();
-		d.done_value = (unsigned long long)m->seq;
-		d.fseq = (unsigned long long)m->fseq;
-		d.n_slabs = nwg;
-		d.nboxes = gp.x;
-		d.geo = m->geo_id;
-		d.rgb = scan_rgb;
-		Pipe* const solo_pipe = solo ? m->b_bpipe.as<Pipe>() : nullptr;
-		{
-			ProfScope ps(m, "k_fcast");
-			// LDS beside the bit grid: ray constants + segment queue. Sized for the rays a workgroup gets (a round of `batch`
-			// rays; more rays = more rounds), not for the worst case: what the ray kernel leaves free on a CU is what the
-			// kernels of the other two streams can run in beside it.
-			u32 batch = (u32)std::min<long long>(512, std::max<long long>(64, m->opt_cast_batch));
-			u32 qcap = (u32)std::min<long long>(2048, std::max<long long>(2 * batch, m->opt_cast_qcap));
-			const u32 prio = (u32)m->opt_cast_prio;
-			const u32 cthreads = m->opt_cast_threads >= 1024 ? 1024u : (m->opt_cast_threads >= 768 ? 768u : 512u);
-			auto ldsFor = [&](u32 b, u32 q) { return (size_t)fg.gr.bytes + (size_t)b * (sizeof(RayConst) + sizeof(RayHdr)) + (size_t)q * sizeof(SegRec) + 256u; };
-			if (ldsFor(batch, qcap) > (160u << 10) - 256u) {
-				batch = UFO_CAST_BATCH;
-				qcap = UFO_CAST_QCAP;
-			}
-			const size_t lds = ldsFor(batch, qcap);
-			{
-				static const bool trace = nullptr != getenv("UFOMAP_TRACE_GRID");
-				if (trace)
-					fprintf(stderr, "[ufomap] fast grid: %d x %d x %d blocks, %llu bytes; k_fcast: %u workgroups, %zu bytes of LDS each\n", fg.gr.nb[0], fg.gr.nb[1],
-					        fg.gr.nb[2], (unsigned long long)fg.gr.bytes, nwg, lds);
-			}
-			if (discrete)
-				hipLaunchKernelGGL(k_fcast<true>, dim3(nwg), dim3(cthreads), lds, m->cs, m->g, fg, sensor, d_xyz, N, max_range, 0u, m->b_first.as<u32>(),
-				                   m->b_ray_end.as<D3>(), cap_wg, m->b_slabs.as<u32>(), (u32)std::max(8, m->opt_cast_k), ctl, ctl, sp, m->ing, m->b_hit_code.as<PointRec>(), batch, qcap, prio, solo_pipe, d);
-			else
-				hipLaunchKernelGGL(k_fcast<false>, dim3(nwg), dim3(cthreads), lds, m->cs, m->g, fg, sensor, d_xyz, N, max_range, 0u, m->b_first.as<u32>(),
-				                   m->b_ray_end.as<D3>(), cap_wg, m->b_slabs.as<u32>(), (u32)std::max(8, m->opt_cast_k), ctl, ctl, sp, m->ing, m->b_hit_code.as<PointRec>(), batch, qcap, prio, solo_pipe, d);
-		}
-		if (solo) {
-			// (k_fcast has written the descriptor itself)
-		} else if (!batch_step) {
-			// Asynchronous calls in a row: the descriptor is kept back and published by the next scan's gate kernel (k_done_gate)
-			// -- or by whatever needs this scan's tree update first (flushDeferred) -- one launch less per scan on this stream.
-			if (lazy_done && m->gates) {
-				m->sd_saved = d;
-				m->sd_pending = true;
-			} else {
-				hipLaunchKernelGGL(k_scan_done, dim3(1), dim3(1), 0, m->sstream, m->b_pipe.as<Pipe>(), d);
-			}
-		} else {
-			// the other ranks get this scan as two bit grids, not as 256 slabs: merged here, on the scan stream
-			DescPack pk{};
-			pk.d[0] = d;
-			pk.d[0].fseq = 0;
-			Pipe* bp = m->b_bpipe.as<Pipe>();
-			hipLaunchKernelGGL(k_batch_descs, dim3(1), dim3(64), 0, m->sstream, bp, pk, 1u);
-			ProfScope ps(m, "k_fmerge");
-			const u32 n4 = (u32)(fg.gr.bytes >> 4);
-			hipLaunchKernelGGL(k_fmerge, dim3(std::min<u32>((n4 + 63) / 64, 1024) + 1u), dim3(1024), 0, m->sstream, fg, bp, 0ull, n4);
-		}
-	}
-	HIP_TRY(hipGetLastError());
-	++m->n_fast;
-	return UFOMAP_OK;
-}
-
-// The call returns once the caller's device cloud has been consumed: k_fhits has run (fast path: the word k_signal stores
-// in pinned memory, normally there long before the rest of the call has been enqueued), or the prep stream's event.
-int awaitCloudConsumed(ufomap_map* m)
-{
-	if (m->gates) {
-		volatile unsigned long long* hp = m->h_prep;
-		const auto t0 = std::chrono::steady_clock::now();
-		for (u32 spins = 0; *hp < (unsigned long long)m->seq; ++spins) {
-			if (0 == (spins & 1023u) && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) {
-				HIP_TRY(hipStreamSynchronize(m->pstream));
-				break;
-			}
-		}
-		std::atomic_thread_fence(std::memory_order_acquire);
-		return UFOMAP_OK;
-	}
-	HIP_TRY(hipEventSynchronize(m->prep_ev));
-	return UFOMAP_OK;
-}
-
-// A slot on the map stream for a fast-path scan: k_claim (waits for the scan's scan half, claims the scans before it that
-// have no slot of their own and the scans behind it that are ready), k_fmerge, k_tile, k_ftail -- ONE walk of the tree for
-// the whole run (fast_kernels.h). k < 0: the current set's scan; else the scan of m->alt[k].
-int enqueueSlot(ufomap_map* m, int k)
-{
-	HandOver* const a = k < 0 ? nullptr : &m->alt[k];
-	const FastGeo fg = a ? a->fgeo : m->fgeo;
-	const uint64_t f = a ? a->fseq : m->fseq;
-	ScanCtl* const ctl = (a ? a->b_ctl : m->b_ctl).as<ScanCtl>();
-	const u64 bound = fastBound(m, fg.gr);  // (every block of the grid new: no more, however many scans the walk takes)
-	// The update enqueued just before this one, if it has not been joined: this walk looks at its status when it starts and
-	// stands back if that one did (everything flagged is then repeated in order when it is joined).
-	const u32* prev_stat = nullptr;
-	u64 in_flight = 0;
-	auto scanQueue = [&]() {
-		prev_stat = nullptr;
-		in_flight = 0;
-		int pk = -1;
-		for (int i = 0; i < kAlt; ++i) {
-			const HandOver& o = m->alt[i];
-			if (!o.pending || o.deferred || i == k) continue;
-			// (scans on this scan's own ray grid add nothing: `bound` is every block of that grid, whoever creates it)
-			const bool same_grid = o.fast && 0 == memcmp(o.fgeo.gr.base, fg.gr.base, sizeof(fg.gr.base)) && 0 == memcmp(o.fgeo.gr.nb, fg.gr.nb, sizeof(fg.gr.nb));
-			if (!same_grid) in_flight += o.bound;
-			// (a fast-path scan without a slot of its own goes with a later slot -- possibly this one: its status word is not
-			// written before this walk starts; the scan before it that has a slot is the predecessor to look at)
-			if (o.done_by_flag && !o.has_slot) continue;
-			if (pk < 0 || o.seq > m->alt[pk].seq) pk = i;
-		}
-		if (pk >= 0)
-			prev_stat = m->alt[pk].done_by_flag ? &m->b_pipe.as<Pipe>()->wstat[m->alt[pk].fseq & (UFO_RING - 1u)] : &m->alt[pk].b_ctl.as<ScanCtl>()->err;
-	};
-	scanQueue();
-	m->cs = m->stream;
-	{
-		// node table: room for what this walk can create on top of what the updates in flight can
-		const u64 cap = (u64)m->t.mask + 1;
-		if ((m->used_est + in_flight + bound) * 5 > cap * 3) {
-			if (in_flight) {
-				const int jrc = joinEnqueued(m);  // (the table cannot be exchanged under an update in flight)
-				if (jrc < 0) return jrc;
-				scanQueue();
-			}
-			if ((m->used_est + bound) * 5 > ((u64)m->t.mask + 1) * 3) {
-				const u64 want = tableCapFor(m->used_est + bound, (u64)m->t.mask + 1);
-				if ((m->used_est + bound) * 7 / 4 > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
-				m->cs = m->stream;
-				const int rc = growTable(m, (u32)want);
-				if (rc) return rc;
-			}
-		}
-	}
-	if (m->chg_enabled) {
-		// change detection: every voxel of the ray grid may change (updates run one at a time in this mode, doInsert)
-		const int crc = ensureChangeCap(m, (u64)fg.gr.bytes * 8u);
-		if (crc) return crc;
-	}
-	m->scan_new_bound = bound;
-	m->scan_id += 1;
-	const bool big_grid = !gridFitsLds(fg.gr);
-	{
-		// hand-over records: the tiles' (k_tile), behind them the level-4 blocks' of a grid beyond LDS (k_up); new memory is
-		// zeroed -- a record counts if it carries the walk's number
-		const size_t want = (big_grid ? (size_t)UFO_BIG_MAX_TILES + UFO_FAST_MAX_TILES : (size_t)UFO_FAST_MAX_TILES) * sizeof(TileRec);
-		if (m->b_tilerec.cap < want) {
-			HIP_TRY(hipStreamSynchronize(m->stream));  // (a walk in flight reads the old array)
-			HIP_TRY(m->b_tilerec.reserve(want));
-			HIP_TRY(hipMemsetAsync(m->b_tilerec.p, 0, m->b_tilerec.cap, m->stream));
-		}
-		if (big_grid && !m->b_upbits.p) {
-			HIP_TRY(m->b_upbits.reserve(UFO_FAST_MAX_TILES / 8));
-			HIP_TRY(hipMemsetAsync(m->b_upbits.p, 0, m->b_upbits.cap, m->stream));
-		}
-	}
-	(a ? a->pending : m->pending) = true;
-	(a ? a->deferred : m->deferred) = false;
-	(a ? a->has_slot : m->has_slot) = true;
-	(a ? a->bound : m->bound) = bound;
-	m->cs = m->stream;
-	const bool solo = !a && m->solo;
-	Pipe* pipe = solo ? m->b_bpipe.as<Pipe>() : m->b_pipe.as<Pipe>();
-	const u32 bmax = (u32)std::max(1, std::min<int>(m->opt_batch_max, (int)UFO_BATCH_MAX));
-	// without gates (a tool serialises kernels across streams) the map stream waits for the event behind the newest scan
-	// half; k_claim then finds the scan complete and only takes its decision
-	if (!solo) {
-		if (!m->gates) HIP_TRY(hipStreamWaitEvent(m->stream, m->scan_ev, 0));
-		hipLaunchKernelGGL(k_claim, dim3(1), dim3(64), 0, m->stream, pipe, (unsigned long long)f, bmax, ctl, gateTicks(m), a ? a->h_res : m->h_res,
-		                   (unsigned long long)(a ? a->seq : m->seq));
-	}
-	{
-		ProfScope ps(m, "k_fmerge");
-		const u32 n4 = (u32)(fg.gr.bytes >> 4);
-		// (a grid beyond LDS has no slabs to merge: sixteen of the kernel's seventeen waves per workgroup would only meet at its barriers)
-		hipLaunchKernelGGL(k_fmerge, dim3(std::min<u32>((n4 + 63) / 64, 1024) + 1u), dim3(big_grid ? 64 : 1024), 0, m->cs, fg, pipe, (unsigned long long)f, n4);
-	}
-	const float miss = (float)m->g.miss_log;  // insert depth 0 (OMB:311)
-	{
-		ProfScope ps(m, "k_tile");
-		const u32 tw = (m->opt_tile_waves >= 1 && m->opt_tile_waves <= 4) ? (u32)m->opt_tile_waves : 4u;  // wavefronts (= tiles) per workgroup
-		if (m->g.color)
-			hipLaunchKernelGGL(k_tile<true>, dim3((fg.ntiles + tw - 1) / tw), dim3(64u * tw), 0, m->cs, m->t, m->g, fg, pipe, (unsigned long long)f,
-			                   m->b_tilerec.as<TileRec>(), m->g.hit, miss, m->scan_id, prev_stat, changeLog(m));
-		else
-			hipLaunchKernelGGL(k_tile<false>, dim3((fg.ntiles + tw - 1) / tw), dim3(64u * tw), 0, m->cs, m->t, m->g, fg, pipe, (unsigned long long)f,
-			                   m->b_tilerec.as<TileRec>(), m->g.hit, miss, m->scan_id, prev_stat, changeLog(m));
-	}
-	const u32 nwords3 = (fg.ntiles + 31u) / 32u;
-	if (big_grid) {
-		// a ray grid beyond LDS: level 4 in parallel (k_up), k_ftail starts above it -- the level-4 blocks are its "tiles"
-		const FastGeo fu = makeUpGeo(fg);
-		TileRec* recs_up = m->b_tilerec.as<TileRec>() + UFO_BIG_MAX_TILES;
-		u32* up_bits = m->b_upbits.as<u32>();
-		{
-			ProfScope ps(m, "k_up");
-			const dim3 gu((fu.ntiles * 8u + 255u) / 256u);
-			if (m->g.color)
-				hipLaunchKernelGGL(k_up<true>, gu, dim3(256), 0, m->cs, m->t, m->g, fg, pipe, (unsigned long long)f, m->b_tilerec.as<TileRec>(), recs_up, up_bits,
-				                   m->scan_id, prev_stat);
-			else
-				hipLaunchKernelGGL(k_up<false>, gu, dim3(256), 0, m->cs, m->t, m->g, fg, pipe, (unsigned long long)f, m->b_tilerec.as<TileRec>(), recs_up, up_bits,
-				                   m->scan_id, prev_stat);
-		}
-		ProfScope ps(m, "k_ftail");
-		if (m->g.color)
-			hipLaunchKernelGGL(k_ftail<true>, dim3(1), dim3(UFO_FTAIL_THREADS), 0, m->cs, m->t, m->g, fu, pipe, (unsigned long long)f, recs_up, m->scan_id, prev_stat,
-			                   m->b_ctl_init.as<ScanCtl>(), up_bits, nwords3);
-		else
-			hipLaunchKernelGGL(k_ftail<false>, dim3(1), dim3(UFO_FTAIL_THREADS), 0, m->cs, m->t, m->g, fu, pipe, (unsigned long long)f, recs_up, m->scan_id, prev_stat,
-			                   m->b_ctl_init.as<ScanCtl>(), up_bits, nwords3);
-	} else {
-		ProfScope ps(m, "k_ftail");
-		if (m->g.color)
-			hipLaunchKernelGGL(k_ftail<true>, dim3(1), dim3(UFO_FTAIL_THREADS), 0, m->cs, m->t, m->g, fg, pipe, (unsigned long long)f, m->b_tilerec.as<TileRec>(),
-			                   m->scan_id, prev_stat, m->b_ctl_init.as<ScanCtl>(), (u32*)nullptr, nwords3);
-		else
-			hipLaunchKernelGGL(k_ftail<false>, dim3(1), dim3(UFO_FTAIL_THREADS), 0, m->cs, m->t, m->g, fg, pipe, (unsigned long long)f, m->b_tilerec.as<TileRec>(),
-			                   m->scan_id, prev_stat, m->b_ctl_init.as<ScanCtl>(), (u32*)nullptr, nwords3);
-	}
-	HIP_TRY(hipGetLastError());
-	return UFOMAP_OK;
-}
-
-// The scans that have no slot on the map stream yet get one: a slot for the newest of them takes the others along (k_claim;
-// one slot per batch_max scans). (The current set holds the newest integration; what waits is always the newest scans,
-// and they share a ray grid: fastScanPhase.)
-int flushDeferred(ufomap_map* m, bool publish)
-{
-	// (publish = false: a scan whose descriptor the host still keeps back stays as it is -- no slot may wait for it --
-	// and what is older gets its slots)
-	if (publish) {
-		const int prc = publishScanDone(m);
-		if (prc) return prc;
-	}
-	int idx[kAlt + 1], n = 0;
-	for (int i = 0; i < kAlt; ++i)
-		if (m->alt[i].pending && m->alt[i].deferred) idx[n++] = i;
-	std::sort(idx, idx + n, [&](int a, int b) { return m->alt[a].seq < m->alt[b].seq; });
-	if (m->pending && m->deferred && !m->sd_pending) idx[n++] = -1;
-	const int bmax = std::max(1, std::min<int>(m->opt_batch_max, (int)UFO_BATCH_MAX));
-	for (int a = 0; a < n; ++a) {
-		if (a + 1 == n || 0 == (a + 1) % bmax) {
-			const int rc = enqueueSlot(m, idx[a]);
-			if (rc) return rc;
-		} else {
-			// (goes with the slot enqueued for a newer scan: joined like any other integration, by its own word in pinned memory)
-			HandOver* const h = idx[a] < 0 ? nullptr : &m->alt[idx[a]];
-			(h ? h->deferred : m->deferred) = false;
-			(h ? h->has_slot : m->has_slot) = false;
-			(h ? h->bound : m->bound) = 0;
-		}
-	}
-	return UFOMAP_OK;
-}
-
-// The ray grid for the next depth-0 scans from a box of ray cells [mn, mx]: first choice the union of the box with the
-// grid predicted so far (a sensor that moves about a room keeps producing boxes inside one hull, and a prediction that
-// covers the hull never misses again), second choice the box alone, each with up to two node blocks of margin for sensor
-// motion -- as long as the ray kernel still fits its bit grid and segment queue in LDS.
-bool gridFromBox(bool had, const Grid& prev, const i32 bmn[3], const i32 bmx[3], Grid* out, bool allow_big = false)
-{
-	// (big: no grid that the ray kernel can hold in LDS -- then a grid in HBM, k_fselect / k_cast<2> / k_up, up to 8 MiB of bits)
-	for (int big = 0; big <= (allow_big ? 1 : 0); ++big)
-	for (int pass = (had && 0 == prev.depth) ? 0 : 1; pass < 2; ++pass) {
-		for (int margin = 2; margin >= 0; --margin) {
-			i32 mn[3], mx[3];
-			for (int k = 0; k < 3; ++k) {
-				mn[k] = bmn[k] - 2 * margin;
-				mx[k] = bmx[k] + 2 * margin;
-				if (0 == pass) {
-					// interior of the previous grid (makeGrid pads by one block on either side)
-					mn[k] = std::min(mn[k], prev.base[k] + 2);
-					mx[k] = std::max(mx[k], prev.base[k] + 2 * prev.nb[k] - 3);
-				}
-			}
-			Grid gr;
-			if (makeGrid(mn, mx, 0, &gr)) continue;
-			const bool packed = 2 * gr.nb[0] < 1023 && 2 * gr.nb[1] < 1023 && 2 * gr.nb[2] < 1023;
-			const u64 bytes1 = (u64)(gridRowBits(gr) >> 3) * (2ull * (u64)gr.nb[1]) * (2ull * (u64)gr.nb[2]);
-			if (!packed) continue;
-			if (big ? bytes1 > (8ull << 20) : ((bytes1 + 15) & ~15ull) + UFO_CAST_LDS_EXTRA > (160u << 10) - 512u) continue;
-			gr.layout = 1;
-			gr.bytes = (bytes1 + 15) & ~15ull;
-			*out = gr;
-			return true;
-		}
-	}
-	return false;
-}
-
-// Predict the ray grid of the next depth-0 scan from the box of the one just finished.
-void predictGrid(ufomap_map* m)
-{
-	const bool had = m->spec_valid;
-	const Grid prev = m->spec_grid;
-	m->spec_valid = false;
-	const ScanArgs& a = m->args;
-	if (!m->opt_spec || !m->opt_merge || !m->opt_cast || !m->opt_bits || !m->opt_dda_seg || m->opt_dda_mode > 0) return;
-	if (0 != a.depth || a.simple || 0 == a.n || 0 == m->h_ctl->n_rays) return;
-	m->spec_valid = gridFromBox(had, prev, m->h_ctl->mb_min, m->h_ctl->mb_max, &m->spec_grid, 0 != m->opt_big && 0 != m->opt_fast && m->g.L >= 6);
-}
-
-int redoBatchStep(ufomap_map* m);
-void predictCommonGrid(ufomap_map* m);
-
+#include "host_fast_path.inl"
 int finishPending(ufomap_map* m)
 {
 	if (!m->pending) return UFOMAP_OK;
@@ -3874,1113 +3255,8 @@ int applyKeysBatchCore(ufomap_map* m, const void* const* d_lists, const ufomap_k
 	return finishPending(m);
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// Batched multi-sensor integration across GPUs behind the C ABI (BASELINE config C4): one process per
-// GPU, every rank ray-casts ITS scan into an update list, ONE RCCL all-gather of fixed-size slots (header + list)
-// moves all lists to all ranks, every rank applies the N lists in rank order with one walk of its replica's tree
-// (ufomap_map_apply_keys_batch) -- the same map on every rank as the reference integrating the N scans one after the
-// other. RCCL is loaded at run time (an already loaded copy is preferred, e.g. the one torch brought): the library has
-// no link-time dependency on it, and a single-GPU host never touches it.
-// ------------------------------------------------------------------------------------------------------------------
-extern "C++" {
-struct IdBytes {
-	char b[128];  // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES)
-};
-namespace
-{
-struct Rccl {
-	void* lib = nullptr;
-	int (*GetUniqueId)(void*) = nullptr;
-	int (*CommInitRank)(void**, int, /* ncclUniqueId by value */ IdBytes, int) = nullptr;
-	int (*CommDestroy)(void*) = nullptr;
-	int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
-	const char* (*GetErrorString)(int) = nullptr;
-};
-Rccl* rccl()
-{
-	// (initialised once, thread-safely: a function-local static)
-	static Rccl r = [] {
-		Rccl x;
-		const char* env = getenv("UFOMAP_RCCL_LIB");
-		void* h = nullptr;
-		if (env && *env) {
-			// the host names the library (tests: a stand-in that runs the collective through shared memory): that one and no other
-			h = dlopen(env, RTLD_NOW | RTLD_LOCAL);
-		} else {
-			const char* names[] = {"librccl.so.1", "librccl.so"};
-			for (const char* name : names) {  // a copy that is already in the process first
-				h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
-				if (h) break;
-			}
-			for (const char* name : names) {
-				if (h) break;
-				h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-			}
-		}
-		if (!h) return x;
-		x.GetUniqueId = reinterpret_cast<decltype(x.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
-		x.CommInitRank = reinterpret_cast<decltype(x.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
-		x.CommDestroy = reinterpret_cast<decltype(x.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
-		x.AllGather = reinterpret_cast<decltype(x.AllGather)>(dlsym(h, "ncclAllGather"));
-		x.GetErrorString = reinterpret_cast<decltype(x.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
-		if (x.GetUniqueId && x.CommInitRank && x.CommDestroy && x.AllGather) x.lib = h;
-		return x;
-	}();
-	return r.lib ? &r : nullptr;
-}
-int rcclFail(int code, const char* what)
-{
-	Rccl* r = rccl();
-	return fail(UFOMAP_ERR_DEVICE, std::string(what) + ": " + ((r && r->GetErrorString) ? r->GetErrorString(code) : "RCCL error ") + " (" +
-	                                   std::to_string(code) + ")");
-}
-constexpr size_t kSlotHeader = 128;  // ufomap_keys_info (40 bytes) + status and ray-cell box of the rank's scan (HdrTail), padded: travels in front of the list
-}  // namespace
-}  // extern "C++"
-
-struct ufomap_comm {
-	void* comm = nullptr;  // ncclComm_t
-	bool own = false;
-	int world = 1, rank = 0, device = 0;
-	size_t cap = 1u << 20;  // bytes per slot; all ranks hold the same value (it only grows, by a rule all ranks apply alike)
-	DevBuf send, recv[2];
-	int flip = 0;
-	uint8_t* h_hdr = nullptr;  // pinned: world headers
-	uint64_t n_regrow = 0;
-	// the ranks' common ray grid for the fast-path form of a step: derived from gathered data only, hence equal on all ranks
-	Grid spec_grid{};
-	bool spec_valid = false;
-	uint64_t n_fast_steps = 0, n_redo_steps = 0;
-};
-
-int ufomap_comm_unique_id(uint8_t id[UFOMAP_COMM_ID_BYTES])
-{
-	if (!id) return fail(UFOMAP_ERR_INVALID, "null argument");
-	Rccl* r = rccl();
-	if (!r) return fail(UFOMAP_ERR_UNSUPPORTED, "librccl not found (set UFOMAP_RCCL_LIB)");
-	static_assert(UFOMAP_COMM_ID_BYTES == sizeof(IdBytes), "ncclUniqueId is 128 bytes");
-	const int e = r->GetUniqueId(id);
-	return e ? rcclFail(e, "ncclGetUniqueId") : UFOMAP_OK;
-}
-
-static ufomap_comm* commAlloc(int world, int rank, int device)
-{
-	if (world < 1 || world > 128 || rank < 0 || rank >= world) {
-		(void)fail(UFOMAP_ERR_INVALID, "comm: need 1 <= world <= 128 and 0 <= rank < world");
-		return nullptr;
-	}
-	if (hipSetDevice(device) != hipSuccess) {
-		(void)fail(UFOMAP_ERR_DEVICE, "hipSetDevice");
-		return nullptr;
-	}
-	ufomap_comm* c = new ufomap_comm;
-	c->world = world;
-	c->rank = rank;
-	c->device = device;
-	if (const char* e = getenv("UFOMAP_COMM_SLOT")) c->cap = std::max<size_t>(256, (size_t)atoll(e));  // (tests: a slot so small that it has to grow)
-	if (hipHostMalloc((void**)&c->h_hdr, (size_t)world * kSlotHeader) != hipSuccess) {
-		delete c;
-		(void)fail(UFOMAP_ERR_DEVICE, "hipHostMalloc");
-		return nullptr;
-	}
-	return c;
-}
-
-ufomap_comm* ufomap_comm_create(const uint8_t id[UFOMAP_COMM_ID_BYTES], int world, int rank, int device)
-{
-	Rccl* r = rccl();
-	if (!r || !id) {
-		(void)fail(UFOMAP_ERR_UNSUPPORTED, "librccl not found (set UFOMAP_RCCL_LIB)");
-		return nullptr;
-	}
-	ufomap_comm* c = commAlloc(world, rank, device);
-	if (!c) return nullptr;
-	IdBytes ib;
-	memcpy(ib.b, id, sizeof(ib.b));
-	const int e = r->CommInitRank(&c->comm, world, ib, rank);
-	if (e) {
-		(void)rcclFail(e, "ncclCommInitRank");
-		(void)hipHostFree(c->h_hdr);
-		delete c;
-		return nullptr;
-	}
-	c->own = true;
-	return c;
-}
-
-ufomap_comm* ufomap_comm_from_nccl(void* nccl_comm, int world, int rank, int device)
-{
-	if (!nccl_comm || !rccl()) {
-		(void)fail(UFOMAP_ERR_UNSUPPORTED, "no communicator / librccl not found");
-		return nullptr;
-	}
-	ufomap_comm* c = commAlloc(world, rank, device);
-	if (c) c->comm = nccl_comm;
-	return c;
-}
-
-void ufomap_comm_destroy(ufomap_comm* c)
-{
-	if (!c) return;
-	(void)hipSetDevice(c->device);
-	(void)hipDeviceSynchronize();
-	if (c->own && c->comm) (void)rccl()->CommDestroy(c->comm);
-	if (c->h_hdr) (void)hipHostFree(c->h_hdr);
-	delete c;
-}
-
-int ufomap_comm_stats(const ufomap_comm* c, uint64_t out[4])
-{
-	if (!c || !out) return fail(UFOMAP_ERR_INVALID, "null argument");
-	out[0] = (uint64_t)c->world;
-	out[1] = (uint64_t)c->rank;
-	out[2] = (uint64_t)c->cap;
-	out[3] = c->n_regrow;
-	return UFOMAP_OK;
-}
-
-extern "C++" {
-namespace
-{
-constexpr size_t kResStride = (sizeof(ScanCtl) + 64 + 63) & ~(size_t)63;  // one pinned result block + the word behind it
-
-// the W - 1 result blocks of the other ranks' scans of a batch step (the own scan reports to the set's h_res)
-ScanCtl* otherResult(uint8_t* all, int w) { return reinterpret_cast<ScanCtl*>(all + (size_t)w * kResStride); }
-
-// Update-list form of a batch step (colour maps, first steps, grids beyond LDS, and the collective repeat of a fast step
-// that a rank's scan did not fit): this rank's scan -> update list (scan stream; never reads the map), ONE all-gather of
-// fixed-size slots [64-byte header | list | padding], all ranks' lists in rank order through one walk of the tree
-// (ufomap_map_apply_keys_batch). A rank whose scan FAILED still takes part in the collective -- with a status word in
-// its header and an empty list -- and every rank returns that error: nobody is left waiting in the all-gather.
-int listBatchStep(ufomap_map* m, ufomap_comm* c, const double origin[3], const double* d_xyz, const uint8_t* d_rgb, size_t n, double max_range,
-                  int discrete, bool in_join)
-{
-	Rccl* r = rccl();
-	const int W = c->world;
-	ufomap_keys_info info;
-	// (in_join: called while a step is being joined -- the current hand-over set is that step's, nothing else is joined or rotated)
-	int scan_rc = in_join ? scanKeysCore(m, origin, d_xyz, m->g.color ? d_rgb : nullptr, n, max_range, 0, discrete, 0, &info)
-	                      : ufomap_map_scan_keys_rgb(m, origin, d_xyz, m->g.color ? d_rgb : nullptr, n, max_range, 0, discrete, 0, &info);
-	std::string scan_msg = scan_rc ? g_err : std::string();
-	if (scan_rc) memset(&info, 0, sizeof(info));
-	auto listBytes = [](const ufomap_keys_info& k) {  // records + colour section
-		return ((size_t)k.n_hit + k.n_miss) * sizeof(Entry) + ((k.reserved & 2u) ? (size_t)k.n_hit * 32u : 0u);
-	};
-	const size_t my_bytes = listBytes(info);
-	struct HdrTail {  // behind the 40 bytes of ufomap_keys_info in the header
-		i32 status;    // 0, or the error code of this rank's scan (its list is empty then)
-		i32 have_box;  // the scan cast rays: box = their cells' bounding box (cells at depth 0)
-		i32 box[6];
-	};
-	static_assert(sizeof(ufomap_keys_info) + sizeof(HdrTail) <= kSlotHeader, "exchange header");
-	std::vector<ufomap_keys_info> infos((size_t)W);
-	std::vector<i32> boxes((size_t)W * 6, 0);
-	std::vector<char> have_box((size_t)W, 0);
-	int first_status = 0, first_rank = -1;
-	for (;;) {
-		// header + list into this rank's slot, ONE all-gather of fixed-size slots, the W headers back to the host
-		hipError_t he = c->send.reserve(c->cap);
-		if (he == hipSuccess) he = c->recv[0].reserve(c->cap * (size_t)W);
-		if (he == hipSuccess) he = c->recv[1].reserve(c->cap * (size_t)W);
-		if (he != hipSuccess) return fail(UFOMAP_ERR_DEVICE, "exchange buffers: out of device memory");  // (before any rank's first collective on these buffers)
-		uint8_t* send = c->send.as<uint8_t>();
-		uint8_t* recv = c->recv[c->flip].as<uint8_t>();
-		memset(c->h_hdr, 0, kSlotHeader);
-		memcpy(c->h_hdr, &info, sizeof(info));
-		{
-			HdrTail t{};
-			t.status = scan_rc;
-			t.have_box = (!scan_rc && n && m->h_ctl->n_rays && m->h_ctl->mb_min[0] <= m->h_ctl->mb_max[0]) ? 1 : 0;
-			for (int a = 0; a < 3 && t.have_box; ++a) {
-				t.box[a] = m->h_ctl->mb_min[a];
-				t.box[3 + a] = m->h_ctl->mb_max[a];
-			}
-			memcpy(c->h_hdr + sizeof(info), &t, sizeof(t));
-		}
-		bool ok = hipMemcpyAsync(send, c->h_hdr, kSlotHeader, hipMemcpyHostToDevice, m->sstream) == hipSuccess;
-		const bool fits = kSlotHeader + my_bytes <= c->cap;  // (if not, the header alone tells everybody how much room is needed)
-		if (ok && fits && my_bytes) ok = hipMemcpyAsync(send + kSlotHeader, m->b_entries.p, my_bytes, hipMemcpyDeviceToDevice, m->sstream) == hipSuccess;
-		const int e = r->AllGather(send, recv, c->cap, /* ncclChar */ 0, c->comm, m->sstream);
-		if (e) return rcclFail(e, "ncclAllGather");
-		HIP_TRY(hipMemcpy2DAsync(c->h_hdr, kSlotHeader, recv, c->cap, kSlotHeader, (size_t)W, hipMemcpyDeviceToHost, m->sstream));
-		HIP_TRY(hipStreamSynchronize(m->sstream));
-		if (!ok) return fail(UFOMAP_ERR_DEVICE, "copy into the exchange slot failed");
-		size_t need = 0;
-		first_status = 0;
-		first_rank = -1;
-		for (int k = 0; k < W; ++k) {
-			const uint8_t* h = c->h_hdr + (size_t)k * kSlotHeader;
-			memcpy(&infos[(size_t)k], h, sizeof(ufomap_keys_info));
-			HdrTail t;
-			memcpy(&t, h + sizeof(ufomap_keys_info), sizeof(t));
-			if (t.status && 0 == first_status) {
-				first_status = t.status;
-				first_rank = k;
-			}
-			have_box[(size_t)k] = t.have_box ? 1 : 0;
-			for (int a = 0; a < 6; ++a) boxes[(size_t)k * 6 + a] = t.box[a];
-			need = std::max(need, kSlotHeader + listBytes(infos[(size_t)k]));
-		}
-		if (need <= c->cap) break;
-		// some rank's list did not fit: every rank sees that in the headers and grows to the same capacity; an update of
-		// an earlier batch that still reads the old receive buffers finishes first
-		if (in_join) HIP_TRY(hipStreamSynchronize(m->stream));
-		else {
-			const int wrc = ufomap_map_wait(m);
-			if (wrc) return wrc;
-		}
-		while (c->cap < need) c->cap *= 2;
-		++c->n_regrow;
-	}
-	if (first_status) {
-		// (every rank takes this exit: the maps stay equal -- none has applied anything of the step)
-		if (scan_rc) return fail(scan_rc, scan_msg);
-		return fail(first_status, "ufomap_map_insert_batch: the scan of rank " + std::to_string(first_rank) + " failed; nothing of this step was applied");
-	}
-	// the ranks' common ray grid for the steps to come (every rank computes it from the same gathered boxes)
-	{
-		i32 mn[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, mx[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
-		bool any = false;
-		for (int k = 0; k < W; ++k) {
-			if (!have_box[(size_t)k]) continue;
-			any = true;
-			for (int a = 0; a < 3; ++a) {
-				mn[a] = std::min(mn[a], boxes[(size_t)k * 6 + a]);
-				mx[a] = std::max(mx[a], boxes[(size_t)k * 6 + 3 + a]);
-			}
-		}
-		const bool had = c->spec_valid;
-		const Grid prev = c->spec_grid;
-		c->spec_valid = any && gridFromBox(had, prev, mn, mx, &c->spec_grid);
-	}
-	// the W lists in rank order, one walk of the tree; with option async_apply the call returns after enqueueing and
-	// the next batch's scan overlaps it (two receive buffers, used alternately)
-	std::vector<const void*> lists((size_t)W);
-	uint8_t* recv = c->recv[c->flip].as<uint8_t>();
-	for (int k = 0; k < W; ++k) lists[(size_t)k] = (infos[(size_t)k].n_hit + infos[(size_t)k].n_miss) ? recv + (size_t)k * c->cap + kSlotHeader : nullptr;
-	c->flip ^= 1;
-	if (in_join) return applyKeysBatchCore(m, lists.data(), infos.data(), W, true);
-	return ufomap_map_apply_keys_batch(m, lists.data(), infos.data(), W);
-}
-
-// The ranks' common ray grid after a fast-path step has been joined: from the boxes of all ranks' scans (the finished
-// control blocks of the walk: every rank holds the same ones).
-void predictCommonGrid(ufomap_map* m)
-{
-	ufomap_comm* c = m->comm;
-	if (!c) return;
-	i32 mn[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, mx[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
-	bool any = false;
-	for (int w = 0; w < m->batch_world; ++w) {
-		const ScanCtl* rc = (w == c->rank) ? m->h_ctl : otherResult(m->h_res_all, w);
-		if (0 == rc->n_rays || rc->mb_min[0] > rc->mb_max[0]) continue;
-		any = true;
-		for (int a = 0; a < 3; ++a) {
-			mn[a] = std::min(mn[a], rc->mb_min[a]);
-			mx[a] = std::max(mx[a], rc->mb_max[a]);
-		}
-	}
-	if (!any) return;  // (a step of empty clouds: the grid stays)
-	const bool had = c->spec_valid;
-	const Grid prev = c->spec_grid;
-	c->spec_valid = gridFromBox(had, prev, mn, mx, &c->spec_grid);
-}
-
-// One step of ufomap_map_insert_batch on the fast path: this rank's scan on the ranks' common ray grid, merged to two bit
-// grids on the scan stream, ONE all-gather of [control block | tile bitmap | ray cells | hit voxels] (~0.2 MB per rank), ONE
-// walk of the tree for the scans of all ranks in rank order (k_tile / k_ftail over W scans) -- enqueued, not awaited: no
-// host round trip inside the step; what the host needs to know (errors, boxes) it reads when the step is joined.
-int fastBatchStep(ufomap_map* m, ufomap_comm* c, const double origin[3], const double* d_xyz, size_t n, double max_range, int discrete)
-{
-	Rccl* r = rccl();
-	const int W = c->world;
-	m->spec_grid = c->spec_grid;
-	m->spec_valid = true;
-	const FastGeo fg = makeFastGeo(c->spec_grid);
-	const size_t G = (size_t)fg.gr.bytes, slot = (UFO_XSLOT_HDR + 2 * G + 255) & ~(size_t)255;
-	m->batch_world = W;
-	m->comm = c;
-	HIP_TRY(m->b_xsend.reserve(slot));
-	HIP_TRY(m->b_xrecv.reserve(slot * (size_t)W));
-	{
-		const size_t pc = m->b_bpipe.cap;
-		HIP_TRY(m->b_bpipe.reserve(sizeof(Pipe)));
-		if (pc != m->b_bpipe.cap) HIP_TRY(hipMemsetAsync(m->b_bpipe.p, 0, sizeof(Pipe), m->sstream));
-	}
-	if (m->h_res_all_world < W) {
-		if (m->h_res_all) HIP_TRY(hipHostFree(m->h_res_all));
-		m->h_res_all = nullptr;
-		HIP_TRY(hipHostMalloc((void**)&m->h_res_all, kResStride * (size_t)W));
-		m->h_res_all_world = W;
-	}
-	if (!m->xchg_ev) HIP_TRY(hipEventCreateWithFlags(&m->xchg_ev, hipEventDisableTiming));
-	for (int w = 0; w < W; ++w) {  // (armed before anything of the step is enqueued)
-		otherResult(m->h_res_all, w)->err = ERR_NOT_STORED;
-		*reinterpret_cast<volatile unsigned long long*>(otherResult(m->h_res_all, w) + 1) = 0ull;
-	}
-	ScanCtl* ctl = m->b_ctl.as<ScanCtl>();
-	int rc = UFOMAP_OK;
-	if (n) {
-		rc = fastScanPhase(m, origin, d_xyz, n, max_range, discrete, true);
-	} else {
-		// an empty cloud on this rank: an empty contribution (the collective is entered all the same)
-		for (int k = 0; k < 8; ++k) m->counts[k] = 0;
-		m->fgeo = fg;
-		m->fast = true;
-		m->fseq = 0;
-		m->chain_ok = false;
-		m->gridM = m->gridH = c->spec_grid;
-		m->haveH = m->haveM = true;
-		m->hit_grid = true;
-		m->last_depth = 0;
-		m->h_res->err = ERR_NOT_STORED;
-		*reinterpret_cast<volatile unsigned long long*>(m->h_res + 1) = 0ull;
-		m->done_by_flag = true;
-		rc = flushDeferred(m);
-		if (!m->ctl_init_done) {
-			ScanCtl init;
-			memset(&init, 0, sizeof(init));
-			for (int a = 0; a < 3; ++a) {
-				init.mb_min[a] = init.hb_min[a] = INT32_MAX;
-				init.mb_max[a] = init.hb_max[a] = INT32_MIN;
-				init.aabb_min[a] = ~0ull;
-				init.aabb_max[a] = 0ull;
-			}
-			HIP_TRY(hipMemcpy(m->b_ctl_init.p, &init, sizeof(ScanCtl), hipMemcpyHostToDevice));
-			m->ctl_init_done = true;
-		}
-		HIP_TRY(m->b_gridM.reserve(G));
-		HIP_TRY(m->b_gridH.reserve(G));
-		HIP_TRY(m->b_tilebits.reserve(UFO_FAST_MAX_TILES / 8));
-		HIP_TRY(hipMemcpyAsync(ctl, m->b_ctl_init.p, sizeof(ScanCtl), hipMemcpyDeviceToDevice, m->sstream));
-		HIP_TRY(hipMemsetAsync(m->b_gridM.p, 0, G, m->sstream));
-		HIP_TRY(hipMemsetAsync(m->b_gridH.p, 0, G, m->sstream));
-		HIP_TRY(hipMemsetAsync(m->b_tilebits.p, 0, UFO_FAST_MAX_TILES / 8, m->sstream));
-		m->ctl_clean = false;
-	}
-	if (rc) return rc;  // (device / allocation failures only: a scan that does not fit flags itself on the device)
-	const u32 n4 = (u32)(G >> 4);
-	uint8_t* send = m->b_xsend.as<uint8_t>();
-	uint8_t* recv = m->b_xrecv.as<uint8_t>();
-	hipLaunchKernelGGL(k_pack_slot, dim3(64), dim3(256), 0, m->sstream, reinterpret_cast<uint4*>(send), reinterpret_cast<const uint4*>(ctl),
-	                   m->b_tilebits.as<uint4>(), m->b_gridM.as<uint4>(), m->b_gridH.as<uint4>(), n4);
-	{
-		const int e = r->AllGather(send, recv, slot, /* ncclChar */ 0, c->comm, m->sstream);
-		if (e) return rcclFail(e, "ncclAllGather");
-	}
-	HIP_TRY(hipEventRecord(m->xchg_ev, m->sstream));
-	// ---- the walk: the scans of ranks 0 .. W-1 in this order (UFO_BATCH_MAX at a time) ----
-	m->cs = m->stream;
-	const u64 bound = fastBound(m, fg.gr);
-	{
-		u64 in_flight = 0;
-		for (int i = 0; i < kAlt; ++i)
-			if (m->alt[i].pending && !(m->alt[i].fast && 0 == memcmp(m->alt[i].fgeo.gr.base, fg.gr.base, sizeof(fg.gr.base)) &&
-			                           0 == memcmp(m->alt[i].fgeo.gr.nb, fg.gr.nb, sizeof(fg.gr.nb))))
-				in_flight += m->alt[i].bound;
-		if ((m->used_est + in_flight + bound) * 5 > ((u64)m->t.mask + 1) * 3) {
-			const int jrc = joinEnqueued(m);  // (deterministic: every rank's replica holds the same number of blocks)
-			if (jrc < 0) return jrc;
-			if ((m->used_est + bound) * 5 > ((u64)m->t.mask + 1) * 3) {
-				const u64 want = tableCapFor(m->used_est + bound, (u64)m->t.mask + 1);
-				if ((m->used_est + bound) * 7 / 4 > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
-				m->cs = m->stream;
-				const int grc = growTable(m, (u32)want);
-				if (grc) return grc;
-			}
-		}
-	}
-	const u32* prev_stat = nullptr;
-	{
-		int pk = -1;
-		for (int i = 0; i < kAlt; ++i) {
-			const HandOver& o = m->alt[i];
-			if (!o.pending || o.deferred || (o.done_by_flag && !o.has_slot)) continue;
-			if (pk < 0 || o.seq > m->alt[pk].seq) pk = i;
-		}
-		if (pk >= 0) {
-			const HandOver& o = m->alt[pk];
-			prev_stat = !o.done_by_flag ? &o.b_ctl.as<ScanCtl>()->err
-			            : o.batch_world ? &o.b_bpipe.as<Pipe>()->wstat[0] : &m->b_pipe.as<Pipe>()->wstat[o.fseq & (UFO_RING - 1u)];
-		}
-	}
-	m->scan_new_bound = bound;
-	HIP_TRY(m->b_tilerec.reserve((size_t)UFO_FAST_MAX_TILES * sizeof(TileRec)));
-	HIP_TRY(hipStreamWaitEvent(m->stream, m->xchg_ev, 0));
-	Pipe* bp = m->b_bpipe.as<Pipe>();
-	const float miss = (float)m->g.miss_log;
-	for (int w0 = 0; w0 < W; w0 += (int)UFO_BATCH_MAX) {
-		const int B = std::min<int>((int)UFO_BATCH_MAX, W - w0);
-		DescPack pk{};
-		for (int b = 0; b < B; ++b) {
-			const int w = w0 + b;
-			uint8_t* base = recv + (size_t)w * slot;
-			ScanDesc& d = pk.d[b];
-			const bool own = w == c->rank;
-			// (the own scan's control block and tile bitmap are the set's: the walk leaves them in their start state)
-			d.ctl = own ? ctl : reinterpret_cast<ScanCtl*>(base);
-			d.tile_bits = own ? m->b_tilebits.as<u32>() : reinterpret_cast<u32*>(base + UFO_XSLOT_CTL);
-			d.gridM = reinterpret_cast<u32*>(base + UFO_XSLOT_HDR);
-			d.gridH = reinterpret_cast<u32*>(base + UFO_XSLOT_HDR + G);
-			d.host_result = own ? m->h_res : otherResult(m->h_res_all, w);
-			d.done_value = (unsigned long long)m->seq;
-			d.fseq = (unsigned long long)b;
-		}
-		m->scan_id += 1;
-		hipLaunchKernelGGL(k_batch_descs, dim3(1), dim3(64), 0, m->stream, bp, pk, (u32)B);
-		{
-			ProfScope ps(m, "k_tile");
-			const u32 tw = (m->opt_tile_waves >= 1 && m->opt_tile_waves <= 4) ? (u32)m->opt_tile_waves : 4u;
-			hipLaunchKernelGGL(k_tile<false>, dim3((fg.ntiles + tw - 1) / tw), dim3(64u * tw), 0, m->stream, m->t, m->g, fg, bp, 0ull, m->b_tilerec.as<TileRec>(), m->g.hit,
-			                   miss, m->scan_id, prev_stat, changeLog(m));
-		}
-		{
-			ProfScope ps(m, "k_ftail");
-			hipLaunchKernelGGL(k_ftail<false>, dim3(1), dim3(UFO_FTAIL_THREADS), 0, m->stream, m->t, m->g, fg, bp, 0ull, m->b_tilerec.as<TileRec>(), m->scan_id, prev_stat,
-			                   m->b_ctl_init.as<ScanCtl>(), (u32*)nullptr, (fg.ntiles + 31u) / 32u);
-		}
-		prev_stat = &bp->wstat[0];  // (a second walk of the same step looks at the first)
-	}
-	HIP_TRY(hipGetLastError());
-	m->pending = true;
-	m->deferred = false;
-	m->has_slot = true;
-	m->bound = bound;
-	m->last_rgb = nullptr;
-	++c->n_fast_steps;
-	return UFOMAP_OK;
-}
-
-// A step of ufomap_map_insert_batch whose walk stood back (the scan of some rank did not fit the common ray grid) is
-// repeated in update-list form by ALL ranks, here -- i.e. while the step is being joined, which every rank does at the same
-// point of its sequence of calls. Nothing of the step has reached the map; the steps enqueued behind it have stood back
-// too and are repeated by their own joins, in order.
-int redoBatchStep(ufomap_map* m)
-{
-	const ScanArgs a = m->args;
-	ufomap_comm* c = m->comm;
-	m->batch_world = 0;
-	m->args.spec = false;
-	m->chain_ok = false;
-	m->first_dirty = true;
-	++m->n_spec_redo;
-	if (!c) return fail(UFOMAP_ERR_INVALID, "batch step without a communicator");
-	++c->n_redo_steps;  // (the list form extends the ranks' common grid by the boxes it gathers)
-	HIP_TRY(hipStreamSynchronize(m->stream));
-	return listBatchStep(m, c, a.origin, a.d_xyz, nullptr, a.n, a.max_range, a.discrete, true);
-}
-}  // namespace
-}  // extern "C++"
-
-int ufomap_comm_counters(const ufomap_comm* c, uint64_t out[4])
-{
-	if (!c || !out) return fail(UFOMAP_ERR_INVALID, "null argument");
-	out[0] = c->n_fast_steps;
-	out[1] = c->n_redo_steps;
-	out[2] = c->spec_valid ? 1u : 0u;
-	out[3] = 0;
-	return UFOMAP_OK;
-}
-
-int ufomap_map_insert_batch(ufomap_map* m, ufomap_comm* c, const double sensor_origin[3], const double* d_xyz, const uint8_t* d_rgb, size_t n,
-                            double max_range, unsigned depth, int discrete)
-{
-	if (!m || !c || !sensor_origin) return fail(UFOMAP_ERR_INVALID, "null argument");
-	if (m->g.color && !d_rgb && n) return fail(UFOMAP_ERR_INVALID, "a colour map needs the points' colours");
-	if (0 != depth) return fail(UFOMAP_ERR_UNSUPPORTED, "insert_batch: insert depth 0 only");
-	if (c->device != m->device) return fail(UFOMAP_ERR_INVALID, "the communicator was created on another device than the map");
-	if (!rccl()) return fail(UFOMAP_ERR_UNSUPPORTED, "librccl not found (set UFOMAP_RCCL_LIB)");
-	HIP_TRY(hipSetDevice(m->device));
-	if (m->poisoned) return fail(UFOMAP_ERR_CAPACITY, "the map is inconsistent after a node table overflow: ufomap_map_clear it");
-	// Which form the step takes is decided from what ALL ranks know alike: the common ray grid (derived from gathered boxes
-	// only), the map's configuration (the same on every rank by contract), never from this rank's cloud.
-	const bool fast = c->spec_valid && m->opt_fast && m->opt_spec && !m->g.color && !m->chg_enabled && m->g.L >= 5 && nullptr == m->ing.data &&
-	                  fastEligible(m, c->spec_grid, 0, 0, nullptr, 1);
-	if (!fast) {
-		// (joins what is in flight where it has to: scan_keys / apply_keys_batch)
-		m->batch_world = 0;
-		return listBatchStep(m, c, sensor_origin, d_xyz, d_rgb, n, max_range, discrete, false);
-	}
-	// Joins happen at fixed points of the sequence of calls -- the step two before this one is joined here -- never "when it
-	// happens to be complete": a step that has to be repeated is repeated by all ranks together (a collective).
-	int prc = rotateSets(m);
-	while (countPendingAlts(m) > 1) {
-		const int jrc = joinOldestAlt(m);
-		if (!prc) prc = jrc;
-	}
-	if (prc) return prc;
-	if (!c->spec_valid) {  // (the join repeated a step through the list form and found no common grid after it)
-		m->batch_world = 0;
-		return listBatchStep(m, c, sensor_origin, d_xyz, d_rgb, n, max_range, discrete, false);
-	}
-	m->seq = ++m->latest_seq;
-	{
-		ScanArgs& a = m->args;
-		a = ScanArgs{};
-		a.spec = true;
-		for (int k = 0; k < 3; ++k) a.origin[k] = sensor_origin[k];
-		a.d_xyz = d_xyz;
-		a.n = n;
-		a.max_range = max_range;
-		a.discrete = discrete;
-	}
-	m->gates = useGates(m);
-	const int rc = fastBatchStep(m, c, sensor_origin, d_xyz, n, max_range, discrete);
-	if (rc) return rc;
-	if (n) {  // (the caller's cloud has been consumed when the call returns: k_fhits kept what a repeat of the step needs)
-		const int wrc = awaitCloudConsumed(m);
-		if (wrc) return wrc;
-	}
-	if (m->opt_async_apply && !m->profiling) return UFOMAP_OK;
-	// not asynchronous: the step is joined here (by every rank)
-	const int jrc = joinOlder(m);
-	HIP_TRY(hipStreamSynchronize(m->stream));
-	const int frc = finishPending(m);
-	return frc ? frc : jrc;
-}
-
-// liblz4, loaded at run time (the reference links it for its I/O only: octree.h:1430-1486)
-extern "C++" {
-namespace
-{
-struct Lz4 {
-	int (*bound)(int) = nullptr;
-	int (*fast)(const char*, char*, int, int, int) = nullptr;
-	int (*hc)(const char*, char*, int, int, int) = nullptr;
-	int (*safe)(const char*, char*, int, int) = nullptr;
-	bool ok = false;
-};
-const Lz4& lz4()
-{
-	static Lz4 z = [] {
-		Lz4 r;
-		void* h = nullptr;
-		for (const char* name : {"liblz4.so.1", "liblz4.so", "/usr/lib/x86_64-linux-gnu/liblz4.so.1"}) {
-			h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-			if (h) break;
-		}
-		if (h) {
-			r.bound = reinterpret_cast<int (*)(int)>(dlsym(h, "LZ4_compressBound"));
-			r.fast = reinterpret_cast<int (*)(const char*, char*, int, int, int)>(dlsym(h, "LZ4_compress_fast"));
-			r.hc = reinterpret_cast<int (*)(const char*, char*, int, int, int)>(dlsym(h, "LZ4_compress_HC"));
-			r.safe = reinterpret_cast<int (*)(const char*, char*, int, int)>(dlsym(h, "LZ4_decompress_safe"));
-			r.ok = r.bound && r.fast && r.hc && r.safe;
-		}
-		return r;
-	}();
-	return z;
-}
-
-// The node stream without the host in the middle (map_kernels.h: k_ser_prefix ... k_ser_copy_out): one synchronisation.
-// Returns 1 when the long way has to be taken (a map too large for the bound, no live root block).
-int serialiseNodesShort(ufomap_map* m, const SerArgs& sa, std::vector<uint8_t>& data)
-{
-	const u32 D = m->g.color ? 7u : 4u;
-	const u32 L = m->g.L;
-	if (!m->opt_ser_short || 0 == m->used_est || L <= sa.min_depth) return 1;
-	const u64 bound = 1ull + (u64)m->used_est * (1ull + 8ull * D) + 64ull;  // every block: a mask byte and eight leaf payloads at most
-	if (bound > (32ull << 20)) return 1;
-	DevBuf &b_cnt = m->b_ser[0], &b_list = m->b_ser[1], &b_size = m->b_ser[2], &b_off = m->b_ser[3], &b_out = m->b_ser[4];
-	const size_t ncap = (size_t)m->t.mask + 1;
-	HIP_TRY(b_cnt.reserve(3 * 32 * 4 + 16 + sizeof(SerLevels)));
-	HIP_TRY(b_list.reserve(((size_t)m->used_est + 8) * 4));
-	HIP_TRY(b_size.reserve(ncap * 8));
-	HIP_TRY(b_off.reserve(ncap * 8));
-	HIP_TRY(b_out.reserve((bound + 15) & ~15ull));
-	if (m->h_out_cap < bound) {
-		if (m->h_out) (void)hipHostFree(m->h_out);
-		m->h_out = nullptr;
-		m->h_out_cap = 0;
-		const size_t want = (size_t)((bound + bound / 2 + 4095) & ~4095ull);
-		HIP_TRY(hipHostMalloc((void**)&m->h_out, want));
-		m->h_out_cap = want;
-	}
-	if (!m->h_ser) HIP_TRY(hipHostMalloc((void**)&m->h_ser, 512));
-	volatile unsigned long long* h_total = reinterpret_cast<volatile unsigned long long*>(m->h_ser + 256);
-	u32* d_cnt = b_cnt.as<u32>();
-	unsigned long long* d_total = reinterpret_cast<unsigned long long*>(d_cnt + 96);
-	SerLevels* d_lv = reinterpret_cast<SerLevels*>(d_cnt + 100);
-	hipStream_t st = m->stream;
-	static const bool trace = nullptr != getenv("UFOMAP_TRACE_SER");
-	const auto t0 = std::chrono::steady_clock::now();
-	HIP_TRY(hipMemsetAsync(b_cnt.p, 0, 3 * 32 * 4 + 16, st));
-	hipLaunchKernelGGL(k_ser_count, gridFor((u64)m->t.mask + 1), dim3(256), 0, st, m->t, m->g, d_cnt);
-	const u32 list_cap = (u32)std::min<u64>(m->used_est + 8, 0xFFFFFFFFull);
-	hipLaunchKernelGGL(k_ser_prefix, dim3(1), dim3(64), 0, st, d_cnt, d_lv, list_cap);
-	HIP_TRY(hipMemsetAsync(b_off.p, 0xFF, ncap * 8, st));
-	hipLaunchKernelGGL(k_ser_collect, gridFor((u64)m->t.mask + 1), dim3(256), 0, st, m->t, m->g, d_cnt + 32, d_cnt + 64, b_list.as<u32>(), list_cap);
-	const u32 first = std::max<u32>(1u, sa.min_depth + 1);  // blocks of nodes above min_depth
-	const u32 l_tail = std::min<u32>(first + 2u, L);        // the two widest levels: a launch each; the rest: one workgroup
-	for (u32 l = first; l < l_tail; ++l)
-		hipLaunchKernelGGL(k_ser_sizes_dev, dim3(1024), dim3(256), 0, st, m->t, m->g, sa, b_list.as<u32>(), d_lv, l, D, b_size.as<u64>());
-	const unsigned long long cap = bound;
-	// (the narrow levels: both passes in one launch when they hold few enough blocks for its LDS -- as the previous
-	// serialisation of this map found; should the map have outgrown that since, the kernel says so and the long way is taken)
-	if (m->ser_tail_blocks <= UFO_SER_TAIL_MAX - 64u && m->ser_tail_first == l_tail) {
-		hipLaunchKernelGGL(k_ser_tail_dev, dim3(1), dim3(1024), 0, st, m->t, m->g, sa, b_list.as<u32>(), d_lv, l_tail, L, D, b_size.as<u64>(), b_off.as<u64>(),
-		                   b_out.as<uint8_t>(), d_total, cap);
-	} else {
-		hipLaunchKernelGGL(k_ser_sizes_tail_dev, dim3(1), dim3(1024), 0, st, m->t, m->g, sa, b_list.as<u32>(), d_lv, l_tail, L, D, b_size.as<u64>(), d_total);
-		hipLaunchKernelGGL(k_ser_write_tail_dev, dim3(1), dim3(1024), 0, st, m->t, m->g, sa, b_list.as<u32>(), d_lv, L, l_tail, D, b_size.as<u64>(), b_off.as<u64>(),
-		                   b_out.as<uint8_t>(), d_total, cap);
-	}
-	for (u32 l = l_tail; l-- > first;)
-		hipLaunchKernelGGL(k_ser_write_dev, dim3(1024), dim3(256), 0, st, m->t, m->g, sa, b_list.as<u32>(), d_lv, l, D, b_size.as<u64>(), b_off.as<u64>(),
-		                   b_out.as<uint8_t>(), d_total, cap);
-	hipLaunchKernelGGL(k_ser_copy_out, dim3(128), dim3(256), 0, st, b_out.as<uint4>(), d_total, cap, reinterpret_cast<uint4*>(m->h_out),
-	                   const_cast<unsigned long long*>(h_total), d_lv, l_tail, L);
-	HIP_TRY(hipGetLastError());
-	const auto t1 = std::chrono::steady_clock::now();
-	HIP_TRY(hipStreamSynchronize(st));
-	const auto t2 = std::chrono::steady_clock::now();
-	const u64 total = *h_total;
-	m->ser_tail_blocks = (u32)std::min<unsigned long long>((unsigned long long)h_total[1], 0xFFFFFFFFull);
-	m->ser_tail_first = l_tail;
-	if (trace) {
-		auto us = [](auto a, auto b) { return (double)std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count() * 1e-3; };
-		fprintf(stderr, "[ufomap] serialise: enqueue %.1f us, wait %.1f us, %llu bytes, table %llu slots, %llu used, %u blocks in the narrow levels (from level %u)\n", us(t0, t1), us(t1, t2),
-		        (unsigned long long)total, (unsigned long long)m->t.mask + 1, (unsigned long long)m->used_est, m->ser_tail_blocks, m->ser_tail_first);
-	}
-	if (0 == total || total > cap) return 1;  // the root is a leaf / the narrow levels outgrew the one-launch form / more than the bound: the long way
-	if (total > 0x7FFFFFFFull) return fail(UFOMAP_ERR_CAPACITY, "map byte stream exceeds 2^31 bytes (the reference's size field is an int)");
-	data.assign(m->h_out, m->h_out + total);
-	return UFOMAP_OK;
-}
-
-// the node stream of writeNodes (occupancy_map_base.h:1457-1533) for the whole map or the part inside a bounding volume
-int serialiseNodes(ufomap_map* m, const SerArgs& sa, std::vector<uint8_t>& data)
-{
-	data.clear();
-	m->cs = m->stream;
-	const u32 D = m->g.color ? 7u : 4u;
-	const u32 L = m->g.L;
-	if (sa.has_bv) {
-		// the root's box against the volume (OMB:1461-1467): nothing is written, not even the root byte
-		const double h = m->g.hs[L];
-		for (int k = 0; k < 3; ++k) {
-			const double min1 = sa.vc[k] - sa.vh[k], max1 = sa.vc[k] + sa.vh[k], min2 = 0.0 - h, max2 = 0.0 + h;
-			if (!(min1 <= max2) || !(min2 <= max1)) return UFOMAP_OK;
-		}
-	}
-	{
-		const int src = serialiseNodesShort(m, sa, data);
-		if (src <= 0) return src;
-		data.clear();
-	}
-	// (scratch kept with the map: a publish per scan must not pay five allocations)
-	DevBuf &b_cnt = m->b_ser[0], &b_list = m->b_ser[1], &b_size = m->b_ser[2], &b_off = m->b_ser[3], &b_out = m->b_ser[4];
-	if (!m->h_ser) HIP_TRY(hipHostMalloc((void**)&m->h_ser, 512));
-	u32* h_cnt = reinterpret_cast<u32*>(m->h_ser);                                    // [32] live blocks per level
-	MapRoot* h_root = reinterpret_cast<MapRoot*>(m->h_ser + 128);
-	unsigned long long* h_total = reinterpret_cast<unsigned long long*>(m->h_ser + 256);
-	u32 h_off[32] = {0};
-	HIP_TRY(b_cnt.reserve(3 * 32 * 4 + 16 + sizeof(SerLevels)));
-	HIP_TRY(hipMemsetAsync(b_cnt.p, 0, 3 * 32 * 4 + 16, m->stream));
-	u32* d_cnt = b_cnt.as<u32>();
-	unsigned long long* d_total = reinterpret_cast<unsigned long long*>(d_cnt + 96);
-	hipLaunchKernelGGL(k_ser_count, gridFor((u64)m->t.mask + 1), dim3(256), 0, m->stream, m->t, m->g, d_cnt);
-	HIP_TRY(hipMemcpyAsync(h_cnt, d_cnt, 32 * 4, hipMemcpyDeviceToHost, m->stream));
-	HIP_TRY(hipMemcpyAsync(h_root, m->b_root.p, sizeof(MapRoot), hipMemcpyDeviceToHost, m->stream));
-	HIP_TRY(hipStreamSynchronize(m->stream));
-	u64 n_live = 0;
-	for (u32 l = 0; l < 32; ++l) {
-		h_off[l] = (u32)n_live;
-		n_live += h_cnt[l];
-	}
-	const MapRoot root = *h_root;
-	if (0 == h_cnt[L] || L <= sa.min_depth) {
-		// the root is (written as) a leaf: children byte 0, then the root's payload (occupancy_map_base.h:1469-1478)
-		data.resize(1 + D);
-		data[0] = 0;
-		memcpy(&data[1], &root.occ, 4);
-		if (D > 4) {
-			data[5] = (uint8_t)root.rgb;
-			data[6] = (uint8_t)(root.rgb >> 8);
-			data[7] = (uint8_t)(root.rgb >> 16);
-		}
-		return UFOMAP_OK;
-	}
-	const u32 first = std::max<u32>(1u, sa.min_depth + 1);  // blocks of nodes above min_depth
-	const size_t ncap = (size_t)m->t.mask + 1;
-	HIP_TRY(b_list.reserve(std::max<u64>(n_live, 1) * 4));
-	HIP_TRY(b_size.reserve(ncap * 8));
-	HIP_TRY(b_off.reserve(ncap * 8));
-	SerLevels lv{};
-	for (u32 l = 0; l < 32; ++l) {
-		lv.off[l] = h_off[l];
-		lv.cnt[l] = h_cnt[l];
-	}
-	HIP_TRY(hipMemcpyAsync(d_cnt + 32, h_off, 32 * 4, hipMemcpyHostToDevice, m->stream));  // (h_off: read by the copy before this function returns -- it synchronises below)
-	HIP_TRY(hipMemsetAsync(b_off.p, 0xFF, ncap * 8, m->stream));
-	hipLaunchKernelGGL(k_ser_collect, gridFor((u64)m->t.mask + 1), dim3(256), 0, m->stream, m->t, m->g, d_cnt + 32, d_cnt + 64, b_list.as<u32>(),
-	                   (u32)std::min<u64>(std::max<u64>(n_live, 1), 0xFFFFFFFFull));
-	// wide levels: a launch each; from the first level of at most 2048 blocks up to the root: ONE workgroup, a barrier per level
-	u32 l_tail = L;
-	while (l_tail > first && h_cnt[l_tail - 1] <= 2048u) --l_tail;
-	for (u32 l = first; l < l_tail; ++l)
-		if (h_cnt[l])
-			hipLaunchKernelGGL(k_ser_sizes, gridFor((u64)h_cnt[l] * 8u), dim3(256), 0, m->stream, m->t, m->g, sa, b_list.as<u32>() + h_off[l], h_cnt[l], l, D,
-			                   b_size.as<u64>());
-	hipLaunchKernelGGL(k_ser_sizes_tail, dim3(1), dim3(1024), 0, m->stream, m->t, m->g, sa, b_list.as<u32>(), lv, l_tail, L, D, b_size.as<u64>(), d_total);
-	HIP_TRY(hipMemcpyAsync(h_total, d_total, 8, hipMemcpyDeviceToHost, m->stream));
-	HIP_TRY(hipStreamSynchronize(m->stream));
-	const u64 total = *h_total;  // 0xFF byte + subtree of the root block
-	if (total > 0x7FFFFFFFull) return fail(UFOMAP_ERR_CAPACITY, "map byte stream exceeds 2^31 bytes (the reference's size field is an int)");
-	HIP_TRY(b_out.reserve(total));
-	hipLaunchKernelGGL(k_ser_write_tail, dim3(1), dim3(1024), 0, m->stream, m->t, m->g, sa, b_list.as<u32>(), lv, L, l_tail, D, b_size.as<u64>(), b_off.as<u64>(),
-	                   b_out.as<uint8_t>());
-	for (u32 l = l_tail; l-- > first;)
-		if (h_cnt[l])
-			hipLaunchKernelGGL(k_ser_write, gridFor((u64)h_cnt[l] * 8u), dim3(256), 0, m->stream, m->t, m->g, sa, b_list.as<u32>() + h_off[l], h_cnt[l], l, D,
-			                   b_size.as<u64>(), b_off.as<u64>(), b_out.as<uint8_t>());
-	data.resize(total);
-	HIP_TRY(hipMemcpyAsync(data.data(), b_out.p, total, hipMemcpyDeviceToHost, m->stream));
-	HIP_TRY(hipStreamSynchronize(m->stream));
-	return UFOMAP_OK;
-}
-}  // namespace
-}  // extern "C++"
-
-size_t ufomap_map_write_ex(ufomap_map* m, const double* aabb_center, const double* aabb_half, int compress, unsigned min_depth,
-                           int compression_acceleration_level, int compression_level, int header, uint8_t* buf, size_t cap,
-                           long long* uncompressed_size)
-{
-	if (!m || ((nullptr == aabb_center) != (nullptr == aabb_half))) {
-		fail(UFOMAP_ERR_INVALID, "null map / half a bounding volume");
-		return (size_t)-1;
-	}
-	if (ufomap_map_wait(m) < 0) return (size_t)-1;
-	SerArgs sa{};
-	sa.has_bv = aabb_center ? 1u : 0u;
-	for (int k = 0; k < 3 && aabb_center; ++k) {
-		sa.vc[k] = aabb_center[k];
-		sa.vh[k] = aabb_half[k];
-	}
-	sa.min_depth = min_depth;
-	std::vector<uint8_t> data;
-	if (serialiseNodes(m, sa, data)) return (size_t)-1;
-	const long long usize = (long long)data.size();
-	if (uncompressed_size) *uncompressed_size = usize;
-	if (compress) {
-		// compressData (octree.h:1430-1458)
-		const Lz4& z = lz4();
-		if (!z.ok) {
-			fail(UFOMAP_ERR_UNSUPPORTED, "liblz4 could not be loaded: compressed output is not available");
-			return (size_t)-1;
-		}
-		const int bound = z.bound((int)data.size());
-		std::vector<uint8_t> comp((size_t)std::max(bound, 1));
-		const int n = 0 >= compression_level
-		                  ? z.fast(reinterpret_cast<const char*>(data.data()), reinterpret_cast<char*>(comp.data()), (int)data.size(), bound,
-		                           compression_acceleration_level)
-		                  : z.hc(reinterpret_cast<const char*>(data.data()), reinterpret_cast<char*>(comp.data()), (int)data.size(), bound,
-		                         compression_level);
-		if (n < 0) {
-			fail(UFOMAP_ERR_DEVICE, "LZ4 compression failed");
-			return (size_t)-1;
-		}
-		comp.resize((size_t)n);
-		data.swap(comp);
-	}
-	std::string h;
-	if (header) {
-		// text header exactly as Octree::write prints it (octree.h:850-861)
-		std::ostringstream hd;
-		hd << "# UFOMap file";
-		hd << "\n# (feel free to add / change comments, but leave the first line as it is!)\n#\n";
-		hd << "version " << "1.0.0" << std::endl;
-		hd << "id " << (m->g.color ? "occupancy_map_color" : "occupancy_map") << std::endl;
-		hd << "resolution " << m->g.res << std::endl;
-		hd << "depth_levels " << m->g.L << std::endl;
-		hd << "compressed " << (compress ? true : false) << std::endl;
-		hd << "uncompressed_data_size " << (int)usize << std::endl;
-		hd << "data" << std::endl;
-		h = hd.str();
-	}
-	const size_t total = h.size() + data.size();
-	if (buf && cap >= total) {
-		memcpy(buf, h.data(), h.size());
-		if (!data.empty()) memcpy(buf + h.size(), data.data(), data.size());
-	}
-	return total;
-}
-
-extern "C++" {
-namespace
-{
-// one pass over a node stream (readNodesRecurs, occupancy_map_base.h:1405-1455): a ReadRec per node with children
-struct StreamParser {
-	const uint8_t* p;
-	size_t n, pos = 0;
-	bool bad = false;
-	u32 D;
-	const MapGeom* g;
-	bool has_bv;
-	double vc[3], vh[3];
-	std::vector<ReadRec> recs[24];  // by level (= depth of the node)
-	size_t n_recs = 0;              // a record (~100 bytes) per node with children: bounded while parsing, not afterwards
-	static constexpr size_t kMaxRecs = 1u << 26;
-
-	bool inside(const double c[3], double h) const
-	{
-		if (!has_bv) return true;
-		for (int k = 0; k < 3; ++k) {
-			const double min1 = vc[k] - vh[k], max1 = vc[k] + vh[k], min2 = c[k] - h, max2 = c[k] + h;
-			if (!(min1 <= max2) || !(min2 <= max1)) return false;
-		}
-		return true;
-	}
-	void leaf(float* v, u32* rgb)
-	{
-		if (pos + D > n) {
-			bad = true;
-			*v = 0;
-			*rgb = 0;
-			return;
-		}
-		memcpy(v, p + pos, 4);
-		*rgb = D > 4 ? ((u32)p[pos + 4] | ((u32)p[pos + 5] << 8) | ((u32)p[pos + 6] << 16)) : 0u;
-		pos += D;
-	}
-	void node(u64 lk, u32 cd, const double c[3], u32 parent)
-	{
-		if (bad || pos >= n) {
-			bad = true;
-			return;
-		}
-		const uint8_t children = p[pos++];
-		if (++n_recs > kMaxRecs) {
-			bad = true;  // (more inner nodes than a map this library can hold: not a stream it wrote)
-			return;
-		}
-		const u32 mine = (u32)recs[cd].size();
-		ReadRec r{};
-		r.lk = lk;
-		r.parent = parent;
-		r.slot = NONE;
-		recs[cd].push_back(r);
-		const double chs = g->hs[cd - 1];
-		u32 set_mask = 0, inner_mask = 0;
-		for (u32 i = 0; i < 8 && !bad; ++i) {
-			const double cc[3] = {c[0] + ((i & 1) ? chs : -chs), c[1] + ((i & 2) ? chs : -chs), c[2] + ((i & 4) ? chs : -chs)};
-			if (!inside(cc, chs)) continue;
-			if ((children >> i) & 1u) {
-				inner_mask |= 1u << i;
-				if (2 == cd) {
-					// a depth-1 child: its 8 voxels follow without a mask byte (OMB:1427-1438)
-					ReadRec cr{};
-					cr.lk = (lk << 3) | (u64)i;
-					cr.parent = mine;
-					cr.slot = NONE;
-					const double ghs = g->hs[0];
-					for (u32 j = 0; j < 8 && !bad; ++j) {
-						const double gc[3] = {cc[0] + ((j & 1) ? ghs : -ghs), cc[1] + ((j & 2) ? ghs : -ghs), cc[2] + ((j & 4) ? ghs : -ghs)};
-						if (!inside(gc, ghs)) continue;
-						cr.set_mask |= 1u << j;
-						leaf(&cr.val[j], &cr.rgb[j]);
-					}
-					if (++n_recs > kMaxRecs) bad = true;
-					recs[1].push_back(cr);
-				} else {
-					node((lk << 3) | (u64)i, cd - 1, cc, mine);
-				}
-			} else {
-				float v;
-				u32 col;
-				leaf(&v, &col);
-				set_mask |= 1u << i;
-				recs[cd][mine].val[i] = v;
-				recs[cd][mine].rgb[i] = col;
-			}
-		}
-		recs[cd][mine].set_mask = set_mask;
-		recs[cd][mine].inner_mask = inner_mask;
-	}
-};
-
-// readNodes (occupancy_map_base.h:1379-1403) on an uncompressed node stream
-int readNodes(ufomap_map* m, const uint8_t* data, size_t n, const double* aabb_center, const double* aabb_half)
-{
-	const u32 L = m->g.L;
-	const u32 D = m->g.color ? 7u : 4u;
-	if (aabb_center) {
-		const double h = m->g.hs[L];
-		for (int k = 0; k < 3; ++k) {
-			const double min1 = aabb_center[k] - aabb_half[k], max1 = aabb_center[k] + aabb_half[k], min2 = 0.0 - h, max2 = 0.0 + h;
-			if (!(min1 <= max2) || !(min2 <= max1)) return UFOMAP_OK;  // no node intersects
-		}
-	}
-	if (n < 1) return fail(UFOMAP_ERR_INVALID, "empty node stream");
-	m->cs = m->stream;
-	m->args = ScanArgs{};
-	ScanCtl init;
-	memset(&init, 0, sizeof(init));
-	for (int k = 0; k < 3; ++k) {
-		init.aabb_min[k] = ~0ull;
-		init.aabb_max[k] = 0ull;
-	}
-	*m->h_ctl = init;
-	HIP_TRY(hipMemcpyAsync(m->b_ctl.p, m->h_ctl, sizeof(ScanCtl), hipMemcpyHostToDevice, m->stream));
-	m->ctl_clean = false;  // (the set's device control block no longer holds the fast path's start state)
-	ScanCtl* ctl = m->b_ctl.as<ScanCtl>();
-	m->scan_id += 1;
-	if (0 == data[0]) {
-		// the stream's root is a leaf: deleteChildren(root), readData, updateNode (occupancy_map_base.h:1394-1399)
-		if (n < 1 + (size_t)D) return fail(UFOMAP_ERR_INVALID, "truncated node stream");
-		float v;
-		memcpy(&v, data + 1, 4);
-		const u32 col = D > 4 ? ((u32)data[5] | ((u32)data[6] << 8) | ((u32)data[7] << 16)) : 0u;
-		hipLaunchKernelGGL(k_vol_root, gridFor((u64)m->t.mask + 1), dim3(256), 0, m->cs, m->t, m->g, v);
-		HIP_TRY(hipMemcpyAsync(reinterpret_cast<char*>(m->b_root.p) + offsetof(MapRoot, rgb), &col, 4, hipMemcpyHostToDevice, m->stream));
-		HIP_TRY(hipStreamSynchronize(m->stream));
-		return UFOMAP_OK;
-	}
-	StreamParser sp;
-	sp.p = data;
-	sp.n = n;
-	sp.pos = 1;  // behind the root's children byte
-	sp.D = D;
-	sp.g = &m->g;
-	sp.has_bv = nullptr != aabb_center;
-	for (int k = 0; k < 3 && aabb_center; ++k) {
-		sp.vc[k] = aabb_center[k];
-		sp.vh[k] = aabb_half[k];
-	}
-	const double c0[3] = {0.0, 0.0, 0.0};
-	sp.node(1, L, c0, NONE);
-	if (sp.bad) return fail(UFOMAP_ERR_INVALID, "truncated node stream");
-	// records level by level, root first; parents are indices into the level above
-	u32 off[24] = {0};
-	u64 total = 0;
-	for (u32 l = L; l >= 1; --l) {
-		off[l] = (u32)total;
-		total += sp.recs[l].size();
-	}
-	if (total > 0x7FFFFFF0ull) return fail(UFOMAP_ERR_CAPACITY, "node stream too large");
-	std::vector<ReadRec> all;
-	all.reserve((size_t)total);
-	for (u32 l = L; l >= 1; --l)
-		for (ReadRec r : sp.recs[l]) {
-			if (r.parent != NONE) r.parent += off[l + 1];
-			all.push_back(r);
-		}
-	// every record may create a block
-	{
-		const u64 cap = (u64)m->t.mask + 1;
-		if ((m->used_est + total) * 5 > cap * 3) {
-			const u64 want = tableCapFor(m->used_est + total, (u64)m->t.mask + 1);
-			if ((m->used_est + total) * 7 / 4 > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
-			int rc = growTable(m, (u32)want);
-			if (rc) return rc;
-		}
-	}
-	const u32 kcap = (u32)std::min<u64>(m->used_est + 8, 0x7FFFFFFFull);
-	HIP_TRY(m->b_crec.reserve((size_t)total * sizeof(ReadRec)));
-	HIP_TRY(m->b_dlist.reserve((size_t)kcap * 4));
-	HIP_TRY(hipMemcpyAsync(m->b_crec.p, all.data(), (size_t)total * sizeof(ReadRec), hipMemcpyHostToDevice, m->stream));
-	ReadRec* rec = m->b_crec.as<ReadRec>();
-	u32* kill = m->b_dlist.as<u32>();
-	for (u32 l = L; l >= 1; --l) {
-		const u32 cnt = (u32)sp.recs[l].size();
-		if (cnt) hipLaunchKernelGGL(k_read_down, gridFor(cnt, 256, 4096), dim3(256), 0, m->cs, m->t, m->g, rec, off[l], off[l] + cnt, l, kill, kcap, m->scan_id, ctl);
-	}
-	hipLaunchKernelGGL(k_vol_kill_mark, dim3(1), dim3(1), 0, m->cs, ctl, 0u);
-	for (u32 l = 0; l + 1 < L; ++l) {
-		hipLaunchKernelGGL(k_vol_kill, gridFor(std::max<u64>(kcap, 256), 256, 4096), dim3(256), 0, m->cs, m->t, kill, kcap, ctl);
-		hipLaunchKernelGGL(k_vol_kill_mark, dim3(1), dim3(1), 0, m->cs, ctl, 1u);
-	}
-	for (u32 l = 1; l <= L; ++l) {
-		const u32 cnt = (u32)sp.recs[l].size();
-		if (cnt) hipLaunchKernelGGL(k_read_up, gridFor(cnt, 256, 4096), dim3(256), 0, m->cs, m->t, m->g, rec, off[l], off[l] + cnt, l, ctl);
-	}
-	HIP_TRY(hipGetLastError());
-	m->pending = true;
-	HIP_TRY(hipStreamSynchronize(m->stream));  // (`all` is pageable: the upload has completed before it goes out of scope)
-	return finishPending(m);
-}
-}  // namespace
-}  // extern "C++"
-
-int ufomap_map_read_data(ufomap_map* m, const uint8_t* data, size_t n, const double* aabb_center, const double* aabb_half,
-                         double resolution, unsigned depth_levels, int uncompressed_data_size, int compressed)
-{
-	if (!m || (n && !data) || ((nullptr == aabb_center) != (nullptr == aabb_half))) return fail(UFOMAP_ERR_INVALID, "null argument");
-	HIP_TRY(hipSetDevice(m->device));
-	int rc = ufomap_map_wait(m);
-	if (rc) return rc;
-	if (m->g.res != resolution || m->g.L != depth_levels) {  // readData (octree.h:760-762)
-		rc = ufomap_map_clear_to(m, resolution, depth_levels);
-		if (rc) return rc;
-	}
-	{
-		// used_est may be stale after a clear
-		MapRoot root;
-		HIP_TRY(hipMemcpy(&root, m->b_root.p, sizeof(MapRoot), hipMemcpyDeviceToHost));
-		m->used_est = root.used;
-	}
-	if (compressed) {
-		// decompressData (octree.h:1460-1486)
-		const Lz4& z = lz4();
-		if (!z.ok) return fail(UFOMAP_ERR_UNSUPPORTED, "liblz4 could not be loaded: compressed input is not available");
-		if (uncompressed_data_size < 0) return fail(UFOMAP_ERR_INVALID, "negative uncompressed_data_size");
-		if (n > 0x7FFFFFFFull) return fail(UFOMAP_ERR_INVALID, "compressed stream longer than 2^31 bytes (LZ4's size arguments are ints)");
-		// (LZ4 cannot expand a block by more than a factor of 255: a header that claims more is not believed -- it would
-		// only size an allocation)
-		if ((u64)uncompressed_data_size > 255ull * (u64)n + 64ull) return fail(UFOMAP_ERR_INVALID, "uncompressed_data_size is impossible for a compressed stream of this length");
-		std::vector<uint8_t> raw((size_t)std::max(uncompressed_data_size, 1));
-		const int got = z.safe(reinterpret_cast<const char*>(data), reinterpret_cast<char*>(raw.data()), (int)n, uncompressed_data_size);
-		if (got < 0) return fail(UFOMAP_ERR_INVALID, "LZ4 decompression failed");
-		return readNodes(m, raw.data(), (size_t)got, aabb_center, aabb_half);
-	}
-	return readNodes(m, data, n, aabb_center, aabb_half);
-}
-
-int ufomap_map_read(ufomap_map* m, const uint8_t* buf, size_t n, double* resolution, unsigned* depth_levels)
-{
-	if (!m || !buf) return fail(UFOMAP_ERR_INVALID, "null argument");
-	// Octree::read / readHeader (octree.h:701-735, 640-688): first line, then "token value" lines up to "data"
-	static const char kHeader[] = "# UFOMap file";
-	if (n < sizeof(kHeader) - 1 || 0 != memcmp(buf, kHeader, sizeof(kHeader) - 1)) return fail(UFOMAP_ERR_INVALID, "not a UFOMap file");
-	size_t pos = 0;
-	auto line = [&](std::string* out) {
-		if (pos >= n) return false;
-		size_t e = pos;
-		while (e < n && buf[e] != '\n') ++e;
-		out->assign(reinterpret_cast<const char*>(buf) + pos, e - pos);
-		pos = std::min(n, e + 1);
-		return true;
-	};
-	std::string ln, id;
-	double res = 0;
-	unsigned levels = 0;
-	int compressed = 0, usize = 0;
-	bool got_data = false;
-	(void)line(&ln);  // the file header line
-	while (line(&ln)) {
-		std::istringstream is(ln);
-		std::string tok;
-		if (!(is >> tok)) continue;
-		if ("data" == tok) {
-			got_data = true;
-			break;
-		}
-		if ('#' == tok[0]) continue;
-		if ("id" == tok) is >> id;
-		else if ("resolution" == tok) is >> res;
-		else if ("depth_levels" == tok) is >> levels;
-		else if ("compressed" == tok) is >> compressed;
-		else if ("uncompressed_data_size" == tok) is >> usize;
-	}
-	if (!got_data || !(res > 0) || levels < 2 || levels > 21) return fail(UFOMAP_ERR_INVALID, "malformed UFOMap header");
-	if (id != (m->g.color ? "occupancy_map_color" : "occupancy_map"))
-		return fail(UFOMAP_ERR_INVALID, "file holds a '" + id + "', the map is a '" + (m->g.color ? "occupancy_map_color" : "occupancy_map") + "'");
-	int rc = ufomap_map_read_data(m, buf + pos, n - pos, nullptr, nullptr, res, levels, usize, compressed);
-	if (rc) return rc;
-	if (resolution) *resolution = res;
-	if (depth_levels) *depth_levels = levels;
-	return UFOMAP_OK;
-}
-
+#include "host_multi_gpu.inl"
+#include "host_serialise.inl"
 int ufomap_map_set_occupied_free_thres(ufomap_map* m, double occupied_thres, double free_thres)
 {
 	if (!m) return fail(UFOMAP_ERR_INVALID, "null map");
