@@ -112,7 +112,7 @@ def cpu_baseline(clouds, seq, budget_s=12.0):
                 ms_per_scan_mean=mean * 1e3, ms_per_scan_median=float(np.median(per_scan)) * 1e3)
 
 
-def other_configs(device, big):
+def other_configs(device, big, only=None):
     """BASELINE configs C1, C5 and C3 (insert depth 6 / 3 / 0) on this GPU: sync calls, cloud resident in HBM, the fixture's scan
     sequence into a fresh map. The map after every scan is compared with the UNMODIFIED reference: its digest recorded in
     tests/golden/digests.json (C1, C5, C3 at depth 0: 85-170 s per scan on the CPU), or the reference run here (C3 at depth 6 / 3)."""
@@ -129,21 +129,26 @@ def other_configs(device, big):
             kw["origin"] = scans.lidar_pose(kw.pop("pose"))
         return getattr(scans, g)(**kw)
 
-    def run(label, params, seq, want, warm_reps):
+    def run(label, params, seq, want, warm_reps, instrument=False):
+        from ufomap_amd import capi
         params = dict(params)
         color = params.pop("color", False)
         m = (OccupancyMapColor if color else OccupancyMap)(device=device, **params)
         ms, ok = [], True
+        allocs_fixture, allocs_warm = [], []
         last = None
         for k, (g, gkw, ikw) in enumerate(seq):
             origin, xyz, rgb = gen(g, gkw)
             d = torch.from_numpy(xyz).to(f"cuda:{device}")
             drgb = torch.from_numpy(rgb).to(f"cuda:{device}") if (rgb is not None and color) else None
             torch.cuda.synchronize()
+            a0 = capi.alloc_counters()
             t0 = time.perf_counter()
             m.insert_device(origin, d.data_ptr(), drgb.data_ptr() if drgb is not None else None, xyz.shape[0], ikw.get("max_range", -1.0),
                             ikw.get("depth", 0), ikw.get("discrete", False))
             ms.append((time.perf_counter() - t0) * 1e3)
+            a1 = capi.alloc_counters()
+            allocs_fixture.append({k: a1[k] - a0[k] for k in a1})
             if want is not None:
                 ok = ok and [str(v) for v in m.digest()] == want[k]
             last = (origin, d, drgb, xyz.shape[0], ikw)
@@ -154,19 +159,43 @@ def other_configs(device, big):
         for _ in range(warm_reps):  # the last scan again into the now warm map (values saturate; what a static sensor costs)
             origin, d, drgb, n, ikw = last
             torch.cuda.synchronize()
+            a0 = capi.alloc_counters()
             t0 = time.perf_counter()
             m.insert_device(origin, d.data_ptr(), drgb.data_ptr() if drgb is not None else None, n, ikw.get("max_range", -1.0), ikw.get("depth", 0),
                             ikw.get("discrete", False))
             warm.append((time.perf_counter() - t0) * 1e3)
+            a1 = capi.alloc_counters()
+            allocs_warm.append({k: a1[k] - a0[k] for k in a1})
+        kernels = None
+        if instrument and last is not None:
+            # one more warm repetition with HIP events around every launch (outside the timed ones): which kernel the time is in
+            origin, d, drgb, n, ikw = last
+            m.set_profiling(True)
+            m.reset_kernel_times()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            m.insert_device(origin, d.data_ptr(), drgb.data_ptr() if drgb is not None else None, n, ikw.get("max_range", -1.0), ikw.get("depth", 0),
+                            ikw.get("discrete", False))
+            prof_ms = (time.perf_counter() - t0) * 1e3
+            kt = m.kernel_times()
+            m.set_profiling(False)
+            kernels = dict(ms_with_events=round(prof_ms, 3),
+                           per_kernel_ms={k: round(v["total_ms"], 3) for k, v in sorted(kt.items(), key=lambda kv: -kv[1]["total_ms"]) if v["launches"]},
+                           launches={k: v["launches"] for k, v in kt.items() if v["launches"]})
         out[label] = dict(points=c["points"], rays=c["rays"], dda_steps=c["steps"], ms_per_scan_fixture=[round(v, 4) for v in ms],
                           ms_warm_median=(float(np.median(warm)) if warm else None), digest_ok=bool(ok), checked_against=("tests/golden/digests.json (unmodified reference)" if want is not None else None),
                           live_blocks=st["inner_nodes"], leaves=st["leaf_nodes"], table_bytes=st["bytes"],
                           fast_path_scans=int(m.debug()[61]), scans=len(seq) + warm_reps)
+        if instrument:
+            out[label].update(ms_warm_all=[round(v, 3) for v in warm], ms_warm_min=float(min(warm)) if warm else None,
+                              device_allocs_in_fixture_calls=allocs_fixture, device_allocs_in_warm_calls=allocs_warm, warm_kernels=kernels)
         return dig
 
-    for label, name, reps in (("C1_lidar16cm_continuous", "c1_full", 10), ("C5_lidar8cm_colour", "c5_colour_8cm", 10)) + ((("C3_rgbd2mm_depth0", "c3_depth0_full", 1),) if big else ()):
+    for label, name, reps in (("C1_lidar16cm_continuous", "c1_full", 10), ("C5_lidar8cm_colour", "c5_colour_8cm", 10)) + ((("C3_rgbd2mm_depth0", "c3_depth0_full", 5),) if big else ()):
+        if only and label not in only:
+            continue
         fx = fixtures[name]
-        run(label, fx["params"], fx["scans"], [s["digest"] for s in fx["steps"]], reps)
+        run(label, fx["params"], fx["scans"], [s["digest"] for s in fx["steps"]], reps, instrument=(label == "C3_rgbd2mm_depth0"))
         if label == "C3_rgbd2mm_depth0":
             # the one bandwidth-bound configuration: SURVEY 8d's B_scan = 24 N + 16 S + 16 (touched voxels) + 40 (touched node blocks),
             # with the fresh map's leaves / inner nodes as the touched voxels / blocks of its single scan
@@ -183,6 +212,8 @@ def other_configs(device, big):
     go, gx, _ = scans.rgbd()
     for depth in (6, 3):
         label = f"C3_rgbd2mm_depth{depth}"
+        if only and label not in only:
+            continue
         seq = [("rgbd", {}, dict(max_range=5.0, depth=depth, discrete=True))] * 2
         dig = run(label, dict(resolution=0.002), seq, None, 6)
         o = OracleMap(0.002, kind=kind)

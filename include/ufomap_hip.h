@@ -351,6 +351,11 @@ int ufomap_map_timeline(ufomap_map* m, unsigned long long* out, size_t n_words, 
  * Not part of the reference's surface. */
 int ufomap_map_debug(ufomap_map* m, uint64_t* out, int n);
 
+/* Diagnostics: device allocations of this process so far -- out[0] hipMalloc calls, [1] hipFree calls, [2] bytes asked
+ * for, [3] host nanoseconds spent inside them, [4] re-hashes of a node table. A warm scan must see none (bench.py reports
+ * the counts inside every timed call of its bandwidth-bound leg). Not part of the reference's surface. */
+void ufomap_alloc_counters(uint64_t out[5]);
+
 /* Raw HIP stream of the map (hipStream_t), for callers that need to order their own work. */
 void* ufomap_map_stream(ufomap_map* m);
 

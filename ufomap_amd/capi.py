@@ -30,7 +30,7 @@ SYMBOLS = [
     "ufomap_map_enable_minmax_change_detection", "ufomap_map_iterate", "ufomap_map_write_ex", "ufomap_map_read", "ufomap_map_read_data",
     "ufomap_map_scan_keys", "ufomap_map_scan_keys_rgb", "ufomap_map_get_keys", "ufomap_map_apply_keys", "ufomap_map_apply_keys_batch",
     "ufomap_comm_unique_id", "ufomap_comm_create", "ufomap_comm_from_nccl", "ufomap_comm_destroy", "ufomap_comm_stats", "ufomap_comm_counters", "ufomap_map_insert_batch", "ufomap_dev_expf", "ufomap_map_timeline",
-    "ufomap_map_stream", "ufomap_map_debug", "ufomap_map_set_option",
+    "ufomap_map_stream", "ufomap_map_debug", "ufomap_map_set_option", "ufomap_alloc_counters",
 ]
 
 _lib = None
@@ -152,8 +152,17 @@ def load():
     lib.ufomap_map_set_option.argtypes = [vp, C.c_char_p, C.c_longlong]
     lib.ufomap_map_stream.restype = vp
     lib.ufomap_map_stream.argtypes = [vp]
+    lib.ufomap_alloc_counters.restype = None
+    lib.ufomap_alloc_counters.argtypes = [u64p]
     _lib = lib
     return lib
+
+
+def alloc_counters():
+    """``ufomap_alloc_counters``: device allocations of this process so far."""
+    out = (C.c_uint64 * 5)()
+    load().ufomap_alloc_counters(out)
+    return dict(zip(("mallocs", "frees", "bytes", "host_ns", "rehashes"), (int(v) for v in out)))
 
 
 def check(rc):

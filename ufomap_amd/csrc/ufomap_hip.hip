@@ -60,6 +60,11 @@ int fail(int code, const std::string& msg)
 		}                                                                                          \
 	} while (0)
 
+// Process-wide counts of device allocations (ufomap_alloc_counters): a warm scan must not allocate -- hipMalloc / hipFree
+// synchronise the device and take as long as the driver's page tables need (the one leg whose time moved 7 x
+// between boxes reports how many it saw inside every timed call).
+std::atomic<uint64_t> g_n_malloc{0}, g_n_free{0}, g_bytes_malloc{0}, g_ns_alloc{0}, g_n_rehash{0};
+
 // grow-only device buffer
 // device allocation, move-only owner: released when it goes out of scope (every early return of the functions below)
 struct DevBuf {
@@ -88,15 +93,22 @@ struct DevBuf {
 	hipError_t reserve(size_t bytes)
 	{
 		if (bytes <= cap) return hipSuccess;
+		const auto t0 = std::chrono::steady_clock::now();
+		size_t want = std::max(bytes, cap + cap / 2);
 		if (p) {
 			hipError_t e = hipFree(p);
+			g_n_free.fetch_add(1, std::memory_order_relaxed);
 			if (e != hipSuccess) return e;
 			p = nullptr;
 			cap = 0;
 		}
-		size_t want = std::max(bytes, cap + cap / 2);
-		want = (want + 255) & ~(size_t)255;
+		// (large buffers in whole 2 MiB pieces: the driver maps them with 2 MiB fragments, and random 64-byte accesses to a
+		// multi-gigabyte node table are then one TLB entry per 2 MiB instead of one per 4 KiB)
+		want = want >= (1u << 21) ? ((want + (1u << 21) - 1) & ~(size_t)((1u << 21) - 1)) : ((want + 255) & ~(size_t)255);
 		hipError_t e = hipMalloc(&p, want);
+		g_n_malloc.fetch_add(1, std::memory_order_relaxed);
+		g_bytes_malloc.fetch_add(want, std::memory_order_relaxed);
+		g_ns_alloc.fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(), std::memory_order_relaxed);
 		if (e != hipSuccess) {
 			p = nullptr;
 			return e;
@@ -106,7 +118,12 @@ struct DevBuf {
 	}
 	void release()
 	{
-		if (p) (void)hipFree(p);
+		if (p) {
+			const auto t0 = std::chrono::steady_clock::now();
+			(void)hipFree(p);
+			g_n_free.fetch_add(1, std::memory_order_relaxed);
+			g_ns_alloc.fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(), std::memory_order_relaxed);
+		}
 		p = nullptr;
 		cap = 0;
 	}
@@ -446,6 +463,7 @@ int growTable(ufomap_map* m, u32 new_cap)
 {
 	Table nt{};
 	TableBufs nb;
+	g_n_rehash.fetch_add(1, std::memory_order_relaxed);
 	int rc = allocTable(m, new_cap, &nt, &nb);
 	if (rc) return rc;
 	u32* d_fail = m->b_ctl.as<u32>() + (sizeof(ScanCtl) + 3) / 4;  // two spare words after the control block: failures, blocks copied
@@ -3381,6 +3399,17 @@ int ufomap_map_debug(ufomap_map* m, uint64_t* out, int n)
 	if (n > 51) out[51] = m->n_phase_resets;  // phaseGuard
 	for (int k = 0; k < 4 && 52 + k < n; ++k) out[52 + k] = m->host_ns[k];  // host time inside doInsert (ns): scan enqueue, map enqueue, join, total
 	return rc;
+}
+
+// device allocations of this process so far: hipMalloc calls, hipFree calls, bytes asked for, host nanoseconds inside them,
+// re-hashes of a node table
+void ufomap_alloc_counters(uint64_t out[5])
+{
+	out[0] = g_n_malloc.load();
+	out[1] = g_n_free.load();
+	out[2] = g_bytes_malloc.load();
+	out[3] = g_ns_alloc.load();
+	out[4] = g_n_rehash.load();
 }
 
 void* ufomap_map_stream(ufomap_map* m) { return m ? (void*)m->stream : nullptr; }
