@@ -1,0 +1,149 @@
+"""Round 4 (run with -m gpu on an MI355X): the VOLUME path (vol_kernels.h) -- depth-0 scans whose ray grid is beyond the
+steady-state path's, e.g. a 2 mm RGB-D frame: ray cells and hit voxels in tile-major brick grids (k_vhits, k_vdda, k_vlist),
+then the tiled tree update over the listed tiles (k_tile<VOL>, k_up level after level, k_ftail). Against the reference scan by
+scan: values, flags, leaf structure under pruning, byte stream; the marking stage against the port's hit / miss codes."""
+import numpy as np
+import pytest
+import torch  # noqa: F401  (before the HIP library)
+
+from conftest import same_dump
+
+pytestmark = pytest.mark.gpu
+
+
+def _kind():
+    import oracle
+    return "reference" if oracle.available("reference") else "port"
+
+
+def _maps(kind="port", **params):
+    from oracle import OracleMap
+    from ufomap_amd import OccupancyMap
+    return OccupancyMap(**params), OracleMap(kind=kind, **params)
+
+
+def _insert(g, origin, xyz, max_range, discrete, async_=False):
+    from ufomap_amd import PointCloud
+    (g.insertPointCloudDiscrete if discrete else g.insertPointCloud)(origin, PointCloud(xyz), max_range, 0, False, 0, async_)
+
+
+def _assert_same_map(g, o, what=""):
+    gl, ol = g.leaves(True), o.leaves(True)
+    assert len(gl[0]) == len(ol[0]), f"{what}: leaf count {len(gl[0])} vs oracle {len(ol[0])}"
+    assert np.array_equal(gl[0], ol[0]) and np.array_equal(gl[1], ol[1]), f"{what}: leaf codes/depths differ"
+    assert np.array_equal(gl[2], ol[2]), f"{what}: log-odds differ"
+    assert same_dump(g.inner(), o.inner()), f"{what}: inner-node dump differs"
+    assert g.write() == o.write(), f"{what}: map byte stream differs"
+
+
+def _force_vol(g):
+    g.set_option("vol", 2)   # also for ray grids the steady-state path would take
+    g.set_option("spec", 0)  # ... which is chosen before the boxes are known: no predicted grids
+
+
+def _wander(n_scans, beams=32, azimuths=512, spread=1.0, seed0=300):
+    from ufomap_amd import scans
+    base = np.array(scans.lidar_pose(0), dtype=np.float64)
+    rng = np.random.default_rng(seed0)
+    out = []
+    for i in range(n_scans):
+        off = rng.uniform(-spread, spread, 3) * [1, 1, 0.1]
+        out.append(scans.lidar64(beams=beams, azimuths=azimuths, origin=tuple(base + off), seed=seed0 + i)[:2])
+    return out
+
+
+@pytest.mark.parametrize("discrete,res", [(True, 0.16), (False, 0.16), (True, 0.08)])
+def test_volume_path_scan_by_scan(discrete, res):
+    """A wandering LiDAR forced onto the volume path: voxels are hit, missed, saturate, collapse and are re-expanded; the map
+    equals the reference's after every few scans, the marking stage the port's hit and miss codes."""
+    g, o = _maps(kind=_kind(), resolution=res)
+    _, p = _maps(kind="port", resolution=res)
+    _force_vol(g)
+    for i, (origin, xyz) in enumerate(_wander(14)):
+        _insert(g, origin, xyz, 12.0, discrete, async_=bool(i & 1))
+        o.insert(origin, xyz, max_range=12.0, discrete=discrete)
+        p.insert(origin, xyz, max_range=12.0, discrete=discrete)
+        g.insertPointCloudWait()
+        assert np.array_equal(g.last_hits(), p.last_hits()), f"scan {i}: hit voxels differ"
+        assert np.array_equal(g.last_misses(), p.last_misses()), f"scan {i}: ray cells differ"
+        assert g.last_counts()["steps"] == p.last_steps(), f"scan {i}: DDA step count differs"
+        if i in (0, 1, 5, 13):
+            _assert_same_map(g, o, f"after scan {i}")
+    d = g.debug()
+    assert d[50] == 14 and d[61] == 0, f"the scans did not take the volume path: {d[48:51]}, fast {d[61]}"
+
+
+def test_volume_path_saturation_and_pruning():
+    """The same two scans over and over: everything saturates, subtrees collapse and are re-expanded (the last-update chain through
+    k_tile, k_up on two levels and k_ftail)."""
+    from ufomap_amd import scans
+    g, o = _maps(kind=_kind(), resolution=0.16)
+    _force_vol(g)
+    poses = [scans.lidar_pose(0), tuple(np.array(scans.lidar_pose(0)) + [0.35, -0.2, 0.0])]
+    clouds = [scans.lidar64(beams=32, azimuths=512, origin=p, seed=7 + k)[:2] for k, p in enumerate(poses)]
+    for i in range(22):
+        origin, xyz = clouds[i & 1]
+        _insert(g, origin, xyz, 8.0, True)
+        o.insert(origin, xyz, max_range=8.0, discrete=True)
+        if i in (1, 9, 21):
+            _assert_same_map(g, o, f"after scan {i}")
+    assert g.debug()[50] == 22
+
+
+def test_volume_path_grows_the_table_in_the_middle_of_a_walk():
+    """With the up-front growth switched off the first walk runs out of its reserve: tiles stand back, the table is exchanged, the
+    tiles that are left are run -- more than once as the map grows; the map stays the reference's."""
+    from ufomap_amd import scans
+    g, o = _maps(kind=_kind(), resolution=0.08)
+    _force_vol(g)
+    g.set_option("vol_pregrow", 0)
+    for s in range(3):
+        origin, xyz, _ = scans.lidar64(beams=32, azimuths=1024, origin=scans.lidar_pose(s), seed=100 + s)
+        _insert(g, origin, xyz, 20.0, True)
+        o.insert(origin, xyz, max_range=20.0, discrete=True)
+        _assert_same_map(g, o, f"scan {s}")
+    d = g.debug()
+    assert d[50] == 3 and d[49] >= 1, f"no growth in the middle of a walk: {d[48:51]}"
+
+
+def test_volume_path_takes_the_rgbd_frame_by_itself():
+    """BASELINE configs[2] at insert depth 0 on a reduced frame (160 x 120 pixels, 2 mm: rays of up to 1 500 cells, 1.1e8 leaves):
+    nothing forced -- the scan's box is beyond the steady-state path -- leaf for leaf against the checker, fresh and warm."""
+    from ufomap_amd import scans
+    import golden_util
+    g, o = _maps(kind=_kind(), resolution=0.002)
+    origin, xyz, _ = scans.rgbd(width=160, height=120)
+    for i in range(2):
+        _insert(g, origin, xyz, 5.0, True)
+        o.insert(origin, xyz, max_range=5.0, discrete=True)
+        gl, ol = g.leaves(True), o.leaves(True)
+        assert same_dump(gl, ol), f"scan {i}: leaves differ"
+        assert same_dump(g.inner(), o.inner()), f"scan {i}: inner nodes differ"
+        assert g.digest() == golden_util.dump_digest(ol, o.inner())
+    d = g.debug()
+    assert d[50] == 2 and d[49] == 0, f"volume path scans {d[50]}, growths in a walk {d[49]}"
+    from ufomap_amd import capi
+    a0 = capi.alloc_counters()
+    _insert(g, origin, xyz, 5.0, True)
+    a1 = capi.alloc_counters()
+    assert a1["mallocs"] == a0["mallocs"] and a1["rehashes"] == a0["rehashes"], "a warm scan allocated device memory"
+
+
+def test_general_path_and_volume_path_agree_on_a_clipped_scan():
+    """A scan with a ray that is clipped at the map cube (a return far outside a small map) turns to the general path by itself:
+    the same map as a handle that never tries the volume path (and the checker's: the segment enters through a min face)."""
+    from ufomap_amd import OccupancyMap, scans
+    g, o = _maps(kind=_kind(), resolution=0.16, depth_levels=8)  # a 41 m cube
+    g2 = OccupancyMap(resolution=0.16, depth_levels=8)
+    g2.set_option("vol", 0)
+    g2.set_option("spec", 0)
+    _force_vol(g)
+    origin, xyz, _ = scans.lidar64(beams=16, azimuths=256)
+    xyz = xyz.copy()
+    xyz[5] = [-60.0, 3.0, 1.0]
+    _insert(g, origin, xyz, -1.0, False)
+    _insert(g2, origin, xyz, -1.0, False)
+    o.insert(origin, xyz, max_range=-1.0, discrete=False)
+    assert g.debug()[48] == 1 and g.debug()[50] == 0
+    assert same_dump(g.leaves(True), g2.leaves(True)) and same_dump(g.inner(), g2.inner())
+    _assert_same_map(g, o, "clipped")

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libufomap_hip.so")
 SOURCES = ["ufomap_hip.hip"]
-HEADERS = ["geom.h", "table.h", "expf_ref.h", "scan_kernels.h", "map_kernels.h", "fast_kernels.h", "host_fast_path.inl", "host_multi_gpu.inl",
+HEADERS = ["geom.h", "table.h", "expf_ref.h", "scan_kernels.h", "map_kernels.h", "fast_kernels.h", "vol_kernels.h", "host_fast_path.inl", "host_vol.inl", "host_multi_gpu.inl",
            "host_serialise.inl", os.path.join("..", "..", "include", "ufomap_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
          "-fgpu-rdc" if False else "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-bitwise-instead-of-logical"]

@@ -1096,13 +1096,30 @@ __device__ inline bool tileKey(const MapGeom& g, const FastGeo& fg, u32 tile, u6
 // hit); misses leave colours alone -- so the last update beneath a node (a miss) never changes a colour and the "reached"
 // chain is the one of plain maps; what colours add: a summary per node (root mean square per channel), "all children
 // equal" includes their colours, and a changed colour summary re-evaluates the parent like a changed value does.
-template <bool COLOR>
+// VOL (the volume path, vol_kernels.h: ray grids of millions of tiles, e.g. a 2 mm RGB-D frame): the wave's tile comes from the
+// list of active tiles, the scan's ray cells and hit voxels from TILE-MAJOR brick grids -- per tile eight 64-bit words, one
+// per 4x4x4 cells, bit = x | y << 2 | z << 4 inside the brick -- i.e. one 64-byte line per tile and grid; one scan per walk.
+// Blocks are created against a reserve (sharded counters): a tile that finds it used up has not written anything yet,
+// flags ERR_GROW and stands back -- the host grows the table and runs the tiles that are left (their records do not carry
+// the walk's number yet).
+struct TileVol {
+	u64* M;           // ray cells
+	u64* H;           // hit voxels
+	const u32* list;  // active tiles
+	u32 count;
+	u32* resv;        // 64 counters of blocks created by this walk
+	u32 resv_lim;     // ... and what each may reach
+	u32 clean;        // leave the tile's words of M and H zeroed (the grids are clean for the next scan)
+};
+template <bool COLOR, bool VOL = false>
 __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, const Pipe* __restrict__ p, unsigned long long f, TileRec* __restrict__ recs,
-                                              float upd_hit, float upd_miss, u32 scan_id, const u32* __restrict__ prev_stat, ChangeLog cl)
+                                              float upd_hit, float upd_miss, u32 scan_id, const u32* __restrict__ prev_stat, ChangeLog cl, TileVol va)
 {
 	const u32 lane = threadIdx.x & 63u;
-	const u32 tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+	u32 tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+	if (VOL) tile = tile < va.count ? va.list[tile] : 0xFFFFFFFFu;
 	if (tile >= fg.ntiles) return;
+	if (VOL && recs[tile].seq == scan_id) return;  // (a repeat after the table has grown: the tile is done)
 	__builtin_amdgcn_s_setprio(2);  // (the map stream is the pipeline's critical path: ahead of the ray kernel's waves)
 	const Pipe::Slot sl = p->slot[f & (UFO_RING - 1u)];
 	const u32 B = sl.B;  // (0: the slot's scan went with an earlier walk)
@@ -1115,7 +1132,8 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 	u32 tmask = 0;  // bit b: the tile holds a ray cell of scan b
 	for (u32 b = 0; b < B; ++b) {
 		errs |= UFO_DESC(b).ctl->err;
-		tmask |= ((UFO_DESC(b).tile_bits[tile >> 5] >> (tile & 31u)) & 1u) << b;
+		if (VOL) tmask |= 1u << b;  // (the list holds active tiles only)
+		else tmask |= ((UFO_DESC(b).tile_bits[tile >> 5] >> (tile & 31u)) & 1u) << b;
 	}
 	if (errs) return;  // (uniform)
 	if (!tmask) return;
@@ -1137,7 +1155,15 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 	const u32 rowW = fg.rowBits >> 5;
 	// the lane's 8 cells in every scan's grids: 8 bits of ray cells + 8 bits of hits per scan, packed (scans 0-7 / 8-15)
 	u64 mmA = 0, mmB = 0, hmA = 0, hmB = 0;
-	{
+	const u32 vbrick = (bx >> 1) | ((by >> 1) << 1) | ((bz >> 1) << 2), vsh = 2u * (bx & 1u) + 8u * (by & 1u) + 32u * (bz & 1u);
+	if (VOL) {
+		// the lane's 2x2x2 cells inside their brick: bits vsh + cx + 4 cy + 16 cz
+		const u64 mw = va.M[(size_t)tile * 8u + vbrick] >> vsh, hw = va.H[(size_t)tile * 8u + vbrick] >> vsh;
+		const u32 ml = (u32)mw, hl = (u32)hw;
+		mmA = (ml & 3u) | (((ml >> 4) & 3u) << 2) | (((ml >> 16) & 3u) << 4) | (((ml >> 20) & 3u) << 6);
+		hmA = (hl & 3u) | (((hl >> 4) & 3u) << 2) | (((hl >> 16) & 3u) << 4) | (((hl >> 20) & 3u) << 6);
+		hmA &= mmA;  // (a hit voxel is a ray cell: the end cell of its point's ray)
+	} else {
 		u32 widx[4];
 		bool wok[4];
 #pragma unroll
@@ -1238,6 +1264,16 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 		if (__ballot(need3 || mk2 || mk1)) {
 			const u32 max_probe = (t.mask >> 1) + 1;
 			bool dummy;
+			if (VOL) {
+				// nothing has been written yet: the blocks this tile creates come out of the walk's reserve, or the tile stands back
+				const u32 need = (u32)__popcll(__ballot(mk1)) + (u32)__popcll(__ballot(mk2)) + (mk3 ? 1u : 0u);
+				u32 over = 0;
+				if (need && 0 == lane) over = (atomicAdd(&va.resv[tile & 63u], need) + need > va.resv_lim) ? 1u : 0u;
+				if (__shfl((int)over, 0)) {
+					if (0 == lane) atomicOr(&UFO_DESC(B - 1u).ctl->err, ERR_GROW);
+					return;
+				}
+			}
 			if (need3 && 0 == lane) {
 				if (mk3) s3 = tableEnsure(t, lk3, scan_id, max_probe, &dummy, &n_created);
 				v3s = t.root->occ;
@@ -1530,6 +1566,10 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 		n_created += __shfl_xor(n_created, o);
 		nhit += __shfl_xor(nhit, o);
 	}
+	if (VOL && va.clean && 0 == vsh) {
+		va.M[(size_t)tile * 8u + vbrick] = 0ull;
+		va.H[(size_t)tile * 8u + vbrick] = 0ull;
+	}
 	if (0 == lane) {
 		t.flags(s3) = fl3r;  // (the parent link of a new block: k_ftail)
 		TileRec r;
@@ -1607,7 +1647,10 @@ __global__ __launch_bounds__(256) void k_up(Table t, MapGeom g, FastGeo fg, cons
 	ScanCtl* const ctl = UFO_DESC(B - 1u).ctl;
 	const u32 L = g.L;
 	const u32 lane = threadIdx.x & 63u, sub = lane & 7u;
-	const UpperLevel u4 = upperLevel(fg, 4u);
+	// (fg.tl = 3: the children are k_tile's tiles, the blocks level 4. The volume path runs this kernel level after level,
+	// fg = the grid of the level below, until k_ftail's LDS holds what is left above)
+	const u32 lv = fg.tl + 1u;
+	const UpperLevel u4 = upperLevel(fg, lv);
 	const u32 n4 = u4.n[0] * u4.n[1] * u4.n[2];
 	const u32 cell = (blockIdx.x * blockDim.x + threadIdx.x) >> 3;
 	// the lane's child: tile (2 * cell + d) of the tile grid
@@ -1630,7 +1673,7 @@ __global__ __launch_bounds__(256) void k_up(Table t, MapGeom g, FastGeo fg, cons
 	const bool act = 0 != grpOr(have ? 1u : 0u, 0);  // (whole groups of 8 lanes)
 	// ---- createNode (octree.h:997-1016): lane 0 of the group finds or creates the block; a new (or revived) block inherits
 	// the value of the nearest node above that has a live block (nothing above level 4 is written during this launch) ----
-	const u64 lk = (1ULL << (3 * (L - 4u))) | morton3((u32)ac[0], (u32)ac[1], (u32)ac[2]);
+	const u64 lk = (1ULL << (3 * (L - lv))) | morton3((u32)ac[0], (u32)ac[1], (u32)ac[2]);
 	u32 s = NONE, n_created = 0, fw = 0;
 	bool cr = false;
 	float vin = 0.f;
@@ -1680,7 +1723,7 @@ __global__ __launch_bounds__(256) void k_up(Table t, MapGeom g, FastGeo fg, cons
 		const u32 bits = r.bits;
 		touched = r.counts & 2047u;
 		created += r.counts >> 25;
-		if (bits & 64u) t.parent(r.slot) = s;  // a new level-3 block: its parent link
+		if ((bits & 64u) && r.slot != NONE) t.parent(r.slot) = s;  // a new level-3 block: its parent link
 		if (bits & 128u) clrb |= 1u << (16 + sub);
 		else if (bits & 64u) setb |= 1u << (16 + sub);
 		key = ((r.last + 1u) << 4) | (sub + 1u);
@@ -1737,7 +1780,7 @@ __global__ __launch_bounds__(256) void k_up(Table t, MapGeom g, FastGeo fg, cons
 			o.last = (topkey >> 4) - 1u;
 			o.rgb = rgb;
 			recs_up[cell] = o;
-			atomicOr(&up_bits[cell >> 5], 1u << (cell & 31u));
+			if (up_bits) atomicOr(&up_bits[cell >> 5], 1u << (cell & 31u));
 		}
 	}
 	for (int o = 32; o > 0; o >>= 1) {

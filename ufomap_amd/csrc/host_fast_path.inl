@@ -106,6 +106,7 @@ int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, si
 	for (int k = 0; k < 8; ++k) m->counts[k] = 0;
 	m->counts[0] = n;
 	m->last_depth = 0;
+	m->vol = false;
 	m->haveH = m->haveM = true;
 	m->gridM = m->spec_grid;
 	m->gridH = m->spec_grid;
@@ -499,10 +500,10 @@ int enqueueSlot(ufomap_map* m, int k)
 		const u32 tw = (m->opt_tile_waves >= 1 && m->opt_tile_waves <= 4) ? (u32)m->opt_tile_waves : 4u;  // wavefronts (= tiles) per workgroup
 		if (m->g.color)
 			hipLaunchKernelGGL(k_tile<true>, dim3((fg.ntiles + tw - 1) / tw), dim3(64u * tw), 0, m->cs, m->t, m->g, fg, pipe, (unsigned long long)f,
-			                   m->b_tilerec.as<TileRec>(), m->g.hit, miss, m->scan_id, prev_stat, changeLog(m));
+			                   m->b_tilerec.as<TileRec>(), m->g.hit, miss, m->scan_id, prev_stat, changeLog(m), TileVol{});
 		else
 			hipLaunchKernelGGL(k_tile<false>, dim3((fg.ntiles + tw - 1) / tw), dim3(64u * tw), 0, m->cs, m->t, m->g, fg, pipe, (unsigned long long)f,
-			                   m->b_tilerec.as<TileRec>(), m->g.hit, miss, m->scan_id, prev_stat, changeLog(m));
+			                   m->b_tilerec.as<TileRec>(), m->g.hit, miss, m->scan_id, prev_stat, changeLog(m), TileVol{});
 	}
 	const u32 nwords3 = (fg.ntiles + 31u) / 32u;
 	if (big_grid) {

@@ -458,7 +458,7 @@ int fastBatchStep(ufomap_map* m, ufomap_comm* c, const double origin[3], const d
 			ProfScope ps(m, "k_tile");
 			const u32 tw = (m->opt_tile_waves >= 1 && m->opt_tile_waves <= 4) ? (u32)m->opt_tile_waves : 4u;
 			hipLaunchKernelGGL(k_tile<false>, dim3((fg.ntiles + tw - 1) / tw), dim3(64u * tw), 0, m->stream, m->t, m->g, fg, bp, 0ull, m->b_tilerec.as<TileRec>(), m->g.hit,
-			                   miss, m->scan_id, prev_stat, changeLog(m));
+			                   miss, m->scan_id, prev_stat, changeLog(m), TileVol{});
 		}
 		{
 			ProfScope ps(m, "k_ftail");

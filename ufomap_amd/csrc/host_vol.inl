@@ -1,0 +1,232 @@
+// host side of the volume path (vol_kernels.h): eligibility and the tile grids of the levels, the scan half (volScan, called by
+// scanPhase once the boxes are known) and the tree update (volMapPhase). Included by ufomap_hip.hip inside its anonymous namespace.
+
+// the grid of the level above fg's (what k_up writes when fg is what it reads)
+FastGeo upGeoOf(const FastGeo& fg)
+{
+	FastGeo u = fg;
+	u64 nt = 1;
+	for (int a = 0; a < 3; ++a) {
+		u.tbase[a] = fg.tbase[a] >> 1;
+		u.nt[a] = (u32)(((fg.tbase[a] + (i32)fg.nt[a] - 1) >> 1) - u.tbase[a] + 1);
+		nt *= u.nt[a];
+	}
+	u.ntiles = (u32)std::min<u64>(nt, 0xFFFFFFFFull);
+	u.tl = fg.tl + 1u;
+	return u;
+}
+
+// A depth-0 scan of a plain map whose ray box the steady-state path cannot take (more than 1022 cells per axis, or a bit grid
+// beyond 8 MiB) and whose brick grids fit the scratch limit.
+bool volPlan(const ufomap_map* m, const Grid& gr, unsigned depth, int simple, unsigned early_stopping, const uint8_t* d_rgb, VolPlan* vp)
+{
+	if (!m->opt_vol || 0 != depth || simple || early_stopping || d_rgb || m->g.color || m->chg_enabled || m->g.L < 6) return false;
+	const bool packed = 2 * gr.nb[0] < 1023 && 2 * gr.nb[1] < 1023 && 2 * gr.nb[2] < 1023;
+	const u64 bytes1 = (u64)(gridRowBits(gr) >> 3) * (2ull * (u64)gr.nb[1]) * (2ull * (u64)gr.nb[2]);
+	if (m->opt_vol < 2 && packed && bytes1 <= (8ull << 20)) return false;  // (the fast path's sizes; option vol = 2: tests run small scans here)
+	for (int a = 0; a < 3; ++a)
+		if (gr.nb[a] > (1 << 20)) return false;
+	FastGeo fg{};
+	fg.gr = gr;
+	u64 nt = 1;
+	for (int a = 0; a < 3; ++a) {
+		fg.tbase[a] = gr.base[a] >> 3;
+		fg.nt[a] = (u32)(((gr.base[a] + 2 * gr.nb[a] - 1) >> 3) - fg.tbase[a] + 1);
+		nt *= fg.nt[a];
+	}
+	if (nt >= (1ull << 28)) return false;  // (32-bit word indices: 8 words per tile)
+	fg.ntiles = (u32)nt;
+	fg.tl = 3;
+	// M + H (64 bytes per tile each), the list, the records
+	if (nt * (64 + 64 + 4 + 40) > m->scratch_limit) return false;
+	vp->n = 0;
+	vp->lv[vp->n++] = fg;
+	vp->rec_total = nt;
+	UpperGeo ug;
+	for (;;) {
+		const FastGeo& top = vp->lv[vp->n - 1];
+		if (top.tl >= m->g.L) return false;
+		if (vp->n > 1 && top.ntiles <= UFO_FAST_MAX_TILES && makeUpperGeo(top, m->g.L, &ug) <= UFO_UPPER_MAX) break;
+		if (vp->n >= 20 || top.tl + 1u >= m->g.L) return false;
+		vp->lv[vp->n] = upGeoOf(top);
+		vp->rec_total += vp->lv[vp->n].ntiles;
+		++vp->n;
+	}
+	for (int a = 0; a < 3; ++a) {
+		vp->vg.cbase[a] = fg.tbase[a] * 8;
+		vp->vg.nt[a] = fg.nt[a];
+	}
+	vp->vg.ntiles = fg.ntiles;
+	return true;
+}
+
+// Scan half of the volume path, after k_classify / k_select / k_reduce_boxes and the read-back of the boxes (scanPhase): hit
+// voxels and ray cells into the brick grids, the list of active tiles. Returns 1 when the scan has to take the general path
+// after all (a ray clipped at the map cube): nothing but scratch has been touched.
+int volScan(ufomap_map* m, const D3& sensor, const VolPlan& vp, u32 n_hits, u32 n_rays)
+{
+	const u64 nt = vp.vg.ntiles;
+	const size_t cm = m->b_vM.cap, ch = m->b_vH.cap, cr = m->b_vrec.cap;
+	HIP_TRY(m->b_vM.reserve(nt * 64));
+	HIP_TRY(m->b_vH.reserve(nt * 64));
+	HIP_TRY(m->b_vlist.reserve(nt * 4));
+	HIP_TRY(m->b_vrec.reserve(vp.rec_total * sizeof(TileRec)));
+	HIP_TRY(m->b_vaux.reserve(1024));
+	HIP_TRY(m->b_vupbits.reserve(UFO_FAST_MAX_TILES / 8));
+	if (cm != m->b_vM.cap || ch != m->b_vH.cap) m->vol_dirty = true;
+	if (cr != m->b_vrec.cap) HIP_TRY(hipMemsetAsync(m->b_vrec.p, 0, m->b_vrec.cap, m->cs));  // (a record counts if it carries the walk's number)
+	if (m->vol_dirty) {
+		HIP_TRY(hipMemsetAsync(m->b_vM.p, 0, m->b_vM.cap, m->cs));
+		HIP_TRY(hipMemsetAsync(m->b_vH.p, 0, m->b_vH.cap, m->cs));
+	}
+	m->vol_dirty = true;  // (until the tree update has left the grids clean)
+	HIP_TRY(hipMemsetAsync(m->b_vaux.p, 0, 1024, m->cs));
+	HIP_TRY(hipMemsetAsync(m->b_vupbits.p, 0, m->b_vupbits.cap, m->cs));
+	ScanCtl* ctl = m->b_ctl.as<ScanCtl>();
+	u32* aux = m->b_vaux.as<u32>();  // [0..63] the reserve's counters, [64] tiles listed, [65] tiles done
+	if (n_hits) {
+		ProfScope ps(m, "k_vhits");
+		hipLaunchKernelGGL(k_vhits, gridFor(n_hits), dim3(256), 0, m->cs, m->g, vp.vg, m->b_hit_code.as<u64>(), ctl, m->b_vH.as<u64>(), ctl);
+	}
+	{
+		ProfScope ps(m, "k_vdda");
+		hipLaunchKernelGGL(k_vdda, dim3((n_rays + 255) / 256), dim3(256), 0, m->cs, m->g, sensor, m->gridM, vp.vg, m->b_vM.as<u64>(), m->b_ray_end.as<D3>(), ctl, ctl);
+	}
+	{
+		ProfScope ps(m, "k_vlist");
+		hipLaunchKernelGGL(k_vlist, gridFor(nt, 1024, 2048), dim3(1024), 0, m->cs, m->b_vM.as<u64>(), (u32)nt, m->b_vlist.as<u32>(), aux + 64);
+	}
+	HIP_TRY(hipMemcpyAsync(m->h_ctl, m->b_ctl.p, sizeof(ScanCtl), hipMemcpyDeviceToHost, m->cs));
+	HIP_TRY(hipMemcpyAsync(&m->vol_count, aux + 64, 4, hipMemcpyDeviceToHost, m->cs));
+	HIP_TRY(hipStreamSynchronize(m->cs));
+	if (m->h_ctl->err & ERR_VOL) {
+		// the general path takes the scan: the flag and the step count of the abandoned walk go, the head kernels' results stay
+		hipLaunchKernelGGL(k_ctl_clear, dim3(1), dim3(1), 0, m->cs, ctl, (u32)(ERR_VOL | ERR_RUNAWAY));
+		HIP_TRY(hipMemsetAsync(&ctl->n_steps, 0, 8, m->cs));
+		++m->n_vol_fallback;
+		return 1;
+	}
+	const int erc = ctlError(m);
+	if (erc) return erc;
+	m->vplan = vp;
+	m->vol = true;
+	++m->n_vol;
+	return UFOMAP_OK;
+}
+
+// Tree update of the volume path on the map stream, synchronous: k_tile<VOL> over the listed tiles, k_up level after level,
+// k_ftail. Blocks are created against a reserve; when it runs out (ERR_GROW) the table is exchanged for a larger one and the
+// tiles that stood back are run -- the others' records carry the walk's number.
+int volMapPhase(ufomap_map* m)
+{
+	const VolPlan& vp = m->vplan;
+	const u32 T = m->vol_count;
+	m->cs = m->stream;
+	m->hit_grid = false;
+	ScanCtl* ctl = m->b_ctl.as<ScanCtl>();
+	if (!m->ctl_init_done) {
+		ScanCtl init;
+		memset(&init, 0, sizeof(init));
+		for (int a = 0; a < 3; ++a) {
+			init.mb_min[a] = init.hb_min[a] = INT32_MAX;
+			init.mb_max[a] = init.hb_max[a] = INT32_MIN;
+			init.aabb_min[a] = ~0ull;
+			init.aabb_max[a] = 0ull;
+		}
+		HIP_TRY(hipMemcpy(m->b_ctl_init.p, &init, sizeof(ScanCtl), hipMemcpyHostToDevice));
+		m->ctl_init_done = true;
+	}
+	{
+		const size_t pc = m->b_bpipe.cap;
+		HIP_TRY(m->b_bpipe.reserve(sizeof(Pipe)));
+		if (pc != m->b_bpipe.cap) HIP_TRY(hipMemsetAsync(m->b_bpipe.p, 0, sizeof(Pipe), m->stream));
+	}
+	Pipe* pipe = m->b_bpipe.as<Pipe>();
+	u32* aux = m->b_vaux.as<u32>();
+	{
+		DescPack pk{};
+		ScanDesc& d = pk.d[0];
+		d.ctl = ctl;
+		d.host_result = m->h_res;
+		d.done_value = (unsigned long long)m->seq;
+		d.tile_bits = m->b_vupbits.as<u32>();  // (never read: k_ftail clears nwords3 = 0 words of it)
+		d.geo = 0;
+		hipLaunchKernelGGL(k_batch_descs, dim3(1), dim3(64), 0, m->stream, pipe, pk, 1u);
+	}
+	// a map that holds little of what the scan touches: room for every block of the listed tiles at once, instead of finding
+	// out half-way; else the walk goes ahead on what there is
+	const u64 worst = (u64)T * 74ull + 4096ull;
+	{
+		const u64 cap = (u64)m->t.mask + 1;
+		if (m->opt_vol_pregrow && m->used_est * 2 < worst && (m->used_est + worst) * 20 > cap * 13) {
+			const u64 want = ((m->used_est + worst) * 20 / 13 + 4095) & ~4095ull;
+			if (want > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
+			const int rc = growTable(m, (u32)want);
+			if (rc) return rc;
+		}
+	}
+	m->scan_id += 1;
+	m->scan_new_bound = 0;
+	const float miss = (float)m->g.miss_log;  // insert depth 0 (OMB:311)
+	const FastGeo& fg = vp.lv[0];
+	TileRec* recs = m->b_vrec.as<TileRec>();
+	for (int attempt = 0;; ++attempt) {
+		if (attempt > 8) return fail(UFOMAP_ERR_CAPACITY, "the node table kept running out of room during one update (internal error)");
+		const u64 cap = (u64)m->t.mask + 1;
+		const u64 lim_total = cap * 3 / 4 > m->used_est ? cap * 3 / 4 - m->used_est : 0;  // (load <= 0.75 at the end of the walk)
+		m->h_res->err = ERR_NOT_STORED;
+		*reinterpret_cast<volatile unsigned long long*>(m->h_res + 1) = 0ull;
+		m->done_by_flag = true;
+		hipLaunchKernelGGL(k_vreset, dim3(1), dim3(64), 0, m->stream, aux, ctl, (u32)(ERR_GROW | ERR_PREV));
+		TileVol va{};
+		va.M = m->b_vM.as<u64>();
+		va.H = m->b_vH.as<u64>();
+		va.list = m->b_vlist.as<u32>();
+		va.count = T;
+		va.resv = aux;
+		va.resv_lim = (u32)std::min<u64>(lim_total / 64, 0x7FFFFFFFull);
+		va.clean = m->opt_vol_clean ? 1u : 0u;
+		{
+			ProfScope ps(m, "k_tile");
+			hipLaunchKernelGGL((k_tile<false, true>), dim3((T + 3) / 4), dim3(256), 0, m->stream, m->t, m->g, fg, pipe, 0ull, recs, m->g.hit, miss, m->scan_id,
+			                   (const u32*)nullptr, ChangeLog{nullptr, 0u, m->g.L}, va);
+		}
+		TileRec* below = recs;
+		for (int k = 1; k < vp.n; ++k) {
+			TileRec* above = below + vp.lv[k - 1].ntiles;
+			ProfScope ps(m, "k_up");
+			hipLaunchKernelGGL(k_up<false>, dim3((u32)(((u64)vp.lv[k].ntiles * 8u + 255u) / 256u)), dim3(256), 0, m->stream, m->t, m->g, vp.lv[k - 1], pipe, 0ull, below,
+			                   above, (k + 1 == vp.n) ? m->b_vupbits.as<u32>() : (u32*)nullptr, m->scan_id, (const u32*)nullptr);
+			below = above;
+		}
+		{
+			ProfScope ps(m, "k_ftail");
+			hipLaunchKernelGGL(k_ftail<false>, dim3(1), dim3(UFO_FTAIL_THREADS), 0, m->stream, m->t, m->g, vp.lv[vp.n - 1], pipe, 0ull, below, m->scan_id, (const u32*)nullptr,
+			                   m->b_ctl_init.as<ScanCtl>(), m->b_vupbits.as<u32>(), 0u);
+		}
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipStreamSynchronize(m->stream));
+		if (!(m->h_res->err & ERR_GROW) || (m->h_res->err & (ERR_NOT_STORED | ERR_TABLE_FULL))) break;
+		// ---- the reserve ran out: a larger table, then the tiles that stood back ----
+		++m->n_vol_grow;
+		HIP_TRY(hipMemsetAsync(aux + 65, 0, 4, m->stream));
+		hipLaunchKernelGGL(k_vfix, gridFor(T), dim3(256), 0, m->stream, m->t, m->g, fg, m->b_vlist.as<u32>(), T, recs, m->scan_id, aux + 65);
+		u32 n_done = 0;
+		HIP_TRY(hipMemcpyAsync(&n_done, aux + 65, 4, hipMemcpyDeviceToHost, m->stream));
+		HIP_TRY(hipStreamSynchronize(m->stream));
+		// (MapRoot::used does not hold what the tiles that are done have created -- k_up adds that -- but the re-hash counts what it copies)
+		const u64 left = (u64)(T - std::min(T, n_done)) * 74ull + 4096ull;
+		const u64 have = std::min<u64>(cap, m->used_est + (u64)n_done * 74ull);
+		u64 want = std::max<u64>(cap + cap / 2, (have + left) * 20 / 13);
+		want = (want + 4095) & ~4095ull;
+		if (want > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
+		const int rc = growTable(m, (u32)want);
+		if (rc) return rc;
+		hipLaunchKernelGGL(k_vfix, gridFor(T), dim3(256), 0, m->stream, m->t, m->g, fg, m->b_vlist.as<u32>(), T, recs, m->scan_id, aux + 65);
+		HIP_TRY(hipMemsetAsync(m->b_vupbits.p, 0, m->b_vupbits.cap, m->stream));
+	}
+	if (0 == m->h_res->err && m->opt_vol_clean) m->vol_dirty = false;
+	m->fast = true;  // (finishPending: the finished control block is in pinned memory, k_ftail left the device copy clean)
+	m->pending = true;
+	return UFOMAP_OK;
+}

@@ -27,6 +27,9 @@ enum : u32 {
 	ERR_NOT_STORED = 0x40000000u,  // (host side only: the pinned result block of a fast-path update has not been written)
 	ERR_PREV = 64u,       // the integration enqueued just before this one flagged an error: this one stands back, the host re-runs both in order
 	ERR_SPEC = 32u,       // the scan was launched on a grid predicted from the previous scan and does not fit it: the host repeats it
+	ERR_GROW = 256u,      // volume path (vol_kernels.h): a tile found the node table's reserve used up and stood back; the host grows the table and
+	                      // runs the tiles that are left
+	ERR_VOL = 512u,       // volume path: a ray that needs the checked walk (clipped at the map cube); the scan takes the general path
 };
 
 // Geometry of one dedup grid: cells at depth `depth`, blocks of 2x2x2 cells.

@@ -38,7 +38,7 @@
 #include <vector>
 
 #include "../../include/ufomap_hip.h"
-#include "fast_kernels.h"
+#include "vol_kernels.h"
 
 using namespace ufo;
 
@@ -305,6 +305,16 @@ struct ufomap_map {
 	uint64_t seq = 0, latest_seq = 0;  // seq: of the integration that uses the current set; latest_seq: of the newest one enqueued
 	FastGeo fgeo{};
 	int opt_fast = 1;  // 0 = never take the fast path (fast_kernels.h)
+	// the volume path (vol_kernels.h, host_vol.inl): depth-0 scans whose ray grid is beyond the steady-state path's
+	int opt_vol = 1;        // 0 = never; 2 = also for the ray grids the steady-state path would take (tests)
+	int opt_vol_pregrow = 1;  // 0: no growth of the node table before a walk (tests: the walk runs out of its reserve)
+	int opt_vol_clean = 0;  // 1: k_tile leaves the brick grids zeroed (no clearing pass before the next scan; ufomap_map_last_misses then has nothing to read)
+	bool vol = false;       // the integration that uses the current set runs on it
+	bool vol_dirty = true;  // the brick grids are not known to be all zero
+	u32 vol_count = 0;      // tiles the scan has listed
+	DevBuf b_vM, b_vH, b_vlist, b_vrec, b_vaux, b_vupbits;
+	VolPlan vplan{};
+	uint64_t n_vol = 0, n_vol_grow = 0, n_vol_fallback = 0;
 	int opt_tile_waves = 4;   // k_tile: tiles per workgroup
 	int opt_gates = 1;        // 0 = events instead of gate kernels between the streams of the steady-state path
 	bool gates = false;       // ... as decided for the scan being enqueued
@@ -620,6 +630,7 @@ int phaseGuard(ufomap_map* m)
 	if (rc) return rc;
 	hipLaunchKernelGGL(k_reset_tags, gridFor((u64)m->t.mask + 1), dim3(256), 0, m->stream, m->t);
 	if (m->b_tilerec.p) HIP_TRY(hipMemsetAsync(m->b_tilerec.p, 0, m->b_tilerec.cap, m->stream));
+	if (m->b_vrec.p) HIP_TRY(hipMemsetAsync(m->b_vrec.p, 0, m->b_vrec.cap, m->stream));
 	HIP_TRY(hipStreamSynchronize(m->stream));
 	m->scan_id = 0;
 	++m->n_phase_resets;
@@ -1147,6 +1158,7 @@ int mapPhase(ufomap_map* m, unsigned depth, const uint8_t* d_rgb, u64 capH, u64 
 int redoScan(ufomap_map* m);
 
 #include "host_fast_path.inl"
+#include "host_vol.inl"
 int finishPending(ufomap_map* m)
 {
 	if (!m->pending) return UFOMAP_OK;
@@ -1226,6 +1238,7 @@ int scanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, const 
 	m->haveH = m->haveM = false;
 	m->last_depth = depth;
 	m->counts[0] = n;
+	m->vol = false;
 	if (0 == n) return UFOMAP_OK;
 	m->scan_id += 1;
 	const u32 N = (u32)n;
@@ -1322,6 +1335,19 @@ int scanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, const 
 		return fail(UFOMAP_ERR_CAPACITY, "hit bounding box too large for the scan grid");
 	if (m->haveM && makeGrid(mmn, mmx, (u32)depth, &m->gridM))
 		return fail(UFOMAP_ERR_CAPACITY, "ray bounding box too large for the scan grid (runaway ray?)");
+	}
+	if (!spec && m->haveM && n_rays) {
+		// a ray box far beyond the steady-state path's grids (a 2 mm RGB-D frame): the volume path -- brick grids, the tiled tree update
+		VolPlan vp;
+		if (volPlan(m, m->gridM, depth, simple, early_stopping, d_rgb, &vp)) {
+			const int vrc = volScan(m, sensor, vp, n_hits, n_rays);
+			if (vrc < 0) return vrc;
+			if (0 == vrc) {
+				*n_hits_out = n_hits;
+				*n_rays_out = n_rays;
+				return UFOMAP_OK;
+			}
+		}
 	}
 	if (!spec && m->haveM && !simple && m->opt_dda_seg != 0 && m->opt_bits != 0 && m->opt_dda_mode <= 0) {
 		// one bit per cell (rows padded to 32 cells) when that fits in LDS: the fast walk kernel (k_walk)
@@ -1752,6 +1778,17 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 	HIP_TRY(hipStreamWaitEvent(m->sstream, m->prep_ev, 0));
 	rc = scanPhase(m, origin, d_xyz, d_rgb, n, max_range, depth, discrete, simple, early_stopping, &n_hits, &n_rays, spec);
 	if (staged) HIP_TRY(hipEventSynchronize(m->copy_ev));
+	if (!rc && n && m->vol) {
+		// the volume path: its scan half has been awaited (the list of tiles was read back); the tree update runs here, synchronously
+		// (an asynchronous call returns a finished integration)
+		lap(0, t_begin);
+		const int prc = joinOlder(m);  // (occupancy_map_base.h:315: the previous integrations are joined first)
+		const auto t_map = std::chrono::steady_clock::now();
+		rc = volMapPhase(m);
+		lap(1, t_map);
+		if (!rc) rc = finishPending(m);
+		return rc ? rc : prc;
+	}
 	if (!rc && n) rc = extractPhase(m, n_hits, n_rays, &capH, &capM, merged);
 	lap(0, t_begin);
 	auto mapHalf = [&](const ScanCtl* prev, u64 extra_used, u32 headroom) { return mapPhase(m, depth, d_rgb, capH, capM, merged, prev, extra_used, headroom); };
@@ -1866,12 +1903,13 @@ int redoScan(ufomap_map* m)
 	int rc = scanPhase(m, a.origin, a.d_xyz, a.d_rgb, a.n, a.max_range, a.depth, a.discrete, a.simple, 0, &n_hits, &n_rays, false);
 	u64 capH = 0, capM = 0;
 	const bool merged = 0 == a.depth && 0 != m->opt_merge;
-	if (!rc) rc = extractPhase(m, n_hits, n_rays, &capH, &capM, merged);
+	const bool vol = !rc && m->vol;
+	if (!rc && !vol) rc = extractPhase(m, n_hits, n_rays, &capH, &capM, merged);
 	if (!rc) rc = (hipStreamSynchronize(m->sstream) == hipSuccess) ? UFOMAP_OK : fail(UFOMAP_ERR_DEVICE, "hipStreamSynchronize");
 	if (!rc) {
 		m->cs = m->stream;
 		m->last_rgb = a.d_rgb;
-		rc = mapPhase(m, a.depth, a.d_rgb, capH, capM, merged);
+		rc = vol ? volMapPhase(m) : mapPhase(m, a.depth, a.d_rgb, capH, capM, merged);
 	}
 	if (!rc) rc = (hipStreamSynchronize(m->stream) == hipSuccess) ? UFOMAP_OK : fail(UFOMAP_ERR_DEVICE, "hipStreamSynchronize");
 	if (!rc) {
@@ -2880,13 +2918,20 @@ size_t ufomap_map_last_misses(ufomap_map* m, uint64_t* codes, size_t cap)
 {
 	if (!m || ufomap_map_wait(m) < 0) return (size_t)-1;
 	if (!m->haveM) return 0;
+	if (m->vol && !m->vol_dirty) {
+		fail(UFOMAP_ERR_UNSUPPORTED, "the ray cells of a scan on the volume path are not kept (option vol_clean = 0 keeps them)");
+		return (size_t)-1;
+	}
 	ScanCtl* ctl = m->b_ctl.as<ScanCtl>();
 	std::vector<uint64_t> h;
 	u32 total = 0;
 	for (int pass = 0; pass < 2; ++pass) {
 		if (hipMemsetAsync(&ctl->n_codes, 0, 4, m->stream) != hipSuccess) return (size_t)-1;
 		if (pass && m->b_codes.reserve((size_t)total * 8) != hipSuccess) return (size_t)-1;
-		if (2 == m->gridM.layout) {
+		if (m->vol) {
+			hipLaunchKernelGGL(k_vcodes, gridFor((u64)m->vplan.vg.ntiles * 8u, 256, 8192), dim3(256), 0, m->stream, m->vplan.vg, m->b_vM.as<u64>(),
+			                   pass ? m->b_codes.as<u64>() : (u64*)nullptr, pass ? total : 0u, ctl);
+		} else if (2 == m->gridM.layout) {
 			const u64 slots = m->miss_set_slots;
 			const MissSet ms{m->b_gridM.as<u64>(), reinterpret_cast<u32*>(m->b_gridM.as<u64>() + slots), (u32)(slots - 1), nullptr};
 			hipLaunchKernelGGL(k_set_codes, gridFor(slots, 256, 8192), dim3(256), 0, m->stream, ms, pass ? m->b_codes.as<u64>() : (u64*)nullptr,
@@ -3375,6 +3420,12 @@ int ufomap_map_set_option(ufomap_map* m, const char* key, long long value)
 		m->opt_dda_block = (int)value;
 	} else if (0 == strcmp(key, "dda_lanes")) {
 		m->opt_dda_lanes = (int)value;
+	} else if (0 == strcmp(key, "vol")) {
+		m->opt_vol = (int)std::max<long long>(0, std::min<long long>(2, value));
+	} else if (0 == strcmp(key, "vol_pregrow")) {
+		m->opt_vol_pregrow = value ? 1 : 0;
+	} else if (0 == strcmp(key, "vol_clean")) {
+		m->opt_vol_clean = value ? 1 : 0;
 	} else if (0 == strcmp(key, "merge_phases")) {
 		m->opt_merge = value ? 1 : 0;
 	} else if (0 == strcmp(key, "entry_guess")) {
@@ -3397,6 +3448,9 @@ int ufomap_map_debug(ufomap_map* m, uint64_t* out, int n)
 	if (n > 59) out[59] = m->n_walk_scans; // ... scans in those walks
 	if (n > 58) out[58] = m->n_gate_timeouts;  // stream hand-overs that timed out (the handle uses events from then on)
 	if (n > 51) out[51] = m->n_phase_resets;  // phaseGuard
+	if (n > 50) out[50] = m->n_vol;            // scans on the volume path (vol_kernels.h)
+	if (n > 49) out[49] = m->n_vol_grow;       // ... times the node table was exchanged in the middle of such a scan's tree update
+	if (n > 48) out[48] = m->n_vol_fallback;   // ... scans that turned to the general path (a ray clipped at the map cube)
 	for (int k = 0; k < 4 && 52 + k < n; ++k) out[52 + k] = m->host_ns[k];  // host time inside doInsert (ns): scan enqueue, map enqueue, join, total
 	return rc;
 }

@@ -1,0 +1,202 @@
+// vol_kernels.h -- the VOLUME path: a depth-0 scan whose ray grid is far beyond anything the steady-state path of
+// fast_kernels.h holds (a 2 mm RGB-D frame at 5 m: 1 500 x 1 800 x 1 400 cells, 7 M depth-3 tiles, 5 * 10^8 DDA steps, 3.5 * 10^8
+// voxels updated -- BASELINE configs[2] at insert depth 0, the one bandwidth-bound configuration), through the SAME tiled
+// tree update (k_tile / k_up / k_ftail) instead of the general path's update list:
+//
+//   k_classify, k_select, k_reduce_boxes   head loops, first point per voxel, boxes (scan_kernels.h; the boxes are read back)
+//   k_vhits      the voxels that receive a hit -> brick grid H
+//   k_vdda       freeSpace (occupancy_map_base.h:1229-1301; computeRayInit / computeRayTakeStep octree.h:1192-1233): one lane per
+//                ray, the reference's sequential FP64 recurrence; marks go to brick grid M through a register that collects
+//                the bits of the brick the ray is in -- one atomic per (ray, brick) instead of one per step
+//   k_vlist      the tiles that hold a ray cell -> list
+//   k_tile<VOL>  one wave per listed tile (fast_kernels.h): everything beneath depth 3, each block record read and written once
+//   k_up x n     levels 4, 5, ... in parallel, eight lanes per block, until what is left above fits k_ftail's LDS
+//   k_ftail      the rest, up to the root; finished control block to pinned memory
+//
+// The grids are TILE-MAJOR: per depth-3 tile (8x8x8 cells) eight 64-bit words, one per 4x4x4-cell brick (brick = bx | by << 1 |
+// bz << 2 inside the tile, bit = x | y << 2 | z << 4 inside the brick). A ray stays inside a brick for 4-6 steps whatever its
+// direction (a row-major bit grid keeps only rays along x together), a tile's bits are ONE 64-byte line for k_tile, and the
+// active-tile list is a streaming pass. What the general path does with these scans -- a 16-byte update-list entry per node
+// block, find-or-create and read-modify-write of 5 * 10^7 hashed 64-byte records, a launch per tree level -- was 27 of its
+// 40 ms.
+#pragma once
+#include "fast_kernels.h"
+
+namespace ufo
+{
+// the tile grid of the scan (FastGeo::tbase / nt / ntiles, tl = 3) and the cell coordinate of its corner
+struct VolGeo {
+	i32 cbase[3];  // = 8 * tbase
+	u32 nt[3];
+	u32 ntiles;
+};
+
+// the tile grids of the levels the walk runs in parallel (host side: host_vol.inl)
+struct VolPlan {
+	FastGeo lv[24];  // lv[0]: the depth-3 tiles; lv[k]: the cells of level 3 + k (k_up's k-th launch writes them)
+	int n = 0;       // levels in lv[]; k_ftail starts above lv[n - 1]
+	u64 rec_total = 0;  // hand-over records of all levels
+	VolGeo vg{};
+};
+
+__device__ __forceinline__ void volWordBit(const VolGeo& vg, u32 x, u32 y, u32 z, u32* word, u32* bit)
+{
+	const u32 tile = ((z >> 3) * vg.nt[1] + (y >> 3)) * vg.nt[0] + (x >> 3);
+	*word = tile * 8u + (((x >> 2) & 1u) | (((y >> 2) & 1u) << 1) | (((z >> 2) & 1u) << 2));
+	*bit = (x & 3u) | ((y & 3u) << 2) | ((z & 3u) << 4);
+}
+
+// the voxels that receive a hit (k_select's list of first points' codes) -> H
+__global__ __launch_bounds__(256) void k_vhits(MapGeom g, VolGeo vg, const u64* __restrict__ hit_code, const ScanCtl* ctl_in, u64* __restrict__ H, ScanCtl* ctl)
+{
+	const u32 n = ctl_in->n_hits;
+	for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		const u64 c = hit_code[i];
+		const i32 x = (i32)compact3(c) - vg.cbase[0], y = (i32)compact3(c >> 1) - vg.cbase[1], z = (i32)compact3(c >> 2) - vg.cbase[2];
+		if (x < 0 || y < 0 || z < 0 || (u32)x >= 8u * vg.nt[0] || (u32)y >= 8u * vg.nt[1] || (u32)z >= 8u * vg.nt[2]) {
+			atomicOr(&ctl->err, ERR_GRID_OOB);  // (cannot happen: the hit box lies inside the ray box)
+			continue;
+		}
+		u32 w, b;
+		volWordBit(vg, (u32)x, (u32)y, (u32)z, &w, &b);
+		atomicOr(reinterpret_cast<unsigned long long*>(&H[w]), 1ull << b);
+	}
+}
+
+// freeSpaceNormal, one lane per ray (the general path's k_dda, marks collected per brick)
+__global__ __launch_bounds__(256) void k_vdda(MapGeom g, D3 sensor, Grid gr, VolGeo vg, u64* __restrict__ M, const D3* __restrict__ ray_end, const ScanCtl* ctl_in,
+                                              ScanCtl* ctl)
+{
+	const u32 n = ctl_in->n_rays;
+	const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	unsigned long long steps = 0;
+	u32 err = 0;
+	if (i < n) {
+		RayState r;
+		raySetup(g, sensor, 0u, gr, ray_end[i], r);
+		if (3 == r.status) {
+			err |= ERR_VOL;  // clipped at the map cube / outside the grid's interior: the checked walk of the general path
+		} else if (1 == r.status) {
+			u32 w, b;
+			volWordBit(vg, (u32)(r.start[0] - vg.cbase[0]), (u32)(r.start[1] - vg.cbase[1]), (u32)(r.start[2] - vg.cbase[2]), &w, &b);
+			atomicOr(reinterpret_cast<unsigned long long*>(&M[w]), 1ull << b);
+			steps = 1;
+		} else if (2 == r.status) {
+			u32 x = (u32)(r.start[0] - vg.cbase[0]), y = (u32)(r.start[1] - vg.cbase[1]), z = (u32)(r.start[2] - vg.cbase[2]);
+			const u32 gx = (u32)(r.goal[0] - vg.cbase[0]), gy = (u32)(r.goal[1] - vg.cbase[1]), gz = (u32)(r.goal[2] - vg.cbase[2]);
+			const u32 sx = (u32)(i32)r.s[0], sy = (u32)(i32)r.s[1], sz = (u32)(i32)r.s[2];
+			double tmx = r.tm[0], tmy = r.tm[1], tmz = r.tm[2];
+			const double tdx = r.td[0], tdy = r.td[1], tdz = r.td[2];
+			const long long idist = __double_as_longlong(r.dist);  // (non-negative doubles order like their bit patterns)
+			const u32 budget = (u32)min(3ull * (1ull << g.L) + 8ull, 0xFFFFFFF0ull);
+			const u32 nt0 = vg.nt[0], nt1 = vg.nt[1];
+			u32 cnt = 0, curw = 0xFFFFFFFFu;
+			u64 acc = 0;
+			bool go;
+			do {
+				++cnt;
+				const u32 tile = ((z >> 3) * nt1 + (y >> 3)) * nt0 + (x >> 3);
+				const u32 w = tile * 8u + (((x >> 2) & 1u) | (((y >> 2) & 1u) << 1) | (((z >> 2) & 1u) << 2));
+				const u32 b = (x & 3u) | ((y & 3u) << 2) | ((z & 3u) << 4);
+				if (w != curw) {
+					if (acc) atomicOr(reinterpret_cast<unsigned long long*>(&M[curw]), acc);
+					curw = w;
+					acc = 0;
+				}
+				acc |= 1ull << b;
+				// minElementIndex (vector3.h:244-251): x if tx <= ty and tx <= tz, else y if ty <= tz, else z; only the chosen
+				// axis' t_max is touched (octree.h:1227-1233)
+				const bool cxy = tmx <= tmy, cxz = tmx <= tmz, cyz = tmy <= tmz;
+				const bool selx = cxy & cxz;
+				const bool sely = !cxy & cyz;
+				const bool selz = !(selx | sely);
+				x += selx ? sx : 0u;
+				y += sely ? sy : 0u;
+				z += selz ? sz : 0u;
+				const double nx = tmx + tdx, ny = tmy + tdy, nz = tmz + tdz;
+				tmx = selx ? nx : tmx;
+				tmy = sely ? ny : tmy;
+				tmz = selz ? nz : tmz;
+				// t_max.min() <= distance (OMB:1300)
+				const bool more = (__double_as_longlong(tmx) <= idist) | (__double_as_longlong(tmy) <= idist) | (__double_as_longlong(tmz) <= idist);
+				go = (((x ^ gx) | (y ^ gy) | (z ^ gz)) != 0u) & more & (cnt < budget);
+			} while (go);
+			if (acc) atomicOr(reinterpret_cast<unsigned long long*>(&M[curw]), acc);
+			if (cnt >= budget) err |= ERR_RUNAWAY;
+			steps = cnt;
+		}
+	}
+	waveAddU64(&ctl->n_steps, steps);
+	if (err) atomicOr(&ctl->err, err);
+}
+
+// the tiles that hold a ray cell -> list (count in *n_out); one thread per tile, one 64-byte line each
+__global__ __launch_bounds__(1024) void k_vlist(const u64* __restrict__ M, u32 ntiles, u32* __restrict__ list, u32* n_out)
+{
+	for (u32 t0 = blockIdx.x * blockDim.x; t0 < ntiles; t0 += gridDim.x * blockDim.x) {
+		const u32 t = t0 + threadIdx.x;
+		bool any = false;
+		if (t < ntiles) {
+			const ulonglong2* p = reinterpret_cast<const ulonglong2*>(M + (size_t)t * 8u);
+			const ulonglong2 a = p[0], b = p[1], c = p[2], d = p[3];
+			any = 0 != (a.x | a.y | b.x | b.y | c.x | c.y | d.x | d.y);
+		}
+		const u32 pos = blockAppend(n_out, any);
+		if (any) list[pos] = t;
+	}
+}
+
+// After the table has been exchanged for a larger one in the middle of a walk: the records of the tiles that are done
+// carry slots of the old table (k_up links new level-3 blocks through them), and their creations are part of the new
+// table's fill already. One thread per listed tile; *n_done counts the tiles that are done.
+__global__ __launch_bounds__(256) void k_vfix(Table t, MapGeom g, FastGeo fg, const u32* __restrict__ list, u32 count, TileRec* __restrict__ recs, u32 scan_id, u32* n_done)
+{
+	const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	bool done = false;
+	if (i < count) {
+		const u32 tile = list[i];
+		TileRec r = recs[tile];
+		if (r.seq == scan_id) {
+			done = true;
+			u64 lk3;
+			if (tileKey(g, fg, tile, &lk3, nullptr)) {
+				r.slot = tableFind(t, lk3);  // (NONE: the block had collapsed and was left behind)
+				r.counts &= (1u << 25) - 1u;
+				recs[tile] = r;
+			}
+		}
+	}
+	const u32 c = (u32)__popcll(__ballot(done));
+	if (0 == (threadIdx.x & 63u) && c) atomicAdd(n_done, c);
+}
+// ray cells of the scan as codes (ufomap_map_last_misses; option vol_clean = 0 keeps the grid): one thread per brick word
+__global__ __launch_bounds__(256) void k_vcodes(VolGeo vg, const u64* __restrict__ M, u64* __restrict__ codes, u32 cap, ScanCtl* ctl)
+{
+	const u64 nwords = (u64)vg.ntiles * 8u;
+	for (u64 w0 = (u64)blockIdx.x * blockDim.x; w0 < nwords; w0 += (u64)gridDim.x * blockDim.x) {  // (uniform: whole waves append)
+		const u64 w = w0 + threadIdx.x;
+		u64 m = w < nwords ? M[w] : 0ull;
+		const u32 cnt = (u32)__popcll(m);
+		u32 pos = waveAppendN(&ctl->n_codes, cnt);
+		if (0 == m) continue;
+		const u32 tile = (u32)(w >> 3), br = (u32)(w & 7u);
+		const u32 tx = tile % vg.nt[0], tr = tile / vg.nt[0];
+		const u32 ty = tr % vg.nt[1], tz = tr / vg.nt[1];
+		while (m) {
+			const u32 bit = (u32)__ffsll((unsigned long long)m) - 1u;
+			m &= m - 1ull;
+			const u32 x = (u32)(vg.cbase[0] + (i32)(8u * tx + 4u * (br & 1u) + (bit & 3u)));
+			const u32 y = (u32)(vg.cbase[1] + (i32)(8u * ty + 4u * ((br >> 1) & 1u) + ((bit >> 2) & 3u)));
+			const u32 z = (u32)(vg.cbase[2] + (i32)(8u * tz + 4u * (br >> 2) + (bit >> 4)));
+			if (pos < cap) codes[pos] = morton3(x, y, z);
+			++pos;
+		}
+	}
+}
+// the reserve's counters -> MapRoot::used has them already through k_up / k_ftail; this only clears them and the walk's flag
+__global__ void k_vreset(u32* resv, ScanCtl* ctl, u32 clear_err)
+{
+	if (threadIdx.x < 64u) resv[threadIdx.x] = 0;
+	if (0 == threadIdx.x && clear_err) atomicAnd(&ctl->err, ~clear_err);
+}
+}  // namespace ufo
