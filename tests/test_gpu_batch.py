@@ -392,7 +392,7 @@ def _batch_cloud(entry):
     return o, (xyz[:0] if empty else xyz)
 
 
-def _batch_rank(rank, world, steps, shim, id_q, out_q, comm_slot):
+def _batch_rank(rank, world, steps, shim, id_q, out_q, comm_slot, fail_at=None):
     import os
     os.environ["UFOMAP_RCCL_LIB"] = shim
     os.environ["UFOMAP_COMM_SLOT"] = str(comm_slot)
@@ -415,6 +415,8 @@ def _batch_rank(rank, world, steps, shim, id_q, out_q, comm_slot):
             origin, xyz = _batch_cloud(plan[(i, rank)])
             d = th.from_numpy(np.ascontiguousarray(xyz)).cuda() if len(xyz) else th.empty(0, dtype=th.float64, device="cuda")
             keep.append(d)
+            if fail_at is not None:  # (step, rank): the scan half of that rank's step 'fails' before the collective (option fail_scan)
+                g.set_option("fail_scan", int(fail_at == (i, rank)))
             g.insert_batch(comm, origin, d.data_ptr() if len(xyz) else 0, len(xyz), 10.0, 0, True)
         g.insertPointCloudWait()
         out_q.put((rank, g.digest(), comm.counters(), comm.stats(), g.debug()[58:64]))
@@ -423,7 +425,11 @@ def _batch_rank(rank, world, steps, shim, id_q, out_q, comm_slot):
         out_q.put((rank, "error: " + repr(e), None, None, None))
 
 
-def test_insert_batch_two_ranks_on_one_gpu():
+@pytest.mark.parametrize("fail_at", [None, (7, 1)])
+def test_insert_batch_two_ranks_on_one_gpu(fail_at):
+    """fail_at = (step, rank): that rank's scan half fails on the host before the step's all-gather (ADVICE r3 / VERDICT r3 5c) --
+    it enters the collective all the same with a flagged empty contribution, nobody hangs, every rank repeats the step in list form
+    and the replicas equal the sequential map."""
     import torch.multiprocessing as mp
     from oracle import OracleMap
     from ufomap_amd import OccupancyMap
@@ -431,7 +437,7 @@ def test_insert_batch_two_ranks_on_one_gpu():
     world, steps = 2, 9
     ctx = mp.get_context("spawn")
     id_q, out_q = ctx.Queue(), ctx.Queue()
-    procs = [ctx.Process(target=_batch_rank, args=(r, world, steps, shim, id_q, out_q, 4096)) for r in range(world)]
+    procs = [ctx.Process(target=_batch_rank, args=(r, world, steps, shim, id_q, out_q, 4096, fail_at)) for r in range(world)]
     for p in procs:
         p.start()
     results = {}
@@ -459,5 +465,5 @@ def test_insert_batch_two_ranks_on_one_gpu():
     c0 = results[0][2]
     assert c0 == results[1][2], "the ranks disagree about which steps took which form"
     assert c0["fast_steps"] >= 4, f"the fast-path form of the step did not run: {c0}"
-    assert c0["repeated_steps"] >= 1, f"the jump should have forced a collective repeat: {c0}"
+    assert c0["repeated_steps"] >= (2 if fail_at else 1), f"the jump (and the injected failure) should have forced collective repeats: {c0}"
     assert results[0][3]["regrown"] >= 1, "the update-list slot should have had to grow (4 KiB to start with)"

@@ -1103,13 +1103,14 @@ __device__ inline bool tileKey(const MapGeom& g, const FastGeo& fg, u32 tile, u6
 // flags ERR_GROW and stands back -- the host grows the table and runs the tiles that are left (their records do not carry
 // the walk's number yet).
 struct TileVol {
-	u64* M;           // ray cells
-	u64* H;           // hit voxels
-	const u32* list;  // active tiles
+	u64* Mx;               // ray cells: eight copies, one per XCD (k_vdda); read, ORed and left zeroed here
+	u64* Mm;               // ... the tile's merged words, for whoever asks for the scan's ray cells afterwards (may be null)
+	u64* H;                // hit voxels; left zeroed
+	const u32* list;       // active tiles
+	const uint8_t* copies; // ... and the copies each was marked in
 	u32 count;
-	u32* resv;        // 64 counters of blocks created by this walk
-	u32 resv_lim;     // ... and what each may reach
-	u32 clean;        // leave the tile's words of M and H zeroed (the grids are clean for the next scan)
+	u32* resv;             // 64 counters of blocks created by this walk
+	u32 resv_lim;          // ... and what each may reach
 };
 template <bool COLOR, bool VOL = false>
 __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, const Pipe* __restrict__ p, unsigned long long f, TileRec* __restrict__ recs,
@@ -1117,7 +1118,11 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 {
 	const u32 lane = threadIdx.x & 63u;
 	u32 tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-	if (VOL) tile = tile < va.count ? va.list[tile] : 0xFFFFFFFFu;
+	u32 vcopies = 0;
+	if (VOL) {
+		vcopies = tile < va.count ? va.copies[tile] : 0u;
+		tile = tile < va.count ? va.list[tile] : 0xFFFFFFFFu;
+	}
 	if (tile >= fg.ntiles) return;
 	if (VOL && recs[tile].seq == scan_id) return;  // (a repeat after the table has grown: the tile is done)
 	__builtin_amdgcn_s_setprio(2);  // (the map stream is the pipeline's critical path: ahead of the ray kernel's waves)
@@ -1158,7 +1163,16 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 	const u32 vbrick = (bx >> 1) | ((by >> 1) << 1) | ((bz >> 1) << 2), vsh = 2u * (bx & 1u) + 8u * (by & 1u) + 32u * (bz & 1u);
 	if (VOL) {
 		// the lane's 2x2x2 cells inside their brick: bits vsh + cx + 4 cy + 16 cz
-		const u64 mw = va.M[(size_t)tile * 8u + vbrick] >> vsh, hw = va.H[(size_t)tile * 8u + vbrick] >> vsh;
+		u64 mword = 0;
+		{
+			const size_t cstride = (size_t)fg.ntiles * 8u;
+			u64 cw[8];
+#pragma unroll
+			for (int k = 0; k < 8; ++k) cw[k] = ((vcopies >> k) & 1u) ? va.Mx[(size_t)k * cstride + (size_t)tile * 8u + vbrick] : 0ull;  // (uniform: in flight together)
+#pragma unroll
+			for (int k = 0; k < 8; ++k) mword |= cw[k];
+		}
+		const u64 mw = mword >> vsh, hw = va.H[(size_t)tile * 8u + vbrick] >> vsh;
 		const u32 ml = (u32)mw, hl = (u32)hw;
 		mmA = (ml & 3u) | (((ml >> 4) & 3u) << 2) | (((ml >> 16) & 3u) << 4) | (((ml >> 20) & 3u) << 6);
 		hmA = (hl & 3u) | (((hl >> 4) & 3u) << 2) | (((hl >> 16) & 3u) << 4) | (((hl >> 20) & 3u) << 6);
@@ -1268,7 +1282,7 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 				// nothing has been written yet: the blocks this tile creates come out of the walk's reserve, or the tile stands back
 				const u32 need = (u32)__popcll(__ballot(mk1)) + (u32)__popcll(__ballot(mk2)) + (mk3 ? 1u : 0u);
 				u32 over = 0;
-				if (need && 0 == lane) over = (atomicAdd(&va.resv[tile & 63u], need) + need > va.resv_lim) ? 1u : 0u;
+				if (need && 0 == lane) over = (atomicAdd(&va.resv[(tile * 0x9E3779B1u) >> 26], need) + need > va.resv_lim) ? 1u : 0u;
 				if (__shfl((int)over, 0)) {
 					if (0 == lane) atomicOr(&UFO_DESC(B - 1u).ctl->err, ERR_GROW);
 					return;
@@ -1566,9 +1580,21 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 		n_created += __shfl_xor(n_created, o);
 		nhit += __shfl_xor(nhit, o);
 	}
-	if (VOL && va.clean && 0 == vsh) {
-		va.M[(size_t)tile * 8u + vbrick] = 0ull;
-		va.H[(size_t)tile * 8u + vbrick] = 0ull;
+	if (VOL && 0 == vsh) {
+		// (the brick's first lane: the scan's words are consumed -- the copies and H are clean for the next scan)
+		const size_t cstride = (size_t)fg.ntiles * 8u;
+		u64 mword = 0;
+#pragma unroll
+		for (int k = 0; k < 8; ++k)
+			if ((vcopies >> k) & 1u) {
+				u64* q = &va.Mx[(size_t)k * cstride + (size_t)tile * 8u + vbrick];
+				const u64 v = *q;
+				if (v) *q = 0ull;
+				mword |= v;
+			}
+		if (va.Mm) va.Mm[(size_t)tile * 8u + vbrick] = mword;
+		u64* qh = &va.H[(size_t)tile * 8u + vbrick];
+		if (*qh) *qh = 0ull;
 	}
 	if (0 == lane) {
 		t.flags(s3) = fl3r;  // (the parent link of a new block: k_ftail)

@@ -437,8 +437,8 @@ int enqueueSlot(ufomap_map* m, int k)
 		// node table: room for what this walk can create on top of what the updates in flight can
 		const u64 cap = (u64)m->t.mask + 1;
 		if ((m->used_est + in_flight + bound) * 5 > cap * 3) {
-			if (in_flight) {
-				const int jrc = joinEnqueued(m);  // (the table cannot be exchanged under an update in flight)
+			if (in_flight || countPendingAlts(m) > 0) {
+				const int jrc = joinEnqueued(m);  // (the table cannot be exchanged under an update in flight -- scans on this scan's own grid included)
 				if (jrc < 0) return jrc;
 				scanQueue();
 			}

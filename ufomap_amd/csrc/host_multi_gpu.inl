@@ -346,9 +346,13 @@ int fastBatchStep(ufomap_map* m, ufomap_comm* c, const double origin[3], const d
 	}
 	ScanCtl* ctl = m->b_ctl.as<ScanCtl>();
 	int rc = UFOMAP_OK;
+	bool failed_locally = false;
 	if (n) {
 		rc = fastScanPhase(m, origin, d_xyz, n, max_range, discrete, true);
-	} else {
+		if (m->opt_fail_scan) rc = fail(UFOMAP_ERR_DEVICE, "injected failure of the scan half (test aid)");
+		failed_locally = 0 != rc;
+	}
+	if (0 == n || failed_locally) {
 		// an empty cloud on this rank: an empty contribution (the collective is entered all the same)
 		for (int k = 0; k < 8; ++k) m->counts[k] = 0;
 		m->fgeo = fg;
@@ -383,8 +387,18 @@ int fastBatchStep(ufomap_map* m, ufomap_comm* c, const double origin[3], const d
 		HIP_TRY(hipMemsetAsync(m->b_gridH.p, 0, G, m->sstream));
 		HIP_TRY(hipMemsetAsync(m->b_tilebits.p, 0, UFO_FAST_MAX_TILES / 8, m->sstream));
 		m->ctl_clean = false;
+		m->first_dirty = true;
+		if (failed_locally) {
+			// The scan half of THIS rank failed (an allocation, a launch): the other ranks are on their way into the step's
+			// all-gather and would wait there for ever. This rank enters it all the same, with an empty contribution whose
+			// control block carries a flag: every rank's walk stands back and the step is repeated in list form when it is
+			// joined -- where a failure that persists is reported by every rank, a passing one is not an error.
+			const u32 e = ERR_SPEC;
+			HIP_TRY(hipMemcpyAsync(&ctl->err, &e, 4, hipMemcpyHostToDevice, m->sstream));
+			rc = UFOMAP_OK;
+		}
 	}
-	if (rc) return rc;  // (device / allocation failures only: a scan that does not fit flags itself on the device)
+	if (rc) return rc;  // (only a failure of the substitute contribution itself is left: fatal for the communicator)
 	const u32 n4 = (u32)(G >> 4);
 	uint8_t* send = m->b_xsend.as<uint8_t>();
 	uint8_t* recv = m->b_xrecv.as<uint8_t>();
@@ -520,8 +534,11 @@ int ufomap_map_insert_batch(ufomap_map* m, ufomap_comm* c, const double sensor_o
 	if (m->poisoned) return fail(UFOMAP_ERR_CAPACITY, "the map is inconsistent after a node table overflow: ufomap_map_clear it");
 	// Which form the step takes is decided from what ALL ranks know alike: the common ray grid (derived from gathered boxes
 	// only), the map's configuration (the same on every rank by contract), never from this rank's cloud.
+	// (more ranks than one walk takes scans: the list form. Several walks per step would each look at their own chunk's flags
+	// only, and a scan of a later chunk that does not fit the common grid would leave the first chunk applied -- on the ranks
+	// of that chunk alone the join would then not repeat the step, and the others' collective repeat would hang: ADVICE r3)
 	const bool fast = c->spec_valid && m->opt_fast && m->opt_spec && !m->g.color && !m->chg_enabled && m->g.L >= 5 && nullptr == m->ing.data &&
-	                  fastEligible(m, c->spec_grid, 0, 0, nullptr, 1);
+	                  c->world <= (int)UFO_BATCH_MAX && fastEligible(m, c->spec_grid, 0, 0, nullptr, 1);
 	if (!fast) {
 		// (joins what is in flight where it has to: scan_keys / apply_keys_batch)
 		m->batch_world = 0;
@@ -534,10 +551,12 @@ int ufomap_map_insert_batch(ufomap_map* m, ufomap_comm* c, const double sensor_o
 		const int jrc = joinOldestAlt(m);
 		if (!prc) prc = jrc;
 	}
-	if (prc) return prc;
+	// (prc: an EARLIER step's failure, reported when this call returns -- after this rank has entered this step's collective:
+	// the other ranks are on their way into it)
 	if (!c->spec_valid) {  // (the join repeated a step through the list form and found no common grid after it)
 		m->batch_world = 0;
-		return listBatchStep(m, c, sensor_origin, d_xyz, d_rgb, n, max_range, discrete, false);
+		const int lrc = listBatchStep(m, c, sensor_origin, d_xyz, d_rgb, n, max_range, discrete, false);
+		return lrc ? lrc : prc;
 	}
 	m->seq = ++m->latest_seq;
 	{
@@ -557,10 +576,10 @@ int ufomap_map_insert_batch(ufomap_map* m, ufomap_comm* c, const double sensor_o
 		const int wrc = awaitCloudConsumed(m);
 		if (wrc) return wrc;
 	}
-	if (m->opt_async_apply && !m->profiling) return UFOMAP_OK;
+	if (m->opt_async_apply && !m->profiling) return prc;
 	// not asynchronous: the step is joined here (by every rank)
 	const int jrc = joinOlder(m);
 	HIP_TRY(hipStreamSynchronize(m->stream));
 	const int frc = finishPending(m);
-	return frc ? frc : jrc;
+	return frc ? frc : (jrc ? jrc : prc);
 }

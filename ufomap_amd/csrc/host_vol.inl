@@ -37,8 +37,8 @@ bool volPlan(const ufomap_map* m, const Grid& gr, unsigned depth, int simple, un
 	if (nt >= (1ull << 28)) return false;  // (32-bit word indices: 8 words per tile)
 	fg.ntiles = (u32)nt;
 	fg.tl = 3;
-	// M + H (64 bytes per tile each), the list, the records
-	if (nt * (64 + 64 + 4 + 40) > m->scratch_limit) return false;
+	// eight copies of M (one per XCD), the merged M, H (64 bytes per tile each), the tile bitmaps, the list, the records
+	if (nt * (8 * 64 + 64 + 64 + 4 + 1 + 1 + 40) > m->scratch_limit) return false;
 	vp->n = 0;
 	vp->lv[vp->n++] = fg;
 	vp->rec_total = nt;
@@ -66,35 +66,43 @@ bool volPlan(const ufomap_map* m, const Grid& gr, unsigned depth, int simple, un
 int volScan(ufomap_map* m, const D3& sensor, const VolPlan& vp, u32 n_hits, u32 n_rays)
 {
 	const u64 nt = vp.vg.ntiles;
-	const size_t cm = m->b_vM.cap, ch = m->b_vH.cap, cr = m->b_vrec.cap;
-	HIP_TRY(m->b_vM.reserve(nt * 64));
+	const size_t tbw = (size_t)((nt + 31) >> 5);
+	const size_t cm = m->b_vM.cap, ch = m->b_vH.cap, cr = m->b_vrec.cap, ct = m->b_vtb.cap;
+	HIP_TRY(m->b_vM.reserve(nt * 64 * 8));
+	HIP_TRY(m->b_vMm.reserve(nt * 64));
 	HIP_TRY(m->b_vH.reserve(nt * 64));
+	HIP_TRY(m->b_vtb.reserve(tbw * 4 * 8));
 	HIP_TRY(m->b_vlist.reserve(nt * 4));
+	HIP_TRY(m->b_vcopies.reserve(nt));
 	HIP_TRY(m->b_vrec.reserve(vp.rec_total * sizeof(TileRec)));
 	HIP_TRY(m->b_vaux.reserve(1024));
 	HIP_TRY(m->b_vupbits.reserve(UFO_FAST_MAX_TILES / 8));
-	if (cm != m->b_vM.cap || ch != m->b_vH.cap) m->vol_dirty = true;
+	if (cm != m->b_vM.cap || ch != m->b_vH.cap || ct != m->b_vtb.cap) m->vol_dirty = true;
+	// (a different tile grid: what an aborted walk may have left marked lies elsewhere -- and a clean walk leaves nothing)
 	if (cr != m->b_vrec.cap) HIP_TRY(hipMemsetAsync(m->b_vrec.p, 0, m->b_vrec.cap, m->cs));  // (a record counts if it carries the walk's number)
 	if (m->vol_dirty) {
+		// (steady state: k_vlist leaves the tile bitmaps clean, k_tile the copies of M and H)
 		HIP_TRY(hipMemsetAsync(m->b_vM.p, 0, m->b_vM.cap, m->cs));
 		HIP_TRY(hipMemsetAsync(m->b_vH.p, 0, m->b_vH.cap, m->cs));
+		HIP_TRY(hipMemsetAsync(m->b_vtb.p, 0, m->b_vtb.cap, m->cs));
 	}
 	m->vol_dirty = true;  // (until the tree update has left the grids clean)
 	HIP_TRY(hipMemsetAsync(m->b_vaux.p, 0, 1024, m->cs));
 	HIP_TRY(hipMemsetAsync(m->b_vupbits.p, 0, m->b_vupbits.cap, m->cs));
 	ScanCtl* ctl = m->b_ctl.as<ScanCtl>();
-	u32* aux = m->b_vaux.as<u32>();  // [0..63] the reserve's counters, [64] tiles listed, [65] tiles done
+	u32* aux = m->b_vaux.as<u32>();  // [0..63] the reserve's counters, [64] tiles listed, [65] tiles done, [66..67] blocks the listed tiles touch
 	if (n_hits) {
 		ProfScope ps(m, "k_vhits");
 		hipLaunchKernelGGL(k_vhits, gridFor(n_hits), dim3(256), 0, m->cs, m->g, vp.vg, m->b_hit_code.as<u64>(), ctl, m->b_vH.as<u64>(), ctl);
 	}
 	{
 		ProfScope ps(m, "k_vdda");
-		hipLaunchKernelGGL(k_vdda, dim3((n_rays + 255) / 256), dim3(256), 0, m->cs, m->g, sensor, m->gridM, vp.vg, m->b_vM.as<u64>(), m->b_ray_end.as<D3>(), ctl, ctl);
+		const u32 nblk = ((n_rays + 255u) / 256u + 7u) & ~7u;  // (a multiple of 8: an eighth of the cloud per XCD)
+		hipLaunchKernelGGL(k_vdda, dim3(nblk), dim3(256), 0, m->cs, m->g, sensor, m->gridM, vp.vg, m->b_vM.as<u64>(), m->b_vtb.as<u32>(), m->b_ray_end.as<D3>(), ctl, ctl, (u32)m->opt_vol_mode);
 	}
 	{
 		ProfScope ps(m, "k_vlist");
-		hipLaunchKernelGGL(k_vlist, gridFor(nt, 1024, 2048), dim3(1024), 0, m->cs, m->b_vM.as<u64>(), (u32)nt, m->b_vlist.as<u32>(), aux + 64);
+		hipLaunchKernelGGL(k_vlist, gridFor(tbw, 256, 2048), dim3(256), 0, m->cs, m->b_vtb.as<u32>(), (u32)nt, m->b_vlist.as<u32>(), m->b_vcopies.as<uint8_t>(), aux + 64);
 	}
 	HIP_TRY(hipMemcpyAsync(m->h_ctl, m->b_ctl.p, sizeof(ScanCtl), hipMemcpyDeviceToHost, m->cs));
 	HIP_TRY(hipMemcpyAsync(&m->vol_count, aux + 64, 4, hipMemcpyDeviceToHost, m->cs));
@@ -155,9 +163,19 @@ int volMapPhase(ufomap_map* m)
 	}
 	// a map that holds little of what the scan touches: room for every block of the listed tiles at once, instead of finding
 	// out half-way; else the walk goes ahead on what there is
-	const u64 worst = (u64)T * 74ull + 4096ull;
+	u64 worst = (u64)T * 74ull + 4096ull;
 	{
 		const u64 cap = (u64)m->t.mask + 1;
+		if (m->opt_vol_pregrow && m->used_est * 2 < worst && (m->used_est + worst) * 20 > cap * 13) {
+			// (gigabytes are at stake: count the blocks the tiles' ray cells really touch instead of 73 per tile)
+			unsigned long long* d_cnt = reinterpret_cast<unsigned long long*>(aux + 66);
+			hipLaunchKernelGGL(k_vcount, dim3((u32)(((u64)T * 8u + 255u) / 256u)), dim3(256), 0, m->stream, m->b_vM.as<u64>(), vp.vg.ntiles, m->b_vlist.as<u32>(), m->b_vcopies.as<uint8_t>(), T,
+			                   d_cnt);
+			unsigned long long h_cnt = 0;
+			HIP_TRY(hipMemcpyAsync(&h_cnt, d_cnt, 8, hipMemcpyDeviceToHost, m->stream));
+			HIP_TRY(hipStreamSynchronize(m->stream));
+			worst = std::min<u64>(worst, (u64)h_cnt + (u64)T / 4 + 4096ull);
+		}
 		if (m->opt_vol_pregrow && m->used_est * 2 < worst && (m->used_est + worst) * 20 > cap * 13) {
 			const u64 want = ((m->used_est + worst) * 20 / 13 + 4095) & ~4095ull;
 			if (want > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
@@ -173,19 +191,20 @@ int volMapPhase(ufomap_map* m)
 	for (int attempt = 0;; ++attempt) {
 		if (attempt > 8) return fail(UFOMAP_ERR_CAPACITY, "the node table kept running out of room during one update (internal error)");
 		const u64 cap = (u64)m->t.mask + 1;
-		const u64 lim_total = cap * 3 / 4 > m->used_est ? cap * 3 / 4 - m->used_est : 0;  // (load <= 0.75 at the end of the walk)
+		const u64 lim_total = cap * 4 / 5 > m->used_est ? cap * 4 / 5 - m->used_est : 0;  // (load <= 0.8 at the end of the walk; the table is sized for 0.65)
 		m->h_res->err = ERR_NOT_STORED;
 		*reinterpret_cast<volatile unsigned long long*>(m->h_res + 1) = 0ull;
 		m->done_by_flag = true;
 		hipLaunchKernelGGL(k_vreset, dim3(1), dim3(64), 0, m->stream, aux, ctl, (u32)(ERR_GROW | ERR_PREV));
 		TileVol va{};
-		va.M = m->b_vM.as<u64>();
+		va.Mx = m->b_vM.as<u64>();
+		va.Mm = m->opt_vol_keep ? m->b_vMm.as<u64>() : nullptr;
 		va.H = m->b_vH.as<u64>();
 		va.list = m->b_vlist.as<u32>();
+		va.copies = m->b_vcopies.as<uint8_t>();
 		va.count = T;
 		va.resv = aux;
 		va.resv_lim = (u32)std::min<u64>(lim_total / 64, 0x7FFFFFFFull);
-		va.clean = m->opt_vol_clean ? 1u : 0u;
 		{
 			ProfScope ps(m, "k_tile");
 			hipLaunchKernelGGL((k_tile<false, true>), dim3((T + 3) / 4), dim3(256), 0, m->stream, m->t, m->g, fg, pipe, 0ull, recs, m->g.hit, miss, m->scan_id,
@@ -210,7 +229,7 @@ int volMapPhase(ufomap_map* m)
 		// ---- the reserve ran out: a larger table, then the tiles that stood back ----
 		++m->n_vol_grow;
 		HIP_TRY(hipMemsetAsync(aux + 65, 0, 4, m->stream));
-		hipLaunchKernelGGL(k_vfix, gridFor(T), dim3(256), 0, m->stream, m->t, m->g, fg, m->b_vlist.as<u32>(), T, recs, m->scan_id, aux + 65);
+		hipLaunchKernelGGL(k_vfix, dim3((T + 255u) / 256u), dim3(256), 0, m->stream, m->t, m->g, fg, m->b_vlist.as<u32>(), T, recs, m->scan_id, aux + 65);
 		u32 n_done = 0;
 		HIP_TRY(hipMemcpyAsync(&n_done, aux + 65, 4, hipMemcpyDeviceToHost, m->stream));
 		HIP_TRY(hipStreamSynchronize(m->stream));
@@ -222,10 +241,10 @@ int volMapPhase(ufomap_map* m)
 		if (want > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
 		const int rc = growTable(m, (u32)want);
 		if (rc) return rc;
-		hipLaunchKernelGGL(k_vfix, gridFor(T), dim3(256), 0, m->stream, m->t, m->g, fg, m->b_vlist.as<u32>(), T, recs, m->scan_id, aux + 65);
+		hipLaunchKernelGGL(k_vfix, dim3((T + 255u) / 256u), dim3(256), 0, m->stream, m->t, m->g, fg, m->b_vlist.as<u32>(), T, recs, m->scan_id, aux + 65);
 		HIP_TRY(hipMemsetAsync(m->b_vupbits.p, 0, m->b_vupbits.cap, m->stream));
 	}
-	if (0 == m->h_res->err && m->opt_vol_clean) m->vol_dirty = false;
+	if (0 == m->h_res->err) m->vol_dirty = false;
 	m->fast = true;  // (finishPending: the finished control block is in pinned memory, k_ftail left the device copy clean)
 	m->pending = true;
 	return UFOMAP_OK;

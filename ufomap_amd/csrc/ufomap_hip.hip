@@ -308,11 +308,13 @@ struct ufomap_map {
 	// the volume path (vol_kernels.h, host_vol.inl): depth-0 scans whose ray grid is beyond the steady-state path's
 	int opt_vol = 1;        // 0 = never; 2 = also for the ray grids the steady-state path would take (tests)
 	int opt_vol_pregrow = 1;  // 0: no growth of the node table before a walk (tests: the walk runs out of its reserve)
-	int opt_vol_clean = 0;  // 1: k_tile leaves the brick grids zeroed (no clearing pass before the next scan; ufomap_map_last_misses then has nothing to read)
+	int opt_fail_scan = 0;  // test aid: the scan half of the next batch steps 'fails' on this rank (host_multi_gpu.inl)
+	int opt_vol_mode = 0;   // measuring aid (k_vdda): bit 0 one copy of M for all XCDs, bit 1 rays in launch order
+	int opt_vol_keep = 1;   // k_tile leaves the merged ray cells of its tiles behind (ufomap_map_last_misses)
 	bool vol = false;       // the integration that uses the current set runs on it
 	bool vol_dirty = true;  // the brick grids are not known to be all zero
 	u32 vol_count = 0;      // tiles the scan has listed
-	DevBuf b_vM, b_vH, b_vlist, b_vrec, b_vaux, b_vupbits;
+	DevBuf b_vM, b_vMm, b_vH, b_vtb, b_vlist, b_vcopies, b_vrec, b_vaux, b_vupbits;  // (b_vM: eight copies, one per XCD)
 	VolPlan vplan{};
 	uint64_t n_vol = 0, n_vol_grow = 0, n_vol_fallback = 0;
 	int opt_tile_waves = 4;   // k_tile: tiles per workgroup
@@ -1192,6 +1194,9 @@ int finishPending(ufomap_map* m)
 		// is repeated below, and this handle hands over with events from now on.
 		++m->n_gate_timeouts;
 		m->opt_gates = 0;
+		// (the scan half may still be running when a gate gives up: nothing of the set is reused or repeated before it has drained)
+		HIP_TRY(hipStreamSynchronize(m->pstream));
+		HIP_TRY(hipStreamSynchronize(m->sstream));
 	}
 	if (m->batch_world) {
 		// a step of ufomap_map_insert_batch: a flagged scan of ANY rank made the walk stand back on every rank (all see the
@@ -2918,8 +2923,8 @@ size_t ufomap_map_last_misses(ufomap_map* m, uint64_t* codes, size_t cap)
 {
 	if (!m || ufomap_map_wait(m) < 0) return (size_t)-1;
 	if (!m->haveM) return 0;
-	if (m->vol && !m->vol_dirty) {
-		fail(UFOMAP_ERR_UNSUPPORTED, "the ray cells of a scan on the volume path are not kept (option vol_clean = 0 keeps them)");
+	if (m->vol && !m->opt_vol_keep) {
+		fail(UFOMAP_ERR_UNSUPPORTED, "the ray cells of a scan on the volume path are not kept (option vol_keep = 1 keeps them)");
 		return (size_t)-1;
 	}
 	ScanCtl* ctl = m->b_ctl.as<ScanCtl>();
@@ -2929,8 +2934,8 @@ size_t ufomap_map_last_misses(ufomap_map* m, uint64_t* codes, size_t cap)
 		if (hipMemsetAsync(&ctl->n_codes, 0, 4, m->stream) != hipSuccess) return (size_t)-1;
 		if (pass && m->b_codes.reserve((size_t)total * 8) != hipSuccess) return (size_t)-1;
 		if (m->vol) {
-			hipLaunchKernelGGL(k_vcodes, gridFor((u64)m->vplan.vg.ntiles * 8u, 256, 8192), dim3(256), 0, m->stream, m->vplan.vg, m->b_vM.as<u64>(),
-			                   pass ? m->b_codes.as<u64>() : (u64*)nullptr, pass ? total : 0u, ctl);
+			hipLaunchKernelGGL(k_vcodes, gridFor((u64)m->vol_count * 8u, 256, 8192), dim3(256), 0, m->stream, m->vplan.vg, m->b_vMm.as<u64>(), m->b_vlist.as<u32>(),
+			                   m->vol_count, pass ? m->b_codes.as<u64>() : (u64*)nullptr, pass ? total : 0u, ctl);
 		} else if (2 == m->gridM.layout) {
 			const u64 slots = m->miss_set_slots;
 			const MissSet ms{m->b_gridM.as<u64>(), reinterpret_cast<u32*>(m->b_gridM.as<u64>() + slots), (u32)(slots - 1), nullptr};
@@ -3424,8 +3429,12 @@ int ufomap_map_set_option(ufomap_map* m, const char* key, long long value)
 		m->opt_vol = (int)std::max<long long>(0, std::min<long long>(2, value));
 	} else if (0 == strcmp(key, "vol_pregrow")) {
 		m->opt_vol_pregrow = value ? 1 : 0;
-	} else if (0 == strcmp(key, "vol_clean")) {
-		m->opt_vol_clean = value ? 1 : 0;
+	} else if (0 == strcmp(key, "fail_scan")) {
+		m->opt_fail_scan = value ? 1 : 0;
+	} else if (0 == strcmp(key, "vol_mode")) {
+		m->opt_vol_mode = (int)(value & 3);
+	} else if (0 == strcmp(key, "vol_keep")) {
+		m->opt_vol_keep = value ? 1 : 0;
 	} else if (0 == strcmp(key, "merge_phases")) {
 		m->opt_merge = value ? 1 : 0;
 	} else if (0 == strcmp(key, "entry_guess")) {

@@ -63,12 +63,28 @@ __global__ __launch_bounds__(256) void k_vhits(MapGeom g, VolGeo vg, const u64* 
 	}
 }
 
-// freeSpaceNormal, one lane per ray (the general path's k_dda, marks collected per brick)
-__global__ __launch_bounds__(256) void k_vdda(MapGeom g, D3 sensor, Grid gr, VolGeo vg, u64* __restrict__ M, const D3* __restrict__ ray_end, const ScanCtl* ctl_in,
-                                              ScanCtl* ctl)
+// The XCD this wave runs on (HW_REG_XCC_ID, bits 3:0). Waves that read the same value share one L2.
+__device__ __forceinline__ u32 xccId() { return (u32)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u; }
+
+// freeSpaceNormal, one lane per ray (the general path's k_dda, marks collected per brick).
+// Where the marks go: a device-scope atomic is executed at the memory side of the fabric (the eight XCDs' L2s are not
+// coherent with each other) -- 10-35 per ns on this part, and 1e8 of them were 9 of this kernel's 9.6 ms. So every XCD marks
+// a copy of M OF ITS OWN, picked by the hardware's XCC id (a fact about where the wave runs, not an assumption about
+// dispatch), with atomics that need no more than the XCD's L2 to be atomic (workgroup scope: no sc1, executed by the L2 all
+// CUs of the XCD share); the lines are written back when the kernel ends like any plain store's. k_tile ORs the copies a
+// tile was marked in -- the per-XCD tile bitmaps say which -- and leaves them zeroed. Blocks are mapped to rays so that
+// (with the usual block b -> XCD b % 8 placement; speed only) an XCD takes one contiguous eighth of the cloud: neighbouring
+// rays share bricks, and a tile is marked in one or two copies, not eight.
+__global__ __launch_bounds__(256) void k_vdda(MapGeom g, D3 sensor, Grid gr, VolGeo vg, u64* __restrict__ Mx, u32* __restrict__ tbx, const D3* __restrict__ ray_end,
+                                              const ScanCtl* ctl_in, ScanCtl* ctl, u32 mode)
 {
+	// (mode, a measuring aid: bit 0 = one copy for all XCDs, bit 1 = blocks take the rays in launch order)
 	const u32 n = ctl_in->n_rays;
-	const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	const u32 per = gridDim.x >> 3;  // (the grid is a multiple of 8 blocks)
+	const u32 i = ((mode & 2u) ? blockIdx.x : ((blockIdx.x & 7u) * per + (blockIdx.x >> 3))) * blockDim.x + threadIdx.x;
+	const u32 xcc = (mode & 1u) ? 0u : xccId();
+	u64* const M = Mx + (size_t)xcc * ((size_t)vg.ntiles * 8u);
+	u32* const tb = tbx + (size_t)xcc * (((size_t)vg.ntiles + 31u) >> 5);
 	unsigned long long steps = 0;
 	u32 err = 0;
 	if (i < n) {
@@ -79,7 +95,8 @@ __global__ __launch_bounds__(256) void k_vdda(MapGeom g, D3 sensor, Grid gr, Vol
 		} else if (1 == r.status) {
 			u32 w, b;
 			volWordBit(vg, (u32)(r.start[0] - vg.cbase[0]), (u32)(r.start[1] - vg.cbase[1]), (u32)(r.start[2] - vg.cbase[2]), &w, &b);
-			atomicOr(reinterpret_cast<unsigned long long*>(&M[w]), 1ull << b);
+			__hip_atomic_fetch_or(&M[w], 1ull << b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			__hip_atomic_fetch_or(&tb[w >> 8], 1u << ((w >> 3) & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			steps = 1;
 		} else if (2 == r.status) {
 			u32 x = (u32)(r.start[0] - vg.cbase[0]), y = (u32)(r.start[1] - vg.cbase[1]), z = (u32)(r.start[2] - vg.cbase[2]);
@@ -99,7 +116,11 @@ __global__ __launch_bounds__(256) void k_vdda(MapGeom g, D3 sensor, Grid gr, Vol
 				const u32 w = tile * 8u + (((x >> 2) & 1u) | (((y >> 2) & 1u) << 1) | (((z >> 2) & 1u) << 2));
 				const u32 b = (x & 3u) | ((y & 3u) << 2) | ((z & 3u) << 4);
 				if (w != curw) {
-					if (acc) atomicOr(reinterpret_cast<unsigned long long*>(&M[curw]), acc);
+					if (acc) __hip_atomic_fetch_or(&M[curw], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+					// (a new tile: its bit in the XCD's tile bitmap -- looked at first: bits only appear during this kernel, the CU's L1
+					// was invalidated when it started, and a stale 0 costs one more atomic; 6e7 atomics were 2 ms of this kernel)
+					if (((w ^ curw) >> 3) && !((tb[tile >> 5] >> (tile & 31u)) & 1u))
+						__hip_atomic_fetch_or(&tb[tile >> 5], 1u << (tile & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 					curw = w;
 					acc = 0;
 				}
@@ -121,7 +142,7 @@ __global__ __launch_bounds__(256) void k_vdda(MapGeom g, D3 sensor, Grid gr, Vol
 				const bool more = (__double_as_longlong(tmx) <= idist) | (__double_as_longlong(tmy) <= idist) | (__double_as_longlong(tmz) <= idist);
 				go = (((x ^ gx) | (y ^ gy) | (z ^ gz)) != 0u) & more & (cnt < budget);
 			} while (go);
-			if (acc) atomicOr(reinterpret_cast<unsigned long long*>(&M[curw]), acc);
+			if (acc) __hip_atomic_fetch_or(&M[curw], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			if (cnt >= budget) err |= ERR_RUNAWAY;
 			steps = cnt;
 		}
@@ -130,20 +151,62 @@ __global__ __launch_bounds__(256) void k_vdda(MapGeom g, D3 sensor, Grid gr, Vol
 	if (err) atomicOr(&ctl->err, err);
 }
 
-// the tiles that hold a ray cell -> list (count in *n_out); one thread per tile, one 64-byte line each
-__global__ __launch_bounds__(1024) void k_vlist(const u64* __restrict__ M, u32 ntiles, u32* __restrict__ list, u32* n_out)
+// the tiles some XCD has marked -> list (tile, copies it was marked in); the bitmaps are left clean. One thread per word of
+// the bitmaps (32 tiles); count in *n_out.
+__global__ __launch_bounds__(256) void k_vlist(u32* __restrict__ tbx, u32 ntiles, u32* __restrict__ list, uint8_t* __restrict__ copies, u32* n_out)
 {
-	for (u32 t0 = blockIdx.x * blockDim.x; t0 < ntiles; t0 += gridDim.x * blockDim.x) {
-		const u32 t = t0 + threadIdx.x;
-		bool any = false;
-		if (t < ntiles) {
-			const ulonglong2* p = reinterpret_cast<const ulonglong2*>(M + (size_t)t * 8u);
-			const ulonglong2 a = p[0], b = p[1], c = p[2], d = p[3];
-			any = 0 != (a.x | a.y | b.x | b.y | c.x | c.y | d.x | d.y);
+	const u32 nwords = (ntiles + 31u) >> 5;
+	for (u32 w0 = blockIdx.x * blockDim.x; w0 < nwords; w0 += gridDim.x * blockDim.x) {  // (uniform)
+		const u32 w = w0 + threadIdx.x;
+		u32 c[8], any = 0;
+#pragma unroll
+		for (int k = 0; k < 8; ++k) {
+			c[k] = w < nwords ? tbx[(size_t)k * nwords + w] : 0u;
+			any |= c[k];
 		}
-		const u32 pos = blockAppend(n_out, any);
-		if (any) list[pos] = t;
+#pragma unroll
+		for (int k = 0; k < 8; ++k)
+			if (c[k]) tbx[(size_t)k * nwords + w] = 0u;
+		u32 pos = waveAppendN(n_out, (u32)__popc(any));
+		while (any) {
+			const u32 bit = (u32)__ffs(any) - 1u;
+			any &= any - 1u;
+			u32 cm = 0;
+#pragma unroll
+			for (int k = 0; k < 8; ++k) cm |= ((c[k] >> bit) & 1u) << k;
+			list[pos] = 32u * w + bit;
+			copies[pos] = (uint8_t)cm;
+			++pos;
+		}
 	}
+}
+
+// node blocks the listed tiles' ray cells touch beneath depth 3 (level 1: 2x2x2 cells with a mark, level 2: bricks with a mark,
+// level 3: the tile): what a walk into an empty map creates -- the table is sized by it. Eight lanes per tile (lane = brick).
+__global__ __launch_bounds__(256) void k_vcount(const u64* __restrict__ Mx, u32 ntiles, const u32* __restrict__ list, const uint8_t* __restrict__ copies, u32 count,
+                                                unsigned long long* out)
+{
+	const u32 i = (blockIdx.x * blockDim.x + threadIdx.x) >> 3, br = threadIdx.x & 7u;
+	u32 nblk = 0;
+	if (i < count) {
+		const u32 tile = list[i];
+		u32 cm = copies[i];
+		u64 m = 0;
+		while (cm) {
+			const u32 k = (u32)__ffs(cm) - 1u;
+			cm &= cm - 1u;
+			m |= Mx[(size_t)k * ((size_t)ntiles * 8u) + (size_t)tile * 8u + br];
+		}
+		// a 2x2x2 block of the brick holds a mark: fold x pairs, y pairs, z pairs onto the block's first cell
+		u64 f = m | (m >> 1);
+		f |= f >> 4;
+		f |= f >> 16;
+		// (cells with even x, y, z: bits 0, 2, 8, 10, and the same + 32)
+		nblk = (u32)__popcll(f & 0x0000050500000505ull) + (m ? 1u : 0u) + (0 == br ? 1u : 0u);
+	}
+	unsigned long long v = nblk;
+	for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+	if (0 == (threadIdx.x & 63u) && v) atomicAdd(out, v);
 }
 
 // After the table has been exchanged for a larger one in the middle of a walk: the records of the tiles that are done
@@ -169,17 +232,19 @@ __global__ __launch_bounds__(256) void k_vfix(Table t, MapGeom g, FastGeo fg, co
 	const u32 c = (u32)__popcll(__ballot(done));
 	if (0 == (threadIdx.x & 63u) && c) atomicAdd(n_done, c);
 }
-// ray cells of the scan as codes (ufomap_map_last_misses; option vol_clean = 0 keeps the grid): one thread per brick word
-__global__ __launch_bounds__(256) void k_vcodes(VolGeo vg, const u64* __restrict__ M, u64* __restrict__ codes, u32 cap, ScanCtl* ctl)
+// ray cells of the scan as codes (ufomap_map_last_misses), from the merged words k_tile left for the listed tiles: one thread per
+// brick word of a listed tile
+__global__ __launch_bounds__(256) void k_vcodes(VolGeo vg, const u64* __restrict__ Mm, const u32* __restrict__ list, u32 count, u64* __restrict__ codes, u32 cap,
+                                                ScanCtl* ctl)
 {
-	const u64 nwords = (u64)vg.ntiles * 8u;
+	const u64 nwords = (u64)count * 8u;
 	for (u64 w0 = (u64)blockIdx.x * blockDim.x; w0 < nwords; w0 += (u64)gridDim.x * blockDim.x) {  // (uniform: whole waves append)
 		const u64 w = w0 + threadIdx.x;
-		u64 m = w < nwords ? M[w] : 0ull;
+		const u32 tile = w < nwords ? list[w >> 3] : 0u, br = (u32)(w & 7u);
+		u64 m = w < nwords ? Mm[(size_t)tile * 8u + br] : 0ull;
 		const u32 cnt = (u32)__popcll(m);
 		u32 pos = waveAppendN(&ctl->n_codes, cnt);
 		if (0 == m) continue;
-		const u32 tile = (u32)(w >> 3), br = (u32)(w & 7u);
 		const u32 tx = tile % vg.nt[0], tr = tile / vg.nt[0];
 		const u32 ty = tr % vg.nt[1], tz = tr / vg.nt[1];
 		while (m) {

@@ -228,8 +228,12 @@ class OccupancyMapBase:
         if n == C.c_size_t(-1).value:
             capi.check(-2)
         if n > buf.size:
-            buf = self._wbuf = np.empty(n + n // 2, np.uint8)
-            self._lib.ufomap_map_write_ex(self._h, pc, ph, *a, _p(buf, C.c_uint8), buf.size, C.byref(us))
+            buf = np.empty(n + n // 2, np.uint8)
+            n = self._lib.ufomap_map_write_ex(self._h, pc, ph, *a, _p(buf, C.c_uint8), buf.size, C.byref(us))
+            if n == C.c_size_t(-1).value or n > buf.size:
+                capi.check(-2)
+            # (a stream of tens of megabytes is not kept for the object's lifetime)
+            self._wbuf = buf if buf.size <= (8 << 20) else None
         return buf[:n].tobytes(), int(us.value)
 
     def read(self, data):
