@@ -422,6 +422,33 @@ def main():
         digests_pc2["server_loop"] = m.digest()
         m.resetMinMaxChangeDetection()
 
+        # ---- the headline loop driven from C++ through the C ABI (examples/bench_loop.cpp): the library without the Python
+        # interpreter and ctypes between two calls -- what a C++ caller such as the reference's server gets ------------------
+        try:
+            import subprocess
+            import tempfile
+            from ufomap_amd import build as hipbuild
+            exe = hipbuild.build_bench_loop(verbose=False)
+            with tempfile.NamedTemporaryFile(suffix=".bin", delete=False) as tf:
+                tf.write(np.array([N_POSES, n_pts], np.uint64).tobytes())
+                for p in range(N_POSES):
+                    tf.write(np.asarray(clouds[p][0], np.float64).tobytes())
+                    tf.write(np.ascontiguousarray(clouds[p][1], np.float64).tobytes())
+                path = tf.name
+            pr = subprocess.run([exe, path, str(W), str(K), str(args.min_timed_s), str(local_rank)], capture_output=True, text=True, timeout=300)
+            os.unlink(path)
+            if pr.returncode == 0:
+                cx = json.loads(pr.stdout.strip().splitlines()[-1])
+                extra["host_cxx"] = dict(rays_per_s=cx["rays_per_s"], ms_per_step=cx["ms_per_step"], repeats=cx["repeats"], timed_region_s=cx["timed_region_s"],
+                                         scans_per_walk=cx["fast_path_scans"] / max(1, cx["tree_walks"]), gate_timeouts=cx["gate_timeouts"],
+                                         note="the same W + K sequence and repetitions as `value`, driven by examples/bench_loop.cpp (a C++ loop over "
+                                              "ufomap_map_insert_device, async) in a process of its own: the library without the Python loop")
+                digests["host_cxx"] = tuple(int(v) for v in cx["digest"])
+            else:
+                extra["host_cxx"] = dict(error=f"rc {pr.returncode}: {pr.stderr.strip()[-300:]}")
+        except Exception as e:  # noqa: BLE001  (the leg is a diagnostic: it must not take the bench line down)
+            extra["host_cxx"] = dict(error=repr(e))
+
         # ---- round 1's figure: one scan re-integrated from a static pose into a saturated map -------------------
         ms = OccupancyMap(RES, device=local_rank)
         d0, o0 = d_clouds[0], clouds[0][0]

@@ -54,6 +54,25 @@ for N in (1, 2, 4, 8):
     m.insertPointCloudWait()
     comm.close()
     del m
+# the honest base of an efficiency: what ONE GPU does alone with the same scans -- the pipelined single-GPU path
+# (ufomap_map_insert_device, async), same sequence, same run -- not N = 1 of the batch path
+m = OccupancyMap(0.16)
+dts = []
+for rep in range(40):
+    m.insertPointCloudWait()
+    m.clear()
+    for i in range(W):
+        m.insert_device(clouds[i % 8][0], d_clouds[i % 8].data_ptr(), None, n_pts, 20.0, 0, True, async_=True)
+    m.insertPointCloudWait()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(W, W + K):
+        m.insert_device(clouds[i % 8][0], d_clouds[i % 8].data_ptr(), None, n_pts, 20.0, 0, True, async_=True)
+    m.insertPointCloudWait()
+    torch.cuda.synchronize()
+    dts.append(time.perf_counter() - t0)
+res["single_gpu_pipelined_ms_per_scan"] = float(np.median(dts[3:])) / K * 1e3
+del m
 # the exchange slot of the fast-path form: 2 KiB + two bit grids of the ranks' common ray grid (the 8 poses' hull: ~95 KB each)
 slot_bytes = 2048 + 2 * 97000
 link_GBs, lat_us = 50.0, 20.0
@@ -65,10 +84,15 @@ for N in (1, 2, 4, 8):
     # Two bounds: the wire entirely hidden behind that walk (the measured step), and entirely exposed (measured step + wire).
     model[N] = dict(wire_ms=wire_ms, step_ms_wire_hidden=step, step_ms_wire_exposed=step + wire_ms,
                     scans_per_s_wire_hidden=N / step * 1e3, scans_per_s_wire_exposed=N / (step + wire_ms) * 1e3)
+one_gpu = 1e3 / res["single_gpu_pipelined_ms_per_scan"]  # scans/s of one GPU integrating on its own
 for N in model:
-    model[N]["efficiency_wire_hidden"] = model[N]["scans_per_s_wire_hidden"] / (N * model[1]["scans_per_s_wire_hidden"])
-    model[N]["efficiency_wire_exposed"] = model[N]["scans_per_s_wire_exposed"] / (N * model[1]["scans_per_s_wire_exposed"])
+    # against N x ONE pipelined GPU (what N maps on N GPUs would integrate without any collective) ...
+    model[N]["efficiency_wire_hidden"] = model[N]["scans_per_s_wire_hidden"] / (N * one_gpu)
+    model[N]["efficiency_wire_exposed"] = model[N]["scans_per_s_wire_exposed"] / (N * one_gpu)
+    # ... and, for comparison with rounds 2 / 3, against N x (N = 1 of the batch path)
+    model[N]["efficiency_vs_batch_N1_wire_hidden"] = model[N]["scans_per_s_wire_hidden"] / (N * model[1]["scans_per_s_wire_hidden"])
+    model[N]["efficiency_vs_batch_N1_wire_exposed"] = model[N]["scans_per_s_wire_exposed"] / (N * model[1]["scans_per_s_wire_exposed"])
 res["model"] = model
 res["model_assumptions"] = (f"ring all-gather over xGMI: {lat_us} us + (N-1) x {slot_bytes} B / {link_GBs} GB/s per link direction; efficiency = scans/s at N / "
-                            "(N x scans/s at N = 1); measured part: everything but the wire, on one MI355X playing rank 0 of N")
+                            "(N x scans/s of ONE GPU on the pipelined single-GPU path, measured in this run); measured part: everything but the wire, on one MI355X playing rank 0 of N")
 print(json.dumps(res))

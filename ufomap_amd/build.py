@@ -38,6 +38,24 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return LIB
 
 
+EXAMPLE_SRC = os.path.join(os.path.dirname(HERE), "examples", "bench_loop.cpp")
+EXAMPLE_BIN = os.path.join(os.path.dirname(HERE), "examples", "bench_loop")
+
+
+def build_bench_loop(verbose: bool = True) -> str:
+    """examples/bench_loop: the bench's headline loop in C++ through the C ABI (bench.py leg "host_cxx")."""
+    build(verbose=verbose)
+    deps = [EXAMPLE_SRC, LIB, os.path.join(os.path.dirname(HERE), "include", "ufomap_hip.h")]
+    if os.path.exists(EXAMPLE_BIN) and all(os.path.getmtime(d) <= os.path.getmtime(EXAMPLE_BIN) for d in deps):
+        return EXAMPLE_BIN
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "-O2", "-std=c++17", "-I" + os.path.join(os.path.dirname(HERE), "include"), EXAMPLE_SRC, "-L" + CSRC, "-lufomap_hip", "-Wl,-rpath," + CSRC, "-o", EXAMPLE_BIN]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return EXAMPLE_BIN
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
     print(LIB)

@@ -1109,7 +1109,7 @@ struct TileVol {
 	const u32* list;       // active tiles
 	const uint8_t* copies; // ... and the copies each was marked in
 	u32 count;
-	u32* resv;             // 64 counters of blocks created by this walk
+	u32* resv;             // 64 counters of tile groups claimed by this walk
 	u32 resv_lim;          // ... and what each may reach
 };
 template <bool COLOR, bool VOL = false>
@@ -1279,8 +1279,9 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 			const u32 max_probe = (t.mask >> 1) + 1;
 			bool dummy;
 			if (VOL) {
-				// nothing has been written yet: the blocks this tile creates come out of the walk's reserve, or the tile stands back
-				const u32 need = (u32)__popcll(__ballot(mk1)) + (u32)__popcll(__ballot(mk2)) + (mk3 ? 1u : 0u);
+				// nothing has been written yet: a tile that needs a group of its own (its level-3 block is not there: table.h) takes it
+				// out of the walk's reserve, or stands back
+				const u32 need = mk3 ? 1u : 0u;
 				u32 over = 0;
 				if (need && 0 == lane) over = (atomicAdd(&va.resv[(tile * 0x9E3779B1u) >> 26], need) + need > va.resv_lim) ? 1u : 0u;
 				if (__shfl((int)over, 0)) {
@@ -2259,6 +2260,14 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 		ctl->used_now = used;  // the host's view of the table's fill
 		ctl->dbg[45] = B;      // (scans this walk applied: the host's statistics)
 		tsMark(p->ts, f, 6, wall_clock64());
+	}
+	if (threadIdx.x < 64u) {
+		u32 ng, nu;
+		tableCounts(t, threadIdx.x, &ng, &nu);
+		if (0 == threadIdx.x) {
+			ctl->used_g_now = ng;
+			ctl->used_u_now = nu;
+		}
 	}
 	// The finished control blocks go to the host's pinned copies from here (no read-back copy, no stream synchronisation on
 	// the host: it polls the word behind a block and reads), and the device copies return to the start state of a scan

@@ -40,9 +40,9 @@ FastGeo makeUpGeo(const FastGeo& fg)
 }
 
 // upper bound of the node blocks one scan inside grid gr can create: every level-1 block of the grid and all ancestors
-u64 fastBound(const ufomap_map* m, const Grid& gr)
+Need fastBound(const ufomap_map* m, const Grid& gr)
 {
-	return blockBound(m, (u64)gr.nb[0] * (u64)gr.nb[1] * (u64)gr.nb[2], gr.nb, 1);
+	return needBound(m, (u64)gr.nb[0] * (u64)gr.nb[1] * (u64)gr.nb[2], gr.nb, 1);
 }
 
 // dense grids of the cells above the tiles (fast_kernels.h: UpperGeo); returns the total number of cells
@@ -408,14 +408,14 @@ int enqueueSlot(ufomap_map* m, int k)
 	const FastGeo fg = a ? a->fgeo : m->fgeo;
 	const uint64_t f = a ? a->fseq : m->fseq;
 	ScanCtl* const ctl = (a ? a->b_ctl : m->b_ctl).as<ScanCtl>();
-	const u64 bound = fastBound(m, fg.gr);  // (every block of the grid new: no more, however many scans the walk takes)
+	const Need bound = fastBound(m, fg.gr);  // (every block of the grid new: no more, however many scans the walk takes)
 	// The update enqueued just before this one, if it has not been joined: this walk looks at its status when it starts and
 	// stands back if that one did (everything flagged is then repeated in order when it is joined).
 	const u32* prev_stat = nullptr;
-	u64 in_flight = 0;
+	Need in_flight;
 	auto scanQueue = [&]() {
 		prev_stat = nullptr;
-		in_flight = 0;
+		in_flight = Need{};
 		int pk = -1;
 		for (int i = 0; i < kAlt; ++i) {
 			const HandOver& o = m->alt[i];
@@ -435,18 +435,15 @@ int enqueueSlot(ufomap_map* m, int k)
 	m->cs = m->stream;
 	{
 		// node table: room for what this walk can create on top of what the updates in flight can
-		const u64 cap = (u64)m->t.mask + 1;
-		if ((m->used_est + in_flight + bound) * 5 > cap * 3) {
-			if (in_flight || countPendingAlts(m) > 0) {
+		if (!tableTakes(m, in_flight + bound)) {
+			if (in_flight.blocks || countPendingAlts(m) > 0) {
 				const int jrc = joinEnqueued(m);  // (the table cannot be exchanged under an update in flight -- scans on this scan's own grid included)
 				if (jrc < 0) return jrc;
 				scanQueue();
 			}
-			if ((m->used_est + bound) * 5 > ((u64)m->t.mask + 1) * 3) {
-				const u64 want = tableCapFor(m->used_est + bound, (u64)m->t.mask + 1);
-				if ((m->used_est + bound) * 7 / 4 > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
+			if (!tableTakes(m, bound)) {
 				m->cs = m->stream;
-				const int rc = growTable(m, (u32)want);
+				const int rc = growFor(m, bound);
 				if (rc) return rc;
 			}
 		}
@@ -476,6 +473,7 @@ int enqueueSlot(ufomap_map* m, int k)
 	(a ? a->pending : m->pending) = true;
 	(a ? a->deferred : m->deferred) = false;
 	(a ? a->has_slot : m->has_slot) = true;
+	if (!(!a && m->solo) && f > m->last_slot_fseq) m->last_slot_fseq = f;
 	(a ? a->bound : m->bound) = bound;
 	m->cs = m->stream;
 	const bool solo = !a && m->solo;
@@ -567,7 +565,7 @@ int flushDeferred(ufomap_map* m, bool publish)
 			HandOver* const h = idx[a] < 0 ? nullptr : &m->alt[idx[a]];
 			(h ? h->deferred : m->deferred) = false;
 			(h ? h->has_slot : m->has_slot) = false;
-			(h ? h->bound : m->bound) = 0;
+			(h ? h->bound : m->bound) = Need{};
 		}
 	}
 	return UFOMAP_OK;

@@ -226,6 +226,9 @@ int listBatchStep(ufomap_map* m, ufomap_comm* c, const double origin[3], const d
 		bool ok = hipMemcpyAsync(send, c->h_hdr, kSlotHeader, hipMemcpyHostToDevice, m->sstream) == hipSuccess;
 		const bool fits = kSlotHeader + my_bytes <= c->cap;  // (if not, the header alone tells everybody how much room is needed)
 		if (ok && fits && my_bytes) ok = hipMemcpyAsync(send + kSlotHeader, m->b_entries.p, my_bytes, hipMemcpyDeviceToDevice, m->sstream) == hipSuccess;
+		// (the collectives of a communicator run in the order they are issued, on every rank alike: the gathers of earlier
+		// bit-grid steps, issued on their own stream, have completed before this one goes out on the scan stream)
+		if (m->gstream) HIP_TRY(hipStreamSynchronize(m->gstream));
 		const int e = r->AllGather(send, recv, c->cap, /* ncclChar */ 0, c->comm, m->sstream);
 		if (e) return rcclFail(e, "ncclAllGather");
 		HIP_TRY(hipMemcpy2DAsync(c->h_hdr, kSlotHeader, recv, c->cap, kSlotHeader, (size_t)W, hipMemcpyDeviceToHost, m->sstream));
@@ -405,27 +408,33 @@ int fastBatchStep(ufomap_map* m, ufomap_comm* c, const double origin[3], const d
 	hipLaunchKernelGGL(k_pack_slot, dim3(64), dim3(256), 0, m->sstream, reinterpret_cast<uint4*>(send), reinterpret_cast<const uint4*>(ctl),
 	                   m->b_tilebits.as<uint4>(), m->b_gridM.as<uint4>(), m->b_gridH.as<uint4>(), n4);
 	{
-		const int e = r->AllGather(send, recv, slot, /* ncclChar */ 0, c->comm, m->sstream);
+		// The collective on a stream of its own: only the walk needs what it gathers, so the wire of step i overlaps the scan
+		// half of step i + 1 (which would queue behind it on the scan stream) as well as the walk of step i - 1.
+		if (!m->gstream) {
+			HIP_TRY(hipStreamCreateWithFlags(&m->gstream, hipStreamNonBlocking));
+			HIP_TRY(hipEventCreateWithFlags(&m->pack_ev, hipEventDisableTiming));
+		}
+		HIP_TRY(hipEventRecord(m->pack_ev, m->sstream));
+		HIP_TRY(hipStreamWaitEvent(m->gstream, m->pack_ev, 0));
+		const int e = r->AllGather(send, recv, slot, /* ncclChar */ 0, c->comm, m->gstream);
 		if (e) return rcclFail(e, "ncclAllGather");
 	}
-	HIP_TRY(hipEventRecord(m->xchg_ev, m->sstream));
+	HIP_TRY(hipEventRecord(m->xchg_ev, m->gstream));
 	// ---- the walk: the scans of ranks 0 .. W-1 in this order (UFO_BATCH_MAX at a time) ----
 	m->cs = m->stream;
-	const u64 bound = fastBound(m, fg.gr);
+	const Need bound = fastBound(m, fg.gr);
 	{
-		u64 in_flight = 0;
+		Need in_flight;
 		for (int i = 0; i < kAlt; ++i)
 			if (m->alt[i].pending && !(m->alt[i].fast && 0 == memcmp(m->alt[i].fgeo.gr.base, fg.gr.base, sizeof(fg.gr.base)) &&
 			                           0 == memcmp(m->alt[i].fgeo.gr.nb, fg.gr.nb, sizeof(fg.gr.nb))))
 				in_flight += m->alt[i].bound;
-		if ((m->used_est + in_flight + bound) * 5 > ((u64)m->t.mask + 1) * 3) {
+		if (!tableTakes(m, in_flight + bound)) {
 			const int jrc = joinEnqueued(m);  // (deterministic: every rank's replica holds the same number of blocks)
 			if (jrc < 0) return jrc;
-			if ((m->used_est + bound) * 5 > ((u64)m->t.mask + 1) * 3) {
-				const u64 want = tableCapFor(m->used_est + bound, (u64)m->t.mask + 1);
-				if ((m->used_est + bound) * 7 / 4 > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
+			if (!tableTakes(m, bound)) {
 				m->cs = m->stream;
-				const int grc = growTable(m, (u32)want);
+				const int grc = growFor(m, bound);
 				if (grc) return grc;
 			}
 		}

@@ -427,11 +427,15 @@ int readNodes(ufomap_map* m, const uint8_t* data, size_t n, const double* aabb_c
 		}
 	// every record may create a block
 	{
-		const u64 cap = (u64)m->t.mask + 1;
-		if ((m->used_est + total) * 5 > cap * 3) {
-			const u64 want = tableCapFor(m->used_est + total, (u64)m->t.mask + 1);
-			if ((m->used_est + total) * 7 / 4 > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
-			int rc = growTable(m, (u32)want);
+		// (a record of level l is a node block of level l: tile groups for the level-3 records, the first region above)
+		Need need;
+		need.blocks = total;
+		for (u32 l = L; l >= 1; --l) {
+			if (L < 4 || l >= 4) need.upper += sp.recs[l].size();
+			else if (3 == l) need.groups += sp.recs[l].size();
+		}
+		if (!tableTakes(m, need)) {
+			int rc = growFor(m, need);
 			if (rc) return rc;
 		}
 	}
@@ -475,9 +479,8 @@ int ufomap_map_read_data(ufomap_map* m, const uint8_t* data, size_t n, const dou
 	}
 	{
 		// used_est may be stale after a clear
-		MapRoot root;
-		HIP_TRY(hipMemcpy(&root, m->b_root.p, sizeof(MapRoot), hipMemcpyDeviceToHost));
-		m->used_est = root.used;
+		const int frc = refreshFill(m);
+		if (frc) return frc;
 	}
 	if (compressed) {
 		// decompressData (octree.h:1460-1486)

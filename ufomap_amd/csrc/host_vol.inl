@@ -161,37 +161,29 @@ int volMapPhase(ufomap_map* m)
 		d.geo = 0;
 		hipLaunchKernelGGL(k_batch_descs, dim3(1), dim3(64), 0, m->stream, pipe, pk, 1u);
 	}
-	// a map that holds little of what the scan touches: room for every block of the listed tiles at once, instead of finding
-	// out half-way; else the walk goes ahead on what there is
-	u64 worst = (u64)T * 74ull + 4096ull;
+	// Node table. The first region takes what the walk can create above the tiles (bounded per level by the listed tiles and by
+	// the level's cells: a few per cent of the table); tile groups: a map that holds little of what the scan touches gets room
+	// for every listed tile at once instead of finding out half-way, else the walk goes ahead on what there is -- new groups
+	// come out of a reserve, and a tile that finds it used up stands back.
 	{
-		const u64 cap = (u64)m->t.mask + 1;
-		if (m->opt_vol_pregrow && m->used_est * 2 < worst && (m->used_est + worst) * 20 > cap * 13) {
-			// (gigabytes are at stake: count the blocks the tiles' ray cells really touch instead of 73 per tile)
-			unsigned long long* d_cnt = reinterpret_cast<unsigned long long*>(aux + 66);
-			hipLaunchKernelGGL(k_vcount, dim3((u32)(((u64)T * 8u + 255u) / 256u)), dim3(256), 0, m->stream, m->b_vM.as<u64>(), vp.vg.ntiles, m->b_vlist.as<u32>(), m->b_vcopies.as<uint8_t>(), T,
-			                   d_cnt);
-			unsigned long long h_cnt = 0;
-			HIP_TRY(hipMemcpyAsync(&h_cnt, d_cnt, 8, hipMemcpyDeviceToHost, m->stream));
-			HIP_TRY(hipStreamSynchronize(m->stream));
-			worst = std::min<u64>(worst, (u64)h_cnt + (u64)T / 4 + 4096ull);
-		}
-		if (m->opt_vol_pregrow && m->used_est * 2 < worst && (m->used_est + worst) * 20 > cap * 13) {
-			const u64 want = ((m->used_est + worst) * 20 / 13 + 4095) & ~4095ull;
-			if (want > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
-			const int rc = growTable(m, (u32)want);
+		Need need;
+		for (int k = 1; k < vp.n; ++k) need.upper += std::min<u64>(T, vp.lv[k].ntiles);
+		need.upper += 2048;
+		need.blocks = need.upper;
+		if (m->opt_vol_pregrow && m->used_g * 2 < T) need.groups = T;
+		if (!tableTakes(m, need)) {
+			const int rc = growFor(m, need);
 			if (rc) return rc;
 		}
 	}
 	m->scan_id += 1;
-	m->scan_new_bound = 0;
+	m->scan_new_bound = Need{};
 	const float miss = (float)m->g.miss_log;  // insert depth 0 (OMB:311)
 	const FastGeo& fg = vp.lv[0];
 	TileRec* recs = m->b_vrec.as<TileRec>();
 	for (int attempt = 0;; ++attempt) {
 		if (attempt > 8) return fail(UFOMAP_ERR_CAPACITY, "the node table kept running out of room during one update (internal error)");
-		const u64 cap = (u64)m->t.mask + 1;
-		const u64 lim_total = cap * 4 / 5 > m->used_est ? cap * 4 / 5 - m->used_est : 0;  // (load <= 0.8 at the end of the walk; the table is sized for 0.65)
+		const u64 lim_total = (u64)m->t.nG * 9 / 10 > m->used_g ? (u64)m->t.nG * 9 / 10 - m->used_g : 0;  // (new tile groups: the directory at most 90 % full)
 		m->h_res->err = ERR_NOT_STORED;
 		*reinterpret_cast<volatile unsigned long long*>(m->h_res + 1) = 0ull;
 		m->done_by_flag = true;
@@ -233,14 +225,15 @@ int volMapPhase(ufomap_map* m)
 		u32 n_done = 0;
 		HIP_TRY(hipMemcpyAsync(&n_done, aux + 65, 4, hipMemcpyDeviceToHost, m->stream));
 		HIP_TRY(hipStreamSynchronize(m->stream));
-		// (MapRoot::used does not hold what the tiles that are done have created -- k_up adds that -- but the re-hash counts what it copies)
-		const u64 left = (u64)(T - std::min(T, n_done)) * 74ull + 4096ull;
-		const u64 have = std::min<u64>(cap, m->used_est + (u64)n_done * 74ull);
-		u64 want = std::max<u64>(cap + cap / 2, (have + left) * 20 / 13);
-		want = (want + 4095) & ~4095ull;
-		if (want > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
-		const int rc = growTable(m, (u32)want);
-		if (rc) return rc;
+		// (the re-hash counts the groups and blocks it copies: what the tiles that are done have created included)
+		{
+			Need need;
+			need.groups = (u64)(T - std::min(T, n_done)) + (u64)std::min(T, n_done);  // (the groups of the tiles that are done are not in used_g yet)
+			const u64 nG = std::max<u64>((u64)m->t.nG + m->t.nG / 2, (m->used_g + need.groups) * 5 / 4 + 64);
+			if ((u64)m->t.capU + UFO_GROUP * nG > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
+			const int rc = growTable(m, (u32)((nG + 63) & ~63ull), m->t.capU);
+			if (rc) return rc;
+		}
 		hipLaunchKernelGGL(k_vfix, dim3((T + 255u) / 256u), dim3(256), 0, m->stream, m->t, m->g, fg, m->b_vlist.as<u32>(), T, recs, m->scan_id, aux + 65);
 		HIP_TRY(hipMemsetAsync(m->b_vupbits.p, 0, m->b_vupbits.cap, m->stream));
 	}

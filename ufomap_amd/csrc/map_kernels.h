@@ -234,11 +234,13 @@ __device__ inline void markDirty(const Table& t, bool want, u32 p, u32* __restri
 // to a phase that reuses an old number. One thread per slot.
 __global__ __launch_bounds__(256) void k_reset_tags(Table t)
 {
-	const u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-	if (s > (u64)t.mask) return;
-	t.stamp((u32)s) = 0;
-	t.tmax[s] = 0;
-	t.lu_fl[s] = 0;
+	// (grid-stride: the host caps its launches at 4096 workgroups -- one thread per slot left the tags of a table of more
+	// than a million slots in place beyond the first million; round 4's tile-major tables are that large for small maps too)
+	for (u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x; s <= (u64)t.mask; s += (u64)gridDim.x * blockDim.x) {
+		t.stamp((u32)s) = 0;
+		t.tmax[s] = 0;
+		t.lu_fl[s] = 0;
+	}
 }
 
 // a few counters from the host, by value (no host buffer whose lifetime anybody has to think about)
@@ -987,6 +989,14 @@ __global__ __launch_bounds__(1024) void k_propagate_tail(Table t, MapGeom g, u32
                                                          u32 first_level, u32 phase, ScanCtl::PhaseCtr* pc, ScanCtl* ctl, u32 dbg_at)
 {
 	if (0 == threadIdx.x) ctl->used_now = t.root->used;  // blocks are only created by k_ensure, long done
+	if (threadIdx.x < 64u) {
+		u32 ng, nu;
+		tableCounts(t, threadIdx.x, &ng, &nu);
+		if (0 == threadIdx.x) {
+			ctl->used_g_now = ng;
+			ctl->used_u_now = nu;
+		}
+	}
 	if (ctl->err) return;
 	for (u32 level = first_level; level <= g.L; ++level) {
 		if (0 == threadIdx.x) ctl->dbg[dbg_at + level] = wall_clock64();
@@ -2091,17 +2101,8 @@ __global__ __launch_bounds__(256) void k_rehash_copy(Table src, Table dst, u32* 
 		if (0 == lk) continue;
 		if (src.flags(s) & F_DEAD) continue;
 		++mine;
-		u32 d = tableHome(dst, lk);
-		bool ok = false;
-		for (u32 probe = 0; probe <= dst.mask; ++probe) {
-			u64 prev = atomicCAS((unsigned long long*)&dst.key(d), 0ULL, (unsigned long long)lk);
-			if (prev == 0) {
-				ok = true;
-				break;
-			}
-			d = tableNext(dst, d);
-		}
-		if (!ok) {
+		const u32 d = tableInsertNew(dst, lk);
+		if (d == NONE) {
 			atomicOr(fail, 1u);
 			continue;
 		}
@@ -2120,6 +2121,16 @@ __global__ __launch_bounds__(256) void k_rehash_copy(Table src, Table dst, u32* 
 	}
 	for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
 	if (0 == (threadIdx.x & 63u) && mine) atomicAdd(copied, mine);
+}
+// fill of a table: [0] groups claimed, [1] blocks of the first region (one wave)
+__global__ void k_table_counts(Table t, u32* out)
+{
+	u32 g, u;
+	tableCounts(t, threadIdx.x, &g, &u);
+	if (0 == threadIdx.x) {
+		out[0] = g;
+		out[1] = u;
+	}
 }
 __global__ __launch_bounds__(256) void k_rehash_parents(Table dst)
 {

@@ -60,6 +60,7 @@ struct ScanCtl {
 	unsigned long long n_steps;
 	u32 n_oob;  // cells dropped because their key lies outside [0, 2^L) (the reference aliases them)
 	u32 used_now;  // MapRoot::used, mirrored here by k_propagate_tail so that the host reads ONE block per update
+	u32 used_g_now, used_u_now;  // ... and the table's fill as its two regions count it (table.h: groups claimed, blocks of the first region)
 	u32 dl_total;      // coarse-miss phase: blocks visited so far (all levels, appended level by level)
 	u32 dl_start[25];  // dl_start[l] .. dl_start[l-1] = range of the level-l blocks in the visit list
 	unsigned long long dbg[64];  // diagnostics (ufomap_map_debug): per-level clocks of the propagation tails

@@ -143,10 +143,10 @@ struct PendingEvent {
 };
 
 struct TableBufs {
-	DevBuf blk, rgb, tmax, luocc, lufl, lurgb;
+	DevBuf blk, rgb, tmax, luocc, lufl, lurgb, gdir, gcnt;
 	void release()
 	{
-		DevBuf* all[] = {&blk, &rgb, &tmax, &luocc, &lufl, &lurgb};
+		DevBuf* all[] = {&blk, &rgb, &tmax, &luocc, &lufl, &lurgb, &gdir, &gcnt};
 		for (DevBuf* b : all) b->release();
 	}
 };
@@ -157,17 +157,22 @@ inline u32 nextPow2(u64 v)
 	while (p < v) p <<= 1;
 	return (u32)std::min<u64>(p, 1ull << 31);
 }
-// Capacity of the node table for `need` blocks (those that are there + those the next update can create): load 0.57 when
-// they all exist -- a little under the 0.6 at which a table is exchanged for a larger one, so that a scan that adds a few
-// per cent does not re-hash gigabytes -- and at least 1.5 x the present capacity, so that a map that keeps growing is
-// re-hashed a logarithmic number of times. Any number (a multiple of 4096), not a power of two: that alone cost up to
-// 2 x (C3 at insert depth 0: 10.7 GB where 6.9 GB do).
-inline u32 tableCapFor(u64 need, u64 cap_now)
-{
-	u64 c = std::max<u64>((need * 7 + 3) / 4, cap_now + cap_now / 2);
-	c = (std::max<u64>(c, 1u << 16) + 4095) & ~4095ull;
-	return (u32)std::min<u64>(c, 1ull << 31);
-}
+// What an update can add to the node table, as its two regions count it (table.h): node blocks in all, tile groups (= new
+// level-3 blocks), blocks of the first region (levels >= 4). The host keeps the table large enough for the upper bound of
+// everything in flight: a walk that finds no free group or slot half-way cannot stand back (the volume path, which
+// creates against a reserve, can).
+struct Need {
+	u64 blocks = 0, groups = 0, upper = 0;
+	Need& operator+=(const Need& o)
+	{
+		blocks += o.blocks;
+		groups += o.groups;
+		upper += o.upper;
+		return *this;
+	}
+};
+inline Need operator+(Need a, const Need& b) { return a += b; }
+inline Need needMin(const Need& a, const Need& b) { return Need{std::min(a.blocks, b.blocks), std::min(a.groups, b.groups), std::min(a.upper, b.upper)}; }
 }  // namespace
 
 // What the map half of scan i needs while the scan half of scan i+1 already runs on the other stream:
@@ -222,7 +227,7 @@ struct HandOver {
 	ScanArgs args;
 	hipEvent_t done_ev = nullptr;  // end of the integration that uses this set
 	bool pending = false;          // that integration has been enqueued and not yet been joined
-	u64 bound = 0;                 // upper bound of the blocks it may add to the node table
+	Need bound;                    // upper bound of what it may add to the node table
 };
 
 struct ufomap_map {
@@ -234,10 +239,12 @@ struct ufomap_map {
 	hipStream_t cs = nullptr;       // stream the helpers currently launch on
 	hipEvent_t done_ev = nullptr, scan_ev = nullptr, prep_ev = nullptr;
 	hipStream_t xstream = nullptr;  // read-back of control blocks whose producers are known to be complete
+	hipStream_t gstream = nullptr;  // the all-gather of a batch step (host_multi_gpu.inl), created with the first such step
+	hipEvent_t pack_ev = nullptr;   // ... its exchange slot has been packed on the scan stream
 	bool prev_flagged = false;      // the integration joined last had flagged an error (finishPending)
 	int opt_early = 1;              // enqueue the map half before the previous integration has been joined (doInsert)
 	HandOver alt[kAlt];             // the other hand-over sets, in no particular order: integrations are told apart by `seq`
-	u64 bound = 0;                  // (of the current set, see HandOver::bound)
+	Need bound;                     // (of the current set, see HandOver::bound)
 	                  // the other set of hand-over buffers
 	int async_status = UFOMAP_OK;   // first error of an integration that was joined by a later call
 	MapGeom g{};
@@ -257,6 +264,7 @@ struct ufomap_map {
 	u32 phase_limit = (1u << 22) - (1u << 12);  // phaseGuard: tags are cleared and the numbering restarts here
 	u64 n_phase_resets = 0;
 	u64 used_est = 0;  // host-side view of MapRoot::used (refreshed at every control-block read)
+	u64 used_g = 0, used_u = 0;  // ... of the groups claimed and the blocks of the first region (table.h)
 	// per-scan buffers
 	DevBuf b_ctl, b_pt_end, b_pt_flag, b_pt_slot, b_ray_end, b_hit_code, b_hit_pt, b_hh_keys;
 	DevBuf b_part0, b_part1, b_slabs, b_hb_keys, b_hb_mask, b_hb_time;  // (b_slabs: per hand-over set on the fast path, HandOver)
@@ -269,6 +277,7 @@ struct ufomap_map {
 	DevBuf b_ts;                  // developer aid (option "tstamps"): device clock at the pipeline's hand-overs (fast_kernels.h: Pipe::ts)
 	DevBuf b_pipe;                // fast path: which walk applies which scan (fast_kernels.h: Pipe), device side
 	uint64_t n_fseq = 0;          // fast-path scans enqueued so far
+	uint64_t last_slot_fseq = 0;  // ... the newest of them whose slot on the map stream has been enqueued (enqueueSlot)
 	u32 geo_id = 0;               // scans with the same geo id may share a walk: same ray grid, no other update of the map between them
 	bool chain_ok = false;        // the update enqueued last on the map stream was a fast-path slot (with ray grid chain_geo)
 	FastGeo chain_geo{};
@@ -356,7 +365,7 @@ struct ufomap_map {
 	u32 hh_mask = 0;  // hit-hash mask of the current scan
 	const uint8_t* last_rgb = nullptr;
 	// diagnostic overrides (ufomap_map_set_option); -1 / 0 = automatic
-	u64 scan_new_bound = 0;  // upper bound of the blocks both phases of the current scan can create
+	Need scan_new_bound;  // upper bound of what both phases of the current scan can create
 	int opt_dda_mode = -1;
 	int opt_dda_seg = 1;  // 0 = force the lane-per-ray kernel
 	int opt_dda_block = 0, opt_dda_lanes = 0;  // 0 = automatic
@@ -446,12 +455,20 @@ inline dim3 gridFor(u64 n, u32 block = 256, u32 maxBlocks = 4096)
 	return dim3((u32)b);
 }
 
-int allocTable(ufomap_map* m, u32 cap, Table* out, TableBufs* tb)
+// the first region for `capU` blocks of levels >= 4, `nG` tile groups (table.h); everything zeroed on the map stream
+int allocTable(ufomap_map* m, u32 nG, u32 capU, Table* out, TableBufs* tb)
 {
+	capU = std::max<u32>(capU, 1024u);
+	nG = std::max<u32>(nG, 64u);
+	const u64 cap64 = (u64)capU + (u64)UFO_GROUP * nG;
+	if (cap64 > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
+	const u32 cap = (u32)cap64;
 	HIP_TRY(tb->blk.reserve((size_t)cap * sizeof(Block)));
 	HIP_TRY(tb->tmax.reserve((size_t)cap * 8));
 	HIP_TRY(tb->luocc.reserve((size_t)cap * 4));
 	HIP_TRY(tb->lufl.reserve((size_t)cap * 4));
+	HIP_TRY(tb->gdir.reserve((size_t)nG * 8));
+	HIP_TRY(tb->gcnt.reserve(128 * 4));
 	if (m->g.color) {
 		HIP_TRY(tb->rgb.reserve((size_t)cap * 32));
 		HIP_TRY(tb->lurgb.reserve((size_t)cap * 4));
@@ -460,6 +477,8 @@ int allocTable(ufomap_map* m, u32 cap, Table* out, TableBufs* tb)
 	HIP_TRY(hipMemsetAsync(tb->blk.p, 0, (size_t)cap * sizeof(Block), m->stream));
 	HIP_TRY(hipMemsetAsync(tb->tmax.p, 0, (size_t)cap * 8, m->stream));
 	HIP_TRY(hipMemsetAsync(tb->lufl.p, 0, (size_t)cap * 4, m->stream));
+	HIP_TRY(hipMemsetAsync(tb->gdir.p, 0, (size_t)nG * 8, m->stream));
+	HIP_TRY(hipMemsetAsync(tb->gcnt.p, 0, 128 * 4, m->stream));
 	out->blk = tb->blk.as<Block>();
 	out->rgb = m->g.color ? tb->rgb.as<u32>() : nullptr;
 	out->tmax = tb->tmax.as<u64>();
@@ -468,36 +487,77 @@ int allocTable(ufomap_map* m, u32 cap, Table* out, TableBufs* tb)
 	out->lu_rgb = m->g.color ? tb->lurgb.as<u32>() : nullptr;
 	out->root = m->b_root.as<MapRoot>();
 	out->mask = cap - 1;
+	out->capU = capU;
+	out->nG = nG;
+	out->gdir = tb->gdir.as<u64>();
+	out->gcnt = tb->gcnt.as<u32>();
+	out->L = m->g.L;
 	return UFOMAP_OK;
 }
 
-int growTable(ufomap_map* m, u32 new_cap)
+int growTable(ufomap_map* m, u32 new_nG, u32 new_capU)
 {
 	Table nt{};
 	TableBufs nb;
 	g_n_rehash.fetch_add(1, std::memory_order_relaxed);
-	int rc = allocTable(m, new_cap, &nt, &nb);
+	int rc = allocTable(m, new_nG, new_capU, &nt, &nb);
 	if (rc) return rc;
-	u32* d_fail = m->b_ctl.as<u32>() + (sizeof(ScanCtl) + 3) / 4;  // two spare words after the control block: failures, blocks copied
-	HIP_TRY(hipMemsetAsync(d_fail, 0, 8, m->cs));
+	if (m->cs != m->stream) HIP_TRY(hipStreamSynchronize(m->stream));  // (the new arrays are zeroed on the map stream)
+	u32* d_fail = m->b_ctl.as<u32>() + (sizeof(ScanCtl) + 3) / 4;  // four spare words after the control block: failures, blocks copied, groups, first-region blocks
+	HIP_TRY(hipMemsetAsync(d_fail, 0, 16, m->cs));
 	{
 		ProfScope ps(m, "k_rehash_copy");
 		hipLaunchKernelGGL(k_rehash_copy, gridFor((u64)m->t.mask + 1), dim3(256), 0, m->cs, m->t, nt, d_fail, d_fail + 1);
 	}
 	{
 		ProfScope ps(m, "k_rehash_parents");
-		hipLaunchKernelGGL(k_rehash_parents, gridFor((u64)new_cap), dim3(256), 0, m->cs, nt);
+		hipLaunchKernelGGL(k_rehash_parents, gridFor((u64)nt.mask + 1), dim3(256), 0, m->cs, nt);
 	}
+	hipLaunchKernelGGL(k_table_counts, dim3(1), dim3(64), 0, m->cs, nt, d_fail + 2);
 	HIP_TRY(hipStreamSynchronize(m->cs));
-	u32 res[2] = {0, 0};
-	HIP_TRY(hipMemcpy(res, d_fail, 8, hipMemcpyDeviceToHost));
-	if (res[0])  // (cannot happen at load <= 0.5; the old table stays, `nb` is released on return)
+	u32 res[4] = {0, 0, 0, 0};
+	HIP_TRY(hipMemcpy(res, d_fail, 16, hipMemcpyDeviceToHost));
+	if (res[0])  // (cannot happen: the new table holds what the old one does and more; the old table stays, `nb` is released on return)
 		return fail(UFOMAP_ERR_CAPACITY, "re-hash into the larger node table failed; map unchanged");
 	// collapsed blocks were left behind: the fill count is what was copied
 	HIP_TRY(hipMemcpy(&m->b_root.as<MapRoot>()->used, &res[1], 4, hipMemcpyHostToDevice));
 	m->used_est = res[1];
+	m->used_g = res[2];
+	m->used_u = res[3];
 	m->tb = std::move(nb);  // (releases the old arrays)
 	m->t = nt;
+	return UFOMAP_OK;
+}
+
+// Does the table take what is in flight plus `need`? Groups up to 85 % of the directory, the first region up to load 0.6.
+bool tableTakes(const ufomap_map* m, const Need& need)
+{
+	return (m->used_g + need.groups) * 20 <= (u64)m->t.nG * 17 && (m->used_u + need.upper) * 5 <= (u64)m->t.capU * 3;
+}
+// ... a table that does (each region that is short: at least 1.5 x what it has, so that a map that keeps growing is
+// re-hashed a logarithmic number of times; 80 % / 57 % full with everything `need` names). Joins nothing: the caller has.
+int growFor(ufomap_map* m, const Need& need)
+{
+	u64 nG = m->t.nG, capU = m->t.capU;
+	if ((m->used_g + need.groups) * 20 > nG * 17) nG = std::max<u64>(nG + nG / 2, (m->used_g + need.groups) * 5 / 4 + 64);
+	if ((m->used_u + need.upper) * 5 > capU * 3) capU = std::max<u64>(capU + capU / 2, (m->used_u + need.upper) * 7 / 4 + 1024);
+	nG = (nG + 63) & ~63ull;
+	capU = (capU + 4095) & ~4095ull;
+	if (capU + UFO_GROUP * nG > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
+	return growTable(m, (u32)nG, (u32)capU);
+}
+// the table's fill from the device (after updates that have no propagation tail to report it: volumes, streams read)
+int refreshFill(ufomap_map* m)
+{
+	u32* d_cnt = m->b_ctl.as<u32>() + (sizeof(ScanCtl) + 3) / 4;
+	hipLaunchKernelGGL(k_table_counts, dim3(1), dim3(64), 0, m->stream, m->t, d_cnt + 2);
+	u32 res[2] = {0, 0};
+	HIP_TRY(hipMemcpyAsync(res, d_cnt + 2, 8, hipMemcpyDeviceToHost, m->stream));
+	HIP_TRY(hipMemcpyAsync(m->h_root, m->b_root.p, sizeof(MapRoot), hipMemcpyDeviceToHost, m->stream));
+	HIP_TRY(hipStreamSynchronize(m->stream));
+	m->used_est = m->h_root->used;
+	m->used_g = res[0];
+	m->used_u = res[1];
 	return UFOMAP_OK;
 }
 
@@ -512,6 +572,7 @@ int resetRoot(ufomap_map* m)
 	HIP_TRY(hipMemcpyAsync(m->b_root.p, m->h_root, offsetof(MapRoot, n_changes), hipMemcpyHostToDevice, m->stream));
 	HIP_TRY(hipStreamSynchronize(m->stream));
 	m->used_est = 0;
+	m->used_g = m->used_u = 0;
 	return UFOMAP_OK;
 }
 
@@ -537,20 +598,27 @@ void setSensorModel(ufomap_map* m, double occupied_thres, double free_thres, dou
 	applyModel(m);
 }
 
-// upper bound on the node blocks a list of n entries at `level` inside a grid of nb[] blocks can
-// need: per level, no more distinct ancestors than entries, nor than fit in the bounding box.
-u64 blockBound(const ufomap_map* m, u64 n, const i32 nb[3], u32 level)
+// upper bound on what a list of n entries at `level` inside a grid of nb[] blocks can add to the node table: per level, no
+// more distinct ancestors than entries, nor than fit in the bounding box. Groups: the level-3 blocks among them.
+Need needBound(const ufomap_map* m, u64 n, const i32 nb[3], u32 level)
 {
-	u64 total = 0;
+	Need r;
 	for (u32 l = level; l <= m->g.L; ++l) {
 		u32 sh = l - level;
 		long double vol = 1;
 		for (int a = 0; a < 3; ++a) vol *= (long double)(((u64)nb[a] >> std::min(sh, 62u)) + 2);
 		u64 lim = vol > 1e18L ? (u64)1e18 : (u64)vol;
-		total += std::min<u64>(n, lim);
+		const u64 c = std::min<u64>(n, lim);
+		r.blocks += c;
+		if (m->g.L < 4 || l >= 4) r.upper += c;
+		else if (3 == l) r.groups += c;
 	}
-	return total + 8;
+	r.blocks += 8;
+	r.upper += 8;
+	if (level <= 3 && m->g.L >= 4) r.groups += 1;
+	return r;
 }
+u64 blockBound(const ufomap_map* m, u64 n, const i32 nb[3], u32 level) { return needBound(m, n, nb, level).blocks; }
 
 // exchange the current hand-over set (members of the map object) with another one
 void swapWith(ufomap_map* m, HandOver& o)
@@ -710,6 +778,10 @@ int joinEnqueued(ufomap_map* m)
 	for (;;) {
 		const int k = oldestPendingAlt(m);
 		if (k < 0 || m->alt[k].deferred) break;
+		// (a scan that goes with the slot of a newer scan -- no slot of its own -- while that slot is still being enqueued: this very
+		// function is called from there when the table has to grow. Nothing of it is on the map stream yet: it waits for company
+		// like a deferred one. Taking its unwritten result block for a finished update released its set under the walk to come.)
+		if (m->alt[k].fast && m->alt[k].done_by_flag && !m->alt[k].has_slot && !m->alt[k].batch_world && m->alt[k].fseq > m->last_slot_fseq) break;
 		const int r = finishSet(m, k);
 		if (!rc) rc = r;
 	}
@@ -764,7 +836,7 @@ int readCtl(ufomap_map* m)
 	HIP_TRY(hipMemcpyAsync(m->h_ctl, m->b_ctl.p, sizeof(ScanCtl), hipMemcpyDeviceToHost, m->cs));
 	HIP_TRY(hipMemcpyAsync(m->h_root, m->b_root.p, sizeof(MapRoot), hipMemcpyDeviceToHost, m->cs));
 	HIP_TRY(hipStreamSynchronize(m->cs));
-	m->used_est = m->h_root->used;
+	m->used_est = m->h_root->used;  // (the regions' counts are not needed where this is called: counting passes before a growth decision)
 	return UFOMAP_OK;
 }
 
@@ -776,11 +848,19 @@ int readCtlDone(ufomap_map* m)
 	HIP_TRY(hipStreamSynchronize(m->xstream));
 	if (m->h_ctl->used_now) {
 		m->used_est = m->h_ctl->used_now;  // MapRoot::used as the propagation tail saw it (after all creations of the update)
+		m->used_g = m->h_ctl->used_g_now;
+		m->used_u = m->h_ctl->used_u_now;
 	} else {
-		// an update without a propagation tail (nothing to apply, or it stood back): read the root
+		// an update without a propagation tail (nothing to apply, or it stood back): read the root and the regions' counters
+		u32* d_cnt = m->b_ctl.as<u32>() + (sizeof(ScanCtl) + 3) / 4;
+		hipLaunchKernelGGL(k_table_counts, dim3(1), dim3(64), 0, m->xstream, m->t, d_cnt + 2);
+		u32 res[2] = {0, 0};
+		HIP_TRY(hipMemcpyAsync(res, d_cnt + 2, 8, hipMemcpyDeviceToHost, m->xstream));
 		HIP_TRY(hipMemcpyAsync(m->h_root, m->b_root.p, sizeof(MapRoot), hipMemcpyDeviceToHost, m->xstream));
 		HIP_TRY(hipStreamSynchronize(m->xstream));
 		m->used_est = m->h_root->used;
+		m->used_g = res[0];
+		m->used_u = res[1];
 	}
 	return UFOMAP_OK;
 }
@@ -942,7 +1022,7 @@ int applyEntries(ufomap_map* m, const Entry* d_entries, u32 cap, u32 which, u32 
 	} else {
 		// coarse misses: level-synchronous walk of the subtrees below the masked children (map_kernels.h S3c)
 		// every live block can be visited: blocks known at the last control-block read + everything this scan may add
-		const u64 dcap64 = std::min<u64>((u64)m->t.mask + 1, m->used_est + m->scan_new_bound + 8);
+		const u64 dcap64 = std::min<u64>((u64)m->t.mask + 1, m->used_est + m->scan_new_bound.blocks + 8);
 		const u32 dcap = (u32)std::min<u64>(dcap64, 0xFFFFFFF0ull);
 		HIP_TRY(m->b_crec.reserve((size_t)cap * sizeof(CoarseRec)));
 		HIP_TRY(m->b_dlist.reserve((size_t)dcap * 4));
@@ -982,7 +1062,7 @@ int applyEntries(ufomap_map* m, const Entry* d_entries, u32 cap, u32 which, u32 
 // extra_used / no_grow: the caller has an update in flight that may add up to extra_used blocks and cannot wait for
 // it here; if the table might not take both, 1 is returned (nothing done) and the caller joins first.
 int sizeTable(ufomap_map* m, const Entry* ent_h, u64 capH, const i32 nbH[3], const Entry* ent_m, u64 capM, const i32 nbM[3],
-              unsigned depth, bool merged = false, u64 extra_used = 0, bool no_grow = false, u32 headroom_scans = 0)
+              unsigned depth, bool merged = false, Need extra_used = Need{}, bool no_grow = false, u32 headroom_scans = 0)
 {
 	// merged list (depth 0) whose hit box lies inside the ray box: all entries are blocks of the miss grid
 	bool h_in_m = merged && capH && capM && m->haveH && m->haveM && nbH == m->gridH.nb && nbM == m->gridM.nb;
@@ -990,22 +1070,23 @@ int sizeTable(ufomap_map* m, const Entry* ent_h, u64 capH, const i32 nbH[3], con
 		h_in_m = m->gridH.base[a] >= m->gridM.base[a] &&
 		         (long long)m->gridH.base[a] + 2ll * m->gridH.nb[a] <= (long long)m->gridM.base[a] + 2ll * m->gridM.nb[a];
 	auto bound = [&](u64 nh, u64 nm) {
-		if (h_in_m) return blockBound(m, nh + nm, nbM, 1);
-		u64 b = 0;
-		if (nh) b += blockBound(m, nh, nbH, 1);
-		if (nm) b += blockBound(m, nm, nbM, (u32)depth + 1);
+		if (h_in_m) return needBound(m, nh + nm, nbM, 1);
+		Need b;
+		if (nh) b += needBound(m, nh, nbH, 1);
+		if (nm) b += needBound(m, nm, nbM, (u32)depth + 1);
 		return b;
 	};
 	m->scan_new_bound = bound(capH, capM);
-	u64 cap = (u64)m->t.mask + 1;
 	// headroom_scans: a stream of pipelined scans keeps up to two more updates of this size in flight; size the
 	// table for that now, so that the following updates can be enqueued without joining their predecessors
-	extra_used += (u64)headroom_scans * m->scan_new_bound;
-	if ((m->used_est + extra_used + m->scan_new_bound) * 5 <= cap * 3) return UFOMAP_OK;  // load factor stays <= 0.6
+	for (u32 k = 0; k < headroom_scans; ++k) extra_used += m->scan_new_bound;
+	if (tableTakes(m, extra_used + m->scan_new_bound)) return UFOMAP_OK;
 	if (no_grow) return 1;
 	// small tables simply grow to the pessimistic size once (cheap, and the fast check passes from then on);
-	// the exact count is worth a kernel and a host round trip only when growing would cost gigabytes
-	const bool cheap = (m->used_est + m->scan_new_bound) * 2 <= (1ull << 22);
+	// the exact count is worth a kernel and a host round trip only when growing would cost hundreds of megabytes
+	// (slots, not blocks: a tile group is 73 of them, whatever it holds)
+	auto slotsFor = [&](const Need& nd) { return (m->used_g + nd.groups) * (u64)UFO_GROUP + m->used_u + nd.upper; };
+	const bool cheap = slotsFor(extra_used + m->scan_new_bound) * 2 <= (1ull << 22);
 	if (!cheap && (ent_h || ent_m)) {
 		ScanCtl* ctl = m->b_ctl.as<ScanCtl>();
 		u32* d_cnt = reinterpret_cast<u32*>(&ctl->dbg[60]);  // two spare words of the control block
@@ -1024,18 +1105,29 @@ int sizeTable(ufomap_map* m, const Entry* ent_h, u64 capH, const i32 nbH[3], con
 		if (rc) return rc;
 		u32 cnt[2];
 		memcpy(cnt, &m->h_ctl->dbg[60], 8);
+		bool counted = false;
 		if (merged) {
-			if (m->h_ctl->n_entries[0] <= capH + capM)
-				m->scan_new_bound = h_in_m ? blockBound(m, cnt[0], nbM, 1) : bound(capH ? cnt[0] : 0, capM ? cnt[0] : 0);
-		} else if (m->h_ctl->n_entries[0] <= capH && m->h_ctl->n_entries[1] <= capM) m->scan_new_bound = bound(cnt[0], cnt[1]);
-		if ((m->used_est + extra_used + m->scan_new_bound) * 5 <= cap * 3) return UFOMAP_OK;
-		// Still growing, and by gigabytes: count the distinct missing parents and grandparents exactly (k_mark_parents)
-		// instead of bounding them by min(entries, cells of the box) -- a merged list inside one box only
-		if (merged && h_in_m && m->h_ctl->n_entries[0] <= capH + capM && cnt[0] > (1u << 20)) {
+			if (m->h_ctl->n_entries[0] <= capH + capM) {
+				m->scan_new_bound = h_in_m ? needBound(m, cnt[0], nbM, 1) : bound(capH ? cnt[0] : 0, capM ? cnt[0] : 0);
+				counted = true;
+			}
+		} else if (m->h_ctl->n_entries[0] <= capH && m->h_ctl->n_entries[1] <= capM) {
+			m->scan_new_bound = bound(cnt[0], cnt[1]);
+			counted = true;
+		}
+		if (tableTakes(m, extra_used + m->scan_new_bound)) return UFOMAP_OK;
+		// Still growing, and by a lot: count the distinct missing parents and grandparents of the level-1 entries exactly
+		// (k_mark_parents) instead of bounding them by min(entries, cells of the box) -- the merged list inside one box, or
+		// the hit list of an update at insert depth > 0 (3e5 hit voxels of a 2 mm frame lie in 1e4 tiles, not in 3e5)
+		const bool one_box = merged && h_in_m;
+		const bool hit_list = !merged && capH && m->haveH && nbH == m->gridH.nb;
+		if (counted && (one_box || hit_list) && cnt[0] > (1u << 16)) {
+			const Grid& gb = one_box ? m->gridM : m->gridH;
+			const u64 n_list = one_box ? capH + capM : capH;
 			ParentBox pb;
 			u64 bits2 = 1, bits3 = 1;
 			for (int a = 0; a < 3; ++a) {
-				const long long b0 = (long long)(m->gridM.base[a] >> 1), b1 = b0 + m->gridM.nb[a] - 1;  // level-1 block coordinates of the box
+				const long long b0 = (long long)(gb.base[a] >> 1), b1 = b0 + gb.nb[a] - 1;  // level-1 block coordinates of the box
 				pb.lo2[a] = (i32)(b0 >> 1);
 				pb.n2[a] = (u32)((b1 >> 1) - (b0 >> 1) + 1);
 				pb.lo3[a] = (i32)(b0 >> 2);
@@ -1051,24 +1143,29 @@ int sizeTable(ufomap_map* m, const Entry* ent_h, u64 capH, const i32 nbH[3], con
 				u32* d2 = bm.as<u32>();
 				u32* d3 = d2 + w2;
 				unsigned long long* d_out = reinterpret_cast<unsigned long long*>(d3 + w3 + ((w2 + w3) & 1));
-				hipLaunchKernelGGL(k_mark_parents, gridFor(capH + capM), dim3(256), 0, m->cs, m->t, m->g, ent_h, &ctl->n_entries[0], (u32)(capH + capM), pb, d2,
-				                   d3);
+				hipLaunchKernelGGL(k_mark_parents, gridFor(n_list), dim3(256), 0, m->cs, m->t, m->g, ent_h, &ctl->n_entries[0], (u32)n_list, pb, d2, d3);
 				hipLaunchKernelGGL(k_popcount, gridFor(w2, 256, 4096), dim3(256), 0, m->cs, d2, w2, d_out);
 				hipLaunchKernelGGL(k_popcount, gridFor(w3, 256, 4096), dim3(256), 0, m->cs, d3, w3, d_out + 1);
 				unsigned long long h_out[2] = {0, 0};
 				HIP_TRY(hipMemcpyAsync(h_out, d_out, 16, hipMemcpyDeviceToHost, m->cs));
 				HIP_TRY(hipStreamSynchronize(m->cs));
 				// level 1: the missing entries; level 2, 3: counted; above: no more than level 3 has, nor than fit in the box
-				u64 b = (u64)cnt[0] + h_out[0] + h_out[1] + 8;
-				for (u32 l = 4; l <= m->g.L; ++l) b += std::min<u64>(h_out[1], levelBound(nbM, l - 1));
-				m->scan_new_bound = std::min(m->scan_new_bound, b);
-				if ((m->used_est + extra_used + m->scan_new_bound) * 5 <= cap * 3) return UFOMAP_OK;
+				Need b;
+				b.blocks = (u64)cnt[0] + h_out[0] + h_out[1] + 8;
+				b.groups = h_out[1] + 1;
+				b.upper = 8;
+				for (u32 l = 4; l <= m->g.L; ++l) {
+					const u64 c = std::min<u64>(h_out[1], levelBound(gb.nb, l - 1));
+					b.blocks += c;
+					b.upper += c;
+				}
+				if (hit_list && capM) b += needBound(m, cnt[1], nbM, (u32)depth + 1);  // (the coarse misses' own entries)
+				m->scan_new_bound = needMin(m->scan_new_bound, b);
+				if (tableTakes(m, extra_used + m->scan_new_bound)) return UFOMAP_OK;
 			}
 		}
 	}
-	const u64 want = tableCapFor(m->used_est + extra_used + m->scan_new_bound, (u64)m->t.mask + 1);
-	if ((m->used_est + extra_used + m->scan_new_bound) * 7 / 4 > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
-	return growTable(m, (u32)want);
+	return growFor(m, extra_used + m->scan_new_bound);
 }
 
 // Update lists from the two grids of the current scan into b_entries: hit entries first, then miss entries.
@@ -1141,7 +1238,7 @@ int extractLists(ufomap_map* m, u64 capH, u64 capM, bool zero_counts, bool merge
 // prev != nullptr: control block of the integration enqueued just before, not yet checked by the host (doInsert);
 // returns 1 (nothing enqueued) if the table might have to grow while that one is in flight.
 int mapPhase(ufomap_map* m, unsigned depth, const uint8_t* d_rgb, u64 capH, u64 capM, bool merged, const ScanCtl* prev = nullptr,
-             u64 extra_used = 0, u32 headroom_scans = 0)
+             Need extra_used = Need{}, u32 headroom_scans = 0)
 {
 	const float miss = (float)(m->g.miss_log / double((2.0 * depth) + 1));  // OMB:311
 	m->hit_grid = false;
@@ -1171,6 +1268,8 @@ int finishPending(ufomap_map* m)
 		// k_ftail stored the finished control block in pinned memory itself and left the device copy in its start state
 		memcpy(m->h_ctl, m->h_res, sizeof(ScanCtl));
 		m->used_est = m->h_ctl->used_now;
+		m->used_g = m->h_ctl->used_g_now;
+		m->used_u = m->h_ctl->used_u_now;
 		m->ctl_clean = true;
 		if (m->h_ctl->dbg[45]) {  // (the last scan of a walk carries the number of scans the walk applied)
 			++m->n_walks;
@@ -1671,7 +1770,7 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 		// scan: its own slot's, or the slot of an earlier scan that found this one's scan half already complete.
 		m->pending = true;
 		m->deferred = true;
-		m->bound = 0;
+		m->bound = Need{};
 		m->last_rgb = nullptr;
 		const auto t_map = std::chrono::steady_clock::now();
 		// No slot of its own for a scan while two slots are still waiting on the map stream: the second of them takes every
@@ -1796,11 +1895,11 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 	}
 	if (!rc && n) rc = extractPhase(m, n_hits, n_rays, &capH, &capM, merged);
 	lap(0, t_begin);
-	auto mapHalf = [&](const ScanCtl* prev, u64 extra_used, u32 headroom) { return mapPhase(m, depth, d_rgb, capH, capM, merged, prev, extra_used, headroom); };
+	auto mapHalf = [&](const ScanCtl* prev, Need extra_used, u32 headroom) { return mapPhase(m, depth, d_rgb, capH, capM, merged, prev, extra_used, headroom); };
 	if (!rc && n) rc = (hipEventRecord(m->scan_ev, m->sstream) == hipSuccess) ? UFOMAP_OK : fail(UFOMAP_ERR_DEVICE, "hipEventRecord");
 	// the update enqueued just before this one, if it has not been joined
 	int pk = -1;
-	u64 in_flight = 0;
+	Need in_flight;
 	for (int i = 0; i < kAlt; ++i) {
 		if (!m->alt[i].pending) continue;
 		in_flight += m->alt[i].bound;
@@ -1847,7 +1946,7 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 			HIP_TRY(hipStreamSynchronize(m->stream));
 			hipLaunchKernelGGL(k_ctl_clear, dim3(1), dim3(1), 0, m->stream, m->b_ctl.as<ScanCtl>(), (u32)ERR_PREV);
 			m->cs = m->stream;
-			rc = mapHalf(nullptr, 0, 0u);
+			rc = mapHalf(nullptr, Need{}, 0u);
 			if (rc) return rc;
 			m->done_by_flag = false;
 			HIP_TRY(hipEventRecord(m->done_ev, m->stream));
@@ -1868,7 +1967,7 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 	m->cs = m->stream;
 	HIP_TRY(hipStreamWaitEvent(m->stream, m->scan_ev, 0));
 	m->last_rgb = d_rgb;
-	rc = mapHalf(nullptr, 0, (async && merged && m->opt_early) ? 2u : 0u);
+	rc = mapHalf(nullptr, Need{}, (async && merged && m->opt_early) ? 2u : 0u);
 	if (rc) return rc;
 	HIP_TRY(hipGetLastError());
 	m->pending = true;
@@ -2032,7 +2131,7 @@ ufomap_map* ufomap_map_create(double resolution, unsigned depth_levels, int auto
 	m->cs = m->stream;
 	memset(m->h_ctl, 0, sizeof(ScanCtl));
 	*m->h_prep = 0ull;
-	if (hipMemset(m->b_root.p, 0, sizeof(MapRoot)) != hipSuccess || allocTable(m, 1u << 16, &m->t, &m->tb) || resetRoot(m)) {
+	if (hipMemset(m->b_root.p, 0, sizeof(MapRoot)) != hipSuccess || allocTable(m, 768u, 8192u, &m->t, &m->tb) || resetRoot(m)) {
 		ufomap_map_destroy(m);
 		return nullptr;
 	}
@@ -2109,6 +2208,8 @@ void ufomap_map_destroy(ufomap_map* m)
 	for (DevBuf& b : m->b_ser) b.release();
 	if (m->done_ev) (void)hipEventDestroy(m->done_ev);
 	if (m->xstream) (void)hipStreamDestroy(m->xstream);
+	if (m->gstream) (void)hipStreamSynchronize(m->gstream), (void)hipStreamDestroy(m->gstream);
+	if (m->pack_ev) (void)hipEventDestroy(m->pack_ev);
 	if (m->stream) (void)hipStreamDestroy(m->stream);
 	delete m;
 }
@@ -2124,6 +2225,8 @@ int ufomap_map_clear(ufomap_map* m)
 	HIP_TRY(hipMemsetAsync(m->t.blk, 0, (size_t)cap * sizeof(Block), m->stream));
 	HIP_TRY(hipMemsetAsync(m->t.tmax, 0, (size_t)cap * 8, m->stream));
 	HIP_TRY(hipMemsetAsync(m->t.lu_fl, 0, (size_t)cap * 4, m->stream));
+	HIP_TRY(hipMemsetAsync(m->t.gdir, 0, (size_t)m->t.nG * 8, m->stream));
+	HIP_TRY(hipMemsetAsync(m->t.gcnt, 0, 128 * 4, m->stream));
 	return resetRoot(m);
 }
 
@@ -2133,10 +2236,15 @@ int ufomap_map_reserve(ufomap_map* m, size_t n_blocks)
 	HIP_TRY(hipSetDevice(m->device));
 	(void)ufomap_map_wait(m);
 	m->cs = m->stream;
-	if ((u64)n_blocks * 7 / 4 > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
-	if ((u64)n_blocks * 5 <= ((u64)m->t.mask + 1) * 3) return UFOMAP_OK;  // (they fit at load 0.6)
-	const u64 want = tableCapFor((u64)n_blocks, 0);
-	return growTable(m, (u32)want);
+	// n_blocks node blocks of a map as scans build it: ~40 live blocks per tile group, a seventh of the groups again above
+	Need need;
+	need.blocks = n_blocks;
+	need.groups = (u64)n_blocks / 40 + 64;
+	need.upper = (u64)n_blocks / 200 + 1024;
+	need.groups = need.groups > m->used_g ? need.groups - m->used_g : 0;
+	need.upper = need.upper > m->used_u ? need.upper - m->used_u : 0;
+	if (tableTakes(m, need)) return UFOMAP_OK;
+	return growFor(m, need);
 }
 
 int ufomap_map_set_scratch_limit(ufomap_map* m, size_t bytes)
@@ -2389,11 +2497,15 @@ int ufomap_map_set_value_volume_ch(ufomap_map* m, const double aabb_center[3], c
 		const u32 rcap = (u32)total;
 		// every visited node may get a new children block
 		{
-			const u64 cap = (u64)m->t.mask + 1;
-			if ((m->used_est + total) * 5 > cap * 3) {
-				const u64 want = tableCapFor(m->used_est + total, (u64)m->t.mask + 1);
-				if ((m->used_est + total) * 7 / 4 > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
-				rc = growTable(m, (u32)want);
+			// (a node of depth cd gets a children block of level cd: tile groups for the depth-3 nodes, the first region above)
+			Need need;
+			need.blocks = total;
+			for (u32 cd = L; cd > min_depth; --cd) {
+				if (m->g.L < 4 || cd >= 4) need.upper += level_cap[cd];
+				else if (3 == cd) need.groups += level_cap[cd];
+			}
+			if (!tableTakes(m, need)) {
+				rc = growFor(m, need);
 				if (rc) return rc;
 			}
 		}
@@ -2440,6 +2552,7 @@ int ufomap_map_clear_to(ufomap_map* m, double resolution, unsigned depth_levels)
 	g.res = resolution;
 	g.rf = 1.0 / resolution;
 	g.L = depth_levels;
+	m->t.L = depth_levels;  // (the table tells a key's level by the position of its sentinel bit: table.h)
 	g.M = (u32)std::pow(2, depth_levels - 1);
 	g.hs[0] = resolution / 2.0;
 	g.hs[1] = resolution;
@@ -2864,7 +2977,7 @@ int ufomap_map_stats(ufomap_map* m, uint64_t* n_inner, uint64_t* n_leaf, uint64_
 	if (n_leaf) *n_leaf = h.n_live ? h.n_leaf : 1;
 	if (bytes) {
 		u64 cap = (u64)m->t.mask + 1;
-		*bytes = cap * (sizeof(Block) + 8 + 8 + (m->g.color ? 32 + 4 : 0));  // record + tmax + last-update record (+ colours)
+		*bytes = cap * (sizeof(Block) + 8 + 8 + (m->g.color ? 32 + 4 : 0)) + (u64)m->t.nG * 8 + 512;  // record + tmax + last-update record (+ colours); tile directory
 	}
 	return UFOMAP_OK;
 }
@@ -3199,14 +3312,14 @@ int applyKeysBatchCore(ufomap_map* m, const void* const* d_lists, const ufomap_k
 		const i32* nbB;          // ... or, merged lists, this one (nullptr otherwise)
 	};
 	auto subNew = [&](const Sub& sb, u64 cnt) {
-		u64 b = blockBound(m, std::min<u64>(cnt, sb.n), sb.nbA, 1);
-		if (sb.nbB) b += blockBound(m, std::min<u64>(cnt, sb.n), sb.nbB, 1);
+		Need b = needBound(m, std::min<u64>(cnt, sb.n), sb.nbA, 1);
+		if (sb.nbB) b += needBound(m, std::min<u64>(cnt, sb.n), sb.nbB, 1);
 		return b;
 	};
 	std::vector<Sub> subs;
 	std::vector<u32> h_cnt;
 	u32 off = 0;
-	u64 new_bound = 0;
+	Need new_bound;
 	for (int j = 0; j < n_lists; ++j) {
 		const Entry* e = static_cast<const Entry*>(d_lists[j]);
 		const u32 nh = infos[j].n_hit, nm = infos[j].n_miss;
@@ -3242,29 +3355,24 @@ int applyKeysBatchCore(ufomap_map* m, const void* const* d_lists, const ufomap_k
 	const u32* d_cnt = m->b_crec.as<u32>();
 	// node table: every entry new is a true upper bound; on a warm map count the missing blocks before growing
 	m->scan_new_bound = new_bound;
-	{
-		const u64 cap = (u64)m->t.mask + 1;
-		if ((m->used_est + new_bound) * 5 > cap * 3) {
-			const bool cheap = (m->used_est + new_bound) * 2 <= (1ull << 22);
-			if (!cheap) {
-				u32* d_miss = reinterpret_cast<u32*>(&ctl->dbg[60]);
-				HIP_TRY(hipMemsetAsync(d_miss, 0, 8, m->cs));
-				for (size_t k = 0; k < subs.size(); ++k)
-					hipLaunchKernelGGL(k_count_missing, gridFor(subs[k].n), dim3(256), 0, m->cs, m->t, subs[k].ent, d_cnt + k, subs[k].n, d_miss);
-				int rc = readCtl(m);
-				if (rc) return rc;
-				u32 cnt = 0;
-				memcpy(&cnt, &m->h_ctl->dbg[60], 4);
-				u64 b = 0;
-				for (const Sub& sb : subs) b += subNew(sb, cnt);
-				m->scan_new_bound = new_bound = std::min(new_bound, b);
-			}
-			if ((m->used_est + new_bound) * 5 > cap * 3) {
-				const u64 want = tableCapFor(m->used_est + new_bound, (u64)m->t.mask + 1);
-				if ((m->used_est + new_bound) * 7 / 4 > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
-				int rc = growTable(m, (u32)want);
-				if (rc) return rc;
-			}
+	if (!tableTakes(m, new_bound)) {
+		const bool cheap = ((m->used_g + new_bound.groups) * (u64)UFO_GROUP + m->used_u + new_bound.upper) * 2 <= (1ull << 22);  // (slots: sizeTable)
+		if (!cheap) {
+			u32* d_miss = reinterpret_cast<u32*>(&ctl->dbg[60]);
+			HIP_TRY(hipMemsetAsync(d_miss, 0, 8, m->cs));
+			for (size_t k = 0; k < subs.size(); ++k)
+				hipLaunchKernelGGL(k_count_missing, gridFor(subs[k].n), dim3(256), 0, m->cs, m->t, subs[k].ent, d_cnt + k, subs[k].n, d_miss);
+			int rc = readCtl(m);
+			if (rc) return rc;
+			u32 cnt = 0;
+			memcpy(&cnt, &m->h_ctl->dbg[60], 4);
+			Need b;
+			for (const Sub& sb : subs) b += subNew(sb, cnt);
+			m->scan_new_bound = new_bound = needMin(new_bound, b);
+		}
+		if (!tableTakes(m, new_bound)) {
+			int rc = growFor(m, new_bound);
+			if (rc) return rc;
 		}
 	}
 	if (m->chg_enabled) {
@@ -3273,7 +3381,7 @@ int applyKeysBatchCore(ufomap_map* m, const void* const* d_lists, const ufomap_k
 	}
 	const ChangeLog cl = changeLog(m);
 	m->scan_id += 1;  // ONE phase for the whole batch
-	const u32 newcap = (u32)std::min<u64>(new_bound, 0xFFFFFFFFull);
+	const u32 newcap = (u32)std::min<u64>(new_bound.blocks, 0xFFFFFFFFull);
 	HIP_TRY(m->b_ent_slot.reserve((size_t)total * 4));
 	HIP_TRY(m->b_newlist.reserve((size_t)newcap * 4));
 	HIP_TRY(m->b_wl0.reserve((size_t)total * 4 + 32));
