@@ -31,6 +31,8 @@ res = {"workload": "C4: 131072-pt LiDAR scans, 16 cm, 20 m, discrete; step i int
 for N in (1, 2, 4, 8):
     m = OccupancyMap(0.16)
     m.set_option("async_apply", 1)
+    if os.environ.get("GATHER_STREAM"):
+        m.set_option("gather_stream", 1)  # (A/B: the all-gather on a stream of its own)
     comm = Comm(Comm.unique_id(), N, 0, 0)
     dts = []
     for rep in range(40):

@@ -147,3 +147,32 @@ def test_general_path_and_volume_path_agree_on_a_clipped_scan():
     assert g.debug()[48] + g.debug()[50] == 1  # (a segment clipped onto a min face is an ordinary ray; one clipped so that a key leaves the range turns back)
     assert same_dump(g.leaves(True), g2.leaves(True)) and same_dump(g.inner(), g2.inner())
     _assert_same_map(g, o, "clipped")
+
+
+@pytest.mark.parametrize("discrete", [True, False])
+def test_simple_ray_casting_on_the_steady_state_path(discrete):
+    """`simple_ray_casting` (freeSpaceSimple, occupancy_map_base.h:1303-1339; a switch of the reference's server) on the
+    steady-state path (k_fcast_simple): a wandering sensor, synchronous and pipelined calls, normal and fixed-step scans mixed in
+    one map -- against the reference scan by scan; the fast-path counter shows where the scans went."""
+    from ufomap_amd import PointCloud
+    g, o = _maps(kind=_kind(), resolution=0.16)
+    _, p = _maps(kind="port", resolution=0.16)
+    n_simple = 0
+    for i, (origin, xyz) in enumerate(_wander(16, spread=0.4)):
+        simple = i % 5 != 4
+        n_simple += simple
+        (g.insertPointCloudDiscrete if discrete else g.insertPointCloud)(origin, PointCloud(xyz), 12.0, 0, simple, 0, bool(i & 1))
+        o.insert(origin, xyz, max_range=12.0, discrete=discrete, simple_ray_casting=simple)
+        p.insert(origin, xyz, max_range=12.0, discrete=discrete, simple_ray_casting=simple)
+        if i in (1, 2, 7, 15):
+            g.insertPointCloudWait()
+            _assert_same_map(g, o, f"after scan {i}")
+            assert np.array_equal(g.last_misses(), p.last_misses()), f"scan {i}: ray cells differ"
+            assert g.last_counts()["steps"] == p.last_steps()
+    d = g.debug()
+    assert d[61] >= 12, f"the scans did not take the steady-state path: {d[61]} of 16"
+    g2, _ = _maps(kind="port", resolution=0.16)
+    g2.set_option("fast_simple", 0)
+    for i, (origin, xyz) in enumerate(_wander(16, spread=0.4)):
+        (g2.insertPointCloudDiscrete if discrete else g2.insertPointCloud)(origin, PointCloud(xyz), 12.0, 0, i % 5 != 4, 0, False)
+    assert same_dump(g.leaves(True), g2.leaves(True)) and same_dump(g.inner(), g2.inner()), "general path and steady-state path differ"

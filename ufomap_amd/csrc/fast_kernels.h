@@ -707,6 +707,97 @@ __global__ __launch_bounds__(1024) void k_fcast(MapGeom g, FastGeo fg, D3 sensor
 }
 
 // ------------------------------------------------------------------------------------------------
+// F2s: the ray kernel of the fast path for SIMPLE ray casting (freeSpaceSimple, occupancy_map_base.h:1303-1339; the server's
+// `simple_ray_casting` switch): n = int(distance / size) fixed steps of dir * size from the ray's end towards the sensor,
+// the cell of every point on the way -- three independent chains of repeated additions per ray, no DDA state, at most a
+// few hundred steps: one lane per ray, marks into the workgroup's LDS copy of the grid, the slab handed over like
+// k_fcast's. Same prologue (the points blockIdx.x, blockIdx.x + gridDim.x, ...; losers of their voxel dropped).
+// ------------------------------------------------------------------------------------------------
+template <bool DISCRETE>
+__global__ __launch_bounds__(1024) void k_fcast_simple(MapGeom g, FastGeo fg, D3 sensor, u32 n, const u32* __restrict__ first, u32* __restrict__ slabs,
+                                                      const ScanCtl* ctl_in, ScanCtl* ctl, unsigned long long* __restrict__ steps_part,
+                                                      const PointRec* __restrict__ recs, Pipe* solo, ScanDesc solo_desc)
+{
+	if (solo && 0 == (threadIdx.x | blockIdx.x)) {
+		solo->ring[0] = solo_desc;
+		solo->slot[0].first = 0;
+		solo->slot[0].B = 1;
+	}
+	extern __shared__ __attribute__((aligned(16))) u32 lds[];
+	__shared__ u32 sh_cnt[2];
+	const u32 err_in = ctl_in->err;
+	const Grid& gr = fg.gr;
+	const u32 lds_words = (u32)(gr.bytes >> 2);
+	{
+		uint4* l4 = reinterpret_cast<uint4*>(lds);
+		for (u32 j = threadIdx.x; j < (lds_words >> 2); j += blockDim.x) l4[j] = make_uint4(0, 0, 0, 0);
+	}
+	if (threadIdx.x < 2u) sh_cnt[threadIdx.x] = 0;
+	if (err_in) return;  // the scan does not fit the predicted grid (k_fhits): it will be repeated (uniform exit)
+	__syncthreads();
+	const u32 rowBits = fg.rowBits, planeBits = fg.planeBits;
+	const u32 lim = 1u << g.L;
+	const u32 lane = threadIdx.x & 63u;
+	unsigned long long steps = 0;
+	u32 err = 0, oob = 0, nray = 0, nhit = 0;
+	const u32 pts = (n > blockIdx.x) ? (n - blockIdx.x + gridDim.x - 1) / gridDim.x : 0u;
+	const double ns = nodeSize(g, 0u);
+	const u64 budget = 3ull * (1ull << g.L) + 8;
+	for (u32 p = threadIdx.x; p < pts; p += blockDim.x) {
+		const u32 i = blockIdx.x + p * gridDim.x;
+		const PointRec r = recs[i];
+		const bool odd = 0 != (r.flags & 4u);
+		bool cast = (r.flags & 1u) && !odd;
+		if ((r.flags & 2u) && !odd) {
+			const bool winner = first[r.cell] == i;
+			nhit += winner ? 1u : 0u;
+			if (DISCRETE && !winner) cast = false;  // OMB:358-360: dropped entirely, no ray
+		}
+		if (!cast) continue;
+		++nray;
+		// freeSpace (OMB:1229-1259) -> freeSpaceSimple: backwards from the ray's end (the fast path admits only segments inside the
+		// map cube: moveLineInside leaves them alone)
+		D3 cur = r.end;
+		D3 dir = sensor - cur;
+		const double dist = norm(dir);
+		dir = dir / dist;
+		const int num_steps = (int)(dist / ns);
+		if (num_steps < 0 || (u64)num_steps > budget) {
+			err |= ERR_RUNAWAY;
+			continue;
+		}
+		const D3 stepv = dir * ns;
+		for (int k = 0; k <= num_steps; ++k) {
+			err |= markBitChecked(gr, lds, rowBits, planeBits, (i32)toKey1(g, cur.x, 0), (i32)toKey1(g, cur.y, 0), (i32)toKey1(g, cur.z, 0), lim, &oob);
+			cur = cur + stepv;
+		}
+		steps += (unsigned long long)num_steps + 1ull;
+	}
+	for (int o = 32; o > 0; o >>= 1) {
+		nray += __shfl_xor(nray, o);
+		nhit += __shfl_xor(nhit, o);
+	}
+	if (0 == lane) {
+		if (nray) atomicAdd(&sh_cnt[0], nray);
+		if (nhit) atomicAdd(&sh_cnt[1], nhit);
+	}
+	__syncthreads();
+	if (0 == threadIdx.x) {
+		steps_part[gridDim.x + blockIdx.x] = sh_cnt[0];
+		steps_part[2u * gridDim.x + blockIdx.x] = sh_cnt[1];
+	}
+	{
+		const uint4* l4 = reinterpret_cast<const uint4*>(lds);
+		uint4* out4 = reinterpret_cast<uint4*>(slabs) + (size_t)blockIdx.x * (lds_words >> 2);
+		const u32 n4 = lds_words >> 2;
+		for (u32 j = threadIdx.x; j < n4; j += blockDim.x) out4[j] = l4[j];
+	}
+	blockStoreSteps(steps, steps_part);
+	if (oob) atomicAdd(&ctl->n_oob, oob);
+	if (err) atomicOr(&ctl->err, err);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Who applies which scan. The tree update of the fast path runs in SLOTS on the map stream -- k_claim, k_fmerge, k_tile,
 // k_ftail, enqueued by the call that brought scan f. When the slot gets its turn (the walk before it has finished, scan
 // f's scan half has finished), k_claim CLAIMS a run of scans for it: every scan up to f that no walk has taken yet (the

@@ -67,7 +67,8 @@ u64 makeUpperGeo(const FastGeo& fg, u32 L, UpperGeo* ug)
 
 bool fastEligible(const ufomap_map* m, const Grid& gr, unsigned depth, int simple, const uint8_t* d_rgb, size_t n, int discrete = 1)
 {
-	if (!m->opt_fast || 0 != depth || simple || m->g.L < 5 || 0 == n || n > (1u << 29)) return false;
+	if (!m->opt_fast || 0 != depth || m->g.L < 5 || 0 == n || n > (1u << 29)) return false;
+	if (simple && (!gridFitsLds(gr) || 0 == m->opt_fast_simple)) return false;  // (fixed-step casting: k_fcast_simple, grids in LDS only)
 	// (a coloured cloud into a plain map, a coloured cloud in continuous mode: the general path reports them)
 	if (d_rgb && (!m->g.color || !discrete)) return false;
 	if (m->g.color && 0 == m->opt_fast_color) return false;
@@ -100,7 +101,7 @@ int publishScanDone(ufomap_map* m)
 }
 
 int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, size_t n, double max_range, int discrete, bool batch_step = false,
-                  bool lazy_done = false, bool solo = false, bool uploaded = false, const uint8_t* d_rgb = nullptr)
+                  bool lazy_done = false, bool solo = false, bool uploaded = false, const uint8_t* d_rgb = nullptr, int simple = 0)
 {
 	HIP_TRY(hipSetDevice(m->device));
 	for (int k = 0; k < 8; ++k) m->counts[k] = 0;
@@ -344,7 +345,15 @@ int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, si
 					fprintf(stderr, "[ufomap] fast grid: %d x %d x %d blocks, %llu bytes; k_fcast: %u workgroups, %zu bytes of LDS each\n", fg.gr.nb[0], fg.gr.nb[1],
 					        fg.gr.nb[2], (unsigned long long)fg.gr.bytes, nwg, lds);
 			}
-			if (discrete)
+			if (simple) {
+				// fixed-step casting (freeSpaceSimple): one lane per ray, the grid alone in LDS
+				if (discrete)
+					hipLaunchKernelGGL(k_fcast_simple<true>, dim3(nwg), dim3(cthreads), (size_t)fg.gr.bytes, m->cs, m->g, fg, sensor, N, m->b_first.as<u32>(), m->b_slabs.as<u32>(), ctl, ctl,
+					                   sp, m->b_hit_code.as<PointRec>(), solo_pipe, d);
+				else
+					hipLaunchKernelGGL(k_fcast_simple<false>, dim3(nwg), dim3(cthreads), (size_t)fg.gr.bytes, m->cs, m->g, fg, sensor, N, m->b_first.as<u32>(), m->b_slabs.as<u32>(), ctl, ctl,
+					                   sp, m->b_hit_code.as<PointRec>(), solo_pipe, d);
+			} else if (discrete)
 				hipLaunchKernelGGL(k_fcast<true>, dim3(nwg), dim3(cthreads), lds, m->cs, m->g, fg, sensor, d_xyz, N, max_range, 0u, m->b_first.as<u32>(),
 				                   m->b_ray_end.as<D3>(), cap_wg, m->b_slabs.as<u32>(), (u32)std::max(8, m->opt_cast_k), ctl, ctl, sp, m->ing, m->b_hit_code.as<PointRec>(), batch, qcap, prio, solo_pipe, d);
 			else
@@ -614,7 +623,7 @@ void predictGrid(ufomap_map* m)
 	m->spec_valid = false;
 	const ScanArgs& a = m->args;
 	if (!m->opt_spec || !m->opt_merge || !m->opt_cast || !m->opt_bits || !m->opt_dda_seg || m->opt_dda_mode > 0) return;
-	if (0 != a.depth || a.simple || 0 == a.n || 0 == m->h_ctl->n_rays) return;
+	if (0 != a.depth || 0 == a.n || 0 == m->h_ctl->n_rays) return;  // (simple ray casting: the same box of ray cells, k_fcast_simple)
 	m->spec_valid = gridFromBox(had, prev, m->h_ctl->mb_min, m->h_ctl->mb_max, &m->spec_grid, 0 != m->opt_big && 0 != m->opt_fast && m->g.L >= 6);
 }
 

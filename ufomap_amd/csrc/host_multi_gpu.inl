@@ -408,18 +408,25 @@ int fastBatchStep(ufomap_map* m, ufomap_comm* c, const double origin[3], const d
 	hipLaunchKernelGGL(k_pack_slot, dim3(64), dim3(256), 0, m->sstream, reinterpret_cast<uint4*>(send), reinterpret_cast<const uint4*>(ctl),
 	                   m->b_tilebits.as<uint4>(), m->b_gridM.as<uint4>(), m->b_gridH.as<uint4>(), n4);
 	{
-		// The collective on a stream of its own: only the walk needs what it gathers, so the wire of step i overlaps the scan
-		// half of step i + 1 (which would queue behind it on the scan stream) as well as the walk of step i - 1.
-		if (!m->gstream) {
-			HIP_TRY(hipStreamCreateWithFlags(&m->gstream, hipStreamNonBlocking));
-			HIP_TRY(hipEventCreateWithFlags(&m->pack_ev, hipEventDisableTiming));
+		// Option gather_stream: the collective on a stream of its own -- only the walk needs what it gathers, so the wire of step i
+		// could overlap the scan half of step i + 1 (which queues behind it on the scan stream). Off by default: with one
+		// more stream in play the runtime's stream -> hardware-queue mapping puts pipeline streams on one queue, and on
+		// one GPU the step measured 0.12 ms against 0.08 (profiles/r04_ab_experiments.log); to be re-measured on a node whose
+		// wire is real.
+		hipStream_t gs = m->sstream;
+		if (m->opt_gather_stream) {
+			if (!m->gstream) {
+				HIP_TRY(hipStreamCreateWithFlags(&m->gstream, hipStreamNonBlocking));
+				HIP_TRY(hipEventCreateWithFlags(&m->pack_ev, hipEventDisableTiming));
+			}
+			HIP_TRY(hipEventRecord(m->pack_ev, m->sstream));
+			HIP_TRY(hipStreamWaitEvent(m->gstream, m->pack_ev, 0));
+			gs = m->gstream;
 		}
-		HIP_TRY(hipEventRecord(m->pack_ev, m->sstream));
-		HIP_TRY(hipStreamWaitEvent(m->gstream, m->pack_ev, 0));
-		const int e = r->AllGather(send, recv, slot, /* ncclChar */ 0, c->comm, m->gstream);
+		const int e = r->AllGather(send, recv, slot, /* ncclChar */ 0, c->comm, gs);
 		if (e) return rcclFail(e, "ncclAllGather");
+		HIP_TRY(hipEventRecord(m->xchg_ev, gs));
 	}
-	HIP_TRY(hipEventRecord(m->xchg_ev, m->gstream));
 	// ---- the walk: the scans of ranks 0 .. W-1 in this order (UFO_BATCH_MAX at a time) ----
 	m->cs = m->stream;
 	const Need bound = fastBound(m, fg.gr);

@@ -211,7 +211,7 @@ __device__ inline bool lastReached(const Table& t, const MapGeom& g, u32 s, u64 
 	u64 tv = tv_known ? *tv_known : t.tmax[s];
 	if ((tv >> 40) != UFO_TAG(phase)) return false;
 	int c = (int)(tv & 7);
-	const u32 cs = tableFind(t, (lk << 3) | (u64)c);  // the child's block: updated in this phase, so it is there (maybe just collapsed)
+	const u32 cs = tableFindChild(t, s, lk, (u32)c);  // the child's block: updated in this phase, so it is there (maybe just collapsed)
 	if (cs == NONE) return false;
 	u32 lf = t.lu_fl[cs];
 	if ((lf >> 9) != (phase & 0x3FFFFFu) || !(lf & 0x100u)) return false;
@@ -757,7 +757,7 @@ __global__ __launch_bounds__(256) void k_coarse_begin(Table t, MapGeom g, const 
 			r.old_occ[c] = v;
 			if (!((e.miss >> c) & 1)) continue;
 			if ((f >> (16 + c)) & 1u) {
-				u32 cs = tableFind(t, (e.lk << 3) | (u64)c);
+				u32 cs = tableFindChild(t, s, e.lk, (u32)c);
 				if (cs != NONE) {
 					r.inner_mask |= 1u << c;
 					visitPush(cs, dlist, dcap, ctl);
@@ -803,7 +803,7 @@ __global__ __launch_bounds__(256) void k_coarse_down(Table t, MapGeom g, u32 lev
 #pragma unroll
 		for (int c = 0; c < 8; ++c) {
 			if (level > 1 && ((f >> (16 + c)) & 1u)) {
-				u32 cs = tableFind(t, (lk << 3) | (u64)c);
+				u32 cs = tableFindChild(t, s, lk, (u32)c);
 				if (cs != NONE) visitPush(cs, dlist, dcap, ctl);
 				continue;
 			}
@@ -1250,7 +1250,7 @@ __global__ __launch_bounds__(256) void k_vol_kill(Table t, u32* __restrict__ kil
 		const u64 lk = t.key(s);
 		for (u32 i = 0; i < 8; ++i) {
 			if (!(f & (1u << (16 + i)))) continue;
-			const u32 cs = tableFind(t, (lk << 3) | (u64)i);
+			const u32 cs = tableFindChild(t, s, lk, i);
 			if (cs == NONE) continue;
 			const u32 kp = atomicAdd(&ctl->n_codes, 1u);
 			if (kp < kcap) kill[kp] = cs;
@@ -1736,7 +1736,7 @@ __device__ inline void serSizesLevel(const Table& t, const MapGeom& g, const Ser
 		if (serChildIn(sa, c, ch, chs)) {
 			add = D;
 			if (level >= 2 && level - 1 > sa.min_depth && ((f >> (16 + ch)) & 1u)) {
-				const u32 cs = tableFind(t, (lk << 3) | (u64)ch);
+				const u32 cs = tableFindChild(t, s, lk, ch);
 				if (cs != NONE && !(t.flags(cs) & F_DEAD)) add = size[cs];
 			}
 		}
@@ -1791,7 +1791,7 @@ __device__ inline void serWriteLevel(const Table& t, const MapGeom& g, const Ser
 		const u32 f = t.flags(s);
 		u32 cslot = NONE;
 		if (level >= 2 && level - 1 > sa.min_depth && ((f >> (16 + ch)) & 1u)) {
-			const u32 cs = tableFind(t, (lk << 3) | (u64)ch);
+			const u32 cs = tableFindChild(t, s, lk, ch);
 			if (cs != NONE && !(t.flags(cs) & F_DEAD)) cslot = cs;
 		}
 		u32 mask = (cslot != NONE) ? (1u << ch) : 0u;
@@ -1934,7 +1934,7 @@ __global__ __launch_bounds__(1024) void k_ser_tail_dev(Table t, MapGeom g, SerAr
 			unsigned long long add = 0;
 			u32 cslot = NONE;
 			if (l >= 2 && l - 1 > sa.min_depth && ((f >> (16 + ch)) & 1u)) {
-				const u32 cs = tableFind(t, (lk << 3) | (u64)ch);
+				const u32 cs = tableFindChild(t, s, lk, ch);
 				if (cs != NONE && !(t.flags(cs) & F_DEAD)) cslot = cs;
 			}
 			if (serChildIn(sa, c, ch, chs)) add = (cslot != NONE) ? size[cslot] : (unsigned long long)D;

@@ -61,6 +61,7 @@ struct ScanCtl {
 	u32 n_oob;  // cells dropped because their key lies outside [0, 2^L) (the reference aliases them)
 	u32 used_now;  // MapRoot::used, mirrored here by k_propagate_tail so that the host reads ONE block per update
 	u32 used_g_now, used_u_now;  // ... and the table's fill as its two regions count it (table.h: groups claimed, blocks of the first region)
+	u32 n_hit_tiles;             // depth-3 nodes that hold a hit voxel of the scan (k_select): what the hits can need in tile groups
 	u32 dl_total;      // coarse-miss phase: blocks visited so far (all levels, appended level by level)
 	u32 dl_start[25];  // dl_start[l] .. dl_start[l-1] = range of the level-l blocks in the visit list
 	unsigned long long dbg[64];  // diagnostics (ufomap_map_debug): per-level clocks of the propagation tails
@@ -563,6 +564,17 @@ __global__ __launch_bounds__(256) void k_select(MapGeom g, D3 sensor, u32 n, u32
 		}
 	}
 	const u32 hpos = blockAppend(&ctl->n_hits, winner);
+	{
+		// Distinct depth-3 nodes (tiles) among the hit voxels, counted through the same hash (keys tagged in bits 62-63; maps of
+		// up to 19 levels, whose codes stay below bit 57): the tile groups the hits can need in the node table -- 3e5 hit
+		// voxels of a 2 mm frame lie in 1e4 tiles, and the bound "every hit in a tile of its own" made that table 73 x too large
+		bool newtile = false;
+		if (winner && g.L <= 19u) {
+			const u64 code = morton3(toKey1(g, end.x, 0), toKey1(g, end.y, 0), toKey1(g, end.z, 0));
+			newtile = hitHashInsertUnique(hh, (code >> 9) | (3ULL << 62), &ctl->err);
+		}
+		(void)blockAppend(&ctl->n_hit_tiles, newtile);
+	}
 	if (winner) {
 		u32 pos = hpos;
 		u32 kx = toKey1(g, end.x, 0), ky = toKey1(g, end.y, 0), kz = toKey1(g, end.z, 0);

@@ -188,6 +188,21 @@ __device__ inline u32 tableFind(const Table& t, u64 lk)
 	return NONE;
 }
 
+// The block of child c of the node block in slot s (key lk): inside a tile group the child's slot follows from the parent's --
+// no hashing, one load (the level-synchronous walks down a subtree and the serialiser look children up by the million).
+__device__ inline u32 tableFindChild(const Table& t, u32 s, u64 lk, u32 c)
+{
+	const u64 ck = (lk << 3) | (u64)c;
+	if (s >= t.capU && t.L >= 4u) {
+		const u32 r = s - t.capU, g = r / UFO_GROUP, j = r - g * UFO_GROUP;
+		if (j >= 64u) {  // (a level-1 block has no child blocks)
+			const u32 cs = groupSlot(t, g, 72u == j ? 64u + c : (j - 64u) * 8u + c);
+			return __hip_atomic_load(&t.key(cs), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ck ? cs : NONE;
+		}
+	}
+	return tableFind(t, ck);
+}
+
 // a slot's key is there, or becomes the caller's: the find-or-create step both regions share
 __device__ __forceinline__ bool slotClaim(const Table& t, u32 s, u64 lk, u64* seen)
 {

@@ -265,6 +265,7 @@ struct ufomap_map {
 	u64 n_phase_resets = 0;
 	u64 used_est = 0;  // host-side view of MapRoot::used (refreshed at every control-block read)
 	u64 used_g = 0, used_u = 0;  // ... of the groups claimed and the blocks of the first region (table.h)
+	u64 hit_tiles = ~0ull;       // depth-3 nodes that hold a hit voxel of the current scan (k_select), if it has been read back
 	// per-scan buffers
 	DevBuf b_ctl, b_pt_end, b_pt_flag, b_pt_slot, b_ray_end, b_hit_code, b_hit_pt, b_hh_keys;
 	DevBuf b_part0, b_part1, b_slabs, b_hb_keys, b_hb_mask, b_hb_time;  // (b_slabs: per hand-over set on the fast path, HandOver)
@@ -317,6 +318,8 @@ struct ufomap_map {
 	// the volume path (vol_kernels.h, host_vol.inl): depth-0 scans whose ray grid is beyond the steady-state path's
 	int opt_vol = 1;        // 0 = never; 2 = also for the ray grids the steady-state path would take (tests)
 	int opt_vol_pregrow = 1;  // 0: no growth of the node table before a walk (tests: the walk runs out of its reserve)
+	int opt_gather_stream = 0;  // batch steps: the all-gather on a stream of its own (host_multi_gpu.inl)
+	int opt_fast_simple = 1; // simple (fixed-step) ray casting on the fast path (0: the general path)
 	int opt_fail_scan = 0;  // test aid: the scan half of the next batch steps 'fails' on this rank (host_multi_gpu.inl)
 	int opt_vol_mode = 0;   // measuring aid (k_vdda): bit 0 one copy of M for all XCDs, bit 1 rays in launch order
 	int opt_vol_keep = 1;   // k_tile leaves the merged ray cells of its tiles behind (ufomap_map_last_misses)
@@ -1072,7 +1075,16 @@ int sizeTable(ufomap_map* m, const Entry* ent_h, u64 capH, const i32 nbH[3], con
 	auto bound = [&](u64 nh, u64 nm) {
 		if (h_in_m) return needBound(m, nh + nm, nbM, 1);
 		Need b;
-		if (nh) b += needBound(m, nh, nbH, 1);
+		if (nh) {
+			Need hb = needBound(m, nh, nbH, 1);
+			if (m->hit_tiles != ~0ull && m->g.L >= 4) {
+				// (the hits' tiles have been counted, k_select: no more groups than that, no more blocks above than tiles per level)
+				Need tb = needBound(m, m->hit_tiles, nbH, 1);
+				hb.groups = std::min(hb.groups, m->hit_tiles + 1);
+				hb.upper = std::min(hb.upper, tb.upper);
+			}
+			b += hb;
+		}
 		if (nm) b += needBound(m, nm, nbM, (u32)depth + 1);
 		return b;
 	};
@@ -1355,7 +1367,7 @@ int scanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, const 
 	HIP_TRY(m->b_ray_end.reserve(n * sizeof(D3)));
 	HIP_TRY(m->b_hit_code.reserve(n * 8));
 	HIP_TRY(m->b_hit_pt.reserve(n * 4));
-	u32 hcap = nextPow2(std::max<u64>(1024, (u64)n * 2 + (depth ? (u64)n * 2 : 0)));  // load <= 0.5 (hits, + ray cells when depth > 0)
+	u32 hcap = nextPow2(std::max<u64>(1024, (u64)n * 3 + (depth ? (u64)n * 2 : 0)));  // load <= 0.5 (hits and their tiles, + ray cells when depth > 0)
 	// keys and point indices in ONE buffer (keys first): one memset per scan instead of two
 	HIP_TRY(m->b_hh_keys.reserve((size_t)hcap * 12));
 	HIP_TRY(hipMemsetAsync(m->b_hh_keys.p, 0xFF, (size_t)hcap * 12, m->cs));
@@ -1407,6 +1419,7 @@ int scanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, const 
 	}
 	HIP_TRY(hipGetLastError());
 	u32 n_rays, n_hits;
+	m->hit_tiles = ~0ull;
 	if (spec) {
 		// No read-back: the rest of the scan is enqueued on the grid predicted from the previous scan, with the
 		// point count as the bound of rays and hits; k_reduce_boxes has flagged the scan (ERR_SPEC) if its box
@@ -1424,6 +1437,7 @@ int scanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, const 
 	n_hits = m->h_ctl->n_hits;
 	m->counts[1] = n_rays;
 	m->counts[3] = n_hits;
+	m->hit_tiles = m->g.L <= 19 ? (u64)m->h_ctl->n_hit_tiles : ~0ull;
 
 	// ---- dedup grids -----------------------------------------------------------------------------
 	i32 hmn[3], hmx[3], mmn[3], mmx[3];
@@ -1732,13 +1746,13 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 	const bool merged = 0 == depth && 0 != m->opt_merge;
 	// Speculation: enqueue the whole scan on the grid predicted from the previous one instead of reading the
 	// bounding boxes back in the middle of the scan half (a host round trip of ~25 us on a 120 us chain).
-	bool spec = (0 == spec_mode ? (m->opt_spec && m->spec_valid) : false) && merged && !simple && 0 == early_stopping && n > 0 &&
+	bool spec = (0 == spec_mode ? (m->opt_spec && m->spec_valid) : false) && merged && 0 == early_stopping && n > 0 &&
 	            n <= (1u << 29) && !(d_rgb && !m->g.color);
 	// the fast path (fast_kernels.h): the whole scan on the predicted grid in five launches, the tree update tiled
 	// (PointCloud2 records with colours: the first kernel that loads the points -- k_fhits here -- leaves the colours in the
 	// set's own array, Ingest::rgb_out, which is what the tree update reads)
 	const bool fast = spec && fastEligible(m, m->spec_grid, depth, simple, d_rgb, n, discrete);
-	if (spec && !fast && !gridFitsLds(m->spec_grid)) spec = false;  // (grids beyond LDS are predicted for the fast path only)
+	if (spec && !fast && (simple || !gridFitsLds(m->spec_grid))) spec = false;  // (grids beyond LDS and fixed-step casting: predicted for the fast path only)
 	{
 		ScanArgs& a = m->args;
 		a.spec = spec;
@@ -1759,7 +1773,7 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 	if (fast) {
 		// a synchronous call with nothing in flight: the whole integration on the map stream (no hand-overs between streams)
 		const bool solo = !async && m->opt_solo && oldestPendingAlt(m) < 0 && !m->sd_pending;
-		rc = fastScanPhase(m, origin, d_xyz, n, max_range, discrete, false, async && !m->profiling && m->opt_early && m->opt_lazy_done, solo, swapped, d_rgb);
+		rc = fastScanPhase(m, origin, d_xyz, n, max_range, discrete, false, async && !m->profiling && m->opt_early && m->opt_lazy_done, solo, swapped, d_rgb, simple);
 		if (!rc && !m->gates && !solo) rc = (hipEventRecord(m->scan_ev, m->sstream) == hipSuccess) ? UFOMAP_OK : fail(UFOMAP_ERR_DEVICE, "hipEventRecord");
 		lap(0, t_begin);
 		if (rc) {
@@ -2148,6 +2162,8 @@ ufomap_map* ufomap_map_create(double resolution, unsigned depth_levels, int auto
 		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cast<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (160 << 10) - 512);
 		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cast<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (160 << 10) - 512);
 		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cast<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (160 << 10) - 512);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fcast_simple<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (160 << 10) - 512);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fcast_simple<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (160 << 10) - 512);
 
 	}
 	for (int a = 0; a < 3; ++a) {
@@ -3537,6 +3553,10 @@ int ufomap_map_set_option(ufomap_map* m, const char* key, long long value)
 		m->opt_vol = (int)std::max<long long>(0, std::min<long long>(2, value));
 	} else if (0 == strcmp(key, "vol_pregrow")) {
 		m->opt_vol_pregrow = value ? 1 : 0;
+	} else if (0 == strcmp(key, "gather_stream")) {
+		m->opt_gather_stream = value ? 1 : 0;
+	} else if (0 == strcmp(key, "fast_simple")) {
+		m->opt_fast_simple = value ? 1 : 0;
 	} else if (0 == strcmp(key, "fail_scan")) {
 		m->opt_fail_scan = value ? 1 : 0;
 	} else if (0 == strcmp(key, "vol_mode")) {
