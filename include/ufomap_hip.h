@@ -35,7 +35,8 @@ extern "C" {
 #define UFOMAP_OK 0
 #define UFOMAP_ERR_INVALID -1     /* bad argument (e.g. depth_levels outside [2,21]: octree.h:931-935) */
 #define UFOMAP_ERR_DEVICE -2      /* HIP runtime error / no device */
-#define UFOMAP_ERR_UNSUPPORTED -3 /* early_stopping > 0 (order-dependent, SURVEY.md 7 hard part 6) */
+#define UFOMAP_ERR_UNSUPPORTED -3 /* what the reference itself does not compile (a coloured cloud in continuous mode), early_stopping > 0 on
+                                    * a ray box whose first-ray array exceeds the scratch limit, insert depth > 0 in a multi-GPU step */
 #define UFOMAP_ERR_RUNAWAY -4     /* a clipped ray left the map cube (reference walks ~2^31 cells); map unchanged */
 #define UFOMAP_ERR_CAPACITY -5    /* scan grid or node table exceeded the configured memory limit */
 

@@ -411,13 +411,14 @@ struct ufo_oracle_map {
 	}
 
 	/* ---- ray casting: octree.h:1192-1233, occupancy_map_base.h:1261-1339 ---- */
-	void emitMiss(std::unordered_set<u64>& set, const u32 k[3], unsigned depth)
+	bool emitMiss(std::unordered_set<u64>& set, const u32 k[3], unsigned depth)
 	{
 		++last_steps;
 		if ((k[0] >> L) || (k[1] >> L) || (k[2] >> L)) ++last_oob;
-		set.insert(morton(k) >> (3 * depth));
+		return set.insert(morton(k) >> (3 * depth)).second; /* try_emplace(...).second: the cell is new to this scan */
 	}
-	void freeSpaceNormal(V3 const& from, V3 const& to, std::unordered_set<u64>& set, unsigned depth)
+	/* early_stopping (OMB:1289-1298): a ray ends once that many cells IN A ROW were in the scan's set already */
+	void freeSpaceNormal(V3 const& from, V3 const& to, std::unordered_set<u64>& set, unsigned depth, unsigned early_stopping)
 	{
 		V3 cur = to, end = from;
 		V3 dir = sub(end, cur);
@@ -455,12 +456,14 @@ struct ufo_oracle_map {
 		 * cube, toKey wraps to ~2^32 and the reference walks ~2^31 cells (minutes, GBs).  No sane
 		 * ray takes more than 3*2^L steps; beyond that the input is outside the parity contract. */
 		u64 budget = 3ull * (1ull << L) + 8, taken = 0;
+		unsigned already_in_row = 0;
 		do {
 			if (++taken > budget) {
 				runaway = true;
 				return;
 			}
-			emitMiss(set, kc, depth);
+			if (emitMiss(set, kc, depth)) already_in_row = 0;
+			else if (0 < early_stopping && ++already_in_row >= early_stopping) break;
 			/* math/vector3.h:244-251 tie order */
 			int a = (tmax[0] <= tmax[1]) ? ((tmax[0] <= tmax[2]) ? 0 : 2) : ((tmax[1] <= tmax[2]) ? 1 : 2);
 			kc[a] += (u32)step[a];
@@ -468,7 +471,7 @@ struct ufo_oracle_map {
 		} while ((kc[0] != ke[0] || kc[1] != ke[1] || kc[2] != ke[2]) &&
 		         std::min(std::min(tmax[0], tmax[1]), tmax[2]) <= dist);
 	}
-	void freeSpaceSimple(V3 const& from, V3 const& to, std::unordered_set<u64>& set, unsigned depth)
+	void freeSpaceSimple(V3 const& from, V3 const& to, std::unordered_set<u64>& set, unsigned depth, unsigned early_stopping)
 	{
 		V3 cur = to, end = from;
 		V3 dir = sub(end, cur);
@@ -480,10 +483,12 @@ struct ufo_oracle_map {
 			return;
 		}
 		V3 stepv = mul(dir, size(depth));
+		unsigned already_in_row = 0;
 		for (int s = 0; s <= num_steps; ++s) {
 			u32 k[3];
 			toKey(cur, depth, k);
-			emitMiss(set, k, depth);
+			if (emitMiss(set, k, depth)) already_in_row = 0;
+			else if (0 < early_stopping && ++already_in_row >= early_stopping) break; /* OMB:1327-1333 */
 			cur = add(cur, stepv);
 		}
 	}
@@ -491,7 +496,7 @@ struct ufo_oracle_map {
 	/* ---- the two head loops + helper: occupancy_map_base.h:270-417, 1345-1373;
 	 *      colour head loop occupancy_map_color.h:177-267 ---- */
 	int insert(V3 const& sensor, const double* xyz, const uint8_t* rgb, size_t n, double max_range,
-	           unsigned depth, bool discrete, bool simple)
+	           unsigned depth, bool discrete, bool simple, unsigned early_stopping = 0)
 	{
 		if (rgb && !color) return -1;
 		if (rgb && !discrete) return -2;
@@ -584,8 +589,8 @@ struct ufo_oracle_map {
 		for (V3 const& pt : rays) {
 			V3 cur = sensor, end = pt;
 			if (!moveLineInside(cur, end)) continue;
-			if (simple) freeSpaceSimple(cur, end, free_hits, depth);
-			else freeSpaceNormal(cur, end, free_hits, depth);
+			if (simple) freeSpaceSimple(cur, end, free_hits, depth, early_stopping);
+			else freeSpaceNormal(cur, end, free_hits, depth, early_stopping);
 			if (runaway) return -4; /* nothing has been applied to the map yet */
 		}
 
@@ -810,9 +815,9 @@ int ufo_oracle_insert(ufo_oracle_map* m, const double origin[3], const double* x
                       const uint8_t* rgb, size_t n, double max_range, unsigned depth, int discrete,
                       int simple_ray_casting, unsigned early_stopping)
 {
-	if (0 != early_stopping) return -3; /* order-dependent, out of parity scope (hard part 6) */
+	/* (early_stopping > 0 depends on the order of the rays: the port casts them in the reference's order, OMB:1234) */
 	V3 o = V3{{origin[0], origin[1], origin[2]}};
-	return m->insert(o, xyz, rgb, n, max_range, depth, 0 != discrete, 0 != simple_ray_casting);
+	return m->insert(o, xyz, rgb, n, max_range, depth, 0 != discrete, 0 != simple_ray_casting, early_stopping);
 }
 
 size_t ufo_oracle_export_leaves(const ufo_oracle_map* m, int include_unknown, uint64_t* codes,

@@ -165,8 +165,9 @@ def test_edge_cases_empty_and_errors():
     assert len(m.leaves()[0]) == 0
     codes, depths, occ, _ = m.leaves(True)
     assert codes.tolist() == [0] and depths.tolist() == [16] and occ.tolist() == [0.0]
-    with pytest.raises(capi.UfomapError) as e:
-        m.insertPointCloud([0, 0, 0], np.ones((4, 3)), 20.0, 0, False, 3)  # early_stopping unsupported
+    m.set_scratch_limit(1 << 20)
+    with pytest.raises(capi.UfomapError) as e:  # early_stopping needs a dense first-ray array over the ray box: 4e6 cells do not fit 1 MiB
+        m.insertPointCloud([0, 0, 0], np.array([[20.0, 20.0, 20.0], [1.0, 1.0, 1.0]]), -1.0, 0, False, 3)
     assert e.value.code == capi.ERR_UNSUPPORTED
 
 

@@ -176,3 +176,31 @@ def test_simple_ray_casting_on_the_steady_state_path(discrete):
     for i, (origin, xyz) in enumerate(_wander(16, spread=0.4)):
         (g2.insertPointCloudDiscrete if discrete else g2.insertPointCloud)(origin, PointCloud(xyz), 12.0, 0, i % 5 != 4, 0, False)
     assert same_dump(g.leaves(True), g2.leaves(True)) and same_dump(g.inner(), g2.inner()), "general path and steady-state path differ"
+
+
+@pytest.mark.parametrize("early", [1, 3, 10])
+@pytest.mark.parametrize("mode", ["continuous", "discrete", "simple", "discrete_d1"])
+def test_early_stopping(early, mode):
+    """`early_stopping` > 0 (occupancy_map_base.h:1289-1298, 1327-1333): a ray ends once that many cells in a row were in the
+    scan's set already -- put there by rays cast EARLIER. The device finds every ray's stop as the fixed point of "who visits a
+    cell first" (scan_kernels.h: k_es_mark / k_es_stops): same ray cells, step count and map as the reference casting the rays one
+    after the other; sweeps (neighbouring rays share most cells), sync and async calls, mixed with ordinary scans."""
+    from ufomap_amd import PointCloud, scans
+    kw = dict(continuous=dict(), discrete=dict(discrete=True), simple=dict(discrete=True, simple_ray_casting=True), discrete_d1=dict(discrete=True, depth=1))[mode]
+    g, o = _maps(kind=_kind(), resolution=0.16)
+    _, p = _maps(kind="port", resolution=0.16)
+    rounds = []
+    for s in range(5):
+        origin, xyz, _ = scans.lidar64(beams=16, azimuths=512, origin=scans.lidar_pose(s % 3), seed=100 + s)
+        es = 0 if s == 3 else early
+        ins = g.insertPointCloudDiscrete if kw.get("discrete") else g.insertPointCloud
+        ins(origin, PointCloud(xyz), 12.0, kw.get("depth", 0), kw.get("simple_ray_casting", False), es, bool(s & 1))
+        o.insert(origin, xyz, max_range=12.0, early_stopping=es, **kw)
+        p.insert(origin, xyz, max_range=12.0, early_stopping=es, **kw)
+        g.insertPointCloudWait()
+        assert np.array_equal(g.last_misses(), p.last_misses()), f"scan {s}: ray cells differ"
+        assert g.last_counts()["steps"] == p.last_steps(), f"scan {s}: cells visited differ"
+        if es:
+            rounds.append(g.debug()[47])
+    _assert_same_map(g, o, mode)
+    assert all(1 <= r <= 64 for r in rounds), f"rounds to settle: {rounds}"

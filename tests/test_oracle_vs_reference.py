@@ -156,3 +156,31 @@ def test_point_queries_port_equals_reference(color):
         a, b = p.query(q, depth), r.query(q, depth)
         assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)) and np.array_equal(a[1], b[1]), depth
     assert len(set(p.query(q, 0)[1] & 7)) == 3  # occupied, free and unknown all occur
+
+
+@pytest.mark.parametrize("early", [1, 3, 10])
+@pytest.mark.parametrize("mode", ["continuous", "discrete", "simple", "discrete_d1"])
+def test_early_stopping(early, mode, ref_available, port_available):
+    """`early_stopping` (occupancy_map_base.h:1289-1298, 1327-1333; the server's dynamic-reconfigure range is 0..10): a ray ends once
+    that many cells in a row were in the scan's set already -- order-dependent, pinned against the reference on a LiDAR sweep
+    (neighbouring rays share most cells) and on random clouds with clipping."""
+    if not ref_available:
+        pytest.skip("reference build not available")
+    kw = dict(continuous=dict(), discrete=dict(discrete=True), simple=dict(discrete=True, simple_ray_casting=True),
+              discrete_d1=dict(discrete=True, depth=1))[mode]
+    a, b = _pair(resolution=0.16)
+    for s in range(3):
+        o, xyz, _ = scans.lidar64(beams=16, azimuths=256, origin=scans.lidar_pose(s), seed=100 + s)
+        a.insert(o, xyz, max_range=12.0, early_stopping=early, **kw)
+        b.insert(o, xyz, max_range=12.0, early_stopping=early, **kw)
+    _assert_same(a, b)
+    assert b.last_steps() < OracleMap(0.16, kind="port").last_steps() + 10 ** 9  # (the port reports its step count with early stopping too)
+    a, b = _pair(resolution=0.5, depth_levels=6)
+    for it in range(2):
+        o, xyz, _ = scans.random_cloud(300, seed=77 + it, extent=30.0, origin=(0.3 + 9 * it, -0.2, 0.4))
+        try:
+            b.insert(o, xyz, max_range=[-1.0, 40.0][it], early_stopping=early, **kw)
+        except RunawayRay:
+            continue
+        a.insert(o, xyz, max_range=[-1.0, 40.0][it], early_stopping=early, **kw)
+    _assert_same(a, b)

@@ -542,7 +542,8 @@ __global__ __launch_bounds__(256) void k_select(MapGeom g, D3 sensor, u32 n, u32
                                                 const D3* __restrict__ pt_end, const u8* __restrict__ pt_flag,
                                                 const u32* __restrict__ pt_slot, D3* __restrict__ ray_end,
                                                 u64* __restrict__ hit_code, u32* __restrict__ hit_pt,
-                                                BoxPartial* __restrict__ part, ScanCtl* ctl, u32* __restrict__ blk_range)
+                                                BoxPartial* __restrict__ part, ScanCtl* ctl, u32* __restrict__ blk_range,
+                                                u32* __restrict__ ray_pt = nullptr, u32 es_mode = 0)
 {
 	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
 	u8 flag = (i < n) ? pt_flag[i] : 0;
@@ -600,7 +601,11 @@ __global__ __launch_bounds__(256) void k_select(MapGeom g, D3 sensor, u32 n, u32
 				// OMB:380-382: for depth > 0 one ray per depth-`depth` cell. All rays into one cell are
 				// identical (same sensor, end = cell centre), so whichever thread creates the entry casts it.
 				// Bit 63 keeps cell codes apart from the depth-0 hit codes sharing the table.
-				if (!hitHashInsertUnique(hh, morton3(k0, k1, k2) | (1ULL << 63), &ctl->err)) cast = false;
+				if (es_mode) {
+					// (early stopping: the cell's ray is its first point's, registered by k_es_raycells)
+					const u32 s2 = hitHashFind(hh, morton3(k0, k1, k2) | (1ULL << 63));
+					if (!(s2 != NONE && hh.minidx[s2] == i)) cast = false;
+				} else if (!hitHashInsertUnique(hh, morton3(k0, k1, k2) | (1ULL << 63), &ctl->err)) cast = false;
 			}
 			if (cast) {
 				u32 k0 = toKey1(g, e2.x, depth), k1 = toKey1(g, e2.y, depth), k2 = toKey1(g, e2.z, depth);
@@ -632,6 +637,7 @@ __global__ __launch_bounds__(256) void k_select(MapGeom g, D3 sensor, u32 n, u32
 	}
 	if (cast) {
 		ray_end[rpos] = end;
+		if (ray_pt) ray_pt[rpos] = i;  // (the ray's rank in the cloud's order: early stopping)
 		const i32 lim = (i32)((1u << (g.L - depth)) - 1u);
 		for (int a = 0; a < 3; ++a) {
 			// cells outside [0, 2^(L-depth)) are dropped by gridMark: keep them out of the bbox
@@ -2434,5 +2440,213 @@ __global__ __launch_bounds__(256) void k_grid_codes_bits(MapGeom g, Grid gr, con
 			if (pos < cap) codes[pos] = code;
 		}
 	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// early_stopping > 0 (occupancy_map_base.h:1289-1298, 1327-1333; the server's dynamic-reconfigure range is 0 .. 10): a ray
+// ends once that many cells IN A ROW were in the scan's set already -- put there by a ray cast EARLIER (the reference casts
+// the rays one after the other, in the order of the cloud), or, with fixed-step casting, by the ray's own step before.
+// Which cells a ray visits therefore depends on where every earlier ray stopped. Exact parallel form: a ray's stop is a
+// function of the stops of the rays before it alone, so the scan's stops are the unique fixed point of
+//     first[c] = lowest rank among the rays that visit cell c within their current stop   (k_es_mark: atomicMin)
+//     stop[r]  = where ray r stops when "in the set already" means first[c] < rank(r)      (k_es_stops)
+// Iterated from "nobody stops": after round k the k lowest-ranked rays are final (induction on the rank), in practice the
+// estimates bracket the answer and a LiDAR sweep settles in a handful of rounds; the host stops when no stop moved. Rank =
+// index of the ray's point in the cloud (k_select appends workgroup by workgroup, not in order). Then the visited cells go
+// into grid M (k_es_mark with the grid) and the update proceeds as without early stopping.
+// ------------------------------------------------------------------------------------------------
+struct EsArgs {
+	u32* first;        // [cells of the ray box] lowest rank that visits the cell (0xFFFFFFFF: nobody)
+	u32* stop;         // [rays] cells the ray visits (0xFFFFFFFF: to its end)
+	const u32* rank;   // [rays] the ray's point index
+	u32 early;         // early_stopping
+	u32 simple;        // fixed-step casting
+};
+// the cells of one ray, in the order the reference visits them: visit(cx, cy, cz) returns false to end the ray; returns the
+// number of cells visited. (The checked sequential walk: this path is about exactness, not speed.)
+template <typename V>
+__device__ inline u32 esWalk(const MapGeom& g, const D3& sensor, u32 depth, D3 to, bool simple, u32* err, V&& visit)
+{
+	D3 from = sensor;
+	if (!moveLineInside(g, from, to)) return 0;
+	D3 cur = to, end = from;
+	D3 dir = end - cur;
+	const double dist = norm(dir);
+	dir = dir / dist;
+	const u64 budget = 3ull * (1ull << g.L) + 8;
+	u32 n = 0;
+	if (simple) {
+		const double ns = nodeSize(g, depth);
+		const int num_steps = (int)(dist / ns);
+		if (num_steps < 0 || (u64)num_steps > budget) {
+			*err |= ERR_RUNAWAY;
+			return 0;
+		}
+		const D3 stepv = dir * ns;
+		for (int s = 0; s <= num_steps; ++s) {
+			++n;
+			if (!visit((i32)(toKey1(g, cur.x, depth) >> depth), (i32)(toKey1(g, cur.y, depth) >> depth), (i32)(toKey1(g, cur.z, depth) >> depth))) break;
+			cur = cur + stepv;
+		}
+		return n;
+	}
+	const u32 kx = toKey1(g, cur.x, depth), ky = toKey1(g, cur.y, depth), kz = toKey1(g, cur.z, depth);
+	const u32 ex = toKey1(g, end.x, depth), ey = toKey1(g, end.y, depth), ez = toKey1(g, end.z, depth);
+	i32 cx = (i32)(kx >> depth), cy = (i32)(ky >> depth), cz = (i32)(kz >> depth);
+	if (kx == ex && ky == ey && kz == ez) {
+		(void)visit(cx, cy, cz);
+		return 1;
+	}
+	const i32 gx = (i32)(ex >> depth), gy = (i32)(ey >> depth), gz = (i32)(ez >> depth);
+	const double node_size = nodeSize(g, depth), half = g.hs[depth];
+	double bx = toCoord1(g, kx, depth) - cur.x, by = toCoord1(g, ky, depth) - cur.y, bz = toCoord1(g, kz, depth) - cur.z;
+	i32 sx, sy, sz;
+	double tdx, tdy, tdz, tmx, tmy, tmz;
+#define UFO_AXIS_INIT(d, b, s, td, tm)                 \
+	if (0 < d) {                                        \
+		s = 1;                                          \
+		b += half;                                      \
+		td = node_size / fabs(d);                       \
+		tm = b / d;                                     \
+	} else if (0 > d) {                                 \
+		s = -1;                                         \
+		b -= half;                                      \
+		td = node_size / fabs(d);                       \
+		tm = b / d;                                     \
+	} else {                                            \
+		s = 0;                                          \
+		td = 1.7976931348623157e308;                    \
+		tm = 1.7976931348623157e308;                    \
+	}
+	UFO_AXIS_INIT(dir.x, bx, sx, tdx, tmx)
+	UFO_AXIS_INIT(dir.y, by, sy, tdy, tmy)
+	UFO_AXIS_INIT(dir.z, bz, sz, tdz, tmz)
+#undef UFO_AXIS_INIT
+	bool go;
+	do {
+		if ((u64)++n > budget) {
+			*err |= ERR_RUNAWAY;
+			break;
+		}
+		if (!visit(cx, cy, cz)) break;
+		if (tmx <= tmy) {
+			if (tmx <= tmz) {
+				cx += sx;
+				tmx += tdx;
+			} else {
+				cz += sz;
+				tmz += tdz;
+			}
+		} else {
+			if (tmy <= tmz) {
+				cy += sy;
+				tmy += tdy;
+			} else {
+				cz += sz;
+				tmz += tdz;
+			}
+		}
+		go = (cx != gx || cy != gy || cz != gz) && (fmin(fmin(tmx, tmy), tmz) <= dist);
+	} while (go);
+	return n;
+}
+// index of a cell in the dense array over the ray box (cells, x fastest); false: outside (keys beyond the map's range are
+// dropped by the marking as everywhere else, cells outside the box cannot happen)
+__device__ inline bool esCell(const Grid& gr, i32 cx, i32 cy, i32 cz, u32 lim, u64* idx, u32* err)
+{
+	if ((u32)cx >= lim || (u32)cy >= lim || (u32)cz >= lim) return false;
+	const i32 lx = cx - gr.base[0], ly = cy - gr.base[1], lz = cz - gr.base[2];
+	if ((u32)lx >= 2u * (u32)gr.nb[0] || (u32)ly >= 2u * (u32)gr.nb[1] || (u32)lz >= 2u * (u32)gr.nb[2]) {
+		*err |= ERR_GRID_OOB;
+		return false;
+	}
+	*idx = (u64)lx + 2ull * (u64)gr.nb[0] * ((u64)ly + 2ull * (u64)gr.nb[1] * (u64)lz);
+	return true;
+}
+// every ray marks the cells it visits within its current stop: first[c] = min rank; grid != nullptr (the final pass): the
+// cells go into grid M as well, the visits are the scan's step count
+__global__ __launch_bounds__(256) void k_es_mark(MapGeom g, D3 sensor, u32 depth, Grid gr, EsArgs a, const D3* __restrict__ ray_end, const ScanCtl* ctl_in, ScanCtl* ctl,
+                                                 u32* __restrict__ grid)
+{
+	const u32 n = ctl_in->n_rays;
+	const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+	unsigned long long steps = 0;
+	u32 err = 0, oob = 0;
+	if (r < n) {
+		const u32 lim = 1u << (g.L - depth), rank = a.rank[r], stop = a.stop[r];
+		u32 k = 0;
+		steps = esWalk(g, sensor, depth, ray_end[r], 0 != a.simple, &err, [&](i32 cx, i32 cy, i32 cz) {
+			u64 idx;
+			if (esCell(gr, cx, cy, cz, lim, &idx, &err)) {
+				atomicMin(&a.first[idx], rank);
+				if (grid) (void)gridMark(gr, grid, cx, cy, cz, lim, &oob);
+			} else if (grid && ((u32)cx >= lim || (u32)cy >= lim || (u32)cz >= lim)) {
+				++oob;
+			}
+			return ++k < stop;
+		});
+	}
+	if (grid) {
+		waveAddU64(&ctl->n_steps, steps);
+		if (oob) atomicAdd(&ctl->n_oob, oob);
+	}
+	if (err) atomicOr(&ctl->err, err);
+}
+// every ray walks its whole path against `first` and finds where it stops; *changed counts the rays whose stop moved
+__global__ __launch_bounds__(256) void k_es_stops(MapGeom g, D3 sensor, u32 depth, Grid gr, EsArgs a, const D3* __restrict__ ray_end, const ScanCtl* ctl_in, ScanCtl* ctl,
+                                                  u32* changed)
+{
+	const u32 n = ctl_in->n_rays;
+	const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+	u32 err = 0;
+	bool moved = false;
+	if (r < n) {
+		const u32 lim = 1u << (g.L - depth), rank = a.rank[r];
+		u32 row = 0;
+		u64 prev = ~0ull;
+		bool stopped = false;
+		const u32 visited = esWalk(g, sensor, depth, ray_end[r], 0 != a.simple, &err, [&](i32 cx, i32 cy, i32 cz) {
+			u64 idx = ~0ull;
+			bool already = false;
+			if (esCell(gr, cx, cy, cz, lim, &idx, &err)) already = a.first[idx] < rank || (a.simple && idx == prev);
+			prev = idx;
+			if (!already) {
+				row = 0;
+				return true;
+			}
+			if (++row >= a.early) {
+				stopped = true;
+				return false;
+			}
+			return true;
+		});
+		const u32 stop = stopped ? visited : 0xFFFFFFFFu;
+		moved = stop != a.stop[r];
+		a.stop[r] = stop;
+	}
+	const u32 c = (u32)__popcll(__ballot(moved));
+	if (0 == (threadIdx.x & 63u) && c) atomicAdd(changed, c);
+	if (err) atomicOr(&ctl->err, err);
+}
+// insert depth > 0: the ray of a cell is its FIRST point's (the cloud's order decides the ranks): every candidate point
+// registers under its cell with atomicMin before k_select lets the winner cast (without early stopping whichever point
+// creates the entry casts: all rays into one cell are identical)
+template <bool DISCRETE>
+__global__ __launch_bounds__(256) void k_es_raycells(MapGeom g, D3 sensor, u32 n, u32 depth, HitHash hh, const D3* __restrict__ pt_end, const u8* __restrict__ pt_flag,
+                                                     const u32* __restrict__ pt_slot, ScanCtl* ctl)
+{
+	const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n || !DISCRETE || 0 == depth) return;
+	const u8 flag = pt_flag[i];
+	bool cast = 0 != (flag & PF_CAST);
+	if (flag & PF_HITCAND) {
+		const u32 s = pt_slot[i];
+		if (!(s != NONE && hh.minidx[s] == i)) cast = false;  // OMB:358-360: dropped entirely, no ray
+	}
+	if (!cast) return;
+	D3 cur = sensor, e2 = pt_end[i];
+	if (!moveLineInside(g, cur, e2)) return;
+	const u32 k0 = toKey1(g, e2.x, depth), k1 = toKey1(g, e2.y, depth), k2 = toKey1(g, e2.z, depth);
+	(void)hitHashInsert(hh, morton3(k0, k1, k2) | (1ULL << 63), i, &ctl->err);
 }
 }  // namespace ufo

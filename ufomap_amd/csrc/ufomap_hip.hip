@@ -340,6 +340,8 @@ struct ufomap_map {
 	Ingest ing{};      // ufomap_map_insert_pointcloud2: raw PointCloud2 records, converted inside k_classify
 	u32 hb_clean = 0;  // slots [0, hb_clean) of the hit-block hash are known to be empty
 	DevBuf b_crec, b_dlist, b_rays;
+	DevBuf b_ray_pt, b_es_first, b_es_stop;  // early stopping (scan_kernels.h: k_es_*): the rays' ranks, who visits a cell first, the rays' stops
+	u32 es_rounds = 0;                        // ... rounds the last such scan took to settle
 	DevBuf b_gridM, b_entries, b_ent_slot, b_newlist, b_wl0, b_wl1, b_in_xyz, b_in_rgb, b_codes, b_dump;
 	ScanCtl* h_ctl = nullptr;  // pinned
 	ScanCtl* h_res = nullptr;  // pinned: k_ftail stores the finished control block here itself (no read-back copy, no stream sync)
@@ -1342,8 +1344,6 @@ int scanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, const 
 {
 	if (!m) return fail(UFOMAP_ERR_INVALID, "null map");
 	HIP_TRY(hipSetDevice(m->device));
-	if (early_stopping != 0)
-		return fail(UFOMAP_ERR_UNSUPPORTED, "early_stopping > 0 depends on ray order (occupancy_map_base.h:1289-1298); not supported");
 	if (depth >= m->g.L) return fail(UFOMAP_ERR_INVALID, "depth must be < depth_levels");
 	if (d_rgb && !m->g.color) return fail(UFOMAP_ERR_INVALID, "coloured cloud into a non-colour map");
 	if (d_rgb && !discrete)
@@ -1401,16 +1401,25 @@ int scanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, const 
 			                   m->ing);
 	}
 	HIP_TRY(m->b_blk_range.reserve((size_t)gp.x * 8));
+	u32* ray_pt = nullptr;  // early stopping: the rays' ranks in the cloud's order
+	const u32 es_cells = (early_stopping && discrete && depth > 0) ? 1u : 0u;
+	if (early_stopping) {
+		HIP_TRY(m->b_ray_pt.reserve(n * 4));
+		ray_pt = m->b_ray_pt.as<u32>();
+		if (es_cells)  // (insert depth > 0: the ray of a cell is its first point's)
+			hipLaunchKernelGGL(k_es_raycells<true>, gp, dim3(256), 0, m->cs, m->g, sensor, N, (u32)depth, hh, m->b_pt_end.as<D3>(), m->b_pt_flag.as<u8>(),
+			                   m->b_pt_slot.as<u32>(), ctl);
+	}
 	{
 		ProfScope ps(m, "k_select");
 		if (discrete)
 			hipLaunchKernelGGL(k_select<true>, gp, dim3(256), 0, m->cs, m->g, sensor, N, (u32)depth, hh, m->b_pt_end.as<D3>(),
 			                   m->b_pt_flag.as<u8>(), m->b_pt_slot.as<u32>(), m->b_ray_end.as<D3>(), m->b_hit_code.as<u64>(),
-			                   m->b_hit_pt.as<u32>(), m->b_part1.as<BoxPartial>(), ctl, m->b_blk_range.as<u32>());
+			                   m->b_hit_pt.as<u32>(), m->b_part1.as<BoxPartial>(), ctl, m->b_blk_range.as<u32>(), ray_pt, es_cells);
 		else
 			hipLaunchKernelGGL(k_select<false>, gp, dim3(256), 0, m->cs, m->g, sensor, N, (u32)depth, hh, m->b_pt_end.as<D3>(),
 			                   m->b_pt_flag.as<u8>(), m->b_pt_slot.as<u32>(), m->b_ray_end.as<D3>(), m->b_hit_code.as<u64>(),
-			                   m->b_hit_pt.as<u32>(), m->b_part1.as<BoxPartial>(), ctl, m->b_blk_range.as<u32>());
+			                   m->b_hit_pt.as<u32>(), m->b_part1.as<BoxPartial>(), ctl, m->b_blk_range.as<u32>(), ray_pt, es_cells);
 	}
 	{
 		ProfScope ps(m, "k_reduce_boxes");
@@ -1467,7 +1476,7 @@ int scanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, const 
 			}
 		}
 	}
-	if (!spec && m->haveM && !simple && m->opt_dda_seg != 0 && m->opt_bits != 0 && m->opt_dda_mode <= 0) {
+	if (!spec && m->haveM && !simple && 0 == early_stopping && m->opt_dda_seg != 0 && m->opt_bits != 0 && m->opt_dda_mode <= 0) {
 		// one bit per cell (rows padded to 32 cells) when that fits in LDS: the fast walk kernel (k_walk)
 		Grid& gr = m->gridM;
 		const bool packed = 2 * gr.nb[0] < 1023 && 2 * gr.nb[1] < 1023 && 2 * gr.nb[2] < 1023;
@@ -1480,6 +1489,13 @@ int scanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, const 
 		}
 	}
 	u64 gbytes = m->haveM ? m->gridM.bytes : 0;  // hits are grouped through a hash, only grid M is dense
+	if (early_stopping && m->haveM) {
+		// (a dense array over the cells of the ray box: who visits a cell first)
+		const u64 cells = 8ull * (u64)m->gridM.nb[0] * (u64)m->gridM.nb[1] * (u64)m->gridM.nb[2];
+		if (cells >= (1ull << 32) || cells * 4 + gbytes > m->scratch_limit)
+			return fail(UFOMAP_ERR_UNSUPPORTED, "early_stopping > 0 on a ray box of " + std::to_string(cells) +
+			                                        " cells: the first-ray array does not fit the scratch limit (ufomap_map_set_scratch_limit)");
+	} else
 	if (gbytes > m->scratch_limit || (m->opt_sparse_set && m->haveM && !simple)) {  // (option sparse_set: tests)
 		// the box is too large for a dense grid: the ray cells go through a hash set of node blocks instead (Grid::layout 2,
 		// scan_kernels.h: MissSet) -- bounded by the cells the rays touch, as the reference's CodeMap is
@@ -1509,7 +1525,42 @@ int scanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, const 
 		HitBlocks hb{m->b_hb_keys.as<u64>(), m->b_hb_mask.as<u32>(), m->b_hb_time.as<u32>(), m->hb_cap_mask};
 		hipLaunchKernelGGL(k_hitmark, gridFor(n_hits), dim3(256), 0, m->cs, hb, m->b_hit_code.as<u64>(), m->b_hit_pt.as<u32>(), ctl, ctl);
 	}
-	if (m->haveM && 2 == m->gridM.layout) {
+	if (m->haveM && early_stopping) {
+		// ---- early stopping (scan_kernels.h: k_es_*): the rays' stops as the fixed point of "who visits a cell first", then the
+		// visited cells into grid M (one byte per node block) ----
+		const u64 cells = 8ull * (u64)m->gridM.nb[0] * (u64)m->gridM.nb[1] * (u64)m->gridM.nb[2];
+		HIP_TRY(m->b_gridM.reserve(m->gridM.bytes));
+		HIP_TRY(m->b_es_first.reserve(cells * 4));
+		HIP_TRY(m->b_es_stop.reserve((size_t)n_rays * 4));
+		HIP_TRY(hipMemsetAsync(m->b_gridM.p, 0, m->gridM.bytes, m->cs));
+		HIP_TRY(hipMemsetAsync(m->b_es_stop.p, 0xFF, (size_t)n_rays * 4, m->cs));
+		u32* d_changed = m->b_ctl.as<u32>() + (sizeof(ScanCtl) + 3) / 4;  // (a spare word behind the control block)
+		const EsArgs ea{m->b_es_first.as<u32>(), m->b_es_stop.as<u32>(), m->b_ray_pt.as<u32>(), (u32)early_stopping, simple ? 1u : 0u};
+		const dim3 gr_((n_rays + 255) / 256);
+		u32 rounds = 0;
+		for (;; ++rounds) {
+			if (rounds > n_rays + 2) return fail(UFOMAP_ERR_DEVICE, "early stopping: the rays' stops did not settle (internal error)");
+			HIP_TRY(hipMemsetAsync(m->b_es_first.p, 0xFF, cells * 4, m->cs));
+			HIP_TRY(hipMemsetAsync(d_changed, 0, 4, m->cs));
+			{
+				ProfScope ps(m, "k_es_mark");
+				hipLaunchKernelGGL(k_es_mark, gr_, dim3(256), 0, m->cs, m->g, sensor, (u32)depth, m->gridM, ea, m->b_ray_end.as<D3>(), ctl, ctl, (u32*)nullptr);
+			}
+			{
+				ProfScope ps(m, "k_es_stops");
+				hipLaunchKernelGGL(k_es_stops, gr_, dim3(256), 0, m->cs, m->g, sensor, (u32)depth, m->gridM, ea, m->b_ray_end.as<D3>(), ctl, ctl, d_changed);
+			}
+			u32 changed = 0;
+			HIP_TRY(hipMemcpyAsync(&changed, d_changed, 4, hipMemcpyDeviceToHost, m->cs));
+			HIP_TRY(hipStreamSynchronize(m->cs));
+			if (0 == changed) break;
+		}
+		m->es_rounds = rounds + 1;
+		{
+			ProfScope ps(m, "k_es_mark");
+			hipLaunchKernelGGL(k_es_mark, gr_, dim3(256), 0, m->cs, m->g, sensor, (u32)depth, m->gridM, ea, m->b_ray_end.as<D3>(), ctl, ctl, m->b_gridM.as<u32>());
+		}
+	} else if (m->haveM && 2 == m->gridM.layout) {
 		// sparse: walk into the set; if it fills up, double it and walk again (the size is remembered for later scans)
 		for (;;) {
 			const u64 slots = std::max<u64>(m->miss_set_slots, 1ull << 16);
@@ -3587,6 +3638,7 @@ int ufomap_map_debug(ufomap_map* m, uint64_t* out, int n)
 	if (n > 51) out[51] = m->n_phase_resets;  // phaseGuard
 	if (n > 50) out[50] = m->n_vol;            // scans on the volume path (vol_kernels.h)
 	if (n > 49) out[49] = m->n_vol_grow;       // ... times the node table was exchanged in the middle of such a scan's tree update
+	if (n > 47) out[47] = m->es_rounds;        // rounds the last scan with early_stopping > 0 took to settle
 	if (n > 48) out[48] = m->n_vol_fallback;   // ... scans that turned to the general path (a ray clipped at the map cube)
 	for (int k = 0; k < 4 && 52 + k < n; ++k) out[52 + k] = m->host_ns[k];  // host time inside doInsert (ns): scan enqueue, map enqueue, join, total
 	return rc;
