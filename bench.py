@@ -112,6 +112,53 @@ def cpu_baseline(clouds, seq, budget_s=12.0):
                 ms_per_scan_mean=mean * 1e3, ms_per_scan_median=float(np.median(per_scan)) * 1e3)
 
 
+def live_traffic(kernels, timeout_s=150):
+    """HBM bytes per launch of `kernels`, measured NOW: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, each in a run of its own with
+    --kernel-trace only, as MI355X_MICROARCH.md prescribes) over a short run of this script's headline leg in a child process. Returns
+    (bytes or None, per-kernel dict, note). The library hands over with events instead of gate kernels when it sees the counter
+    collection (kernels are serialised across streams under it)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if not exe or os.environ.get("UFOMAP_BENCH_CHILD"):
+        return None, {}, "rocprofv3 not on PATH" if not exe else "child run"
+    cmd = [sys.executable, os.path.abspath(__file__), "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-self-check", "--only-headline",
+           "--profile-kernels", "0", "--min-timed-s", "0.05"]
+    env = dict(os.environ, UFOMAP_BENCH_CHILD="1", TMPDIR="/tmp")
+    per = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = tempfile.mkdtemp(prefix="ufo_pmc_", dir="/tmp")
+            subprocess.run([exe, "-f", "csv", "--pmc", counter, "--kernel-trace", "-d", d, "-o", "pmc", "--"] + cmd, cwd="/tmp", env=env,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=False)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            acc = {}
+            for f in files:
+                for r in csv.DictReader(open(f)):
+                    if r.get("Counter_Name") != counter:
+                        continue
+                    k = r.get("Kernel_Name", "").split("(")[0].replace("void ", "").replace("ufo::", "").strip().split("<")[0]
+                    a = acc.setdefault(k, [0, 0.0])
+                    a[0] += 1
+                    a[1] += float(r.get("Counter_Value") or 0)
+            shutil.rmtree(d, ignore_errors=True)
+            for k, (n, tot) in acc.items():
+                per.setdefault(k, {})[counter] = tot / max(n, 1)
+    except Exception as e:  # noqa: BLE001
+        return None, {}, f"rocprofv3 --pmc failed: {e!r}"
+    out = {}
+    for k, v in per.items():
+        if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+            out[k] = (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0  # (the guide's gfx950 correction: the read side doubled)
+    vals = [out.get(k) for k in kernels]
+    if not all(vals):
+        return None, out, "the counters of " + ", ".join(k for k, v in zip(kernels, vals) if not v) + " were not collected"
+    return float(sum(vals)), out, "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, a pass each, over 25 scans of the headline leg in a child process"
+
+
 def other_configs(device, big, only=None):
     """BASELINE configs C1, C5 and C3 (insert depth 6 / 3 / 0) on this GPU: sync calls, cloud resident in HBM, the fixture's scan
     sequence into a fresh map. The map after every scan is compared with the UNMODIFIED reference: its digest recorded in
@@ -237,6 +284,7 @@ def main():
     ap.add_argument("--profile-kernels", type=int, default=1, help="extra leg with every kernel bracketed by HIP events (roofline)")
     ap.add_argument("--min-timed-s", type=float, default=MIN_TIMED_S)
     ap.add_argument("--only-headline", action="store_true", help="skip the extra legs (profiling runs)")
+    ap.add_argument("--no-live-traffic", action="store_true", help="roofline.traffic from profiles/pmc_latest.json instead of two rocprofv3 --pmc passes in this run")
     ap.add_argument("--big", type=int, default=1, help="other_configs: include C3 at insert depth 0 (2 mm, 3.4e8 leaves, ~11 GB of node table)")
     ap.add_argument("--no-other-configs", action="store_true")
     args = ap.parse_args()
@@ -571,9 +619,12 @@ def main():
                                    "): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, scripts/profile_gpu.sh -- a builder-run file, not measured in this run")
                 except Exception:
                     traffic = None
+            traffic_live, traffic_live_kernels, traffic_live_note = (None, {}, "switched off") if args.no_live_traffic else live_traffic(group)
+            if traffic_live is not None:
+                traffic, traffic_src = traffic_live, traffic_live_note
             by_time = max(per_step_ms, key=per_step_ms.get)
             frac_rocprof, rocprof_src = None, None
-            for tag in ("r03", "r02"):
+            for tag in ("r04", "r03", "r02"):
                 f = os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv")
                 if os.path.exists(f):
                     import csv
@@ -584,7 +635,12 @@ def main():
                         rocprof_src = f"profiles/{tag}_kernel_stats.csv (sha256 {hashlib.sha256(open(f, 'rb').read()).hexdigest()[:16]}): rocprofv3 --kernel-trace --stats of this command"
                     break
             roof = dict(bound="hbm", kernel="+".join(group), achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
-                        frac_rocprof=frac_rocprof, frac_rocprof_source=rocprof_src, traffic=traffic, traffic_source=traffic_src, algorithmic_bytes_per_launch=share, avg_launch_us=dur_s * 1e6,
+                        frac_rocprof=frac_rocprof, frac_rocprof_source=rocprof_src, traffic=traffic, traffic_source=traffic_src,
+                        traffic_live_note=traffic_live_note, traffic_per_kernel={k: round(v) for k, v in traffic_live_kernels.items() if k in per_step_ms},
+                        # (round 2's definition of the ray walk -- the slab merge counted with it -- for like-for-like comparisons)
+                        with_fmerge=(dict(avg_launch_us=(kern_ms[dom] + kern_ms["k_fmerge"]) * 1e3, frac=share / ((kern_ms[dom] + kern_ms["k_fmerge"]) * 1e-3) / 1e9 / HBM_PEAK_GBS)
+                                     if "k_fmerge" in kern_ms and dom == "k_fcast" else None),
+                        algorithmic_bytes_per_launch=share, avg_launch_us=dur_s * 1e6,
                         walk_kernel_only=dict(avg_launch_us=kern_ms[dom] * 1e3, achieved_GBs=share / (kern_ms[dom] * 1e-3) / 1e9,
                                               frac=share / (kern_ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS),
                         dominant_by_time=dict(kernel=by_time, us_per_step=per_step_ms[by_time] * 1e3, avg_launch_us=kern_ms[by_time] * 1e3),
@@ -610,7 +666,9 @@ def main():
             "roofline": roof, "self_check": self_check, "pipeline": pipeline,
             "memory": {"table_bytes": mem_stats["bytes"], "live_blocks": mem_stats["inner_nodes"], "leaves": mem_stats["leaf_nodes"],
                        "bytes_per_live_block": mem_stats["bytes_per_block"],
-                       "note": "node table as allocated (64 B block record + 16 B per-phase words per slot, load <= 0.6, sized for three pipelined scans' worst case) after the headline leg's last repetition"},
+                       "note": "node table as allocated after the headline leg's last repetition: tile-major since round 4 -- 73 slots of 80 B per depth-3 tile behind a directory, "
+                               "sized for every tile of the ray grid's hull being new. A LiDAR map is sparse inside its tiles (surfaces; free space is pruned away): ~10 live blocks "
+                               "per 73-slot group, which is what bytes_per_live_block shows; the dense 2 mm RGB-D map (other_configs.C3_rgbd2mm_depth0) holds 47 live blocks per group"},
         }
         out.update(extra)
         if "host_pointer" in extra:

@@ -6,8 +6,11 @@ import os
 import sys
 
 out_dir, tag = sys.argv[1], sys.argv[2]
+sub = sys.argv[3] if len(sys.argv) > 3 else ""  # "c3": the passes over scripts/dev_c3d0.py (directories c3_stats, c3_pmc_fetch, c3_pmc_write)
+if sub:
+    tag = tag + "_" + sub
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-prof = os.path.join(root, "gpurun_out", "profiles_" + tag)
+prof = os.path.join(root, "gpurun_out", "profiles_" + sys.argv[2])
 os.makedirs(prof, exist_ok=True)
 
 
@@ -19,6 +22,7 @@ def short(name):
 
 def find(pattern):
     hits = glob.glob(os.path.join(out_dir, "**", pattern), recursive=True)
+    hits = [h for h in hits if (("/" + sub + "_") in h) == bool(sub)]
     return sorted(hits)[0] if hits else None
 
 
