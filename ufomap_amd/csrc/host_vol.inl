@@ -95,10 +95,26 @@ int volScan(ufomap_map* m, const D3& sensor, const VolPlan& vp, u32 n_hits, u32 
 		ProfScope ps(m, "k_vhits");
 		hipLaunchKernelGGL(k_vhits, gridFor(n_hits), dim3(256), 0, m->cs, m->g, vp.vg, m->b_hit_code.as<u64>(), ctl, m->b_vH.as<u64>(), ctl);
 	}
+	const u32* order = nullptr;
+	if (0 == (m->opt_vol_mode & 4) && n_rays >= 4096u) {
+		// the rays bundled by direction (a counting sort over a cube map of directions): a wave's rays share bricks all the way
+		ProfScope ps(m, "k_vbin");
+		HIP_TRY(m->b_vbin.reserve(((size_t)UFO_VBINS + 2u * (size_t)n_rays) * 4));
+		u32* hist = m->b_vbin.as<u32>();
+		u32* bin_of = hist + UFO_VBINS;
+		u32* ord = bin_of + n_rays;
+		HIP_TRY(hipMemsetAsync(hist, 0, (size_t)UFO_VBINS * 4, m->cs));
+		const dim3 gb((n_rays + 255u) / 256u);
+		hipLaunchKernelGGL(k_vbin_count, gb, dim3(256), 0, m->cs, sensor, m->b_ray_end.as<D3>(), ctl, bin_of, hist);
+		hipLaunchKernelGGL(k_vbin_scan, dim3(1), dim3(1024), 0, m->cs, hist);
+		hipLaunchKernelGGL(k_vbin_scatter, gb, dim3(256), 0, m->cs, ctl, bin_of, hist, ord);
+		order = ord;
+	}
 	{
 		ProfScope ps(m, "k_vdda");
 		const u32 nblk = ((n_rays + 255u) / 256u + 7u) & ~7u;  // (a multiple of 8: an eighth of the cloud per XCD)
-		hipLaunchKernelGGL(k_vdda, dim3(nblk), dim3(256), 0, m->cs, m->g, sensor, m->gridM, vp.vg, m->b_vM.as<u64>(), m->b_vtb.as<u32>(), m->b_ray_end.as<D3>(), ctl, ctl, (u32)m->opt_vol_mode);
+		hipLaunchKernelGGL(k_vdda, dim3(nblk), dim3(256), 0, m->cs, m->g, sensor, m->gridM, vp.vg, m->b_vM.as<u64>(), m->b_vtb.as<u32>(), m->b_ray_end.as<D3>(), ctl, ctl, (u32)m->opt_vol_mode,
+		                   order);
 	}
 	{
 		ProfScope ps(m, "k_vlist");

@@ -321,12 +321,12 @@ struct ufomap_map {
 	int opt_gather_stream = 0;  // batch steps: the all-gather on a stream of its own (host_multi_gpu.inl)
 	int opt_fast_simple = 1; // simple (fixed-step) ray casting on the fast path (0: the general path)
 	int opt_fail_scan = 0;  // test aid: the scan half of the next batch steps 'fails' on this rank (host_multi_gpu.inl)
-	int opt_vol_mode = 0;   // measuring aid (k_vdda): bit 0 one copy of M for all XCDs, bit 1 rays in launch order
+	int opt_vol_mode = 0;   // measuring aid (k_vdda): bit 0 one copy of M for all XCDs, bit 1 blocks in launch order, bit 2 rays in the cloud's order, bit 3 no write-combining table
 	int opt_vol_keep = 1;   // k_tile leaves the merged ray cells of its tiles behind (ufomap_map_last_misses)
 	bool vol = false;       // the integration that uses the current set runs on it
 	bool vol_dirty = true;  // the brick grids are not known to be all zero
 	u32 vol_count = 0;      // tiles the scan has listed
-	DevBuf b_vM, b_vMm, b_vH, b_vtb, b_vlist, b_vcopies, b_vrec, b_vaux, b_vupbits;  // (b_vM: eight copies, one per XCD)
+	DevBuf b_vM, b_vMm, b_vH, b_vtb, b_vlist, b_vcopies, b_vrec, b_vaux, b_vupbits, b_vbin;  // (b_vM: eight copies, one per XCD)
 	VolPlan vplan{};
 	uint64_t n_vol = 0, n_vol_grow = 0, n_vol_fallback = 0;
 	int opt_tile_waves = 4;   // k_tile: tiles per workgroup
@@ -3611,7 +3611,7 @@ int ufomap_map_set_option(ufomap_map* m, const char* key, long long value)
 	} else if (0 == strcmp(key, "fail_scan")) {
 		m->opt_fail_scan = value ? 1 : 0;
 	} else if (0 == strcmp(key, "vol_mode")) {
-		m->opt_vol_mode = (int)(value & 3);
+		m->opt_vol_mode = (int)(value & 15);
 	} else if (0 == strcmp(key, "vol_keep")) {
 		m->opt_vol_keep = value ? 1 : 0;
 	} else if (0 == strcmp(key, "merge_phases")) {

@@ -63,6 +63,80 @@ __global__ __launch_bounds__(256) void k_vhits(MapGeom g, VolGeo vg, const u64* 
 	}
 }
 
+// ---- rays bundled by direction -----------------------------------------------------------------------------------------
+// The marks of a scan are a set: the order the rays are cast in changes nothing but speed. Cast in the cloud's order, a wave's
+// 64 rays are a strip of an image row (or a piece of a LiDAR ring): far from the sensor they are two cells apart, so few
+// of them are in the same brick at the same time. Sorted by direction -- a counting sort over a cube map of 6 x 128 x 128 bins --
+// a wave's rays form a 2D bundle (an 8 x 8 pixel patch of a 640 x 480 frame): they share bricks all the way, and what they
+// flush is merged in LDS before it reaches the L2 (k_vdda: the per-wave table).
+#define UFO_VBINS (6u * 128u * 128u)
+__device__ __forceinline__ u32 dirBin(const D3& sensor, const D3& end)
+{
+	const double dx = end.x - sensor.x, dy = end.y - sensor.y, dz = end.z - sensor.z;
+	const double ax = fabs(dx), ay = fabs(dy), az = fabs(dz);
+	u32 face;
+	double m, a, b;
+	if (ax >= ay && ax >= az) {
+		face = dx < 0 ? 1u : 0u;
+		m = ax;
+		a = dy;
+		b = dz;
+	} else if (ay >= az) {
+		face = dy < 0 ? 3u : 2u;
+		m = ay;
+		a = dx;
+		b = dz;
+	} else {
+		face = dz < 0 ? 5u : 4u;
+		m = az;
+		a = dx;
+		b = dy;
+	}
+	if (!(m > 0)) return 0u;
+	const int ia = min(127, max(0, (int)((a / m + 1.0) * 64.0))), ib = min(127, max(0, (int)((b / m + 1.0) * 64.0)));
+	// (8 x 8 bins form a block of 64 consecutive numbers: neighbouring bins of a sparse scan -- a LiDAR's -- stay neighbours)
+	return face * 16384u + ((u32)(ib >> 3) * 16u + (u32)(ia >> 3)) * 64u + (u32)(ib & 7) * 8u + (u32)(ia & 7);
+}
+__global__ __launch_bounds__(256) void k_vbin_count(D3 sensor, const D3* __restrict__ ray_end, const ScanCtl* ctl_in, u32* __restrict__ bin_of, u32* __restrict__ hist)
+{
+	const u32 n = ctl_in->n_rays;
+	const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= n) return;
+	const u32 b = dirBin(sensor, ray_end[r]);
+	bin_of[r] = b;
+	atomicAdd(&hist[b], 1u);
+}
+// exclusive prefix over the bins (one workgroup of 1024 threads, 96 bins each)
+__global__ __launch_bounds__(1024) void k_vbin_scan(u32* __restrict__ hist)
+{
+	__shared__ u32 wsum[16];
+	constexpr u32 PER = UFO_VBINS / 1024u;
+	const u32 t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+	u32 loc = 0;
+	for (u32 k = 0; k < PER; ++k) loc += hist[t * PER + k];
+	u32 incl = loc;
+	for (int o = 1; o < 64; o <<= 1) {
+		const u32 v = __shfl_up(incl, o);
+		if ((int)lane >= o) incl += v;
+	}
+	if (63u == lane) wsum[wave] = incl;
+	__syncthreads();
+	u32 base = incl - loc;
+	for (u32 w = 0; w < wave; ++w) base += wsum[w];
+	for (u32 k = 0; k < PER; ++k) {
+		const u32 c = hist[t * PER + k];
+		hist[t * PER + k] = base;
+		base += c;
+	}
+}
+__global__ __launch_bounds__(256) void k_vbin_scatter(const ScanCtl* ctl_in, const u32* __restrict__ bin_of, u32* __restrict__ offs, u32* __restrict__ order)
+{
+	const u32 n = ctl_in->n_rays;
+	const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= n) return;
+	order[atomicAdd(&offs[bin_of[r]], 1u)] = r;
+}
+
 // The XCD this wave runs on (HW_REG_XCC_ID, bits 3:0). Waves that read the same value share one L2.
 __device__ __forceinline__ u32 xccId() { return (u32)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u; }
 
@@ -75,19 +149,65 @@ __device__ __forceinline__ u32 xccId() { return (u32)__builtin_amdgcn_s_getreg((
 // tile was marked in -- the per-XCD tile bitmaps say which -- and leaves them zeroed. Blocks are mapped to rays so that
 // (with the usual block b -> XCD b % 8 placement; speed only) an XCD takes one contiguous eighth of the cloud: neighbouring
 // rays share bricks, and a tile is marked in one or two copies, not eight.
+#define UFO_VWC 128u  // entries of a wave's write-combining table (k_vdda)
 __global__ __launch_bounds__(256) void k_vdda(MapGeom g, D3 sensor, Grid gr, VolGeo vg, u64* __restrict__ Mx, u32* __restrict__ tbx, const D3* __restrict__ ray_end,
-                                              const ScanCtl* ctl_in, ScanCtl* ctl, u32 mode)
+                                              const ScanCtl* ctl_in, ScanCtl* ctl, u32 mode, const u32* __restrict__ order)
 {
-	// (mode, a measuring aid: bit 0 = one copy for all XCDs, bit 1 = blocks take the rays in launch order)
+	// (mode, a measuring aid: bit 0 = one copy for all XCDs, bit 1 = blocks take the rays in launch order, bit 3 = no
+	// write-combining table; order == nullptr: the rays in the cloud's order)
+	// The wave's write-combining table: (brick word, bits) pairs on their way to the XCD's copy. A lane that leaves a brick ORs
+	// its bits into the brick's entry if there is one; else it takes the entry over and sends what was in it to the L2 -- the
+	// rays of a bundle enter and leave the same bricks within a few steps of one another, so most flushes end here.
+	__shared__ u32 wc_key[4][UFO_VWC];
+	__shared__ unsigned long long wc_mask[4][UFO_VWC];
+	const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+	const bool use_wc = 0 == (mode & 8u);
+	for (u32 k = lane; k < UFO_VWC; k += 64u) {
+		wc_key[wave][k] = 0xFFFFFFFFu;
+		wc_mask[wave][k] = 0ull;
+	}
 	const u32 n = ctl_in->n_rays;
 	const u32 per = gridDim.x >> 3;  // (the grid is a multiple of 8 blocks)
-	const u32 i = ((mode & 2u) ? blockIdx.x : ((blockIdx.x & 7u) * per + (blockIdx.x >> 3))) * blockDim.x + threadIdx.x;
+	u32 i = ((mode & 2u) ? blockIdx.x : ((blockIdx.x & 7u) * per + (blockIdx.x >> 3))) * blockDim.x + threadIdx.x;
+	const bool live = i < n;
+	if (live && order) i = order[i];
 	const u32 xcc = (mode & 1u) ? 0u : xccId();
 	u64* const M = Mx + (size_t)xcc * ((size_t)vg.ntiles * 8u);
 	u32* const tb = tbx + (size_t)xcc * (((size_t)vg.ntiles + 31u) >> 5);
+	// a lane's (word, bits) on its way out: through the table, or straight to the L2. Called by any subset of a wave's lanes at
+	// the same program point; LDS operations of one wave are executed in program order.
+	auto flush = [&](u32 w, u64 bits) {
+		if (!use_wc) {
+			__hip_atomic_fetch_or(&M[w], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			return;
+		}
+		const u32 slot = (w * 0x9E3779B1u) >> 25;  // 7 bits
+		const u32 k = wc_key[wave][slot];
+		const bool hit = k == w;
+		// 1. lanes whose brick holds the entry: their bits join it (before anybody takes the entry over, below)
+		if (hit) __hip_atomic_fetch_or(&wc_mask[wave][slot], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		u32 prev = k;
+		bool won = false;
+		// 2. the others try to take it over: one lane per entry wins ...
+		if (!hit) {
+			prev = atomicCAS(&wc_key[wave][slot], k, w);
+			won = prev == k;
+		}
+		// ... gets what was in it and sends that on its way
+		if (won) {
+			const u64 old = atomicExch(&wc_mask[wave][slot], (unsigned long long)bits);
+			if (k != 0xFFFFFFFFu && old) __hip_atomic_fetch_or(&M[k], old, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		}
+		// 3. who lost to a lane with the SAME brick joins the new entry (after the winner's exchange); who lost to another
+		// brick goes straight to the L2
+		if (!hit && !won) {
+			if (prev == w) __hip_atomic_fetch_or(&wc_mask[wave][slot], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			else __hip_atomic_fetch_or(&M[w], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		}
+	};
 	unsigned long long steps = 0;
 	u32 err = 0;
-	if (i < n) {
+	if (live) {
 		RayState r;
 		raySetup(g, sensor, 0u, gr, ray_end[i], r);
 		if (3 == r.status) {
@@ -95,7 +215,7 @@ __global__ __launch_bounds__(256) void k_vdda(MapGeom g, D3 sensor, Grid gr, Vol
 		} else if (1 == r.status) {
 			u32 w, b;
 			volWordBit(vg, (u32)(r.start[0] - vg.cbase[0]), (u32)(r.start[1] - vg.cbase[1]), (u32)(r.start[2] - vg.cbase[2]), &w, &b);
-			__hip_atomic_fetch_or(&M[w], 1ull << b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			flush(w, 1ull << b);
 			__hip_atomic_fetch_or(&tb[w >> 8], 1u << ((w >> 3) & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			steps = 1;
 		} else if (2 == r.status) {
@@ -116,7 +236,7 @@ __global__ __launch_bounds__(256) void k_vdda(MapGeom g, D3 sensor, Grid gr, Vol
 				const u32 w = tile * 8u + (((x >> 2) & 1u) | (((y >> 2) & 1u) << 1) | (((z >> 2) & 1u) << 2));
 				const u32 b = (x & 3u) | ((y & 3u) << 2) | ((z & 3u) << 4);
 				if (w != curw) {
-					if (acc) __hip_atomic_fetch_or(&M[curw], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+					if (acc) flush(curw, acc);
 					// (a new tile: its bit in the XCD's tile bitmap -- looked at first: bits only appear during this kernel, the CU's L1
 					// was invalidated when it started, and a stale 0 costs one more atomic; 6e7 atomics were 2 ms of this kernel)
 					if (((w ^ curw) >> 3) && !((tb[tile >> 5] >> (tile & 31u)) & 1u))
@@ -142,11 +262,18 @@ __global__ __launch_bounds__(256) void k_vdda(MapGeom g, D3 sensor, Grid gr, Vol
 				const bool more = (__double_as_longlong(tmx) <= idist) | (__double_as_longlong(tmy) <= idist) | (__double_as_longlong(tmz) <= idist);
 				go = (((x ^ gx) | (y ^ gy) | (z ^ gz)) != 0u) & more & (cnt < budget);
 			} while (go);
-			if (acc) __hip_atomic_fetch_or(&M[curw], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			if (acc) flush(curw, acc);
 			if (cnt >= budget) err |= ERR_RUNAWAY;
 			steps = cnt;
 		}
 	}
+	// what is left in the wave's table (all of its lanes are here: the loops above have ended for every one of them)
+	if (use_wc)
+		for (u32 k = lane; k < UFO_VWC; k += 64u) {
+			const u32 key = wc_key[wave][k];
+			const u64 bits = wc_mask[wave][k];
+			if (key != 0xFFFFFFFFu && bits) __hip_atomic_fetch_or(&M[key], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		}
 	waveAddU64(&ctl->n_steps, steps);
 	if (err) atomicOr(&ctl->err, err);
 }
