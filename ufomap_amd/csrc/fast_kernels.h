@@ -1321,11 +1321,26 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 			}
 		}
 	}
-	u32 s1 = tableFind(t, lk1);
-	u32 sx = NONE;  // lanes 0..7: the level-2 block of group `lane`; lane 8: the level-3 block
-	if (lane < 8u) sx = tableFind(t, (lk3 << 3) | (u64)lane);
-	else if (8u == lane) sx = tableFind(t, lk3);
-	u32 s3 = __shfl(sx, 8), s2 = __shfl(sx, (int)c2);
+	// Tile-major table (table.h): ONE probe of the tile directory; the 73 slots follow from the group, and whether a block is
+	// there is read off the key that arrives with its record -- the records are asked for right after the probe, no round trip
+	// for the keys of their own. (Maps of fewer than four levels have no groups: the blocks one by one.)
+	const bool grouped = t.L >= 4u;
+	u32 s1 = NONE, s2 = NONE, s3 = NONE;
+	if (grouped) {
+		const u32 grp = groupFind(t, lk3);
+		if (grp != NONE) {
+			s1 = groupSlot(t, grp, lane);
+			s2 = groupSlot(t, grp, 64u + c2);
+			s3 = groupSlot(t, grp, 72u);
+		}
+	} else {
+		s1 = tableFind(t, lk1);
+		u32 sx = NONE;  // lanes 0..7: the level-2 block of group `lane`; lane 8: the level-3 block
+		if (lane < 8u) sx = tableFind(t, (lk3 << 3) | (u64)lane);
+		else if (8u == lane) sx = tableFind(t, lk3);
+		s3 = __shfl(sx, 8);
+		s2 = __shfl(sx, (int)c2);
+	}
 	const bool uactive = 0 != (mmA | mmB);                 // the lane's block is touched by some scan of the batch
 	const u32 uact2 = grpOr(uactive ? 1u : 0u, 0);         // ... its level-2 group is
 	// ---- round 2: the records as they are stored (a block found DEAD was collapsed: the node is a leaf, octree.h:1060-1066;
@@ -1335,17 +1350,21 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 	float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 	u32 r2l = 0, r1l = 0;  // COLOR: the colours beside v2l, v1l, v[]
 	u32 col[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	u64 k3 = lk3, k2 = lk2, k1 = lk1;  // the keys the slots hold (grouped tables: a slot of the group may be empty)
 	if (s3 != NONE) {
+		if (grouped) k3 = t.key(s3);
 		fl3r = t.flags(s3);
 		v2l = t.occ(s3)[c2];
 		if (COLOR) r2l = t.rgb[8 * (size_t)s3 + c2];
 	}
 	if (s2 != NONE && uact2) {
+		if (grouped) k2 = t.key(s2);
 		fl2r = t.flags(s2);
 		v1l = t.occ(s2)[c1];
 		if (COLOR) r1l = t.rgb[8 * (size_t)s2 + c1];
 	}
 	if (s1 != NONE && uactive) {
+		if (grouped) k1 = t.key(s1);
 		fl1r = t.flags(s1);
 		const float4* po = reinterpret_cast<const float4*>(t.occ(s1));
 		const float4 ra = po[0], rb = po[1];
@@ -1356,6 +1375,30 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 			const uint4 ca = pc[0], cb = pc[1];
 			col[0] = ca.x; col[1] = ca.y; col[2] = ca.z; col[3] = ca.w;
 			col[4] = cb.x; col[5] = cb.y; col[6] = cb.z; col[7] = cb.w;
+		}
+	}
+	if (grouped) {
+		// a slot whose key is not the block's: the block is not there (what was read from the slot is not its record)
+		if (s3 != NONE && k3 != lk3) {
+			s3 = NONE;
+			fl3r = F_DEAD;
+			v2l = 0.f;
+			r2l = 0;
+		}
+		if (s2 != NONE && uact2 && k2 != lk2) {
+			s2 = NONE;
+			fl2r = F_DEAD;
+			v1l = 0.f;
+			r1l = 0;
+		}
+		if (s1 != NONE && uactive && k1 != lk1) {
+			s1 = NONE;
+			fl1r = F_DEAD;
+#pragma unroll
+			for (int c = 0; c < 8; ++c) {
+				v[c] = 0.f;
+				col[c] = 0;
+			}
 		}
 	}
 	// ---- round 3: createNode for what is missing from the table (octree.h:997-1016); a level-3 block that is not live
