@@ -1218,7 +1218,7 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 	if (VOL && recs[tile].seq == scan_id) return;  // (a repeat after the table has grown: the tile is done)
 	__builtin_amdgcn_s_setprio(2);  // (the map stream is the pipeline's critical path: ahead of the ray kernel's waves)
 	const Pipe::Slot sl = p->slot[f & (UFO_RING - 1u)];
-	const u32 B = sl.B;  // (0: the slot's scan went with an earlier walk)
+	const u32 B = VOL ? 1u : sl.B;  // (0: the slot's scan went with an earlier walk; the volume path: one scan per walk, known at compile time)
 #define UFO_DESC(b) (p->ring[(sl.first + (b)) & (UFO_RING - 1u)])
 	// words that can end the wave here are asked for together (a wave's time is its chain of dependent round trips):
 	// the walk enqueued just before this one flagged itself and left the map alone (this one stands back too, k_ftail

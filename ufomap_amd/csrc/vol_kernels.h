@@ -149,7 +149,7 @@ __device__ __forceinline__ u32 xccId() { return (u32)__builtin_amdgcn_s_getreg((
 // tile was marked in -- the per-XCD tile bitmaps say which -- and leaves them zeroed. Blocks are mapped to rays so that
 // (with the usual block b -> XCD b % 8 placement; speed only) an XCD takes one contiguous eighth of the cloud: neighbouring
 // rays share bricks, and a tile is marked in one or two copies, not eight.
-#define UFO_VWC 128u  // entries of a wave's write-combining table (k_vdda)
+#define UFO_VWC 256u  // entries of a wave's write-combining table (k_vdda)
 __global__ __launch_bounds__(256) void k_vdda(MapGeom g, D3 sensor, Grid gr, VolGeo vg, u64* __restrict__ Mx, u32* __restrict__ tbx, const D3* __restrict__ ray_end,
                                               const ScanCtl* ctl_in, ScanCtl* ctl, u32 mode, const u32* __restrict__ order)
 {
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void k_vdda(MapGeom g, D3 sensor, Grid gr, Vol
 			__hip_atomic_fetch_or(&M[w], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			return;
 		}
-		const u32 slot = (w * 0x9E3779B1u) >> 25;  // 7 bits
+		const u32 slot = (w * 0x9E3779B1u) >> 24;  // 8 bits
 		const u32 k = wc_key[wave][slot];
 		const bool hit = k == w;
 		// 1. lanes whose brick holds the entry: their bits join it (before anybody takes the entry over, below)
