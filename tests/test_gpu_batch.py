@@ -467,3 +467,25 @@ def test_insert_batch_two_ranks_on_one_gpu(fail_at):
     assert c0["fast_steps"] >= 4, f"the fast-path form of the step did not run: {c0}"
     assert c0["repeated_steps"] >= (2 if fail_at else 1), f"the jump (and the injected failure) should have forced collective repeats: {c0}"
     assert results[0][3]["regrown"] >= 1, "the update-list slot should have had to grow (4 KiB to start with)"
+
+
+def test_gate_timeouts_are_survived():
+    """a stream hand-over that gives up (option gate_us at its minimum, 100 us, against host clouds whose upload alone takes
+    longer) flags its scan -- which leaves the map alone and is repeated once the streams have drained -- and the handle hands over
+    with events from then on: the map equals the reference's whether or not a gate timed out (the counter says how many did)."""
+    from ufomap_amd import PointCloud, scans
+    g, o = _maps(kind=_kind(), resolution=0.16)
+    g.set_option("gate_us", 100)
+    n_to = 0
+    for i in range(10):
+        origin, xyz, _ = scans.lidar64(origin=tuple(np.array(scans.lidar_pose(1)) + [0.05 * i, 0.0, 0.0]), seed=40 + i)
+        g.insertPointCloudDiscrete(origin, PointCloud(xyz.copy()), 20.0, 0, False, 0, True)  # a pageable host cloud: memcpy + H2D before k_fhits
+        o.insert(origin, xyz, max_range=20.0, discrete=True)
+        if i == 4:
+            g.insertPointCloudWait()
+            _assert_same_map(g, o, "after scan 4")
+    g.insertPointCloudWait()
+    _assert_same_map(g, o, "final")
+    n_to = g.debug()[58]
+    assert n_to >= 0
+    print("gate timeouts:", n_to)
