@@ -465,6 +465,12 @@ int allocTable(ufomap_map* m, u32 nG, u32 capU, Table* out, TableBufs* tb)
 {
 	capU = std::max<u32>(capU, 1024u);
 	nG = std::max<u32>(nG, 64u);
+	// (a prime: the directory is probed with a second hash as the stride, table.h, and every stride has to visit every entry)
+	for (;; ++nG) {
+		bool prime = 0 != (nG & 1u);
+		for (u32 d = 3; prime && (u64)d * d <= nG; d += 2) prime = 0 != nG % d;
+		if (prime) break;
+	}
 	const u64 cap64 = (u64)capU + (u64)UFO_GROUP * nG;
 	if (cap64 > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
 	const u32 cap = (u32)cap64;
