@@ -489,3 +489,58 @@ def test_gate_timeouts_are_survived():
     n_to = g.debug()[58]
     assert n_to >= 0
     print("gate timeouts:", n_to)
+
+
+def _replicated_world(world, steps, out_q, shim):
+    """One process plays all `world` ranks (tests/cpp/rccl_shim.cpp, UFOMAP_SHIM_REPLICATE: every slot of an all-gather is a copy of the
+    caller's): a step applies this rank's scan `world` times, in order."""
+    import os
+    os.environ["UFOMAP_RCCL_LIB"] = shim
+    os.environ["UFOMAP_SHIM_REPLICATE"] = "1"
+    import torch as th
+    from ufomap_amd import OccupancyMap, scans
+    from ufomap_amd.occupancy_map import Comm
+    try:
+        g = OccupancyMap(0.16)
+        g.set_option("async_apply", 1)
+        comm = Comm(Comm.unique_id(), world, 0, 0)
+        keep = []
+        for i in range(steps):
+            origin, xyz, _ = scans.lidar64(beams=16, azimuths=256, origin=tuple(np.array(scans.lidar_pose(1)) + [0.04 * i, 0.0, 0.0]), seed=70 + i)
+            d = th.from_numpy(np.ascontiguousarray(xyz)).cuda()
+            keep.append(d)
+            g.insert_batch(comm, origin, d.data_ptr(), len(xyz), 10.0, 0, True)
+        g.insertPointCloudWait()
+        out_q.put((g.digest(), comm.counters()))
+        comm.close()
+    except Exception as e:  # noqa: BLE001
+        out_q.put(("error: " + repr(e), None))
+
+
+@pytest.mark.parametrize("world", [16, 17])
+def test_insert_batch_form_by_world_size(world):
+    """one walk takes at most UFO_BATCH_MAX = 16 scans, so a communicator of more ranks must not take the bit-grid
+    form (several walks per step would each look at their own chunk's flags only). 16 ranks: bit-grid steps; 17: the update-list form
+    throughout -- either way the replica equals the reference integrating every step's scan `world` times."""
+    import torch.multiprocessing as mp
+    from ufomap_amd import scans
+    steps = 6
+    ctx = mp.get_context("spawn")
+    out_q = ctx.Queue()
+    p = ctx.Process(target=_replicated_world, args=(world, steps, out_q, _build_shim()))
+    p.start()
+    dig, counters = out_q.get(timeout=300)
+    p.join(timeout=60)
+    assert not isinstance(dig, str), dig
+    from oracle import OracleMap
+    import golden_util
+    o = OracleMap(0.16, kind=_kind())
+    for i in range(steps):
+        origin, xyz, _ = scans.lidar64(beams=16, azimuths=256, origin=tuple(np.array(scans.lidar_pose(1)) + [0.04 * i, 0.0, 0.0]), seed=70 + i)
+        for _ in range(world):
+            o.insert(origin, xyz, max_range=10.0, discrete=True)
+    assert tuple(dig) == tuple(golden_util.dump_digest(o.leaves(True), o.inner())), "the replica differs from the sequential map"
+    if world > 16:
+        assert counters["fast_steps"] == 0, f"a step of {world} ranks took the bit-grid form: {counters}"
+    else:
+        assert counters["fast_steps"] >= 2, f"no bit-grid step with {world} ranks: {counters}"
