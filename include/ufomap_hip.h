@@ -335,7 +335,15 @@ int ufomap_map_insert_batch(ufomap_map* m, ufomap_comm* c, const double sensor_o
  * this long and the handle uses events from then on; default 20000), "cast_global" (0: grids
  * beyond LDS through k_dda_seg instead of k_cast<2>; 2-4: force the box / filter variants on small grids), "sparse_set"
  * (1: every scan's ray cells through the sparse set), "phase_limit" / "scan_id" (when the per-phase tags restart),
- * "async_apply" (apply_keys_batch / insert_batch return after enqueueing). Results never depend on these. */
+ * "async_apply" (apply_keys_batch / insert_batch return after enqueueing); round 4: "vol" (0: depth-0 scans whose ray box is
+ * beyond the steady-state path -- a 2 mm RGB-D frame -- keep to the general path instead of the volume path of vol_kernels.h;
+ * 2: the volume path also for boxes the steady-state path would take), "vol_pregrow" (0: no growth of the node table before a
+ * volume-path walk: it runs out of its reserve and the table is exchanged in the middle of the walk), "vol_keep" (0: the merged
+ * ray cells of a volume-path scan are not kept for ufomap_map_last_misses), "vol_mode" (A/B switches of its ray kernel: bit 0 one
+ * copy of the brick grid for all XCDs, bit 1 blocks in launch order, bit 2 rays in the cloud's order, bit 3 no write-combining
+ * table), "fast_simple" (0: fixed-step ray casting keeps to the general path), "gather_stream" (1: the all-gather of a batch step on
+ * a stream of its own), "fail_scan" (test aid: the scan half of the next batch steps fails on this rank before the collective).
+ * Results never depend on these. */
 int ufomap_map_set_option(ufomap_map* m, const char* key, long long value);
 /* Diagnostics: std::exp(float) as the device evaluates it inside toProb (occupancy_map_base.h:911 with LogitType = float;
  * ufomap_amd/csrc/expf_ref.h), on n host values. tests/: equal to the host's libm expf, which is what the reference calls. */
