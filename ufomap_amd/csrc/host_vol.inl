@@ -132,6 +132,12 @@ int volScan(ufomap_map* m, const D3& sensor, const VolPlan& vp, u32 n_hits, u32 
 	}
 	const int erc = ctlError(m);
 	if (erc) return erc;
+	if (0 == m->vol_count) {
+		// (no ray cell was marked -- cannot happen with n_rays > 0, but a walk over no tiles is not a launch: the general path)
+		++m->n_vol_fallback;
+		HIP_TRY(hipMemsetAsync(&ctl->n_steps, 0, 8, m->cs));
+		return 1;
+	}
 	m->vplan = vp;
 	m->vol = true;
 	++m->n_vol;
