@@ -105,3 +105,16 @@ def test_header_is_plain_c(tmp_path):
     # (without a GPU the program reports that and exits 0; with one it runs a world-1 batch step)
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_cxx_bench_loop_builds_and_fails_loudly_without_a_device(lib):
+    """examples/bench_loop.cpp (bench.py's leg "host_cxx": the headline loop driven from C++ through the C ABI) links against the
+    in-tree library; without a HIP device it ends with an error code instead of pretending to measure anything."""
+    import subprocess
+    from ufomap_amd import build
+    exe = build.build_bench_loop(verbose=False)
+    assert os.path.exists(exe)
+    if lib.ufomap_device_count() > 0:
+        pytest.skip("a HIP device is present: the bench runs the loop")
+    r = subprocess.run([exe, "/nonexistent", "1", "1", "0.01", "0"], capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0
