@@ -1193,6 +1193,8 @@ __device__ inline bool tileKey(const MapGeom& g, const FastGeo& fg, u32 tile, u6
 // Blocks are created against a reserve (sharded counters): a tile that finds it used up has not written anything yet,
 // flags ERR_GROW and stands back -- the host grows the table and runs the tiles that are left (their records do not carry
 // the walk's number yet).
+// 64-bit words of one XCD's copy of the brick grid: whole 256-byte pieces, so that no cache line holds words of two copies
+__host__ __device__ inline size_t volCopyWords(u32 ntiles) { return ((size_t)ntiles * 8u + 31u) & ~(size_t)31u; }
 struct TileVol {
 	u64* Mx;               // ray cells: eight copies, one per XCD (k_vdda); read, ORed and left zeroed here
 	u64* Mm;               // ... the tile's merged words, for whoever asks for the scan's ray cells afterwards (may be null)
@@ -1256,7 +1258,7 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 		// the lane's 2x2x2 cells inside their brick: bits vsh + cx + 4 cy + 16 cz
 		u64 mword = 0;
 		{
-			const size_t cstride = (size_t)fg.ntiles * 8u;
+			const size_t cstride = volCopyWords(fg.ntiles);
 			u64 cw[8];
 #pragma unroll
 			for (int k = 0; k < 8; ++k) cw[k] = ((vcopies >> k) & 1u) ? va.Mx[(size_t)k * cstride + (size_t)tile * 8u + vbrick] : 0ull;  // (uniform: in flight together)
@@ -1717,7 +1719,7 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 	}
 	if (VOL && 0 == vsh) {
 		// (the brick's first lane: the scan's words are consumed -- the copies and H are clean for the next scan)
-		const size_t cstride = (size_t)fg.ntiles * 8u;
+		const size_t cstride = volCopyWords(fg.ntiles);
 		u64 mword = 0;
 #pragma unroll
 		for (int k = 0; k < 8; ++k)

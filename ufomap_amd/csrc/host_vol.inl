@@ -66,9 +66,9 @@ bool volPlan(const ufomap_map* m, const Grid& gr, unsigned depth, int simple, un
 int volScan(ufomap_map* m, const D3& sensor, const VolPlan& vp, u32 n_hits, u32 n_rays)
 {
 	const u64 nt = vp.vg.ntiles;
-	const size_t tbw = (size_t)((nt + 31) >> 5);
+	const size_t tbw = (size_t)volTbWords((u32)nt);
 	const size_t cm = m->b_vM.cap, ch = m->b_vH.cap, cr = m->b_vrec.cap, ct = m->b_vtb.cap;
-	HIP_TRY(m->b_vM.reserve(nt * 64 * 8));
+	HIP_TRY(m->b_vM.reserve(volCopyWords((u32)nt) * 8 * 8));  // (eight copies, each in whole 256-byte pieces)
 	HIP_TRY(m->b_vMm.reserve(nt * 64));
 	HIP_TRY(m->b_vH.reserve(nt * 64));
 	HIP_TRY(m->b_vtb.reserve(tbw * 4 * 8));

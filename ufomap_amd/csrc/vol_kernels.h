@@ -39,6 +39,10 @@ struct VolPlan {
 	VolGeo vg{};
 };
 
+// words of one XCD's tile bitmap: whole 256-byte pieces, so that no cache line holds bits of two XCDs (each XCD's atomics stay in
+// its own L2 until the kernel ends)
+__host__ __device__ inline u32 volTbWords(u32 ntiles) { return (((ntiles + 31u) >> 5) + 63u) & ~63u; }
+
 __device__ __forceinline__ void volWordBit(const VolGeo& vg, u32 x, u32 y, u32 z, u32* word, u32* bit)
 {
 	const u32 tile = ((z >> 3) * vg.nt[1] + (y >> 3)) * vg.nt[0] + (x >> 3);
@@ -172,8 +176,8 @@ __global__ __launch_bounds__(256) void k_vdda(MapGeom g, D3 sensor, Grid gr, Vol
 	const bool live = i < n;
 	if (live && order) i = order[i];
 	const u32 xcc = (mode & 1u) ? 0u : xccId();
-	u64* const M = Mx + (size_t)xcc * ((size_t)vg.ntiles * 8u);
-	u32* const tb = tbx + (size_t)xcc * (((size_t)vg.ntiles + 31u) >> 5);
+	u64* const M = Mx + (size_t)xcc * volCopyWords(vg.ntiles);
+	u32* const tb = tbx + (size_t)xcc * (size_t)volTbWords(vg.ntiles);
 	// a lane's (word, bits) on its way out: through the table, or straight to the L2. Called by any subset of a wave's lanes at
 	// the same program point; LDS operations of one wave are executed in program order.
 	auto flush = [&](u32 w, u64 bits) {
@@ -282,7 +286,7 @@ __global__ __launch_bounds__(256) void k_vdda(MapGeom g, D3 sensor, Grid gr, Vol
 // the bitmaps (32 tiles); count in *n_out.
 __global__ __launch_bounds__(256) void k_vlist(u32* __restrict__ tbx, u32 ntiles, u32* __restrict__ list, uint8_t* __restrict__ copies, u32* n_out)
 {
-	const u32 nwords = (ntiles + 31u) >> 5;
+	const u32 nwords = volTbWords(ntiles);  // (the padding words are never marked)
 	for (u32 w0 = blockIdx.x * blockDim.x; w0 < nwords; w0 += gridDim.x * blockDim.x) {  // (uniform)
 		const u32 w = w0 + threadIdx.x;
 		u32 c[8], any = 0;
@@ -322,7 +326,7 @@ __global__ __launch_bounds__(256) void k_vcount(const u64* __restrict__ Mx, u32 
 		while (cm) {
 			const u32 k = (u32)__ffs(cm) - 1u;
 			cm &= cm - 1u;
-			m |= Mx[(size_t)k * ((size_t)ntiles * 8u) + (size_t)tile * 8u + br];
+			m |= Mx[(size_t)k * volCopyWords(ntiles) + (size_t)tile * 8u + br];
 		}
 		// a 2x2x2 block of the brick holds a mark: fold x pairs, y pairs, z pairs onto the block's first cell
 		u64 f = m | (m >> 1);
