@@ -59,7 +59,8 @@ def test_volume_path_scan_by_scan(discrete, res):
     g, o = _maps(kind=_kind(), resolution=res)
     _, p = _maps(kind="port", resolution=res)
     _force_vol(g)
-    for i, (origin, xyz) in enumerate(_wander(14)):
+    n_scans = 9 if res >= 0.16 else 6  # (the CPU checkers set this test's duration)
+    for i, (origin, xyz) in enumerate(_wander(n_scans)):
         _insert(g, origin, xyz, 12.0, discrete, async_=bool(i & 1))
         o.insert(origin, xyz, max_range=12.0, discrete=discrete)
         p.insert(origin, xyz, max_range=12.0, discrete=discrete)
@@ -67,10 +68,10 @@ def test_volume_path_scan_by_scan(discrete, res):
         assert np.array_equal(g.last_hits(), p.last_hits()), f"scan {i}: hit voxels differ"
         assert np.array_equal(g.last_misses(), p.last_misses()), f"scan {i}: ray cells differ"
         assert g.last_counts()["steps"] == p.last_steps(), f"scan {i}: DDA step count differs"
-        if i in (0, 1, 5, 13):
+        if i in (0, 1, 5, n_scans - 1):
             _assert_same_map(g, o, f"after scan {i}")
     d = g.debug()
-    assert d[50] == 14 and d[61] == 0, f"the scans did not take the volume path: {d[48:51]}, fast {d[61]}"
+    assert d[50] == n_scans and d[61] == 0, f"the scans did not take the volume path: {d[48:51]}, fast {d[61]}"
 
 
 def test_volume_path_saturation_and_pruning():
@@ -81,13 +82,13 @@ def test_volume_path_saturation_and_pruning():
     _force_vol(g)
     poses = [scans.lidar_pose(0), tuple(np.array(scans.lidar_pose(0)) + [0.35, -0.2, 0.0])]
     clouds = [scans.lidar64(beams=32, azimuths=512, origin=p, seed=7 + k)[:2] for k, p in enumerate(poses)]
-    for i in range(22):
+    for i in range(16):
         origin, xyz = clouds[i & 1]
         _insert(g, origin, xyz, 8.0, True)
         o.insert(origin, xyz, max_range=8.0, discrete=True)
-        if i in (1, 9, 21):
+        if i in (1, 9, 15):
             _assert_same_map(g, o, f"after scan {i}")
-    assert g.debug()[50] == 22
+    assert g.debug()[50] == 16
 
 
 def test_volume_path_grows_the_table_in_the_middle_of_a_walk():
