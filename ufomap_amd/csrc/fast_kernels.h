@@ -1195,6 +1195,8 @@ __device__ inline bool tileKey(const MapGeom& g, const FastGeo& fg, u32 tile, u6
 // the walk's number yet).
 // 64-bit words of one XCD's copy of the brick grid: whole 256-byte pieces, so that no cache line holds words of two copies
 __host__ __device__ inline size_t volCopyWords(u32 ntiles) { return ((size_t)ntiles * 8u + 31u) & ~(size_t)31u; }
+#define UFO_UPCNT_STRIDE 32u  // 32-bit words between two of k_up's pairs of counters (volume path; 64 pairs)
+#define UFO_UPCNT_WORDS (64u * UFO_UPCNT_STRIDE)
 struct TileVol {
 	u64* Mx;               // ray cells: eight copies, one per XCD (k_vdda); read, ORed and left zeroed here
 	u64* Mm;               // ... the tile's merged words, for whoever asks for the scan's ray cells afterwards (may be null)
@@ -1799,7 +1801,8 @@ __device__ inline u32 upperCellAt(const UpperLevel& u, u32 off, const i32 c[3])
 // ------------------------------------------------------------------------------------------------
 template <bool COLOR>
 __global__ __launch_bounds__(256) void k_up(Table t, MapGeom g, FastGeo fg, const Pipe* __restrict__ p, unsigned long long f, const TileRec* __restrict__ recs,
-                                            TileRec* __restrict__ recs_up, u32* __restrict__ up_bits, u32 scan_id, const u32* __restrict__ prev_stat)
+                                            TileRec* __restrict__ recs_up, u32* __restrict__ up_bits, u32 scan_id, const u32* __restrict__ prev_stat,
+                                            u32* __restrict__ up_cnt = nullptr)
 {
 	const Pipe::Slot sl = p->slot[f & (UFO_RING - 1u)];
 	const u32 B = sl.B;
@@ -1951,10 +1954,18 @@ __global__ __launch_bounds__(256) void k_up(Table t, MapGeom g, FastGeo fg, cons
 		created += __shfl_xor(created, o);
 	}
 	if (0 == lane) {
-		if (touched) atomicAdd(&ctl->n_entries[0], touched);
-		if (created) {
-			atomicAdd(&t.root->used, created);
-			atomicAdd(&ctl->ph[0].n_new, created);
+		if (up_cnt) {
+			// (the volume path: tens of thousands of waves per launch have something to report, and one word takes an atomic every
+			// ~12 ns however many are in flight -- 64 pairs of counters, 128 bytes apart, folded into the control block by k_ftail)
+			u32* q = up_cnt + UFO_UPCNT_STRIDE * (blockIdx.x & 63u);
+			if (touched) atomicAdd(q, touched);
+			if (created) atomicAdd(q + 1, created);
+		} else {
+			if (touched) atomicAdd(&ctl->n_entries[0], touched);
+			if (created) {
+				atomicAdd(&t.root->used, created);
+				atomicAdd(&ctl->ph[0].n_new, created);
+			}
 		}
 	}
 }
@@ -1964,7 +1975,7 @@ static_assert(UFO_FTAIL_THREADS == UFO_UPPER_MAX, "k_ftail: one thread per cell 
 template <bool COLOR>
 __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g, FastGeo fg, Pipe* __restrict__ p, unsigned long long f,
                                                              const TileRec* __restrict__ recs, u32 scan_id, const u32* __restrict__ prev_stat,
-                                                             const ScanCtl* ctl_init, u32* __restrict__ up_bits, u32 nwords3)
+                                                             const ScanCtl* ctl_init, u32* __restrict__ up_bits, u32 nwords3, u32* __restrict__ up_cnt = nullptr)
 {
 	// (fg.tl = 3: the tiles are k_tile's, their activity bitmap the union of the scans' tile bitmaps. fg.tl = 4, ray grids
 	// beyond LDS: the "tiles" are the level-4 blocks k_up has evaluated, fg describes THEIR grid, up_bits is their activity
@@ -2249,6 +2260,18 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 		if (0 == lane) {
 			if (my_touched) atomicAdd(&ctl->n_entries[0], my_touched);
 			if (my_created) atomicAdd(&created_total, my_created);
+		}
+	}
+	if (up_cnt && threadIdx.x < 64u) {
+		// what the volume path's k_up launches counted (64 pairs of counters): read, left at zero for the next walk
+		u32 a = atomicExch(&up_cnt[UFO_UPCNT_STRIDE * lane], 0u), b = atomicExch(&up_cnt[UFO_UPCNT_STRIDE * lane + 1u], 0u);
+		for (int o = 32; o > 0; o >>= 1) {
+			a += __shfl_xor(a, o);
+			b += __shfl_xor(b, o);
+		}
+		if (0 == lane) {
+			if (a) atomicAdd(&ctl->n_entries[0], a);
+			if (b) atomicAdd(&created_total, b);
 		}
 	}
 	__syncthreads();

@@ -1,6 +1,11 @@
 // host side of the volume path (vol_kernels.h): eligibility and the tile grids of the levels, the scan half (volScan, called by
 // scanPhase once the boxes are known) and the tree update (volMapPhase). Included by ufomap_hip.hip inside its anonymous namespace.
 
+// b_vaux, 32-bit words: [0..63] the reserve's counters, [64] tiles listed, [65] tiles done, [66..67] blocks the listed tiles touch,
+// from UFO_VAUX_UPCNT on k_up's 64 pairs of counters (blocks touched / created above the tiles; k_ftail folds and clears them)
+#define UFO_VAUX_UPCNT 256u
+#define UFO_VAUX_BYTES ((UFO_VAUX_UPCNT + UFO_UPCNT_WORDS) * 4u)
+
 // the grid of the level above fg's (what k_up writes when fg is what it reads)
 FastGeo upGeoOf(const FastGeo& fg)
 {
@@ -75,7 +80,7 @@ int volScan(ufomap_map* m, const D3& sensor, const VolPlan& vp, u32 n_hits, u32 
 	HIP_TRY(m->b_vlist.reserve(nt * 4));
 	HIP_TRY(m->b_vcopies.reserve(nt));
 	HIP_TRY(m->b_vrec.reserve(vp.rec_total * sizeof(TileRec)));
-	HIP_TRY(m->b_vaux.reserve(1024));
+	HIP_TRY(m->b_vaux.reserve(UFO_VAUX_BYTES));
 	HIP_TRY(m->b_vupbits.reserve(UFO_FAST_MAX_TILES / 8));
 	if (cm != m->b_vM.cap || ch != m->b_vH.cap || ct != m->b_vtb.cap) m->vol_dirty = true;
 	// (a different tile grid: what an aborted walk may have left marked lies elsewhere -- and a clean walk leaves nothing)
@@ -87,7 +92,7 @@ int volScan(ufomap_map* m, const D3& sensor, const VolPlan& vp, u32 n_hits, u32 
 		HIP_TRY(hipMemsetAsync(m->b_vtb.p, 0, m->b_vtb.cap, m->cs));
 	}
 	m->vol_dirty = true;  // (until the tree update has left the grids clean)
-	HIP_TRY(hipMemsetAsync(m->b_vaux.p, 0, 1024, m->cs));
+	HIP_TRY(hipMemsetAsync(m->b_vaux.p, 0, UFO_VAUX_BYTES, m->cs));
 	HIP_TRY(hipMemsetAsync(m->b_vupbits.p, 0, m->b_vupbits.cap, m->cs));
 	ScanCtl* ctl = m->b_ctl.as<ScanCtl>();
 	u32* aux = m->b_vaux.as<u32>();  // [0..63] the reserve's counters, [64] tiles listed, [65] tiles done, [66..67] blocks the listed tiles touch
@@ -232,13 +237,13 @@ int volMapPhase(ufomap_map* m)
 			TileRec* above = below + vp.lv[k - 1].ntiles;
 			ProfScope ps(m, "k_up");
 			hipLaunchKernelGGL(k_up<false>, dim3((u32)(((u64)vp.lv[k].ntiles * 8u + 255u) / 256u)), dim3(256), 0, m->stream, m->t, m->g, vp.lv[k - 1], pipe, 0ull, below,
-			                   above, (k + 1 == vp.n) ? m->b_vupbits.as<u32>() : (u32*)nullptr, m->scan_id, (const u32*)nullptr);
+			                   above, (k + 1 == vp.n) ? m->b_vupbits.as<u32>() : (u32*)nullptr, m->scan_id, (const u32*)nullptr, aux + UFO_VAUX_UPCNT);
 			below = above;
 		}
 		{
 			ProfScope ps(m, "k_ftail");
 			hipLaunchKernelGGL(k_ftail<false>, dim3(1), dim3(UFO_FTAIL_THREADS), 0, m->stream, m->t, m->g, vp.lv[vp.n - 1], pipe, 0ull, below, m->scan_id, (const u32*)nullptr,
-			                   m->b_ctl_init.as<ScanCtl>(), m->b_vupbits.as<u32>(), 0u);
+			                   m->b_ctl_init.as<ScanCtl>(), m->b_vupbits.as<u32>(), 0u, aux + UFO_VAUX_UPCNT);
 		}
 		HIP_TRY(hipGetLastError());
 		HIP_TRY(hipStreamSynchronize(m->stream));
