@@ -727,40 +727,53 @@ struct CoarseRec {
 	u32 pad;
 };
 
-__device__ inline void visitPush(u32 slot, u32* __restrict__ dlist, u32 dcap, ScanCtl* ctl)
-{
-	u32 pos = atomicAdd(&ctl->dl_total, 1u);
-	if (pos < dcap) dlist[pos] = slot;
-	else atomicOr(&ctl->err, ERR_TABLE_FULL);
-}
-
 __global__ __launch_bounds__(256) void k_coarse_begin(Table t, MapGeom g, const Entry* __restrict__ entries, const u32* n_entries_p,
                                                       const u32* __restrict__ ent_slot, float miss, CoarseRec* __restrict__ rec,
                                                       u32* __restrict__ dlist, u32 dcap, ScanCtl* ctl, ChangeLog cl)
 {
 	u32 n = *n_entries_p;
 	if (ctl->err) return;
-	for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-		Entry e = entries[i];
-		u32 s = ent_slot[i];
+	// (uniform trip count: the visit list is appended to once per wave and iteration -- a returning atomic on one hot word
+	// per expanded child was eight dependent round trips to the memory side per thread)
+	for (u32 i0 = blockIdx.x * blockDim.x; i0 < n; i0 += gridDim.x * blockDim.x) {
+		const u32 i = i0 + threadIdx.x;
+		const bool valid = i < n;
+		u32 cs[8];
+		u32 npush = 0;
+		Entry e{};
+		u32 s = NONE, f = 0;
+		if (valid) {
+			e = entries[i];
+			s = ent_slot[i];
+			f = t.flags(s);
+#pragma unroll
+			for (int c = 0; c < 8; ++c) {
+				cs[c] = NONE;
+				if (((e.miss >> c) & 1) && ((f >> (16 + c)) & 1u)) cs[c] = tableFindChild(t, s, e.lk, (u32)c);  // (the lookups in flight together)
+				npush += (cs[c] != NONE) ? 1u : 0u;
+			}
+		}
+		u32 pos = waveAppendN(&ctl->dl_total, npush);
+		if (!valid) continue;
 		u32 chg = 0;
 		CoarseRec r;
-		u32 f = t.flags(s);
 		r.old_flags = f;
 		r.leaf_trig = 0;
 		r.inner_mask = 0;
 		r.pad = 0;
 		u32 nf = f;
+#pragma unroll
 		for (int c = 0; c < 8; ++c) {
 			float* pv = t.occ(s) + c;
 			float v = *pv;
 			r.old_occ[c] = v;
 			if (!((e.miss >> c) & 1)) continue;
 			if ((f >> (16 + c)) & 1u) {
-				u32 cs = tableFindChild(t, s, e.lk, (u32)c);
-				if (cs != NONE) {
+				if (cs[c] != NONE) {
 					r.inner_mask |= 1u << c;
-					visitPush(cs, dlist, dcap, ctl);
+					if (pos < dcap) dlist[pos] = cs[c];
+					else atomicOr(&ctl->err, ERR_TABLE_FULL);
+					++pos;
 				}
 			} else {
 				float nv = clampAdd(v, miss, g.cmin, g.cmax);
@@ -791,10 +804,27 @@ __global__ __launch_bounds__(256) void k_coarse_down(Table t, MapGeom g, u32 lev
 {
 	if (ctl->err) return;
 	const u32 lo = ctl->dl_start[level + 1], hi = min(ctl->dl_start[level], dcap);
-	for (u32 i = lo + blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += gridDim.x * blockDim.x) {
-		const u32 s = dlist[i];
-		const u64 lk = t.key(s);
-		const u32 f = t.flags(s);
+	for (u32 i0 = lo + blockIdx.x * blockDim.x; i0 < hi; i0 += gridDim.x * blockDim.x) {  // (uniform: one append per wave and iteration, see k_coarse_begin)
+		const u32 i = i0 + threadIdx.x;
+		const bool valid = i < hi;
+		u32 s = NONE, f = 0;
+		u64 lk = 0;
+		u32 cs[8];
+		u32 npush = 0;
+		if (valid) {
+			s = dlist[i];
+			lk = t.key(s);
+			f = t.flags(s);
+			if (level > 1) {
+#pragma unroll
+				for (int c = 0; c < 8; ++c) {
+					cs[c] = ((f >> (16 + c)) & 1u) ? tableFindChild(t, s, lk, (u32)c) : NONE;  // (the lookups in flight together)
+					npush += (cs[c] != NONE) ? 1u : 0u;
+				}
+			}
+		}
+		u32 pos = (level > 1) ? waveAppendN(&ctl->dl_total, npush) : 0u;
+		if (!valid) continue;
 		float4* po = reinterpret_cast<float4*>(t.occ(s));
 		float4 a = po[0], b = po[1];
 		float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
@@ -803,8 +833,11 @@ __global__ __launch_bounds__(256) void k_coarse_down(Table t, MapGeom g, u32 lev
 #pragma unroll
 		for (int c = 0; c < 8; ++c) {
 			if (level > 1 && ((f >> (16 + c)) & 1u)) {
-				u32 cs = tableFindChild(t, s, lk, (u32)c);
-				if (cs != NONE) visitPush(cs, dlist, dcap, ctl);
+				if (cs[c] != NONE) {
+					if (pos < dcap) dlist[pos] = cs[c];
+					else atomicOr(&ctl->err, ERR_TABLE_FULL);
+					++pos;
+				}
 				continue;
 			}
 			float nv = clampAdd(v[c], miss, g.cmin, g.cmax);
