@@ -146,6 +146,10 @@ def test_write_with_bounding_volume_min_depth_and_lz4(color):
         a, b = g.write_ex(aabb, True, 0, accel, level, header=False), o.write_ex(aabb, True, 0, accel, level, header=False)
         assert a == b, f"compressed aabb={aabb is not None} accel={accel} level={level}"
     assert g.write_ex(None, True, 1)[0] == o.write_ex(None, True, 1)[0]
+    # the same stream the long way (what maps beyond a million blocks take: the host sizes the list and the output between the passes)
+    g.set_option("ser_short", 0)
+    for aabb, min_depth in itertools.product(boxes[:3], [0, 2]):
+        assert g.write_ex(aabb, False, min_depth, header=False) == o.write_ex(aabb, False, min_depth, header=False), f"long way: aabb={aabb is not None} min_depth={min_depth}"
 
 
 @pytest.mark.parametrize("color", [False, True])

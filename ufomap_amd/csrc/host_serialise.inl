@@ -32,6 +32,11 @@ const Lz4& lz4()
 	return z;
 }
 
+// b_ser[0], 32-bit words: [0..31] live blocks per level, [32..63] first list entry per level, [96..97] the stream's length, [100..163]
+// the SerLevels the device-side kernels read, from UFO_SER_BLK_WORD on one row of 32 counts per workgroup of the listing kernels
+#define UFO_SER_BLK_WORD 256u
+#define UFO_SER_CNT_BYTES ((UFO_SER_BLK_WORD + 32u * UFO_SER_NB_MAX) * 4u)
+
 // The node stream without the host in the middle (map_kernels.h: k_ser_prefix ... k_ser_copy_out): one synchronisation.
 // Returns 1 when the long way has to be taken (a map too large for the bound, no live root block).
 int serialiseNodesShort(ufomap_map* m, const SerArgs& sa, std::vector<uint8_t>& data)
@@ -43,7 +48,7 @@ int serialiseNodesShort(ufomap_map* m, const SerArgs& sa, std::vector<uint8_t>& 
 	if (bound > (32ull << 20)) return 1;
 	DevBuf &b_cnt = m->b_ser[0], &b_list = m->b_ser[1], &b_size = m->b_ser[2], &b_off = m->b_ser[3], &b_out = m->b_ser[4];
 	const size_t ncap = (size_t)m->t.mask + 1;
-	HIP_TRY(b_cnt.reserve(3 * 32 * 4 + 16 + sizeof(SerLevels)));
+	HIP_TRY(b_cnt.reserve(UFO_SER_CNT_BYTES));
 	HIP_TRY(b_list.reserve(((size_t)m->used_est + 8) * 4));
 	HIP_TRY(b_size.reserve(ncap * 8));
 	HIP_TRY(b_off.reserve(ncap * 8));
@@ -65,11 +70,13 @@ int serialiseNodesShort(ufomap_map* m, const SerArgs& sa, std::vector<uint8_t>& 
 	static const bool trace = nullptr != getenv("UFOMAP_TRACE_SER");
 	const auto t0 = std::chrono::steady_clock::now();
 	HIP_TRY(hipMemsetAsync(b_cnt.p, 0, 3 * 32 * 4 + 16, st));
-	hipLaunchKernelGGL(k_ser_count, gridFor((u64)m->t.mask + 1), dim3(256), 0, st, m->t, m->g, d_cnt);
+	const u32 nsb = serBlocks(ncap);  // (the listing kernels: a contiguous share of the slots per workgroup, no atomics on device memory)
+	u32* d_blk = d_cnt + UFO_SER_BLK_WORD;
+	hipLaunchKernelGGL(k_ser_count, dim3(nsb), dim3(256), 0, st, m->t, m->g, d_blk);
 	const u32 list_cap = (u32)std::min<u64>(m->used_est + 8, 0xFFFFFFFFull);
-	hipLaunchKernelGGL(k_ser_prefix, dim3(1), dim3(64), 0, st, d_cnt, d_lv, list_cap);
+	hipLaunchKernelGGL(k_ser_prefix, dim3(1), dim3(1024), 0, st, d_cnt, d_lv, list_cap, d_blk, nsb);
 	HIP_TRY(hipMemsetAsync(b_off.p, 0xFF, ncap * 8, st));
-	hipLaunchKernelGGL(k_ser_collect, gridFor((u64)m->t.mask + 1), dim3(256), 0, st, m->t, m->g, d_cnt + 32, d_cnt + 64, b_list.as<u32>(), list_cap);
+	hipLaunchKernelGGL(k_ser_collect, dim3(nsb), dim3(256), 0, st, m->t, m->g, d_cnt + 32, d_blk, b_list.as<u32>(), list_cap);
 	const u32 first = std::max<u32>(1u, sa.min_depth + 1);  // blocks of nodes above min_depth
 	const u32 l_tail = std::min<u32>(first + 2u, L);        // the two widest levels: a launch each; the rest: one workgroup
 	for (u32 l = first; l < l_tail; ++l)
@@ -135,11 +142,15 @@ int serialiseNodes(ufomap_map* m, const SerArgs& sa, std::vector<uint8_t>& data)
 	MapRoot* h_root = reinterpret_cast<MapRoot*>(m->h_ser + 128);
 	unsigned long long* h_total = reinterpret_cast<unsigned long long*>(m->h_ser + 256);
 	u32 h_off[32] = {0};
-	HIP_TRY(b_cnt.reserve(3 * 32 * 4 + 16 + sizeof(SerLevels)));
+	HIP_TRY(b_cnt.reserve(UFO_SER_CNT_BYTES));
 	HIP_TRY(hipMemsetAsync(b_cnt.p, 0, 3 * 32 * 4 + 16, m->stream));
 	u32* d_cnt = b_cnt.as<u32>();
 	unsigned long long* d_total = reinterpret_cast<unsigned long long*>(d_cnt + 96);
-	hipLaunchKernelGGL(k_ser_count, gridFor((u64)m->t.mask + 1), dim3(256), 0, m->stream, m->t, m->g, d_cnt);
+	const u32 nsb = serBlocks((u64)m->t.mask + 1);
+	u32* d_blk = d_cnt + UFO_SER_BLK_WORD;
+	hipLaunchKernelGGL(k_ser_count, dim3(nsb), dim3(256), 0, m->stream, m->t, m->g, d_blk);
+	// (the level counts for the host, the workgroups' places in the list for k_ser_collect; the list is sized from the counts: it fits)
+	hipLaunchKernelGGL(k_ser_prefix, dim3(1), dim3(1024), 0, m->stream, d_cnt, reinterpret_cast<SerLevels*>(d_cnt + 100), 0xFFFFFFFFu, d_blk, nsb);
 	HIP_TRY(hipMemcpyAsync(h_cnt, d_cnt, 32 * 4, hipMemcpyDeviceToHost, m->stream));
 	HIP_TRY(hipMemcpyAsync(h_root, m->b_root.p, sizeof(MapRoot), hipMemcpyDeviceToHost, m->stream));
 	HIP_TRY(hipStreamSynchronize(m->stream));
@@ -173,7 +184,7 @@ int serialiseNodes(ufomap_map* m, const SerArgs& sa, std::vector<uint8_t>& data)
 	}
 	HIP_TRY(hipMemcpyAsync(d_cnt + 32, h_off, 32 * 4, hipMemcpyHostToDevice, m->stream));  // (h_off: read by the copy before this function returns -- it synchronises below)
 	HIP_TRY(hipMemsetAsync(b_off.p, 0xFF, ncap * 8, m->stream));
-	hipLaunchKernelGGL(k_ser_collect, gridFor((u64)m->t.mask + 1), dim3(256), 0, m->stream, m->t, m->g, d_cnt + 32, d_cnt + 64, b_list.as<u32>(),
+	hipLaunchKernelGGL(k_ser_collect, dim3(nsb), dim3(256), 0, m->stream, m->t, m->g, d_cnt + 32, d_blk, b_list.as<u32>(),
 	                   (u32)std::min<u64>(std::max<u64>(n_live, 1), 0xFFFFFFFFull));
 	// wide levels: a launch each; from the first level of at most 2048 blocks up to the root: ONE workgroup, a barrier per level
 	u32 l_tail = L;

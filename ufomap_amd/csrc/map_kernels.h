@@ -1204,18 +1204,28 @@ __device__ inline void volDownLevel(const Table& t, const MapGeom& g, const VolA
 			t.flags(s) = (isFreeV(g, v) ? F_CFREE : 0u) | (isUnknownV(g, v) ? F_CUNK : 0u);
 		}
 		u32 changed = 0;
+		// the children the volume reaches; those that are descended into get their records with ONE reservation (a returning
+		// atomic per child was up to eight dependent round trips to the memory side per node and level)
+		u32 inter = 0;
+#pragma unroll
+		for (u32 i = 0; i < 8; ++i) {
+			const double ci[3] = {me.c[0] + ((i & 1) ? chs : -chs), me.c[1] + ((i & 2) ? chs : -chs), me.c[2] + ((i & 4) ? chs : -chs)};
+			inter |= volIntersects(a, ci, chs) ? (1u << i) : 0u;
+		}
+		const bool descend = 0 != child_depth && a.min_depth < child_depth;
+		u32 next = (descend && inter) ? atomicAdd(&ctl->dl_total, (u32)__popc(inter)) : 0u;
 		for (u32 i = 0; i < 8; ++i) {
 			double cc[3] = {me.c[0], me.c[1], me.c[2]};  // getChildCenter (octree.h:625-633)
 			cc[0] += ((i & 1) ? chs : -chs);
 			cc[1] += ((i & 2) ? chs : -chs);
 			cc[2] += ((i & 4) ? chs : -chs);
-			if (!volIntersects(a, cc, chs)) continue;
+			if (!((inter >> i) & 1u)) continue;
 			float* pv = t.occ(s) + i;
 			if (0 == child_depth) {
 				if (*pv != a.val) changed = 1;  // setOccupancy (OMB:1151-1157)
 				*pv = a.val;
 			} else if (a.min_depth < child_depth) {
-				const u32 pos = atomicAdd(&ctl->dl_total, 1u);
+				const u32 pos = next++;
 				if (pos < rcap) {
 					VolRec ch;
 					ch.lk = (me.lk << 3) | (u64)i;
@@ -1540,32 +1550,94 @@ struct DumpCtl {
 	unsigned long long n_leaf;
 };
 
+// Room for `cnt` records of the calling thread in a list that ONE 64-bit counter fills: one atomic per workgroup and call (the
+// counter is one word: ~12 ns per atomic whoever issues it -- a returning atomic per leaf made the export of the bench map's
+// 2.3e5 leaves 2.3 ms and that of a 2 mm RGB-D frame's 3.5e8 leaves 0.23 s). Every thread of the workgroup (256) calls it.
+__device__ inline unsigned long long blockReserve(unsigned long long* counter, u32 cnt)
+{
+	__shared__ u32 wsum[4];
+	__shared__ unsigned long long bbase;
+	const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	u32 incl = cnt;
+	for (int o = 1; o < 64; o <<= 1) {
+		const u32 v = (u32)__shfl_up((int)incl, o);
+		if ((int)lane >= o) incl += v;
+	}
+	if (63u == lane) wsum[wave] = incl;
+	__syncthreads();
+	if (0 == threadIdx.x) {
+		const u32 tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+		bbase = tot ? atomicAdd(counter, (unsigned long long)tot) : 0ull;
+	}
+	__syncthreads();
+	unsigned long long pos = bbase + (incl - cnt);
+	for (u32 w = 0; w < wave; ++w) pos += wsum[w];
+	__syncthreads();  // (wsum / bbase are reused by the next call)
+	return pos;
+}
+#define UFO_EXPORT_SLOTS 4u  // table slots a thread takes per reservation
+
 __global__ __launch_bounds__(256) void k_export_leaves(Table t, MapGeom g, int include_unknown, u64* __restrict__ codes,
                                                        uint8_t* __restrict__ depths, float* __restrict__ occ,
                                                        u32* __restrict__ rgb, unsigned long long cap, DumpCtl* dc)
 {
-	u32 ncap = t.mask + 1;
-	for (u32 s = blockIdx.x * blockDim.x + threadIdx.x; s < ncap; s += gridDim.x * blockDim.x) {
-		u64 lk = t.key(s);
-		if (0 == lk) continue;
-		u32 f = t.flags(s);
-		if (f & F_DEAD) continue;
-		u32 level = levelOf(g, lk);
-		u64 p = lk ^ (1ULL << (3 * (g.L - level)));
-		atomicAdd(&dc->n_live, 1ULL);
-		for (u32 i = 0; i < 8; ++i) {
-			if (level > 1 && ((f >> (16 + i)) & 1u)) continue;
-			float v = t.occ(s)[i];
-			atomicAdd(&dc->n_leaf, 1ULL);
-			if (!include_unknown && isUnknownV(g, v)) continue;
-			unsigned long long pos = atomicAdd(&dc->n_out, 1ULL);
-			if (pos < cap) {
-				codes[pos] = (p << 3) | (u64)i;
-				depths[pos] = (uint8_t)(level - 1);
-				occ[pos] = v;
-				rgb[pos] = t.rgb ? t.rgb[8 * (size_t)s + i] : 0u;
+	const u32 ncap = t.mask + 1;
+	const u64 span = (u64)gridDim.x * blockDim.x * UFO_EXPORT_SLOTS;
+	u32 n_live = 0, n_leaf = 0;
+	for (u64 s0 = (u64)blockIdx.x * blockDim.x * UFO_EXPORT_SLOTS; s0 < ncap; s0 += span) {  // (uniform: barriers inside)
+		u32 f[UFO_EXPORT_SLOTS], level[UFO_EXPORT_SLOTS], outm[UFO_EXPORT_SLOTS];
+		u64 lk[UFO_EXPORT_SLOTS];
+		float v[UFO_EXPORT_SLOTS][8];
+		u32 cnt = 0;
+#pragma unroll
+		for (u32 k = 0; k < UFO_EXPORT_SLOTS; ++k) {
+			const u64 s = s0 + (u64)k * blockDim.x + threadIdx.x;
+			outm[k] = 0;
+			lk[k] = s < ncap ? t.key((u32)s) : 0ull;
+			f[k] = lk[k] ? t.flags((u32)s) : F_DEAD;
+			if (0 == lk[k] || (f[k] & F_DEAD)) continue;
+			level[k] = levelOf(g, lk[k]);
+			++n_live;
+			const float4* po = reinterpret_cast<const float4*>(t.occ((u32)s));
+			const float4 a = po[0], b = po[1];
+			v[k][0] = a.x; v[k][1] = a.y; v[k][2] = a.z; v[k][3] = a.w;
+			v[k][4] = b.x; v[k][5] = b.y; v[k][6] = b.z; v[k][7] = b.w;
+#pragma unroll
+			for (u32 i = 0; i < 8; ++i) {
+				if (level[k] > 1 && ((f[k] >> (16 + i)) & 1u)) continue;
+				++n_leaf;
+				if (!include_unknown && isUnknownV(g, v[k][i])) continue;
+				outm[k] |= 1u << i;
+			}
+			cnt += (u32)__popc(outm[k]);
+		}
+		unsigned long long pos = blockReserve(&dc->n_out, cnt);
+#pragma unroll
+		for (u32 k = 0; k < UFO_EXPORT_SLOTS; ++k) {
+			if (0 == outm[k]) continue;
+			const u64 s = s0 + (u64)k * blockDim.x + threadIdx.x;
+			const u64 p = lk[k] ^ (1ULL << (3 * (g.L - level[k])));
+#pragma unroll
+			for (u32 i = 0; i < 8; ++i) {
+				if (!((outm[k] >> i) & 1u)) continue;
+				if (pos < cap) {
+					codes[pos] = (p << 3) | (u64)i;
+					depths[pos] = (uint8_t)(level[k] - 1);
+					occ[pos] = v[k][i];
+					rgb[pos] = t.rgb ? t.rgb[8 * (size_t)s + i] : 0u;
+				}
+				++pos;
 			}
 		}
+	}
+	// the two totals: once per wave
+	for (int o = 32; o > 0; o >>= 1) {
+		n_live += (u32)__shfl_xor((int)n_live, o);
+		n_leaf += (u32)__shfl_xor((int)n_leaf, o);
+	}
+	if (0 == (threadIdx.x & 63u)) {
+		if (n_live) atomicAdd(&dc->n_live, (unsigned long long)n_live);
+		if (n_leaf) atomicAdd(&dc->n_leaf, (unsigned long long)n_leaf);
 	}
 }
 
@@ -1573,28 +1645,40 @@ __global__ __launch_bounds__(256) void k_export_inner(Table t, MapGeom g, u64* _
                                                       float* __restrict__ occ, uint8_t* __restrict__ flags,
                                                       u32* __restrict__ rgb, unsigned long long cap, DumpCtl* dc)
 {
-	u32 ncap = t.mask + 1;
-	for (u32 s = blockIdx.x * blockDim.x + threadIdx.x; s < ncap; s += gridDim.x * blockDim.x) {
-		u64 lk = t.key(s);
-		if (0 == lk) continue;
-		u32 f = t.flags(s);
-		if (f & F_DEAD) continue;
-		u32 level = levelOf(g, lk);
-		unsigned long long pos = atomicAdd(&dc->n_out, 1ULL);
-		if (pos >= cap) continue;
-		codes[pos] = lk ^ (1ULL << (3 * (g.L - level)));
-		depths[pos] = (uint8_t)level;
-		if (1 == lk) {
-			occ[pos] = t.root->occ;
-			flags[pos] = (uint8_t)(t.root->flags & 3u);
-			rgb[pos] = t.root->rgb;
-		} else {
-			u32 p = t.parent(s);
-			u32 ci = (u32)(lk & 7);
-			u32 fp = t.flags(p);
-			occ[pos] = t.occ(p)[ci];
-			flags[pos] = (uint8_t)(((fp >> ci) & 1u) | (((fp >> (8 + ci)) & 1u) << 1));
-			rgb[pos] = t.rgb ? t.rgb[8 * (size_t)p + ci] : 0u;
+	const u32 ncap = t.mask + 1;
+	const u64 span = (u64)gridDim.x * blockDim.x * UFO_EXPORT_SLOTS;
+	for (u64 s0 = (u64)blockIdx.x * blockDim.x * UFO_EXPORT_SLOTS; s0 < ncap; s0 += span) {  // (uniform: barriers inside)
+		u64 lk[UFO_EXPORT_SLOTS];
+		u32 cnt = 0;
+#pragma unroll
+		for (u32 k = 0; k < UFO_EXPORT_SLOTS; ++k) {
+			const u64 s = s0 + (u64)k * blockDim.x + threadIdx.x;
+			lk[k] = s < ncap ? t.key((u32)s) : 0ull;
+			if (lk[k] && (t.flags((u32)s) & F_DEAD)) lk[k] = 0ull;
+			cnt += lk[k] ? 1u : 0u;
+		}
+		unsigned long long pos = blockReserve(&dc->n_out, cnt);
+#pragma unroll
+		for (u32 k = 0; k < UFO_EXPORT_SLOTS; ++k) {
+			if (0 == lk[k]) continue;
+			const u32 s = (u32)(s0 + (u64)k * blockDim.x + threadIdx.x);
+			const unsigned long long at = pos++;
+			if (at >= cap) continue;
+			const u32 level = levelOf(g, lk[k]);
+			codes[at] = lk[k] ^ (1ULL << (3 * (g.L - level)));
+			depths[at] = (uint8_t)level;
+			if (1 == lk[k]) {
+				occ[at] = t.root->occ;
+				flags[at] = (uint8_t)(t.root->flags & 3u);
+				rgb[at] = t.root->rgb;
+			} else {
+				u32 p = t.parent(s);
+				u32 ci = (u32)(lk[k] & 7);
+				u32 fp = t.flags(p);
+				occ[at] = t.occ(p)[ci];
+				flags[at] = (uint8_t)(((fp >> ci) & 1u) | (((fp >> (8 + ci)) & 1u) << 1));
+				rgb[at] = t.rgb ? t.rgb[8 * (size_t)p + ci] : 0u;
+			}
 		}
 	}
 }
@@ -1680,45 +1764,56 @@ __global__ __launch_bounds__(256) void k_digest(Table t, MapGeom g, int include_
 // ------------------------------------------------------------------------------------------------
 // (The per-level counters are hot words: tens of thousands of live blocks on 16 of them. A workgroup counts in LDS and adds
 // its totals with one atomic per level -- straight atomics serialise at ~12 ns each: 0.4 ms for a 30 k-block map.)
-__global__ __launch_bounds__(256) void k_ser_count(Table t, MapGeom g, u32* __restrict__ level_cnt)
+// The list of live blocks, level by level, WITHOUT atomics on device memory: every workgroup takes a contiguous share of the
+// table's slots, counts its live blocks per level (k_ser_count: one row of 32 counts per workgroup), k_ser_prefix turns the rows
+// into where each workgroup's blocks of a level start, k_ser_collect walks the same share again and writes. (Until round 4's
+// last day each workgroup added its counts to ONE row of 32 words -- twice 9 000 atomics on two cache lines for the bench map,
+// ~12 ns apiece whatever is in flight: most of the 0.2 ms a publish took.)
+#define UFO_SER_NB_MAX 4096u
+// workgroups of the two listing kernels for a table of ncap slots (a multiple of 32: k_ser_prefix gives 32 lanes to a level)
+__host__ __device__ inline u32 serBlocks(u64 ncap)
+{
+	u64 nb = (ncap + 4095u) / 4096u;
+	nb = (nb + 31u) & ~31ull;
+	return (u32)(nb < 32u ? 32u : (nb > UFO_SER_NB_MAX ? UFO_SER_NB_MAX : nb));
+}
+// the share of workgroup b: [lo, hi), whole multiples of the workgroup's 256 threads
+__device__ inline void serShare(u32 ncap, u32 nblocks, u32 b, u32* lo, u32* hi)
+{
+	const u64 per = ((((u64)ncap + nblocks - 1u) / nblocks) + 255u) & ~255ull;
+	const u64 a = per * b, e = a + per;
+	*lo = (u32)(a < ncap ? a : ncap);
+	*hi = (u32)(e < ncap ? e : ncap);
+}
+__global__ __launch_bounds__(256) void k_ser_count(Table t, MapGeom g, u32* __restrict__ blk_cnt /* [gridDim.x][32] */)
 {
 	__shared__ u32 cnt[32];
 	if (threadIdx.x < 32u) cnt[threadIdx.x] = 0;
 	__syncthreads();
-	u32 ncap = t.mask + 1;
-	for (u32 s = blockIdx.x * blockDim.x + threadIdx.x; s < ncap; s += gridDim.x * blockDim.x) {
+	u32 lo, hi;
+	serShare(t.mask + 1u, gridDim.x, blockIdx.x, &lo, &hi);
+	for (u32 s = lo + threadIdx.x; s < hi; s += blockDim.x) {
 		u64 lk = t.key(s);
 		if (0 == lk || (t.flags(s) & F_DEAD)) continue;
 		atomicAdd(&cnt[levelOf(g, lk)], 1u);
 	}
 	__syncthreads();
-	if (threadIdx.x < 32u && cnt[threadIdx.x]) atomicAdd(&level_cnt[threadIdx.x], cnt[threadIdx.x]);
+	if (threadIdx.x < 32u) blk_cnt[32u * blockIdx.x + threadIdx.x] = cnt[threadIdx.x];
 }
-__global__ __launch_bounds__(256) void k_ser_collect(Table t, MapGeom g, const u32* __restrict__ level_off, u32* __restrict__ level_fill,
+__global__ __launch_bounds__(256) void k_ser_collect(Table t, MapGeom g, const u32* __restrict__ level_off, const u32* __restrict__ blk_base /* [gridDim.x][32], k_ser_prefix */,
                                                      u32* __restrict__ list, u32 list_cap)
 {
-	__shared__ u32 cnt[32], base[32];
-	u32 ncap = t.mask + 1;
-	for (u32 s0 = blockIdx.x * blockDim.x; s0 < ncap; s0 += gridDim.x * blockDim.x) {  // (uniform trip count: barriers inside)
-		if (threadIdx.x < 32u) cnt[threadIdx.x] = 0;
-		__syncthreads();
-		const u32 s = s0 + threadIdx.x;
-		u32 l = 0xFFFFFFFFu, rank = 0;
-		if (s < ncap) {
-			u64 lk = t.key(s);
-			if (0 != lk && !(t.flags(s) & F_DEAD)) {
-				l = levelOf(g, lk);
-				rank = atomicAdd(&cnt[l], 1u);
-			}
-		}
-		__syncthreads();
-		if (threadIdx.x < 32u && cnt[threadIdx.x]) base[threadIdx.x] = atomicAdd(&level_fill[threadIdx.x], cnt[threadIdx.x]);
-		__syncthreads();
-		if (l != 0xFFFFFFFFu) {
-			const u32 at = level_off[l] + base[l] + rank;
-			if (at < list_cap) list[at] = s;
-		}
-		__syncthreads();
+	__shared__ u32 run[32];  // where the workgroup's next block of a level goes, counted from the level's first entry
+	if (threadIdx.x < 32u) run[threadIdx.x] = blk_base[32u * blockIdx.x + threadIdx.x];
+	__syncthreads();
+	u32 lo, hi;
+	serShare(t.mask + 1u, gridDim.x, blockIdx.x, &lo, &hi);
+	for (u32 s = lo + threadIdx.x; s < hi; s += blockDim.x) {
+		u64 lk = t.key(s);
+		if (0 == lk || (t.flags(s) & F_DEAD)) continue;
+		const u32 l = levelOf(g, lk);
+		const u32 at = level_off[l] + atomicAdd(&run[l], 1u);
+		if (at < list_cap) list[at] = s;
 	}
 }
 // Bounding volume and min_depth of Octree::write / writeData (octree.h:779-917): only children whose box intersects the
@@ -1870,21 +1965,41 @@ __global__ __launch_bounds__(1024) void k_ser_write_tail(Table t, MapGeom g, Ser
 // output buffer is sized by the table's fill, the two widest levels get a launch each with a fixed grid, the rest is the
 // one-workgroup tail, and the last kernel copies the stream -- whose length only the device knows -- into pinned host
 // memory with 16-byte stores: ONE stream synchronisation per serialisation instead of three.
-__global__ void k_ser_prefix(u32* __restrict__ cnt /* [0..31] live blocks per level; out: [32..63] first list entry per level */, SerLevels* lv,
-                             u32 list_cap)
+// (1024 threads: 32 lanes per level. blk: k_ser_count's rows in, the workgroups' first entries within their levels out.)
+__global__ __launch_bounds__(1024) void k_ser_prefix(u32* __restrict__ cnt /* out: [0..31] live blocks per level, [32..63] first list entry per level */,
+                                                     SerLevels* lv, u32 list_cap, u32* __restrict__ blk, u32 nblocks)
 {
+	__shared__ u32 tot[32];
+	const u32 level = threadIdx.x >> 5, sub = threadIdx.x & 31u, per = nblocks >> 5;  // (nblocks: a multiple of 32, serBlocks)
+	u32 sum = 0;
+	for (u32 k = 0; k < per; ++k) sum += blk[32u * (sub * per + k) + level];
+	u32 incl = sum;
+	for (int o = 1; o < 32; o <<= 1) {
+		const u32 v = (u32)__shfl_up((int)incl, o, 32);
+		if ((int)sub >= o) incl += v;
+	}
+	u32 runv = incl - sum;
+	for (u32 k = 0; k < per; ++k) {
+		const u32 idx = 32u * (sub * per + k) + level;
+		const u32 c = blk[idx];
+		blk[idx] = runv;
+		runv += c;
+	}
+	if (31u == sub) tot[level] = incl;
+	__syncthreads();
 	if (0 != threadIdx.x) return;
 	u32 off = 0;
-	for (u32 l = 0; l < 32; ++l) off += cnt[l];
+	for (u32 l = 0; l < 32; ++l) off += tot[l];
 	// (the host sized the block list from its view of the table's fill; should the map hold more live blocks than that --
 	// it cannot after a join, but nothing here depends on it -- the levels are reported empty: the stream's length comes
 	// out as 0 and the host takes the long way, which counts first)
 	const bool fits = off <= list_cap;
 	off = 0;
 	for (u32 l = 0; l < 32; ++l) {
-		const u32 c = fits ? cnt[l] : 0u;
+		const u32 c = fits ? tot[l] : 0u;
 		lv->off[l] = off;
 		lv->cnt[l] = c;
+		cnt[l] = c;
 		cnt[32 + l] = off;
 		off += c;
 	}

@@ -2934,10 +2934,10 @@ static size_t exportCommon(ufomap_map* m, bool inner, int include_unknown, uint6
 		}
 		if (bad(hipMemsetAsync(d_dc, 0, sizeof(DumpCtl), m->stream))) return (size_t)-1;
 		if (inner)
-			hipLaunchKernelGGL(k_export_inner, gridFor((u64)m->t.mask + 1), dim3(256), 0, m->stream, m->t, m->g, bc.as<u64>(),
+			hipLaunchKernelGGL(k_export_inner, gridFor(((u64)m->t.mask + UFO_EXPORT_SLOTS) / UFO_EXPORT_SLOTS), dim3(256), 0, m->stream, m->t, m->g, bc.as<u64>(),
 			                   bd.as<uint8_t>(), bo.as<float>(), bf.as<uint8_t>(), br.as<u32>(), dcap, d_dc);
 		else
-			hipLaunchKernelGGL(k_export_leaves, gridFor((u64)m->t.mask + 1), dim3(256), 0, m->stream, m->t, m->g, include_unknown,
+			hipLaunchKernelGGL(k_export_leaves, gridFor(((u64)m->t.mask + UFO_EXPORT_SLOTS) / UFO_EXPORT_SLOTS), dim3(256), 0, m->stream, m->t, m->g, include_unknown,
 			                   bc.as<u64>(), bd.as<uint8_t>(), bo.as<float>(), br.as<u32>(), dcap, d_dc);
 		if (bad(hipMemcpyAsync(&h, d_dc, sizeof(DumpCtl), hipMemcpyDeviceToHost, m->stream))) return (size_t)-1;
 		if (bad(hipStreamSynchronize(m->stream))) return (size_t)-1;
@@ -3040,7 +3040,7 @@ int ufomap_map_stats(ufomap_map* m, uint64_t* n_inner, uint64_t* n_leaf, uint64_
 	DevBuf dcbuf;
 	HIP_TRY(dcbuf.reserve(sizeof(DumpCtl)));
 	HIP_TRY(hipMemsetAsync(dcbuf.p, 0, sizeof(DumpCtl), m->stream));
-	hipLaunchKernelGGL(k_export_leaves, gridFor((u64)m->t.mask + 1), dim3(256), 0, m->stream, m->t, m->g, 1, (u64*)nullptr,
+	hipLaunchKernelGGL(k_export_leaves, gridFor(((u64)m->t.mask + UFO_EXPORT_SLOTS) / UFO_EXPORT_SLOTS), dim3(256), 0, m->stream, m->t, m->g, 1, (u64*)nullptr,
 	                   (uint8_t*)nullptr, (float*)nullptr, (u32*)nullptr, 0ull, dcbuf.as<DumpCtl>());
 	DumpCtl h{};
 	HIP_TRY(hipMemcpyAsync(&h, dcbuf.p, sizeof(DumpCtl), hipMemcpyDeviceToHost, m->stream));
