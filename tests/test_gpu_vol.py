@@ -109,21 +109,21 @@ def test_volume_path_grows_the_table_in_the_middle_of_a_walk():
 
 def test_volume_path_takes_the_rgbd_frame_by_itself():
     """BASELINE configs[2] at insert depth 0 on a reduced frame (160 x 120 pixels, 2 mm: rays of up to 1 500 cells, 1.1e8 leaves):
-    nothing forced -- the scan's box is beyond the steady-state path -- leaf for leaf against the checker, fresh and warm."""
-    from ufomap_amd import scans
+    nothing forced -- the scan's box is beyond the steady-state path. Fresh and warm against the fingerprints of the unmodified
+    reference's dumps (tests/golden/digests.json: c3_depth0_160x120; leaf for leaf against the checker itself:
+    test_gpu_parity2.py::test_c3_depth0_reduced_frame_leaf_for_leaf, which takes this path as well), and what only this path
+    promises: no growth in the middle of a walk, no device allocation in a warm scan."""
+    from ufomap_amd import OccupancyMap, capi, scans
     import golden_util
-    g, o = _maps(kind=_kind(), resolution=0.002)
+    fx = golden_util.digests()["c3_depth0_160x120"]
+    assert fx["scans"][0][1] == dict(width=160, height=120) and fx["params"] == dict(resolution=0.002)
+    g = OccupancyMap(resolution=0.002)
     origin, xyz, _ = scans.rgbd(width=160, height=120)
     for i in range(2):
         _insert(g, origin, xyz, 5.0, True)
-        o.insert(origin, xyz, max_range=5.0, discrete=True)
-        gl, ol = g.leaves(True), o.leaves(True)
-        assert same_dump(gl, ol), f"scan {i}: leaves differ"
-        assert same_dump(g.inner(), o.inner()), f"scan {i}: inner nodes differ"
-        assert g.digest() == golden_util.dump_digest(ol, o.inner())
+        assert g.digest() == tuple(int(v) for v in fx["steps"][i]["digest"]), f"scan {i}: digest differs from the reference's"
     d = g.debug()
     assert d[50] == 2 and d[49] == 0, f"volume path scans {d[50]}, growths in a walk {d[49]}"
-    from ufomap_amd import capi
     a0 = capi.alloc_counters()
     _insert(g, origin, xyz, 5.0, True)
     a1 = capi.alloc_counters()
