@@ -1942,7 +1942,7 @@ __global__ __launch_bounds__(256) void k_up(Table t, MapGeom g, FastGeo fg, cons
 			o.slot = s;
 			o.bits = (fl & 3u) | ((pfl & 3u) << 2) | (evaluated ? 16u : 0u) | (reach_out ? 32u : 0u) | (cr ? 64u : 0u) | (dead ? 128u : 0u) | ((u32)(lk & 7) << 8);
 			o.seq = scan_id;
-			o.counts = 0;  // (the bookkeeping goes straight to the control block, below)
+			o.counts = 0;  // (the bookkeeping does not travel in the record: counters, below)
 			o.last = (topkey >> 4) - 1u;
 			o.rgb = rgb;
 			recs_up[cell] = o;
