@@ -205,3 +205,47 @@ def test_early_stopping(early, mode):
             rounds.append(g.debug()[47])
     _assert_same_map(g, o, mode)
     assert all(1 <= r <= 64 for r in rounds), f"rounds to settle: {rounds}"
+
+
+def _frames_for_cuts():
+    """Scans whose rays differ in what the cuts have to get right: random directions and lengths (every dominant axis, either sign,
+    ties between axes on the diagonals), a LiDAR's bundles, an RGB-D frame's long parallel rays."""
+    from ufomap_amd import scans
+    o1, x1, _ = scans.random_cloud(20000, seed=11, extent=9.0)
+    x1 = x1.copy()
+    diag = np.array([[sx * d, sy * d, sz * d] for d in (1.28, 3.2, 5.12, 7.04) for sx in (-1, 1) for sy in (-1, 0, 1) for sz in (-1, 1)])
+    x1[:len(diag)] = o1 + diag  # (diagonals: t_max ties between the axes all the way)
+    o2, x2, _ = scans.lidar64(beams=32, azimuths=1024, origin=scans.lidar_pose(2), seed=5)
+    o3, x3, _ = scans.rgbd(width=160, height=120)
+    return [("random", 0.08, o1, x1, -1.0), ("lidar", 0.08, o2, x2, 15.0), ("rgbd", 0.004, o3, x3, 5.0)]
+
+
+@pytest.mark.parametrize("discrete", [True, False])
+def test_segmented_ray_walk_marks_the_cells_of_the_sequential_walk(discrete):
+    """Round 5: the volume path's rays are cut into segments of ~K cells that lanes walk one each (k_vcutA / k_vcutB / k_vwalk) --
+    the cut states rebuilt from the three addition chains. Same ray cells, same step count, same map as the one-lane-per-ray kernel
+    (k_vdda, option vol_mode bit 4) for K = 5 ... 192, and as the port's sequential walk (occupancy_map_base.h:1261-1301)."""
+    from oracle import OracleMap
+    from ufomap_amd import OccupancyMap
+    for name, res, origin, xyz, max_range in _frames_for_cuts():
+        ref = OccupancyMap(resolution=res)
+        _force_vol(ref)
+        ref.set_option("vol_mode", 16)
+        _insert(ref, origin, xyz, max_range, discrete)
+        assert ref.debug()[50] == 1, f"{name}: the scan did not take the volume path"
+        cells, steps, dig = ref.last_misses(), ref.last_counts()["steps"], ref.digest()
+        if name != "rgbd":
+            p = OracleMap(kind="port", resolution=res)
+            p.insert(origin, xyz, max_range=max_range, discrete=discrete)
+            assert np.array_equal(cells, p.last_misses()) and steps == p.last_steps(), f"{name}: the sequential kernel differs from the port"
+        for K in (5, 16, 61, 192):
+            g = OccupancyMap(resolution=res)
+            _force_vol(g)
+            g.set_option("vol_seg", K)
+            for rep in range(2):  # (the second scan: the grids and lists of the first have been reused)
+                _insert(g, origin, xyz, max_range, discrete)
+                assert g.debug()[50] == rep + 1
+                assert g.last_counts()["steps"] == steps, f"{name} K={K} scan {rep}: step count {g.last_counts()['steps']} vs {steps}"
+                assert np.array_equal(g.last_misses(), cells), f"{name} K={K} scan {rep}: ray cells differ"
+                if 0 == rep:
+                    assert g.digest() == dig, f"{name} K={K}: maps differ"

@@ -1408,6 +1408,8 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 	// ---- round 3: createNode for what is missing from the table (octree.h:997-1016); a level-3 block that is not live
 	// inherits the value of the nearest node above that has one (the blocks above are not written during this launch) ----
 	u32 n_created = 0;
+	bool new1 = false, new2 = false;  // the lane's level-1 / level-2 block got its key in this walk: the parent link is written
+	const u32 fl1_read = fl1r;        // (the flags word as it is stored: written back only when it changes)
 	float v3s = 0.f;
 	u32 r3s = 0;  // COLOR: the colour that goes with v3s
 	{
@@ -1427,8 +1429,27 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 					return;
 				}
 			}
+			// VOL on a grouped table: the listed tile belongs to THIS wave for the whole launch (the list holds every tile once,
+			// nothing else updates the map meanwhile), so once its group is there -- lane 0's claim in the directory -- the keys of
+			// the blocks it creates are plain stores into the group's slots: no probe and no compare-and-swap per block (a fresh
+			// 2 mm frame creates 4.9e7 blocks; device-scope atomics run at ~1e7 per ms on this part)
+			const bool own = VOL && grouped;
+			u32 grp_own = NONE;
+			if (own) {
+				if (0 == lane) grp_own = (s3 != NONE) ? (s3 - t.capU) / UFO_GROUP : groupEnsure(t, lk3);
+				grp_own = (u32)__shfl((int)grp_own, 0);
+			}
 			if (need3 && 0 == lane) {
-				if (mk3) s3 = tableEnsure(t, lk3, scan_id, max_probe, &dummy, &n_created);
+				if (mk3) {
+					if (own) {
+						if (grp_own != NONE) {
+							s3 = groupSlot(t, grp_own, 72u);
+							t.key(s3) = lk3;
+							t.stamp(s3) = scan_id;
+							++n_created;
+						}
+					} else s3 = tableEnsure(t, lk3, scan_id, max_probe, &dummy, &n_created);
+				}
 				v3s = t.root->occ;
 				if (COLOR) r3s = t.root->rgb;
 				for (u64 k = lk3 >> 3, below = lk3; k >= 1; below = k, k >>= 3) {
@@ -1441,8 +1462,27 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 					if (1 == k) break;
 				}
 			}
-			if (mk2) s2 = tableEnsure(t, lk2, scan_id, max_probe, &dummy, &n_created);
-			if (mk1) s1 = tableEnsure(t, lk1, scan_id, max_probe, &dummy, &n_created);
+			if (own) {
+				if (grp_own != NONE) {
+					if (mk2) {
+						s2 = groupSlot(t, grp_own, 64u + c2);
+						t.key(s2) = lk2;
+						t.stamp(s2) = scan_id;
+						++n_created;
+					}
+					if (mk1) {
+						s1 = groupSlot(t, grp_own, lane);
+						t.key(s1) = lk1;
+						t.stamp(s1) = scan_id;
+						++n_created;
+					}
+				}
+			} else {
+				if (mk2) s2 = tableEnsure(t, lk2, scan_id, max_probe, &dummy, &n_created);
+				if (mk1) s1 = tableEnsure(t, lk1, scan_id, max_probe, &dummy, &n_created);
+			}
+			new1 = mk1;
+			new2 = mk2;
 			s3 = __shfl(s3, 0);
 			v3s = __shfl(v3s, 0);
 			if (COLOR) r3s = (u32)__shfl((int)r3s, 0);
@@ -1459,6 +1499,7 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 	float m3c = 0.f, pm_last = 0.f;   // summary of the level-3 block as last evaluated / before its last update
 	u32 fl3c = 0, pfl_last = 0, last_b = 0, rgb3c = 0;
 	u32 n_touched = 0, nhit = 0;
+	bool wr1 = false;  // the values (or colours) of the lane's level-1 block changed: the record is written
 	for (u32 b = 0; b < B; ++b) {
 		if (8u == b) {
 			mmA = mmB;
@@ -1555,6 +1596,8 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 				}
 				v[c] = x;
 			}
+			// (a saturated voxel's update changes nothing: a record none of whose values changed is not stored)
+			wr1 = wr1 || cr1 || 0 != chg || (COLOR && 0 != hmask);
 			// change detection (OMB:783, 1069-1072): the voxels' codes go to the log, as k_apply_leaf's do
 			if (cl.buf) logChanges(t, cl, (lk1 ^ (1ULL << (3 * (g.L - 1)))) << 3, 0u, chg);
 			// updateNode of a depth-1 node (OMB:1195-1224): max, flags from the 8 voxels, collapsible if all equal
@@ -1690,12 +1733,14 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 	}
 	// ---- every touched record back to the table, once ----
 	if (uactive) {
-		float4* po = reinterpret_cast<float4*>(t.occ(s1));
-		po[0] = make_float4(v[0], v[1], v[2], v[3]);
-		po[1] = make_float4(v[4], v[5], v[6], v[7]);
-		t.flags(s1) = fl1r;
-		t.parent(s1) = s2;
-		if (COLOR) {
+		if (wr1) {
+			float4* po = reinterpret_cast<float4*>(t.occ(s1));
+			po[0] = make_float4(v[0], v[1], v[2], v[3]);
+			po[1] = make_float4(v[4], v[5], v[6], v[7]);
+		}
+		if (fl1r != fl1_read || new1) t.flags(s1) = fl1r;
+		if (new1) t.parent(s1) = s2;  // (a block's parent never changes: linked when the block gets its key)
+		if (COLOR && wr1) {
 			uint4* pc = reinterpret_cast<uint4*>(t.rgb + 8 * (size_t)s1);
 			pc[0] = make_uint4(col[0], col[1], col[2], col[3]);
 			pc[1] = make_uint4(col[4], col[5], col[6], col[7]);
@@ -1708,7 +1753,7 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 		}
 		if (0 == c1) {
 			t.flags(s2) = fl2r;
-			t.parent(s2) = s3;
+			if (new2) t.parent(s2) = s3;
 		}
 	}
 	if (0 == c1 && w3) {
@@ -2436,13 +2481,18 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 	{
 		const u32* init = reinterpret_cast<const u32*>(ctl_init);
 		const u32 used = __hip_atomic_load(&ctl->used_now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		const u32 used_g = __hip_atomic_load(&ctl->used_g_now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		const u32 used_u = __hip_atomic_load(&ctl->used_u_now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		constexpr u32 W = sizeof(ScanCtl) / 4u, W_USED = offsetof(ScanCtl, used_now) / 4u, W_ERR = offsetof(ScanCtl, err) / 4u;
+		constexpr u32 W_USEDG = offsetof(ScanCtl, used_g_now) / 4u, W_USEDU = offsetof(ScanCtl, used_u_now) / 4u;
 		for (u32 k = threadIdx.x; k < B * W; k += blockDim.x) {
 			const u32 b = k / W, w = k % W;
 			u32* dev = reinterpret_cast<u32*>(UFO_DESC(b).ctl);
 			u32* host = reinterpret_cast<u32*>(UFO_DESC(b).host_result);
 			u32 x = __hip_atomic_load(&dev[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			if (W_USED == w) x = used;   // the table's fill after the walk: in every scan's block (the host reads whichever it joins)
+			if (W_USEDG == w) x = used_g;  // ... per region too (a scan that is not the walk's last would report 0 / 0 and the host
+			if (W_USEDU == w) x = used_u;  // would size the next update as if the table were empty: ADVICE r4)
 			if (W_ERR == w) x |= e;      // a failed walk has failed for all of its scans
 			host[w] = x;
 			if (0 == e) dev[w] = init[w];  // (an error raised in this very kernel stays for the host to read)

@@ -115,7 +115,33 @@ int volScan(ufomap_map* m, const D3& sensor, const VolPlan& vp, u32 n_hits, u32 
 		hipLaunchKernelGGL(k_vbin_scatter, gb, dim3(256), 0, m->cs, ctl, bin_of, hist, ord);
 		order = ord;
 	}
-	{
+	// the rays cut into segments of ~K cells that lanes walk one each (vol_kernels.h, round 5) -- unless the segment list would not
+	// fit the scratch limit, or option vol_mode bit 4 asks for the one-lane-per-ray kernel (kept as the cross-check)
+	const u32 K = (u32)std::max(5, m->opt_vol_seg);
+	const u32 per = (((n_rays + 7u) / 8u) + 255u) & ~255u;  // bundled rays per region (an eighth of the scan, whole blocks)
+	const u64 ext = 2ull * ((u64)m->gridM.nb[0] + (u64)m->gridM.nb[1] + (u64)m->gridM.nb[2]);
+	const u64 seg_cap = (u64)per * (ext / (K - 3u) + 2ull);  // (a ray of l1 cells: at most l1 / (K - 3) + 1 segments)
+	const bool segmented = 0 == (m->opt_vol_mode & 16) && 8ull * seg_cap < (1ull << 31) &&
+	                       8ull * seg_cap * (sizeof(VSeg) + 4) + (u64)n_rays * sizeof(VRay) <= m->scratch_limit;
+	if (segmented) {
+		HIP_TRY(m->b_vrays.reserve((size_t)n_rays * sizeof(VRay)));
+		HIP_TRY(m->b_vsegs.reserve((size_t)(8ull * seg_cap) * sizeof(VSeg)));
+		HIP_TRY(m->b_vsord.reserve((size_t)(8ull * seg_cap) * 4));
+		HIP_TRY(m->b_vsegcnt.reserve(8 * UFO_VSEG_CNT_STRIDE * 4));
+		HIP_TRY(hipMemsetAsync(m->b_vsegcnt.p, 0, 8 * UFO_VSEG_CNT_STRIDE * 4, m->cs));
+		{
+			ProfScope ps(m, "k_vcut");
+			hipLaunchKernelGGL(k_vcutA, dim3((n_rays + 255u) / 256u), dim3(256), 0, m->cs, m->g, sensor, m->gridM, vp.vg, m->b_vM.as<u64>(), m->b_vtb.as<u32>(), m->b_ray_end.as<D3>(),
+			                   ctl, ctl, order, K, per, (u32)seg_cap, m->b_vrays.as<VRay>(), m->b_vsegs.as<VSeg>(), m->b_vsord.as<u32>(), m->b_vsegcnt.as<u32>());
+			hipLaunchKernelGGL(k_vcutB, dim3((2u * n_rays + 255u) / 256u), dim3(256), 0, m->cs, ctl, m->b_vrays.as<VRay>(), m->b_vsegs.as<VSeg>(), ctl);
+		}
+		{
+			ProfScope ps(m, "k_vdda");  // (the walk itself keeps the name the bench's per-kernel table knows)
+			const u32 G = (u32)std::max(1, m->opt_vol_walk_blocks);
+			hipLaunchKernelGGL(k_vwalk, dim3(8u * G), dim3(256), 0, m->cs, m->g, vp.vg, m->b_vM.as<u64>(), m->b_vtb.as<u32>(), m->b_vrays.as<VRay>(), m->b_vsegs.as<VSeg>(),
+			                   m->b_vsord.as<u32>(), m->b_vsegcnt.as<u32>(), (u32)seg_cap, ctl, ctl, (u32)m->opt_vol_mode);
+		}
+	} else {
 		ProfScope ps(m, "k_vdda");
 		const u32 nblk = ((n_rays + 255u) / 256u + 7u) & ~7u;  // (a multiple of 8: an eighth of the cloud per XCD)
 		hipLaunchKernelGGL(k_vdda, dim3(nblk), dim3(256), 0, m->cs, m->g, sensor, m->gridM, vp.vg, m->b_vM.as<u64>(), m->b_vtb.as<u32>(), m->b_ray_end.as<D3>(), ctl, ctl, (u32)m->opt_vol_mode,

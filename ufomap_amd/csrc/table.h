@@ -4,7 +4,7 @@
 // createChildren/deleteChildren with new/delete of 8-child arrays). One table slot = one 8-child
 // node block, i.e. the `children` array of one inner node:
 //
-// (struct Block below; rgb and the last-update records are separate arrays)
+// (one array per field, see UFO_SLOT_BYTES below)
 //   key        u64   location key of the inner node:  (1 << 3*(L-d)) | (code >> 3*d), d = node depth
 //                    (sentinel bit encodes the depth; root = 1; 0 = empty slot)
 //   occ[i]     f32   log-odds of child i (child index = x | y<<1 | z<<2, map/code.h:245-248)
@@ -64,19 +64,14 @@ struct ChangeLog {
 	u32 L;
 };
 
-// One table slot: the record of one 8-child node block, 64 bytes, 64-byte aligned -- what a lookup finds (the key),
-// what an update reads and writes (the 8 child values) and what the walk up needs (flags, parent) arrive with ONE
-// memory transaction. (Round 1 kept these as separate arrays: one block touch pulled five cache lines.)
-struct alignas(64) Block {
-	float occ[8];  // log-odds of the 8 children; 16-byte aligned for float4 access
-	u64 key;       // location key, 0 = empty slot
-	u32 flags;
-	u32 parent;
-	u32 stamp;
-	u32 pad[3];
-};
-static_assert(sizeof(Block) == 64, "Block must be one 64-byte record");
-
+// One table slot = one 8-child node block. Since round 5 the fields of a slot live in ARRAYS OF THEIR OWN (occ 32 B, key 8 B,
+// flags / stamp / parent 4 B each: 52 B per slot; round 2-4: one 64-byte record per slot). The tree update of the tile paths
+// (k_tile) is the bandwidth-bound kernel of the one bandwidth-bound configuration (a 2 mm RGB-D frame: 6.6e7 blocks per scan),
+// and a tile's 73 slots are consecutive: with arrays the wave reads 44 B per block (values, key, flags) and writes back the
+// 36 B it changed (values, flags) -- 80 B instead of 128 B per block, every line fully used; the parent link and the stamp
+// are touched when a block is created and by the general path only. The general path's random look-ups pay one more line
+// per touch (the key, then values + flags in flight together); its cost is launches and atomics, not lines.
+#define UFO_SLOT_BYTES 52u
 // TILE-MAJOR (round 4). The node blocks beneath one depth-3 node -- its level-3 block, the 8 level-2 and the 64 level-1 blocks:
 // a TILE of 8x8x8 voxels, what one wavefront of the tiled tree update works on -- lie in 73 consecutive slots (4 672 bytes of
 // records), found through a directory of tile keys: ONE hashed probe per tile instead of 73, and the records of a tile are
@@ -91,7 +86,11 @@ static_assert(sizeof(Block) == 64, "Block must be one 64-byte record");
 // everything in the first region.
 #define UFO_GROUP 73u
 struct Table {
-	Block* blk;
+	float* occA;   // [8 * slot + child]: log-odds of the 8 children (32 B per slot, float4-aligned)
+	u64* keyA;     // [slot]: location key, 0 = empty slot
+	u32* flagsA;   // [slot]
+	u32* stampA;   // [slot]
+	u32* parentA;  // [slot]
 	u32* rgb;  // [8*slot + child], colour maps only (nullptr otherwise)
 	u64* tmax;
 	float* lu_occ;  // [slot]: the block's last-update record (map_kernels.h: publishLast); level-1 blocks park the old value of their last-updated voxel here first
@@ -104,11 +103,11 @@ struct Table {
 	u64* gdir;  // [nG]
 	u32* gcnt;  // [128] sharded counters: [0, 64) groups claimed, [64, 128) blocks created in the first region
 	u32 L;      // depth levels of the map (a key's level = L - position of its sentinel bit / 3)
-	__device__ __forceinline__ u64& key(u32 s) const { return blk[s].key; }
-	__device__ __forceinline__ float* occ(u32 s) const { return blk[s].occ; }
-	__device__ __forceinline__ u32& flags(u32 s) const { return blk[s].flags; }
-	__device__ __forceinline__ u32& parent(u32 s) const { return blk[s].parent; }
-	__device__ __forceinline__ u32& stamp(u32 s) const { return blk[s].stamp; }
+	__device__ __forceinline__ u64& key(u32 s) const { return keyA[s]; }
+	__device__ __forceinline__ float* occ(u32 s) const { return occA + 8 * (size_t)s; }
+	__device__ __forceinline__ u32& flags(u32 s) const { return flagsA[s]; }
+	__device__ __forceinline__ u32& parent(u32 s) const { return parentA[s]; }
+	__device__ __forceinline__ u32& stamp(u32 s) const { return stampA[s]; }
 };
 
 __device__ inline u32 hash64(u64 k)

@@ -322,11 +322,13 @@ struct ufomap_map {
 	int opt_fast_simple = 1; // simple (fixed-step) ray casting on the fast path (0: the general path)
 	int opt_fail_scan = 0;  // test aid: the scan half of the next batch steps 'fails' on this rank (host_multi_gpu.inl)
 	int opt_vol_mode = 0;   // measuring aid (k_vdda): bit 0 one copy of M for all XCDs, bit 1 blocks in launch order, bit 2 rays in the cloud's order, bit 3 no write-combining table
+	int opt_vol_seg = 192;  // cells per segment of a ray on the volume path (k_vcutA / k_vwalk)
+	int opt_vol_walk_blocks = 384;  // workgroups of k_vwalk per eighth of the scan
 	int opt_vol_keep = 1;   // k_tile leaves the merged ray cells of its tiles behind (ufomap_map_last_misses)
 	bool vol = false;       // the integration that uses the current set runs on it
 	bool vol_dirty = true;  // the brick grids are not known to be all zero
 	u32 vol_count = 0;      // tiles the scan has listed
-	DevBuf b_vM, b_vMm, b_vH, b_vtb, b_vlist, b_vcopies, b_vrec, b_vaux, b_vupbits, b_vbin;  // (b_vM: eight copies, one per XCD)
+	DevBuf b_vM, b_vMm, b_vH, b_vtb, b_vlist, b_vcopies, b_vrec, b_vaux, b_vupbits, b_vbin, b_vrays, b_vsegs, b_vsord, b_vsegcnt;  // (b_vM: eight copies, one per XCD)
 	VolPlan vplan{};
 	uint64_t n_vol = 0, n_vol_grow = 0, n_vol_fallback = 0;
 	int opt_tile_waves = 4;   // k_tile: tiles per workgroup
@@ -474,7 +476,7 @@ int allocTable(ufomap_map* m, u32 nG, u32 capU, Table* out, TableBufs* tb)
 	const u64 cap64 = (u64)capU + (u64)UFO_GROUP * nG;
 	if (cap64 > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
 	const u32 cap = (u32)cap64;
-	HIP_TRY(tb->blk.reserve((size_t)cap * sizeof(Block)));
+	HIP_TRY(tb->blk.reserve((size_t)cap * UFO_SLOT_BYTES));
 	HIP_TRY(tb->tmax.reserve((size_t)cap * 8));
 	HIP_TRY(tb->luocc.reserve((size_t)cap * 4));
 	HIP_TRY(tb->lufl.reserve((size_t)cap * 4));
@@ -484,13 +486,19 @@ int allocTable(ufomap_map* m, u32 nG, u32 capU, Table* out, TableBufs* tb)
 		HIP_TRY(tb->rgb.reserve((size_t)cap * 32));
 		HIP_TRY(tb->lurgb.reserve((size_t)cap * 4));
 	}
-	// an empty slot is all zeros: key 0, flags 0, stamp 0 (values and parent are written when a block is created)
-	HIP_TRY(hipMemsetAsync(tb->blk.p, 0, (size_t)cap * sizeof(Block), m->stream));
+	// an empty slot is key 0, flags 0, stamp 0 (values and parent are written when a block is created: not zeroed -- 16 of a
+	// slot's 52 bytes; the fresh scan of a 2 mm frame allocates 7e7 slots)
+	HIP_TRY(hipMemsetAsync((char*)tb->blk.p + (size_t)cap * 32, 0, (size_t)cap * 16, m->stream));
 	HIP_TRY(hipMemsetAsync(tb->tmax.p, 0, (size_t)cap * 8, m->stream));
 	HIP_TRY(hipMemsetAsync(tb->lufl.p, 0, (size_t)cap * 4, m->stream));
 	HIP_TRY(hipMemsetAsync(tb->gdir.p, 0, (size_t)nG * 8, m->stream));
 	HIP_TRY(hipMemsetAsync(tb->gcnt.p, 0, 128 * 4, m->stream));
-	out->blk = tb->blk.as<Block>();
+	// [occ 32 B][key 8 B][flags 4 B][stamp 4 B][parent 4 B] x cap
+	out->occA = tb->blk.as<float>();
+	out->keyA = reinterpret_cast<u64*>((char*)tb->blk.p + (size_t)cap * 32);
+	out->flagsA = reinterpret_cast<u32*>((char*)tb->blk.p + (size_t)cap * 40);
+	out->stampA = reinterpret_cast<u32*>((char*)tb->blk.p + (size_t)cap * 44);
+	out->parentA = reinterpret_cast<u32*>((char*)tb->blk.p + (size_t)cap * 48);
 	out->rgb = m->g.color ? tb->rgb.as<u32>() : nullptr;
 	out->tmax = tb->tmax.as<u64>();
 	out->lu_occ = tb->luocc.as<float>();
@@ -2295,7 +2303,7 @@ int ufomap_map_clear(ufomap_map* m)
 	m->poisoned = false;
 	m->cs = m->stream;
 	u32 cap = m->t.mask + 1;
-	HIP_TRY(hipMemsetAsync(m->t.blk, 0, (size_t)cap * sizeof(Block), m->stream));
+	HIP_TRY(hipMemsetAsync(m->t.keyA, 0, (size_t)cap * 16, m->stream));  // (key, flags, stamp: contiguous, allocTable)
 	HIP_TRY(hipMemsetAsync(m->t.tmax, 0, (size_t)cap * 8, m->stream));
 	HIP_TRY(hipMemsetAsync(m->t.lu_fl, 0, (size_t)cap * 4, m->stream));
 	HIP_TRY(hipMemsetAsync(m->t.gdir, 0, (size_t)m->t.nG * 8, m->stream));
@@ -3050,7 +3058,7 @@ int ufomap_map_stats(ufomap_map* m, uint64_t* n_inner, uint64_t* n_leaf, uint64_
 	if (n_leaf) *n_leaf = h.n_live ? h.n_leaf : 1;
 	if (bytes) {
 		u64 cap = (u64)m->t.mask + 1;
-		*bytes = cap * (sizeof(Block) + 8 + 8 + (m->g.color ? 32 + 4 : 0)) + (u64)m->t.nG * 8 + 512;  // record + tmax + last-update record (+ colours); tile directory
+		*bytes = cap * (UFO_SLOT_BYTES + 8 + 8 + (m->g.color ? 32 + 4 : 0)) + (u64)m->t.nG * 8 + 512;  // record + tmax + last-update record (+ colours); tile directory
 	}
 	return UFOMAP_OK;
 }
@@ -3617,7 +3625,11 @@ int ufomap_map_set_option(ufomap_map* m, const char* key, long long value)
 	} else if (0 == strcmp(key, "fail_scan")) {
 		m->opt_fail_scan = value ? 1 : 0;
 	} else if (0 == strcmp(key, "vol_mode")) {
-		m->opt_vol_mode = (int)(value & 15);
+		m->opt_vol_mode = (int)(value & 31);
+	} else if (0 == strcmp(key, "vol_seg")) {
+		m->opt_vol_seg = (int)std::max<long long>(5, std::min<long long>(65536, value));
+	} else if (0 == strcmp(key, "vol_walk_blocks")) {
+		m->opt_vol_walk_blocks = (int)std::max<long long>(1, std::min<long long>(65536, value));
 	} else if (0 == strcmp(key, "vol_keep")) {
 		m->opt_vol_keep = value ? 1 : 0;
 	} else if (0 == strcmp(key, "merge_phases")) {

@@ -282,6 +282,315 @@ __global__ __launch_bounds__(256) void k_vdda(MapGeom g, D3 sensor, Grid gr, Vol
 	if (err) atomicOr(&ctl->err, err);
 }
 
+// ---- the rays cut into segments of equal work (round 5) -------------------------------------------------------------------
+// k_vdda gives a lane one whole ray: 1 500 cells on average in a 2 mm frame, 2 500 the longest, and a wave is as slow as its
+// longest ray, a SIMD as slow as the waves it happened to get (measured: 0.30 cells per CU and clock, lanes 43 % busy; the longest
+// ray ALONE is a third of the kernel's time). The traversal is a 3-way merge of three independent addition chains (scan_kernels.h,
+// "K2' dda, segmented"; k_fcast cuts its rays the same way inside a workgroup), so the state after the k0-th pop of the ray's
+// dominant axis is rebuilt exactly with ONE addition per skipped cell instead of one DDA step:
+//   k_vcutA   one lane per ray: set-up, segments of ~K cells (cuts every w pops of the dominant axis, counted from the SENSOR's
+//             end: the m-th segment from the sensor of every ray of a bundle covers the same stretch of space), the dominant
+//             chain up to every cut; records into the ray's run of the segment list; the list's ORDER (what the walkers follow):
+//             per wave of 64 bundled rays the segments m = 0 of all rays, then m = 1, ... -- 64 consecutive entries walk through the
+//             same bricks at the same time
+//   k_vcutB   two lanes per ray: the two other axes, the pops that precede each cut (strictly smaller, or equal when the axis
+//             wins ties, vector3.h:244-251)
+//   k_vwalk   one lane per segment, the reference's step (k_vdda's loop) from the cut to the next cut's cell -- a path never
+//             revisits a cell, so "the next segment starts here" is the goal test; marks as in k_vdda
+// Same cells, same step count as the sequential walk (tests: ray cells of both forms against each other and against the port).
+struct VRay {
+	double td[3], dist;
+	u32 goal[3];  // cell relative to the grid's corner (VolGeo::cbase)
+	u32 off;      // the ray's first segment record
+	u32 nseg;     // 0: nothing to walk (a ray inside one cell is marked by k_vcutA)
+	int8_t s[3];
+	uint8_t ax;   // dominant axis
+	u32 pad[2];
+};
+static_assert(sizeof(VRay) == 64, "VRay");
+struct VSeg {
+	double tm[3];  // t_max at the segment's first cell
+	u32 c[3];      // ... the cell, relative to the grid's corner
+	u32 ray;       // position of the ray in the bundled order; bit 31: the ray's first segment (its first cell is always marked)
+};
+static_assert(sizeof(VSeg) == 40, "VSeg");
+#define UFO_VSEG_CNT_STRIDE 32u  // 32-bit words between two regions' segment counters
+
+__global__ __launch_bounds__(256) void k_vcutA(MapGeom g, D3 sensor, Grid gr, VolGeo vg, u64* __restrict__ Mx, u32* __restrict__ tbx, const D3* __restrict__ ray_end,
+                                               const ScanCtl* ctl_in, ScanCtl* ctl, const u32* __restrict__ order, u32 K, u32 per, u32 seg_cap, VRay* __restrict__ rays,
+                                               VSeg* __restrict__ segs, u32* __restrict__ sorder, u32* __restrict__ cnt)
+{
+	const u32 n = ctl_in->n_rays;
+	const u32 i = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63u;
+	const u32 region = min(i / per, 7u);  // (per is a multiple of the block size: uniform)
+	const bool live = i < n;
+	u32 nseg = 0, w = 1, r0 = 0, ax = 0, err = 0;
+	unsigned long long steps = 0;
+	RayState r;
+	r.status = 0;
+	if (live) {
+		raySetup(g, sensor, 0u, gr, ray_end[order ? order[i] : i], r);
+		if (3 == r.status) {
+			err |= ERR_VOL;  // clipped at the map cube / outside the grid's interior: the checked walk of the general path
+		} else if (1 == r.status) {
+			const u32 xcc = xccId();
+			u32 wd, b;
+			volWordBit(vg, (u32)(r.start[0] - vg.cbase[0]), (u32)(r.start[1] - vg.cbase[1]), (u32)(r.start[2] - vg.cbase[2]), &wd, &b);
+			__hip_atomic_fetch_or(&Mx[(size_t)xcc * volCopyWords(vg.ntiles) + wd], 1ull << b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			__hip_atomic_fetch_or(&tbx[(size_t)xcc * (size_t)volTbWords(vg.ntiles) + (wd >> 8)], 1u << ((wd >> 3) & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			steps = 1;
+		} else if (2 == r.status) {
+			const u32 dxn = (u32)abs(r.goal[0] - r.start[0]), dyn = (u32)abs(r.goal[1] - r.start[1]), dzn = (u32)abs(r.goal[2] - r.start[2]);
+			ax = (dxn >= dyn && dxn >= dzn) ? 0u : (dyn >= dzn ? 1u : 2u);
+			const u32 dmax = ax == 0 ? dxn : (ax == 1 ? dyn : dzn);
+			const u32 l1 = dxn + dyn + dzn;
+			w = (u32)(((u64)dmax * K) / l1);
+			if (w < 1u) w = 1u;
+			nseg = (dmax + w - 1u) / w;    // >= 1 (start and goal differ); <= l1 / (K - 3) + 1
+			r0 = dmax - (nseg - 1u) * w;   // pops of the ray's FIRST segment (the short one: the cuts are counted from the sensor's end)
+		}
+	}
+	// the wave's run of the region's segment list
+	u32 incl = nseg, maxn = nseg;
+	for (int o = 1; o < 64; o <<= 1) {
+		const u32 v = __shfl_up(incl, o);
+		if ((int)lane >= o) incl += v;
+	}
+	for (int o = 32; o > 0; o >>= 1) maxn = max(maxn, (u32)__shfl_xor((int)maxn, o));
+	const u32 total = __shfl(incl, 63);
+	u32 base = 0;
+	if (63u == lane && total) base = atomicAdd(&cnt[region * UFO_VSEG_CNT_STRIDE], total);
+	base = __shfl(base, 63);
+	if (base + total > seg_cap) {  // (cannot happen: the host sizes a region for l1 / (K - 3) + 2 segments per ray)
+		err |= ERR_VOL;
+		nseg = 0;
+		maxn = 0;
+	}
+	const u32 rb = region * seg_cap, off = rb + base + incl - nseg;
+	if (live) {
+		VRay vr;
+		vr.td[0] = r.td[0];
+		vr.td[1] = r.td[1];
+		vr.td[2] = r.td[2];
+		vr.dist = r.dist;
+		for (int a = 0; a < 3; ++a) {
+			vr.goal[a] = (u32)(r.goal[a] - vg.cbase[a]);
+			vr.s[a] = r.s[a];
+		}
+		vr.off = off;
+		vr.nseg = nseg;
+		vr.ax = (uint8_t)ax;
+		vr.pad[0] = vr.pad[1] = 0;
+		rays[i] = vr;
+	}
+	// the order the walkers take the segments in: m-th from the sensor's end, m-major
+	{
+		u32 run = 0;
+		for (u32 m = 0; m < maxn; ++m) {  // (uniform)
+			const u64 have = __ballot(nseg > m);
+			if (nseg > m) sorder[rb + base + run + (u32)__popcll(have & ((1ull << lane) - 1ull))] = off + (nseg - 1u - m);
+			run += (u32)__popcll(have);
+		}
+	}
+	if (nseg) {
+		VSeg* q = segs + off;
+		const u32 c0[3] = {(u32)(r.start[0] - vg.cbase[0]), (u32)(r.start[1] - vg.cbase[1]), (u32)(r.start[2] - vg.cbase[2])};
+		VSeg rec;
+		rec.tm[0] = r.tm[0];
+		rec.tm[1] = r.tm[1];
+		rec.tm[2] = r.tm[2];
+		rec.c[0] = c0[0];
+		rec.c[1] = c0[1];
+		rec.c[2] = c0[2];
+		rec.ray = i | 0x80000000u;
+		q[0] = rec;
+		// the dominant chain a*: after k0 pops element A[k0 - 1] (= v) was popped and t_max_a* = A[k0]; v is parked in the cut's two
+		// other t_max fields for the lanes of k_vcutB
+		double ta = ax == 0 ? r.tm[0] : (ax == 1 ? r.tm[1] : r.tm[2]), v = ta;
+		const double tda = ax == 0 ? r.td[0] : (ax == 1 ? r.td[1] : r.td[2]);
+		const i32 sa = ax == 0 ? (i32)r.s[0] : (ax == 1 ? (i32)r.s[1] : (i32)r.s[2]);
+		const u32 ca = ax == 0 ? c0[0] : (ax == 1 ? c0[1] : c0[2]);
+		u32 k0 = 0;
+		for (u32 j = 1; j < nseg; ++j) {
+			u32 np = (1u == j) ? r0 : w;
+			k0 += np;
+			for (; np >= 4u; np -= 4u) {  // (the same sequence of additions, four at a time)
+				const double t1 = ta + tda, t2 = t1 + tda, t3 = t2 + tda;
+				v = t3;
+				ta = t3 + tda;
+			}
+			for (; np > 0u; --np) {
+				v = ta;
+				ta = ta + tda;
+			}
+			rec.tm[0] = ax == 0 ? ta : v;
+			rec.tm[1] = ax == 1 ? ta : v;
+			rec.tm[2] = ax == 2 ? ta : v;
+			const u32 cj = (u32)((i32)ca + sa * (i32)k0);
+			rec.c[0] = ax == 0 ? cj : c0[0];  // (the two other axes: k_vcutB adds the pops that precede the cut)
+			rec.c[1] = ax == 1 ? cj : c0[1];
+			rec.c[2] = ax == 2 ? cj : c0[2];
+			rec.ray = i;
+			q[j] = rec;
+		}
+	}
+	waveAddU64(&ctl->n_steps, steps);
+	if (err) atomicOr(&ctl->err, err);
+}
+
+__global__ __launch_bounds__(256) void k_vcutB(const ScanCtl* ctl_in, const VRay* __restrict__ rays, VSeg* __restrict__ segs, ScanCtl* ctl)
+{
+	const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
+	const u32 i = idx >> 1, role = idx & 1u;
+	if (i >= ctl_in->n_rays) return;
+	const VRay vr = rays[i];
+	if (vr.nseg < 2u) return;
+	VSeg* q = segs + vr.off;
+	const u32 axd = vr.ax;
+	const u32 b = (0 == role) ? (axd == 0 ? 1u : 0u) : (axd == 2 ? 1u : 2u);
+	const bool pri = b < axd;
+	double tb = q[0].tm[b];
+	const double dbt = vr.td[b];
+	const i32 sb = (i32)vr.s[b];
+	const u32 cb0 = q[0].c[b];
+	// ONE loop over the candidates of all cuts: an iteration tests four candidates against the current cut's v and either pops
+	// them all, or pops the ones before v, stores the cut and moves on to the next (k_fcast, step 3b)
+	u32 cb = 0, j = 1, guard = 0;
+	VSeg* o = q + 1;
+	double v = o->tm[b];
+	while (j < vr.nseg) {
+		const double s1 = tb + dbt, s2 = s1 + dbt, s3 = s2 + dbt;
+		const bool c0 = pri ? (tb <= v) : (tb < v);
+		const bool c1 = c0 & (pri ? (s1 <= v) : (s1 < v)), c2 = c1 & (pri ? (s2 <= v) : (s2 < v)), c3 = c2 & (pri ? (s3 <= v) : (s3 < v));
+		if (c3) {
+			tb = s3 + dbt;
+			cb += 4u;
+			if (++guard > (1u << 22)) {
+				atomicOr(&ctl->err, ERR_RUNAWAY);  // (cannot trip: an axis has fewer cells than that)
+				break;
+			}
+			continue;
+		}
+		tb = c2 ? s3 : (c1 ? s2 : (c0 ? s1 : tb));
+		cb += (c0 ? 1u : 0u) + (c1 ? 1u : 0u) + (c2 ? 1u : 0u);
+		o->tm[b] = tb;
+		o->c[b] = (u32)((i32)cb0 + sb * (i32)cb);
+		++j;
+		++o;
+		if (j < vr.nseg) v = o->tm[b];
+	}
+}
+
+__global__ __launch_bounds__(256) void k_vwalk(MapGeom g, VolGeo vg, u64* __restrict__ Mx, u32* __restrict__ tbx, const VRay* __restrict__ rays, const VSeg* __restrict__ segs,
+                                               const u32* __restrict__ sorder, const u32* __restrict__ cnt, u32 seg_cap, const ScanCtl* ctl_in, ScanCtl* ctl, u32 mode)
+{
+	__shared__ u32 wc_key[4][UFO_VWC];
+	__shared__ unsigned long long wc_mask[4][UFO_VWC];
+	const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+	const bool use_wc = 0 == (mode & 8u);
+	for (u32 k = lane; k < UFO_VWC; k += 64u) {
+		wc_key[wave][k] = 0xFFFFFFFFu;
+		wc_mask[wave][k] = 0ull;
+	}
+	if (ctl_in->err) return;  // (a scan the cut kernels flagged -- it takes the general path --: its records are not to be followed)
+	// (blocks b, b + 8, ... share an XCD with the usual placement -- speed only: they take the segments of one contiguous eighth
+	// of the bundled rays, so that a tile is marked in one or two copies; the copy a wave marks is the one of the XCD it RUNS on)
+	const u32 region = blockIdx.x & 7u, G = gridDim.x >> 3;
+	const u32 count = min(cnt[region * UFO_VSEG_CNT_STRIDE], seg_cap);
+	const u32 xcc = xccId();
+	u64* const M = Mx + (size_t)xcc * volCopyWords(vg.ntiles);
+	u32* const tb = tbx + (size_t)xcc * (size_t)volTbWords(vg.ntiles);
+	auto flush = [&](u32 w, u64 bits) {  // (k_vdda's: the wave's write-combining table)
+		if (!use_wc) {
+			__hip_atomic_fetch_or(&M[w], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			return;
+		}
+		const u32 slot = (w * 0x9E3779B1u) >> 24;
+		const u32 k = wc_key[wave][slot];
+		const bool hit = k == w;
+		if (hit) __hip_atomic_fetch_or(&wc_mask[wave][slot], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		u32 prev = k;
+		bool won = false;
+		if (!hit) {
+			prev = atomicCAS(&wc_key[wave][slot], k, w);
+			won = prev == k;
+		}
+		if (won) {
+			const u64 old = atomicExch(&wc_mask[wave][slot], (unsigned long long)bits);
+			if (k != 0xFFFFFFFFu && old) __hip_atomic_fetch_or(&M[k], old, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		}
+		if (!hit && !won) {
+			if (prev == w) __hip_atomic_fetch_or(&wc_mask[wave][slot], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			else __hip_atomic_fetch_or(&M[w], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		}
+	};
+	unsigned long long steps = 0;
+	u32 err = 0;
+	const u32 nt0 = vg.nt[0], nt1 = vg.nt[1];
+	for (u32 qi = (blockIdx.x >> 3) * blockDim.x + threadIdx.x; qi < count; qi += G * blockDim.x) {
+		const u32 sidx = sorder[(size_t)region * seg_cap + qi];
+		const VSeg rec = segs[sidx];
+		const VRay vr = rays[rec.ray & 0x7FFFFFFFu];
+		const bool lastseg = sidx + 1u == vr.off + vr.nseg;
+		u32 gx = vr.goal[0], gy = vr.goal[1], gz = vr.goal[2];
+		if (!lastseg) {
+			const VSeg* nx = segs + sidx + 1u;
+			gx = nx->c[0];
+			gy = nx->c[1];
+			gz = nx->c[2];
+		}
+		u32 x = rec.c[0], y = rec.c[1], z = rec.c[2];
+		const u32 sx = (u32)(i32)vr.s[0], sy = (u32)(i32)vr.s[1], sz = (u32)(i32)vr.s[2];
+		double tmx = rec.tm[0], tmy = rec.tm[1], tmz = rec.tm[2];
+		const double tdx = vr.td[0], tdy = vr.td[1], tdz = vr.td[2];
+		const long long idist = __double_as_longlong(vr.dist);
+		// the ray's first cell is always marked (the reference's do-while); a later segment starts where the sequential walk has
+		// just stepped to: it goes on iff t_max.min() <= distance there (OMB:1300; its cell is not the goal's: fewer pops of the
+		// dominant axis)
+		bool go = (0 != (rec.ray >> 31)) || ((__double_as_longlong(tmx) <= idist) | (__double_as_longlong(tmy) <= idist) | (__double_as_longlong(tmz) <= idist));
+		u32 c = 0, curw = 0xFFFFFFFFu;
+		u64 acc = 0;
+		while (go) {
+			++c;
+			const u32 tile = ((z >> 3) * nt1 + (y >> 3)) * nt0 + (x >> 3);
+			const u32 w = tile * 8u + (((x >> 2) & 1u) | (((y >> 2) & 1u) << 1) | (((z >> 2) & 1u) << 2));
+			const u32 b = (x & 3u) | ((y & 3u) << 2) | ((z & 3u) << 4);
+			if (w != curw) {
+				if (acc) flush(curw, acc);
+				if (((w ^ curw) >> 3) && !((tb[tile >> 5] >> (tile & 31u)) & 1u))
+					__hip_atomic_fetch_or(&tb[tile >> 5], 1u << (tile & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				curw = w;
+				acc = 0;
+			}
+			acc |= 1ull << b;
+			const bool cxy = tmx <= tmy, cxz = tmx <= tmz, cyz = tmy <= tmz;
+			const bool selx = cxy & cxz;
+			const bool sely = !cxy & cyz;
+			const bool selz = !(selx | sely);
+			x += selx ? sx : 0u;
+			y += sely ? sy : 0u;
+			z += selz ? sz : 0u;
+			const double nx = tmx + tdx, ny = tmy + tdy, nz = tmz + tdz;
+			tmx = selx ? nx : tmx;
+			tmy = sely ? ny : tmy;
+			tmz = selz ? nz : tmz;
+			const bool more = (__double_as_longlong(tmx) <= idist) | (__double_as_longlong(tmy) <= idist) | (__double_as_longlong(tmz) <= idist);
+			go = (((x ^ gx) | (y ^ gy) | (z ^ gz)) != 0u) & more & (c < (1u << 16));
+		}
+		if (acc) flush(curw, acc);
+		if (c >= (1u << 16)) err |= ERR_RUNAWAY;  // (a segment is ~K cells by construction)
+		steps += c;
+	}
+	if (use_wc)
+		for (u32 k = lane; k < UFO_VWC; k += 64u) {
+			const u32 key = wc_key[wave][k];
+			const u64 bits = wc_mask[wave][k];
+			if (key != 0xFFFFFFFFu && bits) __hip_atomic_fetch_or(&M[key], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		}
+	waveAddU64(&ctl->n_steps, steps);
+	if (err) atomicOr(&ctl->err, err);
+}
+
 // the tiles some XCD has marked -> list (tile, copies it was marked in); the bitmaps are left clean. One thread per word of
 // the bitmaps (32 tiles); count in *n_out.
 __global__ __launch_bounds__(256) void k_vlist(u32* __restrict__ tbx, u32 ntiles, u32* __restrict__ list, uint8_t* __restrict__ copies, u32* n_out)
