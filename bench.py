@@ -203,7 +203,8 @@ def other_configs(device, big, only=None):
         st = m.stats()
         dig = tuple(m.digest())  # (of the fixture's scans: before the warm repetitions below)
         warm = []
-        for _ in range(warm_reps):  # the last scan again into the now warm map (values saturate; what a static sensor costs)
+        warm_checked = 0
+        for rep in range(warm_reps):  # the last scan again into the now warm map (values saturate; what a static sensor costs)
             origin, d, drgb, n, ikw = last
             torch.cuda.synchronize()
             a0 = capi.alloc_counters()
@@ -213,6 +214,11 @@ def other_configs(device, big, only=None):
             warm.append((time.perf_counter() - t0) * 1e3)
             a1 = capi.alloc_counters()
             allocs_warm.append({k: a1[k] - a0[k] for k in a1})
+            # (outside the timed call: the map after THIS warm scan against the reference's after as many scans of the frame, where
+            # the fixture holds them -- round 4 timed warm scans whose results nobody had checked at full size)
+            if want is not None and len(seq) + rep < len(want):
+                ok = ok and [str(v) for v in m.digest()] == want[len(seq) + rep]
+                warm_checked += 1
         kernels = None
         if instrument and last is not None:
             # one more warm repetition with HIP events around every launch (outside the timed ones): which kernel the time is in
@@ -226,23 +232,58 @@ def other_configs(device, big, only=None):
             prof_ms = (time.perf_counter() - t0) * 1e3
             kt = m.kernel_times()
             m.set_profiling(False)
+            if want is not None and len(seq) + warm_reps < len(want):
+                ok = ok and [str(v) for v in m.digest()] == want[len(seq) + warm_reps]
+                warm_checked += 1
             kernels = dict(ms_with_events=round(prof_ms, 3),
                            per_kernel_ms={k: round(v["total_ms"], 3) for k, v in sorted(kt.items(), key=lambda kv: -kv[1]["total_ms"]) if v["launches"]},
                            launches={k: v["launches"] for k, v in kt.items() if v["launches"]})
         out[label] = dict(points=c["points"], rays=c["rays"], dda_steps=c["steps"], ms_per_scan_fixture=[round(v, 4) for v in ms],
                           ms_warm_median=(float(np.median(warm)) if warm else None), digest_ok=bool(ok), checked_against=("tests/golden/digests.json (unmodified reference)" if want is not None else None),
                           live_blocks=st["inner_nodes"], leaves=st["leaf_nodes"], table_bytes=st["bytes"],
-                          fast_path_scans=int(m.debug()[61]), scans=len(seq) + warm_reps)
+                          fast_path_scans=int(m.debug()[61]), scans=len(seq) + warm_reps, warm_scans_digest_checked=warm_checked)
         if instrument:
             out[label].update(ms_warm_all=[round(v, 3) for v in warm], ms_warm_min=float(min(warm)) if warm else None,
                               device_allocs_in_fixture_calls=allocs_fixture, device_allocs_in_warm_calls=allocs_warm, warm_kernels=kernels)
         return dig
 
+    def c3_pipelined(device, fx):
+        """The frame again and again with async=true: a call returns with its tree update enqueued, the next call casts its rays
+        meanwhile (the volume path's two halves overlap across scans). Map after the last scan against the reference's."""
+        n_async = len(fx["steps"]) - 1
+        if n_async < 2:
+            return None
+        origin, xyz, _ = gen(*fx["scans"][0][:2])
+        ikw = fx["scans"][0][2]
+        d = torch.from_numpy(xyz).to(f"cuda:{device}")
+        m = OccupancyMap(device=device, **fx["params"])
+        # (every hand-over set allocates and clears brick grids of its own when it is first used -- 4.5 GB each for this frame: three
+        # untimed scans touch both sets the pipeline alternates between, then the map is cleared and the counted sequence starts)
+        for k in range(3):
+            m.insert_device(origin, d.data_ptr(), None, xyz.shape[0], ikw.get("max_range", -1.0), 0, True, False, 0, k > 0)
+        m.insertPointCloudWait()
+        m.clear()
+        m.insert_device(origin, d.data_ptr(), None, xyz.shape[0], ikw.get("max_range", -1.0), 0, True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_async):
+            m.insert_device(origin, d.data_ptr(), None, xyz.shape[0], ikw.get("max_range", -1.0), 0, True, False, 0, True)
+        m.insertPointCloudWait()
+        ms = (time.perf_counter() - t0) * 1e3 / n_async
+        ok = [str(v) for v in m.digest()] == fx["steps"][-1]["digest"]
+        return dict(ms_per_scan=ms, scans=n_async, digest_ok=bool(ok), note="async=true calls back to back after one synchronous scan into a fresh map; "
+                    "the final map compared with the unmodified reference's after the same number of scans")
+
     for label, name, reps in (("C1_lidar16cm_continuous", "c1_full", 10), ("C5_lidar8cm_colour", "c5_colour_8cm", 10)) + ((("C3_rgbd2mm_depth0", "c3_depth0_full", 5),) if big else ()):
         if only and label not in only:
             continue
         fx = fixtures[name]
-        run(label, fx["params"], fx["scans"], [s["digest"] for s in fx["steps"]], reps, instrument=(label == "C3_rgbd2mm_depth0"))
+        c3 = label == "C3_rgbd2mm_depth0"
+        # (C3 at insert depth 0: the fixture holds the SAME frame seven times -- the first scan is timed into a fresh map, the others
+        # are the warm repetitions, every one of them compared with the reference's map after as many scans)
+        run(label, fx["params"], fx["scans"][:1] if c3 else fx["scans"], [s["digest"] for s in fx["steps"]], reps, instrument=c3)
+        if c3:
+            out[label]["pipelined"] = c3_pipelined(device, fx)
         if label == "C3_rgbd2mm_depth0":
             # the one bandwidth-bound configuration: SURVEY 8d's B_scan = 24 N + 16 S + 16 (touched voxels) + 40 (touched node blocks),
             # with the fresh map's leaves / inner nodes as the touched voxels / blocks of its single scan

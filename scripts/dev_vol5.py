@@ -29,3 +29,14 @@ for c in combos:
     kt = m.kernel_times(); m.set_profiling(False)
     print(c, "ms", [round(t, 2) for t in ts], {k: round(v["total_ms"], 3) for k, v in sorted(kt.items(), key=lambda kv: -kv[1]["total_ms"])[:8]}, "steps", m.last_counts()["steps"], flush=True)
 print("counts", m.last_counts(), "debug", m.debug()[48:51], "stats", m.stats())
+# pipelined: async calls back to back (the walk of scan i overlaps the ray casting of scan i + 1)
+for asy in (0, 1):
+    m.set_option("vol_async", asy)
+    for _ in range(4):  # (each hand-over set allocates and clears brick grids of its own when it is first used)
+        m.insert_device(go, d.data_ptr(), None, gx.shape[0], 5.0, 0, True, False, 0, True)
+    m.insertPointCloudWait()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(8):
+        m.insert_device(go, d.data_ptr(), None, gx.shape[0], 5.0, 0, True, False, 0, True)
+    m.insertPointCloudWait()
+    print("vol_async", asy, "ms per scan over 8 async calls", round((time.perf_counter() - t0) * 1e3 / 8, 3), flush=True)

@@ -249,3 +249,45 @@ def test_segmented_ray_walk_marks_the_cells_of_the_sequential_walk(discrete):
                 assert np.array_equal(g.last_misses(), cells), f"{name} K={K} scan {rep}: ray cells differ"
                 if 0 == rep:
                     assert g.digest() == dig, f"{name} K={K}: maps differ"
+
+
+@pytest.mark.parametrize("pregrow", [1, 0])
+def test_volume_path_pipelined_scans(pregrow):
+    """Round 5: an asynchronous call returns with the volume path's walk ENQUEUED; the next call casts its rays (brick grids of its
+    own hand-over set) while that walk runs and joins it before its own. Back-to-back asynchronous scans, with and without the
+    up-front table growth (without: walks run out of their reserve and are finished by the call that joins them) -- the map is
+    the reference's after the same scans one by one."""
+    g, o = _maps(kind=_kind(), resolution=0.16)
+    _force_vol(g)
+    g.set_option("vol_pregrow", pregrow)
+    for i, (origin, xyz) in enumerate(_wander(8, spread=2.0)):
+        _insert(g, origin, xyz, 12.0, True, async_=True)
+        o.insert(origin, xyz, max_range=12.0, discrete=True)
+        if i in (4, 7):
+            g.insertPointCloudWait()
+            _assert_same_map(g, o, f"after scan {i}")
+    d = g.debug()
+    assert d[50] == 8, f"the scans did not take the volume path: {d[48:51]}"
+    if not pregrow:
+        assert d[49] >= 1, "no walk ran out of its reserve"
+
+
+@pytest.mark.parametrize("variant", ["async", "vol_sync", "all_sync"])
+def test_volume_path_walk_in_flight_and_other_paths(variant):
+    """A volume-path walk still enqueued when scans of the other paths arrive (steady-state path, general path): each is applied
+    after it, in order."""
+    g, o = _maps(kind=_kind(), resolution=0.16)
+    if variant == "vol_sync":
+        g.set_option("vol_async", 0)
+    seq = _wander(9, spread=0.5)
+    for i, (origin, xyz) in enumerate(seq):
+        forced = i in (0, 1, 4, 5, 8)
+        g.set_option("vol", 2 if forced else 1)
+        g.set_option("spec", 0 if forced or i == 6 else 1)  # (scan 6: the general path)
+        _insert(g, origin, xyz, 12.0, True, async_=variant != "all_sync")
+        o.insert(origin, xyz, max_range=12.0, discrete=True)
+        if variant == "all_sync":
+            _assert_same_map(g, o, f"scan {i}")
+    g.insertPointCloudWait()
+    _assert_same_map(g, o, "mixed paths")
+    assert g.debug()[50] >= 5

@@ -1203,6 +1203,8 @@ struct TileVol {
 	u64* H;                // hit voxels; left zeroed
 	const u32* list;       // active tiles
 	const uint8_t* copies; // ... and the copies each was marked in
+	const u32* slots;      // ... and a guess of the slot of each tile's level-3 block (k_vlist: from the record of an earlier walk)
+	u32 retry;             // the walk is run again after a table growth: tiles whose records carry its number are done
 	u32 count;
 	u32* resv;             // 64 counters of tile groups claimed by this walk
 	u32 resv_lim;          // ... and what each may reach
@@ -1213,13 +1215,15 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 {
 	const u32 lane = threadIdx.x & 63u;
 	u32 tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-	u32 vcopies = 0;
+	u32 vcopies = 0, vslot = NONE;
 	if (VOL) {
 		vcopies = tile < va.count ? va.copies[tile] : 0u;
+		vslot = tile < va.count ? va.slots[tile] : NONE;
 		tile = tile < va.count ? va.list[tile] : 0xFFFFFFFFu;
 	}
 	if (tile >= fg.ntiles) return;
-	if (VOL && recs[tile].seq == scan_id) return;  // (a repeat after the table has grown: the tile is done)
+	if (VOL && va.retry && recs[tile].seq == scan_id) return;  // (a repeat after the table has grown: the tile is done)
+	const u32 spec_slot = VOL ? vslot : recs[tile].slot;  // where the tile's level-3 block was when a walk last left a record for this tile (a guess, checked below)
 	__builtin_amdgcn_s_setprio(2);  // (the map stream is the pipeline's critical path: ahead of the ray kernel's waves)
 	const Pipe::Slot sl = p->slot[f & (UFO_RING - 1u)];
 	const u32 B = VOL ? 1u : sl.B;  // (0: the slot's scan went with an earlier walk; the volume path: one scan per walk, known at compile time)
@@ -1330,80 +1334,104 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 	// for the keys of their own. (Maps of fewer than four levels have no groups: the blocks one by one.)
 	const bool grouped = t.L >= 4u;
 	u32 s1 = NONE, s2 = NONE, s3 = NONE;
-	if (grouped) {
-		const u32 grp = groupFind(t, lk3);
-		if (grp != NONE) {
-			s1 = groupSlot(t, grp, lane);
-			s2 = groupSlot(t, grp, 64u + c2);
-			s3 = groupSlot(t, grp, 72u);
-		}
-	} else {
-		s1 = tableFind(t, lk1);
-		u32 sx = NONE;  // lanes 0..7: the level-2 block of group `lane`; lane 8: the level-3 block
-		if (lane < 8u) sx = tableFind(t, (lk3 << 3) | (u64)lane);
-		else if (8u == lane) sx = tableFind(t, lk3);
-		s3 = __shfl(sx, 8);
-		s2 = __shfl(sx, (int)c2);
-	}
 	const bool uactive = 0 != (mmA | mmB);                 // the lane's block is touched by some scan of the batch
 	const u32 uact2 = grpOr(uactive ? 1u : 0u, 0);         // ... its level-2 group is
-	// ---- round 2: the records as they are stored (a block found DEAD was collapsed: the node is a leaf, octree.h:1060-1066;
-	// a block that is not there counts as DEAD) ----
 	u32 fl3r = F_DEAD, fl2r = F_DEAD, fl1r = F_DEAD;
 	float v2l = 0.f, v1l = 0.f;
 	float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 	u32 r2l = 0, r1l = 0;  // COLOR: the colours beside v2l, v1l, v[]
 	u32 col[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-	u64 k3 = lk3, k2 = lk2, k1 = lk1;  // the keys the slots hold (grouped tables: a slot of the group may be empty)
-	if (s3 != NONE) {
-		if (grouped) k3 = t.key(s3);
-		fl3r = t.flags(s3);
-		v2l = t.occ(s3)[c2];
-		if (COLOR) r2l = t.rgb[8 * (size_t)s3 + c2];
-	}
-	if (s2 != NONE && uact2) {
-		if (grouped) k2 = t.key(s2);
-		fl2r = t.flags(s2);
-		v1l = t.occ(s2)[c1];
-		if (COLOR) r1l = t.rgb[8 * (size_t)s2 + c1];
-	}
-	if (s1 != NONE && uactive) {
-		if (grouped) k1 = t.key(s1);
-		fl1r = t.flags(s1);
-		const float4* po = reinterpret_cast<const float4*>(t.occ(s1));
-		const float4 ra = po[0], rb = po[1];
-		v[0] = ra.x; v[1] = ra.y; v[2] = ra.z; v[3] = ra.w;
-		v[4] = rb.x; v[5] = rb.y; v[6] = rb.z; v[7] = rb.w;
-		if (COLOR) {
-			const uint4* pc = reinterpret_cast<const uint4*>(t.rgb + 8 * (size_t)s1);
-			const uint4 ca = pc[0], cb = pc[1];
-			col[0] = ca.x; col[1] = ca.y; col[2] = ca.z; col[3] = ca.w;
-			col[4] = cb.x; col[5] = cb.y; col[6] = cb.z; col[7] = cb.w;
-		}
-	}
+	// The record a walk left for this tile names the slot of its level-3 block -- same tile grid, same table: the group is
+	// known without the directory (2.2 dependent probes on average), and the key that arrives with the record says whether the
+	// guess was right (another grid, a table exchanged since: the directory after all). One round trip of a wave's four.
+	bool spec = false;
+	u32 grp = NONE;
 	if (grouped) {
-		// a slot whose key is not the block's: the block is not there (what was read from the slot is not its record)
-		if (s3 != NONE && k3 != lk3) {
-			s3 = NONE;
-			fl3r = F_DEAD;
-			v2l = 0.f;
-			r2l = 0;
+		if (spec_slot >= t.capU && spec_slot - t.capU < UFO_GROUP * t.nG && (spec_slot - t.capU) % UFO_GROUP == 72u) {
+			grp = (spec_slot - t.capU) / UFO_GROUP;
+			spec = true;
+		} else grp = groupFind(t, lk3);
+	}
+	for (;;) {  // (at most twice; uniform)
+		s1 = s2 = s3 = NONE;
+		if (grouped) {
+			if (grp != NONE) {
+				s1 = groupSlot(t, grp, lane);
+				s2 = groupSlot(t, grp, 64u + c2);
+				s3 = groupSlot(t, grp, 72u);
+			}
+		} else {
+			s1 = tableFind(t, lk1);
+			u32 sx = NONE;  // lanes 0..7: the level-2 block of group `lane`; lane 8: the level-3 block
+			if (lane < 8u) sx = tableFind(t, (lk3 << 3) | (u64)lane);
+			else if (8u == lane) sx = tableFind(t, lk3);
+			s3 = __shfl(sx, 8);
+			s2 = __shfl(sx, (int)c2);
 		}
-		if (s2 != NONE && uact2 && k2 != lk2) {
-			s2 = NONE;
-			fl2r = F_DEAD;
-			v1l = 0.f;
-			r1l = 0;
+		// ---- round 2: the records as they are stored (a block found DEAD was collapsed: the node is a leaf, octree.h:1060-1066;
+		// a block that is not there counts as DEAD) ----
+		fl3r = fl2r = fl1r = F_DEAD;
+		v2l = v1l = 0.f;
+		r2l = r1l = 0;
+		u64 k3 = lk3, k2 = lk2, k1 = lk1;  // the keys the slots hold (grouped tables: a slot of the group may be empty)
+		if (s3 != NONE) {
+			if (grouped) k3 = t.key(s3);
+			fl3r = t.flags(s3);
+			v2l = t.occ(s3)[c2];
+			if (COLOR) r2l = t.rgb[8 * (size_t)s3 + c2];
 		}
-		if (s1 != NONE && uactive && k1 != lk1) {
-			s1 = NONE;
-			fl1r = F_DEAD;
+		if (s2 != NONE && uact2) {
+			if (grouped) k2 = t.key(s2);
+			fl2r = t.flags(s2);
+			v1l = t.occ(s2)[c1];
+			if (COLOR) r1l = t.rgb[8 * (size_t)s2 + c1];
+		}
+		if (s1 != NONE && uactive) {
+			if (grouped) k1 = t.key(s1);
+			fl1r = t.flags(s1);
+			const float4* po = reinterpret_cast<const float4*>(t.occ(s1));
+			const float4 ra = po[0], rb = po[1];
+			v[0] = ra.x; v[1] = ra.y; v[2] = ra.z; v[3] = ra.w;
+			v[4] = rb.x; v[5] = rb.y; v[6] = rb.z; v[7] = rb.w;
+			if (COLOR) {
+				const uint4* pc = reinterpret_cast<const uint4*>(t.rgb + 8 * (size_t)s1);
+				const uint4 ca = pc[0], cb = pc[1];
+				col[0] = ca.x; col[1] = ca.y; col[2] = ca.z; col[3] = ca.w;
+				col[4] = cb.x; col[5] = cb.y; col[6] = cb.z; col[7] = cb.w;
+			}
+		}
+		if (spec && k3 != lk3) {  // the guess was wrong (uniform): the directory
+			spec = false;
+			grp = groupFind(t, lk3);
+			continue;
+		}
+		if (grouped) {
+			// a slot whose key is not the block's: the block is not there (what was read from the slot is not its record)
+			if (s3 != NONE && k3 != lk3) {
+				s3 = NONE;
+				fl3r = F_DEAD;
+				v2l = 0.f;
+				r2l = 0;
+			}
+			if (s2 != NONE && uact2 && k2 != lk2) {
+				s2 = NONE;
+				fl2r = F_DEAD;
+				v1l = 0.f;
+				r1l = 0;
+			}
+			if (s1 != NONE && uactive && k1 != lk1) {
+				s1 = NONE;
+				fl1r = F_DEAD;
+			}
+		}
+		if (!(s1 != NONE && uactive)) {
 #pragma unroll
 			for (int c = 0; c < 8; ++c) {
 				v[c] = 0.f;
 				col[c] = 0;
 			}
 		}
+		break;
 	}
 	// ---- round 3: createNode for what is missing from the table (octree.h:997-1016); a level-3 block that is not live
 	// inherits the value of the nearest node above that has one (the blocks above are not written during this launch) ----

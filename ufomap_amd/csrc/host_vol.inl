@@ -79,6 +79,7 @@ int volScan(ufomap_map* m, const D3& sensor, const VolPlan& vp, u32 n_hits, u32 
 	HIP_TRY(m->b_vtb.reserve(tbw * 4 * 8));
 	HIP_TRY(m->b_vlist.reserve(nt * 4));
 	HIP_TRY(m->b_vcopies.reserve(nt));
+	HIP_TRY(m->b_vslots.reserve(nt * 4));
 	HIP_TRY(m->b_vrec.reserve(vp.rec_total * sizeof(TileRec)));
 	HIP_TRY(m->b_vaux.reserve(UFO_VAUX_BYTES));
 	HIP_TRY(m->b_vupbits.reserve(UFO_FAST_MAX_TILES / 8));
@@ -122,24 +123,23 @@ int volScan(ufomap_map* m, const D3& sensor, const VolPlan& vp, u32 n_hits, u32 
 	const u64 ext = 2ull * ((u64)m->gridM.nb[0] + (u64)m->gridM.nb[1] + (u64)m->gridM.nb[2]);
 	const u64 seg_cap = (u64)per * (ext / (K - 3u) + 2ull);  // (a ray of l1 cells: at most l1 / (K - 3) + 1 segments)
 	const bool segmented = 0 == (m->opt_vol_mode & 16) && 8ull * seg_cap < (1ull << 31) &&
-	                       8ull * seg_cap * (sizeof(VSeg) + 4) + (u64)n_rays * sizeof(VRay) <= m->scratch_limit;
+	                       8ull * seg_cap * UFO_VSEG_BYTES + (u64)n_rays * sizeof(VRay) <= m->scratch_limit;
 	if (segmented) {
 		HIP_TRY(m->b_vrays.reserve((size_t)n_rays * sizeof(VRay)));
-		HIP_TRY(m->b_vsegs.reserve((size_t)(8ull * seg_cap) * sizeof(VSeg)));
-		HIP_TRY(m->b_vsord.reserve((size_t)(8ull * seg_cap) * 4));
+		HIP_TRY(m->b_vsegs.reserve((size_t)(8ull * seg_cap) * UFO_VSEG_BYTES));
 		HIP_TRY(m->b_vsegcnt.reserve(8 * UFO_VSEG_CNT_STRIDE * 4));
 		HIP_TRY(hipMemsetAsync(m->b_vsegcnt.p, 0, 8 * UFO_VSEG_CNT_STRIDE * 4, m->cs));
+		const VSegs sg = volSegViews(m->b_vsegs.p, (size_t)(8ull * seg_cap));
 		{
 			ProfScope ps(m, "k_vcut");
-			hipLaunchKernelGGL(k_vcutA, dim3((n_rays + 255u) / 256u), dim3(256), 0, m->cs, m->g, sensor, m->gridM, vp.vg, m->b_vM.as<u64>(), m->b_vtb.as<u32>(), m->b_ray_end.as<D3>(),
-			                   ctl, ctl, order, K, per, (u32)seg_cap, m->b_vrays.as<VRay>(), m->b_vsegs.as<VSeg>(), m->b_vsord.as<u32>(), m->b_vsegcnt.as<u32>());
-			hipLaunchKernelGGL(k_vcutB, dim3((2u * n_rays + 255u) / 256u), dim3(256), 0, m->cs, ctl, m->b_vrays.as<VRay>(), m->b_vsegs.as<VSeg>(), ctl);
+			hipLaunchKernelGGL(k_vcut, dim3((n_rays + 255u) / 256u), dim3(256), 0, m->cs, m->g, sensor, m->gridM, vp.vg, m->b_vM.as<u64>(), m->b_vtb.as<u32>(), m->b_ray_end.as<D3>(),
+			                   ctl, ctl, order, K, per, (u32)seg_cap, m->b_vrays.as<VRay>(), sg, m->b_vsegcnt.as<u32>());
 		}
 		{
 			ProfScope ps(m, "k_vdda");  // (the walk itself keeps the name the bench's per-kernel table knows)
 			const u32 G = (u32)std::max(1, m->opt_vol_walk_blocks);
-			hipLaunchKernelGGL(k_vwalk, dim3(8u * G), dim3(256), 0, m->cs, m->g, vp.vg, m->b_vM.as<u64>(), m->b_vtb.as<u32>(), m->b_vrays.as<VRay>(), m->b_vsegs.as<VSeg>(),
-			                   m->b_vsord.as<u32>(), m->b_vsegcnt.as<u32>(), (u32)seg_cap, ctl, ctl, (u32)m->opt_vol_mode);
+			hipLaunchKernelGGL(k_vwalk, dim3(8u * G), dim3(256), (size_t)m->opt_vol_walk_lds, m->cs, m->g, vp.vg, m->b_vM.as<u64>(), m->b_vtb.as<u32>(), m->b_vrays.as<VRay>(), sg,
+			                   m->b_vsegcnt.as<u32>(), (u32)seg_cap, ctl, ctl, (u32)m->opt_vol_mode);
 		}
 	} else {
 		ProfScope ps(m, "k_vdda");
@@ -149,7 +149,8 @@ int volScan(ufomap_map* m, const D3& sensor, const VolPlan& vp, u32 n_hits, u32 
 	}
 	{
 		ProfScope ps(m, "k_vlist");
-		hipLaunchKernelGGL(k_vlist, gridFor(tbw, 256, 2048), dim3(256), 0, m->cs, m->b_vtb.as<u32>(), (u32)nt, m->b_vlist.as<u32>(), m->b_vcopies.as<uint8_t>(), aux + 64);
+		hipLaunchKernelGGL(k_vlist, gridFor(tbw, 256, 2048), dim3(256), 0, m->cs, m->b_vtb.as<u32>(), (u32)nt, m->b_vlist.as<u32>(), m->b_vcopies.as<uint8_t>(), aux + 64, m->b_vrec.as<TileRec>(),
+		                   m->b_vslots.as<u32>());
 	}
 	HIP_TRY(hipMemcpyAsync(m->h_ctl, m->b_ctl.p, sizeof(ScanCtl), hipMemcpyDeviceToHost, m->cs));
 	HIP_TRY(hipMemcpyAsync(&m->vol_count, aux + 64, 4, hipMemcpyDeviceToHost, m->cs));
@@ -175,16 +176,105 @@ int volScan(ufomap_map* m, const D3& sensor, const VolPlan& vp, u32 n_hits, u32 
 	return UFOMAP_OK;
 }
 
-// Tree update of the volume path on the map stream, synchronous: k_tile<VOL> over the listed tiles, k_up level after level,
-// k_ftail. Blocks are created against a reserve; when it runs out (ERR_GROW) the table is exchanged for a larger one and the
-// tiles that stood back are run -- the others' records carry the walk's number.
-int volMapPhase(ufomap_map* m)
+// One pass of the walk over the listed tiles: k_tile<VOL> (tiles whose records carry the walk's number are done), k_up level
+// after level, k_ftail -- which stores the finished control block and the walk's done word to pinned memory.
+int volWalkEnqueue(ufomap_map* m, bool retry = false)
+{
+	const VolPlan& vp = m->vplan;
+	const u32 T = m->vol_count;
+	ScanCtl* ctl = m->b_ctl.as<ScanCtl>();
+	Pipe* pipe = m->b_bpipe.as<Pipe>();
+	u32* aux = m->b_vaux.as<u32>();
+	const float miss = (float)m->g.miss_log;  // insert depth 0 (OMB:311)
+	const FastGeo& fg = vp.lv[0];
+	TileRec* recs = m->b_vrec.as<TileRec>();
+	const u64 lim_total = (u64)m->t.nG * 9 / 10 > m->used_g ? (u64)m->t.nG * 9 / 10 - m->used_g : 0;  // (new tile groups: the directory at most 90 % full)
+	m->h_res->err = ERR_NOT_STORED;
+	*reinterpret_cast<volatile unsigned long long*>(m->h_res + 1) = 0ull;
+	m->done_by_flag = true;
+	hipLaunchKernelGGL(k_vreset, dim3(1), dim3(64), 0, m->stream, aux, ctl, (u32)(ERR_GROW | ERR_PREV));
+	TileVol va{};
+	va.Mx = m->b_vM.as<u64>();
+	va.Mm = m->opt_vol_keep ? m->b_vMm.as<u64>() : nullptr;
+	va.H = m->b_vH.as<u64>();
+	va.list = m->b_vlist.as<u32>();
+	va.copies = m->b_vcopies.as<uint8_t>();
+	va.slots = m->b_vslots.as<u32>();
+	va.retry = retry ? 1u : 0u;
+	va.count = T;
+	va.resv = aux;
+	va.resv_lim = (u32)std::min<u64>(lim_total / 64, 0x7FFFFFFFull);
+	{
+		ProfScope ps(m, "k_tile");
+		hipLaunchKernelGGL((k_tile<false, true>), dim3((T + 3) / 4), dim3(256), 0, m->stream, m->t, m->g, fg, pipe, 0ull, recs, m->g.hit, miss, m->vol_scan_id,
+		                   (const u32*)nullptr, ChangeLog{nullptr, 0u, m->g.L}, va);
+	}
+	TileRec* below = recs;
+	for (int k = 1; k < vp.n; ++k) {
+		TileRec* above = below + vp.lv[k - 1].ntiles;
+		ProfScope ps(m, "k_up");
+		hipLaunchKernelGGL(k_up<false>, dim3((u32)(((u64)vp.lv[k].ntiles * 8u + 255u) / 256u)), dim3(256), 0, m->stream, m->t, m->g, vp.lv[k - 1], pipe, 0ull, below,
+		                   above, (k + 1 == vp.n) ? m->b_vupbits.as<u32>() : (u32*)nullptr, m->vol_scan_id, (const u32*)nullptr, aux + UFO_VAUX_UPCNT);
+		below = above;
+	}
+	{
+		ProfScope ps(m, "k_ftail");
+		hipLaunchKernelGGL(k_ftail<false>, dim3(1), dim3(UFO_FTAIL_THREADS), 0, m->stream, m->t, m->g, vp.lv[vp.n - 1], pipe, 0ull, below, m->vol_scan_id, (const u32*)nullptr,
+		                   m->b_ctl_init.as<ScanCtl>(), m->b_vupbits.as<u32>(), 0u, aux + UFO_VAUX_UPCNT);
+	}
+	HIP_TRY(hipGetLastError());
+	return UFOMAP_OK;
+}
+
+// The walk that was enqueued is awaited. Blocks are created against a reserve; when it ran out (ERR_GROW) the table is exchanged
+// for a larger one and the tiles that stood back are run -- the others' records carry the walk's number.
+int volWalkFinish(ufomap_map* m)
+{
+	const u32 T = m->vol_count;
+	const FastGeo& fg = m->vplan.lv[0];
+	TileRec* recs = m->b_vrec.as<TileRec>();
+	u32* aux = m->b_vaux.as<u32>();
+	m->vol_walk = false;
+	for (int attempt = 0;; ++attempt) {
+		if (attempt > 8) return fail(UFOMAP_ERR_CAPACITY, "the node table kept running out of room during one update (internal error)");
+		HIP_TRY(hipStreamSynchronize(m->stream));
+		if (!(m->h_res->err & ERR_GROW) || (m->h_res->err & (ERR_NOT_STORED | ERR_TABLE_FULL))) break;
+		// ---- the reserve ran out: a larger table, then the tiles that stood back ----
+		++m->n_vol_grow;
+		HIP_TRY(hipMemsetAsync(aux + 65, 0, 4, m->stream));
+		hipLaunchKernelGGL(k_vfix, dim3((T + 255u) / 256u), dim3(256), 0, m->stream, m->t, m->g, fg, m->b_vlist.as<u32>(), T, recs, m->vol_scan_id, aux + 65);
+		u32 n_done = 0;
+		HIP_TRY(hipMemcpyAsync(&n_done, aux + 65, 4, hipMemcpyDeviceToHost, m->stream));
+		HIP_TRY(hipStreamSynchronize(m->stream));
+		// (the re-hash counts the groups and blocks it copies: what the tiles that are done have created included)
+		{
+			Need need;
+			need.groups = (u64)(T - std::min(T, n_done)) + (u64)std::min(T, n_done);  // (the groups of the tiles that are done are not in used_g yet)
+			const u64 nG = std::max<u64>((u64)m->t.nG + m->t.nG / 2, (m->used_g + need.groups) * 5 / 4 + 64);
+			if ((u64)m->t.capU + UFO_GROUP * nG > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
+			const hipStream_t keep = m->cs;
+			m->cs = m->stream;
+			const int rc = growTable(m, (u32)((nG + 63) & ~63ull), m->t.capU);
+			m->cs = keep;
+			if (rc) return rc;
+		}
+		hipLaunchKernelGGL(k_vfix, dim3((T + 255u) / 256u), dim3(256), 0, m->stream, m->t, m->g, fg, m->b_vlist.as<u32>(), T, recs, m->vol_scan_id, aux + 65);
+		HIP_TRY(hipMemsetAsync(m->b_vupbits.p, 0, m->b_vupbits.cap, m->stream));
+		const int rc = volWalkEnqueue(m, true);
+		if (rc) return rc;
+	}
+	if (0 == m->h_res->err) m->vol_dirty = false;
+	return UFOMAP_OK;
+}
+
+// Tree update of the volume path on the map stream: the node table sized for what the walk can add, the walk enqueued; awaited
+// here unless the call is asynchronous (then by whatever joins the integration: finishPending).
+int volMapPhase(ufomap_map* m, bool leave_enqueued = false)
 {
 	const VolPlan& vp = m->vplan;
 	const u32 T = m->vol_count;
 	m->cs = m->stream;
 	m->hit_grid = false;
-	ScanCtl* ctl = m->b_ctl.as<ScanCtl>();
 	if (!m->ctl_init_done) {
 		ScanCtl init;
 		memset(&init, 0, sizeof(init));
@@ -203,11 +293,10 @@ int volMapPhase(ufomap_map* m)
 		if (pc != m->b_bpipe.cap) HIP_TRY(hipMemsetAsync(m->b_bpipe.p, 0, sizeof(Pipe), m->stream));
 	}
 	Pipe* pipe = m->b_bpipe.as<Pipe>();
-	u32* aux = m->b_vaux.as<u32>();
 	{
 		DescPack pk{};
 		ScanDesc& d = pk.d[0];
-		d.ctl = ctl;
+		d.ctl = m->b_ctl.as<ScanCtl>();
 		d.host_result = m->h_res;
 		d.done_value = (unsigned long long)m->seq;
 		d.tile_bits = m->b_vupbits.as<u32>();  // (never read: k_ftail clears nwords3 = 0 words of it)
@@ -233,68 +322,13 @@ int volMapPhase(ufomap_map* m)
 		}
 	}
 	m->scan_id += 1;
+	m->vol_scan_id = m->scan_id;
 	m->scan_new_bound = Need{};
-	const float miss = (float)m->g.miss_log;  // insert depth 0 (OMB:311)
-	const FastGeo& fg = vp.lv[0];
-	TileRec* recs = m->b_vrec.as<TileRec>();
-	for (int attempt = 0;; ++attempt) {
-		if (attempt > 8) return fail(UFOMAP_ERR_CAPACITY, "the node table kept running out of room during one update (internal error)");
-		const u64 lim_total = (u64)m->t.nG * 9 / 10 > m->used_g ? (u64)m->t.nG * 9 / 10 - m->used_g : 0;  // (new tile groups: the directory at most 90 % full)
-		m->h_res->err = ERR_NOT_STORED;
-		*reinterpret_cast<volatile unsigned long long*>(m->h_res + 1) = 0ull;
-		m->done_by_flag = true;
-		hipLaunchKernelGGL(k_vreset, dim3(1), dim3(64), 0, m->stream, aux, ctl, (u32)(ERR_GROW | ERR_PREV));
-		TileVol va{};
-		va.Mx = m->b_vM.as<u64>();
-		va.Mm = m->opt_vol_keep ? m->b_vMm.as<u64>() : nullptr;
-		va.H = m->b_vH.as<u64>();
-		va.list = m->b_vlist.as<u32>();
-		va.copies = m->b_vcopies.as<uint8_t>();
-		va.count = T;
-		va.resv = aux;
-		va.resv_lim = (u32)std::min<u64>(lim_total / 64, 0x7FFFFFFFull);
-		{
-			ProfScope ps(m, "k_tile");
-			hipLaunchKernelGGL((k_tile<false, true>), dim3((T + 3) / 4), dim3(256), 0, m->stream, m->t, m->g, fg, pipe, 0ull, recs, m->g.hit, miss, m->scan_id,
-			                   (const u32*)nullptr, ChangeLog{nullptr, 0u, m->g.L}, va);
-		}
-		TileRec* below = recs;
-		for (int k = 1; k < vp.n; ++k) {
-			TileRec* above = below + vp.lv[k - 1].ntiles;
-			ProfScope ps(m, "k_up");
-			hipLaunchKernelGGL(k_up<false>, dim3((u32)(((u64)vp.lv[k].ntiles * 8u + 255u) / 256u)), dim3(256), 0, m->stream, m->t, m->g, vp.lv[k - 1], pipe, 0ull, below,
-			                   above, (k + 1 == vp.n) ? m->b_vupbits.as<u32>() : (u32*)nullptr, m->scan_id, (const u32*)nullptr, aux + UFO_VAUX_UPCNT);
-			below = above;
-		}
-		{
-			ProfScope ps(m, "k_ftail");
-			hipLaunchKernelGGL(k_ftail<false>, dim3(1), dim3(UFO_FTAIL_THREADS), 0, m->stream, m->t, m->g, vp.lv[vp.n - 1], pipe, 0ull, below, m->scan_id, (const u32*)nullptr,
-			                   m->b_ctl_init.as<ScanCtl>(), m->b_vupbits.as<u32>(), 0u, aux + UFO_VAUX_UPCNT);
-		}
-		HIP_TRY(hipGetLastError());
-		HIP_TRY(hipStreamSynchronize(m->stream));
-		if (!(m->h_res->err & ERR_GROW) || (m->h_res->err & (ERR_NOT_STORED | ERR_TABLE_FULL))) break;
-		// ---- the reserve ran out: a larger table, then the tiles that stood back ----
-		++m->n_vol_grow;
-		HIP_TRY(hipMemsetAsync(aux + 65, 0, 4, m->stream));
-		hipLaunchKernelGGL(k_vfix, dim3((T + 255u) / 256u), dim3(256), 0, m->stream, m->t, m->g, fg, m->b_vlist.as<u32>(), T, recs, m->scan_id, aux + 65);
-		u32 n_done = 0;
-		HIP_TRY(hipMemcpyAsync(&n_done, aux + 65, 4, hipMemcpyDeviceToHost, m->stream));
-		HIP_TRY(hipStreamSynchronize(m->stream));
-		// (the re-hash counts the groups and blocks it copies: what the tiles that are done have created included)
-		{
-			Need need;
-			need.groups = (u64)(T - std::min(T, n_done)) + (u64)std::min(T, n_done);  // (the groups of the tiles that are done are not in used_g yet)
-			const u64 nG = std::max<u64>((u64)m->t.nG + m->t.nG / 2, (m->used_g + need.groups) * 5 / 4 + 64);
-			if ((u64)m->t.capU + UFO_GROUP * nG > (1ull << 31)) return fail(UFOMAP_ERR_CAPACITY, "node table would exceed 2^31 blocks");
-			const int rc = growTable(m, (u32)((nG + 63) & ~63ull), m->t.capU);
-			if (rc) return rc;
-		}
-		hipLaunchKernelGGL(k_vfix, dim3((T + 255u) / 256u), dim3(256), 0, m->stream, m->t, m->g, fg, m->b_vlist.as<u32>(), T, recs, m->scan_id, aux + 65);
-		HIP_TRY(hipMemsetAsync(m->b_vupbits.p, 0, m->b_vupbits.cap, m->stream));
-	}
-	if (0 == m->h_res->err) m->vol_dirty = false;
+	const int erc = volWalkEnqueue(m);
+	if (erc) return erc;
 	m->fast = true;  // (finishPending: the finished control block is in pinned memory, k_ftail left the device copy clean)
 	m->pending = true;
-	return UFOMAP_OK;
+	m->vol_walk = true;
+	if (leave_enqueued) return UFOMAP_OK;
+	return volWalkFinish(m);
 }

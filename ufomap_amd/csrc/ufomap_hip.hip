@@ -228,6 +228,16 @@ struct HandOver {
 	hipEvent_t done_ev = nullptr;  // end of the integration that uses this set
 	bool pending = false;          // that integration has been enqueued and not yet been joined
 	Need bound;                    // upper bound of what it may add to the node table
+	// the volume path (vol_kernels.h): what the tree update of the set's scan reads while the next scan's scan half runs (round 5:
+	// an asynchronous call returns with the walk enqueued; the next call casts its rays meanwhile and joins it before its own walk)
+	DevBuf b_vM, b_vMm, b_vH, b_vtb, b_vlist, b_vcopies, b_vslots, b_vaux, b_vupbits;  // (b_vM: eight copies, one per XCD)
+	DevBuf b_vrec;           // the walk's tile records (a walk that ran out of its reserve is finished from them when it is joined)
+	bool vol = false;        // the integration that uses this set runs on the volume path
+	bool vol_dirty = true;   // the set's brick grids are not known to be all zero
+	bool vol_walk = false;   // ... its walk has been enqueued and not been looked at (volWalkFinish: the reserve may have run out)
+	u32 vol_count = 0;       // tiles the scan has listed
+	u32 vol_scan_id = 0;     // the walk's number (tile records of a walk that is repeated after a table growth carry it)
+	VolPlan vplan{};
 };
 
 struct ufomap_map {
@@ -323,13 +333,17 @@ struct ufomap_map {
 	int opt_fail_scan = 0;  // test aid: the scan half of the next batch steps 'fails' on this rank (host_multi_gpu.inl)
 	int opt_vol_mode = 0;   // measuring aid (k_vdda): bit 0 one copy of M for all XCDs, bit 1 blocks in launch order, bit 2 rays in the cloud's order, bit 3 no write-combining table
 	int opt_vol_seg = 192;  // cells per segment of a ray on the volume path (k_vcutA / k_vwalk)
-	int opt_vol_walk_blocks = 384;  // workgroups of k_vwalk per eighth of the scan
+	int opt_vol_walk_blocks = 1536;  // workgroups of k_vwalk per eighth of the scan
+	int opt_vol_walk_lds = 0;  // extra LDS per workgroup of k_vwalk, bytes: caps its workgroups per CU (what is left takes the tree update of the scan before)
+	int opt_vol_async = 1;  // an asynchronous call returns with the volume path's walk enqueued (0: every call returns a finished integration)
 	int opt_vol_keep = 1;   // k_tile leaves the merged ray cells of its tiles behind (ufomap_map_last_misses)
-	bool vol = false;       // the integration that uses the current set runs on it
-	bool vol_dirty = true;  // the brick grids are not known to be all zero
-	u32 vol_count = 0;      // tiles the scan has listed
-	DevBuf b_vM, b_vMm, b_vH, b_vtb, b_vlist, b_vcopies, b_vrec, b_vaux, b_vupbits, b_vbin, b_vrays, b_vsegs, b_vsord, b_vsegcnt;  // (b_vM: eight copies, one per XCD)
+	// (the current hand-over set's share of the volume path's state: HandOver)
+	bool vol = false, vol_dirty = true, vol_walk = false;
+	u32 vol_count = 0, vol_scan_id = 0;
+	DevBuf b_vM, b_vMm, b_vH, b_vtb, b_vlist, b_vcopies, b_vslots, b_vaux, b_vupbits, b_vrec;
 	VolPlan vplan{};
+	// ... and what all sets share: the scan half's own scratch (scan halves run one after the other on the scan stream)
+	DevBuf b_vbin, b_vrays, b_vsegs, b_vsegcnt;
 	uint64_t n_vol = 0, n_vol_grow = 0, n_vol_fallback = 0;
 	int opt_tile_waves = 4;   // k_tile: tiles per workgroup
 	int opt_gates = 1;        // 0 = events instead of gate kernels between the streams of the steady-state path
@@ -686,6 +700,22 @@ void swapWith(ufomap_map* m, HandOver& o)
 	std::swap(m->done_ev, o.done_ev);
 	std::swap(m->pending, o.pending);
 	std::swap(m->bound, o.bound);
+	std::swap(m->b_vM, o.b_vM);
+	std::swap(m->b_vMm, o.b_vMm);
+	std::swap(m->b_vH, o.b_vH);
+	std::swap(m->b_vtb, o.b_vtb);
+	std::swap(m->b_vlist, o.b_vlist);
+	std::swap(m->b_vcopies, o.b_vcopies);
+	std::swap(m->b_vslots, o.b_vslots);
+	std::swap(m->b_vaux, o.b_vaux);
+	std::swap(m->b_vupbits, o.b_vupbits);
+	std::swap(m->b_vrec, o.b_vrec);
+	std::swap(m->vol, o.vol);
+	std::swap(m->vol_dirty, o.vol_dirty);
+	std::swap(m->vol_walk, o.vol_walk);
+	std::swap(m->vol_count, o.vol_count);
+	std::swap(m->vol_scan_id, o.vol_scan_id);
+	std::swap(m->vplan, o.vplan);
 }
 
 int finishSet(ufomap_map* m, int k);
@@ -720,6 +750,8 @@ int phaseGuard(ufomap_map* m)
 	hipLaunchKernelGGL(k_reset_tags, gridFor((u64)m->t.mask + 1), dim3(256), 0, m->stream, m->t);
 	if (m->b_tilerec.p) HIP_TRY(hipMemsetAsync(m->b_tilerec.p, 0, m->b_tilerec.cap, m->stream));
 	if (m->b_vrec.p) HIP_TRY(hipMemsetAsync(m->b_vrec.p, 0, m->b_vrec.cap, m->stream));
+	for (int i = 0; i < kAlt; ++i)
+		if (m->alt[i].b_vrec.p) HIP_TRY(hipMemsetAsync(m->alt[i].b_vrec.p, 0, m->alt[i].b_vrec.cap, m->stream));
 	HIP_TRY(hipStreamSynchronize(m->stream));
 	m->scan_id = 0;
 	++m->n_phase_resets;
@@ -800,7 +832,7 @@ int joinEnqueued(ufomap_map* m)
 		// (a scan that goes with the slot of a newer scan -- no slot of its own -- while that slot is still being enqueued: this very
 		// function is called from there when the table has to grow. Nothing of it is on the map stream yet: it waits for company
 		// like a deferred one. Taking its unwritten result block for a finished update released its set under the walk to come.)
-		if (m->alt[k].fast && m->alt[k].done_by_flag && !m->alt[k].has_slot && !m->alt[k].batch_world && m->alt[k].fseq > m->last_slot_fseq) break;
+		if (m->alt[k].fast && m->alt[k].done_by_flag && !m->alt[k].has_slot && !m->alt[k].batch_world && !m->alt[k].vol_walk && m->alt[k].fseq > m->last_slot_fseq) break;
 		const int r = finishSet(m, k);
 		if (!rc) rc = r;
 	}
@@ -1286,11 +1318,21 @@ int redoScan(ufomap_map* m);
 
 #include "host_fast_path.inl"
 #include "host_vol.inl"
+int volWalkFinish(ufomap_map* m);
 int finishPending(ufomap_map* m)
 {
 	if (!m->pending) return UFOMAP_OK;
-	m->pending = false;
 	m->cs = m->stream;
+	if (m->vol_walk) {
+		// a walk of the volume path that an asynchronous call left enqueued: awaited here; if its reserve ran out the table is
+		// exchanged and the tiles that stood back are run (nothing else is on the map stream: walks are enqueued one at a time)
+		const int vrc = volWalkFinish(m);
+		if (vrc) {
+			m->pending = false;
+			return vrc;
+		}
+	}
+	m->pending = false;
 	int rc = UFOMAP_OK;
 	if (m->fast && 0 == m->h_res->err) {
 		// k_ftail stored the finished control block in pinned memory itself and left the device copy in its start state
@@ -1835,7 +1877,15 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 	u32 n_hits = 0, n_rays = 0;
 	u64 capH = 0, capM = 0;
 	int rc;
+	auto volWalkPending = [&]() {
+		for (int i = 0; i < kAlt; ++i)
+			if (m->alt[i].pending && m->alt[i].vol_walk) return true;
+		return false;
+	};
 	if (fast) {
+		// (a walk of the volume path that is still enqueued may have to be run again for the tiles that stood back: joined before
+		// anything else is enqueued on the map stream)
+		if (volWalkPending()) (void)joinOlder(m);
 		// a synchronous call with nothing in flight: the whole integration on the map stream (no hand-overs between streams)
 		const bool solo = !async && m->opt_solo && oldestPendingAlt(m) < 0 && !m->sd_pending;
 		rc = fastScanPhase(m, origin, d_xyz, n, max_range, discrete, false, async && !m->profiling && m->opt_early && m->opt_lazy_done, solo, swapped, d_rgb, simple);
@@ -1965,12 +2015,16 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 		// the volume path: its scan half has been awaited (the list of tiles was read back); the tree update runs here, synchronously
 		// (an asynchronous call returns a finished integration)
 		lap(0, t_begin);
-		const int prc = joinOlder(m);  // (occupancy_map_base.h:315: the previous integrations are joined first)
+		const int prc = joinOlder(m);  // (occupancy_map_base.h:315: the previous integrations are joined first -- a volume walk among them)
 		const auto t_map = std::chrono::steady_clock::now();
-		rc = volMapPhase(m);
+		rc = volMapPhase(m, 0 != async && 0 != m->opt_vol_async);
 		lap(1, t_map);
-		if (!rc) rc = finishPending(m);
+		if (!rc && !m->vol_walk) rc = finishPending(m);
 		return rc ? rc : prc;
+	}
+	if (!rc && n && volWalkPending()) {  // (see above: its status is reported by wait() / the async status)
+		(void)joinOlder(m);
+		m->cs = m->sstream;
 	}
 	if (!rc && n) rc = extractPhase(m, n_hits, n_rays, &capH, &capM, merged);
 	lap(0, t_begin);
@@ -3630,6 +3684,10 @@ int ufomap_map_set_option(ufomap_map* m, const char* key, long long value)
 		m->opt_vol_seg = (int)std::max<long long>(5, std::min<long long>(65536, value));
 	} else if (0 == strcmp(key, "vol_walk_blocks")) {
 		m->opt_vol_walk_blocks = (int)std::max<long long>(1, std::min<long long>(65536, value));
+	} else if (0 == strcmp(key, "vol_walk_lds")) {
+		m->opt_vol_walk_lds = (int)std::max<long long>(0, std::min<long long>(128 << 10, value));
+	} else if (0 == strcmp(key, "vol_async")) {
+		m->opt_vol_async = value ? 1 : 0;
 	} else if (0 == strcmp(key, "vol_keep")) {
 		m->opt_vol_keep = value ? 1 : 0;
 	} else if (0 == strcmp(key, "merge_phases")) {

@@ -288,37 +288,53 @@ __global__ __launch_bounds__(256) void k_vdda(MapGeom g, D3 sensor, Grid gr, Vol
 // ray ALONE is a third of the kernel's time). The traversal is a 3-way merge of three independent addition chains (scan_kernels.h,
 // "K2' dda, segmented"; k_fcast cuts its rays the same way inside a workgroup), so the state after the k0-th pop of the ray's
 // dominant axis is rebuilt exactly with ONE addition per skipped cell instead of one DDA step:
-//   k_vcutA   one lane per ray: set-up, segments of ~K cells (cuts every w pops of the dominant axis, counted from the SENSOR's
-//             end: the m-th segment from the sensor of every ray of a bundle covers the same stretch of space), the dominant
-//             chain up to every cut; records into the ray's run of the segment list; the list's ORDER (what the walkers follow):
-//             per wave of 64 bundled rays the segments m = 0 of all rays, then m = 1, ... -- 64 consecutive entries walk through the
-//             same bricks at the same time
-//   k_vcutB   two lanes per ray: the two other axes, the pops that precede each cut (strictly smaller, or equal when the axis
-//             wins ties, vector3.h:244-251)
+//   k_vcut    one lane per ray: set-up, segments of ~K cells (cuts every w pops of the dominant axis, counted from the SENSOR's
+//             end: the m-th segment from the sensor of every ray of a bundle covers the same stretch of space); the three chains
+//             run side by side in registers -- the dominant one up to the cut, the two others while their elements precede the
+//             cut's (strictly smaller, or equal when the axis wins ties, vector3.h:244-251). The records of a wave's 64 bundled
+//             rays go into the segment list m-major -- all rays' segment m, then m - 1, ... -- as arrays per field: every store a
+//             run of consecutive words, and 64 consecutive entries are 64 segments that run through the same bricks side by side.
 //   k_vwalk   one lane per segment, the reference's step (k_vdda's loop) from the cut to the next cut's cell -- a path never
 //             revisits a cell, so "the next segment starts here" is the goal test; marks as in k_vdda
 // Same cells, same step count as the sequential walk (tests: ray cells of both forms against each other and against the port).
+// (First form of the round: the dominant chain in one kernel, the other axes two lanes per ray in a second one that read and wrote
+// 40-byte records scattered over the list -- 0.12 + 0.30 ms of sector-sized accesses; this one 0.4 ms less.)
 struct VRay {
 	double td[3], dist;
-	u32 goal[3];  // cell relative to the grid's corner (VolGeo::cbase)
-	u32 off;      // the ray's first segment record
-	u32 nseg;     // 0: nothing to walk (a ray inside one cell is marked by k_vcutA)
+	u32 nseg;     // 0: nothing to walk (a ray inside one cell is marked by k_vcut)
 	int8_t s[3];
 	uint8_t ax;   // dominant axis
-	u32 pad[2];
+	u32 pad[6];
 };
 static_assert(sizeof(VRay) == 64, "VRay");
-struct VSeg {
-	double tm[3];  // t_max at the segment's first cell
-	u32 c[3];      // ... the cell, relative to the grid's corner
-	u32 ray;       // position of the ray in the bundled order; bit 31: the ray's first segment (its first cell is always marked)
+struct VSegs {  // the segment list, one array per field (8 regions of seg_cap entries)
+	double *tmx, *tmy, *tmz;  // t_max at the segment's first cell
+	u32 *cx, *cy, *cz;        // ... the cell, relative to the grid's corner (VolGeo::cbase)
+	u32 *ex, *ey, *ez;        // where the segment ends: the next segment's first cell, the goal for the ray's last segment
+	u32* ray;                 // position of the ray in the bundled order; bit 31: the ray's first segment (its first cell is always marked)
 };
-static_assert(sizeof(VSeg) == 40, "VSeg");
+#define UFO_VSEG_BYTES 52u
 #define UFO_VSEG_CNT_STRIDE 32u  // 32-bit words between two regions' segment counters
+__host__ inline VSegs volSegViews(void* p, size_t cap)
+{
+	VSegs v;
+	char* c = static_cast<char*>(p);
+	v.tmx = reinterpret_cast<double*>(c);
+	v.tmy = v.tmx + cap;
+	v.tmz = v.tmy + cap;
+	v.cx = reinterpret_cast<u32*>(v.tmz + cap);
+	v.cy = v.cx + cap;
+	v.cz = v.cy + cap;
+	v.ex = v.cz + cap;
+	v.ey = v.ex + cap;
+	v.ez = v.ey + cap;
+	v.ray = v.ez + cap;
+	return v;
+}
 
-__global__ __launch_bounds__(256) void k_vcutA(MapGeom g, D3 sensor, Grid gr, VolGeo vg, u64* __restrict__ Mx, u32* __restrict__ tbx, const D3* __restrict__ ray_end,
-                                               const ScanCtl* ctl_in, ScanCtl* ctl, const u32* __restrict__ order, u32 K, u32 per, u32 seg_cap, VRay* __restrict__ rays,
-                                               VSeg* __restrict__ segs, u32* __restrict__ sorder, u32* __restrict__ cnt)
+__global__ __launch_bounds__(256) void k_vcut(MapGeom g, D3 sensor, Grid gr, VolGeo vg, u64* __restrict__ Mx, u32* __restrict__ tbx, const D3* __restrict__ ray_end,
+                                              const ScanCtl* ctl_in, ScanCtl* ctl, const u32* __restrict__ order, u32 K, u32 per, u32 seg_cap, VRay* __restrict__ rays, VSegs sg,
+                                              u32* __restrict__ cnt)
 {
 	const u32 n = ctl_in->n_rays;
 	const u32 i = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63u;
@@ -326,8 +342,7 @@ __global__ __launch_bounds__(256) void k_vcutA(MapGeom g, D3 sensor, Grid gr, Vo
 	const bool live = i < n;
 	u32 nseg = 0, w = 1, r0 = 0, ax = 0, err = 0;
 	unsigned long long steps = 0;
-	RayState r;
-	r.status = 0;
+	RayState r{};
 	if (live) {
 		raySetup(g, sensor, 0u, gr, ray_end[order ? order[i] : i], r);
 		if (3 == r.status) {
@@ -351,138 +366,118 @@ __global__ __launch_bounds__(256) void k_vcutA(MapGeom g, D3 sensor, Grid gr, Vo
 		}
 	}
 	// the wave's run of the region's segment list
-	u32 incl = nseg, maxn = nseg;
-	for (int o = 1; o < 64; o <<= 1) {
-		const u32 v = __shfl_up(incl, o);
-		if ((int)lane >= o) incl += v;
+	u32 total = nseg, maxn = nseg;
+	for (int o = 32; o > 0; o >>= 1) {
+		total += __shfl_xor(total, o);
+		maxn = max(maxn, (u32)__shfl_xor((int)maxn, o));
 	}
-	for (int o = 32; o > 0; o >>= 1) maxn = max(maxn, (u32)__shfl_xor((int)maxn, o));
-	const u32 total = __shfl(incl, 63);
 	u32 base = 0;
-	if (63u == lane && total) base = atomicAdd(&cnt[region * UFO_VSEG_CNT_STRIDE], total);
-	base = __shfl(base, 63);
+	if (0u == lane && total) base = atomicAdd(&cnt[region * UFO_VSEG_CNT_STRIDE], total);
+	base = __shfl(base, 0);
 	if (base + total > seg_cap) {  // (cannot happen: the host sizes a region for l1 / (K - 3) + 2 segments per ray)
 		err |= ERR_VOL;
 		nseg = 0;
 		maxn = 0;
 	}
-	const u32 rb = region * seg_cap, off = rb + base + incl - nseg;
 	if (live) {
 		VRay vr;
 		vr.td[0] = r.td[0];
 		vr.td[1] = r.td[1];
 		vr.td[2] = r.td[2];
 		vr.dist = r.dist;
-		for (int a = 0; a < 3; ++a) {
-			vr.goal[a] = (u32)(r.goal[a] - vg.cbase[a]);
-			vr.s[a] = r.s[a];
-		}
-		vr.off = off;
+		for (int a = 0; a < 3; ++a) vr.s[a] = r.s[a];
 		vr.nseg = nseg;
 		vr.ax = (uint8_t)ax;
-		vr.pad[0] = vr.pad[1] = 0;
+		for (int a = 0; a < 6; ++a) vr.pad[a] = 0;
 		rays[i] = vr;
 	}
-	// the order the walkers take the segments in: m-th from the sensor's end, m-major
-	{
-		u32 run = 0;
-		for (u32 m = 0; m < maxn; ++m) {  // (uniform)
-			const u64 have = __ballot(nseg > m);
-			if (nseg > m) sorder[rb + base + run + (u32)__popcll(have & ((1ull << lane) - 1ull))] = off + (nseg - 1u - m);
-			run += (u32)__popcll(have);
+	// The three chains. a* = the dominant axis; b0, b1 = the two others in axis order (b0 < b1). After k0 pops of a*: element
+	// A[k0 - 1] (= v) was popped and t_max_a* = A[k0]; of axis b the elements before v were popped -- strictly smaller, or equal
+	// when b wins the tie (b < a*).
+	const u32 c0x = (u32)(r.start[0] - vg.cbase[0]), c0y = (u32)(r.start[1] - vg.cbase[1]), c0z = (u32)(r.start[2] - vg.cbase[2]);
+	double ta = ax == 0 ? r.tm[0] : (ax == 1 ? r.tm[1] : r.tm[2]), v = ta;
+	const double tda = ax == 0 ? r.td[0] : (ax == 1 ? r.td[1] : r.td[2]);
+	double t0 = ax == 0 ? r.tm[1] : r.tm[0], t1 = ax == 2 ? r.tm[1] : r.tm[2];
+	const double d0 = ax == 0 ? r.td[1] : r.td[0], d1 = ax == 2 ? r.td[1] : r.td[2];
+	const bool pri0 = ax != 0u, pri1 = ax == 2u;
+	const i32 sa = ax == 0 ? (i32)r.s[0] : (ax == 1 ? (i32)r.s[1] : (i32)r.s[2]);
+	const i32 s0 = ax == 0 ? (i32)r.s[1] : (i32)r.s[0], s1 = ax == 2 ? (i32)r.s[1] : (i32)r.s[2];
+	u32 k0 = 0, n0 = 0, n1 = 0, guard = 0;
+	auto advance = [&](double& tb, const double dbt, const bool pri, u32& cb) {
+		for (;;) {  // four candidates per iteration (the same sequence of additions)
+			const double q1 = tb + dbt, q2 = q1 + dbt, q3 = q2 + dbt;
+			const bool p0 = pri ? (tb <= v) : (tb < v);
+			const bool p1 = p0 & (pri ? (q1 <= v) : (q1 < v)), p2 = p1 & (pri ? (q2 <= v) : (q2 < v)), p3 = p2 & (pri ? (q3 <= v) : (q3 < v));
+			if (p3) {
+				tb = q3 + dbt;
+				cb += 4u;
+				if (++guard > (1u << 22)) {
+					err |= ERR_RUNAWAY;  // (cannot trip: an axis has fewer cells than that)
+					break;
+				}
+				continue;
+			}
+			tb = p2 ? q3 : (p1 ? q2 : (p0 ? q1 : tb));
+			cb += (p0 ? 1u : 0u) + (p1 ? 1u : 0u) + (p2 ? 1u : 0u);
+			break;
 		}
+	};
+	const size_t rb = (size_t)region * seg_cap;
+	u32 run = 0;
+	size_t prev = 0;
+	for (int m = (int)maxn - 1; m >= 0; --m) {  // (uniform; the list is m-major: the segments far from the sensor first)
+		const bool act = nseg > (u32)m;
+		const u64 have = __ballot(act);
+		if (act) {
+			const u32 j = nseg - 1u - (u32)m;
+			if (j > 0u) {
+				u32 np = (1u == j) ? r0 : w;
+				k0 += np;
+				for (; np >= 4u; np -= 4u) {  // (the same sequence of additions, four at a time)
+					const double a1 = ta + tda, a2 = a1 + tda, a3 = a2 + tda;
+					v = a3;
+					ta = a3 + tda;
+				}
+				for (; np > 0u; --np) {
+					v = ta;
+					ta = ta + tda;
+				}
+				advance(t0, d0, pri0, n0);
+				advance(t1, d1, pri1, n1);
+			}
+			const u32 pa = (u32)(sa * (i32)k0), p0 = (u32)(s0 * (i32)n0), p1 = (u32)(s1 * (i32)n1);
+			const u32 x = c0x + (ax == 0 ? pa : p0), y = c0y + (ax == 0 ? p0 : (ax == 1 ? pa : p1)), z = c0z + (ax == 2 ? pa : p1);
+			const size_t pos = rb + base + run + (u32)__popcll(have & ((1ull << lane) - 1ull));
+			sg.tmx[pos] = ax == 0 ? ta : t0;
+			sg.tmy[pos] = ax == 0 ? t0 : (ax == 1 ? ta : t1);
+			sg.tmz[pos] = ax == 2 ? ta : t1;
+			sg.cx[pos] = x;
+			sg.cy[pos] = y;
+			sg.cz[pos] = z;
+			sg.ray[pos] = i | (0u == j ? 0x80000000u : 0u);
+			if (j > 0u) {  // the segment before ends where this one starts
+				sg.ex[prev] = x;
+				sg.ey[prev] = y;
+				sg.ez[prev] = z;
+			}
+			prev = pos;
+		}
+		run += (u32)__popcll(have);
 	}
 	if (nseg) {
-		VSeg* q = segs + off;
-		const u32 c0[3] = {(u32)(r.start[0] - vg.cbase[0]), (u32)(r.start[1] - vg.cbase[1]), (u32)(r.start[2] - vg.cbase[2])};
-		VSeg rec;
-		rec.tm[0] = r.tm[0];
-		rec.tm[1] = r.tm[1];
-		rec.tm[2] = r.tm[2];
-		rec.c[0] = c0[0];
-		rec.c[1] = c0[1];
-		rec.c[2] = c0[2];
-		rec.ray = i | 0x80000000u;
-		q[0] = rec;
-		// the dominant chain a*: after k0 pops element A[k0 - 1] (= v) was popped and t_max_a* = A[k0]; v is parked in the cut's two
-		// other t_max fields for the lanes of k_vcutB
-		double ta = ax == 0 ? r.tm[0] : (ax == 1 ? r.tm[1] : r.tm[2]), v = ta;
-		const double tda = ax == 0 ? r.td[0] : (ax == 1 ? r.td[1] : r.td[2]);
-		const i32 sa = ax == 0 ? (i32)r.s[0] : (ax == 1 ? (i32)r.s[1] : (i32)r.s[2]);
-		const u32 ca = ax == 0 ? c0[0] : (ax == 1 ? c0[1] : c0[2]);
-		u32 k0 = 0;
-		for (u32 j = 1; j < nseg; ++j) {
-			u32 np = (1u == j) ? r0 : w;
-			k0 += np;
-			for (; np >= 4u; np -= 4u) {  // (the same sequence of additions, four at a time)
-				const double t1 = ta + tda, t2 = t1 + tda, t3 = t2 + tda;
-				v = t3;
-				ta = t3 + tda;
-			}
-			for (; np > 0u; --np) {
-				v = ta;
-				ta = ta + tda;
-			}
-			rec.tm[0] = ax == 0 ? ta : v;
-			rec.tm[1] = ax == 1 ? ta : v;
-			rec.tm[2] = ax == 2 ? ta : v;
-			const u32 cj = (u32)((i32)ca + sa * (i32)k0);
-			rec.c[0] = ax == 0 ? cj : c0[0];  // (the two other axes: k_vcutB adds the pops that precede the cut)
-			rec.c[1] = ax == 1 ? cj : c0[1];
-			rec.c[2] = ax == 2 ? cj : c0[2];
-			rec.ray = i;
-			q[j] = rec;
-		}
+		sg.ex[prev] = (u32)(r.goal[0] - vg.cbase[0]);
+		sg.ey[prev] = (u32)(r.goal[1] - vg.cbase[1]);
+		sg.ez[prev] = (u32)(r.goal[2] - vg.cbase[2]);
 	}
 	waveAddU64(&ctl->n_steps, steps);
 	if (err) atomicOr(&ctl->err, err);
 }
 
-__global__ __launch_bounds__(256) void k_vcutB(const ScanCtl* ctl_in, const VRay* __restrict__ rays, VSeg* __restrict__ segs, ScanCtl* ctl)
-{
-	const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
-	const u32 i = idx >> 1, role = idx & 1u;
-	if (i >= ctl_in->n_rays) return;
-	const VRay vr = rays[i];
-	if (vr.nseg < 2u) return;
-	VSeg* q = segs + vr.off;
-	const u32 axd = vr.ax;
-	const u32 b = (0 == role) ? (axd == 0 ? 1u : 0u) : (axd == 2 ? 1u : 2u);
-	const bool pri = b < axd;
-	double tb = q[0].tm[b];
-	const double dbt = vr.td[b];
-	const i32 sb = (i32)vr.s[b];
-	const u32 cb0 = q[0].c[b];
-	// ONE loop over the candidates of all cuts: an iteration tests four candidates against the current cut's v and either pops
-	// them all, or pops the ones before v, stores the cut and moves on to the next (k_fcast, step 3b)
-	u32 cb = 0, j = 1, guard = 0;
-	VSeg* o = q + 1;
-	double v = o->tm[b];
-	while (j < vr.nseg) {
-		const double s1 = tb + dbt, s2 = s1 + dbt, s3 = s2 + dbt;
-		const bool c0 = pri ? (tb <= v) : (tb < v);
-		const bool c1 = c0 & (pri ? (s1 <= v) : (s1 < v)), c2 = c1 & (pri ? (s2 <= v) : (s2 < v)), c3 = c2 & (pri ? (s3 <= v) : (s3 < v));
-		if (c3) {
-			tb = s3 + dbt;
-			cb += 4u;
-			if (++guard > (1u << 22)) {
-				atomicOr(&ctl->err, ERR_RUNAWAY);  // (cannot trip: an axis has fewer cells than that)
-				break;
-			}
-			continue;
-		}
-		tb = c2 ? s3 : (c1 ? s2 : (c0 ? s1 : tb));
-		cb += (c0 ? 1u : 0u) + (c1 ? 1u : 0u) + (c2 ? 1u : 0u);
-		o->tm[b] = tb;
-		o->c[b] = (u32)((i32)cb0 + sb * (i32)cb);
-		++j;
-		++o;
-		if (j < vr.nseg) v = o->tm[b];
-	}
-}
-
-__global__ __launch_bounds__(256) void k_vwalk(MapGeom g, VolGeo vg, u64* __restrict__ Mx, u32* __restrict__ tbx, const VRay* __restrict__ rays, const VSeg* __restrict__ segs,
-                                               const u32* __restrict__ sorder, const u32* __restrict__ cnt, u32 seg_cap, const ScanCtl* ctl_in, ScanCtl* ctl, u32 mode)
+// (A table keyed by TILE -- an entry holds the tile's eight brick words and goes to the L2 as up to eight atomics and one bit of the
+// tile bitmap -- was measured too: 1.78 ms against 1.65 for this one on the 2 mm frame. What the walk costs is instruction issue,
+// 62 instructions per step outside the table's code, not what reaches the L2; profiles/r05_ab_experiments.log.)
+__global__ __launch_bounds__(256) void k_vwalk(MapGeom g, VolGeo vg, u64* __restrict__ Mx, u32* __restrict__ tbx, const VRay* __restrict__ rays, VSegs sg,
+                                               const u32* __restrict__ cnt, u32 seg_cap, const ScanCtl* ctl_in, ScanCtl* ctl, u32 mode)
 {
 	__shared__ u32 wc_key[4][UFO_VWC];
 	__shared__ unsigned long long wc_mask[4][UFO_VWC];
@@ -528,26 +523,19 @@ __global__ __launch_bounds__(256) void k_vwalk(MapGeom g, VolGeo vg, u64* __rest
 	u32 err = 0;
 	const u32 nt0 = vg.nt[0], nt1 = vg.nt[1];
 	for (u32 qi = (blockIdx.x >> 3) * blockDim.x + threadIdx.x; qi < count; qi += G * blockDim.x) {
-		const u32 sidx = sorder[(size_t)region * seg_cap + qi];
-		const VSeg rec = segs[sidx];
-		const VRay vr = rays[rec.ray & 0x7FFFFFFFu];
-		const bool lastseg = sidx + 1u == vr.off + vr.nseg;
-		u32 gx = vr.goal[0], gy = vr.goal[1], gz = vr.goal[2];
-		if (!lastseg) {
-			const VSeg* nx = segs + sidx + 1u;
-			gx = nx->c[0];
-			gy = nx->c[1];
-			gz = nx->c[2];
-		}
-		u32 x = rec.c[0], y = rec.c[1], z = rec.c[2];
+		const size_t pos = (size_t)region * seg_cap + qi;
+		const u32 rid = sg.ray[pos];
+		const VRay vr = rays[rid & 0x7FFFFFFFu];
+		const u32 gx = sg.ex[pos], gy = sg.ey[pos], gz = sg.ez[pos];
+		u32 x = sg.cx[pos], y = sg.cy[pos], z = sg.cz[pos];
 		const u32 sx = (u32)(i32)vr.s[0], sy = (u32)(i32)vr.s[1], sz = (u32)(i32)vr.s[2];
-		double tmx = rec.tm[0], tmy = rec.tm[1], tmz = rec.tm[2];
+		double tmx = sg.tmx[pos], tmy = sg.tmy[pos], tmz = sg.tmz[pos];
 		const double tdx = vr.td[0], tdy = vr.td[1], tdz = vr.td[2];
 		const long long idist = __double_as_longlong(vr.dist);
 		// the ray's first cell is always marked (the reference's do-while); a later segment starts where the sequential walk has
 		// just stepped to: it goes on iff t_max.min() <= distance there (OMB:1300; its cell is not the goal's: fewer pops of the
 		// dominant axis)
-		bool go = (0 != (rec.ray >> 31)) || ((__double_as_longlong(tmx) <= idist) | (__double_as_longlong(tmy) <= idist) | (__double_as_longlong(tmz) <= idist));
+		bool go = (0 != (rid >> 31)) || ((__double_as_longlong(tmx) <= idist) | (__double_as_longlong(tmy) <= idist) | (__double_as_longlong(tmz) <= idist));
 		u32 c = 0, curw = 0xFFFFFFFFu;
 		u64 acc = 0;
 		while (go) {
@@ -593,7 +581,10 @@ __global__ __launch_bounds__(256) void k_vwalk(MapGeom g, VolGeo vg, u64* __rest
 
 // the tiles some XCD has marked -> list (tile, copies it was marked in); the bitmaps are left clean. One thread per word of
 // the bitmaps (32 tiles); count in *n_out.
-__global__ __launch_bounds__(256) void k_vlist(u32* __restrict__ tbx, u32 ntiles, u32* __restrict__ list, uint8_t* __restrict__ copies, u32* n_out)
+// (... and where each tile's level-3 block was when a walk last left a record for it: k_tile's guess of the tile's group arrives with
+// the list entry, its records are asked for together with the brick words -- one dependent round trip less per wave)
+__global__ __launch_bounds__(256) void k_vlist(u32* __restrict__ tbx, u32 ntiles, u32* __restrict__ list, uint8_t* __restrict__ copies, u32* n_out, const TileRec* __restrict__ recs,
+                                               u32* __restrict__ slots)
 {
 	const u32 nwords = volTbWords(ntiles);  // (the padding words are never marked)
 	for (u32 w0 = blockIdx.x * blockDim.x; w0 < nwords; w0 += gridDim.x * blockDim.x) {  // (uniform)
@@ -616,6 +607,7 @@ __global__ __launch_bounds__(256) void k_vlist(u32* __restrict__ tbx, u32 ntiles
 			for (int k = 0; k < 8; ++k) cm |= ((c[k] >> bit) & 1u) << k;
 			list[pos] = 32u * w + bit;
 			copies[pos] = (uint8_t)cm;
+			slots[pos] = recs[32u * w + bit].slot;
 			++pos;
 		}
 	}
