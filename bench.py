@@ -274,11 +274,22 @@ def other_configs(device, big, only=None):
         return dict(ms_per_scan=ms, scans=n_async, digest_ok=bool(ok), note="async=true calls back to back after one synchronous scan into a fresh map; "
                     "the final map compared with the unmodified reference's after the same number of scans")
 
-    for label, name, reps in (("C1_lidar16cm_continuous", "c1_full", 10), ("C5_lidar8cm_colour", "c5_colour_8cm", 10)) + ((("C3_rgbd2mm_depth0", "c3_depth0_full", 5),) if big else ()):
+    for label, name, reps in (("C1_lidar16cm_continuous", "c1_full", 10), ("C5_lidar8cm_colour", "c5_colour_8cm", 10)) + (
+            (("C3_rgbd2mm_depth0", "c3_depth0_full", 5), ("C3_rgbd2mm_colour_depth0", "c3_colour_full", 5)) if big else ()):
         if only and label not in only:
+            continue
+        if name not in fixtures:
             continue
         fx = fixtures[name]
         c3 = label == "C3_rgbd2mm_depth0"
+        if label == "C3_rgbd2mm_colour_depth0":
+            # the reference's only published figure (README.md:10-11): a COLOURED map at 2 mm, "real-time 2 Hz" = 500 ms per frame.
+            # The same frame with colours on the volume path (round 5; round 4: the general path); fresh + warm, the first warm
+            # repetitions compared with the reference's map after as many scans
+            run(label, fx["params"], fx["scans"][:1], [s["digest"] for s in fx["steps"]], reps, instrument=True)
+            out[label]["reference_published_ms"] = 500.0
+            torch.cuda.empty_cache()
+            continue
         # (C3 at insert depth 0: the fixture holds the SAME frame seven times -- the first scan is timed into a fresh map, the others
         # are the warm repetitions, every one of them compared with the reference's map after as many scans)
         run(label, fx["params"], fx["scans"][:1] if c3 else fx["scans"], [s["digest"] for s in fx["steps"]], reps, instrument=c3)
@@ -530,6 +541,12 @@ def main():
                 cx = json.loads(pr.stdout.strip().splitlines()[-1])
                 extra["host_cxx"] = dict(rays_per_s=cx["rays_per_s"], ms_per_step=cx["ms_per_step"], repeats=cx["repeats"], timed_region_s=cx["timed_region_s"],
                                          scans_per_walk=cx["fast_path_scans"] / max(1, cx["tree_walks"]), gate_timeouts=cx["gate_timeouts"],
+                                         host_us_per_call=cx.get("host_us_per_call"), host_us_scan_half_enqueue=cx.get("host_us_scan_half_enqueue"),
+                                         host_us_map_half_enqueue=cx.get("host_us_map_half_enqueue"), host_us_join=cx.get("host_us_join"),
+                                         device_timeline=dict(cx.get("timeline", {}), note="one more repetition of the C++ loop with the hand-over kernels recording the device "
+                                                              "clock (ufomap_map_timeline): medians. The period of the pipeline is the larger of the scan stream's and the host's "
+                                                              "call rate: a box whose ms_per_step is higher shows WHERE here -- ray_kernel_and_launches_us (device: clock, "
+                                                              "queue mapping) or published_to_next_gate_us / host_us_per_call (host: launch cost)"),
                                          note="the same W + K sequence and repetitions as `value`, driven by examples/bench_loop.cpp (a C++ loop over "
                                               "ufomap_map_insert_device, async) in a process of its own: the library without the Python loop")
                 digests["host_cxx"] = tuple(int(v) for v in cx["digest"])

@@ -6,6 +6,7 @@
 //   clouds.bin: u64 n_poses, u64 n_points, then per pose: 3 doubles (sensor origin) + n_points * 3 doubles
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
@@ -75,10 +76,70 @@ int main(int argc, char** argv)
 	uint64_t dig[6] = {0, 0, 0, 0, 0, 0}, dbg[64] = {0};
 	if (ufomap_map_digest(m, 1, dig)) return 3;
 	ufomap_map_debug(m, dbg, 64);
+	// ---- where the period comes from: the host's time inside the calls (the library's own counters), and -- one more repetition
+	// with the hand-over kernels recording the device clock (option "tstamps") -- the streams' periods and waits on the DEVICE.
+	// A period set by the device (clock, hardware-queue mapping) shows in the scan stream's period; one set by the host in
+	// "gate entered after the previous scan was published" and in the host's microseconds per call.
+	const double calls = (double)(W + K) * reps;
+	const double host_us_call = dbg[55] * 1e-3 / calls, host_scan_us = dbg[52] * 1e-3 / calls, host_map_us = dbg[53] * 1e-3 / calls, host_join_us = dbg[54] * 1e-3 / calls;
+	double tl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	double tl_ms = 0;
+	if (K >= 20 && 0 == ufomap_map_set_option(m, "tstamps", 1)) {
+		const int KT = std::max(K, 200);
+		if (ufomap_map_wait(m) || ufomap_map_clear(m)) return 3;
+		for (int i = 0; i < W; ++i)
+			if (step(i)) return 3;
+		if (ufomap_map_wait(m)) return 3;
+		const auto t0 = std::chrono::steady_clock::now();
+		for (int i = W; i < W + KT; ++i)
+			if (step(i)) return 3;
+		if (ufomap_map_wait(m)) return 3;
+		tl_ms = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e3 / KT;
+		std::vector<unsigned long long> ts(4096 * 8);
+		unsigned long long newest = 0;
+		if (0 == ufomap_map_timeline(m, ts.data(), ts.size(), &newest) && newest > (unsigned long long)KT) {
+			auto rec = [&](unsigned long long f, int k) { return (double)ts[(f % 4096) * 8 + k]; };
+			auto median = [](std::vector<double>& v) {
+				if (v.empty()) return 0.0;
+				std::sort(v.begin(), v.end());
+				return v[v.size() / 2];
+			};
+			std::vector<double> period, fcast, gatew, gap, claimw, walk, spw, wperiod;
+			const unsigned long long lo = newest - KT + 20, hi = newest - 5;
+			double prev_walk_end = 0;
+			for (unsigned long long f = lo; f < hi; ++f) {
+				period.push_back((rec(f + 1, 3) - rec(f, 3)) * 0.01);   // scan half published, consecutive scans (100 MHz clock)
+				fcast.push_back((rec(f, 3) - rec(f, 2)) * 0.01);        // gate open -> scan half published: the ray kernel + launches
+				gatew.push_back((rec(f, 2) - rec(f, 1)) * 0.01);        // the scan stream idle, waiting for the first-point pass
+				gap.push_back((rec(f + 1, 1) - rec(f, 3)) * 0.01);      // published(i) -> gate entered(i + 1): host enqueue + launch latency
+				if (rec(f, 7) > 0) {                                    // the scan whose slot walked
+					claimw.push_back((rec(f, 5) - rec(f, 4)) * 0.01);
+					walk.push_back((rec(f, 6) - rec(f, 5)) * 0.01);
+					spw.push_back(rec(f, 7));
+					if (prev_walk_end > 0) wperiod.push_back((rec(f, 6) - prev_walk_end) * 0.01);
+					prev_walk_end = rec(f, 6);
+				}
+			}
+			tl[0] = median(period);
+			tl[1] = median(fcast);
+			tl[2] = median(gatew);
+			tl[3] = median(gap);
+			tl[4] = median(claimw);
+			tl[5] = median(walk);
+			double sp = 0;
+			for (double v : spw) sp += v;
+			tl[6] = spw.empty() ? 0 : sp / spw.size();
+			tl[7] = median(wperiod);
+		}
+	}
 	std::printf("{\"ms_per_step\": %.6f, \"repeats\": %d, \"timed_region_s\": %.4f, \"rays_per_s\": %.1f, \"digest\": [\"%llu\", \"%llu\", \"%llu\", \"%llu\", \"%llu\", \"%llu\"], "
-	            "\"fast_path_scans\": %llu, \"tree_walks\": %llu, \"gate_timeouts\": %llu}\n",
+	            "\"fast_path_scans\": %llu, \"tree_walks\": %llu, \"gate_timeouts\": %llu, "
+	            "\"host_us_per_call\": %.3f, \"host_us_scan_half_enqueue\": %.3f, \"host_us_map_half_enqueue\": %.3f, \"host_us_join\": %.3f, "
+	            "\"timeline\": {\"ms_per_step_with_stamps\": %.6f, \"scan_stream_period_us\": %.2f, \"ray_kernel_and_launches_us\": %.2f, \"gate_wait_us\": %.2f, "
+	            "\"published_to_next_gate_us\": %.2f, \"claim_wait_us\": %.2f, \"walk_us\": %.2f, \"scans_per_walk\": %.2f, \"walk_period_us\": %.2f}}\n",
 	            total / ((double)K * reps) * 1e3, reps, total, (double)N * K * reps / total, (unsigned long long)dig[0], (unsigned long long)dig[1], (unsigned long long)dig[2],
-	            (unsigned long long)dig[3], (unsigned long long)dig[4], (unsigned long long)dig[5], (unsigned long long)dbg[61], (unsigned long long)dbg[60], (unsigned long long)dbg[58]);
+	            (unsigned long long)dig[3], (unsigned long long)dig[4], (unsigned long long)dig[5], (unsigned long long)dbg[61], (unsigned long long)dbg[60], (unsigned long long)dbg[58],
+	            host_us_call, host_scan_us, host_map_us, host_join_us, tl_ms, tl[0], tl[1], tl[2], tl[3], tl[4], tl[5], tl[6], tl[7]);
 	ufomap_map_destroy(m);
 	return 0;
 }

@@ -27,6 +27,9 @@ CASES = {
     # (seven scans of the same frame: the bench times the first into a fresh map, five warm repetitions and an instrumented one,
     # and compares the map after EVERY one of them -- round 4 timed warm scans whose results nobody had checked at full size)
     "c3_depth0_full": (dict(resolution=0.002), [("rgbd", dict(), dict(max_range=5.0, discrete=True))] * 7),
+    # coloured 2 mm frames (the reference's published figure is a coloured map at 2 mm): reduced, and at full size (two scans)
+    "c3_colour_160x120": (dict(resolution=0.002, color=True), [("rgbd", dict(width=160, height=120, colored=True), dict(max_range=5.0, discrete=True))] * 2),
+    "c3_colour_full": (dict(resolution=0.002, color=True), [("rgbd", dict(colored=True), dict(max_range=5.0, discrete=True))] * 3),
     "c1_full": (dict(resolution=0.16), [("lidar64", dict(), dict(max_range=20.0))] * 2),
     "c2_full_x3": (dict(resolution=0.16), [("lidar64", dict(), dict(max_range=20.0, discrete=True))] * 3),
     "c4_8poses_x2": (dict(resolution=0.16), [("lidar64", dict(pose=s % 8, seed=100 + s % 8), dict(max_range=20.0, discrete=True)) for s in range(16)]),
@@ -43,7 +46,7 @@ def make_scan(gen, kw):
 
 def main():
     assert build("reference"), "the reference oracle is needed (run where /root/reference exists)"
-    path = os.path.join(HERE, "digests.json")
+    path = os.environ.get("UFO_DIGESTS_OUT", os.path.join(HERE, "digests.json"))  # (another file: two generators at a time)
     out = json.load(open(path)) if os.path.exists(path) else {}
     for name in (sys.argv[1:] or list(CASES)):
         params, seq = CASES[name]

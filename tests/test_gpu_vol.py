@@ -291,3 +291,77 @@ def test_volume_path_walk_in_flight_and_other_paths(variant):
     g.insertPointCloudWait()
     _assert_same_map(g, o, "mixed paths")
     assert g.debug()[50] >= 5
+
+
+@pytest.mark.parametrize("mode", ["sync", "async", "mixed_clouds"])
+def test_colour_maps_on_the_volume_path(mode):
+    """Round 5: OccupancyMapColor on the volume path (k_tile<true, VOL>, k_up<true>, k_ftail<true>): a voxel that receives a hit takes
+    the colour of its FIRST point (found through the scan's hit hash) blended with what it has (occupancy_map_color.h:195-287,
+    occupancy_map_color.cpp:142-171), every node above carries the root mean square of its children's colours, pruning needs equal
+    colours -- against the reference scan by scan: leaves with colours, inner nodes, byte stream; a wandering sensor, scans of one
+    colour (subtrees collapse), plain clouds into the colour map in between, asynchronous calls."""
+    from ufomap_amd import scans, OccupancyMapColor, PointCloud, PointCloudColor
+    from oracle import OracleMap
+    from test_gpu_batch import _assert_same_colour_map
+    g, o = OccupancyMapColor(resolution=0.16), OracleMap(kind=_kind(), color=True, resolution=0.16)
+    _force_vol(g)
+    base = np.array(scans.lidar_pose(0), dtype=np.float64)
+    rng = np.random.default_rng(78)
+    n_scans = 12
+    for i in range(n_scans):
+        off = rng.uniform(-0.6, 0.6, 3) * [1, 1, 0.1]
+        origin, xyz, rgb = scans.lidar64(beams=32, azimuths=512, origin=tuple(base + off), seed=600 + i, colored=True)
+        if i % 5 == 4:
+            rgb = np.full_like(rgb, 90 + i)  # (a scan of one colour: whole subtrees become equal and collapse)
+        plain = mode == "mixed_clouds" and i % 3 == 1
+        cloud = PointCloud(xyz) if plain else PointCloudColor(xyz, rgb)
+        async_ = mode == "async" or (mode == "mixed_clouds" and i % 4 == 3)
+        g.insertPointCloudDiscrete(origin, cloud, 12.0, 0, False, 0, async_)
+        o.insert(origin, xyz, None if plain else rgb, max_range=12.0, discrete=True)
+        if i in (1, 6):
+            g.insertPointCloudWait()
+            _assert_same_colour_map(g, o, f"{mode}: after scan {i}")
+    g.insertPointCloudWait()
+    _assert_same_colour_map(g, o, f"{mode}: final")
+    d = g.debug()
+    assert d[50] == n_scans and d[61] == 0, f"the colour scans did not take the volume path: {d[48:51]}, fast {d[61]}"
+
+
+def test_coloured_rgbd_frame_on_the_volume_path():
+    """The reference's only published figure is a COLOURED map at 2 mm (README.md:10-11). A reduced coloured frame (160 x 120 pixels,
+    2 mm, insert depth 0) takes the volume path by itself: fresh and warm against the fingerprints of the unmodified reference's
+    dumps (tests/golden/digests.json: c3_colour_160x120)."""
+    from ufomap_amd import OccupancyMapColor, PointCloudColor, scans
+    import golden_util
+    fx = golden_util.digests().get("c3_colour_160x120")
+    if fx is None:
+        pytest.skip("fixture c3_colour_160x120 not generated")
+    g = OccupancyMapColor(resolution=0.002)
+    origin, xyz, rgb = scans.rgbd(width=160, height=120, colored=True)
+    for i in range(2):
+        g.insertPointCloudDiscrete(origin, PointCloudColor(xyz, rgb), 5.0)
+        assert g.digest() == tuple(int(v) for v in fx["steps"][i]["digest"]), f"scan {i}: digest differs from the reference's"
+    assert g.debug()[50] == 2, "the coloured frame did not take the volume path"
+
+
+def test_per_xcd_marks_equal_the_general_paths_on_random_frames():
+    """The volume path marks one copy of the brick grid PER XCD with atomics that need no more than the XCD's L2 (vol_kernels.h: a
+    start-up self-test checks that assumption on the device). 100 random frames with rays in every direction -- the tiles round the
+    sensor are marked by waves of all eight XCDs -- cell for cell against the general path's ray cells (k_cast / k_dda: one grid,
+    device-scope or LDS marks), both ray kernels of the volume path; the maps stay equal throughout."""
+    from ufomap_amd import OccupancyMap, scans
+    gv, gs, gg = OccupancyMap(resolution=0.1), OccupancyMap(resolution=0.1), OccupancyMap(resolution=0.1)
+    _force_vol(gv)
+    _force_vol(gs)
+    gs.set_option("vol_mode", 16)  # one lane per ray (k_vdda)
+    gg.set_option("vol", 0)
+    gg.set_option("spec", 0)
+    for seed in range(100):
+        origin, xyz, _ = scans.random_cloud(2000 + 37 * seed, seed=900 + seed, extent=3.0 + 0.05 * seed, origin=(0.3 + 0.01 * seed, -0.2, 0.4))
+        for g in (gv, gs, gg):
+            _insert(g, origin, xyz, -1.0, bool(seed & 1))
+        ref = gg.last_misses()
+        assert np.array_equal(gv.last_misses(), ref), f"frame {seed}: the segmented walk's ray cells differ from the general path's"
+        assert np.array_equal(gs.last_misses(), ref), f"frame {seed}: k_vdda's ray cells differ from the general path's"
+    assert gv.debug()[50] == 100 and gs.debug()[50] == 100 and gg.debug()[50] == 0
+    assert gv.digest() == gg.digest() == gs.digest()

@@ -1092,6 +1092,37 @@ __host__ __device__ inline u32 upperCell(const UpperGeo& ug, u32 l, const i32 c[
 // misses are applied after all hits in ascending code order: "the last update beneath a node" is always the miss in
 // the highest touched child of the LAST scan that touched it, at every level.
 // ------------------------------------------------------------------------------------------------
+// What a new node block inherits (createChildren, octree.h:1044-1054): the value (and colour) of the nearest node above that has a
+// live block -- the root node's own when there is none. The NL lanes of a group (lane index `sub` inside it) look the ancestors up
+// side by side: a lone lane walking up the empty path of a fresh map is a dozen DEPENDENT round trips, and a fresh 2 mm frame
+// creates 9e5 tiles -- 2.6 of its tree update's 4.5 ms (round 5). Nothing above the caller's level is written during its launch.
+template <bool COLOR, int NL>
+__device__ inline void inheritLookup(const Table& t, u64 lk, u32 sub, float* vin, u32* cin)
+{
+	const u32 na = (63u - (u32)__clzll((long long)lk)) / 3u;  // ancestors: lk >> 3, lk >> 6, ..., 1
+	u32 best = 0xFFFFFFFFu, bc = 0;
+	float bv = 0.f;
+	for (u32 a = sub; a < na; a += (u32)NL) {
+		const u32 sa = tableFind(t, lk >> (3u * (a + 1u)));
+		if (sa != NONE && !(t.flags(sa) & F_DEAD)) {
+			const u32 child = (u32)((lk >> (3u * a)) & 7);
+			best = a;
+			bv = t.occ(sa)[child];
+			if (COLOR) bc = t.rgb[8 * (size_t)sa + child];
+			break;  // (ascending: the lane's nearest)
+		}
+	}
+	u32 m = best;
+	for (int o = 1; o < NL; o <<= 1) m = min(m, (u32)__shfl_xor((int)m, o));
+	if (0xFFFFFFFFu == m) {
+		*vin = t.root->occ;
+		if (COLOR) *cin = t.root->rgb;
+	} else {
+		const int src = (int)((__lane_id() & ~(u32)(NL - 1)) + (m % (u32)NL));
+		*vin = __shfl(bv, src);
+		if (COLOR) *cin = (u32)__shfl((int)bc, src);
+	}
+}
 struct TileRec {
 	float occ, pre_occ;  // summary of the tile's level-3 block after the batch / just before its last update
 	u32 slot;            // table slot of the level-3 block
@@ -1197,16 +1228,19 @@ __device__ inline bool tileKey(const MapGeom& g, const FastGeo& fg, u32 tile, u6
 __host__ __device__ inline size_t volCopyWords(u32 ntiles) { return ((size_t)ntiles * 8u + 31u) & ~(size_t)31u; }
 #define UFO_UPCNT_STRIDE 32u  // 32-bit words between two of k_up's pairs of counters (volume path; 64 pairs)
 #define UFO_UPCNT_WORDS (64u * UFO_UPCNT_STRIDE)
+#define UFO_RESV_STRIDE 32u
 struct TileVol {
 	u64* Mx;               // ray cells: eight copies, one per XCD (k_vdda); read, ORed and left zeroed here
 	u64* Mm;               // ... the tile's merged words, for whoever asks for the scan's ray cells afterwards (may be null)
 	u64* H;                // hit voxels; left zeroed
 	const u32* list;       // active tiles
 	const uint8_t* copies; // ... and the copies each was marked in
+	HitHash hh;            // colour maps: the scan's hit hash (k_classify: voxel code -> index of the voxel's FIRST point) ...
+	const uint8_t* rgb;    // ... and the cloud's colours, 3 bytes per point (null: a cloud without colours)
 	const u32* slots;      // ... and a guess of the slot of each tile's level-3 block (k_vlist: from the record of an earlier walk)
 	u32 retry;             // the walk is run again after a table growth: tiles whose records carry its number are done
 	u32 count;
-	u32* resv;             // 64 counters of tile groups claimed by this walk
+	u32* resv;             // 64 counters of tile groups claimed by this walk, UFO_RESV_STRIDE words apart (a cache line each)
 	u32 resv_lim;          // ... and what each may reach
 };
 template <bool COLOR, bool VOL = false>
@@ -1451,7 +1485,7 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 				// out of the walk's reserve, or stands back
 				const u32 need = mk3 ? 1u : 0u;
 				u32 over = 0;
-				if (need && 0 == lane) over = (atomicAdd(&va.resv[(tile * 0x9E3779B1u) >> 26], need) + need > va.resv_lim) ? 1u : 0u;
+				if (need && 0 == lane) over = (atomicAdd(&va.resv[((tile * 0x9E3779B1u) >> 26) * UFO_RESV_STRIDE], need) + need > va.resv_lim) ? 1u : 0u;
 				if (__shfl((int)over, 0)) {
 					if (0 == lane) atomicOr(&UFO_DESC(B - 1u).ctl->err, ERR_GROW);
 					return;
@@ -1467,6 +1501,7 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 				if (0 == lane) grp_own = (s3 != NONE) ? (s3 - t.capU) / UFO_GROUP : groupEnsure(t, lk3);
 				grp_own = (u32)__shfl((int)grp_own, 0);
 			}
+			if (need3) inheritLookup<COLOR, 64>(t, lk3, lane, &v3s, &r3s);  // (uniform: every lane gets the values)
 			if (need3 && 0 == lane) {
 				if (mk3) {
 					if (own) {
@@ -1477,17 +1512,6 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 							++n_created;
 						}
 					} else s3 = tableEnsure(t, lk3, scan_id, max_probe, &dummy, &n_created);
-				}
-				v3s = t.root->occ;
-				if (COLOR) r3s = t.root->rgb;
-				for (u64 k = lk3 >> 3, below = lk3; k >= 1; below = k, k >>= 3) {
-					const u32 sa = tableFind(t, k);
-					if (sa != NONE && !(t.flags(sa) & F_DEAD)) {
-						v3s = t.occ(sa)[(u32)(below & 7)];
-						if (COLOR) r3s = t.rgb[8 * (size_t)sa + (u32)(below & 7)];
-						break;
-					}
-					if (1 == k) break;
 				}
 			}
 			if (own) {
@@ -1512,8 +1536,6 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 			new1 = mk1;
 			new2 = mk2;
 			s3 = __shfl(s3, 0);
-			v3s = __shfl(v3s, 0);
-			if (COLOR) r3s = (u32)__shfl((int)r3s, 0);
 			s2 = __shfl(s2, (int)(lane & ~7u));
 			if (__ballot((s3 == NONE) || (uact2 && s2 == NONE) || (uactive && s1 == NONE))) {
 				if (0 == lane) atomicOr(&UFO_DESC(B - 1u).ctl->err, ERR_TABLE_FULL);  // (the host sizes the table for the worst case before launching)
@@ -1590,8 +1612,21 @@ __global__ __launch_bounds__(256) void k_tile(Table t, MapGeom g, FastGeo fg, co
 				// updateValue(code, update, color) (OMC.h:275-277): the colour first, with the occupancy the voxel has before the
 				// hit; the colour is the one of the voxel's FIRST point (OMC.h:195-233), whose index the dense first-point array
 				// holds -- read here (k_fmerge left the array alone for a coloured scan) and cleaned for the set's next scan
-				const uint8_t* rgbp = UFO_DESC(b).rgb;
-				if (rgbp && hmask) {
+				const uint8_t* rgbp = VOL ? va.rgb : UFO_DESC(b).rgb;
+				if (VOL && rgbp && hmask) {
+					// (the volume path: no dense first-point array over a grid of 4e9 cells -- the voxel's first point is looked up in
+					// the scan's hit hash, a few hundred thousand entries for the hits of a frame)
+					const u64 vbase = (lk1 ^ (1ULL << (3 * (g.L - 1)))) << 3;
+#pragma unroll
+					for (int c = 0; c < 8; ++c) {
+						if (!((hmask >> c) & 1u)) continue;
+						const u32 hs = hitHashFind(va.hh, vbase | (u64)c);
+						if (NONE == hs) continue;  // (cannot happen: the hit grid was derived from the hash's entries)
+						const u32 pt = va.hh.minidx[hs];
+						const u32 u = (u32)rgbp[3 * (size_t)pt] | ((u32)rgbp[3 * (size_t)pt + 1] << 8) | ((u32)rgbp[3 * (size_t)pt + 2] << 16);
+						col[c] = blendColor(g, col[c], u, v[c]);
+					}
+				} else if (rgbp && hmask) {
 					u32* fp = UFO_DESC(b).first;
 #pragma unroll
 					for (int c = 0; c < 8; ++c) {
@@ -1919,32 +1954,18 @@ __global__ __launch_bounds__(256) void k_up(Table t, MapGeom g, FastGeo fg, cons
 	u32 cin = 0;
 	if (act && 0 == sub) {
 		s = tableEnsure(t, lk, scan_id, (t.mask >> 1) + 1, &cr, &n_created);
-		if (s == NONE) {
-			atomicOr(&ctl->err, ERR_TABLE_FULL);
-		} else if (cr) {
-			vin = t.root->occ;
-			if (COLOR) cin = t.root->rgb;
-			for (u64 k = lk >> 3, below = lk; k >= 1; below = k, k >>= 3) {
-				const u32 sa = tableFind(t, k);
-				if (sa != NONE && !(t.flags(sa) & F_DEAD)) {
-					vin = t.occ(sa)[(u32)(below & 7)];
-					if (COLOR) cin = t.rgb[8 * (size_t)sa + (u32)(below & 7)];
-					break;
-				}
-				if (1 == k) break;
-			}
-			// leaf children carry the flags of a leaf with this value (OMB:1181-1189)
-			fw = (isFreeV(g, vin) ? F_CFREE : 0u) | (isUnknownV(g, vin) ? F_CUNK : 0u);
-		} else {
-			fw = t.flags(s) & ~F_DIRTY;
-		}
+		if (s == NONE) atomicOr(&ctl->err, ERR_TABLE_FULL);
+		else if (!cr) fw = t.flags(s) & ~F_DIRTY;
 	}
 	const int l0 = (int)(lane & ~7u);
 	s = (u32)__shfl((int)s, l0);
 	cr = 0 != __shfl(cr ? 1 : 0, l0);
+	if (cr) {  // (whole groups of 8 lanes: the ancestors looked up side by side)
+		inheritLookup<COLOR, 8>(t, lk, sub, &vin, &cin);
+		// leaf children carry the flags of a leaf with this value (OMB:1181-1189)
+		fw = (isFreeV(g, vin) ? F_CFREE : 0u) | (isUnknownV(g, vin) ? F_CUNK : 0u);
+	}
 	fw = (u32)__shfl((int)fw, l0);
-	vin = __shfl(vin, l0);
-	cin = (u32)__shfl((int)cin, l0);
 	const bool ok = act && s != NONE;
 	float v = vin;
 	u32 c = cin;

@@ -4,7 +4,11 @@
 // b_vaux, 32-bit words: [0..63] the reserve's counters, [64] tiles listed, [65] tiles done, [66..67] blocks the listed tiles touch,
 // from UFO_VAUX_UPCNT on k_up's 64 pairs of counters (blocks touched / created above the tiles; k_ftail folds and clears them)
 #define UFO_VAUX_UPCNT 256u
-#define UFO_VAUX_BYTES ((UFO_VAUX_UPCNT + UFO_UPCNT_WORDS) * 4u)
+// ... then the reserve's 64 counters, a cache line each (UFO_RESV_STRIDE words apart; words [0..63] are no longer used)
+#define UFO_VAUX_RESV (UFO_VAUX_UPCNT + UFO_UPCNT_WORDS)
+// ... then 64 64-bit counters, 128 bytes apart: the step counts of k_vwalk's waves (k_vlist folds and clears them)
+#define UFO_VAUX_STEPS (UFO_VAUX_RESV + 64u * UFO_RESV_STRIDE)
+#define UFO_VAUX_BYTES ((UFO_VAUX_STEPS + 64u * 32u) * 4u)
 
 // the grid of the level above fg's (what k_up writes when fg is what it reads)
 FastGeo upGeoOf(const FastGeo& fg)
@@ -21,11 +25,38 @@ FastGeo upGeoOf(const FastGeo& fg)
 	return u;
 }
 
+// The assumptions behind the per-XCD copies of the brick grid (vol_kernels.h: k_vselftest), checked on the device once per process:
+// 1 = they hold, -1 = they do not (the volume path stays off). Also -1 under a compiler mode that splits a workgroup's waves over
+// CUs with separate L1s is not needed: the atomics go to the L2 either way.
+int volSelfTest(ufomap_map* m)
+{
+	static std::atomic<int> state{0};
+	int s = state.load(std::memory_order_acquire);
+	if (s) return s;
+	u32* d = nullptr;
+	if (hipMalloc((void**)&d, (8 * 64 + 64) * 4) != hipSuccess) return -1;
+	u32 h[8 * 64 + 64];
+	bool ok = hipMemsetAsync(d, 0, sizeof(h), m->stream) == hipSuccess;
+	if (ok) {
+		hipLaunchKernelGGL(k_vselftest, dim3(8u * UFO_VSELF_BLOCKS), dim3(256), 0, m->stream, d, d + 8 * 64);
+		ok = hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, m->stream) == hipSuccess && hipStreamSynchronize(m->stream) == hipSuccess;
+	}
+	(void)hipFree(d);
+	u64 sum = 0;
+	if (ok)
+		for (int k = 0; k < 8; ++k) sum += h[k * 64];
+	ok = ok && 0 == h[8 * 64] && sum == (u64)8 * UFO_VSELF_BLOCKS * 256 * UFO_VSELF_ADDS;
+	s = ok ? 1 : -1;
+	state.store(s, std::memory_order_release);
+	if (!ok) fprintf(stderr, "[ufomap_amd] the per-XCD atomics self-test failed (%llu additions counted): the volume path is off, scans take the general path\n", (unsigned long long)sum);
+	return s;
+}
+
 // A depth-0 scan of a plain map whose ray box the steady-state path cannot take (more than 1022 cells per axis, or a bit grid
 // beyond 8 MiB) and whose brick grids fit the scratch limit.
 bool volPlan(const ufomap_map* m, const Grid& gr, unsigned depth, int simple, unsigned early_stopping, const uint8_t* d_rgb, VolPlan* vp)
 {
-	if (!m->opt_vol || 0 != depth || simple || early_stopping || d_rgb || m->g.color || m->chg_enabled || m->g.L < 6) return false;
+	if (!m->opt_vol || 0 != depth || simple || early_stopping || ((d_rgb || m->g.color) && !m->opt_vol_color) || m->chg_enabled || m->g.L < 6) return false;
 	const bool packed = 2 * gr.nb[0] < 1023 && 2 * gr.nb[1] < 1023 && 2 * gr.nb[2] < 1023;
 	const u64 bytes1 = (u64)(gridRowBits(gr) >> 3) * (2ull * (u64)gr.nb[1]) * (2ull * (u64)gr.nb[2]);
 	if (m->opt_vol < 2 && packed && bytes1 <= (8ull << 20)) return false;  // (the fast path's sizes; option vol = 2: tests run small scans here)
@@ -62,6 +93,7 @@ bool volPlan(const ufomap_map* m, const Grid& gr, unsigned depth, int simple, un
 		vp->vg.nt[a] = fg.nt[a];
 	}
 	vp->vg.ntiles = fg.ntiles;
+	if (volSelfTest(const_cast<ufomap_map*>(m)) < 0) return false;
 	return true;
 }
 
@@ -139,7 +171,7 @@ int volScan(ufomap_map* m, const D3& sensor, const VolPlan& vp, u32 n_hits, u32 
 			ProfScope ps(m, "k_vdda");  // (the walk itself keeps the name the bench's per-kernel table knows)
 			const u32 G = (u32)std::max(1, m->opt_vol_walk_blocks);
 			hipLaunchKernelGGL(k_vwalk, dim3(8u * G), dim3(256), (size_t)m->opt_vol_walk_lds, m->cs, m->g, vp.vg, m->b_vM.as<u64>(), m->b_vtb.as<u32>(), m->b_vrays.as<VRay>(), sg,
-			                   m->b_vsegcnt.as<u32>(), (u32)seg_cap, ctl, ctl, (u32)m->opt_vol_mode);
+			                   m->b_vsegcnt.as<u32>(), (u32)seg_cap, ctl, ctl, (u32)m->opt_vol_mode, reinterpret_cast<unsigned long long*>(aux + UFO_VAUX_STEPS));
 		}
 	} else {
 		ProfScope ps(m, "k_vdda");
@@ -150,7 +182,7 @@ int volScan(ufomap_map* m, const D3& sensor, const VolPlan& vp, u32 n_hits, u32 
 	{
 		ProfScope ps(m, "k_vlist");
 		hipLaunchKernelGGL(k_vlist, gridFor(tbw, 256, 2048), dim3(256), 0, m->cs, m->b_vtb.as<u32>(), (u32)nt, m->b_vlist.as<u32>(), m->b_vcopies.as<uint8_t>(), aux + 64, m->b_vrec.as<TileRec>(),
-		                   m->b_vslots.as<u32>());
+		                   m->b_vslots.as<u32>(), reinterpret_cast<unsigned long long*>(aux + UFO_VAUX_STEPS), ctl);
 	}
 	HIP_TRY(hipMemcpyAsync(m->h_ctl, m->b_ctl.p, sizeof(ScanCtl), hipMemcpyDeviceToHost, m->cs));
 	HIP_TRY(hipMemcpyAsync(&m->vol_count, aux + 64, 4, hipMemcpyDeviceToHost, m->cs));
@@ -192,7 +224,7 @@ int volWalkEnqueue(ufomap_map* m, bool retry = false)
 	m->h_res->err = ERR_NOT_STORED;
 	*reinterpret_cast<volatile unsigned long long*>(m->h_res + 1) = 0ull;
 	m->done_by_flag = true;
-	hipLaunchKernelGGL(k_vreset, dim3(1), dim3(64), 0, m->stream, aux, ctl, (u32)(ERR_GROW | ERR_PREV));
+	hipLaunchKernelGGL(k_vreset, dim3(1), dim3(64), 0, m->stream, aux + UFO_VAUX_RESV, ctl, (u32)(ERR_GROW | ERR_PREV));
 	TileVol va{};
 	va.Mx = m->b_vM.as<u64>();
 	va.Mm = m->opt_vol_keep ? m->b_vMm.as<u64>() : nullptr;
@@ -202,25 +234,45 @@ int volWalkEnqueue(ufomap_map* m, bool retry = false)
 	va.slots = m->b_vslots.as<u32>();
 	va.retry = retry ? 1u : 0u;
 	va.count = T;
-	va.resv = aux;
+	va.resv = aux + UFO_VAUX_RESV;
 	va.resv_lim = (u32)std::min<u64>(lim_total / 64, 0x7FFFFFFFull);
+	// colour maps (OccupancyMapColor, occupancy_map_color.h:177-287): the colour instances of the same three kernels -- a voxel that
+	// receives a hit takes its first point's colour (found through the scan's hit hash), the summaries carry colours upwards
+	const bool color = m->g.color;
+	if (color) {
+		const u32 hcap = m->hh_mask + 1u;
+		va.hh = HitHash{m->b_hh_keys.as<u64>(), reinterpret_cast<u32*>(m->b_hh_keys.as<u64>() + hcap), m->hh_mask};
+		va.rgb = m->vol_rgb;
+	}
 	{
 		ProfScope ps(m, "k_tile");
-		hipLaunchKernelGGL((k_tile<false, true>), dim3((T + 3) / 4), dim3(256), 0, m->stream, m->t, m->g, fg, pipe, 0ull, recs, m->g.hit, miss, m->vol_scan_id,
-		                   (const u32*)nullptr, ChangeLog{nullptr, 0u, m->g.L}, va);
+		if (color)
+			hipLaunchKernelGGL((k_tile<true, true>), dim3((T + 3) / 4), dim3(256), 0, m->stream, m->t, m->g, fg, pipe, 0ull, recs, m->g.hit, miss, m->vol_scan_id,
+			                   (const u32*)nullptr, ChangeLog{nullptr, 0u, m->g.L}, va);
+		else
+			hipLaunchKernelGGL((k_tile<false, true>), dim3((T + 3) / 4), dim3(256), 0, m->stream, m->t, m->g, fg, pipe, 0ull, recs, m->g.hit, miss, m->vol_scan_id,
+			                   (const u32*)nullptr, ChangeLog{nullptr, 0u, m->g.L}, va);
 	}
 	TileRec* below = recs;
 	for (int k = 1; k < vp.n; ++k) {
 		TileRec* above = below + vp.lv[k - 1].ntiles;
 		ProfScope ps(m, "k_up");
-		hipLaunchKernelGGL(k_up<false>, dim3((u32)(((u64)vp.lv[k].ntiles * 8u + 255u) / 256u)), dim3(256), 0, m->stream, m->t, m->g, vp.lv[k - 1], pipe, 0ull, below,
-		                   above, (k + 1 == vp.n) ? m->b_vupbits.as<u32>() : (u32*)nullptr, m->vol_scan_id, (const u32*)nullptr, aux + UFO_VAUX_UPCNT);
+		const dim3 gu((u32)(((u64)vp.lv[k].ntiles * 8u + 255u) / 256u));
+		u32* ub = (k + 1 == vp.n) ? m->b_vupbits.as<u32>() : (u32*)nullptr;
+		if (color)
+			hipLaunchKernelGGL(k_up<true>, gu, dim3(256), 0, m->stream, m->t, m->g, vp.lv[k - 1], pipe, 0ull, below, above, ub, m->vol_scan_id, (const u32*)nullptr, aux + UFO_VAUX_UPCNT);
+		else
+			hipLaunchKernelGGL(k_up<false>, gu, dim3(256), 0, m->stream, m->t, m->g, vp.lv[k - 1], pipe, 0ull, below, above, ub, m->vol_scan_id, (const u32*)nullptr, aux + UFO_VAUX_UPCNT);
 		below = above;
 	}
 	{
 		ProfScope ps(m, "k_ftail");
-		hipLaunchKernelGGL(k_ftail<false>, dim3(1), dim3(UFO_FTAIL_THREADS), 0, m->stream, m->t, m->g, vp.lv[vp.n - 1], pipe, 0ull, below, m->vol_scan_id, (const u32*)nullptr,
-		                   m->b_ctl_init.as<ScanCtl>(), m->b_vupbits.as<u32>(), 0u, aux + UFO_VAUX_UPCNT);
+		if (color)
+			hipLaunchKernelGGL(k_ftail<true>, dim3(1), dim3(UFO_FTAIL_THREADS), 0, m->stream, m->t, m->g, vp.lv[vp.n - 1], pipe, 0ull, below, m->vol_scan_id, (const u32*)nullptr,
+			                   m->b_ctl_init.as<ScanCtl>(), m->b_vupbits.as<u32>(), 0u, aux + UFO_VAUX_UPCNT);
+		else
+			hipLaunchKernelGGL(k_ftail<false>, dim3(1), dim3(UFO_FTAIL_THREADS), 0, m->stream, m->t, m->g, vp.lv[vp.n - 1], pipe, 0ull, below, m->vol_scan_id, (const u32*)nullptr,
+			                   m->b_ctl_init.as<ScanCtl>(), m->b_vupbits.as<u32>(), 0u, aux + UFO_VAUX_UPCNT);
 	}
 	HIP_TRY(hipGetLastError());
 	return UFOMAP_OK;

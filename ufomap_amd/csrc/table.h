@@ -85,6 +85,10 @@ struct ChangeLog {
 // A block "exists" if its slot's key is set (a claimed group alone creates nothing). Maps with fewer than four levels keep
 // everything in the first region.
 #define UFO_GROUP 73u
+// (128 counters in 512 consecutive bytes are four cache lines: 9e5 atomics of a fresh 2 mm frame's walk on them queued at ~12 ns
+// each whichever of a line's words they named -- 2.6 of that walk's 4.5 ms. A line per counter.)
+#define UFO_GCNT_STRIDE 32u
+#define UFO_GCNT_WORDS (128u * UFO_GCNT_STRIDE)
 struct Table {
 	float* occA;   // [8 * slot + child]: log-odds of the 8 children (32 B per slot, float4-aligned)
 	u64* keyA;     // [slot]: location key, 0 = empty slot
@@ -101,7 +105,7 @@ struct Table {
 	u32 capU;   // slots of the first region
 	u32 nG;     // groups
 	u64* gdir;  // [nG]
-	u32* gcnt;  // [128] sharded counters: [0, 64) groups claimed, [64, 128) blocks created in the first region
+	u32* gcnt;  // 128 sharded counters, UFO_GCNT_STRIDE words apart: [0, 64) groups claimed, [64, 128) blocks created in the first region
 	u32 L;      // depth levels of the map (a key's level = L - position of its sentinel bit / 3)
 	__device__ __forceinline__ u64& key(u32 s) const { return keyA[s]; }
 	__device__ __forceinline__ float* occ(u32 s) const { return occA + 8 * (size_t)s; }
@@ -170,7 +174,7 @@ __device__ inline u32 groupEnsure(const Table& t, u64 lk3)
 		if (k == 0) {
 			const u64 prev = atomicCAS((unsigned long long*)&t.gdir[g], 0ULL, (unsigned long long)lk3);
 			if (prev == 0) {
-				atomicAdd(&t.gcnt[h & 63u], 1u);  // (sharded: every new tile of a scan passes here)
+				atomicAdd(&t.gcnt[(h & 63u) * UFO_GCNT_STRIDE], 1u);  // (sharded: every new tile of a scan passes here)
 				return g;
 			}
 			k = prev;
@@ -280,7 +284,7 @@ __device__ inline u32 tableEnsure(const Table& t, u64 lk, u32 scan_id, u32 max_p
 			t.stamp(s) = scan_id;
 			++*n_created;
 			*created = true;
-			atomicAdd(&t.gcnt[64u + (h & 63u)], 1u);
+			atomicAdd(&t.gcnt[(64u + (h & 63u)) * UFO_GCNT_STRIDE], 1u);
 			return s;
 		}
 		if (seen == lk) return reviveIfDead(t, s, scan_id, created);
@@ -306,7 +310,7 @@ __device__ inline u32 tableInsertNew(const Table& t, u64 lk)
 	u32 s = (u32)(((u64)h * (u64)t.capU) >> 32);
 	for (u32 probe = 0; probe < t.capU; ++probe) {
 		if (slotClaim(t, s, lk, &seen)) {
-			atomicAdd(&t.gcnt[64u + (h & 63u)], 1u);
+			atomicAdd(&t.gcnt[(64u + (h & 63u)) * UFO_GCNT_STRIDE], 1u);
 			return s;
 		}
 		s = (s + 1u == t.capU) ? 0u : s + 1u;
@@ -316,8 +320,8 @@ __device__ inline u32 tableInsertNew(const Table& t, u64 lk)
 // the sharded counters, by one wave: groups claimed, blocks of the first region
 __device__ inline void tableCounts(const Table& t, u32 lane, u32* groups, u32* upper)
 {
-	u32 a = __hip_atomic_load(&t.gcnt[lane & 63u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-	    b = __hip_atomic_load(&t.gcnt[64u + (lane & 63u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	u32 a = __hip_atomic_load(&t.gcnt[(lane & 63u) * UFO_GCNT_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+	    b = __hip_atomic_load(&t.gcnt[(64u + (lane & 63u)) * UFO_GCNT_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	for (int o = 32; o > 0; o >>= 1) {
 		a += __shfl_xor(a, o);
 		b += __shfl_xor(b, o);

@@ -237,6 +237,7 @@ struct HandOver {
 	bool vol_walk = false;   // ... its walk has been enqueued and not been looked at (volWalkFinish: the reserve may have run out)
 	u32 vol_count = 0;       // tiles the scan has listed
 	u32 vol_scan_id = 0;     // the walk's number (tile records of a walk that is repeated after a table growth carry it)
+	const uint8_t* vol_rgb = nullptr;  // the scan's colours (the caller's device array, or the set's own copy of it)
 	VolPlan vplan{};
 };
 
@@ -335,11 +336,13 @@ struct ufomap_map {
 	int opt_vol_seg = 192;  // cells per segment of a ray on the volume path (k_vcutA / k_vwalk)
 	int opt_vol_walk_blocks = 1536;  // workgroups of k_vwalk per eighth of the scan
 	int opt_vol_walk_lds = 0;  // extra LDS per workgroup of k_vwalk, bytes: caps its workgroups per CU (what is left takes the tree update of the scan before)
+	int opt_vol_color = 1;  // colour maps on the volume path (0: the general path, as in round 4)
 	int opt_vol_async = 1;  // an asynchronous call returns with the volume path's walk enqueued (0: every call returns a finished integration)
 	int opt_vol_keep = 1;   // k_tile leaves the merged ray cells of its tiles behind (ufomap_map_last_misses)
 	// (the current hand-over set's share of the volume path's state: HandOver)
 	bool vol = false, vol_dirty = true, vol_walk = false;
 	u32 vol_count = 0, vol_scan_id = 0;
+	const uint8_t* vol_rgb = nullptr;
 	DevBuf b_vM, b_vMm, b_vH, b_vtb, b_vlist, b_vcopies, b_vslots, b_vaux, b_vupbits, b_vrec;
 	VolPlan vplan{};
 	// ... and what all sets share: the scan half's own scratch (scan halves run one after the other on the scan stream)
@@ -495,7 +498,7 @@ int allocTable(ufomap_map* m, u32 nG, u32 capU, Table* out, TableBufs* tb)
 	HIP_TRY(tb->luocc.reserve((size_t)cap * 4));
 	HIP_TRY(tb->lufl.reserve((size_t)cap * 4));
 	HIP_TRY(tb->gdir.reserve((size_t)nG * 8));
-	HIP_TRY(tb->gcnt.reserve(128 * 4));
+	HIP_TRY(tb->gcnt.reserve(UFO_GCNT_WORDS * 4));
 	if (m->g.color) {
 		HIP_TRY(tb->rgb.reserve((size_t)cap * 32));
 		HIP_TRY(tb->lurgb.reserve((size_t)cap * 4));
@@ -506,7 +509,7 @@ int allocTable(ufomap_map* m, u32 nG, u32 capU, Table* out, TableBufs* tb)
 	HIP_TRY(hipMemsetAsync(tb->tmax.p, 0, (size_t)cap * 8, m->stream));
 	HIP_TRY(hipMemsetAsync(tb->lufl.p, 0, (size_t)cap * 4, m->stream));
 	HIP_TRY(hipMemsetAsync(tb->gdir.p, 0, (size_t)nG * 8, m->stream));
-	HIP_TRY(hipMemsetAsync(tb->gcnt.p, 0, 128 * 4, m->stream));
+	HIP_TRY(hipMemsetAsync(tb->gcnt.p, 0, UFO_GCNT_WORDS * 4, m->stream));
 	// [occ 32 B][key 8 B][flags 4 B][stamp 4 B][parent 4 B] x cap
 	out->occA = tb->blk.as<float>();
 	out->keyA = reinterpret_cast<u64*>((char*)tb->blk.p + (size_t)cap * 32);
@@ -715,6 +718,7 @@ void swapWith(ufomap_map* m, HandOver& o)
 	std::swap(m->vol_walk, o.vol_walk);
 	std::swap(m->vol_count, o.vol_count);
 	std::swap(m->vol_scan_id, o.vol_scan_id);
+	std::swap(m->vol_rgb, o.vol_rgb);
 	std::swap(m->vplan, o.vplan);
 }
 
@@ -1523,6 +1527,7 @@ int scanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, const 
 		// a ray box far beyond the steady-state path's grids (a 2 mm RGB-D frame): the volume path -- brick grids, the tiled tree update
 		VolPlan vp;
 		if (volPlan(m, m->gridM, depth, simple, early_stopping, d_rgb, &vp)) {
+			m->vol_rgb = d_rgb;
 			const int vrc = volScan(m, sensor, vp, n_hits, n_rays);
 			if (vrc < 0) return vrc;
 			if (0 == vrc) {
@@ -2361,7 +2366,7 @@ int ufomap_map_clear(ufomap_map* m)
 	HIP_TRY(hipMemsetAsync(m->t.tmax, 0, (size_t)cap * 8, m->stream));
 	HIP_TRY(hipMemsetAsync(m->t.lu_fl, 0, (size_t)cap * 4, m->stream));
 	HIP_TRY(hipMemsetAsync(m->t.gdir, 0, (size_t)m->t.nG * 8, m->stream));
-	HIP_TRY(hipMemsetAsync(m->t.gcnt, 0, 128 * 4, m->stream));
+	HIP_TRY(hipMemsetAsync(m->t.gcnt, 0, UFO_GCNT_WORDS * 4, m->stream));
 	return resetRoot(m);
 }
 
@@ -3686,6 +3691,8 @@ int ufomap_map_set_option(ufomap_map* m, const char* key, long long value)
 		m->opt_vol_walk_blocks = (int)std::max<long long>(1, std::min<long long>(65536, value));
 	} else if (0 == strcmp(key, "vol_walk_lds")) {
 		m->opt_vol_walk_lds = (int)std::max<long long>(0, std::min<long long>(128 << 10, value));
+	} else if (0 == strcmp(key, "vol_color")) {
+		m->opt_vol_color = value ? 1 : 0;
 	} else if (0 == strcmp(key, "vol_async")) {
 		m->opt_vol_async = value ? 1 : 0;
 	} else if (0 == strcmp(key, "vol_keep")) {

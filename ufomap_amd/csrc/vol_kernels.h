@@ -144,6 +144,22 @@ __global__ __launch_bounds__(256) void k_vbin_scatter(const ScanCtl* ctl_in, con
 // The XCD this wave runs on (HW_REG_XCC_ID, bits 3:0). Waves that read the same value share one L2.
 __device__ __forceinline__ u32 xccId() { return (u32)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u; }
 
+// What the per-XCD copies rest on, checked once per process before the volume path is used (volSelfTest, host_vol.inl): (1) XCC_ID
+// reads 0 .. 7; (2) read-modify-write atomics at WORKGROUP scope issued by different workgroups that read the same XCC_ID on one
+// word lose no update -- i.e. they are executed by one L2, the XCD's -- here: every lane adds 1 to the counter of its XCD,
+// UFO_VSELF_ADDS times, from 8 * UFO_VSELF_BLOCKS workgroups; the counters must add up to the number of additions, and the plain
+// loads of the NEXT kernel (the host's copy) must see them: the lines are written back when the kernel ends. A part (or a compiler
+// mode) on which this does not hold fails the test, and the volume path stays off: scans take the general path.
+#define UFO_VSELF_BLOCKS 64u
+#define UFO_VSELF_ADDS 16u
+__global__ __launch_bounds__(256) void k_vselftest(u32* __restrict__ cnt, u32* __restrict__ bad)
+{
+	const u32 raw = (u32)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);
+	if ((raw & 15u) > 7u) atomicOr(bad, 1u);
+	u32* c = cnt + (raw & 7u) * 64u;  // (a 256-byte piece per XCD, like the copies)
+	for (u32 k = 0; k < UFO_VSELF_ADDS; ++k) __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 // freeSpaceNormal, one lane per ray (the general path's k_dda, marks collected per brick).
 // Where the marks go: a device-scope atomic is executed at the memory side of the fabric (the eight XCDs' L2s are not
 // coherent with each other) -- 10-35 per ns on this part, and 1e8 of them were 9 of this kernel's 9.6 ms. So every XCD marks
@@ -157,8 +173,9 @@ __device__ __forceinline__ u32 xccId() { return (u32)__builtin_amdgcn_s_getreg((
 __global__ __launch_bounds__(256) void k_vdda(MapGeom g, D3 sensor, Grid gr, VolGeo vg, u64* __restrict__ Mx, u32* __restrict__ tbx, const D3* __restrict__ ray_end,
                                               const ScanCtl* ctl_in, ScanCtl* ctl, u32 mode, const u32* __restrict__ order)
 {
-	// (mode, a measuring aid: bit 0 = one copy for all XCDs, bit 1 = blocks take the rays in launch order, bit 3 = no
-	// write-combining table; order == nullptr: the rays in the cloud's order)
+	// (mode, a measuring aid: bit 1 = blocks take the rays in launch order, bit 3 = no write-combining table; order == nullptr:
+	// the rays in the cloud's order. Round 4's bit 0 -- ONE copy for all XCDs, marked with the same workgroup-scope atomics -- is gone:
+	// by this file's own argument that is wrong across XCDs.)
 	// The wave's write-combining table: (brick word, bits) pairs on their way to the XCD's copy. A lane that leaves a brick ORs
 	// its bits into the brick's entry if there is one; else it takes the entry over and sends what was in it to the L2 -- the
 	// rays of a bundle enter and leave the same bricks within a few steps of one another, so most flushes end here.
@@ -175,7 +192,7 @@ __global__ __launch_bounds__(256) void k_vdda(MapGeom g, D3 sensor, Grid gr, Vol
 	u32 i = ((mode & 2u) ? blockIdx.x : ((blockIdx.x & 7u) * per + (blockIdx.x >> 3))) * blockDim.x + threadIdx.x;
 	const bool live = i < n;
 	if (live && order) i = order[i];
-	const u32 xcc = (mode & 1u) ? 0u : xccId();
+	const u32 xcc = xccId();
 	u64* const M = Mx + (size_t)xcc * volCopyWords(vg.ntiles);
 	u32* const tb = tbx + (size_t)xcc * (size_t)volTbWords(vg.ntiles);
 	// a lane's (word, bits) on its way out: through the table, or straight to the L2. Called by any subset of a wave's lanes at
@@ -477,8 +494,10 @@ __global__ __launch_bounds__(256) void k_vcut(MapGeom g, D3 sensor, Grid gr, Vol
 // tile bitmap -- was measured too: 1.78 ms against 1.65 for this one on the 2 mm frame. What the walk costs is instruction issue,
 // 62 instructions per step outside the table's code, not what reaches the L2; profiles/r05_ab_experiments.log.)
 __global__ __launch_bounds__(256) void k_vwalk(MapGeom g, VolGeo vg, u64* __restrict__ Mx, u32* __restrict__ tbx, const VRay* __restrict__ rays, VSegs sg,
-                                               const u32* __restrict__ cnt, u32 seg_cap, const ScanCtl* ctl_in, ScanCtl* ctl, u32 mode)
+                                               const u32* __restrict__ cnt, u32 seg_cap, const ScanCtl* ctl_in, ScanCtl* ctl, u32 mode, unsigned long long* __restrict__ steps_sh)
 {
+	// (steps_sh: 64 counters a cache line apart for the waves' step counts -- 5e4 waves adding to ONE word queue at ~12 ns each, and
+	// they finish in generations; k_vlist folds them into the control block)
 	__shared__ u32 wc_key[4][UFO_VWC];
 	__shared__ unsigned long long wc_mask[4][UFO_VWC];
 	const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -575,7 +594,8 @@ __global__ __launch_bounds__(256) void k_vwalk(MapGeom g, VolGeo vg, u64* __rest
 			const u64 bits = wc_mask[wave][k];
 			if (key != 0xFFFFFFFFu && bits) __hip_atomic_fetch_or(&M[key], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		}
-	waveAddU64(&ctl->n_steps, steps);
+	for (int o = 32; o > 0; o >>= 1) steps += __shfl_xor(steps, o);
+	if (0 == lane && steps) atomicAdd(&steps_sh[((blockIdx.x * 4u + wave) & 63u) * 16u], steps);
 	if (err) atomicOr(&ctl->err, err);
 }
 
@@ -584,8 +604,14 @@ __global__ __launch_bounds__(256) void k_vwalk(MapGeom g, VolGeo vg, u64* __rest
 // (... and where each tile's level-3 block was when a walk last left a record for it: k_tile's guess of the tile's group arrives with
 // the list entry, its records are asked for together with the brick words -- one dependent round trip less per wave)
 __global__ __launch_bounds__(256) void k_vlist(u32* __restrict__ tbx, u32 ntiles, u32* __restrict__ list, uint8_t* __restrict__ copies, u32* n_out, const TileRec* __restrict__ recs,
-                                               u32* __restrict__ slots)
+                                               u32* __restrict__ slots, unsigned long long* __restrict__ steps_sh, ScanCtl* ctl)
 {
+	if (steps_sh && 0 == blockIdx.x && threadIdx.x < 64u) {  // (the walkers' step counts, k_vwalk)
+		unsigned long long v = steps_sh[threadIdx.x * 16u];
+		steps_sh[threadIdx.x * 16u] = 0ull;
+		for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+		if (0 == threadIdx.x && v) atomicAdd(&ctl->n_steps, v);
+	}
 	const u32 nwords = volTbWords(ntiles);  // (the padding words are never marked)
 	for (u32 w0 = blockIdx.x * blockDim.x; w0 < nwords; w0 += gridDim.x * blockDim.x) {  // (uniform)
 		const u32 w = w0 + threadIdx.x;
@@ -693,7 +719,7 @@ __global__ __launch_bounds__(256) void k_vcodes(VolGeo vg, const u64* __restrict
 // the reserve's counters -> MapRoot::used has them already through k_up / k_ftail; this only clears them and the walk's flag
 __global__ void k_vreset(u32* resv, ScanCtl* ctl, u32 clear_err)
 {
-	if (threadIdx.x < 64u) resv[threadIdx.x] = 0;
+	if (threadIdx.x < 64u) resv[threadIdx.x * UFO_RESV_STRIDE] = 0;
 	if (0 == threadIdx.x && clear_err) atomicAnd(&ctl->err, ~clear_err);
 }
 }  // namespace ufo
