@@ -707,6 +707,257 @@ __global__ __launch_bounds__(1024) void k_fcast(MapGeom g, FastGeo fg, D3 sensor
 }
 
 // ------------------------------------------------------------------------------------------------
+// F2' (round 5): k_fcast with its phases in front of the walk FUSED. k_fcast runs head loop -> (barrier) -> set-up, one lane
+// per ray -> (barrier) -> segment sizes, prefix sums -> (2 barriers) -> dominant chains, one lane per ray -> (barrier) -> the
+// other axes, two lanes per ray -> (2 barriers) -> walk: a lone workgroup per CU (148 KB of LDS), so every phase is the latency
+// of its own dependent chain with three of sixteen waves busy, and the ray ends go through global memory between the first two.
+// Measured by the kernel's own stamps (workgroup 0, 16 cm LiDAR scan, scripts/dev_fcast.py): head loop 5.1 us, set-up 2.3,
+// sizes 1.5, dominant chains 2.4, other axes + fix-ups 5.2 = 16.4 us in front of a walk of 7.1.
+// Here the lane that looks at a point does everything for the point's ray -- the winner test, clip / keys / computeRayInit, the
+// three addition chains side by side in its registers (k_vcut's loop, vol_kernels.h: the dominant axis up to the cut, the two
+// others while their elements precede the cut's) -- and puts the segments into the LDS queue through one returning LDS atomic:
+// the rays of a 64-point stretch run in all of the workgroup's waves at once, nothing is handed from phase to phase, and ONE
+// barrier stands between the cuts and the walk. Rays that find the queue full wait for the next round (a round = cuts, barrier,
+// walk, barrier); the steady state needs one. Same cells, same step count: the cut states are the same sums.
+// ------------------------------------------------------------------------------------------------
+template <bool DISCRETE>
+__global__ __launch_bounds__(1024) void k_fcast2(MapGeom g, FastGeo fg, D3 sensor, u32 n, const u32* __restrict__ first, u32* __restrict__ slabs, u32 K,
+                                                const ScanCtl* ctl_in, ScanCtl* ctl, unsigned long long* __restrict__ steps_part, const PointRec* __restrict__ recs,
+                                                u32 rcap, u32 qcap, u32 prio, Pipe* solo, ScanDesc solo_desc)
+{
+	if (solo && 0 == (threadIdx.x | blockIdx.x)) {
+		solo->ring[0] = solo_desc;
+		solo->slot[0].first = 0;
+		solo->slot[0].B = 1;
+	}
+	if (prio >= 3u) __builtin_amdgcn_s_setprio(3);
+	else if (2u == prio) __builtin_amdgcn_s_setprio(2);
+	else if (1u == prio) __builtin_amdgcn_s_setprio(1);
+	extern __shared__ __attribute__((aligned(16))) u32 lds[];
+	const u32 err_in = ctl_in->err;  // (looked at once the LDS grid has been cleared: the load is in flight meanwhile)
+	if (0 == (threadIdx.x | blockIdx.x)) ctl->dbg[30] = wall_clock64();  // (diagnostics)
+	const Grid& gr = fg.gr;
+	const u32 lds_words = (u32)(gr.bytes >> 2);
+	RayConst* rc = reinterpret_cast<RayConst*>(lds + lds_words);
+	SegRec* q = reinterpret_cast<SegRec*>(rc + rcap);
+	u32* sh = reinterpret_cast<u32*>(q + qcap);  // [0] rays of the round, [1] queue entries asked for, [2] first entry that was refused, [3] rays cast, [4] voxels hit
+	// the points of this workgroup: blockIdx.x, blockIdx.x + gridDim.x, ... -- their records are asked for before the grid is cleared
+	const u32 pts = (n > blockIdx.x) ? (n - blockIdx.x + gridDim.x - 1) / gridDim.x : 0u;
+	{
+		uint4* l4 = reinterpret_cast<uint4*>(lds);
+		for (u32 j = threadIdx.x; j < (lds_words >> 2); j += blockDim.x) l4[j] = make_uint4(0, 0, 0, 0);
+	}
+	if (threadIdx.x < 8u) sh[threadIdx.x] = (2u == threadIdx.x) ? 0xFFFFFFFFu : 0u;
+	if (err_in) return;  // the scan does not fit the predicted grid (k_fhits): it will be repeated (uniform exit)
+	__syncthreads();
+	if (0 == (threadIdx.x | blockIdx.x)) ctl->dbg[31] = wall_clock64();  // (diagnostics)
+	const u32 rowBits = fg.rowBits, planeBits = fg.planeBits;
+	const u32 lim = 1u << g.L;
+	const u32 lane = threadIdx.x & 63u;
+	unsigned long long steps = 0;
+	u32 err = 0, oob = 0, nhit = 0, ncast = 0;
+	// A lane takes the workgroup's points threadIdx.x, threadIdx.x + blockDim.x, ... one after the other; a ray that finds the
+	// queue full stays with its lane until the next round.
+	u32 pcur = threadIdx.x;
+	bool pending = false;
+	RayState r;
+	r.status = 0;
+	u32 ax = 0, w = 1, nseg = 0, lin0 = 0, glin = 0;
+	i32 dla = 0, dl0 = 0, dl1 = 0;
+	for (u32 round = 0;; ++round) {  // (uniform: a round = cuts, barrier, walk, barrier)
+		for (;;) {
+			if (!pending) {
+				if (pcur >= pts) break;
+				const u32 i = blockIdx.x + pcur * gridDim.x;
+				pcur += blockDim.x;
+				const PointRec pr = recs[i];  // (k_fhits ran the head loop on the point)
+				const bool odd = 0 != (pr.flags & 4u);
+				bool cast = (pr.flags & 1u) && !odd;
+				if ((pr.flags & 2u) && !odd) {
+					// (the voxel receives a hit, OMB:295, 358-360: its first point's; k_fmerge derives the hit grid from the array)
+					const bool winner = first[pr.cell] == i;
+					nhit += winner ? 1u : 0u;
+					if (DISCRETE && !winner) cast = false;  // OMB:358-360: dropped entirely, no ray
+				}
+				if (!cast) continue;
+				++ncast;
+				raySetup(g, sensor, 0u, gr, pr.end, r);
+				if (1 == r.status) {
+					err |= markBitChecked(gr, lds, rowBits, planeBits, r.start[0], r.start[1], r.start[2], lim, &oob);
+					steps += 1;
+				} else if (3 == r.status) {
+					err |= ERR_GRID_OOB;  // cannot happen: pointRay admits only rays inside the grid's interior
+				}
+				if (2 != r.status) continue;
+				const u32 dxn = (u32)abs((i32)(r.gpk & 1023u) - (i32)(r.pk0 & 1023u));
+				const u32 dyn = (u32)abs((i32)((r.gpk >> 10) & 1023u) - (i32)((r.pk0 >> 10) & 1023u));
+				const u32 dzn = (u32)abs((i32)(r.gpk >> 20) - (i32)(r.pk0 >> 20));
+				ax = (dxn >= dyn && dxn >= dzn) ? 0u : (dyn >= dzn ? 1u : 2u);
+				const u32 dmax = ax == 0 ? dxn : (ax == 1 ? dyn : dzn);
+				const u32 l1 = dxn + dyn + dzn;
+				w = (u32)(((u64)dmax * K) / l1);
+				if (w < 1u) w = 1u;
+				nseg = (dmax + w - 1u) / w;  // >= 1 (start and goal differ)
+				lin0 = pkToLin(r.pk0, rowBits, planeBits);
+				glin = pkToLin(r.gpk, rowBits, planeBits);
+				const i32 dlx = (i32)r.s[0], dly = (i32)r.s[1] * (i32)rowBits, dlz = (i32)r.s[2] * (i32)planeBits;
+				dla = ax == 0 ? dlx : (ax == 1 ? dly : dlz);
+				dl0 = ax == 0 ? dly : dlx;
+				dl1 = ax == 2 ? dly : dlz;
+				if (nseg > qcap) {  // (cannot happen: a ray inside a grid of < 1024 cells per axis has at most ~100 segments)
+					err |= ERR_GRID_OOB;
+					continue;
+				}
+				pending = true;
+			}
+			// room for the ray's constants and its segments, or the next round
+			const u32 slot = atomicAdd(&sh[0], 1u);
+			u32 off = 0xFFFFFFFFu;
+			if (slot < rcap) {
+				off = atomicAdd(&sh[1], nseg);
+				if (off + nseg > qcap) {
+					atomicMin(&sh[2], off);  // (every entry from here on belongs to a ray that was refused)
+					off = 0xFFFFFFFFu;
+				}
+			}
+			if (0xFFFFFFFFu == off) break;
+			pending = false;
+			RayConst c;
+			c.td[0] = r.td[0];
+			c.td[1] = r.td[1];
+			c.td[2] = r.td[2];
+			c.dist = r.dist;
+			c.dl[0] = (i32)r.s[0];
+			c.dl[1] = (i32)r.s[1] * (i32)rowBits;
+			c.dl[2] = (i32)r.s[2] * (i32)planeBits;
+			c.glin = glin;
+			rc[slot] = c;
+			// the three chains (vol_kernels.h: k_vcut). a* = the dominant axis, b0 < b1 the two others; after k0 pops of a* element
+			// A[k0 - 1] (= v) was popped and t_max_a* = A[k0]; of axis b the elements before v were popped -- strictly smaller, or
+			// equal when b wins the tie (b < a*, vector3.h:244-251)
+			double ta = ax == 0 ? r.tm[0] : (ax == 1 ? r.tm[1] : r.tm[2]), v = ta;
+			const double tda = ax == 0 ? r.td[0] : (ax == 1 ? r.td[1] : r.td[2]);
+			double t0 = ax == 0 ? r.tm[1] : r.tm[0], t1 = ax == 2 ? r.tm[1] : r.tm[2];
+			const double d0 = ax == 0 ? r.td[1] : r.td[0], d1 = ax == 2 ? r.td[1] : r.td[2];
+			const bool pri0 = ax != 0u, pri1 = ax == 2u;
+			u32 n0 = 0, n1 = 0, guard = 0;
+			auto advance = [&](double& tb, const double dbt, const bool pri, u32& cb) {
+				for (;;) {  // four candidates per iteration (the same sequence of additions)
+					const double q1 = tb + dbt, q2 = q1 + dbt, q3 = q2 + dbt;
+					const bool e0 = pri ? (tb <= v) : (tb < v);
+					const bool e1 = e0 & (pri ? (q1 <= v) : (q1 < v)), e2 = e1 & (pri ? (q2 <= v) : (q2 < v)), e3 = e2 & (pri ? (q3 <= v) : (q3 < v));
+					if (e3) {
+						tb = q3 + dbt;
+						cb += 4u;
+						if (++guard > 1024u) {
+							err |= ERR_RUNAWAY;  // (cannot trip inside a grid of < 1024 cells per axis)
+							break;
+						}
+						continue;
+					}
+					tb = e2 ? q3 : (e1 ? q2 : (e0 ? q1 : tb));
+					cb += (e0 ? 1u : 0u) + (e1 ? 1u : 0u) + (e2 ? 1u : 0u);
+					break;
+				}
+			};
+			u32 lin = lin0;
+			for (u32 j = 0; j < nseg; ++j) {
+				if (j > 0u) {
+					u32 np = w;
+					for (; np >= 4u; np -= 4u) {  // (the same sequence of additions, four at a time)
+						const double a1 = ta + tda, a2 = a1 + tda, a3 = a2 + tda;
+						v = a3;
+						ta = a3 + tda;
+					}
+					for (; np > 0u; --np) {
+						v = ta;
+						ta = ta + tda;
+					}
+					advance(t0, d0, pri0, n0);
+					advance(t1, d1, pri1, n1);
+					lin = lin0 + (u32)((i32)(j * w) * dla + (i32)n0 * dl0 + (i32)n1 * dl1);
+					q[off + j - 1u].end = lin;  // the segment before ends where this one starts
+				}
+				SegRec rec;
+				rec.tm[0] = ax == 0 ? ta : t0;
+				rec.tm[1] = ax == 0 ? t0 : (ax == 1 ? ta : t1);
+				rec.tm[2] = ax == 2 ? ta : t1;
+				rec.lin = lin;
+				rec.end = glin;
+				rec.ray = slot | (0u == j ? 0x80000000u : 0u);
+				rec.pad = 0;
+				q[off + j] = rec;
+			}
+		}
+		{
+			__syncthreads();
+			if (0 == (threadIdx.x | blockIdx.x) && 0 == round) ctl->dbg[35] = wall_clock64();  // (diagnostics)
+			const u32 nsegs = min(min(sh[1], sh[2]), qcap);
+			// ---- every lane walks segments ----
+			for (u32 si = threadIdx.x; si < nsegs; si += blockDim.x) {
+				const SegRec rec = q[si];
+				const RayConst c = rc[rec.ray & 0x7FFFFFFFu];
+				double tmx = rec.tm[0], tmy = rec.tm[1], tmz = rec.tm[2];
+				const double tdx = c.td[0], tdy = c.td[1], tdz = c.td[2];
+				const long long idist = __double_as_longlong(c.dist);
+				const i32 dlx = c.dl[0], dly = c.dl[1], dlz = c.dl[2];
+				const u32 end = rec.end;
+				u32 lin = rec.lin;
+				bool go = (0 != (rec.ray & 0x80000000u)) ||
+				          ((lin != c.glin) && ((__double_as_longlong(tmx) <= idist) | (__double_as_longlong(tmy) <= idist) | (__double_as_longlong(tmz) <= idist)));
+				u32 cnt = 0;
+				while (go) {
+					++cnt;
+					atomicOr(&lds[lin >> 5], 1u << (lin & 31u));
+					const bool cxy = tmx <= tmy, cxz = tmx <= tmz, cyz = tmy <= tmz;
+					const bool selx = cxy & cxz;
+					const bool sely = !cxy & cyz;
+					const bool selz = !(selx | sely);
+					lin += (u32)(selx ? dlx : (sely ? dly : dlz));
+					const double nx = tmx + tdx, ny = tmy + tdy, nz = tmz + tdz;
+					tmx = selx ? nx : tmx;
+					tmy = sely ? ny : tmy;
+					tmz = selz ? nz : tmz;
+					const bool more = (__double_as_longlong(tmx) <= idist) | (__double_as_longlong(tmy) <= idist) | (__double_as_longlong(tmz) <= idist);
+					go = (lin != end) & more & (cnt < 4096u);
+				}
+				if (cnt >= 4096u) err |= ERR_RUNAWAY;  // (a segment is ~K steps by construction)
+				steps += cnt;  // (one cell marked per step taken. k_fcast derives the count from the cells' coordinates: six integer
+				               // divisions per segment, which is why shorter segments made its WALK slower -- 14 us at K = 16 against 7)
+			}
+			const int more_rounds = __syncthreads_or((pending || pcur < pts) ? 1 : 0);  // (the queue and the counters are no longer read)
+			if (!more_rounds) break;
+			if (threadIdx.x < 3u) sh[threadIdx.x] = (2u == threadIdx.x) ? 0xFFFFFFFFu : 0u;
+			__syncthreads();
+		}
+	}
+	for (int o = 32; o > 0; o >>= 1) {
+		nhit += __shfl_xor(nhit, o);
+		ncast += __shfl_xor(ncast, o);
+	}
+	if (0 == lane && nhit) atomicAdd(&sh[4], nhit);
+	if (0 == lane && ncast) atomicAdd(&sh[3], ncast);
+	__syncthreads();
+	if (0 == (threadIdx.x | blockIdx.x)) ctl->dbg[36] = wall_clock64();  // (diagnostics)
+	if (0 == threadIdx.x) {
+		// per-workgroup partials, folded by k_fmerge (256 workgroups adding to one word serialise at ~12 ns each)
+		steps_part[gridDim.x + blockIdx.x] = sh[3];
+		steps_part[2u * gridDim.x + blockIdx.x] = sh[4];
+	}
+	{
+		const uint4* l4 = reinterpret_cast<const uint4*>(lds);
+		uint4* out4 = reinterpret_cast<uint4*>(slabs) + (size_t)blockIdx.x * (lds_words >> 2);
+		const u32 n4 = lds_words >> 2;
+		for (u32 j = threadIdx.x; j < n4; j += blockDim.x) out4[j] = l4[j];
+	}
+	if (0 == (threadIdx.x | blockIdx.x)) ctl->dbg[37] = wall_clock64();  // (diagnostics)
+	blockStoreSteps(steps, steps_part);
+	if (oob) atomicAdd(&ctl->n_oob, oob);
+	if (err) atomicOr(&ctl->err, err);
+	if (0 == (threadIdx.x | blockIdx.x)) ctl->dbg[38] = wall_clock64();  // (diagnostics)
+}
+
+// ------------------------------------------------------------------------------------------------
 // F2s: the ray kernel of the fast path for SIMPLE ray casting (freeSpaceSimple, occupancy_map_base.h:1303-1339; the server's
 // `simple_ray_casting` switch): n = int(distance / size) fixed steps of dir * size from the ray's end towards the sensor,
 // the cell of every point on the way -- three independent chains of repeated additions per ray, no DDA state, at most a
@@ -974,12 +1225,17 @@ __global__ __launch_bounds__(1024) void k_fmerge(FastGeo fg, const Pipe* __restr
 			if (j < n4 && noslab) {
 				if (0 == sl16) acc = grid[j];
 			} else if (j < n4) {
-				for (u32 s = sl16; s < n_slabs; s += 16u) {
-					const uint4 a = slabs[(size_t)s * n4 + j];
-					acc.x |= a.x;
-					acc.y |= a.y;
-					acc.z |= a.z;
-					acc.w |= a.w;
+				// (four slabs' words asked for together: the loop is a chain of round trips otherwise -- 12 of them for 192 slabs)
+				for (u32 s = sl16; s < n_slabs; s += 64u) {
+					const uint4 z4 = make_uint4(0, 0, 0, 0);
+					const uint4 a0 = slabs[(size_t)s * n4 + j];
+					const uint4 a1 = (s + 16u < n_slabs) ? slabs[(size_t)(s + 16u) * n4 + j] : z4;
+					const uint4 a2 = (s + 32u < n_slabs) ? slabs[(size_t)(s + 32u) * n4 + j] : z4;
+					const uint4 a3 = (s + 48u < n_slabs) ? slabs[(size_t)(s + 48u) * n4 + j] : z4;
+					acc.x |= a0.x | a1.x | a2.x | a3.x;
+					acc.y |= a0.y | a1.y | a2.y | a3.y;
+					acc.z |= a0.z | a1.z | a2.z | a3.z;
+					acc.w |= a0.w | a1.w | a2.w | a3.w;
 				}
 			}
 			// the scan's hit grid: one bit per cell that holds a first point (the voxel receives a hit, OMB:295, 358-360), from the

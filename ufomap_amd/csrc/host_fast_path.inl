@@ -353,6 +353,15 @@ int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, si
 				else
 					hipLaunchKernelGGL(k_fcast_simple<false>, dim3(nwg), dim3(cthreads), (size_t)fg.gr.bytes, m->cs, m->g, fg, sensor, N, m->b_first.as<u32>(), m->b_slabs.as<u32>(), ctl, ctl,
 					                   sp, m->b_hit_code.as<PointRec>(), solo_pipe, d);
+			} else if (m->opt_cast_fused) {
+				// (round 5: head loop, set-up and cuts by the lane that looks at the point, one barrier in front of the walk)
+				const size_t lds2 = (size_t)fg.gr.bytes + (size_t)batch * sizeof(RayConst) + (size_t)qcap * sizeof(SegRec) + 256u;
+				if (discrete)
+					hipLaunchKernelGGL(k_fcast2<true>, dim3(nwg), dim3(cthreads), lds2, m->cs, m->g, fg, sensor, N, m->b_first.as<u32>(), m->b_slabs.as<u32>(), (u32)std::max(8, m->opt_cast2_k),
+					                   ctl, ctl, sp, m->b_hit_code.as<PointRec>(), batch, qcap, prio, solo_pipe, d);
+				else
+					hipLaunchKernelGGL(k_fcast2<false>, dim3(nwg), dim3(cthreads), lds2, m->cs, m->g, fg, sensor, N, m->b_first.as<u32>(), m->b_slabs.as<u32>(), (u32)std::max(8, m->opt_cast2_k),
+					                   ctl, ctl, sp, m->b_hit_code.as<PointRec>(), batch, qcap, prio, solo_pipe, d);
 			} else if (discrete)
 				hipLaunchKernelGGL(k_fcast<true>, dim3(nwg), dim3(cthreads), lds, m->cs, m->g, fg, sensor, d_xyz, N, max_range, 0u, m->b_first.as<u32>(),
 				                   m->b_ray_end.as<D3>(), cap_wg, m->b_slabs.as<u32>(), (u32)std::max(8, m->opt_cast_k), ctl, ctl, sp, m->ing, m->b_hit_code.as<PointRec>(), batch, qcap, prio, solo_pipe, d);

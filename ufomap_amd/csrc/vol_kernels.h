@@ -170,6 +170,7 @@ __global__ __launch_bounds__(256) void k_vselftest(u32* __restrict__ cnt, u32* _
 // (with the usual block b -> XCD b % 8 placement; speed only) an XCD takes one contiguous eighth of the cloud: neighbouring
 // rays share bricks, and a tile is marked in one or two copies, not eight.
 #define UFO_VWC 256u  // entries of a wave's write-combining table (k_vdda)
+#define UFO_VSTAGE 4u  // (brick word, bits) entries a lane of k_vwalk parks before the wave sends them on
 __global__ __launch_bounds__(256) void k_vdda(MapGeom g, D3 sensor, Grid gr, VolGeo vg, u64* __restrict__ Mx, u32* __restrict__ tbx, const D3* __restrict__ ray_end,
                                               const ScanCtl* ctl_in, ScanCtl* ctl, u32 mode, const u32* __restrict__ order)
 {
@@ -500,6 +501,13 @@ __global__ __launch_bounds__(256) void k_vwalk(MapGeom g, VolGeo vg, u64* __rest
 	// they finish in generations; k_vlist folds them into the control block)
 	__shared__ u32 wc_key[4][UFO_VWC];
 	__shared__ unsigned long long wc_mask[4][UFO_VWC];
+	// A lane that leaves a brick PARKS (brick word, bits) in a small queue of its own -- two plain LDS stores -- and the wave sends
+	// everybody's parked entries through the write-combining table together, when some lane's queue is full: the table's protocol
+	// (three dependent LDS round trips, a compare-and-swap, the L2 atomics, the tile bitmap's look-at-first) is ~50 instructions that
+	// the whole wave used to issue on nearly EVERY step, because in nearly every step some lane of 64 leaves its brick. Now once per
+	// UFO_VSTAGE-th brick change of the busiest lane (k_vdda keeps the old form: 1.64 -> ... ms, profiles/r05_ab_experiments.log).
+	__shared__ u32 st_w[4][UFO_VSTAGE][64];
+	__shared__ unsigned long long st_m[4][UFO_VSTAGE][64];
 	const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
 	const bool use_wc = 0 == (mode & 8u);
 	for (u32 k = lane; k < UFO_VWC; k += 64u) {
@@ -538,6 +546,31 @@ __global__ __launch_bounds__(256) void k_vwalk(MapGeom g, VolGeo vg, u64* __rest
 			else __hip_atomic_fetch_or(&M[w], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		}
 	};
+	// a tile's bit in the XCD's tile bitmap (looked at first: bits only appear during this kernel, the CU's L1 was invalidated when
+	// it started, and a stale 0 costs one more atomic)
+	auto markTile = [&](u32 tile) {
+		if (!((tb[tile >> 5] >> (tile & 31u)) & 1u)) __hip_atomic_fetch_or(&tb[tile >> 5], 1u << (tile & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+	};
+	u32 nst = 0;  // entries parked in the lane's queue
+	// every lane's parked entries on their way (uniform: called by the whole wave)
+	auto drain = [&]() {
+		u32 last_tile = 0xFFFFFFFFu;
+#pragma unroll
+		for (u32 k = 0; k < UFO_VSTAGE; ++k) {
+			if (k < nst) {
+				const u32 w = st_w[wave][k][lane];
+				flush(w, st_m[wave][k][lane]);
+				if ((w >> 3) != last_tile) markTile(w >> 3);
+				last_tile = w >> 3;
+			}
+		}
+		nst = 0;
+	};
+	auto park = [&](u32 w, u64 bits) {
+		st_w[wave][nst][lane] = w;
+		st_m[wave][nst][lane] = bits;
+		++nst;
+	};
 	unsigned long long steps = 0;
 	u32 err = 0;
 	const u32 nt0 = vg.nt[0], nt1 = vg.nt[1];
@@ -563,13 +596,12 @@ __global__ __launch_bounds__(256) void k_vwalk(MapGeom g, VolGeo vg, u64* __rest
 			const u32 w = tile * 8u + (((x >> 2) & 1u) | (((y >> 2) & 1u) << 1) | (((z >> 2) & 1u) << 2));
 			const u32 b = (x & 3u) | ((y & 3u) << 2) | ((z & 3u) << 4);
 			if (w != curw) {
-				if (acc) flush(curw, acc);
-				if (((w ^ curw) >> 3) && !((tb[tile >> 5] >> (tile & 31u)) & 1u))
-					__hip_atomic_fetch_or(&tb[tile >> 5], 1u << (tile & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				if (acc) park(curw, acc);
 				curw = w;
 				acc = 0;
 			}
 			acc |= 1ull << b;
+			if (__ballot(nst >= UFO_VSTAGE)) drain();  // (uniform)
 			const bool cxy = tmx <= tmy, cxz = tmx <= tmz, cyz = tmy <= tmz;
 			const bool selx = cxy & cxz;
 			const bool sely = !cxy & cyz;
@@ -584,10 +616,11 @@ __global__ __launch_bounds__(256) void k_vwalk(MapGeom g, VolGeo vg, u64* __rest
 			const bool more = (__double_as_longlong(tmx) <= idist) | (__double_as_longlong(tmy) <= idist) | (__double_as_longlong(tmz) <= idist);
 			go = (((x ^ gx) | (y ^ gy) | (z ^ gz)) != 0u) & more & (c < (1u << 16));
 		}
-		if (acc) flush(curw, acc);
+		if (acc) park(curw, acc);  // (room for it: the queue is drained the moment it is full)
 		if (c >= (1u << 16)) err |= ERR_RUNAWAY;  // (a segment is ~K cells by construction)
 		steps += c;
 	}
+	drain();  // (all of the wave's lanes are here: the loops above have ended for every one of them)
 	if (use_wc)
 		for (u32 k = lane; k < UFO_VWC; k += 64u) {
 			const u32 key = wc_key[wave][k];
