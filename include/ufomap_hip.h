@@ -315,6 +315,11 @@ int ufomap_comm_counters(const ufomap_comm* c, uint64_t out[4]);
 int ufomap_map_insert_batch(ufomap_map* m, ufomap_comm* c, const double sensor_origin[3], const double* d_xyz,
                             const uint8_t* d_rgb /* colour maps: 3 bytes per point; else NULL */, size_t n, double max_range,
                             unsigned depth, int discrete);
+/* ... with the two remaining arguments of insertPointCloud / insertPointCloudDiscrete (occupancy_map_base.h:270-273, 340-344):
+ * simple_ray_casting (freeSpaceSimple, 1303-1339) and early_stopping (1289-1298, 1327-1333). Both have to be the same on every
+ * rank (like depth and discrete); a step with either takes the update-list form. */
+int ufomap_map_insert_batch_ex(ufomap_map* m, ufomap_comm* c, const double sensor_origin[3], const double* d_xyz, const uint8_t* d_rgb, size_t n,
+                               double max_range, unsigned depth, int discrete, int simple_ray_casting, unsigned early_stopping);
 
 /* Diagnostic overrides for tests: "dda_mode" (-1 auto; 1 / 2 force the LDS-filter / direct variants of
  * the ray kernel on grids that would fit in LDS), "entry_guess" (cap of the guessed update-list size, to

@@ -392,10 +392,12 @@ def _batch_cloud(entry):
     return o, (xyz[:0] if empty else xyz)
 
 
-def _batch_rank(rank, world, steps, shim, id_q, out_q, comm_slot, fail_at=None):
+def _batch_rank(rank, world, steps, shim, id_q, out_q, comm_slot, fail_at=None, device=0):
     import os
-    os.environ["UFOMAP_RCCL_LIB"] = shim
+    if shim:  # (None: the real librccl, one GPU per rank)
+        os.environ["UFOMAP_RCCL_LIB"] = shim
     os.environ["UFOMAP_COMM_SLOT"] = str(comm_slot)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch as th
     from ufomap_amd import OccupancyMap
     from ufomap_amd.occupancy_map import Comm
@@ -406,14 +408,15 @@ def _batch_rank(rank, world, steps, shim, id_q, out_q, comm_slot, fail_at=None):
                 id_q.put(uid)
         else:
             uid = id_q.get(timeout=120)
-        g = OccupancyMap(0.16)
+        th.cuda.set_device(device)
+        g = OccupancyMap(0.16, device=device)
         g.set_option("async_apply", 1)
-        comm = Comm(uid, world, rank, 0)
+        comm = Comm(uid, world, rank, device)
         plan = _batch_plan(world, steps)
         keep = []
         for i in range(steps):
             origin, xyz = _batch_cloud(plan[(i, rank)])
-            d = th.from_numpy(np.ascontiguousarray(xyz)).cuda() if len(xyz) else th.empty(0, dtype=th.float64, device="cuda")
+            d = th.from_numpy(np.ascontiguousarray(xyz)).cuda(device) if len(xyz) else th.empty(0, dtype=th.float64, device=f"cuda:{device}")
             keep.append(d)
             if fail_at is not None:  # (step, rank): the scan half of that rank's step 'fails' before the collective (option fail_scan)
                 g.set_option("fail_scan", int(fail_at == (i, rank)))
@@ -467,6 +470,64 @@ def test_insert_batch_two_ranks_on_one_gpu(fail_at):
     assert c0["fast_steps"] >= 4, f"the fast-path form of the step did not run: {c0}"
     assert c0["repeated_steps"] >= (2 if fail_at else 1), f"the jump (and the injected failure) should have forced collective repeats: {c0}"
     assert results[0][3]["regrown"] >= 1, "the update-list slot should have had to grow (4 KiB to start with)"
+
+
+def test_insert_batch_two_gpus_real_rccl():
+    """The same two-rank sequence over the REAL librccl, one GPU per rank (ncclAllGather across processes over xGMI / PCIe): runs
+    wherever two GPUs are visible -- the driver's 8-GPU node --, skipped on a one-GPU box (there the shim above stands in). Every
+    replica must equal the map of the same scans one by one in (step, rank) order."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (one-GPU boxes run test_insert_batch_two_ranks_on_one_gpu through the RCCL stand-in)")
+    import torch.multiprocessing as mp
+    from ufomap_amd import OccupancyMap, PointCloud
+    world, steps = 2, 9
+    ctx = mp.get_context("spawn")
+    id_q, out_q = ctx.Queue(), ctx.Queue()
+    procs = [ctx.Process(target=_batch_rank, args=(r, world, steps, None, id_q, out_q, 4096, None, r)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = {}
+    for _ in range(world):
+        r = out_q.get(timeout=600)
+        results[r[0]] = r
+    for p in procs:
+        p.join(timeout=60)
+    for r in range(world):
+        assert not isinstance(results[r][1], str), results[r][1]
+    g1 = OccupancyMap(0.16)
+    plan = _batch_plan(world, steps)
+    for i in range(steps):
+        for r in range(world):
+            origin, xyz = _batch_cloud(plan[(i, r)])
+            g1.insertPointCloudDiscrete(origin, PointCloud(xyz), 10.0)
+    want = g1.digest()
+    for r in range(world):
+        assert results[r][1] == want, f"replica of rank {r} differs from the sequential map"
+    assert results[0][2] == results[1][2] and results[0][2]["fast_steps"] >= 4
+
+
+def test_insert_batch_simple_ray_casting_and_early_stopping():
+    """ufomap_map_insert_batch_ex: the two remaining arguments of insertPointCloudDiscrete (occupancy_map_base.h:340-344) in a batch
+    step -- fixed-step casting and early stopping take the update-list form; world 1 through the real RCCL, against the reference."""
+    import torch
+    from oracle import OracleMap
+    from ufomap_amd import OccupancyMap, Comm, scans
+    g, o = OccupancyMap(0.16), OracleMap(0.16, kind=_kind())
+    comm = Comm(Comm.unique_id(), 1, 0, 0)
+    try:
+        for s in range(6):
+            origin, xyz, _ = scans.lidar64(origin=scans.lidar_pose(s % 3), seed=100 + s, beams=16, azimuths=512)
+            simple, early = (s % 3 == 1), (3 if s % 3 == 2 else 0)
+            d = torch.from_numpy(xyz).cuda()
+            g.insert_batch(comm, origin, d.data_ptr(), xyz.shape[0], 12.0, 0, True, None, simple, early)
+            o.insert(origin, xyz, max_range=12.0, discrete=True, simple_ray_casting=simple, early_stopping=early)
+            torch.cuda.synchronize()
+        g.insertPointCloudWait()
+        _assert_same_map(g, o, "batch steps with simple_ray_casting / early_stopping")
+    finally:
+        g.insertPointCloudWait()
+        comm.close()
 
 
 def test_gate_timeouts_are_survived():

@@ -29,7 +29,7 @@ SYMBOLS = [
     "ufomap_map_set_value_volume_ch", "ufomap_map_enable_change_detection", "ufomap_map_reset_change_detection", "ufomap_map_changes",
     "ufomap_map_enable_minmax_change_detection", "ufomap_map_iterate", "ufomap_map_write_ex", "ufomap_map_read", "ufomap_map_read_data",
     "ufomap_map_scan_keys", "ufomap_map_scan_keys_rgb", "ufomap_map_get_keys", "ufomap_map_apply_keys", "ufomap_map_apply_keys_batch",
-    "ufomap_comm_unique_id", "ufomap_comm_create", "ufomap_comm_from_nccl", "ufomap_comm_destroy", "ufomap_comm_stats", "ufomap_comm_counters", "ufomap_map_insert_batch", "ufomap_dev_expf", "ufomap_map_timeline",
+    "ufomap_comm_unique_id", "ufomap_comm_create", "ufomap_comm_from_nccl", "ufomap_comm_destroy", "ufomap_comm_stats", "ufomap_comm_counters", "ufomap_map_insert_batch", "ufomap_map_insert_batch_ex", "ufomap_dev_expf", "ufomap_map_timeline",
     "ufomap_map_stream", "ufomap_map_debug", "ufomap_map_set_option", "ufomap_alloc_counters",
 ]
 
@@ -131,6 +131,7 @@ def load():
     lib.ufomap_comm_stats.argtypes = [vp, C.POINTER(C.c_uint64)]
     lib.ufomap_comm_counters.argtypes = [vp, C.POINTER(C.c_uint64)]
     lib.ufomap_map_insert_batch.argtypes = [vp, vp, f64p, vp, vp, sz, dbl, C.c_uint, C.c_int]
+    lib.ufomap_map_insert_batch_ex.argtypes = [vp, vp, f64p, vp, vp, sz, dbl, C.c_uint, C.c_int, C.c_int, C.c_uint]
     lib.ufomap_map_timeline.argtypes = [vp, vp, sz, u64p]
     lib.ufomap_map_clear_to.argtypes = [vp, dbl, C.c_uint]
     lib.ufomap_map_get_sensor_model.argtypes = [vp, f64p]

@@ -179,14 +179,26 @@ ScanCtl* otherResult(uint8_t* all, int w) { return reinterpret_cast<ScanCtl*>(al
 // (ufomap_map_apply_keys_batch). A rank whose scan FAILED still takes part in the collective -- with a status word in
 // its header and an empty list -- and every rank returns that error: nobody is left waiting in the all-gather.
 int listBatchStep(ufomap_map* m, ufomap_comm* c, const double origin[3], const double* d_xyz, const uint8_t* d_rgb, size_t n, double max_range,
-                  int discrete, bool in_join)
+                  int discrete, bool in_join, int simple = 0, unsigned early_stopping = 0)
 {
 	Rccl* r = rccl();
 	const int W = c->world;
 	ufomap_keys_info info;
 	// (in_join: called while a step is being joined -- the current hand-over set is that step's, nothing else is joined or rotated)
-	int scan_rc = in_join ? scanKeysCore(m, origin, d_xyz, m->g.color ? d_rgb : nullptr, n, max_range, 0, discrete, 0, &info)
-	                      : ufomap_map_scan_keys_rgb(m, origin, d_xyz, m->g.color ? d_rgb : nullptr, n, max_range, 0, discrete, 0, &info);
+	int scan_rc;
+	if (in_join) {
+		scan_rc = scanKeysCore(m, origin, d_xyz, m->g.color ? d_rgb : nullptr, n, max_range, 0, discrete, simple, &info, early_stopping);
+	} else if (early_stopping) {
+		// (ufomap_map_scan_keys_rgb's prologue, with the argument its signature does not have)
+		scan_rc = (hipSetDevice(m->device) == hipSuccess && hipStreamSynchronize(m->sstream) == hipSuccess) ? UFOMAP_OK : fail(UFOMAP_ERR_DEVICE, "scan stream");
+		if (!scan_rc) {
+			(void)rotateSets(m);
+			m->args = ScanArgs{};
+			scan_rc = scanKeysCore(m, origin, d_xyz, m->g.color ? d_rgb : nullptr, n, max_range, 0, discrete, simple, &info, early_stopping);
+		}
+	} else {
+		scan_rc = ufomap_map_scan_keys_rgb(m, origin, d_xyz, m->g.color ? d_rgb : nullptr, n, max_range, 0, discrete, simple, &info);
+	}
 	std::string scan_msg = scan_rc ? g_err : std::string();
 	if (scan_rc) memset(&info, 0, sizeof(info));
 	auto listBytes = [](const ufomap_keys_info& k) {  // records + colour section
@@ -541,7 +553,15 @@ int ufomap_comm_counters(const ufomap_comm* c, uint64_t out[4])
 int ufomap_map_insert_batch(ufomap_map* m, ufomap_comm* c, const double sensor_origin[3], const double* d_xyz, const uint8_t* d_rgb, size_t n,
                             double max_range, unsigned depth, int discrete)
 {
+	return ufomap_map_insert_batch_ex(m, c, sensor_origin, d_xyz, d_rgb, n, max_range, depth, discrete, 0, 0);
+}
+
+int ufomap_map_insert_batch_ex(ufomap_map* m, ufomap_comm* c, const double sensor_origin[3], const double* d_xyz, const uint8_t* d_rgb, size_t n,
+                               double max_range, unsigned depth, int discrete, int simple_ray_casting, unsigned early_stopping)
+{
 	if (!m || !c || !sensor_origin) return fail(UFOMAP_ERR_INVALID, "null argument");
+	if (d_rgb && !discrete && n)
+		return fail(UFOMAP_ERR_UNSUPPORTED, "OccupancyMapColor::insertPointCloud<PointCloudColor> does not compile in the reference (SURVEY.md 4)");
 	if (m->g.color && !d_rgb && n) return fail(UFOMAP_ERR_INVALID, "a colour map needs the points' colours");
 	if (0 != depth) return fail(UFOMAP_ERR_UNSUPPORTED, "insert_batch: insert depth 0 only");
 	if (c->device != m->device) return fail(UFOMAP_ERR_INVALID, "the communicator was created on another device than the map");
@@ -553,12 +573,14 @@ int ufomap_map_insert_batch(ufomap_map* m, ufomap_comm* c, const double sensor_o
 	// (more ranks than one walk takes scans: the list form. Several walks per step would each look at their own chunk's flags
 	// only, and a scan of a later chunk that does not fit the common grid would leave the first chunk applied -- on the ranks
 	// of that chunk alone the join would then not repeat the step, and the others' collective repeat would hang: ADVICE r3)
+	// (fixed-step casting and early stopping -- the reference's simple_ray_casting / early_stopping arguments, occupancy_map_base.h:
+	// 340-344, the same on every rank by contract -- take the list form: the scan half of the general path casts that way)
 	const bool fast = c->spec_valid && m->opt_fast && m->opt_spec && !m->g.color && !m->chg_enabled && m->g.L >= 5 && nullptr == m->ing.data &&
-	                  c->world <= (int)UFO_BATCH_MAX && fastEligible(m, c->spec_grid, 0, 0, nullptr, 1);
+	                  !simple_ray_casting && 0 == early_stopping && c->world <= (int)UFO_BATCH_MAX && fastEligible(m, c->spec_grid, 0, 0, nullptr, 1);
 	if (!fast) {
 		// (joins what is in flight where it has to: scan_keys / apply_keys_batch)
 		m->batch_world = 0;
-		return listBatchStep(m, c, sensor_origin, d_xyz, d_rgb, n, max_range, discrete, false);
+		return listBatchStep(m, c, sensor_origin, d_xyz, d_rgb, n, max_range, discrete, false, simple_ray_casting, early_stopping);
 	}
 	// Joins happen at fixed points of the sequence of calls -- the step two before this one is joined here -- never "when it
 	// happens to be complete": a step that has to be repeated is repeated by all ranks together (a collective).
@@ -571,7 +593,7 @@ int ufomap_map_insert_batch(ufomap_map* m, ufomap_comm* c, const double sensor_o
 	// the other ranks are on their way into it)
 	if (!c->spec_valid) {  // (the join repeated a step through the list form and found no common grid after it)
 		m->batch_world = 0;
-		const int lrc = listBatchStep(m, c, sensor_origin, d_xyz, d_rgb, n, max_range, discrete, false);
+		const int lrc = listBatchStep(m, c, sensor_origin, d_xyz, d_rgb, n, max_range, discrete, false, simple_ray_casting, early_stopping);
 		return lrc ? lrc : prc;
 	}
 	m->seq = ++m->latest_seq;

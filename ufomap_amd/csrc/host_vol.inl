@@ -56,7 +56,7 @@ int volSelfTest(ufomap_map* m)
 // beyond 8 MiB) and whose brick grids fit the scratch limit.
 bool volPlan(const ufomap_map* m, const Grid& gr, unsigned depth, int simple, unsigned early_stopping, const uint8_t* d_rgb, VolPlan* vp)
 {
-	if (!m->opt_vol || 0 != depth || simple || early_stopping || ((d_rgb || m->g.color) && !m->opt_vol_color) || m->chg_enabled || m->g.L < 6) return false;
+	if (!m->opt_vol || m->keys_mode || 0 != depth || simple || early_stopping || ((d_rgb || m->g.color) && !m->opt_vol_color) || m->chg_enabled || m->g.L < 6) return false;
 	const bool packed = 2 * gr.nb[0] < 1023 && 2 * gr.nb[1] < 1023 && 2 * gr.nb[2] < 1023;
 	const u64 bytes1 = (u64)(gridRowBits(gr) >> 3) * (2ull * (u64)gr.nb[1]) * (2ull * (u64)gr.nb[2]);
 	if (m->opt_vol < 2 && packed && bytes1 <= (8ull << 20)) return false;  // (the fast path's sizes; option vol = 2: tests run small scans here)

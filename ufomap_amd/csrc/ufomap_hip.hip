@@ -341,6 +341,7 @@ struct ufomap_map {
 	int opt_vol_keep = 1;   // k_tile leaves the merged ray cells of its tiles behind (ufomap_map_last_misses)
 	// (the current hand-over set's share of the volume path's state: HandOver)
 	bool vol = false, vol_dirty = true, vol_walk = false;
+	bool keys_mode = false;  // scanPhase is run for an update list (ufomap_map_scan_keys, the list form of a batch step)
 	u32 vol_count = 0, vol_scan_id = 0;
 	const uint8_t* vol_rgb = nullptr;
 	DevBuf b_vM, b_vMm, b_vH, b_vtb, b_vlist, b_vcopies, b_vslots, b_vaux, b_vupbits, b_vrec;
@@ -3262,7 +3263,7 @@ int ufomap_map_scan_keys(ufomap_map* m, const double sensor_origin[3], const dou
 }
 
 int scanKeysCore(ufomap_map* m, const double sensor_origin[3], const double* d_xyz, const uint8_t* d_rgb, size_t n, double max_range, unsigned depth,
-                 int discrete, int simple_ray_casting, ufomap_keys_info* info);
+                 int discrete, int simple_ray_casting, ufomap_keys_info* info, unsigned early_stopping = 0);
 int applyKeysBatchCore(ufomap_map* m, const void* const* d_lists, const ufomap_keys_info* infos, int n_lists, bool sync);
 
 int ufomap_map_scan_keys_rgb(ufomap_map* m, const double sensor_origin[3], const double* d_xyz, const uint8_t* d_rgb, size_t n, double max_range,
@@ -3283,7 +3284,7 @@ int ufomap_map_scan_keys_rgb(ufomap_map* m, const double sensor_origin[3], const
 
 // (the scan itself, on the current hand-over set)
 int scanKeysCore(ufomap_map* m, const double sensor_origin[3], const double* d_xyz, const uint8_t* d_rgb, size_t n, double max_range, unsigned depth,
-                 int discrete, int simple_ray_casting, ufomap_keys_info* info)
+                 int discrete, int simple_ray_casting, ufomap_keys_info* info, unsigned early_stopping)
 {
 	memset(info, 0, sizeof(*info));
 	info->depth = depth;
@@ -3300,7 +3301,9 @@ int scanKeysCore(ufomap_map* m, const double sensor_origin[3], const double* d_x
 	} restore{m};
 	m->cs = m->sstream;
 	u32 n_hits = 0, n_rays = 0;
-	int rc = scanPhase(m, sensor_origin, d_xyz, d_rgb, n, max_range, depth, discrete, simple_ray_casting, 0, &n_hits, &n_rays);
+	m->keys_mode = true;  // (the scan's ray cells are wanted as an update list: not the volume path's brick grids)
+	int rc = scanPhase(m, sensor_origin, d_xyz, d_rgb, n, max_range, depth, discrete, simple_ray_casting, early_stopping, &n_hits, &n_rays);
+	m->keys_mode = false;
 	if (rc || 0 == n) return rc;
 	u64 capH = 0, capM = 0;
 	// insert depth 0: ONE list, a block with hits and misses appears once with both masks (flagged in `reserved`)

@@ -308,12 +308,14 @@ class OccupancyMapBase:
             arr[i] = k
         capi.check(self._lib.ufomap_map_apply_keys_batch(self._h, ptrs, arr, n))
 
-    def insert_batch(self, comm, origin, d_xyz_ptr, n, max_range=-1.0, depth=0, discrete=True, d_rgb_ptr=None):
-        """This rank's scan of a multi-GPU batch (``ufomap_map_insert_batch``): ray casting here, one RCCL all-gather of the
-        update lists, all ranks' lists applied in rank order."""
+    def insert_batch(self, comm, origin, d_xyz_ptr, n, max_range=-1.0, depth=0, discrete=True, d_rgb_ptr=None, simple_ray_casting=False,
+                     early_stopping=0):
+        """This rank's scan of a multi-GPU batch (``ufomap_map_insert_batch_ex``): ray casting here, one RCCL all-gather of the
+        scans (bit grids in the steady state, update lists otherwise), all ranks' scans applied in rank order."""
         o = np.ascontiguousarray(origin, dtype=np.float64)
-        capi.check(self._lib.ufomap_map_insert_batch(self._h, comm._h, _p(o, C.c_double), C.c_void_p(int(d_xyz_ptr)),
-                                                     C.c_void_p(int(d_rgb_ptr)) if d_rgb_ptr else None, n, float(max_range), int(depth), int(discrete)))
+        capi.check(self._lib.ufomap_map_insert_batch_ex(self._h, comm._h, _p(o, C.c_double), C.c_void_p(int(d_xyz_ptr)),
+                                                        C.c_void_p(int(d_rgb_ptr)) if d_rgb_ptr else None, n, float(max_range), int(depth), int(discrete),
+                                                        int(simple_ray_casting), int(early_stopping)))
 
     def set_scratch_limit(self, n_bytes):
         """``ufomap_map_set_scratch_limit``: largest dense per-scan grid; scans beyond it take the sparse set of ray cells."""
