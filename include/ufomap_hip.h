@@ -57,7 +57,10 @@ ufomap_map* ufomap_map_create(double resolution, unsigned depth_levels, int auto
 void ufomap_map_destroy(ufomap_map* m);
 /* Octree::clear() (octree.h:541): back to a single unknown root leaf. */
 int ufomap_map_clear(ufomap_map* m);
-/* Pre-size the node table for n 8-child node blocks (optional; the table grows on demand). */
+/* Pre-size the node table for about n 8-child node blocks: a HINT (optional; the table grows on demand). The table is tile-major --
+ * 73 slots per depth-3 tile that holds anything -- so what n blocks need depends on how dense the map is inside its tiles: the call
+ * sizes for n / 40 tile groups and n / 200 blocks above depth 3, which fits a dense map (a 2 mm RGB-D frame: 47 live blocks per
+ * group); a sparse one (LiDAR: ~10 per group) may still see a re-hash later. */
 int ufomap_map_reserve(ufomap_map* m, size_t n_blocks);
 /* Upper bound in bytes for a scan's dense dedup grid (default 16 GiB). A scan whose bounding box needs more keeps its ray
  * cells in a sparse set of node blocks instead (bounded by the cells the rays touch, as the reference's CodeMap is,

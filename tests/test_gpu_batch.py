@@ -472,6 +472,25 @@ def test_insert_batch_two_ranks_on_one_gpu(fail_at):
     assert results[0][3]["regrown"] >= 1, "the update-list slot should have had to grow (4 KiB to start with)"
 
 
+def test_every_scan_of_a_walk_reports_the_tables_fill():
+    """k_ftail wrote the regions' fill (groups claimed, first-region blocks) into the control block of the walk's LAST
+    scan only; a scan that was not the last, joined by itself, told the host the table was empty. Walks of four scans, joined one
+    scan at a time: the library counts result blocks that report an empty table while the host knows better -- none."""
+    from ufomap_amd import OccupancyMap, PointCloud
+    g = OccupancyMap(resolution=0.16)
+    g.set_option("hold", 4)
+    from test_gpu_vol import _wander
+    seq = _wander(20, spread=0.3)
+    for i, (origin, xyz) in enumerate(seq):
+        g.insertPointCloudDiscrete(origin, PointCloud(xyz), 12.0, 0, False, 0, True)
+        if i % 5 == 4:
+            g.insertPointCloudWait()
+    g.insertPointCloudWait()
+    d = g.debug()
+    assert d[60] < d[59], f"no walk took more than one scan ({d[60]} walks, {d[59]} scans)"
+    assert d[46] == 0, f"{d[46]} joined scans reported an empty node table"
+
+
 def test_insert_batch_two_gpus_real_rccl():
     """The same two-rank sequence over the REAL librccl, one GPU per rank (ncclAllGather across processes over xGMI / PCIe): runs
     wherever two GPUs are visible -- the driver's 8-GPU node --, skipped on a one-GPU box (there the shim above stands in). Every

@@ -341,6 +341,7 @@ struct ufomap_map {
 	int opt_vol_keep = 1;   // k_tile leaves the merged ray cells of its tiles behind (ufomap_map_last_misses)
 	// (the current hand-over set's share of the volume path's state: HandOver)
 	bool vol = false, vol_dirty = true, vol_walk = false;
+	u64 n_fill_zero = 0;     // joined fast-path scans whose result block reported an empty table while the host knew better (must stay 0)
 	bool keys_mode = false;  // scanPhase is run for an update list (ufomap_map_scan_keys, the list form of a batch step)
 	u32 vol_count = 0, vol_scan_id = 0;
 	const uint8_t* vol_rgb = nullptr;
@@ -1344,6 +1345,10 @@ int finishPending(ufomap_map* m)
 	if (m->fast && 0 == m->h_res->err) {
 		// k_ftail stored the finished control block in pinned memory itself and left the device copy in its start state
 		memcpy(m->h_ctl, m->h_res, sizeof(ScanCtl));
+		// (every scan of a walk carries the table's fill after the walk -- round 4 patched one of three words into the blocks of the
+		// scans that were not the walk's last, and the host sized the next update as if the table were empty: ADVICE r4; counted here
+		// so that a test can see it)
+		if (0 == m->h_ctl->used_g_now && m->used_g > 0) ++m->n_fill_zero;
 		m->used_est = m->h_ctl->used_now;
 		m->used_g = m->h_ctl->used_g_now;
 		m->used_u = m->h_ctl->used_u_now;
@@ -1430,7 +1435,10 @@ int scanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, const 
 	HIP_TRY(m->b_ray_end.reserve(n * sizeof(D3)));
 	HIP_TRY(m->b_hit_code.reserve(n * 8));
 	HIP_TRY(m->b_hit_pt.reserve(n * 4));
-	u32 hcap = nextPow2(std::max<u64>(1024, (u64)n * 3 + (depth ? (u64)n * 2 : 0)));  // load <= 0.5 (hits and their tiles, + ray cells when depth > 0)
+	// (at most n hit codes + n tile keys, + n ray cells when depth > 0, in >= 3 n (5 n) slots: load <= 0.67 (0.6) before the rounding up to
+	// a power of two, 0.33-0.67 after; linear probing at 0.67 finds a key in 2 probes on average, hitHashInsert* report ERR_HASH_FULL
+	// only when the table is FULL -- it cannot be: fewer keys than slots)
+	u32 hcap = nextPow2(std::max<u64>(1024, (u64)n * 3 + (depth ? (u64)n * 2 : 0)));
 	// keys and point indices in ONE buffer (keys first): one memset per scan instead of two
 	HIP_TRY(m->b_hh_keys.reserve((size_t)hcap * 12));
 	HIP_TRY(hipMemsetAsync(m->b_hh_keys.p, 0xFF, (size_t)hcap * 12, m->cs));
@@ -3730,6 +3738,7 @@ int ufomap_map_debug(ufomap_map* m, uint64_t* out, int n)
 	if (n > 51) out[51] = m->n_phase_resets;  // phaseGuard
 	if (n > 50) out[50] = m->n_vol;            // scans on the volume path (vol_kernels.h)
 	if (n > 49) out[49] = m->n_vol_grow;       // ... times the node table was exchanged in the middle of such a scan's tree update
+	if (n > 46) out[46] = m->n_fill_zero;     // (must be 0: every scan of a walk reports the table's fill)
 	if (n > 47) out[47] = m->es_rounds;        // rounds the last scan with early_stopping > 0 took to settle
 	if (n > 48) out[48] = m->n_vol_fallback;   // ... scans that turned to the general path (a ray clipped at the map cube)
 	for (int k = 0; k < 4 && 52 + k < n; ++k) out[52 + k] = m->host_ns[k];  // host time inside doInsert (ns): scan enqueue, map enqueue, join, total
