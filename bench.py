@@ -141,6 +141,7 @@ def live_traffic(kernels, timeout_s=150):
                     if r.get("Counter_Name") != counter:
                         continue
                     k = r.get("Kernel_Name", "").split("(")[0].replace("void ", "").replace("ufo::", "").strip().split("<")[0]
+                    k = "k_fcast" if k == "k_fcast2" else k  # (round 5's form of the ray kernel: the library times both as k_fcast)
                     a = acc.setdefault(k, [0, 0.0])
                     a[0] += 1
                     a[1] += float(r.get("Counter_Value") or 0)
@@ -670,7 +671,7 @@ def main():
             if os.path.exists(pmc):
                 try:
                     pj = json.load(open(pmc))
-                    vals = [next((v.get("hbm_bytes_per_launch") for kk, v in pj.items() if kk == k or kk.startswith(k + "<")), None) for k in group]
+                    vals = [next((v.get("hbm_bytes_per_launch") for kk, v in pj.items() if kk == k or kk.startswith(k + "<") or (k == "k_fcast" and kk.startswith("k_fcast2"))), None) for k in group]
                     traffic = sum(v for v in vals if v) if any(vals) else None
                     import hashlib
                     traffic_src = ("profiles/pmc_latest.json (sha256 " + hashlib.sha256(open(pmc, "rb").read()).hexdigest()[:16] +
@@ -682,12 +683,12 @@ def main():
                 traffic, traffic_src = traffic_live, traffic_live_note
             by_time = max(per_step_ms, key=per_step_ms.get)
             frac_rocprof, rocprof_src = None, None
-            for tag in ("r04", "r03", "r02"):
+            for tag in ("r05", "r04", "r03", "r02"):
                 f = os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv")
                 if os.path.exists(f):
                     import csv
                     import hashlib
-                    rows = {r["kernel"].split("<")[0]: float(r["avg_ns"]) for r in csv.DictReader(open(f)) if r.get("avg_ns")}
+                    rows = {("k_fcast" if r["kernel"].split("<")[0] == "k_fcast2" else r["kernel"].split("<")[0]): float(r["avg_ns"]) for r in csv.DictReader(open(f)) if r.get("avg_ns")}
                     if all(k in rows for k in group):
                         frac_rocprof = share / (sum(rows[k] for k in group) * 1e-9) / 1e9 / HBM_PEAK_GBS
                         rocprof_src = f"profiles/{tag}_kernel_stats.csv (sha256 {hashlib.sha256(open(f, 'rb').read()).hexdigest()[:16]}): rocprofv3 --kernel-trace --stats of this command"
@@ -724,7 +725,7 @@ def main():
             "roofline": roof, "self_check": self_check, "pipeline": pipeline,
             "memory": {"table_bytes": mem_stats["bytes"], "live_blocks": mem_stats["inner_nodes"], "leaves": mem_stats["leaf_nodes"],
                        "bytes_per_live_block": mem_stats["bytes_per_block"],
-                       "note": "node table as allocated after the headline leg's last repetition: tile-major since round 4 -- 73 slots of 80 B per depth-3 tile behind a directory, "
+                       "note": "node table as allocated after the headline leg's last repetition: tile-major since round 4 -- 73 slots of 68 B (round 5: one array per field; round 4: 80 B) per depth-3 tile behind a directory, "
                                "sized for every tile of the ray grid's hull being new. A LiDAR map is sparse inside its tiles (surfaces; free space is pruned away): ~10 live blocks "
                                "per 73-slot group, which is what bytes_per_live_block shows; the dense 2 mm RGB-D map (other_configs.C3_rgbd2mm_depth0) holds 47 live blocks per group"},
         }

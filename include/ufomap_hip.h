@@ -347,9 +347,12 @@ int ufomap_map_insert_batch_ex(ufomap_map* m, ufomap_comm* c, const double senso
  * beyond the steady-state path -- a 2 mm RGB-D frame -- keep to the general path instead of the volume path of vol_kernels.h;
  * 2: the volume path also for boxes the steady-state path would take), "vol_pregrow" (0: no growth of the node table before a
  * volume-path walk: it runs out of its reserve and the table is exchanged in the middle of the walk), "vol_keep" (0: the merged
- * ray cells of a volume-path scan are not kept for ufomap_map_last_misses), "vol_mode" (A/B switches of its ray kernel: bit 0 one
- * copy of the brick grid for all XCDs, bit 1 blocks in launch order, bit 2 rays in the cloud's order, bit 3 no write-combining
- * table), "fast_simple" (0: fixed-step ray casting keeps to the general path), "gather_stream" (1: the all-gather of a batch step on
+ * ray cells of a volume-path scan are not kept for ufomap_map_last_misses), "vol_mode" (A/B switches of its ray kernels: bit 1 blocks in launch order, bit 2
+ * rays in the cloud's order, bit 3 no write-combining table, bit 4 one lane per ray (k_vdda) instead of the segmented walk); round 5:
+ * "vol_seg" (cells per segment of a ray on the volume path, default 192), "vol_walk_blocks" (workgroups of its walk per eighth of the
+ * scan), "vol_async" (0: an asynchronous call returns a finished integration on the volume path instead of leaving its walk
+ * enqueued), "vol_color" (0: colour maps keep to the general path), "cast_fused" (0: the steady-state path's ray kernel in its round-3
+ * form, k_fcast), "cast2_k" (cells per segment of the fused ray kernel, default 64), "fast_simple" (0: fixed-step ray casting keeps to the general path), "gather_stream" (1: the all-gather of a batch step on
  * a stream of its own), "fail_scan" (test aid: the scan half of the next batch steps fails on this rank before the collective).
  * Results never depend on these. */
 int ufomap_map_set_option(ufomap_map* m, const char* key, long long value);
