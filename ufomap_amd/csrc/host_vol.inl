@@ -137,15 +137,16 @@ int volScan(ufomap_map* m, const D3& sensor, const VolPlan& vp, u32 n_hits, u32 
 	if (0 == (m->opt_vol_mode & 4) && n_rays >= 4096u) {
 		// the rays bundled by direction (a counting sort over a cube map of directions): a wave's rays share bricks all the way
 		ProfScope ps(m, "k_vbin");
-		HIP_TRY(m->b_vbin.reserve(((size_t)UFO_VBINS + 2u * (size_t)n_rays) * 4));
+		HIP_TRY(m->b_vbin.reserve(((size_t)UFO_VBINS + 128u + 2u * (size_t)n_rays) * 4));
 		u32* hist = m->b_vbin.as<u32>();
-		u32* bin_of = hist + UFO_VBINS;
+		u32* tot = hist + UFO_VBINS;  // (sums of k_vbin_scan1's workgroups)
+		u32* bin_of = tot + 128u;
 		u32* ord = bin_of + n_rays;
 		HIP_TRY(hipMemsetAsync(hist, 0, (size_t)UFO_VBINS * 4, m->cs));
 		const dim3 gb((n_rays + 255u) / 256u);
 		hipLaunchKernelGGL(k_vbin_count, gb, dim3(256), 0, m->cs, sensor, m->b_ray_end.as<D3>(), ctl, bin_of, hist);
-		hipLaunchKernelGGL(k_vbin_scan, dim3(1), dim3(1024), 0, m->cs, hist);
-		hipLaunchKernelGGL(k_vbin_scatter, gb, dim3(256), 0, m->cs, ctl, bin_of, hist, ord);
+		hipLaunchKernelGGL(k_vbin_scan1, dim3(UFO_VBINS / 1024u), dim3(1024), 0, m->cs, hist, tot);
+		hipLaunchKernelGGL(k_vbin_scatter, gb, dim3(256), 0, m->cs, ctl, bin_of, hist, ord, (const u32*)tot);
 		order = ord;
 	}
 	// the rays cut into segments of ~K cells that lanes walk one each (vol_kernels.h, round 5) -- unless the segment list would not

@@ -110,7 +110,30 @@ __global__ __launch_bounds__(256) void k_vbin_count(D3 sensor, const D3* __restr
 	bin_of[r] = b;
 	atomicAdd(&hist[b], 1u);
 }
-// exclusive prefix over the bins (one workgroup of 1024 threads, 96 bins each)
+// exclusive prefix over the bins, in two steps (round 5; the single workgroup below walked 96 bins per thread with stride-96 loads:
+// 58 us): every workgroup scans ITS 1024 bins in place (coalesced) and leaves their sum; the scatter adds the sums of the
+// workgroups before (96 values, scanned by every workgroup of the scatter for itself)
+__global__ __launch_bounds__(1024) void k_vbin_scan1(u32* __restrict__ hist, u32* __restrict__ tot)
+{
+	__shared__ u32 wsum[16];
+	const u32 t = threadIdx.x, lane = t & 63u, wave = t >> 6, i = blockIdx.x * 1024u + t;
+	const u32 c = hist[i];
+	u32 incl = c;
+	for (int o = 1; o < 64; o <<= 1) {
+		const u32 v = __shfl_up(incl, o);
+		if ((int)lane >= o) incl += v;
+	}
+	if (63u == lane) wsum[wave] = incl;
+	__syncthreads();
+	u32 base = 0, all = 0;
+	for (u32 w = 0; w < 16u; ++w) {
+		if (w < wave) base += wsum[w];
+		all += wsum[w];
+	}
+	hist[i] = base + incl - c;
+	if (0 == t) tot[blockIdx.x] = all;
+}
+// (the round-4 form, kept for reference and for tests of the new one)
 __global__ __launch_bounds__(1024) void k_vbin_scan(u32* __restrict__ hist)
 {
 	__shared__ u32 wsum[16];
@@ -133,12 +156,36 @@ __global__ __launch_bounds__(1024) void k_vbin_scan(u32* __restrict__ hist)
 		base += c;
 	}
 }
-__global__ __launch_bounds__(256) void k_vbin_scatter(const ScanCtl* ctl_in, const u32* __restrict__ bin_of, u32* __restrict__ offs, u32* __restrict__ order)
+__global__ __launch_bounds__(256) void k_vbin_scatter(const ScanCtl* ctl_in, const u32* __restrict__ bin_of, u32* __restrict__ offs, u32* __restrict__ order,
+                                                      const u32* __restrict__ tot)
 {
+	// (tot: the sums of k_vbin_scan1's workgroups, UFO_VBINS / 1024 = 96 of them; nullptr: offs holds the full prefix already)
+	__shared__ u32 bbase[UFO_VBINS / 1024u];
+	if (tot) {
+		if (threadIdx.x < 64u) {
+			// two values per lane of the first wave: exclusive prefix over 96 sums
+			const u32 a = tot[threadIdx.x], b = (threadIdx.x + 64u < UFO_VBINS / 1024u) ? tot[threadIdx.x + 64u] : 0u;
+			u32 ia = a;
+			for (int o = 1; o < 64; o <<= 1) {
+				const u32 v = __shfl_up(ia, o);
+				if ((int)threadIdx.x >= o) ia += v;
+			}
+			const u32 first64 = __shfl(ia, 63);
+			u32 ib = b;
+			for (int o = 1; o < 64; o <<= 1) {
+				const u32 v = __shfl_up(ib, o);
+				if ((int)threadIdx.x >= o) ib += v;
+			}
+			bbase[threadIdx.x] = ia - a;
+			if (threadIdx.x + 64u < UFO_VBINS / 1024u) bbase[threadIdx.x + 64u] = first64 + ib - b;
+		}
+		__syncthreads();
+	}
 	const u32 n = ctl_in->n_rays;
 	const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
 	if (r >= n) return;
-	order[atomicAdd(&offs[bin_of[r]], 1u)] = r;
+	const u32 bin = bin_of[r];
+	order[(tot ? bbase[bin >> 10] : 0u) + atomicAdd(&offs[bin], 1u)] = r;
 }
 
 // The XCD this wave runs on (HW_REG_XCC_ID, bits 3:0). Waves that read the same value share one L2.
@@ -645,6 +692,7 @@ __global__ __launch_bounds__(256) void k_vlist(u32* __restrict__ tbx, u32 ntiles
 		for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
 		if (0 == threadIdx.x && v) atomicAdd(&ctl->n_steps, v);
 	}
+	__shared__ u32 wsum[8];
 	const u32 nwords = volTbWords(ntiles);  // (the padding words are never marked)
 	for (u32 w0 = blockIdx.x * blockDim.x; w0 < nwords; w0 += gridDim.x * blockDim.x) {  // (uniform)
 		const u32 w = w0 + threadIdx.x;
@@ -657,7 +705,27 @@ __global__ __launch_bounds__(256) void k_vlist(u32* __restrict__ tbx, u32 ntiles
 #pragma unroll
 		for (int k = 0; k < 8; ++k)
 			if (c[k]) tbx[(size_t)k * nwords + w] = 0u;
-		u32 pos = waveAppendN(n_out, (u32)__popc(any));
+		// (room in the list: ONE atomic per workgroup and pass -- 3 600 waves adding to the one word queued for 43 us of this kernel's 57)
+		u32 pos;
+		{
+			const u32 cnt = (u32)__popc(any), lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+			u32 incl = cnt;
+			for (int o = 1; o < 64; o <<= 1) {
+				const u32 v = __shfl_up(incl, o);
+				if ((int)lane >= o) incl += v;
+			}
+			if (63u == lane) wsum[wv] = incl;
+			__syncthreads();
+			if (0 == threadIdx.x) {
+				const u32 tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+				wsum[4] = tot ? atomicAdd(n_out, tot) : 0u;
+			}
+			__syncthreads();
+			u32 before = 0;
+			for (u32 k = 0; k < wv; ++k) before += wsum[k];
+			pos = wsum[4] + before + incl - cnt;
+			__syncthreads();  // (wsum is reused by the next pass)
+		}
 		while (any) {
 			const u32 bit = (u32)__ffs(any) - 1u;
 			any &= any - 1u;
