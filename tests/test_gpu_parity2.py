@@ -90,6 +90,21 @@ def test_c3_depth0_reduced_frame_leaf_for_leaf():
     assert same_dump(g.minmax_change(), o.minmax_change())
 
 
+def test_c3_coloured_reduced_frame_leaf_for_leaf():
+    """Round 5: the same reduced frame WITH COLOURS into an OccupancyMapColor (the volume path's colour instance, k_tile<true, VOL>):
+    leaf for leaf -- codes, depths, log-odds, colours -- and inner node for inner node against the CPU checker, fresh and warm."""
+    from ufomap_amd import scans
+    g, o = _maps(color=True, kind=_kind(), resolution=0.002)
+    origin, xyz, rgb = scans.rgbd(width=160, height=120, colored=True)
+    for i in range(2):
+        _gpu_insert(g, origin, xyz, rgb, max_range=5.0, discrete=True)
+        o.insert(origin, xyz, rgb, max_range=5.0, discrete=True)
+        gl, ol = g.leaves(True), o.leaves(True)
+        assert same_dump(gl, ol), f"scan {i}: leaves (with colours) differ"
+        assert same_dump(g.inner(), o.inner()), f"scan {i}: inner nodes differ"
+    assert g.debug()[50] == 2, "the coloured frame did not take the volume path"
+
+
 @pytest.mark.parametrize("cfg", ["C1", "C2", "C5"])
 def test_full_configs_against_the_unmodified_reference(cfg):
     """C1 / C2 / C5 at full size with the reference build itself as the checker (one hop less than the port)."""
