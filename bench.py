@@ -244,6 +244,9 @@ def other_configs(device, big, only=None):
                           live_blocks=st["inner_nodes"], leaves=st["leaf_nodes"], table_bytes=st["bytes"],
                           fast_path_scans=int(m.debug()[61]), scans=len(seq) + warm_reps, warm_scans_digest_checked=warm_checked)
         if instrument:
+            # (a fresh map's first scan allocates the table and the scratch arrays: hipMalloc / hipFree of 10-13 GB take 1 ms on one
+            # run and 400 ms on another -- the runtime's business, counted by the library and taken out here)
+            out[label]["ms_per_scan_fixture_minus_alloc_host_time"] = [round(v - a["host_ns"] * 1e-6, 4) for v, a in zip(ms, allocs_fixture)]
             out[label].update(ms_warm_all=[round(v, 3) for v in warm], ms_warm_min=float(min(warm)) if warm else None,
                               device_allocs_in_fixture_calls=allocs_fixture, device_allocs_in_warm_calls=allocs_warm, warm_kernels=kernels)
         return dig

@@ -95,8 +95,18 @@ class OccupancyMapBase:
     def insert_device(self, sensor_origin, d_xyz_ptr, d_rgb_ptr, n, max_range=-1.0, depth=0, discrete=True,
                       simple_ray_casting=False, early_stopping=0, async_=False):
         """Same as the two calls above for a cloud already resident in HBM (raw device pointers)."""
-        o = np.ascontiguousarray(sensor_origin, np.float64)
-        capi.check(self._lib.ufomap_map_insert_device(self._h, _p(o, C.c_double), d_xyz_ptr, d_rgb_ptr, n, float(max_range),
+        # (the ctypes pointer of an origin array is kept: building one costs 2.3 us, a twentieth of a pipelined scan's period -- the
+        # host's time per call is what bounds the steady-state path, DESIGN.md 4b)
+        o = sensor_origin
+        if not (isinstance(o, np.ndarray) and o.dtype == np.float64 and o.flags.c_contiguous):
+            o = np.ascontiguousarray(o, np.float64)
+        cache = self.__dict__.setdefault("_origin_ptrs", {})
+        ent = cache.get(id(o))
+        if ent is None or ent[0] is not o:
+            if len(cache) > 64:
+                cache.clear()
+            ent = cache[id(o)] = (o, _p(o, C.c_double))
+        capi.check(self._lib.ufomap_map_insert_device(self._h, ent[1], d_xyz_ptr, d_rgb_ptr, n, float(max_range),
                                                       int(depth), int(discrete), int(simple_ray_casting), int(early_stopping),
                                                       int(async_)))
 
