@@ -24,8 +24,8 @@
 //   * the tree update is TILED and BATCHED: one wavefront owns one depth-3 node (8x8x8 voxels: 64 level-1 node blocks, 8
 //     level-2 blocks, 1 level-3 block) and does everything the reference's updateValue does beneath it -- createNode with
 //     inheritance, updateOccupancy for hits then misses, updateNode / pruning on the way up (occupancy_map_base.h:
-//     1063-1224, octree.h:997-1162) -- in registers and cross-lane operations, for B scans in order, reading each 64-byte
-//     block record once and writing it once; the few hundred node blocks above depth 3 are finished by ONE workgroup that
+//     1063-1224, octree.h:997-1162) -- in registers and cross-lane operations, for B scans in order, reading each block's
+//     record once and writing it once; the few hundred node blocks above depth 3 are finished by ONE workgroup that
 //     holds them in LDS (k_ftail), where a level costs a barrier instead of a round trip to HBM;
 //   * which scans a walk takes is decided on the device when the walk starts (k_claim): whatever has queued up.
 // Semantics are those of the general path (map_kernels.h: "last-update chain"), which stays in place for everything
@@ -1332,8 +1332,8 @@ __host__ __device__ inline u32 upperCell(const UpperGeo& ug, u32 l, const i32 c[
 // while the B scans go over them (createNode with inheritance, updateOccupancy, updateNode, pruning and re-expansion
 // of what an earlier scan of the batch collapsed: all of it on the register copy), and are written once. Per scan the
 // wave reads 8 words per lane: its cells' bits in the scan's miss grid (ray cells) and hit grid.
-// Reads: those words, one 64-byte block record per lane, the parents' slices (coalesced 4-byte loads).
-// Writes: each touched block record once. Nothing above level 3 is written here: a tile whose level-3 block is new
+// Reads: those words, per lane one block's values, key and flags (44 B from three arrays: table.h), the parents' slices
+// (coalesced 4-byte loads). Writes: each touched block's values and flags once, and only if they changed. Nothing above level 3 is written here: a tile whose level-3 block is new
 // looks its inherited value up (read-only: nobody changes the blocks above during this launch) and leaves the rest --
 // creating the blocks above, linking, their summaries -- to k_ftail.
 //
