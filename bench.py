@@ -177,9 +177,24 @@ def other_configs(device, big, only=None):
             kw["origin"] = scans.lidar_pose(kw.pop("pose"))
         return getattr(scans, g)(**kw)
 
+    def settle_allocator(n_bytes):
+        """After a leg has given tens of GB back, the runtime's next large hipMalloc can take hundreds of ms (409 / 628 ms measured
+        inside the coloured frame's first scan, 1 ms on other runs): let it do that outside any timed call."""
+        try:
+            x = torch.empty(int(n_bytes), dtype=torch.uint8, device=f"cuda:{device}")
+            x.zero_()
+            torch.cuda.synchronize()
+            del x
+            torch.cuda.empty_cache()
+            torch.cuda.synchronize()
+        except Exception:  # noqa: BLE001  (hygiene only)
+            pass
+
     def run(label, params, seq, want, warm_reps, instrument=False):
         from ufomap_amd import capi
         params = dict(params)
+        if instrument:
+            settle_allocator(24 << 30)
         color = params.pop("color", False)
         m = (OccupancyMapColor if color else OccupancyMap)(device=device, **params)
         ms, ok = [], True

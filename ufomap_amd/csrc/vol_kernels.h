@@ -5,9 +5,11 @@
 //
 //   k_classify, k_select, k_reduce_boxes   head loops, first point per voxel, boxes (scan_kernels.h; the boxes are read back)
 //   k_vhits      the voxels that receive a hit -> brick grid H
-//   k_vdda       freeSpace (occupancy_map_base.h:1229-1301; computeRayInit / computeRayTakeStep octree.h:1192-1233): one lane per
-//                ray, the reference's sequential FP64 recurrence; marks go to brick grid M through a register that collects
-//                the bits of the brick the ray is in -- one atomic per (ray, brick) instead of one per step
+//   k_vcut       (round 5) every ray cut into segments of ~192 cells: the exact state at each cut from the three addition chains
+//   k_vwalk      (round 5) freeSpace (occupancy_map_base.h:1229-1301; computeRayInit / computeRayTakeStep octree.h:1192-1233): one
+//                lane per SEGMENT, the reference's FP64 recurrence; marks go to brick grid M through a register that collects the
+//                bits of the brick the ray is in, a per-lane queue and a per-wave write-combining table
+//                (k_vdda: round 4's form, one lane per whole ray -- the cross-check, option vol_mode bit 4)
 //   k_vlist      the tiles that hold a ray cell -> list
 //   k_tile<VOL>  one wave per listed tile (fast_kernels.h): everything beneath depth 3, each block record read and written once
 //   k_up x n     levels 4, 5, ... in parallel, eight lanes per block, until what is left above fits k_ftail's LDS
