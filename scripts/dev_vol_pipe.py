@@ -6,9 +6,13 @@ if len(sys.argv) > 2 and sys.argv[1] == "--show":
     rows = list(csv.DictReader(open(sys.argv[2])))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     tiles = [i for i, r in enumerate(rows) if "k_tile" in r["Kernel_Name"]]
-    lo = tiles[-4] if len(tiles) >= 4 else 0
+    # (the script runs 2 + 8 asynchronous scans, then 2 + 8 synchronous ones: the last four walks are synchronous scans, the four
+    # that end ten walks before the end are asynchronous ones in the steady state)
+    asy = len(sys.argv) > 3 and sys.argv[3] == "async"
+    lo = (tiles[-15] if len(tiles) >= 15 else 0) if asy else (tiles[-4] if len(tiles) >= 4 else 0)
+    hi = (tiles[-11] + 6 if len(tiles) >= 15 else len(rows)) if asy else len(rows)
     t0 = int(rows[lo]["Start_Timestamp"])
-    for r in rows[lo:]:
+    for r in rows[lo:hi]:
         name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("ufo::", "")[:40]
         s, e = (int(r["Start_Timestamp"]) - t0) * 1e-3, (int(r["End_Timestamp"]) - t0) * 1e-3
         if e - s > 8 or "k_tile" in name or "k_vwalk" in name:
