@@ -347,8 +347,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--python-exchange", action="store_true", help="N > 1: exchange the update lists with torch.distributed instead of the C ABI's own RCCL call")
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=8)
+    # (the driver runs `--steps 20 --warmup 5`; the defaults are the same since round 5 -- rounds 2-4 ran 40 / 8 here, and what was
+    # read as "the driver's box is 10 % slower" was the pipeline's fill and drain, ~200 us per timed region, spread over 20 steps
+    # instead of 40: the same box gives 0.0496 ms at K = 20, 0.0443 at 40, 0.0410 at 100, 0.0395 at 400)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-self-check", action="store_true")
     ap.add_argument("--force-batch", action="store_true", help="run the N>1 code path (scan/exchange/apply) even with one rank")

@@ -336,6 +336,7 @@ struct ufomap_map {
 	int opt_vol_seg = 192;  // cells per segment of a ray on the volume path (k_vcutA / k_vwalk)
 	int opt_vol_walk_blocks = 1536;  // workgroups of k_vwalk per eighth of the scan
 	int opt_vol_walk_lds = 0;  // extra LDS per workgroup of k_vwalk, bytes: caps its workgroups per CU (what is left takes the tree update of the scan before)
+	int opt_wait_flush_first = 1;  // ufomap_map_wait enqueues the walk of the scans that wait for company before it synchronises anything
 	int opt_vol_color = 1;  // colour maps on the volume path (0: the general path, as in round 4)
 	int opt_vol_async = 1;  // an asynchronous call returns with the volume path's walk enqueued (0: every call returns a finished integration)
 	int opt_vol_keep = 1;   // k_tile leaves the merged ray cells of its tiles behind (ufomap_map_last_misses)
@@ -2919,10 +2920,17 @@ int ufomap_map_wait(ufomap_map* m)
 {
 	if (!m) return fail(UFOMAP_ERR_INVALID, "null map");
 	HIP_TRY(hipSetDevice(m->device));
+	// (round 5) The scans that were waiting for company get their walk NOW, behind whatever is on the map stream -- its claim kernel
+	// waits for their scan halves on the device -- instead of after the host has seen the scan stream and the earlier walks drain:
+	// one host round trip and four launches less in the tail of every timed region (the driver's 20-step regions carry 10 us of
+	// that tail per step). A flagged integration found below still makes everything behind it stand back and be repeated in order.
+	int early_frc = UFOMAP_OK;
+	if (!m->prev_flagged && UFOMAP_OK == m->async_status && m->opt_wait_flush_first) early_frc = flushDeferred(m);
 	HIP_TRY(hipStreamSynchronize(m->pstream));
 	HIP_TRY(hipStreamSynchronize(m->sstream));
 	// what has been enqueued first, oldest first (a flagged integration is repeated before anything newer is applied) ...
 	int rc = joinEnqueued(m);
+	if (!rc) rc = early_frc;
 	{
 		// ... then the scans whose tree update was still waiting for company
 		const int frc = flushDeferred(m);
@@ -3708,6 +3716,8 @@ int ufomap_map_set_option(ufomap_map* m, const char* key, long long value)
 		m->opt_cast2_k = (int)std::max<long long>(8, std::min<long long>(1024, value));
 	} else if (0 == strcmp(key, "cast_fused")) {
 		m->opt_cast_fused = value ? 1 : 0;
+	} else if (0 == strcmp(key, "wait_flush_first")) {
+		m->opt_wait_flush_first = value ? 1 : 0;
 	} else if (0 == strcmp(key, "vol_color")) {
 		m->opt_vol_color = value ? 1 : 0;
 	} else if (0 == strcmp(key, "vol_async")) {
