@@ -1166,7 +1166,10 @@ __global__ __launch_bounds__(1024) void k_fmerge(FastGeo fg, const Pipe* __restr
 	__shared__ u32 tb[UFO_BIG_MAX_TILES / 32];
 	const Pipe::Slot sl = p->slot[f & (UFO_RING - 1u)];
 	const u32 tb_words = (fg.ntiles + 31u) / 32u;
-	for (u32 b = 0; b < sl.B; ++b) {
+	// (the scans of the walk: one after the other, or -- gridDim.y > 1 -- every gridDim.y-th by this row of workgroups: while the ray
+	// kernel holds three CUs in four the rows queue on the same CUs either way, but the LAST walk of a run of scans has the chip to
+	// itself, and what a timed region waits for at its end is exactly that walk)
+	for (u32 b = blockIdx.y; b < sl.B; b += gridDim.y) {
 		const ScanDesc& d = p->ring[(sl.first + b) & (UFO_RING - 1u)];
 		ScanCtl* ctl = d.ctl;
 		// (n_slabs == 0: a ray grid beyond LDS -- the ray kernel has marked the scan's grid in HBM itself, k_cast<2>; what is left

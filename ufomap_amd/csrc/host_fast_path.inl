@@ -508,7 +508,8 @@ int enqueueSlot(ufomap_map* m, int k)
 		ProfScope ps(m, "k_fmerge");
 		const u32 n4 = (u32)(fg.gr.bytes >> 4);
 		// (a grid beyond LDS has no slabs to merge: sixteen of the kernel's seventeen waves per workgroup would only meet at its barriers)
-		hipLaunchKernelGGL(k_fmerge, dim3(std::min<u32>((n4 + 63) / 64, 1024) + 1u), dim3(big_grid ? 64 : 1024), 0, m->cs, fg, pipe, (unsigned long long)f, n4);
+		hipLaunchKernelGGL(k_fmerge, dim3(std::min<u32>((n4 + 63) / 64, 1024) + 1u, (u32)std::max(1, std::min(m->opt_fmerge_rows, 8))), dim3(big_grid ? 64 : 1024), 0, m->cs, fg, pipe,
+		                   (unsigned long long)f, n4);
 	}
 	const float miss = (float)m->g.miss_log;  // insert depth 0 (OMB:311)
 	{

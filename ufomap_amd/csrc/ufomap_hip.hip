@@ -336,6 +336,7 @@ struct ufomap_map {
 	int opt_vol_seg = 192;  // cells per segment of a ray on the volume path (k_vcutA / k_vwalk)
 	int opt_vol_walk_blocks = 1536;  // workgroups of k_vwalk per eighth of the scan
 	int opt_vol_walk_lds = 0;  // extra LDS per workgroup of k_vwalk, bytes: caps its workgroups per CU (what is left takes the tree update of the scan before)
+	int opt_fmerge_rows = 2;  // rows of workgroups of k_fmerge (a row takes every rows-th scan of the walk)
 	int opt_wait_flush_first = 1;  // ufomap_map_wait enqueues the walk of the scans that wait for company before it synchronises anything
 	int opt_vol_color = 1;  // colour maps on the volume path (0: the general path, as in round 4)
 	int opt_vol_async = 1;  // an asynchronous call returns with the volume path's walk enqueued (0: every call returns a finished integration)
@@ -3716,6 +3717,8 @@ int ufomap_map_set_option(ufomap_map* m, const char* key, long long value)
 		m->opt_cast2_k = (int)std::max<long long>(8, std::min<long long>(1024, value));
 	} else if (0 == strcmp(key, "cast_fused")) {
 		m->opt_cast_fused = value ? 1 : 0;
+	} else if (0 == strcmp(key, "fmerge_rows")) {
+		m->opt_fmerge_rows = (int)value;
 	} else if (0 == strcmp(key, "wait_flush_first")) {
 		m->opt_wait_flush_first = value ? 1 : 0;
 	} else if (0 == strcmp(key, "vol_color")) {
