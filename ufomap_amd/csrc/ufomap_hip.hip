@@ -3708,7 +3708,7 @@ int ufomap_map_set_option(ufomap_map* m, const char* key, long long value)
 	} else if (0 == strcmp(key, "vol_mode")) {
 		m->opt_vol_mode = (int)(value & 31);
 	} else if (0 == strcmp(key, "vol_seg")) {
-		m->opt_vol_seg = (int)std::max<long long>(5, std::min<long long>(65536, value));
+		m->opt_vol_seg = (int)std::max<long long>(5, std::min<long long>(8192, value));  // (a segment has < 4 K cells; k_vwalk gives up at 65 536)
 	} else if (0 == strcmp(key, "vol_walk_blocks")) {
 		m->opt_vol_walk_blocks = (int)std::max<long long>(1, std::min<long long>(65536, value));
 	} else if (0 == strcmp(key, "vol_walk_lds")) {
