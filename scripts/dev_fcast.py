@@ -15,6 +15,9 @@ for i in range(24):
     m.insert_device(clouds[i % 8][0], d[i % 8].data_ptr(), None, n, 20.0, 0, True)
 names = ["start->lds zeroed", "head loop .. cuts", "walk", "slab store", "tail"]
 idx = [30, 31, 35, 36, 37, 38]
+if not any(a.startswith("cast_fused=") and a != "cast_fused=2" for a in sys.argv[1:]):
+    names = ["start->lds zeroed", "survivors listed", "set-up .. cuts", "walk", "slab store", "tail"]
+    idx = [30, 31, 32, 35, 36, 37, 38]
 acc = np.zeros(len(names))
 for i in range(24, 40):
     m.insert_device(clouds[i % 8][0], d[i % 8].data_ptr(), None, n, 20.0, 0, True)
@@ -40,3 +43,7 @@ for rep in range(3):
         m.insert_device(clouds[i % 8][0], d[i % 8].data_ptr(), None, n, 20.0, 0, True, False, 0, True)
     m.insertPointCloudWait(); dt = time.perf_counter() - t0
 print("pipelined us/scan", round(dt / 400 * 1e6, 2), "Grays/s", round(n / (dt / 400) / 1e9, 3))
+g = m.debug()
+st = np.array([g[k] for k in idx], dtype=np.float64)
+print("slowest lane of workgroup 0, clocks: list read + ray end load + raySetup, reservation + cuts:", [int(g[40 + z]) for z in range(2)], "walk: slowest wave's clocks, longest segment, segments:", int(g[42]), int(g[43]), int(g[39]))
+print("k_fcast WG 0 phases of the LAST pipelined scan, us:", {k: round(v, 2) for k, v in zip(names, np.diff(st) * 0.01)}, "total", round((st[-1] - st[0]) * 0.01, 2))

@@ -958,6 +958,354 @@ __global__ __launch_bounds__(1024) void k_fcast2(MapGeom g, FastGeo fg, D3 senso
 }
 
 // ------------------------------------------------------------------------------------------------
+// F2'' (round 6): the ray kernel of the steady state, rebuilt around what a DEPENDENT instruction costs a lone wave on this part
+// (scripts/micro/chain_latency.hip: a dependent FP64 addition 11 clocks, a loop iteration 30, one DDA step of the walk 244-284 --
+// whatever the occupancy: the step is one chain of compares, mask arithmetic and selects). k_fcast2's 25 us were three such chains,
+// one behind the other, with the chip idle beside them:
+//   * in discrete mode three points in four lose their voxel to an earlier point (OMB:358-360): every wave ran the ~1 000
+//     instructions of set-up and cuts with a quarter of its lanes, twice (two points per lane). Here a first pass only LOOKS at the
+//     points (record, first-point array) and appends the indices of the survivors to a list in LDS; after one barrier lane t takes
+//     survivor t -- the rays of a workgroup (~190 of ~680 points) fill three waves;
+//   * the cuts tested the minor axes' elements four at a time in a loop: ~350 clocks of dependent compares, selects and mask
+//     arithmetic per iteration, and a wave runs as many iterations as its slowest lane -- 8 us. Now: a LOWER estimate of how many
+//     elements precede the cut from one multiplication, that many plain additions (the same sequence of sums, 11 clocks each), a
+//     check that the last element skipped really precedes the cut, the rest (one or two) one by one without a branch;
+//   * queue room is reserved once per wave (returning LDS atomics of 64 lanes on one word run one lane after the other).
+// Same cells, same step count: the cut states are the same sums (the 14 scheduling tests, the bench's self-check).
+// ------------------------------------------------------------------------------------------------
+template <bool DISCRETE>
+__global__ __launch_bounds__(1024) void k_fcast3(MapGeom g, FastGeo fg, D3 sensor, u32 n, const u32* __restrict__ first, u32* __restrict__ slabs, u32 K,
+                                                const ScanCtl* ctl_in, ScanCtl* ctl, unsigned long long* __restrict__ steps_part, const PointRec* __restrict__ recs,
+                                                u32 rcap, u32 qcap, u32 lcap, u32 prio, Pipe* solo, ScanDesc solo_desc)
+{
+	if (solo && 0 == (threadIdx.x | blockIdx.x)) {
+		solo->ring[0] = solo_desc;
+		solo->slot[0].first = 0;
+		solo->slot[0].B = 1;
+	}
+	if (prio >= 3u) __builtin_amdgcn_s_setprio(3);
+	else if (2u == prio) __builtin_amdgcn_s_setprio(2);
+	else if (1u == prio) __builtin_amdgcn_s_setprio(1);
+	extern __shared__ __attribute__((aligned(16))) u32 lds[];
+	const u32 err_in = ctl_in->err;  // (looked at once the LDS grid has been cleared: the load is in flight meanwhile)
+	if (0 == (threadIdx.x | blockIdx.x)) ctl->dbg[30] = wall_clock64();  // (diagnostics)
+	const Grid& gr = fg.gr;
+	const u32 lds_words = (u32)(gr.bytes >> 2);
+	RayConst* rc = reinterpret_cast<RayConst*>(lds + lds_words);
+	SegRec* q = reinterpret_cast<SegRec*>(rc + rcap);
+	u32* wl = reinterpret_cast<u32*>(q + qcap);  // the pass's survivors: point indices
+	u32* sh = wl + lcap;  // [0] rays of the round, [1] queue entries asked for, [2] first entry that was refused, [3] rays cast, [4] voxels hit, [5] survivors
+	                      // (lcap: points per pass -- the list holds their survivors; a workgroup with more points takes several passes)
+	const u32 pts = (n > blockIdx.x) ? (n - blockIdx.x + gridDim.x - 1) / gridDim.x : 0u;
+	const u32 lane = threadIdx.x & 63u;
+	u32 nhit = 0;
+	// the first pass's records are asked for before the grid is cleared
+	PointRec pr0;
+	pr0.flags = 0;
+	pr0.cell = 0;
+	if (threadIdx.x < pts && !err_in) pr0 = recs[blockIdx.x + threadIdx.x * gridDim.x];
+	{
+		uint4* l4 = reinterpret_cast<uint4*>(lds);
+		for (u32 j = threadIdx.x; j < (lds_words >> 2); j += blockDim.x) l4[j] = make_uint4(0, 0, 0, 0);
+	}
+	if (threadIdx.x < 16u) sh[threadIdx.x] = (2u == threadIdx.x) ? 0xFFFFFFFFu : 0u;
+	if (err_in) return;  // the scan does not fit the predicted grid (k_fhits): it will be repeated (uniform exit)
+	__syncthreads();
+	if (0 == (threadIdx.x | blockIdx.x)) ctl->dbg[31] = wall_clock64();  // (diagnostics)
+	const u32 rowBits = fg.rowBits, planeBits = fg.planeBits;
+	const u32 lim = 1u << g.L;
+	unsigned long long steps = 0;
+	u32 err = 0, oob = 0, ncast = 0;
+	for (u32 p0 = 0; p0 < pts; p0 += lcap) {  // (uniform; the steady state: one pass)
+		// ---- who casts a ray: the points p0 .. p0 + lcap - 1 of this workgroup (blockIdx.x + p * gridDim.x) ----
+		const u32 pend = min(pts, p0 + lcap);
+		for (u32 pb = p0; pb < pend; pb += blockDim.x) {  // (uniform)
+			const u32 p = pb + threadIdx.x;
+			bool cast = false;
+			u32 i = 0;
+			if (p < pend) {
+				i = blockIdx.x + p * gridDim.x;
+				const PointRec pr = (0 == pb) ? pr0 : recs[i];  // (k_fhits ran the head loop on the point)
+				const bool odd = 0 != (pr.flags & 4u);
+				cast = (pr.flags & 1u) && !odd;
+				if ((pr.flags & 2u) && !odd) {
+					// (the voxel receives a hit, OMB:295, 358-360: its first point's; k_fmerge derives the hit grid from the array)
+					const bool winner = first[pr.cell] == i;
+					nhit += winner ? 1u : 0u;
+					if (DISCRETE && !winner) cast = false;  // OMB:358-360: dropped entirely, no ray
+				}
+			}
+			const u64 m = __ballot(cast);
+			u32 base = 0;
+			if (0 == lane && m) base = atomicAdd(&sh[5], (u32)__popcll(m));
+			base = __shfl(base, 0);
+			if (cast) wl[base + (u32)__popcll(m & ((1ULL << lane) - 1ULL))] = i;
+		}
+		__syncthreads();
+		const u32 nw = sh[5];
+		if (0 == (threadIdx.x | blockIdx.x) && 0 == p0) ctl->dbg[32] = wall_clock64();  // (diagnostics)
+		// ---- lane t: survivors t, t + blockDim, ... -- one per round; a ray that finds the queue full stays with its lane until the next ----
+		u32 wcur = threadIdx.x;
+		bool pending = false;
+		RayState r;
+		r.status = 0;
+		u32 ax = 0, w = 1, nseg = 0, lin0 = 0, glin = 0;
+		i32 dla = 0, dl0 = 0, dl1 = 0;
+		for (u32 round = 0;; ++round) {  // (uniform: a round = set-up and cuts, barrier, walk, barrier)
+			const unsigned long long tq0 = clock64();
+			if (!pending && wcur < nw) {
+				const u32 i = wl[wcur];
+				wcur += blockDim.x;
+				const D3 end = recs[i].end;
+				++ncast;
+				raySetup(g, sensor, 0u, gr, end, r);
+				if (1 == r.status) {
+					err |= markBitChecked(gr, lds, rowBits, planeBits, r.start[0], r.start[1], r.start[2], lim, &oob);
+					steps += 1;
+				} else if (3 == r.status) {
+					err |= ERR_GRID_OOB;  // cannot happen: pointRay admits only rays inside the grid's interior
+				} else if (2 == r.status) {
+					const u32 dxn = (u32)abs((i32)(r.gpk & 1023u) - (i32)(r.pk0 & 1023u));
+					const u32 dyn = (u32)abs((i32)((r.gpk >> 10) & 1023u) - (i32)((r.pk0 >> 10) & 1023u));
+					const u32 dzn = (u32)abs((i32)(r.gpk >> 20) - (i32)(r.pk0 >> 20));
+					ax = (dxn >= dyn && dxn >= dzn) ? 0u : (dyn >= dzn ? 1u : 2u);
+					const u32 dmax = ax == 0 ? dxn : (ax == 1 ? dyn : dzn);
+					const u32 l1 = dxn + dyn + dzn;
+					w = (u32)(((u64)dmax * K) / l1);
+					if (w < 1u) w = 1u;
+					nseg = (dmax + w - 1u) / w;  // >= 1 (start and goal differ)
+					lin0 = pkToLin(r.pk0, rowBits, planeBits);
+					glin = pkToLin(r.gpk, rowBits, planeBits);
+					const i32 dlx = (i32)r.s[0], dly = (i32)r.s[1] * (i32)rowBits, dlz = (i32)r.s[2] * (i32)planeBits;
+					dla = ax == 0 ? dlx : (ax == 1 ? dly : dlz);
+					dl0 = ax == 0 ? dly : dlx;
+					dl1 = ax == 2 ? dly : dlz;
+					if (nseg > qcap) err |= ERR_GRID_OOB;  // (cannot happen: a ray inside a grid of < 1024 cells per axis has at most ~100 segments)
+					else pending = true;
+				}
+			}
+			const unsigned long long tq1 = clock64() + (unsigned long long)(77 == r.status ? 1 : 0);
+			// room for the ray's constants and its segments, or the next round: ONE reservation per wave -- every lane of the wave is here
+			u32 slot = 0xFFFFFFFFu, off = 0xFFFFFFFFu;
+			{
+				const u64 am = __ballot(pending);
+				u32 slot0 = 0;
+				if (0 == lane && am) slot0 = atomicAdd(&sh[0], (u32)__popcll(am));
+				slot0 = __shfl(slot0, 0);
+				if (pending) slot = slot0 + (u32)__popcll(am & ((1ULL << lane) - 1ULL));
+				const u32 want = (pending && slot < rcap) ? nseg : 0u;  // (a ray without room for its constants asks for no queue entries)
+				u32 scan = want;
+				for (int o = 1; o < 64; o <<= 1) {
+					const u32 up = __shfl_up(scan, o);
+					if ((int)lane >= o) scan += up;
+				}
+				const u32 total = __shfl(scan, 63);
+				u32 off0 = 0;
+				if (0 == lane && total) off0 = atomicAdd(&sh[1], total);
+				off0 = __shfl(off0, 0);
+				if (want) {
+					off = off0 + scan - want;
+					if (off + nseg > qcap) {
+						atomicMin(&sh[2], off);  // (every entry from here on belongs to a ray that was refused)
+						off = 0xFFFFFFFFu;
+					}
+				}
+			}
+			if (0xFFFFFFFFu != off) {
+				pending = false;
+				RayConst c;
+				c.td[0] = r.td[0];
+				c.td[1] = r.td[1];
+				c.td[2] = r.td[2];
+				c.dist = r.dist;
+				c.dl[0] = (i32)r.s[0];
+				c.dl[1] = (i32)r.s[1] * (i32)rowBits;
+				c.dl[2] = (i32)r.s[2] * (i32)planeBits;
+				c.glin = glin;
+				rc[slot] = c;
+				// the three chains (k_fcast2 / vol_kernels.h: k_vcut). a* = the dominant axis, b0 < b1 the two others; after k0 pops of a* element
+				// A[k0 - 1] (= v) was popped and t_max_a* = A[k0]; of axis b the elements before v were popped -- strictly smaller, or
+				// equal when b wins the tie (b < a*, vector3.h:244-251)
+				double ta = ax == 0 ? r.tm[0] : (ax == 1 ? r.tm[1] : r.tm[2]), v = ta;
+				const double tda = ax == 0 ? r.td[0] : (ax == 1 ? r.td[1] : r.td[2]);
+				double t0 = ax == 0 ? r.tm[1] : r.tm[0], t1 = ax == 2 ? r.tm[1] : r.tm[2];
+				const double d0 = ax == 0 ? r.td[1] : r.td[0], d1 = ax == 2 ? r.td[1] : r.td[2];
+				const bool pri0 = ax != 0u, pri1 = ax == 2u;
+				u32 n0 = 0, n1 = 0, guard = 0;
+				auto advance = [&](double& tb, const double dbt, const double inv, const bool pri, u32& cb) {
+					const double est = (v - tb) * inv;  // (negative, NaN or huge for an axis the ray does not move along: no skip)
+					u32 kk = (est > 2.0 && est < 4096.0) ? (u32)est - 1u : 0u;  // an element of margin: repeated rounding moves a sum by a few ulp, not by an element -- and the check below decides
+					if (kk) {
+						const u32 k0 = kk;
+						double sv = tb, prev = tb;
+						for (; kk >= 4u; kk -= 4u) {
+							const double s1 = sv + dbt, s2 = s1 + dbt, s3 = s2 + dbt;
+							prev = s3;
+							sv = s3 + dbt;
+						}
+						for (; kk > 0u; --kk) {
+							prev = sv;
+							sv = sv + dbt;
+						}
+						if (pri ? (prev <= v) : (prev < v)) {  // (else: the estimate was too high -- everything one by one, below)
+							tb = sv;
+							cb += k0;
+						}
+					}
+					bool e = true;
+#pragma unroll
+					for (int u = 0; u < 3; ++u) {
+						e = e & (pri ? (tb <= v) : (tb < v));
+						const double nt = tb + dbt;
+						tb = e ? nt : tb;
+						cb += e ? 1u : 0u;
+					}
+					while (e) {
+						e = pri ? (tb <= v) : (tb < v);
+						if (e) {
+							tb = tb + dbt;
+							cb += 1u;
+							if (++guard > 4096u) {
+								err |= ERR_RUNAWAY;  // (cannot trip inside a grid of < 1024 cells per axis)
+								break;
+							}
+						}
+					}
+				};
+				const double i0 = 1.0 / d0, i1 = 1.0 / d1;
+				u32 lin = lin0;
+				for (u32 j = 0; j < nseg; ++j) {
+					if (j > 0u) {
+						u32 np = w;
+						for (; np >= 4u; np -= 4u) {  // (the same sequence of additions, four at a time)
+							const double a1 = ta + tda, a2 = a1 + tda, a3 = a2 + tda;
+							v = a3;
+							ta = a3 + tda;
+						}
+						for (; np > 0u; --np) {
+							v = ta;
+							ta = ta + tda;
+						}
+						advance(t0, d0, i0, pri0, n0);
+						advance(t1, d1, i1, pri1, n1);
+						lin = lin0 + (u32)((i32)(j * w) * dla + (i32)n0 * dl0 + (i32)n1 * dl1);
+						q[off + j - 1u].end = lin;  // the segment before ends where this one starts
+					}
+					SegRec rec;
+					rec.tm[0] = ax == 0 ? ta : t0;
+					rec.tm[1] = ax == 0 ? t0 : (ax == 1 ? ta : t1);
+					rec.tm[2] = ax == 2 ? ta : t1;
+					rec.lin = lin;
+					rec.end = glin;
+					rec.ray = slot | (0u == j ? 0x80000000u : 0u);
+					rec.pad = 0;
+					q[off + j] = rec;
+				}
+			}
+			if (0 == round && 0 == p0 && 0 == blockIdx.x) {  // (diagnostics: the slowest lane's clocks in set-up and cuts, workgroup 0)
+				u32 d0c = (u32)(tq1 - tq0), d1c = (u32)(clock64() - tq1);
+				for (int o = 32; o > 0; o >>= 1) {
+					d0c = max(d0c, (u32)__shfl_xor((int)d0c, o));
+					d1c = max(d1c, (u32)__shfl_xor((int)d1c, o));
+				}
+				if (0 == lane) {
+					atomicMax(&sh[8], d0c);
+					atomicMax(&sh[9], d1c);
+				}
+			}
+			__syncthreads();
+			if (0 == (threadIdx.x | blockIdx.x) && 0 == round && 0 == p0) {  // (diagnostics)
+				ctl->dbg[35] = wall_clock64();
+				ctl->dbg[40] = sh[8];
+				ctl->dbg[41] = sh[9];
+			}
+			const u32 nsegs = min(min(sh[1], sh[2]), qcap);
+			// ---- every lane walks segments ----
+			const unsigned long long tw0 = clock64();
+			u32 wmaxc = 0;
+			for (u32 si = threadIdx.x; si < nsegs; si += blockDim.x) {
+				const SegRec rec = q[si];
+				const RayConst c = rc[rec.ray & 0x7FFFFFFFu];
+				double tmx = rec.tm[0], tmy = rec.tm[1], tmz = rec.tm[2];
+				const double tdx = c.td[0], tdy = c.td[1], tdz = c.td[2];
+				const long long idist = __double_as_longlong(c.dist);
+				const i32 dlx = c.dl[0], dly = c.dl[1], dlz = c.dl[2];
+				const u32 end = rec.end;
+				u32 lin = rec.lin;
+				bool go = (0 != (rec.ray & 0x80000000u)) ||
+				          ((lin != c.glin) && ((__double_as_longlong(tmx) <= idist) | (__double_as_longlong(tmy) <= idist) | (__double_as_longlong(tmz) <= idist)));
+				u32 cnt = 0;
+				while (go) {
+					++cnt;
+					atomicOr(&lds[lin >> 5], 1u << (lin & 31u));
+					const bool cxy = tmx <= tmy, cxz = tmx <= tmz, cyz = tmy <= tmz;
+					const bool selx = cxy & cxz;
+					const bool sely = !cxy & cyz;
+					const bool selz = !(selx | sely);
+					lin += (u32)(selx ? dlx : (sely ? dly : dlz));
+					const double nx = tmx + tdx, ny = tmy + tdy, nz = tmz + tdz;
+					tmx = selx ? nx : tmx;
+					tmy = sely ? ny : tmy;
+					tmz = selz ? nz : tmz;
+					const bool more = (__double_as_longlong(tmx) <= idist) | (__double_as_longlong(tmy) <= idist) | (__double_as_longlong(tmz) <= idist);
+					go = (lin != end) & more & (cnt < 4096u);
+				}
+				if (cnt >= 4096u) err |= ERR_RUNAWAY;  // (a segment is ~K steps by construction)
+				steps += cnt;
+				wmaxc = max(wmaxc, cnt);
+			}
+			if (0 == round && 0 == p0 && 0 == blockIdx.x) {  // (diagnostics)
+				u32 dwc = (u32)(clock64() - tw0);
+				for (int o = 32; o > 0; o >>= 1) {
+					dwc = max(dwc, (u32)__shfl_xor((int)dwc, o));
+					wmaxc = max(wmaxc, (u32)__shfl_xor((int)wmaxc, o));
+				}
+				if (0 == lane) {
+					atomicMax(&sh[10], dwc);
+					atomicMax(&sh[11], wmaxc);
+					sh[12] = nsegs;
+				}
+			}
+			const int more_rounds = __syncthreads_or((pending || wcur < nw) ? 1 : 0);  // (the queue and the counters are no longer read)
+			if (threadIdx.x < 3u) sh[threadIdx.x] = (2u == threadIdx.x) ? 0xFFFFFFFFu : 0u;
+			if (!more_rounds) break;
+			__syncthreads();
+		}
+		if (0 == threadIdx.x) sh[5] = 0;
+		__syncthreads();  // (the list and the counters are free for the next pass)
+	}
+	for (int o = 32; o > 0; o >>= 1) {
+		nhit += __shfl_xor(nhit, o);
+		ncast += __shfl_xor(ncast, o);
+	}
+	if (0 == lane && nhit) atomicAdd(&sh[4], nhit);
+	if (0 == lane && ncast) atomicAdd(&sh[3], ncast);
+	__syncthreads();
+	if (0 == (threadIdx.x | blockIdx.x)) {  // (diagnostics)
+		ctl->dbg[36] = wall_clock64();
+		ctl->dbg[42] = sh[10];
+		ctl->dbg[43] = sh[11];
+		ctl->dbg[39] = sh[12];
+	}
+	if (0 == threadIdx.x) {
+		// per-workgroup partials, folded by k_fmerge (256 workgroups adding to one word serialise at ~12 ns each)
+		steps_part[gridDim.x + blockIdx.x] = sh[3];
+		steps_part[2u * gridDim.x + blockIdx.x] = sh[4];
+	}
+	{
+		const uint4* l4 = reinterpret_cast<const uint4*>(lds);
+		uint4* out4 = reinterpret_cast<uint4*>(slabs) + (size_t)blockIdx.x * (lds_words >> 2);
+		const u32 n4 = lds_words >> 2;
+		for (u32 j = threadIdx.x; j < n4; j += blockDim.x) out4[j] = l4[j];
+	}
+	if (0 == (threadIdx.x | blockIdx.x)) ctl->dbg[37] = wall_clock64();  // (diagnostics)
+	blockStoreSteps(steps, steps_part);
+	if (oob) atomicAdd(&ctl->n_oob, oob);
+	if (err) atomicOr(&ctl->err, err);
+	if (0 == (threadIdx.x | blockIdx.x)) ctl->dbg[38] = wall_clock64();  // (diagnostics)
+}
+
+// ------------------------------------------------------------------------------------------------
 // F2s: the ray kernel of the fast path for SIMPLE ray casting (freeSpaceSimple, occupancy_map_base.h:1303-1339; the server's
 // `simple_ray_casting` switch): n = int(distance / size) fixed steps of dir * size from the ray's end towards the sensor,
 // the cell of every point on the way -- three independent chains of repeated additions per ray, no DDA state, at most a

@@ -332,7 +332,7 @@ int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, si
 			u32 batch = (u32)std::min<long long>(512, std::max<long long>(64, m->opt_cast_batch));
 			u32 qcap = (u32)std::min<long long>(2048, std::max<long long>(2 * batch, m->opt_cast_qcap));
 			const u32 prio = (u32)m->opt_cast_prio;
-			const u32 cthreads = m->opt_cast_threads >= 1024 ? 1024u : (m->opt_cast_threads >= 768 ? 768u : 512u);
+			const u32 cthreads = m->opt_cast_threads >= 1024 ? 1024u : (m->opt_cast_threads >= 768 ? 768u : (m->opt_cast_threads >= 512 ? 512u : 256u));
 			auto ldsFor = [&](u32 b, u32 q) { return (size_t)fg.gr.bytes + (size_t)b * (sizeof(RayConst) + sizeof(RayHdr)) + (size_t)q * sizeof(SegRec) + 256u; };
 			if (ldsFor(batch, qcap) > (160u << 10) - 256u) {
 				batch = UFO_CAST_BATCH;
@@ -353,6 +353,19 @@ int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, si
 				else
 					hipLaunchKernelGGL(k_fcast_simple<false>, dim3(nwg), dim3(cthreads), (size_t)fg.gr.bytes, m->cs, m->g, fg, sensor, N, m->b_first.as<u32>(), m->b_slabs.as<u32>(), ctl, ctl,
 					                   sp, m->b_hit_code.as<PointRec>(), solo_pipe, d);
+			} else if (m->opt_cast_fused >= 2) {
+				// (round 6: the points that cast a ray are packed into a list before anything is set up; the list takes what the grid, the
+				// ray constants and the segment queue leave of the CU's LDS, up to the workgroup's share of the cloud)
+				const size_t fixed = (size_t)fg.gr.bytes + (size_t)batch * sizeof(RayConst) + (size_t)qcap * sizeof(SegRec) + 256u;
+				const size_t room = ((160u << 10) - 512u - fixed) / 4u;
+				const u32 lcap = (u32)std::max<size_t>(64u, std::min<size_t>(room, ((size_t)cap_wg + 63u) & ~(size_t)63u));
+				const size_t lds3 = fixed + 4u * (size_t)lcap;
+				if (discrete)
+					hipLaunchKernelGGL(k_fcast3<true>, dim3(nwg), dim3(cthreads), lds3, m->cs, m->g, fg, sensor, N, m->b_first.as<u32>(), m->b_slabs.as<u32>(), (u32)std::max(8, m->opt_cast2_k),
+					                   ctl, ctl, sp, m->b_hit_code.as<PointRec>(), batch, qcap, lcap, prio, solo_pipe, d);
+				else
+					hipLaunchKernelGGL(k_fcast3<false>, dim3(nwg), dim3(cthreads), lds3, m->cs, m->g, fg, sensor, N, m->b_first.as<u32>(), m->b_slabs.as<u32>(), (u32)std::max(8, m->opt_cast2_k),
+					                   ctl, ctl, sp, m->b_hit_code.as<PointRec>(), batch, qcap, lcap, prio, solo_pipe, d);
 			} else if (m->opt_cast_fused) {
 				// (round 5: head loop, set-up and cuts by the lane that looks at the point, one barrier in front of the walk)
 				const size_t lds2 = (size_t)fg.gr.bytes + (size_t)batch * sizeof(RayConst) + (size_t)qcap * sizeof(SegRec) + 256u;

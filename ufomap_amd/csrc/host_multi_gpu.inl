@@ -560,8 +560,12 @@ int ufomap_map_insert_batch_ex(ufomap_map* m, ufomap_comm* c, const double senso
                                double max_range, unsigned depth, int discrete, int simple_ray_casting, unsigned early_stopping)
 {
 	if (!m || !c || !sensor_origin) return fail(UFOMAP_ERR_INVALID, "null argument");
-	if (d_rgb && !discrete && n)
+	// (decided from the map's configuration and the call's mode, the same on every rank by contract -- never from this rank's cloud:
+	// a rank that returned here while a rank with an empty cloud entered the all-gather would leave that one waiting, ADVICE r5.
+	// A coloured cloud into a plain map is integrated without its colours, as ufomap_map_insert_batch always did.)
+	if (m->g.color && !discrete)
 		return fail(UFOMAP_ERR_UNSUPPORTED, "OccupancyMapColor::insertPointCloud<PointCloudColor> does not compile in the reference (SURVEY.md 4)");
+	if (!m->g.color) d_rgb = nullptr;
 	if (m->g.color && !d_rgb && n) return fail(UFOMAP_ERR_INVALID, "a colour map needs the points' colours");
 	if (0 != depth) return fail(UFOMAP_ERR_UNSUPPORTED, "insert_batch: insert depth 0 only");
 	if (c->device != m->device) return fail(UFOMAP_ERR_INVALID, "the communicator was created on another device than the map");

@@ -397,7 +397,7 @@ struct ufomap_map {
 	int opt_dda_mode = -1;
 	int opt_dda_seg = 1;  // 0 = force the lane-per-ray kernel
 	int opt_dda_block = 0, opt_dda_lanes = 0;  // 0 = automatic
-	int opt_cast_fused = 1;  // the steady-state ray kernel with head loop, set-up and cuts fused per lane (k_fcast2); 0: k_fcast
+	int opt_cast_fused = 2;  // the steady-state ray kernel: 2 = k_fcast3 (round 6: rays packed before set-up, cuts by estimate + check), 1 = k_fcast2, 0 = k_fcast
 	int opt_cast2_k = 64;    // ... its cells per segment (a cut costs ~1.5 us of a lane's chain: measured 32 -> 44.0, 48 -> 43.5, 64 -> 41.4, 96 -> 43.0 us per pipelined scan)
 	int opt_cast = 1, opt_cast_wgs = 0, opt_cast_k = 32;  // fused ray kernel: on/off, workgroups (0 = 256), steps per segment
 	int opt_bits = 1;     // 0 = never use the bit-per-cell grid / k_walk
@@ -3716,7 +3716,7 @@ int ufomap_map_set_option(ufomap_map* m, const char* key, long long value)
 	} else if (0 == strcmp(key, "cast2_k")) {
 		m->opt_cast2_k = (int)std::max<long long>(8, std::min<long long>(1024, value));
 	} else if (0 == strcmp(key, "cast_fused")) {
-		m->opt_cast_fused = value ? 1 : 0;
+		m->opt_cast_fused = (int)std::max<long long>(0, std::min<long long>(2, value));
 	} else if (0 == strcmp(key, "fmerge_rows")) {
 		m->opt_fmerge_rows = (int)value;
 	} else if (0 == strcmp(key, "wait_flush_first")) {
