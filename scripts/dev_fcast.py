@@ -7,6 +7,7 @@ clouds = [scans.lidar64(origin=scans.lidar_pose(s), seed=100 + s) for s in range
 d = [torch.from_numpy(c[1]).cuda() for c in clouds]
 n = clouds[0][1].shape[0]
 m = OccupancyMap(0.16)
+m.set_option("ctl_dbg", 1)
 for kv in sys.argv[1:]:
     k, v = kv.split("=")
     m.set_option(k, int(v))

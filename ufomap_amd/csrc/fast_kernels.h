@@ -1740,31 +1740,98 @@ struct TileRec {
 };
 __device__ inline u32 flagsOf(const MapGeom& g, float v) { return (isFreeV(g, v) ? 1u : 0u) | (isUnknownV(g, v) ? 2u : 0u); }
 // reductions over the 8 lanes that differ in the three lane-index bits starting at bit `sh` (0: a level-2 group, 3: across groups)
-__device__ inline float grpMax(float v, int sh)
+// Round 6: a cross-lane move by __shfl_xor is a ds_bpermute -- an LDS-unit operation, ~120 clocks of latency each, and a reduction is
+// three of them one behind the other: the level loops of k_ftail spent their time there (a level through REGISTERS measured no faster
+// than a level through LDS: 1 900 clocks). Partners inside a row of 16 lanes are reached by DPP instead -- a VALU operand modifier, a
+// few clocks: xor 1 / xor 2 = quad_perm, "the other quad of my eight" = row_half_mirror (lane i <-> 7 - i: any pairing that joins the
+// two quads serves a reduction whose quads are already reduced), xor 8 = row_ror:8. Only the steps across rows (xor 16, xor 32) stay
+// shuffles. Every lane of the wave must be active (all callers: uniform control flow).
+template <int CTRL>
+__device__ __forceinline__ u32 dppU(u32 v)
 {
-	for (int o = 1; o < 8; o <<= 1) v = fmaxf(v, __shfl_xor(v, o << sh));
-	return v;
+	return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
 }
-__device__ inline u32 grpOr(u32 v, int sh)
+template <int CTRL>
+__device__ __forceinline__ float dppF(float v)
 {
-	for (int o = 1; o < 8; o <<= 1) v |= __shfl_xor(v, o << sh);
-	return v;
+	return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
 }
-__device__ inline u32 grpMaxU(u32 v, int sh)
+template <int CTRL>
+__device__ __forceinline__ double dppD(double v)
 {
-	for (int o = 1; o < 8; o <<= 1) v = max(v, (u32)__shfl_xor(v, o << sh));
-	return v;
+	const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+	const u32 lo = dppU<CTRL>((u32)b), hi = dppU<CTRL>((u32)(b >> 32));
+	return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
-__device__ inline bool grpAllEq(float v, int sh, u32 lane)
+#define UFO_DPP_X1 0xB1   // quad_perm [1, 0, 3, 2]
+#define UFO_DPP_X2 0x4E   // quad_perm [2, 3, 0, 1]
+#define UFO_DPP_HM 0x141  // row_half_mirror
+#define UFO_DPP_R8 0x128  // row_ror:8
+__device__ __forceinline__ float grpMax(float v, int sh)
 {
-	// value of the group's first lane, compared by every lane, AND-reduced
-	const float first = __shfl(v, (int)(sh ? (lane & 7u) : (lane & ~7u)));
-	return 0 == grpOr((v == first) ? 0u : 1u, sh);
+	if (0 == sh) {
+		v = fmaxf(v, dppF<UFO_DPP_X1>(v));
+		v = fmaxf(v, dppF<UFO_DPP_X2>(v));
+		return fmaxf(v, dppF<UFO_DPP_HM>(v));
+	}
+	v = fmaxf(v, dppF<UFO_DPP_R8>(v));
+	v = fmaxf(v, __shfl_xor(v, 16));
+	return fmaxf(v, __shfl_xor(v, 32));
 }
-__device__ inline bool grpAllEqU(u32 v, int sh, u32 lane)
+__device__ __forceinline__ float grpMin(float v, int sh)
 {
-	const u32 first = (u32)__shfl((int)v, (int)(sh ? (lane & 7u) : (lane & ~7u)));
-	return 0 == grpOr((v == first) ? 0u : 1u, sh);
+	if (0 == sh) {
+		v = fminf(v, dppF<UFO_DPP_X1>(v));
+		v = fminf(v, dppF<UFO_DPP_X2>(v));
+		return fminf(v, dppF<UFO_DPP_HM>(v));
+	}
+	v = fminf(v, dppF<UFO_DPP_R8>(v));
+	v = fminf(v, __shfl_xor(v, 16));
+	return fminf(v, __shfl_xor(v, 32));
+}
+__device__ __forceinline__ u32 grpOr(u32 v, int sh)
+{
+	if (0 == sh) {
+		v |= dppU<UFO_DPP_X1>(v);
+		v |= dppU<UFO_DPP_X2>(v);
+		return v | dppU<UFO_DPP_HM>(v);
+	}
+	v |= dppU<UFO_DPP_R8>(v);
+	v |= (u32)__shfl_xor((int)v, 16);
+	return v | (u32)__shfl_xor((int)v, 32);
+}
+__device__ __forceinline__ u32 grpMaxU(u32 v, int sh)
+{
+	if (0 == sh) {
+		v = max(v, dppU<UFO_DPP_X1>(v));
+		v = max(v, dppU<UFO_DPP_X2>(v));
+		return max(v, dppU<UFO_DPP_HM>(v));
+	}
+	v = max(v, dppU<UFO_DPP_R8>(v));
+	v = max(v, (u32)__shfl_xor((int)v, 16));
+	return max(v, (u32)__shfl_xor((int)v, 32));
+}
+__device__ __forceinline__ u32 grpMinU(u32 v, int sh)
+{
+	if (0 == sh) {
+		v = min(v, dppU<UFO_DPP_X1>(v));
+		v = min(v, dppU<UFO_DPP_X2>(v));
+		return min(v, dppU<UFO_DPP_HM>(v));
+	}
+	v = min(v, dppU<UFO_DPP_R8>(v));
+	v = min(v, (u32)__shfl_xor((int)v, 16));
+	return min(v, (u32)__shfl_xor((int)v, 32));
+}
+// all eight equal: largest == smallest (log-odds are never NaN; -0 == +0 either way)
+__device__ __forceinline__ bool grpAllEq(float v, int sh, u32 lane)
+{
+	(void)lane;
+	return grpMax(v, sh) == grpMin(v, sh);
+}
+__device__ __forceinline__ bool grpAllEqU(u32 v, int sh, u32 lane)
+{
+	(void)lane;
+	return grpMaxU(v, sh) == grpMinU(v, sh);
 }
 // Colour summary of a node (updateNode of a colour map, OMC.cpp:115-140 = blockSummary, map_kernels.h): per channel the
 // root mean square of the children that have a colour. Sums of at most eight squares of bytes: exact in any order.
@@ -1791,6 +1858,13 @@ __device__ inline u32 grpRgb(u32 c, int sh)
 	double rr = 0, gg = 0, bb = 0;
 	u32 cnt = 0;
 	rgbSq(c, rr, gg, bb, cnt);
+	if (0 == sh) {
+		// (sums of at most eight squares of bytes: exact in any order)
+		rr += dppD<UFO_DPP_X1>(rr); gg += dppD<UFO_DPP_X1>(gg); bb += dppD<UFO_DPP_X1>(bb); cnt += dppU<UFO_DPP_X1>(cnt);
+		rr += dppD<UFO_DPP_X2>(rr); gg += dppD<UFO_DPP_X2>(gg); bb += dppD<UFO_DPP_X2>(bb); cnt += dppU<UFO_DPP_X2>(cnt);
+		rr += dppD<UFO_DPP_HM>(rr); gg += dppD<UFO_DPP_HM>(gg); bb += dppD<UFO_DPP_HM>(bb); cnt += dppU<UFO_DPP_HM>(cnt);
+		return rgbRms(rr, gg, bb, cnt);
+	}
 	for (int o = 1; o < 8; o <<= 1) {
 		rr += __shfl_xor(rr, o << sh);
 		gg += __shfl_xor(gg, o << sh);
@@ -2672,7 +2746,8 @@ static_assert(UFO_FTAIL_THREADS == UFO_UPPER_MAX, "k_ftail: one thread per cell 
 template <bool COLOR>
 __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g, FastGeo fg, Pipe* __restrict__ p, unsigned long long f,
                                                              const TileRec* __restrict__ recs, u32 scan_id, const u32* __restrict__ prev_stat,
-                                                             const ScanCtl* ctl_init, u32* __restrict__ up_bits, u32 nwords3, u32* __restrict__ up_cnt = nullptr)
+                                                             const ScanCtl* ctl_init, u32* __restrict__ up_bits, u32 nwords3, u32* __restrict__ up_cnt = nullptr,
+                                                             u32* __restrict__ up_guess = nullptr, u32 report_dbg = 1u)
 {
 	// (fg.tl = 3: the tiles are k_tile's, their activity bitmap the union of the scans' tile bitmaps. fg.tl = 4, ray grids
 	// beyond LDS: the "tiles" are the level-4 blocks k_up has evaluated, fg describes THEIR grid, up_bits is their activity
@@ -2690,15 +2765,11 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 	__shared__ u32 tbits[UFO_FAST_MAX_TILES / 32], ubits[UFO_UPPER_MAX / 32], uprefix[UFO_UPPER_MAX / 32 + 1];
 	__shared__ u64 nk[UFO_UPPER_MAX];
 	__shared__ unsigned long long top64[UFO_UPPER_MAX];  // (1 + last scan of the batch that touched the subtree) << 40 | (1 + child index of the highest child it touched) << 32 | who that is (tile or node)
-	__shared__ u32 nslot[UFO_UPPER_MAX], npar[UFO_UPPER_MAX], nflags[UFO_UPPER_MAX], out_bits[UFO_UPPER_MAX];
+	__shared__ u32 nslot[UFO_UPPER_MAX], npar[UFO_UPPER_MAX], nflags[UFO_UPPER_MAX], out_bits[UFO_UPPER_MAX], chld[UFO_UPPER_MAX];
 	__shared__ float nocc[UFO_UPPER_MAX][8], out_pre[UFO_UPPER_MAX];
 	__shared__ u32 nrgb[COLOR ? UFO_UPPER_MAX : 1u][8];  // colour maps: the children's colours beside nocc (see k_tile)
 	__shared__ uint8_t dirty[UFO_UPPER_MAX], ncreated[UFO_UPPER_MAX];
-	__shared__ u32 lstart[26], lvl_dirty[26], created_total;
-	// one copy of the activity bitmap per wavefront while it is being filled: LDS atomics of one instruction that hit the same
-	// word are executed one lane after the other, and here nearly all lanes do (neighbouring cells, common ancestors) --
-	// with a shared copy the 16 waves would queue behind one another on top (measured: 5.5 us for 12 levels)
-	__shared__ u32 wbits[UFO_FTAIL_THREADS / 64][UFO_UPPER_MAX / 32];
+	__shared__ u32 lstart[26], lvl_dirty[26], created_total, sh_used, sh_ng, sh_nu;
 	const u32 nwords = (fg.ntiles + 31u) / 32u;
 	{
 		// (one round of loads: the error words and the scans' tile bitmaps, whose union is the walk's)
@@ -2734,7 +2805,7 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 	if (0 == threadIdx.x) ctl->dbg[10] = wall_clock64();  // (diagnostics: ufomap_map_debug)
 	const u32 L = g.L;
 	const u32 lane = threadIdx.x & 63u;
-	for (u32 j = threadIdx.x; j < (UFO_FTAIL_THREADS / 64) * (UFO_UPPER_MAX / 32); j += blockDim.x) (&wbits[0][0])[j] = 0;
+	if (threadIdx.x < UFO_UPPER_MAX / 32) ubits[threadIdx.x] = 0;
 	if (threadIdx.x < 26u) lvl_dirty[threadIdx.x] = 0;
 	if (0 == threadIdx.x) created_total = 0;
 	__syncthreads();
@@ -2744,8 +2815,6 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 	const u32 n4all = u4.n[0] * u4.n[1] * u4.n[2];  // cells of level 4 = first cell of level 5
 	constexpr u32 MAXT = UFO_FAST_MAX_TILES / UFO_FTAIL_THREADS;  // tiles per thread: tile = k * blockDim + thread
 	u32 cell4[MAXT];  // the level-4 parent's cell of the thread's tiles (NONE: tile not active)
-	// (two phases, no atomic whose result anybody waits for: a walk "up until somebody else has been here" is a chain of
-	// dependent LDS round trips per level, and at the start nobody has been anywhere)
 #pragma unroll
 	for (u32 k = 0; k < MAXT; ++k) {
 		const u32 tile = k * blockDim.x + threadIdx.x;
@@ -2759,41 +2828,95 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 		const u32 cell = upperCellAt(u4, 0u, pc);
 		if (cell >= UFO_UPPER_MAX) continue;
 		cell4[k] = cell;
-		__hip_atomic_fetch_or(&wbits[threadIdx.x >> 6][cell >> 5], 1u << (cell & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+	}
+	// first cell of every level (off[l]; off[L+1] = number of cells), by every thread -- a uniform loop of scalar arithmetic; the level
+	// whose range holds this thread's cell is the last one that starts at or below it
+	u32 my_l = tl + 1u, my_off = 0, ncells = 0;
+	{
+		u32 off = 0;
+		for (u32 k = tl + 1u; k <= L; ++k) {
+			const UpperLevel uk = upperLevel(fg, k);
+			if (threadIdx.x >= off) {
+				my_l = k;
+				my_off = off;
+			}
+			off += uk.n[0] * uk.n[1] * uk.n[2];
+		}
+		ncells = min(off, UFO_UPPER_MAX);
+	}
+	// Round 6: no walk "up from every tile" any more (a chain of LDS atomics per level, on sixteen copies of the bitmap so that the waves
+	// would not queue on its words: 4.5 us). A cell's activity is read off the level below directly: a level-4 cell looks at its eight
+	// tiles' bits, one thread each; then every cell of the levels above -- all levels at once -- looks at ITS BOX of the level-4 bitmap,
+	// row by row (a cell of level l covers 2^(l-4) level-4 cells per axis; the grids are small: the box is a few rows of a few bits).
+	// One atomic per 32 lanes (the lanes of a word, by ballot), three barriers.
+	{
+		const u32 cell = threadIdx.x;
+		bool act = false;
+		if (cell < min(n4all, UFO_UPPER_MAX)) {
+			const u32 x = cell % u4.n[0], r = cell / u4.n[0];
+			const i32 X = u4.lo[0] + (i32)x, Y = u4.lo[1] + (i32)(r % u4.n[1]), Z = u4.lo[2] + (i32)(r / u4.n[1]);
+			const i32 lim = (i32)(1u << (L - tl));
+#pragma unroll
+			for (int d = 0; d < 8; ++d) {
+				const i32 cx = 2 * X + (d & 1), cy = 2 * Y + ((d >> 1) & 1), cz = 2 * Z + (d >> 2);
+				const i32 tx = cx - fg.tbase[0], ty = cy - fg.tbase[1], tz = cz - fg.tbase[2];
+				const bool in = tx >= 0 && ty >= 0 && tz >= 0 && (u32)tx < fg.nt[0] && (u32)ty < fg.nt[1] && (u32)tz < fg.nt[2] && cx >= 0 && cy >= 0 && cz >= 0 &&
+				                cx < lim && cy < lim && cz < lim;
+				const u32 tile = in ? (u32)tx + fg.nt[0] * ((u32)ty + fg.nt[1] * (u32)tz) : 0u;
+				act = act || (in && ((tbits[tile >> 5] >> (tile & 31u)) & 1u));
+			}
+		}
+		const u64 bm = __ballot(act);
+		if (0 == lane && (u32)bm) atomicOr(&ubits[threadIdx.x >> 5], (u32)bm);
+		if (32u == lane && (u32)(bm >> 32)) atomicOr(&ubits[threadIdx.x >> 5], (u32)(bm >> 32));
 	}
 	__syncthreads();
 	if (0 == threadIdx.x) ctl->dbg[21] = wall_clock64();
 	{
-		// every active level-4 cell marks its ancestors, level 5 .. L
 		const u32 cell = threadIdx.x;
-		const u32 n4 = min(n4all, UFO_UPPER_MAX);
-		u32 seen = 0;
-		if (cell < n4)
-			for (u32 w = 0; w < UFO_FTAIL_THREADS / 64; ++w) seen |= wbits[w][cell >> 5];
-		if ((seen >> (cell & 31u)) & 1u) {
-			const u32 x = cell % u4.n[0], r = cell / u4.n[0];
-			i32 c[3] = {u4.lo[0] + (i32)x, u4.lo[1] + (i32)(r % u4.n[1]), u4.lo[2] + (i32)(r / u4.n[1])};
-			u32 off = n4all;
-			for (u32 l = tl + 2u; l <= L; ++l) {  // (uniform: the level's geometry is scalar arithmetic)
-				const UpperLevel ul = upperLevel(fg, l);
-				c[0] >>= 1;
-				c[1] >>= 1;
-				c[2] >>= 1;
-				const u32 up = upperCellAt(ul, off, c);
-				if (up < UFO_UPPER_MAX) __hip_atomic_fetch_or(&wbits[threadIdx.x >> 6][up >> 5], 1u << (up & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-				off += ul.n[0] * ul.n[1] * ul.n[2];
+		bool act = false;
+		if (cell >= n4all && cell < ncells) {
+			const u32 lv = my_l;
+			const UpperLevel ul = upperLevel(fg, lv);
+			const u32 c = cell - my_off;
+			const u32 x = c % ul.n[0], r = c / ul.n[0];
+			const i32 X = ul.lo[0] + (i32)x, Y = ul.lo[1] + (i32)(r % ul.n[1]), Z = ul.lo[2] + (i32)(r / ul.n[1]);
+			const u32 sft = min(lv - (tl + 1u), 24u);
+			// the cell's box of level-4 cells, clipped to the level-4 grid
+			const long long bx0 = (long long)X << sft, by0 = (long long)Y << sft, bz0 = (long long)Z << sft, ext = (1ll << sft) - 1;
+			const i32 x0 = (i32)max(bx0, (long long)u4.lo[0]), x1 = (i32)min(bx0 + ext, (long long)u4.lo[0] + (long long)u4.n[0] - 1);
+			const i32 y0 = (i32)max(by0, (long long)u4.lo[1]), y1 = (i32)min(by0 + ext, (long long)u4.lo[1] + (long long)u4.n[1] - 1);
+			const i32 z0 = (i32)max(bz0, (long long)u4.lo[2]), z1 = (i32)min(bz0 + ext, (long long)u4.lo[2] + (long long)u4.n[2] - 1);
+			if (x0 <= x1) {
+				const u32 len = (u32)(x1 - x0 + 1);
+				for (i32 z = z0; z <= z1 && !act; ++z)
+					for (i32 y = y0; y <= y1 && !act; ++y) {
+						u32 start = (u32)(x0 - u4.lo[0]) + u4.n[0] * ((u32)(y - u4.lo[1]) + u4.n[1] * (u32)(z - u4.lo[2]));
+						u32 left = len;
+						while (left && start < UFO_UPPER_MAX) {  // (the row's bits, a word at a time)
+							const u32 b0 = start & 31u, take = min(left, 32u - b0);
+							const u32 mask = (take >= 32u ? 0xFFFFFFFFu : ((1u << take) - 1u)) << b0;
+							if (ubits[start >> 5] & mask) {
+								act = true;
+								break;
+							}
+							start += take;
+							left -= take;
+						}
+					}
 			}
 		}
+		__syncthreads();  // (the level-4 words have been read: the words of the levels above may share them)
+		const u64 bm = __ballot(act);
+		if (0 == lane && (u32)bm) atomicOr(&ubits[threadIdx.x >> 5], (u32)bm);
+		if (32u == lane && (u32)(bm >> 32)) atomicOr(&ubits[threadIdx.x >> 5], (u32)(bm >> 32));
 	}
 	__syncthreads();
 	if (0 == threadIdx.x) ctl->dbg[22] = wall_clock64();
 	if (threadIdx.x < 64u) {
-		// the waves' copies become one bitmap; prefix popcount over its 32 words
+		// prefix popcount over the bitmap's 32 words
 		u32 word = 0;
-		if (lane < UFO_UPPER_MAX / 32) {
-			for (u32 w = 0; w < UFO_FTAIL_THREADS / 64; ++w) word |= wbits[w][lane];
-			ubits[lane] = word;
-		}
+		if (lane < UFO_UPPER_MAX / 32) word = ubits[lane];
 		const u32 c = (u32)__popc(word);
 		u32 incl = c;
 		for (int o = 1; o < 64; o <<= 1) {
@@ -2810,24 +2933,17 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 		if (!((w >> b) & 1u)) return NONE;
 		return uprefix[cell >> 5] + (u32)__popc(w & ((1u << b) - 1u));
 	};
-	// first cell of every level (off[l]; off[L+1] = number of cells), by every thread: a uniform loop of scalar arithmetic
-	u32 my_l = tl + 1u, my_off = 0, ncells = 0;
+	// nodes of level l are [lstart[l], lstart[l+1]): the cells below off[l] that are active
 	{
 		u32 off = 0;
 		for (u32 k = tl + 1u; k <= L; ++k) {
 			const UpperLevel uk = upperLevel(fg, k);
-			if (threadIdx.x >= off) {  // (the level whose range holds this thread's cell is the last one that starts at or below it)
-				my_l = k;
-				my_off = off;
-			}
 			if (threadIdx.x == k) {
-				// nodes of level l are [lstart[l], lstart[l+1]): the cells below off[l] that are active
 				const u32 c0 = min(off, UFO_UPPER_MAX);
 				lstart[k] = uprefix[c0 >> 5] + ((c0 & 31u) ? (u32)__popc(ubits[c0 >> 5] & ((1u << (c0 & 31u)) - 1u)) : 0u);
 			}
 			off += uk.n[0] * uk.n[1] * uk.n[2];
 		}
-		ncells = min(off, UFO_UPPER_MAX);
 		if (threadIdx.x == L + 1u) lstart[L + 1u] = uprefix[ncells >> 5] + ((ncells & 31u) ? (u32)__popc(ubits[ncells >> 5] & ((1u << (ncells & 31u)) - 1u)) : 0u);
 	}
 	const u32 max_probe = (t.mask >> 1) + 1;
@@ -2850,32 +2966,66 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 				par = idOf(upperCellAt(upperLevel(fg, l + 1u), my_off + ul.n[0] * ul.n[1] * ul.n[2], pc));
 			}
 			npar[id] = par;
-			bool cr;
-			const u32 s = tableEnsure(t, lk, scan_id, max_probe, &cr, &n_created);
-			nslot[id] = s;
-			ncreated[id] = cr ? 1 : 0;
+			if (par != NONE) chld[par] = id;  // (a child of the block: THE child where a block has one -- the runs of the level loop)
 			top64[id] = 0;
 			out_bits[id] = 0;
 			out_pre[id] = 0.f;
 			dirty[id] = 0;
-			u32 fl = 0;
-			if (s == NONE) {
-				atomicOr(&ctl->err, ERR_TABLE_FULL);
-			} else if (!cr) {
-				const float4* po = reinterpret_cast<const float4*>(t.occ(s));
+			// Where the cell's block was when a walk last looked (a guess: the same ray grid, the same table -- the steady state): its
+			// key, values and flags are asked for together, and the key that arrives says whether the guess was right; the hashed
+			// find-or-create (two to three dependent round trips more) is for the cells whose guess fails, a block that has to be
+			// created, or one that was collapsed (DEAD: revived like a new one).
+			const u32 gs = up_guess ? up_guess[cell] : NONE;
+			bool cr = false, hit = false;
+			u32 s = NONE, fl = 0;
+			if (gs < t.capU) {
+				const u64 kg = t.key(gs);
+				const float4* po = reinterpret_cast<const float4*>(t.occ(gs));
 				const float4 a = po[0], b = po[1];
-				float4* lo4 = reinterpret_cast<float4*>(nocc[id]);
-				lo4[0] = a;
-				lo4[1] = b;
+				uint4 ca = make_uint4(0, 0, 0, 0), cb = ca;
 				if (COLOR) {
-					const uint4* pc = reinterpret_cast<const uint4*>(t.rgb + 8 * (size_t)s);
-					const uint4 ca = pc[0], cb = pc[1];
-					uint4* lc4 = reinterpret_cast<uint4*>(nrgb[id]);
-					lc4[0] = ca;
-					lc4[1] = cb;
+					const uint4* pc = reinterpret_cast<const uint4*>(t.rgb + 8 * (size_t)gs);
+					ca = pc[0];
+					cb = pc[1];
 				}
-				fl = t.flags(s) & ~F_DIRTY;
+				const u32 fg_ = t.flags(gs);
+				if (kg == lk && !(fg_ & F_DEAD)) {
+					hit = true;
+					s = gs;
+					float4* lo4 = reinterpret_cast<float4*>(nocc[id]);
+					lo4[0] = a;
+					lo4[1] = b;
+					if (COLOR) {
+						uint4* lc4 = reinterpret_cast<uint4*>(nrgb[id]);
+						lc4[0] = ca;
+						lc4[1] = cb;
+					}
+					fl = fg_ & ~F_DIRTY;
+				}
 			}
+			if (!hit) {
+				s = tableEnsure(t, lk, scan_id, max_probe, &cr, &n_created);
+				if (s == NONE) {
+					atomicOr(&ctl->err, ERR_TABLE_FULL);
+				} else if (!cr) {
+					const float4* po = reinterpret_cast<const float4*>(t.occ(s));
+					const float4 a = po[0], b = po[1];
+					float4* lo4 = reinterpret_cast<float4*>(nocc[id]);
+					lo4[0] = a;
+					lo4[1] = b;
+					if (COLOR) {
+						const uint4* pc = reinterpret_cast<const uint4*>(t.rgb + 8 * (size_t)s);
+						const uint4 ca = pc[0], cb = pc[1];
+						uint4* lc4 = reinterpret_cast<uint4*>(nrgb[id]);
+						lc4[0] = ca;
+						lc4[1] = cb;
+					}
+					fl = t.flags(s) & ~F_DIRTY;
+				}
+				if (up_guess && s != NONE) up_guess[cell] = s;
+			}
+			nslot[id] = s;
+			ncreated[id] = cr ? 1 : 0;
 			nflags[id] = fl;
 		}
 	}
@@ -2973,6 +3123,24 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 	}
 	__syncthreads();
 	if (0 == threadIdx.x) ctl->dbg[15] = wall_clock64();  // (diagnostics: ufomap_map_debug)
+	// The table's fill after this walk -- nothing is created from here on -- is asked for NOW, beside the level loop, not behind it
+	// (an atomic's round trip and two rows of sharded counters: 2 us of the 7.7 that used to sit behind the kernel's last stamp).
+	if (0 == threadIdx.x) {
+		u32 used = __hip_atomic_load(&t.root->used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (created_total) {
+			used = atomicAdd(&t.root->used, created_total) + created_total;
+			atomicAdd(&ctl->ph[0].n_new, created_total);
+		}
+		sh_used = used;
+	}
+	if (threadIdx.x >= 64u && threadIdx.x < 128u) {
+		u32 ng, nu;
+		tableCounts(t, threadIdx.x - 64u, &ng, &nu);
+		if (64u == threadIdx.x) {
+			sh_ng = ng;
+			sh_nu = nu;
+		}
+	}
 	// who carries the last update beneath a level-4 block: its highest touched tile (the record is L2-warm)
 	for (u32 i = lstart[tl + 1u] + threadIdx.x; i < lstart[tl + 2u]; i += blockDim.x) {
 		const unsigned long long tt = top64[i];
@@ -3072,13 +3240,177 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 	}
 	if (0 == threadIdx.x) ctl->dbg[17] = wall_clock64();  // (diagnostics: ufomap_map_debug)
 	if (threadIdx.x < 64u) {
-		for (; l <= L; ++l) {
-			const u32 lo = lstart[l], hi = lstart[l + 1];
-			const u32 i = lo + (lane >> 3);
-			const bool ev = step8(i, i < hi, l);
-			if (0 == __ballot(ev)) break;  // nothing was re-evaluated on this level: nothing above can change
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+		bool ended = false;
+		u32 dg_run = 0, dg_step = 0;
+		unsigned long long dg_runc = 0, dg_stepc = 0;
+		while (l <= L && !ended) {
+			{
+				const unsigned long long dg0 = clock64();
+				++dg_step;
+				const u32 lo = lstart[l], hi = lstart[l + 1];
+				const u32 i = lo + (lane >> 3);
+				const bool ev = step8(i, i < hi, l);
+				if (0 == __ballot(ev)) {  // nothing was re-evaluated on this level: nothing above can change
+					ended = true;
+					break;
+				}
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+				++l;
+				dg_stepc += clock64() - dg0;
+			}
+			// ---- 4b. A RUN of levels with as many blocks as the level below: every block has ONE touched child, the block beneath it.
+			// A map is centred on the origin and a sensor near it looks into several octants: from the scan's extent up to the root's
+			// children every level holds the same two or four blocks -- about ten levels of a 16-level map, each a chain of dependent LDS
+			// round trips in step8 (the block's state, its child's record, the parent's slot: ~0.7 us, whoever does them). Here the
+			// group of eight lanes that takes a block keeps going upwards: what the block hands to its parent (summary, flags, "reached",
+			// the summary before its last update) stays in REGISTERS -- moved to the parent's group by shuffles -- and the parent's own
+			// state was asked for from LDS a level ahead: a level costs its arithmetic. Same rules as step8, restated for one child: the
+			// child's hand-over is applied to the parent's copy (value, flags, "is inner" bit when the child collapsed; the parent is
+			// re-evaluated iff that changed something or the child's last update reached it and changed it), then the block's own updateNode.
+			if (l > L) break;
+			const u32 nrun = lstart[l + 1] - lstart[l];
+			if (nrun != lstart[l] - lstart[l - 1u] || nrun > 8u) continue;
+			const u32 q = lane >> 3, sub = lane & 7u;
+			const bool valid = q < nrun;
+			// (the levels' first nodes, a level per lane: read across lanes where the loop needs them, not from LDS)
+			const u32 ls_reg = lstart[min(lane, 25u)];
+			auto lsAt = [&](u32 lv) -> u32 { return (u32)__builtin_amdgcn_readlane((int)ls_reg, (int)__builtin_amdgcn_readfirstlane((int)lv)); };
+			u32 lb = l;  // the run's last level
+			while (lb < L && lsAt(lb + 2u) - lsAt(lb + 1u) == nrun) ++lb;
+			struct Lvl {
+				u32 i, f, ci, ch, p, cc;
+				float v;
+				bool root;
+			};
+			auto loadLvl = [&](u32 lv) -> Lvl {
+				Lvl x;
+				x.i = lsAt(lv) + (valid ? q : 0u);
+				x.v = nocc[x.i][sub];
+				x.cc = COLOR ? nrgb[COLOR ? x.i : 0u][sub] : 0u;
+				x.f = nflags[x.i];
+				const u64 lk = nk[x.i];
+				x.ci = (u32)(lk & 7);
+				x.root = 1 == lk;
+				x.ch = chld[x.i];
+				x.p = npar[x.i];
+				return x;
+			};
+			const unsigned long long dg1 = clock64();
+			Lvl cur = loadLvl(l);
+			// what step8 of the level below left for the run's first blocks
+			bool ev = valid && 0 != dirty[cur.i];
+			const unsigned long long tt0 = top64[cur.i];
+			unsigned long long tt_hi = tt0 & 0xFFFFFF0000000000ull;
+			u32 tc = ((u32)(tt0 >> 32) & 255u) - 1u;
+			const u32 who = min((u32)tt0, UFO_UPPER_MAX - 1u);
+			u32 lub = out_bits[who];
+			float luo = out_pre[who];
+			for (;;) {  // (uniform)
+				++dg_run;
+				const bool more = l < lb;  // the level above belongs to the run as well
+				Lvl nxt = cur;
+				if (more) nxt = loadLvl(l + 1u);  // (asked for now, looked at after this level's arithmetic)
+				if (0 == __ballot(ev)) {
+					ended = true;
+					break;
+				}
+				// updateNode of the group's block (OMB:1195-1224), as in step8
+				const bool reached = ev && 0 != (lub & 4u);
+				const float m = grpMax(cur.v, 0);
+				const bool eq = grpAllEq(cur.v, 0, lane) && (!COLOR || grpAllEqU(cur.cc, 0, lane));
+				const u32 rgb = COLOR ? grpRgb(cur.cc, 0) : 0u;
+				const float pm = grpMax((reached && sub == tc) ? luo : cur.v, 0);
+				const u32 fl = ((cur.f & F_CFREE) ? 1u : 0u) | ((cur.f & F_CUNK) ? 2u : 0u);
+				u32 pfl = fl;
+				if (reached) {
+					const u32 fsub = (cur.f & ~((1u << tc) | (1u << (8 + tc)))) | ((lub & 1u) << tc) | (((lub >> 1) & 1u) << (8 + tc));
+					pfl = ((fsub & F_CFREE) ? 1u : 0u) | ((fsub & F_CUNK) ? 2u : 0u);
+				}
+				const bool dead = ev && reached && eq && 0 == (cur.f & F_INNER);
+				const bool reach_out = reached && !(pm == m && pfl == fl);
+				if (dead) cur.f |= F_DEAD;
+				if (ev && cur.root && 0 == sub) {
+					t.root->occ = m;
+					t.root->flags = fl;
+					if (COLOR) t.root->rgb = rgb;
+				}
+				// the block goes back to LDS (step 5 stores it to the table)
+				if (valid) {
+					nocc[cur.i][sub] = cur.v;
+					if (COLOR) nrgb[COLOR ? cur.i : 0u][sub] = cur.cc;
+					if (0 == sub) nflags[cur.i] = cur.f;
+				}
+				const u32 ob = ev ? ((reach_out ? 4u : 0u) | (pfl & 3u)) : 0u;
+				const float op = ev ? (reached ? pm : m) : 0.f;
+				if (!more) {
+					// the run's last level hands over through LDS, as step8 does: the level above merges chains (or there is none)
+					if (valid && 0 == sub) {
+						const u32 pp = cur.p, ci = cur.ci;
+						if (ev && !cur.root) {
+							if (dead) atomicAnd(&nflags[pp], ~(1u << (16 + ci)));
+							const u32 fp = nflags[pp];
+							const u32 old_fl = ((fp >> ci) & 1u) | (((fp >> (8 + ci)) & 1u) << 1);
+							const bool changed = nocc[pp][ci] != m || old_fl != fl || (COLOR && nrgb[COLOR ? pp : 0u][ci] != rgb);
+							nocc[pp][ci] = m;
+							if (COLOR) nrgb[COLOR ? pp : 0u][ci] = rgb;
+							if (old_fl != fl) {
+								const u32 setm = ((fl & 1u) << ci) | (((fl >> 1) & 1u) << (8 + ci));
+								const u32 clrm = ((1u << ci) | (1u << (8 + ci))) & ~setm;
+								if (setm) atomicOr(&nflags[pp], setm);
+								if (clrm) atomicAnd(&nflags[pp], ~clrm);
+							}
+							if (changed || reach_out) dirty[pp] = 1;
+						}
+						out_bits[cur.i] = ob;
+						out_pre[cur.i] = op;
+						if (pp != NONE) atomicMax(&top64[pp], tt_hi | ((unsigned long long)(ci + 1u) << 32) | cur.i);
+					}
+					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+					++l;
+					break;
+				}
+				// ... every other level through registers: the parent's group fetches what its child's group computed
+				const u32 cq = valid ? (nxt.ch - lsAt(l)) & 7u : 0u;  // the child's group (chld: filled beside step 2)
+				const int src = (int)(8u * cq);
+				const bool c_ev = 0 != __shfl(ev ? 1 : 0, src);
+				const float c_m = __shfl(m, src);
+				const u32 c_fl = (u32)__shfl((int)fl, src);
+				const u32 c_rgb = COLOR ? (u32)__shfl((int)rgb, src) : 0u;
+				const bool c_dead = 0 != __shfl(dead ? 1 : 0, src);
+				const bool c_ro = 0 != __shfl(reach_out ? 1 : 0, src);
+				const u32 c_ob = (u32)__shfl((int)ob, src);
+				const float c_op = __shfl(op, src);
+				const u32 c_ci = (u32)__shfl((int)cur.ci, src);
+				const u32 thi_lo = (u32)__shfl((int)(u32)(tt_hi >> 32), src);
+				tt_hi = (unsigned long long)thi_lo << 32;
+				cur = nxt;
+				ev = false;
+				if (valid && c_ev) {
+					const u32 old_fl = ((cur.f >> c_ci) & 1u) | (((cur.f >> (8 + c_ci)) & 1u) << 1);
+					bool changed = old_fl != c_fl;
+					if (sub == c_ci) {
+						changed = changed || cur.v != c_m || (COLOR && cur.cc != c_rgb);
+						cur.v = c_m;
+						if (COLOR) cur.cc = c_rgb;
+					}
+					changed = 0 != grpOr(changed ? 1u : 0u, 0);
+					cur.f = (cur.f & ~((1u << c_ci) | (1u << (8 + c_ci)))) | ((c_fl & 1u) << c_ci) | (((c_fl >> 1) & 1u) << (8 + c_ci));
+					if (c_dead) cur.f &= ~(1u << (16 + c_ci));
+					ev = changed || c_ro;
+				}
+				tc = c_ci;
+				lub = c_ob;
+				luo = c_op;
+				++l;
+			}
+			dg_runc += clock64() - dg1;
+		}
+		if (0 == threadIdx.x) {  // (diagnostics: levels by step8 / in runs, their clocks)
+			ctl->dbg[24] = dg_step | ((unsigned long long)dg_run << 32);
+			ctl->dbg[25] = dg_stepc;
+			ctl->dbg[26] = dg_runc;
 		}
 	}
 	__syncthreads();
@@ -3106,51 +3438,43 @@ __global__ __launch_bounds__(UFO_FTAIL_THREADS) void k_ftail(Table t, MapGeom g,
 	if (up_bits)
 		for (u32 j = threadIdx.x; j < nwords; j += blockDim.x) up_bits[j] = 0;
 	if (0 == threadIdx.x) {
-		u32 used = __hip_atomic_load(&t.root->used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		if (created_total) {
-			used = atomicAdd(&t.root->used, created_total) + created_total;
-			atomicAdd(&ctl->ph[0].n_new, created_total);
-		}
 		ctl->dbg[19] = wall_clock64();
 		ctl->dbg[20] = U | ((unsigned long long)l << 32);
-		ctl->used_now = used;  // the host's view of the table's fill
 		ctl->dbg[45] = B;      // (scans this walk applied: the host's statistics)
 		tsMark(p->ts, f, 6, wall_clock64());
-	}
-	if (threadIdx.x < 64u) {
-		u32 ng, nu;
-		tableCounts(t, threadIdx.x, &ng, &nu);
-		if (0 == threadIdx.x) {
-			ctl->used_g_now = ng;
-			ctl->used_u_now = nu;
-		}
 	}
 	// The finished control blocks go to the host's pinned copies from here (no read-back copy, no stream synchronisation on
 	// the host: it polls the word behind a block and reads), and the device copies return to the start state of a scan
 	// (no upload before their sets' next scans). A walk that stood back has left above: the host falls back to copies.
+	// What the host reads is the block up to the diagnostics (504 bytes; the clocks behind them only when somebody asked:
+	// option "ctl_dbg" -- every word is a write across PCIe that the kernel's last barrier waits for).
 	__syncthreads();
 	const u32 e = __hip_atomic_load(&ctl->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (raised during the walk: ERR_TABLE_FULL)
 	{
 		const u32* init = reinterpret_cast<const u32*>(ctl_init);
-		const u32 used = __hip_atomic_load(&ctl->used_now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		const u32 used_g = __hip_atomic_load(&ctl->used_g_now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		const u32 used_u = __hip_atomic_load(&ctl->used_u_now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		const u32 used = sh_used, used_g = sh_ng, used_u = sh_nu;
 		constexpr u32 W = sizeof(ScanCtl) / 4u, W_USED = offsetof(ScanCtl, used_now) / 4u, W_ERR = offsetof(ScanCtl, err) / 4u;
 		constexpr u32 W_USEDG = offsetof(ScanCtl, used_g_now) / 4u, W_USEDU = offsetof(ScanCtl, used_u_now) / 4u;
+		constexpr u32 W_CORE = offsetof(ScanCtl, dbg) / 4u, W_WALK = offsetof(ScanCtl, walk_scans) / 4u;
+		const u32 wrep = report_dbg ? W : W_CORE;
 		for (u32 k = threadIdx.x; k < B * W; k += blockDim.x) {
 			const u32 b = k / W, w = k % W;
 			u32* dev = reinterpret_cast<u32*>(UFO_DESC(b).ctl);
-			u32* host = reinterpret_cast<u32*>(UFO_DESC(b).host_result);
-			u32 x = __hip_atomic_load(&dev[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			if (W_USED == w) x = used;   // the table's fill after the walk: in every scan's block (the host reads whichever it joins)
-			if (W_USEDG == w) x = used_g;  // ... per region too (a scan that is not the walk's last would report 0 / 0 and the host
-			if (W_USEDU == w) x = used_u;  // would size the next update as if the table were empty: ADVICE r4)
-			if (W_ERR == w) x |= e;      // a failed walk has failed for all of its scans
-			host[w] = x;
-			if (0 == e) dev[w] = init[w];  // (an error raised in this very kernel stays for the host to read)
+			if (w < wrep) {
+				u32* host = reinterpret_cast<u32*>(UFO_DESC(b).host_result);
+				u32 x = __hip_atomic_load(&dev[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if (W_USED == w) x = used;   // the table's fill after the walk: in every scan's block (the host reads whichever it joins)
+				if (W_USEDG == w) x = used_g;  // ... per region too (a scan that is not the walk's last would report 0 / 0 and the host
+				if (W_USEDU == w) x = used_u;  // would size the next update as if the table were empty: ADVICE r4)
+				if (W_ERR == w) x |= e;      // a failed walk has failed for all of its scans
+				if (W_WALK == w) x = (b + 1u == B) ? B : 0u;
+				host[w] = x;
+			}
+			if (0 == e) dev[w] = w < W_CORE ? init[w] : 0u;  // (an error raised in this very kernel stays for the host to read)
 		}
 	}
 	__syncthreads();  // (every thread's stores to the pinned blocks have been acknowledged: the barrier waits for them)
+	if (report_dbg && threadIdx.x + 1u == B) UFO_DESC(threadIdx.x).host_result->dbg[23] = wall_clock64();  // (diagnostics: the report's duration)
 	if (threadIdx.x < B) {  // (the kernel's last actions; the walk enqueued behind this one looks at the status words)
 		const ScanDesc& d = UFO_DESC(threadIdx.x);
 		p->wstat[(sl.first + threadIdx.x) & (UFO_RING - 1u)] = e ? 1u : 0u;

@@ -496,6 +496,10 @@ int enqueueSlot(ufomap_map* m, int k)
 			HIP_TRY(m->b_tilerec.reserve(want));
 			HIP_TRY(hipMemsetAsync(m->b_tilerec.p, 0, m->b_tilerec.cap, m->stream));
 		}
+		if (!m->b_upguess.p) {
+			HIP_TRY(m->b_upguess.reserve(UFO_UPPER_MAX * sizeof(u32)));
+			HIP_TRY(hipMemsetAsync(m->b_upguess.p, 0xFF, m->b_upguess.cap, m->stream));
+		}
 		if (big_grid && !m->b_upbits.p) {
 			HIP_TRY(m->b_upbits.reserve(UFO_FAST_MAX_TILES / 8));
 			HIP_TRY(hipMemsetAsync(m->b_upbits.p, 0, m->b_upbits.cap, m->stream));
@@ -554,18 +558,18 @@ int enqueueSlot(ufomap_map* m, int k)
 		ProfScope ps(m, "k_ftail");
 		if (m->g.color)
 			hipLaunchKernelGGL(k_ftail<true>, dim3(1), dim3(UFO_FTAIL_THREADS), 0, m->cs, m->t, m->g, fu, pipe, (unsigned long long)f, recs_up, m->scan_id, prev_stat,
-			                   m->b_ctl_init.as<ScanCtl>(), up_bits, nwords3);
+			                   m->b_ctl_init.as<ScanCtl>(), up_bits, nwords3, (u32*)nullptr, m->b_upguess.as<u32>(), (u32)m->opt_ctl_dbg);
 		else
 			hipLaunchKernelGGL(k_ftail<false>, dim3(1), dim3(UFO_FTAIL_THREADS), 0, m->cs, m->t, m->g, fu, pipe, (unsigned long long)f, recs_up, m->scan_id, prev_stat,
-			                   m->b_ctl_init.as<ScanCtl>(), up_bits, nwords3);
+			                   m->b_ctl_init.as<ScanCtl>(), up_bits, nwords3, (u32*)nullptr, m->b_upguess.as<u32>(), (u32)m->opt_ctl_dbg);
 	} else {
 		ProfScope ps(m, "k_ftail");
 		if (m->g.color)
 			hipLaunchKernelGGL(k_ftail<true>, dim3(1), dim3(UFO_FTAIL_THREADS), 0, m->cs, m->t, m->g, fg, pipe, (unsigned long long)f, m->b_tilerec.as<TileRec>(),
-			                   m->scan_id, prev_stat, m->b_ctl_init.as<ScanCtl>(), (u32*)nullptr, nwords3);
+			                   m->scan_id, prev_stat, m->b_ctl_init.as<ScanCtl>(), (u32*)nullptr, nwords3, (u32*)nullptr, m->b_upguess.as<u32>(), (u32)m->opt_ctl_dbg);
 		else
 			hipLaunchKernelGGL(k_ftail<false>, dim3(1), dim3(UFO_FTAIL_THREADS), 0, m->cs, m->t, m->g, fg, pipe, (unsigned long long)f, m->b_tilerec.as<TileRec>(),
-			                   m->scan_id, prev_stat, m->b_ctl_init.as<ScanCtl>(), (u32*)nullptr, nwords3);
+			                   m->scan_id, prev_stat, m->b_ctl_init.as<ScanCtl>(), (u32*)nullptr, nwords3, (u32*)nullptr, m->b_upguess.as<u32>(), (u32)m->opt_ctl_dbg);
 	}
 	HIP_TRY(hipGetLastError());
 	return UFOMAP_OK;

@@ -64,6 +64,7 @@ struct ScanCtl {
 	u32 n_hit_tiles;             // depth-3 nodes that hold a hit voxel of the scan (k_select): what the hits can need in tile groups
 	u32 dl_total;      // coarse-miss phase: blocks visited so far (all levels, appended level by level)
 	u32 dl_start[25];  // dl_start[l] .. dl_start[l-1] = range of the level-l blocks in the visit list
+	u32 walk_scans;    // steady-state path: scans the walk applied, in the block of the walk's last scan (the host's statistics)
 	unsigned long long dbg[64];  // diagnostics (ufomap_map_debug): per-level clocks of the propagation tails
 };
 

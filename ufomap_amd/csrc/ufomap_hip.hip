@@ -286,6 +286,7 @@ struct ufomap_map {
 	DevBuf b_ser[5];              // scratch of the map byte stream (serialiseNodes), kept between calls
 	uint8_t* h_ser = nullptr;     // ... pinned: per-level counts, the root, the stream's length
 	DevBuf b_upbits;              // grids beyond LDS: which level-4 blocks the walk's k_up has evaluated (bitmap; left clean by k_ftail)
+	DevBuf b_upguess;             // k_ftail: where the block of every cell above the tiles was when a walk last looked (guesses, checked by key)
 	DevBuf b_ts;                  // developer aid (option "tstamps"): device clock at the pipeline's hand-overs (fast_kernels.h: Pipe::ts)
 	DevBuf b_pipe;                // fast path: which walk applies which scan (fast_kernels.h: Pipe), device side
 	uint64_t n_fseq = 0;          // fast-path scans enqueued so far
@@ -397,6 +398,7 @@ struct ufomap_map {
 	int opt_dda_mode = -1;
 	int opt_dda_seg = 1;  // 0 = force the lane-per-ray kernel
 	int opt_dda_block = 0, opt_dda_lanes = 0;  // 0 = automatic
+	int opt_ctl_dbg = 0;     // k_ftail also reports the control block's diagnostics (clock stamps: scripts/dev_*.py) to the host -- 512 bytes more across PCIe per scan
 	int opt_cast_fused = 2;  // the steady-state ray kernel: 2 = k_fcast3 (round 6: rays packed before set-up, cuts by estimate + check), 1 = k_fcast2, 0 = k_fcast
 	int opt_cast2_k = 64;    // ... its cells per segment (a cut costs ~1.5 us of a lane's chain: measured 32 -> 44.0, 48 -> 43.5, 64 -> 41.4, 96 -> 43.0 us per pipelined scan)
 	int opt_cast = 1, opt_cast_wgs = 0, opt_cast_k = 32;  // fused ray kernel: on/off, workgroups (0 = 256), steps per segment
@@ -1355,9 +1357,9 @@ int finishPending(ufomap_map* m)
 		m->used_g = m->h_ctl->used_g_now;
 		m->used_u = m->h_ctl->used_u_now;
 		m->ctl_clean = true;
-		if (m->h_ctl->dbg[45]) {  // (the last scan of a walk carries the number of scans the walk applied)
+		if (m->h_ctl->walk_scans) {  // (the last scan of a walk carries the number of scans the walk applied)
 			++m->n_walks;
-			m->n_walk_scans += m->h_ctl->dbg[45];
+			m->n_walk_scans += m->h_ctl->walk_scans;
 		}
 
 	} else {
@@ -3715,6 +3717,8 @@ int ufomap_map_set_option(ufomap_map* m, const char* key, long long value)
 		m->opt_vol_walk_lds = (int)std::max<long long>(0, std::min<long long>(128 << 10, value));
 	} else if (0 == strcmp(key, "cast2_k")) {
 		m->opt_cast2_k = (int)std::max<long long>(8, std::min<long long>(1024, value));
+	} else if (0 == strcmp(key, "ctl_dbg")) {
+		m->opt_ctl_dbg = value ? 1 : 0;
 	} else if (0 == strcmp(key, "cast_fused")) {
 		m->opt_cast_fused = (int)std::max<long long>(0, std::min<long long>(2, value));
 	} else if (0 == strcmp(key, "fmerge_rows")) {
