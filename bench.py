@@ -368,7 +368,7 @@ def main():
 
     # The timed loops are Python: no cyclic garbage collection inside them (as `timeit` does it). With torch imported a full
     # collection stops this thread for ~35 ms -- 800 scans' worth -- once in a few thousand calls; the library's own caller,
-    # a C++ node, has no such pauses (scripts/dev_ab.py shows the per-repetition spread with and without).
+    # a C++ node, has no such pauses (scripts/dev/dev_ab.py shows the per-repetition spread with and without).
     import gc
     gc.collect()
     gc.freeze()

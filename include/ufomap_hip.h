@@ -362,7 +362,7 @@ int ufomap_dev_expf(const float* x, float* out, size_t n, int device);
 /* Diagnostics (option "tstamps" = 1): the device clock (100 MHz) at the hand-overs of the steady-state pipeline, 8 words per
  * fast-path scan, slot = scan number mod 4096: [0] first-point pass done, [1] gate entered, [2] gate open, [3] scan half
  * published, [4] claim entered, [5] claim done, [6] tree update done, [7] scans that walk took. Joins everything first;
- * *newest = number of the newest fast-path scan. scripts/dev_timeline.py prints where each stream waits. */
+ * *newest = number of the newest fast-path scan. scripts/dev/dev_timeline.py prints where each stream waits. */
 int ufomap_map_timeline(ufomap_map* m, unsigned long long* out, size_t n_words, unsigned long long* newest);
 
 /* Diagnostics: up to 64 raw 64-bit words written by the last integration's kernels (per-level

@@ -1,5 +1,5 @@
 """Developer A/B (GPU box): the bench's headline loop (moving sensor, HBM-resident clouds, async) under different options.
-usage: python scripts/dev_ab.py "batch_max=1" "batch_max=8" "batch_max=8,cast_wgs=128" ...
+usage: python scripts/dev/dev_ab.py "batch_max=1" "batch_max=8" "batch_max=8,cast_wgs=128" ...
 Prints ms/scan, pipeline counters and (second pass, events on) average kernel times per configuration."""
 import os
 import sys
@@ -7,7 +7,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch  # noqa: E402
 from ufomap_amd import OccupancyMap, OccupancyMapColor, scans  # noqa: E402
 

@@ -1,6 +1,6 @@
-"""k_fcast's phases by its own clock stamps (workgroup 0, thread 0; 100 MHz): python scripts/dev_fcast.py"""
+"""k_fcast's phases by its own clock stamps (workgroup 0, thread 0; 100 MHz): python scripts/dev/dev_fcast.py"""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from ufomap_amd import OccupancyMap, scans
 clouds = [scans.lidar64(origin=scans.lidar_pose(s), seed=100 + s) for s in range(8)]

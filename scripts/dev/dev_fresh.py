@@ -1,7 +1,7 @@
 """C3 at insert depth 0, the FRESH scan: what its time is made of (allocations, memsets, creations): per-kernel times of the first
 scan into a new map, of the first scan after clear() (buffers kept), and the host's laps."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from ufomap_amd import OccupancyMap, scans, capi
 go, gx, _ = scans.rgbd()

@@ -1,6 +1,6 @@
 """k_ftail's phases by its own clock stamps (ufomap_map_debug words 10..22, 100 MHz), sync scans on the steady-state path."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from ufomap_amd import OccupancyMap, scans
 clouds = [scans.lidar64(origin=scans.lidar_pose(s), seed=100 + s) for s in range(8)]

@@ -1,7 +1,7 @@
 """The bench's headline leg at the driver's settings (25-scan repetitions from a cleared map: 5 warm-up scans, 20 timed, the region ends
-with a wait) under library options: python scripts/dev_k20.py "opt=val,opt=val" ..."""
+with a wait) under library options: python scripts/dev/dev_k20.py "opt=val,opt=val" ..."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from ufomap_amd import OccupancyMap, scans
 clouds = [scans.lidar64(origin=scans.lidar_pose(s), seed=100 + s) for s in range(8)]

@@ -1,12 +1,12 @@
 """Developer A/B (GPU box): latency of a synchronous insert (HBM-resident cloud, moving sensor) under different options.
-usage: python scripts/dev_sync.py "solo=0" "solo=1" ..."""
+usage: python scripts/dev/dev_sync.py "solo=0" "solo=1" ..."""
 import os
 import sys
 import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch  # noqa: E402
 from ufomap_amd import OccupancyMap, scans  # noqa: E402
 

@@ -1,13 +1,13 @@
 """Developer aid (GPU box): where the streams of the steady-state pipeline wait. The bench's headline loop with option
 "tstamps": device clock at every hand-over (include/ufomap_hip.h: ufomap_map_timeline), no tracing tool involved.
-usage: python scripts/dev_timeline.py ["opt=val,opt=val" ...]"""
+usage: python scripts/dev/dev_timeline.py ["opt=val,opt=val" ...]"""
 import os
 import sys
 import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch  # noqa: E402
 from ufomap_amd import OccupancyMap, scans  # noqa: E402
 

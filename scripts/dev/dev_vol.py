@@ -1,6 +1,6 @@
-"""C3 at insert depth 0 on the volume path: per-kernel times for the k_vdda modes (python scripts/dev_vol.py [modes...])"""
+"""C3 at insert depth 0 on the volume path: per-kernel times for the k_vdda modes (python scripts/dev/dev_vol.py [modes...])"""
 import sys, os, time, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from ufomap_amd import OccupancyMap, scans
 go, gx, _ = scans.rgbd()

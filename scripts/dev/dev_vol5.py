@@ -1,7 +1,7 @@
 """C3 at insert depth 0 on the volume path, round 5: the segmented ray walk against the one-lane-per-ray kernel, segment length and
-launch shape sweeps; per-kernel times by HIP events.   python scripts/dev_vol5.py [quick]"""
+launch shape sweeps; per-kernel times by HIP events.   python scripts/dev/dev_vol5.py [quick]"""
 import sys, os, time, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from ufomap_amd import OccupancyMap, scans
 go, gx, _ = scans.rgbd()

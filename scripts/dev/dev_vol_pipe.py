@@ -1,5 +1,5 @@
 """C3 at insert depth 0, asynchronous calls back to back (the volume path's halves overlapping across scans): for a kernel trace.
-   rocprofv3 --kernel-trace -f csv -d out -o t -- python scripts/dev_vol_pipe.py ; python scripts/dev_vol_pipe.py --show out/.../t_kernel_trace.csv"""
+   rocprofv3 --kernel-trace -f csv -d out -o t -- python scripts/dev/dev_vol_pipe.py ; python scripts/dev/dev_vol_pipe.py --show out/.../t_kernel_trace.csv"""
 import sys, os, time
 if len(sys.argv) > 2 and sys.argv[1] == "--show":
     import csv
@@ -18,7 +18,7 @@ if len(sys.argv) > 2 and sys.argv[1] == "--show":
         if e - s > 8 or "k_tile" in name or "k_vwalk" in name:
             print(f"q{r['Queue_Id']:>3} {s:10.1f} {e:10.1f} {e - s:9.1f} us  {name}")
     sys.exit(0)
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from ufomap_amd import OccupancyMap, scans
 go, gx, _ = scans.rgbd()

@@ -2,7 +2,7 @@
 frames that differ from call to call (sensor moves, boxes change, the table grows in the middle of walks, plain and colour maps,
 pre-growth on and off): the digests must agree at every checkpoint.   python scripts/soak_vol.py [scans]"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from ufomap_amd import OccupancyMap, OccupancyMapColor, scans
 n_scans = int(sys.argv[1]) if len(sys.argv) > 1 else 60

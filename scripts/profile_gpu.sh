@@ -19,7 +19,7 @@ find "$OUT" -name "*.csv" | head -20
 python scripts/summarize_prof.py "$OUT" "$TAG"
 # the bandwidth-bound configuration (C3 at insert depth 0, the volume path): per-kernel time and HBM bytes of its kernels
 cd /tmp
-CMD3="python $ROOT/scripts/dev_c3d0.py"
+CMD3="python $ROOT/scripts/dev/dev_c3d0.py"
 timeout 600 rocprofv3 -f csv --kernel-trace --stats -d "$OUT/c3_stats" -o stats -- $CMD3 > "$OUT/c3_stats.log" 2>&1
 timeout 600 rocprofv3 -f csv --pmc FETCH_SIZE --kernel-trace -d "$OUT/c3_pmc_fetch" -o fetch -- $CMD3 > "$OUT/c3_pmc_fetch.log" 2>&1
 timeout 600 rocprofv3 -f csv --pmc WRITE_SIZE --kernel-trace -d "$OUT/c3_pmc_write" -o write -- $CMD3 > "$OUT/c3_pmc_write.log" 2>&1

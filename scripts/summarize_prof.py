@@ -6,7 +6,7 @@ import os
 import sys
 
 out_dir, tag = sys.argv[1], sys.argv[2]
-sub = sys.argv[3] if len(sys.argv) > 3 else ""  # "c3": the passes over scripts/dev_c3d0.py (directories c3_stats, c3_pmc_fetch, c3_pmc_write)
+sub = sys.argv[3] if len(sys.argv) > 3 else ""  # "c3": the passes over scripts/dev/dev_c3d0.py (directories c3_stats, c3_pmc_fetch, c3_pmc_write)
 if sub:
     tag = tag + "_" + sub
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -365,353 +365,12 @@ __device__ __forceinline__ void tsMark(unsigned long long* ts, unsigned long lon
 	if (ts) ts[(f & (UFO_TS_SCANS - 1u)) * 8u + k] = v;
 }
 // ------------------------------------------------------------------------------------------------
-// F2: the ray kernel of the fast path = k_cast (scan_kernels.h: set-up, segment queue, walk; bit grid in LDS) fed from
-// the input cloud instead of a compacted ray list. A workgroup takes the points blockIdx.x, blockIdx.x + gridDim.x, ...;
-// a prologue runs the head loop on them, drops the points that lose their voxel to an earlier point (discrete mode,
-// OMB:358-360: first[cell] != own index) and compacts the surviving ray ends into the workgroup's own stretch of a
-// scratch array; from there on it is k_cast's round structure.
-// ------------------------------------------------------------------------------------------------
-template <bool DISCRETE>
-__global__ __launch_bounds__(1024) void k_fcast(MapGeom g, FastGeo fg, D3 sensor, const double* __restrict__ xyz, u32 n, double max_range,
-                                               u32 color_variant, const u32* __restrict__ first, D3* __restrict__ ray_scratch, u32 cap_wg,
-                                               u32* __restrict__ slabs, u32 k_min, const ScanCtl* ctl_in, ScanCtl* ctl,
-                                               unsigned long long* __restrict__ steps_part, Ingest ing, const PointRec* __restrict__ recs, u32 batch, u32 qcap,
-                                               u32 prio, Pipe* solo, ScanDesc solo_desc)
-{
-	// (solo: a synchronous call with nothing else in flight runs its five kernels on ONE stream -- no hand-over kernels,
-	// no claim; the walk's descriptor is written here, into a Pipe of the scan's own: slot 0 = this scan alone)
-	if (solo && 0 == (threadIdx.x | blockIdx.x)) {
-		solo->ring[0] = solo_desc;
-		solo->slot[0].first = 0;
-		solo->slot[0].B = 1;
-	}
-	// (batch, qcap: rays set up per round and segment queue entries -- they size the workgroup's LDS beside the bit grid,
-	// host_fast_path.inl: fastScanPhase; prio: wave priority, the kernel that sets the pipeline's period shares its SIMDs with the
-	// kernels of the two other streams)
-	if (prio >= 3u) __builtin_amdgcn_s_setprio(3);
-	else if (2u == prio) __builtin_amdgcn_s_setprio(2);
-	else if (1u == prio) __builtin_amdgcn_s_setprio(1);
-	extern __shared__ __attribute__((aligned(16))) u32 lds[];
-	const u32 err_in = ctl_in->err;  // (looked at once the LDS grid has been cleared: the load is in flight meanwhile)
-	if (0 == (threadIdx.x | blockIdx.x)) ctl->dbg[30] = wall_clock64();  // (diagnostics)
-	const Grid& gr = fg.gr;
-	const u32 depth = 0;
-	const u32 lds_words = (u32)(gr.bytes >> 2);
-	RayConst* rc = reinterpret_cast<RayConst*>(lds + lds_words);
-	RayHdr* hd = reinterpret_cast<RayHdr*>(rc + batch);
-	SegRec* q = reinterpret_cast<SegRec*>(hd + batch);
-	u32* sh = reinterpret_cast<u32*>(q + qcap);  // [0..15], [16..31]: per-wave partial sums; [32] ray count; [33] hit count
-	{
-		uint4* l4 = reinterpret_cast<uint4*>(lds);
-		for (u32 j = threadIdx.x; j < (lds_words >> 2); j += blockDim.x) l4[j] = make_uint4(0, 0, 0, 0);
-	}
-	if (0 == threadIdx.x) {
-		sh[32] = 0;
-		sh[33] = 0;
-	}
-	if (err_in) return;  // the scan does not fit the predicted grid (k_fhits): it will be repeated (uniform exit)
-	__syncthreads();
-	const u32 rowBits = fg.rowBits, planeBits = fg.planeBits;
-	const u32 lim = 1u << (g.L - depth);
-	const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-	const u32 nwaves = min(16u, (blockDim.x + 63u) >> 6);
-	unsigned long long steps = 0;
-	u32 err = 0, oob = 0;
-	if (0 == (threadIdx.x | blockIdx.x)) ctl->dbg[31] = wall_clock64();  // (diagnostics)
-	// ---- 0. head loop on this workgroup's points; surviving ray ends -> ray_scratch[blockIdx.x * cap_wg ...] ----
-	{
-		const u32 pts = (n > blockIdx.x) ? (n - blockIdx.x + gridDim.x - 1) / gridDim.x : 0u;
-		D3* mine_out = ray_scratch + (size_t)blockIdx.x * cap_wg;
-		u32 nhit = 0;
-		for (u32 p0 = 0; p0 < pts; p0 += blockDim.x) {  // uniform trip count
-			const u32 p = p0 + threadIdx.x;
-			bool cast = false;
-			D3 end{0, 0, 0};
-			if (p < pts) {
-				const u32 i = blockIdx.x + p * gridDim.x;
-				const PointRec r = recs[i];  // (k_fhits ran the head loop on the point)
-				const bool odd = 0 != (r.flags & 4u);
-				cast = (r.flags & 1u) && !odd;
-				if ((r.flags & 2u) && !odd) {
-					// (the voxel receives a hit, OMB:295, 358-360: its first point's. The scan's hit grid -- what the tree update
-					// reads -- is derived from this array by k_fmerge, which also leaves it clean for the set's next scan: 35 k
-					// scattered atomics less in this kernel, which sets the pipeline's period.)
-					const bool winner = first[r.cell] == i;
-					nhit += winner ? 1u : 0u;
-					if (DISCRETE && !winner) cast = false;  // OMB:358-360: dropped entirely, no ray
-				}
-				end = r.end;
-			}
-			const u64 m = __ballot(cast);
-			u32 base = 0;
-			if (0 == lane && m) base = atomicAdd(&sh[32], (u32)__popcll(m));
-			base = __shfl(base, 0);
-			if (cast) {
-				const u32 pos = base + (u32)__popcll(m & ((1ULL << lane) - 1ULL));
-				if (pos < cap_wg) mine_out[pos] = end;
-			}
-		}
-		for (int o = 32; o > 0; o >>= 1) nhit += __shfl_xor(nhit, o);
-		if (0 == lane && nhit) atomicAdd(&sh[33], nhit);
-	}
-	__syncthreads();
-	const u32 mine = min(sh[32], cap_wg);
-	if (0 == (threadIdx.x | blockIdx.x)) ctl->dbg[32] = wall_clock64();  // (diagnostics)
-	if (0 == threadIdx.x) {
-		// per-workgroup partials, folded by k_fmerge (256 workgroups adding to one word serialise at ~12 ns each)
-		steps_part[gridDim.x + blockIdx.x] = mine;
-		steps_part[2u * gridDim.x + blockIdx.x] = sh[33];
-	}
-	const D3* my_rays = ray_scratch + (size_t)blockIdx.x * cap_wg;
-	for (u32 base = 0; base < mine; base += batch) {
-		__syncthreads();  // previous round's queue and constants are no longer read
-		const u32 t = threadIdx.x;
-		const bool have = t < batch && base + t < mine;
-		// ---- 1. one lane per ray: clip, keys, computeRayInit ----
-		u32 l1 = 0, dmax = 0, ax = 0, status = 0, lin0 = 0;
-		if (have) {
-			RayState r;
-			raySetup(g, sensor, depth, gr, my_rays[base + t], r);
-			status = r.status;
-			if (1 == r.status) {
-				err |= markBitChecked(gr, lds, rowBits, planeBits, r.start[0], r.start[1], r.start[2], lim, &oob);
-				steps += 1;
-			} else if (3 == r.status) {
-				err |= ERR_GRID_OOB;  // cannot happen: pointRay admits only rays inside the grid's interior
-			} else if (2 == r.status) {
-				const u32 dxn = (u32)abs((i32)(r.gpk & 1023u) - (i32)(r.pk0 & 1023u));
-				const u32 dyn = (u32)abs((i32)((r.gpk >> 10) & 1023u) - (i32)((r.pk0 >> 10) & 1023u));
-				const u32 dzn = (u32)abs((i32)(r.gpk >> 20) - (i32)(r.pk0 >> 20));
-				ax = (dxn >= dyn && dxn >= dzn) ? 0u : (dyn >= dzn ? 1u : 2u);
-				dmax = ax == 0 ? dxn : (ax == 1 ? dyn : dzn);
-				l1 = dxn + dyn + dzn;
-				lin0 = pkToLin(r.pk0, rowBits, planeBits);
-				RayConst c;
-				c.td[0] = r.td[0];
-				c.td[1] = r.td[1];
-				c.td[2] = r.td[2];
-				c.dist = r.dist;
-				c.dl[0] = r.s[0];
-				c.dl[1] = (i32)r.s[1] * (i32)rowBits;
-				c.dl[2] = (i32)r.s[2] * (i32)planeBits;
-				c.glin = pkToLin(r.gpk, rowBits, planeBits);
-				rc[t] = c;
-				hd[t].tm[0] = r.tm[0];
-				hd[t].tm[1] = r.tm[1];
-				hd[t].tm[2] = r.tm[2];
-			}
-		}
-		if (0 == (threadIdx.x | blockIdx.x)) ctl->dbg[33] = wall_clock64();  // (diagnostics)
-		// ---- 2. segment length for this round: about K steps, and the queue must hold every segment ----
-		u32 tot = l1, cntr = (2 == status) ? 1u : 0u;
-		for (int o = 32; o > 0; o >>= 1) {
-			tot += __shfl_xor(tot, o);
-			cntr += __shfl_xor(cntr, o);
-		}
-		if (0 == lane && wave < 16u) {
-			sh[wave] = tot;
-			sh[16 + wave] = cntr;
-		}
-		__syncthreads();
-		u32 total = 0, nray2 = 0;
-		for (u32 wv = 0; wv < nwaves; ++wv) {
-			total += sh[wv];
-			nray2 += sh[16 + wv];
-		}
-		// K = k_min unless the queue cannot hold the segments that gives: then the K that is certain to fit
-		u32 K = k_min;
-		const u32 room = qcap - nray2;  // >= qcap - batch > 0
-		const u32 need = (total + room - 1u) / room + 3u;  // (scan_kernels.h, k_cast: at most l1/(K-3) + 1 segments per ray)
-		u32 w = 1, nseg = 0, off = 0, nsegs = 0;
-		for (u32 attempt = 0;; ++attempt) {
-			w = 1;
-			nseg = 0;
-			if (2 == status) {
-				w = (u32)(((u64)dmax * K) / l1);
-				if (w < 1u) w = 1u;
-				nseg = (dmax + w - 1u) / w;  // >= 1 (start and goal differ)
-			}
-			__syncthreads();  // sh[] is reused below
-			u32 incl = nseg;
-			for (int o = 1; o < 64; o <<= 1) {
-				const u32 v = __shfl_up(incl, o);
-				if ((int)lane >= o) incl += v;
-			}
-			if (63u == lane && wave < 16u) sh[wave] = incl;
-			__syncthreads();
-			off = incl - nseg;
-			nsegs = 0;
-			for (u32 wv = 0; wv < nwaves; ++wv) {
-				const u32 v = sh[wv];
-				if (wv < wave) off += v;
-				nsegs += v;
-			}
-			if (nsegs <= qcap || attempt || need <= K) break;  // (uniform)
-			K = need;
-		}
-		if (t < batch) {
-			hd[t].lin0 = lin0;
-			hd[t].ax = ax;
-			hd[t].w = w;
-			hd[t].nseg = nseg;
-			hd[t].off = off;
-		}
-		__syncthreads();
-		if (0 == (threadIdx.x | blockIdx.x)) ctl->dbg[34] = wall_clock64();  // (diagnostics)
-		// ---- 3. cut states from the three independent addition chains (k_dda_seg) ----
-		// 3a. one lane per ray: the dominant chain a*, once. After k0 = j*w pops of a*: element A[k0-1] (= v) was popped
-		// and t_max_a* = A[k0]. v is parked in the cut's two other t_max fields for the lanes of 3b.
-		if (threadIdx.x < batch) {
-			const u32 ry = threadIdx.x;
-			const RayHdr h = hd[ry];
-			if (0 != h.nseg) {
-				const RayConst c = rc[ry];
-				SegRec rec;
-				rec.tm[0] = h.tm[0];
-				rec.tm[1] = h.tm[1];
-				rec.tm[2] = h.tm[2];
-				rec.lin = h.lin0;
-				rec.end = c.glin;
-				rec.ray = ry | 0x80000000u;
-				rec.pad = 0;
-				q[h.off] = rec;
-				const u32 axd = h.ax;
-				const u32 b0 = axd == 0 ? 1u : 0u, b1 = axd == 2 ? 1u : 2u;
-				double ta = axd == 0 ? h.tm[0] : (axd == 1 ? h.tm[1] : h.tm[2]), v = ta;
-				const double tda = axd == 0 ? c.td[0] : (axd == 1 ? c.td[1] : c.td[2]);
-				const i32 da = axd == 0 ? c.dl[0] : (axd == 1 ? c.dl[1] : c.dl[2]);
-				for (u32 j = 1; j < h.nseg; ++j) {
-					// w pops to the next cut, four at a time (the same sequence of additions; v = the last element popped)
-					u32 n = h.w;
-					for (; n >= 4u; n -= 4u) {
-						const double t1 = ta + tda, t2 = t1 + tda, t3 = t2 + tda;
-						v = t3;
-						ta = t3 + tda;
-					}
-					for (; n > 0u; --n) {
-						v = ta;
-						ta = ta + tda;
-					}
-					SegRec* o = &q[h.off + j];
-					o->tm[axd] = ta;
-					o->tm[b0] = v;
-					o->tm[b1] = v;
-					o->lin = h.lin0 + (u32)((i32)(j * h.w) * da);
-					o->end = c.glin;
-					o->ray = ry;
-				}
-			}
-		}
-		__syncthreads();
-		if (0 == (threadIdx.x | blockIdx.x)) ctl->dbg[44] = wall_clock64();  // (diagnostics)
-		// 3b. two lanes per ray, one per other axis: of that axis the elements before v were popped (strictly smaller, or
-		// equal when the axis has priority: the lower axis index wins ties, VEC3:244-251) -- their count moves the cut's
-		// cell; four candidates per iteration (same sequence of additions)
-		for (u32 idx = threadIdx.x; idx < 2u * batch; idx += blockDim.x) {
-			const u32 role = idx >= batch ? 1u : 0u, ry = idx - role * batch;
-			const RayHdr h = hd[ry];
-			if (h.nseg < 2u) continue;
-			const RayConst c = rc[ry];
-			const u32 axd = h.ax;
-			const u32 b = (0 == role) ? (axd == 0 ? 1u : 0u) : (axd == 2 ? 1u : 2u);
-			const bool pri = b < axd;
-			double tb = b == 0 ? h.tm[0] : (b == 1 ? h.tm[1] : h.tm[2]);
-			const double dbt = b == 0 ? c.td[0] : (b == 1 ? c.td[1] : c.td[2]);
-			const i32 dbl = b == 0 ? c.dl[0] : (b == 1 ? c.dl[1] : c.dl[2]);
-			// ONE loop over the candidates of all cuts (a loop per cut would cost a wave, at every cut, the longest run of any
-			// of its rays): an iteration tests four candidates against the current cut's v and either pops them all, or pops
-			// the ones before v, stores the cut and moves on to the next
-			u32 cb = 0, j = 1;
-			SegRec* o = &q[h.off + 1u];
-			double v = o->tm[b];
-			u32 guard = 0;
-			while (j < h.nseg) {
-				const double s1 = tb + dbt, s2 = s1 + dbt, s3 = s2 + dbt;
-				const bool c0 = pri ? (tb <= v) : (tb < v);
-				const bool c1 = c0 & (pri ? (s1 <= v) : (s1 < v)), c2 = c1 & (pri ? (s2 <= v) : (s2 < v)), c3 = c2 & (pri ? (s3 <= v) : (s3 < v));
-				if (c3) {
-					tb = s3 + dbt;
-					cb += 4u;
-					if (++guard > 1024u) {
-						err |= ERR_RUNAWAY;  // (cannot trip inside a grid of < 1024 cells per axis)
-						break;
-					}
-					continue;
-				}
-				tb = c2 ? s3 : (c1 ? s2 : (c0 ? s1 : tb));
-				cb += (c0 ? 1u : 0u) + (c1 ? 1u : 0u) + (c2 ? 1u : 0u);
-				o->tm[b] = tb;
-				if (cb) atomicAdd(&o->lin, (u32)((i32)cb * dbl));
-				++j;
-				++o;
-				if (j < h.nseg) v = o->tm[b];
-			}
-		}
-		__syncthreads();
-		for (u32 si = threadIdx.x; si + 1u < nsegs; si += blockDim.x)
-			if (!(q[si + 1u].ray & 0x80000000u)) q[si].end = q[si + 1u].lin;
-		__syncthreads();
-		if (0 == (threadIdx.x | blockIdx.x)) ctl->dbg[35] = wall_clock64();  // (diagnostics)
-		// ---- 4. every lane walks segments ----
-		for (u32 si = threadIdx.x; si < nsegs; si += blockDim.x) {
-			const SegRec rec = q[si];
-			const RayConst c = rc[rec.ray & 0x7FFFFFFFu];
-			double tmx = rec.tm[0], tmy = rec.tm[1], tmz = rec.tm[2];
-			const double tdx = c.td[0], tdy = c.td[1], tdz = c.td[2];
-			const long long idist = __double_as_longlong(c.dist);
-			const i32 dlx = c.dl[0], dly = c.dl[1], dlz = c.dl[2];
-			const u32 end = rec.end;
-			u32 lin = rec.lin;
-			bool go = (0 != (rec.ray & 0x80000000u)) ||
-			          ((lin != c.glin) && ((__double_as_longlong(tmx) <= idist) | (__double_as_longlong(tmy) <= idist) |
-			                               (__double_as_longlong(tmz) <= idist)));
-			const u32 lin_first = lin;
-			u32 cnt = 0;
-			while (go) {
-				++cnt;
-				atomicOr(&lds[lin >> 5], 1u << (lin & 31u));
-				const bool cxy = tmx <= tmy, cxz = tmx <= tmz, cyz = tmy <= tmz;
-				const bool selx = cxy & cxz;
-				const bool sely = !cxy & cyz;
-				const bool selz = !(selx | sely);
-				lin += (u32)(selx ? dlx : (sely ? dly : dlz));
-				const double nx = tmx + tdx, ny = tmy + tdy, nz = tmz + tdz;
-				tmx = selx ? nx : tmx;
-				tmy = sely ? ny : tmy;
-				tmz = selz ? nz : tmz;
-				const bool more =
-				    (__double_as_longlong(tmx) <= idist) | (__double_as_longlong(tmy) <= idist) | (__double_as_longlong(tmz) <= idist);
-				go = (lin != end) & more & (cnt < 4096u);
-			}
-			if (cnt >= 4096u) err |= ERR_RUNAWAY;  // (a segment is ~K steps by construction)
-			const u32 ny2 = 2u * (u32)gr.nb[1];
-			const u32 r0 = lin_first / rowBits, r1 = lin / rowBits;
-			const i32 ddx = (i32)(lin % rowBits) - (i32)(lin_first % rowBits), ddy = (i32)(r1 % ny2) - (i32)(r0 % ny2),
-			          ddz = (i32)(r1 / ny2) - (i32)(r0 / ny2);
-			steps += (u32)(abs(ddx) + abs(ddy) + abs(ddz));
-		}
-	}
-	__syncthreads();
-	if (0 == (threadIdx.x | blockIdx.x)) ctl->dbg[36] = wall_clock64();  // (diagnostics)
-	{
-		const uint4* l4 = reinterpret_cast<const uint4*>(lds);
-		uint4* out4 = reinterpret_cast<uint4*>(slabs) + (size_t)blockIdx.x * (lds_words >> 2);
-		const u32 n4 = lds_words >> 2;
-		for (u32 j = threadIdx.x; j < n4; j += blockDim.x) out4[j] = l4[j];
-	}
-	if (0 == (threadIdx.x | blockIdx.x)) ctl->dbg[37] = wall_clock64();  // (diagnostics)
-	blockStoreSteps(steps, steps_part);
-	if (oob) atomicAdd(&ctl->n_oob, oob);
-	if (err) atomicOr(&ctl->err, err);
-	if (0 == (threadIdx.x | blockIdx.x)) ctl->dbg[38] = wall_clock64();  // (diagnostics)
-}
-
-// ------------------------------------------------------------------------------------------------
-// F2' (round 5): k_fcast with its phases in front of the walk FUSED. k_fcast runs head loop -> (barrier) -> set-up, one lane
+// F2' (round 5; round 3's k_fcast -- k_cast's round structure fed from the cloud, removed in round 6 -- ran its phases one behind the other):
+// the phases in front of the walk FUSED. k_fcast ran head loop -> (barrier) -> set-up, one lane
 // per ray -> (barrier) -> segment sizes, prefix sums -> (2 barriers) -> dominant chains, one lane per ray -> (barrier) -> the
 // other axes, two lanes per ray -> (2 barriers) -> walk: a lone workgroup per CU (148 KB of LDS), so every phase is the latency
 // of its own dependent chain with three of sixteen waves busy, and the ray ends go through global memory between the first two.
-// Measured by the kernel's own stamps (workgroup 0, 16 cm LiDAR scan, scripts/dev_fcast.py): head loop 5.1 us, set-up 2.3,
+// Measured by the kernel's own stamps (workgroup 0, 16 cm LiDAR scan, scripts/dev/dev_fcast.py): head loop 5.1 us, set-up 2.3,
 // sizes 1.5, dominant chains 2.4, other axes + fix-ups 5.2 = 16.4 us in front of a walk of 7.1.
 // Here the lane that looks at a point does everything for the point's ray -- the winner test, clip / keys / computeRayInit, the
 // three addition chains side by side in its registers (k_vcut's loop, vol_kernels.h: the dominant axis up to the cut, the two

@@ -299,11 +299,10 @@ int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, si
 		// One workgroup per CU is what the ray kernel's LDS allows, and alone it is fastest with one on every CU. In a row
 		// of asynchronous scans it shares the chip with the first-point pass of the next scan and the tree update of the
 		// scan before: with a workgroup on three CUs in four it does not wait for the last CUs those kernels hold, and they
-		// have CUs where nothing else competes (measured, scripts/dev_ab.py cast_wgs=...: 256 -> 0.052, 192 -> 0.046 ms/scan).
+		// have CUs where nothing else competes (measured, scripts/dev/dev_ab.py cast_wgs=...: 256 -> 0.052, 192 -> 0.046 ms/scan).
 		u32 nwg = m->opt_cast_wgs > 0 ? (u32)m->opt_cast_wgs : (lazy_done ? (u32)(3 * m->n_cus / 4) : (u32)m->n_cus);
 		nwg = std::max<u32>(1u, std::min<u32>(nwg, (N + 63u) / 64u));
 		const u32 cap_wg = (N + nwg - 1) / nwg;
-		HIP_TRY(m->b_ray_end.reserve((size_t)cap_wg * nwg * sizeof(D3)));
 		HIP_TRY(m->b_slabs.reserve((size_t)nwg * fg.gr.bytes + (size_t)nwg * 8 * 3));  // slabs + per-workgroup steps / rays / hits (of this set: merged by the walk)
 		unsigned long long* sp = reinterpret_cast<unsigned long long*>(m->b_slabs.as<char>() + (size_t)nwg * fg.gr.bytes);
 		// end of the scan half: the scan's descriptor and number become visible to the walks (k_claim)
@@ -338,8 +337,8 @@ int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, si
 				batch = UFO_CAST_BATCH;
 				qcap = UFO_CAST_QCAP;
 			}
-			const size_t lds = ldsFor(batch, qcap);
 			{
+				const size_t lds = ldsFor(batch, qcap);
 				static const bool trace = nullptr != getenv("UFOMAP_TRACE_GRID");
 				if (trace)
 					fprintf(stderr, "[ufomap] fast grid: %d x %d x %d blocks, %llu bytes; k_fcast: %u workgroups, %zu bytes of LDS each\n", fg.gr.nb[0], fg.gr.nb[1],
@@ -366,8 +365,8 @@ int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, si
 				else
 					hipLaunchKernelGGL(k_fcast3<false>, dim3(nwg), dim3(cthreads), lds3, m->cs, m->g, fg, sensor, N, m->b_first.as<u32>(), m->b_slabs.as<u32>(), (u32)std::max(8, m->opt_cast2_k),
 					                   ctl, ctl, sp, m->b_hit_code.as<PointRec>(), batch, qcap, lcap, prio, solo_pipe, d);
-			} else if (m->opt_cast_fused) {
-				// (round 5: head loop, set-up and cuts by the lane that looks at the point, one barrier in front of the walk)
+			} else {
+				// (round 5's form, kept as the cross-check of k_fcast3 -- option cast_fused = 1: head loop, set-up and cuts by the lane that looks at the point)
 				const size_t lds2 = (size_t)fg.gr.bytes + (size_t)batch * sizeof(RayConst) + (size_t)qcap * sizeof(SegRec) + 256u;
 				if (discrete)
 					hipLaunchKernelGGL(k_fcast2<true>, dim3(nwg), dim3(cthreads), lds2, m->cs, m->g, fg, sensor, N, m->b_first.as<u32>(), m->b_slabs.as<u32>(), (u32)std::max(8, m->opt_cast2_k),
@@ -375,12 +374,7 @@ int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, si
 				else
 					hipLaunchKernelGGL(k_fcast2<false>, dim3(nwg), dim3(cthreads), lds2, m->cs, m->g, fg, sensor, N, m->b_first.as<u32>(), m->b_slabs.as<u32>(), (u32)std::max(8, m->opt_cast2_k),
 					                   ctl, ctl, sp, m->b_hit_code.as<PointRec>(), batch, qcap, prio, solo_pipe, d);
-			} else if (discrete)
-				hipLaunchKernelGGL(k_fcast<true>, dim3(nwg), dim3(cthreads), lds, m->cs, m->g, fg, sensor, d_xyz, N, max_range, 0u, m->b_first.as<u32>(),
-				                   m->b_ray_end.as<D3>(), cap_wg, m->b_slabs.as<u32>(), (u32)std::max(8, m->opt_cast_k), ctl, ctl, sp, m->ing, m->b_hit_code.as<PointRec>(), batch, qcap, prio, solo_pipe, d);
-			else
-				hipLaunchKernelGGL(k_fcast<false>, dim3(nwg), dim3(cthreads), lds, m->cs, m->g, fg, sensor, d_xyz, N, max_range, 0u, m->b_first.as<u32>(),
-				                   m->b_ray_end.as<D3>(), cap_wg, m->b_slabs.as<u32>(), (u32)std::max(8, m->opt_cast_k), ctl, ctl, sp, m->ing, m->b_hit_code.as<PointRec>(), batch, qcap, prio, solo_pipe, d);
+			}
 		}
 		if (solo) {
 			// (k_fcast has written the descriptor itself)

@@ -398,8 +398,8 @@ struct ufomap_map {
 	int opt_dda_mode = -1;
 	int opt_dda_seg = 1;  // 0 = force the lane-per-ray kernel
 	int opt_dda_block = 0, opt_dda_lanes = 0;  // 0 = automatic
-	int opt_ctl_dbg = 0;     // k_ftail also reports the control block's diagnostics (clock stamps: scripts/dev_*.py) to the host -- 512 bytes more across PCIe per scan
-	int opt_cast_fused = 2;  // the steady-state ray kernel: 2 = k_fcast3 (round 6: rays packed before set-up, cuts by estimate + check), 1 = k_fcast2, 0 = k_fcast
+	int opt_ctl_dbg = 0;     // k_ftail also reports the control block's diagnostics (clock stamps: scripts/dev/dev_*.py) to the host -- 512 bytes more across PCIe per scan
+	int opt_cast_fused = 2;  // the steady-state ray kernel: 2 = k_fcast3 (round 6: rays packed before set-up, cuts by estimate + check), else k_fcast2 (round 5, the cross-check)
 	int opt_cast2_k = 64;    // ... its cells per segment (a cut costs ~1.5 us of a lane's chain: measured 32 -> 44.0, 48 -> 43.5, 64 -> 41.4, 96 -> 43.0 us per pipelined scan)
 	int opt_cast = 1, opt_cast_wgs = 0, opt_cast_k = 32;  // fused ray kernel: on/off, workgroups (0 = 256), steps per segment
 	int opt_bits = 1;     // 0 = never use the bit-per-cell grid / k_walk
@@ -3634,8 +3634,6 @@ int ufomap_map_set_option(ufomap_map* m, const char* key, long long value)
 		m->opt_fast = (int)value;
 	} else if (0 == strcmp(key, "async_apply")) {
 		m->opt_async_apply = value ? 1 : 0;
-	} else if (0 == strcmp(key, "tile_waves")) {
-		m->opt_tile_waves = (int)value;
 	} else if (0 == strcmp(key, "gates")) {
 		m->opt_gates = value ? 1 : 0;
 	} else if (0 == strcmp(key, "batch_max")) {
@@ -3652,8 +3650,6 @@ int ufomap_map_set_option(ufomap_map* m, const char* key, long long value)
 			m->b_ts.release();
 		}
 		HIP_TRY(hipMemcpy(reinterpret_cast<char*>(m->b_pipe.p) + offsetof(Pipe, ts), &ts, sizeof(ts), hipMemcpyHostToDevice));
-	} else if (0 == strcmp(key, "vol_fused")) {
-		m->opt_vol_fused = value ? 1 : 0;
 	} else if (0 == strcmp(key, "ser_short")) {
 		m->opt_ser_short = value ? 1 : 0;
 	} else if (0 == strcmp(key, "big")) {
@@ -3693,8 +3689,6 @@ int ufomap_map_set_option(ufomap_map* m, const char* key, long long value)
 		m->opt_cast_k = (int)value;
 	} else if (0 == strcmp(key, "dda_bits")) {
 		m->opt_bits = value ? 1 : 0;
-	} else if (0 == strcmp(key, "dda_block")) {
-		m->opt_dda_block = (int)value;
 	} else if (0 == strcmp(key, "dda_lanes")) {
 		m->opt_dda_lanes = (int)value;
 	} else if (0 == strcmp(key, "vol")) {
@@ -3721,16 +3715,8 @@ int ufomap_map_set_option(ufomap_map* m, const char* key, long long value)
 		m->opt_ctl_dbg = value ? 1 : 0;
 	} else if (0 == strcmp(key, "cast_fused")) {
 		m->opt_cast_fused = (int)std::max<long long>(0, std::min<long long>(2, value));
-	} else if (0 == strcmp(key, "fmerge_rows")) {
-		m->opt_fmerge_rows = (int)value;
-	} else if (0 == strcmp(key, "wait_flush_first")) {
-		m->opt_wait_flush_first = value ? 1 : 0;
-	} else if (0 == strcmp(key, "vol_color")) {
-		m->opt_vol_color = value ? 1 : 0;
 	} else if (0 == strcmp(key, "vol_async")) {
 		m->opt_vol_async = value ? 1 : 0;
-	} else if (0 == strcmp(key, "vol_keep")) {
-		m->opt_vol_keep = value ? 1 : 0;
 	} else if (0 == strcmp(key, "merge_phases")) {
 		m->opt_merge = value ? 1 : 0;
 	} else if (0 == strcmp(key, "entry_guess")) {
