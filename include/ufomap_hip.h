@@ -320,7 +320,9 @@ int ufomap_map_insert_batch(ufomap_map* m, ufomap_comm* c, const double sensor_o
                             unsigned depth, int discrete);
 /* ... with the two remaining arguments of insertPointCloud / insertPointCloudDiscrete (occupancy_map_base.h:270-273, 340-344):
  * simple_ray_casting (freeSpaceSimple, 1303-1339) and early_stopping (1289-1298, 1327-1333). Both have to be the same on every
- * rank (like depth and discrete); a step with either takes the update-list form. */
+ * rank (like depth and discrete); a step with either takes the update-list form. Insert depth > 0 (occupancy_map_base.h:378-386,
+ * 1085-1120; round 6): the update-list form too, the ranks' lists applied one by one in rank order -- each its hits, then its misses at
+ * the insert depth, as the reference does scan after scan (plain maps; a colour map's lists are built at depth 0 only). */
 int ufomap_map_insert_batch_ex(ufomap_map* m, ufomap_comm* c, const double sensor_origin[3], const double* d_xyz, const uint8_t* d_rgb, size_t n,
                                double max_range, unsigned depth, int discrete, int simple_ray_casting, unsigned early_stopping);
 

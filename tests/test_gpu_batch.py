@@ -572,7 +572,57 @@ def test_gate_timeouts_are_survived():
     print("gate timeouts:", n_to)
 
 
-def _replicated_world(world, steps, out_q, shim):
+def test_insert_batch_at_insert_depth():
+    """Batch steps at insert depth > 0 (occupancy_map_base.h:378-386, 1085-1120; the way the reference's README tells RGB-D users to run
+    a fine map): the update-list form, the ranks' lists applied one by one in rank order -- world 1 through the real RCCL, steps at
+    depth 0 (bit-grid form once the common grid is known), 1, 2 and 3 mixed, against the reference scan by scan."""
+    import torch
+    from oracle import OracleMap
+    from ufomap_amd import OccupancyMap, Comm, scans
+    g, o = OccupancyMap(0.08), OracleMap(0.08, kind=_kind())
+    comm = Comm(Comm.unique_id(), 1, 0, 0)
+    try:
+        for s, depth in enumerate([0, 0, 2, 0, 1, 3, 0, 2, 2, 0]):
+            origin, xyz, _ = scans.lidar64(origin=tuple(np.array(scans.lidar_pose(1)) + [0.07 * s, 0.03 * s, 0.0]), seed=300 + s, beams=16, azimuths=512)
+            d = torch.from_numpy(xyz).cuda()
+            g.insert_batch(comm, origin, d.data_ptr(), xyz.shape[0], 9.0, depth, True)
+            o.insert(origin, xyz, max_range=9.0, depth=depth, discrete=True)
+            torch.cuda.synchronize()
+            if s in (2, 5):
+                g.insertPointCloudWait()
+                _assert_same_map(g, o, f"after step {s} (insert depth {depth})")
+        g.insertPointCloudWait()
+        _assert_same_map(g, o, "batch steps at insert depths 0 .. 3")
+    finally:
+        g.insertPointCloudWait()
+        comm.close()
+
+
+def test_insert_batch_at_insert_depth_three_ranks():
+    """... and with three ranks played by one process (tests/cpp/rccl_shim.cpp: every slot of the all-gather a copy of the caller's):
+    every odd step at insert depth 2 -- the lists of the three ranks applied one after the other, hits then misses each, as the
+    reference does scan after scan -- every even step at depth 0."""
+    import torch.multiprocessing as mp
+    from ufomap_amd import scans
+    from oracle import OracleMap
+    import golden_util
+    world, steps, depth = 3, 6, 2
+    ctx = mp.get_context("spawn")
+    out_q = ctx.Queue()
+    p = ctx.Process(target=_replicated_world, args=(world, steps, out_q, _build_shim(), depth))
+    p.start()
+    dig, counters = out_q.get(timeout=300)
+    p.join(timeout=60)
+    assert not isinstance(dig, str), dig
+    o = OracleMap(0.16, kind=_kind())
+    for i in range(steps):
+        origin, xyz, _ = scans.lidar64(beams=16, azimuths=256, origin=tuple(np.array(scans.lidar_pose(1)) + [0.04 * i, 0.0, 0.0]), seed=70 + i)
+        for _ in range(world):
+            o.insert(origin, xyz, max_range=10.0, depth=depth if i % 2 else 0, discrete=True)
+    assert tuple(dig) == tuple(golden_util.dump_digest(o.leaves(True), o.inner())), "the replica differs from the sequential map"
+
+
+def _replicated_world(world, steps, out_q, shim, depth=0):
     """One process plays all `world` ranks (tests/cpp/rccl_shim.cpp, UFOMAP_SHIM_REPLICATE: every slot of an all-gather is a copy of the
     caller's): a step applies this rank's scan `world` times, in order."""
     import os
@@ -590,7 +640,7 @@ def _replicated_world(world, steps, out_q, shim):
             origin, xyz, _ = scans.lidar64(beams=16, azimuths=256, origin=tuple(np.array(scans.lidar_pose(1)) + [0.04 * i, 0.0, 0.0]), seed=70 + i)
             d = th.from_numpy(np.ascontiguousarray(xyz)).cuda()
             keep.append(d)
-            g.insert_batch(comm, origin, d.data_ptr(), len(xyz), 10.0, 0, True)
+            g.insert_batch(comm, origin, d.data_ptr(), len(xyz), 10.0, depth if i % 2 else 0, True)
         g.insertPointCloudWait()
         out_q.put((g.digest(), comm.counters()))
         comm.close()

@@ -179,7 +179,7 @@ ScanCtl* otherResult(uint8_t* all, int w) { return reinterpret_cast<ScanCtl*>(al
 // (ufomap_map_apply_keys_batch). A rank whose scan FAILED still takes part in the collective -- with a status word in
 // its header and an empty list -- and every rank returns that error: nobody is left waiting in the all-gather.
 int listBatchStep(ufomap_map* m, ufomap_comm* c, const double origin[3], const double* d_xyz, const uint8_t* d_rgb, size_t n, double max_range,
-                  int discrete, bool in_join, int simple = 0, unsigned early_stopping = 0)
+                  int discrete, bool in_join, int simple = 0, unsigned early_stopping = 0, unsigned depth = 0)
 {
 	Rccl* r = rccl();
 	const int W = c->world;
@@ -187,17 +187,17 @@ int listBatchStep(ufomap_map* m, ufomap_comm* c, const double origin[3], const d
 	// (in_join: called while a step is being joined -- the current hand-over set is that step's, nothing else is joined or rotated)
 	int scan_rc;
 	if (in_join) {
-		scan_rc = scanKeysCore(m, origin, d_xyz, m->g.color ? d_rgb : nullptr, n, max_range, 0, discrete, simple, &info, early_stopping);
+		scan_rc = scanKeysCore(m, origin, d_xyz, m->g.color ? d_rgb : nullptr, n, max_range, depth, discrete, simple, &info, early_stopping);
 	} else if (early_stopping) {
 		// (ufomap_map_scan_keys_rgb's prologue, with the argument its signature does not have)
 		scan_rc = (hipSetDevice(m->device) == hipSuccess && hipStreamSynchronize(m->sstream) == hipSuccess) ? UFOMAP_OK : fail(UFOMAP_ERR_DEVICE, "scan stream");
 		if (!scan_rc) {
 			(void)rotateSets(m);
 			m->args = ScanArgs{};
-			scan_rc = scanKeysCore(m, origin, d_xyz, m->g.color ? d_rgb : nullptr, n, max_range, 0, discrete, simple, &info, early_stopping);
+			scan_rc = scanKeysCore(m, origin, d_xyz, m->g.color ? d_rgb : nullptr, n, max_range, depth, discrete, simple, &info, early_stopping);
 		}
 	} else {
-		scan_rc = ufomap_map_scan_keys_rgb(m, origin, d_xyz, m->g.color ? d_rgb : nullptr, n, max_range, 0, discrete, simple, &info);
+		scan_rc = ufomap_map_scan_keys_rgb(m, origin, d_xyz, m->g.color ? d_rgb : nullptr, n, max_range, depth, discrete, simple, &info);
 	}
 	std::string scan_msg = scan_rc ? g_err : std::string();
 	if (scan_rc) memset(&info, 0, sizeof(info));
@@ -228,7 +228,8 @@ int listBatchStep(ufomap_map* m, ufomap_comm* c, const double origin[3], const d
 		{
 			HdrTail t{};
 			t.status = scan_rc;
-			t.have_box = (!scan_rc && n && m->h_ctl->n_rays && m->h_ctl->mb_min[0] <= m->h_ctl->mb_max[0]) ? 1 : 0;
+			// (the box of ray cells predicts the ranks' common ray grid of depth-0 steps: cells at another insert depth do not)
+			t.have_box = (!scan_rc && n && 0 == depth && m->h_ctl->n_rays && m->h_ctl->mb_min[0] <= m->h_ctl->mb_max[0]) ? 1 : 0;
 			for (int a = 0; a < 3 && t.have_box; ++a) {
 				t.box[a] = m->h_ctl->mb_min[a];
 				t.box[3 + a] = m->h_ctl->mb_max[a];
@@ -300,6 +301,18 @@ int listBatchStep(ufomap_map* m, ufomap_comm* c, const double origin[3], const d
 	uint8_t* recv = c->recv[c->flip].as<uint8_t>();
 	for (int k = 0; k < W; ++k) lists[(size_t)k] = (infos[(size_t)k].n_hit + infos[(size_t)k].n_miss) ? recv + (size_t)k * c->cap + kSlotHeader : nullptr;
 	c->flip ^= 1;
+	if (depth > 0) {
+		// Insert depth > 0 (occupancy_map_base.h:378-386, 1085-1120: a miss is applied to a whole subtree; the reference's recommended way
+		// to run a fine map, ufomap_mapping/README.md:38-39): the lists of the ranks one by one, in rank order -- each its hits, then its
+		// misses at the insert depth (ufomap_map_apply_keys), exactly what the reference does scan after scan. One walk for all ranks'
+		// lists would have to order the first list's misses before the second list's hits, which one pass cannot.
+		for (int k = 0; k < W; ++k) {
+			if (!lists[(size_t)k]) continue;
+			const int arc = ufomap_map_apply_keys(m, lists[(size_t)k], &infos[(size_t)k]);
+			if (arc) return arc;
+		}
+		return UFOMAP_OK;
+	}
 	if (in_join) return applyKeysBatchCore(m, lists.data(), infos.data(), W, true);
 	return ufomap_map_apply_keys_batch(m, lists.data(), infos.data(), W);
 }
@@ -567,7 +580,8 @@ int ufomap_map_insert_batch_ex(ufomap_map* m, ufomap_comm* c, const double senso
 		return fail(UFOMAP_ERR_UNSUPPORTED, "OccupancyMapColor::insertPointCloud<PointCloudColor> does not compile in the reference (SURVEY.md 4)");
 	if (!m->g.color) d_rgb = nullptr;
 	if (m->g.color && !d_rgb && n) return fail(UFOMAP_ERR_INVALID, "a colour map needs the points' colours");
-	if (0 != depth) return fail(UFOMAP_ERR_UNSUPPORTED, "insert_batch: insert depth 0 only");
+	if (depth >= m->g.L) return fail(UFOMAP_ERR_INVALID, "depth must be < depth_levels");
+	if (0 != depth && m->g.color) return fail(UFOMAP_ERR_UNSUPPORTED, "insert_batch: update lists with colour are built at insert depth 0 only");
 	if (c->device != m->device) return fail(UFOMAP_ERR_INVALID, "the communicator was created on another device than the map");
 	if (!rccl()) return fail(UFOMAP_ERR_UNSUPPORTED, "librccl not found (set UFOMAP_RCCL_LIB)");
 	HIP_TRY(hipSetDevice(m->device));
@@ -580,11 +594,15 @@ int ufomap_map_insert_batch_ex(ufomap_map* m, ufomap_comm* c, const double senso
 	// (fixed-step casting and early stopping -- the reference's simple_ray_casting / early_stopping arguments, occupancy_map_base.h:
 	// 340-344, the same on every rank by contract -- take the list form: the scan half of the general path casts that way)
 	const bool fast = c->spec_valid && m->opt_fast && m->opt_spec && !m->g.color && !m->chg_enabled && m->g.L >= 5 && nullptr == m->ing.data &&
-	                  !simple_ray_casting && 0 == early_stopping && c->world <= (int)UFO_BATCH_MAX && fastEligible(m, c->spec_grid, 0, 0, nullptr, 1);
+	                  !simple_ray_casting && 0 == early_stopping && 0 == depth && c->world <= (int)UFO_BATCH_MAX && fastEligible(m, c->spec_grid, 0, 0, nullptr, 1);
 	if (!fast) {
 		// (joins what is in flight where it has to: scan_keys / apply_keys_batch)
+		if (0 != depth) {  // (bit-grid steps still in flight are joined first -- at the same point of every rank's sequence of calls)
+			const int wrc = ufomap_map_wait(m);
+			if (wrc) return wrc;
+		}
 		m->batch_world = 0;
-		return listBatchStep(m, c, sensor_origin, d_xyz, d_rgb, n, max_range, discrete, false, simple_ray_casting, early_stopping);
+		return listBatchStep(m, c, sensor_origin, d_xyz, d_rgb, n, max_range, discrete, false, simple_ray_casting, early_stopping, depth);
 	}
 	// Joins happen at fixed points of the sequence of calls -- the step two before this one is joined here -- never "when it
 	// happens to be complete": a step that has to be repeated is repeated by all ranks together (a collective).
