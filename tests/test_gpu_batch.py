@@ -138,7 +138,9 @@ def test_fast_path_counter_and_general_path_agree_on_the_bench_sequence():
 
 @pytest.mark.parametrize("opts", [{"solo": 0}, {"solo": 1}, {"lazy_done": 0}, {"lazy_done": 1, "cast_wgs": 64}, {"cast_wgs": 256, "cast_batch": 96, "cast_qcap": 256},
                                   {"cast_threads": 1024, "cast_wgs": 100, "cast_batch": 320}, {"cast_prio": 3, "tstamps": 1},
-                                  {"cast_fused": 2}, {"cast_fused": 2, "cast_wgs": 7, "cast_batch": 64, "cast_qcap": 128}, {"cast_fused": 1}])
+                                  {"cast_fused": 2}, {"cast_fused": 2, "cast_wgs": 7, "cast_batch": 64, "cast_qcap": 128}, {"cast_fused": 1}, {"cast_oct": 0}, {"cast_oct": 0, "cast_fused": 1},
+                                  {"cast_oct": 1, "cast_wgs": 9}, {"cast_oct": 1, "cast_threads": 256}, {"cast_oct": 1, "cast_wgs": 40, "cast2_k": 16},
+                                  {"cast_oct": 1, "cast_wgs": 700, "cast_threads": 256, "cast2_k": 24}])
 def test_scheduling_options_never_change_the_map(opts):
     """How the five kernels are enqueued -- a synchronous call alone on the map stream (solo), the end of a scan half
     published by the next scan's gate kernel (lazy_done), the ray kernel's workgroups / rays per round / segment queue --

@@ -39,6 +39,28 @@
 
 namespace ufo
 {
+// cross-lane moves by DPP (a VALU operand modifier, a few clocks) instead of ds_bpermute (an LDS-unit operation, ~120 clocks): see grpMax below
+template <int CTRL>
+__device__ __forceinline__ u32 dppU(u32 v)
+{
+	return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+template <int CTRL>
+__device__ __forceinline__ float dppF(float v)
+{
+	return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ double dppD(double v)
+{
+	const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+	const u32 lo = dppU<CTRL>((u32)b), hi = dppU<CTRL>((u32)(b >> 32));
+	return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+#define UFO_DPP_X1 0xB1   // quad_perm [1, 0, 3, 2]
+#define UFO_DPP_X2 0x4E   // quad_perm [2, 3, 0, 1]
+#define UFO_DPP_HM 0x141  // row_half_mirror
+#define UFO_DPP_R8 0x128  // row_ror:8
 // Geometry shared by these kernels: the predicted bit grid (Grid::layout 1) and the depth-3 tiles that cover it.
 struct FastGeo {
 	Grid gr;
@@ -59,6 +81,8 @@ struct PointRay {
 	bool cast;    // a ray is cast unless the point loses its voxel to an earlier point (discrete mode)
 	bool hitcand; // the point lies in range: its voxel receives a hit if the point is the first one in it
 	bool odd;     // needs the general path: clipped at the map cube, or outside the predicted grid
+	u32 oct;      // octant of the ray's end cell as seen from the sensor's cell: bit a set = end cell >= sensor cell on axis a (k_fcast4)
+	u32 l1;       // ... and the ray's length in cells (sum over the axes)
 };
 template <bool DISCRETE>
 __device__ inline PointRay pointRay(const MapGeom& g, const FastGeo& fg, const D3& sensor, const double* __restrict__ xyz, const Ingest& ing,
@@ -67,6 +91,8 @@ __device__ inline PointRay pointRay(const MapGeom& g, const FastGeo& fg, const D
 	PointRay r;
 	r.cast = r.hitcand = r.odd = false;
 	r.cell = 0;
+	r.oct = 0;
+	r.l1 = 0;
 	D3 end;
 	if (!loadPoint(xyz, ing, i, &end)) {
 		r.end = end;
@@ -138,6 +164,8 @@ __device__ inline PointRay pointRay(const MapGeom& g, const FastGeo& fg, const D
 		le[a] = ke - fg.gr.base[a];
 		ls[a] = ks - fg.gr.base[a];
 		if (le[a] < 1 || le[a] > mx[a] || ls[a] < 1 || ls[a] > mx[a]) r.odd = true;
+		r.oct |= (le[a] >= ls[a] ? 1u : 0u) << a;
+		r.l1 += (u32)abs(le[a] - ls[a]);
 	}
 	if (r.hitcand && !r.odd) {
 		// the hit voxel: the original point's (== the ray end's voxel in both modes; continuous mode: hit_at == end)
@@ -162,16 +190,23 @@ struct PointRec {
 	u32 cell;   // hit voxel's index in the grid (hit candidates only)
 	u32 flags;  // 1 cast, 2 hit candidate, 4 odd
 };
-template <bool DISCRETE>
+// BIN (round 6, k_fcast4): the records of the points that may cast a ray leave the kernel SORTED BY OCTANT inside every workgroup's
+// 256-point stretch (a counting sort on ballots), with the stretch's eight counts beside them -- a workgroup of the ray kernel takes
+// the rays of ONE octant, whose cells lie in one sub-box of the grid. The record carries the point's index (flags | index << 3).
+template <bool DISCRETE, bool BIN = false>
 __global__ __launch_bounds__(256) void k_fhits(MapGeom g, FastGeo fg, D3 sensor, const double* __restrict__ xyz, u32 n, double max_range,
                                                u32 color_variant, u32* __restrict__ first, BoxPartial* __restrict__ part, ScanCtl* ctl,
                                                Ingest ing, PointRec* __restrict__ recs, double* __restrict__ keep, const uint8_t* __restrict__ rgb_in,
-                                               uint8_t* __restrict__ rgb_keep)
+                                               uint8_t* __restrict__ rgb_keep, uint4* __restrict__ bcnt = nullptr, u32* __restrict__ bwgt = nullptr)
 {
 	const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
 	double amn[3] = {1e300, 1e300, 1e300}, amx[3] = {-1e300, -1e300, -1e300};
 	i32 ck[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, ek[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
 	bool odd = false;
+	PointRec pr;
+	pr.flags = 0;
+	u32 boct = 8u;  // BIN: the octant the point's record goes to (8: no record -- the point casts no ray)
+	u32 bl1 = 0;    // ... and its ray's length in cells
 	if (i < n) {
 		if (keep) {
 			// The caller's cloud is read by THIS kernel only: the point as it enters the head loop (map frame, float64; NaN for a
@@ -190,11 +225,16 @@ __global__ __launch_bounds__(256) void k_fhits(MapGeom g, FastGeo fg, D3 sensor,
 		}
 		const PointRay r = pointRay<DISCRETE>(g, fg, sensor, xyz, ing, i, max_range, color_variant, amn, amx);
 		odd = r.odd;
-		PointRec pr;
 		pr.end = r.end;
 		pr.cell = r.cell;
 		pr.flags = (r.cast ? 1u : 0u) | (r.hitcand ? 2u : 0u) | (r.odd ? 4u : 0u);
-		recs[i] = pr;
+		if (BIN) {
+			pr.flags |= i << 3;
+			if (r.cast && !r.odd) {
+				boct = r.oct;
+				bl1 = min(r.l1, 4095u);
+			}
+		} else recs[i] = pr;
 		if (!r.odd) {
 			if (r.hitcand) atomicMin(&first[r.cell], i);
 			if (r.cast) {
@@ -207,6 +247,40 @@ __global__ __launch_bounds__(256) void k_fhits(MapGeom g, FastGeo fg, D3 sensor,
 		}
 	}
 	if (__ballot(odd) && 0 == (threadIdx.x & 63u)) atomicOr(&ctl->err, ERR_SPEC);
+	if (BIN) {
+		__shared__ u32 wcnt[4][8], wsum[8];
+		const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+		if (threadIdx.x < 8u) wsum[threadIdx.x] = 0;
+		__syncthreads();
+		// (the octant's share of the ray kernel's WORK: the sum of squared lengths -- a point far away casts a long ray AND is likely to
+		// be the first of its voxel; tracks the octants' true DDA steps within ~10 % on LiDAR scans where the counts are off by 3.6x)
+		if (boct < 8u) atomicAdd(&wsum[boct], bl1 * bl1);
+		u64 mine = 0;
+#pragma unroll
+		for (u32 o = 0; o < 8u; ++o) {
+			const u64 mo = __ballot(boct == o);
+			if (boct == o) mine = mo;
+			if (0 == lane) wcnt[wave][o] = (u32)__popcll(mo);
+		}
+		__syncthreads();
+		u32 tot[8];
+#pragma unroll
+		for (u32 o = 0; o < 8u; ++o) tot[o] = wcnt[0][o] + wcnt[1][o] + wcnt[2][o] + wcnt[3][o];
+		if (boct < 8u) {
+			u32 pos = (u32)__popcll(mine & ((1ULL << lane) - 1ULL));
+#pragma unroll
+			for (u32 o = 0; o < 8u; ++o) {
+				if (o < boct) pos += tot[o];
+				if (o == boct)
+					for (u32 w = 0; w < 4u; ++w)
+						if (w < wave) pos += wcnt[w][o];
+			}
+			recs[(size_t)blockIdx.x * 256u + pos] = pr;
+		}
+		if (0 == threadIdx.x) bcnt[blockIdx.x] = make_uint4(tot[0] | (tot[1] << 16), tot[2] | (tot[3] << 16), tot[4] | (tot[5] << 16), tot[6] | (tot[7] << 16));
+		if (threadIdx.x < 8u) bwgt[8u * blockIdx.x + threadIdx.x] = wsum[threadIdx.x];
+		__syncthreads();  // (blockBoxReduce's shared arrays follow)
+	}
 	i32 none_lo[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, none_hi[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
 	blockBoxReduce(part, 7u, amn, amx, none_lo, none_hi, ck, ek);  // (folded by k_fmerge's last workgroup)
 }
@@ -325,6 +399,43 @@ __device__ inline void foldBoxes(const BoxPartial* __restrict__ boxes, u32 nboxe
 	}
 }
 
+// ---- octant sub-boxes of a ray grid around the sensor's cell (k_fcast4, below) ----
+struct OctGeo {
+	u32 s[3];            // the sensor's cell, local to the ray grid
+	u32 xw0[2], nxw[2];  // per x bit of the octant: first 32-bit word of a sub-row, words per sub-row
+	u32 y0[2], ny[2], z0[2], nz[2];
+	u32 wmax4;           // the largest sub-box, in 16-byte units
+};
+__host__ __device__ inline u32 octWords4(const OctGeo& og, u32 o) { return (og.nxw[o & 1u] * og.ny[(o >> 1) & 1u] * og.nz[o >> 2] + 3u) >> 2; }
+__host__ __device__ inline bool makeOctGeo(const MapGeom& g, const FastGeo& fg, const D3& sensor, OctGeo* og)
+{
+	const u32 n[3] = {2u * (u32)fg.gr.nb[0], 2u * (u32)fg.gr.nb[1], 2u * (u32)fg.gr.nb[2]};
+	for (int a = 0; a < 3; ++a) {
+		const long long c = (long long)toKey1(g, sensor[a], 0) - (long long)fg.gr.base[a];
+		if (c < 0 || c >= (long long)n[a]) return false;  // (the scan will be flagged: the sensor lies outside its predicted grid)
+		og->s[a] = (u32)c;
+	}
+	og->xw0[0] = 0;
+	og->nxw[0] = (og->s[0] >> 5) + 1u;
+	og->xw0[1] = og->s[0] >> 5;
+	og->nxw[1] = ((n[0] - 1u) >> 5) - og->xw0[1] + 1u;
+	og->y0[0] = 0;
+	og->ny[0] = og->s[1] + 1u;
+	og->y0[1] = og->s[1];
+	og->ny[1] = n[1] - og->s[1];
+	og->z0[0] = 0;
+	og->nz[0] = og->s[2] + 1u;
+	og->z0[1] = og->s[2];
+	og->nz[1] = n[2] - og->s[2];
+	og->wmax4 = 0;
+	for (u32 o = 0; o < 8u; ++o) og->wmax4 = max(og->wmax4, octWords4(*og, o));
+	return true;
+}
+struct OctTab {  // left by workgroup 0 of the ray kernel for k_fmerge
+	OctGeo og;
+	u32 wg_start[9];   // workgroups wg_start[o] .. wg_start[o + 1] - 1 took octant o
+	u32 slab_off4[9];  // where the first of them stored its sub-box, in 16-byte units
+};
 // ---- scans as the tree update sees them (who applies which scan: see k_claim below) ----
 #define UFO_RING 16u       // scans in flight per handle (a power of two, > the number of hand-over sets)
 #define UFO_BATCH_MAX 16u  // scans per walk
@@ -345,6 +456,7 @@ struct ScanDesc {  // a scan as the tree update sees it: written into the ring w
 	u32 pad;
 	const uint8_t* rgb;                  // colour maps: the points' colours (3 bytes each; nullptr: a cloud without colours). The walk
 	                                     // then reads `first` itself (the colour of a voxel's first point, OMC.h:195-233) and cleans it
+	const OctTab* oct;                   // k_fcast4: the slabs are octant sub-boxes -- the table its first workgroup left (nullptr: copies of the whole grid)
 };
 struct Pipe {
 	unsigned long long scan_done;  // fast-path number of the newest scan whose scan half has finished (the scan stream works them off in order)
@@ -965,6 +1077,468 @@ __global__ __launch_bounds__(1024) void k_fcast3(MapGeom g, FastGeo fg, D3 senso
 }
 
 // ------------------------------------------------------------------------------------------------
+// F2''' (round 6): OCTANT SUB-BOXES. Every ray of a scan starts at the sensor, so the cells of a ray lie in the box spanned by the
+// sensor's cell and the ray's end cell -- inside ONE of the eight sub-boxes the sensor's cell cuts the ray grid into (the sensor's
+// row / plane belongs to both sides; x in whole 32-bit words). k_fcast2/3 keep the WHOLE grid in a workgroup's LDS (82 KB of 148:
+// one workgroup per CU) and hand 192 copies of it to the tree update: 20 MB written and read back for 0.1 MB of grid -- the largest
+// waste of the scan. Here k_fhits leaves the points' records sorted by octant (per 256-point stretch, with the
+// stretch's eight counts), a workgroup of the ray kernel takes rays of one octant and keeps only that octant's sub-box in LDS
+// (10-20 KB: two or three workgroups per CU, each with its own segment queue), and what it hands over is the sub-box: a few MB per scan.
+//   * which workgroups take which octant is decided IN the kernel, from the scan's own counts (every workgroup adds up the stretches'
+//     counts -- 8 KB -- and splits the launch in proportion, at least one workgroup per octant that has points): a LiDAR looks down,
+//     its upper four octants hold 7 % of the rays; workgroup 0 leaves the table (first workgroup and slab offset per octant) for k_fmerge;
+//   * workgroup j of an octant's n takes the stretches j, j + n, ...: their records of the octant are contiguous, the first pass looks
+//     at them and lists the survivors (k_fcast3), then set-up, cuts, queue, walk as there -- with the sub-box's strides.
+// Same cells, same step count.
+// ------------------------------------------------------------------------------------------------
+// The launch's G workgroups split over the octants in proportion to their work (tot: k_fhits' sums of squared ray lengths), at least one
+// per octant that has any; the same arithmetic in every workgroup.
+__device__ inline void octAllocate(const unsigned long long tot[8], u32 G, const OctGeo& og, u32 wg_start[9], u32 slab_off4[9])
+{
+	unsigned long long T = 0;
+	u32 nzo = 0, big = 0;
+	for (u32 o = 0; o < 8u; ++o) {
+		T += tot[o];
+		nzo += tot[o] ? 1u : 0u;
+		if (tot[o] > tot[big]) big = o;
+	}
+	u32 nw[8], sum = 0;
+	for (u32 o = 0; o < 8u; ++o) {
+		nw[o] = tot[o] ? 1u + (u32)((double)(G - nzo) * ((double)tot[o] / (double)T)) : 0u;  // (rounded down: what is left goes to the largest)
+		sum += nw[o];
+	}
+	if (T) nw[big] += G - sum;  // (what the rounding left)
+	u32 ws = 0, so = 0;
+	for (u32 o = 0; o < 8u; ++o) {
+		wg_start[o] = ws;
+		slab_off4[o] = so;
+		ws += nw[o];
+		so += nw[o] * octWords4(og, o);
+	}
+	wg_start[8] = ws;
+	slab_off4[8] = so;
+}
+template <bool DISCRETE>
+__global__ __launch_bounds__(512) void k_fcast4(MapGeom g, FastGeo fg, D3 sensor, OctGeo og, u32 nsrc, const uint4* __restrict__ bcnt, const u32* __restrict__ bwgt,
+                                               const PointRec* __restrict__ brecs, const u32* __restrict__ first, uint4* __restrict__ slabs, OctTab* __restrict__ tab, u32 K,
+                                               const ScanCtl* ctl_in, ScanCtl* ctl, unsigned long long* __restrict__ steps_part, u32 rcap, u32 qcap, u32 lcap, u32 prio,
+                                               Pipe* solo, ScanDesc solo_desc)
+{
+	if (solo && 0 == (threadIdx.x | blockIdx.x)) {
+		solo->ring[0] = solo_desc;
+		solo->slot[0].first = 0;
+		solo->slot[0].B = 1;
+	}
+	if (prio >= 3u) __builtin_amdgcn_s_setprio(3);
+	else if (2u == prio) __builtin_amdgcn_s_setprio(2);
+	else if (1u == prio) __builtin_amdgcn_s_setprio(1);
+	extern __shared__ __attribute__((aligned(16))) u32 lds[];
+	const u32 err_in = ctl_in->err;  // (looked at once the LDS grid has been cleared: the load is in flight meanwhile)
+	if (0 == (threadIdx.x | blockIdx.x)) ctl->dbg[30] = wall_clock64();  // (diagnostics)
+	const Grid& gr = fg.gr;
+	const u32 lds_words = og.wmax4 * 4u;
+	RayConst* rc = reinterpret_cast<RayConst*>(lds + lds_words);
+	SegRec* q = reinterpret_cast<SegRec*>(rc + rcap);
+	u32* wl = reinterpret_cast<u32*>(q + qcap);  // the window's survivors: indices of their records
+	u32* srcb = wl + lcap;                        // per stretch of the cloud: where the octant's records start ...
+	u32* srcp = srcb + ((nsrc + 2u) & ~1u);       // ... and how many records of the octant lie before the stretch ([nsrc]: all of them)
+	unsigned long long* wtot = reinterpret_cast<unsigned long long*>(srcp + ((nsrc + 2u) & ~1u));  // [8] the octants' work
+	u32* sh = reinterpret_cast<u32*>(wtot + 8);  // [0] rays of the round, [1] queue entries asked for, [2] first entry refused, [3] rays cast, [4] voxels hit,
+	                                             // [5] survivors, [6] running prefix, [8..12] diagnostics, [24..39] wave totals of the prefix
+	const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+	{
+		uint4* l4 = reinterpret_cast<uint4*>(lds);
+		for (u32 j4 = threadIdx.x; j4 < og.wmax4; j4 += blockDim.x) l4[j4] = make_uint4(0, 0, 0, 0);
+	}
+	if (threadIdx.x < 40u) sh[threadIdx.x] = (2u == threadIdx.x) ? 0xFFFFFFFFu : 0u;
+	if (threadIdx.x < 8u) wtot[threadIdx.x] = 0ull;
+	if (err_in) return;  // the scan does not fit the predicted grid (k_fhits): it will be repeated (uniform exit)
+	__syncthreads();
+	// ---- the octants' work (k_fhits: sums of squared ray lengths per stretch and octant) ----
+	for (u32 w0 = 0; w0 < nsrc; w0 += blockDim.x) {  // (uniform)
+		const u32 wv = w0 + threadIdx.x;
+		if (wv < nsrc) {
+			const uint4 wa = reinterpret_cast<const uint4*>(bwgt)[2u * wv], wb = reinterpret_cast<const uint4*>(bwgt)[2u * wv + 1u];
+			const u32 v8[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+#pragma unroll
+			for (u32 o = 0; o < 8u; ++o)
+				if (v8[o]) atomicAdd(&wtot[o], (unsigned long long)v8[o]);
+		}
+	}
+	__syncthreads();
+	if (0 == (threadIdx.x | blockIdx.x)) ctl->dbg[31] = wall_clock64();  // (diagnostics)
+	u32 wg_start[9], slab_off4[9];
+	{
+		unsigned long long tot[8];
+		for (u32 o = 0; o < 8u; ++o) tot[o] = wtot[o];
+		octAllocate(tot, gridDim.x, og, wg_start, slab_off4);
+	}
+	if (0 == blockIdx.x && threadIdx.x < 9u) {
+		if (0 == threadIdx.x) tab->og = og;
+		tab->wg_start[threadIdx.x] = wg_start[threadIdx.x];
+		tab->slab_off4[threadIdx.x] = slab_off4[threadIdx.x];
+	}
+	u32 oct = 0;
+	for (u32 o = 1; o < 8u; ++o)
+		if (blockIdx.x >= wg_start[o]) oct = o;  // (the last octant whose first workgroup is at or below this one: empty octants share their successor's start)
+	const u32 jwg = blockIdx.x - wg_start[oct], nwg = wg_start[oct + 1u] - wg_start[oct];
+	// the sub-box: a cell's bit is (x - 32 xw0) + rowBits ((y - y0) + ny (z - z0))
+	const u32 ox = oct & 1u, oy = (oct >> 1) & 1u, oz = oct >> 2;
+	const u32 bx0 = 32u * og.xw0[ox], rowBits = 32u * og.nxw[ox], by0 = og.y0[oy], bny = og.ny[oy], bz0 = og.z0[oz], bnz = og.nz[oz];
+	const u32 planeBits = rowBits * bny;
+	auto subLin = [&](u32 x, u32 y, u32 z) -> u32 {  // (0xFFFFFFFF: outside the sub-box)
+		const u32 dx = x - bx0, dy = y - by0, dz = z - bz0;
+		return (dx < rowBits && dy < bny && dz < bnz) ? dx + rowBits * (dy + bny * dz) : 0xFFFFFFFFu;
+	};
+	// ---- the octant's records across the cloud: stretch wv holds cnt of them from record 256 wv + st; srcp = how many lie before ----
+	for (u32 w0 = 0; w0 < nsrc; w0 += blockDim.x) {  // (uniform)
+		const u32 wv = w0 + threadIdx.x;
+		u32 cnt_e = 0, st = 0;
+		if (wv < nsrc) {
+			const uint4 c = bcnt[wv];
+			const u32 v8[8] = {c.x & 0xFFFFu, c.x >> 16, c.y & 0xFFFFu, c.y >> 16, c.z & 0xFFFFu, c.z >> 16, c.w & 0xFFFFu, c.w >> 16};
+#pragma unroll
+			for (u32 o = 0; o < 8u; ++o) {
+				if (o < oct) st += v8[o];
+				if (o == oct) cnt_e = v8[o];
+			}
+			srcb[wv] = wv * 256u + st;
+		}
+		u32 scan = cnt_e;
+		for (int o2 = 1; o2 < 64; o2 <<= 1) {
+			const u32 up = __shfl_up(scan, o2);
+			if ((int)lane >= o2) scan += up;
+		}
+		if (63u == lane) sh[24u + wave] = scan;
+		__syncthreads();
+		u32 before = sh[6], total = 0;
+		for (u32 wv2 = 0; wv2 < nwaves; ++wv2) {
+			const u32 v = sh[24u + wv2];
+			if (wv2 < wave) before += v;
+			total += v;
+		}
+		if (wv < nsrc) srcp[wv] = before + scan - cnt_e;
+		__syncthreads();
+		if (0 == threadIdx.x) sh[6] += total;
+	}
+	__syncthreads();
+	const u32 npts_oct = sh[6];
+	if (0 == threadIdx.x) srcp[nsrc] = npts_oct;
+	unsigned long long steps = 0;
+	u32 err = 0, oob = 0, ncast = 0, nhit = 0;
+	bool first_pass = true;
+	// this workgroup's records: jwg, jwg + nwg, ... of the octant's -- neighbouring rays go to different workgroups, every workgroup
+	// sees the octant's mix of lengths (as k_fcast2 / 3 take every gridDim-th point of the cloud)
+	const u32 nmine = (nwg && npts_oct > jwg) ? (npts_oct - jwg + nwg - 1u) / nwg : 0u;
+	{
+		for (u32 f0 = 0; f0 < nmine; f0 += lcap) {  // (uniform; the steady state: one window)
+			// ---- who casts a ray: this workgroup's records f0 .. f0 + lcap - 1 ----
+			const u32 fend = min(nmine, f0 + lcap);
+			for (u32 fb = f0; fb < fend; fb += blockDim.x) {  // (uniform)
+				const u32 mf = fb + threadIdx.x;
+				bool cast = false;
+				u32 ri = 0;
+				if (mf < fend) {
+					const u32 kf = jwg + mf * nwg;
+					// the stretch that holds record kf of the octant: the last one with srcp <= kf
+					u32 lo = 0, hi = nsrc;
+					while (hi - lo > 1u) {
+						const u32 mid = (lo + hi) >> 1;
+						if (srcp[mid] <= kf) lo = mid;
+						else hi = mid;
+					}
+					ri = srcb[lo] + (kf - srcp[lo]);
+					const PointRec pr = brecs[ri];  // (k_fhits ran the head loop on the point: a record is a point that may cast a ray)
+					const u32 i = pr.flags >> 3;
+					cast = true;
+					if (pr.flags & 2u) {
+						// (the voxel receives a hit, OMB:295, 358-360: its first point's; k_fmerge derives the hit grid from the array)
+						const bool winner = first[pr.cell] == i;
+						nhit += winner ? 1u : 0u;
+						if (DISCRETE && !winner) cast = false;  // OMB:358-360: dropped entirely, no ray
+					}
+				}
+				const u64 mb = __ballot(cast);
+				u32 base = 0;
+				if (0 == lane && mb) base = atomicAdd(&sh[5], (u32)__popcll(mb));
+				base = __shfl(base, 0);
+				if (cast) wl[base + (u32)__popcll(mb & ((1ULL << lane) - 1ULL))] = ri;
+			}
+			__syncthreads();
+			const u32 nw = sh[5];
+			if (0 == (threadIdx.x | blockIdx.x) && first_pass) ctl->dbg[32] = wall_clock64();  // (diagnostics)
+			// ---- lane t: survivors t, t + blockDim, ... -- one per round; a ray that finds the queue full stays with its lane until the next ----
+			u32 wcur = threadIdx.x;
+			bool pending = false;
+			RayState r;
+			r.status = 0;
+			u32 ax = 0, w = 1, nseg = 0, lin0 = 0, glin = 0;
+			i32 dla = 0, dl0 = 0, dl1 = 0;
+			for (u32 round = 0;; ++round) {  // (uniform: a round = set-up and cuts, barrier, walk, barrier)
+				const unsigned long long tq0 = clock64();
+				if (!pending && wcur < nw) {
+					const u32 ri = wl[wcur];
+					wcur += blockDim.x;
+					const D3 end = brecs[ri].end;
+					++ncast;
+					raySetup(g, sensor, 0u, gr, end, r);
+					if (1 == r.status) {
+						// (start == goal: the sensor's own cell, which every octant's sub-box holds)
+						const u32 sl = subLin((u32)(r.start[0] - gr.base[0]), (u32)(r.start[1] - gr.base[1]), (u32)(r.start[2] - gr.base[2]));
+						if (0xFFFFFFFFu == sl) err |= ERR_GRID_OOB;
+						else atomicOr(&lds[sl >> 5], 1u << (sl & 31u));
+						steps += 1;
+					} else if (3 == r.status) {
+						err |= ERR_GRID_OOB;  // cannot happen: pointRay admits only rays inside the grid's interior
+					} else if (2 == r.status) {
+						const u32 dxn = (u32)abs((i32)(r.gpk & 1023u) - (i32)(r.pk0 & 1023u));
+						const u32 dyn = (u32)abs((i32)((r.gpk >> 10) & 1023u) - (i32)((r.pk0 >> 10) & 1023u));
+						const u32 dzn = (u32)abs((i32)(r.gpk >> 20) - (i32)(r.pk0 >> 20));
+						ax = (dxn >= dyn && dxn >= dzn) ? 0u : (dyn >= dzn ? 1u : 2u);
+						const u32 dmax = ax == 0 ? dxn : (ax == 1 ? dyn : dzn);
+						const u32 l1 = dxn + dyn + dzn;
+						w = (u32)(((u64)dmax * K) / l1);
+						if (w < 1u) w = 1u;
+						nseg = (dmax + w - 1u) / w;  // >= 1 (start and goal differ)
+						lin0 = subLin(r.pk0 & 1023u, (r.pk0 >> 10) & 1023u, r.pk0 >> 20);
+						glin = subLin(r.gpk & 1023u, (r.gpk >> 10) & 1023u, r.gpk >> 20);
+						if (0xFFFFFFFFu == lin0 || 0xFFFFFFFFu == glin) {  // (cannot happen: k_fhits sorted the ray into the octant of its end cell)
+							err |= ERR_GRID_OOB;
+							nseg = qcap + 1u;
+						}
+						const i32 dlx = (i32)r.s[0], dly = (i32)r.s[1] * (i32)rowBits, dlz = (i32)r.s[2] * (i32)planeBits;
+						dla = ax == 0 ? dlx : (ax == 1 ? dly : dlz);
+						dl0 = ax == 0 ? dly : dlx;
+						dl1 = ax == 2 ? dly : dlz;
+						if (nseg > qcap) err |= ERR_GRID_OOB;  // (cannot happen: a ray inside a grid of < 1024 cells per axis has at most ~100 segments)
+						else pending = true;
+					}
+				}
+				const unsigned long long tq1 = clock64() + (unsigned long long)(77 == r.status ? 1 : 0);
+				// room for the ray's constants and its segments, or the next round: ONE reservation per wave -- every lane of the wave is here
+				u32 slot = 0xFFFFFFFFu, off = 0xFFFFFFFFu;
+				{
+					const u64 am = __ballot(pending);
+					u32 slot0 = 0;
+					if (0 == lane && am) slot0 = atomicAdd(&sh[0], (u32)__popcll(am));
+					slot0 = __shfl(slot0, 0);
+					if (pending) slot = slot0 + (u32)__popcll(am & ((1ULL << lane) - 1ULL));
+					const u32 want = (pending && slot < rcap) ? nseg : 0u;  // (a ray without room for its constants asks for no queue entries)
+					u32 scan = want;
+					for (int o = 1; o < 64; o <<= 1) {
+						const u32 up = __shfl_up(scan, o);
+						if ((int)lane >= o) scan += up;
+					}
+					const u32 total = __shfl(scan, 63);
+					u32 off0 = 0;
+					if (0 == lane && total) off0 = atomicAdd(&sh[1], total);
+					off0 = __shfl(off0, 0);
+					if (want) {
+						off = off0 + scan - want;
+						if (off + nseg > qcap) {
+							atomicMin(&sh[2], off);  // (every entry from here on belongs to a ray that was refused)
+							off = 0xFFFFFFFFu;
+						}
+					}
+				}
+				if (0xFFFFFFFFu != off) {
+					pending = false;
+					RayConst c;
+					c.td[0] = r.td[0];
+					c.td[1] = r.td[1];
+					c.td[2] = r.td[2];
+					c.dist = r.dist;
+					c.dl[0] = (i32)r.s[0];
+					c.dl[1] = (i32)r.s[1] * (i32)rowBits;
+					c.dl[2] = (i32)r.s[2] * (i32)planeBits;
+					c.glin = glin;
+					rc[slot] = c;
+					// the three chains (k_fcast2 / vol_kernels.h: k_vcut). a* = the dominant axis, b0 < b1 the two others; after k0 pops of a* element
+					// A[k0 - 1] (= v) was popped and t_max_a* = A[k0]; of axis b the elements before v were popped -- strictly smaller, or
+					// equal when b wins the tie (b < a*, vector3.h:244-251)
+					double ta = ax == 0 ? r.tm[0] : (ax == 1 ? r.tm[1] : r.tm[2]), v = ta;
+					const double tda = ax == 0 ? r.td[0] : (ax == 1 ? r.td[1] : r.td[2]);
+					double t0 = ax == 0 ? r.tm[1] : r.tm[0], t1 = ax == 2 ? r.tm[1] : r.tm[2];
+					const double d0 = ax == 0 ? r.td[1] : r.td[0], d1 = ax == 2 ? r.td[1] : r.td[2];
+					const bool pri0 = ax != 0u, pri1 = ax == 2u;
+					u32 n0 = 0, n1 = 0, guard = 0;
+					auto advance = [&](double& tb, const double dbt, const double inv, const bool pri, u32& cb) {
+						const double est = (v - tb) * inv;  // (negative, NaN or huge for an axis the ray does not move along: no skip)
+						u32 kk = (est > 2.0 && est < 4096.0) ? (u32)est - 1u : 0u;  // an element of margin: repeated rounding moves a sum by a few ulp, not by an element -- and the check below decides
+						if (kk) {
+							const u32 k0 = kk;
+							double sv = tb, prev = tb;
+							for (; kk >= 4u; kk -= 4u) {
+								const double s1 = sv + dbt, s2 = s1 + dbt, s3 = s2 + dbt;
+								prev = s3;
+								sv = s3 + dbt;
+							}
+							for (; kk > 0u; --kk) {
+								prev = sv;
+								sv = sv + dbt;
+							}
+							if (pri ? (prev <= v) : (prev < v)) {  // (else: the estimate was too high -- everything one by one, below)
+								tb = sv;
+								cb += k0;
+							}
+						}
+						bool e = true;
+	#pragma unroll
+						for (int u = 0; u < 3; ++u) {
+							e = e & (pri ? (tb <= v) : (tb < v));
+							const double nt = tb + dbt;
+							tb = e ? nt : tb;
+							cb += e ? 1u : 0u;
+						}
+						while (e) {
+							e = pri ? (tb <= v) : (tb < v);
+							if (e) {
+								tb = tb + dbt;
+								cb += 1u;
+								if (++guard > 4096u) {
+									err |= ERR_RUNAWAY;  // (cannot trip inside a grid of < 1024 cells per axis)
+									break;
+								}
+							}
+						}
+					};
+					const double i0 = 1.0 / d0, i1 = 1.0 / d1;
+					u32 lin = lin0;
+					for (u32 j = 0; j < nseg; ++j) {
+						if (j > 0u) {
+							u32 np = w;
+							for (; np >= 4u; np -= 4u) {  // (the same sequence of additions, four at a time)
+								const double a1 = ta + tda, a2 = a1 + tda, a3 = a2 + tda;
+								v = a3;
+								ta = a3 + tda;
+							}
+							for (; np > 0u; --np) {
+								v = ta;
+								ta = ta + tda;
+							}
+							advance(t0, d0, i0, pri0, n0);
+							advance(t1, d1, i1, pri1, n1);
+							lin = lin0 + (u32)((i32)(j * w) * dla + (i32)n0 * dl0 + (i32)n1 * dl1);
+							q[off + j - 1u].end = lin;  // the segment before ends where this one starts
+						}
+						SegRec rec;
+						rec.tm[0] = ax == 0 ? ta : t0;
+						rec.tm[1] = ax == 0 ? t0 : (ax == 1 ? ta : t1);
+						rec.tm[2] = ax == 2 ? ta : t1;
+						rec.lin = lin;
+						rec.end = glin;
+						rec.ray = slot | (0u == j ? 0x80000000u : 0u);
+						rec.pad = 0;
+						q[off + j] = rec;
+					}
+				}
+				if (0 == round && first_pass && 0 == blockIdx.x) {  // (diagnostics: the slowest lane's clocks in set-up and cuts, workgroup 0)
+					u32 d0c = (u32)(tq1 - tq0), d1c = (u32)(clock64() - tq1);
+					for (int o = 32; o > 0; o >>= 1) {
+						d0c = max(d0c, (u32)__shfl_xor((int)d0c, o));
+						d1c = max(d1c, (u32)__shfl_xor((int)d1c, o));
+					}
+					if (0 == lane) {
+						atomicMax(&sh[8], d0c);
+						atomicMax(&sh[9], d1c);
+					}
+				}
+				__syncthreads();
+				if (0 == (threadIdx.x | blockIdx.x) && 0 == round && first_pass) {  // (diagnostics)
+					ctl->dbg[35] = wall_clock64();
+					ctl->dbg[40] = sh[8];
+					ctl->dbg[41] = sh[9];
+				}
+				const u32 nsegs = min(min(sh[1], sh[2]), qcap);
+				// ---- every lane walks segments ----
+				const unsigned long long tw0 = clock64();
+				u32 wmaxc = 0;
+				for (u32 si = threadIdx.x; si < nsegs; si += blockDim.x) {
+					const SegRec rec = q[si];
+					const RayConst c = rc[rec.ray & 0x7FFFFFFFu];
+					double tmx = rec.tm[0], tmy = rec.tm[1], tmz = rec.tm[2];
+					const double tdx = c.td[0], tdy = c.td[1], tdz = c.td[2];
+					const long long idist = __double_as_longlong(c.dist);
+					const i32 dlx = c.dl[0], dly = c.dl[1], dlz = c.dl[2];
+					const u32 end = rec.end;
+					u32 lin = rec.lin;
+					bool go = (0 != (rec.ray & 0x80000000u)) ||
+					          ((lin != c.glin) && ((__double_as_longlong(tmx) <= idist) | (__double_as_longlong(tmy) <= idist) | (__double_as_longlong(tmz) <= idist)));
+					u32 cnt = 0;
+					while (go) {
+						++cnt;
+						atomicOr(&lds[lin >> 5], 1u << (lin & 31u));
+						const bool cxy = tmx <= tmy, cxz = tmx <= tmz, cyz = tmy <= tmz;
+						const bool selx = cxy & cxz;
+						const bool sely = !cxy & cyz;
+						const bool selz = !(selx | sely);
+						lin += (u32)(selx ? dlx : (sely ? dly : dlz));
+						const double nx = tmx + tdx, ny = tmy + tdy, nz = tmz + tdz;
+						tmx = selx ? nx : tmx;
+						tmy = sely ? ny : tmy;
+						tmz = selz ? nz : tmz;
+						const bool more = (__double_as_longlong(tmx) <= idist) | (__double_as_longlong(tmy) <= idist) | (__double_as_longlong(tmz) <= idist);
+						go = (lin != end) & more & (cnt < 4096u);
+					}
+					if (cnt >= 4096u) err |= ERR_RUNAWAY;  // (a segment is ~K steps by construction)
+					steps += cnt;
+					wmaxc = max(wmaxc, cnt);
+				}
+				if (0 == round && first_pass && 0 == blockIdx.x) {  // (diagnostics)
+					u32 dwc = (u32)(clock64() - tw0);
+					for (int o = 32; o > 0; o >>= 1) {
+						dwc = max(dwc, (u32)__shfl_xor((int)dwc, o));
+						wmaxc = max(wmaxc, (u32)__shfl_xor((int)wmaxc, o));
+					}
+					if (0 == lane) {
+						atomicMax(&sh[10], dwc);
+						atomicMax(&sh[11], wmaxc);
+						sh[12] = nsegs;
+					}
+				}
+				const int more_rounds = __syncthreads_or((pending || wcur < nw) ? 1 : 0);  // (the queue and the counters are no longer read)
+				if (threadIdx.x < 3u) sh[threadIdx.x] = (2u == threadIdx.x) ? 0xFFFFFFFFu : 0u;
+				if (!more_rounds) break;
+				__syncthreads();
+			}
+			if (0 == threadIdx.x) sh[5] = 0;
+			first_pass = false;
+			__syncthreads();  // (the list and the counters are free for the next window)
+		}
+	}
+	for (int o2 = 32; o2 > 0; o2 >>= 1) {
+		nhit += __shfl_xor(nhit, o2);
+		ncast += __shfl_xor(ncast, o2);
+	}
+	if (0 == lane && nhit) atomicAdd(&sh[4], nhit);
+	if (0 == lane && ncast) atomicAdd(&sh[3], ncast);
+	__syncthreads();
+	if (0 == (threadIdx.x | blockIdx.x)) {  // (diagnostics)
+		ctl->dbg[36] = wall_clock64();
+		ctl->dbg[42] = sh[10];
+		ctl->dbg[43] = sh[11];
+		ctl->dbg[39] = sh[12];
+	}
+	if (0 == threadIdx.x) {
+		// per-workgroup partials, folded by k_fmerge (hundreds of workgroups adding to one word serialise at ~12 ns each)
+		steps_part[gridDim.x + blockIdx.x] = sh[3];
+		steps_part[2u * gridDim.x + blockIdx.x] = sh[4];
+	}
+	if (nwg) {
+		// the sub-box to its place among the octant's slabs
+		const u32 w4 = octWords4(og, oct);
+		const uint4* l4 = reinterpret_cast<const uint4*>(lds);
+		uint4* out4 = slabs + (size_t)slab_off4[oct] + (size_t)jwg * w4;
+		for (u32 j4 = threadIdx.x; j4 < w4; j4 += blockDim.x) out4[j4] = l4[j4];
+	}
+	if (0 == (threadIdx.x | blockIdx.x)) ctl->dbg[37] = wall_clock64();  // (diagnostics)
+	blockStoreSteps(steps, steps_part);
+	if (oob) atomicAdd(&ctl->n_oob, oob);
+	if (err) atomicOr(&ctl->err, err);
+	if (0 == (threadIdx.x | blockIdx.x)) ctl->dbg[38] = wall_clock64();  // (diagnostics)
+}
+
+// ------------------------------------------------------------------------------------------------
 // F2s: the ray kernel of the fast path for SIMPLE ray casting (freeSpaceSimple, occupancy_map_base.h:1303-1339; the server's
 // `simple_ray_casting` switch): n = int(distance / size) fixed steps of dir * size from the ray's end towards the sensor,
 // the cell of every point on the way -- three independent chains of repeated additions per ray, no DDA state, at most a
@@ -1235,6 +1809,36 @@ __global__ __launch_bounds__(1024) void k_fmerge(FastGeo fg, const Pipe* __restr
 			if (j < n4 && noslab) {
 				if (0 == sl16) acc = grid[j];
 			} else if (j < n4) {
+				if (d.oct) {
+					// (k_fcast4: a word of the grid lies in the sub-box of one octant -- of up to eight on the sensor's row / plane / word --
+					// and only that octant's workgroups have a copy of it: sixteen slab lanes share them)
+					const OctTab* ot = d.oct;
+					const OctGeo og = ot->og;
+					const u32* sw = reinterpret_cast<const u32*>(slabs);
+					const u32 sxw = og.s[0] >> 5, nzf = 2u * (u32)fg.gr.nb[2];
+					u32 accw[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+					for (u32 k = 0; k < 4u; ++k) {
+						const u32 widx = 4u * j + k;
+						const u32 row = widx / rowW, wx = widx - row * rowW;
+						const u32 z = row / ny, y = row - z * ny;
+						if (z >= nzf) continue;  // (padding behind the last row)
+						// which sides of the sensor's word / row / plane the word lies on (the sensor's own belong to both)
+						const u32 ax = (wx <= sxw ? 1u : 0u) | (wx >= sxw ? 2u : 0u), ay = (y <= og.s[1] ? 1u : 0u) | (y >= og.s[1] ? 2u : 0u),
+						          az = (z <= og.s[2] ? 1u : 0u) | (z >= og.s[2] ? 2u : 0u);
+						for (u32 o = 0; o < 8u; ++o) {
+							const u32 ox = o & 1u, oy = (o >> 1) & 1u, oz = o >> 2;
+							if (!((ax >> ox) & (ay >> oy) & (az >> oz) & 1u)) continue;
+							const u32 nw = ot->wg_start[o + 1u] - ot->wg_start[o];
+							if (0 == nw) continue;
+							const u32 sub = (wx - og.xw0[ox]) + og.nxw[ox] * ((y - og.y0[oy]) + og.ny[oy] * (z - og.z0[oz]));
+							const size_t w4x4 = 4u * (size_t)octWords4(og, o);
+							const u32* base = sw + 4u * (size_t)ot->slab_off4[o] + sub;
+							for (u32 jj = sl16; jj < nw; jj += 16u) accw[k] |= base[(size_t)jj * w4x4];
+						}
+					}
+					acc = make_uint4(accw[0], accw[1], accw[2], accw[3]);
+				} else
 				// (asking for four slabs' words at a time was measured and lost: 13.3 -> 16.3 us by events, 15.3 -> 21.6 under rocprofv3)
 				for (u32 s = sl16; s < n_slabs; s += 16u) {
 					const uint4 a = slabs[(size_t)s * n4 + j];
@@ -1405,27 +2009,6 @@ __device__ inline u32 flagsOf(const MapGeom& g, float v) { return (isFreeV(g, v)
 // few clocks: xor 1 / xor 2 = quad_perm, "the other quad of my eight" = row_half_mirror (lane i <-> 7 - i: any pairing that joins the
 // two quads serves a reduction whose quads are already reduced), xor 8 = row_ror:8. Only the steps across rows (xor 16, xor 32) stay
 // shuffles. Every lane of the wave must be active (all callers: uniform control flow).
-template <int CTRL>
-__device__ __forceinline__ u32 dppU(u32 v)
-{
-	return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
-}
-template <int CTRL>
-__device__ __forceinline__ float dppF(float v)
-{
-	return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
-}
-template <int CTRL>
-__device__ __forceinline__ double dppD(double v)
-{
-	const unsigned long long b = (unsigned long long)__double_as_longlong(v);
-	const u32 lo = dppU<CTRL>((u32)b), hi = dppU<CTRL>((u32)(b >> 32));
-	return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
-#define UFO_DPP_X1 0xB1   // quad_perm [1, 0, 3, 2]
-#define UFO_DPP_X2 0x4E   // quad_perm [2, 3, 0, 1]
-#define UFO_DPP_HM 0x141  // row_half_mirror
-#define UFO_DPP_R8 0x128  // row_ror:8
 __device__ __forceinline__ float grpMax(float v, int sh)
 {
 	if (0 == sh) {

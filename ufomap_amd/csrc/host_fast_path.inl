@@ -167,7 +167,7 @@ int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, si
 	HIP_TRY(m->b_gridM.reserve(fg.gr.bytes));
 	HIP_TRY(m->b_gridH.reserve(fg.gr.bytes));  // hit voxels, the ray grid's layout: zeroed by k_fhits, marked by k_fcast, read by k_tile
 	m->hit_grid = true;
-	HIP_TRY(m->b_hit_code.reserve(n * sizeof(PointRec)));  // (per-point records of the head loop: k_fhits -> k_fcast)
+	HIP_TRY(m->b_hit_code.reserve(((n + 255) / 256) * 256 * sizeof(PointRec)));  // (per-point records of the head loop: k_fhits -> k_fcast; whole 256-point stretches)
 	// a cloud in the caller's device memory (or raw records) is kept as float64 points for a possible repeat of the scan; a
 	// host cloud already lies in the set's own staging buffer
 	double* keep = nullptr;
@@ -208,14 +208,47 @@ int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, si
 	m->ctl_clean = false;  // (until that scan's tree update has been joined and found clean)
 	const dim3 gp((N + 255) / 256);
 	HIP_TRY(m->b_part1.reserve((size_t)gp.x * sizeof(BoxPartial)));
+	// Round 6: octant sub-boxes (k_fcast4) -- a workgroup of the ray kernel takes rays of ONE octant around the sensor's cell and keeps
+	// only that sub-box of the grid in LDS; k_fhits leaves the points' records sorted by octant. Needs the sub-boxes to be small (a
+	// sensor in a corner of its grid looks into one octant that is the whole grid: then the whole-grid kernel).
+	OctGeo og{};
+	u32 oct_wgs = 0, oct_threads = 0, oct_rcap = 0, oct_qcap = 0, oct_lcap = 0;
+	size_t oct_lds = 0, oct_sp = 0, oct_tab = 0, oct_bcnt = 0;
+	bool oct = !big && !simple && 0 != m->opt_cast_oct && makeOctGeo(m->g, fg, sensor, &og);
+	if (oct) {
+		oct_threads = m->opt_cast_threads >= 512 ? 512u : 256u;
+		oct_rcap = oct_threads / 2u;
+		oct_qcap = 2u * oct_threads;
+		oct_lcap = 2u * oct_threads;
+		const size_t ns2 = ((size_t)gp.x + 2u) & ~(size_t)1u;  // (per stretch of the cloud: where the octant's records start, how many lie before)
+		oct_lds = (size_t)og.wmax4 * 16u + (size_t)oct_rcap * sizeof(RayConst) + (size_t)oct_qcap * sizeof(SegRec) + 4u * (size_t)oct_lcap + 8u * ns2 + 64u + 64u * 4u;
+		oct = gp.x <= 4096u && oct_lds <= (size_t)std::max(16, m->opt_cast_oct_lds) * 1024u;
+		// two workgroups per CU (three in four CUs when scans are pipelined: the kernels of the other two streams want CUs of their own)
+		oct_wgs = m->opt_cast_wgs > 0 ? (u32)m->opt_cast_wgs : (u32)(lazy_done ? 3 * m->n_cus / 2 : 2 * m->n_cus);
+		oct_wgs = std::max<u32>(8u, std::min<u32>(oct_wgs, std::max<u32>(8u, (N + 63u) / 64u)));
+	}
+	if (oct) {
+		// slabs | per-workgroup steps / rays / hits | the table for k_fmerge | the stretches' counts -- one buffer of the set
+		oct_sp = (size_t)oct_wgs * og.wmax4 * 16u;
+		oct_tab = (oct_sp + (size_t)oct_wgs * 8u * 3u + 15u) & ~(size_t)15u;
+		oct_bcnt = oct_tab + ((sizeof(OctTab) + 15u) & ~(size_t)15u);
+		HIP_TRY(m->b_slabs.reserve(oct_bcnt + (size_t)gp.x * 48u));  // (per stretch: eight 16-bit counts, eight 32-bit weights)
+	}
 	{
 		ProfScope ps(m, "k_fhits");
-		if (discrete)
-			hipLaunchKernelGGL(k_fhits<true>, gp, dim3(256), 0, m->cs, m->g, fg, sensor, d_xyz, N, max_range, color_variant, m->b_first.as<u32>(),
-			                   m->b_part1.as<BoxPartial>(), ctl, m->ing, m->b_hit_code.as<PointRec>(), keep, d_rgb, keep_rgb);
+		uint4* const bc = oct ? reinterpret_cast<uint4*>(m->b_slabs.as<char>() + oct_bcnt) : nullptr;
+		if (oct && discrete)
+			hipLaunchKernelGGL((k_fhits<true, true>), gp, dim3(256), 0, m->cs, m->g, fg, sensor, d_xyz, N, max_range, color_variant, m->b_first.as<u32>(),
+			                   m->b_part1.as<BoxPartial>(), ctl, m->ing, m->b_hit_code.as<PointRec>(), keep, d_rgb, keep_rgb, bc, reinterpret_cast<u32*>(bc + gp.x));
+		else if (oct)
+			hipLaunchKernelGGL((k_fhits<false, true>), gp, dim3(256), 0, m->cs, m->g, fg, sensor, d_xyz, N, max_range, 0u, m->b_first.as<u32>(),
+			                   m->b_part1.as<BoxPartial>(), ctl, m->ing, m->b_hit_code.as<PointRec>(), keep, (const uint8_t*)nullptr, (uint8_t*)nullptr, bc, reinterpret_cast<u32*>(bc + gp.x));
+		else if (discrete)
+			hipLaunchKernelGGL((k_fhits<true, false>), gp, dim3(256), 0, m->cs, m->g, fg, sensor, d_xyz, N, max_range, color_variant, m->b_first.as<u32>(),
+			                   m->b_part1.as<BoxPartial>(), ctl, m->ing, m->b_hit_code.as<PointRec>(), keep, d_rgb, keep_rgb, (uint4*)nullptr, (u32*)nullptr);
 		else
-			hipLaunchKernelGGL(k_fhits<false>, gp, dim3(256), 0, m->cs, m->g, fg, sensor, d_xyz, N, max_range, 0u, m->b_first.as<u32>(),
-			                   m->b_part1.as<BoxPartial>(), ctl, m->ing, m->b_hit_code.as<PointRec>(), keep, nullptr, nullptr);
+			hipLaunchKernelGGL((k_fhits<false, false>), gp, dim3(256), 0, m->cs, m->g, fg, sensor, d_xyz, N, max_range, 0u, m->b_first.as<u32>(),
+			                   m->b_part1.as<BoxPartial>(), ctl, m->ing, m->b_hit_code.as<PointRec>(), keep, (const uint8_t*)nullptr, (uint8_t*)nullptr, (uint4*)nullptr, (u32*)nullptr);
 	}
 	// stream-to-stream hand-overs of this path: k_signal / k_gate (fast_kernels.h), not events
 	m->gates = useGates(m);
@@ -302,9 +335,10 @@ int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, si
 		// have CUs where nothing else competes (measured, scripts/dev/dev_ab.py cast_wgs=...: 256 -> 0.052, 192 -> 0.046 ms/scan).
 		u32 nwg = m->opt_cast_wgs > 0 ? (u32)m->opt_cast_wgs : (lazy_done ? (u32)(3 * m->n_cus / 4) : (u32)m->n_cus);
 		nwg = std::max<u32>(1u, std::min<u32>(nwg, (N + 63u) / 64u));
+		if (oct) nwg = oct_wgs;
 		const u32 cap_wg = (N + nwg - 1) / nwg;
-		HIP_TRY(m->b_slabs.reserve((size_t)nwg * fg.gr.bytes + (size_t)nwg * 8 * 3));  // slabs + per-workgroup steps / rays / hits (of this set: merged by the walk)
-		unsigned long long* sp = reinterpret_cast<unsigned long long*>(m->b_slabs.as<char>() + (size_t)nwg * fg.gr.bytes);
+		if (!oct) HIP_TRY(m->b_slabs.reserve((size_t)nwg * fg.gr.bytes + (size_t)nwg * 8 * 3));  // slabs + per-workgroup steps / rays / hits (of this set: merged by the walk)
+		unsigned long long* sp = reinterpret_cast<unsigned long long*>(m->b_slabs.as<char>() + (oct ? oct_sp : (size_t)nwg * fg.gr.bytes));
 		// end of the scan half: the scan's descriptor and number become visible to the walks (k_claim)
 		ScanDesc d{};
 		d.slabs = m->b_slabs.as<uint4>();
@@ -322,6 +356,7 @@ int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, si
 		d.nboxes = gp.x;
 		d.geo = m->geo_id;
 		d.rgb = scan_rgb;
+		d.oct = oct ? reinterpret_cast<const OctTab*>(m->b_slabs.as<char>() + oct_tab) : nullptr;
 		Pipe* const solo_pipe = solo ? m->b_bpipe.as<Pipe>() : nullptr;
 		{
 			ProfScope ps(m, "k_fcast");
@@ -352,6 +387,16 @@ int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, si
 				else
 					hipLaunchKernelGGL(k_fcast_simple<false>, dim3(nwg), dim3(cthreads), (size_t)fg.gr.bytes, m->cs, m->g, fg, sensor, N, m->b_first.as<u32>(), m->b_slabs.as<u32>(), ctl, ctl,
 					                   sp, m->b_hit_code.as<PointRec>(), solo_pipe, d);
+			} else if (oct) {
+				OctTab* const tab = reinterpret_cast<OctTab*>(m->b_slabs.as<char>() + oct_tab);
+				const uint4* const bc = reinterpret_cast<const uint4*>(m->b_slabs.as<char>() + oct_bcnt);
+				const u32 Kc = (u32)std::max(8, m->opt_cast2_k);
+				if (discrete)
+					hipLaunchKernelGGL(k_fcast4<true>, dim3(nwg), dim3(oct_threads), oct_lds, m->cs, m->g, fg, sensor, og, (u32)gp.x, bc, reinterpret_cast<const u32*>(bc + gp.x), m->b_hit_code.as<PointRec>(), m->b_first.as<u32>(),
+					                   m->b_slabs.as<uint4>(), tab, Kc, ctl, ctl, sp, oct_rcap, oct_qcap, oct_lcap, prio, solo_pipe, d);
+				else
+					hipLaunchKernelGGL(k_fcast4<false>, dim3(nwg), dim3(oct_threads), oct_lds, m->cs, m->g, fg, sensor, og, (u32)gp.x, bc, reinterpret_cast<const u32*>(bc + gp.x), m->b_hit_code.as<PointRec>(), m->b_first.as<u32>(),
+					                   m->b_slabs.as<uint4>(), tab, Kc, ctl, ctl, sp, oct_rcap, oct_qcap, oct_lcap, prio, solo_pipe, d);
 			} else if (m->opt_cast_fused >= 2) {
 				// (round 6: the points that cast a ray are packed into a list before anything is set up; the list takes what the grid, the
 				// ray constants and the segment queue leave of the CU's LDS, up to the workgroup's share of the cloud)

@@ -398,6 +398,9 @@ struct ufomap_map {
 	int opt_dda_mode = -1;
 	int opt_dda_seg = 1;  // 0 = force the lane-per-ray kernel
 	int opt_dda_block = 0, opt_dda_lanes = 0;  // 0 = automatic
+	int opt_cast_oct = 0;        // 1: the steady-state ray kernel on octant sub-boxes (k_fcast4: 5 MB of slabs per scan instead of 20 -- and, measured, a
+	                             // SLOWER scan: 0.0476 against 0.0415 ms); 0: a copy of the whole grid per workgroup (k_fcast3 / k_fcast2)
+	int opt_cast_oct_lds = 80;   // ... as long as a workgroup's LDS (sub-box, queue, lists) stays below this many KiB
 	int opt_ctl_dbg = 0;     // k_ftail also reports the control block's diagnostics (clock stamps: scripts/dev/dev_*.py) to the host -- 512 bytes more across PCIe per scan
 	int opt_cast_fused = 2;  // the steady-state ray kernel: 2 = k_fcast3 (round 6: rays packed before set-up, cuts by estimate + check), else k_fcast2 (round 5, the cross-check)
 	int opt_cast2_k = 64;    // ... its cells per segment (a cut costs ~1.5 us of a lane's chain: measured 32 -> 44.0, 48 -> 43.5, 64 -> 41.4, 96 -> 43.0 us per pipelined scan)
@@ -3711,6 +3714,10 @@ int ufomap_map_set_option(ufomap_map* m, const char* key, long long value)
 		m->opt_vol_walk_lds = (int)std::max<long long>(0, std::min<long long>(128 << 10, value));
 	} else if (0 == strcmp(key, "cast2_k")) {
 		m->opt_cast2_k = (int)std::max<long long>(8, std::min<long long>(1024, value));
+	} else if (0 == strcmp(key, "cast_oct")) {
+		m->opt_cast_oct = value ? 1 : 0;
+	} else if (0 == strcmp(key, "cast_oct_lds")) {
+		m->opt_cast_oct_lds = (int)std::max<long long>(16, std::min<long long>(159, value));
 	} else if (0 == strcmp(key, "ctl_dbg")) {
 		m->opt_ctl_dbg = value ? 1 : 0;
 	} else if (0 == strcmp(key, "cast_fused")) {
