@@ -165,10 +165,14 @@ def test_edge_cases_empty_and_errors():
     assert len(m.leaves()[0]) == 0
     codes, depths, occ, _ = m.leaves(True)
     assert codes.tolist() == [0] and depths.tolist() == [16] and occ.tolist() == [0.0]
+    # (until round 5 early_stopping needed a dense first-ray array over the ray box -- 4e6 cells do not fit 1 MiB: UNSUPPORTED. Now the
+    # cells the rays visit go into a sparse set: the call succeeds and equals the reference)
     m.set_scratch_limit(1 << 20)
-    with pytest.raises(capi.UfomapError) as e:  # early_stopping needs a dense first-ray array over the ray box: 4e6 cells do not fit 1 MiB
-        m.insertPointCloud([0, 0, 0], np.array([[20.0, 20.0, 20.0], [1.0, 1.0, 1.0]]), -1.0, 0, False, 3)
-    assert e.value.code == capi.ERR_UNSUPPORTED
+    pts = np.array([[20.0, 20.0, 20.0], [1.0, 1.0, 1.0], [19.9, 20.0, 20.0]])
+    m.insertPointCloud([0, 0, 0], pts, -1.0, 0, False, 3)
+    _, o = _maps(resolution=0.16)
+    o.insert([0, 0, 0], pts, max_range=-1.0, early_stopping=3)
+    assert same_dump(m.leaves(True), o.leaves(True)) and same_dump(m.inner(), o.inner())
 
 
 def test_runaway_ray_is_refused_and_map_unchanged():

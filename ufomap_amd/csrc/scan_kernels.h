@@ -2457,7 +2457,13 @@ __global__ __launch_bounds__(256) void k_grid_codes_bits(MapGeom g, Grid gr, con
 // into grid M (k_es_mark with the grid) and the update proceeds as without early stopping.
 // ------------------------------------------------------------------------------------------------
 struct EsArgs {
-	u32* first;        // [cells of the ray box] lowest rank that visits the cell (0xFFFFFFFF: nobody)
+	u32* first;        // [cells of the ray box] lowest rank that visits the cell (0xFFFFFFFF: nobody); nullptr: the sparse form below
+	// Round 6: a ray box whose dense array does not fit the scratch limit (a 2 mm frame at insert depth 0: 4e9 cells = 15 GB) keeps "who
+	// visits a cell first" in a hash of the cells the rays DO visit (key = the cell's index in the box, open addressing; the host doubles
+	// it and repeats the round when it fills up) -- bounded by the scan's ray cells, as the reference's CodeMap is (CODE:568-785)
+	u64* hkeys;        // [hmask + 1] cell index (~0: empty)
+	u32* hvals;        // [hmask + 1] lowest rank
+	u32 hmask;
 	u32* stop;         // [rays] cells the ray visits (0xFFFFFFFF: to its end)
 	const u32* rank;   // [rays] the ray's point index
 	u32 early;         // early_stopping
@@ -2564,6 +2570,49 @@ __device__ inline bool esCell(const Grid& gr, i32 cx, i32 cy, i32 cz, u32 lim, u
 	*idx = (u64)lx + 2ull * (u64)gr.nb[0] * ((u64)ly + 2ull * (u64)gr.nb[1] * (u64)lz);
 	return true;
 }
+__device__ inline u32 esHash(u64 k)
+{
+	k ^= k >> 33;
+	k *= 0xff51afd7ed558ccdULL;
+	k ^= k >> 29;
+	return (u32)k;
+}
+// first[idx] = min(first[idx], rank)
+__device__ inline void esFirstMin(const EsArgs& a, u64 idx, u32 rank, u32* err)
+{
+	if (a.first) {
+		atomicMin(&a.first[idx], rank);
+		return;
+	}
+	u32 s = esHash(idx) & a.hmask;
+	for (u32 probe = 0; probe <= a.hmask; ++probe) {
+		u64 k = __hip_atomic_load(&a.hkeys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (k == ~0ull) {
+			const u64 prev = atomicCAS((unsigned long long*)&a.hkeys[s], ~0ull, (unsigned long long)idx);
+			k = (prev == ~0ull) ? idx : prev;
+		}
+		if (k == idx) {
+			atomicMin(&a.hvals[s], rank);
+			return;
+		}
+		if (probe >= 256u) break;  // (the set is filling up: the host doubles it and repeats the round)
+		s = (s + 1u) & a.hmask;
+	}
+	*err |= ERR_ENTRIES;
+}
+// first[idx] (0xFFFFFFFF: nobody visits the cell)
+__device__ inline u32 esFirstGet(const EsArgs& a, u64 idx)
+{
+	if (a.first) return a.first[idx];
+	u32 s = esHash(idx) & a.hmask;
+	for (u32 probe = 0; probe <= 256u; ++probe) {
+		const u64 k = __hip_atomic_load(&a.hkeys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (k == idx) return a.hvals[s];
+		if (k == ~0ull) return 0xFFFFFFFFu;
+		s = (s + 1u) & a.hmask;
+	}
+	return 0xFFFFFFFFu;  // (cannot happen in a round whose marking pass did not overflow: an insert gives up after as many probes)
+}
 // every ray marks the cells it visits within its current stop: first[c] = min rank; grid != nullptr (the final pass): the
 // cells go into grid M as well, the visits are the scan's step count
 __global__ __launch_bounds__(256) void k_es_mark(MapGeom g, D3 sensor, u32 depth, Grid gr, EsArgs a, const D3* __restrict__ ray_end, const ScanCtl* ctl_in, ScanCtl* ctl,
@@ -2579,7 +2628,7 @@ __global__ __launch_bounds__(256) void k_es_mark(MapGeom g, D3 sensor, u32 depth
 		steps = esWalk(g, sensor, depth, ray_end[r], 0 != a.simple, &err, [&](i32 cx, i32 cy, i32 cz) {
 			u64 idx;
 			if (esCell(gr, cx, cy, cz, lim, &idx, &err)) {
-				atomicMin(&a.first[idx], rank);
+				esFirstMin(a, idx, rank, &err);
 				if (grid) (void)gridMark(gr, grid, cx, cy, cz, lim, &oob);
 			} else if (grid && ((u32)cx >= lim || (u32)cy >= lim || (u32)cz >= lim)) {
 				++oob;
@@ -2609,7 +2658,7 @@ __global__ __launch_bounds__(256) void k_es_stops(MapGeom g, D3 sensor, u32 dept
 		const u32 visited = esWalk(g, sensor, depth, ray_end[r], 0 != a.simple, &err, [&](i32 cx, i32 cy, i32 cz) {
 			u64 idx = ~0ull;
 			bool already = false;
-			if (esCell(gr, cx, cy, cz, lim, &idx, &err)) already = a.first[idx] < rank || (a.simple && idx == prev);
+			if (esCell(gr, cx, cy, cz, lim, &idx, &err)) already = esFirstGet(a, idx) < rank || (a.simple && idx == prev);
 			prev = idx;
 			if (!already) {
 				row = 0;

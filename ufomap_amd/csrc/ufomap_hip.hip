@@ -364,6 +364,7 @@ struct ufomap_map {
 	Ingest ing{};      // ufomap_map_insert_pointcloud2: raw PointCloud2 records, converted inside k_classify
 	u32 hb_clean = 0;  // slots [0, hb_clean) of the hit-block hash are known to be empty
 	DevBuf b_crec, b_dlist, b_rays;
+	u64 es_set_slots = 0;  // early stopping, sparse form: slots of the set of first rays the last such scan needed
 	DevBuf b_ray_pt, b_es_first, b_es_stop;  // early stopping (scan_kernels.h: k_es_*): the rays' ranks, who visits a cell first, the rays' stops
 	u32 es_rounds = 0;                        // ... rounds the last such scan took to settle
 	DevBuf b_gridM, b_entries, b_ent_slot, b_newlist, b_wl0, b_wl1, b_in_xyz, b_in_rgb, b_codes, b_dump;
@@ -401,6 +402,7 @@ struct ufomap_map {
 	int opt_cast_oct = 0;        // 1: the steady-state ray kernel on octant sub-boxes (k_fcast4: 5 MB of slabs per scan instead of 20 -- and, measured, a
 	                             // SLOWER scan: 0.0476 against 0.0415 ms); 0: a copy of the whole grid per workgroup (k_fcast3 / k_fcast2)
 	int opt_cast_oct_lds = 80;   // ... as long as a workgroup's LDS (sub-box, queue, lists) stays below this many KiB
+	int opt_es_sparse = 0;       // tests: early stopping keeps "who visits a cell first" in the sparse set whatever the ray box needs (2: starting from 1 Ki slots)
 	int opt_ctl_dbg = 0;     // k_ftail also reports the control block's diagnostics (clock stamps: scripts/dev/dev_*.py) to the host -- 512 bytes more across PCIe per scan
 	int opt_cast_fused = 2;  // the steady-state ray kernel: 2 = k_fcast3 (round 6: rays packed before set-up, cuts by estimate + check), else k_fcast2 (round 5, the cross-check)
 	int opt_cast2_k = 64;    // ... its cells per segment (a cut costs ~1.5 us of a lane's chain: measured 32 -> 44.0, 48 -> 43.5, 64 -> 41.4, 96 -> 43.0 us per pipelined scan)
@@ -1570,10 +1572,11 @@ int scanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, const 
 	u64 gbytes = m->haveM ? m->gridM.bytes : 0;  // hits are grouped through a hash, only grid M is dense
 	if (early_stopping && m->haveM) {
 		// (a dense array over the cells of the ray box: who visits a cell first)
-		const u64 cells = 8ull * (u64)m->gridM.nb[0] * (u64)m->gridM.nb[1] * (u64)m->gridM.nb[2];
-		if (cells >= (1ull << 32) || cells * 4 + gbytes > m->scratch_limit)
-			return fail(UFOMAP_ERR_UNSUPPORTED, "early_stopping > 0 on a ray box of " + std::to_string(cells) +
-			                                        " cells: the first-ray array does not fit the scratch limit (ufomap_map_set_scratch_limit)");
+		// (round 6: a box whose dense array does not fit takes the sparse form -- a hash of the cells the rays visit, scan_kernels.h: EsArgs;
+		// what still has to fit is grid M itself, one byte per node block of the box)
+		if (gbytes > m->scratch_limit)
+			return fail(UFOMAP_ERR_UNSUPPORTED, "early_stopping > 0 on a ray box whose dedup grid needs " + std::to_string(gbytes) +
+			                                        " bytes > scratch limit (ufomap_map_set_scratch_limit)");
 	} else
 	if (gbytes > m->scratch_limit || (m->opt_sparse_set && m->haveM && !simple)) {  // (option sparse_set: tests)
 		// the box is too large for a dense grid: the ray cells go through a hash set of node blocks instead (Grid::layout 2,
@@ -1609,22 +1612,51 @@ int scanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, const 
 		// visited cells into grid M (one byte per node block) ----
 		const u64 cells = 8ull * (u64)m->gridM.nb[0] * (u64)m->gridM.nb[1] * (u64)m->gridM.nb[2];
 		HIP_TRY(m->b_gridM.reserve(m->gridM.bytes));
-		HIP_TRY(m->b_es_first.reserve(cells * 4));
+		// who visits a cell first: a dense array over the box's cells, or -- when that does not fit (4 bytes per cell) -- a hash of the
+		// cells the rays visit, doubled and the round repeated when it fills up (its size is remembered for later scans)
+		const bool es_sparse = cells >= (1ull << 32) || cells * 4 + m->gridM.bytes > m->scratch_limit || 0 != m->opt_es_sparse;
+		u64 es_slots = 0;
+		if (es_sparse) {
+			es_slots = std::max<u64>(m->es_set_slots, std::max<u64>(1ull << 16, nextPow2((u64)n_rays * 32)));
+			if (2 == m->opt_es_sparse) es_slots = 1ull << 10;  // (tests: the set has to grow inside the round)
+			if (es_slots * 12 + m->gridM.bytes > m->scratch_limit && es_slots > (1ull << 16))
+				return fail(UFOMAP_ERR_UNSUPPORTED, "early_stopping > 0: the set of first rays does not fit the scratch limit (ufomap_map_set_scratch_limit)");
+			HIP_TRY(m->b_es_first.reserve(es_slots * 12));
+		} else HIP_TRY(m->b_es_first.reserve(cells * 4));
 		HIP_TRY(m->b_es_stop.reserve((size_t)n_rays * 4));
 		HIP_TRY(hipMemsetAsync(m->b_gridM.p, 0, m->gridM.bytes, m->cs));
 		HIP_TRY(hipMemsetAsync(m->b_es_stop.p, 0xFF, (size_t)n_rays * 4, m->cs));
 		u32* d_changed = m->b_ctl.as<u32>() + (sizeof(ScanCtl) + 3) / 4;  // (a spare word behind the control block)
-		const EsArgs ea{m->b_es_first.as<u32>(), m->b_es_stop.as<u32>(), m->b_ray_pt.as<u32>(), (u32)early_stopping, simple ? 1u : 0u};
+		EsArgs ea{es_sparse ? nullptr : m->b_es_first.as<u32>(), es_sparse ? m->b_es_first.as<u64>() : nullptr,
+		          es_sparse ? reinterpret_cast<u32*>(m->b_es_first.as<u64>() + es_slots) : nullptr, es_sparse ? (u32)(es_slots - 1) : 0u, m->b_es_stop.as<u32>(),
+		          m->b_ray_pt.as<u32>(), (u32)early_stopping, simple ? 1u : 0u};
 		const dim3 gr_((n_rays + 255) / 256);
 		u32 rounds = 0;
 		for (;; ++rounds) {
 			if (rounds > n_rays + 2) return fail(UFOMAP_ERR_DEVICE, "early stopping: the rays' stops did not settle (internal error)");
-			HIP_TRY(hipMemsetAsync(m->b_es_first.p, 0xFF, cells * 4, m->cs));
-			HIP_TRY(hipMemsetAsync(d_changed, 0, 4, m->cs));
-			{
-				ProfScope ps(m, "k_es_mark");
-				hipLaunchKernelGGL(k_es_mark, gr_, dim3(256), 0, m->cs, m->g, sensor, (u32)depth, m->gridM, ea, m->b_ray_end.as<D3>(), ctl, ctl, (u32*)nullptr);
+			for (;;) {  // (the marking pass; sparse form: again with a set twice the size when it filled up)
+				if (es_sparse) HIP_TRY(hipMemsetAsync(m->b_es_first.p, 0xFF, es_slots * 12, m->cs));
+				else HIP_TRY(hipMemsetAsync(m->b_es_first.p, 0xFF, cells * 4, m->cs));
+				HIP_TRY(hipMemsetAsync(d_changed, 0, 4, m->cs));
+				{
+					ProfScope ps(m, "k_es_mark");
+					hipLaunchKernelGGL(k_es_mark, gr_, dim3(256), 0, m->cs, m->g, sensor, (u32)depth, m->gridM, ea, m->b_ray_end.as<D3>(), ctl, ctl, (u32*)nullptr);
+				}
+				if (!es_sparse) break;
+				u32 eflags = 0;
+				HIP_TRY(hipMemcpyAsync(&eflags, &ctl->err, 4, hipMemcpyDeviceToHost, m->cs));
+				HIP_TRY(hipStreamSynchronize(m->cs));
+				if (!(eflags & ERR_ENTRIES)) break;
+				hipLaunchKernelGGL(k_ctl_clear, dim3(1), dim3(1), 0, m->cs, ctl, (u32)ERR_ENTRIES);
+				es_slots *= 2;
+				if (es_slots * 12 + m->gridM.bytes > m->scratch_limit || es_slots > (1ull << 31))
+					return fail(UFOMAP_ERR_UNSUPPORTED, "early_stopping > 0: the set of first rays does not fit the scratch limit (ufomap_map_set_scratch_limit)");
+				HIP_TRY(m->b_es_first.reserve(es_slots * 12));
+				ea.hkeys = m->b_es_first.as<u64>();
+				ea.hvals = reinterpret_cast<u32*>(ea.hkeys + es_slots);
+				ea.hmask = (u32)(es_slots - 1);
 			}
+			m->es_set_slots = es_sparse ? es_slots : m->es_set_slots;
 			{
 				ProfScope ps(m, "k_es_stops");
 				hipLaunchKernelGGL(k_es_stops, gr_, dim3(256), 0, m->cs, m->g, sensor, (u32)depth, m->gridM, ea, m->b_ray_end.as<D3>(), ctl, ctl, d_changed);
@@ -3718,6 +3750,8 @@ int ufomap_map_set_option(ufomap_map* m, const char* key, long long value)
 		m->opt_cast_oct = value ? 1 : 0;
 	} else if (0 == strcmp(key, "cast_oct_lds")) {
 		m->opt_cast_oct_lds = (int)std::max<long long>(16, std::min<long long>(159, value));
+	} else if (0 == strcmp(key, "es_sparse")) {
+		m->opt_es_sparse = (int)std::max<long long>(0, std::min<long long>(2, value));
 	} else if (0 == strcmp(key, "ctl_dbg")) {
 		m->opt_ctl_dbg = value ? 1 : 0;
 	} else if (0 == strcmp(key, "cast_fused")) {
