@@ -141,7 +141,7 @@ def live_traffic(kernels, timeout_s=150):
                     if r.get("Counter_Name") != counter:
                         continue
                     k = r.get("Kernel_Name", "").split("(")[0].replace("void ", "").replace("ufo::", "").strip().split("<")[0]
-                    k = "k_fcast" if k == "k_fcast2" else k  # (round 5's form of the ray kernel: the library times both as k_fcast)
+                    k = "k_fcast" if k in ("k_fcast2", "k_fcast3", "k_fcast4") else k  # (the later forms of the ray kernel: the library times them all as k_fcast)
                     a = acc.setdefault(k, [0, 0.0])
                     a[0] += 1
                     a[1] += float(r.get("Counter_Value") or 0)
@@ -508,6 +508,27 @@ def main():
         extra["sync_latency"] = dict(leg_summary(run_leg(m, step_sync, min(args.min_timed_s, 0.25))), note="async=false, HBM-resident clouds")
         digests["sync"] = m.digest()
 
+        # ---- one step of the multi-GPU batch path with ONE rank (the N = 1 line carries what `--force-batch`
+        # measures): ufomap_map_insert_batch through the real RCCL -- scan, pack, all-gather of one slot, the walk -- so that the
+        # driver's run shows what a batch step costs beside a pipelined single-GPU scan, whether or not a multi-GPU node is at hand
+        try:
+            from ufomap_amd import Comm
+            comm1 = Comm(Comm.unique_id(), 1, 0, local_rank)
+            m.set_option("async_apply", 1)  # (as ufomap_amd.dist.CBatchIntegrator does: a step returns with its walk enqueued)
+
+            def step_batch1(i):
+                p = pose_of(i)
+                m.insert_batch(comm1, clouds[p][0], d_clouds[p].data_ptr(), n_pts, MAX_RANGE, DEPTH, True)
+            extra["batch_step_n1"] = dict(leg_summary(run_leg(m, step_batch1, min(args.min_timed_s, 0.25))), rccl_ranks=1, counters=comm1.counters(),
+                                          note="ufomap_map_insert_batch with a communicator of ONE rank over the real librccl (the N > 1 code path: bit-grid steps, "
+                                               "one all-gather per step, the walk enqueued by the host); compare with ms_per_step of the pipelined single-GPU path")
+            digests["batch_n1"] = m.digest()
+            m.insertPointCloudWait()
+            m.set_option("async_apply", 0)
+            comm1.close()
+        except Exception as e:  # (librccl missing on the box: reported, the other legs stand)
+            extra["batch_step_n1"] = dict(error=repr(e))
+
         # ---- the raw records of a PointCloud2 (float32 x, y, z, pad: 16 B/point) + the sensor's pose, host memory --------
         rec = []
         ident = np.array([1.0, 0.0, 0.0, 0.0])
@@ -692,7 +713,7 @@ def main():
             if os.path.exists(pmc):
                 try:
                     pj = json.load(open(pmc))
-                    vals = [next((v.get("hbm_bytes_per_launch") for kk, v in pj.items() if kk == k or kk.startswith(k + "<") or (k == "k_fcast" and kk.startswith("k_fcast2"))), None) for k in group]
+                    vals = [next((v.get("hbm_bytes_per_launch") for kk, v in pj.items() if kk == k or kk.startswith(k + "<") or (k == "k_fcast" and kk.startswith(("k_fcast2", "k_fcast3", "k_fcast4")))), None) for k in group]
                     traffic = sum(v for v in vals if v) if any(vals) else None
                     import hashlib
                     traffic_src = ("profiles/pmc_latest.json (sha256 " + hashlib.sha256(open(pmc, "rb").read()).hexdigest()[:16] +
@@ -704,12 +725,12 @@ def main():
                 traffic, traffic_src = traffic_live, traffic_live_note
             by_time = max(per_step_ms, key=per_step_ms.get)
             frac_rocprof, rocprof_src = None, None
-            for tag in ("r05", "r04", "r03", "r02"):
+            for tag in ("r06", "r05", "r04", "r03", "r02"):
                 f = os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv")
                 if os.path.exists(f):
                     import csv
                     import hashlib
-                    rows = {("k_fcast" if r["kernel"].split("<")[0] == "k_fcast2" else r["kernel"].split("<")[0]): float(r["avg_ns"]) for r in csv.DictReader(open(f)) if r.get("avg_ns")}
+                    rows = {("k_fcast" if r["kernel"].split("<")[0] in ("k_fcast2", "k_fcast3", "k_fcast4") else r["kernel"].split("<")[0]): float(r["avg_ns"]) for r in csv.DictReader(open(f)) if r.get("avg_ns")}
                     if all(k in rows for k in group):
                         frac_rocprof = share / (sum(rows[k] for k in group) * 1e-9) / 1e9 / HBM_PEAK_GBS
                         rocprof_src = f"profiles/{tag}_kernel_stats.csv (sha256 {hashlib.sha256(open(f, 'rb').read()).hexdigest()[:16]}): rocprofv3 --kernel-trace --stats of this command"
@@ -742,7 +763,8 @@ def main():
                        "configs[3]: batch of N concurrent 131072-pt LiDAR scans per step (moving sensors), 16 cm leaf, one scan per GPU, ONE RCCL all-gather of the scans as bit grids, every replica applies all N in rank order with one walk of the tree",
                        "points_per_scan": n_pts, "rays_cast_mean": mean_rays, "dda_steps_mean": mean_steps, "per_pose": counts,
                        "leaf_m": RES, "max_range_m": MAX_RANGE, "depth_levels": 16, "parallelism": f"scan-per-gpu x{world}",
-                       **({"batch_impl": batch_impl} if batch_mode else {})},
+                       **({"batch_impl": batch_impl, "rccl_ranks": world} if batch_mode else {})},
+            **({"rccl_ranks": world} if batch_mode else {}),
             "roofline": roof, "self_check": self_check, "pipeline": pipeline,
             "memory": {"table_bytes": mem_stats["bytes"], "live_blocks": mem_stats["inner_nodes"], "leaves": mem_stats["leaf_nodes"],
                        "bytes_per_live_block": mem_stats["bytes_per_block"],
