@@ -64,7 +64,10 @@ int ufomap_map_clear(ufomap_map* m);
 int ufomap_map_reserve(ufomap_map* m, size_t n_blocks);
 /* Upper bound in bytes for a scan's dense dedup grid (default 16 GiB). A scan whose bounding box needs more keeps its ray
  * cells in a sparse set of node blocks instead (bounded by the cells the rays touch, as the reference's CodeMap is,
- * code.h:568-785; slower per step); the set itself must fit the limit too. */
+ * code.h:568-785; slower per step); the set itself must fit the limit too. The limit bounds the scratch of ONE scan: scratch buffers
+ * belong to the hand-over set of the scan that uses them, grow-only, and a handle fed asynchronously keeps two to three sets busy (up
+ * to eight exist) -- e.g. the volume path's brick grids of a 2 mm RGB-D frame are 4.5 GB per set, 9 GB for a pipelined stream of such
+ * frames. They are released with the handle (ufomap_map_destroy). */
 int ufomap_map_set_scratch_limit(ufomap_map* m, size_t bytes);
 
 /* ---- sensor model setters (occupancy_map_base.h:746-773), probabilities, not log-odds ------- */

@@ -25,12 +25,15 @@ FastGeo upGeoOf(const FastGeo& fg)
 	return u;
 }
 
-// The assumptions behind the per-XCD copies of the brick grid (vol_kernels.h: k_vselftest), checked on the device once per process:
+// The assumptions behind the per-XCD copies of the brick grid (vol_kernels.h: k_vselftest), checked on the device once per process and device:
 // 1 = they hold, -1 = they do not (the volume path stays off). Also -1 under a compiler mode that splits a workgroup's waves over
 // CUs with separate L1s is not needed: the atomics go to the L2 either way.
 int volSelfTest(ufomap_map* m)
 {
-	static std::atomic<int> state{0};
+	// (per DEVICE: what is tested -- XCC_ID's range, workgroup-scope atomics at the XCD's L2 -- is a property of the device, and a
+	// process may hold maps on several; run when a map is created, ufomap_map_create, not inside a scan that may be timed: ADVICE r5)
+	static std::atomic<int> states[64];
+	std::atomic<int>& state = states[(unsigned)m->device & 63u];
 	int s = state.load(std::memory_order_acquire);
 	if (s) return s;
 	u32* d = nullptr;

@@ -333,7 +333,7 @@ struct ufomap_map {
 	int opt_gather_stream = 0;  // batch steps: the all-gather on a stream of its own (host_multi_gpu.inl)
 	int opt_fast_simple = 1; // simple (fixed-step) ray casting on the fast path (0: the general path)
 	int opt_fail_scan = 0;  // test aid: the scan half of the next batch steps 'fails' on this rank (host_multi_gpu.inl)
-	int opt_vol_mode = 0;   // measuring aid (k_vdda): bit 0 one copy of M for all XCDs, bit 1 blocks in launch order, bit 2 rays in the cloud's order, bit 3 no write-combining table
+	int opt_vol_mode = 0;   // measuring aid (k_vdda / k_vwalk): bit 1 blocks in launch order, bit 2 rays in the cloud's order, bit 3 no write-combining table, bit 4 one lane per ray (k_vdda)
 	int opt_vol_seg = 192;  // cells per segment of a ray on the volume path (k_vcutA / k_vwalk)
 	int opt_vol_walk_blocks = 1536;  // workgroups of k_vwalk per eighth of the scan
 	int opt_vol_walk_lds = 0;  // extra LDS per workgroup of k_vwalk, bytes: caps its workgroups per CU (what is left takes the tree update of the scan before)
@@ -1937,10 +1937,11 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 			if (m->alt[i].pending && m->alt[i].vol_walk) return true;
 		return false;
 	};
+	int vprc = UFOMAP_OK;  // result of joining a volume walk an earlier asynchronous call left enqueued
 	if (fast) {
 		// (a walk of the volume path that is still enqueued may have to be run again for the tiles that stood back: joined before
 		// anything else is enqueued on the map stream)
-		if (volWalkPending()) (void)joinOlder(m);
+		if (volWalkPending()) vprc = joinOlder(m);  // (its result is this call's too: a table growth inside that join may have failed)
 		// a synchronous call with nothing in flight: the whole integration on the map stream (no hand-overs between streams)
 		const bool solo = !async && m->opt_solo && oldestPendingAlt(m) < 0 && !m->sd_pending;
 		rc = fastScanPhase(m, origin, d_xyz, n, max_range, discrete, false, async && !m->profiling && m->opt_early && m->opt_lazy_done, solo, swapped, d_rgb, simple);
@@ -2012,10 +2013,11 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 				fprintf(stderr, "[fast dbg] first[]: %zu of %zu entries not clean, tile bitmap: %zu words not clean, dirty flag %d\n", bad, h.size(), badt,
 				        (int)m->first_dirty);
 			}
-			return rc ? rc : prc;
+			return rc ? rc : (prc ? prc : vprc);
 		}
 		const auto t_join = std::chrono::steady_clock::now();
 		prc = joinCompleted(m);
+		if (!prc) prc = vprc;
 		if (m->prev_flagged) {
 			// an integration that was joined had flagged itself (and has been repeated, or has failed): every walk enqueued
 			// behind it stood back. Drain in order -- each is repeated by its own join -- before anything new is enqueued.
@@ -2077,8 +2079,8 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 		if (!rc && !m->vol_walk) rc = finishPending(m);
 		return rc ? rc : prc;
 	}
-	if (!rc && n && volWalkPending()) {  // (see above: its status is reported by wait() / the async status)
-		(void)joinOlder(m);
+	if (!rc && n && volWalkPending()) {  // (see above; its result is this call's too, below)
+		vprc = joinOlder(m);
 		m->cs = m->sstream;
 	}
 	if (!rc && n) rc = extractPhase(m, n_hits, n_rays, &capH, &capM, merged);
@@ -2143,10 +2145,11 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 		m->pending = true;
 		m->deferred = false;
 		m->bound = m->scan_new_bound;
-		return prc;
+		return prc ? prc : vprc;
 	}
 	// join the previous integrations (occupancy_map_base.h:315): their status is reported by wait()/this call
 	prc = joinOlder(m);
+	if (!prc) prc = vprc;
 	if (rc || 0 == n) {
 		if (rc) (void)hipStreamSynchronize(m->sstream);
 		return rc ? rc : prc;
@@ -2340,6 +2343,7 @@ ufomap_map* ufomap_map_create(double resolution, unsigned depth_levels, int auto
 		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fcast_simple<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (160 << 10) - 512);
 
 	}
+	if (m->opt_vol) (void)volSelfTest(m);  // (the per-XCD atomics the volume path rests on, once per device -- here, not inside a scan)
 	for (int a = 0; a < 3; ++a) {
 		m->min_change[a] = g.hs[g.L];  // resetMinMaxChangeDetection (occupancy_map_base.h:806-810)
 		m->max_change[a] = -g.hs[g.L];

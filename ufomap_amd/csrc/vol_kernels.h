@@ -601,7 +601,10 @@ __global__ __launch_bounds__(256) void k_vwalk(MapGeom g, VolGeo vg, u64* __rest
 		if (!((tb[tile >> 5] >> (tile & 31u)) & 1u)) __hip_atomic_fetch_or(&tb[tile >> 5], 1u << (tile & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 	};
 	u32 nst = 0;  // entries parked in the lane's queue
-	// every lane's parked entries on their way (uniform: called by the whole wave)
+	// The lanes' parked entries on their way. Called by the lanes that are still walking (the call inside the walk loop sits in
+	// divergent code: a lane whose segment has ended is not there) and, behind the loop, by the whole wave: correct either way ONLY
+	// because flush and markTile use no cross-lane operation -- a lane sends its own entries; LDS operations of a wave run in program
+	// order, which is all the write-combining table's protocol needs. (do not add a shuffle or a ballot to either.)
 	auto drain = [&]() {
 		u32 last_tile = 0xFFFFFFFFu;
 #pragma unroll
@@ -616,6 +619,13 @@ __global__ __launch_bounds__(256) void k_vwalk(MapGeom g, VolGeo vg, u64* __rest
 		nst = 0;
 	};
 	auto park = [&](u32 w, u64 bits) {
+		// (the queue holds UFO_VSTAGE entries per lane; the ballot behind every step drains a full one before the next park -- enforced,
+		// not assumed: an entry that finds the queue full goes out directly)
+		if (nst >= UFO_VSTAGE) {
+			flush(w, bits);
+			markTile(w >> 3);
+			return;
+		}
 		st_w[wave][nst][lane] = w;
 		st_m[wave][nst][lane] = bits;
 		++nst;
@@ -650,7 +660,7 @@ __global__ __launch_bounds__(256) void k_vwalk(MapGeom g, VolGeo vg, u64* __rest
 				acc = 0;
 			}
 			acc |= 1ull << b;
-			if (__ballot(nst >= UFO_VSTAGE)) drain();  // (uniform)
+			if (__ballot(nst >= UFO_VSTAGE)) drain();  // (the lanes still walking: see drain)
 			const bool cxy = tmx <= tmy, cxz = tmx <= tmz, cyz = tmy <= tmz;
 			const bool selx = cxy & cxz;
 			const bool sely = !cxy & cyz;
