@@ -313,6 +313,40 @@ def test_device_cloud_may_be_reused_as_soon_as_the_call_returns(color):
         assert g.debug()[63] >= 1, "the jumps should have forced repeats"
 
 
+@pytest.mark.parametrize("kind", ["pageable", "pageable_colour", "pinned", "inline"])
+def test_host_cloud_may_be_reused_as_soon_as_the_call_returns(kind):
+    """ufomap_map_insert(async=1) with a full-size HOST cloud (131 072 points: 3 MB, the size from which a helper thread copies the
+    cloud into the set's pinned staging buffer while the calling thread enqueues the scan -- round 6; `inline`: the calling thread
+    copies, option stage_thread = 0; `pinned`: the caller's own pinned buffer, DMA'd from where it lies and awaited when the call
+    ends): the caller's arrays are overwritten the moment each call has returned, scans that have to be repeated (the sensor
+    jumps) included. The map must equal the reference's."""
+    from oracle import OracleMap
+    from ufomap_amd import OccupancyMap, OccupancyMapColor, PointCloud, PointCloudColor, scans
+    color = kind == "pageable_colour"
+    g = (OccupancyMapColor if color else OccupancyMap)(0.16)
+    if kind == "inline":
+        g.set_option("stage_thread", 0)
+    o = OracleMap(0.16, kind="port", color=color)
+    base = np.array(scans.lidar_pose(2), dtype=np.float64)
+    offs = [(0, 0, 0), (0.05, 0, 0), (0.1, 0.05, 0), (5.0, 3.0, 0.2), (5.1, 3.0, 0.2), (0.1, 0, 0), (0.15, 0, 0), (0, 0, 0)]
+    n = 64 * 2048
+    buf = torch.empty((n, 3), dtype=torch.float64).pin_memory().numpy() if kind == "pinned" else np.empty((n, 3), dtype=np.float64)
+    cbuf = np.empty((n, 3), dtype=np.uint8)
+    for i, off in enumerate(offs):
+        origin, xyz, rgb = scans.lidar64(origin=tuple(base + np.array(off)), seed=700 + i, colored=color)
+        buf[:] = xyz
+        if color:
+            cbuf[:] = rgb
+        cloud = PointCloudColor(buf, cbuf) if color else PointCloud(buf)
+        g.insertPointCloudDiscrete(origin, cloud, 20.0, 0, False, 0, True)
+        buf[:] = 1000.0 + i  # the arrays are the caller's again
+        cbuf[:] = 7
+        o.insert(origin, xyz, rgb if color else None, max_range=20.0, discrete=True)
+    g.insertPointCloudWait()
+    gl, ol = g.leaves(True), o.leaves(True)
+    assert all(np.array_equal(a, b) for a, b in zip(gl, ol)) and same_dump(g.inner(), o.inner())
+
+
 _FEW_QUEUES = r"""
 import sys, time
 import numpy as np

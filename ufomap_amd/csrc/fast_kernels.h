@@ -3759,6 +3759,22 @@ __global__ void k_gate(const unsigned long long* flag, unsigned long long value,
 {
 	gateWait(flag, value, ctl, max_ticks, ts, f);
 }
+// Round 6: a gate that waits for the HOST -- a pageable cloud is copied into the set's pinned staging buffer by a helper thread while the
+// calling thread enqueues the scan (ufomap_hip.hip: uploadCloud); the asynchronous H2D copy of the staging buffer sits behind this
+// one-wave kernel on the prep stream, which polls the pinned word the helper stores when the copy is complete. (Nothing a tool that
+// serialises kernels could deadlock: the producer is a host thread.)
+__global__ void k_host_gate(const unsigned long long* flag, unsigned long long value, unsigned long long max_ticks, u32* err_out)
+{
+	if (0 != threadIdx.x) return;
+	const unsigned long long t0 = wall_clock64();
+	while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < value) {
+		__builtin_amdgcn_s_sleep(8);
+		if (wall_clock64() - t0 > max_ticks) {  // (100 MHz clock; cannot happen: the call joins the helper before it returns)
+			if (err_out) atomicOr(err_out, ERR_GATE);
+			return;
+		}
+	}
+}
 // The end of one scan half and the gate of the next in ONE launch (asynchronous calls in a row: the host keeps the
 // descriptor of scan i back and hands it over with the gate of scan i+1 -- one one-wave kernel per scan on the scan stream
 // instead of two; whatever needs scan i before another scan arrives publishes it with k_scan_done, ufomap_hip.hip:

@@ -34,6 +34,9 @@
 #include <sstream>
 #include <chrono>
 #include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -241,6 +244,70 @@ struct HandOver {
 	VolPlan vplan{};
 };
 
+// Round 6: the helper that copies a pageable host cloud into the set's pinned staging buffer while the calling thread enqueues the
+// scan (uploadCloud). One per handle, started by the first such call; it touches host memory only -- no HIP call is ever made from it.
+struct StageWorker {
+	std::thread th;
+	std::mutex mu;
+	std::condition_variable cv;
+	std::atomic<bool> quit{false};
+	bool sleeping = false;
+	struct Job {
+		void* dst[2];
+		const void* src[2];
+		size_t bytes[2];
+	} job{};
+	std::atomic<unsigned long long> posted{0}, done{0};
+	volatile unsigned long long* flag = nullptr;  // pinned: the number of the newest finished copy -- what k_host_gate polls
+	void run()
+	{
+		unsigned long long seen = 0;
+		for (;;) {
+			// a cloud a few tens of microseconds after the last one is the steady state: spin briefly, then sleep
+			const auto t0 = std::chrono::steady_clock::now();
+			while (posted.load(std::memory_order_acquire) == seen) {
+				if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200)) {
+					std::unique_lock<std::mutex> lk(mu);
+					sleeping = true;
+					cv.wait(lk, [&] { return quit.load() || posted.load(std::memory_order_acquire) != seen; });
+					sleeping = false;
+				}
+			}
+			if (quit.load()) return;
+			seen = posted.load(std::memory_order_acquire);
+			for (int k = 0; k < 2; ++k)
+				if (job.bytes[k]) memcpy(job.dst[k], job.src[k], job.bytes[k]);
+			std::atomic_thread_fence(std::memory_order_release);
+			*flag = seen;
+			done.store(seen, std::memory_order_release);
+		}
+	}
+	void post(const Job& j)
+	{
+		job = j;
+		posted.fetch_add(1, std::memory_order_release);
+		std::lock_guard<std::mutex> lk(mu);
+		if (sleeping) cv.notify_one();
+	}
+	void wait()
+	{
+		const unsigned long long want = posted.load(std::memory_order_relaxed);
+		while (done.load(std::memory_order_acquire) < want) {
+		}
+	}
+	void stop()
+	{
+		if (!th.joinable()) return;
+		{
+			std::lock_guard<std::mutex> lk(mu);
+			quit.store(true);
+			cv.notify_one();
+		}
+		posted.fetch_add(1, std::memory_order_release);  // (a worker that is spinning leaves its loop and looks at `quit`)
+		th.join();
+	}
+};
+
 struct ufomap_map {
 	int device = 0;
 	hipStream_t stream = nullptr;   // map stream: everything that touches the node table
@@ -378,6 +445,11 @@ struct ufomap_map {
 	void* h_stage = nullptr;   // pinned staging buffer of the current hand-over set (HandOver::h_stage)
 	size_t h_stage_cap = 0;
 	hipEvent_t copy_ev = nullptr;  // end of the H2D copy of a cloud that lies in caller-owned pinned memory
+	bool copy_wait = false;        // ... which the call that enqueued it has not awaited yet (copyDone)
+	StageWorker* stager = nullptr; // copies pageable clouds into pinned staging beside the calling thread (uploadCloud)
+	unsigned long long* h_stage_flag = nullptr;  // pinned: StageWorker::flag
+	bool stage_wait = false;       // the helper is still reading the caller's cloud: joined when the call ends (copyDone)
+	int opt_stage_thread = 1;      // 0: the calling thread copies the cloud itself before it enqueues anything (as until round 5)
 	MapRoot* h_root = nullptr;  // pinned
 	size_t scratch_limit = 16ull << 30;
 	// state of the last integration
@@ -2390,6 +2462,12 @@ void ufomap_map_destroy(ufomap_map* m)
 	if (m->h_ctl) (void)hipHostFree(m->h_ctl);
 	if (m->h_res) (void)hipHostFree(m->h_res);
 	if (m->sig_prep) (void)hipFree(m->sig_prep);
+	if (m->stager) {
+		m->stager->stop();
+		delete m->stager;
+		m->stager = nullptr;
+	}
+	if (m->h_stage_flag) (void)hipHostFree(m->h_stage_flag);
 	if (m->h_stage) (void)hipHostFree(m->h_stage);
 	if (m->h_res_all) (void)hipHostFree(m->h_res_all);
 	if (m->xchg_ev) (void)hipEventDestroy(m->xchg_ev);
@@ -2478,6 +2556,20 @@ int ufomap_map_insert_device(ufomap_map* m, const double sensor_origin[3], const
 //    async=true the copy of scan i+1 overlaps the kernels of scan i; the staging buffer is free again when the set's
 //    integration has been joined (rotateSets), which is before the set is used for another scan;
 //  * caller-owned pinned memory (hipHostMalloc / hipHostRegister): DMA straight from it; only the copy is awaited.
+// the DMA out of a caller-owned pinned cloud has finished (the caller may reuse the buffer when the call returns)
+static int copyDone(ufomap_map* m, int rc)
+{
+	if (m->stage_wait) {  // (the helper thread has read all of the caller's pageable cloud)
+		m->stage_wait = false;
+		m->stager->wait();
+	}
+	if (m->copy_wait) {
+		m->copy_wait = false;
+		const hipError_t e = hipEventSynchronize(m->copy_ev);
+		if (e != hipSuccess && !rc) return fail(UFOMAP_ERR_DEVICE, hipGetErrorString(e));
+	}
+	return rc;
+}
 static int uploadCloud(ufomap_map* m, const void* a, size_t a_bytes, const void* b, size_t b_bytes, const void** d_a, const void** d_b)
 {
 	*d_a = *d_b = nullptr;
@@ -2493,8 +2585,10 @@ static int uploadCloud(ufomap_map* m, const void* a, size_t a_bytes, const void*
 	if (isPinned(a) && (!b_bytes || isPinned(b))) {
 		HIP_TRY(hipMemcpyAsync(m->b_in_xyz.p, a, a_bytes, hipMemcpyHostToDevice, m->pstream));
 		if (b_bytes) HIP_TRY(hipMemcpyAsync(m->b_in_rgb.p, b, b_bytes, hipMemcpyHostToDevice, m->pstream));
+		// (the caller's pinned buffer is read by the DMA engine until this event: awaited when the CALL ends, copyDone -- not here:
+		// round 6. Until round 5 the host sat through the 66 us of the copy and only then enqueued the scan's 30 us of launches.)
 		HIP_TRY(hipEventRecord(m->copy_ev, m->pstream));
-		HIP_TRY(hipEventSynchronize(m->copy_ev));
+		m->copy_wait = true;
 	} else {
 		const size_t off_b = (a_bytes + 255) & ~(size_t)255, need = off_b + b_bytes;
 		if (need > m->h_stage_cap) {
@@ -2505,8 +2599,32 @@ static int uploadCloud(ufomap_map* m, const void* a, size_t a_bytes, const void*
 			HIP_TRY(hipHostMalloc(&m->h_stage, want));
 			m->h_stage_cap = want;
 		}
-		memcpy(m->h_stage, a, a_bytes);
-		if (b_bytes) memcpy(static_cast<char*>(m->h_stage) + off_b, b, b_bytes);
+		if (m->opt_stage_thread && a_bytes >= (256u << 10) && useGates(m)) {
+			// Round 6: the copy into the staging buffer (60 us for a 3 MB cloud) by a helper thread WHILE this thread enqueues the scan
+			// (30 us of launches): the asynchronous H2D copy waits behind a one-wave gate kernel for the helper's word. The call joins the
+			// helper before it returns (copyDone): the caller's cloud is never referenced afterwards, as before.
+			if (!m->stager) {
+				if (hipHostMalloc((void**)&m->h_stage_flag, 64) != hipSuccess) return fail(UFOMAP_ERR_DEVICE, "pinned memory for the staging flag");
+				*m->h_stage_flag = 0ull;
+				m->stager = new StageWorker();
+				m->stager->flag = m->h_stage_flag;
+				m->stager->th = std::thread([w = m->stager] { w->run(); });
+			}
+			StageWorker::Job j{};
+			j.dst[0] = m->h_stage;
+			j.src[0] = a;
+			j.bytes[0] = a_bytes;
+			j.dst[1] = static_cast<char*>(m->h_stage) + off_b;
+			j.src[1] = b;
+			j.bytes[1] = b_bytes;
+			m->stager->post(j);
+			m->stage_wait = true;
+			hipLaunchKernelGGL(k_host_gate, dim3(1), dim3(64), 0, m->pstream, m->h_stage_flag, m->stager->posted.load(std::memory_order_relaxed), 200000000ull,
+			                   (u32*)nullptr);
+		} else {
+			memcpy(m->h_stage, a, a_bytes);
+			if (b_bytes) memcpy(static_cast<char*>(m->h_stage) + off_b, b, b_bytes);
+		}
 		HIP_TRY(hipMemcpyAsync(m->b_in_xyz.p, m->h_stage, a_bytes, hipMemcpyHostToDevice, m->pstream));
 		if (b_bytes) HIP_TRY(hipMemcpyAsync(m->b_in_rgb.p, static_cast<char*>(m->h_stage) + off_b, b_bytes, hipMemcpyHostToDevice, m->pstream));
 	}
@@ -2524,9 +2642,9 @@ int ufomap_map_insert(ufomap_map* m, const double sensor_origin[3], const double
 	(void)rotateSets(m);  // the staging buffers belong to the hand-over set of THIS scan
 	const void *d_xyz = nullptr, *d_rgb = nullptr;
 	const int urc = uploadCloud(m, xyz, n * 24, rgb, rgb ? n * 3 : 0, &d_xyz, &d_rgb);
-	if (urc) return urc;
-	return doInsert(m, sensor_origin, static_cast<const double*>(d_xyz), static_cast<const uint8_t*>(d_rgb), n, max_range, depth, discrete,
-	                simple_ray_casting, early_stopping, async, true);
+	if (urc) return copyDone(m, urc);
+	return copyDone(m, doInsert(m, sensor_origin, static_cast<const double*>(d_xyz), static_cast<const uint8_t*>(d_rgb), n, max_range, depth, discrete,
+	                            simple_ray_casting, early_stopping, async, true));
 }
 
 int ufomap_map_insert_pointcloud2(ufomap_map* m, const double translation[3], const double rotation_wxyz[4], const void* data,
@@ -2551,7 +2669,7 @@ int ufomap_map_insert_pointcloud2(ufomap_map* m, const double translation[3], co
 		// stream (point_step bytes per point), not 24 bytes of float64 per point
 		const void *d_a = nullptr, *d_b = nullptr;
 		const int urc = uploadCloud(m, data, n_points * (size_t)point_step, nullptr, 0, &d_a, &d_b);
-		if (urc) return urc;
+		if (urc) return copyDone(m, urc);
 		d_data = static_cast<const uint8_t*>(d_a);
 	}
 	uint8_t* d_rgb = nullptr;
@@ -2559,7 +2677,7 @@ int ufomap_map_insert_pointcloud2(ufomap_map* m, const double translation[3], co
 		e = m->b_in_rgb.reserve(n_points * 3);
 		d_rgb = m->b_in_rgb.as<uint8_t>();
 	}
-	if (e != hipSuccess) return fail(UFOMAP_ERR_DEVICE, hipGetErrorString(e));
+	if (e != hipSuccess) return copyDone(m, fail(UFOMAP_ERR_DEVICE, hipGetErrorString(e)));
 	Ingest ing{};
 	ing.data = d_data;
 	ing.step = point_step;
@@ -2577,7 +2695,7 @@ int ufomap_map_insert_pointcloud2(ufomap_map* m, const double translation[3], co
 	const int rc = doInsert(m, translation, reinterpret_cast<const double*>(d_data), d_rgb, n_points, max_range, depth, discrete,
 	                        simple_ray_casting, early_stopping, async, true, 0, data_on_device ? 1 : 0);
 	m->ing = Ingest{};
-	return rc;
+	return copyDone(m, rc);
 }
 
 int ufomap_map_query(ufomap_map* m, const double* xyz, int xyz_on_device, size_t n, unsigned depth, float* logodds, uint8_t* state)
@@ -3756,6 +3874,8 @@ int ufomap_map_set_option(ufomap_map* m, const char* key, long long value)
 		m->opt_cast_oct_lds = (int)std::max<long long>(16, std::min<long long>(159, value));
 	} else if (0 == strcmp(key, "es_sparse")) {
 		m->opt_es_sparse = (int)std::max<long long>(0, std::min<long long>(2, value));
+	} else if (0 == strcmp(key, "stage_thread")) {
+		m->opt_stage_thread = value ? 1 : 0;
 	} else if (0 == strcmp(key, "ctl_dbg")) {
 		m->opt_ctl_dbg = value ? 1 : 0;
 	} else if (0 == strcmp(key, "cast_fused")) {
