@@ -439,6 +439,8 @@ struct OctTab {  // left by workgroup 0 of the ray kernel for k_fmerge
 // ---- scans as the tree update sees them (who applies which scan: see k_claim below) ----
 #define UFO_RING 16u       // scans in flight per handle (a power of two, > the number of hand-over sets)
 #define UFO_BATCH_MAX 16u  // scans per walk
+#define UFO_XSLOT_CTL 1024u  // a rank's exchange slot of a batch step: [control block | tile bitmap at UFO_XSLOT_CTL | bit grids at UFO_XSLOT_HDR]
+#define UFO_XSLOT_HDR 2048u
 struct ScanDesc {  // a scan as the tree update sees it: written into the ring when its scan half ends (k_scan_done)
 	const uint4* slabs;                  // the ray kernel's per-workgroup copies of the ray grid ...
 	const unsigned long long* parts;     // ... and step / ray / hit counts (merged by the walk that takes the scan)
@@ -468,6 +470,7 @@ struct Pipe {
 	u32 wstat[UFO_RING];           // wstat[f & 15]: 0 = the walk that took scan f applied it; else it stood back / failed
 	ScanDesc ring[UFO_RING];
 	unsigned long long* ts;        // developer aid (option "tstamps"): device clock at the pipeline's hand-overs, 8 words per scan
+	u32 merge_arrivals, pad_;      // k_fmerge_batch: workgroups of the launch that have finished (left at 0 by the last one)
 };
 // [0] k_signal (first-point pass done)  [1] gate entered  [2] gate open  [3] scan half published  [4] k_claim entered
 // [5] k_claim done  [6] k_ftail done  [7] scans the walk took; 100 MHz clock
@@ -1663,8 +1666,6 @@ __global__ void k_batch_descs(Pipe* p, DescPack pack, u32 B)
 }
 // What a rank contributes to the exchange of a batch step, in one piece: [control block (1 KiB) | tile bitmap (1 KiB) |
 // ray cells | hit voxels] -- 2 KiB + two bit grids, ~200 KB for a 16 cm / 20 m scan (the update list of the same scan: 0.8 MB).
-#define UFO_XSLOT_CTL 1024u
-#define UFO_XSLOT_HDR 2048u
 static_assert(sizeof(ScanCtl) <= UFO_XSLOT_CTL && UFO_FAST_MAX_TILES / 8u <= UFO_XSLOT_HDR - UFO_XSLOT_CTL, "exchange slot layout");
 __global__ __launch_bounds__(256) void k_pack_slot(uint4* __restrict__ dst, const uint4* __restrict__ ctl, const uint4* __restrict__ tile_bits,
                                                    const uint4* __restrict__ gridM, const uint4* __restrict__ gridH, u32 n4)
@@ -1740,177 +1741,223 @@ __global__ void k_claim(Pipe* p, unsigned long long f, u32 bmax, ScanCtl* ctl, u
 // tree-update kernels start from that bitmap instead of searching the grid. First kernel of a walk: for every scan the
 // walk has claimed.
 // ------------------------------------------------------------------------------------------------
+// One scan of a walk merged: the slabs ORed into the scan's ray grid, its hit grid from the first-point array, its tile bitmap; the
+// launch's last workgroup folds the per-workgroup counts and boxes instead (k_fmerge, k_fmerge_batch)
+__device__ __forceinline__ void fmergeScan(const FastGeo& fg, const ScanDesc& d, u32 n4, uint4 (*part)[64], uint8_t (*hb)[64], u32* tb)
+{
+	const u32 tb_words = (fg.ntiles + 31u) / 32u;
+	ScanCtl* ctl = d.ctl;
+	// (n_slabs == 0: a ray grid beyond LDS -- the ray kernel has marked the scan's grid in HBM itself, k_cast<2>; what is left
+	// to do here is the hit grid and the tile bitmap)
+	const bool noslab = 0 == d.n_slabs;
+	if (blockIdx.x + 1u == gridDim.x) {
+		// The LAST workgroup of the launch does not merge: it folds the scan's per-workgroup results
+		foldBoxes(d.boxes, d.nboxes, ctl);
+		if (threadIdx.x < 64u) {
+			unsigned long long v = 0, r = 0, h = 0;
+			for (u32 s = threadIdx.x; s < d.n_slabs; s += 64u) {
+				v += d.parts[s];
+				r += d.parts[d.n_slabs + s];
+				h += d.parts[2u * d.n_slabs + s];
+			}
+			for (int o = 32; o > 0; o >>= 1) {
+				v += __shfl_xor(v, o);
+				r += __shfl_xor(r, o);
+				h += __shfl_xor(h, o);
+			}
+			if (noslab) {
+				// (a grid beyond LDS: rays cast / voxels hit per 256-point stretch of the cloud, k_fselect)
+				r = h = 0;
+				for (u32 s = threadIdx.x; s < d.nboxes; s += 64u) {
+					const unsigned long long q = d.parts[s];
+					r += q & 0xFFFFFFFFull;
+					h += q >> 32;
+				}
+				for (int o = 32; o > 0; o >>= 1) {
+					r += __shfl_xor(r, o);
+					h += __shfl_xor(h, o);
+				}
+				v = 0;  // (k_cast<2> has added its steps itself)
+			}
+			if (0 == threadIdx.x && 0 == ctl->err) {
+				if (v) atomicAdd(&ctl->n_steps, v);
+				ctl->n_rays = (u32)r;
+				ctl->n_hits = (u32)h;
+			}
+		}
+		__syncthreads();  // (foldBoxes' shared arrays are reused for the next scan)
+		return;
+	}
+	const u32 nmerge = gridDim.x - 1u;  // workgroups that merge
+	if (ctl->err) return;               // (uniform: the scan was flagged by its scan half; the walk will stand back)
+	const uint4* __restrict__ slabs = d.slabs;
+	uint4* __restrict__ grid = reinterpret_cast<uint4*>(d.gridM);
+	const u32 n_slabs = d.n_slabs;
+	const u32 col = threadIdx.x & 63u, sl16 = threadIdx.x >> 6;
+	for (u32 j = threadIdx.x; j < tb_words; j += blockDim.x) tb[j] = 0;
+	__syncthreads();
+	const u32 rowW = fg.rowBits >> 5, ny = 2u * (u32)fg.gr.nb[1];
+	for (u32 j0 = blockIdx.x * 64u; j0 < n4; j0 += nmerge * 64u) {
+		const u32 j = j0 + col;
+		uint4 acc = make_uint4(0, 0, 0, 0);
+		if (j < n4 && noslab) {
+			if (0 == sl16) acc = grid[j];
+		} else if (j < n4) {
+			if (d.oct) {
+				// (k_fcast4: a word of the grid lies in the sub-box of one octant -- of up to eight on the sensor's row / plane / word --
+				// and only that octant's workgroups have a copy of it: sixteen slab lanes share them)
+				const OctTab* ot = d.oct;
+				const OctGeo og = ot->og;
+				const u32* sw = reinterpret_cast<const u32*>(slabs);
+				const u32 sxw = og.s[0] >> 5, nzf = 2u * (u32)fg.gr.nb[2];
+				u32 accw[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+				for (u32 k = 0; k < 4u; ++k) {
+					const u32 widx = 4u * j + k;
+					const u32 row = widx / rowW, wx = widx - row * rowW;
+					const u32 z = row / ny, y = row - z * ny;
+					if (z >= nzf) continue;  // (padding behind the last row)
+					// which sides of the sensor's word / row / plane the word lies on (the sensor's own belong to both)
+					const u32 ax = (wx <= sxw ? 1u : 0u) | (wx >= sxw ? 2u : 0u), ay = (y <= og.s[1] ? 1u : 0u) | (y >= og.s[1] ? 2u : 0u),
+					          az = (z <= og.s[2] ? 1u : 0u) | (z >= og.s[2] ? 2u : 0u);
+					for (u32 o = 0; o < 8u; ++o) {
+						const u32 ox = o & 1u, oy = (o >> 1) & 1u, oz = o >> 2;
+						if (!((ax >> ox) & (ay >> oy) & (az >> oz) & 1u)) continue;
+						const u32 nw = ot->wg_start[o + 1u] - ot->wg_start[o];
+						if (0 == nw) continue;
+						const u32 sub = (wx - og.xw0[ox]) + og.nxw[ox] * ((y - og.y0[oy]) + og.ny[oy] * (z - og.z0[oz]));
+						const size_t w4x4 = 4u * (size_t)octWords4(og, o);
+						const u32* base = sw + 4u * (size_t)ot->slab_off4[o] + sub;
+						for (u32 jj = sl16; jj < nw; jj += 16u) accw[k] |= base[(size_t)jj * w4x4];
+					}
+				}
+				acc = make_uint4(accw[0], accw[1], accw[2], accw[3]);
+			} else
+			// (asking for four slabs' words at a time was measured and lost: 13.3 -> 16.3 us by events, 15.3 -> 21.6 under rocprofv3)
+			for (u32 s = sl16; s < n_slabs; s += 16u) {
+				const uint4 a = slabs[(size_t)s * n4 + j];
+				acc.x |= a.x;
+				acc.y |= a.y;
+				acc.z |= a.z;
+				acc.w |= a.w;
+			}
+		}
+		// the scan's hit grid: one bit per cell that holds a first point (the voxel receives a hit, OMB:295, 358-360), from the
+		// dense first-point array -- 128 entries per column, eight per slab lane -- which is left clean for the set's next scan
+		u32 hbits = 0;
+		if (j < n4 && d.first && !noslab) {  // (noslab: k_fselect has built the hit grid)
+			uint4* f4 = reinterpret_cast<uint4*>(d.first + (size_t)128u * j + 8u * sl16);
+			const uint4 fa = f4[0], fb = f4[1];
+			hbits = (fa.x != 0xFFFFFFFFu ? 1u : 0u) | (fa.y != 0xFFFFFFFFu ? 2u : 0u) | (fa.z != 0xFFFFFFFFu ? 4u : 0u) | (fa.w != 0xFFFFFFFFu ? 8u : 0u) |
+			        (fb.x != 0xFFFFFFFFu ? 16u : 0u) | (fb.y != 0xFFFFFFFFu ? 32u : 0u) | (fb.z != 0xFFFFFFFFu ? 64u : 0u) | (fb.w != 0xFFFFFFFFu ? 128u : 0u);
+			if (hbits && !d.rgb) {  // (a coloured scan: k_tile reads the first points -- whose colour the voxel gets -- and cleans up)
+				f4[0] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+				f4[1] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+			}
+		}
+		hb[sl16][col] = (uint8_t)hbits;
+		part[sl16][col] = acc;
+		__syncthreads();
+		if (0 == sl16 && j < n4) {
+			if (d.first && !noslab) {
+				uint4 hv;
+				hv.x = (u32)hb[0][col] | ((u32)hb[1][col] << 8) | ((u32)hb[2][col] << 16) | ((u32)hb[3][col] << 24);
+				hv.y = (u32)hb[4][col] | ((u32)hb[5][col] << 8) | ((u32)hb[6][col] << 16) | ((u32)hb[7][col] << 24);
+				hv.z = (u32)hb[8][col] | ((u32)hb[9][col] << 8) | ((u32)hb[10][col] << 16) | ((u32)hb[11][col] << 24);
+				hv.w = (u32)hb[12][col] | ((u32)hb[13][col] << 8) | ((u32)hb[14][col] << 16) | ((u32)hb[15][col] << 24);
+				reinterpret_cast<uint4*>(d.gridH)[j] = hv;
+			}
+			if (!noslab) {
+				for (u32 k = 1; k < 16u; ++k) {
+					const uint4 a = part[k][col];
+					acc.x |= a.x;
+					acc.y |= a.y;
+					acc.z |= a.z;
+					acc.w |= a.w;
+				}
+				grid[j] = acc;
+			}
+			const u32 wv[4] = {acc.x, acc.y, acc.z, acc.w};
+			for (u32 k = 0; k < 4u; ++k) {
+				u32 m = wv[k];
+				if (0 == m) continue;
+				const u32 widx = 4u * j + k;
+				const u32 row = widx / rowW, wx = widx % rowW;
+				const u32 ly = row % ny, lz = row / ny;
+				if (lz >= 2u * (u32)fg.gr.nb[2]) continue;  // (padding behind the last row)
+				const i32 ty = ((fg.gr.base[1] + (i32)ly) >> 3) - fg.tbase[1], tz = ((fg.gr.base[2] + (i32)lz) >> 3) - fg.tbase[2];
+				while (m) {
+					const u32 bit = (u32)__ffs(m) - 1u;
+					const i32 ax = fg.gr.base[0] + (i32)(32u * wx + bit);
+					const i32 tx = (ax >> 3) - fg.tbase[0];
+					// all cells of this word that fall into the same tile
+					const i32 first_in_tile = ((ax >> 3) << 3) - fg.gr.base[0] - (i32)(32u * wx);  // bit index of the tile's first cell (may be < 0)
+					const u32 lo = (u32)max(first_in_tile, 0), hi = (u32)min(first_in_tile + 8, 32);
+					const u32 span = (hi >= 32u ? 0xFFFFFFFFu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
+					m &= ~span;
+					const u32 tile = (u32)tx + fg.nt[0] * ((u32)ty + fg.nt[1] * (u32)tz);
+					if (tile < fg.ntiles) atomicOr(&tb[tile >> 5], 1u << (tile & 31u));
+				}
+			}
+		}
+		__syncthreads();
+	}
+	for (u32 j = threadIdx.x; j < tb_words; j += blockDim.x)
+		if (tb[j]) atomicOr(&d.tile_bits[j], tb[j]);
+	__syncthreads();  // (tb is cleared for the next scan)
+}
 __global__ __launch_bounds__(1024) void k_fmerge(FastGeo fg, const Pipe* __restrict__ p, unsigned long long f, u32 n4)
 {
 	__shared__ uint4 part[16][64];
 	__shared__ uint8_t hb[16][64];
 	__shared__ u32 tb[UFO_BIG_MAX_TILES / 32];
 	const Pipe::Slot sl = p->slot[f & (UFO_RING - 1u)];
-	const u32 tb_words = (fg.ntiles + 31u) / 32u;
 	// (the scans of the walk: one after the other, or -- gridDim.y > 1 -- every gridDim.y-th by this row of workgroups: while the ray
 	// kernel holds three CUs in four the rows queue on the same CUs either way, but the LAST walk of a run of scans has the chip to
 	// itself, and what a timed region waits for at its end is exactly that walk)
-	for (u32 b = blockIdx.y; b < sl.B; b += gridDim.y) {
-		const ScanDesc& d = p->ring[(sl.first + b) & (UFO_RING - 1u)];
-		ScanCtl* ctl = d.ctl;
-		// (n_slabs == 0: a ray grid beyond LDS -- the ray kernel has marked the scan's grid in HBM itself, k_cast<2>; what is left
-		// to do here is the hit grid and the tile bitmap)
-		const bool noslab = 0 == d.n_slabs;
-		if (blockIdx.x + 1u == gridDim.x) {
-			// The LAST workgroup of the launch does not merge: it folds the scan's per-workgroup results
-			foldBoxes(d.boxes, d.nboxes, ctl);
-			if (threadIdx.x < 64u) {
-				unsigned long long v = 0, r = 0, h = 0;
-				for (u32 s = threadIdx.x; s < d.n_slabs; s += 64u) {
-					v += d.parts[s];
-					r += d.parts[d.n_slabs + s];
-					h += d.parts[2u * d.n_slabs + s];
-				}
-				for (int o = 32; o > 0; o >>= 1) {
-					v += __shfl_xor(v, o);
-					r += __shfl_xor(r, o);
-					h += __shfl_xor(h, o);
-				}
-				if (noslab) {
-					// (a grid beyond LDS: rays cast / voxels hit per 256-point stretch of the cloud, k_fselect)
-					r = h = 0;
-					for (u32 s = threadIdx.x; s < d.nboxes; s += 64u) {
-						const unsigned long long q = d.parts[s];
-						r += q & 0xFFFFFFFFull;
-						h += q >> 32;
-					}
-					for (int o = 32; o > 0; o >>= 1) {
-						r += __shfl_xor(r, o);
-						h += __shfl_xor(h, o);
-					}
-					v = 0;  // (k_cast<2> has added its steps itself)
-				}
-				if (0 == threadIdx.x && 0 == ctl->err) {
-					if (v) atomicAdd(&ctl->n_steps, v);
-					ctl->n_rays = (u32)r;
-					ctl->n_hits = (u32)h;
-				}
-			}
-			__syncthreads();  // (foldBoxes' shared arrays are reused for the next scan)
-			continue;
+	for (u32 b = blockIdx.y; b < sl.B; b += gridDim.y) fmergeScan(fg, p->ring[(sl.first + b) & (UFO_RING - 1u)], n4, part, hb, tb);
+}
+// A batch step's own scan (several GPUs, ufomap_map_insert_batch; round 6): merged STRAIGHT INTO the rank's exchange slot -- `own.gridM` /
+// `own.gridH` point into it -- and the workgroup that finishes last adds the slot's header (the finished control block and tile bitmap)
+// and the descriptors of the step's walk (the scans of all ranks, in the receive buffer: known to the host before the step starts).
+// What k_batch_descs + k_fmerge + k_pack_slot on the scan stream and k_batch_descs on the map stream did in four launches.
+// Hand-over inside the launch: every wave's stores drained, the workgroup's release, a ticket; the last ticket acquires and reads
+// what the others' atomics and stores left with loads that bypass its L1 (the guide's last-arriver recipe).
+static_assert(0 == sizeof(ScanCtl) % 8u, "the control block is copied in 8-byte words");
+__global__ __launch_bounds__(1024) void k_fmerge_batch(FastGeo fg, Pipe* __restrict__ p, ScanDesc own, u32 n4, unsigned long long* __restrict__ slot_hdr, DescPack walk, u32 B)
+{
+	__shared__ uint4 part[16][64];
+	__shared__ uint8_t hb[16][64];
+	__shared__ u32 tb[UFO_BIG_MAX_TILES / 32];
+	fmergeScan(fg, own, n4, part, hb, tb);
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	__syncthreads();
+	if (0 == threadIdx.x) {
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		const u32 t = __hip_atomic_fetch_add(&p->merge_arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		const u32 last = (t + 1u == gridDim.x) ? 1u : 0u;
+		if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+		tb[0] = last;
+	}
+	__syncthreads();
+	if (!tb[0]) return;
+	const unsigned long long* cw = reinterpret_cast<const unsigned long long*>(own.ctl);
+	const unsigned long long* tw = reinterpret_cast<const unsigned long long*>(own.tile_bits);
+	for (u32 j = threadIdx.x; j < UFO_XSLOT_HDR / 8u; j += blockDim.x) {
+		unsigned long long v = 0ull;
+		if (j < UFO_XSLOT_CTL / 8u) {
+			if (j < (u32)(sizeof(ScanCtl) / 8u)) v = __hip_atomic_load(cw + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		} else if (j - UFO_XSLOT_CTL / 8u < UFO_FAST_MAX_TILES / 64u) {
+			v = __hip_atomic_load(tw + (j - UFO_XSLOT_CTL / 8u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}
-		const u32 nmerge = gridDim.x - 1u;  // workgroups that merge
-		if (ctl->err) continue;             // (uniform: the scan was flagged by its scan half; the walk will stand back)
-		const uint4* __restrict__ slabs = d.slabs;
-		uint4* __restrict__ grid = reinterpret_cast<uint4*>(d.gridM);
-		const u32 n_slabs = d.n_slabs;
-		const u32 col = threadIdx.x & 63u, sl16 = threadIdx.x >> 6;
-		for (u32 j = threadIdx.x; j < tb_words; j += blockDim.x) tb[j] = 0;
-		__syncthreads();
-		const u32 rowW = fg.rowBits >> 5, ny = 2u * (u32)fg.gr.nb[1];
-		for (u32 j0 = blockIdx.x * 64u; j0 < n4; j0 += nmerge * 64u) {
-			const u32 j = j0 + col;
-			uint4 acc = make_uint4(0, 0, 0, 0);
-			if (j < n4 && noslab) {
-				if (0 == sl16) acc = grid[j];
-			} else if (j < n4) {
-				if (d.oct) {
-					// (k_fcast4: a word of the grid lies in the sub-box of one octant -- of up to eight on the sensor's row / plane / word --
-					// and only that octant's workgroups have a copy of it: sixteen slab lanes share them)
-					const OctTab* ot = d.oct;
-					const OctGeo og = ot->og;
-					const u32* sw = reinterpret_cast<const u32*>(slabs);
-					const u32 sxw = og.s[0] >> 5, nzf = 2u * (u32)fg.gr.nb[2];
-					u32 accw[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-					for (u32 k = 0; k < 4u; ++k) {
-						const u32 widx = 4u * j + k;
-						const u32 row = widx / rowW, wx = widx - row * rowW;
-						const u32 z = row / ny, y = row - z * ny;
-						if (z >= nzf) continue;  // (padding behind the last row)
-						// which sides of the sensor's word / row / plane the word lies on (the sensor's own belong to both)
-						const u32 ax = (wx <= sxw ? 1u : 0u) | (wx >= sxw ? 2u : 0u), ay = (y <= og.s[1] ? 1u : 0u) | (y >= og.s[1] ? 2u : 0u),
-						          az = (z <= og.s[2] ? 1u : 0u) | (z >= og.s[2] ? 2u : 0u);
-						for (u32 o = 0; o < 8u; ++o) {
-							const u32 ox = o & 1u, oy = (o >> 1) & 1u, oz = o >> 2;
-							if (!((ax >> ox) & (ay >> oy) & (az >> oz) & 1u)) continue;
-							const u32 nw = ot->wg_start[o + 1u] - ot->wg_start[o];
-							if (0 == nw) continue;
-							const u32 sub = (wx - og.xw0[ox]) + og.nxw[ox] * ((y - og.y0[oy]) + og.ny[oy] * (z - og.z0[oz]));
-							const size_t w4x4 = 4u * (size_t)octWords4(og, o);
-							const u32* base = sw + 4u * (size_t)ot->slab_off4[o] + sub;
-							for (u32 jj = sl16; jj < nw; jj += 16u) accw[k] |= base[(size_t)jj * w4x4];
-						}
-					}
-					acc = make_uint4(accw[0], accw[1], accw[2], accw[3]);
-				} else
-				// (asking for four slabs' words at a time was measured and lost: 13.3 -> 16.3 us by events, 15.3 -> 21.6 under rocprofv3)
-				for (u32 s = sl16; s < n_slabs; s += 16u) {
-					const uint4 a = slabs[(size_t)s * n4 + j];
-					acc.x |= a.x;
-					acc.y |= a.y;
-					acc.z |= a.z;
-					acc.w |= a.w;
-				}
-			}
-			// the scan's hit grid: one bit per cell that holds a first point (the voxel receives a hit, OMB:295, 358-360), from the
-			// dense first-point array -- 128 entries per column, eight per slab lane -- which is left clean for the set's next scan
-			u32 hbits = 0;
-			if (j < n4 && d.first && !noslab) {  // (noslab: k_fselect has built the hit grid)
-				uint4* f4 = reinterpret_cast<uint4*>(d.first + (size_t)128u * j + 8u * sl16);
-				const uint4 fa = f4[0], fb = f4[1];
-				hbits = (fa.x != 0xFFFFFFFFu ? 1u : 0u) | (fa.y != 0xFFFFFFFFu ? 2u : 0u) | (fa.z != 0xFFFFFFFFu ? 4u : 0u) | (fa.w != 0xFFFFFFFFu ? 8u : 0u) |
-				        (fb.x != 0xFFFFFFFFu ? 16u : 0u) | (fb.y != 0xFFFFFFFFu ? 32u : 0u) | (fb.z != 0xFFFFFFFFu ? 64u : 0u) | (fb.w != 0xFFFFFFFFu ? 128u : 0u);
-				if (hbits && !d.rgb) {  // (a coloured scan: k_tile reads the first points -- whose colour the voxel gets -- and cleans up)
-					f4[0] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-					f4[1] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-				}
-			}
-			hb[sl16][col] = (uint8_t)hbits;
-			part[sl16][col] = acc;
-			__syncthreads();
-			if (0 == sl16 && j < n4) {
-				if (d.first && !noslab) {
-					uint4 hv;
-					hv.x = (u32)hb[0][col] | ((u32)hb[1][col] << 8) | ((u32)hb[2][col] << 16) | ((u32)hb[3][col] << 24);
-					hv.y = (u32)hb[4][col] | ((u32)hb[5][col] << 8) | ((u32)hb[6][col] << 16) | ((u32)hb[7][col] << 24);
-					hv.z = (u32)hb[8][col] | ((u32)hb[9][col] << 8) | ((u32)hb[10][col] << 16) | ((u32)hb[11][col] << 24);
-					hv.w = (u32)hb[12][col] | ((u32)hb[13][col] << 8) | ((u32)hb[14][col] << 16) | ((u32)hb[15][col] << 24);
-					reinterpret_cast<uint4*>(d.gridH)[j] = hv;
-				}
-				if (!noslab) {
-					for (u32 k = 1; k < 16u; ++k) {
-						const uint4 a = part[k][col];
-						acc.x |= a.x;
-						acc.y |= a.y;
-						acc.z |= a.z;
-						acc.w |= a.w;
-					}
-					grid[j] = acc;
-				}
-				const u32 wv[4] = {acc.x, acc.y, acc.z, acc.w};
-				for (u32 k = 0; k < 4u; ++k) {
-					u32 m = wv[k];
-					if (0 == m) continue;
-					const u32 widx = 4u * j + k;
-					const u32 row = widx / rowW, wx = widx % rowW;
-					const u32 ly = row % ny, lz = row / ny;
-					if (lz >= 2u * (u32)fg.gr.nb[2]) continue;  // (padding behind the last row)
-					const i32 ty = ((fg.gr.base[1] + (i32)ly) >> 3) - fg.tbase[1], tz = ((fg.gr.base[2] + (i32)lz) >> 3) - fg.tbase[2];
-					while (m) {
-						const u32 bit = (u32)__ffs(m) - 1u;
-						const i32 ax = fg.gr.base[0] + (i32)(32u * wx + bit);
-						const i32 tx = (ax >> 3) - fg.tbase[0];
-						// all cells of this word that fall into the same tile
-						const i32 first_in_tile = ((ax >> 3) << 3) - fg.gr.base[0] - (i32)(32u * wx);  // bit index of the tile's first cell (may be < 0)
-						const u32 lo = (u32)max(first_in_tile, 0), hi = (u32)min(first_in_tile + 8, 32);
-						const u32 span = (hi >= 32u ? 0xFFFFFFFFu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
-						m &= ~span;
-						const u32 tile = (u32)tx + fg.nt[0] * ((u32)ty + fg.nt[1] * (u32)tz);
-						if (tile < fg.ntiles) atomicOr(&tb[tile >> 5], 1u << (tile & 31u));
-					}
-				}
-			}
-			__syncthreads();
-		}
-		for (u32 j = threadIdx.x; j < tb_words; j += blockDim.x)
-			if (tb[j]) atomicOr(&d.tile_bits[j], tb[j]);
-		__syncthreads();  // (tb is cleared for the next scan)
+		slot_hdr[j] = v;
+	}
+	if (threadIdx.x < B) p->ring[threadIdx.x] = walk.d[threadIdx.x];
+	if (0 == threadIdx.x) {
+		p->slot[0].first = 0;
+		p->slot[0].B = B;
+		p->merge_arrivals = 0u;  // (for the set's next step)
 	}
 }
 

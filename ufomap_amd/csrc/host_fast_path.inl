@@ -433,15 +433,16 @@ int fastScanPhase(ufomap_map* m, const double origin[3], const double* d_xyz, si
 				hipLaunchKernelGGL(k_scan_done, dim3(1), dim3(1), 0, m->sstream, m->b_pipe.as<Pipe>(), d);
 			}
 		} else {
-			// the other ranks get this scan as two bit grids, not as 256 slabs: merged here, on the scan stream
-			DescPack pk{};
-			pk.d[0] = d;
-			pk.d[0].fseq = 0;
-			Pipe* bp = m->b_bpipe.as<Pipe>();
-			hipLaunchKernelGGL(k_batch_descs, dim3(1), dim3(64), 0, m->sstream, bp, pk, 1u);
+			// the other ranks get this scan as two bit grids, not as 256 slabs: merged here, on the scan stream -- straight into this
+			// rank's exchange slot, with the slot's header and the descriptors of the step's walk (k_fmerge_batch)
+			ScanDesc own = d;
+			own.fseq = 0;
+			own.gridM = reinterpret_cast<u32*>(m->batch_send + UFO_XSLOT_HDR);
+			own.gridH = reinterpret_cast<u32*>(m->batch_send + UFO_XSLOT_HDR + (size_t)fg.gr.bytes);
 			ProfScope ps(m, "k_fmerge");
 			const u32 n4 = (u32)(fg.gr.bytes >> 4);
-			hipLaunchKernelGGL(k_fmerge, dim3(std::min<u32>((n4 + 63) / 64, 1024) + 1u), dim3(1024), 0, m->sstream, fg, bp, 0ull, n4);
+			hipLaunchKernelGGL(k_fmerge_batch, dim3(std::min<u32>((n4 + 63) / 64, 1024) + 1u), dim3(1024), 0, m->sstream, fg, m->b_bpipe.as<Pipe>(), own, n4,
+			                   reinterpret_cast<unsigned long long*>(m->batch_send), *m->batch_pack, m->batch_B);
 		}
 	}
 	HIP_TRY(hipGetLastError());

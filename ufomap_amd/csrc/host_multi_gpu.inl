@@ -373,10 +373,38 @@ int fastBatchStep(ufomap_map* m, ufomap_comm* c, const double origin[3], const d
 		*reinterpret_cast<volatile unsigned long long*>(otherResult(m->h_res_all, w) + 1) = 0ull;
 	}
 	ScanCtl* ctl = m->b_ctl.as<ScanCtl>();
+	uint8_t* send = m->b_xsend.as<uint8_t>();
+	uint8_t* recv = m->b_xrecv.as<uint8_t>();
+	{
+		// (the set's tile bitmap: named by the walk's descriptors, which are built before the scan half is enqueued)
+		const size_t ct = m->b_tilebits.cap;
+		HIP_TRY(m->b_tilebits.reserve(UFO_FAST_MAX_TILES / 8));
+		if (ct != m->b_tilebits.cap) m->first_dirty = true;
+	}
+	// the walk: the scans of ranks 0 .. W-1 in this order (W <= UFO_BATCH_MAX: ufomap_map_insert_batch_ex)
+	DescPack pk{};
+	for (int w = 0; w < W && w < (int)UFO_BATCH_MAX; ++w) {
+		uint8_t* base = recv + (size_t)w * slot;
+		ScanDesc& d = pk.d[w];
+		const bool own = w == c->rank;
+		// (the own scan's control block and tile bitmap are the set's: the walk leaves them in their start state)
+		d.ctl = own ? ctl : reinterpret_cast<ScanCtl*>(base);
+		d.tile_bits = own ? m->b_tilebits.as<u32>() : reinterpret_cast<u32*>(base + UFO_XSLOT_CTL);
+		d.gridM = reinterpret_cast<u32*>(base + UFO_XSLOT_HDR);
+		d.gridH = reinterpret_cast<u32*>(base + UFO_XSLOT_HDR + G);
+		d.host_result = own ? m->h_res : otherResult(m->h_res_all, w);
+		d.done_value = (unsigned long long)m->seq;
+		d.fseq = (unsigned long long)w;
+	}
+	m->batch_pack = &pk;
+	m->batch_B = (u32)std::min<int>(W, (int)UFO_BATCH_MAX);
+	m->batch_send = send;
 	int rc = UFOMAP_OK;
 	bool failed_locally = false;
 	if (n) {
+		const auto t_scan = std::chrono::steady_clock::now();
 		rc = fastScanPhase(m, origin, d_xyz, n, max_range, discrete, true);
+		m->host_ns[0] += (u64)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_scan).count();
 		if (m->opt_fail_scan) rc = fail(UFOMAP_ERR_DEVICE, "injected failure of the scan half (test aid)");
 		failed_locally = 0 != rc;
 	}
@@ -426,12 +454,15 @@ int fastBatchStep(ufomap_map* m, ufomap_comm* c, const double origin[3], const d
 			rc = UFOMAP_OK;
 		}
 	}
+	m->batch_pack = nullptr;
 	if (rc) return rc;  // (only a failure of the substitute contribution itself is left: fatal for the communicator)
-	const u32 n4 = (u32)(G >> 4);
-	uint8_t* send = m->b_xsend.as<uint8_t>();
-	uint8_t* recv = m->b_xrecv.as<uint8_t>();
-	hipLaunchKernelGGL(k_pack_slot, dim3(64), dim3(256), 0, m->sstream, reinterpret_cast<uint4*>(send), reinterpret_cast<const uint4*>(ctl),
-	                   m->b_tilebits.as<uint4>(), m->b_gridM.as<uint4>(), m->b_gridH.as<uint4>(), n4);
+	// (a scan that was enqueued has merged itself into the slot and left the walk's descriptors: k_fmerge_batch)
+	const bool packed = 0 != n && !failed_locally;
+	if (!packed) {
+		const u32 n4 = (u32)(G >> 4);
+		hipLaunchKernelGGL(k_pack_slot, dim3(64), dim3(256), 0, m->sstream, reinterpret_cast<uint4*>(send), reinterpret_cast<const uint4*>(ctl),
+		                   m->b_tilebits.as<uint4>(), m->b_gridM.as<uint4>(), m->b_gridH.as<uint4>(), n4);
+	}
 	{
 		// Option gather_stream: the collective on a stream of its own -- only the walk needs what it gathers, so the wire of step i
 		// could overlap the scan half of step i + 1 (which queues behind it on the scan stream). Off by default: with one
@@ -490,25 +521,10 @@ int fastBatchStep(ufomap_map* m, ufomap_comm* c, const double origin[3], const d
 	HIP_TRY(hipStreamWaitEvent(m->stream, m->xchg_ev, 0));
 	Pipe* bp = m->b_bpipe.as<Pipe>();
 	const float miss = (float)m->g.miss_log;
-	for (int w0 = 0; w0 < W; w0 += (int)UFO_BATCH_MAX) {
-		const int B = std::min<int>((int)UFO_BATCH_MAX, W - w0);
-		DescPack pk{};
-		for (int b = 0; b < B; ++b) {
-			const int w = w0 + b;
-			uint8_t* base = recv + (size_t)w * slot;
-			ScanDesc& d = pk.d[b];
-			const bool own = w == c->rank;
-			// (the own scan's control block and tile bitmap are the set's: the walk leaves them in their start state)
-			d.ctl = own ? ctl : reinterpret_cast<ScanCtl*>(base);
-			d.tile_bits = own ? m->b_tilebits.as<u32>() : reinterpret_cast<u32*>(base + UFO_XSLOT_CTL);
-			d.gridM = reinterpret_cast<u32*>(base + UFO_XSLOT_HDR);
-			d.gridH = reinterpret_cast<u32*>(base + UFO_XSLOT_HDR + G);
-			d.host_result = own ? m->h_res : otherResult(m->h_res_all, w);
-			d.done_value = (unsigned long long)m->seq;
-			d.fseq = (unsigned long long)b;
-		}
+	{
+		const int B = std::min<int>((int)UFO_BATCH_MAX, W);
 		m->scan_id += 1;
-		hipLaunchKernelGGL(k_batch_descs, dim3(1), dim3(64), 0, m->stream, bp, pk, (u32)B);
+		if (!packed) hipLaunchKernelGGL(k_batch_descs, dim3(1), dim3(64), 0, m->stream, bp, pk, (u32)B);
 		{
 			ProfScope ps(m, "k_tile");
 			const u32 tw = (m->opt_tile_waves >= 1 && m->opt_tile_waves <= 4) ? (u32)m->opt_tile_waves : 4u;
@@ -520,7 +536,6 @@ int fastBatchStep(ufomap_map* m, ufomap_comm* c, const double origin[3], const d
 			hipLaunchKernelGGL(k_ftail<false>, dim3(1), dim3(UFO_FTAIL_THREADS), 0, m->stream, m->t, m->g, fg, bp, 0ull, m->b_tilerec.as<TileRec>(), m->scan_id, prev_stat,
 			                   m->b_ctl_init.as<ScanCtl>(), (u32*)nullptr, (fg.ntiles + 31u) / 32u);
 		}
-		prev_stat = &bp->wstat[0];  // (a second walk of the same step looks at the first)
 	}
 	HIP_TRY(hipGetLastError());
 	m->pending = true;
@@ -606,11 +621,15 @@ int ufomap_map_insert_batch_ex(ufomap_map* m, ufomap_comm* c, const double senso
 	}
 	// Joins happen at fixed points of the sequence of calls -- the step two before this one is joined here -- never "when it
 	// happens to be complete": a step that has to be repeated is repeated by all ranks together (a collective).
+	// (diagnostics, ufomap_map_debug 52..55: host time in the step's joins + wait for the cloud, scan half, rest of the step, total)
+	const auto t_call = std::chrono::steady_clock::now();
+	auto since = [&](std::chrono::steady_clock::time_point t) { return (u64)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t).count(); };
 	int prc = rotateSets(m);
-	while (countPendingAlts(m) > 1) {
+	while (countPendingAlts(m) > m->opt_batch_depth - 1) {
 		const int jrc = joinOldestAlt(m);
 		if (!prc) prc = jrc;
 	}
+	m->host_ns[2] += since(t_call);
 	// (prc: an EARLIER step's failure, reported when this call returns -- after this rank has entered this step's collective:
 	// the other ranks are on their way into it)
 	if (!c->spec_valid) {  // (the join repeated a step through the list form and found no common grid after it)
@@ -630,12 +649,17 @@ int ufomap_map_insert_batch_ex(ufomap_map* m, ufomap_comm* c, const double senso
 		a.discrete = discrete;
 	}
 	m->gates = useGates(m);
+	const auto t_step = std::chrono::steady_clock::now();
 	const int rc = fastBatchStep(m, c, sensor_origin, d_xyz, n, max_range, discrete);
 	if (rc) return rc;
+	m->host_ns[1] += since(t_step);
 	if (n) {  // (the caller's cloud has been consumed when the call returns: k_fhits kept what a repeat of the step needs)
+		const auto t_wait = std::chrono::steady_clock::now();
 		const int wrc = awaitCloudConsumed(m);
 		if (wrc) return wrc;
+		m->host_ns[2] += since(t_wait);
 	}
+	m->host_ns[3] += since(t_call);
 	if (m->opt_async_apply && !m->profiling) return prc;
 	// not asynchronous: the step is joined here (by every rank)
 	const int jrc = joinOlder(m);

@@ -389,6 +389,11 @@ struct ufomap_map {
 	int opt_lazy_done = 1;        // asynchronous fast-path calls: the end of scan half i is published by the gate kernel of scan i+1 (k_done_gate)
 	ScanDesc sd_saved{};          // ... the descriptor kept back,
 	bool sd_pending = false;      // ... if any
+	// a batch step's own scan is merged into its exchange slot, which also gets the walk's descriptors (fastBatchStep -> fastScanPhase -> k_fmerge_batch)
+	const DescPack* batch_pack = nullptr;
+	u32 batch_B = 0;
+	uint8_t* batch_send = nullptr;
+	int opt_batch_depth = 2;      // batch steps in flight behind the one being enqueued before the oldest is joined (insert_batch: the same on every rank)
 	int opt_hold = 0;             // test aid: a slot is enqueued for every hold-th scan only (walks over several scans whatever the timing)
 	int opt_gate_us = 20000;      // a stream hand-over gives up after this long (and the handle stops using gates)
 	uint64_t seq = 0, latest_seq = 0;  // seq: of the integration that uses the current set; latest_seq: of the newest one enqueued
@@ -3825,6 +3830,8 @@ int ufomap_map_set_option(ufomap_map* m, const char* key, long long value)
 		m->opt_cast_prio = (int)std::max<long long>(0, std::min<long long>(3, value));
 	} else if (0 == strcmp(key, "lazy_done")) {
 		m->opt_lazy_done = value ? 1 : 0;
+	} else if (0 == strcmp(key, "batch_depth")) {
+		m->opt_batch_depth = (int)std::max<long long>(1, std::min<long long>(value, kAlt - 2));
 	} else if (0 == strcmp(key, "hold")) {
 		m->opt_hold = (int)std::max<long long>(0, std::min<long long>(value, kAlt));
 	} else if (0 == strcmp(key, "gate_us")) {
