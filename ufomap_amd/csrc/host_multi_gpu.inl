@@ -619,7 +619,7 @@ int ufomap_map_insert_batch_ex(ufomap_map* m, ufomap_comm* c, const double senso
 		m->batch_world = 0;
 		return listBatchStep(m, c, sensor_origin, d_xyz, d_rgb, n, max_range, discrete, false, simple_ray_casting, early_stopping, depth);
 	}
-	// Joins happen at fixed points of the sequence of calls -- the step two before this one is joined here -- never "when it
+	// Joins happen at fixed points of the sequence of calls -- the step `batch_depth` (3) before this one is joined here -- never "when it
 	// happens to be complete": a step that has to be repeated is repeated by all ranks together (a collective).
 	// (diagnostics, ufomap_map_debug 52..55: host time in the step's joins + wait for the cloud, scan half, rest of the step, total)
 	const auto t_call = std::chrono::steady_clock::now();

@@ -76,7 +76,7 @@ int serialiseNodesShort(ufomap_map* m, const SerArgs& sa, std::vector<uint8_t>& 
 	const u32 list_cap = (u32)std::min<u64>(m->used_est + 8, 0xFFFFFFFFull);
 	hipLaunchKernelGGL(k_ser_prefix, dim3(1), dim3(1024), 0, st, d_cnt, d_lv, list_cap, d_blk, nsb);
 	HIP_TRY(hipMemsetAsync(b_off.p, 0xFF, ncap * 8, st));
-	hipLaunchKernelGGL(k_ser_collect, dim3(nsb), dim3(256), 0, st, m->t, m->g, d_cnt + 32, d_blk, b_list.as<u32>(), list_cap);
+	hipLaunchKernelGGL(k_ser_collect, dim3(nsb), dim3(256), 0, st, m->t, m->g, d_cnt + 32, d_blk, b_list.as<u32>(), list_cap, b_size.as<unsigned long long>());
 	const u32 first = std::max<u32>(1u, sa.min_depth + 1);  // blocks of nodes above min_depth
 	const u32 l_tail = std::min<u32>(first + 2u, L);        // the two widest levels: a launch each; the rest: one workgroup
 	for (u32 l = first; l < l_tail; ++l)
@@ -84,9 +84,14 @@ int serialiseNodesShort(ufomap_map* m, const SerArgs& sa, std::vector<uint8_t>& 
 	const unsigned long long cap = bound;
 	// (the narrow levels: both passes in one launch when they hold few enough blocks for its LDS -- as the previous
 	// serialisation of this map found; should the map have outgrown that since, the kernel says so and the long way is taken)
-	if (m->ser_tail_blocks <= UFO_SER_TAIL_MAX - 64u && m->ser_tail_first == l_tail) {
-		hipLaunchKernelGGL(k_ser_tail_dev, dim3(1), dim3(1024), 0, st, m->t, m->g, sa, b_list.as<u32>(), d_lv, l_tail, L, D, b_size.as<u64>(), b_off.as<u64>(),
-		                   b_out.as<uint8_t>(), d_total, cap);
+	if (m->ser_tail_blocks <= UFO_SER_TAIL_MAX - 64u && m->ser_tail_first == l_tail && ncap <= (1ull << 31)) {
+		// (what the one workgroup needs to know about the children of these levels' blocks is looked up by the whole chip first)
+		DevBuf& b_tail = m->b_ser[5];
+		HIP_TRY(b_tail.reserve((size_t)UFO_SER_TAIL_MAX * 8u * 4u * 2u));
+		u32* gcw = b_tail.as<u32>();
+		u32* gcs = gcw + (size_t)UFO_SER_TAIL_MAX * 8u;
+		hipLaunchKernelGGL(k_ser_tail_prep, dim3(UFO_SER_TAIL_MAX * 8u / 256u), dim3(256), 0, st, m->t, m->g, sa, b_list.as<u32>(), d_lv, l_tail, L, D, b_size.as<u64>(), gcw, gcs);
+		hipLaunchKernelGGL(k_ser_tail_dev, dim3(1), dim3(1024), 0, st, m->t, m->g, b_list.as<u32>(), d_lv, l_tail, L, D, gcw, gcs, b_off.as<u64>(), b_out.as<uint8_t>(), d_total, cap);
 	} else {
 		hipLaunchKernelGGL(k_ser_sizes_tail_dev, dim3(1), dim3(1024), 0, st, m->t, m->g, sa, b_list.as<u32>(), d_lv, l_tail, L, D, b_size.as<u64>(), d_total);
 		hipLaunchKernelGGL(k_ser_write_tail_dev, dim3(1), dim3(1024), 0, st, m->t, m->g, sa, b_list.as<u32>(), d_lv, L, l_tail, D, b_size.as<u64>(), b_off.as<u64>(),

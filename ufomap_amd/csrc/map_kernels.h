@@ -1801,7 +1801,7 @@ __global__ __launch_bounds__(256) void k_ser_count(Table t, MapGeom g, u32* __re
 	if (threadIdx.x < 32u) blk_cnt[32u * blockIdx.x + threadIdx.x] = cnt[threadIdx.x];
 }
 __global__ __launch_bounds__(256) void k_ser_collect(Table t, MapGeom g, const u32* __restrict__ level_off, const u32* __restrict__ blk_base /* [gridDim.x][32], k_ser_prefix */,
-                                                     u32* __restrict__ list, u32 list_cap)
+                                                     u32* __restrict__ list, u32 list_cap, unsigned long long* __restrict__ pos_out = nullptr)
 {
 	__shared__ u32 run[32];  // where the workgroup's next block of a level goes, counted from the level's first entry
 	if (threadIdx.x < 32u) run[threadIdx.x] = blk_base[32u * blockIdx.x + threadIdx.x];
@@ -1814,6 +1814,9 @@ __global__ __launch_bounds__(256) void k_ser_collect(Table t, MapGeom g, const u
 		const u32 l = levelOf(g, lk);
 		const u32 at = level_off[l] + atomicAdd(&run[l], 1u);
 		if (at < list_cap) list[at] = s;
+		// (where the block stands in the list, in the array of subtree sizes: read by k_ser_tail_prep for the blocks of the narrow levels --
+		// their sizes are never stored there -- and overwritten by the size for the others before anybody reads it)
+		if (pos_out) pos_out[s] = at;
 	}
 }
 // Bounding volume and min_depth of Octree::write / writeData (octree.h:779-917): only children whose box intersects the
@@ -2042,58 +2045,99 @@ __global__ __launch_bounds__(1024) void k_ser_write_tail_dev(Table t, MapGeom g,
 		if (0 == l) break;
 	}
 }
-// Both passes over the narrow levels by ONE workgroup in one launch: sizes bottom-up, then offsets and bytes top-down,
-// with what the first pass found out about every child (its block's slot, its share of the stream) kept in LDS -- the
-// second pass costs no hash probe and no flag word, i.e. one dependent global load per level (the block's own offset)
-// instead of five. Up to UFO_SER_TAIL_MAX blocks in these levels (else the two separate kernels).
+// The narrow levels (a launch per level and pass would be fourteen launches of a few blocks each): k_ser_tail_prep + k_ser_tail_dev.
+// Up to UFO_SER_TAIL_MAX blocks in these levels (else the two separate one-workgroup kernels above).
 #define UFO_SER_TAIL_MAX 2048u
-__global__ __launch_bounds__(1024) void k_ser_tail_dev(Table t, MapGeom g, SerArgs sa, const u32* __restrict__ list, const SerLevels* lvp, u32 l_tail, u32 L,
-                                                       u32 D, u64* __restrict__ size, u64* __restrict__ off, uint8_t* __restrict__ out,
-                                                       unsigned long long* __restrict__ total_out, unsigned long long cap)
+#define UFO_SER_TAIL_CHILD 0x80000000u  // gcs: the child's block is one of the narrow levels' -- the low bits are its place among them
+#define UFO_SER_TAIL_OPEN 0xFFFFFFFFu   // gcw: ... and inside the volume: its share of the stream is that block's size, known to the one-workgroup pass
+// What the narrow levels' pass needs to know about every child of every block in them, found by the whole chip at once (round 6: until
+// then the one workgroup looked the children up itself, level after level -- a hash probe and three dependent loads per level and pass
+// of 128 blocks: 97 us for the bench map's 1 400 blocks in levels 3 .. 16 against 6 + 12 us now). Eight lanes per block.
+__global__ __launch_bounds__(256) void k_ser_tail_prep(Table t, MapGeom g, SerArgs sa, const u32* __restrict__ list, const SerLevels* lvp, u32 l_tail, u32 L, u32 D,
+                                                       const u64* __restrict__ size, u32* __restrict__ gcw, u32* __restrict__ gcs)
 {
-	__shared__ u32 cw[UFO_SER_TAIL_MAX][8], cs_[UFO_SER_TAIL_MAX][8];  // per child: bytes it contributes (0: outside the volume), slot of its block (NONE: a leaf)
 	__shared__ u32 lo[32], ln[32];
 	if (threadIdx.x < 32u) {
 		lo[threadIdx.x] = lvp->off[threadIdx.x];
 		ln[threadIdx.x] = lvp->cnt[threadIdx.x];
 	}
 	__syncthreads();
-	const u32 base = lo[l_tail];
-	if (lo[L] + ln[L] - base > UFO_SER_TAIL_MAX) {  // (uniform) more blocks than the LDS arrays hold: the host takes the long way
+	const u32 base = lo[l_tail], nb = lo[L] + ln[L] - base;
+	if (nb > UFO_SER_TAIL_MAX) return;  // (uniform; the one-workgroup pass says so to the host)
+	const u32 ch = threadIdx.x & 7u;
+	for (u32 j = (blockIdx.x * blockDim.x + threadIdx.x) >> 3; j < nb; j += (gridDim.x * blockDim.x) >> 3) {
+		u32 l = l_tail;
+		while (l < L && base + j >= lo[l] + ln[l]) ++l;
+		const u32 s = list[base + j];
+		const u64 lk = t.key(s);
+		double c[3] = {0, 0, 0};
+		if (sa.has_bv) keyCenter(g, lk, l, c);
+		const u32 f = t.flags(s);
+		u32 cslot = NONE;
+		if (l >= 2 && l - 1 > sa.min_depth && ((f >> (16 + ch)) & 1u)) {
+			const u32 cs = tableFindChild(t, s, lk, ch);
+			if (cs != NONE && !(t.flags(cs) & F_DEAD)) cslot = cs;
+		}
+		const bool in = serChildIn(sa, c, ch, g.hs[l - 1]);
+		u32 w = 0, code = cslot;
+		if (cslot != NONE && l - 1 >= l_tail) {
+			code = UFO_SER_TAIL_CHILD | ((u32)size[cslot] - base);  // (k_ser_collect's tag: the child block's place in the list)
+			if (in) w = UFO_SER_TAIL_OPEN;
+		} else if (in) {
+			w = (cslot != NONE) ? (u32)size[cslot] : D;
+		}
+		gcw[8u * j + ch] = w;
+		gcs[8u * j + ch] = code;
+	}
+}
+// Both passes over the narrow levels by ONE workgroup in one launch: sizes bottom-up, then offsets and bytes top-down, on what
+// k_ser_tail_prep left about every child (its block, its share of the stream) -- copied to LDS, where the sizes and offsets of these
+// levels' blocks live too: a level costs LDS reads, a shuffle scan and a barrier, no trip to memory.
+__global__ __launch_bounds__(1024) void k_ser_tail_dev(Table t, MapGeom g, const u32* __restrict__ list, const SerLevels* lvp, u32 l_tail, u32 L, u32 D,
+                                                       const u32* __restrict__ gcw, const u32* __restrict__ gcs, u64* __restrict__ off, uint8_t* __restrict__ out,
+                                                       unsigned long long* __restrict__ total_out, unsigned long long cap)
+{
+	__shared__ __attribute__((aligned(16))) u32 cw[UFO_SER_TAIL_MAX][8], cs_[UFO_SER_TAIL_MAX][8];
+	__shared__ u32 szl[UFO_SER_TAIL_MAX], offl[UFO_SER_TAIL_MAX];  // the blocks' subtree sizes; where their subtrees start in the stream
+	__shared__ u32 lo[32], ln[32];
+	if (threadIdx.x < 32u) {
+		lo[threadIdx.x] = lvp->off[threadIdx.x];
+		ln[threadIdx.x] = lvp->cnt[threadIdx.x];
+	}
+	__syncthreads();
+	const u32 base = lo[l_tail], nb = lo[L] + ln[L] - base;
+	if (nb > UFO_SER_TAIL_MAX) {  // (uniform) more blocks than the LDS arrays hold: the host takes the long way
 		if (0 == threadIdx.x) *total_out = ~0ull;
 		return;
 	}
+	{
+		const uint4* a4 = reinterpret_cast<const uint4*>(gcw);
+		const uint4* b4 = reinterpret_cast<const uint4*>(gcs);
+		uint4* cw4 = reinterpret_cast<uint4*>(&cw[0][0]);
+		uint4* cs4 = reinterpret_cast<uint4*>(&cs_[0][0]);
+		for (u32 i = threadIdx.x; i < 2u * nb; i += blockDim.x) {
+			cw4[i] = a4[i];
+			cs4[i] = b4[i];
+		}
+		for (u32 i = threadIdx.x; i < nb; i += blockDim.x) offl[i] = 0xFFFFFFFFu;
+	}
+	__syncthreads();
 	const u32 ch = threadIdx.x & 7u;
-	auto levelSync = [] {
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-		__syncthreads();
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-	};
 	// ---- sizes, bottom-up (serSizesLevel, eight lanes per block) ----
 	for (u32 l = l_tail; l <= L; ++l) {
-		const double chs = g.hs[l - 1];
 		for (u32 i = threadIdx.x >> 3; i < ln[l]; i += blockDim.x >> 3) {
 			const u32 j = lo[l] - base + i;
-			const u32 s = list[lo[l] + i];
-			const u64 lk = t.key(s);
-			double c[3] = {0, 0, 0};
-			if (sa.has_bv) keyCenter(g, lk, l, c);
-			const u32 f = t.flags(s);
-			unsigned long long add = 0;
-			u32 cslot = NONE;
-			if (l >= 2 && l - 1 > sa.min_depth && ((f >> (16 + ch)) & 1u)) {
-				const u32 cs = tableFindChild(t, s, lk, ch);
-				if (cs != NONE && !(t.flags(cs) & F_DEAD)) cslot = cs;
+			u32 add = cw[j][ch];
+			if (UFO_SER_TAIL_OPEN == add) {
+				add = szl[cs_[j][ch] & ~UFO_SER_TAIL_CHILD];
+				cw[j][ch] = add;
 			}
-			if (serChildIn(sa, c, ch, chs)) add = (cslot != NONE) ? size[cslot] : (unsigned long long)D;
-			cw[j][ch] = (u32)add;
-			cs_[j][ch] = cslot;
-			for (int o = 1; o < 8; o <<= 1) add += __shfl_xor(add, o);
-			if (0 == ch) size[s] = add + ((1 == l) ? 0ull : 1ull);
+			for (int o = 1; o < 8; o <<= 1) add += (u32)__shfl_xor((int)add, o);
+			if (0 == ch) szl[j] = add + ((1 == l) ? 0u : 1u);
 		}
-		levelSync();
+		__syncthreads();
 	}
-	const unsigned long long total = ln[L] ? 1ull + size[list[lo[L]]] : 0ull;  // (no live root block: the root is a leaf, the host writes that stream itself)
+	const unsigned long long total = ln[L] ? 1ull + (unsigned long long)szl[lo[L] - base] : 0ull;  // (no live root block: the root is a leaf, the host writes that stream itself)
 	if (0 == threadIdx.x) *total_out = total;
 	if (0 == total || total > cap) return;  // (uniform; too large for the host's bound cannot happen)
 	// ---- offsets and bytes, top-down (serWriteLevel) ----
@@ -2101,25 +2145,30 @@ __global__ __launch_bounds__(1024) void k_ser_tail_dev(Table t, MapGeom g, SerAr
 	for (u32 l = L; l + 1 > l_tail; --l) {
 		for (u32 i = threadIdx.x >> 3; i < ln[l]; i += blockDim.x >> 3) {
 			const u32 j = lo[l] - base + i;
-			const u32 s = list[lo[l] + i];
-			const u64 at0 = (l == L) ? 1ull : off[s];  // the root's subtree starts behind the 0xFF byte of writeNodes
-			if (at0 == ~0ull) continue;
-			const u32 w = cw[j][ch], cslot = cs_[j][ch];
-			u32 mask = (cslot != NONE) ? (1u << ch) : 0u;
+			const u32 at0 = (l == L) ? 1u : offl[j];  // the root's subtree starts behind the 0xFF byte of writeNodes
+			if (at0 == 0xFFFFFFFFu) continue;
+			const u32 w = cw[j][ch], code = cs_[j][ch];
+			u32 mask = (code != NONE) ? (1u << ch) : 0u;
 			for (int o = 1; o < 8; o <<= 1) mask |= (u32)__shfl_xor((int)mask, o);
 			u32 incl = w;
 			for (int o = 1; o < 8; o <<= 1) {
 				const u32 v = (u32)__shfl_up((int)incl, o);
 				if ((int)ch >= o) incl += v;
 			}
-			const u64 at = at0 + ((l >= 2) ? 1ull : 0ull) + (u64)(incl - w);
+			const u32 at = at0 + ((l >= 2) ? 1u : 0u) + (incl - w);
 			if (0 == ch && l >= 2) out[at0] = (uint8_t)mask;
 			if (w) {
-				if (cslot != NONE) off[cslot] = at;
-				else serPutLeaf(out, at, t.occ(s)[ch], t.rgb ? t.rgb[8 * (size_t)s + ch] : 0u, D);
+				if (NONE == code) {
+					const u32 s = list[lo[l] + i];
+					serPutLeaf(out, at, t.occ(s)[ch], t.rgb ? t.rgb[8 * (size_t)s + ch] : 0u, D);
+				} else if (code & UFO_SER_TAIL_CHILD) {
+					offl[code & ~UFO_SER_TAIL_CHILD] = at;
+				} else {
+					off[code] = at;
+				}
 			}
 		}
-		levelSync();
+		__syncthreads();
 		if (0 == l) break;
 	}
 }
