@@ -1158,10 +1158,11 @@ __global__ void k_vol_begin(VolRec* __restrict__ rec, ScanCtl* ctl, u32 L)
 
 // One level of the descent: the records of depth `cd` nodes are [dl_start[cd], dl_start[cd-1]).
 // kill: blocks whose subtree deleteChildren removes (children at min_depth that had been expanded).
+// (lo, hi: the level's records; the children's records are reserved at next_base + *next_cnt -- k_vol_down: the running total in
+// the control block, k_vol_all: a counter per level in LDS)
 __device__ inline void volDownLevel(const Table& t, const MapGeom& g, const VolArgs& a, u32 cd, VolRec* __restrict__ rec, u32 rcap, u32* __restrict__ kill,
-                                    u32 kcap, u32 scan_id, ScanCtl* ctl)
+                                    u32 kcap, u32 scan_id, ScanCtl* ctl, u32 lo, u32 hi, u32* next_cnt, u32 next_base)
 {
-	const u32 lo = ctl->dl_start[cd], hi = min(ctl->dl_start[cd - 1], rcap);
 	const u32 max_probe = (t.mask >> 1) + 1;
 	const u32 child_depth = cd - 1;
 	const double chs = g.hs[child_depth];
@@ -1213,7 +1214,7 @@ __device__ inline void volDownLevel(const Table& t, const MapGeom& g, const VolA
 			inter |= volIntersects(a, ci, chs) ? (1u << i) : 0u;
 		}
 		const bool descend = 0 != child_depth && a.min_depth < child_depth;
-		u32 next = (descend && inter) ? atomicAdd(&ctl->dl_total, (u32)__popc(inter)) : 0u;
+		u32 next = (descend && inter) ? next_base + atomicAdd(next_cnt, (u32)__popc(inter)) : 0u;
 		for (u32 i = 0; i < 8; ++i) {
 			double cc[3] = {me.c[0], me.c[1], me.c[2]};  // getChildCenter (octree.h:625-633)
 			cc[0] += ((i & 1) ? chs : -chs);
@@ -1269,7 +1270,7 @@ __device__ inline void volDownLevel(const Table& t, const MapGeom& g, const VolA
 __global__ __launch_bounds__(256) void k_vol_down(Table t, MapGeom g, VolArgs a, u32 cd, VolRec* __restrict__ rec, u32 rcap,
                                                   u32* __restrict__ kill, u32 kcap, u32 scan_id, ScanCtl* ctl)
 {
-	volDownLevel(t, g, a, cd, rec, rcap, kill, kcap, scan_id, ctl);
+	volDownLevel(t, g, a, cd, rec, rcap, kill, kcap, scan_id, ctl, ctl->dl_start[cd], min(ctl->dl_start[cd - 1], rcap), &ctl->dl_total, 0u);
 }
 
 // Breadth-first removal of subtrees: blocks kill[lo, hi) die, their live child blocks are appended.
@@ -1304,10 +1305,9 @@ __global__ __launch_bounds__(256) void k_vol_kill(Table t, u32* __restrict__ kil
 }
 
 // One level of the way back: `return !changed || updateNode(node, depth)` (OMB:1030) for the depth-`cd` records.
-__device__ inline void volUpLevel(const Table& t, const MapGeom& g, u32 cd, VolRec* __restrict__ rec, u32 rcap, const ScanCtl* ctl)
+__device__ inline void volUpLevel(const Table& t, const MapGeom& g, u32 cd, VolRec* __restrict__ rec, const ScanCtl* ctl, u32 lo, u32 hi)
 {
 	if (ctl->err) return;
-	const u32 lo = ctl->dl_start[cd], hi = min(ctl->dl_start[cd - 1], rcap);
 	for (u32 r = lo + blockIdx.x * blockDim.x + threadIdx.x; r < hi; r += gridDim.x * blockDim.x) {
 		const VolRec me = rec[r];
 		bool ret = true;
@@ -1324,19 +1324,23 @@ __device__ inline void volUpLevel(const Table& t, const MapGeom& g, u32 cd, VolR
 
 __global__ __launch_bounds__(256) void k_vol_up(Table t, MapGeom g, u32 cd, VolRec* __restrict__ rec, u32 rcap, const ScanCtl* ctl)
 {
-	volUpLevel(t, g, cd, rec, rcap, ctl);
+	volUpLevel(t, g, cd, rec, ctl, ctl->dl_start[cd], min(ctl->dl_start[cd - 1], rcap));
 }
 // A volume of a few thousand nodes at most (the robot's own box, cleared after every scan: server.cpp:122-160) at
 // min_depth 0: the whole descent and the way back by ONE workgroup, a barrier per level -- instead of three launches per
 // level (48 for 16 levels, ~4 us each and nothing to do in most of them).
 __global__ __launch_bounds__(1024) void k_vol_all(Table t, MapGeom g, VolArgs a, u32 L, VolRec* __restrict__ rec, u32 rcap, u32* __restrict__ kill, u32 kcap,
-                                                  u32 scan_id, ScanCtl* ctl)
+                                                  u32 scan_id, ScanCtl* ctl, ScanCtl* host_result, unsigned long long done_value)
 {
 	auto levelSync = [] {
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 		__syncthreads();
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 	};
+	// (round 6: where a level's records start and how many children it has reserved live in LDS -- a returning atomic on the control
+	// block and a second barrier per level, to publish the next level's start, cost the descent a trip to memory per level)
+	__shared__ u32 lstart[26], lcnt[26];  // records of depth cd: [lstart[cd], lstart[cd - 1]); lcnt[cd]: reserved for depth cd
+	if (threadIdx.x < 26u) lcnt[threadIdx.x] = 0;
 	if (0 == threadIdx.x) {
 		VolRec r;
 		r.lk = 1;
@@ -1346,23 +1350,45 @@ __global__ __launch_bounds__(1024) void k_vol_all(Table t, MapGeom g, VolArgs a,
 		r.changed = 0;
 		r.pad = 0;
 		rec[0] = r;
-		ctl->dl_start[L] = 0;
-		ctl->dl_total = 1;
-		ctl->dl_start[L - 1] = 1;
 	}
 	levelSync();
+	u32 lo = 0, hi = 1;  // (uniform: the level's records)
 	for (u32 cd = L; cd > a.min_depth; --cd) {
-		volDownLevel(t, g, a, cd, rec, rcap, kill, kcap, scan_id, ctl);
+		volDownLevel(t, g, a, cd, rec, rcap, kill, kcap, scan_id, ctl, lo, min(hi, rcap), &lcnt[cd - 1], hi);
 		levelSync();
-		if (cd - 1 > a.min_depth && cd >= 2) {
-			if (0 == threadIdx.x) ctl->dl_start[cd - 2] = ctl->dl_total;  // (k_coarse_mark)
-			levelSync();
+		if (0 == threadIdx.x) lstart[cd] = lo;  // (for the way back)
+		const u32 n = lcnt[cd - 1];             // (complete: nobody adds to it after this level)
+		lo = hi;
+		hi += n;
+	}
+	if (0 == threadIdx.x) lstart[a.min_depth] = lo;
+	levelSync();
+	for (u32 cd = a.min_depth + 1; cd <= L; ++cd) {
+		volUpLevel(t, g, cd, rec, ctl, lstart[cd], min(lstart[cd - 1], rcap));
+		levelSync();
+	}
+	// Round 6: the finished control block -- with the table's fill, which the host sizes the next update by -- goes to the host's
+	// pinned copy from here, followed by the word the host polls (as k_ftail does for a scan): the call needed a stream
+	// synchronisation, a read-back copy, a counting kernel and two more copies with a second synchronisation for it (60 us).
+	if (!host_result) return;
+	if (threadIdx.x < 64u) {
+		u32 ng, nu;
+		tableCounts(t, threadIdx.x, &ng, &nu);
+		if (0 == threadIdx.x) {
+			ctl->used_now = __hip_atomic_load(&t.root->used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			ctl->used_g_now = ng;
+			ctl->used_u_now = nu;
 		}
 	}
-	for (u32 cd = a.min_depth + 1; cd <= L; ++cd) {
-		volUpLevel(t, g, cd, rec, rcap, ctl);
-		levelSync();
+	levelSync();
+	{
+		constexpr u32 W_CORE = offsetof(ScanCtl, dbg) / 4u;
+		const u32* dev = reinterpret_cast<const u32*>(ctl);
+		u32* host = reinterpret_cast<u32*>(host_result);
+		for (u32 w = threadIdx.x; w < W_CORE; w += blockDim.x) host[w] = __hip_atomic_load(&dev[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	}
+	__syncthreads();  // (every thread's stores to the pinned block have been acknowledged: the barrier waits for them)
+	if (0 == threadIdx.x) __hip_atomic_store(reinterpret_cast<unsigned long long*>(host_result + 1), done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // min_depth == depth_levels: the root itself is set (OMB:505-511) -- every block dies

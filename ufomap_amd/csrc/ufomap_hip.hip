@@ -446,6 +446,7 @@ struct ufomap_map {
 	ScanCtl* h_res = nullptr;  // pinned: k_ftail stores the finished control block here itself (no read-back copy, no stream sync)
 	unsigned long long* sig_prep = nullptr;  // (HandOver)
 	bool done_by_flag = false;
+	bool res_direct = false;      // ... by a kernel of the general path that stored the result block itself (setValueVolume: k_vol_all)
 	bool ctl_clean = false;    // the device control block holds the fast path's start state (k_ftail left it so): no upload
 	DevBuf b_ctl_init;         // that start state, uploaded once
 	bool ctl_init_done = false;
@@ -1446,9 +1447,16 @@ int finishPending(ufomap_map* m)
 			m->n_walk_scans += m->h_ctl->walk_scans;
 		}
 
+	} else if (m->res_direct && m->done_by_flag && 0 == (m->h_res->err & ERR_NOT_STORED)) {
+		// (setValueVolume's one-workgroup walk has stored the block, the table's fill included: k_vol_all)
+		memcpy(m->h_ctl, m->h_res, offsetof(ScanCtl, dbg));
+		m->used_est = m->h_ctl->used_now;
+		m->used_g = m->h_ctl->used_g_now;
+		m->used_u = m->h_ctl->used_u_now;
 	} else {
 		rc = readCtlDone(m);
 	}
+	m->res_direct = false;
 	if (rc) return rc;
 	drainEvents(m);
 	if (m->h_ctl->err) m->prev_flagged = true;  // (sticky: doInsert resets it before a join)
@@ -2788,6 +2796,7 @@ int ufomap_map_set_value_volume_ch(ufomap_map* m, const double aabb_center[3], c
 	}
 	m->cs = m->stream;
 	m->args = ScanArgs{};
+	bool res_direct = false;
 	ScanCtl init;
 	memset(&init, 0, sizeof(init));
 	for (int k = 0; k < 3; ++k) {
@@ -2835,7 +2844,12 @@ int ufomap_map_set_value_volume_ch(ufomap_map* m, const double aabb_center[3], c
 		u32* kill = m->b_dlist.as<u32>();
 		if (0 == min_depth && total <= 8192 && m->opt_vol_fused) {
 			// (a small volume: one workgroup walks all levels, map_kernels.h: k_vol_all)
-			hipLaunchKernelGGL(k_vol_all, dim3(1), dim3(1024), 0, m->cs, m->t, m->g, a, L, rec, rcap, kill, kcap, m->scan_id, ctl);
+			// (... and reports to the pinned result block itself: no synchronisation, no read-back below)
+			m->seq = ++m->latest_seq;
+			m->h_res->err = ERR_NOT_STORED;
+			*reinterpret_cast<volatile unsigned long long*>(m->h_res + 1) = 0ull;
+			res_direct = true;
+			hipLaunchKernelGGL(k_vol_all, dim3(1), dim3(1024), 0, m->cs, m->t, m->g, a, L, rec, rcap, kill, kcap, m->scan_id, ctl, m->h_res, (unsigned long long)m->seq);
 		} else {
 		hipLaunchKernelGGL(k_vol_begin, dim3(1), dim3(1), 0, m->cs, rec, ctl, L);
 		for (u32 cd = L; cd > min_depth; --cd) {
@@ -2856,7 +2870,22 @@ int ufomap_map_set_value_volume_ch(ufomap_map* m, const double aabb_center[3], c
 	}
 	HIP_TRY(hipGetLastError());
 	m->pending = true;
-	HIP_TRY(hipStreamSynchronize(m->stream));
+	if (res_direct) {
+		m->done_by_flag = true;
+		m->res_direct = true;
+		volatile unsigned long long* done = reinterpret_cast<volatile unsigned long long*>(m->h_res + 1);
+		const auto t0 = std::chrono::steady_clock::now();
+		for (u32 spins = 0; *done != (unsigned long long)m->seq; ++spins) {
+			if (0 == (spins & 1023u) && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) {
+				HIP_TRY(hipStreamSynchronize(m->stream));
+				if (*done != (unsigned long long)m->seq) return fail(UFOMAP_ERR_DEVICE, "setValueVolume: the walk did not report");
+				break;
+			}
+		}
+		std::atomic_thread_fence(std::memory_order_acquire);
+	} else {
+		HIP_TRY(hipStreamSynchronize(m->stream));
+	}
 	return finishPending(m);
 }
 
@@ -3091,6 +3120,12 @@ int ufomap_map_wait(ufomap_map* m)
 	// waits for their scan halves on the device -- instead of after the host has seen the scan stream and the earlier walks drain:
 	// one host round trip and four launches less in the tail of every timed region (the driver's 20-step regions carry 10 us of
 	// that tail per step). A flagged integration found below still makes everything behind it stand back and be repeated in order.
+	if (!m->pending && 0 == countPendingAlts(m) && !m->sd_pending && UFOMAP_OK == m->async_status && !m->prev_flagged) {
+		// (nothing in flight -- every kernel of the prep and scan streams belongs to an integration, and the last one has been joined:
+		// the getters that call this before they read a host-side value do not pay two stream synchronisations for it)
+		m->chain_ok = false;
+		return UFOMAP_OK;
+	}
 	int early_frc = UFOMAP_OK;
 	if (!m->prev_flagged && UFOMAP_OK == m->async_status && m->opt_wait_flush_first) early_frc = flushDeferred(m);
 	HIP_TRY(hipStreamSynchronize(m->pstream));
