@@ -75,8 +75,8 @@ int serialiseNodesShort(ufomap_map* m, const SerArgs& sa, std::vector<uint8_t>& 
 	hipLaunchKernelGGL(k_ser_count, dim3(nsb), dim3(256), 0, st, m->t, m->g, d_blk);
 	const u32 list_cap = (u32)std::min<u64>(m->used_est + 8, 0xFFFFFFFFull);
 	hipLaunchKernelGGL(k_ser_prefix, dim3(1), dim3(1024), 0, st, d_cnt, d_lv, list_cap, d_blk, nsb);
-	HIP_TRY(hipMemsetAsync(b_off.p, 0xFF, ncap * 8, st));
-	hipLaunchKernelGGL(k_ser_collect, dim3(nsb), dim3(256), 0, st, m->t, m->g, d_cnt + 32, d_blk, b_list.as<u32>(), list_cap, b_size.as<unsigned long long>());
+	hipLaunchKernelGGL(k_ser_collect, dim3(nsb), dim3(256), 0, st, m->t, m->g, d_cnt + 32, d_blk, b_list.as<u32>(), list_cap, b_size.as<unsigned long long>(),
+	                   b_off.as<unsigned long long>());
 	const u32 first = std::max<u32>(1u, sa.min_depth + 1);  // blocks of nodes above min_depth
 	const u32 l_tail = std::min<u32>(first + 2u, L);        // the two widest levels: a launch each; the rest: one workgroup
 	for (u32 l = first; l < l_tail; ++l)

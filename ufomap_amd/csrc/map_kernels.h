@@ -1305,7 +1305,7 @@ __global__ __launch_bounds__(256) void k_vol_kill(Table t, u32* __restrict__ kil
 }
 
 // One level of the way back: `return !changed || updateNode(node, depth)` (OMB:1030) for the depth-`cd` records.
-__device__ inline void volUpLevel(const Table& t, const MapGeom& g, u32 cd, VolRec* __restrict__ rec, const ScanCtl* ctl, u32 lo, u32 hi)
+__device__ inline void volUpLevel(const Table& t, const MapGeom& g, u32 cd, VolRec* __restrict__ rec, const ScanCtl* ctl, u32 lo, u32 hi, u32* marked = nullptr)
 {
 	if (ctl->err) return;
 	for (u32 r = lo + blockIdx.x * blockDim.x + threadIdx.x; r < hi; r += gridDim.x * blockDim.x) {
@@ -1318,7 +1318,10 @@ __device__ inline void volUpLevel(const Table& t, const MapGeom& g, u32 cd, VolR
 			if (sm.collapsible) collapseBlock(t, me.slot, me.lk);
 			ret = writeToParent(t, g, me.slot, me.lk, sm);
 		}
-		if (ret && me.parent != NONE) atomicOr(&rec[me.parent].changed, 1u);
+		if (ret && me.parent != NONE) {
+			atomicOr(&rec[me.parent].changed, 1u);
+			if (marked) *marked = 1u;  // (k_vol_all, LDS: the level above has something to do)
+		}
 	}
 }
 
@@ -1330,7 +1333,7 @@ __global__ __launch_bounds__(256) void k_vol_up(Table t, MapGeom g, u32 cd, VolR
 // min_depth 0: the whole descent and the way back by ONE workgroup, a barrier per level -- instead of three launches per
 // level (48 for 16 levels, ~4 us each and nothing to do in most of them).
 __global__ __launch_bounds__(1024) void k_vol_all(Table t, MapGeom g, VolArgs a, u32 L, VolRec* __restrict__ rec, u32 rcap, u32* __restrict__ kill, u32 kcap,
-                                                  u32 scan_id, ScanCtl* ctl, ScanCtl* host_result, unsigned long long done_value)
+                                                  u32 scan_id, ScanCtl* ctl, ScanCtl* host_result, unsigned long long done_value, u32 init_ctl)
 {
 	auto levelSync = [] {
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1339,8 +1342,15 @@ __global__ __launch_bounds__(1024) void k_vol_all(Table t, MapGeom g, VolArgs a,
 	};
 	// (round 6: where a level's records start and how many children it has reserved live in LDS -- a returning atomic on the control
 	// block and a second barrier per level, to publish the next level's start, cost the descent a trip to memory per level)
-	__shared__ u32 lstart[26], lcnt[26];  // records of depth cd: [lstart[cd], lstart[cd - 1]); lcnt[cd]: reserved for depth cd
-	if (threadIdx.x < 26u) lcnt[threadIdx.x] = 0;
+	__shared__ u32 lstart[26], lcnt[26], lmark[26];  // records of depth cd: [lstart[cd], lstart[cd - 1]); lcnt[cd]: reserved for depth cd
+	if (threadIdx.x < 26u) lcnt[threadIdx.x] = lmark[threadIdx.x] = 0;
+	if (init_ctl) {
+		// (the control block's start state: zero but for the box of changes -- written here instead of uploaded by the host)
+		u32* cw = reinterpret_cast<u32*>(ctl);
+		for (u32 w = threadIdx.x; w < (u32)(sizeof(ScanCtl) / 4u); w += blockDim.x) cw[w] = 0u;
+		levelSync();
+		if (threadIdx.x < 3u) ctl->aabb_min[threadIdx.x] = ~0ull;
+	}
 	if (0 == threadIdx.x) {
 		VolRec r;
 		r.lk = 1;
@@ -1364,8 +1374,10 @@ __global__ __launch_bounds__(1024) void k_vol_all(Table t, MapGeom g, VolArgs a,
 	if (0 == threadIdx.x) lstart[a.min_depth] = lo;
 	levelSync();
 	for (u32 cd = a.min_depth + 1; cd <= L; ++cd) {
-		volUpLevel(t, g, cd, rec, ctl, lstart[cd], min(lstart[cd - 1], rcap));
+		volUpLevel(t, g, cd, rec, ctl, lstart[cd], min(lstart[cd - 1], rcap), &lmark[cd + 1]);
 		levelSync();
+		// (a record is only ever marked from the level below: when none was, nothing is left to do on the way to the root)
+		if (0 == lmark[cd + 1]) break;
 	}
 	// Round 6: the finished control block -- with the table's fill, which the host sizes the next update by -- goes to the host's
 	// pinned copy from here, followed by the word the host polls (as k_ftail does for a scan): the call needed a stream
@@ -1827,7 +1839,8 @@ __global__ __launch_bounds__(256) void k_ser_count(Table t, MapGeom g, u32* __re
 	if (threadIdx.x < 32u) blk_cnt[32u * blockIdx.x + threadIdx.x] = cnt[threadIdx.x];
 }
 __global__ __launch_bounds__(256) void k_ser_collect(Table t, MapGeom g, const u32* __restrict__ level_off, const u32* __restrict__ blk_base /* [gridDim.x][32], k_ser_prefix */,
-                                                     u32* __restrict__ list, u32 list_cap, unsigned long long* __restrict__ pos_out = nullptr)
+                                                     u32* __restrict__ list, u32 list_cap, unsigned long long* __restrict__ pos_out = nullptr,
+                                                     unsigned long long* __restrict__ off_out = nullptr)
 {
 	__shared__ u32 run[32];  // where the workgroup's next block of a level goes, counted from the level's first entry
 	if (threadIdx.x < 32u) run[threadIdx.x] = blk_base[32u * blockIdx.x + threadIdx.x];
@@ -1843,6 +1856,8 @@ __global__ __launch_bounds__(256) void k_ser_collect(Table t, MapGeom g, const u
 		// (where the block stands in the list, in the array of subtree sizes: read by k_ser_tail_prep for the blocks of the narrow levels --
 		// their sizes are never stored there -- and overwritten by the size for the others before anybody reads it)
 		if (pos_out) pos_out[s] = at;
+		// (... and "no place in the stream yet" for every block that can get one: the serialiser's offsets need no fill of the whole array)
+		if (off_out) off_out[s] = ~0ull;
 	}
 }
 // Bounding volume and min_depth of Octree::write / writeData (octree.h:779-917): only children whose box intersects the

@@ -2804,7 +2804,10 @@ int ufomap_map_set_value_volume_ch(ufomap_map* m, const double aabb_center[3], c
 		init.aabb_max[k] = 0ull;
 	}
 	*m->h_ctl = init;
-	HIP_TRY(hipMemcpyAsync(m->b_ctl.p, m->h_ctl, sizeof(ScanCtl), hipMemcpyHostToDevice, m->stream));
+	// (the one-workgroup walk writes the block's start state itself: no upload in front of it)
+	const bool one_wg = L != min_depth && 0 == min_depth && m->opt_vol_fused;
+	if (!one_wg) HIP_TRY(hipMemcpyAsync(m->b_ctl.p, m->h_ctl, sizeof(ScanCtl), hipMemcpyHostToDevice, m->stream));
+	bool ctl_uploaded = !one_wg;
 	m->ctl_clean = false;  // (the set's device control block no longer holds the fast path's start state)
 	ScanCtl* ctl = m->b_ctl.as<ScanCtl>();
 	m->scan_id += 1;
@@ -2842,6 +2845,10 @@ int ufomap_map_set_value_volume_ch(ufomap_map* m, const double aabb_center[3], c
 		HIP_TRY(m->b_dlist.reserve((size_t)kcap * 4));
 		VolRec* rec = m->b_crec.as<VolRec>();
 		u32* kill = m->b_dlist.as<u32>();
+		if (!(0 == min_depth && total <= 8192 && m->opt_vol_fused) && !ctl_uploaded) {
+			HIP_TRY(hipMemcpyAsync(m->b_ctl.p, m->h_ctl, sizeof(ScanCtl), hipMemcpyHostToDevice, m->stream));
+			ctl_uploaded = true;
+		}
 		if (0 == min_depth && total <= 8192 && m->opt_vol_fused) {
 			// (a small volume: one workgroup walks all levels, map_kernels.h: k_vol_all)
 			// (... and reports to the pinned result block itself: no synchronisation, no read-back below)
@@ -2849,7 +2856,7 @@ int ufomap_map_set_value_volume_ch(ufomap_map* m, const double aabb_center[3], c
 			m->h_res->err = ERR_NOT_STORED;
 			*reinterpret_cast<volatile unsigned long long*>(m->h_res + 1) = 0ull;
 			res_direct = true;
-			hipLaunchKernelGGL(k_vol_all, dim3(1), dim3(1024), 0, m->cs, m->t, m->g, a, L, rec, rcap, kill, kcap, m->scan_id, ctl, m->h_res, (unsigned long long)m->seq);
+			hipLaunchKernelGGL(k_vol_all, dim3(1), dim3(1024), 0, m->cs, m->t, m->g, a, L, rec, rcap, kill, kcap, m->scan_id, ctl, m->h_res, (unsigned long long)m->seq, ctl_uploaded ? 0u : 1u);
 		} else {
 		hipLaunchKernelGGL(k_vol_begin, dim3(1), dim3(1), 0, m->cs, rec, ctl, L);
 		for (u32 cd = L; cd > min_depth; --cd) {
