@@ -11,6 +11,9 @@ for kind in ("pageable", "pinned"):
     for st in (0, 1):
         m = OccupancyMap(0.16)
         m.set_option("stage_thread", st)
+        for o in sys.argv[1:]:
+            k, v = o.split("=")
+            m.set_option(k, int(v))
         pcs = [PointCloud(c[1].copy()) for c in clouds] if kind == "pageable" else [PointCloud(t.numpy()) for t in pinned]
         for rep in range(3):
             m.insertPointCloudWait(); m.clear()

@@ -3822,6 +3822,32 @@ __global__ void k_host_gate(const unsigned long long* flag, unsigned long long v
 		}
 	}
 }
+// A pageable cloud on its way from the helper thread's staging buffer (pinned) to HBM, piece by piece: the workgroups of piece k wait
+// for the helper's word to say that piece k has been copied, then read it across PCIe themselves -- the cloud is in HBM one piece's
+// transfer after the helper's last byte (a call that waits for its scan: 40 us sooner than behind a DMA transfer of the whole cloud).
+// Measured alternatives (profiles/r06_ab_experiments.log): hipMemcpyAsync per piece -- every extra copy costs the stream ~20 us;
+// more than ~32 workgroups -- slower, 128 of them 3x; the word passed on through HBM by one polling wave -- no different.
+__global__ __launch_bounds__(256) void k_stage_copy(const unsigned long long* flag, unsigned long long job, u32 first_piece, const uint8_t* __restrict__ src,
+                                                    uint8_t* __restrict__ dst, unsigned long long bytes, unsigned long long chunk, u32 wgs_per_piece,
+                                                    unsigned long long max_ticks)
+{
+	const u32 piece = blockIdx.x / wgs_per_piece, w = blockIdx.x % wgs_per_piece;
+	if (0 == threadIdx.x) {
+		const unsigned long long want = (job << 8) | (unsigned long long)(first_piece + piece + 1u), t0 = wall_clock64();
+		while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
+			__builtin_amdgcn_s_sleep(8);
+			if (wall_clock64() - t0 > max_ticks) break;  // (100 MHz clock; cannot happen: the call joins the helper before it returns)
+		}
+	}
+	__syncthreads();
+	const unsigned long long lo = (unsigned long long)piece * chunk, hi = min(lo + chunk, bytes);  // (chunk: a multiple of 16)
+	if (lo >= hi) return;
+	const unsigned long long n16 = (hi - lo) >> 4;
+	const uint4* s4 = reinterpret_cast<const uint4*>(src + lo);
+	uint4* d4 = reinterpret_cast<uint4*>(dst + lo);
+	for (unsigned long long i = (unsigned long long)w * blockDim.x + threadIdx.x; i < n16; i += (unsigned long long)wgs_per_piece * blockDim.x) d4[i] = s4[i];
+	if (0 == w && threadIdx.x < (u32)((hi - lo) & 15ull)) dst[lo + (n16 << 4) + threadIdx.x] = src[lo + (n16 << 4) + threadIdx.x];
+}
 // The end of one scan half and the gate of the next in ONE launch (asynchronous calls in a row: the host keeps the
 // descriptor of scan i back and hands it over with the gate of scan i+1 -- one one-wave kernel per scan on the scan stream
 // instead of two; whatever needs scan i before another scan arrives publishes it with k_scan_done, ufomap_hip.hip:

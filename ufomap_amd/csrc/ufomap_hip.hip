@@ -256,9 +256,12 @@ struct StageWorker {
 		void* dst[2];
 		const void* src[2];
 		size_t bytes[2];
+		size_t chunk;  // the first range goes in pieces of this size, announced one by one: its H2D copy starts behind the first
 	} job{};
 	std::atomic<unsigned long long> posted{0}, done{0};
-	volatile unsigned long long* flag = nullptr;  // pinned: the number of the newest finished copy -- what k_host_gate polls
+	// pinned, what k_host_gate polls: (job number << 8) | pieces of the job that have been copied -- the second range is the last piece
+	volatile unsigned long long* flag = nullptr;
+	static u32 pieces(const Job& j) { return (u32)((j.bytes[0] + j.chunk - 1) / j.chunk) + (j.bytes[1] ? 1u : 0u); }
 	void run()
 	{
 		unsigned long long seen = 0;
@@ -275,10 +278,17 @@ struct StageWorker {
 			}
 			if (quit.load()) return;
 			seen = posted.load(std::memory_order_acquire);
-			for (int k = 0; k < 2; ++k)
-				if (job.bytes[k]) memcpy(job.dst[k], job.src[k], job.bytes[k]);
-			std::atomic_thread_fence(std::memory_order_release);
-			*flag = seen;
+			u32 piece = 0;
+			for (size_t off = 0; off < job.bytes[0]; off += job.chunk) {
+				memcpy(static_cast<char*>(job.dst[0]) + off, static_cast<const char*>(job.src[0]) + off, std::min(job.chunk, job.bytes[0] - off));
+				std::atomic_thread_fence(std::memory_order_release);
+				*flag = (seen << 8) | (unsigned long long)++piece;
+			}
+			if (job.bytes[1]) {
+				memcpy(job.dst[1], job.src[1], job.bytes[1]);
+				std::atomic_thread_fence(std::memory_order_release);
+				*flag = (seen << 8) | (unsigned long long)++piece;
+			}
 			done.store(seen, std::memory_order_release);
 		}
 	}
@@ -393,6 +403,7 @@ struct ufomap_map {
 	const DescPack* batch_pack = nullptr;
 	u32 batch_B = 0;
 	uint8_t* batch_send = nullptr;
+	int opt_stage_pieces = 8;     // a pageable cloud reaches its pinned staging buffer -- and from there HBM -- in this many pieces (uploadCloud)
 	int opt_batch_depth = 3;      // batch steps in flight, the one being enqueued included, before the oldest is joined (insert_batch: the same on
 	                              // every rank). 2 until round 6: the host then enqueued step i only after the walk of step i - 2 -- i.e. when the scan
 	                              // half of step i - 1 was ending -- and the scan stream idled for the time of the enqueue (0.078 -> 0.060 ms per step)
@@ -2632,16 +2643,35 @@ static int uploadCloud(ufomap_map* m, const void* a, size_t a_bytes, const void*
 			j.dst[1] = static_cast<char*>(m->h_stage) + off_b;
 			j.src[1] = b;
 			j.bytes[1] = b_bytes;
+			// With nothing in flight -- a caller that waits for every scan, like the reference's server -- the cloud goes on in PIECES: the
+			// workgroups of k_stage_copy read piece k across PCIe while the helper copies piece k + 1, and the cloud is in HBM one piece's
+			// transfer after the helper's last byte instead of a whole DMA transfer (server loop 0.420 -> 0.380 ms). In a row of
+			// asynchronous calls the transfer overlaps the scan before anyway, and the DMA engine does it without a CU (91 vs 95-105 us/scan).
+			const bool in_pieces = m->opt_stage_pieces > 0 && 0 == countPendingAlts(m);
+			const u32 np = in_pieces ? (u32)std::min(16, m->opt_stage_pieces) : 1u;
+			j.chunk = std::max<size_t>(((a_bytes + np - 1) / np + 4095) & ~(size_t)4095, 64u << 10);
 			m->stager->post(j);
 			m->stage_wait = true;
-			hipLaunchKernelGGL(k_host_gate, dim3(1), dim3(64), 0, m->pstream, m->h_stage_flag, m->stager->posted.load(std::memory_order_relaxed), 200000000ull,
-			                   (u32*)nullptr);
+			const unsigned long long job = m->stager->posted.load(std::memory_order_relaxed);
+			const u32 pa = (u32)((a_bytes + j.chunk - 1) / j.chunk), wgs = 4u;
+			if (!in_pieces) {
+				hipLaunchKernelGGL(k_host_gate, dim3(1), dim3(64), 0, m->pstream, m->h_stage_flag, (job << 8) | (unsigned long long)(pa + (b_bytes ? 1u : 0u)), 200000000ull,
+				                   (u32*)nullptr);
+				HIP_TRY(hipMemcpyAsync(m->b_in_xyz.p, m->h_stage, a_bytes, hipMemcpyHostToDevice, m->pstream));
+				if (b_bytes) HIP_TRY(hipMemcpyAsync(m->b_in_rgb.p, static_cast<char*>(m->h_stage) + off_b, b_bytes, hipMemcpyHostToDevice, m->pstream));
+			} else {
+				hipLaunchKernelGGL(k_stage_copy, dim3(pa * wgs), dim3(256), 0, m->pstream, m->h_stage_flag, job, 0u, static_cast<const uint8_t*>(m->h_stage), m->b_in_xyz.as<uint8_t>(),
+				                   (unsigned long long)a_bytes, (unsigned long long)j.chunk, wgs, 200000000ull);
+				if (b_bytes)
+					hipLaunchKernelGGL(k_stage_copy, dim3(wgs), dim3(256), 0, m->pstream, m->h_stage_flag, job, pa, static_cast<const uint8_t*>(m->h_stage) + off_b,
+					                   m->b_in_rgb.as<uint8_t>(), (unsigned long long)b_bytes, (unsigned long long)((b_bytes + 15) & ~(size_t)15), wgs, 200000000ull);
+			}
 		} else {
 			memcpy(m->h_stage, a, a_bytes);
 			if (b_bytes) memcpy(static_cast<char*>(m->h_stage) + off_b, b, b_bytes);
+			HIP_TRY(hipMemcpyAsync(m->b_in_xyz.p, m->h_stage, a_bytes, hipMemcpyHostToDevice, m->pstream));
+			if (b_bytes) HIP_TRY(hipMemcpyAsync(m->b_in_rgb.p, static_cast<char*>(m->h_stage) + off_b, b_bytes, hipMemcpyHostToDevice, m->pstream));
 		}
-		HIP_TRY(hipMemcpyAsync(m->b_in_xyz.p, m->h_stage, a_bytes, hipMemcpyHostToDevice, m->pstream));
-		if (b_bytes) HIP_TRY(hipMemcpyAsync(m->b_in_rgb.p, static_cast<char*>(m->h_stage) + off_b, b_bytes, hipMemcpyHostToDevice, m->pstream));
 	}
 	*d_a = m->b_in_xyz.p;
 	if (b_bytes) *d_b = m->b_in_rgb.p;
@@ -3874,6 +3904,8 @@ int ufomap_map_set_option(ufomap_map* m, const char* key, long long value)
 		m->opt_cast_prio = (int)std::max<long long>(0, std::min<long long>(3, value));
 	} else if (0 == strcmp(key, "lazy_done")) {
 		m->opt_lazy_done = value ? 1 : 0;
+	} else if (0 == strcmp(key, "stage_pieces")) {
+		m->opt_stage_pieces = (int)std::max<long long>(0, std::min<long long>(value, 16));
 	} else if (0 == strcmp(key, "batch_depth")) {
 		m->opt_batch_depth = (int)std::max<long long>(1, std::min<long long>(value, kAlt - 2));
 	} else if (0 == strcmp(key, "hold")) {
