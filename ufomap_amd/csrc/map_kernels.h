@@ -1403,6 +1403,200 @@ __global__ __launch_bounds__(1024) void k_vol_all(Table t, MapGeom g, VolArgs a,
 	if (0 == threadIdx.x) __hip_atomic_store(reinterpret_cast<unsigned long long*>(host_result + 1), done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// The same for a volume of at most UFO_VOL_SMALL nodes (the robot's box: ~400), round 6 -- k_vol_all's descent costs a trip to memory or two
+// per level whatever the level holds (the node's record, written a level earlier; the hash probe for its block): 47 us for 16 levels.
+// WHICH nodes are visited is geometry alone (every child whose box meets the volume, OMB:507-518 -- a leaf on the way gets children), so:
+//   G  the records of all levels, level by level, in LDS (the box tests of one level, an LDS reservation, a barrier);
+//   T  every record's block found or created -- all levels at once, one round of probes;
+//   C  (only if a block was created, i.e. hardly ever after the first scans) the new blocks' contents, top-down: copies of the parent node;
+//   V  the values of the depth-0 nodes, all at once;
+//   U  updateNode bottom-up, stopping where no parent was marked (k_vol_all's way back).
+#define UFO_VOL_SMALL 1024u
+__global__ __launch_bounds__(1024) void k_vol_small(Table t, MapGeom g, VolArgs a, u32 L, u32 scan_id, ScanCtl* ctl, ScanCtl* host_result, unsigned long long done_value)
+{
+	__shared__ VolRec recs[UFO_VOL_SMALL];
+	__shared__ u32 lstart[26], lcnt[26], lmark[26], any_created;
+	auto levelSync = [] {
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+		__syncthreads();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+	};
+	if (threadIdx.x < 26u) lcnt[threadIdx.x] = lmark[threadIdx.x] = 0;
+	{
+		// (the control block's start state: zero but for the box of changes)
+		u32* cw = reinterpret_cast<u32*>(ctl);
+		for (u32 w = threadIdx.x; w < (u32)(sizeof(ScanCtl) / 4u); w += blockDim.x) cw[w] = 0u;
+	}
+	if (0 == threadIdx.x) {
+		any_created = 0;
+		VolRec r;
+		r.lk = 1;
+		r.c[0] = r.c[1] = r.c[2] = 0.0;
+		r.parent = NONE;
+		r.slot = NONE;
+		r.changed = 0;
+		r.pad = 0;
+		recs[0] = r;
+	}
+	levelSync();
+	if (threadIdx.x < 3u) ctl->aabb_min[threadIdx.x] = ~0ull;
+	// ---- G ----
+	u32 lo = 0, hi = 1, overflow = 0;
+	for (u32 cd = L; cd >= 1u; --cd) {
+		const double chs = g.hs[cd - 1u];
+		for (u32 r = lo + threadIdx.x; r < hi; r += blockDim.x) {
+			const VolRec me = recs[r];
+			u32 inter = 0;
+#pragma unroll
+			for (u32 i = 0; i < 8; ++i) {
+				const double ci[3] = {me.c[0] + ((i & 1) ? chs : -chs), me.c[1] + ((i & 2) ? chs : -chs), me.c[2] + ((i & 4) ? chs : -chs)};
+				inter |= volIntersects(a, ci, chs) ? (1u << i) : 0u;
+			}
+			recs[r].pad = inter;
+			if (cd >= 2u && inter) {
+				u32 next = hi + atomicAdd(&lcnt[cd - 1u], (u32)__popc(inter));
+				for (u32 i = 0; i < 8; ++i) {
+					if (!((inter >> i) & 1u)) continue;
+					const u32 pos = next++;
+					if (pos >= UFO_VOL_SMALL) {
+						overflow = 1;  // (cannot happen: the host's bound on the records is at most the array)
+						continue;
+					}
+					VolRec ch;
+					ch.lk = (me.lk << 3) | (u64)i;
+					ch.c[0] = me.c[0] + ((i & 1) ? chs : -chs);  // getChildCenter (octree.h:625-633)
+					ch.c[1] = me.c[1] + ((i & 2) ? chs : -chs);
+					ch.c[2] = me.c[2] + ((i & 4) ? chs : -chs);
+					ch.parent = r;
+					ch.slot = NONE;
+					ch.changed = 0;
+					ch.pad = 0;
+					recs[pos] = ch;
+				}
+			}
+		}
+		__syncthreads();
+		if (0 == threadIdx.x) lstart[cd] = lo;
+		const u32 n = lcnt[cd - 1u];
+		lo = hi;
+		hi = min(hi + n, (u32)UFO_VOL_SMALL);
+	}
+	if (0 == threadIdx.x) lstart[0] = lo;
+	if (overflow) atomicOr(&ctl->err, ERR_ENTRIES);
+	const u32 n_rec = lo;  // (uniform: level 1 is the last one with records)
+	// ---- T ----
+	{
+		const u32 max_probe = (t.mask >> 1) + 1;
+		u32 n_created = 0;
+		for (u32 r = threadIdx.x; r < n_rec; r += blockDim.x) {
+			bool created;
+			const u32 s = tableEnsure(t, recs[r].lk, scan_id, max_probe, &created, &n_created);
+			if (s == NONE) atomicOr(&ctl->err, ERR_TABLE_FULL);
+			recs[r].slot = s;
+			if (created) {
+				recs[r].pad |= 0x100u;
+				any_created = 1u;
+			}
+		}
+		for (int o = 32; o > 0; o >>= 1) n_created += __shfl_xor(n_created, o);
+		if (__lane_id() == 0 && n_created) atomicAdd(&t.root->used, n_created);
+	}
+	levelSync();
+	if (__hip_atomic_load(&ctl->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+		// (nothing but new, unlinked blocks has been written: the host reports the table as full, as it does for k_vol_all)
+	} else {
+		// ---- C ----
+		if (any_created) {
+			for (u32 cd = L; cd >= 1u; --cd) {
+				for (u32 r = lstart[cd] + threadIdx.x; r < lstart[cd - 1u]; r += blockDim.x) {
+					const VolRec me = recs[r];
+					if (!(me.pad & 0x100u)) continue;
+					// createChildren (octree.h:1022-1058): a leaf node gets its 8 children, each a copy of the node
+					const u32 s = me.slot;
+					float v;
+					u32 col = 0;
+					if (1 == me.lk) {
+						t.parent(s) = NONE;
+						v = t.root->occ;
+						col = t.root->rgb;
+					} else {
+						const u32 p = recs[me.parent].slot, ci = (u32)(me.lk & 7);
+						t.parent(s) = p;
+						atomicOr(&t.flags(p), 1u << (16 + ci));
+						v = t.occ(p)[ci];
+						if (g.color) col = t.rgb[8 * (size_t)p + ci];
+					}
+					const float4 vv = make_float4(v, v, v, v);
+					float4* po = reinterpret_cast<float4*>(t.occ(s));
+					po[0] = vv;
+					po[1] = vv;
+					if (g.color) {
+						const uint4 cc = make_uint4(col, col, col, col);
+						uint4* pc = reinterpret_cast<uint4*>(t.rgb + 8 * (size_t)s);
+						pc[0] = cc;
+						pc[1] = cc;
+					}
+					// leaf children carry the flags of a leaf with this value (as k_init_new; OMB:1181-1189)
+					t.flags(s) = (isFreeV(g, v) ? F_CFREE : 0u) | (isUnknownV(g, v) ? F_CUNK : 0u);
+				}
+				levelSync();
+			}
+		}
+		// ---- V ---- setOccupancy on the depth-0 nodes the volume reaches (OMB:1151-1157)
+		for (u32 r = lstart[1] + threadIdx.x; r < lstart[0]; r += blockDim.x) {
+			const u32 s = recs[r].slot, inter = recs[r].pad & 0xFFu;
+			u32 changed = 0;
+			for (u32 i = 0; i < 8; ++i) {
+				if (!((inter >> i) & 1u)) continue;
+				float* pv = t.occ(s) + i;
+				if (*pv != a.val) changed = 1;
+				*pv = a.val;
+			}
+			recs[r].changed = changed;
+		}
+		levelSync();
+		// ---- U ---- (volUpLevel on the LDS records)
+		for (u32 cd = 1; cd <= L; ++cd) {
+			for (u32 r = lstart[cd] + threadIdx.x; r < lstart[cd - 1u]; r += blockDim.x) {
+				const VolRec me = recs[r];
+				bool ret = true;
+				if (me.changed) {
+					// updateNode of a node with children (OMB:1191-1224): summary, collapse, compare
+					const u32 f = t.flags(me.slot);
+					const Summ sm = blockSummary(t, g, me.slot, cd, f);
+					if (sm.collapsible) collapseBlock(t, me.slot, me.lk);
+					ret = writeToParent(t, g, me.slot, me.lk, sm);
+				}
+				if (ret && me.parent != NONE) {
+					atomicOr(&recs[me.parent].changed, 1u);
+					lmark[cd + 1u] = 1u;
+				}
+			}
+			levelSync();
+			if (0 == lmark[cd + 1u]) break;  // (a record is only ever marked from the level below)
+		}
+	}
+	// ---- the finished control block to the host's pinned copy, then the word the host polls (as k_vol_all) ----
+	if (threadIdx.x < 64u) {
+		u32 ng, nu;
+		tableCounts(t, threadIdx.x, &ng, &nu);
+		if (0 == threadIdx.x) {
+			ctl->used_now = __hip_atomic_load(&t.root->used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			ctl->used_g_now = ng;
+			ctl->used_u_now = nu;
+		}
+	}
+	levelSync();
+	{
+		constexpr u32 W_CORE = offsetof(ScanCtl, dbg) / 4u;
+		const u32* dev = reinterpret_cast<const u32*>(ctl);
+		u32* host = reinterpret_cast<u32*>(host_result);
+		for (u32 w = threadIdx.x; w < W_CORE; w += blockDim.x) host[w] = __hip_atomic_load(&dev[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
+	__syncthreads();  // (every thread's stores to the pinned block have been acknowledged: the barrier waits for them)
+	if (0 == threadIdx.x) __hip_atomic_store(reinterpret_cast<unsigned long long*>(host_result + 1), done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // min_depth == depth_levels: the root itself is set (OMB:505-511) -- every block dies
 __global__ __launch_bounds__(256) void k_vol_root(Table t, MapGeom g, float val)
 {

@@ -2879,7 +2879,14 @@ int ufomap_map_set_value_volume_ch(ufomap_map* m, const double aabb_center[3], c
 			HIP_TRY(hipMemcpyAsync(m->b_ctl.p, m->h_ctl, sizeof(ScanCtl), hipMemcpyHostToDevice, m->stream));
 			ctl_uploaded = true;
 		}
-		if (0 == min_depth && total <= 8192 && m->opt_vol_fused) {
+		if (0 == min_depth && total <= UFO_VOL_SMALL && m->opt_vol_fused && !ctl_uploaded) {
+			// (the robot's box: the records of all levels in LDS, the blocks looked up at once, map_kernels.h: k_vol_small; reports itself)
+			m->seq = ++m->latest_seq;
+			m->h_res->err = ERR_NOT_STORED;
+			*reinterpret_cast<volatile unsigned long long*>(m->h_res + 1) = 0ull;
+			res_direct = true;
+			hipLaunchKernelGGL(k_vol_small, dim3(1), dim3(1024), 0, m->cs, m->t, m->g, a, L, m->scan_id, ctl, m->h_res, (unsigned long long)m->seq);
+		} else if (0 == min_depth && total <= 8192 && m->opt_vol_fused) {
 			// (a small volume: one workgroup walks all levels, map_kernels.h: k_vol_all)
 			// (... and reports to the pinned result block itself: no synchronisation, no read-back below)
 			m->seq = ++m->latest_seq;
