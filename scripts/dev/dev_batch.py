@@ -2,16 +2,25 @@
 path: ms per step, how long the calls take on the host.  python scripts/dev/dev_batch.py [steps]
 Under `rocprofv3 --kernel-trace` + scripts/dev/trace_seq.py the kernels of a few steps per hardware queue."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+WORLD = int(os.environ.get("WORLD", "1"))  # > 1: one GPU plays rank 0 of WORLD (the all-gather stand-in of scripts/bench_batch_model.py)
+if WORLD > 1:
+    import subprocess
+    shim_src, shim = os.path.join(ROOT, "tests", "cpp", "rccl_shim.cpp"), os.path.join(ROOT, "tests", "cpp", "librccl_shim.so")
+    if not os.path.exists(shim) or os.path.getmtime(shim) < os.path.getmtime(shim_src):
+        subprocess.run(["/opt/rocm/bin/hipcc", "-O2", "-shared", "-fPIC", shim_src, "-o", shim, "-lrt"], check=True)
+    os.environ["UFOMAP_RCCL_LIB"] = os.path.join(ROOT, "tests", "cpp", "librccl_shim.so")
+    os.environ["UFOMAP_SHIM_REPLICATE"] = "1"
 import numpy as np, torch
 from ufomap_amd import OccupancyMap, Comm, scans
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 clouds = [scans.lidar64(origin=scans.lidar_pose(s), seed=100 + s) for s in range(8)]
 n = clouds[0][1].shape[0]
 d = [torch.from_numpy(c[1]).cuda() for c in clouds]
-for mode in ("single", "batch"):
+for mode in (("batch",) if WORLD > 1 else ("single", "batch")):
     m = OccupancyMap(0.16)
-    comm = Comm(Comm.unique_id(), 1, 0, 0) if mode == "batch" else None
+    comm = Comm(Comm.unique_id(), WORLD, 0, 0) if mode == "batch" else None
     if comm:
         m.set_option("async_apply", 1)
     for o in sys.argv[2:]:

@@ -39,7 +39,9 @@ const Lz4& lz4()
 
 // The node stream without the host in the middle (map_kernels.h: k_ser_prefix ... k_ser_copy_out): one synchronisation.
 // Returns 1 when the long way has to be taken (a map too large for the bound, no live root block).
-int serialiseNodesShort(ufomap_map* m, const SerArgs& sa, std::vector<uint8_t>& data)
+// (in_place: the caller reads the stream where the device left it, in the handle's pinned buffer -- *in_place = its length -- instead of
+// from a copy in `data`: a server's per-scan publish of 300 KB pays for every copy)
+int serialiseNodesShort(ufomap_map* m, const SerArgs& sa, std::vector<uint8_t>& data, size_t* in_place = nullptr)
 {
 	const u32 D = m->g.color ? 7u : 4u;
 	const u32 L = m->g.L;
@@ -116,14 +118,16 @@ int serialiseNodesShort(ufomap_map* m, const SerArgs& sa, std::vector<uint8_t>& 
 	}
 	if (0 == total || total > cap) return 1;  // the root is a leaf / the narrow levels outgrew the one-launch form / more than the bound: the long way
 	if (total > 0x7FFFFFFFull) return fail(UFOMAP_ERR_CAPACITY, "map byte stream exceeds 2^31 bytes (the reference's size field is an int)");
-	data.assign(m->h_out, m->h_out + total);
+	if (in_place) *in_place = (size_t)total;
+	else data.assign(m->h_out, m->h_out + total);
 	return UFOMAP_OK;
 }
 
 // the node stream of writeNodes (occupancy_map_base.h:1457-1533) for the whole map or the part inside a bounding volume
-int serialiseNodes(ufomap_map* m, const SerArgs& sa, std::vector<uint8_t>& data)
+int serialiseNodes(ufomap_map* m, const SerArgs& sa, std::vector<uint8_t>& data, size_t* in_place = nullptr)
 {
 	data.clear();
+	if (in_place) *in_place = 0;
 	m->cs = m->stream;
 	const u32 D = m->g.color ? 7u : 4u;
 	const u32 L = m->g.L;
@@ -136,9 +140,10 @@ int serialiseNodes(ufomap_map* m, const SerArgs& sa, std::vector<uint8_t>& data)
 		}
 	}
 	{
-		const int src = serialiseNodesShort(m, sa, data);
+		const int src = serialiseNodesShort(m, sa, data, in_place);
 		if (src <= 0) return src;
 		data.clear();
+		if (in_place) *in_place = 0;
 	}
 	// (scratch kept with the map: a publish per scan must not pay five allocations)
 	DevBuf &b_cnt = m->b_ser[0], &b_list = m->b_ser[1], &b_size = m->b_ser[2], &b_off = m->b_ser[3], &b_out = m->b_ser[4];
@@ -235,8 +240,12 @@ size_t ufomap_map_write_ex(ufomap_map* m, const double* aabb_center, const doubl
 	}
 	sa.min_depth = min_depth;
 	std::vector<uint8_t> data;
-	if (serialiseNodes(m, sa, data)) return (size_t)-1;
-	const long long usize = (long long)data.size();
+	size_t pinned_n = 0;
+	if (serialiseNodes(m, sa, data, &pinned_n)) return (size_t)-1;
+	// (the stream: in the handle's pinned buffer when the device-side serialiser produced it, else in `data`)
+	const uint8_t* src = pinned_n ? m->h_out : data.data();
+	size_t src_n = pinned_n ? pinned_n : data.size();
+	const long long usize = (long long)src_n;
 	if (uncompressed_size) *uncompressed_size = usize;
 	if (compress) {
 		// compressData (octree.h:1430-1458)
@@ -245,19 +254,19 @@ size_t ufomap_map_write_ex(ufomap_map* m, const double* aabb_center, const doubl
 			fail(UFOMAP_ERR_UNSUPPORTED, "liblz4 could not be loaded: compressed output is not available");
 			return (size_t)-1;
 		}
-		const int bound = z.bound((int)data.size());
+		const int bound = z.bound((int)src_n);
 		std::vector<uint8_t> comp((size_t)std::max(bound, 1));
 		const int n = 0 >= compression_level
-		                  ? z.fast(reinterpret_cast<const char*>(data.data()), reinterpret_cast<char*>(comp.data()), (int)data.size(), bound,
-		                           compression_acceleration_level)
-		                  : z.hc(reinterpret_cast<const char*>(data.data()), reinterpret_cast<char*>(comp.data()), (int)data.size(), bound,
-		                         compression_level);
+		                  ? z.fast(reinterpret_cast<const char*>(src), reinterpret_cast<char*>(comp.data()), (int)src_n, bound, compression_acceleration_level)
+		                  : z.hc(reinterpret_cast<const char*>(src), reinterpret_cast<char*>(comp.data()), (int)src_n, bound, compression_level);
 		if (n < 0) {
 			fail(UFOMAP_ERR_DEVICE, "LZ4 compression failed");
 			return (size_t)-1;
 		}
 		comp.resize((size_t)n);
 		data.swap(comp);
+		src = data.data();
+		src_n = data.size();
 	}
 	std::string h;
 	if (header) {
@@ -274,10 +283,10 @@ size_t ufomap_map_write_ex(ufomap_map* m, const double* aabb_center, const doubl
 		hd << "data" << std::endl;
 		h = hd.str();
 	}
-	const size_t total = h.size() + data.size();
+	const size_t total = h.size() + src_n;
 	if (buf && cap >= total) {
 		memcpy(buf, h.data(), h.size());
-		if (!data.empty()) memcpy(buf + h.size(), data.data(), data.size());
+		if (src_n) memcpy(buf + h.size(), src, src_n);
 	}
 	return total;
 }

@@ -2334,6 +2334,7 @@ __global__ __launch_bounds__(1024) void k_ser_tail_dev(Table t, MapGeom g, const
 {
 	__shared__ __attribute__((aligned(16))) u32 cw[UFO_SER_TAIL_MAX][8], cs_[UFO_SER_TAIL_MAX][8];
 	__shared__ u32 szl[UFO_SER_TAIL_MAX], offl[UFO_SER_TAIL_MAX];  // the blocks' subtree sizes; where their subtrees start in the stream
+	__shared__ u32 slotl[UFO_SER_TAIL_MAX];                        // their table slots (a leaf's payload is one dependent load, not two)
 	__shared__ u32 lo[32], ln[32];
 	if (threadIdx.x < 32u) {
 		lo[threadIdx.x] = lvp->off[threadIdx.x];
@@ -2354,7 +2355,10 @@ __global__ __launch_bounds__(1024) void k_ser_tail_dev(Table t, MapGeom g, const
 			cw4[i] = a4[i];
 			cs4[i] = b4[i];
 		}
-		for (u32 i = threadIdx.x; i < nb; i += blockDim.x) offl[i] = 0xFFFFFFFFu;
+		for (u32 i = threadIdx.x; i < nb; i += blockDim.x) {
+			offl[i] = 0xFFFFFFFFu;
+			slotl[i] = list[base + i];
+		}
 	}
 	__syncthreads();
 	const u32 ch = threadIdx.x & 7u;
@@ -2394,7 +2398,7 @@ __global__ __launch_bounds__(1024) void k_ser_tail_dev(Table t, MapGeom g, const
 			if (0 == ch && l >= 2) out[at0] = (uint8_t)mask;
 			if (w) {
 				if (NONE == code) {
-					const u32 s = list[lo[l] + i];
+					const u32 s = slotl[j];
 					serPutLeaf(out, at, t.occ(s)[ch], t.rgb ? t.rgb[8 * (size_t)s + ch] : 0u, D);
 				} else if (code & UFO_SER_TAIL_CHILD) {
 					offl[code & ~UFO_SER_TAIL_CHILD] = at;
