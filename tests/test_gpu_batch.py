@@ -429,7 +429,7 @@ def _batch_cloud(entry):
     return o, (xyz[:0] if empty else xyz)
 
 
-def _batch_rank(rank, world, steps, shim, id_q, out_q, comm_slot, fail_at=None, device=0):
+def _batch_rank(rank, world, steps, shim, id_q, out_q, comm_slot, fail_at=None, device=0, batch_depth=None):
     import os
     if shim:  # (None: the real librccl, one GPU per rank)
         os.environ["UFOMAP_RCCL_LIB"] = shim
@@ -448,6 +448,8 @@ def _batch_rank(rank, world, steps, shim, id_q, out_q, comm_slot, fail_at=None, 
         th.cuda.set_device(device)
         g = OccupancyMap(0.16, device=device)
         g.set_option("async_apply", 1)
+        if batch_depth is not None:  # (steps in flight before the oldest is joined: the same on every rank)
+            g.set_option("batch_depth", batch_depth)
         comm = Comm(uid, world, rank, device)
         plan = _batch_plan(world, steps)
         keep = []
@@ -465,11 +467,12 @@ def _batch_rank(rank, world, steps, shim, id_q, out_q, comm_slot, fail_at=None, 
         out_q.put((rank, "error: " + repr(e), None, None, None))
 
 
-@pytest.mark.parametrize("fail_at", [None, (7, 1)])
-def test_insert_batch_two_ranks_on_one_gpu(fail_at):
+@pytest.mark.parametrize("fail_at,batch_depth", [(None, None), ((7, 1), None), (None, 2), ((7, 1), 5), ((3, 0), 6)])
+def test_insert_batch_two_ranks_on_one_gpu(fail_at, batch_depth):
     """fail_at = (step, rank): that rank's scan half fails on the host before the step's all-gather (ADVICE r3 / VERDICT r3 5c) --
     it enters the collective all the same with a flagged empty contribution, nobody hangs, every rank repeats the step in list form
-    and the replicas equal the sequential map."""
+    and the replicas equal the sequential map. batch_depth: how many steps are in flight before the oldest is joined (3 by default,
+    2 until round 6) -- a flagged step then has up to five steps enqueued behind it, which stand back and are repeated in order."""
     import torch.multiprocessing as mp
     from oracle import OracleMap
     from ufomap_amd import OccupancyMap
@@ -477,7 +480,7 @@ def test_insert_batch_two_ranks_on_one_gpu(fail_at):
     world, steps = 2, 9
     ctx = mp.get_context("spawn")
     id_q, out_q = ctx.Queue(), ctx.Queue()
-    procs = [ctx.Process(target=_batch_rank, args=(r, world, steps, shim, id_q, out_q, 4096, fail_at)) for r in range(world)]
+    procs = [ctx.Process(target=_batch_rank, args=(r, world, steps, shim, id_q, out_q, 4096, fail_at, 0, batch_depth)) for r in range(world)]
     for p in procs:
         p.start()
     results = {}

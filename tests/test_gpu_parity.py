@@ -328,6 +328,31 @@ def test_set_value_volume_robot_clearing(color):
     assert same_dump(g2.leaves(True), o2.leaves(True)) and same_dump(g2.inner(), o2.inner())
 
 
+@pytest.mark.parametrize("half", [1.2, 1.6, 3.0])
+def test_set_value_volume_by_size(half):
+    """setValueVolume at min_depth 0 takes one of three forms by the number of nodes the volume can meet (ufomap_hip.hip:
+    ufomap_map_set_value_volume_ch): the records of all levels in LDS (k_vol_small, <= 1024: a 1.2 m half size is ~980), one workgroup
+    level by level (k_vol_all, <= 8192: 1.6 m is ~2250), a launch per level and direction (3 m: ~9700) -- each against the reference's
+    recursion, on a map with scans in it (nothing created, values and summaries change) and on a fresh one (everything created)."""
+    from ufomap_amd import scans
+    g, o = _maps(color=False, resolution=0.16)
+    for s in range(2):
+        origin, xyz, _ = scans.lidar64(beams=32, azimuths=512, origin=scans.lidar_pose(s), seed=11 + s)
+        _gpu_insert(g, origin, xyz, None, max_range=12.0, discrete=True)
+        o.insert(origin, xyz, None, max_range=12.0, discrete=True)
+        c = np.array(origin) + np.array([0.07, -0.05, 0.03])
+        for val in (g.getClampingThresMin(), 0.5):
+            g.setValueVolume(c - half, c + half, val, 0)
+            o.setValueVolume(c - half, c + half, val, 0)
+            assert same_dump(g.leaves(True), o.leaves(True)), f"scan {s} value {val}: leaves differ"
+            assert same_dump(g.inner(), o.inner()), f"scan {s} value {val}: inner nodes differ"
+    assert g.write() == o.write()
+    g2, o2 = _maps(color=False, resolution=0.16)
+    g2.setValueVolume([-half, -half + 0.1, -half], [half, half, half - 0.2], 0.3, 0)
+    o2.setValueVolume([-half, -half + 0.1, -half], [half, half, half - 0.2], 0.3, 0)
+    assert same_dump(g2.leaves(True), o2.leaves(True)) and same_dump(g2.inner(), o2.inner())
+
+
 @pytest.mark.parametrize("color", [False, True])
 def test_point_queries(color):
     """batched getState / contains* / log-odds queries against the oracle (which is pinned on the
