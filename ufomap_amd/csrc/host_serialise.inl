@@ -71,7 +71,6 @@ int serialiseNodesShort(ufomap_map* m, const SerArgs& sa, std::vector<uint8_t>& 
 	hipStream_t st = m->stream;
 	static const bool trace = nullptr != getenv("UFOMAP_TRACE_SER");
 	const auto t0 = std::chrono::steady_clock::now();
-	HIP_TRY(hipMemsetAsync(b_cnt.p, 0, 3 * 32 * 4 + 16, st));
 	const u32 nsb = serBlocks(ncap);  // (the listing kernels: a contiguous share of the slots per workgroup, no atomics on device memory)
 	u32* d_blk = d_cnt + UFO_SER_BLK_WORD;
 	hipLaunchKernelGGL(k_ser_count, dim3(nsb), dim3(256), 0, st, m->t, m->g, d_blk);

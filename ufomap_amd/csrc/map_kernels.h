@@ -2241,6 +2241,7 @@ __global__ __launch_bounds__(1024) void k_ser_prefix(u32* __restrict__ cnt /* ou
 		cnt[32 + l] = off;
 		off += c;
 	}
+	cnt[96] = cnt[97] = 0u;  // (the stream's length: written by the narrow levels' kernel; no fill of the block in front of the listing)
 }
 __global__ __launch_bounds__(256) void k_ser_sizes_dev(Table t, MapGeom g, SerArgs sa, const u32* __restrict__ list, const SerLevels* lv, u32 level, u32 D,
                                                        u64* __restrict__ size)
