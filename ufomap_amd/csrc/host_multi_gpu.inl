@@ -463,6 +463,7 @@ int fastBatchStep(ufomap_map* m, ufomap_comm* c, const double origin[3], const d
 		hipLaunchKernelGGL(k_pack_slot, dim3(64), dim3(256), 0, m->sstream, reinterpret_cast<uint4*>(send), reinterpret_cast<const uint4*>(ctl),
 		                   m->b_tilebits.as<uint4>(), m->b_gridM.as<uint4>(), m->b_gridH.as<uint4>(), n4);
 	}
+	bool xgate = false;
 	{
 		// Option gather_stream: the collective on a stream of its own -- only the walk needs what it gathers, so the wire of step i
 		// could overlap the scan half of step i + 1 (which queues behind it on the scan stream). Off by default: with one
@@ -479,9 +480,22 @@ int fastBatchStep(ufomap_map* m, ufomap_comm* c, const double origin[3], const d
 			HIP_TRY(hipStreamWaitEvent(m->gstream, m->pack_ev, 0));
 			gs = m->gstream;
 		}
+		xgate = m->gates && gs == m->sstream;  // (a stream of its own may share a hardware queue with the map stream: a gate there could wait for ever)
 		const int e = r->AllGather(send, recv, slot, /* ncclChar */ 0, c->comm, gs);
 		if (e) return rcclFail(e, "ncclAllGather");
-		HIP_TRY(hipEventRecord(m->xchg_ev, gs));
+		// the walk waits for the gathered slots: a one-thread kernel behind the collective stores the step's number, a one-wave kernel in
+		// front of the walk waits for it (k_signal / k_gate as everywhere in the steady state: 2-3 us per hand-over against 9-15 for an
+		// event pair, and 4 us less on the host) -- events when kernels may be serialised across streams (useGates)
+		if (xgate) {
+			if (!m->b_sig_xchg.p) {
+				HIP_TRY(m->b_sig_xchg.reserve(64));
+				HIP_TRY(hipMemsetAsync(m->b_sig_xchg.p, 0, 64, gs));
+			}
+			hipLaunchKernelGGL(k_signal, dim3(1), dim3(1), 0, gs, m->b_sig_xchg.as<unsigned long long>(), (unsigned long long)m->seq, (unsigned long long*)nullptr,
+			                   (unsigned long long*)nullptr, 0ull);
+		} else {
+			HIP_TRY(hipEventRecord(m->xchg_ev, gs));
+		}
 	}
 	// ---- the walk: the scans of ranks 0 .. W-1 in this order (UFO_BATCH_MAX at a time) ----
 	m->cs = m->stream;
@@ -518,7 +532,14 @@ int fastBatchStep(ufomap_map* m, ufomap_comm* c, const double origin[3], const d
 	}
 	m->scan_new_bound = bound;
 	HIP_TRY(m->b_tilerec.reserve((size_t)UFO_FAST_MAX_TILES * sizeof(TileRec)));
-	HIP_TRY(hipStreamWaitEvent(m->stream, m->xchg_ev, 0));
+	if (xgate) {
+		// (a collective that has not delivered within 10 s has failed: the walk then stands back on this rank, which is reported when the
+		// step is joined -- the communicator is beyond repair either way)
+		hipLaunchKernelGGL(k_gate, dim3(1), dim3(1), 0, m->stream, m->b_sig_xchg.as<unsigned long long>(), (unsigned long long)m->seq, ctl, 1000000000ull,
+		                   (unsigned long long*)nullptr, 0ull);
+	} else {
+		HIP_TRY(hipStreamWaitEvent(m->stream, m->xchg_ev, 0));
+	}
 	Pipe* bp = m->b_bpipe.as<Pipe>();
 	const float miss = (float)m->g.miss_log;
 	{

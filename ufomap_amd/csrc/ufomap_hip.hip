@@ -379,6 +379,7 @@ struct ufomap_map {
 	uint8_t* h_res_all = nullptr;
 	int h_res_all_world = 0;
 	hipEvent_t xchg_ev = nullptr;
+	DevBuf b_sig_xchg;           // ... or, with gates, the word a kernel behind the all-gather stores the step's number in (fastBatchStep)
 	uint64_t fseq = 0;            // (HandOver)
 	DevBuf b_keep, b_keep_rgb;    // (HandOver)
 	unsigned long long* h_prep = nullptr;  // pinned: integration number of the newest scan whose k_fhits has finished (k_signal)
@@ -2497,6 +2498,7 @@ void ufomap_map_destroy(ufomap_map* m)
 	if (m->h_stage) (void)hipHostFree(m->h_stage);
 	if (m->h_res_all) (void)hipHostFree(m->h_res_all);
 	if (m->xchg_ev) (void)hipEventDestroy(m->xchg_ev);
+	m->b_sig_xchg.release();
 	for (DevBuf* b : {&m->b_xsend, &m->b_xrecv, &m->b_bpipe}) b->release();
 	if (m->copy_ev) (void)hipEventDestroy(m->copy_ev);
 	if (m->h_root) (void)hipHostFree(m->h_root);
