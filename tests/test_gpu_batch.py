@@ -347,6 +347,34 @@ def test_host_cloud_may_be_reused_as_soon_as_the_call_returns(kind):
     assert all(np.array_equal(a, b) for a, b in zip(gl, ol)) and same_dump(g.inner(), o.inner())
 
 
+@pytest.mark.parametrize("color", [False, True])
+def test_host_clouds_of_many_sizes_awaited_one_by_one(color):
+    """A pageable host cloud whose scan is awaited (nothing in flight when it arrives: the reference's server) reaches HBM in pieces --
+    k_stage_copy's workgroups read piece k from the staging buffer while the helper thread copies piece k + 1, round 6 -- from 256 KB on;
+    smaller clouds are copied by the calling thread. Sizes around that threshold, odd point counts (24 n and 3 n bytes are then no
+    multiples of 16: the last bytes of a piece go one by one), the option's extremes; every scan awaited, the caller's arrays overwritten
+    after every call. The map must equal the one the same clouds give from device memory."""
+    from ufomap_amd import OccupancyMap, OccupancyMapColor, PointCloud, PointCloudColor, scans
+    cls = OccupancyMapColor if color else OccupancyMap
+    g, ref = cls(0.16), cls(0.16)
+    ref.set_option("stage_thread", 0)
+    full = 64 * 2048
+    sizes = [full, 10923, 10922, 1, 50001, full - 1, 87383, 0, full]
+    for i, n in enumerate(sizes):
+        g.set_option("stage_pieces", (8, 1, 16, 3)[i % 4])
+        origin, xyz, rgb = scans.lidar64(origin=scans.lidar_pose(i % 4), seed=900 + i, colored=color)
+        xyz, rgb = xyz[:n], (rgb[:n] if color else None)
+        buf, cbuf = xyz.copy(), (rgb.copy() if color else None)
+        g.insertPointCloudDiscrete(origin, PointCloudColor(buf, cbuf) if color else PointCloud(buf), 20.0, 0, False, 0, True)
+        buf[:] = -5.0
+        if color:
+            cbuf[:] = 9
+        g.insertPointCloudWait()
+        ref.insertPointCloudDiscrete(origin, PointCloudColor(xyz, rgb) if color else PointCloud(xyz), 20.0, 0, False, 0, False)
+    assert g.digest() == ref.digest()
+    assert all(np.array_equal(a, b) for a, b in zip(g.leaves(True), ref.leaves(True)))
+
+
 _FEW_QUEUES = r"""
 import sys, time
 import numpy as np
