@@ -639,6 +639,52 @@ def test_gate_timeouts_are_survived():
     print("gate timeouts:", n_to)
 
 
+def test_single_scans_after_batch_steps_and_a_destroyed_communicator():
+    """A hand-over set that held a batch step kept the step's communicator until round 6: taking a scan of ufomap_map_insert next, it
+    predicted the RANKS' grid through that pointer when the scan was joined -- freed memory once ufomap_comm_destroy had run (bench.py's
+    batch_step_n1 leg followed by its host legs: one run in eight died of a corrupted heap) -- and skipped the map's own prediction.
+    Batch steps over every set, the communicator destroyed, a long row of single scans (the sensor jumps twice: repeats), more batch
+    steps on a second communicator, single scans again: the map equals the reference's, and the single scans keep taking the steady-state
+    path (their ray grid is predicted from their own boxes again)."""
+    from oracle import OracleMap
+    from ufomap_amd import OccupancyMap, PointCloud, scans
+    from ufomap_amd.occupancy_map import Comm
+    g = OccupancyMap(0.16)
+    o = OracleMap(0.16, kind=_kind())
+    keep = []
+    k = 0
+
+    def cloud(i, jump=0.0):
+        return scans.lidar64(beams=16, azimuths=512, origin=tuple(np.array(scans.lidar_pose(1)) + [0.03 * i + jump, 0.0, 0.0]), seed=300 + i)[:2]
+
+    for phase in range(2):
+        comm = Comm(Comm.unique_id(), 1, 0, 0)
+        g.set_option("async_apply", 1)
+        for _ in range(12):  # (more steps than there are hand-over sets: every set has carried one)
+            origin, xyz = cloud(k)
+            d = torch.from_numpy(np.ascontiguousarray(xyz)).cuda()
+            keep.append(d)
+            g.insert_batch(comm, origin, d.data_ptr(), len(xyz), 10.0, 0, True)
+            o.insert(origin, xyz, max_range=10.0, discrete=True)
+            k += 1
+        g.insertPointCloudWait()
+        g.set_option("async_apply", 0)
+        assert comm.counters()["fast_steps"] >= 6
+        comm.close()
+        del comm
+        junk = [bytearray(200) for _ in range(2000)]  # (the freed communicator's memory is likely to be handed out again)
+        fast0 = g.debug()[61]
+        for i in range(20):
+            origin, xyz = cloud(k, jump=4.0 if i in (7, 8, 9) else 0.0)
+            g.insertPointCloudDiscrete(origin, PointCloud(xyz), 10.0, 0, False, 0, True)
+            o.insert(origin, xyz, max_range=10.0, discrete=True)
+            k += 1
+        g.insertPointCloudWait()
+        del junk
+        assert g.debug()[61] - fast0 >= 14, "the single scans after the batch steps should take the steady-state path"
+    _assert_same_map(g, o, "batch steps, destroyed communicators and single scans on one map")
+
+
 def test_insert_batch_at_insert_depth():
     """Batch steps at insert depth > 0 (occupancy_map_base.h:378-386, 1085-1120; the way the reference's README tells RGB-D users to run
     a fine map): the update-list form, the ranks' lists applied one by one in rank order -- world 1 through the real RCCL, steps at

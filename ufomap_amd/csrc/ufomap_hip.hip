@@ -1493,12 +1493,19 @@ int finishPending(ufomap_map* m)
 		if (m->h_ctl->err & (ERR_SPEC | ERR_PREV | ERR_GATE | ERR_RUNAWAY)) return redoBatchStep(m);
 		if (0 == m->h_ctl->err) predictCommonGrid(m);
 	}
+	// The step's communicator has been looked at for the last time: the set does not carry it into its next integration. (Until round 6
+	// it did: a set that had held a batch step and then took a scan of ufomap_map_insert predicted the RANKS' grid from it when it
+	// was joined -- through a pointer that ufomap_comm_destroy may have freed by then -- and skipped the map's own prediction.
+	// bench.py's batch_step_n1 leg followed by its host legs: one run in eight died of the corrupted heap.)
+	const bool was_batch_step = 0 != m->batch_world;
+	m->batch_world = 0;
+	m->comm = nullptr;
 	if (m->h_ctl->err && m->args.n && (m->args.spec || (m->h_ctl->err & (ERR_PREV | ERR_GATE)))) return redoScan(m);
 	rc = ctlError(m);
 	if (rc) return rc;
 	m->counts[1] = m->h_ctl->n_rays;
 	m->counts[3] = m->h_ctl->n_hits;
-	if (m->args.n && !m->batch_world) predictGrid(m);  // (non-scan updates leave the prediction as it is)
+	if (m->args.n && !was_batch_step) predictGrid(m);  // (non-scan updates leave the prediction as it is)
 	m->counts[5] = (u64)m->h_ctl->n_entries[0] + m->h_ctl->n_entries[1];
 	m->counts[2] = m->h_ctl->n_steps;
 	m->counts[6] = (u64)m->h_ctl->ph[0].n_new + m->h_ctl->ph[1].n_new;
