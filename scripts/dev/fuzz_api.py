@@ -1,0 +1,152 @@
+"""Developer aid (GPU box): random sequences of calls on ONE map -- host / device / PointCloud2 clouds, synchronous and asynchronous, insert
+depths, continuous and discrete, robot clearing, batch steps over a one-rank communicator that comes and goes, byte streams, clear -- against
+the CPU checker after every few calls (round 6: a hand-over set that carried state from one kind of call into the next was what crashed the
+bench; this looks for the next one).   python scripts/dev/fuzz_api.py [seeds=6] [ops=120] [first_seed=0]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+from oracle import OracleMap, RunawayRay  # noqa: E402
+from oracle import ingest as oracle_ingest  # noqa: E402
+from ufomap_amd import OccupancyMap, PointCloud, scans  # noqa: E402
+from ufomap_amd.occupancy_map import Comm  # noqa: E402
+
+
+def same_dump(a, b):
+    return len(a) == len(b) and all(x.shape == y.shape and np.array_equal(x, y) for x, y in zip(a, b))
+
+
+n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+n_ops = int(sys.argv[2]) if len(sys.argv) > 2 else 120
+first = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+check_from = int(os.environ.get("FUZZ_CHECK_FROM", "1000000"))  # (from this call on, the maps are compared after every FUZZ_CHECK_EVERY-th call)
+check_every = int(os.environ.get("FUZZ_CHECK_EVERY", "1"))
+print_all = bool(os.environ.get("FUZZ_PRINT"))
+skip = set(filter(None, os.environ.get("FUZZ_SKIP", "").split(",")))  # kinds of calls that are left out (both maps)
+kind = "reference" if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libufo_ref.so")) else "port"
+
+
+def check(g, o, what):
+    g.insertPointCloudWait()
+    ok = same_dump(g.leaves(True), o.leaves(True)) and same_dump(g.inner(), o.inner())
+    if not ok:
+        raise AssertionError(what)
+
+
+bad = 0
+for seed in range(first, first + n_seeds):
+    rng = np.random.default_rng(seed)
+    g, o = OccupancyMap(0.16), OracleMap(0.16, kind=kind)
+    comm, keep, log = None, [], []
+    pose = np.array(scans.lidar_pose(int(rng.integers(0, 4))), dtype=np.float64)
+    try:
+        for step in range(n_ops):
+            op = rng.choice(["host", "host", "dev", "dev", "pc2", "batch", "batch", "vol", "bytes", "wait", "clear", "comm", "big", "cont", "depth"],
+                            p=[0.14, 0.1, 0.12, 0.1, 0.08, 0.1, 0.08, 0.07, 0.04, 0.05, 0.01, 0.04, 0.03, 0.02, 0.02])
+            if rng.random() < 0.12:
+                pose = pose + rng.normal(0, 1.5, 3) * np.array([1, 1, 0.1])  # (a jump: the predicted grid misses, the scan is repeated)
+            else:
+                pose = pose + rng.normal(0, 0.04, 3) * np.array([1, 1, 0.2])
+            origin = tuple(pose)
+            asyn = bool(rng.random() < 0.7)
+            r2 = np.random.default_rng([seed, step])  # (the call's own parameters: skipping a kind of call leaves the rest of the sequence as it is)
+            beams, az = (64, 2048) if op == "big" else (16, int(r2.choice([128, 512])))
+            _, xyz, _ = scans.lidar64(beams=beams, azimuths=az, origin=origin, seed=int(r2.integers(1 << 30)))
+            if r2.random() < 0.05:
+                xyz = xyz[:int(r2.integers(0, 3))]
+            log.append((step, op, asyn, len(xyz)))
+            if op in skip:
+                continue
+            if op in ("host", "big"):
+                buf = xyz.copy()
+                g.insertPointCloudDiscrete(origin, PointCloud(buf), 12.0, 0, False, 0, asyn)
+                buf[:] = 7.0
+                o.insert(origin, xyz, max_range=12.0, discrete=True)
+            elif op == "cont":
+                g.insertPointCloud(origin, PointCloud(xyz), 12.0, 0, False, 0, asyn)
+                o.insert(origin, xyz, max_range=12.0, discrete=False)
+            elif op == "depth":
+                d = int(r2.integers(1, 3))
+                g.insertPointCloudDiscrete(origin, PointCloud(xyz), 12.0, d, False, 0, asyn)
+                o.insert(origin, xyz, max_range=12.0, discrete=True, depth=d)
+            elif op == "dev":
+                d = torch.from_numpy(np.ascontiguousarray(xyz)).cuda()
+                keep.append(d)
+                g.insert_device(origin, d.data_ptr() if len(xyz) else 0, None, len(xyz), 12.0, 0, discrete=True, async_=asyn)
+                o.insert(origin, xyz, max_range=12.0, discrete=True)
+            elif op == "pc2":
+                rec = np.zeros((len(xyz), 4), np.float32)
+                rec[:, :3] = (xyz - np.asarray(origin)[None, :]).astype(np.float32)
+                raw = np.ascontiguousarray(rec).view(np.uint8).reshape(-1)
+                if len(xyz):
+                    g.insertPointCloud2(np.asarray(origin), np.array([1.0, 0, 0, 0]), raw, 16, (0, 4, 8), None, 12.0, 0, True, False, 0, asyn)
+                    xyz32, _ = oracle_ingest(raw, 16, (0, 4, 8), None, np.array([1.0, 0, 0, 0]), np.asarray(origin), kind)  # (the reference's rosToUfo + transform)
+                    o.insert(origin, xyz32, max_range=12.0, discrete=True)
+            elif op == "batch":
+                if comm is None:
+                    comm = Comm(Comm.unique_id(), 1, 0, 0)
+                g.set_option("async_apply", int(asyn))
+                for _ in range(int(r2.integers(1, 5))):
+                    d = torch.from_numpy(np.ascontiguousarray(xyz)).cuda()
+                    keep.append(d)
+                    dep = int(r2.integers(0, 3)) if r2.random() < 0.1 else 0
+                    g.insert_batch(comm, origin, d.data_ptr() if len(xyz) else 0, len(xyz), 12.0, dep, True)
+                    o.insert(origin, xyz, max_range=12.0, discrete=True, depth=dep)
+            elif op == "comm":
+                if comm is not None:
+                    g.insertPointCloudWait()
+                    comm.close()
+                    comm = None
+            elif op == "vol":
+                ext = r2.uniform(0.2, 1.8, 3)
+                md = int(r2.integers(0, 3))
+                val = float(r2.choice([g.getClampingThresMin(), 0.5, 0.3]))
+                g.setValueVolume(pose - ext, pose + ext, val, md)
+                o.setValueVolume(pose - ext, pose + ext, val, md)
+            elif op == "bytes":
+                g.insertPointCloudWait()
+                a, b = g.write(), o.write()
+                if a != b:
+                    same = same_dump(g.leaves(True), o.leaves(True)) and same_dump(g.inner(), o.inner())
+                    a2 = g.write()
+                    na, nb = np.frombuffer(a, np.uint8), np.frombuffer(b, np.uint8)
+                    k = min(len(na), len(nb))
+                    d = np.nonzero(na[:k] != nb[:k])[0]
+                    raise AssertionError(f"byte streams differ: {len(a)} vs {len(b)} bytes, first difference at {int(d[0]) if len(d) else k} of {len(d)}; maps equal: {same}; "
+                                         f"a second write equals the checker's: {a2 == b}; debug {g.debug()[40:64]}")
+                ext = r2.uniform(0.5, 4.0, 3)
+                a = g.write_ex(aabb=(pose - ext, pose + ext), compress=False, min_depth=int(r2.integers(0, 2)), header=False)[0]
+                log[-1] = log[-1] + (len(a),)
+            elif op == "wait":
+                check(g, o, f"seed {seed} step {step}: maps differ")
+            elif op == "clear":
+                g.insertPointCloudWait()
+                g.clear()
+                o = OracleMap(0.16, kind=kind)
+            if len(keep) > 64:
+                g.insertPointCloudWait()
+                keep.clear()
+            if step >= check_from and (step - check_from) % check_every == 0:
+                check(g, o, f"seed {seed} step {step} ({op}): maps differ")
+        check(g, o, f"seed {seed}: maps differ at the end")
+        if g.write() != o.write():
+            raise AssertionError("byte streams differ at the end")
+        print(f"seed {seed}: ok ({n_ops} calls, {g.debug()[61]} steady-state scans)", flush=True)
+    except RunawayRay:
+        print(f"seed {seed}: skipped (a runaway ray in the checker)", flush=True)
+    except Exception as e:  # noqa: BLE001
+        bad += 1
+        print(f"seed {seed}: FAILED at {log[-1] if log else None}: {e!r}\n  last calls: {log if print_all else log[-12:]}", flush=True)
+    finally:
+        if comm is not None:
+            try:
+                g.insertPointCloudWait()
+            except Exception:  # noqa: BLE001
+                pass
+            comm.close()
+        del g, o
+print(f"{bad} of {n_seeds} sequences failed")
+sys.exit(1 if bad else 0)

@@ -500,7 +500,10 @@ int enqueueSlot(ufomap_map* m, int k)
 			if (pk < 0 || o.seq > m->alt[pk].seq) pk = i;
 		}
 		if (pk >= 0)
-			prev_stat = m->alt[pk].done_by_flag ? &m->b_pipe.as<Pipe>()->wstat[m->alt[pk].fseq & (UFO_RING - 1u)] : &m->alt[pk].b_ctl.as<ScanCtl>()->err;
+			// (a batch step's walk reports in the step's own Pipe -- round 6: this looked at the shared ring's word for a batch predecessor, so a
+			// scan of ufomap_map_insert enqueued behind a batch step that stood back was applied BEFORE the step's repeat: scripts/dev/fuzz_api.py)
+			prev_stat = !m->alt[pk].done_by_flag ? &m->alt[pk].b_ctl.as<ScanCtl>()->err
+			            : m->alt[pk].batch_world ? &m->alt[pk].b_bpipe.as<Pipe>()->wstat[0] : &m->b_pipe.as<Pipe>()->wstat[m->alt[pk].fseq & (UFO_RING - 1u)];
 	};
 	scanQueue();
 	m->cs = m->stream;

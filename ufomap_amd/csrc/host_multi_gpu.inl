@@ -488,8 +488,11 @@ int fastBatchStep(ufomap_map* m, ufomap_comm* c, const double origin[3], const d
 		// event pair, and 4 us less on the host) -- events when kernels may be serialised across streams (useGates)
 		if (xgate) {
 			if (!m->b_sig_xchg.p) {
+				// (zero BEFORE any gate can look at it: the gate of this very step is on another stream, and recycled device memory is
+				// not zero -- a gate that found a large number there opened before the all-gather had delivered: scripts/dev/fuzz_api.py)
 				HIP_TRY(m->b_sig_xchg.reserve(64));
 				HIP_TRY(hipMemsetAsync(m->b_sig_xchg.p, 0, 64, gs));
+				HIP_TRY(hipStreamSynchronize(gs));
 			}
 			hipLaunchKernelGGL(k_signal, dim3(1), dim3(1), 0, gs, m->b_sig_xchg.as<unsigned long long>(), (unsigned long long)m->seq, (unsigned long long*)nullptr,
 			                   (unsigned long long*)nullptr, 0ull);
@@ -531,7 +534,16 @@ int fastBatchStep(ufomap_map* m, ufomap_comm* c, const double origin[3], const d
 		}
 	}
 	m->scan_new_bound = bound;
-	HIP_TRY(m->b_tilerec.reserve((size_t)UFO_FAST_MAX_TILES * sizeof(TileRec)));
+	{
+		// (the tiles' hand-over records are told apart by the phase they were written in: a new array starts zeroed, as in enqueueSlot --
+		// until round 6 a map whose FIRST steady-state update was a batch step walked over whatever the allocation held: scripts/dev/fuzz_api.py)
+		const size_t want = (size_t)UFO_FAST_MAX_TILES * sizeof(TileRec);
+		if (m->b_tilerec.cap < want) {
+			HIP_TRY(hipStreamSynchronize(m->stream));  // (a walk in flight reads the old array)
+			HIP_TRY(m->b_tilerec.reserve(want));
+			HIP_TRY(hipMemsetAsync(m->b_tilerec.p, 0, m->b_tilerec.cap, m->stream));
+		}
+	}
 	if (xgate) {
 		// (a collective that has not delivered within 10 s has failed: the walk then stands back on this rank, which is reported when the
 		// step is joined -- the communicator is beyond repair either way)
@@ -584,7 +596,13 @@ int redoBatchStep(ufomap_map* m)
 	if (!c) return fail(UFOMAP_ERR_INVALID, "batch step without a communicator");
 	++c->n_redo_steps;  // (the list form extends the ranks' common grid by the boxes it gathers)
 	HIP_TRY(hipStreamSynchronize(m->stream));
-	return listBatchStep(m, c, a.origin, a.d_xyz, nullptr, a.n, a.max_range, a.discrete, true);
+	// (the step may be repeated from inside ANOTHER call's join -- a ufomap_map_insert_pointcloud2 whose record layout is in m->ing at this
+	// moment: the step's own cloud is plain float64 points. Round 6: the repeat read them through that layout, scripts/dev/fuzz_api.py.)
+	const Ingest sing = m->ing;
+	m->ing = Ingest{};
+	const int rc = listBatchStep(m, c, a.origin, a.d_xyz, nullptr, a.n, a.max_range, a.discrete, true);
+	m->ing = sing;
+	return rc;
 }
 }  // namespace
 }  // extern "C++"

@@ -117,6 +117,18 @@ struct DevBuf {
 			return e;
 		}
 		cap = want;
+		// Test aid (UFOMAP_POISON=<byte>): new device memory is filled with that byte -- the driver hands out zeroed pages to a fresh
+		// process, so a buffer that is read before it is written only shows in a process that has freed memory before (round 6:
+		// scripts/dev/fuzz_api.py found one that way); with the poison it shows at once, in any test.
+		static const int poison = [] {
+			const char* v = getenv("UFOMAP_POISON");
+			return v && *v ? (int)(strtol(v, nullptr, 0) & 0xFF) : -1;
+		}();
+		if (poison >= 0 && want <= (1ull << 32)) {
+			e = hipMemset(p, poison, want);
+			if (e == hipSuccess) e = hipDeviceSynchronize();  // (the fill runs on the null stream, which the handle's non-blocking streams do not wait for)
+			if (e != hipSuccess) return e;
+		}
 		return hipSuccess;
 	}
 	void release()
@@ -2449,6 +2461,7 @@ ufomap_map* ufomap_map_create(double resolution, unsigned depth_levels, int auto
 		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fcast_simple<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (160 << 10) - 512);
 
 	}
+	(void)hipDeviceSynchronize();  // (the fills above ran on the null stream, which the handle's non-blocking streams do not wait for)
 	if (m->opt_vol) (void)volSelfTest(m);  // (the per-XCD atomics the volume path rests on, once per device -- here, not inside a scan)
 	for (int a = 0; a < 3; ++a) {
 		m->min_change[a] = g.hs[g.L];  // resetMinMaxChangeDetection (occupancy_map_base.h:806-810)
