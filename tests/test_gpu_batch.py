@@ -1,6 +1,8 @@
 """Round 3 (run with -m gpu on an MI355X): ONE walk of the tree for a batch of scans (fast_kernels.h: k_tile / k_ftail
 over B scans) must leave exactly the map the reference leaves after integrating the scans one after the other
 (occupancy_map_base.h:340-417 called B times) -- values, flags, leaf structure under pruning, byte stream."""
+import os
+
 import numpy as np
 import pytest
 import torch  # noqa: F401  (before the HIP library: torch brings its own copy of the HIP runtime, and the first one loaded owns the GPU)
@@ -637,6 +639,22 @@ def test_gate_timeouts_are_survived():
     n_to = g.debug()[58]
     assert n_to >= 0
     print("gate timeouts:", n_to)
+
+
+@pytest.mark.parametrize("seeds", ["3 120 11", "4 150 13", "2 150 23", "2 150 40", "2 150 55"])
+def test_random_call_sequences_against_the_checker(seeds):
+    """scripts/dev/fuzz_api.py: random sequences of calls on one map -- host / device / PointCloud2 clouds, synchronous and asynchronous,
+    insert depths, continuous and discrete, robot clearing, batch steps over a one-rank communicator that comes and goes, byte streams,
+    clear -- compared with the CPU checker after every few calls, several maps one after the other in one process (recycled device
+    memory). The seeds are the ones that found round 6's four bugs in the seams between the kinds of calls: a scan behind a batch step
+    that stood back applied before the step's repeat; a batch step as a map's first steady-state update on an unzeroed record array; a
+    batch step repeated from inside a PointCloud2 call reading its cloud through that call's record layout; the word behind the
+    all-gather polled before it was zeroed."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pr = subprocess.run([sys.executable, os.path.join(root, "scripts", "dev", "fuzz_api.py")] + seeds.split(), capture_output=True, text=True, timeout=900, cwd=root)
+    assert 0 == pr.returncode, pr.stdout[-3000:] + pr.stderr[-1500:]
 
 
 def test_single_scans_after_batch_steps_and_a_destroyed_communicator():
