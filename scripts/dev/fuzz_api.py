@@ -11,7 +11,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 from oracle import OracleMap, RunawayRay  # noqa: E402
 from oracle import ingest as oracle_ingest  # noqa: E402
-from ufomap_amd import OccupancyMap, PointCloud, scans  # noqa: E402
+from ufomap_amd import OccupancyMap, OccupancyMapColor, PointCloud, PointCloudColor, scans  # noqa: E402
 from ufomap_amd.occupancy_map import Comm  # noqa: E402
 
 
@@ -25,6 +25,8 @@ first = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 check_from = int(os.environ.get("FUZZ_CHECK_FROM", "1000000"))  # (from this call on, the maps are compared after every FUZZ_CHECK_EVERY-th call)
 check_every = int(os.environ.get("FUZZ_CHECK_EVERY", "1"))
 print_all = bool(os.environ.get("FUZZ_PRINT"))
+ext_ops = bool(os.environ.get("FUZZ_EXT")) or bool(os.environ.get("FUZZ_COLOR"))  # more kinds of calls: early stopping / fixed-step casting, point queries
+color = bool(os.environ.get("FUZZ_COLOR"))  # OccupancyMapColor with coloured clouds (discrete only: the reference's continuous form does not compile with colours)
 skip = set(filter(None, os.environ.get("FUZZ_SKIP", "").split(",")))  # kinds of calls that are left out (both maps)
 kind = "reference" if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libufo_ref.so")) else "port"
 
@@ -39,13 +41,21 @@ def check(g, o, what):
 bad = 0
 for seed in range(first, first + n_seeds):
     rng = np.random.default_rng(seed)
-    g, o = OccupancyMap(0.16), OracleMap(0.16, kind=kind)
+    g, o = (OccupancyMapColor if color else OccupancyMap)(0.16), OracleMap(0.16, kind=kind, color=color)
+    for kv in filter(None, os.environ.get("FUZZ_OPTS", "").split(",")):  # options for the map: "early_map=0,lazy_done=0"
+        g.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     comm, keep, log = None, [], []
     pose = np.array(scans.lidar_pose(int(rng.integers(0, 4))), dtype=np.float64)
     try:
         for step in range(n_ops):
-            op = rng.choice(["host", "host", "dev", "dev", "pc2", "batch", "batch", "vol", "bytes", "wait", "clear", "comm", "big", "cont", "depth"],
-                            p=[0.14, 0.1, 0.12, 0.1, 0.08, 0.1, 0.08, 0.07, 0.04, 0.05, 0.01, 0.04, 0.03, 0.02, 0.02])
+            if ext_ops:
+                op = rng.choice(["host", "host", "dev", "dev", "pc2", "batch", "batch", "vol", "bytes", "wait", "clear", "comm", "big", "cont", "depth", "es", "query"],
+                                p=[0.12, 0.1, 0.11, 0.09, 0.08, 0.1, 0.07, 0.07, 0.04, 0.04, 0.01, 0.04, 0.03, 0.02, 0.02, 0.03, 0.03])
+            else:  # (the table the seeds of tests/test_gpu_batch.py: test_random_call_sequences_against_the_checker were found with)
+                op = rng.choice(["host", "host", "dev", "dev", "pc2", "batch", "batch", "vol", "bytes", "wait", "clear", "comm", "big", "cont", "depth"],
+                                p=[0.14, 0.1, 0.12, 0.1, 0.08, 0.1, 0.08, 0.07, 0.04, 0.05, 0.01, 0.04, 0.03, 0.02, 0.02])
+            if color and op in ("cont", "pc2"):
+                op = "host"
             if rng.random() < 0.12:
                 pose = pose + rng.normal(0, 1.5, 3) * np.array([1, 1, 0.1])  # (a jump: the predicted grid misses, the scan is repeated)
             else:
@@ -54,29 +64,49 @@ for seed in range(first, first + n_seeds):
             asyn = bool(rng.random() < 0.7)
             r2 = np.random.default_rng([seed, step])  # (the call's own parameters: skipping a kind of call leaves the rest of the sequence as it is)
             beams, az = (64, 2048) if op == "big" else (16, int(r2.choice([128, 512])))
-            _, xyz, _ = scans.lidar64(beams=beams, azimuths=az, origin=origin, seed=int(r2.integers(1 << 30)))
+            _, xyz, rgb = scans.lidar64(beams=beams, azimuths=az, origin=origin, seed=int(r2.integers(1 << 30)), colored=color)
             if r2.random() < 0.05:
-                xyz = xyz[:int(r2.integers(0, 3))]
+                k_pts = int(r2.integers(0, 3))
+                xyz, rgb = xyz[:k_pts], (rgb[:k_pts] if color else None)
+            if not color:
+                rgb = None
+
+            def cloud(a, c):
+                return PointCloudColor(a, c) if color else PointCloud(a)
             log.append((step, op, asyn, len(xyz)))
             if op in skip:
                 continue
             if op in ("host", "big"):
-                buf = xyz.copy()
-                g.insertPointCloudDiscrete(origin, PointCloud(buf), 12.0, 0, False, 0, asyn)
+                buf, cbuf = xyz.copy(), (rgb.copy() if color else None)
+                g.insertPointCloudDiscrete(origin, cloud(buf, cbuf), 12.0, 0, False, 0, asyn)
                 buf[:] = 7.0
-                o.insert(origin, xyz, max_range=12.0, discrete=True)
+                if color:
+                    cbuf[:] = 3
+                o.insert(origin, xyz, rgb, max_range=12.0, discrete=True)
             elif op == "cont":
                 g.insertPointCloud(origin, PointCloud(xyz), 12.0, 0, False, 0, asyn)
                 o.insert(origin, xyz, max_range=12.0, discrete=False)
             elif op == "depth":
                 d = int(r2.integers(1, 3))
-                g.insertPointCloudDiscrete(origin, PointCloud(xyz), 12.0, d, False, 0, asyn)
-                o.insert(origin, xyz, max_range=12.0, discrete=True, depth=d)
+                g.insertPointCloudDiscrete(origin, cloud(xyz, rgb), 12.0, d, False, 0, asyn)
+                o.insert(origin, xyz, rgb, max_range=12.0, discrete=True, depth=d)
+            elif op == "es":
+                simple, es = bool(r2.random() < 0.5), int(r2.integers(0, 4))
+                log[-1] = log[-1] + (f"simple={simple} es={es}",)
+                g.insertPointCloudDiscrete(origin, cloud(xyz, rgb), 12.0, 0, simple, es, asyn)
+                o.insert(origin, xyz, rgb, max_range=12.0, discrete=True, simple_ray_casting=simple, early_stopping=es)
+            elif op == "query":
+                q = np.concatenate([xyz[::7] + r2.normal(0, 0.1, xyz[::7].shape), r2.uniform(-15, 15, (500, 3))]) if len(xyz) else r2.uniform(-15, 15, (500, 3))
+                qd = int(r2.integers(0, 4))
+                a, b = g.query(q, qd), o.query(q, qd)
+                if not (np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)) and np.array_equal(a[1], b[1])):
+                    raise AssertionError(f"point queries at depth {qd} differ")
             elif op == "dev":
                 d = torch.from_numpy(np.ascontiguousarray(xyz)).cuda()
-                keep.append(d)
-                g.insert_device(origin, d.data_ptr() if len(xyz) else 0, None, len(xyz), 12.0, 0, discrete=True, async_=asyn)
-                o.insert(origin, xyz, max_range=12.0, discrete=True)
+                dc = torch.from_numpy(np.ascontiguousarray(rgb)).cuda() if color else None
+                keep.extend([d, dc])
+                g.insert_device(origin, d.data_ptr() if len(xyz) else 0, (dc.data_ptr() if len(xyz) else 0) if color else None, len(xyz), 12.0, 0, discrete=True, async_=asyn)
+                o.insert(origin, xyz, rgb, max_range=12.0, discrete=True)
             elif op == "pc2":
                 rec = np.zeros((len(xyz), 4), np.float32)
                 rec[:, :3] = (xyz - np.asarray(origin)[None, :]).astype(np.float32)
@@ -91,10 +121,11 @@ for seed in range(first, first + n_seeds):
                 g.set_option("async_apply", int(asyn))
                 for _ in range(int(r2.integers(1, 5))):
                     d = torch.from_numpy(np.ascontiguousarray(xyz)).cuda()
-                    keep.append(d)
-                    dep = int(r2.integers(0, 3)) if r2.random() < 0.1 else 0
-                    g.insert_batch(comm, origin, d.data_ptr() if len(xyz) else 0, len(xyz), 12.0, dep, True)
-                    o.insert(origin, xyz, max_range=12.0, discrete=True, depth=dep)
+                    dc = torch.from_numpy(np.ascontiguousarray(rgb)).cuda() if color else None
+                    keep.extend([d, dc])
+                    dep = int(r2.integers(0, 3)) if (r2.random() < 0.1 and not color) else 0
+                    g.insert_batch(comm, origin, d.data_ptr() if len(xyz) else 0, len(xyz), 12.0, dep, True, (dc.data_ptr() if len(xyz) else 0) if color else None)
+                    o.insert(origin, xyz, rgb, max_range=12.0, discrete=True, depth=dep)
             elif op == "comm":
                 if comm is not None:
                     g.insertPointCloudWait()
@@ -125,7 +156,7 @@ for seed in range(first, first + n_seeds):
             elif op == "clear":
                 g.insertPointCloudWait()
                 g.clear()
-                o = OracleMap(0.16, kind=kind)
+                o = OracleMap(0.16, kind=kind, color=color)
             if len(keep) > 64:
                 g.insertPointCloudWait()
                 keep.clear()

@@ -2218,7 +2218,10 @@ int doInsert(ufomap_map* m, const double origin[3], const double* d_xyz, const u
 	// updates are still in flight. The first kernel looks at the predecessor's error flags: if it flagged itself, this
 	// update stands back too (ERR_PREV, which cascades) and everything flagged is re-run in order when it is joined.
 	bool early = false;
-	if (!rc && n && async && merged && m->opt_early && pk >= 0 && !m->profiling) {
+	// (only behind an update of the same kind: one that reports through its control block. Behind a walk of the steady-state path -- which
+	// reports through the pipe's status words and hands its control block back in the start state -- the predecessor is joined first;
+	// round 6: scripts/dev/fuzz_api.py found a map that differed after an early-stopping scan enqueued behind a steady-state scan.)
+	if (!rc && n && async && merged && m->opt_early && pk >= 0 && !m->alt[pk].done_by_flag && !m->profiling) {
 		m->cs = m->stream;
 		HIP_TRY(hipStreamWaitEvent(m->stream, m->scan_ev, 0));
 		m->last_rgb = d_rgb;
