@@ -300,7 +300,10 @@ int ufomap_map_apply_keys_batch(ufomap_map* m, const void* const* d_lists, const
  * grow alike on all ranks; a step whose common grid a rank's scan does not fit is repeated in that form by ALL ranks when
  * it is joined. Contract: every rank makes the same sequence of calls on its map with the same map parameters and
  * options (joins happen at fixed points of that sequence); cloud, size (0 allowed), pose and max_range are the rank's
- * own. A rank whose scan fails still takes part in the collective and every rank returns the error. Insert depth 0: the
+ * own. A rank whose scan fails still takes part in the collective and every rank returns the error. Change detection: the
+ * min / max change box grows by THIS rank's scans of bit-grid steps only (list-form steps and the other ranks' scans do
+ * not reach it), and per-code change detection makes every step take the list form -- use ufomap_map_insert where the
+ * reference's change-detection results are needed. Insert depth 0: the
  * bit-grid form, up to "batch_depth" (3) steps in flight with option "async_apply"; depth > 0: the list form, joined first.
  * d_xyz / d_rgb are consumed when the call returns. librccl is loaded at run time (a copy already in the process is
  * preferred; UFOMAP_RCCL_LIB names the library to use instead -- then that one only).

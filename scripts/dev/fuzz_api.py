@@ -26,6 +26,9 @@ check_from = int(os.environ.get("FUZZ_CHECK_FROM", "1000000"))  # (from this cal
 check_every = int(os.environ.get("FUZZ_CHECK_EVERY", "1"))
 print_all = bool(os.environ.get("FUZZ_PRINT"))
 ext_ops = bool(os.environ.get("FUZZ_EXT")) or bool(os.environ.get("FUZZ_COLOR"))  # more kinds of calls: early stopping / fixed-step casting, point queries
+chg = os.environ.get("FUZZ_CHG", "")  # "codes": the per-code change set, "box": the min / max change box -- compared (and reset) with every comparison of the maps
+RES = float(os.environ.get("FUZZ_RES", "0.16"))  # leaf size; FUZZ_RANGE: max_range (a fine map with a long range takes the ray grid beyond LDS)
+RANGE = float(os.environ.get("FUZZ_RANGE", "12.0"))
 color = bool(os.environ.get("FUZZ_COLOR"))  # OccupancyMapColor with coloured clouds (discrete only: the reference's continuous form does not compile with colours)
 skip = set(filter(None, os.environ.get("FUZZ_SKIP", "").split(",")))  # kinds of calls that are left out (both maps)
 kind = "reference" if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libufo_ref.so")) else "port"
@@ -36,12 +39,28 @@ def check(g, o, what):
     ok = same_dump(g.leaves(True), o.leaves(True)) and same_dump(g.inner(), o.inner())
     if not ok:
         raise AssertionError(what)
+    if chg == "codes":
+        if not same_dump(g.changes(), o.changes()):
+            raise AssertionError(what + " (the change sets)")
+        g.resetChangeDetection()
+        o.resetChangeDetection()
+    elif chg == "box":
+        a, b = g.minmax_change(), o.minmax_change()
+        if not (np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])):
+            raise AssertionError(what + f" (the change boxes: {a} vs {b})")
+        # (the boxes accumulate: the checker has no reset)
 
 
 bad = 0
 for seed in range(first, first + n_seeds):
     rng = np.random.default_rng(seed)
-    g, o = (OccupancyMapColor if color else OccupancyMap)(0.16), OracleMap(0.16, kind=kind, color=color)
+    g, o = (OccupancyMapColor if color else OccupancyMap)(RES), OracleMap(RES, kind=kind, color=color)
+    if chg == "codes":
+        g.enableChangeDetection(True)
+        o.enableChangeDetection(True)
+    elif chg == "box":
+        g.enableMinMaxChangeDetection(True)
+        o.enableMinMaxChangeDetection(True)
     for kv in filter(None, os.environ.get("FUZZ_OPTS", "").split(",")):  # options for the map: "early_map=0,lazy_done=0"
         g.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     comm, keep, log = None, [], []
@@ -49,13 +68,15 @@ for seed in range(first, first + n_seeds):
     try:
         for step in range(n_ops):
             if ext_ops:
-                op = rng.choice(["host", "host", "dev", "dev", "pc2", "batch", "batch", "vol", "bytes", "wait", "clear", "comm", "big", "cont", "depth", "es", "query"],
-                                p=[0.12, 0.1, 0.11, 0.09, 0.08, 0.1, 0.07, 0.07, 0.04, 0.04, 0.01, 0.04, 0.03, 0.02, 0.02, 0.03, 0.03])
+                op = rng.choice(["host", "host", "dev", "dev", "pc2", "batch", "batch", "vol", "bytes", "wait", "clear", "comm", "big", "cont", "depth", "es", "query", "read"],
+                                p=[0.12, 0.1, 0.11, 0.09, 0.08, 0.1, 0.07, 0.07, 0.03, 0.04, 0.01, 0.04, 0.03, 0.02, 0.02, 0.03, 0.02, 0.02])
             else:  # (the table the seeds of tests/test_gpu_batch.py: test_random_call_sequences_against_the_checker were found with)
                 op = rng.choice(["host", "host", "dev", "dev", "pc2", "batch", "batch", "vol", "bytes", "wait", "clear", "comm", "big", "cont", "depth"],
                                 p=[0.14, 0.1, 0.12, 0.1, 0.08, 0.1, 0.08, 0.07, 0.04, 0.05, 0.01, 0.04, 0.03, 0.02, 0.02])
             if color and op in ("cont", "pc2"):
                 op = "host"
+            if chg and op == "clear":  # (a cleared map is a NEW checker map here, whose change set / box starts empty: the reference's clear() keeps them)
+                op = "wait"
             if rng.random() < 0.12:
                 pose = pose + rng.normal(0, 1.5, 3) * np.array([1, 1, 0.1])  # (a jump: the predicted grid misses, the scan is repeated)
             else:
@@ -78,23 +99,23 @@ for seed in range(first, first + n_seeds):
                 continue
             if op in ("host", "big"):
                 buf, cbuf = xyz.copy(), (rgb.copy() if color else None)
-                g.insertPointCloudDiscrete(origin, cloud(buf, cbuf), 12.0, 0, False, 0, asyn)
+                g.insertPointCloudDiscrete(origin, cloud(buf, cbuf), RANGE, 0, False, 0, asyn)
                 buf[:] = 7.0
                 if color:
                     cbuf[:] = 3
-                o.insert(origin, xyz, rgb, max_range=12.0, discrete=True)
+                o.insert(origin, xyz, rgb, max_range=RANGE, discrete=True)
             elif op == "cont":
-                g.insertPointCloud(origin, PointCloud(xyz), 12.0, 0, False, 0, asyn)
-                o.insert(origin, xyz, max_range=12.0, discrete=False)
+                g.insertPointCloud(origin, PointCloud(xyz), RANGE, 0, False, 0, asyn)
+                o.insert(origin, xyz, max_range=RANGE, discrete=False)
             elif op == "depth":
                 d = int(r2.integers(1, 3))
-                g.insertPointCloudDiscrete(origin, cloud(xyz, rgb), 12.0, d, False, 0, asyn)
-                o.insert(origin, xyz, rgb, max_range=12.0, discrete=True, depth=d)
+                g.insertPointCloudDiscrete(origin, cloud(xyz, rgb), RANGE, d, False, 0, asyn)
+                o.insert(origin, xyz, rgb, max_range=RANGE, discrete=True, depth=d)
             elif op == "es":
                 simple, es = bool(r2.random() < 0.5), int(r2.integers(0, 4))
                 log[-1] = log[-1] + (f"simple={simple} es={es}",)
-                g.insertPointCloudDiscrete(origin, cloud(xyz, rgb), 12.0, 0, simple, es, asyn)
-                o.insert(origin, xyz, rgb, max_range=12.0, discrete=True, simple_ray_casting=simple, early_stopping=es)
+                g.insertPointCloudDiscrete(origin, cloud(xyz, rgb), RANGE, 0, simple, es, asyn)
+                o.insert(origin, xyz, rgb, max_range=RANGE, discrete=True, simple_ray_casting=simple, early_stopping=es)
             elif op == "query":
                 q = np.concatenate([xyz[::7] + r2.normal(0, 0.1, xyz[::7].shape), r2.uniform(-15, 15, (500, 3))]) if len(xyz) else r2.uniform(-15, 15, (500, 3))
                 qd = int(r2.integers(0, 4))
@@ -105,16 +126,16 @@ for seed in range(first, first + n_seeds):
                 d = torch.from_numpy(np.ascontiguousarray(xyz)).cuda()
                 dc = torch.from_numpy(np.ascontiguousarray(rgb)).cuda() if color else None
                 keep.extend([d, dc])
-                g.insert_device(origin, d.data_ptr() if len(xyz) else 0, (dc.data_ptr() if len(xyz) else 0) if color else None, len(xyz), 12.0, 0, discrete=True, async_=asyn)
-                o.insert(origin, xyz, rgb, max_range=12.0, discrete=True)
+                g.insert_device(origin, d.data_ptr() if len(xyz) else 0, (dc.data_ptr() if len(xyz) else 0) if color else None, len(xyz), RANGE, 0, discrete=True, async_=asyn)
+                o.insert(origin, xyz, rgb, max_range=RANGE, discrete=True)
             elif op == "pc2":
                 rec = np.zeros((len(xyz), 4), np.float32)
                 rec[:, :3] = (xyz - np.asarray(origin)[None, :]).astype(np.float32)
                 raw = np.ascontiguousarray(rec).view(np.uint8).reshape(-1)
                 if len(xyz):
-                    g.insertPointCloud2(np.asarray(origin), np.array([1.0, 0, 0, 0]), raw, 16, (0, 4, 8), None, 12.0, 0, True, False, 0, asyn)
+                    g.insertPointCloud2(np.asarray(origin), np.array([1.0, 0, 0, 0]), raw, 16, (0, 4, 8), None, RANGE, 0, True, False, 0, asyn)
                     xyz32, _ = oracle_ingest(raw, 16, (0, 4, 8), None, np.array([1.0, 0, 0, 0]), np.asarray(origin), kind)  # (the reference's rosToUfo + transform)
-                    o.insert(origin, xyz32, max_range=12.0, discrete=True)
+                    o.insert(origin, xyz32, max_range=RANGE, discrete=True)
             elif op == "batch":
                 if comm is None:
                     comm = Comm(Comm.unique_id(), 1, 0, 0)
@@ -124,8 +145,8 @@ for seed in range(first, first + n_seeds):
                     dc = torch.from_numpy(np.ascontiguousarray(rgb)).cuda() if color else None
                     keep.extend([d, dc])
                     dep = int(r2.integers(0, 3)) if (r2.random() < 0.1 and not color) else 0
-                    g.insert_batch(comm, origin, d.data_ptr() if len(xyz) else 0, len(xyz), 12.0, dep, True, (dc.data_ptr() if len(xyz) else 0) if color else None)
-                    o.insert(origin, xyz, rgb, max_range=12.0, discrete=True, depth=dep)
+                    g.insert_batch(comm, origin, d.data_ptr() if len(xyz) else 0, len(xyz), RANGE, dep, True, (dc.data_ptr() if len(xyz) else 0) if color else None)
+                    o.insert(origin, xyz, rgb, max_range=RANGE, discrete=True, depth=dep)
             elif op == "comm":
                 if comm is not None:
                     g.insertPointCloudWait()
@@ -151,12 +172,19 @@ for seed in range(first, first + n_seeds):
                 ext = r2.uniform(0.5, 4.0, 3)
                 a = g.write_ex(aabb=(pose - ext, pose + ext), compress=False, min_depth=int(r2.integers(0, 2)), header=False)[0]
                 log[-1] = log[-1] + (len(a),)
+            elif op == "read":
+                # a message of the map's own (a sub-volume, as the server publishes it) merged back after the next update has changed things
+                box = (pose - r2.uniform(0.5, 3.0, 3), pose + r2.uniform(0.5, 3.0, 3))
+                blob, usz = o.write_ex(aabb=box, compress=bool(r2.random() < 0.3), min_depth=0, header=False)
+                comp = usz != len(blob) and usz > 0
+                g.readData(blob, RES, 16, usz if usz > 0 else len(blob), comp, box)
+                o.readData(blob, RES, 16, usz if usz > 0 else len(blob), comp, box)
             elif op == "wait":
                 check(g, o, f"seed {seed} step {step}: maps differ")
             elif op == "clear":
                 g.insertPointCloudWait()
                 g.clear()
-                o = OracleMap(0.16, kind=kind, color=color)
+                o = OracleMap(RES, kind=kind, color=color)
             if len(keep) > 64:
                 g.insertPointCloudWait()
                 keep.clear()
