@@ -3030,7 +3030,10 @@ int ufomap_map_reset_change_detection(ufomap_map* m)
 	if (!m) return fail(UFOMAP_ERR_INVALID, "null map");
 	HIP_TRY(hipSetDevice(m->device));
 	int rc = ufomap_map_wait(m);
-	HIP_TRY(hipMemset(reinterpret_cast<char*>(m->b_root.p) + offsetof(MapRoot, n_changes), 0, 8));
+	// (on the map stream and awaited: a fill on the null stream is not ordered with the handle's non-blocking streams -- an update
+	// enqueued right after this call could log changes BEFORE the counter was zeroed and lose them)
+	HIP_TRY(hipMemsetAsync(reinterpret_cast<char*>(m->b_root.p) + offsetof(MapRoot, n_changes), 0, 8, m->stream));
+	HIP_TRY(hipStreamSynchronize(m->stream));
 	return rc;
 }
 
@@ -3913,6 +3916,7 @@ int ufomap_map_set_option(ufomap_map* m, const char* key, long long value)
 		if (value) {
 			HIP_TRY(m->b_ts.reserve((size_t)UFO_TS_SCANS * 64));
 			HIP_TRY(hipMemset(m->b_ts.p, 0, (size_t)UFO_TS_SCANS * 64));
+			HIP_TRY(hipDeviceSynchronize());
 			ts = m->b_ts.as<unsigned long long>();
 		} else {
 			m->b_ts.release();
