@@ -301,9 +301,8 @@ int ufomap_map_apply_keys_batch(ufomap_map* m, const void* const* d_lists, const
  * it is joined. Contract: every rank makes the same sequence of calls on its map with the same map parameters and
  * options (joins happen at fixed points of that sequence); cloud, size (0 allowed), pose and max_range are the rank's
  * own. A rank whose scan fails still takes part in the collective and every rank returns the error. Change detection: the
- * min / max change box grows by THIS rank's scans of bit-grid steps only (list-form steps and the other ranks' scans do
- * not reach it), and per-code change detection makes every step take the list form -- use ufomap_map_insert where the
- * reference's change-detection results are needed. Insert depth 0: the
+ * min / max change box of every replica grows by every rank's scan (the boxes travel with the step); per-code change
+ * detection makes every step take the list form. Insert depth 0: the
  * bit-grid form, up to "batch_depth" (3) steps in flight with option "async_apply"; depth > 0: the list form, joined first.
  * d_xyz / d_rgb are consumed when the call returns. librccl is loaded at run time (a copy already in the process is
  * preferred; UFOMAP_RCCL_LIB names the library to use instead -- then that one only).

@@ -209,10 +209,12 @@ int listBatchStep(ufomap_map* m, ufomap_comm* c, const double origin[3], const d
 		i32 status;    // 0, or the error code of this rank's scan (its list is empty then)
 		i32 have_box;  // the scan cast rays: box = their cells' bounding box (cells at depth 0)
 		i32 box[6];
+		double chg[6];  // the scan's contribution to the min / max change box (OMB:1367; none: chg[0] > chg[3]) -- every replica's box grows by every rank's scan
 	};
 	static_assert(sizeof(ufomap_keys_info) + sizeof(HdrTail) <= kSlotHeader, "exchange header");
 	std::vector<ufomap_keys_info> infos((size_t)W);
 	std::vector<i32> boxes((size_t)W * 6, 0);
+	std::vector<double> chgs((size_t)W * 6, 0.0);
 	std::vector<char> have_box((size_t)W, 0);
 	int first_status = 0, first_rank = -1;
 	for (;;) {
@@ -234,6 +236,13 @@ int listBatchStep(ufomap_map* m, ufomap_comm* c, const double origin[3], const d
 				t.box[a] = m->h_ctl->mb_min[a];
 				t.box[3 + a] = m->h_ctl->mb_max[a];
 			}
+			t.chg[0] = 1.0;
+			t.chg[3] = 0.0;
+			if (!scan_rc && n && m->h_ctl->aabb_min[0] != ~0ull)
+				for (int a = 0; a < 3; ++a) {
+					t.chg[a] = decD(m->h_ctl->aabb_min[a]);
+					t.chg[3 + a] = decD(m->h_ctl->aabb_max[a]);
+				}
 			memcpy(c->h_hdr + sizeof(info), &t, sizeof(t));
 		}
 		bool ok = hipMemcpyAsync(send, c->h_hdr, kSlotHeader, hipMemcpyHostToDevice, m->sstream) == hipSuccess;
@@ -261,6 +270,7 @@ int listBatchStep(ufomap_map* m, ufomap_comm* c, const double origin[3], const d
 			}
 			have_box[(size_t)k] = t.have_box ? 1 : 0;
 			for (int a = 0; a < 6; ++a) boxes[(size_t)k * 6 + a] = t.box[a];
+			for (int a = 0; a < 6; ++a) chgs[(size_t)k * 6 + a] = t.chg[a];
 			need = std::max(need, kSlotHeader + listBytes(infos[(size_t)k]));
 		}
 		if (need <= c->cap) break;
@@ -295,6 +305,16 @@ int listBatchStep(ufomap_map* m, ufomap_comm* c, const double origin[3], const d
 		const Grid prev = c->spec_grid;
 		c->spec_valid = any && gridFromBox(had, prev, mn, mx, &c->spec_grid);
 	}
+	// (the step is going to be applied: every rank's scan reaches the min / max change box of every replica, OMB:1367)
+	if (m->minmax_enabled)
+		for (int k = 0; k < W; ++k) {
+			const double* q = &chgs[(size_t)k * 6];
+			if (q[0] > q[3]) continue;
+			for (int a = 0; a < 3; ++a) {
+				m->min_change[a] = std::min(m->min_change[a], q[a]);
+				m->max_change[a] = std::max(m->max_change[a], q[3 + a]);
+			}
+		}
 	// the W lists in rank order, one walk of the tree; with option async_apply the call returns after enqueueing and
 	// the next batch's scan overlaps it (two receive buffers, used alternately)
 	std::vector<const void*> lists((size_t)W);
@@ -334,6 +354,17 @@ void predictCommonGrid(ufomap_map* m)
 			mx[a] = std::max(mx[a], rc->mb_max[a]);
 		}
 	}
+	// (... and the min / max change box from the OTHER ranks' scans: the own scan's is taken in by finishPending like any scan's)
+	if (m->minmax_enabled)
+		for (int w = 0; w < m->batch_world; ++w) {
+			if (w == c->rank) continue;
+			const ScanCtl* rc = otherResult(m->h_res_all, w);
+			if (~0ull == rc->aabb_min[0]) continue;
+			for (int a = 0; a < 3; ++a) {
+				m->min_change[a] = std::min(m->min_change[a], decD(rc->aabb_min[a]));
+				m->max_change[a] = std::max(m->max_change[a], decD(rc->aabb_max[a]));
+			}
+		}
 	if (!any) return;  // (a step of empty clouds: the grid stays)
 	const bool had = c->spec_valid;
 	const Grid prev = c->spec_grid;
