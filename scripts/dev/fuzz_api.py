@@ -40,8 +40,16 @@ def check(g, o, what):
     if not ok:
         raise AssertionError(what)
     if chg == "codes":
-        if not same_dump(g.changes(), o.changes()):
-            raise AssertionError(what + " (the change sets)")
+        ga, oa = g.changes(), o.changes()  # (the reference's change set is an unordered set: compared as sets)
+        sg = set(zip(ga[1].tolist(), ga[0].tolist()))
+        so = set(zip(oa[1].tolist(), oa[0].tolist()))
+        # (... of nodes: after scans at insert depth > 0 the reference's set holds several Codes whose low bits differ for ONE node -- the
+        # checker's export lists them all, 48 452 entries for 43 974 nodes in one sequence; the library reports each node once)
+        if sg != so:
+            only_g, only_o = sorted(sg - so), sorted(so - sg)
+            by_d = lambda xs: {d: sum(1 for x in xs if x[0] == d) for d in sorted({x[0] for x in xs})}  # noqa: E731
+            raise AssertionError(what + f" (the change sets: {len(sg)} vs {len(so)} codes, arrays of {len(ga[0])} vs {len(oa[0])}; only here by depth {by_d(only_g)}, only in the checker {by_d(only_o)}; "
+                                        f"e.g. {only_g[:3]} / {only_o[:3]})")
         g.resetChangeDetection()
         o.resetChangeDetection()
     elif chg == "box":
