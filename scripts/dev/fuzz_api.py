@@ -7,6 +7,14 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
+WORLD = int(os.environ.get("FUZZ_WORLD", "1"))  # > 1: this process plays rank 0 of WORLD (tests/cpp/rccl_shim.cpp: every slot of an all-gather is a copy of the caller's)
+if WORLD > 1:
+    import subprocess
+    shim_src, shim = os.path.join(ROOT, "tests", "cpp", "rccl_shim.cpp"), os.path.join(ROOT, "tests", "cpp", "librccl_shim.so")
+    if not os.path.exists(shim) or os.path.getmtime(shim) < os.path.getmtime(shim_src):
+        subprocess.run(["/opt/rocm/bin/hipcc", "-O2", "-shared", "-fPIC", shim_src, "-o", shim, "-lrt"], check=True)
+    os.environ["UFOMAP_RCCL_LIB"] = shim
+    os.environ["UFOMAP_SHIM_REPLICATE"] = "1"
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 from oracle import OracleMap, RunawayRay  # noqa: E402
@@ -146,7 +154,7 @@ for seed in range(first, first + n_seeds):
                     o.insert(origin, xyz32, max_range=RANGE, discrete=True)
             elif op == "batch":
                 if comm is None:
-                    comm = Comm(Comm.unique_id(), 1, 0, 0)
+                    comm = Comm(Comm.unique_id(), WORLD, 0, 0)
                 g.set_option("async_apply", int(asyn))
                 for _ in range(int(r2.integers(1, 5))):
                     d = torch.from_numpy(np.ascontiguousarray(xyz)).cuda()
@@ -154,7 +162,8 @@ for seed in range(first, first + n_seeds):
                     keep.extend([d, dc])
                     dep = int(r2.integers(0, 3)) if (r2.random() < 0.1 and not color) else 0
                     g.insert_batch(comm, origin, d.data_ptr() if len(xyz) else 0, len(xyz), RANGE, dep, True, (dc.data_ptr() if len(xyz) else 0) if color else None)
-                    o.insert(origin, xyz, rgb, max_range=RANGE, discrete=True, depth=dep)
+                    for _w in range(WORLD):  # (the step applies the scans of ranks 0 .. WORLD-1 in this order: here the same scan WORLD times)
+                        o.insert(origin, xyz, rgb, max_range=RANGE, discrete=True, depth=dep)
             elif op == "comm":
                 if comm is not None:
                     g.insertPointCloudWait()

@@ -657,6 +657,19 @@ def test_random_call_sequences_against_the_checker(seeds):
     assert 0 == pr.returncode, pr.stdout[-3000:] + pr.stderr[-1500:]
 
 
+@pytest.mark.parametrize("mode", [{"FUZZ_WORLD": "3", "FUZZ_CHG": "box", "FUZZ_EXT": "1"}, {"FUZZ_COLOR": "1"}, {"FUZZ_CHG": "codes", "FUZZ_EXT": "1"}])
+def test_random_call_sequences_other_modes(mode):
+    """The same with this process playing rank 0 of three (every batch step applies the scan three times; the min / max change box of every
+    replica grows by every rank's scan), on a colour map, and with the per-code change set compared as a set of nodes."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    _build_shim()
+    pr = subprocess.run([sys.executable, os.path.join(root, "scripts", "dev", "fuzz_api.py"), "3", "80", "1200"], capture_output=True, text=True, timeout=900, cwd=root,
+                        env=dict(os.environ, **mode))
+    assert 0 == pr.returncode, pr.stdout[-3000:] + pr.stderr[-1500:]
+
+
 def test_single_scans_after_batch_steps_and_a_destroyed_communicator():
     """A hand-over set that held a batch step kept the step's communicator until round 6: taking a scan of ufomap_map_insert next, it
     predicted the RANKS' grid through that pointer when the scan was joined -- freed memory once ufomap_comm_destroy had run (bench.py's
